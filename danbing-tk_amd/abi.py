@@ -1,0 +1,64 @@
+"""ctypes mirror of include/dbtk.h (struct layouts and constants only)."""
+import ctypes as C
+
+MAX_READ_LEN = 256
+NAN64 = 0xFFFFFFFFFFFFFFFF
+NAN32 = 0xFFFFFFFF
+ABI_VERSION = 1
+
+(OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NO_DEVICE, ERR_HIP, ERR_READ_TOO_LONG, ERR_NOMEM, ERR_UNSUPPORTED,
+ ERR_OVERFLOW) = range(10)
+
+(STAGE_SHORT, STAGE_SUBFILTER, STAGE_KFILTER, STAGE_LOCUS, STAGE_QC, STAGE_BAIT, STAGE_ASGN, STAGE_COUNTED,
+ STAGE_EXTRACT) = range(9)
+
+(C_NREADS, C_SUBFILTERED, C_KMERFILTERED, C_BAITFILTERED, C_QUALFILTERED, C_LOCUSFILTERED, C_QCFILTERED,
+ C_THREADING, C_FEASIBLE, C_ASGN, C_NSHORT, C_NHASH0, C_NHASH1, C_ALGO_PROBES) = range(14)
+C_COUNT = 16
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u16p = C.POINTER(C.c_uint16)
+u8p = C.POINTER(C.c_uint8)
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in
+                ("ksize", "n_filter", "nm_filter", "cthreshold", "nm_tr", "max_nt", "qth", "okam", "qc", "bait",
+                 "bubbles", "extract", "trace")] + [("reserved", C.c_uint32 * 7)]
+
+
+class RpggArrays(C.Structure):
+    _fields_ = [
+        ("ksize", C.c_uint32), ("nloci", C.c_uint64),
+        ("nkeys", C.c_uint64), ("keys", u64p), ("vals", u32p),
+        ("nvv", C.c_uint64), ("vv", u32p),
+        ("fl_cnt", u64p), ("fl_ks", u64p),
+        ("tre_cnt", u64p), ("tre_ks", u64p),
+        ("tr_cnt", u64p), ("tr_ks", u64p),
+        ("qc", u8p),
+        ("bt_cnt", u64p), ("bt_ks", u64p), ("bt_vs", u16p),
+    ]
+
+
+class MateRec(C.Structure):
+    _fields_ = [(n, C.c_int16) for n in ("si", "ei", "si_", "ei_", "nt", "bs", "ti")] + \
+               [(n, C.c_uint8) for n in ("kf", "hf", "bf", "qf", "af", "rm")] + \
+               [("nk", C.c_uint16), ("as2", C.c_uint8 * (MAX_READ_LEN // 4))]
+
+    def annot(self):
+        """The `as` vector (0 '*', 1 '.', 2 '=')."""
+        return [(self.as2[i >> 2] >> (2 * (i & 3))) & 3 for i in range(self.nk)]
+
+
+class PairRec(C.Structure):
+    _fields_ = [("pair", C.c_uint32), ("stage", C.c_uint32), ("dst", C.c_uint32), ("dst0", C.c_uint32),
+                ("nm1", C.c_int32), ("nm2", C.c_int32), ("r1", MateRec), ("r2", MateRec)]
+
+
+def default_params(**kw) -> Params:
+    """Defaults of the reference: src/aQueryFasta_thread.cpp:26-34, 2336-2339."""
+    p = Params(ksize=21, n_filter=4, nm_filter=1, cthreshold=10, nm_tr=40, max_nt=2, qth=20, okam=1)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p

@@ -1,0 +1,218 @@
+/*
+ * dbtk.h — C-ABI of the MI355X-native `danbing-tk align` hot path.
+ *
+ * The reference (ChaissonLab/danbing-tk) has no plugin/FFI interface: its
+ * boundary is the process (argv, RPGG files, FASTA/FASTQ, stdout, output
+ * files) and, inside the process, the worker seam `CountWords<T>(void*)`
+ * (src/aQueryFasta_thread.cpp:1802-2283).  The entry points below sit exactly
+ * on that seam: what the worker does between its two critical sections
+ * (src/aQueryFasta_thread.cpp:1988-2249) for one batch of read pairs, plus the
+ * loaders (src/aQueryFasta_thread.cpp:2459-2500) and the dumps
+ * (src/aQueryFasta_thread.cpp:2631-2656) either side of it.
+ *
+ * Conventions: every function returns a dbtk_status_t (0 = ok); no exceptions
+ * cross the boundary; all buffers are caller-owned unless stated; handles are
+ * opaque.  A dbtk_rpgg_t is immutable after load and may be shared by any
+ * number of contexts; a dbtk_ctx_t belongs to one GPU and one host thread at a
+ * time.  There is no CPU fallback: if no HIP device is usable, ctx creation
+ * fails with DBTK_ERR_NO_DEVICE.
+ */
+#ifndef DBTK_H_
+#define DBTK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DBTK_ABI_VERSION 1u
+
+/* Reads longer than this are rejected (DBTK_ERR_READ_TOO_LONG).  The
+ * reference's per-read k-mer multiplicity is a uint8_t pair (`PE_KMC`,
+ * src/aQueryFasta_thread.cpp:42: "not compatible with reads longer than
+ * 255 bp"); 256 is one wavefront x 4 k-mer positions per lane. */
+#define DBTK_MAX_READ_LEN 256u
+#define DBTK_NAN64 0xFFFFFFFFFFFFFFFFull
+#define DBTK_NAN32 0xFFFFFFFFu
+
+typedef enum dbtk_status {
+    DBTK_OK = 0,
+    DBTK_ERR_ARG = 1,            /* null / inconsistent argument            */
+    DBTK_ERR_IO = 2,             /* missing or truncated file (reference: assert -> abort) */
+    DBTK_ERR_FORMAT = 3,         /* file does not parse                      */
+    DBTK_ERR_NO_DEVICE = 4,      /* no usable HIP device: there is no CPU path */
+    DBTK_ERR_HIP = 5,            /* a HIP runtime call failed (see dbtk_last_error) */
+    DBTK_ERR_READ_TOO_LONG = 6,
+    DBTK_ERR_NOMEM = 7,
+    DBTK_ERR_UNSUPPORTED = 8,    /* flag combination the reference accepts but HEAD leaves dead */
+    DBTK_ERR_OVERFLOW = 9        /* record buffer too small; nothing was lost, call again larger */
+} dbtk_status_t;
+
+/* ---- parameters: the reference's globals + Counts flags ------------------
+ * src/aQueryFasta_thread.cpp:26-34 (globals), 2336-2339 (defaults),
+ * 2344-2429 (flags). */
+typedef struct dbtk_params {
+    uint32_t ksize;        /* -k   [21]  (2..31: edges need 2(k+1) <= 64 bits) */
+    uint32_t n_filter;     /* -kf N  [4]  N_FILTER  */
+    uint32_t nm_filter;    /* -kf M  [1]  NM_FILTER */
+    uint32_t cthreshold;   /* -cth [10]  (uint16_t in the reference) */
+    uint32_t nm_tr;        /* -c   [40]  NM_TR      */
+    uint32_t max_nt;       /*      [2]   MAX_NT (not a CLI flag) */
+    uint32_t qth;          /* -qth [20]  bait quality threshold */
+    uint32_t okam;         /* !-ka [1]   emit kmer-assignment records */
+    uint32_t qc;           /* -qc        per-locus QC mask present in the RPGG handle */
+    uint32_t bait;         /* -b         bait filter (FPSv1) */
+    uint32_t bubbles;      /* -bu        count novel (k+1)-mers */
+    uint32_t extract;      /* -e 1|2     extract mode: locus assignment only */
+    uint32_t trace;        /* test hook: emit a record for EVERY pair, not only kam ones */
+    uint32_t reserved[7];
+} dbtk_params_t;
+
+/* ---- RPGG in flat (file-equivalent) form ----------------------------------
+ * Exactly the arrays the reference's loaders read:
+ *   keys/vals/vv      PREF.kmers.dbi   readBinaryIndex      src/aQueryFasta_thread.h:654-673
+ *   fl_cnt/fl_ks      PREF.fl.kdb      readBinaryKmerSetDB  src/aQueryFasta_thread.h:675-698
+ *   tre_cnt/tre_ks    PREF.tre.kdb     (same reader)
+ *   tr_cnt/tr_ks      PREF.tr.kmers    readKmersWithZeroCount src/aQueryFasta_thread.h:469-480
+ *                     (k-mers in FILE order, per locus)
+ *   qc                -qc FILE         readQCFile           src/kmerIO.hpp:111-120 (0/1 per locus, may be NULL)
+ *   bt_*              PREF.bt.kmdb     readBinaryBaitDB     src/aQueryFasta_thread.h:542-547 (may be NULL)
+ */
+typedef struct dbtk_rpgg_arrays {
+    uint32_t ksize;
+    uint64_t nloci;
+    uint64_t nkeys;  const uint64_t* keys;  const uint32_t* vals;
+    uint64_t nvv;    const uint32_t* vv;
+    const uint64_t* fl_cnt;  const uint64_t* fl_ks;    /* fl_cnt[nloci]; fl_ks[sum]   */
+    const uint64_t* tre_cnt; const uint64_t* tre_ks;   /* may be NULL when !bubbles   */
+    const uint64_t* tr_cnt;  const uint64_t* tr_ks;    /* file order                  */
+    const uint8_t*  qc;                                 /* NULL or nloci bytes 0/1     */
+    const uint64_t* bt_cnt;  const uint64_t* bt_ks;  const uint16_t* bt_vs; /* NULL or bait DB */
+} dbtk_rpgg_arrays_t;
+
+typedef struct dbtk_rpgg dbtk_rpgg_t;
+typedef struct dbtk_ctx  dbtk_ctx_t;
+
+/* ---- per-pair record -------------------------------------------------------
+ * Fields of `km_asgn_t` / `km_asgn_read_t` (src/aQueryFasta_thread.cpp:93-144)
+ * as they stand when the reference pushes a kam record
+ * (src/aQueryFasta_thread.cpp:2169-2175).  `as` is 2 bits per k-mer position
+ * (0 '*', 1 '.', 2 '='), position i in bits [2*(i%4), +2) of byte i/4. */
+typedef struct dbtk_mate_rec {
+    int16_t si, ei, si_, ei_, nt, bs, ti;   /* -1 = unset, as in the reference */
+    uint8_t kf, hf, bf, qf, af, rm;         /* filter flags */
+    uint16_t nk;                            /* size of `as` (0 when assignTRkmc did not run) */
+    uint8_t as2[DBTK_MAX_READ_LEN / 4];
+} dbtk_mate_rec_t;
+
+enum {
+    DBTK_STAGE_SHORT = 0,     /* no valid k-mer window in a mate      AQ.cpp:2037 */
+    DBTK_STAGE_SUBFILTER = 1, /* rejected by subfilter                AQ.cpp:2046 */
+    DBTK_STAGE_KFILTER = 2,   /* both mates rejected by kfilter       AQ.cpp:2054 */
+    DBTK_STAGE_LOCUS = 3,     /* countHit found no locus              AQ.cpp:2058 */
+    DBTK_STAGE_QC = 4,        /* locus fails QC mask                  AQ.cpp:2059 */
+    DBTK_STAGE_BAIT = 5,      /* bait filter removed the pair         AQ.cpp:2120 */
+    DBTK_STAGE_ASGN = 6,      /* both mates rejected by assignTRkmc   AQ.cpp:2145 */
+    DBTK_STAGE_COUNTED = 7,   /* counts were accumulated              AQ.cpp:2146 */
+    DBTK_STAGE_EXTRACT = 8    /* -e: pair assigned, reported only     AQ.cpp:2094 */
+};
+
+typedef struct dbtk_pair_rec {
+    uint32_t pair;        /* index of the pair inside the batch */
+    uint32_t stage;       /* DBTK_STAGE_* where the pair ended  */
+    uint32_t dst;         /* destLocus (== nloci when unassigned) */
+    uint32_t dst0;        /* destLocus0 = top.idx (DBTK_NAN32 before countHit) */
+    int32_t  nm1, nm2;    /* top.fc / top.rc (partial sums, AQ.cpp:436-438) */
+    dbtk_mate_rec_t r1, r2;
+} dbtk_pair_rec_t;
+
+/* Global counters, in the order the reference prints them
+ * (src/aQueryFasta_thread.cpp:2617-2626), then the per-batch extras
+ * (src/aQueryFasta_thread.cpp:2266-2277). */
+enum {
+    DBTK_C_NREADS = 0, DBTK_C_SUBFILTERED, DBTK_C_KMERFILTERED, DBTK_C_BAITFILTERED,
+    DBTK_C_QUALFILTERED, DBTK_C_LOCUSFILTERED, DBTK_C_QCFILTERED, DBTK_C_THREADING,
+    DBTK_C_FEASIBLE, DBTK_C_ASGN, DBTK_C_NSHORT, DBTK_C_NHASH0, DBTK_C_NHASH1,
+    DBTK_C_ALGO_PROBES,   /* index lookups the reference algorithm performs (SURVEY 8d's P) */
+    DBTK_C_COUNT = 16
+};
+
+/* ---- RPGG -----------------------------------------------------------------*/
+/* Load PREF.{tr.kmers,kmers.dbi,fl.kdb,tre.kdb} (+ optional qc / bait files,
+ * NULL to skip).  Replaces src/aQueryFasta_thread.cpp:2459,2490-2500. */
+dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_file,
+                             const char* bait_file, dbtk_rpgg_t** out);
+/* Same handle from caller arrays (copied). */
+dbtk_status_t dbtk_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a, dbtk_rpgg_t** out);
+void          dbtk_rpgg_free(dbtk_rpgg_t* h);
+uint64_t      dbtk_rpgg_nloci(const dbtk_rpgg_t* h);
+uint64_t      dbtk_rpgg_ntrkmers(const dbtk_rpgg_t* h);  /* == length of the counts vector */
+uint64_t      dbtk_rpgg_nkeys(const dbtk_rpgg_t* h);
+/* Flat view of the loaded arrays (valid while the handle lives). */
+dbtk_status_t dbtk_rpgg_view(const dbtk_rpgg_t* h, dbtk_rpgg_arrays_t* out);
+/* Output order: out_slot[i] = position in OUT.trkmc.ar of the i-th k-mer of
+ * PREF.tr.kmers (file order, loci concatenated).  This is the iteration order
+ * of the reference's per-locus std::unordered_map (src/binaryKmerIO.hpp:31-51,
+ * src/aQueryFasta_thread.h:926-937). */
+dbtk_status_t dbtk_rpgg_output_order(const dbtk_rpgg_t* h, uint64_t* out_slot);
+
+/* ---- context (one per GPU) ------------------------------------------------*/
+void          dbtk_params_default(dbtk_params_t* p);
+dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int device_id,
+                              dbtk_ctx_t** out);
+void          dbtk_ctx_free(dbtk_ctx_t* ctx);
+
+/* One batch of complete read pairs: the body of the hot loop
+ * (src/aQueryFasta_thread.cpp:2002-2249).  Read 2p is `seq1`, read 2p+1 is
+ * `seq2` of pair p (the reference's seqs[seqi], seqs[seqi+1]); read r occupies
+ * seq_bytes[seq_offsets[r] .. seq_offsets[r+1]).  qual_bytes (same offsets) is
+ * NULL for FASTA.  Counts accumulate inside the context.  Up to rec_cap
+ * records are written to `recs` in pair order; *nrec receives how many the
+ * batch produced (DBTK_ERR_OVERFLOW if > rec_cap; counts are still complete).
+ * recs may be NULL when the parameters produce no records. */
+dbtk_status_t dbtk_align_batch(dbtk_ctx_t* ctx, const uint8_t* seq_bytes,
+                               const uint64_t* seq_offsets, const uint8_t* qual_bytes,
+                               uint64_t npairs, dbtk_pair_rec_t* recs, uint64_t rec_cap,
+                               uint64_t* nrec);
+
+/* Device-resident variant used when the reads already sit in HBM (bench, or a
+ * caller that overlaps its own H2D copies): d_seq / d_offsets are device
+ * pointers with the same meaning, max_read_len the longest read in the batch.
+ * Asynchronous on the context's stream; records are not produced. */
+dbtk_status_t dbtk_align_batch_device(dbtk_ctx_t* ctx, const void* d_seq, const void* d_offsets,
+                                      uint64_t npairs, uint32_t max_read_len);
+dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* ctx);
+
+/* Copy the accumulated results to the host.  counts[ntrkmers] is in
+ * OUT.trkmc.ar order; kmc[nloci]; nmapread[nloci]; counters[DBTK_C_COUNT].
+ * Any pointer may be NULL. */
+dbtk_status_t dbtk_ctx_counts(dbtk_ctx_t* ctx, uint64_t* counts, uint64_t* kmc,
+                              uint32_t* nmapread, uint64_t* counters);
+/* Device addresses + lengths of the same accumulators, for the one RCCL
+ * all-reduce that replaces the reference's shared-memory atomics
+ * (src/aQueryFasta_thread.cpp:2146-2158, 1887-1895) across GPUs.  All four live
+ * in ONE contiguous uint64 buffer: *d_base, *n_u64 (nmapread widened to u64). */
+dbtk_status_t dbtk_ctx_accum_buffer(dbtk_ctx_t* ctx, void** d_base, uint64_t* n_u64);
+dbtk_status_t dbtk_ctx_reset(dbtk_ctx_t* ctx);
+
+/* In-process multi-GPU reduce (one context per GPU, RCCL over xGMI). */
+dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n);
+
+/* Per-kernel device time of the last batch, HIP events on the ctx stream, ms.
+ * names[i] are static strings; returns how many were filled (<= cap). */
+int dbtk_ctx_kernel_times(dbtk_ctx_t* ctx, const char** names, float* ms, int cap);
+
+/* ---- dumps: src/aQueryFasta_thread.cpp:2631-2641 --------------------------*/
+/* with_names = 0: OUT.trkmc.ar + OUT.tr.summary.txt; 1: OUT.tr.kmers (-on). */
+dbtk_status_t dbtk_write_outputs(const dbtk_rpgg_t* h, const uint64_t* counts, const uint64_t* kmc,
+                                 const uint32_t* nmapread, const char* out_prefix, int with_names);
+
+const char* dbtk_last_error(void);
+uint32_t    dbtk_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBTK_H_ */

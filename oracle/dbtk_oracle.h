@@ -1,0 +1,57 @@
+/*
+ * dbtk_oracle.h — CPU oracle for the `danbing-tk align` hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference
+ * algorithm (ChaissonLab/danbing-tk, src/aQueryFasta_thread.cpp) used as the
+ * checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ * Nothing in the product (danbing-tk_amd/) may include, link or call it.
+ *
+ * Parity pinning: the reference holds no golden vectors for this path
+ * (SURVEY.md 4, 8c).  The oracle is pinned against the reference itself,
+ * compiled from /root/reference into oracle/_ref/ (Makefile in this
+ * directory): function by function through oracle/_ref/libdbtk_refharness.so
+ * and end to end against oracle/_ref/danbing-tk, and against the fixtures
+ * those produced under tests/golden/.
+ */
+#ifndef DBTK_ORACLE_H_
+#define DBTK_ORACLE_H_
+
+#include "../include/dbtk.h" /* struct layouts only (params, records, flat RPGG) */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_rpgg orc_rpgg_t;
+
+orc_rpgg_t* orc_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a);
+/* Reads PREF.kmers.dbi / PREF.fl.kdb / PREF.tre.kdb / PREF.tr.kmers (+qc). */
+orc_rpgg_t* orc_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_file);
+void        orc_rpgg_free(orc_rpgg_t* g);
+uint64_t    orc_rpgg_nloci(const orc_rpgg_t* g);
+uint64_t    orc_rpgg_ntrkmers(const orc_rpgg_t* g);
+const uint64_t* orc_rpgg_tr_cnt(const orc_rpgg_t* g);
+const uint64_t* orc_rpgg_tr_ks(const orc_rpgg_t* g);
+
+/* The hot loop over a batch (src/aQueryFasta_thread.cpp:2002-2249).
+ * counts_fileorder[ntrkmers] is indexed like PREF.tr.kmers (file order), NOT
+ * like OUT.trkmc.ar; all outputs ACCUMULATE.  recs: NULL, or npairs records
+ * (one per pair, `trace` semantics of include/dbtk.h). */
+int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq,
+              const uint64_t* off, uint64_t npairs, uint64_t* counts_fileorder, uint64_t* kmc,
+              uint32_t* nmapread, uint64_t* counters, dbtk_pair_rec_t* recs);
+
+/* Function-level restatements (for pinning against the reference harness). */
+uint64_t orc_nurc(uint64_t kmer, uint32_t k);                               /* getNuRC  AQ.h:165-178 */
+uint64_t orc_read2kmers_edges(const uint8_t* read, uint64_t rlen, uint32_t k,
+                              uint64_t* kmers, uint64_t* edges);            /* AQ.h:274-311; returns kmers.size() */
+void     orc_sort_index(const uint64_t* data, uint64_t n, uint64_t* idx);   /* getSortedIndex AQ.cpp:247-250 == GCC std::sort */
+/* libstdc++ std::unordered_map<size_t,...> iteration order after inserting
+ * keys[0..n) with operator[] (AQ.h:469-480 then AQ.h:929-936 / BIO:36-46):
+ * order[j] = index into keys of the j-th element visited. Returns 0 on success. */
+int      orc_umap_order(const uint64_t* keys, uint64_t n, uint64_t* order);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,205 @@
+/*
+ * ref_harness.cpp — function-level access to the REAL reference.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This translation unit contains no reference
+ * code: it #includes the reference's own source where it lies under
+ * /root/reference (the include path is given by oracle/Makefile) with `main`
+ * renamed, and exports thin extern "C" shims around the reference's functions
+ * so the tests can pin the C oracle (dbtk_oracle.c) and the HIP path against
+ * them one routine at a time.  Output: oracle/_ref/libdbtk_refharness.so
+ * (git-ignored; it travels to the GPU box with the snapshot).
+ *
+ * ref_pair_*() drives the reference's functions in the order CountWords does
+ * (src/aQueryFasta_thread.cpp:2035-2158); only that glue is restated here,
+ * every computation is the reference's.
+ */
+#define main danbing_tk_reference_main
+#include "aQueryFasta_thread.cpp"
+#undef main
+
+#include "../include/dbtk.h"
+
+namespace {
+struct RefDB {
+    uint64_t nloci = 0;
+    kmerIndex_uint32_umap kmerDBi;
+    vector<uint32_t> kmerDBi_vv;
+    kset_db_t flankDB, trEdgeDB;
+    vector<kmer_aCount_umap> trKmerDB;
+    vector<uint8_t> qcFilter;
+    vector<uint32_t> hits1, hits2;
+    /* key -> file-order index of PREF.tr.kmers, per locus */
+    vector<unordered_map<uint64_t, uint64_t>> fileIndex;
+    uint64_t ntr = 0;
+};
+
+void fill_mate(dbtk_mate_rec_t& m, km_asgn_read_t& r) {
+    memset(&m, 0, sizeof(m));
+    m.si = r.si; m.ei = r.ei; m.si_ = r.si_; m.ei_ = r.ei_; m.nt = r.nt; m.bs = r.bs; m.ti = r.ti;
+    m.kf = r.kf; m.hf = r.hf; m.bf = r.bf; m.qf = r.qf; m.af = r.af; m.rm = r.rm;
+    m.nk = r.as.size();
+    for (size_t i = 0; i < r.as.size(); ++i) m.as2[i >> 2] |= (uint8_t)((r.as[i] & 3) << (2 * (i & 3)));
+}
+}  // namespace
+
+extern "C" {
+
+void ref_set_params(uint64_t k, uint64_t nfilter, uint64_t nmfilter, uint64_t max_nt, uint64_t nm_tr) {
+    ksize = k;
+    rmask = (1ULL << 2 * (ksize - 1)) - 1;
+    N_FILTER = nfilter;
+    NM_FILTER = nmfilter;
+    MAX_NT = max_nt;
+    NM_TR = nm_tr;
+}
+
+uint64_t ref_nurc(uint64_t kmer, uint64_t k) { return getNuRC(kmer, k); }
+
+uint64_t ref_read2kmers_edges(const char* read, uint64_t rlen, uint64_t k, uint64_t* kmers, uint64_t* edges) {
+    string s(read, rlen);
+    vector<size_t> ks, es;
+    read2kmers_edges(ks, es, s, k);
+    for (size_t i = 0; i < ks.size(); ++i) kmers[i] = ks[i];
+    for (size_t i = 0; i < es.size(); ++i) edges[i] = es[i];
+    return ks.size();
+}
+
+void ref_sort_index(const uint64_t* data, uint64_t n, uint64_t* idx) {
+    vector<uint64_t> d(data, data + n), ind(n);
+    getSortedIndex(d, ind);
+    for (uint64_t i = 0; i < n; ++i) idx[i] = ind[i];
+}
+
+/* iteration order of kmer_aCount_umap after `db[key] = 0` in input order
+ * (readKmersWithZeroCount, src/aQueryFasta_thread.h:469-480) */
+void ref_umap_order(const uint64_t* keys, uint64_t n, uint64_t* order) {
+    kmer_aCount_umap m;
+    unordered_map<uint64_t, uint64_t> first;
+    for (uint64_t i = 0; i < n; ++i) {
+        m[keys[i]] = 0;
+        if (!first.count(keys[i])) first[keys[i]] = i;
+    }
+    uint64_t j = 0;
+    for (auto& p : m) order[j++] = first[p.first];
+    for (; j < n; ++j) order[j] = (uint64_t)-1;
+}
+
+void* ref_db_load(const char* prefix, const char* qc_file) {
+    RefDB* db = new RefDB;
+    string pref(prefix);
+    db->nloci = countLoci(pref + ".tr.kmers");
+    db->trKmerDB = vector<kmer_aCount_umap>(db->nloci);
+    readBinaryIndex(db->kmerDBi, db->kmerDBi_vv, pref);
+    readBinaryKmerSetDB(db->flankDB, pref + ".fl");
+    readBinaryKmerSetDB(db->trEdgeDB, pref + ".tre");
+    readKmersWithZeroCount(db->trKmerDB, pref + ".tr.kmers");
+    db->qcFilter.resize(db->nloci);
+    if (qc_file) readQCFile(db->qcFilter, string(qc_file));
+    db->hits1.assign(db->nloci + 1, 0);
+    db->hits2.assign(db->nloci + 1, 0);
+    db->fileIndex.resize(db->nloci);
+    {
+        ifstream f(pref + ".tr.kmers");
+        string line;
+        size_t idx = -1;
+        uint64_t fi = 0;
+        while (getline(f, line)) {
+            if (line[0] == '>') { ++idx; }
+            else {
+                uint64_t km = stoul(line);
+                if (!db->fileIndex[idx].count(km)) db->fileIndex[idx][km] = fi;
+                ++fi;
+            }
+        }
+        db->ntr = fi;
+    }
+    return db;
+}
+void ref_db_free(void* h) { delete (RefDB*)h; }
+uint64_t ref_db_nloci(void* h) { return ((RefDB*)h)->nloci; }
+uint64_t ref_db_ntr(void* h) { return ((RefDB*)h)->ntr; }
+
+/* One pair through the reference's live path.  Accumulates like orc_align. */
+void ref_pair(void* h, const char* s1, uint64_t l1, const char* s2, uint64_t l2, uint32_t Cth, int okam, int qc,
+              uint64_t* counts_fileorder, uint64_t* kmc, uint32_t* nmapread, uint64_t* C, dbtk_pair_rec_t* rec,
+              uint32_t pair_index) {
+    RefDB& db = *(RefDB*)h;
+    const uint64_t nloci = db.nloci;
+    uint16_t Cthreshold = Cth;
+    string seq1(s1, l1), seq2(s2, l2);
+    vector<uint64_t> caks1, caks2, caes1, caes2;
+    vector<kmerIndex_uint32_umap::iterator> its1, its2;
+    vector<PE_KMC> dup;
+    log_t log;
+    int rm1 = 0, rm2 = 0, kf1 = 0, kf2 = 0, hf1 = 0, hf2 = 0, bf1 = 0, bf2 = 0, qf1 = 0, qf2 = 0, af1 = 0, af2 = 0;
+    int qn1 = 0, qn2 = 0, qm1 = 0, qm2 = 0, nm1 = 0, nm2 = 0;
+    uint64_t destLocus = nloci, destLocus0 = NAN32;
+    uint64_t nhash0 = 0, nhash1 = 0;
+    uint32_t stage = 0;
+    km_asgn_t kam;
+    C[DBTK_C_NREADS] += 2;
+
+    read2kmers_edges(caks1, caes1, seq1, ksize);
+    read2kmers_edges(caks2, caes2, seq2, ksize);
+    do {
+        if (not caks1.size() or not caks2.size()) { C[DBTK_C_NSHORT] += 1; stage = DBTK_STAGE_SHORT; break; }
+        if (N_FILTER and NM_FILTER) {
+            bool sub = subfilter(caks1, caks2, db.kmerDBi, nhash0);
+            if (sub) { C[DBTK_C_SUBFILTERED] += 2; stage = DBTK_STAGE_SUBFILTER; break; }
+        }
+        kfilter(caks1, caks2, its1, its2, db.kmerDBi, Cthreshold, nhash1, kf1, kf2, rm1, rm2);
+        C[DBTK_C_KMERFILTERED] += kf1 + kf2;
+        if (rm1 and rm2) { stage = DBTK_STAGE_KFILTER; break; }
+        destLocus = countHit(db.kmerDBi_vv, its1, its2, db.hits1, db.hits2, dup, nloci, Cthreshold, log, destLocus0, nm1, nm2,
+                             hf1, hf2, rm1, rm2);
+        C[DBTK_C_LOCUSFILTERED] += hf1 + hf2;
+        if (destLocus == nloci) { stage = DBTK_STAGE_LOCUS; break; }
+        if (qc and not db.qcFilter[destLocus]) { C[DBTK_C_QCFILTERED] += 2 - rm1 - rm2; stage = DBTK_STAGE_QC; break; }
+        C[DBTK_C_THREADING] += 2;
+        C[DBTK_C_FEASIBLE] += 2;
+        vector<kmer_aCount_umap::iterator> kits1, kits2;
+        if (okam or not rm1 or not rm2) {
+            kmer_aCount_umap& trKmers = db.trKmerDB[destLocus0];
+            unordered_set<uint64_t>& flKmers = db.flankDB[destLocus0];
+            assignTRkmc(caks1, trKmers, flKmers, kits1, kam.r1, af1, rm1, okam);
+            assignTRkmc(caks2, trKmers, flKmers, kits2, kam.r2, af2, rm2, okam);
+        }
+        if (rm1 and rm2) { destLocus = nloci; stage = DBTK_STAGE_ASGN; }
+        else {
+            int n = 2 - rm1 - rm2;
+            nmapread[destLocus] += n;
+            C[DBTK_C_ASGN] += n;
+            kmc[destLocus] += (kam.r1.ei - kam.r1.si) + (kam.r2.ei - kam.r2.si);
+            auto& as1 = kam.r1.as;
+            auto& as2 = kam.r2.as;
+            auto& fidx = db.fileIndex[destLocus0];
+            if (not rm1) { for (int i = 0; i < (int)as1.size(); ++i) { if (as1[i] == 2) { ++counts_fileorder[fidx[kits1[i]->first]]; } } }
+            if (not rm2) { for (int i = 0; i < (int)as2.size(); ++i) { if (as2[i] == 2) { ++counts_fileorder[fidx[kits2[i]->first]]; } } }
+            stage = DBTK_STAGE_COUNTED;
+        }
+    } while (0);
+    C[DBTK_C_NHASH0] += nhash0;
+    C[DBTK_C_NHASH1] += nhash1;
+    if (rec) {
+        kam.r1.assign(kf1, hf1, bf1, qf1, af1, rm1, qm1, qn1);
+        kam.r2.assign(kf2, hf2, bf2, qf2, af2, rm2, qm2, qn2);
+        rec->pair = pair_index;
+        rec->stage = stage;
+        rec->dst = destLocus;
+        rec->dst0 = destLocus0;
+        rec->nm1 = nm1;
+        rec->nm2 = nm2;
+        fill_mate(rec->r1, kam.r1);
+        fill_mate(rec->r2, kam.r2);
+    }
+}
+
+void ref_align(void* h, const char* seq, const uint64_t* off, uint64_t npairs, uint32_t Cth, int okam, int qc,
+               uint64_t* counts_fileorder, uint64_t* kmc, uint32_t* nmapread, uint64_t* C, dbtk_pair_rec_t* recs) {
+    for (uint64_t p = 0; p < npairs; ++p) {
+        ref_pair(h, seq + off[2 * p], off[2 * p + 1] - off[2 * p], seq + off[2 * p + 1], off[2 * p + 2] - off[2 * p + 1], Cth, okam,
+                 qc, counts_fileorder, kmc, nmapread, C, recs ? recs + p : nullptr, (uint32_t)p);
+    }
+}
+
+}  // extern "C"

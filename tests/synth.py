@@ -1,0 +1,231 @@
+"""Seeded synthetic RPGG + read generator for the parity tests (numpy only).
+
+Nothing here comes from the reference: loci are random flank + motif-repeat
+sequences, haplotypes differ by copy number and point variation, reads are
+150 bp PE tiles with optional substitutions / indels / N / lowercase, chimeric
+pairs, background pairs and short reads.  RPGG *files* are produced from the
+haplotype FASTAs by the reference's own tools (oracle/_ref/fa2kmers + ktools
+serialize; recipe of SURVEY.md 8c) so the inputs of every parity test are in
+the reference's on-disk formats.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from dataclasses import dataclass, field
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+COMP = np.zeros(256, dtype=np.uint8)
+for a, b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+    COMP[a] = b
+
+
+def ref_tool(name: str) -> str:
+    p = os.path.join(REFDIR, name)
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p} missing: run `make -C oracle ref` where /root/reference exists")
+    return p
+
+
+def have_ref() -> bool:
+    return all(os.path.exists(os.path.join(REFDIR, t)) for t in ("danbing-tk", "ktools", "fa2kmers", "libdbtk_refharness.so"))
+
+
+def revcomp(s: np.ndarray) -> np.ndarray:
+    return COMP[s[::-1]]
+
+
+@dataclass
+class Loci:
+    flank: int
+    haps: list  # haps[h][l] = uint8 array: flank + TR + flank
+    nloci: int = 0
+    nhap: int = 0
+
+
+def make_loci(nloci=3, nhap=3, flank=500, tr_min=60, tr_max=900, seed=1, shared_frac=0.0, motif_min=5, motif_max=40,
+              variation=0.15) -> Loci:
+    """Random loci.  With shared_frac > 0 a locus copies 300 bp of its left
+    flank from the previous locus (k-mers shared by loci -> odd `val` / vv)."""
+    rng = np.random.default_rng(seed)
+    haps = [[] for _ in range(nhap)]
+    prev_lf = None
+    for l in range(nloci):
+        lf = BASES[rng.integers(0, 4, flank)]
+        rf = BASES[rng.integers(0, 4, flank)]
+        if prev_lf is not None and rng.random() < shared_frac:
+            n = min(300, flank)
+            lf[flank - n:] = prev_lf[flank - n:]
+        prev_lf = lf
+        motif = BASES[rng.integers(0, 4, rng.integers(motif_min, motif_max + 1))]
+        trlen = int(np.exp(rng.uniform(np.log(tr_min), np.log(tr_max))))
+        ncopy = max(2, trlen // len(motif))
+        for h in range(nhap):
+            nc = max(1, ncopy + int(rng.integers(-3, 4)))
+            copies = []
+            for _ in range(nc):
+                m = motif.copy()
+                if rng.random() < variation:
+                    m[rng.integers(0, len(m))] = BASES[rng.integers(0, 4)]
+                copies.append(m)
+            tr = np.concatenate(copies)
+            haps[h].append(np.concatenate([lf, tr, rf]))
+    return Loci(flank=flank, haps=haps, nloci=nloci, nhap=nhap)
+
+
+def write_hap_fastas(loci: Loci, outdir: str) -> list:
+    os.makedirs(outdir, exist_ok=True)
+    fns = []
+    for h, hap in enumerate(loci.haps):
+        fn = os.path.join(outdir, f"h{h}.fa")
+        with open(fn, "wb") as f:
+            for l, s in enumerate(hap):
+                f.write(b">locus%d\n" % l)
+                f.write(s.tobytes() + b"\n")
+        fns.append(fn)
+    return fns
+
+
+def build_rpgg_with_reference(loci: Loci, outdir: str, k=21, name="pan") -> str:
+    """SURVEY.md 8c recipe: fa2kmers (tr/fl/graph), fa2kmers -tr -k k+1 (tre),
+    ktools serialize.  Returns the RPGG prefix."""
+    fas = write_hap_fastas(loci, outdir)
+    pref = os.path.join(outdir, name)
+    fs = str(loci.flank)
+    run = lambda *a: subprocess.run(list(a), check=True, cwd=outdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    run(ref_tool("fa2kmers"), "-g", "-k", str(k), "-fsi", fs, "-fso", fs, "-on", name, "-fa", str(len(fas)), *fas)
+    run(ref_tool("fa2kmers"), "-tr", "-k", str(k + 1), "-fsi", fs, "-fso", fs, "-on", name + "e", "-fa", str(len(fas)), *fas)
+    shutil.move(os.path.join(outdir, name + "e.tr.kmers"), pref + ".tre.kmers")
+    run(ref_tool("ktools"), "serialize", name)
+    return pref
+
+
+@dataclass
+class Reads:
+    seqs: list = field(default_factory=list)    # list of bytes; read 2p, 2p+1 = pair p
+    titles: list = field(default_factory=list)  # one per pair (no /1 /2)
+    quals: list = field(default_factory=list)
+
+    def packed(self):
+        off = np.zeros(len(self.seqs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(s) for s in self.seqs], dtype=np.uint64)
+        buf = np.frombuffer(b"".join(self.seqs), dtype=np.uint8).copy() if self.seqs else np.zeros(0, np.uint8)
+        return buf, off
+
+    @property
+    def npairs(self):
+        return len(self.seqs) // 2
+
+
+def _mutate(rng, s: np.ndarray, sub, indel, nrate, lower) -> np.ndarray:
+    s = s.copy()
+    if sub > 0:
+        m = rng.random(len(s)) < sub
+        s[m] = BASES[rng.integers(0, 4, int(m.sum()))]
+    if indel > 0 and rng.random() < indel * len(s):
+        p = int(rng.integers(1, len(s) - 1))
+        if rng.random() < 0.5:
+            s = np.concatenate([s[:p], BASES[rng.integers(0, 4, 1)], s[p:-1]])
+        else:
+            s = np.concatenate([s[:p], s[p + 1:], BASES[rng.integers(0, 4, 1)]])
+    if nrate > 0:
+        m = rng.random(len(s)) < nrate
+        s[m] = ord("N")
+    if lower > 0 and rng.random() < lower:
+        p = int(rng.integers(0, len(s)))
+        s[p] = s[p] | 0x20
+    return s
+
+
+def sim_reads(loci: Loci, npairs=1000, rlen=150, frag=(300, 500), seed=2, sub=0.0, indel=0.0, nrate=0.0, lower=0.0,
+              chimeric=0.0, background=0.0, short=0.0, with_qual=False) -> Reads:
+    """Pairs in the orientation the reference's reader hands to the hot loop:
+    seqs[2p] and seqs[2p+1] are simply the two mates."""
+    rng = np.random.default_rng(seed)
+    out = Reads()
+    for p in range(npairs):
+        u = rng.random()
+        if u < background:
+            a = BASES[rng.integers(0, 4, rlen)]
+            b = BASES[rng.integers(0, 4, rlen)]
+            name = "bg"
+        else:
+            def mate_from(l, h):
+                s = loci.haps[h][l]
+                fl = int(rng.integers(frag[0], frag[1] + 1))
+                fl = min(fl, len(s))
+                beg = int(rng.integers(0, len(s) - fl + 1))
+                return s[beg:beg + rlen], revcomp(s[beg + fl - rlen:beg + fl])
+            l = int(rng.integers(0, loci.nloci)); h = int(rng.integers(0, loci.nhap))
+            a, b = mate_from(l, h)
+            name = f"l{l}h{h}"
+            if rng.random() < chimeric:
+                l2 = int(rng.integers(0, loci.nloci)); h2 = int(rng.integers(0, loci.nhap))
+                _, b = mate_from(l2, h2)
+                name += f"x{l2}"
+            if rng.random() < 0.5:
+                a, b = b, a
+        a = _mutate(rng, a, sub, indel, nrate, lower)
+        b = _mutate(rng, b, sub, indel, nrate, lower)
+        if rng.random() < short:
+            n = int(rng.integers(0, 70))
+            if rng.random() < 0.5:
+                a = a[:n]
+            else:
+                b = b[:n]
+        out.seqs += [a.tobytes(), b.tobytes()]
+        out.titles.append(f"r{p}:{name}")
+        if with_qual:
+            out.quals += [bytes(rng.integers(33 + 2, 33 + 41, len(a), dtype=np.uint8)),
+                          bytes(rng.integers(33 + 2, 33 + 41, len(b), dtype=np.uint8))]
+    return out
+
+
+def write_fasta(reads: Reads, fn: str, fastq=False, interleave=True):
+    """Mates are written so that the reference's reader (AQ.cpp:1918-1976)
+    rebuilds seqs[2p] = reads.seqs[2p]: it makes `seq1` the LATER record of a
+    title and `seq2` the parked one, so mate 2p+1 is written first."""
+    with open(fn, "wb") as f:
+        for p in range(reads.npairs):
+            t = reads.titles[p].encode()
+            for which, tag in ((2 * p + 1, b"/2"), (2 * p, b"/1")):
+                if fastq:
+                    f.write(b"@" + t + tag + b"\n" + reads.seqs[which] + b"\n+\n" + reads.quals[which] + b"\n")
+                else:
+                    f.write(b">" + t + tag + b"\n" + reads.seqs[which] + b"\n")
+
+
+def read_rpgg_files(pref: str):
+    """Flat arrays of the HEAD on-disk RPGG (layouts: SURVEY.md 2.3)."""
+    with open(pref + ".kmers.dbi", "rb") as f:
+        nk = int(np.frombuffer(f.read(8), np.uint64)[0])
+        keys = np.frombuffer(f.read(8 * nk), np.uint64).copy()
+        vals = np.frombuffer(f.read(4 * nk), np.uint32).copy()
+        nvv = int(np.frombuffer(f.read(8), np.uint64)[0])
+        vv = np.frombuffer(f.read(4 * nvv), np.uint32).copy()
+
+    def kdb(fn):
+        with open(fn, "rb") as f:
+            nl = int(np.frombuffer(f.read(8), np.uint64)[0])
+            cnt = np.frombuffer(f.read(8 * nl), np.uint64).copy()
+            n = int(np.frombuffer(f.read(8), np.uint64)[0])
+            ks = np.frombuffer(f.read(8 * n), np.uint64).copy()
+        return cnt, ks
+
+    fl_cnt, fl_ks = kdb(pref + ".fl.kdb")
+    tre_cnt, tre_ks = kdb(pref + ".tre.kdb")
+    tr_cnt, tr_ks = [], []
+    with open(pref + ".tr.kmers") as f:
+        for line in f:
+            if line[0] == ">":
+                tr_cnt.append(0)
+            else:
+                tr_ks.append(int(line.split()[0]))
+                tr_cnt[-1] += 1
+    return dict(keys=keys, vals=vals, vv=vv, fl_cnt=fl_cnt, fl_ks=fl_ks, tre_cnt=tre_cnt, tre_ks=tre_ks,
+                tr_cnt=np.array(tr_cnt, np.uint64), tr_ks=np.array(tr_ks, np.uint64), nloci=len(tr_cnt))
