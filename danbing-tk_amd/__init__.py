@@ -2,6 +2,219 @@
 
 Import with importlib.import_module("danbing-tk_amd") (the hyphen follows the
 reference's name).  `abi` mirrors include/dbtk.h; `Dbtk` binds the C-ABI of
-libdbtk_hip.so and raises if the HIP library is missing — there is no CPU path.
+libdbtk_hip.so (hand-written HIP for gfx950, built by csrc/Makefile) and raises
+if that library is missing — there is no CPU execution path.
 """
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
 from . import abi  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdbtk_hip.so")
+
+u64p, u32p, u8p = abi.u64p, abi.u32p, abi.u8p
+
+
+class DbtkError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"dbtk status {status}: {msg}")
+        self.status = status
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def bind_common(L):
+    """Prototypes of the host-side entry points (shared with the test emulator)."""
+    L.dbtk_last_error.restype = C.c_char_p
+    L.dbtk_abi_version.restype = C.c_uint32
+    L.dbtk_rpgg_load.restype = C.c_int
+    L.dbtk_rpgg_load.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.dbtk_rpgg_from_arrays.restype = C.c_int
+    L.dbtk_rpgg_from_arrays.argtypes = [C.POINTER(abi.RpggArrays), C.POINTER(C.c_void_p)]
+    L.dbtk_rpgg_free.argtypes = [C.c_void_p]
+    for f in ("dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys"):
+        getattr(L, f).restype = C.c_uint64
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.dbtk_rpgg_view.restype = C.c_int
+    L.dbtk_rpgg_view.argtypes = [C.c_void_p, C.POINTER(abi.RpggArrays)]
+    L.dbtk_rpgg_output_order.restype = C.c_int
+    L.dbtk_rpgg_output_order.argtypes = [C.c_void_p, u64p]
+    L.dbtk_params_default.argtypes = [C.POINTER(abi.Params)]
+    L.dbtk_write_outputs.restype = C.c_int
+    L.dbtk_write_outputs.argtypes = [C.c_void_p, u64p, u64p, u32p, C.c_char_p, C.c_int]
+
+
+class Rpgg:
+    """Immutable RPGG handle (dbtk_rpgg_t)."""
+
+    def __init__(self, lib, handle):
+        self._lib, self.h = lib, handle
+        L = lib.L
+        self.nloci = L.dbtk_rpgg_nloci(handle)
+        self.ntrkmers = L.dbtk_rpgg_ntrkmers(handle)
+        self.nkeys = L.dbtk_rpgg_nkeys(handle)
+
+    def output_order(self):
+        v = abi.RpggArrays()
+        self._lib._chk(self._lib.L.dbtk_rpgg_view(self.h, C.byref(v)))
+        n = int(sum(v.tr_cnt[i] for i in range(self.nloci)))
+        out = np.zeros(n, np.uint64)
+        self._lib._chk(self._lib.L.dbtk_rpgg_output_order(self.h, _ptr(out, u64p)))
+        return out
+
+    def view(self):
+        v = abi.RpggArrays()
+        self._lib._chk(self._lib.L.dbtk_rpgg_view(self.h, C.byref(v)))
+        return v
+
+    def write_outputs(self, counts, kmc, nmapread, out_prefix, with_names=False):
+        self._lib._chk(self._lib.L.dbtk_write_outputs(self.h, _ptr(counts, u64p), _ptr(kmc, u64p), _ptr(nmapread, u32p),
+                                                      out_prefix.encode(), int(with_names)))
+
+    def close(self):
+        if self.h:
+            self._lib.L.dbtk_rpgg_free(self.h)
+            self.h = None
+
+
+class _HostSide:
+    def _chk(self, st):
+        if st != abi.OK:
+            raise DbtkError(st, self.L.dbtk_last_error().decode())
+
+    def load(self, prefix, k=21, qc_file=None, bait_file=None) -> Rpgg:
+        h = C.c_void_p()
+        self._chk(self.L.dbtk_rpgg_load(prefix.encode(), k, qc_file.encode() if qc_file else None,
+                                        bait_file.encode() if bait_file else None, C.byref(h)))
+        return Rpgg(self, h)
+
+    def from_arrays(self, k, keys, vals, vv, fl_cnt, fl_ks, tr_cnt, tr_ks, tre_cnt=None, tre_ks=None, qc=None) -> Rpgg:
+        keep = [np.ascontiguousarray(x, t) if x is not None else None for x, t in
+                ((keys, np.uint64), (vals, np.uint32), (vv, np.uint32), (fl_cnt, np.uint64), (fl_ks, np.uint64),
+                 (tre_cnt, np.uint64), (tre_ks, np.uint64), (tr_cnt, np.uint64), (tr_ks, np.uint64), (qc, np.uint8))]
+        a = abi.RpggArrays(ksize=k, nloci=len(keep[7]), nkeys=len(keep[0]), keys=_ptr(keep[0], u64p), vals=_ptr(keep[1], u32p),
+                           nvv=len(keep[2]), vv=_ptr(keep[2], u32p), fl_cnt=_ptr(keep[3], u64p), fl_ks=_ptr(keep[4], u64p),
+                           tre_cnt=_ptr(keep[5], u64p), tre_ks=_ptr(keep[6], u64p), tr_cnt=_ptr(keep[7], u64p),
+                           tr_ks=_ptr(keep[8], u64p), qc=_ptr(keep[9], u8p))
+        h = C.c_void_p()
+        self._chk(self.L.dbtk_rpgg_from_arrays(C.byref(a), C.byref(h)))
+        return Rpgg(self, h)
+
+
+class Context:
+    """Per-GPU context (dbtk_ctx_t)."""
+
+    def __init__(self, lib, rpgg: Rpgg, params: abi.Params, device=0):
+        self._lib, self.rpgg, self.params = lib, rpgg, params
+        h = C.c_void_p()
+        lib._chk(lib.L.dbtk_ctx_create(rpgg.h, C.byref(params), device, C.byref(h)))
+        self.h = h
+
+    def align(self, seq, off, qual=None, rec_cap=None):
+        """One batch of pairs from host buffers.  Returns the batch's records
+        (ctypes array, pair order) — counts accumulate inside the context."""
+        L = self._lib.L
+        off = np.ascontiguousarray(off, np.uint64)
+        seq = np.ascontiguousarray(seq, np.uint8)
+        npairs = (len(off) - 1) // 2
+        p = self.params
+        want = bool(p.trace or p.okam or p.extract)
+        cap = npairs if rec_cap is None else rec_cap
+        recs = (abi.PairRec * max(cap, 1))() if want and cap else None
+        nrec = C.c_uint64(0)
+        seqp = _ptr(seq if seq.size else np.zeros(1, np.uint8), u8p)
+        self._lib._chk(L.dbtk_align_batch(self.h, seqp, _ptr(off, u64p), _ptr(qual, u8p), npairs, recs, cap if recs else 0,
+                                          C.byref(nrec)))
+        return recs, int(nrec.value)
+
+    def align_device(self, d_seq_ptr, d_off_ptr, npairs, max_read_len):
+        self._lib._chk(self._lib.L.dbtk_align_batch_device(self.h, C.c_void_p(d_seq_ptr), C.c_void_p(d_off_ptr), npairs,
+                                                           max_read_len))
+
+    def synchronize(self):
+        self._lib._chk(self._lib.L.dbtk_ctx_synchronize(self.h))
+
+    def counts(self):
+        g = self.rpgg
+        counts = np.zeros(g.ntrkmers, np.uint64)
+        kmc = np.zeros(g.nloci, np.uint64)
+        nmap = np.zeros(g.nloci, np.uint32)
+        ctr = np.zeros(abi.C_COUNT, np.uint64)
+        self._lib._chk(self._lib.L.dbtk_ctx_counts(self.h, _ptr(counts, u64p), _ptr(kmc, u64p), _ptr(nmap, u32p), _ptr(ctr, u64p)))
+        return dict(counts=counts, kmc=kmc, nmapread=nmap, counters=ctr)
+
+    def accum_buffer(self):
+        base = C.c_void_p()
+        n = C.c_uint64()
+        self._lib._chk(self._lib.L.dbtk_ctx_accum_buffer(self.h, C.byref(base), C.byref(n)))
+        return base.value, int(n.value)
+
+    def reset(self):
+        self._lib._chk(self._lib.L.dbtk_ctx_reset(self.h))
+
+    def kernel_times(self):
+        names = (C.c_char_p * 8)()
+        ms = (C.c_float * 8)()
+        n = self._lib.L.dbtk_ctx_kernel_times(self.h, names, ms, 8)
+        return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+    def close(self):
+        if self.h:
+            self._lib.L.dbtk_ctx_free(self.h)
+            self.h = None
+
+
+class Dbtk(_HostSide):
+    """The product: C-ABI of libdbtk_hip.so.  Fails loudly when the HIP
+    extension has not been built — nothing falls back to the CPU."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not found: build it with `make -C danbing-tk_amd/csrc` "
+                                    "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = self.L = C.CDLL(path)
+        bind_common(L)
+        L.dbtk_ctx_create.restype = C.c_int
+        L.dbtk_ctx_create.argtypes = [C.c_void_p, C.POINTER(abi.Params), C.c_int, C.POINTER(C.c_void_p)]
+        L.dbtk_ctx_free.argtypes = [C.c_void_p]
+        L.dbtk_align_batch.restype = C.c_int
+        L.dbtk_align_batch.argtypes = [C.c_void_p, u8p, u64p, u8p, C.c_uint64, C.POINTER(abi.PairRec), C.c_uint64, u64p]
+        L.dbtk_align_batch_device.restype = C.c_int
+        L.dbtk_align_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+        L.dbtk_ctx_synchronize.restype = C.c_int
+        L.dbtk_ctx_synchronize.argtypes = [C.c_void_p]
+        L.dbtk_ctx_counts.restype = C.c_int
+        L.dbtk_ctx_counts.argtypes = [C.c_void_p, u64p, u64p, u32p, u64p]
+        L.dbtk_ctx_accum_buffer.restype = C.c_int
+        L.dbtk_ctx_accum_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), u64p]
+        L.dbtk_ctx_reset.restype = C.c_int
+        L.dbtk_ctx_reset.argtypes = [C.c_void_p]
+        L.dbtk_ctx_kernel_times.restype = C.c_int
+        L.dbtk_ctx_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+        L.dbtk_allreduce.restype = C.c_int
+        L.dbtk_allreduce.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        if L.dbtk_abi_version() != abi.ABI_VERSION:
+            raise RuntimeError("libdbtk_hip.so ABI version mismatch")
+
+    def context(self, rpgg: Rpgg, params: abi.Params, device=0) -> Context:
+        return Context(self, rpgg, params, device)
+
+    def allreduce(self, ctxs):
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        self._chk(self.L.dbtk_allreduce(arr, len(ctxs)))
+
+
+# every symbol include/dbtk.h declares (checked by the CPU test-suite)
+EXPORTS = [
+    "dbtk_rpgg_load", "dbtk_rpgg_from_arrays", "dbtk_rpgg_free", "dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys",
+    "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
+    "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
+    "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_write_outputs", "dbtk_last_error", "dbtk_abi_version",
+]

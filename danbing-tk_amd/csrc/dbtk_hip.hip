@@ -1,0 +1,501 @@
+// dbtk_hip.hip — gfx950 kernels + per-GPU context of the align hot path.
+//
+// The kernel bodies live in dbtk_kernels.h; this file binds them to the
+// hardware (DevX: wave64 ballot / shuffles, __syncthreads, global + LDS
+// atomics), owns the HBM-resident tables and accumulators, and implements the
+// device half of include/dbtk.h.  There is no host execution path: without a
+// HIP device dbtk_ctx_create fails with DBTK_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "dbtk_internal.h"
+#include "dbtk_kernels.h"
+
+using namespace dbtk;
+
+// ------------------------------------------------------------------ DevX ---
+struct DevX {
+    void* sm;
+    __device__ int tid() const { return (int)threadIdx.x; }
+    __device__ int nthreads() const { return (int)blockDim.x; }
+    __device__ uint32_t bid() const { return blockIdx.x; }
+    __device__ uint32_t nblocks() const { return gridDim.x; }
+    __device__ int lane() const { return (int)(threadIdx.x & 63); }
+    __device__ void sync() const { __syncthreads(); }
+    __device__ uint64_t ballot(bool p) const { return __ballot(p); }
+    __device__ uint32_t wave_sum(uint32_t v) const {
+        for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
+    __device__ uint32_t wave_excl_scan(uint32_t v) const {
+        uint32_t inc = v;
+        const int l = (int)(threadIdx.x & 63);
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if (l >= o) inc += t;
+        }
+        return inc - v;
+    }
+    __device__ uint32_t bcast(uint32_t v, int src) const { return __shfl(v, src, 64); }
+    __device__ void atomic_add(uint64_t* p, uint64_t v) const { atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
+    __device__ uint32_t atomic_add(uint32_t* p, uint32_t v) const { return atomicAdd(p, v); }
+    __device__ uint64_t atomic_cas(uint64_t* p, uint64_t e, uint64_t d) const {
+        return atomicCAS(reinterpret_cast<unsigned long long*>(p), (unsigned long long)e, (unsigned long long)d);
+    }
+    __device__ void atomic_max(uint64_t* p, uint64_t v) const { atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
+    __device__ void atomic_or(uint64_t* p, uint64_t v) const { atomicOr(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
+    __device__ uint32_t lds_add(uint32_t* p, uint32_t v) const { return atomicAdd(p, v); }
+    __device__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
+    template <class T> __device__ T* smem() const { return reinterpret_cast<T*>(sm); }
+};
+
+// --------------------------------------------------------------- kernels ---
+__global__ void __launch_bounds__(256) k_fill_idx(IdxSlot* s, uint64_t cap) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+        s[i].key = NAN64;
+        s[i].val = 0;
+    }
+}
+__global__ void __launch_bounds__(256) k_idx_insert(IdxBuildArgs a) { DevX x{nullptr}; body_idx_insert(x, a); }
+__global__ void __launch_bounds__(256) k_idx_finalize(IdxSlot* s, uint64_t cap) { DevX x{nullptr}; body_idx_finalize(x, s, cap); }
+__global__ void __launch_bounds__(256) k_cls_insert(ClsBuildArgs a) { DevX x{nullptr}; body_cls_insert(x, a); }
+
+__global__ void __launch_bounds__(K1_NT) k_encode_subfilter(BatchArgs a) {
+    __shared__ __attribute__((aligned(16))) K1Smem sm;
+    DevX x{&sm};
+    body_encode_subfilter(x, a);
+}
+__global__ void __launch_bounds__(64) k_pair(BatchArgs a) {
+    __shared__ __attribute__((aligned(16))) PairSmem sm;
+    DevX x{&sm};
+    body_pair(x, a);
+}
+
+// ---------------------------------------------------------------- context --
+#define HIPCHK(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            set_error(std::string(#call) + ": " + hipGetErrorString(e_));                             \
+            return DBTK_ERR_HIP;                                                                      \
+        }                                                                                             \
+    } while (0)
+
+namespace {
+constexpr int MAX_TIMED = 8;
+struct Timed { const char* name; hipEvent_t beg, end; bool used; };
+}  // namespace
+
+struct dbtk_ctx {
+    const dbtk_rpgg* g = nullptr;
+    dbtk_params_t P;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevTables T;
+    // device allocations
+    IdxSlot* d_idx = nullptr;
+    ClsSlot* d_cls = nullptr;
+    uint32_t* d_vv = nullptr;
+    uint8_t* d_qc = nullptr;
+    uint16_t* d_perm = nullptr;
+    uint64_t* d_accum = nullptr;  // counts | kmc | nmapread | counters
+    uint64_t n_accum = 0, ntr = 0;
+    uint32_t* d_small = nullptr;  // nsurv, ticket, nrec, errflag
+    uint32_t* d_surv = nullptr; uint64_t surv_cap = 0;
+    uint8_t* d_seq = nullptr; uint64_t seq_cap = 0;
+    uint64_t* d_off = nullptr; uint64_t off_cap = 0;
+    dbtk_pair_rec_t* d_recs = nullptr; uint64_t rec_cap = 0;
+    uint64_t* d_vote = nullptr;
+    uint32_t* d_epoch = nullptr;
+    int pair_blocks = 0, num_cu = 0;
+    Timed timed[MAX_TIMED];
+    int ntimed = 0;
+};
+
+namespace {
+
+uint64_t pow2_at_least(uint64_t n) {
+    uint64_t c = 1024;
+    while (c < n) c <<= 1;
+    return c;
+}
+uint32_t log2u(uint64_t c) { return 63u - (uint32_t)__builtin_clzll(c); }
+
+void free_ctx(dbtk_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (int i = 0; i < MAX_TIMED; ++i) {
+        if (c->timed[i].beg) (void)hipEventDestroy(c->timed[i].beg);
+        if (c->timed[i].end) (void)hipEventDestroy(c->timed[i].end);
+    }
+    void* ptrs[] = {c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
+                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+dbtk_status_t build_tables(dbtk_ctx* c) {
+    const dbtk_rpgg* g = c->g;
+    const uint64_t nloci = g->nloci;
+    hipStream_t s = c->stream;
+    // ---- index
+    const uint64_t nkeys = g->keys.size();
+    const uint64_t icap = pow2_at_least(2 * nkeys + 2);
+    HIPCHK(hipMalloc(&c->d_idx, icap * sizeof(IdxSlot)));
+    hipLaunchKernelGGL(k_fill_idx, dim3(2048), dim3(256), 0, s, c->d_idx, icap);
+    if (nkeys) {
+        uint64_t* dk = nullptr; uint32_t* dv = nullptr;
+        HIPCHK(hipMalloc(&dk, nkeys * 8));
+        HIPCHK(hipMalloc(&dv, nkeys * 4));
+        HIPCHK(hipMemcpyAsync(dk, g->keys.data(), nkeys * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dv, g->vals.data(), nkeys * 4, hipMemcpyHostToDevice, s));
+        IdxBuildArgs a{c->d_idx, icap - 1, 64 - log2u(icap), dk, dv, nkeys};
+        hipLaunchKernelGGL(k_idx_insert, dim3(2048), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_idx_finalize, dim3(2048), dim3(256), 0, s, c->d_idx, icap);
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipFree(dk));
+        HIPCHK(hipFree(dv));
+    }
+    // ---- vv (never empty on the device: odd vals index it)
+    HIPCHK(hipMalloc(&c->d_vv, (g->vv.size() + 1) * 4));
+    if (!g->vv.empty()) HIPCHK(hipMemcpyAsync(c->d_vv, g->vv.data(), g->vv.size() * 4, hipMemcpyHostToDevice, s));
+    // ---- class table: TR pass first, then flank (flank overrides)
+    const uint64_t ntrf = g->tr_ks.size(), nfl = g->fl_ks.size();
+    const uint64_t ccap = pow2_at_least(2 * (ntrf + nfl) + 2);
+    HIPCHK(hipMalloc(&c->d_cls, ccap * sizeof(ClsSlot)));
+    HIPCHK(hipMemsetAsync(c->d_cls, 0xFF, ccap * sizeof(ClsSlot), s));
+    {
+        std::vector<uint64_t> beg(nloci + 1, 0);
+        uint64_t *dks = nullptr, *dbeg = nullptr, *dslot = nullptr;
+        const uint64_t nmax = ntrf > nfl ? ntrf : nfl;
+        HIPCHK(hipMalloc(&dks, (nmax + 1) * 8));
+        HIPCHK(hipMalloc(&dslot, (ntrf + 1) * 8));
+        HIPCHK(hipMalloc(&dbeg, (nloci + 1) * 8));
+        for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->tr_cnt[l];
+        if (ntrf) {
+            HIPCHK(hipMemcpyAsync(dks, g->tr_ks.data(), ntrf * 8, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(dslot, g->out_slot.data(), ntrf * 8, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(dbeg, beg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
+            ClsBuildArgs a{c->d_cls, ccap - 1, 64 - log2u(ccap), dks, dbeg, (uint32_t)nloci, dslot, ntrf};
+            hipLaunchKernelGGL(k_cls_insert, dim3(2048), dim3(256), 0, s, a);
+            HIPCHK(hipStreamSynchronize(s));
+        }
+        for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->fl_cnt[l];
+        if (nfl) {
+            HIPCHK(hipMemcpyAsync(dks, g->fl_ks.data(), nfl * 8, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(dbeg, beg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
+            ClsBuildArgs a{c->d_cls, ccap - 1, 64 - log2u(ccap), dks, dbeg, (uint32_t)nloci, nullptr, nfl};
+            hipLaunchKernelGGL(k_cls_insert, dim3(2048), dim3(256), 0, s, a);
+            HIPCHK(hipStreamSynchronize(s));
+        }
+        HIPCHK(hipFree(dks));
+        HIPCHK(hipFree(dslot));
+        HIPCHK(hipFree(dbeg));
+    }
+    // ---- QC mask
+    if (!g->qc.empty()) {
+        HIPCHK(hipMalloc(&c->d_qc, nloci));
+        HIPCHK(hipMemcpyAsync(c->d_qc, g->qc.data(), nloci, hipMemcpyHostToDevice, s));
+    }
+    // ---- introsort permutation of n equal keys (the common case: every k-mer unique to one locus)
+    {
+        std::vector<uint16_t> perm((size_t)NHMAX * (NHMAX + 1) / 2 + 1);
+        std::vector<uint32_t> key(NHMAX, 1);
+        int stack[3 * 40];
+        for (int n = 1; n <= NHMAX; ++n) gcc_sort_index(perm.data() + (size_t)n * (n - 1) / 2, n, key.data(), stack);
+        HIPCHK(hipMalloc(&c->d_perm, perm.size() * 2));
+        HIPCHK(hipMemcpyAsync(c->d_perm, perm.data(), perm.size() * 2, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    DevTables& T = c->T;
+    T.idx = c->d_idx; T.idx_mask = icap - 1; T.idx_shift = 64 - log2u(icap);
+    T.vv = c->d_vv;
+    T.cls = c->d_cls; T.cls_mask = ccap - 1; T.cls_shift = 64 - log2u(ccap);
+    T.qc = c->d_qc;
+    T.permtab = c->d_perm;
+    T.nloci = (uint32_t)nloci;
+    T.ksize = g->ksize;
+    return DBTK_OK;
+}
+
+template <class T>
+dbtk_status_t ensure(T** p, uint64_t* cap, uint64_t need) {
+    if (need <= *cap && *p) return DBTK_OK;
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr;
+    const uint64_t ncap = need + need / 4 + 64;
+    HIPCHK(hipMalloc(p, ncap * sizeof(T)));
+    *cap = ncap;
+    return DBTK_OK;
+}
+
+Timed* timer(dbtk_ctx* c, const char* name) {
+    if (c->ntimed >= MAX_TIMED) return nullptr;
+    Timed* t = &c->timed[c->ntimed++];
+    t->name = name;
+    t->used = true;
+    return t;
+}
+
+// K1 + pair kernel over reads already in HBM.
+dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_off, uint64_t seq_len, uint64_t npairs,
+                           dbtk_pair_rec_t* d_recs, uint32_t rec_cap) {
+    hipStream_t s = c->stream;
+    if (npairs >= 0xFFFFFFFFull) { set_error("batch too large (pair index is 32-bit)"); return DBTK_ERR_ARG; }
+    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, npairs + 1);
+    if (st) return st;
+    HIPCHK(hipMemsetAsync(c->d_small, 0, 4 * sizeof(uint32_t), s));
+    BatchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.T = c->T; a.P = c->P;
+    a.seq = d_seq; a.off = d_off; a.seq_len = seq_len; a.npairs = npairs;
+    a.surv = c->d_surv; a.nsurv = c->d_small + 0; a.ticket = c->d_small + 1; a.nrec = c->d_small + 2; a.errflag = c->d_small + 3;
+    a.counts = c->d_accum;
+    a.kmc = c->d_accum + c->ntr;
+    a.nmapread = a.kmc + c->g->nloci;
+    a.counters = a.nmapread + c->g->nloci;
+    a.recs = d_recs; a.rec_cap = rec_cap;
+    a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
+    c->ntimed = 0;
+    if (npairs == 0) return DBTK_OK;
+    const uint64_t ntiles = (npairs + K1_TP - 1) / K1_TP;
+    const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->num_cu * 8 ? ntiles : (uint64_t)c->num_cu * 8);
+    Timed* t1 = timer(c, "k_encode_subfilter");
+    HIPCHK(hipEventRecord(t1->beg, s));
+    hipLaunchKernelGGL(k_encode_subfilter, dim3(g1), dim3(K1_NT), 0, s, a);
+    HIPCHK(hipEventRecord(t1->end, s));
+    Timed* t2 = timer(c, "k_pair");
+    HIPCHK(hipEventRecord(t2->beg, s));
+    hipLaunchKernelGGL(k_pair, dim3(c->pair_blocks), dim3(64), 0, s, a);
+    HIPCHK(hipEventRecord(t2->end, s));
+    HIPCHK(hipGetLastError());
+    return DBTK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int device_id, dbtk_ctx_t** out) {
+    if (!h || !p || !out) { set_error("null argument"); return DBTK_ERR_ARG; }
+    *out = nullptr;
+    if (p->ksize != h->ksize) { set_error("params.ksize differs from the RPGG's k"); return DBTK_ERR_ARG; }
+    if (p->n_filter == 1) { set_error("-kf 1 M divides by zero in the reference (subfilter); refusing"); return DBTK_ERR_ARG; }
+    if (p->n_filter > 32) { set_error("-kf N: N > 32 unsupported"); return DBTK_ERR_UNSUPPORTED; }
+    if (p->bait || p->bubbles) { set_error("-b / -bu are not implemented yet"); return DBTK_ERR_UNSUPPORTED; }
+    if (p->qc && h->qc.empty()) { set_error("params.qc set but the RPGG handle has no QC mask"); return DBTK_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device: this library has no CPU execution path");
+        return DBTK_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= ndev) { set_error("device_id out of range"); return DBTK_ERR_ARG; }
+    HIPCHK(hipSetDevice(device_id));
+    dbtk_ctx* c = new dbtk_ctx;
+    memset(c->timed, 0, sizeof(c->timed));
+    c->g = h; c->P = *p; c->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free_ctx(c); set_error("hipGetDeviceProperties failed"); return DBTK_ERR_HIP; }
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->pair_blocks = c->num_cu * 8;
+    dbtk_status_t st = DBTK_OK;
+    do {
+        if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); st = DBTK_ERR_HIP; break; }
+        for (int i = 0; i < MAX_TIMED && !st; ++i)
+            if (hipEventCreate(&c->timed[i].beg) != hipSuccess || hipEventCreate(&c->timed[i].end) != hipSuccess) { set_error("hipEventCreate failed"); st = DBTK_ERR_HIP; }
+        if (st) break;
+        if ((st = build_tables(c))) break;
+        c->ntr = h->out_kmer.size();
+        c->n_accum = c->ntr + 2 * h->nloci + DBTK_C_COUNT;
+        auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && !st) { set_error(std::string(what) + ": " + hipGetErrorString(e)); st = DBTK_ERR_HIP; } };
+        chk(hipMalloc(&c->d_accum, c->n_accum * 8), "hipMalloc accum");
+        chk(hipMalloc(&c->d_small, 64), "hipMalloc small");
+        chk(hipMalloc(&c->d_vote, (size_t)c->pair_blocks * (h->nloci + 1) * 8), "hipMalloc vote scratch");
+        chk(hipMalloc(&c->d_epoch, (size_t)c->pair_blocks * 4), "hipMalloc epoch");
+        if (st) break;
+        chk(hipMemsetAsync(c->d_accum, 0, c->n_accum * 8, c->stream), "memset");
+        chk(hipMemsetAsync(c->d_vote, 0, (size_t)c->pair_blocks * (h->nloci + 1) * 8, c->stream), "memset");
+        chk(hipMemsetAsync(c->d_epoch, 0, (size_t)c->pair_blocks * 4, c->stream), "memset");
+        chk(hipStreamSynchronize(c->stream), "sync");
+    } while (0);
+    if (st) { free_ctx(c); return st; }
+    *out = c;
+    return DBTK_OK;
+}
+
+void dbtk_ctx_free(dbtk_ctx_t* ctx) { free_ctx(ctx); }
+
+dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t* off, const uint8_t* qual,
+                               uint64_t npairs, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
+    (void)qual;  // base qualities only matter to the bait filter (-b), not implemented yet
+    if (!c || !off || (!seq && npairs)) { set_error("null argument"); return DBTK_ERR_ARG; }
+    if (nrec) *nrec = 0;
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t nreads = 2 * npairs;
+    for (uint64_t r = 0; r < nreads; ++r) {
+        if (off[r + 1] < off[r]) { set_error("seq_offsets not monotone"); return DBTK_ERR_ARG; }
+        if (off[r + 1] - off[r] > DBTK_MAX_READ_LEN) {
+            set_error("read longer than DBTK_MAX_READ_LEN (256): the reference's PE_KMC is uint8_t, src/aQueryFasta_thread.cpp:42");
+            return DBTK_ERR_READ_TOO_LONG;
+        }
+    }
+    if (npairs == 0) return DBTK_OK;
+    const uint64_t base = off[0], nbytes = off[nreads] - base;
+    dbtk_status_t st;
+    if ((st = ensure(&c->d_seq, &c->seq_cap, nbytes + 32))) return st;
+    if ((st = ensure(&c->d_off, &c->off_cap, nreads + 1))) return st;
+    hipStream_t s = c->stream;
+    if (nbytes) HIPCHK(hipMemcpyAsync(c->d_seq, seq + base, nbytes, hipMemcpyHostToDevice, s));
+    if (base == 0) {
+        HIPCHK(hipMemcpyAsync(c->d_off, off, (nreads + 1) * 8, hipMemcpyHostToDevice, s));
+    } else {
+        std::vector<uint64_t> o2(nreads + 1);
+        for (uint64_t r = 0; r <= nreads; ++r) o2[r] = off[r] - base;
+        HIPCHK(hipMemcpy(c->d_off, o2.data(), (nreads + 1) * 8, hipMemcpyHostToDevice));
+    }
+    const bool want_recs = recs && rec_cap && (c->P.trace || c->P.okam || c->P.extract);
+    uint64_t dcap = 0;
+    if (want_recs) {
+        dcap = c->P.trace ? npairs : (rec_cap < npairs ? rec_cap : npairs);
+        if (c->P.trace && rec_cap < npairs) { set_error("trace mode needs rec_cap >= npairs"); return DBTK_ERR_ARG; }
+        if ((st = ensure(&c->d_recs, &c->rec_cap, dcap))) return st;
+    }
+    if ((st = launch_batch(c, c->d_seq, c->d_off, nbytes, npairs, want_recs ? c->d_recs : nullptr, (uint32_t)dcap))) return st;
+    uint32_t small[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(small, c->d_small, sizeof(small), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (small[3]) { set_error("device reported an over-long read"); return (dbtk_status_t)small[3]; }
+    if (want_recs) {
+        const uint64_t produced = c->P.trace ? npairs : small[2];
+        if (nrec) *nrec = produced;
+        const uint64_t ncopy = produced < dcap ? produced : dcap;
+        if (ncopy) HIPCHK(hipMemcpy(recs, c->d_recs, ncopy * sizeof(dbtk_pair_rec_t), hipMemcpyDeviceToHost));
+        if (!c->P.trace) {
+            // compaction order is arbitrary on the device; the reference's order within a batch is pair order
+            std::sort(recs, recs + ncopy, [](const dbtk_pair_rec_t& x, const dbtk_pair_rec_t& y) { return x.pair < y.pair; });
+            if (produced > dcap) { set_error("record buffer too small"); return DBTK_ERR_OVERFLOW; }
+        }
+    }
+    return DBTK_OK;
+}
+
+dbtk_status_t dbtk_align_batch_device(dbtk_ctx_t* c, const void* d_seq, const void* d_offsets, uint64_t npairs,
+                                      uint32_t max_read_len) {
+    if (!c || !d_seq || !d_offsets) { set_error("null argument"); return DBTK_ERR_ARG; }
+    if (max_read_len > DBTK_MAX_READ_LEN) { set_error("max_read_len > DBTK_MAX_READ_LEN"); return DBTK_ERR_READ_TOO_LONG; }
+    if (((uintptr_t)d_seq & 15) != 0) { set_error("d_seq must be 16-byte aligned"); return DBTK_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    // d_seq is 16-byte aligned and device allocations are page-granular, so the aligned 16-byte
+    // chunk holding the last base is always readable: no byte-wise tail needed (seq_len = max).
+    return launch_batch(c, (const uint8_t*)d_seq, (const uint64_t*)d_offsets, ~0ull, npairs, nullptr, 0);
+}
+
+dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* c) {
+    if (!c) { set_error("null argument"); return DBTK_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint32_t err = 0;
+    HIPCHK(hipMemcpy(&err, c->d_small + 3, 4, hipMemcpyDeviceToHost));
+    if (err) { set_error("device reported an over-long read"); return (dbtk_status_t)err; }
+    return DBTK_OK;
+}
+
+dbtk_status_t dbtk_ctx_counts(dbtk_ctx_t* c, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* counters) {
+    if (!c) { set_error("null argument"); return DBTK_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint64_t nloci = c->g->nloci;
+    if (counts && c->ntr) HIPCHK(hipMemcpy(counts, c->d_accum, c->ntr * 8, hipMemcpyDeviceToHost));
+    if (kmc && nloci) HIPCHK(hipMemcpy(kmc, c->d_accum + c->ntr, nloci * 8, hipMemcpyDeviceToHost));
+    if (nmapread && nloci) {
+        std::vector<uint64_t> w(nloci);
+        HIPCHK(hipMemcpy(w.data(), c->d_accum + c->ntr + nloci, nloci * 8, hipMemcpyDeviceToHost));
+        for (uint64_t l = 0; l < nloci; ++l) nmapread[l] = (uint32_t)w[l];  // atomic_uint32_t in the reference
+    }
+    if (counters) HIPCHK(hipMemcpy(counters, c->d_accum + c->ntr + 2 * nloci, DBTK_C_COUNT * 8, hipMemcpyDeviceToHost));
+    return DBTK_OK;
+}
+
+dbtk_status_t dbtk_ctx_accum_buffer(dbtk_ctx_t* c, void** d_base, uint64_t* n_u64) {
+    if (!c || !d_base || !n_u64) { set_error("null argument"); return DBTK_ERR_ARG; }
+    *d_base = c->d_accum;
+    *n_u64 = c->n_accum;
+    return DBTK_OK;
+}
+
+dbtk_status_t dbtk_ctx_reset(dbtk_ctx_t* c) {
+    if (!c) { set_error("null argument"); return DBTK_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->d_accum, 0, c->n_accum * 8, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DBTK_OK;
+}
+
+int dbtk_ctx_kernel_times(dbtk_ctx_t* c, const char** names, float* ms, int cap) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    int n = 0;
+    for (int i = 0; i < c->ntimed && n < cap; ++i) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, c->timed[i].beg, c->timed[i].end) != hipSuccess) continue;
+        names[n] = c->timed[i].name;
+        ms[n] = t;
+        ++n;
+    }
+    return n;
+}
+
+// One RCCL all-reduce (sum, uint64) over the accumulator buffers of n contexts
+// in this process: the cross-GPU form of the reference's shared atomics
+// (src/aQueryFasta_thread.cpp:2146-2158, 1887-1895).  librccl is loaded on first
+// use so that single-GPU runs do not pay for it.
+dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n) {
+    if (!ctxs || n <= 0) { set_error("null argument"); return DBTK_ERR_ARG; }
+    if (n == 1) return DBTK_OK;
+    typedef void* comm_t;
+    typedef int (*commInitAll_t)(comm_t*, int, const int*);
+    typedef int (*allReduce_t)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
+    typedef int (*group_t)(void);
+    typedef int (*commDestroy_t)(comm_t);
+    static void* lib = nullptr;
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { set_error(std::string("cannot load librccl: ") + dlerror()); return DBTK_ERR_HIP; }
+    auto commInitAll = (commInitAll_t)dlsym(lib, "ncclCommInitAll");
+    auto allReduce = (allReduce_t)dlsym(lib, "ncclAllReduce");
+    auto groupStart = (group_t)dlsym(lib, "ncclGroupStart");
+    auto groupEnd = (group_t)dlsym(lib, "ncclGroupEnd");
+    auto commDestroy = (commDestroy_t)dlsym(lib, "ncclCommDestroy");
+    if (!commInitAll || !allReduce || !groupStart || !groupEnd || !commDestroy) { set_error("librccl lacks the expected symbols"); return DBTK_ERR_HIP; }
+    std::vector<comm_t> comms(n);
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; ++i) {
+        devs[i] = ctxs[i]->device;
+        if (ctxs[i]->n_accum != ctxs[0]->n_accum) { set_error("contexts belong to different RPGGs"); return DBTK_ERR_ARG; }
+    }
+    if (commInitAll(comms.data(), n, devs.data()) != 0) { set_error("ncclCommInitAll failed"); return DBTK_ERR_HIP; }
+    const int ncclUint64 = 5, ncclSum = 0;
+    int rc = groupStart();
+    for (int i = 0; i < n && !rc; ++i) {
+        (void)hipSetDevice(ctxs[i]->device);
+        rc = allReduce(ctxs[i]->d_accum, ctxs[i]->d_accum, ctxs[i]->n_accum, ncclUint64, ncclSum, comms[i], ctxs[i]->stream);
+    }
+    rc |= groupEnd();
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(ctxs[i]->device);
+        (void)hipStreamSynchronize(ctxs[i]->stream);
+        commDestroy(comms[i]);
+    }
+    if (rc) { set_error("ncclAllReduce failed"); return DBTK_ERR_HIP; }
+    return DBTK_OK;
+}
+
+}  // extern "C"

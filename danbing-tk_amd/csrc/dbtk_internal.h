@@ -1,0 +1,37 @@
+// dbtk_internal.h — host-side structures shared by dbtk_rpgg.cpp and dbtk_hip.hip.
+#ifndef DBTK_INTERNAL_H_
+#define DBTK_INTERNAL_H_
+
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dbtk.h"
+
+// The RPGG exactly as the reference's loaders see it (flat, file-equivalent),
+// plus the output order derived once at load time.
+struct dbtk_rpgg {
+    uint32_t ksize = 0;
+    uint64_t nloci = 0;
+    std::vector<uint64_t> keys;   // PREF.kmers.dbi
+    std::vector<uint32_t> vals;
+    std::vector<uint32_t> vv;
+    std::vector<uint64_t> fl_cnt, fl_ks;    // PREF.fl.kdb
+    std::vector<uint64_t> tre_cnt, tre_ks;  // PREF.tre.kdb (may be empty)
+    std::vector<uint64_t> tr_cnt, tr_ks;    // PREF.tr.kmers, file order
+    std::vector<uint8_t> qc;                // empty or nloci
+    std::vector<uint64_t> bt_cnt, bt_ks;    // PREF.bt.kmdb (may be empty)
+    std::vector<uint16_t> bt_vs;
+    // derived
+    std::vector<uint64_t> out_slot;   // file index -> position in OUT.trkmc.ar
+    std::vector<uint64_t> out_kmer;   // position -> k-mer
+    std::vector<uint64_t> out_beg;    // nloci+1: first position of each locus
+};
+
+namespace dbtk {
+void set_error(const std::string& msg);
+dbtk_status_t finish_rpgg(dbtk_rpgg* g);  // validation + output order
+}  // namespace dbtk
+
+#endif

@@ -1,0 +1,303 @@
+// dbtk_rpgg.cpp — host side of the RPGG handle: the reference's on-disk formats
+// in (loaders of src/aQueryFasta_thread.cpp:2459-2500) and out (dumps of
+// src/aQueryFasta_thread.cpp:2631-2641).  No device code here.
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <thread>
+#include <unordered_map>
+
+#include "dbtk_internal.h"
+
+namespace dbtk {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace dbtk
+using dbtk::set_error;
+
+extern "C" const char* dbtk_last_error(void) { return dbtk::g_err.c_str(); }
+extern "C" uint32_t dbtk_abi_version(void) { return DBTK_ABI_VERSION; }
+
+namespace {
+
+struct File {
+    FILE* f = nullptr;
+    explicit File(const std::string& fn, const char* mode) { f = fopen(fn.c_str(), mode); }
+    ~File() { if (f) fclose(f); }
+    template <class T> bool read(T* p, size_t n) { return n == 0 || fread(p, sizeof(T), n, f) == n; }
+    template <class T> bool write(const T* p, size_t n) { return n == 0 || fwrite(p, sizeof(T), n, f) == n; }
+};
+
+// PREF.*.kdb: u64 nloci | u64 cnt[nloci] | u64 nk | u64 ks[nk]
+// (serializeKsetDB, src/binaryKmerIO.hpp:128-139; reader src/aQueryFasta_thread.h:675-698)
+dbtk_status_t read_kdb(const std::string& fn, uint64_t nloci, std::vector<uint64_t>& cnt, std::vector<uint64_t>& ks) {
+    File f(fn, "rb");
+    if (!f.f) { set_error("cannot open " + fn); return DBTK_ERR_IO; }
+    uint64_t nl = 0, nk = 0;
+    if (!f.read(&nl, 1)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+    if (nl != nloci) { set_error(fn + ": locus count differs from tr.kmers"); return DBTK_ERR_FORMAT; }
+    cnt.resize(nl);
+    if (!f.read(cnt.data(), nl) || !f.read(&nk, 1)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+    uint64_t sum = 0;
+    for (uint64_t c : cnt) sum += c;
+    if (sum != nk) { set_error(fn + ": per-locus counts do not add up"); return DBTK_ERR_FORMAT; }
+    ks.resize(nk);
+    if (!f.read(ks.data(), nk)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+    return DBTK_OK;
+}
+
+// PREF.tr.kmers: ">locus" lines and "KMER[\tVALUE]" lines; only the first field
+// is used (countLoci src/kmerIO.hpp:33-45, readKmersWithZeroCount
+// src/aQueryFasta_thread.h:469-480).
+dbtk_status_t read_tr_kmers(const std::string& fn, std::vector<uint64_t>& cnt, std::vector<uint64_t>& ks) {
+    File f(fn, "rb");
+    if (!f.f) { set_error("cannot open " + fn); return DBTK_ERR_IO; }
+    fseek(f.f, 0, SEEK_END);
+    const long sz = ftell(f.f);
+    fseek(f.f, 0, SEEK_SET);
+    std::vector<char> buf((size_t)sz + 1);
+    if (sz && fread(buf.data(), 1, (size_t)sz, f.f) != (size_t)sz) { set_error("short read on " + fn); return DBTK_ERR_IO; }
+    buf[(size_t)sz] = '\n';
+    const char* p = buf.data();
+    const char* end = p + sz;
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p) + 1);
+        if (*p == '>') {
+            cnt.push_back(0);
+        } else if (nl > p) {
+            if (cnt.empty()) { set_error(fn + ": k-mer before the first '>' line"); return DBTK_ERR_FORMAT; }
+            uint64_t v = 0;
+            const char* q = p;
+            while (q < nl && (*q == ' ' || *q == '\t')) ++q;
+            if (q == nl || *q < '0' || *q > '9') { set_error(fn + ": not a k-mer line"); return DBTK_ERR_FORMAT; }
+            while (q < nl && *q >= '0' && *q <= '9') v = v * 10 + (uint64_t)(*q++ - '0');
+            ks.push_back(v);
+            cnt.back()++;
+        }
+        p = nl + 1;
+    }
+    return DBTK_OK;
+}
+
+}  // namespace
+
+namespace dbtk {
+
+// Output order + sanity checks.  The reference writes per-locus counts in the
+// iteration order of std::unordered_map<size_t, atomic<size_t>> filled in file
+// order (src/aQueryFasta_thread.h:469-480 -> src/binaryKmerIO.hpp:36-46,
+// src/aQueryFasta_thread.h:929-936); libstdc++'s own container is the order
+// oracle here, instantiated the same way (identity hash, operator[] inserts).
+dbtk_status_t finish_rpgg(dbtk_rpgg* g) {
+    const uint64_t nloci = g->nloci;
+    if (g->ksize < 2 || g->ksize > 31) { set_error("k must be in 2..31"); return DBTK_ERR_ARG; }
+    if (g->tr_cnt.size() != nloci || g->fl_cnt.size() != nloci) { set_error("per-locus count arrays have the wrong length"); return DBTK_ERR_FORMAT; }
+    if (nloci >= 0x7FFFFFFFull) { set_error("too many loci"); return DBTK_ERR_FORMAT; }
+    // every locus id reachable from the index must exist (the reference would index hits1[] out of bounds)
+    for (size_t i = 0; i < g->vals.size(); ++i) {
+        const uint32_t v = g->vals[i];
+        if (v & 1) {
+            const uint64_t o = v >> 1;
+            if (o >= g->vv.size() || o + 1 + g->vv[o] > g->vv.size()) { set_error("kmers.dbi: value points outside vv"); return DBTK_ERR_FORMAT; }
+        } else if ((v >> 1) >= nloci) { set_error("kmers.dbi: locus id out of range"); return DBTK_ERR_FORMAT; }
+    }
+    for (size_t o = 0; o < g->vv.size();) {
+        const uint64_t n = g->vv[o];
+        if (o + 1 + n > g->vv.size()) break;  // tail not addressed by any value: ignored
+        for (uint64_t j = 0; j < n; ++j)
+            if (g->vv[o + 1 + j] >= nloci) { set_error("kmers.dbi: vv locus id out of range"); return DBTK_ERR_FORMAT; }
+        o += 1 + n;
+    }
+    std::vector<uint64_t> beg(nloci + 1, 0);
+    for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->tr_cnt[l];
+    const uint64_t ntr = beg[nloci];
+    if (g->tr_ks.size() != ntr) { set_error("tr k-mer array has the wrong length"); return DBTK_ERR_FORMAT; }
+    g->out_slot.assign(ntr, 0);
+    g->out_beg.assign(nloci + 1, 0);
+    std::vector<uint64_t> uniq(nloci, 0);
+    // pass 1 (parallel over loci): local order within each locus
+    const unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nth; ++t) {
+        th.emplace_back([&, t]() {
+            for (uint64_t l = t; l < nloci; l += nth) {
+                std::unordered_map<size_t, uint64_t> m;  // value: first file index of the key
+                for (uint64_t i = beg[l]; i < beg[l + 1]; ++i) {
+                    const size_t before = m.size();
+                    uint64_t& v = m[(size_t)g->tr_ks[i]];  // operator[], like `kmerDB[idx][stoul(line)] = 0`
+                    if (m.size() != before) v = i;
+                }
+                uint64_t pos = 0;
+                for (auto& p : m) g->out_slot[p.second] = pos++;  // local position, made global below
+                // duplicate lines of a k-mer share the node of its first occurrence
+                for (uint64_t i = beg[l]; i < beg[l + 1]; ++i) {
+                    const uint64_t first_i = m.find((size_t)g->tr_ks[i])->second;
+                    if (first_i != i) g->out_slot[i] = g->out_slot[first_i];
+                }
+                uniq[l] = pos;
+            }
+        });
+    }
+    for (auto& x : th) x.join();
+    for (uint64_t l = 0; l < nloci; ++l) g->out_beg[l + 1] = g->out_beg[l] + uniq[l];
+    g->out_kmer.assign(g->out_beg[nloci], 0);
+    for (uint64_t l = 0; l < nloci; ++l)
+        for (uint64_t i = beg[l]; i < beg[l + 1]; ++i) {
+            g->out_slot[i] += g->out_beg[l];
+            g->out_kmer[g->out_slot[i]] = g->tr_ks[i];
+        }
+    if (g->out_beg[nloci] >= 0xFFFFFFF0ull) { set_error("too many TR k-mers for 32-bit slots"); return DBTK_ERR_FORMAT; }
+    return DBTK_OK;
+}
+
+}  // namespace dbtk
+
+extern "C" {
+
+dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_file, const char* bait_file,
+                             dbtk_rpgg_t** out) {
+    if (!prefix || !out) { set_error("null argument"); return DBTK_ERR_ARG; }
+    *out = nullptr;
+    std::unique_ptr<dbtk_rpgg> g(new dbtk_rpgg);
+    g->ksize = ksize;
+    const std::string pref(prefix);
+    dbtk_status_t st = read_tr_kmers(pref + ".tr.kmers", g->tr_cnt, g->tr_ks);
+    if (st) return st;
+    g->nloci = g->tr_cnt.size();
+    {
+        // PREF.kmers.dbi: u64 nk | u64 keys[nk] | u32 vals[nk] | u64 nvv | u32 vv[nvv]
+        // (src/kmertools.cpp:271-280; reader src/aQueryFasta_thread.h:654-673)
+        const std::string fn = pref + ".kmers.dbi";
+        File f(fn, "rb");
+        if (!f.f) { set_error("cannot open " + fn); return DBTK_ERR_IO; }
+        uint64_t nk = 0, nvv = 0;
+        if (!f.read(&nk, 1)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+        g->keys.resize(nk);
+        g->vals.resize(nk);
+        if (!f.read(g->keys.data(), nk) || !f.read(g->vals.data(), nk) || !f.read(&nvv, 1)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+        g->vv.resize(nvv);
+        if (!f.read(g->vv.data(), nvv)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+    }
+    if ((st = read_kdb(pref + ".fl.kdb", g->nloci, g->fl_cnt, g->fl_ks))) return st;
+    if ((st = read_kdb(pref + ".tre.kdb", g->nloci, g->tre_cnt, g->tre_ks))) return st;
+    if (qc_file) {  // readQCFile, src/kmerIO.hpp:111-120
+        File f(qc_file, "rb");
+        if (!f.f) { set_error(std::string("cannot open ") + qc_file); return DBTK_ERR_IO; }
+        g->qc.resize(g->nloci);
+        if (!f.read(g->qc.data(), g->nloci)) { set_error(std::string("truncated ") + qc_file); return DBTK_ERR_IO; }
+        for (auto& b : g->qc) b = (uint8_t)(b - 48);
+    }
+    if (bait_file) {
+        // PREF.bt.kmdb: u64 nloci | u64 cnt[nloci] | u64 nk | u64 sizeofval | u64 ks[nk] | u16 vs[nk]
+        // (serializeKmapDB src/binaryKmerIO.hpp:53-68; reader :70-98)
+        File f(bait_file, "rb");
+        if (!f.f) { set_error(std::string("cannot open ") + bait_file); return DBTK_ERR_IO; }
+        uint64_t nl = 0, nk = 0, szv = 0;
+        if (!f.read(&nl, 1) || nl != g->nloci) { set_error("bait DB: locus count differs"); return DBTK_ERR_FORMAT; }
+        g->bt_cnt.resize(nl);
+        if (!f.read(g->bt_cnt.data(), nl) || !f.read(&nk, 1) || !f.read(&szv, 1) || szv != 2) { set_error("bait DB: bad header"); return DBTK_ERR_FORMAT; }
+        g->bt_ks.resize(nk);
+        g->bt_vs.resize(nk);
+        if (!f.read(g->bt_ks.data(), nk) || !f.read(g->bt_vs.data(), nk)) { set_error("bait DB truncated"); return DBTK_ERR_IO; }
+    }
+    if ((st = dbtk::finish_rpgg(g.get()))) return st;
+    *out = g.release();
+    return DBTK_OK;
+}
+
+dbtk_status_t dbtk_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a, dbtk_rpgg_t** out) {
+    if (!a || !out || !a->tr_cnt || !a->fl_cnt) { set_error("null argument"); return DBTK_ERR_ARG; }
+    *out = nullptr;
+    std::unique_ptr<dbtk_rpgg> g(new dbtk_rpgg);
+    g->ksize = a->ksize;
+    g->nloci = a->nloci;
+    auto sum = [&](const uint64_t* c) { uint64_t s = 0; for (uint64_t l = 0; l < a->nloci; ++l) s += c[l]; return s; };
+    g->keys.assign(a->keys, a->keys + a->nkeys);
+    g->vals.assign(a->vals, a->vals + a->nkeys);
+    if (a->nvv) g->vv.assign(a->vv, a->vv + a->nvv);
+    g->fl_cnt.assign(a->fl_cnt, a->fl_cnt + a->nloci);
+    { const uint64_t n = sum(a->fl_cnt); if (n) g->fl_ks.assign(a->fl_ks, a->fl_ks + n); }
+    g->tr_cnt.assign(a->tr_cnt, a->tr_cnt + a->nloci);
+    { const uint64_t n = sum(a->tr_cnt); if (n) g->tr_ks.assign(a->tr_ks, a->tr_ks + n); }
+    if (a->tre_cnt) {
+        g->tre_cnt.assign(a->tre_cnt, a->tre_cnt + a->nloci);
+        const uint64_t n = sum(a->tre_cnt);
+        if (n) g->tre_ks.assign(a->tre_ks, a->tre_ks + n);
+    }
+    if (a->qc) g->qc.assign(a->qc, a->qc + a->nloci);
+    if (a->bt_cnt) {
+        g->bt_cnt.assign(a->bt_cnt, a->bt_cnt + a->nloci);
+        const uint64_t n = sum(a->bt_cnt);
+        if (n) { g->bt_ks.assign(a->bt_ks, a->bt_ks + n); g->bt_vs.assign(a->bt_vs, a->bt_vs + n); }
+    }
+    const dbtk_status_t st = dbtk::finish_rpgg(g.get());
+    if (st) return st;
+    *out = g.release();
+    return DBTK_OK;
+}
+
+void dbtk_rpgg_free(dbtk_rpgg_t* h) { delete h; }
+uint64_t dbtk_rpgg_nloci(const dbtk_rpgg_t* h) { return h ? h->nloci : 0; }
+uint64_t dbtk_rpgg_ntrkmers(const dbtk_rpgg_t* h) { return h ? h->out_kmer.size() : 0; }
+uint64_t dbtk_rpgg_nkeys(const dbtk_rpgg_t* h) { return h ? h->keys.size() : 0; }
+
+dbtk_status_t dbtk_rpgg_view(const dbtk_rpgg_t* h, dbtk_rpgg_arrays_t* o) {
+    if (!h || !o) { set_error("null argument"); return DBTK_ERR_ARG; }
+    memset(o, 0, sizeof(*o));
+    o->ksize = h->ksize; o->nloci = h->nloci;
+    o->nkeys = h->keys.size(); o->keys = h->keys.data(); o->vals = h->vals.data();
+    o->nvv = h->vv.size(); o->vv = h->vv.data();
+    o->fl_cnt = h->fl_cnt.data(); o->fl_ks = h->fl_ks.data();
+    if (!h->tre_cnt.empty()) { o->tre_cnt = h->tre_cnt.data(); o->tre_ks = h->tre_ks.data(); }
+    o->tr_cnt = h->tr_cnt.data(); o->tr_ks = h->tr_ks.data();
+    if (!h->qc.empty()) o->qc = h->qc.data();
+    if (!h->bt_cnt.empty()) { o->bt_cnt = h->bt_cnt.data(); o->bt_ks = h->bt_ks.data(); o->bt_vs = h->bt_vs.data(); }
+    return DBTK_OK;
+}
+
+dbtk_status_t dbtk_rpgg_output_order(const dbtk_rpgg_t* h, uint64_t* out_slot) {
+    if (!h || !out_slot) { set_error("null argument"); return DBTK_ERR_ARG; }
+    if (!h->out_slot.empty()) memcpy(out_slot, h->out_slot.data(), h->out_slot.size() * sizeof(uint64_t));
+    return DBTK_OK;
+}
+
+void dbtk_params_default(dbtk_params_t* p) {  // src/aQueryFasta_thread.cpp:26-34, 2336-2339
+    memset(p, 0, sizeof(*p));
+    p->ksize = 21; p->n_filter = 4; p->nm_filter = 1; p->cthreshold = 10; p->nm_tr = 40; p->max_nt = 2; p->qth = 20;
+    p->okam = 1;
+}
+
+dbtk_status_t dbtk_write_outputs(const dbtk_rpgg_t* h, const uint64_t* counts, const uint64_t* kmc,
+                                 const uint32_t* nmapread, const char* out_prefix, int with_names) {
+    if (!h || !counts || !out_prefix) { set_error("null argument"); return DBTK_ERR_ARG; }
+    const std::string pref(out_prefix);
+    const uint64_t nk = h->out_kmer.size();
+    if (with_names) {  // writeKmersWithName, src/aQueryFasta_thread.h:926-937
+        File f(pref + ".tr.kmers", "wb");
+        if (!f.f) { set_error("cannot create " + pref + ".tr.kmers"); return DBTK_ERR_IO; }
+        for (uint64_t l = 0; l < h->nloci; ++l) {
+            fprintf(f.f, ">%llu\n", (unsigned long long)l);
+            for (uint64_t i = h->out_beg[l]; i < h->out_beg[l + 1]; ++i)
+                fprintf(f.f, "%llu\t%llu\n", (unsigned long long)h->out_kmer[i], (unsigned long long)counts[i]);
+        }
+        return DBTK_OK;
+    }
+    {  // dumpTRKmers -> serializeKarray, src/aQueryFasta_thread.h:968-973, src/binaryKmerIO.hpp:179-188
+        File f(pref + ".trkmc.ar", "wb");
+        if (!f.f) { set_error("cannot create " + pref + ".trkmc.ar"); return DBTK_ERR_IO; }
+        if (!f.write(&nk, 1) || !f.write(counts, nk)) { set_error("write failed"); return DBTK_ERR_IO; }
+    }
+    if (kmc && nmapread) {  // writeTRKmerSummary, src/aQueryFasta_thread.h:976-983
+        File f(pref + ".tr.summary.txt", "wb");
+        if (!f.f) { set_error("cannot create " + pref + ".tr.summary.txt"); return DBTK_ERR_IO; }
+        for (uint64_t l = 0; l < h->nloci; ++l)
+            fprintf(f.f, "%u\t%llu\n", nmapread[l], (unsigned long long)kmc[l]);
+    }
+    return DBTK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+// dbtk_sort.h — GCC libstdc++ std::sort, restated for index arrays in LDS.
+//
+// Why this exists: the reference orders a pair's unique k-mers by their number
+// of mapped loci with an UNSTABLE std::sort (getSortedIndex / fillstats,
+// src/aQueryFasta_thread.cpp:247-250, 320-327) and then votes with early
+// termination, so the tie permutation of GCC's introsort decides which locus a
+// chimeric pair is assigned to (SURVEY.md finding 3a).  This is the algorithm of
+// bits/stl_algo.h:1800-1957 + bits/stl_heap.h (GCC 11): introsort loop with
+// threshold 16, median-of-3 moved to `first`, unguarded Hoare partition, depth
+// limit 2*floor(log2 n) falling back to heapsort, then insertion sort of the
+// first 16 and unguarded insertion of the rest.
+//
+// idx: uint16_t indices (values 0..n-1), key: the sort key per ORIGINAL index.
+// Comparator: key[a] < key[b].  The recursion of __introsort_loop is replaced
+// by an explicit stack: the sub-ranges are disjoint, so the order in which they
+// are processed does not change the result.
+#ifndef DBTK_SORT_H_
+#define DBTK_SORT_H_
+
+#include "dbtk_tables.h"
+
+namespace dbtk {
+
+struct SortLt {
+    const uint32_t* key;
+    DBTK_HD bool operator()(uint16_t a, uint16_t b) const { return key[a] < key[b]; }
+};
+
+DBTK_HD void s_unguarded_linear_insert(uint16_t* a, int last, const SortLt& lt) {
+    const uint16_t val = a[last];
+    int next = last - 1;
+    while (lt(val, a[next])) {
+        a[last] = a[next];
+        last = next;
+        --next;
+    }
+    a[last] = val;
+}
+
+DBTK_HD void s_insertion_sort(uint16_t* a, int first, int last, const SortLt& lt) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        if (lt(a[i], a[first])) {
+            const uint16_t val = a[i];
+            for (int j = i; j > first; --j) a[j] = a[j - 1];  // move_backward
+            a[first] = val;
+        } else {
+            s_unguarded_linear_insert(a, i, lt);
+        }
+    }
+}
+
+DBTK_HD void s_push_heap(uint16_t* a, int first, int hole, int top, uint16_t value, const SortLt& lt) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && lt(a[first + parent], value)) {
+        a[first + hole] = a[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a[first + hole] = value;
+}
+
+DBTK_HD void s_adjust_heap(uint16_t* a, int first, int hole, int len, uint16_t value, const SortLt& lt) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (lt(a[first + child], a[first + child - 1])) child--;
+        a[first + hole] = a[first + child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a[first + hole] = a[first + child - 1];
+        hole = child - 1;
+    }
+    s_push_heap(a, first, hole, top, value, lt);
+}
+
+DBTK_HD void s_heapsort(uint16_t* a, int first, int last, const SortLt& lt) {  // __partial_sort(first,last,last)
+    const int len = last - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        for (;;) {
+            const uint16_t v = a[first + parent];
+            s_adjust_heap(a, first, parent, len, v, lt);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    while (last - first > 1) {
+        --last;
+        const uint16_t v = a[last];
+        a[last] = a[first];
+        s_adjust_heap(a, first, 0, last - first, v, lt);
+    }
+}
+
+DBTK_HD void s_swap(uint16_t* a, int i, int j) {
+    const uint16_t t = a[i];
+    a[i] = a[j];
+    a[j] = t;
+}
+
+DBTK_HD int s_partition_pivot(uint16_t* a, int first, int last, const SortLt& lt) {
+    const int mid = first + (last - first) / 2;
+    {  // __move_median_to_first(first, first+1, mid, last-1)
+        const int x = first + 1, y = mid, z = last - 1;
+        if (lt(a[x], a[y])) {
+            if (lt(a[y], a[z])) s_swap(a, first, y);
+            else if (lt(a[x], a[z])) s_swap(a, first, z);
+            else s_swap(a, first, x);
+        } else if (lt(a[x], a[z])) s_swap(a, first, x);
+        else if (lt(a[y], a[z])) s_swap(a, first, z);
+        else s_swap(a, first, y);
+    }
+    int lo = first + 1, hi = last;  // __unguarded_partition(first+1, last, pivot = first)
+    for (;;) {
+        while (lt(a[lo], a[first])) ++lo;
+        --hi;
+        while (lt(a[first], a[hi])) --hi;
+        if (!(lo < hi)) return lo;
+        s_swap(a, lo, hi);
+        ++lo;
+    }
+}
+
+// stack: caller-provided int[3 * 40] scratch (first, last, depth triples).
+DBTK_HD void gcc_sort_index(uint16_t* a, int n, const uint32_t* key, int* stack) {
+    for (int i = 0; i < n; ++i) a[i] = (uint16_t)i;  // std::iota
+    if (n == 0) return;
+    const SortLt lt{key};
+    int sp = 0;
+    stack[0] = 0;
+    stack[1] = n;
+    stack[2] = 2 * (31 - __builtin_clz((unsigned)n));  // std::__lg(n) * 2
+    sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = stack[3 * sp], last = stack[3 * sp + 1], depth = stack[3 * sp + 2];
+        while (last - first > 16) {
+            if (depth == 0) {
+                s_heapsort(a, first, last, lt);
+                break;
+            }
+            --depth;
+            const int cut = s_partition_pivot(a, first, last, lt);
+            stack[3 * sp] = cut;  // the recursive call __introsort_loop(cut, last, depth)
+            stack[3 * sp + 1] = last;
+            stack[3 * sp + 2] = depth;
+            ++sp;
+            last = cut;
+        }
+    }
+    if (n > 16) {  // __final_insertion_sort
+        s_insertion_sort(a, 0, 16, lt);
+        for (int i = 16; i != n; ++i) s_unguarded_linear_insert(a, i, lt);
+    } else {
+        s_insertion_sort(a, 0, n, lt);
+    }
+}
+
+}  // namespace dbtk
+#endif

@@ -186,3 +186,44 @@ def rec_str(r):
         return (f"si={x.si} ei={x.ei} si_={x.si_} ei_={x.ei_} nt={x.nt} bs={x.bs} ti={x.ti} "
                 f"kf={x.kf} hf={x.hf} af={x.af} rm={x.rm} nk={x.nk}")
     return f"pair={r.pair} stage={r.stage} dst={r.dst} dst0={r.dst0} nm=({r.nm1},{r.nm2}) r1[{m(r.r1)}] r2[{m(r.r2)}]"
+
+
+class Emu(pkg._HostSide):
+    """TEST-ONLY: the kernel bodies of dbtk_kernels.h run on coroutine lanes
+    (tests/emu/emu.cpp).  Lets the CPU suite check the device logic; it is not
+    a backend of the product."""
+
+    def __init__(self):
+        path = os.path.join(ROOT, "tests", "emu", "libdbtk_emu.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: run `make -C tests/emu`")
+        L = self.L = C.CDLL(path)
+        pkg.bind_common(L)
+        L.emu_tables_create.restype = C.c_void_p
+        L.emu_tables_create.argtypes = [C.c_void_p]
+        L.emu_tables_free.argtypes = [C.c_void_p]
+        L.emu_align.restype = C.c_int
+        L.emu_align.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.Params), u8p, u64p, C.c_uint64, u64p, u64p, u32p, u64p,
+                                C.POINTER(abi.PairRec), C.c_uint64, u64p, C.c_uint32, C.c_uint32]
+
+    def tables(self, rpgg):
+        return self.L.emu_tables_create(rpgg.h)
+
+    def align(self, rpgg, tables, params, seq, off, grid_k1=3, grid_pair=5):
+        npairs = (len(off) - 1) // 2
+        counts = np.zeros(rpgg.ntrkmers, np.uint64)
+        kmc = np.zeros(rpgg.nloci, np.uint64)
+        nmap = np.zeros(rpgg.nloci, np.uint32)
+        ctr = np.zeros(abi.C_COUNT, np.uint64)
+        want = bool(params.trace or params.okam or params.extract)
+        recs = (abi.PairRec * max(npairs, 1))() if want else None
+        nrec = C.c_uint64(0)
+        seq = np.ascontiguousarray(seq, np.uint8)
+        if seq.size == 0:
+            seq = np.zeros(1, np.uint8)
+        rc = self.L.emu_align(rpgg.h, tables, C.byref(params), _p(seq, u8p), _p(off, u64p), npairs, _p(counts, u64p),
+                              _p(kmc, u64p), _p(nmap, u32p), _p(ctr, u64p), recs, npairs if recs else 0, C.byref(nrec),
+                              grid_k1, grid_pair)
+        if rc:
+            raise RuntimeError(f"emu_align -> {rc}")
+        return dict(counts=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs, nrec=int(nrec.value))

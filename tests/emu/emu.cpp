@@ -1,0 +1,241 @@
+// tests/emu/emu.cpp — TEST-ONLY SPMD emulator for the kernel bodies.
+//
+// This is not a CPU backend and is not part of the product: libdbtk_hip.so
+// neither contains nor can reach it.  It exists so that the exact kernel
+// bodies of danbing-tk_amd/csrc/dbtk_kernels.h (the code hipcc compiles for
+// gfx950) can be run in this GPU-less container against the oracle before GPU
+// minutes are spent: each GPU thread becomes a ucontext coroutine, a block is
+// scheduled round-robin from barrier to barrier, wave64 collectives (ballot,
+// scans, broadcasts) go through a scratch array, atomics are plain operations.
+// Blocks run one after another, which is one of the schedules the GPU may pick.
+#include <string.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+#include "../../danbing-tk_amd/csrc/dbtk_internal.h"
+#include "../../danbing-tk_amd/csrc/dbtk_kernels.h"
+
+using namespace dbtk;
+
+namespace {
+
+struct EmuBlock;
+struct EmuX {
+    EmuBlock* b;
+    int t;
+    int tid() const { return t; }
+    int nthreads() const;
+    uint32_t bid() const;
+    uint32_t nblocks() const;
+    int lane() const { return t & 63; }
+    void sync() const;
+    uint64_t ballot(bool p) const;
+    uint32_t wave_sum(uint32_t v) const;
+    uint32_t wave_excl_scan(uint32_t v) const;
+    uint32_t bcast(uint32_t v, int src) const;
+    void atomic_add(uint64_t* p, uint64_t v) const { *p += v; }
+    uint32_t atomic_add(uint32_t* p, uint32_t v) const { uint32_t o = *p; *p += v; return o; }
+    uint64_t atomic_cas(uint64_t* p, uint64_t e, uint64_t d) const { uint64_t o = *p; if (o == e) *p = d; return o; }
+    void atomic_max(uint64_t* p, uint64_t v) const { if (v > *p) *p = v; }
+    void atomic_or(uint64_t* p, uint64_t v) const { *p |= v; }
+    uint32_t lds_add(uint32_t* p, uint32_t v) const { uint32_t o = *p; *p += v; return o; }
+    void lds_or(uint32_t* p, uint32_t v) const { *p |= v; }
+    template <class T> T* smem() const;
+};
+
+struct EmuBlock {
+    int nt = 0;
+    uint32_t bid = 0, nblocks = 0;
+    std::vector<uint64_t> smem;  // 8-byte aligned backing store
+    ucontext_t mainctx;
+    std::vector<ucontext_t> ctx;
+    std::vector<std::vector<char>> stacks;
+    std::vector<char> done;
+    std::vector<uint64_t> scratch;
+    int cur = 0;
+    std::function<void(EmuX&)> body;
+
+    void yield() { swapcontext(&ctx[cur], &mainctx); }
+};
+
+thread_local EmuBlock* g_blk = nullptr;
+
+void lane_entry() {
+    EmuBlock* b = g_blk;
+    const int t = b->cur;
+    EmuX x{b, t};
+    b->body(x);
+    b->done[t] = 1;
+    b->scratch[t] = 0;
+    swapcontext(&b->ctx[t], &b->mainctx);
+}
+
+int EmuX::nthreads() const { return b->nt; }
+uint32_t EmuX::bid() const { return b->bid; }
+uint32_t EmuX::nblocks() const { return b->nblocks; }
+void EmuX::sync() const { b->yield(); }
+template <class T> T* EmuX::smem() const { return reinterpret_cast<T*>(b->smem.data()); }
+uint64_t EmuX::ballot(bool p) const {
+    b->scratch[t] = p;
+    b->yield();
+    uint64_t m = 0;
+    const int w0 = t & ~63;
+    for (int l = 0; l < 64 && w0 + l < b->nt; ++l)
+        if (!b->done[w0 + l] && b->scratch[w0 + l]) m |= 1ull << l;
+    b->yield();
+    return m;
+}
+uint32_t EmuX::wave_sum(uint32_t v) const {
+    b->scratch[t] = v;
+    b->yield();
+    uint32_t s = 0;
+    const int w0 = t & ~63;
+    for (int l = 0; l < 64 && w0 + l < b->nt; ++l) s += (uint32_t)b->scratch[w0 + l];
+    b->yield();
+    return s;
+}
+uint32_t EmuX::wave_excl_scan(uint32_t v) const {
+    b->scratch[t] = v;
+    b->yield();
+    uint32_t s = 0;
+    const int w0 = t & ~63;
+    for (int l = 0; l < (t & 63); ++l) s += (uint32_t)b->scratch[w0 + l];
+    b->yield();
+    return s;
+}
+uint32_t EmuX::bcast(uint32_t v, int src) const {
+    b->scratch[t] = v;
+    b->yield();
+    const uint32_t r = (uint32_t)b->scratch[(t & ~63) + src];
+    b->yield();
+    return r;
+}
+
+void run_grid(uint32_t nblocks, int nt, size_t smem_bytes, std::function<void(EmuX&)> body) {
+    const size_t STK = 256 * 1024;
+    EmuBlock b;
+    b.nt = nt;
+    b.nblocks = nblocks;
+    b.body = body;
+    b.ctx.resize(nt);
+    b.stacks.resize(nt);
+    for (auto& s : b.stacks) s.resize(STK);
+    b.done.assign(nt, 0);
+    b.scratch.assign(nt, 0);
+    g_blk = &b;
+    for (uint32_t bid = 0; bid < nblocks; ++bid) {
+        b.bid = bid;
+        b.smem.assign(smem_bytes / 8 + 2, 0xA5A5A5A5A5A5A5A5ull);  // LDS is NOT zeroed on the GPU either
+        for (int t = 0; t < nt; ++t) {
+            b.done[t] = 0;
+            b.scratch[t] = 0;
+            getcontext(&b.ctx[t]);
+            b.ctx[t].uc_stack.ss_sp = b.stacks[t].data();
+            b.ctx[t].uc_stack.ss_size = STK;
+            b.ctx[t].uc_link = &b.mainctx;
+            makecontext(&b.ctx[t], lane_entry, 0);
+        }
+        bool alive = true;
+        while (alive) {
+            alive = false;
+            for (int t = 0; t < nt; ++t) {
+                if (b.done[t]) continue;
+                b.cur = t;
+                swapcontext(&b.mainctx, &b.ctx[t]);
+                if (!b.done[t]) alive = true;
+            }
+        }
+    }
+    g_blk = nullptr;
+}
+
+struct EmuTables {
+    std::vector<IdxSlot> idx;
+    std::vector<ClsSlot> cls;
+    std::vector<uint32_t> vv;
+    std::vector<uint16_t> perm;
+    DevTables T;
+};
+
+}  // namespace
+
+extern "C" {
+
+void* emu_tables_create(const dbtk_rpgg_t* g) {
+    EmuTables* e = new EmuTables;
+    auto pow2 = [](uint64_t n) { uint64_t c = 1024; while (c < n) c <<= 1; return c; };
+    auto lg = [](uint64_t c) { return 63u - (uint32_t)__builtin_clzll(c); };
+    const uint64_t nloci = g->nloci;
+    const uint64_t icap = pow2(2 * g->keys.size() + 2);
+    e->idx.assign(icap, IdxSlot{NAN64, 0});
+    {
+        IdxBuildArgs a{e->idx.data(), icap - 1, 64 - lg(icap), g->keys.data(), g->vals.data(), g->keys.size()};
+        run_grid(3, 64, 0, [&](EmuX& x) { body_idx_insert(x, a); });
+        run_grid(3, 64, 0, [&](EmuX& x) { body_idx_finalize(x, e->idx.data(), icap); });
+    }
+    e->vv = g->vv;
+    e->vv.push_back(0);
+    const uint64_t ccap = pow2(2 * (g->tr_ks.size() + g->fl_ks.size()) + 2);
+    e->cls.assign(ccap, ClsSlot{NAN64, ~0ull});
+    {
+        std::vector<uint64_t> beg(nloci + 1, 0);
+        for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->tr_cnt[l];
+        ClsBuildArgs a{e->cls.data(), ccap - 1, 64 - lg(ccap), g->tr_ks.data(), beg.data(), (uint32_t)nloci, g->out_slot.data(), g->tr_ks.size()};
+        run_grid(3, 64, 0, [&](EmuX& x) { body_cls_insert(x, a); });
+        for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->fl_cnt[l];
+        ClsBuildArgs f{e->cls.data(), ccap - 1, 64 - lg(ccap), g->fl_ks.data(), beg.data(), (uint32_t)nloci, nullptr, g->fl_ks.size()};
+        run_grid(3, 64, 0, [&](EmuX& x) { body_cls_insert(x, f); });
+    }
+    e->perm.resize((size_t)NHMAX * (NHMAX + 1) / 2 + 1);
+    {
+        std::vector<uint32_t> key(NHMAX, 1);
+        int stack[3 * 40];
+        for (int n = 1; n <= NHMAX; ++n) gcc_sort_index(e->perm.data() + (size_t)n * (n - 1) / 2, n, key.data(), stack);
+    }
+    DevTables& T = e->T;
+    T.idx = e->idx.data(); T.idx_mask = icap - 1; T.idx_shift = 64 - lg(icap);
+    T.vv = e->vv.data();
+    T.cls = e->cls.data(); T.cls_mask = ccap - 1; T.cls_shift = 64 - lg(ccap);
+    T.qc = g->qc.empty() ? nullptr : g->qc.data();
+    T.permtab = e->perm.data();
+    T.nloci = (uint32_t)nloci;
+    T.ksize = g->ksize;
+    return e;
+}
+void emu_tables_free(void* e) { delete (EmuTables*)e; }
+
+// Same outputs as dbtk_align_batch + dbtk_ctx_counts (counts in OUT.trkmc.ar order).
+int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
+              uint64_t npairs, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* counters,
+              dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec, uint32_t grid_k1, uint32_t grid_pair) {
+    EmuTables* e = (EmuTables*)tables;
+    const uint64_t nloci = g->nloci, ntr = g->out_kmer.size();
+    std::vector<uint64_t> accum(ntr + 2 * nloci + DBTK_C_COUNT, 0);
+    std::vector<uint32_t> surv(npairs + 1), small(4, 0), epoch(grid_pair, 0);
+    std::vector<uint64_t> vote((size_t)grid_pair * (nloci + 1), 0);
+    // device-like sequence buffer: 16-byte aligned copy
+    const uint64_t nbytes = off[2 * npairs];
+    std::vector<uint64_t> seqbuf(nbytes / 8 + 8, 0);
+    memcpy(seqbuf.data(), seq, nbytes);
+    BatchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.T = e->T; a.P = *p;
+    a.seq = (const uint8_t*)seqbuf.data(); a.off = off; a.seq_len = nbytes; a.npairs = npairs;
+    a.surv = surv.data(); a.nsurv = &small[0]; a.ticket = &small[1]; a.nrec = &small[2]; a.errflag = &small[3];
+    a.counts = accum.data(); a.kmc = a.counts + ntr; a.nmapread = a.kmc + nloci; a.counters = a.nmapread + nloci;
+    a.recs = recs; a.rec_cap = (uint32_t)rec_cap;
+    a.vote_scratch = vote.data(); a.vote_epoch = epoch.data();
+    run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter(x, a); });
+    run_grid(grid_pair, 64, sizeof(PairSmem), [&](EmuX& x) { body_pair(x, a); });
+    if (small[3]) return (int)small[3];
+    memcpy(counts, accum.data(), ntr * 8);
+    memcpy(kmc, accum.data() + ntr, nloci * 8);
+    for (uint64_t l = 0; l < nloci; ++l) nmapread[l] = (uint32_t)accum[ntr + nloci + l];
+    memcpy(counters, accum.data() + ntr + 2 * nloci, DBTK_C_COUNT * 8);
+    if (nrec) *nrec = p->trace ? npairs : small[2];
+    return 0;
+}
+
+}  // extern "C"

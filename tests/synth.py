@@ -229,3 +229,98 @@ def read_rpgg_files(pref: str):
                 tr_cnt[-1] += 1
     return dict(keys=keys, vals=vals, vv=vv, fl_cnt=fl_cnt, fl_ks=fl_ks, tre_cnt=tre_cnt, tre_ks=tre_ks,
                 tr_cnt=np.array(tr_cnt, np.uint64), tr_ks=np.array(tr_ks, np.uint64), nloci=len(tr_cnt))
+
+
+# --------------------------------------------------------------------------
+# Array-level RPGG builder (numpy).  Used for cases the reference's tools are
+# too slow or too big for (hundreds of loci sharing k-mers); oracle and product
+# both consume the SAME arrays, so this builder only has to be self-consistent,
+# not identical to fa2kmers/ktools.
+CODE = np.full(256, -1, dtype=np.int64)
+for _i, _c in enumerate(b"ACGT"):
+    CODE[_c] = _i
+
+
+def canon_kmers(seq: np.ndarray, k: int):
+    """(canonical k-mers, valid mask) for every window of seq (uint8 ASCII)."""
+    c = CODE[seq]
+    n = len(seq) - k + 1
+    if n <= 0:
+        return np.zeros(0, np.uint64), np.zeros(0, bool)
+    win = np.lib.stride_tricks.sliding_window_view(c, k)
+    valid = (win >= 0).all(axis=1)
+    w = np.where(win < 0, 0, win).astype(np.uint64)
+    sh = (2 * np.arange(k - 1, -1, -1)).astype(np.uint64)
+    fw = (w << sh).sum(axis=1, dtype=np.uint64)
+    rc = ((np.uint64(3) - w[:, ::-1]) << sh).sum(axis=1, dtype=np.uint64)
+    return np.minimum(fw, rc), valid
+
+
+def _uniq_in_order(a):
+    _, idx = np.unique(a, return_index=True)
+    return a[np.sort(idx)]
+
+
+def build_rpgg_arrays(loci: Loci, k=21):
+    """Flat RPGG (the layout of read_rpgg_files) straight from the haplotypes."""
+    fs = loci.flank
+    tr_cnt, tr_ks, fl_cnt, fl_ks, tre_cnt, tre_ks = [], [], [], [], [], []
+    for l in range(loci.nloci):
+        tr, fl, tre = [], [], []
+        for h in range(loci.nhap):
+            s = loci.haps[h][l]
+            ks, ok = canon_kmers(s, k)
+            n = len(ks)
+            pos = np.arange(n)
+            in_tr = (pos >= fs) & (pos <= len(s) - fs - k)
+            tr.append(ks[ok & in_tr])
+            fl.append(ks[ok & ~in_tr])
+            es, eok = canon_kmers(s, k + 1)
+            epos = np.arange(len(es))
+            tre.append(es[eok & (epos >= fs) & (epos <= len(s) - fs - k - 1)])
+        tr = _uniq_in_order(np.concatenate(tr))
+        fl = _uniq_in_order(np.concatenate(fl))
+        tre = _uniq_in_order(np.concatenate(tre))
+        tr_cnt.append(len(tr)); tr_ks.append(tr)
+        fl_cnt.append(len(fl)); fl_ks.append(fl)
+        tre_cnt.append(len(tre)); tre_ks.append(tre)
+    # index: k-mer -> locus<<1 | vv offset<<1|1 (readKmerIndex + serialize semantics: tr loci first, then fl)
+    allk = np.concatenate(tr_ks + fl_ks)
+    alll = np.concatenate([np.full(n, l, np.uint32) for l, n in enumerate(tr_cnt)] +
+                          [np.full(n, l, np.uint32) for l, n in enumerate(fl_cnt)])
+    order = np.argsort(allk, kind="stable")
+    sk, sl = allk[order], alll[order]
+    starts = np.r_[0, np.nonzero(sk[1:] != sk[:-1])[0] + 1, len(sk)]
+    keys, vals, vv = [], [], []
+    for a, b in zip(starts[:-1], starts[1:]):
+        ls = _uniq_in_order(sl[a:b])
+        keys.append(sk[a])
+        if len(ls) == 1:
+            vals.append(int(ls[0]) << 1)
+        else:
+            vals.append((len(vv) << 1) | 1)
+            vv.append(len(ls))
+            vv.extend(int(x) for x in ls)
+    rng = np.random.default_rng(12345)
+    perm = rng.permutation(len(keys))  # the on-disk key order is arbitrary (hash-map iteration order)
+    return dict(keys=np.array(keys, np.uint64)[perm], vals=np.array(vals, np.uint32)[perm], vv=np.array(vv, np.uint32),
+                fl_cnt=np.array(fl_cnt, np.uint64), fl_ks=np.concatenate(fl_ks).astype(np.uint64),
+                tre_cnt=np.array(tre_cnt, np.uint64), tre_ks=np.concatenate(tre_ks).astype(np.uint64),
+                tr_cnt=np.array(tr_cnt, np.uint64), tr_ks=np.concatenate(tr_ks).astype(np.uint64), nloci=loci.nloci)
+
+
+def write_rpgg_files(arr, pref: str):
+    """HEAD on-disk formats from flat arrays."""
+    with open(pref + ".kmers.dbi", "wb") as f:
+        f.write(np.uint64(len(arr["keys"])).tobytes() + arr["keys"].tobytes() + arr["vals"].tobytes())
+        f.write(np.uint64(len(arr["vv"])).tobytes() + arr["vv"].tobytes())
+    for tag, c, ks in (("fl", "fl_cnt", "fl_ks"), ("tre", "tre_cnt", "tre_ks")):
+        with open(f"{pref}.{tag}.kdb", "wb") as f:
+            f.write(np.uint64(len(arr[c])).tobytes() + arr[c].tobytes() + np.uint64(len(arr[ks])).tobytes() + arr[ks].tobytes())
+    with open(pref + ".tr.kmers", "w") as f:
+        i = 0
+        for l, n in enumerate(arr["tr_cnt"]):
+            f.write(f">{l}\n")
+            for km in arr["tr_ks"][i:i + int(n)]:
+                f.write(f"{int(km)}\t0\n")
+            i += int(n)

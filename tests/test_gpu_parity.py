@@ -1,0 +1,111 @@
+"""GPU parity: the HIP path (through the C-ABI of libdbtk_hip.so) against the
+oracle on the same seeded inputs.  Integer outputs must be bit-exact: counts in
+OUT.trkmc.ar order, kmc, nmapread, the reference's counters, and every field
+of every per-pair record."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import bind
+import synth
+from cases import CASES, make_case
+
+abi = bind.abi
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dbtk():
+    return bind.pkg.Dbtk()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return bind.Oracle()
+
+
+def compare(o, g, order, ntr, npairs, recs=True):
+    co = np.zeros(ntr, np.uint64)
+    np.add.at(co, order.astype(np.int64), o["counts_file"])
+    assert (co == g["counts"]).all(), f"{int((co != g['counts']).sum())} k-mer counts differ"
+    assert (o["kmc"] == g["kmc"]).all()
+    assert (o["nmapread"] == g["nmapread"]).all()
+    assert (o["counters"] == g["counters"]).all(), (o["counters"], g["counters"])
+    if recs:
+        d = bind.recs_equal(o["recs"], g["recs"], npairs)
+        assert d < 0, f"record {d}:\n  oracle {bind.rec_str(o['recs'][d])}\n  hip    {bind.rec_str(g['recs'][d])}"
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_hip_matches_oracle(case, dbtk, oracle, tmp_path):
+    c = make_case(case, str(tmp_path))
+    go = oracle.load(c.prefix, c.k, c.qc_file)
+    g = dbtk.load(c.prefix, c.k, c.qc_file)
+    order = g.output_order()
+    seq, off = c.reads.packed()
+    for kw in c.param_sets:
+        p = abi.default_params(ksize=c.k, trace=1, **kw)
+        o = oracle.align(go, p, seq, off)
+        ctx = dbtk.context(g, p)
+        recs, nrec = ctx.align(seq, off)
+        res = ctx.counts()
+        res["recs"] = recs
+        assert nrec == c.reads.npairs
+        compare(o, res, order, g.ntrkmers, c.reads.npairs)
+        # kam mode (no trace): only counted pairs, in pair order
+        p2 = abi.default_params(ksize=c.k, **kw)
+        if p2.okam or p2.extract:
+            ctx2 = dbtk.context(g, p2)
+            recs2, n2 = ctx2.align(seq, off)
+            want = [r for r in o["recs"] if r.stage in (abi.STAGE_COUNTED, abi.STAGE_EXTRACT)]
+            assert n2 == len(want)
+            sz = C.sizeof(abi.PairRec)
+            for i, r in enumerate(want):
+                assert bytes(recs2[i]) == bytes(r)[:sz]
+            ctx2.close()
+        ctx.close()
+    oracle.free(go)
+    g.close()
+
+
+def test_batches_accumulate_and_split_invariance(dbtk, oracle, tmp_path):
+    """Batch boundaries do not change results (AQ.cpp:1918-1976: all effects additive)."""
+    c = make_case("mixed", str(tmp_path))
+    g = dbtk.load(c.prefix, c.k)
+    go = oracle.load(c.prefix, c.k)
+    seq, off = c.reads.packed()
+    p = abi.default_params(ksize=c.k, cthreshold=45, okam=0)
+    o = oracle.align(go, p, seq, off)
+    ctx = dbtk.context(g, p)
+    n = c.reads.npairs
+    cuts = [0, 1, 7, n // 3, n // 3, n - 1, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ctx.align(seq, off[2 * a:2 * b + 1])
+    res = ctx.counts()
+    compare(o, res, g.output_order(), g.ntrkmers, n, recs=False)
+    ctx.close()
+
+
+def test_empty_and_degenerate_batches(dbtk, tmp_path):
+    c = make_case("clean", str(tmp_path))
+    g = dbtk.load(c.prefix, c.k)
+    p = abi.default_params(ksize=c.k, trace=1)
+    ctx = dbtk.context(g, p)
+    recs, n = ctx.align(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert n == 0
+    # empty reads, reads shorter than k, all-N reads
+    reads = synth.Reads()
+    reads.seqs = [b"", b"", b"ACGT", b"ACGTACGTAC", b"N" * 150, b"A" * 150, b"A" * 150, b"N" * 150]
+    reads.titles = ["a", "b", "c", "d"]
+    seq, off = reads.packed()
+    recs, n = ctx.align(seq, off)
+    assert n == 4 and all(recs[i].stage == abi.STAGE_SHORT for i in range(4))
+    res = ctx.counts()
+    assert res["counters"][abi.C_NSHORT] == 4 and res["counters"][abi.C_NREADS] == 8
+    assert res["counts"].sum() == 0
+    with pytest.raises(bind.pkg.DbtkError) as e:
+        ctx.align(np.frombuffer(b"A" * 300 + b"C" * 10, np.uint8), np.array([0, 300, 310], np.uint64))
+    assert e.value.status == abi.ERR_READ_TOO_LONG
+    ctx.close()
