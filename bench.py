@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — `danbing-tk align` hot path on N MI355X (one process per GPU).
+
+Workload (BASELINE.json configs[1], named in config.workload): the release-scale
+synthetic RPGG of SURVEY.md 8(d) (80 000 loci, ~1.4e8 index keys; the real
+release RPGG is not available offline), replicated per GPU, and 10 M synthetic
+150 bp PE reads per GPU (WGS-like mix: `--hit-frac` of the pairs tiled from the
+loci with 0.1-0.5 % substitutions, the rest uniform random), aligned with
+`-k 21 -kf 4 1 -cth 45 -ka`.  A "step" is one pass of the hot path (encode ->
+subfilter -> kfilter probe -> vote -> assign -> count) over the rank's resident
+read set; reads are in HBM before the timed region.  N > 1: reads shard across
+ranks (weak scaling, no data-path collective); the accumulators are summed once
+at the end with one RCCL all-reduce, inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
+objects: `roofline` (dominant kernel, algorithmic bytes / HIP-event time) and
+`cpu_baseline` (the oracle, a plain-C port of the reference path, timed on one
+host core over a bounded sample of the same workload).
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nloci", type=int, default=80000, help="loci of the synthetic RPGG (80000 = release scale)")
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (pairs = reads/2)")
+    ap.add_argument("--hit-frac", type=float, default=0.02, help="fraction of pairs drawn from the loci (WGS-like: 0.02)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 = skip)")
+    ap.add_argument("--parity-pairs", type=int, default=20000, help="pairs re-checked against the oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("danbing-tk_amd")
+    abi = pkg.abi
+    dbtk = pkg.Dbtk()  # raises if the HIP extension is missing: no CPU fallback
+    log = (lambda *a: print("[bench]", *a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
+
+    # ---- workload: RPGG replica per GPU, read shard per rank
+    ncpu = os.cpu_count() or 8
+    nth = max(2, ncpu // world)
+    t0 = time.time()
+    syn = pkg.Synth(nloci=args.nloci, k=21, flank=700, seed=20250808, nthreads=nth)
+    arrs = syn.arrays()
+    log(f"synthetic RPGG: {args.nloci} loci, {arrs.nkeys} index keys in {time.time() - t0:.1f}s ({nth} threads)")
+    t0 = time.time()
+    h = C.c_void_p()
+    dbtk._chk(dbtk.L.dbtk_rpgg_from_arrays(C.byref(arrs), C.byref(h)))
+    g = pkg.Rpgg(dbtk, h)
+    params = abi.default_params(ksize=21, n_filter=4, nm_filter=1, cthreshold=45, okam=0)
+    ctx = dbtk.context(g, params, device=local_rank)
+    log(f"handle + HBM tables: {g.ntrkmers} TR k-mers, {time.time() - t0:.1f}s")
+    npairs = args.reads // 2
+    rlen = 150
+    t0 = time.time()
+    seq, off = syn.reads(npairs, rlen=rlen, hit_frac=args.hit_frac, seed=1, first_pair=rank * npairs, nthreads=nth)
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    log(f"reads: {npairs} pairs/GPU resident in HBM, {time.time() - t0:.1f}s")
+
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    acc_ptr, acc_n = ctx.accum_buffer()
+    acc_t = torch.empty(acc_n, dtype=torch.int64, device=dev) if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        ctx.align_device(d_seq.data_ptr(), d_off.data_ptr(), npairs, rlen)
+
+    def reduce_counts():
+        """The one exchange of the path: sum of the per-GPU accumulators over xGMI."""
+        if world == 1:
+            return
+        ctx.synchronize()
+        assert hip.hipMemcpy(acc_t.data_ptr(), acc_ptr, acc_n * 8, 3) == 0
+        dist.all_reduce(acc_t)  # RCCL sum; int64 adds wrap exactly like the reference's uint64 atomics
+        assert hip.hipMemcpy(acc_ptr, acc_t.data_ptr(), acc_n * 8, 3) == 0
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    ctx.reset()
+    ctx.timers_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    ktimes = ctx.kernel_times()      # before the reduce: per-rank counters for the roofline
+    local = ctx.counts()
+    reduce_counts()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    total_reads = 2 * npairs * args.steps * world
+    value = total_reads / dt
+
+    # ---- roofline of the dominant kernel (this rank): algorithmic bytes of SURVEY.md 8(d) per launch
+    ctr = local["counters"].astype(np.float64) / max(args.steps, 1)  # per step == per launch
+    alg = {
+        # every read byte once + 12 B per subfilter probe
+        "k_encode_subfilter": ctr[abi.C_BASES] + 12.0 * (ctr[abi.C_ALGO_PROBES] - ctr[abi.C_NHASH1]),
+        # 12 B per kfilter probe + 4 B per vv word + 8 B per classified k-mer + 16 B per count increment
+        "k_pair": 12.0 * ctr[abi.C_NHASH1] + 4.0 * ctr[abi.C_ALGO_VV] + 8.0 * ctr[abi.C_ALGO_CLS] + 16.0 * ctr[abi.C_ALGO_INC],
+    }
+    per_kernel = {}
+    for name, (ms, n) in ktimes.items():
+        avg = ms / max(n, 1)
+        per_kernel[name] = dict(avg_ms=avg, launches=n, algorithmic_bytes=alg.get(name, 0.0),
+                                gbs=(alg.get(name, 0.0) / (avg * 1e-3) / 1e9) if avg > 0 else 0.0)
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"] * per_kernel[k]["launches"])
+    roof = dict(bound="hbm", kernel=dom, achieved=per_kernel[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=per_kernel[dom]["gbs"] / HBM_PEAK_GBS, traffic=None,
+                algorithmic_bytes_per_launch=per_kernel[dom]["algorithmic_bytes"], avg_ms=per_kernel[dom]["avg_ms"],
+                kernels=per_kernel)
+
+    out = None
+    if rank == 0:
+        cpu = None
+        parity = None
+        if world == 1 and (args.cpu_seconds > 0 or args.parity_pairs > 0):
+            import bind
+            orc = bind.Oracle()
+            t0 = time.time()
+            go = orc.from_arrays(arrs)
+            log(f"oracle tables: {time.time() - t0:.1f}s")
+            if args.parity_pairs > 0:
+                n = min(args.parity_pairs, npairs)
+                ctx.reset()
+                ctx.align(seq[:2 * n * rlen], off[:2 * n + 1])
+                r = ctx.counts()
+                o = orc.align(go, params, seq[:2 * n * rlen], off[:2 * n + 1], trace=False)
+                co = np.zeros(g.ntrkmers, np.uint64)
+                np.add.at(co, g.output_order().astype(np.int64), o["counts_file"])
+                ok = bool((co == r["counts"]).all() and (o["kmc"] == r["kmc"]).all() and (o["nmapread"] == r["nmapread"]).all()
+                          and (o["counters"] == r["counters"]).all())
+                parity = dict(pairs=n, bit_exact=ok)
+                log(f"parity on {n} pairs: {'bit-exact' if ok else 'MISMATCH'}")
+                if not ok:
+                    raise SystemExit("GPU result differs from the oracle")
+            if args.cpu_seconds > 0:
+                chunk, done, t_cpu = 250_000, 0, 0.0
+                while done < npairs and t_cpu < args.cpu_seconds:
+                    n = min(chunk, npairs - done)
+                    t1 = time.perf_counter()
+                    orc.align(go, params, seq[2 * done * rlen:2 * (done + n) * rlen], off[:2 * n + 1], trace=False)
+                    t_cpu += time.perf_counter() - t1
+                    done += n
+                cpu = dict(value=2 * done / t_cpu, unit="reads/s", cores=1, kind="port",
+                           sample=f"first {2 * done} reads of the same read set and RPGG, oracle/dbtk_oracle.c on 1 host core, {t_cpu:.1f} s")
+                log(f"cpu baseline: {cpu['value']:.0f} reads/s on 1 core")
+            orc.free(go)
+        out = {
+            "metric": "paired reads/sec aligned to RPGG (k=21)", "value": value, "unit": "reads/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"release-scale synthetic RPGG ({args.nloci} loci, {arrs.nkeys} index keys, {g.ntrkmers} TR k-mers) "
+                                   f"replicated per GPU; {args.reads} x 150bp PE reads per GPU per step, {args.hit_frac:.0%} of pairs from loci; "
+                                   f"-k 21 -kf 4 1 -cth 45 -ka; RCCL all-reduce of counts at the end",
+                       "reads_per_gpu": args.reads, "read_len": rlen, "hit_frac": args.hit_frac, "k": 21, "cth": 45},
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -160,10 +160,15 @@ class Context:
         self._lib._chk(self._lib.L.dbtk_ctx_reset(self.h))
 
     def kernel_times(self):
+        """{kernel: (total_ms, launches)} since timers_reset()."""
         names = (C.c_char_p * 8)()
-        ms = (C.c_float * 8)()
-        n = self._lib.L.dbtk_ctx_kernel_times(self.h, names, ms, 8)
-        return {names[i].decode(): float(ms[i]) for i in range(n)}
+        ms = (C.c_double * 8)()
+        cnt = (C.c_uint64 * 8)()
+        n = self._lib.L.dbtk_ctx_kernel_times(self.h, names, ms, cnt, 8)
+        return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
+
+    def timers_reset(self):
+        self._lib.L.dbtk_ctx_timers_reset(self.h)
 
     def close(self):
         if self.h:
@@ -197,7 +202,8 @@ class Dbtk(_HostSide):
         L.dbtk_ctx_reset.restype = C.c_int
         L.dbtk_ctx_reset.argtypes = [C.c_void_p]
         L.dbtk_ctx_kernel_times.restype = C.c_int
-        L.dbtk_ctx_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+        L.dbtk_ctx_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), u64p, C.c_int]
+        L.dbtk_ctx_timers_reset.argtypes = [C.c_void_p]
         L.dbtk_allreduce.restype = C.c_int
         L.dbtk_allreduce.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         if L.dbtk_abi_version() != abi.ABI_VERSION:
@@ -216,5 +222,42 @@ EXPORTS = [
     "dbtk_rpgg_load", "dbtk_rpgg_from_arrays", "dbtk_rpgg_free", "dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys",
     "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
-    "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_write_outputs", "dbtk_last_error", "dbtk_abi_version",
+    "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_write_outputs", "dbtk_last_error", "dbtk_abi_version",
 ]
+
+
+class Synth:
+    """Seeded release-scale workload generator (csrc/dbtk_synth.cpp): a flat
+    RPGG + 150 bp read pairs, for bench.py and the scale tests."""
+
+    def __init__(self, nloci=80000, k=21, flank=700, seed=20250808, nthreads=0, path=os.path.join(_HERE, "libdbtk_synth.so")):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not found: run `make -C danbing-tk_amd/csrc`")
+        L = self.L = C.CDLL(path)
+        L.dbtk_synth_create.restype = C.c_void_p
+        L.dbtk_synth_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
+        L.dbtk_synth_free.argtypes = [C.c_void_p]
+        L.dbtk_synth_arrays.argtypes = [C.c_void_p, C.POINTER(abi.RpggArrays)]
+        L.dbtk_synth_nbases.restype = C.c_uint64
+        L.dbtk_synth_nbases.argtypes = [C.c_void_p]
+        L.dbtk_synth_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_uint64, u8p, C.c_uint32]
+        self.h = L.dbtk_synth_create(nloci, k, flank, seed, nthreads)
+        self.k, self.nloci = k, nloci
+
+    def arrays(self) -> abi.RpggArrays:
+        a = abi.RpggArrays()
+        self.L.dbtk_synth_arrays(self.h, C.byref(a))
+        return a
+
+    def reads(self, npairs, rlen=150, hit_frac=1.0, seed=1, first_pair=0, out=None, nthreads=0):
+        """(seq bytes, offsets) — read r is seq[r*rlen:(r+1)*rlen]."""
+        if out is None:
+            out = np.empty(npairs * 2 * rlen, np.uint8)
+        self.L.dbtk_synth_reads(self.h, npairs, first_pair, rlen, float(hit_frac), seed, _ptr(out, u8p), nthreads)
+        off = np.arange(2 * npairs + 1, dtype=np.uint64) * np.uint64(rlen)
+        return out, off
+
+    def close(self):
+        if self.h:
+            self.L.dbtk_synth_free(self.h)
+            self.h = None

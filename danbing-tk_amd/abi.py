@@ -13,8 +13,9 @@ ABI_VERSION = 1
  STAGE_EXTRACT) = range(9)
 
 (C_NREADS, C_SUBFILTERED, C_KMERFILTERED, C_BAITFILTERED, C_QUALFILTERED, C_LOCUSFILTERED, C_QCFILTERED,
- C_THREADING, C_FEASIBLE, C_ASGN, C_NSHORT, C_NHASH0, C_NHASH1, C_ALGO_PROBES) = range(14)
-C_COUNT = 16
+ C_THREADING, C_FEASIBLE, C_ASGN, C_NSHORT, C_NHASH0, C_NHASH1, C_ALGO_PROBES, C_ALGO_VV, C_ALGO_CLS, C_ALGO_INC,
+ C_SURVIVORS, C_BASES) = range(19)
+C_COUNT = 24
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)

@@ -88,8 +88,18 @@ __global__ void __launch_bounds__(64) k_pair(BatchArgs a) {
     } while (0)
 
 namespace {
-constexpr int MAX_TIMED = 8;
-struct Timed { const char* name; hipEvent_t beg, end; bool used; };
+// Per-kernel timing: a pool of HIP event pairs recorded on the context's stream
+// around every launch; folded into (total ms, launches) when the pool fills or
+// when the caller asks.
+constexpr int NKERN = 2;       // k_encode_subfilter, k_pair
+constexpr int EVPOOL = 128;    // launches in flight before a fold
+struct Timed {
+    const char* name;
+    hipEvent_t beg[EVPOOL], end[EVPOOL];
+    int used;
+    double total_ms;
+    uint64_t launches;
+};
 }  // namespace
 
 struct dbtk_ctx {
@@ -114,8 +124,7 @@ struct dbtk_ctx {
     uint64_t* d_vote = nullptr;
     uint32_t* d_epoch = nullptr;
     int pair_blocks = 0, num_cu = 0;
-    Timed timed[MAX_TIMED];
-    int ntimed = 0;
+    Timed timed[NKERN];
 };
 
 namespace {
@@ -130,10 +139,11 @@ uint32_t log2u(uint64_t c) { return 63u - (uint32_t)__builtin_clzll(c); }
 void free_ctx(dbtk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (int i = 0; i < MAX_TIMED; ++i) {
-        if (c->timed[i].beg) (void)hipEventDestroy(c->timed[i].beg);
-        if (c->timed[i].end) (void)hipEventDestroy(c->timed[i].end);
-    }
+    for (int i = 0; i < NKERN; ++i)
+        for (int j = 0; j < EVPOOL; ++j) {
+            if (c->timed[i].beg[j]) (void)hipEventDestroy(c->timed[i].beg[j]);
+            if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
+        }
     void* ptrs[] = {c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -236,12 +246,22 @@ dbtk_status_t ensure(T** p, uint64_t* cap, uint64_t need) {
     return DBTK_OK;
 }
 
-Timed* timer(dbtk_ctx* c, const char* name) {
-    if (c->ntimed >= MAX_TIMED) return nullptr;
-    Timed* t = &c->timed[c->ntimed++];
-    t->name = name;
-    t->used = true;
-    return t;
+// fold the recorded event pairs of one kernel into its totals (stream must be idle)
+void fold_timer(Timed& t) {
+    for (int j = 0; j < t.used; ++j) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.beg[j], t.end[j]) == hipSuccess) { t.total_ms += ms; ++t.launches; }
+    }
+    t.used = 0;
+}
+dbtk_status_t timed_slot(dbtk_ctx* c, int k, int* slot) {
+    Timed& t = c->timed[k];
+    if (t.used == EVPOOL) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < NKERN; ++i) fold_timer(c->timed[i]);
+    }
+    *slot = t.used++;
+    return DBTK_OK;
 }
 
 // K1 + pair kernel over reads already in HBM.
@@ -263,18 +283,17 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     a.counters = a.nmapread + c->g->nloci;
     a.recs = d_recs; a.rec_cap = rec_cap;
     a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
-    c->ntimed = 0;
     if (npairs == 0) return DBTK_OK;
     const uint64_t ntiles = (npairs + K1_TP - 1) / K1_TP;
     const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->num_cu * 8 ? ntiles : (uint64_t)c->num_cu * 8);
-    Timed* t1 = timer(c, "k_encode_subfilter");
-    HIPCHK(hipEventRecord(t1->beg, s));
+    int e1 = 0, e2 = 0;
+    if ((st = timed_slot(c, 0, &e1)) || (st = timed_slot(c, 1, &e2))) return st;
+    HIPCHK(hipEventRecord(c->timed[0].beg[e1], s));
     hipLaunchKernelGGL(k_encode_subfilter, dim3(g1), dim3(K1_NT), 0, s, a);
-    HIPCHK(hipEventRecord(t1->end, s));
-    Timed* t2 = timer(c, "k_pair");
-    HIPCHK(hipEventRecord(t2->beg, s));
+    HIPCHK(hipEventRecord(c->timed[0].end[e1], s));
+    HIPCHK(hipEventRecord(c->timed[1].beg[e2], s));
     hipLaunchKernelGGL(k_pair, dim3(c->pair_blocks), dim3(64), 0, s, a);
-    HIPCHK(hipEventRecord(t2->end, s));
+    HIPCHK(hipEventRecord(c->timed[1].end[e2], s));
     HIPCHK(hipGetLastError());
     return DBTK_OK;
 }
@@ -308,8 +327,11 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
     dbtk_status_t st = DBTK_OK;
     do {
         if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); st = DBTK_ERR_HIP; break; }
-        for (int i = 0; i < MAX_TIMED && !st; ++i)
-            if (hipEventCreate(&c->timed[i].beg) != hipSuccess || hipEventCreate(&c->timed[i].end) != hipSuccess) { set_error("hipEventCreate failed"); st = DBTK_ERR_HIP; }
+        c->timed[0].name = "k_encode_subfilter";
+        c->timed[1].name = "k_pair";
+        for (int i = 0; i < NKERN && !st; ++i)
+            for (int j = 0; j < EVPOOL && !st; ++j)
+                if (hipEventCreate(&c->timed[i].beg[j]) != hipSuccess || hipEventCreate(&c->timed[i].end[j]) != hipSuccess) { set_error("hipEventCreate failed"); st = DBTK_ERR_HIP; }
         if (st) break;
         if ((st = build_tables(c))) break;
         c->ntr = h->out_kmer.size();
@@ -438,19 +460,26 @@ dbtk_status_t dbtk_ctx_reset(dbtk_ctx_t* c) {
     return DBTK_OK;
 }
 
-int dbtk_ctx_kernel_times(dbtk_ctx_t* c, const char** names, float* ms, int cap) {
+int dbtk_ctx_kernel_times(dbtk_ctx_t* c, const char** names, double* total_ms, uint64_t* launches, int cap) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     int n = 0;
-    for (int i = 0; i < c->ntimed && n < cap; ++i) {
-        float t = 0;
-        if (hipEventElapsedTime(&t, c->timed[i].beg, c->timed[i].end) != hipSuccess) continue;
+    for (int i = 0; i < NKERN && n < cap; ++i) {
+        fold_timer(c->timed[i]);
         names[n] = c->timed[i].name;
-        ms[n] = t;
+        total_ms[n] = c->timed[i].total_ms;
+        launches[n] = c->timed[i].launches;
         ++n;
     }
     return n;
+}
+
+void dbtk_ctx_timers_reset(dbtk_ctx_t* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < NKERN; ++i) { c->timed[i].used = 0; c->timed[i].total_ms = 0; c->timed[i].launches = 0; }
 }
 
 // One RCCL all-reduce (sum, uint64) over the accumulator buffers of n contexts

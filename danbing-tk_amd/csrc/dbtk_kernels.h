@@ -151,7 +151,7 @@ struct K1Smem {
     uint16_t rlen[2 * K1_TP];
     uint8_t any[2 * K1_TP];    // read has at least one valid k-mer window
     uint32_t hm1[K1_TP], hm2[K1_TP];  // hit masks of the sampled positions
-    uint32_t cnt[8];           // block counters: nshort, nsub, nhash0, nprobe
+    uint32_t cnt[8];           // block counters: nshort, nsub, nhash0, nprobe, nsurv, nbases
 };
 
 // true iff bases [b, b+len) of the stream contain a run of >= k valid bases
@@ -225,6 +225,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
             const uint32_t len = (uint32_t)(o1 - o0), b = (uint32_t)(o0 - A0);
             sm.bpos[tid] = b;
             sm.rlen[tid] = (uint16_t)len;
+            x.lds_add(&sm.cnt[5], len);
             sm.any[tid] = any_valid_window(sm.vd, b, len, k);
         }
         x.sync();
@@ -279,6 +280,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
             if (stage == 0xFFFFFFFFu) {
                 const uint32_t at = x.atomic_add(a.nsurv, 1u);
                 a.surv[at] = pair;
+                x.lds_add(&sm.cnt[4], 1);
             } else if (a.P.trace && a.recs) {
                 write_early_rec(&a.recs[pair], pair, stage, a.T.nloci);
             }
@@ -290,6 +292,8 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         if (sm.cnt[1]) x.atomic_add(&a.counters[DBTK_C_SUBFILTERED], (uint64_t)sm.cnt[1]);
         if (sm.cnt[2]) x.atomic_add(&a.counters[DBTK_C_NHASH0], (uint64_t)sm.cnt[2]);
         if (sm.cnt[3]) x.atomic_add(&a.counters[DBTK_C_ALGO_PROBES], (uint64_t)sm.cnt[3]);
+        if (sm.cnt[4]) x.atomic_add(&a.counters[DBTK_C_SURVIVORS], (uint64_t)sm.cnt[4]);
+        if (sm.cnt[5]) x.atomic_add(&a.counters[DBTK_C_BASES], (uint64_t)sm.cnt[5]);
     }
 }
 
@@ -415,7 +419,7 @@ DBTK_HD void updatetop2(uint64_t cf, uint32_t ind, uint64_t cr, Asgn& top, Asgn&
 // find_matching_locus + the accept test of countHit
 // (src/aQueryFasta_thread.cpp:364-422, 436-451) on the permuted unique list.
 DBTK_HD void vote(const DevTables& T, const uint16_t* ord, const uint32_t* uval, const uint32_t* dd, int nu, uint32_t cth,
-                  HitMap& hm, Asgn& top) {
+                  HitMap& hm, Asgn& top, uint64_t& nvvw) {
     Asgn second{NAN32, 0, 0};
     top = Asgn{NAN32, 0, 0};
     uint64_t total = 0;
@@ -428,6 +432,7 @@ DBTK_HD void vote(const DevTables& T, const uint16_t* ord, const uint32_t* uval,
         rem -= d1 + d2;
         if (vi & 1) {
             const uint32_t n = T.vv[vi >> 1];
+            nvvw += 1 + n;
             for (uint32_t j = 0; j < n; ++j) {
                 const uint32_t locus = T.vv[(vi >> 1) + 1 + j];
                 const uint32_t h = hitmap_add(hm, locus, add);
@@ -448,8 +453,11 @@ DBTK_HD void vote(const DevTables& T, const uint16_t* ord, const uint32_t* uval,
                 remj -= e1 + e2;
                 if (vj & 1) {
                     const uint32_t n = T.vv[vj >> 1];
-                    for (uint32_t q = 0; q < n; ++q)
+                    nvvw += 1;
+                    for (uint32_t q = 0; q < n; ++q) {
+                        nvvw += 1;
                         if (T.vv[(vj >> 1) + 1 + q] == top.idx) { top.fc += e1; top.rc += e2; break; }
+                    }
                 } else if ((vj >> 1) == top.idx) {
                     top.fc += e1; top.rc += e2;
                 }
@@ -467,7 +475,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     const uint32_t k = T.ksize, cth = a.P.cthreshold, nloci = T.nloci;
     const bool okam = a.P.okam != 0;
     // per-block counters, flushed once at the end
-    uint64_t c_kf = 0, c_hf = 0, c_qc = 0, c_thr = 0, c_feas = 0, c_asgn = 0, c_nhash1 = 0;
+    uint64_t c_kf = 0, c_hf = 0, c_qc = 0, c_thr = 0, c_feas = 0, c_asgn = 0, c_nhash1 = 0, c_vv = 0, c_cls = 0, c_inc = 0;
 
     for (;;) {
         uint32_t t = 0;
@@ -626,6 +634,11 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 const uint32_t c = (v & 1) ? T.vv[v >> 1] : 1u;
                 sm.u.v.nml[u] = c;
             }
+            {
+                uint32_t odd = 0;
+                for (uint32_t u = lane; u < nu; u += 64) odd += sm.uval[u] & 1;
+                c_vv += x.wave_sum(odd);
+            }
             for (uint32_t i = lane; i < (uint32_t)LCAP; i += 64) sm.u.v.lkey[i] = NAN32;
             x.sync();
             {
@@ -649,7 +662,9 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 const uint32_t ep = a.vote_epoch[x.bid()] + 1;
                 HitMap hmap{sm.u.v.lkey, sm.lhit, 0, a.vote_scratch + (size_t)x.bid() * ((size_t)nloci + 1), ep, false};
                 Asgn top;
-                vote(T, sm.u.v.ord, sm.uval, sm.dd, (int)nu, cth, hmap, top);
+                uint64_t nvvw = 0;
+                vote(T, sm.u.v.ord, sm.uval, sm.dd, (int)nu, cth, hmap, top, nvvw);
+                c_vv += nvvw;
                 if (hmap.spilled) a.vote_epoch[x.bid()] = ep;
                 sm.res[0] = (int32_t)(uint32_t)top.idx;
                 sm.res[1] = (int32_t)top.fc;
@@ -682,6 +697,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                         if (!okam && rm[m]) continue;
                         const uint32_t nk = m ? nk1 : nk0;
                         nas[m] = nk;
+                        c_cls += nk;
                         uint32_t mytr = 0;
                         for (uint32_t i = lane; i < nk; i += 64) {
                             const uint64_t km = sm.kmer[m][i];
@@ -720,8 +736,10 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                         c_asgn += (uint64_t)nmap;
                         for (int m = 0; m < 2; ++m) {
                             if (rm[m]) continue;
+                            uint32_t myinc = 0;
                             for (uint32_t i = lane; i < nas[m]; i += 64)
-                                if (sm.as[m][i] == 2) x.atomic_add(&a.counts[sm.hval[m][i]], 1ull);
+                                if (sm.as[m][i] == 2) { x.atomic_add(&a.counts[sm.hval[m][i]], 1ull); ++myinc; }
+                            c_inc += x.wave_sum(myinc);
                         }
                     }
                 }
@@ -771,6 +789,9 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         if (c_thr) x.atomic_add(&a.counters[DBTK_C_THREADING], c_thr);
         if (c_feas) x.atomic_add(&a.counters[DBTK_C_FEASIBLE], c_feas);
         if (c_asgn) x.atomic_add(&a.counters[DBTK_C_ASGN], c_asgn);
+        if (c_vv) x.atomic_add(&a.counters[DBTK_C_ALGO_VV], c_vv);
+        if (c_cls) x.atomic_add(&a.counters[DBTK_C_ALGO_CLS], c_cls);
+        if (c_inc) x.atomic_add(&a.counters[DBTK_C_ALGO_INC], c_inc);
         if (c_nhash1) {
             x.atomic_add(&a.counters[DBTK_C_NHASH1], c_nhash1);
             x.atomic_add(&a.counters[DBTK_C_ALGO_PROBES], c_nhash1);

@@ -135,8 +135,14 @@ enum {
     DBTK_C_NREADS = 0, DBTK_C_SUBFILTERED, DBTK_C_KMERFILTERED, DBTK_C_BAITFILTERED,
     DBTK_C_QUALFILTERED, DBTK_C_LOCUSFILTERED, DBTK_C_QCFILTERED, DBTK_C_THREADING,
     DBTK_C_FEASIBLE, DBTK_C_ASGN, DBTK_C_NSHORT, DBTK_C_NHASH0, DBTK_C_NHASH1,
-    DBTK_C_ALGO_PROBES,   /* index lookups the reference algorithm performs (SURVEY 8d's P) */
-    DBTK_C_COUNT = 16
+    /* algorithmic work of SURVEY.md 8(d): B = 2L + 12 P + 4 V + 8 A + 16 I per pair */
+    DBTK_C_ALGO_PROBES,   /* P: index lookups the reference algorithm performs (subfilter + kfilter) */
+    DBTK_C_ALGO_VV,       /* V: uint32 words of vv read by fillstats / find_matching_locus */
+    DBTK_C_ALGO_CLS,      /* A: k-mers classified by assignTRkmc (one flank/TR lookup each) */
+    DBTK_C_ALGO_INC,      /* I: TR k-mer count increments */
+    DBTK_C_SURVIVORS,     /* pairs that passed subfilter (entered kfilter) */
+    DBTK_C_BASES,         /* bases of all reads handed to the hot loop (sum of L) */
+    DBTK_C_COUNT = 24
 };
 
 /* ---- RPGG -----------------------------------------------------------------*/
@@ -200,9 +206,12 @@ dbtk_status_t dbtk_ctx_reset(dbtk_ctx_t* ctx);
 /* In-process multi-GPU reduce (one context per GPU, RCCL over xGMI). */
 dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n);
 
-/* Per-kernel device time of the last batch, HIP events on the ctx stream, ms.
- * names[i] are static strings; returns how many were filled (<= cap). */
-int dbtk_ctx_kernel_times(dbtk_ctx_t* ctx, const char** names, float* ms, int cap);
+/* Per-kernel device time accumulated since dbtk_ctx_timers_reset (HIP events
+ * recorded on the context's stream around every launch): total_ms[i] over
+ * launches[i] launches of kernel names[i] (static strings).  Synchronises the
+ * stream.  Returns how many kernels were filled (<= cap). */
+int  dbtk_ctx_kernel_times(dbtk_ctx_t* ctx, const char** names, double* total_ms, uint64_t* launches, int cap);
+void dbtk_ctx_timers_reset(dbtk_ctx_t* ctx);
 
 /* ---- dumps: src/aQueryFasta_thread.cpp:2631-2641 --------------------------*/
 /* with_names = 0: OUT.trkmc.ar + OUT.tr.summary.txt; 1: OUT.tr.kmers (-on). */

@@ -649,7 +649,8 @@ static inline void touch(hits_t* h, uint32_t locus) {
 
 /* countHit, AQ.cpp:424-453 = fillstats (308-329) + find_matching_locus (364-422). */
 static uint64_t count_hit(const orc_rpgg_t* g, hit_t* its1, uint64_t n1, hit_t* its2, uint64_t n2, hits_t* H,
-                          uint32_t cth, uint64_t* tri0, int* nm1, int* nm2, int* hf1, int* hf2, int* rm1, int* rm2) {
+                          uint32_t cth, uint64_t* tri0, int* nm1, int* nm2, int* hf1, int* hf2, int* rm1, int* rm2,
+                          uint64_t* nvvw) {
     /* countDupRemove, AQ.cpp:257-296 */
     uint64_t n = n1 + n2;
     hit_o_t* all = (hit_o_t*)malloc((n + 1) * sizeof(hit_o_t));
@@ -676,7 +677,10 @@ static uint64_t count_hit(const orc_rpgg_t* g, hit_t* its1, uint64_t n1, hit_t* 
     /* fillstats, AQ.cpp:311-328 */
     uint64_t* nml = (uint64_t*)malloc(nu * 8);
     uint64_t* ord = (uint64_t*)malloc(nu * 8);
-    for (uint64_t i = 0; i < nu; ++i) nml[i] = (u[i].val % 2) ? g->vv[u[i].val >> 1] : 1;
+    for (uint64_t i = 0; i < nu; ++i) {
+        nml[i] = (u[i].val % 2) ? g->vv[u[i].val >> 1] : 1;
+        *nvvw += u[i].val % 2; /* one vv word read */
+    }
     orc_sort_index(nml, nu, ord);
     hit_t* su = (hit_t*)malloc(nu * sizeof(hit_t));
     pe_kmc_t* sdup = (pe_kmc_t*)malloc(nu * sizeof(pe_kmc_t));
@@ -695,6 +699,7 @@ static uint64_t count_hit(const orc_rpgg_t* g, hit_t* its1, uint64_t n1, hit_t* 
         uint32_t vi = su[i].val;
         if (vi % 2) {
             uint64_t j0 = (vi >> 1) + 1, j1 = j0 + g->vv[vi >> 1];
+            *nvvw += 1 + (j1 - j0);
             for (; j0 < j1; ++j0) {
                 uint32_t locus = g->vv[j0];
                 touch(H, locus);
@@ -717,7 +722,9 @@ static uint64_t count_hit(const orc_rpgg_t* g, hit_t* its1, uint64_t n1, hit_t* 
                 uint32_t vj = su[j].val;
                 if (vj % 2) {
                     uint64_t j0 = (vj >> 1) + 1, j1 = j0 + g->vv[vj >> 1];
+                    *nvvw += 1;
                     for (; j0 < j1; ++j0) {
+                        *nvvw += 1;
                         if (g->vv[j0] == top.idx) { top.fc += sdup[j].first; top.rc += sdup[j].second; break; }
                     }
                 } else if ((vj >> 1) == top.idx) {
@@ -845,11 +852,13 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
     uint64_t *caks1 = malloc(ML * 8), *caks2 = malloc(ML * 8), *caes1 = malloc(ML * 8), *caes2 = malloc(ML * 8);
     hit_t *its1 = malloc(ML * sizeof(hit_t)), *its2 = malloc(ML * sizeof(hit_t));
     uint64_t nShort = 0, nSub = 0, nKf = 0, nLocus = 0, nQC = 0, nThr = 0, nFeas = 0, nAsgn = 0, nhash0 = 0, nhash1 = 0, nprobe = 0;
+    uint64_t nvvw = 0, ncls = 0, ninc = 0, nsurv = 0, nbases = 0;
 
     for (uint64_t pi = 0; pi < npairs; ++pi) {
         const uint8_t* s1 = seq + off[2 * pi];     uint64_t l1 = off[2 * pi + 1] - off[2 * pi];
         const uint8_t* s2 = seq + off[2 * pi + 1]; uint64_t l2 = off[2 * pi + 2] - off[2 * pi + 1];
         if (l1 > ML || l2 > ML) return DBTK_ERR_READ_TOO_LONG;
+        nbases += l1 + l2;
         dbtk_pair_rec_t* rec = recs ? &recs[pi] : NULL;
         kmr_t r1, r2;
         kmr_init(&r1); kmr_init(&r2);
@@ -864,6 +873,7 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
         if (p->n_filter && p->nm_filter) {
             if (subfilter(g, p, caks1, nk1, caks2, nk2, &nhash0, &nprobe)) { nSub += 2; stage = DBTK_STAGE_SUBFILTER; goto emit; }
         }
+        ++nsurv;
         /* kfilter, AQ.cpp:190-200, 2052-2054 */
         {
             uint64_t n1 = 0, n2 = 0, h1before = nhash1;
@@ -877,7 +887,7 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
             nKf += (uint64_t)(kf1 + kf2);
             if (rm1 && rm2) { stage = DBTK_STAGE_KFILTER; goto emit; }
             /* AQ.cpp:2056-2062 */
-            destLocus = count_hit(g, its1, n1, its2, n2, &H, p->cthreshold, &destLocus0, &nm1, &nm2, &hf1, &hf2, &rm1, &rm2);
+            destLocus = count_hit(g, its1, n1, its2, n2, &H, p->cthreshold, &destLocus0, &nm1, &nm2, &hf1, &hf2, &rm1, &rm2, &nvvw);
             nLocus += (uint64_t)(hf1 + hf2);
             if (destLocus == nloci) { stage = DBTK_STAGE_LOCUS; goto emit; }
             if (p->qc && g->qc && !g->qc[destLocus]) { nQC += (uint64_t)(2 - rm1 - rm2); stage = DBTK_STAGE_QC; goto emit; }
@@ -887,6 +897,8 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
         if (p->extract) { stage = DBTK_STAGE_EXTRACT; goto emit; } /* AQ.cpp:2094-2099 */
         /* AQ.cpp:2138-2158 */
         if (okam || !rm1 || !rm2) {
+            if (okam || !rm1) ncls += nk1;
+            if (okam || !rm2) ncls += nk2;
             assign_trkmc(g, p, caks1, (int)nk1, destLocus0, &r1, &af1, &rm1, okam);
             assign_trkmc(g, p, caks2, (int)nk2, destLocus0, &r2, &af2, &rm2, okam);
         }
@@ -896,8 +908,8 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
             nmapread[destLocus] += (uint32_t)n;
             nAsgn += (uint64_t)n;
             kmc[destLocus] += (uint64_t)(int64_t)((r1.ei - r1.si) + (r2.ei - r2.si));
-            if (!rm1) for (int i = 0; i < r1.nas; ++i) if (r1.as[i] == 2) ++counts[r1.its[i]];
-            if (!rm2) for (int i = 0; i < r2.nas; ++i) if (r2.as[i] == 2) ++counts[r2.its[i]];
+            if (!rm1) for (int i = 0; i < r1.nas; ++i) if (r1.as[i] == 2) { ++counts[r1.its[i]]; ++ninc; }
+            if (!rm2) for (int i = 0; i < r2.nas; ++i) if (r2.as[i] == 2) { ++counts[r2.its[i]]; ++ninc; }
             stage = DBTK_STAGE_COUNTED;
         }
     emit:
@@ -925,6 +937,11 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
     C[DBTK_C_NHASH0] += nhash0;
     C[DBTK_C_NHASH1] += nhash1;
     C[DBTK_C_ALGO_PROBES] += nprobe;
+    C[DBTK_C_ALGO_VV] += nvvw;
+    C[DBTK_C_ALGO_CLS] += ncls;
+    C[DBTK_C_ALGO_INC] += ninc;
+    C[DBTK_C_SURVIVORS] += nsurv;
+    C[DBTK_C_BASES] += nbases;
     free(H.hits1); free(H.hits2); free(H.touched);
     free(caks1); free(caks2); free(caes1); free(caes2); free(its1); free(its2);
     return 0;
