@@ -61,6 +61,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     pkg = importlib.import_module("danbing-tk_amd")
+    par = importlib.import_module("danbing-tk_amd.parallel")
     abi = pkg.abi
     dbtk = pkg.Dbtk()  # raises if the HIP extension is missing: no CPU fallback
     log = (lambda *a: print("[bench]", *a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
@@ -107,7 +108,7 @@ def main():
             return
         ctx.synchronize()
         assert hip.hipMemcpy(acc_t.data_ptr(), acc_ptr, acc_n * 8, 3) == 0
-        dist.all_reduce(acc_t)  # RCCL sum; int64 adds wrap exactly like the reference's uint64 atomics
+        par.allreduce_accum(acc_t)  # RCCL sum; int64 adds wrap exactly like the reference's uint64 atomics
         assert hip.hipMemcpy(acc_ptr, acc_t.data_ptr(), acc_n * 8, 3) == 0
 
     for _ in range(args.warmup):
