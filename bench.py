@@ -134,18 +134,21 @@ def main():
     value = total_reads / dt
 
     # ---- roofline of the dominant kernel (this rank): algorithmic bytes of SURVEY.md 8(d) per launch
-    ctr = local["counters"].astype(np.float64) / max(args.steps, 1)  # per step == per launch
+    ctr = local["counters"].astype(np.float64)  # totals over the timed steps
     alg = {
         # every read byte once + 12 B per subfilter probe
         "k_encode_subfilter": ctr[abi.C_BASES] + 12.0 * (ctr[abi.C_ALGO_PROBES] - ctr[abi.C_NHASH1]),
-        # 12 B per kfilter probe + 4 B per vv word + 8 B per classified k-mer + 16 B per count increment
-        "k_pair": 12.0 * ctr[abi.C_NHASH1] + 4.0 * ctr[abi.C_ALGO_VV] + 8.0 * ctr[abi.C_ALGO_CLS] + 16.0 * ctr[abi.C_ALGO_INC],
+        # the probe kernel: 12 B (8 B key + 4 B value) per kfilter look-up the reference performs
+        "k_probe": 12.0 * ctr[abi.C_NHASH1],
+        # resolve: 4 B per vv word + 8 B per classified k-mer + 16 B per count increment
+        "k_pair": 4.0 * ctr[abi.C_ALGO_VV] + 8.0 * ctr[abi.C_ALGO_CLS] + 16.0 * ctr[abi.C_ALGO_INC],
     }
     per_kernel = {}
-    for name, (ms, n) in ktimes.items():
+    for name, (ms, n) in ktimes.items():  # large steps run as several sub-batch launches: price per launch
         avg = ms / max(n, 1)
-        per_kernel[name] = dict(avg_ms=avg, launches=n, algorithmic_bytes=alg.get(name, 0.0),
-                                gbs=(alg.get(name, 0.0) / (avg * 1e-3) / 1e9) if avg > 0 else 0.0)
+        per_launch = alg.get(name, 0.0) / max(n, 1)
+        per_kernel[name] = dict(avg_ms=avg, launches=n, algorithmic_bytes=per_launch,
+                                gbs=(per_launch / (avg * 1e-3) / 1e9) if avg > 0 else 0.0)
     dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"] * per_kernel[k]["launches"])
     roof = dict(bound="hbm", kernel=dom, achieved=per_kernel[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=per_kernel[dom]["gbs"] / HBM_PEAK_GBS, traffic=None,

@@ -1,0 +1,126 @@
+// dbtk_assign.h — assignTRkmc's state machine on 256-bit masks.
+//
+// The reference scans the per-position states as[i] in {0 unknown, 1 flank,
+// 2 TR} once, left to right (src/aQueryFasta_thread.cpp:1477-1555).  On the GPU
+// the states of a mate arrive as wave ballots: K = positions with a known state
+// (as != 0), R = positions in state TR (as == 2), 64 positions per word.  The
+// scan's result is a function of a handful of features of those masks — the
+// first known state, the first two state transitions among known positions, and
+// the unknown tract that ends exactly at each transition — which are extracted
+// here with log-step fill-forward and bit scans by ONE lane in a few hundred
+// operations instead of a 130-step dependent loop.  assign_scan (the literal
+// restatement, dbtk_kernels.h) stays as the reference form; tests/emu checks the
+// two against each other on random and exhaustive inputs.
+#ifndef DBTK_ASSIGN_H_
+#define DBTK_ASSIGN_H_
+
+#include "dbtk_tables.h"
+
+namespace dbtk {
+
+struct MateState {  // km_asgn_read_t fields the state machine writes, AQ.cpp:93-108
+    int si, ei, nt, bs, ti, si_, ei_, af, rm;
+};
+
+struct Bits256 {
+    uint64_t w[4];
+};
+
+DBTK_HD Bits256 b_shl(const Bits256& a, int d) {  // bit i -> bit i + d
+    Bits256 r;
+    const int ws = d >> 6, bs = d & 63;
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        uint64_t v = 0;
+        if (i - ws >= 0) {
+            v = a.w[i - ws] << bs;
+            if (bs && i - ws - 1 >= 0) v |= a.w[i - ws - 1] >> (64 - bs);
+        }
+        r.w[i] = v;
+    }
+    return r;
+}
+DBTK_HD int b_popc(const Bits256& a) {
+    return __builtin_popcountll(a.w[0]) + __builtin_popcountll(a.w[1]) + __builtin_popcountll(a.w[2]) + __builtin_popcountll(a.w[3]);
+}
+DBTK_HD bool b_test(const Bits256& a, int i) { return (a.w[i >> 6] >> (i & 63)) & 1; }
+DBTK_HD int b_first(const Bits256& a) {  // lowest set bit, 256 if none
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (a.w[i]) return 64 * i + __builtin_ctzll(a.w[i]);
+    return 256;
+}
+DBTK_HD int b_last_below(const Bits256& a, int n) {  // highest set bit < n, -1 if none
+    for (int i = 3; i >= 0; --i) {
+        uint64_t v = a.w[i];
+        const int lo = 64 * i;
+        if (n <= lo) continue;
+        if (n < lo + 64) v &= (1ull << (n - lo)) - 1;
+        if (v) return lo + 63 - __builtin_clzll(v);
+    }
+    return -1;
+}
+DBTK_HD Bits256 b_clear_lowest(const Bits256& a) {
+    Bits256 r = a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (r.w[i]) { r.w[i] &= r.w[i] - 1; return r; }
+    return r;
+}
+
+// K, R: masks over positions [0, nk); R subset of K.  ntr: number of TR states
+// reduced to uint8_t (AQ.cpp:1454).  r.rm on entry = the mate is already removed.
+DBTK_HD void assign_bits(Bits256 K, Bits256 R, int nk, uint32_t ntr, const dbtk_params_t& P, MateState& r) {
+    if (r.rm) { r.nt = -1; r.bs = -1; r.ti = -1; return; }
+    // fill-forward: Fv[i] = TR bit of the last known position <= i, Fm[i] = such a position exists
+    Bits256 Fv = R, Fm = K;
+#pragma unroll
+    for (int d = 1; d < 256; d <<= 1) {
+        const Bits256 sv = b_shl(Fv, d), sm = b_shl(Fm, d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { Fv.w[i] |= sv.w[i] & ~Fm.w[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { Fm.w[i] |= sm.w[i]; }
+    }
+    const Bits256 pv = b_shl(Fv, 1), pm = b_shl(Fm, 1);
+    Bits256 T;  // transitions: known position whose state differs from the last known state before it
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T.w[i] = K.w[i] & pm.w[i] & (R.w[i] ^ pv.w[i]);
+    const int ntot = b_popc(T);
+    const int i0 = b_first(K);
+    r.bs = (i0 < 256) ? (b_test(R, i0) ? 2 : 1) : 0;
+    const int ti1 = b_first(T);
+    const Bits256 T2 = b_clear_lowest(T);
+    const int ti2 = b_first(T2);
+    const int maxnt = (int)P.max_nt;
+    // the scan's early returns, in the order it meets them
+    if (ntot >= 1 && maxnt >= 1) r.ti = ti1;  // ti1 is recorded after the nt > MAX_NT test of that step
+    if (ntot >= 2 && maxnt >= 2 && r.bs == 2) { r.nt = 2; r.af = 1; r.rm = 1; return; }  // TR-flank-TR
+    if (ntot > maxnt) { r.nt = maxnt + 1; r.af = 1; r.rm = 1; return; }
+    r.nt = ntot;
+    // unknown tract that ends exactly at a transition: [last known before + 1, transition)
+    int si1 = -1, ei1 = -1, si2 = -1, ei2 = -1;
+    if (ntot >= 1 && ti1 > 0 && !b_test(K, ti1 - 1)) { si1 = b_last_below(K, ti1) + 1; ei1 = ti1; }
+    if (ntot >= 2 && ti2 > 0 && !b_test(K, ti2 - 1)) { si2 = b_last_below(K, ti2) + 1; ei2 = ti2; }
+    if (ntot == 0) {
+        if (r.bs != 2) { r.af = 1; r.rm = 1; return; }
+        r.si = 0; r.ei = nk; r.si_ = 0; r.ei_ = nk;
+    } else if (ntot == 1) {
+        if (r.bs == 1) {
+            r.si = si1 >= 0 ? (si1 + ei1) / 2 : ti1; r.ei = nk;
+            r.si_ = si1 >= 0 ? ei1 : ti1; r.ei_ = nk;
+        } else {
+            r.si = 0; r.ei = si1 >= 0 ? (si1 + ei1) / 2 : ti1;
+            r.si_ = 0; r.ei_ = si1 >= 0 ? si1 : ti1;
+        }
+    } else {
+        if (ntr < P.nm_tr) { r.af = 1; r.rm = 1; return; }
+        r.si = (si1 >= 0 ? (si1 + ei1) / 2 : ti1);
+        r.ei = (si2 >= 0 ? (si2 + ei2) / 2 : ti2);
+        r.si_ = ei1 >= 0 ? ei1 : ti1;
+        r.ei_ = si2 >= 0 ? si2 : ti2;
+    }
+}
+
+}  // namespace dbtk
+#endif

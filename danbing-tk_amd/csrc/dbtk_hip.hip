@@ -29,9 +29,12 @@ struct DevX {
     __device__ int lane() const { return (int)(threadIdx.x & 63); }
     __device__ void sync() const { __syncthreads(); }
     __device__ uint64_t ballot(bool p) const { return __ballot(p); }
+    // wave-uniform results are returned through readfirstlane/readlane so that the compiler keeps
+    // them (and every loop bound, length and flag derived from them) in SGPRs with scalar branches
+    __device__ uint32_t uni(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ uint32_t wave_sum(uint32_t v) const {
         for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     }
     __device__ uint32_t wave_excl_scan(uint32_t v) const {
         uint32_t inc = v;
@@ -42,7 +45,17 @@ struct DevX {
         }
         return inc - v;
     }
-    __device__ uint32_t bcast(uint32_t v, int src) const { return __shfl(v, src, 64); }
+    template <int E> __device__ void shfl_xor64(const uint64_t (&in)[E], uint64_t (&out)[E], int mask) const {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)in[j], mask, 64);
+            const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(in[j] >> 32), mask, 64);
+            out[j] = ((uint64_t)hi << 32) | lo;
+        }
+    }
+    __device__ uint32_t bcast(uint32_t v, int src) const {  // src must be wave-uniform
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
+    }
     __device__ void atomic_add(uint64_t* p, uint64_t v) const { atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
     __device__ uint32_t atomic_add(uint32_t* p, uint32_t v) const { return atomicAdd(p, v); }
     __device__ uint64_t atomic_cas(uint64_t* p, uint64_t e, uint64_t d) const {
@@ -50,6 +63,7 @@ struct DevX {
     }
     __device__ void atomic_max(uint64_t* p, uint64_t v) const { atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
     __device__ void atomic_or(uint64_t* p, uint64_t v) const { atomicOr(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
+    __device__ uint64_t clock() const { return (uint64_t)clock64(); }
     __device__ uint32_t lds_add(uint32_t* p, uint32_t v) const { return atomicAdd(p, v); }
     __device__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
     template <class T> __device__ T* smem() const { return reinterpret_cast<T*>(sm); }
@@ -65,11 +79,17 @@ __global__ void __launch_bounds__(256) k_fill_idx(IdxSlot* s, uint64_t cap) {
 __global__ void __launch_bounds__(256) k_idx_insert(IdxBuildArgs a) { DevX x{nullptr}; body_idx_insert(x, a); }
 __global__ void __launch_bounds__(256) k_idx_finalize(IdxSlot* s, uint64_t cap) { DevX x{nullptr}; body_idx_finalize(x, s, cap); }
 __global__ void __launch_bounds__(256) k_cls_insert(ClsBuildArgs a) { DevX x{nullptr}; body_cls_insert(x, a); }
+__global__ void __launch_bounds__(256) k_idx_aux(IdxAuxArgs a) { DevX x{nullptr}; body_idx_aux(x, a); }
 
 __global__ void __launch_bounds__(K1_NT) k_encode_subfilter(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) K1Smem sm;
     DevX x{&sm};
     body_encode_subfilter(x, a);
+}
+__global__ void __launch_bounds__(64) k_probe(BatchArgs a) {
+    __shared__ __attribute__((aligned(16))) ProbeSmem sm;
+    DevX x{&sm};
+    body_probe(x, a);
 }
 __global__ void __launch_bounds__(64) k_pair(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) PairSmem sm;
@@ -91,7 +111,7 @@ namespace {
 // Per-kernel timing: a pool of HIP event pairs recorded on the context's stream
 // around every launch; folded into (total ms, launches) when the pool fills or
 // when the caller asks.
-constexpr int NKERN = 2;       // k_encode_subfilter, k_pair
+constexpr int NKERN = 3;       // k_encode_subfilter, k_probe, k_pair
 constexpr int EVPOOL = 128;    // launches in flight before a fold
 struct Timed {
     const char* name;
@@ -121,9 +141,11 @@ struct dbtk_ctx {
     uint8_t* d_seq = nullptr; uint64_t seq_cap = 0;
     uint64_t* d_off = nullptr; uint64_t off_cap = 0;
     dbtk_pair_rec_t* d_recs = nullptr; uint64_t rec_cap = 0;
+    HitEnt* d_hit = nullptr; uint64_t hit_cap = 0;
     uint64_t* d_vote = nullptr;
     uint32_t* d_epoch = nullptr;
     int pair_blocks = 0, num_cu = 0;
+    uint32_t consistent = 0;
     Timed timed[NKERN];
 };
 
@@ -145,7 +167,7 @@ void free_ctx(dbtk_ctx* c) {
             if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
         }
     void* ptrs[] = {c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
-                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch};
+                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hit};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -181,6 +203,9 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     const uint64_t ccap = pow2_at_least(2 * (ntrf + nfl) + 2);
     HIPCHK(hipMalloc(&c->d_cls, ccap * sizeof(ClsSlot)));
     HIPCHK(hipMemsetAsync(c->d_cls, 0xFF, ccap * sizeof(ClsSlot), s));
+    uint64_t* dstats = nullptr;  // [0] index memberships, [1] of them missing from the class table, [2] class entries
+    HIPCHK(hipMalloc(&dstats, 3 * 8));
+    HIPCHK(hipMemsetAsync(dstats, 0, 3 * 8, s));
     {
         std::vector<uint64_t> beg(nloci + 1, 0);
         uint64_t *dks = nullptr, *dbeg = nullptr, *dslot = nullptr;
@@ -193,7 +218,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
             HIPCHK(hipMemcpyAsync(dks, g->tr_ks.data(), ntrf * 8, hipMemcpyHostToDevice, s));
             HIPCHK(hipMemcpyAsync(dslot, g->out_slot.data(), ntrf * 8, hipMemcpyHostToDevice, s));
             HIPCHK(hipMemcpyAsync(dbeg, beg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
-            ClsBuildArgs a{c->d_cls, ccap - 1, 64 - log2u(ccap), dks, dbeg, (uint32_t)nloci, dslot, ntrf};
+            ClsBuildArgs a{c->d_cls, ccap - 1, 64 - log2u(ccap), dks, dbeg, (uint32_t)nloci, dslot, ntrf, dstats + 2};
             hipLaunchKernelGGL(k_cls_insert, dim3(2048), dim3(256), 0, s, a);
             HIPCHK(hipStreamSynchronize(s));
         }
@@ -201,7 +226,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         if (nfl) {
             HIPCHK(hipMemcpyAsync(dks, g->fl_ks.data(), nfl * 8, hipMemcpyHostToDevice, s));
             HIPCHK(hipMemcpyAsync(dbeg, beg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
-            ClsBuildArgs a{c->d_cls, ccap - 1, 64 - log2u(ccap), dks, dbeg, (uint32_t)nloci, nullptr, nfl};
+            ClsBuildArgs a{c->d_cls, ccap - 1, 64 - log2u(ccap), dks, dbeg, (uint32_t)nloci, nullptr, nfl, dstats + 2};
             hipLaunchKernelGGL(k_cls_insert, dim3(2048), dim3(256), 0, s, a);
             HIPCHK(hipStreamSynchronize(s));
         }
@@ -232,6 +257,17 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     T.permtab = c->d_perm;
     T.nloci = (uint32_t)nloci;
     T.ksize = g->ksize;
+    T.consistent = 0;
+    {   // class of single-locus k-mers into the index slots + index-vs-sets consistency verdict
+        IdxAuxArgs a{c->d_idx, icap, T, dstats};
+        hipLaunchKernelGGL(k_idx_aux, dim3(2048), dim3(256), 0, s, a);
+        uint64_t st[3] = {0, 0, 0};
+        HIPCHK(hipMemcpyAsync(st, dstats, sizeof(st), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipFree(dstats));
+        T.consistent = (st[1] == 0 && st[0] == st[2]) ? 1u : 0u;
+        c->consistent = T.consistent;
+    }
     return DBTK_OK;
 }
 
@@ -264,37 +300,55 @@ dbtk_status_t timed_slot(dbtk_ctx* c, int k, int* slot) {
     return DBTK_OK;
 }
 
-// K1 + pair kernel over reads already in HBM.
+// K1 -> K2 -> K3 over reads already in HBM.  Large batches are cut into sub-batches so that the
+// K2 -> K3 hit buffer stays bounded; batch boundaries never change results (all effects are additive).
+constexpr uint64_t SUB_PAIRS = 1ull << 21;
+
 dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_off, uint64_t seq_len, uint64_t npairs,
-                           dbtk_pair_rec_t* d_recs, uint32_t rec_cap) {
+                           uint32_t max_read_len, dbtk_pair_rec_t* d_recs, uint32_t rec_cap) {
     hipStream_t s = c->stream;
     if (npairs >= 0xFFFFFFFFull) { set_error("batch too large (pair index is 32-bit)"); return DBTK_ERR_ARG; }
-    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, npairs + 1);
+    const uint64_t sub = npairs < SUB_PAIRS ? npairs : SUB_PAIRS;
+    const uint32_t k = c->g->ksize;
+    const uint32_t nkmax = max_read_len >= k ? max_read_len - k + 1 : 1;
+    const uint32_t nkp = 64 * ((nkmax + 63) / 64);
+    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, sub + 1);
     if (st) return st;
-    HIPCHK(hipMemsetAsync(c->d_small, 0, 4 * sizeof(uint32_t), s));
-    BatchArgs a;
-    memset(&a, 0, sizeof(a));
-    a.T = c->T; a.P = c->P;
-    a.seq = d_seq; a.off = d_off; a.seq_len = seq_len; a.npairs = npairs;
-    a.surv = c->d_surv; a.nsurv = c->d_small + 0; a.ticket = c->d_small + 1; a.nrec = c->d_small + 2; a.errflag = c->d_small + 3;
-    a.counts = c->d_accum;
-    a.kmc = c->d_accum + c->ntr;
-    a.nmapread = a.kmc + c->g->nloci;
-    a.counters = a.nmapread + c->g->nloci;
-    a.recs = d_recs; a.rec_cap = rec_cap;
-    a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
-    if (npairs == 0) return DBTK_OK;
-    const uint64_t ntiles = (npairs + K1_TP - 1) / K1_TP;
-    const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->num_cu * 8 ? ntiles : (uint64_t)c->num_cu * 8);
-    int e1 = 0, e2 = 0;
-    if ((st = timed_slot(c, 0, &e1)) || (st = timed_slot(c, 1, &e2))) return st;
-    HIPCHK(hipEventRecord(c->timed[0].beg[e1], s));
-    hipLaunchKernelGGL(k_encode_subfilter, dim3(g1), dim3(K1_NT), 0, s, a);
-    HIPCHK(hipEventRecord(c->timed[0].end[e1], s));
-    HIPCHK(hipEventRecord(c->timed[1].beg[e2], s));
-    hipLaunchKernelGGL(k_pair, dim3(c->pair_blocks), dim3(64), 0, s, a);
-    HIPCHK(hipEventRecord(c->timed[1].end[e2], s));
-    HIPCHK(hipGetLastError());
+    if ((st = ensure(&c->d_hit, &c->hit_cap, sub * 2 * nkp))) return st;
+    HIPCHK(hipMemsetAsync(c->d_small + 2, 0, 2 * sizeof(uint32_t), s));  // nrec, errflag: once per batch
+    for (uint64_t p0 = 0; p0 < npairs; p0 += sub) {
+        const uint64_t np = npairs - p0 < sub ? npairs - p0 : sub;
+        HIPCHK(hipMemsetAsync(c->d_small, 0, 2 * sizeof(uint32_t), s));  // nsurv, ticket
+        BatchArgs a;
+        memset(&a, 0, sizeof(a));
+        a.T = c->T; a.P = c->P;
+        a.seq = d_seq; a.off = d_off + 2 * p0; a.seq_len = seq_len; a.npairs = np;
+        a.surv = c->d_surv; a.nsurv = c->d_small + 0; a.ticket = c->d_small + 1; a.nrec = c->d_small + 2; a.errflag = c->d_small + 3;
+        a.counts = c->d_accum;
+        a.kmc = c->d_accum + c->ntr;
+        a.nmapread = a.kmc + c->g->nloci;
+        a.counters = a.nmapread + c->g->nloci;
+        a.recs = d_recs; a.rec_cap = rec_cap;
+        a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
+        a.hitbuf = c->d_hit; a.nkp = nkp; a.pair_base = (uint32_t)p0;
+#ifdef DBTK_STAMPS
+        a.dbg = reinterpret_cast<uint64_t*>(c->d_small + 8);  // 16 u64 after the four counters
+#endif
+        const uint64_t ntiles = (np + K1_TP - 1) / K1_TP;
+        const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->num_cu * 8 ? ntiles : (uint64_t)c->num_cu * 8);
+        int e[NKERN];
+        for (int i = 0; i < NKERN; ++i) if ((st = timed_slot(c, i, &e[i]))) return st;
+        HIPCHK(hipEventRecord(c->timed[0].beg[e[0]], s));
+        hipLaunchKernelGGL(k_encode_subfilter, dim3(g1), dim3(K1_NT), 0, s, a);
+        HIPCHK(hipEventRecord(c->timed[0].end[e[0]], s));
+        HIPCHK(hipEventRecord(c->timed[1].beg[e[1]], s));
+        hipLaunchKernelGGL(k_probe, dim3(c->num_cu * 32), dim3(64), 0, s, a);
+        HIPCHK(hipEventRecord(c->timed[1].end[e[1]], s));
+        HIPCHK(hipEventRecord(c->timed[2].beg[e[2]], s));
+        hipLaunchKernelGGL(k_pair, dim3(c->pair_blocks), dim3(64), 0, s, a);
+        HIPCHK(hipEventRecord(c->timed[2].end[e[2]], s));
+        HIPCHK(hipGetLastError());
+    }
     return DBTK_OK;
 }
 
@@ -328,7 +382,8 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
     do {
         if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); st = DBTK_ERR_HIP; break; }
         c->timed[0].name = "k_encode_subfilter";
-        c->timed[1].name = "k_pair";
+        c->timed[1].name = "k_probe";
+        c->timed[2].name = "k_pair";
         for (int i = 0; i < NKERN && !st; ++i)
             for (int j = 0; j < EVPOOL && !st; ++j)
                 if (hipEventCreate(&c->timed[i].beg[j]) != hipSuccess || hipEventCreate(&c->timed[i].end[j]) != hipSuccess) { set_error("hipEventCreate failed"); st = DBTK_ERR_HIP; }
@@ -338,7 +393,8 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         c->n_accum = c->ntr + 2 * h->nloci + DBTK_C_COUNT;
         auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && !st) { set_error(std::string(what) + ": " + hipGetErrorString(e)); st = DBTK_ERR_HIP; } };
         chk(hipMalloc(&c->d_accum, c->n_accum * 8), "hipMalloc accum");
-        chk(hipMalloc(&c->d_small, 64), "hipMalloc small");
+        chk(hipMalloc(&c->d_small, 256), "hipMalloc small");
+        if (!st) chk(hipMemsetAsync(c->d_small, 0, 256, c->stream), "memset");
         chk(hipMalloc(&c->d_vote, (size_t)c->pair_blocks * (h->nloci + 1) * 8), "hipMalloc vote scratch");
         chk(hipMalloc(&c->d_epoch, (size_t)c->pair_blocks * 4), "hipMalloc epoch");
         if (st) break;
@@ -389,7 +445,9 @@ dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t
         if (c->P.trace && rec_cap < npairs) { set_error("trace mode needs rec_cap >= npairs"); return DBTK_ERR_ARG; }
         if ((st = ensure(&c->d_recs, &c->rec_cap, dcap))) return st;
     }
-    if ((st = launch_batch(c, c->d_seq, c->d_off, nbytes, npairs, want_recs ? c->d_recs : nullptr, (uint32_t)dcap))) return st;
+    uint32_t maxlen = 0;
+    for (uint64_t r = 0; r < nreads; ++r) maxlen = std::max<uint32_t>(maxlen, (uint32_t)(off[r + 1] - off[r]));
+    if ((st = launch_batch(c, c->d_seq, c->d_off, nbytes, npairs, maxlen, want_recs ? c->d_recs : nullptr, (uint32_t)dcap))) return st;
     uint32_t small[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(small, c->d_small, sizeof(small), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -416,7 +474,7 @@ dbtk_status_t dbtk_align_batch_device(dbtk_ctx_t* c, const void* d_seq, const vo
     HIPCHK(hipSetDevice(c->device));
     // d_seq is 16-byte aligned and device allocations are page-granular, so the aligned 16-byte
     // chunk holding the last base is always readable: no byte-wise tail needed (seq_len = max).
-    return launch_batch(c, (const uint8_t*)d_seq, (const uint64_t*)d_offsets, ~0ull, npairs, nullptr, 0);
+    return launch_batch(c, (const uint8_t*)d_seq, (const uint64_t*)d_offsets, ~0ull, npairs, max_read_len, nullptr, 0);
 }
 
 dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* c) {
@@ -474,6 +532,15 @@ int dbtk_ctx_kernel_times(dbtk_ctx_t* c, const char** names, double* total_ms, u
     }
     return n;
 }
+
+#ifdef DBTK_STAMPS
+// diagnostic build only: the 16 per-phase cycle sums of k_pair since context creation
+int dbtk_debug_stamps(dbtk_ctx_t* c, uint64_t* out16) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    return (int)hipMemcpy(out16, c->d_small + 8, 16 * 8, hipMemcpyDeviceToHost);
+}
+#endif
 
 void dbtk_ctx_timers_reset(dbtk_ctx_t* c) {
     if (!c) return;

@@ -8,7 +8,8 @@
 // part of, linked into, or reachable from libdbtk_hip.so.
 //
 // X provides: tid() nthreads() bid() nblocks() lane() sync() ballot(bool)
-//   wave_sum(u32) wave_excl_scan(u32) bcast(u32, srclane)
+//   wave_sum(u32) wave_excl_scan(u32) bcast(u32, srclane) shfl_xor64<E>(in[E], out[E], lanemask)
+//   uni(u32: value known to be wave-uniform)
 //   atomic_add(u64*,u64) atomic_add(u32*,u32)->old atomic_cas(u64*,exp,des)->old
 //   atomic_max(u64*,u64) atomic_or(u64*,u64) lds_add(u32*,u32)->old lds_or(u32*,u32)
 //   smem<T>()
@@ -21,6 +22,7 @@
 #ifndef DBTK_KERNELS_H_
 #define DBTK_KERNELS_H_
 
+#include "dbtk_assign.h"
 #include "dbtk_sort.h"
 #include "dbtk_tables.h"
 
@@ -57,6 +59,42 @@ DBTK_HD void body_idx_finalize(X& x, IdxSlot* slots, uint64_t cap) {
         slots[i].val &= 0xFFFFFFFFull;
 }
 
+// After both tables exist: (1) check that the index and the per-locus flank/TR
+// sets describe the same (k-mer, locus) memberships — `ktools serialize` builds
+// the index from exactly those sets (src/kmertools.cpp:232-258), but the four
+// files are loaded independently, so this is verified, not assumed; (2) store the
+// class of every single-locus k-mer next to its val.  stats[0] += memberships in
+// the index, stats[1] += memberships missing from the class table.
+struct IdxAuxArgs {
+    IdxSlot* slots;
+    uint64_t cap;
+    DevTables T;  // cls, vv valid
+    uint64_t* stats;
+};
+template <class X>
+DBTK_HD void body_idx_aux(X& x, const IdxAuxArgs& a) {
+    uint64_t nmemb = 0, nmiss = 0;
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.cap; i += (uint64_t)x.nblocks() * x.nthreads()) {
+        const uint64_t key = a.slots[i].key;
+        if (key == NAN64) continue;
+        const uint32_t v = (uint32_t)a.slots[i].val;
+        if (v & 1) {
+            const uint32_t n = a.T.vv[v >> 1];
+            for (uint32_t j = 0; j < n; ++j) {
+                ++nmemb;
+                if (cls_lookup(a.T, key, a.T.vv[(v >> 1) + 1 + j]) == CLS_NONE) ++nmiss;
+            }
+        } else {
+            ++nmemb;
+            const uint32_t c = cls_lookup(a.T, key, v >> 1);
+            if (c == CLS_NONE) ++nmiss;
+            a.slots[i].val = (uint64_t)v | ((uint64_t)c << 32);
+        }
+    }
+    if (nmemb) x.atomic_add(&a.stats[0], nmemb);
+    if (nmiss) x.atomic_add(&a.stats[1], nmiss);
+}
+
 struct ClsBuildArgs {
     ClsSlot* slots;
     uint64_t mask;
@@ -66,6 +104,7 @@ struct ClsBuildArgs {
     uint32_t nloci;
     const uint64_t* outslot;  // TR pass: slot in OUT.trkmc.ar order; nullptr = flank pass
     uint64_t n;
+    uint64_t* nentries;       // += number of distinct (k-mer, locus) entries created
 };
 
 template <class X>
@@ -85,7 +124,7 @@ DBTK_HD void body_cls_insert(X& x, const ClsBuildArgs& a) {
             const uint64_t prev = x.atomic_cas(&a.slots[s].kmer, NAN64, kmer);
             if (prev == NAN64 || prev == kmer) {
                 const uint64_t plc = x.atomic_cas(&a.slots[s].lc, ~0ull, lc);
-                if (plc == ~0ull) break;               // slot is ours
+                if (plc == ~0ull) { x.atomic_add(a.nentries, 1ull); break; }  // slot is ours
                 if ((uint32_t)(plc >> 32) == locus) {  // same (k-mer, locus): flank overrides TR
                     if (cls == CLS_FLANK) x.atomic_or(&a.slots[s].lc, 0xFFFFFFFFull);
                     break;
@@ -117,7 +156,23 @@ struct BatchArgs {
     uint32_t* errflag;
     uint64_t* vote_scratch;  // per block: nloci+1 stamped hit words (see vote)
     uint32_t* vote_epoch;    // per block
+    uint64_t* dbg;           // diagnostic build only (-DDBTK_STAMPS): per-phase cycle sums of k_pair
+    struct HitEnt* hitbuf;   // K2 -> K3: [survivor][mate][nkp] probe results
+    uint32_t nkp;            // positions reserved per read in hitbuf (multiple of 64)
+    uint32_t pair_base;      // index of this sub-batch's first pair inside the caller's batch (records)
 };
+
+// In-kernel stamps (cdna_hip_programming.md 7): only in the separate diagnostic
+// library built with -DDBTK_STAMPS; the product build compiles them away.
+#ifdef DBTK_STAMPS
+#define DBTK_STAMP_DECL uint64_t st_acc[16] = {0}; uint64_t st_last = x.clock();
+#define DBTK_STAMP(i) do { const uint64_t now_ = x.clock(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
+#define DBTK_STAMP_FLUSH do { if (lane == 0 && a.dbg) for (int i_ = 0; i_ < 16; ++i_) if (st_acc[i_]) x.atomic_add(&a.dbg[i_], st_acc[i_]); } while (0)
+#else
+#define DBTK_STAMP_DECL
+#define DBTK_STAMP(i) do { } while (0)
+#define DBTK_STAMP_FLUSH do { } while (0)
+#endif
 
 // ----------------------------------------------------------------- records --
 DBTK_HD void mate_rec_init(dbtk_mate_rec_t* m) {
@@ -282,7 +337,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                 a.surv[at] = pair;
                 x.lds_add(&sm.cnt[4], 1);
             } else if (a.P.trace && a.recs) {
-                write_early_rec(&a.recs[pair], pair, stage, a.T.nloci);
+                write_early_rec(&a.recs[pair + a.pair_base], pair + a.pair_base, stage, a.T.nloci);
             }
         }
         x.sync();
@@ -301,11 +356,9 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
 // One wavefront (64-thread block) per surviving pair.
 constexpr int LCAP = 512;        // per-pair locus map in LDS (vote); spills to vote_scratch
 constexpr int LLIMIT = 384;
+constexpr int NSLOT = NKMAX / 64;  // k-mer positions per lane per mate
 struct PairSmem {
-    uint32_t pk[2][20];
-    uint16_t vd[2][20];
-    uint64_t kmer[2][NKMAX];   // canonical k-mers by read position (caks1 / caks2)
-    uint32_t hval[2][NKMAX];   // index val by position; later the class/slot of the position
+    uint32_t hval[2][NKMAX];   // index val by read position (NOHIT = not in the index)
     union {
         struct { uint64_t skey[NHMAX]; uint16_t sinfo[NHMAX]; } s;                     // hit list being sorted
         struct { uint32_t nml[NHMAX]; uint32_t lkey[LCAP]; uint16_t ord[NHMAX]; } v;    // vote phase
@@ -313,20 +366,14 @@ struct PairSmem {
     uint32_t uval[NHMAX];      // unique k-mers in ascending key order: index val
     uint32_t dd[NHMAX];        // PE_KMC dup: count in mate 0 | count in mate 1 << 16
     uint32_t lhit[LCAP];
-    uint8_t as[2][NKMAX];
     int stack[3 * 40];
-    // scalars
-    uint32_t len[2], nk[2];
-    int32_t res[16];           // vote result: tri, tri0, fc, rc ...
+    int32_t res[8];            // vote result
     int32_t mres[2][12];       // per-mate assign results
 };
 
-struct MateState {  // km_asgn_read_t fields the state machine writes, AQ.cpp:93-108
-    int si, ei, nt, bs, ti, si_, ei_, af, rm;
-};
-
-// assignTRkmc's scan (src/aQueryFasta_thread.cpp:1470-1555) over the states
-// as[0..nk); ntr = number of TR states, already reduced to uint8_t.
+// assignTRkmc's scan, literally (src/aQueryFasta_thread.cpp:1470-1555), over the
+// states as[0..nk); ntr = number of TR states, already reduced to uint8_t.  The
+// kernels use assign_bits (dbtk_assign.h); this form is what it is checked against.
 DBTK_HD void assign_scan(const uint8_t* as, int nk, uint32_t ntr, const dbtk_params_t& P, MateState& r) {
     int s = 0, s_ = 0, s__ = 0;
     int ti2 = -1, si1 = -1, ei1 = -1, si2 = -1, ei2 = -1;
@@ -415,9 +462,12 @@ DBTK_HD void updatetop2(uint64_t cf, uint32_t ind, uint64_t cr, Asgn& top, Asgn&
         second.fc = cf; second.rc = cr;
     }
 }
+DBTK_HD bool get_acm1(uint64_t fc, uint64_t rc, uint64_t rem, uint64_t cth) {  // AQ.cpp:354-357
+    return (fc < cth && cth - fc <= rem) || (rc < cth && cth - rc <= rem);
+}
 
-// find_matching_locus + the accept test of countHit
-// (src/aQueryFasta_thread.cpp:364-422, 436-451) on the permuted unique list.
+// find_matching_locus (src/aQueryFasta_thread.cpp:364-422) on the permuted
+// unique list, general form (any number of loci per k-mer); lane 0 only.
 DBTK_HD void vote(const DevTables& T, const uint16_t* ord, const uint32_t* uval, const uint32_t* dd, int nu, uint32_t cth,
                   HitMap& hm, Asgn& top, uint64_t& nvvw) {
     Asgn second{NAN32, 0, 0};
@@ -446,7 +496,7 @@ DBTK_HD void vote(const DevTables& T, const uint16_t* ord, const uint32_t* uval,
         if (!((top.fc + top.rc - second.fc - second.rc) < rem)) {  // !get_acm2
             int j = i;
             uint64_t remj = rem;
-            while ((top.fc < cth && cth - top.fc <= remj) || (top.rc < cth && cth - top.rc <= remj)) {  // get_acm1
+            while (get_acm1(top.fc, top.rc, remj, cth)) {
                 if (++j >= nu) break;
                 const uint32_t uj = ord[j], vj = uval[uj];
                 const uint32_t e1 = dd[uj] & 0xFF, e2 = (dd[uj] >> 16) & 0xFF;
@@ -467,6 +517,194 @@ DBTK_HD void vote(const DevTables& T, const uint16_t* ord, const uint32_t* uval,
     }
 }
 
+// The same vote when every unique k-mer maps to ONE and the same locus (all
+// `val` equal and even — the common case of a read pair from a non-shared
+// region).  Then `second` never gets a locus, top's sums are the prefix sums
+// S_i of the permuted dups, the early stop is the first i with 2*S_i >= total,
+// and the get_acm1 loop ends at the first j >= i whose prefix sums fail the
+// test: three wave scans instead of a serial loop.  Lane l owns permuted
+// entries [8l, 8l+8).  Returns fc | rc << 16 (same on every lane).
+template <class X>
+DBTK_HD uint32_t vote_single_locus(X& x, const uint16_t* perm_row, const uint32_t* dd, uint32_t nu, uint32_t cth) {
+    const uint32_t lane = (uint32_t)x.lane(), b0 = 8 * lane;
+    uint32_t pre[8], run = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t i = b0 + j;
+        if (i < nu) run += dd[perm_row[i]] & 0x00FF00FFu;  // uint8_t counts, AQ.cpp:42
+        pre[j] = run;
+    }
+    const uint32_t excl = x.wave_excl_scan(run);
+    const uint32_t tot2 = x.wave_sum(run);
+    const uint32_t total = (tot2 & 0xFFFF) + (tot2 >> 16);
+    uint32_t firstA = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        const uint32_t i = b0 + j, p = excl + pre[j], S = (p & 0xFFFF) + (p >> 16);
+        if (i < nu && 2 * S >= total) firstA = i;
+    }
+    const uint64_t mA = x.ballot(firstA != 0xFFFFFFFFu);
+    const uint32_t istar = x.bcast(firstA, mA ? (int)__builtin_ctzll(mA) : 0);
+    uint32_t firstB = 0xFFFFFFFFu, pB = 0;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        const uint32_t i = b0 + j, p = excl + pre[j], f = p & 0xFFFF, r = p >> 16;
+        if (i < nu && i >= istar && !get_acm1(f, r, total - f - r, cth)) { firstB = i; pB = p; }
+    }
+    const uint64_t mB = x.ballot(firstB != 0xFFFFFFFFu);
+    const uint32_t res = x.bcast(pB, mB ? (int)__builtin_ctzll(mB) : 0);
+    return mB ? res : tot2;  // loop ran off the end: every k-mer was added
+}
+
+// Bitonic sort of N = 64 * E composite keys held E per lane (element e = lane * E + j), ascending.
+// Strides below E are compare-exchanges inside a lane's registers; larger strides exchange with
+// lane ^ (stride / E) through the cross-lane network (ds_bpermute, no memory).  ~1.6 k VALU for
+// N = 512 against ~8 k for the O(n^2 / 64) rank sort it replaces.
+template <int E, class X>
+DBTK_HD void bitonic_sort(X& x, uint64_t (&v)[E]) {
+    const uint32_t lane = (uint32_t)x.lane();
+    constexpr int N = 64 * E;
+#pragma unroll
+    for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+        for (int d = size >> 1; d > 0; d >>= 1) {
+            if (d >= E) {
+                const uint32_t ld = (uint32_t)(d / E);
+                const bool lower = (lane & ld) == 0;
+                const bool asc = size >= N ? true : (((lane * E) & (uint32_t)size) == 0);
+                const bool keep_min = lower == asc;
+                uint64_t o[E];
+                x.template shfl_xor64<E>(v, o, (int)ld);  // partner lane's E keys
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const bool take = keep_min ? (o[j] < v[j]) : (o[j] > v[j]);
+                    v[j] = take ? o[j] : v[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    if ((j & d) == 0) {
+                        // ascending block iff bit `size` of the element index is clear
+                        const bool asc = size >= N ? true : (size >= E ? (((lane * E) & (uint32_t)size) == 0) : ((j & size) == 0));
+                        const uint64_t a0 = v[j], b0 = v[j | d];
+                        const bool sw = asc ? (b0 < a0) : (a0 < b0);
+                        v[j] = sw ? b0 : a0;
+                        v[j | d] = sw ? a0 : b0;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ======================================================================= K2 =
+// kfilter's probes (src/aQueryFasta_thread.cpp:204-209, 215-220) as a kernel of
+// their own: one wavefront per surviving READ, tiny footprint (0.5 KB LDS), so
+// that the chip's random-gather pipes stay full.  The read is fetched as aligned
+// dwords, packed to 2 bits/base in LDS, every lane extracts its <= 4 canonical
+// k-mer windows (read2kmers_edges, AQ.h:274-311), and linear probing runs in
+// wave-wide rounds with all of a lane's probes in flight.  Output: one 16-byte
+// HitEnt {k-mer, val, aux} per read position, coalesced, into the HBM hit buffer
+// that the resolve kernel (K3) consumes.  Every position is probed; what the
+// reference would NOT have probed (after kfilter's abort) is discounted from
+// nhash1 by K3.
+struct HitEnt {
+    uint64_t km;   // canonical k-mer at the position, NAN64 = window with a non-ACGT base
+    uint32_t val;  // index val, NOHIT when the k-mer is not in the index
+    uint32_t aux;  // class of a single-locus k-mer at its locus (see IdxSlot)
+};
+struct ProbeSmem {
+    uint32_t raw[72];
+    uint32_t pk[20];
+    uint16_t vd[20];
+};
+
+template <class X>
+DBTK_HD void body_probe(X& x, const BatchArgs& a) {
+    ProbeSmem& sm = *x.template smem<ProbeSmem>();
+    const int lane = x.lane();
+    const DevTables& T = a.T;
+    const uint32_t k = T.ksize;
+    const uint32_t nitems = 2 * *a.nsurv;
+    for (uint32_t it = x.bid(); it < nitems; it += x.nblocks()) {
+        const uint32_t t = it >> 1, m = it & 1;
+        const uint32_t pair = a.surv[t];
+        const uint64_t o0 = a.off[2 * (uint64_t)pair + m], o1 = a.off[2 * (uint64_t)pair + m + 1];
+        uint32_t len = (uint32_t)(o1 - o0);
+        if (len > (uint32_t)MAXL) { *a.errflag = DBTK_ERR_READ_TOO_LONG; len = MAXL; }  // stay inside LDS
+        const uint64_t a0 = o0 & ~3ull;
+        const uint32_t rsh = (uint32_t)(o0 - a0), nw = (rsh + len + 3) >> 2;
+        x.sync();  // previous read's LDS is dead
+        for (uint32_t w = lane; w < nw; w += 64) {
+            const uint64_t g = a0 + 4ull * w;
+            uint32_t v = 0;
+            if (g + 4 <= a.seq_len) v = *reinterpret_cast<const uint32_t*>(a.seq + g);
+            else for (int b = 0; b < 4; ++b) if (g + b < a.seq_len) v |= (uint32_t)a.seq[g + b] << (8 * b);
+            sm.raw[w] = v;
+        }
+        if (lane < 4) sm.raw[nw + lane] = 0;
+        x.sync();
+        if (lane < 16) {
+            const int c = lane;
+            const uint32_t B = rsh + 16 * c, j = B >> 2, r8 = 8 * (B & 3);
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t v = 0;
+                if (16u * c + 4 * q < len) {
+                    const uint32_t lo = sm.raw[j + q], hi = sm.raw[j + q + 1];
+                    v = r8 ? ((lo >> r8) | (hi << (32 - r8))) : lo;
+                    const uint32_t left = len - (16 * c + 4 * q);  // bytes of this word inside the read
+                    if (left < 4) v &= (1u << (8 * left)) - 1;
+                }
+                w[q] = v;
+            }
+            uint32_t vd;
+            sm.pk[c] = pack16(w, &vd);
+            sm.vd[c] = (uint16_t)vd;  // bytes past the read are 0 -> invalid
+            if (c < 4) { sm.pk[16 + c] = 0; sm.vd[16 + c] = 0; }
+        }
+        x.sync();
+        const uint32_t nk = len >= k ? len - k + 1 : 0;
+        const uint32_t nsl = (nk + 63) >> 6;
+        uint64_t km[NSLOT], hh[NSLOT];
+        uint32_t hv[NSLOT], ha[NSLOT];
+        bool open[NSLOT];
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const uint32_t i = 64 * s + lane;
+            km[s] = NAN64; hv[s] = NOHIT; ha[s] = 0; hh[s] = 0; open[s] = false;
+            if ((uint32_t)s < nsl && i < nk) {
+                km[s] = window_kmer(sm.pk, sm.vd, i, k, nullptr, nullptr);
+                hh[s] = hash_idx(km[s], T.idx_shift);
+                open[s] = km[s] != NAN64;
+            }
+        }
+        for (;;) {  // linear probing in wave-wide rounds
+            IdxSlot q[NSLOT];
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s)
+                if (open[s]) q[s] = T.idx[hh[s]];
+            bool again = false;
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s)
+                if (open[s]) {
+                    if (q[s].key == km[s]) { hv[s] = (uint32_t)q[s].val; ha[s] = (uint32_t)(q[s].val >> 32); open[s] = false; }
+                    else if (q[s].key == NAN64) open[s] = false;
+                    else { hh[s] = (hh[s] + 1) & T.idx_mask; again = true; }
+                }
+            if (x.ballot(again) == 0) break;
+        }
+        HitEnt* out = a.hitbuf + (size_t)it * a.nkp;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const uint32_t i = 64 * s + lane;
+            if ((uint32_t)s < nsl && i < nk) out[i] = HitEnt{km[s], hv[s], ha[s]};
+        }
+    }
+}
+
+// ======================================================================= K3 =
 template <class X>
 DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     PairSmem& sm = *x.template smem<PairSmem>();
@@ -476,137 +714,177 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     const bool okam = a.P.okam != 0;
     // per-block counters, flushed once at the end
     uint64_t c_kf = 0, c_hf = 0, c_qc = 0, c_thr = 0, c_feas = 0, c_asgn = 0, c_nhash1 = 0, c_vv = 0, c_cls = 0, c_inc = 0;
+    DBTK_STAMP_DECL
+    const uint32_t nsurv = *a.nsurv;
 
     for (;;) {
         uint32_t t = 0;
         if (lane == 0) t = x.atomic_add(a.ticket, 1u);
         t = x.bcast(t, 0);
-        if (t >= *a.nsurv) break;
-        const uint32_t pair = a.surv[t];
+        if (t >= nsurv) break;
+        const uint32_t pair = a.surv[t] + a.pair_base;
         x.sync();  // previous pair's LDS is dead from here on
+        DBTK_STAMP(0);  // ticket
 
-        // ---- P0: load + pack both reads (lanes 0..15 mate 0, 16..31 mate 1)
-        if (lane < 32) {
-            const int m = lane >> 4, c = lane & 15;
-            const uint64_t o0 = a.off[2 * (uint64_t)pair + m], o1 = a.off[2 * (uint64_t)pair + m + 1];
-            uint32_t len = (uint32_t)(o1 - o0);
-            if (len > (uint32_t)MAXL) { *a.errflag = DBTK_ERR_READ_TOO_LONG; len = MAXL; }  // stay inside LDS
-            uint32_t w[4] = {0, 0, 0, 0};
-            for (int b = 0; b < 16; ++b) {
-                const uint32_t p = 16 * c + b;
-                if (p < len) w[b >> 2] |= (uint32_t)a.seq[o0 + p] << (8 * (b & 3));
-            }
-            uint32_t vd;
-            sm.pk[m][c] = pack16(w, &vd);
-            sm.vd[m][c] = (uint16_t)vd;  // bytes past the read are 0 -> invalid
-            if (c < 4) { sm.pk[m][16 + c] = 0; sm.vd[m][16 + c] = 0; }
-            if (c == 0) { sm.len[m] = len; sm.nk[m] = len >= k ? len - k + 1 : 0; }
-        }
-        x.sync();
-        const uint32_t nk0 = sm.nk[0], nk1 = sm.nk[1];
-
-        // ---- P1: canonical k-mers by position (read2kmers_edges, AQ.h:274-311)
+        // ---- P3: the probe kernel's results for both reads, one coalesced 16-byte load per position
+        uint32_t nkm[2];
+#pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const uint32_t nk = m ? nk1 : nk0;
-            for (uint32_t i = lane; i < nk; i += 64) sm.kmer[m][i] = window_kmer(sm.pk[m], sm.vd[m], i, k, nullptr, nullptr);
+            const uint64_t ls = a.surv[t];
+            uint32_t len = (uint32_t)(a.off[2 * ls + m + 1] - a.off[2 * ls + m]);
+            if (len > (uint32_t)MAXL) len = MAXL;
+            nkm[m] = len >= k ? len - k + 1 : 0;
         }
-        x.sync();
-
-        // ---- P3: kfilter (AQ.cpp:190-224): probe every position; a mate fails
-        // when its misses exceed nk - Cth; nhash1 counts probes up to the abort.
         int kf[2], rm[2], hf[2] = {0, 0}, af[2] = {0, 0};
-        uint32_t nhit[2] = {0, 0};
-        kf[0] = nk0 < cth; kf[1] = nk1 < cth;
+        kf[0] = nkm[0] < cth; kf[1] = nkm[1] < cth;
         rm[0] = kf[0]; rm[1] = kf[1];
-        if (!(rm[0] && rm[1])) {
+        const bool both_short = rm[0] && rm[1];
+        uint64_t km[2][NSLOT];
+        uint32_t hv[2][NSLOT], ha[2][NSLOT];
+        const uint32_t nsl = ((nkm[0] > nkm[1] ? nkm[0] : nkm[1]) + 63) >> 6;  // slots in use (3 for 150 bp reads)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const HitEnt* in = a.hitbuf + ((size_t)2 * t + m) * a.nkp;
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                const uint32_t i = 64 * s + lane;
+                km[m][s] = NAN64; hv[m][s] = NOHIT; ha[m][s] = 0;
+                if ((uint32_t)s < nsl && i < nkm[m]) {
+                    const HitEnt e = in[i];
+                    km[m][s] = e.km; hv[m][s] = e.val; ha[m][s] = e.aux;
+                    sm.hval[m][i] = e.val;
+                }
+            }
+        }
+        DBTK_STAMP(3);  // hit-buffer loads
+        if (!both_short) {
+#pragma unroll
             for (int m = 0; m < 2; ++m) {
                 if (rm[m]) continue;
-                const uint32_t nk = m ? nk1 : nk0;
-                const uint32_t maxns = nk - cth;
-                uint32_t cum_miss = 0, hits = 0, abort_at = nk;  // abort_at: position of the (maxns+1)-th miss
-                for (uint32_t base = 0; base < nk; base += 64) {
-                    const uint32_t i = base + lane;
-                    uint32_t v = NOHIT;
-                    if (i < nk) {
-                        const uint64_t km = sm.kmer[m][i];
-                        if (km != NAN64) v = idx_lookup(T, km);
-                        sm.hval[m][i] = v;
-                    }
-                    const uint64_t missmask = x.ballot(i < nk && v == NOHIT);
+                const uint32_t nk = nkm[m], maxns = nk - cth;
+                uint32_t cum_miss = 0, abort_at = nk;  // abort_at: position of the (maxns+1)-th miss
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    if ((uint32_t)s >= nsl) continue;
+                    const uint32_t i = 64 * s + lane;
+                    const uint64_t missmask = x.ballot(i < nk && hv[m][s] == NOHIT);
                     const uint32_t nm = (uint32_t)__builtin_popcountll(missmask);
                     if (abort_at == nk && cum_miss + nm > maxns) {
                         uint64_t mm = missmask;  // the (maxns + 1 - cum_miss)-th set bit
                         for (uint32_t r = maxns - cum_miss; r > 0; --r) mm &= mm - 1;
-                        abort_at = base + (uint32_t)__builtin_ctzll(mm);
+                        abort_at = 64 * s + (uint32_t)__builtin_ctzll(mm);
                     }
                     cum_miss += nm;
-                    hits += (uint32_t)__builtin_popcountll(x.ballot(i < nk && v != NOHIT));
                 }
-                if (abort_at != nk) {  // its.clear(); kf = 1
-                    kf[m] = 1; rm[m] = 1;
-                    c_nhash1 += abort_at + 1;
-                } else {
-                    nhit[m] = hits;
-                    c_nhash1 += nk;
-                }
+                if (abort_at != nk) { kf[m] = 1; rm[m] = 1; c_nhash1 += abort_at + 1; }  // its.clear(); kf = 1
+                else c_nhash1 += nk;
             }
         }
         c_kf += (uint64_t)(kf[0] + kf[1]);
-        x.sync();
+        DBTK_STAMP(4);  // kfilter verdicts
 
         uint32_t stage = DBTK_STAGE_KFILTER, dst = nloci, dst0 = NAN32;
         int nm1 = 0, nm2 = 0;
         MateState ms[2];
         for (int m = 0; m < 2; ++m) ms[m] = MateState{-1, -1, 0, 0, -1, -1, -1, 0, 0};
         uint32_t nas[2] = {0, 0};
+        uint64_t Kw[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, Rw[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 
         if (!(rm[0] && rm[1])) {
             // ---- P4: gather the hit lists (its1 ++ its2 with the orient bit, AQ.cpp:263-266)
             uint32_t n = 0;
+#pragma unroll
             for (int m = 0; m < 2; ++m) {
                 if (rm[m]) continue;
-                const uint32_t nk = m ? nk1 : nk0;
-                for (uint32_t base = 0; base < nk; base += 64) {
-                    const uint32_t i = base + lane;
-                    const bool hit = i < nk && sm.hval[m][i] != NOHIT;
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    if ((uint32_t)s >= nsl) continue;
+                    const uint32_t i = 64 * s + lane;
+                    const bool hit = i < nkm[m] && hv[m][s] != NOHIT;
                     const uint64_t hm = x.ballot(hit);
                     if (hit) {
                         const uint32_t at = n + (uint32_t)__builtin_popcountll(hm & ((1ull << lane) - 1));
-                        sm.u.s.skey[at] = sm.kmer[m][i];
+                        sm.u.s.skey[at] = km[m][s];
                         sm.u.s.sinfo[at] = (uint16_t)((m << 8) | i);
                     }
                     n += (uint32_t)__builtin_popcountll(hm);
                 }
             }
             x.sync();
+            DBTK_STAMP(5);  // gather
             // ---- P5: sort by key (rank sort; (key, info) is a strict total order),
             // then run-length encode into unique k-mers + PE_KMC dups (AQ.cpp:268-295)
             {
-                uint64_t myk[8]; uint16_t myi[8]; uint32_t rk[8];
-                const int nown = (int)((n + 63 - lane) / 64);  // entries lane, lane+64, ...
+                // composite (key << 9 | mate << 8 | position) when it fits 64 bits (k <= 27), else two-word compare
+                const bool narrow = 2 * k + 9 <= 64;
+                const int nown = (int)((n + 63 - lane) / 64);   // entries lane, lane+64, ... owned by this lane
+                const int nmax = (int)((n + 63) / 64);          // wave-uniform bound
+                uint64_t myk[8]; uint32_t myi[8]; uint32_t rk[8];
+#pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    rk[j] = 0;
-                    if (j < nown) { myk[j] = sm.u.s.skey[lane + 64 * j]; myi[j] = sm.u.s.sinfo[lane + 64 * j]; }
-                    else { myk[j] = 0; myi[j] = 0; }
+                    rk[j] = 0; myk[j] = ~0ull; myi[j] = 0xFFFFu;
+                    if (!narrow && j < nown) {
+                        const uint64_t kk = sm.u.s.skey[lane + 64 * j];
+                        const uint32_t ii = sm.u.s.sinfo[lane + 64 * j];
+                        myk[j] = kk;
+                        myi[j] = ii;
+                    }
                 }
-                for (uint32_t f = 0; f < n; ++f) {
-                    const uint64_t fk = sm.u.s.skey[f];
-                    const uint16_t fi = sm.u.s.sinfo[f];
-                    for (int j = 0; j < 8; ++j) rk[j] += (fk < myk[j]) || (fk == myk[j] && fi < myi[j]);
+                if (narrow) {
+                    // bitonic network on composite keys, 4 (n <= 256) or 8 per lane; pad with ~0
+                    if (n <= 256) {
+                        uint64_t v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t e = 4 * (uint32_t)lane + j;
+                            v[j] = e < n ? ((sm.u.s.skey[e] << 9) | sm.u.s.sinfo[e]) : ~0ull;
+                        }
+                        bitonic_sort<4>(x, v);
+                        x.sync();
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t e = 4 * (uint32_t)lane + j;
+                            if (e < n) { sm.u.s.skey[e] = v[j] >> 9; sm.u.s.sinfo[e] = (uint16_t)(v[j] & 0x1FF); }
+                        }
+                    } else {
+                        uint64_t v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint32_t e = 8 * (uint32_t)lane + j;
+                            v[j] = e < n ? ((sm.u.s.skey[e] << 9) | sm.u.s.sinfo[e]) : ~0ull;
+                        }
+                        bitonic_sort<8>(x, v);
+                        x.sync();
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint32_t e = 8 * (uint32_t)lane + j;
+                            if (e < n) { sm.u.s.skey[e] = v[j] >> 9; sm.u.s.sinfo[e] = (uint16_t)(v[j] & 0x1FF); }
+                        }
+                    }
+                } else {
+                    for (uint32_t f = 0; f < n; ++f) {
+                        const uint64_t fk = sm.u.s.skey[f];
+                        const uint32_t fi = sm.u.s.sinfo[f];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (j < nmax) rk[j] += (fk < myk[j]) || (fk == myk[j] && fi < myi[j]);
+                    }
+                    x.sync();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j < nown) { sm.u.s.skey[rk[j]] = myk[j]; sm.u.s.sinfo[rk[j]] = (uint16_t)myi[j]; }
                 }
-                x.sync();
-                for (int j = 0; j < 8; ++j)
-                    if (j < nown) { sm.u.s.skey[rk[j]] = myk[j]; sm.u.s.sinfo[rk[j]] = myi[j]; }
                 for (uint32_t i = lane; i < (uint32_t)NHMAX; i += 64) sm.dd[i] = 0;
                 x.sync();
             }
+            DBTK_STAMP(6);  // rank sort
             uint32_t nu;
             {
                 // contiguous ownership: lane owns sorted entries [8*lane, 8*lane+8)
                 const uint32_t b0 = 8 * (uint32_t)lane;
                 uint32_t heads = 0;
-                uint64_t prevk = (b0 > 0 && b0 <= n) ? sm.u.s.skey[b0 - 1] : 0;
+                const uint64_t prevk = (b0 > 0 && b0 <= n) ? sm.u.s.skey[b0 - 1] : 0;
                 uint64_t ks[8];
+#pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t r = b0 + j;
                     ks[j] = r < n ? sm.u.s.skey[r] : 0;
@@ -614,66 +892,79 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 }
                 uint32_t uidx = x.wave_excl_scan(heads);  // unique index of my first head
                 nu = x.wave_sum(heads);
-                // a non-head entry belongs to the most recent head at or before it
-                for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {  // a non-head entry belongs to the most recent head at or before it
                     const uint32_t r = b0 + j;
-                    if (r >= n) break;
-                    const bool head = (r == 0 || ks[j] != (j ? ks[j - 1] : prevk));
-                    if (head) ++uidx;
-                    const uint32_t u = uidx - 1;
-                    const uint16_t info = sm.u.s.sinfo[r];
-                    if (head) sm.uval[u] = sm.hval[info >> 8][info & 0xFF];
-                    x.lds_add(&sm.dd[u], (info >> 8) ? 0x10000u : 1u);
+                    if (r < n) {
+                        const bool head = (r == 0 || ks[j] != (j ? ks[j - 1] : prevk));
+                        if (head) ++uidx;
+                        const uint32_t u = uidx - 1;
+                        const uint16_t info = sm.u.s.sinfo[r];
+                        if (head) sm.uval[u] = sm.hval[info >> 8][info & 0xFF];
+                        x.lds_add(&sm.dd[u], (info >> 8) ? 0x10000u : 1u);
+                    }
                 }
             }
             x.sync();
-            // ---- P6: number of mapped loci per unique k-mer (AQ.cpp:311-317); skey/sinfo are dead now
-            bool alleq = true;
-            for (uint32_t u = lane; u < nu; u += 64) {
-                const uint32_t v = sm.uval[u];
-                const uint32_t c = (v & 1) ? T.vv[v >> 1] : 1u;
-                sm.u.v.nml[u] = c;
-            }
+            DBTK_STAMP(7);  // dedup
+            // ---- P6: loci per unique k-mer (AQ.cpp:311-317); skey/sinfo are dead now
+            bool alleq, single;
             {
+                const uint32_t v0 = nu ? x.uni(sm.uval[0]) : 0;
                 uint32_t odd = 0;
-                for (uint32_t u = lane; u < nu; u += 64) odd += sm.uval[u] & 1;
-                c_vv += x.wave_sum(odd);
+                bool vdiff = false;
+                for (uint32_t u = lane; u < nu; u += 64) {
+                    const uint32_t v = sm.uval[u];
+                    odd += v & 1;
+                    vdiff |= v != v0;
+                }
+                const uint32_t nodd = x.wave_sum(odd);
+                c_vv += nodd;
+                single = nu && nodd == 0 && x.ballot(vdiff) == 0;  // one locus, every k-mer unique to it
+                alleq = single;
+                if (!single) {
+                    for (uint32_t u = lane; u < nu; u += 64) {
+                        const uint32_t v = sm.uval[u];
+                        sm.u.v.nml[u] = (v & 1) ? T.vv[v >> 1] : 1u;
+                    }
+                    for (uint32_t i = lane; i < (uint32_t)LCAP; i += 64) sm.u.v.lkey[i] = NAN32;
+                    x.sync();
+                    const uint32_t n0 = nu ? x.uni(sm.u.v.nml[0]) : 0;
+                    bool diff = false;
+                    for (uint32_t u = lane; u < nu; u += 64) diff |= sm.u.v.nml[u] != n0;
+                    alleq = x.ballot(diff) == 0;
+                }
             }
-            for (uint32_t i = lane; i < (uint32_t)LCAP; i += 64) sm.u.v.lkey[i] = NAN32;
-            x.sync();
-            {
-                const uint32_t n0 = sm.u.v.nml[0];
-                bool diff = false;
-                for (uint32_t u = lane; u < nu; u += 64) diff |= sm.u.v.nml[u] != n0;
-                alleq = x.ballot(diff) == 0;
+            DBTK_STAMP(8);  // nml / single-locus test
+            // ---- P7 + P8: the permutation std::sort applies (AQ.cpp:320-327) and the vote
+            const uint16_t* perm_row = T.permtab + (size_t)nu * (nu ? nu - 1 : 0) / 2;  // introsort of nu equal keys
+            if (single) {
+                const uint32_t fr = vote_single_locus(x, perm_row, sm.dd, nu, cth);
+                dst0 = x.uni(sm.uval[0]) >> 1;
+                nm1 = (int)(fr & 0xFFFF); nm2 = (int)(fr >> 16);
+            } else {
+                if (alleq) { for (uint32_t i = lane; i < nu; i += 64) sm.u.v.ord[i] = perm_row[i]; }
+                else if (lane == 0) gcc_sort_index(sm.u.v.ord, (int)nu, sm.u.v.nml, sm.stack);
+                x.sync();
+                if (lane == 0) {
+                    for (uint32_t u = 0; u < nu; ++u) sm.dd[u] &= 0x00FF00FFu;  // PE_KMC counts are uint8_t
+                    const uint32_t ep = a.vote_epoch[x.bid()] + 1;
+                    HitMap hmap{sm.u.v.lkey, sm.lhit, 0, a.vote_scratch + (size_t)x.bid() * ((size_t)nloci + 1), ep, false};
+                    Asgn top;
+                    uint64_t nvvw = 0;
+                    vote(T, sm.u.v.ord, sm.uval, sm.dd, (int)nu, cth, hmap, top, nvvw);
+                    c_vv += nvvw;
+                    if (hmap.spilled) a.vote_epoch[x.bid()] = ep;
+                    sm.res[0] = (int32_t)(uint32_t)top.idx;
+                    sm.res[1] = (int32_t)top.fc;
+                    sm.res[2] = (int32_t)top.rc;
+                }
+                x.sync();
+                dst0 = x.uni((uint32_t)sm.res[0]);
+                nm1 = (int)x.uni((uint32_t)sm.res[1]); nm2 = (int)x.uni((uint32_t)sm.res[2]);
             }
-            // ---- P7: the permutation std::sort applies (AQ.cpp:320-327)
-            if (alleq) {
-                const uint16_t* row = T.permtab + (size_t)nu * (nu - 1) / 2;
-                for (uint32_t i = lane; i < nu; i += 64) sm.u.v.ord[i] = row[i];
-            } else if (lane == 0) {
-                gcc_sort_index(sm.u.v.ord, (int)nu, sm.u.v.nml, sm.stack);
-            }
-            x.sync();
-            // ---- P8: vote (lane 0)
-            if (lane == 0) {
-                // PE_KMC counts are uint8_t in the reference: reduce them here
-                for (uint32_t u = 0; u < nu; ++u) sm.dd[u] &= 0x00FF00FFu;
-                const uint32_t ep = a.vote_epoch[x.bid()] + 1;
-                HitMap hmap{sm.u.v.lkey, sm.lhit, 0, a.vote_scratch + (size_t)x.bid() * ((size_t)nloci + 1), ep, false};
-                Asgn top;
-                uint64_t nvvw = 0;
-                vote(T, sm.u.v.ord, sm.uval, sm.dd, (int)nu, cth, hmap, top, nvvw);
-                c_vv += nvvw;
-                if (hmap.spilled) a.vote_epoch[x.bid()] = ep;
-                sm.res[0] = (int32_t)(uint32_t)top.idx;
-                sm.res[1] = (int32_t)top.fc;
-                sm.res[2] = (int32_t)top.rc;
-            }
-            x.sync();
-            dst0 = (uint32_t)sm.res[0];
-            nm1 = sm.res[1]; nm2 = sm.res[2];
-            {
+            DBTK_STAMP(single ? 9 : 10);  // vote: fast / general
+            {  // countHit's accept test, AQ.cpp:439-451
                 const uint64_t fc = (uint64_t)(uint32_t)nm1, rc = (uint64_t)(uint32_t)nm2;
                 const bool test1 = fc >= cth && rc >= cth, test2 = (fc + rc) >= 2ull * cth;
                 if ((test1 || test2) && dst0 != NAN32) dst = dst0;
@@ -690,40 +981,48 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     stage = DBTK_STAGE_EXTRACT;
                 } else {
                     c_thr += 2; c_feas += 2;
-                    // ---- P10: assignTRkmc against the DBs of destLocus0 (AQ.cpp:2138-2144)
-                    uint32_t ntr[2] = {0, 0};
+                    // ---- P10: assignTRkmc against the DBs of destLocus0 (AQ.cpp:2138-2144).  State of a
+                    // position: flank 1 beats TR 2 (AQ.cpp:1467-1468).  With a consistent RPGG the class of a
+                    // single-locus k-mer rides in the index slot (`aux`): no second probe.
+                    uint32_t slot[2][NSLOT], ntr[2] = {0, 0};
+#pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         ms[m].rm = rm[m];
                         if (!okam && rm[m]) continue;
-                        const uint32_t nk = m ? nk1 : nk0;
-                        nas[m] = nk;
-                        c_cls += nk;
+                        nas[m] = nkm[m];
+                        c_cls += nkm[m];
                         uint32_t mytr = 0;
-                        for (uint32_t i = lane; i < nk; i += 64) {
-                            const uint64_t km = sm.kmer[m][i];
+#pragma unroll
+                        for (int s = 0; s < NSLOT; ++s) {
+                            slot[m][s] = CLS_NONE;
+                            if ((uint32_t)s >= nsl) continue;
+                            const uint32_t i = 64 * s + lane;
                             uint32_t c = CLS_NONE;
-                            if (km != NAN64) c = cls_lookup(T, km, dst0);
-                            const uint8_t s = (c == CLS_FLANK) ? 1 : (c == CLS_NONE ? 0 : 2);
-                            sm.as[m][i] = s;
-                            sm.hval[m][i] = c;
-                            mytr += s == 2;
+                            if (i < nkm[m] && km[m][s] != NAN64) {
+                                const uint32_t v = hv[m][s];
+                                if (T.consistent && v == NOHIT) c = CLS_NONE;
+                                else if (T.consistent && !(v & 1)) c = ((v >> 1) == dst0) ? ha[m][s] : CLS_NONE;
+                                else c = cls_lookup(T, km[m][s], dst0);
+                            }
+                            slot[m][s] = c;
+                            const uint64_t kb = x.ballot(c != CLS_NONE), rb = x.ballot(c != CLS_NONE && c != CLS_FLANK);
+                            Kw[m][s] = kb; Rw[m][s] = rb;
+                            mytr += (uint32_t)__builtin_popcountll(rb);
                         }
-                        ntr[m] = x.wave_sum(mytr) & 0xFF;  // uint8_t ntr, AQ.cpp:1454
+                        ntr[m] = mytr & 0xFF;  // uint8_t ntr, AQ.cpp:1454 (mytr is already wave-uniform)
                     }
-                    x.sync();
-                    if (lane < 2 && nas[lane]) {
-                        MateState r = ms[lane];
-                        assign_scan(sm.as[lane], (int)nas[lane], ntr[lane], a.P, r);
-                        int32_t* o = sm.mres[lane];
-                        o[0] = r.si; o[1] = r.ei; o[2] = r.nt; o[3] = r.bs; o[4] = r.ti; o[5] = r.si_; o[6] = r.ei_; o[7] = r.af; o[8] = r.rm;
-                    }
-                    x.sync();
+                    DBTK_STAMP(11);  // states
+#pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         if (!nas[m]) continue;
-                        const int32_t* o = sm.mres[m];
-                        ms[m] = MateState{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8]};
+                        // K / R are wave-uniform ballots: the whole state machine runs on the scalar unit
+                        Bits256 K, R;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { K.w[q] = Kw[m][q]; R.w[q] = Rw[m][q]; }
+                        assign_bits(K, R, (int)nas[m], ntr[m], a.P, ms[m]);
                         af[m] = ms[m].af; rm[m] = ms[m].rm;
                     }
+                    DBTK_STAMP(12);  // assign_bits
                     // ---- P11: accumulate (AQ.cpp:2145-2158)
                     if (rm[0] && rm[1]) { dst = nloci; stage = DBTK_STAGE_ASGN; }
                     else {
@@ -734,17 +1033,21 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                             x.atomic_add(&a.kmc[dst], (uint64_t)(int64_t)((ms[0].ei - ms[0].si) + (ms[1].ei - ms[1].si)));
                         }
                         c_asgn += (uint64_t)nmap;
+#pragma unroll
                         for (int m = 0; m < 2; ++m) {
                             if (rm[m]) continue;
-                            uint32_t myinc = 0;
-                            for (uint32_t i = lane; i < nas[m]; i += 64)
-                                if (sm.as[m][i] == 2) { x.atomic_add(&a.counts[sm.hval[m][i]], 1ull); ++myinc; }
-                            c_inc += x.wave_sum(myinc);
+#pragma unroll
+                            for (int s = 0; s < NSLOT; ++s) {
+                                const uint32_t c = slot[m][s];
+                                if (c != CLS_NONE && c != CLS_FLANK) x.atomic_add(&a.counts[c], 1ull);
+                                c_inc += (uint64_t)__builtin_popcountll(Rw[m][s]);
+                            }
                         }
                     }
                 }
             }
         }
+        DBTK_STAMP(13);  // accumulate
         // ---- P12: record (kam: AQ.cpp:2169-2175; trace: every pair)
         const bool want = a.recs && (a.P.trace || (okam && stage == DBTK_STAGE_COUNTED) ||
                                      (a.P.extract && stage == DBTK_STAGE_EXTRACT));
@@ -759,29 +1062,36 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 if (lane == 0) {
                     r->pair = pair; r->stage = stage; r->dst = dst; r->dst0 = dst0; r->nm1 = nm1; r->nm2 = nm2;
                 }
-                if (lane < 2) {
-                    dbtk_mate_rec_t* mr = lane ? &r->r2 : &r->r1;
-                    const MateState& s = ms[lane];
-                    mr->si = (int16_t)s.si; mr->ei = (int16_t)s.ei; mr->si_ = (int16_t)s.si_; mr->ei_ = (int16_t)s.ei_;
-                    mr->nt = (int16_t)s.nt; mr->bs = (int16_t)s.bs; mr->ti = (int16_t)s.ti;
-                    mr->kf = (uint8_t)kf[lane]; mr->hf = (uint8_t)hf[lane]; mr->bf = 0; mr->qf = 0;
-                    mr->af = (uint8_t)af[lane]; mr->rm = (uint8_t)rm[lane];
-                    mr->nk = (uint16_t)nas[lane];
-                }
+#pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     dbtk_mate_rec_t* mr = m ? &r->r2 : &r->r1;
-                    if (lane < MAXL / 4) {
-                        uint8_t b = 0;
-                        for (int q = 0; q < 4; ++q) {
-                            const uint32_t i = 4 * lane + q;
-                            if (i < nas[m]) b |= (uint8_t)((sm.as[m][i] & 3) << (2 * q));
-                        }
-                        mr->as2[lane] = b;
+                    if (lane == 0) {
+                        const MateState& s = ms[m];
+                        mr->si = (int16_t)s.si; mr->ei = (int16_t)s.ei; mr->si_ = (int16_t)s.si_; mr->ei_ = (int16_t)s.ei_;
+                        mr->nt = (int16_t)s.nt; mr->bs = (int16_t)s.bs; mr->ti = (int16_t)s.ti;
+                        mr->kf = (uint8_t)kf[m]; mr->hf = (uint8_t)hf[m]; mr->bf = 0; mr->qf = 0;
+                        mr->af = (uint8_t)af[m]; mr->rm = (uint8_t)rm[m];
+                        mr->nk = (uint16_t)nas[m];
                     }
+                    // as2 byte `lane` = states of positions 4*lane .. 4*lane+3 (0 '*', 1 '.', 2 '=')
+                    const int wq = lane >> 4, sh = 4 * (lane & 15);
+                    uint64_t kq = Kw[m][0], rq = Rw[m][0];
+                    if (wq == 1) { kq = Kw[m][1]; rq = Rw[m][1]; }
+                    if (wq == 2) { kq = Kw[m][2]; rq = Rw[m][2]; }
+                    if (wq == 3) { kq = Kw[m][3]; rq = Rw[m][3]; }
+                    const uint32_t k4 = (uint32_t)(kq >> sh) & 0xF, r4 = (uint32_t)(rq >> sh) & 0xF;
+                    uint8_t b = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t st = ((k4 >> q) & 1) + ((r4 >> q) & 1);  // known: 1, known and TR: 2
+                        if ((uint32_t)(4 * lane + q) < nas[m]) b |= (uint8_t)(st << (2 * q));
+                    }
+                    mr->as2[lane] = b;
                 }
             }
         }
     }
+    DBTK_STAMP_FLUSH;
     if (lane == 0) {
         if (c_kf) x.atomic_add(&a.counters[DBTK_C_KMERFILTERED], c_kf);
         if (c_hf) x.atomic_add(&a.counters[DBTK_C_LOCUSFILTERED], c_hf);

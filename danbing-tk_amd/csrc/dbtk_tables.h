@@ -40,7 +40,8 @@ constexpr int NHMAX = 2 * NKMAX;             // hits per pair
 // so that the LAST assignment of a duplicated key wins, as operator[] does.
 struct IdxSlot {
     uint64_t key;  // NAN64 = empty
-    uint64_t val;  // low 32 bits after finalize
+    uint64_t val;  // low 32 bits: val.  High 32 bits (`aux`): for a k-mer unique to one locus (even val) its
+                   // class at that locus — CLS_FLANK or its OUT.trkmc.ar slot — so that assignTRkmc needs no second probe
 };
 
 // ---- class table: for locus l, k-mer km: flank (PREF.fl.kdb) beats TR
@@ -64,6 +65,7 @@ struct DevTables {
     const uint16_t* permtab;  // introsort permutation of n equal keys, n = 1..NHMAX, row n at n(n-1)/2
     uint32_t nloci;
     uint32_t ksize;
+    uint32_t consistent;  // index memberships == flank/TR sets (verified on the GPU at load): `aux` may be used
 };
 
 DBTK_HD uint64_t hash_idx(uint64_t key, uint32_t shift) {
@@ -83,6 +85,17 @@ DBTK_HD uint32_t idx_lookup(const DevTables& T, uint64_t key) {
         const IdxSlot s = T.idx[i];
         if (s.key == key) return (uint32_t)s.val;
         if (s.key == NAN64) return NOHIT;
+        i = (i + 1) & T.idx_mask;
+    }
+}
+
+// same, returning val | aux << 32 (low word NOHIT on a miss)
+DBTK_HD uint64_t idx_lookup64(const DevTables& T, uint64_t key) {
+    uint64_t i = hash_idx(key, T.idx_shift);
+    for (;;) {
+        const IdxSlot s = T.idx[i];
+        if (s.key == key) return s.val;
+        if (s.key == NAN64) return (uint64_t)NOHIT;
         i = (i + 1) & T.idx_mask;
     }
 }

@@ -202,12 +202,26 @@ class Emu(pkg._HostSide):
         L.emu_tables_create.restype = C.c_void_p
         L.emu_tables_create.argtypes = [C.c_void_p]
         L.emu_tables_free.argtypes = [C.c_void_p]
+        L.emu_tables_consistent.restype = C.c_uint32
+        L.emu_tables_consistent.argtypes = [C.c_void_p]
+        L.emu_tables_set_consistent.argtypes = [C.c_void_p, C.c_uint32]
+        L.emu_selftest_assign.restype = C.c_uint64
+        L.emu_selftest_assign.argtypes = [C.c_uint64, C.c_uint64]
         L.emu_align.restype = C.c_int
         L.emu_align.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.Params), u8p, u64p, C.c_uint64, u64p, u64p, u32p, u64p,
                                 C.POINTER(abi.PairRec), C.c_uint64, u64p, C.c_uint32, C.c_uint32]
 
     def tables(self, rpgg):
         return self.L.emu_tables_create(rpgg.h)
+
+    def consistent(self, tables):
+        return int(self.L.emu_tables_consistent(tables))
+
+    def set_consistent(self, tables, v):
+        self.L.emu_tables_set_consistent(tables, int(v))
+
+    def selftest_assign(self, seed, iters):
+        return int(self.L.emu_selftest_assign(seed, iters))
 
     def align(self, rpgg, tables, params, seq, off, grid_k1=3, grid_pair=5):
         npairs = (len(off) - 1) // 2

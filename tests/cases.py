@@ -67,6 +67,13 @@ def case_k25(tmp):
     return Case(_rpgg(tmp, "k25", loci, 25), 25, reads, [dict(cthreshold=45, okam=1)])
 
 
+def case_k31(tmp):
+    """Largest k (62-bit k-mers): the sort falls back from the composite-key bitonic network to two-word keys."""
+    loci = synth.make_loci(nloci=8, nhap=2, flank=500, seed=10, shared_frac=0.3)
+    reads = synth.sim_reads(loci, npairs=400, seed=19, sub=0.004, chimeric=0.2, background=0.1)
+    return Case(_np_rpgg(tmp, "k31", loci, 31), 31, reads, [dict(cthreshold=40, okam=1)])
+
+
 def case_qc(tmp):
     loci = synth.make_loci(nloci=12, nhap=3, flank=500, seed=5)
     pref = _rpgg(tmp, "qc", loci, 21)
@@ -104,8 +111,29 @@ def case_spill(tmp):
     return Case(_np_rpgg(tmp, "spill", loci, 21), 21, reads, [dict(cthreshold=30, okam=1), dict(cthreshold=45, okam=0)])
 
 
-CASES = dict(clean=case_clean, mixed=case_mixed, shared=case_shared, k25=case_k25, qc=case_qc, lengths=case_lengths,
-             kf=case_kf, spill=case_spill)
+def case_inconsistent(tmp):
+    """Index and flank/TR sets that do NOT describe the same memberships (files mixed from different
+    builds): the load-time check must notice and the kernels must use the general class-table path."""
+    loci = synth.make_loci(nloci=10, nhap=2, flank=500, seed=41, shared_frac=0.4)
+    arr = synth.build_rpgg_arrays(loci, 21)
+    rng = np.random.default_rng(5)
+    keep = rng.random(len(arr["keys"])) > 0.1          # 10 % of the index keys dropped
+    arr["keys"], arr["vals"] = arr["keys"][keep], arr["vals"][keep]
+    drop = rng.random(len(arr["fl_ks"])) < 0.05          # and 5 % of the flank k-mers dropped from fl.kdb
+    cnt, out, i = [], [], 0
+    for n in arr["fl_cnt"]:
+        seg = arr["fl_ks"][i:i + int(n)][~drop[i:i + int(n)]]
+        out.append(seg); cnt.append(len(seg)); i += int(n)
+    arr["fl_ks"], arr["fl_cnt"] = np.concatenate(out), np.array(cnt, np.uint64)
+    d = os.path.join(tmp, "inconsistent")
+    os.makedirs(d, exist_ok=True)
+    synth.write_rpgg_files(arr, os.path.join(d, "pan"))
+    reads = synth.sim_reads(loci, npairs=500, seed=18, sub=0.004, chimeric=0.2)
+    return Case(os.path.join(d, "pan"), 21, reads, [dict(cthreshold=30, okam=1), dict(cthreshold=45, okam=0)])
+
+
+CASES = dict(clean=case_clean, mixed=case_mixed, shared=case_shared, k25=case_k25, k31=case_k31, qc=case_qc, lengths=case_lengths,
+             kf=case_kf, spill=case_spill, inconsistent=case_inconsistent)
 
 
 def make_case(name, tmp) -> Case:

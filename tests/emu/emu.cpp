@@ -11,6 +11,7 @@
 #include <string.h>
 #include <ucontext.h>
 
+#include <algorithm>
 #include <functional>
 #include <vector>
 
@@ -35,11 +36,14 @@ struct EmuX {
     uint32_t wave_sum(uint32_t v) const;
     uint32_t wave_excl_scan(uint32_t v) const;
     uint32_t bcast(uint32_t v, int src) const;
+    template <int E> void shfl_xor64(const uint64_t (&in)[E], uint64_t (&out)[E], int mask) const;
     void atomic_add(uint64_t* p, uint64_t v) const { *p += v; }
     uint32_t atomic_add(uint32_t* p, uint32_t v) const { uint32_t o = *p; *p += v; return o; }
     uint64_t atomic_cas(uint64_t* p, uint64_t e, uint64_t d) const { uint64_t o = *p; if (o == e) *p = d; return o; }
     void atomic_max(uint64_t* p, uint64_t v) const { if (v > *p) *p = v; }
     void atomic_or(uint64_t* p, uint64_t v) const { *p |= v; }
+    uint64_t clock() const { return 0; }
+    uint32_t uni(uint32_t v) const { return v; }
     uint32_t lds_add(uint32_t* p, uint32_t v) const { uint32_t o = *p; *p += v; return o; }
     void lds_or(uint32_t* p, uint32_t v) const { *p |= v; }
     template <class T> T* smem() const;
@@ -53,7 +57,7 @@ struct EmuBlock {
     std::vector<ucontext_t> ctx;
     std::vector<std::vector<char>> stacks;
     std::vector<char> done;
-    std::vector<uint64_t> scratch;
+    std::vector<uint64_t> scratch, vscratch;
     int cur = 0;
     std::function<void(EmuX&)> body;
 
@@ -105,6 +109,12 @@ uint32_t EmuX::wave_excl_scan(uint32_t v) const {
     b->yield();
     return s;
 }
+template <int E> void EmuX::shfl_xor64(const uint64_t (&in)[E], uint64_t (&out)[E], int mask) const {
+    for (int j = 0; j < E; ++j) b->vscratch[(size_t)t * 8 + j] = in[j];
+    b->yield();
+    for (int j = 0; j < E; ++j) out[j] = b->vscratch[(size_t)(t ^ mask) * 8 + j];
+    b->yield();
+}
 uint32_t EmuX::bcast(uint32_t v, int src) const {
     b->scratch[t] = v;
     b->yield();
@@ -124,6 +134,7 @@ void run_grid(uint32_t nblocks, int nt, size_t smem_bytes, std::function<void(Em
     for (auto& s : b.stacks) s.resize(STK);
     b.done.assign(nt, 0);
     b.scratch.assign(nt, 0);
+    b.vscratch.assign((size_t)nt * 8, 0);
     g_blk = &b;
     for (uint32_t bid = 0; bid < nblocks; ++bid) {
         b.bid = bid;
@@ -156,6 +167,7 @@ struct EmuTables {
     std::vector<ClsSlot> cls;
     std::vector<uint32_t> vv;
     std::vector<uint16_t> perm;
+    uint64_t stats[3] = {0, 0, 0};
     DevTables T;
 };
 
@@ -182,10 +194,10 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
     {
         std::vector<uint64_t> beg(nloci + 1, 0);
         for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->tr_cnt[l];
-        ClsBuildArgs a{e->cls.data(), ccap - 1, 64 - lg(ccap), g->tr_ks.data(), beg.data(), (uint32_t)nloci, g->out_slot.data(), g->tr_ks.size()};
+        ClsBuildArgs a{e->cls.data(), ccap - 1, 64 - lg(ccap), g->tr_ks.data(), beg.data(), (uint32_t)nloci, g->out_slot.data(), g->tr_ks.size(), &e->stats[2]};
         run_grid(3, 64, 0, [&](EmuX& x) { body_cls_insert(x, a); });
         for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->fl_cnt[l];
-        ClsBuildArgs f{e->cls.data(), ccap - 1, 64 - lg(ccap), g->fl_ks.data(), beg.data(), (uint32_t)nloci, nullptr, g->fl_ks.size()};
+        ClsBuildArgs f{e->cls.data(), ccap - 1, 64 - lg(ccap), g->fl_ks.data(), beg.data(), (uint32_t)nloci, nullptr, g->fl_ks.size(), &e->stats[2]};
         run_grid(3, 64, 0, [&](EmuX& x) { body_cls_insert(x, f); });
     }
     e->perm.resize((size_t)NHMAX * (NHMAX + 1) / 2 + 1);
@@ -202,9 +214,55 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
     T.permtab = e->perm.data();
     T.nloci = (uint32_t)nloci;
     T.ksize = g->ksize;
+    T.consistent = 0;
+    {
+        IdxAuxArgs a{e->idx.data(), icap, T, e->stats};
+        run_grid(3, 64, 0, [&](EmuX& x) { body_idx_aux(x, a); });
+        T.consistent = (e->stats[1] == 0 && e->stats[0] == e->stats[2]) ? 1u : 0u;
+    }
     return e;
 }
 void emu_tables_free(void* e) { delete (EmuTables*)e; }
+uint32_t emu_tables_consistent(void* e) { return ((EmuTables*)e)->T.consistent; }
+void emu_tables_set_consistent(void* e, uint32_t v) { ((EmuTables*)e)->T.consistent = v; }
+
+// assign_bits (the mask form the kernels use) against assign_scan (the literal
+// restatement of AQ.cpp:1470-1555) on `iters` random state vectors.  Returns the
+// number of mismatches.
+uint64_t emu_selftest_assign(uint64_t seed, uint64_t iters) {
+    uint64_t bad = 0, s = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (uint64_t it = 0; it < iters; ++it) {
+        const int nk = 1 + (int)(rnd() % 256);
+        uint8_t as[256];
+        const int mode = (int)(rnd() % 6);
+        // runs of equal states (realistic) or per-position noise
+        int i = 0;
+        while (i < nk) {
+            const int st = (int)(rnd() % 3);
+            int len = mode < 4 ? 1 + (int)(rnd() % (mode == 0 ? 3 : mode == 1 ? 20 : 90)) : 1;
+            for (; len > 0 && i < nk; --len) as[i++] = (uint8_t)st;
+        }
+        dbtk_params_t P;
+        memset(&P, 0, sizeof(P));
+        P.max_nt = (rnd() % 8 == 0) ? (uint32_t)(rnd() % 4) : 2;
+        P.nm_tr = (uint32_t)(rnd() % 80);
+        uint32_t ntr = 0;
+        Bits256 K{{0, 0, 0, 0}}, R{{0, 0, 0, 0}};
+        for (int j = 0; j < nk; ++j) {
+            if (as[j]) K.w[j >> 6] |= 1ull << (j & 63);
+            if (as[j] == 2) { R.w[j >> 6] |= 1ull << (j & 63); ++ntr; }
+        }
+        ntr &= 0xFF;
+        for (int rm = 0; rm < 2; ++rm) {
+            MateState a{-1, -1, 0, 0, -1, -1, -1, 0, rm}, b = a;
+            assign_scan(as, nk, ntr, P, a);
+            assign_bits(K, R, nk, ntr, P, b);
+            if (memcmp(&a, &b, sizeof(a)) != 0) ++bad;
+        }
+    }
+    return bad;
+}
 
 // Same outputs as dbtk_align_batch + dbtk_ctx_counts (counts in OUT.trkmc.ar order).
 int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
@@ -227,7 +285,15 @@ int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const 
     a.counts = accum.data(); a.kmc = a.counts + ntr; a.nmapread = a.kmc + nloci; a.counters = a.nmapread + nloci;
     a.recs = recs; a.rec_cap = (uint32_t)rec_cap;
     a.vote_scratch = vote.data(); a.vote_epoch = epoch.data();
+    uint32_t maxlen = 1;
+    for (uint64_t r = 0; r < 2 * npairs; ++r) maxlen = std::max<uint32_t>(maxlen, (uint32_t)(off[r + 1] - off[r]));
+    const uint32_t nkmax = maxlen >= g->ksize ? maxlen - g->ksize + 1 : 1;
+    a.nkp = 64 * ((nkmax + 63) / 64);
+    std::vector<HitEnt> hit((size_t)npairs * 2 * a.nkp + 1);
+    a.hitbuf = hit.data();
+    a.pair_base = 0;
     run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter(x, a); });
+    run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe(x, a); });
     run_grid(grid_pair, 64, sizeof(PairSmem), [&](EmuX& x) { body_pair(x, a); });
     if (small[3]) return (int)small[3];
     memcpy(counts, accum.data(), ntr * 8);

@@ -30,20 +30,30 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
     T = E.tables(g)
     order = g.output_order().astype(np.int64)
     seq, off = c.reads.packed()
+    # the load-time check: index memberships == flank/TR sets  <=>  the class rides in the index slot
+    assert E.consistent(T) == (0 if case == "inconsistent" else 1)
     for i, kw in enumerate(c.param_sets):
         p = abi.default_params(ksize=c.k, trace=1, **kw)
         a = O.align(go, p, seq, off)
-        b = E.align(g, T, p, seq, off, grid_k1=1 + i, grid_pair=2 + 3 * i)
         co = np.zeros(g.ntrkmers, np.uint64)
         np.add.at(co, order, a["counts_file"])
-        assert (co == b["counts"]).all()
-        assert (a["kmc"] == b["kmc"]).all() and (a["nmapread"] == b["nmapread"]).all()
-        assert (a["counters"] == b["counters"]).all(), (a["counters"], b["counters"])
-        d = bind.recs_equal(a["recs"], b["recs"], c.reads.npairs)
-        assert d < 0, f"{bind.rec_str(a['recs'][d])}\n{bind.rec_str(b['recs'][d])}"
+        for mode in ((1, 0) if E.consistent(T) else (0,)):  # fused-aux path and the general class-table path
+            E.set_consistent(T, mode)
+            b = E.align(g, T, p, seq, off, grid_k1=1 + i, grid_pair=2 + 3 * i)
+            assert (co == b["counts"]).all()
+            assert (a["kmc"] == b["kmc"]).all() and (a["nmapread"] == b["nmapread"]).all()
+            assert (a["counters"] == b["counters"]).all(), (a["counters"], b["counters"])
+            d = bind.recs_equal(a["recs"], b["recs"], c.reads.npairs)
+            assert d < 0, f"{bind.rec_str(a['recs'][d])}\n{bind.rec_str(b['recs'][d])}"
+        E.set_consistent(T, 1 if case != "inconsistent" else 0)
     E.L.emu_tables_free(T)
     O.free(go)
     g.close()
+
+
+def test_assign_bits_equals_literal_scan(E):
+    """The mask form of assignTRkmc used by the kernels vs the literal restatement of AQ.cpp:1470-1555."""
+    assert E.selftest_assign(7, 400000) == 0
 
 
 @pytest.mark.parametrize("name", sorted(GOLD))

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of k_pair from the -DDBTK_STAMPS build
+(make -C danbing-tk_amd/csrc stamps).  Read the SHARES, not the run time."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("danbing-tk_amd")
+abi = pkg.abi
+NAMES = ["ticket", "-", "-", "hit-buffer loads", "kfilter verdict", "gather", "rank sort", "dedup", "nml/single test",
+         "vote fast", "vote general", "states", "assign_bits", "accumulate", "-", "-"]
+
+
+def main():
+    nloci = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+    npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+    hit = float(sys.argv[3]) if len(sys.argv) > 3 else 0.02
+    lib = pkg.Dbtk(os.path.join(ROOT, "danbing-tk_amd", "libdbtk_hip_stamps.so"))
+    lib.L.dbtk_debug_stamps.argtypes = [C.c_void_p, abi.u64p]
+    syn = pkg.Synth(nloci=nloci)
+    a = syn.arrays()
+    h = C.c_void_p()
+    lib._chk(lib.L.dbtk_rpgg_from_arrays(C.byref(a), C.byref(h)))
+    g = pkg.Rpgg(lib, h)
+    p = abi.default_params(cthreshold=45, okam=0)
+    ctx = lib.context(g, p)
+    seq, off = syn.reads(npairs, hit_frac=hit)
+    for _ in range(3):
+        ctx.align(seq, off)
+    st = np.zeros(16, np.uint64)
+    lib.L.dbtk_debug_stamps(ctx.h, st.ctypes.data_as(abi.u64p))
+    tot = float(st.sum())
+    r = ctx.counts()["counters"]
+    print(f"survivors/step {r[abi.C_SURVIVORS] / 3:.0f}  kernels {ctx.kernel_times()}")
+    for n, v in zip(NAMES, st):
+        if v:
+            print(f"{n:18s} {100 * float(v) / tot:6.2f} %   {float(v) / (r[abi.C_SURVIVORS]):10.0f} cycles/pair")
+
+
+if __name__ == "__main__":
+    main()
