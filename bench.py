@@ -116,16 +116,21 @@ def main():
     ctx.synchronize()
     ctx.reset()
     ctx.timers_reset()
+    if os.environ.get("DBTK_NO_TIMERS"):  # diagnostic: cost of the per-kernel event records themselves
+        ctx.timers_enable(False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     ctx.synchronize()
-    ktimes = ctx.kernel_times()      # before the reduce: per-rank counters for the roofline
-    local = ctx.counts()
+    if world > 1:  # per-rank work counters, before the reduce sums them over ranks (96 B device->host)
+        local_ctr = ctx.counters()
     reduce_counts()
     barrier()
     dt = time.perf_counter() - t0
+    ktimes = ctx.kernel_times()      # HIP events recorded inside the timed region, read after it
+    if world == 1:
+        local_ctr = ctx.counters()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -134,7 +139,7 @@ def main():
     value = total_reads / dt
 
     # ---- roofline of the dominant kernel (this rank): algorithmic bytes of SURVEY.md 8(d) per launch
-    ctr = local["counters"].astype(np.float64)  # totals over the timed steps
+    ctr = local_ctr.astype(np.float64)  # totals over the timed steps
     alg = {
         # every read byte once + 12 B per subfilter probe
         "k_encode_subfilter": ctr[abi.C_BASES] + 12.0 * (ctr[abi.C_ALGO_PROBES] - ctr[abi.C_NHASH1]),

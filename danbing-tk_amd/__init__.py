@@ -150,6 +150,11 @@ class Context:
         self._lib._chk(self._lib.L.dbtk_ctx_counts(self.h, _ptr(counts, u64p), _ptr(kmc, u64p), _ptr(nmap, u32p), _ptr(ctr, u64p)))
         return dict(counts=counts, kmc=kmc, nmapread=nmap, counters=ctr)
 
+    def counters(self):
+        ctr = np.zeros(abi.C_COUNT, np.uint64)
+        self._lib._chk(self._lib.L.dbtk_ctx_counts(self.h, None, None, None, _ptr(ctr, u64p)))
+        return ctr
+
     def accum_buffer(self):
         base = C.c_void_p()
         n = C.c_uint64()
@@ -169,6 +174,9 @@ class Context:
 
     def timers_reset(self):
         self._lib.L.dbtk_ctx_timers_reset(self.h)
+
+    def timers_enable(self, on=True):
+        self._lib.L.dbtk_ctx_timers_enable(self.h, int(on))
 
     def close(self):
         if self.h:
@@ -204,6 +212,7 @@ class Dbtk(_HostSide):
         L.dbtk_ctx_kernel_times.restype = C.c_int
         L.dbtk_ctx_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), u64p, C.c_int]
         L.dbtk_ctx_timers_reset.argtypes = [C.c_void_p]
+        L.dbtk_ctx_timers_enable.argtypes = [C.c_void_p, C.c_int]
         L.dbtk_allreduce.restype = C.c_int
         L.dbtk_allreduce.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         if L.dbtk_abi_version() != abi.ABI_VERSION:
@@ -222,7 +231,7 @@ EXPORTS = [
     "dbtk_rpgg_load", "dbtk_rpgg_from_arrays", "dbtk_rpgg_free", "dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys",
     "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
-    "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_write_outputs", "dbtk_last_error", "dbtk_abi_version",
+    "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_write_outputs", "dbtk_last_error", "dbtk_abi_version",
 ]
 
 

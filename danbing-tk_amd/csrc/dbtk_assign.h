@@ -68,11 +68,11 @@ DBTK_HD Bits256 b_clear_lowest(const Bits256& a) {
     return r;
 }
 
-// K, R: masks over positions [0, nk); R subset of K.  ntr: number of TR states
-// reduced to uint8_t (AQ.cpp:1454).  r.rm on entry = the mate is already removed.
-DBTK_HD void assign_bits(Bits256 K, Bits256 R, int nk, uint32_t ntr, const dbtk_params_t& P, MateState& r) {
-    if (r.rm) { r.nt = -1; r.bs = -1; r.ti = -1; return; }
-    // fill-forward: Fv[i] = TR bit of the last known position <= i, Fm[i] = such a position exists
+// Transition mask by log-step fill-forward on the masks alone (used by the self-test and as the
+// definition the wave-scan form in k_pair must reproduce): T[i] = position i is known, a known
+// position exists before it, and the last such position has the other state.
+DBTK_HD Bits256 transitions_from_masks(const Bits256& K, const Bits256& R) {
+    // Fv[i] = TR bit of the last known position <= i, Fm[i] = such a position exists
     Bits256 Fv = R, Fm = K;
 #pragma unroll
     for (int d = 1; d < 256; d <<= 1) {
@@ -83,9 +83,17 @@ DBTK_HD void assign_bits(Bits256 K, Bits256 R, int nk, uint32_t ntr, const dbtk_
         for (int i = 0; i < 4; ++i) { Fm.w[i] |= sm.w[i]; }
     }
     const Bits256 pv = b_shl(Fv, 1), pm = b_shl(Fm, 1);
-    Bits256 T;  // transitions: known position whose state differs from the last known state before it
+    Bits256 T;
 #pragma unroll
     for (int i = 0; i < 4; ++i) T.w[i] = K.w[i] & pm.w[i] & (R.w[i] ^ pv.w[i]);
+    return T;
+}
+
+// K, R: masks over positions [0, nk); R subset of K; T: the transition mask.  ntr: number of TR
+// states reduced to uint8_t (AQ.cpp:1454).  r.rm on entry = the mate is already removed.
+DBTK_HD void assign_masks(const Bits256& K, const Bits256& R, const Bits256& T, int nk, uint32_t ntr, const dbtk_params_t& P,
+                          MateState& r) {
+    if (r.rm) { r.nt = -1; r.bs = -1; r.ti = -1; return; }
     const int ntot = b_popc(T);
     const int i0 = b_first(K);
     r.bs = (i0 < 256) ? (b_test(R, i0) ? 2 : 1) : 0;
@@ -120,6 +128,11 @@ DBTK_HD void assign_bits(Bits256 K, Bits256 R, int nk, uint32_t ntr, const dbtk_
         r.si_ = ei1 >= 0 ? ei1 : ti1;
         r.ei_ = si2 >= 0 ? si2 : ti2;
     }
+}
+
+DBTK_HD void assign_bits(Bits256 K, Bits256 R, int nk, uint32_t ntr, const dbtk_params_t& P, MateState& r) {
+    const Bits256 T = transitions_from_masks(K, R);
+    assign_masks(K, R, T, nk, ntr, P, r);
 }
 
 }  // namespace dbtk

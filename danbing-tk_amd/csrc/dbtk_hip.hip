@@ -27,7 +27,14 @@ struct DevX {
     __device__ uint32_t bid() const { return blockIdx.x; }
     __device__ uint32_t nblocks() const { return gridDim.x; }
     __device__ int lane() const { return (int)(threadIdx.x & 63); }
-    __device__ void sync() const { __syncthreads(); }
+    // Every kernel here runs ONE wavefront per block, so "sync" only has to order this wave's own
+    // LDS traffic: a wavefront-scope fence (compiler ordering; the LDS executes a wave's operations
+    // in order) instead of __syncthreads(), whose s_waitcnt vmcnt(0) would drain the prefetched loads
+    // and the fire-and-forget count atomics at every phase boundary.
+    __device__ void sync() const {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     __device__ uint64_t ballot(bool p) const { return __ballot(p); }
     // wave-uniform results are returned through readfirstlane/readlane so that the compiler keeps
     // them (and every loop bound, length and flag derived from them) in SGPRs with scalar branches
@@ -53,6 +60,15 @@ struct DevX {
             out[j] = ((uint64_t)hi << 32) | lo;
         }
     }
+    __device__ uint32_t wave_scan_lastnz(uint32_t v) const {  // inclusive scan, op(a, b) = b ? b : a
+        const int l = (int)(threadIdx.x & 63);
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(v, o, 64);
+            if (l >= o && v == 0) v = t;
+        }
+        return v;
+    }
+    __device__ uint32_t shfl_up1(uint32_t v) const { return __shfl_up(v, 1, 64); }
     __device__ uint32_t bcast(uint32_t v, int src) const {  // src must be wave-uniform
         return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
     }
@@ -142,6 +158,9 @@ struct dbtk_ctx {
     uint64_t* d_off = nullptr; uint64_t off_cap = 0;
     dbtk_pair_rec_t* d_recs = nullptr; uint64_t rec_cap = 0;
     HitEnt* d_hit = nullptr; uint64_t hit_cap = 0;
+    uint32_t* d_tickets = nullptr; uint64_t tickets_cap = 0;
+    int k1_blocks = 0;
+    bool timers_on = true;
     uint64_t* d_vote = nullptr;
     uint32_t* d_epoch = nullptr;
     int pair_blocks = 0, num_cu = 0;
@@ -167,7 +186,7 @@ void free_ctx(dbtk_ctx* c) {
             if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
         }
     void* ptrs[] = {c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
-                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hit};
+                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hit, c->d_tickets};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -300,55 +319,61 @@ dbtk_status_t timed_slot(dbtk_ctx* c, int k, int* slot) {
     return DBTK_OK;
 }
 
-// K1 -> K2 -> K3 over reads already in HBM.  Large batches are cut into sub-batches so that the
-// K2 -> K3 hit buffer stays bounded; batch boundaries never change results (all effects are additive).
-constexpr uint64_t SUB_PAIRS = 1ull << 21;
+// K1 over the whole batch, then K2 -> K3 over chunks of the survivor list (the K2 -> K3 hit
+// buffer holds SURV_CAP pairs).  How many survivors there are is known only on the device, so
+// ceil(npairs / SURV_CAP) chunk iterations are enqueued and the kernels of a chunk past the end
+// of the list exit at once; nothing waits for the host.
+constexpr uint64_t SURV_CAP = 1ull << 20;
+constexpr uint32_t SMALL_WORDS = 64;  // d_small: nsurv, tile ticket, nrec, errflag, [8..] per-chunk tickets, stamps at +32
 
 dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_off, uint64_t seq_len, uint64_t npairs,
                            uint32_t max_read_len, dbtk_pair_rec_t* d_recs, uint32_t rec_cap) {
     hipStream_t s = c->stream;
     if (npairs >= 0xFFFFFFFFull) { set_error("batch too large (pair index is 32-bit)"); return DBTK_ERR_ARG; }
-    const uint64_t sub = npairs < SUB_PAIRS ? npairs : SUB_PAIRS;
+    if (npairs == 0) return DBTK_OK;
     const uint32_t k = c->g->ksize;
     const uint32_t nkmax = max_read_len >= k ? max_read_len - k + 1 : 1;
     const uint32_t nkp = 64 * ((nkmax + 63) / 64);
-    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, sub + 1);
+    const uint64_t tcap = npairs < SURV_CAP ? npairs : SURV_CAP;
+    const uint64_t nchunks = (npairs + tcap - 1) / tcap;
+    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, npairs + 1);
     if (st) return st;
-    if ((st = ensure(&c->d_hit, &c->hit_cap, sub * 2 * nkp))) return st;
-    HIPCHK(hipMemsetAsync(c->d_small + 2, 0, 2 * sizeof(uint32_t), s));  // nrec, errflag: once per batch
-    for (uint64_t p0 = 0; p0 < npairs; p0 += sub) {
-        const uint64_t np = npairs - p0 < sub ? npairs - p0 : sub;
-        HIPCHK(hipMemsetAsync(c->d_small, 0, 2 * sizeof(uint32_t), s));  // nsurv, ticket
-        BatchArgs a;
-        memset(&a, 0, sizeof(a));
-        a.T = c->T; a.P = c->P;
-        a.seq = d_seq; a.off = d_off + 2 * p0; a.seq_len = seq_len; a.npairs = np;
-        a.surv = c->d_surv; a.nsurv = c->d_small + 0; a.ticket = c->d_small + 1; a.nrec = c->d_small + 2; a.errflag = c->d_small + 3;
-        a.counts = c->d_accum;
-        a.kmc = c->d_accum + c->ntr;
-        a.nmapread = a.kmc + c->g->nloci;
-        a.counters = a.nmapread + c->g->nloci;
-        a.recs = d_recs; a.rec_cap = rec_cap;
-        a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
-        a.hitbuf = c->d_hit; a.nkp = nkp; a.pair_base = (uint32_t)p0;
+    if ((st = ensure(&c->d_hit, &c->hit_cap, tcap * 2 * nkp))) return st;
+    if ((st = ensure(&c->d_tickets, &c->tickets_cap, nchunks + 1))) return st;
+    HIPCHK(hipMemsetAsync(c->d_small, 0, 8 * sizeof(uint32_t), s));
+    HIPCHK(hipMemsetAsync(c->d_tickets, 0, (nchunks + 1) * sizeof(uint32_t), s));
+    BatchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.T = c->T; a.P = c->P;
+    a.seq = d_seq; a.off = d_off; a.seq_len = seq_len; a.npairs = npairs;
+    a.surv = c->d_surv; a.nsurv = c->d_small + 0; a.tile_ticket = c->d_small + 1; a.nrec = c->d_small + 2; a.errflag = c->d_small + 3;
+    a.counts = c->d_accum;
+    a.kmc = c->d_accum + c->ntr;
+    a.nmapread = a.kmc + c->g->nloci;
+    a.counters = a.nmapread + c->g->nloci;
+    a.recs = d_recs; a.rec_cap = rec_cap;
+    a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
+    a.hitbuf = c->d_hit; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
 #ifdef DBTK_STAMPS
-        a.dbg = reinterpret_cast<uint64_t*>(c->d_small + 8);  // 16 u64 after the four counters
+    a.dbg = reinterpret_cast<uint64_t*>(c->d_small + 32);
 #endif
-        const uint64_t ntiles = (np + K1_TP - 1) / K1_TP;
-        const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->num_cu * 8 ? ntiles : (uint64_t)c->num_cu * 8);
-        int e[NKERN];
-        for (int i = 0; i < NKERN; ++i) if ((st = timed_slot(c, i, &e[i]))) return st;
-        HIPCHK(hipEventRecord(c->timed[0].beg[e[0]], s));
-        hipLaunchKernelGGL(k_encode_subfilter, dim3(g1), dim3(K1_NT), 0, s, a);
-        HIPCHK(hipEventRecord(c->timed[0].end[e[0]], s));
-        HIPCHK(hipEventRecord(c->timed[1].beg[e[1]], s));
+    const uint64_t ntiles = (npairs + K1_TP - 1) / K1_TP;
+    const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->k1_blocks ? ntiles : (uint64_t)c->k1_blocks);  // resident waves
+    int e = 0;
+    const bool tm = c->timers_on;
+    if (tm) { if ((st = timed_slot(c, 0, &e))) return st; HIPCHK(hipEventRecord(c->timed[0].beg[e], s)); }
+    hipLaunchKernelGGL(k_encode_subfilter, dim3(g1), dim3(K1_NT), 0, s, a);
+    if (tm) HIPCHK(hipEventRecord(c->timed[0].end[e], s));
+    for (uint64_t ch = 0; ch < nchunks; ++ch) {
+        a.t0 = (uint32_t)(ch * tcap);
+        a.ticket = c->d_tickets + ch;
+        if (tm) { if ((st = timed_slot(c, 1, &e))) return st; HIPCHK(hipEventRecord(c->timed[1].beg[e], s)); }
         hipLaunchKernelGGL(k_probe, dim3(c->num_cu * 32), dim3(64), 0, s, a);
-        HIPCHK(hipEventRecord(c->timed[1].end[e[1]], s));
-        HIPCHK(hipEventRecord(c->timed[2].beg[e[2]], s));
+        if (tm) { HIPCHK(hipEventRecord(c->timed[1].end[e], s)); if ((st = timed_slot(c, 2, &e))) return st; HIPCHK(hipEventRecord(c->timed[2].beg[e], s)); }
         hipLaunchKernelGGL(k_pair, dim3(c->pair_blocks), dim3(64), 0, s, a);
-        HIPCHK(hipEventRecord(c->timed[2].end[e[2]], s));
-        HIPCHK(hipGetLastError());
+        if (tm) HIPCHK(hipEventRecord(c->timed[2].end[e], s));
     }
+    HIPCHK(hipGetLastError());
     return DBTK_OK;
 }
 
@@ -378,6 +403,12 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free_ctx(c); set_error("hipGetDeviceProperties failed"); return DBTK_ERR_HIP; }
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->pair_blocks = c->num_cu * 8;
+    {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_subfilter, K1_NT, 0) != hipSuccess || nb <= 0) nb = 4;
+        c->k1_blocks = c->num_cu * nb;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pair, 64, 0) == hipSuccess && nb > 0) c->pair_blocks = c->num_cu * nb;
+    }
     dbtk_status_t st = DBTK_OK;
     do {
         if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); st = DBTK_ERR_HIP; break; }
@@ -393,8 +424,8 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         c->n_accum = c->ntr + 2 * h->nloci + DBTK_C_COUNT;
         auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && !st) { set_error(std::string(what) + ": " + hipGetErrorString(e)); st = DBTK_ERR_HIP; } };
         chk(hipMalloc(&c->d_accum, c->n_accum * 8), "hipMalloc accum");
-        chk(hipMalloc(&c->d_small, 256), "hipMalloc small");
-        if (!st) chk(hipMemsetAsync(c->d_small, 0, 256, c->stream), "memset");
+        chk(hipMalloc(&c->d_small, 4 * SMALL_WORDS + 32 * 8), "hipMalloc small");
+        if (!st) chk(hipMemsetAsync(c->d_small, 0, 4 * SMALL_WORDS + 32 * 8, c->stream), "memset");
         chk(hipMalloc(&c->d_vote, (size_t)c->pair_blocks * (h->nloci + 1) * 8), "hipMalloc vote scratch");
         chk(hipMalloc(&c->d_epoch, (size_t)c->pair_blocks * 4), "hipMalloc epoch");
         if (st) break;
@@ -538,9 +569,13 @@ int dbtk_ctx_kernel_times(dbtk_ctx_t* c, const char** names, double* total_ms, u
 int dbtk_debug_stamps(dbtk_ctx_t* c, uint64_t* out16) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    return (int)hipMemcpy(out16, c->d_small + 8, 16 * 8, hipMemcpyDeviceToHost);
+    return (int)hipMemcpy(out16, c->d_small + 32, 32 * 8, hipMemcpyDeviceToHost);
 }
 #endif
+
+void dbtk_ctx_timers_enable(dbtk_ctx_t* c, int on) {
+    if (c) c->timers_on = on != 0;
+}
 
 void dbtk_ctx_timers_reset(dbtk_ctx_t* c) {
     if (!c) return;

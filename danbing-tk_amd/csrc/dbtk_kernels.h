@@ -9,6 +9,7 @@
 //
 // X provides: tid() nthreads() bid() nblocks() lane() sync() ballot(bool)
 //   wave_sum(u32) wave_excl_scan(u32) bcast(u32, srclane) shfl_xor64<E>(in[E], out[E], lanemask)
+//   wave_scan_lastnz(u32): inclusive scan with op(a, b) = b ? b : a;  shfl_up1(u32): value of lane - 1
 //   uni(u32: value known to be wave-uniform)
 //   atomic_add(u64*,u64) atomic_add(u32*,u32)->old atomic_cas(u64*,exp,des)->old
 //   atomic_max(u64*,u64) atomic_or(u64*,u64) lds_add(u32*,u32)->old lds_or(u32*,u32)
@@ -160,14 +161,16 @@ struct BatchArgs {
     struct HitEnt* hitbuf;   // K2 -> K3: [survivor][mate][nkp] probe results
     uint32_t nkp;            // positions reserved per read in hitbuf (multiple of 64)
     uint32_t pair_base;      // index of this sub-batch's first pair inside the caller's batch (records)
+    uint32_t t0, tcap;       // K2/K3 work on survivors [t0, min(t0 + tcap, *nsurv)): the hit buffer holds tcap pairs
+    uint32_t* tile_ticket;   // K1 work counter (tiles)
 };
 
 // In-kernel stamps (cdna_hip_programming.md 7): only in the separate diagnostic
 // library built with -DDBTK_STAMPS; the product build compiles them away.
 #ifdef DBTK_STAMPS
-#define DBTK_STAMP_DECL uint64_t st_acc[16] = {0}; uint64_t st_last = x.clock();
+#define DBTK_STAMP_DECL uint64_t st_acc[32] = {0}; uint64_t st_last = x.clock();
 #define DBTK_STAMP(i) do { const uint64_t now_ = x.clock(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
-#define DBTK_STAMP_FLUSH do { if (lane == 0 && a.dbg) for (int i_ = 0; i_ < 16; ++i_) if (st_acc[i_]) x.atomic_add(&a.dbg[i_], st_acc[i_]); } while (0)
+#define DBTK_STAMP_FLUSH do { if (lane == 0 && a.dbg) for (int i_ = 0; i_ < 32; ++i_) if (st_acc[i_]) x.atomic_add(&a.dbg[i_], st_acc[i_]); } while (0)
 #else
 #define DBTK_STAMP_DECL
 #define DBTK_STAMP(i) do { } while (0)
@@ -191,22 +194,19 @@ DBTK_HD void write_early_rec(dbtk_pair_rec_t* r, uint32_t pair, uint32_t stage, 
 // ======================================================================= K1 =
 // encode + subfilter (read2kmers_edges' validity + subfilter,
 // src/aQueryFasta_thread.h:274-311, src/aQueryFasta_thread.cpp:172-188, 2035-2051).
-// A 256-thread block takes tiles of K1_TP consecutive pairs: the tile's bytes
-// are contiguous in the batch, so they are fetched with 16-byte coalesced loads
-// and packed straight into LDS (2 bits + 1 validity bit per base); the
-// N_FILTER sampled windows of mate 1 are probed by 4 lanes per pair, mate 2 only
-// for pairs whose mate 1 passed — the same probes the reference performs.
-constexpr int K1_NT = 256;
-constexpr int K1_TP = 64;                              // pairs per tile
+// One wavefront per block, no block barriers: a wave takes tiles of K1_TP = 16
+// consecutive pairs (their bytes are contiguous in the batch), fetches them with
+// coalesced 16-byte loads, packs them to 2 bits + 1 validity bit per base in its
+// LDS slice, and probes the N_FILTER sampled windows of mate 1 with 4 lanes per
+// pair (sample s on lane 4*pair + s%4); the group verdicts come from one ballot.
+// Mate 2 is probed only for pairs whose mate 1 passed — the probes the reference
+// performs.  Small footprint (3 KB LDS), so many waves per CU hide the probe latency.
+constexpr int K1_NT = 64;
+constexpr int K1_TP = 16;                              // pairs per tile
 constexpr int K1_CH = K1_TP * 2 * MAXL / 16 + 4;       // 16-base chunks per tile (+ slack)
 struct K1Smem {
     uint32_t pk[K1_CH];
     uint16_t vd[K1_CH];
-    uint32_t bpos[2 * K1_TP];  // stream position of each read's first base
-    uint16_t rlen[2 * K1_TP];
-    uint8_t any[2 * K1_TP];    // read has at least one valid k-mer window
-    uint32_t hm1[K1_TP], hm2[K1_TP];  // hit masks of the sampled positions
-    uint32_t cnt[8];           // block counters: nshort, nsub, nhash0, nprobe, nsurv, nbases
 };
 
 // true iff bases [b, b+len) of the stream contain a run of >= k valid bases
@@ -235,24 +235,29 @@ DBTK_HD bool any_valid_window(const uint16_t* vd, uint32_t b, uint32_t len, uint
 template <class X>
 DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     K1Smem& sm = *x.template smem<K1Smem>();
-    const int tid = x.tid();
+    const uint32_t lane = (uint32_t)x.lane();
     const uint32_t k = a.P.ksize, NF = a.P.n_filter, NM = a.P.nm_filter;
     const bool dosub = NF && NM;
-    if (tid < 8) sm.cnt[tid] = 0;
-    if (tid == 0 && x.bid() == 0) x.atomic_add(&a.counters[DBTK_C_NREADS], 2 * a.npairs);  // nReads, AQ.cpp:1977
-    x.sync();
-    for (uint64_t tile = x.bid(); tile * K1_TP < a.npairs; tile += x.nblocks()) {
+    const uint32_t grp = lane >> 2, sub = lane & 3;  // pair of the tile this lane works for, sample phase
+    uint64_t c_short = 0, c_sub = 0, c_nhash = 0, c_probe = 0, c_surv = 0, c_bases = 0;  // per-lane partial sums
+    if (lane == 0 && x.bid() == 0) x.atomic_add(&a.counters[DBTK_C_NREADS], 2 * a.npairs);  // nReads, AQ.cpp:1977
+    const uint64_t ntiles = (a.npairs + K1_TP - 1) / K1_TP;
+    const int lane_ = (int)lane; (void)lane_;
+    DBTK_STAMP_DECL
+    for (uint64_t tile = x.bid(); tile < ntiles; tile += x.nblocks()) {
         const uint64_t p0 = tile * K1_TP;
         const uint32_t np = (uint32_t)((a.npairs - p0 < (uint64_t)K1_TP) ? a.npairs - p0 : K1_TP);
         const uint64_t B0 = a.off[2 * p0], B1 = a.off[2 * (p0 + np)];
         const uint64_t A0 = B0 & ~15ull;
         const uint32_t nch = (uint32_t)((B1 - A0 + 15) >> 4);
         if (nch + 3 > (uint32_t)K1_CH) {  // a read longer than DBTK_MAX_READ_LEN slipped through
-            if (tid == 0) *a.errflag = DBTK_ERR_READ_TOO_LONG;
+            if (lane == 0) *a.errflag = DBTK_ERR_READ_TOO_LONG;
             continue;
         }
+        x.sync();  // the previous tile's LDS is dead
+        DBTK_STAMP(16);  // tile set-up (offset loads)
         // A: pack the tile
-        for (uint32_t c = tid; c < nch + 3; c += K1_NT) {
+        for (uint32_t c = lane; c < nch + 3; c += K1_NT) {
             uint32_t pk = 0, vd = 0;
             if (c < nch) {
                 const uint64_t g = A0 + 16ull * c;
@@ -272,49 +277,59 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
             sm.pk[c] = pk;
             sm.vd[c] = (uint16_t)vd;
         }
-        if (tid < K1_TP) { sm.hm1[tid] = 0; sm.hm2[tid] = 0; }
         x.sync();
-        // B: per-read geometry and "has a valid window" (caks.size() != 0, AQ.cpp:2037)
-        if ((uint32_t)tid < 2 * np) {
-            const uint64_t o0 = a.off[2 * p0 + tid], o1 = a.off[2 * p0 + tid + 1];
-            const uint32_t len = (uint32_t)(o1 - o0), b = (uint32_t)(o0 - A0);
-            sm.bpos[tid] = b;
-            sm.rlen[tid] = (uint16_t)len;
-            x.lds_add(&sm.cnt[5], len);
-            sm.any[tid] = any_valid_window(sm.vd, b, len, k);
+        DBTK_STAMP(17);  // loads + pack
+        // B: per-read geometry and "has a valid window" (caks.size() != 0, AQ.cpp:2037): lane r < 2*np owns read r
+        bool myany = false;
+        if (lane < 2 * np) {
+            const uint64_t o0 = a.off[2 * p0 + lane], o1 = a.off[2 * p0 + lane + 1];
+            const uint32_t len = (uint32_t)(o1 - o0);
+            myany = any_valid_window(sm.vd, (uint32_t)(o0 - A0), len, k);
+            c_bases += len;
         }
-        x.sync();
-        // C/D: sampled probes, 4 lanes per pair; mate index 0 = seq1 first
-        for (int mate = 0; mate < 2 && dosub; ++mate) {
-            const uint32_t j = (uint32_t)tid >> 2;
-            if (j < np && sm.any[2 * j] && sm.any[2 * j + 1]) {
-                bool go = true;
-                if (mate == 1) go = (uint32_t)__builtin_popcount(sm.hm1[j]) >= NM;
+        const uint64_t anym = x.ballot(myany);                       // bit r: read r has a window
+        const bool gvalid = grp < np;
+        const bool gany = gvalid && ((anym >> (2 * grp)) & 3) == 3;  // both mates of my pair
+        DBTK_STAMP(18);  // valid-window test
+        // C/D: sampled probes; hm[mate] = hit mask of the sampled positions of my pair (same on its 4 lanes)
+        uint32_t hm[2] = {0, 0};
+        if (dosub) {
+            for (int mate = 0; mate < 2; ++mate) {
+                const bool go = gany && (mate == 0 || (uint32_t)__builtin_popcount(hm[0]) >= NM);
+                if (mate == 1 && x.ballot(go) == 0) break;  // nobody's mate 1 passed: the usual case
+                uint32_t bpos = 0, L = 1, S = 0;
                 if (go) {
-                    const uint32_t r = 2 * j + mate;
-                    const uint32_t L = sm.rlen[r] - k + 1, S = L / (NF - 1);
-                    for (uint32_t s = (uint32_t)tid & 3; s < NF; s += 4) {
-                        const uint32_t pos = (s != NF - 1) ? s * S : L - 1;
-                        const uint64_t km = window_kmer(sm.pk, sm.vd, sm.bpos[r] + pos, k, nullptr, nullptr);
-                        if (km != NAN64 && idx_lookup(a.T, km) != NOHIT) x.lds_or(mate ? &sm.hm2[j] : &sm.hm1[j], 1u << s);
+                    const uint64_t o0 = a.off[2 * (p0 + grp) + mate], o1 = a.off[2 * (p0 + grp) + mate + 1];
+                    bpos = (uint32_t)(o0 - A0);
+                    L = (uint32_t)(o1 - o0) - k + 1;
+                    S = L / (NF - 1);
+                }
+                for (uint32_t s0 = 0; s0 < NF; s0 += 4) {
+                    const uint32_t sidx = s0 + sub;
+                    bool hit = false;
+                    if (go && sidx < NF) {
+                        const uint32_t pos = (sidx != NF - 1) ? sidx * S : L - 1;
+                        const uint64_t km = window_kmer(sm.pk, sm.vd, bpos + pos, k, nullptr, nullptr);
+                        hit = km != NAN64 && idx_lookup(a.T, km) != NOHIT;
                     }
+                    const uint64_t hb = x.ballot(hit);
+                    hm[mate] |= (uint32_t)((hb >> (4 * grp)) & 0xF) << s0;
                 }
             }
-            x.sync();
         }
-        // E: verdicts
-        if ((uint32_t)tid < np) {
-            const uint32_t j = tid;
-            const uint32_t pair = (uint32_t)(p0 + j);
+        DBTK_STAMP(19);  // sampled probes
+        // E: verdicts, one lane per pair
+        bool pass = false;
+        if (gvalid && sub == 0) {
             uint32_t stage = 0xFFFFFFFFu;
-            if (!sm.any[2 * j] || !sm.any[2 * j + 1]) {
+            if (!gany) {
                 stage = DBTK_STAGE_SHORT;
-                x.lds_add(&sm.cnt[0], 1);
+                ++c_short;
             } else if (dosub) {
                 uint32_t nhash = 0, nprobe = 0, h = 0;
                 bool brk = false;
                 for (uint32_t i = 0; i < NF; ++i) {  // AQ.cpp:176-180: ++nhash only when the loop continues
-                    h += (sm.hm1[j] >> i) & 1; ++nprobe;
+                    h += (hm[0] >> i) & 1; ++nprobe;
                     if (h >= NM) { brk = true; break; }
                     ++nhash;
                 }
@@ -322,33 +337,49 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                 if (!rej) {
                     h = 0; brk = false;
                     for (uint32_t i = 0; i < NF; ++i) {
-                        h += (sm.hm2[j] >> i) & 1; ++nprobe;
+                        h += (hm[1] >> i) & 1; ++nprobe;
                         if (h >= NM) { brk = true; break; }
                         ++nhash;
                     }
                     rej = !brk;
                 }
-                x.lds_add(&sm.cnt[2], nhash);
-                x.lds_add(&sm.cnt[3], nprobe);
-                if (rej) { stage = DBTK_STAGE_SUBFILTER; x.lds_add(&sm.cnt[1], 2); }
+                c_nhash += nhash; c_probe += nprobe;
+                if (rej) { stage = DBTK_STAGE_SUBFILTER; c_sub += 2; }
             }
-            if (stage == 0xFFFFFFFFu) {
-                const uint32_t at = x.atomic_add(a.nsurv, 1u);
-                a.surv[at] = pair;
-                x.lds_add(&sm.cnt[4], 1);
-            } else if (a.P.trace && a.recs) {
-                write_early_rec(&a.recs[pair + a.pair_base], pair + a.pair_base, stage, a.T.nloci);
+            pass = stage == 0xFFFFFFFFu;
+            if (!pass && a.P.trace && a.recs) {
+                const uint32_t pair = (uint32_t)(p0 + grp) + a.pair_base;
+                write_early_rec(&a.recs[pair], pair, stage, a.T.nloci);
             }
         }
-        x.sync();
+        const uint64_t pm = x.ballot(pass);
+        if (pm) {  // survivors of the tile: one atomic for the wave, kept in pair order
+            uint32_t base = 0;
+            if (lane == 0) base = x.atomic_add(a.nsurv, (uint32_t)__builtin_popcountll(pm));
+            base = x.bcast(base, 0);
+            if (pass) {
+                a.surv[base + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1))] = (uint32_t)(p0 + grp);
+                ++c_surv;
+            }
+        }
+        DBTK_STAMP(20);  // verdict + survivor append
     }
-    if (tid == 0) {
-        if (sm.cnt[0]) x.atomic_add(&a.counters[DBTK_C_NSHORT], (uint64_t)sm.cnt[0]);
-        if (sm.cnt[1]) x.atomic_add(&a.counters[DBTK_C_SUBFILTERED], (uint64_t)sm.cnt[1]);
-        if (sm.cnt[2]) x.atomic_add(&a.counters[DBTK_C_NHASH0], (uint64_t)sm.cnt[2]);
-        if (sm.cnt[3]) x.atomic_add(&a.counters[DBTK_C_ALGO_PROBES], (uint64_t)sm.cnt[3]);
-        if (sm.cnt[4]) x.atomic_add(&a.counters[DBTK_C_SURVIVORS], (uint64_t)sm.cnt[4]);
-        if (sm.cnt[5]) x.atomic_add(&a.counters[DBTK_C_BASES], (uint64_t)sm.cnt[5]);
+    {
+        const int lane = lane_;
+        DBTK_STAMP_FLUSH;
+    }
+    // flush: wave sums, one atomic each
+    const uint32_t s_short = x.wave_sum((uint32_t)c_short), s_sub = x.wave_sum((uint32_t)c_sub), s_surv = x.wave_sum((uint32_t)c_surv);
+    const uint32_t s_nhash = x.wave_sum((uint32_t)c_nhash), s_probe = x.wave_sum((uint32_t)c_probe);
+    const uint32_t b_lo = x.wave_sum((uint32_t)(c_bases & 0xFFFFF)), b_hi = x.wave_sum((uint32_t)(c_bases >> 20));
+    if (lane == 0) {
+        if (s_short) x.atomic_add(&a.counters[DBTK_C_NSHORT], (uint64_t)s_short);
+        if (s_sub) x.atomic_add(&a.counters[DBTK_C_SUBFILTERED], (uint64_t)s_sub);
+        if (s_nhash) x.atomic_add(&a.counters[DBTK_C_NHASH0], (uint64_t)s_nhash);
+        if (s_probe) x.atomic_add(&a.counters[DBTK_C_ALGO_PROBES], (uint64_t)s_probe);
+        if (s_surv) x.atomic_add(&a.counters[DBTK_C_SURVIVORS], (uint64_t)s_surv);
+        const uint64_t bases = (uint64_t)b_lo + ((uint64_t)b_hi << 20);
+        if (bases) x.atomic_add(&a.counters[DBTK_C_BASES], bases);
     }
 }
 
@@ -357,15 +388,27 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
 constexpr int LCAP = 512;        // per-pair locus map in LDS (vote); spills to vote_scratch
 constexpr int LLIMIT = 384;
 constexpr int NSLOT = NKMAX / 64;  // k-mer positions per lane per mate
+constexpr int NBKT = 256;          // buckets of the hit-list sort (top 8 bits of the k-mer: monotone in the key)
 struct PairSmem {
     uint32_t hval[2][NKMAX];   // index val by read position (NOHIT = not in the index)
     union {
         struct { uint64_t skey[NHMAX]; uint16_t sinfo[NHMAX]; } s;                     // hit list being sorted
         struct { uint32_t nml[NHMAX]; uint32_t lkey[LCAP]; uint16_t ord[NHMAX]; } v;    // vote phase
     } u;
-    uint32_t uval[NHMAX];      // unique k-mers in ascending key order: index val
-    uint32_t dd[NHMAX];        // PE_KMC dup: count in mate 0 | count in mate 1 << 16
-    uint32_t lhit[LCAP];
+    union {
+        struct {
+            uint32_t uval[NHMAX];  // unique k-mers in ascending key order: index val
+            uint32_t dd[NHMAX];    // PE_KMC dup: count in mate 0 | count in mate 1 << 16
+            uint32_t lhit[LCAP];
+            uint16_t poff[NHMAX];  // vote: where a multi-locus k-mer's loci sit in the LDS pool (0xFFFF: read vv in HBM)
+        } a;
+        struct {                   // bucket sort of the hit list (before any of the above is live)
+            uint64_t tmpk[NHMAX];
+            uint16_t tmpi[NHMAX];
+            uint32_t cnt[NBKT];
+            uint16_t bst[NBKT];
+        } b;
+    } w;
     int stack[3 * 40];
     int32_t res[8];            // vote result
     int32_t mres[2][12];       // per-mate assign results
@@ -468,8 +511,10 @@ DBTK_HD bool get_acm1(uint64_t fc, uint64_t rc, uint64_t rem, uint64_t cth) {  /
 
 // find_matching_locus (src/aQueryFasta_thread.cpp:364-422) on the permuted
 // unique list, general form (any number of loci per k-mer); lane 0 only.
+// Loci of multi-locus k-mers come from `pool` (LDS, filled in parallel beforehand) at poff[u]
+// when they fit there (poff[u] != 0xFFFF), else straight from vv in HBM.
 DBTK_HD void vote(const DevTables& T, const uint16_t* ord, const uint32_t* uval, const uint32_t* dd, int nu, uint32_t cth,
-                  HitMap& hm, Asgn& top, uint64_t& nvvw) {
+                  HitMap& hm, Asgn& top, uint64_t& nvvw, const uint32_t* nml, const uint32_t* pool, const uint16_t* poff) {
     Asgn second{NAN32, 0, 0};
     top = Asgn{NAN32, 0, 0};
     uint64_t total = 0;
@@ -481,10 +526,11 @@ DBTK_HD void vote(const DevTables& T, const uint16_t* ord, const uint32_t* uval,
         const uint32_t add = d1 | (d2 << 16);
         rem -= d1 + d2;
         if (vi & 1) {
-            const uint32_t n = T.vv[vi >> 1];
+            const uint32_t n = nml[u];
+            const bool inl = poff[u] != 0xFFFFu;
             nvvw += 1 + n;
             for (uint32_t j = 0; j < n; ++j) {
-                const uint32_t locus = T.vv[(vi >> 1) + 1 + j];
+                const uint32_t locus = inl ? pool[poff[u] + j] : T.vv[(vi >> 1) + 1 + j];
                 const uint32_t h = hitmap_add(hm, locus, add);
                 updatetop2(h & 0xFFFF, locus, h >> 16, top, second);
             }
@@ -502,11 +548,13 @@ DBTK_HD void vote(const DevTables& T, const uint16_t* ord, const uint32_t* uval,
                 const uint32_t e1 = dd[uj] & 0xFF, e2 = (dd[uj] >> 16) & 0xFF;
                 remj -= e1 + e2;
                 if (vj & 1) {
-                    const uint32_t n = T.vv[vj >> 1];
+                    const uint32_t n = nml[uj];
+                    const bool inl = poff[uj] != 0xFFFFu;
                     nvvw += 1;
                     for (uint32_t q = 0; q < n; ++q) {
                         nvvw += 1;
-                        if (T.vv[(vj >> 1) + 1 + q] == top.idx) { top.fc += e1; top.rc += e2; break; }
+                        const uint32_t locus = inl ? pool[poff[uj] + q] : T.vv[(vj >> 1) + 1 + q];
+                        if (locus == top.idx) { top.fc += e1; top.rc += e2; break; }
                     }
                 } else if ((vj >> 1) == top.idx) {
                     top.fc += e1; top.rc += e2;
@@ -556,47 +604,6 @@ DBTK_HD uint32_t vote_single_locus(X& x, const uint16_t* perm_row, const uint32_
     return mB ? res : tot2;  // loop ran off the end: every k-mer was added
 }
 
-// Bitonic sort of N = 64 * E composite keys held E per lane (element e = lane * E + j), ascending.
-// Strides below E are compare-exchanges inside a lane's registers; larger strides exchange with
-// lane ^ (stride / E) through the cross-lane network (ds_bpermute, no memory).  ~1.6 k VALU for
-// N = 512 against ~8 k for the O(n^2 / 64) rank sort it replaces.
-template <int E, class X>
-DBTK_HD void bitonic_sort(X& x, uint64_t (&v)[E]) {
-    const uint32_t lane = (uint32_t)x.lane();
-    constexpr int N = 64 * E;
-#pragma unroll
-    for (int size = 2; size <= N; size <<= 1) {
-#pragma unroll
-        for (int d = size >> 1; d > 0; d >>= 1) {
-            if (d >= E) {
-                const uint32_t ld = (uint32_t)(d / E);
-                const bool lower = (lane & ld) == 0;
-                const bool asc = size >= N ? true : (((lane * E) & (uint32_t)size) == 0);
-                const bool keep_min = lower == asc;
-                uint64_t o[E];
-                x.template shfl_xor64<E>(v, o, (int)ld);  // partner lane's E keys
-#pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    const bool take = keep_min ? (o[j] < v[j]) : (o[j] > v[j]);
-                    v[j] = take ? o[j] : v[j];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    if ((j & d) == 0) {
-                        // ascending block iff bit `size` of the element index is clear
-                        const bool asc = size >= N ? true : (size >= E ? (((lane * E) & (uint32_t)size) == 0) : ((j & size) == 0));
-                        const uint64_t a0 = v[j], b0 = v[j | d];
-                        const bool sw = asc ? (b0 < a0) : (a0 < b0);
-                        v[j] = sw ? b0 : a0;
-                        v[j | d] = sw ? a0 : b0;
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ======================================================================= K2 =
 // kfilter's probes (src/aQueryFasta_thread.cpp:204-209, 215-220) as a kernel of
 // their own: one wavefront per surviving READ, tiny footprint (0.5 KB LDS), so
@@ -625,9 +632,11 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
     const int lane = x.lane();
     const DevTables& T = a.T;
     const uint32_t k = T.ksize;
-    const uint32_t nitems = 2 * *a.nsurv;
+    const uint32_t ns = *a.nsurv;
+    const uint32_t tend = ns - a.t0 < a.tcap ? ns : a.t0 + a.tcap;  // (ns >= t0 checked by the caller loop below)
+    const uint32_t nitems = ns > a.t0 ? 2 * (tend - a.t0) : 0;
     for (uint32_t it = x.bid(); it < nitems; it += x.nblocks()) {
-        const uint32_t t = it >> 1, m = it & 1;
+        const uint32_t t = a.t0 + (it >> 1), m = it & 1;
         const uint32_t pair = a.surv[t];
         const uint64_t o0 = a.off[2 * (uint64_t)pair + m], o1 = a.off[2 * (uint64_t)pair + m + 1];
         uint32_t len = (uint32_t)(o1 - o0);
@@ -716,17 +725,30 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     uint64_t c_kf = 0, c_hf = 0, c_qc = 0, c_thr = 0, c_feas = 0, c_asgn = 0, c_nhash1 = 0, c_vv = 0, c_cls = 0, c_inc = 0;
     DBTK_STAMP_DECL
     const uint32_t nsurv = *a.nsurv;
+    const uint32_t tend = (nsurv > a.t0 && nsurv - a.t0 < a.tcap) ? nsurv : a.t0 + a.tcap;
+    const uint32_t nslp = a.nkp >> 6;  // slots the hit buffer reserves per read
+
+    // Software pipeline over pairs: the ticket and the probe results of pair i+1 are requested while
+    // pair i is being resolved, so their HBM latency is off the critical path.
+    uint32_t tk = 0;
+    if (lane == 0) tk = x.atomic_add(a.ticket, 1u);
+    uint32_t t = x.bcast(tk, 0) + a.t0;
+    HitEnt nx[2][NSLOT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            nx[m][s] = HitEnt{NAN64, NOHIT, 0};
+            if ((uint32_t)s < nslp && t < tend && t < nsurv) nx[m][s] = a.hitbuf[((size_t)2 * (t - a.t0) + m) * a.nkp + 64 * s + lane];
+        }
 
     for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) t = x.atomic_add(a.ticket, 1u);
-        t = x.bcast(t, 0);
-        if (t >= nsurv) break;
+        if (t >= tend || t >= nsurv) break;
         const uint32_t pair = a.surv[t] + a.pair_base;
         x.sync();  // previous pair's LDS is dead from here on
         DBTK_STAMP(0);  // ticket
 
-        // ---- P3: the probe kernel's results for both reads, one coalesced 16-byte load per position
+        // ---- P3: the probe kernel's results for both reads (requested one iteration ago)
         uint32_t nkm[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -743,19 +765,25 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         uint32_t hv[2][NSLOT], ha[2][NSLOT];
         const uint32_t nsl = ((nkm[0] > nkm[1] ? nkm[0] : nkm[1]) + 63) >> 6;  // slots in use (3 for 150 bp reads)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const HitEnt* in = a.hitbuf + ((size_t)2 * t + m) * a.nkp;
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
                 const uint32_t i = 64 * s + lane;
                 km[m][s] = NAN64; hv[m][s] = NOHIT; ha[m][s] = 0;
                 if ((uint32_t)s < nsl && i < nkm[m]) {
-                    const HitEnt e = in[i];
-                    km[m][s] = e.km; hv[m][s] = e.val; ha[m][s] = e.aux;
-                    sm.hval[m][i] = e.val;
+                    km[m][s] = nx[m][s].km; hv[m][s] = nx[m][s].val; ha[m][s] = nx[m][s].aux;
+                    sm.hval[m][i] = nx[m][s].val;
                 }
             }
-        }
+        // request the next pair
+        if (lane == 0) tk = x.atomic_add(a.ticket, 1u);
+        const uint32_t tnext = x.bcast(tk, 0) + a.t0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s)
+                if ((uint32_t)s < nslp && tnext < tend && tnext < nsurv)
+                    nx[m][s] = a.hitbuf[((size_t)2 * (tnext - a.t0) + m) * a.nkp + 64 * s + lane];
         DBTK_STAMP(3);  // hit-buffer loads
         if (!both_short) {
 #pragma unroll
@@ -812,71 +840,62 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
             }
             x.sync();
             DBTK_STAMP(5);  // gather
-            // ---- P5: sort by key (rank sort; (key, info) is a strict total order),
-            // then run-length encode into unique k-mers + PE_KMC dups (AQ.cpp:268-295)
+            // ---- P5: sort the hit list by key, then run-length encode into unique k-mers + PE_KMC dups
+            // (AQ.cpp:268-295).  Order-preserving bucket sort in LDS: bucket = the k-mer's top 8 bits
+            // (monotone in the key), slots claimed with LDS atomics, exact rank inside the (tiny) bucket by
+            // comparing (key, info) with its other members.  O(n) instead of a comparison network.
             {
-                // composite (key << 9 | mate << 8 | position) when it fits 64 bits (k <= 27), else two-word compare
-                const bool narrow = 2 * k + 9 <= 64;
-                const int nown = (int)((n + 63 - lane) / 64);   // entries lane, lane+64, ... owned by this lane
-                const int nmax = (int)((n + 63) / 64);          // wave-uniform bound
-                uint64_t myk[8]; uint32_t myi[8]; uint32_t rk[8];
+                const uint32_t bsh = 2 * k > 8 ? 2 * k - 8 : 0;
+                const int nown = (int)((n + 63 - lane) / 64);  // entries lane, lane+64, ... owned by this lane
+                uint64_t myk[8]; uint32_t myi[8], mys[8];
+                for (uint32_t i = lane; i < (uint32_t)NBKT; i += 64) sm.w.b.cnt[i] = 0;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    rk[j] = 0; myk[j] = ~0ull; myi[j] = 0xFFFFu;
-                    if (!narrow && j < nown) {
-                        const uint64_t kk = sm.u.s.skey[lane + 64 * j];
-                        const uint32_t ii = sm.u.s.sinfo[lane + 64 * j];
-                        myk[j] = kk;
-                        myi[j] = ii;
-                    }
+                    myk[j] = 0; myi[j] = 0; mys[j] = 0;
+                    if (j < nown) { myk[j] = sm.u.s.skey[lane + 64 * j]; myi[j] = sm.u.s.sinfo[lane + 64 * j]; }
                 }
-                if (narrow) {
-                    // bitonic network on composite keys, 4 (n <= 256) or 8 per lane; pad with ~0
-                    if (n <= 256) {
-                        uint64_t v[4];
+                x.sync();
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const uint32_t e = 4 * (uint32_t)lane + j;
-                            v[j] = e < n ? ((sm.u.s.skey[e] << 9) | sm.u.s.sinfo[e]) : ~0ull;
-                        }
-                        bitonic_sort<4>(x, v);
-                        x.sync();
+                for (int j = 0; j < 8; ++j)
+                    if (j < nown) mys[j] = x.lds_add(&sm.w.b.cnt[(uint32_t)(myk[j] >> bsh) & (NBKT - 1)], 1u);  // slot in bucket
+                x.sync();
+                {   // bucket starts: lane owns buckets [4 * lane, 4 * lane + 4)
+                    uint32_t c4[4], sum = 0;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const uint32_t e = 4 * (uint32_t)lane + j;
-                            if (e < n) { sm.u.s.skey[e] = v[j] >> 9; sm.u.s.sinfo[e] = (uint16_t)(v[j] & 0x1FF); }
-                        }
-                    } else {
-                        uint64_t v[8];
+                    for (int q = 0; q < 4; ++q) { c4[q] = sm.w.b.cnt[4 * lane + q]; sum += c4[q]; }
+                    uint32_t at = x.wave_excl_scan(sum);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const uint32_t e = 8 * (uint32_t)lane + j;
-                            v[j] = e < n ? ((sm.u.s.skey[e] << 9) | sm.u.s.sinfo[e]) : ~0ull;
-                        }
-                        bitonic_sort<8>(x, v);
-                        x.sync();
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const uint32_t e = 8 * (uint32_t)lane + j;
-                            if (e < n) { sm.u.s.skey[e] = v[j] >> 9; sm.u.s.sinfo[e] = (uint16_t)(v[j] & 0x1FF); }
-                        }
-                    }
-                } else {
-                    for (uint32_t f = 0; f < n; ++f) {
-                        const uint64_t fk = sm.u.s.skey[f];
-                        const uint32_t fi = sm.u.s.sinfo[f];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) if (j < nmax) rk[j] += (fk < myk[j]) || (fk == myk[j] && fi < myi[j]);
-                    }
-                    x.sync();
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (j < nown) { sm.u.s.skey[rk[j]] = myk[j]; sm.u.s.sinfo[rk[j]] = (uint16_t)myi[j]; }
+                    for (int q = 0; q < 4; ++q) { sm.w.b.bst[4 * lane + q] = (uint16_t)at; at += c4[q]; }
                 }
-                for (uint32_t i = lane; i < (uint32_t)NHMAX; i += 64) sm.dd[i] = 0;
+                x.sync();
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < nown) {
+                        const uint32_t b = (uint32_t)(myk[j] >> bsh) & (NBKT - 1);
+                        const uint32_t at = sm.w.b.bst[b] + mys[j];
+                        sm.w.b.tmpk[at] = myk[j];
+                        sm.w.b.tmpi[at] = (uint16_t)myi[j];
+                    }
+                x.sync();
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < nown) {
+                        const uint32_t b = (uint32_t)(myk[j] >> bsh) & (NBKT - 1);
+                        const uint32_t b0 = sm.w.b.bst[b], bn = sm.w.b.cnt[b];
+                        uint32_t rk = 0;
+                        for (uint32_t q = 0; q < bn; ++q) {
+                            const uint64_t ok = sm.w.b.tmpk[b0 + q];
+                            const uint32_t oi = sm.w.b.tmpi[b0 + q];
+                            rk += (ok < myk[j]) || (ok == myk[j] && oi < myi[j]);
+                        }
+                        sm.u.s.skey[b0 + rk] = myk[j];
+                        sm.u.s.sinfo[b0 + rk] = (uint16_t)myi[j];
+                    }
+                x.sync();
+                for (uint32_t i = lane; i < (uint32_t)NHMAX; i += 64) sm.w.a.dd[i] = 0;
                 x.sync();
             }
-            DBTK_STAMP(6);  // rank sort
+            DBTK_STAMP(6);  // sort
             uint32_t nu;
             {
                 // contiguous ownership: lane owns sorted entries [8*lane, 8*lane+8)
@@ -900,8 +919,8 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                         if (head) ++uidx;
                         const uint32_t u = uidx - 1;
                         const uint16_t info = sm.u.s.sinfo[r];
-                        if (head) sm.uval[u] = sm.hval[info >> 8][info & 0xFF];
-                        x.lds_add(&sm.dd[u], (info >> 8) ? 0x10000u : 1u);
+                        if (head) sm.w.a.uval[u] = sm.hval[info >> 8][info & 0xFF];
+                        x.lds_add(&sm.w.a.dd[u], (info >> 8) ? 0x10000u : 1u);
                     }
                 }
             }
@@ -910,11 +929,11 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
             // ---- P6: loci per unique k-mer (AQ.cpp:311-317); skey/sinfo are dead now
             bool alleq, single;
             {
-                const uint32_t v0 = nu ? x.uni(sm.uval[0]) : 0;
+                const uint32_t v0 = nu ? x.uni(sm.w.a.uval[0]) : 0;
                 uint32_t odd = 0;
                 bool vdiff = false;
                 for (uint32_t u = lane; u < nu; u += 64) {
-                    const uint32_t v = sm.uval[u];
+                    const uint32_t v = sm.w.a.uval[u];
                     odd += v & 1;
                     vdiff |= v != v0;
                 }
@@ -924,11 +943,33 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 alleq = single;
                 if (!single) {
                     for (uint32_t u = lane; u < nu; u += 64) {
-                        const uint32_t v = sm.uval[u];
+                        const uint32_t v = sm.w.a.uval[u];
                         sm.u.v.nml[u] = (v & 1) ? T.vv[v >> 1] : 1u;
                     }
                     for (uint32_t i = lane; i < (uint32_t)LCAP; i += 64) sm.u.v.lkey[i] = NAN32;
                     x.sync();
+                    {   // loci lists of the multi-locus k-mers into LDS (hval is dead after the dedup), all lanes
+                        // loading in parallel: the vote itself then runs without touching HBM
+                        const uint32_t b0 = 8 * (uint32_t)lane;
+                        uint32_t need = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (b0 + j < nu && (sm.w.a.uval[b0 + j] & 1)) need += sm.u.v.nml[b0 + j];
+                        uint32_t at = x.wave_excl_scan(need);
+                        uint32_t* pool = &sm.hval[0][0];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint32_t u = b0 + j;
+                            if (u < nu) {
+                                const uint32_t v = sm.w.a.uval[u], nn = (v & 1) ? sm.u.v.nml[u] : 0;
+                                if (nn && at + nn <= (uint32_t)(2 * NKMAX)) {
+                                    sm.w.a.poff[u] = (uint16_t)at;
+                                    for (uint32_t q = 0; q < nn; ++q) pool[at + q] = T.vv[(v >> 1) + 1 + q];
+                                } else sm.w.a.poff[u] = 0xFFFFu;
+                                at += nn;
+                            }
+                        }
+                        x.sync();
+                    }
                     const uint32_t n0 = nu ? x.uni(sm.u.v.nml[0]) : 0;
                     bool diff = false;
                     for (uint32_t u = lane; u < nu; u += 64) diff |= sm.u.v.nml[u] != n0;
@@ -939,20 +980,34 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
             // ---- P7 + P8: the permutation std::sort applies (AQ.cpp:320-327) and the vote
             const uint16_t* perm_row = T.permtab + (size_t)nu * (nu ? nu - 1 : 0) / 2;  // introsort of nu equal keys
             if (single) {
-                const uint32_t fr = vote_single_locus(x, perm_row, sm.dd, nu, cth);
-                dst0 = x.uni(sm.uval[0]) >> 1;
+                const uint32_t fr = vote_single_locus(x, perm_row, sm.w.a.dd, nu, cth);
+                dst0 = x.uni(sm.w.a.uval[0]) >> 1;
                 nm1 = (int)(fr & 0xFFFF); nm2 = (int)(fr >> 16);
             } else {
                 if (alleq) { for (uint32_t i = lane; i < nu; i += 64) sm.u.v.ord[i] = perm_row[i]; }
-                else if (lane == 0) gcc_sort_index(sm.u.v.ord, (int)nu, sm.u.v.nml, sm.stack);
+                else {
+                    // exact std::sort on packed (nml << 9 | index) words held in the (not yet used) locus map
+                    bool big = false;
+                    for (uint32_t u = lane; u < nu; u += 64) big |= sm.u.v.nml[u] >= (1u << 23);
+                    const bool packed = x.ballot(big) == 0;
+                    if (packed) {
+                        for (uint32_t u = lane; u < nu; u += 64) sm.u.v.lkey[u] = (sm.u.v.nml[u] << 9) | u;
+                        x.sync();
+                        if (lane == 0) gcc_sort(sm.u.v.lkey, (int)nu, PackedLt{}, sm.stack);
+                        x.sync();
+                        for (uint32_t i = lane; i < nu; i += 64) sm.u.v.ord[i] = (uint16_t)(sm.u.v.lkey[i] & 0x1FF);
+                        x.sync();
+                        for (uint32_t i = lane; i < (uint32_t)LCAP; i += 64) sm.u.v.lkey[i] = NAN32;
+                    } else if (lane == 0) gcc_sort_index(sm.u.v.ord, (int)nu, sm.u.v.nml, sm.stack);
+                }
                 x.sync();
                 if (lane == 0) {
-                    for (uint32_t u = 0; u < nu; ++u) sm.dd[u] &= 0x00FF00FFu;  // PE_KMC counts are uint8_t
+                    for (uint32_t u = 0; u < nu; ++u) sm.w.a.dd[u] &= 0x00FF00FFu;  // PE_KMC counts are uint8_t
                     const uint32_t ep = a.vote_epoch[x.bid()] + 1;
-                    HitMap hmap{sm.u.v.lkey, sm.lhit, 0, a.vote_scratch + (size_t)x.bid() * ((size_t)nloci + 1), ep, false};
+                    HitMap hmap{sm.u.v.lkey, sm.w.a.lhit, 0, a.vote_scratch + (size_t)x.bid() * ((size_t)nloci + 1), ep, false};
                     Asgn top;
                     uint64_t nvvw = 0;
-                    vote(T, sm.u.v.ord, sm.uval, sm.dd, (int)nu, cth, hmap, top, nvvw);
+                    vote(T, sm.u.v.ord, sm.w.a.uval, sm.w.a.dd, (int)nu, cth, hmap, top, nvvw, sm.u.v.nml, &sm.hval[0][0], sm.w.a.poff);
                     c_vv += nvvw;
                     if (hmap.spilled) a.vote_epoch[x.bid()] = ep;
                     sm.res[0] = (int32_t)(uint32_t)top.idx;
@@ -964,6 +1019,10 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 nm1 = (int)x.uni((uint32_t)sm.res[1]); nm2 = (int)x.uni((uint32_t)sm.res[2]);
             }
             DBTK_STAMP(single ? 9 : 10);  // vote: fast / general
+#ifdef DBTK_STAMPS
+            st_acc[single ? 24 : (alleq ? 25 : 26)] += 1;  // pairs per vote path
+            st_acc[27] += nu; st_acc[28] += n;
+#endif
             {  // countHit's accept test, AQ.cpp:439-451
                 const uint64_t fc = (uint64_t)(uint32_t)nm1, rc = (uint64_t)(uint32_t)nm2;
                 const bool test1 = fc >= cth && rc >= cth, test2 = (fc + rc) >= 2ull * cth;
@@ -985,13 +1044,14 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     // position: flank 1 beats TR 2 (AQ.cpp:1467-1468).  With a consistent RPGG the class of a
                     // single-locus k-mer rides in the index slot (`aux`): no second probe.
                     uint32_t slot[2][NSLOT], ntr[2] = {0, 0};
+                    uint64_t Tw[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // transitions between known states
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         ms[m].rm = rm[m];
                         if (!okam && rm[m]) continue;
                         nas[m] = nkm[m];
                         c_cls += nkm[m];
-                        uint32_t mytr = 0;
+                        uint32_t mytr = 0, carry = 0;  // carry: last known state of the previous 64 positions
 #pragma unroll
                         for (int s = 0; s < NSLOT; ++s) {
                             slot[m][s] = CLS_NONE;
@@ -1005,21 +1065,30 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                                 else c = cls_lookup(T, km[m][s], dst0);
                             }
                             slot[m][s] = c;
-                            const uint64_t kb = x.ballot(c != CLS_NONE), rb = x.ballot(c != CLS_NONE && c != CLS_FLANK);
+                            const uint32_t st = (c == CLS_NONE) ? 0u : (c == CLS_FLANK ? 1u : 2u);
+                            const uint64_t kb = x.ballot(st != 0), rb = x.ballot(st == 2);
                             Kw[m][s] = kb; Rw[m][s] = rb;
                             mytr += (uint32_t)__builtin_popcountll(rb);
+                            // last known state at or before each position (wave scan), then strictly before
+                            const uint32_t inc = x.wave_scan_lastnz(st);
+                            uint32_t prev = x.shfl_up1(inc);
+                            if (lane == 0) prev = 0;
+                            if (prev == 0) prev = carry;
+                            Tw[m][s] = x.ballot(st != 0 && prev != 0 && prev != st);
+                            const uint32_t last = x.bcast(inc, 63);
+                            if (last) carry = last;
                         }
-                        ntr[m] = mytr & 0xFF;  // uint8_t ntr, AQ.cpp:1454 (mytr is already wave-uniform)
+                        ntr[m] = mytr & 0xFF;  // uint8_t ntr, AQ.cpp:1454 (mytr is wave-uniform)
                     }
                     DBTK_STAMP(11);  // states
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         if (!nas[m]) continue;
-                        // K / R are wave-uniform ballots: the whole state machine runs on the scalar unit
-                        Bits256 K, R;
+                        // K / R / T are wave-uniform ballots: the rest of the state machine is scalar work
+                        Bits256 K, R, Tm;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { K.w[q] = Kw[m][q]; R.w[q] = Rw[m][q]; }
-                        assign_bits(K, R, (int)nas[m], ntr[m], a.P, ms[m]);
+                        for (int q = 0; q < 4; ++q) { K.w[q] = Kw[m][q]; R.w[q] = Rw[m][q]; Tm.w[q] = Tw[m][q]; }
+                        assign_masks(K, R, Tm, (int)nas[m], ntr[m], a.P, ms[m]);
                         af[m] = ms[m].af; rm[m] = ms[m].rm;
                     }
                     DBTK_STAMP(12);  // assign_bits
@@ -1090,6 +1159,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 }
             }
         }
+        t = tnext;
     }
     DBTK_STAMP_FLUSH;
     if (lane == 0) {

@@ -21,13 +21,20 @@
 
 namespace dbtk {
 
-struct SortLt {
+struct SortLt {  // indices compared through a key array: getSortedIndex's comparator, literally
+    typedef uint16_t elem_t;
     const uint32_t* key;
     DBTK_HD bool operator()(uint16_t a, uint16_t b) const { return key[a] < key[b]; }
 };
+// The same order on packed words (key << 9 | index): one LDS read per element instead of two.
+// The comparator looks at the key bits only, so ties behave exactly as in the index form.
+struct PackedLt {
+    typedef uint32_t elem_t;
+    DBTK_HD bool operator()(uint32_t a, uint32_t b) const { return (a >> 9) < (b >> 9); }
+};
 
-DBTK_HD void s_unguarded_linear_insert(uint16_t* a, int last, const SortLt& lt) {
-    const uint16_t val = a[last];
+template <class Lt> DBTK_HD void s_unguarded_linear_insert(typename Lt::elem_t* a, int last, const Lt& lt) {
+    const typename Lt::elem_t val = a[last];
     int next = last - 1;
     while (lt(val, a[next])) {
         a[last] = a[next];
@@ -37,11 +44,11 @@ DBTK_HD void s_unguarded_linear_insert(uint16_t* a, int last, const SortLt& lt) 
     a[last] = val;
 }
 
-DBTK_HD void s_insertion_sort(uint16_t* a, int first, int last, const SortLt& lt) {
+template <class Lt> DBTK_HD void s_insertion_sort(typename Lt::elem_t* a, int first, int last, const Lt& lt) {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
         if (lt(a[i], a[first])) {
-            const uint16_t val = a[i];
+            const typename Lt::elem_t val = a[i];
             for (int j = i; j > first; --j) a[j] = a[j - 1];  // move_backward
             a[first] = val;
         } else {
@@ -50,7 +57,7 @@ DBTK_HD void s_insertion_sort(uint16_t* a, int first, int last, const SortLt& lt
     }
 }
 
-DBTK_HD void s_push_heap(uint16_t* a, int first, int hole, int top, uint16_t value, const SortLt& lt) {
+template <class Lt> DBTK_HD void s_push_heap(typename Lt::elem_t* a, int first, int hole, int top, typename Lt::elem_t value, const Lt& lt) {
     int parent = (hole - 1) / 2;
     while (hole > top && lt(a[first + parent], value)) {
         a[first + hole] = a[first + parent];
@@ -60,7 +67,7 @@ DBTK_HD void s_push_heap(uint16_t* a, int first, int hole, int top, uint16_t val
     a[first + hole] = value;
 }
 
-DBTK_HD void s_adjust_heap(uint16_t* a, int first, int hole, int len, uint16_t value, const SortLt& lt) {
+template <class Lt> DBTK_HD void s_adjust_heap(typename Lt::elem_t* a, int first, int hole, int len, typename Lt::elem_t value, const Lt& lt) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
@@ -77,12 +84,12 @@ DBTK_HD void s_adjust_heap(uint16_t* a, int first, int hole, int len, uint16_t v
     s_push_heap(a, first, hole, top, value, lt);
 }
 
-DBTK_HD void s_heapsort(uint16_t* a, int first, int last, const SortLt& lt) {  // __partial_sort(first,last,last)
+template <class Lt> DBTK_HD void s_heapsort(typename Lt::elem_t* a, int first, int last, const Lt& lt) {  // __partial_sort(first,last,last)
     const int len = last - first;
     if (len >= 2) {
         int parent = (len - 2) / 2;
         for (;;) {
-            const uint16_t v = a[first + parent];
+            const typename Lt::elem_t v = a[first + parent];
             s_adjust_heap(a, first, parent, len, v, lt);
             if (parent == 0) break;
             parent--;
@@ -90,19 +97,19 @@ DBTK_HD void s_heapsort(uint16_t* a, int first, int last, const SortLt& lt) {  /
     }
     while (last - first > 1) {
         --last;
-        const uint16_t v = a[last];
+        const typename Lt::elem_t v = a[last];
         a[last] = a[first];
         s_adjust_heap(a, first, 0, last - first, v, lt);
     }
 }
 
-DBTK_HD void s_swap(uint16_t* a, int i, int j) {
-    const uint16_t t = a[i];
+template <class E> DBTK_HD void s_swap(E* a, int i, int j) {
+    const E t = a[i];
     a[i] = a[j];
     a[j] = t;
 }
 
-DBTK_HD int s_partition_pivot(uint16_t* a, int first, int last, const SortLt& lt) {
+template <class Lt> DBTK_HD int s_partition_pivot(typename Lt::elem_t* a, int first, int last, const Lt& lt) {
     const int mid = first + (last - first) / 2;
     {  // __move_median_to_first(first, first+1, mid, last-1)
         const int x = first + 1, y = mid, z = last - 1;
@@ -125,11 +132,9 @@ DBTK_HD int s_partition_pivot(uint16_t* a, int first, int last, const SortLt& lt
     }
 }
 
-// stack: caller-provided int[3 * 40] scratch (first, last, depth triples).
-DBTK_HD void gcc_sort_index(uint16_t* a, int n, const uint32_t* key, int* stack) {
-    for (int i = 0; i < n; ++i) a[i] = (uint16_t)i;  // std::iota
+// std::sort(a, a + n, lt).  stack: caller-provided int[3 * 40] scratch (first, last, depth triples).
+template <class Lt> DBTK_HD void gcc_sort(typename Lt::elem_t* a, int n, const Lt& lt, int* stack) {
     if (n == 0) return;
-    const SortLt lt{key};
     int sp = 0;
     stack[0] = 0;
     stack[1] = n;
@@ -158,6 +163,12 @@ DBTK_HD void gcc_sort_index(uint16_t* a, int n, const uint32_t* key, int* stack)
     } else {
         s_insertion_sort(a, 0, n, lt);
     }
+}
+
+// getSortedIndex (src/aQueryFasta_thread.cpp:247-250): iota, then std::sort by key[index].
+DBTK_HD void gcc_sort_index(uint16_t* a, int n, const uint32_t* key, int* stack) {
+    for (int i = 0; i < n; ++i) a[i] = (uint16_t)i;  // std::iota
+    gcc_sort(a, n, SortLt{key}, stack);
 }
 
 }  // namespace dbtk

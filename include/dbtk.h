@@ -212,6 +212,7 @@ dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n);
  * stream.  Returns how many kernels were filled (<= cap). */
 int  dbtk_ctx_kernel_times(dbtk_ctx_t* ctx, const char** names, double* total_ms, uint64_t* launches, int cap);
 void dbtk_ctx_timers_reset(dbtk_ctx_t* ctx);
+void dbtk_ctx_timers_enable(dbtk_ctx_t* ctx, int on);  /* default on; off = no event records on the stream */
 
 /* ---- dumps: src/aQueryFasta_thread.cpp:2631-2641 --------------------------*/
 /* with_names = 0: OUT.trkmc.ar + OUT.tr.summary.txt; 1: OUT.tr.kmers (-on). */

@@ -207,6 +207,8 @@ class Emu(pkg._HostSide):
         L.emu_tables_set_consistent.argtypes = [C.c_void_p, C.c_uint32]
         L.emu_selftest_assign.restype = C.c_uint64
         L.emu_selftest_assign.argtypes = [C.c_uint64, C.c_uint64]
+        L.emu_selftest_sort.restype = C.c_uint64
+        L.emu_selftest_sort.argtypes = [C.c_uint64, C.c_uint64]
         L.emu_align.restype = C.c_int
         L.emu_align.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.Params), u8p, u64p, C.c_uint64, u64p, u64p, u32p, u64p,
                                 C.POINTER(abi.PairRec), C.c_uint64, u64p, C.c_uint32, C.c_uint32]
@@ -222,6 +224,9 @@ class Emu(pkg._HostSide):
 
     def selftest_assign(self, seed, iters):
         return int(self.L.emu_selftest_assign(seed, iters))
+
+    def selftest_sort(self, seed, iters):
+        return int(self.L.emu_selftest_sort(seed, iters))
 
     def align(self, rpgg, tables, params, seq, off, grid_k1=3, grid_pair=5):
         npairs = (len(off) - 1) // 2

@@ -36,6 +36,8 @@ struct EmuX {
     uint32_t wave_sum(uint32_t v) const;
     uint32_t wave_excl_scan(uint32_t v) const;
     uint32_t bcast(uint32_t v, int src) const;
+    uint32_t wave_scan_lastnz(uint32_t v) const;
+    uint32_t shfl_up1(uint32_t v) const;
     template <int E> void shfl_xor64(const uint64_t (&in)[E], uint64_t (&out)[E], int mask) const;
     void atomic_add(uint64_t* p, uint64_t v) const { *p += v; }
     uint32_t atomic_add(uint32_t* p, uint32_t v) const { uint32_t o = *p; *p += v; return o; }
@@ -114,6 +116,22 @@ template <int E> void EmuX::shfl_xor64(const uint64_t (&in)[E], uint64_t (&out)[
     b->yield();
     for (int j = 0; j < E; ++j) out[j] = b->vscratch[(size_t)(t ^ mask) * 8 + j];
     b->yield();
+}
+uint32_t EmuX::wave_scan_lastnz(uint32_t v) const {
+    b->scratch[t] = v;
+    b->yield();
+    uint32_t r = 0;
+    const int w0 = t & ~63;
+    for (int l = 0; l <= (t & 63); ++l) if (b->scratch[w0 + l]) r = (uint32_t)b->scratch[w0 + l];
+    b->yield();
+    return r;
+}
+uint32_t EmuX::shfl_up1(uint32_t v) const {
+    b->scratch[t] = v;
+    b->yield();
+    const uint32_t r = (t & 63) ? (uint32_t)b->scratch[t - 1] : v;
+    b->yield();
+    return r;
 }
 uint32_t EmuX::bcast(uint32_t v, int src) const {
     b->scratch[t] = v;
@@ -226,6 +244,43 @@ void emu_tables_free(void* e) { delete (EmuTables*)e; }
 uint32_t emu_tables_consistent(void* e) { return ((EmuTables*)e)->T.consistent; }
 void emu_tables_set_consistent(void* e, uint32_t v) { ((EmuTables*)e)->T.consistent = v; }
 
+// gcc_sort (index form and packed form, the code the kernels run) against the host's real
+// std::sort with getSortedIndex's comparator, on tie-heavy, sorted, reversed and
+// median-of-3-killer key sequences.  Returns the number of mismatching runs.
+uint64_t emu_selftest_sort(uint64_t seed, uint64_t iters) {
+    uint64_t bad = 0, s = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    int stack[3 * 40];
+    for (uint64_t it = 0; it < iters; ++it) {
+        const int n = (int)(rnd() % 513);
+        std::vector<uint32_t> key(n ? n : 1);
+        const int mode = (int)(rnd() % 6);
+        const uint32_t hi = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : mode == 3 ? 50 : 100000;
+        for (int i = 0; i < n; ++i) key[i] = 1 + (uint32_t)(rnd() % hi);
+        if (mode == 4) std::sort(key.begin(), key.begin() + n);
+        if (mode == 5 && n >= 4) {  // median-of-3 killer: drives introsort into its heapsort fallback
+            const int k2 = n / 2;
+            std::fill(key.begin(), key.end(), 0u);
+            for (int i = 1; i <= k2; ++i) {
+                if (i % 2) { key[i - 1] = (uint32_t)i; key[i] = (uint32_t)(k2 + i); }
+                key[k2 + i - 1] = (uint32_t)(2 * i);
+            }
+        }
+        std::vector<uint64_t> ref(n);
+        for (int i = 0; i < n; ++i) ref[i] = (uint64_t)i;
+        std::sort(ref.begin(), ref.end(), [&](uint64_t a, uint64_t b) { return key[a] < key[b]; });
+        std::vector<uint16_t> a(n ? n : 1);
+        gcc_sort_index(a.data(), n, key.data(), stack);
+        std::vector<uint32_t> pk(n ? n : 1);
+        for (int i = 0; i < n; ++i) pk[i] = (key[i] << 9) | (uint32_t)i;
+        gcc_sort(pk.data(), n, PackedLt{}, stack);
+        bool ok = true;
+        for (int i = 0; i < n; ++i) ok &= a[i] == ref[i] && (pk[i] & 0x1FF) == ref[i];
+        bad += !ok;
+    }
+    return bad;
+}
+
 // assign_bits (the mask form the kernels use) against assign_scan (the literal
 // restatement of AQ.cpp:1470-1555) on `iters` random state vectors.  Returns the
 // number of mismatches.
@@ -292,9 +347,21 @@ int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const 
     std::vector<HitEnt> hit((size_t)npairs * 2 * a.nkp + 1);
     a.hitbuf = hit.data();
     a.pair_base = 0;
+    // survivor chunks: a small hit buffer forces several K2 -> K3 iterations, as on the device
+    const uint32_t tcap = npairs > 7 ? (uint32_t)(npairs / 3 + 1) : (uint32_t)(npairs ? npairs : 1);
+    hit.assign((size_t)tcap * 2 * a.nkp + 1, HitEnt{0, 0, 0});
+    a.hitbuf = hit.data();
+    a.tcap = tcap;
+    uint32_t tile_ticket = 0;
+    a.tile_ticket = &tile_ticket;
     run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter(x, a); });
-    run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe(x, a); });
-    run_grid(grid_pair, 64, sizeof(PairSmem), [&](EmuX& x) { body_pair(x, a); });
+    for (uint32_t t0 = 0; t0 < (uint32_t)(npairs ? npairs : 1); t0 += tcap) {
+        a.t0 = t0;
+        uint32_t ticket = 0;
+        a.ticket = &ticket;
+        run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe(x, a); });
+        run_grid(grid_pair, 64, sizeof(PairSmem), [&](EmuX& x) { body_pair(x, a); });
+    }
     if (small[3]) return (int)small[3];
     memcpy(counts, accum.data(), ntr * 8);
     memcpy(kmc, accum.data() + ntr, nloci * 8);

@@ -51,6 +51,11 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
     g.close()
 
 
+def test_device_sort_is_gcc_std_sort(E):
+    """dbtk_sort.h (index form and packed form) against this host's std::sort, incl. the heapsort fallback."""
+    assert E.selftest_sort(3, 20000) == 0
+
+
 def test_assign_bits_equals_literal_scan(E):
     """The mask form of assignTRkmc used by the kernels vs the literal restatement of AQ.cpp:1470-1555."""
     assert E.selftest_assign(7, 400000) == 0

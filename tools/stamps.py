@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("danbing-tk_amd")
 abi = pkg.abi
 NAMES = ["ticket", "-", "-", "hit-buffer loads", "kfilter verdict", "gather", "rank sort", "dedup", "nml/single test",
-         "vote fast", "vote general", "states", "assign_bits", "accumulate", "-", "-"]
+         "vote fast", "vote general", "states", "assign_bits", "accumulate", "-", "-",
+         "K1 tile set-up", "K1 loads+pack", "K1 valid-window", "K1 sampled probes", "K1 verdict+append"] + ["-"] * 11
 
 
 def main():
@@ -32,14 +33,21 @@ def main():
     seq, off = syn.reads(npairs, hit_frac=hit)
     for _ in range(3):
         ctx.align(seq, off)
-    st = np.zeros(16, np.uint64)
+    st = np.zeros(32, np.uint64)
     lib.L.dbtk_debug_stamps(ctx.h, st.ctypes.data_as(abi.u64p))
-    tot = float(st.sum())
     r = ctx.counts()["counters"]
     print(f"survivors/step {r[abi.C_SURVIVORS] / 3:.0f}  kernels {ctx.kernel_times()}")
-    for n, v in zip(NAMES, st):
+    tot = float(st[:16].sum())
+    for n, v in zip(NAMES[:16], st[:16]):
         if v:
             print(f"{n:18s} {100 * float(v) / tot:6.2f} %   {float(v) / (r[abi.C_SURVIVORS]):10.0f} cycles/pair")
+    print(f"vote paths: single-locus {st[24]}  all-equal-nml {st[25]}  introsort {st[26]}   mean nu {st[27] / max(1, st[24] + st[25] + st[26]):.1f}  mean n {st[28] / max(1, st[24] + st[25] + st[26]):.1f}")
+    st[24:] = 0
+    tot = float(st[16:].sum())
+    ntiles = 3 * ((npairs + 15) // 16)
+    for n, v in zip(NAMES[16:], st[16:]):
+        if v:
+            print(f"{n:18s} {100 * float(v) / tot:6.2f} %   {float(v) / ntiles:10.0f} cycles/tile")
 
 
 if __name__ == "__main__":
