@@ -35,7 +35,7 @@ def bind_common(L):
     L.dbtk_last_error.restype = C.c_char_p
     L.dbtk_abi_version.restype = C.c_uint32
     L.dbtk_rpgg_load.restype = C.c_int
-    L.dbtk_rpgg_load.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.dbtk_rpgg_load.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.dbtk_rpgg_from_arrays.restype = C.c_int
     L.dbtk_rpgg_from_arrays.argtypes = [C.POINTER(abi.RpggArrays), C.POINTER(C.c_void_p)]
     L.dbtk_rpgg_free.argtypes = [C.c_void_p]
@@ -89,10 +89,10 @@ class _HostSide:
         if st != abi.OK:
             raise DbtkError(st, self.L.dbtk_last_error().decode())
 
-    def load(self, prefix, k=21, qc_file=None, bait_file=None) -> Rpgg:
+    def load(self, prefix, k=21, qc_file=None, bait_file=None, flags=0) -> Rpgg:
         h = C.c_void_p()
         self._chk(self.L.dbtk_rpgg_load(prefix.encode(), k, qc_file.encode() if qc_file else None,
-                                        bait_file.encode() if bait_file else None, C.byref(h)))
+                                        bait_file.encode() if bait_file else None, flags, C.byref(h)))
         return Rpgg(self, h)
 
     def from_arrays(self, k, keys, vals, vv, fl_cnt, fl_ks, tr_cnt, tr_ks, tre_cnt=None, tre_ks=None, qc=None) -> Rpgg:

@@ -1,0 +1,382 @@
+// dbtk_cli.cpp — `danbing-tk`-compatible command line over the C-ABI (include/dbtk.h).
+//
+// Drop-in for the process boundary of the reference's aligner
+// (src/aQueryFasta_thread.cpp:2286-2660, flag table in SURVEY.md Appendix C):
+// same flags with the same order sensitivity around -qs, the same RPGG files in,
+// the same output files and stdout records out.  What runs between the reader
+// and the writers is the HIP hot path (libdbtk_hip.so); this file is host glue:
+//   * argv loop                                   AQ.cpp:2344-2429
+//   * reader + on-the-fly mate pairing            AQ.cpp:1918-1976 (critical section A)
+//   * kam / extracted-read writers                AQ.cpp:1618-1681 (critical section B)
+//   * totals, dumps                               AQ.cpp:2617-2656
+// New flags live under their own namespace: --gpus N (GPUs to use, default 1).
+// stderr is informational (the reference's also carries timings); stdout and the
+// output files are byte-compatible.
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/dbtk.h"
+
+namespace {
+
+[[noreturn]] void die_assert(const std::string& what) {
+    // the reference `assert`s on unusable files (abort, exit status 134)
+    fprintf(stderr, "danbing-tk: %s\n", what.c_str());
+    abort();
+}
+
+struct Opts {
+    bool bait = false, aug = false, threading = false, tc = false, aln = false, aln_minimal = false, okam = true, g2pan = false;
+    bool writeKmerName = false, outputBubbles = false, invkmer = false, isFastq = false, trackBait = false, qc = false;
+    int simmode = 0, extractFastX = 0, verbosity = 0, ngpus = 1;
+    uint64_t trim = 0, thread_cth = 100, Cthreshold = 10, nproc = 1, ksize = 21, qth = 20, N_FILTER = 4, NM_FILTER = 1, NM_TR = 40,
+             MAX_NT = 2, maxncorrection = 4;
+    float readsPerBatchFactor = 1;
+    std::string trPrefix, trFname, fastxFname, outPrefix, qcFn, baitFname;
+};
+
+bool readable(const std::string& fn) {
+    FILE* f = fopen(fn.c_str(), "rb");
+    if (!f) return false;
+    fclose(f);
+    return true;
+}
+
+void usage() {
+    fprintf(stderr,
+            "\nUsage: danbing-tk [-bu] [-ka] [-qc] [-k] [-kf] [-cth] [-qth] [-b] [-c] [-r] [-p] <-fa|-fq> -qs <-o|-on>\n"
+            "  (MI355X build: the alignment hot path runs on the GPU through libdbtk_hip.so)\n"
+            "Input:\n"
+            "  -fa <STR> | -fq <STR>  paired reads as FASTA | FASTQ (e.g. samtools fasta/fastq -n); mates are paired on the fly\n"
+            "  -qs <STR>              prefix of the RPGG files (PREF.tr.kmers, PREF.kmers.dbi, PREF.fl.kdb, PREF.tre.kdb)\n"
+            "Output:\n"
+            "  -o <STR> | -on <STR>   output prefix (OUT.trkmc.ar + OUT.tr.summary.txt | OUT.tr.kmers with names)\n"
+            "  -ka                    no k-mer assignment (kam) records on stdout\n"
+            "  -bu                    write read (k+1)-mers absent from the graph\n"
+            "Algorithm:\n"
+            "  -k <INT> [21]  -kf <N> <M> [4 1]  -cth <INT> [10]  -c <INT> [40]  -qth <INT> [20]  -qc <FILE>  -b [FILE]\n"
+            "Execution:\n"
+            "  -p <INT>  -r <FLOAT>   accepted for compatibility (threads / batch factor: batch = 300000*r reads)\n"
+            "  --gpus <INT>           GPUs to spread batches over [1]\n"
+            "Developer:\n"
+            "  -s <1|2>  -e <1|2>  -v <INT>  -g|-gc|-gcc <INT> [INT]  -a  -ae  -tb  -ik  -t <INT>  -m <FILE>  -au\n\n");
+}
+
+// ---- reader: AQ.cpp:1918-1976 -------------------------------------------------------------------
+struct Reader {
+    FILE* f = nullptr;
+    std::vector<char> buf;
+    size_t pos = 0, end = 0;
+    bool eof = false;
+    bool fill() {
+        if (eof) return false;
+        if (pos < end) memmove(buf.data(), buf.data() + pos, end - pos);
+        end -= pos; pos = 0;
+        if (buf.size() - end < (1u << 20)) buf.resize(buf.size() * 2);
+        const size_t n = fread(buf.data() + end, 1, buf.size() - end, f);
+        if (n == 0) { eof = true; return false; }
+        end += n;
+        return true;
+    }
+    // std::getline semantics: false only when no characters are left
+    bool getline(std::string& out) {
+        for (;;) {
+            const char* nl = (const char*)memchr(buf.data() + pos, '\n', end - pos);
+            if (nl) { out.assign(buf.data() + pos, nl - (buf.data() + pos)); pos = nl - buf.data() + 1; return true; }
+            if (!fill()) {
+                if (pos == end) { out.clear(); return false; }
+                out.assign(buf.data() + pos, end - pos); pos = end;
+                return true;
+            }
+        }
+    }
+    bool at_eof() { return pos == end && !fill(); }  // in->peek() == EOF
+};
+
+inline void prunePEinfo(std::string& title) {  // AQ.cpp:455-462
+    const size_t len = title.size();
+    if (len >= 2 && title[len - 2] == '/' && (title[len - 1] == '1' || title[len - 1] == '2')) title.resize(len - 2);
+}
+
+struct Batch {
+    std::vector<std::string> seqs, quals, titles;  // seqs[2p], seqs[2p+1]: pair p; titles[p]
+    std::vector<uint64_t> src;                     // simmode: source locus per pair
+    uint64_t nreads = 0;
+};
+
+uint64_t parse_src(const std::string& title, int simmode, uint64_t nloci) {
+    if (simmode == 1) {  // >LOCUS.xxx   (AQ.cpp:478-489)
+        const size_t first = title.find('.');
+        return strtoull(title.substr(1, first).c_str(), nullptr, 10);
+    }
+    // simmode 2: >CHR:START-END:LOCUS  (AQ.cpp:492-506)
+    const size_t p1 = title.find(':'), p2 = title.find(':', p1 + 1);
+    const std::string val = title.substr(p2 + 1);
+    if (!val.empty() && val[0] == '.') return nloci;
+    return strtoull(val.c_str(), nullptr, 10);
+}
+
+// ---- writers: AQ.cpp:1618-1681 --------------------------------------------------------------------
+std::string annot2str(const dbtk_mate_rec_t& m) {  // km_asgn_t::annot2str_, AQ.cpp:121-138
+    static const char chs[3] = {'*', '.', '='};
+    if (m.nk == 0) return "*";
+    auto st = [&](int i) { return (m.as2[i >> 2] >> (2 * (i & 3))) & 3; };
+    std::string s;
+    int ct = 1, a0 = st(0);
+    for (int i = 1; i < m.nk; ++i) {
+        const int a1 = st(i);
+        if (a0 != a1) { s += std::to_string(ct) + chs[a0]; ct = 1; }
+        else ++ct;
+        a0 = a1;
+    }
+    s += std::to_string(ct) + chs[a0];
+    return s;
+}
+std::string na(int v) { return v == -1 ? std::string(".") : std::to_string(v); }
+void mate_fields(std::string& o, const dbtk_mate_rec_t& r) {
+    o += std::to_string(r.kf) + ':' + std::to_string(r.hf) + ':' + std::to_string(r.bf) + ':' + std::to_string(r.qf) + ':' +
+         std::to_string(r.af) + ':' + std::to_string(r.rm) + ":0:0:" + na(r.si) + ':' + na(r.nt) + ':' + na(r.bs) + ':' + na(r.ti);
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+    if (argc < 2) { usage(); return 0; }
+    std::vector<std::string> args(argv, argv + argc);
+    Opts o;
+    auto need = [&](size_t i) -> const std::string& {
+        if (i >= args.size()) die_assert("missing value after " + args[i - 1]);  // the reference reads past argv here
+        return args[i];
+    };
+    for (size_t argi = 1; argi < args.size(); ++argi) {  // order-sensitive like AQ.cpp:2344-2429
+        const std::string& a = args[argi];
+        if (a == "-b") {
+            o.bait = true;
+            if (need(argi + 1)[0] != '-') o.baitFname = args[++argi];
+        }
+        else if (a == "-v") o.verbosity = atoi(need(++argi).c_str());
+        else if (a == "-e") o.extractFastX = atoi(need(++argi).c_str());
+        else if (a == "-bu") o.outputBubbles = true;
+        else if (a == "-t") o.trim = strtoull(need(++argi).c_str(), nullptr, 10);
+        else if (a == "-s") o.simmode = atoi(need(++argi).c_str());
+        else if (a == "-m") { o.g2pan = true; if (!readable(need(++argi))) die_assert("cannot open " + args[argi]); }
+        else if (a == "-au") o.aug = true;
+        else if (a == "-g" || a == "-gc" || a == "-gcc") {
+            o.threading = true;
+            if (a == "-gcc") o.tc = true;
+            o.thread_cth = strtoull(need(++argi).c_str(), nullptr, 10);
+            if (need(argi + 1)[0] != '-') o.maxncorrection = strtoull(args[++argi].c_str(), nullptr, 10);
+        }
+        else if (a == "-a") o.aln = true;
+        else if (a == "-ae") { o.aln = true; o.aln_minimal = true; }
+        else if (a == "-ka") o.okam = false;
+        else if (a == "-kf") { o.N_FILTER = strtoull(need(++argi).c_str(), nullptr, 10); o.NM_FILTER = strtoull(need(++argi).c_str(), nullptr, 10); }
+        else if (a == "-r") o.readsPerBatchFactor = strtof(need(++argi).c_str(), nullptr);
+        else if (a == "-c") o.NM_TR = strtoull(need(++argi).c_str(), nullptr, 10);
+        else if (a == "-ik") o.invkmer = true;
+        else if (a == "-k") o.ksize = strtoull(need(++argi).c_str(), nullptr, 10);
+        else if (a == "-tb") o.trackBait = true;
+        else if (a == "-qc") { o.qc = true; o.qcFn = need(++argi); if (!readable(o.qcFn)) die_assert("cannot open " + o.qcFn); }
+        else if (a == "-qs") {
+            o.trPrefix = need(++argi);
+            o.trFname = o.trim ? o.trPrefix + ".tr.trim" + std::to_string(o.trim) + ".kmers" : o.trPrefix + ".tr.kmers";
+            if (!readable(o.trFname)) die_assert("cannot open " + o.trFname);
+            if (o.aug && !readable(o.trPrefix + ".tr.aug.kmers")) die_assert("cannot open " + o.trPrefix + ".tr.aug.kmers");
+            if (o.bait) {
+                if (o.baitFname.empty()) o.baitFname = o.trPrefix + (o.qc ? ".qc.bt.kmdb" : ".bt.kmdb");
+                if (!readable(o.baitFname)) die_assert("cannot open " + o.baitFname);
+            }
+        }
+        else if (a == "-fa" || a == "-fq") {
+            o.isFastq = a == "-fq";
+            o.fastxFname = need(++argi);
+            if (!readable(o.fastxFname)) die_assert("cannot open " + o.fastxFname);
+        }
+        else if (a == "-o" || a == "-on") {
+            o.writeKmerName = a == "-on";
+            o.outPrefix = need(++argi);
+            FILE* f = fopen((o.outPrefix + ".trkmc.ar").c_str(), "wb");  // truncated at parse time, AQ.cpp:2417
+            if (!f) die_assert("cannot create " + o.outPrefix + ".trkmc.ar");
+            fclose(f);
+        }
+        else if (a == "-p") o.nproc = strtoull(need(++argi).c_str(), nullptr, 10);
+        else if (a == "-cth") o.Cthreshold = strtoull(need(++argi).c_str(), nullptr, 10);
+        else if (a == "-qth") o.qth = strtoull(need(++argi).c_str(), nullptr, 10);
+        else if (a == "--gpus") o.ngpus = atoi(need(++argi).c_str());
+        else {
+            fprintf(stderr, "invalid option: %s\n", a.c_str());
+            abort();  // the reference does `throw;` with no active exception -> std::terminate
+        }
+    }
+    if (o.trim) die_assert("-t (trimmed tr.kmers) is not supported by this build");
+    if (o.outputBubbles || o.bait || o.trackBait) die_assert("-bu / -b / -tb are not implemented in this build yet");
+
+    fprintf(stderr,
+            "use baitDB: %d\nextract fastX: %d\noutput bubbles: %d\nis Fastq: %d\nsim mode: %d\ngraph threading mode: %d\n"
+            "output kmer assignment (kam): %d\nk: %llu\n# of subsampled kmers in pre-filtering: %llu\n"
+            "minimal # of matches in pre-filtering: %llu\nCthreshold: %llu\nmin # of kmer matches for TR spanning read: %llu\n"
+            "fastx: %s\nquery: %s.(tr/ntr).kmers\nGPUs: %d\n\n",
+            o.bait, o.extractFastX, o.outputBubbles, o.isFastq, o.simmode, o.threading, o.okam, (unsigned long long)o.ksize,
+            (unsigned long long)o.N_FILTER, (unsigned long long)o.NM_FILTER, (unsigned long long)o.Cthreshold,
+            (unsigned long long)o.NM_TR, o.fastxFname.c_str(), o.trPrefix.c_str(), o.ngpus);
+
+    // ---- load (AQ.cpp:2459-2504)
+    time_t time1 = time(nullptr);
+    dbtk_rpgg_t* rpgg = nullptr;
+    if (dbtk_rpgg_load(o.trPrefix.c_str(), (uint32_t)o.ksize, o.qc ? o.qcFn.c_str() : nullptr, nullptr,
+                       o.extractFastX ? DBTK_LOAD_INDEX_ONLY : 0, &rpgg))
+        die_assert(dbtk_last_error());
+    const uint64_t nloci = dbtk_rpgg_nloci(rpgg);
+    fprintf(stderr, "total number of loci in %s: %llu\n", o.trFname.c_str(), (unsigned long long)nloci);
+    fprintf(stderr, "deserialized graph/index and read tr.kmers in %ld sec.\n# unique kmers in kmerDBi: %llu\n", (long)(time(nullptr) - time1),
+            (unsigned long long)dbtk_rpgg_nkeys(rpgg));
+
+    dbtk_params_t P;
+    dbtk_params_default(&P);
+    P.ksize = (uint32_t)o.ksize; P.n_filter = (uint32_t)o.N_FILTER; P.nm_filter = (uint32_t)o.NM_FILTER;
+    P.cthreshold = (uint32_t)(uint16_t)o.Cthreshold;  // uint16_t in the reference (AQ.cpp:1765)
+    P.nm_tr = (uint32_t)o.NM_TR; P.max_nt = (uint32_t)o.MAX_NT; P.qth = (uint32_t)o.qth;
+    P.okam = o.okam; P.qc = o.qc; P.extract = (uint32_t)o.extractFastX; P.threading = o.threading; P.simmode = (uint32_t)o.simmode;
+    if (o.ngpus < 1) o.ngpus = 1;
+    std::vector<dbtk_ctx_t*> ctx(o.ngpus, nullptr);
+    for (int d = 0; d < o.ngpus; ++d)
+        if (dbtk_ctx_create(rpgg, &P, d, &ctx[d])) die_assert(dbtk_last_error());
+
+    // ---- the batch loop (AQ.cpp:1869-2282): read a batch, align it on a GPU, write its records
+    Reader in;
+    in.f = fopen(o.fastxFname.c_str(), "rb");
+    if (!in.f) die_assert("cannot open " + o.fastxFname);
+    in.buf.resize(8u << 20);
+    const uint64_t readsPerBatch = (uint64_t)(300000 * o.readsPerBatchFactor);
+    const uint64_t minReadSize = (uint16_t)o.Cthreshold + o.ksize - 1;
+    std::unordered_map<std::string, std::pair<std::string, std::string>> parked;  // readDB / fqDB
+    const bool want_recs = o.okam || o.extractFastX;
+    uint64_t nReads = 0;
+    time1 = time(nullptr);
+    fprintf(stderr, "threads created\n");
+    int next_gpu = 0;
+    std::string out;  // stdout of one batch
+    std::vector<uint8_t> flat;
+    std::vector<uint64_t> off;
+    std::vector<dbtk_pair_rec_t> recs;
+    for (;;) {
+        if (in.at_eof()) break;
+        Batch b;
+        std::string title, seq1, qtitle, qual1, seq2, qual2;
+        while (b.nreads < readsPerBatch && !in.at_eof()) {
+            bool se = true;  // still single-ended
+            while (se) {
+                in.getline(title);
+                in.getline(seq1);
+                if (o.isFastq) { in.getline(qtitle); in.getline(qual1); }
+                prunePEinfo(title);
+                auto it = parked.find(title);
+                if (it != parked.end()) {
+                    if (seq1.size() < minReadSize || it->second.first.size() < minReadSize) { parked.erase(it); continue; }
+                    seq2 = std::move(it->second.first);
+                    qual2 = std::move(it->second.second);
+                    parked.erase(it);
+                    se = false;
+                    break;
+                }
+                parked[title] = std::make_pair(seq1, qual1);
+                if (in.at_eof()) break;
+            }
+            if (se) break;  // input exhausted with this record unpaired (FASTA: AQ.cpp:1967)
+            if (o.simmode) b.src.push_back(parse_src(title, o.simmode, nloci));
+            b.titles.push_back(title);
+            b.seqs.push_back(seq1); b.seqs.push_back(seq2);
+            if (o.isFastq) { b.quals.push_back(qual1); b.quals.push_back(qual2); }
+            b.nreads += 2;
+        }
+        nReads += b.nreads;
+        fprintf(stderr, "Buffered reading %llu\t%llu\t%zu\n", (unsigned long long)b.nreads, (unsigned long long)nReads, parked.size());
+        if (b.nreads == 0) continue;
+        const time_t time2 = time(nullptr);
+        // flatten: read r = flat[off[r] .. off[r+1])
+        off.assign(b.nreads + 1, 0);
+        for (uint64_t r = 0; r < b.nreads; ++r) off[r + 1] = off[r] + b.seqs[r].size();
+        flat.resize(off[b.nreads] + 1);
+        for (uint64_t r = 0; r < b.nreads; ++r) memcpy(flat.data() + off[r], b.seqs[r].data(), b.seqs[r].size());
+        const uint64_t npairs = b.nreads / 2;
+        if (want_recs) recs.resize(npairs);
+        uint64_t nrec = 0;
+        dbtk_ctx_t* c = ctx[next_gpu];
+        next_gpu = (next_gpu + 1) % o.ngpus;
+        const dbtk_status_t st = dbtk_align_batch(c, flat.data(), off.data(), nullptr, npairs, want_recs ? recs.data() : nullptr,
+                                                  want_recs ? npairs : 0, &nrec);
+        if (st) die_assert(std::string("align: ") + dbtk_last_error());
+        // ---- critical section B: stdout
+        out.clear();
+        for (uint64_t i = 0; i < nrec; ++i) {
+            const dbtk_pair_rec_t& r = recs[i];
+            const uint64_t p = r.pair;
+            if (o.extractFastX) {  // writeExtractedReads, AQ.cpp:1618-1644: mate 2p+1 first, then 2p
+                for (int which = 1; which >= 0; --which) {
+                    out += b.titles[p];
+                    if (o.extractFastX != 1) { out += ':'; out += std::to_string(r.dst); }
+                    out += '\n'; out += b.seqs[2 * p + which]; out += '\n';
+                    if (o.isFastq) { out += "+\n"; out += b.quals[2 * p + which]; out += '\n'; }
+                }
+                continue;
+            }
+            const uint64_t src = o.simmode ? b.src[p] : ~0ull;
+            const bool src_ok = src != nloci && src != ~0ull;
+            if (!(src_ok || r.dst != nloci)) continue;  // AQ.cpp:2169
+            out += (src == ~0ull ? std::string(".") : std::to_string((int)src)); out += '\t';
+            out += std::to_string(r.dst); out += '\t';
+            out += std::to_string(r.dst != r.dst0 ? (int)r.dst0 : -1); out += '\t';
+            out += std::to_string(r.r2.ei - r.r2.si); out += '\t';
+            out += std::to_string(r.r1.ei - r.r1.si); out += '\t';
+            out += "kf:hf:bf:qf:af:rm:qn:qm:si:nt:bs:ti\t";
+            mate_fields(out, r.r2); out += '\t';
+            mate_fields(out, r.r1); out += '\t';
+            out += annot2str(r.r2); out += '\t';
+            out += annot2str(r.r1); out += '\t';
+            out += b.titles[p].substr(1); out += '\t';
+            out += b.seqs[2 * p + 1]; out += '\t';
+            out += o.isFastq ? b.quals[2 * p + 1] : std::string("."); out += '\t';
+            out += b.seqs[2 * p]; out += '\t';
+            out += o.isFastq ? b.quals[2 * p] : std::string("."); out += '\n';
+        }
+        if (!out.empty()) fwrite(out.data(), 1, out.size(), stdout);
+        fprintf(stderr, "Batch query in %ld sec. %llu pairs, %llu records\n", (long)(time(nullptr) - time2), (unsigned long long)npairs,
+                (unsigned long long)nrec);
+    }
+    fclose(in.f);
+    fflush(stdout);
+
+    // ---- totals + dumps (AQ.cpp:2611-2656)
+    if (o.ngpus > 1 && dbtk_allreduce(ctx.data(), o.ngpus)) die_assert(dbtk_last_error());
+    std::vector<uint64_t> counts(dbtk_rpgg_ntrkmers(rpgg)), kmc(nloci), counters(DBTK_C_COUNT);
+    std::vector<uint32_t> nmapread(nloci);
+    if (dbtk_ctx_counts(ctx[0], counts.data(), kmc.data(), nmapread.data(), counters.data())) die_assert(dbtk_last_error());
+    fprintf(stderr,
+            "%llu reads processed in total.\n%llu reads removed by subsampled kmer-filter.\n%llu reads removed by kmer-filter.\n"
+            "%llu reads removed by bait locus.\n%llu reads removed by qual filter.\n%llu reads removed during locus assignment.\n"
+            "%llu reads removed by QC filter.\n%llu reads entered threading step.\n%llu reads passsed threading.\n"
+            "%llu reads assigned to TR region.\nparallel query completed in %ld sec.\n",
+            (unsigned long long)nReads, (unsigned long long)counters[DBTK_C_SUBFILTERED], (unsigned long long)counters[DBTK_C_KMERFILTERED],
+            (unsigned long long)counters[DBTK_C_BAITFILTERED], (unsigned long long)counters[DBTK_C_QUALFILTERED],
+            (unsigned long long)counters[DBTK_C_LOCUSFILTERED], (unsigned long long)counters[DBTK_C_QCFILTERED],
+            (unsigned long long)counters[DBTK_C_THREADING], (unsigned long long)counters[DBTK_C_FEASIBLE],
+            (unsigned long long)counters[DBTK_C_ASGN], (long)(time(nullptr) - time1));
+    if (!o.extractFastX) {
+        fprintf(stderr, "writing kmers...\n");
+        if (dbtk_write_outputs(rpgg, counts.data(), kmc.data(), nmapread.data(), o.outPrefix.c_str(), o.writeKmerName))
+            die_assert(dbtk_last_error());
+    }
+    for (auto c : ctx) dbtk_ctx_free(c);
+    dbtk_rpgg_free(rpgg);
+    fprintf(stderr, "all done!\n");
+    return 0;
+}

@@ -1035,6 +1035,8 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 if (a.P.qc && T.qc && !T.qc[dst]) {  // AQ.cpp:2059-2062
                     c_qc += (uint64_t)(2 - rm[0] - rm[1]);
                     stage = DBTK_STAGE_QC;
+                } else if (a.P.threading) {  // AQ.cpp:2070-2090: `alned` stays false at HEAD, nothing else happens
+                    c_thr += 2;
                 } else if (a.P.extract) {  // AQ.cpp:2094-2099
                     c_thr += 2; c_feas += 2;
                     stage = DBTK_STAGE_EXTRACT;
@@ -1119,6 +1121,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         DBTK_STAMP(13);  // accumulate
         // ---- P12: record (kam: AQ.cpp:2169-2175; trace: every pair)
         const bool want = a.recs && (a.P.trace || (okam && stage == DBTK_STAGE_COUNTED) ||
+                                     (okam && a.P.simmode && stage == DBTK_STAGE_ASGN) ||
                                      (a.P.extract && stage == DBTK_STAGE_EXTRACT));
         if (want) {
             uint32_t at = pair;

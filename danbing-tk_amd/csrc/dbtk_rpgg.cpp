@@ -159,7 +159,7 @@ dbtk_status_t finish_rpgg(dbtk_rpgg* g) {
 extern "C" {
 
 dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_file, const char* bait_file,
-                             dbtk_rpgg_t** out) {
+                             uint32_t flags, dbtk_rpgg_t** out) {
     if (!prefix || !out) { set_error("null argument"); return DBTK_ERR_ARG; }
     *out = nullptr;
     std::unique_ptr<dbtk_rpgg> g(new dbtk_rpgg);
@@ -182,9 +182,18 @@ dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_
         g->vv.resize(nvv);
         if (!f.read(g->vv.data(), nvv)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
     }
-    if ((st = read_kdb(pref + ".fl.kdb", g->nloci, g->fl_cnt, g->fl_ks))) return st;
-    if ((st = read_kdb(pref + ".tre.kdb", g->nloci, g->tre_cnt, g->tre_ks))) return st;
-    if (qc_file) {  // readQCFile, src/kmerIO.hpp:111-120
+    if (flags & DBTK_LOAD_INDEX_ONLY) {
+        g->fl_cnt.assign(g->nloci, 0);
+        g->tre_cnt.assign(g->nloci, 0);
+    } else {
+        if ((st = read_kdb(pref + ".fl.kdb", g->nloci, g->fl_cnt, g->fl_ks))) return st;
+        if ((st = read_kdb(pref + ".tre.kdb", g->nloci, g->tre_cnt, g->tre_ks))) return st;
+    }
+    if (qc_file && (flags & DBTK_LOAD_INDEX_ONLY)) {
+        // extract mode never calls readQCFile (AQ.cpp:2484-2488): the mask stays as constructed, all zero
+        // (AQ.cpp:2471), so with -qc every assigned pair fails the QC gate.  Reproduced as is.
+        g->qc.assign(g->nloci, 0);
+    } else if (qc_file) {  // readQCFile, src/kmerIO.hpp:111-120
         File f(qc_file, "rb");
         if (!f.f) { set_error(std::string("cannot open ") + qc_file); return DBTK_ERR_IO; }
         g->qc.resize(g->nloci);

@@ -67,7 +67,10 @@ typedef struct dbtk_params {
     uint32_t bubbles;      /* -bu        count novel (k+1)-mers */
     uint32_t extract;      /* -e 1|2     extract mode: locus assignment only */
     uint32_t trace;        /* test hook: emit a record for EVERY pair, not only kam ones */
-    uint32_t reserved[7];
+    uint32_t threading;    /* -g/-gc/-gcc: accepted like the reference; at HEAD its call sites are commented out
+                              (AQ.cpp:2072-2088), so assigned pairs are only counted as "entered threading" */
+    uint32_t simmode;      /* -s 1|2: also emit records of pairs whose two mates assignTRkmc rejected (AQ.cpp:2169) */
+    uint32_t reserved[5];
 } dbtk_params_t;
 
 /* ---- RPGG in flat (file-equivalent) form ----------------------------------
@@ -148,8 +151,9 @@ enum {
 /* ---- RPGG -----------------------------------------------------------------*/
 /* Load PREF.{tr.kmers,kmers.dbi,fl.kdb,tre.kdb} (+ optional qc / bait files,
  * NULL to skip).  Replaces src/aQueryFasta_thread.cpp:2459,2490-2500. */
+#define DBTK_LOAD_INDEX_ONLY 1u  /* -e (extract) mode: only PREF.tr.kmers + PREF.kmers.dbi are read (AQ.cpp:2484-2488) */
 dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_file,
-                             const char* bait_file, dbtk_rpgg_t** out);
+                             const char* bait_file, uint32_t flags, dbtk_rpgg_t** out);
 /* Same handle from caller arrays (copied). */
 dbtk_status_t dbtk_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a, dbtk_rpgg_t** out);
 void          dbtk_rpgg_free(dbtk_rpgg_t* h);

@@ -893,7 +893,8 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
             if (p->qc && g->qc && !g->qc[destLocus]) { nQC += (uint64_t)(2 - rm1 - rm2); stage = DBTK_STAGE_QC; goto emit; }
         }
         nThr += 2;  /* AQ.cpp:2070 */
-        nFeas += 2; /* AQ.cpp:2092 (threading is dead at HEAD: `not threading` branch) */
+        if (p->threading) { stage = DBTK_STAGE_LOCUS; goto emit; } /* AQ.cpp:2072-2090: `alned` stays false at HEAD */
+        nFeas += 2; /* AQ.cpp:2092 */
         if (p->extract) { stage = DBTK_STAGE_EXTRACT; goto emit; } /* AQ.cpp:2094-2099 */
         /* AQ.cpp:2138-2158 */
         if (okam || !rm1 || !rm2) {

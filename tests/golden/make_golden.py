@@ -63,6 +63,11 @@ def main():
         subprocess.run([dtk] + cmd[1:], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         os.remove(os.path.join(d, "refon.trkmc.ar"))
         cmds.append(" ".join(cmd))
+        # 3) -e 2: extracted pairs with the assigned locus appended to the title
+        cmd = ["danbing-tk", "-e", "2"] + base
+        with open(os.path.join(d, "ref.extract.txt"), "wb") as so:
+            subprocess.run([dtk] + cmd[1:], cwd=d, check=True, stdout=so, stderr=subprocess.DEVNULL)
+        cmds.append(" ".join(cmd) + " > ref.extract.txt")
         with open(os.path.join(d, "cmd.txt"), "w") as f:
             f.write("\n".join(cmds) + "\n")
         # stderr has timings: keep only the totals block

@@ -1,0 +1,111 @@
+"""The reference-compatible command line (danbing-tk_amd/bin/danbing-tk): argv
+behaviour on CPU, and on a GPU the same commands as tests/golden/*/cmd.txt must
+reproduce the reference binary's stdout and output files byte for byte."""
+import os
+import shutil
+import signal
+import subprocess
+
+import pytest
+
+import bind
+import cases
+import synth
+from test_oracle import GOLD
+
+ROOT = bind.ROOT
+CLI = os.path.join(ROOT, "danbing-tk_amd", "bin", "danbing-tk")
+GOLDEN = cases.GOLDEN
+
+
+def run(args, cwd=None, **kw):
+    return subprocess.run([CLI] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+
+
+def test_usage_and_invalid_option():
+    r = run([])
+    assert r.returncode == 0 and b"Usage: danbing-tk" in r.stderr and r.stdout == b""   # AQ.cpp:2288-2333
+    r = run(["-nope"])
+    assert r.returncode == -signal.SIGABRT and b"invalid option: -nope" in r.stderr       # AQ.cpp:2424-2427 (`throw;`)
+
+
+def test_missing_files_abort(tmp_path):
+    r = run(["-qs", str(tmp_path / "nothing")])
+    assert r.returncode == -signal.SIGABRT                                               # assert(trFile), AQ.cpp:2391
+    d = os.path.join(GOLDEN, "g1_k21")
+    r = run(["-fa", str(tmp_path / "no.fa"), "-qs", "pan"], cwd=d)
+    assert r.returncode == -signal.SIGABRT                                               # assert(fastxFile), AQ.cpp:2412
+
+
+def test_output_file_is_truncated_at_parse_time(tmp_path):
+    out = tmp_path / "o"
+    (tmp_path / "o.trkmc.ar").write_bytes(b"stale")
+    run(["-o", str(out), "-nope"])
+    assert (tmp_path / "o.trkmc.ar").read_bytes() == b""                                 # AQ.cpp:2417
+
+
+def test_refuses_to_run_without_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    d = os.path.join(GOLDEN, "g1_k21")
+    r = run(["-k", "21", "-fa", "reads.fa", "-qs", "pan", "-o", str(tmp_path / "o")], cwd=d)
+    assert r.returncode == -signal.SIGABRT and b"no CPU execution path" in r.stderr
+
+
+def golden_cmds(name):
+    d = os.path.join(GOLDEN, name)
+    return d, [l.strip() for l in open(os.path.join(d, "cmd.txt")) if l.strip()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_cli_reproduces_reference_binary(name, tmp_path):
+    d, cmds = golden_cmds(name)
+    w = str(tmp_path / "w")
+    shutil.copytree(d, w)
+    for f in os.listdir(w):
+        if f.startswith("ref"):
+            os.remove(os.path.join(w, f))
+    for line in cmds:
+        parts = line.split(" > ")
+        args = parts[0].split()[1:]
+        r = run(args, cwd=w)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        if len(parts) == 2:
+            assert r.stdout == open(os.path.join(d, parts[1]), "rb").read(), f"stdout of `{line}` differs"
+    for f in ("ref.trkmc.ar", "ref.tr.summary.txt", "refon.tr.kmers"):
+        assert open(os.path.join(w, f), "rb").read() == open(os.path.join(d, f), "rb").read(), f
+    assert os.path.getsize(os.path.join(w, "refon.trkmc.ar")) == 0      # -on leaves the truncated .trkmc.ar empty
+    tot = [l for l in open(os.path.join(d, "ref.totals.txt"))]
+    # the totals block of stderr (first run) matches the reference's
+    r = run(cmds[0].split(" > ")[0].split()[1:], cwd=w)
+    mine = [l + "\n" for l in r.stderr.decode().split("\n") if l[:1].isdigit() and " reads " in l]
+    assert mine == tot
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not synth.have_ref(), reason="oracle/_ref not built")
+def test_cli_vs_reference_binary_live(tmp_path):
+    """A fresh mid-size case, reference binary and this CLI run side by side (FASTQ, mates not adjacent)."""
+    loci = synth.make_loci(nloci=60, nhap=3, flank=500, seed=77, shared_frac=0.4)
+    d = str(tmp_path)
+    synth.build_rpgg_with_reference(loci, d, k=21)
+    reads = synth.sim_reads(loci, npairs=6000, seed=78, sub=0.006, indel=0.001, nrate=0.002, chimeric=0.3, background=0.2, short=0.02,
+                            with_qual=True)
+    # interleave: all /2 mates first, then all /1 mates (the reader pairs by title across the whole file)
+    with open(os.path.join(d, "r.fq"), "wb") as f:
+        for which, tag in ((1, b"/2"), (0, b"/1")):
+            for p in range(reads.npairs):
+                f.write(b"@" + reads.titles[p].encode() + tag + b"\n" + reads.seqs[2 * p + which] + b"\n+\n" + reads.quals[2 * p + which] + b"\n")
+    for flags in (["-cth", "45"], ["-cth", "20", "-kf", "8", "2", "-r", "0.01"], ["-e", "1"], ["-gc", "85", "3"]):
+        outs = []
+        for exe, tag in ((synth.ref_tool("danbing-tk"), "ref"), (CLI, "hip")):
+            a = ["-k", "21"] + flags + ["-fq", "r.fq", "-qs", "pan", "-o", tag]
+            r = subprocess.run([exe] + a, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0, r.stderr.decode()[-1000:]
+            outs.append(r.stdout)
+        assert outs[0] == outs[1], f"stdout differs for {flags}"
+        if "-e" not in flags:
+            for ext in (".trkmc.ar", ".tr.summary.txt"):
+                assert open(os.path.join(d, "ref" + ext), "rb").read() == open(os.path.join(d, "hip" + ext), "rb").read(), (flags, ext)
