@@ -114,6 +114,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.synchronize()
+    reduce_counts()  # untimed: RCCL communicator / kernel warm-up (the reduced values are discarded by the reset)
     ctx.reset()
     ctx.timers_reset()
     if os.environ.get("DBTK_NO_TIMERS"):  # diagnostic: cost of the per-kernel event records themselves
