@@ -102,15 +102,16 @@ __global__ void __launch_bounds__(K1_NT) k_encode_subfilter(BatchArgs a) {
     DevX x{&sm};
     body_encode_subfilter(x, a);
 }
-__global__ void __launch_bounds__(64) k_probe(BatchArgs a) {
+// K2 / K3 are instantiated per NS = 64-position slots a read needs (2: <= 128 positions, 3: 150 bp reads, 4: up to 256 bp)
+template <int NS> __global__ void __launch_bounds__(64) k_probe(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) ProbeSmem sm;
     DevX x{&sm};
-    body_probe(x, a);
+    body_probe<NS>(x, a);
 }
-__global__ void __launch_bounds__(64) k_pair(BatchArgs a) {
-    __shared__ __attribute__((aligned(16))) PairSmem sm;
+template <int NS, bool RECS> __global__ void __launch_bounds__(64) k_pair(BatchArgs a) {
+    __shared__ __attribute__((aligned(16))) PairSmemT<NS> sm;
     DevX x{&sm};
-    body_pair(x, a);
+    body_pair<NS, RECS>(x, a);
 }
 
 // ---------------------------------------------------------------- context --
@@ -163,7 +164,7 @@ struct dbtk_ctx {
     bool timers_on = true;
     uint64_t* d_vote = nullptr;
     uint32_t* d_epoch = nullptr;
-    int pair_blocks = 0, num_cu = 0;
+    int pair_blocks[3] = {0, 0, 0}, num_cu = 0, max_pair_blocks = 0;
     uint32_t consistent = 0;
     Timed timed[NKERN];
 };
@@ -334,6 +335,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     const uint32_t k = c->g->ksize;
     const uint32_t nkmax = max_read_len >= k ? max_read_len - k + 1 : 1;
     const uint32_t nkp = 64 * ((nkmax + 63) / 64);
+    const uint32_t ns = nkp / 64;
     const uint64_t tcap = npairs < SURV_CAP ? npairs : SURV_CAP;
     const uint64_t nchunks = (npairs + tcap - 1) / tcap;
     dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, npairs + 1);
@@ -368,9 +370,24 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         a.t0 = (uint32_t)(ch * tcap);
         a.ticket = c->d_tickets + ch;
         if (tm) { if ((st = timed_slot(c, 1, &e))) return st; HIPCHK(hipEventRecord(c->timed[1].beg[e], s)); }
-        hipLaunchKernelGGL(k_probe, dim3(c->num_cu * 32), dim3(64), 0, s, a);
+        switch (ns) {
+            case 1: case 2: hipLaunchKernelGGL(k_probe<2>, dim3(c->num_cu * 32), dim3(64), 0, s, a); break;
+            case 3: hipLaunchKernelGGL(k_probe<3>, dim3(c->num_cu * 32), dim3(64), 0, s, a); break;
+            default: hipLaunchKernelGGL(k_probe<4>, dim3(c->num_cu * 32), dim3(64), 0, s, a); break;
+        }
         if (tm) { HIPCHK(hipEventRecord(c->timed[1].end[e], s)); if ((st = timed_slot(c, 2, &e))) return st; HIPCHK(hipEventRecord(c->timed[2].beg[e], s)); }
-        hipLaunchKernelGGL(k_pair, dim3(c->pair_blocks), dim3(64), 0, s, a);
+        // RECS = false: no record buffer (-ka without -e): record emission is compiled out
+        const int nsi = ns <= 2 ? 0 : (ns == 3 ? 1 : 2);
+        const dim3 gp(c->pair_blocks[nsi]);
+        if (d_recs) {
+            if (nsi == 0) hipLaunchKernelGGL((k_pair<2, true>), gp, dim3(64), 0, s, a);
+            else if (nsi == 1) hipLaunchKernelGGL((k_pair<3, true>), gp, dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((k_pair<4, true>), gp, dim3(64), 0, s, a);
+        } else {
+            if (nsi == 0) hipLaunchKernelGGL((k_pair<2, false>), gp, dim3(64), 0, s, a);
+            else if (nsi == 1) hipLaunchKernelGGL((k_pair<3, false>), gp, dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((k_pair<4, false>), gp, dim3(64), 0, s, a);
+        }
         if (tm) HIPCHK(hipEventRecord(c->timed[2].end[e], s));
     }
     HIPCHK(hipGetLastError());
@@ -402,12 +419,18 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free_ctx(c); set_error("hipGetDeviceProperties failed"); return DBTK_ERR_HIP; }
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->pair_blocks = c->num_cu * 8;
     {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_subfilter, K1_NT, 0) != hipSuccess || nb <= 0) nb = 4;
         c->k1_blocks = c->num_cu * nb;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pair, 64, 0) == hipSuccess && nb > 0) c->pair_blocks = c->num_cu * nb;
+        // resident waves of each resolve-kernel instance (one vote-spill scratch row per resident wave)
+        const void* kp[3] = {(const void*)k_pair<2, true>, (const void*)k_pair<3, true>, (const void*)k_pair<4, true>};
+        for (int i = 0; i < 3; ++i) {
+            nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kp[i], 64, 0) != hipSuccess || nb <= 0) nb = 8;
+            c->pair_blocks[i] = c->num_cu * nb;
+            c->max_pair_blocks = std::max(c->max_pair_blocks, c->pair_blocks[i]);
+        }
     }
     dbtk_status_t st = DBTK_OK;
     do {
@@ -426,12 +449,12 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         chk(hipMalloc(&c->d_accum, c->n_accum * 8), "hipMalloc accum");
         chk(hipMalloc(&c->d_small, 4 * SMALL_WORDS + 32 * 8), "hipMalloc small");
         if (!st) chk(hipMemsetAsync(c->d_small, 0, 4 * SMALL_WORDS + 32 * 8, c->stream), "memset");
-        chk(hipMalloc(&c->d_vote, (size_t)c->pair_blocks * (h->nloci + 1) * 8), "hipMalloc vote scratch");
-        chk(hipMalloc(&c->d_epoch, (size_t)c->pair_blocks * 4), "hipMalloc epoch");
+        chk(hipMalloc(&c->d_vote, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8), "hipMalloc vote scratch");
+        chk(hipMalloc(&c->d_epoch, (size_t)c->max_pair_blocks * 4), "hipMalloc epoch");
         if (st) break;
         chk(hipMemsetAsync(c->d_accum, 0, c->n_accum * 8, c->stream), "memset");
-        chk(hipMemsetAsync(c->d_vote, 0, (size_t)c->pair_blocks * (h->nloci + 1) * 8, c->stream), "memset");
-        chk(hipMemsetAsync(c->d_epoch, 0, (size_t)c->pair_blocks * 4, c->stream), "memset");
+        chk(hipMemsetAsync(c->d_vote, 0, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8, c->stream), "memset");
+        chk(hipMemsetAsync(c->d_epoch, 0, (size_t)c->max_pair_blocks * 4, c->stream), "memset");
         chk(hipStreamSynchronize(c->stream), "sync");
     } while (0);
     if (st) { free_ctx(c); return st; }

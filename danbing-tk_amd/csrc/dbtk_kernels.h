@@ -385,33 +385,34 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
 
 // ================================================================= K2 .. K4 =
 // One wavefront (64-thread block) per surviving pair.
-constexpr int LCAP = 512;        // per-pair locus map in LDS (vote); spills to vote_scratch
-constexpr int LLIMIT = 384;
-constexpr int NSLOT = NKMAX / 64;  // k-mer positions per lane per mate
+constexpr int NSLOT = NKMAX / 64;  // upper bound of k-mer positions per lane per mate
 constexpr int NBKT = 256;          // buckets of the hit-list sort (top 8 bits of the k-mer: monotone in the key)
-struct PairSmem {
-    uint32_t hval[2][NKMAX];   // index val by read position (NOHIT = not in the index)
+// LDS of the resolve kernel, sized by NS = 64-position slots per read (3 for 150 bp reads): NH hit
+// entries per pair, LC slots in the per-pair locus map of the vote (which spills to vote_scratch).
+template <int NS>
+struct PairSmemT {
+    static constexpr int NK = 64 * NS, NH = 128 * NS, LC = NS >= 3 ? 512 : 256;  // LC >= NH: the map doubles as sort scratch
+    uint32_t hval[2][NK];      // index val by read position (NOHIT = not in the index); later the vote's loci pool
     union {
-        struct { uint64_t skey[NHMAX]; uint16_t sinfo[NHMAX]; } s;                     // hit list being sorted
-        struct { uint32_t nml[NHMAX]; uint32_t lkey[LCAP]; uint16_t ord[NHMAX]; } v;    // vote phase
+        struct { uint64_t skey[NH]; uint16_t sinfo[NH]; } s;                      // hit list being sorted
+        struct { uint32_t nml[NH]; uint32_t lkey[LC]; uint16_t ord[NH]; } v;       // vote phase
     } u;
     union {
         struct {
-            uint32_t uval[NHMAX];  // unique k-mers in ascending key order: index val
-            uint32_t dd[NHMAX];    // PE_KMC dup: count in mate 0 | count in mate 1 << 16
-            uint32_t lhit[LCAP];
-            uint16_t poff[NHMAX];  // vote: where a multi-locus k-mer's loci sit in the LDS pool (0xFFFF: read vv in HBM)
+            uint32_t uval[NH];  // unique k-mers in ascending key order: index val
+            uint32_t dd[NH];    // PE_KMC dup: count in mate 0 | count in mate 1 << 16
+            uint32_t lhit[LC];
+            uint16_t poff[NH];  // vote: where a multi-locus k-mer's loci sit in the LDS pool (0xFFFF: read vv in HBM)
         } a;
-        struct {                   // bucket sort of the hit list (before any of the above is live)
-            uint64_t tmpk[NHMAX];
-            uint16_t tmpi[NHMAX];
+        struct {                // bucket sort of the hit list (before any of the above is live)
+            uint64_t tmpk[NH];
+            uint16_t tmpi[NH];
             uint32_t cnt[NBKT];
             uint16_t bst[NBKT];
         } b;
     } w;
     int stack[3 * 40];
     int32_t res[8];            // vote result
-    int32_t mres[2][12];       // per-mate assign results
 };
 
 // assignTRkmc's scan, literally (src/aQueryFasta_thread.cpp:1470-1555), over the
@@ -474,17 +475,18 @@ DBTK_HD void assign_scan(const uint8_t* as, int nk, uint32_t ntr, const dbtk_par
 struct HitMap {
     uint32_t* lkey; uint32_t* lhit; uint32_t n;
     uint64_t* g; uint32_t epoch; bool spilled;
+    uint32_t cap, shift, limit;  // LDS map: cap = 2^(32 - shift) slots, migrate to HBM beyond `limit` loci
 };
 DBTK_HD uint32_t hitmap_add(HitMap& m, uint32_t locus, uint32_t add) {  // returns the new h1 | h2<<16
     if (!m.spilled) {
-        uint32_t i = (locus * 0x9E3779B1u) >> 23;  // LCAP = 512
+        uint32_t i = (locus * 0x9E3779B1u) >> m.shift;
         for (;;) {
             if (m.lkey[i] == locus) { m.lhit[i] += add; return m.lhit[i]; }
             if (m.lkey[i] == NAN32) break;
-            i = (i + 1) & (LCAP - 1);
+            i = (i + 1) & (m.cap - 1);
         }
-        if (m.n < (uint32_t)LLIMIT) { m.lkey[i] = locus; m.lhit[i] = add; ++m.n; return add; }
-        for (int j = 0; j < LCAP; ++j)  // migrate
+        if (m.n < m.limit) { m.lkey[i] = locus; m.lhit[i] = add; ++m.n; return add; }
+        for (uint32_t j = 0; j < m.cap; ++j)  // migrate
             if (m.lkey[j] != NAN32) m.g[m.lkey[j]] = ((uint64_t)m.epoch << 32) | m.lhit[j];
         m.spilled = true;
     }
@@ -571,13 +573,13 @@ DBTK_HD void vote(const DevTables& T, const uint16_t* ord, const uint32_t* uval,
 // S_i of the permuted dups, the early stop is the first i with 2*S_i >= total,
 // and the get_acm1 loop ends at the first j >= i whose prefix sums fail the
 // test: three wave scans instead of a serial loop.  Lane l owns permuted
-// entries [8l, 8l+8).  Returns fc | rc << 16 (same on every lane).
-template <class X>
+// entries [EPL*l, EPL*l + EPL).  Returns fc | rc << 16 (same on every lane).
+template <int EPL, class X>
 DBTK_HD uint32_t vote_single_locus(X& x, const uint16_t* perm_row, const uint32_t* dd, uint32_t nu, uint32_t cth) {
-    const uint32_t lane = (uint32_t)x.lane(), b0 = 8 * lane;
-    uint32_t pre[8], run = 0;
+    const uint32_t lane = (uint32_t)x.lane(), b0 = EPL * lane;
+    uint32_t pre[EPL], run = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < EPL; ++j) {
         const uint32_t i = b0 + j;
         if (i < nu) run += dd[perm_row[i]] & 0x00FF00FFu;  // uint8_t counts, AQ.cpp:42
         pre[j] = run;
@@ -587,7 +589,7 @@ DBTK_HD uint32_t vote_single_locus(X& x, const uint16_t* perm_row, const uint32_
     const uint32_t total = (tot2 & 0xFFFF) + (tot2 >> 16);
     uint32_t firstA = 0xFFFFFFFFu;
 #pragma unroll
-    for (int j = 7; j >= 0; --j) {
+    for (int j = EPL - 1; j >= 0; --j) {
         const uint32_t i = b0 + j, p = excl + pre[j], S = (p & 0xFFFF) + (p >> 16);
         if (i < nu && 2 * S >= total) firstA = i;
     }
@@ -595,7 +597,7 @@ DBTK_HD uint32_t vote_single_locus(X& x, const uint16_t* perm_row, const uint32_
     const uint32_t istar = x.bcast(firstA, mA ? (int)__builtin_ctzll(mA) : 0);
     uint32_t firstB = 0xFFFFFFFFu, pB = 0;
 #pragma unroll
-    for (int j = 7; j >= 0; --j) {
+    for (int j = EPL - 1; j >= 0; --j) {
         const uint32_t i = b0 + j, p = excl + pre[j], f = p & 0xFFFF, r = p >> 16;
         if (i < nu && i >= istar && !get_acm1(f, r, total - f - r, cth)) { firstB = i; pB = p; }
     }
@@ -626,8 +628,9 @@ struct ProbeSmem {
     uint16_t vd[20];
 };
 
-template <class X>
+template <int NS, class X>
 DBTK_HD void body_probe(X& x, const BatchArgs& a) {
+    constexpr int NSLOT = NS;  // 64-position slots per read (shadows the global upper bound)
     ProbeSmem& sm = *x.template smem<ProbeSmem>();
     const int lane = x.lane();
     const DevTables& T = a.T;
@@ -714,9 +717,12 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
 }
 
 // ======================================================================= K3 =
-template <class X>
+template <int NS, bool RECS, class X>
 DBTK_HD void body_pair(X& x, const BatchArgs& a) {
-    PairSmem& sm = *x.template smem<PairSmem>();
+    typedef PairSmemT<NS> Smem;
+    constexpr int NSLOT = NS, NHMAX = Smem::NH, LCAP = Smem::LC;  // shadow the global upper bounds
+    constexpr int EPL = 2 * NS;  // hit-list entries per lane
+    Smem& sm = *x.template smem<Smem>();
     const int lane = x.lane();
     const DevTables& T = a.T;
     const uint32_t k = T.ksize, cth = a.P.cthreshold, nloci = T.nloci;
@@ -847,16 +853,16 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
             {
                 const uint32_t bsh = 2 * k > 8 ? 2 * k - 8 : 0;
                 const int nown = (int)((n + 63 - lane) / 64);  // entries lane, lane+64, ... owned by this lane
-                uint64_t myk[8]; uint32_t myi[8], mys[8];
+                uint64_t myk[EPL]; uint32_t myi[EPL], mys[EPL];
                 for (uint32_t i = lane; i < (uint32_t)NBKT; i += 64) sm.w.b.cnt[i] = 0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < EPL; ++j) {
                     myk[j] = 0; myi[j] = 0; mys[j] = 0;
                     if (j < nown) { myk[j] = sm.u.s.skey[lane + 64 * j]; myi[j] = sm.u.s.sinfo[lane + 64 * j]; }
                 }
                 x.sync();
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < EPL; ++j)
                     if (j < nown) mys[j] = x.lds_add(&sm.w.b.cnt[(uint32_t)(myk[j] >> bsh) & (NBKT - 1)], 1u);  // slot in bucket
                 x.sync();
                 {   // bucket starts: lane owns buckets [4 * lane, 4 * lane + 4)
@@ -869,7 +875,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 }
                 x.sync();
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < EPL; ++j)
                     if (j < nown) {
                         const uint32_t b = (uint32_t)(myk[j] >> bsh) & (NBKT - 1);
                         const uint32_t at = sm.w.b.bst[b] + mys[j];
@@ -878,7 +884,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     }
                 x.sync();
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < EPL; ++j)
                     if (j < nown) {
                         const uint32_t b = (uint32_t)(myk[j] >> bsh) & (NBKT - 1);
                         const uint32_t b0 = sm.w.b.bst[b], bn = sm.w.b.cnt[b];
@@ -898,13 +904,13 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
             DBTK_STAMP(6);  // sort
             uint32_t nu;
             {
-                // contiguous ownership: lane owns sorted entries [8*lane, 8*lane+8)
-                const uint32_t b0 = 8 * (uint32_t)lane;
+                // contiguous ownership: lane owns sorted entries [EPL*lane, EPL*lane + EPL)
+                const uint32_t b0 = EPL * (uint32_t)lane;
                 uint32_t heads = 0;
                 const uint64_t prevk = (b0 > 0 && b0 <= n) ? sm.u.s.skey[b0 - 1] : 0;
-                uint64_t ks[8];
+                uint64_t ks[EPL];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < EPL; ++j) {
                     const uint32_t r = b0 + j;
                     ks[j] = r < n ? sm.u.s.skey[r] : 0;
                     if (r < n && (r == 0 || ks[j] != (j ? ks[j - 1] : prevk))) ++heads;
@@ -912,7 +918,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 uint32_t uidx = x.wave_excl_scan(heads);  // unique index of my first head
                 nu = x.wave_sum(heads);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {  // a non-head entry belongs to the most recent head at or before it
+                for (int j = 0; j < EPL; ++j) {  // a non-head entry belongs to the most recent head at or before it
                     const uint32_t r = b0 + j;
                     if (r < n) {
                         const bool head = (r == 0 || ks[j] != (j ? ks[j - 1] : prevk));
@@ -950,18 +956,18 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     x.sync();
                     {   // loci lists of the multi-locus k-mers into LDS (hval is dead after the dedup), all lanes
                         // loading in parallel: the vote itself then runs without touching HBM
-                        const uint32_t b0 = 8 * (uint32_t)lane;
+                        const uint32_t b0 = EPL * (uint32_t)lane;
                         uint32_t need = 0;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) if (b0 + j < nu && (sm.w.a.uval[b0 + j] & 1)) need += sm.u.v.nml[b0 + j];
+                        for (int j = 0; j < EPL; ++j) if (b0 + j < nu && (sm.w.a.uval[b0 + j] & 1)) need += sm.u.v.nml[b0 + j];
                         uint32_t at = x.wave_excl_scan(need);
                         uint32_t* pool = &sm.hval[0][0];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
+                        for (int j = 0; j < EPL; ++j) {
                             const uint32_t u = b0 + j;
                             if (u < nu) {
                                 const uint32_t v = sm.w.a.uval[u], nn = (v & 1) ? sm.u.v.nml[u] : 0;
-                                if (nn && at + nn <= (uint32_t)(2 * NKMAX)) {
+                                if (nn && at + nn <= (uint32_t)NHMAX) {
                                     sm.w.a.poff[u] = (uint16_t)at;
                                     for (uint32_t q = 0; q < nn; ++q) pool[at + q] = T.vv[(v >> 1) + 1 + q];
                                 } else sm.w.a.poff[u] = 0xFFFFu;
@@ -980,7 +986,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
             // ---- P7 + P8: the permutation std::sort applies (AQ.cpp:320-327) and the vote
             const uint16_t* perm_row = T.permtab + (size_t)nu * (nu ? nu - 1 : 0) / 2;  // introsort of nu equal keys
             if (single) {
-                const uint32_t fr = vote_single_locus(x, perm_row, sm.w.a.dd, nu, cth);
+                const uint32_t fr = vote_single_locus<EPL>(x, perm_row, sm.w.a.dd, nu, cth);
                 dst0 = x.uni(sm.w.a.uval[0]) >> 1;
                 nm1 = (int)(fr & 0xFFFF); nm2 = (int)(fr >> 16);
             } else {
@@ -1004,7 +1010,8 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 if (lane == 0) {
                     for (uint32_t u = 0; u < nu; ++u) sm.w.a.dd[u] &= 0x00FF00FFu;  // PE_KMC counts are uint8_t
                     const uint32_t ep = a.vote_epoch[x.bid()] + 1;
-                    HitMap hmap{sm.u.v.lkey, sm.w.a.lhit, 0, a.vote_scratch + (size_t)x.bid() * ((size_t)nloci + 1), ep, false};
+                    HitMap hmap{sm.u.v.lkey, sm.w.a.lhit, 0, a.vote_scratch + (size_t)x.bid() * ((size_t)nloci + 1), ep, false,
+                                (uint32_t)LCAP, LCAP == 512 ? 23u : 24u, (uint32_t)(LCAP * 3 / 4)};
                     Asgn top;
                     uint64_t nvvw = 0;
                     vote(T, sm.u.v.ord, sm.w.a.uval, sm.w.a.dd, (int)nu, cth, hmap, top, nvvw, sm.u.v.nml, &sm.hval[0][0], sm.w.a.poff);
@@ -1120,7 +1127,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         }
         DBTK_STAMP(13);  // accumulate
         // ---- P12: record (kam: AQ.cpp:2169-2175; trace: every pair)
-        const bool want = a.recs && (a.P.trace || (okam && stage == DBTK_STAGE_COUNTED) ||
+        const bool want = RECS && a.recs && (a.P.trace || (okam && stage == DBTK_STAGE_COUNTED) ||
                                      (okam && a.P.simmode && stage == DBTK_STAGE_ASGN) ||
                                      (a.P.extract && stage == DBTK_STAGE_EXTRACT));
         if (want) {

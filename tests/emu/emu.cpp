@@ -359,8 +359,19 @@ int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const 
         a.t0 = t0;
         uint32_t ticket = 0;
         a.ticket = &ticket;
-        run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe(x, a); });
-        run_grid(grid_pair, 64, sizeof(PairSmem), [&](EmuX& x) { body_pair(x, a); });
+        switch (a.nkp / 64) {  // same dispatch as the device launcher
+            case 1: case 2:
+                run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<2>(x, a); });
+                run_grid(grid_pair, 64, sizeof(PairSmemT<2>), [&](EmuX& x) { if (a.recs) body_pair<2, true>(x, a); else body_pair<2, false>(x, a); });
+                break;
+            case 3:
+                run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<3>(x, a); });
+                run_grid(grid_pair, 64, sizeof(PairSmemT<3>), [&](EmuX& x) { if (a.recs) body_pair<3, true>(x, a); else body_pair<3, false>(x, a); });
+                break;
+            default:
+                run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<4>(x, a); });
+                run_grid(grid_pair, 64, sizeof(PairSmemT<4>), [&](EmuX& x) { if (a.recs) body_pair<4, true>(x, a); else body_pair<4, false>(x, a); });
+        }
     }
     if (small[3]) return (int)small[3];
     memcpy(counts, accum.data(), ntr * 8);
