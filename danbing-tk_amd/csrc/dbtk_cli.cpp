@@ -218,7 +218,7 @@ int main(int argc, char* argv[]) {
         }
     }
     if (o.trim) die_assert("-t (trimmed tr.kmers) is not supported by this build");
-    if (o.outputBubbles || o.bait || o.trackBait) die_assert("-bu / -b / -tb are not implemented in this build yet");
+    if (o.trackBait) die_assert("-tb (bait hit tracking) is not supported by this build");
 
     fprintf(stderr,
             "use baitDB: %d\nextract fastX: %d\noutput bubbles: %d\nis Fastq: %d\nsim mode: %d\ngraph threading mode: %d\n"
@@ -232,8 +232,9 @@ int main(int argc, char* argv[]) {
     // ---- load (AQ.cpp:2459-2504)
     time_t time1 = time(nullptr);
     dbtk_rpgg_t* rpgg = nullptr;
-    if (dbtk_rpgg_load(o.trPrefix.c_str(), (uint32_t)o.ksize, o.qc ? o.qcFn.c_str() : nullptr, nullptr,
-                       o.extractFastX ? DBTK_LOAD_INDEX_ONLY : 0, &rpgg))
+    const bool use_bait = o.bait && !o.extractFastX && !o.threading;  // baitDB is only read and used on that path
+    if (dbtk_rpgg_load(o.trPrefix.c_str(), (uint32_t)o.ksize, o.qc ? o.qcFn.c_str() : nullptr,
+                       use_bait ? o.baitFname.c_str() : nullptr, o.extractFastX ? DBTK_LOAD_INDEX_ONLY : 0, &rpgg))
         die_assert(dbtk_last_error());
     const uint64_t nloci = dbtk_rpgg_nloci(rpgg);
     fprintf(stderr, "total number of loci in %s: %llu\n", o.trFname.c_str(), (unsigned long long)nloci);
@@ -246,6 +247,8 @@ int main(int argc, char* argv[]) {
     P.cthreshold = (uint32_t)(uint16_t)o.Cthreshold;  // uint16_t in the reference (AQ.cpp:1765)
     P.nm_tr = (uint32_t)o.NM_TR; P.max_nt = (uint32_t)o.MAX_NT; P.qth = (uint32_t)o.qth;
     P.okam = o.okam; P.qc = o.qc; P.extract = (uint32_t)o.extractFastX; P.threading = o.threading; P.simmode = (uint32_t)o.simmode;
+    P.bait = use_bait;
+    P.bubbles = o.outputBubbles && !o.extractFastX && !o.threading;  // countNovelEdges only runs on the assignment path
     if (o.ngpus < 1) o.ngpus = 1;
     std::vector<dbtk_ctx_t*> ctx(o.ngpus, nullptr);
     for (int d = 0; d < o.ngpus; ++d)
@@ -265,7 +268,7 @@ int main(int argc, char* argv[]) {
     fprintf(stderr, "threads created\n");
     int next_gpu = 0;
     std::string out;  // stdout of one batch
-    std::vector<uint8_t> flat;
+    std::vector<uint8_t> flat, flatq;
     std::vector<uint64_t> off;
     std::vector<dbtk_pair_rec_t> recs;
     for (;;) {
@@ -307,13 +310,18 @@ int main(int argc, char* argv[]) {
         for (uint64_t r = 0; r < b.nreads; ++r) off[r + 1] = off[r] + b.seqs[r].size();
         flat.resize(off[b.nreads] + 1);
         for (uint64_t r = 0; r < b.nreads; ++r) memcpy(flat.data() + off[r], b.seqs[r].data(), b.seqs[r].size());
+        const bool send_qual = use_bait && o.isFastq;
+        if (send_qual) {  // qualities feed qString2qMask (AQ.cpp:2104-2107); a quality string is as long as its read
+            flatq.assign(off[b.nreads] + 1, (uint8_t)'!');
+            for (uint64_t r = 0; r < b.nreads; ++r) memcpy(flatq.data() + off[r], b.quals[r].data(), std::min(b.quals[r].size(), b.seqs[r].size()));
+        }
         const uint64_t npairs = b.nreads / 2;
         if (want_recs) recs.resize(npairs);
         uint64_t nrec = 0;
         dbtk_ctx_t* c = ctx[next_gpu];
         next_gpu = (next_gpu + 1) % o.ngpus;
-        const dbtk_status_t st = dbtk_align_batch(c, flat.data(), off.data(), nullptr, npairs, want_recs ? recs.data() : nullptr,
-                                                  want_recs ? npairs : 0, &nrec);
+        const dbtk_status_t st = dbtk_align_batch(c, flat.data(), off.data(), send_qual ? flatq.data() : nullptr, npairs,
+                                                  want_recs ? recs.data() : nullptr, want_recs ? npairs : 0, &nrec);
         if (st) die_assert(std::string("align: ") + dbtk_last_error());
         // ---- critical section B: stdout
         out.clear();
@@ -374,6 +382,13 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, "writing kmers...\n");
         if (dbtk_write_outputs(rpgg, counts.data(), kmc.data(), nmapread.data(), o.outPrefix.c_str(), o.writeKmerName))
             die_assert(dbtk_last_error());
+        if (o.outputBubbles) {  // dumpBubbles, AQ.cpp:2648-2651
+            fprintf(stderr, "writing bubbles...\n");
+            if (P.bubbles) {
+                for (int d = 1; d < o.ngpus; ++d) if (dbtk_ctx_merge_bubbles(ctx[0], ctx[d])) die_assert(dbtk_last_error());
+                if (dbtk_ctx_write_bubbles(ctx[0], o.outPrefix.c_str())) die_assert(dbtk_last_error());
+            }
+        }
     }
     for (auto c : ctx) dbtk_ctx_free(c);
     dbtk_rpgg_free(rpgg);

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "dbtk_internal.h"
@@ -160,6 +161,16 @@ struct dbtk_ctx {
     dbtk_pair_rec_t* d_recs = nullptr; uint64_t rec_cap = 0;
     HitEnt* d_hit = nullptr; uint64_t hit_cap = 0;
     uint32_t* d_tickets = nullptr; uint64_t tickets_cap = 0;
+    // optional gates
+    ClsSlot* d_tre = nullptr; ClsSlot* d_bait = nullptr;
+    uint8_t* d_qual = nullptr; uint64_t qual_cap = 0;
+    uint64_t* d_edge = nullptr; uint64_t edge_cap = 0;
+    uint64_t* d_qmask = nullptr; uint64_t qmask_cap = 0;
+    BubEvent* d_events = nullptr; uint64_t events_cap = 0;
+    uint32_t* d_nevents = nullptr;
+    // bubbleDB (bubble_db_t: per locus unordered_map<size_t, uint32_t>, src/aQueryFasta_thread.h:41), filled batch by
+    // batch exactly like accumBubbles (AQ.cpp:1599-1606) so that the dump order matches the reference's
+    std::vector<std::unordered_map<size_t, uint32_t>> bubbleDB;
     int k1_blocks = 0;
     bool timers_on = true;
     uint64_t* d_vote = nullptr;
@@ -187,7 +198,8 @@ void free_ctx(dbtk_ctx* c) {
             if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
         }
     void* ptrs[] = {c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
-                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hit, c->d_tickets};
+                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hit, c->d_tickets,
+                    c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -291,6 +303,36 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     return DBTK_OK;
 }
 
+// (key, locus) -> value table from per-locus arrays (tre edges: value unused; bait: min << 8 | max)
+dbtk_status_t build_kl_table(dbtk_ctx* c, const std::vector<uint64_t>& cnt, const std::vector<uint64_t>& ks,
+                             const std::vector<uint16_t>* vals, ClsSlot** out, uint64_t* mask, uint32_t* shift) {
+    hipStream_t s = c->stream;
+    const uint64_t nloci = c->g->nloci, n = ks.size();
+    const uint64_t cap = pow2_at_least(2 * n + 2);
+    HIPCHK(hipMalloc(out, cap * sizeof(ClsSlot)));
+    HIPCHK(hipMemsetAsync(*out, 0xFF, cap * sizeof(ClsSlot), s));
+    *mask = cap - 1;
+    *shift = 64 - log2u(cap);
+    if (!n) { HIPCHK(hipStreamSynchronize(s)); return DBTK_OK; }
+    std::vector<uint64_t> beg(nloci + 1, 0), v64(n, 0);
+    for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + cnt[l];
+    if (vals) for (uint64_t i = 0; i < n; ++i) v64[i] = (*vals)[i];
+    uint64_t *dks = nullptr, *dbeg = nullptr, *dval = nullptr, *dn = nullptr;
+    HIPCHK(hipMalloc(&dks, n * 8));
+    HIPCHK(hipMalloc(&dval, n * 8));
+    HIPCHK(hipMalloc(&dbeg, (nloci + 1) * 8));
+    HIPCHK(hipMalloc(&dn, 8));
+    HIPCHK(hipMemsetAsync(dn, 0, 8, s));
+    HIPCHK(hipMemcpyAsync(dks, ks.data(), n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dval, v64.data(), n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dbeg, beg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
+    ClsBuildArgs a{*out, cap - 1, 64 - log2u(cap), dks, dbeg, (uint32_t)nloci, dval, n, dn};
+    hipLaunchKernelGGL(k_cls_insert, dim3(1024), dim3(256), 0, s, a);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(dks)); HIPCHK(hipFree(dval)); HIPCHK(hipFree(dbeg)); HIPCHK(hipFree(dn));
+    return DBTK_OK;
+}
+
 template <class T>
 dbtk_status_t ensure(T** p, uint64_t* cap, uint64_t need) {
     if (need <= *cap && *p) return DBTK_OK;
@@ -328,7 +370,7 @@ constexpr uint64_t SURV_CAP = 1ull << 20;
 constexpr uint32_t SMALL_WORDS = 64;  // d_small: nsurv, tile ticket, nrec, errflag, [8..] per-chunk tickets, stamps at +32
 
 dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_off, uint64_t seq_len, uint64_t npairs,
-                           uint32_t max_read_len, dbtk_pair_rec_t* d_recs, uint32_t rec_cap) {
+                           uint32_t max_read_len, dbtk_pair_rec_t* d_recs, uint32_t rec_cap, const uint8_t* d_qual = nullptr) {
     hipStream_t s = c->stream;
     if (npairs >= 0xFFFFFFFFull) { set_error("batch too large (pair index is 32-bit)"); return DBTK_ERR_ARG; }
     if (npairs == 0) return DBTK_OK;
@@ -344,6 +386,14 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     if ((st = ensure(&c->d_tickets, &c->tickets_cap, nchunks + 1))) return st;
     HIPCHK(hipMemsetAsync(c->d_small, 0, 8 * sizeof(uint32_t), s));
     HIPCHK(hipMemsetAsync(c->d_tickets, 0, (nchunks + 1) * sizeof(uint32_t), s));
+    if (c->P.bubbles) {
+        if ((st = ensure(&c->d_edge, &c->edge_cap, tcap * 2 * nkp))) return st;
+        // every position of every kept mate could be novel; bounded so that the log stays < 6.4 GB
+        const uint64_t ecap = std::min<uint64_t>(npairs * 2 * nkmax, 1ull << 28);
+        if ((st = ensure(&c->d_events, &c->events_cap, ecap))) return st;
+        HIPCHK(hipMemsetAsync(c->d_nevents, 0, sizeof(uint32_t), s));
+    }
+    if (c->P.bait && d_qual && (st = ensure(&c->d_qmask, &c->qmask_cap, tcap * 2 * 4))) return st;
     BatchArgs a;
     memset(&a, 0, sizeof(a));
     a.T = c->T; a.P = c->P;
@@ -356,6 +406,8 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     a.recs = d_recs; a.rec_cap = rec_cap;
     a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
     a.hitbuf = c->d_hit; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
+    if (c->P.bubbles) { a.edgebuf = c->d_edge; a.events = c->d_events; a.nevents = c->d_nevents; a.events_cap = (uint32_t)std::min<uint64_t>(c->events_cap, 0xFFFFFFFFull); }
+    if (c->P.bait && d_qual) { a.qual = d_qual; a.qmaskbuf = c->d_qmask; }
 #ifdef DBTK_STAMPS
     a.dbg = reinterpret_cast<uint64_t*>(c->d_small + 32);
 #endif
@@ -404,7 +456,8 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
     if (p->ksize != h->ksize) { set_error("params.ksize differs from the RPGG's k"); return DBTK_ERR_ARG; }
     if (p->n_filter == 1) { set_error("-kf 1 M divides by zero in the reference (subfilter); refusing"); return DBTK_ERR_ARG; }
     if (p->n_filter > 32) { set_error("-kf N: N > 32 unsupported"); return DBTK_ERR_UNSUPPORTED; }
-    if (p->bait || p->bubbles) { set_error("-b / -bu are not implemented yet"); return DBTK_ERR_UNSUPPORTED; }
+    if (p->bait && h->bt_cnt.empty()) { set_error("params.bait set but the RPGG handle has no bait DB"); return DBTK_ERR_ARG; }
+    if (p->bubbles && (h->tre_cnt.empty() || p->extract)) { set_error("params.bubbles needs PREF.tre.kdb (and is not an extract-mode flag)"); return DBTK_ERR_ARG; }
     if (p->qc && h->qc.empty()) { set_error("params.qc set but the RPGG handle has no QC mask"); return DBTK_ERR_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -443,6 +496,16 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
                 if (hipEventCreate(&c->timed[i].beg[j]) != hipSuccess || hipEventCreate(&c->timed[i].end[j]) != hipSuccess) { set_error("hipEventCreate failed"); st = DBTK_ERR_HIP; }
         if (st) break;
         if ((st = build_tables(c))) break;
+        if (p->bubbles) {
+            if ((st = build_kl_table(c, h->tre_cnt, h->tre_ks, nullptr, &c->d_tre, &c->T.tre_mask, &c->T.tre_shift))) break;
+            c->T.tre = c->d_tre;
+            c->bubbleDB.resize(h->nloci);
+            if (hipMalloc(&c->d_nevents, 4) != hipSuccess) { set_error("hipMalloc nevents"); st = DBTK_ERR_HIP; break; }
+        }
+        if (p->bait) {
+            if ((st = build_kl_table(c, h->bt_cnt, h->bt_ks, &h->bt_vs, &c->d_bait, &c->T.bait_mask, &c->T.bait_shift))) break;
+            c->T.bait = c->d_bait;
+        }
         c->ntr = h->out_kmer.size();
         c->n_accum = c->ntr + 2 * h->nloci + DBTK_C_COUNT;
         auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && !st) { set_error(std::string(what) + ": " + hipGetErrorString(e)); st = DBTK_ERR_HIP; } };
@@ -466,7 +529,6 @@ void dbtk_ctx_free(dbtk_ctx_t* ctx) { free_ctx(ctx); }
 
 dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t* off, const uint8_t* qual,
                                uint64_t npairs, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
-    (void)qual;  // base qualities only matter to the bait filter (-b), not implemented yet
     if (!c || !off || (!seq && npairs)) { set_error("null argument"); return DBTK_ERR_ARG; }
     if (nrec) *nrec = 0;
     HIPCHK(hipSetDevice(c->device));
@@ -501,11 +563,38 @@ dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t
     }
     uint32_t maxlen = 0;
     for (uint64_t r = 0; r < nreads; ++r) maxlen = std::max<uint32_t>(maxlen, (uint32_t)(off[r + 1] - off[r]));
-    if ((st = launch_batch(c, c->d_seq, c->d_off, nbytes, npairs, maxlen, want_recs ? c->d_recs : nullptr, (uint32_t)dcap))) return st;
+    const bool use_qual = c->P.bait && qual;  // base qualities only matter to the bait filter (-b with -fq)
+    if (use_qual) {
+        if ((st = ensure(&c->d_qual, &c->qual_cap, nbytes + 32))) return st;
+        if (nbytes) HIPCHK(hipMemcpyAsync(c->d_qual, qual + base, nbytes, hipMemcpyHostToDevice, s));
+    }
+    if ((st = launch_batch(c, c->d_seq, c->d_off, nbytes, npairs, maxlen, want_recs ? c->d_recs : nullptr, (uint32_t)dcap,
+                           use_qual ? c->d_qual : nullptr))) return st;
     uint32_t small[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(small, c->d_small, sizeof(small), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (small[3]) { set_error("device reported an over-long read"); return (dbtk_status_t)small[3]; }
+    if (c->P.bubbles) {
+        // Replay the batch's novel edges the way the reference accumulates them: the worker's per-batch
+        // `bubbles[destLocus][edge]` is filled in pair order, mate 1 before mate 2, positions ascending
+        // (AQ.cpp:2161-2166), then merged map by map into bubbleDB (accumBubbles, AQ.cpp:1599-1606).
+        uint32_t nev = 0;
+        HIPCHK(hipMemcpy(&nev, c->d_nevents, 4, hipMemcpyDeviceToHost));
+        if (nev > c->events_cap) { set_error("bubble event log overflow"); return DBTK_ERR_OVERFLOW; }
+        std::vector<BubEvent> ev(nev);
+        if (nev) HIPCHK(hipMemcpy(ev.data(), c->d_events, (size_t)nev * sizeof(BubEvent), hipMemcpyDeviceToHost));
+        std::sort(ev.begin(), ev.end(), [](const BubEvent& x, const BubEvent& y) {
+            if (x.pair != y.pair) return x.pair < y.pair;
+            if (x.mate != y.mate) return x.mate < y.mate;
+            return x.pos < y.pos;
+        });
+        std::unordered_map<uint64_t, std::unordered_map<size_t, uint32_t>> bubbles;  // bubbles_t, AQ.cpp:43
+        for (const BubEvent& e : ev) ++bubbles[e.locus][(size_t)e.edge];
+        for (auto& pl : bubbles) {
+            auto& bu_o = c->bubbleDB[pl.first];
+            for (auto& q : pl.second) bu_o[q.first] += q.second;
+        }
+    }
     if (want_recs) {
         const uint64_t produced = c->P.trace ? npairs : small[2];
         if (nrec) *nrec = produced;
@@ -569,6 +658,39 @@ dbtk_status_t dbtk_ctx_reset(dbtk_ctx_t* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(c->d_accum, 0, c->n_accum * 8, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return DBTK_OK;
+}
+
+// OUT.bub.kmdb: dumpBubbles -> dumpKmerMapDB("bub", ..., th = 5) (src/aQueryFasta_thread.h:999-1008):
+// flattenKmapDB keeps the entries with count >= 5 in map iteration order (src/binaryKmerIO.hpp:31-51), then
+// serializeKmapDB writes u64 nloci | u64 index[nloci] | u64 nk | u64 sizeof(val) = 8 | u64 ks[nk] | u64 vs[nk].
+dbtk_status_t dbtk_ctx_write_bubbles(dbtk_ctx_t* c, const char* out_prefix) {
+    if (!c || !out_prefix) { set_error("null argument"); return DBTK_ERR_ARG; }
+    if (!c->P.bubbles) { set_error("context was not created with params.bubbles"); return DBTK_ERR_ARG; }
+    const uint64_t nloci = c->g->nloci;
+    std::vector<uint64_t> index(nloci), ks, vs;
+    for (uint64_t l = 0; l < nloci; ++l) {
+        uint64_t kept = 0;
+        for (auto& p : c->bubbleDB[l])
+            if ((int)p.second >= 5) { ks.push_back(p.first); vs.push_back(p.second); ++kept; }
+        index[l] = kept;
+    }
+    const std::string fn = std::string(out_prefix) + ".bub.kmdb";
+    FILE* f = fopen(fn.c_str(), "wb");
+    if (!f) { set_error("cannot create " + fn); return DBTK_ERR_IO; }
+    const uint64_t nk = ks.size(), szv = 8;
+    bool ok = fwrite(&nloci, 8, 1, f) == 1 && (nloci == 0 || fwrite(index.data(), 8, nloci, f) == nloci) && fwrite(&nk, 8, 1, f) == 1 &&
+              fwrite(&szv, 8, 1, f) == 1 && (nk == 0 || (fwrite(ks.data(), 8, nk, f) == nk && fwrite(vs.data(), 8, nk, f) == nk));
+    fclose(f);
+    if (!ok) { set_error("write failed: " + fn); return DBTK_ERR_IO; }
+    return DBTK_OK;
+}
+
+// Multi-GPU: fold src's bubble DB into dst's (after the run; the reference's order is unspecified for -p > 1).
+dbtk_status_t dbtk_ctx_merge_bubbles(dbtk_ctx_t* dst, dbtk_ctx_t* src) {
+    if (!dst || !src || dst->bubbleDB.size() != src->bubbleDB.size()) { set_error("bad argument"); return DBTK_ERR_ARG; }
+    for (size_t l = 0; l < src->bubbleDB.size(); ++l)
+        for (auto& q : src->bubbleDB[l]) dst->bubbleDB[l][q.first] += q.second;
     return DBTK_OK;
 }
 

@@ -161,6 +161,12 @@ struct BatchArgs {
     struct HitEnt* hitbuf;   // K2 -> K3: [survivor][mate][nkp] probe results
     uint32_t nkp;            // positions reserved per read in hitbuf (multiple of 64)
     uint32_t pair_base;      // index of this sub-batch's first pair inside the caller's batch (records)
+    const uint8_t* qual;     // base qualities (same offsets as seq), nullptr for FASTA; only read when P.bait
+    uint64_t* edgebuf;       // -bu: K2 -> K3 canonical (k+1)-mers [survivor][mate][nkp]
+    uint64_t* qmaskbuf;      // -b with qualities: K2 -> K3 k-mer quality masks [survivor][mate][4 x u64]
+    struct BubEvent* events; // -bu: novel-edge log
+    uint32_t* nevents;
+    uint32_t events_cap;
     uint32_t t0, tcap;       // K2/K3 work on survivors [t0, min(t0 + tcap, *nsurv)): the hit buffer holds tcap pairs
     uint32_t* tile_ticket;   // K1 work counter (tiles)
 };
@@ -622,11 +628,50 @@ struct HitEnt {
     uint32_t val;  // index val, NOHIT when the k-mer is not in the index
     uint32_t aux;  // class of a single-locus k-mer at its locus (see IdxSlot)
 };
+struct BubEvent {  // one novel read (k+1)-mer (countNovelEdges, AQ.cpp:1559-1567)
+    uint32_t pair, mate, pos, locus;
+    uint64_t edge;
+};
 struct ProbeSmem {
     uint32_t raw[72];
     uint32_t pk[20];
     uint16_t vd[20];
+    uint32_t qraw[72];   // base qualities of the read (only with -b and qualities)
+    uint32_t qmask[8];
 };
+
+// qString2qMask (src/aQueryFasta_thread.h:1038-1071), statement by statement, on the quality bytes
+// q[0..nq): bit i of out = k-mer i passes.  Its bounds compare the BASE index with the number of
+// K-MERS, so the scan stops early near the read end: reproduced as is.  One lane, only with -b -fq.
+DBTK_HD void qmask_scan(const uint8_t* q, int nq, int qth, int ksize, uint32_t* out) {
+    const int nk = nq - ksize + 1;
+    if (nk <= 0) return;
+    int qi = 0, ki = 0;
+    while ((int)q[qi] - 33 < qth) { ++qi; ++ki; if (qi >= nk) return; }
+    while (qi < nk) {
+        bool pass = true;
+        for (int qj = qi; qi < qj + ksize; ++qi) {
+            if ((int)q[qi] - 33 < qth) {
+                pass = false;
+                ki = qi;
+                while ((int)q[qi] - 33 < qth) { ++qi; ++ki; if (qi >= nk) return; }
+                break;
+            }
+        }
+        if (pass) {
+            out[ki >> 5] |= 1u << (ki & 31);
+            ++ki;
+            if (qi >= nk) return;
+            while ((int)q[qi] - 33 >= qth) {
+                out[ki >> 5] |= 1u << (ki & 31);
+                ++qi; ++ki;
+                if (qi >= nk) return;
+            }
+            ki = qi;
+            while ((int)q[qi] - 33 < qth) { ++qi; ++ki; if (qi >= nk) return; }
+        }
+    }
+}
 
 template <int NS, class X>
 DBTK_HD void body_probe(X& x, const BatchArgs& a) {
@@ -638,7 +683,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
     const uint32_t ns = *a.nsurv;
     const uint32_t tend = ns - a.t0 < a.tcap ? ns : a.t0 + a.tcap;  // (ns >= t0 checked by the caller loop below)
     const uint32_t nitems = ns > a.t0 ? 2 * (tend - a.t0) : 0;
-    for (uint32_t it = x.bid(); it < nitems; it += x.nblocks()) {
+    for (uint32_t it = x.bid(); it < nitems; it += x.nblocks()) {  // `it` = hit-buffer row of (survivor, mate)
         const uint32_t t = a.t0 + (it >> 1), m = it & 1;
         const uint32_t pair = a.surv[t];
         const uint64_t o0 = a.off[2 * (uint64_t)pair + m], o1 = a.off[2 * (uint64_t)pair + m + 1];
@@ -713,6 +758,23 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             const uint32_t i = 64 * s + lane;
             if ((uint32_t)s < nsl && i < nk) out[i] = HitEnt{km[s], hv[s], ha[s]};
         }
+        if (a.edgebuf) {  // -bu: canonical (k+1)-mers = read2kmers_edges' `edges` (AQ.h:290-295): window of k+1 bases
+            uint64_t* eo = a.edgebuf + (size_t)it * a.nkp;
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                const uint32_t i = 64 * s + lane;
+                if ((uint32_t)s < nsl && i + 1 < nk) eo[i] = window_kmer(sm.pk, sm.vd, i, k + 1, nullptr, nullptr);
+            }
+        }
+        if (a.qmaskbuf) {  // -b with qualities
+            x.sync();
+            for (uint32_t w = lane; w < nw; w += 64) sm.qraw[w] = *reinterpret_cast<const uint32_t*>(a.qual + a0 + 4ull * w);
+            if (lane < 8) sm.qmask[lane] = 0;
+            x.sync();
+            if (lane == 0) qmask_scan(reinterpret_cast<const uint8_t*>(sm.qraw) + rsh, (int)len, (int)a.P.qth, (int)k, sm.qmask);
+            x.sync();
+            if (lane < 4) a.qmaskbuf[(size_t)it * 4 + lane] = (uint64_t)sm.qmask[2 * lane] | ((uint64_t)sm.qmask[2 * lane + 1] << 32);
+        }
     }
 }
 
@@ -728,7 +790,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     const uint32_t k = T.ksize, cth = a.P.cthreshold, nloci = T.nloci;
     const bool okam = a.P.okam != 0;
     // per-block counters, flushed once at the end
-    uint64_t c_kf = 0, c_hf = 0, c_qc = 0, c_thr = 0, c_feas = 0, c_asgn = 0, c_nhash1 = 0, c_vv = 0, c_cls = 0, c_inc = 0;
+    uint64_t c_kf = 0, c_hf = 0, c_qc = 0, c_thr = 0, c_feas = 0, c_asgn = 0, c_nhash1 = 0, c_vv = 0, c_cls = 0, c_inc = 0, c_bait = 0;
     DBTK_STAMP_DECL
     const uint32_t nsurv = *a.nsurv;
     const uint32_t tend = (nsurv > a.t0 && nsurv - a.t0 < a.tcap) ? nsurv : a.t0 + a.tcap;
@@ -763,7 +825,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
             if (len > (uint32_t)MAXL) len = MAXL;
             nkm[m] = len >= k ? len - k + 1 : 0;
         }
-        int kf[2], rm[2], hf[2] = {0, 0}, af[2] = {0, 0};
+        int kf[2], rm[2], hf[2] = {0, 0}, af[2] = {0, 0}, bf[2] = {0, 0};
         kf[0] = nkm[0] < cth; kf[1] = nkm[1] < cth;
         rm[0] = kf[0]; rm[1] = kf[1];
         const bool both_short = rm[0] && rm[1];
@@ -1049,6 +1111,49 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     stage = DBTK_STAGE_EXTRACT;
                 } else {
                     c_thr += 2; c_feas += 2;
+                    if (a.P.bait) {
+                        // ---- bait gate (bfilter_FPSv1, AQ.cpp:1377-1419; call site 2111-2126): a mate is flagged when a
+                        // k-mer of baitDB[destLocus] occurs in it (uint8_t count, over quality-passing positions when the
+                        // input has qualities) outside [min, max]; either flag removes both mates.
+                        int bfl[2] = {0, 0};
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            uint64_t qm[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+                            if (a.qmaskbuf) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) qm[q] = a.qmaskbuf[((size_t)2 * (t - a.t0) + m) * 4 + q];
+                            }
+                            uint32_t th[NSLOT];
+                            bool on[NSLOT];
+#pragma unroll
+                            for (int s = 0; s < NSLOT; ++s) {
+                                const uint32_t i = 64 * s + lane;
+                                on[s] = i < nkm[m] && km[m][s] != NAN64 && ((qm[s] >> lane) & 1);
+                                th[s] = on[s] ? kl_lookup(T.bait, T.bait_mask, T.bait_shift, km[m][s], dst) : CLS_NONE;
+                            }
+#pragma unroll
+                            for (int s = 0; s < NSLOT; ++s) {
+                                uint64_t pend = x.ballot(th[s] != CLS_NONE);
+                                while (pend) {  // one bait k-mer at a time: its multiplicity among the mate's counted positions
+                                    const int src = (int)__builtin_ctzll(pend);
+                                    const uint64_t K = ((uint64_t)x.bcast((uint32_t)(km[m][s] >> 32), src) << 32) | x.bcast((uint32_t)km[m][s], src);
+                                    const uint32_t thr = x.bcast(th[s], src);
+                                    uint32_t cnt = 0;
+#pragma unroll
+                                    for (int s2 = 0; s2 < NSLOT; ++s2) cnt += (uint32_t)__builtin_popcountll(x.ballot(on[s2] && km[m][s2] == K));
+                                    cnt &= 0xFF;  // kc8_t counts in uint8_t
+                                    const uint32_t mi = (thr >> 8) & 0xFF, ma = thr & 0xFF;
+                                    if (cnt < mi || cnt > ma) bfl[m] = 1;
+                                    pend &= ~x.ballot(th[s] != CLS_NONE && km[m][s] == K);
+                                }
+                            }
+                        }
+                        bf[0] = bfl[0]; bf[1] = bfl[1];
+                        if (bf[0] || bf[1]) {
+                            c_bait += (uint64_t)((bf[0] & !rm[0]) + (bf[1] & !rm[1]));
+                            rm[0] = 1; rm[1] = 1;
+                        }
+                    }
                     // ---- P10: assignTRkmc against the DBs of destLocus0 (AQ.cpp:2138-2144).  State of a
                     // position: flank 1 beats TR 2 (AQ.cpp:1467-1468).  With a consistent RPGG the class of a
                     // single-locus k-mer rides in the index slot (`aux`): no second probe.
@@ -1102,7 +1207,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     }
                     DBTK_STAMP(12);  // assign_bits
                     // ---- P11: accumulate (AQ.cpp:2145-2158)
-                    if (rm[0] && rm[1]) { dst = nloci; stage = DBTK_STAGE_ASGN; }
+                    if (rm[0] && rm[1]) { dst = nloci; stage = (bf[0] || bf[1]) ? DBTK_STAGE_BAIT : DBTK_STAGE_ASGN; }
                     else {
                         stage = DBTK_STAGE_COUNTED;
                         const int nmap = 2 - rm[0] - rm[1];
@@ -1121,6 +1226,27 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                                 c_inc += (uint64_t)__builtin_popcountll(Rw[m][s]);
                             }
                         }
+                        if (a.P.bubbles && a.edgebuf) {
+                            // ---- novel edges of the kept mates (countNovelEdges, AQ.cpp:1559-1567; call site 2161-2166):
+                            // read (k+1)-mers at positions [si_, ei_ - 1) that are not in trEdgeDB[destLocus]
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                if (rm[m]) continue;
+                                const uint64_t* ein = a.edgebuf + ((size_t)2 * (t - a.t0) + m) * a.nkp;
+                                const int lo = ms[m].si_, hi = ms[m].ei_ - 1;
+#pragma unroll
+                                for (int s = 0; s < NSLOT; ++s) {
+                                    const int i = 64 * s + lane;
+                                    if (i >= lo && i < hi) {
+                                        const uint64_t e = ein[i];
+                                        if (e != NAN64 && kl_lookup(T.tre, T.tre_mask, T.tre_shift, e, dst) == CLS_NONE) {
+                                            const uint32_t at = x.atomic_add(a.nevents, 1u);
+                                            if (at < a.events_cap) a.events[at] = BubEvent{pair, (uint32_t)m, (uint32_t)i, dst, e};
+                                        }
+                                    }
+                                }
+                            }
+                        }
                     }
                 }
             }
@@ -1128,7 +1254,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         DBTK_STAMP(13);  // accumulate
         // ---- P12: record (kam: AQ.cpp:2169-2175; trace: every pair)
         const bool want = RECS && a.recs && (a.P.trace || (okam && stage == DBTK_STAGE_COUNTED) ||
-                                     (okam && a.P.simmode && stage == DBTK_STAGE_ASGN) ||
+                                     (okam && a.P.simmode && (stage == DBTK_STAGE_ASGN || stage == DBTK_STAGE_BAIT)) ||
                                      (a.P.extract && stage == DBTK_STAGE_EXTRACT));
         if (want) {
             uint32_t at = pair;
@@ -1148,7 +1274,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                         const MateState& s = ms[m];
                         mr->si = (int16_t)s.si; mr->ei = (int16_t)s.ei; mr->si_ = (int16_t)s.si_; mr->ei_ = (int16_t)s.ei_;
                         mr->nt = (int16_t)s.nt; mr->bs = (int16_t)s.bs; mr->ti = (int16_t)s.ti;
-                        mr->kf = (uint8_t)kf[m]; mr->hf = (uint8_t)hf[m]; mr->bf = 0; mr->qf = 0;
+                        mr->kf = (uint8_t)kf[m]; mr->hf = (uint8_t)hf[m]; mr->bf = (uint8_t)bf[m]; mr->qf = 0;
                         mr->af = (uint8_t)af[m]; mr->rm = (uint8_t)rm[m];
                         mr->nk = (uint16_t)nas[m];
                     }
@@ -1179,6 +1305,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         if (c_thr) x.atomic_add(&a.counters[DBTK_C_THREADING], c_thr);
         if (c_feas) x.atomic_add(&a.counters[DBTK_C_FEASIBLE], c_feas);
         if (c_asgn) x.atomic_add(&a.counters[DBTK_C_ASGN], c_asgn);
+        if (c_bait) x.atomic_add(&a.counters[DBTK_C_BAITFILTERED], c_bait);
         if (c_vv) x.atomic_add(&a.counters[DBTK_C_ALGO_VV], c_vv);
         if (c_cls) x.atomic_add(&a.counters[DBTK_C_ALGO_CLS], c_cls);
         if (c_inc) x.atomic_add(&a.counters[DBTK_C_ALGO_INC], c_inc);

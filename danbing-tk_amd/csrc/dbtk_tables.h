@@ -66,6 +66,10 @@ struct DevTables {
     uint32_t nloci;
     uint32_t ksize;
     uint32_t consistent;  // index memberships == flank/TR sets (verified on the GPU at load): `aux` may be used
+    // optional gates: (canonical (k+1)-mer, locus) set of PREF.tre.kdb for -bu; (k-mer, locus) -> (min << 8 | max) of
+    // PREF.bt.kmdb for -b.  Same slot layout and probing as the class table.
+    const ClsSlot* tre; uint64_t tre_mask; uint32_t tre_shift;
+    const ClsSlot* bait; uint64_t bait_mask; uint32_t bait_shift;
 };
 
 DBTK_HD uint64_t hash_idx(uint64_t key, uint32_t shift) {
@@ -108,6 +112,17 @@ DBTK_HD uint32_t cls_lookup(const DevTables& T, uint64_t kmer, uint32_t locus) {
         if (s.kmer == kmer && (uint32_t)(s.lc >> 32) == locus) return (uint32_t)s.lc;
         if (s.kmer == NAN64) return CLS_NONE;
         i = (i + 1) & T.cls_mask;
+    }
+}
+
+// generic (key, locus) probe of a ClsSlot table; CLS_NONE when absent
+DBTK_HD uint32_t kl_lookup(const ClsSlot* tab, uint64_t mask, uint32_t shift, uint64_t key, uint32_t locus) {
+    uint64_t i = hash_cls(key, locus, shift);
+    for (;;) {
+        const ClsSlot s = tab[i];
+        if (s.kmer == key && (uint32_t)(s.lc >> 32) == locus) return (uint32_t)s.lc;
+        if (s.kmer == NAN64) return CLS_NONE;
+        i = (i + 1) & mask;
     }
 }
 

@@ -63,8 +63,8 @@ typedef struct dbtk_params {
     uint32_t qth;          /* -qth [20]  bait quality threshold */
     uint32_t okam;         /* !-ka [1]   emit kmer-assignment records */
     uint32_t qc;           /* -qc        per-locus QC mask present in the RPGG handle */
-    uint32_t bait;         /* -b         bait filter (FPSv1) */
-    uint32_t bubbles;      /* -bu        count novel (k+1)-mers */
+    uint32_t bait;         /* -b         bait filter (FPSv1); needs the bait DB in the RPGG handle */
+    uint32_t bubbles;      /* -bu        count novel (k+1)-mers; needs PREF.tre.kdb; host-buffer batches only */
     uint32_t extract;      /* -e 1|2     extract mode: locus assignment only */
     uint32_t trace;        /* test hook: emit a record for EVERY pair, not only kam ones */
     uint32_t threading;    /* -g/-gc/-gcc: accepted like the reference; at HEAD its call sites are commented out
@@ -217,6 +217,11 @@ dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n);
 int  dbtk_ctx_kernel_times(dbtk_ctx_t* ctx, const char** names, double* total_ms, uint64_t* launches, int cap);
 void dbtk_ctx_timers_reset(dbtk_ctx_t* ctx);
 void dbtk_ctx_timers_enable(dbtk_ctx_t* ctx, int on);  /* default on; off = no event records on the stream */
+
+/* -bu: the per-locus novel (k+1)-mer counts accumulated by dbtk_align_batch (host path) -> OUT.bub.kmdb
+ * (dumpBubbles, src/aQueryFasta_thread.h:1006-1008: entries with count >= 5).  merge: fold another GPU's DB in. */
+dbtk_status_t dbtk_ctx_write_bubbles(dbtk_ctx_t* ctx, const char* out_prefix);
+dbtk_status_t dbtk_ctx_merge_bubbles(dbtk_ctx_t* dst, dbtk_ctx_t* src);
 
 /* ---- dumps: src/aQueryFasta_thread.cpp:2631-2641 --------------------------*/
 /* with_names = 0: OUT.trkmc.ar + OUT.tr.summary.txt; 1: OUT.tr.kmers (-on). */

@@ -346,6 +346,7 @@ int orc_umap_order(const uint64_t* keys, uint64_t n, uint64_t* order) {
 }
 
 /* ------------------------------------------------------------------- RPGG */
+typedef struct { uint64_t k, i; } ki_t;
 struct orc_rpgg {
     uint32_t k;
     uint64_t nloci;
@@ -367,6 +368,9 @@ struct orc_rpgg {
     uint64_t* tre_beg;
     uint64_t* tre_ks;  /* sorted within locus, may be NULL */
     uint8_t* qc;
+    /* baitDB[l] (AQ.h:542-547): k-mers sorted within locus + thresholds */
+    uint64_t* bt_beg;
+    ki_t* bt;          /* .k = k-mer, .i = (min << 8 | max) */
 };
 
 static inline uint64_t mix64(uint64_t x) {
@@ -386,7 +390,6 @@ static int cmp_u64(const void* a, const void* b) {
     uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
     return x < y ? -1 : x > y;
 }
-typedef struct { uint64_t k, i; } ki_t;
 static int cmp_ki(const void* a, const void* b) {
     const ki_t* x = (const ki_t*)a; const ki_t* y = (const ki_t*)b;
     if (x->k != y->k) return x->k < y->k ? -1 : 1;
@@ -546,8 +549,36 @@ orc_rpgg_t* orc_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_fil
     return g;
 }
 
+void orc_rpgg_set_bait(orc_rpgg_t* g, const uint64_t* bt_cnt, const uint64_t* bt_ks, const uint16_t* bt_vs) {
+    free(g->bt_beg); free(g->bt);
+    g->bt_beg = (uint64_t*)malloc((g->nloci + 1) * 8);
+    g->bt_beg[0] = 0;
+    for (uint64_t l = 0; l < g->nloci; ++l) g->bt_beg[l + 1] = g->bt_beg[l] + bt_cnt[l];
+    const uint64_t n = g->bt_beg[g->nloci];
+    g->bt = (ki_t*)malloc((n + 1) * sizeof(ki_t));
+    for (uint64_t i = 0; i < n; ++i) { g->bt[i].k = bt_ks[i]; g->bt[i].i = bt_vs[i]; }
+    for (uint64_t l = 0; l < g->nloci; ++l) qsort(g->bt + g->bt_beg[l], (size_t)bt_cnt[l], sizeof(ki_t), cmp_ki);
+}
+/* deserializeKmapDB, BIO:70-98: u64 nloci | u64 cnt[nloci] | u64 nk | u64 sizeofval | u64 ks[nk] | u16 vs[nk] */
+int orc_rpgg_load_bait(orc_rpgg_t* g, const char* fn) {
+    FILE* f = fopen(fn, "rb");
+    if (!f) return -1;
+    uint64_t nl, nk, szv;
+    if (fread(&nl, 8, 1, f) != 1 || nl != g->nloci) { fclose(f); return -1; }
+    uint64_t* cnt = (uint64_t*)read_all(f, nl * 8);
+    if (!cnt || fread(&nk, 8, 1, f) != 1 || fread(&szv, 8, 1, f) != 1 || szv != 2) { fclose(f); return -1; }
+    uint64_t* ks = (uint64_t*)read_all(f, nk * 8);
+    uint16_t* vs = (uint16_t*)read_all(f, nk * 2);
+    fclose(f);
+    if (!ks || !vs) return -1;
+    orc_rpgg_set_bait(g, cnt, ks, vs);
+    free(cnt); free(ks); free(vs);
+    return 0;
+}
+
 void orc_rpgg_free(orc_rpgg_t* g) {
     if (!g) return;
+    free(g->bt_beg); free(g->bt);
     free(g->hkeys); free(g->hvals); free(g->vv); free(g->fl_beg); free(g->fl_ks); free(g->tr_beg);
     free(g->tr_cnt); free(g->tr_ks_file); free(g->tr_ks); free(g->tr_fi); free(g->tre_beg); free(g->tre_ks); free(g->qc);
     free(g);
@@ -829,6 +860,72 @@ static void assign_trkmc(const orc_rpgg_t* g, const dbtk_params_t* p, const uint
     }
 }
 
+/* qString2qMask, AQ.h:1038-1071, statement by statement (its bounds compare the BASE index with the
+ * number of K-MERS, so the scan stops early near the read end: reproduced as is). */
+void orc_qstring2qmask(const uint8_t* qual, int nq, int qth, int ksize, uint8_t* qkm) {
+    int nk = nq - ksize + 1;
+    int qi = 0, ki = 0;
+    int* qscore = (int*)malloc((size_t)(nq > 0 ? nq : 1) * sizeof(int));
+    for (int i = 0; i < nq; ++i) qscore[i] = (int)qual[i] - 33;
+    for (int i = 0; i < nk; ++i) qkm[i] = 0;
+    while (qscore[qi] < qth) { ++qi; ++ki; if (qi >= nk) { free(qscore); return; } }
+    while (qi < nk) {
+        int pass = 1;
+        for (int qj = qi; qi < qj + ksize; ++qi) {
+            if (qscore[qi] < qth) {
+                pass = 0;
+                ki = qi;
+                while (qscore[qi] < qth) { ++qi; ++ki; if (qi >= nk) { free(qscore); return; } }
+                break;
+            }
+        }
+        if (pass) {
+            qkm[ki] = 1;
+            ++ki;
+            if (qi >= nk) { free(qscore); return; }
+            while (qscore[qi] >= qth) {
+                qkm[ki] = 1;
+                ++qi; ++ki;
+                if (qi >= nk) { free(qscore); return; }
+            }
+            ki = qi;
+            while (qscore[qi] < qth) { ++qi; ++ki; if (qi >= nk) { free(qscore); return; } }
+        }
+    }
+    free(qscore);
+}
+
+/* bfilter_FPSv1, AQ.cpp:1377-1419 (both overloads; km == NULL: every k-mer counts).  The k-mer
+ * multiset is counted in uint8_t (kc8_t); any k-mer of the bait DB whose count is outside
+ * [min, max] flags the mate.  NAN64 entries are keys like any other (never in the DB). */
+static void bfilter(const orc_rpgg_t* g, uint64_t locus, const uint64_t* ks, int nk, const uint8_t* km, int* bf) {
+    if (!nk) return;
+    uint64_t* tmp = (uint64_t*)malloc((size_t)nk * 8);
+    int n = 0;
+    for (int i = 0; i < nk; ++i) if (!km || km[i]) tmp[n++] = ks[i];
+    qsort(tmp, (size_t)n, 8, cmp_u64);
+    for (int i = 0; i < n;) {
+        int j = i;
+        while (j < n && tmp[j] == tmp[i]) ++j;
+        const uint8_t cnt = (uint8_t)(j - i);
+        uint64_t lo = g->bt_beg[locus], hi = g->bt_beg[locus + 1];
+        while (lo < hi) { uint64_t mid = lo + (hi - lo) / 2; if (g->bt[mid].k < tmp[i]) lo = mid + 1; else hi = mid; }
+        if (lo < g->bt_beg[locus + 1] && g->bt[lo].k == tmp[i]) {
+            const uint16_t th = (uint16_t)g->bt[lo].i;
+            const uint8_t mi = (uint8_t)(th >> 8), ma = (uint8_t)(th & 0xff);
+            if (cnt < mi || cnt > ma) { *bf = 1; break; }
+        }
+        i = j;
+    }
+    free(tmp);
+}
+
+static int tre_has(const orc_rpgg_t* g, uint64_t locus, uint64_t e) {
+    uint64_t pos;
+    bs_has(g->tre_ks, g->tre_beg[locus], g->tre_beg[locus + 1], e, &pos);
+    return pos < g->tre_beg[locus + 1] && g->tre_ks[pos] == e;
+}
+
 static void fill_mate_rec(dbtk_mate_rec_t* m, const kmr_t* r) {
     memset(m, 0, sizeof(*m));
     m->si = (int16_t)r->si; m->ei = (int16_t)r->ei; m->si_ = (int16_t)r->si_; m->ei_ = (int16_t)r->ei_;
@@ -841,6 +938,17 @@ static void fill_mate_rec(dbtk_mate_rec_t* m, const kmr_t* r) {
 
 int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off, uint64_t npairs,
               uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* C, dbtk_pair_rec_t* recs) {
+    uint64_t nev = 0;
+    return orc_align_ex(g, p, seq, off, NULL, npairs, counts, kmc, nmapread, C, recs, NULL, 0, &nev);
+}
+
+int orc_align_ex(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off, const uint8_t* qual,
+                 uint64_t npairs, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* C, dbtk_pair_rec_t* recs,
+                 orc_bub_event_t* ev, uint64_t evcap, uint64_t* nev) {
+    uint64_t nBait = 0;
+    *nev = 0;
+    if (p->bait && !g->bt_beg) return DBTK_ERR_ARG;
+    if (p->bubbles && !g->tre_beg) return DBTK_ERR_ARG;
     const uint32_t k = p->ksize;
     const uint64_t nloci = g->nloci;
     const int okam = (int)p->okam;
@@ -862,7 +970,7 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
         dbtk_pair_rec_t* rec = recs ? &recs[pi] : NULL;
         kmr_t r1, r2;
         kmr_init(&r1); kmr_init(&r2);
-        int rm1 = 0, rm2 = 0, kf1 = 0, kf2 = 0, hf1 = 0, hf2 = 0, af1 = 0, af2 = 0, nm1 = 0, nm2 = 0;
+        int rm1 = 0, rm2 = 0, kf1 = 0, kf2 = 0, hf1 = 0, hf2 = 0, af1 = 0, af2 = 0, nm1 = 0, nm2 = 0, bf1 = 0, bf2 = 0;
         uint64_t destLocus = nloci, destLocus0 = NAN32;
         uint32_t stage;
         /* AQ.cpp:2035-2044 */
@@ -896,6 +1004,22 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
         if (p->threading) { stage = DBTK_STAGE_LOCUS; goto emit; } /* AQ.cpp:2072-2090: `alned` stays false at HEAD */
         nFeas += 2; /* AQ.cpp:2092 */
         if (p->extract) { stage = DBTK_STAGE_EXTRACT; goto emit; } /* AQ.cpp:2094-2099 */
+        if (p->bait) { /* AQ.cpp:2104-2126 */
+            uint8_t q1[DBTK_MAX_READ_LEN], q2[DBTK_MAX_READ_LEN];
+            const uint8_t *m1 = NULL, *m2 = NULL;
+            if (qual) {
+                orc_qstring2qmask(qual + off[2 * pi], (int)l1, (int)p->qth, (int)k, q1);
+                orc_qstring2qmask(qual + off[2 * pi + 1], (int)l2, (int)p->qth, (int)k, q2);
+                m1 = q1; m2 = q2;
+            }
+            bfilter(g, destLocus, caks1, (int)nk1, m1, &bf1);
+            bfilter(g, destLocus, caks2, (int)nk2, m2, &bf2);
+            if (bf1 || bf2) {
+                nBait += (uint64_t)((bf1 & !rm1) + (bf2 & !rm2));
+                rm1 = 1; rm2 = 1;
+                destLocus = nloci;
+            }
+        }
         /* AQ.cpp:2138-2158 */
         if (okam || !rm1 || !rm2) {
             if (okam || !rm1) ncls += nk1;
@@ -903,7 +1027,7 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
             assign_trkmc(g, p, caks1, (int)nk1, destLocus0, &r1, &af1, &rm1, okam);
             assign_trkmc(g, p, caks2, (int)nk2, destLocus0, &r2, &af2, &rm2, okam);
         }
-        if (rm1 && rm2) { destLocus = nloci; stage = DBTK_STAGE_ASGN; }
+        if (rm1 && rm2) { destLocus = nloci; stage = (bf1 || bf2) ? DBTK_STAGE_BAIT : DBTK_STAGE_ASGN; }
         else {
             int n = 2 - rm1 - rm2;
             nmapread[destLocus] += (uint32_t)n;
@@ -911,12 +1035,27 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
             kmc[destLocus] += (uint64_t)(int64_t)((r1.ei - r1.si) + (r2.ei - r2.si));
             if (!rm1) for (int i = 0; i < r1.nas; ++i) if (r1.as[i] == 2) { ++counts[r1.its[i]]; ++ninc; }
             if (!rm2) for (int i = 0; i < r2.nas; ++i) if (r2.as[i] == 2) { ++counts[r2.its[i]]; ++ninc; }
+            if (p->bubbles) { /* countNovelEdges, AQ.cpp:1559-1567, for the kept mates (AQ.cpp:2161-2166) */
+                for (int m = 0; m < 2; ++m) {
+                    if (m ? rm2 : rm1) continue;
+                    const kmr_t* r = m ? &r2 : &r1;
+                    const uint64_t* es = m ? caes2 : caes1;
+                    for (int i = r->si_; i < r->ei_ - 1; ++i) {
+                        const uint64_t e = es[i];
+                        if (e == NAN64) continue;
+                        if (!tre_has(g, destLocus, e)) {
+                            if (ev && *nev < evcap) { ev[*nev].pair = (uint32_t)pi; ev[*nev].mate = (uint32_t)m; ev[*nev].pos = (uint32_t)i; ev[*nev].locus = (uint32_t)destLocus; ev[*nev].edge = e; }
+                            ++*nev;
+                        }
+                    }
+                }
+            }
             stage = DBTK_STAGE_COUNTED;
         }
     emit:
         if (rec) {
-            r1.kf = kf1; r1.hf = hf1; r1.af = af1; r1.rm = rm1;
-            r2.kf = kf2; r2.hf = hf2; r2.af = af2; r2.rm = rm2;
+            r1.kf = kf1; r1.hf = hf1; r1.af = af1; r1.rm = rm1; r1.bf = bf1;
+            r2.kf = kf2; r2.hf = hf2; r2.af = af2; r2.rm = rm2; r2.bf = bf2;
             rec->pair = (uint32_t)pi;
             rec->stage = stage;
             rec->dst = (uint32_t)destLocus;
@@ -932,6 +1071,7 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
     C[DBTK_C_KMERFILTERED] += nKf;
     C[DBTK_C_LOCUSFILTERED] += nLocus;
     C[DBTK_C_QCFILTERED] += nQC;
+    C[DBTK_C_BAITFILTERED] += nBait;
     C[DBTK_C_THREADING] += nThr;
     C[DBTK_C_FEASIBLE] += nFeas;
     C[DBTK_C_ASGN] += nAsgn;

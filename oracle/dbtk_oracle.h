@@ -41,6 +41,22 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq,
               const uint64_t* off, uint64_t npairs, uint64_t* counts_fileorder, uint64_t* kmc,
               uint32_t* nmapread, uint64_t* counters, dbtk_pair_rec_t* recs);
 
+/* Novel-edge events of -bu in processing order (countNovelEdges, AQ.cpp:1559-1567): pair, mate
+ * (0 = seq1), position, destLocus, canonical (k+1)-mer. */
+typedef struct orc_bub_event { uint32_t pair, mate, pos, locus; uint64_t edge; } orc_bub_event_t;
+
+/* Same loop with the optional gates: qual (NULL for FASTA; same offsets as seq) feeds the bait
+ * filter's quality mask (-b with -fq); bubble events are appended to ev[0..cap) and *nev gets
+ * the number produced (ev may be NULL when !p->bubbles). */
+int orc_align_ex(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
+                 const uint8_t* qual, uint64_t npairs, uint64_t* counts_fileorder, uint64_t* kmc, uint32_t* nmapread,
+                 uint64_t* counters, dbtk_pair_rec_t* recs, orc_bub_event_t* ev, uint64_t cap, uint64_t* nev);
+/* Attach a bait DB (PREF.bt.kmdb layout: per-locus counts, k-mers, (min<<8|max)). */
+void orc_rpgg_set_bait(orc_rpgg_t* g, const uint64_t* bt_cnt, const uint64_t* bt_ks, const uint16_t* bt_vs);
+int  orc_rpgg_load_bait(orc_rpgg_t* g, const char* bait_file);
+/* qString2qMask, AQ.h:1038-1071: mask[i] = 1 iff k-mer i passes (mask has nq-k+1 bytes, pre-zeroed by the callee). */
+void orc_qstring2qmask(const uint8_t* qual, int nq, int qth, int ksize, uint8_t* mask);
+
 /* Function-level restatements (for pinning against the reference harness). */
 uint64_t orc_nurc(uint64_t kmer, uint32_t k);                               /* getNuRC  AQ.h:165-178 */
 uint64_t orc_read2kmers_edges(const uint8_t* read, uint64_t rlen, uint32_t k,

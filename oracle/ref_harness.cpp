@@ -31,7 +31,9 @@ struct RefDB {
     /* key -> file-order index of PREF.tr.kmers, per locus */
     vector<unordered_map<uint64_t, uint64_t>> fileIndex;
     uint64_t ntr = 0;
+    bait_fps_db_t baitDB;
 };
+struct BubEvent { uint32_t pair, mate, pos, locus; uint64_t edge; };  // == orc_bub_event_t
 
 void fill_mate(dbtk_mate_rec_t& m, km_asgn_read_t& r) {
     memset(&m, 0, sizeof(m));
@@ -116,13 +118,22 @@ void* ref_db_load(const char* prefix, const char* qc_file) {
     return db;
 }
 void ref_db_free(void* h) { delete (RefDB*)h; }
+/* readBinaryBaitDB reads PREF.bt.kmdb (src/aQueryFasta_thread.h:542-547) */
+void ref_db_load_bait(void* h, const char* prefix) { readBinaryBaitDB(((RefDB*)h)->baitDB, string(prefix)); }
+void ref_qstring2qmask(const char* qual, int nq, int qth_, int k, uint8_t* mask) {
+    string q(qual, nq);
+    vector<bool> m;
+    qString2qMask(q, qth_, k, m);
+    for (size_t i = 0; i < m.size(); ++i) mask[i] = m[i];
+}
 uint64_t ref_db_nloci(void* h) { return ((RefDB*)h)->nloci; }
 uint64_t ref_db_ntr(void* h) { return ((RefDB*)h)->ntr; }
 
 /* One pair through the reference's live path.  Accumulates like orc_align. */
 void ref_pair(void* h, const char* s1, uint64_t l1, const char* s2, uint64_t l2, uint32_t Cth, int okam, int qc,
               uint64_t* counts_fileorder, uint64_t* kmc, uint32_t* nmapread, uint64_t* C, dbtk_pair_rec_t* rec,
-              uint32_t pair_index) {
+              uint32_t pair_index, const char* q1 = nullptr, const char* q2 = nullptr, int bait = 0, int bubbles_on = 0,
+              BubEvent* ev = nullptr, uint64_t evcap = 0, uint64_t* nev = nullptr) {
     RefDB& db = *(RefDB*)h;
     const uint64_t nloci = db.nloci;
     uint16_t Cthreshold = Cth;
@@ -157,6 +168,27 @@ void ref_pair(void* h, const char* s1, uint64_t l1, const char* s2, uint64_t l2,
         if (qc and not db.qcFilter[destLocus]) { C[DBTK_C_QCFILTERED] += 2 - rm1 - rm2; stage = DBTK_STAGE_QC; break; }
         C[DBTK_C_THREADING] += 2;
         C[DBTK_C_FEASIBLE] += 2;
+        if (bait) {  // AQ.cpp:2101-2126
+            vector<bool> qkm1, qkm2;
+            bt_tracker_t tkr;
+            auto& baitdb = db.baitDB[destLocus];
+            if (q1) {
+                string qs1(q1, l1), qs2(q2, l2);
+                qString2qMask(qs1, qth, ksize, qkm1);
+                qString2qMask(qs2, qth, ksize, qkm2);
+                bfilter_FPSv1(baitdb, caks1, qkm1, bf1, false, tkr, destLocus);
+                bfilter_FPSv1(baitdb, caks2, qkm2, bf2, false, tkr, destLocus);
+            } else {
+                bfilter_FPSv1(baitdb, caks1, bf1, false, tkr, destLocus);
+                bfilter_FPSv1(baitdb, caks2, bf2, false, tkr, destLocus);
+            }
+            if (bf1 or bf2) {
+                C[DBTK_C_BAITFILTERED] += (bf1 & !rm1) + (bf2 & !rm2);
+                rm1 = 1;
+                rm2 = 1;
+                destLocus = nloci;
+            }
+        }
         vector<kmer_aCount_umap::iterator> kits1, kits2;
         if (okam or not rm1 or not rm2) {
             kmer_aCount_umap& trKmers = db.trKmerDB[destLocus0];
@@ -164,7 +196,7 @@ void ref_pair(void* h, const char* s1, uint64_t l1, const char* s2, uint64_t l2,
             assignTRkmc(caks1, trKmers, flKmers, kits1, kam.r1, af1, rm1, okam);
             assignTRkmc(caks2, trKmers, flKmers, kits2, kam.r2, af2, rm2, okam);
         }
-        if (rm1 and rm2) { destLocus = nloci; stage = DBTK_STAGE_ASGN; }
+        if (rm1 and rm2) { destLocus = nloci; stage = (bf1 or bf2) ? DBTK_STAGE_BAIT : DBTK_STAGE_ASGN; }
         else {
             int n = 2 - rm1 - rm2;
             nmapread[destLocus] += n;
@@ -175,6 +207,22 @@ void ref_pair(void* h, const char* s1, uint64_t l1, const char* s2, uint64_t l2,
             auto& fidx = db.fileIndex[destLocus0];
             if (not rm1) { for (int i = 0; i < (int)as1.size(); ++i) { if (as1[i] == 2) { ++counts_fileorder[fidx[kits1[i]->first]]; } } }
             if (not rm2) { for (int i = 0; i < (int)as2.size(); ++i) { if (as2[i] == 2) { ++counts_fileorder[fidx[kits2[i]->first]]; } } }
+            if (bubbles_on) {  // AQ.cpp:2161-2166 with countNovelEdges' loop (AQ.cpp:1559-1567) spelled out to keep the order
+                unordered_set<uint64_t>& tres = db.trEdgeDB[destLocus];
+                for (int m = 0; m < 2; ++m) {
+                    if (m ? rm2 : rm1) continue;
+                    km_asgn_read_t& r = m ? kam.r2 : kam.r1;
+                    vector<uint64_t>& es = m ? caes2 : caes1;
+                    for (int i = r.si_; i < r.ei_ - 1; ++i) {
+                        auto e = es[i];
+                        if (e == NAN64) { continue; }
+                        if (tres.count(e) == 0) {
+                            if (ev && *nev < evcap) ev[*nev] = BubEvent{pair_index, (uint32_t)m, (uint32_t)i, (uint32_t)destLocus, e};
+                            ++*nev;
+                        }
+                    }
+                }
+            }
             stage = DBTK_STAGE_COUNTED;
         }
     } while (0);
@@ -199,6 +247,18 @@ void ref_align(void* h, const char* seq, const uint64_t* off, uint64_t npairs, u
     for (uint64_t p = 0; p < npairs; ++p) {
         ref_pair(h, seq + off[2 * p], off[2 * p + 1] - off[2 * p], seq + off[2 * p + 1], off[2 * p + 2] - off[2 * p + 1], Cth, okam,
                  qc, counts_fileorder, kmc, nmapread, C, recs ? recs + p : nullptr, (uint32_t)p);
+    }
+}
+
+void ref_align_ex(void* h, const char* seq, const uint64_t* off, const char* qual, uint64_t npairs, uint32_t Cth, int okam, int qc,
+                  uint32_t qth_, int bait, int bubbles_on, uint64_t* counts_fileorder, uint64_t* kmc, uint32_t* nmapread, uint64_t* C,
+                  dbtk_pair_rec_t* recs, BubEvent* ev, uint64_t evcap, uint64_t* nev) {
+    qth = qth_;
+    *nev = 0;
+    for (uint64_t p = 0; p < npairs; ++p) {
+        ref_pair(h, seq + off[2 * p], off[2 * p + 1] - off[2 * p], seq + off[2 * p + 1], off[2 * p + 2] - off[2 * p + 1], Cth, okam,
+                 qc, counts_fileorder, kmc, nmapread, C, recs ? recs + p : nullptr, (uint32_t)p,
+                 qual ? qual + off[2 * p] : nullptr, qual ? qual + off[2 * p + 1] : nullptr, bait, bubbles_on, ev, evcap, nev);
     }
 }
 

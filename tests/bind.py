@@ -27,6 +27,15 @@ def _p(a, t):
     return a.ctypes.data_as(t) if a is not None else None
 
 
+class BubEvent(C.Structure):
+    _fields_ = [("pair", C.c_uint32), ("mate", C.c_uint32), ("pos", C.c_uint32), ("locus", C.c_uint32), ("edge", C.c_uint64)]
+
+
+def events_array(ev, n):
+    return np.frombuffer(ev, dtype=np.dtype([("pair", "<u4"), ("mate", "<u4"), ("pos", "<u4"), ("locus", "<u4"), ("edge", "<u8")]),
+                         count=n).copy()
+
+
 class Oracle:
     def __init__(self):
         path = os.path.join(ROOT, "oracle", "liboracle.so")
@@ -45,6 +54,12 @@ class Oracle:
         L.orc_align.restype = C.c_int
         L.orc_align.argtypes = [C.c_void_p, C.POINTER(abi.Params), u8p, u64p, C.c_uint64, u64p, u64p, u32p, u64p,
                                 C.POINTER(abi.PairRec)]
+        L.orc_align_ex.restype = C.c_int
+        L.orc_align_ex.argtypes = [C.c_void_p, C.POINTER(abi.Params), u8p, u64p, u8p, C.c_uint64, u64p, u64p, u32p, u64p,
+                                   C.POINTER(abi.PairRec), C.POINTER(BubEvent), C.c_uint64, u64p]
+        L.orc_rpgg_load_bait.restype = C.c_int
+        L.orc_rpgg_load_bait.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_qstring2qmask.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_nurc.restype = C.c_uint64
         L.orc_nurc.argtypes = [C.c_uint64, C.c_uint32]
         L.orc_read2kmers_edges.restype = C.c_uint64
@@ -82,6 +97,35 @@ class Oracle:
         if rc:
             raise RuntimeError(f"orc_align -> {rc}")
         return dict(counts_file=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs)
+
+    def load_bait(self, h, bait_file):
+        if self.L.orc_rpgg_load_bait(h, bait_file.encode()):
+            raise IOError(f"oracle could not load {bait_file}")
+
+    def qmask(self, qual: bytes, qth, k):
+        m = np.zeros(max(len(qual), 1), np.uint8)
+        self.L.orc_qstring2qmask(qual, len(qual), qth, k, _p(m, u8p))
+        return m[:max(len(qual) - k + 1, 0)]
+
+    def align_ex(self, h, params, seq, off, qual=None, trace=True, evcap=1 << 20):
+        npairs = (len(off) - 1) // 2
+        nloci = self.L.orc_rpgg_nloci(h)
+        ntr = self.L.orc_rpgg_ntrkmers(h)
+        counts = np.zeros(ntr, np.uint64)
+        kmc = np.zeros(nloci, np.uint64)
+        nmap = np.zeros(nloci, np.uint32)
+        ctr = np.zeros(abi.C_COUNT, np.uint64)
+        recs = (abi.PairRec * npairs)() if trace else None
+        ev = (BubEvent * evcap)() if params.bubbles else None
+        nev = C.c_uint64(0)
+        seq = np.ascontiguousarray(seq, np.uint8)
+        rc = self.L.orc_align_ex(h, C.byref(params), _p(seq, u8p), _p(off, u64p), _p(qual, u8p), npairs, _p(counts, u64p),
+                                 _p(kmc, u64p), _p(nmap, u32p), _p(ctr, u64p), recs, ev, evcap if ev else 0, C.byref(nev))
+        if rc:
+            raise RuntimeError(f"orc_align_ex -> {rc}")
+        assert nev.value <= evcap
+        return dict(counts_file=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs,
+                    events=events_array(ev, nev.value) if ev else None)
 
     def read2kmers_edges(self, read: bytes, k):
         n = max(len(read), 1)
@@ -127,6 +171,11 @@ class RefHarness:
         L.ref_db_ntr.argtypes = [C.c_void_p]
         L.ref_align.argtypes = [C.c_void_p, C.c_char_p, u64p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, u64p, u64p, u32p,
                                 u64p, C.POINTER(abi.PairRec)]
+        L.ref_align_ex.argtypes = [C.c_void_p, C.c_char_p, u64p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_uint32,
+                                   C.c_int, C.c_int, u64p, u64p, u32p, u64p, C.POINTER(abi.PairRec), C.POINTER(BubEvent),
+                                   C.c_uint64, u64p]
+        L.ref_db_load_bait.argtypes = [C.c_void_p, C.c_char_p]
+        L.ref_qstring2qmask.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, u8p]
 
     def set_params(self, p):
         self.L.ref_set_params(p.ksize, p.n_filter, p.nm_filter, p.max_nt, p.nm_tr)
@@ -155,6 +204,32 @@ class RefHarness:
 
     def free(self, h):
         self.L.ref_db_free(h)
+
+    def load_bait(self, h, prefix):
+        self.L.ref_db_load_bait(h, prefix.encode())
+
+    def qmask(self, qual: bytes, qth, k):
+        m = np.zeros(max(len(qual), 1), np.uint8)
+        self.L.ref_qstring2qmask(qual, len(qual), qth, k, _p(m, u8p))
+        return m[:max(len(qual) - k + 1, 0)]
+
+    def align_ex(self, h, params, seq, off, qual=None, evcap=1 << 20):
+        self.set_params(params)
+        npairs = (len(off) - 1) // 2
+        nloci = self.L.ref_db_nloci(h)
+        ntr = self.L.ref_db_ntr(h)
+        counts = np.zeros(ntr, np.uint64)
+        kmc = np.zeros(nloci, np.uint64)
+        nmap = np.zeros(nloci, np.uint32)
+        ctr = np.zeros(abi.C_COUNT, np.uint64)
+        recs = (abi.PairRec * npairs)()
+        ev = (BubEvent * evcap)()
+        nev = C.c_uint64(0)
+        seq = np.ascontiguousarray(seq, np.uint8)
+        self.L.ref_align_ex(h, seq.tobytes(), _p(off, u64p), qual.tobytes() if qual is not None else None, npairs,
+                            params.cthreshold, int(params.okam), int(params.qc), params.qth, int(params.bait), int(params.bubbles),
+                            _p(counts, u64p), _p(kmc, u64p), _p(nmap, u32p), _p(ctr, u64p), recs, ev, evcap, C.byref(nev))
+        return dict(counts_file=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs, events=events_array(ev, nev.value))
 
     def align(self, h, params, seq, off, trace=True):
         self.set_params(params)
@@ -209,12 +284,35 @@ class Emu(pkg._HostSide):
         L.emu_selftest_assign.argtypes = [C.c_uint64, C.c_uint64]
         L.emu_selftest_sort.restype = C.c_uint64
         L.emu_selftest_sort.argtypes = [C.c_uint64, C.c_uint64]
+        L.emu_align_ex.restype = C.c_int
+        L.emu_align_ex.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.Params), u8p, u64p, u8p, C.c_uint64, u64p, u64p, u32p, u64p,
+                                   C.POINTER(abi.PairRec), C.c_uint64, u64p, C.c_uint32, C.c_uint32, C.POINTER(BubEvent), C.c_uint64,
+                                   u64p]
         L.emu_align.restype = C.c_int
         L.emu_align.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.Params), u8p, u64p, C.c_uint64, u64p, u64p, u32p, u64p,
                                 C.POINTER(abi.PairRec), C.c_uint64, u64p, C.c_uint32, C.c_uint32]
 
     def tables(self, rpgg):
         return self.L.emu_tables_create(rpgg.h)
+
+    def align_ex(self, rpgg, tables, params, seq, off, qual=None, evcap=1 << 20):
+        npairs = (len(off) - 1) // 2
+        counts = np.zeros(rpgg.ntrkmers, np.uint64)
+        kmc = np.zeros(rpgg.nloci, np.uint64)
+        nmap = np.zeros(rpgg.nloci, np.uint32)
+        ctr = np.zeros(abi.C_COUNT, np.uint64)
+        recs = (abi.PairRec * max(npairs, 1))()
+        ev = (BubEvent * evcap)()
+        nrec, nev = C.c_uint64(0), C.c_uint64(0)
+        seq = np.ascontiguousarray(seq, np.uint8)
+        rc = self.L.emu_align_ex(rpgg.h, tables, C.byref(params), _p(seq, u8p), _p(off, u64p), _p(qual, u8p), npairs,
+                                 _p(counts, u64p), _p(kmc, u64p), _p(nmap, u32p), _p(ctr, u64p), recs, npairs, C.byref(nrec), 2, 3,
+                                 ev, evcap, C.byref(nev))
+        if rc:
+            raise RuntimeError(f"emu_align_ex -> {rc}")
+        e = events_array(ev, min(nev.value, evcap))
+        e = e[np.lexsort((e["pos"], e["mate"], e["pair"]))]
+        return dict(counts=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs, events=e)
 
     def consistent(self, tables):
         return int(self.L.emu_tables_consistent(tables))

@@ -185,6 +185,7 @@ struct EmuTables {
     std::vector<ClsSlot> cls;
     std::vector<uint32_t> vv;
     std::vector<uint16_t> perm;
+    std::vector<ClsSlot> tre, bait;
     uint64_t stats[3] = {0, 0, 0};
     DevTables T;
 };
@@ -233,6 +234,20 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
     T.nloci = (uint32_t)nloci;
     T.ksize = g->ksize;
     T.consistent = 0;
+    auto kl_table = [&](const std::vector<uint64_t>& cnt, const std::vector<uint64_t>& ks, const std::vector<uint16_t>* vals,
+                        std::vector<ClsSlot>& tab, const ClsSlot** out, uint64_t* mask, uint32_t* shift) {
+        const uint64_t cap = pow2(2 * ks.size() + 2);
+        tab.assign(cap, ClsSlot{NAN64, ~0ull});
+        std::vector<uint64_t> beg(nloci + 1, 0), v64(ks.size(), 0);
+        for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + cnt[l];
+        if (vals) for (size_t i = 0; i < ks.size(); ++i) v64[i] = (*vals)[i];
+        uint64_t nent = 0;
+        ClsBuildArgs b{tab.data(), cap - 1, 64 - lg(cap), ks.data(), beg.data(), (uint32_t)nloci, v64.data(), ks.size(), &nent};
+        if (!ks.empty()) run_grid(3, 64, 0, [&](EmuX& x) { body_cls_insert(x, b); });
+        *out = tab.data(); *mask = cap - 1; *shift = 64 - lg(cap);
+    };
+    if (!g->tre_cnt.empty()) kl_table(g->tre_cnt, g->tre_ks, nullptr, e->tre, &T.tre, &T.tre_mask, &T.tre_shift);
+    if (!g->bt_cnt.empty()) kl_table(g->bt_cnt, g->bt_ks, &g->bt_vs, e->bait, &T.bait, &T.bait_mask, &T.bait_shift);
     {
         IdxAuxArgs a{e->idx.data(), icap, T, e->stats};
         run_grid(3, 64, 0, [&](EmuX& x) { body_idx_aux(x, a); });
@@ -320,9 +335,23 @@ uint64_t emu_selftest_assign(uint64_t seed, uint64_t iters) {
 }
 
 // Same outputs as dbtk_align_batch + dbtk_ctx_counts (counts in OUT.trkmc.ar order).
+int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
+                 const uint8_t* qual, uint64_t npairs, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* counters,
+                 dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec, uint32_t grid_k1, uint32_t grid_pair, BubEvent* ev,
+                 uint64_t evcap, uint64_t* nev);
+
 int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
               uint64_t npairs, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* counters,
               dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec, uint32_t grid_k1, uint32_t grid_pair) {
+    uint64_t nev = 0;
+    return emu_align_ex(g, tables, p, seq, off, nullptr, npairs, counts, kmc, nmapread, counters, recs, rec_cap, nrec, grid_k1, grid_pair,
+                        nullptr, 0, &nev);
+}
+
+int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
+                 const uint8_t* qual, uint64_t npairs, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* counters,
+                 dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec, uint32_t grid_k1, uint32_t grid_pair, BubEvent* ev,
+                 uint64_t evcap, uint64_t* nev) {
     EmuTables* e = (EmuTables*)tables;
     const uint64_t nloci = g->nloci, ntr = g->out_kmer.size();
     std::vector<uint64_t> accum(ntr + 2 * nloci + DBTK_C_COUNT, 0);
@@ -354,6 +383,18 @@ int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const 
     a.tcap = tcap;
     uint32_t tile_ticket = 0;
     a.tile_ticket = &tile_ticket;
+    std::vector<uint64_t> edgebuf, qmaskbuf, qualbuf;
+    uint32_t nevents = 0;
+    if (p->bubbles) {
+        edgebuf.assign((size_t)tcap * 2 * a.nkp + 1, 0);
+        a.edgebuf = edgebuf.data(); a.events = ev; a.nevents = &nevents; a.events_cap = (uint32_t)evcap;
+    }
+    if (p->bait && qual) {
+        qualbuf.assign(nbytes / 8 + 8, 0);
+        memcpy(qualbuf.data(), qual, nbytes);
+        qmaskbuf.assign((size_t)tcap * 2 * 4 + 1, 0);
+        a.qual = (const uint8_t*)qualbuf.data(); a.qmaskbuf = qmaskbuf.data();
+    }
     run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter(x, a); });
     for (uint32_t t0 = 0; t0 < (uint32_t)(npairs ? npairs : 1); t0 += tcap) {
         a.t0 = t0;
@@ -379,6 +420,7 @@ int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const 
     for (uint64_t l = 0; l < nloci; ++l) nmapread[l] = (uint32_t)accum[ntr + nloci + l];
     memcpy(counters, accum.data() + ntr + 2 * nloci, DBTK_C_COUNT * 8);
     if (nrec) *nrec = p->trace ? npairs : small[2];
+    *nev = nevents;
     return 0;
 }
 

@@ -32,8 +32,54 @@ SETS = {
 }
 
 
+def bait_bubble_set(dtk):
+    """g4: -bu and -b.  Reads come from a haplotype that is NOT in the RPGG (a few substitutions per
+    locus), so the same novel (k+1)-mers recur and pass dumpBubbles' count >= 5 threshold."""
+    import numpy as np
+    name = "g4_bait_bubbles"
+    d = os.path.join(HERE, name)
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    loci = synth.make_loci(nloci=6, nhap=2, flank=500, seed=104, tr_max=500)
+    synth.build_rpgg_with_reference(loci, d, k=21)
+    rng = np.random.default_rng(7)
+    mut = synth.Loci(flank=loci.flank, haps=[[s.copy() for s in loci.haps[0]]], nloci=loci.nloci, nhap=1)
+    for s in mut.haps[0]:
+        for p in rng.integers(loci.flank + 5, len(s) - loci.flank - 5, 3):
+            s[p] = synth.BASES[(int(np.where(synth.BASES == s[p])[0][0]) + 1) % 4]
+    reads = synth.sim_reads(mut, npairs=900, seed=204, sub=0.002, with_qual=True)
+    synth.make_bait_db(loci, reads, d, per_locus=25)
+    synth.write_fasta(reads, os.path.join(d, "reads.fq"), fastq=True)
+    fa = synth.Reads(seqs=reads.seqs, titles=reads.titles)
+    synth.write_fasta(fa, os.path.join(d, "reads.fa"))
+    for f in os.listdir(d):
+        if f.startswith("pan.") and f.split(".", 1)[1] not in ("tr.kmers", "kmers.dbi", "fl.kdb", "tre.kdb", "bt.kmdb"):
+            os.remove(os.path.join(d, f))
+        elif f.startswith("h") and f.endswith(".fa"):
+            os.remove(os.path.join(d, f))
+    cmds = []
+    for tag, args in (("refbu", ["-bu", "-k", "21", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-p", "1"]),
+                      ("refbt", ["-b", "-k", "21", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-p", "1"]),
+                      ("refbq", ["-bu", "-b", "-qth", "25", "-k", "21", "-cth", "30", "-fq", "reads.fq", "-qs", "pan", "-p", "1"])):
+        cmd = ["danbing-tk"] + args + ["-o", tag]
+        with open(os.path.join(d, tag + ".kam.txt"), "wb") as so, open(os.path.join(d, tag + ".stderr.txt"), "wb") as se:
+            subprocess.run([dtk] + cmd[1:], cwd=d, check=True, stdout=so, stderr=se)
+        keep = [l for l in open(os.path.join(d, tag + ".stderr.txt"), errors="replace") if l[:1].isdigit() and " reads " in l]
+        open(os.path.join(d, tag + ".totals.txt"), "w").writelines(keep)
+        os.remove(os.path.join(d, tag + ".stderr.txt"))
+        cmds.append(" ".join(cmd) + f" > {tag}.kam.txt")
+    open(os.path.join(d, "cmd.txt"), "w").write("\n".join(cmds) + "\n")
+    sz = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
+    print(name, sorted(os.listdir(d)), f"{sz / 1024:.0f} KiB")
+    for tag in ("refbu", "refbq"):
+        import numpy as np
+        a = np.fromfile(os.path.join(d, tag + ".bub.kmdb"), np.uint64)
+        print("  ", tag, "bubble k-mers kept:", int(a[1 + int(a[0])]))
+
+
 def main():
     dtk = synth.ref_tool("danbing-tk")
+    bait_bubble_set(dtk)
     for name, (lk, k, rk, fastq, flags, qc) in SETS.items():
         d = os.path.join(HERE, name)
         shutil.rmtree(d, ignore_errors=True)

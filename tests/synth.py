@@ -181,8 +181,13 @@ def sim_reads(loci: Loci, npairs=1000, rlen=150, frag=(300, 500), seed=2, sub=0.
         out.seqs += [a.tobytes(), b.tobytes()]
         out.titles.append(f"r{p}:{name}")
         if with_qual:
-            out.quals += [bytes(rng.integers(33 + 2, 33 + 41, len(a), dtype=np.uint8)),
-                          bytes(rng.integers(33 + 2, 33 + 41, len(b), dtype=np.uint8))]
+            def q(n):  # mostly Q30-40, ~2 % low-quality bases, occasionally a low-quality tail
+                v = rng.integers(33 + 30, 33 + 41, n, dtype=np.uint8)
+                v[rng.random(n) < 0.02] = 33 + int(rng.integers(2, 15))
+                if n and rng.random() < 0.2:
+                    v[int(rng.integers(n // 2, n)):] = 33 + 8
+                return bytes(v)
+            out.quals += [q(len(a)), q(len(b))]
     return out
 
 
@@ -324,3 +329,27 @@ def write_rpgg_files(arr, pref: str):
             for km in arr["tr_ks"][i:i + int(n)]:
                 f.write(f"{int(km)}\t0\n")
             i += int(n)
+
+
+def make_bait_db(loci: Loci, reads: Reads, outdir: str, k=21, seed=5, per_locus=40, name="pan"):
+    """A bait DB (PREF.bt.kmdb) for the -b gate, serialised by the reference's own `ktools serialize-bt`
+    from a text file: for every locus a few k-mers taken from the READS with (min, max) thresholds —
+    (255, 0) "any occurrence is a false positive", (2, 9) "at least twice", (0, 1) "at most once"."""
+    rng = np.random.default_rng(seed)
+    pool = []
+    for s in reads.seqs[: 2 * 400]:
+        ks, ok = canon_kmers(np.frombuffer(s, np.uint8), k)
+        pool.append(ks[ok])
+    pool = np.unique(np.concatenate(pool)) if pool else np.zeros(0, np.uint64)
+    fn = os.path.join(outdir, name + ".bait.txt")
+    with open(fn, "w") as f:
+        for l in range(loci.nloci):
+            f.write(f">{l}\n")
+            if len(pool) == 0:
+                continue
+            for km in rng.choice(pool, size=min(per_locus, len(pool)), replace=False):
+                mi, ma = [(255, 0), (2, 9), (0, 1), (1, 1)][int(rng.integers(0, 4))]
+                f.write(f"{int(km)}\t{mi}\t{ma}\n")
+    subprocess.run([ref_tool("ktools"), "serialize-bt", fn, str(loci.nloci), os.path.join(outdir, name)], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return os.path.join(outdir, name + ".bt.kmdb")

@@ -51,6 +51,39 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
     g.close()
 
 
+@pytest.mark.skipif(not __import__("synth").have_ref(), reason="needs oracle/_ref (ktools serialize-bt builds the bait DB)")
+@pytest.mark.parametrize("fastq", [False, True])
+def test_bait_and_bubble_kernels_match_oracle(O, E, tmp_path, fastq):
+    import synth
+    loci = synth.make_loci(nloci=10, nhap=3, flank=500, seed=61, shared_frac=0.3)
+    d = str(tmp_path)
+    pref = synth.build_rpgg_with_reference(loci, d, k=21)
+    reads = synth.sim_reads(loci, npairs=700, seed=62, sub=0.01, indel=0.002, nrate=0.002, chimeric=0.3, background=0.1, with_qual=fastq)
+    bait = synth.make_bait_db(loci, reads, d)
+    go = O.load(pref, 21)
+    O.load_bait(go, bait)
+    g = E.load(pref, 21, bait_file=bait)
+    T = E.tables(g)
+    order = g.output_order().astype(np.int64)
+    seq, off = reads.packed()
+    qual = np.frombuffer(b"".join(reads.quals), np.uint8).copy() if fastq else None
+    for kw in (dict(bait=1, bubbles=1, cthreshold=45), dict(bait=1, cthreshold=20, okam=0), dict(bubbles=1, cthreshold=30, simmode=2)):
+        p = abi.default_params(ksize=21, trace=1, **kw)
+        a = O.align_ex(go, p, seq, off, qual)
+        b = E.align_ex(g, T, p, seq, off, qual)
+        co = np.zeros(g.ntrkmers, np.uint64)
+        np.add.at(co, order, a["counts_file"])
+        assert (co == b["counts"]).all() and (a["kmc"] == b["kmc"]).all() and (a["nmapread"] == b["nmapread"]).all()
+        assert (a["counters"] == b["counters"]).all(), (a["counters"], b["counters"])
+        dd = bind.recs_equal(a["recs"], b["recs"], reads.npairs)
+        assert dd < 0, f"{bind.rec_str(a['recs'][dd])}\n{bind.rec_str(b['recs'][dd])}"
+        if p.bubbles:
+            assert len(a["events"]) == len(b["events"]) and (a["events"] == b["events"]).all()
+    E.L.emu_tables_free(T)
+    O.free(go)
+    g.close()
+
+
 def test_device_sort_is_gcc_std_sort(E):
     """dbtk_sort.h (index form and packed form) against this host's std::sort, incl. the heapsort fallback."""
     assert E.selftest_sort(3, 20000) == 0

@@ -70,6 +70,51 @@ def test_hip_matches_oracle(case, dbtk, oracle, tmp_path):
     g.close()
 
 
+@pytest.mark.skipif(not synth.have_ref(), reason="needs oracle/_ref (ktools serialize-bt builds the bait DB)")
+@pytest.mark.parametrize("fastq", [False, True])
+def test_bait_and_bubble_gates_match_oracle(dbtk, oracle, tmp_path, fastq):
+    """-b (bfilter_FPSv1 + qString2qMask) and -bu (countNovelEdges) through the C-ABI."""
+    loci = synth.make_loci(nloci=10, nhap=3, flank=500, seed=61, shared_frac=0.3)
+    d = str(tmp_path)
+    pref = synth.build_rpgg_with_reference(loci, d, k=21)
+    reads = synth.sim_reads(loci, npairs=1500, seed=62, sub=0.01, indel=0.002, nrate=0.002, chimeric=0.3, background=0.1, with_qual=fastq)
+    bait = synth.make_bait_db(loci, reads, d)
+    go = oracle.load(pref, 21)
+    oracle.load_bait(go, bait)
+    g = dbtk.load(pref, 21, bait_file=bait)
+    seq, off = reads.packed()
+    qual = np.frombuffer(b"".join(reads.quals), np.uint8).copy() if fastq else None
+    for kw in (dict(bait=1, bubbles=1, cthreshold=45), dict(bait=1, cthreshold=20, okam=0), dict(bubbles=1, cthreshold=30, simmode=2)):
+        p = abi.default_params(ksize=21, trace=1, **kw)
+        o = oracle.align_ex(go, p, seq, off, qual)
+        ctx = dbtk.context(g, p)
+        recs, nrec = ctx.align(seq, off, qual=qual)
+        res = ctx.counts()
+        res["recs"] = recs
+        compare(o, res, g.output_order(), g.ntrkmers, reads.npairs)
+        if p.bait:
+            assert res["counters"][abi.C_BAITFILTERED] > 0
+        if p.bubbles:
+            ctx.write_bubbles(str(tmp_path / "o"))
+            a = np.fromfile(str(tmp_path / "o.bub.kmdb"), np.uint64)
+            nl = int(a[0]); nk = int(a[1 + nl])
+            assert nl == g.nloci and a[2 + nl] == 8 and len(a) == 3 + nl + 2 * nk and (a[3 + nl + nk:] >= 5).all()
+            # every dumped (locus, edge) has exactly the oracle's count
+            ev = o["events"]
+            want = {}
+            for l, e in zip(ev["locus"], ev["edge"]):
+                want[(int(l), int(e))] = want.get((int(l), int(e)), 0) + 1
+            want = {k: v for k, v in want.items() if v >= 5}
+            got, i = {}, 0
+            for l in range(nl):
+                for _ in range(int(a[1 + l])):
+                    got[(l, int(a[3 + nl + i]))] = int(a[3 + nl + nk + i]); i += 1
+            assert got == want
+        ctx.close()
+    oracle.free(go)
+    g.close()
+
+
 def test_batches_accumulate_and_split_invariance(dbtk, oracle, tmp_path):
     """Batch boundaries do not change results (AQ.cpp:1918-1976: all effects additive)."""
     c = make_case("mixed", str(tmp_path))

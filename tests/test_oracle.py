@@ -120,6 +120,56 @@ def test_pipeline_matches_reference_functions(case, O, R, tmp_path):
     R.free(gr)
 
 
+@needs_ref
+def test_qstring2qmask_matches_reference(O, R):
+    rng = np.random.default_rng(4)
+    for it in range(3000):
+        n = int(rng.integers(45, 256))
+        k = int(rng.choice([21, 25]))
+        mode = it % 4
+        q = rng.integers(33 + (25 if mode == 0 else 2), 33 + 41, n, dtype=np.uint8)
+        if mode == 2:
+            q[rng.integers(0, n, 3)] = 33 + 3
+        if mode == 3:
+            q[: int(rng.integers(0, n))] = 33 + 5
+        qb = q.tobytes()
+        for qth in (20, 10):
+            assert (O.qmask(qb, qth, k) == R.qmask(qb, qth, k)).all(), (it, n, k, qth)
+
+
+@needs_ref
+@pytest.mark.parametrize("fastq", [False, True])
+def test_bait_and_bubbles_match_reference_functions(O, R, tmp_path, fastq):
+    """-b (bfilter_FPSv1 + qString2qMask) and -bu (countNovelEdges) through the reference's own functions."""
+    loci = synth.make_loci(nloci=10, nhap=3, flank=500, seed=61, shared_frac=0.3)
+    d = str(tmp_path)
+    pref = synth.build_rpgg_with_reference(loci, d, k=21)
+    reads = synth.sim_reads(loci, npairs=1500, seed=62, sub=0.01, indel=0.002, nrate=0.002, chimeric=0.3, background=0.1,
+                            with_qual=fastq)
+    bait = synth.make_bait_db(loci, reads, d)
+    go, gr = O.load(pref, 21), R.load(pref)
+    O.load_bait(go, bait)
+    R.load_bait(gr, pref)
+    seq, off = reads.packed()
+    qual = np.frombuffer(b"".join(reads.quals), np.uint8).copy() if fastq else None
+    for kw in (dict(bait=1, bubbles=1, cthreshold=45), dict(bait=1, cthreshold=20, okam=0), dict(bubbles=1, cthreshold=30)):
+        p = abi.default_params(ksize=21, **kw)
+        a = O.align_ex(go, p, seq, off, qual)
+        b = R.align_ex(gr, p, seq, off, qual)
+        for f in ("counts_file", "kmc", "nmapread"):
+            assert (a[f] == b[f]).all(), f
+        ca = a["counters"].copy()
+        ca[abi.C_ALGO_PROBES:] = 0
+        assert (ca == b["counters"]).all(), (ca, b["counters"])
+        dd = bind.recs_equal(a["recs"], b["recs"], reads.npairs)
+        assert dd < 0, f"{bind.rec_str(a['recs'][dd])}\n{bind.rec_str(b['recs'][dd])}"
+        if p.bubbles:
+            assert len(a["events"]) == len(b["events"]) and (a["events"] == b["events"]).all()
+            assert len(a["events"]) > 100
+        if p.bait:
+            assert a["counters"][abi.C_BAITFILTERED] > 0
+
+
 GOLD = {
     "g1_k21": dict(k=21, fastq=False, params=dict(cthreshold=45), qc=False),
     "g2_shared_fq": dict(k=21, fastq=True, params=dict(), qc=False),
