@@ -70,6 +70,10 @@ struct DevX {
         return v;
     }
     __device__ uint32_t shfl_up1(uint32_t v) const { return __shfl_up(v, 1, 64); }
+    // lane 4q+j reads lane 4q+Pj (DPP quad_perm: no LDS traffic).  Every lane of the wave must be active at the call.
+    template <int P0, int P1, int P2, int P3> __device__ uint32_t quad_perm(uint32_t v) const {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, true);
+    }
     __device__ uint32_t bcast(uint32_t v, int src) const {  // src must be wave-uniform
         return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
     }
@@ -87,14 +91,14 @@ struct DevX {
 };
 
 // --------------------------------------------------------------- kernels ---
-__global__ void __launch_bounds__(256) k_fill_idx(IdxSlot* s, uint64_t cap) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
-        s[i].key = NAN64;
-        s[i].val = 0;
+__global__ void __launch_bounds__(256) k_fill_idx(IdxBucket* b, uint64_t nslots) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t)gridDim.x * blockDim.x) {
+        b[i >> 2].key[i & 3] = NAN64;
+        b[i >> 2].val[i & 3] = 0;
     }
 }
 __global__ void __launch_bounds__(256) k_idx_insert(IdxBuildArgs a) { DevX x{nullptr}; body_idx_insert(x, a); }
-__global__ void __launch_bounds__(256) k_idx_finalize(IdxSlot* s, uint64_t cap) { DevX x{nullptr}; body_idx_finalize(x, s, cap); }
+__global__ void __launch_bounds__(256) k_idx_finalize(IdxBucket* b, uint64_t nslots) { DevX x{nullptr}; body_idx_finalize(x, b, nslots); }
 __global__ void __launch_bounds__(256) k_cls_insert(ClsBuildArgs a) { DevX x{nullptr}; body_cls_insert(x, a); }
 __global__ void __launch_bounds__(256) k_idx_aux(IdxAuxArgs a) { DevX x{nullptr}; body_idx_aux(x, a); }
 
@@ -147,7 +151,7 @@ struct dbtk_ctx {
     hipStream_t stream = nullptr;
     DevTables T;
     // device allocations
-    IdxSlot* d_idx = nullptr;
+    IdxBucket* d_idx = nullptr;
     ClsSlot* d_cls = nullptr;
     uint32_t* d_vv = nullptr;
     uint8_t* d_qc = nullptr;
@@ -211,8 +215,12 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     hipStream_t s = c->stream;
     // ---- index
     const uint64_t nkeys = g->keys.size();
-    const uint64_t icap = pow2_at_least(2 * nkeys + 2);
-    HIPCHK(hipMalloc(&c->d_idx, icap * sizeof(IdxSlot)));
+    // slots = 4 per bucket; DBTK_IDX_SPARSITY (default 4) = minimum slots per key before rounding up to a power of two:
+    // at 4..8 slots per key a lookup leaves its home bucket about once in a thousand (HBM is plentiful: 16 B per slot)
+    uint64_t sparsity = 4;
+    if (const char* e = getenv("DBTK_IDX_SPARSITY")) { const long v = atol(e); if (v >= 2 && v <= 64) sparsity = (uint64_t)v; }
+    const uint64_t icap = pow2_at_least(sparsity * nkeys + 8), nbkt = icap / 4;
+    HIPCHK(hipMalloc(&c->d_idx, nbkt * sizeof(IdxBucket)));
     hipLaunchKernelGGL(k_fill_idx, dim3(2048), dim3(256), 0, s, c->d_idx, icap);
     if (nkeys) {
         uint64_t* dk = nullptr; uint32_t* dv = nullptr;
@@ -220,7 +228,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         HIPCHK(hipMalloc(&dv, nkeys * 4));
         HIPCHK(hipMemcpyAsync(dk, g->keys.data(), nkeys * 8, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(dv, g->vals.data(), nkeys * 4, hipMemcpyHostToDevice, s));
-        IdxBuildArgs a{c->d_idx, icap - 1, 64 - log2u(icap), dk, dv, nkeys};
+        IdxBuildArgs a{c->d_idx, nbkt - 1, 64 - log2u(nbkt), dk, dv, nkeys};
         hipLaunchKernelGGL(k_idx_insert, dim3(2048), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_idx_finalize, dim3(2048), dim3(256), 0, s, c->d_idx, icap);
         HIPCHK(hipStreamSynchronize(s));
@@ -282,7 +290,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         HIPCHK(hipStreamSynchronize(s));
     }
     DevTables& T = c->T;
-    T.idx = c->d_idx; T.idx_mask = icap - 1; T.idx_shift = 64 - log2u(icap);
+    T.idx = c->d_idx; T.idx_mask = nbkt - 1; T.idx_shift = 64 - log2u(nbkt);
     T.vv = c->d_vv;
     T.cls = c->d_cls; T.cls_mask = ccap - 1; T.cls_shift = 64 - log2u(ccap);
     T.qc = c->d_qc;

@@ -31,8 +31,8 @@ namespace dbtk {
 
 // ------------------------------------------------------------------ build --
 struct IdxBuildArgs {
-    IdxSlot* slots;
-    uint64_t mask;
+    IdxBucket* bkt;
+    uint64_t mask;   // buckets - 1
     uint32_t shift;
     const uint64_t* keys;
     const uint32_t* vals;
@@ -43,21 +43,26 @@ template <class X>
 DBTK_HD void body_idx_insert(X& x, const IdxBuildArgs& a) {
     for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.n; i += (uint64_t)x.nblocks() * x.nthreads()) {
         const uint64_t key = a.keys[i];
-        uint64_t s = hash_idx(key, a.shift);
+        uint64_t b = hash_idx(key, a.shift);
         for (;;) {
-            const uint64_t prev = x.atomic_cas(&a.slots[s].key, NAN64, key);
-            if (prev == NAN64 || prev == key) {
-                x.atomic_max(&a.slots[s].val, (i << 32) | a.vals[i]);  // kmerDBi[key] = val: last one wins
-                break;
+            bool placed = false;
+            for (int j = 0; j < 4 && !placed; ++j) {  // slots are claimed in order, so the occupied ones form a prefix
+                const uint64_t prev = x.atomic_cas(&a.bkt[b].key[j], NAN64, key);
+                if (prev == NAN64 || (prev & ~IDX_OVF) == key) {
+                    x.atomic_max(&a.bkt[b].val[j], (i << 32) | a.vals[i]);  // kmerDBi[key] = val: last one wins
+                    placed = true;
+                }
             }
-            s = (s + 1) & a.mask;
+            if (placed) break;
+            x.atomic_or(&a.bkt[b].key[3], IDX_OVF);  // full: lookups of absent keys must go on from here
+            b = (b + 1) & a.mask;
         }
     }
 }
 template <class X>
-DBTK_HD void body_idx_finalize(X& x, IdxSlot* slots, uint64_t cap) {
-    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < cap; i += (uint64_t)x.nblocks() * x.nthreads())
-        slots[i].val &= 0xFFFFFFFFull;
+DBTK_HD void body_idx_finalize(X& x, IdxBucket* bkt, uint64_t nslots) {
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < nslots; i += (uint64_t)x.nblocks() * x.nthreads())
+        bkt[i >> 2].val[i & 3] &= 0xFFFFFFFFull;
 }
 
 // After both tables exist: (1) check that the index and the per-locus flank/TR
@@ -67,18 +72,19 @@ DBTK_HD void body_idx_finalize(X& x, IdxSlot* slots, uint64_t cap) {
 // class of every single-locus k-mer next to its val.  stats[0] += memberships in
 // the index, stats[1] += memberships missing from the class table.
 struct IdxAuxArgs {
-    IdxSlot* slots;
-    uint64_t cap;
+    IdxBucket* bkt;
+    uint64_t nslots;
     DevTables T;  // cls, vv valid
     uint64_t* stats;
 };
 template <class X>
 DBTK_HD void body_idx_aux(X& x, const IdxAuxArgs& a) {
     uint64_t nmemb = 0, nmiss = 0;
-    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.cap; i += (uint64_t)x.nblocks() * x.nthreads()) {
-        const uint64_t key = a.slots[i].key;
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.nslots; i += (uint64_t)x.nblocks() * x.nthreads()) {
+        uint64_t key = a.bkt[i >> 2].key[i & 3];
         if (key == NAN64) continue;
-        const uint32_t v = (uint32_t)a.slots[i].val;
+        key &= ~IDX_OVF;
+        const uint32_t v = (uint32_t)a.bkt[i >> 2].val[i & 3];
         if (v & 1) {
             const uint32_t n = a.T.vv[v >> 1];
             for (uint32_t j = 0; j < n; ++j) {
@@ -89,7 +95,7 @@ DBTK_HD void body_idx_aux(X& x, const IdxAuxArgs& a) {
             ++nmemb;
             const uint32_t c = cls_lookup(a.T, key, v >> 1);
             if (c == CLS_NONE) ++nmiss;
-            a.slots[i].val = (uint64_t)v | ((uint64_t)c << 32);
+            a.bkt[i >> 2].val[i & 3] = (uint64_t)v | ((uint64_t)c << 32);
         }
     }
     if (nmemb) x.atomic_add(&a.stats[0], nmemb);
@@ -197,6 +203,18 @@ DBTK_HD void write_early_rec(dbtk_pair_rec_t* r, uint32_t pair, uint32_t stage, 
     for (int i = 0; i < MAXL / 4; ++i) { r->r1.as2[i] = 0; r->r2.as2[i] = 0; }
 }
 
+template <int P0, int P1, int P2, int P3, class X>
+DBTK_HD uint64_t quad_perm64(X& x, uint64_t v) {
+    const uint32_t lo = x.template quad_perm<P0, P1, P2, P3>((uint32_t)v), hi = x.template quad_perm<P0, P1, P2, P3>((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+// The 16 bytes of bucket b that lane part `part` (0..3) of a cooperating lane group reads: keys 0,1 | keys 2,3 | values 0,1 | values 2,3.
+DBTK_HD void bucket_part(const IdxBucket* idx, uint64_t b, uint32_t part, uint64_t* a0, uint64_t* a1) {
+    const uint4 q = reinterpret_cast<const uint4*>(idx + b)[part];
+    *a0 = ((uint64_t)q.y << 32) | q.x;
+    *a1 = ((uint64_t)q.w << 32) | q.z;
+}
+
 // ======================================================================= K1 =
 // encode + subfilter (read2kmers_edges' validity + subfilter,
 // src/aQueryFasta_thread.h:274-311, src/aQueryFasta_thread.cpp:172-188, 2035-2051).
@@ -206,13 +224,20 @@ DBTK_HD void write_early_rec(dbtk_pair_rec_t* r, uint32_t pair, uint32_t stage, 
 // LDS slice, and probes the N_FILTER sampled windows of mate 1 with 4 lanes per
 // pair (sample s on lane 4*pair + s%4); the group verdicts come from one ballot.
 // Mate 2 is probed only for pairs whose mate 1 passed — the probes the reference
-// performs.  Small footprint (3 KB LDS), so many waves per CU hide the probe latency.
+// performs.  The wave is software-pipelined over its tiles: while tile t is being
+// probed (one HBM round trip per probe, see IdxBucket) the bytes and read offsets
+// of tile t+1 are already in flight into registers and the tile geometry of t+2
+// into SGPRs, so the streaming and the random traffic overlap inside every wave.
 constexpr int K1_NT = 64;
 constexpr int K1_TP = 16;                              // pairs per tile
 constexpr int K1_CH = K1_TP * 2 * MAXL / 16 + 4;       // 16-base chunks per tile (+ slack)
+constexpr int K1_SBF = 48;                             // survivors buffered per wave before one atomic appends them
+constexpr int K1_PF = 5;                               // chunks per lane fetched ahead (320 chunks: a tile of 150 bp pairs has <= 301)
 struct K1Smem {
     uint32_t pk[K1_CH];
     uint16_t vd[K1_CH];
+    uint16_t rb[2 * K1_TP], rl[2 * K1_TP];  // per read of the tile: first base (relative to the tile's A0), length
+    uint32_t sbuf[K1_SBF + K1_TP];          // survivors not yet appended to the global list
 };
 
 // true iff bases [b, b+len) of the stream contain a run of >= k valid bases
@@ -238,6 +263,14 @@ DBTK_HD bool any_valid_window(const uint16_t* vd, uint32_t b, uint32_t len, uint
     return found;
 }
 
+// The last, partial 16 bytes of the batch at g as four little-endian words; bytes past the end read as 0.
+// Rare (one chunk per batch): kept as a rolled loop off the hot path.
+DBTK_HD void load_tail_chunk(const uint8_t* seq, uint64_t seq_len, uint64_t g, uint32_t w[4]) {
+    w[0] = w[1] = w[2] = w[3] = 0;
+#pragma nounroll
+    for (uint32_t b = 0; b < 16 && g + b < seq_len; ++b) w[b >> 2] |= (uint32_t)seq[g + b] << (8 * (b & 3));
+}
+
 template <class X>
 DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     K1Smem& sm = *x.template smem<K1Smem>();
@@ -245,54 +278,125 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     const uint32_t k = a.P.ksize, NF = a.P.n_filter, NM = a.P.nm_filter;
     const bool dosub = NF && NM;
     const uint32_t grp = lane >> 2, sub = lane & 3;  // pair of the tile this lane works for, sample phase
-    uint64_t c_short = 0, c_sub = 0, c_nhash = 0, c_probe = 0, c_surv = 0, c_bases = 0;  // per-lane partial sums
+    uint32_t c_short = 0, c_sub = 0, c_nhash = 0, c_probe = 0, c_surv = 0;  // per-lane partial sums (a wave sees < 2^32 pairs)
+    uint64_t c_bases = 0;
     if (lane == 0 && x.bid() == 0) x.atomic_add(&a.counters[DBTK_C_NREADS], 2 * a.npairs);  // nReads, AQ.cpp:1977
     const uint64_t ntiles = (a.npairs + K1_TP - 1) / K1_TP;
     const int lane_ = (int)lane; (void)lane_;
     DBTK_STAMP_DECL
-    for (uint64_t tile = x.bid(); tile < ntiles; tile += x.nblocks()) {
-        const uint64_t p0 = tile * K1_TP;
-        const uint32_t np = (uint32_t)((a.npairs - p0 < (uint64_t)K1_TP) ? a.npairs - p0 : K1_TP);
-        const uint64_t B0 = a.off[2 * p0], B1 = a.off[2 * (p0 + np)];
-        const uint64_t A0 = B0 & ~15ull;
-        const uint32_t nch = (uint32_t)((B1 - A0 + 15) >> 4);
-        if (nch + 3 > (uint32_t)K1_CH) {  // a read longer than DBTK_MAX_READ_LEN slipped through
-            if (lane == 0) *a.errflag = DBTK_ERR_READ_TOO_LONG;
-            continue;
+    // Tile geometry comes from two offsets; they are requested two tiles ahead and only turned into
+    // (A0, nch) when their tile becomes the one being fetched, so nothing waits on them.
+    auto tile_p0 = [&](uint64_t tile) { return tile * K1_TP; };
+    auto tile_np = [&](uint64_t tile) { const uint64_t p0 = tile * K1_TP; return (uint32_t)((a.npairs - p0 < (uint64_t)K1_TP) ? a.npairs - p0 : K1_TP); };
+    uint32_t w[K1_PF][4];        // this lane's chunks lane, lane+64, ... of the tile in flight
+    uint64_t ro0 = 0, ro1 = 0;   // lane r < 2*np: offsets of read r of the tile in flight
+    // Straight-line loads only (no per-load branches, or the compiler waits for each one in turn): a lane whose
+    // chunk is outside the tile, or is the partial last chunk of the batch, reads the batch's first 16 bytes instead
+    // and the pack step ignores what came back.  Precondition (kept by the host side): 16 bytes are readable at a.seq.
+    auto fetch = [&](uint64_t p0, uint32_t np, uint64_t A0, uint32_t nch) {
+#pragma unroll
+        for (int j = 0; j < K1_PF; ++j) {
+            const uint32_t c = lane + 64u * j;
+            uint64_t gb = A0 + 16ull * c;
+#ifdef DBTK_STAMPS
+            if (a.P.reserved[0] & 2) gb = 16ull * c;  // diagnostic: no streaming traffic (every tile reads the first tile's bytes)
+#endif
+            const uint4 q = *reinterpret_cast<const uint4*>(a.seq + ((c < nch && gb + 16 <= a.seq_len) ? gb : 0ull));
+            w[j][0] = q.x; w[j][1] = q.y; w[j][2] = q.z; w[j][3] = q.w;
         }
-        x.sync();  // the previous tile's LDS is dead
-        DBTK_STAMP(16);  // tile set-up (offset loads)
-        // A: pack the tile
-        for (uint32_t c = lane; c < nch + 3; c += K1_NT) {
-            uint32_t pk = 0, vd = 0;
-            if (c < nch) {
-                const uint64_t g = A0 + 16ull * c;
-                uint32_t w[4];
-                if (g + 16 <= a.seq_len) {
-                    const uint4 q = *reinterpret_cast<const uint4*>(a.seq + g);
-                    w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-                } else {
-                    for (int j = 0; j < 4; ++j) {
-                        w[j] = 0;
-                        for (int b = 0; b < 4; ++b)
-                            if (g + 4 * j + b < a.seq_len) w[j] |= (uint32_t)a.seq[g + 4 * j + b] << (8 * b);
-                    }
-                }
-                pk = pack16(w, &vd);
-            }
-            sm.pk[c] = pk;
-            sm.vd[c] = (uint16_t)vd;
-        }
+        const uint32_t r = lane < 2 * np ? lane : 2 * np - 1;
+        ro0 = a.off[2 * p0 + r]; ro1 = a.off[2 * p0 + r + 1];
+    };
+    uint32_t nsb = 0;  // survivors waiting in sm.sbuf (wave-uniform)
+    auto flush_survivors = [&]() {
         x.sync();
-        DBTK_STAMP(17);  // loads + pack
+        uint32_t base = 0;
+        if (lane == 0) base = x.atomic_add(a.nsurv, nsb);
+        base = x.bcast(base, 0);
+        for (uint32_t i = lane; i < nsb; i += K1_NT) a.surv[base + i] = sm.sbuf[i];
+        x.sync();
+    };
+    const uint64_t stride = x.nblocks();
+    uint64_t tile = x.bid();
+    uint64_t cB0 = 0, cB1 = 0, nB0 = 0, nB1 = 0;  // first/last offset of the current tile and of the next one
+    if (tile < ntiles) {
+        cB0 = a.off[2 * tile_p0(tile)]; cB1 = a.off[2 * (tile_p0(tile) + tile_np(tile))];
+        fetch(tile_p0(tile), tile_np(tile), cB0 & ~15ull, (uint32_t)((cB1 - (cB0 & ~15ull) + 15) >> 4));
+    }
+    if (tile + stride < ntiles) { nB0 = a.off[2 * tile_p0(tile + stride)]; nB1 = a.off[2 * (tile_p0(tile + stride) + tile_np(tile + stride))]; }
+    for (; tile < ntiles; tile += stride) {
+        const uint64_t p0 = tile_p0(tile), A0 = cB0 & ~15ull;
+        const uint32_t np = tile_np(tile), nch = (uint32_t)((cB1 - A0 + 15) >> 4);
+        const bool toolong = nch + 3 > (uint32_t)K1_CH;  // a read longer than DBTK_MAX_READ_LEN slipped through
+        if (toolong && lane == 0) *a.errflag = DBTK_ERR_READ_TOO_LONG;
+        x.sync();  // the previous tile's LDS is dead
+        DBTK_STAMP(16);  // tile set-up
+        // A: pack the tile.  Fast form: 2-bit codes only, plus "some byte is not ACGT" per lane.
+        uint32_t bad = 0;
+        if (!toolong) {
+#pragma unroll
+            for (int j = 0; j < K1_PF; ++j) {
+                const uint32_t c = lane + 64u * j;
+                if (c < nch + 3) {
+                    if (c >= nch) w[j][0] = w[j][1] = w[j][2] = w[j][3] = 0;  // padding
+                    else if (A0 + 16ull * c + 16 > a.seq_len) {  // (through a temporary: w must stay in registers)
+                        uint32_t t[4];
+                        load_tail_chunk(a.seq, a.seq_len, A0 + 16ull * c, t);
+                        w[j][0] = t[0]; w[j][1] = t[1]; w[j][2] = t[2]; w[j][3] = t[3];
+                    }
+                    uint32_t b = 0;
+                    sm.pk[c] = pack16_fast(w[j], &b);
+                    if (c < nch) bad |= b;
+                }
+            }
+            for (uint32_t c = lane + 64u * K1_PF; c < nch + 3; c += K1_NT) {  // reads longer than 150 bp: the rest of the tile, exact form
+                uint32_t t[4] = {0, 0, 0, 0}, vd = 0;
+                const uint64_t gb = A0 + 16ull * c;
+                if (c < nch) {
+                    if (gb + 16 <= a.seq_len) { const uint4 q = *reinterpret_cast<const uint4*>(a.seq + gb); t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w; }
+                    else load_tail_chunk(a.seq, a.seq_len, gb, t);
+                }
+                sm.pk[c] = pack16(t, &vd);
+                sm.vd[c] = (uint16_t)vd;
+                if (c < nch && vd != 0xFFFFu) bad = 1;
+            }
+        }
+        // Every base of the tile is ACGT (the usual case): every window is valid and no validity bits are needed.
+        // Otherwise (an N somewhere, or the zero padding after the batch's last read) compute them exactly.
+        const bool clean = x.ballot(bad != 0) == 0;
+        if (!clean && !toolong) {
+#pragma unroll
+            for (int j = 0; j < K1_PF; ++j) {
+                const uint32_t c = lane + 64u * j;
+                if (c < nch + 3) {
+                    uint32_t vd = 0;
+                    (void)pack16(w[j], &vd);
+                    sm.vd[c] = (uint16_t)vd;
+                }
+            }
+        }
+        const uint64_t o0 = ro0, o1 = ro1;
+        // the next tile's bytes, and the geometry of the one after, start their trip now
+        const uint64_t t1 = tile + stride, t2 = t1 + stride;
+        cB0 = nB0; cB1 = nB1;
+        {   // unconditional (a dummy fetch of nothing past the last tile) so that the loads land straight in w/ro
+            const bool h1 = t1 < ntiles, h2 = t2 < ntiles;
+            const uint64_t A1 = cB0 & ~15ull;
+            fetch(h1 ? tile_p0(t1) : 0, h1 ? tile_np(t1) : 1u, A1, h1 ? (uint32_t)((cB1 - A1 + 15) >> 4) : 0u);
+            nB0 = a.off[h2 ? 2 * tile_p0(t2) : 0]; nB1 = a.off[h2 ? 2 * (tile_p0(t2) + tile_np(t2)) : 0];
+        }
+        if (toolong) continue;
+        DBTK_STAMP(17);  // pack + issue of the next fetch
         // B: per-read geometry and "has a valid window" (caks.size() != 0, AQ.cpp:2037): lane r < 2*np owns read r
         bool myany = false;
         if (lane < 2 * np) {
-            const uint64_t o0 = a.off[2 * p0 + lane], o1 = a.off[2 * p0 + lane + 1];
             const uint32_t len = (uint32_t)(o1 - o0);
-            myany = any_valid_window(sm.vd, (uint32_t)(o0 - A0), len, k);
+            sm.rb[lane] = (uint16_t)(o0 - A0);
+            sm.rl[lane] = (uint16_t)len;
             c_bases += len;
         }
+        x.sync();
+        if (lane < 2 * np) myany = clean ? (uint32_t)(o1 - o0) >= k : any_valid_window(sm.vd, sm.rb[lane], sm.rl[lane], k);
         const uint64_t anym = x.ballot(myany);                       // bit r: read r has a window
         const bool gvalid = grp < np;
         const bool gany = gvalid && ((anym >> (2 * grp)) & 3) == 3;  // both mates of my pair
@@ -305,71 +409,102 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                 if (mate == 1 && x.ballot(go) == 0) break;  // nobody's mate 1 passed: the usual case
                 uint32_t bpos = 0, L = 1, S = 0;
                 if (go) {
-                    const uint64_t o0 = a.off[2 * (p0 + grp) + mate], o1 = a.off[2 * (p0 + grp) + mate + 1];
-                    bpos = (uint32_t)(o0 - A0);
-                    L = (uint32_t)(o1 - o0) - k + 1;
+                    bpos = sm.rb[2 * grp + mate];
+                    L = (uint32_t)sm.rl[2 * grp + mate] - k + 1;
                     S = L / (NF - 1);
                 }
                 for (uint32_t s0 = 0; s0 < NF; s0 += 4) {
                     const uint32_t sidx = s0 + sub;
-                    bool hit = false;
+                    uint64_t km = NAN64;
                     if (go && sidx < NF) {
                         const uint32_t pos = (sidx != NF - 1) ? sidx * S : L - 1;
-                        const uint64_t km = window_kmer(sm.pk, sm.vd, bpos + pos, k, nullptr, nullptr);
-                        hit = km != NAN64 && idx_lookup(a.T, km) != NOHIT;
+                        km = clean ? window_kmer_clean(sm.pk, bpos + pos, k) : window_kmer(sm.pk, sm.vd, bpos + pos, k, nullptr, nullptr);
                     }
-                    const uint64_t hb = x.ballot(hit);
-                    hm[mate] |= (uint32_t)((hb >> (4 * grp)) & 0xF) << s0;
+#ifdef DBTK_STAMPS
+                    if (a.P.reserved[0] & 1) km = NAN64;  // diagnostic: no probes
+#endif
+                    const uint32_t hb = km != NAN64 ? (uint32_t)hash_idx(km, a.T.idx_shift) : 0u;
+                    // Two rounds; in round r the lane pairs {0,1} and {2,3} of the group look up samples 2r and 2r+1:
+                    // each lane reads two of the bucket's four keys, so one load instruction fetches the keys of 32
+                    // probes and a probe is ONE request to the memory system.
+                    uint32_t hits = 0;
+                    uint64_t kq[2], k0[2], k1[2];
+                    uint32_t bq[2];
+                    kq[0] = quad_perm64<0, 0, 1, 1>(x, km); kq[1] = quad_perm64<2, 2, 3, 3>(x, km);
+                    bq[0] = x.template quad_perm<0, 0, 1, 1>(hb); bq[1] = x.template quad_perm<2, 2, 3, 3>(hb);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {  // both rounds' loads are in flight together
+                        k0[r] = NAN64; k1[r] = NAN64;
+                        if (kq[r] != NAN64) bucket_part(a.T.idx, bq[r], sub & 1, &k0[r], &k1[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        bool open = kq[r] != NAN64, hitl = false;
+                        uint64_t hmask;
+                        for (;;) {
+                            bool again = false;
+                            if (open) {
+                                hitl = k0[r] == kq[r] || (k1[r] & ~IDX_OVF) == kq[r];
+                                again = (sub & 1) && k1[r] != NAN64 && (k1[r] & IDX_OVF);  // key[3]: full, and an insert walked past
+                            }
+                            hmask = x.ballot(hitl);
+                            const uint64_t amask = x.ballot(again);
+                            open = open && ((hmask >> (lane & ~1u)) & 3) == 0 && ((amask >> (lane | 1u)) & 1);
+                            if (x.ballot(open) == 0) break;
+                            if (open) {  // rare: on to the next bucket
+                                bq[r] = (bq[r] + 1) & (uint32_t)a.T.idx_mask;
+                                bucket_part(a.T.idx, bq[r], sub & 1, &k0[r], &k1[r]);
+                            }
+                        }
+                        const uint32_t g4 = (uint32_t)(hmask >> (lane & ~3u)) & 0xF;
+                        hits |= ((g4 & 3) ? 1u : 0u) << (2 * r) | ((g4 >> 2) ? 1u : 0u) << (2 * r + 1);
+                    }
+                    hm[mate] |= hits << s0;
                 }
             }
         }
         DBTK_STAMP(19);  // sampled probes
-        // E: verdicts, one lane per pair
+        // E: verdicts (computed on every lane of a pair's group, counted on its first)
         bool pass = false;
-        if (gvalid && sub == 0) {
+        {
+            const bool lead = gvalid && sub == 0;
             uint32_t stage = 0xFFFFFFFFu;
             if (!gany) {
                 stage = DBTK_STAGE_SHORT;
-                ++c_short;
+                c_short += lead;
             } else if (dosub) {
-                uint32_t nhash = 0, nprobe = 0, h = 0;
-                bool brk = false;
-                for (uint32_t i = 0; i < NF; ++i) {  // AQ.cpp:176-180: ++nhash only when the loop continues
-                    h += (hm[0] >> i) & 1; ++nprobe;
-                    if (h >= NM) { brk = true; break; }
-                    ++nhash;
+                // subfilter's loop (AQ.cpp:176-180) stops at the NM-th hit, at sample p: p+1 probes, ++nhash p times;
+                // without NM hits it runs over all NF samples
+                uint32_t nhash = 0, nprobe = 0;
+                bool rej = false;
+                for (int mate = 0; mate < 2 && !rej; ++mate) {
+                    uint32_t r = hm[mate];
+                    for (uint32_t i = 1; i < NM; ++i) r &= r - 1;
+                    const uint32_t pth = r ? (uint32_t)__builtin_ctz(r) : NF;
+                    nhash += pth; nprobe += r ? pth + 1 : NF;
+                    rej = r == 0;
                 }
-                bool rej = !brk;
-                if (!rej) {
-                    h = 0; brk = false;
-                    for (uint32_t i = 0; i < NF; ++i) {
-                        h += (hm[1] >> i) & 1; ++nprobe;
-                        if (h >= NM) { brk = true; break; }
-                        ++nhash;
-                    }
-                    rej = !brk;
-                }
-                c_nhash += nhash; c_probe += nprobe;
-                if (rej) { stage = DBTK_STAGE_SUBFILTER; c_sub += 2; }
+                if (lead) { c_nhash += nhash; c_probe += nprobe; }
+                if (rej) { stage = DBTK_STAGE_SUBFILTER; c_sub += lead ? 2 : 0; }
             }
-            pass = stage == 0xFFFFFFFFu;
-            if (!pass && a.P.trace && a.recs) {
+            pass = lead && stage == 0xFFFFFFFFu;
+            if (lead && !pass && a.P.trace && a.recs) {
                 const uint32_t pair = (uint32_t)(p0 + grp) + a.pair_base;
                 write_early_rec(&a.recs[pair], pair, stage, a.T.nloci);
             }
         }
         const uint64_t pm = x.ballot(pass);
-        if (pm) {  // survivors of the tile: one atomic for the wave, kept in pair order
-            uint32_t base = 0;
-            if (lane == 0) base = x.atomic_add(a.nsurv, (uint32_t)__builtin_popcountll(pm));
-            base = x.bcast(base, 0);
+        if (pm) {  // survivors go to the wave's LDS buffer (pair order inside the tile); one atomic per K1_SBF of them
             if (pass) {
-                a.surv[base + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1))] = (uint32_t)(p0 + grp);
+                sm.sbuf[nsb + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1))] = (uint32_t)(p0 + grp);
                 ++c_surv;
             }
+            nsb += (uint32_t)__builtin_popcountll(pm);
+            if (nsb >= (uint32_t)K1_SBF) { flush_survivors(); nsb = 0; }
         }
         DBTK_STAMP(20);  // verdict + survivor append
     }
+    if (nsb) flush_survivors();
     {
         const int lane = lane_;
         DBTK_STAMP_FLUSH;
@@ -638,6 +773,8 @@ struct ProbeSmem {
     uint16_t vd[20];
     uint32_t qraw[72];   // base qualities of the read (only with -b and qualities)
     uint32_t qmask[8];
+    uint64_t km[NKMAX];  // canonical k-mer per position (NAN64: window not valid)
+    uint32_t hb[NKMAX];  // its home bucket
 };
 
 // qString2qMask (src/aQueryFasta_thread.h:1038-1071), statement by statement, on the quality bytes
@@ -725,38 +862,69 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         const uint32_t nk = len >= k ? len - k + 1 : 0;
         const uint32_t nsl = (nk + 63) >> 6;
         uint64_t km[NSLOT], hh[NSLOT];
-        uint32_t hv[NSLOT], ha[NSLOT];
         bool open[NSLOT];
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             const uint32_t i = 64 * s + lane;
-            km[s] = NAN64; hv[s] = NOHIT; ha[s] = 0; hh[s] = 0; open[s] = false;
+            km[s] = NAN64; hh[s] = 0; open[s] = false;
             if ((uint32_t)s < nsl && i < nk) {
                 km[s] = window_kmer(sm.pk, sm.vd, i, k, nullptr, nullptr);
                 hh[s] = hash_idx(km[s], T.idx_shift);
                 open[s] = km[s] != NAN64;
             }
         }
-        for (;;) {  // linear probing in wave-wide rounds
-            IdxSlot q[NSLOT];
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s)
-                if (open[s]) q[s] = T.idx[hh[s]];
-            bool again = false;
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s)
-                if (open[s]) {
-                    if (q[s].key == km[s]) { hv[s] = (uint32_t)q[s].val; ha[s] = (uint32_t)(q[s].val >> 32); open[s] = false; }
-                    else if (q[s].key == NAN64) open[s] = false;
-                    else { hh[s] = (hh[s] + 1) & T.idx_mask; again = true; }
-                }
-            if (x.ballot(again) == 0) break;
-        }
-        HitEnt* out = a.hitbuf + (size_t)it * a.nkp;
+        // Stage (k-mer, home bucket) per position in LDS, then look the positions up 16 at a time: the four lanes of a
+        // quad read the four 16-byte parts of one bucket (keys 0,1 | keys 2,3 | values 0,1 | values 2,3), so a lookup
+        // is one request for one 64-byte line and ends in its home bucket unless that bucket is full AND overflowed.
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             const uint32_t i = 64 * s + lane;
-            if ((uint32_t)s < nsl && i < nk) out[i] = HitEnt{km[s], hv[s], ha[s]};
+            if ((uint32_t)s < nsl && i < nk) { sm.km[i] = km[s]; sm.hb[i] = open[s] ? (uint32_t)hh[s] : 0u; }
+        }
+        x.sync();
+        HitEnt* out = a.hitbuf + (size_t)it * a.nkp;
+        const uint32_t sub = lane & 3, qd = lane >> 2;
+        constexpr int NB = 4;  // buckets in flight per lane
+        for (uint32_t i0 = 0; i0 < nk; i0 += 16 * NB) {
+            uint32_t ii[NB], bq[NB];
+            uint64_t kq[NB], a0[NB], a1[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                ii[u] = i0 + 16 * u + qd;
+                kq[u] = NAN64; bq[u] = 0; a0[u] = 0; a1[u] = 0;
+                if (ii[u] < nk) { kq[u] = sm.km[ii[u]]; bq[u] = sm.hb[ii[u]]; }
+                if (kq[u] != NAN64) bucket_part(T.idx, bq[u], sub, &a0[u], &a1[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                if (i0 + 16 * u >= nk) break;  // uniform
+                bool open1 = kq[u] != NAN64, hitl = false;
+                uint64_t myval = 0;
+                for (;;) {
+                    const uint64_t v0 = quad_perm64<2, 3, 2, 3>(x, a0[u]), v1 = quad_perm64<2, 3, 2, 3>(x, a1[u]);  // values -> the lanes holding their keys
+                    bool again = false;
+                    if (open1 && sub < 2) {
+                        if (a0[u] == kq[u]) { hitl = true; myval = v0; }
+                        else if ((a1[u] & ~IDX_OVF) == kq[u]) { hitl = true; myval = v1; }
+                        again = sub == 1 && a1[u] != NAN64 && (a1[u] & IDX_OVF);
+                    }
+                    const uint64_t hmask = x.ballot(hitl), amask = x.ballot(again);
+                    const bool qhit = ((hmask >> (lane & ~3u)) & 0xF) != 0;
+                    open1 = open1 && !qhit && ((amask >> ((lane & ~3u) + 1)) & 1);
+                    if (x.ballot(open1) == 0) {
+                        if (ii[u] < nk) {
+                            if (hitl) out[ii[u]] = HitEnt{kq[u], (uint32_t)myval, (uint32_t)(myval >> 32)};
+                            else if (sub == 0 && !qhit) out[ii[u]] = HitEnt{kq[u], NOHIT, 0};
+                        }
+                        break;
+                    }
+                    a0[u] = 0; a1[u] = 0;
+                    if (open1) {  // rare: on to the next bucket
+                        bq[u] = (bq[u] + 1) & (uint32_t)T.idx_mask;
+                        bucket_part(T.idx, bq[u], sub, &a0[u], &a1[u]);
+                    }
+                }
+            }
         }
         if (a.edgebuf) {  // -bu: canonical (k+1)-mers = read2kmers_edges' `edges` (AQ.h:290-295): window of k+1 bases
             uint64_t* eo = a.edgebuf + (size_t)it * a.nkp;

@@ -18,7 +18,7 @@
 #define DBTK_HD_NOINLINE __host__ __device__ __noinline__
 #else
 #define DBTK_HD inline
-#define DBTK_HD_NOINLINE
+#define DBTK_HD_NOINLINE inline
 struct uint4 { uint32_t x, y, z, w; };  // host (tests/emu) stand-in for HIP's vector type
 #endif
 
@@ -33,16 +33,25 @@ constexpr int MAXL = DBTK_MAX_READ_LEN;      // bases per read
 constexpr int NKMAX = 256;                   // k-mer positions per mate (4 per lane)
 constexpr int NHMAX = 2 * NKMAX;             // hits per pair
 
-// ---- k-mer index: PREF.kmers.dbi (src/aQueryFasta_thread.h:654-673) as an
-// open-addressed, linear-probed table of 16-byte slots.  `val` keeps the
-// reference's encoding: even -> locus = val>>1, odd -> vv[val>>1] = n followed
-// by n loci.  During the build `val` temporarily holds (file index << 32 | val)
-// so that the LAST assignment of a duplicated key wins, as operator[] does.
-struct IdxSlot {
-    uint64_t key;  // NAN64 = empty
-    uint64_t val;  // low 32 bits: val.  High 32 bits (`aux`): for a k-mer unique to one locus (even val) its
-                   // class at that locus — CLS_FLANK or its OUT.trkmc.ar slot — so that assignTRkmc needs no second probe
+// ---- k-mer index: PREF.kmers.dbi (src/aQueryFasta_thread.h:654-673) as a
+// bucketed open-addressed table in HBM.  A bucket is one 64-byte line: four
+// keys, then the four values (SoA, so the encode kernel — which only needs
+// "present or not" — reads 32 bytes).  A key lives in the first bucket, in probe
+// order from its home bucket, that had a free slot; slots of a bucket fill in
+// order 0..3, so key[3] == NAN64 <=> the bucket has a free slot, and bit 63 of
+// key[3] (IDX_OVF; k <= 31 keeps canonical k-mers below 2^62) records that some
+// insert walked past this full bucket.  A lookup therefore ends in its home
+// bucket — one HBM line, one round trip — unless that bucket is full AND has
+// overflowed.  `val` keeps the reference's encoding: even -> locus = val>>1,
+// odd -> vv[val>>1] = n followed by n loci.  During the build `val` temporarily
+// holds (file index << 32 | val) so that the LAST assignment of a duplicated key
+// wins, as operator[] does.
+struct __attribute__((aligned(64))) IdxBucket {
+    uint64_t key[4];  // NAN64 = empty
+    uint64_t val[4];  // low 32 bits: val.  High 32 bits (`aux`): for a k-mer unique to one locus (even val) its
+                      // class at that locus — CLS_FLANK or its OUT.trkmc.ar slot — so that assignTRkmc needs no second probe
 };
+constexpr uint64_t IDX_OVF = 1ull << 63;
 
 // ---- class table: for locus l, k-mer km: flank (PREF.fl.kdb) beats TR
 // (PREF.tr.kmers) exactly as assignTRkmc tests them
@@ -54,9 +63,9 @@ struct ClsSlot {
 };
 
 struct DevTables {
-    const IdxSlot* idx;
-    uint64_t idx_mask;   // capacity - 1 (power of two)
-    uint32_t idx_shift;  // 64 - log2(capacity)
+    const IdxBucket* idx;
+    uint64_t idx_mask;   // buckets - 1 (power of two)
+    uint32_t idx_shift;  // 64 - log2(buckets)
     const uint32_t* vv;
     const ClsSlot* cls;
     uint64_t cls_mask;
@@ -82,25 +91,45 @@ DBTK_HD uint64_t hash_cls(uint64_t kmer, uint32_t locus, uint32_t shift) {
     return (x * 0x9E3779B97F4A7C15ull) >> shift;
 }
 
-// kmerDBi.find(kmer): returns val or NOHIT.
-DBTK_HD uint32_t idx_lookup(const DevTables& T, uint64_t key) {
-    uint64_t i = hash_idx(key, T.idx_shift);
-    for (;;) {
-        const IdxSlot s = T.idx[i];
-        if (s.key == key) return (uint32_t)s.val;
-        if (s.key == NAN64) return NOHIT;
-        i = (i + 1) & T.idx_mask;
-    }
+// The four keys of a bucket: two 16-byte loads.
+DBTK_HD void bucket_keys(const IdxBucket* b, uint64_t k[4]) {
+    const uint4 lo = reinterpret_cast<const uint4*>(b)[0], hi = reinterpret_cast<const uint4*>(b)[1];
+    k[0] = ((uint64_t)lo.y << 32) | lo.x; k[1] = ((uint64_t)lo.w << 32) | lo.z;
+    k[2] = ((uint64_t)hi.y << 32) | hi.x; k[3] = ((uint64_t)hi.w << 32) | hi.z;
+}
+// Where `key` stands in a bucket: 0..3 = its slot, BKT_MISS = not in the table, BKT_NEXT = look in the next bucket.
+constexpr int BKT_MISS = 4, BKT_NEXT = 5;
+DBTK_HD int bucket_find(const uint64_t k[4], uint64_t key) {
+    int r = (k[3] != NAN64 && (k[3] & IDX_OVF)) ? BKT_NEXT : BKT_MISS;
+    if (k[3] != NAN64 && (k[3] & ~IDX_OVF) == key) r = 3;
+    if (k[2] == key) r = 2;
+    if (k[1] == key) r = 1;
+    if (k[0] == key) r = 0;
+    return r;
 }
 
-// same, returning val | aux << 32 (low word NOHIT on a miss)
+// kmerDBi.find(kmer): returns val | aux << 32, low word NOHIT on a miss.
 DBTK_HD uint64_t idx_lookup64(const DevTables& T, uint64_t key) {
-    uint64_t i = hash_idx(key, T.idx_shift);
+    uint64_t b = hash_idx(key, T.idx_shift);
     for (;;) {
-        const IdxSlot s = T.idx[i];
-        if (s.key == key) return s.val;
-        if (s.key == NAN64) return (uint64_t)NOHIT;
-        i = (i + 1) & T.idx_mask;
+        uint64_t k[4];
+        bucket_keys(&T.idx[b], k);
+        const int r = bucket_find(k, key);
+        if (r < 4) return T.idx[b].val[r];
+        if (r == BKT_MISS) return (uint64_t)NOHIT;
+        b = (b + 1) & T.idx_mask;
+    }
+}
+DBTK_HD uint32_t idx_lookup(const DevTables& T, uint64_t key) { return (uint32_t)idx_lookup64(T, key); }
+// kmerDBi.count(kmer): keys only
+DBTK_HD bool idx_contains(const DevTables& T, uint64_t key) {
+    uint64_t b = hash_idx(key, T.idx_shift);
+    for (;;) {
+        uint64_t k[4];
+        bucket_keys(&T.idx[b], k);
+        const int r = bucket_find(k, key);
+        if (r != BKT_NEXT) return r < 4;
+        b = (b + 1) & T.idx_mask;
     }
 }
 
@@ -155,6 +184,32 @@ DBTK_HD uint32_t pack16(const uint32_t w[4], uint32_t* valid16) {
     return (p0 << 24) | (p1 << 16) | (p2 << 8) | p3;
 }
 
+// ---- the same packing on the streaming path of the encode kernel, where instruction count is the bound:
+// byte-select and 24-bit multiply instead of shifts/masks, and validity only as "any byte of the chunk is not
+// ACGT" (nonzero *bad).  Exact validity bits are recomputed with pack16 for the rare tile that has such a byte.
+DBTK_HD uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {  // v_perm_b32: selector byte 0..3 -> lo, 4..7 -> hi
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t src = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) r |= (uint32_t)((src >> (8 * ((sel >> (8 * i)) & 7))) & 0xFF) << (8 * i);
+    return r;
+#endif
+}
+// 4 ASCII bases -> their 2-bit codes gathered in BYTE 2 of the result (base 0 in bits 23:22); other bytes are scratch
+DBTK_HD uint32_t pack4_b2(uint32_t x, uint32_t* bad) {
+    const uint32_t t = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+    *bad |= x ^ byte_perm(0u, 0x54474341u, t);  // expected byte of each code vs the input byte
+    // (t & 0xFFFFFF) * (2^22 + 2^12 + 2^2): codes 0,1,2 land at bits 23:22, 21:20, 19:18 (no carries); code 3 comes down from bits 25:24
+    return ((t & 0x00FFFFFFu) * 0x00401004u) | (t >> 8);
+}
+DBTK_HD uint32_t pack16_fast(const uint32_t w[4], uint32_t* bad) {
+    const uint32_t r0 = pack4_b2(w[0], bad), r1 = pack4_b2(w[1], bad), r2 = pack4_b2(w[2], bad), r3 = pack4_b2(w[3], bad);
+    const uint32_t hi = byte_perm(r0, r1, 0x06020000u), lo = byte_perm(r2, r3, 0x00000602u);
+    return byte_perm(hi, lo, 0x07060100u);
+}
+
 // Reverse complement of a k-mer held in the low 2k bits (getNuRC,
 // src/aQueryFasta_thread.h:165-178): reverse the 2-bit symbols, complement.
 DBTK_HD uint64_t revcomp2(uint64_t x, uint32_t k) {
@@ -182,6 +237,17 @@ DBTK_HD uint64_t window_kmer(const uint32_t* pk, const uint16_t* vd, uint32_t b,
     if (fw_out) *fw_out = fw;
     if (rc_out) *rc_out = rc;
     if (vk != ((1ull << k) - 1)) return NAN64;
+    return fw < rc ? fw : rc;
+}
+
+// The same window when every base of the stream is known to be valid (no validity words are read).
+DBTK_HD uint64_t window_kmer_clean(const uint32_t* pk, uint32_t b, uint32_t k) {
+    const uint32_t w = b >> 4, o = b & 15;
+    const uint64_t hi = ((uint64_t)pk[w] << 32) | pk[w + 1];
+    const uint64_t lo = (uint64_t)pk[w + 2] << 32;
+    const uint64_t x = o ? ((hi << (2 * o)) | (lo >> (64 - 2 * o))) : hi;
+    const uint64_t fw = x >> (64 - 2 * k);
+    const uint64_t rc = revcomp2(fw, k);
     return fw < rc ? fw : rc;
 }
 

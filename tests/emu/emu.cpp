@@ -4,12 +4,16 @@
 // neither contains nor can reach it.  It exists so that the exact kernel
 // bodies of danbing-tk_amd/csrc/dbtk_kernels.h (the code hipcc compiles for
 // gfx950) can be run in this GPU-less container against the oracle before GPU
-// minutes are spent: each GPU thread becomes a ucontext coroutine, a block is
+// minutes are spent: each GPU thread becomes a coroutine (a hand-rolled x86-64 stack switch:
+// glibc's swapcontext makes a sigprocmask system call per switch), a block is
 // scheduled round-robin from barrier to barrier, wave64 collectives (ballot,
 // scans, broadcasts) go through a scratch array, atomics are plain operations.
 // Blocks run one after another, which is one of the schedules the GPU may pick.
 #include <string.h>
-#include <ucontext.h>
+
+#if !defined(__x86_64__)
+#error "the test emulator's coroutine switch is written for x86-64"
+#endif
 
 #include <algorithm>
 #include <functional>
@@ -19,6 +23,32 @@
 #include "../../danbing-tk_amd/csrc/dbtk_kernels.h"
 
 using namespace dbtk;
+
+// emu_switch(&save_sp, load_sp): push the callee-saved registers, park this stack's pointer in *save_sp,
+// continue on the stack whose parked pointer is load_sp.
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch,.-emu_switch
+)");
 
 namespace {
 
@@ -38,6 +68,7 @@ struct EmuX {
     uint32_t bcast(uint32_t v, int src) const;
     uint32_t wave_scan_lastnz(uint32_t v) const;
     uint32_t shfl_up1(uint32_t v) const;
+    template <int P0, int P1, int P2, int P3> uint32_t quad_perm(uint32_t v) const;
     template <int E> void shfl_xor64(const uint64_t (&in)[E], uint64_t (&out)[E], int mask) const;
     void atomic_add(uint64_t* p, uint64_t v) const { *p += v; }
     uint32_t atomic_add(uint32_t* p, uint32_t v) const { uint32_t o = *p; *p += v; return o; }
@@ -55,15 +86,15 @@ struct EmuBlock {
     int nt = 0;
     uint32_t bid = 0, nblocks = 0;
     std::vector<uint64_t> smem;  // 8-byte aligned backing store
-    ucontext_t mainctx;
-    std::vector<ucontext_t> ctx;
+    void* mainsp = nullptr;
+    std::vector<void*> sp;  // parked stack pointer per lane
     std::vector<std::vector<char>> stacks;
     std::vector<char> done;
     std::vector<uint64_t> scratch, vscratch;
     int cur = 0;
     std::function<void(EmuX&)> body;
 
-    void yield() { swapcontext(&ctx[cur], &mainctx); }
+    void yield() { emu_switch(&sp[cur], mainsp); }
 };
 
 thread_local EmuBlock* g_blk = nullptr;
@@ -75,7 +106,8 @@ void lane_entry() {
     b->body(x);
     b->done[t] = 1;
     b->scratch[t] = 0;
-    swapcontext(&b->ctx[t], &b->mainctx);
+    emu_switch(&b->sp[t], b->mainsp);  // never resumed
+    __builtin_trap();
 }
 
 int EmuX::nthreads() const { return b->nt; }
@@ -133,6 +165,14 @@ uint32_t EmuX::shfl_up1(uint32_t v) const {
     b->yield();
     return r;
 }
+template <int P0, int P1, int P2, int P3> uint32_t EmuX::quad_perm(uint32_t v) const {
+    b->scratch[t] = v;
+    b->yield();
+    const int p[4] = {P0, P1, P2, P3};
+    const uint32_t r = (uint32_t)b->scratch[(t & ~3) + p[t & 3]];
+    b->yield();
+    return r;
+}
 uint32_t EmuX::bcast(uint32_t v, int src) const {
     b->scratch[t] = v;
     b->yield();
@@ -147,7 +187,7 @@ void run_grid(uint32_t nblocks, int nt, size_t smem_bytes, std::function<void(Em
     b.nt = nt;
     b.nblocks = nblocks;
     b.body = body;
-    b.ctx.resize(nt);
+    b.sp.resize(nt);
     b.stacks.resize(nt);
     for (auto& s : b.stacks) s.resize(STK);
     b.done.assign(nt, 0);
@@ -160,11 +200,13 @@ void run_grid(uint32_t nblocks, int nt, size_t smem_bytes, std::function<void(Em
         for (int t = 0; t < nt; ++t) {
             b.done[t] = 0;
             b.scratch[t] = 0;
-            getcontext(&b.ctx[t]);
-            b.ctx[t].uc_stack.ss_sp = b.stacks[t].data();
-            b.ctx[t].uc_stack.ss_size = STK;
-            b.ctx[t].uc_link = &b.mainctx;
-            makecontext(&b.ctx[t], lane_entry, 0);
+            // fresh stack: six zeroed callee-saved registers, then lane_entry as the "return address" (16-byte aligned slot,
+            // so that lane_entry starts with the stack alignment of a called function)
+            uintptr_t top = ((uintptr_t)b.stacks[t].data() + STK) & ~(uintptr_t)15;
+            void** slot = (void**)(top - 16);
+            slot[0] = (void*)lane_entry;
+            for (int r = 1; r <= 6; ++r) slot[-r] = nullptr;
+            b.sp[t] = (void*)(slot - 6);
         }
         bool alive = true;
         while (alive) {
@@ -172,7 +214,7 @@ void run_grid(uint32_t nblocks, int nt, size_t smem_bytes, std::function<void(Em
             for (int t = 0; t < nt; ++t) {
                 if (b.done[t]) continue;
                 b.cur = t;
-                swapcontext(&b.mainctx, &b.ctx[t]);
+                emu_switch(&b.mainsp, b.sp[t]);
                 if (!b.done[t]) alive = true;
             }
         }
@@ -181,7 +223,7 @@ void run_grid(uint32_t nblocks, int nt, size_t smem_bytes, std::function<void(Em
 }
 
 struct EmuTables {
-    std::vector<IdxSlot> idx;
+    std::vector<IdxBucket> idx;
     std::vector<ClsSlot> cls;
     std::vector<uint32_t> vv;
     std::vector<uint16_t> perm;
@@ -199,10 +241,10 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
     auto pow2 = [](uint64_t n) { uint64_t c = 1024; while (c < n) c <<= 1; return c; };
     auto lg = [](uint64_t c) { return 63u - (uint32_t)__builtin_clzll(c); };
     const uint64_t nloci = g->nloci;
-    const uint64_t icap = pow2(2 * g->keys.size() + 2);
-    e->idx.assign(icap, IdxSlot{NAN64, 0});
+    const uint64_t icap = pow2(2 * g->keys.size() + 8), nbkt = icap / 4;
+    e->idx.assign(nbkt, IdxBucket{{NAN64, NAN64, NAN64, NAN64}, {0, 0, 0, 0}});
     {
-        IdxBuildArgs a{e->idx.data(), icap - 1, 64 - lg(icap), g->keys.data(), g->vals.data(), g->keys.size()};
+        IdxBuildArgs a{e->idx.data(), nbkt - 1, 64 - lg(nbkt), g->keys.data(), g->vals.data(), g->keys.size()};
         run_grid(3, 64, 0, [&](EmuX& x) { body_idx_insert(x, a); });
         run_grid(3, 64, 0, [&](EmuX& x) { body_idx_finalize(x, e->idx.data(), icap); });
     }
@@ -226,7 +268,7 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
         for (int n = 1; n <= NHMAX; ++n) gcc_sort_index(e->perm.data() + (size_t)n * (n - 1) / 2, n, key.data(), stack);
     }
     DevTables& T = e->T;
-    T.idx = e->idx.data(); T.idx_mask = icap - 1; T.idx_shift = 64 - lg(icap);
+    T.idx = e->idx.data(); T.idx_mask = nbkt - 1; T.idx_shift = 64 - lg(nbkt);
     T.vv = e->vv.data();
     T.cls = e->cls.data(); T.cls_mask = ccap - 1; T.cls_shift = 64 - lg(ccap);
     T.qc = g->qc.empty() ? nullptr : g->qc.data();
