@@ -43,28 +43,37 @@ DBTK_HD Bits256 b_shl(const Bits256& a, int d) {  // bit i -> bit i + d
 DBTK_HD int b_popc(const Bits256& a) {
     return __builtin_popcountll(a.w[0]) + __builtin_popcountll(a.w[1]) + __builtin_popcountll(a.w[2]) + __builtin_popcountll(a.w[3]);
 }
-DBTK_HD bool b_test(const Bits256& a, int i) { return (a.w[i >> 6] >> (i & 63)) & 1; }
+// word i of a, selected without indexing the array by a run-time value (that would move it from registers to scratch memory)
+DBTK_HD uint64_t b_word(const Bits256& a, int i) { return i == 0 ? a.w[0] : (i == 1 ? a.w[1] : (i == 2 ? a.w[2] : a.w[3])); }
+DBTK_HD bool b_test(const Bits256& a, int i) { return (b_word(a, i >> 6) >> (i & 63)) & 1; }
 DBTK_HD int b_first(const Bits256& a) {  // lowest set bit, 256 if none
+    int r = 256;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (a.w[i]) return 64 * i + __builtin_ctzll(a.w[i]);
-    return 256;
+    for (int i = 3; i >= 0; --i)
+        if (a.w[i]) r = 64 * i + __builtin_ctzll(a.w[i]);
+    return r;
 }
 DBTK_HD int b_last_below(const Bits256& a, int n) {  // highest set bit < n, -1 if none
-    for (int i = 3; i >= 0; --i) {
+    int r = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
         uint64_t v = a.w[i];
         const int lo = 64 * i;
-        if (n <= lo) continue;
-        if (n < lo + 64) v &= (1ull << (n - lo)) - 1;
-        if (v) return lo + 63 - __builtin_clzll(v);
+        if (n <= lo) v = 0;
+        else if (n < lo + 64) v &= (1ull << (n - lo)) - 1;
+        if (v) r = lo + 63 - __builtin_clzll(v);
     }
-    return -1;
+    return r;
 }
 DBTK_HD Bits256 b_clear_lowest(const Bits256& a) {
     Bits256 r = a;
+    bool done = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (r.w[i]) { r.w[i] &= r.w[i] - 1; return r; }
+    for (int i = 0; i < 4; ++i) {
+        const bool here = !done && r.w[i] != 0;
+        if (here) r.w[i] &= r.w[i] - 1;
+        done = done || here;
+    }
     return r;
 }
 
@@ -86,6 +95,24 @@ DBTK_HD Bits256 transitions_from_masks(const Bits256& K, const Bits256& R) {
     Bits256 T;
 #pragma unroll
     for (int i = 0; i < 4; ++i) T.w[i] = K.w[i] & pm.w[i] & (R.w[i] ^ pv.w[i]);
+    return T;
+}
+
+// The same on one 64-position word with a carry from the words before it (carry: 0 = no known
+// position so far, 1 = the last one is flank, 2 = TR).  K and R are wave ballots, so all of this
+// is scalar-unit work: six fill steps instead of a cross-lane scan.
+DBTK_HD uint64_t transitions_word(uint64_t K, uint64_t R, uint32_t& carry) {
+    uint64_t Fv = R, Fm = K;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Fv |= (Fv << d) & ~Fm;
+        Fm |= Fm << d;
+    }
+    const uint64_t cv = carry == 2 ? ~0ull : 0ull, cm = carry ? ~0ull : 0ull;
+    Fv |= ~Fm & cv;
+    Fm |= cm;
+    const uint64_t T = K & ((Fm << 1) | (cm & 1)) & (R ^ ((Fv << 1) | (cv & 1)));
+    if (Fm >> 63) carry = (Fv >> 63) ? 2u : 1u;
     return T;
 }
 

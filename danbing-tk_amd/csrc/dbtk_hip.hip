@@ -113,6 +113,11 @@ template <int NS> __global__ void __launch_bounds__(64) k_probe(BatchArgs a) {
     DevX x{&sm};
     body_probe<NS>(x, a);
 }
+template <int NS, bool RECS> __global__ void __launch_bounds__(64) k_pair_usual(BatchArgs a) {
+    __shared__ UsualSmem sm;
+    DevX x{&sm};
+    body_pair_usual<NS, RECS>(x, a);
+}
 template <int NS, bool RECS> __global__ void __launch_bounds__(64) k_pair(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) PairSmemT<NS> sm;
     DevX x{&sm};
@@ -133,7 +138,7 @@ namespace {
 // Per-kernel timing: a pool of HIP event pairs recorded on the context's stream
 // around every launch; folded into (total ms, launches) when the pool fills or
 // when the caller asks.
-constexpr int NKERN = 3;       // k_encode_subfilter, k_probe, k_pair
+constexpr int NKERN = 4;       // k_encode_subfilter, k_probe, k_pair_usual, k_pair
 constexpr int EVPOOL = 128;    // launches in flight before a fold
 struct Timed {
     const char* name;
@@ -152,6 +157,7 @@ struct dbtk_ctx {
     DevTables T;
     // device allocations
     IdxBucket* d_idx = nullptr;
+    uint32_t* d_trbeg = nullptr;
     ClsSlot* d_cls = nullptr;
     uint32_t* d_vv = nullptr;
     uint8_t* d_qc = nullptr;
@@ -163,7 +169,10 @@ struct dbtk_ctx {
     uint8_t* d_seq = nullptr; uint64_t seq_cap = 0;
     uint64_t* d_off = nullptr; uint64_t off_cap = 0;
     dbtk_pair_rec_t* d_recs = nullptr; uint64_t rec_cap = 0;
-    HitEnt* d_hit = nullptr; uint64_t hit_cap = 0;
+    uint64_t* d_hitkm = nullptr; uint64_t hitkm_cap = 0;   // K2 -> K3 (see BatchArgs)
+    HitVA* d_hitva = nullptr; uint64_t hitva_cap = 0;
+    uint32_t* d_hitnk = nullptr; uint64_t hitnk_cap = 0;
+    uint32_t* d_gen = nullptr; uint64_t gen_cap = 0;        // K3a -> K3b
     uint32_t* d_tickets = nullptr; uint64_t tickets_cap = 0;
     // optional gates
     ClsSlot* d_tre = nullptr; ClsSlot* d_bait = nullptr;
@@ -179,7 +188,7 @@ struct dbtk_ctx {
     bool timers_on = true;
     uint64_t* d_vote = nullptr;
     uint32_t* d_epoch = nullptr;
-    int pair_blocks[3] = {0, 0, 0}, num_cu = 0, max_pair_blocks = 0;
+    int pair_blocks[3] = {0, 0, 0}, usual_blocks[3] = {0, 0, 0}, num_cu = 0, max_pair_blocks = 0;
     uint32_t consistent = 0;
     Timed timed[NKERN];
 };
@@ -201,8 +210,8 @@ void free_ctx(dbtk_ctx* c) {
             if (c->timed[i].beg[j]) (void)hipEventDestroy(c->timed[i].beg[j]);
             if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
         }
-    void* ptrs[] = {c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
-                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hit, c->d_tickets,
+    void* ptrs[] = {c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
+                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_gen, c->d_tickets,
                     c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -289,7 +298,15 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         HIPCHK(hipMemcpyAsync(c->d_perm, perm.data(), perm.size() * 2, hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
     }
+    {   // first output slot of each locus
+        std::vector<uint32_t> tb(nloci + 1, 0);
+        for (uint64_t l = 0; l <= nloci; ++l) tb[l] = (uint32_t)g->out_beg[l];
+        HIPCHK(hipMalloc(&c->d_trbeg, (nloci + 1) * 4));
+        HIPCHK(hipMemcpyAsync(c->d_trbeg, tb.data(), (nloci + 1) * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
     DevTables& T = c->T;
+    T.trbeg = c->d_trbeg;
     T.idx = c->d_idx; T.idx_mask = nbkt - 1; T.idx_shift = 64 - log2u(nbkt);
     T.vv = c->d_vv;
     T.cls = c->d_cls; T.cls_mask = ccap - 1; T.cls_shift = 64 - log2u(ccap);
@@ -390,10 +407,13 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     const uint64_t nchunks = (npairs + tcap - 1) / tcap;
     dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, npairs + 1);
     if (st) return st;
-    if ((st = ensure(&c->d_hit, &c->hit_cap, tcap * 2 * nkp))) return st;
-    if ((st = ensure(&c->d_tickets, &c->tickets_cap, nchunks + 1))) return st;
+    if ((st = ensure(&c->d_hitkm, &c->hitkm_cap, tcap * 2 * nkp))) return st;
+    if ((st = ensure(&c->d_hitva, &c->hitva_cap, tcap * 2 * nkp))) return st;
+    if ((st = ensure(&c->d_hitnk, &c->hitnk_cap, tcap * 2))) return st;
+    if ((st = ensure(&c->d_gen, &c->gen_cap, tcap))) return st;
+    if ((st = ensure(&c->d_tickets, &c->tickets_cap, 2 * (nchunks + 1)))) return st;  // per chunk: a ticket counter and a passed-on counter
     HIPCHK(hipMemsetAsync(c->d_small, 0, 8 * sizeof(uint32_t), s));
-    HIPCHK(hipMemsetAsync(c->d_tickets, 0, (nchunks + 1) * sizeof(uint32_t), s));
+    HIPCHK(hipMemsetAsync(c->d_tickets, 0, 2 * (nchunks + 1) * sizeof(uint32_t), s));
     if (c->P.bubbles) {
         if ((st = ensure(&c->d_edge, &c->edge_cap, tcap * 2 * nkp))) return st;
         // every position of every kept mate could be novel; bounded so that the log stays < 6.4 GB
@@ -413,7 +433,10 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     a.counters = a.nmapread + c->g->nloci;
     a.recs = d_recs; a.rec_cap = rec_cap;
     a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
-    a.hitbuf = c->d_hit; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
+    a.hitkm = c->d_hitkm; a.hitva = c->d_hitva; a.hitnk = c->d_hitnk; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
+    // the usual-pair kernel takes the pairs it can finish and passes the rest on; it needs the class of a k-mer next to its
+    // index value (consistent RPGG) and does not do the trace, bait or bubble work
+    const bool usual = c->T.consistent && !c->P.trace && !c->P.bait && !c->P.bubbles;
     if (c->P.bubbles) { a.edgebuf = c->d_edge; a.events = c->d_events; a.nevents = c->d_nevents; a.events_cap = (uint32_t)std::min<uint64_t>(c->events_cap, 0xFFFFFFFFull); }
     if (c->P.bait && d_qual) { a.qual = d_qual; a.qmaskbuf = c->d_qmask; }
 #ifdef DBTK_STAMPS
@@ -435,9 +458,26 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             case 3: hipLaunchKernelGGL(k_probe<3>, dim3(c->num_cu * 32), dim3(64), 0, s, a); break;
             default: hipLaunchKernelGGL(k_probe<4>, dim3(c->num_cu * 32), dim3(64), 0, s, a); break;
         }
-        if (tm) { HIPCHK(hipEventRecord(c->timed[1].end[e], s)); if ((st = timed_slot(c, 2, &e))) return st; HIPCHK(hipEventRecord(c->timed[2].beg[e], s)); }
+        if (tm) HIPCHK(hipEventRecord(c->timed[1].end[e], s));
         // RECS = false: no record buffer (-ka without -e): record emission is compiled out
         const int nsi = ns <= 2 ? 0 : (ns == 3 ? 1 : 2);
+        a.gen_list = nullptr; a.ngen = nullptr;
+        if (usual) {
+            a.gen_list = c->d_gen; a.ngen = c->d_tickets + (nchunks + 1) + ch;
+            const dim3 gu(c->usual_blocks[nsi]);
+            if (tm) { if ((st = timed_slot(c, 2, &e))) return st; HIPCHK(hipEventRecord(c->timed[2].beg[e], s)); }
+            if (d_recs) {
+                if (nsi == 0) hipLaunchKernelGGL((k_pair_usual<2, true>), gu, dim3(64), 0, s, a);
+                else if (nsi == 1) hipLaunchKernelGGL((k_pair_usual<3, true>), gu, dim3(64), 0, s, a);
+                else hipLaunchKernelGGL((k_pair_usual<4, true>), gu, dim3(64), 0, s, a);
+            } else {
+                if (nsi == 0) hipLaunchKernelGGL((k_pair_usual<2, false>), gu, dim3(64), 0, s, a);
+                else if (nsi == 1) hipLaunchKernelGGL((k_pair_usual<3, false>), gu, dim3(64), 0, s, a);
+                else hipLaunchKernelGGL((k_pair_usual<4, false>), gu, dim3(64), 0, s, a);
+            }
+            if (tm) HIPCHK(hipEventRecord(c->timed[2].end[e], s));
+        }
+        if (tm) { if ((st = timed_slot(c, 3, &e))) return st; HIPCHK(hipEventRecord(c->timed[3].beg[e], s)); }
         const dim3 gp(c->pair_blocks[nsi]);
         if (d_recs) {
             if (nsi == 0) hipLaunchKernelGGL((k_pair<2, true>), gp, dim3(64), 0, s, a);
@@ -448,7 +488,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             else if (nsi == 1) hipLaunchKernelGGL((k_pair<3, false>), gp, dim3(64), 0, s, a);
             else hipLaunchKernelGGL((k_pair<4, false>), gp, dim3(64), 0, s, a);
         }
-        if (tm) HIPCHK(hipEventRecord(c->timed[2].end[e], s));
+        if (tm) HIPCHK(hipEventRecord(c->timed[3].end[e], s));
     }
     HIPCHK(hipGetLastError());
     return DBTK_OK;
@@ -491,6 +531,10 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kp[i], 64, 0) != hipSuccess || nb <= 0) nb = 8;
             c->pair_blocks[i] = c->num_cu * nb;
             c->max_pair_blocks = std::max(c->max_pair_blocks, c->pair_blocks[i]);
+            const void* ku[3] = {(const void*)k_pair_usual<2, true>, (const void*)k_pair_usual<3, true>, (const void*)k_pair_usual<4, true>};
+            nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ku[i], 64, 0) != hipSuccess || nb <= 0) nb = 16;
+            c->usual_blocks[i] = c->num_cu * nb;
         }
     }
     dbtk_status_t st = DBTK_OK;
@@ -498,7 +542,8 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); st = DBTK_ERR_HIP; break; }
         c->timed[0].name = "k_encode_subfilter";
         c->timed[1].name = "k_probe";
-        c->timed[2].name = "k_pair";
+        c->timed[2].name = "k_pair_usual";
+        c->timed[3].name = "k_pair";
         for (int i = 0; i < NKERN && !st; ++i)
             for (int j = 0; j < EVPOOL && !st; ++j)
                 if (hipEventCreate(&c->timed[i].beg[j]) != hipSuccess || hipEventCreate(&c->timed[i].end[j]) != hipSuccess) { set_error("hipEventCreate failed"); st = DBTK_ERR_HIP; }
@@ -518,8 +563,8 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         c->n_accum = c->ntr + 2 * h->nloci + DBTK_C_COUNT;
         auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && !st) { set_error(std::string(what) + ": " + hipGetErrorString(e)); st = DBTK_ERR_HIP; } };
         chk(hipMalloc(&c->d_accum, c->n_accum * 8), "hipMalloc accum");
-        chk(hipMalloc(&c->d_small, 4 * SMALL_WORDS + 32 * 8), "hipMalloc small");
-        if (!st) chk(hipMemsetAsync(c->d_small, 0, 4 * SMALL_WORDS + 32 * 8, c->stream), "memset");
+        chk(hipMalloc(&c->d_small, 4 * SMALL_WORDS + 48 * 8), "hipMalloc small");
+        if (!st) chk(hipMemsetAsync(c->d_small, 0, 4 * SMALL_WORDS + 48 * 8, c->stream), "memset");
         chk(hipMalloc(&c->d_vote, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8), "hipMalloc vote scratch");
         chk(hipMalloc(&c->d_epoch, (size_t)c->max_pair_blocks * 4), "hipMalloc epoch");
         if (st) break;
@@ -722,7 +767,7 @@ int dbtk_ctx_kernel_times(dbtk_ctx_t* c, const char** names, double* total_ms, u
 int dbtk_debug_stamps(dbtk_ctx_t* c, uint64_t* out16) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    return (int)hipMemcpy(out16, c->d_small + 32, 32 * 8, hipMemcpyDeviceToHost);
+    return (int)hipMemcpy(out16, c->d_small + 32, 48 * 8, hipMemcpyDeviceToHost);
 }
 #endif
 

@@ -164,8 +164,14 @@ struct BatchArgs {
     uint64_t* vote_scratch;  // per block: nloci+1 stamped hit words (see vote)
     uint32_t* vote_epoch;    // per block
     uint64_t* dbg;           // diagnostic build only (-DDBTK_STAMPS): per-phase cycle sums of k_pair
-    struct HitEnt* hitbuf;   // K2 -> K3: [survivor][mate][nkp] probe results
-    uint32_t nkp;            // positions reserved per read in hitbuf (multiple of 64)
+    // K2 -> K3, per (survivor, mate) row of nkp positions: the canonical k-mers, the index results (val, aux), and
+    // per row the number of positions.  Split so that the usual-pair kernel reads 8 bytes per position, not 16.
+    uint64_t* hitkm;
+    struct HitVA* hitva;
+    uint32_t* hitnk;         // [2 * tcap]
+    uint32_t nkp;            // positions reserved per read in the hit buffers (multiple of 64)
+    uint32_t* gen_list;      // K3a -> K3b: survivors (t) that need the general resolve kernel; nullptr: K3b takes every survivor
+    uint32_t* ngen;
     uint32_t pair_base;      // index of this sub-batch's first pair inside the caller's batch (records)
     const uint8_t* qual;     // base qualities (same offsets as seq), nullptr for FASTA; only read when P.bait
     uint64_t* edgebuf;       // -bu: K2 -> K3 canonical (k+1)-mers [survivor][mate][nkp]
@@ -180,9 +186,9 @@ struct BatchArgs {
 // In-kernel stamps (cdna_hip_programming.md 7): only in the separate diagnostic
 // library built with -DDBTK_STAMPS; the product build compiles them away.
 #ifdef DBTK_STAMPS
-#define DBTK_STAMP_DECL uint64_t st_acc[32] = {0}; uint64_t st_last = x.clock();
+#define DBTK_STAMP_DECL uint64_t st_acc[48] = {0}; uint64_t st_last = x.clock();
 #define DBTK_STAMP(i) do { const uint64_t now_ = x.clock(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
-#define DBTK_STAMP_FLUSH do { if (lane == 0 && a.dbg) for (int i_ = 0; i_ < 32; ++i_) if (st_acc[i_]) x.atomic_add(&a.dbg[i_], st_acc[i_]); } while (0)
+#define DBTK_STAMP_FLUSH do { if (lane == 0 && a.dbg) for (int i_ = 0; i_ < 48; ++i_) if (st_acc[i_]) x.atomic_add(&a.dbg[i_], st_acc[i_]); } while (0)
 #else
 #define DBTK_STAMP_DECL
 #define DBTK_STAMP(i) do { } while (0)
@@ -761,7 +767,10 @@ DBTK_HD uint32_t vote_single_locus(X& x, const uint16_t* perm_row, const uint32_
 struct HitEnt {
     uint64_t km;   // canonical k-mer at the position, NAN64 = window with a non-ACGT base
     uint32_t val;  // index val, NOHIT when the k-mer is not in the index
-    uint32_t aux;  // class of a single-locus k-mer at its locus (see IdxSlot)
+    uint32_t aux;  // class of a single-locus k-mer at its locus (see IdxBucket)
+};
+struct HitVA {     // the (val, aux) half, stored apart from the k-mers
+    uint32_t val, aux;
 };
 struct BubEvent {  // one novel read (k+1)-mer (countNovelEdges, AQ.cpp:1559-1567)
     uint32_t pair, mate, pos, locus;
@@ -882,7 +891,9 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             if ((uint32_t)s < nsl && i < nk) { sm.km[i] = km[s]; sm.hb[i] = open[s] ? (uint32_t)hh[s] : 0u; }
         }
         x.sync();
-        HitEnt* out = a.hitbuf + (size_t)it * a.nkp;
+        uint64_t* outk = a.hitkm + (size_t)it * a.nkp;
+        HitVA* outv = a.hitva + (size_t)it * a.nkp;
+        if (lane == 0) a.hitnk[it] = nk;
         const uint32_t sub = lane & 3, qd = lane >> 2;
         constexpr int NB = 4;  // buckets in flight per lane
         for (uint32_t i0 = 0; i0 < nk; i0 += 16 * NB) {
@@ -913,8 +924,8 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                     open1 = open1 && !qhit && ((amask >> ((lane & ~3u) + 1)) & 1);
                     if (x.ballot(open1) == 0) {
                         if (ii[u] < nk) {
-                            if (hitl) out[ii[u]] = HitEnt{kq[u], (uint32_t)myval, (uint32_t)(myval >> 32)};
-                            else if (sub == 0 && !qhit) out[ii[u]] = HitEnt{kq[u], NOHIT, 0};
+                            if (hitl) { outk[ii[u]] = kq[u]; outv[ii[u]] = HitVA{(uint32_t)myval, (uint32_t)(myval >> 32)}; }
+                            else if (sub == 0 && !qhit) { outk[ii[u]] = kq[u]; outv[ii[u]] = HitVA{NOHIT, 0}; }
                         }
                         break;
                     }
@@ -946,7 +957,278 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
     }
 }
 
-// ======================================================================= K3 =
+// ---- one pair's record (kam: AQ.cpp:2169-2175; trace: every pair).  Trace records are indexed by pair, the others compacted.
+template <class X>
+DBTK_HD void emit_pair_record(X& x, const BatchArgs& a, int lane, uint32_t pair, uint32_t stage, uint32_t dst, uint32_t dst0, int nm1,
+                              int nm2, const MateState (&ms)[2], const int (&kf)[2], const int (&hf)[2], const int (&bf)[2],
+                              const int (&af)[2], const int (&rm)[2], const uint32_t (&nas)[2], const uint64_t (&Kw)[2][4],
+                              const uint64_t (&Rw)[2][4]) {
+    uint32_t at = pair;
+    if (!a.P.trace) {
+        if (lane == 0) at = x.atomic_add(a.nrec, 1u);
+        at = x.bcast(at, 0);
+    }
+    if (at >= a.rec_cap) return;
+    dbtk_pair_rec_t* r = &a.recs[at];
+    if (lane == 0) {
+        r->pair = pair; r->stage = stage; r->dst = dst; r->dst0 = dst0;
+        r->nm1 = a.P.trace ? nm1 : 0; r->nm2 = a.P.trace ? nm2 : 0;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        dbtk_mate_rec_t* mr = m ? &r->r2 : &r->r1;
+        if (lane == 0) {
+            const MateState& st = ms[m];
+            mr->si = (int16_t)st.si; mr->ei = (int16_t)st.ei; mr->si_ = (int16_t)st.si_; mr->ei_ = (int16_t)st.ei_;
+            mr->nt = (int16_t)st.nt; mr->bs = (int16_t)st.bs; mr->ti = (int16_t)st.ti;
+            mr->kf = (uint8_t)kf[m]; mr->hf = (uint8_t)hf[m]; mr->bf = (uint8_t)bf[m]; mr->qf = 0;
+            mr->af = (uint8_t)af[m]; mr->rm = (uint8_t)rm[m];
+            mr->nk = (uint16_t)nas[m];
+        }
+        // as2 byte `lane` = states of positions 4*lane .. 4*lane+3 (0 '*', 1 '.', 2 '=')
+        const int wq = lane >> 4, sh = 4 * (lane & 15);
+        uint64_t kq = Kw[m][0], rq = Rw[m][0];
+        if (wq == 1) { kq = Kw[m][1]; rq = Rw[m][1]; }
+        if (wq == 2) { kq = Kw[m][2]; rq = Rw[m][2]; }
+        if (wq == 3) { kq = Kw[m][3]; rq = Rw[m][3]; }
+        const uint32_t k4 = (uint32_t)(kq >> sh) & 0xF, r4 = (uint32_t)(rq >> sh) & 0xF;
+        uint8_t b = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t st = ((k4 >> q) & 1) + ((r4 >> q) & 1);  // known: 1, known and TR: 2
+            if ((uint32_t)(4 * lane + q) < nas[m]) b |= (uint8_t)(st << (2 * q));
+        }
+        mr->as2[lane] = b;
+    }
+}
+
+// ====================================================================== K3a =
+// The usual pair: both mates pass kfilter, every k-mer found in the index is unique to ONE and the same locus, and
+// each mate has at least cth found positions.  Then countHit needs no sorting and no vote: with a single candidate
+// locus `second` stays empty and top.(fc, rc) are prefix sums of the per-k-mer dups in vote order; find_matching_locus
+// keeps adding while a strand is below cth and can still reach it (get_acm1, AQ.cpp:354-357), which with totals
+// D1, D2 >= cth (D = the mate's found positions = the sum of its dups) can only end with fc >= cth and rc >= cth —
+// accepted by test1 (AQ.cpp:439-451) whatever the order was.  What is left is a streaming pass: 8 bytes per position
+// from the probe kernel, ballots, the scalar state machine, the count atomics.  No LDS staging, few registers, so many
+// waves per SIMD; pairs are taken at a fixed stride (the work per pair is uniform) with the next pair's loads in flight.
+// Any other pair is passed on to the general resolve kernel untouched.  Needs: consistent RPGG (the class of a k-mer
+// rides with its index value), no trace, no -b, no -bu — otherwise the host does not launch it.
+constexpr uint32_t HWIN = 2048;  // counters of the pair's locus staged in LDS (loci with more TR k-mers: the rest goes straight to HBM)
+struct UsualSmem {
+    uint32_t gbuf[64];         // passed-on survivors not yet appended to gen_list
+    uint32_t hist[HWIN / 2];   // two 16-bit increments per word (a pair adds < 2^16 to any counter)
+};
+
+template <int NS, bool RECS, class X>
+DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
+    constexpr int NSLOT = NS;
+    UsualSmem& sm = *x.template smem<UsualSmem>();
+    const int lane = x.lane();
+    const DevTables& T = a.T;
+    const uint32_t cth = a.P.cthreshold, nloci = T.nloci;
+    const bool okam = a.P.okam != 0;
+    uint64_t c_qc = 0, c_thr = 0, c_feas = 0, c_asgn = 0, c_cls = 0, c_inc = 0, c_nhash1 = 0;
+    const uint32_t nsurv = *a.nsurv;
+    const uint64_t tlim64 = (uint64_t)a.t0 + a.tcap;
+    const uint32_t tlim = nsurv < tlim64 ? nsurv : (uint32_t)tlim64;
+    const uint32_t nslp = a.nkp >> 6;
+    const uint32_t stride = x.nblocks();
+    uint32_t ngb = 0;
+    auto flush_gen = [&]() {
+        x.sync();
+        uint32_t base = 0;
+        if (lane == 0) base = x.atomic_add(a.ngen, ngb);
+        base = x.bcast(base, 0);
+        if ((uint32_t)lane < ngb) a.gen_list[base + lane] = sm.gbuf[lane];
+        x.sync();
+        ngb = 0;
+    };
+    HitVA nx[2][NSLOT];
+    uint32_t nxnk[2] = {0, 0}, nxpair = 0;
+    auto request = [&](uint32_t tt) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                nx[m][s] = HitVA{NOHIT, 0};
+                if ((uint32_t)s < nslp) nx[m][s] = a.hitva[((size_t)2 * (tt - a.t0) + m) * a.nkp + 64 * s + lane];
+            }
+            nxnk[m] = a.hitnk[2 * (tt - a.t0) + m];
+        }
+        nxpair = a.surv[tt];
+    };
+    // The loop is arranged around one hardware fact: vector-memory operations complete in issue order, so waiting for
+    // a load also waits for every atomic issued before it, and a counter atomic is a slow read-modify-write at the
+    // memory side.  Hence: the next pair's loads are issued at the top of an iteration and taken delivery of (into
+    // registers) just BEFORE this pair's atomics and record stores go out; those then have a whole iteration to finish.
+    uint32_t pair = 0, nkm[2] = {0, 0}, nsl = 0;
+    uint32_t hv[2][NSLOT], ha[2][NSLOT];
+    auto deliver = [&]() {
+        pair = x.uni(nxpair) + a.pair_base;
+        nkm[0] = x.uni(nxnk[0]); nkm[1] = x.uni(nxnk[1]);
+        nsl = ((nkm[0] > nkm[1] ? nkm[0] : nkm[1]) + 63) >> 6;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                const uint32_t i = 64 * s + lane;
+                const bool in = (uint32_t)s < nsl && i < nkm[m];
+                hv[m][s] = in ? nx[m][s].val : NOHIT;
+                ha[m][s] = in ? nx[m][s].aux : 0u;
+            }
+    };
+    DBTK_STAMP_DECL
+    uint32_t t = a.t0 + x.bid();
+    if (t < tlim) { request(t); deliver(); }
+    for (; t < tlim; t += stride) {
+        DBTK_STAMP(39);  // loop overhead / record of the previous pair
+        request(t + stride < tlim ? t + stride : t);  // (past the end: a harmless reload, so that the loads stay straight-line)
+        const uint32_t pair_cur = pair;
+        // kfilter (AQ.cpp:190-228) aborts a mate at its (nk - cth + 1)-th miss, i.e. iff it has fewer than cth found positions
+        uint32_t nhit[2] = {0, 0}, v0 = NOHIT;
+        bool vdiff = false;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                if ((uint32_t)s >= nsl) continue;
+                const bool hit = hv[m][s] != NOHIT;
+                const uint64_t hmk = x.ballot(hit);
+                nhit[m] += (uint32_t)__builtin_popcountll(hmk);
+                if (v0 == NOHIT && hmk) v0 = x.bcast(hv[m][s], (int)__builtin_ctzll(hmk));
+                vdiff |= hit && hv[m][s] != v0;
+            }
+        const bool usual = nkm[0] >= cth && nkm[1] >= cth && nhit[0] >= cth && nhit[1] >= cth && nhit[0] && nhit[1] && !(v0 & 1) &&
+                           x.ballot(vdiff) == 0;
+        DBTK_STAMP(32);  // request + usual test
+        uint32_t dst0 = NAN32, dst = nloci, stage = DBTK_STAGE_LOCUS;
+        MateState ms[2];
+        for (int m = 0; m < 2; ++m) ms[m] = MateState{-1, -1, 0, 0, -1, -1, -1, 0, 0};
+        uint32_t nas[2] = {0, 0};
+        uint64_t Kw[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, Rw[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        int kf[2] = {0, 0}, hf[2] = {0, 0}, bf[2] = {0, 0}, af[2] = {0, 0}, rm[2] = {0, 0};
+        uint32_t base = 0, win = 0;
+        if (usual) {
+            c_nhash1 += nkm[0] + nkm[1];  // kfilter ran over both mates in full
+            dst0 = v0 >> 1;
+            dst = dst0;
+            const uint32_t trb0 = T.trbeg[dst0], trb1 = T.trbeg[dst0 + 1];  // the locus' counter range
+            if (a.P.qc && T.qc && !T.qc[dst]) {  // AQ.cpp:2059-2062
+                c_qc += 2;
+                stage = DBTK_STAGE_QC;
+            } else if (a.P.threading) {  // AQ.cpp:2070-2090: `alned` stays false at HEAD, nothing else happens
+                c_thr += 2;
+            } else if (a.P.extract) {  // AQ.cpp:2094-2099
+                c_thr += 2; c_feas += 2;
+                stage = DBTK_STAGE_EXTRACT;
+            } else {
+                c_thr += 2; c_feas += 2;
+                // assignTRkmc (AQ.cpp:2138-2144): the class of a found k-mer at the one locus rides with its index value
+                uint32_t ntr[2] = {0, 0};
+                uint64_t Tw[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    nas[m] = nkm[m];
+                    c_cls += nkm[m];
+                    uint32_t mytr = 0, carry = 0;
+#pragma unroll
+                    for (int s = 0; s < NSLOT; ++s) {
+                        if ((uint32_t)s >= nsl) continue;
+                        const uint32_t c = hv[m][s] != NOHIT ? ha[m][s] : CLS_NONE;
+                        const uint64_t kb = x.ballot(c != CLS_NONE), rb = x.ballot(c != CLS_NONE && c != CLS_FLANK);
+                        Kw[m][s] = kb; Rw[m][s] = rb;
+                        mytr += (uint32_t)__builtin_popcountll(rb);
+                        Tw[m][s] = transitions_word(kb, rb, carry);
+                    }
+                    ntr[m] = mytr & 0xFF;  // uint8_t ntr, AQ.cpp:1454
+                }
+                DBTK_STAMP(33);  // states
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    Bits256 K, R, Tm;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { K.w[q] = Kw[m][q]; R.w[q] = Rw[m][q]; Tm.w[q] = Tw[m][q]; }
+                    assign_masks(K, R, Tm, (int)nas[m], ntr[m], a.P, ms[m]);
+                    af[m] = ms[m].af; rm[m] = ms[m].rm;
+                }
+                DBTK_STAMP(34);  // assign
+                // accumulate (AQ.cpp:2145-2158)
+                if (rm[0] && rm[1]) { dst = nloci; stage = DBTK_STAGE_ASGN; }
+                else {
+                    stage = DBTK_STAGE_COUNTED;
+                    c_asgn += (uint64_t)(2 - rm[0] - rm[1]);
+                    // The increments of one pair all fall in its locus' contiguous counter range, but scattered over it
+                    // (slot order is a hash order) and often repeated (tandem repeats).  A random 8-byte atomic costs a
+                    // 64-byte read-modify-write at the memory side (~24 G/s chip-wide, tools/atomics.hip), so the pair's
+                    // increments are first summed in an LDS window over the range and then flushed with lanes on
+                    // consecutive counters: one transaction per touched 64-byte line instead of one per k-mer.
+                    base = x.uni(trb0);
+                    win = x.uni(trb1) - base < HWIN ? x.uni(trb1) - base : HWIN;
+                    for (uint32_t w = lane; w < (win + 1) / 2; w += 64) sm.hist[w] = 0;
+                    x.sync();
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        if (rm[m]) continue;
+#pragma unroll
+                        for (int s = 0; s < NSLOT; ++s) {
+                            if ((uint32_t)s >= nsl) continue;
+                            const uint32_t c = hv[m][s] != NOHIT ? ha[m][s] : CLS_NONE;
+                            if (c != CLS_NONE && c != CLS_FLANK) {
+                                const uint32_t o = c - base;
+                                if (o < win) x.lds_add(&sm.hist[o >> 1], 1u << (16 * (o & 1)));
+                                else x.atomic_add(&a.counts[c], 1ull);
+                            }
+                            c_inc += (uint64_t)__builtin_popcountll(Rw[m][s]);
+                        }
+                    }
+                    x.sync();
+                }
+            }
+        }
+        DBTK_STAMP(35);  // LDS histogram
+        deliver();  // the next pair's probe results, before anything of this pair goes out to memory
+        DBTK_STAMP(36);  // delivery of the next pair
+        if (!usual) {  // the general kernel redoes this pair from its probe results
+            if (lane == 0) sm.gbuf[ngb] = t;
+            if (++ngb == 64) flush_gen();
+            continue;
+        }
+        if (stage == DBTK_STAGE_COUNTED) {
+            if (lane == 0) {
+                x.atomic_add(&a.nmapread[dst], (uint64_t)(2 - rm[0] - rm[1]));
+                x.atomic_add(&a.kmc[dst], (uint64_t)(int64_t)((ms[0].ei - ms[0].si) + (ms[1].ei - ms[1].si)));
+            }
+#ifdef DBTK_STAMPS
+            if (a.P.reserved[0] & 4) win = 0;  // diagnostic: no count atomics
+#endif
+            for (uint32_t i = lane; i < win; i += 64) {
+                const uint32_t v = (sm.hist[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                if (v) x.atomic_add(&a.counts[base + i], (uint64_t)v);
+            }
+            x.sync();
+        }
+        DBTK_STAMP(37);  // count atomics
+        const bool want = RECS && a.recs && ((okam && stage == DBTK_STAGE_COUNTED) || (okam && a.P.simmode && stage == DBTK_STAGE_ASGN) ||
+                                             (a.P.extract && stage == DBTK_STAGE_EXTRACT));
+        if (want) emit_pair_record(x, a, lane, pair_cur, stage, dst, dst0, 0, 0, ms, kf, hf, bf, af, rm, nas, Kw, Rw);
+    }
+    if (ngb) flush_gen();
+    DBTK_STAMP_FLUSH;
+    if (lane == 0) {
+        if (c_qc) x.atomic_add(&a.counters[DBTK_C_QCFILTERED], c_qc);
+        if (c_thr) x.atomic_add(&a.counters[DBTK_C_THREADING], c_thr);
+        if (c_feas) x.atomic_add(&a.counters[DBTK_C_FEASIBLE], c_feas);
+        if (c_asgn) x.atomic_add(&a.counters[DBTK_C_ASGN], c_asgn);
+        if (c_cls) x.atomic_add(&a.counters[DBTK_C_ALGO_CLS], c_cls);
+        if (c_inc) x.atomic_add(&a.counters[DBTK_C_ALGO_INC], c_inc);
+        if (c_nhash1) {
+            x.atomic_add(&a.counters[DBTK_C_NHASH1], c_nhash1);
+            x.atomic_add(&a.counters[DBTK_C_ALGO_PROBES], c_nhash1);
+        }
+    }
+}
+
+// ====================================================================== K3b =
 template <int NS, bool RECS, class X>
 DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     typedef PairSmemT<NS> Smem;
@@ -961,39 +1243,51 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     uint64_t c_kf = 0, c_hf = 0, c_qc = 0, c_thr = 0, c_feas = 0, c_asgn = 0, c_nhash1 = 0, c_vv = 0, c_cls = 0, c_inc = 0, c_bait = 0;
     DBTK_STAMP_DECL
     const uint32_t nsurv = *a.nsurv;
-    const uint32_t tend = (nsurv > a.t0 && nsurv - a.t0 < a.tcap) ? nsurv : a.t0 + a.tcap;
-    const uint32_t nslp = a.nkp >> 6;  // slots the hit buffer reserves per read
+    const uint32_t nslp = a.nkp >> 6;  // slots the hit buffers reserve per read
 
-    // Software pipeline over pairs: the ticket and the probe results of pair i+1 are requested while
-    // pair i is being resolved, so their HBM latency is off the critical path.
-    uint32_t tk = 0;
-    if (lane == 0) tk = x.atomic_add(a.ticket, 1u);
-    uint32_t t = x.bcast(tk, 0) + a.t0;
+    // Work items: every survivor of the chunk, or (after the usual-pair kernel) the ones it passed on.
+    // Software pipeline, three deep, so that nothing is waited for in the iteration that requested it: the ticket of
+    // item i+2 (atomic), the survivor index of item i+1 (list lookup), the probe results of item i+1 (hit buffers).
+    const bool listmode = a.gen_list != nullptr;
+    const uint32_t nitems = listmode ? *a.ngen : (nsurv > a.t0 ? ((nsurv - a.t0 < a.tcap) ? nsurv - a.t0 : a.tcap) : 0u);
+    constexpr uint32_t NOITEM = 0xFFFFFFFFu;
+    auto take = [&]() { uint32_t v = 0; if (lane == 0) v = x.atomic_add(a.ticket, 1u); return v; };  // lane 0 holds the ticket
+    auto lookup = [&](uint32_t q) -> uint32_t { return q < nitems ? (listmode ? a.gen_list[q] : a.t0 + q) : NOITEM; };
     HitEnt nx[2][NSLOT];
+    uint32_t nxnk[2] = {0, 0}, nxpair = 0;
+    auto request = [&](uint32_t tt) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m) {
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            nx[m][s] = HitEnt{NAN64, NOHIT, 0};
-            if ((uint32_t)s < nslp && t < tend && t < nsurv) nx[m][s] = a.hitbuf[((size_t)2 * (t - a.t0) + m) * a.nkp + 64 * s + lane];
+            for (int s = 0; s < NSLOT; ++s) {
+                nx[m][s] = HitEnt{NAN64, NOHIT, 0};
+                if ((uint32_t)s < nslp && tt != NOITEM) {
+                    const size_t row = ((size_t)2 * (tt - a.t0) + m) * a.nkp + 64 * s + lane;
+                    const HitVA va = a.hitva[row];
+                    nx[m][s] = HitEnt{a.hitkm[row], va.val, va.aux};
+                }
+            }
+            if (tt != NOITEM) nxnk[m] = a.hitnk[2 * (tt - a.t0) + m];
         }
+        if (tt != NOITEM) nxpair = a.surv[tt];
+    };
+    uint32_t t = x.uni(lookup(x.bcast(take(), 0)));
+    request(t);
+    uint32_t tB = lookup(x.bcast(take(), 0));
+    uint32_t tkA = take();
 
     for (;;) {
-        if (t >= tend || t >= nsurv) break;
-        const uint32_t pair = a.surv[t] + a.pair_base;
+        if (t == NOITEM) break;
+        const uint32_t pair = x.uni(nxpair) + a.pair_base;
         x.sync();  // previous pair's LDS is dead from here on
         DBTK_STAMP(0);  // ticket
 
         // ---- P3: the probe kernel's results for both reads (requested one iteration ago)
         uint32_t nkm[2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const uint64_t ls = a.surv[t];
-            uint32_t len = (uint32_t)(a.off[2 * ls + m + 1] - a.off[2 * ls + m]);
-            if (len > (uint32_t)MAXL) len = MAXL;
-            nkm[m] = len >= k ? len - k + 1 : 0;
-        }
+        for (int m = 0; m < 2; ++m) nkm[m] = x.uni(nxnk[m]);  // positions of the read (the probe kernel clamps reads to MAXL)
         int kf[2], rm[2], hf[2] = {0, 0}, af[2] = {0, 0}, bf[2] = {0, 0};
+        uint32_t nhit[2] = {0, 0};  // positions of the mate found in the index
         kf[0] = nkm[0] < cth; kf[1] = nkm[1] < cth;
         rm[0] = kf[0]; rm[1] = kf[1];
         const bool both_short = rm[0] && rm[1];
@@ -1011,15 +1305,11 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     sm.hval[m][i] = nx[m][s].val;
                 }
             }
-        // request the next pair
-        if (lane == 0) tk = x.atomic_add(a.ticket, 1u);
-        const uint32_t tnext = x.bcast(tk, 0) + a.t0;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s)
-                if ((uint32_t)s < nslp && tnext < tend && tnext < nsurv)
-                    nx[m][s] = a.hitbuf[((size_t)2 * (tnext - a.t0) + m) * a.nkp + 64 * s + lane];
+        // next item's data, the item after that, and a new ticket
+        const uint32_t tnext = x.uni(tB);
+        request(tnext);
+        tB = lookup(x.bcast(tkA, 0));
+        tkA = take();
         DBTK_STAMP(3);  // hit-buffer loads
         if (!both_short) {
 #pragma unroll
@@ -1040,6 +1330,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     }
                     cum_miss += nm;
                 }
+                nhit[m] = nk - cum_miss;
                 if (abort_at != nk) { kf[m] = 1; rm[m] = 1; c_nhash1 += abort_at + 1; }  // its.clear(); kf = 1
                 else c_nhash1 += nk;
             }
@@ -1055,6 +1346,37 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         uint64_t Kw[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, Rw[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 
         if (!(rm[0] && rm[1])) {
+            // ---- The usual pair: both mates kept, every hit k-mer unique to ONE and the same locus, and at least
+            // cth hit positions in each mate.  Then countHit's outcome needs no sorting at all: with a single
+            // candidate locus `second` stays empty and top.(fc, rc) are prefix sums of the per-k-mer dups in vote
+            // order; find_matching_locus keeps adding while a strand is below cth and can still reach it
+            // (get_acm1, AQ.cpp:354-357), which with totals D1, D2 >= cth (D = the mate's hit positions, the sum of
+            // its dups) can only end with fc >= cth and rc >= cth — accepted by test1 (AQ.cpp:439-451) whatever
+            // the order was.  The partial sums themselves (nm1/nm2) are only reported in trace mode, which takes
+            // the general path below.
+            bool usual = false;
+            uint32_t v0 = NOHIT;
+            if (!a.P.trace && !rm[0] && !rm[1] && nhit[0] >= cth && nhit[1] >= cth && nhit[0] && nhit[1]) {
+                bool vdiff = false;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int s = 0; s < NSLOT; ++s) {
+                        if ((uint32_t)s >= nsl) continue;
+                        const uint32_t i = 64 * s + lane;
+                        const bool hit = i < nkm[m] && hv[m][s] != NOHIT;
+                        if (v0 == NOHIT) {
+                            const uint64_t hmk = x.ballot(hit);
+                            if (hmk) v0 = x.bcast(hv[m][s], (int)__builtin_ctzll(hmk));
+                        }
+                        vdiff |= hit && hv[m][s] != v0;
+                    }
+                usual = !(v0 & 1) && x.ballot(vdiff) == 0;
+            }
+            if (usual) {
+                dst0 = v0 >> 1;
+                nm1 = (int)nhit[0]; nm2 = (int)nhit[1];  // >= cth each: accepted below
+            } else {
             // ---- P4: gather the hit lists (its1 ++ its2 with the orient bit, AQ.cpp:263-266)
             uint32_t n = 0;
 #pragma unroll
@@ -1260,6 +1582,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
             st_acc[single ? 24 : (alleq ? 25 : 26)] += 1;  // pairs per vote path
             st_acc[27] += nu; st_acc[28] += n;
 #endif
+            }  // general path
             {  // countHit's accept test, AQ.cpp:439-451
                 const uint64_t fc = (uint64_t)(uint32_t)nm1, rc = (uint64_t)(uint32_t)nm2;
                 const bool test1 = fc >= cth && rc >= cth, test2 = (fc + rc) >= 2ull * cth;
@@ -1333,7 +1656,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                         if (!okam && rm[m]) continue;
                         nas[m] = nkm[m];
                         c_cls += nkm[m];
-                        uint32_t mytr = 0, carry = 0;  // carry: last known state of the previous 64 positions
+                        uint32_t mytr = 0, carry = 0;  // carry: last known state before this word
 #pragma unroll
                         for (int s = 0; s < NSLOT; ++s) {
                             slot[m][s] = CLS_NONE;
@@ -1351,14 +1674,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                             const uint64_t kb = x.ballot(st != 0), rb = x.ballot(st == 2);
                             Kw[m][s] = kb; Rw[m][s] = rb;
                             mytr += (uint32_t)__builtin_popcountll(rb);
-                            // last known state at or before each position (wave scan), then strictly before
-                            const uint32_t inc = x.wave_scan_lastnz(st);
-                            uint32_t prev = x.shfl_up1(inc);
-                            if (lane == 0) prev = 0;
-                            if (prev == 0) prev = carry;
-                            Tw[m][s] = x.ballot(st != 0 && prev != 0 && prev != st);
-                            const uint32_t last = x.bcast(inc, 63);
-                            if (last) carry = last;
+                            Tw[m][s] = transitions_word(kb, rb, carry);  // known position whose last known predecessor has the other state
                         }
                         ntr[m] = mytr & 0xFF;  // uint8_t ntr, AQ.cpp:1454 (mytr is wave-uniform)
                     }
@@ -1424,45 +1740,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         const bool want = RECS && a.recs && (a.P.trace || (okam && stage == DBTK_STAGE_COUNTED) ||
                                      (okam && a.P.simmode && (stage == DBTK_STAGE_ASGN || stage == DBTK_STAGE_BAIT)) ||
                                      (a.P.extract && stage == DBTK_STAGE_EXTRACT));
-        if (want) {
-            uint32_t at = pair;
-            if (!a.P.trace) {
-                if (lane == 0) at = x.atomic_add(a.nrec, 1u);
-                at = x.bcast(at, 0);
-            }
-            if (at < a.rec_cap) {
-                dbtk_pair_rec_t* r = &a.recs[at];
-                if (lane == 0) {
-                    r->pair = pair; r->stage = stage; r->dst = dst; r->dst0 = dst0; r->nm1 = nm1; r->nm2 = nm2;
-                }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    dbtk_mate_rec_t* mr = m ? &r->r2 : &r->r1;
-                    if (lane == 0) {
-                        const MateState& s = ms[m];
-                        mr->si = (int16_t)s.si; mr->ei = (int16_t)s.ei; mr->si_ = (int16_t)s.si_; mr->ei_ = (int16_t)s.ei_;
-                        mr->nt = (int16_t)s.nt; mr->bs = (int16_t)s.bs; mr->ti = (int16_t)s.ti;
-                        mr->kf = (uint8_t)kf[m]; mr->hf = (uint8_t)hf[m]; mr->bf = (uint8_t)bf[m]; mr->qf = 0;
-                        mr->af = (uint8_t)af[m]; mr->rm = (uint8_t)rm[m];
-                        mr->nk = (uint16_t)nas[m];
-                    }
-                    // as2 byte `lane` = states of positions 4*lane .. 4*lane+3 (0 '*', 1 '.', 2 '=')
-                    const int wq = lane >> 4, sh = 4 * (lane & 15);
-                    uint64_t kq = Kw[m][0], rq = Rw[m][0];
-                    if (wq == 1) { kq = Kw[m][1]; rq = Rw[m][1]; }
-                    if (wq == 2) { kq = Kw[m][2]; rq = Rw[m][2]; }
-                    if (wq == 3) { kq = Kw[m][3]; rq = Rw[m][3]; }
-                    const uint32_t k4 = (uint32_t)(kq >> sh) & 0xF, r4 = (uint32_t)(rq >> sh) & 0xF;
-                    uint8_t b = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t st = ((k4 >> q) & 1) + ((r4 >> q) & 1);  // known: 1, known and TR: 2
-                        if ((uint32_t)(4 * lane + q) < nas[m]) b |= (uint8_t)(st << (2 * q));
-                    }
-                    mr->as2[lane] = b;
-                }
-            }
-        }
+        if (want) emit_pair_record(x, a, lane, pair, stage, dst, dst0, nm1, nm2, ms, kf, hf, bf, af, rm, nas, Kw, Rw);
         t = tnext;
     }
     DBTK_STAMP_FLUSH;

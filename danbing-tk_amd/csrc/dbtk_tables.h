@@ -72,6 +72,7 @@ struct DevTables {
     uint32_t cls_shift;
     const uint8_t* qc;        // nullptr or nloci bytes
     const uint16_t* permtab;  // introsort permutation of n equal keys, n = 1..NHMAX, row n at n(n-1)/2
+    const uint32_t* trbeg;    // nloci + 1: first OUT.trkmc.ar slot of each locus (its TR k-mers' counters are contiguous)
     uint32_t nloci;
     uint32_t ksize;
     uint32_t consistent;  // index memberships == flank/TR sets (verified on the GPU at load): `aux` may be used

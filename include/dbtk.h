@@ -127,7 +127,7 @@ typedef struct dbtk_pair_rec {
     uint32_t stage;       /* DBTK_STAGE_* where the pair ended  */
     uint32_t dst;         /* destLocus (== nloci when unassigned) */
     uint32_t dst0;        /* destLocus0 = top.idx (DBTK_NAN32 before countHit) */
-    int32_t  nm1, nm2;    /* top.fc / top.rc (partial sums, AQ.cpp:436-438) */
+    int32_t  nm1, nm2;    /* top.fc / top.rc (partial sums, AQ.cpp:436-438): trace mode only, 0 otherwise (not part of any output) */
     dbtk_mate_rec_t r1, r2;
 } dbtk_pair_rec_t;
 

@@ -227,6 +227,7 @@ struct EmuTables {
     std::vector<ClsSlot> cls;
     std::vector<uint32_t> vv;
     std::vector<uint16_t> perm;
+    std::vector<uint32_t> trbeg;
     std::vector<ClsSlot> tre, bait;
     uint64_t stats[3] = {0, 0, 0};
     DevTables T;
@@ -267,7 +268,10 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
         int stack[3 * 40];
         for (int n = 1; n <= NHMAX; ++n) gcc_sort_index(e->perm.data() + (size_t)n * (n - 1) / 2, n, key.data(), stack);
     }
+    e->trbeg.assign(nloci + 1, 0);
+    for (uint64_t l = 0; l <= nloci; ++l) e->trbeg[l] = (uint32_t)g->out_beg[l];
     DevTables& T = e->T;
+    T.trbeg = e->trbeg.data();
     T.idx = e->idx.data(); T.idx_mask = nbkt - 1; T.idx_shift = 64 - lg(nbkt);
     T.vv = e->vv.data();
     T.cls = e->cls.data(); T.cls_mask = ccap - 1; T.cls_shift = 64 - lg(ccap);
@@ -415,14 +419,15 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     for (uint64_t r = 0; r < 2 * npairs; ++r) maxlen = std::max<uint32_t>(maxlen, (uint32_t)(off[r + 1] - off[r]));
     const uint32_t nkmax = maxlen >= g->ksize ? maxlen - g->ksize + 1 : 1;
     a.nkp = 64 * ((nkmax + 63) / 64);
-    std::vector<HitEnt> hit((size_t)npairs * 2 * a.nkp + 1);
-    a.hitbuf = hit.data();
     a.pair_base = 0;
-    // survivor chunks: a small hit buffer forces several K2 -> K3 iterations, as on the device
+    // survivor chunks: small hit buffers force several K2 -> K3 iterations, as on the device
     const uint32_t tcap = npairs > 7 ? (uint32_t)(npairs / 3 + 1) : (uint32_t)(npairs ? npairs : 1);
-    hit.assign((size_t)tcap * 2 * a.nkp + 1, HitEnt{0, 0, 0});
-    a.hitbuf = hit.data();
+    std::vector<uint64_t> hitkm((size_t)tcap * 2 * a.nkp + 1, 0);
+    std::vector<HitVA> hitva((size_t)tcap * 2 * a.nkp + 1, HitVA{0, 0});
+    std::vector<uint32_t> hitnk((size_t)tcap * 2 + 1, 0), gen(tcap + 1, 0);
+    a.hitkm = hitkm.data(); a.hitva = hitva.data(); a.hitnk = hitnk.data();
     a.tcap = tcap;
+    const bool usual = e->T.consistent && !p->trace && !p->bait && !p->bubbles;  // as the device launcher decides
     uint32_t tile_ticket = 0;
     a.tile_ticket = &tile_ticket;
     std::vector<uint64_t> edgebuf, qmaskbuf, qualbuf;
@@ -442,17 +447,23 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         a.t0 = t0;
         uint32_t ticket = 0;
         a.ticket = &ticket;
+        uint32_t ngen = 0;
+        a.gen_list = usual ? gen.data() : nullptr;
+        a.ngen = usual ? &ngen : nullptr;
         switch (a.nkp / 64) {  // same dispatch as the device launcher
             case 1: case 2:
                 run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<2>(x, a); });
+                if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<2, true>(x, a); else body_pair_usual<2, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<2>), [&](EmuX& x) { if (a.recs) body_pair<2, true>(x, a); else body_pair<2, false>(x, a); });
                 break;
             case 3:
                 run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<3>(x, a); });
+                if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<3, true>(x, a); else body_pair_usual<3, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<3>), [&](EmuX& x) { if (a.recs) body_pair<3, true>(x, a); else body_pair<3, false>(x, a); });
                 break;
             default:
                 run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<4>(x, a); });
+                if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<4, true>(x, a); else body_pair_usual<4, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<4>), [&](EmuX& x) { if (a.recs) body_pair<4, true>(x, a); else body_pair<4, false>(x, a); });
         }
     }

@@ -46,6 +46,15 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
             d = bind.recs_equal(a["recs"], b["recs"], c.reads.npairs)
             assert d < 0, f"{bind.rec_str(a['recs'][d])}\n{bind.rec_str(b['recs'][d])}"
         E.set_consistent(T, 1 if case != "inconsistent" else 0)
+        # without trace the usual pair (one locus, >= cth hits per mate) skips the sort and the vote: same counts and totals
+        p2 = abi.default_params(ksize=c.k, **kw)
+        a2 = O.align(go, p2, seq, off, trace=False)
+        b2 = E.align(g, T, p2, seq, off, grid_k1=2, grid_pair=3)
+        co2 = np.zeros(g.ntrkmers, np.uint64)
+        np.add.at(co2, order, a2["counts_file"])
+        assert (co2 == b2["counts"]).all()
+        assert (a2["kmc"] == b2["kmc"]).all() and (a2["nmapread"] == b2["nmapread"]).all()
+        assert (a2["counters"] == b2["counters"]).all(), (a2["counters"], b2["counters"])
     E.L.emu_tables_free(T)
     O.free(go)
     g.close()

@@ -29,11 +29,12 @@ def main():
     lib._chk(lib.L.dbtk_rpgg_from_arrays(C.byref(a), C.byref(h)))
     g = pkg.Rpgg(lib, h)
     p = abi.default_params(cthreshold=45, okam=0)
+    p.reserved[0] = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # diagnostic knobs of the stamps build
     ctx = lib.context(g, p)
     seq, off = syn.reads(npairs, hit_frac=hit)
     for _ in range(3):
         ctx.align(seq, off)
-    st = np.zeros(32, np.uint64)
+    st = np.zeros(48, np.uint64)
     lib.L.dbtk_debug_stamps(ctx.h, st.ctypes.data_as(abi.u64p))
     r = ctx.counts()["counters"]
     print(f"survivors/step {r[abi.C_SURVIVORS] / 3:.0f}  kernels {ctx.kernel_times()}")
@@ -42,12 +43,19 @@ def main():
         if v:
             print(f"{n:18s} {100 * float(v) / tot:6.2f} %   {float(v) / (r[abi.C_SURVIVORS]):10.0f} cycles/pair")
     print(f"vote paths: single-locus {st[24]}  all-equal-nml {st[25]}  introsort {st[26]}   mean nu {st[27] / max(1, st[24] + st[25] + st[26]):.1f}  mean n {st[28] / max(1, st[24] + st[25] + st[26]):.1f}")
-    st[24:] = 0
-    tot = float(st[16:].sum())
+    st[24:32] = 0
+    tot = float(st[16:32].sum())
     ntiles = 3 * ((npairs + 15) // 16)
-    for n, v in zip(NAMES[16:], st[16:]):
+    for n, v in zip(NAMES[16:32], st[16:32]):
         if v:
             print(f"{n:18s} {100 * float(v) / tot:6.2f} %   {float(v) / ntiles:10.0f} cycles/tile")
+
+
+    u = st[32:48]
+    names = {32: "usual: request+test", 33: "usual: states", 34: "usual: assign", 35: "usual: LDS histogram", 36: "usual: delivery", 37: "usual: count atomics", 39: "usual: loop/record"}
+    tot = float(u.sum())
+    for i, n in names.items():
+        print(f"{n:22s} {100 * float(st[i]) / max(tot, 1):6.2f} %   {float(st[i]) / r[abi.C_SURVIVORS]:10.0f} cycles/pair")
 
 
 if __name__ == "__main__":
