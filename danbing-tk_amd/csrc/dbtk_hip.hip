@@ -44,6 +44,10 @@ struct DevX {
         for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     }
+    __device__ uint32_t wave_min(uint32_t v) const {
+        for (int o = 32; o; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64); v = t < v ? t : v; }
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    }
     __device__ uint32_t wave_excl_scan(uint32_t v) const {
         uint32_t inc = v;
         const int l = (int)(threadIdx.x & 63);

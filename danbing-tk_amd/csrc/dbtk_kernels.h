@@ -1082,6 +1082,9 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
     if (t < tlim) { request(t); deliver(); }
     for (; t < tlim; t += stride) {
         DBTK_STAMP(39);  // loop overhead / record of the previous pair
+#ifdef DBTK_STAMPS
+        if (!(a.P.reserved[0] & 8))  // diagnostic: no loads after the first pair (every pair re-resolves the same data)
+#endif
         request(t + stride < tlim ? t + stride : t);  // (past the end: a harmless reload, so that the loads stay straight-line)
         const uint32_t pair_cur = pair;
         // kfilter (AQ.cpp:190-228) aborts a mate at its (nk - cth + 1)-th miss, i.e. iff it has fewer than cth found positions
@@ -1194,6 +1197,9 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
             continue;
         }
         if (stage == DBTK_STAGE_COUNTED) {
+#ifdef DBTK_STAMPS
+            if (!(a.P.reserved[0] & 16))  // diagnostic: no per-locus atomics
+#endif
             if (lane == 0) {
                 x.atomic_add(&a.nmapread[dst], (uint64_t)(2 - rm[0] - rm[1]));
                 x.atomic_add(&a.kmc[dst], (uint64_t)(int64_t)((ms[0].ei - ms[0].si) + (ms[1].ei - ms[1].si)));
@@ -1251,7 +1257,10 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     const bool listmode = a.gen_list != nullptr;
     const uint32_t nitems = listmode ? *a.ngen : (nsurv > a.t0 ? ((nsurv - a.t0 < a.tcap) ? nsurv - a.t0 : a.tcap) : 0u);
     constexpr uint32_t NOITEM = 0xFFFFFFFFu;
-    auto take = [&]() { uint32_t v = 0; if (lane == 0) v = x.atomic_add(a.ticket, 1u); return v; };  // lane 0 holds the ticket
+    if (nitems == 0) return;  // (an empty chunk must not touch the ticket: thousands of atomics on one address serialize)
+    // items bid and bid + nblocks are this wave's by convention; further ones come from the shared counter
+    const uint32_t nb = x.nblocks();
+    auto take = [&]() { uint32_t v = 0; if (lane == 0) v = 2 * nb + x.atomic_add(a.ticket, 1u); return v; };  // lane 0 holds the ticket
     auto lookup = [&](uint32_t q) -> uint32_t { return q < nitems ? (listmode ? a.gen_list[q] : a.t0 + q) : NOITEM; };
     HitEnt nx[2][NSLOT];
     uint32_t nxnk[2] = {0, 0}, nxpair = 0;
@@ -1271,9 +1280,9 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         }
         if (tt != NOITEM) nxpair = a.surv[tt];
     };
-    uint32_t t = x.uni(lookup(x.bcast(take(), 0)));
+    uint32_t t = x.uni(lookup(x.bid()));
     request(t);
-    uint32_t tB = lookup(x.bcast(take(), 0));
+    uint32_t tB = lookup(x.bid() + nb);
     uint32_t tkA = take();
 
     for (;;) {
@@ -1551,9 +1560,10 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     if (packed) {
                         for (uint32_t u = lane; u < nu; u += 64) sm.u.v.lkey[u] = (sm.u.v.nml[u] << 9) | u;
                         x.sync();
-                        if (lane == 0) gcc_sort(sm.u.v.lkey, (int)nu, PackedLt{}, sm.stack);
-                        x.sync();
-                        for (uint32_t i = lane; i < nu; i += 64) sm.u.v.ord[i] = (uint16_t)(sm.u.v.lkey[i] & 0x1FF);
+                        // the whole wave sorts; lhit (idle until the vote) is its position scratch and then its output
+                        uint16_t* const pos16 = reinterpret_cast<uint16_t*>(sm.w.a.lhit);
+                        wave_gcc_sort_packed(x, sm.u.v.lkey, (int)nu, pos16, pos16 + NHMAX, sm.w.a.lhit, sm.stack);
+                        for (uint32_t i = lane; i < nu; i += 64) sm.u.v.ord[i] = (uint16_t)(sm.w.a.lhit[i] & 0x1FF);
                         x.sync();
                         for (uint32_t i = lane; i < (uint32_t)LCAP; i += 64) sm.u.v.lkey[i] = NAN32;
                     } else if (lane == 0) gcc_sort_index(sm.u.v.ord, (int)nu, sm.u.v.nml, sm.stack);

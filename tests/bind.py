@@ -282,6 +282,8 @@ class Emu(pkg._HostSide):
         L.emu_tables_set_consistent.argtypes = [C.c_void_p, C.c_uint32]
         L.emu_selftest_assign.restype = C.c_uint64
         L.emu_selftest_assign.argtypes = [C.c_uint64, C.c_uint64]
+        L.emu_selftest_wavesort.restype = C.c_uint64
+        L.emu_selftest_wavesort.argtypes = [C.c_uint64, C.c_uint64]
         L.emu_selftest_sort.restype = C.c_uint64
         L.emu_selftest_sort.argtypes = [C.c_uint64, C.c_uint64]
         L.emu_align_ex.restype = C.c_int
@@ -322,6 +324,9 @@ class Emu(pkg._HostSide):
 
     def selftest_assign(self, seed, iters):
         return int(self.L.emu_selftest_assign(seed, iters))
+
+    def selftest_wavesort(self, seed, iters):
+        return int(self.L.emu_selftest_wavesort(seed, iters))
 
     def selftest_sort(self, seed, iters):
         return int(self.L.emu_selftest_sort(seed, iters))

@@ -64,6 +64,7 @@ struct EmuX {
     void sync() const;
     uint64_t ballot(bool p) const;
     uint32_t wave_sum(uint32_t v) const;
+    uint32_t wave_min(uint32_t v) const;
     uint32_t wave_excl_scan(uint32_t v) const;
     uint32_t bcast(uint32_t v, int src) const;
     uint32_t wave_scan_lastnz(uint32_t v) const;
@@ -131,6 +132,15 @@ uint32_t EmuX::wave_sum(uint32_t v) const {
     uint32_t s = 0;
     const int w0 = t & ~63;
     for (int l = 0; l < 64 && w0 + l < b->nt; ++l) s += (uint32_t)b->scratch[w0 + l];
+    b->yield();
+    return s;
+}
+uint32_t EmuX::wave_min(uint32_t v) const {
+    b->scratch[t] = v;
+    b->yield();
+    uint32_t s = 0xFFFFFFFFu;
+    const int w0 = t & ~63;
+    for (int l = 0; l < 64 && w0 + l < b->nt; ++l) if (!b->done[w0 + l] && (uint32_t)b->scratch[w0 + l] < s) s = (uint32_t)b->scratch[w0 + l];
     b->yield();
     return s;
 }
@@ -337,6 +347,41 @@ uint64_t emu_selftest_sort(uint64_t seed, uint64_t iters) {
         gcc_sort(pk.data(), n, PackedLt{}, stack);
         bool ok = true;
         for (int i = 0; i < n; ++i) ok &= a[i] == ref[i] && (pk[i] & 0x1FF) == ref[i];
+        bad += !ok;
+    }
+    return bad;
+}
+
+// wave_gcc_sort_packed (64 emulated lanes) against the host's real std::sort, same key families.
+uint64_t emu_selftest_wavesort(uint64_t seed, uint64_t iters) {
+    uint64_t bad = 0, s = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (uint64_t it = 0; it < iters; ++it) {
+        const int n = (int)(rnd() % 385);
+        std::vector<uint32_t> key(n ? n : 1);
+        const int mode = (int)(rnd() % 7);
+        const uint32_t hi = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : mode == 3 ? 50 : 100000;
+        for (int i = 0; i < n; ++i) key[i] = 1 + (uint32_t)(rnd() % hi);
+        if (mode == 4) std::sort(key.begin(), key.begin() + n);
+        if (mode == 6) { std::sort(key.begin(), key.begin() + n); std::reverse(key.begin(), key.begin() + n); }
+        if (mode == 5 && n >= 4) {  // median-of-3 killer: drives introsort into its heapsort fallback
+            const int k2 = n / 2;
+            std::fill(key.begin(), key.end(), 0u);
+            for (int i = 1; i <= k2; ++i) {
+                if (i % 2) { key[i - 1] = (uint32_t)i; key[i] = (uint32_t)(k2 + i); }
+                key[k2 + i - 1] = (uint32_t)(2 * i);
+            }
+        }
+        std::vector<uint64_t> ref(n);
+        for (int i = 0; i < n; ++i) ref[i] = (uint64_t)i;
+        std::sort(ref.begin(), ref.end(), [&](uint64_t a, uint64_t b) { return key[a] < key[b]; });
+        std::vector<uint32_t> pk(n + 1), out(n + 1, 0);
+        std::vector<uint16_t> ap(n + 1), bp(n + 1);
+        std::vector<int> stack(3 * 40);
+        for (int i = 0; i < n; ++i) pk[i] = (key[i] << 9) | (uint32_t)i;
+        run_grid(1, 64, 0, [&](EmuX& x) { wave_gcc_sort_packed(x, pk.data(), n, ap.data(), bp.data(), out.data(), stack.data()); });
+        bool ok = true;
+        for (int i = 0; i < n; ++i) ok &= (out[i] & 0x1FF) == ref[i];
         bad += !ok;
     }
     return bad;

@@ -98,6 +98,11 @@ def test_device_sort_is_gcc_std_sort(E):
     assert E.selftest_sort(3, 20000) == 0
 
 
+def test_wave_sort_is_gcc_std_sort(E):
+    """The wave-parallel introsort of the general resolve kernel vs this host's std::sort (ties, sorted, reversed, killer sequences)."""
+    assert E.selftest_wavesort(5, 1200) == 0
+
+
 def test_assign_bits_equals_literal_scan(E):
     """The mask form of assignTRkmc used by the kernels vs the literal restatement of AQ.cpp:1470-1555."""
     assert E.selftest_assign(7, 400000) == 0
