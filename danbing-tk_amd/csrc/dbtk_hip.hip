@@ -48,6 +48,14 @@ struct DevX {
         for (int o = 32; o; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64); v = t < v ? t : v; }
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     }
+    __device__ uint32_t wave_scan_max(uint32_t v) const {  // inclusive
+        const int l = (int)(threadIdx.x & 63);
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(v, o, 64);
+            if (l >= o && t > v) v = t;
+        }
+        return v;
+    }
     __device__ uint32_t wave_excl_scan(uint32_t v) const {
         uint32_t inc = v;
         const int l = (int)(threadIdx.x & 63);

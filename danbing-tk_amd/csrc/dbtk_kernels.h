@@ -539,7 +539,7 @@ constexpr int NBKT = 256;          // buckets of the hit-list sort (top 8 bits o
 template <int NS>
 struct PairSmemT {
     static constexpr int NK = 64 * NS, NH = 128 * NS, LC = NS >= 3 ? 512 : 256;  // LC >= NH: the map doubles as sort scratch
-    uint32_t hval[2][NK];      // index val by read position (NOHIT = not in the index); later the vote's loci pool
+    uint32_t hval[2][NK];      // index val by read position (NOHIT = not in the index)
     union {
         struct { uint64_t skey[NH]; uint16_t sinfo[NH]; } s;                      // hit list being sorted
         struct { uint32_t nml[NH]; uint32_t lkey[LC]; uint16_t ord[NH]; } v;       // vote phase
@@ -560,6 +560,7 @@ struct PairSmemT {
     } w;
     int stack[3 * 40];
     int32_t res[8];            // vote result
+    uint32_t evd[2 * NH];      // the vote's loci pool (lists of the multi-locus k-mers), then top - second per event
 };
 
 // assignTRkmc's scan, literally (src/aQueryFasta_thread.cpp:1470-1555), over the
@@ -751,6 +752,197 @@ DBTK_HD uint32_t vote_single_locus(X& x, const uint16_t* perm_row, const uint32_
     const uint64_t mB = x.ballot(firstB != 0xFFFFFFFFu);
     const uint32_t res = x.bcast(pB, mB ? (int)__builtin_ctzll(mB) : 0);
     return mB ? res : tot2;  // loop ran off the end: every k-mer was added
+}
+
+// find_matching_locus (src/aQueryFasta_thread.cpp:364-422) in its general form — any number of loci per k-mer — by the
+// whole wave.  The serial loop is a stream of EVENTS (k-mer i of the vote order, locus q of its list): each event adds
+// the k-mer's dups to its locus' running counts h and offers (h, locus) to updatetop2.  Stated without the loop:
+//   * h of an event = sum of the adds of the events of the same locus up to it          (masked prefix sums per locus);
+//   * top's sum after event e = M_e, the prefix maximum of s = h.f + h.r; e is a RECORD iff s_e > M_{e-1}; top's locus
+//     and counts are those of the last record (updatetop2's first branch fires exactly on records);
+//   * second's sum only ever grows: a record that changes top's locus sets it to M_{e-1} (the old top, >= second), a
+//     non-record raises it to s_e if larger, a record of the same locus leaves it.  So it is the prefix maximum of
+//     c_e = M_{e-1} | 0 | s_e for those three kinds — no per-locus bookkeeping;
+//   * the early stop is the first k-mer whose last event has M - second >= remain (AQ.cpp:405, !get_acm2);
+//   * from there on only top grows, by the dups of the following k-mers that list top's locus, until get_acm1 fails or
+//     the k-mers run out — prefix sums again, as in vote_single_locus.
+// Every step is a wave scan or a ballot; nothing is serial.  Arrays (LDS): ord/uval/dd/nml/poff/pool as for vote();
+// ev_loc, ev_h, evd: ECAP words each of scratch; ev_loc and ev_h MAY overlay the input arrays (those are read into registers
+// before the first event is written).  Returns false, having written nothing, when the events do not fit (more than ECAP)
+// or a loci list is not in the LDS pool: the caller then runs vote().
+// Steps (k-mers in vote order) are owned chunk-wise: step 64*q + lane sits in slot q of lane `lane`.
+template <int EPL, int ECAP, class X>
+DBTK_HD bool vote_parallel(X& x, const uint16_t* ord, const uint32_t* uval, const uint32_t* dd, const uint32_t* nml, const uint16_t* poff,
+                           const uint32_t* pool, uint32_t* ev_loc, uint32_t* ev_h, uint32_t* evd, uint32_t nu, uint32_t cth, Asgn& top,
+                           uint64_t& nvvw) {
+    const uint32_t lane = (uint32_t)x.lane();
+    constexpr uint32_t LAST = 1u << 31, LOCM = LAST - 1;
+    if (nu == 0) return false;
+    // ---- per step: dups, list length, where its events start, remain after it
+    uint32_t sd[EPL], sn[EPL], sval[EPL], spo[EPL], soff[EPL], srem[EPL];
+    uint32_t cd = 0, cn = 0;
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+        const uint32_t i = 64 * q + lane;
+        sd[q] = 0; sn[q] = 0; sval[q] = 0; spo[q] = 0;
+        if (i < nu) {
+            const uint32_t u = ord[i];
+            sval[q] = uval[u];
+            sd[q] = dd[u] & 0x00FF00FFu;  // uint8_t counts, AQ.cpp:42
+            sn[q] = (sval[q] & 1) ? nml[u] : 1u;
+            if (sval[q] & 1) { spo[q] = poff[u]; bad |= spo[q] == 0xFFFFu; }
+        }
+        const uint32_t ds = (sd[q] & 0xFFFF) + (sd[q] >> 16);
+        srem[q] = cd + x.wave_excl_scan(ds) + ds;  // inclusive prefix of the dups, for now
+        soff[q] = cn + x.wave_excl_scan(sn[q]);
+        cd += x.wave_sum(ds);
+        cn += x.wave_sum(sn[q]);
+    }
+    const uint32_t total = cd, E = cn;
+    if (x.ballot(bad) != 0 || E > (uint32_t)ECAP) return false;
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) srem[q] = total - srem[q];
+    x.sync();
+    // ---- events: locus (| LAST on a k-mer's last event), and the k-mer's dups where h will be
+#pragma unroll
+    for (int q = 0; q < EPL; ++q)
+        for (uint32_t j = 0; j < sn[q]; ++j) {
+            const uint32_t loc = (sval[q] & 1) ? pool[spo[q] + j] : (sval[q] >> 1);
+            ev_loc[soff[q] + j] = loc | (j + 1 == sn[q] ? LAST : 0u);
+            ev_h[soff[q] + j] = sd[q];
+        }
+    x.sync();
+    const uint32_t nch = (E + 63) >> 6;
+    // ---- h: per distinct locus (ascending), a masked running sum over the events
+    {
+        bool started = false;
+        uint32_t prev = 0;
+        for (;;) {
+            uint32_t mymin = 0xFFFFFFFFu;
+            for (uint32_t e = lane; e < E; e += 64) {
+                const uint32_t l = ev_loc[e] & LOCM;
+                if ((!started || l > prev) && l < mymin) mymin = l;
+            }
+            const uint32_t L = x.wave_min(mymin);
+            if (L == 0xFFFFFFFFu) break;
+            uint32_t carry = 0;
+            for (uint32_t c = 0; c < nch; ++c) {
+                const uint32_t e = 64 * c + lane;
+                const bool m = e < E && (ev_loc[e] & LOCM) == L;
+                if (x.ballot(m) == 0) continue;
+                const uint32_t v = m ? ev_h[e] : 0u;
+                const uint32_t incl = carry + x.wave_excl_scan(v) + v;
+                if (m) ev_h[e] = incl;
+                carry = x.bcast(incl, 63);
+            }
+            prev = L;
+            started = true;
+        }
+    }
+    x.sync();
+    // ---- top / second along the events: evd[e] = (M_e - second_e) | record_e << 31
+    {
+        uint32_t cM = 0, cS2 = 0, cTop = 0;  // carries: prefix max of s, of c, last record's locus + 1
+        for (uint32_t c = 0; c < nch; ++c) {
+            const uint32_t e = 64 * c + lane;
+            const bool in = e < E;
+            const uint32_t h = in ? ev_h[e] : 0u, s = (h & 0xFFFF) + (h >> 16), loc = in ? (ev_loc[e] & LOCM) : 0u;
+            const uint32_t im = x.wave_scan_max(s);
+            uint32_t em = x.shfl_up1(im);  // exclusive prefix max
+            if (lane == 0) em = 0;
+            if (em < cM) em = cM;
+            const bool rec = in && s > em;
+            const uint32_t il = x.wave_scan_lastnz(rec ? loc + 1 : 0u);
+            uint32_t pl = x.shfl_up1(il);  // top's locus + 1 before this event
+            if (lane == 0) pl = 0;
+            if (pl == 0) pl = cTop;
+            const uint32_t cc = !in ? 0u : (rec ? (pl != loc + 1 ? em : 0u) : s);
+            uint32_t s2 = x.wave_scan_max(cc);
+            if (s2 < cS2) s2 = cS2;
+            const uint32_t M = s > em ? s : em;
+            if (in) evd[e] = (M - s2) | (rec ? LAST : 0u);
+            const uint32_t lm = x.bcast(M, 63), ls2 = x.bcast(s2, 63), ll = x.bcast(il, 63);
+            cM = lm; cS2 = ls2;
+            if (ll) cTop = ll;
+        }
+    }
+    x.sync();
+    // ---- the early stop: first k-mer with M - second >= remain at its last event
+    uint32_t istar = nu - 1;
+    {
+        bool found = false;
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) {
+            const uint32_t i = 64 * q + lane;
+            const bool t = i < nu && (evd[soff[q] + sn[q] - 1] & LOCM) >= srem[q];
+            const uint64_t mk = x.ballot(t);
+            if (!found && mk) { istar = 64 * q + (uint32_t)__builtin_ctzll(mk); found = true; }
+        }
+    }
+    // top at that point: the last record at or before the k-mer's last event
+    const uint32_t qs = istar >> 6, ls = istar & 63;
+    uint32_t estar = 0;
+#pragma unroll
+    for (int q = 0; q < EPL; ++q)
+        if ((uint32_t)q == qs) estar = x.bcast(soff[q] + sn[q] - 1, (int)ls);
+    uint32_t er = 0;
+    for (uint32_t c = 0; c <= (estar >> 6); ++c) {
+        const uint32_t e = 64 * c + lane;
+        const uint64_t mk = x.ballot(e <= estar && (evd[e] & LAST));
+        if (mk) er = 64 * c + 63 - (uint32_t)__builtin_clzll(mk);
+    }
+    const uint32_t tloc = x.uni(ev_loc[er]) & LOCM;
+    uint32_t th = x.uni(ev_h[er]);
+    // ---- countHit's traffic so far, and the tail: k-mers after istar that list top's locus
+    uint32_t vvw = 0, g[EPL], w[EPL];
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+        const uint32_t i = 64 * q + lane;
+        const bool multi = sval[q] & 1;
+        if (i < nu && i <= istar && multi) vvw += 1 + sn[q];
+        g[q] = 0; w[q] = 0;
+        if (i < nu && i > istar) {
+            uint32_t pos = sn[q];
+            for (uint32_t j = 0; j < sn[q]; ++j)
+                if ((ev_loc[soff[q] + j] & LOCM) == tloc) { pos = j; break; }
+            if (pos < sn[q]) g[q] = sd[q];
+            if (multi) w[q] = 1 + (pos < sn[q] ? pos + 1 : sn[q]);
+        }
+    }
+    nvvw += x.wave_sum(vvw);
+    // get_acm1 at istar with top as it stands, then after each further k-mer; stop at the first failure
+    {
+        const uint32_t f0 = th & 0xFFFF, r0 = th >> 16;
+        uint32_t rem_star = 0;
+#pragma unroll
+        for (int q = 0; q < EPL; ++q)
+            if ((uint32_t)q == qs) rem_star = x.bcast(srem[q], (int)ls);
+        if (get_acm1(f0, r0, rem_star, cth)) {
+            uint32_t cg = th, cw = 0;
+            bool done = false;
+#pragma unroll
+            for (int q = 0; q < EPL; ++q) {
+                if (done || 64u * q >= nu || 64u * q + 63 <= istar) continue;  // (uniform)
+                const uint32_t i = 64 * q + lane;
+                const uint32_t ig = cg + x.wave_excl_scan(g[q]) + g[q], iw = cw + x.wave_excl_scan(w[q]) + w[q];
+                const bool stop = i < nu && i > istar && !get_acm1(ig & 0xFFFF, ig >> 16, srem[q], cth);
+                const uint64_t mk = x.ballot(stop);
+                if (mk) {
+                    const int l = (int)__builtin_ctzll(mk);
+                    th = x.bcast(ig, l);
+                    nvvw += x.bcast(iw, l);
+                    done = true;
+                } else {  // through the chunk (or to the last k-mer)
+                    const uint32_t lastl = (nu - 64 * q < 64) ? nu - 64 * q - 1 : 63;
+                    cg = x.bcast(ig, (int)lastl); cw = x.bcast(iw, (int)lastl);
+                }
+            }
+            if (!done) { th = cg; nvvw += cw; }  // ++j >= nu: every remaining k-mer was looked at
+        }
+    }
+    top.idx = tloc; top.fc = th & 0xFFFF; top.rc = th >> 16;
+    return true;
 }
 
 // ======================================================================= K2 =
@@ -1258,9 +1450,9 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     const uint32_t nitems = listmode ? *a.ngen : (nsurv > a.t0 ? ((nsurv - a.t0 < a.tcap) ? nsurv - a.t0 : a.tcap) : 0u);
     constexpr uint32_t NOITEM = 0xFFFFFFFFu;
     if (nitems == 0) return;  // (an empty chunk must not touch the ticket: thousands of atomics on one address serialize)
-    // items bid and bid + nblocks are this wave's by convention; further ones come from the shared counter
+    // item bid is this wave's by convention; further ones come from the shared counter (the work per item varies a lot)
     const uint32_t nb = x.nblocks();
-    auto take = [&]() { uint32_t v = 0; if (lane == 0) v = 2 * nb + x.atomic_add(a.ticket, 1u); return v; };  // lane 0 holds the ticket
+    auto take = [&]() { uint32_t v = 0; if (lane == 0) v = nb + x.atomic_add(a.ticket, 1u); return v; };  // lane 0 holds the ticket
     auto lookup = [&](uint32_t q) -> uint32_t { return q < nitems ? (listmode ? a.gen_list[q] : a.t0 + q) : NOITEM; };
     HitEnt nx[2][NSLOT];
     uint32_t nxnk[2] = {0, 0}, nxpair = 0;
@@ -1282,9 +1474,12 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     };
     uint32_t t = x.uni(lookup(x.bid()));
     request(t);
-    uint32_t tB = lookup(x.bid() + nb);
+    uint32_t tB = lookup(x.bcast(take(), 0));
     uint32_t tkA = take();
 
+#ifdef DBTK_STAMPS
+    uint64_t pair_t0_ = x.clock();
+#endif
     for (;;) {
         if (t == NOITEM) break;
         const uint32_t pair = x.uni(nxpair) + a.pair_base;
@@ -1515,20 +1710,20 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     }
                     for (uint32_t i = lane; i < (uint32_t)LCAP; i += 64) sm.u.v.lkey[i] = NAN32;
                     x.sync();
-                    {   // loci lists of the multi-locus k-mers into LDS (hval is dead after the dedup), all lanes
+                    {   // loci lists of the multi-locus k-mers into the LDS pool, all lanes
                         // loading in parallel: the vote itself then runs without touching HBM
                         const uint32_t b0 = EPL * (uint32_t)lane;
                         uint32_t need = 0;
 #pragma unroll
                         for (int j = 0; j < EPL; ++j) if (b0 + j < nu && (sm.w.a.uval[b0 + j] & 1)) need += sm.u.v.nml[b0 + j];
                         uint32_t at = x.wave_excl_scan(need);
-                        uint32_t* pool = &sm.hval[0][0];
+                        uint32_t* pool = sm.evd;  // (the parallel vote reads the pool before it writes evd over it)
 #pragma unroll
                         for (int j = 0; j < EPL; ++j) {
                             const uint32_t u = b0 + j;
                             if (u < nu) {
                                 const uint32_t v = sm.w.a.uval[u], nn = (v & 1) ? sm.u.v.nml[u] : 0;
-                                if (nn && at + nn <= (uint32_t)NHMAX) {
+                                if (nn && at + nn <= 2u * NHMAX) {
                                     sm.w.a.poff[u] = (uint16_t)at;
                                     for (uint32_t q = 0; q < nn; ++q) pool[at + q] = T.vv[(v >> 1) + 1 + q];
                                 } else sm.w.a.poff[u] = 0xFFFFu;
@@ -1569,23 +1764,39 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     } else if (lane == 0) gcc_sort_index(sm.u.v.ord, (int)nu, sm.u.v.nml, sm.stack);
                 }
                 x.sync();
-                if (lane == 0) {
-                    for (uint32_t u = 0; u < nu; ++u) sm.w.a.dd[u] &= 0x00FF00FFu;  // PE_KMC counts are uint8_t
-                    const uint32_t ep = a.vote_epoch[x.bid()] + 1;
-                    HitMap hmap{sm.u.v.lkey, sm.w.a.lhit, 0, a.vote_scratch + (size_t)x.bid() * ((size_t)nloci + 1), ep, false,
-                                (uint32_t)LCAP, LCAP == 512 ? 23u : 24u, (uint32_t)(LCAP * 3 / 4)};
-                    Asgn top;
-                    uint64_t nvvw = 0;
-                    vote(T, sm.u.v.ord, sm.w.a.uval, sm.w.a.dd, (int)nu, cth, hmap, top, nvvw, sm.u.v.nml, &sm.hval[0][0], sm.w.a.poff);
-                    c_vv += nvvw;
-                    if (hmap.spilled) a.vote_epoch[x.bid()] = ep;
-                    sm.res[0] = (int32_t)(uint32_t)top.idx;
-                    sm.res[1] = (int32_t)top.fc;
-                    sm.res[2] = (int32_t)top.rc;
+                Asgn ptop{NAN32, 0, 0};
+                uint64_t pvvw = 0;
+                // event scratch: 2 * NHMAX words each (a k-mer has one event per locus; the loci lists come from the pool of 2 * NHMAX);
+                // two of the three overlay the vote's input arrays, which are in registers by the time the events are written
+                static_assert(sizeof(sm.u) >= 8 * NHMAX && sizeof(sm.w) >= 8 * NHMAX, "event scratch does not fit");
+                if (vote_parallel<NHMAX / 64, 2 * NHMAX>(x, sm.u.v.ord, sm.w.a.uval, sm.w.a.dd, sm.u.v.nml, sm.w.a.poff, sm.evd,
+                                                        reinterpret_cast<uint32_t*>(&sm.u), reinterpret_cast<uint32_t*>(&sm.w), sm.evd, nu, cth,
+                                                        ptop, pvvw)) {
+                    c_vv += pvvw;
+                    dst0 = (uint32_t)ptop.idx;
+                    nm1 = (int)ptop.fc; nm2 = (int)ptop.rc;
+                } else {  // events do not fit in LDS: the literal loop on one lane
+#ifdef DBTK_STAMPS
+                    st_acc[44] += 1;
+#endif
+                    if (lane == 0) {
+                        for (uint32_t u = 0; u < nu; ++u) sm.w.a.dd[u] &= 0x00FF00FFu;  // PE_KMC counts are uint8_t
+                        const uint32_t ep = a.vote_epoch[x.bid()] + 1;
+                        HitMap hmap{sm.u.v.lkey, sm.w.a.lhit, 0, a.vote_scratch + (size_t)x.bid() * ((size_t)nloci + 1), ep, false,
+                                    (uint32_t)LCAP, LCAP == 512 ? 23u : 24u, (uint32_t)(LCAP * 3 / 4)};
+                        Asgn top;
+                        uint64_t nvvw = 0;
+                        vote(T, sm.u.v.ord, sm.w.a.uval, sm.w.a.dd, (int)nu, cth, hmap, top, nvvw, sm.u.v.nml, sm.evd, sm.w.a.poff);
+                        c_vv += nvvw;
+                        if (hmap.spilled) a.vote_epoch[x.bid()] = ep;
+                        sm.res[0] = (int32_t)(uint32_t)top.idx;
+                        sm.res[1] = (int32_t)top.fc;
+                        sm.res[2] = (int32_t)top.rc;
+                    }
+                    x.sync();
+                    dst0 = x.uni((uint32_t)sm.res[0]);
+                    nm1 = (int)x.uni((uint32_t)sm.res[1]); nm2 = (int)x.uni((uint32_t)sm.res[2]);
                 }
-                x.sync();
-                dst0 = x.uni((uint32_t)sm.res[0]);
-                nm1 = (int)x.uni((uint32_t)sm.res[1]); nm2 = (int)x.uni((uint32_t)sm.res[2]);
             }
             DBTK_STAMP(single ? 9 : 10);  // vote: fast / general
 #ifdef DBTK_STAMPS
@@ -1751,6 +1962,14 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                                      (okam && a.P.simmode && (stage == DBTK_STAGE_ASGN || stage == DBTK_STAGE_BAIT)) ||
                                      (a.P.extract && stage == DBTK_STAGE_EXTRACT));
         if (want) emit_pair_record(x, a, lane, pair, stage, dst, dst0, nm1, nm2, ms, kf, hf, bf, af, rm, nas, Kw, Rw);
+#ifdef DBTK_STAMPS
+        {
+            const uint64_t now_ = x.clock();
+            if (lane == 0 && a.dbg) x.atomic_max(&a.dbg[45], now_ - pair_t0_);
+            pair_t0_ = now_;
+            st_acc[46] += 1;
+        }
+#endif
         t = tnext;
     }
     DBTK_STAMP_FLUSH;

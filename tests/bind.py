@@ -284,6 +284,8 @@ class Emu(pkg._HostSide):
         L.emu_selftest_assign.argtypes = [C.c_uint64, C.c_uint64]
         L.emu_selftest_wavesort.restype = C.c_uint64
         L.emu_selftest_wavesort.argtypes = [C.c_uint64, C.c_uint64]
+        L.emu_selftest_vote.restype = C.c_uint64
+        L.emu_selftest_vote.argtypes = [C.c_uint64, C.c_uint64]
         L.emu_selftest_sort.restype = C.c_uint64
         L.emu_selftest_sort.argtypes = [C.c_uint64, C.c_uint64]
         L.emu_align_ex.restype = C.c_int
@@ -327,6 +329,9 @@ class Emu(pkg._HostSide):
 
     def selftest_wavesort(self, seed, iters):
         return int(self.L.emu_selftest_wavesort(seed, iters))
+
+    def selftest_vote(self, seed, iters):
+        return int(self.L.emu_selftest_vote(seed, iters))
 
     def selftest_sort(self, seed, iters):
         return int(self.L.emu_selftest_sort(seed, iters))

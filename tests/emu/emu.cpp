@@ -9,6 +9,8 @@
 // scheduled round-robin from barrier to barrier, wave64 collectives (ballot,
 // scans, broadcasts) go through a scratch array, atomics are plain operations.
 // Blocks run one after another, which is one of the schedules the GPU may pick.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #if !defined(__x86_64__)
@@ -65,6 +67,7 @@ struct EmuX {
     uint64_t ballot(bool p) const;
     uint32_t wave_sum(uint32_t v) const;
     uint32_t wave_min(uint32_t v) const;
+    uint32_t wave_scan_max(uint32_t v) const;
     uint32_t wave_excl_scan(uint32_t v) const;
     uint32_t bcast(uint32_t v, int src) const;
     uint32_t wave_scan_lastnz(uint32_t v) const;
@@ -144,6 +147,15 @@ uint32_t EmuX::wave_min(uint32_t v) const {
     b->yield();
     return s;
 }
+uint32_t EmuX::wave_scan_max(uint32_t v) const {
+    b->scratch[t] = v;
+    b->yield();
+    uint32_t r = 0;
+    const int w0 = t & ~63;
+    for (int l = 0; l <= (t & 63); ++l) if ((uint32_t)b->scratch[w0 + l] > r) r = (uint32_t)b->scratch[w0 + l];
+    b->yield();
+    return r;
+}
 uint32_t EmuX::wave_excl_scan(uint32_t v) const {
     b->scratch[t] = v;
     b->yield();
@@ -198,8 +210,10 @@ void run_grid(uint32_t nblocks, int nt, size_t smem_bytes, std::function<void(Em
     b.nblocks = nblocks;
     b.body = body;
     b.sp.resize(nt);
-    b.stacks.resize(nt);
-    for (auto& s : b.stacks) s.resize(STK);
+    static thread_local std::vector<std::vector<char>> stack_pool;  // kept across calls: the selftests launch thousands of grids
+    if ((int)stack_pool.size() < nt) stack_pool.resize(nt);
+    for (int t = 0; t < nt; ++t) if (stack_pool[t].size() < STK) stack_pool[t].resize(STK);
+    b.stacks.clear();
     b.done.assign(nt, 0);
     b.scratch.assign(nt, 0);
     b.vscratch.assign((size_t)nt * 8, 0);
@@ -212,7 +226,7 @@ void run_grid(uint32_t nblocks, int nt, size_t smem_bytes, std::function<void(Em
             b.scratch[t] = 0;
             // fresh stack: six zeroed callee-saved registers, then lane_entry as the "return address" (16-byte aligned slot,
             // so that lane_entry starts with the stack alignment of a called function)
-            uintptr_t top = ((uintptr_t)b.stacks[t].data() + STK) & ~(uintptr_t)15;
+            uintptr_t top = ((uintptr_t)stack_pool[t].data() + STK) & ~(uintptr_t)15;
             void** slot = (void**)(top - 16);
             slot[0] = (void*)lane_entry;
             for (int r = 1; r <= 6; ++r) slot[-r] = nullptr;
@@ -383,6 +397,71 @@ uint64_t emu_selftest_wavesort(uint64_t seed, uint64_t iters) {
         bool ok = true;
         for (int i = 0; i < n; ++i) ok &= (out[i] & 0x1FF) == ref[i];
         bad += !ok;
+    }
+    return bad;
+}
+
+// vote_parallel (64 emulated lanes) against the literal find_matching_locus loop vote(), on random tie-heavy inputs:
+// few loci, small dups, multi-locus k-mers, random vote order and threshold.  Returns the number of mismatches.
+uint64_t emu_selftest_vote(uint64_t seed, uint64_t iters) {
+    uint64_t bad = 0, s = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    constexpr int NH = 384, LC = 512;
+    for (uint64_t it = 0; it < iters; ++it) {
+        const int nu = 1 + (int)(rnd() % (it % 5 == 0 ? 300 : 60));
+        const int D = 1 + (int)(rnd() % 6);
+        const uint32_t cth = (uint32_t)(rnd() % 60);
+        std::vector<uint16_t> ord(NH), poff(NH, 0xFFFF);
+        std::vector<uint32_t> uval(NH, 0), dd(NH, 0), nml(NH, 1), pool(NH, 0), vv;
+        for (int i = 0; i < nu; ++i) ord[i] = (uint16_t)i;
+        for (int i = nu - 1; i > 0; --i) std::swap(ord[i], ord[rnd() % (i + 1)]);
+        uint32_t at = 0;
+        for (int u = 0; u < nu; ++u) {
+            const uint32_t d1 = (uint32_t)(rnd() % 4), d2 = (uint32_t)(rnd() % 4);
+            dd[u] = (d1 | (d2 << 16)) ? (d1 | (d2 << 16)) : 1u;
+            dd[u] |= (uint32_t)(rnd() % 2) << 8 << 0;  // junk above the uint8_t count of mate 0: must be masked away
+            dd[u] &= 0x01FF01FFu;
+            const int n = (rnd() % 3 == 0 && at + 4 < (uint32_t)NH) ? 2 + (int)(rnd() % 3) : 1;
+            if (n == 1) { uval[u] = (uint32_t)(rnd() % D) << 1; nml[u] = 1; }
+            else {
+                uval[u] = ((uint32_t)vv.size() << 1) | 1u;
+                vv.push_back((uint32_t)n);
+                nml[u] = (uint32_t)n;
+                poff[u] = (uint16_t)at;
+                for (int q = 0; q < n; ++q) { const uint32_t l = (uint32_t)(rnd() % D); vv.push_back(l); pool[at++] = l; }
+            }
+        }
+        vv.push_back(0);
+        DevTables T;
+        memset(&T, 0, sizeof(T));
+        T.vv = vv.data();
+        // serial reference
+        std::vector<uint32_t> lkey(LC, NAN32), lhit(LC, 0), dd2 = dd;
+        for (int u = 0; u < nu; ++u) dd2[u] &= 0x00FF00FFu;
+        std::vector<uint64_t> g(8, 0);
+        HitMap hm{lkey.data(), lhit.data(), 0, g.data(), 1, false, (uint32_t)LC, 23u, (uint32_t)(LC * 3 / 4)};
+        Asgn t0;
+        uint64_t v0 = 0;
+        vote(T, ord.data(), uval.data(), dd2.data(), nu, cth, hm, t0, v0, nml.data(), pool.data(), poff.data());
+        // the wave
+        std::vector<uint32_t> el(LC, 0), eh(LC, 0), ed(LC, 0);
+        Asgn t1{NAN32, 0, 0};
+        uint64_t v1 = 0;
+        bool ran = false;
+        run_grid(1, 64, 0, [&](EmuX& x) {
+            Asgn tt{NAN32, 0, 0};
+            uint64_t vvw = 0;
+            const bool ok = vote_parallel<NH / 64, LC>(x, ord.data(), uval.data(), dd.data(), nml.data(), poff.data(), pool.data(), el.data(),
+                                                       eh.data(), ed.data(), (uint32_t)nu, cth, tt, vvw);
+            if (x.lane() == 17) { t1 = tt; v1 = vvw; ran = ok; }
+        });
+        uint32_t nev = 0;
+        for (int u = 0; u < nu; ++u) nev += nml[u];
+        const bool fits = nev <= (uint32_t)LC;  // otherwise it must decline (the kernel then runs the literal loop)
+        if (ran != fits || (ran && (t0.idx != t1.idx || t0.fc != t1.fc || t0.rc != t1.rc || v0 != v1))) {
+            if (getenv("EMU_DEBUG")) fprintf(stderr, "it=%llu nu=%d D=%d cth=%u ran=%d serial idx=%llu fc=%llu rc=%llu vv=%llu | wave idx=%llu fc=%llu rc=%llu vv=%llu\n", (unsigned long long)it, nu, D, cth, (int)ran, (unsigned long long)t0.idx, (unsigned long long)t0.fc, (unsigned long long)t0.rc, (unsigned long long)v0, (unsigned long long)t1.idx, (unsigned long long)t1.fc, (unsigned long long)t1.rc, (unsigned long long)v1);
+            ++bad;
+        }
     }
     return bad;
 }

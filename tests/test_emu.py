@@ -100,7 +100,12 @@ def test_device_sort_is_gcc_std_sort(E):
 
 def test_wave_sort_is_gcc_std_sort(E):
     """The wave-parallel introsort of the general resolve kernel vs this host's std::sort (ties, sorted, reversed, killer sequences)."""
-    assert E.selftest_wavesort(5, 1200) == 0
+    assert E.selftest_wavesort(5, 4000) == 0
+
+
+def test_wave_vote_is_find_matching_locus(E):
+    """The scan form of the general vote vs the literal find_matching_locus loop, on tie-heavy random event streams."""
+    assert E.selftest_vote(11, 30000) == 0
 
 
 def test_assign_bits_equals_literal_scan(E):

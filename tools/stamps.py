@@ -51,6 +51,8 @@ def main():
             print(f"{n:18s} {100 * float(v) / tot:6.2f} %   {float(v) / ntiles:10.0f} cycles/tile")
 
 
+    print(f"general kernel: {st[46]} pairs, {st[44]} serial-vote fallbacks, slowest pair {st[45]} cycles")
+    st[44:47] = 0
     u = st[32:48]
     names = {32: "usual: request+test", 33: "usual: states", 34: "usual: assign", 35: "usual: LDS histogram", 36: "usual: delivery", 37: "usual: count atomics", 39: "usual: loop/record"}
     tot = float(u.sum())
