@@ -114,6 +114,14 @@ __global__ void __launch_bounds__(256) k_idx_finalize(IdxBucket* b, uint64_t nsl
 __global__ void __launch_bounds__(256) k_cls_insert(ClsBuildArgs a) { DevX x{nullptr}; body_cls_insert(x, a); }
 __global__ void __launch_bounds__(256) k_idx_aux(IdxAuxArgs a) { DevX x{nullptr}; body_idx_aux(x, a); }
 
+// counters[c] += sum of its replicas; replicas back to zero
+__global__ void __launch_bounds__(64) k_fold_counters(uint64_t* counters, uint64_t* rep) {
+    const uint32_t c = threadIdx.x;
+    if (c >= DBTK_C_COUNT) return;
+    uint64_t s = 0;
+    for (uint32_t r = 0; r < CTR_REP; ++r) { s += rep[(size_t)r * CTR_STRIDE + c]; rep[(size_t)r * CTR_STRIDE + c] = 0; }
+    counters[c] += s;
+}
 __global__ void __launch_bounds__(K1_NT) k_encode_subfilter(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) K1Smem sm;
     DevX x{&sm};
@@ -175,6 +183,7 @@ struct dbtk_ctx {
     uint8_t* d_qc = nullptr;
     uint16_t* d_perm = nullptr;
     uint64_t* d_accum = nullptr;  // counts | kmc | nmapread | counters
+    uint64_t* d_ctr = nullptr;    // counter replicas (folded into d_accum's counters at the end of every batch)
     uint64_t n_accum = 0, ntr = 0;
     uint32_t* d_small = nullptr;  // nsurv, ticket, nrec, errflag
     uint32_t* d_surv = nullptr; uint64_t surv_cap = 0;
@@ -222,7 +231,7 @@ void free_ctx(dbtk_ctx* c) {
             if (c->timed[i].beg[j]) (void)hipEventDestroy(c->timed[i].beg[j]);
             if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
         }
-    void* ptrs[] = {c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
+    void* ptrs[] = {c->d_ctr, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_gen, c->d_tickets,
                     c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -443,6 +452,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     a.kmc = c->d_accum + c->ntr;
     a.nmapread = a.kmc + c->g->nloci;
     a.counters = a.nmapread + c->g->nloci;
+    a.ctr_rep = c->d_ctr;
     a.recs = d_recs; a.rec_cap = rec_cap;
     a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
     a.hitkm = c->d_hitkm; a.hitva = c->d_hitva; a.hitnk = c->d_hitnk; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
@@ -502,6 +512,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         }
         if (tm) HIPCHK(hipEventRecord(c->timed[3].end[e], s));
     }
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, a.counters, c->d_ctr);
     HIPCHK(hipGetLastError());
     return DBTK_OK;
 }
@@ -546,6 +557,7 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
             const void* ku[3] = {(const void*)k_pair_usual<2, true>, (const void*)k_pair_usual<3, true>, (const void*)k_pair_usual<4, true>};
             nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ku[i], 64, 0) != hipSuccess || nb <= 0) nb = 16;
+            if (const char* e = getenv("DBTK_USUAL_WPC")) { const int v = atoi(e); if (v > 0 && v < nb) nb = v; }  // diagnostic: waves per CU
             c->usual_blocks[i] = c->num_cu * nb;
         }
     }
@@ -575,6 +587,8 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         c->n_accum = c->ntr + 2 * h->nloci + DBTK_C_COUNT;
         auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && !st) { set_error(std::string(what) + ": " + hipGetErrorString(e)); st = DBTK_ERR_HIP; } };
         chk(hipMalloc(&c->d_accum, c->n_accum * 8), "hipMalloc accum");
+        chk(hipMalloc(&c->d_ctr, (size_t)CTR_REP * CTR_STRIDE * 8), "hipMalloc counter replicas");
+        if (!st) chk(hipMemsetAsync(c->d_ctr, 0, (size_t)CTR_REP * CTR_STRIDE * 8, c->stream), "memset");
         chk(hipMalloc(&c->d_small, 4 * SMALL_WORDS + 48 * 8), "hipMalloc small");
         if (!st) chk(hipMemsetAsync(c->d_small, 0, 4 * SMALL_WORDS + 48 * 8, c->stream), "memset");
         chk(hipMalloc(&c->d_vote, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8), "hipMalloc vote scratch");

@@ -157,6 +157,7 @@ struct BatchArgs {
     uint64_t* kmc;
     uint64_t* nmapread;   // widened; low 32 bits are the reference's uint32 counter
     uint64_t* counters;   // DBTK_C_*
+    uint64_t* ctr_rep;    // nullptr, or CTR_REP replicas of the counters, CTR_STRIDE words apart (see counters_of)
     dbtk_pair_rec_t* recs;  // nullptr, or rec_cap records
     uint32_t* nrec;         // kam mode: compaction counter (may exceed rec_cap)
     uint32_t rec_cap;
@@ -182,6 +183,15 @@ struct BatchArgs {
     uint32_t t0, tcap;       // K2/K3 work on survivors [t0, min(t0 + tcap, *nsurv)): the hit buffer holds tcap pairs
     uint32_t* tile_ticket;   // K1 work counter (tiles)
 };
+
+// Thousands of waves each flush a handful of counters at their end; atomics on ONE address serialize at the memory side
+// (tens of nanoseconds each), which showed up as a fixed cost per resident wave.  On the device the waves therefore add
+// into CTR_REP replicas on separate cache lines, and a tiny kernel folds the replicas into the real counters after the batch.
+constexpr uint32_t CTR_REP = 256, CTR_STRIDE = 32;
+template <class X>
+DBTK_HD uint64_t* counters_of(X& x, const BatchArgs& a) {
+    return a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (CTR_REP - 1)) * CTR_STRIDE : a.counters;
+}
 
 // In-kernel stamps (cdna_hip_programming.md 7): only in the separate diagnostic
 // library built with -DDBTK_STAMPS; the product build compiles them away.
@@ -279,6 +289,7 @@ DBTK_HD void load_tail_chunk(const uint8_t* seq, uint64_t seq_len, uint64_t g, u
 
 template <class X>
 DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
+    uint64_t* const ctr = counters_of(x, a);
     K1Smem& sm = *x.template smem<K1Smem>();
     const uint32_t lane = (uint32_t)x.lane();
     const uint32_t k = a.P.ksize, NF = a.P.n_filter, NM = a.P.nm_filter;
@@ -286,7 +297,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     const uint32_t grp = lane >> 2, sub = lane & 3;  // pair of the tile this lane works for, sample phase
     uint32_t c_short = 0, c_sub = 0, c_nhash = 0, c_probe = 0, c_surv = 0;  // per-lane partial sums (a wave sees < 2^32 pairs)
     uint64_t c_bases = 0;
-    if (lane == 0 && x.bid() == 0) x.atomic_add(&a.counters[DBTK_C_NREADS], 2 * a.npairs);  // nReads, AQ.cpp:1977
+    if (lane == 0 && x.bid() == 0) x.atomic_add(&ctr[DBTK_C_NREADS], 2 * a.npairs);  // nReads, AQ.cpp:1977
     const uint64_t ntiles = (a.npairs + K1_TP - 1) / K1_TP;
     const int lane_ = (int)lane; (void)lane_;
     DBTK_STAMP_DECL
@@ -520,13 +531,13 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     const uint32_t s_nhash = x.wave_sum((uint32_t)c_nhash), s_probe = x.wave_sum((uint32_t)c_probe);
     const uint32_t b_lo = x.wave_sum((uint32_t)(c_bases & 0xFFFFF)), b_hi = x.wave_sum((uint32_t)(c_bases >> 20));
     if (lane == 0) {
-        if (s_short) x.atomic_add(&a.counters[DBTK_C_NSHORT], (uint64_t)s_short);
-        if (s_sub) x.atomic_add(&a.counters[DBTK_C_SUBFILTERED], (uint64_t)s_sub);
-        if (s_nhash) x.atomic_add(&a.counters[DBTK_C_NHASH0], (uint64_t)s_nhash);
-        if (s_probe) x.atomic_add(&a.counters[DBTK_C_ALGO_PROBES], (uint64_t)s_probe);
-        if (s_surv) x.atomic_add(&a.counters[DBTK_C_SURVIVORS], (uint64_t)s_surv);
+        if (s_short) x.atomic_add(&ctr[DBTK_C_NSHORT], (uint64_t)s_short);
+        if (s_sub) x.atomic_add(&ctr[DBTK_C_SUBFILTERED], (uint64_t)s_sub);
+        if (s_nhash) x.atomic_add(&ctr[DBTK_C_NHASH0], (uint64_t)s_nhash);
+        if (s_probe) x.atomic_add(&ctr[DBTK_C_ALGO_PROBES], (uint64_t)s_probe);
+        if (s_surv) x.atomic_add(&ctr[DBTK_C_SURVIVORS], (uint64_t)s_surv);
         const uint64_t bases = (uint64_t)b_lo + ((uint64_t)b_hi << 20);
-        if (bases) x.atomic_add(&a.counters[DBTK_C_BASES], bases);
+        if (bases) x.atomic_add(&ctr[DBTK_C_BASES], bases);
     }
 }
 
@@ -1021,21 +1032,54 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
     const uint32_t ns = *a.nsurv;
     const uint32_t tend = ns - a.t0 < a.tcap ? ns : a.t0 + a.tcap;  // (ns >= t0 checked by the caller loop below)
     const uint32_t nitems = ns > a.t0 ? 2 * (tend - a.t0) : 0;
-    for (uint32_t it = x.bid(); it < nitems; it += x.nblocks()) {  // `it` = hit-buffer row of (survivor, mate)
-        const uint32_t t = a.t0 + (it >> 1), m = it & 1;
-        const uint32_t pair = a.surv[t];
-        const uint64_t o0 = a.off[2 * (uint64_t)pair + m], o1 = a.off[2 * (uint64_t)pair + m + 1];
+    // Rows are taken at a fixed stride and fetched through a three-deep pipeline, so that a wave is (almost) always
+    // probing: while row `it` is looked up, the bytes of row it+S are in flight into registers, the offsets of row it+2S
+    // are being fetched, and the pair index of row it+3S.  All of these loads are unconditional (indices clamped to
+    // something valid) so that the compiler leaves them in flight.  Precondition kept by the host side: the batch
+    // buffer is readable up to seq_len rounded up to a multiple of 16.
+    const uint32_t S = x.nblocks();
+    auto surv_of = [&](uint32_t row) { return a.surv[a.t0 + ((row < nitems ? row : 0u) >> 1)]; };
+    uint32_t rw0 = 0, rw1 = 0;   // row `it`: dwords lane and 64 + lane of the read, from its 4-byte-aligned start
+    uint64_t o0C = 0, o1C = 0;   //           its offsets
+    uint64_t o0B = 0, o1B = 0;   // row it + S: offsets (in flight)
+    uint32_t pairA = 0;          // row it + 2S: pair index (in flight)
+    auto fetch_bytes = [&](uint64_t o0, uint64_t o1) {
+        uint32_t len = (uint32_t)(o1 - o0);
+        if (len > (uint32_t)MAXL) len = MAXL;
+        const uint64_t a0 = o0 & ~3ull;
+        const uint32_t nw = ((uint32_t)(o0 - a0) + len + 3) >> 2;
+        rw0 = *reinterpret_cast<const uint32_t*>(a.seq + ((uint32_t)lane < nw ? a0 + 4ull * lane : 0ull));
+        rw1 = *reinterpret_cast<const uint32_t*>(a.seq + (64u + lane < nw ? a0 + 4ull * (64 + lane) : 0ull));
+    };
+    auto fetch_offsets = [&](uint32_t pair, uint32_t row) {
+        const uint64_t r = 2 * (uint64_t)pair + (row & 1);
+        o0B = a.off[r]; o1B = a.off[r + 1];
+    };
+    {
+        const uint32_t it0 = x.bid();
+        if (it0 < nitems) {
+            fetch_offsets(x.uni(surv_of(it0)), it0);
+            o0C = o0B; o1C = o1B;
+            fetch_bytes(o0C, o1C);
+        }
+        if (it0 + S < nitems) fetch_offsets(x.uni(surv_of(it0 + S)), it0 + S);
+        pairA = surv_of(it0 + 2 * S);
+    }
+    for (uint32_t it = x.bid(); it < nitems; it += S) {  // `it` = hit-buffer row of (survivor, mate)
+        const uint64_t o0 = o0C, o1 = o1C;
         uint32_t len = (uint32_t)(o1 - o0);
         if (len > (uint32_t)MAXL) { *a.errflag = DBTK_ERR_READ_TOO_LONG; len = MAXL; }  // stay inside LDS
         const uint64_t a0 = o0 & ~3ull;
         const uint32_t rsh = (uint32_t)(o0 - a0), nw = (rsh + len + 3) >> 2;
         x.sync();  // previous read's LDS is dead
-        for (uint32_t w = lane; w < nw; w += 64) {
-            const uint64_t g = a0 + 4ull * w;
-            uint32_t v = 0;
-            if (g + 4 <= a.seq_len) v = *reinterpret_cast<const uint32_t*>(a.seq + g);
-            else for (int b = 0; b < 4; ++b) if (g + b < a.seq_len) v |= (uint32_t)a.seq[g + b] << (8 * b);
-            sm.raw[w] = v;
+        if ((uint32_t)lane < nw) sm.raw[lane] = rw0;
+        if (64u + lane < nw) sm.raw[64 + lane] = rw1;
+        {   // advance the pipeline: bytes of row it+S, offsets of row it+2S, pair index of row it+3S
+            const bool hasB = it + S < nitems, hasA = it + 2 * S < nitems;
+            o0C = hasB ? o0B : 0ull; o1C = hasB ? o1B : 0ull;
+            fetch_bytes(o0C, o1C);
+            fetch_offsets(hasA ? x.uni(pairA) : x.uni(pairA) * 0u, hasA ? it + 2 * S : 0u);
+            pairA = surv_of(it + 3 * S);
         }
         if (lane < 4) sm.raw[nw + lane] = 0;
         x.sync();
@@ -1213,6 +1257,7 @@ struct UsualSmem {
 
 template <int NS, bool RECS, class X>
 DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
+    uint64_t* const ctr = counters_of(x, a);
     constexpr int NSLOT = NS;
     UsualSmem& sm = *x.template smem<UsualSmem>();
     const int lane = x.lane();
@@ -1413,15 +1458,15 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
     if (ngb) flush_gen();
     DBTK_STAMP_FLUSH;
     if (lane == 0) {
-        if (c_qc) x.atomic_add(&a.counters[DBTK_C_QCFILTERED], c_qc);
-        if (c_thr) x.atomic_add(&a.counters[DBTK_C_THREADING], c_thr);
-        if (c_feas) x.atomic_add(&a.counters[DBTK_C_FEASIBLE], c_feas);
-        if (c_asgn) x.atomic_add(&a.counters[DBTK_C_ASGN], c_asgn);
-        if (c_cls) x.atomic_add(&a.counters[DBTK_C_ALGO_CLS], c_cls);
-        if (c_inc) x.atomic_add(&a.counters[DBTK_C_ALGO_INC], c_inc);
+        if (c_qc) x.atomic_add(&ctr[DBTK_C_QCFILTERED], c_qc);
+        if (c_thr) x.atomic_add(&ctr[DBTK_C_THREADING], c_thr);
+        if (c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], c_feas);
+        if (c_asgn) x.atomic_add(&ctr[DBTK_C_ASGN], c_asgn);
+        if (c_cls) x.atomic_add(&ctr[DBTK_C_ALGO_CLS], c_cls);
+        if (c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], c_inc);
         if (c_nhash1) {
-            x.atomic_add(&a.counters[DBTK_C_NHASH1], c_nhash1);
-            x.atomic_add(&a.counters[DBTK_C_ALGO_PROBES], c_nhash1);
+            x.atomic_add(&ctr[DBTK_C_NHASH1], c_nhash1);
+            x.atomic_add(&ctr[DBTK_C_ALGO_PROBES], c_nhash1);
         }
     }
 }
@@ -1429,6 +1474,7 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
 // ====================================================================== K3b =
 template <int NS, bool RECS, class X>
 DBTK_HD void body_pair(X& x, const BatchArgs& a) {
+    uint64_t* const ctr = counters_of(x, a);
     typedef PairSmemT<NS> Smem;
     constexpr int NSLOT = NS, NHMAX = Smem::NH, LCAP = Smem::LC;  // shadow the global upper bounds
     constexpr int EPL = 2 * NS;  // hit-list entries per lane
@@ -1974,19 +2020,19 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     }
     DBTK_STAMP_FLUSH;
     if (lane == 0) {
-        if (c_kf) x.atomic_add(&a.counters[DBTK_C_KMERFILTERED], c_kf);
-        if (c_hf) x.atomic_add(&a.counters[DBTK_C_LOCUSFILTERED], c_hf);
-        if (c_qc) x.atomic_add(&a.counters[DBTK_C_QCFILTERED], c_qc);
-        if (c_thr) x.atomic_add(&a.counters[DBTK_C_THREADING], c_thr);
-        if (c_feas) x.atomic_add(&a.counters[DBTK_C_FEASIBLE], c_feas);
-        if (c_asgn) x.atomic_add(&a.counters[DBTK_C_ASGN], c_asgn);
-        if (c_bait) x.atomic_add(&a.counters[DBTK_C_BAITFILTERED], c_bait);
-        if (c_vv) x.atomic_add(&a.counters[DBTK_C_ALGO_VV], c_vv);
-        if (c_cls) x.atomic_add(&a.counters[DBTK_C_ALGO_CLS], c_cls);
-        if (c_inc) x.atomic_add(&a.counters[DBTK_C_ALGO_INC], c_inc);
+        if (c_kf) x.atomic_add(&ctr[DBTK_C_KMERFILTERED], c_kf);
+        if (c_hf) x.atomic_add(&ctr[DBTK_C_LOCUSFILTERED], c_hf);
+        if (c_qc) x.atomic_add(&ctr[DBTK_C_QCFILTERED], c_qc);
+        if (c_thr) x.atomic_add(&ctr[DBTK_C_THREADING], c_thr);
+        if (c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], c_feas);
+        if (c_asgn) x.atomic_add(&ctr[DBTK_C_ASGN], c_asgn);
+        if (c_bait) x.atomic_add(&ctr[DBTK_C_BAITFILTERED], c_bait);
+        if (c_vv) x.atomic_add(&ctr[DBTK_C_ALGO_VV], c_vv);
+        if (c_cls) x.atomic_add(&ctr[DBTK_C_ALGO_CLS], c_cls);
+        if (c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], c_inc);
         if (c_nhash1) {
-            x.atomic_add(&a.counters[DBTK_C_NHASH1], c_nhash1);
-            x.atomic_add(&a.counters[DBTK_C_ALGO_PROBES], c_nhash1);
+            x.atomic_add(&ctr[DBTK_C_NHASH1], c_nhash1);
+            x.atomic_add(&ctr[DBTK_C_ALGO_PROBES], c_nhash1);
         }
     }
 }
