@@ -32,6 +32,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+PMC_SUMMARY = "r01d_buckets_pmc.csv"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -160,8 +161,19 @@ def main():
         per_kernel[name] = dict(avg_ms=avg, launches=n, algorithmic_bytes=per_launch,
                                 gbs=(per_launch / (avg * 1e-3) / 1e9) if avg > 0 else 0.0)
     dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"] * per_kernel[k]["launches"])
+    # HBM bytes per launch of the dominant kernel from the committed PMC summary of this same command (a separate
+    # rocprofv3 --pmc FETCH_SIZE pass, profiles/README.md), corrected as MI355X_MICROARCH.md prescribes for gfx950: a wide
+    # coalesced stream is reported at half its bytes, so half of the read bytes (the only such stream of K1) is added back.
+    traffic, traffic_src = None, None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_SUMMARY)
+    if dom == "k_encode_subfilter" and args.reads == 10_000_000 and abs(args.hit_frac - 0.02) < 1e-9 and os.path.exists(pmc):
+        for line in open(pmc):
+            f = line.strip().split(",")
+            if f[0] == dom and f[1] == "FETCH_SIZE":
+                traffic = float(f[3]) * 1024.0 + 0.5 * ctr[abi.C_BASES] / max(per_kernel[dom]["launches"], 1)
+                traffic_src = f"profiles/{PMC_SUMMARY}: FETCH_SIZE mean per launch (KB) x 1024 + half of the coalesced read stream"
     roof = dict(bound="hbm", kernel=dom, achieved=per_kernel[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=per_kernel[dom]["gbs"] / HBM_PEAK_GBS, traffic=None,
+                frac=per_kernel[dom]["gbs"] / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                 algorithmic_bytes_per_launch=per_kernel[dom]["algorithmic_bytes"], avg_ms=per_kernel[dom]["avg_ms"],
                 kernels=per_kernel)
 

@@ -190,7 +190,9 @@ dbtk_status_t dbtk_align_batch(dbtk_ctx_t* ctx, const uint8_t* seq_bytes,
 /* Device-resident variant used when the reads already sit in HBM (bench, or a
  * caller that overlaps its own H2D copies): d_seq / d_offsets are device
  * pointers with the same meaning, max_read_len the longest read in the batch.
- * Asynchronous on the context's stream; records are not produced. */
+ * d_seq must be 16-byte aligned and readable up to the end of the last read
+ * rounded up to a multiple of 16 (any hipMalloc'd buffer is).  Asynchronous on
+ * the context's stream; records are not produced. */
 dbtk_status_t dbtk_align_batch_device(dbtk_ctx_t* ctx, const void* d_seq, const void* d_offsets,
                                       uint64_t npairs, uint32_t max_read_len);
 dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* ctx);
