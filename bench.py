@@ -39,13 +39,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nloci", type=int, default=80000, help="loci of the synthetic RPGG (80000 = release scale)")
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (pairs = reads/2)")
     ap.add_argument("--hit-frac", type=float, default=0.02, help="fraction of pairs drawn from the loci (WGS-like: 0.02)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--parity-pairs", type=int, default=20000, help="pairs re-checked against the oracle (0 = skip)")
+    ap.add_argument("--lib", default=None, help="diagnostic: another build of libdbtk_hip.so (tuning variants)")
     args = ap.parse_args()
 
     import torch
@@ -64,7 +65,7 @@ def main():
     pkg = importlib.import_module("danbing-tk_amd")
     par = importlib.import_module("danbing-tk_amd.parallel")
     abi = pkg.abi
-    dbtk = pkg.Dbtk()  # raises if the HIP extension is missing: no CPU fallback
+    dbtk = pkg.Dbtk(args.lib) if args.lib else pkg.Dbtk()  # raises if the HIP extension is missing: no CPU fallback
     log = (lambda *a: print("[bench]", *a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
 
     # ---- workload: RPGG replica per GPU, read shard per rank
@@ -93,7 +94,17 @@ def main():
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     acc_ptr, acc_n = ctx.accum_buffer()
-    acc_t = torch.empty(acc_n, dtype=torch.int64, device=dev) if world > 1 else None
+    acc_t, acc_inplace = None, False
+    if world > 1:
+        try:  # a tensor over the context's accumulator itself: the reduce then needs no staging copies
+            class _Acc:
+                __cuda_array_interface__ = {"shape": (acc_n,), "typestr": "<i8", "data": (acc_ptr, False), "version": 2}
+            acc_t = torch.as_tensor(_Acc(), device=dev)
+            acc_inplace = acc_t.data_ptr() == acc_ptr
+        except Exception:
+            acc_inplace = False
+        if not acc_inplace:
+            acc_t = torch.empty(acc_n, dtype=torch.int64, device=dev)
 
     def barrier():
         if world > 1:
@@ -108,9 +119,11 @@ def main():
         if world == 1:
             return
         ctx.synchronize()
-        assert hip.hipMemcpy(acc_t.data_ptr(), acc_ptr, acc_n * 8, 3) == 0
+        if not acc_inplace:
+            assert hip.hipMemcpy(acc_t.data_ptr(), acc_ptr, acc_n * 8, 3) == 0
         par.allreduce_accum(acc_t)  # RCCL sum; int64 adds wrap exactly like the reference's uint64 atomics
-        assert hip.hipMemcpy(acc_ptr, acc_t.data_ptr(), acc_n * 8, 3) == 0
+        if not acc_inplace:
+            assert hip.hipMemcpy(acc_ptr, acc_t.data_ptr(), acc_n * 8, 3) == 0
 
     for _ in range(args.warmup):
         step()

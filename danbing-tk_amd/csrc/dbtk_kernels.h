@@ -956,6 +956,9 @@ DBTK_HD bool vote_parallel(X& x, const uint16_t* ord, const uint32_t* uval, cons
     return true;
 }
 
+#ifndef DBTK_K2_NB
+#define DBTK_K2_NB 4  // tuning knob of the probe kernel (variant builds: -DDBTK_K2_NB=n)
+#endif
 // ======================================================================= K2 =
 // kfilter's probes (src/aQueryFasta_thread.cpp:204-209, 215-220) as a kernel of
 // their own: one wavefront per surviving READ, tiny footprint (0.5 KB LDS), so
@@ -1131,7 +1134,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         HitVA* outv = a.hitva + (size_t)it * a.nkp;
         if (lane == 0) a.hitnk[it] = nk;
         const uint32_t sub = lane & 3, qd = lane >> 2;
-        constexpr int NB = 4;  // buckets in flight per lane
+        constexpr int NB = DBTK_K2_NB;  // buckets in flight per lane
         for (uint32_t i0 = 0; i0 < nk; i0 += 16 * NB) {
             uint32_t ii[NB], bq[NB];
             uint64_t kq[NB], a0[NB], a1[NB];

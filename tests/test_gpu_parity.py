@@ -164,3 +164,15 @@ def test_empty_and_degenerate_batches(dbtk, tmp_path):
         ctx.align(np.frombuffer(b"A" * 300 + b"C" * 10, np.uint8), np.array([0, 300, 310], np.uint64))
     assert e.value.status == abi.ERR_READ_TOO_LONG
     ctx.close()
+
+
+def test_accumulator_as_torch_tensor_and_rccl(tmp_path):
+    """bench.py reduces the accumulator in place: a torch tensor over the context's device buffer through RCCL (1 rank).
+    In a child process, torch imported first as in bench.py (its HIP runtime must be the one libdbtk_hip.so binds to)."""
+    import subprocess
+    import sys
+    c = make_case("clean", str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_torch_accum.py"), c.prefix, str(c.k)],
+                       capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517"))
+    assert r.returncode == 0 and "ACCUM-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
