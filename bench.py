@@ -46,6 +46,10 @@ def main():
     ap.add_argument("--hit-frac", type=float, default=0.02, help="fraction of pairs drawn from the loci (WGS-like: 0.02)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--parity-pairs", type=int, default=20000, help="pairs re-checked against the oracle (0 = skip)")
+    ap.add_argument("--lanes", type=int, default=1, choices=(1, 2),
+                    help="streams the context alternates successive batches on.  2 (the library's default) overlaps one batch's encode kernel "
+                         "with the other's probe kernel (+9 %% reads/s) but then a kernel's launch duration includes its neighbour's work, "
+                         "so the roofline measurement runs on one lane")
     ap.add_argument("--lib", default=None, help="diagnostic: another build of libdbtk_hip.so (tuning variants)")
     args = ap.parse_args()
 
@@ -62,6 +66,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
+    os.environ["DBTK_LANES"] = str(args.lanes)
     pkg = importlib.import_module("danbing-tk_amd")
     par = importlib.import_module("danbing-tk_amd.parallel")
     abi = pkg.abi
@@ -233,7 +238,7 @@ def main():
             "config": {"workload": f"release-scale synthetic RPGG ({args.nloci} loci, {arrs.nkeys} index keys, {g.ntrkmers} TR k-mers) "
                                    f"replicated per GPU; {args.reads} x 150bp PE reads per GPU per step, {args.hit_frac:.0%} of pairs from loci; "
                                    f"-k 21 -kf 4 1 -cth 45 -ka; RCCL all-reduce of counts at the end",
-                       "reads_per_gpu": args.reads, "read_len": rlen, "hit_frac": args.hit_frac, "k": 21, "cth": 45},
+                       "lanes": args.lanes, "reads_per_gpu": args.reads, "read_len": rlen, "hit_frac": args.hit_frac, "k": 21, "cth": 45},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(out), flush=True)

@@ -119,8 +119,8 @@ __global__ void __launch_bounds__(64) k_fold_counters(uint64_t* counters, uint64
     const uint32_t c = threadIdx.x;
     if (c >= DBTK_C_COUNT) return;
     uint64_t s = 0;
-    for (uint32_t r = 0; r < CTR_REP; ++r) { s += rep[(size_t)r * CTR_STRIDE + c]; rep[(size_t)r * CTR_STRIDE + c] = 0; }
-    counters[c] += s;
+    for (uint32_t r = 0; r < CTR_REP; ++r) s += atomicExch(reinterpret_cast<unsigned long long*>(&rep[(size_t)r * CTR_STRIDE + c]), 0ull);
+    if (s) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[c]), (unsigned long long)s);  // (the other lane may be folding too)
 }
 __global__ void __launch_bounds__(K1_NT) k_encode_subfilter(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) K1Smem sm;
@@ -212,6 +212,22 @@ struct dbtk_ctx {
     int pair_blocks[3] = {0, 0, 0}, usual_blocks[3] = {0, 0, 0}, num_cu = 0, max_pair_blocks = 0;
     uint32_t consistent = 0;
     Timed timed[NKERN];
+    // Second lane of the device-resident entry point: successive batches alternate between two streams, each with its own
+    // per-batch scratch, so that one batch's VALU-bound encode kernel overlaps the other's request-bound probe kernel
+    // (tables and accumulators are shared; the adds are atomic).  `alt` holds the lane that is not current.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        uint32_t* d_small = nullptr;
+        uint32_t* d_surv = nullptr; uint64_t surv_cap = 0;
+        uint64_t* d_hitkm = nullptr; uint64_t hitkm_cap = 0;
+        HitVA* d_hitva = nullptr; uint64_t hitva_cap = 0;
+        uint32_t* d_hitnk = nullptr; uint64_t hitnk_cap = 0;
+        uint32_t* d_gen = nullptr; uint64_t gen_cap = 0;
+        uint32_t* d_tickets = nullptr; uint64_t tickets_cap = 0;
+        uint64_t* d_vote = nullptr;
+        uint32_t* d_epoch = nullptr;
+    } alt;
+    bool two_lanes = false;
 };
 
 namespace {
@@ -235,6 +251,9 @@ void free_ctx(dbtk_ctx* c) {
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_gen, c->d_tickets,
                     c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    void* aptrs[] = {c->alt.d_small, c->alt.d_surv, c->alt.d_hitkm, c->alt.d_hitva, c->alt.d_hitnk, c->alt.d_gen, c->alt.d_tickets, c->alt.d_vote, c->alt.d_epoch};
+    for (void* p : aptrs) if (p) (void)hipFree(p);
+    if (c->alt.stream) (void)hipStreamDestroy(c->alt.stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -398,10 +417,25 @@ void fold_timer(Timed& t) {
     }
     t.used = 0;
 }
+void switch_lane(dbtk_ctx* c) {
+    std::swap(c->stream, c->alt.stream); std::swap(c->d_small, c->alt.d_small);
+    std::swap(c->d_surv, c->alt.d_surv); std::swap(c->surv_cap, c->alt.surv_cap);
+    std::swap(c->d_hitkm, c->alt.d_hitkm); std::swap(c->hitkm_cap, c->alt.hitkm_cap);
+    std::swap(c->d_hitva, c->alt.d_hitva); std::swap(c->hitva_cap, c->alt.hitva_cap);
+    std::swap(c->d_hitnk, c->alt.d_hitnk); std::swap(c->hitnk_cap, c->alt.hitnk_cap);
+    std::swap(c->d_gen, c->alt.d_gen); std::swap(c->gen_cap, c->alt.gen_cap);
+    std::swap(c->d_tickets, c->alt.d_tickets); std::swap(c->tickets_cap, c->alt.tickets_cap);
+    std::swap(c->d_vote, c->alt.d_vote); std::swap(c->d_epoch, c->alt.d_epoch);
+}
+hipError_t sync_all(dbtk_ctx* c) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && c->alt.stream) e = hipStreamSynchronize(c->alt.stream);
+    return e;
+}
 dbtk_status_t timed_slot(dbtk_ctx* c, int k, int* slot) {
     Timed& t = c->timed[k];
     if (t.used == EVPOOL) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(sync_all(c));
         for (int i = 0; i < NKERN; ++i) fold_timer(c->timed[i]);
     }
     *slot = t.used++;
@@ -597,6 +631,23 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         chk(hipMemsetAsync(c->d_accum, 0, c->n_accum * 8, c->stream), "memset");
         chk(hipMemsetAsync(c->d_vote, 0, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8, c->stream), "memset");
         chk(hipMemsetAsync(c->d_epoch, 0, (size_t)c->max_pair_blocks * 4, c->stream), "memset");
+        // the second lane (not with -bu: its event log is replayed batch by batch on the host; not in the stamps build)
+#ifndef DBTK_STAMPS
+        {   // DBTK_LANES=1|2 (default 2)
+            const char* e = getenv("DBTK_LANES");
+            c->two_lanes = !p->bubbles && !(e && atoi(e) == 1);
+        }
+#endif
+        if (c->two_lanes) {
+            chk(hipStreamCreate(&c->alt.stream), "hipStreamCreate");
+            chk(hipMalloc(&c->alt.d_small, 4 * SMALL_WORDS + 48 * 8), "hipMalloc small");
+            chk(hipMalloc(&c->alt.d_vote, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8), "hipMalloc vote scratch");
+            chk(hipMalloc(&c->alt.d_epoch, (size_t)c->max_pair_blocks * 4), "hipMalloc epoch");
+            if (st) break;
+            chk(hipMemsetAsync(c->alt.d_small, 0, 4 * SMALL_WORDS + 48 * 8, c->stream), "memset");
+            chk(hipMemsetAsync(c->alt.d_vote, 0, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8, c->stream), "memset");
+            chk(hipMemsetAsync(c->alt.d_epoch, 0, (size_t)c->max_pair_blocks * 4, c->stream), "memset");
+        }
         chk(hipStreamSynchronize(c->stream), "sync");
     } while (0);
     if (st) { free_ctx(c); return st; }
@@ -696,23 +747,25 @@ dbtk_status_t dbtk_align_batch_device(dbtk_ctx_t* c, const void* d_seq, const vo
     HIPCHK(hipSetDevice(c->device));
     // d_seq is 16-byte aligned and device allocations are page-granular, so the aligned 16-byte
     // chunk holding the last base is always readable: no byte-wise tail needed (seq_len = max).
+    if (c->two_lanes) switch_lane(c);  // successive batches alternate between the two streams
     return launch_batch(c, (const uint8_t*)d_seq, (const uint64_t*)d_offsets, ~0ull, npairs, max_read_len, nullptr, 0);
 }
 
 dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* c) {
     if (!c) { set_error("null argument"); return DBTK_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    uint32_t err = 0;
+    HIPCHK(sync_all(c));
+    uint32_t err = 0, err2 = 0;
     HIPCHK(hipMemcpy(&err, c->d_small + 3, 4, hipMemcpyDeviceToHost));
-    if (err) { set_error("device reported an over-long read"); return (dbtk_status_t)err; }
+    if (c->alt.d_small) HIPCHK(hipMemcpy(&err2, c->alt.d_small + 3, 4, hipMemcpyDeviceToHost));
+    if (err || err2) { set_error("device reported an over-long read"); return (dbtk_status_t)(err ? err : err2); }
     return DBTK_OK;
 }
 
 dbtk_status_t dbtk_ctx_counts(dbtk_ctx_t* c, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* counters) {
     if (!c) { set_error("null argument"); return DBTK_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     const uint64_t nloci = c->g->nloci;
     if (counts && c->ntr) HIPCHK(hipMemcpy(counts, c->d_accum, c->ntr * 8, hipMemcpyDeviceToHost));
     if (kmc && nloci) HIPCHK(hipMemcpy(kmc, c->d_accum + c->ntr, nloci * 8, hipMemcpyDeviceToHost));
@@ -735,8 +788,9 @@ dbtk_status_t dbtk_ctx_accum_buffer(dbtk_ctx_t* c, void** d_base, uint64_t* n_u6
 dbtk_status_t dbtk_ctx_reset(dbtk_ctx_t* c) {
     if (!c) { set_error("null argument"); return DBTK_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
+    HIPCHK(sync_all(c));
     HIPCHK(hipMemsetAsync(c->d_accum, 0, c->n_accum * 8, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     return DBTK_OK;
 }
 
@@ -776,7 +830,7 @@ dbtk_status_t dbtk_ctx_merge_bubbles(dbtk_ctx_t* dst, dbtk_ctx_t* src) {
 int dbtk_ctx_kernel_times(dbtk_ctx_t* c, const char** names, double* total_ms, uint64_t* launches, int cap) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     int n = 0;
     for (int i = 0; i < NKERN && n < cap; ++i) {
         fold_timer(c->timed[i]);
@@ -792,7 +846,7 @@ int dbtk_ctx_kernel_times(dbtk_ctx_t* c, const char** names, double* total_ms, u
 // diagnostic build only: the 16 per-phase cycle sums of k_pair since context creation
 int dbtk_debug_stamps(dbtk_ctx_t* c, uint64_t* out16) {
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     return (int)hipMemcpy(out16, c->d_small + 32, 48 * 8, hipMemcpyDeviceToHost);
 }
 #endif
@@ -804,7 +858,7 @@ void dbtk_ctx_timers_enable(dbtk_ctx_t* c, int on) {
 void dbtk_ctx_timers_reset(dbtk_ctx_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     for (int i = 0; i < NKERN; ++i) { c->timed[i].used = 0; c->timed[i].total_ms = 0; c->timed[i].launches = 0; }
 }
 
@@ -841,6 +895,7 @@ dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n) {
     int rc = groupStart();
     for (int i = 0; i < n && !rc; ++i) {
         (void)hipSetDevice(ctxs[i]->device);
+        (void)sync_all(ctxs[i]);
         rc = allReduce(ctxs[i]->d_accum, ctxs[i]->d_accum, ctxs[i]->n_accum, ncclUint64, ncclSum, comms[i], ctxs[i]->stream);
     }
     rc |= groupEnd();

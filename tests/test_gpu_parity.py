@@ -176,3 +176,39 @@ def test_accumulator_as_torch_tensor_and_rccl(tmp_path):
                        capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517"))
     assert r.returncode == 0 and "ACCUM-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_device_entry_alternating_lanes(dbtk, oracle, tmp_path, lanes, monkeypatch):
+    """dbtk_align_batch_device (reads resident in HBM, asynchronous): five batches, alternating between the context's two
+    streams when DBTK_LANES=2, must add up to five times the oracle's single-batch result."""
+    monkeypatch.setenv("DBTK_LANES", str(lanes))
+    c = make_case("mixed", str(tmp_path))
+    go = oracle.load(c.prefix, c.k, c.qc_file)
+    g = dbtk.load(c.prefix, c.k, c.qc_file)
+    seq, off = c.reads.packed()
+    p = abi.default_params(ksize=c.k, **dict(c.param_sets[0], okam=0))
+    o = oracle.align(go, p, seq, off, trace=False)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    d_seq, d_off = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_seq), len(seq) + 64) == 0 and hip.hipMalloc(C.byref(d_off), off.nbytes) == 0
+    assert hip.hipMemcpy(d_seq, seq.ctypes.data_as(C.c_void_p), len(seq), 1) == 0
+    assert hip.hipMemcpy(d_off, off.ctypes.data_as(C.c_void_p), off.nbytes, 1) == 0
+    ctx = dbtk.context(g, p)
+    maxlen = int(np.diff(off.astype(np.int64)).max())
+    for _ in range(5):
+        ctx.align_device(d_seq.value, d_off.value, c.reads.npairs, maxlen)
+    ctx.synchronize()
+    r = ctx.counts()
+    co = np.zeros(g.ntrkmers, np.uint64)
+    np.add.at(co, g.output_order().astype(np.int64), o["counts_file"])
+    assert (5 * co == r["counts"]).all()
+    assert (5 * o["kmc"] == r["kmc"]).all() and (5 * o["nmapread"].astype(np.uint64) == r["nmapread"]).all()
+    assert (5 * o["counters"] == r["counters"]).all(), (o["counters"], r["counters"])
+    ctx.close()
+    hip.hipFree(d_seq); hip.hipFree(d_off)
+    oracle.free(go)
+    g.close()
