@@ -9,6 +9,9 @@
 //   * reader + on-the-fly mate pairing            AQ.cpp:1918-1976 (critical section A)
 //   * kam / extracted-read writers                AQ.cpp:1618-1681 (critical section B)
 //   * totals, dumps                               AQ.cpp:2617-2656
+// Ingest: the three stages overlap — one thread parses and pairs (no per-line strings: spans of
+// the read buffer go straight into the batch's flat arrays), one thread per GPU aligns, the main thread formats and
+// writes the records in batch order.
 // New flags live under their own namespace: --gpus N (GPUs to use, default 1).
 // stderr is informational (the reference's also carries timings); stdout and the
 // output files are byte-compatible.
@@ -19,6 +22,11 @@
 #include <time.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -99,6 +107,17 @@ struct Reader {
             }
         }
     }
+    // the same line as a span of the buffer (valid until the next call)
+    bool getspan(const char** p, size_t* n) {
+        for (;;) {
+            const char* nl = (const char*)memchr(buf.data() + pos, '\n', end - pos);
+            if (nl) { *p = buf.data() + pos; *n = nl - (buf.data() + pos); pos = nl - buf.data() + 1; return true; }
+            if (!fill()) {
+                *p = buf.data() + pos; *n = end - pos; pos = end;
+                return *n != 0;
+            }
+        }
+    }
     bool at_eof() { return pos == end && !fill(); }  // in->peek() == EOF
 };
 
@@ -107,10 +126,37 @@ inline void prunePEinfo(std::string& title) {  // AQ.cpp:455-462
     if (len >= 2 && title[len - 2] == '/' && (title[len - 1] == '1' || title[len - 1] == '2')) title.resize(len - 2);
 }
 
-struct Batch {
-    std::vector<std::string> seqs, quals, titles;  // seqs[2p], seqs[2p+1]: pair p; titles[p]
-    std::vector<uint64_t> src;                     // simmode: source locus per pair
-    uint64_t nreads = 0;
+struct Batch {  // one batch on its way through the stages; read r = flat[off[r], off[r+1]); reads 2p, 2p+1 = pair p
+    uint64_t index = 0, nreads = 0, nReads_so_far = 0;
+    size_t nparked = 0;
+    std::vector<uint8_t> flat;  std::vector<uint64_t> off;   // sequences
+    std::vector<char> qar;      std::vector<uint64_t> qoff;  // qualities as read (FASTQ)
+    std::vector<char> tar;      std::vector<uint64_t> toff;  // pruned titles, one per pair
+    std::vector<uint64_t> src;                               // simmode: source locus per pair
+    std::vector<dbtk_pair_rec_t> recs;
+    uint64_t nrec = 0;
+    long gpu_sec = 0;
+    std::string title(uint64_t p) const { return std::string(tar.data() + toff[p], toff[p + 1] - toff[p]); }
+    void add_read(const char* sp, size_t sn, const char* qp, size_t qn, bool fq) {
+        flat.insert(flat.end(), sp, sp + sn); off.push_back(flat.size());
+        if (fq) { qar.insert(qar.end(), qp, qp + qn); qoff.push_back(qar.size()); }
+    }
+};
+
+// bounded hand-over between two stages
+template <class T>
+struct Chan {
+    std::mutex m; std::condition_variable cv;
+    std::deque<T> q; size_t cap = 4; bool closed = false;
+    void push(T v) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return q.size() < cap; }); q.push_back(std::move(v)); cv.notify_all(); }
+    bool pop(T& v) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !q.empty() || closed; });
+        if (q.empty()) return false;
+        v = std::move(q.front()); q.pop_front(); cv.notify_all();
+        return true;
+    }
+    void close() { std::lock_guard<std::mutex> l(m); closed = true; cv.notify_all(); }
 };
 
 uint64_t parse_src(const std::string& title, int simmode, uint64_t nloci) {
@@ -254,112 +300,174 @@ int main(int argc, char* argv[]) {
     for (int d = 0; d < o.ngpus; ++d)
         if (dbtk_ctx_create(rpgg, &P, d, &ctx[d])) die_assert(dbtk_last_error());
 
-    // ---- the batch loop (AQ.cpp:1869-2282): read a batch, align it on a GPU, write its records
+    // ---- the batch loop (AQ.cpp:1869-2282) as three overlapped stages: parse + pair | align (one thread per GPU) | write
     Reader in;
     in.f = fopen(o.fastxFname.c_str(), "rb");
     if (!in.f) die_assert("cannot open " + o.fastxFname);
-    in.buf.resize(8u << 20);
+    in.buf.resize(32u << 20);
     const uint64_t readsPerBatch = (uint64_t)(300000 * o.readsPerBatchFactor);
     const uint64_t minReadSize = (uint16_t)o.Cthreshold + o.ksize - 1;
-    std::unordered_map<std::string, std::pair<std::string, std::string>> parked;  // readDB / fqDB
     const bool want_recs = o.okam || o.extractFastX;
+    const bool fq = o.isFastq;
     uint64_t nReads = 0;
     time1 = time(nullptr);
     fprintf(stderr, "threads created\n");
-    int next_gpu = 0;
-    std::string out;  // stdout of one batch
-    std::vector<uint8_t> flat, flatq;
-    std::vector<uint64_t> off;
-    std::vector<dbtk_pair_rec_t> recs;
-    for (;;) {
-        if (in.at_eof()) break;
-        Batch b;
-        std::string title, seq1, qtitle, qual1, seq2, qual2;
-        while (b.nreads < readsPerBatch && !in.at_eof()) {
-            bool se = true;  // still single-ended
-            while (se) {
-                in.getline(title);
-                in.getline(seq1);
-                if (o.isFastq) { in.getline(qtitle); in.getline(qual1); }
-                prunePEinfo(title);
-                auto it = parked.find(title);
-                if (it != parked.end()) {
-                    if (seq1.size() < minReadSize || it->second.first.size() < minReadSize) { parked.erase(it); continue; }
-                    seq2 = std::move(it->second.first);
-                    qual2 = std::move(it->second.second);
-                    parked.erase(it);
-                    se = false;
-                    break;
+    typedef std::unique_ptr<Batch> BatchP;
+    Chan<BatchP> parsed, aligned;
+
+    // Stage A — reader + on-the-fly mate pairing (AQ.cpp:1918-1976).  The reference parks every record under its title in a
+    // map until a record with the same title arrives; here the most recently parked record is held outside the map, so
+    // that interleaved input (mates adjacent) never touches the map.  A record matches the held one first, then the map —
+    // the held one is by construction the latest record parked under its title, so the outcome is the reference's.
+    std::thread parser([&] {
+        std::unordered_map<std::string, std::pair<std::string, std::string>> parked;  // readDB / fqDB
+        std::string held_title, held_seq, held_qual, key, cur_seq;
+        bool held = false;
+        uint64_t index = 0;
+        for (;;) {
+            if (in.at_eof()) break;
+            BatchP b(new Batch);
+            b->off.push_back(0); b->qoff.push_back(0); b->toff.push_back(0);
+            while (b->nreads < readsPerBatch && !in.at_eof()) {
+                const char *tp, *sp, *qp = nullptr, *xp;
+                size_t tn, sn, qn = 0, xn;
+                // the reference issues these getlines unconditionally: past the end they yield empty strings
+                in.getspan(&tp, &tn);
+                key.assign(tp, tn);  // (the span dies with the next getspan)
+                prunePEinfo(key);
+                in.getspan(&sp, &sn);
+                if (fq) {  // two more lines follow: keep the sequence while the buffer may move
+                    cur_seq.assign(sp, sn);
+                    in.getspan(&xp, &xn);
+                    in.getspan(&qp, &qn);
+                    sp = cur_seq.data(); sn = cur_seq.size();
                 }
-                parked[title] = std::make_pair(seq1, qual1);
-                if (in.at_eof()) break;
-            }
-            if (se) break;  // input exhausted with this record unpaired (FASTA: AQ.cpp:1967)
-            if (o.simmode) b.src.push_back(parse_src(title, o.simmode, nloci));
-            b.titles.push_back(title);
-            b.seqs.push_back(seq1); b.seqs.push_back(seq2);
-            if (o.isFastq) { b.quals.push_back(qual1); b.quals.push_back(qual2); }
-            b.nreads += 2;
-        }
-        nReads += b.nreads;
-        fprintf(stderr, "Buffered reading %llu\t%llu\t%zu\n", (unsigned long long)b.nreads, (unsigned long long)nReads, parked.size());
-        if (b.nreads == 0) continue;
-        const time_t time2 = time(nullptr);
-        // flatten: read r = flat[off[r] .. off[r+1])
-        off.assign(b.nreads + 1, 0);
-        for (uint64_t r = 0; r < b.nreads; ++r) off[r + 1] = off[r] + b.seqs[r].size();
-        flat.resize(off[b.nreads] + 1);
-        for (uint64_t r = 0; r < b.nreads; ++r) memcpy(flat.data() + off[r], b.seqs[r].data(), b.seqs[r].size());
-        const bool send_qual = use_bait && o.isFastq;
-        if (send_qual) {  // qualities feed qString2qMask (AQ.cpp:2104-2107); a quality string is as long as its read
-            flatq.assign(off[b.nreads] + 1, (uint8_t)'!');
-            for (uint64_t r = 0; r < b.nreads; ++r) memcpy(flatq.data() + off[r], b.quals[r].data(), std::min(b.quals[r].size(), b.seqs[r].size()));
-        }
-        const uint64_t npairs = b.nreads / 2;
-        if (want_recs) recs.resize(npairs);
-        uint64_t nrec = 0;
-        dbtk_ctx_t* c = ctx[next_gpu];
-        next_gpu = (next_gpu + 1) % o.ngpus;
-        const dbtk_status_t st = dbtk_align_batch(c, flat.data(), off.data(), send_qual ? flatq.data() : nullptr, npairs,
-                                                  want_recs ? recs.data() : nullptr, want_recs ? npairs : 0, &nrec);
-        if (st) die_assert(std::string("align: ") + dbtk_last_error());
-        // ---- critical section B: stdout
-        out.clear();
-        for (uint64_t i = 0; i < nrec; ++i) {
-            const dbtk_pair_rec_t& r = recs[i];
-            const uint64_t p = r.pair;
-            if (o.extractFastX) {  // writeExtractedReads, AQ.cpp:1618-1644: mate 2p+1 first, then 2p
-                for (int which = 1; which >= 0; --which) {
-                    out += b.titles[p];
-                    if (o.extractFastX != 1) { out += ':'; out += std::to_string(r.dst); }
-                    out += '\n'; out += b.seqs[2 * p + which]; out += '\n';
-                    if (o.isFastq) { out += "+\n"; out += b.quals[2 * p + which]; out += '\n'; }
+                const char *s2p = nullptr, *q2p = nullptr;
+                size_t s2n = 0, q2n = 0;
+                bool matched = false;
+                std::pair<std::string, std::string> from_map;
+                if (held && held_title == key) {
+                    s2p = held_seq.data(); s2n = held_seq.size(); q2p = held_qual.data(); q2n = held_qual.size();
+                    held = false;
+                    matched = true;
+                } else if (!parked.empty()) {
+                    auto it = parked.find(key);
+                    if (it != parked.end()) {
+                        from_map = std::move(it->second);
+                        parked.erase(it);
+                        s2p = from_map.first.data(); s2n = from_map.first.size(); q2p = from_map.second.data(); q2n = from_map.second.size();
+                        matched = true;
+                    }
                 }
-                continue;
+                if (!matched) {  // park this record; the previously held one moves into the map
+                    if (held) parked[held_title] = std::make_pair(held_seq, held_qual);
+                    held_title = key; held_seq.assign(sp, sn); held_qual.assign(qp ? qp : "", qn);
+                    held = true;
+                    if (in.at_eof()) break;
+                    continue;
+                }
+                if (sn < minReadSize || s2n < minReadSize) continue;  // AQ.cpp:1940-1943: the pair is dropped
+                if (o.simmode) b->src.push_back(parse_src(key, o.simmode, nloci));
+                b->tar.insert(b->tar.end(), key.begin(), key.end()); b->toff.push_back(b->tar.size());
+                b->add_read(sp, sn, qp, qn, fq);      // seqs[2p]: the record that completed the pair
+                b->add_read(s2p, s2n, q2p, q2n, fq);  // seqs[2p+1]: the parked one
+                b->nreads += 2;
             }
-            const uint64_t src = o.simmode ? b.src[p] : ~0ull;
-            const bool src_ok = src != nloci && src != ~0ull;
-            if (!(src_ok || r.dst != nloci)) continue;  // AQ.cpp:2169
-            out += (src == ~0ull ? std::string(".") : std::to_string((int)src)); out += '\t';
-            out += std::to_string(r.dst); out += '\t';
-            out += std::to_string(r.dst != r.dst0 ? (int)r.dst0 : -1); out += '\t';
-            out += std::to_string(r.r2.ei - r.r2.si); out += '\t';
-            out += std::to_string(r.r1.ei - r.r1.si); out += '\t';
-            out += "kf:hf:bf:qf:af:rm:qn:qm:si:nt:bs:ti\t";
-            mate_fields(out, r.r2); out += '\t';
-            mate_fields(out, r.r1); out += '\t';
-            out += annot2str(r.r2); out += '\t';
-            out += annot2str(r.r1); out += '\t';
-            out += b.titles[p].substr(1); out += '\t';
-            out += b.seqs[2 * p + 1]; out += '\t';
-            out += o.isFastq ? b.quals[2 * p + 1] : std::string("."); out += '\t';
-            out += b.seqs[2 * p]; out += '\t';
-            out += o.isFastq ? b.quals[2 * p] : std::string("."); out += '\n';
+            nReads += b->nreads;
+            b->nReads_so_far = nReads;
+            b->nparked = parked.size() + (held ? 1 : 0);
+            fprintf(stderr, "Buffered reading %llu\t%llu\t%zu\n", (unsigned long long)b->nreads, (unsigned long long)nReads, b->nparked);
+            if (b->nreads == 0) continue;
+            b->index = index++;
+            parsed.push(std::move(b));
         }
-        if (!out.empty()) fwrite(out.data(), 1, out.size(), stdout);
-        fprintf(stderr, "Batch query in %ld sec. %llu pairs, %llu records\n", (long)(time(nullptr) - time2), (unsigned long long)npairs,
-                (unsigned long long)nrec);
+        parsed.close();
+    });
+
+    // Stage B — one thread per GPU: the batch through the hot path (replaces AQ.cpp:1988-2249)
+    std::vector<std::thread> workers;
+    std::mutex done_m;
+    int workers_left = o.ngpus;
+    for (int d = 0; d < o.ngpus; ++d)
+        workers.emplace_back([&, d] {
+            BatchP b;
+            std::vector<uint8_t> flatq;
+            while (parsed.pop(b)) {
+                const time_t t2 = time(nullptr);
+                const uint64_t npairs = b->nreads / 2;
+                const bool send_qual = use_bait && fq;
+                if (send_qual) {  // qualities feed qString2qMask (AQ.cpp:2104-2107); a quality string is as long as its read
+                    flatq.assign(b->flat.size() + 1, (uint8_t)'!');
+                    for (uint64_t r = 0; r < b->nreads; ++r)
+                        memcpy(flatq.data() + b->off[r], b->qar.data() + b->qoff[r], std::min(b->qoff[r + 1] - b->qoff[r], b->off[r + 1] - b->off[r]));
+                }
+                if (want_recs) b->recs.resize(npairs);
+                b->flat.push_back(0);
+                const dbtk_status_t st = dbtk_align_batch(ctx[d], b->flat.data(), b->off.data(), send_qual ? flatq.data() : nullptr, npairs,
+                                                          want_recs ? b->recs.data() : nullptr, want_recs ? npairs : 0, &b->nrec);
+                if (st) die_assert(std::string("align: ") + dbtk_last_error());
+                b->gpu_sec = (long)(time(nullptr) - t2);
+                aligned.push(std::move(b));
+            }
+            std::lock_guard<std::mutex> l(done_m);
+            if (--workers_left == 0) aligned.close();
+        });
+
+    // Stage C — critical section B (AQ.cpp:2253-2279): stdout, in batch order
+    {
+        std::map<uint64_t, BatchP> waiting;
+        uint64_t next = 0;
+        std::string out;
+        BatchP got;
+        auto emit = [&](const Batch& b) {
+            out.clear();
+            auto seq = [&](uint64_t r) { return std::string((const char*)b.flat.data() + b.off[r], b.off[r + 1] - b.off[r]); };
+            auto qual = [&](uint64_t r) { return std::string(b.qar.data() + b.qoff[r], b.qoff[r + 1] - b.qoff[r]); };
+            for (uint64_t i = 0; i < b.nrec; ++i) {
+                const dbtk_pair_rec_t& r = b.recs[i];
+                const uint64_t p = r.pair;
+                if (o.extractFastX) {  // writeExtractedReads, AQ.cpp:1618-1644: mate 2p+1 first, then 2p
+                    for (int which = 1; which >= 0; --which) {
+                        out += b.title(p);
+                        if (o.extractFastX != 1) { out += ':'; out += std::to_string(r.dst); }
+                        out += '\n'; out += seq(2 * p + which); out += '\n';
+                        if (fq) { out += "+\n"; out += qual(2 * p + which); out += '\n'; }
+                    }
+                    continue;
+                }
+                const uint64_t src = o.simmode ? b.src[p] : ~0ull;
+                const bool src_ok = src != nloci && src != ~0ull;
+                if (!(src_ok || r.dst != nloci)) continue;  // AQ.cpp:2169
+                out += (src == ~0ull ? std::string(".") : std::to_string((int)src)); out += '\t';
+                out += std::to_string(r.dst); out += '\t';
+                out += std::to_string(r.dst != r.dst0 ? (int)r.dst0 : -1); out += '\t';
+                out += std::to_string(r.r2.ei - r.r2.si); out += '\t';
+                out += std::to_string(r.r1.ei - r.r1.si); out += '\t';
+                out += "kf:hf:bf:qf:af:rm:qn:qm:si:nt:bs:ti\t";
+                mate_fields(out, r.r2); out += '\t';
+                mate_fields(out, r.r1); out += '\t';
+                out += annot2str(r.r2); out += '\t';
+                out += annot2str(r.r1); out += '\t';
+                out += b.title(p).substr(1); out += '\t';
+                out += seq(2 * p + 1); out += '\t';
+                out += fq ? qual(2 * p + 1) : std::string("."); out += '\t';
+                out += seq(2 * p); out += '\t';
+                out += fq ? qual(2 * p) : std::string("."); out += '\n';
+            }
+            if (!out.empty()) fwrite(out.data(), 1, out.size(), stdout);
+            fprintf(stderr, "Batch query in %ld sec. %llu pairs, %llu records\n", b.gpu_sec, (unsigned long long)(b.nreads / 2), (unsigned long long)b.nrec);
+        };
+        while (aligned.pop(got)) {
+            waiting[got->index] = std::move(got);
+            for (auto it = waiting.find(next); it != waiting.end(); it = waiting.find(next)) {
+                emit(*it->second);
+                waiting.erase(it);
+                ++next;
+            }
+        }
     }
+    parser.join();
+    for (auto& w : workers) w.join();
     fclose(in.f);
     fflush(stdout);
 

@@ -115,10 +115,27 @@ def test_cli_vs_reference_binary_live(tmp_path):
         for which, tag in ((1, b"/2"), (0, b"/1")):
             for p in range(reads.npairs):
                 f.write(b"@" + reads.titles[p].encode() + tag + b"\n" + reads.seqs[2 * p + which] + b"\n+\n" + reads.quals[2 * p + which] + b"\n")
-    for flags in (["-cth", "45"], ["-cth", "20", "-kf", "8", "2", "-r", "0.01"], ["-e", "1"], ["-gc", "85", "3"]):
+    # mates adjacent (the parser's held-record path), many small batches, with singletons, a triple and a late straggler mixed in
+    with open(os.path.join(d, "r.fa"), "wb") as f:
+        for p in range(reads.npairs):
+            t = b">" + reads.titles[p].encode()
+            if p % 97 == 5:
+                f.write(t + b"/1\n" + reads.seqs[2 * p] + b"\n")                      # singleton: stays parked
+                continue
+            f.write(t + b"/1\n" + reads.seqs[2 * p] + b"\n" + t + b"/2\n" + reads.seqs[2 * p + 1] + b"\n")
+            if p % 131 == 7:
+                f.write(t + b"/1\n" + reads.seqs[2 * p] + b"\n")                      # third record of a title: parked again
+            if p % 211 == 9 and p > 300:
+                q = p - 300 + (5 - (p - 300) % 97) % 97                                  # a singleton seen long ago finds its mate
+                if q % 97 == 5 and q < p:
+                    f.write(b">" + reads.titles[q].encode() + b"/2\n" + reads.seqs[2 * q + 1] + b"\n")
+    for flags in (["-cth", "45"], ["-cth", "20", "-kf", "8", "2", "-r", "0.01"], ["-e", "1"], ["-gc", "85", "3"], ["-cth", "30", "-r", "0.004", "FA"]):
         outs = []
+        fa = flags[-1] == "FA"
+        if fa:
+            flags = flags[:-1]
         for exe, tag in ((synth.ref_tool("danbing-tk"), "ref"), (CLI, "hip")):
-            a = ["-k", "21"] + flags + ["-fq", "r.fq", "-qs", "pan", "-o", tag]
+            a = ["-k", "21"] + flags + (["-fa", "r.fa"] if fa else ["-fq", "r.fq"]) + ["-qs", "pan", "-o", tag]
             r = subprocess.run([exe] + a, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert r.returncode == 0, r.stderr.decode()[-1000:]
             outs.append(r.stdout)
