@@ -304,7 +304,6 @@ int main(int argc, char* argv[]) {
     Reader in;
     in.f = fopen(o.fastxFname.c_str(), "rb");
     if (!in.f) die_assert("cannot open " + o.fastxFname);
-    in.buf.resize(32u << 20);
     const uint64_t readsPerBatch = (uint64_t)(300000 * o.readsPerBatchFactor);
     const uint64_t minReadSize = (uint16_t)o.Cthreshold + o.ksize - 1;
     const bool want_recs = o.okam || o.extractFastX;
@@ -314,43 +313,143 @@ int main(int argc, char* argv[]) {
     fprintf(stderr, "threads created\n");
     typedef std::unique_ptr<Batch> BatchP;
     Chan<BatchP> parsed, aligned;
+    auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
+    const double loop_t0 = now();
+    double pair_busy = 0, gpu_busy = 0, write_busy = 0;  // seconds each stage spent working (not waiting)
 
-    // Stage A — reader + on-the-fly mate pairing (AQ.cpp:1918-1976).  The reference parks every record under its title in a
-    // map until a record with the same title arrives; here the most recently parked record is held outside the map, so
-    // that interleaved input (mates adjacent) never touches the map.  A record matches the held one first, then the map —
-    // the held one is by construction the latest record parked under its title, so the outcome is the reference's.
+    // Stage A — reader, line splitters, on-the-fly mate pairing (AQ.cpp:1918-1976), all overlapped:
+    //   A0 (1 thread)  reads the file in large blocks cut at record boundaries (2 lines per FASTA record, 4 per FASTQ: the
+    //                  newline count of a block tells where its last whole record ends);
+    //   A1 (n threads) split a block into records: spans (offset, length) of title / sequence / quality, nothing copied;
+    //   A2 (1 thread)  takes the blocks back in file order and pairs.  The reference parks every record under its title in a
+    //                  map until a record with the same title arrives; here the most recently parked record is held outside
+    //                  the map, so that interleaved input (mates adjacent) never touches the map.  A record matches the held
+    //                  one first, then the map — the held one is by construction the latest record parked under its title,
+    //                  so the outcome is the reference's.  Paired reads are copied once, into the batch's flat arrays.
+    struct Rec { uint32_t t, tn, s, sn, q, qn; };
+    struct Block { uint64_t index = 0; std::vector<char> data; size_t len = 0; std::vector<Rec> recs; };
+    typedef std::unique_ptr<Block> BlockP;
+    Chan<BlockP> raw, split;
+    const unsigned hw = std::max(4u, std::thread::hardware_concurrency());
+    const int nsplit = (int)std::min(16u, std::max(2u, hw / 8));
+    raw.cap = split.cap = 2 * (size_t)nsplit;
+    const size_t L = fq ? 4 : 2;
+    std::thread reader([&] {
+        const size_t BLK = 32u << 20;
+        std::vector<char> carry;
+        uint64_t index = 0;
+        bool eof = false;
+        while (!eof) {
+            BlockP b(new Block);
+            b->data.resize(carry.size() + BLK);
+            memcpy(b->data.data(), carry.data(), carry.size());
+            size_t end = carry.size();
+            carry.clear();
+            size_t cut = 0;
+            for (;;) {
+                const size_t n = fread(b->data.data() + end, 1, b->data.size() - end, in.f);
+                end += n;
+                if (n == 0) { eof = true; cut = end; break; }
+                // whole records in [0, end): the first floor(newlines / L) * L lines
+                const size_t nl = (size_t)std::count(b->data.data(), b->data.data() + end, '\n');
+                if (nl >= L) {
+                    size_t drop = nl % L;  // trailing whole lines that start an unfinished record
+                    const char* p = (const char*)memrchr(b->data.data(), '\n', end);
+                    while (drop--) p = (const char*)memrchr(b->data.data(), '\n', p - b->data.data());
+                    cut = p - b->data.data() + 1;
+                    break;
+                }
+                b->data.resize(b->data.size() + BLK);  // a record longer than the block: read on
+            }
+            carry.assign(b->data.data() + cut, b->data.data() + end);
+            b->len = cut;
+            if (b->len == 0) continue;
+            if (b->len >= 0xFFFFFFFFull) die_assert("input block too large");
+            b->index = index++;
+            raw.push(std::move(b));
+        }
+        raw.close();
+    });
+    std::vector<std::thread> splitters;
+    std::mutex split_m;
+    int splitters_left = nsplit;
+    for (int w = 0; w < nsplit; ++w)
+        splitters.emplace_back([&] {
+            BlockP b;
+            while (raw.pop(b)) {
+                const char* d0 = b->data.data();
+                const size_t len = b->len;
+                size_t pos = 0;
+                b->recs.reserve(len / 300 + 16);
+                auto line = [&](uint32_t* o, uint32_t* n) {  // std::getline: the rest of the data when no newline is left
+                    if (pos >= len) { *o = (uint32_t)len; *n = 0; return; }
+                    const char* nlp = (const char*)memchr(d0 + pos, '\n', len - pos);
+                    const size_t e = nlp ? (size_t)(nlp - d0) : len;
+                    *o = (uint32_t)pos; *n = (uint32_t)(e - pos);
+                    pos = nlp ? e + 1 : len;
+                };
+                while (pos < len) {
+                    Rec r{0, 0, 0, 0, 0, 0};
+                    uint32_t xo, xn;
+                    line(&r.t, &r.tn);
+                    line(&r.s, &r.sn);
+                    if (fq) { line(&xo, &xn); line(&r.q, &r.qn); }
+                    // prunePEinfo, AQ.cpp:455-462
+                    if (r.tn >= 2 && d0[r.t + r.tn - 2] == '/' && (d0[r.t + r.tn - 1] == '1' || d0[r.t + r.tn - 1] == '2')) r.tn -= 2;
+                    b->recs.push_back(r);
+                }
+                split.push(std::move(b));
+            }
+            std::lock_guard<std::mutex> l(split_m);
+            if (--splitters_left == 0) split.close();
+        });
     std::thread parser([&] {
         std::unordered_map<std::string, std::pair<std::string, std::string>> parked;  // readDB / fqDB
-        std::string held_title, held_seq, held_qual, key, cur_seq;
+        std::string held_title, held_seq, held_qual, key;
         bool held = false;
-        uint64_t index = 0;
+        uint64_t index = 0, next_block = 0;
+        std::map<uint64_t, BlockP> waiting;
+        BlockP blk;          // the block being consumed
+        size_t ri = 0;       // next record of it
+        bool drained = false;
+        auto have_record = [&]() -> bool {  // !in.at_eof()
+            for (;;) {
+                if (blk && ri < blk->recs.size()) return true;
+                blk.reset();
+                auto it = waiting.find(next_block);
+                while (it == waiting.end() && !drained) {
+                    BlockP got;
+                    if (!split.pop(got)) { drained = true; break; }
+                    waiting[got->index] = std::move(got);
+                    it = waiting.find(next_block);
+                }
+                if (it == waiting.end()) return false;
+                blk = std::move(it->second);
+                waiting.erase(it);
+                ++next_block;
+                ri = 0;
+            }
+        };
         for (;;) {
-            if (in.at_eof()) break;
+            if (!have_record()) break;
             BatchP b(new Batch);
             b->off.push_back(0); b->qoff.push_back(0); b->toff.push_back(0);
-            while (b->nreads < readsPerBatch && !in.at_eof()) {
-                const char *tp, *sp, *qp = nullptr, *xp;
-                size_t tn, sn, qn = 0, xn;
-                // the reference issues these getlines unconditionally: past the end they yield empty strings
-                in.getspan(&tp, &tn);
-                key.assign(tp, tn);  // (the span dies with the next getspan)
-                prunePEinfo(key);
-                in.getspan(&sp, &sn);
-                if (fq) {  // two more lines follow: keep the sequence while the buffer may move
-                    cur_seq.assign(sp, sn);
-                    in.getspan(&xp, &xn);
-                    in.getspan(&qp, &qn);
-                    sp = cur_seq.data(); sn = cur_seq.size();
-                }
+            double tb = now();
+            while (b->nreads < readsPerBatch && have_record()) {
+                const Rec& r = blk->recs[ri++];
+                const char* d0 = blk->data.data();
+                const char *tp = d0 + r.t, *sp = d0 + r.s, *qp = d0 + r.q;
+                const size_t tn = r.tn, sn = r.sn, qn = r.qn;
                 const char *s2p = nullptr, *q2p = nullptr;
                 size_t s2n = 0, q2n = 0;
                 bool matched = false;
                 std::pair<std::string, std::string> from_map;
-                if (held && held_title == key) {
+                if (held && held_title.size() == tn && memcmp(held_title.data(), tp, tn) == 0) {
                     s2p = held_seq.data(); s2n = held_seq.size(); q2p = held_qual.data(); q2n = held_qual.size();
                     held = false;
                     matched = true;
                 } else if (!parked.empty()) {
+                    key.assign(tp, tn);
                     auto it = parked.find(key);
                     if (it != parked.end()) {
                         from_map = std::move(it->second);
@@ -361,18 +460,19 @@ int main(int argc, char* argv[]) {
                 }
                 if (!matched) {  // park this record; the previously held one moves into the map
                     if (held) parked[held_title] = std::make_pair(held_seq, held_qual);
-                    held_title = key; held_seq.assign(sp, sn); held_qual.assign(qp ? qp : "", qn);
+                    held_title.assign(tp, tn); held_seq.assign(sp, sn); held_qual.assign(qp, qn);
                     held = true;
-                    if (in.at_eof()) break;
+                    if (!have_record()) break;
                     continue;
                 }
                 if (sn < minReadSize || s2n < minReadSize) continue;  // AQ.cpp:1940-1943: the pair is dropped
-                if (o.simmode) b->src.push_back(parse_src(key, o.simmode, nloci));
-                b->tar.insert(b->tar.end(), key.begin(), key.end()); b->toff.push_back(b->tar.size());
+                if (o.simmode) b->src.push_back(parse_src(std::string(tp, tn), o.simmode, nloci));
+                b->tar.insert(b->tar.end(), tp, tp + tn); b->toff.push_back(b->tar.size());
                 b->add_read(sp, sn, qp, qn, fq);      // seqs[2p]: the record that completed the pair
                 b->add_read(s2p, s2n, q2p, q2n, fq);  // seqs[2p+1]: the parked one
                 b->nreads += 2;
             }
+            pair_busy += now() - tb;  // (includes waiting for the splitters when they are the slower stage)
             nReads += b->nreads;
             b->nReads_so_far = nReads;
             b->nparked = parked.size() + (held ? 1 : 0);
@@ -394,6 +494,7 @@ int main(int argc, char* argv[]) {
             std::vector<uint8_t> flatq;
             while (parsed.pop(b)) {
                 const time_t t2 = time(nullptr);
+                const double tg = now();
                 const uint64_t npairs = b->nreads / 2;
                 const bool send_qual = use_bait && fq;
                 if (send_qual) {  // qualities feed qString2qMask (AQ.cpp:2104-2107); a quality string is as long as its read
@@ -407,6 +508,7 @@ int main(int argc, char* argv[]) {
                                                           want_recs ? b->recs.data() : nullptr, want_recs ? npairs : 0, &b->nrec);
                 if (st) die_assert(std::string("align: ") + dbtk_last_error());
                 b->gpu_sec = (long)(time(nullptr) - t2);
+                { std::lock_guard<std::mutex> l(done_m); gpu_busy += now() - tg; }
                 aligned.push(std::move(b));
             }
             std::lock_guard<std::mutex> l(done_m);
@@ -460,16 +562,22 @@ int main(int argc, char* argv[]) {
         while (aligned.pop(got)) {
             waiting[got->index] = std::move(got);
             for (auto it = waiting.find(next); it != waiting.end(); it = waiting.find(next)) {
+                const double tw = now();
                 emit(*it->second);
+                write_busy += now() - tw;
                 waiting.erase(it);
                 ++next;
             }
         }
     }
+    reader.join();
+    for (auto& w : splitters) w.join();
     parser.join();
     for (auto& w : workers) w.join();
     fclose(in.f);
     fflush(stdout);
+    fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads\n",
+            now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit);
 
     // ---- totals + dumps (AQ.cpp:2611-2656)
     if (o.ngpus > 1 && dbtk_allreduce(ctx.data(), o.ngpus)) die_assert(dbtk_last_error());
