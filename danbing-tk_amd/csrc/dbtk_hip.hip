@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(256) k_fill_idx(IdxBucket* b, uint64_t nslots)
     }
 }
 __global__ void __launch_bounds__(256) k_idx_insert(IdxBuildArgs a) { DevX x{nullptr}; body_idx_insert(x, a); }
+__global__ void __launch_bounds__(256) k_flt_insert(FltBuildArgs a) { DevX x{nullptr}; body_flt_insert(x, a); }
 __global__ void __launch_bounds__(256) k_idx_finalize(IdxBucket* b, uint64_t nslots) { DevX x{nullptr}; body_idx_finalize(x, b, nslots); }
 __global__ void __launch_bounds__(256) k_cls_insert(ClsBuildArgs a) { DevX x{nullptr}; body_cls_insert(x, a); }
 __global__ void __launch_bounds__(256) k_idx_aux(IdxAuxArgs a) { DevX x{nullptr}; body_idx_aux(x, a); }
@@ -177,6 +178,7 @@ struct dbtk_ctx {
     DevTables T;
     // device allocations
     IdxBucket* d_idx = nullptr;
+    uint64_t* d_flt = nullptr; uint64_t flt_words = 0;
     uint32_t* d_trbeg = nullptr;
     ClsSlot* d_cls = nullptr;
     uint32_t* d_vv = nullptr;
@@ -247,7 +249,7 @@ void free_ctx(dbtk_ctx* c) {
             if (c->timed[i].beg[j]) (void)hipEventDestroy(c->timed[i].beg[j]);
             if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
         }
-    void* ptrs[] = {c->d_ctr, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
+    void* ptrs[] = {c->d_flt, c->d_ctr, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_gen, c->d_tickets,
                     c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -279,6 +281,17 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         HIPCHK(hipMemcpyAsync(dv, g->vals.data(), nkeys * 4, hipMemcpyHostToDevice, s));
         IdxBuildArgs a{c->d_idx, nbkt - 1, 64 - log2u(nbkt), dk, dv, nkeys};
         hipLaunchKernelGGL(k_idx_insert, dim3(2048), dim3(256), 0, s, a);
+        {   // presence filter: DBTK_FILTER_BPK bits per key (default 4, 0 = none), rounded up to a power of two of words
+            uint64_t bpk = 4;
+            if (const char* e = getenv("DBTK_FILTER_BPK")) { const long v = atol(e); if (v >= 0 && v <= 64) bpk = (uint64_t)v; }
+            if (bpk) {
+                c->flt_words = pow2_at_least((bpk * nkeys + 63) / 64);
+                HIPCHK(hipMalloc(&c->d_flt, c->flt_words * 8));
+                HIPCHK(hipMemsetAsync(c->d_flt, 0, c->flt_words * 8, s));
+                FltBuildArgs fa{c->d_flt, c->flt_words - 1, dk, nkeys};
+                hipLaunchKernelGGL(k_flt_insert, dim3(2048), dim3(256), 0, s, fa);
+            }
+        }
         hipLaunchKernelGGL(k_idx_finalize, dim3(2048), dim3(256), 0, s, c->d_idx, icap);
         HIPCHK(hipStreamSynchronize(s));
         HIPCHK(hipFree(dk));
@@ -347,6 +360,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     }
     DevTables& T = c->T;
     T.trbeg = c->d_trbeg;
+    T.flt = c->d_flt; T.flt_mask = c->flt_words ? c->flt_words - 1 : 0;
     T.idx = c->d_idx; T.idx_mask = nbkt - 1; T.idx_shift = 64 - log2u(nbkt);
     T.vv = c->d_vv;
     T.cls = c->d_cls; T.cls_mask = ccap - 1; T.cls_shift = 64 - log2u(ccap);

@@ -59,6 +59,19 @@ DBTK_HD void body_idx_insert(X& x, const IdxBuildArgs& a) {
         }
     }
 }
+struct FltBuildArgs {
+    uint64_t* words;
+    uint64_t mask;
+    const uint64_t* keys;
+    uint64_t n;
+};
+template <class X>
+DBTK_HD void body_flt_insert(X& x, const FltBuildArgs& a) {
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.n; i += (uint64_t)x.nblocks() * x.nthreads()) {
+        const uint64_t h = hash_mix(a.keys[i]);
+        x.atomic_or(&a.words[flt_word(h, a.mask)], flt_bits(h));
+    }
+}
 template <class X>
 DBTK_HD void body_idx_finalize(X& x, IdxBucket* bkt, uint64_t nslots) {
     for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < nslots; i += (uint64_t)x.nblocks() * x.nthreads())
@@ -307,18 +320,23 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     auto tile_np = [&](uint64_t tile) { const uint64_t p0 = tile * K1_TP; return (uint32_t)((a.npairs - p0 < (uint64_t)K1_TP) ? a.npairs - p0 : K1_TP); };
     uint32_t w[K1_PF][4];        // this lane's chunks lane, lane+64, ... of the tile in flight
     uint64_t ro0 = 0, ro1 = 0;   // lane r < 2*np: offsets of read r of the tile in flight
-    // Straight-line loads only (no per-load branches, or the compiler waits for each one in turn): a lane whose
-    // chunk is outside the tile, or is the partial last chunk of the batch, reads the batch's first 16 bytes instead
-    // and the pack step ignores what came back.  Precondition (kept by the host side): 16 bytes are readable at a.seq.
-    auto fetch = [&](uint64_t p0, uint32_t np, uint64_t A0, uint32_t nch) {
+    // Straight-line loads only (no per-load branches, or the compiler waits for each one in turn), addressed as a
+    // wave-uniform base plus a 32-bit lane offset.  Chunks past the tile are simply read (they are the next tile's bytes;
+    // the pack step never looks at them); a chunk that would cross the end of the batch reads the base instead and the
+    // pack step replaces it.  Precondition (kept by the host side): 16 bytes are readable at a.seq.
+    auto fetch = [&](uint64_t p0, uint32_t np, uint64_t A0) {
+        const bool inb = A0 + 16 <= a.seq_len;
+#ifdef DBTK_STAMPS
+        const uint8_t* base = a.seq + ((inb && !(a.P.reserved[0] & 2)) ? A0 : 0ull);  // (knob 2: no streaming traffic)
+#else
+        const uint8_t* base = a.seq + (inb ? A0 : 0ull);
+#endif
+        const uint64_t rem64 = inb ? a.seq_len - A0 : 0ull;
+        const uint32_t rem = rem64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem64;  // bytes readable from base (saturated)
 #pragma unroll
         for (int j = 0; j < K1_PF; ++j) {
-            const uint32_t c = lane + 64u * j;
-            uint64_t gb = A0 + 16ull * c;
-#ifdef DBTK_STAMPS
-            if (a.P.reserved[0] & 2) gb = 16ull * c;  // diagnostic: no streaming traffic (every tile reads the first tile's bytes)
-#endif
-            const uint4 q = *reinterpret_cast<const uint4*>(a.seq + ((c < nch && gb + 16 <= a.seq_len) ? gb : 0ull));
+            const uint32_t o = 16u * (lane + 64u * j);
+            const uint4 q = *reinterpret_cast<const uint4*>(base + (o + 16u <= rem ? o : 0u));
             w[j][0] = q.x; w[j][1] = q.y; w[j][2] = q.z; w[j][3] = q.w;
         }
         const uint32_t r = lane < 2 * np ? lane : 2 * np - 1;
@@ -338,7 +356,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     uint64_t cB0 = 0, cB1 = 0, nB0 = 0, nB1 = 0;  // first/last offset of the current tile and of the next one
     if (tile < ntiles) {
         cB0 = a.off[2 * tile_p0(tile)]; cB1 = a.off[2 * (tile_p0(tile) + tile_np(tile))];
-        fetch(tile_p0(tile), tile_np(tile), cB0 & ~15ull, (uint32_t)((cB1 - (cB0 & ~15ull) + 15) >> 4));
+        fetch(tile_p0(tile), tile_np(tile), cB0 & ~15ull);
     }
     if (tile + stride < ntiles) { nB0 = a.off[2 * tile_p0(tile + stride)]; nB1 = a.off[2 * (tile_p0(tile + stride) + tile_np(tile + stride))]; }
     for (; tile < ntiles; tile += stride) {
@@ -350,13 +368,13 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         DBTK_STAMP(16);  // tile set-up
         // A: pack the tile.  Fast form: 2-bit codes only, plus "some byte is not ACGT" per lane.
         uint32_t bad = 0;
+        const bool tile_tail = A0 + 16ull * nch > a.seq_len;  // only the batch's last tile can hold the partial last chunk
         if (!toolong) {
 #pragma unroll
             for (int j = 0; j < K1_PF; ++j) {
                 const uint32_t c = lane + 64u * j;
-                if (c < nch + 3) {
-                    if (c >= nch) w[j][0] = w[j][1] = w[j][2] = w[j][3] = 0;  // padding
-                    else if (A0 + 16ull * c + 16 > a.seq_len) {  // (through a temporary: w must stay in registers)
+                if (c < nch + 3) {  // (chunks nch .. nch+2 are padding: whatever was fetched will do)
+                    if (tile_tail && c < nch && A0 + 16ull * c + 16 > a.seq_len) {  // (through a temporary: w must stay in registers)
                         uint32_t t[4];
                         load_tail_chunk(a.seq, a.seq_len, A0 + 16ull * c, t);
                         w[j][0] = t[0]; w[j][1] = t[1]; w[j][2] = t[2]; w[j][3] = t[3];
@@ -399,7 +417,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         {   // unconditional (a dummy fetch of nothing past the last tile) so that the loads land straight in w/ro
             const bool h1 = t1 < ntiles, h2 = t2 < ntiles;
             const uint64_t A1 = cB0 & ~15ull;
-            fetch(h1 ? tile_p0(t1) : 0, h1 ? tile_np(t1) : 1u, A1, h1 ? (uint32_t)((cB1 - A1 + 15) >> 4) : 0u);
+            fetch(h1 ? tile_p0(t1) : 0, h1 ? tile_np(t1) : 1u, h1 ? A1 : 0ull);
             nB0 = a.off[h2 ? 2 * tile_p0(t2) : 0]; nB1 = a.off[h2 ? 2 * (tile_p0(t2) + tile_np(t2)) : 0];
         }
         if (toolong) continue;
@@ -440,7 +458,12 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
 #ifdef DBTK_STAMPS
                     if (a.P.reserved[0] & 1) km = NAN64;  // diagnostic: no probes
 #endif
-                    const uint32_t hb = km != NAN64 ? (uint32_t)hash_idx(km, a.T.idx_shift) : 0u;
+                    const uint64_t hmix = hash_mix(km);
+                    if (a.T.flt && km != NAN64) {  // presence filter: "no" is final, and needs no HBM line
+                        const uint64_t fb = flt_bits(hmix);
+                        if ((a.T.flt[flt_word(hmix, a.T.flt_mask)] & fb) != fb) km = NAN64;
+                    }
+                    const uint32_t hb = km != NAN64 ? (uint32_t)(hmix >> a.T.idx_shift) : 0u;
                     // Two rounds; in round r the lane pairs {0,1} and {2,3} of the group look up samples 2r and 2r+1:
                     // each lane reads two of the bucket's four keys, so one load instruction fetches the keys of 32
                     // probes and a probe is ONE request to the memory system.

@@ -72,6 +72,8 @@ struct DevTables {
     uint32_t cls_shift;
     const uint8_t* qc;        // nullptr or nloci bytes
     const uint16_t* permtab;  // introsort permutation of n equal keys, n = 1..NHMAX, row n at n(n-1)/2
+    const uint64_t* flt;      // presence filter words (nullptr: none), flt_mask = words - 1
+    uint64_t flt_mask;
     const uint32_t* trbeg;    // nloci + 1: first OUT.trkmc.ar slot of each locus (its TR k-mers' counters are contiguous)
     uint32_t nloci;
     uint32_t ksize;
@@ -82,10 +84,18 @@ struct DevTables {
     const ClsSlot* bait; uint64_t bait_mask; uint32_t bait_shift;
 };
 
-DBTK_HD uint64_t hash_idx(uint64_t key, uint32_t shift) {
+DBTK_HD uint64_t hash_mix(uint64_t key) {
     key ^= key >> 29;
-    return (key * 0x9E3779B97F4A7C15ull) >> shift;
+    return key * 0x9E3779B97F4A7C15ull;
 }
+DBTK_HD uint64_t hash_idx(uint64_t key, uint32_t shift) { return hash_mix(key) >> shift; }
+// ---- presence filter in front of the index (encode kernel only).  98 % of the sampled k-mers of WGS reads are not in
+// the index, and each such probe costs a 64-byte line of HBM traffic next to the read stream it competes with.  A
+// word-blocked Bloom filter of ~4 bits per key (64 MB at release scale) stays resident in the 256 MB Infinity Cache
+// behind the stream; "no" is final, "maybe" (the keys themselves plus ~20 % of the others) goes on to the table, so
+// the answer is exact.  Three bits of one 64-bit word per key, all taken from the same mixing product as the bucket.
+DBTK_HD uint64_t flt_word(uint64_t h, uint64_t mask) { return (h >> 30) & mask; }
+DBTK_HD uint64_t flt_bits(uint64_t h) { return (1ull << ((h >> 6) & 63)) | (1ull << ((h >> 12) & 63)) | (1ull << ((h >> 18) & 63)); }
 DBTK_HD uint64_t hash_cls(uint64_t kmer, uint32_t locus, uint32_t shift) {
     uint64_t x = kmer ^ ((uint64_t)locus * 0xD6E8FEB86659FD93ull);
     x ^= x >> 31;

@@ -252,6 +252,7 @@ struct EmuTables {
     std::vector<uint32_t> vv;
     std::vector<uint16_t> perm;
     std::vector<uint32_t> trbeg;
+    std::vector<uint64_t> flt;
     std::vector<ClsSlot> tre, bait;
     uint64_t stats[3] = {0, 0, 0};
     DevTables T;
@@ -272,6 +273,10 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
         IdxBuildArgs a{e->idx.data(), nbkt - 1, 64 - lg(nbkt), g->keys.data(), g->vals.data(), g->keys.size()};
         run_grid(3, 64, 0, [&](EmuX& x) { body_idx_insert(x, a); });
         run_grid(3, 64, 0, [&](EmuX& x) { body_idx_finalize(x, e->idx.data(), icap); });
+        // presence filter (deliberately small here: many false positives exercise the "maybe" path)
+        e->flt.assign(pow2((2 * g->keys.size() + 63) / 64) / 1024 ? pow2((2 * g->keys.size() + 63) / 64) : 1024, 0);
+        FltBuildArgs fa{e->flt.data(), e->flt.size() - 1, g->keys.data(), g->keys.size()};
+        run_grid(3, 64, 0, [&](EmuX& x) { body_flt_insert(x, fa); });
     }
     e->vv = g->vv;
     e->vv.push_back(0);
@@ -296,6 +301,7 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
     for (uint64_t l = 0; l <= nloci; ++l) e->trbeg[l] = (uint32_t)g->out_beg[l];
     DevTables& T = e->T;
     T.trbeg = e->trbeg.data();
+    T.flt = e->flt.data(); T.flt_mask = e->flt.size() - 1;
     T.idx = e->idx.data(); T.idx_mask = nbkt - 1; T.idx_shift = 64 - lg(nbkt);
     T.vv = e->vv.data();
     T.cls = e->cls.data(); T.cls_mask = ccap - 1; T.cls_shift = 64 - lg(ccap);
