@@ -212,3 +212,47 @@ def test_device_entry_alternating_lanes(dbtk, oracle, tmp_path, lanes, monkeypat
     hip.hipFree(d_seq); hip.hipFree(d_off)
     oracle.free(go)
     g.close()
+
+
+def test_release_scale_properties(dbtk, oracle):
+    """At a scale the oracle cannot cover in seconds (6000-locus synthetic RPGG of the bench's generator, 1.2 M reads with
+    20 % from the loci): size-independent properties — additivity over batch splits, the counters' conservation laws,
+    sum of counts == counted increments — plus the oracle itself on a 30 000-pair slice."""
+    syn = bind.pkg.Synth(nloci=6000)
+    arrs = syn.arrays()
+    h = C.c_void_p()
+    dbtk._chk(dbtk.L.dbtk_rpgg_from_arrays(C.byref(arrs), C.byref(h)))
+    g = bind.pkg.Rpgg(dbtk, h)
+    npairs = 600_000
+    seq, off = syn.reads(npairs, hit_frac=0.2)
+    p = abi.default_params(ksize=21, n_filter=4, nm_filter=1, cthreshold=45, okam=0)
+    whole = dbtk.context(g, p)
+    whole.align(seq, off)
+    w = whole.counts()
+    parts = dbtk.context(g, p)
+    cuts = [0, 1, 4097, 250_000, 250_016, npairs]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        base = int(off[2 * a])
+        parts.align(seq[base:int(off[2 * b])], off[2 * a:2 * b + 1] - np.uint64(base))
+    q = parts.counts()
+    for k in ("counts", "kmc", "nmapread", "counters"):
+        assert (w[k] == q[k]).all(), k
+    ctr = w["counters"]
+    assert ctr[abi.C_NREADS] == 2 * npairs
+    assert int(w["counts"].sum()) == int(ctr[abi.C_ALGO_INC])          # every increment lands in exactly one counter
+    assert int(w["nmapread"].astype(np.uint64).sum()) == int(ctr[abi.C_ASGN])  # reads counted per locus == reads assigned
+    # the funnel: every read is short, subfiltered, k-mer-filtered, locus-filtered, QC-filtered or enters threading
+    funnel = 2 * int(ctr[abi.C_NSHORT]) + sum(int(ctr[i]) for i in (abi.C_SUBFILTERED, abi.C_KMERFILTERED, abi.C_LOCUSFILTERED, abi.C_QCFILTERED, abi.C_THREADING))
+    assert funnel == 2 * npairs, (funnel, ctr)
+    assert ctr[abi.C_ASGN] <= ctr[abi.C_FEASIBLE] <= ctr[abi.C_THREADING]
+    # and the oracle on a slice
+    n = 30_000
+    orc_g = oracle.from_arrays(arrs)
+    o = oracle.align(orc_g, p, seq[:int(off[2 * n])], off[:2 * n + 1], trace=False)
+    c3 = dbtk.context(g, p)
+    c3.align(seq[:int(off[2 * n])], off[:2 * n + 1])
+    compare(o, c3.counts(), g.output_order(), g.ntrkmers, 0, recs=False)
+    oracle.free(orc_g)
+    for c in (whole, parts, c3):
+        c.close()
+    g.close()
