@@ -8,18 +8,21 @@
 // part of, linked into, or reachable from libdbtk_hip.so.
 //
 // X provides: tid() nthreads() bid() nblocks() lane() sync() ballot(bool)
-//   wave_sum(u32) wave_excl_scan(u32) bcast(u32, srclane) shfl_xor64<E>(in[E], out[E], lanemask)
+//   wave_sum(u32) wave_min(u32) wave_excl_scan(u32) wave_scan_max(u32) bcast(u32, srclane)
 //   wave_scan_lastnz(u32): inclusive scan with op(a, b) = b ? b : a;  shfl_up1(u32): value of lane - 1
+//   quad_perm<P0,P1,P2,P3>(u32): lane 4q+j reads lane 4q+Pj (DPP);  shfl_xor64<E>(in[E], out[E], lanemask)
 //   uni(u32: value known to be wave-uniform)
 //   atomic_add(u64*,u64) atomic_add(u32*,u32)->old atomic_cas(u64*,exp,des)->old
 //   atomic_max(u64*,u64) atomic_or(u64*,u64) lds_add(u32*,u32)->old lds_or(u32*,u32)
 //   smem<T>()
+// Every kernel runs one wavefront per block, so sync() only orders the wave's own LDS traffic.
 //
-// Kernels (SURVEY.md 7, K1..K4):
-//   body_idx_insert / body_idx_finalize / body_cls_insert  table build in HBM
-//   body_encode_subfilter   K1: 2-bit encode + subfilter, 256-thread blocks, 64-pair tiles
-//   body_pair               K2..K4: one wavefront per surviving pair:
-//                           kfilter probe -> dedup -> introsort -> vote -> assign -> count
+// Kernels (DESIGN.md 4):
+//   body_idx_insert / body_idx_finalize / body_idx_aux / body_flt_insert / body_cls_insert   table build in HBM
+//   body_encode_subfilter   K1:  2-bit encode + subfilter over tiles of 16 pairs (presence filter, then bucket probes)
+//   body_probe              K2:  kfilter's look-ups, one wave per surviving read, results to the hit buffers
+//   body_pair_usual         K3a: the usual pair (one locus, enough hits): no sort, no vote; passes the rest on
+//   body_pair               K3b: the general resolve: dedup -> introsort -> vote -> assign -> count (+ bait, bubbles)
 #ifndef DBTK_KERNELS_H_
 #define DBTK_KERNELS_H_
 
@@ -1109,25 +1112,37 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         }
         if (lane < 4) sm.raw[nw + lane] = 0;
         x.sync();
+        uint32_t bad = 0;  // some base of the read is not ACGT (bytes past the read do not count)
+        uint32_t w[4] = {0, 0, 0, 0};
         if (lane < 16) {
             const int c = lane;
             const uint32_t B = rsh + 16 * c, j = B >> 2, r8 = 8 * (B & 3);
-            uint32_t w[4];
+            uint32_t r4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                uint32_t v = 0;
+                uint32_t v = 0, inmask = 0;
                 if (16u * c + 4 * q < len) {
                     const uint32_t lo = sm.raw[j + q], hi = sm.raw[j + q + 1];
                     v = r8 ? ((lo >> r8) | (hi << (32 - r8))) : lo;
                     const uint32_t left = len - (16 * c + 4 * q);  // bytes of this word inside the read
-                    if (left < 4) v &= (1u << (8 * left)) - 1;
+                    inmask = left < 4 ? (1u << (8 * left)) - 1 : 0xFFFFFFFFu;
+                    v &= inmask;
                 }
                 w[q] = v;
+                uint32_t b = 0;
+                r4[q] = pack4_b2(v, &b);
+                bad |= b & inmask;
             }
+            sm.pk[c] = byte_perm(byte_perm(r4[0], r4[1], 0x06020000u), byte_perm(r4[2], r4[3], 0x00000602u), 0x07060100u);
+            if (c < 4) sm.pk[16 + c] = 0;
+        }
+        // every base ACGT (the usual read): all windows are valid and no validity bits are needed; else compute them exactly
+        const bool clean = x.ballot(bad != 0) == 0;
+        if (!clean && lane < 16) {
             uint32_t vd;
-            sm.pk[c] = pack16(w, &vd);
-            sm.vd[c] = (uint16_t)vd;  // bytes past the read are 0 -> invalid
-            if (c < 4) { sm.pk[16 + c] = 0; sm.vd[16 + c] = 0; }
+            (void)pack16(w, &vd);
+            sm.vd[lane] = (uint16_t)vd;  // bytes past the read are 0 -> invalid
+            if (lane < 4) sm.vd[16 + lane] = 0;
         }
         x.sync();
         const uint32_t nk = len >= k ? len - k + 1 : 0;
@@ -1139,7 +1154,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             const uint32_t i = 64 * s + lane;
             km[s] = NAN64; hh[s] = 0; open[s] = false;
             if ((uint32_t)s < nsl && i < nk) {
-                km[s] = window_kmer(sm.pk, sm.vd, i, k, nullptr, nullptr);
+                km[s] = clean ? window_kmer_clean(sm.pk, i, k) : window_kmer(sm.pk, sm.vd, i, k, nullptr, nullptr);
                 hh[s] = hash_idx(km[s], T.idx_shift);
                 open[s] = km[s] != NAN64;
             }
@@ -1166,6 +1181,9 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                 ii[u] = i0 + 16 * u + qd;
                 kq[u] = NAN64; bq[u] = 0; a0[u] = 0; a1[u] = 0;
                 if (ii[u] < nk) { kq[u] = sm.km[ii[u]]; bq[u] = sm.hb[ii[u]]; }
+#ifdef DBTK_STAMPS
+                if (a.P.reserved[0] & 64) bq[u] &= 1023;  // diagnostic: every look-up in the first 64 KB of the table (cache hits)
+#endif
                 if (kq[u] != NAN64) bucket_part(T.idx, bq[u], sub, &a0[u], &a1[u]);
             }
 #pragma unroll
@@ -1186,8 +1204,13 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                     open1 = open1 && !qhit && ((amask >> ((lane & ~3u) + 1)) & 1);
                     if (x.ballot(open1) == 0) {
                         if (ii[u] < nk) {
-                            if (hitl) { outk[ii[u]] = kq[u]; outv[ii[u]] = HitVA{(uint32_t)myval, (uint32_t)(myval >> 32)}; }
-                            else if (sub == 0 && !qhit) { outk[ii[u]] = kq[u]; outv[ii[u]] = HitVA{NOHIT, 0}; }
+#ifdef DBTK_STAMPS
+                            const bool wk = !(a.P.reserved[0] & 32);  // diagnostic: no k-mer writes
+#else
+                            const bool wk = true;
+#endif
+                            if (hitl) { if (wk) outk[ii[u]] = kq[u]; outv[ii[u]] = HitVA{(uint32_t)myval, (uint32_t)(myval >> 32)}; }
+                            else if (sub == 0 && !qhit) { if (wk) outk[ii[u]] = kq[u]; outv[ii[u]] = HitVA{NOHIT, 0}; }
                         }
                         break;
                     }
@@ -1204,7 +1227,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
                 const uint32_t i = 64 * s + lane;
-                if ((uint32_t)s < nsl && i + 1 < nk) eo[i] = window_kmer(sm.pk, sm.vd, i, k + 1, nullptr, nullptr);
+                if ((uint32_t)s < nsl && i + 1 < nk) eo[i] = clean ? window_kmer_clean(sm.pk, i, k + 1) : window_kmer(sm.pk, sm.vd, i, k + 1, nullptr, nullptr);
             }
         }
         if (a.qmaskbuf) {  // -b with qualities

@@ -132,18 +132,6 @@ DBTK_HD uint64_t idx_lookup64(const DevTables& T, uint64_t key) {
     }
 }
 DBTK_HD uint32_t idx_lookup(const DevTables& T, uint64_t key) { return (uint32_t)idx_lookup64(T, key); }
-// kmerDBi.count(kmer): keys only
-DBTK_HD bool idx_contains(const DevTables& T, uint64_t key) {
-    uint64_t b = hash_idx(key, T.idx_shift);
-    for (;;) {
-        uint64_t k[4];
-        bucket_keys(&T.idx[b], k);
-        const int r = bucket_find(k, key);
-        if (r != BKT_NEXT) return r < 4;
-        b = (b + 1) & T.idx_mask;
-    }
-}
-
 // flankDB[locus].count(km) / trKmers[locus].find(km) in one probe.
 DBTK_HD uint32_t cls_lookup(const DevTables& T, uint64_t kmer, uint32_t locus) {
     uint64_t i = hash_cls(kmer, locus, T.cls_shift);
