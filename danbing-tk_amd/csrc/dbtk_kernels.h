@@ -1016,6 +1016,7 @@ struct ProbeSmem {
     uint32_t qmask[8];
     uint64_t km[NKMAX];  // canonical k-mer per position (NAN64: window not valid)
     uint32_t hb[NKMAX];  // its home bucket
+    uint64_t rva[NKMAX]; // look-up result per position: val | aux << 32 (val = NOHIT: not in the index)
 };
 
 // qString2qMask (src/aQueryFasta_thread.h:1038-1071), statement by statement, on the quality bytes
@@ -1094,7 +1095,9 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         if (it0 + S < nitems) fetch_offsets(x.uni(surv_of(it0 + S)), it0 + S);
         pairA = surv_of(it0 + 2 * S);
     }
+    DBTK_STAMP_DECL
     for (uint32_t it = x.bid(); it < nitems; it += S) {  // `it` = hit-buffer row of (survivor, mate)
+        DBTK_STAMP(43);  // loop / extras of the previous row
         const uint64_t o0 = o0C, o1 = o1C;
         uint32_t len = (uint32_t)(o1 - o0);
         if (len > (uint32_t)MAXL) { *a.errflag = DBTK_ERR_READ_TOO_LONG; len = MAXL; }  // stay inside LDS
@@ -1138,6 +1141,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         }
         // every base ACGT (the usual read): all windows are valid and no validity bits are needed; else compute them exactly
         const bool clean = x.ballot(bad != 0) == 0;
+        DBTK_STAMP(40);  // fetch pipeline, raw to LDS, pack
         if (!clean && lane < 16) {
             uint32_t vd;
             (void)pack16(w, &vd);
@@ -1168,60 +1172,81 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             if ((uint32_t)s < nsl && i < nk) { sm.km[i] = km[s]; sm.hb[i] = open[s] ? (uint32_t)hh[s] : 0u; }
         }
         x.sync();
+        DBTK_STAMP(41);  // windows, hash, staging
         uint64_t* outk = a.hitkm + (size_t)it * a.nkp;
         HitVA* outv = a.hitva + (size_t)it * a.nkp;
         if (lane == 0) a.hitnk[it] = nk;
         const uint32_t sub = lane & 3, qd = lane >> 2;
         constexpr int NB = DBTK_K2_NB;  // buckets in flight per lane
+        // One evaluation of a quad's bucket parts against its k-mer: the two key lanes compare, the value lanes' words reach
+        // them by DPP; the hit lane stores the result, lane 0 of the quad stores the miss, and `more` says that the quad must
+        // look into the next bucket (full and overflowed, no match).  Returns the wave's ballot of `more`.
+        auto settle = [&](bool active, uint32_t pos, uint64_t kq, uint64_t p0, uint64_t p1, bool& more) -> uint64_t {
+            const uint64_t v0 = quad_perm64<2, 3, 2, 3>(x, p0), v1 = quad_perm64<2, 3, 2, 3>(x, p1);
+            const bool live = active && kq != NAN64, keyl = sub < 2;
+            const bool m0 = live && keyl && p0 == kq, m1 = live && keyl && (p1 & ~IDX_OVF) == kq;
+            const bool ovf = live && sub == 1 && p1 != NAN64 && (p1 & IDX_OVF);
+            const uint64_t hmask = x.ballot(m0 || m1), omask = x.ballot(ovf);
+            const bool qhit = ((hmask >> (lane & ~3u)) & 0xF) != 0;
+            more = live && !qhit && ((omask >> ((lane & ~3u) + 1)) & 1);
+            // results are collected in LDS and leave for HBM once per read, coalesced (a store between two look-up rounds
+            // would sit in front of the next round's loads: vector-memory operations complete in issue order)
+            if (active && pos < nk) {
+                if (m0 || m1) sm.rva[pos] = m0 ? v0 : v1;
+                else if (sub == 0 && !qhit && !more) sm.rva[pos] = (uint64_t)NOHIT;
+            }
+            return x.ballot(more);
+        };
         for (uint32_t i0 = 0; i0 < nk; i0 += 16 * NB) {
             uint32_t ii[NB], bq[NB];
             uint64_t kq[NB], a0[NB], a1[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 ii[u] = i0 + 16 * u + qd;
-                kq[u] = NAN64; bq[u] = 0; a0[u] = 0; a1[u] = 0;
-                if (ii[u] < nk) { kq[u] = sm.km[ii[u]]; bq[u] = sm.hb[ii[u]]; }
+                // straight-line loads (LDS and HBM alike): a closed lane reads position 0 / bucket 0 and ignores it, so that
+                // the NB bucket loads are all in flight together (a load under a branch makes the compiler wait for it)
+                const uint32_t ic = ii[u] < nk ? ii[u] : 0u;
+                kq[u] = sm.km[ic]; bq[u] = sm.hb[ic];
+                if (ii[u] >= nk) { kq[u] = NAN64; bq[u] = 0; }
 #ifdef DBTK_STAMPS
                 if (a.P.reserved[0] & 64) bq[u] &= 1023;  // diagnostic: every look-up in the first 64 KB of the table (cache hits)
 #endif
-                if (kq[u] != NAN64) bucket_part(T.idx, bq[u], sub, &a0[u], &a1[u]);
+                bucket_part(T.idx, bq[u], sub, &a0[u], &a1[u]);  // (bq = 0 for a position without a k-mer)
             }
+            uint64_t anymore = 0;
+            bool more[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                if (i0 + 16 * u >= nk) break;  // uniform
-                bool open1 = kq[u] != NAN64, hitl = false;
-                uint64_t myval = 0;
-                for (;;) {
-                    const uint64_t v0 = quad_perm64<2, 3, 2, 3>(x, a0[u]), v1 = quad_perm64<2, 3, 2, 3>(x, a1[u]);  // values -> the lanes holding their keys
-                    bool again = false;
-                    if (open1 && sub < 2) {
-                        if (a0[u] == kq[u]) { hitl = true; myval = v0; }
-                        else if ((a1[u] & ~IDX_OVF) == kq[u]) { hitl = true; myval = v1; }
-                        again = sub == 1 && a1[u] != NAN64 && (a1[u] & IDX_OVF);
-                    }
-                    const uint64_t hmask = x.ballot(hitl), amask = x.ballot(again);
-                    const bool qhit = ((hmask >> (lane & ~3u)) & 0xF) != 0;
-                    open1 = open1 && !qhit && ((amask >> ((lane & ~3u) + 1)) & 1);
-                    if (x.ballot(open1) == 0) {
-                        if (ii[u] < nk) {
-#ifdef DBTK_STAMPS
-                            const bool wk = !(a.P.reserved[0] & 32);  // diagnostic: no k-mer writes
-#else
-                            const bool wk = true;
-#endif
-                            if (hitl) { if (wk) outk[ii[u]] = kq[u]; outv[ii[u]] = HitVA{(uint32_t)myval, (uint32_t)(myval >> 32)}; }
-                            else if (sub == 0 && !qhit) { if (wk) outk[ii[u]] = kq[u]; outv[ii[u]] = HitVA{NOHIT, 0}; }
-                        }
-                        break;
-                    }
-                    a0[u] = 0; a1[u] = 0;
-                    if (open1) {  // rare: on to the next bucket
-                        bq[u] = (bq[u] + 1) & (uint32_t)T.idx_mask;
-                        bucket_part(T.idx, bq[u], sub, &a0[u], &a1[u]);
+                more[u] = false;
+                if (i0 + 16 * u < nk) anymore |= settle(true, ii[u], kq[u], a0[u], a1[u], more[u]);  // (uniform condition)
+            }
+            if (anymore) {  // rare (about one look-up in a thousand): walk on, bucket by bucket
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    bool m = more[u];
+                    uint32_t b = bq[u];
+                    while (x.ballot(m)) {
+                        b = (b + 1) & (uint32_t)T.idx_mask;
+                        uint64_t p0 = 0, p1 = 0;
+                        if (m) bucket_part(T.idx, b, sub, &p0, &p1);
+                        bool m2 = false;
+                        (void)settle(m, ii[u], kq[u], p0, p1, m2);
+                        m = m2;
                     }
                 }
             }
         }
+        x.sync();
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const uint32_t i = 64 * s + lane;
+            if ((uint32_t)s < nsl && i < nk) {
+                const uint64_t v = sm.rva[i];
+                outk[i] = km[s];
+                outv[i] = HitVA{(uint32_t)v, (uint32_t)(v >> 32)};
+            }
+        }
+        DBTK_STAMP(42);  // look-ups + result stores
         if (a.edgebuf) {  // -bu: canonical (k+1)-mers = read2kmers_edges' `edges` (AQ.h:290-295): window of k+1 bases
             uint64_t* eo = a.edgebuf + (size_t)it * a.nkp;
 #pragma unroll
@@ -1240,6 +1265,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             if (lane < 4) a.qmaskbuf[(size_t)it * 4 + lane] = (uint64_t)sm.qmask[2 * lane] | ((uint64_t)sm.qmask[2 * lane + 1] << 32);
         }
     }
+    DBTK_STAMP_FLUSH;
 }
 
 // ---- one pair's record (kam: AQ.cpp:2169-2175; trace: every pair).  Trace records are indexed by pair, the others compacted.

@@ -53,6 +53,11 @@ def main():
 
     print(f"general kernel: {st[46]} pairs, {st[44]} serial-vote fallbacks, slowest pair {st[45]} cycles")
     st[44:47] = 0
+    k2 = {40: "K2 fetch+pack", 41: "K2 windows+hash+stage", 42: "K2 look-ups+stores", 43: "K2 loop/extras"}
+    nrows = 2.0 * r[abi.C_SURVIVORS]
+    for i, n in k2.items():
+        print(f"{n:22s} {float(st[i]) / nrows:10.0f} cycles/read")
+    st[40:44] = 0
     u = st[32:48]
     names = {32: "usual: request+test", 33: "usual: states", 34: "usual: assign", 35: "usual: LDS histogram", 36: "usual: delivery", 37: "usual: count atomics", 39: "usual: loop/record"}
     tot = float(u.sum())
