@@ -198,6 +198,8 @@ struct BatchArgs {
     uint32_t events_cap;
     uint32_t t0, tcap;       // K2/K3 work on survivors [t0, min(t0 + tcap, *nsurv)): the hit buffer holds tcap pairs
     uint32_t* tile_ticket;   // K1 work counter (tiles)
+    uint32_t vzero;          // always 0: `lane * vzero` makes an address look lane-dependent, so that a load whose value is only
+                             // needed an iteration later is not turned into scalars (and waited for) right where it is issued
 };
 
 // Thousands of waves each flush a handful of counters at their end; atomics on ONE address serialize at the memory side
@@ -356,12 +358,15 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     };
     const uint64_t stride = x.nblocks();
     uint64_t tile = x.bid();
-    uint64_t cB0 = 0, cB1 = 0, nB0 = 0, nB1 = 0;  // first/last offset of the current tile and of the next one
+    uint64_t cB0 = 0, cB1 = 0;  // first/last offset of the current tile (wave-uniform)
+    uint64_t nB0 = 0, nB1 = 0;  // ... of the next one: in flight in vector registers, made uniform only when their tile comes up
+    const uint64_t lz = (uint64_t)lane * a.vzero;  // 0
+    auto uni64 = [&](uint64_t v) { return ((uint64_t)x.uni((uint32_t)(v >> 32)) << 32) | x.uni((uint32_t)v); };
     if (tile < ntiles) {
         cB0 = a.off[2 * tile_p0(tile)]; cB1 = a.off[2 * (tile_p0(tile) + tile_np(tile))];
         fetch(tile_p0(tile), tile_np(tile), cB0 & ~15ull);
     }
-    if (tile + stride < ntiles) { nB0 = a.off[2 * tile_p0(tile + stride)]; nB1 = a.off[2 * (tile_p0(tile + stride) + tile_np(tile + stride))]; }
+    if (tile + stride < ntiles) { nB0 = a.off[2 * tile_p0(tile + stride) + lz]; nB1 = a.off[2 * (tile_p0(tile + stride) + tile_np(tile + stride)) + lz]; }
     for (; tile < ntiles; tile += stride) {
         const uint64_t p0 = tile_p0(tile), A0 = cB0 & ~15ull;
         const uint32_t np = tile_np(tile), nch = (uint32_t)((cB1 - A0 + 15) >> 4);
@@ -416,12 +421,12 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         const uint64_t o0 = ro0, o1 = ro1;
         // the next tile's bytes, and the geometry of the one after, start their trip now
         const uint64_t t1 = tile + stride, t2 = t1 + stride;
-        cB0 = nB0; cB1 = nB1;
+        cB0 = uni64(nB0); cB1 = uni64(nB1);  // (requested one iteration ago)
         {   // unconditional (a dummy fetch of nothing past the last tile) so that the loads land straight in w/ro
             const bool h1 = t1 < ntiles, h2 = t2 < ntiles;
             const uint64_t A1 = cB0 & ~15ull;
             fetch(h1 ? tile_p0(t1) : 0, h1 ? tile_np(t1) : 1u, h1 ? A1 : 0ull);
-            nB0 = a.off[h2 ? 2 * tile_p0(t2) : 0]; nB1 = a.off[h2 ? 2 * (tile_p0(t2) + tile_np(t2)) : 0];
+            nB0 = a.off[(h2 ? 2 * tile_p0(t2) : 0) + lz]; nB1 = a.off[(h2 ? 2 * (tile_p0(t2) + tile_np(t2)) : 0) + lz];
         }
         if (toolong) continue;
         DBTK_STAMP(17);  // pack + issue of the next fetch
@@ -476,10 +481,8 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                     kq[0] = quad_perm64<0, 0, 1, 1>(x, km); kq[1] = quad_perm64<2, 2, 3, 3>(x, km);
                     bq[0] = x.template quad_perm<0, 0, 1, 1>(hb); bq[1] = x.template quad_perm<2, 2, 3, 3>(hb);
 #pragma unroll
-                    for (int r = 0; r < 2; ++r) {  // both rounds' loads are in flight together
-                        k0[r] = NAN64; k1[r] = NAN64;
-                        if (kq[r] != NAN64) bucket_part(a.T.idx, bq[r], sub & 1, &k0[r], &k1[r]);
-                    }
+                    for (int r = 0; r < 2; ++r)  // both rounds' loads in flight together: unconditional (bucket 0 for a lane without a probe)
+                        bucket_part(a.T.idx, bq[r], sub & 1, &k0[r], &k1[r]);
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         bool open = kq[r] != NAN64, hitl = false;
