@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(64) k_fold_counters(uint64_t* counters, uint64
     for (uint32_t r = 0; r < CTR_REP; ++r) s += atomicExch(reinterpret_cast<unsigned long long*>(&rep[(size_t)r * CTR_STRIDE + c]), 0ull);
     if (s) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[c]), (unsigned long long)s);  // (the other lane may be folding too)
 }
-__global__ void __launch_bounds__(K1_NT) k_encode_subfilter(BatchArgs a) {
+__global__ void __launch_bounds__(K1_NT, 4) k_encode_subfilter(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) K1Smem sm;
     DevX x{&sm};
     body_encode_subfilter(x, a);
