@@ -40,31 +40,27 @@ struct DevX {
     // wave-uniform results are returned through readfirstlane/readlane so that the compiler keeps
     // them (and every loop bound, length and flag derived from them) in SGPRs with scalar branches
     __device__ uint32_t uni(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-    __device__ uint32_t wave_sum(uint32_t v) const {
-        for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-    }
-    __device__ uint32_t wave_min(uint32_t v) const {
-        for (int o = 32; o; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64); v = t < v ? t : v; }
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-    }
-    __device__ uint32_t wave_scan_max(uint32_t v) const {  // inclusive
-        const int l = (int)(threadIdx.x & 63);
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(v, o, 64);
-            if (l >= o && t > v) v = t;
-        }
+    // Wave-wide inclusive scans in six DPP steps (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then row_bcast 15 and 31
+    // across the rows) instead of six ds_bpermute round trips through the LDS crossbar.  OP(cur, earlier) must be associative;
+    // lanes without a source keep the identity 0.
+    template <class OP> __device__ static uint32_t dpp_scan(uint32_t v, OP op) {
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));  // row_shr:4
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));  // row_shr:8
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
         return v;
     }
-    __device__ uint32_t wave_excl_scan(uint32_t v) const {
-        uint32_t inc = v;
-        const int l = (int)(threadIdx.x & 63);
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o, 64);
-            if (l >= o) inc += t;
-        }
-        return inc - v;
+    struct OpAdd { __device__ uint32_t operator()(uint32_t c, uint32_t e) const { return c + e; } };
+    struct OpMax { __device__ uint32_t operator()(uint32_t c, uint32_t e) const { return c > e ? c : e; } };
+    struct OpLastNz { __device__ uint32_t operator()(uint32_t c, uint32_t e) const { return c ? c : e; } };
+    __device__ uint32_t wave_sum(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readlane((int)dpp_scan(v, OpAdd{}), 63); }
+    __device__ uint32_t wave_min(uint32_t v) const {  // as a max-scan of the complement
+        return ~(uint32_t)__builtin_amdgcn_readlane((int)dpp_scan(~v, OpMax{}), 63);
     }
+    __device__ uint32_t wave_scan_max(uint32_t v) const { return dpp_scan(v, OpMax{}); }  // inclusive
+    __device__ uint32_t wave_excl_scan(uint32_t v) const { return dpp_scan(v, OpAdd{}) - v; }
     template <int E> __device__ void shfl_xor64(const uint64_t (&in)[E], uint64_t (&out)[E], int mask) const {
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -73,15 +69,10 @@ struct DevX {
             out[j] = ((uint64_t)hi << 32) | lo;
         }
     }
-    __device__ uint32_t wave_scan_lastnz(uint32_t v) const {  // inclusive scan, op(a, b) = b ? b : a
-        const int l = (int)(threadIdx.x & 63);
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(v, o, 64);
-            if (l >= o && v == 0) v = t;
-        }
-        return v;
+    __device__ uint32_t wave_scan_lastnz(uint32_t v) const { return dpp_scan(v, OpLastNz{}); }  // inclusive scan, op(a, b) = b ? b : a
+    __device__ uint32_t shfl_up1(uint32_t v) const {  // value of lane - 1 (lane 0 keeps its own): wave_shr:1
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
     }
-    __device__ uint32_t shfl_up1(uint32_t v) const { return __shfl_up(v, 1, 64); }
     // lane 4q+j reads lane 4q+Pj (DPP quad_perm: no LDS traffic).  Every lane of the wave must be active at the call.
     template <int P0, int P1, int P2, int P3> __device__ uint32_t quad_perm(uint32_t v) const {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, true);
