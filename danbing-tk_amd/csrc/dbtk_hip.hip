@@ -451,7 +451,7 @@ dbtk_status_t timed_slot(dbtk_ctx* c, int k, int* slot) {
 // buffer holds SURV_CAP pairs).  How many survivors there are is known only on the device, so
 // ceil(npairs / SURV_CAP) chunk iterations are enqueued and the kernels of a chunk past the end
 // of the list exit at once; nothing waits for the host.
-constexpr uint64_t SURV_CAP = 1ull << 22;  // 26 GB of hit buffers at 150 bp: fewer (mostly empty) chunk launches per batch
+constexpr uint64_t SURV_CAP = 1ull << 23;  // at most 51 GB of hit buffers at 150 bp (allocated for the batch size actually seen): one chunk for batches of up to 8 M pairs
 constexpr uint32_t SMALL_WORDS = 64;  // d_small: nsurv, tile ticket, nrec, errflag, [8..] per-chunk tickets, stamps at +32
 
 dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_off, uint64_t seq_len, uint64_t npairs,
