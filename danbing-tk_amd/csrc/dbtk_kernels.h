@@ -1596,8 +1596,32 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         }
         if (tt != NOITEM) nxpair = a.surv[tt];
     };
+    // The current item's probe results live in km / hv / ha (+ sm.hval) from the moment they are taken delivery of: at the
+    // end of the previous item, just BEFORE that item's count atomics went out — a wait for a load also waits for every
+    // older store or atomic (vector memory completes in issue order), and a counter atomic is a slow memory-side RMW.
+    uint64_t km[2][NSLOT];
+    uint32_t hv[2][NSLOT], ha[2][NSLOT];
+    uint32_t nkm[2] = {0, 0}, pair_cur = 0;
+    auto deliver = [&]() {
+        pair_cur = x.uni(nxpair) + a.pair_base;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) nkm[m] = x.uni(nxnk[m]);  // positions of the read (the probe kernel clamps reads to MAXL)
+        const uint32_t nslN = ((nkm[0] > nkm[1] ? nkm[0] : nkm[1]) + 63) >> 6;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                const uint32_t i = 64 * s + lane;
+                km[m][s] = NAN64; hv[m][s] = NOHIT; ha[m][s] = 0;
+                if ((uint32_t)s < nslN && i < nkm[m]) {
+                    km[m][s] = nx[m][s].km; hv[m][s] = nx[m][s].val; ha[m][s] = nx[m][s].aux;
+                    sm.hval[m][i] = nx[m][s].val;  // (read by the dedup only: dead by the time the next item is delivered)
+                }
+            }
+    };
     uint32_t t = x.uni(lookup(x.bid()));
     request(t);
+    deliver();
     uint32_t tB = lookup(x.bcast(take(), 0));
     uint32_t tkA = take();
 
@@ -1606,33 +1630,18 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
 #endif
     for (;;) {
         if (t == NOITEM) break;
-        const uint32_t pair = x.uni(nxpair) + a.pair_base;
+        const uint32_t pair = pair_cur;
+        bool delivered = false;
         x.sync();  // previous pair's LDS is dead from here on
         DBTK_STAMP(0);  // ticket
 
-        // ---- P3: the probe kernel's results for both reads (requested one iteration ago)
-        uint32_t nkm[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) nkm[m] = x.uni(nxnk[m]);  // positions of the read (the probe kernel clamps reads to MAXL)
+        // ---- P3: the probe kernel's results for both reads are in km / hv / ha
         int kf[2], rm[2], hf[2] = {0, 0}, af[2] = {0, 0}, bf[2] = {0, 0};
         uint32_t nhit[2] = {0, 0};  // positions of the mate found in the index
         kf[0] = nkm[0] < cth; kf[1] = nkm[1] < cth;
         rm[0] = kf[0]; rm[1] = kf[1];
         const bool both_short = rm[0] && rm[1];
-        uint64_t km[2][NSLOT];
-        uint32_t hv[2][NSLOT], ha[2][NSLOT];
         const uint32_t nsl = ((nkm[0] > nkm[1] ? nkm[0] : nkm[1]) + 63) >> 6;  // slots in use (3 for 150 bp reads)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                const uint32_t i = 64 * s + lane;
-                km[m][s] = NAN64; hv[m][s] = NOHIT; ha[m][s] = 0;
-                if ((uint32_t)s < nsl && i < nkm[m]) {
-                    km[m][s] = nx[m][s].km; hv[m][s] = nx[m][s].val; ha[m][s] = nx[m][s].aux;
-                    sm.hval[m][i] = nx[m][s].val;
-                }
-            }
         // next item's data, the item after that, and a new ticket
         const uint32_t tnext = x.uni(tB);
         request(tnext);
@@ -2035,6 +2044,9 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                         af[m] = ms[m].af; rm[m] = ms[m].rm;
                     }
                     DBTK_STAMP(12);  // assign_bits
+                    // ---- the next item's probe results, before anything of this one goes out to memory
+                    deliver();
+                    delivered = true;
                     // ---- P11: accumulate (AQ.cpp:2145-2158)
                     if (rm[0] && rm[1]) { dst = nloci; stage = (bf[0] || bf[1]) ? DBTK_STAGE_BAIT : DBTK_STAGE_ASGN; }
                     else {
@@ -2085,6 +2097,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         const bool want = RECS && a.recs && (a.P.trace || (okam && stage == DBTK_STAGE_COUNTED) ||
                                      (okam && a.P.simmode && (stage == DBTK_STAGE_ASGN || stage == DBTK_STAGE_BAIT)) ||
                                      (a.P.extract && stage == DBTK_STAGE_EXTRACT));
+        if (!delivered) deliver();
         if (want) emit_pair_record(x, a, lane, pair, stage, dst, dst0, nm1, nm2, ms, kf, hf, bf, af, rm, nas, Kw, Rw);
 #ifdef DBTK_STAMPS
         {
