@@ -1,8 +1,8 @@
 // dbtk_hip.hip — gfx950 kernels + per-GPU context of the align hot path.
 //
 // The kernel bodies live in dbtk_kernels.h; this file binds them to the
-// hardware (DevX: wave64 ballot / shuffles, __syncthreads, global + LDS
-// atomics), owns the HBM-resident tables and accumulators, and implements the
+// hardware (DevX: wave64 ballots, DPP scans and quad permutes, wavefront-scope
+// fences, global + LDS atomics), owns the HBM-resident tables and accumulators, and implements the
 // device half of include/dbtk.h.  There is no host execution path: without a
 // HIP device dbtk_ctx_create fails with DBTK_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>

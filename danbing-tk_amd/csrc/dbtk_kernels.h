@@ -989,15 +989,14 @@ DBTK_HD bool vote_parallel(X& x, const uint16_t* ord, const uint32_t* uval, cons
 #define DBTK_K2_NB 4  // tuning knob of the probe kernel (variant builds: -DDBTK_K2_NB=n)
 #endif
 // ======================================================================= K2 =
-// kfilter's probes (src/aQueryFasta_thread.cpp:204-209, 215-220) as a kernel of
-// their own: one wavefront per surviving READ, tiny footprint (0.5 KB LDS), so
-// that the chip's random-gather pipes stay full.  The read is fetched as aligned
-// dwords, packed to 2 bits/base in LDS, every lane extracts its <= 4 canonical
-// k-mer windows (read2kmers_edges, AQ.h:274-311), and linear probing runs in
-// wave-wide rounds with all of a lane's probes in flight.  Output: one 16-byte
-// HitEnt {k-mer, val, aux} per read position, coalesced, into the HBM hit buffer
-// that the resolve kernel (K3) consumes.  Every position is probed; what the
-// reference would NOT have probed (after kfilter's abort) is discounted from
+// kfilter's look-ups (src/aQueryFasta_thread.cpp:204-209, 215-220) as a kernel of their own: one wavefront per
+// surviving READ, rows taken at a fixed stride through a three-deep fetch pipeline (pair index -> offsets -> bytes).
+// The read is packed to 2 bits/base in LDS, every lane extracts its <= 4 canonical k-mer windows
+// (read2kmers_edges, AQ.h:274-311) and their home buckets, and the positions are then looked up 16 at a time: the four
+// lanes of a quad read the four 16-byte parts of one bucket, so a look-up is one request for one 64-byte line.  The
+// results {val, aux} are collected in LDS and leave once per read, coalesced, for the hit buffers that the resolve
+// kernels (K3a / K3b) consume: k-mers and {val, aux} in separate arrays, plus the number of positions of the row.
+// Every position is looked up; what the reference would NOT have probed (after kfilter's abort) is discounted from
 // nhash1 by K3.
 struct HitEnt {
     uint64_t km;   // canonical k-mer at the position, NAN64 = window with a non-ACGT base

@@ -156,6 +156,10 @@ dbtk_status_t finish_rpgg(dbtk_rpgg* g) {
 
 }  // namespace dbtk
 
+namespace {
+bool file_exists(const std::string& fn) { FILE* f = fopen(fn.c_str(), "rb"); if (f) fclose(f); return f != nullptr; }
+}  // namespace
+
 extern "C" {
 
 dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_file, const char* bait_file,
@@ -168,7 +172,9 @@ dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_
     dbtk_status_t st = read_tr_kmers(pref + ".tr.kmers", g->tr_cnt, g->tr_ks);
     if (st) return st;
     g->nloci = g->tr_cnt.size();
-    {
+    const bool head_index = file_exists(pref + ".kmers.dbi");
+    const bool legacy = !head_index && file_exists(pref + ".kmerDBi.umap");
+    if (!legacy) {
         // PREF.kmers.dbi: u64 nk | u64 keys[nk] | u32 vals[nk] | u64 nvv | u32 vv[nvv]
         // (src/kmertools.cpp:271-280; reader src/aQueryFasta_thread.h:654-673)
         const std::string fn = pref + ".kmers.dbi";
@@ -181,9 +187,55 @@ dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_
         if (!f.read(g->keys.data(), nk) || !f.read(g->vals.data(), nk) || !f.read(&nvv, 1)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
         g->vv.resize(nvv);
         if (!f.read(g->vv.data(), nvv)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+    } else {
+        // v1.3 RPGG (what README / pipeline name; fixtures test/QC/input/pan.*), accepted when the HEAD files
+        // are absent:  PREF.kmerDBi.umap = u64 n | n x (u64 key, u64 val), val even -> locus = val >> 1, odd -> row val >> 1
+        // of PREF.kmerDBi.vv = u64 n_outer | per row u64 len | u32 loci[len].  Converted to the HEAD encoding (odd val ->
+        // offset into one flat u32 array whose entry is the row length followed by the loci).
+        const std::string fu = pref + ".kmerDBi.umap", fv = pref + ".kmerDBi.vv";
+        File f(fu, "rb");
+        if (!f.f) { set_error("cannot open " + fu); return DBTK_ERR_IO; }
+        uint64_t nk = 0;
+        if (!f.read(&nk, 1)) { set_error("truncated " + fu); return DBTK_ERR_IO; }
+        std::vector<uint64_t> kv(2 * nk);
+        if (!f.read(kv.data(), 2 * nk)) { set_error("truncated " + fu); return DBTK_ERR_IO; }
+        std::vector<uint64_t> rowoff;  // flat offset of every .vv row
+        {
+            File h(fv, "rb");
+            uint64_t nout = 0;
+            if (h.f && h.read(&nout, 1)) {
+                for (uint64_t r = 0; r < nout; ++r) {
+                    uint64_t len = 0;
+                    if (!h.read(&len, 1) || len >= 0xFFFFFFFFull) { set_error("truncated " + fv); return DBTK_ERR_IO; }
+                    rowoff.push_back(g->vv.size());
+                    g->vv.push_back((uint32_t)len);
+                    const size_t at = g->vv.size();
+                    g->vv.resize(at + len);
+                    if (!h.read(g->vv.data() + at, len)) { set_error("truncated " + fv); return DBTK_ERR_IO; }
+                }
+            }
+        }
+        g->keys.resize(nk);
+        g->vals.resize(nk);
+        for (uint64_t i = 0; i < nk; ++i) {
+            const uint64_t v = kv[2 * i + 1];
+            g->keys[i] = kv[2 * i];
+            if (v & 1) {
+                if ((v >> 1) >= rowoff.size() || rowoff[v >> 1] >= 0x7FFFFFFFull) { set_error(fu + ": value points outside " + fv); return DBTK_ERR_FORMAT; }
+                g->vals[i] = (uint32_t)((rowoff[v >> 1] << 1) | 1);
+            } else {
+                if ((v >> 1) >= 0x7FFFFFFFull) { set_error(fu + ": locus out of range"); return DBTK_ERR_FORMAT; }
+                g->vals[i] = (uint32_t)v;
+            }
+        }
     }
     if (flags & DBTK_LOAD_INDEX_ONLY) {
         g->fl_cnt.assign(g->nloci, 0);
+        g->tre_cnt.assign(g->nloci, 0);
+    } else if (legacy) {
+        // flank k-mers: PREF.ntr.kmers (text, the v1.3 name of .fl.kmers); no edge DB in v1.3 (so no -bu)
+        if ((st = read_tr_kmers(pref + ".ntr.kmers", g->fl_cnt, g->fl_ks))) return st;
+        if (g->fl_cnt.size() != g->nloci) { set_error(pref + ".ntr.kmers: locus count differs from .tr.kmers"); return DBTK_ERR_FORMAT; }
         g->tre_cnt.assign(g->nloci, 0);
     } else {
         if ((st = read_kdb(pref + ".fl.kdb", g->nloci, g->fl_cnt, g->fl_ks))) return st;

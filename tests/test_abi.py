@@ -82,3 +82,108 @@ def test_no_cpu_fallback(lib):
         lib.context(g, p)
     assert e.value.status == abi.ERR_NO_DEVICE
     g.close()
+
+
+LEGACY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "legacy_v13")
+
+
+def _view_arrays(g):
+    v = g.view()
+
+    def arr(p, n, dt):
+        return np.ctypeslib.as_array(p, shape=(int(n),)).view(dt).copy() if n and bool(p) else np.zeros(0, dt)
+    nl = int(v.nloci)
+    out = dict(keys=arr(v.keys, v.nkeys, np.uint64), vals=arr(v.vals, v.nkeys, np.uint32), vv=arr(v.vv, v.nvv, np.uint32))
+    for c, ks in (("fl_cnt", "fl_ks"), ("tr_cnt", "tr_ks"), ("tre_cnt", "tre_ks")):
+        out[c] = arr(getattr(v, c), nl, np.uint64)
+        out[ks] = arr(getattr(v, ks), int(out[c].sum()) if len(out[c]) else 0, np.uint64)
+    return out
+
+
+def _index_map(a):
+    """key -> sorted loci, decoding the HEAD value encoding (even: one locus; odd: offset of (n, loci...) in vv)."""
+    m = {}
+    for k, v in zip(a["keys"].tolist(), a["vals"].tolist()):
+        if v & 1:
+            o = v >> 1
+            n = int(a["vv"][o])
+            m[k] = tuple(sorted(a["vv"][o + 1:o + 1 + n].tolist()))
+        else:
+            m[k] = (v >> 1,)
+    return m
+
+
+def test_legacy_v13_fixture_loads(lib):
+    """The reference's own binary fixtures (test/QC/input/pan.*: v1.3 `kmerDBi.umap/.vv`, the formats README and the
+    pipelines name) load through dbtk_rpgg_load when the HEAD files are absent: index keys == TR k-mers + flank k-mers,
+    every value = locus 0, exactly as SURVEY.md 2.3 decodes them."""
+    g = lib.load(os.path.join(LEGACY, "pan"), 21)
+    a = _view_arrays(g)
+    assert g.nloci == 1
+    tr = [int(l.split()[0]) for l in open(os.path.join(LEGACY, "pan.tr.kmers")) if l[0] != ">"]
+    fl = [int(l.split()[0]) for l in open(os.path.join(LEGACY, "pan.ntr.kmers")) if l[0] != ">"]
+    assert a["tr_ks"].tolist() == tr and a["fl_ks"].tolist() == fl
+    assert len(a["keys"]) == 1499 and set(a["keys"].tolist()) == set(tr) | set(fl)
+    assert (a["vals"] == 0).all() and len(a["vv"]) == 0
+    assert g.ntrkmers == len(set(tr))
+    g.close()
+
+
+@pytest.mark.skipif(not __import__("synth").have_ref(), reason="needs oracle/_ref (ktools serialize)")
+def test_legacy_v13_equals_head_files_of_the_same_sets(lib, tmp_path):
+    """The same k-mer sets serialised by the reference's `ktools serialize` (HEAD format) give the same handle; and a
+    multi-locus RPGG written in the v1.3 layout (with non-empty `.vv` rows) decodes to the HEAD arrays it was made from."""
+    import shutil
+    import subprocess
+    import synth
+    d = str(tmp_path)
+    shutil.copy(os.path.join(LEGACY, "pan.tr.kmers"), os.path.join(d, "pan.tr.kmers"))
+    shutil.copy(os.path.join(LEGACY, "pan.ntr.kmers"), os.path.join(d, "pan.fl.kmers"))
+    open(os.path.join(d, "pan.tre.kmers"), "w").write(">0\n")
+    r = subprocess.run([synth.ref_tool("ktools"), "serialize", "pan"], cwd=d, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    gh, gl = lib.load(os.path.join(d, "pan"), 21), lib.load(os.path.join(LEGACY, "pan"), 21)
+    ah, al = _view_arrays(gh), _view_arrays(gl)
+    assert _index_map(ah) == _index_map(al)
+    assert ah["tr_ks"].tolist() == al["tr_ks"].tolist() and sorted(ah["fl_ks"].tolist()) == sorted(al["fl_ks"].tolist())
+    assert (gh.output_order() == gl.output_order()).all()
+    gh.close(); gl.close()
+    # multi-locus, shared k-mers: HEAD files by the reference's tools -> rewritten in the v1.3 layout -> loaded -> same index
+    loci = synth.make_loci(nloci=5, nhap=2, flank=300, seed=91, shared_frac=0.6)
+    d2 = os.path.join(d, "m")
+    os.makedirs(d2)
+    pref = synth.build_rpgg_with_reference(loci, d2, k=21)
+    g1 = lib.load(pref, 21)
+    a1 = _view_arrays(g1)
+    assert (a1["vals"] & 1).any()
+    d3 = os.path.join(d, "v13")
+    os.makedirs(d3)
+    rows, kv = [], []
+    for k, v in zip(a1["keys"].tolist(), a1["vals"].tolist()):
+        if v & 1:
+            o = v >> 1
+            n = int(a1["vv"][o])
+            rows.append(a1["vv"][o + 1:o + 1 + n].astype(np.uint32))
+            kv += [k, ((len(rows) - 1) << 1) | 1]
+        else:
+            kv += [k, v]
+    with open(os.path.join(d3, "pan.kmerDBi.umap"), "wb") as f:
+        f.write(np.uint64(len(a1["keys"])).tobytes() + np.array(kv, np.uint64).tobytes())
+    with open(os.path.join(d3, "pan.kmerDBi.vv"), "wb") as f:
+        f.write(np.uint64(len(rows)).tobytes())
+        for row in rows:
+            f.write(np.uint64(len(row)).tobytes() + row.tobytes())
+    shutil.copy(pref + ".tr.kmers", os.path.join(d3, "pan.tr.kmers"))
+    with open(os.path.join(d3, "pan.ntr.kmers"), "w") as f:
+        i = 0
+        for l, n in enumerate(a1["fl_cnt"].tolist()):
+            f.write(f">{l}\n")
+            for km in a1["fl_ks"][i:i + n].tolist():
+                f.write(f"{km}\t0\n")
+            i += n
+    g2 = lib.load(os.path.join(d3, "pan"), 21)
+    a2 = _view_arrays(g2)
+    assert _index_map(a1) == _index_map(a2)
+    assert a1["fl_ks"].tolist() == a2["fl_ks"].tolist() and a1["tr_ks"].tolist() == a2["tr_ks"].tolist()
+    assert (g1.output_order() == g2.output_order()).all()
+    g1.close(); g2.close()

@@ -256,3 +256,37 @@ def test_release_scale_properties(dbtk, oracle):
     for c in (whole, parts, c3):
         c.close()
     g.close()
+
+
+def test_legacy_v13_rpgg_end_to_end(dbtk, oracle):
+    """The reference's own v1.3 fixture (tests/golden/legacy_v13) loaded by dbtk_rpgg_load, reads stitched from its k-mers:
+    the HIP path against the oracle on the same flat arrays."""
+    import test_abi
+    g = dbtk.load(os.path.join(test_abi.LEGACY, "pan"), 21)
+    a = test_abi._view_arrays(g)
+    go = oracle.from_arrays(g.view())
+    rng = np.random.default_rng(3)
+    pool = np.concatenate([a["tr_ks"], a["fl_ks"]])
+
+    def dec(km):
+        return "".join("ACGT"[(int(km) >> (2 * (20 - i))) & 3] for i in range(21))
+    reads = synth.Reads()
+    for p in range(300):
+        for _ in range(2):
+            s = "".join(dec(pool[rng.integers(len(pool))]) for _ in range(8))[:150]
+            if rng.random() < 0.3:
+                s = s[:70] + "".join(rng.choice(list("ACGT"), 80))
+            reads.seqs.append(s.encode())
+        reads.titles.append(f"r{p}")
+    seq, off = reads.packed()
+    for kw in (dict(cthreshold=2, trace=1), dict(cthreshold=2, okam=0), dict(cthreshold=5)):
+        p = abi.default_params(ksize=21, **kw)
+        o = oracle.align(go, p, seq, off, trace=bool(kw.get("trace")))
+        ctx = dbtk.context(g, p)
+        recs, nrec = ctx.align(seq, off)
+        res = ctx.counts()
+        res["recs"] = recs
+        compare(o, res, g.output_order(), g.ntrkmers, reads.npairs, recs=bool(kw.get("trace")))
+        ctx.close()
+    oracle.free(go)
+    g.close()
