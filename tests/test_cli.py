@@ -143,3 +143,40 @@ def test_cli_vs_reference_binary_live(tmp_path):
         if "-e" not in flags:
             for ext in (".trkmc.ar", ".tr.summary.txt"):
                 assert open(os.path.join(d, "ref" + ext), "rb").read() == open(os.path.join(d, "hip" + ext), "rb").read(), (flags, ext)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not synth.have_ref(), reason="oracle/_ref not built")
+def test_cli_accepts_v13_rpgg(tmp_path):
+    """`-qs PREF` with only the v1.3 files (PREF.kmerDBi.umap/.vv, PREF.ntr.kmers, PREF.tr.kmers — the reference's own fixture):
+    same stdout and output files as with the HEAD files that `ktools serialize` makes from the same k-mer sets, and as the
+    reference binary on those."""
+    import shutil
+    import numpy as np
+    leg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "legacy_v13")
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "v13"))
+    os.makedirs(os.path.join(d, "head"))
+    for f in ("pan.tr.kmers", "pan.ntr.kmers", "pan.kmerDBi.umap", "pan.kmerDBi.vv"):
+        shutil.copy(os.path.join(leg, f), os.path.join(d, "v13", f))
+    shutil.copy(os.path.join(leg, "pan.tr.kmers"), os.path.join(d, "head", "pan.tr.kmers"))
+    shutil.copy(os.path.join(leg, "pan.ntr.kmers"), os.path.join(d, "head", "pan.fl.kmers"))
+    open(os.path.join(d, "head", "pan.tre.kmers"), "w").write(">0\n")
+    assert subprocess.run([synth.ref_tool("ktools"), "serialize", "pan"], cwd=os.path.join(d, "head")).returncode == 0
+    ks = [int(l.split()[0]) for f in ("pan.tr.kmers", "pan.ntr.kmers") for l in open(os.path.join(leg, f)) if l[0] != ">"]
+    rng = np.random.default_rng(8)
+
+    def dec(km):
+        return "".join("ACGT"[(km >> (2 * (20 - i))) & 3] for i in range(21))
+    with open(os.path.join(d, "r.fa"), "w") as f:
+        for p in range(400):
+            for m in (1, 2):
+                f.write(f">r{p}/{m}\n" + "".join(dec(ks[rng.integers(len(ks))]) for _ in range(8))[:150] + "\n")
+    outs = {}
+    for tag, exe, sub in (("v13", CLI, "v13"), ("head", CLI, "head"), ("ref", synth.ref_tool("danbing-tk"), "head")):
+        r = subprocess.run([exe, "-k", "21", "-cth", "3", "-fa", os.path.join(d, "r.fa"), "-qs", "pan", "-o", tag], cwd=os.path.join(d, sub),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-1000:]
+        outs[tag] = (r.stdout, open(os.path.join(d, sub, tag + ".trkmc.ar"), "rb").read(), open(os.path.join(d, sub, tag + ".tr.summary.txt"), "rb").read())
+    assert outs["v13"] == outs["head"] == outs["ref"]
+    assert len(outs["ref"][0]) > 0
