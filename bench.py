@@ -190,8 +190,17 @@ def main():
             if f[0] == dom and f[1] == "FETCH_SIZE":
                 traffic = float(f[3]) * 1024.0 + 0.5 * ctr[abi.C_BASES] / max(per_kernel[dom]["launches"], 1)
                 traffic_src = f"profiles/{PMC_SUMMARY}: FETCH_SIZE mean per launch (KB) x 1024 + half of the coalesced read stream"
+    # the same summary's TCC_MISS_sum: L2-miss requests per launch — the resource K1 actually saturates (tools/lat.hip: the chip
+    # serves about 50-58 G random requests/s whatever is behind them)
+    requests = None
+    if traffic is not None:
+        for line in open(pmc):
+            f = line.strip().split(",")
+            if f[0] == dom and f[1] == "TCC_MISS_sum":
+                requests = dict(per_launch=float(f[3]), rate_per_s=float(f[3]) / (per_kernel[dom]["avg_ms"] * 1e-3),
+                                ceiling_per_s="5.0e10-5.8e10 (tools/lat.hip)", source=f"profiles/{PMC_SUMMARY}: TCC_MISS_sum")
     roof = dict(bound="hbm", kernel=dom, achieved=per_kernel[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=per_kernel[dom]["gbs"] / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                frac=per_kernel[dom]["gbs"] / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, l2_miss_requests=requests,
                 algorithmic_bytes_per_launch=per_kernel[dom]["algorithmic_bytes"], avg_ms=per_kernel[dom]["avg_ms"],
                 kernels=per_kernel)
 

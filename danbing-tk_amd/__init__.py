@@ -39,6 +39,8 @@ def bind_common(L):
     L.dbtk_rpgg_from_arrays.restype = C.c_int
     L.dbtk_rpgg_from_arrays.argtypes = [C.POINTER(abi.RpggArrays), C.POINTER(C.c_void_p)]
     L.dbtk_rpgg_free.argtypes = [C.c_void_p]
+    L.dbtk_rpgg_serialize.restype = C.c_int
+    L.dbtk_rpgg_serialize.argtypes = [C.c_char_p]
     for f in ("dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys"):
         getattr(L, f).restype = C.c_uint64
         getattr(L, f).argtypes = [C.c_void_p]
@@ -94,6 +96,10 @@ class _HostSide:
         self._chk(self.L.dbtk_rpgg_load(prefix.encode(), k, qc_file.encode() if qc_file else None,
                                         bait_file.encode() if bait_file else None, flags, C.byref(h)))
         return Rpgg(self, h)
+
+    def serialize(self, prefix):
+        """`ktools serialize PREF`: text k-mer files -> PREF.kmers.dbi / .fl.kdb / .tre.kdb."""
+        self._chk(self.L.dbtk_rpgg_serialize(prefix.encode()))
 
     def from_arrays(self, k, keys, vals, vv, fl_cnt, fl_ks, tr_cnt, tr_ks, tre_cnt=None, tre_ks=None, qc=None) -> Rpgg:
         keep = [np.ascontiguousarray(x, t) if x is not None else None for x, t in
@@ -238,7 +244,7 @@ EXPORTS = [
     "dbtk_rpgg_load", "dbtk_rpgg_from_arrays", "dbtk_rpgg_free", "dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys",
     "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
-    "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_write_outputs", "dbtk_last_error", "dbtk_abi_version",
+    "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
 ]
 
 

@@ -7,7 +7,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <memory>
+#include <unordered_set>
 #include <thread>
 #include <unordered_map>
 
@@ -330,6 +332,92 @@ void dbtk_params_default(dbtk_params_t* p) {  // src/aQueryFasta_thread.cpp:26-3
     memset(p, 0, sizeof(*p));
     p->ksize = 21; p->n_filter = 4; p->nm_filter = 1; p->cthreshold = 10; p->nm_tr = 40; p->max_nt = 2; p->qth = 20;
     p->okam = 1;
+}
+
+// `ktools serialize` (src/kmertools.cpp:221-345).  The byte layout of the three outputs depends on the iteration order of
+// the reference's std::unordered_map<size_t, size_t> / std::unordered_set<uint64_t>; the same containers filled in the
+// same order iterate in the same order, so they are used as such.
+dbtk_status_t dbtk_rpgg_serialize(const char* prefix) {
+    if (!prefix) { set_error("null argument"); return DBTK_ERR_ARG; }
+    const std::string pref(prefix);
+    // text k-mer file -> (locus index, first field) per line, in file order
+    auto for_each_kmer = [&](const std::string& fn, const std::function<void(uint64_t, uint64_t)>& fnc, uint64_t* nloci) -> dbtk_status_t {
+        File f(fn, "rb");
+        if (!f.f) { set_error("cannot open " + fn); return DBTK_ERR_IO; }
+        fseek(f.f, 0, SEEK_END);
+        const long sz = ftell(f.f);
+        fseek(f.f, 0, SEEK_SET);
+        std::vector<char> buf((size_t)sz + 1);
+        if (sz && fread(buf.data(), 1, (size_t)sz, f.f) != (size_t)sz) { set_error("read failed: " + fn); return DBTK_ERR_IO; }
+        buf[sz] = 0;
+        uint64_t idx = ~0ull;  // ++ on every '>' line (the reference starts at -1)
+        const char* p = buf.data();
+        const char* end = p + sz;
+        while (p < end) {
+            const char* nl = (const char*)memchr(p, '\n', end - p);
+            const char* e = nl ? nl : end;
+            if (e > p) {
+                if (*p == '>') ++idx;
+                else fnc(idx, strtoull(p, nullptr, 10));  // stoul / stoull: the first field
+            }
+            p = nl ? nl + 1 : end;
+        }
+        if (nloci) *nloci = idx + 1;
+        return DBTK_OK;
+    };
+    // ---- PREF.kmers.dbi (readKmerIndex on .tr.kmers then .fl.kmers, then the flattening of kmertools.cpp:240-280)
+    std::unordered_map<size_t, size_t> kmerDBi;
+    std::vector<std::vector<uint32_t>> vec;
+    uint64_t nloci = 0;
+    for (const char* ext : {".tr.kmers", ".fl.kmers"}) {
+        uint32_t vsize = (uint32_t)vec.size();
+        dbtk_status_t st = for_each_kmer(pref + ext, [&](uint64_t idx64, uint64_t kmer) {
+            const uint32_t idx = (uint32_t)idx64;
+            auto it = kmerDBi.find(kmer);
+            if (it != kmerDBi.end()) {
+                const uint32_t vi = (uint32_t)it->second;
+                if (vi % 2) {
+                    bool good = true;
+                    for (uint32_t x : vec[vi >> 1]) if (x == idx) { good = false; break; }
+                    if (good) vec[vi >> 1].push_back(idx);
+                } else if ((vi >> 1) != idx) {
+                    vec.push_back(std::vector<uint32_t>{vi >> 1, idx});
+                    it->second = ((vsize++) << 1) + 1;
+                }
+            } else {
+                kmerDBi[kmer] = (idx << 1);
+            }
+        }, ext[1] == 't' ? &nloci : nullptr);
+        if (st) return st;
+    }
+    {
+        std::vector<uint32_t> vv, vvi;
+        for (auto& v : vec) { vvi.push_back((uint32_t)vv.size()); vv.push_back((uint32_t)v.size()); vv.insert(vv.end(), v.begin(), v.end()); }
+        for (auto& p : kmerDBi) if (p.second % 2) p.second = ((size_t)vvi[p.second >> 1] << 1) + 1;
+        const uint64_t nk = kmerDBi.size(), nvv = vv.size();
+        std::vector<uint64_t> keys(nk);
+        std::vector<uint32_t> vals(nk);
+        uint64_t ki = 0;
+        for (auto& p : kmerDBi) { keys[ki] = p.first; vals[ki] = (uint32_t)p.second; ++ki; }
+        File f(pref + ".kmers.dbi", "wb");
+        if (!f.f || !f.write(&nk, 1) || !f.write(keys.data(), nk) || !f.write(vals.data(), nk) || !f.write(&nvv, 1) || !f.write(vv.data(), nvv)) {
+            set_error("cannot write " + pref + ".kmers.dbi"); return DBTK_ERR_IO;
+        }
+    }
+    // ---- PREF.fl.kdb, PREF.tre.kdb: per locus an unordered_set, flattened in iteration order
+    for (const char* tp : {"fl", "tre"}) {
+        std::vector<std::unordered_set<uint64_t>> db(nloci);
+        dbtk_status_t st = for_each_kmer(pref + "." + tp + ".kmers", [&](uint64_t idx, uint64_t kmer) { if (idx < nloci) db[idx].insert(kmer); }, nullptr);
+        if (st) return st;
+        std::vector<uint64_t> index(nloci), ks;
+        for (uint64_t l = 0; l < nloci; ++l) { index[l] = db[l].size(); for (uint64_t km : db[l]) ks.push_back(km); }
+        const uint64_t nk = ks.size();
+        File f(pref + "." + tp + ".kdb", "wb");
+        if (!f.f || !f.write(&nloci, 1) || !f.write(index.data(), nloci) || !f.write(&nk, 1) || !f.write(ks.data(), nk)) {
+            set_error("cannot write " + pref + "." + tp + ".kdb"); return DBTK_ERR_IO;
+        }
+    }
+    return DBTK_OK;
 }
 
 dbtk_status_t dbtk_write_outputs(const dbtk_rpgg_t* h, const uint64_t* counts, const uint64_t* kmc,

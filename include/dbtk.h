@@ -226,6 +226,14 @@ dbtk_status_t dbtk_ctx_write_bubbles(dbtk_ctx_t* ctx, const char* out_prefix);
 dbtk_status_t dbtk_ctx_merge_bubbles(dbtk_ctx_t* dst, dbtk_ctx_t* src);
 
 /* ---- dumps: src/aQueryFasta_thread.cpp:2631-2641 --------------------------*/
+/* `ktools serialize PREF` (src/kmertools.cpp:221-345): PREF.tr.kmers + PREF.fl.kmers
+ * -> PREF.kmers.dbi (readKmerIndex, src/kmerIO.hpp:47-78), PREF.fl.kmers ->
+ * PREF.fl.kdb, PREF.tre.kmers -> PREF.tre.kdb (flattenKsetDB / serializeKsetDB,
+ * src/binaryKmerIO.hpp:116-139), byte for byte (the orders inside the files are
+ * libstdc++ unordered_map / unordered_set iteration orders, reproduced with the
+ * same containers filled in the same order).  Host only, no GPU needed. */
+dbtk_status_t dbtk_rpgg_serialize(const char* prefix);
+
 /* with_names = 0: OUT.trkmc.ar + OUT.tr.summary.txt; 1: OUT.tr.kmers (-on). */
 dbtk_status_t dbtk_write_outputs(const dbtk_rpgg_t* h, const uint64_t* counts, const uint64_t* kmc,
                                  const uint32_t* nmapread, const char* out_prefix, int with_names);

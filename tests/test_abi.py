@@ -187,3 +187,26 @@ def test_legacy_v13_equals_head_files_of_the_same_sets(lib, tmp_path):
     assert a1["fl_ks"].tolist() == a2["fl_ks"].tolist() and a1["tr_ks"].tolist() == a2["tr_ks"].tolist()
     assert (g1.output_order() == g2.output_order()).all()
     g1.close(); g2.close()
+
+
+@pytest.mark.skipif(not __import__("synth").have_ref(), reason="needs oracle/_ref (ktools serialize)")
+@pytest.mark.parametrize("shared", [0.0, 0.6])
+def test_serialize_is_ktools_serialize(lib, tmp_path, shared):
+    """dbtk_rpgg_serialize writes PREF.kmers.dbi / .fl.kdb / .tre.kdb byte for byte as the reference's `ktools serialize`
+    (the orders inside are libstdc++ hash-container iteration orders)."""
+    import shutil
+    import synth
+    loci = synth.make_loci(nloci=12, nhap=3, flank=400, seed=17, shared_frac=shared)
+    d = str(tmp_path / "ref")
+    os.makedirs(d)
+    pref = synth.build_rpgg_with_reference(loci, d, k=21)  # fa2kmers + ktools serialize
+    d2 = str(tmp_path / "mine")
+    os.makedirs(d2)
+    for ext in (".tr.kmers", ".fl.kmers", ".tre.kmers"):
+        shutil.copy(pref + ext, os.path.join(d2, "pan" + ext))
+    lib.serialize(os.path.join(d2, "pan"))
+    for ext in (".kmers.dbi", ".fl.kdb", ".tre.kdb"):
+        a, b = open(pref + ext, "rb").read(), open(os.path.join(d2, "pan" + ext), "rb").read()
+        assert a == b, ext
+    with pytest.raises(pkg.DbtkError):
+        lib.serialize(str(tmp_path / "nope"))

@@ -180,3 +180,23 @@ def test_cli_accepts_v13_rpgg(tmp_path):
         outs[tag] = (r.stdout, open(os.path.join(d, sub, tag + ".trkmc.ar"), "rb").read(), open(os.path.join(d, sub, tag + ".tr.summary.txt"), "rb").read())
     assert outs["v13"] == outs["head"] == outs["ref"]
     assert len(outs["ref"][0]) > 0
+
+
+@pytest.mark.skipif(not synth.have_ref(), reason="oracle/_ref not built")
+def test_ktools_serialize_binary(tmp_path):
+    """bin/ktools serialize PREF == the reference's ktools serialize PREF, byte for byte (host only: runs without a GPU)."""
+    import shutil
+    loci = synth.make_loci(nloci=7, nhap=3, flank=300, seed=23, shared_frac=0.5)
+    d = str(tmp_path / "ref")
+    os.makedirs(d)
+    pref = synth.build_rpgg_with_reference(loci, d, k=21)
+    d2 = str(tmp_path / "mine")
+    os.makedirs(d2)
+    for ext in (".tr.kmers", ".fl.kmers", ".tre.kmers"):
+        shutil.copy(pref + ext, os.path.join(d2, "pan" + ext))
+    kt = os.path.join(os.path.dirname(CLI), "ktools")
+    r = subprocess.run([kt, "serialize", "pan"], cwd=d2, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    for ext in (".kmers.dbi", ".fl.kdb", ".tre.kdb"):
+        assert open(pref + ext, "rb").read() == open(os.path.join(d2, "pan" + ext), "rb").read(), ext
+    assert subprocess.run([kt], stderr=subprocess.PIPE).returncode == 0
