@@ -98,22 +98,20 @@ DBTK_HD Bits256 transitions_from_masks(const Bits256& K, const Bits256& R) {
     return T;
 }
 
-// The same on one 64-position word with a carry from the words before it (carry: 0 = no known
-// position so far, 1 = the last one is flank, 2 = TR).  K and R are wave ballots, so all of this
-// is scalar-unit work: six fill steps instead of a cross-lane scan.
+// The same on one 64-position word with a carry from the words before it, by carry propagation instead of fill steps:
+// adding F << 1 (F = known flank positions) to ~K lets a carry run from just after every flank position through the
+// unknown positions (ones in ~K) and stop on the next known one — so (~K + (F << 1)) & K marks the known positions whose
+// last known predecessor is flank; likewise with R for TR.  A transition is a TR position after a flank one or a flank
+// position after a TR one.  Two injections never meet: a run starts after a known position and ends at the next known one.
+// `carry`: bit 0 / bit 1 = a flank / TR run is still open at the end of the previous word (a carry out of bit 63, or the
+// injection of a flank / TR position at bit 63).  K and R are wave ballots, so all of this is scalar-unit work.
 DBTK_HD uint64_t transitions_word(uint64_t K, uint64_t R, uint32_t& carry) {
-    uint64_t Fv = R, Fm = K;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        Fv |= (Fv << d) & ~Fm;
-        Fm |= Fm << d;
-    }
-    const uint64_t cv = carry == 2 ? ~0ull : 0ull, cm = carry ? ~0ull : 0ull;
-    Fv |= ~Fm & cv;
-    Fm |= cm;
-    const uint64_t T = K & ((Fm << 1) | (cm & 1)) & (R ^ ((Fv << 1) | (cv & 1)));
-    if (Fm >> 63) carry = (Fv >> 63) ? 2u : 1u;
-    return T;
+    const uint64_t F = K & ~R, nK = ~K;
+    const uint64_t aF = (F << 1) | (carry & 1), aR = (R << 1) | ((carry >> 1) & 1);
+    const uint64_t sF = nK + aF, sR = nK + aR;
+    const uint32_t cF = (uint32_t)(sF < nK) | (uint32_t)(F >> 63), cR = (uint32_t)(sR < nK) | (uint32_t)(R >> 63);
+    carry = cF | (cR << 1);
+    return (sF & K & R) | (sR & K & F);
 }
 
 // K, R: masks over positions [0, nk); R subset of K; T: the transition mask.  ntr: number of TR

@@ -500,6 +500,12 @@ uint64_t emu_selftest_assign(uint64_t seed, uint64_t iters) {
             if (as[j] == 2) { R.w[j >> 6] |= 1ull << (j & 63); ++ntr; }
         }
         ntr &= 0xFF;
+        {   // the word-wise carry-propagation form the kernels use == the log-step fill-forward definition
+            const Bits256 Tdef = transitions_from_masks(K, R);
+            uint32_t carry = 0;
+            for (int wi = 0; wi < 4; ++wi)
+                if (transitions_word(K.w[wi], R.w[wi], carry) != Tdef.w[wi]) { ++bad; break; }
+        }
         for (int rm = 0; rm < 2; ++rm) {
             MateState a{-1, -1, 0, 0, -1, -1, -1, 0, rm}, b = a;
             assign_scan(as, nk, ntr, P, a);
