@@ -122,23 +122,22 @@ DBTK_HD void assign_masks(const Bits256& K, const Bits256& R, const Bits256& T, 
     const int ntot = b_popc(T);
     const int i0 = b_first(K);
     r.bs = (i0 < 256) ? (b_test(R, i0) ? 2 : 1) : 0;
-    const int ti1 = b_first(T);
-    const Bits256 T2 = b_clear_lowest(T);
-    const int ti2 = b_first(T2);
     const int maxnt = (int)P.max_nt;
-    // the scan's early returns, in the order it meets them
+    // the scan's early returns, in the order it meets them (only what each case needs is computed)
+    const int ti1 = ntot >= 1 ? b_first(T) : 256;
     if (ntot >= 1 && maxnt >= 1) r.ti = ti1;  // ti1 is recorded after the nt > MAX_NT test of that step
     if (ntot >= 2 && maxnt >= 2 && r.bs == 2) { r.nt = 2; r.af = 1; r.rm = 1; return; }  // TR-flank-TR
     if (ntot > maxnt) { r.nt = maxnt + 1; r.af = 1; r.rm = 1; return; }
     r.nt = ntot;
-    // unknown tract that ends exactly at a transition: [last known before + 1, transition)
-    int si1 = -1, ei1 = -1, si2 = -1, ei2 = -1;
-    if (ntot >= 1 && ti1 > 0 && !b_test(K, ti1 - 1)) { si1 = b_last_below(K, ti1) + 1; ei1 = ti1; }
-    if (ntot >= 2 && ti2 > 0 && !b_test(K, ti2 - 1)) { si2 = b_last_below(K, ti2) + 1; ei2 = ti2; }
     if (ntot == 0) {
         if (r.bs != 2) { r.af = 1; r.rm = 1; return; }
         r.si = 0; r.ei = nk; r.si_ = 0; r.ei_ = nk;
-    } else if (ntot == 1) {
+        return;
+    }
+    // unknown tract that ends exactly at a transition: [last known before + 1, transition)
+    int si1 = -1, ei1 = -1;
+    if (ti1 > 0 && !b_test(K, ti1 - 1)) { si1 = b_last_below(K, ti1) + 1; ei1 = ti1; }
+    if (ntot == 1) {
         if (r.bs == 1) {
             r.si = si1 >= 0 ? (si1 + ei1) / 2 : ti1; r.ei = nk;
             r.si_ = si1 >= 0 ? ei1 : ti1; r.ei_ = nk;
@@ -146,13 +145,16 @@ DBTK_HD void assign_masks(const Bits256& K, const Bits256& R, const Bits256& T, 
             r.si = 0; r.ei = si1 >= 0 ? (si1 + ei1) / 2 : ti1;
             r.si_ = 0; r.ei_ = si1 >= 0 ? si1 : ti1;
         }
-    } else {
-        if (ntr < P.nm_tr) { r.af = 1; r.rm = 1; return; }
-        r.si = (si1 >= 0 ? (si1 + ei1) / 2 : ti1);
-        r.ei = (si2 >= 0 ? (si2 + ei2) / 2 : ti2);
-        r.si_ = ei1 >= 0 ? ei1 : ti1;
-        r.ei_ = si2 >= 0 ? si2 : ti2;
+        return;
     }
+    if (ntr < P.nm_tr) { r.af = 1; r.rm = 1; return; }
+    const int ti2 = b_first(b_clear_lowest(T));
+    int si2 = -1, ei2 = -1;
+    if (ti2 > 0 && !b_test(K, ti2 - 1)) { si2 = b_last_below(K, ti2) + 1; ei2 = ti2; }
+    r.si = (si1 >= 0 ? (si1 + ei1) / 2 : ti1);
+    r.ei = (si2 >= 0 ? (si2 + ei2) / 2 : ti2);
+    r.si_ = ei1 >= 0 ? ei1 : ti1;
+    r.ei_ = si2 >= 0 ? si2 : ti2;
 }
 
 DBTK_HD void assign_bits(Bits256 K, Bits256 R, int nk, uint32_t ntr, const dbtk_params_t& P, MateState& r) {
