@@ -463,7 +463,9 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     const uint32_t nkmax = max_read_len >= k ? max_read_len - k + 1 : 1;
     const uint32_t nkp = 64 * ((nkmax + 63) / 64);
     const uint32_t ns = nkp / 64;
-    const uint64_t tcap = npairs < SURV_CAP ? npairs : SURV_CAP;
+    uint64_t cap = SURV_CAP;
+    if (const char* e = getenv("DBTK_SURV_CAP")) { const long long v = atoll(e); if (v > 0) cap = (uint64_t)v; }  // (tests: force several chunks)
+    const uint64_t tcap = npairs < cap ? npairs : cap;
     const uint64_t nchunks = (npairs + tcap - 1) / tcap;
     dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, npairs + 1);
     if (st) return st;

@@ -290,3 +290,28 @@ def test_legacy_v13_rpgg_end_to_end(dbtk, oracle):
         ctx.close()
     oracle.free(go)
     g.close()
+
+
+def test_survivor_chunks_on_device(dbtk, oracle, tmp_path, monkeypatch):
+    """The K2 -> K3 hit buffers hold DBTK_SURV_CAP survivors; with a tiny cap one batch runs as many chunk iterations
+    (the path batches of more than 8 M pairs take): same results, records included."""
+    monkeypatch.setenv("DBTK_SURV_CAP", "37")
+    c = make_case("shared", str(tmp_path))
+    go = oracle.load(c.prefix, c.k, c.qc_file)
+    g = dbtk.load(c.prefix, c.k, c.qc_file)
+    seq, off = c.reads.packed()
+    for kw in (dict(trace=1), dict(okam=0), dict()):
+        p = abi.default_params(ksize=c.k, **dict(c.param_sets[0], **kw))
+        o = oracle.align(go, p, seq, off, trace=True)
+        ctx = dbtk.context(g, p)
+        recs, nrec = ctx.align(seq, off)
+        res = ctx.counts()
+        if kw.get("trace"):
+            res["recs"] = recs
+            compare(o, res, g.output_order(), g.ntrkmers, c.reads.npairs)
+        else:
+            oo = oracle.align(go, p, seq, off, trace=False)
+            compare(oo, res, g.output_order(), g.ntrkmers, 0, recs=False)
+        ctx.close()
+    oracle.free(go)
+    g.close()
