@@ -1363,9 +1363,9 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                nx[m][s] = HitVA{NOHIT, 0};
-                if ((uint32_t)s < nslp) nx[m][s] = a.hitva[((size_t)2 * (tt - a.t0) + m) * a.nkp + 64 * s + lane];
+            for (int s = 0; s < NSLOT; ++s) {  // straight-line loads (a slot the rows do not have re-reads the last one; deliver() masks it)
+                const uint32_t sc = (uint32_t)s < nslp ? (uint32_t)s : nslp - 1;
+                nx[m][s] = a.hitva[((size_t)2 * (tt - a.t0) + m) * a.nkp + 64 * sc + lane];
             }
             nxnk[m] = a.hitnk[2 * (tt - a.t0) + m];
         }
@@ -1580,20 +1580,19 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     HitEnt nx[2][NSLOT];
     uint32_t nxnk[2] = {0, 0}, nxpair = 0;
     auto request = [&](uint32_t tt) {
+        const uint32_t tc = tt != NOITEM ? tt : a.t0;  // (what comes back for "no item" is never used: the loop ends first)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                nx[m][s] = HitEnt{NAN64, NOHIT, 0};
-                if ((uint32_t)s < nslp && tt != NOITEM) {
-                    const size_t row = ((size_t)2 * (tt - a.t0) + m) * a.nkp + 64 * s + lane;
-                    const HitVA va = a.hitva[row];
-                    nx[m][s] = HitEnt{a.hitkm[row], va.val, va.aux};
-                }
+            for (int s = 0; s < NSLOT; ++s) {  // straight-line loads: no item -> row 0, a slot the rows do not have -> the last one
+                const uint32_t sc = (uint32_t)s < nslp ? (uint32_t)s : nslp - 1;
+                const size_t row = ((size_t)2 * (tc - a.t0) + m) * a.nkp + 64 * sc + lane;
+                const HitVA va = a.hitva[row];
+                nx[m][s] = HitEnt{a.hitkm[row], va.val, va.aux};
             }
-            if (tt != NOITEM) nxnk[m] = a.hitnk[2 * (tt - a.t0) + m];
+            nxnk[m] = a.hitnk[2 * (tc - a.t0) + m];
         }
-        if (tt != NOITEM) nxpair = a.surv[tt];
+        nxpair = a.surv[tc];
     };
     // The current item's probe results live in km / hv / ha (+ sm.hval) from the moment they are taken delivery of: at the
     // end of the previous item, just BEFORE that item's count atomics went out — a wait for a load also waits for every
