@@ -144,6 +144,9 @@ class Context:
         self._lib._chk(self._lib.L.dbtk_align_batch_device(self.h, C.c_void_p(d_seq_ptr), C.c_void_p(d_off_ptr), npairs,
                                                            max_read_len))
 
+    def write_bait_hits(self, out_prefix):
+        self._lib._chk(self._lib.L.dbtk_ctx_write_bait_hits(self.h, out_prefix.encode()))
+
     def write_bubbles(self, out_prefix):
         self._lib._chk(self._lib.L.dbtk_ctx_write_bubbles(self.h, out_prefix.encode()))
 
@@ -226,6 +229,10 @@ class Dbtk(_HostSide):
         L.dbtk_ctx_write_bubbles.argtypes = [C.c_void_p, C.c_char_p]
         L.dbtk_ctx_merge_bubbles.restype = C.c_int
         L.dbtk_ctx_merge_bubbles.argtypes = [C.c_void_p, C.c_void_p]
+        L.dbtk_ctx_write_bait_hits.restype = C.c_int
+        L.dbtk_ctx_write_bait_hits.argtypes = [C.c_void_p, C.c_char_p]
+        L.dbtk_ctx_merge_bait_hits.restype = C.c_int
+        L.dbtk_ctx_merge_bait_hits.argtypes = [C.c_void_p, C.c_void_p]
         L.dbtk_allreduce.restype = C.c_int
         L.dbtk_allreduce.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         if L.dbtk_abi_version() != abi.ABI_VERSION:
@@ -244,7 +251,7 @@ EXPORTS = [
     "dbtk_rpgg_load", "dbtk_rpgg_from_arrays", "dbtk_rpgg_free", "dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys",
     "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
-    "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
+    "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
 ]
 
 

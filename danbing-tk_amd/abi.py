@@ -26,7 +26,7 @@ u8p = C.POINTER(C.c_uint8)
 class Params(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in
                 ("ksize", "n_filter", "nm_filter", "cthreshold", "nm_tr", "max_nt", "qth", "okam", "qc", "bait",
-                 "bubbles", "extract", "trace", "threading", "simmode")] + [("reserved", C.c_uint32 * 5)]
+                 "bubbles", "extract", "trace", "threading", "simmode")] + [("reserved", C.c_uint32 * 4), ("trackbait", C.c_uint32)]
 
 
 class RpggArrays(C.Structure):

@@ -264,7 +264,6 @@ int main(int argc, char* argv[]) {
         }
     }
     if (o.trim) die_assert("-t (trimmed tr.kmers) is not supported by this build");
-    if (o.trackBait) die_assert("-tb (bait hit tracking) is not supported by this build");
 
     fprintf(stderr,
             "use baitDB: %d\nextract fastX: %d\noutput bubbles: %d\nis Fastq: %d\nsim mode: %d\ngraph threading mode: %d\n"
@@ -293,6 +292,7 @@ int main(int argc, char* argv[]) {
     P.cthreshold = (uint32_t)(uint16_t)o.Cthreshold;  // uint16_t in the reference (AQ.cpp:1765)
     P.nm_tr = (uint32_t)o.NM_TR; P.max_nt = (uint32_t)o.MAX_NT; P.qth = (uint32_t)o.qth;
     P.okam = o.okam; P.qc = o.qc; P.extract = (uint32_t)o.extractFastX; P.threading = o.threading; P.simmode = (uint32_t)o.simmode;
+    P.trackbait = (o.trackBait && use_bait) ? 1 : 0;  // -tb only does something inside the bait filter (AQ.cpp:2111-2119)
     P.bait = use_bait;
     P.bubbles = o.outputBubbles && !o.extractFastX && !o.threading;  // countNovelEdges only runs on the assignment path
     if (o.ngpus < 1) o.ngpus = 1;
@@ -598,6 +598,22 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, "writing kmers...\n");
         if (dbtk_write_outputs(rpgg, counts.data(), kmc.data(), nmapread.data(), o.outPrefix.c_str(), o.writeKmerName))
             die_assert(dbtk_last_error());
+        if (P.trackbait) {  // dumpBaitKmerHits, AQ.cpp:2652-2655
+            fprintf(stderr, "writing bait kmer hit statistics...\n");
+            for (int d = 1; d < o.ngpus; ++d) if (dbtk_ctx_merge_bait_hits(ctx[0], ctx[d])) die_assert(dbtk_last_error());
+            if (dbtk_ctx_write_bait_hits(ctx[0], o.outPrefix.c_str())) die_assert(dbtk_last_error());
+        } else if (o.trackBait) {
+            // -tb where the bait filter never runs (no -b, or -g): the reference still dumps its tracker — sized nloci when -b
+            // read a bait DB (AQ.cpp:2496-2499), empty otherwise
+            fprintf(stderr, "writing bait kmer hit statistics...\n");
+            const uint64_t nl = o.bait ? nloci : 0, zero = 0, szv = 8;
+            FILE* f = fopen((o.outPrefix + ".btk.kmdb").c_str(), "wb");
+            if (!f) die_assert("cannot create " + o.outPrefix + ".btk.kmdb");
+            fwrite(&nl, 8, 1, f);
+            for (uint64_t l = 0; l < nl; ++l) fwrite(&zero, 8, 1, f);
+            fwrite(&zero, 8, 1, f); fwrite(&szv, 8, 1, f);
+            fclose(f);
+        }
         if (o.outputBubbles) {  // dumpBubbles, AQ.cpp:2648-2651
             fprintf(stderr, "writing bubbles...\n");
             if (P.bubbles) {

@@ -198,6 +198,10 @@ struct dbtk_ctx {
     // bubbleDB (bubble_db_t: per locus unordered_map<size_t, uint32_t>, src/aQueryFasta_thread.h:41), filled batch by
     // batch exactly like accumBubbles (AQ.cpp:1599-1606) so that the dump order matches the reference's
     std::vector<std::unordered_map<size_t, uint32_t>> bubbleDB;
+    // -tb: btTK (bt_tracker_db_t, src/aQueryFasta_thread.h:44) and a host copy of baitDB for the replay
+    std::vector<std::unordered_map<uint64_t, uint64_t>> btTK;
+    std::vector<std::unordered_map<uint64_t, uint16_t>> baitDB_host;
+    std::vector<dbtk_pair_rec_t> own_recs;  // record buffer when the caller passes none but -tb needs the bait-stage records
     int k1_blocks = 0;
     bool timers_on = true;
     uint64_t* d_vote = nullptr;
@@ -569,6 +573,7 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
     if (p->n_filter == 1) { set_error("-kf 1 M divides by zero in the reference (subfilter); refusing"); return DBTK_ERR_ARG; }
     if (p->n_filter > 32) { set_error("-kf N: N > 32 unsupported"); return DBTK_ERR_UNSUPPORTED; }
     if (p->bait && h->bt_cnt.empty()) { set_error("params.bait set but the RPGG handle has no bait DB"); return DBTK_ERR_ARG; }
+    if (p->trackbait && !p->bait) { set_error("params.trackbait needs params.bait"); return DBTK_ERR_ARG; }
     if (p->bubbles && (h->tre_cnt.empty() || p->extract)) { set_error("params.bubbles needs PREF.tre.kdb (and is not an extract-mode flag)"); return DBTK_ERR_ARG; }
     if (p->qc && h->qc.empty()) { set_error("params.qc set but the RPGG handle has no QC mask"); return DBTK_ERR_ARG; }
     int ndev = 0;
@@ -614,6 +619,13 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
                 if (hipEventCreate(&c->timed[i].beg[j]) != hipSuccess || hipEventCreate(&c->timed[i].end[j]) != hipSuccess) { set_error("hipEventCreate failed"); st = DBTK_ERR_HIP; }
         if (st) break;
         if ((st = build_tables(c))) break;
+        if (p->trackbait) {
+            c->btTK.resize(h->nloci);
+            c->baitDB_host.resize(h->nloci);
+            uint64_t i = 0;
+            for (uint64_t l = 0; l < h->nloci; ++l)
+                for (uint64_t j = 0; j < h->bt_cnt[l]; ++j, ++i) c->baitDB_host[l][h->bt_ks[i]] = h->bt_vs[i];
+        }
         if (p->bubbles) {
             if ((st = build_kl_table(c, h->tre_cnt, h->tre_ks, nullptr, &c->d_tre, &c->T.tre_mask, &c->T.tre_shift))) break;
             c->T.tre = c->d_tre;
@@ -691,7 +703,13 @@ dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t
         for (uint64_t r = 0; r <= nreads; ++r) o2[r] = off[r] - base;
         HIPCHK(hipMemcpy(c->d_off, o2.data(), (nreads + 1) * 8, hipMemcpyHostToDevice));
     }
-    const bool want_recs = recs && rec_cap && (c->P.trace || c->P.okam || c->P.extract);
+    bool want_recs = recs && rec_cap && (c->P.trace || c->P.okam || c->P.extract);
+    if (c->P.trackbait && !want_recs) {  // the replay needs the bait-stage records even when the caller wants none
+        c->own_recs.resize(npairs);
+        recs = c->own_recs.data();
+        rec_cap = npairs;
+        want_recs = true;
+    }
     uint64_t dcap = 0;
     if (want_recs) {
         dcap = c->P.trace ? npairs : (rec_cap < npairs ? rec_cap : npairs);
@@ -741,6 +759,54 @@ dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t
             // compaction order is arbitrary on the device; the reference's order within a batch is pair order
             std::sort(recs, recs + ncopy, [](const dbtk_pair_rec_t& x, const dbtk_pair_rec_t& y) { return x.pair < y.pair; });
             if (produced > dcap) { set_error("record buffer too small"); return DBTK_ERR_OVERFLOW; }
+        }
+        if (c->P.trackbait) {
+            // ---- -tb: for every mate the bait filter flagged, the k-mer that made bfilter_FPSv1 return — the FIRST violated one
+            // in the iteration order of its kc8_t (unordered_map<uint64_t, uint8_t>, AQ.cpp:1380-1394 / 1401-1417), found by
+            // filling the same container in the same order.  Per batch into tkr (AQ.cpp:1993), then accumBaitKmerHits (1608-1616).
+            std::unordered_map<uint32_t, std::unordered_map<uint64_t, uint64_t>> tkr;
+            const uint32_t k = c->g->ksize;
+            std::vector<uint64_t> ks;
+            for (uint64_t i = 0; i < ncopy; ++i) {
+                const dbtk_pair_rec_t& r = recs[i];
+                if (r.stage != DBTK_STAGE_BAIT) continue;
+                for (int m = 0; m < 2; ++m) {
+                    if (!(m ? r.r2.bf : r.r1.bf)) continue;
+                    const uint64_t o0 = off[2 * (uint64_t)r.pair + m], o1 = off[2 * (uint64_t)r.pair + m + 1];
+                    const uint8_t* rd = seq + o0;
+                    const uint64_t len = o1 - o0;
+                    if (len < k) continue;
+                    // read2kmers_edges' k-mers: canonical k-mer per position, NAN64 where the window has a non-ACGT base
+                    ks.assign(len - k + 1, NAN64);
+                    uint64_t fw = 0, rc = 0, run = 0;
+                    const uint64_t mask = (k < 32) ? ((1ull << (2 * k)) - 1) : ~0ull;
+                    for (uint64_t b = 0; b < len; ++b) {
+                        uint64_t code;
+                        switch (rd[b]) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break; default: code = 4; }
+                        if (code == 4) { run = 0; fw = rc = 0; continue; }
+                        fw = ((fw << 2) | code) & mask;
+                        rc = (rc >> 2) | ((3 - code) << (2 * (k - 1)));
+                        if (++run >= k) ks[b + 1 - k] = fw < rc ? fw : rc;
+                    }
+                    uint32_t qm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    const bool fq = qual != nullptr;
+                    if (fq) qmask_scan(qual + o0, (int)len, (int)c->P.qth, (int)k, qm);
+                    std::unordered_map<uint64_t, uint8_t> kc;  // kc8_t
+                    for (uint64_t p = 0; p < ks.size(); ++p)
+                        if (!fq || ((qm[p >> 5] >> (p & 31)) & 1)) ++kc[ks[p]];
+                    const auto& baitdb = c->baitDB_host[r.dst0];
+                    for (auto& pc : kc) {
+                        auto it = baitdb.find(pc.first);
+                        if (it == baitdb.end()) continue;
+                        const uint8_t mi = (uint8_t)(it->second >> 8), ma = (uint8_t)(it->second & 0xff);
+                        if (pc.second < mi || pc.second > ma) { ++tkr[r.dst0][pc.first]; break; }
+                    }
+                }
+            }
+            for (auto& p1 : tkr) {
+                auto& t = c->btTK[p1.first];
+                for (auto& p2 : p1.second) t[p2.first] += p2.second;
+            }
         }
     }
     return DBTK_OK;
@@ -823,6 +889,34 @@ dbtk_status_t dbtk_ctx_write_bubbles(dbtk_ctx_t* c, const char* out_prefix) {
               fwrite(&szv, 8, 1, f) == 1 && (nk == 0 || (fwrite(ks.data(), 8, nk, f) == nk && fwrite(vs.data(), 8, nk, f) == nk));
     fclose(f);
     if (!ok) { set_error("write failed: " + fn); return DBTK_ERR_IO; }
+    return DBTK_OK;
+}
+
+// OUT.btk.kmdb: dumpBaitKmerHits -> dumpKmerMapDB("btk", ..., th = 0) (src/aQueryFasta_thread.h:998-1012): every entry, map iteration
+// order, serializeKmapDB layout u64 nloci | u64 index[nloci] | u64 nk | u64 sizeof(val) = 8 | u64 ks[nk] | u64 vs[nk].
+dbtk_status_t dbtk_ctx_write_bait_hits(dbtk_ctx_t* c, const char* out_prefix) {
+    if (!c || !out_prefix) { set_error("null argument"); return DBTK_ERR_ARG; }
+    if (!c->P.trackbait) { set_error("context was not created with params.trackbait"); return DBTK_ERR_ARG; }
+    const uint64_t nloci = c->g->nloci;
+    std::vector<uint64_t> index(nloci), ks, vs;
+    for (uint64_t l = 0; l < nloci; ++l) {
+        for (auto& p : c->btTK[l]) { ks.push_back(p.first); vs.push_back(p.second); }
+        index[l] = c->btTK[l].size();
+    }
+    const std::string fn = std::string(out_prefix) + ".btk.kmdb";
+    FILE* f = fopen(fn.c_str(), "wb");
+    if (!f) { set_error("cannot create " + fn); return DBTK_ERR_IO; }
+    const uint64_t nk = ks.size(), szv = 8;
+    bool ok = fwrite(&nloci, 8, 1, f) == 1 && (nloci == 0 || fwrite(index.data(), 8, nloci, f) == nloci) && fwrite(&nk, 8, 1, f) == 1 &&
+              fwrite(&szv, 8, 1, f) == 1 && (nk == 0 || (fwrite(ks.data(), 8, nk, f) == nk && fwrite(vs.data(), 8, nk, f) == nk));
+    fclose(f);
+    if (!ok) { set_error("write failed: " + fn); return DBTK_ERR_IO; }
+    return DBTK_OK;
+}
+dbtk_status_t dbtk_ctx_merge_bait_hits(dbtk_ctx_t* dst, dbtk_ctx_t* src) {
+    if (!dst || !src || dst->btTK.size() != src->btTK.size()) { set_error("bad argument"); return DBTK_ERR_ARG; }
+    for (size_t l = 0; l < src->btTK.size(); ++l)
+        for (auto& q : src->btTK[l]) dst->btTK[l][q.first] += q.second;
     return DBTK_OK;
 }
 

@@ -2094,7 +2094,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         // ---- P12: record (kam: AQ.cpp:2169-2175; trace: every pair)
         const bool want = RECS && a.recs && (a.P.trace || (okam && stage == DBTK_STAGE_COUNTED) ||
                                      (okam && a.P.simmode && (stage == DBTK_STAGE_ASGN || stage == DBTK_STAGE_BAIT)) ||
-                                     (a.P.extract && stage == DBTK_STAGE_EXTRACT));
+                                     (a.P.extract && stage == DBTK_STAGE_EXTRACT) || (a.P.trackbait && stage == DBTK_STAGE_BAIT));
         if (!delivered) deliver();
         if (want) emit_pair_record(x, a, lane, pair, stage, dst, dst0, nm1, nm2, ms, kf, hf, bf, af, rm, nas, Kw, Rw);
 #ifdef DBTK_STAMPS

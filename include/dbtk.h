@@ -70,7 +70,9 @@ typedef struct dbtk_params {
     uint32_t threading;    /* -g/-gc/-gcc: accepted like the reference; at HEAD its call sites are commented out
                               (AQ.cpp:2072-2088), so assigned pairs are only counted as "entered threading" */
     uint32_t simmode;      /* -s 1|2: also emit records of pairs whose two mates assignTRkmc rejected (AQ.cpp:2169) */
-    uint32_t reserved[5];
+    uint32_t reserved[4];
+    uint32_t trackbait;    /* -tb: per locus, count the bait k-mer that made bfilter_FPSv1 flag a mate (AQ.cpp:1391,1414);
+                              with -b, host-buffer batches only; such pairs then also yield records (stage DBTK_STAGE_BAIT) */
 } dbtk_params_t;
 
 /* ---- RPGG in flat (file-equivalent) form ----------------------------------
@@ -219,6 +221,11 @@ dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n);
 int  dbtk_ctx_kernel_times(dbtk_ctx_t* ctx, const char** names, double* total_ms, uint64_t* launches, int cap);
 void dbtk_ctx_timers_reset(dbtk_ctx_t* ctx);
 void dbtk_ctx_timers_enable(dbtk_ctx_t* ctx, int on);  /* default on; off = no event records on the stream */
+
+/* -tb: OUT.btk.kmdb = dumpBaitKmerHits (src/aQueryFasta_thread.h:1010-1012): the per-locus (bait k-mer -> times it was
+ * the first violated one) maps in the reference's iteration order, serializeKmapDB layout with 8-byte values. */
+dbtk_status_t dbtk_ctx_write_bait_hits(dbtk_ctx_t* ctx, const char* out_prefix);
+dbtk_status_t dbtk_ctx_merge_bait_hits(dbtk_ctx_t* dst, dbtk_ctx_t* src);
 
 /* -bu: the per-locus novel (k+1)-mer counts accumulated by dbtk_align_batch (host path) -> OUT.bub.kmdb
  * (dumpBubbles, src/aQueryFasta_thread.h:1006-1008: entries with count >= 5).  merge: fold another GPU's DB in. */

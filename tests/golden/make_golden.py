@@ -60,7 +60,11 @@ def bait_bubble_set(dtk):
     cmds = []
     for tag, args in (("refbu", ["-bu", "-k", "21", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-p", "1"]),
                       ("refbt", ["-b", "-k", "21", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-p", "1"]),
-                      ("refbq", ["-bu", "-b", "-qth", "25", "-k", "21", "-cth", "30", "-fq", "reads.fq", "-qs", "pan", "-p", "1"])):
+                      ("refbq", ["-bu", "-b", "-qth", "25", "-k", "21", "-cth", "30", "-fq", "reads.fq", "-qs", "pan", "-p", "1"]),
+                      # -tb: OUT.btk.kmdb (with -b: FASTA and FASTQ; without -b: the empty tracker)
+                      ("reftb", ["-b", "-tb", "-k", "21", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-p", "1"]),
+                      ("reftq", ["-tb", "-b", "-qth", "25", "-k", "21", "-cth", "30", "-fq", "reads.fq", "-qs", "pan", "-p", "1"]),
+                      ("reftn", ["-tb", "-k", "21", "-cth", "45", "-ka", "-fa", "reads.fa", "-qs", "pan", "-p", "1"])):
         cmd = ["danbing-tk"] + args + ["-o", tag]
         with open(os.path.join(d, tag + ".kam.txt"), "wb") as so, open(os.path.join(d, tag + ".stderr.txt"), "wb") as se:
             subprocess.run([dtk] + cmd[1:], cwd=d, check=True, stdout=so, stderr=se)
