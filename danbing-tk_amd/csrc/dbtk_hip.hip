@@ -87,6 +87,7 @@ struct DevX {
     }
     __device__ void atomic_max(uint64_t* p, uint64_t v) const { atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
     __device__ void atomic_or(uint64_t* p, uint64_t v) const { atomicOr(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
+    __device__ uint32_t atomic_or32(uint32_t* p, uint32_t v) const { return atomicOr(p, v); }
     __device__ uint64_t clock() const { return (uint64_t)clock64(); }
     __device__ uint32_t lds_add(uint32_t* p, uint32_t v) const { return atomicAdd(p, v); }
     __device__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
@@ -117,7 +118,23 @@ __global__ void __launch_bounds__(64) k_fold_counters(uint64_t* counters, uint64
 __global__ void __launch_bounds__(K1_NT, 4) k_encode_subfilter(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) K1Smem sm;
     DevX x{&sm};
-    body_encode_subfilter(x, a);
+    body_encode_subfilter<false>(x, a);
+}
+// the encode stage in its binned form: encode + sort the filter queries by partition | filter + exact look-ups | candidates
+__global__ void __launch_bounds__(K1_NT, 4) k_encode_bin(BatchArgs a) {
+    __shared__ __attribute__((aligned(16))) K1BinSmem sm;
+    DevX x{&sm};
+    body_encode_subfilter<true>(x, a);
+}
+__global__ void __launch_bounds__(64) k_filter_bins(BatchArgs a) {
+    __shared__ __attribute__((aligned(16))) FltSmem sm;
+    DevX x{&sm};
+    body_filter_bins(x, a);
+}
+__global__ void __launch_bounds__(64) k_subfilter_cand(BatchArgs a) {
+    __shared__ __attribute__((aligned(16))) CandSmem sm;
+    DevX x{&sm};
+    body_subfilter_cand(x, a);
 }
 // K2 / K3 are instantiated per NS = 64-position slots a read needs (2: <= 128 positions, 3: 150 bp reads, 4: up to 256 bp)
 template <int NS> __global__ void __launch_bounds__(64) k_probe(BatchArgs a) {
@@ -150,7 +167,7 @@ namespace {
 // Per-kernel timing: a pool of HIP event pairs recorded on the context's stream
 // around every launch; folded into (total ms, launches) when the pool fills or
 // when the caller asks.
-constexpr int NKERN = 4;       // k_encode_subfilter, k_probe, k_pair_usual, k_pair
+constexpr int NKERN = 7;       // k_encode_subfilter (the whole encode stage), k_probe, k_pair_usual, k_pair; the three kernels of the binned encode stage
 constexpr int EVPOOL = 128;    // launches in flight before a fold
 struct Timed {
     const char* name;
@@ -160,6 +177,15 @@ struct Timed {
     uint64_t launches;
 };
 }  // namespace
+
+// per-batch scratch of the binned encode stage (one per lane)
+struct BinScratch {
+    uint64_t* bins = nullptr; uint64_t bins_cap = 0;
+    uint32_t* bincnt = nullptr; uint64_t bincnt_cap = 0;
+    uint64_t* ovf = nullptr; uint64_t ovf_cap = 0;
+    uint32_t* ovf_hdr = nullptr; uint64_t ovf_hdr_cap = 0;
+    uint32_t* cand = nullptr; uint64_t cand_cap = 0;
+};
 
 struct dbtk_ctx {
     const dbtk_rpgg* g = nullptr;
@@ -202,7 +228,9 @@ struct dbtk_ctx {
     std::vector<std::unordered_map<uint64_t, uint64_t>> btTK;
     std::vector<std::unordered_map<uint64_t, uint16_t>> baitDB_host;
     std::vector<dbtk_pair_rec_t> own_recs;  // record buffer when the caller passes none but -tb needs the bait-stage records
-    int k1_blocks = 0;
+    int k1_blocks = 0, k1bin_blocks = 0;
+    BinScratch bin;
+    int k1_binned = 0;   // DBTK_K1_BINNED: 0 never, 1 always (where it applies), -1 for batches of >= 65536 pairs
     bool timers_on = true;
     uint64_t* d_vote = nullptr;
     uint32_t* d_epoch = nullptr;
@@ -223,6 +251,7 @@ struct dbtk_ctx {
         uint32_t* d_tickets = nullptr; uint64_t tickets_cap = 0;
         uint64_t* d_vote = nullptr;
         uint32_t* d_epoch = nullptr;
+        BinScratch bin;
     } alt;
     bool two_lanes = false;
 };
@@ -250,6 +279,10 @@ void free_ctx(dbtk_ctx* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     void* aptrs[] = {c->alt.d_small, c->alt.d_surv, c->alt.d_hitkm, c->alt.d_hitva, c->alt.d_hitnk, c->alt.d_gen, c->alt.d_tickets, c->alt.d_vote, c->alt.d_epoch};
     for (void* p : aptrs) if (p) (void)hipFree(p);
+    for (BinScratch* b : {&c->bin, &c->alt.bin}) {
+        void* bp[] = {b->bins, b->bincnt, b->ovf, b->ovf_hdr, b->cand};
+        for (void* p : bp) if (p) (void)hipFree(p);
+    }
     if (c->alt.stream) (void)hipStreamDestroy(c->alt.stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -283,7 +316,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
                 c->flt_words = pow2_at_least((bpk * nkeys + 63) / 64);
                 HIPCHK(hipMalloc(&c->d_flt, c->flt_words * 8));
                 HIPCHK(hipMemsetAsync(c->d_flt, 0, c->flt_words * 8, s));
-                FltBuildArgs fa{c->d_flt, c->flt_words - 1, dk, nkeys};
+                FltBuildArgs fa{c->d_flt, log2u(c->flt_words), g->ksize, dk, nkeys};
                 hipLaunchKernelGGL(k_flt_insert, dim3(2048), dim3(256), 0, s, fa);
             }
         }
@@ -355,7 +388,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     }
     DevTables& T = c->T;
     T.trbeg = c->d_trbeg;
-    T.flt = c->d_flt; T.flt_mask = c->flt_words ? c->flt_words - 1 : 0;
+    T.flt = c->d_flt; T.flt_logw = c->flt_words ? log2u(c->flt_words) : 0;
     T.idx = c->d_idx; T.idx_mask = nbkt - 1; T.idx_shift = 64 - log2u(nbkt);
     T.vv = c->d_vv;
     T.cls = c->d_cls; T.cls_mask = ccap - 1; T.cls_shift = 64 - log2u(ccap);
@@ -435,6 +468,7 @@ void switch_lane(dbtk_ctx* c) {
     std::swap(c->d_gen, c->alt.d_gen); std::swap(c->gen_cap, c->alt.gen_cap);
     std::swap(c->d_tickets, c->alt.d_tickets); std::swap(c->tickets_cap, c->alt.tickets_cap);
     std::swap(c->d_vote, c->alt.d_vote); std::swap(c->d_epoch, c->alt.d_epoch);
+    std::swap(c->bin, c->alt.bin);
 }
 hipError_t sync_all(dbtk_ctx* c) {
     hipError_t e = hipStreamSynchronize(c->stream);
@@ -510,12 +544,64 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     a.dbg = reinterpret_cast<uint64_t*>(c->d_small + 32);
 #endif
     const uint64_t ntiles = (npairs + K1_TP - 1) / K1_TP;
-    const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->k1_blocks ? ntiles : (uint64_t)c->k1_blocks);  // resident waves
     int e = 0;
     const bool tm = c->timers_on;
-    if (tm) { if ((st = timed_slot(c, 0, &e))) return st; HIPCHK(hipEventRecord(c->timed[0].beg[e], s)); }
-    hipLaunchKernelGGL(k_encode_subfilter, dim3(g1), dim3(K1_NT), 0, s, a);
-    if (tm) HIPCHK(hipEventRecord(c->timed[0].end[e], s));
+    auto rec_beg = [&](int kslot) -> dbtk_status_t { if (!tm) return DBTK_OK; dbtk_status_t r = timed_slot(c, kslot, &e); if (r) return r; HIPCHK(hipEventRecord(c->timed[kslot].beg[e], s)); return DBTK_OK; };
+    auto rec_end = [&](int kslot) -> dbtk_status_t { if (tm) HIPCHK(hipEventRecord(c->timed[kslot].end[e], s)); return DBTK_OK; };
+    // The encode stage.  Binned form (see body_filter_bins) where it applies: a presence filter, subfilter on, no trace
+    // records, and a query (mixed k-mer without its partition bits | pair index) fits 64 bits.
+    const uint32_t nfr = (c->P.n_filter + 3) / 4;  // query rounds per tile
+    uint32_t pb = c->T.flt_logw > 18 ? c->T.flt_logw - 18 : 0;  // partitions of 2^18 words = 2 MB: resident in an XCD's 4 MB L2
+    if (const char* ev = getenv("DBTK_K1_PB")) { const int v = atoi(ev); if (v >= 0) pb = (uint32_t)v; }  // (tests)
+    pb = std::min<uint32_t>({pb, (uint32_t)BIN_MAXPB, c->T.flt_logw, 2 * k});
+    bool binned = c->d_flt && c->P.n_filter && c->P.nm_filter && !c->P.trace && c->k1_binned != 0 &&
+                  (c->k1_binned == 1 || npairs >= 65536) && (2 * k - pb) + (64 - (uint32_t)__builtin_clzll(npairs)) <= 64;
+    if (binned) {
+        const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->k1bin_blocks ? ntiles : (uint64_t)c->k1bin_blocks);
+        const uint32_t nparts = 1u << pb;
+        const uint64_t qwave = ((ntiles + g1 - 1) / g1) * 64 * nfr;  // queries one encode wave can emit
+        uint64_t bcap = ((qwave / nparts) * 3 / 2 + 64 + BIN_G - 1) / BIN_G * BIN_G;  // 1.5 x the even share (+ slack): the rest overflows
+        if (const char* ev = getenv("DBTK_K1_BINCAP")) { const long v = atol(ev); if (v >= 0) bcap = (uint64_t)v / BIN_G * BIN_G; }  // (tests: force overflow groups)
+        const uint64_t ngroups = ntiles * 64 * nfr / BIN_G + (uint64_t)g1 * nparts + 64;  // every query overflowing + every partial group
+        if ((uint64_t)g1 * nparts * bcap >= (1ull << 40)) binned = false;
+        if (binned) {
+            BinScratch& b = c->bin;
+            if ((st = ensure(&b.bins, &b.bins_cap, (uint64_t)g1 * nparts * bcap + BIN_G))) return st;
+            if ((st = ensure(&b.bincnt, &b.bincnt_cap, (uint64_t)g1 * nparts))) return st;
+            if ((st = ensure(&b.ovf, &b.ovf_cap, ngroups * BIN_G))) return st;
+            if ((st = ensure(&b.ovf_hdr, &b.ovf_hdr_cap, ngroups))) return st;
+            if ((st = ensure(&b.cand, &b.cand_cap, (npairs + 31) / 32 + 64))) return st;
+            HIPCHK(hipMemsetAsync(b.cand, 0, ((npairs + 31) / 32) * sizeof(uint32_t), s));
+            a.bins = b.bins; a.bincnt = b.bincnt; a.bin_cap = (uint32_t)bcap; a.bin_pb = pb; a.bin_waves = g1;
+            a.ovf = b.ovf; a.ovf_hdr = b.ovf_hdr; a.novf = c->d_small + 4; a.candbits = b.cand;
+            if (tm)  // slot 0 brackets the three launches: no fold of the event pools may fall in between
+                for (int i : {0, 4, 5, 6})
+                    if (c->timed[i].used == EVPOOL) {
+                        HIPCHK(sync_all(c));
+                        for (int j = 0; j < NKERN; ++j) fold_timer(c->timed[j]);
+                        break;
+                    }
+            if ((st = rec_beg(0))) return st;
+            const int e0 = e;
+            if ((st = rec_beg(4))) return st;
+            hipLaunchKernelGGL(k_encode_bin, dim3(g1), dim3(K1_NT), 0, s, a);
+            if ((st = rec_end(4))) return st;
+            if ((st = rec_beg(5))) return st;
+            hipLaunchKernelGGL(k_filter_bins, dim3(c->num_cu * 16), dim3(64), 0, s, a);
+            if ((st = rec_end(5))) return st;
+            if ((st = rec_beg(6))) return st;
+            hipLaunchKernelGGL(k_subfilter_cand, dim3(c->num_cu * 8), dim3(64), 0, s, a);
+            if ((st = rec_end(6))) return st;
+            e = e0;
+            if ((st = rec_end(0))) return st;
+        }
+    }
+    if (!binned) {
+        const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->k1_blocks ? ntiles : (uint64_t)c->k1_blocks);  // resident waves
+        if ((st = rec_beg(0))) return st;
+        hipLaunchKernelGGL(k_encode_subfilter, dim3(g1), dim3(K1_NT), 0, s, a);
+        if ((st = rec_end(0))) return st;
+    }
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         a.t0 = (uint32_t)(ch * tcap);
         a.ticket = c->d_tickets + ch;
@@ -593,6 +679,10 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_subfilter, K1_NT, 0) != hipSuccess || nb <= 0) nb = 4;
         c->k1_blocks = c->num_cu * nb;
+        nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_bin, K1_NT, 0) != hipSuccess || nb <= 0) nb = 4;
+        c->k1bin_blocks = c->num_cu * nb;
+        if (const char* ev = getenv("DBTK_K1_BINNED")) c->k1_binned = atoi(ev);
         // resident waves of each resolve-kernel instance (one vote-spill scratch row per resident wave)
         const void* kp[3] = {(const void*)k_pair<2, true>, (const void*)k_pair<3, true>, (const void*)k_pair<4, true>};
         for (int i = 0; i < 3; ++i) {
@@ -614,6 +704,9 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         c->timed[1].name = "k_probe";
         c->timed[2].name = "k_pair_usual";
         c->timed[3].name = "k_pair";
+        c->timed[4].name = "k_encode_bin";
+        c->timed[5].name = "k_filter_bins";
+        c->timed[6].name = "k_subfilter_cand";
         for (int i = 0; i < NKERN && !st; ++i)
             for (int j = 0; j < EVPOOL && !st; ++j)
                 if (hipEventCreate(&c->timed[i].beg[j]) != hipSuccess || hipEventCreate(&c->timed[i].end[j]) != hipSuccess) { set_error("hipEventCreate failed"); st = DBTK_ERR_HIP; }

@@ -26,6 +26,8 @@
 #ifndef DBTK_KERNELS_H_
 #define DBTK_KERNELS_H_
 
+#include <type_traits>
+
 #include "dbtk_assign.h"
 #include "dbtk_sort.h"
 #include "dbtk_tables.h"
@@ -64,15 +66,15 @@ DBTK_HD void body_idx_insert(X& x, const IdxBuildArgs& a) {
 }
 struct FltBuildArgs {
     uint64_t* words;
-    uint64_t mask;
+    uint32_t logw, ksize;  // 2^logw words; k
     const uint64_t* keys;
     uint64_t n;
 };
 template <class X>
 DBTK_HD void body_flt_insert(X& x, const FltBuildArgs& a) {
     for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.n; i += (uint64_t)x.nblocks() * x.nthreads()) {
-        const uint64_t h = hash_mix(a.keys[i]);
-        x.atomic_or(&a.words[flt_word(h, a.mask)], flt_bits(h));
+        const uint64_t m = kmix(a.keys[i], a.ksize);
+        x.atomic_or(&a.words[flt_word(m, a.ksize, a.logw)], flt_bits(m));
     }
 }
 template <class X>
@@ -198,6 +200,16 @@ struct BatchArgs {
     uint32_t events_cap;
     uint32_t t0, tcap;       // K2/K3 work on survivors [t0, min(t0 + tcap, *nsurv)): the hit buffer holds tcap pairs
     uint32_t* tile_ticket;   // K1 work counter (tiles)
+    // Binned encode stage (body_encode_subfilter<true> -> body_filter_bins -> body_subfilter_cand): per (encode wave,
+    // filter partition) a segment of bin_cap queries, the number each segment holds, groups of BIN_G queries that
+    // found their segment full, and one bit per pair: "a sampled k-mer of mate 1 is in the index".
+    uint64_t* bins;
+    uint32_t* bincnt;
+    uint32_t bin_cap, bin_pb, bin_waves;  // segment capacity (multiple of BIN_G), log2(partitions) <= 6, encode waves
+    uint64_t* ovf;
+    uint32_t* ovf_hdr;       // per overflow group: partition | entries << 8
+    uint32_t* novf;
+    uint32_t* candbits;
     uint32_t vzero;          // always 0: `lane * vzero` makes an address look lane-dependent, so that a load whose value is only
                              // needed an iteration later is not turned into scalars (and waited for) right where it is issued
 };
@@ -274,6 +286,17 @@ struct K1Smem {
     uint32_t sbuf[K1_SBF + K1_TP];          // survivors not yet appended to the global list
 };
 
+// The binned form of the stage stages its filter queries per partition in the wave's LDS: a ring of BIN_RC queries per
+// partition, flushed BIN_G (= one 128-byte line) at a time.
+constexpr int BIN_RC = 32, BIN_G = 16, BIN_MAXPB = 6;
+constexpr uint64_t BIN_OVF = 1ull << 63;
+struct K1BinSmem : K1Smem {
+    uint64_t ring[64 * BIN_RC];
+    uint64_t fld[64];                // flush list: destination (element index into bins, or BIN_OVF | index into ovf)
+    uint32_t flh[64];                // flush list: partition << 16 | ring position of the group's first entry
+    uint32_t tail[64], head[64];     // per partition: queries accepted / flushed so far (sequence numbers)
+};
+
 // true iff bases [b, b+len) of the stream contain a run of >= k valid bases
 DBTK_HD bool any_valid_window(const uint16_t* vd, uint32_t b, uint32_t len, uint32_t k) {
     if (len < k) return false;
@@ -305,10 +328,11 @@ DBTK_HD void load_tail_chunk(const uint8_t* seq, uint64_t seq_len, uint64_t g, u
     for (uint32_t b = 0; b < 16 && g + b < seq_len; ++b) w[b >> 2] |= (uint32_t)seq[g + b] << (8 * (b & 3));
 }
 
-template <class X>
+template <bool BIN, class X>
 DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     uint64_t* const ctr = counters_of(x, a);
-    K1Smem& sm = *x.template smem<K1Smem>();
+    using SM = typename std::conditional<BIN, K1BinSmem, K1Smem>::type;
+    SM& sm = *x.template smem<SM>();
     const uint32_t lane = (uint32_t)x.lane();
     const uint32_t k = a.P.ksize, NF = a.P.n_filter, NM = a.P.nm_filter;
     const bool dosub = NF && NM;
@@ -355,6 +379,76 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         base = x.bcast(base, 0);
         for (uint32_t i = lane; i < nsb; i += K1_NT) a.surv[base + i] = sm.sbuf[i];
         x.sync();
+    };
+    // ---- binned form: lane p owns partition p's ring (myhead: first entry not yet flushed, rcount: entries in its segment)
+    const uint32_t nparts = BIN ? 1u << a.bin_pb : 0u;
+    uint32_t myhead = 0, rcount = 0;
+    if constexpr (BIN) {
+        sm.tail[lane] = 0; sm.head[lane] = 0;
+        x.sync();
+    }
+    // flush one group of BIN_G entries of every partition that holds that many (all = false), or what is left (all = true)
+    auto bin_flush = [&](uint32_t n, bool all) -> uint32_t {
+        if constexpr (BIN) {
+            for (;;) {
+                const bool mine = all ? n > 0 : n >= (uint32_t)BIN_G;
+                const uint64_t fm = x.ballot(mine);
+                if (fm == 0) break;
+                const uint32_t nF = (uint32_t)__builtin_popcountll(fm);
+                if (mine) {
+                    const uint32_t r = (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1));
+                    const uint32_t cnt = n < (uint32_t)BIN_G ? n : (uint32_t)BIN_G;
+                    uint64_t dst;
+                    if (rcount + cnt <= a.bin_cap) {
+                        dst = ((uint64_t)x.bid() * nparts + lane) * a.bin_cap + rcount;
+                        rcount += cnt;
+                    } else {  // the segment is full (skewed input): the group goes to the overflow list
+                        const uint32_t g = x.atomic_add(a.novf, 1u);
+                        a.ovf_hdr[g] = lane | (cnt << 8);
+                        dst = BIN_OVF | ((uint64_t)g * BIN_G);
+                    }
+                    sm.fld[r] = dst;
+                    sm.flh[r] = (lane << 16) | (cnt << 8) | (myhead & (BIN_RC - 1));
+                    myhead += cnt; n -= cnt;
+                }
+                x.sync();
+                for (uint32_t i = 0; i < nF; i += 4) {  // 16 lanes per group: one 128-byte line per group
+                    const uint32_t r = i + (lane >> 4), j = lane & 15;
+                    if (r < nF) {
+                        const uint32_t ph = sm.flh[r];
+                        const uint64_t d = sm.fld[r];
+                        if (j < ((ph >> 8) & 0xFF)) {
+                            const uint64_t v = sm.ring[(ph >> 16) * BIN_RC + (((ph & 0xFF) + j) & (BIN_RC - 1))];
+                            ((d & BIN_OVF) ? a.ovf : a.bins)[(d & ~BIN_OVF) + j] = v;
+                        }
+                    }
+                }
+                x.sync();
+            }
+        }
+        return n;
+    };
+    // every lane with `pend` appends `rec` to partition `part`
+    auto bin_push = [&](bool pend, uint32_t part, uint64_t rec) {
+        if constexpr (BIN) {
+            for (;;) {
+                if (pend) {
+                    const uint32_t s = x.lds_add(&sm.tail[part], 1u);
+                    if (s - sm.head[part] < (uint32_t)BIN_RC) { sm.ring[part * BIN_RC + (s & (BIN_RC - 1))] = rec; pend = false; }
+                }
+                x.sync();
+                uint32_t n = 0;
+                if (lane < nparts) {
+                    uint32_t t = sm.tail[lane];
+                    if (t - myhead > (uint32_t)BIN_RC) { t = myhead + BIN_RC; sm.tail[lane] = t; }  // (the lanes that found the ring full try again)
+                    n = t - myhead;
+                }
+                (void)bin_flush(n, false);
+                if (lane < nparts) sm.head[lane] = myhead;
+                x.sync();
+                if (x.ballot(pend) == 0) break;
+            }
+        }
     };
     const uint64_t stride = x.nblocks();
     uint64_t tile = x.bid();
@@ -446,7 +540,26 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         DBTK_STAMP(18);  // valid-window test
         // C/D: sampled probes; hm[mate] = hit mask of the sampled positions of my pair (same on its 4 lanes)
         uint32_t hm[2] = {0, 0};
-        if (dosub) {
+        if constexpr (BIN) {
+            // the sampled k-mers of mate 1 travel to the filter kernel, sorted by filter partition
+            const uint32_t sh = 2 * k - a.bin_pb;
+            uint32_t bpos = 0, L = 1, S = 0;
+            if (gany) {
+                bpos = sm.rb[2 * grp];
+                L = (uint32_t)sm.rl[2 * grp] - k + 1;
+                S = L / (NF - 1);
+            }
+            for (uint32_t s0 = 0; s0 < NF; s0 += 4) {
+                const uint32_t sidx = s0 + sub;
+                uint64_t km = NAN64;
+                if (gany && sidx < NF) {
+                    const uint32_t pos = (sidx != NF - 1) ? sidx * S : L - 1;
+                    km = clean ? window_kmer_clean(sm.pk, bpos + pos, k) : window_kmer(sm.pk, sm.vd, bpos + pos, k, nullptr, nullptr);
+                }
+                const uint64_t m = kmix(km & ((1ull << (2 * k)) - 1), k);
+                bin_push(km != NAN64, (uint32_t)(m >> sh), (m & ((1ull << sh) - 1)) | ((uint64_t)(p0 + grp) << sh));
+            }
+        } else if (dosub) {
             for (int mate = 0; mate < 2; ++mate) {
                 const bool go = gany && (mate == 0 || (uint32_t)__builtin_popcount(hm[0]) >= NM);
                 if (mate == 1 && x.ballot(go) == 0) break;  // nobody's mate 1 passed: the usual case
@@ -468,8 +581,8 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
 #endif
                     const uint64_t hmix = hash_mix(km);
                     if (a.T.flt && km != NAN64) {  // presence filter: "no" is final, and needs no HBM line
-                        const uint64_t fb = flt_bits(hmix);
-                        if ((a.T.flt[flt_word(hmix, a.T.flt_mask)] & fb) != fb) km = NAN64;
+                        const uint64_t fm = kmix(km, k), fb = flt_bits(fm);
+                        if ((a.T.flt[flt_word(fm, k, a.T.flt_logw)] & fb) != fb) km = NAN64;
                     }
                     const uint32_t hb = km != NAN64 ? (uint32_t)(hmix >> a.T.idx_shift) : 0u;
                     // Two rounds; in round r the lane pairs {0,1} and {2,3} of the group look up samples 2r and 2r+1:
@@ -518,6 +631,11 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
             if (!gany) {
                 stage = DBTK_STAGE_SHORT;
                 c_short += lead;
+            } else if (BIN) {
+                // provisional: "no sample of mate 1 is in the index" (NF probes, rejected); body_subfilter_cand corrects
+                // the pairs for which the filter kernel finds one
+                if (lead) { c_nhash += NF; c_probe += NF; c_sub += 2; }
+                stage = DBTK_STAGE_SUBFILTER;
             } else if (dosub) {
                 // subfilter's loop (AQ.cpp:176-180) stops at the NM-th hit, at sample p: p+1 probes, ++nhash p times;
                 // without NM hits it runs over all NF samples
@@ -551,6 +669,10 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         DBTK_STAMP(20);  // verdict + survivor append
     }
     if (nsb) flush_survivors();
+    if constexpr (BIN) {
+        (void)bin_flush(lane < nparts ? sm.tail[lane] - myhead : 0u, true);
+        if (lane < nparts) a.bincnt[(size_t)x.bid() * nparts + lane] = rcount;
+    }
     {
         const int lane = lane_;
         DBTK_STAMP_FLUSH;
@@ -567,6 +689,198 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         if (s_surv) x.atomic_add(&ctr[DBTK_C_SURVIVORS], (uint64_t)s_surv);
         const uint64_t bases = (uint64_t)b_lo + ((uint64_t)b_hi << 20);
         if (bases) x.atomic_add(&ctr[DBTK_C_BASES], bases);
+    }
+}
+
+
+// ------------------------------------------------ K1, binned form: stages 2 and 3 --
+// Why: a sampled k-mer costs one request to the memory system whatever answers it, and the chip completes ~55 G L2-miss
+// requests per second (tools/lat.hip) — 4 filter words per rejected pair were 20 M of the direct kernel's 36 M requests.
+// Sorted by filter partition, the same queries hit a 2 MB slice of the filter that stays in the L2 of the XCD working on
+// it: the encode kernel writes them as coalesced 128-byte lines (1/16 request per query), this kernel streams them back
+// (1/16) and the filter words are L2 hits.  "Maybe" (a few %) goes to the exact table as before.
+//
+// body_filter_bins: blocks b, b+8, b+16, ... share an XCD (MI355X_MICROARCH.md; an affinity, never a correctness
+// assumption), so group b % 8 takes the partitions p = b % 8 (mod 8), one after the other, and the blocks of a group
+// divide a partition's segments among themselves.  Maybes wait in LDS and are looked up 64 at a time.
+struct FltSmem {
+    uint64_t qk[128];
+    uint32_t qp[128];
+};
+constexpr int FLT_U = 4;  // queries per lane in flight
+template <class X>
+DBTK_HD void body_filter_bins(X& x, const BatchArgs& a) {
+    FltSmem& sm = *x.template smem<FltSmem>();
+    const uint32_t lane = (uint32_t)x.lane(), k = a.P.ksize;
+    const uint32_t nparts = 1u << a.bin_pb, sh = 2 * k - a.bin_pb, logw = a.T.flt_logw;
+    const uint64_t lowmask = (1ull << sh) - 1;
+    const uint64_t below = (1ull << lane) - 1;
+    uint32_t nq = 0;  // maybes waiting (wave-uniform)
+    auto drain = [&](bool all) {
+        while (nq >= 64 || (all && nq)) {
+            const uint32_t take = nq < 64 ? nq : 64, at = nq - take + lane;
+            if (lane < take) {
+                const uint32_t pair = sm.qp[at];
+                if (idx_contains(a.T, sm.qk[at])) (void)x.atomic_or32(&a.candbits[pair >> 5], 1u << (pair & 31));
+            }
+            nq -= take;
+            x.sync();
+        }
+    };
+    // FLT_U queries per lane: all the records, then all the filter words, in flight together
+    auto process = [&](const uint64_t* src, uint32_t cnt, uint32_t j0, uint32_t part) {
+        uint64_t rec[FLT_U], wd[FLT_U], m[FLT_U];
+        bool v[FLT_U];
+#pragma unroll
+        for (int u = 0; u < FLT_U; ++u) {
+            const uint32_t j = j0 + 64u * u + lane;
+            v[u] = j < cnt;
+            rec[u] = src[v[u] ? j : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < FLT_U; ++u) {
+            m[u] = ((uint64_t)part << sh) | (rec[u] & lowmask);
+            wd[u] = a.T.flt[v[u] ? flt_word(m[u], k, logw) : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < FLT_U; ++u) {
+            const uint64_t fb = flt_bits(m[u]);
+            const bool maybe = v[u] && (wd[u] & fb) == fb;
+            const uint64_t mm = x.ballot(maybe);
+            if (mm) {
+                if (maybe) {
+                    const uint32_t pos = nq + (uint32_t)__builtin_popcountll(mm & below);
+                    sm.qk[pos] = kunmix(m[u], k);
+                    sm.qp[pos] = (uint32_t)(rec[u] >> sh);
+                }
+                nq += (uint32_t)__builtin_popcountll(mm);
+                x.sync();
+                drain(false);
+            }
+        }
+    };
+    const uint32_t ngrp = x.nblocks() >= 8 ? 8u : 1u;
+    const uint32_t g = x.bid() % ngrp, i0 = x.bid() / ngrp, G = (x.nblocks() - g + ngrp - 1) / ngrp;  // blocks of my group
+    for (uint32_t p = g; p < nparts; p += ngrp)
+        for (uint32_t w = i0; w < a.bin_waves; w += G) {
+            const size_t seg = (size_t)w * nparts + p;
+            const uint32_t cnt = x.uni(a.bincnt[seg]);
+            const uint64_t* src = a.bins + seg * a.bin_cap;
+            for (uint32_t j0 = 0; j0 < cnt; j0 += 64u * FLT_U) process(src, cnt, j0, p);
+        }
+    {   // groups that found their segment full: any partition, no locality (skewed input only)
+        const uint32_t novf = x.uni(*a.novf);
+        for (uint32_t gi = x.bid(); gi < novf; gi += x.nblocks()) {
+            const uint32_t hdr = x.uni(a.ovf_hdr[gi]);
+            process(a.ovf + (size_t)gi * BIN_G, hdr >> 8, 0, hdr & 0xFF);
+        }
+    }
+    drain(true);
+}
+
+// body_subfilter_cand: the pairs whose bit the filter kernel set (a few %) get subfilter exactly as the reference runs it
+// (AQ.cpp:172-188) — eight lanes per pair, one per (mate, sample), k bytes of the read each — and the counters the encode
+// kernel booked provisionally for them are corrected (64-bit wrap-around adds).
+constexpr int K1C_LIST = 2048;
+struct CandSmem {
+    uint32_t list[K1C_LIST];
+    uint32_t sbuf[K1_SBF + 8];
+};
+// canonical k-mer of the k bytes at p, NAN64 if one of them is not ACGT
+DBTK_HD uint64_t kmer_of_bytes(const uint8_t* p, uint32_t k) {
+    uint64_t fw = 0;
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        const uint32_t c = p[i], code = ((c >> 1) ^ (c >> 2)) & 3;
+        bad |= c ^ ((0x54474341u >> (8 * code)) & 0xFFu);
+        fw = (fw << 2) | code;
+    }
+    if (bad) return NAN64;
+    const uint64_t rc = revcomp2(fw, k);
+    return fw < rc ? fw : rc;
+}
+template <class X>
+DBTK_HD void body_subfilter_cand(X& x, const BatchArgs& a) {
+    uint64_t* const ctr = counters_of(x, a);
+    CandSmem& sm = *x.template smem<CandSmem>();
+    const uint32_t lane = (uint32_t)x.lane();
+    const uint32_t k = a.P.ksize, NF = a.P.n_filter, NM = a.P.nm_filter;
+    const uint64_t below = (1ull << lane) - 1;
+    const uint64_t nwords = (a.npairs + 31) / 32;
+    uint64_t d_nhash = 0, d_probe = 0, d_sub = 0;  // corrections (modulo 2^64)
+    uint32_t c_surv = 0, nsb = 0;
+    auto flush_survivors = [&]() {
+        x.sync();
+        uint32_t base = 0;
+        if (lane == 0) base = x.atomic_add(a.nsurv, nsb);
+        base = x.bcast(base, 0);
+        for (uint32_t i = lane; i < nsb; i += 64) a.surv[base + i] = sm.sbuf[i];
+        x.sync();
+    };
+    for (uint64_t w0 = (uint64_t)x.bid() * 64; w0 < nwords; w0 += (uint64_t)x.nblocks() * 64) {
+        uint32_t word = 0;
+        if (w0 + lane < nwords) {
+            word = a.candbits[w0 + lane];
+            if (word) a.candbits[w0 + lane] = 0;  // (left clean for the next batch)
+        }
+        const uint32_t cnt = (uint32_t)__builtin_popcount(word);
+        uint32_t at = x.wave_excl_scan(cnt);
+        const uint32_t total = x.bcast(at + cnt, 63);
+        if (total == 0) continue;
+        x.sync();
+        for (uint32_t wd = word; wd; wd &= wd - 1) sm.list[at++] = (uint32_t)((w0 + lane) * 32) + (uint32_t)__builtin_ctz(wd);
+        x.sync();
+        for (uint32_t b = 0; b < total; b += 8) {
+            const uint32_t slot = b + (lane >> 3), mate = (lane >> 2) & 1, sub = lane & 3;
+            const bool valid = slot < total;
+            const uint32_t pair = valid ? sm.list[slot] : 0u;
+            const uint64_t o0 = a.off[2 * (uint64_t)pair + mate], o1 = a.off[2 * (uint64_t)pair + mate + 1];
+            const uint32_t L = (uint32_t)(o1 - o0) - k + 1, S = L / (NF - 1);  // (every candidate has a window in both mates)
+            uint32_t hm[2] = {0, 0};
+            for (uint32_t s0 = 0; s0 < NF; s0 += 4) {
+                const uint32_t sidx = s0 + sub;
+                bool hit = false;
+                if (valid && sidx < NF) {
+                    const uint32_t pos = (sidx != NF - 1) ? sidx * S : L - 1;
+                    const uint64_t km = kmer_of_bytes(a.seq + o0 + pos, k);
+                    hit = km != NAN64 && idx_contains(a.T, km);
+                }
+                const uint32_t h8 = (uint32_t)(x.ballot(hit) >> (lane & ~7u)) & 0xFFu;
+                hm[0] |= (h8 & 15u) << s0;
+                hm[1] |= (h8 >> 4) << s0;
+            }
+            // the verdict of body_encode_subfilter, minus what was booked there: NF, NF, 2
+            const bool lead = valid && (lane & 7) == 0;
+            uint32_t nhash = 0, nprobe = 0;
+            bool rej = false;
+            for (int mt = 0; mt < 2 && !rej; ++mt) {
+                uint32_t r = hm[mt];
+                for (uint32_t i = 1; i < NM; ++i) r &= r - 1;
+                const uint32_t pth = r ? (uint32_t)__builtin_ctz(r) : NF;
+                nhash += pth; nprobe += r ? pth + 1 : NF;
+                rej = r == 0;
+            }
+            if (lead) { d_nhash += (uint64_t)nhash - NF; d_probe += (uint64_t)nprobe - NF; d_sub -= rej ? 0 : 2; }
+            const bool pass = lead && !rej;
+            const uint64_t pm = x.ballot(pass);
+            if (pm) {
+                if (pass) { sm.sbuf[nsb + (uint32_t)__builtin_popcountll(pm & below)] = pair; ++c_surv; }
+                nsb += (uint32_t)__builtin_popcountll(pm);
+                if (nsb >= (uint32_t)K1_SBF) { flush_survivors(); nsb = 0; }
+            }
+        }
+        x.sync();
+    }
+    if (nsb) flush_survivors();
+    // wave sums of the corrections (two 32-bit halves each), one atomic each
+    auto sum64 = [&](uint64_t v) { return (uint64_t)x.wave_sum((uint32_t)(v & 0xFFFFF)) + ((uint64_t)x.wave_sum((uint32_t)((v >> 20) & 0xFFFFF)) << 20) + ((uint64_t)x.wave_sum((uint32_t)(v >> 40)) << 40); };
+    const uint64_t s_nhash = sum64(d_nhash), s_probe = sum64(d_probe), s_sub = sum64(d_sub);
+    const uint32_t s_surv = x.wave_sum(c_surv);
+    if (lane == 0) {
+        if (s_nhash) x.atomic_add(&ctr[DBTK_C_NHASH0], s_nhash);
+        if (s_probe) x.atomic_add(&ctr[DBTK_C_ALGO_PROBES], s_probe);
+        if (s_sub) x.atomic_add(&ctr[DBTK_C_SUBFILTERED], s_sub);
+        if (s_surv) x.atomic_add(&ctr[DBTK_C_SURVIVORS], (uint64_t)s_surv);
     }
 }
 

@@ -72,8 +72,8 @@ struct DevTables {
     uint32_t cls_shift;
     const uint8_t* qc;        // nullptr or nloci bytes
     const uint16_t* permtab;  // introsort permutation of n equal keys, n = 1..NHMAX, row n at n(n-1)/2
-    const uint64_t* flt;      // presence filter words (nullptr: none), flt_mask = words - 1
-    uint64_t flt_mask;
+    const uint64_t* flt;      // presence filter words (nullptr: none), 2^flt_logw of them
+    uint32_t flt_logw;
     const uint32_t* trbeg;    // nloci + 1: first OUT.trkmc.ar slot of each locus (its TR k-mers' counters are contiguous)
     uint32_t nloci;
     uint32_t ksize;
@@ -89,13 +89,39 @@ DBTK_HD uint64_t hash_mix(uint64_t key) {
     return key * 0x9E3779B97F4A7C15ull;
 }
 DBTK_HD uint64_t hash_idx(uint64_t key, uint32_t shift) { return hash_mix(key) >> shift; }
-// ---- presence filter in front of the index (encode kernel only).  98 % of the sampled k-mers of WGS reads are not in
+// ---- presence filter in front of the index (encode stage only).  98 % of the sampled k-mers of WGS reads are not in
 // the index, and each such probe costs a 64-byte line of HBM traffic next to the read stream it competes with.  A
-// word-blocked Bloom filter of ~4 bits per key (64 MB at release scale) stays resident in the 256 MB Infinity Cache
-// behind the stream; "no" is final, "maybe" (the keys themselves plus ~20 % of the others) goes on to the table, so
-// the answer is exact.  Three bits of one 64-bit word per key, all taken from the same mixing product as the bucket.
-DBTK_HD uint64_t flt_word(uint64_t h, uint64_t mask) { return (h >> 30) & mask; }
-DBTK_HD uint64_t flt_bits(uint64_t h) { return (1ull << ((h >> 6) & 63)) | (1ull << ((h >> 12) & 63)) | (1ull << ((h >> 18) & 63)); }
+// word-blocked Bloom filter of ~4 bits per key (128 MB at release scale) answers them: "no" is final, "maybe" (the keys
+// themselves plus a few % of the others) goes on to the table, so the answer is exact.  Three bits of one 64-bit word per key.
+// The filter is addressed through a BIJECTIVE mix of the 2k-bit k-mer onto 2k bits (odd multiplications modulo 2^2k and
+// xor-shifts by k are each invertible): the top bits pick the word, so a contiguous range of the filter ("partition") is a
+// contiguous range of mixed values, and a query can travel as the low bits of its mixed value — the binned encode stage packs
+// (mixed value without the partition bits | pair index) into 8 bytes and the filter kernel recovers the k-mer with kunmix.
+constexpr uint64_t KMIX_C1 = 0x9E3779B97F4A7C15ull, KMIX_C2 = 0xD6E8FEB86659FD93ull;
+constexpr uint64_t inv_odd64(uint64_t a) {  // a^-1 modulo 2^64 (Newton: doubles the correct bits per step)
+    uint64_t x = a;
+    for (int i = 0; i < 6; ++i) x *= 2 - a * x;
+    return x;
+}
+constexpr uint64_t KMIX_I1 = inv_odd64(KMIX_C1), KMIX_I2 = inv_odd64(KMIX_C2);
+static_assert(KMIX_C1 * KMIX_I1 == 1 && KMIX_C2 * KMIX_I2 == 1, "modular inverses");
+DBTK_HD uint64_t kmix(uint64_t km, uint32_t k) {  // k <= 31
+    const uint64_t M = (1ull << (2 * k)) - 1;
+    uint64_t m = (km * KMIX_C1) & M;
+    m ^= m >> k;
+    m = (m * KMIX_C2) & M;
+    return m ^ (m >> k);
+}
+DBTK_HD uint64_t kunmix(uint64_t m, uint32_t k) {
+    const uint64_t M = (1ull << (2 * k)) - 1;
+    m ^= m >> k;
+    m = (m * KMIX_I2) & M;
+    m ^= m >> k;
+    return (m * KMIX_I1) & M;
+}
+// word of a mixed value in a filter of 2^logw words: its top bits
+DBTK_HD uint64_t flt_word(uint64_t m, uint32_t k, uint32_t logw) { return logw <= 2 * k ? m >> (2 * k - logw) : m; }
+DBTK_HD uint64_t flt_bits(uint64_t m) { return (1ull << (m & 63)) | (1ull << ((m >> 6) & 63)) | (1ull << ((m >> 12) & 63)); }
 DBTK_HD uint64_t hash_cls(uint64_t kmer, uint32_t locus, uint32_t shift) {
     uint64_t x = kmer ^ ((uint64_t)locus * 0xD6E8FEB86659FD93ull);
     x ^= x >> 31;
@@ -132,6 +158,18 @@ DBTK_HD uint64_t idx_lookup64(const DevTables& T, uint64_t key) {
     }
 }
 DBTK_HD uint32_t idx_lookup(const DevTables& T, uint64_t key) { return (uint32_t)idx_lookup64(T, key); }
+// kmerDBi.count(kmer): the keys only
+DBTK_HD bool idx_contains(const DevTables& T, uint64_t key) {
+    uint64_t b = hash_idx(key, T.idx_shift);
+    for (;;) {
+        uint64_t k[4];
+        bucket_keys(&T.idx[b], k);
+        const int r = bucket_find(k, key);
+        if (r < 4) return true;
+        if (r == BKT_MISS) return false;
+        b = (b + 1) & T.idx_mask;
+    }
+}
 // flankDB[locus].count(km) / trKmers[locus].find(km) in one probe.
 DBTK_HD uint32_t cls_lookup(const DevTables& T, uint64_t kmer, uint32_t locus) {
     uint64_t i = hash_cls(kmer, locus, T.cls_shift);

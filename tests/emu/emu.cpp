@@ -79,6 +79,7 @@ struct EmuX {
     uint64_t atomic_cas(uint64_t* p, uint64_t e, uint64_t d) const { uint64_t o = *p; if (o == e) *p = d; return o; }
     void atomic_max(uint64_t* p, uint64_t v) const { if (v > *p) *p = v; }
     void atomic_or(uint64_t* p, uint64_t v) const { *p |= v; }
+    uint32_t atomic_or32(uint32_t* p, uint32_t v) const { uint32_t o = *p; *p |= v; return o; }
     uint64_t clock() const { return 0; }
     uint32_t uni(uint32_t v) const { return v; }
     uint32_t lds_add(uint32_t* p, uint32_t v) const { uint32_t o = *p; *p += v; return o; }
@@ -275,7 +276,7 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
         run_grid(3, 64, 0, [&](EmuX& x) { body_idx_finalize(x, e->idx.data(), icap); });
         // presence filter (deliberately small here: many false positives exercise the "maybe" path)
         e->flt.assign(pow2((2 * g->keys.size() + 63) / 64) / 1024 ? pow2((2 * g->keys.size() + 63) / 64) : 1024, 0);
-        FltBuildArgs fa{e->flt.data(), e->flt.size() - 1, g->keys.data(), g->keys.size()};
+        FltBuildArgs fa{e->flt.data(), (uint32_t)(63 - __builtin_clzll(e->flt.size())), g->ksize, g->keys.data(), g->keys.size()};
         run_grid(3, 64, 0, [&](EmuX& x) { body_flt_insert(x, fa); });
     }
     e->vv = g->vv;
@@ -301,7 +302,7 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
     for (uint64_t l = 0; l <= nloci; ++l) e->trbeg[l] = (uint32_t)g->out_beg[l];
     DevTables& T = e->T;
     T.trbeg = e->trbeg.data();
-    T.flt = e->flt.data(); T.flt_mask = e->flt.size() - 1;
+    T.flt = e->flt.data(); T.flt_logw = (uint32_t)(63 - __builtin_clzll(e->flt.size()));
     T.idx = e->idx.data(); T.idx_mask = nbkt - 1; T.idx_shift = 64 - lg(nbkt);
     T.vv = e->vv.data();
     T.cls = e->cls.data(); T.cls_mask = ccap - 1; T.cls_shift = 64 - lg(ccap);
@@ -522,6 +523,11 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
                  dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec, uint32_t grid_k1, uint32_t grid_pair, BubEvent* ev,
                  uint64_t evcap, uint64_t* nev);
 
+// the binned encode stage: off (0), or on with 2^pb filter partitions, segments of `cap` queries and `nflt` filter waves
+static int g_binned = 0;
+static uint32_t g_bin_pb = 0, g_bin_cap = 64, g_bin_nflt = 8;
+void emu_set_binned(int on, uint32_t pb, uint32_t cap, uint32_t nflt) { g_binned = on; g_bin_pb = pb; g_bin_cap = cap / BIN_G * BIN_G; g_bin_nflt = nflt ? nflt : 1; }
+
 int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
               uint64_t npairs, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* counters,
               dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec, uint32_t grid_k1, uint32_t grid_pair) {
@@ -578,7 +584,24 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         qmaskbuf.assign((size_t)tcap * 2 * 4 + 1, 0);
         a.qual = (const uint8_t*)qualbuf.data(); a.qmaskbuf = qmaskbuf.data();
     }
-    run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter(x, a); });
+    std::vector<uint32_t> small2(4, 0);
+    const uint32_t pb = std::min<uint32_t>({g_bin_pb, (uint32_t)BIN_MAXPB, a.T.flt_logw, 2 * g->ksize}), nparts = 1u << pb;
+    // (as the device launcher decides: a query = mixed k-mer without its partition bits | pair index must fit 64 bits)
+    if (g_binned && a.T.flt && p->n_filter && p->nm_filter && !p->trace && npairs &&
+        (2 * g->ksize - pb) + (64 - (uint32_t)__builtin_clzll(npairs)) <= 64) {
+        const uint64_t ntiles = (npairs + K1_TP - 1) / K1_TP, nfr = (p->n_filter + 3) / 4;
+        const uint64_t ngroups = ntiles * 64 * nfr / BIN_G + (uint64_t)grid_k1 * nparts + 64;
+        std::vector<uint64_t> bins((size_t)grid_k1 * nparts * g_bin_cap + BIN_G, 0), ovf(ngroups * BIN_G, 0);
+        std::vector<uint32_t> bincnt((size_t)grid_k1 * nparts, 0xFFFFFFFFu), ovf_hdr(ngroups, 0), cand((npairs + 31) / 32 + 1, 0);
+        a.bins = bins.data(); a.bincnt = bincnt.data(); a.bin_cap = g_bin_cap; a.bin_pb = pb; a.bin_waves = grid_k1;
+        a.ovf = ovf.data(); a.ovf_hdr = ovf_hdr.data(); a.novf = &small2[0]; a.candbits = cand.data();
+        run_grid(grid_k1, K1_NT, sizeof(K1BinSmem), [&](EmuX& x) { body_encode_subfilter<true>(x, a); });
+        run_grid(g_bin_nflt, 64, sizeof(FltSmem), [&](EmuX& x) { body_filter_bins(x, a); });
+        run_grid(grid_k1 + 1, 64, sizeof(CandSmem), [&](EmuX& x) { body_subfilter_cand(x, a); });
+        for (uint32_t w : cand) if (w) return -77;  // the candidate bitmap is left clean
+    } else {
+        run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter<false>(x, a); });
+    }
     for (uint32_t t0 = 0; t0 < (uint32_t)(npairs ? npairs : 1); t0 += tcap) {
         a.t0 = t0;
         uint32_t ticket = 0;
