@@ -228,7 +228,7 @@ struct dbtk_ctx {
     std::vector<std::unordered_map<uint64_t, uint64_t>> btTK;
     std::vector<std::unordered_map<uint64_t, uint16_t>> baitDB_host;
     std::vector<dbtk_pair_rec_t> own_recs;  // record buffer when the caller passes none but -tb needs the bait-stage records
-    int k1_blocks = 0, k1bin_blocks = 0;
+    int k1_blocks = 0, k1bin_blocks = 0, flt_wpc = 16;
     BinScratch bin;
     int k1_binned = 0;   // DBTK_K1_BINNED: 0 never, 1 always (where it applies), -1 for batches of >= 65536 pairs
     bool timers_on = true;
@@ -562,14 +562,14 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         const uint64_t qwave = ((ntiles + g1 - 1) / g1) * 64 * nfr;  // queries one encode wave can emit
         uint64_t bcap = ((qwave / nparts) * 3 / 2 + 64 + BIN_G - 1) / BIN_G * BIN_G;  // 1.5 x the even share (+ slack): the rest overflows
         if (const char* ev = getenv("DBTK_K1_BINCAP")) { const long v = atol(ev); if (v >= 0) bcap = (uint64_t)v / BIN_G * BIN_G; }  // (tests: force overflow groups)
-        const uint64_t ngroups = ntiles * 64 * nfr / BIN_G + (uint64_t)g1 * nparts + 64;  // every query overflowing + every partial group
+        const uint64_t novfmax = ntiles * 64 * nfr + 64;  // every query overflowing
         if ((uint64_t)g1 * nparts * bcap >= (1ull << 40)) binned = false;
         if (binned) {
             BinScratch& b = c->bin;
             if ((st = ensure(&b.bins, &b.bins_cap, (uint64_t)g1 * nparts * bcap + BIN_G))) return st;
             if ((st = ensure(&b.bincnt, &b.bincnt_cap, (uint64_t)g1 * nparts))) return st;
-            if ((st = ensure(&b.ovf, &b.ovf_cap, ngroups * BIN_G))) return st;
-            if ((st = ensure(&b.ovf_hdr, &b.ovf_hdr_cap, ngroups))) return st;
+            if ((st = ensure(&b.ovf, &b.ovf_cap, novfmax))) return st;
+            if ((st = ensure(&b.ovf_hdr, &b.ovf_hdr_cap, novfmax))) return st;
             if ((st = ensure(&b.cand, &b.cand_cap, (npairs + 31) / 32 + 64))) return st;
             HIPCHK(hipMemsetAsync(b.cand, 0, ((npairs + 31) / 32) * sizeof(uint32_t), s));
             a.bins = b.bins; a.bincnt = b.bincnt; a.bin_cap = (uint32_t)bcap; a.bin_pb = pb; a.bin_waves = g1;
@@ -587,10 +587,10 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             hipLaunchKernelGGL(k_encode_bin, dim3(g1), dim3(K1_NT), 0, s, a);
             if ((st = rec_end(4))) return st;
             if ((st = rec_beg(5))) return st;
-            hipLaunchKernelGGL(k_filter_bins, dim3(c->num_cu * 16), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(k_filter_bins, dim3(c->num_cu * c->flt_wpc), dim3(64), 0, s, a);
             if ((st = rec_end(5))) return st;
             if ((st = rec_beg(6))) return st;
-            hipLaunchKernelGGL(k_subfilter_cand, dim3(c->num_cu * 8), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(k_subfilter_cand, dim3(c->num_cu * 8), dim3(64), 0, s, a);  // (few waves: each ends with one atomic on the survivor counter)
             if ((st = rec_end(6))) return st;
             e = e0;
             if ((st = rec_end(0))) return st;
@@ -681,8 +681,10 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         c->k1_blocks = c->num_cu * nb;
         nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_bin, K1_NT, 0) != hipSuccess || nb <= 0) nb = 4;
+        if (const char* ev = getenv("DBTK_K1_WPC")) { const int v = atoi(ev); if (v > 0 && v < nb) nb = v; }  // diagnostic: encode waves per CU
         c->k1bin_blocks = c->num_cu * nb;
         if (const char* ev = getenv("DBTK_K1_BINNED")) c->k1_binned = atoi(ev);
+        if (const char* ev = getenv("DBTK_FLT_WPC")) { const int v = atoi(ev); if (v > 0) c->flt_wpc = v; }  // diagnostic: filter waves per CU
         // resident waves of each resolve-kernel instance (one vote-spill scratch row per resident wave)
         const void* kp[3] = {(const void*)k_pair<2, true>, (const void*)k_pair<3, true>, (const void*)k_pair<4, true>};
         for (int i = 0; i < 3; ++i) {

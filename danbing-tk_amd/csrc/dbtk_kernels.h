@@ -201,13 +201,13 @@ struct BatchArgs {
     uint32_t t0, tcap;       // K2/K3 work on survivors [t0, min(t0 + tcap, *nsurv)): the hit buffer holds tcap pairs
     uint32_t* tile_ticket;   // K1 work counter (tiles)
     // Binned encode stage (body_encode_subfilter<true> -> body_filter_bins -> body_subfilter_cand): per (encode wave,
-    // filter partition) a segment of bin_cap queries, the number each segment holds, groups of BIN_G queries that
+    // filter partition) a segment of bin_cap queries, the number each segment holds, the queries that
     // found their segment full, and one bit per pair: "a sampled k-mer of mate 1 is in the index".
     uint64_t* bins;
     uint32_t* bincnt;
     uint32_t bin_cap, bin_pb, bin_waves;  // segment capacity (multiple of BIN_G), log2(partitions) <= 6, encode waves
-    uint64_t* ovf;
-    uint32_t* ovf_hdr;       // per overflow group: partition | entries << 8
+    uint64_t* ovf;           // queries that found their segment full, and their partitions
+    uint32_t* ovf_hdr;
     uint32_t* novf;
     uint32_t* candbits;
     uint32_t vzero;          // always 0: `lane * vzero` makes an address look lane-dependent, so that a load whose value is only
@@ -286,15 +286,11 @@ struct K1Smem {
     uint32_t sbuf[K1_SBF + K1_TP];          // survivors not yet appended to the global list
 };
 
-// The binned form of the stage stages its filter queries per partition in the wave's LDS: a ring of BIN_RC queries per
-// partition, flushed BIN_G (= one 128-byte line) at a time.
-constexpr int BIN_RC = 32, BIN_G = 16, BIN_MAXPB = 6;
-constexpr uint64_t BIN_OVF = 1ull << 63;
+// The binned form of the stage appends each filter query to the segment of its (wave, partition): the position comes
+// from a counter in the wave's LDS, the 8-byte stores of a segment's current line merge in the XCD's write-back L2.
+constexpr int BIN_G = 16, BIN_MAXPB = 6;  // segments are sized in lines of 16 queries; at most 64 partitions
 struct K1BinSmem : K1Smem {
-    uint64_t ring[64 * BIN_RC];
-    uint64_t fld[64];                // flush list: destination (element index into bins, or BIN_OVF | index into ovf)
-    uint32_t flh[64];                // flush list: partition << 16 | ring position of the group's first entry
-    uint32_t tail[64], head[64];     // per partition: queries accepted / flushed so far (sequence numbers)
+    uint32_t tail[64];  // per partition: queries emitted so far
 };
 
 // true iff bases [b, b+len) of the stream contain a run of >= k valid bases
@@ -380,73 +376,22 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         for (uint32_t i = lane; i < nsb; i += K1_NT) a.surv[base + i] = sm.sbuf[i];
         x.sync();
     };
-    // ---- binned form: lane p owns partition p's ring (myhead: first entry not yet flushed, rcount: entries in its segment)
+    // ---- binned form
     const uint32_t nparts = BIN ? 1u << a.bin_pb : 0u;
-    uint32_t myhead = 0, rcount = 0;
     if constexpr (BIN) {
-        sm.tail[lane] = 0; sm.head[lane] = 0;
+        sm.tail[lane] = 0;
         x.sync();
     }
-    // flush one group of BIN_G entries of every partition that holds that many (all = false), or what is left (all = true)
-    auto bin_flush = [&](uint32_t n, bool all) -> uint32_t {
+    // every lane with `has` appends `rec` to the segment of partition `part` (or, the segment full — skewed input — to the overflow list)
+    auto bin_push = [&](bool has, uint32_t part, uint64_t rec) {
         if constexpr (BIN) {
-            for (;;) {
-                const bool mine = all ? n > 0 : n >= (uint32_t)BIN_G;
-                const uint64_t fm = x.ballot(mine);
-                if (fm == 0) break;
-                const uint32_t nF = (uint32_t)__builtin_popcountll(fm);
-                if (mine) {
-                    const uint32_t r = (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1));
-                    const uint32_t cnt = n < (uint32_t)BIN_G ? n : (uint32_t)BIN_G;
-                    uint64_t dst;
-                    if (rcount + cnt <= a.bin_cap) {
-                        dst = ((uint64_t)x.bid() * nparts + lane) * a.bin_cap + rcount;
-                        rcount += cnt;
-                    } else {  // the segment is full (skewed input): the group goes to the overflow list
-                        const uint32_t g = x.atomic_add(a.novf, 1u);
-                        a.ovf_hdr[g] = lane | (cnt << 8);
-                        dst = BIN_OVF | ((uint64_t)g * BIN_G);
-                    }
-                    sm.fld[r] = dst;
-                    sm.flh[r] = (lane << 16) | (cnt << 8) | (myhead & (BIN_RC - 1));
-                    myhead += cnt; n -= cnt;
+            if (has) {
+                const uint32_t s = x.lds_add(&sm.tail[part], 1u);
+                if (s < a.bin_cap) a.bins[((uint64_t)x.bid() * nparts + part) * a.bin_cap + s] = rec;
+                else {
+                    const uint32_t g = x.atomic_add(a.novf, 1u);
+                    a.ovf[g] = rec; a.ovf_hdr[g] = part;
                 }
-                x.sync();
-                for (uint32_t i = 0; i < nF; i += 4) {  // 16 lanes per group: one 128-byte line per group
-                    const uint32_t r = i + (lane >> 4), j = lane & 15;
-                    if (r < nF) {
-                        const uint32_t ph = sm.flh[r];
-                        const uint64_t d = sm.fld[r];
-                        if (j < ((ph >> 8) & 0xFF)) {
-                            const uint64_t v = sm.ring[(ph >> 16) * BIN_RC + (((ph & 0xFF) + j) & (BIN_RC - 1))];
-                            ((d & BIN_OVF) ? a.ovf : a.bins)[(d & ~BIN_OVF) + j] = v;
-                        }
-                    }
-                }
-                x.sync();
-            }
-        }
-        return n;
-    };
-    // every lane with `pend` appends `rec` to partition `part`
-    auto bin_push = [&](bool pend, uint32_t part, uint64_t rec) {
-        if constexpr (BIN) {
-            for (;;) {
-                if (pend) {
-                    const uint32_t s = x.lds_add(&sm.tail[part], 1u);
-                    if (s - sm.head[part] < (uint32_t)BIN_RC) { sm.ring[part * BIN_RC + (s & (BIN_RC - 1))] = rec; pend = false; }
-                }
-                x.sync();
-                uint32_t n = 0;
-                if (lane < nparts) {
-                    uint32_t t = sm.tail[lane];
-                    if (t - myhead > (uint32_t)BIN_RC) { t = myhead + BIN_RC; sm.tail[lane] = t; }  // (the lanes that found the ring full try again)
-                    n = t - myhead;
-                }
-                (void)bin_flush(n, false);
-                if (lane < nparts) sm.head[lane] = myhead;
-                x.sync();
-                if (x.ballot(pend) == 0) break;
             }
         }
     };
@@ -556,6 +501,9 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                     const uint32_t pos = (sidx != NF - 1) ? sidx * S : L - 1;
                     km = clean ? window_kmer_clean(sm.pk, bpos + pos, k) : window_kmer(sm.pk, sm.vd, bpos + pos, k, nullptr, nullptr);
                 }
+#ifdef DBTK_STAMPS
+                if (a.P.reserved[0] & 1) km = NAN64;  // diagnostic: no queries
+#endif
                 const uint64_t m = kmix(km & ((1ull << (2 * k)) - 1), k);
                 bin_push(km != NAN64, (uint32_t)(m >> sh), (m & ((1ull << sh) - 1)) | ((uint64_t)(p0 + grp) << sh));
             }
@@ -670,8 +618,8 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     }
     if (nsb) flush_survivors();
     if constexpr (BIN) {
-        (void)bin_flush(lane < nparts ? sm.tail[lane] - myhead : 0u, true);
-        if (lane < nparts) a.bincnt[(size_t)x.bid() * nparts + lane] = rcount;
+        x.sync();
+        if (lane < nparts) a.bincnt[(size_t)x.bid() * nparts + lane] = sm.tail[lane] < a.bin_cap ? sm.tail[lane] : a.bin_cap;
     }
     {
         const int lane = lane_;
@@ -728,7 +676,7 @@ DBTK_HD void body_filter_bins(X& x, const BatchArgs& a) {
         }
     };
     // FLT_U queries per lane: all the records, then all the filter words, in flight together
-    auto process = [&](const uint64_t* src, uint32_t cnt, uint32_t j0, uint32_t part) {
+    auto process = [&](const uint64_t* src, const uint32_t* parts, uint32_t cnt, uint32_t j0, uint32_t part) {
         uint64_t rec[FLT_U], wd[FLT_U], m[FLT_U];
         bool v[FLT_U];
 #pragma unroll
@@ -739,6 +687,7 @@ DBTK_HD void body_filter_bins(X& x, const BatchArgs& a) {
         }
 #pragma unroll
         for (int u = 0; u < FLT_U; ++u) {
+            if (parts) part = parts[v[u] ? j0 + 64u * u + lane : 0];  // (overflow list: a partition per query)
             m[u] = ((uint64_t)part << sh) | (rec[u] & lowmask);
             wd[u] = a.T.flt[v[u] ? flt_word(m[u], k, logw) : 0];
         }
@@ -766,14 +715,11 @@ DBTK_HD void body_filter_bins(X& x, const BatchArgs& a) {
             const size_t seg = (size_t)w * nparts + p;
             const uint32_t cnt = x.uni(a.bincnt[seg]);
             const uint64_t* src = a.bins + seg * a.bin_cap;
-            for (uint32_t j0 = 0; j0 < cnt; j0 += 64u * FLT_U) process(src, cnt, j0, p);
+            for (uint32_t j0 = 0; j0 < cnt; j0 += 64u * FLT_U) process(src, nullptr, cnt, j0, p);
         }
-    {   // groups that found their segment full: any partition, no locality (skewed input only)
+    {   // queries that found their segment full: any partition, no locality (skewed input only)
         const uint32_t novf = x.uni(*a.novf);
-        for (uint32_t gi = x.bid(); gi < novf; gi += x.nblocks()) {
-            const uint32_t hdr = x.uni(a.ovf_hdr[gi]);
-            process(a.ovf + (size_t)gi * BIN_G, hdr >> 8, 0, hdr & 0xFF);
-        }
+        for (uint32_t j0 = x.bid() * 64u * FLT_U; j0 < novf; j0 += x.nblocks() * 64u * FLT_U) process(a.ovf, a.ovf_hdr, novf, j0, 0);
     }
     drain(true);
 }
@@ -781,7 +727,8 @@ DBTK_HD void body_filter_bins(X& x, const BatchArgs& a) {
 // body_subfilter_cand: the pairs whose bit the filter kernel set (a few %) get subfilter exactly as the reference runs it
 // (AQ.cpp:172-188) — eight lanes per pair, one per (mate, sample), k bytes of the read each — and the counters the encode
 // kernel booked provisionally for them are corrected (64-bit wrap-around adds).
-constexpr int K1C_LIST = 2048;
+constexpr int K1C_W = 64;               // bitmap words (of 32 pairs) a wave takes at a time
+constexpr int K1C_LIST = 32 * K1C_W;
 struct CandSmem {
     uint32_t list[K1C_LIST];
     uint32_t sbuf[K1_SBF + 8];
@@ -817,9 +764,9 @@ DBTK_HD void body_subfilter_cand(X& x, const BatchArgs& a) {
         for (uint32_t i = lane; i < nsb; i += 64) a.surv[base + i] = sm.sbuf[i];
         x.sync();
     };
-    for (uint64_t w0 = (uint64_t)x.bid() * 64; w0 < nwords; w0 += (uint64_t)x.nblocks() * 64) {
+    for (uint64_t w0 = (uint64_t)x.bid() * K1C_W; w0 < nwords; w0 += (uint64_t)x.nblocks() * K1C_W) {
         uint32_t word = 0;
-        if (w0 + lane < nwords) {
+        if (lane < (uint32_t)K1C_W && w0 + lane < nwords) {
             word = a.candbits[w0 + lane];
             if (word) a.candbits[w0 + lane] = 0;  // (left clean for the next batch)
         }

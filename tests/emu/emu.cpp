@@ -590,9 +590,9 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     if (g_binned && a.T.flt && p->n_filter && p->nm_filter && !p->trace && npairs &&
         (2 * g->ksize - pb) + (64 - (uint32_t)__builtin_clzll(npairs)) <= 64) {
         const uint64_t ntiles = (npairs + K1_TP - 1) / K1_TP, nfr = (p->n_filter + 3) / 4;
-        const uint64_t ngroups = ntiles * 64 * nfr / BIN_G + (uint64_t)grid_k1 * nparts + 64;
-        std::vector<uint64_t> bins((size_t)grid_k1 * nparts * g_bin_cap + BIN_G, 0), ovf(ngroups * BIN_G, 0);
-        std::vector<uint32_t> bincnt((size_t)grid_k1 * nparts, 0xFFFFFFFFu), ovf_hdr(ngroups, 0), cand((npairs + 31) / 32 + 1, 0);
+        const uint64_t novfmax = ntiles * 64 * nfr + 64;
+        std::vector<uint64_t> bins((size_t)grid_k1 * nparts * g_bin_cap + BIN_G, 0), ovf(novfmax, 0);
+        std::vector<uint32_t> bincnt((size_t)grid_k1 * nparts, 0xFFFFFFFFu), ovf_hdr(novfmax, 0), cand((npairs + 31) / 32 + 1, 0);
         a.bins = bins.data(); a.bincnt = bincnt.data(); a.bin_cap = g_bin_cap; a.bin_pb = pb; a.bin_waves = grid_k1;
         a.ovf = ovf.data(); a.ovf_hdr = ovf_hdr.data(); a.novf = &small2[0]; a.candbits = cand.data();
         run_grid(grid_k1, K1_NT, sizeof(K1BinSmem), [&](EmuX& x) { body_encode_subfilter<true>(x, a); });

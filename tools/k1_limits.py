@@ -39,7 +39,7 @@ def main():
         ctx.synchronize()
         kt = ctx.kernel_times()
         ms = kt["k_encode_subfilter"][0] / kt["k_encode_subfilter"][1]
-        print(f"{name:24s} K1 {ms:.3f} ms for {npairs} pairs = {npairs * 300 / ms / 1e6:.0f} GB/s of read bytes; all: " + ", ".join(f"{k} {v[0] / 5:.2f}" for k, v in kt.items()))
+        print(f"{name:24s} K1 {ms:.3f} ms for {npairs} pairs = {npairs * 300 / ms / 1e6:.0f} GB/s of read bytes; all: " + ", ".join(f"{k} {v[0] / 5:.2f}" for k, v in kt.items() if v[1]))
         ctx.close()
 
 
