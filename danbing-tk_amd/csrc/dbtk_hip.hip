@@ -690,6 +690,8 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         for (int i = 0; i < 3; ++i) {
             nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kp[i], 64, 0) != hipSuccess || nb <= 0) nb = 8;
+            if (const char* e = getenv("DBTK_PAIR_WPC")) { const int v = atoi(e); if (v > 0 && v < nb) nb = v; }  // diagnostic: waves per CU
+            if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_pair<%d>: %d waves per CU\n", i + 2, nb);
             c->pair_blocks[i] = c->num_cu * nb;
             c->max_pair_blocks = std::max(c->max_pair_blocks, c->pair_blocks[i]);
             const void* ku[3] = {(const void*)k_pair_usual<2, true>, (const void*)k_pair_usual<3, true>, (const void*)k_pair_usual<4, true>};

@@ -1834,9 +1834,11 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     const uint32_t nitems = listmode ? *a.ngen : (nsurv > a.t0 ? ((nsurv - a.t0 < a.tcap) ? nsurv - a.t0 : a.tcap) : 0u);
     constexpr uint32_t NOITEM = 0xFFFFFFFFu;
     if (nitems == 0) return;  // (an empty chunk must not touch the ticket: thousands of atomics on one address serialize)
-    // item bid is this wave's by convention; further ones come from the shared counter (the work per item varies a lot)
+    // Items bid, bid + nb, ...: a fixed stride.  (A shared ticket counter balanced the varying work per item better, but
+    // 20 000 atomics on one address serialize at ~18 ns each: they, not the work, were the kernel's 0.2 ms.)
     const uint32_t nb = x.nblocks();
-    auto take = [&]() { uint32_t v = 0; if (lane == 0) v = nb + x.atomic_add(a.ticket, 1u); return v; };  // lane 0 holds the ticket
+    uint32_t myq = x.bid();
+    auto take = [&]() { myq += nb; return myq; };
     auto lookup = [&](uint32_t q) -> uint32_t { return q < nitems ? (listmode ? a.gen_list[q] : a.t0 + q) : NOITEM; };
     HitEnt nx[2][NSLOT];
     uint32_t nxnk[2] = {0, 0}, nxpair = 0;
@@ -1886,6 +1888,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
 
 #ifdef DBTK_STAMPS
     uint64_t pair_t0_ = x.clock();
+    uint32_t diag_need = 0, diag_nu = 0;
 #endif
     for (;;) {
         if (t == NOITEM) break;
@@ -2109,6 +2112,9 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
 #pragma unroll
                         for (int j = 0; j < EPL; ++j) if (b0 + j < nu && (sm.w.a.uval[b0 + j] & 1)) need += sm.u.v.nml[b0 + j];
                         uint32_t at = x.wave_excl_scan(need);
+#ifdef DBTK_STAMPS
+                        diag_need = x.wave_sum(need);
+#endif
                         uint32_t* pool = sm.evd;  // (the parallel vote reads the pool before it writes evd over it)
 #pragma unroll
                         for (int j = 0; j < EPL; ++j) {
@@ -2156,6 +2162,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     } else if (lane == 0) gcc_sort_index(sm.u.v.ord, (int)nu, sm.u.v.nml, sm.stack);
                 }
                 x.sync();
+                DBTK_STAMP(14);  // the sort of the vote order
                 Asgn ptop{NAN32, 0, 0};
                 uint64_t pvvw = 0;
                 // event scratch: 2 * NHMAX words each (a k-mer has one event per locus; the loci lists come from the pool of 2 * NHMAX);
@@ -2194,6 +2201,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
 #ifdef DBTK_STAMPS
             st_acc[single ? 24 : (alleq ? 25 : 26)] += 1;  // pairs per vote path
             st_acc[27] += nu; st_acc[28] += n;
+            diag_nu = nu;
 #endif
             }  // general path
             {  // countHit's accept test, AQ.cpp:439-451
@@ -2361,7 +2369,17 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
 #ifdef DBTK_STAMPS
         {
             const uint64_t now_ = x.clock();
-            if (lane == 0 && a.dbg) x.atomic_max(&a.dbg[45], now_ - pair_t0_);
+            if (lane == 0 && a.dbg) {
+                x.atomic_max(&a.dbg[45], now_ - pair_t0_);
+                // the slowest pair with its size: cycles << 32 | events of multi-locus k-mers << 12 | distinct k-mers
+                x.atomic_max(&a.dbg[47], ((now_ - pair_t0_) << 32) | ((uint64_t)(diag_need > 0xFFFFFu ? 0xFFFFFu : diag_need) << 12) | (diag_nu & 0xFFF));
+                // histogram of pair times: 2^b cycles
+                const uint64_t dcy = now_ - pair_t0_;
+                uint32_t bkt = 0;
+                while (bkt < 5 && (dcy >> (12 + 2 * bkt))) ++bkt;
+                x.atomic_add(&a.dbg[bkt < 3 ? 21 + bkt : 26 + bkt], 1ull);
+            }
+            diag_need = 0; diag_nu = 0;
             pair_t0_ = now_;
             st_acc[46] += 1;
         }

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("danbing-tk_amd")
 abi = pkg.abi
 NAMES = ["ticket", "-", "-", "hit-buffer loads", "kfilter verdict", "gather", "rank sort", "dedup", "nml/single test",
-         "vote fast", "vote general", "states", "assign_bits", "accumulate", "-", "-",
+         "vote fast", "vote general", "states", "assign_bits", "accumulate", "vote-order sort", "-",
          "K1 tile set-up", "K1 loads+pack", "K1 valid-window", "K1 sampled probes", "K1 verdict+append"] + ["-"] * 11
 
 
@@ -52,6 +52,8 @@ def main():
 
 
     print(f"general kernel: {st[46]} pairs, {st[44]} serial-vote fallbacks, slowest pair {st[45]} cycles")
+    print(f"  slowest pair: {int(st[47]) >> 32} cycles, {(int(st[47]) >> 12) & 0xFFFFF} loci-list words, {int(st[47]) & 0xFFF} distinct k-mers")
+    print("  pair times (cycles, all 3 steps): " + ", ".join(f"<2^{12 + 2 * b}: {int(st[21 + b if b < 3 else 26 + b])}" for b in range(6)))
     st[44:47] = 0
     k2 = {40: "K2 fetch+pack", 41: "K2 windows+hash+stage", 42: "K2 look-ups+stores", 43: "K2 loop/extras"}
     nrows = 2.0 * r[abi.C_SURVIVORS]
