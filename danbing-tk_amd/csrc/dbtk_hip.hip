@@ -147,7 +147,7 @@ template <int NS, bool RECS> __global__ void __launch_bounds__(64) k_pair_usual(
     DevX x{&sm};
     body_pair_usual<NS, RECS>(x, a);
 }
-template <int NS, bool RECS> __global__ void __launch_bounds__(64) k_pair(BatchArgs a) {
+template <int NS, bool RECS> __global__ void __launch_bounds__(64, NS <= 3 ? 2 : 1) k_pair(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) PairSmemT<NS> sm;
     DevX x{&sm};
     body_pair<NS, RECS>(x, a);
@@ -212,6 +212,7 @@ struct dbtk_ctx {
     uint64_t* d_hitkm = nullptr; uint64_t hitkm_cap = 0;   // K2 -> K3 (see BatchArgs)
     HitVA* d_hitva = nullptr; uint64_t hitva_cap = 0;
     uint32_t* d_hitnk = nullptr; uint64_t hitnk_cap = 0;
+    uint64_t* d_hitoff = nullptr; uint64_t hitoff_cap = 0;
     uint32_t* d_gen = nullptr; uint64_t gen_cap = 0;        // K3a -> K3b
     uint32_t* d_tickets = nullptr; uint64_t tickets_cap = 0;
     // optional gates
@@ -247,6 +248,7 @@ struct dbtk_ctx {
         uint64_t* d_hitkm = nullptr; uint64_t hitkm_cap = 0;
         HitVA* d_hitva = nullptr; uint64_t hitva_cap = 0;
         uint32_t* d_hitnk = nullptr; uint64_t hitnk_cap = 0;
+        uint64_t* d_hitoff = nullptr; uint64_t hitoff_cap = 0;
         uint32_t* d_gen = nullptr; uint64_t gen_cap = 0;
         uint32_t* d_tickets = nullptr; uint64_t tickets_cap = 0;
         uint64_t* d_vote = nullptr;
@@ -274,10 +276,10 @@ void free_ctx(dbtk_ctx* c) {
             if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
         }
     void* ptrs[] = {c->d_flt, c->d_ctr, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
-                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_gen, c->d_tickets,
+                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
                     c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    void* aptrs[] = {c->alt.d_small, c->alt.d_surv, c->alt.d_hitkm, c->alt.d_hitva, c->alt.d_hitnk, c->alt.d_gen, c->alt.d_tickets, c->alt.d_vote, c->alt.d_epoch};
+    void* aptrs[] = {c->alt.d_small, c->alt.d_surv, c->alt.d_hitkm, c->alt.d_hitva, c->alt.d_hitnk, c->alt.d_hitoff, c->alt.d_gen, c->alt.d_tickets, c->alt.d_vote, c->alt.d_epoch};
     for (void* p : aptrs) if (p) (void)hipFree(p);
     for (BinScratch* b : {&c->bin, &c->alt.bin}) {
         void* bp[] = {b->bins, b->bincnt, b->ovf, b->ovf_hdr, b->cand};
@@ -465,6 +467,7 @@ void switch_lane(dbtk_ctx* c) {
     std::swap(c->d_hitkm, c->alt.d_hitkm); std::swap(c->hitkm_cap, c->alt.hitkm_cap);
     std::swap(c->d_hitva, c->alt.d_hitva); std::swap(c->hitva_cap, c->alt.hitva_cap);
     std::swap(c->d_hitnk, c->alt.d_hitnk); std::swap(c->hitnk_cap, c->alt.hitnk_cap);
+    std::swap(c->d_hitoff, c->alt.d_hitoff); std::swap(c->hitoff_cap, c->alt.hitoff_cap);
     std::swap(c->d_gen, c->alt.d_gen); std::swap(c->gen_cap, c->alt.gen_cap);
     std::swap(c->d_tickets, c->alt.d_tickets); std::swap(c->tickets_cap, c->alt.tickets_cap);
     std::swap(c->d_vote, c->alt.d_vote); std::swap(c->d_epoch, c->alt.d_epoch);
@@ -507,7 +510,9 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     const uint64_t nchunks = (npairs + tcap - 1) / tcap;
     dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, npairs + 1);
     if (st) return st;
-    if ((st = ensure(&c->d_hitkm, &c->hitkm_cap, tcap * 2 * nkp))) return st;
+    static const bool keep_km = [] { const char* e = getenv("DBTK_HITKM"); return e && atoi(e) == 1; }();  // diagnostic: the k-mers travel K2 -> K3 as they used to
+    if (keep_km && (st = ensure(&c->d_hitkm, &c->hitkm_cap, tcap * 2 * nkp))) return st;
+    if ((st = ensure(&c->d_hitoff, &c->hitoff_cap, tcap * 2))) return st;
     if ((st = ensure(&c->d_hitva, &c->hitva_cap, tcap * 2 * nkp))) return st;
     if ((st = ensure(&c->d_hitnk, &c->hitnk_cap, tcap * 2))) return st;
     if ((st = ensure(&c->d_gen, &c->gen_cap, tcap))) return st;
@@ -534,7 +539,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     a.ctr_rep = c->d_ctr;
     a.recs = d_recs; a.rec_cap = rec_cap;
     a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
-    a.hitkm = c->d_hitkm; a.hitva = c->d_hitva; a.hitnk = c->d_hitnk; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
+    a.hitkm = keep_km ? c->d_hitkm : nullptr; a.hitva = c->d_hitva; a.hitnk = c->d_hitnk; a.hitoff = c->d_hitoff; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
     // the usual-pair kernel takes the pairs it can finish and passes the rest on; it needs the class of a k-mer next to its
     // index value (consistent RPGG) and does not do the trace, bait or bubble work
     const bool usual = c->T.consistent && !c->P.trace && !c->P.bait && !c->P.bubbles;

@@ -183,11 +183,14 @@ struct BatchArgs {
     uint64_t* vote_scratch;  // per block: nloci+1 stamped hit words (see vote)
     uint32_t* vote_epoch;    // per block
     uint64_t* dbg;           // diagnostic build only (-DDBTK_STAMPS): per-phase cycle sums of k_pair
-    // K2 -> K3, per (survivor, mate) row of nkp positions: the canonical k-mers, the index results (val, aux), and
-    // per row the number of positions.  Split so that the usual-pair kernel reads 8 bytes per position, not 16.
+    // K2 -> K3, per (survivor, mate) row of nkp positions: the index results (val, aux), and per row the number of
+    // positions and the read's offset.  The canonical k-mers do NOT travel (hitkm == nullptr): the probe kernel is bound
+    // by its requests to the fabric, a quarter of which were result writes; only the general resolve kernel needs the
+    // k-mers, for an eighth of the pairs, and re-encodes them from the read.  (hitkm != nullptr: diagnostic, the old way.)
     uint64_t* hitkm;
     struct HitVA* hitva;
     uint32_t* hitnk;         // [2 * tcap]
+    uint64_t* hitoff;        // [2 * tcap]: where the read starts in seq (the general resolve kernel re-encodes its k-mers from there)
     uint32_t nkp;            // positions reserved per read in the hit buffers (multiple of 64)
     uint32_t* gen_list;      // K3a -> K3b: survivors (t) that need the general resolve kernel; nullptr: K3b takes every survivor
     uint32_t* ngen;
@@ -860,6 +863,10 @@ struct PairSmemT {
         } b;
     } w;
     int stack[3 * 40];
+    // re-encoding of the pair's reads (deliver): raw bytes from each read's 4-byte-aligned start, then 2-bit packed + validity
+    uint32_t raw[2][MAXL / 4 + 6];
+    uint32_t pk[2][MAXL / 16 + 4];
+    uint16_t vd[2][MAXL / 16 + 4];
     int32_t res[8];            // vote result
     uint32_t evd[2 * NH];      // the vote's loci pool (lists of the multi-locus k-mers), then top - second per event
 };
@@ -1438,7 +1445,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         DBTK_STAMP(41);  // windows, hash, staging
         uint64_t* outk = a.hitkm + (size_t)it * a.nkp;
         HitVA* outv = a.hitva + (size_t)it * a.nkp;
-        if (lane == 0) a.hitnk[it] = nk;
+        if (lane == 0) { a.hitnk[it] = nk; a.hitoff[it] = o0; }
         const uint32_t sub = lane & 3, qd = lane >> 2;
         constexpr int NB = DBTK_K2_NB;  // buckets in flight per lane
         // One evaluation of a quad's bucket parts against its k-mer: the two key lanes compare, the value lanes' words reach
@@ -1505,7 +1512,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             const uint32_t i = 64 * s + lane;
             if ((uint32_t)s < nsl && i < nk) {
                 const uint64_t v = sm.rva[i];
-                outk[i] = km[s];
+                if (a.hitkm) outk[i] = km[s];
                 outv[i] = HitVA{(uint32_t)v, (uint32_t)(v >> 32)};
             }
         }
@@ -1839,21 +1846,44 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     const uint32_t nb = x.nblocks();
     uint32_t myq = x.bid();
     auto take = [&]() { myq += nb; return myq; };
-    auto lookup = [&](uint32_t q) -> uint32_t { return q < nitems ? (listmode ? a.gen_list[q] : a.t0 + q) : NOITEM; };
-    HitEnt nx[2][NSLOT];
-    uint32_t nxnk[2] = {0, 0}, nxpair = 0;
-    auto request = [&](uint32_t tt) {
+    auto lookup = [&](uint32_t q) -> uint32_t {  // (an unconditional load: one issued under a branch is waited for on the spot)
+        const uint32_t qq = q < nitems ? q : 0u;
+        const uint32_t v = listmode ? a.gen_list[qq] : a.t0 + qq;
+        return q < nitems ? v : NOITEM;
+    };
+    // Pipeline, so that nothing is waited for in the iteration that requested it (all loads straight-line, wave-uniform
+    // values kept in vector registers until they are used — see `vzero`):
+    //   item i+3: its survivor index (list lookup)            -> tD
+    //   item i+2: its reads' offsets and position counts      -> ofC, nkC
+    //   item i+1: its probe results, its pair index, its bytes -> nx*, taken delivery of at the end of item i
+    const uint32_t lzz = (uint32_t)lane * a.vzero;  // 0
+    HitVA nx[2][NSLOT];
+    uint32_t nxpair = 0, nxrw[2][2] = {{0, 0}, {0, 0}};
+    uint64_t nxo0[2] = {0, 0};   // where the bytes in flight start, and how many positions they make
+    uint32_t nxnk[2] = {0, 0};
+    uint64_t ofC[2] = {0, 0};    // item i+2 (in flight)
+    uint32_t nkC[2] = {0, 0};
+    auto rowof = [&](uint32_t tt, int m) { return (size_t)2 * ((tt != NOITEM ? tt : a.t0) - a.t0) + m; };
+    auto fetch_meta = [&](uint32_t tt) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { ofC[m] = a.hitoff[rowof(tt, m) + lzz]; nkC[m] = a.hitnk[rowof(tt, m) + lzz]; }
+    };
+    // probe results + bytes of item tt, whose offsets / position counts are o0[], nk[]
+    auto request = [&](uint32_t tt, const uint64_t o0[2], const uint32_t nk[2]) {
         const uint32_t tc = tt != NOITEM ? tt : a.t0;  // (what comes back for "no item" is never used: the loop ends first)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {  // straight-line loads: no item -> row 0, a slot the rows do not have -> the last one
                 const uint32_t sc = (uint32_t)s < nslp ? (uint32_t)s : nslp - 1;
-                const size_t row = ((size_t)2 * (tc - a.t0) + m) * a.nkp + 64 * sc + lane;
-                const HitVA va = a.hitva[row];
-                nx[m][s] = HitEnt{a.hitkm[row], va.val, va.aux};
+                nx[m][s] = a.hitva[rowof(tc, m) * a.nkp + 64 * sc + lane];
             }
-            nxnk[m] = a.hitnk[2 * (tc - a.t0) + m];
+            const uint32_t len = nk[m] ? nk[m] + k - 1 : 0;  // (<= MAXL: the probe kernel clamps)
+            const uint64_t a0 = o0[m] & ~3ull;
+            const uint32_t nw = ((uint32_t)(o0[m] - a0) + len + 3) >> 2;
+            nxrw[m][0] = *reinterpret_cast<const uint32_t*>(a.seq + (lane < nw ? a0 + 4ull * lane : 0ull));
+            nxrw[m][1] = *reinterpret_cast<const uint32_t*>(a.seq + (64u + lane < nw ? a0 + 4ull * (64 + lane) : 0ull));
+            nxo0[m] = o0[m]; nxnk[m] = nk[m];
         }
         nxpair = a.surv[tc];
     };
@@ -1865,9 +1895,41 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     uint32_t nkm[2] = {0, 0}, pair_cur = 0;
     auto deliver = [&]() {
         pair_cur = x.uni(nxpair) + a.pair_base;
+        uint32_t rsh[2], len[2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) nkm[m] = x.uni(nxnk[m]);  // positions of the read (the probe kernel clamps reads to MAXL)
+        for (int m = 0; m < 2; ++m) {
+            nkm[m] = nxnk[m];  // positions of the read (the probe kernel clamps reads to MAXL)
+            len[m] = nkm[m] ? nkm[m] + k - 1 : 0;
+            rsh[m] = (uint32_t)(nxo0[m] & 3);
+        }
         const uint32_t nslN = ((nkm[0] > nkm[1] ? nkm[0] : nkm[1]) + 63) >> 6;
+        // the k-mers: raw bytes -> LDS, 16 lanes per mate pack 16 bases each (bytes past the read are 0 = invalid), windows
+        x.sync();
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const uint32_t nw = (rsh[m] + len[m] + 3) >> 2;
+            if (lane < nw) sm.raw[m][lane] = nxrw[m][0];
+            if (64u + lane < nw) sm.raw[m][64 + lane] = nxrw[m][1];
+            if (lane < 4) sm.raw[m][nw + lane] = 0;
+        }
+        x.sync();
+        if (lane < 32) {
+            const int m = (int)(lane >> 4);
+            const uint32_t c = lane & 15, B = rsh[m] + 16 * c, j = B >> 2, r8 = 8 * (B & 3);
+            uint32_t w[4] = {0, 0, 0, 0}, vdb = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (16u * c + 4 * q < len[m]) {
+                    const uint32_t lo = sm.raw[m][j + q], hi = sm.raw[m][j + q + 1];
+                    const uint32_t v = r8 ? ((lo >> r8) | (hi << (32 - r8))) : lo;
+                    const uint32_t left = len[m] - (16 * c + 4 * q);  // bytes of this word inside the read
+                    w[q] = v & (left < 4 ? (1u << (8 * left)) - 1 : 0xFFFFFFFFu);
+                }
+            sm.pk[m][c] = pack16(w, &vdb);
+            sm.vd[m][c] = (uint16_t)vdb;
+            if (c < 4) { sm.pk[m][16 + c] = 0; sm.vd[m][16 + c] = 0; }
+        }
+        x.sync();
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1875,16 +1937,24 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 const uint32_t i = 64 * s + lane;
                 km[m][s] = NAN64; hv[m][s] = NOHIT; ha[m][s] = 0;
                 if ((uint32_t)s < nslN && i < nkm[m]) {
-                    km[m][s] = nx[m][s].km; hv[m][s] = nx[m][s].val; ha[m][s] = nx[m][s].aux;
+                    km[m][s] = window_kmer(sm.pk[m], sm.vd[m], i, k, nullptr, nullptr);
+                    hv[m][s] = nx[m][s].val; ha[m][s] = nx[m][s].aux;
                     sm.hval[m][i] = nx[m][s].val;  // (read by the dedup only: dead by the time the next item is delivered)
                 }
             }
     };
+    auto uni64 = [&](uint64_t v) { return ((uint64_t)x.uni((uint32_t)(v >> 32)) << 32) | x.uni((uint32_t)v); };
     uint32_t t = x.uni(lookup(x.bid()));
-    request(t);
-    deliver();
-    uint32_t tB = lookup(x.bcast(take(), 0));
-    uint32_t tkA = take();
+    {   // prologue: item 0 through all its stages
+        fetch_meta(t);
+        const uint64_t o0[2] = {uni64(ofC[0]), uni64(ofC[1])};
+        const uint32_t nk[2] = {x.uni(nkC[0]), x.uni(nkC[1])};
+        request(t, o0, nk);
+        deliver();
+    }
+    uint32_t tB = x.uni(lookup(take()));        // item 1 (value)
+    fetch_meta(tB);                             //         its offsets (in flight)
+    uint32_t tD = lookup(take() + lzz);         // item 2 (in flight)
 
 #ifdef DBTK_STAMPS
     uint64_t pair_t0_ = x.clock();
@@ -1904,11 +1974,16 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         rm[0] = kf[0]; rm[1] = kf[1];
         const bool both_short = rm[0] && rm[1];
         const uint32_t nsl = ((nkm[0] > nkm[1] ? nkm[0] : nkm[1]) + 63) >> 6;  // slots in use (3 for 150 bp reads)
-        // next item's data, the item after that, and a new ticket
-        const uint32_t tnext = x.uni(tB);
-        request(tnext);
-        tB = lookup(x.bcast(tkA, 0));
-        tkA = take();
+        // the pipeline moves on: data of the next item, offsets of the one after, survivor index of the third
+        const uint32_t tnext = tB;
+        {
+            const uint64_t o0[2] = {uni64(ofC[0]), uni64(ofC[1])};
+            const uint32_t nk[2] = {x.uni(nkC[0]), x.uni(nkC[1])};
+            request(tnext, o0, nk);
+        }
+        tB = x.uni(tD);
+        fetch_meta(tB);
+        tD = lookup(take() + lzz);
         DBTK_STAMP(3);  // hit-buffer loads
         if (!both_short) {
 #pragma unroll

@@ -524,6 +524,8 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
                  uint64_t evcap, uint64_t* nev);
 
 // the binned encode stage: off (0), or on with 2^pb filter partitions, segments of `cap` queries and `nflt` filter waves
+static int g_keep_km = 0;  // 1: the k-mers travel from the probe body to the resolve body (the old way)
+void emu_set_keep_km(int on) { g_keep_km = on; }
 static int g_binned = 0;
 static uint32_t g_bin_pb = 0, g_bin_cap = 64, g_bin_nflt = 8;
 void emu_set_binned(int on, uint32_t pb, uint32_t cap, uint32_t nflt) { g_binned = on; g_bin_pb = pb; g_bin_cap = cap / BIN_G * BIN_G; g_bin_nflt = nflt ? nflt : 1; }
@@ -567,7 +569,8 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     std::vector<uint64_t> hitkm((size_t)tcap * 2 * a.nkp + 1, 0);
     std::vector<HitVA> hitva((size_t)tcap * 2 * a.nkp + 1, HitVA{0, 0});
     std::vector<uint32_t> hitnk((size_t)tcap * 2 + 1, 0), gen(tcap + 1, 0);
-    a.hitkm = hitkm.data(); a.hitva = hitva.data(); a.hitnk = hitnk.data();
+    std::vector<uint64_t> hitoff((size_t)tcap * 2 + 1, 0);
+    a.hitkm = g_keep_km ? hitkm.data() : nullptr; a.hitva = hitva.data(); a.hitnk = hitnk.data(); a.hitoff = hitoff.data();
     a.tcap = tcap;
     const bool usual = e->T.consistent && !p->trace && !p->bait && !p->bubbles;  // as the device launcher decides
     uint32_t tile_ticket = 0;
