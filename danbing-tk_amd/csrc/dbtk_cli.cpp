@@ -313,9 +313,26 @@ int main(int argc, char* argv[]) {
     fprintf(stderr, "threads created\n");
     typedef std::unique_ptr<Batch> BatchP;
     Chan<BatchP> parsed, aligned;
+    // written batches go back to the pairing stage with their arrays' capacity (as the input blocks do, below)
+    std::mutex bpool_m;
+    std::vector<BatchP> bpool;
+    auto recycle_batch = [&](BatchP b) {
+        if (!b) return;
+        b->flat.clear(); b->off.clear(); b->qar.clear(); b->qoff.clear(); b->tar.clear(); b->toff.clear(); b->src.clear();
+        b->index = 0; b->nreads = 0; b->nReads_so_far = 0; b->nparked = 0; b->nrec = 0; b->gpu_sec = 0;
+        std::lock_guard<std::mutex> l(bpool_m);
+        if (bpool.size() < 16) bpool.push_back(std::move(b));
+    };
+    auto fresh_batch = [&]() -> BatchP {
+        {
+            std::lock_guard<std::mutex> l(bpool_m);
+            if (!bpool.empty()) { BatchP b = std::move(bpool.back()); bpool.pop_back(); return b; }
+        }
+        return BatchP(new Batch);
+    };
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
     const double loop_t0 = now();
-    double pair_busy = 0, gpu_busy = 0, write_busy = 0;  // seconds each stage spent working (not waiting)
+    double read_busy = 0, pair_busy = 0, gpu_busy = 0, write_busy = 0;  // seconds each stage spent working (not waiting)
 
     // Stage A — reader, line splitters, on-the-fly mate pairing (AQ.cpp:1918-1976), all overlapped:
     //   A0 (1 thread)  reads the file in large blocks cut at record boundaries (2 lines per FASTA record, 4 per FASTQ: the
@@ -326,21 +343,62 @@ int main(int argc, char* argv[]) {
     //                  the map, so that interleaved input (mates adjacent) never touches the map.  A record matches the held
     //                  one first, then the map — the held one is by construction the latest record parked under its title,
     //                  so the outcome is the reference's.  Paired reads are copied once, into the batch's flat arrays.
+    //                  Interleaved input is paired in A1 already: a block whose records 2j, 2j+1 all carry equal titles is
+    //                  laid out there as the batch arrays it will become ("the record that completed the pair" first), and
+    //                  A2 — when nothing is parked, which is then always — appends it with a few block copies.  Any other
+    //                  block, or any parked record, takes the record-by-record path; both give the reference's outcome.
     struct Rec { uint32_t t, tn, s, sn, q, qn; };
-    struct Block { uint64_t index = 0; std::vector<char> data; size_t len = 0; std::vector<Rec> recs; };
+    struct RawBuf {  // a block's bytes: grown without zero-filling (the reader is a single thread on the critical path)
+        std::unique_ptr<char[]> p; size_t n = 0;
+        char* data() { return p.get(); }
+        const char* data() const { return p.get(); }
+        size_t size() const { return n; }
+        void resize(size_t m) {
+            if (m <= n) return;
+            std::unique_ptr<char[]> q(new char[m]);
+            if (n) memcpy(q.get(), p.get(), n);
+            p = std::move(q); n = m;
+        }
+    };
+    struct Block {
+        uint64_t index = 0; RawBuf data; size_t len = 0; std::vector<Rec> recs;
+        bool clean = false;  // every record pairs with its neighbour: `mini` holds the kept pairs in batch layout
+        Batch mini;
+        uint64_t mpos = 0;   // pairs of `mini` already handed on
+    };
     typedef std::unique_ptr<Block> BlockP;
     Chan<BlockP> raw, split;
+    // used blocks go back to the reader: fresh 32 MB buffers cost a page fault per 4 KB, on the one thread that limits the ingest
+    std::mutex pool_m;
+    std::vector<BlockP> pool;
+    auto recycle = [&](BlockP b) {
+        if (!b) return;
+        b->recs.clear(); b->clean = false; b->mpos = 0; b->len = 0;
+        Batch& m = b->mini;
+        m.flat.clear(); m.off.clear(); m.qar.clear(); m.qoff.clear(); m.tar.clear(); m.toff.clear(); m.nreads = 0;
+        std::lock_guard<std::mutex> l(pool_m);
+        if (pool.size() < 64) pool.push_back(std::move(b));
+    };
+    auto fresh_block = [&]() -> BlockP {
+        {
+            std::lock_guard<std::mutex> l(pool_m);
+            if (!pool.empty()) { BlockP b = std::move(pool.back()); pool.pop_back(); return b; }
+        }
+        return BlockP(new Block);
+    };
     const unsigned hw = std::max(4u, std::thread::hardware_concurrency());
     const int nsplit = (int)std::min(16u, std::max(2u, hw / 8));
     raw.cap = split.cap = 2 * (size_t)nsplit;
     const size_t L = fq ? 4 : 2;
     std::thread reader([&] {
-        const size_t BLK = 32u << 20;
+        size_t BLK = 32u << 20;
+        if (const char* e = getenv("DBTK_INGEST_BLOCK")) { const long v = atol(e); if (v >= 64) BLK = (size_t)v; }  // (tests: many small blocks)
         std::vector<char> carry;
         uint64_t index = 0;
         bool eof = false;
         while (!eof) {
-            BlockP b(new Block);
+            const double tr = now();
+            BlockP b = fresh_block();
             b->data.resize(carry.size() + BLK);
             memcpy(b->data.data(), carry.data(), carry.size());
             size_t end = carry.size();
@@ -366,6 +424,7 @@ int main(int argc, char* argv[]) {
             if (b->len == 0) continue;
             if (b->len >= 0xFFFFFFFFull) die_assert("input block too large");
             b->index = index++;
+            read_busy += now() - tr;
             raw.push(std::move(b));
         }
         raw.close();
@@ -398,6 +457,29 @@ int main(int argc, char* argv[]) {
                     if (r.tn >= 2 && d0[r.t + r.tn - 2] == '/' && (d0[r.t + r.tn - 1] == '1' || d0[r.t + r.tn - 1] == '2')) r.tn -= 2;
                     b->recs.push_back(r);
                 }
+                // interleaved input: pair here, in parallel
+                const size_t nr = b->recs.size();
+                bool clean = nr > 0 && nr % 2 == 0 && !o.simmode;
+                for (size_t j = 0; clean && j < nr; j += 2) {
+                    const Rec &x = b->recs[j], &y = b->recs[j + 1];
+                    clean = x.tn == y.tn && memcmp(d0 + x.t, d0 + y.t, x.tn) == 0;
+                }
+                if (clean) {
+                    Batch& m = b->mini;
+                    m.off.reserve(nr + 1); m.toff.reserve(nr / 2 + 1);
+                    m.off.push_back(0); m.qoff.push_back(0); m.toff.push_back(0);
+                    m.flat.reserve(len); m.tar.reserve(len / 8);
+                    if (fq) { m.qar.reserve(len / 2); m.qoff.reserve(nr + 1); }
+                    for (size_t j = 0; j < nr; j += 2) {
+                        const Rec &x = b->recs[j], &y = b->recs[j + 1];  // x is parked, y completes the pair
+                        if (y.sn < minReadSize || x.sn < minReadSize) continue;  // AQ.cpp:1940-1943: the pair is dropped
+                        m.tar.insert(m.tar.end(), d0 + y.t, d0 + y.t + y.tn); m.toff.push_back(m.tar.size());
+                        m.add_read(d0 + y.s, y.sn, d0 + y.q, y.qn, fq);
+                        m.add_read(d0 + x.s, x.sn, d0 + x.q, x.qn, fq);
+                        m.nreads += 2;
+                    }
+                    b->clean = true;
+                }
                 split.push(std::move(b));
             }
             std::lock_guard<std::mutex> l(split_m);
@@ -415,7 +497,7 @@ int main(int argc, char* argv[]) {
         auto have_record = [&]() -> bool {  // !in.at_eof()
             for (;;) {
                 if (blk && ri < blk->recs.size()) return true;
-                blk.reset();
+                recycle(std::move(blk));
                 auto it = waiting.find(next_block);
                 while (it == waiting.end() && !drained) {
                     BlockP got;
@@ -432,10 +514,29 @@ int main(int argc, char* argv[]) {
         };
         for (;;) {
             if (!have_record()) break;
-            BatchP b(new Batch);
+            BatchP b = fresh_batch();
             b->off.push_back(0); b->qoff.push_back(0); b->toff.push_back(0);
             double tb = now();
             while (b->nreads < readsPerBatch && have_record()) {
+                if (blk->clean && !held && parked.empty() && (ri == 0 || blk->mpos)) {
+                    // a pre-paired block and nothing parked: append as many of its pairs as the batch still takes
+                    Batch& m = blk->mini;
+                    const uint64_t avail = m.nreads / 2 - blk->mpos, room = (readsPerBatch - b->nreads + 1) / 2;
+                    const uint64_t n = avail < room ? avail : room, p0 = blk->mpos;
+                    auto append = [](auto& dst, auto& doff, const auto& src, const auto& soff, uint64_t i0, uint64_t i1) {
+                        const uint64_t base = dst.size(), s0 = soff[i0];
+                        dst.insert(dst.end(), src.begin() + s0, src.begin() + soff[i1]);
+                        for (uint64_t i = i0 + 1; i <= i1; ++i) doff.push_back(base + (soff[i] - s0));
+                    };
+                    append(b->flat, b->off, m.flat, m.off, 2 * p0, 2 * (p0 + n));
+                    if (fq) append(b->qar, b->qoff, m.qar, m.qoff, 2 * p0, 2 * (p0 + n));
+                    append(b->tar, b->toff, m.tar, m.toff, p0, p0 + n);
+                    b->nreads += 2 * n;
+                    blk->mpos += n;
+                    if (blk->mpos == m.nreads / 2) ri = blk->recs.size();  // the block is used up
+                    else ri = 1;                                            // (not 0: the block stays on this path)
+                    continue;
+                }
                 const Rec& r = blk->recs[ri++];
                 const char* d0 = blk->data.data();
                 const char *tp = d0 + r.t, *sp = d0 + r.s, *qp = d0 + r.q;
@@ -565,6 +666,7 @@ int main(int argc, char* argv[]) {
                 const double tw = now();
                 emit(*it->second);
                 write_busy += now() - tw;
+                recycle_batch(std::move(it->second));
                 waiting.erase(it);
                 ++next;
             }
@@ -576,8 +678,8 @@ int main(int argc, char* argv[]) {
     for (auto& w : workers) w.join();
     fclose(in.f);
     fflush(stdout);
-    fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads\n",
-            now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit);
+    fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: reading %.2f s, pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads\n",
+            now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, read_busy, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit);
 
     // ---- totals + dumps (AQ.cpp:2611-2656)
     if (o.ngpus > 1 && dbtk_allreduce(ctx.data(), o.ngpus)) die_assert(dbtk_last_error());

@@ -129,14 +129,31 @@ def test_cli_vs_reference_binary_live(tmp_path):
                 q = p - 300 + (5 - (p - 300) % 97) % 97                                  # a singleton seen long ago finds its mate
                 if q % 97 == 5 and q < p:
                     f.write(b">" + reads.titles[q].encode() + b"/2\n" + reads.seqs[2 * q + 1] + b"\n")
-    for flags in (["-cth", "45"], ["-cth", "20", "-kf", "8", "2", "-r", "0.01"], ["-e", "1"], ["-gc", "85", "3"], ["-cth", "30", "-r", "0.004", "FA"]):
+    # interleaved FASTQ (the ingest pairs such blocks in its parallel stage), with an orphan a third of the way in whose mate
+    # arrives at two thirds: in between something is parked and every block goes record by record
+    with open(os.path.join(d, "r2.fq"), "wb") as f:
+        rec = lambda p, w: b"@" + reads.titles[p].encode() + (b"/1", b"/2")[w] + b"\n" + reads.seqs[2 * p + w] + b"\n+\n" + reads.quals[2 * p + w] + b"\n"
+        for p in range(reads.npairs):
+            if p == reads.npairs // 3:
+                f.write(rec(0, 0))
+            if p == 2 * reads.npairs // 3:
+                f.write(rec(0, 1))
+            if p:
+                f.write(rec(p, 0) + rec(p, 1))
+    for flags in (["-cth", "45"], ["-cth", "20", "-kf", "8", "2", "-r", "0.01"], ["-e", "1"], ["-gc", "85", "3"], ["-cth", "30", "-r", "0.004", "FA"],
+                  ["-cth", "30", "-r", "0.004", "FA", "BLK"], ["-cth", "45", "-r", "0.003", "FQ2", "BLK"], ["-cth", "45", "FQ2"]):
         outs = []
+        env = dict(os.environ)
+        if flags[-1] == "BLK":  # many small input blocks: pre-paired and record-by-record blocks alternate, batches end inside blocks
+            flags = flags[:-1]
+            env["DBTK_INGEST_BLOCK"] = "30000"
         fa = flags[-1] == "FA"
-        if fa:
+        fq2 = flags[-1] == "FQ2"
+        if fa or fq2:
             flags = flags[:-1]
         for exe, tag in ((synth.ref_tool("danbing-tk"), "ref"), (CLI, "hip")):
-            a = ["-k", "21"] + flags + (["-fa", "r.fa"] if fa else ["-fq", "r.fq"]) + ["-qs", "pan", "-o", tag]
-            r = subprocess.run([exe] + a, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            a = ["-k", "21"] + flags + (["-fa", "r.fa"] if fa else ["-fq", "r2.fq" if fq2 else "r.fq"]) + ["-qs", "pan", "-o", tag]
+            r = subprocess.run([exe] + a, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
             assert r.returncode == 0, r.stderr.decode()[-1000:]
             outs.append(r.stdout)
         assert outs[0] == outs[1], f"stdout differs for {flags}"
