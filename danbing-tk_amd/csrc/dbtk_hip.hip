@@ -512,7 +512,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     if (st) return st;
     static const bool keep_km = [] { const char* e = getenv("DBTK_HITKM"); return e && atoi(e) == 1; }();  // diagnostic: the k-mers travel K2 -> K3 as they used to
     if (keep_km && (st = ensure(&c->d_hitkm, &c->hitkm_cap, tcap * 2 * nkp))) return st;
-    if ((st = ensure(&c->d_hitoff, &c->hitoff_cap, tcap * 2))) return st;
+    if ((st = ensure(&c->d_hitoff, &c->hitoff_cap, tcap * 4))) return st;  // offsets, then headers
     if ((st = ensure(&c->d_hitva, &c->hitva_cap, tcap * 2 * nkp))) return st;
     if ((st = ensure(&c->d_hitnk, &c->hitnk_cap, tcap * 2))) return st;
     if ((st = ensure(&c->d_gen, &c->gen_cap, tcap))) return st;
@@ -539,7 +539,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     a.ctr_rep = c->d_ctr;
     a.recs = d_recs; a.rec_cap = rec_cap;
     a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
-    a.hitkm = keep_km ? c->d_hitkm : nullptr; a.hitva = c->d_hitva; a.hitnk = c->d_hitnk; a.hitoff = c->d_hitoff; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
+    a.hitkm = keep_km ? c->d_hitkm : nullptr; a.hitaux = reinterpret_cast<uint32_t*>(c->d_hitva); a.hitval = a.hitaux + tcap * 2 * nkp; a.hitnk = c->d_hitnk; a.hitoff = c->d_hitoff; a.hithdr = c->d_hitoff + tcap * 2; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
     // the usual-pair kernel takes the pairs it can finish and passes the rest on; it needs the class of a k-mer next to its
     // index value (consistent RPGG) and does not do the trace, bait or bubble work
     const bool usual = c->T.consistent && !c->P.trace && !c->P.bait && !c->P.bubbles;

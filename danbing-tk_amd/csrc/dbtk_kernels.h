@@ -188,7 +188,13 @@ struct BatchArgs {
     // by its requests to the fabric, a quarter of which were result writes; only the general resolve kernel needs the
     // k-mers, for an eighth of the pairs, and re-encodes them from the read.  (hitkm != nullptr: diagnostic, the old way.)
     uint64_t* hitkm;
-    struct HitVA* hitva;
+    // The index results of a row, split: `hitaux` (class at the locus, AUX_MISS where the k-mer is not in the index) is always
+    // written; `hitval` only for a read whose found k-mers are NOT all unique to one and the same locus — for the others
+    // (most reads from a locus) the one index value, the number of found positions and the flag sit in `hithdr`
+    // (val | found << 32 | 1 << 63), the usual-pair kernel reads 4 bytes per position and decides from the two headers.
+    uint32_t* hitaux;
+    uint32_t* hitval;
+    uint64_t* hithdr;        // [2 * tcap]
     uint32_t* hitnk;         // [2 * tcap]
     uint64_t* hitoff;        // [2 * tcap]: where the read starts in seq (the general resolve kernel re-encodes its k-mers from there)
     uint32_t nkp;            // positions reserved per read in the hit buffers (multiple of 64)
@@ -221,6 +227,8 @@ struct BatchArgs {
 // (tens of nanoseconds each), which showed up as a fixed cost per resident wave.  On the device the waves therefore add
 // into CTR_REP replicas on separate cache lines, and a tiny kernel folds the replicas into the real counters after the batch.
 constexpr uint32_t CTR_REP = 256, CTR_STRIDE = 32;
+constexpr uint32_t AUX_MISS = 0xFFFFFFFDu;  // hitaux: the position's k-mer is not in the index (next to CLS_NONE, CLS_FLANK)
+constexpr uint64_t HDR_UNIFORM = 1ull << 63;
 template <class X>
 DBTK_HD uint64_t* counters_of(X& x, const BatchArgs& a) {
     return a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (CTR_REP - 1)) * CTR_STRIDE : a.counters;
@@ -1444,7 +1452,8 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         x.sync();
         DBTK_STAMP(41);  // windows, hash, staging
         uint64_t* outk = a.hitkm + (size_t)it * a.nkp;
-        HitVA* outv = a.hitva + (size_t)it * a.nkp;
+        uint32_t* outa = a.hitaux + (size_t)it * a.nkp;
+        uint32_t* outv = a.hitval + (size_t)it * a.nkp;
         if (lane == 0) { a.hitnk[it] = nk; a.hitoff[it] = o0; }
         const uint32_t sub = lane & 3, qd = lane >> 2;
         constexpr int NB = DBTK_K2_NB;  // buckets in flight per lane
@@ -1507,13 +1516,32 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             }
         }
         x.sync();
+        {   // the read's results: found positions, and whether they are all unique to one and the same locus
+            uint64_t rv[NSLOT];
+            uint32_t nh = 0, v0 = NOHIT;
+            bool vdiff = false;
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            const uint32_t i = 64 * s + lane;
-            if ((uint32_t)s < nsl && i < nk) {
-                const uint64_t v = sm.rva[i];
-                if (a.hitkm) outk[i] = km[s];
-                outv[i] = HitVA{(uint32_t)v, (uint32_t)(v >> 32)};
+            for (int s = 0; s < NSLOT; ++s) {
+                const uint32_t i = 64 * s + lane;
+                const bool in = (uint32_t)s < nsl && i < nk;
+                rv[s] = in ? sm.rva[i] : (uint64_t)NOHIT;
+                const uint32_t v = (uint32_t)rv[s];
+                const uint64_t hmk = x.ballot(v != NOHIT);
+                nh += (uint32_t)__builtin_popcountll(hmk);
+                if (v0 == NOHIT && hmk) v0 = x.bcast(v, (int)__builtin_ctzll(hmk));
+                vdiff |= v != NOHIT && v != v0;
+            }
+            const bool uniform = T.consistent && nh && !(v0 & 1) && x.ballot(vdiff) == 0;
+            if (lane == 0) a.hithdr[it] = (uint64_t)v0 | ((uint64_t)nh << 32) | (uniform ? HDR_UNIFORM : 0ull);
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                const uint32_t i = 64 * s + lane;
+                if ((uint32_t)s < nsl && i < nk) {
+                    const uint32_t v = (uint32_t)rv[s];
+                    if (a.hitkm) outk[i] = km[s];
+                    outa[i] = v != NOHIT ? (uint32_t)(rv[s] >> 32) : AUX_MISS;
+                    if (!uniform) outv[i] = v;
+                }
             }
         }
         DBTK_STAMP(42);  // look-ups + result stores
@@ -1625,17 +1653,19 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
         x.sync();
         ngb = 0;
     };
-    HitVA nx[2][NSLOT];
+    uint32_t nx[2][NSLOT];
     uint32_t nxnk[2] = {0, 0}, nxpair = 0;
+    uint64_t nxhdr[2] = {0, 0};
     auto request = [&](uint32_t tt) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {  // straight-line loads (a slot the rows do not have re-reads the last one; deliver() masks it)
                 const uint32_t sc = (uint32_t)s < nslp ? (uint32_t)s : nslp - 1;
-                nx[m][s] = a.hitva[((size_t)2 * (tt - a.t0) + m) * a.nkp + 64 * sc + lane];
+                nx[m][s] = a.hitaux[((size_t)2 * (tt - a.t0) + m) * a.nkp + 64 * sc + lane];
             }
             nxnk[m] = a.hitnk[2 * (tt - a.t0) + m];
+            nxhdr[m] = a.hithdr[2 * (tt - a.t0) + m];
         }
         nxpair = a.surv[tt];
     };
@@ -1644,20 +1674,24 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
     // memory side.  Hence: the next pair's loads are issued at the top of an iteration and taken delivery of (into
     // registers) just BEFORE this pair's atomics and record stores go out; those then have a whole iteration to finish.
     uint32_t pair = 0, nkm[2] = {0, 0}, nsl = 0;
-    uint32_t hv[2][NSLOT], ha[2][NSLOT];
+    uint32_t ha[2][NSLOT];     // class of the position's k-mer at the pair's locus, AUX_MISS: not in the index
+    uint32_t hval[2] = {NOHIT, NOHIT}, hfound[2] = {0, 0};
+    bool huni[2] = {false, false};
     auto deliver = [&]() {
         pair = x.uni(nxpair) + a.pair_base;
         nkm[0] = x.uni(nxnk[0]); nkm[1] = x.uni(nxnk[1]);
         nsl = ((nkm[0] > nkm[1] ? nkm[0] : nkm[1]) + 63) >> 6;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m) {
+            const uint32_t hlo = x.uni((uint32_t)nxhdr[m]), hhi = x.uni((uint32_t)(nxhdr[m] >> 32));
+            hval[m] = hlo; hfound[m] = hhi & 0x7FFFFFFFu; huni[m] = (hhi >> 31) != 0;
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
                 const uint32_t i = 64 * s + lane;
                 const bool in = (uint32_t)s < nsl && i < nkm[m];
-                hv[m][s] = in ? nx[m][s].val : NOHIT;
-                ha[m][s] = in ? nx[m][s].aux : 0u;
+                ha[m][s] = in ? nx[m][s] : AUX_MISS;
             }
+        }
     };
     DBTK_STAMP_DECL
     uint32_t t = a.t0 + x.bid();
@@ -1670,21 +1704,10 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
         request(t + stride < tlim ? t + stride : t);  // (past the end: a harmless reload, so that the loads stay straight-line)
         const uint32_t pair_cur = pair;
         // kfilter (AQ.cpp:190-228) aborts a mate at its (nk - cth + 1)-th miss, i.e. iff it has fewer than cth found positions
-        uint32_t nhit[2] = {0, 0}, v0 = NOHIT;
-        bool vdiff = false;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                if ((uint32_t)s >= nsl) continue;
-                const bool hit = hv[m][s] != NOHIT;
-                const uint64_t hmk = x.ballot(hit);
-                nhit[m] += (uint32_t)__builtin_popcountll(hmk);
-                if (v0 == NOHIT && hmk) v0 = x.bcast(hv[m][s], (int)__builtin_ctzll(hmk));
-                vdiff |= hit && hv[m][s] != v0;
-            }
-        const bool usual = nkm[0] >= cth && nkm[1] >= cth && nhit[0] >= cth && nhit[1] >= cth && nhit[0] && nhit[1] && !(v0 & 1) &&
-                           x.ballot(vdiff) == 0;
+        // (the probe kernel counted the found positions of each read and checked that they share one even index value)
+        const uint32_t nhit[2] = {hfound[0], hfound[1]}, v0 = hval[0];
+        const bool usual = nkm[0] >= cth && nkm[1] >= cth && nhit[0] >= cth && nhit[1] >= cth && nhit[0] && nhit[1] && huni[0] && huni[1] &&
+                           hval[0] == hval[1];
         DBTK_STAMP(32);  // request + usual test
         uint32_t dst0 = NAN32, dst = nloci, stage = DBTK_STAGE_LOCUS;
         MateState ms[2];
@@ -1719,7 +1742,7 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
 #pragma unroll
                     for (int s = 0; s < NSLOT; ++s) {
                         if ((uint32_t)s >= nsl) continue;
-                        const uint32_t c = hv[m][s] != NOHIT ? ha[m][s] : CLS_NONE;
+                        const uint32_t c = ha[m][s] != AUX_MISS ? ha[m][s] : CLS_NONE;
                         const uint64_t kb = x.ballot(c != CLS_NONE), rb = x.ballot(c != CLS_NONE && c != CLS_FLANK);
                         Kw[m][s] = kb; Rw[m][s] = rb;
                         mytr += (uint32_t)__builtin_popcountll(rb);
@@ -1757,7 +1780,7 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
 #pragma unroll
                         for (int s = 0; s < NSLOT; ++s) {
                             if ((uint32_t)s >= nsl) continue;
-                            const uint32_t c = hv[m][s] != NOHIT ? ha[m][s] : CLS_NONE;
+                            const uint32_t c = ha[m][s] != AUX_MISS ? ha[m][s] : CLS_NONE;
                             if (c != CLS_NONE && c != CLS_FLANK) {
                                 const uint32_t o = c - base;
                                 if (o < win) x.lds_add(&sm.hist[o >> 1], 1u << (16 * (o & 1)));
@@ -1857,27 +1880,30 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     //   item i+2: its reads' offsets and position counts      -> ofC, nkC
     //   item i+1: its probe results, its pair index, its bytes -> nx*, taken delivery of at the end of item i
     const uint32_t lzz = (uint32_t)lane * a.vzero;  // 0
-    HitVA nx[2][NSLOT];
+    uint32_t nxv[2][NSLOT], nxa[2][NSLOT];
+    uint64_t nxhdr[2] = {0, 0};
     uint32_t nxpair = 0, nxrw[2][2] = {{0, 0}, {0, 0}};
     uint64_t nxo0[2] = {0, 0};   // where the bytes in flight start, and how many positions they make
     uint32_t nxnk[2] = {0, 0};
-    uint64_t ofC[2] = {0, 0};    // item i+2 (in flight)
+    uint64_t ofC[2] = {0, 0}, hdC[2] = {0, 0};    // item i+2 (in flight)
     uint32_t nkC[2] = {0, 0};
     auto rowof = [&](uint32_t tt, int m) { return (size_t)2 * ((tt != NOITEM ? tt : a.t0) - a.t0) + m; };
     auto fetch_meta = [&](uint32_t tt) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) { ofC[m] = a.hitoff[rowof(tt, m) + lzz]; nkC[m] = a.hitnk[rowof(tt, m) + lzz]; }
+        for (int m = 0; m < 2; ++m) { ofC[m] = a.hitoff[rowof(tt, m) + lzz]; nkC[m] = a.hitnk[rowof(tt, m) + lzz]; hdC[m] = a.hithdr[rowof(tt, m) + lzz]; }
     };
     // probe results + bytes of item tt, whose offsets / position counts are o0[], nk[]
-    auto request = [&](uint32_t tt, const uint64_t o0[2], const uint32_t nk[2]) {
+    auto request = [&](uint32_t tt, const uint64_t o0[2], const uint32_t nk[2], const uint64_t hd[2]) {
         const uint32_t tc = tt != NOITEM ? tt : a.t0;  // (what comes back for "no item" is never used: the loop ends first)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {  // straight-line loads: no item -> row 0, a slot the rows do not have -> the last one
                 const uint32_t sc = (uint32_t)s < nslp ? (uint32_t)s : nslp - 1;
-                nx[m][s] = a.hitva[rowof(tc, m) * a.nkp + 64 * sc + lane];
+                nxa[m][s] = a.hitaux[rowof(tc, m) * a.nkp + 64 * sc + lane];
+                nxv[m][s] = a.hitval[rowof(tc, m) * a.nkp + 64 * sc + lane];  // (stale for a read whose header says "uniform")
             }
+            nxhdr[m] = hd[m];
             const uint32_t len = nk[m] ? nk[m] + k - 1 : 0;  // (<= MAXL: the probe kernel clamps)
             const uint64_t a0 = o0[m] & ~3ull;
             const uint32_t nw = ((uint32_t)(o0[m] - a0) + len + 3) >> 2;
@@ -1938,8 +1964,11 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 km[m][s] = NAN64; hv[m][s] = NOHIT; ha[m][s] = 0;
                 if ((uint32_t)s < nslN && i < nkm[m]) {
                     km[m][s] = window_kmer(sm.pk[m], sm.vd[m], i, k, nullptr, nullptr);
-                    hv[m][s] = nx[m][s].val; ha[m][s] = nx[m][s].aux;
-                    sm.hval[m][i] = nx[m][s].val;  // (read by the dedup only: dead by the time the next item is delivered)
+                    const bool found = nxa[m][s] != AUX_MISS;
+                    // a read whose found k-mers all carry one index value has it in its header, not per position
+                    hv[m][s] = (nxhdr[m] & HDR_UNIFORM) ? (found ? (uint32_t)nxhdr[m] : NOHIT) : nxv[m][s];
+                    ha[m][s] = found ? nxa[m][s] : 0u;
+                    sm.hval[m][i] = hv[m][s];  // (read by the dedup only: dead by the time the next item is delivered)
                 }
             }
     };
@@ -1947,9 +1976,9 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     uint32_t t = x.uni(lookup(x.bid()));
     {   // prologue: item 0 through all its stages
         fetch_meta(t);
-        const uint64_t o0[2] = {uni64(ofC[0]), uni64(ofC[1])};
+        const uint64_t o0[2] = {uni64(ofC[0]), uni64(ofC[1])}, hd[2] = {uni64(hdC[0]), uni64(hdC[1])};
         const uint32_t nk[2] = {x.uni(nkC[0]), x.uni(nkC[1])};
-        request(t, o0, nk);
+        request(t, o0, nk, hd);
         deliver();
     }
     uint32_t tB = x.uni(lookup(take()));        // item 1 (value)
@@ -1977,9 +2006,9 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         // the pipeline moves on: data of the next item, offsets of the one after, survivor index of the third
         const uint32_t tnext = tB;
         {
-            const uint64_t o0[2] = {uni64(ofC[0]), uni64(ofC[1])};
+            const uint64_t o0[2] = {uni64(ofC[0]), uni64(ofC[1])}, hd[2] = {uni64(hdC[0]), uni64(hdC[1])};
             const uint32_t nk[2] = {x.uni(nkC[0]), x.uni(nkC[1])};
-            request(tnext, o0, nk);
+            request(tnext, o0, nk, hd);
         }
         tB = x.uni(tD);
         fetch_meta(tB);

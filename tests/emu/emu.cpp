@@ -569,8 +569,8 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     std::vector<uint64_t> hitkm((size_t)tcap * 2 * a.nkp + 1, 0);
     std::vector<HitVA> hitva((size_t)tcap * 2 * a.nkp + 1, HitVA{0, 0});
     std::vector<uint32_t> hitnk((size_t)tcap * 2 + 1, 0), gen(tcap + 1, 0);
-    std::vector<uint64_t> hitoff((size_t)tcap * 2 + 1, 0);
-    a.hitkm = g_keep_km ? hitkm.data() : nullptr; a.hitva = hitva.data(); a.hitnk = hitnk.data(); a.hitoff = hitoff.data();
+    std::vector<uint64_t> hitoff((size_t)tcap * 4 + 1, 0);
+    a.hitkm = g_keep_km ? hitkm.data() : nullptr; a.hitaux = reinterpret_cast<uint32_t*>(hitva.data()); a.hitval = a.hitaux + (size_t)tcap * 2 * a.nkp; a.hitnk = hitnk.data(); a.hitoff = hitoff.data(); a.hithdr = hitoff.data() + (size_t)tcap * 2;
     a.tcap = tcap;
     const bool usual = e->T.consistent && !p->trace && !p->bait && !p->bubbles;  // as the device launcher decides
     uint32_t tile_ticket = 0;
