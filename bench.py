@@ -32,7 +32,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PMC_SUMMARY = "r01h_final_pmc.csv"
+PMC_SUMMARY = "r01i_final_pmc.csv"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 

@@ -229,7 +229,7 @@ struct dbtk_ctx {
     std::vector<std::unordered_map<uint64_t, uint64_t>> btTK;
     std::vector<std::unordered_map<uint64_t, uint16_t>> baitDB_host;
     std::vector<dbtk_pair_rec_t> own_recs;  // record buffer when the caller passes none but -tb needs the bait-stage records
-    int k1_blocks = 0, k1bin_blocks = 0, flt_wpc = 16;
+    int k1_blocks = 0, k1bin_blocks = 0, flt_wpc = 16, probe_wpc = 32;
     BinScratch bin;
     int k1_binned = 0;   // DBTK_K1_BINNED: 0 never, 1 always (where it applies), -1 for batches of >= 65536 pairs
     bool timers_on = true;
@@ -612,9 +612,9 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         a.ticket = c->d_tickets + ch;
         if (tm) { if ((st = timed_slot(c, 1, &e))) return st; HIPCHK(hipEventRecord(c->timed[1].beg[e], s)); }
         switch (ns) {
-            case 1: case 2: hipLaunchKernelGGL(k_probe<2>, dim3(c->num_cu * 32), dim3(64), 0, s, a); break;
-            case 3: hipLaunchKernelGGL(k_probe<3>, dim3(c->num_cu * 32), dim3(64), 0, s, a); break;
-            default: hipLaunchKernelGGL(k_probe<4>, dim3(c->num_cu * 32), dim3(64), 0, s, a); break;
+            case 1: case 2: hipLaunchKernelGGL(k_probe<2>, dim3(c->num_cu * c->probe_wpc), dim3(64), 0, s, a); break;
+            case 3: hipLaunchKernelGGL(k_probe<3>, dim3(c->num_cu * c->probe_wpc), dim3(64), 0, s, a); break;
+            default: hipLaunchKernelGGL(k_probe<4>, dim3(c->num_cu * c->probe_wpc), dim3(64), 0, s, a); break;
         }
         if (tm) HIPCHK(hipEventRecord(c->timed[1].end[e], s));
         // RECS = false: no record buffer (-ka without -e): record emission is compiled out
@@ -689,6 +689,7 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         if (const char* ev = getenv("DBTK_K1_WPC")) { const int v = atoi(ev); if (v > 0 && v < nb) nb = v; }  // diagnostic: encode waves per CU
         c->k1bin_blocks = c->num_cu * nb;
         if (const char* ev = getenv("DBTK_K1_BINNED")) c->k1_binned = atoi(ev);
+        if (const char* ev = getenv("DBTK_PROBE_WPC")) { const int v = atoi(ev); if (v > 0) c->probe_wpc = v; }  // probe waves per CU
         if (const char* ev = getenv("DBTK_FLT_WPC")) { const int v = atoi(ev); if (v > 0) c->flt_wpc = v; }  // diagnostic: filter waves per CU
         // resident waves of each resolve-kernel instance (one vote-spill scratch row per resident wave)
         const void* kp[3] = {(const void*)k_pair<2, true>, (const void*)k_pair<3, true>, (const void*)k_pair<4, true>};
