@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nloci", type=int, default=80000, help="loci of the synthetic RPGG (80000 = release scale)")
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (pairs = reads/2)")
