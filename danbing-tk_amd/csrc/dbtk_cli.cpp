@@ -16,6 +16,7 @@
 // stderr is informational (the reference's also carries timings); stdout and the
 // output files are byte-compatible.
 #include <errno.h>
+#include <immintrin.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -120,6 +121,25 @@ struct Reader {
     }
     bool at_eof() { return pos == end && !fill(); }  // in->peek() == EOF
 };
+
+// newlines in [p, p + n): the one full pass over the input on a single thread (the cutter), so it gets the wide registers where the CPU has them
+__attribute__((target("avx2"))) static size_t count_nl_avx2(const char* p, size_t n) {
+    const __m256i nl = _mm256_set1_epi8('\n');
+    size_t c = 0, i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const uint32_t m0 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i)), nl));
+        const uint32_t m1 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i + 32)), nl));
+        const uint32_t m2 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i + 64)), nl));
+        const uint32_t m3 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i + 96)), nl));
+        c += (size_t)__builtin_popcountll(((uint64_t)m1 << 32) | m0) + (size_t)__builtin_popcountll(((uint64_t)m3 << 32) | m2);
+    }
+    for (; i < n; ++i) c += p[i] == '\n';
+    return c;
+}
+static size_t count_nl(const char* p, size_t n) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    return avx2 ? count_nl_avx2(p, n) : (size_t)std::count(p, p + n, '\n');
+}
 
 inline void prunePEinfo(std::string& title) {  // AQ.cpp:455-462
     const size_t len = title.size();
@@ -332,7 +352,7 @@ int main(int argc, char* argv[]) {
     };
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
     const double loop_t0 = now();
-    double read_busy = 0, pair_busy = 0, gpu_busy = 0, write_busy = 0;  // seconds each stage spent working (not waiting)
+    double read_busy = 0, cut_busy = 0, pair_busy = 0, gpu_busy = 0, write_busy = 0;  // seconds each stage spent working (not waiting)
 
     // Stage A — reader, line splitters, on-the-fly mate pairing (AQ.cpp:1918-1976), all overlapped:
     //   A0 (1 thread)  reads the file in large blocks cut at record boundaries (2 lines per FASTA record, 4 per FASTQ: the
@@ -361,7 +381,7 @@ int main(int argc, char* argv[]) {
         }
     };
     struct Block {
-        uint64_t index = 0; RawBuf data; size_t len = 0; std::vector<Rec> recs;
+        uint64_t index = 0; RawBuf data; size_t base = 0, len = 0; std::vector<Rec> recs;  // the block's bytes: data[base, base + len)
         bool clean = false;  // every record pairs with its neighbour: `mini` holds the kept pairs in batch layout
         Batch mini;
         uint64_t mpos = 0;   // pairs of `mini` already handed on
@@ -373,7 +393,7 @@ int main(int argc, char* argv[]) {
     std::vector<BlockP> pool;
     auto recycle = [&](BlockP b) {
         if (!b) return;
-        b->recs.clear(); b->clean = false; b->mpos = 0; b->len = 0;
+        b->recs.clear(); b->clean = false; b->mpos = 0; b->len = 0; b->base = 0;
         Batch& m = b->mini;
         m.flat.clear(); m.off.clear(); m.qar.clear(); m.qoff.clear(); m.tar.clear(); m.toff.clear(); m.nreads = 0;
         std::lock_guard<std::mutex> l(pool_m);
@@ -390,42 +410,75 @@ int main(int argc, char* argv[]) {
     const int nsplit = (int)std::min(16u, std::max(2u, hw / 8));
     raw.cap = split.cap = 2 * (size_t)nsplit;
     const size_t L = fq ? 4 : 2;
-    std::thread reader([&] {
-        size_t BLK = 32u << 20;
-        if (const char* e = getenv("DBTK_INGEST_BLOCK")) { const long v = atol(e); if (v >= 64) BLK = (size_t)v; }  // (tests: many small blocks)
-        std::vector<char> carry;
-        uint64_t index = 0;
-        bool eof = false;
-        while (!eof) {
+    // A0 as two threads, so that the copy out of the page cache and the newline count overlap: `io` freads fixed-size
+    // chunks behind some headroom; `reader` (the cutter) puts the unfinished record of the previous chunk in front (into the
+    // headroom), counts the newlines and cuts at the last whole record.
+    size_t BLK = 32u << 20;
+    if (const char* e = getenv("DBTK_INGEST_BLOCK")) { const long v = atol(e); if (v >= 64) BLK = (size_t)v; }  // (tests: many small blocks)
+    const size_t HEAD = std::min<size_t>(1u << 20, BLK);  // room for the carried-over partial record in front of a chunk
+    Chan<BlockP> chunks;
+    chunks.cap = 4;
+    std::thread io([&] {
+        for (;;) {
             const double tr = now();
             BlockP b = fresh_block();
-            b->data.resize(carry.size() + BLK);
-            memcpy(b->data.data(), carry.data(), carry.size());
-            size_t end = carry.size();
-            carry.clear();
-            size_t cut = 0;
-            for (;;) {
-                const size_t n = fread(b->data.data() + end, 1, b->data.size() - end, in.f);
-                end += n;
-                if (n == 0) { eof = true; cut = end; break; }
-                // whole records in [0, end): the first floor(newlines / L) * L lines
-                const size_t nl = (size_t)std::count(b->data.data(), b->data.data() + end, '\n');
-                if (nl >= L) {
-                    size_t drop = nl % L;  // trailing whole lines that start an unfinished record
-                    const char* p = (const char*)memrchr(b->data.data(), '\n', end);
-                    while (drop--) p = (const char*)memrchr(b->data.data(), '\n', p - b->data.data());
-                    cut = p - b->data.data() + 1;
-                    break;
-                }
-                b->data.resize(b->data.size() + BLK);  // a record longer than the block: read on
-            }
-            carry.assign(b->data.data() + cut, b->data.data() + end);
-            b->len = cut;
-            if (b->len == 0) continue;
-            if (b->len >= 0xFFFFFFFFull) die_assert("input block too large");
-            b->index = index++;
+            b->data.resize(HEAD + BLK);
+            const size_t n = fread(b->data.data() + HEAD, 1, BLK, in.f);
+            if (n == 0) break;
+            b->base = HEAD; b->len = n;
             read_busy += now() - tr;
-            raw.push(std::move(b));
+            chunks.push(std::move(b));
+        }
+        chunks.close();
+    });
+    std::thread reader([&] {
+        std::vector<char> carry;
+        uint64_t index = 0;
+        BlockP b;
+        auto emit = [&](BlockP blk) {
+            if (blk->len == 0) return;
+            if (blk->len >= 0xFFFFFFFFull) die_assert("input block too large");
+            blk->index = index++;
+            raw.push(std::move(blk));
+        };
+        while (chunks.pop(b)) {
+            const double tr = now();
+            if (carry.size() <= b->base) {  // the usual case: the partial record goes into the headroom
+                b->base -= carry.size();
+                memcpy(b->data.data() + b->base, carry.data(), carry.size());
+                b->len += carry.size();
+            } else {  // a partial record longer than the headroom (a record longer than a chunk): rebuild the block
+                BlockP nb = fresh_block();
+                nb->data.resize(carry.size() + b->len);
+                memcpy(nb->data.data(), carry.data(), carry.size());
+                memcpy(nb->data.data() + carry.size(), b->data.data() + b->base, b->len);
+                nb->base = 0; nb->len = carry.size() + b->len;
+                recycle(std::move(b));
+                b = std::move(nb);
+            }
+            carry.clear();
+            const char* d = b->data.data() + b->base;
+            const size_t end = b->len;
+            // whole records in [0, end): the first floor(newlines / L) * L lines
+            const size_t nl = count_nl(d, end);
+            size_t cut = 0;
+            if (nl >= L) {
+                size_t drop = nl % L;  // trailing whole lines that start an unfinished record
+                const char* p = (const char*)memrchr(d, '\n', end);
+                while (drop--) p = (const char*)memrchr(d, '\n', p - d);
+                cut = p - d + 1;
+            }
+            carry.assign(d + cut, d + end);
+            b->len = cut;
+            cut_busy += now() - tr;
+            if (cut) emit(std::move(b)); else recycle(std::move(b));
+        }
+        if (!carry.empty()) {  // end of file: what is left is the last block (std::getline semantics for a missing last newline)
+            BlockP nb = fresh_block();
+            nb->data.resize(carry.size());
+            memcpy(nb->data.data(), carry.data(), carry.size());
+            nb->base = 0; nb->len = carry.size();
+            emit(std::move(nb));
         }
         raw.close();
     });
@@ -436,7 +489,7 @@ int main(int argc, char* argv[]) {
         splitters.emplace_back([&] {
             BlockP b;
             while (raw.pop(b)) {
-                const char* d0 = b->data.data();
+                const char* d0 = b->data.data() + b->base;
                 const size_t len = b->len;
                 size_t pos = 0;
                 b->recs.reserve(len / 300 + 16);
@@ -538,7 +591,7 @@ int main(int argc, char* argv[]) {
                     continue;
                 }
                 const Rec& r = blk->recs[ri++];
-                const char* d0 = blk->data.data();
+                const char* d0 = blk->data.data() + blk->base;
                 const char *tp = d0 + r.t, *sp = d0 + r.s, *qp = d0 + r.q;
                 const size_t tn = r.tn, sn = r.sn, qn = r.qn;
                 const char *s2p = nullptr, *q2p = nullptr;
@@ -672,14 +725,15 @@ int main(int argc, char* argv[]) {
             }
         }
     }
+    io.join();
     reader.join();
     for (auto& w : splitters) w.join();
     parser.join();
     for (auto& w : workers) w.join();
     fclose(in.f);
     fflush(stdout);
-    fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: reading %.2f s, pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads\n",
-            now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, read_busy, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit);
+    fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: reading %.2f s, cutting %.2f s, pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads\n",
+            now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, read_busy, cut_busy, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit);
 
     // ---- totals + dumps (AQ.cpp:2611-2656)
     if (o.ngpus > 1 && dbtk_allreduce(ctx.data(), o.ngpus)) die_assert(dbtk_last_error());
