@@ -210,7 +210,7 @@ struct dbtk_ctx {
     uint64_t* d_off = nullptr; uint64_t off_cap = 0;
     dbtk_pair_rec_t* d_recs = nullptr; uint64_t rec_cap = 0;
     uint64_t* d_hitkm = nullptr; uint64_t hitkm_cap = 0;   // K2 -> K3 (see BatchArgs)
-    HitVA* d_hitva = nullptr; uint64_t hitva_cap = 0;
+    uint64_t* d_hitva = nullptr; uint64_t hitva_cap = 0;   // aux words of every row, then val words (4 + 4 bytes per position)
     uint32_t* d_hitnk = nullptr; uint64_t hitnk_cap = 0;
     uint64_t* d_hitoff = nullptr; uint64_t hitoff_cap = 0;
     uint32_t* d_gen = nullptr; uint64_t gen_cap = 0;        // K3a -> K3b
@@ -246,7 +246,7 @@ struct dbtk_ctx {
         uint32_t* d_small = nullptr;
         uint32_t* d_surv = nullptr; uint64_t surv_cap = 0;
         uint64_t* d_hitkm = nullptr; uint64_t hitkm_cap = 0;
-        HitVA* d_hitva = nullptr; uint64_t hitva_cap = 0;
+        uint64_t* d_hitva = nullptr; uint64_t hitva_cap = 0;   // aux words of every row, then val words (4 + 4 bytes per position)
         uint32_t* d_hitnk = nullptr; uint64_t hitnk_cap = 0;
         uint64_t* d_hitoff = nullptr; uint64_t hitoff_cap = 0;
         uint32_t* d_gen = nullptr; uint64_t gen_cap = 0;
@@ -531,7 +531,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     memset(&a, 0, sizeof(a));
     a.T = c->T; a.P = c->P;
     a.seq = d_seq; a.off = d_off; a.seq_len = seq_len; a.npairs = npairs;
-    a.surv = c->d_surv; a.nsurv = c->d_small + 0; a.tile_ticket = c->d_small + 1; a.nrec = c->d_small + 2; a.errflag = c->d_small + 3;
+    a.surv = c->d_surv; a.nsurv = c->d_small + 0; a.nrec = c->d_small + 2; a.errflag = c->d_small + 3;
     a.counts = c->d_accum;
     a.kmc = c->d_accum + c->ntr;
     a.nmapread = a.kmc + c->g->nloci;
@@ -609,7 +609,6 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     }
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         a.t0 = (uint32_t)(ch * tcap);
-        a.ticket = c->d_tickets + ch;
         if (tm) { if ((st = timed_slot(c, 1, &e))) return st; HIPCHK(hipEventRecord(c->timed[1].beg[e], s)); }
         switch (ns) {
             case 1: case 2: hipLaunchKernelGGL(k_probe<2>, dim3(c->num_cu * c->probe_wpc), dim3(64), 0, s, a); break;

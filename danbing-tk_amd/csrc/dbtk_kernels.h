@@ -170,7 +170,6 @@ struct BatchArgs {
     uint64_t npairs;
     uint32_t* surv;       // K1 -> pair kernel: indices of pairs that passed subfilter
     uint32_t* nsurv;
-    uint32_t* ticket;     // pair kernel work counter
     uint64_t* counts;     // OUT.trkmc.ar order
     uint64_t* kmc;
     uint64_t* nmapread;   // widened; low 32 bits are the reference's uint32 counter
@@ -208,7 +207,6 @@ struct BatchArgs {
     uint32_t* nevents;
     uint32_t events_cap;
     uint32_t t0, tcap;       // K2/K3 work on survivors [t0, min(t0 + tcap, *nsurv)): the hit buffer holds tcap pairs
-    uint32_t* tile_ticket;   // K1 work counter (tiles)
     // Binned encode stage (body_encode_subfilter<true> -> body_filter_bins -> body_subfilter_cand): per (encode wave,
     // filter partition) a segment of bin_cap queries, the number each segment holds, the queries that
     // found their segment full, and one bit per pair: "a sampled k-mer of mate 1 is in the index".
@@ -1271,17 +1269,9 @@ DBTK_HD bool vote_parallel(X& x, const uint16_t* ord, const uint32_t* uval, cons
 // (read2kmers_edges, AQ.h:274-311) and their home buckets, and the positions are then looked up 16 at a time: the four
 // lanes of a quad read the four 16-byte parts of one bucket, so a look-up is one request for one 64-byte line.  The
 // results {val, aux} are collected in LDS and leave once per read, coalesced, for the hit buffers that the resolve
-// kernels (K3a / K3b) consume: k-mers and {val, aux} in separate arrays, plus the number of positions of the row.
+// kernels (K3a / K3b) consume (BatchArgs: hitaux / hitval / hithdr / hitnk / hitoff).
 // Every position is looked up; what the reference would NOT have probed (after kfilter's abort) is discounted from
 // nhash1 by K3.
-struct HitEnt {
-    uint64_t km;   // canonical k-mer at the position, NAN64 = window with a non-ACGT base
-    uint32_t val;  // index val, NOHIT when the k-mer is not in the index
-    uint32_t aux;  // class of a single-locus k-mer at its locus (see IdxBucket)
-};
-struct HitVA {     // the (val, aux) half, stored apart from the k-mers
-    uint32_t val, aux;
-};
 struct BubEvent {  // one novel read (k+1)-mer (countNovelEdges, AQ.cpp:1559-1567)
     uint32_t pair, mate, pos, locus;
     uint64_t edge;

@@ -555,7 +555,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     memset(&a, 0, sizeof(a));
     a.T = e->T; a.P = *p;
     a.seq = (const uint8_t*)seqbuf.data(); a.off = off; a.seq_len = nbytes; a.npairs = npairs;
-    a.surv = surv.data(); a.nsurv = &small[0]; a.ticket = &small[1]; a.nrec = &small[2]; a.errflag = &small[3];
+    a.surv = surv.data(); a.nsurv = &small[0]; a.nrec = &small[2]; a.errflag = &small[3];
     a.counts = accum.data(); a.kmc = a.counts + ntr; a.nmapread = a.kmc + nloci; a.counters = a.nmapread + nloci;
     a.recs = recs; a.rec_cap = (uint32_t)rec_cap;
     a.vote_scratch = vote.data(); a.vote_epoch = epoch.data();
@@ -567,14 +567,12 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     // survivor chunks: small hit buffers force several K2 -> K3 iterations, as on the device
     const uint32_t tcap = npairs > 7 ? (uint32_t)(npairs / 3 + 1) : (uint32_t)(npairs ? npairs : 1);
     std::vector<uint64_t> hitkm((size_t)tcap * 2 * a.nkp + 1, 0);
-    std::vector<HitVA> hitva((size_t)tcap * 2 * a.nkp + 1, HitVA{0, 0});
+    std::vector<uint64_t> hitva((size_t)tcap * 2 * a.nkp + 1, 0);  // aux words of every row, then val words
     std::vector<uint32_t> hitnk((size_t)tcap * 2 + 1, 0), gen(tcap + 1, 0);
     std::vector<uint64_t> hitoff((size_t)tcap * 4 + 1, 0);
     a.hitkm = g_keep_km ? hitkm.data() : nullptr; a.hitaux = reinterpret_cast<uint32_t*>(hitva.data()); a.hitval = a.hitaux + (size_t)tcap * 2 * a.nkp; a.hitnk = hitnk.data(); a.hitoff = hitoff.data(); a.hithdr = hitoff.data() + (size_t)tcap * 2;
     a.tcap = tcap;
     const bool usual = e->T.consistent && !p->trace && !p->bait && !p->bubbles;  // as the device launcher decides
-    uint32_t tile_ticket = 0;
-    a.tile_ticket = &tile_ticket;
     std::vector<uint64_t> edgebuf, qmaskbuf, qualbuf;
     uint32_t nevents = 0;
     if (p->bubbles) {
@@ -607,8 +605,6 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     }
     for (uint32_t t0 = 0; t0 < (uint32_t)(npairs ? npairs : 1); t0 += tcap) {
         a.t0 = t0;
-        uint32_t ticket = 0;
-        a.ticket = &ticket;
         uint32_t ngen = 0;
         a.gen_list = usual ? gen.data() : nullptr;
         a.ngen = usual ? &ngen : nullptr;
