@@ -631,7 +631,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         if (lane < nparts) a.bincnt[(size_t)x.bid() * nparts + lane] = sm.tail[lane] < a.bin_cap ? sm.tail[lane] : a.bin_cap;
     }
     {
-        const int lane = lane_;
+        const int lane = lane_; (void)lane;
         DBTK_STAMP_FLUSH;
     }
     // flush: wave sums, one atomic each
@@ -1897,7 +1897,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
             const uint32_t len = nk[m] ? nk[m] + k - 1 : 0;  // (<= MAXL: the probe kernel clamps)
             const uint64_t a0 = o0[m] & ~3ull;
             const uint32_t nw = ((uint32_t)(o0[m] - a0) + len + 3) >> 2;
-            nxrw[m][0] = *reinterpret_cast<const uint32_t*>(a.seq + (lane < nw ? a0 + 4ull * lane : 0ull));
+            nxrw[m][0] = *reinterpret_cast<const uint32_t*>(a.seq + ((uint32_t)lane < nw ? a0 + 4ull * lane : 0ull));
             nxrw[m][1] = *reinterpret_cast<const uint32_t*>(a.seq + (64u + lane < nw ? a0 + 4ull * (64 + lane) : 0ull));
             nxo0[m] = o0[m]; nxnk[m] = nk[m];
         }
@@ -1924,7 +1924,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const uint32_t nw = (rsh[m] + len[m] + 3) >> 2;
-            if (lane < nw) sm.raw[m][lane] = nxrw[m][0];
+            if ((uint32_t)lane < nw) sm.raw[m][lane] = nxrw[m][0];
             if (64u + lane < nw) sm.raw[m][64 + lane] = nxrw[m][1];
             if (lane < 4) sm.raw[m][nw + lane] = 0;
         }
