@@ -345,3 +345,13 @@ def test_binned_encode_stage_on_device(case, pb, cap, dbtk, oracle, tmp_path, mo
             ctx.close()
     oracle.free(go)
     g.close()
+
+
+def test_randomised_parity_soak():
+    """tools/fuzz_parity.py: random RPGGs (k 17/21/25, shared flanks), read sets (64-250 bp, substitutions, indels, N, chimeras,
+    background) and parameters; trace records and counts against the oracle.  (600 seeds were run when this was added.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "16", "900"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]

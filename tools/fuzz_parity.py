@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU: random RPGGs, read sets and parameters, the HIP path against the oracle
+(records in trace mode, counts / totals / counters without).   python tools/fuzz_parity.py [nseeds] [first_seed]"""
+import importlib
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bind  # noqa: E402
+import cases  # noqa: E402
+import synth  # noqa: E402
+
+abi = bind.pkg.abi
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    dbtk, orc = bind.pkg.Dbtk(), bind.Oracle()
+    bad = 0
+    for seed in range(s0, s0 + n):
+        rng = np.random.default_rng(seed)
+        k = int(rng.choice([21, 21, 21, 17, 25]))
+        loci = synth.make_loci(nloci=int(rng.integers(3, 40)), nhap=int(rng.integers(1, 4)), flank=int(rng.integers(300, 700)), seed=seed,
+                               shared_frac=float(rng.choice([0.0, 0.2, 0.6, 1.0])), tr_min=int(rng.integers(40, 200)), tr_max=int(rng.integers(300, 1200)))
+        rlen = int(rng.choice([150, 150, 100, 250, 64]))
+        reads = synth.sim_reads(loci, npairs=int(rng.integers(50, 900)), rlen=rlen, seed=seed + 7, sub=float(rng.choice([0.0, 0.005, 0.03])),
+                                indel=float(rng.choice([0.0, 0.002])), nrate=float(rng.choice([0.0, 0.003, 0.02])),
+                                chimeric=float(rng.choice([0.0, 0.3])), background=float(rng.choice([0.0, 0.3])), frag=(max(300, rlen), max(320, rlen) + 250))
+        with tempfile.TemporaryDirectory() as d:
+            pref = cases._np_rpgg(d, "f", loci, k)
+            go, g = orc.load(pref, k, None), dbtk.load(pref, k, None)
+            seq, off = reads.packed()
+            cth = int(rng.choice([45, 30, 10, 60]))
+            if rlen - k + 1 < cth:
+                cth = max(1, (rlen - k + 1) // 2)
+            kw = dict(cthreshold=cth, okam=int(rng.integers(0, 2)))
+            if rng.random() < 0.3:
+                kw.update(n_filter=int(rng.choice([2, 4, 8])), nm_filter=int(rng.choice([1, 2])))
+            ok = True
+            for trace in (1, 0):
+                p = abi.default_params(ksize=k, trace=trace, **kw)
+                o = orc.align(go, p, seq, off, trace=bool(trace))
+                ctx = dbtk.context(g, p)
+                recs, nrec = ctx.align(seq, off)
+                r = ctx.counts()
+                co = np.zeros(g.ntrkmers, np.uint64)
+                np.add.at(co, g.output_order().astype(np.int64), o["counts_file"])
+                same = bool((co == r["counts"]).all() and (o["kmc"] == r["kmc"]).all() and (o["nmapread"] == r["nmapread"]).all()
+                            and (o["counters"] == r["counters"]).all())
+                if trace and same:
+                    same = bind.recs_equal(o["recs"], recs, reads.npairs) < 0
+                ok &= same
+                ctx.close()
+            orc.free(go)
+            g.close()
+        print(f"seed {seed}: k={k} rlen={rlen} pairs={reads.npairs} {kw} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+        bad += not ok
+    print(f"{n - bad}/{n} seeds bit-exact")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
