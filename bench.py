@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--hit-frac", type=float, default=0.02, help="fraction of pairs drawn from the loci (WGS-like: 0.02)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--parity-pairs", type=int, default=100000, help="pairs of the CPU-baseline sample whose oracle result is compared with the HIP path (0 = skip; needs --cpu-seconds > 0)")
-    ap.add_argument("--lanes", type=int, default=1, choices=(1, 2),
+    ap.add_argument("--lanes", type=int, default=1, choices=(1, 2, 3),
                     help="streams the context alternates successive batches on.  2 (the library's default) overlaps one batch's encode kernel "
                          "with the other's probe kernel (+9 %% reads/s) but then a kernel's launch duration includes its neighbour's work, "
                          "so the roofline measurement runs on one lane")

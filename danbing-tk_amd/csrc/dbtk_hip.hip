@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <deque>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -255,7 +256,8 @@ struct dbtk_ctx {
         uint32_t* d_epoch = nullptr;
         BinScratch bin;
     } alt;
-    bool two_lanes = false;
+    std::deque<Lane> parked;  // lanes beyond the second (DBTK_LANES > 2): switch_lane goes round all of them
+    bool two_lanes = false;   // more than one lane
 };
 
 namespace {
@@ -279,9 +281,16 @@ void free_ctx(dbtk_ctx* c) {
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
                     c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    void* aptrs[] = {c->alt.d_small, c->alt.d_surv, c->alt.d_hitkm, c->alt.d_hitva, c->alt.d_hitnk, c->alt.d_hitoff, c->alt.d_gen, c->alt.d_tickets, c->alt.d_vote, c->alt.d_epoch};
-    for (void* p : aptrs) if (p) (void)hipFree(p);
-    for (BinScratch* b : {&c->bin, &c->alt.bin}) {
+    std::vector<dbtk_ctx::Lane*> others{&c->alt};
+    for (auto& l : c->parked) others.push_back(&l);
+    std::vector<BinScratch*> bins{&c->bin};
+    for (dbtk_ctx::Lane* l : others) {
+        void* aptrs[] = {l->d_small, l->d_surv, l->d_hitkm, l->d_hitva, l->d_hitnk, l->d_hitoff, l->d_gen, l->d_tickets, l->d_vote, l->d_epoch};
+        for (void* p : aptrs) if (p) (void)hipFree(p);
+        bins.push_back(&l->bin);
+        if (l != &c->alt && l->stream) (void)hipStreamDestroy(l->stream);
+    }
+    for (BinScratch* b : bins) {
         void* bp[] = {b->bins, b->bincnt, b->ovf, b->ovf_hdr, b->cand};
         for (void* p : bp) if (p) (void)hipFree(p);
     }
@@ -472,10 +481,16 @@ void switch_lane(dbtk_ctx* c) {
     std::swap(c->d_tickets, c->alt.d_tickets); std::swap(c->tickets_cap, c->alt.tickets_cap);
     std::swap(c->d_vote, c->alt.d_vote); std::swap(c->d_epoch, c->alt.d_epoch);
     std::swap(c->bin, c->alt.bin);
+    if (!c->parked.empty()) {  // round robin: the lane just left goes to the back of the queue, the longest-parked one is next
+        c->parked.push_back(c->alt);
+        c->alt = c->parked.front();
+        c->parked.pop_front();
+    }
 }
 hipError_t sync_all(dbtk_ctx* c) {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && c->alt.stream) e = hipStreamSynchronize(c->alt.stream);
+    for (auto& l : c->parked) if (e == hipSuccess && l.stream) e = hipStreamSynchronize(l.stream);
     return e;
 }
 dbtk_status_t timed_slot(dbtk_ctx* c, int k, int* slot) {
@@ -752,23 +767,29 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         chk(hipMemsetAsync(c->d_accum, 0, c->n_accum * 8, c->stream), "memset");
         chk(hipMemsetAsync(c->d_vote, 0, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8, c->stream), "memset");
         chk(hipMemsetAsync(c->d_epoch, 0, (size_t)c->max_pair_blocks * 4, c->stream), "memset");
-        // the second lane (not with -bu: its event log is replayed batch by batch on the host; not in the stamps build)
+        // further lanes (not with -bu: its event log is replayed batch by batch on the host; not in the stamps build)
+        int nlanes = 1;
 #ifndef DBTK_STAMPS
-        {   // DBTK_LANES=1|2 (default 2)
+        {   // DBTK_LANES=1..3 (default 2; a third lane gains another 2 %, a fourth fell apart: 25 ms/step)
             const char* e = getenv("DBTK_LANES");
-            c->two_lanes = !p->bubbles && !(e && atoi(e) == 1);
+            nlanes = (e && atoi(e) >= 1 && atoi(e) <= 3) ? atoi(e) : 2;
+            if (p->bubbles) nlanes = 1;
+            c->two_lanes = nlanes > 1;
         }
 #endif
-        if (c->two_lanes) {
-            chk(hipStreamCreate(&c->alt.stream), "hipStreamCreate");
-            chk(hipMalloc(&c->alt.d_small, 4 * SMALL_WORDS + 48 * 8), "hipMalloc small");
-            chk(hipMalloc(&c->alt.d_vote, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8), "hipMalloc vote scratch");
-            chk(hipMalloc(&c->alt.d_epoch, (size_t)c->max_pair_blocks * 4), "hipMalloc epoch");
+        for (int li = 1; li < nlanes; ++li) {
+            dbtk_ctx::Lane l;
+            chk(hipStreamCreate(&l.stream), "hipStreamCreate");
+            chk(hipMalloc(&l.d_small, 4 * SMALL_WORDS + 48 * 8), "hipMalloc small");
+            chk(hipMalloc(&l.d_vote, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8), "hipMalloc vote scratch");
+            chk(hipMalloc(&l.d_epoch, (size_t)c->max_pair_blocks * 4), "hipMalloc epoch");
+            if (li == 1) c->alt = l; else c->parked.push_back(l);
             if (st) break;
-            chk(hipMemsetAsync(c->alt.d_small, 0, 4 * SMALL_WORDS + 48 * 8, c->stream), "memset");
-            chk(hipMemsetAsync(c->alt.d_vote, 0, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8, c->stream), "memset");
-            chk(hipMemsetAsync(c->alt.d_epoch, 0, (size_t)c->max_pair_blocks * 4, c->stream), "memset");
+            chk(hipMemsetAsync(l.d_small, 0, 4 * SMALL_WORDS + 48 * 8, c->stream), "memset");
+            chk(hipMemsetAsync(l.d_vote, 0, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8, c->stream), "memset");
+            chk(hipMemsetAsync(l.d_epoch, 0, (size_t)c->max_pair_blocks * 4, c->stream), "memset");
         }
+        if (st) break;
         chk(hipStreamSynchronize(c->stream), "sync");
     } while (0);
     if (st) { free_ctx(c); return st; }
@@ -933,6 +954,11 @@ dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* c) {
     uint32_t err = 0, err2 = 0;
     HIPCHK(hipMemcpy(&err, c->d_small + 3, 4, hipMemcpyDeviceToHost));
     if (c->alt.d_small) HIPCHK(hipMemcpy(&err2, c->alt.d_small + 3, 4, hipMemcpyDeviceToHost));
+    for (auto& l : c->parked) {
+        uint32_t e3 = 0;
+        if (l.d_small) HIPCHK(hipMemcpy(&e3, l.d_small + 3, 4, hipMemcpyDeviceToHost));
+        if (e3) err2 = e3;
+    }
     if (err || err2) { set_error("device reported an over-long read"); return (dbtk_status_t)(err ? err : err2); }
     return DBTK_OK;
 }

@@ -178,7 +178,7 @@ def test_accumulator_as_torch_tensor_and_rccl(tmp_path):
     assert r.returncode == 0 and "ACCUM-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("lanes", [1, 2])
+@pytest.mark.parametrize("lanes", [1, 2, 3])
 def test_device_entry_alternating_lanes(dbtk, oracle, tmp_path, lanes, monkeypatch):
     """dbtk_align_batch_device (reads resident in HBM, asynchronous): five batches, alternating between the context's two
     streams when DBTK_LANES=2, must add up to five times the oracle's single-batch result."""
