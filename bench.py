@@ -50,6 +50,7 @@ def main():
                     help="streams the context alternates successive batches on.  2 (the library's default) overlaps one batch's encode kernel "
                          "with the other's probe kernel (+9 %% reads/s) but then a kernel's launch duration includes its neighbour's work, "
                          "so the roofline measurement runs on one lane")
+    ap.add_argument("--extra-lanes", action="store_true", help="after the timed region, also run the same steps on two overlapped lanes (the library's default) and report them as `two_lanes`")
     ap.add_argument("--lib", default=None, help="diagnostic: another build of libdbtk_hip.so (tuning variants)")
     args = ap.parse_args()
 
@@ -211,10 +212,11 @@ def main():
                 algorithmic_bytes_per_launch=per_kernel[dom]["algorithmic_bytes"], avg_ms=per_kernel[dom]["avg_ms"],
                 kernels=per_kernel)
 
-    # ---- untimed extra (N=1 only): the same steps on the library's default of two overlapped lanes (DBTK_LANES=2; the timed
+    # ---- untimed extra (--extra-lanes, N=1 only; off by default so that a profile of the default command holds the timed launches
+    # and nothing else): the same steps on the library's default of two overlapped lanes (DBTK_LANES=2; the timed
     # region above runs on one lane so that a kernel's launch duration is its own) — reported beside `value`, never as it
     two_lanes = None
-    if world == 1 and args.lanes == 1 and not os.environ.get("DBTK_BENCH_NO_EXTRA"):
+    if world == 1 and args.lanes == 1 and args.extra_lanes:
         os.environ["DBTK_LANES"] = "2"
         ctx2 = dbtk.context(g, params, device=local_rank)
         os.environ["DBTK_LANES"] = "1"

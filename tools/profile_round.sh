@@ -2,7 +2,7 @@
 # The committed evidence of a round: tools/profile_round.sh r01h  ->  gpurun_out/<tag>_*  (copy to profiles/)
 tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.log
+python3 bench.py --extra-lanes > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.log
 python3 bench.py --lanes 2 --cpu-seconds 0 > gpurun_out/${tag}_lanes2_bench.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --cpu-seconds 0 --parity-pairs 0 > /dev/null 2>&1
 cp $(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats.csv
