@@ -697,6 +697,7 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
     {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_subfilter, K1_NT, 0) != hipSuccess || nb <= 0) nb = 4;
+        if (const char* ev = getenv("DBTK_ENC_WPC")) { const int v = atoi(ev); if (v > 0) nb = v; }  // diagnostic: encode waves per CU (more than resident: several rounds)
         c->k1_blocks = c->num_cu * nb;
         nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_bin, K1_NT, 0) != hipSuccess || nb <= 0) nb = 4;
