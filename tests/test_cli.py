@@ -160,6 +160,14 @@ def test_cli_vs_reference_binary_live(tmp_path):
         if "-e" not in flags:
             for ext in (".trkmc.ar", ".tr.summary.txt"):
                 assert open(os.path.join(d, "ref" + ext), "rb").read() == open(os.path.join(d, "hip" + ext), "rb").read(), (flags, ext)
+    # the pipeline form of the reference's README (`samtools fasta ... | danbing-tk -fa /dev/stdin`): a pipe, not a seekable file
+    with open(os.path.join(d, "r.fa"), "rb") as f:
+        r = subprocess.run([CLI, "-k", "21", "-cth", "30", "-fa", "/dev/stdin", "-qs", "pan", "-o", "pipe"], cwd=d, stdin=f,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    r2 = subprocess.run([CLI, "-k", "21", "-cth", "30", "-fa", "r.fa", "-qs", "pan", "-o", "file"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r2.returncode == 0 and r.stdout == r2.stdout
+    assert open(os.path.join(d, "pipe.trkmc.ar"), "rb").read() == open(os.path.join(d, "file.trkmc.ar"), "rb").read()
 
 
 @pytest.mark.gpu
