@@ -241,7 +241,13 @@ def main():
             # ---- the cpu_baseline leg: the oracle (oracle/dbtk_oracle.c, the checker) timed on a bounded sample of the same
             # workload; its result on the first chunk doubles as this run's parity check of the HIP path.
             import bind
-            orc = bind.Oracle()
+            try:
+                orc = bind.Oracle()
+            except OSError:  # the checker is not built (oracle/liboracle.so: __graft_entry__.build() makes it): build it now
+                import subprocess
+                subprocess.run(["make", "-C", os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle"), "oracle"], check=False,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                orc = bind.Oracle()
             t0 = time.time()
             go = orc.from_arrays(arrs)
             log(f"oracle tables: {time.time() - t0:.1f}s")
