@@ -50,6 +50,7 @@ def main():
                     help="streams the context alternates successive batches on.  2 (the library's default) overlaps one batch's encode kernel "
                          "with the other's probe kernel (+9 %% reads/s) but then a kernel's launch duration includes its neighbour's work, "
                          "so the roofline measurement runs on one lane")
+    ap.add_argument("--timer-every", type=int, default=4, help="record the per-kernel HIP events on every n-th step (each step's 8 records cost ~30 us)")
     ap.add_argument("--extra-lanes", action="store_true", help="after the timed region, also run the same steps on two overlapped lanes (the library's default) and report them as `two_lanes`")
     ap.add_argument("--lib", default=None, help="diagnostic: another build of libdbtk_hip.so (tuning variants)")
     args = ap.parse_args()
@@ -137,6 +138,7 @@ def main():
     reduce_counts()  # untimed: RCCL communicator / kernel warm-up (the reduced values are discarded by the reset)
     ctx.reset()
     ctx.timers_reset()
+    ctx.timers_enable(args.timer_every)  # HIP-event pairs around the kernels of every n-th step of the timed region
     if os.environ.get("DBTK_NO_TIMERS"):  # diagnostic: cost of the per-kernel event records themselves
         ctx.timers_enable(False)
     barrier()
@@ -181,10 +183,13 @@ def main():
             t = ktimes.pop(part)
             if t[1]:
                 ktimes[f"k_encode_subfilter: {part}"] = t
+    # the event pairs sit around the kernels of every `timer_every`-th step: n timed launches stand for n * steps / timed steps launches
+    timed_steps = (args.steps + args.timer_every - 1) // max(args.timer_every, 1) if args.timer_every > 1 else args.steps
     for name, (ms, n) in ktimes.items():  # large steps run as several sub-batch launches: price per launch
         avg = ms / max(n, 1)
-        per_launch = alg.get(name, 0.0) / max(n, 1)
-        per_kernel[name] = dict(avg_ms=avg, launches=n, algorithmic_bytes=per_launch,
+        launches = n * args.steps / max(timed_steps, 1)
+        per_launch = alg.get(name, 0.0) / max(launches, 1)
+        per_kernel[name] = dict(avg_ms=avg, launches=launches, timed_launches=n, algorithmic_bytes=per_launch,
                                 gbs=(per_launch / (avg * 1e-3) / 1e9) if avg > 0 else 0.0)
     dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"] * per_kernel[k]["launches"])
     # HBM bytes per launch of the dominant kernel from the committed PMC summary of this same command (a separate

@@ -234,6 +234,8 @@ struct dbtk_ctx {
     BinScratch bin;
     int k1_binned = 0;   // DBTK_K1_BINNED: 0 never, 1 always (where it applies), -1 for batches of >= 65536 pairs
     bool timers_on = true;
+    uint32_t timers_every = 1;  // event records around the kernels of every n-th batch (8 records cost ~30 us per batch)
+    uint64_t batch_no = 0;
     uint64_t* d_vote = nullptr;
     uint32_t* d_epoch = nullptr;
     int pair_blocks[3] = {0, 0, 0}, usual_blocks[3] = {0, 0, 0}, num_cu = 0, max_pair_blocks = 0;
@@ -565,7 +567,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
 #endif
     const uint64_t ntiles = (npairs + K1_TP - 1) / K1_TP;
     int e = 0;
-    const bool tm = c->timers_on;
+    const bool tm = c->timers_on && (c->batch_no++ % c->timers_every) == 0;
     auto rec_beg = [&](int kslot) -> dbtk_status_t { if (!tm) return DBTK_OK; dbtk_status_t r = timed_slot(c, kslot, &e); if (r) return r; HIPCHK(hipEventRecord(c->timed[kslot].beg[e], s)); return DBTK_OK; };
     auto rec_end = [&](int kslot) -> dbtk_status_t { if (tm) HIPCHK(hipEventRecord(c->timed[kslot].end[e], s)); return DBTK_OK; };
     // The encode stage.  Binned form (see body_filter_bins) where it applies: a presence filter, subfilter on, no trace
@@ -1082,7 +1084,10 @@ int dbtk_debug_stamps(dbtk_ctx_t* c, uint64_t* out16) {
 #endif
 
 void dbtk_ctx_timers_enable(dbtk_ctx_t* c, int on) {
-    if (c) c->timers_on = on != 0;
+    if (!c) return;
+    c->timers_on = on > 0;
+    c->timers_every = on > 1 ? (uint32_t)on : 1u;
+    c->batch_no = 0;
 }
 
 void dbtk_ctx_timers_reset(dbtk_ctx_t* c) {

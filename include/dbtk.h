@@ -220,7 +220,8 @@ dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n);
  * stream.  Returns how many kernels were filled (<= cap). */
 int  dbtk_ctx_kernel_times(dbtk_ctx_t* ctx, const char** names, double* total_ms, uint64_t* launches, int cap);
 void dbtk_ctx_timers_reset(dbtk_ctx_t* ctx);
-void dbtk_ctx_timers_enable(dbtk_ctx_t* ctx, int on);  /* default on; off = no event records on the stream */
+void dbtk_ctx_timers_enable(dbtk_ctx_t* ctx, int on);  /* default 1: event records around every kernel of every batch (~30 us per batch);
+                                                          * 0 = none; n > 1 = only around the kernels of every n-th batch (sampling) */
 
 /* -tb: OUT.btk.kmdb = dumpBaitKmerHits (src/aQueryFasta_thread.h:1010-1012): the per-locus (bait k-mer -> times it was
  * the first violated one) maps in the reference's iteration order, serializeKmapDB layout with 8-byte values. */
