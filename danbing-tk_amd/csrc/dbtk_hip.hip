@@ -205,7 +205,7 @@ struct dbtk_ctx {
     uint64_t* d_accum = nullptr;  // counts | kmc | nmapread | counters
     uint64_t* d_ctr = nullptr;    // counter replicas (folded into d_accum's counters at the end of every batch)
     uint64_t n_accum = 0, ntr = 0;
-    uint32_t* d_small = nullptr;  // nsurv, ticket, nrec, errflag
+    uint32_t* d_small = nullptr;  // nsurv, novf, nrec, errflag
     uint32_t* d_surv = nullptr; uint64_t surv_cap = 0;
     uint8_t* d_seq = nullptr; uint64_t seq_cap = 0;
     uint64_t* d_off = nullptr; uint64_t off_cap = 0;
@@ -510,7 +510,7 @@ dbtk_status_t timed_slot(dbtk_ctx* c, int k, int* slot) {
 // ceil(npairs / SURV_CAP) chunk iterations are enqueued and the kernels of a chunk past the end
 // of the list exit at once; nothing waits for the host.
 constexpr uint64_t SURV_CAP = 1ull << 23;  // at most 51 GB of hit buffers at 150 bp (allocated for the batch size actually seen): one chunk for batches of up to 8 M pairs
-constexpr uint32_t SMALL_WORDS = 64;  // d_small: nsurv, tile ticket, nrec, errflag, [8..] per-chunk tickets, stamps at +32
+constexpr uint32_t SMALL_WORDS = 64;  // d_small: nsurv, novf (binned encode stage), nrec, errflag (sticky until reported); stamps at +32
 
 dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_off, uint64_t seq_len, uint64_t npairs,
                            uint32_t max_read_len, dbtk_pair_rec_t* d_recs, uint32_t rec_cap, const uint8_t* d_qual = nullptr) {
@@ -534,7 +534,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     if ((st = ensure(&c->d_hitnk, &c->hitnk_cap, tcap * 2))) return st;
     if ((st = ensure(&c->d_gen, &c->gen_cap, tcap))) return st;
     if ((st = ensure(&c->d_tickets, &c->tickets_cap, 2 * (nchunks + 1)))) return st;  // per chunk: a ticket counter and a passed-on counter
-    HIPCHK(hipMemsetAsync(c->d_small, 0, 8 * sizeof(uint32_t), s));
+    HIPCHK(hipMemsetAsync(c->d_small, 0, 3 * sizeof(uint32_t), s));  // nsurv, novf, nrec; the error word (3) stays until it has been reported
     HIPCHK(hipMemsetAsync(c->d_tickets, 0, 2 * (nchunks + 1) * sizeof(uint32_t), s));
     if (c->P.bubbles) {
         if ((st = ensure(&c->d_edge, &c->edge_cap, tcap * 2 * nkp))) return st;
@@ -595,7 +595,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             if ((st = ensure(&b.cand, &b.cand_cap, (npairs + 31) / 32 + 64))) return st;
             HIPCHK(hipMemsetAsync(b.cand, 0, ((npairs + 31) / 32) * sizeof(uint32_t), s));
             a.bins = b.bins; a.bincnt = b.bincnt; a.bin_cap = (uint32_t)bcap; a.bin_pb = pb; a.bin_waves = g1;
-            a.ovf = b.ovf; a.ovf_hdr = b.ovf_hdr; a.novf = c->d_small + 4; a.candbits = b.cand;
+            a.ovf = b.ovf; a.ovf_hdr = b.ovf_hdr; a.novf = c->d_small + 1; a.candbits = b.cand;
             if (tm)  // slot 0 brackets the three launches: no fold of the event pools may fall in between
                 for (int i : {0, 4, 5, 6})
                     if (c->timed[i].used == EVPOOL) {
@@ -854,7 +854,11 @@ dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t
     uint32_t small[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(small, c->d_small, sizeof(small), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (small[3]) { set_error("device reported an over-long read"); return (dbtk_status_t)small[3]; }
+    if (small[3]) {
+        (void)hipMemsetAsync(c->d_small + 3, 0, 4, s);
+        set_error("device reported an over-long read");
+        return (dbtk_status_t)small[3];
+    }
     if (c->P.bubbles) {
         // Replay the batch's novel edges the way the reference accumulates them: the worker's per-batch
         // `bubbles[destLocus][edge]` is filled in pair order, mate 1 before mate 2, positions ascending
@@ -962,7 +966,13 @@ dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* c) {
         if (l.d_small) HIPCHK(hipMemcpy(&e3, l.d_small + 3, 4, hipMemcpyDeviceToHost));
         if (e3) err2 = e3;
     }
-    if (err || err2) { set_error("device reported an over-long read"); return (dbtk_status_t)(err ? err : err2); }
+    if (err || err2) {  // reported once: the words are cleared
+        (void)hipMemset(c->d_small + 3, 0, 4);
+        if (c->alt.d_small) (void)hipMemset(c->alt.d_small + 3, 0, 4);
+        for (auto& l : c->parked) if (l.d_small) (void)hipMemset(l.d_small + 3, 0, 4);
+        set_error("device reported an over-long read");
+        return (dbtk_status_t)(err ? err : err2);
+    }
     return DBTK_OK;
 }
 

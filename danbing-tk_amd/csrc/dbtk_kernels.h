@@ -1343,7 +1343,8 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
     uint32_t pairA = 0;          // row it + 2S: pair index (in flight)
     auto fetch_bytes = [&](uint64_t o0, uint64_t o1) {
         uint32_t len = (uint32_t)(o1 - o0);
-        if (len > (uint32_t)MAXL) len = MAXL;
+        const uint32_t lmax = (uint32_t)MAXL < a.nkp + k - 1 ? (uint32_t)MAXL : a.nkp + k - 1;
+        if (len > lmax) len = lmax;
         const uint64_t a0 = o0 & ~3ull;
         const uint32_t nw = ((uint32_t)(o0 - a0) + len + 3) >> 2;
         rw0 = *reinterpret_cast<const uint32_t*>(a.seq + ((uint32_t)lane < nw ? a0 + 4ull * lane : 0ull));
@@ -1368,7 +1369,9 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         DBTK_STAMP(43);  // loop / extras of the previous row
         const uint64_t o0 = o0C, o1 = o1C;
         uint32_t len = (uint32_t)(o1 - o0);
-        if (len > (uint32_t)MAXL) { *a.errflag = DBTK_ERR_READ_TOO_LONG; len = MAXL; }  // stay inside LDS
+        // stay inside LDS and inside the row of the hit buffers (sized from the caller's max_read_len: a longer read breaks the contract)
+        const uint32_t lmax = (uint32_t)MAXL < a.nkp + k - 1 ? (uint32_t)MAXL : a.nkp + k - 1;
+        if (len > lmax) { *a.errflag = DBTK_ERR_READ_TOO_LONG; len = lmax; }
         const uint64_t a0 = o0 & ~3ull;
         const uint32_t rsh = (uint32_t)(o0 - a0), nw = (rsh + len + 3) >> 2;
         x.sync();  // previous read's LDS is dead

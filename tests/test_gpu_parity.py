@@ -355,3 +355,33 @@ def test_randomised_parity_soak():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "16", "900"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+def test_device_entry_reports_a_read_longer_than_promised(dbtk, tmp_path):
+    """dbtk_align_batch_device trusts max_read_len (it sizes the rows of the hit buffers).  A longer read must not write past its
+    row: the probe kernel clamps it and raises the sticky error word, which dbtk_ctx_synchronize reports once — also when
+    further batches ran in between."""
+    c = make_case("mixed", str(tmp_path))
+    g = dbtk.load(c.prefix, c.k, c.qc_file)
+    seq, off = c.reads.packed()
+    p = abi.default_params(ksize=c.k, **dict(c.param_sets[0], okam=0))
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    d_seq, d_off = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_seq), len(seq) + 64) == 0 and hip.hipMalloc(C.byref(d_off), off.nbytes) == 0
+    assert hip.hipMemcpy(d_seq, seq.ctypes.data_as(C.c_void_p), len(seq), 1) == 0
+    assert hip.hipMemcpy(d_off, off.ctypes.data_as(C.c_void_p), off.nbytes, 1) == 0
+    maxlen = int(np.diff(off.astype(np.int64)).max())
+    ctx = dbtk.context(g, p)
+    ctx.align_device(d_seq.value, d_off.value, c.reads.npairs, 100)      # the reads are 150 bases
+    for _ in range(3):
+        ctx.align_device(d_seq.value, d_off.value, c.reads.npairs, maxlen)
+    with pytest.raises(bind.pkg.DbtkError) as e:
+        ctx.synchronize()
+    assert e.value.status == abi.ERR_READ_TOO_LONG
+    ctx.synchronize()  # reported once
+    ctx.close()
+    hip.hipFree(d_seq); hip.hipFree(d_off)
+    g.close()
