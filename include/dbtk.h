@@ -194,7 +194,11 @@ dbtk_status_t dbtk_align_batch(dbtk_ctx_t* ctx, const uint8_t* seq_bytes,
  * pointers with the same meaning, max_read_len the longest read in the batch.
  * d_seq must be 16-byte aligned and readable up to the end of the last read
  * rounded up to a multiple of 16 (any hipMalloc'd buffer is).  Asynchronous on
- * the context's stream; records are not produced. */
+ * the context's streams (successive batches go round DBTK_LANES of them);
+ * records are not produced.  A read longer than max_read_len (or than
+ * DBTK_MAX_READ_LEN) is not validated on the host here: the device truncates it
+ * to what was promised and raises an error word that the next
+ * dbtk_ctx_synchronize returns, once, as DBTK_ERR_READ_TOO_LONG. */
 dbtk_status_t dbtk_align_batch_device(dbtk_ctx_t* ctx, const void* d_seq, const void* d_offsets,
                                       uint64_t npairs, uint32_t max_read_len);
 dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* ctx);
