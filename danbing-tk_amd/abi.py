@@ -4,7 +4,9 @@ import ctypes as C
 MAX_READ_LEN = 256
 NAN64 = 0xFFFFFFFFFFFFFFFF
 NAN32 = 0xFFFFFFFF
-ABI_VERSION = 1
+ABI_VERSION = 2
+THREAD_CAP = 384
+THREADING_HEAD, THREADING_V13 = 1, 2
 
 (OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NO_DEVICE, ERR_HIP, ERR_READ_TOO_LONG, ERR_NOMEM, ERR_UNSUPPORTED,
  ERR_OVERFLOW) = range(10)
@@ -26,7 +28,7 @@ u8p = C.POINTER(C.c_uint8)
 class Params(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in
                 ("ksize", "n_filter", "nm_filter", "cthreshold", "nm_tr", "max_nt", "qth", "okam", "qc", "bait",
-                 "bubbles", "extract", "trace", "threading", "simmode")] + [("reserved", C.c_uint32 * 4), ("trackbait", C.c_uint32)]
+                 "bubbles", "extract", "trace", "threading", "simmode", "thread_cth", "maxncorrection", "correction", "aln", "trackbait", "diag")]
 
 
 class RpggArrays(C.Structure):
@@ -39,6 +41,7 @@ class RpggArrays(C.Structure):
         ("tr_cnt", u64p), ("tr_ks", u64p),
         ("qc", u8p),
         ("bt_cnt", u64p), ("bt_ks", u64p), ("bt_vs", u16p),
+        ("gr_cnt", u64p), ("gr_ks", u64p), ("gr_ms", u8p),
     ]
 
 
@@ -57,9 +60,18 @@ class PairRec(C.Structure):
                 ("nm1", C.c_int32), ("nm2", C.c_int32), ("r1", MateRec), ("r2", MateRec)]
 
 
+class ThreadRec(C.Structure):
+    """What isThreadFeasible leaves behind for one read (include/dbtk.h: dbtk_thread_rec_t)."""
+    _fields_ = [("ret", C.c_int32), ("ni", C.c_int32), ("nkm", C.c_uint32), ("nes", C.c_uint32), ("ntr", C.c_uint32),
+                ("flags", C.c_uint32),
+                ("es_t", C.c_uint8 * THREAD_CAP), ("es_r", C.c_uint8 * THREAD_CAP), ("es_g", C.c_uint8 * THREAD_CAP),
+                ("tr", C.c_uint8 * THREAD_CAP), ("kmers", C.c_uint64 * THREAD_CAP)]
+
+
 def default_params(**kw) -> Params:
     """Defaults of the reference: src/aQueryFasta_thread.cpp:26-34, 2336-2339."""
-    p = Params(ksize=21, n_filter=4, nm_filter=1, cthreshold=10, nm_tr=40, max_nt=2, qth=20, okam=1)
+    p = Params(ksize=21, n_filter=4, nm_filter=1, cthreshold=10, nm_tr=40, max_nt=2, qth=20, okam=1, thread_cth=100,
+               maxncorrection=4)
     for k, v in kw.items():
         setattr(p, k, v)
     return p

@@ -361,7 +361,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     auto fetch = [&](uint64_t p0, uint32_t np, uint64_t A0) {
         const bool inb = A0 + 16 <= a.seq_len;
 #ifdef DBTK_STAMPS
-        const uint8_t* base = a.seq + ((inb && !(a.P.reserved[0] & 2)) ? A0 : 0ull);  // (knob 2: no streaming traffic)
+        const uint8_t* base = a.seq + ((inb && !(a.P.diag & 2)) ? A0 : 0ull);  // (knob 2: no streaming traffic)
 #else
         const uint8_t* base = a.seq + (inb ? A0 : 0ull);
 #endif
@@ -511,7 +511,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                     km = clean ? window_kmer_clean(sm.pk, bpos + pos, k) : window_kmer(sm.pk, sm.vd, bpos + pos, k, nullptr, nullptr);
                 }
 #ifdef DBTK_STAMPS
-                if (a.P.reserved[0] & 1) km = NAN64;  // diagnostic: no queries
+                if (a.P.diag & 1) km = NAN64;  // diagnostic: no queries
 #endif
                 const uint64_t m = kmix(km & ((1ull << (2 * k)) - 1), k);
                 bin_push(km != NAN64, (uint32_t)(m >> sh), (m & ((1ull << sh) - 1)) | ((uint64_t)(p0 + grp) << sh));
@@ -534,7 +534,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                         km = clean ? window_kmer_clean(sm.pk, bpos + pos, k) : window_kmer(sm.pk, sm.vd, bpos + pos, k, nullptr, nullptr);
                     }
 #ifdef DBTK_STAMPS
-                    if (a.P.reserved[0] & 1) km = NAN64;  // diagnostic: no probes
+                    if (a.P.diag & 1) km = NAN64;  // diagnostic: no probes
 #endif
                     const uint64_t hmix = hash_mix(km);
                     if (a.T.flt && km != NAN64) {  // presence filter: "no" is final, and needs no HBM line
@@ -1481,7 +1481,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                 kq[u] = sm.km[ic]; bq[u] = sm.hb[ic];
                 if (ii[u] >= nk) { kq[u] = NAN64; bq[u] = 0; }
 #ifdef DBTK_STAMPS
-                if (a.P.reserved[0] & 64) bq[u] &= 1023;  // diagnostic: every look-up in the first 64 KB of the table (cache hits)
+                if (a.P.diag & 64) bq[u] &= 1023;  // diagnostic: every look-up in the first 64 KB of the table (cache hits)
 #endif
                 bucket_part(T.idx, bq[u], sub, &a0[u], &a1[u]);  // (bq = 0 for a position without a k-mer)
             }
@@ -1692,7 +1692,7 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
     for (; t < tlim; t += stride) {
         DBTK_STAMP(39);  // loop overhead / record of the previous pair
 #ifdef DBTK_STAMPS
-        if (!(a.P.reserved[0] & 8))  // diagnostic: no loads after the first pair (every pair re-resolves the same data)
+        if (!(a.P.diag & 8))  // diagnostic: no loads after the first pair (every pair re-resolves the same data)
 #endif
         request(t + stride < tlim ? t + stride : t);  // (past the end: a harmless reload, so that the loads stay straight-line)
         const uint32_t pair_cur = pair;
@@ -1796,14 +1796,14 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
         }
         if (stage == DBTK_STAGE_COUNTED) {
 #ifdef DBTK_STAMPS
-            if (!(a.P.reserved[0] & 16))  // diagnostic: no per-locus atomics
+            if (!(a.P.diag & 16))  // diagnostic: no per-locus atomics
 #endif
             if (lane == 0) {
                 x.atomic_add(&a.nmapread[dst], (uint64_t)(2 - rm[0] - rm[1]));
                 x.atomic_add(&a.kmc[dst], (uint64_t)(int64_t)((ms[0].ei - ms[0].si) + (ms[1].ei - ms[1].si)));
             }
 #ifdef DBTK_STAMPS
-            if (a.P.reserved[0] & 4) win = 0;  // diagnostic: no count atomics
+            if (a.P.diag & 4) win = 0;  // diagnostic: no count atomics
 #endif
             for (uint32_t i = lane; i < win; i += 64) {
                 const uint32_t v = (sm.hist[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DBTK_ABI_VERSION 1u
+#define DBTK_ABI_VERSION 2u
 
 /* Reads longer than this are rejected (DBTK_ERR_READ_TOO_LONG).  The
  * reference's per-read k-mer multiplicity is a uint8_t pair (`PE_KMC`,
@@ -67,12 +67,20 @@ typedef struct dbtk_params {
     uint32_t bubbles;      /* -bu        count novel (k+1)-mers; needs PREF.tre.kdb; host-buffer batches only */
     uint32_t extract;      /* -e 1|2     extract mode: locus assignment only */
     uint32_t trace;        /* test hook: emit a record for EVERY pair, not only kam ones */
-    uint32_t threading;    /* -g/-gc/-gcc: accepted like the reference; at HEAD its call sites are commented out
-                              (AQ.cpp:2072-2088), so assigned pairs are only counted as "entered threading" */
+    uint32_t threading;    /* 0 off.  1 = -g/-gc/-gcc as the mounted HEAD runs them: the call sites are commented out
+                              (AQ.cpp:2072-2088), so assigned pairs are only counted as "entered threading".
+                              2 = the v1.3 contract those comments spell out (DBTK_THREADING_V13, CLI: --v13-threading):
+                              both mates are walked through graphDB[destLocus] with isThreadFeasible (AQ.cpp:1114-1260),
+                              the pair is kept if either walk is feasible, TR k-mers are counted in "exact" mode
+                              (AQ.cpp:2072-2088, 2189-2194); needs the graph in the RPGG handle (DBTK_LOAD_GRAPH) */
     uint32_t simmode;      /* -s 1|2: also emit records of pairs whose two mates assignTRkmc rejected (AQ.cpp:2169) */
-    uint32_t reserved[4];
+    uint32_t thread_cth;   /* -g/-gc/-gcc N [100]  minimal number of walked k-mers per read (AQ.cpp:2338, 1122) */
+    uint32_t maxncorrection; /* -gc/-gcc N M [4]   corrections allowed per read (AQ.cpp:33) */
+    uint32_t correction;   /* -gc/-gcc: error correction on (plain -g walks without it) */
+    uint32_t aln;          /* 0; 1 = -a: an alignment record for every walked pair; 2 = -ae: only for kept pairs (AQ.cpp:2232-2248) */
     uint32_t trackbait;    /* -tb: per locus, count the bait k-mer that made bfilter_FPSv1 flag a mate (AQ.cpp:1391,1414);
                               with -b, host-buffer batches only; such pairs then also yield records (stage DBTK_STAGE_BAIT) */
+    uint32_t diag;         /* 0.  Diagnostic knobs of the profiling tools (tools/k1_limits.py): results are wrong when set */
 } dbtk_params_t;
 
 /* ---- RPGG in flat (file-equivalent) form ----------------------------------
@@ -84,6 +92,7 @@ typedef struct dbtk_params {
  *                     (k-mers in FILE order, per locus)
  *   qc                -qc FILE         readQCFile           src/kmerIO.hpp:111-120 (0/1 per locus, may be NULL)
  *   bt_*              PREF.bt.kmdb     readBinaryBaitDB     src/aQueryFasta_thread.h:542-547 (may be NULL)
+ *   gr_*              PREF.graph.kmers readGraphKmers       src/aQueryFasta_thread.h:550-575 (may be NULL)
  */
 typedef struct dbtk_rpgg_arrays {
     uint32_t ksize;
@@ -95,10 +104,40 @@ typedef struct dbtk_rpgg_arrays {
     const uint64_t* tr_cnt;  const uint64_t* tr_ks;    /* file order                  */
     const uint8_t*  qc;                                 /* NULL or nloci bytes 0/1     */
     const uint64_t* bt_cnt;  const uint64_t* bt_ks;  const uint16_t* bt_vs; /* NULL or bait DB */
+    /* graphDB (v1.3 threading): per locus the de Bruijn nodes (non-canonical k-mers of both strands) and their
+     * out-edge masks, bit b = successor ((node & rmask) << 2) | b exists (T/G/C/A = bits 3..0).
+     * PREF.graph.kmers (text, readGraphKmers src/aQueryFasta_thread.h:550-575) or PREF.graph.umap (v1.3 binary).
+     * NULL when no graph is loaded. */
+    const uint64_t* gr_cnt;  const uint64_t* gr_ks;  const uint8_t* gr_ms;
 } dbtk_rpgg_arrays_t;
 
 typedef struct dbtk_rpgg dbtk_rpgg_t;
 typedef struct dbtk_ctx  dbtk_ctx_t;
+
+#define DBTK_THREADING_HEAD 1u
+#define DBTK_THREADING_V13  2u
+
+/* ---- graph walk: what isThreadFeasible leaves behind for one read ------------
+ * (src/aQueryFasta_thread.cpp:1114-1260; cigar_t / edit_t at :46-68).  The walk may insert k-mers and
+ * edit operations (deletions), so the arrays have room for DBTK_THREAD_CAP entries:
+ * every inserted k-mer is paid for with >= 5 extended ones (MSC, AQ.cpp:1120), so a read of
+ * DBTK_MAX_READ_LEN bases cannot grow past 5/4 of its size. */
+#define DBTK_THREAD_CAP 384u
+typedef struct dbtk_thread_rec {
+    int32_t  ret;      /* 0 infeasible, 1 feasible, 2 feasible with corrections */
+    int32_t  ni;       /* cg.ni */
+    uint32_t nkm;      /* kmers.size(): the walked (corrected) k-mers, non-canonical, NAN64 where the read had none */
+    uint32_t nes;      /* cg.es.size(): one edit per read base + one per deletion */
+    uint32_t ntr;      /* cg.tr.size(): one annotation per walked k-mer */
+    uint32_t flags;    /* DBTK_THREAD_F_* */
+    uint8_t  es_t[DBTK_THREAD_CAP];  /* edit_t::t  '*' '=' 'X' 'D' 'I' */
+    uint8_t  es_r[DBTK_THREAD_CAP];  /* edit_t::r  read base, 0 for an inserted deletion */
+    uint8_t  es_g[DBTK_THREAD_CAP];  /* edit_t::g  graph base ('A','C','G','T'), 0 when none */
+    uint8_t  tr[DBTK_THREAD_CAP];    /* '*' unaligned, '.' flank, '=' TR */
+    uint64_t kmers[DBTK_THREAD_CAP];
+} dbtk_thread_rec_t;
+#define DBTK_THREAD_F_OVERFLOW 1u    /* the walk outgrew DBTK_THREAD_CAP (never at <= DBTK_MAX_READ_LEN) */
+#define DBTK_THREAD_F_MISSING_NODE 2u /* the reference would assert: a successor named by an edge mask is not in the graph (AQ.cpp:528-532) */
 
 /* ---- per-pair record -------------------------------------------------------
  * Fields of `km_asgn_t` / `km_asgn_read_t` (src/aQueryFasta_thread.cpp:93-144)

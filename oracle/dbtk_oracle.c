@@ -371,6 +371,10 @@ struct orc_rpgg {
     /* baitDB[l] (AQ.h:542-547): k-mers sorted within locus + thresholds */
     uint64_t* bt_beg;
     ki_t* bt;          /* .k = k-mer, .i = (min << 8 | max) */
+    /* graphDB[l] (AQ.h:32, 550-575): nodes sorted within locus + out-edge masks */
+    uint64_t* gr_beg;
+    uint64_t* gr_ks;
+    uint8_t* gr_ms;
 };
 
 static inline uint64_t mix64(uint64_t x) {
@@ -468,6 +472,7 @@ orc_rpgg_t* orc_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a) {
         g->qc = (uint8_t*)malloc(a->nloci + 1);
         memcpy(g->qc, a->qc, a->nloci);
     }
+    if (a->gr_cnt) orc_rpgg_set_graph(g, a->gr_cnt, a->gr_ks, a->gr_ms);
     return g;
 }
 
@@ -576,9 +581,86 @@ int orc_rpgg_load_bait(orc_rpgg_t* g, const char* fn) {
     return 0;
 }
 
+/* graphDB: kmerDB[idx][kmer] |= c (readGraphKmers, AQ.h:550-575): duplicates of a node OR their masks */
+typedef struct { uint64_t k; uint8_t m; } km_t;
+static int cmp_km(const void* a, const void* b) {
+    const km_t* x = (const km_t*)a; const km_t* y = (const km_t*)b;
+    return x->k < y->k ? -1 : x->k > y->k;
+}
+void orc_rpgg_set_graph(orc_rpgg_t* g, const uint64_t* gr_cnt, const uint64_t* gr_ks, const uint8_t* gr_ms) {
+    free(g->gr_beg); free(g->gr_ks); free(g->gr_ms);
+    uint64_t n = 0, mx = 0;
+    for (uint64_t l = 0; l < g->nloci; ++l) { n += gr_cnt[l]; if (gr_cnt[l] > mx) mx = gr_cnt[l]; }
+    g->gr_beg = (uint64_t*)malloc((g->nloci + 1) * 8);
+    g->gr_ks = (uint64_t*)malloc((n + 1) * 8);
+    g->gr_ms = (uint8_t*)malloc(n + 1);
+    km_t* tmp = (km_t*)malloc((mx + 1) * sizeof(km_t));
+    uint64_t src = 0, dst = 0;
+    for (uint64_t l = 0; l < g->nloci; ++l) {
+        const uint64_t c = gr_cnt[l];
+        for (uint64_t i = 0; i < c; ++i) { tmp[i].k = gr_ks[src + i]; tmp[i].m = gr_ms[src + i]; }
+        qsort(tmp, (size_t)c, sizeof(km_t), cmp_km);
+        g->gr_beg[l] = dst;
+        for (uint64_t i = 0; i < c; ++i) {
+            if (dst > g->gr_beg[l] && g->gr_ks[dst - 1] == tmp[i].k) g->gr_ms[dst - 1] |= tmp[i].m;
+            else { g->gr_ks[dst] = tmp[i].k; g->gr_ms[dst] = tmp[i].m; ++dst; }
+        }
+        src += c;
+    }
+    g->gr_beg[g->nloci] = dst;
+    free(tmp);
+}
+/* PREF.graph.kmers (text, AQ.h:550-575) or, when the name ends in ".umap", the v1.3 binary
+ * `u64 nloci | per locus: u64 n | n x (u64 node, u8 mask)`. */
+int orc_rpgg_load_graph(orc_rpgg_t* g, const char* fn) {
+    const size_t fl = strlen(fn);
+    const int binary = fl > 5 && strcmp(fn + fl - 5, ".umap") == 0;
+    FILE* f = fopen(fn, binary ? "rb" : "r");
+    if (!f) return -1;
+    uint64_t* cnt = (uint64_t*)calloc(g->nloci + 1, 8);
+    uint64_t cap = 1 << 16, n = 0;
+    uint64_t* ks = (uint64_t*)malloc(cap * 8);
+    uint8_t* ms = (uint8_t*)malloc(cap);
+    int rc = 0;
+#define GR_PUSH(K, M) do { if (n == cap) { cap *= 2; ks = (uint64_t*)realloc(ks, cap * 8); ms = (uint8_t*)realloc(ms, cap); } ks[n] = (K); ms[n] = (M); ++n; } while (0)
+    if (binary) {
+        uint64_t nl;
+        if (fread(&nl, 8, 1, f) != 1 || nl != g->nloci) rc = -1;
+        for (uint64_t l = 0; !rc && l < nl; ++l) {
+            uint64_t c;
+            if (fread(&c, 8, 1, f) != 1) { rc = -1; break; }
+            cnt[l] = c;
+            for (uint64_t i = 0; i < c; ++i) {
+                uint64_t node; uint8_t m;
+                if (fread(&node, 8, 1, f) != 1 || fread(&m, 1, 1, f) != 1) { rc = -1; break; }
+                GR_PUSH(node, m);
+            }
+        }
+    } else {
+        char line[256];
+        int64_t l = -1;
+        while (fgets(line, sizeof line, f)) {
+            if (line[0] == '>') { ++l; continue; }
+            if (l < 0 || (uint64_t)l >= g->nloci) { rc = -1; break; }
+            char* tab = NULL;
+            const uint64_t node = strtoull(line, &tab, 10);
+            const uint64_t m = (tab && *tab == '\t') ? strtoull(tab + 1, NULL, 10) : 0;
+            GR_PUSH(node, (uint8_t)m);
+            ++cnt[l];
+        }
+    }
+#undef GR_PUSH
+    fclose(f);
+    if (!rc) orc_rpgg_set_graph(g, cnt, ks, ms);
+    free(cnt); free(ks); free(ms);
+    return rc;
+}
+int orc_rpgg_has_graph(const orc_rpgg_t* g) { return g->gr_beg != NULL; }
+
 void orc_rpgg_free(orc_rpgg_t* g) {
     if (!g) return;
     free(g->bt_beg); free(g->bt);
+    free(g->gr_beg); free(g->gr_ks); free(g->gr_ms);
     free(g->hkeys); free(g->hvals); free(g->vv); free(g->fl_beg); free(g->fl_ks); free(g->tr_beg);
     free(g->tr_cnt); free(g->tr_ks_file); free(g->tr_ks); free(g->tr_fi); free(g->tre_beg); free(g->tre_ks); free(g->qc);
     free(g);
@@ -603,6 +685,8 @@ static inline int64_t tr_find(const orc_rpgg_t* g, uint64_t locus, uint64_t km) 
     }
     return -1;
 }
+
+#include "dbtk_oracle_walk.c" /* the graph walk (isThreadFeasible & co.), same translation unit */
 
 /* -------------------------------------------------------------- hot path */
 typedef struct { uint64_t key; uint32_t val; } hit_t; /* what an index iterator dereferences to */

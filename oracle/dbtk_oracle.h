@@ -57,6 +57,20 @@ int  orc_rpgg_load_bait(orc_rpgg_t* g, const char* bait_file);
 /* qString2qMask, AQ.h:1038-1071: mask[i] = 1 iff k-mer i passes (mask has nq-k+1 bytes, pre-zeroed by the callee). */
 void orc_qstring2qmask(const uint8_t* qual, int nq, int qth, int ksize, uint8_t* mask);
 
+/* graphDB for the v1.3 threading path: PREF.graph.kmers (text) or PREF.graph.umap (v1.3 binary). */
+void orc_rpgg_set_graph(orc_rpgg_t* g, const uint64_t* gr_cnt, const uint64_t* gr_ks, const uint8_t* gr_ms);
+int  orc_rpgg_load_graph(orc_rpgg_t* g, const char* graph_file);
+int  orc_rpgg_has_graph(const orc_rpgg_t* g);
+/* isThreadFeasible (AQ.cpp:1114-1260) after cigar_t::init, for one read against graphDB[locus] / trKmers[locus].
+ * Returns 0 / 1 / 2 like the reference, -1 where the reference would assert (flags in out).  out and
+ * noncakmers (>= len entries: the uncorrected k-mers of read2kmers(canonical=false, keepN=true)) may be NULL. */
+int  orc_thread(const orc_rpgg_t* g, uint64_t locus, const uint8_t* seq, uint64_t len, uint32_t k, uint32_t thread_cth,
+                int correction, uint32_t maxncorrection, dbtk_thread_rec_t* out, uint64_t* noncakmers);
+uint64_t orc_read2kmers_nonca(const uint8_t* read, uint64_t rlen, uint32_t k, uint64_t* kmers); /* AQ.h:246-271 */
+/* writeCigar / writeAnnot (AQ.cpp:1683-1740) into buf; return the length the text needs. */
+size_t orc_write_cigar(const dbtk_thread_rec_t* r, char* buf, size_t cap);
+size_t orc_write_annot(const dbtk_thread_rec_t* r, char* buf, size_t cap);
+
 /* Function-level restatements (for pinning against the reference harness). */
 uint64_t orc_nurc(uint64_t kmer, uint32_t k);                               /* getNuRC  AQ.h:165-178 */
 uint64_t orc_read2kmers_edges(const uint8_t* read, uint64_t rlen, uint32_t k,

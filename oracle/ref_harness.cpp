@@ -19,7 +19,36 @@
 
 #include "../include/dbtk.h"
 
+#include <setjmp.h>
+#include <signal.h>
+
 namespace {
+/* The reference asserts (abort) on an unclean graph (AQ.cpp:528-532) and inside threadCheck; the harness turns
+ * such an abort into a return code instead of losing the test process. */
+sigjmp_buf g_abort_env;
+volatile sig_atomic_t g_abort_armed = 0;
+void on_abort(int) { if (g_abort_armed) { g_abort_armed = 0; siglongjmp(g_abort_env, 1); } }
+struct AbortTrap {
+    struct sigaction old;
+    AbortTrap() { struct sigaction sa; memset(&sa, 0, sizeof(sa)); sa.sa_handler = on_abort; sa.sa_flags = SA_NODEFER; sigaction(SIGABRT, &sa, &old); }
+    ~AbortTrap() { g_abort_armed = 0; sigaction(SIGABRT, &old, nullptr); }
+};
+/* std::cout captured while writeCigar / writeAnnot / writeAlignments run (they print, AQ.cpp:1683-1759) */
+struct CoutCapture {
+    std::ostringstream ss; std::streambuf* old;
+    CoutCapture() { old = std::cout.rdbuf(ss.rdbuf()); }
+    ~CoutCapture() { std::cout.rdbuf(old); }
+};
+void fill_thread_rec(dbtk_thread_rec_t* o, int ret, cigar_t& cg, vector<uint64_t>& kmers) {
+    memset(o, 0, sizeof(*o));
+    o->ret = ret; o->ni = cg.ni;
+    o->nkm = kmers.size(); o->nes = cg.es.size(); o->ntr = cg.tr.size();
+    if (o->nkm > DBTK_THREAD_CAP || o->nes > DBTK_THREAD_CAP || o->ntr > DBTK_THREAD_CAP) { o->flags |= DBTK_THREAD_F_OVERFLOW; }
+    for (size_t i = 0; i < kmers.size() && i < DBTK_THREAD_CAP; ++i) o->kmers[i] = kmers[i];
+    for (size_t i = 0; i < cg.es.size() && i < DBTK_THREAD_CAP; ++i) { o->es_t[i] = cg.es[i].t; o->es_r[i] = cg.es[i].r; o->es_g[i] = cg.es[i].g; }
+    for (size_t i = 0; i < cg.tr.size() && i < DBTK_THREAD_CAP; ++i) o->tr[i] = cg.tr[i];
+}
+
 struct RefDB {
     uint64_t nloci = 0;
     kmerIndex_uint32_umap kmerDBi;
@@ -32,6 +61,7 @@ struct RefDB {
     vector<unordered_map<uint64_t, uint64_t>> fileIndex;
     uint64_t ntr = 0;
     bait_fps_db_t baitDB;
+    vector<GraphType> graphDB;   /* readGraphKmers(PREF.graph.kmers), AQ.h:550-575 */
 };
 struct BubEvent { uint32_t pair, mate, pos, locus; uint64_t edge; };  // == orc_bub_event_t
 
@@ -118,6 +148,62 @@ void* ref_db_load(const char* prefix, const char* qc_file) {
     return db;
 }
 void ref_db_free(void* h) { delete (RefDB*)h; }
+/* graph loader of the v1.3 contract: readGraphKmers (src/aQueryFasta_thread.h:550-575) on PREF.graph.kmers */
+void ref_db_load_graph(void* h, const char* graph_kmers_file) {
+    RefDB* db = (RefDB*)h;
+    db->graphDB = vector<GraphType>(db->nloci);
+    std::streambuf* old = std::cerr.rdbuf(nullptr);
+    readGraphKmers(db->graphDB, string(graph_kmers_file));
+    std::cerr.rdbuf(old);
+    std::cerr.clear();
+}
+void ref_set_thread_params(uint64_t maxncorr, int verb) { maxncorrection = maxncorr; verbosity = verb; }
+
+/* isThreadFeasible (src/aQueryFasta_thread.cpp:1114-1260) for one read against graphDB[locus] / trKmerDB[locus],
+ * called the way the v1.3 call site does (AQ.cpp:2072-2075): cigar_t::init, then the walk; tc = also threadCheck
+ * (AQ.cpp:1276-1342, -gcc) when the walk is feasible.  Returns the walk's code, or -1 if the reference aborted
+ * (assert).  cigar/annot receive what writeCigar(cg.es) / writeAnnot(cg.tr) print (AQ.cpp:1683-1740), NUL-terminated;
+ * *flagged = threadCheck wrote a "[!]" line; noncak[nk] = the uncorrected k-mers (read2kmers keepN). */
+int ref_thread(void* h, uint32_t locus, const char* s, uint64_t len, uint32_t thread_cth, int correction, int tc,
+               dbtk_thread_rec_t* out, uint64_t* noncak, char* cigar, char* annot, uint64_t strcap, int* flagged) {
+    RefDB& db = *(RefDB*)h;
+    AbortTrap trap;
+    string seq(s, len);
+    vector<uint64_t> noncakmers, akmers;
+    cigar_t cg;
+    log_t log;
+    int ret = -1;
+    if (flagged) *flagged = 0;
+    std::streambuf* olderr = std::cerr.rdbuf(nullptr);
+    g_abort_armed = 1;
+    if (sigsetjmp(g_abort_env, 1) == 0) {
+        cg.init(seq);
+        ret = isThreadFeasible(db.graphDB[locus], seq, noncakmers, akmers, thread_cth, correction != 0, cg, db.trKmerDB[locus], log);
+        if (out) fill_thread_rec(out, ret, cg, akmers);
+        if (noncak) for (size_t i = 0; i < noncakmers.size(); ++i) noncak[i] = noncakmers[i];
+        if (cigar) {
+            CoutCapture cap;
+            writeCigar(cg.es);
+            snprintf(cigar, strcap, "%s", cap.ss.str().c_str());
+        }
+        if (annot) {
+            CoutCapture cap;
+            writeAnnot(cg.tr);
+            snprintf(annot, strcap, "%s", cap.ss.str().c_str());
+        }
+        if (tc && ret) {
+            threadCheck(db.graphDB[locus], seq, akmers, cg, log);
+            if (flagged && log.m.str().find("[!]") != string::npos) *flagged = 1;
+        }
+        g_abort_armed = 0;
+    } else {
+        ret = -1;
+        if (out) { out->ret = -1; }
+    }
+    std::cerr.rdbuf(olderr);
+    std::cerr.clear();
+    return ret;
+}
 /* readBinaryBaitDB reads PREF.bt.kmdb (src/aQueryFasta_thread.h:542-547) */
 void ref_db_load_bait(void* h, const char* prefix) { readBinaryBaitDB(((RefDB*)h)->baitDB, string(prefix)); }
 void ref_qstring2qmask(const char* qual, int nq, int qth_, int k, uint8_t* mask) {

@@ -28,7 +28,7 @@ def main():
     d_off = torch.from_numpy(off.view(np.int64)).to("cuda:0")
     for name, knob in (("full", 0), ("no probes", 1), ("no streaming", 2), ("neither", 3)):
         prm = abi.default_params(cthreshold=45, okam=0, n_filter=4, nm_filter=1)
-        prm.reserved[0] = knob
+        prm.diag = knob
         ctx = lib.context(g, prm)
         for _ in range(2):
             ctx.align_device(d_seq.data_ptr(), d_off.data_ptr(), npairs, 150)

@@ -29,7 +29,7 @@ def main():
     lib._chk(lib.L.dbtk_rpgg_from_arrays(C.byref(a), C.byref(h)))
     g = pkg.Rpgg(lib, h)
     p = abi.default_params(cthreshold=45, okam=0)
-    p.reserved[0] = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # diagnostic knobs of the stamps build
+    p.diag = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # diagnostic knobs of the stamps build
     ctx = lib.context(g, p)
     seq, off = syn.reads(npairs, hit_frac=hit)
     for _ in range(3):
