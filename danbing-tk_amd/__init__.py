@@ -101,14 +101,17 @@ class _HostSide:
         """`ktools serialize PREF`: text k-mer files -> PREF.kmers.dbi / .fl.kdb / .tre.kdb."""
         self._chk(self.L.dbtk_rpgg_serialize(prefix.encode()))
 
-    def from_arrays(self, k, keys, vals, vv, fl_cnt, fl_ks, tr_cnt, tr_ks, tre_cnt=None, tre_ks=None, qc=None) -> Rpgg:
+    def from_arrays(self, k, keys, vals, vv, fl_cnt, fl_ks, tr_cnt, tr_ks, tre_cnt=None, tre_ks=None, qc=None, gr_cnt=None, gr_ks=None,
+                    gr_ms=None) -> Rpgg:
         keep = [np.ascontiguousarray(x, t) if x is not None else None for x, t in
                 ((keys, np.uint64), (vals, np.uint32), (vv, np.uint32), (fl_cnt, np.uint64), (fl_ks, np.uint64),
-                 (tre_cnt, np.uint64), (tre_ks, np.uint64), (tr_cnt, np.uint64), (tr_ks, np.uint64), (qc, np.uint8))]
+                 (tre_cnt, np.uint64), (tre_ks, np.uint64), (tr_cnt, np.uint64), (tr_ks, np.uint64), (qc, np.uint8),
+                 (gr_cnt, np.uint64), (gr_ks, np.uint64), (gr_ms, np.uint8))]
         a = abi.RpggArrays(ksize=k, nloci=len(keep[7]), nkeys=len(keep[0]), keys=_ptr(keep[0], u64p), vals=_ptr(keep[1], u32p),
                            nvv=len(keep[2]), vv=_ptr(keep[2], u32p), fl_cnt=_ptr(keep[3], u64p), fl_ks=_ptr(keep[4], u64p),
                            tre_cnt=_ptr(keep[5], u64p), tre_ks=_ptr(keep[6], u64p), tr_cnt=_ptr(keep[7], u64p),
-                           tr_ks=_ptr(keep[8], u64p), qc=_ptr(keep[9], u8p))
+                           tr_ks=_ptr(keep[8], u64p), qc=_ptr(keep[9], u8p), gr_cnt=_ptr(keep[10], u64p),
+                           gr_ks=_ptr(keep[11], u64p), gr_ms=_ptr(keep[12], u8p))
         h = C.c_void_p()
         self._chk(self.L.dbtk_rpgg_from_arrays(C.byref(a), C.byref(h)))
         return Rpgg(self, h)
@@ -139,6 +142,25 @@ class Context:
         self._lib._chk(L.dbtk_align_batch(self.h, seqp, _ptr(off, u64p), _ptr(qual, u8p), npairs, recs, cap if recs else 0,
                                           C.byref(nrec)))
         return recs, int(nrec.value)
+
+    def thread(self, seq, off, loci):
+        """dbtk_thread_batch: read r walked through graphDB[loci[r]]; returns a ctypes array of abi.ThreadRec."""
+        off = np.ascontiguousarray(off, np.uint64)
+        seq = np.ascontiguousarray(seq, np.uint8)
+        loci = np.ascontiguousarray(loci, np.uint32)
+        n = len(off) - 1
+        recs = (abi.ThreadRec * max(n, 1))()
+        self._lib._chk(self._lib.L.dbtk_thread_batch(self.h, _ptr(seq if seq.size else np.zeros(1, np.uint8), u8p), _ptr(off, u64p),
+                                                     _ptr(loci, u32p), n, recs))
+        return recs
+
+    def walk_results(self, cap, with_recs=False):
+        """dbtk_ctx_walk_results of the last align(): (WalkRes array, ThreadRec array or None, n)."""
+        res = (abi.WalkRes * max(cap, 1))()
+        trecs = (abi.ThreadRec * max(2 * cap, 1))() if with_recs else None
+        n = C.c_uint64(0)
+        self._lib._chk(self._lib.L.dbtk_ctx_walk_results(self.h, res, trecs, cap, C.byref(n)))
+        return res, trecs, int(n.value)
 
     def align_device(self, d_seq_ptr, d_off_ptr, npairs, max_read_len):
         self._lib._chk(self._lib.L.dbtk_align_batch_device(self.h, C.c_void_p(d_seq_ptr), C.c_void_p(d_off_ptr), npairs,
@@ -211,6 +233,10 @@ class Dbtk(_HostSide):
         L.dbtk_ctx_free.argtypes = [C.c_void_p]
         L.dbtk_align_batch.restype = C.c_int
         L.dbtk_align_batch.argtypes = [C.c_void_p, u8p, u64p, u8p, C.c_uint64, C.POINTER(abi.PairRec), C.c_uint64, u64p]
+        L.dbtk_thread_batch.restype = C.c_int
+        L.dbtk_thread_batch.argtypes = [C.c_void_p, u8p, u64p, u32p, C.c_uint64, C.POINTER(abi.ThreadRec)]
+        L.dbtk_ctx_walk_results.restype = C.c_int
+        L.dbtk_ctx_walk_results.argtypes = [C.c_void_p, C.POINTER(abi.WalkRes), C.POINTER(abi.ThreadRec), C.c_uint64, u64p]
         L.dbtk_align_batch_device.restype = C.c_int
         L.dbtk_align_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
         L.dbtk_ctx_synchronize.restype = C.c_int
@@ -252,6 +278,7 @@ EXPORTS = [
     "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
     "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
+    "dbtk_thread_batch", "dbtk_ctx_walk_results",
 ]
 
 

@@ -68,6 +68,13 @@ class ThreadRec(C.Structure):
                 ("tr", C.c_uint8 * THREAD_CAP), ("kmers", C.c_uint64 * THREAD_CAP)]
 
 
+class WalkRes(C.Structure):
+    _fields_ = [("pair", C.c_uint32), ("dst", C.c_uint32), ("ret1", C.c_int8), ("ret2", C.c_int8), ("pad", C.c_uint8 * 2)]
+
+
+LOAD_INDEX_ONLY, LOAD_GRAPH = 1, 2
+
+
 def default_params(**kw) -> Params:
     """Defaults of the reference: src/aQueryFasta_thread.cpp:26-34, 2336-2339."""
     p = Params(ksize=21, n_filter=4, nm_filter=1, cthreshold=10, nm_tr=40, max_nt=2, qth=20, okam=1, thread_cth=100,

@@ -154,6 +154,19 @@ template <int NS, bool RECS> __global__ void __launch_bounds__(64, NS <= 3 ? 2 :
     body_pair<NS, RECS>(x, a);
 }
 
+__global__ void __launch_bounds__(256) k_gr_insert(GrBuildArgs a) { DevX x{nullptr}; body_gr_insert(x, a); }
+// the graph walk (dbtk_walk.h): one wave per read (function mode) / per pair (the hot path with threading = 2)
+__global__ void __launch_bounds__(64) k_walk_reads(WalkArgs a) {
+    __shared__ __attribute__((aligned(16))) WalkSmem sm;
+    DevX x{&sm};
+    body_walk_reads(x, a);
+}
+__global__ void __launch_bounds__(64) k_walk_pairs(WalkArgs a) {
+    __shared__ __attribute__((aligned(16))) WalkSmem sm;
+    DevX x{&sm};
+    body_walk_pairs(x, a);
+}
+
 // ---------------------------------------------------------------- context --
 #define HIPCHK(call)                                                                                  \
     do {                                                                                              \
@@ -168,7 +181,7 @@ namespace {
 // Per-kernel timing: a pool of HIP event pairs recorded on the context's stream
 // around every launch; folded into (total ms, launches) when the pool fills or
 // when the caller asks.
-constexpr int NKERN = 7;       // k_encode_subfilter (the whole encode stage), k_probe, k_pair_usual, k_pair; the three kernels of the binned encode stage
+constexpr int NKERN = 8;       // k_encode_subfilter (the whole encode stage), k_probe, k_pair_usual, k_pair; the three kernels of the binned encode stage; k_walk_pairs
 constexpr int EVPOOL = 128;    // launches in flight before a fold
 struct Timed {
     const char* name;
@@ -199,6 +212,7 @@ struct dbtk_ctx {
     uint64_t* d_flt = nullptr; uint64_t flt_words = 0;
     uint32_t* d_trbeg = nullptr;
     ClsSlot* d_cls = nullptr;
+    GrSlot* d_gr = nullptr;       // graph table (threading = 2), nullptr when the handle holds no graph
     uint32_t* d_vv = nullptr;
     uint8_t* d_qc = nullptr;
     uint16_t* d_perm = nullptr;
@@ -216,6 +230,11 @@ struct dbtk_ctx {
     uint64_t* d_hitoff = nullptr; uint64_t hitoff_cap = 0;
     uint32_t* d_gen = nullptr; uint64_t gen_cap = 0;        // K3a -> K3b
     uint32_t* d_tickets = nullptr; uint64_t tickets_cap = 0;
+    uint32_t* d_walk = nullptr; uint64_t walk_cap = 0;       // threading = 2, per survivor: destLocus [cap], then the walk's return codes [cap]
+    dbtk_thread_rec_t* d_trecs = nullptr; uint64_t trecs_cap = 0;  // thread records (function mode; pair mode with trace / -a)
+    uint32_t* d_loci = nullptr; uint64_t loci_cap = 0;       // function mode: locus per read
+    uint64_t last_walk_npairs = 0; bool last_walk_recs = false;  // what dbtk_ctx_walk_results may fetch
+    int walk_blocks = 0;
     // optional gates
     ClsSlot* d_tre = nullptr; ClsSlot* d_bait = nullptr;
     uint8_t* d_qual = nullptr; uint64_t qual_cap = 0;
@@ -254,6 +273,7 @@ struct dbtk_ctx {
         uint64_t* d_hitoff = nullptr; uint64_t hitoff_cap = 0;
         uint32_t* d_gen = nullptr; uint64_t gen_cap = 0;
         uint32_t* d_tickets = nullptr; uint64_t tickets_cap = 0;
+        uint32_t* d_walk = nullptr; uint64_t walk_cap = 0;
         uint64_t* d_vote = nullptr;
         uint32_t* d_epoch = nullptr;
         BinScratch bin;
@@ -281,13 +301,13 @@ void free_ctx(dbtk_ctx* c) {
         }
     void* ptrs[] = {c->d_flt, c->d_ctr, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
-                    c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents};
+                    c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_gr, c->d_walk, c->d_trecs, c->d_loci};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     std::vector<dbtk_ctx::Lane*> others{&c->alt};
     for (auto& l : c->parked) others.push_back(&l);
     std::vector<BinScratch*> bins{&c->bin};
     for (dbtk_ctx::Lane* l : others) {
-        void* aptrs[] = {l->d_small, l->d_surv, l->d_hitkm, l->d_hitva, l->d_hitnk, l->d_hitoff, l->d_gen, l->d_tickets, l->d_vote, l->d_epoch};
+        void* aptrs[] = {l->d_small, l->d_surv, l->d_hitkm, l->d_hitva, l->d_hitnk, l->d_hitoff, l->d_gen, l->d_tickets, l->d_vote, l->d_epoch, l->d_walk};
         for (void* p : aptrs) if (p) (void)hipFree(p);
         bins.push_back(&l->bin);
         if (l != &c->alt && l->stream) (void)hipStreamDestroy(l->stream);
@@ -423,6 +443,50 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     return DBTK_OK;
 }
 
+// Graph table (dbtk_tables.h: GrSlot) from graphDB's flat arrays + the TR k-mers: graph pass, then TR pass.
+dbtk_status_t build_graph_table(dbtk_ctx* c) {
+    const dbtk_rpgg* g = c->g;
+    hipStream_t s = c->stream;
+    const uint64_t nloci = g->nloci, ngr = g->gr_ks.size(), ntrf = g->tr_ks.size();
+    for (uint64_t l = 0; l < nloci; ++l)
+        if (g->out_beg[l + 1] - g->out_beg[l] >= (1ull << (32 - GR_SLOT_SHIFT))) { set_error("a locus has more than 2^21 TR k-mers: graph table slot field too small"); return DBTK_ERR_UNSUPPORTED; }
+    const uint64_t cap = pow2_at_least(ngr + ngr / 2 + 2 * ntrf + 2);  // > the entries whatever the files hold; the two strands of a node share one, so the load is ~0.2-0.35
+    HIPCHK(hipMalloc(&c->d_gr, cap * sizeof(GrSlot)));
+    HIPCHK(hipMemsetAsync(c->d_gr, 0xFF, cap * sizeof(GrSlot), s));
+    std::vector<uint64_t> beg(nloci + 1, 0);
+    uint64_t *dks = nullptr, *dbeg = nullptr, *dslot = nullptr, *dn = nullptr;
+    uint8_t* dms = nullptr;
+    const uint64_t nmax = ngr > ntrf ? ngr : ntrf;
+    HIPCHK(hipMalloc(&dks, (nmax + 1) * 8));
+    HIPCHK(hipMalloc(&dms, ngr + 1));
+    HIPCHK(hipMalloc(&dslot, (ntrf + 1) * 8));
+    HIPCHK(hipMalloc(&dbeg, (nloci + 1) * 8));
+    HIPCHK(hipMalloc(&dn, 8));
+    HIPCHK(hipMemsetAsync(dn, 0, 8, s));
+    GrBuildArgs a{c->d_gr, cap - 1, 64 - log2u(cap), g->ksize, dks, dms, dbeg, (uint32_t)nloci, nullptr, c->d_trbeg, ngr, dn};
+    if (ngr) {
+        for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->gr_cnt[l];
+        HIPCHK(hipMemcpyAsync(dks, g->gr_ks.data(), ngr * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dms, g->gr_ms.data(), ngr, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dbeg, beg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_gr_insert, dim3(2048), dim3(256), 0, s, a);
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    if (ntrf) {
+        for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->tr_cnt[l];
+        HIPCHK(hipMemcpyAsync(dks, g->tr_ks.data(), ntrf * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dslot, g->out_slot.data(), ntrf * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dbeg, beg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
+        a.ms = nullptr; a.outslot = dslot; a.n = ntrf;
+        hipLaunchKernelGGL(k_gr_insert, dim3(2048), dim3(256), 0, s, a);
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipFree(dks)); HIPCHK(hipFree(dms)); HIPCHK(hipFree(dslot)); HIPCHK(hipFree(dbeg)); HIPCHK(hipFree(dn));
+    c->T.gr = c->d_gr; c->T.gr_mask = cap - 1; c->T.gr_shift = 64 - log2u(cap);
+    return DBTK_OK;
+}
+
 // (key, locus) -> value table from per-locus arrays (tre edges: value unused; bait: min << 8 | max)
 dbtk_status_t build_kl_table(dbtk_ctx* c, const std::vector<uint64_t>& cnt, const std::vector<uint64_t>& ks,
                              const std::vector<uint16_t>* vals, ClsSlot** out, uint64_t* mask, uint32_t* shift) {
@@ -481,6 +545,7 @@ void switch_lane(dbtk_ctx* c) {
     std::swap(c->d_hitoff, c->alt.d_hitoff); std::swap(c->hitoff_cap, c->alt.hitoff_cap);
     std::swap(c->d_gen, c->alt.d_gen); std::swap(c->gen_cap, c->alt.gen_cap);
     std::swap(c->d_tickets, c->alt.d_tickets); std::swap(c->tickets_cap, c->alt.tickets_cap);
+    std::swap(c->d_walk, c->alt.d_walk); std::swap(c->walk_cap, c->alt.walk_cap);
     std::swap(c->d_vote, c->alt.d_vote); std::swap(c->d_epoch, c->alt.d_epoch);
     std::swap(c->bin, c->alt.bin);
     if (!c->parked.empty()) {  // round robin: the lane just left goes to the back of the queue, the longest-parked one is next
@@ -513,7 +578,8 @@ constexpr uint64_t SURV_CAP = 1ull << 23;  // at most 51 GB of hit buffers at 15
 constexpr uint32_t SMALL_WORDS = 64;  // d_small: nsurv, novf (binned encode stage), nrec, errflag (sticky until reported); stamps at +32
 
 dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_off, uint64_t seq_len, uint64_t npairs,
-                           uint32_t max_read_len, dbtk_pair_rec_t* d_recs, uint32_t rec_cap, const uint8_t* d_qual = nullptr) {
+                           uint32_t max_read_len, dbtk_pair_rec_t* d_recs, uint32_t rec_cap, const uint8_t* d_qual = nullptr,
+                           dbtk_thread_rec_t* walk_trecs = nullptr) {
     hipStream_t s = c->stream;
     if (npairs >= 0xFFFFFFFFull) { set_error("batch too large (pair index is 32-bit)"); return DBTK_ERR_ARG; }
     if (npairs == 0) return DBTK_OK;
@@ -534,6 +600,11 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     if ((st = ensure(&c->d_hitnk, &c->hitnk_cap, tcap * 2))) return st;
     if ((st = ensure(&c->d_gen, &c->gen_cap, tcap))) return st;
     if ((st = ensure(&c->d_tickets, &c->tickets_cap, 2 * (nchunks + 1)))) return st;  // per chunk: a ticket counter and a passed-on counter
+    const bool walking = c->P.threading == DBTK_THREADING_V13;
+    if (walking) {
+        if ((st = ensure(&c->d_walk, &c->walk_cap, 2 * npairs))) return st;
+        HIPCHK(hipMemsetAsync(c->d_walk, 0xFF, npairs * sizeof(uint32_t), s));  // NAN32: the pair does not reach threading
+    }
     HIPCHK(hipMemsetAsync(c->d_small, 0, 3 * sizeof(uint32_t), s));  // nsurv, novf, nrec; the error word (3) stays until it has been reported
     HIPCHK(hipMemsetAsync(c->d_tickets, 0, 2 * (nchunks + 1) * sizeof(uint32_t), s));
     if (c->P.bubbles) {
@@ -556,6 +627,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     a.ctr_rep = c->d_ctr;
     a.recs = d_recs; a.rec_cap = rec_cap;
     a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
+    a.walk_dst = walking ? c->d_walk : nullptr;
     a.hitkm = keep_km ? c->d_hitkm : nullptr; a.hitaux = reinterpret_cast<uint32_t*>(c->d_hitva); a.hitval = a.hitaux + tcap * 2 * nkp; a.hitnk = c->d_hitnk; a.hitoff = c->d_hitoff; a.hithdr = c->d_hitoff + tcap * 2; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
     // the usual-pair kernel takes the pairs it can finish and passes the rest on; it needs the class of a k-mer next to its
     // index value (consistent RPGG) and does not do the trace, bait or bubble work
@@ -664,6 +736,18 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         }
         if (tm) HIPCHK(hipEventRecord(c->timed[3].end[e], s));
     }
+    if (walking) {  // the graph walk over every pair that reached threading, both mates (AQ.cpp:2072-2088), exact counting (:2189-2194)
+        WalkArgs w;
+        memset(&w, 0, sizeof(w));
+        w.T = c->T; w.P = c->P; w.seq = d_seq; w.off = d_off;
+        w.surv = c->d_surv; w.nsurv = c->d_small + 0;
+        w.walk_dst = c->d_walk; w.walk_ret = c->d_walk + npairs;
+        w.counts = a.counts; w.counters = a.counters; w.ctr_rep = c->d_ctr;
+        w.trecs = walk_trecs; w.errflag = c->d_small + 3;
+        if (tm) { if ((st = timed_slot(c, 7, &e))) return st; HIPCHK(hipEventRecord(c->timed[7].beg[e], s)); }
+        hipLaunchKernelGGL(k_walk_pairs, dim3(c->walk_blocks), dim3(64), 0, s, w);
+        if (tm) HIPCHK(hipEventRecord(c->timed[7].end[e], s));
+    }
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, a.counters, c->d_ctr);
     HIPCHK(hipGetLastError());
     return DBTK_OK;
@@ -683,6 +767,9 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
     if (p->trackbait && !p->bait) { set_error("params.trackbait needs params.bait"); return DBTK_ERR_ARG; }
     if (p->bubbles && (h->tre_cnt.empty() || p->extract)) { set_error("params.bubbles needs PREF.tre.kdb (and is not an extract-mode flag)"); return DBTK_ERR_ARG; }
     if (p->qc && h->qc.empty()) { set_error("params.qc set but the RPGG handle has no QC mask"); return DBTK_ERR_ARG; }
+    if (p->threading > DBTK_THREADING_V13) { set_error("params.threading: 0, 1 (HEAD) or 2 (v1.3)"); return DBTK_ERR_ARG; }
+    if (p->threading == DBTK_THREADING_V13 && h->gr_cnt.empty()) { set_error("params.threading = 2 needs the graph in the RPGG handle (DBTK_LOAD_GRAPH)"); return DBTK_ERR_ARG; }
+    if (p->threading == DBTK_THREADING_V13 && p->extract) { set_error("threading = 2 with -e is not supported"); return DBTK_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_error("no HIP device: this library has no CPU execution path");
@@ -734,11 +821,19 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         c->timed[4].name = "k_encode_bin";
         c->timed[5].name = "k_filter_bins";
         c->timed[6].name = "k_subfilter_cand";
+        c->timed[7].name = "k_walk_pairs";
+        {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_walk_pairs, 64, 0) != hipSuccess || nb <= 0) nb = 8;
+            if (const char* e = getenv("DBTK_WALK_WPC")) { const int v = atoi(e); if (v > 0) nb = v; }
+            c->walk_blocks = c->num_cu * nb;
+        }
         for (int i = 0; i < NKERN && !st; ++i)
             for (int j = 0; j < EVPOOL && !st; ++j)
                 if (hipEventCreate(&c->timed[i].beg[j]) != hipSuccess || hipEventCreate(&c->timed[i].end[j]) != hipSuccess) { set_error("hipEventCreate failed"); st = DBTK_ERR_HIP; }
         if (st) break;
         if ((st = build_tables(c))) break;
+        if (!h->gr_cnt.empty() && (st = build_graph_table(c))) break;
         if (p->trackbait) {
             c->btTK.resize(h->nloci);
             c->baitDB_host.resize(h->nloci);
@@ -849,8 +944,12 @@ dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t
         if ((st = ensure(&c->d_qual, &c->qual_cap, nbytes + 32))) return st;
         if (nbytes) HIPCHK(hipMemcpyAsync(c->d_qual, qual + base, nbytes, hipMemcpyHostToDevice, s));
     }
+    const bool walk_recs = c->P.threading == DBTK_THREADING_V13 && (c->P.trace || c->P.aln);
+    if (walk_recs && (st = ensure(&c->d_trecs, &c->trecs_cap, 2 * npairs))) return st;
+    c->last_walk_npairs = c->P.threading == DBTK_THREADING_V13 ? npairs : 0;
+    c->last_walk_recs = walk_recs;
     if ((st = launch_batch(c, c->d_seq, c->d_off, nbytes, npairs, maxlen, want_recs ? c->d_recs : nullptr, (uint32_t)dcap,
-                           use_qual ? c->d_qual : nullptr))) return st;
+                           use_qual ? c->d_qual : nullptr, walk_recs ? c->d_trecs : nullptr))) return st;
     uint32_t small[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(small, c->d_small, sizeof(small), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -938,6 +1037,73 @@ dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t
                 for (auto& p2 : p1.second) t[p2.first] += p2.second;
             }
         }
+    }
+    return DBTK_OK;
+}
+
+// Function-level entry of the graph walk (tests, and callers that want isThreadFeasible alone).
+dbtk_status_t dbtk_thread_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t* off, const uint32_t* loci, uint64_t nreads,
+                                dbtk_thread_rec_t* recs) {
+    if (!c || !off || !loci || !recs || (!seq && nreads)) { set_error("null argument"); return DBTK_ERR_ARG; }
+    if (!c->d_gr) { set_error("the RPGG handle holds no graph (DBTK_LOAD_GRAPH)"); return DBTK_ERR_ARG; }
+    if (nreads >= 0x7FFFFFFFull) { set_error("too many reads"); return DBTK_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    for (uint64_t r = 0; r < nreads; ++r) {
+        if (off[r + 1] < off[r]) { set_error("seq_offsets not monotone"); return DBTK_ERR_ARG; }
+        if (off[r + 1] - off[r] > DBTK_MAX_READ_LEN) { set_error("read longer than DBTK_MAX_READ_LEN"); return DBTK_ERR_READ_TOO_LONG; }
+        if (loci[r] >= c->g->nloci) { set_error("locus out of range"); return DBTK_ERR_ARG; }
+    }
+    if (!nreads) return DBTK_OK;
+    const uint64_t base = off[0], nbytes = off[nreads] - base;
+    dbtk_status_t st;
+    if ((st = ensure(&c->d_seq, &c->seq_cap, nbytes + 32))) return st;
+    if ((st = ensure(&c->d_off, &c->off_cap, nreads + 1))) return st;
+    if ((st = ensure(&c->d_loci, &c->loci_cap, nreads))) return st;
+    if ((st = ensure(&c->d_trecs, &c->trecs_cap, nreads))) return st;
+    hipStream_t s = c->stream;
+    std::vector<uint64_t> o2(nreads + 1);
+    for (uint64_t r = 0; r <= nreads; ++r) o2[r] = off[r] - base;
+    if (nbytes) HIPCHK(hipMemcpyAsync(c->d_seq, seq + base, nbytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_off, o2.data(), (nreads + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_loci, loci, nreads * 4, hipMemcpyHostToDevice, s));
+    WalkArgs w;
+    memset(&w, 0, sizeof(w));
+    w.T = c->T; w.P = c->P; w.seq = c->d_seq; w.off = c->d_off;
+    w.read_locus = c->d_loci; w.nreads = (uint32_t)nreads; w.trecs = c->d_trecs; w.errflag = c->d_small + 3;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nreads, (uint64_t)c->walk_blocks);
+    hipLaunchKernelGGL(k_walk_reads, dim3(grid), dim3(64), 0, s, w);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(recs, c->d_trecs, nreads * sizeof(dbtk_thread_rec_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return DBTK_OK;
+}
+
+// What the walk decided for the pairs of the last host-buffer batch that reached threading, in pair order.
+dbtk_status_t dbtk_ctx_walk_results(dbtk_ctx_t* c, dbtk_walk_res_t* res, dbtk_thread_rec_t* trecs, uint64_t cap, uint64_t* n) {
+    if (!c || !n) { set_error("null argument"); return DBTK_ERR_ARG; }
+    *n = 0;
+    if (!c->last_walk_npairs) return DBTK_OK;
+    if (trecs && !c->last_walk_recs) { set_error("thread records are only kept with params.trace or params.aln"); return DBTK_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint32_t nsurv = 0;
+    HIPCHK(hipMemcpy(&nsurv, c->d_small, 4, hipMemcpyDeviceToHost));
+    const uint64_t np = c->last_walk_npairs;
+    std::vector<uint32_t> dst(nsurv), ret(nsurv), surv(nsurv);
+    if (nsurv) {
+        HIPCHK(hipMemcpy(dst.data(), c->d_walk, (size_t)nsurv * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ret.data(), c->d_walk + np, (size_t)nsurv * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(surv.data(), c->d_surv, (size_t)nsurv * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> walked;  // (pair, t)
+    for (uint32_t t = 0; t < nsurv; ++t) if (dst[t] != NAN32) walked.emplace_back(surv[t], t);
+    std::sort(walked.begin(), walked.end());
+    *n = walked.size();
+    if (walked.size() > cap) { set_error("result buffer too small"); return DBTK_ERR_OVERFLOW; }
+    for (size_t i = 0; i < walked.size(); ++i) {
+        const uint32_t t = walked[i].second;
+        if (res) { res[i].pair = walked[i].first; res[i].dst = dst[t]; res[i].ret1 = (int8_t)(ret[t] & 0xFF); res[i].ret2 = (int8_t)((ret[t] >> 8) & 0xFF); res[i].pad[0] = res[i].pad[1] = 0; }
+        if (trecs) HIPCHK(hipMemcpy(&trecs[2 * i], &c->d_trecs[2 * (size_t)t], 2 * sizeof(dbtk_thread_rec_t), hipMemcpyDeviceToHost));
     }
     return DBTK_OK;
 }

@@ -23,6 +23,8 @@ struct dbtk_rpgg {
     std::vector<uint8_t> qc;                // empty or nloci
     std::vector<uint64_t> bt_cnt, bt_ks;    // PREF.bt.kmdb (may be empty)
     std::vector<uint16_t> bt_vs;
+    std::vector<uint64_t> gr_cnt, gr_ks;    // PREF.graph.kmers / PREF.graph.umap (empty: no graph loaded)
+    std::vector<uint8_t> gr_ms;
     // derived
     std::vector<uint64_t> out_slot;   // file index -> position in OUT.trkmc.ar
     std::vector<uint64_t> out_kmer;   // position -> k-mer

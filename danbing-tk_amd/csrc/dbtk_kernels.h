@@ -31,6 +31,7 @@
 #include "dbtk_assign.h"
 #include "dbtk_sort.h"
 #include "dbtk_tables.h"
+#include "dbtk_walk.h"
 
 namespace dbtk {
 
@@ -217,6 +218,8 @@ struct BatchArgs {
     uint32_t* ovf_hdr;
     uint32_t* novf;
     uint32_t* candbits;
+    uint32_t* walk_dst;      // threading = 2 (v1.3): per survivor, destLocus of a pair that reaches threading (else left NAN32);
+                             // the walk kernel (dbtk_walk.h: body_walk_pairs) takes it from there
     uint32_t vzero;          // always 0: `lane * vzero` makes an address look lane-dependent, so that a load whose value is only
                              // needed an iteration later is not turned into scalars (and waited for) right where it is issued
 };
@@ -225,6 +228,7 @@ struct BatchArgs {
 // (tens of nanoseconds each), which showed up as a fixed cost per resident wave.  On the device the waves therefore add
 // into CTR_REP replicas on separate cache lines, and a tiny kernel folds the replicas into the real counters after the batch.
 constexpr uint32_t CTR_REP = 256, CTR_STRIDE = 32;
+static_assert(CTR_REP == W_CTR_REP && CTR_STRIDE == W_CTR_STRIDE, "dbtk_walk.h addresses the same counter replicas");
 constexpr uint32_t AUX_MISS = 0xFFFFFFFDu;  // hitaux: the position's k-mer is not in the index (next to CLS_NONE, CLS_FLANK)
 constexpr uint64_t HDR_UNIFORM = 1ull << 63;
 template <class X>
@@ -1717,8 +1721,9 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
             if (a.P.qc && T.qc && !T.qc[dst]) {  // AQ.cpp:2059-2062
                 c_qc += 2;
                 stage = DBTK_STAGE_QC;
-            } else if (a.P.threading) {  // AQ.cpp:2070-2090: `alned` stays false at HEAD, nothing else happens
-                c_thr += 2;
+            } else if (a.P.threading) {  // AQ.cpp:2070-2090: `alned` stays false at HEAD, nothing else happens;
+                c_thr += 2;              // v1.3 (threading = 2): the walk kernel takes the pair from here
+                if (a.P.threading == DBTK_THREADING_V13 && lane == 0) a.walk_dst[t] = dst;
             } else if (a.P.extract) {  // AQ.cpp:2094-2099
                 c_thr += 2; c_feas += 2;
                 stage = DBTK_STAGE_EXTRACT;
@@ -2313,8 +2318,9 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 if (a.P.qc && T.qc && !T.qc[dst]) {  // AQ.cpp:2059-2062
                     c_qc += (uint64_t)(2 - rm[0] - rm[1]);
                     stage = DBTK_STAGE_QC;
-                } else if (a.P.threading) {  // AQ.cpp:2070-2090: `alned` stays false at HEAD, nothing else happens
-                    c_thr += 2;
+                } else if (a.P.threading) {  // AQ.cpp:2070-2090: `alned` stays false at HEAD, nothing else happens;
+                    c_thr += 2;              // v1.3 (threading = 2): the walk kernel takes the pair from here
+                    if (a.P.threading == DBTK_THREADING_V13 && lane == 0) a.walk_dst[t] = dst;
                 } else if (a.P.extract) {  // AQ.cpp:2094-2099
                     c_thr += 2; c_feas += 2;
                     stage = DBTK_STAGE_EXTRACT;

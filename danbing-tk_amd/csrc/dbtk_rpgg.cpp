@@ -85,6 +85,73 @@ dbtk_status_t read_tr_kmers(const std::string& fn, std::vector<uint64_t>& cnt, s
     return DBTK_OK;
 }
 
+// graphDB of the v1.3 threading path.  PREF.graph.kmers: text, ">locus" lines then "NODE\tMASK" lines
+// (readGraphKmers, src/aQueryFasta_thread.h:550-575: `kmerDB[idx][kmer] |= mask`, so repeated nodes OR — kept as
+// repeated entries here, the device table ORs them).  PREF.graph.umap: the v1.3 binary
+// `u64 nloci | per locus: u64 n | n x (u64 node, u8 mask)` (fixture test/QC/input/pan.graph.umap).
+dbtk_status_t read_graph_text(const std::string& fn, uint64_t nloci, std::vector<uint64_t>& cnt, std::vector<uint64_t>& ks,
+                              std::vector<uint8_t>& ms) {
+    File f(fn, "rb");
+    if (!f.f) { set_error("cannot open " + fn); return DBTK_ERR_IO; }
+    cnt.assign(nloci, 0);
+    std::vector<char> buf(1 << 24);
+    std::string carry;
+    int64_t locus = -1;
+    auto line = [&](const char* p, const char* e) -> bool {
+        if (p == e) return true;
+        if (*p == '>') { ++locus; return (uint64_t)locus < nloci; }
+        if (locus < 0) return false;
+        uint64_t v = 0, m = 0;
+        const char* q = p;
+        if (*q < '0' || *q > '9') return false;
+        while (q < e && *q >= '0' && *q <= '9') v = v * 10 + (uint64_t)(*q++ - '0');
+        if (q < e && *q == '\t') { ++q; while (q < e && *q >= '0' && *q <= '9') m = m * 10 + (uint64_t)(*q++ - '0'); }
+        ks.push_back(v);
+        ms.push_back((uint8_t)m);
+        cnt[(size_t)locus]++;
+        return true;
+    };
+    for (;;) {
+        const size_t n = fread(buf.data(), 1, buf.size(), f.f);
+        if (!n) break;
+        const char* p = buf.data();
+        const char* end = p + n;
+        while (p < end) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+            if (!nl) { carry.append(p, end); break; }
+            bool ok;
+            if (!carry.empty()) { carry.append(p, nl); ok = line(carry.data(), carry.data() + carry.size()); carry.clear(); }
+            else ok = line(p, nl);
+            if (!ok) { set_error(fn + ": not a graph k-mer file (or more loci than PREF.tr.kmers)"); return DBTK_ERR_FORMAT; }
+            p = nl + 1;
+        }
+    }
+    if (!carry.empty() && !line(carry.data(), carry.data() + carry.size())) { set_error(fn + ": bad last line"); return DBTK_ERR_FORMAT; }
+    return DBTK_OK;
+}
+dbtk_status_t read_graph_umap(const std::string& fn, uint64_t nloci, std::vector<uint64_t>& cnt, std::vector<uint64_t>& ks,
+                              std::vector<uint8_t>& ms) {
+    File f(fn, "rb");
+    if (!f.f) { set_error("cannot open " + fn); return DBTK_ERR_IO; }
+    uint64_t nl = 0;
+    if (!f.read(&nl, 1)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+    if (nl != nloci) { set_error(fn + ": locus count differs from tr.kmers"); return DBTK_ERR_FORMAT; }
+    cnt.assign(nloci, 0);
+    std::vector<uint8_t> rec;
+    for (uint64_t l = 0; l < nl; ++l) {
+        uint64_t n = 0;
+        if (!f.read(&n, 1) || n > (1ull << 40)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+        cnt[l] = n;
+        rec.resize(n * 9);
+        if (!f.read(rec.data(), n * 9)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+        const size_t at = ks.size();
+        ks.resize(at + n);
+        ms.resize(at + n);
+        for (uint64_t i = 0; i < n; ++i) { memcpy(&ks[at + i], &rec[9 * i], 8); ms[at + i] = rec[9 * i + 8]; }
+    }
+    return DBTK_OK;
+}
+
 }  // namespace
 
 namespace dbtk {
@@ -113,6 +180,16 @@ dbtk_status_t finish_rpgg(dbtk_rpgg* g) {
         for (uint64_t j = 0; j < n; ++j)
             if (g->vv[o + 1 + j] >= nloci) { set_error("kmers.dbi: vv locus id out of range"); return DBTK_ERR_FORMAT; }
         o += 1 + n;
+    }
+    if (!g->bt_cnt.empty()) {  // the bait DB's per-locus counts index bt_ks / bt_vs (trackbait loop, build_kl_table)
+        uint64_t s = 0;
+        for (uint64_t c : g->bt_cnt) s += c;
+        if (g->bt_cnt.size() != nloci || s != g->bt_ks.size() || s != g->bt_vs.size()) { set_error("bait DB: per-locus counts do not add up"); return DBTK_ERR_FORMAT; }
+    }
+    if (!g->gr_cnt.empty()) {
+        uint64_t s = 0;
+        for (uint64_t c : g->gr_cnt) s += c;
+        if (g->gr_cnt.size() != nloci || s != g->gr_ks.size() || s != g->gr_ms.size()) { set_error("graph: per-locus counts do not add up"); return DBTK_ERR_FORMAT; }
     }
     std::vector<uint64_t> beg(nloci + 1, 0);
     for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->tr_cnt[l];
@@ -263,9 +340,20 @@ dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_
         if (!f.read(&nl, 1) || nl != g->nloci) { set_error("bait DB: locus count differs"); return DBTK_ERR_FORMAT; }
         g->bt_cnt.resize(nl);
         if (!f.read(g->bt_cnt.data(), nl) || !f.read(&nk, 1) || !f.read(&szv, 1) || szv != 2) { set_error("bait DB: bad header"); return DBTK_ERR_FORMAT; }
+        {   // sanity before sizing anything from the header: the file must hold what it announces
+            fseek(f.f, 0, SEEK_END);
+            const uint64_t fsz = (uint64_t)ftell(f.f);
+            if (nk > fsz / 10) { set_error("bait DB: k-mer count exceeds the file size"); return DBTK_ERR_FORMAT; }
+            fseek(f.f, (long)(8 * (3 + nl)), SEEK_SET);
+        }
         g->bt_ks.resize(nk);
         g->bt_vs.resize(nk);
         if (!f.read(g->bt_ks.data(), nk) || !f.read(g->bt_vs.data(), nk)) { set_error("bait DB truncated"); return DBTK_ERR_IO; }
+    }
+    if (flags & DBTK_LOAD_GRAPH) {
+        if (file_exists(pref + ".graph.kmers")) st = read_graph_text(pref + ".graph.kmers", g->nloci, g->gr_cnt, g->gr_ks, g->gr_ms);
+        else st = read_graph_umap(pref + ".graph.umap", g->nloci, g->gr_cnt, g->gr_ks, g->gr_ms);
+        if (st) return st;
     }
     if ((st = dbtk::finish_rpgg(g.get()))) return st;
     *out = g.release();
@@ -297,6 +385,11 @@ dbtk_status_t dbtk_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a, dbtk_rpgg_t** o
         const uint64_t n = sum(a->bt_cnt);
         if (n) { g->bt_ks.assign(a->bt_ks, a->bt_ks + n); g->bt_vs.assign(a->bt_vs, a->bt_vs + n); }
     }
+    if (a->gr_cnt) {
+        g->gr_cnt.assign(a->gr_cnt, a->gr_cnt + a->nloci);
+        const uint64_t n = sum(a->gr_cnt);
+        if (n) { g->gr_ks.assign(a->gr_ks, a->gr_ks + n); g->gr_ms.assign(a->gr_ms, a->gr_ms + n); }
+    }
     const dbtk_status_t st = dbtk::finish_rpgg(g.get());
     if (st) return st;
     *out = g.release();
@@ -319,6 +412,7 @@ dbtk_status_t dbtk_rpgg_view(const dbtk_rpgg_t* h, dbtk_rpgg_arrays_t* o) {
     o->tr_cnt = h->tr_cnt.data(); o->tr_ks = h->tr_ks.data();
     if (!h->qc.empty()) o->qc = h->qc.data();
     if (!h->bt_cnt.empty()) { o->bt_cnt = h->bt_cnt.data(); o->bt_ks = h->bt_ks.data(); o->bt_vs = h->bt_vs.data(); }
+    if (!h->gr_cnt.empty()) { o->gr_cnt = h->gr_cnt.data(); o->gr_ks = h->gr_ks.data(); o->gr_ms = h->gr_ms.data(); }
     return DBTK_OK;
 }
 

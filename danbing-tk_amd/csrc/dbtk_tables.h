@@ -62,6 +62,21 @@ struct ClsSlot {
     uint64_t lc;    // ~0 = not yet written (build only)
 };
 
+// ---- graph table (v1.3 threading): graphDB[locus] (GraphType = unordered_map<node, out-edge mask>,
+// src/aQueryFasta_thread.h:32, loader :550-575) and trKmers[locus] folded into ONE open-addressed table keyed by
+// (canonical k-mer, locus), so that a single probe answers everything the walk asks about a k-mer at a locus:
+// is the k-mer (as given, non-canonical) a node and what are its out-edges, the same for its reverse complement
+// (errorCorrection_backward walks the other strand, AQ.cpp:1091-1106), is its canonical form a TR k-mer
+// (cg.tr annotation, AQ.cpp:886) and which OUT.trkmc.ar counter is it ("exact" counting, AQ.cpp:2189-2194).
+// li = locus << 32 | info; info: bits 0-3 out-edge mask of the canonical form taken as a node (bit b: successor
+// ((node & rmask) << 2) | b exists), bit 4 that node exists; bits 5-8 / bit 9 the same for the reverse-complement
+// form; bit 10 TR k-mer of the locus; bits 11-31 its counter relative to the locus' first one.
+struct GrSlot {
+    uint64_t kmer;  // NAN64 = empty
+    uint64_t li;    // ~0 = not yet written (build only)
+};
+constexpr uint32_t GR_HAS = 1u << 4, GR_OPP = 5, GR_TR = 1u << 10, GR_SLOT_SHIFT = 11;
+
 struct DevTables {
     const IdxBucket* idx;
     uint64_t idx_mask;   // buckets - 1 (power of two)
@@ -82,6 +97,7 @@ struct DevTables {
     // PREF.bt.kmdb for -b.  Same slot layout and probing as the class table.
     const ClsSlot* tre; uint64_t tre_mask; uint32_t tre_shift;
     const ClsSlot* bait; uint64_t bait_mask; uint32_t bait_shift;
+    const GrSlot* gr; uint64_t gr_mask; uint32_t gr_shift;  // nullptr: no graph loaded
 };
 
 DBTK_HD uint64_t hash_mix(uint64_t key) {
@@ -189,6 +205,17 @@ DBTK_HD uint32_t kl_lookup(const ClsSlot* tab, uint64_t mask, uint32_t shift, ui
         if (s.kmer == key && (uint32_t)(s.lc >> 32) == locus) return (uint32_t)s.lc;
         if (s.kmer == NAN64) return CLS_NONE;
         i = (i + 1) & mask;
+    }
+}
+
+// (canonical k-mer, locus) -> info of the graph table; 0 when absent (a stored info is never 0)
+DBTK_HD uint32_t gr_lookup(const DevTables& T, uint64_t canon, uint32_t locus) {
+    uint64_t i = hash_cls(canon, locus, T.gr_shift);
+    for (;;) {
+        const GrSlot s = T.gr[i];
+        if (s.kmer == canon && (uint32_t)(s.li >> 32) == locus) return (uint32_t)s.li;
+        if (s.kmer == NAN64) return 0;
+        i = (i + 1) & T.gr_mask;
     }
 }
 

@@ -1,0 +1,865 @@
+// dbtk_walk.h — the graph-threading walk of the v1.3 contract as a wave64 kernel body.
+//
+// = isThreadFeasible and everything under it (src/aQueryFasta_thread.cpp:1114-1260: find_anchor :878-888,
+// errorCorrection_forward :898-1089, errorCorrection_backward :1091-1106, thread_ext_t::get_edit :627-647,
+// edit_kmers_forward :828-862, edit_kmers_backward :649-825, annot_gap :1108-1111) plus the call-site glue the
+// reference keeps in comments (:2072-2088 both mates walked, pair kept if either is feasible; :2189-2194 "exact" counting).
+//
+// One wavefront walks one read; the walk is a sequential state machine in the reference, here it is laid out over
+// the wave like this:
+//   * the read's non-canonical k-mers (read2kmers keepN, AQ.h:246-271) are extracted by the lanes and ALL looked up
+//     in the graph table up front (dbtk_tables.h: one probe per k-mer answers node / out-edges of both strands /
+//     TR k-mer / counter), so the common step of the walk — "is k-mer ki a successor of k-mer ki-1" — is a bit test
+//     on data already in LDS, and whole runs of matching k-mers are accepted with one ballot;
+//   * what is left is handled one event at a time with wave-uniform control flow: N, homopolymer, re-anchoring
+//     (find_anchor is a ballot over the next 64 positions), and error correction;
+//   * errorCorrection_forward's eight edit classes are 62 independent hypotheses (4 + 16 + 4 + 16 + 1 + 4 + 1 + 16):
+//     one per lane, all extended in lockstep, one graph probe per live lane and step; the lane numbering IS
+//     get_edit's scan order, so the winner is a wave maximum of (score, 255 - lane); the reachability cube
+//     (graph_triplet_t, AQ.cpp:865-875) is 20 probes in two rounds held as 4 + 16 four-bit masks;
+//   * the array surgery of edit_kmers_forward / _backward (vector::insert / erase on k-mers, annotations and edit
+//     operations) is done by all lanes as block shifts; only the edit-tract merging of edit_kmers_backward
+//     (AQ.cpp:712-822), a few dozen dependent byte operations, runs on lane 0.
+// The k-mer / annotation / edit arrays are fixed-capacity LDS arrays (DBTK_THREAD_CAP entries: every inserted k-mer
+// costs at least MSC = 5 extended ones).
+//
+// Quirks of the reference that results depend on and that are kept: the unsigned wrap of `kmers[ki] - oldnt + nt0`
+// when the k-mer is NAN64 (AQ.cpp:930), getNextNucs leaving the next-base set stale when the node is absent
+// (AQ.cpp:547-557), `nkmers` frozen at the read's original size (AQ.cpp:1126, 1182), `++ncorrection` on top of the
+// edits after a mid-read backward correction (AQ.cpp:1204), nskip / ncorrection wrapping as size_t.  Where the
+// reference asserts (a successor named by an edge mask is missing, AQ.cpp:528-532) the walk ends with
+// DBTK_THREAD_F_MISSING_NODE and ret = -1.
+#ifndef DBTK_WALK_H_
+#define DBTK_WALK_H_
+
+#include "dbtk_tables.h"
+
+namespace dbtk {
+
+constexpr int WCAP = DBTK_THREAD_CAP;
+constexpr uint32_t W_MSC = 5;  // min score for thread extension, AQ.cpp:1120
+constexpr uint32_t W_CTR_REP = 256, W_CTR_STRIDE = 32;  // == CTR_REP / CTR_STRIDE of dbtk_kernels.h (counter replicas)
+
+// ------------------------------------------------------------------ build --
+struct GrBuildArgs {
+    GrSlot* slots;
+    uint64_t mask;
+    uint32_t shift, ksize;
+    const uint64_t* ks;       // graph pass: nodes (non-canonical); TR pass: the locus' TR k-mers (file order)
+    const uint8_t* ms;        // graph pass: out-edge masks; nullptr = TR pass
+    const uint64_t* beg;      // nloci + 1 prefix offsets into ks
+    uint32_t nloci;
+    const uint64_t* outslot;  // TR pass: OUT.trkmc.ar slot of entry i
+    const uint32_t* trbeg;    // TR pass: first slot of each locus
+    uint64_t n;
+    uint64_t* nentries;       // += distinct (k-mer, locus) entries
+};
+template <class X>
+DBTK_HD void body_gr_insert(X& x, const GrBuildArgs& a) {
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.n; i += (uint64_t)x.nblocks() * x.nthreads()) {
+        uint32_t lo = 0, hi = a.nloci;  // locus of entry i: beg[l] <= i < beg[l+1]
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (a.beg[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t locus = lo;
+        uint64_t canon;
+        uint32_t bits;
+        if (a.ms) {  // kmerDB[idx][kmer] |= c (readGraphKmers, AQ.h:571): repeated nodes OR
+            const uint64_t node = a.ks[i], rc = revcomp2(node, a.ksize);
+            const bool isf = node <= rc;
+            canon = isf ? node : rc;
+            const uint32_t b = (a.ms[i] & 0xFu) | GR_HAS;
+            bits = isf ? b : b << GR_OPP;
+        } else {
+            canon = a.ks[i];
+            bits = GR_TR | (((uint32_t)a.outslot[i] - a.trbeg[locus]) << GR_SLOT_SHIFT);
+        }
+        const uint64_t li = ((uint64_t)locus << 32) | bits;
+        uint64_t s = hash_cls(canon, locus, a.shift);
+        for (;;) {
+            const uint64_t prev = x.atomic_cas(&a.slots[s].kmer, NAN64, canon);
+            if (prev == NAN64 || prev == canon) {
+                const uint64_t pl = x.atomic_cas(&a.slots[s].li, ~0ull, li);
+                if (pl == ~0ull) { x.atomic_add(a.nentries, 1ull); break; }
+                if ((uint32_t)(pl >> 32) == locus) { x.atomic_or(&a.slots[s].li, (uint64_t)bits); break; }
+            }
+            s = (s + 1) & a.mask;
+        }
+    }
+}
+
+// -------------------------------------------------------------- the walk --
+struct WalkArgs {
+    DevTables T;
+    dbtk_params_t P;
+    const uint8_t* seq;   // reads back to back; read r = [off[r], off[r+1])
+    const uint64_t* off;
+    // pair mode (the hot path, threading = 2): survivors [0, *nsurv) of the batch; walk_dst[t] = destLocus of survivor t
+    // after countHit and the QC gate, NAN32 = the pair never reached threading
+    const uint32_t* surv;
+    const uint32_t* nsurv;
+    uint32_t* walk_dst;      // in: destLocus; out: destLocus after threading (nloci when neither mate is feasible)
+    uint32_t* walk_ret;      // out, per survivor: ret of mate 0 | ret of mate 1 << 8 (as int8)
+    uint64_t* counts;        // OUT.trkmc.ar order
+    uint64_t* counters;      // DBTK_C_*
+    uint64_t* ctr_rep;       // nullptr or replicas (dbtk_kernels.h: counters_of)
+    // function mode (tests, dbtk_thread_batch): read r walked against read_locus[r]
+    const uint32_t* read_locus;
+    uint32_t nreads;
+    dbtk_thread_rec_t* trecs;  // function mode: one per read.  pair mode: nullptr, or two per survivor (trace / -a records)
+    uint64_t* noncak;          // function mode: nullptr or nreads x MAXL uncorrected k-mers
+    uint32_t* errflag;
+};
+
+struct WalkSmem {
+    uint32_t raw[72];
+    uint32_t pk[20];
+    uint16_t vd[20];
+    uint64_t km[WCAP + 8];    // the walked k-mers: non-canonical, NAN64 where the read has none
+    uint16_t gi[WCAP + 8];    // graph info of km[i] as oriented: bits 0-3 out-edges, bit 4 is a node; bits 5-9 the same for its
+                              // reverse complement; bit 10 its canonical form is a TR k-mer of the locus
+    uint8_t tr[WCAP + 8];     // cg.tr
+    uint8_t es_t[WCAP + 8], es_r[WCAP + 8], es_g[WCAP + 8];  // cg.es
+    uint32_t slot[2][NKMAX];  // per mate: counter of the UNcorrected k-mer at each position (NAN32: not a TR k-mer)
+    uint8_t bases[48];        // edit_kmers_*: bases to roll in / leading bases
+    uint8_t cube[24];         // errorCorrection_forward: m1[4], m2[16]
+    int32_t st[8];            // lane-0 regions hand their scalars back through here
+    uint64_t st64[2];
+};
+
+DBTK_HD uint64_t w_roll(uint64_t kmer, uint64_t rmask, uint64_t b) { return ((kmer & rmask) << 2) + b; }
+DBTK_HD uint8_t w_comp_char(uint8_t c) {  // baseComplement on a base letter, AQ.h:71-87
+    return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 127;
+}
+DBTK_HD uint32_t w_code(uint8_t c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u; }
+
+// graph info of a non-canonical k-mer at the locus, oriented (see WalkSmem::gi); *slot gets its counter or NAN32
+DBTK_HD uint32_t w_info(const DevTables& T, uint32_t locus, uint64_t fw, uint32_t k, uint32_t* slot) {
+    if (slot) *slot = NAN32;
+    if (fw == NAN64) return 0;
+    const uint64_t rc = revcomp2(fw, k);
+    const bool isf = fw <= rc;
+    const uint32_t info = gr_lookup(T, isf ? fw : rc, locus);
+    if (slot && (info & GR_TR)) *slot = T.trbeg[locus] + (info >> GR_SLOT_SHIFT);
+    const uint32_t a = info & 0x1Fu, b = (info >> GR_OPP) & 0x1Fu;
+    return (isf ? (a | (b << GR_OPP)) : (b | (a << GR_OPP))) | (info & GR_TR);
+}
+
+// Edit classes in get_edit's scan order (AQ.cpp:627-647) = lane numbering of the hypotheses:
+//   0-3 1X(nt0)   4-7 1D(nt0)   8 1I   9 + 13 nt0 + 3 nt1 + {0: 2X, 1: X+D, 2: 2D}   9 + 13 nt0 + 12: X+I(nt0)   61: 2I
+enum { H_1X, H_1D, H_1I, H_2X, H_XD, H_2D, H_XI, H_2I, H_NONE };
+DBTK_HD void w_hyp(int id, int* type, uint32_t* nt0, uint32_t* nt1) {
+    *nt0 = 0; *nt1 = 0;
+    if (id < 4) { *type = H_1X; *nt0 = (uint32_t)id; }
+    else if (id < 8) { *type = H_1D; *nt0 = (uint32_t)id - 4; }
+    else if (id == 8) *type = H_1I;
+    else if (id < 61) {
+        const int r = id - 9, q = r % 13;
+        *nt0 = (uint32_t)(r / 13);
+        if (q == 12) *type = H_XI;
+        else { *nt1 = (uint32_t)(q / 3); *type = q % 3 == 0 ? H_2X : q % 3 == 1 ? H_XD : H_2D; }
+    } else if (id == 61) *type = H_2I;
+    else *type = H_NONE;
+}
+
+struct WalkState {
+    int ki, ni, nkm, nes, ntr;
+    uint64_t nskip, ncorr;
+    uint32_t flags;
+};
+
+// errorCorrection_forward (AQ.cpp:898-1089) at index ki of the walk's k-mers, or — backward = true —
+// errorCorrection_backward (AQ.cpp:1091-1106): the same on the reverse-complemented prefix before the anchor ki1.
+// Returns skip; on success *wid = the winning hypothesis, *wscore its score.
+template <class X>
+DBTK_HD bool walk_ec(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, bool backward, int ki, int nkm, uint32_t mes,
+                     int* wid, uint32_t* wscore, uint32_t* flags) {
+    const int lane = x.lane();
+    const uint32_t k = T.ksize;
+    const uint64_t rmask = (1ull << 2 * (k - 1)) - 1;
+    // V(j) = kmers[kiV + j] of the array the reference corrects on: forward the walk's own k-mers at ki + j;
+    // backward kmers_rc[1 + j] = RC(kmers[ki - 1 - j]), kmers_rc[0] = RC(node)
+    auto V = [&](int j) -> uint64_t {
+        if (!backward) return sm.km[ki + j];
+        const uint64_t v = sm.km[ki - 1 - j];
+        return v == NAN64 ? NAN64 : revcomp2(v, k);
+    };
+    const int n = backward ? ki : nkm - ki;  // nkmers - ki of the corrected array
+    const int ngood = (int)k + 2 < n ? (int)k + 2 : n;
+    // the node whose successors seed the hypotheses, and its out-edges
+    const uint32_t gS = backward ? ((uint32_t)sm.gi[ki] >> GR_OPP) & 0x1Fu : (uint32_t)sm.gi[ki - 1] & 0x1Fu;
+    const uint64_t S = backward ? revcomp2(sm.km[ki], k) : sm.km[ki - 1];
+    if (!(gS & GR_HAS)) { *flags |= DBTK_THREAD_F_MISSING_NODE; return true; }  // getOutNodes asserts
+    const uint32_t mask0 = gS & 0xFu;
+    // reachability: m1[nt0] = out-edges of successor nt0, m2[nt0][nt1] = out-edges of its successor nt1
+    x.sync();
+    bool missing = false;
+    {
+        uint32_t m = 0;
+        if (lane < 4 && ((mask0 >> lane) & 1)) {
+            const uint32_t g = w_info(T, locus, w_roll(S, rmask, (uint64_t)lane), k, nullptr);
+            if (!(g & GR_HAS)) missing = true;
+            m = g & 0xFu;
+        }
+        if (lane < 4) sm.cube[lane] = (uint8_t)m;
+    }
+    x.sync();
+    {
+        uint32_t m = 0;
+        if (lane >= 4 && lane < 20) {
+            const uint32_t nt0 = (uint32_t)(lane - 4) >> 2, nt1 = (uint32_t)(lane - 4) & 3;
+            if (((mask0 >> nt0) & 1) && ((sm.cube[nt0] >> nt1) & 1)) {
+                const uint32_t g = w_info(T, locus, w_roll(w_roll(S, rmask, nt0), rmask, nt1), k, nullptr);
+                if (!(g & GR_HAS)) missing = true;
+                m = g & 0xFu;
+            }
+            sm.cube[lane] = (uint8_t)m;
+        }
+    }
+    x.sync();
+    if (x.ballot(missing)) { *flags |= DBTK_THREAD_F_MISSING_NODE; return true; }
+    uint32_t nts1 = 0, nts2 = 0, nn1[4];  // nn1[nt0] = get_nnts(nt0): nt1 with some nt2 behind it
+    for (uint32_t a = 0; a < 4; ++a) {
+        nts1 |= sm.cube[a];
+        nn1[a] = 0;
+        for (uint32_t b = 0; b < 4; ++b) {
+            const uint32_t m2 = sm.cube[4 + 4 * a + b];
+            nts2 |= m2;
+            if (m2) nn1[a] |= 1u << b;
+        }
+    }
+    auto good = [&](int j) { return j < ngood && V(j) != NAN64; };
+    const uint64_t v0 = V(0);
+    const uint64_t oldnt = v0 % 4;
+    const bool g0 = good(0), g1 = good(1), g2 = good(2);
+    const uint32_t b0 = (uint32_t)(v0 % 4), b1 = g1 ? (uint32_t)(V(1) % 4) : 0, b2 = g2 ? (uint32_t)(V(2) % 4) : 0;
+    const bool c1X = g1 && ((nts1 >> b1) & 1);
+    const bool c2X = !c1X && g2 && mes >= 2 && ((nts2 >> b2) & 1);
+    const bool cXI = g2 && mes >= 2 && ((nts1 >> b2) & 1);
+    const bool cXD = g1 && mes >= 2 && ((nts2 >> b1) & 1);
+    const bool c1I = g1 && ((mask0 >> b1) & 1);
+    const bool c1D = g0 && ((nts1 >> b0) & 1);
+    const bool c2I = g2 && mes >= 2 && ((mask0 >> b2) & 1);
+    const bool c2D = g0 && mes >= 2 && ((nts2 >> b0) & 1);
+    // this lane's hypothesis
+    int type; uint32_t nt0, nt1;
+    w_hyp(lane, &type, &nt0, &nt1);
+    const uint64_t base0 = v0 - oldnt + nt0;  // corrected read kmer (wraps on NAN64 like the reference)
+    const uint64_t prevk = backward ? revcomp2(sm.km[ki], k) : sm.km[ki - 1];  // kmers[ki - 1] of the corrected array
+    const bool two = type == H_2X || type == H_XD || type == H_2D;
+    const bool seeded = ((mask0 >> nt0) & 1) && (!two || ((nn1[nt0] >> nt1) & 1));
+    bool alive = false;
+    uint64_t cr = 0;
+    uint32_t nn = 0;
+    int j0 = 0, jl = 0;
+    const int lim0 = (int)k < n ? (int)k : n, lim1 = (int)k + 1 < n ? (int)k + 1 : n, lim2 = (int)k + 2 < n ? (int)k + 2 : n;
+    switch (type) {
+        case H_1X: alive = c1X && seeded; cr = base0; nn = nn1[nt0]; j0 = 1; jl = lim1; break;
+        case H_1D: alive = c1D && seeded; cr = base0; nn = nn1[nt0]; j0 = 0; jl = lim0; break;
+        case H_1I: alive = c1I; cr = prevk; nn = mask0; j0 = 1; jl = lim1; break;
+        case H_2X: alive = c2X && seeded; cr = w_roll(base0, rmask, nt1); nn = sm.cube[4 + 4 * nt0 + nt1]; j0 = 2; jl = lim2; break;
+        case H_XD: alive = cXD && seeded; cr = w_roll(base0, rmask, nt1); nn = sm.cube[4 + 4 * nt0 + nt1]; j0 = 1; jl = lim1; break;
+        case H_2D: alive = c2D && seeded; cr = w_roll(base0, rmask, nt1); nn = sm.cube[4 + 4 * nt0 + nt1]; j0 = 0; jl = lim0; break;
+        case H_XI: alive = cXI && seeded; cr = base0; nn = nn1[nt0]; j0 = 2; jl = lim2; break;
+        case H_2I: alive = c2I; cr = prevk; nn = mask0; j0 = 2; jl = lim2; break;
+        default: break;
+    }
+    uint32_t cnt = 0;
+    for (int j = 0; j < lim2; ++j) {
+        if (!x.ballot(alive && j < jl)) break;
+        const uint64_t vj = V(j);
+        const bool act = alive && j >= j0 && j < jl;
+        if (act) {
+            if (vj == NAN64) alive = false;  // good[j] is false
+            else {
+                cr = w_roll(cr, rmask, vj % 4);
+                if ((nn >> (cr % 4)) & 1) {
+                    ++cnt;
+                    const uint32_t g = w_info(T, locus, cr, k, nullptr);  // getNextNucs: only an existing node replaces the set
+                    if (g & GR_HAS) nn = g & 0xFu;
+                } else alive = false;
+            }
+        }
+    }
+    // get_edit: the strictly best score in scan order; one edit needs >= MSC extended k-mers, two edits >= 2 MSC and mes > 1
+    const bool twoed = type == H_2X || type == H_XD || type == H_2D || type == H_XI || type == H_2I;
+    const bool valid = type != H_NONE && cnt >= (twoed ? 2 * W_MSC : W_MSC) && (!twoed || mes > 1);
+    const uint32_t key = valid ? (cnt << 8) | (255u - (uint32_t)lane) : 0u;
+    const uint32_t best = ~x.wave_min(~key);
+    *wscore = best >> 8;
+    *wid = (int)(255u - (best & 255u));
+    return best == 0;
+}
+
+// the edits of a hypothesis: t[], g[] (graph base letters), returns how many
+DBTK_HD uint8_t w_letter(uint32_t nt) { return (uint8_t)(0x54474341u >> (8 * nt)); }  // alphabet[nt]: 'A' 'C' 'G' 'T'
+DBTK_HD int w_edits(int id, uint8_t t[2], uint8_t g[2]) {
+    int type; uint32_t nt0, nt1;
+    w_hyp(id, &type, &nt0, &nt1);
+    t[0] = t[1] = 0; g[0] = g[1] = 0;
+    switch (type) {
+        case H_1X: t[0] = 'X'; g[0] = w_letter(nt0); return 1;
+        case H_1D: t[0] = 'D'; g[0] = w_letter(nt0); return 1;
+        case H_1I: t[0] = 'I'; return 1;
+        case H_2X: t[0] = 'X'; g[0] = w_letter(nt0); t[1] = 'X'; g[1] = w_letter(nt1); return 2;
+        case H_XD: t[0] = 'X'; g[0] = w_letter(nt0); t[1] = 'D'; g[1] = w_letter(nt1); return 2;
+        case H_2D: t[0] = 'D'; g[0] = w_letter(nt0); t[1] = 'D'; g[1] = w_letter(nt1); return 2;
+        case H_XI: t[0] = 'X'; g[0] = w_letter(nt0); t[1] = 'I'; return 2;
+        case H_2I: t[0] = 'I'; t[1] = 'I'; return 2;
+        default: return 0;
+    }
+}
+
+// Block shift of the walk's arrays by the whole wave: elements [from, n) move by `d` (+: towards the end).
+template <class X, class E>
+DBTK_HD void w_shift(X& x, E* a, int from, int n, int d) {
+    const int lane = x.lane();
+    constexpr int R = (WCAP + 63) / 64;
+    E v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int i = from + 64 * r + lane; if (i < n) v[r] = a[i]; }
+    x.sync();
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int i = from + 64 * r + lane; if (i < n && i + d >= 0 && i + d < WCAP) a[i + d] = v[r]; }
+    x.sync();
+}
+
+// One read through isThreadFeasible.  The read's arrays must be in sm (walk_load).  Returns ret (wave-uniform).
+template <class X>
+DBTK_HD int walk_read(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_t& P, uint32_t locus, int len, WalkState& S) {
+    const int lane = x.lane();
+    const uint32_t k = T.ksize;
+    const uint64_t rmask = (1ull << 2 * (k - 1)) - 1;
+    const bool correction = P.correction != 0;
+    const uint64_t maxc = P.maxncorrection;
+    S.ki = 0; S.ni = 0; S.nkm = len - (int)k + 1; S.nes = len; S.ntr = S.nkm; S.nskip = 0; S.ncorr = 0; S.flags = 0;
+    const uint64_t nkmers = (uint64_t)S.nkm;  // frozen (AQ.cpp:1126)
+    const uint64_t maxnskip = nkmers >= P.thread_cth ? nkmers - P.thread_cth : 0;
+
+    auto refresh = [&](int lo, int hi) {  // graph info of km[lo, hi) again (they were rewritten)
+        if (lo < 0) lo = 0;
+        if (hi > S.nkm) hi = S.nkm;
+        x.sync();
+        for (int i = lo + lane; i < hi; i += 64) sm.gi[i] = (uint16_t)w_info(T, locus, sm.km[i], k, nullptr);
+        x.sync();
+    };
+    // find_anchor, AQ.cpp:878-888
+    auto find_anchor = [&]() -> bool {
+        for (;;) {
+            const int p = S.ki + lane;
+            const bool is = p < S.nkm && (sm.gi[p] & GR_HAS);
+            const uint64_t m = x.ballot(is);
+            const int lim = S.nkm - S.ki < 64 ? S.nkm - S.ki : 64;
+            const int adv = m ? __builtin_ctzll(m) : lim;
+            S.nskip += (uint64_t)adv; S.ni += adv; S.ki += adv;
+            if (m) break;
+            if (S.ki >= S.nkm) return false;
+        }
+        x.sync();
+        if (lane == 0) sm.tr[S.ki] = (sm.gi[S.ki] & GR_TR) ? '=' : '.';
+        if (lane < (int)k && sm.es_t[S.ni + lane] == '*') sm.es_t[S.ni + lane] = '=';
+        x.sync();
+        return true;
+    };
+
+    // edit_kmers_forward, AQ.cpp:828-862
+    auto edit_forward = [&](int wid, uint32_t score) {
+        uint8_t et[2], eg[2];
+        const int ne = w_edits(wid, et, eg);
+        int nm = 0, nd = 0, nins = 0;
+        for (int e = 0; e < ne; ++e) { nm += et[e] == 'X'; nd += et[e] == 'D'; nins += et[e] == 'I'; }
+        const int ki0 = S.ki, dt_km = nd - nins, dt_ki = nm + nd;
+        const int n0 = S.nkm - ki0;
+        // the bases to roll in after kmers[ki0 - 1]: the graph bases of the X / D edits, then the read's own bases from
+        // old position ki0 + nm + nins on, while they are good and the rewritten k-mer stays inside min(size, ki + k)
+        x.sync();
+        if (lane < 40) {
+            uint8_t b = 4;
+            int q = 0;
+            for (int e = 0; e < ne; ++e) if (et[e] != 'I') { if (lane == q) b = (uint8_t)w_code(eg[e]); ++q; }
+            if (lane >= dt_ki) {
+                const int o = nm + nins + (lane - dt_ki);  // old offset from ki0
+                if (o < n0 && sm.km[ki0 + o] != NAN64) b = (uint8_t)(sm.km[ki0 + o] % 4);
+            }
+            sm.bases[lane] = b;
+        }
+        x.sync();
+        if (dt_km) {
+            const int from = ki0 + nm + nins;
+            w_shift(x, sm.km, from, S.nkm, dt_km);
+            w_shift(x, sm.gi, from, S.nkm, dt_km);
+            S.nkm += dt_km;
+            if (S.nkm > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; S.nkm = WCAP; }
+        }
+        const int ki = ki0 + dt_ki;
+        int nb = dt_ki;  // rewritten k-mers: the corrected ones, then the extended ones
+        {
+            const int lim = S.nkm < ki + (int)k ? S.nkm : ki + (int)k;
+            for (int i = ki; i < lim; ++i) { if (sm.bases[nb] > 3) break; ++nb; }
+        }
+        {
+            uint64_t v = sm.km[ki0 - 1];
+            if (lane < nb) {
+                for (int q = 0; q <= lane; ++q) v = w_roll(v, rmask, sm.bases[q]);
+            }
+            x.sync();
+            if (lane < nb) sm.km[ki0 + lane] = v;
+        }
+        refresh(ki0, ki0 + nb);
+        if (dt_km) {  // cg.tr.resize(size + dt_km, '*')
+            const int nn = S.ntr + dt_km;
+            for (int i = S.ntr + lane; i < nn && i < WCAP; i += 64) sm.tr[i] = '*';
+            S.ntr = nn > WCAP ? WCAP : nn;
+        }
+        if (nd) {  // cg.es.insert(begin + ni + k - 1 + nm, edit_t('D', 0, '*')) x nd
+            const int at = S.ni + (int)k - 1 + nm;
+            w_shift(x, sm.es_t, at, S.nes, nd);
+            w_shift(x, sm.es_r, at, S.nes, nd);
+            w_shift(x, sm.es_g, at, S.nes, nd);
+            if (lane < nd) { sm.es_t[at + lane] = 'D'; sm.es_r[at + lane] = 0; sm.es_g[at + lane] = '*'; }
+            S.nes += nd;
+            if (S.nes > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; S.nes = WCAP; }
+        }
+        x.sync();
+        for (int i = lane; i < dt_ki + (int)score; i += 64) sm.tr[ki0 + i] = (sm.gi[ki0 + i] & GR_TR) ? '=' : '.';
+        if (lane < ne) { sm.es_t[S.ni + (int)k - 1 + lane] = et[lane]; sm.es_g[S.ni + (int)k - 1 + lane] = eg[lane]; }
+        for (int i = lane; i < (int)score; i += 64) sm.es_t[S.ni + ne + (int)k - 1 + i] = '=';
+        x.sync();
+        S.ni += ne + (int)score - 1;
+        S.ki = ki + (int)score - 1;  // the last edited kmer
+        S.ncorr += (uint64_t)ne;
+    };
+
+    // edit_kmers_backward, AQ.cpp:649-825, for the anchor at *pki; txt's nm / nd / ni / score are handed back
+    auto edit_backward = [&](int wid, uint32_t score, int* pki, int* onm, int* ond, int* oni) {
+        uint8_t et[2], eg[2];
+        const int ne = w_edits(wid, et, eg);
+        int nm = 0, nd = 0, nins = 0;
+        for (int e = 0; e < ne; ++e) { nm += et[e] == 'X'; nd += et[e] == 'D'; nins += et[e] == 'I'; }
+        *onm = nm; *ond = nd; *oni = nins;
+        const int dt_km = nd - nins;
+        int ki = *pki;
+        S.ni += nd;
+        if (dt_km > 0) {  // kmers.insert(begin + ki, 0) / cg.tr.insert(begin + ki, '*'), dt_km times
+            w_shift(x, sm.km, ki, S.nkm, dt_km);
+            w_shift(x, sm.gi, ki, S.nkm, dt_km);
+            w_shift(x, sm.tr, ki, S.ntr, dt_km);
+            if (lane < dt_km) { sm.km[ki + lane] = 0; sm.gi[ki + lane] = 0; sm.tr[ki + lane] = '*'; }
+        } else if (dt_km < 0) {  // erase [ki + dt_km, ki)
+            w_shift(x, sm.km, ki, S.nkm, dt_km);
+            w_shift(x, sm.gi, ki, S.nkm, dt_km);
+            w_shift(x, sm.tr, ki, S.ntr, dt_km);
+        }
+        S.nkm += dt_km; S.ntr += dt_km;
+        if (S.nkm > WCAP || S.ntr > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; if (S.nkm > WCAP) S.nkm = WCAP; if (S.ntr > WCAP) S.ntr = WCAP; }
+        ki += dt_km;
+        x.sync();
+        // corrected kmers (X / D edits, walking down from the anchor), then extended ones while the old k-mers were good:
+        // kmers[i - 1] = (kmers[i] >> 2) + leading base, the base being the complement of the edit's graph base or
+        // the old k-mer's own
+        const int ncor = nm + nd;
+        const int ki_ = ki - ncor;
+        int next = 0;  // extended
+        {
+            int lo = ki_ - (int)k; if (lo < 0) lo = 0;
+            for (int i = ki_; i > lo; --i) { if (sm.km[i - 1] == NAN64) break; ++next; }
+        }
+        if (lane < 40) {
+            uint8_t b = 0;
+            int q = 0;
+            for (int e = 0; e < ne; ++e) if (et[e] != 'I') { if (lane == q) b = (uint8_t)(3 - w_code(eg[e])); ++q; }
+            if (lane >= ncor && lane < ncor + next) b = (uint8_t)(sm.km[ki_ - 1 - (lane - ncor)] >> (2 * (k - 1)));
+            sm.bases[lane] = b;
+        }
+        x.sync();
+        {
+            uint64_t v = sm.km[ki];
+            if (lane < ncor + next) {
+                for (int q = 0; q <= lane; ++q) v = (v >> 2) + ((uint64_t)sm.bases[q] << (2 * (k - 1)));
+            }
+            x.sync();
+            if (lane < ncor + next) sm.km[ki - 1 - lane] = v;
+        }
+        refresh(ki - ncor - next, ki);
+        // the rest is sequential byte work on a few entries: lane 0
+        if (lane == 0) {
+            uint64_t nrk = 0;
+            const int lb = ki - nm - nd - (int)score;
+            for (int i = ki - 1; i >= lb; --i) {
+                if (sm.tr[i] == '*') ++nrk;
+                sm.tr[i] = (sm.gi[i] & GR_TR) ? '=' : '.';
+            }
+            nrk -= (uint64_t)(nm + nd);
+            uint64_t nskip = S.nskip - nrk, ncorr = S.ncorr + (uint64_t)ne;
+            int ni = S.ni, nes = S.nes;
+            auto es_ins = [&](int at) {
+                if (nes >= WCAP) return;
+                for (int i = nes; i > at; --i) { sm.es_t[i] = sm.es_t[i - 1]; sm.es_r[i] = sm.es_r[i - 1]; sm.es_g[i] = sm.es_g[i - 1]; }
+                sm.es_t[at] = 'D'; sm.es_r[at] = 0; sm.es_g[at] = '*';
+                ++nes;
+            };
+            auto es_del = [&](int at) {
+                for (int i = at; i + 1 < nes; ++i) { sm.es_t[i] = sm.es_t[i + 1]; sm.es_r[i] = sm.es_r[i + 1]; sm.es_g[i] = sm.es_g[i + 1]; }
+                --nes;
+            };
+            auto t_at = [&](int i) -> uint8_t { return (i < 0 || i >= nes) ? (uint8_t)0 : sm.es_t[i]; };
+            int cni = 0;  // cumulative # of ins
+            const int nti_ = ki - dt_km;
+            for (int i = 0; i < nti_ + cni; ++i) if (sm.es_t[i] == 'I') ++cni;
+            int nti = nti_ + cni - 1;  // cg.tr index -> cg.es index
+            for (int i = 0; i < ne; ++i, --nti) {  // CIGAR of edits
+                if (et[i] == 'D') { ++nti; es_ins(nti); }
+                if (sm.es_t[nti] == 'D') {
+                    if (et[i] == 'I') { es_del(nti); --ni; }  // delete edit immediately
+                    else sm.es_g[nti] = w_comp_char(eg[i]);
+                } else {
+                    while (sm.es_t[nti] == 'I') --nti;
+                    sm.es_t[nti] = et[i];
+                    sm.es_g[nti] = eg[i] ? w_comp_char(eg[i]) : (uint8_t)0;
+                }
+            }
+            int e0 = nti + 1, e1 = e0;
+            for (uint32_t i = 0; i < score; ++i, --nti) {  // CIGAR of extended alignment
+                const uint8_t c = sm.es_t[nti];
+                if (c == '=') { }
+                else if (c == '*') sm.es_t[nti] = '=';
+                else break;
+            }
+            {   // find edit_tract
+                uint8_t c = t_at(e1);
+                while (c == 'X' || c == 'D' || c == 'I') { ++e1; c = t_at(e1); }
+                c = t_at(e0 - 1);
+                while (c == 'X' || c == 'D' || c == 'I') { --e0; c = t_at(e0 - 1); }
+            }
+            // merge edits if possible: rnts / gnts = the read / graph bases inside the tract
+            int nets = e1 - e0, nr = 0, ng = 0;
+            for (int i = e0; i < e1; ++i) { nr += sm.es_r[i] != 0; ng += sm.es_g[i] != 0; }
+            auto rnt = [&](int q) -> uint8_t { for (int i = e0; i < e1; ++i) if (sm.es_r[i] && q-- == 0) return sm.es_r[i]; return 0; };
+            auto gnt = [&](int q) -> uint8_t { for (int i = e0; i < e1; ++i) if (sm.es_g[i] && q-- == 0) return sm.es_g[i]; return 0; };
+            if (nr == ng) {
+                bool no_edit = true;
+                for (int i = 0; i < nr; ++i) if (rnt(i) != gnt(i)) { no_edit = false; break; }
+                if (no_edit) {  // edits canceled out
+                    int dt_es = 0;
+                    for (int i = e0; i < e1; ++i) {
+                        if (sm.es_t[i + dt_es] == 'D') { es_del(i + dt_es); --dt_es; }
+                        else { sm.es_t[i + dt_es] = '='; sm.es_g[i + dt_es] = 0; }
+                    }
+                    ni += dt_es;
+                    ncorr -= (uint64_t)(e1 - e0);
+                    nskip -= (uint64_t)(e1 - e0);
+                } else if (nets != nr) {  // D + I (same position) -> X: the tract shrinks
+                    uint8_t rn[64], gn[64];
+                    for (int i = 0; i < nr && i < 64; ++i) { rn[i] = rnt(i); gn[i] = gnt(i); }
+                    int dt_es = 0;
+                    const int dt_es_ = nr - nets;
+                    int j = 0, kk = 0;
+                    for (int i = e0; i < e1; ++i) {
+                        if (sm.es_t[i + dt_es] == 'D' && dt_es != dt_es_) { es_del(i + dt_es); --dt_es; }
+                        else {
+                            if (rn[kk & 63] == gn[kk & 63]) { sm.es_t[i + dt_es] = '='; sm.es_g[i + dt_es] = 0; }
+                            else { sm.es_t[i + dt_es] = 'X'; sm.es_g[i + dt_es] = gn[j & 63]; }
+                            ++j; ++kk;
+                        }
+                    }
+                    ni += dt_es;
+                    ncorr += (uint64_t)(int64_t)dt_es;
+                    nskip += (uint64_t)(int64_t)dt_es;
+                } else {  // match / mismatch only
+                    for (int i = 0; i < nr; ++i) {
+                        if (sm.es_r[e0 + i] && sm.es_r[e0 + i] == sm.es_g[e0 + i]) {  // (here every entry has both bases) edit reverted
+                            sm.es_t[e0 + i] = '='; sm.es_g[e0 + i] = 0;
+                            --ncorr; --nskip;
+                        }
+                    }
+                }
+            } else {
+                for (int i = 0; i < nets; ++i) {
+                    if (sm.es_r[e0 + i] == sm.es_g[e0 + i]) { sm.es_t[e0 + i] = '='; sm.es_g[e0 + i] = 0; --ncorr; --nskip; }
+                }
+            }
+            sm.st[0] = ni; sm.st[1] = nes;
+            sm.st64[0] = nskip; sm.st64[1] = ncorr;
+        }
+        x.sync();
+        S.ni = (int)x.uni((uint32_t)sm.st[0]); S.nes = (int)x.uni((uint32_t)sm.st[1]);
+        {
+            const uint64_t a = sm.st64[0], b = sm.st64[1];
+            S.nskip = ((uint64_t)x.uni((uint32_t)(a >> 32)) << 32) | x.uni((uint32_t)a);
+            S.ncorr = ((uint64_t)x.uni((uint32_t)(b >> 32)) << 32) | x.uni((uint32_t)b);
+        }
+        x.sync();
+        if (S.nes > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; S.nes = WCAP; }
+        *pki = ki;
+    };
+
+#define W_FAIL_CHECK() do { if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) return -1; } while (0)
+    if (!find_anchor()) return 0;
+    if (S.ki > 0 && correction && S.ncorr < maxc && (uint32_t)S.ki >= W_MSC + 1) {  // leading unaligned kmers: backward first
+        const uint32_t mes = (uint32_t)S.ki >= 2 * W_MSC + 2 ? 2 : 1;
+        int wid; uint32_t score;
+        const bool skip = walk_ec(x, sm, T, locus, true, S.ki, S.nkm, mes, &wid, &score, &S.flags);
+        W_FAIL_CHECK();
+        if (!skip) { int a, b, c; edit_backward(wid, score, &S.ki, &a, &b, &c); W_FAIL_CHECK(); }
+    }
+    ++S.ki; ++S.ni;
+    while (S.ki < S.nkm) {
+        // runs of plain matches: k-mer p continues k-mer p - 1 and is one of its successors in the graph
+        {
+            const int p = S.ki + lane;
+            bool ism = false;
+            if (p < S.nkm) {
+                const uint64_t kv = sm.km[p], pv = sm.km[p - 1];
+                const uint32_t g = sm.gi[p - 1];
+                ism = kv != NAN64 && pv != NAN64 && kv != pv && (g & GR_HAS) && ((g >> (kv % 4)) & 1) && kv == w_roll(pv, rmask, kv % 4);
+            }
+            const uint64_t m = x.ballot(ism);
+            const int run = ~m ? __builtin_ctzll(~m) : 64;
+            if (run) {
+                if (lane < run) {
+                    sm.tr[p] = (sm.gi[p] & GR_TR) ? '=' : '.';
+                    sm.es_t[S.ni + (int)k - 1 + lane] = '=';
+                }
+                S.ki += run; S.ni += run;
+                continue;
+            }
+        }
+        x.sync();
+        const uint64_t kv = sm.km[S.ki], pv = sm.km[S.ki - 1];
+        if (kv == NAN64 || kv == pv) {  // "N" in read / homopolymer run
+            if (lane == 0) { sm.tr[S.ki] = '*'; sm.es_t[S.ni + (int)k - 1] = '*'; }
+            ++S.nskip;
+            if (S.nskip > maxnskip) return 0;
+            ++S.ki; ++S.ni;
+            continue;
+        }
+        if (pv == NAN64) {  // triggered after passing 'N'
+            if (!find_anchor()) break;
+            if (S.nskip > maxnskip) return 0;
+            ++S.ki; ++S.ni;
+            continue;
+        }
+        if (!(sm.gi[S.ki - 1] & GR_HAS)) { S.flags |= DBTK_THREAD_F_MISSING_NODE; return -1; }  // getOutNodes(node) asserts
+        // read kmer has no matching node in the graph, try error correction
+        if ((uint64_t)S.ki + W_MSC >= nkmers) {  // not enough info
+            S.nskip += nkmers - (uint64_t)S.ki;
+            return S.nskip <= maxnskip ? (S.ncorr ? 2 : 1) : 0;
+        }
+        if (correction && S.ncorr < maxc) {
+            uint32_t mes = (uint32_t)(S.nkm - S.ki) >= 2 * W_MSC + 2 ? 2 : 1;
+            int wid; uint32_t score;
+            bool skip = walk_ec(x, sm, T, locus, false, S.ki, S.nkm, mes, &wid, &score, &S.flags);
+            W_FAIL_CHECK();
+            if (!skip) {  // passed forward correction
+                uint8_t et[2], eg[2];
+                S.nskip += (uint64_t)w_edits(wid, et, eg);
+                if (S.nskip > maxnskip) return 0;
+                edit_forward(wid, score);
+                W_FAIL_CHECK();
+            } else {
+                if (!find_anchor()) break;
+                mes = 2;  // always have enough info to make 2 edits
+                skip = walk_ec(x, sm, T, locus, true, S.ki, S.nkm, mes, &wid, &score, &S.flags);
+                W_FAIL_CHECK();
+                if (!skip) {  // passed reverse correction
+                    int nm, nd, nins;
+                    edit_backward(wid, score, &S.ki, &nm, &nd, &nins);
+                    W_FAIL_CHECK();
+                    ++S.ncorr;
+                    uint64_t ki64 = (uint64_t)S.ki;
+                    uint64_t reach = ki64 - (uint64_t)nm - (uint64_t)nd;
+                    uint64_t gap = (k < reach ? k : reach) - score;
+                    uint64_t ki0 = ki64, ki1 = ki64;
+                    uint32_t sc = score;
+                    while (!skip && gap) {  // forward and backward threads not fully patched
+                        ki0 = ki1;
+                        ki1 = ki0 - (uint64_t)nm - (uint64_t)nd - sc;
+                        mes = ki1 >= 2 * W_MSC + 2 ? 2 : 1;
+                        if (ki1 < W_MSC + 1) break;
+                        if (!(sm.gi[ki1] & GR_HAS)) { S.flags |= DBTK_THREAD_F_MISSING_NODE; return -1; }  // assert(g.count(node_))
+                        skip = walk_ec(x, sm, T, locus, true, (int)ki1, S.nkm, mes, &wid, &sc, &S.flags);
+                        W_FAIL_CHECK();
+                        if (!skip) {
+                            int k1 = (int)ki1;
+                            edit_backward(wid, sc, &k1, &nm, &nd, &nins);
+                            W_FAIL_CHECK();
+                            ki1 = (uint64_t)k1;
+                            S.ki += nd - nins;
+                            reach = ki1 - (uint64_t)nm - (uint64_t)nd;
+                            gap = (k < reach ? k : reach) - sc;
+                        }
+                    }
+                    if (gap) {  // annot_gap, AQ.cpp:1108-1111
+                        x.sync();
+                        for (uint64_t i = lane; i < gap; i += 64) { const int64_t q = (int64_t)ki1 - 1 - (int64_t)i; if (q >= 0 && q < WCAP) sm.tr[q] = '*'; }
+                        x.sync();
+                        S.nskip -= gap;
+                    }
+                    if (S.nskip > maxnskip) return 0;
+                }
+                if (skip) {  // either initial or iterative backward correction failed
+                    if (!find_anchor()) break;
+                    if (S.nskip > maxnskip) return 0;
+                }
+            }
+        } else {
+            if (!find_anchor()) break;
+            if (S.nskip > maxnskip) return 0;
+        }
+        ++S.ki; ++S.ni;
+    }
+#undef W_FAIL_CHECK
+    return (S.nskip <= maxnskip && S.ncorr <= maxc) ? (S.ncorr ? 2 : 1) : 0;
+}
+
+// Read r of the batch into the walk's LDS arrays: k-mers, their graph info at `locus`, cg.init (AQ.cpp:62-67).
+// Returns the read's length, 0 when it is shorter than k or longer than the arrays (flagged).
+template <class X>
+DBTK_HD int walk_load(X& x, WalkSmem& sm, const DevTables& T, const uint8_t* seq, uint64_t o0, uint64_t o1, uint32_t locus,
+                      uint32_t* slot, uint64_t* noncak, uint32_t* errflag) {
+    const int lane = x.lane();
+    const uint32_t k = T.ksize;
+    uint32_t len = (uint32_t)(o1 - o0);
+    if (len > (uint32_t)MAXL) { if (lane == 0 && errflag) *errflag = DBTK_ERR_READ_TOO_LONG; len = MAXL; }
+    const uint64_t a0 = o0 & ~3ull;
+    const uint32_t rsh = (uint32_t)(o0 - a0), nw = (rsh + len + 3) >> 2;
+    x.sync();
+    for (uint32_t w = lane; w < nw; w += 64) sm.raw[w] = *reinterpret_cast<const uint32_t*>(seq + a0 + 4ull * w);
+    if (lane < 4) sm.raw[nw + lane] = 0;
+    x.sync();
+    if (lane < 16) {
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t v = 0;
+            if (16u * lane + 4 * q < len) {
+                const uint32_t B = rsh + 16 * lane + 4 * q, j = B >> 2, r8 = 8 * (B & 3);
+                const uint32_t lo = sm.raw[j], hi = sm.raw[j + 1];
+                v = r8 ? ((lo >> r8) | (hi << (32 - r8))) : lo;
+                const uint32_t left = len - (16 * lane + 4 * q);
+                if (left < 4) v &= (1u << (8 * left)) - 1;
+            }
+            w[q] = v;
+        }
+        uint32_t vd;
+        sm.pk[lane] = pack16(w, &vd);
+        sm.vd[lane] = (uint16_t)vd;  // bytes past the read are 0 -> invalid
+        if (lane < 4) { sm.pk[16 + lane] = 0; sm.vd[16 + lane] = 0; }
+    }
+    x.sync();
+    const int nk = len >= k ? (int)(len - k + 1) : 0;
+    for (int i = lane; i < (int)len; i += 64) {
+        const uint32_t B = rsh + (uint32_t)i;
+        sm.es_t[i] = '*';
+        sm.es_r[i] = (uint8_t)(sm.raw[B >> 2] >> (8 * (B & 3)));
+        sm.es_g[i] = 0;
+    }
+    for (int i = lane; i < NKMAX; i += 64) {
+        uint64_t fw = NAN64;
+        uint32_t sl = NAN32, g = 0;
+        if (i < nk) {
+            uint64_t f;
+            if (window_kmer(sm.pk, sm.vd, (uint32_t)i, k, &f, nullptr) != NAN64) fw = f;
+            g = w_info(T, locus, fw, k, &sl);
+            sm.km[i] = fw;
+            sm.gi[i] = (uint16_t)g;
+            sm.tr[i] = '*';
+            if (noncak) noncak[i] = fw;
+        }
+        if (slot) slot[i] = sl;
+    }
+    x.sync();
+    return (int)len;
+}
+
+// What the walk left in LDS -> a thread record in HBM.
+template <class X>
+DBTK_HD void walk_store(X& x, const WalkSmem& sm, const WalkState& S, int ret, dbtk_thread_rec_t* o) {
+    const int lane = x.lane();
+    x.sync();
+    if (lane == 0) {
+        o->ret = ret; o->ni = S.ni; o->nkm = (uint32_t)S.nkm; o->nes = (uint32_t)S.nes; o->ntr = (uint32_t)S.ntr; o->flags = S.flags;
+    }
+    for (int i = lane; i < WCAP; i += 64) {
+        o->es_t[i] = i < S.nes ? sm.es_t[i] : (uint8_t)0;
+        o->es_r[i] = i < S.nes ? sm.es_r[i] : (uint8_t)0;
+        o->es_g[i] = i < S.nes ? sm.es_g[i] : (uint8_t)0;
+        o->tr[i] = i < S.ntr ? sm.tr[i] : (uint8_t)0;
+        o->kmers[i] = i < S.nkm ? sm.km[i] : 0ull;
+    }
+    x.sync();
+}
+
+// Function mode: read r against read_locus[r] (one wave per read, reads at a fixed stride).
+template <class X>
+DBTK_HD void body_walk_reads(X& x, const WalkArgs& a) {
+    WalkSmem& sm = *x.template smem<WalkSmem>();
+    const uint32_t k = a.T.ksize;
+    for (uint32_t r = x.bid(); r < a.nreads; r += x.nblocks()) {
+        const uint64_t o0 = a.off[r], o1 = a.off[r + 1];
+        const uint32_t locus = a.read_locus[r];
+        WalkState S;
+        int ret = -1;
+        const int len = walk_load(x, sm, a.T, a.seq, o0, o1, locus, nullptr, a.noncak ? a.noncak + (size_t)r * MAXL : nullptr, a.errflag);
+        // the reference indexes kmers[0] of an empty vector when the read has no valid k-mer (the hot path never
+        // hands such a read to the walk: both mates have one, AQ.cpp:2037)
+        bool any = false;
+        for (int i = x.lane(); i < len - (int)k + 1; i += 64) any |= sm.km[i] != NAN64;
+        if (len >= (int)k && locus < a.T.nloci && x.ballot(any)) ret = walk_read(x, sm, a.T, a.P, locus, len, S);
+        else { S.ki = 0; S.ni = 0; S.nkm = 0; S.nes = 0; S.ntr = 0; S.nskip = 0; S.ncorr = 0; S.flags = DBTK_THREAD_F_OVERFLOW; }
+        if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) ret = -1;
+        walk_store(x, sm, S, ret, &a.trecs[r]);
+    }
+}
+
+// Pair mode, the v1.3 call-site glue (AQ.cpp:2072-2088, 2090-2092, 2189-2194): both mates of an assigned pair are
+// walked through graphDB[destLocus]; if either walk is feasible the pair is kept (nFeasibleReads += 2) and every
+// uncorrected k-mer of both mates that is a TR k-mer of the locus is counted ("exact" mode: the canonical multiset of
+// the reads' k-mers added to trKmers, i.e. one increment per position); else destLocus = nloci.
+template <class X>
+DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
+    WalkSmem& sm = *x.template smem<WalkSmem>();
+    const int lane = x.lane();
+    uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
+    const uint32_t nsurv = *a.nsurv;
+    uint64_t c_feas = 0, c_inc = 0;
+    for (uint32_t t = x.bid(); t < nsurv; t += x.nblocks()) {
+        const uint32_t dst = a.walk_dst[t];
+        if (dst == NAN32) continue;
+        const uint32_t pair = a.surv[t];
+        int ret[2];
+        for (int m = 0; m < 2; ++m) {
+            const uint64_t o0 = a.off[2 * (uint64_t)pair + m], o1 = a.off[2 * (uint64_t)pair + m + 1];
+            WalkState S;
+            const int len = walk_load(x, sm, a.T, a.seq, o0, o1, dst, sm.slot[m], nullptr, a.errflag);
+            ret[m] = walk_read(x, sm, a.T, a.P, dst, len, S);
+            if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) { ret[m] = 0; if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_FORMAT; }
+            if (a.trecs) walk_store(x, sm, S, ret[m], &a.trecs[2 * (size_t)t + m]);
+        }
+        const bool alned = ret[0] || ret[1];
+        x.sync();
+        if (alned) {
+            c_feas += 2;
+            for (int m = 0; m < 2; ++m)
+                for (int i = lane; i < NKMAX; i += 64) {
+                    const uint32_t s = sm.slot[m][i];
+                    const bool hit = s != NAN32;
+                    if (hit) x.atomic_add(&a.counts[s], 1ull);
+                    c_inc += (uint64_t)__builtin_popcountll(x.ballot(hit));
+                }
+        }
+        if (lane == 0) {
+            a.walk_dst[t] = alned ? dst : a.T.nloci;
+            a.walk_ret[t] = ((uint32_t)ret[0] & 0xFFu) | (((uint32_t)ret[1] & 0xFFu) << 8);
+        }
+        x.sync();
+    }
+    if (lane == 0) {
+        if (c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], c_feas);
+        if (c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], c_inc);
+    }
+}
+
+}  // namespace dbtk
+#endif

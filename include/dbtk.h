@@ -193,6 +193,8 @@ enum {
 /* Load PREF.{tr.kmers,kmers.dbi,fl.kdb,tre.kdb} (+ optional qc / bait files,
  * NULL to skip).  Replaces src/aQueryFasta_thread.cpp:2459,2490-2500. */
 #define DBTK_LOAD_INDEX_ONLY 1u  /* -e (extract) mode: only PREF.tr.kmers + PREF.kmers.dbi are read (AQ.cpp:2484-2488) */
+#define DBTK_LOAD_GRAPH 2u       /* also graphDB for threading = 2: PREF.graph.kmers (text, readGraphKmers AQ.h:550-575), or,
+                                    when that file is absent, the v1.3 binary PREF.graph.umap */
 dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_file,
                              const char* bait_file, uint32_t flags, dbtk_rpgg_t** out);
 /* Same handle from caller arrays (copied). */
@@ -227,6 +229,21 @@ dbtk_status_t dbtk_align_batch(dbtk_ctx_t* ctx, const uint8_t* seq_bytes,
                                const uint64_t* seq_offsets, const uint8_t* qual_bytes,
                                uint64_t npairs, dbtk_pair_rec_t* recs, uint64_t rec_cap,
                                uint64_t* nrec);
+
+/* ---- graph walk (threading = 2) ------------------------------------------------------------
+ * Function-level entry: read r = seq_bytes[seq_offsets[r] .. seq_offsets[r+1]) is walked through graphDB[loci[r]] with
+ * the context's thread_cth / correction / maxncorrection: cigar_t::init + isThreadFeasible
+ * (src/aQueryFasta_thread.cpp:62-67, 1114-1260, as called at :2073-2076).  recs[nreads] receives what the walk left
+ * behind; ret = -1 (with a flag) where the reference would have asserted, and for a read without any valid k-mer
+ * (which the hot path never hands to the walk).  Host buffers; needs the graph in the RPGG handle (DBTK_LOAD_GRAPH). */
+dbtk_status_t dbtk_thread_batch(dbtk_ctx_t* ctx, const uint8_t* seq_bytes, const uint64_t* seq_offsets,
+                                const uint32_t* loci, uint64_t nreads, dbtk_thread_rec_t* recs);
+/* What threading did to the pairs of the last dbtk_align_batch call that reached it (AQ.cpp:2070-2088), in pair order:
+ * destLocus afterwards (nloci = neither mate's walk was feasible) and isThreadFeasible's two return codes
+ * (ret1: seq1 = read 2p, ret2: seq2 = read 2p+1).  trecs (NULL, or 2 * cap entries: seq1's then seq2's record of
+ * every result) needs params.trace or params.aln.  *n = number of results (DBTK_ERR_OVERFLOW if > cap). */
+typedef struct dbtk_walk_res { uint32_t pair, dst; int8_t ret1, ret2; uint8_t pad[2]; } dbtk_walk_res_t;
+dbtk_status_t dbtk_ctx_walk_results(dbtk_ctx_t* ctx, dbtk_walk_res_t* res, dbtk_thread_rec_t* trecs, uint64_t cap, uint64_t* n);
 
 /* Device-resident variant used when the reads already sit in HBM (bench, or a
  * caller that overlaps its own H2D copies): d_seq / d_offsets are device

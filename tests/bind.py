@@ -67,6 +67,15 @@ class Oracle:
         L.orc_sort_index.argtypes = [u64p, C.c_uint64, u64p]
         L.orc_umap_order.restype = C.c_int
         L.orc_umap_order.argtypes = [u64p, C.c_uint64, u64p]
+        L.orc_rpgg_load_graph.restype = C.c_int
+        L.orc_rpgg_load_graph.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_thread.restype = C.c_int
+        L.orc_thread.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32,
+                                 C.POINTER(abi.ThreadRec), u64p]
+        L.orc_write_cigar.restype = C.c_size_t
+        L.orc_write_cigar.argtypes = [C.POINTER(abi.ThreadRec), C.c_char_p, C.c_size_t]
+        L.orc_write_annot.restype = C.c_size_t
+        L.orc_write_annot.argtypes = [C.POINTER(abi.ThreadRec), C.c_char_p, C.c_size_t]
 
     def load(self, prefix, k, qc_file=None):
         h = self.L.orc_rpgg_load(prefix.encode(), k, qc_file.encode() if qc_file else None)
@@ -76,6 +85,23 @@ class Oracle:
 
     def from_arrays(self, arrs: "abi.RpggArrays"):
         return self.L.orc_rpgg_from_arrays(C.byref(arrs))
+
+    def load_graph(self, h, graph_file):
+        if self.L.orc_rpgg_load_graph(h, graph_file.encode()):
+            raise IOError(f"oracle could not load {graph_file}")
+
+    def thread(self, h, locus, read: bytes, params, rec=None):
+        """orc_thread: (ret, ThreadRec)."""
+        rec = rec if rec is not None else abi.ThreadRec()
+        r = self.L.orc_thread(h, locus, read, len(read), params.ksize, params.thread_cth, int(params.correction), params.maxncorrection,
+                              C.byref(rec), None)
+        return r, rec
+
+    def cigar_annot(self, rec):
+        b1, b2 = C.create_string_buffer(4096), C.create_string_buffer(4096)
+        self.L.orc_write_cigar(C.byref(rec), b1, 4096)
+        self.L.orc_write_annot(C.byref(rec), b2, 4096)
+        return b1.value.decode(), b2.value.decode()
 
     def free(self, h):
         self.L.orc_rpgg_free(h)
@@ -152,9 +178,21 @@ class Oracle:
 class RefHarness:
     """The real reference's functions (needs oracle/_ref/libdbtk_refharness.so)."""
 
-    def __init__(self):
+    def __init__(self, private_copy=False):
+        """private_copy: load a fresh copy of the library (own statics).  The reference keeps `static` constants
+        derived from the global ksize inside edit_kmers_backward (AQ.cpp:653-654): one loaded library can only
+        walk with the k of its first correction."""
         path = os.path.join(ROOT, "oracle", "_ref", "libdbtk_refharness.so")
-        L = self.L = C.CDLL(path)
+        if private_copy:
+            import shutil
+            import tempfile
+            fd, tmp = tempfile.mkstemp(suffix=".so", prefix="refharness_")
+            os.close(fd)
+            shutil.copyfile(path, tmp)
+            L = self.L = C.CDLL(tmp)
+            os.unlink(tmp)
+        else:
+            L = self.L = C.CDLL(path)
         L.ref_set_params.argtypes = [C.c_uint64] * 5
         L.ref_nurc.restype = C.c_uint64
         L.ref_nurc.argtypes = [C.c_uint64, C.c_uint64]
@@ -176,9 +214,26 @@ class RefHarness:
                                    C.c_uint64, u64p]
         L.ref_db_load_bait.argtypes = [C.c_void_p, C.c_char_p]
         L.ref_qstring2qmask.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, u8p]
+        L.ref_db_load_graph.argtypes = [C.c_void_p, C.c_char_p]
+        L.ref_set_thread_params.argtypes = [C.c_uint64, C.c_int]
+        L.ref_thread.restype = C.c_int
+        L.ref_thread.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.POINTER(abi.ThreadRec),
+                                 u64p, C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_int)]
 
     def set_params(self, p):
         self.L.ref_set_params(p.ksize, p.n_filter, p.nm_filter, p.max_nt, p.nm_tr)
+        self.L.ref_set_thread_params(p.maxncorrection, 0)
+
+    def load_graph(self, h, graph_kmers_file):
+        self.L.ref_db_load_graph(h, graph_kmers_file.encode())
+
+    def thread(self, h, locus, read: bytes, params, tc=False, rec=None):
+        """ref_thread: (ret, ThreadRec, cigar, annot, flagged by threadCheck)."""
+        rec = rec if rec is not None else abi.ThreadRec()
+        cig, ann, fl = C.create_string_buffer(4096), C.create_string_buffer(4096), C.c_int(0)
+        r = self.L.ref_thread(h, locus, read, len(read), params.thread_cth, int(params.correction), int(tc), C.byref(rec), None, cig, ann,
+                              4096, C.byref(fl))
+        return r, rec, cig.value.decode(), ann.value.decode(), fl.value
 
     def read2kmers_edges(self, read: bytes, k):
         n = max(len(read), 1)
@@ -297,6 +352,23 @@ class Emu(pkg._HostSide):
         L.emu_align.restype = C.c_int
         L.emu_align.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.Params), u8p, u64p, C.c_uint64, u64p, u64p, u32p, u64p,
                                 C.POINTER(abi.PairRec), C.c_uint64, u64p, C.c_uint32, C.c_uint32]
+        L.emu_thread_batch.restype = C.c_int
+        L.emu_thread_batch.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.Params), u8p, u64p, u32p, C.c_uint64,
+                                       C.POINTER(abi.ThreadRec), C.c_uint32]
+        L.emu_set_walk_trecs.argtypes = [C.POINTER(abi.ThreadRec)]
+        L.emu_walk_results.restype = C.c_uint64
+        L.emu_walk_results.argtypes = [C.POINTER(abi.WalkRes), u32p, C.c_uint64]
+
+    def thread(self, rpgg, tables, params, seq, off, loci, grid=5):
+        off = np.ascontiguousarray(off, np.uint64)
+        seq = np.ascontiguousarray(seq, np.uint8)
+        loci = np.ascontiguousarray(loci, np.uint32)
+        n = len(off) - 1
+        recs = (abi.ThreadRec * max(n, 1))()
+        rc = self.L.emu_thread_batch(rpgg.h, tables, C.byref(params), _p(seq, u8p), _p(off, u64p), _p(loci, u32p), n, recs, grid)
+        if rc:
+            raise RuntimeError(f"emu_thread_batch -> {rc}")
+        return recs
 
     def tables(self, rpgg):
         return self.L.emu_tables_create(rpgg.h)

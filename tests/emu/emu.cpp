@@ -255,6 +255,7 @@ struct EmuTables {
     std::vector<uint32_t> trbeg;
     std::vector<uint64_t> flt;
     std::vector<ClsSlot> tre, bait;
+    std::vector<GrSlot> gr;
     uint64_t stats[3] = {0, 0, 0};
     DevTables T;
 };
@@ -330,7 +331,38 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
         run_grid(3, 64, 0, [&](EmuX& x) { body_idx_aux(x, a); });
         T.consistent = (e->stats[1] == 0 && e->stats[0] == e->stats[2]) ? 1u : 0u;
     }
+    if (!g->gr_cnt.empty()) {  // graph table: graph pass, then TR pass (as build_graph_table does on the device)
+        const uint64_t ngr = g->gr_ks.size(), ntrf = g->tr_ks.size();
+        const uint64_t cap = pow2(ngr + ngr / 2 + 2 * ntrf + 2);
+        e->gr.assign(cap, GrSlot{NAN64, ~0ull});
+        std::vector<uint64_t> beg(nloci + 1, 0);
+        uint64_t nent = 0;
+        for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->gr_cnt[l];
+        GrBuildArgs a{e->gr.data(), cap - 1, 64 - lg(cap), g->ksize, g->gr_ks.data(), g->gr_ms.data(), beg.data(), (uint32_t)nloci, nullptr, e->trbeg.data(), ngr, &nent};
+        if (ngr) run_grid(3, 64, 0, [&](EmuX& x) { body_gr_insert(x, a); });
+        for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->tr_cnt[l];
+        a.ks = g->tr_ks.data(); a.ms = nullptr; a.outslot = g->out_slot.data(); a.n = ntrf;
+        if (ntrf) run_grid(3, 64, 0, [&](EmuX& x) { body_gr_insert(x, a); });
+        T.gr = e->gr.data(); T.gr_mask = cap - 1; T.gr_shift = 64 - lg(cap);
+    }
     return e;
+}
+
+// dbtk_thread_batch on the emulated lanes (body_walk_reads, dbtk_walk.h)
+int emu_thread_batch(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
+                     const uint32_t* loci, uint64_t nreads, dbtk_thread_rec_t* recs, uint32_t grid) {
+    EmuTables* e = (EmuTables*)tables;
+    if (!e->T.gr) return -1;
+    const uint64_t nbytes = off[nreads];
+    std::vector<uint64_t> seqbuf(nbytes / 8 + 8, 0);
+    memcpy(seqbuf.data(), seq, nbytes);
+    uint32_t err = 0;
+    WalkArgs w;
+    memset(&w, 0, sizeof(w));
+    w.T = e->T; w.P = *p; w.seq = (const uint8_t*)seqbuf.data(); w.off = off;
+    w.read_locus = loci; w.nreads = (uint32_t)nreads; w.trecs = recs; w.errflag = &err;
+    run_grid(grid ? grid : 1, 64, sizeof(WalkSmem), [&](EmuX& x) { body_walk_reads(x, w); });
+    return (int)err;
 }
 void emu_tables_free(void* e) { delete (EmuTables*)e; }
 uint32_t emu_tables_consistent(void* e) { return ((EmuTables*)e)->T.consistent; }
@@ -523,6 +555,19 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
                  dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec, uint32_t grid_k1, uint32_t grid_pair, BubEvent* ev,
                  uint64_t evcap, uint64_t* nev);
 
+// threading = 2: results of the last emu_align_ex (what dbtk_ctx_walk_results returns), thread records when a buffer was lent
+static std::vector<dbtk_walk_res_t> g_walk_res;
+static std::vector<uint32_t> g_walk_t;
+static dbtk_thread_rec_t* g_walk_trecs = nullptr;  // 2 per survivor index
+void emu_set_walk_trecs(dbtk_thread_rec_t* buf) { g_walk_trecs = buf; }
+uint64_t emu_walk_results(dbtk_walk_res_t* res, uint32_t* tidx, uint64_t cap) {
+    std::vector<size_t> ord(g_walk_res.size());
+    for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return g_walk_res[a].pair < g_walk_res[b].pair; });
+    for (size_t i = 0; i < ord.size() && i < cap; ++i) { res[i] = g_walk_res[ord[i]]; res[i].pad[0] = res[i].pad[1] = 0; if (tidx) tidx[i] = g_walk_t[ord[i]]; }
+    return g_walk_res.size();
+}
+
 // the binned encode stage: off (0), or on with 2^pb filter partitions, segments of `cap` queries and `nflt` filter waves
 static int g_keep_km = 0;  // 1: the k-mers travel from the probe body to the resolve body (the old way)
 void emu_set_keep_km(int on) { g_keep_km = on; }
@@ -559,6 +604,8 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     a.counts = accum.data(); a.kmc = a.counts + ntr; a.nmapread = a.kmc + nloci; a.counters = a.nmapread + nloci;
     a.recs = recs; a.rec_cap = (uint32_t)rec_cap;
     a.vote_scratch = vote.data(); a.vote_epoch = epoch.data();
+    std::vector<uint32_t> walk(2 * npairs + 2, NAN32);
+    a.walk_dst = walk.data();
     uint32_t maxlen = 1;
     for (uint64_t r = 0; r < 2 * npairs; ++r) maxlen = std::max<uint32_t>(maxlen, (uint32_t)(off[r + 1] - off[r]));
     const uint32_t nkmax = maxlen >= g->ksize ? maxlen - g->ksize + 1 : 1;
@@ -624,6 +671,21 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
                 if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<4, true>(x, a); else body_pair_usual<4, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<4>), [&](EmuX& x) { if (a.recs) body_pair<4, true>(x, a); else body_pair<4, false>(x, a); });
         }
+    }
+    if (p->threading == DBTK_THREADING_V13) {
+        WalkArgs w;
+        memset(&w, 0, sizeof(w));
+        w.T = e->T; w.P = *p; w.seq = a.seq; w.off = off;
+        w.surv = surv.data(); w.nsurv = &small[0];
+        w.walk_dst = walk.data(); w.walk_ret = walk.data() + npairs;
+        w.counts = a.counts; w.counters = a.counters;
+        w.trecs = g_walk_trecs; w.errflag = &small[3];
+        run_grid(grid_pair, 64, sizeof(WalkSmem), [&](EmuX& x) { body_walk_pairs(x, w); });
+        g_walk_res.clear();
+        for (uint32_t t = 0; t < small[0]; ++t)
+            if (walk[t] != NAN32) g_walk_res.push_back({surv[t], walk[t], (int8_t)(walk[npairs + t] & 0xFF), (int8_t)((walk[npairs + t] >> 8) & 0xFF), {(uint8_t)(t & 0xFF), (uint8_t)0}});
+        g_walk_t.clear();
+        for (uint32_t t = 0; t < small[0]; ++t) if (walk[t] != NAN32) g_walk_t.push_back(t);
     }
     if (small[3]) return (int)small[3];
     memcpy(counts, accum.data(), ntr * 8);
