@@ -13,9 +13,16 @@
  * (src/aQueryFasta_thread.cpp:2035-2158); only that glue is restated here,
  * every computation is the reference's.
  */
+/* The reference prints its records to std::cout (writeCigar, writeAnnot, writeAlignments ...).  The harness hands
+ * them back as strings, so `cout` inside the reference's translation unit is a stream the harness owns. */
+#include <iostream>
+#include <sstream>
+namespace std { static ostream dbtk_harness_cout(nullptr); }  /* (in std so that the reference's `using std::cout;` still parses) */
+#define cout dbtk_harness_cout
 #define main danbing_tk_reference_main
 #include "aQueryFasta_thread.cpp"
 #undef main
+#undef cout
 
 #include "../include/dbtk.h"
 
@@ -36,8 +43,8 @@ struct AbortTrap {
 /* std::cout captured while writeCigar / writeAnnot / writeAlignments run (they print, AQ.cpp:1683-1759) */
 struct CoutCapture {
     std::ostringstream ss; std::streambuf* old;
-    CoutCapture() { old = std::cout.rdbuf(ss.rdbuf()); }
-    ~CoutCapture() { std::cout.rdbuf(old); }
+    CoutCapture() { old = std::dbtk_harness_cout.rdbuf(ss.rdbuf()); std::dbtk_harness_cout.clear(); }
+    ~CoutCapture() { std::dbtk_harness_cout.rdbuf(old); }
 };
 void fill_thread_rec(dbtk_thread_rec_t* o, int ret, cigar_t& cg, vector<uint64_t>& kmers) {
     memset(o, 0, sizeof(*o));

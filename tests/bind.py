@@ -178,21 +178,9 @@ class Oracle:
 class RefHarness:
     """The real reference's functions (needs oracle/_ref/libdbtk_refharness.so)."""
 
-    def __init__(self, private_copy=False):
-        """private_copy: load a fresh copy of the library (own statics).  The reference keeps `static` constants
-        derived from the global ksize inside edit_kmers_backward (AQ.cpp:653-654): one loaded library can only
-        walk with the k of its first correction."""
+    def __init__(self):
         path = os.path.join(ROOT, "oracle", "_ref", "libdbtk_refharness.so")
-        if private_copy:
-            import shutil
-            import tempfile
-            fd, tmp = tempfile.mkstemp(suffix=".so", prefix="refharness_")
-            os.close(fd)
-            shutil.copyfile(path, tmp)
-            L = self.L = C.CDLL(tmp)
-            os.unlink(tmp)
-        else:
-            L = self.L = C.CDLL(path)
+        L = self.L = C.CDLL(path)
         L.ref_set_params.argtypes = [C.c_uint64] * 5
         L.ref_nurc.restype = C.c_uint64
         L.ref_nurc.argtypes = [C.c_uint64, C.c_uint64]

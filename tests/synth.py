@@ -314,6 +314,59 @@ def build_rpgg_arrays(loci: Loci, k=21):
                 tr_cnt=np.array(tr_cnt, np.uint64), tr_ks=np.concatenate(tr_ks).astype(np.uint64), nloci=loci.nloci)
 
 
+def fw_kmers(seq: np.ndarray, k: int) -> np.ndarray:
+    """Non-canonical k-mers of every window of an all-ACGT sequence."""
+    c = CODE[seq].astype(np.uint64)
+    win = np.lib.stride_tricks.sliding_window_view(c, k)
+    sh = (2 * np.arange(k - 1, -1, -1)).astype(np.uint64)
+    return (win << sh).sum(axis=1, dtype=np.uint64)
+
+
+def build_graph_arrays(loci: Loci, k=21):
+    """graphDB as buildKmerGraph makes it (src/aQueryFasta_thread.h:215-243: both strands of every haplotype,
+    out-edge bit per successor base, no self loops, the last k-mer of a strand present with whatever mask it has).
+    Returns (gr_cnt, gr_ks, gr_ms), nodes sorted within a locus."""
+    cnt, ks, ms = [], [], []
+    for l in range(loci.nloci):
+        g = {}
+        for h in range(loci.nhap):
+            s = loci.haps[h][l]
+            for strand in (s, revcomp(s)):
+                f = fw_kmers(strand, k)
+                nxt = CODE[strand[k:]]
+                for i in range(len(f) - 1):
+                    a, b = int(f[i]), int(f[i + 1])
+                    g[a] = g.get(a, 0) | ((1 << int(nxt[i])) if a != b else 0)
+                g[int(f[-1])] = g.get(int(f[-1]), 0)
+        nodes = sorted(g)
+        cnt.append(len(nodes)); ks += nodes; ms += [g[n] for n in nodes]
+    return np.array(cnt, np.uint64), np.array(ks, np.uint64), np.array(ms, np.uint8)
+
+
+def write_graph_file(gr, pref: str, binary=False):
+    """PREF.graph.kmers (text, what fa2kmers -g writes) or the v1.3 binary PREF.graph.umap."""
+    cnt, ks, ms = gr
+    if binary:
+        with open(pref + ".graph.umap", "wb") as f:
+            f.write(np.uint64(len(cnt)).tobytes())
+            i = 0
+            for n in cnt:
+                n = int(n)
+                f.write(np.uint64(n).tobytes())
+                rec = np.zeros(n, dtype=[("k", "<u8"), ("m", "u1")])
+                rec["k"] = ks[i:i + n]; rec["m"] = ms[i:i + n]
+                f.write(rec.tobytes())
+                i += n
+        return
+    with open(pref + ".graph.kmers", "w") as f:
+        i = 0
+        for l, n in enumerate(cnt):
+            f.write(f">{l}\n")
+            for j in range(i, i + int(n)):
+                f.write(f"{int(ks[j])}\t{int(ms[j])}\n")
+            i += int(n)
+
+
 def write_rpgg_files(arr, pref: str):
     """HEAD on-disk formats from flat arrays."""
     with open(pref + ".kmers.dbi", "wb") as f:

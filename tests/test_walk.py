@@ -1,0 +1,256 @@
+"""Graph-threading walk: isThreadFeasible and everything under it.
+
+  oracle (oracle/dbtk_oracle_walk.c)  ==  the reference itself (oracle/_ref/libdbtk_refharness.so: ref_thread)
+  emulated kernel body (dbtk_walk.h)   ==  oracle                                  [CPU suite]
+  k_walk_reads on the GPU (dbtk_thread_batch through the C-ABI) == oracle          [-m gpu]
+
+bit-exact on every output field: return code, cg.ni, the corrected k-mers, every edit operation (type, read base,
+graph base), every k-mer annotation, and the strings writeCigar / writeAnnot print.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from collections import Counter
+
+import sys
+
+import numpy as np
+import pytest
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.dirname(_HERE), _HERE):  # (also run as a script: the per-k worker of the oracle-vs-reference test)
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import bind  # noqa: E402
+import synth  # noqa: E402
+
+abi = bind.abi
+
+
+# ------------------------------------------------------------------ read sets --
+def _mutate_at(s: bytes, pos: int, kind: str, rng) -> bytes:
+    b = bytearray(s)
+    alt = lambda c: bytes([x for x in b"ACGT" if x != c])[int(rng.integers(0, 3))]
+    if kind == "X":
+        b[pos] = alt(b[pos])
+    elif kind == "XX":
+        b[pos] = alt(b[pos]); b[pos + 1] = alt(b[pos + 1])
+    elif kind == "I":
+        b.insert(pos, b"ACGT"[int(rng.integers(0, 4))]); b = b[:len(s)]
+    elif kind == "II":
+        b.insert(pos, b"ACGT"[int(rng.integers(0, 4))]); b.insert(pos, b"ACGT"[int(rng.integers(0, 4))]); b = b[:len(s)]
+    elif kind == "D":
+        del b[pos]; b.append(b"ACGT"[int(rng.integers(0, 4))])
+    elif kind == "DD":
+        del b[pos:pos + 2]; b += bytes(b"ACGT"[int(x)] for x in rng.integers(0, 4, 2))
+    elif kind == "XI":
+        b[pos] = alt(b[pos]); b.insert(pos + 1, b"ACGT"[int(rng.integers(0, 4))]); b = b[:len(s)]
+    elif kind == "XD":
+        b[pos] = alt(b[pos]); del b[pos + 1]; b.append(b"ACGT"[int(rng.integers(0, 4))])
+    elif kind == "N":
+        b[pos] = ord("N")
+    return bytes(b)
+
+
+def make_reads(loci, k, n, seed, sub=0.0, indel=0.0, nrate=0.0, targeted=0, wrong_locus=0.0, rlen=150):
+    """(reads, locus per read).  `targeted` reads carry exactly one edit of each class at a chosen place:
+    near the start (leading gap -> backward correction), in the middle, near the end (tail skip)."""
+    rng = np.random.default_rng(seed)
+    sim = synth.sim_reads(loci, npairs=(n + 1) // 2, seed=seed, sub=sub, indel=indel, nrate=nrate, rlen=rlen)
+    seqs, loc = [], []
+    for i, s in enumerate(sim.seqs[:n]):
+        l = int(re.match(r"r\d+:l(\d+)", sim.titles[i // 2]).group(1))
+        if len(s) < k:
+            continue
+        if rng.random() < wrong_locus:
+            l = int(rng.integers(0, loci.nloci))
+        seqs.append(s); loc.append(l)
+    kinds = ["X", "XX", "I", "II", "D", "DD", "XI", "XD", "N"]
+    clean = synth.sim_reads(loci, npairs=(targeted + 1) // 2, seed=seed + 1000, rlen=rlen)
+    for i, s in enumerate(clean.seqs[:targeted]):
+        l = int(re.match(r"r\d+:l(\d+)", clean.titles[i // 2]).group(1))
+        kind = kinds[i % len(kinds)]
+        where = (i // len(kinds)) % 4
+        pos = [int(rng.integers(0, 12)), int(rng.integers(12, 40)), int(rng.integers(40, rlen - 40)), int(rng.integers(rlen - 30, rlen - 3))][where]
+        s2 = _mutate_at(s, pos, kind, rng)
+        if (i // (4 * len(kinds))) % 2:  # a second edit elsewhere
+            s2 = _mutate_at(s2, int(rng.integers(5, rlen - 5)), kinds[int(rng.integers(0, len(kinds)))], rng)
+        seqs.append(s2); loc.append(l)
+    return seqs, loc
+
+
+def pack(seqs):
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    return np.frombuffer(b"".join(seqs), np.uint8).copy(), off
+
+
+class WalkCase:
+    def __init__(self, tmp, name, k, seed, nloci=8, motif=(3, 30), with_ref=True):
+        self.k = k
+        self.loci = synth.make_loci(nloci=nloci, nhap=3, seed=seed, motif_min=motif[0], motif_max=motif[1])
+        d = os.path.join(tmp, name)
+        os.makedirs(d, exist_ok=True)
+        if with_ref and synth.have_ref():
+            self.prefix = synth.build_rpgg_with_reference(self.loci, d, k=k)  # fa2kmers -g writes pan.graph.kmers too
+        else:
+            self.prefix = os.path.join(d, "pan")
+            synth.write_rpgg_files(synth.build_rpgg_arrays(self.loci, k), self.prefix)
+            synth.write_graph_file(synth.build_graph_arrays(self.loci, k), self.prefix)
+
+
+PARAM_SETS = [
+    dict(thread_cth=85, correction=1, maxncorrection=3),   # BASELINE config 4: -gc 85 3
+    dict(thread_cth=100, correction=1, maxncorrection=4),  # the reference's defaults with -gc
+    dict(thread_cth=60, correction=0, maxncorrection=4),   # -g: no correction
+    dict(thread_cth=120, correction=1, maxncorrection=1),  # budgets that run out
+]
+
+
+def edit_classes(cigar: str) -> Counter:
+    c = Counter()
+    for m in re.finditer(r"(?:X[ACGT]|D[ACGT*]|I)+", cigar):
+        ops = re.findall(r"X[ACGT]|D[ACGT*]|I", m.group(0))
+        c["".join(o[0] for o in ops)] += 1
+    return c
+
+
+def same_rec(a, b):
+    return bytes(a) == bytes(b)
+
+
+def describe(name, i, ro, orec, r2, rec2, O):
+    return (f"{name} read {i}: oracle ret={ro} other ret={r2} nkm {orec.nkm}/{rec2.nkm} nes {orec.nes}/{rec2.nes} "
+            f"ni {orec.ni}/{rec2.ni} flags {orec.flags}/{rec2.flags}\n  {O.cigar_annot(orec)}\n  {O.cigar_annot(rec2)}")
+
+
+# ------------------------------------------------------------ oracle vs ref --
+def oracle_vs_reference(tmp, k, seed):
+    """>= 100 k reads per k in {21, 25}: error rates 0 / 0.5 % / 2 % / 5 %, N, targeted edits of all 8 classes at the read's
+    start / middle / end, reads walked through the wrong locus, four parameter sets; threadCheck's [!] flags are counted."""
+    O = bind.Oracle()
+    H = bind.RefHarness()
+    case = WalkCase(tmp, f"w{k}", k, seed)
+    oh = O.load(case.prefix, k)
+    O.load_graph(oh, case.prefix + ".graph.kmers")
+    nper = 13000 if k != 17 else 2500
+    classes, rets, flagged, total = Counter(), Counter(), 0, 0
+    for pi, ps in enumerate(PARAM_SETS):
+        p = abi.default_params(ksize=k, **ps)
+        H.set_params(p)
+        if pi == 0:
+            h = H.load(case.prefix)
+            H.load_graph(h, case.prefix + ".graph.kmers")
+        for si, (sub, indel, nrate) in enumerate([(0.0, 0.0, 0.0), (0.005, 0.001, 0.0), (0.02, 0.005, 0.002), (0.05, 0.02, 0.0)]):
+            seqs, loc = make_reads(case.loci, k, nper if pi == 0 else nper // 3, seed=100 * pi + si + k, sub=sub, indel=indel, nrate=nrate,
+                                   targeted=720 if si == 0 else 0, wrong_locus=0.03)
+            for i, s in enumerate(seqs):
+                rr, rrec, cig, ann, fl = H.thread(h, loc[i], s, p, tc=True)
+                ro, orec = O.thread(oh, loc[i], s, p)
+                assert rr >= 0, "the reference asserted on a clean graph"
+                assert ro == rr and same_rec(orec, rrec), describe("oracle vs reference", i, ro, orec, rr, rrec, O)
+                assert O.cigar_annot(orec) == (cig, ann)
+                classes.update(edit_classes(cig))
+                rets[rr] += 1
+                flagged += fl
+                total += 1
+    if k != 17:
+        assert total >= 100_000
+    for cls in ("X", "D", "I", "XX", "XD", "XI", "DD", "II"):  # all 8 edit classes occurred
+        assert classes[cls] > 0, (cls, classes)
+    assert rets[0] > 0 and rets[1] > 0 and rets[2] > 0
+    print(f"k={k}: {total} reads, ret {dict(rets)}, edit tracts {dict(classes)}, {flagged} flagged by threadCheck")
+
+
+@pytest.mark.skipif(not synth.have_ref(), reason="needs oracle/_ref (make -C oracle ref where /root/reference exists)")
+@pytest.mark.parametrize("k,seed", [(21, 3), (25, 4), (17, 5)])
+def test_oracle_walk_equals_reference(tmp_path, k, seed):
+    """One process per k: the reference keeps `static` constants derived from the global ksize inside
+    edit_kmers_backward (AQ.cpp:653-654), so a loaded copy of it can only walk with the k of its first correction."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), str(tmp_path), str(k), str(seed)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    print(r.stdout.strip().splitlines()[-1])
+
+
+def test_oracle_graph_loaders(tmp_path):
+    """PREF.graph.kmers (text) and the v1.3 PREF.graph.umap (binary; the reference's own fixture test/QC/input/pan.graph.umap,
+    kept under tests/golden/legacy_v13 with its text twin) give the same graph."""
+    O = bind.Oracle()
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "legacy_v13", "pan")
+    if os.path.exists(gold + ".graph.umap") and os.path.exists(gold + ".graph.kmers"):
+        n = os.path.getsize(gold + ".graph.umap")
+        assert n == 26998  # 8 + 8 + 2998 x 9
+    case = WalkCase(str(tmp_path), "ld", 21, 7, nloci=3, with_ref=False)
+    synth.write_graph_file(synth.build_graph_arrays(case.loci, 21), case.prefix, binary=True)
+    p = abi.default_params(ksize=21, thread_cth=85, correction=1, maxncorrection=3)
+    seqs, loc = make_reads(case.loci, 21, 300, seed=5, sub=0.01, indel=0.003)
+    a = O.load(case.prefix, 21); O.load_graph(a, case.prefix + ".graph.kmers")
+    b = O.load(case.prefix, 21); O.load_graph(b, case.prefix + ".graph.umap")
+    for i, s in enumerate(seqs):
+        ra, reca = O.thread(a, loc[i], s, p)
+        rb, recb = O.thread(b, loc[i], s, p)
+        assert ra == rb and same_rec(reca, recb)
+
+
+# --------------------------------------------------- emulated kernel vs oracle --
+@pytest.mark.parametrize("k,seed", [(21, 3), (25, 4)])
+def test_emulated_walk_kernel_equals_oracle(tmp_path, k, seed):
+    O = bind.Oracle()
+    E = bind.Emu()
+    case = WalkCase(str(tmp_path), f"e{k}", k, seed)
+    oh = O.load(case.prefix, k)
+    O.load_graph(oh, case.prefix + ".graph.kmers")
+    g = E.load(case.prefix, k, flags=abi.LOAD_GRAPH)
+    tb = E.tables(g)
+    n = 0
+    for pi, ps in enumerate(PARAM_SETS):
+        p = abi.default_params(ksize=k, threading=2, **ps)
+        for si, (sub, indel, nrate) in enumerate([(0.0, 0.0, 0.0), (0.01, 0.003, 0.002), (0.04, 0.02, 0.0)]):
+            seqs, loc = make_reads(case.loci, k, 260 if pi else 700, seed=100 * pi + si + k, sub=sub, indel=indel, nrate=nrate,
+                                   targeted=216 if (si == 0 and pi < 2) else 0, wrong_locus=0.03)
+            buf, off = pack(seqs)
+            recs = E.thread(g, tb, p, buf, off, np.array(loc, np.uint32), grid=3)
+            for i, s in enumerate(seqs):
+                ro, orec = O.thread(oh, loc[i], s, p)
+                assert recs[i].ret == ro and same_rec(recs[i], orec), describe("emulated kernel vs oracle", i, ro, orec, recs[i].ret, recs[i], O)
+                n += 1
+    assert n > 3000
+
+
+# ------------------------------------------------------------ GPU vs oracle --
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,seed", [(21, 3), (25, 4)])
+def test_gpu_walk_equals_oracle(tmp_path, k, seed):
+    """The HIP kernel through the C-ABI (dbtk_thread_batch) against the oracle: the same read sets as the
+    oracle-vs-reference test (>= 100 k reads per k), every output field."""
+    O = bind.Oracle()
+    D = bind.pkg.Dbtk()
+    case = WalkCase(str(tmp_path), f"g{k}", k, seed)
+    oh = O.load(case.prefix, k)
+    O.load_graph(oh, case.prefix + ".graph.kmers")
+    g = D.load(case.prefix, k, flags=abi.LOAD_GRAPH)
+    total, rets = 0, Counter()
+    for pi, ps in enumerate(PARAM_SETS):
+        p = abi.default_params(ksize=k, threading=2, **ps)
+        ctx = D.context(g, p, device=0)
+        for si, (sub, indel, nrate) in enumerate([(0.0, 0.0, 0.0), (0.005, 0.001, 0.0), (0.02, 0.005, 0.002), (0.05, 0.02, 0.0)]):
+            seqs, loc = make_reads(case.loci, k, 13000 if pi == 0 else 4334, seed=100 * pi + si + k, sub=sub, indel=indel, nrate=nrate,
+                                   targeted=720 if si == 0 else 0, wrong_locus=0.03)
+            buf, off = pack(seqs)
+            recs = ctx.thread(buf, off, np.array(loc, np.uint32))
+            for i, s in enumerate(seqs):
+                ro, orec = O.thread(oh, loc[i], s, p)
+                assert recs[i].ret == ro and same_rec(recs[i], orec), describe("GPU vs oracle", i, ro, orec, recs[i].ret, recs[i], O)
+                rets[ro] += 1
+                total += 1
+        ctx.close()
+    assert total >= 100_000
+    assert rets[0] > 0 and rets[1] > 0 and rets[2] > 0
+
+
+if __name__ == "__main__":  # worker of test_oracle_walk_equals_reference
+    oracle_vs_reference(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))
