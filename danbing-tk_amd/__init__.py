@@ -51,6 +51,8 @@ def bind_common(L):
     L.dbtk_params_default.argtypes = [C.POINTER(abi.Params)]
     L.dbtk_write_outputs.restype = C.c_int
     L.dbtk_write_outputs.argtypes = [C.c_void_p, u64p, u64p, u32p, C.c_char_p, C.c_int]
+    L.dbtk_aln_format.restype = C.c_size_t
+    L.dbtk_aln_format.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
 
 
 class Rpgg:
@@ -162,6 +164,26 @@ class Context:
         self._lib._chk(self._lib.L.dbtk_ctx_walk_results(self.h, res, trecs, cap, C.byref(n)))
         return res, trecs, int(n.value)
 
+    def aln_records(self):
+        """dbtk_ctx_aln_records of the last align(): list of (AlnHdr copy, "cigar2\\tannot2\\tcigar1\\tannot1")."""
+        L = self._lib.L
+        n, st, cap = C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+        rc = L.dbtk_ctx_aln_records(self.h, None, 0, C.byref(n), C.byref(st), C.byref(cap))
+        if rc not in (abi.OK, abi.ERR_OVERFLOW):
+            self._lib._chk(rc)
+        if not n.value:
+            return []
+        buf = (C.c_uint8 * (n.value * st.value))()
+        self._lib._chk(L.dbtk_ctx_aln_records(self.h, buf, len(buf), C.byref(n), C.byref(st), C.byref(cap)))
+        out = []
+        txt = C.create_string_buffer(8192)
+        for i in range(n.value):
+            rec = C.byref(buf, i * st.value)
+            hdr = abi.AlnHdr.from_buffer_copy(buf, i * st.value)
+            L.dbtk_aln_format(rec, cap.value, txt, 8192)
+            out.append((hdr, txt.value.decode()))
+        return out
+
     def align_device(self, d_seq_ptr, d_off_ptr, npairs, max_read_len):
         self._lib._chk(self._lib.L.dbtk_align_batch_device(self.h, C.c_void_p(d_seq_ptr), C.c_void_p(d_off_ptr), npairs,
                                                            max_read_len))
@@ -237,6 +259,8 @@ class Dbtk(_HostSide):
         L.dbtk_thread_batch.argtypes = [C.c_void_p, u8p, u64p, u32p, C.c_uint64, C.POINTER(abi.ThreadRec)]
         L.dbtk_ctx_walk_results.restype = C.c_int
         L.dbtk_ctx_walk_results.argtypes = [C.c_void_p, C.POINTER(abi.WalkRes), C.POINTER(abi.ThreadRec), C.c_uint64, u64p]
+        L.dbtk_ctx_aln_records.restype = C.c_int
+        L.dbtk_ctx_aln_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, u32p]
         L.dbtk_align_batch_device.restype = C.c_int
         L.dbtk_align_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
         L.dbtk_ctx_synchronize.restype = C.c_int
@@ -278,7 +302,7 @@ EXPORTS = [
     "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
     "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
-    "dbtk_thread_batch", "dbtk_ctx_walk_results",
+    "dbtk_thread_batch", "dbtk_ctx_walk_results", "dbtk_ctx_aln_records", "dbtk_aln_format",
 ]
 
 

@@ -12,7 +12,7 @@ THREADING_HEAD, THREADING_V13 = 1, 2
  ERR_OVERFLOW) = range(10)
 
 (STAGE_SHORT, STAGE_SUBFILTER, STAGE_KFILTER, STAGE_LOCUS, STAGE_QC, STAGE_BAIT, STAGE_ASGN, STAGE_COUNTED,
- STAGE_EXTRACT) = range(9)
+ STAGE_EXTRACT, STAGE_THREADING) = range(10)
 
 (C_NREADS, C_SUBFILTERED, C_KMERFILTERED, C_BAITFILTERED, C_QUALFILTERED, C_LOCUSFILTERED, C_QCFILTERED,
  C_THREADING, C_FEASIBLE, C_ASGN, C_NSHORT, C_NHASH0, C_NHASH1, C_ALGO_PROBES, C_ALGO_VV, C_ALGO_CLS, C_ALGO_INC,
@@ -70,6 +70,11 @@ class ThreadRec(C.Structure):
 
 class WalkRes(C.Structure):
     _fields_ = [("pair", C.c_uint32), ("dst", C.c_uint32), ("ret1", C.c_int8), ("ret2", C.c_int8), ("pad", C.c_uint8 * 2)]
+
+
+class AlnHdr(C.Structure):
+    _fields_ = [("pair", C.c_uint32), ("dst", C.c_uint32), ("ret1", C.c_int8), ("ret2", C.c_int8), ("pad", C.c_uint8 * 2),
+                ("nes1", C.c_uint16), ("ntr1", C.c_uint16), ("nes2", C.c_uint16), ("ntr2", C.c_uint16), ("pad2", C.c_uint32)]
 
 
 LOAD_INDEX_ONLY, LOAD_GRAPH = 1, 2

@@ -233,6 +233,8 @@ struct dbtk_ctx {
     uint32_t* d_walk = nullptr; uint64_t walk_cap = 0;       // threading = 2, per survivor: destLocus [cap], then the walk's return codes [cap]
     dbtk_thread_rec_t* d_trecs = nullptr; uint64_t trecs_cap = 0;  // thread records (function mode; pair mode with trace / -a)
     uint32_t* d_loci = nullptr; uint64_t loci_cap = 0;       // function mode: locus per read
+    uint8_t* d_aln = nullptr; uint64_t aln_bytes = 0;        // -a / -ae: compact alignment records of the last host-buffer batch
+    uint32_t aln_stride = 0, aln_cap = 0; uint64_t aln_max = 0;
     uint64_t last_walk_npairs = 0; bool last_walk_recs = false;  // what dbtk_ctx_walk_results may fetch
     int walk_blocks = 0;
     // optional gates
@@ -301,7 +303,7 @@ void free_ctx(dbtk_ctx* c) {
         }
     void* ptrs[] = {c->d_flt, c->d_ctr, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
-                    c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_gr, c->d_walk, c->d_trecs, c->d_loci};
+                    c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_gr, c->d_walk, c->d_trecs, c->d_loci, c->d_aln};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     std::vector<dbtk_ctx::Lane*> others{&c->alt};
     for (auto& l : c->parked) others.push_back(&l);
@@ -579,7 +581,7 @@ constexpr uint32_t SMALL_WORDS = 64;  // d_small: nsurv, novf (binned encode sta
 
 dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_off, uint64_t seq_len, uint64_t npairs,
                            uint32_t max_read_len, dbtk_pair_rec_t* d_recs, uint32_t rec_cap, const uint8_t* d_qual = nullptr,
-                           dbtk_thread_rec_t* walk_trecs = nullptr) {
+                           dbtk_thread_rec_t* walk_trecs = nullptr, bool walk_aln = false) {
     hipStream_t s = c->stream;
     if (npairs >= 0xFFFFFFFFull) { set_error("batch too large (pair index is 32-bit)"); return DBTK_ERR_ARG; }
     if (npairs == 0) return DBTK_OK;
@@ -744,6 +746,22 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         w.walk_dst = c->d_walk; w.walk_ret = c->d_walk + npairs;
         w.counts = a.counts; w.counters = a.counters; w.ctr_rep = c->d_ctr;
         w.trecs = walk_trecs; w.errflag = c->d_small + 3;
+        if (walk_aln) {
+            // a record holds, per mate, cg.es and cg.tr: the read's bases plus what deletions can add (dbtk.h: DBTK_THREAD_CAP)
+            const uint32_t acap = std::min<uint32_t>(DBTK_THREAD_CAP, (max_read_len + max_read_len / 4 + 8 + 7) & ~7u);
+            c->aln_cap = acap;
+            c->aln_stride = (uint32_t)sizeof(dbtk_aln_hdr_t) + 4 * acap;
+            c->aln_max = npairs + (uint64_t)ALN_CHUNK * c->walk_blocks;
+            if (c->aln_max * c->aln_stride > c->aln_bytes) {
+                if (c->d_aln) HIPCHK(hipFree(c->d_aln));
+                c->d_aln = nullptr; c->aln_bytes = 0;
+                HIPCHK(hipMalloc(&c->d_aln, c->aln_max * c->aln_stride));
+                c->aln_bytes = c->aln_max * c->aln_stride;
+            }
+            HIPCHK(hipMemsetAsync(c->d_small + 4, 0, 4, s));
+            w.aln = c->d_aln; w.aln_stride = c->aln_stride; w.aln_cap = acap; w.aln_max = (uint32_t)std::min<uint64_t>(c->aln_max, 0xFFFFFFFFull);
+            w.naln = c->d_small + 4;
+        }
         if (tm) { if ((st = timed_slot(c, 7, &e))) return st; HIPCHK(hipEventRecord(c->timed[7].beg[e], s)); }
         hipLaunchKernelGGL(k_walk_pairs, dim3(c->walk_blocks), dim3(64), 0, s, w);
         if (tm) HIPCHK(hipEventRecord(c->timed[7].end[e], s));
@@ -944,12 +962,14 @@ dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t
         if ((st = ensure(&c->d_qual, &c->qual_cap, nbytes + 32))) return st;
         if (nbytes) HIPCHK(hipMemcpyAsync(c->d_qual, qual + base, nbytes, hipMemcpyHostToDevice, s));
     }
-    const bool walk_recs = c->P.threading == DBTK_THREADING_V13 && (c->P.trace || c->P.aln);
+    const bool walk_recs = c->P.threading == DBTK_THREADING_V13 && c->P.trace;
     if (walk_recs && (st = ensure(&c->d_trecs, &c->trecs_cap, 2 * npairs))) return st;
     c->last_walk_npairs = c->P.threading == DBTK_THREADING_V13 ? npairs : 0;
     c->last_walk_recs = walk_recs;
+    const bool walk_aln = c->P.threading == DBTK_THREADING_V13 && c->P.aln;
+    if (!walk_aln) c->aln_max = 0;
     if ((st = launch_batch(c, c->d_seq, c->d_off, nbytes, npairs, maxlen, want_recs ? c->d_recs : nullptr, (uint32_t)dcap,
-                           use_qual ? c->d_qual : nullptr, walk_recs ? c->d_trecs : nullptr))) return st;
+                           use_qual ? c->d_qual : nullptr, walk_recs ? c->d_trecs : nullptr, walk_aln))) return st;
     uint32_t small[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(small, c->d_small, sizeof(small), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1083,7 +1103,7 @@ dbtk_status_t dbtk_ctx_walk_results(dbtk_ctx_t* c, dbtk_walk_res_t* res, dbtk_th
     if (!c || !n) { set_error("null argument"); return DBTK_ERR_ARG; }
     *n = 0;
     if (!c->last_walk_npairs) return DBTK_OK;
-    if (trecs && !c->last_walk_recs) { set_error("thread records are only kept with params.trace or params.aln"); return DBTK_ERR_ARG; }
+    if (trecs && !c->last_walk_recs) { set_error("thread records are only kept with params.trace"); return DBTK_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     uint32_t nsurv = 0;
@@ -1105,6 +1125,31 @@ dbtk_status_t dbtk_ctx_walk_results(dbtk_ctx_t* c, dbtk_walk_res_t* res, dbtk_th
         if (res) { res[i].pair = walked[i].first; res[i].dst = dst[t]; res[i].ret1 = (int8_t)(ret[t] & 0xFF); res[i].ret2 = (int8_t)((ret[t] >> 8) & 0xFF); res[i].pad[0] = res[i].pad[1] = 0; }
         if (trecs) HIPCHK(hipMemcpy(&trecs[2 * i], &c->d_trecs[2 * (size_t)t], 2 * sizeof(dbtk_thread_rec_t), hipMemcpyDeviceToHost));
     }
+    return DBTK_OK;
+}
+
+// -a / -ae: the compact alignment records of the last host-buffer batch, invalid slots dropped, pair order.
+dbtk_status_t dbtk_ctx_aln_records(dbtk_ctx_t* c, void* buf, uint64_t buf_bytes, uint64_t* nrec, uint32_t* stride, uint32_t* cap) {
+    if (!c || !nrec || !stride || !cap) { set_error("null argument"); return DBTK_ERR_ARG; }
+    *nrec = 0; *stride = c->aln_stride; *cap = c->aln_cap;
+    if (!c->aln_max || !c->d_aln) return DBTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint32_t nslots = 0;
+    HIPCHK(hipMemcpy(&nslots, c->d_small + 4, 4, hipMemcpyDeviceToHost));
+    if (nslots > c->aln_max) { set_error("alignment record buffer overflow"); return DBTK_ERR_OVERFLOW; }
+    const size_t st = c->aln_stride;
+    std::vector<uint8_t> raw((size_t)nslots * st);
+    if (nslots) HIPCHK(hipMemcpy(raw.data(), c->d_aln, raw.size(), hipMemcpyDeviceToHost));
+    std::vector<std::pair<uint32_t, uint32_t>> order;  // (pair, slot)
+    for (uint32_t i = 0; i < nslots; ++i) {
+        const dbtk_aln_hdr_t* h = reinterpret_cast<const dbtk_aln_hdr_t*>(raw.data() + (size_t)i * st);
+        if (h->pair != NAN32) order.emplace_back(h->pair, i);
+    }
+    std::sort(order.begin(), order.end());
+    *nrec = order.size();
+    if (order.size() * st > buf_bytes || (!buf && !order.empty())) { set_error("alignment record buffer too small"); return DBTK_ERR_OVERFLOW; }
+    for (size_t i = 0; i < order.size(); ++i) memcpy((uint8_t*)buf + i * st, raw.data() + (size_t)order[i].second * st, st);
     return DBTK_OK;
 }
 

@@ -1723,7 +1723,7 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
                 stage = DBTK_STAGE_QC;
             } else if (a.P.threading) {  // AQ.cpp:2070-2090: `alned` stays false at HEAD, nothing else happens;
                 c_thr += 2;              // v1.3 (threading = 2): the walk kernel takes the pair from here
-                if (a.P.threading == DBTK_THREADING_V13 && lane == 0) a.walk_dst[t] = dst;
+                if (a.P.threading == DBTK_THREADING_V13) { stage = DBTK_STAGE_THREADING; if (lane == 0) a.walk_dst[t] = dst; }
             } else if (a.P.extract) {  // AQ.cpp:2094-2099
                 c_thr += 2; c_feas += 2;
                 stage = DBTK_STAGE_EXTRACT;
@@ -2320,7 +2320,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                     stage = DBTK_STAGE_QC;
                 } else if (a.P.threading) {  // AQ.cpp:2070-2090: `alned` stays false at HEAD, nothing else happens;
                     c_thr += 2;              // v1.3 (threading = 2): the walk kernel takes the pair from here
-                    if (a.P.threading == DBTK_THREADING_V13 && lane == 0) a.walk_dst[t] = dst;
+                    if (a.P.threading == DBTK_THREADING_V13) { stage = DBTK_STAGE_THREADING; if (lane == 0) a.walk_dst[t] = dst; }
                 } else if (a.P.extract) {  // AQ.cpp:2094-2099
                     c_thr += 2; c_feas += 2;
                     stage = DBTK_STAGE_EXTRACT;

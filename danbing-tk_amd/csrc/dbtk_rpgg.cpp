@@ -396,6 +396,67 @@ dbtk_status_t dbtk_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a, dbtk_rpgg_t** o
     return DBTK_OK;
 }
 
+// writeCigar / writeAnnot (src/aQueryFasta_thread.cpp:1683-1740) on a compact alignment record (dbtk.h: dbtk_aln_hdr_t
+// + es1 tr1 es2 tr2), printed in writeAlignments' order (AQ.cpp:1751-1757): cigar2 annot2 cigar1 annot1, tab-separated.
+size_t dbtk_aln_format(const void* rec, uint32_t cap, char* out, size_t out_cap) {
+    const dbtk_aln_hdr_t* h = (const dbtk_aln_hdr_t*)rec;
+    const uint8_t* base = (const uint8_t*)rec + sizeof(dbtk_aln_hdr_t);
+    size_t n = 0;
+    auto putc_ = [&](char c) { if (n + 1 < out_cap) out[n] = c; ++n; };
+    auto puti = [&](int v) { char b[16]; const int l = snprintf(b, sizeof b, "%d", v); for (int i = 0; i < l; ++i) putc_(b[i]); };
+    static const char TT[8] = {'*', '=', 'X', 'D', 'I', '?', '?', '?'};
+    static const char GG[8] = {0, 'A', 'C', 'G', 'T', '*', '?', '?'};
+    auto cigar = [&](const uint8_t* es, int sz) {  // writeCigar
+        if (!sz) { putc_('*'); return; }
+        int ct = 1;
+        char t0 = TT[es[0] & 7], g0 = GG[(es[0] >> 3) & 7], t1 = 0, g1 = 0;
+        for (int i = 1; i < sz; ++i) {
+            t1 = TT[es[i] & 7]; g1 = GG[(es[i] >> 3) & 7];
+            if (t0 == '=' || t0 == '.' || t0 == '*') {
+                while (t1 == t0) {
+                    ++ct; ++i;
+                    if (i == sz) break;
+                    t1 = TT[es[i] & 7]; g1 = GG[(es[i] >> 3) & 7];
+                }
+                puti(ct); putc_(t0);
+            } else if (t0 == 'X') { putc_('X'); putc_(g0); }
+            else if (t0 == 'D') {
+                if (t1 == 'I') { putc_('X'); putc_(g0); ++i; }  // ins + del printed as a mismatch
+                else { putc_('D'); putc_(g0); }
+            } else if (t0 == 'I') {
+                if (t1 == 'D') { putc_('X'); putc_(g1); ++i; }
+                else putc_('I');
+            } else putc_(t0);
+            if (i == sz) return;
+            ct = 1;
+            t0 = TT[es[i] & 7]; g0 = GG[(es[i] >> 3) & 7];
+        }
+        puti(ct); putc_(t0);
+    };
+    auto annot = [&](const uint8_t* tr, int sz) {  // writeAnnot
+        if (!sz) { putc_('*'); return; }
+        int ct = 1;
+        uint8_t c0 = tr[0];
+        for (int i = 1; i < sz; ++i) {
+            if (c0 == '=' || c0 == '.' || c0 == '*') {
+                while (tr[i] == c0) { ++ct; ++i; if (i == sz) break; }
+                puti(ct); putc_((char)c0);
+            } else putc_((char)c0);
+            if (i == sz) return;
+            ct = 1;
+            c0 = tr[i];
+        }
+        puti(ct); putc_((char)c0);
+    };
+    auto clamp = [&](uint16_t v) { return (int)(v < cap ? v : cap); };
+    cigar(base + 2 * (size_t)cap, clamp(h->nes2)); putc_('\t');
+    annot(base + 3 * (size_t)cap, clamp(h->ntr2)); putc_('\t');
+    cigar(base, clamp(h->nes1)); putc_('\t');
+    annot(base + (size_t)cap, clamp(h->ntr1));
+    if (out_cap) out[n < out_cap ? n : out_cap - 1] = 0;
+    return n;
+}
+
 void dbtk_rpgg_free(dbtk_rpgg_t* h) { delete h; }
 uint64_t dbtk_rpgg_nloci(const dbtk_rpgg_t* h) { return h ? h->nloci : 0; }
 uint64_t dbtk_rpgg_ntrkmers(const dbtk_rpgg_t* h) { return h ? h->out_kmer.size() : 0; }

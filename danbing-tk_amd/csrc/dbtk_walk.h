@@ -110,7 +110,17 @@ struct WalkArgs {
     dbtk_thread_rec_t* trecs;  // function mode: one per read.  pair mode: nullptr, or two per survivor (trace / -a records)
     uint64_t* noncak;          // function mode: nullptr or nreads x MAXL uncorrected k-mers
     uint32_t* errflag;
+    // -a / -ae (AQ.cpp:2232-2240): compact alignment records, one per emitted pair (layout: dbtk.h, dbtk_aln_hdr_t)
+    uint8_t* aln;              // nullptr: none
+    uint32_t aln_stride, aln_cap, aln_max;  // bytes per record, entries per packed array, records the buffer holds
+    uint32_t* naln;            // slots handed out (in chunks of ALN_CHUNK per wave)
 };
+constexpr uint32_t ALN_CHUNK = 16;
+DBTK_HD uint8_t aln_pack(uint8_t t, uint8_t g) {  // edit_t (t, g) in one byte: dbtk.h DBTK_ALN_*
+    const uint32_t tc = t == '*' ? 0u : t == '=' ? 1u : t == 'X' ? 2u : t == 'D' ? 3u : t == 'I' ? 4u : 7u;
+    const uint32_t gc = g == 0 ? 0u : g == 'A' ? 1u : g == 'C' ? 2u : g == 'G' ? 3u : g == 'T' ? 4u : 5u;
+    return (uint8_t)(tc | (gc << 3));
+}
 
 struct WalkSmem {
     uint32_t raw[72];
@@ -791,6 +801,25 @@ DBTK_HD void walk_store(X& x, const WalkSmem& sm, const WalkState& S, int ret, d
     x.sync();
 }
 
+// What the walk left in LDS -> mate m's half of a compact alignment record.
+template <class X>
+DBTK_HD void walk_store_aln(X& x, const WalkSmem& sm, const WalkState& S, int ret, uint8_t* rec, uint32_t cap, int m) {
+    const int lane = x.lane();
+    dbtk_aln_hdr_t* h = reinterpret_cast<dbtk_aln_hdr_t*>(rec);
+    uint8_t* es = rec + sizeof(dbtk_aln_hdr_t) + (size_t)(2 * m) * cap;
+    uint8_t* tr = es + cap;
+    x.sync();
+    if (lane == 0) {
+        if (m == 0) { h->ret1 = (int8_t)ret; h->nes1 = (uint16_t)S.nes; h->ntr1 = (uint16_t)S.ntr; }
+        else { h->ret2 = (int8_t)ret; h->nes2 = (uint16_t)S.nes; h->ntr2 = (uint16_t)S.ntr; }
+    }
+    for (int i = lane; i < (int)cap; i += 64) {
+        es[i] = i < S.nes ? aln_pack(sm.es_t[i], sm.es_g[i]) : (uint8_t)0;
+        tr[i] = i < S.ntr ? sm.tr[i] : (uint8_t)0;
+    }
+    x.sync();
+}
+
 // Function mode: read r against read_locus[r] (one wave per read, reads at a fixed stride).
 template <class X>
 DBTK_HD void body_walk_reads(X& x, const WalkArgs& a) {
@@ -824,11 +853,24 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
     uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
     const uint32_t nsurv = *a.nsurv;
     uint64_t c_feas = 0, c_inc = 0;
+    uint32_t slot_base = 0, slot_used = ALN_CHUNK;  // alignment records: slots are taken ALN_CHUNK at a time (one atomic per chunk)
     for (uint32_t t = x.bid(); t < nsurv; t += x.nblocks()) {
         const uint32_t dst = a.walk_dst[t];
         if (dst == NAN32) continue;
         const uint32_t pair = a.surv[t];
         int ret[2];
+        uint8_t* arec = nullptr;
+        if (a.aln) {
+            if (slot_used == ALN_CHUNK) {
+                uint32_t b = 0;
+                if (lane == 0) b = x.atomic_add(a.naln, ALN_CHUNK);
+                slot_base = x.bcast(b, 0);
+                slot_used = 0;
+            }
+            const uint32_t slot = slot_base + slot_used++;
+            if (slot < a.aln_max) arec = a.aln + (size_t)slot * a.aln_stride;
+            else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
+        }
         for (int m = 0; m < 2; ++m) {
             const uint64_t o0 = a.off[2 * (uint64_t)pair + m], o1 = a.off[2 * (uint64_t)pair + m + 1];
             WalkState S;
@@ -836,8 +878,15 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
             ret[m] = walk_read(x, sm, a.T, a.P, dst, len, S);
             if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) { ret[m] = 0; if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_FORMAT; }
             if (a.trecs) walk_store(x, sm, S, ret[m], &a.trecs[2 * (size_t)t + m]);
+            if (arec) walk_store_aln(x, sm, S, ret[m], arec, a.aln_cap, m);
         }
         const bool alned = ret[0] || ret[1];
+        if (arec && lane == 0) {  // -a: every walked pair; -ae: only the kept ones (AQ.cpp:2234)
+            dbtk_aln_hdr_t* h = reinterpret_cast<dbtk_aln_hdr_t*>(arec);
+            h->pair = (a.P.aln == 2 && !alned) ? NAN32 : pair;
+            h->dst = alned ? dst : a.T.nloci;
+            h->pad[0] = h->pad[1] = 0;
+        }
         x.sync();
         if (alned) {
             c_feas += 2;
@@ -855,6 +904,11 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
         }
         x.sync();
     }
+    if (a.aln && lane == 0)  // the slots of the last chunk that were not used
+        for (; slot_used < ALN_CHUNK; ++slot_used) {
+            const uint32_t slot = slot_base + slot_used;
+            if (slot < a.aln_max) reinterpret_cast<dbtk_aln_hdr_t*>(a.aln + (size_t)slot * a.aln_stride)->pair = NAN32;
+        }
     if (lane == 0) {
         if (c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], c_feas);
         if (c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], c_inc);

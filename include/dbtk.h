@@ -160,7 +160,9 @@ enum {
     DBTK_STAGE_BAIT = 5,      /* bait filter removed the pair         AQ.cpp:2120 */
     DBTK_STAGE_ASGN = 6,      /* both mates rejected by assignTRkmc   AQ.cpp:2145 */
     DBTK_STAGE_COUNTED = 7,   /* counts were accumulated              AQ.cpp:2146 */
-    DBTK_STAGE_EXTRACT = 8    /* -e: pair assigned, reported only     AQ.cpp:2094 */
+    DBTK_STAGE_EXTRACT = 8,   /* -e: pair assigned, reported only     AQ.cpp:2094 */
+    DBTK_STAGE_THREADING = 9  /* threading = 2: the pair reached the graph walk (AQ.cpp:2070); what the walk decided is in
+                                 dbtk_ctx_walk_results */
 };
 
 typedef struct dbtk_pair_rec {
@@ -244,6 +246,25 @@ dbtk_status_t dbtk_thread_batch(dbtk_ctx_t* ctx, const uint8_t* seq_bytes, const
  * every result) needs params.trace or params.aln.  *n = number of results (DBTK_ERR_OVERFLOW if > cap). */
 typedef struct dbtk_walk_res { uint32_t pair, dst; int8_t ret1, ret2; uint8_t pad[2]; } dbtk_walk_res_t;
 dbtk_status_t dbtk_ctx_walk_results(dbtk_ctx_t* ctx, dbtk_walk_res_t* res, dbtk_thread_rec_t* trecs, uint64_t cap, uint64_t* n);
+
+/* -a / -ae (params.aln, threading = 2): the alignment records of the last dbtk_align_batch call, in pair order —
+ * every pair that was walked (-a) or only those kept (-ae), AQ.cpp:2232-2240.  A record is a header followed by four
+ * byte arrays of `cap` entries each: es1[cap] tr1[cap] es2[cap] tr2[cap] (1 = seq1 = read 2p, 2 = seq2 = read 2p+1);
+ * es = cg.es with an edit in one byte: type (bits 0-2: 0 '*', 1 '=', 2 'X', 3 'D', 4 'I') | graph base << 3 (0 none,
+ * 1 'A', 2 'C', 3 'G', 4 'T', 5 '*'), tr = cg.tr as characters.  dbtk_aln_format prints a record's four strings the way
+ * writeAlignments does (writeCigar / writeAnnot, AQ.cpp:1683-1740): "cigar2 \t annot2 \t cigar1 \t annot1". */
+typedef struct dbtk_aln_hdr {
+    uint32_t pair, dst;       /* pair index inside the batch; destLocus after threading (nloci: removed by threading) */
+    int8_t ret1, ret2;        /* isThreadFeasible's return codes */
+    uint8_t pad[2];
+    uint16_t nes1, ntr1, nes2, ntr2;
+    uint32_t pad2;
+} dbtk_aln_hdr_t;
+/* buf receives *nrec records of *stride bytes each (DBTK_ERR_OVERFLOW if buf_bytes is too small: *nrec and *stride
+ * then say what is needed). */
+dbtk_status_t dbtk_ctx_aln_records(dbtk_ctx_t* ctx, void* buf, uint64_t buf_bytes, uint64_t* nrec, uint32_t* stride, uint32_t* cap);
+/* Returns the length of the text (without the terminating NUL it also writes when it fits). */
+size_t dbtk_aln_format(const void* rec, uint32_t cap, char* out, size_t out_cap);
 
 /* Device-resident variant used when the reads already sit in HBM (bench, or a
  * caller that overlaps its own H2D copies): d_seq / d_offsets are device

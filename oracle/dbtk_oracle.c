@@ -1029,7 +1029,14 @@ int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, c
 int orc_align_ex(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off, const uint8_t* qual,
                  uint64_t npairs, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* C, dbtk_pair_rec_t* recs,
                  orc_bub_event_t* ev, uint64_t evcap, uint64_t* nev) {
+    return orc_align_walk(g, p, seq, off, qual, npairs, counts, kmc, nmapread, C, recs, ev, evcap, nev, NULL);
+}
+
+int orc_align_walk(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off, const uint8_t* qual,
+                   uint64_t npairs, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* C, dbtk_pair_rec_t* recs,
+                   orc_bub_event_t* ev, uint64_t evcap, uint64_t* nev, orc_walk_out_t* walk) {
     uint64_t nBait = 0;
+    if (walk) walk->n = 0;
     *nev = 0;
     if (p->bait && !g->bt_beg) return DBTK_ERR_ARG;
     if (p->bubbles && !g->tre_beg) return DBTK_ERR_ARG;
@@ -1085,6 +1092,45 @@ int orc_align_ex(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq
             if (p->qc && g->qc && !g->qc[destLocus]) { nQC += (uint64_t)(2 - rm1 - rm2); stage = DBTK_STAGE_QC; goto emit; }
         }
         nThr += 2;  /* AQ.cpp:2070 */
+        if (p->threading == DBTK_THREADING_V13) {
+            /* The v1.3 call sites the reference keeps in comments.  AQ.cpp:2072-2088: both mates are walked through
+             * graphDB[destLocus] (sam.init1/2 + isThreadFeasible); the pair is kept if either walk is feasible, else
+             * destLocus = nloci.  AQ.cpp:2090-2092: nFeasibleReads += 2.  AQ.cpp:2189-2194 (countMode 0, "exact"): the
+             * canonical multiset of the UNcorrected k-mers of both mates (noncaVec2CaUmap, AQ.h:392-399) is added to
+             * the locus' TR k-mers.  AQ.cpp:2232-2240: with -a every walked pair yields an alignment record, with -ae
+             * only the kept ones. */
+            if (!g->gr_beg) return DBTK_ERR_ARG;
+            dbtk_thread_rec_t* t1 = NULL; dbtk_thread_rec_t* t2 = NULL;
+            if (walk && walk->trecs && walk->n < walk->cap) { t1 = &walk->trecs[2 * walk->n]; t2 = t1 + 1; }
+            uint64_t nonca1[DBTK_MAX_READ_LEN], nonca2[DBTK_MAX_READ_LEN];
+            const uint64_t locus0 = destLocus;
+            const int alned0 = orc_thread(g, destLocus, s1, l1, k, p->thread_cth, (int)p->correction, p->maxncorrection, t1, nonca1);
+            const int alned1 = orc_thread(g, destLocus, s2, l2, k, p->thread_cth, (int)p->correction, p->maxncorrection, t2, nonca2);
+            if (alned0 < 0 || alned1 < 0) return DBTK_ERR_FORMAT; /* the reference would have asserted (unclean graph) */
+            stage = DBTK_STAGE_THREADING;
+            if (alned0 || alned1) {
+                nFeas += 2;
+                for (int m = 0; m < 2; ++m) {
+                    const uint64_t* nk = m ? nonca2 : nonca1;
+                    const uint64_t n = m ? nk2 : nk1;
+                    for (uint64_t i = 0; i < n; ++i) {
+                        if (nk[i] == NAN64) continue;
+                        const uint64_t rc = orc_nurc(nk[i], k);
+                        const int64_t it = tr_find(g, destLocus, nk[i] <= rc ? nk[i] : rc);
+                        if (it >= 0) { ++counts[it]; ++ninc; }
+                    }
+                }
+            } else destLocus = nloci; /* removed by threading */
+            if (walk) {
+                if (walk->n < walk->cap && walk->res) {
+                    dbtk_walk_res_t* w = &walk->res[walk->n];
+                    w->pair = (uint32_t)pi; w->dst = (uint32_t)destLocus; w->ret1 = (int8_t)alned0; w->ret2 = (int8_t)alned1; w->pad[0] = w->pad[1] = 0;
+                }
+                ++walk->n;
+            }
+            destLocus = locus0; /* the pair record keeps the locus the pair was walked through */
+            goto emit;
+        }
         if (p->threading) { stage = DBTK_STAGE_LOCUS; goto emit; } /* AQ.cpp:2072-2090: `alned` stays false at HEAD */
         nFeas += 2; /* AQ.cpp:2092 */
         if (p->extract) { stage = DBTK_STAGE_EXTRACT; goto emit; } /* AQ.cpp:2094-2099 */

@@ -51,6 +51,12 @@ typedef struct orc_bub_event { uint32_t pair, mate, pos, locus; uint64_t edge; }
 int orc_align_ex(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
                  const uint8_t* qual, uint64_t npairs, uint64_t* counts_fileorder, uint64_t* kmc, uint32_t* nmapread,
                  uint64_t* counters, dbtk_pair_rec_t* recs, orc_bub_event_t* ev, uint64_t cap, uint64_t* nev);
+/* The same loop with threading = 2 (the v1.3 call sites, AQ.cpp:2072-2088, 2189-2194): every pair that reaches threading
+ * appends a result (pair order) and, when trecs != NULL, its two thread records.  n = results produced (may exceed cap). */
+typedef struct orc_walk_out { dbtk_walk_res_t* res; dbtk_thread_rec_t* trecs; uint64_t cap, n; } orc_walk_out_t;
+int orc_align_walk(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
+                   const uint8_t* qual, uint64_t npairs, uint64_t* counts_fileorder, uint64_t* kmc, uint32_t* nmapread,
+                   uint64_t* counters, dbtk_pair_rec_t* recs, orc_bub_event_t* ev, uint64_t cap, uint64_t* nev, orc_walk_out_t* walk);
 /* Attach a bait DB (PREF.bt.kmdb layout: per-locus counts, k-mers, (min<<8|max)). */
 void orc_rpgg_set_bait(orc_rpgg_t* g, const uint64_t* bt_cnt, const uint64_t* bt_ks, const uint16_t* bt_vs);
 int  orc_rpgg_load_bait(orc_rpgg_t* g, const char* bait_file);
@@ -70,6 +76,9 @@ uint64_t orc_read2kmers_nonca(const uint8_t* read, uint64_t rlen, uint32_t k, ui
 /* writeCigar / writeAnnot (AQ.cpp:1683-1740) into buf; return the length the text needs. */
 size_t orc_write_cigar(const dbtk_thread_rec_t* r, char* buf, size_t cap);
 size_t orc_write_annot(const dbtk_thread_rec_t* r, char* buf, size_t cap);
+/* one line of writeAlignments (AQ.cpp:1742-1759); src < 0 prints '.' */
+size_t orc_write_alignment(int64_t src, uint32_t dst, const char* title, const uint8_t* seq1, uint64_t l1, const uint8_t* seq2, uint64_t l2,
+                           const dbtk_thread_rec_t* r1, const dbtk_thread_rec_t* r2, char* buf, size_t cap);
 
 /* Function-level restatements (for pinning against the reference harness). */
 uint64_t orc_nurc(uint64_t kmer, uint32_t k);                               /* getNuRC  AQ.h:165-178 */

@@ -297,11 +297,11 @@ static void edit_kmers_backward(walk_t* w, txt_t* t, uint64_t* pki, uint64_t* nc
             while (c == 'X' || c == 'D' || c == 'I') { --e0; c = es_t_at(cg, e0 - 1); }
         }
         /* merge edits if possible */
-        uint8_t ets[WCAP], rnts[WCAP], gnts[WCAP];
-        int nets = 0, nr = 0, ng = 0;
+        uint8_t rnts[WCAP], gnts[WCAP];
+        int nets = 0, nr = 0, ng = 0; /* ets.size(), rnts.size(), gnts.size() */
         for (int i = e0; i < e1; ++i) {
             const edit_t e = cg->es[i];
-            ets[nets++] = e.t;
+            ++nets;
             if (e.r) rnts[nr++] = e.r;
             if (e.g) gnts[ng++] = e.g;
         }
@@ -772,5 +772,29 @@ size_t orc_write_cigar(const dbtk_thread_rec_t* r, char* buf, size_t cap) { /* w
         t0 = r->es_t[i]; g0 = r->es_g[i];
     }
     n = w_puti(buf, cap, n, ct); n = w_putc(buf, cap, n, (char)t0);
+    return n;
+}
+
+/* One record of writeAlignments (AQ.cpp:1742-1759): `src dst title seq2 seq1 cigar2 annot2 cigar1 annot1\n` with src '.'
+ * outside simulation mode; r1 / r2 = the thread records of seq1 (read 2p) / seq2 (read 2p+1). */
+size_t orc_write_alignment(int64_t src, uint32_t dst, const char* title, const uint8_t* seq1, uint64_t l1, const uint8_t* seq2, uint64_t l2,
+                           const dbtk_thread_rec_t* r1, const dbtk_thread_rec_t* r2, char* buf, size_t cap) {
+    size_t n = 0;
+    char tmp[4096];
+    if (cap) buf[0] = 0;
+    if (src < 0) n = w_putc(buf, cap, n, '.'); else n = w_puti(buf, cap, n, (int)src);
+    n = w_putc(buf, cap, n, '\t');
+    n = w_puti(buf, cap, n, (int)dst);
+    n = w_putc(buf, cap, n, '\t');
+    n = w_put(buf, cap, n, title);
+    n = w_putc(buf, cap, n, '\t');
+    for (uint64_t i = 0; i < l2; ++i) n = w_putc(buf, cap, n, (char)seq2[i]);
+    n = w_putc(buf, cap, n, '\t');
+    for (uint64_t i = 0; i < l1; ++i) n = w_putc(buf, cap, n, (char)seq1[i]);
+    n = w_putc(buf, cap, n, '\t');
+    orc_write_cigar(r2, tmp, sizeof tmp); n = w_put(buf, cap, n, tmp); n = w_putc(buf, cap, n, '\t');
+    orc_write_annot(r2, tmp, sizeof tmp); n = w_put(buf, cap, n, tmp); n = w_putc(buf, cap, n, '\t');
+    orc_write_cigar(r1, tmp, sizeof tmp); n = w_put(buf, cap, n, tmp); n = w_putc(buf, cap, n, '\t');
+    orc_write_annot(r1, tmp, sizeof tmp); n = w_put(buf, cap, n, tmp); n = w_putc(buf, cap, n, '\n');
     return n;
 }

@@ -355,4 +355,135 @@ void ref_align_ex(void* h, const char* seq, const uint64_t* off, const char* qua
     }
 }
 
+/* The hot loop with the v1.3 threading call sites live.  Everything up to the QC gate is ref_pair's sequence
+ * (AQ.cpp:2035-2062); then the lines the reference keeps in comments are executed as written there:
+ *   AQ.cpp:2072-2088  sam.init1/2 + isThreadFeasible on both mates (+ threadCheck with tc), alned = alned0 || alned1,
+ *                     noncaVec2CaUmap of both mates' uncorrected k-mers, else destLocus = nloci
+ *   AQ.cpp:2090-2092  nFeasibleReads += 2
+ *   AQ.cpp:2189-2194  countMode 0 ("exact"): trKmers[p.first] += p.second for the k-mers found there
+ *   AQ.cpp:2232-2240  -a: every walked pair -> sams; -ae: only pairs with destLocus != nloci
+ * and the batch's records are printed by the reference's writeAlignments (AQ.cpp:1742-1759).
+ * res / trecs: per walked pair (pair order); aln_text receives the lines; titles = '\n'-separated, one per pair. */
+int64_t ref_align_v13(void* h, const char* seq, const uint64_t* off, const char* titles_blob, uint64_t npairs, uint32_t Cth, int qc,
+                      uint32_t thread_cth, int correction, int tc, int aln, int aln_minimal, uint64_t* counts_fileorder, uint64_t* C,
+                      dbtk_walk_res_t* res, dbtk_thread_rec_t* trecs, uint64_t rescap, uint64_t* nres, char* aln_text, uint64_t aln_cap) {
+    RefDB& db = *(RefDB*)h;
+    AbortTrap trap;
+    const uint64_t nloci = db.nloci;
+    uint16_t Cthreshold = Cth;
+    vector<string> seqs, titles;
+    {
+        const char* t = titles_blob;
+        for (uint64_t p = 0; p < npairs; ++p) {
+            const char* e = t ? strchr(t, '\n') : nullptr;
+            titles.push_back(t ? (e ? string(t, e) : string(t)) : string("r"));
+            if (t) t = e ? e + 1 : nullptr;
+            seqs.push_back(string(seq + off[2 * p], off[2 * p + 1] - off[2 * p]));
+            seqs.push_back(string(seq + off[2 * p + 1], off[2 * p + 2] - off[2 * p + 1]));
+        }
+    }
+    vector<uint64_t> alnindices;
+    vector<sam_t> sams;
+    *nres = 0;
+    std::streambuf* olderr = std::cerr.rdbuf(nullptr);
+    g_abort_armed = 1;
+    int64_t rc = 0;
+    if (sigsetjmp(g_abort_env, 1) == 0) {
+        uint64_t seqi = 0;
+        while (seqi < 2 * npairs) {
+            vector<uint64_t> caks1, caks2, caes1, caes2;
+            vector<kmerIndex_uint32_umap::iterator> its1, its2;
+            vector<PE_KMC> dup;
+            log_t log;
+            int rm1 = 0, rm2 = 0, kf1 = 0, kf2 = 0, hf1 = 0, hf2 = 0, nm1 = 0, nm2 = 0;
+            uint64_t destLocus, destLocus0 = NAN32, nhash0 = 0, nhash1 = 0;
+            string* seq1 = &seqs[seqi];
+            string* seq2 = &seqs[seqi + 1];
+            seqi += 2;
+            C[DBTK_C_NREADS] += 2;
+            read2kmers_edges(caks1, caes1, *seq1, ksize);
+            read2kmers_edges(caks2, caes2, *seq2, ksize);
+            if (not caks1.size() or not caks2.size()) { C[DBTK_C_NSHORT] += 1; continue; }
+            if (N_FILTER and NM_FILTER) {
+                const bool sub = subfilter(caks1, caks2, db.kmerDBi, nhash0);
+                C[DBTK_C_NHASH0] += nhash0;
+                if (sub) { C[DBTK_C_SUBFILTERED] += 2; continue; }
+            }
+            kfilter(caks1, caks2, its1, its2, db.kmerDBi, Cthreshold, nhash1, kf1, kf2, rm1, rm2);
+            C[DBTK_C_NHASH1] += nhash1;
+            C[DBTK_C_KMERFILTERED] += kf1 + kf2;
+            if (rm1 and rm2) { continue; }
+            destLocus = countHit(db.kmerDBi_vv, its1, its2, db.hits1, db.hits2, dup, nloci, Cthreshold, log, destLocus0, nm1, nm2, hf1, hf2, rm1, rm2);
+            C[DBTK_C_LOCUSFILTERED] += hf1 + hf2;
+            if (destLocus == nloci) { continue; }
+            if (qc and not db.qcFilter[destLocus]) { C[DBTK_C_QCFILTERED] += 2 - rm1 - rm2; continue; }
+
+            bool alned = false;
+            int alned0 = 0, alned1 = 0;
+            sam_t sam;
+            GraphType& gf = db.graphDB[destLocus];
+            C[DBTK_C_THREADING] += 2;
+            kmerCount_umap cakmers;
+            vector<uint64_t> noncakmers0, noncakmers1, akmers0, akmers1;
+            const uint64_t walked = destLocus;
+            {   // if (threading) {            AQ.cpp:2072-2088
+                sam.init1(*seq1);
+                alned0 = isThreadFeasible(gf, *seq1, noncakmers0, akmers0, thread_cth, correction != 0, sam.r1, db.trKmerDB[destLocus], log);
+                sam.init2(*seq2);
+                alned1 = isThreadFeasible(gf, *seq2, noncakmers1, akmers1, thread_cth, correction != 0, sam.r2, db.trKmerDB[destLocus], log);
+                if (*nres < rescap && trecs) {  // (what the walk left, before threadCheck may mark cg.tr)
+                    fill_thread_rec(&trecs[2 * *nres], alned0, sam.r1, akmers0);
+                    fill_thread_rec(&trecs[2 * *nres + 1], alned1, sam.r2, akmers1);
+                }
+                if (tc) {
+                    if (alned0) { threadCheck(gf, *seq1, akmers0, sam.r1, log); }
+                    if (alned1) { threadCheck(gf, *seq2, akmers1, sam.r2, log); }
+                }
+                if (alned0 or alned1) {
+                    alned = true;
+                    noncaVec2CaUmap(noncakmers0, cakmers, ksize);
+                    noncaVec2CaUmap(noncakmers1, cakmers, ksize);
+                }
+                else { destLocus = nloci; } // removed by threading
+            }
+            if (alned) {                    // AQ.cpp:2090-2092, 2189-2194
+                C[DBTK_C_FEASIBLE] += 2;
+                kmer_aCount_umap& trKmers = db.trKmerDB[walked];
+                auto& fidx = db.fileIndex[walked];
+                for (auto& p : cakmers) {
+                    auto it = trKmers.find(p.first);
+                    if (it != trKmers.end()) { counts_fileorder[fidx[p.first]] += p.second; C[DBTK_C_ALGO_INC] += p.second; }
+                }
+            }
+            if (*nres < rescap && res) {
+                dbtk_walk_res_t& w = res[*nres];
+                w.pair = (uint32_t)(seqi / 2 - 1); w.dst = (uint32_t)destLocus; w.ret1 = (int8_t)alned0; w.ret2 = (int8_t)alned1; w.pad[0] = w.pad[1] = 0;
+            }
+            ++*nres;
+            if (aln) {                      // AQ.cpp:2232-2240 (not simmode)
+                if ((aln_minimal and destLocus != nloci) or (not aln_minimal)) {
+                    alnindices.push_back(seqi);
+                    sam.src = -1;           // srcLocus = -1 outside simulation mode (AQ.cpp:2000)
+                    sam.dst = destLocus;
+                    sams.push_back(sam);
+                }
+            }
+        }
+        if (aln && aln_text) {
+            CoutCapture cap;
+            writeAlignments(seqs, titles, alnindices, sams);
+            const string out = cap.ss.str();
+            rc = (int64_t)out.size();
+            if (out.size() < aln_cap) memcpy(aln_text, out.data(), out.size());
+            if (aln_cap) aln_text[out.size() < aln_cap ? out.size() : aln_cap - 1] = 0;
+        }
+        g_abort_armed = 0;
+    } else {
+        rc = -1;
+    }
+    std::cerr.rdbuf(olderr);
+    std::cerr.clear();
+    return rc;
+}
+
 }  // extern "C"

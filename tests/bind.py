@@ -36,6 +36,18 @@ def events_array(ev, n):
                          count=n).copy()
 
 
+class WalkOut(C.Structure):
+    _fields_ = [("res", C.POINTER(abi.WalkRes)), ("trecs", C.POINTER(abi.ThreadRec)), ("cap", C.c_uint64), ("n", C.c_uint64)]
+
+
+def aln_line(O, res, trecs, i, title: str, s1: bytes, s2: bytes, nloci):
+    """The -a / -ae record of walk result i (writeAlignments, AQ.cpp:1742-1759) from its two thread records."""
+    buf = C.create_string_buffer(16384)
+    O.L.orc_write_alignment(-1, res[i].dst, title.encode(), s1, len(s1), s2, len(s2), C.byref(trecs[2 * i]), C.byref(trecs[2 * i + 1]), buf,
+                            16384)
+    return buf.value.decode()
+
+
 class Oracle:
     def __init__(self):
         path = os.path.join(ROOT, "oracle", "liboracle.so")
@@ -76,6 +88,12 @@ class Oracle:
         L.orc_write_cigar.argtypes = [C.POINTER(abi.ThreadRec), C.c_char_p, C.c_size_t]
         L.orc_write_annot.restype = C.c_size_t
         L.orc_write_annot.argtypes = [C.POINTER(abi.ThreadRec), C.c_char_p, C.c_size_t]
+        L.orc_write_alignment.restype = C.c_size_t
+        L.orc_write_alignment.argtypes = [C.c_int64, C.c_uint32, C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64,
+                                          C.POINTER(abi.ThreadRec), C.POINTER(abi.ThreadRec), C.c_char_p, C.c_size_t]
+        L.orc_align_walk.restype = C.c_int
+        L.orc_align_walk.argtypes = [C.c_void_p, C.POINTER(abi.Params), u8p, u64p, u8p, C.c_uint64, u64p, u64p, u32p, u64p,
+                                     C.POINTER(abi.PairRec), C.POINTER(BubEvent), C.c_uint64, u64p, C.POINTER(WalkOut)]
 
     def load(self, prefix, k, qc_file=None):
         h = self.L.orc_rpgg_load(prefix.encode(), k, qc_file.encode() if qc_file else None)
@@ -127,6 +145,27 @@ class Oracle:
     def load_bait(self, h, bait_file):
         if self.L.orc_rpgg_load_bait(h, bait_file.encode()):
             raise IOError(f"oracle could not load {bait_file}")
+
+    def align_walk(self, h, params, seq, off, trace=False, with_recs=True):
+        """The hot loop with threading = 2: orc_align_walk.  Adds walk results (pair order) + their thread records."""
+        npairs = (len(off) - 1) // 2
+        nloci = self.L.orc_rpgg_nloci(h)
+        ntr = self.L.orc_rpgg_ntrkmers(h)
+        counts = np.zeros(ntr, np.uint64)
+        kmc = np.zeros(nloci, np.uint64)
+        nmap = np.zeros(nloci, np.uint32)
+        ctr = np.zeros(abi.C_COUNT, np.uint64)
+        recs = (abi.PairRec * npairs)() if trace else None
+        res = (abi.WalkRes * max(npairs, 1))()
+        trecs = (abi.ThreadRec * max(2 * npairs, 1))() if with_recs else None
+        wo = WalkOut(res, trecs, npairs, 0)
+        nev = C.c_uint64(0)
+        seq = np.ascontiguousarray(seq, np.uint8)
+        rc = self.L.orc_align_walk(h, C.byref(params), _p(seq, u8p), _p(off, u64p), None, npairs, _p(counts, u64p), _p(kmc, u64p),
+                                   _p(nmap, u32p), _p(ctr, u64p), recs, None, 0, C.byref(nev), C.byref(wo))
+        if rc:
+            raise RuntimeError(f"orc_align_walk -> {rc}")
+        return dict(counts_file=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs, res=res, trecs=trecs, nres=int(wo.n))
 
     def qmask(self, qual: bytes, qth, k):
         m = np.zeros(max(len(qual), 1), np.uint8)
@@ -211,6 +250,31 @@ class RefHarness:
     def set_params(self, p):
         self.L.ref_set_params(p.ksize, p.n_filter, p.nm_filter, p.max_nt, p.nm_tr)
         self.L.ref_set_thread_params(p.maxncorrection, 0)
+
+    def align_v13(self, h, params, seq, off, titles, tc=False):
+        """ref_align_v13: the hot loop with the reference's commented-out v1.3 threading call sites executed."""
+        self.set_params(params)
+        L = self.L
+        L.ref_align_v13.restype = C.c_int64
+        L.ref_align_v13.argtypes = [C.c_void_p, C.c_char_p, u64p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, u64p, u64p, C.POINTER(abi.WalkRes), C.POINTER(abi.ThreadRec), C.c_uint64, u64p,
+                                    C.c_char_p, C.c_uint64]
+        npairs = (len(off) - 1) // 2
+        ntr = L.ref_db_ntr(h)
+        counts = np.zeros(ntr, np.uint64)
+        ctr = np.zeros(abi.C_COUNT, np.uint64)
+        res = (abi.WalkRes * max(npairs, 1))()
+        trecs = (abi.ThreadRec * max(2 * npairs, 1))()
+        nres = C.c_uint64(0)
+        cap = 64 + npairs * 2048
+        text = C.create_string_buffer(cap)
+        seq = np.ascontiguousarray(seq, np.uint8)
+        rc = L.ref_align_v13(h, seq.tobytes(), _p(off, u64p), "\n".join(titles).encode(), npairs, params.cthreshold, int(params.qc),
+                             params.thread_cth, int(params.correction), int(tc), int(params.aln != 0), int(params.aln == 2),
+                             _p(counts, u64p), _p(ctr, u64p), res, trecs, npairs, C.byref(nres), text, cap)
+        if rc < 0:
+            raise RuntimeError("the reference asserted")
+        return dict(counts_file=counts, counters=ctr, res=res, trecs=trecs, nres=int(nres.value), aln=text.raw[:rc].decode())
 
     def load_graph(self, h, graph_kmers_file):
         self.L.ref_db_load_graph(h, graph_kmers_file.encode())
@@ -346,6 +410,28 @@ class Emu(pkg._HostSide):
         L.emu_set_walk_trecs.argtypes = [C.POINTER(abi.ThreadRec)]
         L.emu_walk_results.restype = C.c_uint64
         L.emu_walk_results.argtypes = [C.POINTER(abi.WalkRes), u32p, C.c_uint64]
+
+    def walk_results(self, cap):
+        res = (abi.WalkRes * max(cap, 1))()
+        n = self.L.emu_walk_results(res, None, cap)
+        return res, int(n)
+
+    def aln_records(self):
+        """[(AlnHdr, "cigar2\\tannot2\\tcigar1\\tannot1")] of the last align() with params.aln (as Context.aln_records)."""
+        L = self.L
+        L.emu_aln_records.restype = C.c_uint64
+        L.emu_aln_records.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p]
+        st, cap = C.c_uint32(0), C.c_uint32(0)
+        n = L.emu_aln_records(None, 0, C.byref(st), C.byref(cap))
+        if not n:
+            return []
+        buf = (C.c_uint8 * (n * st.value))()
+        L.emu_aln_records(buf, len(buf), C.byref(st), C.byref(cap))
+        out, txt = [], C.create_string_buffer(8192)
+        for i in range(n):
+            L.dbtk_aln_format(C.byref(buf, i * st.value), cap.value, txt, 8192)
+            out.append((abi.AlnHdr.from_buffer_copy(buf, i * st.value), txt.value.decode()))
+        return out
 
     def thread(self, rpgg, tables, params, seq, off, loci, grid=5):
         off = np.ascontiguousarray(off, np.uint64)

@@ -560,6 +560,13 @@ static std::vector<dbtk_walk_res_t> g_walk_res;
 static std::vector<uint32_t> g_walk_t;
 static dbtk_thread_rec_t* g_walk_trecs = nullptr;  // 2 per survivor index
 void emu_set_walk_trecs(dbtk_thread_rec_t* buf) { g_walk_trecs = buf; }
+static std::vector<uint8_t> g_aln;  // compact alignment records of the last emu_align_ex (-a / -ae)
+static uint32_t g_aln_stride = 0, g_aln_cap = 0;
+uint64_t emu_aln_records(uint8_t* buf, uint64_t bytes, uint32_t* stride, uint32_t* cap) {
+    *stride = g_aln_stride; *cap = g_aln_cap;
+    if (buf && bytes >= g_aln.size() && !g_aln.empty()) memcpy(buf, g_aln.data(), g_aln.size());
+    return g_aln_stride ? g_aln.size() / g_aln_stride : 0;
+}
 uint64_t emu_walk_results(dbtk_walk_res_t* res, uint32_t* tidx, uint64_t cap) {
     std::vector<size_t> ord(g_walk_res.size());
     for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
@@ -680,7 +687,26 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         w.walk_dst = walk.data(); w.walk_ret = walk.data() + npairs;
         w.counts = a.counts; w.counters = a.counters;
         w.trecs = g_walk_trecs; w.errflag = &small[3];
+        std::vector<uint8_t> alnraw;
+        uint32_t naln = 0;
+        g_aln.clear();
+        if (p->aln) {
+            g_aln_cap = std::min<uint32_t>(DBTK_THREAD_CAP, (maxlen + maxlen / 4 + 8 + 7) & ~7u);
+            g_aln_stride = (uint32_t)sizeof(dbtk_aln_hdr_t) + 4 * g_aln_cap;
+            const uint64_t amax = npairs + (uint64_t)ALN_CHUNK * grid_pair;
+            alnraw.assign(amax * g_aln_stride, 0);
+            w.aln = alnraw.data(); w.aln_stride = g_aln_stride; w.aln_cap = g_aln_cap; w.aln_max = (uint32_t)amax; w.naln = &naln;
+        }
         run_grid(grid_pair, 64, sizeof(WalkSmem), [&](EmuX& x) { body_walk_pairs(x, w); });
+        if (p->aln) {  // as dbtk_ctx_aln_records: drop the invalid slots, pair order
+            std::vector<std::pair<uint32_t, uint32_t>> order;
+            for (uint32_t i = 0; i < naln; ++i) {
+                const dbtk_aln_hdr_t* h = reinterpret_cast<const dbtk_aln_hdr_t*>(alnraw.data() + (size_t)i * g_aln_stride);
+                if (h->pair != NAN32) order.emplace_back(h->pair, i);
+            }
+            std::sort(order.begin(), order.end());
+            for (auto& o : order) g_aln.insert(g_aln.end(), alnraw.begin() + (size_t)o.second * g_aln_stride, alnraw.begin() + (size_t)(o.second + 1) * g_aln_stride);
+        }
         g_walk_res.clear();
         for (uint32_t t = 0; t < small[0]; ++t)
             if (walk[t] != NAN32) g_walk_res.push_back({surv[t], walk[t], (int8_t)(walk[npairs + t] & 0xFF), (int8_t)((walk[npairs + t] >> 8) & 0xFF), {(uint8_t)(t & 0xFF), (uint8_t)0}});

@@ -165,6 +165,55 @@ def oracle_vs_reference(tmp, k, seed):
     print(f"k={k}: {total} reads, ret {dict(rets)}, edit tracts {dict(classes)}, {flagged} flagged by threadCheck")
 
 
+# ---- the hot loop with threading = 2 (v1.3 call sites): pair mode ---------------------------------------------
+PAIR_IDX = [abi.C_NREADS, abi.C_SUBFILTERED, abi.C_KMERFILTERED, abi.C_LOCUSFILTERED, abi.C_QCFILTERED, abi.C_THREADING,
+            abi.C_FEASIBLE, abi.C_NSHORT, abi.C_NHASH0, abi.C_NHASH1, abi.C_ALGO_INC]
+
+
+def pair_reads(case, seed, npairs=1500):
+    return synth.sim_reads(case.loci, npairs=npairs, sub=0.02, indel=0.004, seed=seed, nrate=0.002, chimeric=0.2, background=0.2, short=0.03)
+
+
+def expected_aln(O, o, reads, aln, nloci):
+    """(pair, dst, "cigar2 annot2 cigar1 annot1") per emitted pair + the text writeAlignments prints, from the oracle's results."""
+    recs, lines = [], []
+    for i in range(o["nres"]):
+        w = o["res"][i]
+        if aln == 2 and w.dst == nloci:
+            continue
+        c1, a1 = O.cigar_annot(o["trecs"][2 * i])
+        c2, a2 = O.cigar_annot(o["trecs"][2 * i + 1])
+        recs.append((w.pair, w.dst, f"{c2}\t{a2}\t{c1}\t{a1}"))
+        lines.append(bind.aln_line(O, o["res"], o["trecs"], i, reads.titles[w.pair], reads.seqs[2 * w.pair], reads.seqs[2 * w.pair + 1], nloci))
+    return recs, "".join(lines)
+
+
+def glue_oracle_vs_reference(tmp, k, seed):
+    """orc_align_walk against the reference's functions driven through the commented-out v1.3 call sites
+    (oracle/ref_harness.cpp: ref_align_v13): walk results, thread records, exact counts, counters, and the -a / -ae text."""
+    O = bind.Oracle()
+    H = bind.RefHarness()
+    case = WalkCase(tmp, f"p{k}", k, seed)
+    oh = O.load(case.prefix, k); O.load_graph(oh, case.prefix + ".graph.kmers")
+    h = H.load(case.prefix); H.load_graph(h, case.prefix + ".graph.kmers")
+    for aln, ps in ((1, PARAM_SETS[0]), (2, PARAM_SETS[1]), (2, PARAM_SETS[3])):
+        p = abi.default_params(ksize=k, cthreshold=45, threading=2, aln=aln, okam=0, **ps)
+        reads = pair_reads(case, seed=5 + aln + ps["thread_cth"])
+        seq, off = reads.packed()
+        r = H.align_v13(h, p, seq, off, reads.titles)
+        o = O.align_walk(oh, p, seq, off)
+        n = o["nres"]
+        assert n == r["nres"] and n > 500
+        assert bytes(r["res"])[:8 * n] == bytes(o["res"])[:8 * n]
+        sz = C.sizeof(abi.ThreadRec)
+        assert bytes(r["trecs"])[:2 * n * sz] == bytes(o["trecs"])[:2 * n * sz]
+        assert (r["counts_file"] == o["counts_file"]).all() and o["counts_file"].sum() > 0
+        assert (r["counters"][PAIR_IDX] == o["counters"][PAIR_IDX]).all()
+        _, text = expected_aln(O, o, reads, aln, case.loci.nloci)
+        assert text == r["aln"]
+    print(f"glue k={k}: ok")
+
+
 @pytest.mark.skipif(not synth.have_ref(), reason="needs oracle/_ref (make -C oracle ref where /root/reference exists)")
 @pytest.mark.parametrize("k,seed", [(21, 3), (25, 4), (17, 5)])
 def test_oracle_walk_equals_reference(tmp_path, k, seed):
@@ -173,7 +222,9 @@ def test_oracle_walk_equals_reference(tmp_path, k, seed):
     import subprocess
     r = subprocess.run([sys.executable, os.path.abspath(__file__), str(tmp_path), str(k), str(seed)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    print(r.stdout.strip().splitlines()[-1])
+    out = [l for l in r.stdout.strip().splitlines() if l.startswith(("k=", "glue"))]
+    assert len(out) == 2 and out[1].endswith("ok")
+    print("\n".join(out))
 
 
 def test_oracle_graph_loaders(tmp_path):
@@ -221,7 +272,70 @@ def test_emulated_walk_kernel_equals_oracle(tmp_path, k, seed):
     assert n > 3000
 
 
+def check_pair_mode(run, O, oh, case, k, nloci):
+    """run(p, seq, off) -> dict(counts (OUT.trkmc.ar order), counters, res, nres, aln, order): compared with the oracle."""
+    for aln, ps in ((1, PARAM_SETS[0]), (2, PARAM_SETS[1]), (0, PARAM_SETS[2]), (2, PARAM_SETS[3])):
+        p = abi.default_params(ksize=k, cthreshold=45, threading=2, aln=aln, okam=0, **ps)
+        reads = pair_reads(case, seed=5 + aln + ps["thread_cth"])
+        seq, off = reads.packed()
+        o = O.align_walk(oh, p, seq, off)
+        g = run(p, seq, off)
+        co = np.zeros(len(g["counts"]), np.uint64)
+        np.add.at(co, g["order"].astype(np.int64), o["counts_file"])
+        assert (co == g["counts"]).all() and co.sum() > 0
+        assert (o["counters"] == g["counters"]).all(), (o["counters"], g["counters"])
+        n = o["nres"]
+        assert g["nres"] == n and bytes(g["res"])[:8 * n] == bytes(o["res"])[:8 * n]
+        exp, _ = expected_aln(O, o, reads, aln, nloci)
+        if aln:
+            assert [(h.pair, h.dst, t) for h, t in g["aln"]] == exp
+        else:
+            assert g["aln"] == []
+
+
+@pytest.mark.parametrize("k,seed", [(21, 3), (25, 4)])
+def test_emulated_pair_mode_equals_oracle(tmp_path, k, seed):
+    """K1..K3 + the walk kernel's pair mode on the emulated lanes: exact counts, all counters, walk results, -a / -ae records."""
+    O = bind.Oracle()
+    E = bind.Emu()
+    case = WalkCase(str(tmp_path), f"ep{k}", k, seed)
+    oh = O.load(case.prefix, k); O.load_graph(oh, case.prefix + ".graph.kmers")
+    g = E.load(case.prefix, k, flags=abi.LOAD_GRAPH)
+    tb = E.tables(g)
+    order = g.output_order()
+
+    def run(p, seq, off):
+        e = E.align(g, tb, p, seq, off)
+        res, nres = E.walk_results(len(off))
+        return dict(counts=e["counts"], counters=e["counters"], res=res, nres=nres, aln=E.aln_records(), order=order)
+    check_pair_mode(run, O, oh, case, k, case.loci.nloci)
+
+
 # ------------------------------------------------------------ GPU vs oracle --
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,seed", [(21, 3), (25, 4)])
+def test_gpu_pair_mode_equals_oracle(tmp_path, k, seed):
+    """BASELINE config 4's path (k = 25, -gc 85 3) and config 5's (-ae) through the C-ABI: dbtk_align_batch with
+    threading = 2, then dbtk_ctx_counts / dbtk_ctx_walk_results / dbtk_ctx_aln_records, against the oracle."""
+    O = bind.Oracle()
+    D = bind.pkg.Dbtk()
+    case = WalkCase(str(tmp_path), f"gp{k}", k, seed)
+    oh = O.load(case.prefix, k); O.load_graph(oh, case.prefix + ".graph.kmers")
+    g = D.load(case.prefix, k, flags=abi.LOAD_GRAPH)
+    order = g.output_order()
+
+    def run(p, seq, off):
+        ctx = D.context(g, p, device=0)
+        ctx.align(seq, off)
+        r = ctx.counts()
+        res, _, nres = ctx.walk_results(len(off))
+        out = dict(counts=r["counts"], counters=r["counters"], res=res, nres=nres, aln=ctx.aln_records(), order=order)
+        ctx.close()
+        return out
+    check_pair_mode(run, O, oh, case, k, case.loci.nloci)
+
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,seed", [(21, 3), (25, 4)])
 def test_gpu_walk_equals_oracle(tmp_path, k, seed):
@@ -254,3 +368,4 @@ def test_gpu_walk_equals_oracle(tmp_path, k, seed):
 
 if __name__ == "__main__":  # worker of test_oracle_walk_equals_reference
     oracle_vs_reference(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))
+    glue_oracle_vs_reference(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))
