@@ -21,8 +21,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <functional>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -46,7 +49,10 @@ namespace {
 struct Opts {
     bool bait = false, aug = false, threading = false, tc = false, aln = false, aln_minimal = false, okam = true, g2pan = false;
     bool writeKmerName = false, outputBubbles = false, invkmer = false, isFastq = false, trackBait = false, qc = false;
-    int simmode = 0, extractFastX = 0, verbosity = 0, ngpus = 1;
+    int simmode = 0, extractFastX = 0, verbosity = 0, ngpus = 1, gzLevel = 6, emitThreads = 0;
+    bool correction = true;
+    bool v13 = false;       // --v13-threading: -g/-gc/-gcc run the graph walk of the v1.3 contract instead of HEAD's dead path
+    std::string alnGz;      // --aln-gz FILE: the -a / -ae records gzip-compressed into FILE (instead of plain on stdout)
     uint64_t trim = 0, thread_cth = 100, Cthreshold = 10, nproc = 1, ksize = 21, qth = 20, N_FILTER = 4, NM_FILTER = 1, NM_TR = 40,
              MAX_NT = 2, maxncorrection = 4;
     float readsPerBatchFactor = 1;
@@ -76,6 +82,12 @@ void usage() {
             "Execution:\n"
             "  -p <INT>  -r <FLOAT>   accepted for compatibility (threads / batch factor: batch = 300000*r reads)\n"
             "  --gpus <INT>           GPUs to spread batches over [1]\n"
+            "  --v13-threading        -g/-gc/-gcc <INT> [INT] walk both mates through PREF.graph.kmers (or PREF.graph.umap) with error\n"
+            "                         correction as danbing-tk v1.3 did (at this HEAD the reference leaves those flags dead: all-zero output);\n"
+            "                         TR k-mers are then counted in \"exact\" mode and -a / -ae print alignment records on stdout\n"
+            "  --aln-gz <FILE>        write the -a / -ae records gzip-compressed to FILE (deflated on --emit-threads host threads\n"
+            "                         while the GPU works on the next batches) instead of plain text on stdout\n"
+            "  --emit-threads <INT>   host threads formatting / compressing records [cores / 2]   --gz-level <INT> [6]\n"
             "Developer:\n"
             "  -s <1|2>  -e <1|2>  -v <INT>  -g|-gc|-gcc <INT> [INT]  -a  -ae  -tb  -ik  -t <INT>  -m <FILE>  -au\n\n");
 }
@@ -155,6 +167,8 @@ struct Batch {  // one batch on its way through the stages; read r = flat[off[r]
     std::vector<uint64_t> src;                               // simmode: source locus per pair
     std::vector<dbtk_pair_rec_t> recs;
     uint64_t nrec = 0;
+    std::vector<uint8_t> aln;   // -a / -ae: compact alignment records (dbtk_ctx_aln_records)
+    uint64_t naln = 0; uint32_t aln_stride = 0, aln_cap = 0;
     long gpu_sec = 0;
     std::string title(uint64_t p) const { return std::string(tar.data() + toff[p], toff[p + 1] - toff[p]); }
     void add_read(const char* sp, size_t sn, const char* qp, size_t qn, bool fq) {
@@ -238,6 +252,7 @@ int main(int argc, char* argv[]) {
         else if (a == "-au") o.aug = true;
         else if (a == "-g" || a == "-gc" || a == "-gcc") {
             o.threading = true;
+            o.correction = a != "-g";  // usage text (AQ.cpp:2325-2326): -g walks without error correction, -gc / -gcc with
             if (a == "-gcc") o.tc = true;
             o.thread_cth = strtoull(need(++argi).c_str(), nullptr, 10);
             if (need(argi + 1)[0] != '-') o.maxncorrection = strtoull(args[++argi].c_str(), nullptr, 10);
@@ -278,6 +293,10 @@ int main(int argc, char* argv[]) {
         else if (a == "-cth") o.Cthreshold = strtoull(need(++argi).c_str(), nullptr, 10);
         else if (a == "-qth") o.qth = strtoull(need(++argi).c_str(), nullptr, 10);
         else if (a == "--gpus") o.ngpus = atoi(need(++argi).c_str());
+        else if (a == "--v13-threading") o.v13 = true;
+        else if (a == "--aln-gz") o.alnGz = need(++argi);
+        else if (a == "--emit-threads") o.emitThreads = atoi(need(++argi).c_str());
+        else if (a == "--gz-level") o.gzLevel = atoi(need(++argi).c_str());
         else {
             fprintf(stderr, "invalid option: %s\n", a.c_str());
             abort();  // the reference does `throw;` with no active exception -> std::terminate
@@ -298,8 +317,11 @@ int main(int argc, char* argv[]) {
     time_t time1 = time(nullptr);
     dbtk_rpgg_t* rpgg = nullptr;
     const bool use_bait = o.bait && !o.extractFastX && !o.threading;  // baitDB is only read and used on that path
+    const bool walk = o.v13 && o.threading && !o.extractFastX;          // the graph walk of the v1.3 contract (AQ.cpp:2072-2088)
+    const bool emit_aln = walk && o.aln;                                 // -a / -ae records (AQ.cpp:2232-2248)
     if (dbtk_rpgg_load(o.trPrefix.c_str(), (uint32_t)o.ksize, o.qc ? o.qcFn.c_str() : nullptr,
-                       use_bait ? o.baitFname.c_str() : nullptr, o.extractFastX ? DBTK_LOAD_INDEX_ONLY : 0, &rpgg))
+                       use_bait ? o.baitFname.c_str() : nullptr,
+                       (o.extractFastX ? DBTK_LOAD_INDEX_ONLY : 0) | (walk ? DBTK_LOAD_GRAPH : 0), &rpgg))
         die_assert(dbtk_last_error());
     const uint64_t nloci = dbtk_rpgg_nloci(rpgg);
     fprintf(stderr, "total number of loci in %s: %llu\n", o.trFname.c_str(), (unsigned long long)nloci);
@@ -311,7 +333,11 @@ int main(int argc, char* argv[]) {
     P.ksize = (uint32_t)o.ksize; P.n_filter = (uint32_t)o.N_FILTER; P.nm_filter = (uint32_t)o.NM_FILTER;
     P.cthreshold = (uint32_t)(uint16_t)o.Cthreshold;  // uint16_t in the reference (AQ.cpp:1765)
     P.nm_tr = (uint32_t)o.NM_TR; P.max_nt = (uint32_t)o.MAX_NT; P.qth = (uint32_t)o.qth;
-    P.okam = o.okam; P.qc = o.qc; P.extract = (uint32_t)o.extractFastX; P.threading = o.threading; P.simmode = (uint32_t)o.simmode;
+    P.okam = o.okam; P.qc = o.qc; P.extract = (uint32_t)o.extractFastX; P.simmode = (uint32_t)o.simmode;
+    P.threading = walk ? DBTK_THREADING_V13 : (o.threading ? DBTK_THREADING_HEAD : 0);
+    P.thread_cth = (uint32_t)o.thread_cth; P.maxncorrection = (uint32_t)o.maxncorrection;
+    P.correction = o.correction;
+    P.aln = emit_aln ? (o.aln_minimal ? 2 : 1) : 0;
     P.trackbait = (o.trackBait && use_bait) ? 1 : 0;  // -tb only does something inside the bait filter (AQ.cpp:2111-2119)
     P.bait = use_bait;
     P.bubbles = o.outputBubbles && !o.extractFastX && !o.threading;  // countNovelEdges only runs on the assignment path
@@ -339,7 +365,7 @@ int main(int argc, char* argv[]) {
     auto recycle_batch = [&](BatchP b) {
         if (!b) return;
         b->flat.clear(); b->off.clear(); b->qar.clear(); b->qoff.clear(); b->tar.clear(); b->toff.clear(); b->src.clear();
-        b->index = 0; b->nreads = 0; b->nReads_so_far = 0; b->nparked = 0; b->nrec = 0; b->gpu_sec = 0;
+        b->index = 0; b->nreads = 0; b->nReads_so_far = 0; b->nparked = 0; b->nrec = 0; b->gpu_sec = 0; b->naln = 0;
         std::lock_guard<std::mutex> l(bpool_m);
         if (bpool.size() < 16) bpool.push_back(std::move(b));
     };
@@ -661,6 +687,16 @@ int main(int argc, char* argv[]) {
                 const dbtk_status_t st = dbtk_align_batch(ctx[d], b->flat.data(), b->off.data(), send_qual ? flatq.data() : nullptr, npairs,
                                                           want_recs ? b->recs.data() : nullptr, want_recs ? npairs : 0, &b->nrec);
                 if (st) die_assert(std::string("align: ") + dbtk_last_error());
+                if (emit_aln) {
+                    uint64_t n = 0;
+                    dbtk_status_t sa = dbtk_ctx_aln_records(ctx[d], b->aln.data(), b->aln.size(), &n, &b->aln_stride, &b->aln_cap);
+                    if (sa == DBTK_ERR_OVERFLOW) {
+                        b->aln.resize((size_t)n * b->aln_stride);
+                        sa = dbtk_ctx_aln_records(ctx[d], b->aln.data(), b->aln.size(), &n, &b->aln_stride, &b->aln_cap);
+                    }
+                    if (sa) die_assert(std::string("alignment records: ") + dbtk_last_error());
+                    b->naln = n;
+                }
                 b->gpu_sec = (long)(time(nullptr) - t2);
                 { std::lock_guard<std::mutex> l(done_m); gpu_busy += now() - tg; }
                 aligned.push(std::move(b));
@@ -670,13 +706,68 @@ int main(int argc, char* argv[]) {
         });
 
     // Stage C — critical section B (AQ.cpp:2253-2279): stdout, in batch order
+    FILE* gzout = nullptr;
+    if (emit_aln && !o.alnGz.empty()) { gzout = fopen(o.alnGz.c_str(), "wb"); if (!gzout) die_assert("cannot create " + o.alnGz); }
+    const int emit_threads = o.emitThreads > 0 ? o.emitThreads : (int)std::max(1u, hw / 2);
+    uint64_t aln_bytes = 0;
     {
         std::map<uint64_t, BatchP> waiting;
         uint64_t next = 0;
         std::string out;
         BatchP got;
+        // -a / -ae: writeAlignments (AQ.cpp:1742-1759), `src dst title seq2 seq1 cigar2 annot2 cigar1 annot1`, formatted (and,
+        // with --aln-gz, deflated into independent gzip members) in chunks by a pool of host threads while the GPU threads
+        // are already on the next batches; the chunks leave in record order.
+        auto emit_alignments = [&](const Batch& b) {
+            const uint64_t n = b.naln;
+            if (!n) return;
+            const uint64_t CH = 2048;
+            const uint64_t nch = (n + CH - 1) / CH;
+            std::vector<std::string> chunk(nch);
+            std::atomic<uint64_t> nextc{0};
+            auto work = [&] {
+                char txt[8192];
+                std::string t;
+                for (;;) {
+                    const uint64_t c = nextc.fetch_add(1);
+                    if (c >= nch) break;
+                    t.clear();
+                    for (uint64_t i = c * CH; i < std::min(n, (c + 1) * CH); ++i) {
+                        const uint8_t* rec = b.aln.data() + (size_t)i * b.aln_stride;
+                        const dbtk_aln_hdr_t* h = (const dbtk_aln_hdr_t*)rec;
+                        const uint64_t p = h->pair;
+                        t += ".\t";  // srcLocus is -1 outside simulation mode
+                        t += std::to_string((int)h->dst); t += '\t';
+                        t.append(b.tar.data() + b.toff[p], b.toff[p + 1] - b.toff[p]); t += '\t';
+                        t.append((const char*)b.flat.data() + b.off[2 * p + 1], b.off[2 * p + 2] - b.off[2 * p + 1]); t += '\t';
+                        t.append((const char*)b.flat.data() + b.off[2 * p], b.off[2 * p + 1] - b.off[2 * p]); t += '\t';
+                        const size_t l = dbtk_aln_format(rec, b.aln_cap, txt, sizeof txt);
+                        t.append(txt, std::min(l, sizeof txt - 1)); t += '\n';
+                    }
+                    if (gzout) {  // one gzip member per chunk: `zcat FILE` is the concatenation
+                        z_stream z;
+                        memset(&z, 0, sizeof z);
+                        if (deflateInit2(&z, o.gzLevel, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die_assert("deflateInit2 failed");
+                        std::string gz(deflateBound(&z, t.size()) + 64, '\0');
+                        z.next_in = (Bytef*)t.data(); z.avail_in = (uInt)t.size();
+                        z.next_out = (Bytef*)&gz[0]; z.avail_out = (uInt)gz.size();
+                        if (deflate(&z, Z_FINISH) != Z_STREAM_END) die_assert("deflate failed");
+                        gz.resize(gz.size() - z.avail_out);
+                        deflateEnd(&z);
+                        chunk[c].swap(gz);
+                    } else chunk[c] = t;
+                }
+            };
+            const int nt = (int)std::min<uint64_t>(nch, (uint64_t)emit_threads);
+            std::vector<std::thread> th;
+            for (int i = 1; i < nt; ++i) th.emplace_back(work);
+            work();
+            for (auto& x : th) x.join();
+            for (auto& c : chunk) { fwrite(c.data(), 1, c.size(), gzout ? gzout : stdout); aln_bytes += c.size(); }
+        };
         auto emit = [&](const Batch& b) {
             out.clear();
+            if (emit_aln) emit_alignments(b);
             auto seq = [&](uint64_t r) { return std::string((const char*)b.flat.data() + b.off[r], b.off[r + 1] - b.off[r]); };
             auto qual = [&](uint64_t r) { return std::string(b.qar.data() + b.qoff[r], b.qoff[r + 1] - b.qoff[r]); };
             for (uint64_t i = 0; i < b.nrec; ++i) {
@@ -732,6 +823,7 @@ int main(int argc, char* argv[]) {
     for (auto& w : workers) w.join();
     fclose(in.f);
     fflush(stdout);
+    if (gzout) fclose(gzout);
     fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: reading %.2f s, cutting %.2f s, pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads\n",
             now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, read_busy, cut_busy, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit);
 

@@ -1165,10 +1165,9 @@ dbtk_status_t dbtk_align_batch_device(dbtk_ctx_t* c, const void* d_seq, const vo
     return launch_batch(c, (const uint8_t*)d_seq, (const uint64_t*)d_offsets, ~0ull, npairs, max_read_len, nullptr, 0);
 }
 
-dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* c) {
-    if (!c) { set_error("null argument"); return DBTK_ERR_ARG; }
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(sync_all(c));
+// The sticky error words of all lanes (a read longer than promised was truncated on the device: the accumulators are
+// tainted from then on).  Reported once, then cleared.
+static dbtk_status_t take_error_words(dbtk_ctx_t* c) {
     uint32_t err = 0, err2 = 0;
     HIPCHK(hipMemcpy(&err, c->d_small + 3, 4, hipMemcpyDeviceToHost));
     if (c->alt.d_small) HIPCHK(hipMemcpy(&err2, c->alt.d_small + 3, 4, hipMemcpyDeviceToHost));
@@ -1177,20 +1176,30 @@ dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* c) {
         if (l.d_small) HIPCHK(hipMemcpy(&e3, l.d_small + 3, 4, hipMemcpyDeviceToHost));
         if (e3) err2 = e3;
     }
-    if (err || err2) {  // reported once: the words are cleared
+    if (err || err2) {
         (void)hipMemset(c->d_small + 3, 0, 4);
         if (c->alt.d_small) (void)hipMemset(c->alt.d_small + 3, 0, 4);
         for (auto& l : c->parked) if (l.d_small) (void)hipMemset(l.d_small + 3, 0, 4);
-        set_error("device reported an over-long read");
-        return (dbtk_status_t)(err ? err : err2);
+        const uint32_t e = err ? err : err2;
+        set_error(e == DBTK_ERR_READ_TOO_LONG ? "device reported an over-long read (the accumulators include truncated reads)"
+                                              : "device reported an error during the batch");
+        return (dbtk_status_t)e;
     }
     return DBTK_OK;
+}
+
+dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* c) {
+    if (!c) { set_error("null argument"); return DBTK_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(sync_all(c));
+    return take_error_words(c);
 }
 
 dbtk_status_t dbtk_ctx_counts(dbtk_ctx_t* c, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* counters) {
     if (!c) { set_error("null argument"); return DBTK_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(sync_all(c));
+    { const dbtk_status_t es = take_error_words(c); if (es) return es; }  // never hand out tainted accumulators silently
     const uint64_t nloci = c->g->nloci;
     if (counts && c->ntr) HIPCHK(hipMemcpy(counts, c->d_accum, c->ntr * 8, hipMemcpyDeviceToHost));
     if (kmc && nloci) HIPCHK(hipMemcpy(kmc, c->d_accum + c->ntr, nloci * 8, hipMemcpyDeviceToHost));
@@ -1215,6 +1224,9 @@ dbtk_status_t dbtk_ctx_reset(dbtk_ctx_t* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(sync_all(c));
     HIPCHK(hipMemsetAsync(c->d_accum, 0, c->n_accum * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_small + 3, 0, 4, c->stream));  // a stale error word would be reported against the next run
+    if (c->alt.d_small) HIPCHK(hipMemsetAsync(c->alt.d_small + 3, 0, 4, c->stream));
+    for (auto& l : c->parked) if (l.d_small) HIPCHK(hipMemsetAsync(l.d_small + 3, 0, 4, c->stream));
     HIPCHK(sync_all(c));
     return DBTK_OK;
 }
@@ -1345,6 +1357,10 @@ dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n) {
     for (int i = 0; i < n; ++i) {
         devs[i] = ctxs[i]->device;
         if (ctxs[i]->n_accum != ctxs[0]->n_accum) { set_error("contexts belong to different RPGGs"); return DBTK_ERR_ARG; }
+        HIPCHK(hipSetDevice(ctxs[i]->device));
+        HIPCHK(sync_all(ctxs[i]));
+        const dbtk_status_t es = take_error_words(ctxs[i]);  // do not spread tainted accumulators over the other GPUs
+        if (es) return es;
     }
     if (commInitAll(comms.data(), n, devs.data()) != 0) { set_error("ncclCommInitAll failed"); return DBTK_ERR_HIP; }
     const int ncclUint64 = 5, ncclSum = 0;

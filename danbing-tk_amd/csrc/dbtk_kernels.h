@@ -351,6 +351,9 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     if (lane == 0 && x.bid() == 0) x.atomic_add(&ctr[DBTK_C_NREADS], 2 * a.npairs);  // nReads, AQ.cpp:1977
     const uint64_t ntiles = (a.npairs + K1_TP - 1) / K1_TP;
     const int lane_ = (int)lane; (void)lane_;
+    // Bytes readable at a.seq.  The device entry point does not know the batch's length on the host (~0): the contract there is
+    // "readable up to the end of the last read rounded up to 16" (dbtk.h), so that is what the fetch guards work with.
+    const uint64_t seq_len = a.seq_len != ~0ull ? a.seq_len : ((a.off[2 * a.npairs] + 15) & ~15ull);
     DBTK_STAMP_DECL
     // Tile geometry comes from two offsets; they are requested two tiles ahead and only turned into
     // (A0, nch) when their tile becomes the one being fetched, so nothing waits on them.
@@ -363,13 +366,13 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     // the pack step never looks at them); a chunk that would cross the end of the batch reads the base instead and the
     // pack step replaces it.  Precondition (kept by the host side): 16 bytes are readable at a.seq.
     auto fetch = [&](uint64_t p0, uint32_t np, uint64_t A0) {
-        const bool inb = A0 + 16 <= a.seq_len;
+        const bool inb = A0 + 16 <= seq_len;
 #ifdef DBTK_STAMPS
         const uint8_t* base = a.seq + ((inb && !(a.P.diag & 2)) ? A0 : 0ull);  // (knob 2: no streaming traffic)
 #else
         const uint8_t* base = a.seq + (inb ? A0 : 0ull);
 #endif
-        const uint64_t rem64 = inb ? a.seq_len - A0 : 0ull;
+        const uint64_t rem64 = inb ? seq_len - A0 : 0ull;
         const uint32_t rem = rem64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem64;  // bytes readable from base (saturated)
 #pragma unroll
         for (int j = 0; j < K1_PF; ++j) {
@@ -428,15 +431,15 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         DBTK_STAMP(16);  // tile set-up
         // A: pack the tile.  Fast form: 2-bit codes only, plus "some byte is not ACGT" per lane.
         uint32_t bad = 0;
-        const bool tile_tail = A0 + 16ull * nch > a.seq_len;  // only the batch's last tile can hold the partial last chunk
+        const bool tile_tail = A0 + 16ull * nch > seq_len;  // only the batch's last tile can hold the partial last chunk
         if (!toolong) {
 #pragma unroll
             for (int j = 0; j < K1_PF; ++j) {
                 const uint32_t c = lane + 64u * j;
                 if (c < nch + 3) {  // (chunks nch .. nch+2 are padding: whatever was fetched will do)
-                    if (tile_tail && c < nch && A0 + 16ull * c + 16 > a.seq_len) {  // (through a temporary: w must stay in registers)
+                    if (tile_tail && c < nch && A0 + 16ull * c + 16 > seq_len) {  // (through a temporary: w must stay in registers)
                         uint32_t t[4];
-                        load_tail_chunk(a.seq, a.seq_len, A0 + 16ull * c, t);
+                        load_tail_chunk(a.seq, seq_len, A0 + 16ull * c, t);
                         w[j][0] = t[0]; w[j][1] = t[1]; w[j][2] = t[2]; w[j][3] = t[3];
                     }
                     uint32_t b = 0;
@@ -448,8 +451,8 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                 uint32_t t[4] = {0, 0, 0, 0}, vd = 0;
                 const uint64_t gb = A0 + 16ull * c;
                 if (c < nch) {
-                    if (gb + 16 <= a.seq_len) { const uint4 q = *reinterpret_cast<const uint4*>(a.seq + gb); t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w; }
-                    else load_tail_chunk(a.seq, a.seq_len, gb, t);
+                    if (gb + 16 <= seq_len) { const uint4 q = *reinterpret_cast<const uint4*>(a.seq + gb); t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w; }
+                    else load_tail_chunk(a.seq, seq_len, gb, t);
                 }
                 sm.pk[c] = pack16(t, &vd);
                 sm.vd[c] = (uint16_t)vd;

@@ -275,7 +275,14 @@ size_t dbtk_aln_format(const void* rec, uint32_t cap, char* out, size_t out_cap)
  * records are not produced.  A read longer than max_read_len (or than
  * DBTK_MAX_READ_LEN) is not validated on the host here: the device truncates it
  * to what was promised and raises an error word that the next
- * dbtk_ctx_synchronize returns, once, as DBTK_ERR_READ_TOO_LONG. */
+ * dbtk_ctx_synchronize / dbtk_ctx_counts / dbtk_allreduce returns, once, as
+ * DBTK_ERR_READ_TOO_LONG; the accumulators are tainted from then on
+ * (dbtk_ctx_reset clears both).
+ * Stream ordering: the kernels run on the context's own streams, which are NOT
+ * ordered against the stream that produced d_seq / d_offsets.  The inputs must
+ * be complete before the call (synchronize the producing stream, or make it
+ * wait on an event first) and must stay untouched until dbtk_ctx_synchronize
+ * (or dbtk_ctx_counts / dbtk_allreduce) has returned. */
 dbtk_status_t dbtk_align_batch_device(dbtk_ctx_t* ctx, const void* d_seq, const void* d_offsets,
                                       uint64_t npairs, uint32_t max_read_len);
 dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* ctx);

@@ -90,7 +90,7 @@ def test_cli_reproduces_reference_binary(name, tmp_path):
         if not tag:
             continue
         for f in sorted(os.listdir(d)):
-            if not f.startswith(tag + ".") or f.endswith(".kam.txt") or f.endswith(".extract.txt"):
+            if not f.startswith(tag + ".") or f.endswith((".kam.txt", ".extract.txt", ".aln.txt")):
                 continue
             if f.endswith(".totals.txt"):
                 mine = [l + "\n" for l in r.stderr.decode().split("\n") if l[:1].isdigit() and " reads " in l]
@@ -225,3 +225,21 @@ def test_ktools_serialize_binary(tmp_path):
     for ext in (".kmers.dbi", ".fl.kdb", ".tre.kdb"):
         assert open(pref + ext, "rb").read() == open(os.path.join(d2, "pan" + ext), "rb").read(), ext
     assert subprocess.run([kt], stderr=subprocess.PIPE).returncode == 0
+
+
+@pytest.mark.gpu
+def test_cli_aln_gz_is_the_stdout_stream(tmp_path):
+    """--aln-gz FILE (BASELINE config 5: gzip on the host, overlapped): `zcat FILE` is what stdout carries without it —
+    the golden -ae records of g5 — whatever the number of deflate threads and chunks."""
+    import gzip
+    d, _ = golden_cmds("g5_walk_k25")
+    w = str(tmp_path / "w")
+    shutil.copytree(d, w)
+    want = open(os.path.join(d, "refae.aln.txt"), "rb").read()
+    for extra in ([], ["--emit-threads", "3", "--gz-level", "1"]):
+        r = run(["--v13-threading", "-gc", "85", "3", "-ae", "-ka", "-k", "25", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-o", "gz",
+                 "--aln-gz", "out.aln.gz"] + extra, cwd=w)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert r.stdout == b""
+        assert gzip.open(os.path.join(w, "out.aln.gz"), "rb").read() == want
+        assert open(os.path.join(w, "gz.trkmc.ar"), "rb").read() == open(os.path.join(d, "refae.trkmc.ar"), "rb").read()

@@ -311,6 +311,35 @@ def test_emulated_pair_mode_equals_oracle(tmp_path, k, seed):
     check_pair_mode(run, O, oh, case, k, case.loci.nloci)
 
 
+def test_oracle_reproduces_golden_g5():
+    """The committed vectors of tests/golden/g5_walk_k25 (made by tests/golden/make_golden_walk.py from the reference's own
+    functions): alignment records, exact counts in OUT.trkmc.ar order, totals."""
+    import refio
+    O = bind.Oracle()
+    d = os.path.join(_HERE, "golden", "g5_walk_k25")
+    pref = os.path.join(d, "pan")
+    oh = O.load(pref, 25); O.load_graph(oh, pref + ".graph.kmers")
+    tr = synth.read_rpgg_files(pref)
+    for tag, aln, tcth, maxc in (("refae", 2, 85, 3), ("refa", 1, 100, 4), ("refg", 0, 85, 3)):
+        p = abi.default_params(ksize=25, cthreshold=45, threading=2, aln=aln, okam=0, thread_cth=tcth, correction=1, maxncorrection=maxc)
+        rd = refio.read_pairs(os.path.join(d, "reads.fa"), False, p.cthreshold + p.ksize - 1)
+        seq, off = rd.packed()
+        o = O.align_walk(oh, p, seq, off)
+        _, text = expected_aln(O, o, rd, aln, len(tr["tr_cnt"]))
+        assert (text if aln else "") == open(os.path.join(d, tag + ".aln.txt")).read()
+        out, i = [], 0
+        for n in tr["tr_cnt"]:
+            n = int(n)
+            out.append(o["counts_file"][i:i + n][O.umap_order(tr["tr_ks"][i:i + n]).astype(np.int64)])
+            i += n
+        ar = np.fromfile(os.path.join(d, tag + ".trkmc.ar"), np.uint64)
+        assert ar[0] == len(ar) - 1 and (ar[1:] == np.concatenate(out)).all() and ar[1:].sum() > 0
+        tot = [int(l.split()[0]) for l in open(os.path.join(d, tag + ".totals.txt"))]
+        c = o["counters"]
+        assert tot == [int(x) for x in (c[abi.C_NREADS], c[abi.C_SUBFILTERED], c[abi.C_KMERFILTERED], 0, 0, c[abi.C_LOCUSFILTERED],
+                                        c[abi.C_QCFILTERED], c[abi.C_THREADING], c[abi.C_FEASIBLE], 0)]
+
+
 # ------------------------------------------------------------ GPU vs oracle --
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,seed", [(21, 3), (25, 4)])
