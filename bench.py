@@ -1,42 +1,61 @@
 #!/usr/bin/env python3
 """bench.py — `danbing-tk align` hot path on N MI355X (one process per GPU).
 
-Workload (BASELINE.json configs[1], named in config.workload): the release-scale
-synthetic RPGG of SURVEY.md 8(d) (80 000 loci, ~1.4e8 index keys; the real
-release RPGG is not available offline), replicated per GPU, and 10 M synthetic
-150 bp PE reads per GPU (WGS-like mix: `--hit-frac` of the pairs tiled from the
-loci with 0.1-0.5 % substitutions, the rest uniform random), aligned with
-`-k 21 -kf 4 1 -cth 45 -ka`.  A "step" is one pass of the hot path (encode ->
-subfilter -> kfilter probe -> vote -> assign -> count) over the rank's resident
-read set; reads are in HBM before the timed region.  N > 1: reads shard across
-ranks (weak scaling, no data-path collective); the accumulators are summed once
-at the end with one RCCL all-reduce, inside the timed region.
+Workload (BASELINE.json configs[1], named in config.workload): the release-scale synthetic RPGG of SURVEY.md 8(d)
+(80 000 loci, ~1.4e8 index keys; the real release RPGG is not available offline), replicated per GPU, and 10 M
+synthetic 150 bp PE reads per GPU (WGS-like mix: `--hit-frac` of the pairs tiled from the loci with 0.1-0.5 %
+substitutions, the rest uniform random), aligned with `-k 21 -kf 4 1 -cth 45 -ka`.  A "step" is one pass of the hot
+path (encode -> subfilter -> kfilter probe -> vote -> assign -> count) over the rank's resident read set; reads are in
+HBM before the timed region.  N > 1: reads shard across ranks (weak scaling, no data-path collective); the accumulators
+are summed once at the end with one RCCL all-reduce, inside the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
-objects: `roofline` (dominant kernel, algorithmic bytes / HIP-event time) and
-`cpu_baseline` (the oracle, a plain-C port of the reference path, timed on one
-host core over a bounded sample of the same workload).
+`python bench.py --gpus N` without a launcher spawns the N ranks itself (torch.distributed.run as a child process,
+before anything here touches a GPU) and relays rank 0's line.
+
+ONE JSON line on rank 0 (contract in the task statement), with these extra objects:
+  roofline      the dominant kernel of the timed region: algorithmic bytes / HIP-event time inside the region
+  probe_roofline  the same figures for k_probe, the kernel the north star's 40 % target names
+  mixes         N = 1: the all-hit mix (every pair from a locus: k_probe dominates) and the graph-walk mix
+                (threading = 2, `-gc 85 3`: config 4's path on the k = 21 RPGG), each with its own ms/step and kernel table
+  end_to_end    N = 1: the same workload through host buffers (PCIe) and through this repo's CLI (parse -> counts)
+  cpu_baseline  the REFERENCE's own pthread binary (oracle/_ref/danbing-tk, compiled from /root/reference) on the same
+                RPGG written out as the files it loads and a FASTA sample of the same reads, at -p 1 / 8 / all host
+                threads; `port` beside it = the plain-C oracle on one core (which also parity-checks this run)
 """
 import argparse
 import ctypes as C
+import hashlib
 import importlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PMC_SUMMARY = "r01i_final_pmc.csv"
+PMC_SUMMARY = "r02_pmc.json"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_SOURCES = ("dbtk_kernels.h", "dbtk_walk.h", "dbtk_tables.h", "dbtk_sort.h", "dbtk_assign.h", "dbtk_devx.h", "dbtk_hip.hip")
 
 
-def main():
+def kernel_source_hash():
+    """Identifies the kernels a PMC summary was collected for: sha256 over the device sources."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "danbing-tk_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -44,16 +63,113 @@ def main():
     ap.add_argument("--nloci", type=int, default=80000, help="loci of the synthetic RPGG (80000 = release scale)")
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (pairs = reads/2)")
     ap.add_argument("--hit-frac", type=float, default=0.02, help="fraction of pairs drawn from the loci (WGS-like: 0.02)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 = skip)")
-    ap.add_argument("--parity-pairs", type=int, default=100000, help="pairs of the CPU-baseline sample whose oracle result is compared with the HIP path (0 = skip; needs --cpu-seconds > 0)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the one-core oracle leg (0 = skip it and the parity check)")
+    ap.add_argument("--parity-pairs", type=int, default=100000, help="pairs whose oracle result is compared with the HIP path")
+    ap.add_argument("--ref-reads", type=int, default=8_000_000, help="reads of the FASTA sample the reference binary is timed on (0 = skip the reference leg)")
+    ap.add_argument("--ref-threads", type=int, nargs="*", default=None, help="-p values for the reference binary [1 8 <all host threads>]")
+    ap.add_argument("--mix-reads", type=int, default=4_000_000, help="reads per step of the extra mixes (all-hit, walk); 0 = skip them")
+    ap.add_argument("--mix-steps", type=int, default=10)
+    ap.add_argument("--no-walk", action="store_true", help="skip the graph-walk mix (threading = 2)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (host buffers, CLI)")
     ap.add_argument("--lanes", type=int, default=1, choices=(1, 2, 3),
                     help="streams the context alternates successive batches on.  2 (the library's default) overlaps one batch's encode kernel "
-                         "with the other's probe kernel (+9 %% reads/s) but then a kernel's launch duration includes its neighbour's work, "
-                         "so the roofline measurement runs on one lane")
-    ap.add_argument("--timer-every", type=int, default=4, help="record the per-kernel HIP events on every n-th step (each step's 8 records cost ~30 us)")
-    ap.add_argument("--extra-lanes", action="store_true", help="after the timed region, also run the same steps on two overlapped lanes (the library's default) and report them as `two_lanes`")
+                         "with the other's probe kernel but then a kernel's launch duration includes its neighbour's work, so the roofline "
+                         "measurement runs on one lane")
+    ap.add_argument("--timer-every", type=int, default=4, help="record the per-kernel HIP events on every n-th step")
+    ap.add_argument("--extra-lanes", action="store_true", help="also run the timed steps on two overlapped lanes and report them as `two_lanes`")
     ap.add_argument("--lib", default=None, help="diagnostic: another build of libdbtk_hip.so (tuning variants)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as children (torch.distributed.run, rendezvous on
+    127.0.0.1) BEFORE this process has touched a GPU, wait for them, relay rank 0's JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def kernel_table(ktimes, alg, steps, timed_steps):
+    """{kernel: avg ms, launches, algorithmic bytes per launch, GB/s}; the resolve stage's two kernels are priced together."""
+    kt = dict(ktimes)
+    if "k_pair_usual" in kt:
+        u, g_ = kt.pop("k_pair_usual"), kt.get("k_pair", (0.0, 0))
+        kt["k_pair"] = (u[0] + g_[0], max(u[1], g_[1]))
+        kt["k_pair: usual-pair part"] = u
+    for part in ("k_encode_bin", "k_filter_bins", "k_subfilter_cand"):
+        if part in kt:
+            t = kt.pop(part)
+            if t[1]:
+                kt[f"k_encode_subfilter: {part}"] = t
+    out = {}
+    for name, (ms, n) in kt.items():
+        if not n:
+            continue
+        avg = ms / n
+        launches = n * steps / max(timed_steps, 1)
+        per_launch = alg.get(name, 0.0) / max(launches, 1)
+        out[name] = dict(avg_ms=avg, launches=launches, timed_launches=n, algorithmic_bytes=per_launch,
+                         gbs=(per_launch / (avg * 1e-3) / 1e9) if avg > 0 else 0.0)
+    return out
+
+
+def algorithmic_bytes(abi, ctr, walk_probes=0.0):
+    """B = 2L + 12 P + 4 V + 8 A + 16 I, split over the kernels that do the work."""
+    return {
+        "k_encode_subfilter": ctr[abi.C_BASES] + 12.0 * (ctr[abi.C_ALGO_PROBES] - ctr[abi.C_NHASH1]),
+        "k_probe": 12.0 * ctr[abi.C_NHASH1],
+        "k_pair": 4.0 * ctr[abi.C_ALGO_VV] + 8.0 * ctr[abi.C_ALGO_CLS] + 16.0 * ctr[abi.C_ALGO_INC],
+        # the walk: one graph look-up (8 B node + 1 B edge mask, the PREF.graph.umap entry) and one TR-set look-up (8 B) per
+        # k-mer of both mates of every walked pair, + 16 B per count increment
+        "k_walk_pairs": walk_probes * 17.0 + 16.0 * ctr[abi.C_ALGO_INC],
+    }
+
+
+def roofline_of(name, table):
+    k = table[name]
+    return dict(bound="hbm", kernel=name, achieved=k["gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=k["gbs"] / HBM_PEAK_GBS,
+                algorithmic_bytes_per_launch=k["algorithmic_bytes"], avg_ms=k["avg_ms"])
+
+
+def pmc_traffic(kernel, table, ctr_bases_per_launch):
+    """HBM bytes per launch from the committed PMC summary — only if it was collected for THESE kernel sources."""
+    fn = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+    if not os.path.exists(fn):
+        return None, None, True
+    d = json.load(open(fn))
+    if d.get("kernel_source_hash") != kernel_source_hash():
+        return None, None, True
+    k = d.get("kernels", {}).get(kernel)
+    if not k or "FETCH_SIZE_KB" not in k:
+        return None, None, True
+    # guide's gfx950 correction: a wide coalesced stream is reported at half its bytes; K1's read stream is the only one
+    add = 0.5 * ctr_bases_per_launch if kernel == "k_encode_subfilter" else 0.0
+    return k["FETCH_SIZE_KB"] * 1024.0 + add, f"profiles/{PMC_SUMMARY} ({d.get('command', '')})", False
+
+
+def time_steps(ctx, fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    ctx.synchronize()
+    ctx.reset()
+    ctx.timers_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    ctx.synchronize()
+    return time.perf_counter() - t0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -61,12 +177,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+        ranks_seen = dist.get_world_size()
 
     os.environ["DBTK_LANES"] = str(args.lanes)
     pkg = importlib.import_module("danbing-tk_amd")
@@ -74,14 +190,48 @@ def main():
     abi = pkg.abi
     dbtk = pkg.Dbtk(args.lib) if args.lib else pkg.Dbtk()  # raises if the HIP extension is missing: no CPU fallback
     log = (lambda *a: print("[bench]", *a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
+    t_start = time.time()
+    solo = world == 1
+    do_mixes = solo and args.mix_reads > 0
+    do_walk = do_mixes and not args.no_walk
+    do_ref = solo and rank == 0 and args.ref_reads > 0 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "danbing-tk"))
 
     # ---- workload: RPGG replica per GPU, read shard per rank
     ncpu = os.cpu_count() or 8
     nth = max(2, ncpu // world)
     t0 = time.time()
     syn = pkg.Synth(nloci=args.nloci, k=21, flank=700, seed=20250808, nthreads=nth)
+    if do_walk:
+        syn.graph(nth)
     arrs = syn.arrays()
-    log(f"synthetic RPGG: {args.nloci} loci, {arrs.nkeys} index keys in {time.time() - t0:.1f}s ({nth} threads)")
+    log(f"synthetic RPGG: {args.nloci} loci, {arrs.nkeys} index keys{', graph' if do_walk else ''} in {time.time() - t0:.1f}s ({nth} threads)")
+    npairs = args.reads // 2
+    rlen = 150
+    t0 = time.time()
+    seq, off = syn.reads(npairs, rlen=rlen, hit_frac=args.hit_frac, seed=1, first_pair=rank * npairs, nthreads=nth)
+    log(f"reads: {npairs} pairs/GPU generated, {time.time() - t0:.1f}s")
+
+    # ---- the reference binary needs the RPGG as files and a FASTA sample; its -p 1 / -p 8 runs go on in the background
+    # (9 host threads) while the GPU part runs; the all-threads run comes after the timed region, alone
+    ref_dir, ref_procs, ref_results = None, [], []
+    if do_ref:
+        import ref_baseline
+        ref_dir = tempfile.mkdtemp(prefix="dbtk_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        t0 = time.time()
+        syn.write_files(os.path.join(ref_dir, "pan"))
+        nref = min(args.ref_reads // 2, npairs)
+        syn.write_fasta(seq, nref, os.path.join(ref_dir, "reads.fa"), rlen=rlen)
+        syn.write_fasta(seq, max(nref // 4, 1), os.path.join(ref_dir, "reads_small.fa"), rlen=rlen)
+        log(f"reference inputs: RPGG files + {2 * nref}-read FASTA in {ref_dir}, {time.time() - t0:.1f}s")
+        pvals = args.ref_threads if args.ref_threads else [1, 8, ncpu]
+        import threading
+        def bg(pv, fa):
+            ref_results.append(dict(ref_baseline.run_reference(os.path.join(ROOT, "oracle", "_ref", "danbing-tk"), ref_dir, fa, pv), fasta=fa))
+        for pv in [p for p in pvals if p <= 8]:
+            th = threading.Thread(target=bg, args=(pv, "reads_small.fa" if pv == 1 else "reads.fa"))
+            th.start()
+            ref_procs.append(th)
+
     t0 = time.time()
     h = C.c_void_p()
     dbtk._chk(dbtk.L.dbtk_rpgg_from_arrays(C.byref(arrs), C.byref(h)))
@@ -89,14 +239,9 @@ def main():
     params = abi.default_params(ksize=21, n_filter=4, nm_filter=1, cthreshold=45, okam=0)
     ctx = dbtk.context(g, params, device=local_rank)
     log(f"handle + HBM tables: {g.ntrkmers} TR k-mers, {time.time() - t0:.1f}s")
-    npairs = args.reads // 2
-    rlen = 150
-    t0 = time.time()
-    seq, off = syn.reads(npairs, rlen=rlen, hit_frac=args.hit_frac, seed=1, first_pair=rank * npairs, nthreads=nth)
     d_seq = torch.from_numpy(seq).to(dev)
     d_off = torch.from_numpy(off.view(np.int64)).to(dev)
     torch.cuda.synchronize()
-    log(f"reads: {npairs} pairs/GPU resident in HBM, {time.time() - t0:.1f}s")
 
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -139,14 +284,14 @@ def main():
     ctx.reset()
     ctx.timers_reset()
     ctx.timers_enable(args.timer_every)  # HIP-event pairs around the kernels of every n-th step of the timed region
-    if os.environ.get("DBTK_NO_TIMERS"):  # diagnostic: cost of the per-kernel event records themselves
+    if os.environ.get("DBTK_NO_TIMERS"):
         ctx.timers_enable(False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     ctx.synchronize()
-    if world > 1:  # per-rank work counters, before the reduce sums them over ranks (96 B device->host)
+    if world > 1:  # per-rank work counters, before the reduce sums them over ranks
         local_ctr = ctx.counters()
     reduce_counts()
     barrier()
@@ -160,98 +305,103 @@ def main():
         dt = float(tt.item())
     total_reads = 2 * npairs * args.steps * world
     value = total_reads / dt
+    log(f"timed region: {args.steps} steps, {dt / args.steps * 1e3:.3f} ms/step, {value / 1e9:.2f} G reads/s on {world} GPU(s)")
 
-    # ---- roofline of the dominant kernel (this rank): algorithmic bytes of SURVEY.md 8(d) per launch
-    ctr = local_ctr.astype(np.float64)  # totals over the timed steps
-    alg = {
-        # every read byte once + 12 B per subfilter probe
-        "k_encode_subfilter": ctr[abi.C_BASES] + 12.0 * (ctr[abi.C_ALGO_PROBES] - ctr[abi.C_NHASH1]),
-        # the probe kernel: 12 B (8 B key + 4 B value) per kfilter look-up the reference performs
-        "k_probe": 12.0 * ctr[abi.C_NHASH1],
-        # resolve: 4 B per vv word + 8 B per classified k-mer + 16 B per count increment
-        "k_pair": 4.0 * ctr[abi.C_ALGO_VV] + 8.0 * ctr[abi.C_ALGO_CLS] + 16.0 * ctr[abi.C_ALGO_INC],
-    }
-    per_kernel = {}
-    if "k_pair_usual" in ktimes:  # the resolve stage is two kernels (usual pairs, then the rest): priced together
-        u, g_ = ktimes.pop("k_pair_usual"), ktimes.get("k_pair", (0.0, 0))
-        ktimes["k_pair"] = (u[0] + g_[0], max(u[1], g_[1]))
-        ktimes["k_pair: usual-pair part"] = u
-    # the encode stage in its binned form is three launches (encode + sort the filter queries by partition, filter + exact
-    # look-ups, candidates); "k_encode_subfilter" is timed around all three and priced as one, the parts are listed beside it
-    for part in ("k_encode_bin", "k_filter_bins", "k_subfilter_cand"):
-        if part in ktimes:
-            t = ktimes.pop(part)
-            if t[1]:
-                ktimes[f"k_encode_subfilter: {part}"] = t
-    # the event pairs sit around the kernels of every `timer_every`-th step: n timed launches stand for n * steps / timed steps launches
+    # ---- roofline (this rank): algorithmic bytes of SURVEY.md 8(d) per launch / HIP-event time
+    ctr = local_ctr.astype(np.float64)
     timed_steps = (args.steps + args.timer_every - 1) // max(args.timer_every, 1) if args.timer_every > 1 else args.steps
-    for name, (ms, n) in ktimes.items():  # large steps run as several sub-batch launches: price per launch
-        avg = ms / max(n, 1)
-        launches = n * args.steps / max(timed_steps, 1)
-        per_launch = alg.get(name, 0.0) / max(launches, 1)
-        per_kernel[name] = dict(avg_ms=avg, launches=launches, timed_launches=n, algorithmic_bytes=per_launch,
-                                gbs=(per_launch / (avg * 1e-3) / 1e9) if avg > 0 else 0.0)
-    dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"] * per_kernel[k]["launches"])
-    # HBM bytes per launch of the dominant kernel from the committed PMC summary of this same command (a separate
-    # rocprofv3 --pmc FETCH_SIZE pass, profiles/README.md), corrected as MI355X_MICROARCH.md prescribes for gfx950: a wide
-    # coalesced stream is reported at half its bytes, so half of the read bytes (the only such stream of K1) is added back.
-    traffic, traffic_src = None, None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_SUMMARY)
-    if dom == "k_encode_subfilter" and args.reads == 10_000_000 and abs(args.hit_frac - 0.02) < 1e-9 and os.path.exists(pmc):
-        for line in open(pmc):
-            f = line.strip().split(",")
-            if f[0] == dom and f[1] == "FETCH_SIZE":
-                traffic = float(f[3]) * 1024.0 + 0.5 * ctr[abi.C_BASES] / max(per_kernel[dom]["launches"], 1)
-                traffic_src = f"profiles/{PMC_SUMMARY}: FETCH_SIZE mean per launch (KB) x 1024 + half of the coalesced read stream"
-    # the same summary's TCC_MISS_sum: L2-miss requests per launch — the resource K1 actually saturates (tools/lat.hip: the chip
-    # serves about 50-58 G random requests/s whatever is behind them)
-    requests = None
-    if traffic is not None:
-        for line in open(pmc):
-            f = line.strip().split(",")
-            if f[0] == dom and f[1] == "TCC_MISS_sum":
-                requests = dict(per_launch=float(f[3]), rate_per_s=float(f[3]) / (per_kernel[dom]["avg_ms"] * 1e-3),
-                                ceiling_per_s="5.0e10-5.8e10 (tools/lat.hip)", source=f"profiles/{PMC_SUMMARY}: TCC_MISS_sum")
-    roof = dict(bound="hbm", kernel=dom, achieved=per_kernel[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=per_kernel[dom]["gbs"] / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, l2_miss_requests=requests,
-                algorithmic_bytes_per_launch=per_kernel[dom]["algorithmic_bytes"], avg_ms=per_kernel[dom]["avg_ms"],
-                kernels=per_kernel)
+    table = kernel_table(ktimes, algorithmic_bytes(abi, ctr), args.steps, timed_steps)
+    dom = max((k for k in table if ":" not in k), key=lambda k: table[k]["avg_ms"] * table[k]["launches"])
+    roof = roofline_of(dom, table)
+    traffic, traffic_src, stale = pmc_traffic(dom, table, ctr[abi.C_BASES] / max(table[dom]["launches"], 1))
+    roof.update(traffic=traffic, traffic_source=traffic_src, traffic_stale=stale, kernels=table)
+    probe_roof = roofline_of("k_probe", table) if "k_probe" in table else None
 
-    # ---- untimed extra (--extra-lanes, N=1 only; off by default so that a profile of the default command holds the timed launches
-    # and nothing else): the same steps on the library's default of two overlapped lanes (DBTK_LANES=2; the timed
-    # region above runs on one lane so that a kernel's launch duration is its own) — reported beside `value`, never as it
     two_lanes = None
-    if world == 1 and args.lanes == 1 and args.extra_lanes:
+    if solo and args.lanes == 1 and args.extra_lanes:
         os.environ["DBTK_LANES"] = "2"
         ctx2 = dbtk.context(g, params, device=local_rank)
         os.environ["DBTK_LANES"] = "1"
         ctx2.timers_enable(False)
-        for _ in range(args.warmup):
-            ctx2.align_device(d_seq.data_ptr(), d_off.data_ptr(), npairs, rlen)
-        ctx2.synchronize()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            ctx2.align_device(d_seq.data_ptr(), d_off.data_ptr(), npairs, rlen)
-        ctx2.synchronize()
-        dt2 = time.perf_counter() - t2
+        dt2 = time_steps(ctx2, lambda: ctx2.align_device(d_seq.data_ptr(), d_off.data_ptr(), npairs, rlen), args.steps, args.warmup)
         two_lanes = dict(value=2 * npairs * args.steps / dt2, unit="reads/s", ms_per_step=dt2 / args.steps * 1e3,
                          note="untimed extra: same steps, context with DBTK_LANES=2 (successive batches alternate between two streams)")
         ctx2.close()
 
-    out = None
-    if rank == 0:
-        cpu = None
-        parity = None
-        if world == 1 and args.cpu_seconds > 0:
-            # ---- the cpu_baseline leg: the oracle (oracle/dbtk_oracle.c, the checker) timed on a bounded sample of the same
-            # workload; its result on the first chunk doubles as this run's parity check of the HIP path.
+    # ---- N = 1 extras: further read mixes, end to end, CPU baselines
+    mixes, e2e, cpu, parity = None, None, None, None
+    if solo and rank == 0:
+        mixes = {}
+        if do_mixes:
+            mp = args.mix_reads // 2
+            # all-hit: every pair tiled from a locus (SURVEY 8d mix 1): the probe and resolve kernels carry the step
+            ah_seq, ah_off = syn.reads(mp, rlen=rlen, hit_frac=1.0, seed=2, nthreads=nth)
+            d_ah = torch.from_numpy(ah_seq).to(dev)
+            d_aho = torch.from_numpy(ah_off.view(np.int64)).to(dev)
+            torch.cuda.synchronize()
+            ctx.timers_enable(1)
+            dta = time_steps(ctx, lambda: ctx.align_device(d_ah.data_ptr(), d_aho.data_ptr(), mp, rlen), args.mix_steps, 2)
+            ta = kernel_table(ctx.kernel_times(), algorithmic_bytes(abi, ctx.counters().astype(np.float64)), args.mix_steps, args.mix_steps)
+            doma = max((k for k in ta if ":" not in k), key=lambda k: ta[k]["avg_ms"] * ta[k]["launches"])
+            mixes["all_hit"] = dict(workload=f"{2 * mp} reads per step, 100 % of pairs from loci, -k 21 -kf 4 1 -cth 45 -ka",
+                                    value=2 * mp * args.mix_steps / dta, unit="reads/s", ms_per_step=dta / args.mix_steps * 1e3,
+                                    steps=args.mix_steps, roofline=dict(roofline_of(doma, ta), kernels=ta),
+                                    probe_roofline=roofline_of("k_probe", ta) if "k_probe" in ta else None)
+            log(f"all-hit mix: {dta / args.mix_steps * 1e3:.3f} ms/step, {mixes['all_hit']['value'] / 1e9:.2f} G reads/s, dominant {doma} "
+                f"{ta[doma]['avg_ms']:.3f} ms = {ta[doma]['gbs']:.0f} GB/s algorithmic")
+            if do_walk:
+                # config 4's path: every assigned pair walked through its locus' graph with error correction (-gc 85 3), exact counting
+                pw = abi.default_params(ksize=21, n_filter=4, nm_filter=1, cthreshold=45, okam=0, threading=abi.THREADING_V13, thread_cth=85,
+                                        correction=1, maxncorrection=3)
+                t0 = time.time()
+                ctxw = dbtk.context(g, pw, device=local_rank)
+                log(f"walk context (graph table in HBM): {time.time() - t0:.1f}s")
+                ctxw.timers_enable(1)
+                dtw = time_steps(ctxw, lambda: ctxw.align_device(d_ah.data_ptr(), d_aho.data_ptr(), mp, rlen), args.mix_steps, 2)
+                cw = ctxw.counters().astype(np.float64)
+                walked_kmers = cw[abi.C_THREADING] * (rlen - 21 + 1)  # k-mers of the reads that entered threading
+                tw = kernel_table(ctxw.kernel_times(), algorithmic_bytes(abi, cw, walked_kmers), args.mix_steps, args.mix_steps)
+                domw = max((k for k in tw if ":" not in k), key=lambda k: tw[k]["avg_ms"] * tw[k]["launches"])
+                mixes["walk_gc85_3"] = dict(workload=f"{2 * mp} reads per step, 100 % of pairs from loci, --v13-threading -gc 85 3 -k 21 -kf 4 1 -cth 45 -ka",
+                                            value=2 * mp * args.mix_steps / dtw, unit="reads/s", ms_per_step=dtw / args.mix_steps * 1e3,
+                                            steps=args.mix_steps, reads_walked_per_step=cw[abi.C_THREADING] / args.mix_steps,
+                                            reads_feasible_per_step=cw[abi.C_FEASIBLE] / args.mix_steps,
+                                            roofline=dict(roofline_of(domw, tw), kernels=tw))
+                log(f"walk mix: {dtw / args.mix_steps * 1e3:.3f} ms/step, {mixes['walk_gc85_3']['value'] / 1e6:.1f} M reads/s, dominant {domw} {tw[domw]['avg_ms']:.3f} ms")
+                ctxw.close()
+            del d_ah, d_aho
+        if not args.no_e2e:
+            # the same batch handed over as HOST buffers: validation + PCIe copies + kernels, one batch after the other
+            e2e = {}
+            ctx.timers_enable(0)
+            ctx.reset()
+            ctx.align(seq, off)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ctx.align(seq, off)
+            th = (time.perf_counter() - t0) / 3
+            e2e["host_buffers"] = dict(value=2 * npairs / th, unit="reads/s", ms_per_batch=th * 1e3,
+                                       note="dbtk_align_batch: pageable host buffers -> H2D -> kernels, per 10 M-read batch")
+            log(f"host-buffer batches: {th * 1e3:.1f} ms per batch, {2 * npairs / th / 1e6:.0f} M reads/s")
+            cli = os.path.join(ROOT, "danbing-tk_amd", "bin", "danbing-tk")
+            if ref_dir and os.path.exists(cli):
+                t0 = time.perf_counter()
+                r = subprocess.run([cli, "-k", "21", "-kf", "4", "1", "-cth", "45", "-ka", "-fa", "reads.fa", "-qs", "pan", "-o", "cli"], cwd=ref_dir,
+                                   capture_output=True, text=True)
+                tcli = time.perf_counter() - t0
+                ing = [l for l in r.stderr.splitlines() if l.startswith("ingest:")]
+                e2e["cli"] = dict(wall_s=tcli, returncode=r.returncode, reads=2 * nref, batch_loop=ing[0] if ing else None,
+                                  note="this repo's danbing-tk on the reference leg's files: RPGG load + HBM tables + parse + pair + align + dump")
+                log(f"CLI end to end: {tcli:.1f}s wall; {ing[0] if ing else ''}")
+
+        # ---- cpu baselines
+        port = None
+        if args.cpu_seconds > 0:
             import bind
             try:
                 orc = bind.Oracle()
-            except OSError:  # the checker is not built (oracle/liboracle.so: __graft_entry__.build() makes it): build it now
-                import subprocess
-                subprocess.run(["make", "-C", os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle"), "oracle"], check=False,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            except OSError:
+                subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 orc = bind.Oracle()
             t0 = time.time()
             go = orc.from_arrays(arrs)
@@ -276,20 +426,50 @@ def main():
                     if not ok:
                         raise SystemExit("GPU result differs from the oracle")
                 done += n
-            cpu = dict(value=2 * done / t_cpu, unit="reads/s", cores=1, kind="port",
-                       sample=f"first {2 * done} reads of the same read set and RPGG, oracle/dbtk_oracle.c on 1 host core, {t_cpu:.1f} s",
-                       checked=parity)
-            log(f"cpu baseline: {cpu['value']:.0f} reads/s on 1 core")
+            port = dict(value=2 * done / t_cpu, unit="reads/s", cores=1, kind="port",
+                        sample=f"first {2 * done} reads of the same read set and RPGG, oracle/dbtk_oracle.c on 1 host core, {t_cpu:.1f} s", checked=parity)
+            log(f"oracle (port) on 1 core: {port['value']:.0f} reads/s")
             orc.free(go)
+        if do_ref:
+            for th in ref_procs:
+                th.join()
+            pvals = args.ref_threads if args.ref_threads else [1, 8, ncpu]
+            for pv in [p for p in pvals if p > 8]:
+                ref_results.append(dict(ref_baseline.run_reference(os.path.join(ROOT, "oracle", "_ref", "danbing-tk"), ref_dir, "reads.fa", pv), fasta="reads.fa"))
+            runs = []
+            for r in sorted(ref_results, key=lambda r: r["p"]):
+                if r.get("query_s") and r.get("reads"):
+                    runs.append(dict(threads=r["p"], reads=r["reads"], query_s=r["query_s"], load_s=r["load_s"], value=r["reads"] / r["query_s"], unit="reads/s"))
+                    log(f"reference binary -p {r['p']}: {r['reads']} reads in {r['query_s']:.1f}s = {r['reads'] / r['query_s'] / 1e3:.0f} k reads/s (load {r['load_s']:.0f}s)")
+            if runs:
+                best = max(runs, key=lambda r: r["value"])
+                model = ""
+                try:
+                    model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+                except Exception:
+                    pass
+                cpu = dict(value=best["value"], unit="reads/s", cores=best["threads"], kind="reference",
+                           sample=f"oracle/_ref/danbing-tk (the reference compiled from /root/reference) -k 21 -kf 4 1 -cth 45 -ka -p {best['threads']} on the same "
+                                  f"RPGG written as its HEAD files and the first {best['reads']} reads of the same read set as 2-line FASTA; timed from its "
+                                  f"'threads created' line to 'parallel query completed' ({best['query_s']:.1f} s); best of the -p values in `runs`",
+                           host=f"{ncpu} hardware threads, {model}", runs=runs, port=port)
+        if cpu is None and port is not None:
+            cpu = port
+        if ref_dir:
+            shutil.rmtree(ref_dir, ignore_errors=True)
+
+    if rank == 0:
         out = {
-            "metric": "paired reads/sec aligned to RPGG (k=21)", "value": value, "unit": "reads/s", "n_gpus": world,
+            "metric": "paired reads/sec aligned to RPGG (k=21)", "value": value, "unit": "reads/s", "n_gpus": world, "ranks_seen": ranks_seen,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"release-scale synthetic RPGG ({args.nloci} loci, {arrs.nkeys} index keys, {g.ntrkmers} TR k-mers) "
                                    f"replicated per GPU; {args.reads} x 150bp PE reads per GPU per step, {args.hit_frac:.0%} of pairs from loci; "
                                    f"-k 21 -kf 4 1 -cth 45 -ka; RCCL all-reduce of counts at the end",
-                       "lanes": args.lanes, "reads_per_gpu": args.reads, "read_len": rlen, "hit_frac": args.hit_frac, "k": 21, "cth": 45},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "two_lanes": two_lanes,
+                       "lanes": args.lanes, "reads_per_gpu": args.reads, "read_len": rlen, "hit_frac": args.hit_frac, "k": 21, "cth": 45,
+                       "kernel_source_hash": kernel_source_hash()},
+            "roofline": roof, "probe_roofline": probe_roof, "mixes": mixes, "end_to_end": e2e, "cpu_baseline": cpu, "parity": parity,
+            "two_lanes": two_lanes, "bench_wall_s": time.time() - t_start,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -321,6 +321,11 @@ class Synth:
         L.dbtk_synth_nbases.restype = C.c_uint64
         L.dbtk_synth_nbases.argtypes = [C.c_void_p]
         L.dbtk_synth_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_uint64, u8p, C.c_uint32]
+        L.dbtk_synth_graph.argtypes = [C.c_void_p, C.c_uint32]
+        L.dbtk_synth_write_files.restype = C.c_int
+        L.dbtk_synth_write_files.argtypes = [C.c_void_p, C.c_char_p]
+        L.dbtk_synth_write_fasta.restype = C.c_int
+        L.dbtk_synth_write_fasta.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_char_p]
         self.h = L.dbtk_synth_create(nloci, k, flank, seed, nthreads)
         self.k, self.nloci = k, nloci
 
@@ -328,6 +333,19 @@ class Synth:
         a = abi.RpggArrays()
         self.L.dbtk_synth_arrays(self.h, C.byref(a))
         return a
+
+    def graph(self, nthreads=0):
+        """Build graphDB (both strands of every haplotype); arrays() then carries gr_cnt / gr_ks / gr_ms."""
+        self.L.dbtk_synth_graph(self.h, nthreads)
+
+    def write_files(self, prefix):
+        """The RPGG as the HEAD files the reference binary loads (PREF.tr.kmers, .kmers.dbi, .fl.kdb, .tre.kdb)."""
+        if self.L.dbtk_synth_write_files(self.h, prefix.encode()):
+            raise IOError(f"could not write {prefix}.*")
+
+    def write_fasta(self, seq, npairs, fn, rlen=150, first_pair=0):
+        if self.L.dbtk_synth_write_fasta(_ptr(seq, u8p), npairs, rlen, first_pair, fn.encode()):
+            raise IOError(f"could not write {fn}")
 
     def reads(self, npairs, rlen=150, hit_frac=1.0, seed=1, first_pair=0, out=None, nthreads=0):
         """(seq bytes, offsets) — read r is seq[r*rlen:(r+1)*rlen]."""

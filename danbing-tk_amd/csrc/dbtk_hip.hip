@@ -16,84 +16,11 @@
 #include <unordered_map>
 #include <vector>
 
+#include "dbtk_devx.h"
 #include "dbtk_internal.h"
 #include "dbtk_kernels.h"
 
 using namespace dbtk;
-
-// ------------------------------------------------------------------ DevX ---
-struct DevX {
-    void* sm;
-    __device__ int tid() const { return (int)threadIdx.x; }
-    __device__ int nthreads() const { return (int)blockDim.x; }
-    __device__ uint32_t bid() const { return blockIdx.x; }
-    __device__ uint32_t nblocks() const { return gridDim.x; }
-    __device__ int lane() const { return (int)(threadIdx.x & 63); }
-    // Every kernel here runs ONE wavefront per block, so "sync" only has to order this wave's own
-    // LDS traffic: a wavefront-scope fence (compiler ordering; the LDS executes a wave's operations
-    // in order) instead of __syncthreads(), whose s_waitcnt vmcnt(0) would drain the prefetched loads
-    // and the fire-and-forget count atomics at every phase boundary.
-    __device__ void sync() const {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    __device__ uint64_t ballot(bool p) const { return __ballot(p); }
-    // wave-uniform results are returned through readfirstlane/readlane so that the compiler keeps
-    // them (and every loop bound, length and flag derived from them) in SGPRs with scalar branches
-    __device__ uint32_t uni(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-    // Wave-wide inclusive scans in six DPP steps (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then row_bcast 15 and 31
-    // across the rows) instead of six ds_bpermute round trips through the LDS crossbar.  OP(cur, earlier) must be associative;
-    // lanes without a source keep the identity 0.
-    template <class OP> __device__ static uint32_t dpp_scan(uint32_t v, OP op) {
-        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
-        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
-        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));  // row_shr:4
-        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));  // row_shr:8
-        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
-        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
-        return v;
-    }
-    struct OpAdd { __device__ uint32_t operator()(uint32_t c, uint32_t e) const { return c + e; } };
-    struct OpMax { __device__ uint32_t operator()(uint32_t c, uint32_t e) const { return c > e ? c : e; } };
-    struct OpLastNz { __device__ uint32_t operator()(uint32_t c, uint32_t e) const { return c ? c : e; } };
-    __device__ uint32_t wave_sum(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readlane((int)dpp_scan(v, OpAdd{}), 63); }
-    __device__ uint32_t wave_min(uint32_t v) const {  // as a max-scan of the complement
-        return ~(uint32_t)__builtin_amdgcn_readlane((int)dpp_scan(~v, OpMax{}), 63);
-    }
-    __device__ uint32_t wave_scan_max(uint32_t v) const { return dpp_scan(v, OpMax{}); }  // inclusive
-    __device__ uint32_t wave_excl_scan(uint32_t v) const { return dpp_scan(v, OpAdd{}) - v; }
-    template <int E> __device__ void shfl_xor64(const uint64_t (&in)[E], uint64_t (&out)[E], int mask) const {
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)in[j], mask, 64);
-            const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(in[j] >> 32), mask, 64);
-            out[j] = ((uint64_t)hi << 32) | lo;
-        }
-    }
-    __device__ uint32_t wave_scan_lastnz(uint32_t v) const { return dpp_scan(v, OpLastNz{}); }  // inclusive scan, op(a, b) = b ? b : a
-    __device__ uint32_t shfl_up1(uint32_t v) const {  // value of lane - 1 (lane 0 keeps its own): wave_shr:1
-        return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
-    }
-    // lane 4q+j reads lane 4q+Pj (DPP quad_perm: no LDS traffic).  Every lane of the wave must be active at the call.
-    template <int P0, int P1, int P2, int P3> __device__ uint32_t quad_perm(uint32_t v) const {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, true);
-    }
-    __device__ uint32_t bcast(uint32_t v, int src) const {  // src must be wave-uniform
-        return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
-    }
-    __device__ void atomic_add(uint64_t* p, uint64_t v) const { atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
-    __device__ uint32_t atomic_add(uint32_t* p, uint32_t v) const { return atomicAdd(p, v); }
-    __device__ uint64_t atomic_cas(uint64_t* p, uint64_t e, uint64_t d) const {
-        return atomicCAS(reinterpret_cast<unsigned long long*>(p), (unsigned long long)e, (unsigned long long)d);
-    }
-    __device__ void atomic_max(uint64_t* p, uint64_t v) const { atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
-    __device__ void atomic_or(uint64_t* p, uint64_t v) const { atomicOr(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
-    __device__ uint32_t atomic_or32(uint32_t* p, uint32_t v) const { return atomicOr(p, v); }
-    __device__ uint64_t clock() const { return (uint64_t)clock64(); }
-    __device__ uint32_t lds_add(uint32_t* p, uint32_t v) const { return atomicAdd(p, v); }
-    __device__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
-    template <class T> __device__ T* smem() const { return reinterpret_cast<T*>(sm); }
-};
 
 // --------------------------------------------------------------- kernels ---
 __global__ void __launch_bounds__(256) k_fill_idx(IdxBucket* b, uint64_t nslots) {
@@ -851,7 +778,7 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
                 if (hipEventCreate(&c->timed[i].beg[j]) != hipSuccess || hipEventCreate(&c->timed[i].end[j]) != hipSuccess) { set_error("hipEventCreate failed"); st = DBTK_ERR_HIP; }
         if (st) break;
         if ((st = build_tables(c))) break;
-        if (!h->gr_cnt.empty() && (st = build_graph_table(c))) break;
+        if (p->threading == DBTK_THREADING_V13 && (st = build_graph_table(c))) break;  // (only a walking context pays for the graph table)
         if (p->trackbait) {
             c->btTK.resize(h->nloci);
             c->baitDB_host.resize(h->nloci);

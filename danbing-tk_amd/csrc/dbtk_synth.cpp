@@ -19,8 +19,11 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <stdio.h>
+
 #include <algorithm>
 #include <atomic>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -57,6 +60,8 @@ struct Synth {
     // flat RPGG
     std::vector<uint64_t> keys; std::vector<uint32_t> vals, vv;
     std::vector<uint64_t> fl_cnt, fl_ks, tr_cnt, tr_ks, tre_cnt;
+    std::vector<uint64_t> gr_cnt, gr_ks;  // graphDB (dbtk_synth_graph): nodes of both strands, sorted within a locus
+    std::vector<uint8_t> gr_ms;
 };
 
 template <class F>
@@ -285,6 +290,131 @@ void dbtk_synth_arrays(void* h, dbtk_rpgg_arrays_t* a) {
     a->fl_cnt = s->fl_cnt.data(); a->fl_ks = s->fl_ks.data();
     a->tr_cnt = s->tr_cnt.data(); a->tr_ks = s->tr_ks.data();
     a->tre_cnt = nullptr; a->tre_ks = nullptr;  // TR edges only matter to -bu
+    if (!s->gr_cnt.empty()) { a->gr_cnt = s->gr_cnt.data(); a->gr_ks = s->gr_ks.data(); a->gr_ms = s->gr_ms.data(); }
+}
+
+// graphDB of the haplotypes, as `fa2kmers -g` builds it (buildKmerGraph, src/aQueryFasta_thread.h:215-243): every k-mer of
+// both strands of every haplotype is a node; bit b of its mask: the successor ((node & rmask) << 2) | b follows it
+// somewhere; no self loops.  After this call dbtk_synth_arrays also hands out gr_cnt / gr_ks / gr_ms.
+void dbtk_synth_graph(void* h, uint32_t nthreads) {
+    Synth* s = (Synth*)h;
+    if (!s->gr_cnt.empty()) return;
+    const unsigned nth = nthreads ? nthreads : std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t k = s->k, nloci = s->nloci;
+    const uint64_t mask = (k < 32) ? ((1ull << (2 * k)) - 1) : ~0ull;
+    std::vector<std::vector<uint64_t>> nk(nloci);
+    std::vector<std::vector<uint8_t>> nm(nloci);
+    parallel_for(nloci, nth, [&](uint64_t b, uint64_t e, unsigned) {
+        std::vector<std::pair<uint64_t, uint8_t>> v;
+        std::vector<uint8_t> rcs;
+        for (uint64_t l = b; l < e; ++l) {
+            v.clear();
+            for (uint32_t hi = s->locus_hap0[l]; hi < s->locus_hap0[l + 1]; ++hi) {
+                const uint8_t* hs = s->seq.data() + s->hap_beg[hi];
+                const uint32_t hl = (uint32_t)(s->hap_beg[hi + 1] - s->hap_beg[hi]);
+                rcs.resize(hl);
+                for (uint32_t i = 0; i < hl; ++i) { const uint8_t c = hs[hl - 1 - i]; rcs[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; }
+                for (int strand = 0; strand < 2; ++strand) {
+                    const uint8_t* q = strand ? rcs.data() : hs;
+                    uint64_t fw = 0;
+                    for (uint32_t i = 0; i < hl; ++i) {
+                        fw = ((fw << 2) | (uint64_t)code(q[i])) & mask;
+                        if (i + 1 < k) continue;
+                        uint8_t m = 0;
+                        if (i + 1 < hl) {
+                            const uint64_t nx = ((fw << 2) | (uint64_t)code(q[i + 1])) & mask;
+                            if (nx != fw) m = (uint8_t)(1u << code(q[i + 1]));
+                        }
+                        v.emplace_back(fw, m);
+                    }
+                }
+            }
+            std::sort(v.begin(), v.end());
+            for (size_t i = 0; i < v.size(); ++i) {
+                if (!nk[l].empty() && nk[l].back() == v[i].first) nm[l].back() |= v[i].second;
+                else { nk[l].push_back(v[i].first); nm[l].push_back(v[i].second); }
+            }
+        }
+    });
+    s->gr_cnt.resize(nloci);
+    std::vector<uint64_t> gb(nloci + 1, 0);
+    for (uint32_t l = 0; l < nloci; ++l) { s->gr_cnt[l] = nk[l].size(); gb[l + 1] = gb[l] + nk[l].size(); }
+    s->gr_ks.resize(gb[nloci]); s->gr_ms.resize(gb[nloci]);
+    parallel_for(nloci, nth, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t l = b; l < e; ++l) {
+            if (!nk[l].empty()) { memcpy(s->gr_ks.data() + gb[l], nk[l].data(), nk[l].size() * 8); memcpy(s->gr_ms.data() + gb[l], nm[l].data(), nm[l].size()); }
+            std::vector<uint64_t>().swap(nk[l]);
+            std::vector<uint8_t>().swap(nm[l]);
+        }
+    });
+}
+
+// The RPGG as the files the reference's `danbing-tk` loads (HEAD formats): PREF.tr.kmers (text),
+// PREF.kmers.dbi, PREF.fl.kdb, PREF.tre.kdb (no edges: only -bu reads them) — for bench.py's reference-binary
+// baseline, which must see the same RPGG as the GPU.  Returns 0 on success.
+int dbtk_synth_write_files(void* h, const char* prefix) {
+    Synth* s = (Synth*)h;
+    const std::string pref(prefix);
+    auto put = [](FILE* f, const void* p, size_t n) { return n == 0 || fwrite(p, 1, n, f) == n; };
+    {
+        FILE* f = fopen((pref + ".tr.kmers").c_str(), "wb");
+        if (!f) return -1;
+        std::vector<char> buf;
+        buf.reserve(1 << 24);
+        uint64_t i = 0;
+        char line[64];
+        for (uint32_t l = 0; l < s->nloci; ++l) {
+            int n = snprintf(line, sizeof line, ">%u\n", l);
+            buf.insert(buf.end(), line, line + n);
+            for (uint64_t j = 0; j < s->tr_cnt[l]; ++j, ++i) {
+                n = snprintf(line, sizeof line, "%llu\t0\n", (unsigned long long)s->tr_ks[i]);
+                buf.insert(buf.end(), line, line + n);
+            }
+            if (buf.size() > (1u << 24) - 4096) { if (!put(f, buf.data(), buf.size())) { fclose(f); return -1; } buf.clear(); }
+        }
+        const bool ok = put(f, buf.data(), buf.size());
+        if (fclose(f) || !ok) return -1;
+    }
+    {
+        FILE* f = fopen((pref + ".kmers.dbi").c_str(), "wb");
+        if (!f) return -1;
+        const uint64_t nk = s->keys.size(), nvv = s->vv.size();
+        const bool ok = put(f, &nk, 8) && put(f, s->keys.data(), nk * 8) && put(f, s->vals.data(), nk * 4) && put(f, &nvv, 8) && put(f, s->vv.data(), nvv * 4);
+        if (fclose(f) || !ok) return -1;
+    }
+    for (int which = 0; which < 2; ++which) {
+        FILE* f = fopen((pref + (which ? ".tre.kdb" : ".fl.kdb")).c_str(), "wb");
+        if (!f) return -1;
+        const uint64_t nl = s->nloci, nk = which ? 0 : s->fl_ks.size();
+        const std::vector<uint64_t>& cnt = which ? s->tre_cnt : s->fl_cnt;
+        const bool ok = put(f, &nl, 8) && put(f, cnt.data(), nl * 8) && put(f, &nk, 8) && (which || put(f, s->fl_ks.data(), nk * 8));
+        if (fclose(f) || !ok) return -1;
+    }
+    return 0;
+}
+
+// Interleaved 2-line FASTA (">p<index>/1", "/2") of npairs pairs laid out as dbtk_synth_reads makes them: the input file of
+// the reference binary for bench.py's CPU baseline.  Returns 0 on success.
+int dbtk_synth_write_fasta(const uint8_t* reads, uint64_t npairs, uint32_t rlen, uint64_t first_pair, const char* fn) {
+    FILE* f = fopen(fn, "wb");
+    if (!f) return -1;
+    std::vector<char> buf;
+    buf.reserve(1 << 24);
+    char t[48];
+    bool ok = true;
+    for (uint64_t p = 0; p < npairs && ok; ++p) {
+        for (int m = 0; m < 2; ++m) {
+            const int n = snprintf(t, sizeof t, ">p%llu/%d\n", (unsigned long long)(first_pair + p), m + 1);
+            buf.insert(buf.end(), t, t + n);
+            const uint8_t* r = reads + (2 * p + m) * (uint64_t)rlen;
+            buf.insert(buf.end(), r, r + rlen);
+            buf.push_back('\n');
+        }
+        if (buf.size() > (1u << 24) - 1024) { ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size(); buf.clear(); }
+    }
+    if (ok && !buf.empty()) ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    if (fclose(f)) ok = false;
+    return ok ? 0 : -1;
 }
 
 uint64_t dbtk_synth_nbases(void* h) { return ((Synth*)h)->seq.size(); }

@@ -134,6 +134,7 @@ struct WalkSmem {
     uint32_t slot[2][NKMAX];  // per mate: counter of the UNcorrected k-mer at each position (NAN32: not a TR k-mer)
     uint8_t bases[48];        // edit_kmers_*: bases to roll in / leading bases
     uint8_t cube[24];         // errorCorrection_forward: m1[4], m2[16]
+    uint8_t scr[128];         // edit_kmers_backward: the read / graph bases of an edit tract
     int32_t st[8];            // lane-0 regions hand their scalars back through here
     uint64_t st64[2];
 };
@@ -183,7 +184,7 @@ struct WalkState {
 // errorCorrection_backward (AQ.cpp:1091-1106): the same on the reverse-complemented prefix before the anchor ki1.
 // Returns skip; on success *wid = the winning hypothesis, *wscore its score.
 template <class X>
-DBTK_HD bool walk_ec(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, bool backward, int ki, int nkm, uint32_t mes,
+DBTK_HD_NOINLINE bool walk_ec(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, bool backward, int ki, int nkm, uint32_t mes,
                      int* wid, uint32_t* wscore, uint32_t* flags) {
     const int lane = x.lane();
     const uint32_t k = T.ksize;
@@ -335,6 +336,280 @@ DBTK_HD void w_shift(X& x, E* a, int from, int n, int d) {
     x.sync();
 }
 
+// graph info of km[lo, hi) again (they were rewritten)
+template <class X>
+DBTK_HD void walk_refresh(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, const WalkState& S, int lo, int hi) {
+    const int lane = x.lane();
+    const uint32_t k = T.ksize;
+    if (lo < 0) lo = 0;
+    if (hi > S.nkm) hi = S.nkm;
+    x.sync();
+    for (int i = lo + lane; i < hi; i += 64) sm.gi[i] = (uint16_t)w_info(T, locus, sm.km[i], k, nullptr);
+    x.sync();
+}
+
+// find_anchor, AQ.cpp:878-888
+template <class X>
+DBTK_HD_NOINLINE bool walk_find_anchor(X& x, WalkSmem& sm, uint32_t k, WalkState& S) {
+    const int lane = x.lane();
+    for (;;) {
+        const int p = S.ki + lane;
+        const bool is = p < S.nkm && (sm.gi[p] & GR_HAS);
+        const uint64_t m = x.ballot(is);
+        const int lim = S.nkm - S.ki < 64 ? S.nkm - S.ki : 64;
+        const int adv = m ? __builtin_ctzll(m) : lim;
+        S.nskip += (uint64_t)adv; S.ni += adv; S.ki += adv;
+        if (m) break;
+        if (S.ki >= S.nkm) return false;
+    }
+    x.sync();
+    if (lane == 0) sm.tr[S.ki] = (sm.gi[S.ki] & GR_TR) ? '=' : '.';
+    if (lane < (int)k && sm.es_t[S.ni + lane] == '*') sm.es_t[S.ni + lane] = '=';
+    x.sync();
+    return true;
+}
+
+// edit_kmers_forward, AQ.cpp:828-862
+template <class X>
+DBTK_HD_NOINLINE void walk_edit_forward(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, WalkState& S, int wid, uint32_t score) {
+    const int lane = x.lane();
+    const uint32_t k = T.ksize;
+    const uint64_t rmask = (1ull << 2 * (k - 1)) - 1;
+    auto refresh = [&](int lo, int hi) { walk_refresh(x, sm, T, locus, S, lo, hi); };
+    uint8_t et[2], eg[2];
+    const int ne = w_edits(wid, et, eg);
+    int nm = 0, nd = 0, nins = 0;
+    for (int e = 0; e < ne; ++e) { nm += et[e] == 'X'; nd += et[e] == 'D'; nins += et[e] == 'I'; }
+    const int ki0 = S.ki, dt_km = nd - nins, dt_ki = nm + nd;
+    const int n0 = S.nkm - ki0;
+    // the bases to roll in after kmers[ki0 - 1]: the graph bases of the X / D edits, then the read's own bases from
+    // old position ki0 + nm + nins on, while they are good and the rewritten k-mer stays inside min(size, ki + k)
+    x.sync();
+    if (lane < 40) {
+        uint8_t b = 4;
+        int q = 0;
+        for (int e = 0; e < ne; ++e) if (et[e] != 'I') { if (lane == q) b = (uint8_t)w_code(eg[e]); ++q; }
+        if (lane >= dt_ki) {
+            const int o = nm + nins + (lane - dt_ki);  // old offset from ki0
+            if (o < n0 && sm.km[ki0 + o] != NAN64) b = (uint8_t)(sm.km[ki0 + o] % 4);
+        }
+        sm.bases[lane] = b;
+    }
+    x.sync();
+    if (dt_km) {
+        const int from = ki0 + nm + nins;
+        w_shift(x, sm.km, from, S.nkm, dt_km);
+        w_shift(x, sm.gi, from, S.nkm, dt_km);
+        S.nkm += dt_km;
+        if (S.nkm > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; S.nkm = WCAP; }
+    }
+    const int ki = ki0 + dt_ki;
+    int nb = dt_ki;  // rewritten k-mers: the corrected ones, then the extended ones
+    {
+        const int lim = S.nkm < ki + (int)k ? S.nkm : ki + (int)k;
+        for (int i = ki; i < lim; ++i) { if (sm.bases[nb] > 3) break; ++nb; }
+    }
+    {
+        uint64_t v = sm.km[ki0 - 1];
+        if (lane < nb) {
+            for (int q = 0; q <= lane; ++q) v = w_roll(v, rmask, sm.bases[q]);
+        }
+        x.sync();
+        if (lane < nb) sm.km[ki0 + lane] = v;
+    }
+    refresh(ki0, ki0 + nb);
+    if (dt_km) {  // cg.tr.resize(size + dt_km, '*')
+        const int nn = S.ntr + dt_km;
+        for (int i = S.ntr + lane; i < nn && i < WCAP; i += 64) sm.tr[i] = '*';
+        S.ntr = nn > WCAP ? WCAP : nn;
+    }
+    if (nd) {  // cg.es.insert(begin + ni + k - 1 + nm, edit_t('D', 0, '*')) x nd
+        const int at = S.ni + (int)k - 1 + nm;
+        w_shift(x, sm.es_t, at, S.nes, nd);
+        w_shift(x, sm.es_r, at, S.nes, nd);
+        w_shift(x, sm.es_g, at, S.nes, nd);
+        if (lane < nd) { sm.es_t[at + lane] = 'D'; sm.es_r[at + lane] = 0; sm.es_g[at + lane] = '*'; }
+        S.nes += nd;
+        if (S.nes > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; S.nes = WCAP; }
+    }
+    x.sync();
+    for (int i = lane; i < dt_ki + (int)score; i += 64) sm.tr[ki0 + i] = (sm.gi[ki0 + i] & GR_TR) ? '=' : '.';
+    if (lane < ne) { sm.es_t[S.ni + (int)k - 1 + lane] = et[lane]; sm.es_g[S.ni + (int)k - 1 + lane] = eg[lane]; }
+    for (int i = lane; i < (int)score; i += 64) sm.es_t[S.ni + ne + (int)k - 1 + i] = '=';
+    x.sync();
+    S.ni += ne + (int)score - 1;
+    S.ki = ki + (int)score - 1;  // the last edited kmer
+    S.ncorr += (uint64_t)ne;
+}
+
+// edit_kmers_backward, AQ.cpp:649-825, for the anchor at *pki; txt's nm / nd / ni / score are handed back
+template <class X>
+DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, WalkState& S, int wid, uint32_t score, int* pki,
+                                         int* onm, int* ond, int* oni) {
+    const int lane = x.lane();
+    const uint32_t k = T.ksize;
+    auto refresh = [&](int lo, int hi) { walk_refresh(x, sm, T, locus, S, lo, hi); };
+    uint8_t et[2], eg[2];
+    const int ne = w_edits(wid, et, eg);
+    int nm = 0, nd = 0, nins = 0;
+    for (int e = 0; e < ne; ++e) { nm += et[e] == 'X'; nd += et[e] == 'D'; nins += et[e] == 'I'; }
+    *onm = nm; *ond = nd; *oni = nins;
+    const int dt_km = nd - nins;
+    int ki = *pki;
+    S.ni += nd;
+    if (dt_km > 0) {  // kmers.insert(begin + ki, 0) / cg.tr.insert(begin + ki, '*'), dt_km times
+        w_shift(x, sm.km, ki, S.nkm, dt_km);
+        w_shift(x, sm.gi, ki, S.nkm, dt_km);
+        w_shift(x, sm.tr, ki, S.ntr, dt_km);
+        if (lane < dt_km) { sm.km[ki + lane] = 0; sm.gi[ki + lane] = 0; sm.tr[ki + lane] = '*'; }
+    } else if (dt_km < 0) {  // erase [ki + dt_km, ki)
+        w_shift(x, sm.km, ki, S.nkm, dt_km);
+        w_shift(x, sm.gi, ki, S.nkm, dt_km);
+        w_shift(x, sm.tr, ki, S.ntr, dt_km);
+    }
+    S.nkm += dt_km; S.ntr += dt_km;
+    if (S.nkm > WCAP || S.ntr > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; if (S.nkm > WCAP) S.nkm = WCAP; if (S.ntr > WCAP) S.ntr = WCAP; }
+    ki += dt_km;
+    x.sync();
+    // corrected kmers (X / D edits, walking down from the anchor), then extended ones while the old k-mers were good:
+    // kmers[i - 1] = (kmers[i] >> 2) + leading base, the base being the complement of the edit's graph base or
+    // the old k-mer's own
+    const int ncor = nm + nd;
+    const int ki_ = ki - ncor;
+    int next = 0;  // extended
+    {
+        int lo = ki_ - (int)k; if (lo < 0) lo = 0;
+        for (int i = ki_; i > lo; --i) { if (sm.km[i - 1] == NAN64) break; ++next; }
+    }
+    if (lane < 40) {
+        uint8_t b = 0;
+        int q = 0;
+        for (int e = 0; e < ne; ++e) if (et[e] != 'I') { if (lane == q) b = (uint8_t)(3 - w_code(eg[e])); ++q; }
+        if (lane >= ncor && lane < ncor + next) b = (uint8_t)(sm.km[ki_ - 1 - (lane - ncor)] >> (2 * (k - 1)));
+        sm.bases[lane] = b;
+    }
+    x.sync();
+    {
+        uint64_t v = sm.km[ki];
+        if (lane < ncor + next) {
+            for (int q = 0; q <= lane; ++q) v = (v >> 2) + ((uint64_t)sm.bases[q] << (2 * (k - 1)));
+        }
+        x.sync();
+        if (lane < ncor + next) sm.km[ki - 1 - lane] = v;
+    }
+    refresh(ki - ncor - next, ki);
+    // the rest is sequential byte work on a few entries: lane 0
+    if (lane == 0) {
+        uint64_t nrk = 0;
+        const int lb = ki - nm - nd - (int)score;
+        for (int i = ki - 1; i >= lb; --i) {
+            if (sm.tr[i] == '*') ++nrk;
+            sm.tr[i] = (sm.gi[i] & GR_TR) ? '=' : '.';
+        }
+        nrk -= (uint64_t)(nm + nd);
+        uint64_t nskip = S.nskip - nrk, ncorr = S.ncorr + (uint64_t)ne;
+        int ni = S.ni, nes = S.nes;
+        auto es_ins = [&](int at) {
+            if (nes >= WCAP) return;
+            for (int i = nes; i > at; --i) { sm.es_t[i] = sm.es_t[i - 1]; sm.es_r[i] = sm.es_r[i - 1]; sm.es_g[i] = sm.es_g[i - 1]; }
+            sm.es_t[at] = 'D'; sm.es_r[at] = 0; sm.es_g[at] = '*';
+            ++nes;
+        };
+        auto es_del = [&](int at) {
+            for (int i = at; i + 1 < nes; ++i) { sm.es_t[i] = sm.es_t[i + 1]; sm.es_r[i] = sm.es_r[i + 1]; sm.es_g[i] = sm.es_g[i + 1]; }
+            --nes;
+        };
+        auto t_at = [&](int i) -> uint8_t { return (i < 0 || i >= nes) ? (uint8_t)0 : sm.es_t[i]; };
+        int cni = 0;  // cumulative # of ins
+        const int nti_ = ki - dt_km;
+        for (int i = 0; i < nti_ + cni; ++i) if (sm.es_t[i] == 'I') ++cni;
+        int nti = nti_ + cni - 1;  // cg.tr index -> cg.es index
+        for (int i = 0; i < ne; ++i, --nti) {  // CIGAR of edits
+            if (et[i] == 'D') { ++nti; es_ins(nti); }
+            if (sm.es_t[nti] == 'D') {
+                if (et[i] == 'I') { es_del(nti); --ni; }  // delete edit immediately
+                else sm.es_g[nti] = w_comp_char(eg[i]);
+            } else {
+                while (sm.es_t[nti] == 'I') --nti;
+                sm.es_t[nti] = et[i];
+                sm.es_g[nti] = eg[i] ? w_comp_char(eg[i]) : (uint8_t)0;
+            }
+        }
+        int e0 = nti + 1, e1 = e0;
+        for (uint32_t i = 0; i < score; ++i, --nti) {  // CIGAR of extended alignment
+            const uint8_t c = sm.es_t[nti];
+            if (c == '=') { }
+            else if (c == '*') sm.es_t[nti] = '=';
+            else break;
+        }
+        {   // find edit_tract
+            uint8_t c = t_at(e1);
+            while (c == 'X' || c == 'D' || c == 'I') { ++e1; c = t_at(e1); }
+            c = t_at(e0 - 1);
+            while (c == 'X' || c == 'D' || c == 'I') { --e0; c = t_at(e0 - 1); }
+        }
+        // merge edits if possible: rnts / gnts = the read / graph bases inside the tract
+        int nets = e1 - e0, nr = 0, ng = 0;
+        for (int i = e0; i < e1; ++i) { nr += sm.es_r[i] != 0; ng += sm.es_g[i] != 0; }
+        auto rnt = [&](int q) -> uint8_t { for (int i = e0; i < e1; ++i) if (sm.es_r[i] && q-- == 0) return sm.es_r[i]; return 0; };
+        auto gnt = [&](int q) -> uint8_t { for (int i = e0; i < e1; ++i) if (sm.es_g[i] && q-- == 0) return sm.es_g[i]; return 0; };
+        if (nr == ng) {
+            bool no_edit = true;
+            for (int i = 0; i < nr; ++i) if (rnt(i) != gnt(i)) { no_edit = false; break; }
+            if (no_edit) {  // edits canceled out
+                int dt_es = 0;
+                for (int i = e0; i < e1; ++i) {
+                    if (sm.es_t[i + dt_es] == 'D') { es_del(i + dt_es); --dt_es; }
+                    else { sm.es_t[i + dt_es] = '='; sm.es_g[i + dt_es] = 0; }
+                }
+                ni += dt_es;
+                ncorr -= (uint64_t)(e1 - e0);
+                nskip -= (uint64_t)(e1 - e0);
+            } else if (nets != nr) {  // D + I (same position) -> X: the tract shrinks
+                uint8_t rn[64], gn[64];
+                for (int i = 0; i < nr && i < 64; ++i) { rn[i] = rnt(i); gn[i] = gnt(i); }
+                int dt_es = 0;
+                const int dt_es_ = nr - nets;
+                int j = 0, kk = 0;
+                for (int i = e0; i < e1; ++i) {
+                    if (sm.es_t[i + dt_es] == 'D' && dt_es != dt_es_) { es_del(i + dt_es); --dt_es; }
+                    else {
+                        if (rn[kk & 63] == gn[kk & 63]) { sm.es_t[i + dt_es] = '='; sm.es_g[i + dt_es] = 0; }
+                        else { sm.es_t[i + dt_es] = 'X'; sm.es_g[i + dt_es] = gn[j & 63]; }
+                        ++j; ++kk;
+                    }
+                }
+                ni += dt_es;
+                ncorr += (uint64_t)(int64_t)dt_es;
+                nskip += (uint64_t)(int64_t)dt_es;
+            } else {  // match / mismatch only
+                for (int i = 0; i < nr; ++i) {
+                    if (sm.es_r[e0 + i] && sm.es_r[e0 + i] == sm.es_g[e0 + i]) {  // (here every entry has both bases) edit reverted
+                        sm.es_t[e0 + i] = '='; sm.es_g[e0 + i] = 0;
+                        --ncorr; --nskip;
+                    }
+                }
+            }
+        } else {
+            for (int i = 0; i < nets; ++i) {
+                if (sm.es_r[e0 + i] == sm.es_g[e0 + i]) { sm.es_t[e0 + i] = '='; sm.es_g[e0 + i] = 0; --ncorr; --nskip; }
+            }
+        }
+        sm.st[0] = ni; sm.st[1] = nes;
+        sm.st64[0] = nskip; sm.st64[1] = ncorr;
+    }
+    x.sync();
+    S.ni = (int)x.uni((uint32_t)sm.st[0]); S.nes = (int)x.uni((uint32_t)sm.st[1]);
+    {
+        const uint64_t a = sm.st64[0], b = sm.st64[1];
+        S.nskip = ((uint64_t)x.uni((uint32_t)(a >> 32)) << 32) | x.uni((uint32_t)a);
+        S.ncorr = ((uint64_t)x.uni((uint32_t)(b >> 32)) << 32) | x.uni((uint32_t)b);
+    }
+    x.sync();
+    if (S.nes > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; S.nes = WCAP; }
+    *pki = ki;
+}
+
 // One read through isThreadFeasible.  The read's arrays must be in sm (walk_load).  Returns ret (wave-uniform).
 template <class X>
 DBTK_HD int walk_read(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_t& P, uint32_t locus, int len, WalkState& S) {
@@ -347,261 +622,10 @@ DBTK_HD int walk_read(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_
     const uint64_t nkmers = (uint64_t)S.nkm;  // frozen (AQ.cpp:1126)
     const uint64_t maxnskip = nkmers >= P.thread_cth ? nkmers - P.thread_cth : 0;
 
-    auto refresh = [&](int lo, int hi) {  // graph info of km[lo, hi) again (they were rewritten)
-        if (lo < 0) lo = 0;
-        if (hi > S.nkm) hi = S.nkm;
-        x.sync();
-        for (int i = lo + lane; i < hi; i += 64) sm.gi[i] = (uint16_t)w_info(T, locus, sm.km[i], k, nullptr);
-        x.sync();
-    };
-    // find_anchor, AQ.cpp:878-888
-    auto find_anchor = [&]() -> bool {
-        for (;;) {
-            const int p = S.ki + lane;
-            const bool is = p < S.nkm && (sm.gi[p] & GR_HAS);
-            const uint64_t m = x.ballot(is);
-            const int lim = S.nkm - S.ki < 64 ? S.nkm - S.ki : 64;
-            const int adv = m ? __builtin_ctzll(m) : lim;
-            S.nskip += (uint64_t)adv; S.ni += adv; S.ki += adv;
-            if (m) break;
-            if (S.ki >= S.nkm) return false;
-        }
-        x.sync();
-        if (lane == 0) sm.tr[S.ki] = (sm.gi[S.ki] & GR_TR) ? '=' : '.';
-        if (lane < (int)k && sm.es_t[S.ni + lane] == '*') sm.es_t[S.ni + lane] = '=';
-        x.sync();
-        return true;
-    };
-
-    // edit_kmers_forward, AQ.cpp:828-862
-    auto edit_forward = [&](int wid, uint32_t score) {
-        uint8_t et[2], eg[2];
-        const int ne = w_edits(wid, et, eg);
-        int nm = 0, nd = 0, nins = 0;
-        for (int e = 0; e < ne; ++e) { nm += et[e] == 'X'; nd += et[e] == 'D'; nins += et[e] == 'I'; }
-        const int ki0 = S.ki, dt_km = nd - nins, dt_ki = nm + nd;
-        const int n0 = S.nkm - ki0;
-        // the bases to roll in after kmers[ki0 - 1]: the graph bases of the X / D edits, then the read's own bases from
-        // old position ki0 + nm + nins on, while they are good and the rewritten k-mer stays inside min(size, ki + k)
-        x.sync();
-        if (lane < 40) {
-            uint8_t b = 4;
-            int q = 0;
-            for (int e = 0; e < ne; ++e) if (et[e] != 'I') { if (lane == q) b = (uint8_t)w_code(eg[e]); ++q; }
-            if (lane >= dt_ki) {
-                const int o = nm + nins + (lane - dt_ki);  // old offset from ki0
-                if (o < n0 && sm.km[ki0 + o] != NAN64) b = (uint8_t)(sm.km[ki0 + o] % 4);
-            }
-            sm.bases[lane] = b;
-        }
-        x.sync();
-        if (dt_km) {
-            const int from = ki0 + nm + nins;
-            w_shift(x, sm.km, from, S.nkm, dt_km);
-            w_shift(x, sm.gi, from, S.nkm, dt_km);
-            S.nkm += dt_km;
-            if (S.nkm > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; S.nkm = WCAP; }
-        }
-        const int ki = ki0 + dt_ki;
-        int nb = dt_ki;  // rewritten k-mers: the corrected ones, then the extended ones
-        {
-            const int lim = S.nkm < ki + (int)k ? S.nkm : ki + (int)k;
-            for (int i = ki; i < lim; ++i) { if (sm.bases[nb] > 3) break; ++nb; }
-        }
-        {
-            uint64_t v = sm.km[ki0 - 1];
-            if (lane < nb) {
-                for (int q = 0; q <= lane; ++q) v = w_roll(v, rmask, sm.bases[q]);
-            }
-            x.sync();
-            if (lane < nb) sm.km[ki0 + lane] = v;
-        }
-        refresh(ki0, ki0 + nb);
-        if (dt_km) {  // cg.tr.resize(size + dt_km, '*')
-            const int nn = S.ntr + dt_km;
-            for (int i = S.ntr + lane; i < nn && i < WCAP; i += 64) sm.tr[i] = '*';
-            S.ntr = nn > WCAP ? WCAP : nn;
-        }
-        if (nd) {  // cg.es.insert(begin + ni + k - 1 + nm, edit_t('D', 0, '*')) x nd
-            const int at = S.ni + (int)k - 1 + nm;
-            w_shift(x, sm.es_t, at, S.nes, nd);
-            w_shift(x, sm.es_r, at, S.nes, nd);
-            w_shift(x, sm.es_g, at, S.nes, nd);
-            if (lane < nd) { sm.es_t[at + lane] = 'D'; sm.es_r[at + lane] = 0; sm.es_g[at + lane] = '*'; }
-            S.nes += nd;
-            if (S.nes > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; S.nes = WCAP; }
-        }
-        x.sync();
-        for (int i = lane; i < dt_ki + (int)score; i += 64) sm.tr[ki0 + i] = (sm.gi[ki0 + i] & GR_TR) ? '=' : '.';
-        if (lane < ne) { sm.es_t[S.ni + (int)k - 1 + lane] = et[lane]; sm.es_g[S.ni + (int)k - 1 + lane] = eg[lane]; }
-        for (int i = lane; i < (int)score; i += 64) sm.es_t[S.ni + ne + (int)k - 1 + i] = '=';
-        x.sync();
-        S.ni += ne + (int)score - 1;
-        S.ki = ki + (int)score - 1;  // the last edited kmer
-        S.ncorr += (uint64_t)ne;
-    };
-
-    // edit_kmers_backward, AQ.cpp:649-825, for the anchor at *pki; txt's nm / nd / ni / score are handed back
+    auto find_anchor = [&]() { return walk_find_anchor(x, sm, k, S); };
+    auto edit_forward = [&](int wid, uint32_t score) { walk_edit_forward(x, sm, T, locus, S, wid, score); };
     auto edit_backward = [&](int wid, uint32_t score, int* pki, int* onm, int* ond, int* oni) {
-        uint8_t et[2], eg[2];
-        const int ne = w_edits(wid, et, eg);
-        int nm = 0, nd = 0, nins = 0;
-        for (int e = 0; e < ne; ++e) { nm += et[e] == 'X'; nd += et[e] == 'D'; nins += et[e] == 'I'; }
-        *onm = nm; *ond = nd; *oni = nins;
-        const int dt_km = nd - nins;
-        int ki = *pki;
-        S.ni += nd;
-        if (dt_km > 0) {  // kmers.insert(begin + ki, 0) / cg.tr.insert(begin + ki, '*'), dt_km times
-            w_shift(x, sm.km, ki, S.nkm, dt_km);
-            w_shift(x, sm.gi, ki, S.nkm, dt_km);
-            w_shift(x, sm.tr, ki, S.ntr, dt_km);
-            if (lane < dt_km) { sm.km[ki + lane] = 0; sm.gi[ki + lane] = 0; sm.tr[ki + lane] = '*'; }
-        } else if (dt_km < 0) {  // erase [ki + dt_km, ki)
-            w_shift(x, sm.km, ki, S.nkm, dt_km);
-            w_shift(x, sm.gi, ki, S.nkm, dt_km);
-            w_shift(x, sm.tr, ki, S.ntr, dt_km);
-        }
-        S.nkm += dt_km; S.ntr += dt_km;
-        if (S.nkm > WCAP || S.ntr > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; if (S.nkm > WCAP) S.nkm = WCAP; if (S.ntr > WCAP) S.ntr = WCAP; }
-        ki += dt_km;
-        x.sync();
-        // corrected kmers (X / D edits, walking down from the anchor), then extended ones while the old k-mers were good:
-        // kmers[i - 1] = (kmers[i] >> 2) + leading base, the base being the complement of the edit's graph base or
-        // the old k-mer's own
-        const int ncor = nm + nd;
-        const int ki_ = ki - ncor;
-        int next = 0;  // extended
-        {
-            int lo = ki_ - (int)k; if (lo < 0) lo = 0;
-            for (int i = ki_; i > lo; --i) { if (sm.km[i - 1] == NAN64) break; ++next; }
-        }
-        if (lane < 40) {
-            uint8_t b = 0;
-            int q = 0;
-            for (int e = 0; e < ne; ++e) if (et[e] != 'I') { if (lane == q) b = (uint8_t)(3 - w_code(eg[e])); ++q; }
-            if (lane >= ncor && lane < ncor + next) b = (uint8_t)(sm.km[ki_ - 1 - (lane - ncor)] >> (2 * (k - 1)));
-            sm.bases[lane] = b;
-        }
-        x.sync();
-        {
-            uint64_t v = sm.km[ki];
-            if (lane < ncor + next) {
-                for (int q = 0; q <= lane; ++q) v = (v >> 2) + ((uint64_t)sm.bases[q] << (2 * (k - 1)));
-            }
-            x.sync();
-            if (lane < ncor + next) sm.km[ki - 1 - lane] = v;
-        }
-        refresh(ki - ncor - next, ki);
-        // the rest is sequential byte work on a few entries: lane 0
-        if (lane == 0) {
-            uint64_t nrk = 0;
-            const int lb = ki - nm - nd - (int)score;
-            for (int i = ki - 1; i >= lb; --i) {
-                if (sm.tr[i] == '*') ++nrk;
-                sm.tr[i] = (sm.gi[i] & GR_TR) ? '=' : '.';
-            }
-            nrk -= (uint64_t)(nm + nd);
-            uint64_t nskip = S.nskip - nrk, ncorr = S.ncorr + (uint64_t)ne;
-            int ni = S.ni, nes = S.nes;
-            auto es_ins = [&](int at) {
-                if (nes >= WCAP) return;
-                for (int i = nes; i > at; --i) { sm.es_t[i] = sm.es_t[i - 1]; sm.es_r[i] = sm.es_r[i - 1]; sm.es_g[i] = sm.es_g[i - 1]; }
-                sm.es_t[at] = 'D'; sm.es_r[at] = 0; sm.es_g[at] = '*';
-                ++nes;
-            };
-            auto es_del = [&](int at) {
-                for (int i = at; i + 1 < nes; ++i) { sm.es_t[i] = sm.es_t[i + 1]; sm.es_r[i] = sm.es_r[i + 1]; sm.es_g[i] = sm.es_g[i + 1]; }
-                --nes;
-            };
-            auto t_at = [&](int i) -> uint8_t { return (i < 0 || i >= nes) ? (uint8_t)0 : sm.es_t[i]; };
-            int cni = 0;  // cumulative # of ins
-            const int nti_ = ki - dt_km;
-            for (int i = 0; i < nti_ + cni; ++i) if (sm.es_t[i] == 'I') ++cni;
-            int nti = nti_ + cni - 1;  // cg.tr index -> cg.es index
-            for (int i = 0; i < ne; ++i, --nti) {  // CIGAR of edits
-                if (et[i] == 'D') { ++nti; es_ins(nti); }
-                if (sm.es_t[nti] == 'D') {
-                    if (et[i] == 'I') { es_del(nti); --ni; }  // delete edit immediately
-                    else sm.es_g[nti] = w_comp_char(eg[i]);
-                } else {
-                    while (sm.es_t[nti] == 'I') --nti;
-                    sm.es_t[nti] = et[i];
-                    sm.es_g[nti] = eg[i] ? w_comp_char(eg[i]) : (uint8_t)0;
-                }
-            }
-            int e0 = nti + 1, e1 = e0;
-            for (uint32_t i = 0; i < score; ++i, --nti) {  // CIGAR of extended alignment
-                const uint8_t c = sm.es_t[nti];
-                if (c == '=') { }
-                else if (c == '*') sm.es_t[nti] = '=';
-                else break;
-            }
-            {   // find edit_tract
-                uint8_t c = t_at(e1);
-                while (c == 'X' || c == 'D' || c == 'I') { ++e1; c = t_at(e1); }
-                c = t_at(e0 - 1);
-                while (c == 'X' || c == 'D' || c == 'I') { --e0; c = t_at(e0 - 1); }
-            }
-            // merge edits if possible: rnts / gnts = the read / graph bases inside the tract
-            int nets = e1 - e0, nr = 0, ng = 0;
-            for (int i = e0; i < e1; ++i) { nr += sm.es_r[i] != 0; ng += sm.es_g[i] != 0; }
-            auto rnt = [&](int q) -> uint8_t { for (int i = e0; i < e1; ++i) if (sm.es_r[i] && q-- == 0) return sm.es_r[i]; return 0; };
-            auto gnt = [&](int q) -> uint8_t { for (int i = e0; i < e1; ++i) if (sm.es_g[i] && q-- == 0) return sm.es_g[i]; return 0; };
-            if (nr == ng) {
-                bool no_edit = true;
-                for (int i = 0; i < nr; ++i) if (rnt(i) != gnt(i)) { no_edit = false; break; }
-                if (no_edit) {  // edits canceled out
-                    int dt_es = 0;
-                    for (int i = e0; i < e1; ++i) {
-                        if (sm.es_t[i + dt_es] == 'D') { es_del(i + dt_es); --dt_es; }
-                        else { sm.es_t[i + dt_es] = '='; sm.es_g[i + dt_es] = 0; }
-                    }
-                    ni += dt_es;
-                    ncorr -= (uint64_t)(e1 - e0);
-                    nskip -= (uint64_t)(e1 - e0);
-                } else if (nets != nr) {  // D + I (same position) -> X: the tract shrinks
-                    uint8_t rn[64], gn[64];
-                    for (int i = 0; i < nr && i < 64; ++i) { rn[i] = rnt(i); gn[i] = gnt(i); }
-                    int dt_es = 0;
-                    const int dt_es_ = nr - nets;
-                    int j = 0, kk = 0;
-                    for (int i = e0; i < e1; ++i) {
-                        if (sm.es_t[i + dt_es] == 'D' && dt_es != dt_es_) { es_del(i + dt_es); --dt_es; }
-                        else {
-                            if (rn[kk & 63] == gn[kk & 63]) { sm.es_t[i + dt_es] = '='; sm.es_g[i + dt_es] = 0; }
-                            else { sm.es_t[i + dt_es] = 'X'; sm.es_g[i + dt_es] = gn[j & 63]; }
-                            ++j; ++kk;
-                        }
-                    }
-                    ni += dt_es;
-                    ncorr += (uint64_t)(int64_t)dt_es;
-                    nskip += (uint64_t)(int64_t)dt_es;
-                } else {  // match / mismatch only
-                    for (int i = 0; i < nr; ++i) {
-                        if (sm.es_r[e0 + i] && sm.es_r[e0 + i] == sm.es_g[e0 + i]) {  // (here every entry has both bases) edit reverted
-                            sm.es_t[e0 + i] = '='; sm.es_g[e0 + i] = 0;
-                            --ncorr; --nskip;
-                        }
-                    }
-                }
-            } else {
-                for (int i = 0; i < nets; ++i) {
-                    if (sm.es_r[e0 + i] == sm.es_g[e0 + i]) { sm.es_t[e0 + i] = '='; sm.es_g[e0 + i] = 0; --ncorr; --nskip; }
-                }
-            }
-            sm.st[0] = ni; sm.st[1] = nes;
-            sm.st64[0] = nskip; sm.st64[1] = ncorr;
-        }
-        x.sync();
-        S.ni = (int)x.uni((uint32_t)sm.st[0]); S.nes = (int)x.uni((uint32_t)sm.st[1]);
-        {
-            const uint64_t a = sm.st64[0], b = sm.st64[1];
-            S.nskip = ((uint64_t)x.uni((uint32_t)(a >> 32)) << 32) | x.uni((uint32_t)a);
-            S.ncorr = ((uint64_t)x.uni((uint32_t)(b >> 32)) << 32) | x.uni((uint32_t)b);
-        }
-        x.sync();
-        if (S.nes > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; S.nes = WCAP; }
-        *pki = ki;
+        walk_edit_backward(x, sm, T, locus, S, wid, score, pki, onm, ond, oni);
     };
 
 #define W_FAIL_CHECK() do { if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) return -1; } while (0)
@@ -785,7 +809,7 @@ DBTK_HD int walk_load(X& x, WalkSmem& sm, const DevTables& T, const uint8_t* seq
 
 // What the walk left in LDS -> a thread record in HBM.
 template <class X>
-DBTK_HD void walk_store(X& x, const WalkSmem& sm, const WalkState& S, int ret, dbtk_thread_rec_t* o) {
+DBTK_HD_NOINLINE void walk_store(X& x, const WalkSmem& sm, const WalkState& S, int ret, dbtk_thread_rec_t* o) {
     const int lane = x.lane();
     x.sync();
     if (lane == 0) {
@@ -803,7 +827,7 @@ DBTK_HD void walk_store(X& x, const WalkSmem& sm, const WalkState& S, int ret, d
 
 // What the walk left in LDS -> mate m's half of a compact alignment record.
 template <class X>
-DBTK_HD void walk_store_aln(X& x, const WalkSmem& sm, const WalkState& S, int ret, uint8_t* rec, uint32_t cap, int m) {
+DBTK_HD_NOINLINE void walk_store_aln(X& x, const WalkSmem& sm, const WalkState& S, int ret, uint8_t* rec, uint32_t cap, int m) {
     const int lane = x.lane();
     dbtk_aln_hdr_t* h = reinterpret_cast<dbtk_aln_hdr_t*>(rec);
     uint8_t* es = rec + sizeof(dbtk_aln_hdr_t) + (size_t)(2 * m) * cap;
