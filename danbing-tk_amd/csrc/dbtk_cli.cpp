@@ -51,6 +51,7 @@ struct Opts {
     bool writeKmerName = false, outputBubbles = false, invkmer = false, isFastq = false, trackBait = false, qc = false;
     int simmode = 0, extractFastX = 0, verbosity = 0, ngpus = 1, gzLevel = 6, emitThreads = 0;
     bool correction = true;
+    bool parseOnly = false;  // --parse-only: run the ingest (reader, splitters, pairing) and report what it handed on; no GPU
     bool v13 = false;       // --v13-threading: -g/-gc/-gcc run the graph walk of the v1.3 contract instead of HEAD's dead path
     std::string alnGz;      // --aln-gz FILE: the -a / -ae records gzip-compressed into FILE (instead of plain on stdout)
     uint64_t trim = 0, thread_cth = 100, Cthreshold = 10, nproc = 1, ksize = 21, qth = 20, N_FILTER = 4, NM_FILTER = 1, NM_TR = 40,
@@ -294,6 +295,7 @@ int main(int argc, char* argv[]) {
         else if (a == "-qth") o.qth = strtoull(need(++argi).c_str(), nullptr, 10);
         else if (a == "--gpus") o.ngpus = atoi(need(++argi).c_str());
         else if (a == "--v13-threading") o.v13 = true;
+        else if (a == "--parse-only") o.parseOnly = true;
         else if (a == "--aln-gz") o.alnGz = need(++argi);
         else if (a == "--emit-threads") o.emitThreads = atoi(need(++argi).c_str());
         else if (a == "--gz-level") o.gzLevel = atoi(need(++argi).c_str());
@@ -343,8 +345,12 @@ int main(int argc, char* argv[]) {
     P.bubbles = o.outputBubbles && !o.extractFastX && !o.threading;  // countNovelEdges only runs on the assignment path
     if (o.ngpus < 1) o.ngpus = 1;
     std::vector<dbtk_ctx_t*> ctx(o.ngpus, nullptr);
-    for (int d = 0; d < o.ngpus; ++d)
-        if (dbtk_ctx_create(rpgg, &P, d, &ctx[d])) die_assert(dbtk_last_error());
+    if (!o.parseOnly)
+        for (int d = 0; d < o.ngpus; ++d)
+            if (dbtk_ctx_create(rpgg, &P, d, &ctx[d])) die_assert(dbtk_last_error());
+    // --parse-only: what the pairing stage handed to the aligner stage: pairs, bases, and an order-independent digest
+    // of (title, seq1, seq2[, qual1, qual2]) per pair (FNV-1a per pair, summed), for the ingest tests (no GPU needed)
+    std::atomic<uint64_t> po_pairs{0}, po_bases{0}, po_digest{0};
 
     // ---- the batch loop (AQ.cpp:1869-2282) as three overlapped stages: parse + pair | align (one thread per GPU) | write
     Reader in;
@@ -471,7 +477,7 @@ int main(int argc, char* argv[]) {
             const double tr = now();
             if (carry.size() <= b->base) {  // the usual case: the partial record goes into the headroom
                 b->base -= carry.size();
-                memcpy(b->data.data() + b->base, carry.data(), carry.size());
+                if (!carry.empty()) memcpy(b->data.data() + b->base, carry.data(), carry.size());
                 b->len += carry.size();
             } else {  // a partial record longer than the headroom (a record longer than a chunk): rebuild the block
                 BlockP nb = fresh_block();
@@ -676,6 +682,20 @@ int main(int argc, char* argv[]) {
                 const time_t t2 = time(nullptr);
                 const double tg = now();
                 const uint64_t npairs = b->nreads / 2;
+                if (o.parseOnly) {
+                    uint64_t dg = 0;
+                    auto fnv = [](uint64_t h, const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; for (size_t i = 0; i < n; ++i) { h ^= q[i]; h *= 0x100000001B3ull; } h ^= 0xFF; h *= 0x100000001B3ull; return h; };
+                    for (uint64_t pr = 0; pr < npairs; ++pr) {
+                        uint64_t hsh = 0xCBF29CE484222325ull;
+                        hsh = fnv(hsh, b->tar.data() + b->toff[pr], b->toff[pr + 1] - b->toff[pr]);
+                        for (int m = 0; m < 2; ++m) hsh = fnv(hsh, b->flat.data() + b->off[2 * pr + m], b->off[2 * pr + m + 1] - b->off[2 * pr + m]);
+                        if (fq) for (int m = 0; m < 2; ++m) hsh = fnv(hsh, b->qar.data() + b->qoff[2 * pr + m], b->qoff[2 * pr + m + 1] - b->qoff[2 * pr + m]);
+                        dg += hsh;
+                    }
+                    po_pairs += npairs; po_bases += b->flat.size(); po_digest += dg;
+                    aligned.push(std::move(b));
+                    continue;
+                }
                 const bool send_qual = use_bait && fq;
                 if (send_qual) {  // qualities feed qString2qMask (AQ.cpp:2104-2107); a quality string is as long as its read
                     flatq.assign(b->flat.size() + 1, (uint8_t)'!');
@@ -827,6 +847,11 @@ int main(int argc, char* argv[]) {
     fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: reading %.2f s, cutting %.2f s, pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads\n",
             now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, read_busy, cut_busy, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit);
 
+    if (o.parseOnly) {
+        printf("parse-only\t%llu\t%llu\t%llu\n", (unsigned long long)po_pairs.load(), (unsigned long long)po_bases.load(), (unsigned long long)po_digest.load());
+        dbtk_rpgg_free(rpgg);
+        return 0;
+    }
     // ---- totals + dumps (AQ.cpp:2611-2656)
     if (o.ngpus > 1 && dbtk_allreduce(ctx.data(), o.ngpus)) die_assert(dbtk_last_error());
     std::vector<uint64_t> counts(dbtk_rpgg_ntrkmers(rpgg)), kmc(nloci), counters(DBTK_C_COUNT);

@@ -81,6 +81,7 @@ template <int NS, bool RECS> __global__ void __launch_bounds__(64, NS <= 3 ? 2 :
     body_pair<NS, RECS>(x, a);
 }
 
+__global__ void __launch_bounds__(256) k_mz_insert(MzBuildArgs a) { DevX x{nullptr}; body_mz_insert(x, a); }
 __global__ void __launch_bounds__(256) k_gr_insert(GrBuildArgs a) { DevX x{nullptr}; body_gr_insert(x, a); }
 // the graph walk (dbtk_walk.h): one wave per read (function mode) / per pair (the hot path with threading = 2)
 __global__ void __launch_bounds__(64) k_walk_reads(WalkArgs a) {
@@ -139,6 +140,7 @@ struct dbtk_ctx {
     uint64_t* d_flt = nullptr; uint64_t flt_words = 0;
     uint32_t* d_trbeg = nullptr;
     ClsSlot* d_cls = nullptr;
+    MzBucket* d_mz = nullptr;     // the probe kernel's minimizer-grouped copy of the index
     GrSlot* d_gr = nullptr;       // graph table (threading = 2), nullptr when the handle holds no graph
     uint32_t* d_vv = nullptr;
     uint8_t* d_qc = nullptr;
@@ -230,7 +232,7 @@ void free_ctx(dbtk_ctx* c) {
         }
     void* ptrs[] = {c->d_flt, c->d_ctr, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
-                    c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_gr, c->d_walk, c->d_trecs, c->d_loci, c->d_aln};
+                    c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_gr, c->d_walk, c->d_trecs, c->d_loci, c->d_aln, c->d_mz};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     std::vector<dbtk_ctx::Lane*> others{&c->alt};
     for (auto& l : c->parked) others.push_back(&l);
@@ -349,6 +351,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         HIPCHK(hipStreamSynchronize(s));
     }
     DevTables& T = c->T;
+    memset(&T, 0, sizeof(T));  // optional tables (tre, bait, gr, mz) stay null unless built
     T.trbeg = c->d_trbeg;
     T.flt = c->d_flt; T.flt_logw = c->flt_words ? log2u(c->flt_words) : 0;
     T.idx = c->d_idx; T.idx_mask = nbkt - 1; T.idx_shift = 64 - log2u(nbkt);
@@ -368,6 +371,25 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         HIPCHK(hipFree(dstats));
         T.consistent = (st[1] == 0 && st[0] == st[2]) ? 1u : 0u;
         c->consistent = T.consistent;
+    }
+    {   // the probe kernel's minimizer-grouped copy of the index (DBTK_MZ=0: look up the plain index instead)
+        bool on = true;
+        if (const char* e = getenv("DBTK_MZ")) on = atoi(e) != 0;
+        if (on && nkeys) {
+            uint64_t per = 6;  // buckets per 8 keys: load ~0.1-0.17 (14 GB at release scale; nine keys in ten then sit in their home bucket)
+            if (const char* e = getenv("DBTK_MZ_SPARSITY")) { const long v = atol(e); if (v >= 2 && v <= 64) per = (uint64_t)v; }
+            const uint64_t nb = pow2_at_least(nkeys * per / 8 + 8);
+            HIPCHK(hipMalloc(&c->d_mz, nb * sizeof(MzBucket)));
+            HIPCHK(hipMemsetAsync(c->d_mz, 0xFF, nb * sizeof(MzBucket), s));
+            uint32_t m = MZ_M;
+            if (const char* e = getenv("DBTK_MZ_M")) { const int v = atoi(e); if (v >= 4 && v <= 16) m = (uint32_t)v; }
+            if (m > g->ksize) m = g->ksize;
+            MzBuildArgs a{c->d_idx, icap, c->d_mz, nb - 1, 64 - log2u(nb), g->ksize, m};
+            hipLaunchKernelGGL(k_mz_insert, dim3(2048), dim3(256), 0, s, a);
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipGetLastError());
+            T.mz = c->d_mz; T.mz_mask = nb - 1; T.mz_shift = 64 - log2u(nb); T.mz_m = m;
+        }
     }
     return DBTK_OK;
 }

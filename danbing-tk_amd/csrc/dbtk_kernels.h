@@ -121,6 +121,38 @@ DBTK_HD void body_idx_aux(X& x, const IdxAuxArgs& a) {
     if (nmiss) x.atomic_add(&a.stats[1], nmiss);
 }
 
+// The probe kernel's minimizer-grouped copy of the index, filled from the finished plain index (keys are unique there and
+// carry val | aux): every occupied slot is re-inserted under its k-mer's minimizer.
+struct MzBuildArgs {
+    const IdxBucket* idx;
+    uint64_t nslots;   // 4 per IdxBucket
+    MzBucket* mz;
+    uint64_t mask;     // buckets - 1
+    uint32_t shift, ksize, m;
+};
+template <class X>
+DBTK_HD void body_mz_insert(X& x, const MzBuildArgs& a) {
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.nslots; i += (uint64_t)x.nblocks() * x.nthreads()) {
+        uint64_t key = a.idx[i >> 2].key[i & 3];
+        if (key == NAN64) continue;
+        key &= ~IDX_OVF;
+        const uint64_t va = a.idx[i >> 2].val[i & 3];
+        const uint64_t b = mz_bucket(kmer_minimizer(key, a.ksize, a.m), a.shift);
+        bool placed = false;
+        for (int j = 0; j < 8 && !placed; ++j) {  // slots are claimed in order, so the occupied ones form a prefix
+            if (x.atomic_cas(&a.mz[b].key[j], NAN64, key) == NAN64) {
+                a.mz[b].val[j] = (uint32_t)va;
+                a.mz[b].aux[j] = (uint32_t)(va >> 32);
+                placed = true;
+            }
+        }
+        // no room: the key stays in the plain index only, and the bucket says so (bit 63 of key[7]) — a look-up that does not
+        // find its key in a bucket so marked asks the plain index (two levels, never a chain: heavy minimizers are those of
+        // tandem repeats, whose chains would otherwise be tens of buckets long)
+        if (!placed) x.atomic_or(&a.mz[b].key[7], IDX_OVF);
+    }
+}
+
 struct ClsBuildArgs {
     ClsSlot* slots;
     uint64_t mask;
@@ -1283,15 +1315,27 @@ struct BubEvent {  // one novel read (k+1)-mer (countNovelEdges, AQ.cpp:1559-156
     uint32_t pair, mate, pos, locus;
     uint64_t edge;
 };
+constexpr int MZ_RB = 32;  // runs (buckets) staged in LDS at a time: 4 KB
 struct ProbeSmem {
     uint32_t raw[72];
     uint32_t pk[20];
     uint16_t vd[20];
     uint32_t qraw[72];   // base qualities of the read (only with -b and qualities)
     uint32_t qmask[8];
-    uint64_t km[NKMAX];  // canonical k-mer per position (NAN64: window not valid)
-    uint32_t hb[NKMAX];  // its home bucket
-    uint64_t rva[NKMAX]; // look-up result per position: val | aux << 32 (val = NOHIT: not in the index)
+    // Two phases share one region (what bounds this kernel is round trips per wave times waves per CU, so its LDS is kept small):
+    union {
+        struct {  // look-up list of the plain index
+            uint64_t km[NKMAX];  // canonical k-mer per list entry (NAN64: window not valid)
+            uint32_t hb[NKMAX];  // its home bucket
+            uint64_t rva[NKMAX]; // look-up result per POSITION: val | aux << 32 (val = NOHIT: not in the index)
+            uint32_t pm[NKMAX];  // minimizer path: the position a list entry stands for
+        };
+        struct {  // minimizer-grouped look-ups (T.mz), before the list phase
+            uint32_t hm[MAXL + 8];      // hashes of the read's m-mers by base position
+            uint32_t rb[NKMAX];         // the bucket of every run of positions with one minimizer
+            uint64_t stg[MZ_RB][17];    // the buckets of MZ_RB runs at a time (17, not 16, words per row: rows on different LDS banks)
+        };
+    };
 };
 
 // qString2qMask (src/aQueryFasta_thread.h:1038-1071), statement by statement, on the quality bytes
@@ -1441,6 +1485,106 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                 open[s] = km[s] != NAN64;
             }
         }
+        uint64_t* outk = a.hitkm + (size_t)it * a.nkp;
+        uint32_t* outa = a.hitaux + (size_t)it * a.nkp;
+        uint32_t* outv = a.hitval + (size_t)it * a.nkp;
+        if (lane == 0) { a.hitnk[it] = nk; a.hitoff[it] = o0; }
+        uint64_t rvv[NSLOT];  // minimizer path: this lane's own results
+        bool pend2[NSLOT];    //                 positions its home bucket could not answer
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) { rvv[s] = (uint64_t)NOHIT; pend2[s] = false; }
+        if (T.mz) {
+            // ---- look-ups through the minimizer-grouped copy of the index (MzBucket, dbtk_tables.h): one 128-byte bucket per
+            // RUN of positions sharing a minimizer instead of one 64-byte bucket per position
+            const uint32_t m = T.mz_m, wn = k - m + 1;
+            const uint32_t nmm = len >= m ? len - m + 1 : 0;
+            for (uint32_t j = lane; j < nmm; j += 64) {  // hashed canonical m-mer at every base position
+                uint32_t hv = 0xFFFFFFFFu;
+                if (clean) hv = mmer_hash(window_fw_clean(sm.pk, j, m), m);
+                else { uint64_t f, r; if (window_kmer(sm.pk, sm.vd, j, m, &f, &r) != NAN64) hv = mmer_hash(f, m); }
+                sm.hm[j] = hv;
+            }
+            x.sync();
+            DBTK_STAMP(16);  // (K2, minimizer path) windows + m-mer hashes
+            uint32_t bk[NSLOT], rid[NSLOT];
+            uint32_t nruns = 0;  // runs so far (wave-uniform)
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                const uint32_t i = 64 * s + lane;
+                bk[s] = 0xFFFFFFFFu; rid[s] = 0;
+                if ((uint32_t)s >= nsl) continue;
+                if (open[s]) {
+                    uint32_t mzv = 0xFFFFFFFFu;
+                    for (uint32_t t = 0; t < wn; ++t) { const uint32_t h = sm.hm[i + t]; mzv = h < mzv ? h : mzv; }
+                    bk[s] = (uint32_t)mz_bucket(mzv, T.mz_shift);
+                }
+                // a position opens a run when its bucket differs from the previous position's
+                uint32_t prev = x.shfl_up1(bk[s]);
+                if (lane == 0) prev = 0xFFFFFFFFu;
+                if (s > 0) { const uint32_t carry = x.bcast(bk[s - 1], 63); if (lane == 0) prev = carry; }
+                const bool start = open[s] && bk[s] != prev;
+                const uint64_t sb = x.ballot(start);
+                const uint32_t upto = (uint32_t)__builtin_popcountll(sb & ((2ull << lane) - 1));  // starts at lanes <= this one
+                rid[s] = nruns + upto - 1;  // (meaningful for open positions only: an open non-start continues the run before it)
+                if (start) sm.rb[rid[s]] = bk[s];
+                nruns += (uint32_t)__builtin_popcountll(sb);
+            }
+            x.sync();
+            DBTK_STAMP(17);  // minimizers + runs
+            const uint32_t fq8 = lane >> 3, part = lane & 7;  // bucket fetch: 8 lanes x 16 bytes per bucket, 8 buckets per load instruction
+            for (uint32_t r0 = 0; r0 < nruns; r0 += MZ_RB) {
+                x.sync();
+                uint4 q[MZ_RB / 8];
+#pragma unroll
+                for (int u = 0; u < MZ_RB / 8; ++u) {  // the loads first, all in flight together (a run past the end re-reads bucket 0)
+                    const uint32_t run = r0 + 8 * u + fq8;
+                    const uint64_t b = run < nruns ? (uint64_t)sm.rb[run] : 0ull;
+                    q[u] = reinterpret_cast<const uint4*>(T.mz + b)[part];
+                }
+#pragma unroll
+                for (int u = 0; u < MZ_RB / 8; ++u) {
+                    const uint32_t t = 8 * u + fq8;
+                    sm.stg[t][2 * part] = ((uint64_t)q[u].y << 32) | q[u].x; sm.stg[t][2 * part + 1] = ((uint64_t)q[u].w << 32) | q[u].z;
+                }
+                x.sync();
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    if (!((uint32_t)s < nsl && open[s] && rid[s] >= r0 && rid[s] < r0 + MZ_RB)) continue;
+                    const uint64_t* kk = sm.stg[rid[s] - r0];
+                    int hit = -1;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) if (kk[j] == km[s]) hit = j;
+                    const uint64_t k7 = kk[7];
+                    if (k7 != NAN64 && (k7 & ~IDX_OVF) == km[s]) hit = 7;
+                    if (hit >= 0) {
+                        const uint32_t* va = reinterpret_cast<const uint32_t*>(kk + 8);
+                        rvv[s] = (uint64_t)va[hit] | ((uint64_t)va[8 + hit] << 32);
+                    } else if (k7 != NAN64 && (k7 & IDX_OVF)) pend2[s] = true;  // the bucket turned keys away: ask the plain index
+                }
+            }
+            DBTK_STAMP(18);  // home buckets: fetch + search
+#ifdef DBTK_STAMPS
+            st_acc[19] += nruns;
+#endif
+        }
+        // ---- look-ups in the plain index: every position (no minimizer-grouped copy), or the positions the home buckets left open
+        uint32_t nl = nk;        // entries of the look-up list in sm.km / sm.hb
+        const bool mapped = T.mz != nullptr;  // list entry j stands for position sm.pm[j] (else: for position j)
+        if (mapped) {
+            x.sync();
+            nl = 0;
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                if ((uint32_t)s >= nsl) continue;
+                const uint64_t pb = x.ballot(pend2[s]);
+                if (pend2[s]) {
+                    const uint32_t j = nl + (uint32_t)__builtin_popcountll(pb & ((1ull << lane) - 1));
+                    sm.km[j] = km[s]; sm.hb[j] = (uint32_t)hh[s]; sm.pm[j] = 64u * s + lane;
+                }
+                nl += (uint32_t)__builtin_popcountll(pb);
+            }
+            x.sync();
+        } else {
         // Stage (k-mer, home bucket) per position in LDS, then look the positions up 16 at a time: the four lanes of a
         // quad read the four 16-byte parts of one bucket (keys 0,1 | keys 2,3 | values 0,1 | values 2,3), so a lookup
         // is one request for one 64-byte line and ends in its home bucket unless that bucket is full AND overflowed.
@@ -1450,11 +1594,8 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             if ((uint32_t)s < nsl && i < nk) { sm.km[i] = km[s]; sm.hb[i] = open[s] ? (uint32_t)hh[s] : 0u; }
         }
         x.sync();
+        }
         DBTK_STAMP(41);  // windows, hash, staging
-        uint64_t* outk = a.hitkm + (size_t)it * a.nkp;
-        uint32_t* outa = a.hitaux + (size_t)it * a.nkp;
-        uint32_t* outv = a.hitval + (size_t)it * a.nkp;
-        if (lane == 0) { a.hitnk[it] = nk; a.hitoff[it] = o0; }
         const uint32_t sub = lane & 3, qd = lane >> 2;
         constexpr int NB = DBTK_K2_NB;  // buckets in flight per lane
         // One evaluation of a quad's bucket parts against its k-mer: the two key lanes compare, the value lanes' words reach
@@ -1476,7 +1617,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             }
             return x.ballot(more);
         };
-        for (uint32_t i0 = 0; i0 < nk; i0 += 16 * NB) {
+        for (uint32_t i0 = 0; i0 < nl; i0 += 16 * NB) {
             uint32_t ii[NB], bq[NB];
             uint64_t kq[NB], a0[NB], a1[NB];
 #pragma unroll
@@ -1484,8 +1625,9 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                 ii[u] = i0 + 16 * u + qd;
                 // straight-line loads (LDS and HBM alike): a closed lane reads position 0 / bucket 0 and ignores it, so that
                 // the NB bucket loads are all in flight together (a load under a branch makes the compiler wait for it)
-                const uint32_t ic = ii[u] < nk ? ii[u] : 0u;
+                const uint32_t ic = ii[u] < nl ? ii[u] : 0u;
                 kq[u] = sm.km[ic]; bq[u] = sm.hb[ic];
+                if (mapped) ii[u] = ii[u] < nl ? sm.pm[ic] : 0xFFFFFFFFu;  // the position the entry stands for
                 if (ii[u] >= nk) { kq[u] = NAN64; bq[u] = 0; }
 #ifdef DBTK_STAMPS
                 if (a.P.diag & 64) bq[u] &= 1023;  // diagnostic: every look-up in the first 64 KB of the table (cache hits)
@@ -1497,7 +1639,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 more[u] = false;
-                if (i0 + 16 * u < nk) anymore |= settle(true, ii[u], kq[u], a0[u], a1[u], more[u]);  // (uniform condition)
+                if (i0 + 16 * u < nl) anymore |= settle(true, ii[u], kq[u], a0[u], a1[u], more[u]);  // (uniform condition)
             }
             if (anymore) {  // rare (about one look-up in a thousand): walk on, bucket by bucket
 #pragma unroll
@@ -1515,6 +1657,11 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                 }
             }
         }
+        if (mapped) {  // the open positions' results come back through LDS
+            x.sync();
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) if ((uint32_t)s < nsl && pend2[s]) rvv[s] = sm.rva[64 * s + lane];
+        }
         x.sync();
         {   // the read's results: found positions, and whether they are all unique to one and the same locus
             uint64_t rv[NSLOT];
@@ -1524,7 +1671,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             for (int s = 0; s < NSLOT; ++s) {
                 const uint32_t i = 64 * s + lane;
                 const bool in = (uint32_t)s < nsl && i < nk;
-                rv[s] = in ? sm.rva[i] : (uint64_t)NOHIT;
+                rv[s] = in ? (T.mz ? rvv[s] : sm.rva[i]) : (uint64_t)NOHIT;
                 const uint32_t v = (uint32_t)rv[s];
                 const uint64_t hmk = x.ballot(v != NOHIT);
                 nh += (uint32_t)__builtin_popcountll(hmk);

@@ -62,6 +62,23 @@ struct ClsSlot {
     uint64_t lc;    // ~0 = not yet written (build only)
 };
 
+// ---- the probe kernel's own copy of the index, grouped by MINIMIZER.  A random look-up costs one request to the memory
+// fabric whatever its size, and the chip completes ~50-58 G of them per second (tools/lat.hip): with one request per k-mer
+// the probe kernel sits on that ceiling at < 10 % of the HBM roofline.  The ~130 k-mers of a read overlap, so consecutive
+// ones share most of their m-mers: all keys whose smallest hashed canonical m-mer (m = 13) is the same — the k-mer's
+// minimizer, identical for a k-mer and its reverse complement — live in the same 128-byte bucket (8 keys, then their 8
+// index values, then their 8 classes).  A bucket that had to turn keys away says so in bit 63 of key[7]; those keys (one in
+// ten: the heavy minimizers of tandem repeats, and bucket collisions) are found in the plain index instead — two levels,
+// never a chain.  A read then needs one bucket per RUN of positions with the same minimizer (a new one every ~4
+// positions): the probe kernel stages those buckets in LDS and every position searches its run's bucket there.
+struct __attribute__((aligned(128))) MzBucket {
+    uint64_t key[8];  // NAN64 = empty; slots fill in order
+    uint32_t val[8];
+    uint32_t aux[8];
+};
+constexpr uint32_t MZ_M = 15;  // m-mer length (k < 15: the k-mer itself); a stretch of unique sequence puts k - m + 1 = 7 keys in a bucket of 8
+
+struct DevTables;
 // ---- graph table (v1.3 threading): graphDB[locus] (GraphType = unordered_map<node, out-edge mask>,
 // src/aQueryFasta_thread.h:32, loader :550-575) and trKmers[locus] folded into ONE open-addressed table keyed by
 // (canonical k-mer, locus), so that a single probe answers everything the walk asks about a k-mer at a locus:
@@ -98,6 +115,7 @@ struct DevTables {
     const ClsSlot* tre; uint64_t tre_mask; uint32_t tre_shift;
     const ClsSlot* bait; uint64_t bait_mask; uint32_t bait_shift;
     const GrSlot* gr; uint64_t gr_mask; uint32_t gr_shift;  // nullptr: no graph loaded
+    const MzBucket* mz; uint64_t mz_mask; uint32_t mz_shift, mz_m;  // nullptr: the probe kernel looks up the plain index
 };
 
 DBTK_HD uint64_t hash_mix(uint64_t key) {
@@ -283,6 +301,25 @@ DBTK_HD uint64_t revcomp2(uint64_t x, uint32_t k) {
     return (~x) >> (64 - 2 * k);
 }
 
+// Hash of a canonical m-mer (m <= 16) that orders the m-mers of a k-mer; the k-mer's minimizer is the smallest.
+DBTK_HD uint32_t mmer_hash(uint64_t fw, uint32_t m) {
+    const uint64_t rc = revcomp2(fw, m);
+    uint32_t x = (uint32_t)(fw < rc ? fw : rc);
+    x ^= x >> 13; x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 16;
+    return x;
+}
+// Minimizer (as a hash value) of a k-mer given in either orientation: min over its k - m + 1 m-mers.
+DBTK_HD uint32_t kmer_minimizer(uint64_t kmer, uint32_t k, uint32_t m) {
+    const uint64_t mm = (1ull << 2 * m) - 1;
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i + m <= k; ++i) {
+        const uint32_t h = mmer_hash((kmer >> (2 * (k - m - i))) & mm, m);
+        best = h < best ? h : best;
+    }
+    return best;
+}
+DBTK_HD uint64_t mz_bucket(uint32_t minimizer, uint32_t shift) { return ((uint64_t)minimizer * 0x9E3779B97F4A7C15ull) >> shift; }
+
 // Window of k bases starting at base `b` of a packed stream (pk: 16 bases per
 // word, vd: 16 validity bits per entry, both big-endian; two zero entries of
 // padding must follow the data).  Returns the canonical k-mer
@@ -302,6 +339,15 @@ DBTK_HD uint64_t window_kmer(const uint32_t* pk, const uint16_t* vd, uint32_t b,
     if (rc_out) *rc_out = rc;
     if (vk != ((1ull << k) - 1)) return NAN64;
     return fw < rc ? fw : rc;
+}
+
+// Forward strand only of the same window (every base known to be valid).
+DBTK_HD uint64_t window_fw_clean(const uint32_t* pk, uint32_t b, uint32_t k) {
+    const uint32_t w = b >> 4, o = b & 15;
+    const uint64_t hi = ((uint64_t)pk[w] << 32) | pk[w + 1];
+    const uint64_t lo = (uint64_t)pk[w + 2] << 32;
+    const uint64_t x = o ? ((hi << (2 * o)) | (lo >> (64 - 2 * o))) : hi;
+    return x >> (64 - 2 * k);
 }
 
 // The same window when every base of the stream is known to be valid (no validity words are read).

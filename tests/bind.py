@@ -50,7 +50,7 @@ def aln_line(O, res, trecs, i, title: str, s1: bytes, s2: bytes, nloci):
 
 class Oracle:
     def __init__(self):
-        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        path = os.environ.get("DBTK_ORACLE_LIB", os.path.join(ROOT, "oracle", "liboracle.so"))  # (make asan: the sanitized build)
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path}: run `make -C oracle oracle`")
         L = self.L = C.CDLL(path)
@@ -376,7 +376,7 @@ class Emu(pkg._HostSide):
     a backend of the product."""
 
     def __init__(self):
-        path = os.path.join(ROOT, "tests", "emu", "libdbtk_emu.so")
+        path = os.environ.get("DBTK_EMU_LIB", os.path.join(ROOT, "tests", "emu", "libdbtk_emu.so"))
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path}: run `make -C tests/emu`")
         L = self.L = C.CDLL(path)

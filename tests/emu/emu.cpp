@@ -256,6 +256,7 @@ struct EmuTables {
     std::vector<uint64_t> flt;
     std::vector<ClsSlot> tre, bait;
     std::vector<GrSlot> gr;
+    std::vector<MzBucket> mz;
     uint64_t stats[3] = {0, 0, 0};
     DevTables T;
 };
@@ -302,6 +303,7 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
     e->trbeg.assign(nloci + 1, 0);
     for (uint64_t l = 0; l <= nloci; ++l) e->trbeg[l] = (uint32_t)g->out_beg[l];
     DevTables& T = e->T;
+    memset(&T, 0, sizeof(T));  // optional tables (tre, bait, gr, mz) stay null unless built
     T.trbeg = e->trbeg.data();
     T.flt = e->flt.data(); T.flt_logw = (uint32_t)(63 - __builtin_clzll(e->flt.size()));
     T.idx = e->idx.data(); T.idx_mask = nbkt - 1; T.idx_shift = 64 - lg(nbkt);
@@ -330,6 +332,18 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
         IdxAuxArgs a{e->idx.data(), icap, T, e->stats};
         run_grid(3, 64, 0, [&](EmuX& x) { body_idx_aux(x, a); });
         T.consistent = (e->stats[1] == 0 && e->stats[0] == e->stats[2]) ? 1u : 0u;
+    }
+    if (!getenv("DBTK_MZ") || atoi(getenv("DBTK_MZ"))) {  // the probe body's minimizer-grouped copy of the index (small: chains get exercised)
+        const uint64_t nb = pow2((g->keys.size() * 2) / 8 + 8) / 1024 ? pow2((g->keys.size() * 2) / 8 + 8) : 1024;
+        MzBucket empty;
+        memset(&empty, 0xFF, sizeof(empty));
+        e->mz.assign(nb, empty);
+        uint32_t m = MZ_M;
+        if (const char* ev = getenv("DBTK_MZ_M")) m = (uint32_t)atoi(ev);
+        if (m > g->ksize) m = g->ksize;
+        MzBuildArgs a{e->idx.data(), icap, e->mz.data(), nb - 1, 64 - lg(nb), g->ksize, m};
+        run_grid(3, 64, 0, [&](EmuX& x) { body_mz_insert(x, a); });
+        T.mz = e->mz.data(); T.mz_mask = nb - 1; T.mz_shift = 64 - lg(nb); T.mz_m = m;
     }
     if (!g->gr_cnt.empty()) {  // graph table: graph pass, then TR pass (as build_graph_table does on the device)
         const uint64_t ngr = g->gr_ks.size(), ntrf = g->tr_ks.size();

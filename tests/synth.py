@@ -33,6 +33,8 @@ def ref_tool(name: str) -> str:
 
 
 def have_ref() -> bool:
+    if os.environ.get("DBTK_NO_REF"):  # (make asan: the compiled reference is not sanitizer-clean and not ours to fix)
+        return False
     return all(os.path.exists(os.path.join(REFDIR, t)) for t in ("danbing-tk", "ktools", "fa2kmers", "libdbtk_refharness.so"))
 
 

@@ -14,7 +14,7 @@ import synth
 from test_oracle import GOLD
 
 ROOT = bind.ROOT
-CLI = os.path.join(ROOT, "danbing-tk_amd", "bin", "danbing-tk")
+CLI = os.environ.get("DBTK_CLI", os.path.join(ROOT, "danbing-tk_amd", "bin", "danbing-tk"))  # (make asan points it at the sanitized build)
 GOLDEN = cases.GOLDEN
 
 
@@ -243,3 +243,79 @@ def test_cli_aln_gz_is_the_stdout_stream(tmp_path):
         assert r.stdout == b""
         assert gzip.open(os.path.join(w, "out.aln.gz"), "rb").read() == want
         assert open(os.path.join(w, "gz.trkmc.ar"), "rb").read() == open(os.path.join(d, "refae.trkmc.ar"), "rb").read()
+
+
+# ---- the ingest (reader, splitters, pairing) on the CPU: `--parse-only` reports what the pairing stage handed on --------
+def _digest(reads, fastq):
+    """pairs, bases and the order-independent digest dbtk_cli.cpp computes with --parse-only, from tests/refio.py's restatement
+    of the reference's reader (AQ.cpp:1918-1976)."""
+    M = (1 << 64) - 1
+
+    def fnv(h, b):
+        for c in b:
+            h = ((h ^ c) * 0x100000001B3) & M
+        return ((h ^ 0xFF) * 0x100000001B3) & M
+    dg = 0
+    for p in range(reads.npairs):
+        h = fnv(0xCBF29CE484222325, reads.titles[p].encode())
+        h = fnv(fnv(h, reads.seqs[2 * p]), reads.seqs[2 * p + 1])
+        if fastq:
+            h = fnv(fnv(h, reads.quals[2 * p]), reads.quals[2 * p + 1])
+        dg = (dg + h) & M
+    return reads.npairs, sum(len(s) for s in reads.seqs), dg
+
+
+def _write_records(fn, recs, fastq):
+    with open(fn, "wb") as f:
+        for t, s, q in recs:
+            f.write(t + b"\n" + s + b"\n" + ((b"+\n" + q + b"\n") if fastq else b""))
+
+
+@pytest.mark.parametrize("fastq", [False, True])
+def test_ingest_pairs_like_the_reference_reader(tmp_path, fastq):
+    """Interleaved mates, mates far apart, singletons, a title seen three and four times, short reads, /1 /2 suffixes, a
+    missing final newline — through block sizes from a few records to one block: the pairs handed to the aligner are
+    exactly those of the reference's reader (as restated in tests/refio.py)."""
+    import numpy as np
+    import refio
+    rng = np.random.default_rng(11 + fastq)
+    mk = lambda n: bytes(rng.choice(list(b"ACGTN"), n, p=[.24, .24, .24, .24, .04]).astype(np.uint8))
+    q = lambda n: bytes(rng.integers(35, 74, n).astype(np.uint8)) if fastq else b""
+    lead = b"@" if fastq else b">"
+    recs, late = [], []
+    for i in range(900):
+        t = lead + b"r%d" % i
+        n1, n2 = (int(rng.integers(20, 151)) for _ in range(2))
+        a, b = (t + b"/1", mk(n1), q(n1)), (t + b"/2", mk(n2), q(n2))
+        u = rng.random()
+        if u < 0.6:
+            recs += [a, b]                      # adjacent
+        elif u < 0.8:
+            recs.append(a); late.append(b)      # mate arrives much later
+        elif u < 0.9:
+            recs.append(a)                      # singleton
+        elif u < 0.95:
+            recs += [a, b, (t + b"/1", mk(80), q(80))]            # a triple
+        else:
+            recs += [a, b, (t + b"/1", mk(90), q(90)), (t, mk(95), q(95))]  # four of a kind
+        if len(late) > 40 and rng.random() < 0.3:
+            rng.shuffle(late)
+            recs += late
+            late = []
+    recs += late
+    fn = str(tmp_path / ("reads.fq" if fastq else "reads.fa"))
+    _write_records(fn, recs, fastq)
+    with open(fn, "rb+") as f:  # no newline after the last line
+        f.seek(-1, 2)
+        f.truncate()
+    d = os.path.join(GOLDEN, "g1_k21")
+    for cth in (10, 45):
+        want = _digest(refio.read_pairs(fn, fastq, cth + 21 - 1), fastq)
+        for blk in ("64", "300", "5000", None):
+            env = dict(os.environ)
+            if blk:
+                env["DBTK_INGEST_BLOCK"] = blk
+            r = run(["--parse-only", "-k", "21", "-cth", str(cth), "-fq" if fastq else "-fa", fn, "-qs", "pan", "-o", str(tmp_path / "o")], cwd=d, env=env)
+            assert r.returncode == 0, r.stderr.decode()[-1500:]
+            got = tuple(int(x) for x in r.stdout.decode().split()[1:])
+            assert got == want, (blk, cth, got, want)

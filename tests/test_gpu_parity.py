@@ -215,28 +215,32 @@ def test_device_entry_alternating_lanes(dbtk, oracle, tmp_path, lanes, monkeypat
 
 
 def test_release_scale_properties(dbtk, oracle):
-    """At a scale the oracle cannot cover in seconds (6000-locus synthetic RPGG of the bench's generator, 1.2 M reads with
-    20 % from the loci): size-independent properties — additivity over batch splits, the counters' conservation laws,
-    sum of counts == counted increments — plus the oracle itself on a 30 000-pair slice."""
-    syn = bind.pkg.Synth(nloci=6000)
+    """BASELINE config 2 at its full size: the bench's release-scale synthetic RPGG (80 000 loci, 1.4e8 index keys) and
+    10 M reads (2 % of the pairs from the loci).  Size-independent properties — additivity over batch splits, the
+    counters' conservation laws, sum of counts == counted increments — plus the oracle itself on a 100 000-pair slice of
+    that batch, on a 100 000-pair ALL-HIT slice (every pair from a locus: the probe / resolve kernels' regime), and on an
+    all-hit slice through the graph walk (threading = 2, -gc 85 3)."""
+    syn = bind.pkg.Synth(nloci=80000)
+    syn.graph()
     arrs = syn.arrays()
     h = C.c_void_p()
     dbtk._chk(dbtk.L.dbtk_rpgg_from_arrays(C.byref(arrs), C.byref(h)))
     g = bind.pkg.Rpgg(dbtk, h)
-    npairs = 600_000
-    seq, off = syn.reads(npairs, hit_frac=0.2)
+    npairs = 5_000_000
+    seq, off = syn.reads(npairs, hit_frac=0.02)
     p = abi.default_params(ksize=21, n_filter=4, nm_filter=1, cthreshold=45, okam=0)
     whole = dbtk.context(g, p)
     whole.align(seq, off)
     w = whole.counts()
     parts = dbtk.context(g, p)
-    cuts = [0, 1, 4097, 250_000, 250_016, npairs]
+    cuts = [0, 1, 4097, 2_500_000, 2_500_016, npairs]
     for a, b in zip(cuts[:-1], cuts[1:]):
         base = int(off[2 * a])
         parts.align(seq[base:int(off[2 * b])], off[2 * a:2 * b + 1] - np.uint64(base))
     q = parts.counts()
     for k in ("counts", "kmc", "nmapread", "counters"):
         assert (w[k] == q[k]).all(), k
+    parts.close()
     ctr = w["counters"]
     assert ctr[abi.C_NREADS] == 2 * npairs
     assert int(w["counts"].sum()) == int(ctr[abi.C_ALGO_INC])          # every increment lands in exactly one counter
@@ -245,16 +249,36 @@ def test_release_scale_properties(dbtk, oracle):
     funnel = 2 * int(ctr[abi.C_NSHORT]) + sum(int(ctr[i]) for i in (abi.C_SUBFILTERED, abi.C_KMERFILTERED, abi.C_LOCUSFILTERED, abi.C_QCFILTERED, abi.C_THREADING))
     assert funnel == 2 * npairs, (funnel, ctr)
     assert ctr[abi.C_ASGN] <= ctr[abi.C_FEASIBLE] <= ctr[abi.C_THREADING]
-    # and the oracle on a slice
-    n = 30_000
+    # the oracle on a slice of the same batch
+    n = 100_000
     orc_g = oracle.from_arrays(arrs)
     o = oracle.align(orc_g, p, seq[:int(off[2 * n])], off[:2 * n + 1], trace=False)
-    c3 = dbtk.context(g, p)
-    c3.align(seq[:int(off[2 * n])], off[:2 * n + 1])
-    compare(o, c3.counts(), g.output_order(), g.ntrkmers, 0, recs=False)
+    whole.reset()
+    whole.align(seq[:int(off[2 * n])], off[:2 * n + 1])
+    compare(o, whole.counts(), g.output_order(), g.ntrkmers, 0, recs=False)
+    # all-hit slice: every pair from a locus
+    hseq, hoff = syn.reads(n, hit_frac=1.0, seed=2)
+    o = oracle.align(orc_g, p, hseq, hoff, trace=False)
+    assert o["counters"][abi.C_THREADING] > n and o["counters"][abi.C_ASGN] > n // 20
+    whole.reset()
+    whole.align(hseq, hoff)
+    compare(o, whole.counts(), g.output_order(), g.ntrkmers, 0, recs=False)
+    whole.close()
+    # the same all-hit slice through the graph walk (config 4's flags on this RPGG)
+    n2 = 30_000
+    pw = abi.default_params(ksize=21, n_filter=4, nm_filter=1, cthreshold=45, okam=0, threading=abi.THREADING_V13, thread_cth=85,
+                            correction=1, maxncorrection=3)
+    ow = oracle.align_walk(orc_g, pw, hseq[:int(hoff[2 * n2])], hoff[:2 * n2 + 1], with_recs=False)
+    cw = dbtk.context(g, pw)
+    cw.align(hseq[:int(hoff[2 * n2])], hoff[:2 * n2 + 1])
+    r = cw.counts()
+    co = np.zeros(g.ntrkmers, np.uint64)
+    np.add.at(co, g.output_order().astype(np.int64), ow["counts_file"])
+    assert (co == r["counts"]).all() and co.sum() > 0 and (ow["counters"] == r["counters"]).all()
+    res, _, nres = cw.walk_results(n2)
+    assert nres == ow["nres"] and bytes(res)[:8 * nres] == bytes(ow["res"])[:8 * nres]
+    cw.close()
     oracle.free(orc_g)
-    for c in (whole, parts, c3):
-        c.close()
     g.close()
 
 

@@ -55,7 +55,8 @@ def main():
     print(f"  slowest pair: {int(st[47]) >> 32} cycles, {(int(st[47]) >> 12) & 0xFFFFF} loci-list words, {int(st[47]) & 0xFFF} distinct k-mers")
     print("  pair times (cycles, all 3 steps): " + ", ".join(f"<2^{12 + 2 * b}: {int(st[21 + b if b < 3 else 26 + b])}" for b in range(6)))
     st[44:47] = 0
-    k2 = {40: "K2 fetch+pack", 41: "K2 windows+hash+stage", 42: "K2 look-ups+stores", 43: "K2 loop/extras"}
+    k2 = {40: "K2 fetch+pack", 16: "K2 mz: m-mer hashes", 17: "K2 mz: minimizers+runs", 18: "K2 mz: home buckets", 41: "K2 windows/list stage", 42: "K2 look-ups+stores", 43: "K2 loop/extras"}
+    print(f"K2 runs per read: {float(st[19]) / 64 / max(2.0 * r[abi.C_SURVIVORS], 1):.1f}")
     nrows = 2.0 * r[abi.C_SURVIVORS]
     for i, n in k2.items():
         print(f"{n:22s} {float(st[i]) / nrows:10.0f} cycles/read")
