@@ -84,14 +84,17 @@ template <int NS, bool RECS> __global__ void __launch_bounds__(64, NS <= 3 ? 2 :
 __global__ void __launch_bounds__(256) k_mz_insert(MzBuildArgs a) { DevX x{nullptr}; body_mz_insert(x, a); }
 __global__ void __launch_bounds__(256) k_gr_insert(GrBuildArgs a) { DevX x{nullptr}; body_gr_insert(x, a); }
 // the graph walk (dbtk_walk.h): one wave per read (function mode) / per pair (the hot path with threading = 2)
+#ifndef DBTK_WALK_WAVES
+#define DBTK_WALK_WAVES 2  // waves per SIMD the pair kernel is compiled for (register budget 512 / this): 3, 4 and 5 measured no faster
+#endif
 __global__ void __launch_bounds__(64) k_walk_reads(WalkArgs a) {
     __shared__ __attribute__((aligned(16))) WalkSmem sm;
     DevX x{&sm};
     body_walk_reads(x, a);
 }
-__global__ void __launch_bounds__(64) k_walk_pairs(WalkArgs a) {
-    __shared__ __attribute__((aligned(16))) WalkSmem sm;
-    DevX x{&sm};
+__global__ void __launch_bounds__(64, DBTK_WALK_WAVES) k_walk_pairs(WalkArgs a) {
+    __shared__ __attribute__((aligned(16))) WalkSmem sm[2];  // one set of arrays per mate
+    DevX x{sm};
     body_walk_pairs(x, a);
 }
 
@@ -695,6 +698,9 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         w.walk_dst = c->d_walk; w.walk_ret = c->d_walk + npairs;
         w.counts = a.counts; w.counters = a.counters; w.ctr_rep = c->d_ctr;
         w.trecs = walk_trecs; w.errflag = c->d_small + 3;
+#ifdef DBTK_STAMPS
+        w.dbg = reinterpret_cast<uint64_t*>(c->d_small + 32);
+#endif
         if (walk_aln) {
             // a record holds, per mate, cg.es and cg.tr: the read's bases plus what deletions can add (dbtk.h: DBTK_THREAD_CAP)
             const uint32_t acap = std::min<uint32_t>(DBTK_THREAD_CAP, (max_read_len + max_read_len / 4 + 8 + 7) & ~7u);

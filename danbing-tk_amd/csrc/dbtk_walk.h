@@ -114,7 +114,17 @@ struct WalkArgs {
     uint8_t* aln;              // nullptr: none
     uint32_t aln_stride, aln_cap, aln_max;  // bytes per record, entries per packed array, records the buffer holds
     uint32_t* naln;            // slots handed out (in chunks of ALN_CHUNK per wave)
+    uint64_t* dbg;             // diagnostic build only (-DDBTK_STAMPS): per-phase cycle sums
 };
+#ifdef DBTK_STAMPS
+#define W_STAMP_DECL uint64_t wst[8] = {0}; uint64_t wlast = x.clock();
+#define W_STAMP(i) do { const uint64_t now_ = x.clock(); wst[i] += now_ - wlast; wlast = now_; } while (0)
+#define W_STAMP_FLUSH do { if (lane == 0 && a.dbg) for (int i_ = 0; i_ < 8; ++i_) if (wst[i_]) x.atomic_add(&a.dbg[i_], wst[i_]); } while (0)
+#else
+#define W_STAMP_DECL
+#define W_STAMP(i) do { } while (0)
+#define W_STAMP_FLUSH do { } while (0)
+#endif
 constexpr uint32_t ALN_CHUNK = 16;
 DBTK_HD uint8_t aln_pack(uint8_t t, uint8_t g) {  // edit_t (t, g) in one byte: dbtk.h DBTK_ALN_*
     const uint32_t tc = t == '*' ? 0u : t == '=' ? 1u : t == 'X' ? 2u : t == 'D' ? 3u : t == 'I' ? 4u : 7u;
@@ -277,21 +287,58 @@ DBTK_HD_NOINLINE bool walk_ec(X& x, WalkSmem& sm, const DevTables& T, uint32_t l
         default: break;
     }
     uint32_t cnt = 0;
-    for (int j = 0; j < lim2; ++j) {
+    // The nodes a hypothesis visits do not depend on what the graph answers — only how far it gets does.  So: the first
+    // W_PH1 steps of all hypotheses in lockstep (one probe per live lane and step: most hypotheses die there), then every
+    // survivor's remaining steps AT ONCE — lane t rolls the survivor's k-mer t + 1 bases on and probes that node, and
+    // the sequential rule "extend while the next base is in the current next-base set; an existing node replaces the set,
+    // an absent one leaves it" (getNextNucs) becomes a last-present-mask scan over the lanes and one ballot.
+    x.sync();
+    if (lane < 48) { uint8_t b = 4; if (lane < lim2) { const uint64_t vj = V(lane); if (vj != NAN64) b = (uint8_t)(vj % 4); } sm.bases[lane] = b; }
+    x.sync();
+    constexpr int W_PH1 = 3;
+    for (int j = 0; j < lim2 && j < W_PH1; ++j) {
         if (!x.ballot(alive && j < jl)) break;
-        const uint64_t vj = V(j);
+        const uint32_t b = sm.bases[j];
         const bool act = alive && j >= j0 && j < jl;
         if (act) {
-            if (vj == NAN64) alive = false;  // good[j] is false
+            if (b > 3) alive = false;  // good[j] is false
             else {
-                cr = w_roll(cr, rmask, vj % 4);
-                if ((nn >> (cr % 4)) & 1) {
+                cr = w_roll(cr, rmask, b);
+                if ((nn >> b) & 1) {
                     ++cnt;
                     const uint32_t g = w_info(T, locus, cr, k, nullptr);  // getNextNucs: only an existing node replaces the set
                     if (g & GR_HAS) nn = g & 0xFu;
                 } else alive = false;
             }
         }
+    }
+    for (;;) {
+        const uint64_t sv = x.ballot(alive && W_PH1 < jl);
+        if (!sv) break;
+        const int L = (int)__builtin_ctzll(sv);
+        const uint64_t crL = ((uint64_t)x.bcast((uint32_t)(cr >> 32), L) << 32) | x.bcast((uint32_t)cr, L);
+        const uint32_t nnL = x.bcast(nn, L);
+        const int jlL = (int)x.bcast((uint32_t)jl, L);
+        const int j = W_PH1 + lane;  // this lane's step of the survivor
+        bool valid = j < jlL;
+        uint64_t node = crL;
+        if (valid) {
+            for (int q = W_PH1; q <= j; ++q) {
+                const uint32_t b = sm.bases[q];
+                if (b > 3) { valid = false; break; }  // a k-mer without all its bases ends the extension (good[] false)
+                node = w_roll(node, rmask, b);
+            }
+        }
+        uint32_t pm = 0;
+        if (valid) { const uint32_t g = w_info(T, locus, node, k, nullptr); if (g & GR_HAS) pm = 0x10u | (g & 0xFu); }
+        const uint32_t sc = x.wave_scan_lastnz(pm);  // the latest existing node's out-edges at or before this step
+        uint32_t before = x.shfl_up1(sc);
+        if (lane == 0) before = 0;
+        const uint32_t nnb = before ? (before & 0xFu) : nnL;  // the next-base set this step is tested against
+        const bool ok = valid && ((nnb >> (node % 4)) & 1);
+        const uint64_t bad = x.ballot(!ok);
+        const uint32_t adv = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+        if (lane == L) { cnt += adv; alive = false; }
     }
     // get_edit: the strictly best score in scan order; one edit needs >= MSC extended k-mers, two edits >= 2 MSC and mes > 1
     const bool twoed = type == H_2X || type == H_XD || type == H_2D || type == H_XI || type == H_2I;
@@ -350,7 +397,7 @@ DBTK_HD void walk_refresh(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus
 
 // find_anchor, AQ.cpp:878-888
 template <class X>
-DBTK_HD_NOINLINE bool walk_find_anchor(X& x, WalkSmem& sm, uint32_t k, WalkState& S) {
+DBTK_HD bool walk_find_anchor(X& x, WalkSmem& sm, uint32_t k, WalkState& S) {
     const int lane = x.lane();
     for (;;) {
         const int p = S.ki + lane;
@@ -610,34 +657,54 @@ DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm, const DevTables& T,
     *pki = ki;
 }
 
-// One read through isThreadFeasible.  The read's arrays must be in sm (walk_load).  Returns ret (wave-uniform).
+// isThreadFeasible in full (the read's arrays in sm, the state initialised): from its beginning (phase 0), or picking the main
+// loop up at S.ki (phase 1) where walk_read's inlined common path met its first event.  A separate function: the common path
+// (anchor at the first k-mer, runs of matches to the end) then stays small enough to live in registers — anything this
+// routine spills goes to scratch memory, behind the flood of graph look-ups the kernel keeps in flight.
 template <class X>
-DBTK_HD int walk_read(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_t& P, uint32_t locus, int len, WalkState& S) {
+DBTK_HD_NOINLINE int walk_slow(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_t& P, uint32_t locus, int len, WalkState& S, int phase) {
     const int lane = x.lane();
     const uint32_t k = T.ksize;
     const uint64_t rmask = (1ull << 2 * (k - 1)) - 1;
     const bool correction = P.correction != 0;
     const uint64_t maxc = P.maxncorrection;
-    S.ki = 0; S.ni = 0; S.nkm = len - (int)k + 1; S.nes = len; S.ntr = S.nkm; S.nskip = 0; S.ncorr = 0; S.flags = 0;
-    const uint64_t nkmers = (uint64_t)S.nkm;  // frozen (AQ.cpp:1126)
+    const uint64_t nkmers = (uint64_t)(len - (int)k + 1);  // frozen (AQ.cpp:1126)
     const uint64_t maxnskip = nkmers >= P.thread_cth ? nkmers - P.thread_cth : 0;
 
+    // The walk's state lives in registers.  The rare, large pieces (error correction, the k-mer / CIGAR surgery) are separate
+    // functions so that the common path stays small; they get a COPY of the state: a reference would pin S in scratch memory
+    // and turn every `S.ki += run` of the common path into a load and a store.
     auto find_anchor = [&]() { return walk_find_anchor(x, sm, k, S); };
-    auto edit_forward = [&](int wid, uint32_t score) { walk_edit_forward(x, sm, T, locus, S, wid, score); };
-    auto edit_backward = [&](int wid, uint32_t score, int* pki, int* onm, int* ond, int* oni) {
-        walk_edit_backward(x, sm, T, locus, S, wid, score, pki, onm, ond, oni);
+    auto edit_forward = [&](int wid, uint32_t score) { WalkState t = S; walk_edit_forward(x, sm, T, locus, t, wid, score); S = t; };
+    // (anchor = -1: the walk's own position S.ki, which the routine moves; else an earlier anchor, handed back)
+    auto edit_backward = [&](int wid, uint32_t score, int anchor, int* onm, int* ond, int* oni) -> int {
+        WalkState t = S;
+        int tki = anchor < 0 ? t.ki : anchor, a = 0, b = 0, c = 0;
+        walk_edit_backward(x, sm, T, locus, t, wid, score, &tki, &a, &b, &c);
+        S = t;
+        if (anchor < 0) S.ki = tki;
+        *onm = a; *ond = b; *oni = c;
+        return tki;
+    };
+    auto ec = [&](bool backward, int ki, uint32_t mes, int* wid, uint32_t* wscore) {
+        int w = 0; uint32_t sc = 0, fl = 0;
+        const bool skip = walk_ec(x, sm, T, locus, backward, ki, S.nkm, mes, &w, &sc, &fl);
+        *wid = w; *wscore = sc; S.flags |= fl;
+        return skip;
     };
 
 #define W_FAIL_CHECK() do { if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) return -1; } while (0)
+    if (phase == 0) {
     if (!find_anchor()) return 0;
     if (S.ki > 0 && correction && S.ncorr < maxc && (uint32_t)S.ki >= W_MSC + 1) {  // leading unaligned kmers: backward first
         const uint32_t mes = (uint32_t)S.ki >= 2 * W_MSC + 2 ? 2 : 1;
         int wid; uint32_t score;
-        const bool skip = walk_ec(x, sm, T, locus, true, S.ki, S.nkm, mes, &wid, &score, &S.flags);
+        const bool skip = ec(true, S.ki, mes, &wid, &score);
         W_FAIL_CHECK();
-        if (!skip) { int a, b, c; edit_backward(wid, score, &S.ki, &a, &b, &c); W_FAIL_CHECK(); }
+        if (!skip) { int a, b, c; (void)edit_backward(wid, score, -1, &a, &b, &c); W_FAIL_CHECK(); }
     }
     ++S.ki; ++S.ni;
+    }
     while (S.ki < S.nkm) {
         // runs of plain matches: k-mer p continues k-mer p - 1 and is one of its successors in the graph
         {
@@ -683,7 +750,7 @@ DBTK_HD int walk_read(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_
         if (correction && S.ncorr < maxc) {
             uint32_t mes = (uint32_t)(S.nkm - S.ki) >= 2 * W_MSC + 2 ? 2 : 1;
             int wid; uint32_t score;
-            bool skip = walk_ec(x, sm, T, locus, false, S.ki, S.nkm, mes, &wid, &score, &S.flags);
+            bool skip = ec(false, S.ki, mes, &wid, &score);
             W_FAIL_CHECK();
             if (!skip) {  // passed forward correction
                 uint8_t et[2], eg[2];
@@ -694,11 +761,11 @@ DBTK_HD int walk_read(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_
             } else {
                 if (!find_anchor()) break;
                 mes = 2;  // always have enough info to make 2 edits
-                skip = walk_ec(x, sm, T, locus, true, S.ki, S.nkm, mes, &wid, &score, &S.flags);
+                skip = ec(true, S.ki, mes, &wid, &score);
                 W_FAIL_CHECK();
                 if (!skip) {  // passed reverse correction
                     int nm, nd, nins;
-                    edit_backward(wid, score, &S.ki, &nm, &nd, &nins);
+                    (void)edit_backward(wid, score, -1, &nm, &nd, &nins);
                     W_FAIL_CHECK();
                     ++S.ncorr;
                     uint64_t ki64 = (uint64_t)S.ki;
@@ -712,11 +779,10 @@ DBTK_HD int walk_read(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_
                         mes = ki1 >= 2 * W_MSC + 2 ? 2 : 1;
                         if (ki1 < W_MSC + 1) break;
                         if (!(sm.gi[ki1] & GR_HAS)) { S.flags |= DBTK_THREAD_F_MISSING_NODE; return -1; }  // assert(g.count(node_))
-                        skip = walk_ec(x, sm, T, locus, true, (int)ki1, S.nkm, mes, &wid, &sc, &S.flags);
+                        skip = ec(true, (int)ki1, mes, &wid, &sc);
                         W_FAIL_CHECK();
                         if (!skip) {
-                            int k1 = (int)ki1;
-                            edit_backward(wid, sc, &k1, &nm, &nd, &nins);
+                            const int k1 = edit_backward(wid, sc, (int)ki1, &nm, &nd, &nins);
                             W_FAIL_CHECK();
                             ki1 = (uint64_t)k1;
                             S.ki += nd - nins;
@@ -747,23 +813,77 @@ DBTK_HD int walk_read(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_
     return (S.nskip <= maxnskip && S.ncorr <= maxc) ? (S.ncorr ? 2 : 1) : 0;
 }
 
-// Read r of the batch into the walk's LDS arrays: k-mers, their graph info at `locus`, cg.init (AQ.cpp:62-67).
-// Returns the read's length, 0 when it is shorter than k or longer than the arrays (flagged).
+// One read through isThreadFeasible.  The read's arrays must be in sm (walk_load).  Returns ret (wave-uniform).
+// Inlined: the common path — the read's first k-mer is a node (find_anchor, AQ.cpp:878-888, stops at once) and every
+// further k-mer continues its predecessor along an edge of the graph (AQ.cpp:1167-1180), 64 positions per ballot.  The
+// first position that is anything else (N, homopolymer, no such edge, ...) hands the walk to walk_slow.
 template <class X>
-DBTK_HD int walk_load(X& x, WalkSmem& sm, const DevTables& T, const uint8_t* seq, uint64_t o0, uint64_t o1, uint32_t locus,
-                      uint32_t* slot, uint64_t* noncak, uint32_t* errflag) {
+DBTK_HD int walk_read(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_t& P, uint32_t locus, int len, WalkState& S) {
     const int lane = x.lane();
     const uint32_t k = T.ksize;
-    uint32_t len = (uint32_t)(o1 - o0);
-    if (len > (uint32_t)MAXL) { if (lane == 0 && errflag) *errflag = DBTK_ERR_READ_TOO_LONG; len = MAXL; }
+    const uint64_t rmask = (1ull << 2 * (k - 1)) - 1;
+    S.ki = 0; S.ni = 0; S.nkm = len - (int)k + 1; S.nes = len; S.ntr = S.nkm; S.nskip = 0; S.ncorr = 0; S.flags = 0;
+    int phase = 0;
+    if (sm.gi[0] & GR_HAS) {  // the anchor is the first k-mer
+        if (lane == 0) sm.tr[0] = (sm.gi[0] & GR_TR) ? '=' : '.';
+        if (lane < (int)k) sm.es_t[lane] = '=';  // (all '*' so far)
+        x.sync();
+        S.ki = 1; S.ni = 1;
+        phase = 1;
+        while (S.ki < S.nkm) {
+            const int p = S.ki + lane;
+            bool ism = false;
+            if (p < S.nkm) {
+                const uint64_t kv = sm.km[p], pv = sm.km[p - 1];
+                const uint32_t g = sm.gi[p - 1];
+                ism = kv != NAN64 && pv != NAN64 && kv != pv && (g & GR_HAS) && ((g >> (kv % 4)) & 1) && kv == w_roll(pv, rmask, kv % 4);
+            }
+            const uint64_t m = x.ballot(ism);
+            const int run = ~m ? __builtin_ctzll(~m) : 64;
+            if (!run) break;
+            if (lane < run) {
+                sm.tr[p] = (sm.gi[p] & GR_TR) ? '=' : '.';
+                sm.es_t[S.ni + (int)k - 1 + lane] = '=';
+            }
+            S.ki += run; S.ni += run;
+        }
+        if (S.ki >= S.nkm) { x.sync(); return 1; }  // nothing skipped, nothing corrected: feasible (AQ.cpp:1259)
+    }
+    WalkState t = S;  // (a copy: S itself stays in registers)
+    const int ret = walk_slow(x, sm, T, P, locus, len, t, phase);
+    S = t;
+    return ret;
+}
+
+// ---- a read into the walk's LDS arrays, in stages so that the pair kernel can keep the memory round trips of the next read
+// (its bytes) and of both mates (their graph look-ups) in flight together:
+//   walk_raw_words   the read's bytes as 4-byte words from its 4-byte-aligned start, two per lane (loads only)
+//   walk_stage       words -> LDS, 2-bit pack + validity, cg.init (AQ.cpp:62-67)
+//   walk_probe_issue the read's non-canonical k-mers (read2kmers keepN, AQ.h:246-271) and the FIRST slot of every k-mer's
+//                    probe sequence in the graph table (loads only: up to four per lane, all in flight)
+//   walk_probe_finish  the look-ups resolved (a look-up rarely needs a second slot) -> k-mers, graph info, counters in LDS
+constexpr int W_R = NKMAX / 64;
+struct WalkProbe {  // what stays in registers while the look-ups are in flight: canonical k-mer and the first slot read
+    uint64_t cn[W_R];
+    GrSlot first[W_R];
+};
+DBTK_HD void walk_raw_words(const uint8_t* seq, uint64_t o0, uint32_t len, int lane, uint32_t w[2]) {
     const uint64_t a0 = o0 & ~3ull;
-    const uint32_t rsh = (uint32_t)(o0 - a0), nw = (rsh + len + 3) >> 2;
+    const uint32_t nw = ((uint32_t)(o0 - a0) + len + 3) >> 2;
+    w[0] = *reinterpret_cast<const uint32_t*>(seq + ((uint32_t)lane < nw ? a0 + 4ull * lane : a0));
+    w[1] = *reinterpret_cast<const uint32_t*>(seq + (64u + lane < nw ? a0 + 4ull * (64 + lane) : a0));
+}
+template <class X>
+DBTK_HD void walk_stage(X& x, WalkSmem& sm, const uint32_t w[2], uint64_t o0, uint32_t len) {
+    const int lane = x.lane();
+    const uint32_t rsh = (uint32_t)(o0 & 3), nw = (rsh + len + 3) >> 2;
     x.sync();
-    for (uint32_t w = lane; w < nw; w += 64) sm.raw[w] = *reinterpret_cast<const uint32_t*>(seq + a0 + 4ull * w);
+    if ((uint32_t)lane < nw) sm.raw[lane] = w[0];
+    if (64u + lane < nw) sm.raw[64 + lane] = w[1];
     if (lane < 4) sm.raw[nw + lane] = 0;
     x.sync();
     if (lane < 16) {
-        uint32_t w[4];
+        uint32_t q4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint32_t v = 0;
@@ -774,36 +894,86 @@ DBTK_HD int walk_load(X& x, WalkSmem& sm, const DevTables& T, const uint8_t* seq
                 const uint32_t left = len - (16 * lane + 4 * q);
                 if (left < 4) v &= (1u << (8 * left)) - 1;
             }
-            w[q] = v;
+            q4[q] = v;
         }
         uint32_t vd;
-        sm.pk[lane] = pack16(w, &vd);
+        sm.pk[lane] = pack16(q4, &vd);
         sm.vd[lane] = (uint16_t)vd;  // bytes past the read are 0 -> invalid
         if (lane < 4) { sm.pk[16 + lane] = 0; sm.vd[16 + lane] = 0; }
     }
-    x.sync();
-    const int nk = len >= k ? (int)(len - k + 1) : 0;
     for (int i = lane; i < (int)len; i += 64) {
         const uint32_t B = rsh + (uint32_t)i;
         sm.es_t[i] = '*';
         sm.es_r[i] = (uint8_t)(sm.raw[B >> 2] >> (8 * (B & 3)));
         sm.es_g[i] = 0;
     }
-    for (int i = lane; i < NKMAX; i += 64) {
-        uint64_t fw = NAN64;
-        uint32_t sl = NAN32, g = 0;
+    x.sync();
+}
+template <class X>
+DBTK_HD void walk_probe_issue(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, uint32_t len, WalkProbe& P, uint64_t* noncak) {
+    const int lane = x.lane();
+    const uint32_t k = T.ksize;
+    const int nk = len >= k ? (int)(len - k + 1) : 0;
+#pragma unroll
+    for (int r = 0; r < W_R; ++r) {
+        const int i = 64 * r + lane;
+        uint64_t fw = NAN64, idx = 0;
+        P.cn[r] = NAN64;
         if (i < nk) {
             uint64_t f;
             if (window_kmer(sm.pk, sm.vd, (uint32_t)i, k, &f, nullptr) != NAN64) fw = f;
-            g = w_info(T, locus, fw, k, &sl);
             sm.km[i] = fw;
-            sm.gi[i] = (uint16_t)g;
             sm.tr[i] = '*';
             if (noncak) noncak[i] = fw;
         }
-        if (slot) slot[i] = sl;
+        if (fw != NAN64) {
+            const uint64_t rc = revcomp2(fw, k);
+            P.cn[r] = fw <= rc ? fw : rc;
+            idx = hash_cls(P.cn[r], locus, T.gr_shift);
+        }
+        P.first[r] = T.gr[idx];  // (a position without a k-mer reads slot 0 and ignores it)
+    }
+}
+template <class X>
+DBTK_HD void walk_probe_finish(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, uint32_t len, const WalkProbe& P, uint32_t* slot) {
+    const int lane = x.lane();
+    const uint32_t k = T.ksize;
+    const int nk = len >= k ? (int)(len - k + 1) : 0;
+#pragma unroll
+    for (int r = 0; r < W_R; ++r) {
+        const int i = 64 * r + lane;
+        uint32_t info = 0;
+        if (P.cn[r] != NAN64) {
+            GrSlot sl = P.first[r];
+            uint64_t j = hash_cls(P.cn[r], locus, T.gr_shift);
+            for (;;) {
+                if (sl.kmer == P.cn[r] && (uint32_t)(sl.li >> 32) == locus) { info = (uint32_t)sl.li; break; }
+                if (sl.kmer == NAN64) break;
+                j = (j + 1) & T.gr_mask;
+                sl = T.gr[j];
+            }
+        }
+        if (i < nk) {
+            const bool isf = sm.km[i] == P.cn[r];  // the k-mer as read is its canonical form
+            const uint32_t a = info & 0x1Fu, b = (info >> GR_OPP) & 0x1Fu;
+            sm.gi[i] = (uint16_t)((isf ? (a | (b << GR_OPP)) : (b | (a << GR_OPP))) | (info & GR_TR));
+        }
+        if (slot) slot[i] = (info & GR_TR) ? T.trbeg[locus] + (info >> GR_SLOT_SHIFT) : NAN32;
     }
     x.sync();
+}
+// All stages for one read (function mode).  Returns the read's length (clamped to the arrays, flagged).
+template <class X>
+DBTK_HD int walk_load(X& x, WalkSmem& sm, const DevTables& T, const uint8_t* seq, uint64_t o0, uint64_t o1, uint32_t locus,
+                      uint32_t* slot, uint64_t* noncak, uint32_t* errflag) {
+    uint32_t len = (uint32_t)(o1 - o0);
+    if (len > (uint32_t)MAXL) { if (x.lane() == 0 && errflag) *errflag = DBTK_ERR_READ_TOO_LONG; len = MAXL; }
+    uint32_t w[2];
+    walk_raw_words(seq, o0, len, x.lane(), w);
+    walk_stage(x, sm, w, o0, len);
+    WalkProbe P;
+    walk_probe_issue(x, sm, T, locus, len, P, noncak);
+    walk_probe_finish(x, sm, T, locus, len, P, slot);
     return (int)len;
 }
 
@@ -872,67 +1042,129 @@ DBTK_HD void body_walk_reads(X& x, const WalkArgs& a) {
 // the reads' k-mers added to trKmers, i.e. one increment per position); else destLocus = nloci.
 template <class X>
 DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
-    WalkSmem& sm = *x.template smem<WalkSmem>();
+    WalkSmem* const smm = x.template smem<WalkSmem>();  // one set of arrays per mate
     const int lane = x.lane();
     uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
     const uint32_t nsurv = *a.nsurv;
+    if (nsurv == 0) return;  // (the clamped prefetches below read entry 0 of the survivor list)
+    const uint32_t S_ = x.nblocks();
     uint64_t c_feas = 0, c_inc = 0;
     uint32_t slot_base = 0, slot_used = ALN_CHUNK;  // alignment records: slots are taken ALN_CHUNK at a time (one atomic per chunk)
-    for (uint32_t t = x.bid(); t < nsurv; t += x.nblocks()) {
-        const uint32_t dst = a.walk_dst[t];
-        if (dst == NAN32) continue;
-        const uint32_t pair = a.surv[t];
-        int ret[2];
-        uint8_t* arec = nullptr;
-        if (a.aln) {
-            if (slot_used == ALN_CHUNK) {
-                uint32_t b = 0;
-                if (lane == 0) b = x.atomic_add(a.naln, ALN_CHUNK);
-                slot_base = x.bcast(b, 0);
-                slot_used = 0;
-            }
-            const uint32_t slot = slot_base + slot_used++;
-            if (slot < a.aln_max) arec = a.aln + (size_t)slot * a.aln_stride;
-            else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
-        }
-        for (int m = 0; m < 2; ++m) {
-            const uint64_t o0 = a.off[2 * (uint64_t)pair + m], o1 = a.off[2 * (uint64_t)pair + m + 1];
-            WalkState S;
-            const int len = walk_load(x, sm, a.T, a.seq, o0, o1, dst, sm.slot[m], nullptr, a.errflag);
-            ret[m] = walk_read(x, sm, a.T, a.P, dst, len, S);
-            if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) { ret[m] = 0; if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_FORMAT; }
-            if (a.trecs) walk_store(x, sm, S, ret[m], &a.trecs[2 * (size_t)t + m]);
-            if (arec) walk_store_aln(x, sm, S, ret[m], arec, a.aln_cap, m);
-        }
-        const bool alned = ret[0] || ret[1];
-        if (arec && lane == 0) {  // -a: every walked pair; -ae: only the kept ones (AQ.cpp:2234)
-            dbtk_aln_hdr_t* h = reinterpret_cast<dbtk_aln_hdr_t*>(arec);
-            h->pair = (a.P.aln == 2 && !alned) ? NAN32 : pair;
-            h->dst = alned ? dst : a.T.nloci;
-            h->pad[0] = h->pad[1] = 0;
-        }
-        x.sync();
-        if (alned) {
-            c_feas += 2;
-            for (int m = 0; m < 2; ++m)
-                for (int i = lane; i < NKMAX; i += 64) {
-                    const uint32_t s = sm.slot[m][i];
-                    const bool hit = s != NAN32;
-                    if (hit) x.atomic_add(&a.counts[s], 1ull);
-                    c_inc += (uint64_t)__builtin_popcountll(x.ballot(hit));
+    // A pair's data hangs on a chain of dependent loads: survivor -> (destLocus, pair index) -> the reads' offsets -> their bytes
+    // -> their k-mers' graph look-ups.  What bounds this kernel is round trips per wave, so the chain is software-pipelined
+    // over the wave's items (t, t + S, ...): while item i is walked, the bytes of item i + 1, the offsets of item i + 2 and
+    // the (destLocus, pair) of item i + 3 are in flight; all of these loads are unconditional (clamped indices).
+    auto meta = [&](uint32_t t, uint32_t* dst, uint32_t* pair) {
+        const uint32_t tc = t < nsurv ? t : 0u;
+        const uint32_t d = a.walk_dst[tc];
+        *pair = a.surv[tc];
+        *dst = t < nsurv ? d : NAN32;
+    };
+    auto offs = [&](uint32_t pair, uint64_t o[3]) {
+        o[0] = a.off[2 * (uint64_t)pair]; o[1] = a.off[2 * (uint64_t)pair + 1]; o[2] = a.off[2 * (uint64_t)pair + 2];
+    };
+    auto clampl = [&](uint64_t o0, uint64_t o1) { const uint64_t l = o1 - o0; return (uint32_t)(l > (uint64_t)MAXL ? (uint64_t)MAXL : l); };
+    auto raws = [&](const uint64_t o[3], uint32_t w[2][2]) {
+        walk_raw_words(a.seq, o[0], clampl(o[0], o[1]), lane, w[0]);
+        walk_raw_words(a.seq, o[1], clampl(o[1], o[2]), lane, w[1]);
+    };
+    auto uni64 = [&](uint64_t v) { return ((uint64_t)x.uni((uint32_t)(v >> 32)) << 32) | x.uni((uint32_t)v); };
+    uint32_t tA = x.bid();
+    uint32_t dstA, pairA, dstB, pairB, dstC, pairC, dstD, pairD;
+    uint64_t oA[3], oB[3], oC[3];
+    uint32_t wA[2][2], wB[2][2];
+    meta(tA, &dstA, &pairA); meta(tA + S_, &dstB, &pairB); meta(tA + 2 * S_, &dstC, &pairC);
+    dstA = x.uni(dstA); pairA = x.uni(pairA); dstB = x.uni(dstB); pairB = x.uni(pairB);
+    offs(pairA, oA); offs(pairB, oB);
+    for (int q = 0; q < 3; ++q) { oA[q] = uni64(oA[q]); oB[q] = uni64(oB[q]); }
+    raws(oA, wA);
+    W_STAMP_DECL
+    for (; tA < nsurv; tA += S_) {
+        W_STAMP(7);  // loop tail / pipeline rotation
+        // the next items' loads, before anything of this item is waited for
+        raws(oB, wB);
+        dstC = x.uni(dstC); pairC = x.uni(pairC);
+        offs(pairC, oC);
+        meta(tA + 3 * S_, &dstD, &pairD);
+        const uint32_t t = tA, dst = dstA, pair = pairA;
+        if (dst != NAN32) {
+            int ret[2] = {0, 0};
+            uint8_t* arec = nullptr;
+            if (a.aln) {
+                if (slot_used == ALN_CHUNK) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = x.atomic_add(a.naln, ALN_CHUNK);
+                    slot_base = x.bcast(b, 0);
+                    slot_used = 0;
                 }
+                const uint32_t slot = slot_base + slot_used++;
+                if (slot < a.aln_max) arec = a.aln + (size_t)slot * a.aln_stride;
+                else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
+            }
+            uint32_t len[2];
+            len[0] = (uint32_t)(oA[1] - oA[0]); len[1] = (uint32_t)(oA[2] - oA[1]);
+            for (int m = 0; m < 2; ++m) if (len[m] > (uint32_t)MAXL) { if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_READ_TOO_LONG; len[m] = MAXL; }
+            // both mates: bytes -> LDS -> k-mers, and the graph look-ups of both in flight together
+            WalkProbe P0, P1;
+            W_STAMP(0);  // prefetch issue + record slot
+            walk_stage(x, smm[0], wA[0], oA[0], len[0]);
+            walk_stage(x, smm[1], wA[1], oA[1], len[1]);
+            W_STAMP(1);  // bytes (arrive) -> LDS, pack, cg.init
+            walk_probe_issue(x, smm[0], a.T, dst, len[0], P0, nullptr);
+            walk_probe_issue(x, smm[1], a.T, dst, len[1], P1, nullptr);
+            W_STAMP(2);  // k-mers + first-slot loads issued
+            walk_probe_finish(x, smm[0], a.T, dst, len[0], P0, smm[0].slot[0]);
+            walk_probe_finish(x, smm[1], a.T, dst, len[1], P1, smm[0].slot[1]);
+            W_STAMP(3);  // look-ups resolved -> LDS
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                WalkState S;
+                if (a.P.diag & 1) { ret[m] = 1; S.flags = 0; S.nes = S.ntr = S.nkm = 0; S.ni = 0; S.ki = 0; S.nskip = S.ncorr = 0; }  // diagnostic: no walk
+                else ret[m] = walk_read(x, smm[m], a.T, a.P, dst, (int)len[m], S);
+                if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) { ret[m] = 0; if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_FORMAT; }
+                if (a.trecs) walk_store(x, smm[m], S, ret[m], &a.trecs[2 * (size_t)t + m]);
+                if (arec) walk_store_aln(x, smm[m], S, ret[m], arec, a.aln_cap, m);
+                W_STAMP(4 + m);  // the walk of mate m
+            }
+            const bool alned = ret[0] || ret[1];
+            if (arec && lane == 0) {  // -a: every walked pair; -ae: only the kept ones (AQ.cpp:2234)
+                dbtk_aln_hdr_t* h = reinterpret_cast<dbtk_aln_hdr_t*>(arec);
+                h->pair = (a.P.aln == 2 && !alned) ? NAN32 : pair;
+                h->dst = alned ? dst : a.T.nloci;
+                h->pad[0] = h->pad[1] = 0;
+            }
+            x.sync();
+            if (alned) {
+                c_feas += 2;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    for (int i = lane; i < NKMAX; i += 64) {
+                        const uint32_t s = smm[0].slot[m][i];
+                        const bool hit = s != NAN32;
+                        if (hit && !(a.P.diag & 2)) x.atomic_add(&a.counts[s], 1ull);  // (diagnostic 2: no count atomics)
+                        c_inc += (uint64_t)__builtin_popcountll(x.ballot(hit));
+                    }
+            }
+            if (lane == 0) {
+                a.walk_dst[t] = alned ? dst : a.T.nloci;
+                a.walk_ret[t] = ((uint32_t)ret[0] & 0xFFu) | (((uint32_t)ret[1] & 0xFFu) << 8);
+            }
+            x.sync();
+            W_STAMP(6);  // counting + results
         }
-        if (lane == 0) {
-            a.walk_dst[t] = alned ? dst : a.T.nloci;
-            a.walk_ret[t] = ((uint32_t)ret[0] & 0xFFu) | (((uint32_t)ret[1] & 0xFFu) << 8);
-        }
-        x.sync();
+        // the pipeline moves on
+        dstA = dstB; pairA = pairB;
+        for (int q = 0; q < 3; ++q) { oA[q] = oB[q]; oB[q] = uni64(oC[q]); }
+        for (int m = 0; m < 2; ++m) { wA[m][0] = wB[m][0]; wA[m][1] = wB[m][1]; }
+        dstB = dstC; pairB = pairC;
+        dstC = dstD; pairC = pairD;
     }
     if (a.aln && lane == 0)  // the slots of the last chunk that were not used
         for (; slot_used < ALN_CHUNK; ++slot_used) {
             const uint32_t slot = slot_base + slot_used;
             if (slot < a.aln_max) reinterpret_cast<dbtk_aln_hdr_t*>(a.aln + (size_t)slot * a.aln_stride)->pair = NAN32;
         }
+    W_STAMP_FLUSH;
     if (lane == 0) {
         if (c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], c_feas);
         if (c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], c_inc);

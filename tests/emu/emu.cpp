@@ -711,7 +711,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
             alnraw.assign(amax * g_aln_stride, 0);
             w.aln = alnraw.data(); w.aln_stride = g_aln_stride; w.aln_cap = g_aln_cap; w.aln_max = (uint32_t)amax; w.naln = &naln;
         }
-        run_grid(grid_pair, 64, sizeof(WalkSmem), [&](EmuX& x) { body_walk_pairs(x, w); });
+        run_grid(grid_pair, 64, 2 * sizeof(WalkSmem), [&](EmuX& x) { body_walk_pairs(x, w); });
         if (p->aln) {  // as dbtk_ctx_aln_records: drop the invalid slots, pair order
             std::vector<std::pair<uint32_t, uint32_t>> order;
             for (uint32_t i = 0; i < naln; ++i) {
