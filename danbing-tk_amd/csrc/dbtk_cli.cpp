@@ -20,6 +20,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <sys/types.h>
 #include <time.h>
 #include <zlib.h>
 
@@ -33,6 +35,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -353,17 +356,141 @@ int main(int argc, char* argv[]) {
     std::atomic<uint64_t> po_pairs{0}, po_bases{0}, po_digest{0};
 
     // ---- the batch loop (AQ.cpp:1869-2282) as three overlapped stages: parse + pair | align (one thread per GPU) | write
-    Reader in;
-    in.f = fopen(o.fastxFname.c_str(), "rb");
-    if (!in.f) die_assert("cannot open " + o.fastxFname);
     const uint64_t readsPerBatch = (uint64_t)(300000 * o.readsPerBatchFactor);
     const uint64_t minReadSize = (uint16_t)o.Cthreshold + o.ksize - 1;
     const bool want_recs = o.okam || o.extractFastX;
     const bool fq = o.isFastq;
-    uint64_t nReads = 0;
     time1 = time(nullptr);
     fprintf(stderr, "threads created\n");
     typedef std::unique_ptr<Batch> BatchP;
+    auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
+    const double loop_t0 = now();
+    const unsigned hw = std::max(4u, std::thread::hardware_concurrency());
+    FILE* gzout = nullptr;
+    if (emit_aln && !o.alnGz.empty()) { gzout = fopen(o.alnGz.c_str(), "wb"); if (!gzout) die_assert("cannot create " + o.alnGz); }
+    const int emit_threads = o.emitThreads > 0 ? o.emitThreads : (int)std::max(1u, hw / 2);
+    uint64_t aln_bytes = 0;
+    std::mutex out_m, tot_m;  // stdout / the gzip file (one batch at a time); the totals below
+    uint64_t nReads = 0;
+    double read_busy = 0, cut_busy = 0, pair_busy = 0, gpu_busy = 0, write_busy = 0;  // seconds each stage spent working (not waiting), summed over the shards
+    int nsplit_used = 0;
+    // -a / -ae: writeAlignments (AQ.cpp:1742-1759), `src dst title seq2 seq1 cigar2 annot2 cigar1 annot1`, formatted (and,
+    // with --aln-gz, deflated into independent gzip members) in chunks by a pool of host threads while the GPU threads
+    // are already on the next batches; the chunks leave in record order.
+    auto emit_alignments = [&](const Batch& b) {
+        const uint64_t n = b.naln;
+        if (!n) return;
+        const uint64_t CH = 2048;
+        const uint64_t nch = (n + CH - 1) / CH;
+        std::vector<std::string> chunk(nch);
+        std::atomic<uint64_t> nextc{0};
+        auto work = [&] {
+            char txt[8192];
+            std::string t;
+            for (;;) {
+                const uint64_t c = nextc.fetch_add(1);
+                if (c >= nch) break;
+                t.clear();
+                for (uint64_t i = c * CH; i < std::min(n, (c + 1) * CH); ++i) {
+                    const uint8_t* rec = b.aln.data() + (size_t)i * b.aln_stride;
+                    const dbtk_aln_hdr_t* h = (const dbtk_aln_hdr_t*)rec;
+                    const uint64_t p = h->pair;
+                    t += ".\t";  // srcLocus is -1 outside simulation mode
+                    t += std::to_string((int)h->dst); t += '\t';
+                    t.append(b.tar.data() + b.toff[p], b.toff[p + 1] - b.toff[p]); t += '\t';
+                    t.append((const char*)b.flat.data() + b.off[2 * p + 1], b.off[2 * p + 2] - b.off[2 * p + 1]); t += '\t';
+                    t.append((const char*)b.flat.data() + b.off[2 * p], b.off[2 * p + 1] - b.off[2 * p]); t += '\t';
+                    const size_t l = dbtk_aln_format(rec, b.aln_cap, txt, sizeof txt);
+                    t.append(txt, std::min(l, sizeof txt - 1)); t += '\n';
+                }
+                if (gzout) {  // one gzip member per chunk: `zcat FILE` is the concatenation
+                    z_stream z;
+                    memset(&z, 0, sizeof z);
+                    if (deflateInit2(&z, o.gzLevel, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die_assert("deflateInit2 failed");
+                    std::string gz(deflateBound(&z, t.size()) + 64, '\0');
+                    z.next_in = (Bytef*)t.data(); z.avail_in = (uInt)t.size();
+                    z.next_out = (Bytef*)&gz[0]; z.avail_out = (uInt)gz.size();
+                    if (deflate(&z, Z_FINISH) != Z_STREAM_END) die_assert("deflate failed");
+                    gz.resize(gz.size() - z.avail_out);
+                    deflateEnd(&z);
+                    chunk[c].swap(gz);
+                } else chunk[c] = t;
+            }
+        };
+        const int nt = (int)std::min<uint64_t>(nch, (uint64_t)emit_threads);
+        std::vector<std::thread> th;
+        for (int i = 1; i < nt; ++i) th.emplace_back(work);
+        work();
+        for (auto& x : th) x.join();
+        { std::lock_guard<std::mutex> lk(out_m); for (auto& c : chunk) { fwrite(c.data(), 1, c.size(), gzout ? gzout : stdout); aln_bytes += c.size(); } }
+    };
+    auto emit = [&](const Batch& b) {
+        std::string out;
+        if (emit_aln) emit_alignments(b);
+        auto seq = [&](uint64_t r) { return std::string((const char*)b.flat.data() + b.off[r], b.off[r + 1] - b.off[r]); };
+        auto qual = [&](uint64_t r) { return std::string(b.qar.data() + b.qoff[r], b.qoff[r + 1] - b.qoff[r]); };
+        for (uint64_t i = 0; i < b.nrec; ++i) {
+            const dbtk_pair_rec_t& r = b.recs[i];
+            const uint64_t p = r.pair;
+            if (o.extractFastX) {  // writeExtractedReads, AQ.cpp:1618-1644: mate 2p+1 first, then 2p
+                for (int which = 1; which >= 0; --which) {
+                    out += b.title(p);
+                    if (o.extractFastX != 1) { out += ':'; out += std::to_string(r.dst); }
+                    out += '\n'; out += seq(2 * p + which); out += '\n';
+                    if (fq) { out += "+\n"; out += qual(2 * p + which); out += '\n'; }
+                }
+                continue;
+            }
+            const uint64_t src = o.simmode ? b.src[p] : ~0ull;
+            const bool src_ok = src != nloci && src != ~0ull;
+            if (!(src_ok || r.dst != nloci)) continue;  // AQ.cpp:2169
+            out += (src == ~0ull ? std::string(".") : std::to_string((int)src)); out += '\t';
+            out += std::to_string(r.dst); out += '\t';
+            out += std::to_string(r.dst != r.dst0 ? (int)r.dst0 : -1); out += '\t';
+            out += std::to_string(r.r2.ei - r.r2.si); out += '\t';
+            out += std::to_string(r.r1.ei - r.r1.si); out += '\t';
+            out += "kf:hf:bf:qf:af:rm:qn:qm:si:nt:bs:ti\t";
+            mate_fields(out, r.r2); out += '\t';
+            mate_fields(out, r.r1); out += '\t';
+            out += annot2str(r.r2); out += '\t';
+            out += annot2str(r.r1); out += '\t';
+            out += b.title(p).substr(1); out += '\t';
+            out += seq(2 * p + 1); out += '\t';
+            out += fq ? qual(2 * p + 1) : std::string("."); out += '\t';
+            out += seq(2 * p); out += '\t';
+            out += fq ? qual(2 * p) : std::string("."); out += '\n';
+        }
+        if (!out.empty()) { std::lock_guard<std::mutex> lk(out_m); fwrite(out.data(), 1, out.size(), stdout); }
+        fprintf(stderr, "Batch query in %ld sec. %llu pairs, %llu records\n", b.gpu_sec, (unsigned long long)(b.nreads / 2), (unsigned long long)b.nrec);
+    };
+    // --parse-only: what the pairing stage handed on (pairs, bases, order-independent digest)
+    auto digest_batch = [&](const Batch& b) {
+        const uint64_t npairs = b.nreads / 2;
+        uint64_t dg = 0;
+        auto fnv = [](uint64_t h, const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; for (size_t i = 0; i < n; ++i) { h ^= q[i]; h *= 0x100000001B3ull; } h ^= 0xFF; h *= 0x100000001B3ull; return h; };
+        for (uint64_t pr = 0; pr < npairs; ++pr) {
+            uint64_t hsh = 0xCBF29CE484222325ull;
+            hsh = fnv(hsh, b.tar.data() + b.toff[pr], b.toff[pr + 1] - b.toff[pr]);
+            for (int m = 0; m < 2; ++m) hsh = fnv(hsh, b.flat.data() + b.off[2 * pr + m], b.off[2 * pr + m + 1] - b.off[2 * pr + m]);
+            if (fq) for (int m = 0; m < 2; ++m) hsh = fnv(hsh, b.qar.data() + b.qoff[2 * pr + m], b.qoff[2 * pr + m + 1] - b.qoff[2 * pr + m]);
+            dg += hsh;
+        }
+        po_pairs += npairs; po_bases += b.flat.size(); po_digest += dg;
+    };
+    // Multi-GPU ingest: with --gpus N and a seekable input the file is cut into N byte ranges at record boundaries and every
+    // GPU gets its own reader / splitters / pairing / aligner / writer pipeline over its range (one pipeline feeding N GPUs
+    // left them idle: the kernels take ~100 x less time than the parse).  Mates are paired INSIDE a range; a range's records
+    // that found no partner (mates on either side of a cut, singletons) are collected and paired across ranges at the end,
+    // in range order — for titles that occur at most twice this is exactly the single reader's outcome.
+    struct Left { std::string title, seq, qual; };
+    auto run_shard = [&](const int shard, const int gpu0, const int ngpu_here, const uint64_t lo, const uint64_t hi, std::vector<Left>& leftovers) {
+    Reader in;
+    in.f = fopen(o.fastxFname.c_str(), "rb");
+    if (!in.f) die_assert("cannot open " + o.fastxFname);
+    if (lo && fseeko(in.f, (off_t)lo, SEEK_SET)) die_assert("cannot seek in " + o.fastxFname);
+    uint64_t remaining = hi - lo;  // bytes of this range still to read
+    uint64_t nReads = 0;
+    double read_busy = 0, cut_busy = 0, pair_busy = 0, gpu_busy = 0, write_busy = 0;
     Chan<BatchP> parsed, aligned;
     // written batches go back to the pairing stage with their arrays' capacity (as the input blocks do, below)
     std::mutex bpool_m;
@@ -382,9 +509,6 @@ int main(int argc, char* argv[]) {
         }
         return BatchP(new Batch);
     };
-    auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
-    const double loop_t0 = now();
-    double read_busy = 0, cut_busy = 0, pair_busy = 0, gpu_busy = 0, write_busy = 0;  // seconds each stage spent working (not waiting)
 
     // Stage A — reader, line splitters, on-the-fly mate pairing (AQ.cpp:1918-1976), all overlapped:
     //   A0 (1 thread)  reads the file in large blocks cut at record boundaries (2 lines per FASTA record, 4 per FASTQ: the
@@ -438,8 +562,7 @@ int main(int argc, char* argv[]) {
         }
         return BlockP(new Block);
     };
-    const unsigned hw = std::max(4u, std::thread::hardware_concurrency());
-    const int nsplit = (int)std::min(16u, std::max(2u, hw / 8));
+    const int nsplit = (int)std::min(16u, std::max(2u, hw / 8 / (unsigned)std::max(1, o.ngpus / ngpu_here)));
     raw.cap = split.cap = 2 * (size_t)nsplit;
     const size_t L = fq ? 4 : 2;
     // A0 as two threads, so that the copy out of the page cache and the newline count overlap: `io` freads fixed-size
@@ -455,8 +578,10 @@ int main(int argc, char* argv[]) {
             const double tr = now();
             BlockP b = fresh_block();
             b->data.resize(HEAD + BLK);
-            const size_t n = fread(b->data.data() + HEAD, 1, BLK, in.f);
+            const size_t want = (size_t)std::min<uint64_t>(BLK, remaining);
+            const size_t n = want ? fread(b->data.data() + HEAD, 1, want, in.f) : 0;
             if (n == 0) break;
+            remaining -= n;
             b->base = HEAD; b->len = n;
             read_busy += now() - tr;
             chunks.push(std::move(b));
@@ -667,14 +792,17 @@ int main(int argc, char* argv[]) {
             b->index = index++;
             parsed.push(std::move(b));
         }
+        // what found no partner inside this range goes on to the cross-range pairing
+        if (held) leftovers.push_back(Left{held_title, held_seq, held_qual});
+        for (auto& kv : parked) leftovers.push_back(Left{kv.first, kv.second.first, kv.second.second});
         parsed.close();
     });
 
     // Stage B — one thread per GPU: the batch through the hot path (replaces AQ.cpp:1988-2249)
     std::vector<std::thread> workers;
     std::mutex done_m;
-    int workers_left = o.ngpus;
-    for (int d = 0; d < o.ngpus; ++d)
+    int workers_left = ngpu_here;
+    for (int d = gpu0; d < gpu0 + ngpu_here; ++d)
         workers.emplace_back([&, d] {
             BatchP b;
             std::vector<uint8_t> flatq;
@@ -683,16 +811,7 @@ int main(int argc, char* argv[]) {
                 const double tg = now();
                 const uint64_t npairs = b->nreads / 2;
                 if (o.parseOnly) {
-                    uint64_t dg = 0;
-                    auto fnv = [](uint64_t h, const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; for (size_t i = 0; i < n; ++i) { h ^= q[i]; h *= 0x100000001B3ull; } h ^= 0xFF; h *= 0x100000001B3ull; return h; };
-                    for (uint64_t pr = 0; pr < npairs; ++pr) {
-                        uint64_t hsh = 0xCBF29CE484222325ull;
-                        hsh = fnv(hsh, b->tar.data() + b->toff[pr], b->toff[pr + 1] - b->toff[pr]);
-                        for (int m = 0; m < 2; ++m) hsh = fnv(hsh, b->flat.data() + b->off[2 * pr + m], b->off[2 * pr + m + 1] - b->off[2 * pr + m]);
-                        if (fq) for (int m = 0; m < 2; ++m) hsh = fnv(hsh, b->qar.data() + b->qoff[2 * pr + m], b->qoff[2 * pr + m + 1] - b->qoff[2 * pr + m]);
-                        dg += hsh;
-                    }
-                    po_pairs += npairs; po_bases += b->flat.size(); po_digest += dg;
+                    digest_batch(*b);
                     aligned.push(std::move(b));
                     continue;
                 }
@@ -726,104 +845,11 @@ int main(int argc, char* argv[]) {
         });
 
     // Stage C — critical section B (AQ.cpp:2253-2279): stdout, in batch order
-    FILE* gzout = nullptr;
-    if (emit_aln && !o.alnGz.empty()) { gzout = fopen(o.alnGz.c_str(), "wb"); if (!gzout) die_assert("cannot create " + o.alnGz); }
-    const int emit_threads = o.emitThreads > 0 ? o.emitThreads : (int)std::max(1u, hw / 2);
-    uint64_t aln_bytes = 0;
     {
         std::map<uint64_t, BatchP> waiting;
         uint64_t next = 0;
         std::string out;
         BatchP got;
-        // -a / -ae: writeAlignments (AQ.cpp:1742-1759), `src dst title seq2 seq1 cigar2 annot2 cigar1 annot1`, formatted (and,
-        // with --aln-gz, deflated into independent gzip members) in chunks by a pool of host threads while the GPU threads
-        // are already on the next batches; the chunks leave in record order.
-        auto emit_alignments = [&](const Batch& b) {
-            const uint64_t n = b.naln;
-            if (!n) return;
-            const uint64_t CH = 2048;
-            const uint64_t nch = (n + CH - 1) / CH;
-            std::vector<std::string> chunk(nch);
-            std::atomic<uint64_t> nextc{0};
-            auto work = [&] {
-                char txt[8192];
-                std::string t;
-                for (;;) {
-                    const uint64_t c = nextc.fetch_add(1);
-                    if (c >= nch) break;
-                    t.clear();
-                    for (uint64_t i = c * CH; i < std::min(n, (c + 1) * CH); ++i) {
-                        const uint8_t* rec = b.aln.data() + (size_t)i * b.aln_stride;
-                        const dbtk_aln_hdr_t* h = (const dbtk_aln_hdr_t*)rec;
-                        const uint64_t p = h->pair;
-                        t += ".\t";  // srcLocus is -1 outside simulation mode
-                        t += std::to_string((int)h->dst); t += '\t';
-                        t.append(b.tar.data() + b.toff[p], b.toff[p + 1] - b.toff[p]); t += '\t';
-                        t.append((const char*)b.flat.data() + b.off[2 * p + 1], b.off[2 * p + 2] - b.off[2 * p + 1]); t += '\t';
-                        t.append((const char*)b.flat.data() + b.off[2 * p], b.off[2 * p + 1] - b.off[2 * p]); t += '\t';
-                        const size_t l = dbtk_aln_format(rec, b.aln_cap, txt, sizeof txt);
-                        t.append(txt, std::min(l, sizeof txt - 1)); t += '\n';
-                    }
-                    if (gzout) {  // one gzip member per chunk: `zcat FILE` is the concatenation
-                        z_stream z;
-                        memset(&z, 0, sizeof z);
-                        if (deflateInit2(&z, o.gzLevel, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die_assert("deflateInit2 failed");
-                        std::string gz(deflateBound(&z, t.size()) + 64, '\0');
-                        z.next_in = (Bytef*)t.data(); z.avail_in = (uInt)t.size();
-                        z.next_out = (Bytef*)&gz[0]; z.avail_out = (uInt)gz.size();
-                        if (deflate(&z, Z_FINISH) != Z_STREAM_END) die_assert("deflate failed");
-                        gz.resize(gz.size() - z.avail_out);
-                        deflateEnd(&z);
-                        chunk[c].swap(gz);
-                    } else chunk[c] = t;
-                }
-            };
-            const int nt = (int)std::min<uint64_t>(nch, (uint64_t)emit_threads);
-            std::vector<std::thread> th;
-            for (int i = 1; i < nt; ++i) th.emplace_back(work);
-            work();
-            for (auto& x : th) x.join();
-            for (auto& c : chunk) { fwrite(c.data(), 1, c.size(), gzout ? gzout : stdout); aln_bytes += c.size(); }
-        };
-        auto emit = [&](const Batch& b) {
-            out.clear();
-            if (emit_aln) emit_alignments(b);
-            auto seq = [&](uint64_t r) { return std::string((const char*)b.flat.data() + b.off[r], b.off[r + 1] - b.off[r]); };
-            auto qual = [&](uint64_t r) { return std::string(b.qar.data() + b.qoff[r], b.qoff[r + 1] - b.qoff[r]); };
-            for (uint64_t i = 0; i < b.nrec; ++i) {
-                const dbtk_pair_rec_t& r = b.recs[i];
-                const uint64_t p = r.pair;
-                if (o.extractFastX) {  // writeExtractedReads, AQ.cpp:1618-1644: mate 2p+1 first, then 2p
-                    for (int which = 1; which >= 0; --which) {
-                        out += b.title(p);
-                        if (o.extractFastX != 1) { out += ':'; out += std::to_string(r.dst); }
-                        out += '\n'; out += seq(2 * p + which); out += '\n';
-                        if (fq) { out += "+\n"; out += qual(2 * p + which); out += '\n'; }
-                    }
-                    continue;
-                }
-                const uint64_t src = o.simmode ? b.src[p] : ~0ull;
-                const bool src_ok = src != nloci && src != ~0ull;
-                if (!(src_ok || r.dst != nloci)) continue;  // AQ.cpp:2169
-                out += (src == ~0ull ? std::string(".") : std::to_string((int)src)); out += '\t';
-                out += std::to_string(r.dst); out += '\t';
-                out += std::to_string(r.dst != r.dst0 ? (int)r.dst0 : -1); out += '\t';
-                out += std::to_string(r.r2.ei - r.r2.si); out += '\t';
-                out += std::to_string(r.r1.ei - r.r1.si); out += '\t';
-                out += "kf:hf:bf:qf:af:rm:qn:qm:si:nt:bs:ti\t";
-                mate_fields(out, r.r2); out += '\t';
-                mate_fields(out, r.r1); out += '\t';
-                out += annot2str(r.r2); out += '\t';
-                out += annot2str(r.r1); out += '\t';
-                out += b.title(p).substr(1); out += '\t';
-                out += seq(2 * p + 1); out += '\t';
-                out += fq ? qual(2 * p + 1) : std::string("."); out += '\t';
-                out += seq(2 * p); out += '\t';
-                out += fq ? qual(2 * p) : std::string("."); out += '\n';
-            }
-            if (!out.empty()) fwrite(out.data(), 1, out.size(), stdout);
-            fprintf(stderr, "Batch query in %ld sec. %llu pairs, %llu records\n", b.gpu_sec, (unsigned long long)(b.nreads / 2), (unsigned long long)b.nrec);
-        };
         while (aligned.pop(got)) {
             waiting[got->index] = std::move(got);
             for (auto it = waiting.find(next); it != waiting.end(); it = waiting.find(next)) {
@@ -842,8 +868,106 @@ int main(int argc, char* argv[]) {
     parser.join();
     for (auto& w : workers) w.join();
     fclose(in.f);
+    (void)shard;
+    return std::make_tuple(nReads, read_busy, cut_busy, pair_busy, gpu_busy, write_busy, nsplit);
+    };  // run_shard
+    // the ranges
+    std::vector<uint64_t> cuts{0, ~0ull};
+    {
+        struct stat sb;
+        uint64_t min_size = 64u << 20;  // below this one pipeline is as good
+        if (const char* e = getenv("DBTK_SHARD_MIN")) min_size = strtoull(e, nullptr, 10);  // (tests)
+        if (o.ngpus > 1 && !o.simmode && stat(o.fastxFname.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size > min_size) {
+            const uint64_t size = (uint64_t)sb.st_size;
+            FILE* f = fopen(o.fastxFname.c_str(), "rb");
+            std::vector<uint64_t> c{0};
+            std::vector<char> buf(1 << 20);
+            for (int i = 1; f && i < o.ngpus; ++i) {
+                // the first record start at or after size * i / N: a line that begins with '>' (2-line FASTA: sequence lines never do),
+                // or — FASTQ, where a quality line may begin with '@' — a line beginning with '@' whose second next line begins with '+'
+                uint64_t at = size / o.ngpus * i;
+                if (fseeko(f, (off_t)at, SEEK_SET)) break;
+                const size_t n = fread(buf.data(), 1, buf.size(), f);
+                size_t p = 0, found = n;
+                while (p < n && buf[p] != '\n') ++p;  // skip to the end of the line the cut fell into
+                ++p;
+                while (p < n) {
+                    const char* l1 = (const char*)memchr(buf.data() + p, '\n', n - p);
+                    if (!l1) break;
+                    if (!fq) { if (buf[p] == '>') { found = p; break; } }
+                    else if (buf[p] == '@') {
+                        const char* l2 = (const char*)memchr(l1 + 1, '\n', n - (l1 + 1 - buf.data()));
+                        if (l2 && (size_t)(l2 + 1 - buf.data()) < n && l2[1] == '+') { found = p; break; }
+                    }
+                    p = l1 + 1 - buf.data();
+                }
+                if (found == n) { c.clear(); break; }  // (no record start in sight: lines longer than the window) -> one range
+                c.push_back(at + found);
+            }
+            if (f) fclose(f);
+            if ((int)c.size() == o.ngpus) { c.push_back(size); cuts = c; }
+        }
+    }
+    const int nshards = (int)cuts.size() - 1;
+    std::vector<std::vector<Left>> lefts(nshards);
+    {
+        std::vector<std::thread> shards;
+        auto one = [&](int i) {
+            const auto r = nshards == 1 ? run_shard(0, 0, o.ngpus, 0, ~0ull, lefts[0]) : run_shard(i, i, 1, cuts[i], cuts[i + 1], lefts[i]);
+            std::lock_guard<std::mutex> lk(tot_m);
+            nReads += std::get<0>(r); read_busy += std::get<1>(r); cut_busy += std::get<2>(r); pair_busy += std::get<3>(r);
+            gpu_busy += std::get<4>(r); write_busy += std::get<5>(r); nsplit_used += std::get<6>(r);
+        };
+        for (int i = 1; i < nshards; ++i) shards.emplace_back(one, i);
+        one(0);
+        for (auto& t : shards) t.join();
+    }
+    if (nshards > 1) {
+        // cross-range pairing of what the ranges left over, in range order (the reader's rule: the first record of a title is
+        // parked, the next one with that title completes the pair as seq1), then one last batch on GPU 0
+        std::unordered_map<std::string, std::pair<std::string, std::string>> parked;
+        Batch b;
+        b.off.push_back(0); b.qoff.push_back(0); b.toff.push_back(0);
+        for (auto& lv : lefts)
+            for (auto& r : lv) {
+                auto it = parked.find(r.title);
+                if (it == parked.end()) { parked[r.title] = std::make_pair(r.seq, r.qual); continue; }
+                const std::string s2 = it->second.first, q2 = it->second.second;
+                parked.erase(it);
+                if (r.seq.size() < minReadSize || s2.size() < minReadSize) continue;
+                b.tar.insert(b.tar.end(), r.title.begin(), r.title.end()); b.toff.push_back(b.tar.size());
+                b.add_read(r.seq.data(), r.seq.size(), r.qual.data(), r.qual.size(), fq);
+                b.add_read(s2.data(), s2.size(), q2.data(), q2.size(), fq);
+                b.nreads += 2;
+            }
+        nReads += b.nreads;
+        fprintf(stderr, "cross-range pairing: %llu reads\n", (unsigned long long)b.nreads);
+        if (b.nreads && !o.parseOnly) {
+            const uint64_t npairs = b.nreads / 2;
+            std::vector<uint8_t> flatq;
+            const bool send_qual = use_bait && fq;
+            if (send_qual) {
+                flatq.assign(b.flat.size() + 1, (uint8_t)'!');
+                for (uint64_t r = 0; r < b.nreads; ++r)
+                    memcpy(flatq.data() + b.off[r], b.qar.data() + b.qoff[r], std::min(b.qoff[r + 1] - b.qoff[r], b.off[r + 1] - b.off[r]));
+            }
+            if (want_recs) b.recs.resize(npairs);
+            b.flat.push_back(0);
+            if (dbtk_align_batch(ctx[0], b.flat.data(), b.off.data(), send_qual ? flatq.data() : nullptr, npairs, want_recs ? b.recs.data() : nullptr,
+                                 want_recs ? npairs : 0, &b.nrec)) die_assert(std::string("align: ") + dbtk_last_error());
+            if (emit_aln) {
+                uint64_t n = 0;
+                dbtk_status_t sa = dbtk_ctx_aln_records(ctx[0], nullptr, 0, &n, &b.aln_stride, &b.aln_cap);
+                if (sa == DBTK_ERR_OVERFLOW) { b.aln.resize((size_t)n * b.aln_stride); sa = dbtk_ctx_aln_records(ctx[0], b.aln.data(), b.aln.size(), &n, &b.aln_stride, &b.aln_cap); }
+                if (sa) die_assert(std::string("alignment records: ") + dbtk_last_error());
+                b.naln = n;
+            }
+            emit(b);
+        } else if (b.nreads && o.parseOnly) digest_batch(b);
+    }
     fflush(stdout);
     if (gzout) fclose(gzout);
+    const int nsplit = nsplit_used;
     fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: reading %.2f s, cutting %.2f s, pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads\n",
             now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, read_busy, cut_busy, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit);
 

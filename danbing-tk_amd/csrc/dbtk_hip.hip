@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <deque>
+#include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -132,7 +134,21 @@ struct BinScratch {
     uint32_t* cand = nullptr; uint64_t cand_cap = 0;
 };
 
+// The HBM tables of an RPGG on a device, shared by every context created for that (handle, device): the index and its
+// minimizer-grouped copy, the presence filter, the class table, vv, ... are built by the first context and freed with the
+// last one (two contexts on one GPU used to hold two copies: 26 GB each at release scale).  The optional tables (graph,
+// TR edges, bait) are added by the first context that needs them.
+struct TableShare {
+    int refs = 0;
+    IdxBucket* d_idx = nullptr; uint64_t* d_flt = nullptr; uint64_t flt_words = 0; uint32_t* d_trbeg = nullptr; ClsSlot* d_cls = nullptr;
+    MzBucket* d_mz = nullptr; GrSlot* d_gr = nullptr; uint32_t* d_vv = nullptr; uint8_t* d_qc = nullptr; uint16_t* d_perm = nullptr;
+    ClsSlot* d_tre = nullptr; ClsSlot* d_bait = nullptr;
+    DevTables T;
+    uint32_t consistent = 0;
+};
+
 struct dbtk_ctx {
+    TableShare* share = nullptr;
     const dbtk_rpgg* g = nullptr;
     dbtk_params_t P;
     int device = 0;
@@ -225,17 +241,36 @@ uint64_t pow2_at_least(uint64_t n) {
 }
 uint32_t log2u(uint64_t c) { return 63u - (uint32_t)__builtin_clzll(c); }
 
+std::mutex g_share_m;
+std::map<std::pair<const dbtk_rpgg*, int>, TableShare*> g_shares;
+
+void release_share(dbtk_ctx* c) {
+    std::lock_guard<std::mutex> l(g_share_m);
+    TableShare* sh = c->share;
+    if (!sh) {  // the context never got as far as sharing: the tables (if any) are its own
+        void* own[] = {c->d_flt, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_tre, c->d_bait, c->d_gr, c->d_mz};
+        for (void* p : own) if (p) (void)hipFree(p);
+        return;
+    }
+    if (--sh->refs > 0) return;
+    void* ptrs[] = {sh->d_flt, sh->d_trbeg, sh->d_idx, sh->d_cls, sh->d_vv, sh->d_qc, sh->d_perm, sh->d_tre, sh->d_bait, sh->d_gr, sh->d_mz};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    g_shares.erase(std::make_pair(c->g, c->device));
+    delete sh;
+}
+
 void free_ctx(dbtk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    release_share(c);
     for (int i = 0; i < NKERN; ++i)
         for (int j = 0; j < EVPOOL; ++j) {
             if (c->timed[i].beg[j]) (void)hipEventDestroy(c->timed[i].beg[j]);
             if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
         }
-    void* ptrs[] = {c->d_flt, c->d_ctr, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_accum, c->d_small, c->d_surv,
+    void* ptrs[] = {c->d_ctr, c->d_accum, c->d_small, c->d_surv,
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
-                    c->d_tre, c->d_bait, c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_gr, c->d_walk, c->d_trecs, c->d_loci, c->d_aln, c->d_mz};
+                    c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_walk, c->d_trecs, c->d_loci, c->d_aln};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     std::vector<dbtk_ctx::Lane*> others{&c->alt};
     for (auto& l : c->parked) others.push_back(&l);
@@ -805,8 +840,40 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
             for (int j = 0; j < EVPOOL && !st; ++j)
                 if (hipEventCreate(&c->timed[i].beg[j]) != hipSuccess || hipEventCreate(&c->timed[i].end[j]) != hipSuccess) { set_error("hipEventCreate failed"); st = DBTK_ERR_HIP; }
         if (st) break;
-        if ((st = build_tables(c))) break;
-        if (p->threading == DBTK_THREADING_V13 && (st = build_graph_table(c))) break;  // (only a walking context pays for the graph table)
+        {   // the tables: shared per (handle, device)
+            std::lock_guard<std::mutex> lk(g_share_m);
+            const auto key = std::make_pair(h, device_id);
+            auto it = g_shares.find(key);
+            TableShare* sh = it != g_shares.end() ? it->second : nullptr;
+            auto to_share = [&](TableShare* t) {
+                t->d_idx = c->d_idx; t->d_flt = c->d_flt; t->flt_words = c->flt_words; t->d_trbeg = c->d_trbeg; t->d_cls = c->d_cls; t->d_mz = c->d_mz;
+                t->d_gr = c->d_gr; t->d_vv = c->d_vv; t->d_qc = c->d_qc; t->d_perm = c->d_perm; t->d_tre = c->d_tre; t->d_bait = c->d_bait;
+                t->T = c->T; t->consistent = c->consistent;
+            };
+            if (!sh) {
+                if ((st = build_tables(c))) break;
+                sh = new TableShare;
+                to_share(sh);
+                g_shares[key] = sh;
+            } else {
+                c->d_idx = sh->d_idx; c->d_flt = sh->d_flt; c->flt_words = sh->flt_words; c->d_trbeg = sh->d_trbeg; c->d_cls = sh->d_cls; c->d_mz = sh->d_mz;
+                c->d_gr = sh->d_gr; c->d_vv = sh->d_vv; c->d_qc = sh->d_qc; c->d_perm = sh->d_perm; c->d_tre = sh->d_tre; c->d_bait = sh->d_bait;
+                c->T = sh->T; c->consistent = sh->consistent;
+            }
+            c->share = sh;
+            ++sh->refs;
+            // optional tables, by the first context that needs them (only a walking context pays for the graph table)
+            if (p->threading == DBTK_THREADING_V13 && !c->d_gr) { if ((st = build_graph_table(c))) break; }
+            if (p->bubbles && !c->d_tre) {
+                if ((st = build_kl_table(c, h->tre_cnt, h->tre_ks, nullptr, &c->d_tre, &c->T.tre_mask, &c->T.tre_shift))) break;
+                c->T.tre = c->d_tre;
+            }
+            if (p->bait && !c->d_bait) {
+                if ((st = build_kl_table(c, h->bt_cnt, h->bt_ks, &h->bt_vs, &c->d_bait, &c->T.bait_mask, &c->T.bait_shift))) break;
+                c->T.bait = c->d_bait;
+            }
+            to_share(sh);
+        }
         if (p->trackbait) {
             c->btTK.resize(h->nloci);
             c->baitDB_host.resize(h->nloci);
@@ -815,14 +882,8 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
                 for (uint64_t j = 0; j < h->bt_cnt[l]; ++j, ++i) c->baitDB_host[l][h->bt_ks[i]] = h->bt_vs[i];
         }
         if (p->bubbles) {
-            if ((st = build_kl_table(c, h->tre_cnt, h->tre_ks, nullptr, &c->d_tre, &c->T.tre_mask, &c->T.tre_shift))) break;
-            c->T.tre = c->d_tre;
             c->bubbleDB.resize(h->nloci);
             if (hipMalloc(&c->d_nevents, 4) != hipSuccess) { set_error("hipMalloc nevents"); st = DBTK_ERR_HIP; break; }
-        }
-        if (p->bait) {
-            if ((st = build_kl_table(c, h->bt_cnt, h->bt_ks, &h->bt_vs, &c->d_bait, &c->T.bait_mask, &c->T.bait_shift))) break;
-            c->T.bait = c->d_bait;
         }
         c->ntr = h->out_kmer.size();
         c->n_accum = c->ntr + 2 * h->nloci + DBTK_C_COUNT;

@@ -319,3 +319,45 @@ def test_ingest_pairs_like_the_reference_reader(tmp_path, fastq):
             assert r.returncode == 0, r.stderr.decode()[-1500:]
             got = tuple(int(x) for x in r.stdout.decode().split()[1:])
             assert got == want, (blk, cth, got, want)
+
+
+@pytest.mark.parametrize("fastq", [False, True])
+def test_sharded_ingest_equals_single_reader(tmp_path, fastq):
+    """--gpus N on a seekable file: N byte ranges cut at record boundaries, each with its own reader / pairing pipeline,
+    what a range could not pair is paired across ranges at the end.  The pairs handed to the aligners (titles occurring at
+    most twice: adjacent mates, mates far apart — also across the cuts —, singletons, short reads) are the single reader's."""
+    import numpy as np
+    import refio
+    rng = np.random.default_rng(21 + fastq)
+    mk = lambda n: bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8))
+    q = lambda n: bytes(rng.integers(35, 74, n).astype(np.uint8)) if fastq else b""
+    lead = b"@" if fastq else b">"
+    recs, late = [], []
+    for i in range(3000):
+        t = lead + b"r%d" % i
+        n1, n2 = (int(rng.integers(25, 151)) for _ in range(2))
+        a, b = (t + b"/1", mk(n1), (b"@" + q(n1)[1:]) if fastq and i % 7 == 0 else q(n1)), (t + b"/2", mk(n2), q(n2))  # (some quality lines begin with '@')
+        u = rng.random()
+        if u < 0.7:
+            recs += [a, b]
+        elif u < 0.9:
+            recs.append(a); late.append(b)
+        else:
+            recs.append(a)
+        if len(late) > 300 and rng.random() < 0.05:
+            rng.shuffle(late)
+            recs += late
+            late = []
+    recs += late
+    fn = str(tmp_path / ("reads.fq" if fastq else "reads.fa"))
+    _write_records(fn, recs, fastq)
+    d = os.path.join(GOLDEN, "g1_k21")
+    want = _digest(refio.read_pairs(fn, fastq, 45 + 21 - 1), fastq)
+    for gpus in ("1", "2", "5"):
+        r = run(["--parse-only", "--gpus", gpus, "-k", "21", "-cth", "45", "-fq" if fastq else "-fa", fn, "-qs", "pan", "-o", str(tmp_path / "o")], cwd=d,
+                env=dict(os.environ, DBTK_SHARD_MIN="0"))
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        got = tuple(int(x) for x in r.stdout.decode().split()[1:])
+        assert got == want, (gpus, got, want)
+        if gpus != "1":
+            assert b"cross-range pairing" in r.stderr

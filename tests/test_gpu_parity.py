@@ -409,3 +409,69 @@ def test_device_entry_reports_a_read_longer_than_promised(dbtk, tmp_path):
     ctx.close()
     hip.hipFree(d_seq); hip.hipFree(d_off)
     g.close()
+
+
+def test_contexts_share_device_tables(dbtk, oracle, tmp_path):
+    """Contexts created for the same (RPGG handle, device) share one set of HBM tables (built by the first, freed with the
+    last): a second and third context cost only their accumulators and scratch, and still give the oracle's result — also
+    after the first context has been closed."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+    syn = bind.pkg.Synth(nloci=4000)
+    arrs = syn.arrays()
+    h = C.c_void_p()
+    dbtk._chk(dbtk.L.dbtk_rpgg_from_arrays(C.byref(arrs), C.byref(h)))
+    g = bind.pkg.Rpgg(dbtk, h)
+    p = abi.default_params(ksize=21, cthreshold=45, okam=0)
+    m0 = free_bytes()
+    c1 = dbtk.context(g, p)
+    m1 = free_bytes()
+    c2 = dbtk.context(g, p)
+    c3 = dbtk.context(g, abi.default_params(ksize=21, cthreshold=30, okam=0))
+    m3 = free_bytes()
+    first, extra = m0 - m1, (m1 - m3) / 2
+    assert first > 500e6 and extra < 0.25 * first, (first, extra)   # tables ~1 GB here; a further context: accumulators + vote scratch
+    seq, off = syn.reads(20000, hit_frac=0.5, seed=4)
+    go = oracle.from_arrays(arrs)
+    o = oracle.align(go, p, seq, off, trace=False)
+    c1.close()                                                        # the tables outlive their builder
+    c2.align(seq, off)
+    compare(o, c2.counts(), g.output_order(), g.ntrkmers, 0, recs=False)
+    c2.close(); c3.close()
+    assert free_bytes() >= m0 - 64e6                                 # and go with the last context
+    oracle.free(go)
+    g.close()
+
+
+def test_two_gpu_allreduce_equals_single_gpu(dbtk, oracle):
+    """The one exchange of the path on real hardware: two contexts on two GPUs take halves of the pairs, dbtk_allreduce (RCCL
+    over xGMI) sums their accumulators, and both then hold the single-GPU / oracle result.  Skipped on a 1-GPU box."""
+    hip = C.CDLL("libamdhip64.so")
+    n = C.c_int(0)
+    if hip.hipGetDeviceCount(C.byref(n)) != 0 or n.value < 2:
+        pytest.skip("needs two GPUs")
+    syn = bind.pkg.Synth(nloci=3000)
+    arrs = syn.arrays()
+    h = C.c_void_p()
+    dbtk._chk(dbtk.L.dbtk_rpgg_from_arrays(C.byref(arrs), C.byref(h)))
+    g = bind.pkg.Rpgg(dbtk, h)
+    p = abi.default_params(ksize=21, cthreshold=45, okam=0)
+    npairs = 60000
+    seq, off = syn.reads(npairs, hit_frac=0.5, seed=6)
+    go = oracle.from_arrays(arrs)
+    o = oracle.align(go, p, seq, off, trace=False)
+    ctxs = [dbtk.context(g, p, device=d) for d in range(2)]
+    half = npairs // 2
+    ctxs[0].align(seq[:int(off[2 * half])], off[:2 * half + 1])
+    ctxs[1].align(seq[int(off[2 * half]):], off[2 * half:] - off[2 * half])
+    dbtk.allreduce(ctxs)
+    for c in ctxs:
+        compare(o, c.counts(), g.output_order(), g.ntrkmers, 0, recs=False)
+        c.close()
+    oracle.free(go)
+    g.close()
