@@ -48,23 +48,7 @@ __global__ void __launch_bounds__(64) k_fold_counters(uint64_t* counters, uint64
 __global__ void __launch_bounds__(K1_NT, 4) k_encode_subfilter(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) K1Smem sm;
     DevX x{&sm};
-    body_encode_subfilter<false>(x, a);
-}
-// the encode stage in its binned form: encode + sort the filter queries by partition | filter + exact look-ups | candidates
-__global__ void __launch_bounds__(K1_NT, 4) k_encode_bin(BatchArgs a) {
-    __shared__ __attribute__((aligned(16))) K1BinSmem sm;
-    DevX x{&sm};
-    body_encode_subfilter<true>(x, a);
-}
-__global__ void __launch_bounds__(64) k_filter_bins(BatchArgs a) {
-    __shared__ __attribute__((aligned(16))) FltSmem sm;
-    DevX x{&sm};
-    body_filter_bins(x, a);
-}
-__global__ void __launch_bounds__(64) k_subfilter_cand(BatchArgs a) {
-    __shared__ __attribute__((aligned(16))) CandSmem sm;
-    DevX x{&sm};
-    body_subfilter_cand(x, a);
+    body_encode_subfilter(x, a);
 }
 // K2 / K3 are instantiated per NS = 64-position slots a read needs (2: <= 128 positions, 3: 150 bp reads, 4: up to 256 bp)
 template <int NS> __global__ void __launch_bounds__(64) k_probe(BatchArgs a) {
@@ -114,7 +98,7 @@ namespace {
 // Per-kernel timing: a pool of HIP event pairs recorded on the context's stream
 // around every launch; folded into (total ms, launches) when the pool fills or
 // when the caller asks.
-constexpr int NKERN = 8;       // k_encode_subfilter (the whole encode stage), k_probe, k_pair_usual, k_pair; the three kernels of the binned encode stage; k_walk_pairs
+constexpr int NKERN = 5;       // k_encode_subfilter, k_probe, k_pair_usual, k_pair, k_walk_pairs
 constexpr int EVPOOL = 128;    // launches in flight before a fold
 struct Timed {
     const char* name;
@@ -125,14 +109,6 @@ struct Timed {
 };
 }  // namespace
 
-// per-batch scratch of the binned encode stage (one per lane)
-struct BinScratch {
-    uint64_t* bins = nullptr; uint64_t bins_cap = 0;
-    uint32_t* bincnt = nullptr; uint64_t bincnt_cap = 0;
-    uint64_t* ovf = nullptr; uint64_t ovf_cap = 0;
-    uint32_t* ovf_hdr = nullptr; uint64_t ovf_hdr_cap = 0;
-    uint32_t* cand = nullptr; uint64_t cand_cap = 0;
-};
 
 // The HBM tables of an RPGG on a device, shared by every context created for that (handle, device): the index and its
 // minimizer-grouped copy, the presence filter, the class table, vv, ... are built by the first context and freed with the
@@ -199,9 +175,7 @@ struct dbtk_ctx {
     std::vector<std::unordered_map<uint64_t, uint64_t>> btTK;
     std::vector<std::unordered_map<uint64_t, uint16_t>> baitDB_host;
     std::vector<dbtk_pair_rec_t> own_recs;  // record buffer when the caller passes none but -tb needs the bait-stage records
-    int k1_blocks = 0, k1bin_blocks = 0, flt_wpc = 16, probe_wpc = 32;
-    BinScratch bin;
-    int k1_binned = 0;   // DBTK_K1_BINNED: 0 never, 1 always (where it applies), -1 for batches of >= 65536 pairs
+    int k1_blocks = 0, probe_wpc = 32;
     bool timers_on = true;
     uint32_t timers_every = 1;  // event records around the kernels of every n-th batch (8 records cost ~30 us per batch)
     uint64_t batch_no = 0;
@@ -226,7 +200,6 @@ struct dbtk_ctx {
         uint32_t* d_walk = nullptr; uint64_t walk_cap = 0;
         uint64_t* d_vote = nullptr;
         uint32_t* d_epoch = nullptr;
-        BinScratch bin;
     } alt;
     std::deque<Lane> parked;  // lanes beyond the second (DBTK_LANES > 2): switch_lane goes round all of them
     bool two_lanes = false;   // more than one lane
@@ -274,16 +247,10 @@ void free_ctx(dbtk_ctx* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     std::vector<dbtk_ctx::Lane*> others{&c->alt};
     for (auto& l : c->parked) others.push_back(&l);
-    std::vector<BinScratch*> bins{&c->bin};
     for (dbtk_ctx::Lane* l : others) {
         void* aptrs[] = {l->d_small, l->d_surv, l->d_hitkm, l->d_hitva, l->d_hitnk, l->d_hitoff, l->d_gen, l->d_tickets, l->d_vote, l->d_epoch, l->d_walk};
         for (void* p : aptrs) if (p) (void)hipFree(p);
-        bins.push_back(&l->bin);
         if (l != &c->alt && l->stream) (void)hipStreamDestroy(l->stream);
-    }
-    for (BinScratch* b : bins) {
-        void* bp[] = {b->bins, b->bincnt, b->ovf, b->ovf_hdr, b->cand};
-        for (void* p : bp) if (p) (void)hipFree(p);
     }
     if (c->alt.stream) (void)hipStreamDestroy(c->alt.stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -536,7 +503,6 @@ void switch_lane(dbtk_ctx* c) {
     std::swap(c->d_tickets, c->alt.d_tickets); std::swap(c->tickets_cap, c->alt.tickets_cap);
     std::swap(c->d_walk, c->alt.d_walk); std::swap(c->walk_cap, c->alt.walk_cap);
     std::swap(c->d_vote, c->alt.d_vote); std::swap(c->d_epoch, c->alt.d_epoch);
-    std::swap(c->bin, c->alt.bin);
     if (!c->parked.empty()) {  // round robin: the lane just left goes to the back of the queue, the longest-parked one is next
         c->parked.push_back(c->alt);
         c->alt = c->parked.front();
@@ -564,7 +530,7 @@ dbtk_status_t timed_slot(dbtk_ctx* c, int k, int* slot) {
 // ceil(npairs / SURV_CAP) chunk iterations are enqueued and the kernels of a chunk past the end
 // of the list exit at once; nothing waits for the host.
 constexpr uint64_t SURV_CAP = 1ull << 23;  // at most 51 GB of hit buffers at 150 bp (allocated for the batch size actually seen): one chunk for batches of up to 8 M pairs
-constexpr uint32_t SMALL_WORDS = 64;  // d_small: nsurv, novf (binned encode stage), nrec, errflag (sticky until reported); stamps at +32
+constexpr uint32_t SMALL_WORDS = 64;  // d_small: nsurv, (unused), nrec, errflag (sticky until reported); stamps at +32
 
 dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_off, uint64_t seq_len, uint64_t npairs,
                            uint32_t max_read_len, dbtk_pair_rec_t* d_recs, uint32_t rec_cap, const uint8_t* d_qual = nullptr,
@@ -631,59 +597,11 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     const bool tm = c->timers_on && (c->batch_no++ % c->timers_every) == 0;
     auto rec_beg = [&](int kslot) -> dbtk_status_t { if (!tm) return DBTK_OK; dbtk_status_t r = timed_slot(c, kslot, &e); if (r) return r; HIPCHK(hipEventRecord(c->timed[kslot].beg[e], s)); return DBTK_OK; };
     auto rec_end = [&](int kslot) -> dbtk_status_t { if (tm) HIPCHK(hipEventRecord(c->timed[kslot].end[e], s)); return DBTK_OK; };
-    // The encode stage.  Binned form (see body_filter_bins) where it applies: a presence filter, subfilter on, no trace
-    // records, and a query (mixed k-mer without its partition bits | pair index) fits 64 bits.
-    const uint32_t nfr = (c->P.n_filter + 3) / 4;  // query rounds per tile
-    uint32_t pb = c->T.flt_logw > 18 ? c->T.flt_logw - 18 : 0;  // partitions of 2^18 words = 2 MB: resident in an XCD's 4 MB L2
-    if (const char* ev = getenv("DBTK_K1_PB")) { const int v = atoi(ev); if (v >= 0) pb = (uint32_t)v; }  // (tests)
-    pb = std::min<uint32_t>({pb, (uint32_t)BIN_MAXPB, c->T.flt_logw, 2 * k});
-    bool binned = c->d_flt && c->P.n_filter && c->P.nm_filter && !c->P.trace && c->k1_binned != 0 &&
-                  (c->k1_binned == 1 || npairs >= 65536) && (2 * k - pb) + (64 - (uint32_t)__builtin_clzll(npairs)) <= 64;
-    if (binned) {
-        const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->k1bin_blocks ? ntiles : (uint64_t)c->k1bin_blocks);
-        const uint32_t nparts = 1u << pb;
-        const uint64_t qwave = ((ntiles + g1 - 1) / g1) * 64 * nfr;  // queries one encode wave can emit
-        uint64_t bcap = ((qwave / nparts) * 3 / 2 + 64 + BIN_G - 1) / BIN_G * BIN_G;  // 1.5 x the even share (+ slack): the rest overflows
-        if (const char* ev = getenv("DBTK_K1_BINCAP")) { const long v = atol(ev); if (v >= 0) bcap = (uint64_t)v / BIN_G * BIN_G; }  // (tests: force overflow groups)
-        const uint64_t novfmax = ntiles * 64 * nfr + 64;  // every query overflowing
-        if ((uint64_t)g1 * nparts * bcap >= (1ull << 40)) binned = false;
-        if (binned) {
-            BinScratch& b = c->bin;
-            if ((st = ensure(&b.bins, &b.bins_cap, (uint64_t)g1 * nparts * bcap + BIN_G))) return st;
-            if ((st = ensure(&b.bincnt, &b.bincnt_cap, (uint64_t)g1 * nparts))) return st;
-            if ((st = ensure(&b.ovf, &b.ovf_cap, novfmax))) return st;
-            if ((st = ensure(&b.ovf_hdr, &b.ovf_hdr_cap, novfmax))) return st;
-            if ((st = ensure(&b.cand, &b.cand_cap, (npairs + 31) / 32 + 64))) return st;
-            HIPCHK(hipMemsetAsync(b.cand, 0, ((npairs + 31) / 32) * sizeof(uint32_t), s));
-            a.bins = b.bins; a.bincnt = b.bincnt; a.bin_cap = (uint32_t)bcap; a.bin_pb = pb; a.bin_waves = g1;
-            a.ovf = b.ovf; a.ovf_hdr = b.ovf_hdr; a.novf = c->d_small + 1; a.candbits = b.cand;
-            if (tm)  // slot 0 brackets the three launches: no fold of the event pools may fall in between
-                for (int i : {0, 4, 5, 6})
-                    if (c->timed[i].used == EVPOOL) {
-                        HIPCHK(sync_all(c));
-                        for (int j = 0; j < NKERN; ++j) fold_timer(c->timed[j]);
-                        break;
-                    }
-            if ((st = rec_beg(0))) return st;
-            const int e0 = e;
-            if ((st = rec_beg(4))) return st;
-            hipLaunchKernelGGL(k_encode_bin, dim3(g1), dim3(K1_NT), 0, s, a);
-            if ((st = rec_end(4))) return st;
-            if ((st = rec_beg(5))) return st;
-            hipLaunchKernelGGL(k_filter_bins, dim3(c->num_cu * c->flt_wpc), dim3(64), 0, s, a);
-            if ((st = rec_end(5))) return st;
-            if ((st = rec_beg(6))) return st;
-            hipLaunchKernelGGL(k_subfilter_cand, dim3(c->num_cu * 8), dim3(64), 0, s, a);  // (few waves: each ends with one atomic on the survivor counter)
-            if ((st = rec_end(6))) return st;
-            e = e0;
-            if ((st = rec_end(0))) return st;
-        }
-    }
-    if (!binned) {
-        const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->k1_blocks ? ntiles : (uint64_t)c->k1_blocks);  // resident waves
-        if ((st = rec_beg(0))) return st;
-        hipLaunchKernelGGL(k_encode_subfilter, dim3(g1), dim3(K1_NT), 0, s, a);
-        if ((st = rec_end(0))) return st;
+    {   // the encode stage
+    const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->k1_blocks ? ntiles : (uint64_t)c->k1_blocks);  // resident waves
+    if ((st = rec_beg(0))) return st;
+    hipLaunchKernelGGL(k_encode_subfilter, dim3(g1), dim3(K1_NT), 0, s, a);
+    if ((st = rec_end(0))) return st;
     }
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         a.t0 = (uint32_t)(ch * tcap);
@@ -752,9 +670,9 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             w.aln = c->d_aln; w.aln_stride = c->aln_stride; w.aln_cap = acap; w.aln_max = (uint32_t)std::min<uint64_t>(c->aln_max, 0xFFFFFFFFull);
             w.naln = c->d_small + 4;
         }
-        if (tm) { if ((st = timed_slot(c, 7, &e))) return st; HIPCHK(hipEventRecord(c->timed[7].beg[e], s)); }
+        if (tm) { if ((st = timed_slot(c, 4, &e))) return st; HIPCHK(hipEventRecord(c->timed[4].beg[e], s)); }
         hipLaunchKernelGGL(k_walk_pairs, dim3(c->walk_blocks), dim3(64), 0, s, w);
-        if (tm) HIPCHK(hipEventRecord(c->timed[7].end[e], s));
+        if (tm) HIPCHK(hipEventRecord(c->timed[4].end[e], s));
     }
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, a.counters, c->d_ctr);
     HIPCHK(hipGetLastError());
@@ -796,13 +714,7 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_subfilter, K1_NT, 0) != hipSuccess || nb <= 0) nb = 4;
         if (const char* ev = getenv("DBTK_ENC_WPC")) { const int v = atoi(ev); if (v > 0) nb = v; }  // diagnostic: encode waves per CU (more than resident: several rounds)
         c->k1_blocks = c->num_cu * nb;
-        nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_bin, K1_NT, 0) != hipSuccess || nb <= 0) nb = 4;
-        if (const char* ev = getenv("DBTK_K1_WPC")) { const int v = atoi(ev); if (v > 0 && v < nb) nb = v; }  // diagnostic: encode waves per CU
-        c->k1bin_blocks = c->num_cu * nb;
-        if (const char* ev = getenv("DBTK_K1_BINNED")) c->k1_binned = atoi(ev);
         if (const char* ev = getenv("DBTK_PROBE_WPC")) { const int v = atoi(ev); if (v > 0) c->probe_wpc = v; }  // probe waves per CU
-        if (const char* ev = getenv("DBTK_FLT_WPC")) { const int v = atoi(ev); if (v > 0) c->flt_wpc = v; }  // diagnostic: filter waves per CU
         // resident waves of each resolve-kernel instance (one vote-spill scratch row per resident wave)
         const void* kp[3] = {(const void*)k_pair<2, true>, (const void*)k_pair<3, true>, (const void*)k_pair<4, true>};
         for (int i = 0; i < 3; ++i) {
@@ -826,10 +738,7 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
         c->timed[1].name = "k_probe";
         c->timed[2].name = "k_pair_usual";
         c->timed[3].name = "k_pair";
-        c->timed[4].name = "k_encode_bin";
-        c->timed[5].name = "k_filter_bins";
-        c->timed[6].name = "k_subfilter_cand";
-        c->timed[7].name = "k_walk_pairs";
+        c->timed[4].name = "k_walk_pairs";
         {
             int nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_walk_pairs, 64, 0) != hipSuccess || nb <= 0) nb = 8;

@@ -240,16 +240,6 @@ struct BatchArgs {
     uint32_t* nevents;
     uint32_t events_cap;
     uint32_t t0, tcap;       // K2/K3 work on survivors [t0, min(t0 + tcap, *nsurv)): the hit buffer holds tcap pairs
-    // Binned encode stage (body_encode_subfilter<true> -> body_filter_bins -> body_subfilter_cand): per (encode wave,
-    // filter partition) a segment of bin_cap queries, the number each segment holds, the queries that
-    // found their segment full, and one bit per pair: "a sampled k-mer of mate 1 is in the index".
-    uint64_t* bins;
-    uint32_t* bincnt;
-    uint32_t bin_cap, bin_pb, bin_waves;  // segment capacity (multiple of BIN_G), log2(partitions) <= 6, encode waves
-    uint64_t* ovf;           // queries that found their segment full, and their partitions
-    uint32_t* ovf_hdr;
-    uint32_t* novf;
-    uint32_t* candbits;
     uint32_t* walk_dst;      // threading = 2 (v1.3): per survivor, destLocus of a pair that reaches threading (else left NAN32);
                              // the walk kernel (dbtk_walk.h: body_walk_pairs) takes it from there
     uint32_t vzero;          // always 0: `lane * vzero` makes an address look lane-dependent, so that a load whose value is only
@@ -331,12 +321,6 @@ struct K1Smem {
     uint32_t sbuf[K1_SBF + K1_TP];          // survivors not yet appended to the global list
 };
 
-// The binned form of the stage appends each filter query to the segment of its (wave, partition): the position comes
-// from a counter in the wave's LDS, the 8-byte stores of a segment's current line merge in the XCD's write-back L2.
-constexpr int BIN_G = 16, BIN_MAXPB = 6;  // segments are sized in lines of 16 queries; at most 64 partitions
-struct K1BinSmem : K1Smem {
-    uint32_t tail[64];  // per partition: queries emitted so far
-};
 
 // true iff bases [b, b+len) of the stream contain a run of >= k valid bases
 DBTK_HD bool any_valid_window(const uint16_t* vd, uint32_t b, uint32_t len, uint32_t k) {
@@ -369,10 +353,10 @@ DBTK_HD void load_tail_chunk(const uint8_t* seq, uint64_t seq_len, uint64_t g, u
     for (uint32_t b = 0; b < 16 && g + b < seq_len; ++b) w[b >> 2] |= (uint32_t)seq[g + b] << (8 * (b & 3));
 }
 
-template <bool BIN, class X>
+template <class X>
 DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     uint64_t* const ctr = counters_of(x, a);
-    using SM = typename std::conditional<BIN, K1BinSmem, K1Smem>::type;
+    using SM = K1Smem;
     SM& sm = *x.template smem<SM>();
     const uint32_t lane = (uint32_t)x.lane();
     const uint32_t k = a.P.ksize, NF = a.P.n_filter, NM = a.P.nm_filter;
@@ -423,25 +407,6 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         base = x.bcast(base, 0);
         for (uint32_t i = lane; i < nsb; i += K1_NT) a.surv[base + i] = sm.sbuf[i];
         x.sync();
-    };
-    // ---- binned form
-    const uint32_t nparts = BIN ? 1u << a.bin_pb : 0u;
-    if constexpr (BIN) {
-        sm.tail[lane] = 0;
-        x.sync();
-    }
-    // every lane with `has` appends `rec` to the segment of partition `part` (or, the segment full — skewed input — to the overflow list)
-    auto bin_push = [&](bool has, uint32_t part, uint64_t rec) {
-        if constexpr (BIN) {
-            if (has) {
-                const uint32_t s = x.lds_add(&sm.tail[part], 1u);
-                if (s < a.bin_cap) a.bins[((uint64_t)x.bid() * nparts + part) * a.bin_cap + s] = rec;
-                else {
-                    const uint32_t g = x.atomic_add(a.novf, 1u);
-                    a.ovf[g] = rec; a.ovf_hdr[g] = part;
-                }
-            }
-        }
     };
     const uint64_t stride = x.nblocks();
     uint64_t tile = x.bid();
@@ -533,29 +498,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         DBTK_STAMP(18);  // valid-window test
         // C/D: sampled probes; hm[mate] = hit mask of the sampled positions of my pair (same on its 4 lanes)
         uint32_t hm[2] = {0, 0};
-        if constexpr (BIN) {
-            // the sampled k-mers of mate 1 travel to the filter kernel, sorted by filter partition
-            const uint32_t sh = 2 * k - a.bin_pb;
-            uint32_t bpos = 0, L = 1, S = 0;
-            if (gany) {
-                bpos = sm.rb[2 * grp];
-                L = (uint32_t)sm.rl[2 * grp] - k + 1;
-                S = L / (NF - 1);
-            }
-            for (uint32_t s0 = 0; s0 < NF; s0 += 4) {
-                const uint32_t sidx = s0 + sub;
-                uint64_t km = NAN64;
-                if (gany && sidx < NF) {
-                    const uint32_t pos = (sidx != NF - 1) ? sidx * S : L - 1;
-                    km = clean ? window_kmer_clean(sm.pk, bpos + pos, k) : window_kmer(sm.pk, sm.vd, bpos + pos, k, nullptr, nullptr);
-                }
-#ifdef DBTK_STAMPS
-                if (a.P.diag & 1) km = NAN64;  // diagnostic: no queries
-#endif
-                const uint64_t m = kmix(km & ((1ull << (2 * k)) - 1), k);
-                bin_push(km != NAN64, (uint32_t)(m >> sh), (m & ((1ull << sh) - 1)) | ((uint64_t)(p0 + grp) << sh));
-            }
-        } else if (dosub) {
+        if (dosub) {
             for (int mate = 0; mate < 2; ++mate) {
                 const bool go = gany && (mate == 0 || (uint32_t)__builtin_popcount(hm[0]) >= NM);
                 if (mate == 1 && x.ballot(go) == 0) break;  // nobody's mate 1 passed: the usual case
@@ -627,11 +570,6 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
             if (!gany) {
                 stage = DBTK_STAGE_SHORT;
                 c_short += lead;
-            } else if (BIN) {
-                // provisional: "no sample of mate 1 is in the index" (NF probes, rejected); body_subfilter_cand corrects
-                // the pairs for which the filter kernel finds one
-                if (lead) { c_nhash += NF; c_probe += NF; c_sub += 2; }
-                stage = DBTK_STAGE_SUBFILTER;
             } else if (dosub) {
                 // subfilter's loop (AQ.cpp:176-180) stops at the NM-th hit, at sample p: p+1 probes, ++nhash p times;
                 // without NM hits it runs over all NF samples
@@ -665,10 +603,6 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         DBTK_STAMP(20);  // verdict + survivor append
     }
     if (nsb) flush_survivors();
-    if constexpr (BIN) {
-        x.sync();
-        if (lane < nparts) a.bincnt[(size_t)x.bid() * nparts + lane] = sm.tail[lane] < a.bin_cap ? sm.tail[lane] : a.bin_cap;
-    }
     {
         const int lane = lane_; (void)lane;
         DBTK_STAMP_FLUSH;
@@ -688,196 +622,6 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     }
 }
 
-
-// ------------------------------------------------ K1, binned form: stages 2 and 3 --
-// Why: a sampled k-mer costs one request to the memory system whatever answers it, and the chip completes ~55 G L2-miss
-// requests per second (tools/lat.hip) — 4 filter words per rejected pair were 20 M of the direct kernel's 36 M requests.
-// Sorted by filter partition, the same queries hit a 2 MB slice of the filter that stays in the L2 of the XCD working on
-// it: the encode kernel writes them as coalesced 128-byte lines (1/16 request per query), this kernel streams them back
-// (1/16) and the filter words are L2 hits.  "Maybe" (a few %) goes to the exact table as before.
-//
-// body_filter_bins: blocks b, b+8, b+16, ... share an XCD (MI355X_MICROARCH.md; an affinity, never a correctness
-// assumption), so group b % 8 takes the partitions p = b % 8 (mod 8), one after the other, and the blocks of a group
-// divide a partition's segments among themselves.  Maybes wait in LDS and are looked up 64 at a time.
-struct FltSmem {
-    uint64_t qk[128];
-    uint32_t qp[128];
-};
-constexpr int FLT_U = 4;  // queries per lane in flight
-template <class X>
-DBTK_HD void body_filter_bins(X& x, const BatchArgs& a) {
-    FltSmem& sm = *x.template smem<FltSmem>();
-    const uint32_t lane = (uint32_t)x.lane(), k = a.P.ksize;
-    const uint32_t nparts = 1u << a.bin_pb, sh = 2 * k - a.bin_pb, logw = a.T.flt_logw;
-    const uint64_t lowmask = (1ull << sh) - 1;
-    const uint64_t below = (1ull << lane) - 1;
-    uint32_t nq = 0;  // maybes waiting (wave-uniform)
-    auto drain = [&](bool all) {
-        while (nq >= 64 || (all && nq)) {
-            const uint32_t take = nq < 64 ? nq : 64, at = nq - take + lane;
-            if (lane < take) {
-                const uint32_t pair = sm.qp[at];
-                if (idx_contains(a.T, sm.qk[at])) (void)x.atomic_or32(&a.candbits[pair >> 5], 1u << (pair & 31));
-            }
-            nq -= take;
-            x.sync();
-        }
-    };
-    // FLT_U queries per lane: all the records, then all the filter words, in flight together
-    auto process = [&](const uint64_t* src, const uint32_t* parts, uint32_t cnt, uint32_t j0, uint32_t part) {
-        uint64_t rec[FLT_U], wd[FLT_U], m[FLT_U];
-        bool v[FLT_U];
-#pragma unroll
-        for (int u = 0; u < FLT_U; ++u) {
-            const uint32_t j = j0 + 64u * u + lane;
-            v[u] = j < cnt;
-            rec[u] = src[v[u] ? j : 0];
-        }
-#pragma unroll
-        for (int u = 0; u < FLT_U; ++u) {
-            if (parts) part = parts[v[u] ? j0 + 64u * u + lane : 0];  // (overflow list: a partition per query)
-            m[u] = ((uint64_t)part << sh) | (rec[u] & lowmask);
-            wd[u] = a.T.flt[v[u] ? flt_word(m[u], k, logw) : 0];
-        }
-#pragma unroll
-        for (int u = 0; u < FLT_U; ++u) {
-            const uint64_t fb = flt_bits(m[u]);
-            const bool maybe = v[u] && (wd[u] & fb) == fb;
-            const uint64_t mm = x.ballot(maybe);
-            if (mm) {
-                if (maybe) {
-                    const uint32_t pos = nq + (uint32_t)__builtin_popcountll(mm & below);
-                    sm.qk[pos] = kunmix(m[u], k);
-                    sm.qp[pos] = (uint32_t)(rec[u] >> sh);
-                }
-                nq += (uint32_t)__builtin_popcountll(mm);
-                x.sync();
-                drain(false);
-            }
-        }
-    };
-    const uint32_t ngrp = x.nblocks() >= 8 ? 8u : 1u;
-    const uint32_t g = x.bid() % ngrp, i0 = x.bid() / ngrp, G = (x.nblocks() - g + ngrp - 1) / ngrp;  // blocks of my group
-    for (uint32_t p = g; p < nparts; p += ngrp)
-        for (uint32_t w = i0; w < a.bin_waves; w += G) {
-            const size_t seg = (size_t)w * nparts + p;
-            const uint32_t cnt = x.uni(a.bincnt[seg]);
-            const uint64_t* src = a.bins + seg * a.bin_cap;
-            for (uint32_t j0 = 0; j0 < cnt; j0 += 64u * FLT_U) process(src, nullptr, cnt, j0, p);
-        }
-    {   // queries that found their segment full: any partition, no locality (skewed input only)
-        const uint32_t novf = x.uni(*a.novf);
-        for (uint32_t j0 = x.bid() * 64u * FLT_U; j0 < novf; j0 += x.nblocks() * 64u * FLT_U) process(a.ovf, a.ovf_hdr, novf, j0, 0);
-    }
-    drain(true);
-}
-
-// body_subfilter_cand: the pairs whose bit the filter kernel set (a few %) get subfilter exactly as the reference runs it
-// (AQ.cpp:172-188) — eight lanes per pair, one per (mate, sample), k bytes of the read each — and the counters the encode
-// kernel booked provisionally for them are corrected (64-bit wrap-around adds).
-constexpr int K1C_W = 64;               // bitmap words (of 32 pairs) a wave takes at a time
-constexpr int K1C_LIST = 32 * K1C_W;
-struct CandSmem {
-    uint32_t list[K1C_LIST];
-    uint32_t sbuf[K1_SBF + 8];
-};
-// canonical k-mer of the k bytes at p, NAN64 if one of them is not ACGT
-DBTK_HD uint64_t kmer_of_bytes(const uint8_t* p, uint32_t k) {
-    uint64_t fw = 0;
-    uint32_t bad = 0;
-    for (uint32_t i = 0; i < k; ++i) {
-        const uint32_t c = p[i], code = ((c >> 1) ^ (c >> 2)) & 3;
-        bad |= c ^ ((0x54474341u >> (8 * code)) & 0xFFu);
-        fw = (fw << 2) | code;
-    }
-    if (bad) return NAN64;
-    const uint64_t rc = revcomp2(fw, k);
-    return fw < rc ? fw : rc;
-}
-template <class X>
-DBTK_HD void body_subfilter_cand(X& x, const BatchArgs& a) {
-    uint64_t* const ctr = counters_of(x, a);
-    CandSmem& sm = *x.template smem<CandSmem>();
-    const uint32_t lane = (uint32_t)x.lane();
-    const uint32_t k = a.P.ksize, NF = a.P.n_filter, NM = a.P.nm_filter;
-    const uint64_t below = (1ull << lane) - 1;
-    const uint64_t nwords = (a.npairs + 31) / 32;
-    uint64_t d_nhash = 0, d_probe = 0, d_sub = 0;  // corrections (modulo 2^64)
-    uint32_t c_surv = 0, nsb = 0;
-    auto flush_survivors = [&]() {
-        x.sync();
-        uint32_t base = 0;
-        if (lane == 0) base = x.atomic_add(a.nsurv, nsb);
-        base = x.bcast(base, 0);
-        for (uint32_t i = lane; i < nsb; i += 64) a.surv[base + i] = sm.sbuf[i];
-        x.sync();
-    };
-    for (uint64_t w0 = (uint64_t)x.bid() * K1C_W; w0 < nwords; w0 += (uint64_t)x.nblocks() * K1C_W) {
-        uint32_t word = 0;
-        if (lane < (uint32_t)K1C_W && w0 + lane < nwords) {
-            word = a.candbits[w0 + lane];
-            if (word) a.candbits[w0 + lane] = 0;  // (left clean for the next batch)
-        }
-        const uint32_t cnt = (uint32_t)__builtin_popcount(word);
-        uint32_t at = x.wave_excl_scan(cnt);
-        const uint32_t total = x.bcast(at + cnt, 63);
-        if (total == 0) continue;
-        x.sync();
-        for (uint32_t wd = word; wd; wd &= wd - 1) sm.list[at++] = (uint32_t)((w0 + lane) * 32) + (uint32_t)__builtin_ctz(wd);
-        x.sync();
-        for (uint32_t b = 0; b < total; b += 8) {
-            const uint32_t slot = b + (lane >> 3), mate = (lane >> 2) & 1, sub = lane & 3;
-            const bool valid = slot < total;
-            const uint32_t pair = valid ? sm.list[slot] : 0u;
-            const uint64_t o0 = a.off[2 * (uint64_t)pair + mate], o1 = a.off[2 * (uint64_t)pair + mate + 1];
-            const uint32_t L = (uint32_t)(o1 - o0) - k + 1, S = L / (NF - 1);  // (every candidate has a window in both mates)
-            uint32_t hm[2] = {0, 0};
-            for (uint32_t s0 = 0; s0 < NF; s0 += 4) {
-                const uint32_t sidx = s0 + sub;
-                bool hit = false;
-                if (valid && sidx < NF) {
-                    const uint32_t pos = (sidx != NF - 1) ? sidx * S : L - 1;
-                    const uint64_t km = kmer_of_bytes(a.seq + o0 + pos, k);
-                    hit = km != NAN64 && idx_contains(a.T, km);
-                }
-                const uint32_t h8 = (uint32_t)(x.ballot(hit) >> (lane & ~7u)) & 0xFFu;
-                hm[0] |= (h8 & 15u) << s0;
-                hm[1] |= (h8 >> 4) << s0;
-            }
-            // the verdict of body_encode_subfilter, minus what was booked there: NF, NF, 2
-            const bool lead = valid && (lane & 7) == 0;
-            uint32_t nhash = 0, nprobe = 0;
-            bool rej = false;
-            for (int mt = 0; mt < 2 && !rej; ++mt) {
-                uint32_t r = hm[mt];
-                for (uint32_t i = 1; i < NM; ++i) r &= r - 1;
-                const uint32_t pth = r ? (uint32_t)__builtin_ctz(r) : NF;
-                nhash += pth; nprobe += r ? pth + 1 : NF;
-                rej = r == 0;
-            }
-            if (lead) { d_nhash += (uint64_t)nhash - NF; d_probe += (uint64_t)nprobe - NF; d_sub -= rej ? 0 : 2; }
-            const bool pass = lead && !rej;
-            const uint64_t pm = x.ballot(pass);
-            if (pm) {
-                if (pass) { sm.sbuf[nsb + (uint32_t)__builtin_popcountll(pm & below)] = pair; ++c_surv; }
-                nsb += (uint32_t)__builtin_popcountll(pm);
-                if (nsb >= (uint32_t)K1_SBF) { flush_survivors(); nsb = 0; }
-            }
-        }
-        x.sync();
-    }
-    if (nsb) flush_survivors();
-    // wave sums of the corrections (two 32-bit halves each), one atomic each
-    auto sum64 = [&](uint64_t v) { return (uint64_t)x.wave_sum((uint32_t)(v & 0xFFFFF)) + ((uint64_t)x.wave_sum((uint32_t)((v >> 20) & 0xFFFFF)) << 20) + ((uint64_t)x.wave_sum((uint32_t)(v >> 40)) << 40); };
-    const uint64_t s_nhash = sum64(d_nhash), s_probe = sum64(d_probe), s_sub = sum64(d_sub);
-    const uint32_t s_surv = x.wave_sum(c_surv);
-    if (lane == 0) {
-        if (s_nhash) x.atomic_add(&ctr[DBTK_C_NHASH0], s_nhash);
-        if (s_probe) x.atomic_add(&ctr[DBTK_C_ALGO_PROBES], s_probe);
-        if (s_sub) x.atomic_add(&ctr[DBTK_C_SUBFILTERED], s_sub);
-        if (s_surv) x.atomic_add(&ctr[DBTK_C_SURVIVORS], (uint64_t)s_surv);
-    }
-}
 
 // ================================================================= K2 .. K4 =
 // One wavefront (64-thread block) per surviving pair.

@@ -395,8 +395,6 @@ class Emu(pkg._HostSide):
         L.emu_selftest_vote.argtypes = [C.c_uint64, C.c_uint64]
         L.emu_selftest_sort.restype = C.c_uint64
         L.emu_selftest_sort.argtypes = [C.c_uint64, C.c_uint64]
-        L.emu_set_binned.restype = None
-        L.emu_set_binned.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]
         L.emu_align_ex.restype = C.c_int
         L.emu_align_ex.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.Params), u8p, u64p, u8p, C.c_uint64, u64p, u64p, u32p, u64p,
                                    C.POINTER(abi.PairRec), C.c_uint64, u64p, C.c_uint32, C.c_uint32, C.POINTER(BubEvent), C.c_uint64,
@@ -465,10 +463,6 @@ class Emu(pkg._HostSide):
         e = events_array(ev, min(nev.value, evcap))
         e = e[np.lexsort((e["pos"], e["mate"], e["pair"]))]
         return dict(counts=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs, events=e)
-
-    def set_binned(self, on, pb=0, cap=64, nflt=8):
-        """Encode stage in its binned form (off by default): 2^pb filter partitions, segments of `cap` queries, `nflt` filter waves."""
-        self.L.emu_set_binned(int(on), pb, cap, nflt)
 
     def consistent(self, tables):
         return int(self.L.emu_tables_consistent(tables))

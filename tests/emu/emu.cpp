@@ -589,12 +589,8 @@ uint64_t emu_walk_results(dbtk_walk_res_t* res, uint32_t* tidx, uint64_t cap) {
     return g_walk_res.size();
 }
 
-// the binned encode stage: off (0), or on with 2^pb filter partitions, segments of `cap` queries and `nflt` filter waves
 static int g_keep_km = 0;  // 1: the k-mers travel from the probe body to the resolve body (the old way)
 void emu_set_keep_km(int on) { g_keep_km = on; }
-static int g_binned = 0;
-static uint32_t g_bin_pb = 0, g_bin_cap = 64, g_bin_nflt = 8;
-void emu_set_binned(int on, uint32_t pb, uint32_t cap, uint32_t nflt) { g_binned = on; g_bin_pb = pb; g_bin_cap = cap / BIN_G * BIN_G; g_bin_nflt = nflt ? nflt : 1; }
 
 int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
               uint64_t npairs, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* counters,
@@ -653,24 +649,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         qmaskbuf.assign((size_t)tcap * 2 * 4 + 1, 0);
         a.qual = (const uint8_t*)qualbuf.data(); a.qmaskbuf = qmaskbuf.data();
     }
-    std::vector<uint32_t> small2(4, 0);
-    const uint32_t pb = std::min<uint32_t>({g_bin_pb, (uint32_t)BIN_MAXPB, a.T.flt_logw, 2 * g->ksize}), nparts = 1u << pb;
-    // (as the device launcher decides: a query = mixed k-mer without its partition bits | pair index must fit 64 bits)
-    if (g_binned && a.T.flt && p->n_filter && p->nm_filter && !p->trace && npairs &&
-        (2 * g->ksize - pb) + (64 - (uint32_t)__builtin_clzll(npairs)) <= 64) {
-        const uint64_t ntiles = (npairs + K1_TP - 1) / K1_TP, nfr = (p->n_filter + 3) / 4;
-        const uint64_t novfmax = ntiles * 64 * nfr + 64;
-        std::vector<uint64_t> bins((size_t)grid_k1 * nparts * g_bin_cap + BIN_G, 0), ovf(novfmax, 0);
-        std::vector<uint32_t> bincnt((size_t)grid_k1 * nparts, 0xFFFFFFFFu), ovf_hdr(novfmax, 0), cand((npairs + 31) / 32 + 1, 0);
-        a.bins = bins.data(); a.bincnt = bincnt.data(); a.bin_cap = g_bin_cap; a.bin_pb = pb; a.bin_waves = grid_k1;
-        a.ovf = ovf.data(); a.ovf_hdr = ovf_hdr.data(); a.novf = &small2[0]; a.candbits = cand.data();
-        run_grid(grid_k1, K1_NT, sizeof(K1BinSmem), [&](EmuX& x) { body_encode_subfilter<true>(x, a); });
-        run_grid(g_bin_nflt, 64, sizeof(FltSmem), [&](EmuX& x) { body_filter_bins(x, a); });
-        run_grid(grid_k1 + 1, 64, sizeof(CandSmem), [&](EmuX& x) { body_subfilter_cand(x, a); });
-        for (uint32_t w : cand) if (w) return -77;  // the candidate bitmap is left clean
-    } else {
-        run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter<false>(x, a); });
-    }
+    run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter(x, a); });
     for (uint32_t t0 = 0; t0 < (uint32_t)(npairs ? npairs : 1); t0 += tcap) {
         a.t0 = t0;
         uint32_t ngen = 0;

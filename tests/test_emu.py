@@ -55,17 +55,6 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
         assert (co2 == b2["counts"]).all()
         assert (a2["kmc"] == b2["kmc"]).all() and (a2["nmapread"] == b2["nmapread"]).all()
         assert (a2["counters"] == b2["counters"]).all(), (a2["counters"], b2["counters"])
-        # the binned encode stage (queries sorted by filter partition -> filter kernel -> candidates): same everything,
-        # with one partition, with overflowing segments, and with 64 partitions and fewer filter waves than XCD groups
-        for pb, cap, nflt in (((0, 4096, 3), (3, 16, 8), (6, 48, 11)) if i == 0 else ((6, 32, 9),)):
-            E.set_binned(1, pb, cap, nflt)
-            try:
-                b3 = E.align(g, T, p2, seq, off, grid_k1=1 + i, grid_pair=3)
-            finally:
-                E.set_binned(0)
-            assert (co2 == b3["counts"]).all()
-            assert (a2["kmc"] == b3["kmc"]).all() and (a2["nmapread"] == b3["nmapread"]).all()
-            assert (a2["counters"] == b3["counters"]).all(), (pb, cap, a2["counters"], b3["counters"])
     E.L.emu_tables_free(T)
     O.free(go)
     g.close()

@@ -341,36 +341,6 @@ def test_survivor_chunks_on_device(dbtk, oracle, tmp_path, monkeypatch):
     g.close()
 
 
-@pytest.mark.parametrize("pb,cap", [("0", "-1"), ("3", "16"), ("6", "-1")])
-@pytest.mark.parametrize("case", ["mixed", "lengths", "kf", "k25"])
-def test_binned_encode_stage_on_device(case, pb, cap, dbtk, oracle, tmp_path, monkeypatch):
-    """The encode stage in its binned form (k_encode_bin -> k_filter_bins -> k_subfilter_cand; batches of >= 65536 pairs
-    take it by default) forced on small batches: one filter partition, segments of 16 queries (everything else goes
-    through the overflow groups), 64 partitions.  Same counts, totals and counters as the oracle; kam records too."""
-    if case not in CASES:
-        pytest.skip("no such case")
-    monkeypatch.setenv("DBTK_K1_BINNED", "1")
-    monkeypatch.setenv("DBTK_K1_PB", pb)
-    monkeypatch.setenv("DBTK_K1_BINCAP", cap)
-    c = make_case(case, str(tmp_path))
-    go = oracle.load(c.prefix, c.k, c.qc_file)
-    g = dbtk.load(c.prefix, c.k, c.qc_file)
-    seq, off = c.reads.packed()
-    for kw in c.param_sets:
-        for extra in (dict(okam=0), dict()):
-            p = abi.default_params(ksize=c.k, **dict(kw, **extra))
-            o = oracle.align(go, p, seq, off, trace=False)
-            ctx = dbtk.context(g, p)
-            for _ in range(2):  # twice: the candidate bitmap and the counters of the stage start clean again
-                ctx.align(seq, off)
-            r = ctx.counts()
-            o2 = {k_: (v * 2 if k_ in ("counts_file", "kmc", "nmapread", "counters") else v) for k_, v in o.items()}
-            compare(o2, r, g.output_order(), g.ntrkmers, 0, recs=False)
-            ctx.close()
-    oracle.free(go)
-    g.close()
-
-
 def test_randomised_parity_soak():
     """tools/fuzz_parity.py: random RPGGs (k 17/21/25, shared flanks), read sets (64-250 bp, substitutions, indels, N, chimeras,
     background) and parameters; trace records and counts against the oracle.  (600 seeds were run when this was added.)"""
