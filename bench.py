@@ -41,7 +41,6 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PMC_SUMMARY = "r02_pmc.json"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 KERNEL_SOURCES = ("dbtk_kernels.h", "dbtk_walk.h", "dbtk_tables.h", "dbtk_sort.h", "dbtk_assign.h", "dbtk_devx.h", "dbtk_hip.hip")
 
@@ -137,20 +136,40 @@ def roofline_of(name, table):
                 algorithmic_bytes_per_launch=k["algorithmic_bytes"], avg_ms=k["avg_ms"])
 
 
+def pmc_summary():
+    """The committed PMC summary (profiles/*_pmc.json, tools/profile_round.sh) that was collected for THESE kernel sources."""
+    import glob
+    h = kernel_source_hash()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(fn))
+        except ValueError:
+            continue
+        if d.get("kernel_source_hash") == h:
+            return d, os.path.basename(fn)
+    return None, None
+
+
 def pmc_traffic(kernel, table, ctr_bases_per_launch):
     """HBM bytes per launch from the committed PMC summary — only if it was collected for THESE kernel sources."""
-    fn = os.path.join(ROOT, "profiles", PMC_SUMMARY)
-    if not os.path.exists(fn):
-        return None, None, True
-    d = json.load(open(fn))
-    if d.get("kernel_source_hash") != kernel_source_hash():
+    d, name = pmc_summary()
+    if d is None:
         return None, None, True
     k = d.get("kernels", {}).get(kernel)
     if not k or "FETCH_SIZE_KB" not in k:
         return None, None, True
     # guide's gfx950 correction: a wide coalesced stream is reported at half its bytes; K1's read stream is the only one
     add = 0.5 * ctr_bases_per_launch if kernel == "k_encode_subfilter" else 0.0
-    return k["FETCH_SIZE_KB"] * 1024.0 + add, f"profiles/{PMC_SUMMARY} ({d.get('command', '')})", False
+    return k["FETCH_SIZE_KB"] * 1024.0 + add, f"profiles/{name} ({d.get('command', '')})", False
+
+
+def pmc_mix_traffic(kernel):
+    """HBM bytes of the largest launch of `kernel` in the all-hit mix, from the same summary (None if stale / absent)."""
+    d, _ = pmc_summary()
+    if d is None:
+        return None
+    k = d.get("mix_all_hit", {}).get(kernel)
+    return k["FETCH_SIZE_KB"] * 1024.0 if k and "FETCH_SIZE_KB" in k else None
 
 
 def time_steps(ctx, fn, steps, warmup):
@@ -330,12 +349,16 @@ def main():
 
     # ---- N = 1 extras: further read mixes, end to end, CPU baselines
     mixes, e2e, cpu, parity = None, None, None, None
+    nhit = 0  # pairs of the all-hit FASTA the CLI walk legs read
     if solo and rank == 0:
         mixes = {}
         if do_mixes:
             mp = args.mix_reads // 2
             # all-hit: every pair tiled from a locus (SURVEY 8d mix 1): the probe and resolve kernels carry the step
             ah_seq, ah_off = syn.reads(mp, rlen=rlen, hit_frac=1.0, seed=2, nthreads=nth)
+            if ref_dir and do_walk:
+                nhit = min(mp, 1_000_000)
+                syn.write_fasta(ah_seq, nhit, os.path.join(ref_dir, "reads_hit.fa"), rlen=rlen)
             d_ah = torch.from_numpy(ah_seq).to(dev)
             d_aho = torch.from_numpy(ah_off.view(np.int64)).to(dev)
             torch.cuda.synchronize()
@@ -346,7 +369,8 @@ def main():
             mixes["all_hit"] = dict(workload=f"{2 * mp} reads per step, 100 % of pairs from loci, -k 21 -kf 4 1 -cth 45 -ka",
                                     value=2 * mp * args.mix_steps / dta, unit="reads/s", ms_per_step=dta / args.mix_steps * 1e3,
                                     steps=args.mix_steps, roofline=dict(roofline_of(doma, ta), kernels=ta),
-                                    probe_roofline=roofline_of("k_probe", ta) if "k_probe" in ta else None)
+                                    probe_roofline=dict(roofline_of("k_probe", ta), traffic=pmc_mix_traffic("k_probe"))
+                                    if "k_probe" in ta else None)
             log(f"all-hit mix: {dta / args.mix_steps * 1e3:.3f} ms/step, {mixes['all_hit']['value'] / 1e9:.2f} G reads/s, dominant {doma} "
                 f"{ta[doma]['avg_ms']:.3f} ms = {ta[doma]['gbs']:.0f} GB/s algorithmic")
             if do_walk:
@@ -393,6 +417,25 @@ def main():
                 e2e["cli"] = dict(wall_s=tcli, returncode=r.returncode, reads=2 * nref, batch_loop=ing[0] if ing else None,
                                   note="this repo's danbing-tk on the reference leg's files: RPGG load + HBM tables + parse + pair + align + dump")
                 log(f"CLI end to end: {tcli:.1f}s wall; {ing[0] if ing else ''}")
+                if do_walk and nhit and os.path.exists(os.path.join(ref_dir, "pan.graph.umap")):
+                    # config 5: the walk with and without the -ae emit (records formatted + deflated on host threads while the GPU runs
+                    # on), on an all-hit read file so that every pair is walked and printed
+                    legs = {}
+                    base = [cli, "-k", "21", "-kf", "4", "1", "-cth", "45", "--v13-threading", "-gc", "85", "3", "-fa", "reads_hit.fa", "-qs", "pan", "-o", "cliw"]
+                    for name, extra in (("walk", []), ("walk_ae_gz", ["-ae", "--aln-gz", "cliw.aln.gz"])):
+                        t0 = time.perf_counter()
+                        r = subprocess.run(base + extra, cwd=ref_dir, capture_output=True, text=True)
+                        tw = time.perf_counter() - t0
+                        ing = [l for l in r.stderr.splitlines() if l.startswith("ingest:")]
+                        legs[name] = dict(wall_s=tw, returncode=r.returncode, batch_loop=ing[0] if ing else None)
+                    gz = os.path.join(ref_dir, "cliw.aln.gz")
+                    legs["aln_gz_bytes"] = os.path.getsize(gz) if os.path.exists(gz) else None
+                    legs["reads"] = 2 * nhit
+                    legs["note"] = ("this repo's danbing-tk --v13-threading -gc 85 3 on an all-hit FASTA, without and with -ae --aln-gz: "
+                                    "wall seconds including the RPGG + graph load; the difference is what the emit costs end to end")
+                    e2e["cli_walk_emit"] = legs
+                    log(f"CLI walk: {legs['walk']['wall_s']:.1f}s; with -ae --aln-gz: {legs['walk_ae_gz']['wall_s']:.1f}s "
+                        f"({legs['aln_gz_bytes']} bytes of .aln.gz for {2 * nhit} reads)")
 
         # ---- cpu baselines
         port = None

@@ -350,7 +350,7 @@ void dbtk_synth_graph(void* h, uint32_t nthreads) {
 }
 
 // The RPGG as the files the reference's `danbing-tk` loads (HEAD formats): PREF.tr.kmers (text),
-// PREF.kmers.dbi, PREF.fl.kdb, PREF.tre.kdb (no edges: only -bu reads them) — for bench.py's reference-binary
+// PREF.kmers.dbi, PREF.fl.kdb, PREF.tre.kdb (no edges: only -bu reads them), and PREF.graph.umap once the graph exists — for bench.py's reference-binary
 // baseline, which must see the same RPGG as the GPU.  Returns 0 on success.
 int dbtk_synth_write_files(void* h, const char* prefix) {
     Synth* s = (Synth*)h;
@@ -388,6 +388,22 @@ int dbtk_synth_write_files(void* h, const char* prefix) {
         const uint64_t nl = s->nloci, nk = which ? 0 : s->fl_ks.size();
         const std::vector<uint64_t>& cnt = which ? s->tre_cnt : s->fl_cnt;
         const bool ok = put(f, &nl, 8) && put(f, cnt.data(), nl * 8) && put(f, &nk, 8) && (which || put(f, s->fl_ks.data(), nk * 8));
+        if (fclose(f) || !ok) return -1;
+    }
+    if (!s->gr_cnt.empty()) {  // the graph (after dbtk_synth_graph), in the v1.3 PREF.graph.umap layout: nloci, then per locus n and n x (u64 node, u8 out-edge mask)
+        FILE* f = fopen((pref + ".graph.umap").c_str(), "wb");
+        if (!f) return -1;
+        const uint64_t nl = s->nloci;
+        bool ok = put(f, &nl, 8);
+        std::vector<uint8_t> rec;
+        uint64_t at = 0;
+        for (uint32_t l = 0; l < s->nloci && ok; ++l) {
+            const uint64_t n = s->gr_cnt[l];
+            rec.resize(n * 9);
+            for (uint64_t i = 0; i < n; ++i) { memcpy(&rec[9 * i], &s->gr_ks[at + i], 8); rec[9 * i + 8] = s->gr_ms[at + i]; }
+            at += n;
+            ok = put(f, &n, 8) && put(f, rec.data(), rec.size());
+        }
         if (fclose(f) || !ok) return -1;
     }
     return 0;

@@ -222,3 +222,26 @@ def test_serialize_is_ktools_serialize(lib, tmp_path, shared):
         assert a == b, ext
     with pytest.raises(pkg.DbtkError):
         lib.serialize(str(tmp_path / "nope"))
+
+
+def test_synth_files_load_back(lib, tmp_path):
+    """The workload generator's files (HEAD formats + PREF.graph.umap) load to the arrays it hands out in memory."""
+    pkg = bind.pkg
+    syn = pkg.Synth(nloci=40, k=21, seed=5)
+    syn.graph()
+    a = syn.arrays()
+    syn.write_files(str(tmp_path / "pan"))
+    g = lib.load(str(tmp_path / "pan"), k=21, flags=pkg.abi.LOAD_GRAPH)
+    v = g.view()
+    assert v.nloci == a.nloci and v.nkeys == a.nkeys
+    def arr(p, n, dt):
+        return np.ctypeslib.as_array(p, shape=(n,)).astype(dt).copy() if n else np.zeros(0, dt)
+    for view in (v, a):
+        view._gn = int(arr(view.gr_cnt, view.nloci, np.uint64).sum())
+    assert v._gn == a._gn and v._gn > 0
+    assert np.array_equal(arr(v.gr_cnt, v.nloci, np.uint64), arr(a.gr_cnt, a.nloci, np.uint64))
+    assert np.array_equal(arr(v.gr_ks, v._gn, np.uint64), arr(a.gr_ks, a._gn, np.uint64))
+    assert np.array_equal(arr(v.gr_ms, v._gn, np.uint8), arr(a.gr_ms, a._gn, np.uint8))
+    assert np.array_equal(np.sort(arr(v.keys, v.nkeys, np.uint64)), np.sort(arr(a.keys, a.nkeys, np.uint64)))
+    g.close()
+    syn.close()
