@@ -85,6 +85,27 @@ __global__ void __launch_bounds__(64, DBTK_WALK_WAVES) k_walk_pairs(WalkArgs a) 
 }
 
 // ---------------------------------------------------------------- context --
+// Every kernel launch is checked: a launch-configuration error at once (hipGetLastError is a host-side query) and — in a
+// debug build (-DDBTK_DEBUG_LAUNCH) or with DBTK_SYNC_LAUNCHES=1 in the environment — the kernel's own faults too, by waiting
+// for it, so that an error carries the name of the kernel that raised it instead of surfacing at the next synchronisation.
+#ifndef DBTK_DEBUG_LAUNCH
+#define DBTK_DEBUG_LAUNCH 0
+#endif
+static bool sync_launches() {
+    static const bool v = [] { const char* e = getenv("DBTK_SYNC_LAUNCHES"); return (e && atoi(e) != 0) || DBTK_DEBUG_LAUNCH; }();
+    return v;
+}
+#define LAUNCH(kern, grid, block, stream, ...)                                                        \
+    do {                                                                                              \
+        hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);                                \
+        hipError_t e_ = hipGetLastError();                                                            \
+        if (e_ == hipSuccess && sync_launches()) e_ = hipStreamSynchronize(stream);                   \
+        if (e_ != hipSuccess) {                                                                       \
+            set_error(std::string("kernel " #kern ": ") + hipGetErrorString(e_));                     \
+            return DBTK_ERR_HIP;                                                                      \
+        }                                                                                             \
+    } while (0)
+
 #define HIPCHK(call)                                                                                  \
     do {                                                                                              \
         hipError_t e_ = (call);                                                                       \
@@ -269,7 +290,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     if (const char* e = getenv("DBTK_IDX_SPARSITY")) { const long v = atol(e); if (v >= 2 && v <= 64) sparsity = (uint64_t)v; }
     const uint64_t icap = pow2_at_least(sparsity * nkeys + 8), nbkt = icap / 4;
     HIPCHK(hipMalloc(&c->d_idx, nbkt * sizeof(IdxBucket)));
-    hipLaunchKernelGGL(k_fill_idx, dim3(2048), dim3(256), 0, s, c->d_idx, icap);
+    LAUNCH(k_fill_idx, dim3(2048), dim3(256), s, c->d_idx, icap);
     if (nkeys) {
         uint64_t* dk = nullptr; uint32_t* dv = nullptr;
         HIPCHK(hipMalloc(&dk, nkeys * 8));
@@ -277,7 +298,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         HIPCHK(hipMemcpyAsync(dk, g->keys.data(), nkeys * 8, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(dv, g->vals.data(), nkeys * 4, hipMemcpyHostToDevice, s));
         IdxBuildArgs a{c->d_idx, nbkt - 1, 64 - log2u(nbkt), dk, dv, nkeys};
-        hipLaunchKernelGGL(k_idx_insert, dim3(2048), dim3(256), 0, s, a);
+        LAUNCH(k_idx_insert, dim3(2048), dim3(256), s, a);
         {   // presence filter: DBTK_FILTER_BPK bits per key (default 4, 0 = none), rounded up to a power of two of words
             uint64_t bpk = 4;
             if (const char* e = getenv("DBTK_FILTER_BPK")) { const long v = atol(e); if (v >= 0 && v <= 64) bpk = (uint64_t)v; }
@@ -286,10 +307,10 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
                 HIPCHK(hipMalloc(&c->d_flt, c->flt_words * 8));
                 HIPCHK(hipMemsetAsync(c->d_flt, 0, c->flt_words * 8, s));
                 FltBuildArgs fa{c->d_flt, log2u(c->flt_words), g->ksize, dk, nkeys};
-                hipLaunchKernelGGL(k_flt_insert, dim3(2048), dim3(256), 0, s, fa);
+                LAUNCH(k_flt_insert, dim3(2048), dim3(256), s, fa);
             }
         }
-        hipLaunchKernelGGL(k_idx_finalize, dim3(2048), dim3(256), 0, s, c->d_idx, icap);
+        LAUNCH(k_idx_finalize, dim3(2048), dim3(256), s, c->d_idx, icap);
         HIPCHK(hipStreamSynchronize(s));
         HIPCHK(hipFree(dk));
         HIPCHK(hipFree(dv));
@@ -318,7 +339,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
             HIPCHK(hipMemcpyAsync(dslot, g->out_slot.data(), ntrf * 8, hipMemcpyHostToDevice, s));
             HIPCHK(hipMemcpyAsync(dbeg, beg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
             ClsBuildArgs a{c->d_cls, ccap - 1, 64 - log2u(ccap), dks, dbeg, (uint32_t)nloci, dslot, ntrf, dstats + 2};
-            hipLaunchKernelGGL(k_cls_insert, dim3(2048), dim3(256), 0, s, a);
+            LAUNCH(k_cls_insert, dim3(2048), dim3(256), s, a);
             HIPCHK(hipStreamSynchronize(s));
         }
         for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->fl_cnt[l];
@@ -326,7 +347,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
             HIPCHK(hipMemcpyAsync(dks, g->fl_ks.data(), nfl * 8, hipMemcpyHostToDevice, s));
             HIPCHK(hipMemcpyAsync(dbeg, beg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
             ClsBuildArgs a{c->d_cls, ccap - 1, 64 - log2u(ccap), dks, dbeg, (uint32_t)nloci, nullptr, nfl, dstats + 2};
-            hipLaunchKernelGGL(k_cls_insert, dim3(2048), dim3(256), 0, s, a);
+            LAUNCH(k_cls_insert, dim3(2048), dim3(256), s, a);
             HIPCHK(hipStreamSynchronize(s));
         }
         HIPCHK(hipFree(dks));
@@ -369,7 +390,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     T.consistent = 0;
     {   // class of single-locus k-mers into the index slots + index-vs-sets consistency verdict
         IdxAuxArgs a{c->d_idx, icap, T, dstats};
-        hipLaunchKernelGGL(k_idx_aux, dim3(2048), dim3(256), 0, s, a);
+        LAUNCH(k_idx_aux, dim3(2048), dim3(256), s, a);
         uint64_t st[3] = {0, 0, 0};
         HIPCHK(hipMemcpyAsync(st, dstats, sizeof(st), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -390,7 +411,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
             if (const char* e = getenv("DBTK_MZ_M")) { const int v = atoi(e); if (v >= 4 && v <= 16) m = (uint32_t)v; }
             if (m > g->ksize) m = g->ksize;
             MzBuildArgs a{c->d_idx, icap, c->d_mz, nb - 1, 64 - log2u(nb), g->ksize, m};
-            hipLaunchKernelGGL(k_mz_insert, dim3(2048), dim3(256), 0, s, a);
+            LAUNCH(k_mz_insert, dim3(2048), dim3(256), s, a);
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipGetLastError());
             T.mz = c->d_mz; T.mz_mask = nb - 1; T.mz_shift = 64 - log2u(nb); T.mz_m = m;
@@ -425,7 +446,7 @@ dbtk_status_t build_graph_table(dbtk_ctx* c) {
         HIPCHK(hipMemcpyAsync(dks, g->gr_ks.data(), ngr * 8, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(dms, g->gr_ms.data(), ngr, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(dbeg, beg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_gr_insert, dim3(2048), dim3(256), 0, s, a);
+        LAUNCH(k_gr_insert, dim3(2048), dim3(256), s, a);
         HIPCHK(hipStreamSynchronize(s));
     }
     if (ntrf) {
@@ -434,7 +455,7 @@ dbtk_status_t build_graph_table(dbtk_ctx* c) {
         HIPCHK(hipMemcpyAsync(dslot, g->out_slot.data(), ntrf * 8, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(dbeg, beg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
         a.ms = nullptr; a.outslot = dslot; a.n = ntrf;
-        hipLaunchKernelGGL(k_gr_insert, dim3(2048), dim3(256), 0, s, a);
+        LAUNCH(k_gr_insert, dim3(2048), dim3(256), s, a);
         HIPCHK(hipStreamSynchronize(s));
     }
     HIPCHK(hipGetLastError());
@@ -467,7 +488,7 @@ dbtk_status_t build_kl_table(dbtk_ctx* c, const std::vector<uint64_t>& cnt, cons
     HIPCHK(hipMemcpyAsync(dval, v64.data(), n * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(dbeg, beg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
     ClsBuildArgs a{*out, cap - 1, 64 - log2u(cap), dks, dbeg, (uint32_t)nloci, dval, n, dn};
-    hipLaunchKernelGGL(k_cls_insert, dim3(1024), dim3(256), 0, s, a);
+    LAUNCH(k_cls_insert, dim3(1024), dim3(256), s, a);
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipFree(dks)); HIPCHK(hipFree(dval)); HIPCHK(hipFree(dbeg)); HIPCHK(hipFree(dn));
     return DBTK_OK;
@@ -600,16 +621,16 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     {   // the encode stage
     const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->k1_blocks ? ntiles : (uint64_t)c->k1_blocks);  // resident waves
     if ((st = rec_beg(0))) return st;
-    hipLaunchKernelGGL(k_encode_subfilter, dim3(g1), dim3(K1_NT), 0, s, a);
+    LAUNCH(k_encode_subfilter, dim3(g1), dim3(K1_NT), s, a);
     if ((st = rec_end(0))) return st;
     }
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         a.t0 = (uint32_t)(ch * tcap);
         if (tm) { if ((st = timed_slot(c, 1, &e))) return st; HIPCHK(hipEventRecord(c->timed[1].beg[e], s)); }
         switch (ns) {
-            case 1: case 2: hipLaunchKernelGGL(k_probe<2>, dim3(c->num_cu * c->probe_wpc), dim3(64), 0, s, a); break;
-            case 3: hipLaunchKernelGGL(k_probe<3>, dim3(c->num_cu * c->probe_wpc), dim3(64), 0, s, a); break;
-            default: hipLaunchKernelGGL(k_probe<4>, dim3(c->num_cu * c->probe_wpc), dim3(64), 0, s, a); break;
+            case 1: case 2: LAUNCH(k_probe<2>, dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); break;
+            case 3: LAUNCH(k_probe<3>, dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); break;
+            default: LAUNCH(k_probe<4>, dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); break;
         }
         if (tm) HIPCHK(hipEventRecord(c->timed[1].end[e], s));
         // RECS = false: no record buffer (-ka without -e): record emission is compiled out
@@ -620,26 +641,26 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             const dim3 gu(c->usual_blocks[nsi]);
             if (tm) { if ((st = timed_slot(c, 2, &e))) return st; HIPCHK(hipEventRecord(c->timed[2].beg[e], s)); }
             if (d_recs) {
-                if (nsi == 0) hipLaunchKernelGGL((k_pair_usual<2, true>), gu, dim3(64), 0, s, a);
-                else if (nsi == 1) hipLaunchKernelGGL((k_pair_usual<3, true>), gu, dim3(64), 0, s, a);
-                else hipLaunchKernelGGL((k_pair_usual<4, true>), gu, dim3(64), 0, s, a);
+                if (nsi == 0) LAUNCH((k_pair_usual<2, true>), gu, dim3(64), s, a);
+                else if (nsi == 1) LAUNCH((k_pair_usual<3, true>), gu, dim3(64), s, a);
+                else LAUNCH((k_pair_usual<4, true>), gu, dim3(64), s, a);
             } else {
-                if (nsi == 0) hipLaunchKernelGGL((k_pair_usual<2, false>), gu, dim3(64), 0, s, a);
-                else if (nsi == 1) hipLaunchKernelGGL((k_pair_usual<3, false>), gu, dim3(64), 0, s, a);
-                else hipLaunchKernelGGL((k_pair_usual<4, false>), gu, dim3(64), 0, s, a);
+                if (nsi == 0) LAUNCH((k_pair_usual<2, false>), gu, dim3(64), s, a);
+                else if (nsi == 1) LAUNCH((k_pair_usual<3, false>), gu, dim3(64), s, a);
+                else LAUNCH((k_pair_usual<4, false>), gu, dim3(64), s, a);
             }
             if (tm) HIPCHK(hipEventRecord(c->timed[2].end[e], s));
         }
         if (tm) { if ((st = timed_slot(c, 3, &e))) return st; HIPCHK(hipEventRecord(c->timed[3].beg[e], s)); }
         const dim3 gp(c->pair_blocks[nsi]);
         if (d_recs) {
-            if (nsi == 0) hipLaunchKernelGGL((k_pair<2, true>), gp, dim3(64), 0, s, a);
-            else if (nsi == 1) hipLaunchKernelGGL((k_pair<3, true>), gp, dim3(64), 0, s, a);
-            else hipLaunchKernelGGL((k_pair<4, true>), gp, dim3(64), 0, s, a);
+            if (nsi == 0) LAUNCH((k_pair<2, true>), gp, dim3(64), s, a);
+            else if (nsi == 1) LAUNCH((k_pair<3, true>), gp, dim3(64), s, a);
+            else LAUNCH((k_pair<4, true>), gp, dim3(64), s, a);
         } else {
-            if (nsi == 0) hipLaunchKernelGGL((k_pair<2, false>), gp, dim3(64), 0, s, a);
-            else if (nsi == 1) hipLaunchKernelGGL((k_pair<3, false>), gp, dim3(64), 0, s, a);
-            else hipLaunchKernelGGL((k_pair<4, false>), gp, dim3(64), 0, s, a);
+            if (nsi == 0) LAUNCH((k_pair<2, false>), gp, dim3(64), s, a);
+            else if (nsi == 1) LAUNCH((k_pair<3, false>), gp, dim3(64), s, a);
+            else LAUNCH((k_pair<4, false>), gp, dim3(64), s, a);
         }
         if (tm) HIPCHK(hipEventRecord(c->timed[3].end[e], s));
     }
@@ -671,10 +692,10 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             w.naln = c->d_small + 4;
         }
         if (tm) { if ((st = timed_slot(c, 4, &e))) return st; HIPCHK(hipEventRecord(c->timed[4].beg[e], s)); }
-        hipLaunchKernelGGL(k_walk_pairs, dim3(c->walk_blocks), dim3(64), 0, s, w);
+        LAUNCH(k_walk_pairs, dim3(c->walk_blocks), dim3(64), s, w);
         if (tm) HIPCHK(hipEventRecord(c->timed[4].end[e], s));
     }
-    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, a.counters, c->d_ctr);
+    LAUNCH(k_fold_counters, dim3(1), dim3(64), s, a.counters, c->d_ctr);
     HIPCHK(hipGetLastError());
     return DBTK_OK;
 }
@@ -1016,7 +1037,7 @@ dbtk_status_t dbtk_thread_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_
     w.T = c->T; w.P = c->P; w.seq = c->d_seq; w.off = c->d_off;
     w.read_locus = c->d_loci; w.nreads = (uint32_t)nreads; w.trecs = c->d_trecs; w.errflag = c->d_small + 3;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nreads, (uint64_t)c->walk_blocks);
-    hipLaunchKernelGGL(k_walk_reads, dim3(grid), dim3(64), 0, s, w);
+    LAUNCH(k_walk_reads, dim3(grid), dim3(64), s, w);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(recs, c->d_trecs, nreads * sizeof(dbtk_thread_rec_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

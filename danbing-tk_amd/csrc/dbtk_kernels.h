@@ -1216,17 +1216,28 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         }
         x.sync();
         const uint32_t nk = len >= k ? len - k + 1 : 0;
-        const uint32_t nsl = (nk + 63) >> 6;
-        uint64_t km[NSLOT], hh[NSLOT];
+        // Lane l owns the npl CONSECUTIVE positions l * npl .. l * npl + npl - 1: its windows are shifts of one 32-base word, its
+        // minimizers share all but npl - 1 of their m-mers, and its results are neighbours in the hit buffers.
+        const uint32_t npl = (nk + 63) >> 6;
+        const uint32_t p0 = (uint32_t)lane * npl;
+        const uint32_t m = T.mz ? T.mz_m : 0u, wn = T.mz ? k - m + 1 : 0u;
+        const uint32_t nmm = (T.mz && len >= m) ? len - m + 1 : 0u;  // m-mers of the read (minimizer path)
+        const bool fastw = clean && k + npl - 1 <= 32;  // (m <= 16 < k: the m-mers fit whenever the k-mers do)
+        uint64_t W = 0, RW = 0;  // the 32 bases from p0, and their reverse complement (base t of the window at bits 2t of RW)
+        if (fastw && (p0 < nk || p0 < nmm)) { W = window_fw_clean(sm.pk, p0, 32); RW = revcomp2(W, 32); }
+        const uint64_t kmask = (1ull << (2 * k)) - 1;
+        uint64_t km[NSLOT];
         bool open[NSLOT];
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            const uint32_t i = 64 * s + lane;
-            km[s] = NAN64; hh[s] = 0; open[s] = false;
-            if ((uint32_t)s < nsl && i < nk) {
-                km[s] = clean ? window_kmer_clean(sm.pk, i, k) : window_kmer(sm.pk, sm.vd, i, k, nullptr, nullptr);
-                hh[s] = hash_idx(km[s], T.idx_shift);
-                open[s] = km[s] != NAN64;
+        for (int j = 0; j < NSLOT; ++j) {
+            const uint32_t i = p0 + j;
+            km[j] = NAN64; open[j] = false;
+            if ((uint32_t)j < npl && i < nk) {
+                if (fastw) {
+                    const uint64_t fw = (W >> (2 * (32 - k - j))) & kmask, rc = (RW >> (2 * j)) & kmask;
+                    km[j] = fw < rc ? fw : rc;
+                } else km[j] = clean ? window_kmer_clean(sm.pk, i, k) : window_kmer(sm.pk, sm.vd, i, k, nullptr, nullptr);
+                open[j] = km[j] != NAN64;
             }
         }
         uint64_t* outk = a.hitkm + (size_t)it * a.nkp;
@@ -1236,42 +1247,76 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         uint64_t rvv[NSLOT];  // minimizer path: this lane's own results
         bool pend2[NSLOT];    //                 positions its home bucket could not answer
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) { rvv[s] = (uint64_t)NOHIT; pend2[s] = false; }
+        for (int j = 0; j < NSLOT; ++j) { rvv[j] = (uint64_t)NOHIT; pend2[j] = false; }
         if (T.mz) {
             // ---- look-ups through the minimizer-grouped copy of the index (MzBucket, dbtk_tables.h): one 128-byte bucket per
             // RUN of positions sharing a minimizer instead of one 64-byte bucket per position
-            const uint32_t m = T.mz_m, wn = k - m + 1;
-            const uint32_t nmm = len >= m ? len - m + 1 : 0;
-            for (uint32_t j = lane; j < nmm; j += 64) {  // hashed canonical m-mer at every base position
+            const uint32_t mmask = (uint32_t)((1ull << (2 * m)) - 1);
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) {  // hashed canonical m-mer at the lane's base positions
+                const uint32_t q = p0 + j;
+                if ((uint32_t)j < npl && q < nmm) {
+                    uint32_t hv = 0xFFFFFFFFu;
+                    if (fastw) hv = mmer_hash2((uint32_t)(W >> (2 * (32 - m - j))) & mmask, (uint32_t)(RW >> (2 * j)) & mmask);
+                    else if (clean) hv = mmer_hash(window_fw_clean(sm.pk, q, m), m);
+                    else { uint64_t f, r; if (window_kmer(sm.pk, sm.vd, q, m, &f, &r) != NAN64) hv = mmer_hash(f, m); }
+                    sm.hm[q] = hv;
+                }
+            }
+            for (uint32_t q = 64 * npl + lane; q < nmm; q += 64) {  // (the last wn - 1 m-mers of a read that fills its lanes)
                 uint32_t hv = 0xFFFFFFFFu;
-                if (clean) hv = mmer_hash(window_fw_clean(sm.pk, j, m), m);
-                else { uint64_t f, r; if (window_kmer(sm.pk, sm.vd, j, m, &f, &r) != NAN64) hv = mmer_hash(f, m); }
-                sm.hm[j] = hv;
+                if (clean) hv = mmer_hash(window_fw_clean(sm.pk, q, m), m);
+                else { uint64_t f, r; if (window_kmer(sm.pk, sm.vd, q, m, &f, &r) != NAN64) hv = mmer_hash(f, m); }
+                sm.hm[q] = hv;
             }
             x.sync();
             DBTK_STAMP(16);  // (K2, minimizer path) windows + m-mer hashes
+            // minimizer of position p0 + j = min of hm[p0 + j .. p0 + j + wn): the windows of one lane share hm[p0 + npl - 1 .. p0 + wn)
             uint32_t bk[NSLOT], rid[NSLOT];
-            uint32_t nruns = 0;  // runs so far (wave-uniform)
+            bool st[NSLOT];
+            if (wn >= npl) {
+                uint32_t cm = 0xFFFFFFFFu;  // the shared part
+                if (p0 < nk) for (uint32_t t = npl - 1; t < wn; ++t) { const uint32_t h = sm.hm[p0 + t]; cm = h < cm ? h : cm; }
 #pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                const uint32_t i = 64 * s + lane;
-                bk[s] = 0xFFFFFFFFu; rid[s] = 0;
-                if ((uint32_t)s >= nsl) continue;
-                if (open[s]) {
-                    uint32_t mzv = 0xFFFFFFFFu;
-                    for (uint32_t t = 0; t < wn; ++t) { const uint32_t h = sm.hm[i + t]; mzv = h < mzv ? h : mzv; }
-                    bk[s] = (uint32_t)mz_bucket(mzv, T.mz_shift);
+                for (int j = 0; j < NSLOT; ++j) {
+                    bk[j] = 0xFFFFFFFFu;
+                    if (open[j]) {
+                        uint32_t mzv = cm;
+                        for (uint32_t t = (uint32_t)j; t < npl - 1; ++t) { const uint32_t h = sm.hm[p0 + t]; mzv = h < mzv ? h : mzv; }  // before the shared part
+                        for (uint32_t t = wn; t < wn + j; ++t) { const uint32_t h = sm.hm[p0 + t]; mzv = h < mzv ? h : mzv; }        // after it
+                        bk[j] = (uint32_t)mz_bucket(mzv, T.mz_shift);
+                    }
                 }
-                // a position opens a run when its bucket differs from the previous position's
-                uint32_t prev = x.shfl_up1(bk[s]);
-                if (lane == 0) prev = 0xFFFFFFFFu;
-                if (s > 0) { const uint32_t carry = x.bcast(bk[s - 1], 63); if (lane == 0) prev = carry; }
-                const bool start = open[s] && bk[s] != prev;
-                const uint64_t sb = x.ballot(start);
-                const uint32_t upto = (uint32_t)__builtin_popcountll(sb & ((2ull << lane) - 1));  // starts at lanes <= this one
-                rid[s] = nruns + upto - 1;  // (meaningful for open positions only: an open non-start continues the run before it)
-                if (start) sm.rb[rid[s]] = bk[s];
-                nruns += (uint32_t)__builtin_popcountll(sb);
+            } else {  // (k - m + 1 < npl: nothing shared worth the name)
+#pragma unroll
+                for (int j = 0; j < NSLOT; ++j) {
+                    bk[j] = 0xFFFFFFFFu;
+                    if (open[j]) {
+                        uint32_t mzv = 0xFFFFFFFFu;
+                        for (uint32_t t = 0; t < wn; ++t) { const uint32_t h = sm.hm[p0 + j + t]; mzv = h < mzv ? h : mzv; }
+                        bk[j] = (uint32_t)mz_bucket(mzv, T.mz_shift);
+                    }
+                }
+            }
+            // a position opens a run when its bucket differs from the previous position's
+            uint32_t lastbk = bk[0];
+#pragma unroll
+            for (int j = 1; j < NSLOT; ++j) if ((uint32_t)j < npl) lastbk = bk[j];
+            uint32_t prev = x.shfl_up1(lastbk);
+            if (lane == 0) prev = 0xFFFFFFFFu;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) {
+                st[j] = open[j] && bk[j] != prev;
+                cnt += st[j] ? 1u : 0u;
+                prev = bk[j];
+            }
+            uint32_t r = x.wave_excl_scan(cnt);             // runs opened by the lanes before this one
+            const uint32_t nruns = x.bcast(r + cnt, 63);    // (wave-uniform)
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) {
+                if (st[j]) { sm.rb[r] = bk[j]; ++r; }
+                rid[j] = r - 1;  // (meaningful for open positions only: an open non-start continues the run before it)
             }
             x.sync();
             DBTK_STAMP(17);  // minimizers + runs
@@ -1282,7 +1327,10 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
 #pragma unroll
                 for (int u = 0; u < MZ_RB / 8; ++u) {  // the loads first, all in flight together (a run past the end re-reads bucket 0)
                     const uint32_t run = r0 + 8 * u + fq8;
-                    const uint64_t b = run < nruns ? (uint64_t)sm.rb[run] : 0ull;
+                    uint64_t b = run < nruns ? (uint64_t)sm.rb[run] : 0ull;
+#ifdef DBTK_STAMPS
+                    if (a.P.diag & 128) b &= 511;  // diagnostic: every home bucket in the first 64 KB of the table (cache hits)
+#endif
                     q[u] = reinterpret_cast<const uint4*>(T.mz + b)[part];
                 }
 #pragma unroll
@@ -1292,18 +1340,18 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                 }
                 x.sync();
 #pragma unroll
-                for (int s = 0; s < NSLOT; ++s) {
-                    if (!((uint32_t)s < nsl && open[s] && rid[s] >= r0 && rid[s] < r0 + MZ_RB)) continue;
-                    const uint64_t* kk = sm.stg[rid[s] - r0];
+                for (int j = 0; j < NSLOT; ++j) {
+                    if (!(open[j] && rid[j] >= r0 && rid[j] < r0 + MZ_RB)) continue;
+                    const uint64_t* kk = sm.stg[rid[j] - r0];
                     int hit = -1;
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) if (kk[j] == km[s]) hit = j;
+                    for (int e = 0; e < 7; ++e) if (kk[e] == km[j]) hit = e;
                     const uint64_t k7 = kk[7];
-                    if (k7 != NAN64 && (k7 & ~IDX_OVF) == km[s]) hit = 7;
+                    if (k7 != NAN64 && (k7 & ~IDX_OVF) == km[j]) hit = 7;
                     if (hit >= 0) {
                         const uint32_t* va = reinterpret_cast<const uint32_t*>(kk + 8);
-                        rvv[s] = (uint64_t)va[hit] | ((uint64_t)va[8 + hit] << 32);
-                    } else if (k7 != NAN64 && (k7 & IDX_OVF)) pend2[s] = true;  // the bucket turned keys away: ask the plain index
+                        rvv[j] = (uint64_t)va[hit] | ((uint64_t)va[8 + hit] << 32);
+                    } else if (k7 != NAN64 && (k7 & IDX_OVF)) pend2[j] = true;  // the bucket turned keys away: ask the plain index
                 }
             }
             DBTK_STAMP(18);  // home buckets: fetch + search
@@ -1313,17 +1361,17 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         }
         // ---- look-ups in the plain index: every position (no minimizer-grouped copy), or the positions the home buckets left open
         uint32_t nl = nk;        // entries of the look-up list in sm.km / sm.hb
-        const bool mapped = T.mz != nullptr;  // list entry j stands for position sm.pm[j] (else: for position j)
+        const bool mapped = T.mz != nullptr;  // list entry e stands for position sm.pm[e] (else: for position e)
         if (mapped) {
             x.sync();
             nl = 0;
 #pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                if ((uint32_t)s >= nsl) continue;
-                const uint64_t pb = x.ballot(pend2[s]);
-                if (pend2[s]) {
-                    const uint32_t j = nl + (uint32_t)__builtin_popcountll(pb & ((1ull << lane) - 1));
-                    sm.km[j] = km[s]; sm.hb[j] = (uint32_t)hh[s]; sm.pm[j] = 64u * s + lane;
+            for (int j = 0; j < NSLOT; ++j) {
+                if ((uint32_t)j >= npl) continue;
+                const uint64_t pb = x.ballot(pend2[j]);
+                if (pend2[j]) {
+                    const uint32_t e = nl + (uint32_t)__builtin_popcountll(pb & ((1ull << lane) - 1));
+                    sm.km[e] = km[j]; sm.hb[e] = (uint32_t)hash_idx(km[j], T.idx_shift); sm.pm[e] = p0 + j;
                 }
                 nl += (uint32_t)__builtin_popcountll(pb);
             }
@@ -1333,9 +1381,9 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         // quad read the four 16-byte parts of one bucket (keys 0,1 | keys 2,3 | values 0,1 | values 2,3), so a lookup
         // is one request for one 64-byte line and ends in its home bucket unless that bucket is full AND overflowed.
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            const uint32_t i = 64 * s + lane;
-            if ((uint32_t)s < nsl && i < nk) { sm.km[i] = km[s]; sm.hb[i] = open[s] ? (uint32_t)hh[s] : 0u; }
+        for (int j = 0; j < NSLOT; ++j) {
+            const uint32_t i = p0 + j;
+            if ((uint32_t)j < npl && i < nk) { sm.km[i] = km[j]; sm.hb[i] = open[j] ? (uint32_t)hash_idx(km[j], T.idx_shift) : 0u; }
         }
         x.sync();
         }
@@ -1345,11 +1393,11 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         // One evaluation of a quad's bucket parts against its k-mer: the two key lanes compare, the value lanes' words reach
         // them by DPP; the hit lane stores the result, lane 0 of the quad stores the miss, and `more` says that the quad must
         // look into the next bucket (full and overflowed, no match).  Returns the wave's ballot of `more`.
-        auto settle = [&](bool active, uint32_t pos, uint64_t kq, uint64_t p0, uint64_t p1, bool& more) -> uint64_t {
-            const uint64_t v0 = quad_perm64<2, 3, 2, 3>(x, p0), v1 = quad_perm64<2, 3, 2, 3>(x, p1);
+        auto settle = [&](bool active, uint32_t pos, uint64_t kq, uint64_t p0_, uint64_t p1_, bool& more) -> uint64_t {
+            const uint64_t v0 = quad_perm64<2, 3, 2, 3>(x, p0_), v1 = quad_perm64<2, 3, 2, 3>(x, p1_);
             const bool live = active && kq != NAN64, keyl = sub < 2;
-            const bool m0 = live && keyl && p0 == kq, m1 = live && keyl && (p1 & ~IDX_OVF) == kq;
-            const bool ovf = live && sub == 1 && p1 != NAN64 && (p1 & IDX_OVF);
+            const bool m0 = live && keyl && p0_ == kq, m1 = live && keyl && (p1_ & ~IDX_OVF) == kq;
+            const bool ovf = live && sub == 1 && p1_ != NAN64 && (p1_ & IDX_OVF);
             const uint64_t hmask = x.ballot(m0 || m1), omask = x.ballot(ovf);
             const bool qhit = ((hmask >> (lane & ~3u)) & 0xF) != 0;
             more = live && !qhit && ((omask >> ((lane & ~3u) + 1)) & 1);
@@ -1388,23 +1436,18 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             if (anymore) {  // rare (about one look-up in a thousand): walk on, bucket by bucket
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    bool m = more[u];
+                    bool mo = more[u];
                     uint32_t b = bq[u];
-                    while (x.ballot(m)) {
+                    while (x.ballot(mo)) {
                         b = (b + 1) & (uint32_t)T.idx_mask;
-                        uint64_t p0 = 0, p1 = 0;
-                        if (m) bucket_part(T.idx, b, sub, &p0, &p1);
+                        uint64_t q0 = 0, q1 = 0;
+                        if (mo) bucket_part(T.idx, b, sub, &q0, &q1);
                         bool m2 = false;
-                        (void)settle(m, ii[u], kq[u], p0, p1, m2);
-                        m = m2;
+                        (void)settle(mo, ii[u], kq[u], q0, q1, m2);
+                        mo = m2;
                     }
                 }
             }
-        }
-        if (mapped) {  // the open positions' results come back through LDS
-            x.sync();
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s) if ((uint32_t)s < nsl && pend2[s]) rvv[s] = sm.rva[64 * s + lane];
         }
         x.sync();
         {   // the read's results: found positions, and whether they are all unique to one and the same locus
@@ -1412,25 +1455,25 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             uint32_t nh = 0, v0 = NOHIT;
             bool vdiff = false;
 #pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                const uint32_t i = 64 * s + lane;
-                const bool in = (uint32_t)s < nsl && i < nk;
-                rv[s] = in ? (T.mz ? rvv[s] : sm.rva[i]) : (uint64_t)NOHIT;
-                const uint32_t v = (uint32_t)rv[s];
+            for (int j = 0; j < NSLOT; ++j) {
+                const uint32_t i = p0 + j;
+                const bool in = (uint32_t)j < npl && i < nk;
+                rv[j] = in ? ((mapped && !pend2[j]) ? rvv[j] : sm.rva[i]) : (uint64_t)NOHIT;
+                const uint32_t v = (uint32_t)rv[j];
                 const uint64_t hmk = x.ballot(v != NOHIT);
                 nh += (uint32_t)__builtin_popcountll(hmk);
-                if (v0 == NOHIT && hmk) v0 = x.bcast(v, (int)__builtin_ctzll(hmk));
+                if (v0 == NOHIT && hmk) v0 = x.bcast(v, (int)__builtin_ctzll(hmk));  // (any found value: it only counts when all are equal)
                 vdiff |= v != NOHIT && v != v0;
             }
             const bool uniform = T.consistent && nh && !(v0 & 1) && x.ballot(vdiff) == 0;
             if (lane == 0) a.hithdr[it] = (uint64_t)v0 | ((uint64_t)nh << 32) | (uniform ? HDR_UNIFORM : 0ull);
 #pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                const uint32_t i = 64 * s + lane;
-                if ((uint32_t)s < nsl && i < nk) {
-                    const uint32_t v = (uint32_t)rv[s];
-                    if (a.hitkm) outk[i] = km[s];
-                    outa[i] = v != NOHIT ? (uint32_t)(rv[s] >> 32) : AUX_MISS;
+            for (int j = 0; j < NSLOT; ++j) {
+                const uint32_t i = p0 + j;
+                if ((uint32_t)j < npl && i < nk) {
+                    const uint32_t v = (uint32_t)rv[j];
+                    if (a.hitkm) outk[i] = km[j];
+                    outa[i] = v != NOHIT ? (uint32_t)(rv[j] >> 32) : AUX_MISS;
                     if (!uniform) outv[i] = v;
                 }
             }
@@ -1441,7 +1484,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
                 const uint32_t i = 64 * s + lane;
-                if ((uint32_t)s < nsl && i + 1 < nk) eo[i] = clean ? window_kmer_clean(sm.pk, i, k + 1) : window_kmer(sm.pk, sm.vd, i, k + 1, nullptr, nullptr);
+                if ((uint32_t)s < npl && i + 1 < nk) eo[i] = clean ? window_kmer_clean(sm.pk, i, k + 1) : window_kmer(sm.pk, sm.vd, i, k + 1, nullptr, nullptr);
             }
         }
         if (a.qmaskbuf) {  // -b with qualities

@@ -302,12 +302,12 @@ DBTK_HD uint64_t revcomp2(uint64_t x, uint32_t k) {
 }
 
 // Hash of a canonical m-mer (m <= 16) that orders the m-mers of a k-mer; the k-mer's minimizer is the smallest.
-DBTK_HD uint32_t mmer_hash(uint64_t fw, uint32_t m) {
-    const uint64_t rc = revcomp2(fw, m);
-    uint32_t x = (uint32_t)(fw < rc ? fw : rc);
+DBTK_HD uint32_t mmer_hash2(uint32_t fw, uint32_t rc) {  // the two strands given
+    uint32_t x = fw < rc ? fw : rc;
     x ^= x >> 13; x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 16;
     return x;
 }
+DBTK_HD uint32_t mmer_hash(uint64_t fw, uint32_t m) { return mmer_hash2((uint32_t)fw, (uint32_t)revcomp2(fw, m)); }
 // Minimizer (as a hash value) of a k-mer given in either orientation: min over its k - m + 1 m-mers.
 DBTK_HD uint32_t kmer_minimizer(uint64_t kmer, uint32_t k, uint32_t m) {
     const uint64_t mm = (1ull << 2 * m) - 1;

@@ -4,6 +4,8 @@ OUT.trkmc.ar order, kmc, nmapread, the reference's counters, and every field
 of every per-pair record."""
 import ctypes as C
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -445,3 +447,44 @@ def test_two_gpu_allreduce_equals_single_gpu(dbtk, oracle):
         c.close()
     oracle.free(go)
     g.close()
+
+
+def test_checked_launches_mode(tmp_path):
+    """DBTK_SYNC_LAUNCHES=1 (what the debug build, `make -C danbing-tk_amd/csrc debug`, hard-wires): every launch is waited
+    for and checked by name.  Same results; run in a child process because the switch is read once per process."""
+    code = """
+import sys, ctypes as C
+sys.path.insert(0, %r)
+import bind
+import numpy as np
+abi = bind.abi
+dbtk = bind.pkg.Dbtk()
+orc = bind.Oracle()
+syn = bind.pkg.Synth(nloci=300)
+syn.graph()
+arrs = syn.arrays()
+h = C.c_void_p()
+dbtk._chk(dbtk.L.dbtk_rpgg_from_arrays(C.byref(arrs), C.byref(h)))
+g = bind.pkg.Rpgg(dbtk, h)
+seq, off = syn.reads(3000, hit_frac=0.6, seed=9)
+for p in (abi.default_params(ksize=21, cthreshold=45, okam=0),
+          abi.default_params(ksize=21, cthreshold=45, okam=0, threading=abi.THREADING_V13, thread_cth=85, correction=1, maxncorrection=3)):
+    ctx = dbtk.context(g, p)
+    ctx.align(seq, off)
+    r = ctx.counts()
+    go = orc.from_arrays(arrs)
+    if p.threading == abi.THREADING_V13:
+        o = orc.align_walk(go, p, seq, off)
+    else:
+        o = orc.align(go, p, seq, off, trace=False)
+    co = np.zeros(g.ntrkmers, np.uint64)
+    np.add.at(co, g.output_order().astype(np.int64), o["counts_file"])
+    assert (co == r["counts"]).all(), "counts differ"
+    assert (o["kmc"] == r["kmc"]).all() and (o["nmapread"] == r["nmapread"]).all()
+    assert (o["counters"] == r["counters"]).all(), (o["counters"], r["counters"])
+    ctx.close()
+print("checked-launches ok")
+""" % os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, DBTK_SYNC_LAUNCHES="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "checked-launches ok" in r.stdout, r.stdout + r.stderr

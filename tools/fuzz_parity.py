@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity soak on the GPU: random RPGGs, read sets and parameters, the HIP path against the oracle
-(records in trace mode, counts / totals / counters without).   python tools/fuzz_parity.py [nseeds] [first_seed]"""
+(records in trace mode, counts / totals / counters without).   python tools/fuzz_parity.py [nseeds] [first_seed]
+python tools/fuzz_parity.py walk [nseeds] [first_seed]: the same for the hot loop with threading = 2 (graph walk, exact
+counts, walk results, -a / -ae records)."""
 import importlib
 import os
 import sys
@@ -18,7 +20,62 @@ import synth  # noqa: E402
 abi = bind.pkg.abi
 
 
+def walk_main(argv):
+    """Random RPGGs with their graphs, read sets with errors of every kind, random walk parameters: dbtk_align_batch with
+    threading = 2 against orc_align_walk (counts, kmc, nmapread, counters, walk results, alignment records)."""
+    import test_walk
+    n = int(argv[0]) if argv else 20
+    s0 = int(argv[1]) if len(argv) > 1 else 5000
+    dbtk, orc = bind.pkg.Dbtk(), bind.Oracle()
+    bad = 0
+    for seed in range(s0, s0 + n):
+        rng = np.random.default_rng(seed)
+        k = int(rng.choice([21, 21, 25, 25, 17]))
+        loci = synth.make_loci(nloci=int(rng.integers(3, 60)), nhap=int(rng.integers(1, 4)), flank=int(rng.integers(300, 700)), seed=seed,
+                               shared_frac=float(rng.choice([0.0, 0.2, 0.6])), tr_min=int(rng.integers(40, 200)), tr_max=int(rng.integers(300, 1200)))
+        rlen = int(rng.choice([150, 150, 100, 250, 80]))
+        reads = synth.sim_reads(loci, npairs=int(rng.integers(100, 1500)), rlen=rlen, seed=seed + 7, sub=float(rng.choice([0.0, 0.005, 0.02, 0.05])),
+                                indel=float(rng.choice([0.0, 0.002, 0.01])), nrate=float(rng.choice([0.0, 0.003])),
+                                chimeric=float(rng.choice([0.0, 0.2])), background=float(rng.choice([0.0, 0.2])), frag=(max(300, rlen), max(320, rlen) + 250))
+        nk = rlen - k + 1
+        cth = min(int(rng.choice([45, 30, 10])), max(1, nk // 2))
+        ps = dict(thread_cth=int(rng.integers(max(1, nk // 3), nk + 10)), correction=int(rng.integers(0, 2)), maxncorrection=int(rng.integers(0, 5)))
+        aln = int(rng.integers(0, 3))
+        with tempfile.TemporaryDirectory() as d:
+            pref = os.path.join(d, "pan")
+            synth.write_rpgg_files(synth.build_rpgg_arrays(loci, k), pref)
+            synth.write_graph_file(synth.build_graph_arrays(loci, k), pref, binary=bool(seed & 1))
+            go = orc.load(pref, k)
+            orc.load_graph(go, pref + (".graph.umap" if seed & 1 else ".graph.kmers"))
+            g = dbtk.load(pref, k, flags=abi.LOAD_GRAPH)
+            p = abi.default_params(ksize=k, cthreshold=cth, threading=2, aln=aln, okam=0, **ps)
+            seq, off = reads.packed()
+            o = orc.align_walk(go, p, seq, off)
+            ctx = dbtk.context(g, p)
+            ctx.align(seq, off)
+            r = ctx.counts()
+            res, _, nres = ctx.walk_results(len(off))
+            got_aln = ctx.aln_records()
+            co = np.zeros(g.ntrkmers, np.uint64)
+            np.add.at(co, g.output_order().astype(np.int64), o["counts_file"])
+            ok = bool((co == r["counts"]).all() and (o["kmc"] == r["kmc"]).all() and (o["nmapread"] == r["nmapread"]).all()
+                      and (o["counters"] == r["counters"]).all())
+            m = o["nres"]
+            ok &= nres == m and bytes(res)[:8 * m] == bytes(o["res"])[:8 * m]
+            exp, _ = test_walk.expected_aln(orc, o, reads, aln, loci.nloci)
+            ok &= ([(h.pair, h.dst, t) for h, t in got_aln] == exp) if aln else (got_aln == [])
+            ctx.close()
+            orc.free(go)
+            g.close()
+        print(f"walk seed {seed}: k={k} rlen={rlen} pairs={reads.npairs} cth={cth} aln={aln} {ps} walked={m} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+        bad += not ok
+    print(f"{n - bad}/{n} walk seeds bit-exact")
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "walk":
+        return walk_main(sys.argv[2:])
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     dbtk, orc = bind.pkg.Dbtk(), bind.Oracle()
