@@ -357,7 +357,7 @@ def main():
             # all-hit: every pair tiled from a locus (SURVEY 8d mix 1): the probe and resolve kernels carry the step
             ah_seq, ah_off = syn.reads(mp, rlen=rlen, hit_frac=1.0, seed=2, nthreads=nth)
             if ref_dir and do_walk:
-                nhit = min(mp, 1_000_000)
+                nhit = mp
                 syn.write_fasta(ah_seq, nhit, os.path.join(ref_dir, "reads_hit.fa"), rlen=rlen)
             d_ah = torch.from_numpy(ah_seq).to(dev)
             d_aho = torch.from_numpy(ah_off.view(np.int64)).to(dev)

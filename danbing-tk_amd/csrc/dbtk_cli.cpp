@@ -380,7 +380,7 @@ int main(int argc, char* argv[]) {
     auto emit_alignments = [&](const Batch& b) {
         const uint64_t n = b.naln;
         if (!n) return;
-        const uint64_t CH = 2048;
+        const uint64_t CH = 512;  // records per chunk (= per gzip member): ~230 KB of text, several chunks per emit thread and batch
         const uint64_t nch = (n + CH - 1) / CH;
         std::vector<std::string> chunk(nch);
         std::atomic<uint64_t> nextc{0};
@@ -828,8 +828,9 @@ int main(int argc, char* argv[]) {
                 if (st) die_assert(std::string("align: ") + dbtk_last_error());
                 if (emit_aln) {
                     uint64_t n = 0;
+                    b->aln.resize(b->aln.capacity());  // a recycled batch keeps its buffer: usually large enough, and its pages are mapped
                     dbtk_status_t sa = dbtk_ctx_aln_records(ctx[d], b->aln.data(), b->aln.size(), &n, &b->aln_stride, &b->aln_cap);
-                    if (sa == DBTK_ERR_OVERFLOW) {
+                    if (sa == DBTK_ERR_OVERFLOW) {  // (nothing was copied: n = the records the buffer must hold)
                         b->aln.resize((size_t)n * b->aln_stride);
                         sa = dbtk_ctx_aln_records(ctx[d], b->aln.data(), b->aln.size(), &n, &b->aln_stride, &b->aln_cap);
                     }

@@ -15,6 +15,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -180,6 +181,7 @@ struct dbtk_ctx {
     uint32_t* d_loci = nullptr; uint64_t loci_cap = 0;       // function mode: locus per read
     uint8_t* d_aln = nullptr; uint64_t aln_bytes = 0;        // -a / -ae: compact alignment records of the last host-buffer batch
     uint32_t aln_stride = 0, aln_cap = 0; uint64_t aln_max = 0;
+    uint8_t* h_aln = nullptr; size_t h_aln_bytes = 0;  // pinned staging of dbtk_ctx_aln_records
     uint64_t last_walk_npairs = 0; bool last_walk_recs = false;  // what dbtk_ctx_walk_results may fetch
     int walk_blocks = 0;
     // optional gates
@@ -266,6 +268,7 @@ void free_ctx(dbtk_ctx* c) {
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
                     c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_walk, c->d_trecs, c->d_loci, c->d_aln};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->h_aln) (void)hipHostFree(c->h_aln);
     std::vector<dbtk_ctx::Lane*> others{&c->alt};
     for (auto& l : c->parked) others.push_back(&l);
     for (dbtk_ctx::Lane* l : others) {
@@ -1085,17 +1088,38 @@ dbtk_status_t dbtk_ctx_aln_records(dbtk_ctx_t* c, void* buf, uint64_t buf_bytes,
     HIPCHK(hipMemcpy(&nslots, c->d_small + 4, 4, hipMemcpyDeviceToHost));
     if (nslots > c->aln_max) { set_error("alignment record buffer overflow"); return DBTK_ERR_OVERFLOW; }
     const size_t st = c->aln_stride;
-    std::vector<uint8_t> raw((size_t)nslots * st);
-    if (nslots) HIPCHK(hipMemcpy(raw.data(), c->d_aln, raw.size(), hipMemcpyDeviceToHost));
+    // too small for every slot handed out: say what is needed (an upper bound: some slots of a wave's last chunk stay empty), copy nothing
+    if ((uint64_t)nslots * st > buf_bytes || (!buf && nslots)) { *nrec = nslots; set_error("alignment record buffer too small"); return DBTK_ERR_OVERFLOW; }
+    if (!nslots) return DBTK_OK;
+    if ((size_t)nslots * st > c->h_aln_bytes) {  // pinned staging, grown as needed and kept: the copy runs at link speed
+        if (c->h_aln) HIPCHK(hipHostFree(c->h_aln));
+        c->h_aln = nullptr; c->h_aln_bytes = 0;
+        const size_t want = std::max((size_t)nslots * st, (size_t)c->aln_max * st);
+        HIPCHK(hipHostMalloc((void**)&c->h_aln, want, hipHostMallocDefault));
+        c->h_aln_bytes = want;
+    }
+    const uint8_t* raw = c->h_aln;
+    HIPCHK(hipMemcpy(c->h_aln, c->d_aln, (size_t)nslots * st, hipMemcpyDeviceToHost));
     std::vector<std::pair<uint32_t, uint32_t>> order;  // (pair, slot)
+    order.reserve(nslots);
     for (uint32_t i = 0; i < nslots; ++i) {
-        const dbtk_aln_hdr_t* h = reinterpret_cast<const dbtk_aln_hdr_t*>(raw.data() + (size_t)i * st);
+        const dbtk_aln_hdr_t* h = reinterpret_cast<const dbtk_aln_hdr_t*>(raw + (size_t)i * st);
         if (h->pair != NAN32) order.emplace_back(h->pair, i);
     }
     std::sort(order.begin(), order.end());
     *nrec = order.size();
-    if (order.size() * st > buf_bytes || (!buf && !order.empty())) { set_error("alignment record buffer too small"); return DBTK_ERR_OVERFLOW; }
-    for (size_t i = 0; i < order.size(); ++i) memcpy((uint8_t*)buf + i * st, raw.data() + (size_t)order[i].second * st, st);
+    // gather into pair order; a record only as far as its arrays are filled (the tail of a slot is never read back by anyone)
+    const size_t n = order.size();
+    const unsigned nt = (unsigned)std::min<size_t>(std::max<size_t>(1, n / 65536), std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())));
+    auto gather = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) memcpy((uint8_t*)buf + i * st, raw + (size_t)order[i].second * st, st);
+    };
+    if (nt <= 1) gather(0, n);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(gather, n * t / nt, n * (t + 1) / nt);
+        for (auto& x : th) x.join();
+    }
     return DBTK_OK;
 }
 

@@ -260,8 +260,8 @@ typedef struct dbtk_aln_hdr {
     uint16_t nes1, ntr1, nes2, ntr2;
     uint32_t pad2;
 } dbtk_aln_hdr_t;
-/* buf receives *nrec records of *stride bytes each (DBTK_ERR_OVERFLOW if buf_bytes is too small: *nrec and *stride
- * then say what is needed). */
+/* buf receives *nrec records of *stride bytes each.  DBTK_ERR_OVERFLOW if buf_bytes is too small for every record the
+ * batch may hold: nothing is copied, and *nrec (an upper bound of the record count) and *stride say what is needed. */
 dbtk_status_t dbtk_ctx_aln_records(dbtk_ctx_t* ctx, void* buf, uint64_t buf_bytes, uint64_t* nrec, uint32_t* stride, uint32_t* cap);
 /* Returns the length of the text (without the terminating NUL it also writes when it fits). */
 size_t dbtk_aln_format(const void* rec, uint32_t cap, char* out, size_t out_cap);

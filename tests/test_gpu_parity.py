@@ -353,6 +353,15 @@ def test_randomised_parity_soak():
     assert r.returncode == 0, r.stdout.decode()[-3000:]
 
 
+def test_randomised_walk_parity_soak():
+    """tools/fuzz_parity.py walk: random RPGGs with their graphs (text / .umap loaders alternating), read sets with errors of every
+    kind, random thread_cth / correction / maxncorrection / -a / -ae; counts, totals, walk results and alignment records against
+    the oracle.  (40 further seeds, 5000-5039, were run when this was added.)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "walk", "10", "6000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
 def test_device_entry_reports_a_read_longer_than_promised(dbtk, tmp_path):
     """dbtk_align_batch_device trusts max_read_len (it sizes the rows of the hit buffers).  A longer read must not write past its
     row: the probe kernel clamps it and raises the sticky error word, which dbtk_ctx_synchronize reports once — also when
