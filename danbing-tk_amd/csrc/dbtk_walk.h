@@ -120,7 +120,12 @@ struct WalkArgs {
 #define W_STAMP_DECL uint64_t wst[8] = {0}; uint64_t wlast = x.clock();
 #define W_STAMP(i) do { const uint64_t now_ = x.clock(); wst[i] += now_ - wlast; wlast = now_; } while (0)
 #define W_STAMP_FLUSH do { if (lane == 0 && a.dbg) for (int i_ = 0; i_ < 8; ++i_) if (wst[i_]) x.atomic_add(&a.dbg[i_], wst[i_]); } while (0)
+// inside the out-of-line routines: sums kept in LDS (WalkSmem::dst_), lane 0 only
+#define WS_BEGIN() do { if (x.lane() == 0) sm.dlast = x.clock(); } while (0)
+#define WS(i) do { if (x.lane() == 0) { const uint64_t now_ = x.clock(); sm.dst_[i] += now_ - sm.dlast; sm.dlast = now_; } } while (0)
 #else
+#define WS_BEGIN() do { } while (0)
+#define WS(i) do { } while (0)
 #define W_STAMP_DECL
 #define W_STAMP(i) do { } while (0)
 #define W_STAMP_FLUSH do { } while (0)
@@ -147,6 +152,9 @@ struct WalkSmem {
     uint8_t scr[128];         // edit_kmers_backward: the read / graph bases of an edit tract
     int32_t st[8];            // lane-0 regions hand their scalars back through here
     uint64_t st64[2];
+#ifdef DBTK_STAMPS
+    uint64_t dst_[8], dlast;  // diagnostic: cycle sums of the slow walk's parts
+#endif
 };
 
 DBTK_HD uint64_t w_roll(uint64_t kmer, uint64_t rmask, uint64_t b) { return ((kmer & rmask) << 2) + b; }
@@ -674,21 +682,26 @@ DBTK_HD_NOINLINE int walk_slow(X& x, WalkSmem& sm, const DevTables& T, const dbt
     // The walk's state lives in registers.  The rare, large pieces (error correction, the k-mer / CIGAR surgery) are separate
     // functions so that the common path stays small; they get a COPY of the state: a reference would pin S in scratch memory
     // and turn every `S.ki += run` of the common path into a load and a store.
-    auto find_anchor = [&]() { return walk_find_anchor(x, sm, k, S); };
-    auto edit_forward = [&](int wid, uint32_t score) { WalkState t = S; walk_edit_forward(x, sm, T, locus, t, wid, score); S = t; };
+    WS_BEGIN();
+    auto find_anchor = [&]() { WS(5); const bool r_ = walk_find_anchor(x, sm, k, S); WS(4); return r_; };
+    auto edit_forward = [&](int wid, uint32_t score) { WS(5); WalkState t = S; walk_edit_forward(x, sm, T, locus, t, wid, score); S = t; WS(1); };
     // (anchor = -1: the walk's own position S.ki, which the routine moves; else an earlier anchor, handed back)
     auto edit_backward = [&](int wid, uint32_t score, int anchor, int* onm, int* ond, int* oni) -> int {
+        WS(5);
         WalkState t = S;
         int tki = anchor < 0 ? t.ki : anchor, a = 0, b = 0, c = 0;
         walk_edit_backward(x, sm, T, locus, t, wid, score, &tki, &a, &b, &c);
         S = t;
+        WS(3);
         if (anchor < 0) S.ki = tki;
         *onm = a; *ond = b; *oni = c;
         return tki;
     };
     auto ec = [&](bool backward, int ki, uint32_t mes, int* wid, uint32_t* wscore) {
         int w = 0; uint32_t sc = 0, fl = 0;
+        WS(5);
         const bool skip = walk_ec(x, sm, T, locus, backward, ki, S.nkm, mes, &w, &sc, &fl);
+        WS(backward ? 2 : 0);
         *wid = w; *wscore = sc; S.flags |= fl;
         return skip;
     };
@@ -810,6 +823,7 @@ DBTK_HD_NOINLINE int walk_slow(X& x, WalkSmem& sm, const DevTables& T, const dbt
         ++S.ki; ++S.ni;
     }
 #undef W_FAIL_CHECK
+    WS(5);
     return (S.nskip <= maxnskip && S.ncorr <= maxc) ? (S.ncorr ? 2 : 1) : 0;
 }
 
@@ -1043,6 +1057,9 @@ DBTK_HD void body_walk_reads(X& x, const WalkArgs& a) {
 template <class X>
 DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
     WalkSmem* const smm = x.template smem<WalkSmem>();  // one set of arrays per mate
+#ifdef DBTK_STAMPS
+    if (x.lane() == 0) for (int m_ = 0; m_ < 2; ++m_) for (int i_ = 0; i_ < 8; ++i_) smm[m_].dst_[i_] = 0;
+#endif
     const int lane = x.lane();
     uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
     const uint32_t nsurv = *a.nsurv;
@@ -1165,6 +1182,9 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
             if (slot < a.aln_max) reinterpret_cast<dbtk_aln_hdr_t*>(a.aln + (size_t)slot * a.aln_stride)->pair = NAN32;
         }
     W_STAMP_FLUSH;
+#ifdef DBTK_STAMPS
+    if (lane == 0 && a.dbg) for (int m_ = 0; m_ < 2; ++m_) for (int i_ = 0; i_ < 8; ++i_) if (smm[m_].dst_[i_]) x.atomic_add(&a.dbg[8 + i_], smm[m_].dst_[i_]);
+#endif
     if (lane == 0) {
         if (c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], c_feas);
         if (c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], c_inc);

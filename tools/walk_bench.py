@@ -52,6 +52,8 @@ def main():
             npair = float(c[abi.C_THREADING]) / 2
             names = ["prefetch issue", "stage (bytes arrive)", "probe issue", "probe finish", "walk mate 0", "walk mate 1", "count+results", "loop tail"]
             print("   cycles per pair: " + ", ".join(f"{n} {float(st[i]) / npair:.0f}" for i, n in enumerate(names)))
+            sub = ["EC forward", "edit forward", "EC backward", "edit backward", "find_anchor", "slow walk: the rest"]
+            print("   inside the slow walk, per pair: " + ", ".join(f"{n} {float(st[8 + i]) / npair:.0f}" for i, n in enumerate(sub)))
         ctx.close()
 
 
