@@ -1182,33 +1182,39 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         if (lane < 4) sm.raw[nw + lane] = 0;
         x.sync();
         uint32_t bad = 0;  // some base of the read is not ACGT (bytes past the read do not count)
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (lane < 16) {
-            const int c = lane;
-            const uint32_t B = rsh + 16 * c, j = B >> 2, r8 = 8 * (B & 3);
-            uint32_t r4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t v = 0, inmask = 0;
-                if (16u * c + 4 * q < len) {
-                    const uint32_t lo = sm.raw[j + q], hi = sm.raw[j + q + 1];
-                    v = r8 ? ((lo >> r8) | (hi << (32 - r8))) : lo;
-                    const uint32_t left = len - (16 * c + 4 * q);  // bytes of this word inside the read
-                    inmask = left < 4 ? (1u << (8 * left)) - 1 : 0xFFFFFFFFu;
-                    v &= inmask;
-                }
-                w[q] = v;
-                uint32_t b = 0;
-                r4[q] = pack4_b2(v, &b);
-                bad |= b & inmask;
+        {   // 2-bit pack, four bases per lane: lane l packs bytes 4l .. 4l + 3 of the read into byte l of the big-endian stream
+            const uint32_t B = rsh + 4u * lane, j = B >> 2, r8 = 8 * (B & 3);
+            uint32_t v = 0, inmask = 0;
+            if (4u * lane < len) {
+                const uint32_t lo = sm.raw[j], hi = sm.raw[j + 1];
+                v = r8 ? ((lo >> r8) | (hi << (32 - r8))) : lo;
+                const uint32_t left = len - 4u * lane;  // bytes of this word inside the read
+                inmask = left < 4 ? (1u << (8 * left)) - 1 : 0xFFFFFFFFu;
+                v &= inmask;
             }
-            sm.pk[c] = byte_perm(byte_perm(r4[0], r4[1], 0x06020000u), byte_perm(r4[2], r4[3], 0x00000602u), 0x07060100u);
-            if (c < 4) sm.pk[16 + c] = 0;
+            uint32_t b = 0;
+            const uint32_t r4 = pack4_b2(v, &b);
+            bad = b & inmask;
+            reinterpret_cast<uint8_t*>(sm.pk)[4 * (lane >> 2) + 3 - (lane & 3)] = (uint8_t)(r4 >> 16);
+            if (lane < 4) sm.pk[16 + lane] = 0;
         }
         // every base ACGT (the usual read): all windows are valid and no validity bits are needed; else compute them exactly
         const bool clean = x.ballot(bad != 0) == 0;
         DBTK_STAMP(40);  // fetch pipeline, raw to LDS, pack
-        if (!clean && lane < 16) {
+        if (!clean && lane < 16) {  // (rare) validity bits, 16 bases per lane
+            const int c = lane;
+            const uint32_t B = rsh + 16 * c, j = B >> 2, r8 = 8 * (B & 3);
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (16u * c + 4 * q < len) {
+                    const uint32_t lo = sm.raw[j + q], hi = sm.raw[j + q + 1];
+                    uint32_t v = r8 ? ((lo >> r8) | (hi << (32 - r8))) : lo;
+                    const uint32_t left = len - (16 * c + 4 * q);
+                    v &= left < 4 ? (1u << (8 * left)) - 1 : 0xFFFFFFFFu;
+                    w[q] = v;
+                }
+            }
             uint32_t vd;
             (void)pack16(w, &vd);
             sm.vd[lane] = (uint16_t)vd;  // bytes past the read are 0 -> invalid
@@ -1389,7 +1395,6 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         }
         DBTK_STAMP(41);  // windows, hash, staging
         const uint32_t sub = lane & 3, qd = lane >> 2;
-        constexpr int NB = DBTK_K2_NB;  // buckets in flight per lane
         // One evaluation of a quad's bucket parts against its k-mer: the two key lanes compare, the value lanes' words reach
         // them by DPP; the hit lane stores the result, lane 0 of the quad stores the miss, and `more` says that the quad must
         // look into the next bucket (full and overflowed, no match).  Returns the wave's ballot of `more`.
@@ -1409,6 +1414,9 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             }
             return x.ballot(more);
         };
+        // buckets in flight per lane: DBTK_K2_NB when every position is looked up, 2 for the (short) list the home buckets leave
+        auto lookups = [&](auto nbtag) {
+        constexpr int NB = decltype(nbtag)::value;
         for (uint32_t i0 = 0; i0 < nl; i0 += 16 * NB) {
             uint32_t ii[NB], bq[NB];
             uint64_t kq[NB], a0[NB], a1[NB];
@@ -1449,6 +1457,8 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                 }
             }
         }
+        };
+        if (mapped) lookups(std::integral_constant<int, 2>{}); else lookups(std::integral_constant<int, DBTK_K2_NB>{});
         x.sync();
         {   // the read's results: found positions, and whether they are all unique to one and the same locus
             uint64_t rv[NSLOT];
