@@ -52,10 +52,13 @@ __global__ void __launch_bounds__(K1_NT, 4) k_encode_subfilter(BatchArgs a) {
     body_encode_subfilter(x, a);
 }
 // K2 / K3 are instantiated per NS = 64-position slots a read needs (2: <= 128 positions, 3: 150 bp reads, 4: up to 256 bp)
-template <int NS> __global__ void __launch_bounds__(64) k_probe(BatchArgs a) {
+#ifndef DBTK_K2_WPE
+#define DBTK_K2_WPE 5  // waves per SIMD the probe kernel's registers are budgeted for (96 VGPRs; 4: 109 VGPRs, 4 % slower; 6: spills, 8 % slower)
+#endif
+template <int NS, bool MZ> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_K2_WPE, 8))) k_probe(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) ProbeSmem sm;
     DevX x{&sm};
-    body_probe<NS>(x, a);
+    body_probe<NS, MZ>(x, a);
 }
 template <int NS, bool RECS> __global__ void __launch_bounds__(64) k_pair_usual(BatchArgs a) {
     __shared__ UsualSmem sm;
@@ -631,9 +634,9 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         a.t0 = (uint32_t)(ch * tcap);
         if (tm) { if ((st = timed_slot(c, 1, &e))) return st; HIPCHK(hipEventRecord(c->timed[1].beg[e], s)); }
         switch (ns) {
-            case 1: case 2: LAUNCH(k_probe<2>, dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); break;
-            case 3: LAUNCH(k_probe<3>, dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); break;
-            default: LAUNCH(k_probe<4>, dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); break;
+            case 1: case 2: if (a.T.mz) LAUNCH((k_probe<2, true>), dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); else LAUNCH((k_probe<2, false>), dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); break;
+            case 3: if (a.T.mz) LAUNCH((k_probe<3, true>), dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); else LAUNCH((k_probe<3, false>), dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); break;
+            default: if (a.T.mz) LAUNCH((k_probe<4, true>), dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); else LAUNCH((k_probe<4, false>), dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); break;
         }
         if (tm) HIPCHK(hipEventRecord(c->timed[1].end[e], s));
         // RECS = false: no record buffer (-ka without -e): record emission is compiled out

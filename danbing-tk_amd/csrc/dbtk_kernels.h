@@ -1115,7 +1115,9 @@ DBTK_HD void qmask_scan(const uint8_t* q, int nq, int qth, int ksize, uint32_t* 
     }
 }
 
-template <int NS, class X>
+// MZ: the context holds the minimizer-grouped copy of the index (T.mz): the two ways of looking up are two kernels, so that
+// neither pays for the other's registers
+template <int NS, bool MZ, class X>
 DBTK_HD void body_probe(X& x, const BatchArgs& a) {
     constexpr int NSLOT = NS;  // 64-position slots per read (shadows the global upper bound)
     ProbeSmem& sm = *x.template smem<ProbeSmem>();
@@ -1226,8 +1228,8 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         // minimizers share all but npl - 1 of their m-mers, and its results are neighbours in the hit buffers.
         const uint32_t npl = (nk + 63) >> 6;
         const uint32_t p0 = (uint32_t)lane * npl;
-        const uint32_t m = T.mz ? T.mz_m : 0u, wn = T.mz ? k - m + 1 : 0u;
-        const uint32_t nmm = (T.mz && len >= m) ? len - m + 1 : 0u;  // m-mers of the read (minimizer path)
+        const uint32_t m = MZ ? T.mz_m : 0u, wn = MZ ? k - m + 1 : 0u;
+        const uint32_t nmm = (MZ && len >= m) ? len - m + 1 : 0u;  // m-mers of the read (minimizer path)
         const bool fastw = clean && k + npl - 1 <= 32;  // (m <= 16 < k: the m-mers fit whenever the k-mers do)
         uint64_t W = 0, RW = 0;  // the 32 bases from p0, and their reverse complement (base t of the window at bits 2t of RW)
         if (fastw && (p0 < nk || p0 < nmm)) { W = window_fw_clean(sm.pk, p0, 32); RW = revcomp2(W, 32); }
@@ -1254,7 +1256,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         bool pend2[NSLOT];    //                 positions its home bucket could not answer
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) { rvv[j] = (uint64_t)NOHIT; pend2[j] = false; }
-        if (T.mz) {
+        if (MZ) {
             // ---- look-ups through the minimizer-grouped copy of the index (MzBucket, dbtk_tables.h): one 128-byte bucket per
             // RUN of positions sharing a minimizer instead of one 64-byte bucket per position
             const uint32_t mmask = (uint32_t)((1ull << (2 * m)) - 1);
@@ -1367,7 +1369,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         }
         // ---- look-ups in the plain index: every position (no minimizer-grouped copy), or the positions the home buckets left open
         uint32_t nl = nk;        // entries of the look-up list in sm.km / sm.hb
-        const bool mapped = T.mz != nullptr;  // list entry e stands for position sm.pm[e] (else: for position e)
+        constexpr bool mapped = MZ;  // list entry e stands for position sm.pm[e] (else: for position e)
         if (mapped) {
             x.sync();
             nl = 0;

@@ -657,17 +657,17 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         a.ngen = usual ? &ngen : nullptr;
         switch (a.nkp / 64) {  // same dispatch as the device launcher
             case 1: case 2:
-                run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<2>(x, a); });
+                run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { if (a.T.mz) body_probe<2, true>(x, a); else body_probe<2, false>(x, a); });
                 if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<2, true>(x, a); else body_pair_usual<2, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<2>), [&](EmuX& x) { if (a.recs) body_pair<2, true>(x, a); else body_pair<2, false>(x, a); });
                 break;
             case 3:
-                run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<3>(x, a); });
+                run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { if (a.T.mz) body_probe<3, true>(x, a); else body_probe<3, false>(x, a); });
                 if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<3, true>(x, a); else body_pair_usual<3, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<3>), [&](EmuX& x) { if (a.recs) body_pair<3, true>(x, a); else body_pair<3, false>(x, a); });
                 break;
             default:
-                run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<4>(x, a); });
+                run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { if (a.T.mz) body_probe<4, true>(x, a); else body_probe<4, false>(x, a); });
                 if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<4, true>(x, a); else body_pair_usual<4, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<4>), [&](EmuX& x) { if (a.recs) body_pair<4, true>(x, a); else body_pair<4, false>(x, a); });
         }
