@@ -422,17 +422,22 @@ def main():
                     # on), on an all-hit read file so that every pair is walked and printed
                     legs = {}
                     base = [cli, "-k", "21", "-kf", "4", "1", "-cth", "45", "--v13-threading", "-gc", "85", "3", "-fa", "reads_hit.fa", "-qs", "pan", "-o", "cliw"]
-                    for name, extra in (("walk", []), ("walk_ae_gz", ["-ae", "--aln-gz", "cliw.aln.gz"])):
+                    for name, extra in (("walk", []), ("walk_ae_gz", ["-ae", "--aln-gz", "cliw.aln.gz"]),
+                                        ("walk_ae_gz_level6", ["-ae", "--aln-gz", "cliw6.aln.gz", "--gz-level", "6"])):
                         t0 = time.perf_counter()
                         r = subprocess.run(base + extra, cwd=ref_dir, capture_output=True, text=True)
                         tw = time.perf_counter() - t0
                         ing = [l for l in r.stderr.splitlines() if l.startswith("ingest:")]
-                        legs[name] = dict(wall_s=tw, returncode=r.returncode, batch_loop=ing[0] if ing else None)
+                        em = [l for l in r.stderr.splitlines() if l.startswith("emit:")]
+                        legs[name] = dict(wall_s=tw, returncode=r.returncode, batch_loop=ing[0] if ing else None, emit=em[0] if em else None)
                     gz = os.path.join(ref_dir, "cliw.aln.gz")
                     legs["aln_gz_bytes"] = os.path.getsize(gz) if os.path.exists(gz) else None
                     legs["reads"] = 2 * nhit
-                    legs["note"] = ("this repo's danbing-tk --v13-threading -gc 85 3 on an all-hit FASTA, without and with -ae --aln-gz: "
-                                    "wall seconds including the RPGG + graph load; the difference is what the emit costs end to end")
+                    gz6 = os.path.join(ref_dir, "cliw6.aln.gz")
+                    legs["aln_gz_level6_bytes"] = os.path.getsize(gz6) if os.path.exists(gz6) else None
+                    legs["note"] = ("this repo's danbing-tk --v13-threading -gc 85 3 on an all-hit FASTA, without and with -ae --aln-gz (zlib level 1, "
+                                    "the default here, and level 6 = gzip's default): wall seconds including the RPGG + graph load; the difference is "
+                                    "what the emit costs end to end.  At level 6 the emit is bound by deflate on the host cores (about 230 bytes of text per read)")
                     e2e["cli_walk_emit"] = legs
                     log(f"CLI walk: {legs['walk']['wall_s']:.1f}s; with -ae --aln-gz: {legs['walk_ae_gz']['wall_s']:.1f}s "
                         f"({legs['aln_gz_bytes']} bytes of .aln.gz for {2 * nhit} reads)")

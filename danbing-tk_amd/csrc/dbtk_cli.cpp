@@ -52,7 +52,7 @@ namespace {
 struct Opts {
     bool bait = false, aug = false, threading = false, tc = false, aln = false, aln_minimal = false, okam = true, g2pan = false;
     bool writeKmerName = false, outputBubbles = false, invkmer = false, isFastq = false, trackBait = false, qc = false;
-    int simmode = 0, extractFastX = 0, verbosity = 0, ngpus = 1, gzLevel = 6, emitThreads = 0;
+    int simmode = 0, extractFastX = 0, verbosity = 0, ngpus = 1, gzLevel = 1, emitThreads = 0;
     bool correction = true;
     bool parseOnly = false;  // --parse-only: run the ingest (reader, splitters, pairing) and report what it handed on; no GPU
     bool v13 = false;       // --v13-threading: -g/-gc/-gcc run the graph walk of the v1.3 contract instead of HEAD's dead path
@@ -91,7 +91,8 @@ void usage() {
             "                         TR k-mers are then counted in \"exact\" mode and -a / -ae print alignment records on stdout\n"
             "  --aln-gz <FILE>        write the -a / -ae records gzip-compressed to FILE (deflated on --emit-threads host threads\n"
             "                         while the GPU works on the next batches) instead of plain text on stdout\n"
-            "  --emit-threads <INT>   host threads formatting / compressing records [cores / 2]   --gz-level <INT> [6]\n"
+            "  --emit-threads <INT>   host threads formatting / compressing records [cores / 2]\n"
+            "  --gz-level <INT>       zlib level of --aln-gz [1: measured 40x less deflate time than gzip's default 6 for 16 %% more bytes]\n"
             "Developer:\n"
             "  -s <1|2>  -e <1|2>  -v <INT>  -g|-gc|-gcc <INT> [INT]  -a  -ae  -tb  -ik  -t <INT>  -m <FILE>  -au\n\n");
 }
@@ -171,7 +172,12 @@ struct Batch {  // one batch on its way through the stages; read r = flat[off[r]
     std::vector<uint64_t> src;                               // simmode: source locus per pair
     std::vector<dbtk_pair_rec_t> recs;
     uint64_t nrec = 0;
-    std::vector<uint8_t> aln;   // -a / -ae: compact alignment records (dbtk_ctx_aln_records)
+    struct RawBuf {  // bytes without the zero fill of vector::resize (a batch's records: >100 MB)
+        std::unique_ptr<uint8_t[]> p; size_t cap = 0;
+        uint8_t* data() const { return p.get(); }
+        size_t size() const { return cap; }
+        void grow(size_t n) { if (n > cap) { p.reset(new uint8_t[n]); cap = n; } }
+    } aln;                      // -a / -ae: compact alignment records (dbtk_ctx_aln_records)
     uint64_t naln = 0; uint32_t aln_stride = 0, aln_cap = 0;
     long gpu_sec = 0;
     std::string title(uint64_t p) const { return std::string(tar.data() + toff[p], toff[p + 1] - toff[p]); }
@@ -371,6 +377,7 @@ int main(int argc, char* argv[]) {
     const int emit_threads = o.emitThreads > 0 ? o.emitThreads : (int)std::max(1u, hw / 2);
     uint64_t aln_bytes = 0;
     std::mutex out_m, tot_m;  // stdout / the gzip file (one batch at a time); the totals below
+    std::atomic<uint64_t> rec_us{0}, fmt_us{0}, gz_us{0};  // -a / -ae: record read-back (wall), formatting and deflate (summed over the emit threads)
     uint64_t nReads = 0;
     double read_busy = 0, cut_busy = 0, pair_busy = 0, gpu_busy = 0, write_busy = 0;  // seconds each stage spent working (not waiting), summed over the shards
     int nsplit_used = 0;
@@ -391,6 +398,7 @@ int main(int argc, char* argv[]) {
                 const uint64_t c = nextc.fetch_add(1);
                 if (c >= nch) break;
                 t.clear();
+                const double tf0 = now();
                 for (uint64_t i = c * CH; i < std::min(n, (c + 1) * CH); ++i) {
                     const uint8_t* rec = b.aln.data() + (size_t)i * b.aln_stride;
                     const dbtk_aln_hdr_t* h = (const dbtk_aln_hdr_t*)rec;
@@ -403,6 +411,8 @@ int main(int argc, char* argv[]) {
                     const size_t l = dbtk_aln_format(rec, b.aln_cap, txt, sizeof txt);
                     t.append(txt, std::min(l, sizeof txt - 1)); t += '\n';
                 }
+                const double tf1 = now();
+                fmt_us += (uint64_t)((tf1 - tf0) * 1e6);
                 if (gzout) {  // one gzip member per chunk: `zcat FILE` is the concatenation
                     z_stream z;
                     memset(&z, 0, sizeof z);
@@ -414,6 +424,7 @@ int main(int argc, char* argv[]) {
                     gz.resize(gz.size() - z.avail_out);
                     deflateEnd(&z);
                     chunk[c].swap(gz);
+                    gz_us += (uint64_t)((now() - tf1) * 1e6);
                 } else chunk[c] = t;
             }
         };
@@ -828,14 +839,16 @@ int main(int argc, char* argv[]) {
                 if (st) die_assert(std::string("align: ") + dbtk_last_error());
                 if (emit_aln) {
                     uint64_t n = 0;
-                    b->aln.resize(b->aln.capacity());  // a recycled batch keeps its buffer: usually large enough, and its pages are mapped
+                    const double tr0 = now();
+                    // (a recycled batch keeps its buffer: usually large enough, and its pages are mapped)
                     dbtk_status_t sa = dbtk_ctx_aln_records(ctx[d], b->aln.data(), b->aln.size(), &n, &b->aln_stride, &b->aln_cap);
                     if (sa == DBTK_ERR_OVERFLOW) {  // (nothing was copied: n = the records the buffer must hold)
-                        b->aln.resize((size_t)n * b->aln_stride);
+                        b->aln.grow((size_t)n * b->aln_stride);
                         sa = dbtk_ctx_aln_records(ctx[d], b->aln.data(), b->aln.size(), &n, &b->aln_stride, &b->aln_cap);
                     }
                     if (sa) die_assert(std::string("alignment records: ") + dbtk_last_error());
                     b->naln = n;
+                    rec_us += (uint64_t)((now() - tr0) * 1e6);
                 }
                 b->gpu_sec = (long)(time(nullptr) - t2);
                 { std::lock_guard<std::mutex> l(done_m); gpu_busy += now() - tg; }
@@ -959,7 +972,7 @@ int main(int argc, char* argv[]) {
             if (emit_aln) {
                 uint64_t n = 0;
                 dbtk_status_t sa = dbtk_ctx_aln_records(ctx[0], nullptr, 0, &n, &b.aln_stride, &b.aln_cap);
-                if (sa == DBTK_ERR_OVERFLOW) { b.aln.resize((size_t)n * b.aln_stride); sa = dbtk_ctx_aln_records(ctx[0], b.aln.data(), b.aln.size(), &n, &b.aln_stride, &b.aln_cap); }
+                if (sa == DBTK_ERR_OVERFLOW) { b.aln.grow((size_t)n * b.aln_stride); sa = dbtk_ctx_aln_records(ctx[0], b.aln.data(), b.aln.size(), &n, &b.aln_stride, &b.aln_cap); }
                 if (sa) die_assert(std::string("alignment records: ") + dbtk_last_error());
                 b.naln = n;
             }
@@ -969,6 +982,8 @@ int main(int argc, char* argv[]) {
     fflush(stdout);
     if (gzout) fclose(gzout);
     const int nsplit = nsplit_used;
+    if (emit_aln) fprintf(stderr, "emit: record read-back %.2f s; formatting %.2f thread-s, deflate %.2f thread-s on up to %d threads; %llu bytes out\n",
+                          rec_us.load() / 1e6, fmt_us.load() / 1e6, gz_us.load() / 1e6, emit_threads, (unsigned long long)aln_bytes);
     fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: reading %.2f s, cutting %.2f s, pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads\n",
             now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, read_busy, cut_busy, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit);
 

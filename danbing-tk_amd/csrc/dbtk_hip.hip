@@ -1113,7 +1113,7 @@ dbtk_status_t dbtk_ctx_aln_records(dbtk_ctx_t* c, void* buf, uint64_t buf_bytes,
     *nrec = order.size();
     // gather into pair order; a record only as far as its arrays are filled (the tail of a slot is never read back by anyone)
     const size_t n = order.size();
-    const unsigned nt = (unsigned)std::min<size_t>(std::max<size_t>(1, n / 65536), std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())));
+    const unsigned nt = (unsigned)std::min<size_t>(std::max<size_t>(1, n / 16384), std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())));
     auto gather = [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) memcpy((uint8_t*)buf + i * st, raw + (size_t)order[i].second * st, st);
     };
