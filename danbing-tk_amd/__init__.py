@@ -305,6 +305,65 @@ EXPORTS = [
     "dbtk_thread_batch", "dbtk_ctx_walk_results", "dbtk_ctx_aln_records", "dbtk_aln_format",
 ]
 
+# include/dbtk_pred.h (the danbing-tk-pred step)
+EXPORTS_PRED = [
+    "dbtk_pred_create", "dbtk_pred_free", "dbtk_pred_create_from_file", "dbtk_pred_nk", "dbtk_pred_ntr", "dbtk_pred_load_samples",
+    "dbtk_pred_correct", "dbtk_pred_matrix", "dbtk_pred_bias", "dbtk_pred_times",
+]
+
+
+class Pred:
+    """include/dbtk_pred.h through ctypes: the cohort matrix in HBM, normalisation and bias correction on the GPU."""
+
+    def __init__(self, lib, ns, nk_cum, nik_cum, iki, ikmc, nk=None, device=0):
+        self._lib = lib
+        L = lib.L
+        L.dbtk_pred_create.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, u32p, u32p, C.c_uint64, u32p, u8p, C.POINTER(C.c_void_p)]
+        L.dbtk_pred_free.argtypes = [C.c_void_p]
+        L.dbtk_pred_free.restype = None
+        L.dbtk_pred_load_samples.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, u64p, C.POINTER(C.c_float)]
+        L.dbtk_pred_correct.argtypes = [C.c_void_p]
+        L.dbtk_pred_matrix.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.dbtk_pred_bias.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.dbtk_pred_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        self.nk_cum = np.ascontiguousarray(nk_cum, np.uint32)
+        self.nik_cum = np.ascontiguousarray(nik_cum, np.uint32)
+        self.iki = np.ascontiguousarray(iki, np.uint32)
+        self.ikmc = np.ascontiguousarray(ikmc, np.uint8)
+        self.ns, self.ntr = int(ns), len(self.nk_cum)
+        self.nk = int(nk if nk is not None else (self.nk_cum[-1] if self.ntr else 0))
+        self.h = C.c_void_p()
+        lib._chk(L.dbtk_pred_create(device, self.ns, self.nk, self.ntr, _ptr(self.nk_cum, u32p), _ptr(self.nik_cum, u32p), len(self.iki),
+                                    _ptr(self.iki, u32p), _ptr(self.ikmc, u8p), C.byref(self.h)))
+
+    def load(self, first, counts, depths):
+        counts = np.ascontiguousarray(counts, np.uint64)
+        depths = np.ascontiguousarray(depths, np.float32)
+        self._lib._chk(self._lib.L.dbtk_pred_load_samples(self.h, first, counts.shape[0], _ptr(counts, u64p), depths.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def correct(self):
+        self._lib._chk(self._lib.L.dbtk_pred_correct(self.h))
+
+    def matrix(self):
+        out = np.empty((self.nk, self.ns), np.float32)
+        self._lib._chk(self._lib.L.dbtk_pred_matrix(self.h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def bias(self):
+        out = np.empty((self.ntr, self.ns), np.float32)
+        self._lib._chk(self._lib.L.dbtk_pred_bias(self.h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def times(self):
+        ms = (C.c_float * 3)()
+        self._lib._chk(self._lib.L.dbtk_pred_times(self.h, ms))
+        return list(ms)
+
+    def close(self):
+        if self.h:
+            self._lib.L.dbtk_pred_free(self.h)
+            self.h = None
+
 
 class Synth:
     """Seeded release-scale workload generator (csrc/dbtk_synth.cpp): a flat
