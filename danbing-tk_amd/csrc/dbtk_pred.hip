@@ -82,23 +82,28 @@ __global__ void __launch_bounds__(256) k_pred_bias_norm(const uint32_t* __restri
     const float mean = part[0] / (float)ns;
     for (uint64_t s = threadIdx.x; s < ns; s += 256) b[s] = b[s] / mean;
 }
-// the correcting pass (pred.h:230): every k-mer column of the locus divided by the locus' bias, sample by sample.  One
-// block per PR_ROWS rows of G (a row = one k-mer, ns floats): streamed once, read and written in place.
+// the correcting pass (pred.h:230): every k-mer column of the locus divided by the locus' bias, sample by sample.  G is
+// streamed once, read and written in place: a wave takes PR_ROWS consecutive rows (a row = one k-mer, ns floats) and walks
+// the samples 64 at a time, so that PR_ROWS independent loads are in flight per lane; loc[k] = the row's locus (NOLOC: left alone).
 constexpr int PR_ROWS = 8;
-__global__ void __launch_bounds__(256) k_pred_correct(float* __restrict__ G, const uint32_t* __restrict__ nk_cum, const uint32_t* __restrict__ nik_cum,
-                                                      const float* __restrict__ bias, uint64_t nk, uint64_t ns, uint32_t ntr) {
-    for (int r = 0; r < PR_ROWS; ++r) {
-        const uint64_t k = (uint64_t)blockIdx.x * PR_ROWS + r;
-        if (k >= nk) return;
-        uint32_t lo = 0, hi = ntr;  // the locus of row k: first tri with nk_cum[tri] > k
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (nk_cum[mid] > k) hi = mid; else lo = mid + 1; }
-        const uint32_t tri = lo;
-        if (tri >= ntr) return;
-        const uint32_t isi = tri ? nik_cum[tri - 1] : 0u, iei = nik_cum[tri];
-        if (isi == iei) continue;
-        float* g = G + k * ns;
-        const float* b = bias + (uint64_t)tri * ns;
-        for (uint64_t s = threadIdx.x; s < ns; s += 256) g[s] = g[s] / b[s];
+constexpr uint32_t NOLOC = 0xFFFFFFFFu;
+__global__ void __launch_bounds__(256) k_pred_correct(float* __restrict__ G, const uint32_t* __restrict__ loc, const float* __restrict__ bias, uint64_t nk, uint64_t ns) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * 4 + w) * PR_ROWS;
+    if (r0 >= nk) return;
+    uint32_t tri[PR_ROWS];
+#pragma unroll
+    for (int r = 0; r < PR_ROWS; ++r) tri[r] = r0 + r < nk ? loc[r0 + r] : NOLOC;
+    for (uint64_t s = lane; s < ns; s += 64) {
+        float g[PR_ROWS], b[PR_ROWS];
+#pragma unroll
+        for (int r = 0; r < PR_ROWS; ++r) {
+            const bool on = tri[r] != NOLOC;
+            g[r] = on ? G[(r0 + r) * ns + s] : 0.f;
+            b[r] = on ? bias[(uint64_t)tri[r] * ns + s] : 1.f;
+        }
+#pragma unroll
+        for (int r = 0; r < PR_ROWS; ++r) if (tri[r] != NOLOC) G[(r0 + r) * ns + s] = g[r] / b[r];
     }
 }
 
@@ -107,7 +112,7 @@ struct dbtk_pred {
     uint64_t ns = 0, nk = 0, ntr = 0, nik = 0;
     float* d_G = nullptr;
     float* d_bias = nullptr;
-    uint32_t *d_nk = nullptr, *d_nik = nullptr, *d_iki = nullptr;
+    uint32_t *d_nk = nullptr, *d_nik = nullptr, *d_iki = nullptr, *d_loc = nullptr;  // d_loc[k]: locus of k-mer k, NOLOC where bias_correction skips it
     float* d_ikmc = nullptr;
     uint64_t* d_counts = nullptr; float* d_depth = nullptr; uint64_t stage_cap = 0;  // staging of dbtk_pred_load_samples
     hipStream_t stream = nullptr;
@@ -136,6 +141,12 @@ dbtk_status_t dbtk_pred_create(int device_id, uint64_t ns, uint64_t nk, uint64_t
     p->device = device_id; p->ns = ns; p->nk = nk; p->ntr = ntr; p->nik = nik;
     std::vector<float> kc(nik);
     for (uint64_t j = 0; j < nik; ++j) kc[j] = (float)ikmc[j];
+    std::vector<uint32_t> loc(nk, NOLOC);  // (k-mers past the last locus' cumulative count belong to no locus, like in the reference's loop)
+    for (uint64_t t = 0; t < ntr; ++t) {
+        const uint32_t a = t ? nk_cum[t - 1] : 0u, b = nk_cum[t], c = t ? nik_cum[t - 1] : 0u, d = nik_cum[t];
+        if (a == b || c == d) continue;
+        for (uint32_t k = a; k < b; ++k) loc[k] = (uint32_t)t;
+    }
     dbtk_status_t st = DBTK_OK;
     auto fail = [&](hipError_t e, const char* what) { set_error(std::string(what) + ": " + hipGetErrorString(e)); st = DBTK_ERR_HIP; };
     hipError_t e;
@@ -146,6 +157,8 @@ dbtk_status_t dbtk_pred_create(int device_id, uint64_t ns, uint64_t nk, uint64_t
     if (!st && (e = hipMalloc(&p->d_nk, ntr * 4)) != hipSuccess) fail(e, "hipMalloc");
     if (!st && (e = hipMalloc(&p->d_nik, ntr * 4)) != hipSuccess) fail(e, "hipMalloc");
     if (!st && (e = hipMalloc(&p->d_iki, (nik + 1) * 4)) != hipSuccess) fail(e, "hipMalloc");
+    if (!st && (e = hipMalloc(&p->d_loc, nk * 4)) != hipSuccess) fail(e, "hipMalloc");
+    if (!st && (e = hipMemcpyAsync(p->d_loc, loc.data(), nk * 4, hipMemcpyHostToDevice, p->stream)) != hipSuccess) fail(e, "hipMemcpy");
     if (!st && (e = hipMalloc(&p->d_ikmc, (nik + 1) * 4)) != hipSuccess) fail(e, "hipMalloc");
     if (!st && (e = hipMemsetAsync(p->d_G, 0, nk * ns * sizeof(float), p->stream)) != hipSuccess) fail(e, "hipMemset");
     if (!st && (e = hipMemsetAsync(p->d_bias, 0, ntr * ns * sizeof(float), p->stream)) != hipSuccess) fail(e, "hipMemset");
@@ -162,7 +175,7 @@ dbtk_status_t dbtk_pred_create(int device_id, uint64_t ns, uint64_t nk, uint64_t
 void dbtk_pred_free(dbtk_pred_t* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    void* ptrs[] = {p->d_G, p->d_bias, p->d_nk, p->d_nik, p->d_iki, p->d_ikmc, p->d_counts, p->d_depth};
+    void* ptrs[] = {p->d_G, p->d_bias, p->d_nk, p->d_nik, p->d_iki, p->d_loc, p->d_ikmc, p->d_counts, p->d_depth};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -233,8 +246,8 @@ dbtk_status_t dbtk_pred_correct(dbtk_pred_t* p) {
     hipLaunchKernelGGL(k_pred_bias_norm, dim3((uint32_t)p->ntr), dim3(256), 0, s, p->d_nk, p->d_nik, p->d_bias, p->ns);
     PCHK(hipGetLastError());
     PCHK(hipEventRecord(p->ev[2], s));
-    const uint64_t nb = (p->nk + PR_ROWS - 1) / PR_ROWS;
-    hipLaunchKernelGGL(k_pred_correct, dim3((uint32_t)nb), dim3(256), 0, s, p->d_G, p->d_nk, p->d_nik, p->d_bias, p->nk, p->ns, (uint32_t)p->ntr);
+    const uint64_t nb = (p->nk + 4 * PR_ROWS - 1) / (4 * PR_ROWS);
+    hipLaunchKernelGGL(k_pred_correct, dim3((uint32_t)nb), dim3(256), 0, s, p->d_G, p->d_loc, p->d_bias, p->nk, p->ns);
     PCHK(hipGetLastError());
     PCHK(hipEventRecord(p->ev[3], s));
     PCHK(hipStreamSynchronize(s));
