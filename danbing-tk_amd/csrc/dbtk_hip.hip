@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(K1_NT, 4) k_encode_subfilter(BatchArgs a) {
 }
 // K2 / K3 are instantiated per NS = 64-position slots a read needs (2: <= 128 positions, 3: 150 bp reads, 4: up to 256 bp)
 #ifndef DBTK_K2_WPE
-#define DBTK_K2_WPE 5  // waves per SIMD the probe kernel's registers are budgeted for (96 VGPRs; 4: 109 VGPRs, 4 % slower; 6: spills, 8 % slower)
+#define DBTK_K2_WPE 4  // waves per SIMD the probe kernel's registers are budgeted for (5: 96 VGPRs but 13 spilled words, 3 % slower; 6: 8 % slower)
 #endif
 template <int NS, bool MZ> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_K2_WPE, 8))) k_probe(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) ProbeSmem sm;

@@ -1367,23 +1367,63 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             st_acc[19] += nruns;
 #endif
         }
-        // ---- look-ups in the plain index: every position (no minimizer-grouped copy), or the positions the home buckets left open
+        // ---- look-ups in the plain index
         uint32_t nl = nk;        // entries of the look-up list in sm.km / sm.hb
-        constexpr bool mapped = MZ;  // list entry e stands for position sm.pm[e] (else: for position e)
+        constexpr bool mapped = MZ;
         if (mapped) {
-            x.sync();
-            nl = 0;
+            // The positions the home buckets left open (about one in ten, clustered): every lane looks its own up, the whole
+            // 64-byte bucket per position (four 16-byte loads of one line), all of a lane's loads in flight together.  No list,
+            // no LDS, no ballots: with a dozen look-ups per read the quad-cooperative form below costs more in instructions
+            // than it saves in requests.
+            bool anyp = false;
 #pragma unroll
-            for (int j = 0; j < NSLOT; ++j) {
-                if ((uint32_t)j >= npl) continue;
-                const uint64_t pb = x.ballot(pend2[j]);
-                if (pend2[j]) {
-                    const uint32_t e = nl + (uint32_t)__builtin_popcountll(pb & ((1ull << lane) - 1));
-                    sm.km[e] = km[j]; sm.hb[e] = (uint32_t)hash_idx(km[j], T.idx_shift); sm.pm[e] = p0 + j;
+            for (int j = 0; j < NSLOT; ++j) anyp |= pend2[j];
+            if (x.ballot(anyp)) {
+                uint4 bw[NSLOT][4];
+                uint32_t hb[NSLOT];
+                auto eval = [&](int j, bool on, bool& more) {  // one bucket against km[j]: result, or "walk on" (full + overflowed, no match)
+                    const uint64_t k0 = ((uint64_t)bw[j][0].y << 32) | bw[j][0].x, k1 = ((uint64_t)bw[j][0].w << 32) | bw[j][0].z;
+                    const uint64_t k2 = ((uint64_t)bw[j][1].y << 32) | bw[j][1].x, k3 = ((uint64_t)bw[j][1].w << 32) | bw[j][1].z;
+                    const uint64_t v0 = ((uint64_t)bw[j][2].y << 32) | bw[j][2].x, v1 = ((uint64_t)bw[j][2].w << 32) | bw[j][2].z;
+                    const uint64_t v2 = ((uint64_t)bw[j][3].y << 32) | bw[j][3].x, v3 = ((uint64_t)bw[j][3].w << 32) | bw[j][3].z;
+                    const uint64_t kq = km[j];
+                    more = false;
+                    if (!on) return;
+                    if (k0 == kq) rvv[j] = v0;
+                    else if (k1 == kq) rvv[j] = v1;
+                    else if (k2 == kq) rvv[j] = v2;
+                    else if ((k3 & ~IDX_OVF) == kq) rvv[j] = v3;
+                    else if (k3 != NAN64 && (k3 & IDX_OVF)) more = true;
+                    else rvv[j] = (uint64_t)NOHIT;
+                };
+#pragma unroll
+                for (int j = 0; j < NSLOT; ++j) {  // the loads, straight-line (a closed lane re-reads bucket 0)
+                    hb[j] = pend2[j] ? (uint32_t)hash_idx(km[j], T.idx_shift) : 0u;
+                    const uint4* bp = reinterpret_cast<const uint4*>(T.idx + hb[j]);
+                    if ((uint32_t)j < npl) { bw[j][0] = bp[0]; bw[j][1] = bp[1]; bw[j][2] = bp[2]; bw[j][3] = bp[3]; }
+                    else { bw[j][0] = bw[j][1] = bw[j][2] = bw[j][3] = uint4{0, 0, 0, 0}; }
                 }
-                nl += (uint32_t)__builtin_popcountll(pb);
+                bool more[NSLOT];
+                bool anym = false;
+#pragma unroll
+                for (int j = 0; j < NSLOT; ++j) { eval(j, pend2[j] && (uint32_t)j < npl, more[j]); anym |= more[j]; }
+                if (x.ballot(anym)) {  // rare (about one look-up in a thousand): walk on, bucket by bucket
+#pragma unroll
+                    for (int j = 0; j < NSLOT; ++j) {
+                        bool mo = more[j];
+                        uint32_t bb = hb[j];
+                        while (x.ballot(mo)) {
+                            bb = (bb + 1) & (uint32_t)T.idx_mask;
+                            const uint4* bp = reinterpret_cast<const uint4*>(T.idx + (mo ? bb : 0u));
+                            bw[j][0] = bp[0]; bw[j][1] = bp[1]; bw[j][2] = bp[2]; bw[j][3] = bp[3];
+                            bool m2 = false;
+                            eval(j, mo, m2);
+                            mo = m2;
+                        }
+                    }
+                }
             }
-            x.sync();
+            nl = 0;
         } else {
         // Stage (k-mer, home bucket) per position in LDS, then look the positions up 16 at a time: the four lanes of a
         // quad read the four 16-byte parts of one bucket (keys 0,1 | keys 2,3 | values 0,1 | values 2,3), so a lookup
@@ -1416,7 +1456,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             }
             return x.ballot(more);
         };
-        // buckets in flight per lane: DBTK_K2_NB when every position is looked up, 2 for the (short) list the home buckets leave
+        // DBTK_K2_NB buckets in flight per lane
         auto lookups = [&](auto nbtag) {
         constexpr int NB = decltype(nbtag)::value;
         for (uint32_t i0 = 0; i0 < nl; i0 += 16 * NB) {
@@ -1460,7 +1500,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             }
         }
         };
-        if (mapped) lookups(std::integral_constant<int, 2>{}); else lookups(std::integral_constant<int, DBTK_K2_NB>{});
+        if (!mapped) lookups(std::integral_constant<int, DBTK_K2_NB>{});
         x.sync();
         {   // the read's results: found positions, and whether they are all unique to one and the same locus
             uint64_t rv[NSLOT];
@@ -1470,7 +1510,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             for (int j = 0; j < NSLOT; ++j) {
                 const uint32_t i = p0 + j;
                 const bool in = (uint32_t)j < npl && i < nk;
-                rv[j] = in ? ((mapped && !pend2[j]) ? rvv[j] : sm.rva[i]) : (uint64_t)NOHIT;
+                rv[j] = in ? (mapped ? rvv[j] : sm.rva[i]) : (uint64_t)NOHIT;
                 const uint32_t v = (uint32_t)rv[j];
                 const uint64_t hmk = x.ballot(v != NOHIT);
                 nh += (uint32_t)__builtin_popcountll(hmk);
