@@ -101,11 +101,6 @@ def kernel_table(ktimes, alg, steps, timed_steps):
         u, g_ = kt.pop("k_pair_usual"), kt.get("k_pair", (0.0, 0))
         kt["k_pair"] = (u[0] + g_[0], max(u[1], g_[1]))
         kt["k_pair: usual-pair part"] = u
-    for part in ("k_encode_bin", "k_filter_bins", "k_subfilter_cand"):
-        if part in kt:
-            t = kt.pop(part)
-            if t[1]:
-                kt[f"k_encode_subfilter: {part}"] = t
     out = {}
     for name, (ms, n) in kt.items():
         if not n:
