@@ -26,8 +26,6 @@
 #ifndef DBTK_KERNELS_H_
 #define DBTK_KERNELS_H_
 
-#include <type_traits>
-
 #include "dbtk_assign.h"
 #include "dbtk_sort.h"
 #include "dbtk_tables.h"
@@ -1072,7 +1070,6 @@ struct ProbeSmem {
             uint64_t km[NKMAX];  // canonical k-mer per list entry (NAN64: window not valid)
             uint32_t hb[NKMAX];  // its home bucket
             uint64_t rva[NKMAX]; // look-up result per POSITION: val | aux << 32 (val = NOHIT: not in the index)
-            uint32_t pm[NKMAX];  // minimizer path: the position a list entry stands for
         };
         struct {  // minimizer-grouped look-ups (T.mz), before the list phase
             uint32_t hm[MAXL + 8];      // hashes of the read's m-mers by base position
@@ -1368,9 +1365,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
 #endif
         }
         // ---- look-ups in the plain index
-        uint32_t nl = nk;        // entries of the look-up list in sm.km / sm.hb
-        constexpr bool mapped = MZ;
-        if (mapped) {
+        if constexpr (MZ) {
             // The positions the home buckets left open (about one in ten, clustered): every lane looks its own up, the whole
             // 64-byte bucket per position (four 16-byte loads of one line), all of a lane's loads in flight together.  No list,
             // no LDS, no ballots: with a dozen look-ups per read the quad-cooperative form below costs more in instructions
@@ -1423,9 +1418,8 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                     }
                 }
             }
-            nl = 0;
         } else {
-        // Stage (k-mer, home bucket) per position in LDS, then look the positions up 16 at a time: the four lanes of a
+        // Every position (no minimizer-grouped copy).  Stage (k-mer, home bucket) per position in LDS, then look the positions up 16 at a time: the four lanes of a
         // quad read the four 16-byte parts of one bucket (keys 0,1 | keys 2,3 | values 0,1 | values 2,3), so a lookup
         // is one request for one 64-byte line and ends in its home bucket unless that bucket is full AND overflowed.
 #pragma unroll
@@ -1434,8 +1428,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             if ((uint32_t)j < npl && i < nk) { sm.km[i] = km[j]; sm.hb[i] = open[j] ? (uint32_t)hash_idx(km[j], T.idx_shift) : 0u; }
         }
         x.sync();
-        }
-        DBTK_STAMP(41);  // windows, hash, staging
+        const uint32_t nl = nk;  // entries of the look-up list in sm.km / sm.hb: one per position
         const uint32_t sub = lane & 3, qd = lane >> 2;
         // One evaluation of a quad's bucket parts against its k-mer: the two key lanes compare, the value lanes' words reach
         // them by DPP; the hit lane stores the result, lane 0 of the quad stores the miss, and `more` says that the quad must
@@ -1456,9 +1449,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             }
             return x.ballot(more);
         };
-        // DBTK_K2_NB buckets in flight per lane
-        auto lookups = [&](auto nbtag) {
-        constexpr int NB = decltype(nbtag)::value;
+        constexpr int NB = DBTK_K2_NB;  // buckets in flight per lane
         for (uint32_t i0 = 0; i0 < nl; i0 += 16 * NB) {
             uint32_t ii[NB], bq[NB];
             uint64_t kq[NB], a0[NB], a1[NB];
@@ -1469,7 +1460,6 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                 // the NB bucket loads are all in flight together (a load under a branch makes the compiler wait for it)
                 const uint32_t ic = ii[u] < nl ? ii[u] : 0u;
                 kq[u] = sm.km[ic]; bq[u] = sm.hb[ic];
-                if (mapped) ii[u] = ii[u] < nl ? sm.pm[ic] : 0xFFFFFFFFu;  // the position the entry stands for
                 if (ii[u] >= nk) { kq[u] = NAN64; bq[u] = 0; }
 #ifdef DBTK_STAMPS
                 if (a.P.diag & 64) bq[u] &= 1023;  // diagnostic: every look-up in the first 64 KB of the table (cache hits)
@@ -1499,8 +1489,8 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                 }
             }
         }
-        };
-        if (!mapped) lookups(std::integral_constant<int, DBTK_K2_NB>{});
+        }
+        DBTK_STAMP(41);  // look-ups in the plain index
         x.sync();
         {   // the read's results: found positions, and whether they are all unique to one and the same locus
             uint64_t rv[NSLOT];
@@ -1510,7 +1500,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             for (int j = 0; j < NSLOT; ++j) {
                 const uint32_t i = p0 + j;
                 const bool in = (uint32_t)j < npl && i < nk;
-                rv[j] = in ? (mapped ? rvv[j] : sm.rva[i]) : (uint64_t)NOHIT;
+                rv[j] = in ? (MZ ? rvv[j] : sm.rva[i]) : (uint64_t)NOHIT;
                 const uint32_t v = (uint32_t)rv[j];
                 const uint64_t hmk = x.ballot(v != NOHIT);
                 nh += (uint32_t)__builtin_popcountll(hmk);

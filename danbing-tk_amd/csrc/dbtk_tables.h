@@ -127,31 +127,15 @@ DBTK_HD uint64_t hash_idx(uint64_t key, uint32_t shift) { return hash_mix(key) >
 // the index, and each such probe costs a 64-byte line of HBM traffic next to the read stream it competes with.  A
 // word-blocked Bloom filter of ~4 bits per key (128 MB at release scale) answers them: "no" is final, "maybe" (the keys
 // themselves plus a few % of the others) goes on to the table, so the answer is exact.  Three bits of one 64-bit word per key.
-// The filter is addressed through a BIJECTIVE mix of the 2k-bit k-mer onto 2k bits (odd multiplications modulo 2^2k and
-// xor-shifts by k are each invertible): the top bits pick the word, so a contiguous range of the filter ("partition") is a
-// contiguous range of mixed values, and a query can travel as the low bits of its mixed value — the binned encode stage packs
-// (mixed value without the partition bits | pair index) into 8 bytes and the filter kernel recovers the k-mer with kunmix.
+// The filter is addressed through a mix of the 2k-bit k-mer onto 2k bits (odd multiplications modulo 2^2k and xor-shifts
+// by k): the top bits pick the word, the low 18 bits its three bit positions.
 constexpr uint64_t KMIX_C1 = 0x9E3779B97F4A7C15ull, KMIX_C2 = 0xD6E8FEB86659FD93ull;
-constexpr uint64_t inv_odd64(uint64_t a) {  // a^-1 modulo 2^64 (Newton: doubles the correct bits per step)
-    uint64_t x = a;
-    for (int i = 0; i < 6; ++i) x *= 2 - a * x;
-    return x;
-}
-constexpr uint64_t KMIX_I1 = inv_odd64(KMIX_C1), KMIX_I2 = inv_odd64(KMIX_C2);
-static_assert(KMIX_C1 * KMIX_I1 == 1 && KMIX_C2 * KMIX_I2 == 1, "modular inverses");
 DBTK_HD uint64_t kmix(uint64_t km, uint32_t k) {  // k <= 31
     const uint64_t M = (1ull << (2 * k)) - 1;
     uint64_t m = (km * KMIX_C1) & M;
     m ^= m >> k;
     m = (m * KMIX_C2) & M;
     return m ^ (m >> k);
-}
-DBTK_HD uint64_t kunmix(uint64_t m, uint32_t k) {
-    const uint64_t M = (1ull << (2 * k)) - 1;
-    m ^= m >> k;
-    m = (m * KMIX_I2) & M;
-    m ^= m >> k;
-    return (m * KMIX_I1) & M;
 }
 // word of a mixed value in a filter of 2^logw words: its top bits
 DBTK_HD uint64_t flt_word(uint64_t m, uint32_t k, uint32_t logw) { return logw <= 2 * k ? m >> (2 * k - logw) : m; }
