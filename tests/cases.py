@@ -74,6 +74,20 @@ def case_k31(tmp):
     return Case(_np_rpgg(tmp, "k31", loci, 31), 31, reads, [dict(cthreshold=40, okam=1)])
 
 
+def case_k31long(tmp):
+    """k = 31 with 250 bp reads: a lane owns four positions, and their windows (31 + 3 bases) do not fit the one 32-base word
+    the probe kernel usually shifts them out of; k = 30 / 29 sit on the boundary.  Includes N (the validity path)."""
+    loci = synth.make_loci(nloci=8, nhap=2, flank=600, seed=31, shared_frac=0.3, tr_min=200, tr_max=1200)
+    reads = synth.sim_reads(loci, npairs=300, rlen=250, frag=(300, 600), seed=32, sub=0.004, nrate=0.001, chimeric=0.1, background=0.1)
+    return Case(_np_rpgg(tmp, "k31long", loci, 31), 31, reads, [dict(cthreshold=60, okam=1)])
+
+
+def case_k30long(tmp):
+    loci = synth.make_loci(nloci=6, nhap=2, flank=600, seed=33, shared_frac=0.3, tr_min=200, tr_max=900)
+    reads = synth.sim_reads(loci, npairs=250, rlen=200, frag=(300, 600), seed=34, sub=0.004, chimeric=0.1, background=0.1)
+    return Case(_np_rpgg(tmp, "k30long", loci, 30), 30, reads, [dict(cthreshold=50, okam=1)])
+
+
 def case_qc(tmp):
     loci = synth.make_loci(nloci=12, nhap=3, flank=500, seed=5)
     pref = _rpgg(tmp, "qc", loci, 21)
@@ -132,7 +146,8 @@ def case_inconsistent(tmp):
     return Case(os.path.join(d, "pan"), 21, reads, [dict(cthreshold=30, okam=1), dict(cthreshold=45, okam=0)])
 
 
-CASES = dict(clean=case_clean, mixed=case_mixed, shared=case_shared, k25=case_k25, k31=case_k31, qc=case_qc, lengths=case_lengths,
+CASES = dict(clean=case_clean, mixed=case_mixed, shared=case_shared, k25=case_k25, k31=case_k31, k31long=case_k31long, k30long=case_k30long,
+             qc=case_qc, lengths=case_lengths,
              kf=case_kf, spill=case_spill, inconsistent=case_inconsistent)
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity soak on the GPU: random RPGGs, read sets and parameters, the HIP path against the oracle
-(records in trace mode, counts / totals / counters without).   python tools/fuzz_parity.py [nseeds] [first_seed]
+(records in trace mode, counts / totals / counters without).   python tools/fuzz_parity.py [nseeds] [first_seed] [k,k,...]
 python tools/fuzz_parity.py walk [nseeds] [first_seed]: the same for the hot loop with threading = 2 (graph walk, exact
 counts, walk results, -a / -ae records)."""
 import importlib
@@ -18,6 +18,7 @@ import cases  # noqa: E402
 import synth  # noqa: E402
 
 abi = bind.pkg.abi
+KSET = []  # optional third argument: the k values to draw from (default: 17 / 21 / 25)
 
 
 def walk_main(argv):
@@ -30,10 +31,10 @@ def walk_main(argv):
     bad = 0
     for seed in range(s0, s0 + n):
         rng = np.random.default_rng(seed)
-        k = int(rng.choice([21, 21, 25, 25, 17]))
+        k = int(rng.choice(KSET if KSET else [21, 21, 25, 25, 17]))
         loci = synth.make_loci(nloci=int(rng.integers(3, 60)), nhap=int(rng.integers(1, 4)), flank=int(rng.integers(300, 700)), seed=seed,
                                shared_frac=float(rng.choice([0.0, 0.2, 0.6])), tr_min=int(rng.integers(40, 200)), tr_max=int(rng.integers(300, 1200)))
-        rlen = int(rng.choice([150, 150, 100, 250, 80]))
+        rlen = int(rng.choice([150, 150, 100, 250, 80] if not KSET else [150, 250, 200, 100]))
         reads = synth.sim_reads(loci, npairs=int(rng.integers(100, 1500)), rlen=rlen, seed=seed + 7, sub=float(rng.choice([0.0, 0.005, 0.02, 0.05])),
                                 indel=float(rng.choice([0.0, 0.002, 0.01])), nrate=float(rng.choice([0.0, 0.003])),
                                 chimeric=float(rng.choice([0.0, 0.2])), background=float(rng.choice([0.0, 0.2])), frag=(max(300, rlen), max(320, rlen) + 250))
@@ -74,6 +75,9 @@ def walk_main(argv):
 
 
 def main():
+    global KSET
+    if len(sys.argv) > 1 and "," in sys.argv[-1] or (len(sys.argv) > 3 and sys.argv[-1].isdigit() and sys.argv[1] != "walk") or (len(sys.argv) > 4 and sys.argv[-1].isdigit()):
+        KSET = [int(v) for v in sys.argv.pop().split(",")]
     if len(sys.argv) > 1 and sys.argv[1] == "walk":
         return walk_main(sys.argv[2:])
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
@@ -82,10 +86,10 @@ def main():
     bad = 0
     for seed in range(s0, s0 + n):
         rng = np.random.default_rng(seed)
-        k = int(rng.choice([21, 21, 21, 17, 25]))
+        k = int(rng.choice(KSET if KSET else [21, 21, 21, 17, 25]))
         loci = synth.make_loci(nloci=int(rng.integers(3, 40)), nhap=int(rng.integers(1, 4)), flank=int(rng.integers(300, 700)), seed=seed,
                                shared_frac=float(rng.choice([0.0, 0.2, 0.6, 1.0])), tr_min=int(rng.integers(40, 200)), tr_max=int(rng.integers(300, 1200)))
-        rlen = int(rng.choice([150, 150, 100, 250, 64]))
+        rlen = int(rng.choice([150, 150, 100, 250, 64] if not KSET else [150, 250, 200, 100]))
         reads = synth.sim_reads(loci, npairs=int(rng.integers(50, 900)), rlen=rlen, seed=seed + 7, sub=float(rng.choice([0.0, 0.005, 0.03])),
                                 indel=float(rng.choice([0.0, 0.002])), nrate=float(rng.choice([0.0, 0.003, 0.02])),
                                 chimeric=float(rng.choice([0.0, 0.3])), background=float(rng.choice([0.0, 0.3])), frag=(max(300, rlen), max(320, rlen) + 250))
