@@ -194,7 +194,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ranks_seen = 1
-    if world > 1:
+    # the collective path (RCCL process group, barrier, all-reduce of the accumulators): with more than one rank — or, to
+    # exercise exactly that code on a one-GPU box, under a launcher with DBTK_BENCH_FORCE_DIST=1 (a world of one)
+    use_dist = world > 1 or (os.environ.get("DBTK_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
         ranks_seen = dist.get_world_size()
 
@@ -261,7 +264,7 @@ def main():
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     acc_ptr, acc_n = ctx.accum_buffer()
     acc_t, acc_inplace = None, False
-    if world > 1:
+    if use_dist:
         try:  # a tensor over the context's accumulator itself: the reduce then needs no staging copies
             class _Acc:
                 __cuda_array_interface__ = {"shape": (acc_n,), "typestr": "<i8", "data": (acc_ptr, False), "version": 2}
@@ -273,7 +276,7 @@ def main():
             acc_t = torch.empty(acc_n, dtype=torch.int64, device=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -282,7 +285,7 @@ def main():
 
     def reduce_counts():
         """The one exchange of the path: sum of the per-GPU accumulators over xGMI."""
-        if world == 1:
+        if not use_dist:
             return
         ctx.synchronize()
         if not acc_inplace:
@@ -313,7 +316,7 @@ def main():
     ktimes = ctx.kernel_times()      # HIP events recorded inside the timed region, read after it
     if world == 1:
         local_ctr = ctx.counters()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -515,7 +518,7 @@ def main():
             "two_lanes": two_lanes, "bench_wall_s": time.time() - t_start,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -32,6 +32,6 @@ def allreduce_accum(t, group=None):
     """Sum an int64 torch tensor holding the accumulator buffer over all ranks.
     Two's-complement int64 adds wrap exactly like the reference's uint64 adds."""
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():  # (also with one rank: the same RCCL call, a copy onto itself)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
