@@ -710,7 +710,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
 
 extern "C" {
 
-dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int device_id, dbtk_ctx_t** out) {
+static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_params_t* p, int device_id, dbtk_ctx_t** out) {
     if (!h || !p || !out) { set_error("null argument"); return DBTK_ERR_ARG; }
     *out = nullptr;
     if (p->ksize != h->ksize) { set_error("params.ksize differs from the RPGG's k"); return DBTK_ERR_ARG; }
@@ -867,7 +867,7 @@ dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int 
 
 void dbtk_ctx_free(dbtk_ctx_t* ctx) { free_ctx(ctx); }
 
-dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t* off, const uint8_t* qual,
+static dbtk_status_t dbtk_align_batch_impl(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t* off, const uint8_t* qual,
                                uint64_t npairs, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
     if (!c || !off || (!seq && npairs)) { set_error("null argument"); return DBTK_ERR_ARG; }
     if (nrec) *nrec = 0;
@@ -1014,7 +1014,7 @@ dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t
 }
 
 // Function-level entry of the graph walk (tests, and callers that want isThreadFeasible alone).
-dbtk_status_t dbtk_thread_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t* off, const uint32_t* loci, uint64_t nreads,
+static dbtk_status_t dbtk_thread_batch_impl(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t* off, const uint32_t* loci, uint64_t nreads,
                                 dbtk_thread_rec_t* recs) {
     if (!c || !off || !loci || !recs || (!seq && nreads)) { set_error("null argument"); return DBTK_ERR_ARG; }
     if (!c->d_gr) { set_error("the RPGG handle holds no graph (DBTK_LOAD_GRAPH)"); return DBTK_ERR_ARG; }
@@ -1051,7 +1051,7 @@ dbtk_status_t dbtk_thread_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_
 }
 
 // What the walk decided for the pairs of the last host-buffer batch that reached threading, in pair order.
-dbtk_status_t dbtk_ctx_walk_results(dbtk_ctx_t* c, dbtk_walk_res_t* res, dbtk_thread_rec_t* trecs, uint64_t cap, uint64_t* n) {
+static dbtk_status_t dbtk_ctx_walk_results_impl(dbtk_ctx_t* c, dbtk_walk_res_t* res, dbtk_thread_rec_t* trecs, uint64_t cap, uint64_t* n) {
     if (!c || !n) { set_error("null argument"); return DBTK_ERR_ARG; }
     *n = 0;
     if (!c->last_walk_npairs) return DBTK_OK;
@@ -1081,7 +1081,7 @@ dbtk_status_t dbtk_ctx_walk_results(dbtk_ctx_t* c, dbtk_walk_res_t* res, dbtk_th
 }
 
 // -a / -ae: the compact alignment records of the last host-buffer batch, invalid slots dropped, pair order.
-dbtk_status_t dbtk_ctx_aln_records(dbtk_ctx_t* c, void* buf, uint64_t buf_bytes, uint64_t* nrec, uint32_t* stride, uint32_t* cap) {
+static dbtk_status_t dbtk_ctx_aln_records_impl(dbtk_ctx_t* c, void* buf, uint64_t buf_bytes, uint64_t* nrec, uint32_t* stride, uint32_t* cap) {
     if (!c || !nrec || !stride || !cap) { set_error("null argument"); return DBTK_ERR_ARG; }
     *nrec = 0; *stride = c->aln_stride; *cap = c->aln_cap;
     if (!c->aln_max || !c->d_aln) return DBTK_OK;
@@ -1207,7 +1207,7 @@ dbtk_status_t dbtk_ctx_reset(dbtk_ctx_t* c) {
 // OUT.bub.kmdb: dumpBubbles -> dumpKmerMapDB("bub", ..., th = 5) (src/aQueryFasta_thread.h:999-1008):
 // flattenKmapDB keeps the entries with count >= 5 in map iteration order (src/binaryKmerIO.hpp:31-51), then
 // serializeKmapDB writes u64 nloci | u64 index[nloci] | u64 nk | u64 sizeof(val) = 8 | u64 ks[nk] | u64 vs[nk].
-dbtk_status_t dbtk_ctx_write_bubbles(dbtk_ctx_t* c, const char* out_prefix) {
+static dbtk_status_t dbtk_ctx_write_bubbles_impl(dbtk_ctx_t* c, const char* out_prefix) {
     if (!c || !out_prefix) { set_error("null argument"); return DBTK_ERR_ARG; }
     if (!c->P.bubbles) { set_error("context was not created with params.bubbles"); return DBTK_ERR_ARG; }
     const uint64_t nloci = c->g->nloci;
@@ -1231,7 +1231,7 @@ dbtk_status_t dbtk_ctx_write_bubbles(dbtk_ctx_t* c, const char* out_prefix) {
 
 // OUT.btk.kmdb: dumpBaitKmerHits -> dumpKmerMapDB("btk", ..., th = 0) (src/aQueryFasta_thread.h:998-1012): every entry, map iteration
 // order, serializeKmapDB layout u64 nloci | u64 index[nloci] | u64 nk | u64 sizeof(val) = 8 | u64 ks[nk] | u64 vs[nk].
-dbtk_status_t dbtk_ctx_write_bait_hits(dbtk_ctx_t* c, const char* out_prefix) {
+static dbtk_status_t dbtk_ctx_write_bait_hits_impl(dbtk_ctx_t* c, const char* out_prefix) {
     if (!c || !out_prefix) { set_error("null argument"); return DBTK_ERR_ARG; }
     if (!c->P.trackbait) { set_error("context was not created with params.trackbait"); return DBTK_ERR_ARG; }
     const uint64_t nloci = c->g->nloci;
@@ -1351,6 +1351,31 @@ dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n) {
     }
     if (rc) { set_error("ncclAllReduce failed"); return DBTK_ERR_HIP; }
     return DBTK_OK;
+}
+
+// ---- the entry points above that parse files or allocate host memory, behind the exception barrier (dbtk_internal.h: guarded)
+dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int device_id, dbtk_ctx_t** out) {
+    return dbtk::guarded([&] { return dbtk_ctx_create_impl(h, p, device_id, out); });
+}
+dbtk_status_t dbtk_align_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t* off, const uint8_t* qual,
+                               uint64_t npairs, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
+    return dbtk::guarded([&] { return dbtk_align_batch_impl(c, seq, off, qual, npairs, recs, rec_cap, nrec); });
+}
+dbtk_status_t dbtk_thread_batch(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t* off, const uint32_t* loci, uint64_t nreads,
+                                dbtk_thread_rec_t* recs) {
+    return dbtk::guarded([&] { return dbtk_thread_batch_impl(c, seq, off, loci, nreads, recs); });
+}
+dbtk_status_t dbtk_ctx_walk_results(dbtk_ctx_t* c, dbtk_walk_res_t* res, dbtk_thread_rec_t* trecs, uint64_t cap, uint64_t* n) {
+    return dbtk::guarded([&] { return dbtk_ctx_walk_results_impl(c, res, trecs, cap, n); });
+}
+dbtk_status_t dbtk_ctx_aln_records(dbtk_ctx_t* c, void* buf, uint64_t buf_bytes, uint64_t* nrec, uint32_t* stride, uint32_t* cap) {
+    return dbtk::guarded([&] { return dbtk_ctx_aln_records_impl(c, buf, buf_bytes, nrec, stride, cap); });
+}
+dbtk_status_t dbtk_ctx_write_bubbles(dbtk_ctx_t* c, const char* out_prefix) {
+    return dbtk::guarded([&] { return dbtk_ctx_write_bubbles_impl(c, out_prefix); });
+}
+dbtk_status_t dbtk_ctx_write_bait_hits(dbtk_ctx_t* c, const char* out_prefix) {
+    return dbtk::guarded([&] { return dbtk_ctx_write_bait_hits_impl(c, out_prefix); });
 }
 
 }  // extern "C"

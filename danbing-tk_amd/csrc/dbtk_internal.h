@@ -4,6 +4,8 @@
 
 #include <stdint.h>
 
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -34,6 +36,14 @@ struct dbtk_rpgg {
 namespace dbtk {
 void set_error(const std::string& msg);
 dbtk_status_t finish_rpgg(dbtk_rpgg* g);  // validation + output order
+// No exception crosses the C-ABI: an entry point that parses files or allocates host memory runs its body through this
+// (a count field of a damaged file can ask for terabytes: std::bad_alloc / std::length_error become status codes).
+template <class F> dbtk_status_t guarded(F&& f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc&) { set_error("out of host memory (a damaged file, or a batch too large for this host)"); return DBTK_ERR_NOMEM; }
+    catch (const std::exception& e) { set_error(std::string("internal error: ") + e.what()); return DBTK_ERR_FORMAT; }
+    catch (...) { set_error("internal error"); return DBTK_ERR_FORMAT; }
+}
 }  // namespace dbtk
 
 #endif

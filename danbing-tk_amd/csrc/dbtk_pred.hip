@@ -122,7 +122,7 @@ struct dbtk_pred {
 
 extern "C" {
 
-dbtk_status_t dbtk_pred_create(int device_id, uint64_t ns, uint64_t nk, uint64_t ntr, const uint32_t* nk_cum, const uint32_t* nik_cum,
+static dbtk_status_t dbtk_pred_create_impl(int device_id, uint64_t ns, uint64_t nk, uint64_t ntr, const uint32_t* nk_cum, const uint32_t* nik_cum,
                                uint64_t nik, const uint32_t* iki, const uint8_t* ikmc, dbtk_pred_t** out) {
     if (!out || !nk_cum || !nik_cum || (nik && (!iki || !ikmc))) { set_error("null argument"); return DBTK_ERR_ARG; }
     *out = nullptr;
@@ -182,7 +182,7 @@ void dbtk_pred_free(dbtk_pred_t* p) {
     delete p;
 }
 
-dbtk_status_t dbtk_pred_create_from_file(int device_id, uint64_t ns, const char* ikmer_meta, dbtk_pred_t** out) {
+static dbtk_status_t dbtk_pred_create_from_file_impl(int device_id, uint64_t ns, const char* ikmer_meta, dbtk_pred_t** out) {
     if (!ikmer_meta || !out) { set_error("null argument"); return DBTK_ERR_ARG; }
     *out = nullptr;
     FILE* f = fopen(ikmer_meta, "rb");
@@ -210,7 +210,7 @@ dbtk_status_t dbtk_pred_create_from_file(int device_id, uint64_t ns, const char*
 uint64_t dbtk_pred_nk(const dbtk_pred_t* p) { return p ? p->nk : 0; }
 uint64_t dbtk_pred_ntr(const dbtk_pred_t* p) { return p ? p->ntr : 0; }
 
-dbtk_status_t dbtk_pred_load_samples(dbtk_pred_t* p, uint64_t first_sample, uint64_t n, const uint64_t* counts, const float* read_depth) {
+static dbtk_status_t dbtk_pred_load_samples_impl(dbtk_pred_t* p, uint64_t first_sample, uint64_t n, const uint64_t* counts, const float* read_depth) {
     if (!p || !counts || !read_depth) { set_error("null argument"); return DBTK_ERR_ARG; }
     if (first_sample + n > p->ns || n > 0xFFFFFFFFull) { set_error("sample range outside the cohort"); return DBTK_ERR_ARG; }
     if (!n) return DBTK_OK;
@@ -271,6 +271,18 @@ dbtk_status_t dbtk_pred_times(dbtk_pred_t* p, float ms[3]) {
     if (!p || !ms) { set_error("null argument"); return DBTK_ERR_ARG; }
     for (int i = 0; i < 3; ++i) ms[i] = p->ms[i];
     return DBTK_OK;
+}
+
+// ---- the entry points above that parse files or allocate host memory, behind the exception barrier (dbtk_internal.h: guarded)
+dbtk_status_t dbtk_pred_create(int device_id, uint64_t ns, uint64_t nk, uint64_t ntr, const uint32_t* nk_cum, const uint32_t* nik_cum,
+                               uint64_t nik, const uint32_t* iki, const uint8_t* ikmc, dbtk_pred_t** out) {
+    return dbtk::guarded([&] { return dbtk_pred_create_impl(device_id, ns, nk, ntr, nk_cum, nik_cum, nik, iki, ikmc, out); });
+}
+dbtk_status_t dbtk_pred_create_from_file(int device_id, uint64_t ns, const char* ikmer_meta, dbtk_pred_t** out) {
+    return dbtk::guarded([&] { return dbtk_pred_create_from_file_impl(device_id, ns, ikmer_meta, out); });
+}
+dbtk_status_t dbtk_pred_load_samples(dbtk_pred_t* p, uint64_t first_sample, uint64_t n, const uint64_t* counts, const float* read_depth) {
+    return dbtk::guarded([&] { return dbtk_pred_load_samples_impl(p, first_sample, n, counts, read_depth); });
 }
 
 }  // extern "C"

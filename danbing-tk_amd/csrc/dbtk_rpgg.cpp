@@ -241,7 +241,7 @@ bool file_exists(const std::string& fn) { FILE* f = fopen(fn.c_str(), "rb"); if 
 
 extern "C" {
 
-dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_file, const char* bait_file,
+static dbtk_status_t dbtk_rpgg_load_impl(const char* prefix, uint32_t ksize, const char* qc_file, const char* bait_file,
                              uint32_t flags, dbtk_rpgg_t** out) {
     if (!prefix || !out) { set_error("null argument"); return DBTK_ERR_ARG; }
     *out = nullptr;
@@ -360,7 +360,7 @@ dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_
     return DBTK_OK;
 }
 
-dbtk_status_t dbtk_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a, dbtk_rpgg_t** out) {
+static dbtk_status_t dbtk_rpgg_from_arrays_impl(const dbtk_rpgg_arrays_t* a, dbtk_rpgg_t** out) {
     if (!a || !out || !a->tr_cnt || !a->fl_cnt) { set_error("null argument"); return DBTK_ERR_ARG; }
     *out = nullptr;
     std::unique_ptr<dbtk_rpgg> g(new dbtk_rpgg);
@@ -492,7 +492,7 @@ void dbtk_params_default(dbtk_params_t* p) {  // src/aQueryFasta_thread.cpp:26-3
 // `ktools serialize` (src/kmertools.cpp:221-345).  The byte layout of the three outputs depends on the iteration order of
 // the reference's std::unordered_map<size_t, size_t> / std::unordered_set<uint64_t>; the same containers filled in the
 // same order iterate in the same order, so they are used as such.
-dbtk_status_t dbtk_rpgg_serialize(const char* prefix) {
+static dbtk_status_t dbtk_rpgg_serialize_impl(const char* prefix) {
     if (!prefix) { set_error("null argument"); return DBTK_ERR_ARG; }
     const std::string pref(prefix);
     // text k-mer file -> (locus index, first field) per line, in file order
@@ -575,7 +575,7 @@ dbtk_status_t dbtk_rpgg_serialize(const char* prefix) {
     return DBTK_OK;
 }
 
-dbtk_status_t dbtk_write_outputs(const dbtk_rpgg_t* h, const uint64_t* counts, const uint64_t* kmc,
+static dbtk_status_t dbtk_write_outputs_impl(const dbtk_rpgg_t* h, const uint64_t* counts, const uint64_t* kmc,
                                  const uint32_t* nmapread, const char* out_prefix, int with_names) {
     if (!h || !counts || !out_prefix) { set_error("null argument"); return DBTK_ERR_ARG; }
     const std::string pref(out_prefix);
@@ -602,6 +602,22 @@ dbtk_status_t dbtk_write_outputs(const dbtk_rpgg_t* h, const uint64_t* counts, c
             fprintf(f.f, "%u\t%llu\n", nmapread[l], (unsigned long long)kmc[l]);
     }
     return DBTK_OK;
+}
+
+// ---- the entry points above that parse files or allocate host memory, behind the exception barrier (dbtk_internal.h: guarded)
+dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_file, const char* bait_file,
+                             uint32_t flags, dbtk_rpgg_t** out) {
+    return dbtk::guarded([&] { return dbtk_rpgg_load_impl(prefix, ksize, qc_file, bait_file, flags, out); });
+}
+dbtk_status_t dbtk_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a, dbtk_rpgg_t** out) {
+    return dbtk::guarded([&] { return dbtk_rpgg_from_arrays_impl(a, out); });
+}
+dbtk_status_t dbtk_rpgg_serialize(const char* prefix) {
+    return dbtk::guarded([&] { return dbtk_rpgg_serialize_impl(prefix); });
+}
+dbtk_status_t dbtk_write_outputs(const dbtk_rpgg_t* h, const uint64_t* counts, const uint64_t* kmc,
+                                 const uint32_t* nmapread, const char* out_prefix, int with_names) {
+    return dbtk::guarded([&] { return dbtk_write_outputs_impl(h, counts, kmc, nmapread, out_prefix, with_names); });
 }
 
 }  // extern "C"

@@ -83,6 +83,29 @@ def test_load_errors(lib, tmp_path):
     assert e.value.status == abi.ERR_IO
 
 
+def test_damaged_count_field_is_a_status_not_a_crash(lib, tmp_path):
+    """A count field of a damaged file can ask for exabytes: the loaders answer with a status code (no exception crosses the
+    C-ABI, the process lives on)."""
+    import shutil
+    import struct
+    c = cases.make_case("clean", str(tmp_path))
+    d = os.path.dirname(c.prefix)
+    for fn, patch in (("fl.kdb", lambda b: b[:8] + struct.pack("<Q", 1 << 60) + b[16:8 + 8 * struct.unpack("<Q", b[:8])[0]]
+                                 + struct.pack("<Q", (1 << 60) + sum(struct.unpack("<%dQ" % (struct.unpack("<Q", b[:8])[0] - 1), b[16:8 + 8 * struct.unpack("<Q", b[:8])[0]])))),
+                      ("kmers.dbi", lambda b: struct.pack("<Q", 1 << 59) + b[8:])):
+        bad = os.path.join(str(tmp_path), "bad_" + fn.replace(".", "_"))
+        shutil.copytree(d, bad)
+        pref = os.path.join(bad, os.path.basename(c.prefix))
+        raw = open(pref + "." + fn, "rb").read()
+        open(pref + "." + fn, "wb").write(patch(raw))
+        with pytest.raises(pkg.DbtkError) as e:
+            lib.load(pref, c.k)
+        assert e.value.status in (abi.ERR_NOMEM, abi.ERR_IO, abi.ERR_FORMAT), e.value
+    g = lib.load(c.prefix, c.k)   # and the library still works
+    assert g.nloci > 0
+    g.close()
+
+
 def test_no_cpu_fallback(lib):
     """Without a HIP device the product refuses to create a context."""
     import torch
