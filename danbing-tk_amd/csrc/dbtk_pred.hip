@@ -137,8 +137,6 @@ static dbtk_status_t dbtk_pred_create_impl(int device_id, uint64_t ns, uint64_t 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device (the library has no CPU path)"); return DBTK_ERR_NO_DEVICE; }
     if (device_id < 0 || device_id >= ndev) { set_error("device_id out of range"); return DBTK_ERR_ARG; }
     PCHK(hipSetDevice(device_id));
-    dbtk_pred* p = new dbtk_pred;
-    p->device = device_id; p->ns = ns; p->nk = nk; p->ntr = ntr; p->nik = nik;
     std::vector<float> kc(nik);
     for (uint64_t j = 0; j < nik; ++j) kc[j] = (float)ikmc[j];
     std::vector<uint32_t> loc(nk, NOLOC);  // (k-mers past the last locus' cumulative count belong to no locus, like in the reference's loop)
@@ -147,6 +145,8 @@ static dbtk_status_t dbtk_pred_create_impl(int device_id, uint64_t ns, uint64_t 
         if (a == b || c == d) continue;
         for (uint32_t k = a; k < b; ++k) loc[k] = (uint32_t)t;
     }
+    dbtk_pred* p = new dbtk_pred;  // (after the host-side vectors: nothing below throws)
+    p->device = device_id; p->ns = ns; p->nk = nk; p->ntr = ntr; p->nik = nik;
     dbtk_status_t st = DBTK_OK;
     auto fail = [&](hipError_t e, const char* what) { set_error(std::string(what) + ": " + hipGetErrorString(e)); st = DBTK_ERR_HIP; };
     hipError_t e;
