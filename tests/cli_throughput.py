@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end command line: this CLI (GPU) next to the reference binary (its pthread CPU path, -p = host cores) on the same
 FASTA and the same on-disk RPGG.  Needs oracle/_ref (built in the container, travels to the GPU box) and a GPU.
-    python tools/cli_throughput.py [nloci] [npairs] [hit_frac]
+    python tests/cli_throughput.py [nloci] [npairs] [hit_frac]
 Prints reads/s of both and checks that OUT.trkmc.ar / stdout are byte-identical."""
 import ctypes as C
 import importlib

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak on the GPU: random RPGGs, read sets and parameters, the HIP path against the oracle
-(records in trace mode, counts / totals / counters without).   python tools/fuzz_parity.py [nseeds] [first_seed] [k,k,...]
-python tools/fuzz_parity.py walk [nseeds] [first_seed]: the same for the hot loop with threading = 2 (graph walk, exact
+(records in trace mode, counts / totals / counters without).   python tests/fuzz_parity.py [nseeds] [first_seed] [k,k,...]
+python tests/fuzz_parity.py walk [nseeds] [first_seed]: the same for the hot loop with threading = 2 (graph walk, exact
 counts, walk results, -a / -ae records)."""
 import importlib
 import os
@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # (this file lives there: it drives the oracle, which only tests may do)
 import bind  # noqa: E402
 import cases  # noqa: E402
 import synth  # noqa: E402

@@ -344,21 +344,21 @@ def test_survivor_chunks_on_device(dbtk, oracle, tmp_path, monkeypatch):
 
 
 def test_randomised_parity_soak():
-    """tools/fuzz_parity.py: random RPGGs (k 17/21/25, shared flanks), read sets (64-250 bp, substitutions, indels, N, chimeras,
+    """tests/fuzz_parity.py: random RPGGs (k 17/21/25, shared flanks), read sets (64-250 bp, substitutions, indels, N, chimeras,
     background) and parameters; trace records and counts against the oracle.  (600 seeds were run when this was added.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "16", "900"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "16", "900"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
 
 
 def test_randomised_walk_parity_soak():
-    """tools/fuzz_parity.py walk: random RPGGs with their graphs (text / .umap loaders alternating), read sets with errors of every
+    """tests/fuzz_parity.py walk: random RPGGs with their graphs (text / .umap loaders alternating), read sets with errors of every
     kind, random thread_cth / correction / maxncorrection / -a / -ae; counts, totals, walk results and alignment records against
     the oracle.  (40 further seeds, 5000-5039, were run when this was added.)"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "walk", "10", "6000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "walk", "10", "6000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
 
 

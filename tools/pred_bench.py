@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the danbing-tk-pred kernels on one MI355X (include/dbtk_pred.h): a synthetic cohort of ns samples over an
 RPGG of ntr loci x kpl k-mers, a tenth of them invariant.  Prints the kernel times and their HBM rates (algorithmic bytes:
-bias sums 4 B per (invariant k-mer, sample); correction 8 B per matrix entry, read + write) next to numpy on the host.
+bias sums 4 B per (invariant k-mer, sample); correction 8 B per matrix entry, read + write).
     python tools/pred_bench.py [ns] [ntr] [kpl]"""
 import importlib
 import os
@@ -12,7 +12,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 pkg = importlib.import_module("danbing-tk_amd")
 
 
@@ -43,13 +42,6 @@ def main():
     print(f"cohort {ns} samples x {nk} k-mers ({4 * nk * ns / 1e9:.2f} GB matrix), {ntr} loci, {len(iki)} invariant k-mers; load (host RNG + PCIe) {t_load:.1f}s")
     print(f"k_pred_bias {ms[0]:.3f} ms = {bytes_bias / ms[0] / 1e6:.0f} GB/s   k_pred_bias_norm {ms[1]:.3f} ms   "
           f"k_pred_correct {ms[2]:.3f} ms = {bytes_cor / ms[2] / 1e6:.0f} GB/s ({bytes_cor / ms[2] / 1e6 / 8000:.1%} of 8 TB/s)")
-    if ns * nk <= 3e8:  # numpy on the host, same arithmetic
-        import pred_oracle as PO
-        raw = P.matrix()
-        meta = dict(ntr=ntr, nk_cum=nk_cum, nik_cum=nik_cum, iki=iki, ikmc=ikmc)
-        t0 = time.time()
-        PO.bias_correction(raw, meta)
-        print(f"oracle (numpy, 1 core): {time.time() - t0:.1f}s")
     P.close()
 
 
