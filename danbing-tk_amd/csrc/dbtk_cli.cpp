@@ -52,7 +52,7 @@ namespace {
 struct Opts {
     bool bait = false, aug = false, threading = false, tc = false, aln = false, aln_minimal = false, okam = true, g2pan = false;
     bool writeKmerName = false, outputBubbles = false, invkmer = false, isFastq = false, trackBait = false, qc = false;
-    int simmode = 0, extractFastX = 0, verbosity = 0, ngpus = 1, gzLevel = 1, emitThreads = 0;
+    int simmode = 0, extractFastX = 0, verbosity = 0, ngpus = 1, gzLevel = 1, emitThreads = 0, ingestShards = 0;
     bool correction = true;
     bool parseOnly = false;  // --parse-only: run the ingest (reader, splitters, pairing) and report what it handed on; no GPU
     bool v13 = false;       // --v13-threading: -g/-gc/-gcc run the graph walk of the v1.3 contract instead of HEAD's dead path
@@ -91,6 +91,8 @@ void usage() {
             "                         TR k-mers are then counted in \"exact\" mode and -a / -ae print alignment records on stdout\n"
             "  --aln-gz <FILE>        write the -a / -ae records gzip-compressed to FILE (deflated on --emit-threads host threads\n"
             "                         while the GPU works on the next batches) instead of plain text on stdout\n"
+            "  --ingest-shards <INT>  cut a seekable input file into this many byte ranges, each read, split and paired by its own\n"
+            "                         pipeline with its own context (tables are shared per GPU) [the number of GPUs]\n"
             "  --emit-threads <INT>   host threads formatting / compressing records [cores / 2]\n"
             "  --gz-level <INT>       zlib level of --aln-gz [1: measured 40x less deflate time than gzip's default 6 for 16 %% more bytes]\n"
             "Developer:\n"
@@ -307,6 +309,7 @@ int main(int argc, char* argv[]) {
         else if (a == "--parse-only") o.parseOnly = true;
         else if (a == "--aln-gz") o.alnGz = need(++argi);
         else if (a == "--emit-threads") o.emitThreads = atoi(need(++argi).c_str());
+        else if (a == "--ingest-shards") o.ingestShards = atoi(need(++argi).c_str());
         else if (a == "--gz-level") o.gzLevel = atoi(need(++argi).c_str());
         else {
             fprintf(stderr, "invalid option: %s\n", a.c_str());
@@ -494,6 +497,7 @@ int main(int argc, char* argv[]) {
     // that found no partner (mates on either side of a cut, singletons) are collected and paired across ranges at the end,
     // in range order — for titles that occur at most twice this is exactly the single reader's outcome.
     struct Left { std::string title, seq, qual; };
+    int npipes = 1;  // ingest pipelines running side by side (set once the ranges are known)
     auto run_shard = [&](const int shard, const int gpu0, const int ngpu_here, const uint64_t lo, const uint64_t hi, std::vector<Left>& leftovers) {
     Reader in;
     in.f = fopen(o.fastxFname.c_str(), "rb");
@@ -573,7 +577,7 @@ int main(int argc, char* argv[]) {
         }
         return BlockP(new Block);
     };
-    const int nsplit = (int)std::min(16u, std::max(2u, hw / 8 / (unsigned)std::max(1, o.ngpus / ngpu_here)));
+    const int nsplit = (int)std::min(16u, std::max(2u, hw / 8 / (unsigned)std::max(1, npipes)));  // (the pipelines share the host's threads)
     raw.cap = split.cap = 2 * (size_t)nsplit;
     const size_t L = fq ? 4 : 2;
     // A0 as two threads, so that the copy out of the page cache and the newline count overlap: `io` freads fixed-size
@@ -891,15 +895,16 @@ int main(int argc, char* argv[]) {
         struct stat sb;
         uint64_t min_size = 64u << 20;  // below this one pipeline is as good
         if (const char* e = getenv("DBTK_SHARD_MIN")) min_size = strtoull(e, nullptr, 10);  // (tests)
-        if (o.ngpus > 1 && !o.simmode && stat(o.fastxFname.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size > min_size) {
+        const int want = std::max(o.ngpus, o.ingestShards);  // ranges asked for: one per GPU, or more (--ingest-shards)
+        if (want > 1 && !o.simmode && stat(o.fastxFname.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size > min_size) {
             const uint64_t size = (uint64_t)sb.st_size;
             FILE* f = fopen(o.fastxFname.c_str(), "rb");
             std::vector<uint64_t> c{0};
             std::vector<char> buf(1 << 20);
-            for (int i = 1; f && i < o.ngpus; ++i) {
+            for (int i = 1; f && i < want; ++i) {
                 // the first record start at or after size * i / N: a line that begins with '>' (2-line FASTA: sequence lines never do),
                 // or — FASTQ, where a quality line may begin with '@' — a line beginning with '@' whose second next line begins with '+'
-                uint64_t at = size / o.ngpus * i;
+                uint64_t at = size / want * i;
                 if (fseeko(f, (off_t)at, SEEK_SET)) break;
                 const size_t n = fread(buf.data(), 1, buf.size(), f);
                 size_t p = 0, found = n;
@@ -919,10 +924,18 @@ int main(int argc, char* argv[]) {
                 c.push_back(at + found);
             }
             if (f) fclose(f);
-            if ((int)c.size() == o.ngpus) { c.push_back(size); cuts = c; }
+            if ((int)c.size() == want) { c.push_back(size); cuts = c; }
         }
     }
     const int nshards = (int)cuts.size() - 1;
+    npipes = nshards;
+    // more ranges than GPUs: range i gets a context of its own on GPU i % ngpus (the contexts of a GPU share its tables;
+    // an aligner thread and its context belong together: dbtk_align_batch is re-entrant per context, not within one)
+    if (!o.parseOnly)
+        for (int i = (int)ctx.size(); i < nshards; ++i) {
+            ctx.push_back(nullptr);
+            if (dbtk_ctx_create(rpgg, &P, i % o.ngpus, &ctx[i])) die_assert(dbtk_last_error());
+        }
     std::vector<std::vector<Left>> lefts(nshards);
     {
         std::vector<std::thread> shards;
@@ -993,10 +1006,22 @@ int main(int argc, char* argv[]) {
         return 0;
     }
     // ---- totals + dumps (AQ.cpp:2611-2656)
-    if (o.ngpus > 1 && dbtk_allreduce(ctx.data(), o.ngpus)) die_assert(dbtk_last_error());
+    const int nctx = (int)ctx.size();
     std::vector<uint64_t> counts(dbtk_rpgg_ntrkmers(rpgg)), kmc(nloci), counters(DBTK_C_COUNT);
     std::vector<uint32_t> nmapread(nloci);
-    if (dbtk_ctx_counts(ctx[0], counts.data(), kmc.data(), nmapread.data(), counters.data())) die_assert(dbtk_last_error());
+    if (nctx == o.ngpus) {  // one context per GPU: the sum is RCCL's (AQ.cpp:2146-2158 across devices)
+        if (o.ngpus > 1 && dbtk_allreduce(ctx.data(), o.ngpus)) die_assert(dbtk_last_error());
+        if (dbtk_ctx_counts(ctx[0], counts.data(), kmc.data(), nmapread.data(), counters.data())) die_assert(dbtk_last_error());
+    } else {  // several contexts per GPU (--ingest-shards): their accumulators are summed on the host
+        std::vector<uint64_t> c1(counts.size()), k1(nloci), r1(DBTK_C_COUNT);
+        std::vector<uint32_t> n1(nloci);
+        for (int d = 0; d < nctx; ++d) {
+            if (dbtk_ctx_counts(ctx[d], c1.data(), k1.data(), n1.data(), r1.data())) die_assert(dbtk_last_error());
+            for (size_t i = 0; i < counts.size(); ++i) counts[i] += c1[i];
+            for (uint64_t l = 0; l < nloci; ++l) { kmc[l] += k1[l]; nmapread[l] += n1[l]; }
+            for (int i = 0; i < DBTK_C_COUNT; ++i) counters[i] += r1[i];
+        }
+    }
     fprintf(stderr,
             "%llu reads processed in total.\n%llu reads removed by subsampled kmer-filter.\n%llu reads removed by kmer-filter.\n"
             "%llu reads removed by bait locus.\n%llu reads removed by qual filter.\n%llu reads removed during locus assignment.\n"
@@ -1013,7 +1038,7 @@ int main(int argc, char* argv[]) {
             die_assert(dbtk_last_error());
         if (P.trackbait) {  // dumpBaitKmerHits, AQ.cpp:2652-2655
             fprintf(stderr, "writing bait kmer hit statistics...\n");
-            for (int d = 1; d < o.ngpus; ++d) if (dbtk_ctx_merge_bait_hits(ctx[0], ctx[d])) die_assert(dbtk_last_error());
+            for (int d = 1; d < nctx; ++d) if (dbtk_ctx_merge_bait_hits(ctx[0], ctx[d])) die_assert(dbtk_last_error());
             if (dbtk_ctx_write_bait_hits(ctx[0], o.outPrefix.c_str())) die_assert(dbtk_last_error());
         } else if (o.trackBait) {
             // -tb where the bait filter never runs (no -b, or -g): the reference still dumps its tracker — sized nloci when -b
@@ -1030,7 +1055,7 @@ int main(int argc, char* argv[]) {
         if (o.outputBubbles) {  // dumpBubbles, AQ.cpp:2648-2651
             fprintf(stderr, "writing bubbles...\n");
             if (P.bubbles) {
-                for (int d = 1; d < o.ngpus; ++d) if (dbtk_ctx_merge_bubbles(ctx[0], ctx[d])) die_assert(dbtk_last_error());
+                for (int d = 1; d < nctx; ++d) if (dbtk_ctx_merge_bubbles(ctx[0], ctx[d])) die_assert(dbtk_last_error());
                 if (dbtk_ctx_write_bubbles(ctx[0], o.outPrefix.c_str())) die_assert(dbtk_last_error());
             }
         }

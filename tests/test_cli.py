@@ -168,6 +168,15 @@ def test_cli_vs_reference_binary_live(tmp_path):
     r2 = subprocess.run([CLI, "-k", "21", "-cth", "30", "-fa", "r.fa", "-qs", "pan", "-o", "file"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r2.returncode == 0 and r.stdout == r2.stdout
     assert open(os.path.join(d, "pipe.trkmc.ar"), "rb").read() == open(os.path.join(d, "file.trkmc.ar"), "rb").read()
+    # four ingest pipelines with a context each on the one GPU (--ingest-shards): the same counts and the same kam lines (as
+    # a set: the ranges' batches leave in completion order, like the reference's with -p > 1)
+    r3 = subprocess.run([CLI, "-k", "21", "-cth", "30", "--ingest-shards", "4", "-fa", "r.fa", "-qs", "pan", "-o", "sh4"], cwd=d,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, DBTK_SHARD_MIN="0"))
+    assert r3.returncode == 0, r3.stderr.decode()[-1000:]
+    assert b"cross-range pairing" in r3.stderr
+    assert open(os.path.join(d, "sh4.trkmc.ar"), "rb").read() == open(os.path.join(d, "file.trkmc.ar"), "rb").read()
+    assert open(os.path.join(d, "sh4.tr.summary.txt"), "rb").read() == open(os.path.join(d, "file.tr.summary.txt"), "rb").read()
+    assert sorted(r3.stdout.splitlines()) == sorted(r2.stdout.splitlines())
 
 
 @pytest.mark.gpu
@@ -361,3 +370,8 @@ def test_sharded_ingest_equals_single_reader(tmp_path, fastq):
         assert got == want, (gpus, got, want)
         if gpus != "1":
             assert b"cross-range pairing" in r.stderr
+    # more ranges than GPUs (--ingest-shards): the same pairs again
+    r = run(["--parse-only", "--gpus", "2", "--ingest-shards", "7", "-k", "21", "-cth", "45", "-fq" if fastq else "-fa", fn, "-qs", "pan", "-o", str(tmp_path / "o")],
+            cwd=d, env=dict(os.environ, DBTK_SHARD_MIN="0"))
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    assert tuple(int(x) for x in r.stdout.decode().split()[1:]) == want
