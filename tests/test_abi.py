@@ -83,6 +83,7 @@ def test_load_errors(lib, tmp_path):
     assert e.value.status == abi.ERR_IO
 
 
+@pytest.mark.skipif(os.environ.get("DBTK_ASAN") == "1", reason="ASan's operator new cannot throw: an impossible size is fatal there by design")
 def test_damaged_count_field_is_a_status_not_a_crash(lib, tmp_path):
     """A count field of a damaged file can ask for exabytes: the loaders answer with a status code (no exception crosses the
     C-ABI, the process lives on)."""
