@@ -39,12 +39,32 @@ struct DevX {
         v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
         return v;
     }
+    // The same scan inside each HALF of the wave (lanes 0-31, 32-63): without the last step lane 31 / lane 63 hold their half's total.
+    template <class OP> __device__ static uint32_t dpp_scan_half(uint32_t v, OP op) {
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+        return v;
+    }
     struct OpAdd { __device__ uint32_t operator()(uint32_t c, uint32_t e) const { return c + e; } };
     struct OpMax { __device__ uint32_t operator()(uint32_t c, uint32_t e) const { return c > e ? c : e; } };
     struct OpLastNz { __device__ uint32_t operator()(uint32_t c, uint32_t e) const { return c ? c : e; } };
     __device__ uint32_t wave_sum(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readlane((int)dpp_scan(v, OpAdd{}), 63); }
     __device__ uint32_t wave_min(uint32_t v) const {  // as a max-scan of the complement
         return ~(uint32_t)__builtin_amdgcn_readlane((int)dpp_scan(~v, OpMax{}), 63);
+    }
+    // sum / maximum over the lane's half of the wave (the probe kernel works on one mate per half)
+    __device__ uint32_t half_sum(uint32_t v) const {
+        const uint32_t s = dpp_scan_half(v, OpAdd{});
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)s, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
+        return (threadIdx.x & 32) ? hi : lo;
+    }
+    __device__ uint32_t half_max(uint32_t v) const {
+        const uint32_t s = dpp_scan_half(v, OpMax{});
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)s, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
+        return (threadIdx.x & 32) ? hi : lo;
     }
     __device__ uint32_t wave_scan_max(uint32_t v) const { return dpp_scan(v, OpMax{}); }  // inclusive
     __device__ uint32_t wave_excl_scan(uint32_t v) const { return dpp_scan(v, OpAdd{}) - v; }

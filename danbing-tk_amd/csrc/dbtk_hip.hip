@@ -53,12 +53,21 @@ __global__ void __launch_bounds__(K1_NT, 4) k_encode_subfilter(BatchArgs a) {
 }
 // K2 / K3 are instantiated per NS = 64-position slots a read needs (2: <= 128 positions, 3: 150 bp reads, 4: up to 256 bp)
 #ifndef DBTK_K2_WPE
-#define DBTK_K2_WPE 4  // waves per SIMD the probe kernel's registers are budgeted for (5: 96 VGPRs but 13 spilled words, 3 % slower; 6: 8 % slower)
+#define DBTK_K2_WPE 4  // waves per SIMD the general probe kernel's registers are budgeted for
 #endif
-template <int NS, bool MZ> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_K2_WPE, 8))) k_probe(BatchArgs a) {
+template <int NS> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_K2_WPE, 8))) k_probe_general(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) ProbeSmem sm;
     DevX x{&sm};
-    body_probe<NS, MZ>(x, a);
+    body_probe<NS>(x, a);
+}
+// the lean probe kernel (dbtk_probe2.h): NPL positions per lane, windows of WN m-mers
+#ifndef DBTK_P2_WPE
+#define DBTK_P2_WPE 4  // waves per SIMD its registers are budgeted for
+#endif
+template <int NPL, int WN> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_P2_WPE, 8))) k_probe(BatchArgs a) {
+    __shared__ Probe2SmemT<NPL> sm;
+    DevX x{&sm};
+    body_probe2<NPL, WN>(x, a);
 }
 template <int NS, bool RECS> __global__ void __launch_bounds__(64) k_pair_usual(BatchArgs a) {
     __shared__ UsualSmem sm;
@@ -72,6 +81,10 @@ template <int NS, bool RECS> __global__ void __launch_bounds__(64, NS <= 3 ? 2 :
 }
 
 __global__ void __launch_bounds__(256) k_mz_insert(MzBuildArgs a) { DevX x{nullptr}; body_mz_insert(x, a); }
+__global__ void __launch_bounds__(256) k_mz_fill(MzSlot* t, uint64_t n) { DevX x{nullptr}; body_mz_fill(x, t, n); }
+__global__ void __launch_bounds__(256) k_surv_key(SurvSortArgs a) { DevX x{nullptr}; body_surv_key(x, a); }
+__global__ void __launch_bounds__(64) k_surv_scan(SurvSortArgs a, int step) { DevX x{nullptr}; body_surv_scan(x, a, step); }
+__global__ void __launch_bounds__(256) k_surv_scatter(SurvSortArgs a) { DevX x{nullptr}; body_surv_scatter(x, a); }
 __global__ void __launch_bounds__(256) k_gr_insert(GrBuildArgs a) { DevX x{nullptr}; body_gr_insert(x, a); }
 // the graph walk (dbtk_walk.h): one wave per read (function mode) / per pair (the hot path with threading = 2)
 #ifndef DBTK_WALK_WAVES
@@ -123,7 +136,7 @@ namespace {
 // Per-kernel timing: a pool of HIP event pairs recorded on the context's stream
 // around every launch; folded into (total ms, launches) when the pool fills or
 // when the caller asks.
-constexpr int NKERN = 5;       // k_encode_subfilter, k_probe, k_pair_usual, k_pair, k_walk_pairs
+constexpr int NKERN = 6;       // k_encode_subfilter, k_probe, k_pair_usual, k_pair, k_walk_pairs, k_surv_sort (its three kernels)
 constexpr int EVPOOL = 128;    // launches in flight before a fold
 struct Timed {
     const char* name;
@@ -142,7 +155,7 @@ struct Timed {
 struct TableShare {
     int refs = 0;
     IdxBucket* d_idx = nullptr; uint64_t* d_flt = nullptr; uint64_t flt_words = 0; uint32_t* d_trbeg = nullptr; ClsSlot* d_cls = nullptr;
-    MzBucket* d_mz = nullptr; GrSlot* d_gr = nullptr; uint32_t* d_vv = nullptr; uint8_t* d_qc = nullptr; uint16_t* d_perm = nullptr;
+    MzSlot* d_mz = nullptr; MzSlot* d_ovf = nullptr; GrSlot* d_gr = nullptr; uint32_t* d_vv = nullptr; uint8_t* d_qc = nullptr; uint16_t* d_perm = nullptr;
     ClsSlot* d_tre = nullptr; ClsSlot* d_bait = nullptr;
     DevTables T;
     uint32_t consistent = 0;
@@ -160,7 +173,8 @@ struct dbtk_ctx {
     uint64_t* d_flt = nullptr; uint64_t flt_words = 0;
     uint32_t* d_trbeg = nullptr;
     ClsSlot* d_cls = nullptr;
-    MzBucket* d_mz = nullptr;     // the probe kernel's minimizer-grouped copy of the index
+    MzSlot* d_mz = nullptr;       // the probe kernel's minimizer-grouped copy of the index (level 1)
+    MzSlot* d_ovf = nullptr;      //   ... and its overflow table (level 2)
     GrSlot* d_gr = nullptr;       // graph table (threading = 2), nullptr when the handle holds no graph
     uint32_t* d_vv = nullptr;
     uint8_t* d_qc = nullptr;
@@ -169,11 +183,11 @@ struct dbtk_ctx {
     uint64_t* d_ctr = nullptr;    // counter replicas (folded into d_accum's counters at the end of every batch)
     uint64_t n_accum = 0, ntr = 0;
     uint32_t* d_small = nullptr;  // nsurv, novf, nrec, errflag
-    uint32_t* d_surv = nullptr; uint64_t surv_cap = 0;
+    uint32_t* d_surv = nullptr; uint64_t surv_cap = 0;  // the encode stage's survivor list | the list in locus order | keys | histogram
+    uint32_t* d_sorted = nullptr;                       // (inside d_surv) the sorted list of the last batch: what K2, K3 and the walk index
     uint8_t* d_seq = nullptr; uint64_t seq_cap = 0;
     uint64_t* d_off = nullptr; uint64_t off_cap = 0;
     dbtk_pair_rec_t* d_recs = nullptr; uint64_t rec_cap = 0;
-    uint64_t* d_hitkm = nullptr; uint64_t hitkm_cap = 0;   // K2 -> K3 (see BatchArgs)
     uint64_t* d_hitva = nullptr; uint64_t hitva_cap = 0;   // aux words of every row, then val words (4 + 4 bytes per position)
     uint32_t* d_hitnk = nullptr; uint64_t hitnk_cap = 0;
     uint64_t* d_hitoff = nullptr; uint64_t hitoff_cap = 0;
@@ -201,6 +215,7 @@ struct dbtk_ctx {
     std::vector<std::unordered_map<uint64_t, uint64_t>> btTK;
     std::vector<std::unordered_map<uint64_t, uint16_t>> baitDB_host;
     std::vector<dbtk_pair_rec_t> own_recs;  // record buffer when the caller passes none but -tb needs the bait-stage records
+    uint64_t mz_turned = 0;       // keys in the overflow table
     int k1_blocks = 0, probe_wpc = 32;
     bool timers_on = true;
     uint32_t timers_every = 1;  // event records around the kernels of every n-th batch (8 records cost ~30 us per batch)
@@ -216,8 +231,7 @@ struct dbtk_ctx {
     struct Lane {
         hipStream_t stream = nullptr;
         uint32_t* d_small = nullptr;
-        uint32_t* d_surv = nullptr; uint64_t surv_cap = 0;
-        uint64_t* d_hitkm = nullptr; uint64_t hitkm_cap = 0;
+        uint32_t* d_surv = nullptr; uint64_t surv_cap = 0; uint32_t* d_sorted = nullptr;
         uint64_t* d_hitva = nullptr; uint64_t hitva_cap = 0;   // aux words of every row, then val words (4 + 4 bytes per position)
         uint32_t* d_hitnk = nullptr; uint64_t hitnk_cap = 0;
         uint64_t* d_hitoff = nullptr; uint64_t hitoff_cap = 0;
@@ -247,12 +261,12 @@ void release_share(dbtk_ctx* c) {
     std::lock_guard<std::mutex> l(g_share_m);
     TableShare* sh = c->share;
     if (!sh) {  // the context never got as far as sharing: the tables (if any) are its own
-        void* own[] = {c->d_flt, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_tre, c->d_bait, c->d_gr, c->d_mz};
+        void* own[] = {c->d_flt, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_tre, c->d_bait, c->d_gr, c->d_mz, c->d_ovf};
         for (void* p : own) if (p) (void)hipFree(p);
         return;
     }
     if (--sh->refs > 0) return;
-    void* ptrs[] = {sh->d_flt, sh->d_trbeg, sh->d_idx, sh->d_cls, sh->d_vv, sh->d_qc, sh->d_perm, sh->d_tre, sh->d_bait, sh->d_gr, sh->d_mz};
+    void* ptrs[] = {sh->d_flt, sh->d_trbeg, sh->d_idx, sh->d_cls, sh->d_vv, sh->d_qc, sh->d_perm, sh->d_tre, sh->d_bait, sh->d_gr, sh->d_mz, sh->d_ovf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     g_shares.erase(std::make_pair(c->g, c->device));
     delete sh;
@@ -268,14 +282,14 @@ void free_ctx(dbtk_ctx* c) {
             if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
         }
     void* ptrs[] = {c->d_ctr, c->d_accum, c->d_small, c->d_surv,
-                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitkm, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
+                    c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
                     c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_walk, c->d_trecs, c->d_loci, c->d_aln};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->h_aln) (void)hipHostFree(c->h_aln);
     std::vector<dbtk_ctx::Lane*> others{&c->alt};
     for (auto& l : c->parked) others.push_back(&l);
     for (dbtk_ctx::Lane* l : others) {
-        void* aptrs[] = {l->d_small, l->d_surv, l->d_hitkm, l->d_hitva, l->d_hitnk, l->d_hitoff, l->d_gen, l->d_tickets, l->d_vote, l->d_epoch, l->d_walk};
+        void* aptrs[] = {l->d_small, l->d_surv, l->d_hitva, l->d_hitnk, l->d_hitoff, l->d_gen, l->d_tickets, l->d_vote, l->d_epoch, l->d_walk};
         for (void* p : aptrs) if (p) (void)hipFree(p);
         if (l != &c->alt && l->stream) (void)hipStreamDestroy(l->stream);
     }
@@ -404,23 +418,38 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         T.consistent = (st[1] == 0 && st[0] == st[2]) ? 1u : 0u;
         c->consistent = T.consistent;
     }
-    {   // the probe kernel's minimizer-grouped copy of the index (DBTK_MZ=0: look up the plain index instead)
+    {   // the probe kernel's minimizer-grouped copy of the index, for the values of k its lean form exists for
+        // (DBTK_MZ=0: do without: the general probe kernel then looks every position up in the plain index)
         bool on = true;
         if (const char* e = getenv("DBTK_MZ")) on = atoi(e) != 0;
-        if (on && nkeys) {
-            uint64_t per = 6;  // buckets per 8 keys: load ~0.1-0.17 (14 GB at release scale; nine keys in ten then sit in their home bucket)
-            if (const char* e = getenv("DBTK_MZ_SPARSITY")) { const long v = atol(e); if (v >= 2 && v <= 64) per = (uint64_t)v; }
-            const uint64_t nb = pow2_at_least(nkeys * per / 8 + 8);
-            HIPCHK(hipMalloc(&c->d_mz, nb * sizeof(MzBucket)));
-            HIPCHK(hipMemsetAsync(c->d_mz, 0xFF, nb * sizeof(MzBucket), s));
-            uint32_t m = MZ_M;
-            if (const char* e = getenv("DBTK_MZ_M")) { const int v = atoi(e); if (v >= 4 && v <= 16) m = (uint32_t)v; }
-            if (m > g->ksize) m = g->ksize;
-            MzBuildArgs a{c->d_idx, icap, c->d_mz, nb - 1, 64 - log2u(nb), g->ksize, m};
+        const uint32_t m = mz_m_for_k(g->ksize);
+        if (on && m && nkeys) {
+            uint64_t per = 6;  // buckets per 8 keys (17 GB at release scale): what keeps two minimizers out of one bucket
+            if (const char* e = getenv("DBTK_MZ_SPARSITY")) { const long v = atol(e); if (v >= 1 && v <= 64) per = (uint64_t)v; }
+            uint64_t nb = pow2_at_least(nkeys * per / 8 + 8);
+            if (nb > (1ull << 28)) nb = 1ull << 28;  // the bucket number comes out of 28 bits of the minimizer's hash
+            HIPCHK(hipMalloc(&c->d_mz, nb * MZ_SLOTS * sizeof(MzSlot)));
+            LAUNCH(k_mz_fill, dim3(2048), dim3(256), s, c->d_mz, nb * MZ_SLOTS);
+            uint64_t* dn = nullptr;
+            HIPCHK(hipMalloc(&dn, 8));
+            HIPCHK(hipMemsetAsync(dn, 0, 8, s));
+            MzBuildArgs a{c->d_idx, icap, c->d_mz, (uint32_t)(nb - 1), nullptr, 0, g->ksize, m, 0, dn};
+            LAUNCH(k_mz_insert, dim3(2048), dim3(256), s, a);  // level 1; counts the keys it turns away
+            uint64_t nturned = 0;
+            HIPCHK(hipMemcpyAsync(&nturned, dn, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipFree(dn));
+            uint64_t ocap = pow2_at_least(4 * nturned + 8);  // level 2: those keys, at most a quarter full
+            if (ocap > (1ull << 32)) { set_error("overflow table of the probe kernel: more than 2^30 keys"); return DBTK_ERR_UNSUPPORTED; }
+            HIPCHK(hipMalloc(&c->d_ovf, ocap * sizeof(MzSlot)));
+            LAUNCH(k_mz_fill, dim3(2048), dim3(256), s, c->d_ovf, ocap);
+            a.ovf = c->d_ovf; a.ovf_mask = (uint32_t)(ocap - 1); a.pass = 1;
             LAUNCH(k_mz_insert, dim3(2048), dim3(256), s, a);
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipGetLastError());
-            T.mz = c->d_mz; T.mz_mask = nb - 1; T.mz_shift = 64 - log2u(nb); T.mz_m = m;
+            T.mz = c->d_mz; T.mz_mask = nb - 1; T.mz_m = m;
+            T.ovf = c->d_ovf; T.ovf_mask = ocap - 1;
+            c->mz_turned = nturned;
         }
     }
     return DBTK_OK;
@@ -521,8 +550,7 @@ void fold_timer(Timed& t) {
 }
 void switch_lane(dbtk_ctx* c) {
     std::swap(c->stream, c->alt.stream); std::swap(c->d_small, c->alt.d_small);
-    std::swap(c->d_surv, c->alt.d_surv); std::swap(c->surv_cap, c->alt.surv_cap);
-    std::swap(c->d_hitkm, c->alt.d_hitkm); std::swap(c->hitkm_cap, c->alt.hitkm_cap);
+    std::swap(c->d_surv, c->alt.d_surv); std::swap(c->surv_cap, c->alt.surv_cap); std::swap(c->d_sorted, c->alt.d_sorted);
     std::swap(c->d_hitva, c->alt.d_hitva); std::swap(c->hitva_cap, c->alt.hitva_cap);
     std::swap(c->d_hitnk, c->alt.d_hitnk); std::swap(c->hitnk_cap, c->alt.hitnk_cap);
     std::swap(c->d_hitoff, c->alt.d_hitoff); std::swap(c->hitoff_cap, c->alt.hitoff_cap);
@@ -573,10 +601,9 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     if (const char* e = getenv("DBTK_SURV_CAP")) { const long long v = atoll(e); if (v > 0) cap = (uint64_t)v; }  // (tests: force several chunks)
     const uint64_t tcap = npairs < cap ? npairs : cap;
     const uint64_t nchunks = (npairs + tcap - 1) / tcap;
-    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, npairs + 1);
+    const uint64_t nloci = c->g->nloci;
+    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, 3 * (npairs + 1) + nloci + 2 + SCAN_BLOCKS);
     if (st) return st;
-    static const bool keep_km = [] { const char* e = getenv("DBTK_HITKM"); return e && atoi(e) == 1; }();  // diagnostic: the k-mers travel K2 -> K3 as they used to
-    if (keep_km && (st = ensure(&c->d_hitkm, &c->hitkm_cap, tcap * 2 * nkp))) return st;
     if ((st = ensure(&c->d_hitoff, &c->hitoff_cap, tcap * 4))) return st;  // offsets, then headers
     if ((st = ensure(&c->d_hitva, &c->hitva_cap, tcap * 2 * nkp))) return st;
     if ((st = ensure(&c->d_hitnk, &c->hitnk_cap, tcap * 2))) return st;
@@ -610,7 +637,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     a.recs = d_recs; a.rec_cap = rec_cap;
     a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
     a.walk_dst = walking ? c->d_walk : nullptr;
-    a.hitkm = keep_km ? c->d_hitkm : nullptr; a.hitaux = reinterpret_cast<uint32_t*>(c->d_hitva); a.hitval = a.hitaux + tcap * 2 * nkp; a.hitnk = c->d_hitnk; a.hitoff = c->d_hitoff; a.hithdr = c->d_hitoff + tcap * 2; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
+    a.hitaux = reinterpret_cast<uint32_t*>(c->d_hitva); a.hitval = a.hitaux + tcap * 2 * nkp; a.hitnk = c->d_hitnk; a.hitoff = c->d_hitoff; a.hithdr = c->d_hitoff + tcap * 2; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
     // the usual-pair kernel takes the pairs it can finish and passes the rest on; it needs the class of a k-mer next to its
     // index value (consistent RPGG) and does not do the trace, bait or bubble work
     const bool usual = c->T.consistent && !c->P.trace && !c->P.bait && !c->P.bubbles;
@@ -630,13 +657,39 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     LAUNCH(k_encode_subfilter, dim3(g1), dim3(K1_NT), s, a);
     if ((st = rec_end(0))) return st;
     }
+    {   // the survivor list in locus order (dbtk_probe2.h: body_surv_*): what every later kernel indexes
+        SurvSortArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.T = c->T; sa.P = c->P; sa.seq = d_seq; sa.off = d_off; sa.surv = c->d_surv; sa.nsurv = c->d_small + 0;
+        sa.sorted = c->d_surv + (npairs + 1); sa.key = sa.sorted + (npairs + 1); sa.hist = sa.key + (npairs + 1);
+        HIPCHK(hipMemsetAsync(sa.hist, 0, (nloci + 2) * sizeof(uint32_t), s));
+        const uint32_t gs = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)c->num_cu * 8);
+        if ((st = rec_beg(5))) return st;
+        LAUNCH(k_surv_key, dim3(gs), dim3(256), s, sa);
+        LAUNCH(k_surv_scan, dim3(SCAN_BLOCKS), dim3(64), s, sa, 0);
+        LAUNCH(k_surv_scan, dim3(SCAN_BLOCKS), dim3(64), s, sa, 1);
+        LAUNCH(k_surv_scatter, dim3(gs), dim3(256), s, sa);
+        if ((st = rec_end(5))) return st;
+        c->d_sorted = sa.sorted;
+        a.surv = sa.sorted;
+        if (getenv("DBTK_NOSORT")) { c->d_sorted = c->d_surv; a.surv = c->d_surv; }  // (diagnostic A/B: the encode stage's order)
+    }
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         a.t0 = (uint32_t)(ch * tcap);
         if (tm) { if ((st = timed_slot(c, 1, &e))) return st; HIPCHK(hipEventRecord(c->timed[1].beg[e], s)); }
-        switch (ns) {
-            case 1: case 2: if (a.T.mz) LAUNCH((k_probe<2, true>), dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); else LAUNCH((k_probe<2, false>), dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); break;
-            case 3: if (a.T.mz) LAUNCH((k_probe<3, true>), dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); else LAUNCH((k_probe<3, false>), dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); break;
-            default: if (a.T.mz) LAUNCH((k_probe<4, true>), dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); else LAUNCH((k_probe<4, false>), dim3(c->num_cu * c->probe_wpc), dim3(64), s, a); break;
+        {
+            // the lean form (dbtk_probe2.h) where its conditions hold: the tables exist for this k, no read longer than its
+            // lanes cover, none of the optional per-read extras (-bu edges, -b quality masks); otherwise the general form
+            const dim3 gpr(c->num_cu * c->probe_wpc);
+            const uint32_t wn = a.T.mz ? k - a.T.mz_m + 1 : 0;
+            const int npl = !a.T.mz || a.edgebuf || a.qmaskbuf ? 0 : (max_read_len <= 32 * 3 + a.T.mz_m - 1 ? 3 : max_read_len <= 32 * 5 + a.T.mz_m - 1 ? 5 : 0);
+            if (npl == 3 && wn == 7) LAUNCH((k_probe<3, 7>), gpr, dim3(64), s, a);
+            else if (npl == 3 && wn == 11) LAUNCH((k_probe<3, 11>), gpr, dim3(64), s, a);
+            else if (npl == 5 && wn == 7) LAUNCH((k_probe<5, 7>), gpr, dim3(64), s, a);
+            else if (npl == 5 && wn == 11) LAUNCH((k_probe<5, 11>), gpr, dim3(64), s, a);
+            else if (ns <= 2) LAUNCH((k_probe_general<2>), gpr, dim3(64), s, a);
+            else if (ns == 3) LAUNCH((k_probe_general<3>), gpr, dim3(64), s, a);
+            else LAUNCH((k_probe_general<4>), gpr, dim3(64), s, a);
         }
         if (tm) HIPCHK(hipEventRecord(c->timed[1].end[e], s));
         // RECS = false: no record buffer (-ka without -e): record emission is compiled out
@@ -674,7 +727,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         WalkArgs w;
         memset(&w, 0, sizeof(w));
         w.T = c->T; w.P = c->P; w.seq = d_seq; w.off = d_off;
-        w.surv = c->d_surv; w.nsurv = c->d_small + 0;
+        w.surv = c->d_sorted; w.nsurv = c->d_small + 0;
         w.walk_dst = c->d_walk; w.walk_ret = c->d_walk + npairs;
         w.counts = a.counts; w.counters = a.counters; w.ctr_rep = c->d_ctr;
         w.trecs = walk_trecs; w.errflag = c->d_small + 3;
@@ -766,6 +819,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
         c->timed[2].name = "k_pair_usual";
         c->timed[3].name = "k_pair";
         c->timed[4].name = "k_walk_pairs";
+        c->timed[5].name = "k_surv_sort";
         {
             int nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_walk_pairs, 64, 0) != hipSuccess || nb <= 0) nb = 8;
@@ -782,7 +836,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             auto it = g_shares.find(key);
             TableShare* sh = it != g_shares.end() ? it->second : nullptr;
             auto to_share = [&](TableShare* t) {
-                t->d_idx = c->d_idx; t->d_flt = c->d_flt; t->flt_words = c->flt_words; t->d_trbeg = c->d_trbeg; t->d_cls = c->d_cls; t->d_mz = c->d_mz;
+                t->d_idx = c->d_idx; t->d_flt = c->d_flt; t->flt_words = c->flt_words; t->d_trbeg = c->d_trbeg; t->d_cls = c->d_cls; t->d_mz = c->d_mz; t->d_ovf = c->d_ovf;
                 t->d_gr = c->d_gr; t->d_vv = c->d_vv; t->d_qc = c->d_qc; t->d_perm = c->d_perm; t->d_tre = c->d_tre; t->d_bait = c->d_bait;
                 t->T = c->T; t->consistent = c->consistent;
             };
@@ -792,7 +846,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
                 to_share(sh);
                 g_shares[key] = sh;
             } else {
-                c->d_idx = sh->d_idx; c->d_flt = sh->d_flt; c->flt_words = sh->flt_words; c->d_trbeg = sh->d_trbeg; c->d_cls = sh->d_cls; c->d_mz = sh->d_mz;
+                c->d_idx = sh->d_idx; c->d_flt = sh->d_flt; c->flt_words = sh->flt_words; c->d_trbeg = sh->d_trbeg; c->d_cls = sh->d_cls; c->d_mz = sh->d_mz; c->d_ovf = sh->d_ovf;
                 c->d_gr = sh->d_gr; c->d_vv = sh->d_vv; c->d_qc = sh->d_qc; c->d_perm = sh->d_perm; c->d_tre = sh->d_tre; c->d_bait = sh->d_bait;
                 c->T = sh->T; c->consistent = sh->consistent;
             }
@@ -1065,7 +1119,7 @@ static dbtk_status_t dbtk_ctx_walk_results_impl(dbtk_ctx_t* c, dbtk_walk_res_t* 
     if (nsurv) {
         HIPCHK(hipMemcpy(dst.data(), c->d_walk, (size_t)nsurv * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(ret.data(), c->d_walk + np, (size_t)nsurv * 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(surv.data(), c->d_surv, (size_t)nsurv * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(surv.data(), c->d_sorted, (size_t)nsurv * 4, hipMemcpyDeviceToHost));
     }
     std::vector<std::pair<uint32_t, uint32_t>> walked;  // (pair, t)
     for (uint32_t t = 0; t < nsurv; ++t) if (dst[t] != NAN32) walked.emplace_back(surv[t], t);

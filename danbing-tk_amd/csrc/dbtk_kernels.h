@@ -119,38 +119,6 @@ DBTK_HD void body_idx_aux(X& x, const IdxAuxArgs& a) {
     if (nmiss) x.atomic_add(&a.stats[1], nmiss);
 }
 
-// The probe kernel's minimizer-grouped copy of the index, filled from the finished plain index (keys are unique there and
-// carry val | aux): every occupied slot is re-inserted under its k-mer's minimizer.
-struct MzBuildArgs {
-    const IdxBucket* idx;
-    uint64_t nslots;   // 4 per IdxBucket
-    MzBucket* mz;
-    uint64_t mask;     // buckets - 1
-    uint32_t shift, ksize, m;
-};
-template <class X>
-DBTK_HD void body_mz_insert(X& x, const MzBuildArgs& a) {
-    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.nslots; i += (uint64_t)x.nblocks() * x.nthreads()) {
-        uint64_t key = a.idx[i >> 2].key[i & 3];
-        if (key == NAN64) continue;
-        key &= ~IDX_OVF;
-        const uint64_t va = a.idx[i >> 2].val[i & 3];
-        const uint64_t b = mz_bucket(kmer_minimizer(key, a.ksize, a.m), a.shift);
-        bool placed = false;
-        for (int j = 0; j < 8 && !placed; ++j) {  // slots are claimed in order, so the occupied ones form a prefix
-            if (x.atomic_cas(&a.mz[b].key[j], NAN64, key) == NAN64) {
-                a.mz[b].val[j] = (uint32_t)va;
-                a.mz[b].aux[j] = (uint32_t)(va >> 32);
-                placed = true;
-            }
-        }
-        // no room: the key stays in the plain index only, and the bucket says so (bit 63 of key[7]) — a look-up that does not
-        // find its key in a bucket so marked asks the plain index (two levels, never a chain: heavy minimizers are those of
-        // tandem repeats, whose chains would otherwise be tens of buckets long)
-        if (!placed) x.atomic_or(&a.mz[b].key[7], IDX_OVF);
-    }
-}
-
 struct ClsBuildArgs {
     ClsSlot* slots;
     uint64_t mask;
@@ -214,10 +182,8 @@ struct BatchArgs {
     uint32_t* vote_epoch;    // per block
     uint64_t* dbg;           // diagnostic build only (-DDBTK_STAMPS): per-phase cycle sums of k_pair
     // K2 -> K3, per (survivor, mate) row of nkp positions: the index results (val, aux), and per row the number of
-    // positions and the read's offset.  The canonical k-mers do NOT travel (hitkm == nullptr): the probe kernel is bound
-    // by its requests to the fabric, a quarter of which were result writes; only the general resolve kernel needs the
-    // k-mers, for an eighth of the pairs, and re-encodes them from the read.  (hitkm != nullptr: diagnostic, the old way.)
-    uint64_t* hitkm;
+    // positions and the read's offset.  The canonical k-mers do NOT travel: only the general resolve kernel needs them, for
+    // an eighth of the pairs, and re-encodes them from the read.
     // The index results of a row, split: `hitaux` (class at the locus, AUX_MISS where the k-mer is not in the index) is always
     // written; `hitval` only for a read whose found k-mers are NOT all unique to one and the same locus — for the others
     // (most reads from a locus) the one index value, the number of found positions and the flag sit in `hithdr`
@@ -264,7 +230,11 @@ DBTK_HD uint64_t* counters_of(X& x, const BatchArgs& a) {
 #define DBTK_STAMP_FLUSH do { if (lane == 0 && a.dbg) for (int i_ = 0; i_ < 48; ++i_) if (st_acc[i_]) x.atomic_add(&a.dbg[i_], st_acc[i_]); } while (0)
 #else
 #define DBTK_STAMP_DECL
+#if defined(DBTK_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+#define DBTK_STAMP(i) asm volatile("; MARK " #i)  // (ISA reading aid: the phase boundaries as comments in the -S output)
+#else
 #define DBTK_STAMP(i) do { } while (0)
+#endif
 #define DBTK_STAMP_FLUSH do { } while (0)
 #endif
 
@@ -1057,26 +1027,16 @@ struct BubEvent {  // one novel read (k+1)-mer (countNovelEdges, AQ.cpp:1559-156
     uint32_t pair, mate, pos, locus;
     uint64_t edge;
 };
-constexpr int MZ_RB = 32;  // runs (buckets) staged in LDS at a time: 4 KB
 struct ProbeSmem {
     uint32_t raw[72];
     uint32_t pk[20];
     uint16_t vd[20];
     uint32_t qraw[72];   // base qualities of the read (only with -b and qualities)
     uint32_t qmask[8];
-    // Two phases share one region (what bounds this kernel is round trips per wave times waves per CU, so its LDS is kept small):
-    union {
-        struct {  // look-up list of the plain index
-            uint64_t km[NKMAX];  // canonical k-mer per list entry (NAN64: window not valid)
-            uint32_t hb[NKMAX];  // its home bucket
-            uint64_t rva[NKMAX]; // look-up result per POSITION: val | aux << 32 (val = NOHIT: not in the index)
-        };
-        struct {  // minimizer-grouped look-ups (T.mz), before the list phase
-            uint32_t hm[MAXL + 8];      // hashes of the read's m-mers by base position
-            uint32_t rb[NKMAX];         // the bucket of every run of positions with one minimizer
-            uint64_t stg[MZ_RB][17];    // the buckets of MZ_RB runs at a time (17, not 16, words per row: rows on different LDS banks)
-        };
-    };
+    // look-up list of the plain index
+    uint64_t km[NKMAX];  // canonical k-mer per list entry (NAN64: window not valid)
+    uint32_t hb[NKMAX];  // its home bucket
+    uint64_t rva[NKMAX]; // look-up result per POSITION: val | aux << 32 (val = NOHIT: not in the index)
 };
 
 // qString2qMask (src/aQueryFasta_thread.h:1038-1071), statement by statement, on the quality bytes
@@ -1112,9 +1072,9 @@ DBTK_HD void qmask_scan(const uint8_t* q, int nq, int qth, int ksize, uint32_t* 
     }
 }
 
-// MZ: the context holds the minimizer-grouped copy of the index (T.mz): the two ways of looking up are two kernels, so that
-// neither pays for the other's registers
-template <int NS, bool MZ, class X>
+// The probe kernel in its general form: any k <= 31, reads up to 64 * NS + k - 1 bases, -bu edges, -b quality masks; every
+// position is looked up in the plain index.  The lean form for the usual geometry is body_probe2 (dbtk_probe2.h).
+template <int NS, class X>
 DBTK_HD void body_probe(X& x, const BatchArgs& a) {
     constexpr int NSLOT = NS;  // 64-position slots per read (shadows the global upper bound)
     ProbeSmem& sm = *x.template smem<ProbeSmem>();
@@ -1225,11 +1185,9 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
         // minimizers share all but npl - 1 of their m-mers, and its results are neighbours in the hit buffers.
         const uint32_t npl = (nk + 63) >> 6;
         const uint32_t p0 = (uint32_t)lane * npl;
-        const uint32_t m = MZ ? T.mz_m : 0u, wn = MZ ? k - m + 1 : 0u;
-        const uint32_t nmm = (MZ && len >= m) ? len - m + 1 : 0u;  // m-mers of the read (minimizer path)
-        const bool fastw = clean && k + npl - 1 <= 32;  // (m <= 16 < k: the m-mers fit whenever the k-mers do)
+        const bool fastw = clean && k + npl - 1 <= 32;
         uint64_t W = 0, RW = 0;  // the 32 bases from p0, and their reverse complement (base t of the window at bits 2t of RW)
-        if (fastw && (p0 < nk || p0 < nmm)) { W = window_fw_clean(sm.pk, p0, 32); RW = revcomp2(W, 32); }
+        if (fastw && p0 < nk) { W = window_fw_clean(sm.pk, p0, 32); RW = revcomp2(W, 32); }
         const uint64_t kmask = (1ull << (2 * k)) - 1;
         uint64_t km[NSLOT];
         bool open[NSLOT];
@@ -1245,181 +1203,11 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                 open[j] = km[j] != NAN64;
             }
         }
-        uint64_t* outk = a.hitkm + (size_t)it * a.nkp;
         uint32_t* outa = a.hitaux + (size_t)it * a.nkp;
         uint32_t* outv = a.hitval + (size_t)it * a.nkp;
         if (lane == 0) { a.hitnk[it] = nk; a.hitoff[it] = o0; }
-        uint64_t rvv[NSLOT];  // minimizer path: this lane's own results
-        bool pend2[NSLOT];    //                 positions its home bucket could not answer
-#pragma unroll
-        for (int j = 0; j < NSLOT; ++j) { rvv[j] = (uint64_t)NOHIT; pend2[j] = false; }
-        if (MZ) {
-            // ---- look-ups through the minimizer-grouped copy of the index (MzBucket, dbtk_tables.h): one 128-byte bucket per
-            // RUN of positions sharing a minimizer instead of one 64-byte bucket per position
-            const uint32_t mmask = (uint32_t)((1ull << (2 * m)) - 1);
-#pragma unroll
-            for (int j = 0; j < NSLOT; ++j) {  // hashed canonical m-mer at the lane's base positions
-                const uint32_t q = p0 + j;
-                if ((uint32_t)j < npl && q < nmm) {
-                    uint32_t hv = 0xFFFFFFFFu;
-                    if (fastw) hv = mmer_hash2((uint32_t)(W >> (2 * (32 - m - j))) & mmask, (uint32_t)(RW >> (2 * j)) & mmask);
-                    else if (clean) hv = mmer_hash(window_fw_clean(sm.pk, q, m), m);
-                    else { uint64_t f, r; if (window_kmer(sm.pk, sm.vd, q, m, &f, &r) != NAN64) hv = mmer_hash(f, m); }
-                    sm.hm[q] = hv;
-                }
-            }
-            for (uint32_t q = 64 * npl + lane; q < nmm; q += 64) {  // (the last wn - 1 m-mers of a read that fills its lanes)
-                uint32_t hv = 0xFFFFFFFFu;
-                if (clean) hv = mmer_hash(window_fw_clean(sm.pk, q, m), m);
-                else { uint64_t f, r; if (window_kmer(sm.pk, sm.vd, q, m, &f, &r) != NAN64) hv = mmer_hash(f, m); }
-                sm.hm[q] = hv;
-            }
-            x.sync();
-            DBTK_STAMP(16);  // (K2, minimizer path) windows + m-mer hashes
-            // minimizer of position p0 + j = min of hm[p0 + j .. p0 + j + wn): the windows of one lane share hm[p0 + npl - 1 .. p0 + wn)
-            uint32_t bk[NSLOT], rid[NSLOT];
-            bool st[NSLOT];
-            if (wn >= npl) {
-                uint32_t cm = 0xFFFFFFFFu;  // the shared part
-                if (p0 < nk) for (uint32_t t = npl - 1; t < wn; ++t) { const uint32_t h = sm.hm[p0 + t]; cm = h < cm ? h : cm; }
-#pragma unroll
-                for (int j = 0; j < NSLOT; ++j) {
-                    bk[j] = 0xFFFFFFFFu;
-                    if (open[j]) {
-                        uint32_t mzv = cm;
-                        for (uint32_t t = (uint32_t)j; t < npl - 1; ++t) { const uint32_t h = sm.hm[p0 + t]; mzv = h < mzv ? h : mzv; }  // before the shared part
-                        for (uint32_t t = wn; t < wn + j; ++t) { const uint32_t h = sm.hm[p0 + t]; mzv = h < mzv ? h : mzv; }        // after it
-                        bk[j] = (uint32_t)mz_bucket(mzv, T.mz_shift);
-                    }
-                }
-            } else {  // (k - m + 1 < npl: nothing shared worth the name)
-#pragma unroll
-                for (int j = 0; j < NSLOT; ++j) {
-                    bk[j] = 0xFFFFFFFFu;
-                    if (open[j]) {
-                        uint32_t mzv = 0xFFFFFFFFu;
-                        for (uint32_t t = 0; t < wn; ++t) { const uint32_t h = sm.hm[p0 + j + t]; mzv = h < mzv ? h : mzv; }
-                        bk[j] = (uint32_t)mz_bucket(mzv, T.mz_shift);
-                    }
-                }
-            }
-            // a position opens a run when its bucket differs from the previous position's
-            uint32_t lastbk = bk[0];
-#pragma unroll
-            for (int j = 1; j < NSLOT; ++j) if ((uint32_t)j < npl) lastbk = bk[j];
-            uint32_t prev = x.shfl_up1(lastbk);
-            if (lane == 0) prev = 0xFFFFFFFFu;
-            uint32_t cnt = 0;
-#pragma unroll
-            for (int j = 0; j < NSLOT; ++j) {
-                st[j] = open[j] && bk[j] != prev;
-                cnt += st[j] ? 1u : 0u;
-                prev = bk[j];
-            }
-            uint32_t r = x.wave_excl_scan(cnt);             // runs opened by the lanes before this one
-            const uint32_t nruns = x.bcast(r + cnt, 63);    // (wave-uniform)
-#pragma unroll
-            for (int j = 0; j < NSLOT; ++j) {
-                if (st[j]) { sm.rb[r] = bk[j]; ++r; }
-                rid[j] = r - 1;  // (meaningful for open positions only: an open non-start continues the run before it)
-            }
-            x.sync();
-            DBTK_STAMP(17);  // minimizers + runs
-            const uint32_t fq8 = lane >> 3, part = lane & 7;  // bucket fetch: 8 lanes x 16 bytes per bucket, 8 buckets per load instruction
-            for (uint32_t r0 = 0; r0 < nruns; r0 += MZ_RB) {
-                x.sync();
-                uint4 q[MZ_RB / 8];
-#pragma unroll
-                for (int u = 0; u < MZ_RB / 8; ++u) {  // the loads first, all in flight together (a run past the end re-reads bucket 0)
-                    const uint32_t run = r0 + 8 * u + fq8;
-                    uint64_t b = run < nruns ? (uint64_t)sm.rb[run] : 0ull;
-#ifdef DBTK_STAMPS
-                    if (a.P.diag & 128) b &= 511;  // diagnostic: every home bucket in the first 64 KB of the table (cache hits)
-#endif
-                    q[u] = reinterpret_cast<const uint4*>(T.mz + b)[part];
-                }
-#pragma unroll
-                for (int u = 0; u < MZ_RB / 8; ++u) {
-                    const uint32_t t = 8 * u + fq8;
-                    sm.stg[t][2 * part] = ((uint64_t)q[u].y << 32) | q[u].x; sm.stg[t][2 * part + 1] = ((uint64_t)q[u].w << 32) | q[u].z;
-                }
-                x.sync();
-#pragma unroll
-                for (int j = 0; j < NSLOT; ++j) {
-                    if (!(open[j] && rid[j] >= r0 && rid[j] < r0 + MZ_RB)) continue;
-                    const uint64_t* kk = sm.stg[rid[j] - r0];
-                    int hit = -1;
-#pragma unroll
-                    for (int e = 0; e < 7; ++e) if (kk[e] == km[j]) hit = e;
-                    const uint64_t k7 = kk[7];
-                    if (k7 != NAN64 && (k7 & ~IDX_OVF) == km[j]) hit = 7;
-                    if (hit >= 0) {
-                        const uint32_t* va = reinterpret_cast<const uint32_t*>(kk + 8);
-                        rvv[j] = (uint64_t)va[hit] | ((uint64_t)va[8 + hit] << 32);
-                    } else if (k7 != NAN64 && (k7 & IDX_OVF)) pend2[j] = true;  // the bucket turned keys away: ask the plain index
-                }
-            }
-            DBTK_STAMP(18);  // home buckets: fetch + search
-#ifdef DBTK_STAMPS
-            st_acc[19] += nruns;
-#endif
-        }
         // ---- look-ups in the plain index
-        if constexpr (MZ) {
-            // The positions the home buckets left open (about one in ten, clustered): every lane looks its own up, the whole
-            // 64-byte bucket per position (four 16-byte loads of one line), all of a lane's loads in flight together.  No list,
-            // no LDS, no ballots: with a dozen look-ups per read the quad-cooperative form below costs more in instructions
-            // than it saves in requests.
-            bool anyp = false;
-#pragma unroll
-            for (int j = 0; j < NSLOT; ++j) anyp |= pend2[j];
-            if (x.ballot(anyp)) {
-                uint4 bw[NSLOT][4];
-                uint32_t hb[NSLOT];
-                auto eval = [&](int j, bool on, bool& more) {  // one bucket against km[j]: result, or "walk on" (full + overflowed, no match)
-                    const uint64_t k0 = ((uint64_t)bw[j][0].y << 32) | bw[j][0].x, k1 = ((uint64_t)bw[j][0].w << 32) | bw[j][0].z;
-                    const uint64_t k2 = ((uint64_t)bw[j][1].y << 32) | bw[j][1].x, k3 = ((uint64_t)bw[j][1].w << 32) | bw[j][1].z;
-                    const uint64_t v0 = ((uint64_t)bw[j][2].y << 32) | bw[j][2].x, v1 = ((uint64_t)bw[j][2].w << 32) | bw[j][2].z;
-                    const uint64_t v2 = ((uint64_t)bw[j][3].y << 32) | bw[j][3].x, v3 = ((uint64_t)bw[j][3].w << 32) | bw[j][3].z;
-                    const uint64_t kq = km[j];
-                    more = false;
-                    if (!on) return;
-                    if (k0 == kq) rvv[j] = v0;
-                    else if (k1 == kq) rvv[j] = v1;
-                    else if (k2 == kq) rvv[j] = v2;
-                    else if ((k3 & ~IDX_OVF) == kq) rvv[j] = v3;
-                    else if (k3 != NAN64 && (k3 & IDX_OVF)) more = true;
-                    else rvv[j] = (uint64_t)NOHIT;
-                };
-#pragma unroll
-                for (int j = 0; j < NSLOT; ++j) {  // the loads, straight-line (a closed lane re-reads bucket 0)
-                    hb[j] = pend2[j] ? (uint32_t)hash_idx(km[j], T.idx_shift) : 0u;
-                    const uint4* bp = reinterpret_cast<const uint4*>(T.idx + hb[j]);
-                    if ((uint32_t)j < npl) { bw[j][0] = bp[0]; bw[j][1] = bp[1]; bw[j][2] = bp[2]; bw[j][3] = bp[3]; }
-                    else { bw[j][0] = bw[j][1] = bw[j][2] = bw[j][3] = uint4{0, 0, 0, 0}; }
-                }
-                bool more[NSLOT];
-                bool anym = false;
-#pragma unroll
-                for (int j = 0; j < NSLOT; ++j) { eval(j, pend2[j] && (uint32_t)j < npl, more[j]); anym |= more[j]; }
-                if (x.ballot(anym)) {  // rare (about one look-up in a thousand): walk on, bucket by bucket
-#pragma unroll
-                    for (int j = 0; j < NSLOT; ++j) {
-                        bool mo = more[j];
-                        uint32_t bb = hb[j];
-                        while (x.ballot(mo)) {
-                            bb = (bb + 1) & (uint32_t)T.idx_mask;
-                            const uint4* bp = reinterpret_cast<const uint4*>(T.idx + (mo ? bb : 0u));
-                            bw[j][0] = bp[0]; bw[j][1] = bp[1]; bw[j][2] = bp[2]; bw[j][3] = bp[3];
-                            bool m2 = false;
-                            eval(j, mo, m2);
-                            mo = m2;
-                        }
-                    }
-                }
-            }
-        } else {
-        // Every position (no minimizer-grouped copy).  Stage (k-mer, home bucket) per position in LDS, then look the positions up 16 at a time: the four lanes of a
+        // Stage (k-mer, home bucket) per position in LDS, then look the positions up 16 at a time: the four lanes of a
         // quad read the four 16-byte parts of one bucket (keys 0,1 | keys 2,3 | values 0,1 | values 2,3), so a lookup
         // is one request for one 64-byte line and ends in its home bucket unless that bucket is full AND overflowed.
 #pragma unroll
@@ -1489,7 +1277,6 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                 }
             }
         }
-        }
         DBTK_STAMP(41);  // look-ups in the plain index
         x.sync();
         {   // the read's results: found positions, and whether they are all unique to one and the same locus
@@ -1500,7 +1287,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
             for (int j = 0; j < NSLOT; ++j) {
                 const uint32_t i = p0 + j;
                 const bool in = (uint32_t)j < npl && i < nk;
-                rv[j] = in ? (MZ ? rvv[j] : sm.rva[i]) : (uint64_t)NOHIT;
+                rv[j] = in ? sm.rva[i] : (uint64_t)NOHIT;
                 const uint32_t v = (uint32_t)rv[j];
                 const uint64_t hmk = x.ballot(v != NOHIT);
                 nh += (uint32_t)__builtin_popcountll(hmk);
@@ -1514,7 +1301,6 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
                 const uint32_t i = p0 + j;
                 if ((uint32_t)j < npl && i < nk) {
                     const uint32_t v = (uint32_t)rv[j];
-                    if (a.hitkm) outk[i] = km[j];
                     outa[i] = v != NOHIT ? (uint32_t)(rv[j] >> 32) : AUX_MISS;
                     if (!uniform) outv[i] = v;
                 }
@@ -1541,6 +1327,10 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
     }
     DBTK_STAMP_FLUSH;
 }
+
+}  // namespace dbtk
+#include "dbtk_probe2.h"
+namespace dbtk {
 
 // ---- one pair's record (kam: AQ.cpp:2169-2175; trace: every pair).  Trace records are indexed by pair, the others compacted.
 template <class X>
@@ -1618,7 +1408,12 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
     const uint64_t tlim64 = (uint64_t)a.t0 + a.tcap;
     const uint32_t tlim = nsurv < tlim64 ? nsurv : (uint32_t)tlim64;
     const uint32_t nslp = a.nkp >> 6;
-    const uint32_t stride = x.nblocks();
+    // The survivor list is in locus order (dbtk_probe2.h: body_surv_*).  A wave takes a CONTIGUOUS range of it, so that the waves
+    // running at the same time are a range apart — on different loci: fifty pairs of one locus resolved side by side would send
+    // all their count atomics to the same few counters at once (atomics on one address serialize).
+    const uint32_t nit = tlim > a.t0 ? tlim - a.t0 : 0u, per = (nit + x.nblocks() - 1) / x.nblocks();
+    const uint64_t tb64 = (uint64_t)a.t0 + (uint64_t)x.bid() * per;
+    const uint32_t tbeg = tb64 < tlim ? (uint32_t)tb64 : tlim, tfin = tb64 + per < tlim ? (uint32_t)(tb64 + per) : tlim;
     uint32_t ngb = 0;
     auto flush_gen = [&]() {
         x.sync();
@@ -1670,14 +1465,14 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
         }
     };
     DBTK_STAMP_DECL
-    uint32_t t = a.t0 + x.bid();
-    if (t < tlim) { request(t); deliver(); }
-    for (; t < tlim; t += stride) {
+    uint32_t t = tbeg;
+    if (t < tfin) { request(t); deliver(); }
+    for (; t < tfin; ++t) {
         DBTK_STAMP(39);  // loop overhead / record of the previous pair
 #ifdef DBTK_STAMPS
         if (!(a.P.diag & 8))  // diagnostic: no loads after the first pair (every pair re-resolves the same data)
 #endif
-        request(t + stride < tlim ? t + stride : t);  // (past the end: a harmless reload, so that the loads stay straight-line)
+        request(t + 1 < tfin ? t + 1 : t);  // (past the end: a harmless reload, so that the loads stay straight-line)
         const uint32_t pair_cur = pair;
         // kfilter (AQ.cpp:190-228) aborts a mate at its (nk - cth + 1)-th miss, i.e. iff it has fewer than cth found positions
         // (the probe kernel counted the found positions of each read and checked that they share one even index value)
@@ -1841,15 +1636,18 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     const uint32_t nitems = listmode ? *a.ngen : (nsurv > a.t0 ? ((nsurv - a.t0 < a.tcap) ? nsurv - a.t0 : a.tcap) : 0u);
     constexpr uint32_t NOITEM = 0xFFFFFFFFu;
     if (nitems == 0) return;  // (an empty chunk must not touch the ticket: thousands of atomics on one address serialize)
-    // Items bid, bid + nb, ...: a fixed stride.  (A shared ticket counter balanced the varying work per item better, but
-    // 20 000 atomics on one address serialize at ~18 ns each: they, not the work, were the kernel's 0.2 ms.)
-    const uint32_t nb = x.nblocks();
-    uint32_t myq = x.bid();
-    auto take = [&]() { myq += nb; return myq; };
+    // A contiguous range of the items per wave (the list is in locus order, or — after the usual-pair kernel — in runs of it:
+    // waves side by side then work on different loci, see body_pair_usual).  (A shared ticket counter balanced the varying work
+    // per item better, but 20 000 atomics on one address serialize at ~18 ns each: they, not the work, were the kernel's 0.2 ms.)
+    const uint32_t qper = (nitems + x.nblocks() - 1) / x.nblocks();
+    const uint64_t qb64 = (uint64_t)x.bid() * qper;
+    const uint32_t qend = qb64 + qper < nitems ? (uint32_t)(qb64 + qper) : nitems;
+    uint32_t myq = qb64 < nitems ? (uint32_t)qb64 : nitems;
+    auto take = [&]() { myq += 1; return myq; };
     auto lookup = [&](uint32_t q) -> uint32_t {  // (an unconditional load: one issued under a branch is waited for on the spot)
-        const uint32_t qq = q < nitems ? q : 0u;
+        const uint32_t qq = q < qend ? q : 0u;
         const uint32_t v = listmode ? a.gen_list[qq] : a.t0 + qq;
-        return q < nitems ? v : NOITEM;
+        return q < qend ? v : NOITEM;
     };
     // Pipeline, so that nothing is waited for in the iteration that requested it (all loads straight-line, wave-uniform
     // values kept in vector registers until they are used — see `vzero`):
@@ -1950,7 +1748,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
             }
     };
     auto uni64 = [&](uint64_t v) { return ((uint64_t)x.uni((uint32_t)(v >> 32)) << 32) | x.uni((uint32_t)v); };
-    uint32_t t = x.uni(lookup(x.bid()));
+    uint32_t t = x.uni(lookup(myq));
     {   // prologue: item 0 through all its stages
         fetch_meta(t);
         const uint64_t o0[2] = {uni64(ofC[0]), uni64(ofC[1])}, hd[2] = {uni64(hdC[0]), uni64(hdC[1])};

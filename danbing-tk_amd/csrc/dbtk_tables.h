@@ -62,21 +62,33 @@ struct ClsSlot {
     uint64_t lc;    // ~0 = not yet written (build only)
 };
 
-// ---- the probe kernel's own copy of the index, grouped by MINIMIZER.  A random look-up costs one request to the memory
-// fabric whatever its size, and the chip completes ~50-58 G of them per second (tools/lat.hip): with one request per k-mer
-// the probe kernel sits on that ceiling at < 10 % of the HBM roofline.  The ~130 k-mers of a read overlap, so consecutive
-// ones share most of their m-mers: all keys whose smallest hashed canonical m-mer (m = 13) is the same — the k-mer's
-// minimizer, identical for a k-mer and its reverse complement — live in the same 128-byte bucket (8 keys, then their 8
-// index values, then their 8 classes).  A bucket that had to turn keys away says so in bit 63 of key[7]; those keys (one in
-// ten: the heavy minimizers of tandem repeats, and bucket collisions) are found in the plain index instead — two levels,
-// never a chain.  A read then needs one bucket per RUN of positions with the same minimizer (a new one every ~4
-// positions): the probe kernel stages those buckets in LDS and every position searches its run's bucket there.
-struct __attribute__((aligned(128))) MzBucket {
-    uint64_t key[8];  // NAN64 = empty; slots fill in order
-    uint32_t val[8];
-    uint32_t aux[8];
+// ---- the probe kernel's own copy of the index: two levels, both of 16-byte slots {k-mer, val, aux}.
+//
+// Level 1 is grouped by MINIMIZER and slotted by OFFSET.  The ~130 k-mers of a read overlap, so consecutive ones share
+// most of their m-mers: every k-mer is filed under its minimizer (the canonical m-mer with the smallest hash among its
+// k - m + 1 m-mers; the same for a k-mer and its reverse complement), one 128-byte bucket per minimizer, and INSIDE the
+// bucket at the slot given by where the minimizer sits in the canonical k-mer (offset 0 .. k - m, modulo 8).  A stretch of
+// unique sequence puts the k - m + 1 k-mers around a minimizer into k - m + 1 different slots of one bucket — a perfect
+// hash — so a position of a read finds its k-mer with ONE 16-byte load and ONE comparison, and the consecutive positions
+// that share a minimizer load from one 128-byte line (the later ones hit in the L1).  Nothing is staged, searched or
+// scanned.  A slot holds one key; a key that finds its slot taken (the heavy minimizers of tandem repeats: many k-mers with
+// the same minimizer at the same offset) sets the slot's MZ_TURNED bit and goes to level 2.
+//
+// Level 2 (the overflow table) holds exactly the keys level 1 turned away, open-addressed by a hash of the k-mer, linear
+// probing, at most a quarter full: a look-up that finds MZ_TURNED on a slot holding another key goes there; one that finds
+// a free slot or a mismatch without the bit is a miss.  Two levels, never a chain.
+//
+// Minimizer rule (builder and probe kernel must agree exactly, ties included): order the m-mers of the CANONICAL k-mer by
+// (hash >> 4, offset), smallest first.  The probe kernel sees the read's orientation: for a window whose reverse complement
+// is the canonical form the offsets run backwards, so it takes the LAST smallest hash there (see body_probe2).
+struct __attribute__((aligned(16))) MzSlot {
+    uint64_t key;  // canonical k-mer (< 2^62) | MZ_TURNED; MZ_EMPTY = free
+    uint32_t val;  // the index value
+    uint32_t aux;  // class of a single-locus k-mer at its locus (IdxBucket::val's high word)
 };
-constexpr uint32_t MZ_M = 15;  // m-mer length (k < 15: the k-mer itself); a stretch of unique sequence puts k - m + 1 = 7 keys in a bucket of 8
+constexpr uint64_t MZ_TURNED = 1ull << 63;
+constexpr uint64_t MZ_EMPTY = 0x3FFFFFFFFFFFFFFFull;  // poly-T at k = 31, never canonical (poly-A is): matches no k-mer, carries no flag
+constexpr uint32_t MZ_SLOTS = 8;                      // slots per level-1 bucket (128 bytes)
 
 struct DevTables;
 // ---- graph table (v1.3 threading): graphDB[locus] (GraphType = unordered_map<node, out-edge mask>,
@@ -115,7 +127,8 @@ struct DevTables {
     const ClsSlot* tre; uint64_t tre_mask; uint32_t tre_shift;
     const ClsSlot* bait; uint64_t bait_mask; uint32_t bait_shift;
     const GrSlot* gr; uint64_t gr_mask; uint32_t gr_shift;  // nullptr: no graph loaded
-    const MzBucket* mz; uint64_t mz_mask; uint32_t mz_shift, mz_m;  // nullptr: the probe kernel looks up the plain index
+    const MzSlot* mz; uint64_t mz_mask; uint32_t mz_m;  // level 1 (mz_mask = buckets - 1 <= 2^28 - 1); nullptr: the probe kernel looks up the plain index
+    const MzSlot* ovf; uint64_t ovf_mask;               // level 2 (ovf_mask = slots - 1 <= 2^32 - 1)
 };
 
 DBTK_HD uint64_t hash_mix(uint64_t key) {
@@ -285,24 +298,40 @@ DBTK_HD uint64_t revcomp2(uint64_t x, uint32_t k) {
     return (~x) >> (64 - 2 * k);
 }
 
-// Hash of a canonical m-mer (m <= 16) that orders the m-mers of a k-mer; the k-mer's minimizer is the smallest.
+// Hash of a canonical m-mer (m <= 16) that orders the m-mers of a k-mer; the k-mer's minimizer is the smallest.  One
+// multiplication (the probe kernel hashes every base of every read): the xor-shift in front spreads the high bases over the
+// word, the one behind brings the product's well-mixed high bits down into the bits the bucket number is taken from.
 DBTK_HD uint32_t mmer_hash2(uint32_t fw, uint32_t rc) {  // the two strands given
-    uint32_t x = fw < rc ? fw : rc;
-    x ^= x >> 13; x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 16;
+    uint32_t x = (fw < rc ? fw : rc) ^ 0x2545F491u;      // (poly-A must not hash to the smallest value)
+    x ^= x >> 14; x *= 0x9E3779B1u; x ^= x >> 15;
     return x;
 }
 DBTK_HD uint32_t mmer_hash(uint64_t fw, uint32_t m) { return mmer_hash2((uint32_t)fw, (uint32_t)revcomp2(fw, m)); }
-// Minimizer (as a hash value) of a k-mer given in either orientation: min over its k - m + 1 m-mers.
-DBTK_HD uint32_t kmer_minimizer(uint64_t kmer, uint32_t k, uint32_t m) {
+// Ordering key of the m-mer at window offset t (t <= 15): the hash without its low four bits, then the offset.
+DBTK_HD uint32_t mz_order(uint32_t h, uint32_t t) { return (h & ~15u) | t; }
+// Minimizer of a CANONICAL k-mer: *mz28 = its hash >> 4, *off = its (first) offset in the k-mer.  k - m + 1 <= 16.
+DBTK_HD void mz_of_kmer(uint64_t kmer, uint32_t k, uint32_t m, uint32_t* mz28, uint32_t* off) {
     const uint64_t mm = (1ull << 2 * m) - 1;
     uint32_t best = 0xFFFFFFFFu;
     for (uint32_t i = 0; i + m <= k; ++i) {
-        const uint32_t h = mmer_hash((kmer >> (2 * (k - m - i))) & mm, m);
-        best = h < best ? h : best;
+        const uint32_t o = mz_order(mmer_hash((kmer >> (2 * (k - m - i))) & mm, m), i);
+        best = o < best ? o : best;
     }
-    return best;
+    *mz28 = best >> 4; *off = best & 15u;
 }
-DBTK_HD uint64_t mz_bucket(uint32_t minimizer, uint32_t shift) { return ((uint64_t)minimizer * 0x9E3779B97F4A7C15ull) >> shift; }
+// Bucket of a minimizer.  The smallest of several hashes is a small number: its high bits are biased towards zero, its low
+// bits are not, so the high bits are folded onto unbiased ones before the mask (no multiplication: once per position).
+DBTK_HD uint32_t mz_bucket(uint32_t mz28, uint32_t mask) { return (mz28 ^ (mz28 << 9)) & mask; }
+DBTK_HD uint32_t mz_slot(uint32_t off) { return off & (MZ_SLOTS - 1); }
+// Slot of a k-mer in the overflow table (before the mask).
+DBTK_HD uint32_t ovf_hash(uint64_t kmer) {
+    uint32_t h = (uint32_t)kmer ^ ((uint32_t)(kmer >> 32) * 0x9E3779B1u);
+    h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+    return h;
+}
+// The minimizer length used for k, and whether the probe kernel's fast form (dbtk_probe2.h) exists for it: it is
+// instantiated for windows of k - m + 1 = 7 (k = 19 .. 22) and 11 (k = 23 .. 26) m-mers.  0: no level-1 / level-2 tables.
+DBTK_HD uint32_t mz_m_for_k(uint32_t k) { return (k >= 19 && k <= 22) ? k - 6 : (k >= 23 && k <= 26) ? k - 10 : 0u; }
 
 // Window of k bases starting at base `b` of a packed stream (pk: 16 bases per
 // word, vd: 16 validity bits per entry, both big-endian; two zero entries of

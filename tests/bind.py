@@ -409,6 +409,13 @@ class Emu(pkg._HostSide):
         L.emu_walk_results.restype = C.c_uint64
         L.emu_walk_results.argtypes = [C.POINTER(abi.WalkRes), u32p, C.c_uint64]
 
+    def probe_stats(self):
+        """(general-probe-body runs, lean-probe-body runs since the last call, keys the last tables' level 1 turned away)"""
+        out = np.zeros(3, np.uint64)
+        self.L.emu_probe_stats.argtypes = [u64p]
+        self.L.emu_probe_stats(out.ctypes.data_as(u64p))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def walk_results(self, cap):
         res = (abi.WalkRes * max(cap, 1))()
         n = self.L.emu_walk_results(res, None, cap)

@@ -109,6 +109,26 @@ def case_lengths(tmp):
     return Case(_rpgg(tmp, "lengths", loci, 21), 21, reads, [dict(cthreshold=45, okam=1), dict(cthreshold=10, okam=1)])
 
 
+def case_short21(tmp):
+    """Reads of at most 110 bases, k = 21: the probe kernel's three-positions-per-lane form (window of 7 m-mers);
+    lengths down to k + 15, N bases (the exact-validity path of that form)."""
+    loci = synth.make_loci(nloci=8, nhap=2, flank=500, seed=23, tr_min=200, tr_max=900)
+    rng = np.random.default_rng(4)
+    reads = synth.Reads()
+    for L in (100, 110, 66, 36):
+        r = synth.sim_reads(loci, npairs=120, rlen=L, seed=int(rng.integers(1 << 30)), sub=0.004, nrate=0.002, frag=(max(300, L), 520))
+        reads.seqs += r.seqs
+        reads.titles += [f"L{L}_{t}" for t in r.titles]
+    return Case(_rpgg(tmp, "short21", loci, 21), 21, reads, [dict(cthreshold=30, okam=1), dict(cthreshold=10, okam=0)])
+
+
+def case_short25(tmp):
+    """The same form at k = 25 (window of 11 m-mers)."""
+    loci = synth.make_loci(nloci=8, nhap=2, flank=500, seed=24, shared_frac=0.3, tr_min=200, tr_max=900)
+    reads = synth.sim_reads(loci, npairs=400, rlen=100, seed=25, sub=0.006, nrate=0.001, chimeric=0.2, background=0.1)
+    return Case(_np_rpgg(tmp, "short25", loci, 25), 25, reads, [dict(cthreshold=30, okam=1)])
+
+
 def case_kf(tmp):
     loci = synth.make_loci(nloci=12, nhap=3, flank=500, seed=5)
     reads = synth.sim_reads(loci, npairs=600, seed=16, sub=0.03, background=0.3, nrate=0.002)
@@ -147,8 +167,12 @@ def case_inconsistent(tmp):
 
 
 CASES = dict(clean=case_clean, mixed=case_mixed, shared=case_shared, k25=case_k25, k31=case_k31, k31long=case_k31long, k30long=case_k30long,
-             qc=case_qc, lengths=case_lengths,
+             qc=case_qc, lengths=case_lengths, short21=case_short21, short25=case_short25,
              kf=case_kf, spill=case_spill, inconsistent=case_inconsistent)
+
+
+# cases whose geometry the lean probe kernel (dbtk_probe2.h) takes; the others run the general one
+LEAN_PROBE = {"clean", "mixed", "shared", "k25", "qc", "short21", "short25", "kf", "spill", "inconsistent"}
 
 
 def make_case(name, tmp) -> Case:

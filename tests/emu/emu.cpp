@@ -67,6 +67,8 @@ struct EmuX {
     uint64_t ballot(bool p) const;
     uint32_t wave_sum(uint32_t v) const;
     uint32_t wave_min(uint32_t v) const;
+    uint32_t half_sum(uint32_t v) const;
+    uint32_t half_max(uint32_t v) const;
     uint32_t wave_scan_max(uint32_t v) const;
     uint32_t wave_excl_scan(uint32_t v) const;
     uint32_t bcast(uint32_t v, int src) const;
@@ -145,6 +147,24 @@ uint32_t EmuX::wave_min(uint32_t v) const {
     uint32_t s = 0xFFFFFFFFu;
     const int w0 = t & ~63;
     for (int l = 0; l < 64 && w0 + l < b->nt; ++l) if (!b->done[w0 + l] && (uint32_t)b->scratch[w0 + l] < s) s = (uint32_t)b->scratch[w0 + l];
+    b->yield();
+    return s;
+}
+uint32_t EmuX::half_sum(uint32_t v) const {
+    b->scratch[t] = v;
+    b->yield();
+    uint32_t s = 0;
+    const int h0 = t & ~31;
+    for (int l = 0; l < 32 && h0 + l < b->nt; ++l) s += (uint32_t)b->scratch[h0 + l];
+    b->yield();
+    return s;
+}
+uint32_t EmuX::half_max(uint32_t v) const {
+    b->scratch[t] = v;
+    b->yield();
+    uint32_t s = 0;
+    const int h0 = t & ~31;
+    for (int l = 0; l < 32 && h0 + l < b->nt; ++l) if ((uint32_t)b->scratch[h0 + l] > s) s = (uint32_t)b->scratch[h0 + l];
     b->yield();
     return s;
 }
@@ -256,13 +276,14 @@ struct EmuTables {
     std::vector<uint64_t> flt;
     std::vector<ClsSlot> tre, bait;
     std::vector<GrSlot> gr;
-    std::vector<MzBucket> mz;
+    std::vector<MzSlot> mz, ovf;
     uint64_t stats[3] = {0, 0, 0};
     DevTables T;
 };
 
 }  // namespace
 
+static uint64_t g_probe_runs[2] = {0, 0}, g_mz_turned = 0;
 extern "C" {
 
 void* emu_tables_create(const dbtk_rpgg_t* g) {
@@ -333,17 +354,21 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
         run_grid(3, 64, 0, [&](EmuX& x) { body_idx_aux(x, a); });
         T.consistent = (e->stats[1] == 0 && e->stats[0] == e->stats[2]) ? 1u : 0u;
     }
-    if (!getenv("DBTK_MZ") || atoi(getenv("DBTK_MZ"))) {  // the probe body's minimizer-grouped copy of the index (small: chains get exercised)
+    // the probe body's minimizer-grouped copy of the index (small: many turned-away keys exercise level 2), built as
+    // build_tables does on the device: level 1 + count, then the overflow table sized from the count
+    if (mz_m_for_k(g->ksize) && (!getenv("DBTK_MZ") || atoi(getenv("DBTK_MZ")))) {
         const uint64_t nb = pow2((g->keys.size() * 2) / 8 + 8) / 1024 ? pow2((g->keys.size() * 2) / 8 + 8) : 1024;
-        MzBucket empty;
-        memset(&empty, 0xFF, sizeof(empty));
-        e->mz.assign(nb, empty);
-        uint32_t m = MZ_M;
-        if (const char* ev = getenv("DBTK_MZ_M")) m = (uint32_t)atoi(ev);
-        if (m > g->ksize) m = g->ksize;
-        MzBuildArgs a{e->idx.data(), icap, e->mz.data(), nb - 1, 64 - lg(nb), g->ksize, m};
+        e->mz.assign(nb * MZ_SLOTS, MzSlot{MZ_EMPTY, 0, 0});
+        uint64_t nturned = 0;
+        MzBuildArgs a{e->idx.data(), icap, e->mz.data(), (uint32_t)(nb - 1), nullptr, 0, g->ksize, mz_m_for_k(g->ksize), 0, &nturned};
         run_grid(3, 64, 0, [&](EmuX& x) { body_mz_insert(x, a); });
-        T.mz = e->mz.data(); T.mz_mask = nb - 1; T.mz_shift = 64 - lg(nb); T.mz_m = m;
+        g_mz_turned = nturned;
+        const uint64_t ocap = pow2(4 * nturned + 8);
+        e->ovf.assign(ocap, MzSlot{MZ_EMPTY, 0, 0});
+        a.ovf = e->ovf.data(); a.ovf_mask = (uint32_t)(ocap - 1); a.pass = 1;
+        run_grid(3, 64, 0, [&](EmuX& x) { body_mz_insert(x, a); });
+        T.mz = e->mz.data(); T.mz_mask = nb - 1; T.mz_m = a.m;
+        T.ovf = e->ovf.data(); T.ovf_mask = ocap - 1;
     }
     if (!g->gr_cnt.empty()) {  // graph table: graph pass, then TR pass (as build_graph_table does on the device)
         const uint64_t ngr = g->gr_ks.size(), ntrf = g->tr_ks.size();
@@ -589,9 +614,10 @@ uint64_t emu_walk_results(dbtk_walk_res_t* res, uint32_t* tidx, uint64_t cap) {
     return g_walk_res.size();
 }
 
-static int g_keep_km = 0;  // 1: the k-mers travel from the probe body to the resolve body (the old way)
-void emu_set_keep_km(int on) { g_keep_km = on; }
 
+// which probe body the last calls of emu_align_ex dispatched: [0] general (body_probe), [1] lean (body_probe2); and the
+// keys level 1 of the last emu_tables_create turned away (= entries of its overflow table)
+void emu_probe_stats(uint64_t* out) { out[0] = g_probe_runs[0]; out[1] = g_probe_runs[1]; out[2] = g_mz_turned; g_probe_runs[0] = g_probe_runs[1] = 0; }
 int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
               uint64_t npairs, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* counters,
               dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec, uint32_t grid_k1, uint32_t grid_pair) {
@@ -630,11 +656,10 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     a.pair_base = 0;
     // survivor chunks: small hit buffers force several K2 -> K3 iterations, as on the device
     const uint32_t tcap = npairs > 7 ? (uint32_t)(npairs / 3 + 1) : (uint32_t)(npairs ? npairs : 1);
-    std::vector<uint64_t> hitkm((size_t)tcap * 2 * a.nkp + 1, 0);
     std::vector<uint64_t> hitva((size_t)tcap * 2 * a.nkp + 1, 0);  // aux words of every row, then val words
     std::vector<uint32_t> hitnk((size_t)tcap * 2 + 1, 0), gen(tcap + 1, 0);
     std::vector<uint64_t> hitoff((size_t)tcap * 4 + 1, 0);
-    a.hitkm = g_keep_km ? hitkm.data() : nullptr; a.hitaux = reinterpret_cast<uint32_t*>(hitva.data()); a.hitval = a.hitaux + (size_t)tcap * 2 * a.nkp; a.hitnk = hitnk.data(); a.hitoff = hitoff.data(); a.hithdr = hitoff.data() + (size_t)tcap * 2;
+    a.hitaux = reinterpret_cast<uint32_t*>(hitva.data()); a.hitval = a.hitaux + (size_t)tcap * 2 * a.nkp; a.hitnk = hitnk.data(); a.hitoff = hitoff.data(); a.hithdr = hitoff.data() + (size_t)tcap * 2;
     a.tcap = tcap;
     const bool usual = e->T.consistent && !p->trace && !p->bait && !p->bubbles;  // as the device launcher decides
     std::vector<uint64_t> edgebuf, qmaskbuf, qualbuf;
@@ -650,24 +675,48 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         a.qual = (const uint8_t*)qualbuf.data(); a.qmaskbuf = qmaskbuf.data();
     }
     run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter(x, a); });
+    std::vector<uint32_t> sorted(npairs + 1), skey(npairs + 1), shist(nloci + 2 + SCAN_BLOCKS, 0);
+    {   // the survivor list in locus order, as launch_batch does
+        SurvSortArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.T = e->T; sa.P = *p; sa.seq = a.seq; sa.off = off; sa.surv = surv.data(); sa.nsurv = &small[0];
+        sa.sorted = sorted.data(); sa.key = skey.data(); sa.hist = shist.data();
+        run_grid(3, 64, 0, [&](EmuX& x) { body_surv_key(x, sa); });
+        run_grid(SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_surv_scan(x, sa, 0); });
+        run_grid(SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_surv_scan(x, sa, 1); });
+        run_grid(3, 64, 0, [&](EmuX& x) { body_surv_scatter(x, sa); });
+        std::vector<uint32_t> a1(surv.begin(), surv.begin() + small[0]), a2(sorted.begin(), sorted.begin() + small[0]);
+        std::sort(a1.begin(), a1.end()); std::sort(a2.begin(), a2.end());
+        if (a1 != a2) return -77;  // the sorted list must be a permutation of the encode stage's
+        a.surv = sorted.data();
+    }
     for (uint32_t t0 = 0; t0 < (uint32_t)(npairs ? npairs : 1); t0 += tcap) {
         a.t0 = t0;
         uint32_t ngen = 0;
         a.gen_list = usual ? gen.data() : nullptr;
         a.ngen = usual ? &ngen : nullptr;
-        switch (a.nkp / 64) {  // same dispatch as the device launcher
+        // same dispatch as the device launcher (launch_batch): the lean probe body where its conditions hold
+        const uint32_t wn = a.T.mz ? g->ksize - a.T.mz_m + 1 : 0;
+        const int npl = !a.T.mz || p->bubbles || (p->bait && qual) ? 0 : (maxlen <= 32 * 3 + a.T.mz_m - 1 ? 3 : maxlen <= 32 * 5 + a.T.mz_m - 1 ? 5 : 0);
+        g_probe_runs[npl ? 1 : 0] += 1;
+        const uint32_t grid_p2 = (grid_pair & 1) ? 8 : grid_pair + 2;  // (a multiple of 8: the lean body's per-XCD split of the list)
+        if (npl == 3 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { body_probe2<3, 7>(x, a); });
+        else if (npl == 3 && wn == 11) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { body_probe2<3, 11>(x, a); });
+        else if (npl == 5 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<5>), [&](EmuX& x) { body_probe2<5, 7>(x, a); });
+        else if (npl == 5 && wn == 11) run_grid(grid_p2, 64, sizeof(Probe2SmemT<5>), [&](EmuX& x) { body_probe2<5, 11>(x, a); });
+        switch (a.nkp / 64) {
             case 1: case 2:
-                run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { if (a.T.mz) body_probe<2, true>(x, a); else body_probe<2, false>(x, a); });
+                if (!npl) run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<2>(x, a); });
                 if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<2, true>(x, a); else body_pair_usual<2, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<2>), [&](EmuX& x) { if (a.recs) body_pair<2, true>(x, a); else body_pair<2, false>(x, a); });
                 break;
             case 3:
-                run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { if (a.T.mz) body_probe<3, true>(x, a); else body_probe<3, false>(x, a); });
+                if (!npl) run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<3>(x, a); });
                 if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<3, true>(x, a); else body_pair_usual<3, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<3>), [&](EmuX& x) { if (a.recs) body_pair<3, true>(x, a); else body_pair<3, false>(x, a); });
                 break;
             default:
-                run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { if (a.T.mz) body_probe<4, true>(x, a); else body_probe<4, false>(x, a); });
+                if (!npl) run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<4>(x, a); });
                 if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<4, true>(x, a); else body_pair_usual<4, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<4>), [&](EmuX& x) { if (a.recs) body_pair<4, true>(x, a); else body_pair<4, false>(x, a); });
         }
@@ -676,7 +725,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         WalkArgs w;
         memset(&w, 0, sizeof(w));
         w.T = e->T; w.P = *p; w.seq = a.seq; w.off = off;
-        w.surv = surv.data(); w.nsurv = &small[0];
+        w.surv = sorted.data(); w.nsurv = &small[0];
         w.walk_dst = walk.data(); w.walk_ret = walk.data() + npairs;
         w.counts = a.counts; w.counters = a.counters;
         w.trecs = g_walk_trecs; w.errflag = &small[3];
@@ -702,7 +751,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         }
         g_walk_res.clear();
         for (uint32_t t = 0; t < small[0]; ++t)
-            if (walk[t] != NAN32) g_walk_res.push_back({surv[t], walk[t], (int8_t)(walk[npairs + t] & 0xFF), (int8_t)((walk[npairs + t] >> 8) & 0xFF), {(uint8_t)(t & 0xFF), (uint8_t)0}});
+            if (walk[t] != NAN32) g_walk_res.push_back({sorted[t], walk[t], (int8_t)(walk[npairs + t] & 0xFF), (int8_t)((walk[npairs + t] >> 8) & 0xFF), {(uint8_t)(t & 0xFF), (uint8_t)0}});
         g_walk_t.clear();
         for (uint32_t t = 0; t < small[0]; ++t) if (walk[t] != NAN32) g_walk_t.push_back(t);
     }

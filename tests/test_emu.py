@@ -32,6 +32,7 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
     seq, off = c.reads.packed()
     # the load-time check: index memberships == flank/TR sets  <=>  the class rides in the index slot
     assert E.consistent(T) == (0 if case == "inconsistent" else 1)
+    E.probe_stats()
     for i, kw in enumerate(c.param_sets):
         p = abi.default_params(ksize=c.k, trace=1, **kw)
         a = O.align(go, p, seq, off)
@@ -55,6 +56,10 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
         assert (co2 == b2["counts"]).all()
         assert (a2["kmc"] == b2["kmc"]).all() and (a2["nmapread"] == b2["nmapread"]).all()
         assert (a2["counters"] == b2["counters"]).all(), (a2["counters"], b2["counters"])
+    general, lean, turned = E.probe_stats()  # the probe body the case is meant to exercise is the one that ran
+    assert (lean > 0 and general == 0) if case in cases.LEAN_PROBE else (general > 0 and lean == 0), (general, lean)
+    if case in ("shared", "spill"):
+        assert turned > 0  # keys in the overflow table: level 2 of the lean body's look-ups is exercised
     E.L.emu_tables_free(T)
     O.free(go)
     g.close()
