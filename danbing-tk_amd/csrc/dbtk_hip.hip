@@ -62,7 +62,7 @@ template <int NS> __global__ void __launch_bounds__(64) __attribute__((amdgpu_wa
 }
 // the lean probe kernel (dbtk_probe2.h): NPL positions per lane, windows of WN m-mers
 #ifndef DBTK_P2_WPE
-#define DBTK_P2_WPE 4  // waves per SIMD its registers are budgeted for
+#define DBTK_P2_WPE 4  // waves per SIMD its registers are budgeted for (its LDS allows 16 waves per CU)
 #endif
 template <int NPL, int WN> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_P2_WPE, 8))) k_probe(BatchArgs a) {
     __shared__ Probe2SmemT<NPL> sm;
@@ -81,7 +81,7 @@ template <int NS, bool RECS> __global__ void __launch_bounds__(64, NS <= 3 ? 2 :
 }
 
 __global__ void __launch_bounds__(256) k_mz_insert(MzBuildArgs a) { DevX x{nullptr}; body_mz_insert(x, a); }
-__global__ void __launch_bounds__(256) k_mz_fill(MzSlot* t, uint64_t n) { DevX x{nullptr}; body_mz_fill(x, t, n); }
+__global__ void __launch_bounds__(256) k_mz_fill(uint64_t* t, uint64_t nwords, int level1) { DevX x{nullptr}; body_mz_fill(x, t, nwords, level1); }
 __global__ void __launch_bounds__(256) k_surv_key(SurvSortArgs a) { DevX x{nullptr}; body_surv_key(x, a); }
 __global__ void __launch_bounds__(64) k_surv_scan(SurvSortArgs a, int step) { DevX x{nullptr}; body_surv_scan(x, a, step); }
 __global__ void __launch_bounds__(256) k_surv_scatter(SurvSortArgs a) { DevX x{nullptr}; body_surv_scatter(x, a); }
@@ -155,7 +155,7 @@ struct Timed {
 struct TableShare {
     int refs = 0;
     IdxBucket* d_idx = nullptr; uint64_t* d_flt = nullptr; uint64_t flt_words = 0; uint32_t* d_trbeg = nullptr; ClsSlot* d_cls = nullptr;
-    MzSlot* d_mz = nullptr; MzSlot* d_ovf = nullptr; GrSlot* d_gr = nullptr; uint32_t* d_vv = nullptr; uint8_t* d_qc = nullptr; uint16_t* d_perm = nullptr;
+    MzBucket* d_mz = nullptr; MzSlot* d_ovf = nullptr; GrSlot* d_gr = nullptr; uint32_t* d_vv = nullptr; uint8_t* d_qc = nullptr; uint16_t* d_perm = nullptr;
     ClsSlot* d_tre = nullptr; ClsSlot* d_bait = nullptr;
     DevTables T;
     uint32_t consistent = 0;
@@ -173,7 +173,7 @@ struct dbtk_ctx {
     uint64_t* d_flt = nullptr; uint64_t flt_words = 0;
     uint32_t* d_trbeg = nullptr;
     ClsSlot* d_cls = nullptr;
-    MzSlot* d_mz = nullptr;       // the probe kernel's minimizer-grouped copy of the index (level 1)
+    MzBucket* d_mz = nullptr;     // the probe kernel's minimizer-grouped copy of the index (level 1)
     MzSlot* d_ovf = nullptr;      //   ... and its overflow table (level 2)
     GrSlot* d_gr = nullptr;       // graph table (threading = 2), nullptr when the handle holds no graph
     uint32_t* d_vv = nullptr;
@@ -216,7 +216,7 @@ struct dbtk_ctx {
     std::vector<std::unordered_map<uint64_t, uint16_t>> baitDB_host;
     std::vector<dbtk_pair_rec_t> own_recs;  // record buffer when the caller passes none but -tb needs the bait-stage records
     uint64_t mz_turned = 0;       // keys in the overflow table
-    int k1_blocks = 0, probe_wpc = 32;
+    int k1_blocks = 0, probe_wpc = 32, probe2_wpc[4] = {8, 8, 8, 8};
     bool timers_on = true;
     uint32_t timers_every = 1;  // event records around the kernels of every n-th batch (8 records cost ~30 us per batch)
     uint64_t batch_no = 0;
@@ -424,12 +424,12 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         if (const char* e = getenv("DBTK_MZ")) on = atoi(e) != 0;
         const uint32_t m = mz_m_for_k(g->ksize);
         if (on && m && nkeys) {
-            uint64_t per = 6;  // buckets per 8 keys (17 GB at release scale): what keeps two minimizers out of one bucket
+            uint64_t per = 6;  // buckets per 8 keys (17 GB at release scale): nine keys in ten then sit in their minimizer's bucket
             if (const char* e = getenv("DBTK_MZ_SPARSITY")) { const long v = atol(e); if (v >= 1 && v <= 64) per = (uint64_t)v; }
             uint64_t nb = pow2_at_least(nkeys * per / 8 + 8);
             if (nb > (1ull << 28)) nb = 1ull << 28;  // the bucket number comes out of 28 bits of the minimizer's hash
-            HIPCHK(hipMalloc(&c->d_mz, nb * MZ_SLOTS * sizeof(MzSlot)));
-            LAUNCH(k_mz_fill, dim3(2048), dim3(256), s, c->d_mz, nb * MZ_SLOTS);
+            HIPCHK(hipMalloc(&c->d_mz, nb * sizeof(MzBucket)));
+            LAUNCH(k_mz_fill, dim3(2048), dim3(256), s, reinterpret_cast<uint64_t*>(c->d_mz), nb * 16, 1);
             uint64_t* dn = nullptr;
             HIPCHK(hipMalloc(&dn, 8));
             HIPCHK(hipMemsetAsync(dn, 0, 8, s));
@@ -439,10 +439,10 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
             HIPCHK(hipMemcpyAsync(&nturned, dn, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipFree(dn));
-            uint64_t ocap = pow2_at_least(4 * nturned + 8);  // level 2: those keys, at most a quarter full
+            uint64_t ocap = pow2_at_least(16 * nturned + 8);  // level 2: those keys, at most a sixteenth full
             if (ocap > (1ull << 32)) { set_error("overflow table of the probe kernel: more than 2^30 keys"); return DBTK_ERR_UNSUPPORTED; }
             HIPCHK(hipMalloc(&c->d_ovf, ocap * sizeof(MzSlot)));
-            LAUNCH(k_mz_fill, dim3(2048), dim3(256), s, c->d_ovf, ocap);
+            LAUNCH(k_mz_fill, dim3(2048), dim3(256), s, reinterpret_cast<uint64_t*>(c->d_ovf), ocap * 2, 0);
             a.ovf = c->d_ovf; a.ovf_mask = (uint32_t)(ocap - 1); a.pass = 1;
             LAUNCH(k_mz_insert, dim3(2048), dim3(256), s, a);
             HIPCHK(hipStreamSynchronize(s));
@@ -683,10 +683,11 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             const dim3 gpr(c->num_cu * c->probe_wpc);
             const uint32_t wn = a.T.mz ? k - a.T.mz_m + 1 : 0;
             const int npl = !a.T.mz || a.edgebuf || a.qmaskbuf ? 0 : (max_read_len <= 32 * 3 + a.T.mz_m - 1 ? 3 : max_read_len <= 32 * 5 + a.T.mz_m - 1 ? 5 : 0);
-            if (npl == 3 && wn == 7) LAUNCH((k_probe<3, 7>), gpr, dim3(64), s, a);
-            else if (npl == 3 && wn == 11) LAUNCH((k_probe<3, 11>), gpr, dim3(64), s, a);
-            else if (npl == 5 && wn == 7) LAUNCH((k_probe<5, 7>), gpr, dim3(64), s, a);
-            else if (npl == 5 && wn == 11) LAUNCH((k_probe<5, 11>), gpr, dim3(64), s, a);
+            // (a wave of the lean form works through one contiguous range of the list: as many waves as are resident at once)
+            if (npl == 3 && wn == 7) LAUNCH((k_probe<3, 7>), dim3(c->num_cu * c->probe2_wpc[0]), dim3(64), s, a);
+            else if (npl == 3 && wn == 11) LAUNCH((k_probe<3, 11>), dim3(c->num_cu * c->probe2_wpc[1]), dim3(64), s, a);
+            else if (npl == 5 && wn == 7) LAUNCH((k_probe<5, 7>), dim3(c->num_cu * c->probe2_wpc[2]), dim3(64), s, a);
+            else if (npl == 5 && wn == 11) LAUNCH((k_probe<5, 11>), dim3(c->num_cu * c->probe2_wpc[3]), dim3(64), s, a);
             else if (ns <= 2) LAUNCH((k_probe_general<2>), gpr, dim3(64), s, a);
             else if (ns == 3) LAUNCH((k_probe_general<3>), gpr, dim3(64), s, a);
             else LAUNCH((k_probe_general<4>), gpr, dim3(64), s, a);
@@ -795,6 +796,16 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
         if (const char* ev = getenv("DBTK_ENC_WPC")) { const int v = atoi(ev); if (v > 0) nb = v; }  // diagnostic: encode waves per CU (more than resident: several rounds)
         c->k1_blocks = c->num_cu * nb;
         if (const char* ev = getenv("DBTK_PROBE_WPC")) { const int v = atoi(ev); if (v > 0) c->probe_wpc = v; }  // probe waves per CU
+        {
+            const void* k2[4] = {(const void*)k_probe<3, 7>, (const void*)k_probe<3, 11>, (const void*)k_probe<5, 7>, (const void*)k_probe<5, 11>};
+            for (int i = 0; i < 4; ++i) {
+                nb = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k2[i], 64, 0) != hipSuccess || nb <= 0) nb = 8;
+                if (const char* ev = getenv("DBTK_PROBE_WPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
+                c->probe2_wpc[i] = nb;
+            }
+            if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_probe<5, 7>: %d waves per CU\n", c->probe2_wpc[2]);
+        }
         // resident waves of each resolve-kernel instance (one vote-spill scratch row per resident wave)
         const void* kp[3] = {(const void*)k_pair<2, true>, (const void*)k_pair<3, true>, (const void*)k_pair<4, true>};
         for (int i = 0; i < 3; ++i) {

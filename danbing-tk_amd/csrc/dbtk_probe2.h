@@ -1,36 +1,44 @@
 // dbtk_probe2.h — the probe kernel (K2) in its lean form: kfilter's look-ups (src/aQueryFasta_thread.cpp:190-224, the
-// `kmerDBi.find(kmers[i])` of every position of both mates) through the offset-slotted, minimizer-grouped copy of the index
-// (dbtk_tables.h: MzSlot).  Included by dbtk_kernels.h (needs BatchArgs); instantiated with DevX on the GPU and with the
-// coroutine lanes of tests/emu on the host.
+// `kmerDBi.find(kmers[i])` of every position of both mates) through the minimizer-grouped copy of the index
+// (dbtk_tables.h: MzBucket, MzSlot).  Included by dbtk_kernels.h (needs BatchArgs); instantiated with DevX on the GPU and
+// with the coroutine lanes of tests/emu on the host.
 //
-// One wave per surviving PAIR, one mate per half-wave: lane l of a half owns the NPL consecutive positions l * NPL ..
-// l * NPL + NPL - 1 of its mate (NPL = 5: reads up to 32 * 5 + m - 1 bases).  Everything a position needs is a shift of
-// one 32-base word W held by its lane and of W's reverse complement:
-//   raw bytes (two dwords per lane, prefetched two pairs ahead)  ->  2 bits per base, 16 bits per lane, into LDS
-//   W, RW                      <- three LDS words
-//   canonical k-mer            <- W >> .., RW >> ..                                  (per position)
-//   hashed canonical m-mer     <- W >> .., RW >> ..  -> LDS                          (per BASE: each is hashed once)
-//   minimizer of every window  <- NPL + WN - 1 LDS words, sliding minimum in registers, twice: first and last smallest
-//                                 hash (the canonical form of a window is the read's strand or the other one, and the
-//                                 builder's tie rule is stated on the canonical form)
-//   bucket, slot               <- the minimizer's hash, its offset in the canonical k-mer
-//   ONE 16-byte load per position (the positions sharing a minimizer read one 128-byte line), ONE comparison
-//   a slot that turned keys away and holds another key: the overflow table, one 16-byte load per probe
-//   results: 4 bytes per position (`aux`), + 4 (`val`) for a read whose found k-mers are not all unique to one locus,
-//            transposed through LDS so that they leave as 16-byte stores.
-// No run detection, no bucket staging, no search loop, no scalar loop over positions: the unrolled body is the same for
-// every read, and the per-read header (found positions, one index value or not) comes from three half-wave reductions.
+// What bounds this kernel is the number of 128-byte lines it asks the memory system for (dbtk_tables.h: a request is a line
+// asked for by one load instruction), so it is built to ask for every line once:
+//   * one wave per surviving PAIR, one mate per half-wave: lane l of a half owns the NPL consecutive positions l * NPL ..
+//     l * NPL + NPL - 1 of its mate (NPL = 5: reads up to 32 * 5 + m - 1 bases); everything a position needs is a shift of
+//     one 32-base word W held by its lane and of W's reverse complement: the canonical k-mer, and the hashed canonical
+//     m-mer of every BASE (each hashed once, exchanged through LDS), whose sliding minimum is the position's minimizer;
+//   * a RUN of positions with one minimizer shares a bucket: run starts are found with one wave scan, and the bucket of
+//     every run is fetched ONCE — 8 lanes x 16 bytes, 8 runs per load instruction, the next chunk of runs in flight while
+//     this one is searched — into LDS, where every position compares its k-mer with the 8 keys of its run's bucket;
+//   * the keys a full bucket turned away (tandem repeats: many k-mers around few m-mers) are in the overflow table, one
+//     16-byte load per look-up — and the same few k-mers come back all along a repeat and in every read of its locus, so the
+//     wave keeps the results of its overflow look-ups in a small LDS cache: the survivor list is in locus order
+//     (body_surv_*, below) and a wave works through a CONTIGUOUS range of it, the reads of one locus one after the other;
+//   * results: 4 bytes per position (`aux`), + 4 (`val`) for a read whose found k-mers are not all unique to one locus,
+//     transposed through LDS so that they leave as 16-byte stores; the per-read header (found positions, one index value or
+//     not) comes from three half-wave reductions.
 #ifndef DBTK_PROBE2_H_
 #define DBTK_PROBE2_H_
 
 namespace dbtk {
 
+constexpr int P2_RCH = 40;    // runs (buckets) staged in LDS at a time (a pair of 150-bp reads has ~66: two chunks)
+constexpr int P2_ROW = 9;     // 16-byte granules per staged bucket: 8 + 1 of padding (rows on different LDS banks)
+constexpr int P2_CACHE = 128; // entries of the wave's cache of overflow look-ups
 template <int NPL>
 struct __attribute__((aligned(16))) Probe2SmemT {
     uint32_t pk[2][20];              // 2-bit stream of each mate from its 4-byte-aligned start: 16 words (+ slack)
     uint16_t vd[2][40];              // validity bits of the same bases (only for a pair with a non-ACGT byte)
-    uint32_t hm[2][32 * NPL + 16];   // hashed canonical m-mer by base position; the last 16 stay 0xFFFFFFFF
-    uint32_t res[2][2][32 * NPL];    // [mate][aux | val][position]: the results on their way to 16-byte stores
+    uint32_t rb[64 * NPL];           // bucket of every run of the pair
+    union {                          // three phases share one region
+        uint32_t hm[2][32 * NPL + 16];                                  // hashed canonical m-mer by base position (the last 16 stay 0xFFFFFFFF)
+        uint4 stg[P2_RCH][P2_ROW];                                      // the buckets of a chunk of runs
+        uint32_t res[2][2][32 * NPL];                                   // [mate][aux | val][position]: results on their way to 16-byte stores
+    };
+    uint4 cache[P2_CACHE];           // {k-mer, val, aux} of overflow look-ups already made (val = NOHIT: not in the index)
+    uint8_t tok[P2_CACHE];           // which lane writes an entry when several want to in one step
 };
 
 // out[j] = min(f[j .. j + WN - 1]), j < NPL, sharing the part common to all windows (WN >= NPL)
@@ -53,9 +61,27 @@ DBTK_HD void sliding_min(const uint32_t (&f)[NPL + WN - 1], uint32_t (&out)[NPL]
     }
 }
 
+// The 16-byte part `part` of the buckets of runs r0 + 8u + fq8, u = 0 .. P2_RCH / 8 - 1: straight-line loads, no branch around them
+// (the array must stay in registers and the loads in flight); a run past the end re-reads bucket 0, one hot line.
+#ifdef DBTK_STAMPS
+#define P2_DIAG_MASK(a) (((a).P.diag & 512) ? 127u : 0xFFFFFFFFu)  /* diagnostic: every bucket in the first 16 KB of the table (cache hits) */
+#else
+#define P2_DIAG_MASK(a) 0xFFFFFFFFu
+#endif
+typedef uint32_t p2_v4u __attribute__((vector_size(16)));  // (a native vector, not HIP's uint4 class: an array of these that lives across
+                                                           // a loop's back edge stays in registers; an array of uint4 went to scratch memory)
+DBTK_HD void p2_fetch_runs(const uint32_t* rb, const MzBucket* mz, uint32_t nruns, uint32_t r0, uint32_t fq8, uint32_t part, uint32_t bmask,
+                           p2_v4u (&q)[P2_RCH / 8]) {
+#pragma unroll
+    for (int u = 0; u < P2_RCH / 8; ++u) {
+        const uint32_t run = r0 + 8 * u + fq8;
+        const uint32_t b = rb[run < nruns ? run : 0u] & bmask;
+        q[u] = reinterpret_cast<const p2_v4u*>(mz + (run < nruns ? (size_t)b : (size_t)0))[part];
+    }
+}
+
 template <int NPL, int WN, class X>
 DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
-    static_assert(NPL + WN - 1 <= 16, "window offsets travel in four bits");
     typedef Probe2SmemT<NPL> SM;
     SM& sm = *x.template smem<SM>();
     const int lane = x.lane();
@@ -64,31 +90,24 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
     const uint32_t k = T.ksize, m = T.mz_m;  // k - m + 1 == WN (the launcher's condition)
     const uint32_t ns = *a.nsurv;
     const uint32_t tend = ns - a.t0 < a.tcap ? ns : a.t0 + a.tcap;
-    const uint32_t npr = ns > a.t0 ? tend - a.t0 : 0;  // pairs of this chunk; pair i -> hit-buffer rows 2i, 2i + 1
-    // Which pairs this wave takes.  The survivor list is sorted by locus (body_surv_*, below): each of the chip's 8 XCDs — blocks
-    // b, b + 8, b + 16, ... share one — takes one contiguous eighth of it, its waves striding through that eighth together, so the
-    // reads of a locus are looked up at about the same time on ONE XCD and find each other's buckets in its L2 (a bucket is
-    // asked for by ~4 reads per batch of all-hit reads; unsorted, each of them fetched it from HBM).
-    const uint32_t nblk = x.nblocks();
-    const bool xcd = (nblk & 7u) == 0;
-    const uint32_t S = xcd ? nblk >> 3 : nblk;                                  // stride of this wave's pairs
-    const uint32_t chunk = xcd ? (npr + 7) >> 3 : npr;
-    const uint32_t lo = xcd ? (x.bid() & 7u) * chunk : 0u;
-    const uint32_t hi = lo + chunk < npr ? lo + chunk : npr;                    // this wave's pairs: lo + w, lo + w + S, ... < hi
-    const uint32_t first = lo + (xcd ? x.bid() >> 3 : x.bid());
+    const uint32_t npr = ns > a.t0 ? tend - a.t0 : 0;  // pairs of this chunk of the list; pair i -> hit-buffer rows 2i, 2i + 1
+    // this wave's pairs: a contiguous range of the (locus-ordered) list
+    const uint32_t per = (npr + x.nblocks() - 1) / x.nblocks();
+    const uint64_t lo64 = (uint64_t)x.bid() * per;
+    const uint32_t first = lo64 < npr ? (uint32_t)lo64 : npr, hi = lo64 + per < npr ? (uint32_t)(lo64 + per) : npr;
     const uint32_t lmax = 32u * NPL + m - 1;  // bases the lanes of a half cover (the launcher promised no read is longer)
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint32_t mmask = (uint32_t)((1ull << (2 * m)) - 1);
     const uint32_t p0 = hl * NPL;
-    if (hl < 16) sm.hm[half][32 * NPL + hl] = 0xFFFFFFFFu;
+    for (uint32_t e = (uint32_t)lane; e < (uint32_t)P2_CACHE; e += 64) sm.cache[e] = uint4{0xFFFFFFFFu, 0x3FFFFFFFu, 0u, 0u};  // MZ_EMPTY
     // Three-deep fetch pipeline, all loads unconditional (clamped to something valid) so that they stay in flight:
-    // while pair i is looked up, the bytes of pair i + S are on their way into registers, the offsets of pair i + 2S
-    // are being fetched, and the survivor entry of pair i + 3S.
+    // while pair i is looked up, the bytes of pair i + 1 are on their way into registers, the offsets of pair i + 2
+    // are being fetched, and the survivor entry of pair i + 3.
     auto surv_of = [&](uint32_t i) { return a.surv[a.t0 + (i < hi ? i : 0u)]; };
     uint32_t rw0 = 0, rw1 = 0;  // pair i: dwords 2 hl and 2 hl + 1 of the mate, from its 4-byte-aligned start
     uint64_t o0C = 0, o1C = 0;  //         its offsets
-    uint64_t o0B = 0, o1B = 0;  // pair i + S: offsets (in flight)
-    uint32_t pairA = 0;         // pair i + 2S: survivor entry (in flight)
+    uint64_t o0B = 0, o1B = 0;  // pair i + 1: offsets (in flight)
+    uint32_t pairA = 0;         // pair i + 2: survivor entry (in flight)
     auto fetch_bytes = [&](uint64_t o0, uint64_t o1) {
         uint32_t len = (uint32_t)(o1 - o0);
         if (len > lmax) len = lmax;
@@ -101,18 +120,15 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
         const uint64_t r = 2 * (uint64_t)pair + half;
         o0B = a.off[r]; o1B = a.off[r + 1];
     };
-    {
-        const uint32_t i0 = first;
-        if (i0 < hi) {
-            fetch_offsets(x.uni(surv_of(i0)));
-            o0C = o0B; o1C = o1B;
-            fetch_bytes(o0C, o1C);
-        }
-        if (i0 + S < hi) fetch_offsets(x.uni(surv_of(i0 + S)));
-        pairA = surv_of(i0 + 2 * S);
+    if (first < hi) {
+        fetch_offsets(x.uni(surv_of(first)));
+        o0C = o0B; o1C = o1B;
+        fetch_bytes(o0C, o1C);
+        if (first + 1 < hi) fetch_offsets(x.uni(surv_of(first + 1)));
+        pairA = surv_of(first + 2);
     }
     DBTK_STAMP_DECL
-    for (uint32_t i = first; i < hi; i += S) {
+    for (uint32_t i = first; i < hi; ++i) {
         DBTK_STAMP(43);  // loop
         const uint64_t o0 = o0C, o1 = o1C;
         uint32_t len = (uint32_t)(o1 - o0);
@@ -121,11 +137,11 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
         const uint32_t rsh = (uint32_t)(o0 - a0);
         const uint32_t d0 = rw0, d1 = rw1;
         {   // advance the pipeline
-            const bool hasB = i + S < hi, hasA = i + 2 * S < hi;
+            const bool hasB = i + 1 < hi, hasA = i + 2 < hi;
             o0C = hasB ? o0B : 0ull; o1C = hasB ? o1B : 0ull;
             fetch_bytes(o0C, o1C);
             fetch_offsets(hasA ? x.uni(pairA) : x.uni(pairA) * 0u);
-            pairA = surv_of(i + 3 * S);
+            pairA = surv_of(i + 3);
         }
         x.sync();  // the previous pair's LDS is dead
         uint32_t bad = 0;
@@ -133,6 +149,7 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
             const uint32_t c0 = pack4_b2(d0, &bad), c1 = pack4_b2(d1, &bad);
             reinterpret_cast<uint16_t*>(sm.pk[half])[hl ^ 1u] = (uint16_t)(((c0 >> 8) & 0xFF00u) | ((c1 >> 16) & 0xFFu));
         }
+        if (hl < 16) sm.hm[half][32 * NPL + hl] = 0xFFFFFFFFu;  // (the region is shared with the later phases: every pair)
         const uint32_t nk = len >= k ? len - k + 1 : 0, nmm = len >= m ? len - m + 1 : 0;
         // Every byte of both mates ACGT (the usual pair): all windows are valid.  (Bytes of the lane's dwords outside the read
         // are the neighbouring reads': a non-ACGT byte there only sends this pair down the exact path for nothing.)
@@ -150,71 +167,132 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
             }
             // canonical k-mers (the m-mer hashes make their round trip through LDS meanwhile)
             uint64_t km[NPL];
-            bool isfw[NPL];
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                const uint64_t fw = (W >> (2 * (32 - k - j))) & kmask, rc = (RW >> (2 * j)) & kmask;
-                isfw[j] = fw < rc;
-                km[j] = isfw[j] ? fw : rc;
-            }
-            DBTK_STAMP(40);  // fetch pipeline, pack, windows, m-mer hashes
-            x.sync();
-            uint32_t f[NPL + WN - 1], g[NPL + WN - 1], mf[NPL], ml[NPL];
-#pragma unroll
-            for (int t = 0; t < NPL + WN - 1; ++t) {
-                f[t] = mz_order(sm.hm[half][p0 + t], (uint32_t)t);  // smallest hash, FIRST one among equals
-                g[t] = f[t] ^ 15u;                                   //                LAST one among equals
-            }
-            sliding_min<NPL, WN>(f, mf);
-            sliding_min<NPL, WN>(g, ml);
-            DBTK_STAMP(16);  // minimizers
-            uint4 q[NPL];
             bool act[NPL];
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
+                const uint64_t fw = (W >> (2 * (32 - k - j))) & kmask, rc = (RW >> (2 * j)) & kmask;
+                km[j] = fw < rc ? fw : rc;
                 act[j] = p0 + j < nk;
-                // strand of the read canonical: the builder's first offset is the first one here, window offset t - j;
-                // other strand: its offsets run backwards, the builder's first is the last one here, WN - 1 - (t - j)
-                const uint32_t sel = isfw[j] ? mf[j] : ml[j];
-                const uint32_t off = (sel & 15u) + (isfw[j] ? (uint32_t)-j : (uint32_t)(j + WN - 16));
-                const uint32_t b = mz_bucket(sel >> 4, (uint32_t)T.mz_mask);
-                size_t at = act[j] ? (size_t)b * MZ_SLOTS + mz_slot(off) : 0;
-#ifdef DBTK_STAMPS
-                if (a.P.diag & 512) at &= 1023;  // diagnostic: every level-1 look-up in the first 16 KB of the table (cache hits)
-#endif
-                q[j] = reinterpret_cast<const uint4*>(T.mz)[at];
+                rv[j] = (uint64_t)NOHIT;
             }
-            bool pend[NPL];
-            bool anyp = false;
+            DBTK_STAMP(40);  // fetch pipeline, pack, windows, m-mer hashes
+            x.sync();
+            uint32_t f[NPL + WN - 1], mz[NPL], bk[NPL];
+#pragma unroll
+            for (int t = 0; t < NPL + WN - 1; ++t) f[t] = sm.hm[half][p0 + t];
+            sliding_min<NPL, WN>(f, mz);
+            // runs: a position opens one when its bucket differs from the previous position's (a mate's first position always does)
+            uint32_t cnt = 0;
+            bool st[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) bk[j] = act[j] ? mz_bucket(mz[j] >> 4, (uint32_t)T.mz_mask) : 0xFFFFFFFFu;
+            uint32_t prev = x.shfl_up1(bk[NPL - 1]);
+            if (hl == 0) prev = 0xFFFFFFFEu;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
-                const bool hit = act[j] && q[j].x == (uint32_t)km[j] && (q[j].y & 0x7FFFFFFFu) == (uint32_t)(km[j] >> 32);
-                pend[j] = act[j] && !hit && (q[j].y >> 31);  // the slot turned keys away: ask the overflow table
-                rv[j] = hit ? ((uint64_t)q[j].w << 32) | q[j].z : (uint64_t)NOHIT;
-                anyp |= pend[j];
+                st[j] = act[j] && bk[j] != prev;
+                cnt += st[j] ? 1u : 0u;
+                prev = bk[j];
             }
-            DBTK_STAMP(18);  // level 1
+            uint32_t r = x.wave_excl_scan(cnt);            // runs opened by the lanes before this one (mate 0's come first)
+            const uint32_t nruns = x.bcast(r + cnt, 63);   // (wave-uniform)
+            uint32_t rid[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                if (st[j]) { sm.rb[r] = bk[j]; ++r; }
+                rid[j] = r - 1;  // (meaningful for active positions only: a non-start continues the run before it)
+            }
+            x.sync();
+            DBTK_STAMP(16);  // minimizers + runs
+            // the buckets, P2_RCH runs at a time: 8 lanes x 16 bytes per bucket, 8 buckets per load instruction; the loads of the
+            // next chunk are issued before this one is searched
+            const uint32_t fq8 = (uint32_t)lane >> 3, part = (uint32_t)lane & 7u;
+            p2_v4u q[P2_RCH / 8];
+            p2_fetch_runs(sm.rb, T.mz, nruns, 0u, fq8, part, P2_DIAG_MASK(a), q);
+            bool pend[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) pend[j] = false;
+            for (uint32_t r0 = 0; r0 < nruns; r0 += P2_RCH) {
+                x.sync();  // (the m-mer hashes / the previous chunk are dead)
+#pragma unroll
+                for (int u = 0; u < P2_RCH / 8; ++u) *reinterpret_cast<p2_v4u*>(&sm.stg[8 * u + fq8][part]) = q[u];
+                p2_fetch_runs(sm.rb, T.mz, nruns, r0 + P2_RCH, fq8, part, P2_DIAG_MASK(a), q);  // the next chunk's loads go out before this one is searched
+                x.sync();
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    const uint32_t row = rid[j] - r0;
+                    const bool mine = act[j] && row < (uint32_t)P2_RCH;
+                    const uint4* rp = sm.stg[mine ? row : 0u];
+                    int hit = -1;
+                    uint32_t w7 = 0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint4 kk = rp[g];
+                        if (kk.x == (uint32_t)km[j] && (kk.y & 0x7FFFFFFFu) == (uint32_t)(km[j] >> 32)) hit = 2 * g;
+                        if (kk.z == (uint32_t)km[j] && (kk.w & 0x7FFFFFFFu) == (uint32_t)(km[j] >> 32)) hit = 2 * g + 1;
+                        if (g == 3) w7 = kk.w;
+                    }
+                    const uint32_t* pl = reinterpret_cast<const uint32_t*>(rp + 4) + 2 * (hit >= 0 ? hit : 0);
+                    const uint64_t pv = (uint64_t)pl[0] | ((uint64_t)pl[1] << 32);
+                    if (mine) {
+                        if (hit >= 0) rv[j] = pv;
+                        else pend[j] = (w7 >> 31) != 0;  // the bucket turned keys away: ask the overflow table
+                    }
+                }
+            }
+            DBTK_STAMP(18);  // level 1: buckets fetched, staged, searched
+            bool anyp = false;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) anyp |= pend[j];
 #ifdef DBTK_STAMPS
             if (a.P.diag & 256) anyp = false;  // diagnostic: no level-2 look-ups (wrong results)
 #endif
             if (x.ballot(anyp)) {
-                uint32_t oi[NPL];
+                // the wave's cache first: the overflow keys are those of tandem repeats, and they come back
+                uint32_t oh[NPL], oi[NPL];
+                bool glob[NPL];
+                anyp = false;
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) oi[j] = ovf_hash(km[j]) & (uint32_t)T.ovf_mask;
-                do {
+                for (int j = 0; j < NPL; ++j) {
+                    oh[j] = ovf_hash(km[j]);
+                    oi[j] = oh[j] & (uint32_t)T.ovf_mask;
+                    glob[j] = false;
+                    if (pend[j]) {
+                        const uint4 c = sm.cache[(oh[j] >> 20) & (P2_CACHE - 1)];
+                        if (c.x == (uint32_t)km[j] && c.y == (uint32_t)(km[j] >> 32)) { rv[j] = ((uint64_t)c.w << 32) | c.z; pend[j] = false; }
+                        else glob[j] = true;
+                    }
+                    anyp |= pend[j];
+                }
+                if (x.ballot(anyp)) {
+                    // (the table is at most a sixteenth full: a look-up that needs a second slot, and with it a second round trip, is one in thirty)
+                    uint4 q2[NPL];
+                    do {
 #pragma unroll
-                    for (int j = 0; j < NPL; ++j) q[j] = reinterpret_cast<const uint4*>(T.ovf)[pend[j] ? oi[j] : 0u];
-                    anyp = false;
+                        for (int j = 0; j < NPL; ++j) q2[j] = reinterpret_cast<const uint4*>(T.ovf)[pend[j] ? oi[j] : 0u];
+                        anyp = false;
+#pragma unroll
+                        for (int j = 0; j < NPL; ++j) {
+                            if (!pend[j]) continue;
+                            const uint64_t key = ((uint64_t)q2[j].y << 32) | q2[j].x;
+                            if (key == km[j]) { rv[j] = ((uint64_t)q2[j].w << 32) | q2[j].z; pend[j] = false; }
+                            else if (key == MZ_EMPTY) pend[j] = false;  // (rv stays NOHIT)
+                            else oi[j] = (oi[j] + 1) & (uint32_t)T.ovf_mask;
+                            anyp |= pend[j];
+                        }
+                    } while (x.ballot(anyp));
+                    // what was looked up goes into the cache (the absent ones too); of the lanes that want one entry in this
+                    // step, the one whose token is left standing writes it
 #pragma unroll
                     for (int j = 0; j < NPL; ++j) {
-                        if (!pend[j]) continue;
-                        const uint64_t key = ((uint64_t)q[j].y << 32) | q[j].x;
-                        if (key == km[j]) { rv[j] = ((uint64_t)q[j].w << 32) | q[j].z; pend[j] = false; }
-                        else if (key == MZ_EMPTY) pend[j] = false;  // (rv stays NOHIT)
-                        else oi[j] = (oi[j] + 1) & (uint32_t)T.ovf_mask;
-                        anyp |= pend[j];
+                        const uint32_t ce = (oh[j] >> 20) & (P2_CACHE - 1);
+                        if (glob[j]) sm.tok[ce] = (uint8_t)lane;
+                        x.sync();
+                        if (glob[j] && sm.tok[ce] == (uint8_t)lane)
+                            sm.cache[ce] = uint4{(uint32_t)km[j], (uint32_t)(km[j] >> 32), (uint32_t)rv[j], (uint32_t)(rv[j] >> 32)};
+                        x.sync();
                     }
-                } while (x.ballot(anyp));
+                }
             }
             DBTK_STAMP(41);  // level 2
         } else {
@@ -228,16 +306,25 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
             }
             reinterpret_cast<uint8_t*>(sm.vd[half])[hl ^ 1u] = (uint8_t)vb;
             x.sync();
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                rv[j] = (uint64_t)NOHIT;
+#pragma nounroll
+            for (int j = 0; j < NPL; ++j) {  // (rolled: this path must not cost the hot one registers)
+                uint64_t r1 = (uint64_t)NOHIT;
                 if (p0 + j < nk) {
                     const uint64_t kq = window_kmer(sm.pk[half], sm.vd[half], rsh + p0 + j, k, nullptr, nullptr);
-                    if (kq != NAN64) rv[j] = idx_lookup64(T, kq);
+                    if (kq != NAN64) r1 = idx_lookup64(T, kq);
                 }
+                sm.res[half][0][p0 + j] = (uint32_t)r1 != NOHIT ? (uint32_t)(r1 >> 32) : AUX_MISS;  // (parked in the results region: it does
+                sm.res[half][1][p0 + j] = (uint32_t)r1;                                              // not overlap pk / vd)
+            }
+            x.sync();
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const uint32_t v = sm.res[half][1][p0 + j];
+                rv[j] = (uint64_t)v | ((uint64_t)sm.res[half][0][p0 + j] << 32);
             }
         }
         {   // the read's results: found positions, and whether they are all unique to one and the same locus
+            x.sync();  // (the staged buckets / validity bits are dead: the region now takes the results)
             uint32_t cnt = 0, vmx = 0, vmn = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
@@ -274,17 +361,18 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
     DBTK_STAMP_FLUSH;
 }
 
-// ---- builders.  Level 1 from the finished plain index (keys unique, val | aux with them): pass 0 claims slots and counts
-// the keys turned away; pass 1 (after the host has sized the overflow table from that count) files those keys in level 2.
+// ---- builders.  Level 1 from the finished plain index (keys unique, val | aux with them): pass 0 claims slots (a bucket's
+// slots fill in order) and counts the keys turned away; pass 1 (after the host has sized the overflow table from that count)
+// files those keys in level 2.
 struct MzBuildArgs {
     const IdxBucket* idx;
     uint64_t nslots;    // 4 per IdxBucket
-    MzSlot* mz;
+    MzBucket* mz;
     uint32_t mz_mask;   // buckets - 1
     MzSlot* ovf;        // pass 1 only
     uint32_t ovf_mask;
     uint32_t ksize, m, pass;
-    uint64_t* nturned;  // pass 0: += keys that found their slot taken
+    uint64_t* nturned;  // pass 0: += keys that found their bucket full
 };
 template <class X>
 DBTK_HD void body_mz_insert(X& x, const MzBuildArgs& a) {
@@ -294,28 +382,31 @@ DBTK_HD void body_mz_insert(X& x, const MzBuildArgs& a) {
         if (key == NAN64) continue;
         key &= ~IDX_OVF;
         const uint64_t va = a.idx[i >> 2].val[i & 3];
-        uint32_t mz28, off;
-        mz_of_kmer(key, a.ksize, a.m, &mz28, &off);
-        MzSlot* s = a.mz + ((size_t)mz_bucket(mz28, a.mz_mask) * MZ_SLOTS + mz_slot(off));
+        MzBucket* b = a.mz + mz_bucket(mz_of_kmer(key, a.ksize, a.m), a.mz_mask);
         if (a.pass == 0) {
-            if (x.atomic_cas(&s->key, MZ_EMPTY, key) == MZ_EMPTY) { s->val = (uint32_t)va; s->aux = (uint32_t)(va >> 32); }
-            else { x.atomic_or(&s->key, MZ_TURNED); ++turned; }
-        } else if ((s->key & ~MZ_TURNED) != key) {
-            uint32_t o = ovf_hash(key) & a.ovf_mask;
-            while (x.atomic_cas(&a.ovf[o].key, MZ_EMPTY, key) != MZ_EMPTY) o = (o + 1) & a.ovf_mask;
-            a.ovf[o].val = (uint32_t)va; a.ovf[o].aux = (uint32_t)(va >> 32);
+            bool placed = false;
+            for (int j = 0; j < 8 && !placed; ++j)
+                if (x.atomic_cas(&b->key[j], MZ_EMPTY, key) == MZ_EMPTY) { b->pl[j].val = (uint32_t)va; b->pl[j].aux = (uint32_t)(va >> 32); placed = true; }
+            if (!placed) { x.atomic_or(&b->key[7], MZ_TURNED); ++turned; }
+        } else {
+            bool there = false;
+            for (int j = 0; j < 8; ++j) there |= (b->key[j] & ~MZ_TURNED) == key;
+            if (!there) {
+                uint32_t o = ovf_hash(key) & a.ovf_mask;
+                while (x.atomic_cas(&a.ovf[o].key, MZ_EMPTY, key) != MZ_EMPTY) o = (o + 1) & a.ovf_mask;
+                a.ovf[o].val = (uint32_t)va; a.ovf[o].aux = (uint32_t)(va >> 32);
+            }
         }
     }
     if (turned) x.atomic_add(a.nturned, turned);
 }
-// every slot of a level-1 / level-2 table free
+// every 16-byte slot of a level-1 / level-2 table free (a bucket = 4 slots' worth of keys, then 4 of payload: the payload words
+// are overwritten with the pattern too, harmlessly)
 template <class X>
-DBTK_HD void body_mz_fill(X& x, MzSlot* t, uint64_t n) {
-    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < n; i += (uint64_t)x.nblocks() * x.nthreads()) {
-        t[i].key = MZ_EMPTY; t[i].val = 0; t[i].aux = 0;
-    }
+DBTK_HD void body_mz_fill(X& x, uint64_t* t, uint64_t nwords, int level1) {
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < nwords; i += (uint64_t)x.nblocks() * x.nthreads())
+        t[i] = level1 ? ((i & 15) < 8 ? MZ_EMPTY : 0ull) : ((i & 1) ? 0ull : MZ_EMPTY);
 }
-
 
 // ---- the survivor list in locus order (a counting sort between the encode stage and the probe kernel).  Pairs are
 // independent and every effect of one is an integer add (src/aQueryFasta_thread.cpp:2146-2158), so the order in which the

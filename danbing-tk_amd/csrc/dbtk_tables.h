@@ -62,33 +62,34 @@ struct ClsSlot {
     uint64_t lc;    // ~0 = not yet written (build only)
 };
 
-// ---- the probe kernel's own copy of the index: two levels, both of 16-byte slots {k-mer, val, aux}.
+// ---- the probe kernel's own copy of the index: two levels.
 //
-// Level 1 is grouped by MINIMIZER and slotted by OFFSET.  The ~130 k-mers of a read overlap, so consecutive ones share
-// most of their m-mers: every k-mer is filed under its minimizer (the canonical m-mer with the smallest hash among its
-// k - m + 1 m-mers; the same for a k-mer and its reverse complement), one 128-byte bucket per minimizer, and INSIDE the
-// bucket at the slot given by where the minimizer sits in the canonical k-mer (offset 0 .. k - m, modulo 8).  A stretch of
-// unique sequence puts the k - m + 1 k-mers around a minimizer into k - m + 1 different slots of one bucket — a perfect
-// hash — so a position of a read finds its k-mer with ONE 16-byte load and ONE comparison, and the consecutive positions
-// that share a minimizer load from one 128-byte line (the later ones hit in the L1).  Nothing is staged, searched or
-// scanned.  A slot holds one key; a key that finds its slot taken (the heavy minimizers of tandem repeats: many k-mers with
-// the same minimizer at the same offset) sets the slot's MZ_TURNED bit and goes to level 2.
+// Level 1 is grouped by MINIMIZER.  The ~130 k-mers of a read overlap, so consecutive ones share most of their m-mers: every
+// k-mer is filed under its minimizer (the canonical m-mer with the smallest hash among its k - m + 1 m-mers; the same for a
+// k-mer and its reverse complement), one 128-byte bucket per minimizer: 8 keys, then their 8 (val, aux) pairs.  The
+// consecutive positions of a read that share a minimizer (a RUN: ~4 positions, ~33 runs per 150-bp read) find their keys in
+// ONE bucket — one 128-byte line, fetched once per run by 8 lanes and searched in LDS.  A bucket that is full turns further
+// keys away and says so (MZ_TURNED on its last key): those keys — the heavy minimizers of tandem repeats, whose hundreds of
+// variant k-mers share a handful of m-mers — go to level 2.
 //
-// Level 2 (the overflow table) holds exactly the keys level 1 turned away, open-addressed by a hash of the k-mer, linear
-// probing, at most a quarter full: a look-up that finds MZ_TURNED on a slot holding another key goes there; one that finds
-// a free slot or a mismatch without the bit is a miss.  Two levels, never a chain.
+// Level 2 (the overflow table) holds exactly the keys level 1 turned away, in 16-byte slots {key, val, aux}, open-addressed
+// by a hash of the k-mer, linear probing, at most a quarter full: a look-up that does not find its key in a bucket marked
+// MZ_TURNED goes there.  Two levels, never a chain.
 //
-// Minimizer rule (builder and probe kernel must agree exactly, ties included): order the m-mers of the CANONICAL k-mer by
-// (hash >> 4, offset), smallest first.  The probe kernel sees the read's orientation: for a window whose reverse complement
-// is the canonical form the offsets run backwards, so it takes the LAST smallest hash there (see body_probe2).
-struct __attribute__((aligned(16))) MzSlot {
-    uint64_t key;  // canonical k-mer (< 2^62) | MZ_TURNED; MZ_EMPTY = free
-    uint32_t val;  // the index value
-    uint32_t aux;  // class of a single-locus k-mer at its locus (IdxBucket::val's high word)
+// What this layout is built around (tools/pend.hip, MI355X): the chip's L1s pass on ~40-48 G requests per second however
+// small they are, where a request is one 128-byte line asked for by one load INSTRUCTION — lanes of the same instruction
+// that want the same line share a request, the same lane asking for the same line with its next instruction pays again,
+// even while the first is still on its way.  So every line is asked for exactly once, by adjacent lanes of one instruction.
+struct __attribute__((aligned(128))) MzBucket {
+    uint64_t key[8];                       // canonical k-mers (< 2^62); MZ_EMPTY = free; slots fill in order; key[7] may carry MZ_TURNED
+    struct { uint32_t val, aux; } pl[8];   // index value; class of a single-locus k-mer at its locus (IdxBucket::val's high word)
+};
+struct __attribute__((aligned(16))) MzSlot {  // level 2
+    uint64_t key;  // MZ_EMPTY = free
+    uint32_t val, aux;
 };
 constexpr uint64_t MZ_TURNED = 1ull << 63;
 constexpr uint64_t MZ_EMPTY = 0x3FFFFFFFFFFFFFFFull;  // poly-T at k = 31, never canonical (poly-A is): matches no k-mer, carries no flag
-constexpr uint32_t MZ_SLOTS = 8;                      // slots per level-1 bucket (128 bytes)
 
 struct DevTables;
 // ---- graph table (v1.3 threading): graphDB[locus] (GraphType = unordered_map<node, out-edge mask>,
@@ -127,7 +128,7 @@ struct DevTables {
     const ClsSlot* tre; uint64_t tre_mask; uint32_t tre_shift;
     const ClsSlot* bait; uint64_t bait_mask; uint32_t bait_shift;
     const GrSlot* gr; uint64_t gr_mask; uint32_t gr_shift;  // nullptr: no graph loaded
-    const MzSlot* mz; uint64_t mz_mask; uint32_t mz_m;  // level 1 (mz_mask = buckets - 1 <= 2^28 - 1); nullptr: the probe kernel looks up the plain index
+    const MzBucket* mz; uint64_t mz_mask; uint32_t mz_m;  // level 1 (mz_mask = buckets - 1 <= 2^28 - 1); nullptr: the probe kernel looks up the plain index
     const MzSlot* ovf; uint64_t ovf_mask;               // level 2 (ovf_mask = slots - 1 <= 2^32 - 1)
 };
 
@@ -307,22 +308,19 @@ DBTK_HD uint32_t mmer_hash2(uint32_t fw, uint32_t rc) {  // the two strands give
     return x;
 }
 DBTK_HD uint32_t mmer_hash(uint64_t fw, uint32_t m) { return mmer_hash2((uint32_t)fw, (uint32_t)revcomp2(fw, m)); }
-// Ordering key of the m-mer at window offset t (t <= 15): the hash without its low four bits, then the offset.
-DBTK_HD uint32_t mz_order(uint32_t h, uint32_t t) { return (h & ~15u) | t; }
-// Minimizer of a CANONICAL k-mer: *mz28 = its hash >> 4, *off = its (first) offset in the k-mer.  k - m + 1 <= 16.
-DBTK_HD void mz_of_kmer(uint64_t kmer, uint32_t k, uint32_t m, uint32_t* mz28, uint32_t* off) {
+// Minimizer of a k-mer (either orientation: the hash is of the canonical m-mer) as the 28 bits its bucket is computed from.
+DBTK_HD uint32_t mz_of_kmer(uint64_t kmer, uint32_t k, uint32_t m) {
     const uint64_t mm = (1ull << 2 * m) - 1;
     uint32_t best = 0xFFFFFFFFu;
     for (uint32_t i = 0; i + m <= k; ++i) {
-        const uint32_t o = mz_order(mmer_hash((kmer >> (2 * (k - m - i))) & mm, m), i);
-        best = o < best ? o : best;
+        const uint32_t h = mmer_hash((kmer >> (2 * (k - m - i))) & mm, m);
+        best = h < best ? h : best;
     }
-    *mz28 = best >> 4; *off = best & 15u;
+    return best >> 4;
 }
 // Bucket of a minimizer.  The smallest of several hashes is a small number: its high bits are biased towards zero, its low
 // bits are not, so the high bits are folded onto unbiased ones before the mask (no multiplication: once per position).
 DBTK_HD uint32_t mz_bucket(uint32_t mz28, uint32_t mask) { return (mz28 ^ (mz28 << 9)) & mask; }
-DBTK_HD uint32_t mz_slot(uint32_t off) { return off & (MZ_SLOTS - 1); }
 // Slot of a k-mer in the overflow table (before the mask).
 DBTK_HD uint32_t ovf_hash(uint64_t kmer) {
     uint32_t h = (uint32_t)kmer ^ ((uint32_t)(kmer >> 32) * 0x9E3779B1u);

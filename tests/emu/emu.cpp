@@ -276,7 +276,8 @@ struct EmuTables {
     std::vector<uint64_t> flt;
     std::vector<ClsSlot> tre, bait;
     std::vector<GrSlot> gr;
-    std::vector<MzSlot> mz, ovf;
+    std::vector<MzBucket> mz;
+    std::vector<MzSlot> ovf;
     uint64_t stats[3] = {0, 0, 0};
     DevTables T;
 };
@@ -358,12 +359,14 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
     // build_tables does on the device: level 1 + count, then the overflow table sized from the count
     if (mz_m_for_k(g->ksize) && (!getenv("DBTK_MZ") || atoi(getenv("DBTK_MZ")))) {
         const uint64_t nb = pow2((g->keys.size() * 2) / 8 + 8) / 1024 ? pow2((g->keys.size() * 2) / 8 + 8) : 1024;
-        e->mz.assign(nb * MZ_SLOTS, MzSlot{MZ_EMPTY, 0, 0});
+        MzBucket empty;
+        for (int j = 0; j < 8; ++j) { empty.key[j] = MZ_EMPTY; empty.pl[j].val = empty.pl[j].aux = 0; }
+        e->mz.assign(nb, empty);
         uint64_t nturned = 0;
         MzBuildArgs a{e->idx.data(), icap, e->mz.data(), (uint32_t)(nb - 1), nullptr, 0, g->ksize, mz_m_for_k(g->ksize), 0, &nturned};
         run_grid(3, 64, 0, [&](EmuX& x) { body_mz_insert(x, a); });
         g_mz_turned = nturned;
-        const uint64_t ocap = pow2(4 * nturned + 8);
+        const uint64_t ocap = pow2(2 * nturned + 8);  // (fuller than on the device: longer probe sequences get exercised)
         e->ovf.assign(ocap, MzSlot{MZ_EMPTY, 0, 0});
         a.ovf = e->ovf.data(); a.ovf_mask = (uint32_t)(ocap - 1); a.pass = 1;
         run_grid(3, 64, 0, [&](EmuX& x) { body_mz_insert(x, a); });
