@@ -656,6 +656,13 @@ int orc_rpgg_load_graph(orc_rpgg_t* g, const char* fn) {
     return rc;
 }
 int orc_rpgg_has_graph(const orc_rpgg_t* g) { return g->gr_beg != NULL; }
+/* graphDB[locus] as (node, mask), ascending nodes: what the loaders made of a file (test accessor) */
+uint64_t orc_rpgg_graph_dump(const orc_rpgg_t* g, uint32_t locus, uint64_t* ks, uint8_t* ms, uint64_t cap) {
+    if (!g->gr_beg || locus >= g->nloci) return 0;
+    const uint64_t b = g->gr_beg[locus], n = g->gr_beg[locus + 1] - b;
+    for (uint64_t i = 0; i < n && i < cap; ++i) { ks[i] = g->gr_ks[b + i]; ms[i] = g->gr_ms[b + i]; }
+    return n;
+}
 
 void orc_rpgg_free(orc_rpgg_t* g) {
     if (!g) return;

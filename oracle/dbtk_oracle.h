@@ -67,6 +67,7 @@ void orc_qstring2qmask(const uint8_t* qual, int nq, int qth, int ksize, uint8_t*
 void orc_rpgg_set_graph(orc_rpgg_t* g, const uint64_t* gr_cnt, const uint64_t* gr_ks, const uint8_t* gr_ms);
 int  orc_rpgg_load_graph(orc_rpgg_t* g, const char* graph_file);
 int  orc_rpgg_has_graph(const orc_rpgg_t* g);
+uint64_t orc_rpgg_graph_dump(const orc_rpgg_t* g, uint32_t locus, uint64_t* ks, uint8_t* ms, uint64_t cap);
 /* isThreadFeasible (AQ.cpp:1114-1260) after cigar_t::init, for one read against graphDB[locus] / trKmers[locus].
  * Returns 0 / 1 / 2 like the reference, -1 where the reference would assert (flags in out).  out and
  * noncakmers (>= len entries: the uncorrected k-mers of read2kmers(canonical=false, keepN=true)) may be NULL. */

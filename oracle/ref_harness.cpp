@@ -164,6 +164,15 @@ void ref_db_load_graph(void* h, const char* graph_kmers_file) {
     std::cerr.rdbuf(old);
     std::cerr.clear();
 }
+/* graphDB[locus] as readGraphKmers left it: (node, mask) in ascending node order (the map itself is unordered) */
+uint64_t ref_graph_dump(void* h, uint32_t locus, uint64_t* ks, uint8_t* ms, uint64_t cap) {
+    RefDB* db = (RefDB*)h;
+    if (locus >= db->graphDB.size()) return 0;
+    std::vector<std::pair<uint64_t, uint8_t>> v(db->graphDB[locus].begin(), db->graphDB[locus].end());
+    std::sort(v.begin(), v.end());
+    for (size_t i = 0; i < v.size() && i < cap; ++i) { ks[i] = v[i].first; ms[i] = v[i].second; }
+    return v.size();
+}
 void ref_set_thread_params(uint64_t maxncorr, int verb) { maxncorrection = maxncorr; verbosity = verb; }
 
 /* isThreadFeasible (src/aQueryFasta_thread.cpp:1114-1260) for one read against graphDB[locus] / trKmerDB[locus],

@@ -108,6 +108,15 @@ class Oracle:
         if self.L.orc_rpgg_load_graph(h, graph_file.encode()):
             raise IOError(f"oracle could not load {graph_file}")
 
+    def graph_dump(self, h, locus, cap=1 << 20):
+        """graphDB[locus] as the oracle's loaders left it: (nodes ascending, masks)."""
+        ks, ms = np.zeros(cap, np.uint64), np.zeros(cap, np.uint8)
+        self.L.orc_rpgg_graph_dump.restype = C.c_uint64
+        self.L.orc_rpgg_graph_dump.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, C.c_uint64]
+        n = int(self.L.orc_rpgg_graph_dump(h, locus, _p(ks, u64p), _p(ms, u8p), cap))
+        assert n <= cap
+        return ks[:n].copy(), ms[:n].copy()
+
     def thread(self, h, locus, read: bytes, params, rec=None):
         """orc_thread: (ret, ThreadRec)."""
         rec = rec if rec is not None else abi.ThreadRec()
@@ -278,6 +287,15 @@ class RefHarness:
 
     def load_graph(self, h, graph_kmers_file):
         self.L.ref_db_load_graph(h, graph_kmers_file.encode())
+
+    def graph_dump(self, h, locus, cap=1 << 20):
+        """graphDB[locus] of the reference after its own readGraphKmers: (nodes ascending, masks)."""
+        ks, ms = np.zeros(cap, np.uint64), np.zeros(cap, np.uint8)
+        self.L.ref_graph_dump.restype = C.c_uint64
+        self.L.ref_graph_dump.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, C.c_uint64]
+        n = int(self.L.ref_graph_dump(h, locus, _p(ks, u64p), _p(ms, u8p), cap))
+        assert n <= cap
+        return ks[:n].copy(), ms[:n].copy()
 
     def thread(self, h, locus, read: bytes, params, tc=False, rec=None):
         """ref_thread: (ret, ThreadRec, cigar, annot, flagged by threadCheck)."""

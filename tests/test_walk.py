@@ -227,24 +227,138 @@ def test_oracle_walk_equals_reference(tmp_path, k, seed):
     print("\n".join(out))
 
 
-def test_oracle_graph_loaders(tmp_path):
-    """PREF.graph.kmers (text) and the v1.3 PREF.graph.umap (binary; the reference's own fixture test/QC/input/pan.graph.umap,
-    kept under tests/golden/legacy_v13 with its text twin) give the same graph."""
+LEGACY = os.path.join(_HERE, "golden", "legacy_v13")
+
+
+def _product_graph(g):
+    """graphDB of a product handle from its flat view: per locus (nodes ascending, masks OR-ed per node)."""
+    v = g.view()
+    nl = int(v.nloci)
+    cnt = np.ctypeslib.as_array(v.gr_cnt, shape=(nl,)).astype(np.int64)
+    n = int(cnt.sum())
+    ks = np.ctypeslib.as_array(v.gr_ks, shape=(n,)).copy()
+    ms = np.ctypeslib.as_array(v.gr_ms, shape=(n,)).copy()
+    out, i = [], 0
+    for c in cnt:
+        d = {}
+        for k_, m_ in zip(ks[i:i + c].tolist(), ms[i:i + c].tolist()):
+            d[k_] = d.get(k_, 0) | m_
+        i += int(c)
+        out.append((np.array(sorted(d), np.uint64), np.array([d[k_] for k_ in sorted(d)], np.uint8)))
+    return out
+
+
+def _legacy_prefix_with(tmp, graph_ext):
+    """The reference's v1.3 fixture with only ONE of its two graph files next to it (the loaders prefer the text form)."""
+    import shutil
+    d = os.path.join(tmp, "leg_" + graph_ext.replace(".", "_"))
+    os.makedirs(d, exist_ok=True)
+    for f in ("pan.kmerDBi.umap", "pan.kmerDBi.vv", "pan.tr.kmers", "pan.ntr.kmers", "pan.graph." + graph_ext):
+        shutil.copy(os.path.join(LEGACY, f), os.path.join(d, f))
+    return os.path.join(d, "pan")
+
+
+def test_reference_graph_fixture_loads_the_same_everywhere(tmp_path):
+    """The reference's own v1.3 graph fixture (test/QC/input/pan.graph.umap and its text twin pan.graph.kmers, byte copies under
+    tests/golden/legacy_v13): the binary loader == the text loader == the reference's readGraphKmers
+    (src/aQueryFasta_thread.h:550-575, through oracle/_ref), node for node and mask for mask, in the oracle AND through
+    dbtk_rpgg_load(DBTK_LOAD_GRAPH)."""
+    umap, text = os.path.join(LEGACY, "pan.graph.umap"), os.path.join(LEGACY, "pan.graph.kmers")
+    assert os.path.getsize(umap) == 26998  # 8 (nloci) + 8 (n) + 2998 x 9 (SURVEY 2.3)
+    raw = open(umap, "rb").read()
+    assert int.from_bytes(raw[:8], "little") == 1 and int.from_bytes(raw[8:16], "little") == 2998
+    lib = bind.pkg.Dbtk()
     O = bind.Oracle()
-    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "legacy_v13", "pan")
-    if os.path.exists(gold + ".graph.umap") and os.path.exists(gold + ".graph.kmers"):
-        n = os.path.getsize(gold + ".graph.umap")
-        assert n == 26998  # 8 + 8 + 2998 x 9 (SURVEY 2.3)
-    case = WalkCase(str(tmp_path), "ld", 21, 7, nloci=3, with_ref=False)
-    synth.write_graph_file(synth.build_graph_arrays(case.loci, 21), case.prefix, binary=True)
+    graphs = {}
+    for ext in ("umap", "kmers"):
+        pref = _legacy_prefix_with(str(tmp_path), ext)
+        g = lib.load(pref, 21, flags=abi.LOAD_GRAPH)  # product loader (csrc/dbtk_rpgg.cpp: read_graph_umap / read_graph_text)
+        graphs["product " + ext] = _product_graph(g)[0]
+        oh = O.from_arrays(g.view())                  # oracle loader (oracle/dbtk_oracle.c: orc_rpgg_load_graph) on the same index
+        O.load_graph(oh, pref + ".graph." + ext)
+        graphs["oracle " + ext] = O.graph_dump(oh, 0)
+        O.free(oh)
+        g.close()
+    if synth.have_ref():  # the reference's own loader, on HEAD files of the same k-mer sets (ktools serialize) + the text graph
+        import shutil
+        import subprocess
+        d = os.path.join(str(tmp_path), "head")
+        os.makedirs(d)
+        shutil.copy(os.path.join(LEGACY, "pan.tr.kmers"), os.path.join(d, "pan.tr.kmers"))
+        shutil.copy(os.path.join(LEGACY, "pan.ntr.kmers"), os.path.join(d, "pan.fl.kmers"))
+        open(os.path.join(d, "pan.tre.kmers"), "w").write(">0\n")
+        assert subprocess.run([synth.ref_tool("ktools"), "serialize", "pan"], cwd=d, capture_output=True).returncode == 0
+        R = bind.RefHarness()
+        rh = R.load(os.path.join(d, "pan"))
+        R.load_graph(rh, text)
+        graphs["reference readGraphKmers"] = R.graph_dump(rh, 0)
+        R.free(rh)
+    first = graphs["oracle umap"]
+    assert len(first[0]) == 2998 and (np.diff(first[0].astype(np.int64)) > 0).all()
+    for name, (ks, ms) in graphs.items():
+        assert len(ks) == len(first[0]) and (ks == first[0]).all() and (ms == first[1]).all(), name
+    # and the file says the same: node i at bytes 16 + 9 i, its mask in the ninth byte
+    nodes = np.frombuffer(raw[16:], np.uint8).reshape(2998, 9)
+    fk = nodes[:, :8].copy().view(np.uint64).ravel()
+    order = np.argsort(fk)
+    assert (fk[order] == first[0]).all() and (nodes[:, 8][order] == first[1]).all()
+
+
+def _reads_from_graph(ks, ms, k, n, rlen, seed, sub=0.0):
+    """Reads spelled by random walks through a graph (node = non-canonical k-mer, bit b of its mask = successor by base b);
+    a walk that reaches a node without successors starts over."""
+    rng = np.random.default_rng(seed)
+    mask = dict(zip(ks.tolist(), ms.tolist()))
+    nodes = [x for x in ks.tolist() if mask[x]]
+    kmask = (1 << (2 * k)) - 1
+    reads = []
+    while len(reads) < n:
+        node = nodes[int(rng.integers(len(nodes)))]
+        s = ["ACGT"[(node >> (2 * (k - 1 - i))) & 3] for i in range(k)]
+        while len(s) < rlen:
+            m = mask.get(node, 0)
+            if not m:
+                break
+            b = int(rng.choice([i for i in range(4) if m >> i & 1]))
+            node = ((node << 2) | b) & kmask
+            s.append("ACGT"[b])
+        if len(s) < rlen:
+            continue
+        r = bytearray("".join(s).encode())
+        for i in np.nonzero(rng.random(rlen) < sub)[0]:
+            r[i] = ord("ACGT"[(b"ACGT".index(r[i]) + 1 + int(rng.integers(3))) % 4])
+        reads.append(bytes(r))
+    return reads
+
+
+def test_oracle_walks_the_reference_graph_fixture_like_the_reference(tmp_path):
+    """Reads stitched from the reference's own graph fixture, walked by the oracle and by the reference's isThreadFeasible on the
+    graph each loaded for itself."""
+    if not synth.have_ref():
+        pytest.skip("needs oracle/_ref")
+    import shutil
+    import subprocess
+    d = os.path.join(str(tmp_path), "head")
+    os.makedirs(d)
+    shutil.copy(os.path.join(LEGACY, "pan.tr.kmers"), os.path.join(d, "pan.tr.kmers"))
+    shutil.copy(os.path.join(LEGACY, "pan.ntr.kmers"), os.path.join(d, "pan.fl.kmers"))
+    open(os.path.join(d, "pan.tre.kmers"), "w").write(">0\n")
+    assert subprocess.run([synth.ref_tool("ktools"), "serialize", "pan"], cwd=d, capture_output=True).returncode == 0
+    O, R = bind.Oracle(), bind.RefHarness()
+    oh = O.load(os.path.join(d, "pan"), 21); O.load_graph(oh, os.path.join(LEGACY, "pan.graph.umap"))
+    rh = R.load(os.path.join(d, "pan")); R.load_graph(rh, os.path.join(LEGACY, "pan.graph.kmers"))
+    ks, ms = O.graph_dump(oh, 0)
     p = abi.default_params(ksize=21, thread_cth=85, correction=1, maxncorrection=3)
-    seqs, loc = make_reads(case.loci, 21, 300, seed=5, sub=0.01, indel=0.003)
-    a = O.load(case.prefix, 21); O.load_graph(a, case.prefix + ".graph.kmers")
-    b = O.load(case.prefix, 21); O.load_graph(b, case.prefix + ".graph.umap")
-    for i, s in enumerate(seqs):
-        ra, reca = O.thread(a, loc[i], s, p)
-        rb, recb = O.thread(b, loc[i], s, p)
-        assert ra == rb and same_rec(reca, recb)
+    R.set_params(p)
+    rets = Counter()
+    for sub in (0.0, 0.01, 0.03):
+        for s in _reads_from_graph(ks, ms, 21, 150, 150, seed=int(100 * sub) + 7, sub=sub):
+            ro, orec = O.thread(oh, 0, s, p)
+            rr, rrec, _, _, _ = R.thread(rh, 0, s, p)
+            assert ro == rr and same_rec(orec, rrec)
+            rets[ro] += 1
+    assert rets[1] > 0 and rets[2] > 0
+    O.free(oh); R.free(rh)
 
 
 # --------------------------------------------------- emulated kernel vs oracle --
@@ -393,6 +507,36 @@ def test_gpu_walk_equals_oracle(tmp_path, k, seed):
         ctx.close()
     assert total >= 100_000
     assert rets[0] > 0 and rets[1] > 0 and rets[2] > 0
+
+
+@pytest.mark.gpu
+def test_gpu_walks_the_reference_graph_fixture(tmp_path):
+    """The reference's v1.3 fixture (pan.kmerDBi.umap/.vv, pan.tr.kmers, pan.ntr.kmers, pan.graph.umap) loaded by dbtk_rpgg_load with
+    DBTK_LOAD_GRAPH; reads stitched from that graph walked by k_walk_reads (dbtk_thread_batch) and by the oracle."""
+    O = bind.Oracle()
+    D = bind.pkg.Dbtk()
+    for ext in ("umap", "kmers"):
+        pref = _legacy_prefix_with(str(tmp_path), ext)
+        g = D.load(pref, 21, flags=abi.LOAD_GRAPH)
+        oh = O.from_arrays(g.view())
+        O.load_graph(oh, pref + ".graph." + ext)
+        ks, ms = O.graph_dump(oh, 0)
+        for ps in PARAM_SETS[:2]:
+            p = abi.default_params(ksize=21, threading=2, **ps)
+            ctx = D.context(g, p, device=0)
+            rets = Counter()
+            for sub in (0.0, 0.01, 0.03):
+                seqs = _reads_from_graph(ks, ms, 21, 400, 150, seed=int(100 * sub) + 11, sub=sub)
+                buf, off = pack(seqs)
+                recs = ctx.thread(buf, off, np.zeros(len(seqs), np.uint32))
+                for i, s_ in enumerate(seqs):
+                    ro, orec = O.thread(oh, 0, s_, p)
+                    assert recs[i].ret == ro and same_rec(recs[i], orec), describe("GPU vs oracle", i, ro, orec, recs[i].ret, recs[i], O)
+                    rets[ro] += 1
+            assert rets[1] > 0 and rets[2] > 0
+            ctx.close()
+        O.free(oh)
+        g.close()
 
 
 if __name__ == "__main__":  # worker of test_oracle_walk_equals_reference
