@@ -36,6 +36,8 @@ def bind_common(L):
     L.dbtk_abi_version.restype = C.c_uint32
     L.dbtk_rpgg_load.restype = C.c_int
     L.dbtk_rpgg_load.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.dbtk_rpgg_load_tr.restype = C.c_int
+    L.dbtk_rpgg_load_tr.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.dbtk_rpgg_from_arrays.restype = C.c_int
     L.dbtk_rpgg_from_arrays.argtypes = [C.POINTER(abi.RpggArrays), C.POINTER(C.c_void_p)]
     L.dbtk_rpgg_free.argtypes = [C.c_void_p]
@@ -93,10 +95,11 @@ class _HostSide:
         if st != abi.OK:
             raise DbtkError(st, self.L.dbtk_last_error().decode())
 
-    def load(self, prefix, k=21, qc_file=None, bait_file=None, flags=0) -> Rpgg:
+    def load(self, prefix, k=21, qc_file=None, bait_file=None, flags=0, tr_file=None) -> Rpgg:
+        """tr_file: the TR k-mer file when it is not PREF.tr.kmers (`-t N`: PREF.tr.trimN.kmers)."""
         h = C.c_void_p()
-        self._chk(self.L.dbtk_rpgg_load(prefix.encode(), k, qc_file.encode() if qc_file else None,
-                                        bait_file.encode() if bait_file else None, flags, C.byref(h)))
+        self._chk(self.L.dbtk_rpgg_load_tr(prefix.encode(), tr_file.encode() if tr_file else None, k, qc_file.encode() if qc_file else None,
+                                           bait_file.encode() if bait_file else None, flags, C.byref(h)))
         return Rpgg(self, h)
 
     def serialize(self, prefix):
@@ -298,7 +301,7 @@ class Dbtk(_HostSide):
 
 # every symbol include/dbtk.h declares (checked by the CPU test-suite)
 EXPORTS = [
-    "dbtk_rpgg_load", "dbtk_rpgg_from_arrays", "dbtk_rpgg_free", "dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys",
+    "dbtk_rpgg_load", "dbtk_rpgg_load_tr", "dbtk_rpgg_from_arrays", "dbtk_rpgg_free", "dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys",
     "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
     "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",

@@ -4,7 +4,7 @@ import ctypes as C
 MAX_READ_LEN = 256
 NAN64 = 0xFFFFFFFFFFFFFFFF
 NAN32 = 0xFFFFFFFF
-ABI_VERSION = 2
+ABI_VERSION = 3
 THREAD_CAP = 384
 THREADING_HEAD, THREADING_V13 = 1, 2
 

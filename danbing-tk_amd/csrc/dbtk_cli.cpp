@@ -316,7 +316,9 @@ int main(int argc, char* argv[]) {
             abort();  // the reference does `throw;` with no active exception -> std::terminate
         }
     }
-    if (o.trim) die_assert("-t (trimmed tr.kmers) is not supported by this build");
+    // DBTK_V13_THREADING=1 in the environment = --v13-threading: the README's command line for the v1.3 contract
+    // (`danbing-tk -gc 85 3 -ae ...`, README.md:38-39) then runs unchanged
+    if (const char* e = getenv("DBTK_V13_THREADING")) if (atoi(e) != 0) o.v13 = true;
 
     fprintf(stderr,
             "use baitDB: %d\nextract fastX: %d\noutput bubbles: %d\nis Fastq: %d\nsim mode: %d\ngraph threading mode: %d\n"
@@ -333,7 +335,7 @@ int main(int argc, char* argv[]) {
     const bool use_bait = o.bait && !o.extractFastX && !o.threading;  // baitDB is only read and used on that path
     const bool walk = o.v13 && o.threading && !o.extractFastX;          // the graph walk of the v1.3 contract (AQ.cpp:2072-2088)
     const bool emit_aln = walk && o.aln;                                 // -a / -ae records (AQ.cpp:2232-2248)
-    if (dbtk_rpgg_load(o.trPrefix.c_str(), (uint32_t)o.ksize, o.qc ? o.qcFn.c_str() : nullptr,
+    if (dbtk_rpgg_load_tr(o.trPrefix.c_str(), o.trim ? o.trFname.c_str() : nullptr, (uint32_t)o.ksize, o.qc ? o.qcFn.c_str() : nullptr,
                        use_bait ? o.baitFname.c_str() : nullptr,
                        (o.extractFastX ? DBTK_LOAD_INDEX_ONLY : 0) | (walk ? DBTK_LOAD_GRAPH : 0), &rpgg))
         die_assert(dbtk_last_error());

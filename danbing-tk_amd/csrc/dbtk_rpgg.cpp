@@ -241,14 +241,15 @@ bool file_exists(const std::string& fn) { FILE* f = fopen(fn.c_str(), "rb"); if 
 
 extern "C" {
 
-static dbtk_status_t dbtk_rpgg_load_impl(const char* prefix, uint32_t ksize, const char* qc_file, const char* bait_file,
+static dbtk_status_t dbtk_rpgg_load_impl(const char* prefix, const char* tr_kmers_file, uint32_t ksize, const char* qc_file, const char* bait_file,
                              uint32_t flags, dbtk_rpgg_t** out) {
     if (!prefix || !out) { set_error("null argument"); return DBTK_ERR_ARG; }
     *out = nullptr;
     std::unique_ptr<dbtk_rpgg> g(new dbtk_rpgg);
     g->ksize = ksize;
     const std::string pref(prefix);
-    dbtk_status_t st = read_tr_kmers(pref + ".tr.kmers", g->tr_cnt, g->tr_ks);
+    // (the TR k-mer file may be named explicitly: -t N reads PREF.tr.trimN.kmers in place of PREF.tr.kmers, AQ.cpp:2389, 2459, 2493)
+    dbtk_status_t st = read_tr_kmers(tr_kmers_file ? std::string(tr_kmers_file) : pref + ".tr.kmers", g->tr_cnt, g->tr_ks);
     if (st) return st;
     g->nloci = g->tr_cnt.size();
     const bool head_index = file_exists(pref + ".kmers.dbi");
@@ -607,7 +608,11 @@ static dbtk_status_t dbtk_write_outputs_impl(const dbtk_rpgg_t* h, const uint64_
 // ---- the entry points above that parse files or allocate host memory, behind the exception barrier (dbtk_internal.h: guarded)
 dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_file, const char* bait_file,
                              uint32_t flags, dbtk_rpgg_t** out) {
-    return dbtk::guarded([&] { return dbtk_rpgg_load_impl(prefix, ksize, qc_file, bait_file, flags, out); });
+    return dbtk::guarded([&] { return dbtk_rpgg_load_impl(prefix, nullptr, ksize, qc_file, bait_file, flags, out); });
+}
+dbtk_status_t dbtk_rpgg_load_tr(const char* prefix, const char* tr_kmers_file, uint32_t ksize, const char* qc_file, const char* bait_file,
+                                uint32_t flags, dbtk_rpgg_t** out) {
+    return dbtk::guarded([&] { return dbtk_rpgg_load_impl(prefix, tr_kmers_file, ksize, qc_file, bait_file, flags, out); });
 }
 dbtk_status_t dbtk_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a, dbtk_rpgg_t** out) {
     return dbtk::guarded([&] { return dbtk_rpgg_from_arrays_impl(a, out); });

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DBTK_ABI_VERSION 2u
+#define DBTK_ABI_VERSION 3u
 
 /* Reads longer than this are rejected (DBTK_ERR_READ_TOO_LONG).  The
  * reference's per-read k-mer multiplicity is a uint8_t pair (`PE_KMC`,
@@ -199,6 +199,11 @@ enum {
                                     when that file is absent, the v1.3 binary PREF.graph.umap */
 dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_file,
                              const char* bait_file, uint32_t flags, dbtk_rpgg_t** out);
+/* The same with the TR k-mer file named explicitly (NULL: PREF.tr.kmers): `-t N` reads PREF.tr.trimN.kmers in its place —
+ * locus count, trKmerDB and with it the OUT.trkmc.ar order (src/aQueryFasta_thread.cpp:2352, 2389, 2459, 2493); every other
+ * file still comes from PREF. */
+dbtk_status_t dbtk_rpgg_load_tr(const char* prefix, const char* tr_kmers_file, uint32_t ksize, const char* qc_file,
+                                const char* bait_file, uint32_t flags, dbtk_rpgg_t** out);
 /* Same handle from caller arrays (copied). */
 dbtk_status_t dbtk_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a, dbtk_rpgg_t** out);
 void          dbtk_rpgg_free(dbtk_rpgg_t* h);

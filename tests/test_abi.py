@@ -149,6 +149,24 @@ def _index_map(a):
     return m
 
 
+def test_load_with_a_named_tr_file(lib, tmp_path):
+    """dbtk_rpgg_load_tr (`-t N`: PREF.tr.trimN.kmers, AQ.cpp:2389): locus count, TR sets and the output order come from the named
+    file, everything else from PREF."""
+    import synth
+    loci = synth.make_loci(nloci=4, nhap=2, flank=300, seed=5)
+    pref = os.path.join(str(tmp_path), "pan")
+    synth.write_rpgg_files(synth.build_rpgg_arrays(loci, 21), pref)
+    lines = open(pref + ".tr.kmers").read().split("\n")
+    kept = [l for i, l in enumerate(lines) if l[:1] == ">" or i % 3]
+    open(pref + ".tr.trim9.kmers", "w").write("\n".join(kept))
+    g0, g1 = lib.load(pref, 21), lib.load(pref, 21, tr_file=pref + ".tr.trim9.kmers")
+    a0, a1 = _view_arrays(g0), _view_arrays(g1)
+    assert g1.nloci == g0.nloci and 0 < g1.ntrkmers < g0.ntrkmers
+    assert a1["tr_ks"].tolist() == [int(l.split()[0]) for l in kept if l and l[0] != ">"]
+    assert (a1["keys"] == a0["keys"]).all() and (a1["fl_ks"] == a0["fl_ks"]).all()
+    g0.close(); g1.close()
+
+
 def test_legacy_v13_fixture_loads(lib):
     """The reference's own binary fixtures (test/QC/input/pan.*: v1.3 `kmerDBi.umap/.vv`, the formats README and the
     pipelines name) load through dbtk_rpgg_load when the HEAD files are absent: index keys == TR k-mers + flank k-mers,

@@ -160,6 +160,28 @@ def test_cli_vs_reference_binary_live(tmp_path):
         if "-e" not in flags:
             for ext in (".trkmc.ar", ".tr.summary.txt"):
                 assert open(os.path.join(d, "ref" + ext), "rb").read() == open(os.path.join(d, "hip" + ext), "rb").read(), (flags, ext)
+    # -t N: PREF.tr.trimN.kmers in place of PREF.tr.kmers (AQ.cpp:2352, 2389): a trimmed file (every fifth TR k-mer dropped, one locus
+    # emptied) -> fewer counters, k-mers of the index that are in no set any more; the reference binary on the same files
+    with open(os.path.join(d, "pan.tr.kmers")) as f, open(os.path.join(d, "pan.tr.trim7.kmers"), "w") as g:
+        nk, locus = 0, -1
+        for line in f:
+            if line[0] == ">":
+                locus += 1
+                g.write(line)
+            else:
+                nk += 1
+                if nk % 5 and locus != 3:
+                    g.write(line)
+    outs = []
+    for exe, tag in ((synth.ref_tool("danbing-tk"), "reft"), (CLI, "hipt")):
+        r = subprocess.run([exe, "-k", "21", "-cth", "45", "-t", "7", "-fa", "r.fa", "-qs", "pan", "-o", tag], cwd=d, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-1000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and len(outs[0]) > 0
+    for ext in (".trkmc.ar", ".tr.summary.txt"):
+        assert open(os.path.join(d, "reft" + ext), "rb").read() == open(os.path.join(d, "hipt" + ext), "rb").read(), ("-t 7", ext)
+    assert os.path.getsize(os.path.join(d, "hipt.trkmc.ar")) < os.path.getsize(os.path.join(d, "hip.trkmc.ar"))
     # the pipeline form of the reference's README (`samtools fasta ... | danbing-tk -fa /dev/stdin`): a pipe, not a seekable file
     with open(os.path.join(d, "r.fa"), "rb") as f:
         r = subprocess.run([CLI, "-k", "21", "-cth", "30", "-fa", "/dev/stdin", "-qs", "pan", "-o", "pipe"], cwd=d, stdin=f,
@@ -252,6 +274,12 @@ def test_cli_aln_gz_is_the_stdout_stream(tmp_path):
         assert r.stdout == b""
         assert gzip.open(os.path.join(w, "out.aln.gz"), "rb").read() == want
         assert open(os.path.join(w, "gz.trkmc.ar"), "rb").read() == open(os.path.join(d, "refae.trkmc.ar"), "rb").read()
+    # the README's own command line for the v1.3 contract (README.md:38-39: no flag of ours), switched by the environment
+    r = subprocess.run([CLI, "-gc", "85", "3", "-ae", "-ka", "-k", "25", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-o", "envsw"], cwd=w,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, DBTK_V13_THREADING="1"))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout == want
+    assert open(os.path.join(w, "envsw.trkmc.ar"), "rb").read() == open(os.path.join(d, "refae.trkmc.ar"), "rb").read()
 
 
 # ---- the ingest (reader, splitters, pairing) on the CPU: `--parse-only` reports what the pairing stage handed on --------
