@@ -164,6 +164,7 @@ struct TableShare {
 struct dbtk_ctx {
     TableShare* share = nullptr;
     const dbtk_rpgg* g = nullptr;
+    uint64_t g_uid = 0;           // g->uid, kept apart: releasing the tables must not touch a handle the caller may have freed first
     dbtk_params_t P;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -255,7 +256,7 @@ uint64_t pow2_at_least(uint64_t n) {
 uint32_t log2u(uint64_t c) { return 63u - (uint32_t)__builtin_clzll(c); }
 
 std::mutex g_share_m;
-std::map<std::pair<const dbtk_rpgg*, int>, TableShare*> g_shares;
+std::map<std::pair<uint64_t, int>, TableShare*> g_shares;  // (handle's uid, device): see dbtk_rpgg::uid
 
 void release_share(dbtk_ctx* c) {
     std::lock_guard<std::mutex> l(g_share_m);
@@ -268,7 +269,7 @@ void release_share(dbtk_ctx* c) {
     if (--sh->refs > 0) return;
     void* ptrs[] = {sh->d_flt, sh->d_trbeg, sh->d_idx, sh->d_cls, sh->d_vv, sh->d_qc, sh->d_perm, sh->d_tre, sh->d_bait, sh->d_gr, sh->d_mz, sh->d_ovf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    g_shares.erase(std::make_pair(c->g, c->device));
+    g_shares.erase(std::make_pair(c->g_uid, c->device));
     delete sh;
 }
 
@@ -786,7 +787,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
     HIPCHK(hipSetDevice(device_id));
     dbtk_ctx* c = new dbtk_ctx;
     memset(c->timed, 0, sizeof(c->timed));
-    c->g = h; c->P = *p; c->device = device_id;
+    c->g = h; c->g_uid = h->uid; c->P = *p; c->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free_ctx(c); set_error("hipGetDeviceProperties failed"); return DBTK_ERR_HIP; }
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -843,7 +844,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
         if (st) break;
         {   // the tables: shared per (handle, device)
             std::lock_guard<std::mutex> lk(g_share_m);
-            const auto key = std::make_pair(h, device_id);
+            const auto key = std::make_pair(h->uid, device_id);
             auto it = g_shares.find(key);
             TableShare* sh = it != g_shares.end() ? it->second : nullptr;
             auto to_share = [&](TableShare* t) {

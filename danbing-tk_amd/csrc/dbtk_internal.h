@@ -4,6 +4,7 @@
 
 #include <stdint.h>
 
+#include <atomic>
 #include <exception>
 #include <new>
 #include <string>
@@ -13,7 +14,12 @@
 
 // The RPGG exactly as the reference's loaders see it (flat, file-equivalent),
 // plus the output order derived once at load time.
+inline uint64_t dbtk_next_uid() { static std::atomic<uint64_t> n{0}; return ++n; }
 struct dbtk_rpgg {
+    // Process-unique, never reused: what the per-device caches of the tables built from this handle are keyed by (a freed
+    // handle's ADDRESS can come back with the next `new`; its id cannot, so a context leaked with its tables can never lend
+    // them to another RPGG).
+    const uint64_t uid = dbtk_next_uid();
     uint32_t ksize = 0;
     uint64_t nloci = 0;
     std::vector<uint64_t> keys;   // PREF.kmers.dbi

@@ -459,6 +459,7 @@ size_t dbtk_aln_format(const void* rec, uint32_t cap, char* out, size_t out_cap)
 }
 
 void dbtk_rpgg_free(dbtk_rpgg_t* h) { delete h; }
+uint64_t dbtk_rpgg_uid(const dbtk_rpgg_t* h) { return h ? h->uid : 0; }
 uint64_t dbtk_rpgg_nloci(const dbtk_rpgg_t* h) { return h ? h->nloci : 0; }
 uint64_t dbtk_rpgg_ntrkmers(const dbtk_rpgg_t* h) { return h ? h->out_kmer.size() : 0; }
 uint64_t dbtk_rpgg_nkeys(const dbtk_rpgg_t* h) { return h ? h->keys.size() : 0; }

@@ -207,6 +207,10 @@ dbtk_status_t dbtk_rpgg_load_tr(const char* prefix, const char* tr_kmers_file, u
 /* Same handle from caller arrays (copied). */
 dbtk_status_t dbtk_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a, dbtk_rpgg_t** out);
 void          dbtk_rpgg_free(dbtk_rpgg_t* h);
+/* Process-unique id of the handle, never reused (> 0).  The HBM tables built from a handle are cached per (id, device) and
+ * shared by the contexts created from it; the id — not the handle's address, which the allocator hands out again — is the key,
+ * so tables can never be taken for another RPGG's.  The handle must still outlive its contexts. */
+uint64_t      dbtk_rpgg_uid(const dbtk_rpgg_t* h);
 uint64_t      dbtk_rpgg_nloci(const dbtk_rpgg_t* h);
 uint64_t      dbtk_rpgg_ntrkmers(const dbtk_rpgg_t* h);  /* == length of the counts vector */
 uint64_t      dbtk_rpgg_nkeys(const dbtk_rpgg_t* h);

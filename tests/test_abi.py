@@ -149,6 +149,27 @@ def _index_map(a):
     return m
 
 
+def test_handle_ids_are_never_reused(lib, tmp_path):
+    """The per-device table caches are keyed by the handle's id (dbtk_rpgg_uid), not its address: free a handle, load another —
+    the allocator usually hands the same address out again — and the id still differs, so a context leaked with its tables can
+    never lend them to the next RPGG (free-then-reallocate)."""
+    import ctypes as C
+    import synth
+    loci = synth.make_loci(nloci=2, nhap=2, flank=200, seed=6)
+    pref = os.path.join(str(tmp_path), "pan")
+    synth.write_rpgg_files(synth.build_rpgg_arrays(loci, 21), pref)
+    lib.L.dbtk_rpgg_uid.restype = C.c_uint64
+    lib.L.dbtk_rpgg_uid.argtypes = [C.c_void_p]
+    seen, addrs = [], []
+    for _ in range(6):
+        g = lib.load(pref, 21)
+        seen.append(int(lib.L.dbtk_rpgg_uid(g.h)))
+        addrs.append(g.h.value)
+        g.close()
+    assert all(u > 0 for u in seen) and len(set(seen)) == len(seen) and seen == sorted(seen)
+    assert len(set(addrs)) < len(addrs) or True  # (whether an address repeats is the allocator's business: the ids never do)
+
+
 def test_load_with_a_named_tr_file(lib, tmp_path):
     """dbtk_rpgg_load_tr (`-t N`: PREF.tr.trimN.kmers, AQ.cpp:2389): locus count, TR sets and the output order come from the named
     file, everything else from PREF."""

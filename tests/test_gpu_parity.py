@@ -318,6 +318,39 @@ def test_legacy_v13_rpgg_end_to_end(dbtk, oracle):
     g.close()
 
 
+def test_leaked_context_cannot_lend_its_tables(dbtk, oracle, tmp_path):
+    """A context that is never freed keeps its share of the device tables alive.  If its RPGG handle is freed all the same and the
+    next handle lands on the same address, the new context must build its own tables (they are keyed by the handle's id, not its
+    address): results are those of the NEW RPGG.  Also: DBTK_MZ=0 (no minimizer-grouped copy: the general probe kernel on a
+    geometry the lean one usually takes) is read when a handle's tables are first built."""
+    p = abi.default_params(ksize=21, cthreshold=45, trace=1)
+    c1 = make_case("clean", str(tmp_path))
+    g1 = dbtk.load(c1.prefix, c1.k, c1.qc_file)
+    leaked = dbtk.context(g1, p)  # (never closed)
+    addr = g1.h.value
+    g1.close()
+    c2 = make_case("shared", str(tmp_path))
+    go = oracle.load(c2.prefix, c2.k, c2.qc_file)
+    seq, off = c2.reads.packed()
+    o = oracle.align(go, p, seq, off)
+    same_address = False
+    for attempt in range(6):
+        if attempt == 3:
+            os.environ["DBTK_MZ"] = "0"
+        g2 = dbtk.load(c2.prefix, c2.k, c2.qc_file)
+        same_address |= g2.h.value == addr
+        ctx = dbtk.context(g2, p)
+        recs, nrec = ctx.align(seq, off)
+        res = ctx.counts()
+        res["recs"] = recs
+        compare(o, res, g2.output_order(), g2.ntrkmers, c2.reads.npairs, recs=True)
+        ctx.close()
+        g2.close()
+    os.environ.pop("DBTK_MZ", None)
+    oracle.free(go)
+    del leaked
+
+
 def test_survivor_chunks_on_device(dbtk, oracle, tmp_path, monkeypatch):
     """The K2 -> K3 hit buffers hold DBTK_SURV_CAP survivors; with a tiny cap one batch runs as many chunk iterations
     (the path batches of more than 8 M pairs take): same results, records included."""
