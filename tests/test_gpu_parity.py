@@ -491,6 +491,31 @@ def test_two_gpu_allreduce_equals_single_gpu(dbtk, oracle):
     g.close()
 
 
+@pytest.mark.gpu
+def test_bench_collective_path_on_one_gpu():
+    """bench.py exactly as the driver starts it for N > 1 — under torch.distributed.run, one rank per GPU, RCCL process group,
+    barriers, the MAX over ranks and the all-reduce of the accumulators — in a world of one (DBTK_BENCH_FORCE_DIST=1), so the
+    code path of the 8-GPU run executes on every 1-GPU box: one rank seen, counts bit-exact against the oracle."""
+    import json
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--nloci", "3000", "--reads", "400000",
+           "--mix-reads", "0", "--no-e2e", "--ref-reads", "0", "--cpu-seconds", "4", "--parity-pairs", "30000"]
+    env = dict(os.environ, DBTK_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["parity"] and d["parity"]["bit_exact"] and d["parity"]["pairs"] >= 30000
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
+
+
 def test_checked_launches_mode(tmp_path):
     """DBTK_SYNC_LAUNCHES=1 (what the debug build, `make -C danbing-tk_amd/csrc debug`, hard-wires): every launch is waited
     for and checked by name.  Same results; run in a child process because the switch is read once per process."""
