@@ -95,6 +95,15 @@ __global__ void __launch_bounds__(64) k_walk_reads(WalkArgs a) {
     DevX x{&sm};
     body_walk_reads(x, a);
 }
+// pair mode, first kernel (dbtk_walk.h: body_walk_fast): decides and counts the pairs one of whose mates threads cleanly
+#ifndef DBTK_WF_WPE
+#define DBTK_WF_WPE 4
+#endif
+template <int NPL> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_WF_WPE, 8))) k_walk_fast(WalkArgs a) {
+    __shared__ WalkFastSmemT<NPL> sm;
+    DevX x{&sm};
+    body_walk_fast<NPL>(x, a);
+}
 __global__ void __launch_bounds__(64, DBTK_WALK_WAVES) k_walk_pairs(WalkArgs a) {
     __shared__ __attribute__((aligned(16))) WalkSmem sm[2];  // one set of arrays per mate
     DevX x{sm};
@@ -201,7 +210,7 @@ struct dbtk_ctx {
     uint32_t aln_stride = 0, aln_cap = 0; uint64_t aln_max = 0;
     uint8_t* h_aln = nullptr; size_t h_aln_bytes = 0;  // pinned staging of dbtk_ctx_aln_records
     uint64_t last_walk_npairs = 0; bool last_walk_recs = false;  // what dbtk_ctx_walk_results may fetch
-    int walk_blocks = 0;
+    int walk_blocks = 0, walkfast_blocks = 0;
     // optional gates
     ClsSlot* d_tre = nullptr; ClsSlot* d_bait = nullptr;
     uint8_t* d_qual = nullptr; uint64_t qual_cap = 0;
@@ -612,7 +621,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     if ((st = ensure(&c->d_tickets, &c->tickets_cap, 2 * (nchunks + 1)))) return st;  // per chunk: a ticket counter and a passed-on counter
     const bool walking = c->P.threading == DBTK_THREADING_V13;
     if (walking) {
-        if ((st = ensure(&c->d_walk, &c->walk_cap, 2 * npairs))) return st;
+        if ((st = ensure(&c->d_walk, &c->walk_cap, 3 * npairs))) return st;  // destLocus | return codes | the fast kernel's leftovers
         HIPCHK(hipMemsetAsync(c->d_walk, 0xFF, npairs * sizeof(uint32_t), s));  // NAN32: the pair does not reach threading
     }
     HIPCHK(hipMemsetAsync(c->d_small, 0, 3 * sizeof(uint32_t), s));  // nsurv, novf, nrec; the error word (3) stays until it has been reported
@@ -752,7 +761,17 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             w.aln = c->d_aln; w.aln_stride = c->aln_stride; w.aln_cap = acap; w.aln_max = (uint32_t)std::min<uint64_t>(c->aln_max, 0xFFFFFFFFull);
             w.naln = c->d_small + 4;
         }
+        // Two kernels when nothing needs the alignment of every mate (no -a / -ae records, no thread records): the lean one
+        // decides and counts the pairs one of whose mates threads cleanly, the one with the error-correction machinery takes the
+        // rest from its list.  (The walk's kernels are timed together: "k_walk_pairs".)
+        const int wnpl = (walk_aln || walk_trecs || k + 4 > 32) ? 0 : (max_read_len <= 32 * 3 + k - 1 && k + 2 <= 32 ? 3 : max_read_len <= 32 * 5 + k - 1 ? 5 : 0);
         if (tm) { if ((st = timed_slot(c, 4, &e))) return st; HIPCHK(hipEventRecord(c->timed[4].beg[e], s)); }
+        if (wnpl && !getenv("DBTK_WALK_ONE_KERNEL")) {
+            w.slow_list = c->d_walk + 2 * npairs; w.nslow = c->d_small + 5;
+            HIPCHK(hipMemsetAsync(c->d_small + 5, 0, 4, s));
+            if (wnpl == 3) LAUNCH((k_walk_fast<3>), dim3(c->walkfast_blocks), dim3(64), s, w);
+            else LAUNCH((k_walk_fast<5>), dim3(c->walkfast_blocks), dim3(64), s, w);
+        }
         LAUNCH(k_walk_pairs, dim3(c->walk_blocks), dim3(64), s, w);
         if (tm) HIPCHK(hipEventRecord(c->timed[4].end[e], s));
     }
@@ -837,6 +856,9 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_walk_pairs, 64, 0) != hipSuccess || nb <= 0) nb = 8;
             if (const char* e = getenv("DBTK_WALK_WPC")) { const int v = atoi(e); if (v > 0) nb = v; }
             c->walk_blocks = c->num_cu * nb;
+            nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_walk_fast<5>, 64, 0) != hipSuccess || nb <= 0) nb = 16;
+            c->walkfast_blocks = c->num_cu * nb;
         }
         for (int i = 0; i < NKERN && !st; ++i)
             for (int j = 0; j < EVPOOL && !st; ++j)

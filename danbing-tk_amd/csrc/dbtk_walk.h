@@ -115,7 +115,12 @@ struct WalkArgs {
     uint32_t aln_stride, aln_cap, aln_max;  // bytes per record, entries per packed array, records the buffer holds
     uint32_t* naln;            // slots handed out (in chunks of ALN_CHUNK per wave)
     uint64_t* dbg;             // diagnostic build only (-DDBTK_STAMPS): per-phase cycle sums
+    // pair mode in two kernels (body_walk_fast, then body_walk_pairs on what it passed on): survivors t the fast kernel could
+    // not decide.  body_walk_fast appends to it; body_walk_pairs takes its items from it (nullptr: every survivor).
+    uint32_t* slow_list;
+    uint32_t* nslow;
 };
+constexpr int8_t WALK_NOT_EVALUATED = -2;  // walk_ret of a mate whose walk nothing needed: its pair was kept by the other mate (dbtk.h)
 #ifdef DBTK_STAMPS
 #define W_STAMP_DECL uint64_t wst[8] = {0}; uint64_t wlast = x.clock();
 #define W_STAMP(i) do { const uint64_t now_ = x.clock(); wst[i] += now_ - wlast; wlast = now_; } while (0)
@@ -1062,7 +1067,7 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
 #endif
     const int lane = x.lane();
     uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
-    const uint32_t nsurv = *a.nsurv;
+    const uint32_t nsurv = a.slow_list ? *a.nslow : *a.nsurv;  // items: the fast kernel's leftovers, or every survivor
     if (nsurv == 0) return;  // (the clamped prefetches below read entry 0 of the survivor list)
     const uint32_t S_ = x.nblocks();
     uint64_t c_feas = 0, c_inc = 0;
@@ -1071,11 +1076,13 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
     // -> their k-mers' graph look-ups.  What bounds this kernel is round trips per wave, so the chain is software-pipelined
     // over the wave's items (t, t + S, ...): while item i is walked, the bytes of item i + 1, the offsets of item i + 2 and
     // the (destLocus, pair) of item i + 3 are in flight; all of these loads are unconditional (clamped indices).
-    auto meta = [&](uint32_t t, uint32_t* dst, uint32_t* pair) {
-        const uint32_t tc = t < nsurv ? t : 0u;
+    auto meta = [&](uint32_t i, uint32_t* dst, uint32_t* pair, uint32_t* tt) {
+        const uint32_t ic = i < nsurv ? i : 0u;
+        const uint32_t tc = a.slow_list ? a.slow_list[ic] : ic;  // (one more link of the chain in list mode: a dependent load)
         const uint32_t d = a.walk_dst[tc];
         *pair = a.surv[tc];
-        *dst = t < nsurv ? d : NAN32;
+        *dst = i < nsurv ? d : NAN32;
+        *tt = tc;
     };
     auto offs = [&](uint32_t pair, uint64_t o[3]) {
         o[0] = a.off[2 * (uint64_t)pair]; o[1] = a.off[2 * (uint64_t)pair + 1]; o[2] = a.off[2 * (uint64_t)pair + 2];
@@ -1087,11 +1094,11 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
     };
     auto uni64 = [&](uint64_t v) { return ((uint64_t)x.uni((uint32_t)(v >> 32)) << 32) | x.uni((uint32_t)v); };
     uint32_t tA = x.bid();
-    uint32_t dstA, pairA, dstB, pairB, dstC, pairC, dstD, pairD;
+    uint32_t dstA, pairA, dstB, pairB, dstC, pairC, dstD, pairD, ttA, ttB, ttC, ttD;
     uint64_t oA[3], oB[3], oC[3];
     uint32_t wA[2][2], wB[2][2];
-    meta(tA, &dstA, &pairA); meta(tA + S_, &dstB, &pairB); meta(tA + 2 * S_, &dstC, &pairC);
-    dstA = x.uni(dstA); pairA = x.uni(pairA); dstB = x.uni(dstB); pairB = x.uni(pairB);
+    meta(tA, &dstA, &pairA, &ttA); meta(tA + S_, &dstB, &pairB, &ttB); meta(tA + 2 * S_, &dstC, &pairC, &ttC);
+    dstA = x.uni(dstA); pairA = x.uni(pairA); dstB = x.uni(dstB); pairB = x.uni(pairB); ttA = x.uni(ttA); ttB = x.uni(ttB);
     offs(pairA, oA); offs(pairB, oB);
     for (int q = 0; q < 3; ++q) { oA[q] = uni64(oA[q]); oB[q] = uni64(oB[q]); }
     raws(oA, wA);
@@ -1100,10 +1107,10 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
         W_STAMP(7);  // loop tail / pipeline rotation
         // the next items' loads, before anything of this item is waited for
         raws(oB, wB);
-        dstC = x.uni(dstC); pairC = x.uni(pairC);
+        dstC = x.uni(dstC); pairC = x.uni(pairC); ttC = x.uni(ttC);
         offs(pairC, oC);
-        meta(tA + 3 * S_, &dstD, &pairD);
-        const uint32_t t = tA, dst = dstA, pair = pairA;
+        meta(tA + 3 * S_, &dstD, &pairD, &ttD);
+        const uint32_t t = ttA, dst = dstA, pair = pairA;
         if (dst != NAN32) {
             int ret[2] = {0, 0};
             uint8_t* arec = nullptr;
@@ -1170,11 +1177,11 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
             W_STAMP(6);  // counting + results
         }
         // the pipeline moves on
-        dstA = dstB; pairA = pairB;
+        dstA = dstB; pairA = pairB; ttA = ttB;
         for (int q = 0; q < 3; ++q) { oA[q] = oB[q]; oB[q] = uni64(oC[q]); }
         for (int m = 0; m < 2; ++m) { wA[m][0] = wB[m][0]; wA[m][1] = wB[m][1]; }
-        dstB = dstC; pairB = pairC;
-        dstC = dstD; pairC = pairD;
+        dstB = dstC; pairB = pairC; ttB = ttC;
+        dstC = dstD; pairC = pairD; ttC = ttD;
     }
     if (a.aln && lane == 0)  // the slots of the last chunk that were not used
         for (; slot_used < ALN_CHUNK; ++slot_used) {
@@ -1185,6 +1192,184 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
 #ifdef DBTK_STAMPS
     if (lane == 0 && a.dbg) for (int m_ = 0; m_ < 2; ++m_) for (int i_ = 0; i_ < 8; ++i_) if (smm[m_].dst_[i_]) x.atomic_add(&a.dbg[8 + i_], smm[m_].dst_[i_]);
 #endif
+    if (lane == 0) {
+        if (c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], c_feas);
+        if (c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], c_inc);
+    }
+}
+
+// ---- pair mode, first kernel: the pairs one of whose mates threads through the graph as it stands.
+// isThreadFeasible on a read whose first k-mer is a node and whose every next k-mer is an out-edge of the one before returns 1
+// without skipping or correcting anything (walk_read's ballot loop above; AQ.cpp:1114-1260, 1259) — most reads.  The v1.3 call
+// site keeps a pair when EITHER mate is feasible and then counts the uncorrected k-mers of BOTH (AQ.cpp:2082-2087, 2189-2194):
+// so as soon as one mate threads cleanly the pair is decided and counted here, whatever the walk of the other mate would find
+// (its return code is reported as WALK_NOT_EVALUATED).  Pairs with no such mate — and everything when alignment records or
+// thread records are wanted — go to body_walk_pairs, the kernel that carries the error-correction machinery (and its 200+
+// registers); this one is the probe kernel's shape: one wave per pair, one mate per half-wave, NPL consecutive positions per
+// lane as shifts of one 32-base word, one 16-byte graph-table load per position, the feasibility of a mate one ballot.
+constexpr int WF_BUF = 64;
+template <int NPL>
+struct __attribute__((aligned(16))) WalkFastSmemT {
+    uint32_t pk[2][20];       // 2-bit stream of each mate from its 4-byte-aligned start
+    uint32_t buf[WF_BUF];     // passed-on survivors not yet appended to the list
+};
+template <int NPL, class X>
+DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
+    typedef WalkFastSmemT<NPL> SM;
+    SM& sm = *x.template smem<SM>();
+    const int lane = x.lane();
+    const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5;
+    const DevTables& T = a.T;
+    const uint32_t k = T.ksize;
+    uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
+    const uint32_t nsurv = *a.nsurv;
+    // a contiguous range of the (locus-ordered) survivor list per wave: the waves running side by side count into different loci
+    const uint32_t per = (nsurv + x.nblocks() - 1) / x.nblocks();
+    const uint64_t lo64 = (uint64_t)x.bid() * per;
+    const uint32_t first = lo64 < nsurv ? (uint32_t)lo64 : nsurv, hi = lo64 + per < nsurv ? (uint32_t)(lo64 + per) : nsurv;
+    const uint32_t lmax = 32u * NPL + k - 1;  // (the launcher promised no read is longer)
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    const uint32_t p0 = hl * NPL;
+    uint64_t c_feas = 0, c_inc = 0;
+    uint32_t nbuf = 0;
+    auto flush = [&]() {
+        x.sync();
+        uint32_t base = 0;
+        if (lane == 0) base = x.atomic_add(a.nslow, nbuf);
+        base = x.bcast(base, 0);
+        if ((uint32_t)lane < nbuf) a.slow_list[base + lane] = sm.buf[lane];
+        x.sync();
+        nbuf = 0;
+    };
+    // three-deep fetch pipeline as in the probe kernel: bytes of pair i + 1, offsets of pair i + 2, (pair, locus) of pair i + 3
+    auto clampi = [&](uint32_t i) { return i < hi ? i : (first < hi ? first : 0u); };
+    uint32_t rw0 = 0, rw1 = 0;
+    uint64_t o0C = 0, o1C = 0, o0B = 0, o1B = 0;
+    uint32_t pairA = 0, dstA = NAN32, dstB = NAN32, dstC = NAN32;
+    auto fetch_bytes = [&](uint64_t o0, uint64_t o1) {
+        uint32_t len = (uint32_t)(o1 - o0);
+        if (len > lmax) len = lmax;
+        const uint64_t a0 = o0 & ~3ull;
+        const uint32_t nw = ((uint32_t)(o0 - a0) + len + 3) >> 2;
+        rw0 = *reinterpret_cast<const uint32_t*>(a.seq + (2 * hl < nw ? a0 + 8ull * hl : 0ull));
+        rw1 = *reinterpret_cast<const uint32_t*>(a.seq + (2 * hl + 1 < nw ? a0 + 8ull * hl + 4 : 0ull));
+    };
+    auto fetch_offsets = [&](uint32_t pair) {
+        const uint64_t r = 2 * (uint64_t)pair + half;
+        o0B = a.off[r]; o1B = a.off[r + 1];
+    };
+    if (first < hi) {
+        fetch_offsets(x.uni(a.surv[first]));
+        dstC = a.walk_dst[first];
+        o0C = o0B; o1C = o1B;
+        fetch_bytes(o0C, o1C);
+        if (first + 1 < hi) { fetch_offsets(x.uni(a.surv[first + 1])); dstB = a.walk_dst[first + 1]; }
+        pairA = a.surv[clampi(first + 2)]; dstA = a.walk_dst[clampi(first + 2)];
+    }
+    for (uint32_t i = first; i < hi; ++i) {
+        const uint64_t o0 = o0C, o1 = o1C;
+        uint32_t len = (uint32_t)(o1 - o0);
+        if (len > lmax) { if (a.errflag) *a.errflag = DBTK_ERR_READ_TOO_LONG; len = lmax; }
+        const uint64_t a0 = o0 & ~3ull;
+        const uint32_t rsh = (uint32_t)(o0 - a0);
+        const uint32_t d0 = rw0, d1 = rw1;
+        const uint32_t dst = x.uni(dstC);
+        {   // advance the pipeline
+            const bool hasB = i + 1 < hi, hasA = i + 2 < hi;
+            o0C = hasB ? o0B : 0ull; o1C = hasB ? o1B : 0ull;
+            fetch_bytes(o0C, o1C);
+            dstC = dstB; dstB = dstA;
+            fetch_offsets(hasA ? x.uni(pairA) : x.uni(pairA) * 0u);
+            pairA = a.surv[clampi(i + 3)]; dstA = a.walk_dst[clampi(i + 3)];
+        }
+        if (dst == NAN32) continue;  // the pair never reached threading (uniform)
+        x.sync();
+        uint32_t bad = 0;
+        {
+            const uint32_t c0 = pack4_b2(d0, &bad), c1 = pack4_b2(d1, &bad);
+            reinterpret_cast<uint16_t*>(sm.pk[half])[hl ^ 1u] = (uint16_t)(((c0 >> 8) & 0xFF00u) | ((c1 >> 16) & 0xFFu));
+        }
+        const uint32_t nk = len >= k ? len - k + 1 : 0;
+        // a mate with a non-ACGT byte does not thread cleanly (a k-mer with an N is no node); bytes of the lane's dwords outside
+        // the read are the neighbouring reads': counting them only sends a mate to the other kernel for nothing
+        const uint64_t badm = x.ballot(bad != 0 && 8 * hl < rsh + len);
+        x.sync();
+        const uint64_t W = window_fw_clean(sm.pk[half], rsh + p0, 32);
+        const uint64_t RW = revcomp2(W, 32);
+        uint64_t fw[NPL], cn[NPL];
+        uint32_t gi[NPL];
+        uint64_t at[NPL];
+        bool act[NPL], open[NPL];
+        uint4 q[NPL];
+        bool anyo = false;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            fw[j] = (W >> (2 * (32 - k - j))) & kmask;
+            const uint64_t rc = (RW >> (2 * j)) & kmask;
+            cn[j] = fw[j] <= rc ? fw[j] : rc;
+            act[j] = p0 + j < nk;
+            at[j] = act[j] ? hash_cls(cn[j], dst, T.gr_shift) : 0ull;
+            q[j] = reinterpret_cast<const uint4*>(T.gr)[at[j]];
+            open[j] = act[j];
+            gi[j] = 0;
+            anyo |= open[j];
+        }
+        while (x.ballot(anyo)) {  // (a look-up rarely needs a second slot)
+            anyo = false;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                if (!open[j]) continue;
+                if (q[j].x == (uint32_t)cn[j] && q[j].y == (uint32_t)(cn[j] >> 32) && q[j].w == dst) { gi[j] = q[j].z; open[j] = false; }
+                else if ((q[j].x & q[j].y) == 0xFFFFFFFFu) open[j] = false;  // empty slot: not in the table
+                else { at[j] = (at[j] + 1) & T.gr_mask; q[j] = reinterpret_cast<const uint4*>(T.gr)[at[j]]; }
+                anyo |= open[j];
+            }
+        }
+        // oriented info of every position (as w_info), then the step test of walk_read: position p continues the walk iff the
+        // k-mer before it is a node with an out-edge labelled by p's last base (and is not p's k-mer itself: a homopolymer)
+        uint32_t go[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const bool isf = fw[j] == cn[j];
+            const uint32_t fa = gi[j] & 0x1Fu, fb = (gi[j] >> GR_OPP) & 0x1Fu;
+            go[j] = isf ? fa : fb;
+        }
+        uint32_t pg = x.shfl_up1(go[NPL - 1]);
+        uint32_t plo = x.shfl_up1((uint32_t)fw[NPL - 1]), phi = x.shfl_up1((uint32_t)(fw[NPL - 1] >> 32));
+        bool fail = false;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const uint64_t pv = ((uint64_t)phi << 32) | plo;
+            if (act[j]) {
+                if (p0 + j == 0) fail |= !(go[j] & GR_HAS);  // the anchor is the first k-mer
+                else fail |= !((pg & GR_HAS) && ((pg >> (uint32_t)(fw[j] & 3)) & 1) && fw[j] != pv);
+            }
+            pg = go[j]; plo = (uint32_t)fw[j]; phi = (uint32_t)(fw[j] >> 32);
+        }
+        const uint64_t failm = x.ballot(fail) | badm;
+        const uint64_t nkm = x.ballot(nk > 0);
+        const bool clean0 = (nkm & 1) && !(failm & 0xFFFFFFFFull), clean1 = ((nkm >> 32) & 1) && !(failm >> 32);
+        if ((clean0 || clean1) && !badm) {  // (uniform) the pair is kept: count the uncorrected k-mers of both mates (AQ.cpp:2189-2194)
+            // (a pair with a non-ACGT byte in either mate is passed on even when its other mate threads: the valid k-mers of the
+            // mate with the N count too, and which of its windows are valid is the other kernel's business)
+            c_feas += 2;
+            const uint32_t tb = T.trbeg[dst];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const bool hit = act[j] && (gi[j] & GR_TR);
+                if (hit) x.atomic_add(&a.counts[tb + (gi[j] >> GR_SLOT_SHIFT)], 1ull);
+                c_inc += (uint64_t)__builtin_popcountll(x.ballot(hit));
+            }
+            if (lane == 0) {
+                a.walk_dst[i] = dst;
+                a.walk_ret[i] = (uint32_t)(uint8_t)(clean0 ? 1 : WALK_NOT_EVALUATED) | ((uint32_t)(uint8_t)(clean1 ? 1 : WALK_NOT_EVALUATED) << 8);
+            }
+        } else {
+            if (lane == 0) sm.buf[nbuf] = i;
+            if (++nbuf == (uint32_t)WF_BUF) flush();
+        }
+    }
+    if (nbuf) flush();
     if (lane == 0) {
         if (c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], c_feas);
         if (c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], c_inc);

@@ -372,6 +372,28 @@ class RefHarness:
         return dict(counts_file=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs)
 
 
+def walk_res_equal(mine, theirs, n, nloci, every_mate):
+    """dbtk_ctx_walk_results against the oracle's: pair and destLocus always; the return codes exactly when every mate's
+    alignment was asked for (-a / -ae, trace) — otherwise a mate whose partner threads cleanly may be reported as
+    DBTK_WALK_NOT_EVALUATED (-2, dbtk.h): then its partner's code is 1 and the pair is kept.  Returns how many were skipped,
+    or -1 on a mismatch."""
+    if every_mate:
+        return 0 if bytes(mine)[:8 * n] == bytes(theirs)[:8 * n] else -1
+    skipped = 0
+    for i in range(n):
+        a, b = mine[i], theirs[i]
+        if (a.pair, a.dst) != (b.pair, b.dst):
+            return -1
+        for m, t, other in ((a.ret1, b.ret1, a.ret2), (a.ret2, b.ret2, a.ret1)):
+            if m == -2:
+                if other != 1 or b.dst == nloci:
+                    return -1
+                skipped += 1
+            elif m != t:
+                return -1
+    return skipped
+
+
 def recs_equal(a, b, n):
     """Byte-compare two PairRec arrays; returns index of first difference or -1."""
     sz = C.sizeof(abi.PairRec)

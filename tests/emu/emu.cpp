@@ -284,7 +284,7 @@ struct EmuTables {
 
 }  // namespace
 
-static uint64_t g_probe_runs[2] = {0, 0}, g_mz_turned = 0;
+static uint64_t g_probe_runs[2] = {0, 0}, g_mz_turned = 0, g_walk_fast_runs = 0, g_walk_slow_pairs = 0;
 extern "C" {
 
 void* emu_tables_create(const dbtk_rpgg_t* g) {
@@ -621,6 +621,8 @@ uint64_t emu_walk_results(dbtk_walk_res_t* res, uint32_t* tidx, uint64_t cap) {
 // which probe body the last calls of emu_align_ex dispatched: [0] general (body_probe), [1] lean (body_probe2); and the
 // keys level 1 of the last emu_tables_create turned away (= entries of its overflow table)
 void emu_probe_stats(uint64_t* out) { out[0] = g_probe_runs[0]; out[1] = g_probe_runs[1]; out[2] = g_mz_turned; g_probe_runs[0] = g_probe_runs[1] = 0; }
+// pair-mode walks since the last call: runs of the lean first kernel, pairs it passed on to the second
+void emu_walk_stats(uint64_t* out) { out[0] = g_walk_fast_runs; out[1] = g_walk_slow_pairs; g_walk_fast_runs = g_walk_slow_pairs = 0; }
 int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
               uint64_t npairs, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* counters,
               dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec, uint32_t grid_k1, uint32_t grid_pair) {
@@ -741,6 +743,17 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
             const uint64_t amax = npairs + (uint64_t)ALN_CHUNK * grid_pair;
             alnraw.assign(amax * g_aln_stride, 0);
             w.aln = alnraw.data(); w.aln_stride = g_aln_stride; w.aln_cap = g_aln_cap; w.aln_max = (uint32_t)amax; w.naln = &naln;
+        }
+        // the two-kernel form where nothing needs every mate's alignment, as launch_batch decides
+        std::vector<uint32_t> slow(npairs + 1, 0);
+        uint32_t nslow = 0;
+        const uint32_t kk = g->ksize;
+        const int wnpl = (p->aln || g_walk_trecs || kk + 4 > 32) ? 0 : (maxlen <= 32 * 3 + kk - 1 && kk + 2 <= 32 ? 3 : maxlen <= 32 * 5 + kk - 1 ? 5 : 0);
+        if (wnpl && !getenv("DBTK_WALK_ONE_KERNEL")) {
+            w.slow_list = slow.data(); w.nslow = &nslow;
+            if (wnpl == 3) run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<3>), [&](EmuX& x) { body_walk_fast<3>(x, w); });
+            else run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<5>), [&](EmuX& x) { body_walk_fast<5>(x, w); });
+            g_walk_fast_runs += 1; g_walk_slow_pairs += nslow;
         }
         run_grid(grid_pair, 64, 2 * sizeof(WalkSmem), [&](EmuX& x) { body_walk_pairs(x, w); });
         if (p->aln) {  // as dbtk_ctx_aln_records: drop the invalid slots, pair order

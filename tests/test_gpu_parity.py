@@ -278,7 +278,7 @@ def test_release_scale_properties(dbtk, oracle):
     np.add.at(co, g.output_order().astype(np.int64), ow["counts_file"])
     assert (co == r["counts"]).all() and co.sum() > 0 and (ow["counters"] == r["counters"]).all()
     res, _, nres = cw.walk_results(n2)
-    assert nres == ow["nres"] and bytes(res)[:8 * nres] == bytes(ow["res"])[:8 * nres]
+    assert nres == ow["nres"] and bind.walk_res_equal(res, ow["res"], nres, g.nloci, every_mate=False) > 0
     cw.close()
     oracle.free(orc_g)
     g.close()

@@ -399,7 +399,9 @@ def check_pair_mode(run, O, oh, case, k, nloci):
         assert (co == g["counts"]).all() and co.sum() > 0
         assert (o["counters"] == g["counters"]).all(), (o["counters"], g["counters"])
         n = o["nres"]
-        assert g["nres"] == n and bytes(g["res"])[:8 * n] == bytes(o["res"])[:8 * n]
+        assert g["nres"] == n
+        skipped = bind.walk_res_equal(g["res"], o["res"], n, nloci, every_mate=bool(aln))
+        assert skipped >= 0 and (aln or skipped > 0)  # (without -a / -ae the lean first kernel decides most pairs)
         exp, _ = expected_aln(O, o, reads, aln, nloci)
         if aln:
             assert [(h.pair, h.dst, t) for h, t in g["aln"]] == exp
