@@ -68,7 +68,10 @@ def parse_args(argv=None):
     ap.add_argument("--ref-threads", type=int, nargs="*", default=None, help="-p values for the reference binary [1 8 <all host threads>]")
     ap.add_argument("--mix-reads", type=int, default=4_000_000, help="reads per step of the extra mixes (all-hit, walk); 0 = skip them")
     ap.add_argument("--mix-steps", type=int, default=10)
-    ap.add_argument("--no-walk", action="store_true", help="skip the graph-walk mix (threading = 2)")
+    ap.add_argument("--no-walk", action="store_true", help="skip the graph-walk mixes (threading = 2)")
+    ap.add_argument("--k25-reads", type=int, default=10_000_000, help="reads per step of the k = 25 graph-walk mix (BASELINE config 4: pipeline/k25.json, -gc 85 3); 0 = skip it")
+    ap.add_argument("--k25-parity-pairs", type=int, default=20000, help="pairs of the k = 25 mix whose oracle result (counts, counters, walk results) is compared")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0, help="the timed step repeated for at least this long (`sustained`); 0 = skip")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (host buffers, CLI)")
     ap.add_argument("--lanes", type=int, default=1, choices=(1, 2, 3),
                     help="streams the context alternates successive batches on.  2 (the library's default) overlaps one batch's encode kernel "
@@ -228,8 +231,7 @@ def main():
     seq, off = syn.reads(npairs, rlen=rlen, hit_frac=args.hit_frac, seed=1, first_pair=rank * npairs, nthreads=nth)
     log(f"reads: {npairs} pairs/GPU generated, {time.time() - t0:.1f}s")
 
-    # ---- the reference binary needs the RPGG as files and a FASTA sample; its -p 1 / -p 8 runs go on in the background
-    # (9 host threads) while the GPU part runs; the all-threads run comes after the timed region, alone
+    # ---- the reference binary needs the RPGG as files and a FASTA sample (written now; its runs come after the GPU legs)
     ref_dir, ref_procs, ref_results = None, [], []
     if do_ref:
         import ref_baseline
@@ -244,10 +246,13 @@ def main():
         import threading
         def bg(pv, fa):
             ref_results.append(dict(ref_baseline.run_reference(os.path.join(ROOT, "oracle", "_ref", "danbing-tk"), ref_dir, fa, pv), fasta=fa))
-        for pv in [p for p in pvals if p <= 8]:
-            th = threading.Thread(target=bg, args=(pv, "reads_small.fa" if pv == 1 else "reads.fa"))
-            th.start()
-            ref_procs.append(th)
+        def start_small_ref_legs():
+            """-p 1 and -p 8 (9 host threads): started only after every GPU leg and CLI leg is done, next to the one-core oracle leg;
+            the all-threads run comes last, alone"""
+            for pv in [p for p in pvals if p <= 8]:
+                th = threading.Thread(target=bg, args=(pv, "reads_small.fa" if pv == 1 else "reads.fa"))
+                th.start()
+                ref_procs.append(th)
 
     t0 = time.time()
     h = C.c_void_p()
@@ -334,6 +339,14 @@ def main():
     roof.update(traffic=traffic, traffic_source=traffic_src, traffic_stale=stale, kernels=table)
     probe_roof = roofline_of("k_probe", table) if "k_probe" in table else None
 
+    sustained = None
+    if solo and args.sustain_seconds > 0:
+        ctx.timers_enable(False)
+        nsus = max(args.steps, int(np.ceil(args.sustain_seconds / max(dt / args.steps, 1e-6))))
+        dts = time_steps(ctx, step, nsus, 0)
+        sustained = dict(value=2 * npairs * nsus / dts, unit="reads/s", steps=nsus, wall_s=dts, ms_per_step=dts / nsus * 1e3,
+                         note="the same step back to back for >= --sustain-seconds of wall time, no per-kernel events")
+        log(f"sustained: {nsus} steps in {dts:.2f}s = {sustained['value'] / 1e9:.2f} G reads/s")
     two_lanes = None
     if solo and args.lanes == 1 and args.extra_lanes:
         os.environ["DBTK_LANES"] = "2"
@@ -346,7 +359,7 @@ def main():
         ctx2.close()
 
     # ---- N = 1 extras: further read mixes, end to end, CPU baselines
-    mixes, e2e, cpu, parity = None, None, None, None
+    mixes, e2e, cpu, parity, k25_check = None, None, None, None, None
     nhit = 0  # pairs of the all-hit FASTA the CLI walk legs read
     if solo and rank == 0:
         mixes = {}
@@ -391,7 +404,66 @@ def main():
                                             roofline=dict(roofline_of(domw, tw), kernels=tw))
                 log(f"walk mix: {dtw / args.mix_steps * 1e3:.3f} ms/step, {mixes['walk_gc85_3']['value'] / 1e6:.1f} M reads/s, dominant {domw} {tw[domw]['avg_ms']:.3f} ms")
                 ctxw.close()
-            del d_ah, d_aho
+            # genome-like background: WGS reads are not uniform random — repeat families shared with the flanks let far more pairs
+            # through subfilter than the 2 % that come from a locus.  Here 15 % of the background pairs carry a 64-base stretch of
+            # some locus (cut from an all-hit read) over one of mate 1's sampled windows: they pass subfilter, reach the probe
+            # kernel and die in kfilter.  Counts are not oracle-checked here (the parity run above uses the headline batch).
+            rng = np.random.default_rng(7)
+            gseq = seq[:2 * mp * rlen].copy()
+            pick = np.nonzero(rng.random(mp) < 0.15)[0]
+            src = rng.integers(0, mp, len(pick))
+            at = rng.choice(np.array([0, (rlen - 21 + 1) // 3, 2 * ((rlen - 21 + 1) // 3), rlen - 64]), len(pick))
+            at = np.minimum(at, rlen - 64)
+            for q in range(64):
+                gseq[2 * pick * rlen + at + q] = ah_seq[2 * src * rlen + 40 + q]
+            d_g = torch.from_numpy(gseq).to(dev)
+            d_go = torch.from_numpy(ah_off.view(np.int64)).to(dev)
+            ctx.timers_enable(1)
+            dtg = time_steps(ctx, lambda: ctx.align_device(d_g.data_ptr(), d_go.data_ptr(), mp, rlen), args.mix_steps, 2)
+            cg = ctx.counters().astype(np.float64)
+            tg = kernel_table(ctx.kernel_times(), algorithmic_bytes(abi, cg), args.mix_steps, args.mix_steps)
+            domg = max((k for k in tg if ":" not in k), key=lambda k: tg[k]["avg_ms"] * tg[k]["launches"])
+            mixes["genome_like"] = dict(workload=f"{2 * mp} reads per step: the headline mix ({args.hit_frac:.0%} of pairs from loci) with 15 % of the background "
+                                                 f"pairs carrying a 64-base repeat shared with a locus over a sampled window, -k 21 -kf 4 1 -cth 45 -ka",
+                                        value=2 * mp * args.mix_steps / dtg, unit="reads/s", ms_per_step=dtg / args.mix_steps * 1e3, steps=args.mix_steps,
+                                        pairs_past_subfilter=cg[abi.C_SURVIVORS] / args.mix_steps / mp,
+                                        roofline=dict(roofline_of(domg, tg), kernels=tg))
+            log(f"genome-like mix: {dtg / args.mix_steps * 1e3:.3f} ms/step, {mixes['genome_like']['value'] / 1e9:.2f} G reads/s, "
+                f"{100 * mixes['genome_like']['pairs_past_subfilter']:.1f} % of pairs past subfilter, dominant {domg}")
+            del d_g, d_go, d_ah, d_aho
+            if do_walk and args.k25_reads > 0:
+                # BASELINE config 4 as stated: k = 25 (pipeline/k25.json:5), -gc 85 3, every assigned pair walked, exact counting
+                t0 = time.time()
+                syn25 = pkg.Synth(nloci=args.nloci, k=25, flank=700, seed=20250808, nthreads=nth)
+                syn25.graph(nth)
+                arrs25 = syn25.arrays()
+                h25 = C.c_void_p()
+                dbtk._chk(dbtk.L.dbtk_rpgg_from_arrays(C.byref(arrs25), C.byref(h25)))
+                g25 = pkg.Rpgg(dbtk, h25)
+                p25 = abi.default_params(ksize=25, n_filter=4, nm_filter=1, cthreshold=45, okam=0, threading=abi.THREADING_V13, thread_cth=85,
+                                         correction=1, maxncorrection=3)
+                ctx25 = dbtk.context(g25, p25, device=local_rank)
+                kp = args.k25_reads // 2
+                s25, o25 = syn25.reads(kp, rlen=rlen, hit_frac=1.0, seed=3, nthreads=nth)
+                d_s25 = torch.from_numpy(s25).to(dev)
+                d_o25 = torch.from_numpy(o25.view(np.int64)).to(dev)
+                torch.cuda.synchronize()
+                log(f"k = 25 RPGG ({arrs25.nkeys} index keys) + graph + HBM tables + {2 * kp} all-hit reads: {time.time() - t0:.1f}s")
+                ctx25.timers_enable(1)
+                dt25 = time_steps(ctx25, lambda: ctx25.align_device(d_s25.data_ptr(), d_o25.data_ptr(), kp, rlen), args.mix_steps, 2)
+                c25 = ctx25.counters().astype(np.float64)
+                t25 = kernel_table(ctx25.kernel_times(), algorithmic_bytes(abi, c25, c25[abi.C_THREADING] * (rlen - 25 + 1)), args.mix_steps, args.mix_steps)
+                dom25 = max((k for k in t25 if ":" not in k), key=lambda k: t25[k]["avg_ms"] * t25[k]["launches"])
+                mixes["walk_k25_gc85_3"] = dict(workload=f"synthetic release-scale RPGG at k = 25 ({args.nloci} loci, {arrs25.nkeys} index keys), {2 * kp} reads per step, "
+                                                         f"100 % of pairs from loci, --v13-threading -gc 85 3 -k 25 -kf 4 1 -cth 45 -ka",
+                                                value=2 * kp * args.mix_steps / dt25, unit="reads/s", ms_per_step=dt25 / args.mix_steps * 1e3, steps=args.mix_steps,
+                                                reads_walked_per_step=c25[abi.C_THREADING] / args.mix_steps, reads_feasible_per_step=c25[abi.C_FEASIBLE] / args.mix_steps,
+                                                roofline=dict(roofline_of(dom25, t25), kernels=t25), parity=None)
+                log(f"k = 25 walk mix: {dt25 / args.mix_steps * 1e3:.3f} ms/step, {mixes['walk_k25_gc85_3']['value'] / 1e6:.1f} M reads/s, dominant {dom25} {t25[dom25]['avg_ms']:.3f} ms")
+                del d_s25, d_o25
+                k25_check = (syn25, arrs25, g25, ctx25, p25, s25, o25) if args.cpu_seconds > 0 and args.k25_parity_pairs > 0 else None
+                if not k25_check:
+                    ctx25.close(); g25.close(); syn25.close()
         if not args.no_e2e:
             # the same batch handed over as HOST buffers: validation + PCIe copies + kernels, one batch after the other
             e2e = {}
@@ -442,6 +514,8 @@ def main():
 
         # ---- cpu baselines
         port = None
+        if do_ref:
+            start_small_ref_legs()
         if args.cpu_seconds > 0:
             import bind
             try:
@@ -476,6 +550,24 @@ def main():
                         sample=f"first {2 * done} reads of the same read set and RPGG, oracle/dbtk_oracle.c on 1 host core, {t_cpu:.1f} s", checked=parity)
             log(f"oracle (port) on 1 core: {port['value']:.0f} reads/s")
             orc.free(go)
+            if k25_check:  # the k = 25 walk mix against the oracle on a slice: counts, counters, walk results
+                syn25, arrs25, g25, ctx25, p25, s25, o25 = k25_check
+                t0 = time.time()
+                go25 = orc.from_arrays(arrs25)
+                n25 = min(args.k25_parity_pairs, len(o25) // 2)
+                ow = orc.align_walk(go25, p25, s25[:2 * n25 * rlen], o25[:2 * n25 + 1], with_recs=False)
+                ctx25.reset()
+                ctx25.align(s25[:2 * n25 * rlen], o25[:2 * n25 + 1])
+                r25 = ctx25.counts()
+                co = np.zeros(g25.ntrkmers, np.uint64)
+                np.add.at(co, g25.output_order().astype(np.int64), ow["counts_file"])
+                res25, _, nres25 = ctx25.walk_results(n25)
+                ok = bool((co == r25["counts"]).all() and (ow["counters"] == r25["counters"]).all() and nres25 == ow["nres"]
+                          and bind.walk_res_equal(res25, ow["res"], nres25, g25.nloci, every_mate=False) >= 0)
+                mixes["walk_k25_gc85_3"]["parity"] = dict(pairs=n25, bit_exact=ok, walked=int(ow["nres"]))
+                log(f"k = 25 walk mix, parity on {n25} pairs ({ow['nres']} walked): {'bit-exact' if ok else 'MISMATCH'} ({time.time() - t0:.0f}s incl. oracle tables)")
+                orc.free(go25)
+                ctx25.close(); g25.close(); syn25.close()
         if do_ref:
             for th in ref_procs:
                 th.join()
@@ -514,7 +606,7 @@ def main():
                                    f"-k 21 -kf 4 1 -cth 45 -ka; RCCL all-reduce of counts at the end",
                        "lanes": args.lanes, "reads_per_gpu": args.reads, "read_len": rlen, "hit_frac": args.hit_frac, "k": 21, "cth": 45,
                        "kernel_source_hash": kernel_source_hash()},
-            "roofline": roof, "probe_roofline": probe_roof, "mixes": mixes, "end_to_end": e2e, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roof, "probe_roofline": probe_roof, "sustained": sustained, "mixes": mixes, "end_to_end": e2e, "cpu_baseline": cpu, "parity": parity,
             "two_lanes": two_lanes, "bench_wall_s": time.time() - t_start,
         }
         print(json.dumps(out), flush=True)

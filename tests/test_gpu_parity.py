@@ -284,6 +284,50 @@ def test_release_scale_properties(dbtk, oracle):
     g.close()
 
 
+def test_release_scale_walk_k25(dbtk, oracle):
+    """BASELINE config 4 as stated: a release-scale synthetic RPGG at k = 25 (pipeline/k25.json:5), all-hit reads through the graph
+    walk with -gc 85 3: counts, all counters and the walk results of a 30 000-pair slice against the oracle; the whole 1 M-pair
+    batch through size-independent properties (additivity over a split, counted increments == sum of counts)."""
+    syn = bind.pkg.Synth(nloci=80000, k=25)
+    syn.graph()
+    arrs = syn.arrays()
+    h = C.c_void_p()
+    dbtk._chk(dbtk.L.dbtk_rpgg_from_arrays(C.byref(arrs), C.byref(h)))
+    g = bind.pkg.Rpgg(dbtk, h)
+    pw = abi.default_params(ksize=25, n_filter=4, nm_filter=1, cthreshold=45, okam=0, threading=abi.THREADING_V13, thread_cth=85,
+                            correction=1, maxncorrection=3)
+    npairs = 1_000_000
+    seq, off = syn.reads(npairs, hit_frac=1.0, seed=3)
+    whole = dbtk.context(g, pw)
+    whole.align(seq, off)
+    w = whole.counts()
+    ctr = w["counters"]
+    assert ctr[abi.C_THREADING] > npairs and ctr[abi.C_FEASIBLE] > ctr[abi.C_THREADING] // 2
+    assert int(w["counts"].sum()) == int(ctr[abi.C_ALGO_INC])
+    parts = dbtk.context(g, pw)
+    for a, b in ((0, 333_333), (333_333, npairs)):
+        base = int(off[2 * a])
+        parts.align(seq[base:int(off[2 * b])], off[2 * a:2 * b + 1] - np.uint64(base))
+    q = parts.counts()
+    for k_ in ("counts", "kmc", "nmapread", "counters"):
+        assert (w[k_] == q[k_]).all(), k_
+    parts.close()
+    n2 = 30_000
+    orc_g = oracle.from_arrays(arrs)
+    ow = oracle.align_walk(orc_g, pw, seq[:int(off[2 * n2])], off[:2 * n2 + 1], with_recs=False)
+    whole.reset()
+    whole.align(seq[:int(off[2 * n2])], off[:2 * n2 + 1])
+    r = whole.counts()
+    co = np.zeros(g.ntrkmers, np.uint64)
+    np.add.at(co, g.output_order().astype(np.int64), ow["counts_file"])
+    assert (co == r["counts"]).all() and co.sum() > 0 and (ow["counters"] == r["counters"]).all()
+    res, _, nres = whole.walk_results(n2)
+    assert nres == ow["nres"] and bind.walk_res_equal(res, ow["res"], nres, g.nloci, every_mate=False) > 0
+    whole.close()
+    oracle.free(orc_g)
+    g.close()
+
+
 def test_legacy_v13_rpgg_end_to_end(dbtk, oracle):
     """The reference's own v1.3 fixture (tests/golden/legacy_v13) loaded by dbtk_rpgg_load, reads stitched from its k-mers:
     the HIP path against the oracle on the same flat arrays."""
