@@ -406,7 +406,7 @@ def main():
                 ctxw.close()
             # genome-like background: WGS reads are not uniform random — repeat families shared with the flanks let far more pairs
             # through subfilter than the 2 % that come from a locus.  Here 15 % of the background pairs carry a 64-base stretch of
-            # some locus (cut from an all-hit read) over one of mate 1's sampled windows: they pass subfilter, reach the probe
+            # some locus (cut from an all-hit pair) over one of the sampled windows of each mate: they pass subfilter, reach the probe
             # kernel and die in kfilter.  Counts are not oracle-checked here (the parity run above uses the headline batch).
             rng = np.random.default_rng(7)
             gseq = seq[:2 * mp * rlen].copy()
@@ -414,8 +414,10 @@ def main():
             src = rng.integers(0, mp, len(pick))
             at = rng.choice(np.array([0, (rlen - 21 + 1) // 3, 2 * ((rlen - 21 + 1) // 3), rlen - 64]), len(pick))
             at = np.minimum(at, rlen - 64)
-            for q in range(64):
+            at2 = np.minimum(rng.choice(np.array([0, (rlen - 21 + 1) // 3, 2 * ((rlen - 21 + 1) // 3), rlen - 64]), len(pick)), rlen - 64)
+            for q in range(64):  # (subfilter wants a hit in BOTH mates, AQ.cpp:172-188: a stretch in each)
                 gseq[2 * pick * rlen + at + q] = ah_seq[2 * src * rlen + 40 + q]
+                gseq[(2 * pick + 1) * rlen + at2 + q] = ah_seq[(2 * src + 1) * rlen + 40 + q]
             d_g = torch.from_numpy(gseq).to(dev)
             d_go = torch.from_numpy(ah_off.view(np.int64)).to(dev)
             ctx.timers_enable(1)
@@ -424,7 +426,7 @@ def main():
             tg = kernel_table(ctx.kernel_times(), algorithmic_bytes(abi, cg), args.mix_steps, args.mix_steps)
             domg = max((k for k in tg if ":" not in k), key=lambda k: tg[k]["avg_ms"] * tg[k]["launches"])
             mixes["genome_like"] = dict(workload=f"{2 * mp} reads per step: the headline mix ({args.hit_frac:.0%} of pairs from loci) with 15 % of the background "
-                                                 f"pairs carrying a 64-base repeat shared with a locus over a sampled window, -k 21 -kf 4 1 -cth 45 -ka",
+                                                 f"pairs carrying, in each mate, a 64-base repeat shared with a locus over a sampled window, -k 21 -kf 4 1 -cth 45 -ka",
                                         value=2 * mp * args.mix_steps / dtg, unit="reads/s", ms_per_step=dtg / args.mix_steps * 1e3, steps=args.mix_steps,
                                         pairs_past_subfilter=cg[abi.C_SURVIVORS] / args.mix_steps / mp,
                                         roofline=dict(roofline_of(domg, tg), kernels=tg))

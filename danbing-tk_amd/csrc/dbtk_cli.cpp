@@ -52,7 +52,7 @@ namespace {
 struct Opts {
     bool bait = false, aug = false, threading = false, tc = false, aln = false, aln_minimal = false, okam = true, g2pan = false;
     bool writeKmerName = false, outputBubbles = false, invkmer = false, isFastq = false, trackBait = false, qc = false;
-    int simmode = 0, extractFastX = 0, verbosity = 0, ngpus = 1, gzLevel = 1, emitThreads = 0, ingestShards = 0;
+    int simmode = 0, extractFastX = 0, verbosity = 0, ngpus = 1, gzLevel = 1, emitThreads = 0, ingestShards = 0, alnAligners = 0;
     bool correction = true;
     bool parseOnly = false;  // --parse-only: run the ingest (reader, splitters, pairing) and report what it handed on; no GPU
     bool v13 = false;       // --v13-threading: -g/-gc/-gcc run the graph walk of the v1.3 contract instead of HEAD's dead path
@@ -94,6 +94,8 @@ void usage() {
             "  --ingest-shards <INT>  cut a seekable input file into this many byte ranges, each read, split and paired by its own\n"
             "                         pipeline with its own context (tables are shared per GPU) [the number of GPUs]\n"
             "  --emit-threads <INT>   host threads formatting / compressing records [cores / 2]\n"
+            "  --aln-aligners <INT>   with -a / -ae: aligner threads (each with its own context) per GPU, so that fetching and formatting one\n"
+            "                         batch's records overlaps the next batches' kernels [4]\n"
             "  --gz-level <INT>       zlib level of --aln-gz [1: measured 40x less deflate time than gzip's default 6 for 16 %% more bytes]\n"
             "Developer:\n"
             "  -s <1|2>  -e <1|2>  -v <INT>  -g|-gc|-gcc <INT> [INT]  -a  -ae  -tb  -ik  -t <INT>  -m <FILE>  -au\n\n");
@@ -181,6 +183,7 @@ struct Batch {  // one batch on its way through the stages; read r = flat[off[r]
         void grow(size_t n) { if (n > cap) { p.reset(new uint8_t[n]); cap = n; } }
     } aln;                      // -a / -ae: compact alignment records (dbtk_ctx_aln_records)
     uint64_t naln = 0; uint32_t aln_stride = 0, aln_cap = 0;
+    std::vector<std::string> aln_chunks;  // -a / -ae: the batch's alignment lines, formatted (and deflated) by the aligner thread's helpers
     long gpu_sec = 0;
     std::string title(uint64_t p) const { return std::string(tar.data() + toff[p], toff[p + 1] - toff[p]); }
     void add_read(const char* sp, size_t sn, const char* qp, size_t qn, bool fq) {
@@ -311,6 +314,7 @@ int main(int argc, char* argv[]) {
         else if (a == "--emit-threads") o.emitThreads = atoi(need(++argi).c_str());
         else if (a == "--ingest-shards") o.ingestShards = atoi(need(++argi).c_str());
         else if (a == "--gz-level") o.gzLevel = atoi(need(++argi).c_str());
+        else if (a == "--aln-aligners") o.alnAligners = atoi(need(++argi).c_str());
         else {
             fprintf(stderr, "invalid option: %s\n", a.c_str());
             abort();  // the reference does `throw;` with no active exception -> std::terminate
@@ -389,12 +393,17 @@ int main(int argc, char* argv[]) {
     // -a / -ae: writeAlignments (AQ.cpp:1742-1759), `src dst title seq2 seq1 cigar2 annot2 cigar1 annot1`, formatted (and,
     // with --aln-gz, deflated into independent gzip members) in chunks by a pool of host threads while the GPU threads
     // are already on the next batches; the chunks leave in record order.
-    auto emit_alignments = [&](const Batch& b) {
+    // Called by the batch's ALIGNER thread right after it has fetched the records (its sibling aligner threads keep the GPU busy
+    // meanwhile: --aln-aligners contexts per GPU); the ordered writer then only writes the finished chunks.
+    const int aln_aligners = emit_aln ? (o.alnAligners > 0 ? o.alnAligners : 4) : 1;
+    auto prepare_alignments = [&](Batch& b) {
         const uint64_t n = b.naln;
+        b.aln_chunks.clear();
         if (!n) return;
         const uint64_t CH = 512;  // records per chunk (= per gzip member): ~230 KB of text, several chunks per emit thread and batch
         const uint64_t nch = (n + CH - 1) / CH;
-        std::vector<std::string> chunk(nch);
+        std::vector<std::string>& chunk = b.aln_chunks;
+        chunk.resize(nch);
         std::atomic<uint64_t> nextc{0};
         auto work = [&] {
             char txt[8192];
@@ -414,7 +423,8 @@ int main(int argc, char* argv[]) {
                     t.append((const char*)b.flat.data() + b.off[2 * p + 1], b.off[2 * p + 2] - b.off[2 * p + 1]); t += '\t';
                     t.append((const char*)b.flat.data() + b.off[2 * p], b.off[2 * p + 1] - b.off[2 * p]); t += '\t';
                     const size_t l = dbtk_aln_format(rec, b.aln_cap, txt, sizeof txt);
-                    t.append(txt, std::min(l, sizeof txt - 1)); t += '\n';
+                    if (l >= sizeof txt) die_assert("an alignment record does not fit its text buffer");
+                    t.append(txt, l); t += '\n';
                 }
                 const double tf1 = now();
                 fmt_us += (uint64_t)((tf1 - tf0) * 1e6);
@@ -433,16 +443,23 @@ int main(int argc, char* argv[]) {
                 } else chunk[c] = t;
             }
         };
-        const int nt = (int)std::min<uint64_t>(nch, (uint64_t)emit_threads);
+        const int nt = (int)std::min<uint64_t>(nch, (uint64_t)std::max(1, emit_threads / aln_aligners));
         std::vector<std::thread> th;
         for (int i = 1; i < nt; ++i) th.emplace_back(work);
         work();
         for (auto& x : th) x.join();
-        { std::lock_guard<std::mutex> lk(out_m); for (auto& c : chunk) { fwrite(c.data(), 1, c.size(), gzout ? gzout : stdout); aln_bytes += c.size(); } }
+    };
+    auto write_alignments = [&](const Batch& b) {
+        std::lock_guard<std::mutex> lk(out_m);
+        FILE* f = gzout ? gzout : stdout;
+        for (auto& c : b.aln_chunks) {
+            if (fwrite(c.data(), 1, c.size(), f) != c.size()) die_assert(gzout ? "write to the --aln-gz file failed" : "write to stdout failed");
+            aln_bytes += c.size();
+        }
     };
     auto emit = [&](const Batch& b) {
         std::string out;
-        if (emit_aln) emit_alignments(b);
+        if (emit_aln) write_alignments(b);
         auto seq = [&](uint64_t r) { return std::string((const char*)b.flat.data() + b.off[r], b.off[r + 1] - b.off[r]); };
         auto qual = [&](uint64_t r) { return std::string(b.qar.data() + b.qoff[r], b.qoff[r + 1] - b.qoff[r]); };
         for (uint64_t i = 0; i < b.nrec; ++i) {
@@ -515,7 +532,7 @@ int main(int argc, char* argv[]) {
     auto recycle_batch = [&](BatchP b) {
         if (!b) return;
         b->flat.clear(); b->off.clear(); b->qar.clear(); b->qoff.clear(); b->tar.clear(); b->toff.clear(); b->src.clear();
-        b->index = 0; b->nreads = 0; b->nReads_so_far = 0; b->nparked = 0; b->nrec = 0; b->gpu_sec = 0; b->naln = 0;
+        b->index = 0; b->nreads = 0; b->nReads_so_far = 0; b->nparked = 0; b->nrec = 0; b->gpu_sec = 0; b->naln = 0; b->aln_chunks.clear();
         std::lock_guard<std::mutex> l(bpool_m);
         if (bpool.size() < 16) bpool.push_back(std::move(b));
     };
@@ -855,6 +872,7 @@ int main(int argc, char* argv[]) {
                     if (sa) die_assert(std::string("alignment records: ") + dbtk_last_error());
                     b->naln = n;
                     rec_us += (uint64_t)((now() - tr0) * 1e6);
+                    prepare_alignments(*b);
                 }
                 b->gpu_sec = (long)(time(nullptr) - t2);
                 { std::lock_guard<std::mutex> l(done_m); gpu_busy += now() - tg; }
@@ -938,11 +956,19 @@ int main(int argc, char* argv[]) {
             ctx.push_back(nullptr);
             if (dbtk_ctx_create(rpgg, &P, i % o.ngpus, &ctx[i])) die_assert(dbtk_last_error());
         }
+    // -a / -ae with one range: several aligner threads per GPU, each with a context of its own (they share the GPU's tables; their
+    // accumulators are summed on the host at the end): while one fetches its batch's records and has them formatted and
+    // deflated, the others keep the GPU busy — the emit then costs the batch loop next to nothing
+    if (!o.parseOnly && emit_aln && nshards == 1)
+        for (int i = (int)ctx.size(); i < aln_aligners * o.ngpus; ++i) {
+            ctx.push_back(nullptr);
+            if (dbtk_ctx_create(rpgg, &P, i % o.ngpus, &ctx[i])) die_assert(dbtk_last_error());
+        }
     std::vector<std::vector<Left>> lefts(nshards);
     {
         std::vector<std::thread> shards;
         auto one = [&](int i) {
-            const auto r = nshards == 1 ? run_shard(0, 0, o.ngpus, 0, ~0ull, lefts[0]) : run_shard(i, i, 1, cuts[i], cuts[i + 1], lefts[i]);
+            const auto r = nshards == 1 ? run_shard(0, 0, o.parseOnly ? o.ngpus : (int)ctx.size(), 0, ~0ull, lefts[0]) : run_shard(i, i, 1, cuts[i], cuts[i + 1], lefts[i]);
             std::lock_guard<std::mutex> lk(tot_m);
             nReads += std::get<0>(r); read_busy += std::get<1>(r); cut_busy += std::get<2>(r); pair_busy += std::get<3>(r);
             gpu_busy += std::get<4>(r); write_busy += std::get<5>(r); nsplit_used += std::get<6>(r);
@@ -990,12 +1016,14 @@ int main(int argc, char* argv[]) {
                 if (sa == DBTK_ERR_OVERFLOW) { b.aln.grow((size_t)n * b.aln_stride); sa = dbtk_ctx_aln_records(ctx[0], b.aln.data(), b.aln.size(), &n, &b.aln_stride, &b.aln_cap); }
                 if (sa) die_assert(std::string("alignment records: ") + dbtk_last_error());
                 b.naln = n;
+                prepare_alignments(b);
             }
             emit(b);
         } else if (b.nreads && o.parseOnly) digest_batch(b);
     }
     fflush(stdout);
-    if (gzout) fclose(gzout);
+    if (fflush(stdout) != 0) die_assert("write to stdout failed");
+    if (gzout && fclose(gzout) != 0) die_assert("closing the --aln-gz file failed");
     const int nsplit = nsplit_used;
     if (emit_aln) fprintf(stderr, "emit: record read-back %.2f s; formatting %.2f thread-s, deflate %.2f thread-s on up to %d threads; %llu bytes out\n",
                           rec_us.load() / 1e6, fmt_us.load() / 1e6, gz_us.load() / 1e6, emit_threads, (unsigned long long)aln_bytes);

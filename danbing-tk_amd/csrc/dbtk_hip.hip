@@ -671,7 +671,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         SurvSortArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.T = c->T; sa.P = c->P; sa.seq = d_seq; sa.off = d_off; sa.surv = c->d_surv; sa.nsurv = c->d_small + 0;
-        sa.sorted = c->d_surv + (npairs + 1); sa.key = sa.sorted + (npairs + 1); sa.hist = sa.key + (npairs + 1);
+        sa.sorted = c->d_surv + (npairs + 1); sa.key = sa.sorted + (npairs + 1); sa.hist = sa.key + (npairs + 1); sa.flag = c->d_small + 6;
         HIPCHK(hipMemsetAsync(sa.hist, 0, (nloci + 2) * sizeof(uint32_t), s));
         const uint32_t gs = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)c->num_cu * 8);
         if ((st = rec_beg(5))) return st;

@@ -421,7 +421,10 @@ struct SurvSortArgs {
     uint32_t* key;           // [nsurv]: locus of the pair's first sampled k-mer found in the index (nloci: none)
     uint32_t* hist;          // [nloci + 2 + SCAN_BLOCKS]: zero before body_surv_key; pairs per key, then (body_surv_scan) first place of each key
     uint32_t* sorted;        // [nsurv]: the list in key order
+    uint32_t* flag;          // 1: sorted by key; 0: too few survivors for the order to matter (fewer than SORT_MIN_PER_LOCUS per locus:
+                             // a WGS batch) — `sorted` is then a plain copy of the list and the key / histogram work is skipped
 };
+constexpr uint32_t SORT_MIN_PER_LOCUS = 4;
 // canonical k-mer of the k bytes at p; NAN64 if one of them is not A, C, G or T
 DBTK_HD uint64_t kmer_of_bytes(const uint8_t* p, uint32_t k) {
     uint64_t fw = 0, rc = 0;
@@ -438,6 +441,9 @@ DBTK_HD uint64_t kmer_of_bytes(const uint8_t* p, uint32_t k) {
 template <class X>
 DBTK_HD void body_surv_key(X& x, const SurvSortArgs& a) {
     const uint32_t n = *a.nsurv, k = a.T.ksize, nloci = a.T.nloci;
+    const bool on = n >= SORT_MIN_PER_LOCUS * nloci;
+    if (x.bid() == 0 && x.tid() == 0) *a.flag = on ? 1u : 0u;
+    if (!on) return;
     const uint32_t NF = (a.P.n_filter && a.P.nm_filter) ? a.P.n_filter : 4u;  // subfilter's sampled positions (AQ.cpp:172-188); four without it
     for (uint32_t t = x.bid() * (uint32_t)x.nthreads() + (uint32_t)x.tid(); t < n; t += x.nblocks() * (uint32_t)x.nthreads()) {
         const uint64_t r = 2 * (uint64_t)a.surv[t];
@@ -464,6 +470,7 @@ DBTK_HD void body_surv_key(X& x, const SurvSortArgs& a) {
 constexpr uint32_t SCAN_BLOCKS = 256;
 template <class X>
 DBTK_HD void body_surv_scan(X& x, const SurvSortArgs& a, int step) {
+    if (!*a.flag) return;
     const uint32_t n = a.T.nloci + 1, lane = (uint32_t)x.lane(), b = x.bid();
     const uint32_t per = ((n + SCAN_BLOCKS - 1) / SCAN_BLOCKS + 63) & ~63u;  // entries per block (whole waves)
     const uint32_t lo = b * per, hi = lo + per < n ? lo + per : n;
@@ -489,8 +496,9 @@ DBTK_HD void body_surv_scan(X& x, const SurvSortArgs& a, int step) {
 template <class X>
 DBTK_HD void body_surv_scatter(X& x, const SurvSortArgs& a) {
     const uint32_t n = *a.nsurv;
+    const bool on = *a.flag != 0;
     for (uint32_t t = x.bid() * (uint32_t)x.nthreads() + (uint32_t)x.tid(); t < n; t += x.nblocks() * (uint32_t)x.nthreads())
-        a.sorted[x.atomic_add(&a.hist[a.key[t]], 1u)] = a.surv[t];
+        a.sorted[on ? x.atomic_add(&a.hist[a.key[t]], 1u) : t] = a.surv[t];
 }
 
 }  // namespace dbtk
