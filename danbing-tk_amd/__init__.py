@@ -187,6 +187,27 @@ class Context:
             out.append((hdr, txt.value.decode()))
         return out
 
+    def aln_text(self, npairs):
+        """dbtk_ctx_aln_text of the last align() (params.aln | abi.ALN_TEXT): list of (pair, dst, "cigar2\\tannot2\\tcigar1\\tannot1")."""
+        L = self._lib.L
+        L.dbtk_ctx_aln_text.restype = C.c_int
+        L.dbtk_ctx_aln_text.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        idx = np.zeros(max(npairs, 1), np.uint32)
+        used = C.c_uint64(0)
+        rc = L.dbtk_ctx_aln_text(self.h, idx.ctypes.data_as(C.POINTER(C.c_uint32)), npairs, None, 0, C.byref(used))
+        if rc not in (abi.OK, abi.ERR_OVERFLOW):
+            self._lib._chk(rc)
+        arena = np.zeros(max(int(used.value), 4), np.uint8)
+        self._lib._chk(L.dbtk_ctx_aln_text(self.h, idx.ctypes.data_as(C.POINTER(C.c_uint32)), npairs, arena.ctypes.data_as(C.c_void_p), len(arena), C.byref(used)))
+        out = []
+        for p_ in range(npairs):
+            o = int(idx[p_])
+            if o == 0xFFFFFFFF:
+                continue
+            dst, ln = int(arena[o:o + 4].view(np.uint32)[0]), int(arena[o + 4:o + 8].view(np.uint32)[0])
+            out.append((p_, dst, arena[o + 8:o + 8 + ln].tobytes().decode()))
+        return out
+
     def align_device(self, d_seq_ptr, d_off_ptr, npairs, max_read_len):
         self._lib._chk(self._lib.L.dbtk_align_batch_device(self.h, C.c_void_p(d_seq_ptr), C.c_void_p(d_off_ptr), npairs,
                                                            max_read_len))
@@ -304,7 +325,7 @@ EXPORTS = [
     "dbtk_rpgg_load", "dbtk_rpgg_load_tr", "dbtk_rpgg_uid", "dbtk_rpgg_from_arrays", "dbtk_rpgg_free", "dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys",
     "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
-    "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
+    "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_aln_text", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
     "dbtk_thread_batch", "dbtk_ctx_walk_results", "dbtk_ctx_aln_records", "dbtk_aln_format",
 ]
 

@@ -5,6 +5,7 @@ MAX_READ_LEN = 256
 NAN64 = 0xFFFFFFFFFFFFFFFF
 NAN32 = 0xFFFFFFFF
 ABI_VERSION = 3
+ALN_TEXT = 4  # params.aln | ALN_TEXT: alignment records in text form (dbtk_ctx_aln_text)
 THREAD_CAP = 384
 THREADING_HEAD, THREADING_V13 = 1, 2
 

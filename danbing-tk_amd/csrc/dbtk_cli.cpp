@@ -181,8 +181,9 @@ struct Batch {  // one batch on its way through the stages; read r = flat[off[r]
         uint8_t* data() const { return p.get(); }
         size_t size() const { return cap; }
         void grow(size_t n) { if (n > cap) { p.reset(new uint8_t[n]); cap = n; } }
-    } aln;                      // -a / -ae: compact alignment records (dbtk_ctx_aln_records)
-    uint64_t naln = 0; uint32_t aln_stride = 0, aln_cap = 0;
+    } aln;                      // -a / -ae: the batch's alignment records in text form (dbtk_ctx_aln_text): the arena ...
+    std::vector<uint32_t> aln_idx;  // ... and where pair p's record starts in it (DBTK_NAN32: none)
+    uint64_t naln = 0;
     std::vector<std::string> aln_chunks;  // -a / -ae: the batch's alignment lines, formatted (and deflated) by the aligner thread's helpers
     long gpu_sec = 0;
     std::string title(uint64_t p) const { return std::string(tar.data() + toff[p], toff[p + 1] - toff[p]); }
@@ -357,7 +358,7 @@ int main(int argc, char* argv[]) {
     P.threading = walk ? DBTK_THREADING_V13 : (o.threading ? DBTK_THREADING_HEAD : 0);
     P.thread_cth = (uint32_t)o.thread_cth; P.maxncorrection = (uint32_t)o.maxncorrection;
     P.correction = o.correction;
-    P.aln = emit_aln ? (o.aln_minimal ? 2 : 1) : 0;
+    P.aln = emit_aln ? ((o.aln_minimal ? 2u : 1u) | DBTK_ALN_TEXT) : 0;  // CIGAR / annotation strings are written by the GPU: a few tens of bytes per pair come back
     P.trackbait = (o.trackBait && use_bait) ? 1 : 0;  // -tb only does something inside the bait filter (AQ.cpp:2111-2119)
     P.bait = use_bait;
     P.bubbles = o.outputBubbles && !o.extractFastX && !o.threading;  // countNovelEdges only runs on the assignment path
@@ -397,8 +398,11 @@ int main(int argc, char* argv[]) {
     // meanwhile: --aln-aligners contexts per GPU); the ordered writer then only writes the finished chunks.
     const int aln_aligners = emit_aln ? (o.alnAligners > 0 ? o.alnAligners : 4) : 1;
     auto prepare_alignments = [&](Batch& b) {
-        const uint64_t n = b.naln;
         b.aln_chunks.clear();
+        std::vector<uint32_t> em;  // the pairs with a record, in pair order (writeAlignments' order, AQ.cpp:1742-1759)
+        const uint64_t npairs_b = b.nreads / 2;
+        for (uint64_t p = 0; p < npairs_b; ++p) if (b.aln_idx[p] != DBTK_NAN32) em.push_back((uint32_t)p);
+        const uint64_t n = b.naln = em.size();
         if (!n) return;
         const uint64_t CH = 512;  // records per chunk (= per gzip member): ~230 KB of text, several chunks per emit thread and batch
         const uint64_t nch = (n + CH - 1) / CH;
@@ -406,25 +410,24 @@ int main(int argc, char* argv[]) {
         chunk.resize(nch);
         std::atomic<uint64_t> nextc{0};
         auto work = [&] {
-            char txt[8192];
             std::string t;
+            t.reserve(CH * 640);
             for (;;) {
                 const uint64_t c = nextc.fetch_add(1);
                 if (c >= nch) break;
                 t.clear();
                 const double tf0 = now();
                 for (uint64_t i = c * CH; i < std::min(n, (c + 1) * CH); ++i) {
-                    const uint8_t* rec = b.aln.data() + (size_t)i * b.aln_stride;
-                    const dbtk_aln_hdr_t* h = (const dbtk_aln_hdr_t*)rec;
-                    const uint64_t p = h->pair;
+                    const uint64_t p = em[i];
+                    const uint8_t* rec = b.aln.data() + b.aln_idx[p];
+                    uint32_t dst, len;
+                    memcpy(&dst, rec, 4); memcpy(&len, rec + 4, 4);
                     t += ".\t";  // srcLocus is -1 outside simulation mode
-                    t += std::to_string((int)h->dst); t += '\t';
+                    t += std::to_string((int)dst); t += '\t';
                     t.append(b.tar.data() + b.toff[p], b.toff[p + 1] - b.toff[p]); t += '\t';
                     t.append((const char*)b.flat.data() + b.off[2 * p + 1], b.off[2 * p + 2] - b.off[2 * p + 1]); t += '\t';
                     t.append((const char*)b.flat.data() + b.off[2 * p], b.off[2 * p + 1] - b.off[2 * p]); t += '\t';
-                    const size_t l = dbtk_aln_format(rec, b.aln_cap, txt, sizeof txt);
-                    if (l >= sizeof txt) die_assert("an alignment record does not fit its text buffer");
-                    t.append(txt, l); t += '\n';
+                    t.append((const char*)rec + 8, len); t += '\n';
                 }
                 const double tf1 = now();
                 fmt_us += (uint64_t)((tf1 - tf0) * 1e6);
@@ -861,16 +864,16 @@ int main(int argc, char* argv[]) {
                                                           want_recs ? b->recs.data() : nullptr, want_recs ? npairs : 0, &b->nrec);
                 if (st) die_assert(std::string("align: ") + dbtk_last_error());
                 if (emit_aln) {
-                    uint64_t n = 0;
+                    uint64_t used = 0;
                     const double tr0 = now();
+                    b->aln_idx.resize(npairs);
                     // (a recycled batch keeps its buffer: usually large enough, and its pages are mapped)
-                    dbtk_status_t sa = dbtk_ctx_aln_records(ctx[d], b->aln.data(), b->aln.size(), &n, &b->aln_stride, &b->aln_cap);
-                    if (sa == DBTK_ERR_OVERFLOW) {  // (nothing was copied: n = the records the buffer must hold)
-                        b->aln.grow((size_t)n * b->aln_stride);
-                        sa = dbtk_ctx_aln_records(ctx[d], b->aln.data(), b->aln.size(), &n, &b->aln_stride, &b->aln_cap);
+                    dbtk_status_t sa = dbtk_ctx_aln_text(ctx[d], b->aln_idx.data(), npairs, b->aln.data(), b->aln.size(), &used);
+                    if (sa == DBTK_ERR_OVERFLOW && used > b->aln.size()) {  // (nothing was copied: `used` = the bytes the buffer must hold)
+                        b->aln.grow((size_t)used + used / 4);
+                        sa = dbtk_ctx_aln_text(ctx[d], b->aln_idx.data(), npairs, b->aln.data(), b->aln.size(), &used);
                     }
                     if (sa) die_assert(std::string("alignment records: ") + dbtk_last_error());
-                    b->naln = n;
                     rec_us += (uint64_t)((now() - tr0) * 1e6);
                     prepare_alignments(*b);
                 }
@@ -1011,11 +1014,11 @@ int main(int argc, char* argv[]) {
             if (dbtk_align_batch(ctx[0], b.flat.data(), b.off.data(), send_qual ? flatq.data() : nullptr, npairs, want_recs ? b.recs.data() : nullptr,
                                  want_recs ? npairs : 0, &b.nrec)) die_assert(std::string("align: ") + dbtk_last_error());
             if (emit_aln) {
-                uint64_t n = 0;
-                dbtk_status_t sa = dbtk_ctx_aln_records(ctx[0], nullptr, 0, &n, &b.aln_stride, &b.aln_cap);
-                if (sa == DBTK_ERR_OVERFLOW) { b.aln.grow((size_t)n * b.aln_stride); sa = dbtk_ctx_aln_records(ctx[0], b.aln.data(), b.aln.size(), &n, &b.aln_stride, &b.aln_cap); }
+                uint64_t used = 0;
+                b.aln_idx.resize(npairs);
+                dbtk_status_t sa = dbtk_ctx_aln_text(ctx[0], b.aln_idx.data(), npairs, nullptr, 0, &used);
+                if (sa == DBTK_ERR_OVERFLOW) { b.aln.grow((size_t)used + 16); sa = dbtk_ctx_aln_text(ctx[0], b.aln_idx.data(), npairs, b.aln.data(), b.aln.size(), &used); }
                 if (sa) die_assert(std::string("alignment records: ") + dbtk_last_error());
-                b.naln = n;
                 prepare_alignments(b);
             }
             emit(b);

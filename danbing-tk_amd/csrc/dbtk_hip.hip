@@ -207,6 +207,9 @@ struct dbtk_ctx {
     dbtk_thread_rec_t* d_trecs = nullptr; uint64_t trecs_cap = 0;  // thread records (function mode; pair mode with trace / -a)
     uint32_t* d_loci = nullptr; uint64_t loci_cap = 0;       // function mode: locus per read
     uint8_t* d_aln = nullptr; uint64_t aln_bytes = 0;        // -a / -ae: compact alignment records of the last host-buffer batch
+    uint8_t* d_txt = nullptr; uint64_t txt_bytes = 0;        // -a / -ae | DBTK_ALN_TEXT: the text arena of the last host-buffer batch
+    uint32_t* d_txtidx = nullptr; uint64_t txtidx_cap = 0;   //   ... and its per-pair index
+    uint64_t txt_cap = 0;                                    //   bytes of the arena the last batch could use
     uint32_t aln_stride = 0, aln_cap = 0; uint64_t aln_max = 0;
     uint8_t* h_aln = nullptr; size_t h_aln_bytes = 0;  // pinned staging of dbtk_ctx_aln_records
     uint64_t last_walk_npairs = 0; bool last_walk_recs = false;  // what dbtk_ctx_walk_results may fetch
@@ -293,7 +296,7 @@ void free_ctx(dbtk_ctx* c) {
         }
     void* ptrs[] = {c->d_ctr, c->d_accum, c->d_small, c->d_surv,
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
-                    c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_walk, c->d_trecs, c->d_loci, c->d_aln};
+                    c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_walk, c->d_trecs, c->d_loci, c->d_aln, c->d_txt, c->d_txtidx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->h_aln) (void)hipHostFree(c->h_aln);
     std::vector<dbtk_ctx::Lane*> others{&c->alt};
@@ -599,7 +602,7 @@ constexpr uint32_t SMALL_WORDS = 64;  // d_small: nsurv, (unused), nrec, errflag
 
 dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_off, uint64_t seq_len, uint64_t npairs,
                            uint32_t max_read_len, dbtk_pair_rec_t* d_recs, uint32_t rec_cap, const uint8_t* d_qual = nullptr,
-                           dbtk_thread_rec_t* walk_trecs = nullptr, bool walk_aln = false) {
+                           dbtk_thread_rec_t* walk_trecs = nullptr, bool walk_aln = false, bool walk_txt = false) {
     hipStream_t s = c->stream;
     if (npairs >= 0xFFFFFFFFull) { set_error("batch too large (pair index is 32-bit)"); return DBTK_ERR_ARG; }
     if (npairs == 0) return DBTK_OK;
@@ -636,7 +639,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     if (c->P.bait && d_qual && (st = ensure(&c->d_qmask, &c->qmask_cap, tcap * 2 * 4))) return st;
     BatchArgs a;
     memset(&a, 0, sizeof(a));
-    a.T = c->T; a.P = c->P;
+    a.T = c->T; a.P = c->P; a.P.aln &= 3u;
     a.seq = d_seq; a.off = d_off; a.seq_len = seq_len; a.npairs = npairs;
     a.surv = c->d_surv; a.nsurv = c->d_small + 0; a.nrec = c->d_small + 2; a.errflag = c->d_small + 3;
     a.counts = c->d_accum;
@@ -737,7 +740,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     if (walking) {  // the graph walk over every pair that reached threading, both mates (AQ.cpp:2072-2088), exact counting (:2189-2194)
         WalkArgs w;
         memset(&w, 0, sizeof(w));
-        w.T = c->T; w.P = c->P; w.seq = d_seq; w.off = d_off;
+        w.T = c->T; w.P = c->P; w.P.aln &= 3u; w.seq = d_seq; w.off = d_off;
         w.surv = c->d_sorted; w.nsurv = c->d_small + 0;
         w.walk_dst = c->d_walk; w.walk_ret = c->d_walk + npairs;
         w.counts = a.counts; w.counters = a.counters; w.ctr_rep = c->d_ctr;
@@ -745,6 +748,22 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
 #ifdef DBTK_STAMPS
         w.dbg = reinterpret_cast<uint64_t*>(c->d_small + 32);
 #endif
+        if (walk_txt) {  // text records: an arena sized for the worst case (two characters per entry, four strings), carved by the waves
+            const uint32_t acap = std::min<uint32_t>(DBTK_THREAD_CAP, (max_read_len + max_read_len / 4 + 8 + 7) & ~7u);
+            c->aln_cap = acap;
+            const uint64_t want = std::min<uint64_t>(npairs * (uint64_t)(8 + 8 * acap + 8) + (uint64_t)TXT_CHUNK * (c->walk_blocks + 1), 0xFFFF0000ull);
+            if (want > c->txt_bytes) {
+                if (c->d_txt) HIPCHK(hipFree(c->d_txt));
+                c->d_txt = nullptr; c->txt_bytes = 0;
+                HIPCHK(hipMalloc(&c->d_txt, want));
+                c->txt_bytes = want;
+            }
+            if ((st = ensure(&c->d_txtidx, &c->txtidx_cap, npairs))) return st;
+            HIPCHK(hipMemsetAsync(c->d_txtidx, 0xFF, npairs * sizeof(uint32_t), s));
+            HIPCHK(hipMemsetAsync(c->d_small + 7, 0, 4, s));
+            c->txt_cap = want;
+            w.txt = c->d_txt; w.txt_idx = c->d_txtidx; w.ntxt = c->d_small + 7; w.txt_cap = (uint32_t)want; w.aln_cap = acap;
+        }
         if (walk_aln) {
             // a record holds, per mate, cg.es and cg.tr: the read's bases plus what deletions can add (dbtk.h: DBTK_THREAD_CAP)
             const uint32_t acap = std::min<uint32_t>(DBTK_THREAD_CAP, (max_read_len + max_read_len / 4 + 8 + 7) & ~7u);
@@ -764,7 +783,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         // Two kernels when nothing needs the alignment of every mate (no -a / -ae records, no thread records): the lean one
         // decides and counts the pairs one of whose mates threads cleanly, the one with the error-correction machinery takes the
         // rest from its list.  (The walk's kernels are timed together: "k_walk_pairs".)
-        const int wnpl = (walk_aln || walk_trecs || k + 4 > 32) ? 0 : (max_read_len <= 32 * 3 + k - 1 && k + 2 <= 32 ? 3 : max_read_len <= 32 * 5 + k - 1 ? 5 : 0);
+        const int wnpl = (walk_aln || walk_txt || walk_trecs || k + 4 > 32) ? 0 : (max_read_len <= 32 * 3 + k - 1 && k + 2 <= 32 ? 3 : max_read_len <= 32 * 5 + k - 1 ? 5 : 0);
         if (tm) { if ((st = timed_slot(c, 4, &e))) return st; HIPCHK(hipEventRecord(c->timed[4].beg[e], s)); }
         if (wnpl && !getenv("DBTK_WALK_ONE_KERNEL")) {
             w.slow_list = c->d_walk + 2 * npairs; w.nslow = c->d_small + 5;
@@ -794,6 +813,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
     if (p->trackbait && !p->bait) { set_error("params.trackbait needs params.bait"); return DBTK_ERR_ARG; }
     if (p->bubbles && (h->tre_cnt.empty() || p->extract)) { set_error("params.bubbles needs PREF.tre.kdb (and is not an extract-mode flag)"); return DBTK_ERR_ARG; }
     if (p->qc && h->qc.empty()) { set_error("params.qc set but the RPGG handle has no QC mask"); return DBTK_ERR_ARG; }
+    if ((p->aln & 3u) == 3u || (p->aln & ~7u)) { set_error("params.aln: 0, 1 (-a) or 2 (-ae), optionally | DBTK_ALN_TEXT"); return DBTK_ERR_ARG; }
     if (p->threading > DBTK_THREADING_V13) { set_error("params.threading: 0, 1 (HEAD) or 2 (v1.3)"); return DBTK_ERR_ARG; }
     if (p->threading == DBTK_THREADING_V13 && h->gr_cnt.empty()) { set_error("params.threading = 2 needs the graph in the RPGG handle (DBTK_LOAD_GRAPH)"); return DBTK_ERR_ARG; }
     if (p->threading == DBTK_THREADING_V13 && p->extract) { set_error("threading = 2 with -e is not supported"); return DBTK_ERR_UNSUPPORTED; }
@@ -1006,10 +1026,12 @@ static dbtk_status_t dbtk_align_batch_impl(dbtk_ctx_t* c, const uint8_t* seq, co
     if (walk_recs && (st = ensure(&c->d_trecs, &c->trecs_cap, 2 * npairs))) return st;
     c->last_walk_npairs = c->P.threading == DBTK_THREADING_V13 ? npairs : 0;
     c->last_walk_recs = walk_recs;
-    const bool walk_aln = c->P.threading == DBTK_THREADING_V13 && c->P.aln;
+    const bool walk_txt = c->P.threading == DBTK_THREADING_V13 && (c->P.aln & 3u) && (c->P.aln & DBTK_ALN_TEXT);
+    const bool walk_aln = c->P.threading == DBTK_THREADING_V13 && (c->P.aln & 3u) && !walk_txt;
     if (!walk_aln) c->aln_max = 0;
+    if (!walk_txt) c->txt_cap = 0;
     if ((st = launch_batch(c, c->d_seq, c->d_off, nbytes, npairs, maxlen, want_recs ? c->d_recs : nullptr, (uint32_t)dcap,
-                           use_qual ? c->d_qual : nullptr, walk_recs ? c->d_trecs : nullptr, walk_aln))) return st;
+                           use_qual ? c->d_qual : nullptr, walk_recs ? c->d_trecs : nullptr, walk_aln, walk_txt))) return st;
     uint32_t small[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(small, c->d_small, sizeof(small), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1211,6 +1233,25 @@ static dbtk_status_t dbtk_ctx_aln_records_impl(dbtk_ctx_t* c, void* buf, uint64_
         for (unsigned t = 0; t < nt; ++t) th.emplace_back(gather, n * t / nt, n * (t + 1) / nt);
         for (auto& x : th) x.join();
     }
+    return DBTK_OK;
+}
+
+// -a / -ae in text form: the per-pair index and the arena of the last host-buffer batch.
+static dbtk_status_t dbtk_ctx_aln_text_impl(dbtk_ctx_t* c, uint32_t* idx, uint64_t idx_cap, void* arena, uint64_t arena_cap, uint64_t* used) {
+    if (!c || !used) { set_error("null argument"); return DBTK_ERR_ARG; }
+    *used = 0;
+    if (!c->txt_cap || !c->d_txt) { for (uint64_t i = 0; idx && i < idx_cap; ++i) idx[i] = NAN32; return DBTK_OK; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint32_t cur = 0;
+    HIPCHK(hipMemcpy(&cur, c->d_small + 7, 4, hipMemcpyDeviceToHost));
+    if (cur > c->txt_cap) { set_error("alignment text arena overflow"); return DBTK_ERR_OVERFLOW; }
+    *used = cur;
+    if (cur > arena_cap || (!arena && cur)) { set_error("alignment text buffer too small"); return DBTK_ERR_OVERFLOW; }
+    const uint64_t np = std::min<uint64_t>(idx_cap, c->last_walk_npairs);
+    if (idx && np) HIPCHK(hipMemcpy(idx, c->d_txtidx, np * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint64_t i = np; idx && i < idx_cap; ++i) idx[i] = NAN32;
+    if (cur) HIPCHK(hipMemcpy(arena, c->d_txt, cur, hipMemcpyDeviceToHost));
     return DBTK_OK;
 }
 
@@ -1458,6 +1499,9 @@ dbtk_status_t dbtk_ctx_walk_results(dbtk_ctx_t* c, dbtk_walk_res_t* res, dbtk_th
 }
 dbtk_status_t dbtk_ctx_aln_records(dbtk_ctx_t* c, void* buf, uint64_t buf_bytes, uint64_t* nrec, uint32_t* stride, uint32_t* cap) {
     return dbtk::guarded([&] { return dbtk_ctx_aln_records_impl(c, buf, buf_bytes, nrec, stride, cap); });
+}
+dbtk_status_t dbtk_ctx_aln_text(dbtk_ctx_t* c, uint32_t* idx, uint64_t idx_cap, void* arena, uint64_t arena_cap, uint64_t* arena_used) {
+    return dbtk::guarded([&] { return dbtk_ctx_aln_text_impl(c, idx, idx_cap, arena, arena_cap, arena_used); });
 }
 dbtk_status_t dbtk_ctx_write_bubbles(dbtk_ctx_t* c, const char* out_prefix) {
     return dbtk::guarded([&] { return dbtk_ctx_write_bubbles_impl(c, out_prefix); });

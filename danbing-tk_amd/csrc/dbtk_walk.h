@@ -114,6 +114,14 @@ struct WalkArgs {
     uint8_t* aln;              // nullptr: none
     uint32_t aln_stride, aln_cap, aln_max;  // bytes per record, entries per packed array, records the buffer holds
     uint32_t* naln;            // slots handed out (in chunks of ALN_CHUNK per wave)
+    // -a / -ae in TEXT form (params.aln & DBTK_ALN_TEXT): writeCigar / writeAnnot run on the device; a record = {u32 dst, u16 len, u16 0}
+    // + "cigar2 \t annot2 \t cigar1 \t annot1" (len bytes, padded to 4), packed into an arena the waves carve TXT_CHUNK bytes at a
+    // time; txt_idx[pair] = the record's byte offset (NAN32: the pair has none).  A few tens of bytes per pair instead of the
+    // fixed-size arrays above: what the command line fetches.
+    uint8_t* txt;              // nullptr: none
+    uint32_t* txt_idx;         // [pairs of the batch], all NAN32 at launch
+    uint32_t* ntxt;            // arena cursor (bytes handed out)
+    uint32_t txt_cap;          // arena bytes
     uint64_t* dbg;             // diagnostic build only (-DDBTK_STAMPS): per-phase cycle sums
     // pair mode in two kernels (body_walk_fast, then body_walk_pairs on what it passed on): survivors t the fast kernel could
     // not decide.  body_walk_fast appends to it; body_walk_pairs takes its items from it (nullptr: every survivor).
@@ -136,6 +144,8 @@ constexpr int8_t WALK_NOT_EVALUATED = -2;  // walk_ret of a mate whose walk noth
 #define W_STAMP_FLUSH do { } while (0)
 #endif
 constexpr uint32_t ALN_CHUNK = 16;
+constexpr uint32_t TXT_CHUNK = 16384;  // arena bytes a wave takes at a time (one atomic per ~200 records)
+constexpr int WTXT = 2 * (WCAP + 8);    // the longest text of one CIGAR / annotation: two characters per entry
 DBTK_HD uint8_t aln_pack(uint8_t t, uint8_t g) {  // edit_t (t, g) in one byte: dbtk.h DBTK_ALN_*
     const uint32_t tc = t == '*' ? 0u : t == '=' ? 1u : t == 'X' ? 2u : t == 'D' ? 3u : t == 'I' ? 4u : 7u;
     const uint32_t gc = g == 0 ? 0u : g == 'A' ? 1u : g == 'C' ? 2u : g == 'G' ? 3u : g == 'T' ? 4u : 5u;
@@ -155,6 +165,8 @@ struct WalkSmem {
     uint8_t bases[48];        // edit_kmers_*: bases to roll in / leading bases
     uint8_t cube[24];         // errorCorrection_forward: m1[4], m2[16]
     uint8_t scr[128];         // edit_kmers_backward: the read / graph bases of an edit tract
+    uint8_t txc[WTXT], txa[WTXT];  // text form of the alignment: this mate's CIGAR and annotation
+    uint32_t txl[2];               // their lengths
     int32_t st[8];            // lane-0 regions hand their scalars back through here
     uint64_t st64[2];
 #ifdef DBTK_STAMPS
@@ -1055,6 +1067,74 @@ DBTK_HD void body_walk_reads(X& x, const WalkArgs& a) {
     }
 }
 
+// writeCigar (src/aQueryFasta_thread.cpp:1683-1722) on cg.es as the walk left it (types t[], graph bases g[]): one lane, the
+// same scan as dbtk_aln_format's (dbtk_rpgg.cpp) on the packed record.  Returns the text's length (<= 2 sz).
+DBTK_HD uint32_t w_fmt_int(uint8_t* out, uint32_t n, int v) {
+    if (v >= 100) out[n++] = (uint8_t)('0' + v / 100);
+    if (v >= 10) out[n++] = (uint8_t)('0' + (v / 10) % 10);
+    out[n++] = (uint8_t)('0' + v % 10);
+    return n;
+}
+DBTK_HD uint32_t w_fmt_cigar(const uint8_t* t, const uint8_t* g, int sz, uint8_t* out) {
+    uint32_t n = 0;
+    if (!sz) { out[n++] = '*'; return n; }
+    auto T = [&](int i) -> uint8_t { const uint8_t c = t[i]; return (c == '*' || c == '=' || c == 'X' || c == 'D' || c == 'I') ? c : (uint8_t)'?'; };
+    auto G = [&](int i) -> uint8_t { const uint8_t c = g[i]; return c == 0 ? (uint8_t)0 : (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : (uint8_t)'*'; };
+    int ct = 1;
+    uint8_t t0 = T(0), g0 = G(0), t1 = 0, g1 = 0;
+    for (int i = 1; i < sz; ++i) {
+        t1 = T(i); g1 = G(i);
+        if (t0 == '=' || t0 == '*') {
+            while (t1 == t0) {
+                ++ct; ++i;
+                if (i == sz) break;
+                t1 = T(i); g1 = G(i);
+            }
+            n = w_fmt_int(out, n, ct); out[n++] = t0;
+        } else if (t0 == 'X') { out[n++] = 'X'; out[n++] = g0; }
+        else if (t0 == 'D') {
+            if (t1 == 'I') { out[n++] = 'X'; out[n++] = g0; ++i; }  // ins + del printed as a mismatch
+            else { out[n++] = 'D'; out[n++] = g0; }
+        } else if (t0 == 'I') {
+            if (t1 == 'D') { out[n++] = 'X'; out[n++] = g1; ++i; }
+            else out[n++] = 'I';
+        } else out[n++] = t0;
+        if (i == sz) return n;
+        ct = 1;
+        t0 = T(i); g0 = G(i);
+    }
+    n = w_fmt_int(out, n, ct); out[n++] = t0;
+    return n;
+}
+// writeAnnot (AQ.cpp:1724-1740) on cg.tr
+DBTK_HD uint32_t w_fmt_annot(const uint8_t* tr, int sz, uint8_t* out) {
+    uint32_t n = 0;
+    if (!sz) { out[n++] = '*'; return n; }
+    int ct = 1;
+    uint8_t c0 = tr[0];
+    for (int i = 1; i < sz; ++i) {
+        if (c0 == '=' || c0 == '.' || c0 == '*') {
+            while (tr[i] == c0) { ++ct; ++i; if (i == sz) break; }
+            n = w_fmt_int(out, n, ct); out[n++] = c0;
+        } else out[n++] = c0;
+        if (i == sz) return n;
+        ct = 1;
+        c0 = tr[i];
+    }
+    n = w_fmt_int(out, n, ct); out[n++] = c0;
+    return n;
+}
+// this mate's two strings into its LDS text buffers: lane 0 the CIGAR, lane 1 the annotation
+template <class X>
+DBTK_HD_NOINLINE void walk_format_text(X& x, WalkSmem& sm, const WalkState& S, uint32_t cap) {
+    const int lane = x.lane();
+    x.sync();
+    const int nes = S.nes < (int)cap ? S.nes : (int)cap, ntr = S.ntr < (int)cap ? S.ntr : (int)cap;  // (as dbtk_aln_format clamps)
+    if (lane == 0) sm.txl[0] = w_fmt_cigar(sm.es_t, sm.es_g, nes, sm.txc);
+    if (lane == 1) sm.txl[1] = w_fmt_annot(sm.tr, ntr, sm.txa);
+    x.sync();
+}
+
 // Pair mode, the v1.3 call-site glue (AQ.cpp:2072-2088, 2090-2092, 2189-2194): both mates of an assigned pair are
 // walked through graphDB[destLocus]; if either walk is feasible the pair is kept (nFeasibleReads += 2) and every
 // uncorrected k-mer of both mates that is a TR k-mer of the locus is counted ("exact" mode: the canonical multiset of
@@ -1072,6 +1152,7 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
     const uint32_t S_ = x.nblocks();
     uint64_t c_feas = 0, c_inc = 0;
     uint32_t slot_base = 0, slot_used = ALN_CHUNK;  // alignment records: slots are taken ALN_CHUNK at a time (one atomic per chunk)
+    uint32_t txt_base = 0, txt_left = 0;             // text records: arena bytes are taken TXT_CHUNK at a time
     // A pair's data hangs on a chain of dependent loads: survivor -> (destLocus, pair index) -> the reads' offsets -> their bytes
     // -> their k-mers' graph look-ups.  What bounds this kernel is round trips per wave, so the chain is software-pipelined
     // over the wave's items (t, t + S, ...): while item i is walked, the bytes of item i + 1, the offsets of item i + 2 and
@@ -1148,6 +1229,7 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
                 if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) { ret[m] = 0; if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_FORMAT; }
                 if (a.trecs) walk_store(x, smm[m], S, ret[m], &a.trecs[2 * (size_t)t + m]);
                 if (arec) walk_store_aln(x, smm[m], S, ret[m], arec, a.aln_cap, m);
+                if (a.txt) walk_format_text(x, smm[m], S, a.aln_cap);
                 W_STAMP(4 + m);  // the walk of mate m
             }
             const bool alned = ret[0] || ret[1];
@@ -1156,6 +1238,37 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
                 h->pair = (a.P.aln == 2 && !alned) ? NAN32 : pair;
                 h->dst = alned ? dst : a.T.nloci;
                 h->pad[0] = h->pad[1] = 0;
+            }
+            if (a.txt && (a.P.aln & 3) != 0 && ((a.P.aln & 3) == 1 || alned)) {  // -a: every walked pair; -ae: only the kept ones
+                // "cigar2 \t annot2 \t cigar1 \t annot1" (writeAlignments' order, AQ.cpp:1751-1757) behind an 8-byte header
+                const uint32_t lc1 = smm[0].txl[0], la1 = smm[0].txl[1], lc2 = smm[1].txl[0], la2 = smm[1].txl[1];
+                const uint32_t len = lc2 + 1 + la2 + 1 + lc1 + 1 + la1, need = (8 + len + 3) & ~3u;
+                if (need > txt_left) {  // (what is left of the old chunk stays unused)
+                    uint32_t b = 0;
+                    if (lane == 0) b = x.atomic_add(a.ntxt, TXT_CHUNK);
+                    txt_base = x.bcast(b, 0);
+                    txt_left = TXT_CHUNK;
+                }
+                if ((uint64_t)txt_base + need <= a.txt_cap) {
+                    uint8_t* r = a.txt + txt_base;
+                    if (lane == 0) {
+                        reinterpret_cast<uint32_t*>(r)[0] = alned ? dst : a.T.nloci;
+                        reinterpret_cast<uint32_t*>(r)[1] = len;
+                        a.txt_idx[pair] = txt_base;
+                    }
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                        uint8_t c;
+                        if (i < lc2) c = smm[1].txc[i];
+                        else if (i == lc2) c = '\t';
+                        else if (i < lc2 + 1 + la2) c = smm[1].txa[i - lc2 - 1];
+                        else if (i == lc2 + 1 + la2) c = '\t';
+                        else if (i < lc2 + la2 + 2 + lc1) c = smm[0].txc[i - lc2 - la2 - 2];
+                        else if (i == lc2 + la2 + 2 + lc1) c = '\t';
+                        else c = smm[0].txa[i - lc2 - la2 - lc1 - 3];
+                        r[8 + i] = c;
+                    }
+                } else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
+                txt_base += need; txt_left -= need;
             }
             x.sync();
             if (alned) {

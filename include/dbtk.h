@@ -77,7 +77,8 @@ typedef struct dbtk_params {
     uint32_t thread_cth;   /* -g/-gc/-gcc N [100]  minimal number of walked k-mers per read (AQ.cpp:2338, 1122) */
     uint32_t maxncorrection; /* -gc/-gcc N M [4]   corrections allowed per read (AQ.cpp:33) */
     uint32_t correction;   /* -gc/-gcc: error correction on (plain -g walks without it) */
-    uint32_t aln;          /* 0; 1 = -a: an alignment record for every walked pair; 2 = -ae: only for kept pairs (AQ.cpp:2232-2248) */
+    uint32_t aln;          /* 0; 1 = -a: an alignment record for every walked pair; 2 = -ae: only for kept pairs (AQ.cpp:2232-2248);
+                              | DBTK_ALN_TEXT: the records in text form (dbtk_ctx_aln_text) instead of the arrays of dbtk_ctx_aln_records */
     uint32_t trackbait;    /* -tb: per locus, count the bait k-mer that made bfilter_FPSv1 flag a mate (AQ.cpp:1391,1414);
                               with -b, host-buffer batches only; such pairs then also yield records (stage DBTK_STAGE_BAIT) */
     uint32_t diag;         /* 0.  Diagnostic knobs of the profiling tools (tools/k1_limits.py): results are wrong when set */
@@ -278,6 +279,13 @@ typedef struct dbtk_aln_hdr {
 dbtk_status_t dbtk_ctx_aln_records(dbtk_ctx_t* ctx, void* buf, uint64_t buf_bytes, uint64_t* nrec, uint32_t* stride, uint32_t* cap);
 /* Returns the length of the text (without the terminating NUL it also writes when it fits). */
 size_t dbtk_aln_format(const void* rec, uint32_t cap, char* out, size_t out_cap);
+/* params.aln | DBTK_ALN_TEXT: writeCigar / writeAnnot (AQ.cpp:1683-1740) run on the device, and what comes back is the text itself —
+ * a few tens of bytes per pair instead of a fixed-size record.  idx[p] (p < idx_cap, the batch's pairs) = byte offset of pair p's
+ * record in `arena`, or DBTK_NAN32 when it has none (never walked; -ae: not kept).  A record = {uint32 dst (nloci: removed by
+ * threading), uint32 len} followed by len bytes "cigar2 \t annot2 \t cigar1 \t annot1" (not NUL-terminated), 4-byte aligned.
+ * *arena_used = bytes of the arena in use; DBTK_ERR_OVERFLOW (nothing copied) when arena_cap is smaller. */
+#define DBTK_ALN_TEXT 4u
+dbtk_status_t dbtk_ctx_aln_text(dbtk_ctx_t* ctx, uint32_t* idx, uint64_t idx_cap, void* arena, uint64_t arena_cap, uint64_t* arena_used);
 
 /* Device-resident variant used when the reads already sit in HBM (bench, or a
  * caller that overlaps its own H2D copies): d_seq / d_offsets are device

@@ -456,6 +456,22 @@ class Emu(pkg._HostSide):
         self.L.emu_probe_stats(out.ctypes.data_as(u64p))
         return int(out[0]), int(out[1]), int(out[2])
 
+    def aln_text(self, npairs):
+        """as Context.aln_text: list of (pair, dst, text)"""
+        self.L.emu_aln_text.restype = C.c_uint64
+        self.L.emu_aln_text.argtypes = [u32p, C.c_uint64, u8p, C.c_uint64]
+        idx = np.zeros(max(npairs, 1), np.uint32)
+        used = int(self.L.emu_aln_text(_p(idx, u32p), npairs, None, 0))
+        arena = np.zeros(max(used, 4), np.uint8)
+        self.L.emu_aln_text(_p(idx, u32p), npairs, _p(arena, u8p), len(arena))
+        out = []
+        for p_ in range(npairs):
+            o = int(idx[p_])
+            if o != 0xFFFFFFFF:
+                dst, ln = int(arena[o:o + 4].view(np.uint32)[0]), int(arena[o + 4:o + 8].view(np.uint32)[0])
+                out.append((p_, dst, arena[o + 8:o + 8 + ln].tobytes().decode()))
+        return out
+
     def walk_results(self, cap):
         res = (abi.WalkRes * max(cap, 1))()
         n = self.L.emu_walk_results(res, None, cap)

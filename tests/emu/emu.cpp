@@ -603,11 +603,19 @@ static std::vector<uint32_t> g_walk_t;
 static dbtk_thread_rec_t* g_walk_trecs = nullptr;  // 2 per survivor index
 void emu_set_walk_trecs(dbtk_thread_rec_t* buf) { g_walk_trecs = buf; }
 static std::vector<uint8_t> g_aln;  // compact alignment records of the last emu_align_ex (-a / -ae)
+static std::vector<uint8_t> g_txt;       // text records of the last emu_align_ex (params.aln | DBTK_ALN_TEXT): the arena in use
+static std::vector<uint32_t> g_txt_idx;  //   ... and its per-pair index
 static uint32_t g_aln_stride = 0, g_aln_cap = 0;
 uint64_t emu_aln_records(uint8_t* buf, uint64_t bytes, uint32_t* stride, uint32_t* cap) {
     *stride = g_aln_stride; *cap = g_aln_cap;
     if (buf && bytes >= g_aln.size() && !g_aln.empty()) memcpy(buf, g_aln.data(), g_aln.size());
     return g_aln_stride ? g_aln.size() / g_aln_stride : 0;
+}
+// as dbtk_ctx_aln_text
+uint64_t emu_aln_text(uint32_t* idx, uint64_t idx_cap, uint8_t* arena, uint64_t arena_cap) {
+    for (uint64_t i = 0; idx && i < idx_cap; ++i) idx[i] = i < g_txt_idx.size() ? g_txt_idx[i] : NAN32;
+    if (arena && arena_cap >= g_txt.size() && !g_txt.empty()) memcpy(arena, g_txt.data(), g_txt.size());
+    return g_txt.size();
 }
 uint64_t emu_walk_results(dbtk_walk_res_t* res, uint32_t* tidx, uint64_t cap) {
     std::vector<size_t> ord(g_walk_res.size());
@@ -729,7 +737,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     if (p->threading == DBTK_THREADING_V13) {
         WalkArgs w;
         memset(&w, 0, sizeof(w));
-        w.T = e->T; w.P = *p; w.seq = a.seq; w.off = off;
+        w.T = e->T; w.P = *p; w.P.aln &= 3u; w.seq = a.seq; w.off = off;
         w.surv = sorted.data(); w.nsurv = &small[0];
         w.walk_dst = walk.data(); w.walk_ret = walk.data() + npairs;
         w.counts = a.counts; w.counters = a.counters;
@@ -737,7 +745,16 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         std::vector<uint8_t> alnraw;
         uint32_t naln = 0;
         g_aln.clear();
-        if (p->aln) {
+        const bool txtmode = (p->aln & 3u) && (p->aln & DBTK_ALN_TEXT);
+        uint32_t ntxt = 0;
+        g_txt.clear(); g_txt_idx.clear();
+        if (txtmode) {
+            g_aln_cap = std::min<uint32_t>(DBTK_THREAD_CAP, (maxlen + maxlen / 4 + 8 + 7) & ~7u);
+            g_txt.assign(npairs * (size_t)(8 + 8 * g_aln_cap + 8) + (size_t)TXT_CHUNK * (grid_pair + 1), 0);
+            g_txt_idx.assign(npairs + 1, NAN32);
+            w.txt = g_txt.data(); w.txt_idx = g_txt_idx.data(); w.ntxt = &ntxt; w.txt_cap = (uint32_t)g_txt.size(); w.aln_cap = g_aln_cap;
+        }
+        if ((p->aln & 3u) && !txtmode) {
             g_aln_cap = std::min<uint32_t>(DBTK_THREAD_CAP, (maxlen + maxlen / 4 + 8 + 7) & ~7u);
             g_aln_stride = (uint32_t)sizeof(dbtk_aln_hdr_t) + 4 * g_aln_cap;
             const uint64_t amax = npairs + (uint64_t)ALN_CHUNK * grid_pair;
@@ -748,7 +765,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         std::vector<uint32_t> slow(npairs + 1, 0);
         uint32_t nslow = 0;
         const uint32_t kk = g->ksize;
-        const int wnpl = (p->aln || g_walk_trecs || kk + 4 > 32) ? 0 : (maxlen <= 32 * 3 + kk - 1 && kk + 2 <= 32 ? 3 : maxlen <= 32 * 5 + kk - 1 ? 5 : 0);
+        const int wnpl = ((p->aln & 3u) || g_walk_trecs || kk + 4 > 32) ? 0 : (maxlen <= 32 * 3 + kk - 1 && kk + 2 <= 32 ? 3 : maxlen <= 32 * 5 + kk - 1 ? 5 : 0);
         if (wnpl && !getenv("DBTK_WALK_ONE_KERNEL")) {
             w.slow_list = slow.data(); w.nslow = &nslow;
             if (wnpl == 3) run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<3>), [&](EmuX& x) { body_walk_fast<3>(x, w); });
@@ -756,7 +773,8 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
             g_walk_fast_runs += 1; g_walk_slow_pairs += nslow;
         }
         run_grid(grid_pair, 64, 2 * sizeof(WalkSmem), [&](EmuX& x) { body_walk_pairs(x, w); });
-        if (p->aln) {  // as dbtk_ctx_aln_records: drop the invalid slots, pair order
+        if (txtmode) g_txt.resize(ntxt <= g_txt.size() ? ntxt : g_txt.size());
+        if ((p->aln & 3u) && !txtmode) {  // as dbtk_ctx_aln_records: drop the invalid slots, pair order
             std::vector<std::pair<uint32_t, uint32_t>> order;
             for (uint32_t i = 0; i < naln; ++i) {
                 const dbtk_aln_hdr_t* h = reinterpret_cast<const dbtk_aln_hdr_t*>(alnraw.data() + (size_t)i * g_aln_stride);

@@ -405,6 +405,10 @@ def check_pair_mode(run, O, oh, case, k, nloci):
         exp, _ = expected_aln(O, o, reads, aln, nloci)
         if aln:
             assert [(h.pair, h.dst, t) for h, t in g["aln"]] == exp
+            # the same records in text form (params.aln | DBTK_ALN_TEXT: writeCigar / writeAnnot run by the kernel)
+            p.aln = aln | abi.ALN_TEXT
+            gt = run(p, seq, off)
+            assert gt["txt"] == exp and (co == gt["counts"]).all() and (o["counters"] == gt["counters"]).all()
         else:
             assert g["aln"] == []
 
@@ -423,7 +427,7 @@ def test_emulated_pair_mode_equals_oracle(tmp_path, k, seed):
     def run(p, seq, off):
         e = E.align(g, tb, p, seq, off)
         res, nres = E.walk_results(len(off))
-        return dict(counts=e["counts"], counters=e["counters"], res=res, nres=nres, aln=E.aln_records(), order=order)
+        return dict(counts=e["counts"], counters=e["counters"], res=res, nres=nres, aln=E.aln_records(), order=order, txt=E.aln_text(len(off) // 2))
     check_pair_mode(run, O, oh, case, k, case.loci.nloci)
 
 
@@ -474,7 +478,7 @@ def test_gpu_pair_mode_equals_oracle(tmp_path, k, seed):
         ctx.align(seq, off)
         r = ctx.counts()
         res, _, nres = ctx.walk_results(len(off))
-        out = dict(counts=r["counts"], counters=r["counters"], res=res, nres=nres, aln=ctx.aln_records(), order=order)
+        out = dict(counts=r["counts"], counters=r["counters"], res=res, nres=nres, aln=ctx.aln_records(), order=order, txt=ctx.aln_text(len(off) // 2))
         ctx.close()
         return out
     check_pair_mode(run, O, oh, case, k, case.loci.nloci)
