@@ -170,6 +170,29 @@ def pmc_mix_traffic(kernel):
     return k["FETCH_SIZE_KB"] * 1024.0 if k and "FETCH_SIZE_KB" in k else None
 
 
+def usable_cpus():
+    """CPUs this process may actually use: hardware threads, capped by the affinity mask and the cgroup CPU quota (the GPU boxes of
+    this pool show 256 hardware threads and a quota of 16 CPUs: the reference's `-p 256` run is a 16-core run)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except Exception:
+            pass
+    return n
+
+
 def time_steps(ctx, fn, steps, warmup):
     for _ in range(warmup):
         fn()
@@ -588,11 +611,11 @@ def main():
                     model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
                 except Exception:
                     pass
-                cpu = dict(value=best["value"], unit="reads/s", cores=best["threads"], kind="reference",
+                cpu = dict(value=best["value"], unit="reads/s", cores=best["threads"], usable_cpus=usable_cpus(), kind="reference",
                            sample=f"oracle/_ref/danbing-tk (the reference compiled from /root/reference) -k 21 -kf 4 1 -cth 45 -ka -p {best['threads']} on the same "
                                   f"RPGG written as its HEAD files and the first {best['reads']} reads of the same read set as 2-line FASTA; timed from its "
                                   f"'threads created' line to 'parallel query completed' ({best['query_s']:.1f} s); best of the -p values in `runs`",
-                           host=f"{ncpu} hardware threads, {model}", runs=runs, port=port)
+                           host=f"{ncpu} hardware threads ({usable_cpus()} usable: CPU quota of the container), {model}", runs=runs, port=port)
         if cpu is None and port is not None:
             cpu = port
         if ref_dir:

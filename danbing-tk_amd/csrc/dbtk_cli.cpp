@@ -23,6 +23,8 @@
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <time.h>
+#include <malloc.h>
+#include <sched.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -93,7 +95,7 @@ void usage() {
             "                         while the GPU works on the next batches) instead of plain text on stdout\n"
             "  --ingest-shards <INT>  cut a seekable input file into this many byte ranges, each read, split and paired by its own\n"
             "                         pipeline with its own context (tables are shared per GPU) [the number of GPUs]\n"
-            "  --emit-threads <INT>   host threads formatting / compressing records [cores / 2]\n"
+            "  --emit-threads <INT>   host threads formatting / compressing records [hardware threads / 4, at most the usable CPUs]\n"
             "  --aln-aligners <INT>   with -a / -ae: aligner threads (each with its own context) per GPU, so that fetching and formatting one\n"
             "                         batch's records overlaps the next batches' kernels [4]\n"
             "  --gz-level <INT>       zlib level of --aln-gz [1: measured 40x less deflate time than gzip's default 6 for 16 %% more bytes]\n"
@@ -184,7 +186,8 @@ struct Batch {  // one batch on its way through the stages; read r = flat[off[r]
     } aln;                      // -a / -ae: the batch's alignment records in text form (dbtk_ctx_aln_text): the arena ...
     std::vector<uint32_t> aln_idx;  // ... and where pair p's record starts in it (DBTK_NAN32: none)
     uint64_t naln = 0;
-    std::vector<std::string> aln_chunks;  // -a / -ae: the batch's alignment lines, formatted (and deflated) by the aligner thread's helpers
+    std::vector<std::string> aln_chunks;  // -a / -ae: the batch's alignment lines, formatted (and deflated) by the emit pool
+    std::vector<uint32_t> aln_em;         //            the pairs that have a record, in pair order
     long gpu_sec = 0;
     std::string title(uint64_t p) const { return std::string(tar.data() + toff[p], toff[p + 1] - toff[p]); }
     void add_read(const char* sp, size_t sn, const char* qp, size_t qn, bool fq) {
@@ -247,6 +250,10 @@ void mate_fields(std::string& o, const dbtk_mate_rec_t& r) {
 
 int main(int argc, char* argv[]) {
     if (argc < 2) { usage(); return 0; }
+    // big blocks come from the heap and stay there: batch buffers of tens of megabytes are grown and recycled all the time, and a
+    // map / unmap per growth serialises every thread of the process on the kernel's memory-map lock
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, -1);
     std::vector<std::string> args(argv, argv + argc);
     Opts o;
     auto need = [&](size_t i) -> const std::string& {
@@ -381,10 +388,31 @@ int main(int argc, char* argv[]) {
     typedef std::unique_ptr<Batch> BatchP;
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
     const double loop_t0 = now();
-    const unsigned hw = std::max(4u, std::thread::hardware_concurrency());
+    // host threads worth starting: the hardware threads, capped by what the container may actually use (its CPU affinity and its
+    // cgroup CPU quota: a 256-thread host with cpu.max = 16 cores runs 64 deflate threads four times slower each)
+    auto usable_cpus = []() -> unsigned {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+            char q[64]; unsigned long long per = 0;
+            if (fscanf(f, "%63s %llu", q, &per) == 2 && per && strcmp(q, "max") != 0) n = std::min<unsigned>(n, (unsigned)std::max(1ull, (strtoull(q, nullptr, 10) + per - 1) / per));
+            fclose(f);
+        } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+            long long quota = -1, per = 100000;
+            if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+            fclose(f1);
+            if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 100000; fclose(f2); }
+            if (quota > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)((quota + per - 1) / per));
+        }
+        return n;
+    };
+    const unsigned cpus = usable_cpus();
+    const unsigned hw = std::max(4u, std::min(std::thread::hardware_concurrency(), 8 * cpus));  // (what the thread counts below are derived from)
     FILE* gzout = nullptr;
     if (emit_aln && !o.alnGz.empty()) { gzout = fopen(o.alnGz.c_str(), "wb"); if (!gzout) die_assert("cannot create " + o.alnGz); }
-    const int emit_threads = o.emitThreads > 0 ? o.emitThreads : (int)std::max(1u, hw / 2);
+    const int emit_threads = o.emitThreads > 0 ? o.emitThreads : (int)std::max(1u, std::min(hw / 4, cpus));  // (never more than the CPUs the
+                                                                                                              // container may use: deflate is pure CPU work)
     uint64_t aln_bytes = 0;
     std::mutex out_m, tot_m;  // stdout / the gzip file (one batch at a time); the totals below
     std::atomic<uint64_t> rec_us{0}, fmt_us{0}, gz_us{0};  // -a / -ae: record read-back (wall), formatting and deflate (summed over the emit threads)
@@ -394,63 +422,84 @@ int main(int argc, char* argv[]) {
     // -a / -ae: writeAlignments (AQ.cpp:1742-1759), `src dst title seq2 seq1 cigar2 annot2 cigar1 annot1`, formatted (and,
     // with --aln-gz, deflated into independent gzip members) in chunks by a pool of host threads while the GPU threads
     // are already on the next batches; the chunks leave in record order.
+    // The emit pool: persistent helper threads (their text / deflate buffers and deflate states live as long as they do — fresh ones
+    // per chunk had a hundred threads queueing on the kernel's memory-map lock, and the ingest's threads behind them), fed chunk
+    // by chunk by the aligner threads, each of which waits for its own batch's chunks.
+    struct EmitTask { Batch* b; uint64_t c; std::atomic<uint64_t>* left; };
+    std::mutex ep_m;
+    std::condition_variable ep_cv, ep_done;
+    std::deque<EmitTask> ep_q;
+    bool ep_stop = false;
+    const uint64_t CH = 512;  // records per chunk (= per gzip member): ~230 KB of text
+    auto emit_worker = [&] {
+        std::string t, gzbuf;
+        t.reserve(CH * 700);
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        bool zinit = false;
+        for (;;) {
+            EmitTask k;
+            {
+                std::unique_lock<std::mutex> l(ep_m);
+                ep_cv.wait(l, [&] { return !ep_q.empty() || ep_stop; });
+                if (ep_q.empty()) break;
+                k = ep_q.front(); ep_q.pop_front();
+            }
+            Batch& b = *k.b;
+            const uint64_t n = b.aln_em.size();
+            t.clear();
+            const double tf0 = now();
+            for (uint64_t i = k.c * CH; i < std::min(n, (k.c + 1) * CH); ++i) {
+                const uint64_t p = b.aln_em[i];
+                const uint8_t* rec = b.aln.data() + b.aln_idx[p];
+                uint32_t dst, len;
+                memcpy(&dst, rec, 4); memcpy(&len, rec + 4, 4);
+                t += ".\t";  // srcLocus is -1 outside simulation mode
+                t += std::to_string((int)dst); t += '\t';
+                t.append(b.tar.data() + b.toff[p], b.toff[p + 1] - b.toff[p]); t += '\t';
+                t.append((const char*)b.flat.data() + b.off[2 * p + 1], b.off[2 * p + 2] - b.off[2 * p + 1]); t += '\t';
+                t.append((const char*)b.flat.data() + b.off[2 * p], b.off[2 * p + 1] - b.off[2 * p]); t += '\t';
+                t.append((const char*)rec + 8, len); t += '\n';
+            }
+            const double tf1 = now();
+            fmt_us += (uint64_t)((tf1 - tf0) * 1e6);
+            if (gzout) {  // one gzip member per chunk: `zcat FILE` is the concatenation
+                if (!zinit) { if (deflateInit2(&z, o.gzLevel, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die_assert("deflateInit2 failed"); zinit = true; }
+                else if (deflateReset(&z) != Z_OK) die_assert("deflateReset failed");
+                const size_t bound = deflateBound(&z, t.size()) + 64;
+                if (gzbuf.size() < bound) gzbuf.resize(bound);
+                z.next_in = (Bytef*)t.data(); z.avail_in = (uInt)t.size();
+                z.next_out = (Bytef*)&gzbuf[0]; z.avail_out = (uInt)gzbuf.size();
+                if (deflate(&z, Z_FINISH) != Z_STREAM_END) die_assert("deflate failed");
+                b.aln_chunks[k.c].assign(gzbuf.data(), gzbuf.size() - z.avail_out);
+                gz_us += (uint64_t)((now() - tf1) * 1e6);
+            } else b.aln_chunks[k.c] = t;
+            if (k.left->fetch_sub(1) == 1) { std::lock_guard<std::mutex> l(ep_m); ep_done.notify_all(); }
+        }
+        if (zinit) deflateEnd(&z);
+    };
+    std::vector<std::thread> emit_pool;
+    if (emit_aln && !o.parseOnly) for (int i = 0; i < emit_threads; ++i) emit_pool.emplace_back(emit_worker);
+    const int aln_aligners = emit_aln ? (o.alnAligners > 0 ? o.alnAligners : 4) : 1;
     // Called by the batch's ALIGNER thread right after it has fetched the records (its sibling aligner threads keep the GPU busy
     // meanwhile: --aln-aligners contexts per GPU); the ordered writer then only writes the finished chunks.
-    const int aln_aligners = emit_aln ? (o.alnAligners > 0 ? o.alnAligners : 4) : 1;
     auto prepare_alignments = [&](Batch& b) {
         b.aln_chunks.clear();
-        std::vector<uint32_t> em;  // the pairs with a record, in pair order (writeAlignments' order, AQ.cpp:1742-1759)
+        b.aln_em.clear();
         const uint64_t npairs_b = b.nreads / 2;
-        for (uint64_t p = 0; p < npairs_b; ++p) if (b.aln_idx[p] != DBTK_NAN32) em.push_back((uint32_t)p);
-        const uint64_t n = b.naln = em.size();
+        for (uint64_t p = 0; p < npairs_b; ++p) if (b.aln_idx[p] != DBTK_NAN32) b.aln_em.push_back((uint32_t)p);
+        const uint64_t n = b.naln = b.aln_em.size();
         if (!n) return;
-        const uint64_t CH = 512;  // records per chunk (= per gzip member): ~230 KB of text, several chunks per emit thread and batch
         const uint64_t nch = (n + CH - 1) / CH;
-        std::vector<std::string>& chunk = b.aln_chunks;
-        chunk.resize(nch);
-        std::atomic<uint64_t> nextc{0};
-        auto work = [&] {
-            std::string t;
-            t.reserve(CH * 640);
-            for (;;) {
-                const uint64_t c = nextc.fetch_add(1);
-                if (c >= nch) break;
-                t.clear();
-                const double tf0 = now();
-                for (uint64_t i = c * CH; i < std::min(n, (c + 1) * CH); ++i) {
-                    const uint64_t p = em[i];
-                    const uint8_t* rec = b.aln.data() + b.aln_idx[p];
-                    uint32_t dst, len;
-                    memcpy(&dst, rec, 4); memcpy(&len, rec + 4, 4);
-                    t += ".\t";  // srcLocus is -1 outside simulation mode
-                    t += std::to_string((int)dst); t += '\t';
-                    t.append(b.tar.data() + b.toff[p], b.toff[p + 1] - b.toff[p]); t += '\t';
-                    t.append((const char*)b.flat.data() + b.off[2 * p + 1], b.off[2 * p + 2] - b.off[2 * p + 1]); t += '\t';
-                    t.append((const char*)b.flat.data() + b.off[2 * p], b.off[2 * p + 1] - b.off[2 * p]); t += '\t';
-                    t.append((const char*)rec + 8, len); t += '\n';
-                }
-                const double tf1 = now();
-                fmt_us += (uint64_t)((tf1 - tf0) * 1e6);
-                if (gzout) {  // one gzip member per chunk: `zcat FILE` is the concatenation
-                    z_stream z;
-                    memset(&z, 0, sizeof z);
-                    if (deflateInit2(&z, o.gzLevel, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die_assert("deflateInit2 failed");
-                    std::string gz(deflateBound(&z, t.size()) + 64, '\0');
-                    z.next_in = (Bytef*)t.data(); z.avail_in = (uInt)t.size();
-                    z.next_out = (Bytef*)&gz[0]; z.avail_out = (uInt)gz.size();
-                    if (deflate(&z, Z_FINISH) != Z_STREAM_END) die_assert("deflate failed");
-                    gz.resize(gz.size() - z.avail_out);
-                    deflateEnd(&z);
-                    chunk[c].swap(gz);
-                    gz_us += (uint64_t)((now() - tf1) * 1e6);
-                } else chunk[c] = t;
-            }
-        };
-        const int nt = (int)std::min<uint64_t>(nch, (uint64_t)std::max(1, emit_threads / aln_aligners));
-        std::vector<std::thread> th;
-        for (int i = 1; i < nt; ++i) th.emplace_back(work);
-        work();
-        for (auto& x : th) x.join();
+        b.aln_chunks.resize(nch);
+        std::atomic<uint64_t> left{nch};
+        {
+            std::lock_guard<std::mutex> l(ep_m);
+            for (uint64_t c = 0; c < nch; ++c) ep_q.push_back(EmitTask{&b, c, &left});
+        }
+        ep_cv.notify_all();
+        std::unique_lock<std::mutex> l(ep_m);
+        ep_done.wait(l, [&] { return left.load() == 0; });
     };
     auto write_alignments = [&](const Batch& b) {
         std::lock_guard<std::mutex> lk(out_m);
@@ -1025,11 +1074,14 @@ int main(int argc, char* argv[]) {
         } else if (b.nreads && o.parseOnly) digest_batch(b);
     }
     fflush(stdout);
+    { std::lock_guard<std::mutex> l(ep_m); ep_stop = true; }
+    ep_cv.notify_all();
+    for (auto& t : emit_pool) t.join();
     if (fflush(stdout) != 0) die_assert("write to stdout failed");
     if (gzout && fclose(gzout) != 0) die_assert("closing the --aln-gz file failed");
     const int nsplit = nsplit_used;
-    if (emit_aln) fprintf(stderr, "emit: record read-back %.2f s; formatting %.2f thread-s, deflate %.2f thread-s on up to %d threads; %llu bytes out\n",
-                          rec_us.load() / 1e6, fmt_us.load() / 1e6, gz_us.load() / 1e6, emit_threads, (unsigned long long)aln_bytes);
+    if (emit_aln) fprintf(stderr, "emit: record read-back %.2f s; formatting %.2f thread-s, deflate %.2f thread-s on %d emit threads (%u usable CPUs); %llu bytes out\n",
+                          rec_us.load() / 1e6, fmt_us.load() / 1e6, gz_us.load() / 1e6, emit_threads, cpus, (unsigned long long)aln_bytes);
     fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: reading %.2f s, cutting %.2f s, pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads\n",
             now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, read_busy, cut_busy, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit);
 

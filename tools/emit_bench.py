@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Diagnostic: BASELINE config 5's bar on one GPU — the command line's batch loop on an all-hit FASTA with the graph walk, without
+and with -ae --aln-gz, for several --aln-aligners / --emit-threads settings.
+    python tools/emit_bench.py [nloci=80000] [npairs=2000000] [variant ...]      variant = "A,T" (aligners, emit threads)"""
+import importlib
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("danbing-tk_amd")
+
+
+def main():
+    nloci = int(sys.argv[1]) if len(sys.argv) > 1 else 80000
+    npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
+    variants = [tuple(int(x) for x in v.split(",")) for v in sys.argv[3:]] or [(4, 64)]
+    d = tempfile.mkdtemp(prefix="dbtk_emit_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        syn = pkg.Synth(nloci=nloci)
+        syn.graph()
+        syn.write_files(os.path.join(d, "pan"))
+        seq, _ = syn.reads(npairs, hit_frac=1.0, seed=2)
+        syn.write_fasta(seq, npairs, os.path.join(d, "reads_hit.fa"))
+        cli = os.path.join(ROOT, "danbing-tk_amd", "bin", "danbing-tk")
+        base = [cli, "-k", "21", "-kf", "4", "1", "-cth", "45", "--v13-threading", "-gc", "85", "3", "-fa", "reads_hit.fa", "-qs", "pan", "-o", "w"]
+
+        def run(extra, tag):
+            r = subprocess.run(base + extra, cwd=d, capture_output=True, text=True)
+            ing = [l for l in r.stderr.splitlines() if l.startswith("ingest:")]
+            em = [l for l in r.stderr.splitlines() if l.startswith("emit:")]
+            print(f"{tag:28s} rc={r.returncode} {ing[0] if ing else r.stderr[-400:]}", flush=True)
+            if em:
+                print(f"{'':28s} {em[0]}", flush=True)
+        run([], "no emit")
+        run([], "no emit (again)")
+        for al, th in variants:
+            run(["-ae", "--aln-gz", "w.aln.gz", "--aln-aligners", str(al), "--emit-threads", str(th)], f"-ae --aln-gz  A={al} T={th}")
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
