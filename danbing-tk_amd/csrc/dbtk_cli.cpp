@@ -328,6 +328,12 @@ int main(int argc, char* argv[]) {
             abort();  // the reference does `throw;` with no active exception -> std::terminate
         }
     }
+    if (o.simmode && o.aln && (o.v13 || (getenv("DBTK_V13_THREADING") && atoi(getenv("DBTK_V13_THREADING"))))) {
+        // writeAlignments prints srcLocus and, in simulation mode, keeps -ae records of pairs threading removed (AQ.cpp:1744-1745,
+        // 2241-2247): not implemented — refuse rather than print '.' in the src column
+        fprintf(stderr, "-s with -a / -ae under --v13-threading is not supported (the src column and the simulation-mode -ae rule are not implemented)\n");
+        return 2;
+    }
     // DBTK_V13_THREADING=1 in the environment = --v13-threading: the README's command line for the v1.3 contract
     // (`danbing-tk -gc 85 3 -ae ...`, README.md:38-39) then runs unchanged
     if (const char* e = getenv("DBTK_V13_THREADING")) if (atoi(e) != 0) o.v13 = true;
@@ -1034,7 +1040,40 @@ int main(int argc, char* argv[]) {
         // parked, the next one with that title completes the pair as seq1), then one last batch on GPU 0
         std::unordered_map<std::string, std::pair<std::string, std::string>> parked;
         Batch b;
-        b.off.push_back(0); b.qoff.push_back(0); b.toff.push_back(0);
+        uint64_t nleft = 0;
+        auto reset_left = [&] { b.flat.clear(); b.off.assign(1, 0); b.qar.clear(); b.qoff.assign(1, 0); b.tar.clear(); b.toff.assign(1, 0); b.src.clear(); b.nreads = 0; b.nrec = 0; };
+        // one batch of what the ranges left over through GPU 0 (in chunks of a batch's size: mates far apart in the file — an R1 block
+        // followed by an R2 block — leave nearly the whole file here, and one batch of that would neither fit the host nor a 32-bit
+        // pair index)
+        auto flush_left = [&] {
+            nReads += b.nreads; nleft += b.nreads;
+            if (b.nreads && !o.parseOnly) {
+                const uint64_t npairs = b.nreads / 2;
+                std::vector<uint8_t> flatq;
+                const bool send_qual = use_bait && fq;
+                if (send_qual) {
+                    flatq.assign(b.flat.size() + 1, (uint8_t)'!');
+                    for (uint64_t r = 0; r < b.nreads; ++r)
+                        memcpy(flatq.data() + b.off[r], b.qar.data() + b.qoff[r], std::min(b.qoff[r + 1] - b.qoff[r], b.off[r + 1] - b.off[r]));
+                }
+                if (want_recs) b.recs.resize(npairs);
+                b.flat.push_back(0);
+                if (dbtk_align_batch(ctx[0], b.flat.data(), b.off.data(), send_qual ? flatq.data() : nullptr, npairs, want_recs ? b.recs.data() : nullptr,
+                                     want_recs ? npairs : 0, &b.nrec)) die_assert(std::string("align: ") + dbtk_last_error());
+                b.flat.pop_back();
+                if (emit_aln) {
+                    uint64_t used = 0;
+                    b.aln_idx.resize(npairs);
+                    dbtk_status_t sa = dbtk_ctx_aln_text(ctx[0], b.aln_idx.data(), npairs, nullptr, 0, &used);
+                    if (sa == DBTK_ERR_OVERFLOW) { b.aln.grow((size_t)used + 16); sa = dbtk_ctx_aln_text(ctx[0], b.aln_idx.data(), npairs, b.aln.data(), b.aln.size(), &used); }
+                    if (sa) die_assert(std::string("alignment records: ") + dbtk_last_error());
+                    prepare_alignments(b);
+                }
+                emit(b);
+            } else if (b.nreads && o.parseOnly) digest_batch(b);
+            reset_left();
+        };
+        reset_left();
         for (auto& lv : lefts)
             for (auto& r : lv) {
                 auto it = parked.find(r.title);
@@ -1042,36 +1081,15 @@ int main(int argc, char* argv[]) {
                 const std::string s2 = it->second.first, q2 = it->second.second;
                 parked.erase(it);
                 if (r.seq.size() < minReadSize || s2.size() < minReadSize) continue;
+                if (o.simmode) b.src.push_back(parse_src(r.title, o.simmode, nloci));
                 b.tar.insert(b.tar.end(), r.title.begin(), r.title.end()); b.toff.push_back(b.tar.size());
                 b.add_read(r.seq.data(), r.seq.size(), r.qual.data(), r.qual.size(), fq);
                 b.add_read(s2.data(), s2.size(), q2.data(), q2.size(), fq);
                 b.nreads += 2;
+                if (b.nreads >= readsPerBatch) flush_left();
             }
-        nReads += b.nreads;
-        fprintf(stderr, "cross-range pairing: %llu reads\n", (unsigned long long)b.nreads);
-        if (b.nreads && !o.parseOnly) {
-            const uint64_t npairs = b.nreads / 2;
-            std::vector<uint8_t> flatq;
-            const bool send_qual = use_bait && fq;
-            if (send_qual) {
-                flatq.assign(b.flat.size() + 1, (uint8_t)'!');
-                for (uint64_t r = 0; r < b.nreads; ++r)
-                    memcpy(flatq.data() + b.off[r], b.qar.data() + b.qoff[r], std::min(b.qoff[r + 1] - b.qoff[r], b.off[r + 1] - b.off[r]));
-            }
-            if (want_recs) b.recs.resize(npairs);
-            b.flat.push_back(0);
-            if (dbtk_align_batch(ctx[0], b.flat.data(), b.off.data(), send_qual ? flatq.data() : nullptr, npairs, want_recs ? b.recs.data() : nullptr,
-                                 want_recs ? npairs : 0, &b.nrec)) die_assert(std::string("align: ") + dbtk_last_error());
-            if (emit_aln) {
-                uint64_t used = 0;
-                b.aln_idx.resize(npairs);
-                dbtk_status_t sa = dbtk_ctx_aln_text(ctx[0], b.aln_idx.data(), npairs, nullptr, 0, &used);
-                if (sa == DBTK_ERR_OVERFLOW) { b.aln.grow((size_t)used + 16); sa = dbtk_ctx_aln_text(ctx[0], b.aln_idx.data(), npairs, b.aln.data(), b.aln.size(), &used); }
-                if (sa) die_assert(std::string("alignment records: ") + dbtk_last_error());
-                prepare_alignments(b);
-            }
-            emit(b);
-        } else if (b.nreads && o.parseOnly) digest_batch(b);
+        flush_left();
+        fprintf(stderr, "cross-range pairing: %llu reads\n", (unsigned long long)nleft);
     }
     fflush(stdout);
     { std::lock_guard<std::mutex> l(ep_m); ep_stop = true; }

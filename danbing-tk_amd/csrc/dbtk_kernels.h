@@ -1403,7 +1403,7 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
     const DevTables& T = a.T;
     const uint32_t cth = a.P.cthreshold, nloci = T.nloci;
     const bool okam = a.P.okam != 0;
-    uint64_t c_qc = 0, c_thr = 0, c_feas = 0, c_asgn = 0, c_cls = 0, c_inc = 0, c_nhash1 = 0;
+    uint64_t c_qc = 0, c_thr = 0, c_feas = 0, c_asgn = 0, c_cls = 0, c_inc = 0, c_nhash1 = 0, c_kf = 0;
     const uint32_t nsurv = *a.nsurv;
     const uint64_t tlim64 = (uint64_t)a.t0 + a.tcap;
     const uint32_t tlim = nsurv < tlim64 ? nsurv : (uint32_t)tlim64;
@@ -1479,6 +1479,37 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
         const uint32_t nhit[2] = {hfound[0], hfound[1]}, v0 = hval[0];
         const bool usual = nkm[0] >= cth && nkm[1] >= cth && nhit[0] >= cth && nhit[1] >= cth && nhit[0] && nhit[1] && huni[0] && huni[1] &&
                            hval[0] == hval[1];
+        // The pair kfilter removes altogether (AQ.cpp:190-228: a mate with fewer than cth k-mers, or whose misses pass nk - cth, is
+        // cleared; both cleared: nothing is left to vote on) — a background pair that got through subfilter on a shared repeat.  It
+        // is decided from the same data: the look-ups kfilter made before it gave up are the positions up to the (nk - cth + 1)-th
+        // miss.  Nothing else happens to such a pair, so it ends here instead of in the general kernel.
+        const bool gone0 = nkm[0] < cth || nhit[0] < cth, gone1 = nkm[1] < cth || nhit[1] < cth;
+        if (gone0 && gone1) {
+            const uint32_t nslk = ((nkm[0] > nkm[1] ? nkm[0] : nkm[1]) + 63) >> 6;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                if (nkm[m] < cth) { c_kf += 1; continue; }  // kf = 1 without a look-up (AQ.cpp:196-199)
+                const uint32_t nk = nkm[m], maxns = nk - cth;
+                uint32_t cum_miss = 0, abort_at = nk;
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    if ((uint32_t)s >= nslk) continue;
+                    const uint32_t i = 64 * s + lane;
+                    const uint64_t missmask = x.ballot(i < nk && ha[m][s] == AUX_MISS);
+                    const uint32_t nm = (uint32_t)__builtin_popcountll(missmask);
+                    if (abort_at == nk && cum_miss + nm > maxns) {
+                        uint64_t mm = missmask;  // the (maxns + 1 - cum_miss)-th set bit
+                        for (uint32_t r = maxns - cum_miss; r > 0; --r) mm &= mm - 1;
+                        abort_at = 64 * s + (uint32_t)__builtin_ctzll(mm);
+                    }
+                    cum_miss += nm;
+                }
+                c_nhash1 += abort_at + 1;  // (found < cth: the abort point exists)
+                c_kf += 1;
+            }
+            deliver();
+            continue;
+        }
         DBTK_STAMP(32);  // request + usual test
         uint32_t dst0 = NAN32, dst = nloci, stage = DBTK_STAGE_LOCUS;
         MateState ms[2];
@@ -1599,6 +1630,7 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
     DBTK_STAMP_FLUSH;
     if (lane == 0) {
         if (c_qc) x.atomic_add(&ctr[DBTK_C_QCFILTERED], c_qc);
+        if (c_kf) x.atomic_add(&ctr[DBTK_C_KMERFILTERED], c_kf);
         if (c_thr) x.atomic_add(&ctr[DBTK_C_THREADING], c_thr);
         if (c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], c_feas);
         if (c_asgn) x.atomic_add(&ctr[DBTK_C_ASGN], c_asgn);
