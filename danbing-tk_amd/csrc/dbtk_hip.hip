@@ -685,7 +685,6 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         if ((st = rec_end(5))) return st;
         c->d_sorted = sa.sorted;
         a.surv = sa.sorted;
-        if (getenv("DBTK_NOSORT")) { c->d_sorted = c->d_surv; a.surv = c->d_surv; }  // (diagnostic A/B: the encode stage's order)
     }
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         a.t0 = (uint32_t)(ch * tcap);
@@ -785,7 +784,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         // rest from its list.  (The walk's kernels are timed together: "k_walk_pairs".)
         const int wnpl = (walk_aln || walk_txt || walk_trecs || k + 4 > 32) ? 0 : (max_read_len <= 32 * 3 + k - 1 && k + 2 <= 32 ? 3 : max_read_len <= 32 * 5 + k - 1 ? 5 : 0);
         if (tm) { if ((st = timed_slot(c, 4, &e))) return st; HIPCHK(hipEventRecord(c->timed[4].beg[e], s)); }
-        if (wnpl && !getenv("DBTK_WALK_ONE_KERNEL")) {
+        if (wnpl) {
             w.slow_list = c->d_walk + 2 * npairs; w.nslow = c->d_small + 5;
             HIPCHK(hipMemsetAsync(c->d_small + 5, 0, 4, s));
             if (wnpl == 3) LAUNCH((k_walk_fast<3>), dim3(c->walkfast_blocks), dim3(64), s, w);

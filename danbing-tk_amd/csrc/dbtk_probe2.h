@@ -226,10 +226,11 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
                     int hit = -1;
                     uint32_t w7 = 0;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
+                    for (int g = 0; g < 4; ++g) {  // (64-bit compares; only key 7 can carry the flag bit)
                         const uint4 kk = rp[g];
-                        if (kk.x == (uint32_t)km[j] && (kk.y & 0x7FFFFFFFu) == (uint32_t)(km[j] >> 32)) hit = 2 * g;
-                        if (kk.z == (uint32_t)km[j] && (kk.w & 0x7FFFFFFFu) == (uint32_t)(km[j] >> 32)) hit = 2 * g + 1;
+                        const uint64_t k0 = ((uint64_t)kk.y << 32) | kk.x, k1 = ((uint64_t)kk.w << 32) | kk.z;
+                        if (k0 == km[j]) hit = 2 * g;
+                        if ((g == 3 ? (k1 & ~MZ_TURNED) : k1) == km[j]) hit = 2 * g + 1;
                         if (g == 3) w7 = kk.w;
                     }
                     const uint32_t* pl = reinterpret_cast<const uint32_t*>(rp + 4) + 2 * (hit >= 0 ? hit : 0);
@@ -284,14 +285,15 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
                     // what was looked up goes into the cache (the absent ones too); of the lanes that want one entry in this
                     // step, the one whose token is left standing writes it
 #pragma unroll
-                    for (int j = 0; j < NPL; ++j) {
+                    for (int j = 0; j < NPL; ++j) if (glob[j]) sm.tok[(oh[j] >> 20) & (P2_CACHE - 1)] = (uint8_t)lane;
+                    x.sync();
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) {  // (two of a lane's own positions on one entry: both pass, the later write stands)
                         const uint32_t ce = (oh[j] >> 20) & (P2_CACHE - 1);
-                        if (glob[j]) sm.tok[ce] = (uint8_t)lane;
-                        x.sync();
                         if (glob[j] && sm.tok[ce] == (uint8_t)lane)
                             sm.cache[ce] = uint4{(uint32_t)km[j], (uint32_t)(km[j] >> 32), (uint32_t)rv[j], (uint32_t)(rv[j] >> 32)};
-                        x.sync();
                     }
+                    x.sync();
                 }
             }
             DBTK_STAMP(41);  // level 2

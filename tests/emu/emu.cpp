@@ -766,7 +766,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         uint32_t nslow = 0;
         const uint32_t kk = g->ksize;
         const int wnpl = ((p->aln & 3u) || g_walk_trecs || kk + 4 > 32) ? 0 : (maxlen <= 32 * 3 + kk - 1 && kk + 2 <= 32 ? 3 : maxlen <= 32 * 5 + kk - 1 ? 5 : 0);
-        if (wnpl && !getenv("DBTK_WALK_ONE_KERNEL")) {
+        if (wnpl) {
             w.slow_list = slow.data(); w.nslow = &nslow;
             if (wnpl == 3) run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<3>), [&](EmuX& x) { body_walk_fast<3>(x, w); });
             else run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<5>), [&](EmuX& x) { body_walk_fast<5>(x, w); });
