@@ -11,6 +11,16 @@
 #include <vector>
 #include "danbing-tk_amd/csrc/dbtk_tables.h"
 using namespace dbtk;
+// (the table header no longer returns the minimizer's offset — the final layout does not use it; the designs simulated here do)
+static inline void mz_of_kmer_off(uint64_t kmer, uint32_t k, uint32_t m, uint32_t* h28, uint32_t* off) {
+    const uint64_t mm = (1ull << 2 * m) - 1;
+    uint32_t best = 0xFFFFFFFFu, bo = 0;
+    for (uint32_t i = 0; i + m <= k; ++i) {
+        const uint32_t h = dbtk::mmer_hash((kmer >> (2 * (k - m - i))) & mm, m);
+        if (h < best) { best = h; bo = i; }
+    }
+    *h28 = best >> 4; *off = bo;
+}
 int main(int argc, char** argv) {
     const uint32_t nloci = argc > 1 ? atoi(argv[1]) : 800, K = 21, M = 15;
     const uint64_t npairs = argc > 2 ? atoll(argv[2]) : 20000;
@@ -27,7 +37,7 @@ int main(int argc, char** argv) {
     std::unordered_map<uint64_t, uint32_t> val;
     for (uint64_t i = 0; i < a.nkeys; ++i) {
         const uint64_t km = a.keys[i]; val[km] = a.vals[i];
-        uint32_t h, o; mz_of_kmer(km, K, M, &h, &o);
+        uint32_t h, o; mz_of_kmer_off(km, K, M, &h, &o);
         const uint64_t b = mz_bucket(h, (uint32_t)(nb - 1)); const uint32_t sl = o & 7;
         { Bk& B = TA[b]; if (B.n < 8) B.key[B.n++] = km; else B.turned = 1; }
         { Bk& B = TB[b]; if (B.key[sl] == NAN64) B.key[sl] = km; else B.tslot |= 1 << sl; }
@@ -73,7 +83,7 @@ int main(int argc, char** argv) {
                                 if (e == km[pos]) { ++l2hit; continue; }
                                 e = km[pos];
                             }
-                            uint32_t h, o; mz_of_kmer(km[pos], K, M, &h, &o);
+                            uint32_t h, o; mz_of_kmer_off(km[pos], K, M, &h, &o);
                             const uint64_t b = mz_bucket(h, (uint32_t)(nb - 1)); const uint32_t sl = o & 7;
                             l1.push_back(b);
                             bool pend;
