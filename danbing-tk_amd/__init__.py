@@ -320,6 +320,62 @@ class Dbtk(_HostSide):
         self._chk(self.L.dbtk_allreduce(arr, len(ctxs)))
 
 
+class Ingest:
+    """dbtk_ingest_*: raw FASTA / FASTQ bytes in, parsed and paired on the device (include/dbtk.h)."""
+
+    def __init__(self, ctx, fastq, min_read_size, chunk_bytes, nslots=3, with_spans=True):
+        self.ctx, self.chunk, self.nslots, self.n = ctx, int(chunk_bytes), int(nslots), 0
+        L = self.L = ctx._lib.L
+        L.dbtk_ingest_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.dbtk_ingest_free.argtypes = [C.c_void_p]
+        L.dbtk_ingest_free.restype = None
+        L.dbtk_ingest_chunk_buffer.argtypes = [C.c_void_p, C.c_uint32]
+        L.dbtk_ingest_chunk_buffer.restype = C.c_void_p
+        L.dbtk_ingest_block.argtypes = [C.c_void_p, C.c_uint32]
+        L.dbtk_ingest_block.restype = C.c_void_p
+        L.dbtk_ingest_submit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_int]
+        L.dbtk_ingest_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.IngestInfo)]
+        L.dbtk_ingest_align.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(abi.PairRec), C.c_uint64, u64p]
+        L.dbtk_ingest_spans.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.IngestSpan), C.c_uint64]
+        self.h = C.c_void_p()
+        ctx._lib._chk(L.dbtk_ingest_create(ctx.h, int(bool(fastq)), int(min_read_size), self.chunk, self.nslots, int(bool(with_spans)), C.byref(self.h)))
+
+    def submit(self, data: bytes, last: bool):
+        slot = self.n % self.nslots
+        assert len(data) <= self.chunk
+        C.memmove(self.L.dbtk_ingest_chunk_buffer(self.h, slot), data, len(data))
+        self.ctx._lib._chk(self.L.dbtk_ingest_submit(self.h, slot, len(data), int(last)))
+        self.n += 1
+        return slot
+
+    def wait(self, slot):
+        info = abi.IngestInfo()
+        self.ctx._lib._chk(self.L.dbtk_ingest_wait(self.h, slot, C.byref(info)))
+        return info
+
+    def align(self, slot, info, sync=True):
+        p = self.ctx.params
+        want = sync and bool(p.trace or p.okam or p.extract) and info.nkept
+        recs = (abi.PairRec * info.nkept)() if want else None
+        nrec = C.c_uint64(0)
+        self.ctx._lib._chk(self.L.dbtk_ingest_align(self.h, slot, int(sync), recs, info.nkept if want else 0, C.byref(nrec)))
+        return recs, int(nrec.value)
+
+    def spans(self, slot, info):
+        """[(title, read 2q, read 2q + 1, qual 2q, qual 2q + 1)] of the block's kept pairs, as bytes."""
+        sp = (abi.IngestSpan * max(info.nkept, 1))()
+        self.ctx._lib._chk(self.L.dbtk_ingest_spans(self.h, slot, sp, info.nkept))
+        base = self.L.dbtk_ingest_block(self.h, slot)
+        g = lambda o, n: C.string_at(base + o, n)
+        return [(g(s.title, s.title_len), g(s.seq[0], s.seq_len[0]), g(s.seq[1], s.seq_len[1]), g(s.qual[0], s.qual_len[0]), g(s.qual[1], s.qual_len[1]))
+                for s in sp[:info.nkept]]
+
+    def close(self):
+        if self.h:
+            self.L.dbtk_ingest_free(self.h)
+            self.h = None
+
+
 # every symbol include/dbtk.h declares (checked by the CPU test-suite)
 EXPORTS = [
     "dbtk_rpgg_load", "dbtk_rpgg_load_tr", "dbtk_rpgg_uid", "dbtk_rpgg_from_arrays", "dbtk_rpgg_free", "dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys",
@@ -327,6 +383,8 @@ EXPORTS = [
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
     "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_aln_text", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
     "dbtk_thread_batch", "dbtk_ctx_walk_results", "dbtk_ctx_aln_records", "dbtk_aln_format",
+    "dbtk_ingest_create", "dbtk_ingest_free", "dbtk_ingest_chunk_buffer", "dbtk_ingest_block", "dbtk_ingest_submit", "dbtk_ingest_wait",
+    "dbtk_ingest_align", "dbtk_ingest_spans",
 ]
 
 # include/dbtk_pred.h (the danbing-tk-pred step)

@@ -4,9 +4,10 @@ import ctypes as C
 MAX_READ_LEN = 256
 NAN64 = 0xFFFFFFFFFFFFFFFF
 NAN32 = 0xFFFFFFFF
-ABI_VERSION = 3
+ABI_VERSION = 4
 ALN_TEXT = 4  # params.aln | ALN_TEXT: alignment records in text form (dbtk_ctx_aln_text)
 THREAD_CAP = 384
+ING_DIRTY, ING_LINES, ING_CARRY, ING_TAIL = 1, 2, 4, 8  # dbtk_ingest_info.flags
 THREADING_HEAD, THREADING_V13 = 1, 2
 
 (OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NO_DEVICE, ERR_HIP, ERR_READ_TOO_LONG, ERR_NOMEM, ERR_UNSUPPORTED,
@@ -88,3 +89,13 @@ def default_params(**kw) -> Params:
     for k, v in kw.items():
         setattr(p, k, v)
     return p
+
+
+class IngestInfo(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("npairs", C.c_uint32), ("nkept", C.c_uint32), ("max_read_len", C.c_uint32),
+                ("first_byte", C.c_uint64), ("cut_byte", C.c_uint64), ("seq_bytes", C.c_uint64)]
+
+
+class IngestSpan(C.Structure):
+    _fields_ = [("title", C.c_uint32), ("title_len", C.c_uint32), ("seq", C.c_uint32 * 2), ("seq_len", C.c_uint32 * 2),
+                ("qual", C.c_uint32 * 2), ("qual_len", C.c_uint32 * 2)]

@@ -16,6 +16,8 @@
 // stderr is informational (the reference's also carries timings); stdout and the
 // output files are byte-compatible.
 #include <errno.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <immintrin.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -56,6 +58,7 @@ struct Opts {
     bool writeKmerName = false, outputBubbles = false, invkmer = false, isFastq = false, trackBait = false, qc = false;
     int simmode = 0, extractFastX = 0, verbosity = 0, ngpus = 1, gzLevel = 1, emitThreads = 0, ingestShards = 0, alnAligners = 0;
     bool correction = true;
+    bool hostIngest = false; // --host-ingest: parse and pair on the host even where the device reader applies
     bool parseOnly = false;  // --parse-only: run the ingest (reader, splitters, pairing) and report what it handed on; no GPU
     bool v13 = false;       // --v13-threading: -g/-gc/-gcc run the graph walk of the v1.3 contract instead of HEAD's dead path
     std::string alnGz;      // --aln-gz FILE: the -a / -ae records gzip-compressed into FILE (instead of plain on stdout)
@@ -95,6 +98,8 @@ void usage() {
             "                         while the GPU works on the next batches) instead of plain text on stdout\n"
             "  --ingest-shards <INT>  cut a seekable input file into this many byte ranges, each read, split and paired by its own\n"
             "                         pipeline with its own context (tables are shared per GPU) [the number of GPUs]\n"
+            "  --host-ingest          parse and pair the reads on the host even where the device reader applies (a regular file without\n"
+            "                         -s / -tb / -a / -ae: there the host only copies bytes and kernels find the records and pair the mates)\n"
             "  --emit-threads <INT>   host threads formatting / compressing records [hardware threads / 4, at most the usable CPUs]\n"
             "  --aln-aligners <INT>   with -a / -ae: aligner threads (each with its own context) per GPU, so that fetching and formatting one\n"
             "                         batch's records overlaps the next batches' kernels [4]\n"
@@ -189,7 +194,15 @@ struct Batch {  // one batch on its way through the stages; read r = flat[off[r]
     std::vector<std::string> aln_chunks;  // -a / -ae: the batch's alignment lines, formatted (and deflated) by the emit pool
     std::vector<uint32_t> aln_em;         //            the pairs that have a record, in pair order
     long gpu_sec = 0;
-    std::string title(uint64_t p) const { return std::string(tar.data() + toff[p], toff[p + 1] - toff[p]); }
+    // a batch the device reader made (dbtk_ingest_*): titles, reads and qualities stay where they were read, in the slot's pinned
+    // block, and the per-pair spans say where
+    const char* blk = nullptr;
+    std::vector<dbtk_ingest_span_t> spans;
+    typedef std::pair<const char*, size_t> Span;
+    Span title_s(uint64_t p) const { return blk ? Span(blk + spans[p].title, spans[p].title_len) : Span(tar.data() + toff[p], toff[p + 1] - toff[p]); }
+    Span seq_s(uint64_t r) const { return blk ? Span(blk + spans[r >> 1].seq[r & 1], spans[r >> 1].seq_len[r & 1]) : Span((const char*)flat.data() + off[r], off[r + 1] - off[r]); }
+    Span qual_s(uint64_t r) const { return blk ? Span(blk + spans[r >> 1].qual[r & 1], spans[r >> 1].qual_len[r & 1]) : Span(qar.data() + qoff[r], qoff[r + 1] - qoff[r]); }
+    std::string title(uint64_t p) const { const Span t = title_s(p); return std::string(t.first, t.second); }
     void add_read(const char* sp, size_t sn, const char* qp, size_t qn, bool fq) {
         flat.insert(flat.end(), sp, sp + sn); off.push_back(flat.size());
         if (fq) { qar.insert(qar.end(), qp, qp + qn); qoff.push_back(qar.size()); }
@@ -318,6 +331,7 @@ int main(int argc, char* argv[]) {
         else if (a == "--gpus") o.ngpus = atoi(need(++argi).c_str());
         else if (a == "--v13-threading") o.v13 = true;
         else if (a == "--parse-only") o.parseOnly = true;
+        else if (a == "--host-ingest") o.hostIngest = true;
         else if (a == "--aln-gz") o.alnGz = need(++argi);
         else if (a == "--emit-threads") o.emitThreads = atoi(need(++argi).c_str());
         else if (a == "--ingest-shards") o.ingestShards = atoi(need(++argi).c_str());
@@ -422,7 +436,8 @@ int main(int argc, char* argv[]) {
     uint64_t aln_bytes = 0;
     std::mutex out_m, tot_m;  // stdout / the gzip file (one batch at a time); the totals below
     std::atomic<uint64_t> rec_us{0}, fmt_us{0}, gz_us{0};  // -a / -ae: record read-back (wall), formatting and deflate (summed over the emit threads)
-    uint64_t nReads = 0;
+    uint64_t nReads = 0, dev_ingest_reads = 0;
+    std::vector<dbtk_ingest_t*> spent_ingests;
     double read_busy = 0, cut_busy = 0, pair_busy = 0, gpu_busy = 0, write_busy = 0;  // seconds each stage spent working (not waiting), summed over the shards
     int nsplit_used = 0;
     // -a / -ae: writeAlignments (AQ.cpp:1742-1759), `src dst title seq2 seq1 cigar2 annot2 cigar1 annot1`, formatted (and,
@@ -462,9 +477,10 @@ int main(int argc, char* argv[]) {
                 memcpy(&dst, rec, 4); memcpy(&len, rec + 4, 4);
                 t += ".\t";  // srcLocus is -1 outside simulation mode
                 t += std::to_string((int)dst); t += '\t';
-                t.append(b.tar.data() + b.toff[p], b.toff[p + 1] - b.toff[p]); t += '\t';
-                t.append((const char*)b.flat.data() + b.off[2 * p + 1], b.off[2 * p + 2] - b.off[2 * p + 1]); t += '\t';
-                t.append((const char*)b.flat.data() + b.off[2 * p], b.off[2 * p + 1] - b.off[2 * p]); t += '\t';
+                const Batch::Span ti = b.title_s(p), s1 = b.seq_s(2 * p + 1), s0 = b.seq_s(2 * p);
+                t.append(ti.first, ti.second); t += '\t';
+                t.append(s1.first, s1.second); t += '\t';
+                t.append(s0.first, s0.second); t += '\t';
                 t.append((const char*)rec + 8, len); t += '\n';
             }
             const double tf1 = now();
@@ -518,8 +534,8 @@ int main(int argc, char* argv[]) {
     auto emit = [&](const Batch& b) {
         std::string out;
         if (emit_aln) write_alignments(b);
-        auto seq = [&](uint64_t r) { return std::string((const char*)b.flat.data() + b.off[r], b.off[r + 1] - b.off[r]); };
-        auto qual = [&](uint64_t r) { return std::string(b.qar.data() + b.qoff[r], b.qoff[r + 1] - b.qoff[r]); };
+        auto seq = [&](uint64_t r) { const Batch::Span x = b.seq_s(r); return std::string(x.first, x.second); };
+        auto qual = [&](uint64_t r) { const Batch::Span x = b.qual_s(r); return std::string(x.first, x.second); };
         for (uint64_t i = 0; i < b.nrec; ++i) {
             const dbtk_pair_rec_t& r = b.recs[i];
             const uint64_t p = r.pair;
@@ -967,6 +983,137 @@ int main(int argc, char* argv[]) {
     (void)shard;
     return std::make_tuple(nReads, read_busy, cut_busy, pair_busy, gpu_busy, write_busy, nsplit);
     };  // run_shard
+    // The reader on the device (include/dbtk.h: dbtk_ingest_*; kernels in dbtk_ingest.h).  For interleaved input the host only moves
+    // bytes: a few threads pread fixed-size chunks of [lo, hi) straight into the pinned buffers of the ingest's slots, this thread
+    // submits them in file order (host-to-device copy + the parse kernels: newline scan, record table, title comparison of
+    // neighbouring records, minimal read size, the batch arrays) and runs every parsed block through the hot path.  The first
+    // block that is not a run of adjacent mates ends it: *resume = the input offset the host reader (run_shard: splitters +
+    // park-by-title pairing) continues from — up to there every record was paired, so nothing is parked there, exactly as in
+    // the reference's reader at that point.  Records (kam lines, -e) are written from the spans the device made, in file order.
+    auto run_device_ingest = [&](dbtk_ctx_t* cx, const uint64_t lo, const uint64_t hi, uint64_t* resume) {
+        size_t CH = 32u << 20;
+        if (const char* e = getenv("DBTK_INGEST_CHUNK")) { const long v = atol(e); if (v >= 4096) CH = (size_t)v; }  // (tests: many small blocks)
+        const bool want_out = want_recs;  // records need titles and reads on the host: the slot's bytes stay until they are written
+        uint32_t NS = 12;  // chunks on their way at once (being read, copied, parsed, or waiting for their records to be written): the readers
+                           // run this many chunks ahead of the oldest one not yet done with
+        if (const char* e = getenv("DBTK_INGEST_SLOTS")) { const int v = atoi(e); if (v >= 2 && v <= 64) NS = (uint32_t)v; }
+        dbtk_ingest_t* ing = nullptr;
+        const double ts0 = now();
+        if (dbtk_ingest_create(cx, fq, (uint32_t)minReadSize, CH, NS, want_out, &ing)) die_assert(dbtk_last_error());
+        const double setup_s = now() - ts0;
+        double first_s = 0, wait_s = 0;
+        const int fd = open(o.fastxFname.c_str(), O_RDONLY);
+        if (fd < 0) die_assert("cannot open " + o.fastxFname);
+        const uint64_t total = hi - lo, nchunks = std::max<uint64_t>(1, (total + CH - 1) / CH);
+        std::mutex m;
+        std::condition_variable cv;
+        std::vector<char> filled(nchunks, 0);
+        uint64_t next_read = 0, nreleased = 0;
+        bool stop = false;
+        double rb = 0, gb = 0, wb = 0;
+        auto io = [&] {
+            for (;;) {
+                uint64_t j;
+                {
+                    std::unique_lock<std::mutex> l(m);
+                    cv.wait(l, [&] { return stop || next_read >= nchunks || next_read < nreleased + NS; });  // (chunk j - NS has left slot j % NS)
+                    if (stop || next_read >= nchunks) return;
+                    j = next_read++;
+                }
+                const double t0 = now();
+                char* dst = (char*)dbtk_ingest_chunk_buffer(ing, (uint32_t)(j % NS));
+                const size_t want = (size_t)std::min<uint64_t>(CH, total - j * CH);
+                size_t got = 0;
+                while (got < want) {
+                    const ssize_t r = pread(fd, dst + got, want - got, (off_t)(lo + j * CH + got));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) die_assert("read error on " + o.fastxFname);
+                    got += (size_t)r;
+                }
+                {
+                    std::lock_guard<std::mutex> l(m);
+                    filled[j] = 1;
+                    rb += now() - t0;
+                }
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> ios;
+        int nio = (int)std::min<uint64_t>(nchunks, std::max(1u, std::min(8u, cpus / 2)));
+        if (const char* e = getenv("DBTK_INGEST_READERS")) { const int v = atoi(e); if (v > 0) nio = v; }
+        for (int i = 0; i < nio; ++i) ios.emplace_back(io);
+        auto release = [&] { { std::lock_guard<std::mutex> l(m); ++nreleased; } cv.notify_all(); };
+        Chan<std::unique_ptr<Batch>> outq;
+        outq.cap = NS;
+        std::thread writer;
+        if (want_out)
+            writer = std::thread([&] {
+                std::unique_ptr<Batch> b;
+                while (outq.pop(b)) {
+                    const double t0 = now();
+                    emit(*b);
+                    wb += now() - t0;
+                    release();
+                }
+            });
+        uint64_t jsub = 0, jaln = 0, nR = 0;
+        *resume = hi;
+        const bool sync = want_out || P.bubbles;  // (-bu replays every batch's novel edges on the host)
+        while (jaln < nchunks) {
+            for (;;) {  // submit what has been read, up to NS - 1 blocks ahead of the one about to be aligned
+                {
+                    std::unique_lock<std::mutex> l(m);
+                    if (jsub == jaln) cv.wait(l, [&] { return filled[jsub] != 0; });
+                    if (!(jsub < nchunks && jsub < jaln + NS && filled[jsub])) break;
+                }
+                const uint64_t nb = std::min<uint64_t>(CH, total - jsub * CH);
+                if (dbtk_ingest_submit(ing, (uint32_t)(jsub % NS), nb, jsub + 1 == nchunks)) die_assert(std::string("ingest: ") + dbtk_last_error());
+                ++jsub;
+            }
+            const double t0 = now();
+            const uint32_t slot = (uint32_t)(jaln % NS);
+            dbtk_ingest_info_t info;
+            if (dbtk_ingest_wait(ing, slot, &info)) die_assert(std::string("ingest: ") + dbtk_last_error());
+            wait_s += now() - t0;
+            if (jaln == 0) first_s = now() - ts0;
+            if (info.flags & (DBTK_ING_DIRTY | DBTK_ING_LINES)) { *resume = lo + info.first_byte; gb += now() - t0; break; }
+            if (want_out) {
+                std::unique_ptr<Batch> b(new Batch);
+                b->index = jaln; b->nreads = 2 * (uint64_t)info.nkept;
+                b->recs.resize(info.nkept);
+                const time_t t2 = time(nullptr);
+                if (dbtk_ingest_align(ing, slot, 1, b->recs.data(), info.nkept, &b->nrec)) die_assert(std::string("align: ") + dbtk_last_error());
+                b->gpu_sec = (long)(time(nullptr) - t2);
+                b->spans.resize(info.nkept);
+                if (dbtk_ingest_spans(ing, slot, b->spans.data(), info.nkept)) die_assert(std::string("ingest: ") + dbtk_last_error());
+                b->blk = (const char*)dbtk_ingest_block(ing, slot);
+                gb += now() - t0;
+                outq.push(std::move(b));
+            } else {
+                if (dbtk_ingest_align(ing, slot, sync ? 1 : 0, nullptr, 0, nullptr)) die_assert(std::string("align: ") + dbtk_last_error());
+                gb += now() - t0;
+                release();
+            }
+            nR += 2 * (uint64_t)info.nkept;
+            fprintf(stderr, "Buffered reading %llu\t%llu\t%d\n", 2 * (unsigned long long)info.nkept, (unsigned long long)nR, 0);
+            if (info.flags) { *resume = lo + info.cut_byte; break; }
+            ++jaln;
+        }
+        { std::lock_guard<std::mutex> l(m); stop = true; }
+        cv.notify_all();
+        for (auto& t : ios) t.join();
+        outq.close();
+        if (writer.joinable()) writer.join();
+        const double tf0 = now();
+        if (dbtk_ctx_synchronize(cx)) die_assert(dbtk_last_error());  // the kernels still in flight
+        { std::lock_guard<std::mutex> lk(tot_m); spent_ingests.push_back(ing); }  // (its pinned and device buffers are freed at exit, not inside the batch loop)
+        close(fd);
+        fprintf(stderr, "device reader: %llu blocks of %zu MB on %d reader threads; setup %.3f s, first block parsed after %.3f s, waiting for parsed blocks %.3f s, drain %.3f s\n",
+                (unsigned long long)jaln, CH >> 20, nio, setup_s, first_s, wait_s, now() - tf0);
+        std::lock_guard<std::mutex> lk(tot_m);
+        nReads += nR; read_busy += rb; gpu_busy += gb; write_busy += wb;
+        dev_ingest_reads += nR;
+    };
     // the ranges
     std::vector<uint64_t> cuts{0, ~0ull};
     {
@@ -1025,8 +1172,23 @@ int main(int argc, char* argv[]) {
     std::vector<std::vector<Left>> lefts(nshards);
     {
         std::vector<std::thread> shards;
+        // the device reader first, where it applies: a regular file (pread at offsets), no per-read work the host must do (-s parses
+        // titles, -tb replays batches from host copies of the reads, -a / -ae has its own several-contexts-per-GPU emit path)
+        struct stat sb;
+        const bool is_file = stat(o.fastxFname.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
+        bool dev_ingest = !o.parseOnly && !o.hostIngest && !o.simmode && !P.trackbait && !emit_aln && is_file;
+        if (const char* e = getenv("DBTK_DEVICE_INGEST")) if (atoi(e) == 0) dev_ingest = false;
         auto one = [&](int i) {
-            const auto r = nshards == 1 ? run_shard(0, 0, o.parseOnly ? o.ngpus : (int)ctx.size(), 0, ~0ull, lefts[0]) : run_shard(i, i, 1, cuts[i], cuts[i + 1], lefts[i]);
+            uint64_t lo = nshards == 1 ? 0 : cuts[i];
+            const uint64_t hi = nshards == 1 ? (is_file ? (uint64_t)sb.st_size : ~0ull) : cuts[i + 1];
+            if (dev_ingest) {
+                uint64_t resume = lo;
+                run_device_ingest(ctx[i], lo, hi, &resume);
+                if (resume >= hi) return;
+                fprintf(stderr, "device reader: input is not interleaved at byte %llu; the host reader takes over\n", (unsigned long long)resume);
+                lo = resume;
+            }
+            const auto r = nshards == 1 ? run_shard(0, 0, o.parseOnly ? o.ngpus : (int)ctx.size(), lo, ~0ull, lefts[0]) : run_shard(i, i, 1, lo, hi, lefts[i]);
             std::lock_guard<std::mutex> lk(tot_m);
             nReads += std::get<0>(r); read_busy += std::get<1>(r); cut_busy += std::get<2>(r); pair_busy += std::get<3>(r);
             gpu_busy += std::get<4>(r); write_busy += std::get<5>(r); nsplit_used += std::get<6>(r);
@@ -1100,8 +1262,9 @@ int main(int argc, char* argv[]) {
     const int nsplit = nsplit_used;
     if (emit_aln) fprintf(stderr, "emit: record read-back %.2f s; formatting %.2f thread-s, deflate %.2f thread-s on %d emit threads (%u usable CPUs); %llu bytes out\n",
                           rec_us.load() / 1e6, fmt_us.load() / 1e6, gz_us.load() / 1e6, emit_threads, cpus, (unsigned long long)aln_bytes);
-    fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: reading %.2f s, cutting %.2f s, pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads\n",
-            now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, read_busy, cut_busy, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit);
+    fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: reading %.2f s, cutting %.2f s, pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads; device reader: %llu reads\n",
+            now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, read_busy, cut_busy, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit,
+            (unsigned long long)dev_ingest_reads);
 
     if (o.parseOnly) {
         printf("parse-only\t%llu\t%llu\t%llu\n", (unsigned long long)po_pairs.load(), (unsigned long long)po_bases.load(), (unsigned long long)po_digest.load());
@@ -1163,6 +1326,7 @@ int main(int argc, char* argv[]) {
             }
         }
     }
+    for (auto g : spent_ingests) dbtk_ingest_free(g);
     for (auto c : ctx) dbtk_ctx_free(c);
     dbtk_rpgg_free(rpgg);
     fprintf(stderr, "all done!\n");

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -22,6 +23,7 @@
 #include "dbtk_devx.h"
 #include "dbtk_internal.h"
 #include "dbtk_kernels.h"
+#include "dbtk_ingest.h"
 
 using namespace dbtk;
 
@@ -86,6 +88,14 @@ __global__ void __launch_bounds__(256) k_surv_key(SurvSortArgs a) { DevX x{nullp
 __global__ void __launch_bounds__(64) k_surv_scan(SurvSortArgs a, int step) { DevX x{nullptr}; body_surv_scan(x, a, step); }
 __global__ void __launch_bounds__(256) k_surv_scatter(SurvSortArgs a) { DevX x{nullptr}; body_surv_scatter(x, a); }
 __global__ void __launch_bounds__(256) k_gr_insert(GrBuildArgs a) { DevX x{nullptr}; body_gr_insert(x, a); }
+// the reader on the device (dbtk_ingest.h): record boundaries, mate pairing and the batch arrays of a block of raw bytes
+__global__ void __launch_bounds__(64) k_ing_count(IngestArgs a) { DevX x{nullptr}; body_ing_count(x, a); }
+__global__ void __launch_bounds__(64) k_ing_scan(IngestArgs a, int step) { DevX x{nullptr}; body_ing_scan(x, a, step); }
+__global__ void __launch_bounds__(64) k_ing_lines(IngestArgs a) { DevX x{nullptr}; body_ing_lines(x, a); }
+__global__ void __launch_bounds__(256) k_ing_pairs(IngestArgs a) { DevX x{nullptr}; body_ing_pairs(x, a); }
+__global__ void __launch_bounds__(64) k_ing_place(IngestArgs a, int step) { DevX x{nullptr}; body_ing_place(x, a, step); }
+__global__ void __launch_bounds__(64) k_ing_gather(IngestArgs a) { DevX x{nullptr}; body_ing_gather(x, a); }
+__global__ void __launch_bounds__(256) k_ing_carry(IngestArgs a) { DevX x{nullptr}; body_ing_carry(x, a); }
 // the graph walk (dbtk_walk.h): one wave per read (function mode) / per pair (the hot path with threading = 2)
 #ifndef DBTK_WALK_WAVES
 #define DBTK_WALK_WAVES 2  // waves per SIMD the pair kernel is compiled for (register budget 512 / this): 3, 4 and 5 measured no faster
@@ -974,33 +984,14 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
 
 void dbtk_ctx_free(dbtk_ctx_t* ctx) { free_ctx(ctx); }
 
-static dbtk_status_t dbtk_align_batch_impl(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t* off, const uint8_t* qual,
-                               uint64_t npairs, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
-    if (!c || !off || (!seq && npairs)) { set_error("null argument"); return DBTK_ERR_ARG; }
-    if (nrec) *nrec = 0;
-    HIPCHK(hipSetDevice(c->device));
-    const uint64_t nreads = 2 * npairs;
-    for (uint64_t r = 0; r < nreads; ++r) {
-        if (off[r + 1] < off[r]) { set_error("seq_offsets not monotone"); return DBTK_ERR_ARG; }
-        if (off[r + 1] - off[r] > DBTK_MAX_READ_LEN) {
-            set_error("read longer than DBTK_MAX_READ_LEN (256): the reference's PE_KMC is uint8_t, src/aQueryFasta_thread.cpp:42");
-            return DBTK_ERR_READ_TOO_LONG;
-        }
-    }
-    if (npairs == 0) return DBTK_OK;
-    const uint64_t base = off[0], nbytes = off[nreads] - base;
+// A batch whose reads are in device memory (d_seq, d_off; d_qual or null), run to completion, with what the host-buffer
+// entry point hands back: records in pair order, the -bu replay, the -tb replay (which needs the reads on the host: seq / off /
+// qual, else null).  Shared by dbtk_align_batch and dbtk_ingest_align.
+static dbtk_status_t run_batch_sync(dbtk_ctx_t* c, const uint8_t* d_seq, const uint64_t* d_off, const uint8_t* d_qual, uint64_t nbytes,
+                                    uint64_t npairs, uint32_t maxlen, const uint8_t* seq, const uint64_t* off, const uint8_t* qual,
+                                    dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
     dbtk_status_t st;
-    if ((st = ensure(&c->d_seq, &c->seq_cap, nbytes + 32))) return st;
-    if ((st = ensure(&c->d_off, &c->off_cap, nreads + 1))) return st;
     hipStream_t s = c->stream;
-    if (nbytes) HIPCHK(hipMemcpyAsync(c->d_seq, seq + base, nbytes, hipMemcpyHostToDevice, s));
-    if (base == 0) {
-        HIPCHK(hipMemcpyAsync(c->d_off, off, (nreads + 1) * 8, hipMemcpyHostToDevice, s));
-    } else {
-        std::vector<uint64_t> o2(nreads + 1);
-        for (uint64_t r = 0; r <= nreads; ++r) o2[r] = off[r] - base;
-        HIPCHK(hipMemcpy(c->d_off, o2.data(), (nreads + 1) * 8, hipMemcpyHostToDevice));
-    }
     bool want_recs = recs && rec_cap && (c->P.trace || c->P.okam || c->P.extract);
     if (c->P.trackbait && !want_recs) {  // the replay needs the bait-stage records even when the caller wants none
         c->own_recs.resize(npairs);
@@ -1014,13 +1005,7 @@ static dbtk_status_t dbtk_align_batch_impl(dbtk_ctx_t* c, const uint8_t* seq, co
         if (c->P.trace && rec_cap < npairs) { set_error("trace mode needs rec_cap >= npairs"); return DBTK_ERR_ARG; }
         if ((st = ensure(&c->d_recs, &c->rec_cap, dcap))) return st;
     }
-    uint32_t maxlen = 0;
-    for (uint64_t r = 0; r < nreads; ++r) maxlen = std::max<uint32_t>(maxlen, (uint32_t)(off[r + 1] - off[r]));
-    const bool use_qual = c->P.bait && qual;  // base qualities only matter to the bait filter (-b with -fq)
-    if (use_qual) {
-        if ((st = ensure(&c->d_qual, &c->qual_cap, nbytes + 32))) return st;
-        if (nbytes) HIPCHK(hipMemcpyAsync(c->d_qual, qual + base, nbytes, hipMemcpyHostToDevice, s));
-    }
+    if (c->P.trackbait && !seq) { set_error("-tb needs the reads in host buffers"); return DBTK_ERR_UNSUPPORTED; }
     const bool walk_recs = c->P.threading == DBTK_THREADING_V13 && c->P.trace;
     if (walk_recs && (st = ensure(&c->d_trecs, &c->trecs_cap, 2 * npairs))) return st;
     c->last_walk_npairs = c->P.threading == DBTK_THREADING_V13 ? npairs : 0;
@@ -1029,8 +1014,8 @@ static dbtk_status_t dbtk_align_batch_impl(dbtk_ctx_t* c, const uint8_t* seq, co
     const bool walk_aln = c->P.threading == DBTK_THREADING_V13 && (c->P.aln & 3u) && !walk_txt;
     if (!walk_aln) c->aln_max = 0;
     if (!walk_txt) c->txt_cap = 0;
-    if ((st = launch_batch(c, c->d_seq, c->d_off, nbytes, npairs, maxlen, want_recs ? c->d_recs : nullptr, (uint32_t)dcap,
-                           use_qual ? c->d_qual : nullptr, walk_recs ? c->d_trecs : nullptr, walk_aln, walk_txt))) return st;
+    if ((st = launch_batch(c, d_seq, d_off, nbytes, npairs, maxlen, want_recs ? c->d_recs : nullptr, (uint32_t)dcap,
+                           d_qual, walk_recs ? c->d_trecs : nullptr, walk_aln, walk_txt))) return st;
     uint32_t small[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(small, c->d_small, sizeof(small), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1120,6 +1105,43 @@ static dbtk_status_t dbtk_align_batch_impl(dbtk_ctx_t* c, const uint8_t* seq, co
         }
     }
     return DBTK_OK;
+}
+
+static dbtk_status_t dbtk_align_batch_impl(dbtk_ctx_t* c, const uint8_t* seq, const uint64_t* off, const uint8_t* qual,
+                               uint64_t npairs, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
+    if (!c || !off || (!seq && npairs)) { set_error("null argument"); return DBTK_ERR_ARG; }
+    if (nrec) *nrec = 0;
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t nreads = 2 * npairs;
+    for (uint64_t r = 0; r < nreads; ++r) {
+        if (off[r + 1] < off[r]) { set_error("seq_offsets not monotone"); return DBTK_ERR_ARG; }
+        if (off[r + 1] - off[r] > DBTK_MAX_READ_LEN) {
+            set_error("read longer than DBTK_MAX_READ_LEN (256): the reference's PE_KMC is uint8_t, src/aQueryFasta_thread.cpp:42");
+            return DBTK_ERR_READ_TOO_LONG;
+        }
+    }
+    if (npairs == 0) return DBTK_OK;
+    const uint64_t base = off[0], nbytes = off[nreads] - base;
+    dbtk_status_t st;
+    if ((st = ensure(&c->d_seq, &c->seq_cap, nbytes + 32))) return st;
+    if ((st = ensure(&c->d_off, &c->off_cap, nreads + 1))) return st;
+    hipStream_t s = c->stream;
+    if (nbytes) HIPCHK(hipMemcpyAsync(c->d_seq, seq + base, nbytes, hipMemcpyHostToDevice, s));
+    if (base == 0) {
+        HIPCHK(hipMemcpyAsync(c->d_off, off, (nreads + 1) * 8, hipMemcpyHostToDevice, s));
+    } else {
+        std::vector<uint64_t> o2(nreads + 1);
+        for (uint64_t r = 0; r <= nreads; ++r) o2[r] = off[r] - base;
+        HIPCHK(hipMemcpy(c->d_off, o2.data(), (nreads + 1) * 8, hipMemcpyHostToDevice));
+    }
+    uint32_t maxlen = 0;
+    for (uint64_t r = 0; r < nreads; ++r) maxlen = std::max<uint32_t>(maxlen, (uint32_t)(off[r + 1] - off[r]));
+    const bool use_qual = c->P.bait && qual;  // base qualities only matter to the bait filter (-b with -fq)
+    if (use_qual) {
+        if ((st = ensure(&c->d_qual, &c->qual_cap, nbytes + 32))) return st;
+        if (nbytes) HIPCHK(hipMemcpyAsync(c->d_qual, qual + base, nbytes, hipMemcpyHostToDevice, s));
+    }
+    return run_batch_sync(c, c->d_seq, c->d_off, use_qual ? c->d_qual : nullptr, nbytes, npairs, maxlen, seq, off, qual, recs, rec_cap, nrec);
 }
 
 // Function-level entry of the graph walk (tests, and callers that want isThreadFeasible alone).
@@ -1481,6 +1503,209 @@ dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n) {
     return DBTK_OK;
 }
 
+// ---- raw-bytes ingest (include/dbtk.h: dbtk_ingest_*; kernels in dbtk_ingest.h) ------------------------------------------
+struct dbtk_ingest {
+    dbtk_ctx* c = nullptr;
+    uint32_t L = 2, min_read = 0, nslots = 0, head = 1u << 20, line_cap = 0, pair_cap = 0;
+    uint64_t chunk = 0;
+    bool with_spans = false, with_qual = false, dead = false;
+    hipStream_t stream = nullptr;       // the parse kernels, block after block
+    hipStream_t copy_stream = nullptr;  // the host-to-device copies: block i + 1's runs while block i is parsed
+    uint64_t raw_bytes = 0;
+    std::unique_ptr<std::mutex[]> slot_m;  // (pinning a slot's host buffer)
+    uint32_t* d_basew = nullptr;  // per slot: where its block starts (written by the block before)
+    IngestHdr* d_hdr = nullptr;   // per slot
+    IngestHdr* h_hdr = nullptr;   // pinned, per slot
+    uint64_t submitted = 0;       // input bytes submitted so far
+    uint64_t nsubmitted = 0, nwaited = 0;
+    int last_byte = '\n';
+    std::vector<uint8_t> carry_host;  // host copy of the bytes the last waited block handed on (the spans of the next block reach into them)
+    struct Slot {
+        uint8_t* h_raw = nullptr; uint8_t* d_raw = nullptr;
+        uint32_t* d_tile = nullptr; uint32_t* d_nlpos = nullptr; uint32_t* d_pk = nullptr; uint32_t* d_kept = nullptr;
+        uint64_t* d_off = nullptr; uint8_t* d_flat = nullptr; uint8_t* d_qual = nullptr; dbtk_ingest_span_t* d_spans = nullptr;
+        hipEvent_t parsed = nullptr, aligned = nullptr, copied = nullptr;
+        bool has_aligned = false, waited = false, pending = false;
+        uint32_t end = 0; uint64_t file_off = 0; int last = 0;
+        IngestHdr hdr;
+    };
+    std::vector<Slot> slots;
+};
+
+static void ingest_free_impl(dbtk_ingest* g) {
+    if (!g) return;
+    if (g->c) (void)hipSetDevice(g->c->device);
+    if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->c) (void)sync_all(g->c);
+    for (auto& S : g->slots) {
+        if (S.h_raw) (void)hipHostFree(S.h_raw);
+        void* ptrs[] = {S.d_raw, S.d_tile, S.d_nlpos, S.d_pk, S.d_kept, S.d_off, S.d_flat, S.d_qual, S.d_spans};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (S.parsed) (void)hipEventDestroy(S.parsed);
+        if (S.aligned) (void)hipEventDestroy(S.aligned);
+        if (S.copied) (void)hipEventDestroy(S.copied);
+    }
+    if (g->d_basew) (void)hipFree(g->d_basew);
+    if (g->d_hdr) (void)hipFree(g->d_hdr);
+    if (g->h_hdr) (void)hipHostFree(g->h_hdr);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
+    delete g;
+}
+
+static dbtk_status_t dbtk_ingest_create_impl(dbtk_ctx_t* c, uint32_t fastq, uint32_t min_read_size, uint64_t chunk_bytes, uint32_t nslots,
+                                             uint32_t with_spans, dbtk_ingest_t** out) {
+    if (!c || !out) { set_error("null argument"); return DBTK_ERR_ARG; }
+    *out = nullptr;
+    if (nslots < 2 || nslots > 64) { set_error("dbtk_ingest_create: 2 .. 64 slots"); return DBTK_ERR_ARG; }
+    if (chunk_bytes < 4096 || chunk_bytes > (1ull << 30)) { set_error("dbtk_ingest_create: chunk_bytes must be 4 KB .. 1 GB"); return DBTK_ERR_ARG; }
+    if (c->P.trackbait) { set_error("dbtk_ingest: -tb replays its batches on the host and needs the reads in host buffers"); return DBTK_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(c->device));
+    dbtk_ingest* g = new dbtk_ingest;
+    g->c = c; g->L = fastq ? 4 : 2; g->min_read = min_read_size; g->nslots = nslots; g->chunk = chunk_bytes;
+    g->head = (uint32_t)std::min<uint64_t>(1u << 20, (chunk_bytes + 15) & ~15ull);
+    g->with_spans = with_spans != 0;
+    g->with_qual = fastq && c->P.bait;  // base qualities only matter to the bait filter
+    const uint64_t raw_bytes = ((uint64_t)g->head + chunk_bytes + 1 + 63) & ~63ull;
+    g->raw_bytes = raw_bytes;
+    g->line_cap = (uint32_t)(raw_bytes / 8 + 64);
+    g->pair_cap = g->line_cap / (2 * g->L) + 1;
+    const uint64_t ntiles = raw_bytes / ING_TILE + 1;
+    g->slots.resize(nslots);
+    g->slot_m.reset(new std::mutex[nslots]);
+    dbtk_status_t st = DBTK_OK;
+    auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && !st) { set_error(std::string(what) + ": " + hipGetErrorString(e)); st = DBTK_ERR_HIP; } };
+    chk(hipStreamCreate(&g->stream), "hipStreamCreate");
+    chk(hipStreamCreate(&g->copy_stream), "hipStreamCreate");
+    chk(hipMalloc(&g->d_basew, nslots * 4), "hipMalloc");
+    chk(hipMalloc(&g->d_hdr, nslots * sizeof(IngestHdr)), "hipMalloc");
+    chk(hipHostMalloc((void**)&g->h_hdr, nslots * sizeof(IngestHdr), hipHostMallocDefault), "hipHostMalloc");
+    for (auto& S : g->slots) {
+        chk(hipMalloc(&S.d_raw, raw_bytes), "hipMalloc (block)");  // (the pinned host buffer: on first use, by the thread that fills it — dbtk_ingest_chunk_buffer)
+        chk(hipMalloc(&S.d_tile, (ntiles + 1 + ING_SCAN_BLOCKS) * 4), "hipMalloc");
+        chk(hipMalloc(&S.d_nlpos, (uint64_t)g->line_cap * 4), "hipMalloc (line table)");
+        chk(hipMalloc(&S.d_pk, ((uint64_t)g->pair_cap + 2 * ING_SCAN_BLOCKS) * 4), "hipMalloc");
+        chk(hipMalloc(&S.d_kept, (uint64_t)g->pair_cap * 4), "hipMalloc");
+        chk(hipMalloc(&S.d_off, (2 * (uint64_t)g->pair_cap + 1) * 8), "hipMalloc");
+        chk(hipMalloc(&S.d_flat, raw_bytes + 64), "hipMalloc (reads)");
+        if (g->with_qual) chk(hipMalloc(&S.d_qual, raw_bytes + 64), "hipMalloc (qualities)");
+        if (g->with_spans) chk(hipMalloc(&S.d_spans, (uint64_t)g->pair_cap * sizeof(dbtk_ingest_span_t)), "hipMalloc (spans)");
+        chk(hipEventCreateWithFlags(&S.parsed, hipEventDisableTiming), "hipEventCreate");
+        chk(hipEventCreateWithFlags(&S.aligned, hipEventDisableTiming), "hipEventCreate");
+        chk(hipEventCreateWithFlags(&S.copied, hipEventDisableTiming), "hipEventCreate");
+        if (st) break;
+    }
+    if (st) { ingest_free_impl(g); return st; }
+    *out = g;
+    return DBTK_OK;
+}
+
+static dbtk_status_t dbtk_ingest_submit_impl(dbtk_ingest_t* g, uint32_t slot, uint64_t nbytes, int last) {
+    if (!g) { set_error("null argument"); return DBTK_ERR_ARG; }
+    if (g->dead) { set_error("dbtk_ingest: a flagged block ended this ingest"); return DBTK_ERR_ARG; }
+    if (slot != g->nsubmitted % g->nslots) { set_error("dbtk_ingest_submit: slots are used round robin"); return DBTK_ERR_ARG; }
+    if (nbytes > g->chunk) { set_error("dbtk_ingest_submit: more than chunk_bytes"); return DBTK_ERR_ARG; }
+    dbtk_ingest::Slot& S = g->slots[slot];
+    if (S.pending) { set_error("dbtk_ingest_submit: the slot's previous block has not been waited for"); return DBTK_ERR_ARG; }
+    if (!S.h_raw && !dbtk_ingest_chunk_buffer(g, slot)) { set_error("hipHostMalloc (chunk buffer) failed"); return DBTK_ERR_NOMEM; }
+    dbtk_ctx* c = g->c;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = g->stream;
+    uint64_t n = nbytes;
+    if (nbytes) g->last_byte = S.h_raw[g->head + nbytes - 1];
+    if (last && g->last_byte != '\n') { S.h_raw[g->head + n++] = '\n'; g->last_byte = '\n'; }  // std::getline: the last line need not end with a newline
+    if (S.has_aligned) HIPCHK(hipStreamWaitEvent(s, S.aligned, 0));  // the align kernels of the slot's previous block still read its arrays
+    // the copy on its own stream (the slot's previous block has been waited for: nothing reads its bytes any more); the kernels wait for it
+    if (n) HIPCHK(hipMemcpyAsync(S.d_raw + g->head, S.h_raw + g->head, n, hipMemcpyHostToDevice, g->copy_stream));
+    HIPCHK(hipEventRecord(S.copied, g->copy_stream));
+    HIPCHK(hipStreamWaitEvent(s, S.copied, 0));
+    if (g->nsubmitted == 0) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(g->d_basew + slot), (int)g->head, 1, s));
+    HIPCHK(hipMemsetAsync(g->d_hdr + slot, 0, sizeof(IngestHdr), s));
+    const uint32_t next = (slot + 1) % g->nslots;
+    IngestArgs a;
+    memset(&a, 0, sizeof(a));
+    a.raw = S.d_raw; a.base_in = g->d_basew + slot; a.end = g->head + (uint32_t)n; a.L = g->L; a.min_read = g->min_read; a.last = last ? 1u : 0u;
+    a.tile_cnt = S.d_tile; a.nlpos = S.d_nlpos; a.line_cap = g->line_cap; a.pk = S.d_pk; a.kept = S.d_kept; a.off = S.d_off;
+    a.flat = S.d_flat; a.qual = S.d_qual; a.spans = S.d_spans; a.hdr = g->d_hdr + slot;
+    a.next_raw = g->slots[next].d_raw; a.base_out = g->d_basew + next; a.head = g->head;
+    const uint32_t ntiles = (a.end + ING_TILE - 1) / ING_TILE;
+    const uint32_t gt = std::min<uint32_t>(ntiles, (uint32_t)c->num_cu * 16);
+    LAUNCH(k_ing_count, dim3(gt), dim3(64), s, a);
+    LAUNCH(k_ing_scan, dim3(ING_SCAN_BLOCKS), dim3(64), s, a, 0);
+    LAUNCH(k_ing_scan, dim3(ING_SCAN_BLOCKS), dim3(64), s, a, 1);
+    LAUNCH(k_ing_lines, dim3(gt), dim3(64), s, a);
+    LAUNCH(k_ing_pairs, dim3(c->num_cu * 4), dim3(256), s, a);
+    LAUNCH(k_ing_place, dim3(ING_SCAN_BLOCKS), dim3(64), s, a, 0);
+    LAUNCH(k_ing_place, dim3(ING_SCAN_BLOCKS), dim3(64), s, a, 1);
+    LAUNCH(k_ing_gather, dim3(c->num_cu * 32), dim3(64), s, a);
+    LAUNCH(k_ing_carry, dim3(1), dim3(256), s, a);
+    HIPCHK(hipMemcpyAsync(g->h_hdr + slot, g->d_hdr + slot, sizeof(IngestHdr), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(S.parsed, s));
+    S.end = a.end; S.file_off = g->submitted; S.last = last; S.pending = true; S.waited = false; S.has_aligned = false;
+    g->submitted += nbytes;
+    ++g->nsubmitted;
+    return DBTK_OK;
+}
+
+static dbtk_status_t dbtk_ingest_wait_impl(dbtk_ingest_t* g, uint32_t slot, dbtk_ingest_info_t* info) {
+    if (!g || !info) { set_error("null argument"); return DBTK_ERR_ARG; }
+    if (slot >= g->nslots || slot != g->nwaited % g->nslots || !g->slots[slot].pending) { set_error("dbtk_ingest_wait: blocks are waited for in the order they were submitted"); return DBTK_ERR_ARG; }
+    dbtk_ingest::Slot& S = g->slots[slot];
+    HIPCHK(hipSetDevice(g->c->device));
+    HIPCHK(hipEventSynchronize(S.parsed));
+    S.hdr = g->h_hdr[slot];
+    S.pending = false; S.waited = true;
+    ++g->nwaited;
+    const IngestHdr& h = S.hdr;
+    // the host's copy of the block gets the bytes the block before handed on (the device copied its own)
+    if (!g->carry_host.empty() && g->carry_host.size() == g->head - h.base) memcpy(S.h_raw + h.base, g->carry_host.data(), g->carry_host.size());
+    g->carry_host.clear();
+    uint32_t flags = h.flags;
+    if (h.cut >= h.base && h.cut <= S.end && h.carry <= g->head && !S.last) g->carry_host.assign(S.h_raw + h.cut, S.h_raw + S.end);
+    if (flags) g->dead = true;
+    info->flags = flags; info->npairs = h.npairs; info->nkept = h.nkept; info->max_read_len = (uint32_t)h.maxlen;
+    info->first_byte = S.file_off - (g->head - h.base);
+    info->cut_byte = info->first_byte + (h.cut - h.base);
+    info->seq_bytes = h.flat_bytes;
+    return DBTK_OK;
+}
+
+static dbtk_status_t dbtk_ingest_align_impl(dbtk_ingest_t* g, uint32_t slot, int sync, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
+    if (!g || slot >= g->nslots) { set_error("null argument"); return DBTK_ERR_ARG; }
+    if (nrec) *nrec = 0;
+    dbtk_ingest::Slot& S = g->slots[slot];
+    if (!S.waited) { set_error("dbtk_ingest_align: wait for the block first"); return DBTK_ERR_ARG; }
+    const IngestHdr& h = S.hdr;
+    if (h.flags & (ING_F_DIRTY | ING_F_LINES_OVF)) { set_error("dbtk_ingest_align: the block is not a run of adjacent mates; continue with a host reader at info.first_byte"); return DBTK_ERR_ARG; }
+    if (h.nkept == 0) return DBTK_OK;
+    if (h.maxlen > DBTK_MAX_READ_LEN) {
+        set_error("read longer than DBTK_MAX_READ_LEN (256): the reference's PE_KMC is uint8_t, src/aQueryFasta_thread.cpp:42");
+        return DBTK_ERR_READ_TOO_LONG;
+    }
+    dbtk_ctx* c = g->c;
+    HIPCHK(hipSetDevice(c->device));
+    if (sync) return run_batch_sync(c, S.d_flat, S.d_off, S.d_qual, ~0ull, h.nkept, (uint32_t)h.maxlen, nullptr, nullptr, nullptr, recs, rec_cap, nrec);
+    if (c->P.bubbles) { set_error("dbtk_ingest_align: -bu is replayed batch by batch on the host: sync = 1"); return DBTK_ERR_ARG; }
+    if (c->two_lanes) switch_lane(c);
+    const dbtk_status_t st = launch_batch(c, S.d_flat, S.d_off, ~0ull, h.nkept, (uint32_t)h.maxlen, nullptr, 0, S.d_qual);
+    if (st) return st;
+    HIPCHK(hipEventRecord(S.aligned, c->stream));
+    S.has_aligned = true;
+    return DBTK_OK;
+}
+
+static dbtk_status_t dbtk_ingest_spans_impl(dbtk_ingest_t* g, uint32_t slot, dbtk_ingest_span_t* spans, uint64_t cap) {
+    if (!g || slot >= g->nslots || (!spans && cap)) { set_error("null argument"); return DBTK_ERR_ARG; }
+    dbtk_ingest::Slot& S = g->slots[slot];
+    if (!g->with_spans) { set_error("dbtk_ingest_spans: the ingest was created without spans"); return DBTK_ERR_ARG; }
+    if (!S.waited) { set_error("dbtk_ingest_spans: wait for the block first"); return DBTK_ERR_ARG; }
+    if (cap < S.hdr.nkept) { set_error("dbtk_ingest_spans: buffer too small"); return DBTK_ERR_OVERFLOW; }
+    HIPCHK(hipSetDevice(g->c->device));
+    if (S.hdr.nkept) HIPCHK(hipMemcpy(spans, S.d_spans, (size_t)S.hdr.nkept * sizeof(dbtk_ingest_span_t), hipMemcpyDeviceToHost));
+    return DBTK_OK;
+}
+
 // ---- the entry points above that parse files or allocate host memory, behind the exception barrier (dbtk_internal.h: guarded)
 dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int device_id, dbtk_ctx_t** out) {
     return dbtk::guarded([&] { return dbtk_ctx_create_impl(h, p, device_id, out); });
@@ -1507,6 +1732,38 @@ dbtk_status_t dbtk_ctx_write_bubbles(dbtk_ctx_t* c, const char* out_prefix) {
 }
 dbtk_status_t dbtk_ctx_write_bait_hits(dbtk_ctx_t* c, const char* out_prefix) {
     return dbtk::guarded([&] { return dbtk_ctx_write_bait_hits_impl(c, out_prefix); });
+}
+
+dbtk_status_t dbtk_ingest_create(dbtk_ctx_t* c, uint32_t fastq, uint32_t min_read_size, uint64_t chunk_bytes, uint32_t nslots, uint32_t with_spans,
+                                 dbtk_ingest_t** out) {
+    return dbtk::guarded([&] { return dbtk_ingest_create_impl(c, fastq, min_read_size, chunk_bytes, nslots, with_spans, out); });
+}
+void dbtk_ingest_free(dbtk_ingest_t* g) { ingest_free_impl(g); }
+void* dbtk_ingest_chunk_buffer(dbtk_ingest_t* g, uint32_t slot) {
+    if (!g || slot >= g->nslots) return nullptr;
+    dbtk_ingest::Slot& S = g->slots[slot];
+    if (!S.h_raw) {  // pinned on first use, by the caller's reader thread (several slots at once: the pinning of one overlaps the reading into another)
+        std::lock_guard<std::mutex> l(g->slot_m[slot]);
+        if (!S.h_raw) {
+            uint8_t* p = nullptr;
+            if (hipSetDevice(g->c->device) != hipSuccess || hipHostMalloc((void**)&p, g->raw_bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+            S.h_raw = p;
+        }
+    }
+    return S.h_raw + g->head;
+}
+const void* dbtk_ingest_block(dbtk_ingest_t* g, uint32_t slot) { return g && slot < g->nslots ? g->slots[slot].h_raw : nullptr; }
+dbtk_status_t dbtk_ingest_submit(dbtk_ingest_t* g, uint32_t slot, uint64_t nbytes, int last) {
+    return dbtk::guarded([&] { return dbtk_ingest_submit_impl(g, slot, nbytes, last); });
+}
+dbtk_status_t dbtk_ingest_wait(dbtk_ingest_t* g, uint32_t slot, dbtk_ingest_info_t* info) {
+    return dbtk::guarded([&] { return dbtk_ingest_wait_impl(g, slot, info); });
+}
+dbtk_status_t dbtk_ingest_align(dbtk_ingest_t* g, uint32_t slot, int sync, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
+    return dbtk::guarded([&] { return dbtk_ingest_align_impl(g, slot, sync, recs, rec_cap, nrec); });
+}
+dbtk_status_t dbtk_ingest_spans(dbtk_ingest_t* g, uint32_t slot, dbtk_ingest_span_t* spans, uint64_t cap) {
+    return dbtk::guarded([&] { return dbtk_ingest_spans_impl(g, slot, spans, cap); });
 }
 
 }  // extern "C"

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DBTK_ABI_VERSION 3u
+#define DBTK_ABI_VERSION 4u
 
 /* Reads longer than this are rejected (DBTK_ERR_READ_TOO_LONG).  The
  * reference's per-read k-mer multiplicity is a uint8_t pair (`PE_KMC`,
@@ -307,6 +307,49 @@ dbtk_status_t dbtk_ctx_aln_text(dbtk_ctx_t* ctx, uint32_t* idx, uint64_t idx_cap
 dbtk_status_t dbtk_align_batch_device(dbtk_ctx_t* ctx, const void* d_seq, const void* d_offsets,
                                       uint64_t npairs, uint32_t max_read_len);
 dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* ctx);
+
+/* ---- raw-bytes ingest: the reader of the batch loop on the device ---------------------------------------------------
+ * Replaces critical section A of the worker (src/aQueryFasta_thread.cpp:1918-1976: getline title / seq [/ + / qual],
+ * prunePEinfo :455-462, on-the-fly mate pairing, the minimal read size :1940-1943) for interleaved input.  The caller only
+ * moves bytes: it reads the input in chunks of at most chunk_bytes, in file order, into the pinned buffer of the next
+ * slot (slots are used round robin) and submits it; record boundaries (2 lines per FASTA record, 4 per FASTQ, counted
+ * from the first submitted byte), pairing and the batch arrays are made by kernels, and what follows a chunk's last whole
+ * pair is carried over to the next chunk on the device.
+ *   submit(slot, nbytes, last)   asynchronous: host-to-device copy + the parse kernels of the block
+ *   wait(slot, &info)            blocks until the block is parsed; info says what it held
+ *   align(slot, ...)             the parsed pairs through the hot path (as dbtk_align_batch_device when sync = 0, as
+ *                                dbtk_align_batch — records, dbtk_ctx_aln_text — when sync = 1)
+ * Calls for successive blocks must be made in order by one thread; submit may run ahead of wait by up to nslots - 1
+ * blocks.  A slot's buffer may be refilled once align (or wait, for a block that is not aligned) has returned and the
+ * caller no longer needs its bytes (dbtk_ingest_spans point into it).
+ * info.flags != 0: the block is not (only) a run of adjacent mates.  DBTK_ING_DIRTY / DBTK_ING_LINES: nothing of it may be
+ * aligned — continue at input offset info.first_byte with a host reader (up to there every record was paired, so nothing
+ * is parked: the state the reference's reader would be in).  DBTK_ING_CARRY / DBTK_ING_TAIL alone: align it, then continue
+ * at info.cut_byte with a host reader.  After a flagged block the ingest object accepts no further blocks. */
+typedef struct dbtk_ingest dbtk_ingest_t;
+#define DBTK_ING_DIRTY 1u   /* neighbouring records with different titles (or an odd record in between) */
+#define DBTK_ING_LINES 2u   /* more lines than the line table holds (lines shorter than 8 bytes on average) */
+#define DBTK_ING_CARRY 4u   /* the bytes after the last whole pair exceed the carry-over room (1 MB) */
+#define DBTK_ING_TAIL  8u   /* the input does not end with a whole pair */
+typedef struct dbtk_ingest_info {
+    uint32_t flags, npairs, nkept, max_read_len;  /* pairs of records in the block; pairs kept (both reads >= min_read_size) */
+    uint64_t first_byte, cut_byte;                /* input offsets (first submitted byte = 0) of the block's first record and
+                                                     of the first byte after its last whole pair */
+    uint64_t seq_bytes;
+} dbtk_ingest_info_t;
+/* kept pair q of a block: where its (pruned) title, reads and quality strings lie in the slot's block buffer
+ * (dbtk_ingest_block); index 0 = read 2q (the record that completed the pair), 1 = read 2q + 1 (the parked one). */
+typedef struct dbtk_ingest_span { uint32_t title, title_len, seq[2], seq_len[2], qual[2], qual_len[2]; } dbtk_ingest_span_t;
+/* with_spans: dbtk_ingest_spans will be called (the per-pair spans are then made with every block). */
+dbtk_status_t dbtk_ingest_create(dbtk_ctx_t* ctx, uint32_t fastq, uint32_t min_read_size, uint64_t chunk_bytes, uint32_t nslots,
+                                 uint32_t with_spans, dbtk_ingest_t** out);
+void          dbtk_ingest_free(dbtk_ingest_t* ing);
+void*         dbtk_ingest_chunk_buffer(dbtk_ingest_t* ing, uint32_t slot);  /* pinned, chunk_bytes: read the chunk into it */
+const void*   dbtk_ingest_block(dbtk_ingest_t* ing, uint32_t slot);         /* what the spans are offsets into (valid after wait) */
+dbtk_status_t dbtk_ingest_submit(dbtk_ingest_t* ing, uint32_t slot, uint64_t nbytes, int last);
+dbtk_status_t dbtk_ingest_wait(dbtk_ingest_t* ing, uint32_t slot, dbtk_ingest_info_t* info);
+dbtk_status_t dbtk_ingest_align(dbtk_ingest_t* ing, uint32_t slot, int sync, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec);
+dbtk_status_t dbtk_ingest_spans(dbtk_ingest_t* ing, uint32_t slot, dbtk_ingest_span_t* spans, uint64_t cap);
 
 /* Copy the accumulated results to the host.  counts[ntrkmers] is in
  * OUT.trkmc.ar order; kmc[nloci]; nmapread[nloci]; counters[DBTK_C_COUNT].

@@ -449,6 +449,39 @@ class Emu(pkg._HostSide):
         L.emu_walk_results.restype = C.c_uint64
         L.emu_walk_results.argtypes = [C.POINTER(abi.WalkRes), u32p, C.c_uint64]
 
+    def ingest(self, data: bytes, fastq, min_read, chunk, head=256, line_cap=None, grid=3):
+        """dbtk_ingest.h's kernel bodies over `data` cut into chunks: (headers, [(title, read 2q, read 2q + 1, qual 2q, qual 2q + 1)],
+        input bytes consumed).  Headers are dicts; the list holds the kept pairs of every block that was not flagged dirty."""
+        class Hdr(C.Structure):
+            _fields_ = [("base", C.c_uint32), ("nlines", C.c_uint32), ("npairs", C.c_uint32), ("nkept", C.c_uint32), ("flags", C.c_uint32),
+                        ("cut", C.c_uint32), ("carry", C.c_uint32), ("pad", C.c_uint32), ("flat_bytes", C.c_uint64), ("maxlen", C.c_uint64),
+                        ("pad2", C.c_uint64 * 3)]
+        L = self.L
+        L.emu_ingest.restype = C.c_int
+        L.emu_ingest.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Hdr), C.c_uint32,
+                                 u8p, u8p, C.c_uint64, u32p, C.c_uint64, u8p, C.c_uint64, u64p]
+        if line_cap is None:
+            line_cap = (head + chunk) // 8 + 64
+        maxb = len(data) // max(chunk, 1) + 3
+        hdrs = (Hdr * maxb)()
+        cap = len(data) + 64
+        flat, qual, titles = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        lens = np.zeros(cap // 2 + 2, np.uint32)
+        tot = np.zeros(4, np.uint64)
+        nb = L.emu_ingest(data, len(data), int(bool(fastq)), min_read, chunk, head, line_cap, grid, hdrs, maxb, _p(flat, u8p), _p(qual, u8p), cap,
+                          _p(lens, u32p), len(lens), _p(titles, u8p), cap, _p(tot, u64p))
+        assert nb >= 0, f"emu_ingest failed: {nb}"
+        H = [{f[0]: getattr(hdrs[i], f[0]) for f in Hdr._fields_[:10]} for i in range(nb)]
+        nflat, nlens, ntit = int(tot[0]), int(tot[1]), int(tot[2])
+        tl = bytes(titles[:ntit]).split(b"\n")[:-1] if ntit else []
+        o, pairs = 0, []
+        fb, qb = bytes(flat[:nflat]), bytes(qual[:nflat])
+        for q in range(nlens // 2):
+            l0, l1 = int(lens[2 * q]), int(lens[2 * q + 1])
+            pairs.append((tl[q], fb[o:o + l0], fb[o + l0:o + l0 + l1], qb[o:o + l0] if fastq else b"", qb[o + l0:o + l0 + l1] if fastq else b""))
+            o += l0 + l1
+        return H, pairs, int(tot[3])
+
     def probe_stats(self):
         """(general-probe-body runs, lean-probe-body runs since the last call, keys the last tables' level 1 turned away)"""
         out = np.zeros(3, np.uint64)

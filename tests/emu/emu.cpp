@@ -23,6 +23,7 @@
 
 #include "../../danbing-tk_amd/csrc/dbtk_internal.h"
 #include "../../danbing-tk_amd/csrc/dbtk_kernels.h"
+#include "../../danbing-tk_amd/csrc/dbtk_ingest.h"
 
 using namespace dbtk;
 
@@ -799,4 +800,71 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     return 0;
 }
 
+// The reader on the device (dbtk_ingest.h) on the emulated lanes: the input cut into chunks, every block through the
+// kernel bodies in the order dbtk_ingest_submit launches them, the carry-over handed from block to block.  Stops after the
+// first flagged block, as the library does.  Out: per block its header; of the kept pairs, concatenated over the blocks,
+// the reads back to back (`flat`), their lengths, the qualities the gather wrote ('!'-padded) and the pruned titles
+// ('\n'-separated).  Returns the number of blocks run (< 0: an output buffer was too small).
+int emu_ingest(const uint8_t* data, uint64_t n, uint32_t fastq, uint32_t min_read, uint32_t chunk, uint32_t head, uint32_t line_cap, uint32_t grid,
+               IngestHdr* hdrs, uint32_t max_blocks, uint8_t* flat, uint8_t* qual, uint64_t flat_cap, uint32_t* lens, uint64_t lens_cap,
+               uint8_t* titles, uint64_t titles_cap, uint64_t* totals) {
+    const uint32_t L = fastq ? 4 : 2, pair_cap = line_cap / (2 * L) + 1;
+    const uint64_t raw_bytes = ((uint64_t)head + chunk + 1 + 63) & ~63ull;
+    std::vector<uint64_t> raw_a(raw_bytes / 8 + 2, 0x4141414141414141ull), raw_b(raw_bytes / 8 + 2, 0x4141414141414141ull);  // (8-byte aligned: the bodies load 8 bytes at a time)
+    std::vector<uint32_t> tile(raw_bytes / ING_TILE + 2 + ING_SCAN_BLOCKS), nlpos(line_cap), pk(pair_cap + 2 * ING_SCAN_BLOCKS), kept(pair_cap);
+    std::vector<uint64_t> off(2 * (uint64_t)pair_cap + 1);
+    std::vector<uint8_t> bflat(raw_bytes + 64), bqual(raw_bytes + 64);
+    std::vector<dbtk_ingest_span_t> spans(pair_cap);
+    uint32_t base_w[2] = {head, head};
+    uint64_t pos = 0, nflat = 0, nlens = 0, ntit = 0;
+    uint32_t blk = 0;
+    int last_byte = '\n';
+    for (;; ++blk) {
+        if (blk >= max_blocks) return -1;
+        uint8_t* cur = (uint8_t*)((blk & 1) ? raw_b.data() : raw_a.data());
+        uint8_t* nxt = (uint8_t*)((blk & 1) ? raw_a.data() : raw_b.data());
+        uint64_t m = std::min<uint64_t>(chunk, n - pos);
+        const bool last = pos + m >= n;
+        memcpy(cur + head, data + pos, m);
+        if (m) last_byte = cur[head + m - 1];
+        pos += m;
+        if (last && last_byte != '\n') { cur[head + m++] = '\n'; last_byte = '\n'; }
+        IngestHdr& h = hdrs[blk];
+        memset(&h, 0, sizeof(h));
+        IngestArgs a;
+        memset(&a, 0, sizeof(a));
+        a.raw = cur; a.base_in = &base_w[blk & 1]; a.end = head + (uint32_t)m; a.L = L; a.min_read = min_read; a.last = last;
+        a.tile_cnt = tile.data(); a.nlpos = nlpos.data(); a.line_cap = line_cap; a.pk = pk.data(); a.kept = kept.data(); a.off = off.data();
+        a.flat = bflat.data(); a.qual = fastq ? bqual.data() : nullptr; a.spans = spans.data(); a.hdr = &h;
+        a.next_raw = nxt; a.base_out = &base_w[(blk + 1) & 1]; a.head = head;
+        const uint32_t g = grid ? grid : 3;
+        run_grid(g, 64, 0, [&](EmuX& x) { body_ing_count(x, a); });
+        run_grid(ING_SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_ing_scan(x, a, 0); });
+        run_grid(ING_SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_ing_scan(x, a, 1); });
+        run_grid(g, 64, 0, [&](EmuX& x) { body_ing_lines(x, a); });
+        run_grid(g, 64, 0, [&](EmuX& x) { body_ing_pairs(x, a); });
+        run_grid(ING_SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_ing_place(x, a, 0); });
+        run_grid(ING_SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_ing_place(x, a, 1); });
+        run_grid(g, 64, 0, [&](EmuX& x) { body_ing_gather(x, a); });
+        run_grid(1, 64, 0, [&](EmuX& x) { body_ing_carry(x, a); });
+        if (!(h.flags & (ING_F_DIRTY | ING_F_LINES_OVF))) {
+            if (nflat + h.flat_bytes > flat_cap || nlens + 2ull * h.nkept > lens_cap) return -2;
+            memcpy(flat + nflat, bflat.data(), h.flat_bytes);
+            if (fastq && qual) memcpy(qual + nflat, bqual.data(), h.flat_bytes);
+            nflat += h.flat_bytes;
+            for (uint64_t r = 0; r < 2ull * h.nkept; ++r) lens[nlens++] = (uint32_t)(off[r + 1] - off[r]);
+            for (uint32_t q = 0; q < h.nkept; ++q) {
+                const dbtk_ingest_span_t& S = spans[q];
+                if (ntit + S.title_len + 1 > titles_cap) return -3;
+                memcpy(titles + ntit, cur + S.title, S.title_len); ntit += S.title_len; titles[ntit++] = '\n';
+                // the spans point at what the gather copied
+                if (S.seq_len[0] != lens[nlens - 2ull * h.nkept + 2 * q] || memcmp(cur + S.seq[0], bflat.data() + off[2 * q], S.seq_len[0])) return -4;
+                if (S.seq_len[1] != lens[nlens - 2ull * h.nkept + 2 * q + 1] || memcmp(cur + S.seq[1], bflat.data() + off[2 * q + 1], S.seq_len[1])) return -4;
+            }
+        }
+        if (h.flags || last) { ++blk; break; }
+    }
+    totals[0] = nflat; totals[1] = nlens; totals[2] = ntit; totals[3] = pos;
+    return (int)blk;
+}
 }  // extern "C"

@@ -403,3 +403,47 @@ def test_sharded_ingest_equals_single_reader(tmp_path, fastq):
             cwd=d, env=dict(os.environ, DBTK_SHARD_MIN="0"))
     assert r.returncode == 0, r.stderr.decode()[-1500:]
     assert tuple(int(x) for x in r.stdout.decode().split()[1:]) == want
+
+
+@pytest.mark.gpu
+def test_cli_device_reader_equals_host_reader(tmp_path):
+    """The reader on the device (dbtk_ingest_*; default for a regular file) against the host reader (--host-ingest) of the same
+    binary, itself pinned to the reference's reader above: same stdout, same output files — interleaved FASTA in many small
+    blocks (records and titles straddle chunks), without a final newline, FASTQ extraction, no-record mode (asynchronous
+    blocks), and an input that stops being interleaved halfway (the host reader takes over at that byte)."""
+    loci = synth.make_loci(nloci=40, nhap=2, flank=500, seed=91, shared_frac=0.3)
+    d = str(tmp_path)
+    arr = synth.build_rpgg_arrays(loci, 21)
+    synth.write_rpgg_files(arr, os.path.join(d, "pan"))
+    reads = synth.sim_reads(loci, npairs=5000, seed=92, sub=0.006, indel=0.001, nrate=0.002, chimeric=0.2, background=0.2, short=0.03, with_qual=True)
+    synth.write_fasta(reads, os.path.join(d, "r.fa"))
+    synth.write_fasta(reads, os.path.join(d, "r.fq"), fastq=True)
+    data = open(os.path.join(d, "r.fa"), "rb").read()
+    open(os.path.join(d, "nonl.fa"), "wb").write(data[:-1])
+    recs = data.split(b">")[1:]
+    half = sum(len(r) + 1 for r in recs[:5000])
+    open(os.path.join(d, "half.fa"), "wb").write(data[:half] + b">orphan/1\n" + reads.seqs[0] + b"\n" + data[half:])
+    for flags, fn, chunk in ((["-cth", "45"], "r.fa", "20000"), (["-cth", "45"], "nonl.fa", "50000"), (["-cth", "45", "-ka"], "r.fa", "8192"),
+                             (["-cth", "30", "-e", "1"], "r.fq", "30000"), (["-cth", "30", "-kf", "8", "2"], "r.fq", None), (["-cth", "45"], "half.fa", "65536")):
+        outs = []
+        for tag, extra in (("host", ["--host-ingest"]), ("dev", [])):
+            env = dict(os.environ)
+            if chunk:
+                env["DBTK_INGEST_CHUNK"] = chunk
+            a = ["-k", "21"] + flags + ["-fq" if fn.endswith(".fq") else "-fa", fn, "-qs", "pan", "-o", tag] + extra
+            r = subprocess.run([CLI] + a, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert r.returncode == 0, r.stderr.decode()[-1500:]
+            outs.append(r)
+        assert outs[0].stdout == outs[1].stdout, (flags, fn)
+        ing = [l for l in outs[1].stderr.decode().splitlines() if l.startswith("ingest:")][0]
+        ndev = int(ing.split("device reader: ")[1].split()[0])
+        total = int(ing.split(" s for ")[1].split()[0])
+        if fn == "half.fa":
+            assert 0 < ndev < total and b"the host reader takes over" in outs[1].stderr
+        else:
+            assert ndev == total > 0, ing
+        assert [l for l in outs[0].stderr.decode().splitlines() if l[:1].isdigit() and " reads " in l] == \
+               [l for l in outs[1].stderr.decode().splitlines() if l[:1].isdigit() and " reads " in l]
+        if "-e" not in flags:
+            for ext in (".trkmc.ar", ".tr.summary.txt"):
+                assert open(os.path.join(d, "host" + ext), "rb").read() == open(os.path.join(d, "dev" + ext), "rb").read(), (flags, fn, ext)
