@@ -42,7 +42,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_SOURCES = ("dbtk_kernels.h", "dbtk_probe2.h", "dbtk_walk.h", "dbtk_tables.h", "dbtk_sort.h", "dbtk_assign.h", "dbtk_devx.h", "dbtk_hip.hip")
+KERNEL_SOURCES = ("dbtk_kernels.h", "dbtk_probe2.h", "dbtk_ingest.h", "dbtk_walk.h", "dbtk_tables.h", "dbtk_sort.h", "dbtk_assign.h", "dbtk_devx.h", "dbtk_hip.hip")
 
 
 def kernel_source_hash():
@@ -71,6 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-walk", action="store_true", help="skip the graph-walk mixes (threading = 2)")
     ap.add_argument("--k25-reads", type=int, default=10_000_000, help="reads per step of the k = 25 graph-walk mix (BASELINE config 4: pipeline/k25.json, -gc 85 3); 0 = skip it")
     ap.add_argument("--k25-parity-pairs", type=int, default=20000, help="pairs of the k = 25 mix whose oracle result (counts, counters, walk results) is compared")
+    ap.add_argument("--ingest-reads", type=int, default=64_000_000, help="reads of the FASTA the command line's batch loop is timed on (end_to_end.cli_ingest); 0 = skip")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="the timed step repeated for at least this long (`sustained`); 0 = skip")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (host buffers, CLI)")
     ap.add_argument("--lanes", type=int, default=1, choices=(1, 2, 3),
@@ -512,6 +513,39 @@ def main():
                 e2e["cli"] = dict(wall_s=tcli, returncode=r.returncode, reads=2 * nref, batch_loop=ing[0] if ing else None,
                                   note="this repo's danbing-tk on the reference leg's files: RPGG load + HBM tables + parse + pair + align + dump")
                 log(f"CLI end to end: {tcli:.1f}s wall; {ing[0] if ing else ''}")
+                # the batch loop on a file large enough for its steady state: the reader on the device (default for a regular file: the
+                # host only copies bytes, kernels find the records and pair the mates) and on the host (--host-ingest), same binary
+                if args.ingest_reads > 0:
+                    big = os.path.join(ref_dir, "reads_big.fa")
+                    t0 = time.perf_counter()
+                    with open(big, "wb") as out:
+                        part = 4_000_000
+                        for p0 in range(0, args.ingest_reads // 2, part):
+                            n = min(part, args.ingest_reads // 2 - p0)
+                            sq, _ = syn.reads(n, rlen=rlen, hit_frac=args.hit_frac, seed=1, first_pair=p0, nthreads=nth)
+                            syn.write_fasta(sq, n, os.path.join(ref_dir, "part.fa"), rlen=rlen, first_pair=p0)
+                            with open(os.path.join(ref_dir, "part.fa"), "rb") as f:
+                                shutil.copyfileobj(f, out, 64 << 20)
+                            del sq
+                    os.unlink(os.path.join(ref_dir, "part.fa"))
+                    tgen = time.perf_counter() - t0
+                    legs = {}
+                    for name, extra in (("device_reader", []), ("host_reader", ["--host-ingest"]), ("device_reader_again", [])):
+                        r = subprocess.run([cli, "-k", "21", "-kf", "4", "1", "-cth", "45", "-ka", "-fa", "reads_big.fa", "-qs", "pan", "-o", "big_" + name] + extra,
+                                           cwd=ref_dir, capture_output=True, text=True)
+                        ing = [l for l in r.stderr.splitlines() if l.startswith("ingest:")]
+                        rate = float(ing[0].split("(")[1].split()[0]) * 1e6 if ing and r.returncode == 0 else None
+                        legs[name] = dict(returncode=r.returncode, value=rate, unit="reads/s", batch_loop=ing[0] if ing else None,
+                                          detail=([l for l in r.stderr.splitlines() if l.startswith("device reader:")] or [None])[0])
+                    same = all(open(os.path.join(ref_dir, "big_device_reader" + e), "rb").read() == open(os.path.join(ref_dir, "big_host_reader" + e), "rb").read()
+                               for e in (".trkmc.ar", ".tr.summary.txt"))
+                    e2e["cli_ingest"] = dict(legs, reads=args.ingest_reads, fasta_bytes=os.path.getsize(big), same_outputs=same,
+                                             note="batch loop of this repo's danbing-tk (-ka) on an interleaved FASTA in /dev/shm, first byte read to last kernel done: "
+                                                  "reader on the device vs reader on the host; the host reader is bound by the container's 16-CPU quota")
+                    os.unlink(big)
+                    log(f"CLI batch loop on {args.ingest_reads / 1e6:.0f} M reads ({e2e['cli_ingest']['fasta_bytes'] / 1e9:.1f} GB, written in {tgen:.0f}s): device reader "
+                        f"{(legs['device_reader']['value'] or 0) / 1e6:.0f} / {(legs['device_reader_again']['value'] or 0) / 1e6:.0f} M reads/s, host reader "
+                        f"{(legs['host_reader']['value'] or 0) / 1e6:.0f} M reads/s, same outputs: {same}")
                 if do_walk and nhit and os.path.exists(os.path.join(ref_dir, "pan.graph.umap")):
                     # config 5: the walk with and without the -ae emit (records formatted + deflated on host threads while the GPU runs
                     # on), on an all-hit read file so that every pair is walked and printed

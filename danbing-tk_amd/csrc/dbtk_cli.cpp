@@ -1039,7 +1039,7 @@ int main(int argc, char* argv[]) {
             }
         };
         std::vector<std::thread> ios;
-        int nio = (int)std::min<uint64_t>(nchunks, std::max(1u, std::min(8u, cpus / 2)));
+        int nio = (int)std::min<uint64_t>(nchunks, std::max(1u, std::min(8u, cpus / 2 / (unsigned)std::max(1, npipes))));  // (the pipelines share the host's threads)
         if (const char* e = getenv("DBTK_INGEST_READERS")) { const int v = atoi(e); if (v > 0) nio = v; }
         for (int i = 0; i < nio; ++i) ios.emplace_back(io);
         auto release = [&] { { std::lock_guard<std::mutex> l(m); ++nreleased; } cv.notify_all(); };
@@ -1146,6 +1146,31 @@ int main(int argc, char* argv[]) {
                     p = l1 + 1 - buf.data();
                 }
                 if (found == n) { c.clear(); break; }  // (no record start in sight: lines longer than the window) -> one range
+                {   // on a PAIR boundary where the file is interleaved: if the record found here carries the title of the record before
+                    // it... which is not in the window; equivalently: if records 0 and 1 from here have different titles but 1 and 2 the
+                    // same, record 0 is the second mate of the pair the cut fell into -> start one record later.  (The device reader needs
+                    // its range to start with a pair; the host reader saves a round through the cross-range pairing.)
+                    const size_t Lr = fq ? 4 : 2;
+                    size_t tb[3], tl[3], q = found;
+                    int have = 0;
+                    for (; have < 3 && q < n; ++have) {
+                        const char* e = (const char*)memchr(buf.data() + q, '\n', n - q);
+                        if (!e) break;
+                        tb[have] = q; tl[have] = (size_t)(e - (buf.data() + q));
+                        if (tl[have] >= 2 && buf[q + tl[have] - 2] == '/' && (buf[q + tl[have] - 1] == '1' || buf[q + tl[have] - 1] == '2')) tl[have] -= 2;  // prunePEinfo
+                        size_t r = q;
+                        bool whole = true;
+                        for (size_t l = 0; l < Lr; ++l) {
+                            const char* e2 = (const char*)memchr(buf.data() + r, '\n', n - r);
+                            if (!e2) { whole = false; break; }
+                            r = (size_t)(e2 - buf.data()) + 1;
+                        }
+                        if (!whole) { ++have; break; }
+                        q = r;
+                    }
+                    auto same = [&](int i, int j) { return tl[i] == tl[j] && memcmp(buf.data() + tb[i], buf.data() + tb[j], tl[i]) == 0; };
+                    if (have == 3 && !same(0, 1) && same(1, 2)) found = tb[1];
+                }
                 c.push_back(at + found);
             }
             if (f) fclose(f);

@@ -447,3 +447,17 @@ def test_cli_device_reader_equals_host_reader(tmp_path):
         if "-e" not in flags:
             for ext in (".trkmc.ar", ".tr.summary.txt"):
                 assert open(os.path.join(d, "host" + ext), "rb").read() == open(os.path.join(d, "dev" + ext), "rb").read(), (flags, fn, ext)
+    # three byte ranges, each with its own device reader and context on the one GPU: the cuts fall on pair boundaries, so every
+    # range is interleaved from its first byte and nothing is left to the cross-range pairing
+    env = dict(os.environ, DBTK_SHARD_MIN="0", DBTK_INGEST_CHUNK="100000")
+    r3 = subprocess.run([CLI, "-k", "21", "-cth", "45", "--ingest-shards", "3", "-fa", "r.fa", "-qs", "pan", "-o", "sh3"], cwd=d, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, env=env)
+    assert r3.returncode == 0, r3.stderr.decode()[-1500:]
+    r1 = subprocess.run([CLI, "-k", "21", "-cth", "45", "-fa", "r.fa", "-qs", "pan", "-o", "one", "--host-ingest"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r1.returncode == 0
+    ing = [l for l in r3.stderr.decode().splitlines() if l.startswith("ingest:")][0]
+    assert int(ing.split("device reader: ")[1].split()[0]) == int(ing.split(" s for ")[1].split()[0]) > 0, ing
+    assert b"cross-range pairing: 0 reads" in r3.stderr
+    assert sorted(r3.stdout.splitlines()) == sorted(r1.stdout.splitlines())
+    for ext in (".trkmc.ar", ".tr.summary.txt"):
+        assert open(os.path.join(d, "sh3" + ext), "rb").read() == open(os.path.join(d, "one" + ext), "rb").read(), ext
