@@ -335,7 +335,7 @@ class Ingest:
         L.dbtk_ingest_block.restype = C.c_void_p
         L.dbtk_ingest_submit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_int]
         L.dbtk_ingest_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.IngestInfo)]
-        L.dbtk_ingest_align.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(abi.PairRec), C.c_uint64, u64p]
+        L.dbtk_ingest_align.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(abi.PairRec), C.c_uint64, u64p]
         L.dbtk_ingest_spans.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.IngestSpan), C.c_uint64]
         self.h = C.c_void_p()
         ctx._lib._chk(L.dbtk_ingest_create(ctx.h, int(bool(fastq)), int(min_read_size), self.chunk, self.nslots, int(bool(with_spans)), C.byref(self.h)))
@@ -353,12 +353,12 @@ class Ingest:
         self.ctx._lib._chk(self.L.dbtk_ingest_wait(self.h, slot, C.byref(info)))
         return info
 
-    def align(self, slot, info, sync=True):
+    def align(self, slot, info, sync=True, ctx=None):
         p = self.ctx.params
         want = sync and bool(p.trace or p.okam or p.extract) and info.nkept
         recs = (abi.PairRec * info.nkept)() if want else None
         nrec = C.c_uint64(0)
-        self.ctx._lib._chk(self.L.dbtk_ingest_align(self.h, slot, int(sync), recs, info.nkept if want else 0, C.byref(nrec)))
+        self.ctx._lib._chk(self.L.dbtk_ingest_align(self.h, slot, ctx.h if ctx else None, int(sync), recs, info.nkept if want else 0, C.byref(nrec)))
         return recs, int(nrec.value)
 
     def spans(self, slot, info):
@@ -369,6 +369,14 @@ class Ingest:
         g = lambda o, n: C.string_at(base + o, n)
         return [(g(s.title, s.title_len), g(s.seq[0], s.seq_len[0]), g(s.seq[1], s.seq_len[1]), g(s.qual[0], s.qual_len[0]), g(s.qual[1], s.qual_len[1]))
                 for s in sp[:info.nkept]]
+
+    def aln_lines(self, slot, gz=False, ctx=None):
+        """(bytes, lines, text bytes): the -a / -ae lines of the block aligned last, as text or as gzip members."""
+        L = self.L
+        L.dbtk_ingest_aln_lines.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), u64p, u64p, u64p]
+        data, nb, nl, tb = C.c_void_p(), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self.ctx._lib._chk(L.dbtk_ingest_aln_lines(self.h, slot, ctx.h if ctx else None, int(gz), C.byref(data), C.byref(nb), C.byref(nl), C.byref(tb)))
+        return (C.string_at(data.value, nb.value) if nb.value else b""), int(nl.value), int(tb.value)
 
     def close(self):
         if self.h:
@@ -384,7 +392,7 @@ EXPORTS = [
     "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_aln_text", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
     "dbtk_thread_batch", "dbtk_ctx_walk_results", "dbtk_ctx_aln_records", "dbtk_aln_format",
     "dbtk_ingest_create", "dbtk_ingest_free", "dbtk_ingest_chunk_buffer", "dbtk_ingest_block", "dbtk_ingest_submit", "dbtk_ingest_wait",
-    "dbtk_ingest_align", "dbtk_ingest_spans",
+    "dbtk_ingest_align", "dbtk_ingest_spans", "dbtk_ingest_aln_lines",
 ]
 
 # include/dbtk_pred.h (the danbing-tk-pred step)

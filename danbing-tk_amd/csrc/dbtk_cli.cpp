@@ -198,6 +198,7 @@ struct Batch {  // one batch on its way through the stages; read r = flat[off[r]
     // block, and the per-pair spans say where
     const char* blk = nullptr;
     std::vector<dbtk_ingest_span_t> spans;
+    const char* aln_dev = nullptr; uint64_t aln_dev_bytes = 0;  // -a / -ae lines the device made (text or gzip members), in the slot's pinned buffer
     typedef std::pair<const char*, size_t> Span;
     Span title_s(uint64_t p) const { return blk ? Span(blk + spans[p].title, spans[p].title_len) : Span(tar.data() + toff[p], toff[p + 1] - toff[p]); }
     Span seq_s(uint64_t r) const { return blk ? Span(blk + spans[r >> 1].seq[r & 1], spans[r >> 1].seq_len[r & 1]) : Span((const char*)flat.data() + off[r], off[r + 1] - off[r]); }
@@ -437,6 +438,7 @@ int main(int argc, char* argv[]) {
     std::mutex out_m, tot_m;  // stdout / the gzip file (one batch at a time); the totals below
     std::atomic<uint64_t> rec_us{0}, fmt_us{0}, gz_us{0};  // -a / -ae: record read-back (wall), formatting and deflate (summed over the emit threads)
     uint64_t nReads = 0, dev_ingest_reads = 0;
+    std::atomic<uint64_t> dev_aln_text{0};  // bytes of -a / -ae text the device assembled (and compressed)
     std::vector<dbtk_ingest_t*> spent_ingests;
     double read_busy = 0, cut_busy = 0, pair_busy = 0, gpu_busy = 0, write_busy = 0;  // seconds each stage spent working (not waiting), summed over the shards
     int nsplit_used = 0;
@@ -530,6 +532,10 @@ int main(int argc, char* argv[]) {
             if (fwrite(c.data(), 1, c.size(), f) != c.size()) die_assert(gzout ? "write to the --aln-gz file failed" : "write to stdout failed");
             aln_bytes += c.size();
         }
+        if (b.aln_dev_bytes) {
+            if (fwrite(b.aln_dev, 1, b.aln_dev_bytes, f) != b.aln_dev_bytes) die_assert(gzout ? "write to the --aln-gz file failed" : "write to stdout failed");
+            aln_bytes += b.aln_dev_bytes;
+        }
     };
     auto emit = [&](const Batch& b) {
         std::string out;
@@ -591,6 +597,7 @@ int main(int argc, char* argv[]) {
     // in range order — for titles that occur at most twice this is exactly the single reader's outcome.
     struct Left { std::string title, seq, qual; };
     int npipes = 1;  // ingest pipelines running side by side (set once the ranges are known)
+    int nshards_now = 1;
     auto run_shard = [&](const int shard, const int gpu0, const int ngpu_here, const uint64_t lo, const uint64_t hi, std::vector<Left>& leftovers) {
     Reader in;
     in.f = fopen(o.fastxFname.c_str(), "rb");
@@ -993,7 +1000,8 @@ int main(int argc, char* argv[]) {
     auto run_device_ingest = [&](dbtk_ctx_t* cx, const uint64_t lo, const uint64_t hi, uint64_t* resume) {
         size_t CH = 32u << 20;
         if (const char* e = getenv("DBTK_INGEST_CHUNK")) { const long v = atol(e); if (v >= 4096) CH = (size_t)v; }  // (tests: many small blocks)
-        const bool want_out = want_recs;  // records need titles and reads on the host: the slot's bytes stay until they are written
+        const bool want_out = want_recs || emit_aln;  // records need titles and reads on the host: the slot's bytes stay until they are written
+                                                      // (-a / -ae lines are made on the device, from the spans)
         uint32_t NS = 12;  // chunks on their way at once (being read, copied, parsed, or waiting for their records to be written): the readers
                            // run this many chunks ahead of the oldest one not yet done with
         if (const char* e = getenv("DBTK_INGEST_SLOTS")) { const int v = atoi(e); if (v >= 2 && v <= 64) NS = (uint32_t)v; }
@@ -1047,15 +1055,61 @@ int main(int argc, char* argv[]) {
         outq.cap = NS;
         std::thread writer;
         if (want_out)
-            writer = std::thread([&] {
-                std::unique_ptr<Batch> b;
-                while (outq.pop(b)) {
-                    const double t0 = now();
-                    emit(*b);
-                    wb += now() - t0;
-                    release();
+            writer = std::thread([&] {  // in block order (the workers below finish in any order)
+                std::map<uint64_t, std::unique_ptr<Batch>> waiting;
+                uint64_t next = 0;
+                std::unique_ptr<Batch> got;
+                while (outq.pop(got)) {
+                    waiting[got->index] = std::move(got);
+                    for (auto it = waiting.find(next); it != waiting.end(); it = waiting.find(next)) {
+                        const double t0 = now();
+                        emit(*it->second);
+                        wb += now() - t0;
+                        waiting.erase(it);
+                        ++next;
+                        release();
+                    }
                 }
             });
+        // a parsed block through the hot path, with what the writer needs: the records, the -a / -ae lines (made and compressed on the
+        // device), the spans of titles and reads.  With -a / -ae several worker threads do this side by side, each with a context of
+        // its own (the contexts of a GPU share its tables): one's wait for its kernels and copies overlaps the others' kernels.
+        struct Work { uint64_t index; uint32_t slot; dbtk_ingest_info_t info; };
+        std::mutex gb_m;
+        auto process = [&](dbtk_ctx_t* wc, const Work& w) {
+            const double t0 = now();
+            std::unique_ptr<Batch> b(new Batch);
+            b->index = w.index; b->nreads = 2 * (uint64_t)w.info.nkept;
+            if (want_recs) b->recs.resize(w.info.nkept);
+            const time_t t2 = time(nullptr);
+            if (dbtk_ingest_align(ing, w.slot, wc, 1, want_recs ? b->recs.data() : nullptr, want_recs ? w.info.nkept : 0, &b->nrec)) die_assert(std::string("align: ") + dbtk_last_error());
+            b->gpu_sec = (long)(time(nullptr) - t2);
+            if (emit_aln) {  // the block's lines, text or gzip members, straight from the device
+                const double tr0 = now();
+                uint64_t nb = 0, nl = 0, tb = 0;
+                const void* data = nullptr;
+                if (dbtk_ingest_aln_lines(ing, w.slot, wc, gzout ? 1 : 0, &data, &nb, &nl, &tb)) die_assert(std::string("alignment lines: ") + dbtk_last_error());
+                b->aln_dev = (const char*)data; b->aln_dev_bytes = nb;  // (in the slot's pinned buffer until the slot is released)
+                b->naln = nl;
+                rec_us += (uint64_t)((now() - tr0) * 1e6);
+                dev_aln_text += tb;
+            }
+            if (want_recs) {
+                b->spans.resize(w.info.nkept);
+                if (dbtk_ingest_spans(ing, w.slot, b->spans.data(), w.info.nkept)) die_assert(std::string("ingest: ") + dbtk_last_error());
+            }
+            b->blk = (const char*)dbtk_ingest_block(ing, w.slot);
+            { std::lock_guard<std::mutex> l(gb_m); gb += now() - t0; }
+            outq.push(std::move(b));
+        };
+        std::vector<dbtk_ctx_t*> wctx{cx};  // the contexts the blocks may be aligned with: this pipeline's, and with -a / -ae the further ones of its GPU
+        if (emit_aln && nshards_now == 1)
+            for (size_t i = 1; i < ctx.size() && (int)wctx.size() < aln_aligners; ++i) if ((int)(i % (size_t)o.ngpus) == 0 && ctx[i] != cx) wctx.push_back(ctx[i]);
+        Chan<Work> wq;
+        wq.cap = NS;
+        std::vector<std::thread> workers;
+        if (want_out && wctx.size() > 1)
+            for (dbtk_ctx_t* wc : wctx) workers.emplace_back([&, wc] { Work w; while (wq.pop(w)) process(wc, w); });
         uint64_t jsub = 0, jaln = 0, nR = 0;
         *resume = hi;
         const bool sync = want_out || P.bubbles;  // (-bu replays every batch's novel edges on the host)
@@ -1076,22 +1130,14 @@ int main(int argc, char* argv[]) {
             if (dbtk_ingest_wait(ing, slot, &info)) die_assert(std::string("ingest: ") + dbtk_last_error());
             wait_s += now() - t0;
             if (jaln == 0) first_s = now() - ts0;
-            if (info.flags & (DBTK_ING_DIRTY | DBTK_ING_LINES)) { *resume = lo + info.first_byte; gb += now() - t0; break; }
+            if (info.flags & (DBTK_ING_DIRTY | DBTK_ING_LINES)) { *resume = lo + info.first_byte; std::lock_guard<std::mutex> l(gb_m); gb += now() - t0; break; }
             if (want_out) {
-                std::unique_ptr<Batch> b(new Batch);
-                b->index = jaln; b->nreads = 2 * (uint64_t)info.nkept;
-                b->recs.resize(info.nkept);
-                const time_t t2 = time(nullptr);
-                if (dbtk_ingest_align(ing, slot, 1, b->recs.data(), info.nkept, &b->nrec)) die_assert(std::string("align: ") + dbtk_last_error());
-                b->gpu_sec = (long)(time(nullptr) - t2);
-                b->spans.resize(info.nkept);
-                if (dbtk_ingest_spans(ing, slot, b->spans.data(), info.nkept)) die_assert(std::string("ingest: ") + dbtk_last_error());
-                b->blk = (const char*)dbtk_ingest_block(ing, slot);
-                gb += now() - t0;
-                outq.push(std::move(b));
+                { std::lock_guard<std::mutex> l(gb_m); gb += now() - t0; }
+                const Work w{jaln, slot, info};
+                if (workers.empty()) process(cx, w); else wq.push(w);
             } else {
-                if (dbtk_ingest_align(ing, slot, sync ? 1 : 0, nullptr, 0, nullptr)) die_assert(std::string("align: ") + dbtk_last_error());
-                gb += now() - t0;
+                if (dbtk_ingest_align(ing, slot, nullptr, sync ? 1 : 0, nullptr, 0, nullptr)) die_assert(std::string("align: ") + dbtk_last_error());
+                { std::lock_guard<std::mutex> l(gb_m); gb += now() - t0; }
                 release();
             }
             nR += 2 * (uint64_t)info.nkept;
@@ -1099,13 +1145,15 @@ int main(int argc, char* argv[]) {
             if (info.flags) { *resume = lo + info.cut_byte; break; }
             ++jaln;
         }
+        wq.close();
+        for (auto& t : workers) t.join();
         { std::lock_guard<std::mutex> l(m); stop = true; }
         cv.notify_all();
         for (auto& t : ios) t.join();
         outq.close();
         if (writer.joinable()) writer.join();
         const double tf0 = now();
-        if (dbtk_ctx_synchronize(cx)) die_assert(dbtk_last_error());  // the kernels still in flight
+        for (dbtk_ctx_t* wc : wctx) if (dbtk_ctx_synchronize(wc)) die_assert(dbtk_last_error());  // the kernels still in flight
         { std::lock_guard<std::mutex> lk(tot_m); spent_ingests.push_back(ing); }  // (its pinned and device buffers are freed at exit, not inside the batch loop)
         close(fd);
         fprintf(stderr, "device reader: %llu blocks of %zu MB on %d reader threads; setup %.3f s, first block parsed after %.3f s, waiting for parsed blocks %.3f s, drain %.3f s\n",
@@ -1179,6 +1227,7 @@ int main(int argc, char* argv[]) {
     }
     const int nshards = (int)cuts.size() - 1;
     npipes = nshards;
+    nshards_now = nshards;
     // more ranges than GPUs: range i gets a context of its own on GPU i % ngpus (the contexts of a GPU share its tables;
     // an aligner thread and its context belong together: dbtk_align_batch is re-entrant per context, not within one)
     if (!o.parseOnly)
@@ -1201,7 +1250,9 @@ int main(int argc, char* argv[]) {
         // titles, -tb replays batches from host copies of the reads, -a / -ae has its own several-contexts-per-GPU emit path)
         struct stat sb;
         const bool is_file = stat(o.fastxFname.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
-        bool dev_ingest = !o.parseOnly && !o.hostIngest && !o.simmode && !P.trackbait && !emit_aln && is_file;
+        // (-a / -ae: the lines are assembled and gzip-compressed on the device too — a Huffman-only deflate, about zlib's level 1 in size; an
+        // explicit --gz-level other than 1 keeps the host's zlib, and with it the host reader)
+        bool dev_ingest = !o.parseOnly && !o.hostIngest && !o.simmode && !P.trackbait && (!emit_aln || o.gzLevel == 1) && is_file;
         if (const char* e = getenv("DBTK_DEVICE_INGEST")) if (atoi(e) == 0) dev_ingest = false;
         auto one = [&](int i) {
             uint64_t lo = nshards == 1 ? 0 : cuts[i];
@@ -1285,8 +1336,10 @@ int main(int argc, char* argv[]) {
     if (fflush(stdout) != 0) die_assert("write to stdout failed");
     if (gzout && fclose(gzout) != 0) die_assert("closing the --aln-gz file failed");
     const int nsplit = nsplit_used;
-    if (emit_aln) fprintf(stderr, "emit: record read-back %.2f s; formatting %.2f thread-s, deflate %.2f thread-s on %d emit threads (%u usable CPUs); %llu bytes out\n",
-                          rec_us.load() / 1e6, fmt_us.load() / 1e6, gz_us.load() / 1e6, emit_threads, cpus, (unsigned long long)aln_bytes);
+    if (emit_aln) fprintf(stderr, "emit: record read-back %.2f s; formatting %.2f thread-s, deflate %.2f thread-s on %d emit threads (%u usable CPUs); %llu bytes out; "
+                          "%llu bytes of text assembled%s on the device\n",
+                          rec_us.load() / 1e6, fmt_us.load() / 1e6, gz_us.load() / 1e6, emit_threads, cpus, (unsigned long long)aln_bytes,
+                          (unsigned long long)dev_aln_text.load(), gzout ? " and compressed" : "");
     fprintf(stderr, "ingest: %.2f s for %llu reads (%.2f M reads/s); busy: reading %.2f s, cutting %.2f s, pairing %.2f s, align %.2f s over %d GPU thread(s), write %.2f s; %d splitter threads; device reader: %llu reads\n",
             now() - loop_t0, (unsigned long long)nReads, nReads / (now() - loop_t0) / 1e6, read_busy, cut_busy, pair_busy, gpu_busy, o.ngpus, write_busy, nsplit,
             (unsigned long long)dev_ingest_reads);

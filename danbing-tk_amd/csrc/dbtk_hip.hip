@@ -24,6 +24,7 @@
 #include "dbtk_internal.h"
 #include "dbtk_kernels.h"
 #include "dbtk_ingest.h"
+#include "dbtk_gz.h"
 
 using namespace dbtk;
 
@@ -96,6 +97,17 @@ __global__ void __launch_bounds__(256) k_ing_pairs(IngestArgs a) { DevX x{nullpt
 __global__ void __launch_bounds__(64) k_ing_place(IngestArgs a, int step) { DevX x{nullptr}; body_ing_place(x, a, step); }
 __global__ void __launch_bounds__(64) k_ing_gather(IngestArgs a) { DevX x{nullptr}; body_ing_gather(x, a); }
 __global__ void __launch_bounds__(256) k_ing_carry(IngestArgs a) { DevX x{nullptr}; body_ing_carry(x, a); }
+// the -a / -ae writer on the device (dbtk_gz.h): the lines of a parsed and walked block, and their gzip members
+__global__ void __launch_bounds__(256) k_aln_len(AlnLineArgs a) { DevX x{nullptr}; body_aln_len(x, a); }
+__global__ void __launch_bounds__(64) k_aln_scan(AlnLineArgs a, int step) { DevX x{nullptr}; body_aln_scan(x, a, step); }
+__global__ void __launch_bounds__(64) k_aln_write(AlnLineArgs a) { DevX x{nullptr}; body_aln_write(x, a); }
+__global__ void __launch_bounds__(64) k_gz_member(GzArgs a) {
+    __shared__ GzSmem sm;
+    DevX x{&sm};
+    body_gz_member(x, a);
+}
+__global__ void __launch_bounds__(64) k_gz_scan(GzArgs a, int step) { DevX x{nullptr}; body_gz_scan(x, a, step); }
+__global__ void __launch_bounds__(64) k_gz_pack(GzArgs a) { DevX x{nullptr}; body_gz_pack(x, a); }
 // the graph walk (dbtk_walk.h): one wave per read (function mode) / per pair (the hot path with threading = 2)
 #ifndef DBTK_WALK_WAVES
 #define DBTK_WALK_WAVES 2  // waves per SIMD the pair kernel is compiled for (register budget 512 / this): 3, 4 and 5 measured no faster
@@ -1519,12 +1531,26 @@ struct dbtk_ingest {
     uint64_t submitted = 0;       // input bytes submitted so far
     uint64_t nsubmitted = 0, nwaited = 0;
     int last_byte = '\n';
+    // -a / -ae lines (dbtk_ingest_aln_lines): device buffers per aligning context (several contexts may work on different slots at once)
+    struct LinesBuf {
+        uint32_t* d_linelen = nullptr; uint64_t linelen_cap = 0;
+        uint8_t* d_text = nullptr; uint64_t text_cap = 0;
+        uint8_t* d_gzout = nullptr; uint64_t gzout_cap = 0;
+        uint8_t* d_packed = nullptr; uint64_t packed_cap = 0;
+        uint32_t* d_outlen = nullptr; uint64_t outlen_cap = 0;
+        uint64_t* d_totals = nullptr;   // text bytes, lines, packed bytes
+        uint64_t* h_totals = nullptr;   // pinned
+    };
+    std::map<dbtk_ctx*, LinesBuf> lines;
+    std::mutex lines_m;
+    uint32_t* d_crctab = nullptr;
     std::vector<uint8_t> carry_host;  // host copy of the bytes the last waited block handed on (the spans of the next block reach into them)
     struct Slot {
         uint8_t* h_raw = nullptr; uint8_t* d_raw = nullptr;
         uint32_t* d_tile = nullptr; uint32_t* d_nlpos = nullptr; uint32_t* d_pk = nullptr; uint32_t* d_kept = nullptr;
         uint64_t* d_off = nullptr; uint8_t* d_flat = nullptr; uint8_t* d_qual = nullptr; dbtk_ingest_span_t* d_spans = nullptr;
         hipEvent_t parsed = nullptr, aligned = nullptr, copied = nullptr;
+        uint8_t* h_lines = nullptr; uint64_t h_lines_cap = 0;  // pinned: the block's -a / -ae lines as the caller's writer sees them
         bool has_aligned = false, waited = false, pending = false;
         uint32_t end = 0; uint64_t file_off = 0; int last = 0;
         IngestHdr hdr;
@@ -1540,12 +1566,20 @@ static void ingest_free_impl(dbtk_ingest* g) {
     if (g->c) (void)sync_all(g->c);
     for (auto& S : g->slots) {
         if (S.h_raw) (void)hipHostFree(S.h_raw);
+        if (S.h_lines) (void)hipHostFree(S.h_lines);
         void* ptrs[] = {S.d_raw, S.d_tile, S.d_nlpos, S.d_pk, S.d_kept, S.d_off, S.d_flat, S.d_qual, S.d_spans};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (S.parsed) (void)hipEventDestroy(S.parsed);
         if (S.aligned) (void)hipEventDestroy(S.aligned);
         if (S.copied) (void)hipEventDestroy(S.copied);
     }
+    for (auto& kv : g->lines) {
+        dbtk_ingest::LinesBuf& B = kv.second;
+        void* ptrs[] = {B.d_linelen, B.d_text, B.d_gzout, B.d_packed, B.d_outlen, B.d_totals};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (B.h_totals) (void)hipHostFree(B.h_totals);
+    }
+    if (g->d_crctab) (void)hipFree(g->d_crctab);
     if (g->d_basew) (void)hipFree(g->d_basew);
     if (g->d_hdr) (void)hipFree(g->d_hdr);
     if (g->h_hdr) (void)hipHostFree(g->h_hdr);
@@ -1671,7 +1705,12 @@ static dbtk_status_t dbtk_ingest_wait_impl(dbtk_ingest_t* g, uint32_t slot, dbtk
     return DBTK_OK;
 }
 
-static dbtk_status_t dbtk_ingest_align_impl(dbtk_ingest_t* g, uint32_t slot, int sync, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
+static dbtk_status_t ingest_ctx(dbtk_ingest_t* g, dbtk_ctx_t* cx, dbtk_ctx** out) {
+    *out = cx ? cx : g->c;
+    if (cx && (cx->device != g->c->device || cx->g != g->c->g)) { set_error("dbtk_ingest: the context must be on the ingest's device and of its RPGG"); return DBTK_ERR_ARG; }
+    return DBTK_OK;
+}
+static dbtk_status_t dbtk_ingest_align_impl(dbtk_ingest_t* g, uint32_t slot, dbtk_ctx_t* cx, int sync, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
     if (!g || slot >= g->nslots) { set_error("null argument"); return DBTK_ERR_ARG; }
     if (nrec) *nrec = 0;
     dbtk_ingest::Slot& S = g->slots[slot];
@@ -1683,7 +1722,8 @@ static dbtk_status_t dbtk_ingest_align_impl(dbtk_ingest_t* g, uint32_t slot, int
         set_error("read longer than DBTK_MAX_READ_LEN (256): the reference's PE_KMC is uint8_t, src/aQueryFasta_thread.cpp:42");
         return DBTK_ERR_READ_TOO_LONG;
     }
-    dbtk_ctx* c = g->c;
+    dbtk_ctx* c = nullptr;
+    { const dbtk_status_t sc = ingest_ctx(g, cx, &c); if (sc) return sc; }
     HIPCHK(hipSetDevice(c->device));
     if (sync) return run_batch_sync(c, S.d_flat, S.d_off, S.d_qual, ~0ull, h.nkept, (uint32_t)h.maxlen, nullptr, nullptr, nullptr, recs, rec_cap, nrec);
     if (c->P.bubbles) { set_error("dbtk_ingest_align: -bu is replayed batch by batch on the host: sync = 1"); return DBTK_ERR_ARG; }
@@ -1703,6 +1743,96 @@ static dbtk_status_t dbtk_ingest_spans_impl(dbtk_ingest_t* g, uint32_t slot, dbt
     if (cap < S.hdr.nkept) { set_error("dbtk_ingest_spans: buffer too small"); return DBTK_ERR_OVERFLOW; }
     HIPCHK(hipSetDevice(g->c->device));
     if (S.hdr.nkept) HIPCHK(hipMemcpy(spans, S.d_spans, (size_t)S.hdr.nkept * sizeof(dbtk_ingest_span_t), hipMemcpyDeviceToHost));
+    return DBTK_OK;
+}
+
+// -a / -ae with the device reader: the lines of the block the context aligned last (dbtk_gz.h)
+static dbtk_status_t dbtk_ingest_aln_lines_impl(dbtk_ingest_t* g, uint32_t slot, dbtk_ctx_t* cx, int gz, const void** data, uint64_t* nbytes, uint64_t* nlines,
+                                                uint64_t* text_bytes) {
+    if (!g || slot >= g->nslots || !nbytes || !data) { set_error("null argument"); return DBTK_ERR_ARG; }
+    *nbytes = 0; *data = nullptr;
+    if (nlines) *nlines = 0;
+    if (text_bytes) *text_bytes = 0;
+    dbtk_ingest::Slot& S = g->slots[slot];
+    dbtk_ctx* c = nullptr;
+    { const dbtk_status_t sc = ingest_ctx(g, cx, &c); if (sc) return sc; }
+    if (!g->with_spans || !S.waited) { set_error("dbtk_ingest_aln_lines: needs an ingest created with spans and a block that has been waited for"); return DBTK_ERR_ARG; }
+    const uint32_t nk = S.hdr.nkept;
+    if (!nk || !c->txt_cap || !c->d_txt || c->last_walk_npairs != nk) return DBTK_OK;  // no text records: no lines
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    dbtk_ingest::LinesBuf* Bp;
+    {
+        std::lock_guard<std::mutex> l(g->lines_m);
+        Bp = &g->lines[c];
+        if (gz && !g->d_crctab) {
+            uint32_t tab[288];
+            gz_tables(tab);
+            HIPCHK(hipMalloc(&g->d_crctab, sizeof(tab)));
+            HIPCHK(hipMemcpy(g->d_crctab, tab, sizeof(tab), hipMemcpyHostToDevice));
+        }
+    }
+    dbtk_ingest::LinesBuf& B = *Bp;
+    auto grow = [&](auto** p, uint64_t* have, uint64_t want, size_t elem) -> dbtk_status_t {
+        if (want <= *have) return DBTK_OK;
+        HIPCHK(hipStreamSynchronize(s));
+        if (*p) HIPCHK(hipFree(*p));
+        *p = nullptr; *have = 0;
+        HIPCHK(hipMalloc((void**)p, (want + want / 4) * elem));
+        *have = want + want / 4;
+        return DBTK_OK;
+    };
+    HIPCHK(hipStreamSynchronize(s));
+    uint32_t cur = 0;
+    HIPCHK(hipMemcpy(&cur, c->d_small + 7, 4, hipMemcpyDeviceToHost));
+    if (cur > c->txt_cap) { set_error("alignment text arena overflow"); return DBTK_ERR_OVERFLOW; }
+    const uint64_t tcap = (uint64_t)(S.end - S.hdr.base) + cur + 24ull * nk + 64;  // every line: bytes of the block + its record + separators and dst
+    const uint64_t nmem = tcap / GZ_MEMBER + 1;
+    dbtk_status_t st;
+    if ((st = grow(&B.d_linelen, &B.linelen_cap, (uint64_t)nk + 2 + ING_SCAN_BLOCKS, 4))) return st;
+    if ((st = grow(&B.d_text, &B.text_cap, tcap, 1))) return st;
+    if (!B.d_totals) { HIPCHK(hipMalloc(&B.d_totals, 4 * 8)); HIPCHK(hipHostMalloc((void**)&B.h_totals, 4 * 8, hipHostMallocDefault)); }
+    HIPCHK(hipMemsetAsync(B.d_totals, 0, 4 * 8, s));
+    AlnLineArgs la;
+    memset(&la, 0, sizeof(la));
+    la.raw = S.d_raw; la.spans = S.d_spans; la.hdr = g->d_hdr + slot; la.txt = c->d_txt; la.txt_idx = c->d_txtidx;
+    la.len = B.d_linelen; la.text = B.d_text; la.total = B.d_totals;
+    LAUNCH(k_aln_len, dim3(c->num_cu * 2), dim3(256), s, la);
+    LAUNCH(k_aln_scan, dim3(ING_SCAN_BLOCKS), dim3(64), s, la, 0);
+    LAUNCH(k_aln_scan, dim3(ING_SCAN_BLOCKS), dim3(64), s, la, 1);
+    LAUNCH(k_aln_write, dim3(c->num_cu * 32), dim3(64), s, la);
+    if (gz) {
+        if ((st = grow(&B.d_gzout, &B.gzout_cap, (nmem + 1) * GZ_STRIDE, 1))) return st;
+        if ((st = grow(&B.d_packed, &B.packed_cap, (nmem + 1) * GZ_STRIDE, 1))) return st;
+        if ((st = grow(&B.d_outlen, &B.outlen_cap, nmem + 4 + ING_SCAN_BLOCKS, 4))) return st;
+        HIPCHK(hipMemsetAsync(B.d_gzout, 0, nmem * GZ_STRIDE, s));
+        GzArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.text = B.d_text; ga.total = B.d_totals; ga.out = B.d_gzout; ga.out_len = B.d_outlen; ga.crc_tab = g->d_crctab;
+        ga.packed = B.d_packed; ga.packed_total = B.d_totals + 2;
+        const uint32_t gm = (uint32_t)std::min<uint64_t>(nmem, (uint64_t)c->num_cu * 16);
+        LAUNCH(k_gz_member, dim3(gm), dim3(64), s, ga);
+        LAUNCH(k_gz_scan, dim3(ING_SCAN_BLOCKS), dim3(64), s, ga, 0);
+        LAUNCH(k_gz_scan, dim3(ING_SCAN_BLOCKS), dim3(64), s, ga, 1);
+        LAUNCH(k_gz_pack, dim3(gm), dim3(64), s, ga);
+    }
+    HIPCHK(hipMemcpyAsync(B.h_totals, B.d_totals, 3 * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (B.h_totals[0] > tcap) { set_error("alignment lines overran their buffer"); return DBTK_ERR_OVERFLOW; }
+    const uint64_t n = gz ? B.h_totals[2] : B.h_totals[0];
+    if (n > S.h_lines_cap) {  // (pinned: the copy runs at the link's speed and the writer reads it where it lands)
+        if (S.h_lines) HIPCHK(hipHostFree(S.h_lines));
+        S.h_lines = nullptr; S.h_lines_cap = 0;
+        HIPCHK(hipHostMalloc((void**)&S.h_lines, n + n / 4 + 4096, hipHostMallocDefault));
+        S.h_lines_cap = n + n / 4 + 4096;
+    }
+    if (n) {
+        HIPCHK(hipMemcpyAsync(S.h_lines, gz ? B.d_packed : B.d_text, n, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    *data = S.h_lines; *nbytes = n;
+    if (nlines) *nlines = B.h_totals[1];
+    if (text_bytes) *text_bytes = B.h_totals[0];
     return DBTK_OK;
 }
 
@@ -1759,11 +1889,16 @@ dbtk_status_t dbtk_ingest_submit(dbtk_ingest_t* g, uint32_t slot, uint64_t nbyte
 dbtk_status_t dbtk_ingest_wait(dbtk_ingest_t* g, uint32_t slot, dbtk_ingest_info_t* info) {
     return dbtk::guarded([&] { return dbtk_ingest_wait_impl(g, slot, info); });
 }
-dbtk_status_t dbtk_ingest_align(dbtk_ingest_t* g, uint32_t slot, int sync, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
-    return dbtk::guarded([&] { return dbtk_ingest_align_impl(g, slot, sync, recs, rec_cap, nrec); });
+dbtk_status_t dbtk_ingest_align(dbtk_ingest_t* g, uint32_t slot, dbtk_ctx_t* cx, int sync, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
+    return dbtk::guarded([&] { return dbtk_ingest_align_impl(g, slot, cx, sync, recs, rec_cap, nrec); });
 }
 dbtk_status_t dbtk_ingest_spans(dbtk_ingest_t* g, uint32_t slot, dbtk_ingest_span_t* spans, uint64_t cap) {
     return dbtk::guarded([&] { return dbtk_ingest_spans_impl(g, slot, spans, cap); });
+}
+
+dbtk_status_t dbtk_ingest_aln_lines(dbtk_ingest_t* g, uint32_t slot, dbtk_ctx_t* cx, int gz, const void** data, uint64_t* nbytes, uint64_t* nlines,
+                                    uint64_t* text_bytes) {
+    return dbtk::guarded([&] { return dbtk_ingest_aln_lines_impl(g, slot, cx, gz, data, nbytes, nlines, text_bytes); });
 }
 
 }  // extern "C"

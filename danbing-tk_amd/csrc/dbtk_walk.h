@@ -1124,14 +1124,97 @@ DBTK_HD uint32_t w_fmt_annot(const uint8_t* tr, int sz, uint8_t* out) {
     n = w_fmt_int(out, n, ct); out[n++] = c0;
     return n;
 }
-// this mate's two strings into its LDS text buffers: lane 0 the CIGAR, lane 1 the annotation
+// The same two scans by the whole wave, 64 entries at a time (one lane per string took a hundred dependent LDS round trips per read
+// and made the -a / -ae walk 2.6 times the plain one).  What a lane prints depends on its neighbours only through three things, all of
+// them scans: the start of the run an '=' / '*' (annotation: '=' / '.' / '*') entry belongs to, the parity of a D / I entry's position in
+// its maximal alternating D-I stretch (writeCigar pairs them greedily from the left: the odd ones are swallowed by the entry before
+// them), and where in the text the lane's token goes.  A token is printed by the lane of its LAST entry.  writeCigar's quirk is kept:
+// a token that starts at the very last entry is printed by the code behind its loop, as "1" + type, whatever the type.
+template <class X>
+DBTK_HD uint32_t wave_fmt_cigar(X& x, const uint8_t* t, const uint8_t* g, int sz, uint8_t* out) {
+    const int lane = x.lane();
+    if (!sz) { if (lane == 0) out[0] = '*'; return 1; }
+    auto T = [&](int i) -> uint32_t { if (i < 0 || i >= sz) return 0u; const uint8_t c = t[i]; return (c == '*' || c == '=' || c == 'X' || c == 'D' || c == 'I') ? c : (uint32_t)'?'; };
+    auto G = [&](int i) -> uint32_t { if (i < 0 || i >= sz) return 0u; const uint8_t c = g[i]; return c == 0 ? 0u : (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : (uint32_t)'*'; };
+    uint32_t base = 0, run0 = 0, alt0 = 0;  // text written so far; (index + 1) of the last run start / alternating-stretch start before this chunk
+    for (int c0 = 0; c0 < sz; c0 += 64) {
+        const int i = c0 + lane;
+        const bool in = i < sz;
+        const uint32_t tp = T(i - 1), tc = T(i), tn = T(i + 1);
+        const bool runny = tc == '=' || tc == '*', di = tc == 'D' || tc == 'I';
+        const bool rstart = in && runny && tp != tc;
+        const bool astart = in && di && !((tp == 'D' || tp == 'I') && tp != tc);
+        const uint32_t rs = x.wave_scan_max(rstart ? (uint32_t)i + 1 : 0u), as = x.wave_scan_max(astart ? (uint32_t)i + 1 : 0u);
+        const uint32_t rbeg = (rs ? rs : run0) - 1, abeg = (as ? as : alt0) - 1;  // (meaningful for runny / di entries: they always have a start)
+        const bool odd = di && (((uint32_t)i - abeg) & 1u);
+        const bool paired = di && !odd && (tn == 'D' || tn == 'I') && tn != tc;  // swallows the next entry
+        const bool rend = runny && tn != tc;
+        const bool lastsolo = in && i == sz - 1 && !odd && !(runny && !rstart);  // a token that starts at the last entry: "1" + type
+        uint32_t n = 0, ct = 0;
+        if (in && !odd) {
+            if (lastsolo) n = 2;
+            else if (runny) { if (rend) { ct = (uint32_t)i - rbeg + 1; n = (ct >= 100 ? 3u : ct >= 10 ? 2u : 1u) + 1; } }
+            else if (tc == 'X' || tc == 'D') n = 2;
+            else if (tc == 'I') n = paired ? 2 : 1;
+            else n = 1;
+        }
+        const uint32_t o = base + x.wave_excl_scan(n);
+        if (n) {
+            if (lastsolo) { out[o] = '1'; out[o + 1] = (uint8_t)tc; }
+            else if (runny) { uint32_t q = w_fmt_int(out, o, (int)ct); out[q] = (uint8_t)tc; }
+            else if (tc == 'X') { out[o] = 'X'; out[o + 1] = (uint8_t)G(i); }
+            else if (tc == 'D') { out[o] = paired ? 'X' : 'D'; out[o + 1] = (uint8_t)G(i); }
+            else if (tc == 'I') { if (paired) { out[o] = 'X'; out[o + 1] = (uint8_t)G(i + 1); } else out[o] = 'I'; }
+            else out[o] = (uint8_t)tc;
+        }
+        base += x.wave_sum(n);
+        const uint32_t r63 = x.bcast(rs, 63), a63 = x.bcast(as, 63);
+        if (r63) run0 = r63;
+        if (a63) alt0 = a63;
+    }
+    return base;
+}
+template <class X>
+DBTK_HD uint32_t wave_fmt_annot(X& x, const uint8_t* tr, int sz, uint8_t* out) {
+    const int lane = x.lane();
+    if (!sz) { if (lane == 0) out[0] = '*'; return 1; }
+    auto C = [&](int i) -> uint32_t { return (i < 0 || i >= sz) ? 0x100u : (uint32_t)tr[i]; };
+    uint32_t base = 0, run0 = 0;
+    for (int c0 = 0; c0 < sz; c0 += 64) {
+        const int i = c0 + lane;
+        const bool in = i < sz;
+        const uint32_t cp = C(i - 1), cc = C(i), cn = C(i + 1);
+        const bool runny = cc == '=' || cc == '.' || cc == '*';
+        const bool rstart = in && runny && cp != cc;
+        const uint32_t rs = x.wave_scan_max(rstart ? (uint32_t)i + 1 : 0u);
+        const uint32_t rbeg = (rs ? rs : run0) - 1;
+        const bool lastsolo = in && i == sz - 1 && !(runny && !rstart);
+        uint32_t n = 0, ct = 0;
+        if (in) {
+            if (lastsolo) n = 2;
+            else if (runny) { if (cn != cc) { ct = (uint32_t)i - rbeg + 1; n = (ct >= 100 ? 3u : ct >= 10 ? 2u : 1u) + 1; } }
+            else n = 1;
+        }
+        const uint32_t o = base + x.wave_excl_scan(n);
+        if (n) {
+            if (lastsolo) { out[o] = '1'; out[o + 1] = (uint8_t)cc; }
+            else if (runny) { uint32_t q = w_fmt_int(out, o, (int)ct); out[q] = (uint8_t)cc; }
+            else out[o] = (uint8_t)cc;
+        }
+        base += x.wave_sum(n);
+        const uint32_t r63 = x.bcast(rs, 63);
+        if (r63) run0 = r63;
+    }
+    return base;
+}
+// this mate's two strings into its LDS text buffers
 template <class X>
 DBTK_HD_NOINLINE void walk_format_text(X& x, WalkSmem& sm, const WalkState& S, uint32_t cap) {
-    const int lane = x.lane();
     x.sync();
     const int nes = S.nes < (int)cap ? S.nes : (int)cap, ntr = S.ntr < (int)cap ? S.ntr : (int)cap;  // (as dbtk_aln_format clamps)
-    if (lane == 0) sm.txl[0] = w_fmt_cigar(sm.es_t, sm.es_g, nes, sm.txc);
-    if (lane == 1) sm.txl[1] = w_fmt_annot(sm.tr, ntr, sm.txa);
+    const uint32_t lc = wave_fmt_cigar(x, sm.es_t, sm.es_g, nes, sm.txc);
+    const uint32_t la = wave_fmt_annot(x, sm.tr, ntr, sm.txa);
+    if (x.lane() == 0) { sm.txl[0] = lc; sm.txl[1] = la; }
     x.sync();
 }
 

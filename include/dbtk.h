@@ -317,7 +317,7 @@ dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* ctx);
  * pair is carried over to the next chunk on the device.
  *   submit(slot, nbytes, last)   asynchronous: host-to-device copy + the parse kernels of the block
  *   wait(slot, &info)            blocks until the block is parsed; info says what it held
- *   align(slot, ...)             the parsed pairs through the hot path (as dbtk_align_batch_device when sync = 0, as
+ *   align(slot, ctx, ...)        the parsed pairs through the hot path (as dbtk_align_batch_device when sync = 0, as
  *                                dbtk_align_batch — records, dbtk_ctx_aln_text — when sync = 1)
  * Calls for successive blocks must be made in order by one thread; submit may run ahead of wait by up to nslots - 1
  * blocks.  A slot's buffer may be refilled once align (or wait, for a block that is not aligned) has returned and the
@@ -348,8 +348,18 @@ void*         dbtk_ingest_chunk_buffer(dbtk_ingest_t* ing, uint32_t slot);  /* p
 const void*   dbtk_ingest_block(dbtk_ingest_t* ing, uint32_t slot);         /* what the spans are offsets into (valid after wait) */
 dbtk_status_t dbtk_ingest_submit(dbtk_ingest_t* ing, uint32_t slot, uint64_t nbytes, int last);
 dbtk_status_t dbtk_ingest_wait(dbtk_ingest_t* ing, uint32_t slot, dbtk_ingest_info_t* info);
-dbtk_status_t dbtk_ingest_align(dbtk_ingest_t* ing, uint32_t slot, int sync, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec);
+/* ctx: NULL = the ingest's own context; another context of the same RPGG on the same device lets several threads run the blocks of one
+ * ingest through the hot path side by side (each thread its own context; sync = 1: its records, its text arena). */
+dbtk_status_t dbtk_ingest_align(dbtk_ingest_t* ing, uint32_t slot, dbtk_ctx_t* ctx, int sync, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec);
 dbtk_status_t dbtk_ingest_spans(dbtk_ingest_t* ing, uint32_t slot, dbtk_ingest_span_t* spans, uint64_t cap);
+/* -a / -ae with the device reader (params.aln | DBTK_ALN_TEXT): writeAlignments' lines (src/aQueryFasta_thread.cpp:1742-1759:
+ * `. dst title seq2 seq1 cigar2 annot2 cigar1 annot1`) of the block aligned last with sync = 1, in pair order, assembled on the device
+ * from the block's bytes and the walk's text records.  gz = 0: the text; gz != 0: gzip members (RFC 1952; 64 KB of text each, one
+ * deflate block with a dynamic Huffman code over the literals, no string matching) whose concatenation `zcat`s to the text.
+ * *data points at *nbytes bytes in a pinned buffer of the slot, valid until the slot's next submit.  *nlines = pairs with a record;
+ * *text_bytes = bytes of the text. */
+dbtk_status_t dbtk_ingest_aln_lines(dbtk_ingest_t* ing, uint32_t slot, dbtk_ctx_t* ctx /* the one that aligned the block; NULL: the ingest's */, int gz,
+                                    const void** data, uint64_t* nbytes, uint64_t* nlines, uint64_t* text_bytes);
 
 /* Copy the accumulated results to the host.  counts[ntrkmers] is in
  * OUT.trkmc.ar order; kmc[nloci]; nmapread[nloci]; counters[DBTK_C_COUNT].

@@ -482,6 +482,16 @@ class Emu(pkg._HostSide):
             o += l0 + l1
         return H, pairs, int(tot[3])
 
+    def gz(self, text: bytes, grid=2):
+        """dbtk_gz.h's member / scan / pack bodies: the gzip stream of `text`."""
+        self.L.emu_gz.restype = C.c_int64
+        self.L.emu_gz.argtypes = [C.c_char_p, C.c_uint64, u8p, C.c_uint64, C.c_uint32]
+        cap = len(text) + len(text) // 7 + (len(text) // 65536 + 2) * 2048
+        out = np.zeros(cap, np.uint8)
+        n = self.L.emu_gz(text, len(text), _p(out, u8p), cap, grid)
+        assert n >= 0
+        return bytes(out[:n])
+
     def probe_stats(self):
         """(general-probe-body runs, lean-probe-body runs since the last call, keys the last tables' level 1 turned away)"""
         out = np.zeros(3, np.uint64)
@@ -565,6 +575,11 @@ class Emu(pkg._HostSide):
 
     def set_consistent(self, tables, v):
         self.L.emu_tables_set_consistent(tables, int(v))
+
+    def selftest_fmt(self, seed, iters):
+        self.L.emu_selftest_fmt.restype = C.c_uint64
+        self.L.emu_selftest_fmt.argtypes = [C.c_uint64, C.c_uint64]
+        return int(self.L.emu_selftest_fmt(seed, iters))
 
     def selftest_assign(self, seed, iters):
         return int(self.L.emu_selftest_assign(seed, iters))

@@ -24,6 +24,7 @@
 #include "../../danbing-tk_amd/csrc/dbtk_internal.h"
 #include "../../danbing-tk_amd/csrc/dbtk_kernels.h"
 #include "../../danbing-tk_amd/csrc/dbtk_ingest.h"
+#include "../../danbing-tk_amd/csrc/dbtk_gz.h"
 
 using namespace dbtk;
 
@@ -866,5 +867,67 @@ int emu_ingest(const uint8_t* data, uint64_t n, uint32_t fastq, uint32_t min_rea
     }
     totals[0] = nflat; totals[1] = nlens; totals[2] = ntit; totals[3] = pos;
     return (int)blk;
+}
+// body_gz_member / body_gz_scan / body_gz_pack (dbtk_gz.h) on the emulated lanes: `text` -> gzip members back to back in `packed`.
+// Returns the number of bytes (< 0: packed_cap too small).
+int64_t emu_gz(const uint8_t* text, uint64_t n, uint8_t* packed, uint64_t packed_cap, uint32_t grid) {
+    const uint32_t nmem = (uint32_t)((n + GZ_MEMBER - 1) / GZ_MEMBER);
+    std::vector<uint32_t> out((size_t)(nmem + 1) * GZ_STRIDE / 4 + 16, 0);
+    std::vector<uint32_t> out_len(nmem + 2 + ING_SCAN_BLOCKS, 0), tab(288);
+    std::vector<uint8_t> tx(n + 8);
+    if (n) memcpy(tx.data(), text, n);
+    gz_tables(tab.data());
+    uint64_t total[2] = {n, 0}, ptotal = 0;
+    std::vector<uint8_t> pk((size_t)(nmem + 1) * GZ_STRIDE);
+    GzArgs a{tx.data(), total, (uint8_t*)out.data(), out_len.data(), tab.data(), pk.data(), &ptotal};
+    run_grid(grid ? grid : 2, 64, sizeof(GzSmem), [&](EmuX& x) { body_gz_member(x, a); });
+    run_grid(ING_SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_gz_scan(x, a, 0); });
+    run_grid(ING_SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_gz_scan(x, a, 1); });
+    run_grid(grid ? grid : 2, 64, 0, [&](EmuX& x) { body_gz_pack(x, a); });
+    if (ptotal > packed_cap) return -1;
+    memcpy(packed, pk.data(), ptotal);
+    return (int64_t)ptotal;
+}
+// wave_fmt_cigar / wave_fmt_annot (dbtk_walk.h: the -a / -ae strings by the whole wave) against the one-lane scans w_fmt_cigar /
+// w_fmt_annot (the restatement of writeCigar / writeAnnot that the reference's own strings pin, tests/test_walk.py) on random edit
+// scripts: long runs, D / I stretches of every parity, tokens starting at the last entry, lengths across the 64-entry chunks.
+// Returns the number of mismatching strings.
+uint64_t emu_selftest_fmt(uint64_t seed, uint64_t iters) {
+    uint64_t bad = 0, s = seed * 0x9E3779B97F4A7C15ull + 7;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (uint64_t it = 0; it < iters; ++it) {
+        const int sz = (int)(rnd() % 5 == 0 ? rnd() % 4 : rnd() % (WCAP - 2));
+        std::vector<uint8_t> t(WCAP + 8, 0), g(WCAP + 8, 0), tr(WCAP + 8, 0), o1(WTXT + 8), o2(WTXT + 8), o3(WTXT + 8), o4(WTXT + 8);
+        const char types[] = "==*XDI=DI?";
+        const char bases[] = "ACGT*";
+        const char ann[] = "==..**=.x";
+        int i = 0;
+        const uint64_t style = rnd() % 3;
+        while (i < sz) {
+            const uint8_t c = style == 0 ? (uint8_t)'=' : (uint8_t)types[rnd() % 10];
+            int run = (c == '=' || c == '*') ? (int)(rnd() % (style == 2 ? 4 : 130)) + 1 : (int)(rnd() % 3) + 1;
+            for (; run > 0 && i < sz; --run, ++i) {
+                t[i] = (c == '?') ? (uint8_t)'q' : c;
+                if ((c == 'D' || c == 'I') && rnd() % 2) t[i] = c == 'D' ? 'I' : 'D';  // alternating stretches of both parities
+                g[i] = rnd() % 7 == 0 ? 0 : (uint8_t)bases[rnd() % 5];
+            }
+            if (style == 0 && rnd() % 3 == 0 && i < sz) { t[i] = (uint8_t)types[3 + rnd() % 3]; g[i] = (uint8_t)bases[rnd() % 4]; ++i; }
+        }
+        i = 0;
+        while (i < sz) {
+            const uint8_t c = (uint8_t)ann[rnd() % 9];
+            int run = (int)(rnd() % 140) + 1;
+            for (; run > 0 && i < sz; --run, ++i) tr[i] = c;
+        }
+        const uint32_t n1 = w_fmt_cigar(t.data(), g.data(), sz, o1.data()), n2 = w_fmt_annot(tr.data(), sz, o2.data());
+        uint32_t n3 = 0, n4 = 0;
+        run_grid(1, 64, 0, [&](EmuX& x) {
+            const uint32_t a = wave_fmt_cigar(x, t.data(), g.data(), sz, o3.data()), b = wave_fmt_annot(x, tr.data(), sz, o4.data());
+            if (x.lane() == 0) { n3 = a; n4 = b; }
+        });
+        if (n1 != n3 || memcmp(o1.data(), o3.data(), n1)) ++bad;
+        if (n2 != n4 || memcmp(o2.data(), o4.data(), n2)) ++bad;
+    }
+    return bad;
 }
 }  // extern "C"

@@ -267,13 +267,19 @@ def test_cli_aln_gz_is_the_stdout_stream(tmp_path):
     w = str(tmp_path / "w")
     shutil.copytree(d, w)
     want = open(os.path.join(d, "refae.aln.txt"), "rb").read()
-    for extra in ([], ["--emit-threads", "3", "--gz-level", "1"]):
-        r = run(["--v13-threading", "-gc", "85", "3", "-ae", "-ka", "-k", "25", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-o", "gz",
-                 "--aln-gz", "out.aln.gz"] + extra, cwd=w)
+    # (a regular interleaved file: the lines are assembled and compressed on the GPU, dbtk_gz.h; --host-ingest / another --gz-level: zlib on
+    # the host's emit pool)
+    for extra in ([], ["--emit-threads", "3", "--gz-level", "1"], ["--host-ingest"], ["--gz-level", "4"]):
+        env = dict(os.environ, DBTK_INGEST_CHUNK="60000") if not extra else dict(os.environ)  # (several blocks, several gzip members each)
+        r = subprocess.run([CLI, "--v13-threading", "-gc", "85", "3", "-ae", "-ka", "-k", "25", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-o", "gz",
+                            "--aln-gz", "out.aln.gz"] + extra, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert r.stdout == b""
         assert gzip.open(os.path.join(w, "out.aln.gz"), "rb").read() == want
         assert open(os.path.join(w, "gz.trkmc.ar"), "rb").read() == open(os.path.join(d, "refae.trkmc.ar"), "rb").read()
+        em = [l for l in r.stderr.decode().splitlines() if l.startswith("emit:")][0]
+        on_device = int(em.split("; ")[-1].split()[0])
+        assert (on_device == len(want)) == (extra in ([], ["--emit-threads", "3", "--gz-level", "1"])), em
     # the README's own command line for the v1.3 contract (README.md:38-39: no flag of ours), switched by the environment
     r = subprocess.run([CLI, "-gc", "85", "3", "-ae", "-ka", "-k", "25", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-o", "envsw"], cwd=w,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, DBTK_V13_THREADING="1"))

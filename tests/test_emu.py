@@ -130,3 +130,10 @@ def test_kernel_bodies_reproduce_reference_binary(name, E):
     check_against_golden(d, b["counts"], b["kmc"], b["nmapread"], b["counters"], b["recs"], reads)
     E.L.emu_tables_free(T)
     g.close()
+
+
+def test_wave_formatters_are_writeCigar_and_writeAnnot(E):
+    """The whole-wave CIGAR / annotation formatters of the -a / -ae walk (dbtk_walk.h: wave_fmt_*) vs the one-lane scans that restate
+    writeCigar / writeAnnot (AQ.cpp:1683-1740; pinned to the reference's strings in tests/test_walk.py): runs across the 64-entry chunks,
+    D / I stretches of both parities, the "1" + type a token starting at the last entry gets from the code behind writeCigar's loop."""
+    assert E.selftest_fmt(3, 20000) == 0

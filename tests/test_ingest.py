@@ -128,6 +128,37 @@ def test_line_table_overflow_and_empty_input(emu):
     assert H[0]["flags"] & 4
 
 
+
+def test_emulated_gzip_members_gunzip_to_the_text(emu):
+    """dbtk_gz.h: the -a / -ae text as gzip members made by the kernel body (byte histogram, minimum-redundancy code lengths limited
+    to 15 bits, canonical codes, lanes writing at scanned bit offsets, CRC-32 combined from the lanes' spans): the system's zlib
+    (which checks every member's CRC-32 and length) must return the text — alignment-like lines, all byte values, one symbol,
+    incompressible bytes, a Fibonacci-skewed histogram (Huffman depths past 15), sizes around the member and span boundaries."""
+    import gzip
+    import zlib
+    rng = random.Random(11)
+
+    def line():
+        return (b".\t%d\t>read%d\t" % (rng.randrange(80000), rng.randrange(10 ** 8)) + bytes(rng.choice(ACGT) for _ in range(150)) + b"\t" +
+                bytes(rng.choice(ACGT) for _ in range(150)) + b"\t150=\t150=\t148=1X1=\t149.1*\n")
+    text = b"".join(line() for _ in range(700))
+    fib, a, b = b"", 1, 1
+    for sym in range(24):  # frequencies 1, 1, 2, 3, 5, ...: the unrestricted code is 23 bits deep
+        fib += bytes([65 + sym]) * a
+        a, b = b, a + b
+    shuffled = bytearray(fib)
+    rng.shuffle(shuffled)
+    cases = [text[:n] for n in (1, 5, 1000, 1023, 1024, 1025, 65535, 65536, 65537, 200000)] + [bytes(range(256)) * 300, b"A" * 70000,
+             bytes(rng.randrange(256) for _ in range(100000)), b"AB" * 40000 + b"C", bytes(shuffled)]
+    for t in cases:
+        z = emu.gz(t, grid=3)
+        assert gzip.decompress(z) == t, len(t)
+        assert z.count(b"\x1f\x8b\x08") >= (len(t) + 65535) // 65536
+    assert emu.gz(b"") == b""
+    z = emu.gz(text[:200000])
+    assert len(z) < 1.1 * len(zlib.compress(text[:200000], 1))  # DNA-dominated text: a Huffman code alone is within 10 % of zlib's level 1
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU
 def _fasta_of(reads, fastq=False, drop_newline=False):
     out = []

@@ -28,8 +28,8 @@ def main():
         cli = os.path.join(ROOT, "danbing-tk_amd", "bin", "danbing-tk")
         base = [cli, "-k", "21", "-kf", "4", "1", "-cth", "45", "--v13-threading", "-gc", "85", "3", "-fa", "reads_hit.fa", "-qs", "pan", "-o", "w"]
 
-        def run(extra, tag):
-            r = subprocess.run(base + extra, cwd=d, capture_output=True, text=True)
+        def run(extra, tag, env=None):
+            r = subprocess.run(base + extra, cwd=d, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
             ing = [l for l in r.stderr.splitlines() if l.startswith("ingest:")]
             em = [l for l in r.stderr.splitlines() if l.startswith("emit:")]
             print(f"{tag:28s} rc={r.returncode} {ing[0] if ing else r.stderr[-400:]}", flush=True)
@@ -37,8 +37,39 @@ def main():
                 print(f"{'':28s} {em[0]}", flush=True)
         run([], "no emit")
         run([], "no emit (again)")
+        run(["--host-ingest"], "no emit, host reader")
+        run(["-ae", "--aln-gz", "w_dev.aln.gz"], "-ae --aln-gz (device)")
+        run(["-ae", "--aln-gz", "w_dev.aln.gz"], "-ae --aln-gz (device, again)")
+        for ev in [dict(kv.split("=") for kv in v.split(",")) for v in os.environ.get("EMIT_BENCH_ENVS", "").split(";") if v]:
+            run([], f"no emit {ev}", ev)
+            run(["-ae", "--aln-gz", "w_dev.aln.gz"], f"-ae --aln-gz (device) {ev}", ev)
+        if os.environ.get("EMIT_BENCH_ROCPROF"):
+            pd = os.path.abspath(os.environ["EMIT_BENCH_ROCPROF"])
+            os.makedirs(pd, exist_ok=True)
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", pd, "--"] + base + ["-ae", "--aln-gz", "w_prof.aln.gz"],
+                               cwd=d, capture_output=True, text=True, env=dict(os.environ, TMPDIR="/tmp"))
+            print("rocprofv3 rc", r.returncode, [l for l in r.stderr.splitlines() if l.startswith("ingest:")])
+            for root, _, files in os.walk(pd):
+                for f in files:
+                    if f.endswith("kernel_stats.csv"):
+                        print("\n".join(l[:150] for l in open(os.path.join(root, f)).read().splitlines()[:22]))
         for al, th in variants:
-            run(["-ae", "--aln-gz", "w.aln.gz", "--aln-aligners", str(al), "--emit-threads", str(th)], f"-ae --aln-gz  A={al} T={th}")
+            run(["-ae", "--aln-gz", "w.aln.gz", "--host-ingest", "--aln-aligners", str(al), "--emit-threads", str(th)], f"-ae --aln-gz host A={al} T={th}")
+        a, b = os.path.join(d, "w_dev.aln.gz"), os.path.join(d, "w.aln.gz")
+        if os.path.exists(a) and os.path.exists(b):
+            import gzip
+            import hashlib
+            def dig(fn):
+                h, n = hashlib.sha256(), 0
+                with gzip.open(fn, "rb") as f:
+                    while True:
+                        blk = f.read(64 << 20)
+                        if not blk:
+                            break
+                        h.update(blk); n += len(blk)
+                return h.hexdigest()[:16], n
+            da, db = dig(a), dig(b)
+            print(f"zcat device stream == zcat host stream: {da == db} ({da[1]} bytes of text; .gz {os.path.getsize(a)} vs {os.path.getsize(b)} bytes)", flush=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
