@@ -552,6 +552,7 @@ def main():
                     legs = {}
                     base = [cli, "-k", "21", "-kf", "4", "1", "-cth", "45", "--v13-threading", "-gc", "85", "3", "-fa", "reads_hit.fa", "-qs", "pan", "-o", "cliw"]
                     for name, extra in (("walk", []), ("walk_ae_gz", ["-ae", "--aln-gz", "cliw.aln.gz"]),
+                                        ("walk_ae_gz_host_zlib1", ["-ae", "--aln-gz", "cliwh.aln.gz", "--host-ingest"]),
                                         ("walk_ae_gz_level6", ["-ae", "--aln-gz", "cliw6.aln.gz", "--gz-level", "6"])):
                         t0 = time.perf_counter()
                         r = subprocess.run(base + extra, cwd=ref_dir, capture_output=True, text=True)
@@ -564,9 +565,11 @@ def main():
                     legs["reads"] = 2 * nhit
                     gz6 = os.path.join(ref_dir, "cliw6.aln.gz")
                     legs["aln_gz_level6_bytes"] = os.path.getsize(gz6) if os.path.exists(gz6) else None
-                    legs["note"] = ("this repo's danbing-tk --v13-threading -gc 85 3 on an all-hit FASTA, without and with -ae --aln-gz (zlib level 1, "
-                                    "the default here, and level 6 = gzip's default): wall seconds including the RPGG + graph load; the difference is "
-                                    "what the emit costs end to end.  At level 6 the emit is bound by deflate on the host cores (about 230 bytes of text per read)")
+                    legs["note"] = ("this repo's danbing-tk --v13-threading -gc 85 3 on an all-hit FASTA, without and with -ae --aln-gz: wall seconds "
+                                    "including the RPGG + graph load, and the batch loop's own line.  walk_ae_gz: the lines are assembled and gzip-compressed "
+                                    "on the GPU (Huffman-only deflate, dbtk_gz.h); walk_ae_gz_host_zlib1 / _level6: zlib on the host's emit pool (level 1, "
+                                    "level 6 = gzip's default), bound by deflate on a 16-CPU container.  With -ae every mate of every pair is aligned (the "
+                                    "record holds both alignments); without it a pair is decided by its first cleanly threading mate")
                     e2e["cli_walk_emit"] = legs
                     log(f"CLI walk: {legs['walk']['wall_s']:.1f}s; with -ae --aln-gz: {legs['walk_ae_gz']['wall_s']:.1f}s "
                         f"({legs['aln_gz_bytes']} bytes of .aln.gz for {2 * nhit} reads)")

@@ -1114,11 +1114,14 @@ int main(int argc, char* argv[]) {
         *resume = hi;
         const bool sync = want_out || P.bubbles;  // (-bu replays every batch's novel edges on the host)
         while (jaln < nchunks) {
-            for (;;) {  // submit what has been read, up to NS - 1 blocks ahead of the one about to be aligned
+            for (;;) {  // submit what has been read, up to NS - 1 blocks ahead of the one about to be aligned — and never block i before block
+                        // i + 1 - NS has been released: parsing block i puts its carried-over bytes in front of the NEXT slot's device block,
+                        // which until then still holds the first record of the block that is being written from it
                 {
                     std::unique_lock<std::mutex> l(m);
-                    if (jsub == jaln) cv.wait(l, [&] { return filled[jsub] != 0; });
-                    if (!(jsub < nchunks && jsub < jaln + NS && filled[jsub])) break;
+                    auto can = [&] { return jsub < nchunks && jsub < jaln + NS && filled[jsub] != 0 && jsub + 1 < nreleased + NS; };
+                    if (jsub == jaln) cv.wait(l, can);
+                    else if (!can()) break;
                 }
                 const uint64_t nb = std::min<uint64_t>(CH, total - jsub * CH);
                 if (dbtk_ingest_submit(ing, (uint32_t)(jsub % NS), nb, jsub + 1 == nchunks)) die_assert(std::string("ingest: ") + dbtk_last_error());

@@ -772,7 +772,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         if (walk_txt) {  // text records: an arena sized for the worst case (two characters per entry, four strings), carved by the waves
             const uint32_t acap = std::min<uint32_t>(DBTK_THREAD_CAP, (max_read_len + max_read_len / 4 + 8 + 7) & ~7u);
             c->aln_cap = acap;
-            const uint64_t want = std::min<uint64_t>(npairs * (uint64_t)(8 + 8 * acap + 8) + (uint64_t)TXT_CHUNK * (c->walk_blocks + 1), 0xFFFF0000ull);
+            const uint64_t want = std::min<uint64_t>(npairs * (uint64_t)(8 + 8 * acap + 8) + (uint64_t)TXT_CHUNK * (c->walk_blocks + c->walkfast_blocks + 2), 0xFFFF0000ull);
             if (want > c->txt_bytes) {
                 if (c->d_txt) HIPCHK(hipFree(c->d_txt));
                 c->d_txt = nullptr; c->txt_bytes = 0;
@@ -801,10 +801,10 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             w.aln = c->d_aln; w.aln_stride = c->aln_stride; w.aln_cap = acap; w.aln_max = (uint32_t)std::min<uint64_t>(c->aln_max, 0xFFFFFFFFull);
             w.naln = c->d_small + 4;
         }
-        // Two kernels when nothing needs the alignment of every mate (no -a / -ae records, no thread records): the lean one
-        // decides and counts the pairs one of whose mates threads cleanly, the one with the error-correction machinery takes the
-        // rest from its list.  (The walk's kernels are timed together: "k_walk_pairs".)
-        const int wnpl = (walk_aln || walk_txt || walk_trecs || k + 4 > 32) ? 0 : (max_read_len <= 32 * 3 + k - 1 && k + 2 <= 32 ? 3 : max_read_len <= 32 * 5 + k - 1 ? 5 : 0);
+        // Two kernels when nothing needs the alignment arrays of every mate (no array records, no thread records): the lean one
+        // decides and counts the pairs one of whose mates threads cleanly — with text records (-a / -ae): the pairs BOTH of whose
+        // mates do, and writes their records itself —, the one with the error-correction machinery takes the rest from its list.  (The walk's kernels are timed together: "k_walk_pairs".)
+        const int wnpl = (walk_aln || walk_trecs || k + 4 > 32) ? 0 : (max_read_len <= 32 * 3 + k - 1 && k + 2 <= 32 ? 3 : max_read_len <= 32 * 5 + k - 1 ? 5 : 0);
         if (tm) { if ((st = timed_slot(c, 4, &e))) return st; HIPCHK(hipEventRecord(c->timed[4].beg[e], s)); }
         if (wnpl) {
             w.slow_list = c->d_walk + 2 * npairs; w.nslow = c->d_small + 5;

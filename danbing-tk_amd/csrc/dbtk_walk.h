@@ -1428,6 +1428,8 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
     const uint32_t p0 = hl * NPL;
     uint64_t c_feas = 0, c_inc = 0;
     uint32_t nbuf = 0;
+    uint32_t txt_base = 0, txt_left = 0;  // text records (-a / -ae): arena bytes are taken TXT_CHUNK at a time, as in body_walk_pairs
+    const bool texting = a.txt && (a.P.aln & 3) != 0;
     auto flush = [&]() {
         x.sync();
         uint32_t base = 0;
@@ -1545,7 +1547,9 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
         const uint64_t failm = x.ballot(fail) | badm;
         const uint64_t nkm = x.ballot(nk > 0);
         const bool clean0 = (nkm & 1) && !(failm & 0xFFFFFFFFull), clean1 = ((nkm >> 32) & 1) && !(failm >> 32);
-        if ((clean0 || clean1) && !badm) {  // (uniform) the pair is kept: count the uncorrected k-mers of both mates (AQ.cpp:2189-2194)
+        // (-a / -ae: the record holds both mates' alignments, so only a pair BOTH of whose mates thread cleanly is finished here — its
+        // strings are "len=" and the run lengths of the TR flags of its k-mers; any other pair goes on to the kernel that aligns)
+        if ((texting ? (clean0 && clean1) : (clean0 || clean1)) && !badm) {  // (uniform) the pair is kept: count the uncorrected k-mers of both mates (AQ.cpp:2189-2194)
             // (a pair with a non-ACGT byte in either mate is passed on even when its other mate threads: the valid k-mers of the
             // mate with the N count too, and which of its windows are valid is the other kernel's business)
             c_feas += 2;
@@ -1559,6 +1563,71 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
             if (lane == 0) {
                 a.walk_dst[i] = dst;
                 a.walk_ret[i] = (uint32_t)(uint8_t)(clean0 ? 1 : WALK_NOT_EVALUATED) | ((uint32_t)(uint8_t)(clean1 ? 1 : WALK_NOT_EVALUATED) << 8);
+            }
+            if (texting) {
+                // writeAnnot on cg.tr of a clean walk (one '=' / '.' per k-mer: is it a TR k-mer of the locus) = the run lengths of the
+                // flags; writeCigar on its cg.es (len matches) = "len=".  A run is printed by the lane of its last position: the flag of
+                // the position after it comes from the lane's own next position or, across lanes, from the ballot of first positions;
+                // where the run began is a max-scan over the positions where the flag changes (each mate's own scale, so that mate 1's
+                // scan never sees mate 0's).
+                bool f[NPL];
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) f[j] = (gi[j] & GR_TR) != 0;
+                const uint64_t f0m = x.ballot(f[0]);
+                const bool fnext = lane < 63 && ((f0m >> (lane + 1)) & 1);  // (lane 31's successor is mate 1's first: never looked at, p0 + NPL - 1 >= nk - 1 there or inactive)
+                const uint32_t scale = half ? 4096u : 0u;
+                uint32_t chg = 0;  // (index + 1 on the mate's scale) of the last position of this lane that starts a run
+                bool fp = x.shfl_up1(f[NPL - 1] ? 1u : 0u) != 0;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    if (act[j] && (p0 + j == 0 || f[j] != fp)) chg = scale + p0 + j + 1;
+                    fp = f[j];
+                }
+                const uint32_t inc = x.wave_scan_max(chg);
+                uint32_t before = x.shfl_up1(inc);  // the last run start in the lanes before this one
+                if (lane == 0 || before < scale + 1) before = scale + 1;  // (a mate's position 0 always starts a run; lane 32 must not see mate 0)
+                uint32_t rl[NPL], ol[NPL], tot = 0;
+                uint32_t st = before;
+                fp = x.shfl_up1(f[NPL - 1] ? 1u : 0u) != 0;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    if (act[j] && (p0 + j == 0 || f[j] != fp)) st = scale + p0 + j + 1;
+                    fp = f[j];
+                    const bool nx = j + 1 < NPL ? f[j + 1] : fnext;
+                    const bool end = act[j] && (p0 + j + 1 == nk || nx != f[j]);
+                    rl[j] = end ? (scale + p0 + j + 1) - st + 1 : 0u;
+                    ol[j] = end ? (rl[j] >= 100 ? 3u : rl[j] >= 10 ? 2u : 1u) + 1u : 0u;
+                    tot += ol[j];
+                }
+                const uint32_t ex = x.wave_excl_scan(tot), la = x.half_sum(tot);
+                const uint32_t la0 = x.bcast(la, 0), la1 = x.bcast(la, 32);
+                const uint32_t len0 = x.bcast(len, 0), len1 = x.bcast(len, 32);  // (each half holds its own mate's length)
+                const uint32_t lc0 = (len0 >= 100 ? 3u : len0 >= 10 ? 2u : 1u) + 1u, lc1 = (len1 >= 100 ? 3u : len1 >= 10 ? 2u : 1u) + 1u;
+                const uint32_t tlen = lc1 + 1 + la1 + 1 + lc0 + 1 + la0, need = (8 + tlen + 3) & ~3u;
+                if (need > txt_left) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = x.atomic_add(a.ntxt, TXT_CHUNK);
+                    txt_base = x.bcast(b, 0);
+                    txt_left = TXT_CHUNK;
+                }
+                if ((uint64_t)txt_base + need <= a.txt_cap) {
+                    uint8_t* r = a.txt + txt_base;
+                    if (lane == 0) {  // header, mate 1's CIGAR, the three tabs, mate 0's CIGAR
+                        reinterpret_cast<uint32_t*>(r)[0] = dst;
+                        reinterpret_cast<uint32_t*>(r)[1] = tlen;
+                        a.txt_idx[a.surv[i]] = txt_base;
+                        uint32_t q = w_fmt_int(r, 8, (int)len1);
+                        r[q] = '='; r[q + 1] = '\t';
+                        r[8 + lc1 + 1 + la1] = '\t';
+                        q = w_fmt_int(r, 8 + lc1 + 1 + la1 + 1, (int)len0);
+                        r[q] = '='; r[q + 1] = '\t';
+                    }
+                    uint32_t o = half ? 8 + lc1 + 1 + (ex - la0) : 8 + lc1 + 1 + la1 + 1 + lc0 + 1 + ex;
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j)
+                        if (ol[j]) { const uint32_t q = w_fmt_int(r, o, (int)rl[j]); r[q] = f[j] ? '=' : '.'; o += ol[j]; }
+                } else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
+                txt_base += need; txt_left -= need;
             }
         } else {
             if (lane == 0) sm.buf[nbuf] = i;

@@ -322,6 +322,8 @@ dbtk_status_t dbtk_ctx_synchronize(dbtk_ctx_t* ctx);
  * Calls for successive blocks must be made in order by one thread; submit may run ahead of wait by up to nslots - 1
  * blocks.  A slot's buffer may be refilled once align (or wait, for a block that is not aligned) has returned and the
  * caller no longer needs its bytes (dbtk_ingest_spans point into it).
+ * Parsing block i puts its carried-over bytes in front of slot (i + 1) % nslots's DEVICE block: submit block i only when the caller is
+ * done with dbtk_ingest_aln_lines of that slot's previous block (block i + 1 - nslots).
  * info.flags != 0: the block is not (only) a run of adjacent mates.  DBTK_ING_DIRTY / DBTK_ING_LINES: nothing of it may be
  * aligned — continue at input offset info.first_byte with a host reader (up to there every record was paired, so nothing
  * is parked: the state the reference's reader would be in).  DBTK_ING_CARRY / DBTK_ING_TAIL alone: align it, then continue

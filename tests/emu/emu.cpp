@@ -752,7 +752,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         g_txt.clear(); g_txt_idx.clear();
         if (txtmode) {
             g_aln_cap = std::min<uint32_t>(DBTK_THREAD_CAP, (maxlen + maxlen / 4 + 8 + 7) & ~7u);
-            g_txt.assign(npairs * (size_t)(8 + 8 * g_aln_cap + 8) + (size_t)TXT_CHUNK * (grid_pair + 1), 0);
+            g_txt.assign(npairs * (size_t)(8 + 8 * g_aln_cap + 8) + (size_t)TXT_CHUNK * (2 * grid_pair + 2), 0);
             g_txt_idx.assign(npairs + 1, NAN32);
             w.txt = g_txt.data(); w.txt_idx = g_txt_idx.data(); w.ntxt = &ntxt; w.txt_cap = (uint32_t)g_txt.size(); w.aln_cap = g_aln_cap;
         }
@@ -767,7 +767,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         std::vector<uint32_t> slow(npairs + 1, 0);
         uint32_t nslow = 0;
         const uint32_t kk = g->ksize;
-        const int wnpl = ((p->aln & 3u) || g_walk_trecs || kk + 4 > 32) ? 0 : (maxlen <= 32 * 3 + kk - 1 && kk + 2 <= 32 ? 3 : maxlen <= 32 * 5 + kk - 1 ? 5 : 0);
+        const int wnpl = (((p->aln & 3u) && !txtmode) || g_walk_trecs || kk + 4 > 32) ? 0 : (maxlen <= 32 * 3 + kk - 1 && kk + 2 <= 32 ? 3 : maxlen <= 32 * 5 + kk - 1 ? 5 : 0);
         if (wnpl) {
             w.slow_list = slow.data(); w.nslow = &nslow;
             if (wnpl == 3) run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<3>), [&](EmuX& x) { body_walk_fast<3>(x, w); });

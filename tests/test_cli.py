@@ -270,7 +270,9 @@ def test_cli_aln_gz_is_the_stdout_stream(tmp_path):
     # (a regular interleaved file: the lines are assembled and compressed on the GPU, dbtk_gz.h; --host-ingest / another --gz-level: zlib on
     # the host's emit pool)
     for extra in ([], ["--emit-threads", "3", "--gz-level", "1"], ["--host-ingest"], ["--gz-level", "4"]):
-        env = dict(os.environ, DBTK_INGEST_CHUNK="60000") if not extra else dict(os.environ)  # (several blocks, several gzip members each)
+        # (several blocks, several gzip members each; three slots: the carried-over bytes of block i + 2 land in front of the device block that
+        # block i's lines are still being assembled from unless the submission holds back)
+        env = dict(os.environ, DBTK_INGEST_CHUNK="60000", DBTK_INGEST_SLOTS="3") if not extra else dict(os.environ)
         r = subprocess.run([CLI, "--v13-threading", "-gc", "85", "3", "-ae", "-ka", "-k", "25", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-o", "gz",
                             "--aln-gz", "out.aln.gz"] + extra, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert r.returncode == 0, r.stderr.decode()[-2000:]

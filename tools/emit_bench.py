@@ -70,6 +70,16 @@ def main():
                 return h.hexdigest()[:16], n
             da, db = dig(a), dig(b)
             print(f"zcat device stream == zcat host stream: {da == db} ({da[1]} bytes of text; .gz {os.path.getsize(a)} vs {os.path.getsize(b)} bytes)", flush=True)
+            if da != db:
+                with gzip.open(a, "rb") as fa, gzip.open(b, "rb") as fb:
+                    nshow = 0
+                    for ln, (x, y) in enumerate(zip(fa, fb)):
+                        if x != y:
+                            fx, fy = x.split(b"\t"), y.split(b"\t")
+                            print(f"line {ln}: device {fx[:3] + fx[5:]}\n         host   {fy[:3] + fy[5:]}", flush=True)
+                            nshow += 1
+                            if nshow == 6:
+                                break
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
