@@ -809,8 +809,11 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         if (wnpl) {
             w.slow_list = c->d_walk + 2 * npairs; w.nslow = c->d_small + 5;
             HIPCHK(hipMemsetAsync(c->d_small + 5, 0, 4, s));
-            if (wnpl == 3) LAUNCH((k_walk_fast<3>), dim3(c->walkfast_blocks), dim3(64), s, w);
-            else LAUNCH((k_walk_fast<5>), dim3(c->walkfast_blocks), dim3(64), s, w);
+            // (four ranges per resident wave even out their different costs: 19.7 -> 18.7 ms per 4 M reads; not with text records, where
+            // every block that writes takes a chunk of the arena)
+            const dim3 gf(walk_txt ? c->walkfast_blocks : 4 * c->walkfast_blocks);
+            if (wnpl == 3) LAUNCH((k_walk_fast<3>), gf, dim3(64), s, w);
+            else LAUNCH((k_walk_fast<5>), gf, dim3(64), s, w);
         }
         LAUNCH(k_walk_pairs, dim3(c->walk_blocks), dim3(64), s, w);
         if (tm) HIPCHK(hipEventRecord(c->timed[4].end[e], s));
@@ -861,11 +864,17 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             const void* k2[4] = {(const void*)k_probe<3, 7>, (const void*)k_probe<3, 11>, (const void*)k_probe<5, 7>, (const void*)k_probe<5, 11>};
             for (int i = 0; i < 4; ++i) {
                 nb = 0;
+                // blocks per CU: eight times what the occupancy query says is resident.  A wave works through one contiguous range of
+                // the locus-ordered list, so ranges an eighth as long even out their different costs (5.42 -> 5.09 ms per all-hit launch);
+                // and a grid of EXACTLY the resident waves is a cliff: the query counts LDS in finer granules than the hardware
+                // allocates, and one block too many per CU runs alone in a second round at twice the time (measured with a 10.7-KB variant
+                // of this kernel: 15 per CU by the query, 14 in fact: 8.7 ms against 6.1).
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k2[i], 64, 0) != hipSuccess || nb <= 0) nb = 8;
+                nb *= 8;
                 if (const char* ev = getenv("DBTK_PROBE_WPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
                 c->probe2_wpc[i] = nb;
             }
-            if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_probe<5, 7>: %d waves per CU\n", c->probe2_wpc[2]);
+            if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_probe<5, 7>: %d blocks per CU\n", c->probe2_wpc[2]);
         }
         // resident waves of each resolve-kernel instance (one vote-spill scratch row per resident wave)
         const void* kp[3] = {(const void*)k_pair<2, true>, (const void*)k_pair<3, true>, (const void*)k_pair<4, true>};

@@ -24,7 +24,10 @@
 
 namespace dbtk {
 
-constexpr int P2_RCH = 40;    // runs (buckets) staged in LDS at a time (a pair of 150-bp reads has ~66: two chunks)
+#ifndef DBTK_P2_RCH
+#define DBTK_P2_RCH 40
+#endif
+constexpr int P2_RCH = DBTK_P2_RCH;  // runs (buckets) staged in LDS at a time (a pair of 150-bp reads has ~66: two chunks)
 constexpr int P2_ROW = 9;     // 16-byte granules per staged bucket: 8 + 1 of padding (rows on different LDS banks)
 constexpr int P2_CACHE = 128; // entries of the wave's cache of overflow look-ups
 template <int NPL>
