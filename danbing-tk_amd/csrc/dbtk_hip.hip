@@ -888,7 +888,8 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             const void* ku[3] = {(const void*)k_pair_usual<2, true>, (const void*)k_pair_usual<3, true>, (const void*)k_pair_usual<4, true>};
             nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ku[i], 64, 0) != hipSuccess || nb <= 0) nb = 16;
-            nb *= 8;  // (ranges an eighth as long, as for the probe kernel: 2.28 -> 1.78 ms per all-hit launch)
+            nb *= 4;  // (ranges a quarter as long, as for the probe kernel: 2.66 -> 1.93 ms per all-hit launch; eight times: 1.78, but the
+                      // genome-like mix, where most survivors leave at once, then pays for the blocks' own start-up: 0.26 -> 0.40 ms)
             if (const char* e = getenv("DBTK_USUAL_WPC")) { const int v = atoi(e); if (v > 0) nb = v; }  // diagnostic: blocks per CU
             c->usual_blocks[i] = c->num_cu * nb;
         }

@@ -37,15 +37,17 @@ def test_struct_layouts(tmp_path):
     assert C.sizeof(abi.MateRec) == 14 + 6 + 2 + 64
     assert C.sizeof(abi.PairRec) == 24 + 2 * C.sizeof(abi.MateRec)
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dbtk.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", '
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dbtk.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", '
                    'sizeof(dbtk_params_t), sizeof(dbtk_mate_rec_t), sizeof(dbtk_pair_rec_t), sizeof(dbtk_thread_rec_t), '
                    'offsetof(dbtk_thread_rec_t, kmers), sizeof(dbtk_walk_res_t), sizeof(dbtk_aln_hdr_t), sizeof(dbtk_rpgg_arrays_t), '
-                   'offsetof(dbtk_params_t, trackbait), offsetof(dbtk_aln_hdr_t, nes1)); return 0; }\n')
+                   'offsetof(dbtk_params_t, trackbait), offsetof(dbtk_aln_hdr_t, nes1), sizeof(dbtk_ingest_info_t), offsetof(dbtk_ingest_info_t, cut_byte), '
+                   'sizeof(dbtk_ingest_span_t)); return 0; }\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(bind.ROOT, "include"), "-o", str(exe), str(src)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert got == [C.sizeof(abi.Params), C.sizeof(abi.MateRec), C.sizeof(abi.PairRec), C.sizeof(abi.ThreadRec), abi.ThreadRec.kmers.offset,
-                   C.sizeof(abi.WalkRes), C.sizeof(abi.AlnHdr), C.sizeof(abi.RpggArrays), abi.Params.trackbait.offset, abi.AlnHdr.nes1.offset]
+                   C.sizeof(abi.WalkRes), C.sizeof(abi.AlnHdr), C.sizeof(abi.RpggArrays), abi.Params.trackbait.offset, abi.AlnHdr.nes1.offset,
+                   C.sizeof(abi.IngestInfo), abi.IngestInfo.cut_byte.offset, C.sizeof(abi.IngestSpan)]
 
 
 @pytest.mark.parametrize("name", sorted(GOLD))
