@@ -258,6 +258,7 @@ struct dbtk_ctx {
     uint64_t* d_vote = nullptr;
     uint32_t* d_epoch = nullptr;
     int pair_blocks[3] = {0, 0, 0}, usual_blocks[3] = {0, 0, 0}, num_cu = 0, max_pair_blocks = 0;
+    int vote_rows = 0;  // rows of the vote-spill pool: the workgroups of the general resolve kernel that can be resident at once
     uint32_t consistent = 0;
     Timed timed[NKERN];
     // Second lane of the device-resident entry point: successive batches alternate between two streams, each with its own
@@ -670,7 +671,8 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     a.counters = a.nmapread + c->g->nloci;
     a.ctr_rep = c->d_ctr;
     a.recs = d_recs; a.rec_cap = rec_cap;
-    a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch;
+    a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch; a.vote_rows = (uint32_t)c->vote_rows;
+    a.vote_busy = reinterpret_cast<uint64_t*>(c->d_epoch + ((c->vote_rows + 1) & ~1));  // (behind the epochs, 8-byte aligned)
     a.walk_dst = walking ? c->d_walk : nullptr;
     a.hitaux = reinterpret_cast<uint32_t*>(c->d_hitva); a.hitval = a.hitaux + tcap * 2 * nkp; a.hitnk = c->d_hitnk; a.hitoff = c->d_hitoff; a.hithdr = c->d_hitoff + tcap * 2; a.nkp = nkp; a.pair_base = 0; a.tcap = (uint32_t)tcap;
     // the usual-pair kernel takes the pairs it can finish and passes the rest on; it needs the class of a k-mer next to its
@@ -883,6 +885,8 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kp[i], 64, 0) != hipSuccess || nb <= 0) nb = 8;
             if (const char* e = getenv("DBTK_PAIR_WPC")) { const int v = atoi(e); if (v > 0) nb = v; }  // diagnostic: blocks per CU (the vote scratch follows)
             if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_pair<%d>: %d waves per CU\n", i + 2, nb);
+            c->vote_rows = std::max(c->vote_rows, c->num_cu * nb);
+            if (!getenv("DBTK_PAIR_WPC")) nb *= 4;  // (ranges a quarter as long, as for the other range kernels: 0.179 -> 0.147 ms in the headline)
             c->pair_blocks[i] = c->num_cu * nb;
             c->max_pair_blocks = std::max(c->max_pair_blocks, c->pair_blocks[i]);
             const void* ku[3] = {(const void*)k_pair_usual<2, true>, (const void*)k_pair_usual<3, true>, (const void*)k_pair_usual<4, true>};
@@ -969,12 +973,12 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
         if (!st) chk(hipMemsetAsync(c->d_ctr, 0, (size_t)CTR_REP * CTR_STRIDE * 8, c->stream), "memset");
         chk(hipMalloc(&c->d_small, 4 * SMALL_WORDS + 48 * 8), "hipMalloc small");
         if (!st) chk(hipMemsetAsync(c->d_small, 0, 4 * SMALL_WORDS + 48 * 8, c->stream), "memset");
-        chk(hipMalloc(&c->d_vote, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8), "hipMalloc vote scratch");
-        chk(hipMalloc(&c->d_epoch, (size_t)c->max_pair_blocks * 4), "hipMalloc epoch");
+        chk(hipMalloc(&c->d_vote, (size_t)c->vote_rows * (h->nloci + 1) * 8), "hipMalloc vote scratch");
+        chk(hipMalloc(&c->d_epoch, (size_t)c->vote_rows * 16), "hipMalloc epoch");
         if (st) break;
         chk(hipMemsetAsync(c->d_accum, 0, c->n_accum * 8, c->stream), "memset");
-        chk(hipMemsetAsync(c->d_vote, 0, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8, c->stream), "memset");
-        chk(hipMemsetAsync(c->d_epoch, 0, (size_t)c->max_pair_blocks * 4, c->stream), "memset");
+        chk(hipMemsetAsync(c->d_vote, 0, (size_t)c->vote_rows * (h->nloci + 1) * 8, c->stream), "memset");
+        chk(hipMemsetAsync(c->d_epoch, 0, (size_t)c->vote_rows * 16, c->stream), "memset");
         // further lanes (not with -bu: its event log is replayed batch by batch on the host; not in the stamps build)
         int nlanes = 1;
 #ifndef DBTK_STAMPS
@@ -989,13 +993,13 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             dbtk_ctx::Lane l;
             chk(hipStreamCreate(&l.stream), "hipStreamCreate");
             chk(hipMalloc(&l.d_small, 4 * SMALL_WORDS + 48 * 8), "hipMalloc small");
-            chk(hipMalloc(&l.d_vote, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8), "hipMalloc vote scratch");
-            chk(hipMalloc(&l.d_epoch, (size_t)c->max_pair_blocks * 4), "hipMalloc epoch");
+            chk(hipMalloc(&l.d_vote, (size_t)c->vote_rows * (h->nloci + 1) * 8), "hipMalloc vote scratch");
+            chk(hipMalloc(&l.d_epoch, (size_t)c->vote_rows * 16), "hipMalloc epoch");
             if (li == 1) c->alt = l; else c->parked.push_back(l);
             if (st) break;
             chk(hipMemsetAsync(l.d_small, 0, 4 * SMALL_WORDS + 48 * 8, c->stream), "memset");
-            chk(hipMemsetAsync(l.d_vote, 0, (size_t)c->max_pair_blocks * (h->nloci + 1) * 8, c->stream), "memset");
-            chk(hipMemsetAsync(l.d_epoch, 0, (size_t)c->max_pair_blocks * 4, c->stream), "memset");
+            chk(hipMemsetAsync(l.d_vote, 0, (size_t)c->vote_rows * (h->nloci + 1) * 8, c->stream), "memset");
+            chk(hipMemsetAsync(l.d_epoch, 0, (size_t)c->vote_rows * 16, c->stream), "memset");
         }
         if (st) break;
         chk(hipStreamSynchronize(c->stream), "sync");

@@ -178,8 +178,10 @@ struct BatchArgs {
     uint32_t* nrec;         // kam mode: compaction counter (may exceed rec_cap)
     uint32_t rec_cap;
     uint32_t* errflag;
-    uint64_t* vote_scratch;  // per block: nloci+1 stamped hit words (see vote)
-    uint32_t* vote_epoch;    // per block
+    uint64_t* vote_scratch;  // a pool of rows of nloci+1 stamped hit words (see vote): taken by a workgroup for the one pair that needs it
+    uint32_t* vote_epoch;    // per row
+    uint64_t* vote_busy;     // per row: taken
+    uint32_t vote_rows;
     uint64_t* dbg;           // diagnostic build only (-DDBTK_STAMPS): per-phase cycle sums of k_pair
     // K2 -> K3, per (survivor, mate) row of nkp positions: the index results (val, aux), and per row the number of
     // positions and the read's offset.  The canonical k-mers do NOT travel: only the general resolve kernel needs them, for
@@ -700,13 +702,14 @@ DBTK_HD uint32_t hitmap_add(HitMap& m, uint32_t locus, uint32_t add) {  // retur
         }
         if (m.n < m.limit) { m.lkey[i] = locus; m.lhit[i] = add; ++m.n; return add; }
         for (uint32_t j = 0; j < m.cap; ++j)  // migrate
-            if (m.lkey[j] != NAN32) m.g[m.lkey[j]] = ((uint64_t)m.epoch << 32) | m.lhit[j];
+            if (m.lkey[j] != NAN32) DBTK_COH_STORE(&m.g[m.lkey[j]], ((uint64_t)m.epoch << 32) | m.lhit[j]);
         m.spilled = true;
     }
-    const uint64_t w = m.g[locus];
+    // (the row was last written by whichever workgroup held it before: its words are read and written at the device-coherent level)
+    const uint64_t w = DBTK_COH_LOAD(&m.g[locus]);
     const uint32_t cur = ((uint32_t)(w >> 32) == m.epoch) ? (uint32_t)w : 0u;
     const uint32_t nw = cur + add;
-    m.g[locus] = ((uint64_t)m.epoch << 32) | nw;
+    DBTK_COH_STORE(&m.g[locus], ((uint64_t)m.epoch << 32) | nw);
     return nw;
 }
 
@@ -2091,14 +2094,20 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
 #endif
                     if (lane == 0) {
                         for (uint32_t u = 0; u < nu; ++u) sm.w.a.dd[u] &= 0x00FF00FFu;  // PE_KMC counts are uint8_t
-                        const uint32_t ep = a.vote_epoch[x.bid()] + 1;
-                        HitMap hmap{sm.u.v.lkey, sm.w.a.lhit, 0, a.vote_scratch + (size_t)x.bid() * ((size_t)nloci + 1), ep, false,
+                        // a row of the spill pool for this pair (as many rows as workgroups can be resident, so one is always free; the grid
+                        // has several times as many workgroups): whoever held it before left its epoch
+                        uint32_t row = x.bid() % a.vote_rows;
+                        while (x.atomic_cas(&a.vote_busy[row], 0ull, 1ull) != 0ull) row = row + 1 < a.vote_rows ? row + 1 : 0u;
+                        const uint32_t ep = DBTK_COH_LOAD(&a.vote_epoch[row]) + 1;
+                        HitMap hmap{sm.u.v.lkey, sm.w.a.lhit, 0, a.vote_scratch + (size_t)row * ((size_t)nloci + 1), ep, false,
                                     (uint32_t)LCAP, LCAP == 512 ? 23u : 24u, (uint32_t)(LCAP * 3 / 4)};
                         Asgn top;
                         uint64_t nvvw = 0;
                         vote(T, sm.u.v.ord, sm.w.a.uval, sm.w.a.dd, (int)nu, cth, hmap, top, nvvw, sm.u.v.nml, sm.evd, sm.w.a.poff);
                         c_vv += nvvw;
-                        if (hmap.spilled) a.vote_epoch[x.bid()] = ep;
+                        if (hmap.spilled) DBTK_COH_STORE(&a.vote_epoch[row], ep);
+                        DBTK_COH_RELEASE();
+                        DBTK_COH_STORE(&a.vote_busy[row], 0ull);
                         sm.res[0] = (int32_t)(uint32_t)top.idx;
                         sm.res[1] = (int32_t)top.fc;
                         sm.res[2] = (int32_t)top.rc;

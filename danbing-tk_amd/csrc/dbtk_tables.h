@@ -22,6 +22,18 @@
 struct uint4 { uint32_t x, y, z, w; };  // host (tests/emu) stand-in for HIP's vector type
 #endif
 
+// Loads / stores that go to the device-coherent level (past the CU's own L1): for the few words one workgroup leaves for
+// whichever workgroup comes next inside the same kernel (dbtk_kernels.h: the pooled vote-spill rows).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DBTK_COH_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define DBTK_COH_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define DBTK_COH_RELEASE() __atomic_thread_fence(__ATOMIC_RELEASE)
+#else
+#define DBTK_COH_LOAD(p) (*(p))
+#define DBTK_COH_STORE(p, v) (*(p) = (v))
+#define DBTK_COH_RELEASE() ((void)0)
+#endif
+
 namespace dbtk {
 
 constexpr uint64_t NAN64 = DBTK_NAN64;

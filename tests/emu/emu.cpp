@@ -661,7 +661,9 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     a.surv = surv.data(); a.nsurv = &small[0]; a.nrec = &small[2]; a.errflag = &small[3];
     a.counts = accum.data(); a.kmc = a.counts + ntr; a.nmapread = a.kmc + nloci; a.counters = a.nmapread + nloci;
     a.recs = recs; a.rec_cap = (uint32_t)rec_cap;
-    a.vote_scratch = vote.data(); a.vote_epoch = epoch.data();
+    // (two rows for any number of workgroups: the pool is taken from and given back per pair)
+    std::vector<uint64_t> vbusy(2, 0);
+    a.vote_scratch = vote.data(); a.vote_epoch = epoch.data(); a.vote_busy = vbusy.data(); a.vote_rows = grid_pair < 2 ? grid_pair : 2;
     std::vector<uint32_t> walk(2 * npairs + 2, NAN32);
     a.walk_dst = walk.data();
     uint32_t maxlen = 1;
