@@ -79,7 +79,8 @@ def parse_args(argv=None):
                          "with the other's probe kernel but then a kernel's launch duration includes its neighbour's work, so the roofline "
                          "measurement runs on one lane")
     ap.add_argument("--timer-every", type=int, default=4, help="record the per-kernel HIP events on every n-th step")
-    ap.add_argument("--extra-lanes", action="store_true", help="also run the timed steps on two overlapped lanes and report them as `two_lanes`")
+    ap.add_argument("--extra-lanes", action="store_true", default=True, help="also run the timed steps on two overlapped lanes (the library's default outside this bench) and report them as `two_lanes` [on]")
+    ap.add_argument("--no-extra-lanes", dest="extra_lanes", action="store_false")
     ap.add_argument("--lib", default=None, help="diagnostic: another build of libdbtk_hip.so (tuning variants)")
     return ap.parse_args(argv)
 
@@ -379,7 +380,7 @@ def main():
         ctx2.timers_enable(False)
         dt2 = time_steps(ctx2, lambda: ctx2.align_device(d_seq.data_ptr(), d_off.data_ptr(), npairs, rlen), args.steps, args.warmup)
         two_lanes = dict(value=2 * npairs * args.steps / dt2, unit="reads/s", ms_per_step=dt2 / args.steps * 1e3,
-                         note="untimed extra: same steps, context with DBTK_LANES=2 (successive batches alternate between two streams)")
+                         note="extra, not `value`: the same steps on a context with the library's default DBTK_LANES=2 (successive batches alternate between two streams, one batch's encode kernel overlaps the other's probe and resolve kernels); `value` is the one-lane figure, whose per-kernel times add up to the step")
         ctx2.close()
 
     # ---- N = 1 extras: further read mixes, end to end, CPU baselines
