@@ -249,11 +249,24 @@ static dbtk_status_t dbtk_rpgg_load_impl(const char* prefix, const char* tr_kmer
     g->ksize = ksize;
     const std::string pref(prefix);
     // (the TR k-mer file may be named explicitly: -t N reads PREF.tr.trimN.kmers in place of PREF.tr.kmers, AQ.cpp:2389, 2459, 2493)
-    dbtk_status_t st = read_tr_kmers(tr_kmers_file ? std::string(tr_kmers_file) : pref + ".tr.kmers", g->tr_cnt, g->tr_ks);
-    if (st) return st;
-    g->nloci = g->tr_cnt.size();
     const bool head_index = file_exists(pref + ".kmers.dbi");
     const bool legacy = !head_index && file_exists(pref + ".kmerDBi.umap");
+    // The HEAD files are read side by side: the text of PREF.tr.kmers is parsed (then PREF.fl.kdb / PREF.tre.kdb read, which are checked
+    // against its locus count) on one thread while PREF.kmers.dbi, the largest, comes in on this one.  (Errors are thread-local
+    // strings: the helper's is handed over with its status.)
+    dbtk_status_t st = DBTK_OK, st_side = DBTK_OK;
+    std::string err_side;
+    const bool side_kdb = !legacy && !(flags & DBTK_LOAD_INDEX_ONLY);
+    std::thread side([&] {
+        st_side = read_tr_kmers(tr_kmers_file ? std::string(tr_kmers_file) : pref + ".tr.kmers", g->tr_cnt, g->tr_ks);
+        if (!st_side && side_kdb) {
+            const uint64_t nl = g->tr_cnt.size();
+            if (!(st_side = read_kdb(pref + ".fl.kdb", nl, g->fl_cnt, g->fl_ks))) st_side = read_kdb(pref + ".tre.kdb", nl, g->tre_cnt, g->tre_ks);
+        }
+        if (st_side) err_side = dbtk::g_err;
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{side};
+    auto read_index = [&]() -> dbtk_status_t {
     if (!legacy) {
         // PREF.kmers.dbi: u64 nk | u64 keys[nk] | u32 vals[nk] | u64 nvv | u32 vv[nvv]
         // (src/kmertools.cpp:271-280; reader src/aQueryFasta_thread.h:654-673)
@@ -309,6 +322,14 @@ static dbtk_status_t dbtk_rpgg_load_impl(const char* prefix, const char* tr_kmer
             }
         }
     }
+    return DBTK_OK;
+    };
+    st = read_index();
+    const std::string err_main = st ? dbtk::g_err : std::string();
+    side.join();
+    if (st_side) { set_error(err_side); return st_side; }  // (PREF.tr.kmers is what the reference opens first: its error comes first)
+    if (st) { set_error(err_main); return st; }
+    g->nloci = g->tr_cnt.size();
     if (flags & DBTK_LOAD_INDEX_ONLY) {
         g->fl_cnt.assign(g->nloci, 0);
         g->tre_cnt.assign(g->nloci, 0);
@@ -317,10 +338,7 @@ static dbtk_status_t dbtk_rpgg_load_impl(const char* prefix, const char* tr_kmer
         if ((st = read_tr_kmers(pref + ".ntr.kmers", g->fl_cnt, g->fl_ks))) return st;
         if (g->fl_cnt.size() != g->nloci) { set_error(pref + ".ntr.kmers: locus count differs from .tr.kmers"); return DBTK_ERR_FORMAT; }
         g->tre_cnt.assign(g->nloci, 0);
-    } else {
-        if ((st = read_kdb(pref + ".fl.kdb", g->nloci, g->fl_cnt, g->fl_ks))) return st;
-        if ((st = read_kdb(pref + ".tre.kdb", g->nloci, g->tre_cnt, g->tre_ks))) return st;
-    }
+    }  // (HEAD: PREF.fl.kdb and PREF.tre.kdb were read by the helper thread)
     if (qc_file && (flags & DBTK_LOAD_INDEX_ONLY)) {
         // extract mode never calls readQCFile (AQ.cpp:2484-2488): the mask stays as constructed, all zero
         // (AQ.cpp:2471), so with -qc every assigned pair fails the QC gate.  Reproduced as is.
