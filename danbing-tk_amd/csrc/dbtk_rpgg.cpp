@@ -258,11 +258,14 @@ static dbtk_status_t dbtk_rpgg_load_impl(const char* prefix, const char* tr_kmer
     std::string err_side;
     const bool side_kdb = !legacy && !(flags & DBTK_LOAD_INDEX_ONLY);
     std::thread side([&] {
-        st_side = read_tr_kmers(tr_kmers_file ? std::string(tr_kmers_file) : pref + ".tr.kmers", g->tr_cnt, g->tr_ks);
-        if (!st_side && side_kdb) {
-            const uint64_t nl = g->tr_cnt.size();
-            if (!(st_side = read_kdb(pref + ".fl.kdb", nl, g->fl_cnt, g->fl_ks))) st_side = read_kdb(pref + ".tre.kdb", nl, g->tre_cnt, g->tre_ks);
-        }
+        st_side = dbtk::guarded([&]() -> dbtk_status_t {  // (no exception may leave the thread: a damaged count field asks for terabytes)
+            dbtk_status_t s1 = read_tr_kmers(tr_kmers_file ? std::string(tr_kmers_file) : pref + ".tr.kmers", g->tr_cnt, g->tr_ks);
+            if (!s1 && side_kdb) {
+                const uint64_t nl = g->tr_cnt.size();
+                if (!(s1 = read_kdb(pref + ".fl.kdb", nl, g->fl_cnt, g->fl_ks))) s1 = read_kdb(pref + ".tre.kdb", nl, g->tre_cnt, g->tre_ks);
+            }
+            return s1;
+        });
         if (st_side) err_side = dbtk::g_err;
     });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{side};
