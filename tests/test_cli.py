@@ -431,8 +431,9 @@ def test_cli_device_reader_equals_host_reader(tmp_path):
     recs = data.split(b">")[1:]
     half = sum(len(r) + 1 for r in recs[:5000])
     open(os.path.join(d, "half.fa"), "wb").write(data[:half] + b">orphan/1\n" + reads.seqs[0] + b"\n" + data[half:])
+    open(os.path.join(d, "odd.fa"), "wb").write(data + b">last/1\n" + reads.seqs[2] + b"\n")  # (ends inside a pair: the tail is the host reader's)
     for flags, fn, chunk in ((["-cth", "45"], "r.fa", "20000"), (["-cth", "45"], "nonl.fa", "50000"), (["-cth", "45", "-ka"], "r.fa", "8192"),
-                             (["-cth", "30", "-e", "1"], "r.fq", "30000"), (["-cth", "30", "-kf", "8", "2"], "r.fq", None), (["-cth", "45"], "half.fa", "65536")):
+                             (["-cth", "30", "-e", "1"], "r.fq", "30000"), (["-cth", "30", "-kf", "8", "2"], "r.fq", None), (["-cth", "45"], "half.fa", "65536"), (["-cth", "45"], "odd.fa", "40000")):
         outs = []
         for tag, extra in (("host", ["--host-ingest"]), ("dev", [])):
             env = dict(os.environ)
@@ -448,6 +449,8 @@ def test_cli_device_reader_equals_host_reader(tmp_path):
         total = int(ing.split(" s for ")[1].split()[0])
         if fn == "half.fa":
             assert 0 < ndev < total and b"the host reader takes over" in outs[1].stderr
+        elif fn == "odd.fa":
+            assert ndev == total > 0 and b"the host reader takes over" in outs[1].stderr  # (every pair on the device; the lone record is parked by the host reader)
         else:
             assert ndev == total > 0, ing
         assert [l for l in outs[0].stderr.decode().splitlines() if l[:1].isdigit() and " reads " in l] == \
