@@ -80,6 +80,9 @@ struct DevX {
     __device__ uint32_t shfl_up1(uint32_t v) const {  // value of lane - 1 (lane 0 keeps its own): wave_shr:1
         return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
     }
+    __device__ uint32_t shfl_down1(uint32_t v) const {  // value of lane + 1 (lane 63 keeps its own): wave_shl:1
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);
+    }
     // lane 4q+j reads lane 4q+Pj (DPP quad_perm: no LDS traffic).  Every lane of the wave must be active at the call.
     template <int P0, int P1, int P2, int P3> __device__ uint32_t quad_perm(uint32_t v) const {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, true);

@@ -8,7 +8,7 @@
 //   * one wave per surviving PAIR, one mate per half-wave: lane l of a half owns the NPL consecutive positions l * NPL ..
 //     l * NPL + NPL - 1 of its mate (NPL = 5: reads up to 32 * 5 + m - 1 bases); everything a position needs is a shift of
 //     one 32-base word W held by its lane and of W's reverse complement: the canonical k-mer, and the hashed canonical
-//     m-mer of every BASE (each hashed once, exchanged through LDS), whose sliding minimum is the position's minimizer;
+//     m-mer of every BASE (each hashed once, handed to the two lanes before by DPP), whose sliding minimum is the position's minimizer;
 //   * a RUN of positions with one minimizer shares a bucket: run starts are found with one wave scan, and the bucket of
 //     every run is fetched ONCE — 8 lanes x 16 bytes, 8 runs per load instruction, the next chunk of runs in flight while
 //     this one is searched — into LDS, where every position compares its k-mer with the 8 keys of its run's bucket;
@@ -35,8 +35,7 @@ struct __attribute__((aligned(16))) Probe2SmemT {
     uint32_t pk[2][20];              // 2-bit stream of each mate from its 4-byte-aligned start: 16 words (+ slack)
     uint16_t vd[2][40];              // validity bits of the same bases (only for a pair with a non-ACGT byte)
     uint32_t rb[64 * NPL];           // bucket of every run of the pair
-    union {                          // three phases share one region
-        uint32_t hm[2][32 * NPL + 16];                                  // hashed canonical m-mer by base position (the last 16 stay 0xFFFFFFFF)
+    union {                          // two phases share one region
         uint4 stg[P2_RCH][P2_ROW];                                      // the buckets of a chunk of runs
         uint32_t res[2][2][32 * NPL];                                   // [mate][aux | val][position]: results on their way to 16-byte stores
     };
@@ -152,7 +151,6 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
             const uint32_t c0 = pack4_b2(d0, &bad), c1 = pack4_b2(d1, &bad);
             reinterpret_cast<uint16_t*>(sm.pk[half])[hl ^ 1u] = (uint16_t)(((c0 >> 8) & 0xFF00u) | ((c1 >> 16) & 0xFFu));
         }
-        if (hl < 16) sm.hm[half][32 * NPL + hl] = 0xFFFFFFFFu;  // (the region is shared with the later phases: every pair)
         const uint32_t nk = len >= k ? len - k + 1 : 0, nmm = len >= m ? len - m + 1 : 0;
         // Every byte of both mates ACGT (the usual pair): all windows are valid.  (Bytes of the lane's dwords outside the read
         // are the neighbouring reads': a non-ACGT byte there only sends this pair down the exact path for nothing.)
@@ -162,12 +160,17 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
             x.sync();
             const uint64_t W = window_fw_clean(sm.pk[half], rsh + p0, 32);  // the 32 bases from position p0
             const uint64_t RW = revcomp2(W, 32);                            // base t of that window at bits 2t
-            // hashed canonical m-mer at the lane's own base positions
+            // hashed canonical m-mer at the lane's own base positions; a position's window reaches into the next two lanes' m-mers:
+            // they come over by DPP (wave_shl), not through LDS.  (Lane 31's neighbours are the other mate's: only windows past the
+            // end of the read reach them, and those positions are not looked up.)
+            uint32_t f[NPL + WN - 1];
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
                 const uint32_t fwm = (uint32_t)(W >> (2 * (32 - m - j))) & mmask, rcm = (uint32_t)(RW >> (2 * j)) & mmask;
-                sm.hm[half][p0 + j] = p0 + j < nmm ? mmer_hash2(fwm, rcm) : 0xFFFFFFFFu;
+                f[j] = p0 + j < nmm ? mmer_hash2(fwm, rcm) : 0xFFFFFFFFu;
             }
+#pragma unroll
+            for (int t = NPL; t < NPL + WN - 1; ++t) f[t] = x.shfl_down1(f[t - NPL]);
             // canonical k-mers (the m-mer hashes make their round trip through LDS meanwhile)
             uint64_t km[NPL];
             bool act[NPL];
@@ -179,10 +182,7 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
                 rv[j] = (uint64_t)NOHIT;
             }
             DBTK_STAMP(40);  // fetch pipeline, pack, windows, m-mer hashes
-            x.sync();
-            uint32_t f[NPL + WN - 1], mz[NPL], bk[NPL];
-#pragma unroll
-            for (int t = 0; t < NPL + WN - 1; ++t) f[t] = sm.hm[half][p0 + t];
+            uint32_t mz[NPL], bk[NPL];
             sliding_min<NPL, WN>(f, mz);
             // runs: a position opens one when its bucket differs from the previous position's (a mate's first position always does)
             uint32_t cnt = 0;
@@ -216,7 +216,7 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
 #pragma unroll
             for (int j = 0; j < NPL; ++j) pend[j] = false;
             for (uint32_t r0 = 0; r0 < nruns; r0 += P2_RCH) {
-                x.sync();  // (the m-mer hashes / the previous chunk are dead)
+                x.sync();  // (the previous chunk is dead)
 #pragma unroll
                 for (int u = 0; u < P2_RCH / 8; ++u) *reinterpret_cast<p2_v4u*>(&sm.stg[8 * u + fq8][part]) = q[u];
                 p2_fetch_runs(sm.rb, T.mz, nruns, r0 + P2_RCH, fq8, part, P2_DIAG_MASK(a), q);  // the next chunk's loads go out before this one is searched

@@ -76,6 +76,7 @@ struct EmuX {
     uint32_t bcast(uint32_t v, int src) const;
     uint32_t wave_scan_lastnz(uint32_t v) const;
     uint32_t shfl_up1(uint32_t v) const;
+    uint32_t shfl_down1(uint32_t v) const;
     template <int P0, int P1, int P2, int P3> uint32_t quad_perm(uint32_t v) const;
     template <int E> void shfl_xor64(const uint64_t (&in)[E], uint64_t (&out)[E], int mask) const;
     void atomic_add(uint64_t* p, uint64_t v) const { *p += v; }
@@ -207,6 +208,13 @@ uint32_t EmuX::shfl_up1(uint32_t v) const {
     b->scratch[t] = v;
     b->yield();
     const uint32_t r = (t & 63) ? (uint32_t)b->scratch[t - 1] : v;
+    b->yield();
+    return r;
+}
+uint32_t EmuX::shfl_down1(uint32_t v) const {
+    b->scratch[t] = v;
+    b->yield();
+    const uint32_t r = ((t & 63) != 63 && t + 1 < b->nt) ? (uint32_t)b->scratch[t + 1] : v;
     b->yield();
     return r;
 }
