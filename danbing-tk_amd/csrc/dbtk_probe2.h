@@ -225,20 +225,20 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
                 for (int j = 0; j < NPL; ++j) {
                     const uint32_t row = rid[j] - r0;
                     const bool mine = act[j] && row < (uint32_t)P2_RCH;
-                    const uint4* rp = sm.stg[mine ? row : 0u];
-                    int hit = -1;
-                    uint32_t w7 = 0;
+                    if (mine) {  // (under the execution mask: the lanes whose rows are in the other chunk cost the LDS nothing: 4.90 -> 4.70 ms)
+                        const uint4* rp = sm.stg[row];
+                        int hit = -1;
+                        uint32_t w7 = 0;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {  // (64-bit compares; only key 7 can carry the flag bit)
-                        const uint4 kk = rp[g];
-                        const uint64_t k0 = ((uint64_t)kk.y << 32) | kk.x, k1 = ((uint64_t)kk.w << 32) | kk.z;
-                        if (k0 == km[j]) hit = 2 * g;
-                        if ((g == 3 ? (k1 & ~MZ_TURNED) : k1) == km[j]) hit = 2 * g + 1;
-                        if (g == 3) w7 = kk.w;
-                    }
-                    const uint32_t* pl = reinterpret_cast<const uint32_t*>(rp + 4) + 2 * (hit >= 0 ? hit : 0);
-                    const uint64_t pv = (uint64_t)pl[0] | ((uint64_t)pl[1] << 32);
-                    if (mine) {
+                        for (int g = 0; g < 4; ++g) {  // (64-bit compares; only key 7 can carry the flag bit)
+                            const uint4 kk = rp[g];
+                            const uint64_t k0 = ((uint64_t)kk.y << 32) | kk.x, k1 = ((uint64_t)kk.w << 32) | kk.z;
+                            if (k0 == km[j]) hit = 2 * g;
+                            if ((g == 3 ? (k1 & ~MZ_TURNED) : k1) == km[j]) hit = 2 * g + 1;
+                            if (g == 3) w7 = kk.w;
+                        }
+                        const uint32_t* pl = reinterpret_cast<const uint32_t*>(rp + 4) + 2 * (hit >= 0 ? hit : 0);
+                        const uint64_t pv = (uint64_t)pl[0] | ((uint64_t)pl[1] << 32);
                         if (hit >= 0) rv[j] = pv;
                         else pend[j] = (w7 >> 31) != 0;  // the bucket turned keys away: ask the overflow table
                     }
