@@ -219,7 +219,8 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
                 x.sync();  // (the previous chunk is dead)
 #pragma unroll
                 for (int u = 0; u < P2_RCH / 8; ++u) *reinterpret_cast<p2_v4u*>(&sm.stg[8 * u + fq8][part]) = q[u];
-                p2_fetch_runs(sm.rb, T.mz, nruns, r0 + P2_RCH, fq8, part, P2_DIAG_MASK(a), q);  // the next chunk's loads go out before this one is searched
+                if (r0 + P2_RCH < nruns)  // (uniform) the next chunk's loads go out before this one is searched
+                    p2_fetch_runs(sm.rb, T.mz, nruns, r0 + P2_RCH, fq8, part, P2_DIAG_MASK(a), q);
                 x.sync();
 #pragma unroll
                 for (int j = 0; j < NPL; ++j) {
