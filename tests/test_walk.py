@@ -548,3 +548,49 @@ def test_gpu_walks_the_reference_graph_fixture(tmp_path):
 if __name__ == "__main__":  # worker of test_oracle_walk_equals_reference
     oracle_vs_reference(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))
     glue_oracle_vs_reference(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aln", [1, 2])
+def test_gpu_device_writer_lines_equal_the_oracles(tmp_path, aln):
+    """dbtk_ingest_aln_lines through the C-ABI: the raw bytes of an interleaved FASTA in, writeAlignments' lines out (AQ.cpp:1742-1759),
+    assembled on the device from the parsed block and the walk's text records — as text and as gzip members — against the lines
+    built from the oracle's alignment strings (which the reference's own writeCigar / writeAnnot pin)."""
+    import gzip
+    k = 21
+    O = bind.Oracle()
+    D = bind.pkg.Dbtk()
+    case = WalkCase(str(tmp_path), f"dw{aln}", k, 3)
+    oh = O.load(case.prefix, k); O.load_graph(oh, case.prefix + ".graph.kmers")
+    g = D.load(case.prefix, k, flags=abi.LOAD_GRAPH)
+    p = abi.default_params(ksize=k, cthreshold=45, threading=2, aln=aln, okam=0, **PARAM_SETS[1])
+    reads = pair_reads(case, seed=77)
+    minread = 45 + k - 1
+    keep = [q for q in range(reads.npairs) if len(reads.seqs[2 * q]) >= minread and len(reads.seqs[2 * q + 1]) >= minread]
+    sub = synth.Reads()
+    for q in keep:
+        sub.seqs += [reads.seqs[2 * q], reads.seqs[2 * q + 1]]
+        sub.titles.append(reads.titles[q])
+    seq, off = sub.packed()
+    o = O.align_walk(oh, p, seq, off)
+    exp, _ = expected_aln(O, o, sub, aln, case.loci.nloci)
+    want = b"".join(b".\t%d\t>%s\t%s\t%s\t%s\n" % (dst, sub.titles[pr].encode(), sub.seqs[2 * pr + 1], sub.seqs[2 * pr], t.encode()) for pr, dst, t in exp)
+    assert want.count(b"\n") > 100
+    data = b"".join(b">" + reads.titles[q].encode() + b"/2\n" + reads.seqs[2 * q + 1] + b"\n>" + reads.titles[q].encode() + b"/1\n" + reads.seqs[2 * q] + b"\n"
+                    for q in range(reads.npairs))
+    p.aln = aln | abi.ALN_TEXT
+    for gz, chunk in ((False, 1 << 22), (True, 1 << 22), (True, 70000)):
+        ctx = D.context(g, p, device=0)
+        ing = bind.pkg.Ingest(ctx, False, minread, chunk, nslots=3, with_spans=True)
+        got, nl = b"", 0
+        nblocks = (len(data) + chunk - 1) // chunk
+        for j in range(nblocks):  # (one block at a time: the lines are those of the block aligned last)
+            slot = ing.submit(data[j * chunk:(j + 1) * chunk], j == nblocks - 1)
+            info = ing.wait(slot)
+            assert info.flags == 0
+            ing.align(slot, info, sync=True)
+            b, n, tb = ing.aln_lines(slot, gz=gz)
+            got += b; nl += n
+            assert gz or tb == len(b)
+        ing.close(); ctx.close()
+        assert (gzip.decompress(got) if gz else got) == want and nl == want.count(b"\n"), (gz, chunk)
