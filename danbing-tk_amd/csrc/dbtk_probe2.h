@@ -432,14 +432,34 @@ struct SurvSortArgs {
 };
 constexpr uint32_t SORT_MIN_PER_LOCUS = 4;
 // canonical k-mer of the k bytes at p; NAN64 if one of them is not A, C, G or T
-DBTK_HD uint64_t kmer_of_bytes(const uint8_t* p, uint32_t k) {
+// The k bytes come in with three 16-byte loads from the 16-byte-aligned chunk below them (a load per byte is a request per byte: a line
+// asked for by one instruction is one request, dbtk_tables.h — 21 requests per survivor made this the most expensive of the sort's three
+// kernels) and are shifted into place; `seq` is readable up to the next multiple of 16 past its last read (dbtk.h): no load goes past the
+// chunk that holds the k-mer's last byte.
+DBTK_HD uint64_t kmer_of_bytes(const uint8_t* seq, uint64_t pos, uint32_t k) {
+    const uint64_t b0 = pos & ~15ull;
+    const uint32_t sh = (uint32_t)(pos & 15);
+    const uint4* c = reinterpret_cast<const uint4*>(seq + b0);
+    const uint32_t i1 = sh + k > 16 ? 1u : 0u, i2 = sh + k > 32 ? 2u : i1;  // (never past the chunk that holds the k-mer's last byte)
+    const uint4 c0 = c[0], c1 = c[i1], c2 = c[i2];
+    const uint64_t q[6] = {((uint64_t)c0.y << 32) | c0.x, ((uint64_t)c0.w << 32) | c0.z, ((uint64_t)c1.y << 32) | c1.x,
+                           ((uint64_t)c1.w << 32) | c1.z, ((uint64_t)c2.y << 32) | c2.x, ((uint64_t)c2.w << 32) | c2.z};
+    uint64_t r[5], w[4];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) r[t] = (sh & 8) ? q[t + 1] : q[t];
+    const uint32_t s = 8 * (sh & 7);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w[t] = s ? (r[t] >> s) | (r[t + 1] << (64 - s)) : r[t];
     uint64_t fw = 0, rc = 0;
     bool ok = true;
-    for (uint32_t i = 0; i < k; ++i) {
-        const uint32_t c = p[i], code = ((c >> 1) ^ (c >> 2)) & 3u;
-        ok = ok && (c == 'A' || c == 'C' || c == 'G' || c == 'T');
-        fw = (fw << 2) | code;
-        rc = (rc >> 2) | ((uint64_t)(3u - code) << (2 * (k - 1)));
+#pragma unroll
+    for (uint32_t i = 0; i < 32; ++i) {
+        if (i < k) {
+            const uint32_t ch = (uint32_t)(w[i >> 3] >> (8 * (i & 7))) & 0xFFu, code = ((ch >> 1) ^ (ch >> 2)) & 3u;
+            ok = ok && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
+            fw = (fw << 2) | code;
+            rc = (rc >> 2) | ((uint64_t)(3u - code) << (2 * (k - 1)));
+        }
     }
     return ok ? (fw < rc ? fw : rc) : NAN64;
 }
@@ -460,7 +480,7 @@ DBTK_HD void body_surv_key(X& x, const SurvSortArgs& a) {
             const uint32_t L = len - k + 1, S = NF > 1 ? L / (NF - 1) : 0;
             for (uint32_t sidx = 0; sidx < NF && key == nloci; ++sidx) {
                 const uint32_t pos = sidx != NF - 1 ? sidx * S : L - 1;
-                const uint64_t km = pos < L ? kmer_of_bytes(a.seq + o0 + pos, k) : NAN64;
+                const uint64_t km = pos < L ? kmer_of_bytes(a.seq, o0 + pos, k) : NAN64;
                 if (km == NAN64) continue;
                 const uint32_t v = idx_lookup(a.T, km);
                 if (v != NOHIT) key = (v & 1u) ? a.T.vv[(v >> 1) + 1] : v >> 1;
