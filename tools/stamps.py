@@ -55,11 +55,12 @@ def main():
     print(f"  slowest pair: {int(st[47]) >> 32} cycles, {(int(st[47]) >> 12) & 0xFFFFF} loci-list words, {int(st[47]) & 0xFFF} distinct k-mers")
     print("  pair times (cycles, all 3 steps): " + ", ".join(f"<2^{12 + 2 * b}: {int(st[21 + b if b < 3 else 26 + b])}" for b in range(6)))
     st[44:47] = 0
-    k2 = {40: "K2 fetch+pack", 16: "K2 mz: m-mer hashes", 17: "K2 mz: minimizers+runs", 18: "K2 mz: home buckets", 41: "K2 windows/list stage", 42: "K2 look-ups+stores", 43: "K2 loop/extras"}
-    print(f"K2 runs per read: {float(st[19]) / 64 / max(2.0 * r[abi.C_SURVIVORS], 1):.1f}")
+    # (the lean probe kernel, dbtk_probe2.h; its stamps 16 and 18 share their words with K1's tile stamps above: with survivors to probe
+    # the K1 lines for those two indexes are not K1's alone)
+    k2 = {40: "K2 fetch+pack+windows+hashes", 16: "K2 minimizers+runs", 18: "K2 level 1 (buckets)", 41: "K2 level 2 (overflow)", 42: "K2 results", 43: "K2 loop"}
     nrows = 2.0 * r[abi.C_SURVIVORS]
     for i, n in k2.items():
-        print(f"{n:22s} {float(st[i]) / nrows:10.0f} cycles/read")
+        print(f"{n:30s} {float(st[i]) / nrows:10.0f} cycles/read")
     st[40:44] = 0
     u = st[32:48]
     names = {32: "usual: request+test", 33: "usual: states", 34: "usual: assign", 35: "usual: LDS histogram", 36: "usual: delivery", 37: "usual: count atomics", 39: "usual: loop/record"}
