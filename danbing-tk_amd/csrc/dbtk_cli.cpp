@@ -364,6 +364,8 @@ int main(int argc, char* argv[]) {
 
     // ---- load (AQ.cpp:2459-2504)
     time_t time1 = time(nullptr);
+    auto wall = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
+    const double tl0 = wall();
     dbtk_rpgg_t* rpgg = nullptr;
     const bool use_bait = o.bait && !o.extractFastX && !o.threading;  // baitDB is only read and used on that path
     const bool walk = o.v13 && o.threading && !o.extractFastX;          // the graph walk of the v1.3 contract (AQ.cpp:2072-2088)
@@ -392,9 +394,11 @@ int main(int argc, char* argv[]) {
     P.bubbles = o.outputBubbles && !o.extractFastX && !o.threading;  // countNovelEdges only runs on the assignment path
     if (o.ngpus < 1) o.ngpus = 1;
     std::vector<dbtk_ctx_t*> ctx(o.ngpus, nullptr);
+    const double tl1 = wall();
     if (!o.parseOnly)
         for (int d = 0; d < o.ngpus; ++d)
             if (dbtk_ctx_create(rpgg, &P, d, &ctx[d])) die_assert(dbtk_last_error());
+    fprintf(stderr, "load: RPGG files %.2f s, tables in HBM %.2f s\n", tl1 - tl0, wall() - tl1);
     // --parse-only: what the pairing stage handed to the aligner stage: pairs, bases, and an order-independent digest
     // of (title, seq1, seq2[, qual1, qual2]) per pair (FNV-1a per pair, summed), for the ingest tests (no GPU needed)
     std::atomic<uint64_t> po_pairs{0}, po_bases{0}, po_digest{0};
