@@ -1499,30 +1499,60 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
         uint64_t at[NPL];
         bool act[NPL], open[NPL];
         uint4 q[NPL];
-        bool anyo = false;
+        // The look-ups, one request each, are what this kernel costs, and six pairs in ten have no cleanly threading mate: so two of a
+        // lane's five positions are looked up first.  A k-mer with a wrong base is no node, and a wrong base makes k consecutive
+        // positions such k-mers: a position (not the mate's last: its own node is never asked for) that is no node settles that its
+        // mate does not thread cleanly; a pair neither of whose mates can (with text records: not both) goes on to the other kernel
+        // without the remaining look-ups.  Whatever the sample misses (a wrong base in the first or last two bases) the full test
+        // below still finds.
+        auto pass = [&](bool first) {
+            bool anyo = false;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                open[j] = act[j] && (((j & 1) == 1) == first);
+                if (open[j]) { at[j] = hash_cls(cn[j], dst, T.gr_shift); q[j] = reinterpret_cast<const uint4*>(T.gr)[at[j]]; }
+                anyo |= open[j];
+            }
+            while (x.ballot(anyo)) {  // (a look-up rarely needs a second slot)
+                anyo = false;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    if (!open[j]) continue;
+                    if (q[j].x == (uint32_t)cn[j] && q[j].y == (uint32_t)(cn[j] >> 32) && q[j].w == dst) { gi[j] = q[j].z; open[j] = false; }
+                    else if ((q[j].x & q[j].y) == 0xFFFFFFFFu) open[j] = false;  // empty slot: not in the table
+                    else { at[j] = (at[j] + 1) & T.gr_mask; q[j] = reinterpret_cast<const uint4*>(T.gr)[at[j]]; }
+                    anyo |= open[j];
+                }
+            }
+        };
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             fw[j] = (W >> (2 * (32 - k - j))) & kmask;
             const uint64_t rc = (RW >> (2 * j)) & kmask;
             cn[j] = fw[j] <= rc ? fw[j] : rc;
             act[j] = p0 + j < nk;
-            at[j] = act[j] ? hash_cls(cn[j], dst, T.gr_shift) : 0ull;
-            q[j] = reinterpret_cast<const uint4*>(T.gr)[at[j]];
-            open[j] = act[j];
-            gi[j] = 0;
-            anyo |= open[j];
+            at[j] = 0; gi[j] = 0; open[j] = false;
+            q[j] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
         }
-        while (x.ballot(anyo)) {  // (a look-up rarely needs a second slot)
-            anyo = false;
+        bool defer = badm != 0;  // (a pair with a non-ACGT byte is the other kernel's whatever its mates do)
+        if (!defer) {
+            pass(true);
+            bool nonode = false;
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                if (!open[j]) continue;
-                if (q[j].x == (uint32_t)cn[j] && q[j].y == (uint32_t)(cn[j] >> 32) && q[j].w == dst) { gi[j] = q[j].z; open[j] = false; }
-                else if ((q[j].x & q[j].y) == 0xFFFFFFFFu) open[j] = false;  // empty slot: not in the table
-                else { at[j] = (at[j] + 1) & T.gr_mask; q[j] = reinterpret_cast<const uint4*>(T.gr)[at[j]]; }
-                anyo |= open[j];
+            for (int j = 1; j < NPL; j += 2) {
+                const uint32_t gs = fw[j] == cn[j] ? gi[j] & 0x1Fu : (gi[j] >> GR_OPP) & 0x1Fu;
+                nonode |= act[j] && p0 + j + 1 < nk && !(gs & GR_HAS);
             }
+            const uint64_t nm = x.ballot(nonode), km0 = x.ballot(nk > 0);
+            const bool can0 = (km0 & 1) && !(nm & 0xFFFFFFFFull), can1 = ((km0 >> 32) & 1) && !(nm >> 32);
+            defer = texting ? !(can0 && can1) : !(can0 || can1);
         }
+        if (defer) {  // (uniform)
+            if (lane == 0) sm.buf[nbuf] = i;
+            if (++nbuf == (uint32_t)WF_BUF) flush();
+            continue;
+        }
+        pass(false);
         // oriented info of every position (as w_info), then the step test of walk_read: position p continues the walk iff the
         // k-mer before it is a node with an out-edge labelled by p's last base (and is not p's k-mer itself: a homopolymer)
         uint32_t go[NPL];
