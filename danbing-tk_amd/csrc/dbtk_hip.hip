@@ -121,11 +121,12 @@ __global__ void __launch_bounds__(64) k_walk_reads(WalkArgs a) {
 #ifndef DBTK_WF_WPE
 #define DBTK_WF_WPE 4
 #endif
-template <int NPL> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_WF_WPE, 8))) k_walk_fast(WalkArgs a) {
+template <int NPL, int WN> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_WF_WPE, 8))) k_walk_fast(WalkArgs a) {
     __shared__ WalkFastSmemT<NPL> sm;
     DevX x{&sm};
-    body_walk_fast<NPL>(x, a);
+    body_walk_fast<NPL, WN>(x, a);
 }
+__global__ void __launch_bounds__(256) k_grmz_insert(GrMzBuildArgs a) { DevX x{nullptr}; body_grmz_insert(x, a); }
 __global__ void __launch_bounds__(64, DBTK_WALK_WAVES) k_walk_pairs(WalkArgs a) {
     __shared__ __attribute__((aligned(16))) WalkSmem sm[2];  // one set of arrays per mate
     DevX x{sm};
@@ -186,7 +187,7 @@ struct Timed {
 struct TableShare {
     int refs = 0;
     IdxBucket* d_idx = nullptr; uint64_t* d_flt = nullptr; uint64_t flt_words = 0; uint32_t* d_trbeg = nullptr; ClsSlot* d_cls = nullptr;
-    MzBucket* d_mz = nullptr; MzSlot* d_ovf = nullptr; GrSlot* d_gr = nullptr; uint32_t* d_vv = nullptr; uint8_t* d_qc = nullptr; uint16_t* d_perm = nullptr;
+    MzBucket* d_mz = nullptr; MzSlot* d_ovf = nullptr; GrSlot* d_gr = nullptr; MzBucket* d_grmz = nullptr; uint32_t* d_vv = nullptr; uint8_t* d_qc = nullptr; uint16_t* d_perm = nullptr;
     ClsSlot* d_tre = nullptr; ClsSlot* d_bait = nullptr;
     DevTables T;
     uint32_t consistent = 0;
@@ -208,6 +209,7 @@ struct dbtk_ctx {
     MzBucket* d_mz = nullptr;     // the probe kernel's minimizer-grouped copy of the index (level 1)
     MzSlot* d_ovf = nullptr;      //   ... and its overflow table (level 2)
     GrSlot* d_gr = nullptr;       // graph table (threading = 2), nullptr when the handle holds no graph
+    MzBucket* d_grmz = nullptr;   //   ... and its minimizer-grouped copy (the lean walk kernel)
     uint32_t* d_vv = nullptr;
     uint8_t* d_qc = nullptr;
     uint16_t* d_perm = nullptr;
@@ -297,12 +299,12 @@ void release_share(dbtk_ctx* c) {
     std::lock_guard<std::mutex> l(g_share_m);
     TableShare* sh = c->share;
     if (!sh) {  // the context never got as far as sharing: the tables (if any) are its own
-        void* own[] = {c->d_flt, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_tre, c->d_bait, c->d_gr, c->d_mz, c->d_ovf};
+        void* own[] = {c->d_flt, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_tre, c->d_bait, c->d_gr, c->d_grmz, c->d_mz, c->d_ovf};
         for (void* p : own) if (p) (void)hipFree(p);
         return;
     }
     if (--sh->refs > 0) return;
-    void* ptrs[] = {sh->d_flt, sh->d_trbeg, sh->d_idx, sh->d_cls, sh->d_vv, sh->d_qc, sh->d_perm, sh->d_tre, sh->d_bait, sh->d_gr, sh->d_mz, sh->d_ovf};
+    void* ptrs[] = {sh->d_flt, sh->d_trbeg, sh->d_idx, sh->d_cls, sh->d_vv, sh->d_qc, sh->d_perm, sh->d_tre, sh->d_bait, sh->d_gr, sh->d_grmz, sh->d_mz, sh->d_ovf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     g_shares.erase(std::make_pair(c->g_uid, c->device));
     delete sh;
@@ -532,6 +534,21 @@ dbtk_status_t build_graph_table(dbtk_ctx* c) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipFree(dks)); HIPCHK(hipFree(dms)); HIPCHK(hipFree(dslot)); HIPCHK(hipFree(dbeg)); HIPCHK(hipFree(dn));
     c->T.gr = c->d_gr; c->T.gr_mask = cap - 1; c->T.gr_shift = 64 - log2u(cap);
+    {   // the lean walk kernel's minimizer-grouped copy of the table, for the values of k its bucket form exists for (DBTK_MZ=0: do without)
+        bool on = true;
+        if (const char* e = getenv("DBTK_MZ")) on = atoi(e) != 0;
+        const uint32_t m = mz_m_for_k(g->ksize);
+        if (on && m) {
+            uint64_t nb = pow2_at_least((ngr + ntrf) * 6 / 8 + 8);  // (an upper bound of the entries: graph nodes + TR k-mers that are no nodes)
+            if (nb > (1ull << 28)) nb = 1ull << 28;
+            HIPCHK(hipMalloc(&c->d_grmz, nb * sizeof(MzBucket)));
+            LAUNCH(k_mz_fill, dim3(2048), dim3(256), s, reinterpret_cast<uint64_t*>(c->d_grmz), nb * 16, 1);
+            GrMzBuildArgs ga{c->d_gr, cap, c->d_grmz, (uint32_t)(nb - 1), g->ksize, m};
+            LAUNCH(k_grmz_insert, dim3(2048), dim3(256), s, ga);
+            HIPCHK(hipStreamSynchronize(s));
+            c->T.grmz = c->d_grmz; c->T.grmz_mask = nb - 1;
+        }
+    }
     return DBTK_OK;
 }
 
@@ -814,8 +831,9 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             // (four ranges per resident wave even out their different costs: 19.7 -> 18.7 ms per 4 M reads; not with text records, where
             // every block that writes takes a chunk of the arena)
             const dim3 gf(walk_txt ? c->walkfast_blocks : 4 * c->walkfast_blocks);
-            if (wnpl == 3) LAUNCH((k_walk_fast<3>), gf, dim3(64), s, w);
-            else LAUNCH((k_walk_fast<5>), gf, dim3(64), s, w);
+            const bool w11 = w.T.grmz && k - mz_m_for_k(k) + 1 == 11;  // (windows of 7 m-mers for k = 19 .. 22, of 11 for k = 23 .. 26)
+            if (wnpl == 3) { if (w11) LAUNCH((k_walk_fast<3, 11>), gf, dim3(64), s, w); else LAUNCH((k_walk_fast<3, 7>), gf, dim3(64), s, w); }
+            else { if (w11) LAUNCH((k_walk_fast<5, 11>), gf, dim3(64), s, w); else LAUNCH((k_walk_fast<5, 7>), gf, dim3(64), s, w); }
         }
         LAUNCH(k_walk_pairs, dim3(c->walk_blocks), dim3(64), s, w);
         if (tm) HIPCHK(hipEventRecord(c->timed[4].end[e], s));
@@ -913,7 +931,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             if (const char* e = getenv("DBTK_WALK_WPC")) { const int v = atoi(e); if (v > 0) nb = v; }
             c->walk_blocks = c->num_cu * nb;
             nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_walk_fast<5>, 64, 0) != hipSuccess || nb <= 0) nb = 16;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_walk_fast<5, 7>, 64, 0) != hipSuccess || nb <= 0) nb = 16;
             c->walkfast_blocks = c->num_cu * nb;
         }
         for (int i = 0; i < NKERN && !st; ++i)
@@ -927,7 +945,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             TableShare* sh = it != g_shares.end() ? it->second : nullptr;
             auto to_share = [&](TableShare* t) {
                 t->d_idx = c->d_idx; t->d_flt = c->d_flt; t->flt_words = c->flt_words; t->d_trbeg = c->d_trbeg; t->d_cls = c->d_cls; t->d_mz = c->d_mz; t->d_ovf = c->d_ovf;
-                t->d_gr = c->d_gr; t->d_vv = c->d_vv; t->d_qc = c->d_qc; t->d_perm = c->d_perm; t->d_tre = c->d_tre; t->d_bait = c->d_bait;
+                t->d_gr = c->d_gr; t->d_grmz = c->d_grmz; t->d_vv = c->d_vv; t->d_qc = c->d_qc; t->d_perm = c->d_perm; t->d_tre = c->d_tre; t->d_bait = c->d_bait;
                 t->T = c->T; t->consistent = c->consistent;
             };
             if (!sh) {
@@ -937,7 +955,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
                 g_shares[key] = sh;
             } else {
                 c->d_idx = sh->d_idx; c->d_flt = sh->d_flt; c->flt_words = sh->flt_words; c->d_trbeg = sh->d_trbeg; c->d_cls = sh->d_cls; c->d_mz = sh->d_mz; c->d_ovf = sh->d_ovf;
-                c->d_gr = sh->d_gr; c->d_vv = sh->d_vv; c->d_qc = sh->d_qc; c->d_perm = sh->d_perm; c->d_tre = sh->d_tre; c->d_bait = sh->d_bait;
+                c->d_gr = sh->d_gr; c->d_grmz = sh->d_grmz; c->d_vv = sh->d_vv; c->d_qc = sh->d_qc; c->d_perm = sh->d_perm; c->d_tre = sh->d_tre; c->d_bait = sh->d_bait;
                 c->T = sh->T; c->consistent = sh->consistent;
             }
             c->share = sh;

@@ -1333,6 +1333,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
 
 }  // namespace dbtk
 #include "dbtk_probe2.h"
+#include "dbtk_walkfast.h"
 namespace dbtk {
 
 // ---- one pair's record (kam: AQ.cpp:2169-2175; trace: every pair).  Trace records are indexed by pair, the others compacted.

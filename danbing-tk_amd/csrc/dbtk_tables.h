@@ -140,6 +140,7 @@ struct DevTables {
     const ClsSlot* tre; uint64_t tre_mask; uint32_t tre_shift;
     const ClsSlot* bait; uint64_t bait_mask; uint32_t bait_shift;
     const GrSlot* gr; uint64_t gr_mask; uint32_t gr_shift;  // nullptr: no graph loaded
+    const MzBucket* grmz; uint64_t grmz_mask;                 // its minimizer-grouped copy (dbtk_walkfast.h), nullptr: none
     const MzBucket* mz; uint64_t mz_mask; uint32_t mz_m;  // level 1 (mz_mask = buckets - 1 <= 2^28 - 1); nullptr: the probe kernel looks up the plain index
     const MzSlot* ovf; uint64_t ovf_mask;               // level 2 (ovf_mask = slots - 1 <= 2^32 - 1)
 };

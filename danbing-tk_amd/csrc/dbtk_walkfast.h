@@ -1,0 +1,365 @@
+// dbtk_walkfast.h — the lean first kernel of the pair-mode graph walk (split off dbtk_walk.h: it shares the probe kernel's bucket
+// machinery, dbtk_probe2.h, and is included behind it by dbtk_kernels.h).
+#ifndef DBTK_WALKFAST_H_
+#define DBTK_WALKFAST_H_
+
+namespace dbtk {
+
+// The minimizer-grouped copy of the graph table: every (canonical k-mer, locus) entry of the hashed table (GrSlot) in the 128-byte bucket
+// of the k-mer's minimizer, key = the k-mer, payload = {locus, info}; a k-mer that is a node at several loci has several entries.  Keys a
+// full bucket turns away (MZ_TURNED on key 7) are found in the hashed table, which stays.
+struct GrMzBuildArgs {
+    const GrSlot* gr;
+    uint64_t nslots;
+    MzBucket* mz;
+    uint32_t mask, ksize, m;
+};
+template <class X>
+DBTK_HD void body_grmz_insert(X& x, const GrMzBuildArgs& a) {
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.nslots; i += (uint64_t)x.nblocks() * x.nthreads()) {
+        const GrSlot s = a.gr[i];
+        if (s.kmer == NAN64) continue;
+        MzBucket* b = a.mz + mz_bucket(mz_of_kmer(s.kmer, a.ksize, a.m), a.mask);
+        bool placed = false;
+        for (int j = 0; j < 8 && !placed; ++j)
+            if (x.atomic_cas(&b->key[j], MZ_EMPTY, s.kmer) == MZ_EMPTY) { b->pl[j].val = (uint32_t)(s.li >> 32); b->pl[j].aux = (uint32_t)s.li; placed = true; }
+        if (!placed) x.atomic_or(&b->key[7], MZ_TURNED);
+    }
+}
+
+// ---- pair mode, first kernel: the pairs one of whose mates threads through the graph as it stands.
+// isThreadFeasible on a read whose first k-mer is a node and whose every next k-mer is an out-edge of the one before returns 1
+// without skipping or correcting anything (walk_read's ballot loop above; AQ.cpp:1114-1260, 1259) — most reads.  The v1.3 call
+// site keeps a pair when EITHER mate is feasible and then counts the uncorrected k-mers of BOTH (AQ.cpp:2082-2087, 2189-2194):
+// so as soon as one mate threads cleanly the pair is decided and counted here, whatever the walk of the other mate would find
+// (its return code is reported as WALK_NOT_EVALUATED).  Pairs with no such mate — and everything when alignment records or
+// thread records are wanted — go to body_walk_pairs, the kernel that carries the error-correction machinery (and its 200+
+// registers); this one is the probe kernel's shape: one wave per pair, one mate per half-wave, NPL consecutive positions per
+// lane as shifts of one 32-base word, one 16-byte graph-table load per position, the feasibility of a mate one ballot.
+constexpr int WF_BUF = 64;
+template <int NPL>
+struct __attribute__((aligned(16))) WalkFastSmemT {
+    uint32_t pk[2][20];       // 2-bit stream of each mate from its 4-byte-aligned start
+    uint32_t buf[WF_BUF];     // passed-on survivors not yet appended to the list
+    uint32_t rb[64 * NPL];    // bucket of every run of the pair (the minimizer-grouped copy of the graph table)
+    uint4 stg[P2_RCH][P2_ROW];  // the buckets of a chunk of runs
+};
+// WN = k - m + 1 m-mers per window when the minimizer-grouped copy of the graph table exists (T.grmz), else unused
+template <int NPL, int WN, class X>
+DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
+    typedef WalkFastSmemT<NPL> SM;
+    SM& sm = *x.template smem<SM>();
+    const int lane = x.lane();
+    const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5;
+    const DevTables& T = a.T;
+    const uint32_t k = T.ksize;
+    uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
+    const uint32_t nsurv = *a.nsurv;
+    // a contiguous range of the (locus-ordered) survivor list per wave: the waves running side by side count into different loci
+    const uint32_t per = (nsurv + x.nblocks() - 1) / x.nblocks();
+    const uint64_t lo64 = (uint64_t)x.bid() * per;
+    const uint32_t first = lo64 < nsurv ? (uint32_t)lo64 : nsurv, hi = lo64 + per < nsurv ? (uint32_t)(lo64 + per) : nsurv;
+    const uint32_t lmax = 32u * NPL + k - 1;  // (the launcher promised no read is longer)
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    const uint32_t p0 = hl * NPL;
+    uint64_t c_feas = 0, c_inc = 0;
+    uint32_t nbuf = 0;
+    uint32_t txt_base = 0, txt_left = 0;  // text records (-a / -ae): arena bytes are taken TXT_CHUNK at a time, as in body_walk_pairs
+    const bool texting = a.txt && (a.P.aln & 3) != 0;
+    auto flush = [&]() {
+        x.sync();
+        uint32_t base = 0;
+        if (lane == 0) base = x.atomic_add(a.nslow, nbuf);
+        base = x.bcast(base, 0);
+        if ((uint32_t)lane < nbuf) a.slow_list[base + lane] = sm.buf[lane];
+        x.sync();
+        nbuf = 0;
+    };
+    // three-deep fetch pipeline as in the probe kernel: bytes of pair i + 1, offsets of pair i + 2, (pair, locus) of pair i + 3
+    auto clampi = [&](uint32_t i) { return i < hi ? i : (first < hi ? first : 0u); };
+    uint32_t rw0 = 0, rw1 = 0;
+    uint64_t o0C = 0, o1C = 0, o0B = 0, o1B = 0;
+    uint32_t pairA = 0, dstA = NAN32, dstB = NAN32, dstC = NAN32;
+    auto fetch_bytes = [&](uint64_t o0, uint64_t o1) {
+        uint32_t len = (uint32_t)(o1 - o0);
+        if (len > lmax) len = lmax;
+        const uint64_t a0 = o0 & ~3ull;
+        const uint32_t nw = ((uint32_t)(o0 - a0) + len + 3) >> 2;
+        rw0 = *reinterpret_cast<const uint32_t*>(a.seq + (2 * hl < nw ? a0 + 8ull * hl : 0ull));
+        rw1 = *reinterpret_cast<const uint32_t*>(a.seq + (2 * hl + 1 < nw ? a0 + 8ull * hl + 4 : 0ull));
+    };
+    auto fetch_offsets = [&](uint32_t pair) {
+        const uint64_t r = 2 * (uint64_t)pair + half;
+        o0B = a.off[r]; o1B = a.off[r + 1];
+    };
+    if (first < hi) {
+        fetch_offsets(x.uni(a.surv[first]));
+        dstC = a.walk_dst[first];
+        o0C = o0B; o1C = o1B;
+        fetch_bytes(o0C, o1C);
+        if (first + 1 < hi) { fetch_offsets(x.uni(a.surv[first + 1])); dstB = a.walk_dst[first + 1]; }
+        pairA = a.surv[clampi(first + 2)]; dstA = a.walk_dst[clampi(first + 2)];
+    }
+    for (uint32_t i = first; i < hi; ++i) {
+        const uint64_t o0 = o0C, o1 = o1C;
+        uint32_t len = (uint32_t)(o1 - o0);
+        if (len > lmax) { if (a.errflag) *a.errflag = DBTK_ERR_READ_TOO_LONG; len = lmax; }
+        const uint64_t a0 = o0 & ~3ull;
+        const uint32_t rsh = (uint32_t)(o0 - a0);
+        const uint32_t d0 = rw0, d1 = rw1;
+        const uint32_t dst = x.uni(dstC);
+        {   // advance the pipeline
+            const bool hasB = i + 1 < hi, hasA = i + 2 < hi;
+            o0C = hasB ? o0B : 0ull; o1C = hasB ? o1B : 0ull;
+            fetch_bytes(o0C, o1C);
+            dstC = dstB; dstB = dstA;
+            fetch_offsets(hasA ? x.uni(pairA) : x.uni(pairA) * 0u);
+            pairA = a.surv[clampi(i + 3)]; dstA = a.walk_dst[clampi(i + 3)];
+        }
+        if (dst == NAN32) continue;  // the pair never reached threading (uniform)
+        x.sync();
+        uint32_t bad = 0;
+        {
+            const uint32_t c0 = pack4_b2(d0, &bad), c1 = pack4_b2(d1, &bad);
+            reinterpret_cast<uint16_t*>(sm.pk[half])[hl ^ 1u] = (uint16_t)(((c0 >> 8) & 0xFF00u) | ((c1 >> 16) & 0xFFu));
+        }
+        const uint32_t nk = len >= k ? len - k + 1 : 0;
+        // a mate with a non-ACGT byte does not thread cleanly (a k-mer with an N is no node); bytes of the lane's dwords outside
+        // the read are the neighbouring reads': counting them only sends a mate to the other kernel for nothing
+        const uint64_t badm = x.ballot(bad != 0 && 8 * hl < rsh + len);
+        x.sync();
+        const uint64_t W = window_fw_clean(sm.pk[half], rsh + p0, 32);
+        const uint64_t RW = revcomp2(W, 32);
+        uint64_t fw[NPL], cn[NPL];
+        uint32_t gi[NPL];
+        uint64_t at[NPL];
+        bool act[NPL], open[NPL];
+        uint4 q[NPL];
+        // The graph nodes of every position.  One 16-byte request per position into the hashed graph table was what this kernel cost
+        // (260 per pair); with the minimizer-grouped copy of the table (T.grmz: the probe kernel's remedy, dbtk_probe2.h) the positions
+        // of a run share a 128-byte bucket that 8 lanes fetch once, and only what a full bucket turned away is still looked up singly.
+        auto single = [&]() {  // open[j]: (canonical k-mer, locus) in the hashed table
+            bool anyo = false;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                if (open[j]) { at[j] = hash_cls(cn[j], dst, T.gr_shift); q[j] = reinterpret_cast<const uint4*>(T.gr)[at[j]]; }
+                anyo |= open[j];
+            }
+            while (x.ballot(anyo)) {  // (a look-up rarely needs a second slot)
+                anyo = false;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    if (!open[j]) continue;
+                    if (q[j].x == (uint32_t)cn[j] && q[j].y == (uint32_t)(cn[j] >> 32) && q[j].w == dst) { gi[j] = q[j].z; open[j] = false; }
+                    else if ((q[j].x & q[j].y) == 0xFFFFFFFFu) open[j] = false;  // empty slot: not in the table
+                    else { at[j] = (at[j] + 1) & T.gr_mask; q[j] = reinterpret_cast<const uint4*>(T.gr)[at[j]]; }
+                    anyo |= open[j];
+                }
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            fw[j] = (W >> (2 * (32 - k - j))) & kmask;
+            const uint64_t rc = (RW >> (2 * j)) & kmask;
+            cn[j] = fw[j] <= rc ? fw[j] : rc;
+            act[j] = p0 + j < nk;
+            at[j] = 0; gi[j] = 0; open[j] = false;
+            q[j] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
+        }
+        if (badm) {  // (uniform) a pair with a non-ACGT byte is the other kernel's whatever its mates do
+            if (lane == 0) sm.buf[nbuf] = i;
+            if (++nbuf == (uint32_t)WF_BUF) flush();
+            continue;
+        }
+        if (T.grmz) {
+            const uint32_t m = mz_m_for_k(k), mmask = (uint32_t)((1ull << (2 * m)) - 1), nmm = len >= m ? len - m + 1 : 0;
+            uint32_t f[NPL + WN - 1], mz[NPL], bk[NPL], rid[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const uint32_t fwm = (uint32_t)(W >> (2 * (32 - m - j))) & mmask, rcm = (uint32_t)(RW >> (2 * j)) & mmask;
+                f[j] = p0 + j < nmm ? mmer_hash2(fwm, rcm) : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int t = NPL; t < NPL + WN - 1; ++t) f[t] = x.shfl_down1(f[t - NPL]);
+            sliding_min<NPL, WN>(f, mz);
+            uint32_t cnt = 0;
+            bool st[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) bk[j] = act[j] ? mz_bucket(mz[j] >> 4, (uint32_t)T.grmz_mask) : 0xFFFFFFFFu;
+            uint32_t prev = x.shfl_up1(bk[NPL - 1]);
+            if (hl == 0) prev = 0xFFFFFFFEu;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                st[j] = act[j] && bk[j] != prev;
+                cnt += st[j] ? 1u : 0u;
+                prev = bk[j];
+            }
+            uint32_t r = x.wave_excl_scan(cnt);
+            const uint32_t nruns = x.bcast(r + cnt, 63);
+            x.sync();
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                if (st[j]) { sm.rb[r] = bk[j]; ++r; }
+                rid[j] = r - 1;
+            }
+            x.sync();
+            const uint32_t fq8 = (uint32_t)lane >> 3, part = (uint32_t)lane & 7u;
+            p2_v4u qq[P2_RCH / 8];
+            p2_fetch_runs(sm.rb, T.grmz, nruns, 0u, fq8, part, 0xFFFFFFFFu, qq);
+            for (uint32_t r0 = 0; r0 < nruns; r0 += P2_RCH) {
+                x.sync();
+#pragma unroll
+                for (int u = 0; u < P2_RCH / 8; ++u) *reinterpret_cast<p2_v4u*>(&sm.stg[8 * u + fq8][part]) = qq[u];
+                if (r0 + P2_RCH < nruns) p2_fetch_runs(sm.rb, T.grmz, nruns, r0 + P2_RCH, fq8, part, 0xFFFFFFFFu, qq);
+                x.sync();
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    const uint32_t row = rid[j] - r0;
+                    if (act[j] && row < (uint32_t)P2_RCH) {
+                        const uint4* rp = sm.stg[row];
+                        uint32_t mm = 0, w7 = 0;  // slots whose key is this k-mer (one per locus that has the node)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const uint4 kk = rp[g];
+                            const uint64_t k0 = ((uint64_t)kk.y << 32) | kk.x, k1 = ((uint64_t)kk.w << 32) | kk.z;
+                            if (k0 == cn[j]) mm |= 1u << (2 * g);
+                            if ((g == 3 ? (k1 & ~MZ_TURNED) : k1) == cn[j]) mm |= 1u << (2 * g + 1);
+                            if (g == 3) w7 = kk.w;
+                        }
+                        bool found = false;
+                        while (mm) {
+                            const uint32_t sl = (uint32_t)__builtin_ctz(mm);
+                            mm &= mm - 1;
+                            const uint32_t* pl = reinterpret_cast<const uint32_t*>(rp + 4) + 2 * sl;
+                            if (pl[0] == dst) { gi[j] = pl[1]; found = true; }
+                        }
+                        open[j] = !found && (w7 >> 31) != 0;  // the bucket turned keys away: ask the hashed table
+                    }
+                }
+            }
+            single();
+        } else {
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) open[j] = act[j];
+            single();
+        }
+        // oriented info of every position (as w_info), then the step test of walk_read: position p continues the walk iff the
+        // k-mer before it is a node with an out-edge labelled by p's last base (and is not p's k-mer itself: a homopolymer)
+        uint32_t go[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const bool isf = fw[j] == cn[j];
+            const uint32_t fa = gi[j] & 0x1Fu, fb = (gi[j] >> GR_OPP) & 0x1Fu;
+            go[j] = isf ? fa : fb;
+        }
+        uint32_t pg = x.shfl_up1(go[NPL - 1]);
+        uint32_t plo = x.shfl_up1((uint32_t)fw[NPL - 1]), phi = x.shfl_up1((uint32_t)(fw[NPL - 1] >> 32));
+        bool fail = false;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const uint64_t pv = ((uint64_t)phi << 32) | plo;
+            if (act[j]) {
+                if (p0 + j == 0) fail |= !(go[j] & GR_HAS);  // the anchor is the first k-mer
+                else fail |= !((pg & GR_HAS) && ((pg >> (uint32_t)(fw[j] & 3)) & 1) && fw[j] != pv);
+            }
+            pg = go[j]; plo = (uint32_t)fw[j]; phi = (uint32_t)(fw[j] >> 32);
+        }
+        const uint64_t failm = x.ballot(fail) | badm;
+        const uint64_t nkm = x.ballot(nk > 0);
+        const bool clean0 = (nkm & 1) && !(failm & 0xFFFFFFFFull), clean1 = ((nkm >> 32) & 1) && !(failm >> 32);
+        // (-a / -ae: the record holds both mates' alignments, so only a pair BOTH of whose mates thread cleanly is finished here — its
+        // strings are "len=" and the run lengths of the TR flags of its k-mers; any other pair goes on to the kernel that aligns)
+        if ((texting ? (clean0 && clean1) : (clean0 || clean1)) && !badm) {  // (uniform) the pair is kept: count the uncorrected k-mers of both mates (AQ.cpp:2189-2194)
+            // (a pair with a non-ACGT byte in either mate is passed on even when its other mate threads: the valid k-mers of the
+            // mate with the N count too, and which of its windows are valid is the other kernel's business)
+            c_feas += 2;
+            const uint32_t tb = T.trbeg[dst];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const bool hit = act[j] && (gi[j] & GR_TR);
+                if (hit) x.atomic_add(&a.counts[tb + (gi[j] >> GR_SLOT_SHIFT)], 1ull);
+                c_inc += (uint64_t)__builtin_popcountll(x.ballot(hit));
+            }
+            if (lane == 0) {
+                a.walk_dst[i] = dst;
+                a.walk_ret[i] = (uint32_t)(uint8_t)(clean0 ? 1 : WALK_NOT_EVALUATED) | ((uint32_t)(uint8_t)(clean1 ? 1 : WALK_NOT_EVALUATED) << 8);
+            }
+            if (texting) {
+                // writeAnnot on cg.tr of a clean walk (one '=' / '.' per k-mer: is it a TR k-mer of the locus) = the run lengths of the
+                // flags; writeCigar on its cg.es (len matches) = "len=".  A run is printed by the lane of its last position: the flag of
+                // the position after it comes from the lane's own next position or, across lanes, from the ballot of first positions;
+                // where the run began is a max-scan over the positions where the flag changes (each mate's own scale, so that mate 1's
+                // scan never sees mate 0's).
+                bool f[NPL];
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) f[j] = (gi[j] & GR_TR) != 0;
+                const uint64_t f0m = x.ballot(f[0]);
+                const bool fnext = lane < 63 && ((f0m >> (lane + 1)) & 1);  // (lane 31's successor is mate 1's first: never looked at, p0 + NPL - 1 >= nk - 1 there or inactive)
+                const uint32_t scale = half ? 4096u : 0u;
+                uint32_t chg = 0;  // (index + 1 on the mate's scale) of the last position of this lane that starts a run
+                bool fp = x.shfl_up1(f[NPL - 1] ? 1u : 0u) != 0;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    if (act[j] && (p0 + j == 0 || f[j] != fp)) chg = scale + p0 + j + 1;
+                    fp = f[j];
+                }
+                const uint32_t inc = x.wave_scan_max(chg);
+                uint32_t before = x.shfl_up1(inc);  // the last run start in the lanes before this one
+                if (lane == 0 || before < scale + 1) before = scale + 1;  // (a mate's position 0 always starts a run; lane 32 must not see mate 0)
+                uint32_t rl[NPL], ol[NPL], tot = 0;
+                uint32_t st = before;
+                fp = x.shfl_up1(f[NPL - 1] ? 1u : 0u) != 0;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    if (act[j] && (p0 + j == 0 || f[j] != fp)) st = scale + p0 + j + 1;
+                    fp = f[j];
+                    const bool nx = j + 1 < NPL ? f[j + 1] : fnext;
+                    const bool end = act[j] && (p0 + j + 1 == nk || nx != f[j]);
+                    rl[j] = end ? (scale + p0 + j + 1) - st + 1 : 0u;
+                    ol[j] = end ? (rl[j] >= 100 ? 3u : rl[j] >= 10 ? 2u : 1u) + 1u : 0u;
+                    tot += ol[j];
+                }
+                const uint32_t ex = x.wave_excl_scan(tot), la = x.half_sum(tot);
+                const uint32_t la0 = x.bcast(la, 0), la1 = x.bcast(la, 32);
+                const uint32_t len0 = x.bcast(len, 0), len1 = x.bcast(len, 32);  // (each half holds its own mate's length)
+                const uint32_t lc0 = (len0 >= 100 ? 3u : len0 >= 10 ? 2u : 1u) + 1u, lc1 = (len1 >= 100 ? 3u : len1 >= 10 ? 2u : 1u) + 1u;
+                const uint32_t tlen = lc1 + 1 + la1 + 1 + lc0 + 1 + la0, need = (8 + tlen + 3) & ~3u;
+                if (need > txt_left) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = x.atomic_add(a.ntxt, TXT_CHUNK);
+                    txt_base = x.bcast(b, 0);
+                    txt_left = TXT_CHUNK;
+                }
+                if ((uint64_t)txt_base + need <= a.txt_cap) {
+                    uint8_t* r = a.txt + txt_base;
+                    if (lane == 0) {  // header, mate 1's CIGAR, the three tabs, mate 0's CIGAR
+                        reinterpret_cast<uint32_t*>(r)[0] = dst;
+                        reinterpret_cast<uint32_t*>(r)[1] = tlen;
+                        a.txt_idx[a.surv[i]] = txt_base;
+                        uint32_t q = w_fmt_int(r, 8, (int)len1);
+                        r[q] = '='; r[q + 1] = '\t';
+                        r[8 + lc1 + 1 + la1] = '\t';
+                        q = w_fmt_int(r, 8 + lc1 + 1 + la1 + 1, (int)len0);
+                        r[q] = '='; r[q + 1] = '\t';
+                    }
+                    uint32_t o = half ? 8 + lc1 + 1 + (ex - la0) : 8 + lc1 + 1 + la1 + 1 + lc0 + 1 + ex;
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j)
+                        if (ol[j]) { const uint32_t q = w_fmt_int(r, o, (int)rl[j]); r[q] = f[j] ? '=' : '.'; o += ol[j]; }
+                } else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
+                txt_base += need; txt_left -= need;
+            }
+        } else {
+            if (lane == 0) sm.buf[nbuf] = i;
+            if (++nbuf == (uint32_t)WF_BUF) flush();
+        }
+    }
+    if (nbuf) flush();
+    if (lane == 0) {
+        if (c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], c_feas);
+        if (c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], c_inc);
+    }
+}
+
+}  // namespace dbtk
+#endif

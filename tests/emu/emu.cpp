@@ -286,7 +286,7 @@ struct EmuTables {
     std::vector<uint64_t> flt;
     std::vector<ClsSlot> tre, bait;
     std::vector<GrSlot> gr;
-    std::vector<MzBucket> mz;
+    std::vector<MzBucket> mz, grmz;
     std::vector<MzSlot> ovf;
     uint64_t stats[3] = {0, 0, 0};
     DevTables T;
@@ -396,6 +396,16 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
         a.ks = g->tr_ks.data(); a.ms = nullptr; a.outslot = g->out_slot.data(); a.n = ntrf;
         if (ntrf) run_grid(3, 64, 0, [&](EmuX& x) { body_gr_insert(x, a); });
         T.gr = e->gr.data(); T.gr_mask = cap - 1; T.gr_shift = 64 - lg(cap);
+        // its minimizer-grouped copy (small: many turned-away entries exercise the single look-ups), as build_graph_table makes it
+        if (mz_m_for_k(g->ksize) && (!getenv("DBTK_MZ") || atoi(getenv("DBTK_MZ")))) {
+            const uint64_t nb = pow2((ngr + ntrf) / 8 + 8) / 64 ? pow2((ngr + ntrf) / 8 + 8) : 64;
+            MzBucket empty;
+            for (int j = 0; j < 8; ++j) { empty.key[j] = MZ_EMPTY; empty.pl[j].val = empty.pl[j].aux = 0; }
+            e->grmz.assign(nb, empty);
+            GrMzBuildArgs ga{e->gr.data(), cap, e->grmz.data(), (uint32_t)(nb - 1), g->ksize, mz_m_for_k(g->ksize)};
+            run_grid(3, 64, 0, [&](EmuX& x) { body_grmz_insert(x, ga); });
+            T.grmz = e->grmz.data(); T.grmz_mask = nb - 1;
+        }
     }
     return e;
 }
@@ -780,8 +790,14 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         const int wnpl = (((p->aln & 3u) && !txtmode) || g_walk_trecs || kk + 4 > 32) ? 0 : (maxlen <= 32 * 3 + kk - 1 && kk + 2 <= 32 ? 3 : maxlen <= 32 * 5 + kk - 1 ? 5 : 0);
         if (wnpl) {
             w.slow_list = slow.data(); w.nslow = &nslow;
-            if (wnpl == 3) run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<3>), [&](EmuX& x) { body_walk_fast<3>(x, w); });
-            else run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<5>), [&](EmuX& x) { body_walk_fast<5>(x, w); });
+            const bool w11 = w.T.grmz && kk - mz_m_for_k(kk) + 1 == 11;
+            if (wnpl == 3) {
+                if (w11) run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<3>), [&](EmuX& x) { body_walk_fast<3, 11>(x, w); });
+                else run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<3>), [&](EmuX& x) { body_walk_fast<3, 7>(x, w); });
+            } else {
+                if (w11) run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<5>), [&](EmuX& x) { body_walk_fast<5, 11>(x, w); });
+                else run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<5>), [&](EmuX& x) { body_walk_fast<5, 7>(x, w); });
+            }
             g_walk_fast_runs += 1; g_walk_slow_pairs += nslow;
         }
         run_grid(grid_pair, 64, 2 * sizeof(WalkSmem), [&](EmuX& x) { body_walk_pairs(x, w); });
