@@ -43,6 +43,8 @@ struct __attribute__((aligned(16))) WalkFastSmemT {
     uint32_t buf[WF_BUF];     // passed-on survivors not yet appended to the list
     uint32_t rb[64 * NPL];    // bucket of every run of the pair (the minimizer-grouped copy of the graph table)
     uint4 stg[P2_RCH][P2_ROW];  // the buckets of a chunk of runs
+    uint4 cache[P2_CACHE];    // {k-mer, info, locus} of single look-ups already made (info 0: no node): the wave works through the reads of a locus
+    uint8_t tok[P2_CACHE];    // which lane writes an entry when several want to in one step
 };
 // WN = k - m + 1 m-mers per window when the minimizer-grouped copy of the graph table exists (T.grmz), else unused
 template <int NPL, int WN, class X>
@@ -62,6 +64,7 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
     const uint32_t lmax = 32u * NPL + k - 1;  // (the launcher promised no read is longer)
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint32_t p0 = hl * NPL;
+    for (uint32_t e = (uint32_t)lane; e < (uint32_t)P2_CACHE; e += 64) sm.cache[e] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu};
     uint64_t c_feas = 0, c_inc = 0;
     uint32_t nbuf = 0;
     uint32_t txt_base = 0, txt_left = 0;  // text records (-a / -ae): arena bytes are taken TXT_CHUNK at a time, as in body_walk_pairs
@@ -237,7 +240,33 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
                     }
                 }
             }
-            single();
+            // what the buckets turned away: the wave's cache first (the k-mers of a tandem repeat come back all along a read and in
+            // every read of its locus), then the hashed table; what was looked up goes into the cache (the absent ones too)
+            bool anyp = false;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) anyp |= open[j];
+            if (x.ballot(anyp)) {
+                uint32_t ce[NPL];
+                bool glob[NPL];
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    ce[j] = (ovf_hash(cn[j]) >> 20) & (P2_CACHE - 1);
+                    glob[j] = false;
+                    if (open[j]) {
+                        const uint4 c = sm.cache[ce[j]];
+                        if (c.x == (uint32_t)cn[j] && c.y == (uint32_t)(cn[j] >> 32) && c.w == dst) { gi[j] = c.z; open[j] = false; }
+                        else glob[j] = true;
+                    }
+                }
+                single();
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) if (glob[j]) sm.tok[ce[j]] = (uint8_t)lane;
+                x.sync();
+#pragma unroll
+                for (int j = 0; j < NPL; ++j)
+                    if (glob[j] && sm.tok[ce[j]] == (uint8_t)lane) sm.cache[ce[j]] = uint4{(uint32_t)cn[j], (uint32_t)(cn[j] >> 32), gi[j], dst};
+                x.sync();
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < NPL; ++j) open[j] = act[j];
