@@ -42,7 +42,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_SOURCES = ("dbtk_kernels.h", "dbtk_probe2.h", "dbtk_ingest.h", "dbtk_walk.h", "dbtk_tables.h", "dbtk_sort.h", "dbtk_assign.h", "dbtk_devx.h", "dbtk_hip.hip")
+KERNEL_SOURCES = ("dbtk_kernels.h", "dbtk_probe2.h", "dbtk_walkfast.h", "dbtk_ingest.h", "dbtk_gz.h", "dbtk_walk.h", "dbtk_tables.h", "dbtk_sort.h", "dbtk_assign.h", "dbtk_devx.h", "dbtk_hip.hip")
 
 
 def kernel_source_hash():
