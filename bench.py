@@ -488,9 +488,19 @@ def main():
                                                 roofline=dict(roofline_of(dom25, t25), kernels=t25), parity=None)
                 log(f"k = 25 walk mix: {dt25 / args.mix_steps * 1e3:.3f} ms/step, {mixes['walk_k25_gc85_3']['value'] / 1e6:.1f} M reads/s, dominant {dom25} {t25[dom25]['avg_ms']:.3f} ms")
                 del d_s25, d_o25
-                k25_check = (syn25, arrs25, g25, ctx25, p25, s25, o25) if args.cpu_seconds > 0 and args.k25_parity_pairs > 0 else None
-                if not k25_check:
-                    ctx25.close(); g25.close(); syn25.close()
+                k25_check = None
+                if args.cpu_seconds > 0 and args.k25_parity_pairs > 0:
+                    # the GPU half of the parity slice now, the oracle half with the CPU legs below: the k = 25 tables (80 GB with the walk's)
+                    # do not stay in HBM while the command-line legs bring their own
+                    n25 = min(args.k25_parity_pairs, len(o25) // 2)
+                    ctx25.reset()
+                    ctx25.align(s25[:2 * n25 * rlen], o25[:2 * n25 + 1])
+                    r25 = ctx25.counts()
+                    res25, _, nres25 = ctx25.walk_results(n25)
+                    k25_check = (syn25, arrs25, p25, s25, o25, n25, r25, res25, nres25, g25.ntrkmers, g25.output_order().astype(np.int64), g25.nloci)
+                else:
+                    syn25.close()
+                ctx25.close(); g25.close()
         if not args.no_e2e:
             # the same batch handed over as HOST buffers: validation + PCIe copies + kernels, one batch after the other
             e2e = {}
@@ -618,23 +628,18 @@ def main():
             log(f"oracle (port) on 1 core: {port['value']:.0f} reads/s")
             orc.free(go)
             if k25_check:  # the k = 25 walk mix against the oracle on a slice: counts, counters, walk results
-                syn25, arrs25, g25, ctx25, p25, s25, o25 = k25_check
+                syn25, arrs25, p25, s25, o25, n25, r25, res25, nres25, ntr25, order25, nloci25 = k25_check
                 t0 = time.time()
                 go25 = orc.from_arrays(arrs25)
-                n25 = min(args.k25_parity_pairs, len(o25) // 2)
                 ow = orc.align_walk(go25, p25, s25[:2 * n25 * rlen], o25[:2 * n25 + 1], with_recs=False)
-                ctx25.reset()
-                ctx25.align(s25[:2 * n25 * rlen], o25[:2 * n25 + 1])
-                r25 = ctx25.counts()
-                co = np.zeros(g25.ntrkmers, np.uint64)
-                np.add.at(co, g25.output_order().astype(np.int64), ow["counts_file"])
-                res25, _, nres25 = ctx25.walk_results(n25)
+                co = np.zeros(ntr25, np.uint64)
+                np.add.at(co, order25, ow["counts_file"])
                 ok = bool((co == r25["counts"]).all() and (ow["counters"] == r25["counters"]).all() and nres25 == ow["nres"]
-                          and bind.walk_res_equal(res25, ow["res"], nres25, g25.nloci, every_mate=False) >= 0)
+                          and bind.walk_res_equal(res25, ow["res"], nres25, nloci25, every_mate=False) >= 0)
                 mixes["walk_k25_gc85_3"]["parity"] = dict(pairs=n25, bit_exact=ok, walked=int(ow["nres"]))
                 log(f"k = 25 walk mix, parity on {n25} pairs ({ow['nres']} walked): {'bit-exact' if ok else 'MISMATCH'} ({time.time() - t0:.0f}s incl. oracle tables)")
                 orc.free(go25)
-                ctx25.close(); g25.close(); syn25.close()
+                syn25.close()
         if do_ref:
             for th in ref_procs:
                 th.join()

@@ -532,6 +532,9 @@ dbtk_status_t build_graph_table(dbtk_ctx* c) {
         HIPCHK(hipStreamSynchronize(s));
     }
     HIPCHK(hipGetLastError());
+    uint64_t nent = 0;  // entries of the table: the two strands of a node share one, most TR k-mers are nodes already
+    HIPCHK(hipMemcpy(&nent, dn, 8, hipMemcpyDeviceToHost));
+    if (nent == 0 || nent > ngr + ntrf) nent = ngr + ntrf;
     HIPCHK(hipFree(dks)); HIPCHK(hipFree(dms)); HIPCHK(hipFree(dslot)); HIPCHK(hipFree(dbeg)); HIPCHK(hipFree(dn));
     c->T.gr = c->d_gr; c->T.gr_mask = cap - 1; c->T.gr_shift = 64 - log2u(cap);
     {   // the lean walk kernel's minimizer-grouped copy of the table, for the values of k its bucket form exists for (DBTK_MZ=0: do without)
@@ -539,7 +542,7 @@ dbtk_status_t build_graph_table(dbtk_ctx* c) {
         if (const char* e = getenv("DBTK_MZ")) on = atoi(e) != 0;
         const uint32_t m = mz_m_for_k(g->ksize);
         if (on && m) {
-            uint64_t nb = pow2_at_least((ngr + ntrf) * 6 / 8 + 8);  // (an upper bound of the entries: graph nodes + TR k-mers that are no nodes)
+            uint64_t nb = pow2_at_least(nent * 6 / 8 + 8);  // 6 buckets per 8 entries, as the index's copy (17 GB at release scale)
             if (nb > (1ull << 28)) nb = 1ull << 28;
             HIPCHK(hipMalloc(&c->d_grmz, nb * sizeof(MzBucket)));
             LAUNCH(k_mz_fill, dim3(2048), dim3(256), s, reinterpret_cast<uint64_t*>(c->d_grmz), nb * 16, 1);
