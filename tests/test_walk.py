@@ -413,7 +413,7 @@ def check_pair_mode(run, O, oh, case, k, nloci):
             assert g["aln"] == []
 
 
-@pytest.mark.parametrize("k,seed", [(21, 3), (25, 4)])
+@pytest.mark.parametrize("k,seed", [(21, 3), (25, 4), (17, 5)])
 def test_emulated_pair_mode_equals_oracle(tmp_path, k, seed):
     """K1..K3 + the walk kernel's pair mode on the emulated lanes: exact counts, all counters, walk results, -a / -ae records."""
     O = bind.Oracle()
@@ -462,7 +462,7 @@ def test_oracle_reproduces_golden_g5():
 
 # ------------------------------------------------------------ GPU vs oracle --
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,seed", [(21, 3), (25, 4)])
+@pytest.mark.parametrize("k,seed", [(21, 3), (25, 4), (17, 5)])  # (k = 17: no minimizer-grouped tables: the lean walk kernel's single look-ups, the general probe kernel)
 def test_gpu_pair_mode_equals_oracle(tmp_path, k, seed):
     """BASELINE config 4's path (k = 25, -gc 85 3) and config 5's (-ae) through the C-ABI: dbtk_align_batch with
     threading = 2, then dbtk_ctx_counts / dbtk_ctx_walk_results / dbtk_ctx_aln_records, against the oracle."""
