@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <deque>
 #include <map>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -478,7 +479,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipFree(dn));
             uint64_t ocap = pow2_at_least(16 * nturned + 8);  // level 2: those keys, at most a sixteenth full
-            if (ocap > (1ull << 32)) { set_error("overflow table of the probe kernel: more than 2^30 keys"); return DBTK_ERR_UNSUPPORTED; }
+            if (ocap > (1ull << 32)) { set_error("overflow table of the probe kernel: more than 2^28 keys turned away by full buckets"); return DBTK_ERR_UNSUPPORTED; }
             HIPCHK(hipMalloc(&c->d_ovf, ocap * sizeof(MzSlot)));
             LAUNCH(k_mz_fill, dim3(2048), dim3(256), s, reinterpret_cast<uint64_t*>(c->d_ovf), ocap * 2, 0);
             a.ovf = c->d_ovf; a.ovf_mask = (uint32_t)(ocap - 1); a.pass = 1;
@@ -794,7 +795,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         if (walk_txt) {  // text records: an arena sized for the worst case (two characters per entry, four strings), carved by the waves
             const uint32_t acap = std::min<uint32_t>(DBTK_THREAD_CAP, (max_read_len + max_read_len / 4 + 8 + 7) & ~7u);
             c->aln_cap = acap;
-            const uint64_t want = std::min<uint64_t>(npairs * (uint64_t)(8 + 8 * acap + 8) + (uint64_t)TXT_CHUNK * (c->walk_blocks + c->walkfast_blocks + 2), 0xFFFF0000ull);
+            const uint64_t want = std::min<uint64_t>(npairs * (uint64_t)(8 + 8 * acap + 8) + (uint64_t)TXT_CHUNK * (c->walk_blocks + c->walkfast_blocks + 2), TXT_ARENA_MAX);
             if (want > c->txt_bytes) {
                 if (c->d_txt) HIPCHK(hipFree(c->d_txt));
                 c->d_txt = nullptr; c->txt_bytes = 0;
@@ -826,7 +827,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         // Two kernels when nothing needs the alignment arrays of every mate (no array records, no thread records): the lean one
         // decides and counts the pairs one of whose mates threads cleanly — with text records (-a / -ae): the pairs BOTH of whose
         // mates do, and writes their records itself —, the one with the error-correction machinery takes the rest from its list.  (The walk's kernels are timed together: "k_walk_pairs".)
-        const int wnpl = (walk_aln || walk_trecs || k + 4 > 32) ? 0 : (max_read_len <= 32 * 3 + k - 1 && k + 2 <= 32 ? 3 : max_read_len <= 32 * 5 + k - 1 ? 5 : 0);
+        const int wnpl = (walk_aln || walk_trecs) ? 0 : walkfast_npl(max_read_len, k, w.T.grmz != nullptr);
         if (tm) { if ((st = timed_slot(c, 4, &e))) return st; HIPCHK(hipEventRecord(c->timed[4].beg[e], s)); }
         if (wnpl) {
             w.slow_list = c->d_walk + 2 * npairs; w.nslow = c->d_small + 5;
@@ -1592,6 +1593,11 @@ struct dbtk_ingest {
         IngestHdr hdr;
     };
     std::vector<Slot> slots;
+    // slot -> dbtk_ingest_aln_lines calls in progress on it: k_aln_write reads the slot's raw block (its carried-over head included) on an
+    // aligning context's stream, while a submit copies new bytes into that buffer on the copy stream and the block before it carries its tail
+    // into the buffer's head on the parse stream.  aln_lines returns only when its kernels are done, so "in progress" is exact; a submit that
+    // would overwrite bytes still being read is refused instead of corrupting the -a / -ae lines.
+    std::unique_ptr<std::atomic<int>[]> lines_busy;
 };
 
 static void ingest_free_impl(dbtk_ingest* g) {
@@ -1644,6 +1650,8 @@ static dbtk_status_t dbtk_ingest_create_impl(dbtk_ctx_t* c, uint32_t fastq, uint
     const uint64_t ntiles = raw_bytes / ING_TILE + 1;
     g->slots.resize(nslots);
     g->slot_m.reset(new std::mutex[nslots]);
+    g->lines_busy.reset(new std::atomic<int>[nslots]);
+    for (uint32_t i = 0; i < nslots; ++i) g->lines_busy[i].store(0);
     dbtk_status_t st = DBTK_OK;
     auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && !st) { set_error(std::string(what) + ": " + hipGetErrorString(e)); st = DBTK_ERR_HIP; } };
     chk(hipStreamCreate(&g->stream), "hipStreamCreate");
@@ -1679,6 +1687,10 @@ static dbtk_status_t dbtk_ingest_submit_impl(dbtk_ingest_t* g, uint32_t slot, ui
     dbtk_ingest::Slot& S = g->slots[slot];
     if (S.pending) { set_error("dbtk_ingest_submit: the slot's previous block has not been waited for"); return DBTK_ERR_ARG; }
     if (!S.h_raw && !dbtk_ingest_chunk_buffer(g, slot)) { set_error("hipHostMalloc (chunk buffer) failed"); return DBTK_ERR_NOMEM; }
+    if (g->lines_busy[slot].load() || g->lines_busy[(slot + 1) % g->nslots].load()) {
+        set_error("dbtk_ingest_submit: dbtk_ingest_aln_lines is still reading this slot's block (or the next slot's, whose head this block's carry-over overwrites)");
+        return DBTK_ERR_ARG;
+    }
     dbtk_ctx* c = g->c;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = g->stream;
@@ -1795,6 +1807,8 @@ static dbtk_status_t dbtk_ingest_aln_lines_impl(dbtk_ingest_t* g, uint32_t slot,
     if (!g->with_spans || !S.waited) { set_error("dbtk_ingest_aln_lines: needs an ingest created with spans and a block that has been waited for"); return DBTK_ERR_ARG; }
     const uint32_t nk = S.hdr.nkept;
     if (!nk || !c->txt_cap || !c->d_txt || c->last_walk_npairs != nk) return DBTK_OK;  // no text records: no lines
+    struct Busy { std::atomic<int>& b; Busy(std::atomic<int>& x) : b(x) { ++b; } ~Busy() { --b; } } busy(g->lines_busy[slot]);
+    if (S.pending) { set_error("dbtk_ingest_aln_lines: the slot has been submitted again"); return DBTK_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     dbtk_ingest::LinesBuf* Bp;

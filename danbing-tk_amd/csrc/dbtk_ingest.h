@@ -187,6 +187,9 @@ DBTK_HD void body_ing_pairs(X& x, const IngestArgs& a) {  // one lane per pair
         for (uint32_t i = 0; same && i < P.tn; ++i) same = a.raw[P.t + i] == a.raw[C.t + i];
         if (!same) dirty = 1;
         const bool keep = P.sn >= a.min_read && C.sn >= a.min_read;
+        // (the packed lengths are 15 bits each: a kept read of 32 767 bases or more cannot be placed by body_ing_place, whose offsets
+        // would disagree with what body_ing_gather copies — the block goes to the host reader instead)
+        if (keep && (P.sn >= 0x7FFFu || C.sn >= 0x7FFFu)) dirty = 1;
         a.pk[p] = keep ? 0x80000000u | ((P.sn < 0x7FFFu ? P.sn : 0x7FFFu) << 15) | (C.sn < 0x7FFFu ? C.sn : 0x7FFFu) : 0u;
         if (keep) { longest = P.sn > longest ? P.sn : longest; longest = C.sn > longest ? C.sn : longest; }
     }

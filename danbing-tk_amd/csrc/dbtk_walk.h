@@ -145,11 +145,25 @@ constexpr int8_t WALK_NOT_EVALUATED = -2;  // walk_ret of a mate whose walk noth
 #endif
 constexpr uint32_t ALN_CHUNK = 16;
 constexpr uint32_t TXT_CHUNK = 16384;  // arena bytes a wave takes at a time (one atomic per ~200 records)
+constexpr uint64_t TXT_ARENA_MAX = 0xF0000000ull;  // largest arena: the 32-bit cursor keeps 256 MB of headroom past it (below)
 constexpr int WTXT = 2 * (WCAP + 8);    // the longest text of one CIGAR / annotation: two characters per entry
 DBTK_HD uint8_t aln_pack(uint8_t t, uint8_t g) {  // edit_t (t, g) in one byte: dbtk.h DBTK_ALN_*
     const uint32_t tc = t == '*' ? 0u : t == '=' ? 1u : t == 'X' ? 2u : t == 'D' ? 3u : t == 'I' ? 4u : 7u;
     const uint32_t gc = g == 0 ? 0u : g == 'A' ? 1u : g == 'C' ? 2u : g == 'G' ? 3u : g == 'T' ? 4u : 5u;
     return (uint8_t)(tc | (gc << 3));
+}
+
+// Lane 0 takes the next TXT_CHUNK bytes of the text arena.  A full arena is sticky: once the cursor has reached the capacity no wave
+// adds to it any more (the cursor is read first), so it cannot wrap past 2^32 and hand out bytes that already hold records — between the
+// read and the add at most one chunk per resident wave goes on top, far less than the headroom TXT_ARENA_MAX leaves.  The base
+// returned for a full arena fails the caller's bounds test; the error word tells the host.
+template <class X>
+DBTK_HD uint32_t txt_carve(X& x, const WalkArgs& a) {
+    if (x.atomic_or32(a.ntxt, 0u) >= a.txt_cap) {
+        if (a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
+        return a.txt_cap;
+    }
+    return x.atomic_add(a.ntxt, TXT_CHUNK);
 }
 
 struct WalkSmem {
@@ -1328,7 +1342,7 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
                 const uint32_t len = lc2 + 1 + la2 + 1 + lc1 + 1 + la1, need = (8 + len + 3) & ~3u;
                 if (need > txt_left) {  // (what is left of the old chunk stays unused)
                     uint32_t b = 0;
-                    if (lane == 0) b = x.atomic_add(a.ntxt, TXT_CHUNK);
+                    if (lane == 0) b = txt_carve(x, a);
                     txt_base = x.bcast(b, 0);
                     txt_left = TXT_CHUNK;
                 }

@@ -37,6 +37,17 @@ DBTK_HD void body_grmz_insert(X& x, const GrMzBuildArgs& a) {
 // registers); this one is the probe kernel's shape: one wave per pair, one mate per half-wave, NPL consecutive positions per
 // lane as shifts of one 32-base word, one 16-byte graph-table load per position, the feasibility of a mate one ballot.
 constexpr int WF_BUF = 64;
+// NPL of the lean kernel for a batch whose longest read has max_read_len bases (0: the kernel does not apply).  A half-wave's lanes hold the
+// k-mers of positions 0 .. 32 NPL - 1 — and, with the minimizer-grouped table, only the m-mers of those base positions: the window of the last
+// k-mer reaches m-mer len - m, so the bound is 32 NPL + m - 1 there (the probe kernel's), not 32 NPL + k - 1 (longer reads took the
+// other mate's m-mers for their tail windows and lost TR k-mers without an error).  One definition for launch_batch and the emulator.
+DBTK_HD int walkfast_npl(uint32_t max_read_len, uint32_t k, bool grmz) {
+    if (k + 4 > 32) return 0;
+    const uint32_t ext = grmz ? mz_m_for_k(k) - 1 : k - 1;
+    if (max_read_len <= 32 * 3 + ext && k + 2 <= 32) return 3;
+    if (max_read_len <= 32 * 5 + ext) return 5;
+    return 0;
+}
 template <int NPL>
 struct __attribute__((aligned(16))) WalkFastSmemT {
     uint32_t pk[2][20];       // 2-bit stream of each mate from its 4-byte-aligned start
@@ -61,7 +72,7 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
     const uint32_t per = (nsurv + x.nblocks() - 1) / x.nblocks();
     const uint64_t lo64 = (uint64_t)x.bid() * per;
     const uint32_t first = lo64 < nsurv ? (uint32_t)lo64 : nsurv, hi = lo64 + per < nsurv ? (uint32_t)(lo64 + per) : nsurv;
-    const uint32_t lmax = 32u * NPL + k - 1;  // (the launcher promised no read is longer)
+    const uint32_t lmax = 32u * NPL + (T.grmz ? mz_m_for_k(k) : k) - 1;  // (walkfast_npl: the launcher promised no read is longer)
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint32_t p0 = hl * NPL;
     for (uint32_t e = (uint32_t)lane; e < (uint32_t)P2_CACHE; e += 64) sm.cache[e] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu};
@@ -355,7 +366,7 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
                 const uint32_t tlen = lc1 + 1 + la1 + 1 + lc0 + 1 + la0, need = (8 + tlen + 3) & ~3u;
                 if (need > txt_left) {
                     uint32_t b = 0;
-                    if (lane == 0) b = x.atomic_add(a.ntxt, TXT_CHUNK);
+                    if (lane == 0) b = txt_carve(x, a);
                     txt_base = x.bcast(b, 0);
                     txt_left = TXT_CHUNK;
                 }

@@ -787,7 +787,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         std::vector<uint32_t> slow(npairs + 1, 0);
         uint32_t nslow = 0;
         const uint32_t kk = g->ksize;
-        const int wnpl = (((p->aln & 3u) && !txtmode) || g_walk_trecs || kk + 4 > 32) ? 0 : (maxlen <= 32 * 3 + kk - 1 && kk + 2 <= 32 ? 3 : maxlen <= 32 * 5 + kk - 1 ? 5 : 0);
+        const int wnpl = (((p->aln & 3u) && !txtmode) || g_walk_trecs) ? 0 : walkfast_npl(maxlen, kk, w.T.grmz != nullptr);
         if (wnpl) {
             w.slow_list = slow.data(); w.nslow = &nslow;
             const bool w11 = w.T.grmz && kk - mz_m_for_k(kk) + 1 == 11;

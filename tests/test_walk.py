@@ -170,8 +170,8 @@ PAIR_IDX = [abi.C_NREADS, abi.C_SUBFILTERED, abi.C_KMERFILTERED, abi.C_LOCUSFILT
             abi.C_FEASIBLE, abi.C_NSHORT, abi.C_NHASH0, abi.C_NHASH1, abi.C_ALGO_INC]
 
 
-def pair_reads(case, seed, npairs=1500):
-    return synth.sim_reads(case.loci, npairs=npairs, sub=0.02, indel=0.004, seed=seed, nrate=0.002, chimeric=0.2, background=0.2, short=0.03)
+def pair_reads(case, seed, npairs=1500, rlen=150):
+    return synth.sim_reads(case.loci, npairs=npairs, sub=0.02, indel=0.004, seed=seed, nrate=0.002, chimeric=0.2, background=0.2, short=0.03, rlen=rlen)
 
 
 def expected_aln(O, o, reads, aln, nloci):
@@ -386,11 +386,12 @@ def test_emulated_walk_kernel_equals_oracle(tmp_path, k, seed):
     assert n > 3000
 
 
-def check_pair_mode(run, O, oh, case, k, nloci):
+def check_pair_mode(run, O, oh, case, k, nloci, rlen=150, sets=((1, 0), (2, 1), (0, 2), (2, 3)), npairs=1500, lean=True):
     """run(p, seq, off) -> dict(counts (OUT.trkmc.ar order), counters, res, nres, aln, order): compared with the oracle."""
-    for aln, ps in ((1, PARAM_SETS[0]), (2, PARAM_SETS[1]), (0, PARAM_SETS[2]), (2, PARAM_SETS[3])):
+    for aln, psi in sets:
+        ps = PARAM_SETS[psi]
         p = abi.default_params(ksize=k, cthreshold=45, threading=2, aln=aln, okam=0, **ps)
-        reads = pair_reads(case, seed=5 + aln + ps["thread_cth"])
+        reads = pair_reads(case, seed=5 + aln + ps["thread_cth"], npairs=npairs, rlen=rlen)
         seq, off = reads.packed()
         o = O.align_walk(oh, p, seq, off)
         g = run(p, seq, off)
@@ -401,7 +402,7 @@ def check_pair_mode(run, O, oh, case, k, nloci):
         n = o["nres"]
         assert g["nres"] == n
         skipped = bind.walk_res_equal(g["res"], o["res"], n, nloci, every_mate=bool(aln))
-        assert skipped >= 0 and (aln or skipped > 0)  # (without -a / -ae the lean first kernel decides most pairs)
+        assert skipped >= 0 and (aln or (skipped > 0) == lean)  # (without -a / -ae the lean first kernel decides most pairs)
         exp, _ = expected_aln(O, o, reads, aln, nloci)
         if aln:
             assert [(h.pair, h.dst, t) for h, t in g["aln"]] == exp
@@ -429,6 +430,30 @@ def test_emulated_pair_mode_equals_oracle(tmp_path, k, seed):
         res, nres = E.walk_results(len(off))
         return dict(counts=e["counts"], counters=e["counters"], res=res, nres=nres, aln=E.aln_records(), order=order, txt=E.aln_text(len(off) // 2))
     check_pair_mode(run, O, oh, case, k, case.loci.nloci)
+
+
+# read lengths either side of what a half-wave of the lean walk kernel covers (walkfast_npl, dbtk_walkfast.h): with the minimizer-grouped
+# graph table 32 NPL + m - 1 (m = 15 at k = 21: 110 and 174), without it 32 NPL + k - 1 (116, 180).  ADVICE r3: at 113, 116, 175 and 180
+# bases the lean kernel was chosen although its lanes do not hold the m-mers of the last windows, and TR k-mers went uncounted.
+LIMIT_RLENS = [110, 111, 116, 174, 175, 180]
+
+
+@pytest.mark.parametrize("rlen", LIMIT_RLENS)
+def test_emulated_pair_mode_at_the_lean_kernels_length_limits(tmp_path, rlen):
+    O = bind.Oracle()
+    E = bind.Emu()
+    k = 21
+    case = WalkCase(str(tmp_path), f"el{rlen}", k, 3)
+    oh = O.load(case.prefix, k); O.load_graph(oh, case.prefix + ".graph.kmers")
+    g = E.load(case.prefix, k, flags=abi.LOAD_GRAPH)
+    tb = E.tables(g)
+    order = g.output_order()
+
+    def run(p, seq, off):
+        e = E.align(g, tb, p, seq, off)
+        res, nres = E.walk_results(len(off))
+        return dict(counts=e["counts"], counters=e["counters"], res=res, nres=nres, aln=E.aln_records(), order=order, txt=E.aln_text(len(off) // 2))
+    check_pair_mode(run, O, oh, case, k, case.loci.nloci, rlen=rlen, sets=((0, 0),), npairs=600, lean=rlen <= 174)
 
 
 def test_oracle_reproduces_golden_g5():
@@ -483,6 +508,27 @@ def test_gpu_pair_mode_equals_oracle(tmp_path, k, seed):
         return out
     check_pair_mode(run, O, oh, case, k, case.loci.nloci)
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,rlen", [(21, r) for r in LIMIT_RLENS] + [(25, 110), (25, 113), (25, 175), (25, 184), (17, 112), (17, 176)])
+def test_gpu_pair_mode_at_the_lean_kernels_length_limits(tmp_path, k, rlen):
+    O = bind.Oracle()
+    D = bind.pkg.Dbtk()
+    case = WalkCase(str(tmp_path), f"gl{k}_{rlen}", k, 3)
+    oh = O.load(case.prefix, k); O.load_graph(oh, case.prefix + ".graph.kmers")
+    g = D.load(case.prefix, k, flags=abi.LOAD_GRAPH)
+    order = g.output_order()
+
+    def run(p, seq, off):
+        ctx = D.context(g, p, device=0)
+        ctx.align(seq, off)
+        r = ctx.counts()
+        res, _, nres = ctx.walk_results(len(off))
+        out = dict(counts=r["counts"], counters=r["counters"], res=res, nres=nres, aln=ctx.aln_records(), order=order, txt=ctx.aln_text(len(off) // 2))
+        ctx.close()
+        return out
+    check_pair_mode(run, O, oh, case, k, case.loci.nloci, rlen=rlen, sets=((0, 0), (2, 1)), npairs=1200,
+                    lean=rlen <= (174 if k != 17 else 176))
 
 
 @pytest.mark.gpu
