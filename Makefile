@@ -15,7 +15,7 @@ all:
 asan-build:
 	mkdir -p $(ASAN_DIR)
 	gcc -std=gnu11 $(SAN) -fPIC -shared -Wall -Wextra -Wno-unused-parameter -o $(ASAN_DIR)/liboracle.so oracle/dbtk_oracle.c -ldl -lm
-	g++ -std=c++17 $(SAN) -fPIC -shared -Wall -Wno-unused-function -Wno-unknown-pragmas -o $(ASAN_DIR)/libdbtk_emu.so tests/emu/emu.cpp danbing-tk_amd/csrc/dbtk_rpgg.cpp -lpthread
+	g++ -std=c++17 $(SAN) -fPIC -shared -Wall -Wno-unused-function -Wno-unknown-pragmas -DDBTK_LOC_Q=40 -o $(ASAN_DIR)/libdbtk_emu.so tests/emu/emu.cpp danbing-tk_amd/csrc/dbtk_rpgg.cpp -lpthread
 	g++ -std=c++17 $(SAN) -Wall -o $(ASAN_DIR)/ktools danbing-tk_amd/csrc/dbtk_ktools.cpp danbing-tk_amd/csrc/dbtk_rpgg.cpp -lpthread
 	g++ -std=c++17 $(SAN) -Wall -o $(ASAN_DIR)/danbing-tk danbing-tk_amd/csrc/dbtk_cli.cpp -Ldanbing-tk_amd -ldbtk_hip -Wl,-rpath,'$$ORIGIN/../../danbing-tk_amd' -lpthread -lz
 

@@ -23,6 +23,8 @@ struct DevX {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    // workgroup barrier, for the kernels that do run several waves per block (dbtk_locus.h: the waves of a block share an LDS image)
+    __device__ void bsync() const { __syncthreads(); }
     __device__ uint64_t ballot(bool p) const { return __ballot(p); }
     // wave-uniform results are returned through readfirstlane/readlane so that the compiler keeps
     // them (and every loop bound, length and flag derived from them) in SGPRs with scalar branches
@@ -95,12 +97,15 @@ struct DevX {
     __device__ uint64_t atomic_cas(uint64_t* p, uint64_t e, uint64_t d) const {
         return atomicCAS(reinterpret_cast<unsigned long long*>(p), (unsigned long long)e, (unsigned long long)d);
     }
+    __device__ uint32_t atomic_cas32(uint32_t* p, uint32_t e, uint32_t d) const { return atomicCAS(p, e, d); }
     __device__ void atomic_max(uint64_t* p, uint64_t v) const { atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
     __device__ void atomic_or(uint64_t* p, uint64_t v) const { atomicOr(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
     __device__ uint32_t atomic_or32(uint32_t* p, uint32_t v) const { return atomicOr(p, v); }
     __device__ uint64_t clock() const { return (uint64_t)clock64(); }
     __device__ uint32_t lds_add(uint32_t* p, uint32_t v) const { return atomicAdd(p, v); }
     __device__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
+    __device__ void lds_max(uint32_t* p, uint32_t v) const { atomicMax(p, v); }
+    __device__ void lds_min(uint32_t* p, uint32_t v) const { atomicMin(p, v); }
     template <class T> __device__ T* smem() const { return reinterpret_cast<T*>(sm); }
 };
 

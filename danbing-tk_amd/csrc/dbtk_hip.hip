@@ -84,6 +84,19 @@ template <int NS, bool RECS> __global__ void __launch_bounds__(64, NS <= 3 ? 2 :
     body_pair<NS, RECS>(x, a);
 }
 
+// per-locus images of the index and the probe kernel that keeps one in LDS (dbtk_locus.h)
+__global__ void __launch_bounds__(256) k_loc_count(LocBuildArgs a) { DevX x{nullptr}; body_loc_count(x, a); }
+__global__ void __launch_bounds__(256) k_loc_clear(LocBuildArgs a) { DevX x{nullptr}; body_loc_clear(x, a); }
+__global__ void __launch_bounds__(256) k_loc_insert(LocBuildArgs a) { DevX x{nullptr}; body_loc_insert(x, a); }
+__global__ void __launch_bounds__(256) k_loc_items(LocItemArgs a) { DevX x{nullptr}; body_loc_items(x, a); }
+__global__ void __launch_bounds__(256) k_loc_rest(LocItemArgs a) { DevX x{nullptr}; body_loc_rest(x, a); }
+constexpr int LOC_IMGB_S = LOC_HDR + (32 << 10), LOC_IMGB_L = LOC_HDR + (32 << LOC_LG_MAX);  // largest image of the two workgroup classes
+constexpr int LOC_NW_S = 8, LOC_NW_L = 16;
+template <int NPL, int NW, int IMGB> __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_probe_locus(BatchArgs a, LocRunArgs r) {
+    __shared__ LocSmemT<NPL, NW, IMGB> sm;
+    DevX x{&sm};
+    body_probe_locus<NPL, NW, IMGB>(x, a, r);
+}
 __global__ void __launch_bounds__(256) k_mz_insert(MzBuildArgs a) { DevX x{nullptr}; body_mz_insert(x, a); }
 __global__ void __launch_bounds__(256) k_mz_fill(uint64_t* t, uint64_t nwords, int level1) { DevX x{nullptr}; body_mz_fill(x, t, nwords, level1); }
 __global__ void __launch_bounds__(256) k_surv_key(SurvSortArgs a) { DevX x{nullptr}; body_surv_key(x, a); }
@@ -190,6 +203,7 @@ struct TableShare {
     IdxBucket* d_idx = nullptr; uint64_t* d_flt = nullptr; uint64_t flt_words = 0; uint32_t* d_trbeg = nullptr; ClsSlot* d_cls = nullptr;
     MzBucket* d_mz = nullptr; MzSlot* d_ovf = nullptr; GrSlot* d_gr = nullptr; MzBucket* d_grmz = nullptr; uint32_t* d_vv = nullptr; uint8_t* d_qc = nullptr; uint16_t* d_perm = nullptr;
     ClsSlot* d_tre = nullptr; ClsSlot* d_bait = nullptr;
+    LocusDir* d_ldir = nullptr; uint8_t* d_limg = nullptr;
     DevTables T;
     uint32_t consistent = 0;
 };
@@ -211,6 +225,11 @@ struct dbtk_ctx {
     MzSlot* d_ovf = nullptr;      //   ... and its overflow table (level 2)
     GrSlot* d_gr = nullptr;       // graph table (threading = 2), nullptr when the handle holds no graph
     MzBucket* d_grmz = nullptr;   //   ... and its minimizer-grouped copy (the lean walk kernel)
+    LocusDir* d_ldir = nullptr;   // per-locus images of the index (dbtk_locus.h): directory,
+    uint8_t* d_limg = nullptr;    //   ... and the images
+    uint64_t limg_bytes = 0, loc_nimg = 0, loc_left_out = 0;
+    int loc_blocks[4] = {0, 0, 0, 0};  // workgroups of k_probe_locus<3 | 5, small | large>
+    int loc_blocks_alt = 0;
     uint32_t* d_vv = nullptr;
     uint8_t* d_qc = nullptr;
     uint16_t* d_perm = nullptr;
@@ -300,12 +319,12 @@ void release_share(dbtk_ctx* c) {
     std::lock_guard<std::mutex> l(g_share_m);
     TableShare* sh = c->share;
     if (!sh) {  // the context never got as far as sharing: the tables (if any) are its own
-        void* own[] = {c->d_flt, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_tre, c->d_bait, c->d_gr, c->d_grmz, c->d_mz, c->d_ovf};
+        void* own[] = {c->d_flt, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_tre, c->d_bait, c->d_gr, c->d_grmz, c->d_mz, c->d_ovf, c->d_ldir, c->d_limg};
         for (void* p : own) if (p) (void)hipFree(p);
         return;
     }
     if (--sh->refs > 0) return;
-    void* ptrs[] = {sh->d_flt, sh->d_trbeg, sh->d_idx, sh->d_cls, sh->d_vv, sh->d_qc, sh->d_perm, sh->d_tre, sh->d_bait, sh->d_gr, sh->d_grmz, sh->d_mz, sh->d_ovf};
+    void* ptrs[] = {sh->d_flt, sh->d_trbeg, sh->d_idx, sh->d_cls, sh->d_vv, sh->d_qc, sh->d_perm, sh->d_tre, sh->d_bait, sh->d_gr, sh->d_grmz, sh->d_mz, sh->d_ovf, sh->d_ldir, sh->d_limg};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     g_shares.erase(std::make_pair(c->g_uid, c->device));
     delete sh;
@@ -337,6 +356,7 @@ void free_ctx(dbtk_ctx* c) {
     delete c;
 }
 
+dbtk_status_t build_locus_images(dbtk_ctx* c);
 dbtk_status_t build_tables(dbtk_ctx* c) {
     const dbtk_rpgg* g = c->g;
     const uint64_t nloci = g->nloci;
@@ -491,6 +511,56 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
             c->mz_turned = nturned;
         }
     }
+    return build_locus_images(c);
+}
+
+// Per-locus images of the index (dbtk_locus.h), from the finished plain index: keys per locus -> image sizes (host) -> empty images
+// -> every (key, locus) membership into its locus' image.  DBTK_LOCUS=0: do without (the global tables answer every look-up).
+dbtk_status_t build_locus_images(dbtk_ctx* c) {
+    const dbtk_rpgg* g = c->g;
+    hipStream_t s = c->stream;
+    const uint64_t nloci = g->nloci;
+    if (const char* e = getenv("DBTK_LOCUS")) if (!atoi(e)) return DBTK_OK;
+    if (!nloci || g->keys.empty() || loc_lg_min(g->ksize) > LOC_LG_MAX || !c->T.consistent) return DBTK_OK;
+    uint32_t *dcnt = nullptr, *dbad = nullptr;
+    HIPCHK(hipMalloc(&dcnt, nloci * 4));
+    HIPCHK(hipMalloc(&dbad, nloci * 4));
+    HIPCHK(hipMemsetAsync(dcnt, 0, nloci * 4, s));
+    HIPCHK(hipMemsetAsync(dbad, 0, nloci * 4, s));
+    LocBuildArgs a;
+    memset(&a, 0, sizeof(a));
+    a.idx = c->d_idx; a.nslots = (c->T.idx_mask + 1) * 4; a.vv = c->d_vv; a.trbeg = c->d_trbeg; a.nloci = (uint32_t)nloci; a.ksize = g->ksize;
+    a.cnt = dcnt; a.bad = dbad;
+    LAUNCH(k_loc_count, dim3(2048), dim3(256), s, a);
+    std::vector<uint32_t> cnt(nloci), bad(nloci);
+    HIPCHK(hipMemcpyAsync(cnt.data(), dcnt, nloci * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<LocusDir> dir(nloci);
+    uint64_t at = 0, nimg = 0;
+    for (uint64_t l = 0; l < nloci; ++l) {
+        const uint32_t lg = loc_lgnb_for(cnt[l], g->ksize);
+        dir[l] = LocusDir{(uint32_t)(at / 16), 0u, lg, (uint32_t)g->out_beg[l]};
+        if (!cnt[l] || lg > LOC_LG_MAX || at + loc_image_bytes(lg) > (16ull << 32)) continue;
+        dir[l].bytes = loc_image_bytes(lg);
+        at += dir[l].bytes;
+        ++nimg;
+    }
+    if (!nimg) { HIPCHK(hipFree(dcnt)); HIPCHK(hipFree(dbad)); return DBTK_OK; }
+    HIPCHK(hipMalloc(&c->d_ldir, nloci * sizeof(LocusDir)));
+    HIPCHK(hipMalloc(&c->d_limg, at + 16));
+    HIPCHK(hipMemcpyAsync(c->d_ldir, dir.data(), nloci * sizeof(LocusDir), hipMemcpyHostToDevice, s));
+    a.dir = c->d_ldir; a.arena = c->d_limg;
+    LAUNCH(k_loc_clear, dim3(4096), dim3(256), s, a);
+    LAUNCH(k_loc_insert, dim3(2048), dim3(256), s, a);
+    HIPCHK(hipMemcpyAsync(bad.data(), dbad, nloci * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    uint64_t nbad = 0;
+    for (uint64_t l = 0; l < nloci; ++l) if (bad[l] && dir[l].bytes) { dir[l].bytes = 0; ++nbad; }
+    if (nbad) HIPCHK(hipMemcpy(c->d_ldir, dir.data(), nloci * sizeof(LocusDir), hipMemcpyHostToDevice));
+    HIPCHK(hipFree(dcnt)); HIPCHK(hipFree(dbad));
+    c->limg_bytes = at; c->loc_nimg = nimg - nbad;
+    c->T.ldir = c->d_ldir; c->T.limg = c->d_limg;
+    if (getenv("DBTK_VERBOSE")) fprintf(stderr, "locus images: %llu of %llu loci, %.1f MB\n", (unsigned long long)c->loc_nimg, (unsigned long long)nloci, at / 1e6);
     return DBTK_OK;
 }
 
@@ -659,7 +729,11 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     const uint64_t tcap = npairs < cap ? npairs : cap;
     const uint64_t nchunks = (npairs + tcap - 1) / tcap;
     const uint64_t nloci = c->g->nloci;
-    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, 3 * (npairs + 1) + nloci + 2 + SCAN_BLOCKS);
+    // behind the survivor lists: the work items of the locus-resident probe kernel (two classes of workgroup) and the list of the
+    // pairs it leaves to the global-table kernel (dbtk_locus.h)
+    const uint64_t surv_words = (3 * (npairs + 1) + nloci + 2 + SCAN_BLOCKS + 3) & ~3ull;
+    const uint64_t item_cap = tcap / LOC_CH + nloci + 2;
+    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, surv_words + 2 * 4 * item_cap + tcap + 4);
     if (st) return st;
     if ((st = ensure(&c->d_hitoff, &c->hitoff_cap, tcap * 4))) return st;  // offsets, then headers
     if ((st = ensure(&c->d_hitva, &c->hitva_cap, tcap * 2 * nkp))) return st;
@@ -740,6 +814,35 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             const dim3 gpr(c->num_cu * c->probe_wpc);
             const uint32_t wn = a.T.mz ? k - a.T.mz_m + 1 : 0;
             const int npl = !a.T.mz || a.edgebuf || a.qmaskbuf ? 0 : (max_read_len <= 32 * 3 + a.T.mz_m - 1 ? 3 : max_read_len <= 32 * 5 + a.T.mz_m - 1 ? 5 : 0);
+            a.sel = nullptr; a.nsel = nullptr;
+            if (npl && a.T.ldir) {
+                // The pairs of loci that have an image: the locus-resident kernel (dbtk_locus.h), image in LDS, one item = one locus'
+                // next LOC_CH pairs of the list; the lean kernel then takes what is left (loci without an image, pairs without a
+                // locus — and everything when the batch has too few survivors per locus for the list to be in locus order).
+                LocItemArgs ia;
+                memset(&ia, 0, sizeof(ia));
+                ia.hist = c->d_surv + 3 * (npairs + 1); ia.nsurv = c->d_small + 0; ia.flag = c->d_small + 6; ia.dir = a.T.ldir;
+                ia.nloci = (uint32_t)nloci; ia.t0 = a.t0; ia.tcap = (uint32_t)tcap;
+                static const bool no_large = [] { const char* e = getenv("DBTK_LOC_L"); return e && !atoi(e); }();  // diagnostic: small workgroups only
+                static const int nw_alt = [] { const char* e = getenv("DBTK_LOC_NW"); return e ? atoi(e) : 0; }();       // diagnostic: 4 waves per small workgroup
+                ia.cap_bytes[0] = LOC_IMGB_S; ia.cap_bytes[1] = no_large ? LOC_IMGB_S : LOC_IMGB_L;
+                ia.items[0] = reinterpret_cast<uint4*>(c->d_surv + surv_words); ia.items[1] = ia.items[0] + item_cap;
+                ia.nitems = c->d_small + 8; ia.item_cap = (uint32_t)item_cap;
+                ia.rest = c->d_surv + surv_words + 2 * 4 * item_cap;
+                HIPCHK(hipMemsetAsync(c->d_small + 8, 0, 3 * sizeof(uint32_t), s));
+                LAUNCH(k_loc_items, dim3((uint32_t)((nloci + 255) / 256)), dim3(256), s, ia);
+                LAUNCH(k_loc_rest, dim3((uint32_t)std::min<uint64_t>((tcap + 255) / 256, (uint64_t)c->num_cu * 8)), dim3(256), s, ia);
+                LocRunArgs r0{a.T.ldir, a.T.limg, ia.items[0], c->d_small + 8}, r1{a.T.ldir, a.T.limg, ia.items[1], c->d_small + 9};
+                if (npl == 3) {
+                    LAUNCH((k_probe_locus<3, LOC_NW_S, LOC_IMGB_S>), dim3(c->loc_blocks[0]), dim3(LOC_NW_S * 64), s, a, r0);
+                    LAUNCH((k_probe_locus<3, LOC_NW_L, LOC_IMGB_L>), dim3(c->loc_blocks[1]), dim3(LOC_NW_L * 64), s, a, r1);
+                } else {
+                    if (nw_alt == 4) LAUNCH((k_probe_locus<5, 4, LOC_IMGB_S>), dim3(c->loc_blocks_alt), dim3(4 * 64), s, a, r0);
+                    else LAUNCH((k_probe_locus<5, LOC_NW_S, LOC_IMGB_S>), dim3(c->loc_blocks[2]), dim3(LOC_NW_S * 64), s, a, r0);
+                    LAUNCH((k_probe_locus<5, LOC_NW_L, LOC_IMGB_L>), dim3(c->loc_blocks[3]), dim3(LOC_NW_L * 64), s, a, r1);
+                }
+                a.sel = ia.rest; a.nsel = c->d_small + 10;
+            }
             // (a wave of the lean form works through one contiguous range of the list: as many waves as are resident at once)
             if (npl == 3 && wn == 7) LAUNCH((k_probe<3, 7>), dim3(c->num_cu * c->probe2_wpc[0]), dim3(64), s, a);
             else if (npl == 3 && wn == 11) LAUNCH((k_probe<3, 11>), dim3(c->num_cu * c->probe2_wpc[1]), dim3(64), s, a);
@@ -899,6 +1002,21 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
                 c->probe2_wpc[i] = nb;
             }
             if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_probe<5, 7>: %d blocks per CU\n", c->probe2_wpc[2]);
+            {   // the locus-resident kernel: as many workgroups as are resident (an item is short: the workgroups take them round robin)
+                const void* kl[4] = {(const void*)k_probe_locus<3, LOC_NW_S, LOC_IMGB_S>, (const void*)k_probe_locus<3, LOC_NW_L, LOC_IMGB_L>,
+                                     (const void*)k_probe_locus<5, LOC_NW_S, LOC_IMGB_S>, (const void*)k_probe_locus<5, LOC_NW_L, LOC_IMGB_L>};
+                for (int i = 0; i < 4; ++i) {
+                    nb = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kl[i], ((i & 1) ? LOC_NW_L : LOC_NW_S) * 64, 0) != hipSuccess || nb <= 0) nb = 1;
+                    if (const char* ev = getenv("DBTK_LOC_BPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
+                    c->loc_blocks[i] = c->num_cu * nb;
+                    if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_probe_locus[%d]: %d workgroups per CU\n", i, nb);
+                }
+                nb = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_probe_locus<5, 4, LOC_IMGB_S>, 4 * 64, 0) != hipSuccess || nb <= 0) nb = 1;
+                if (const char* ev = getenv("DBTK_LOC_BPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
+                c->loc_blocks_alt = c->num_cu * nb;
+            }
         }
         // resident waves of each resolve-kernel instance (one vote-spill scratch row per resident wave)
         const void* kp[3] = {(const void*)k_pair<2, true>, (const void*)k_pair<3, true>, (const void*)k_pair<4, true>};
@@ -949,7 +1067,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             TableShare* sh = it != g_shares.end() ? it->second : nullptr;
             auto to_share = [&](TableShare* t) {
                 t->d_idx = c->d_idx; t->d_flt = c->d_flt; t->flt_words = c->flt_words; t->d_trbeg = c->d_trbeg; t->d_cls = c->d_cls; t->d_mz = c->d_mz; t->d_ovf = c->d_ovf;
-                t->d_gr = c->d_gr; t->d_grmz = c->d_grmz; t->d_vv = c->d_vv; t->d_qc = c->d_qc; t->d_perm = c->d_perm; t->d_tre = c->d_tre; t->d_bait = c->d_bait;
+                t->d_gr = c->d_gr; t->d_grmz = c->d_grmz; t->d_ldir = c->d_ldir; t->d_limg = c->d_limg; t->d_vv = c->d_vv; t->d_qc = c->d_qc; t->d_perm = c->d_perm; t->d_tre = c->d_tre; t->d_bait = c->d_bait;
                 t->T = c->T; t->consistent = c->consistent;
             };
             if (!sh) {
@@ -959,7 +1077,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
                 g_shares[key] = sh;
             } else {
                 c->d_idx = sh->d_idx; c->d_flt = sh->d_flt; c->flt_words = sh->flt_words; c->d_trbeg = sh->d_trbeg; c->d_cls = sh->d_cls; c->d_mz = sh->d_mz; c->d_ovf = sh->d_ovf;
-                c->d_gr = sh->d_gr; c->d_grmz = sh->d_grmz; c->d_vv = sh->d_vv; c->d_qc = sh->d_qc; c->d_perm = sh->d_perm; c->d_tre = sh->d_tre; c->d_bait = sh->d_bait;
+                c->d_gr = sh->d_gr; c->d_grmz = sh->d_grmz; c->d_ldir = sh->d_ldir; c->d_limg = sh->d_limg; c->d_vv = sh->d_vv; c->d_qc = sh->d_qc; c->d_perm = sh->d_perm; c->d_tre = sh->d_tre; c->d_bait = sh->d_bait;
                 c->T = sh->T; c->consistent = sh->consistent;
             }
             c->share = sh;

@@ -208,6 +208,8 @@ struct BatchArgs {
     uint32_t t0, tcap;       // K2/K3 work on survivors [t0, min(t0 + tcap, *nsurv)): the hit buffer holds tcap pairs
     uint32_t* walk_dst;      // threading = 2 (v1.3): per survivor, destLocus of a pair that reaches threading (else left NAN32);
                              // the walk kernel (dbtk_walk.h: body_walk_pairs) takes it from there
+    const uint32_t* sel;     // the lean probe kernel only: nullptr, or the chunk-relative indices of the pairs it is to look up (the pairs the
+    const uint32_t* nsel;    //   locus-resident kernel, dbtk_locus.h, does not take) and their number
     uint32_t vzero;          // always 0: `lane * vzero` makes an address look lane-dependent, so that a load whose value is only
                              // needed an iteration later is not turned into scalars (and waited for) right where it is issued
 };
@@ -1333,6 +1335,7 @@ DBTK_HD void body_probe(X& x, const BatchArgs& a) {
 
 }  // namespace dbtk
 #include "dbtk_probe2.h"
+#include "dbtk_locus.h"
 #include "dbtk_walkfast.h"
 namespace dbtk {
 

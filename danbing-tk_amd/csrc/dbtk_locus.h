@@ -1,0 +1,601 @@
+// dbtk_locus.h — the probe kernel with the locus' own k-mers resident in LDS (K2L): kfilter's look-ups
+// (src/aQueryFasta_thread.cpp:190-224, `kmerDBi.find(kmers[i])` for every position of both mates) for the pairs of a batch that
+// come from loci, answered from a per-locus image of the index instead of the global tables.
+//
+// What bounds the probe kernel on this chip is the number of 128-byte lines it asks the memory system for (dbtk_tables.h: ~45 G
+// requests per second whatever their size), and the minimizer-grouped global table still costs ~33 lines per read.  But the survivor
+// list is in locus order (dbtk_probe2.h: body_surv_*), the k-mers of a read from locus l are — but for sequencing errors and the
+// rare shared k-mer — k-mers of locus l, and a locus has ~2 000 of them: 16 KB.  So every locus gets an IMAGE: its part of the
+// index (every key whose index value names the locus, with what the global look-up would return for it) as a small bucketed hash
+// table, stored in HBM exactly as it will sit in LDS.  A workgroup takes ITEMS = (locus, up to LOC_CH consecutive pairs of its
+// segment of the list), copies the locus' image into LDS with coalesced 16-byte loads (one pass over ~34 KB for ~64 pairs: ~4 lines
+// per pair) and its waves look every position of their pairs up there: 260 LDS probes per pair instead of 70 global lines.  Only what
+// the image cannot answer goes to the global index: positions whose k-mer is not in the image (a k-mer with a sequencing error —
+// which must be PROVEN absent from the whole index, so it is looked up there —, a k-mer of another locus) and the keys shared
+// between loci (their index value is a `vv` list: marked in the image, fetched from the index).  The result per position is what
+// the global tables would have given, bit for bit: an image is a partition of the index, never a second opinion.
+//
+// The image (all words 32-bit; LOC_HDR bytes of header, then nb = 2^lgnb buckets of 32 bytes):
+//   bucket  = tag[4], pay[4].  tag = low 32 bits of the canonical k-mer.  The bucket number is (hi ^ h(lo)) & (nb - 1) with hi the
+//             k-mer's bits from 32 up, so given the bucket and lo the low lgnb bits of hi are implied; the bits of hi above them
+//             (at most 8: 2k - 32 - lgnb <= 8 is the launcher's condition) sit in pay[31:24]: tag + bucket + those bits = the key.
+//   pay     = extra << 24 | LOC_MULTI | LOC_FLANK | LOC_TR | slot.  A k-mer unique to the locus is its FLANK k-mer or its TR k-mer
+//             number `slot` (counter trbeg[l] + slot: IdxBucket::val's high word); LOC_MULTI: the key's index value is a vv list
+//             (or the RPGG's sets disagree about it): ask the index.  A free slot holds LOC_EMPTY (FLANK and TR both set, which
+//             no entry has).
+// A key whose bucket is full when it arrives is simply LEFT OUT of the image (buckets are at most half full: ~4 % of the keys): "not
+// in the image" never means "not in the index", the index answers for it like for any other k-mer the image does not hold.  So a
+// look-up is always exactly one bucket — every lane of a wave the same fixed work, no second probe that one lane in twenty would need
+// and every wave would therefore pay for.
+// Built on the GPU from the finished plain index (body_loc_count -> sizes on the host -> body_loc_clear -> body_loc_insert);
+// written to / read from the sidecar file PREF.dbtk.idx by the host (dbtk_hip.hip).
+#ifndef DBTK_LOCUS_H_
+#define DBTK_LOCUS_H_
+
+namespace dbtk {
+
+constexpr uint32_t LOC_MULTI = 1u << 23, LOC_FLANK = 1u << 22, LOC_TR = 1u << 21, LOC_SLOT = (1u << 21) - 1;
+constexpr uint32_t LOC_EMPTY = 0xFFFFFFFEu;  // pay of a free slot (FLANK and TR both set)
+constexpr uint32_t LOC_MISS = 0xFFFFFFFFu;   // look-up result: the k-mer is not in the image
+constexpr uint32_t LOC_HDR = 16;             // header bytes: lgnb, keys left out, trbeg[l], locus
+constexpr uint32_t LOC_CH = 64;              // pairs per item
+constexpr uint32_t LOC_LG_MIN = 5, LOC_LG_MAX = 11;
+struct LocusDir {
+    uint32_t off16;  // of the image in the arena, in units of 16 bytes
+    uint32_t bytes;  // of the image (a multiple of 16); 0: the locus has none (too large, or built badly): its pairs take the global path
+    uint32_t lgnb;
+    uint32_t trbeg;  // the locus' first counter (T.trbeg[l]: here so that the kernel needs no further load for it)
+};
+// smallest lgnb that leaves at most 8 bits of the key unaccounted for
+DBTK_HD uint32_t loc_lg_min(uint32_t k) { return 2 * k > 40 + LOC_LG_MIN ? 2 * k - 40 : LOC_LG_MIN; }
+// image of a locus with n keys: buckets at most half full
+DBTK_HD uint32_t loc_lgnb_for(uint64_t nkeys, uint32_t k) {
+    uint32_t lg = loc_lg_min(k);
+    while ((4ull << lg) < 2 * nkeys) ++lg;
+    return lg;
+}
+DBTK_HD uint32_t loc_image_bytes(uint32_t lgnb) { return LOC_HDR + (32u << lgnb); }
+DBTK_HD uint32_t loc_bucket(uint32_t lo, uint32_t hi, uint32_t lgnb) { return (hi ^ ((lo * 0x9E3779B1u) >> 15)) & ((1u << lgnb) - 1); }
+
+// ------------------------------------------------------------------ build --
+struct LocBuildArgs {
+    const IdxBucket* idx;
+    uint64_t nslots;        // 4 per IdxBucket
+    const uint32_t* vv;
+    const uint32_t* trbeg;
+    uint32_t nloci, ksize;
+    uint32_t* cnt;          // [nloci] pass 0: keys per locus
+    const LocusDir* dir;    // later passes
+    uint8_t* arena;
+    uint32_t* bad;          // [nloci] != 0: the image could not be built (a TR k-mer's number does not fit the slot field)
+};
+// keys per locus
+template <class X>
+DBTK_HD void body_loc_count(X& x, const LocBuildArgs& a) {
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.nslots; i += (uint64_t)x.nblocks() * x.nthreads()) {
+        const uint64_t key = a.idx[i >> 2].key[i & 3];
+        if (key == NAN64) continue;
+        const uint32_t v = (uint32_t)a.idx[i >> 2].val[i & 3];
+        if (v & 1) {
+            const uint32_t n = a.vv[v >> 1];
+            for (uint32_t j = 0; j < n; ++j) { const uint32_t l = a.vv[(v >> 1) + 1 + j]; if (l < a.nloci) x.atomic_add(&a.cnt[l], 1u); }
+        } else if ((v >> 1) < a.nloci) x.atomic_add(&a.cnt[v >> 1], 1u);
+    }
+}
+// every image empty: one block per locus at a time
+template <class X>
+DBTK_HD void body_loc_clear(X& x, const LocBuildArgs& a) {
+    for (uint32_t l = x.bid(); l < a.nloci; l += x.nblocks()) {
+        const LocusDir d = a.dir[l];
+        if (!d.bytes) continue;
+        uint32_t* w = reinterpret_cast<uint32_t*>(a.arena + 16ull * d.off16);
+        const uint32_t nw = d.bytes / 4;
+        for (uint32_t i = (uint32_t)x.tid(); i < nw; i += (uint32_t)x.nthreads()) {
+            uint32_t v = 0;
+            if (i == 0) v = d.lgnb;
+            else if (i == 2) v = a.trbeg[l];
+            else if (i == 3) v = l;
+            else if (i >= LOC_HDR / 4 && ((i - LOC_HDR / 4) & 7) >= 4) v = LOC_EMPTY;
+            w[i] = v;
+        }
+    }
+}
+// one (key, locus) membership into the locus' image
+template <class X>
+DBTK_HD void loc_insert_one(X& x, const LocBuildArgs& a, uint64_t key, uint32_t l, uint32_t val, uint32_t aux) {
+    if (l >= a.nloci) return;
+    const LocusDir d = a.dir[l];
+    if (!d.bytes) return;
+    uint32_t* w = reinterpret_cast<uint32_t*>(a.arena + 16ull * d.off16);
+    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    const uint32_t b = loc_bucket(lo, hi, d.lgnb), extra = hi >> d.lgnb;
+    uint32_t pay;
+    if ((val & 1) || aux == CLS_NONE) pay = LOC_MULTI;
+    else if (aux == CLS_FLANK) pay = LOC_FLANK;
+    else {
+        const uint32_t slot = aux - a.trbeg[l];
+        if (aux < a.trbeg[l] || slot > LOC_SLOT) { a.bad[l] = 1; return; }
+        pay = LOC_TR | slot;
+    }
+    if (extra > 0xFF) { a.bad[l] = 1; return; }
+    pay |= extra << 24;
+    uint32_t* bk = w + LOC_HDR / 4 + 8 * b;
+    for (int s = 0; s < 4; ++s)
+        if (x.atomic_cas32(&bk[4 + s], LOC_EMPTY, pay) == LOC_EMPTY) { bk[s] = lo; return; }
+    x.atomic_add(&w[1], 1u);  // the bucket is full: the key stays out of the image (the index answers for it)
+}
+template <class X>
+DBTK_HD void body_loc_insert(X& x, const LocBuildArgs& a) {
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.nslots; i += (uint64_t)x.nblocks() * x.nthreads()) {
+        uint64_t key = a.idx[i >> 2].key[i & 3];
+        if (key == NAN64) continue;
+        key &= ~IDX_OVF;
+        const uint64_t va = a.idx[i >> 2].val[i & 3];
+        const uint32_t v = (uint32_t)va, aux = (uint32_t)(va >> 32);
+        if (v & 1) {
+            const uint32_t n = a.vv[v >> 1];
+            for (uint32_t j = 0; j < n; ++j) loc_insert_one(x, a, key, a.vv[(v >> 1) + 1 + j], v, aux);
+        } else loc_insert_one(x, a, key, v >> 1, v, aux);
+    }
+}
+
+// ------------------------------------------------------------------ look-up --
+// pay of `km` in the image at `img` (LDS on the device), LOC_MISS when it is not there.  The plain form: every slot of the home
+// bucket.  (The kernel's unrolled fast path below does the same with its loads issued together.)
+DBTK_HD uint32_t loc_find(const uint32_t* img, uint64_t km) {
+    const uint32_t lgnb = img[0], lo = (uint32_t)km, hi = (uint32_t)(km >> 32);
+    const uint32_t* bk = img + LOC_HDR / 4 + 8 * loc_bucket(lo, hi, lgnb);
+    const uint32_t extra = hi >> lgnb;
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t p = bk[4 + s];
+        if (bk[s] == lo && (p >> 24) == extra && (p & (LOC_FLANK | LOC_TR)) != (LOC_FLANK | LOC_TR)) return p;
+    }
+    return LOC_MISS;
+}
+
+// ------------------------------------------------------------------ items --
+// After the survivor sort hist[l] is where the segment of key l ends in the sorted list (body_surv_scatter advanced every key's
+// first place past its last pair): the segment of l is [hist[l - 1], hist[l]).  One thread per key: the part of its segment inside
+// the chunk [t0, tend) of the list, cut into items of LOC_CH pairs, for the class of workgroup its image fits (0: small, 1: large).
+struct LocItemArgs {
+    const uint32_t* hist;     // [nloci + 1] segment ends (key nloci: no locus)
+    const uint32_t* nsurv;
+    const uint32_t* flag;     // the list is in locus order
+    const LocusDir* dir;
+    uint32_t nloci, t0, tcap;
+    uint32_t cap_bytes[2];    // largest image of each class
+    uint4* items[2];          // {locus, first, end, 0}
+    uint32_t* nitems;         // [2], then [2] = entries of `rest`
+    uint32_t item_cap;
+    uint32_t* rest;           // chunk-relative indices of the pairs no item covers
+};
+DBTK_HD int loc_class(const LocItemArgs& a, uint32_t l) {
+    if (l >= a.nloci) return -1;
+    const uint32_t b = a.dir[l].bytes;
+    return !b ? -1 : b <= a.cap_bytes[0] ? 0 : b <= a.cap_bytes[1] ? 1 : -1;
+}
+template <class X>
+DBTK_HD void body_loc_items(X& x, const LocItemArgs& a) {
+    if (!*a.flag) return;
+    const uint32_t ns = *a.nsurv;
+    const uint32_t tend = ns - a.t0 < a.tcap ? ns : a.t0 + a.tcap;
+    for (uint32_t l = x.bid() * (uint32_t)x.nthreads() + (uint32_t)x.tid(); l < a.nloci; l += x.nblocks() * (uint32_t)x.nthreads()) {
+        const int c = loc_class(a, l);
+        if (c < 0) continue;
+        uint32_t lo = l ? a.hist[l - 1] : 0u, hi = a.hist[l];
+        if (lo < a.t0) lo = a.t0;
+        if (hi > tend) hi = tend;
+        if (lo >= hi) continue;
+        const uint32_t n = (hi - lo + LOC_CH - 1) / LOC_CH;
+        const uint32_t base = x.atomic_add(&a.nitems[c], n);
+        for (uint32_t j = 0; j < n && base + j < a.item_cap; ++j) {
+            const uint32_t f = lo + j * LOC_CH;
+            a.items[c][base + j] = uint4{l, f, f + LOC_CH < hi ? f + LOC_CH : hi, 0u};
+        }
+    }
+}
+// the pairs of the chunk whose key has no image (or no key at all): their indices, for the global-table kernel.  One thread per pair;
+// a wave appends its pairs together, in list order.  With the list not in locus order (a batch with few survivors per locus): all of them.
+template <class X>
+DBTK_HD void body_loc_rest(X& x, const LocItemArgs& a) {
+    const uint32_t ns = *a.nsurv;
+    const uint32_t tend = ns - a.t0 < a.tcap ? ns : a.t0 + a.tcap;
+    const uint32_t n = ns > a.t0 ? tend - a.t0 : 0;
+    const bool sorted = *a.flag != 0;
+    const uint32_t nround = (n + 63) & ~63u;
+    for (uint32_t i = x.bid() * (uint32_t)x.nthreads() + (uint32_t)x.tid(); i < nround; i += x.nblocks() * (uint32_t)x.nthreads()) {
+        bool mine = i < n;
+        if (mine && sorted) {
+            const uint32_t t = a.t0 + i;
+            uint32_t lo = 0, hi = a.nloci + 1;  // first key whose segment ends behind t
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (a.hist[mid] > t) hi = mid; else lo = mid + 1;
+            }
+            mine = loc_class(a, lo) < 0;
+        }
+        const uint64_t m = x.ballot(mine);
+        if (!m) continue;
+        uint32_t base = 0;
+        if (x.lane() == 0) base = x.atomic_add(&a.nitems[2], (uint32_t)__builtin_popcountll(m));
+        base = x.bcast(base, 0);
+        if (mine) a.rest[base + (uint32_t)__builtin_popcountll(m & ((1ull << x.lane()) - 1))] = i;
+    }
+}
+
+// ------------------------------------------------------------------ the kernel --
+// A workgroup of NW waves per item.  Per item a wave owns the pairs q = wave, wave + NW, ... (at most LOC_CH / NW) and works in
+// three phases, so that the latency of what goes to the global index is paid once per item and not once per pair:
+//   1  per pair: 2-bit pack, canonical k-mers, one bucket of the image per position (LDS); the positions the image answers go to
+//      the hit buffers at once (`aux`, 16-byte stores: the values of such positions are all 2 * locus and need not travel);
+//      every other position's k-mer is QUEUED in LDS and stands as "not in the index" for now;
+//   2  the queue against the plain index, 16 look-ups per step, several steps in flight (the four lanes of a quad read the four
+//      16-byte parts of one bucket: one request per look-up); a k-mer found there (one the image left out, a k-mer of another locus,
+//      a key shared between loci) is PATCHED into its row of the hit buffers, and the row's statistics follow;
+//   3  the per-read headers (found positions, the one index value or not); the rare read whose found k-mers do not all have one
+//      index value gets its value row (every position the image answered: 2 * locus; the patched ones already hold theirs).
+#ifndef DBTK_LOC_Q
+#define DBTK_LOC_Q 256
+#endif
+constexpr int LOC_Q = DBTK_LOC_Q;              // queue entries per wave (the test emulator builds with a short queue: look-ups in the middle of a pair)
+constexpr int LOC_ROWS = 2 * (int)LOC_CH / 4;  // rows (mates) of one wave's pairs of an item, for workgroups of at least 4 waves
+template <int NPL>
+struct __attribute__((aligned(16))) LocWaveSmemT {
+    uint32_t pk[2][20];             // 2-bit stream of each mate from its 4-byte-aligned start
+    uint16_t vd[2][40];             // validity bits (only for a pair with a non-ACGT byte)
+    uint32_t res[2][32 * NPL];      // [mate][position]: aux of the pair being looked up, on its way to 16-byte stores
+    uint64_t qkm[LOC_Q];            // queue: k-mers the image could not answer
+    uint32_t qcode[LOC_Q];          //   row << 8 | position
+    uint32_t stat[LOC_ROWS][4];     // per row (local pair << 1 | mate): found positions, largest and smallest index value, hit-buffer row
+    uint32_t patched[LOC_ROWS][NPL];  // per row: positions whose value came from the index (bit p of word p / 32)
+};
+template <int NPL, int NW, int IMGB>
+struct __attribute__((aligned(16))) LocSmemT {
+    uint4 img[IMGB / 16];
+    LocWaveSmemT<NPL> w[NW];
+};
+struct LocRunArgs {
+    const LocusDir* dir;
+    const uint8_t* arena;
+    const uint4* items;
+    const uint32_t* nitems;
+};
+
+template <int NPL, int NW, int IMGB, class X>
+DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
+    typedef LocSmemT<NPL, NW, IMGB> SM;
+    static_assert(NW >= 4 && 2 * ((int)LOC_CH / NW) <= LOC_ROWS, "rows of a wave's pairs of one item");
+    static_assert((IMGB - (int)LOC_HDR) % (16 * NW * 64) == 0, "the largest image is a whole number of 16-byte loads per thread");
+    constexpr int IPT = (IMGB - (int)LOC_HDR) / (16 * NW * 64);  // 16-byte pieces of an image per thread
+    SM& smb = *x.template smem<SM>();
+    const int lane = x.lane();
+    const uint32_t wave = (uint32_t)x.tid() >> 6;
+    LocWaveSmemT<NPL>& sm = smb.w[wave];
+    const uint32_t* bks = reinterpret_cast<const uint32_t*>(smb.img);  // (the image's buckets; its header stays in HBM: the directory says as much)
+    const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5;
+    const DevTables& T = a.T;
+    const uint32_t k = T.ksize;
+    const uint32_t nitems = *r.nitems;
+    const uint32_t lmax = 32u * NPL + k - 1;  // bases the lanes of a half cover (the launcher promised no read is longer)
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    const uint32_t p0 = hl * NPL;
+    const uint32_t sub = (uint32_t)lane & 3u, qd = (uint32_t)lane >> 2;
+    const uint32_t S = x.nblocks();
+    // This wave's pairs, item after item: pair q of an item is the wave's when q % NW == wave.  The fetch pipeline runs along that
+    // sequence ACROSS items (while the workgroup waits for an image, the reads of its first pairs are already on their way).  All loads
+    // unconditional, clamped to something valid, so that they stay in flight.
+    struct Cur { uint32_t it; uint32_t i, end; };  // item, pair (index into the sorted list), the item's end
+    auto desc = [&](uint32_t it) -> uint4 { return r.items[it < nitems ? it : 0u]; };
+    auto seek = [&](uint32_t it) -> Cur {  // first pair of the wave at or after item `it`
+        for (;;) {
+            if (it >= nitems) return Cur{it, 0u, 0u};
+            const uint4 d = desc(it);
+            if (d.y + wave < d.z) return Cur{it, d.y + wave, d.z};
+            it += S;
+        }
+    };
+    auto next = [&](const Cur& c) -> Cur {
+        if (c.it >= nitems) return c;
+        if (c.i + NW < c.end) return Cur{c.it, c.i + NW, c.end};
+        return seek(c.it + S);
+    };
+    uint32_t rw0 = 0, rw1 = 0;
+    uint64_t o0C = 0, o1C = 0, o0B = 0, o1B = 0;
+    uint32_t pairA = 0;
+    auto fetch_bytes = [&](uint64_t o0, uint64_t o1) {
+        uint32_t len = (uint32_t)(o1 - o0);
+        if (len > lmax) len = lmax;
+        const uint64_t a0 = o0 & ~3ull;
+        const uint32_t nw = ((uint32_t)(o0 - a0) + len + 3) >> 2;
+        rw0 = *reinterpret_cast<const uint32_t*>(a.seq + (2 * hl < nw ? a0 + 8ull * hl : 0ull));
+        rw1 = *reinterpret_cast<const uint32_t*>(a.seq + (2 * hl + 1 < nw ? a0 + 8ull * hl + 4 : 0ull));
+    };
+    auto fetch_offsets = [&](uint32_t pair) {
+        const uint64_t rr = 2 * (uint64_t)pair + half;
+        o0B = a.off[rr]; o1B = a.off[rr + 1];
+    };
+    auto surv_at = [&](const Cur& c) { return a.surv[c.it < nitems ? c.i : a.t0]; };
+    Cur cC = seek(x.bid()), cB = next(cC), cA = next(cB);  // pair being looked up; the one whose offsets / whose list entry are in flight
+    if (cC.it < nitems) {
+        fetch_offsets(x.uni(surv_at(cC)));
+        o0C = o0B; o1C = o1B;
+        fetch_bytes(o0C, o1C);
+        if (cB.it < nitems) fetch_offsets(x.uni(surv_at(cB)));
+        pairA = surv_at(cA);
+    }
+    // ---- phase 2: the queue against the plain index; what is found is patched into the hit buffers
+    uint32_t qn = 0;  // queue entries (uniform)
+    auto settle = [&](bool active, uint32_t code, uint64_t kq, uint64_t q0, uint64_t q1, bool& more) -> uint64_t {
+        const uint64_t v0 = quad_perm64<2, 3, 2, 3>(x, q0), v1 = quad_perm64<2, 3, 2, 3>(x, q1);
+        const bool keyl = sub < 2;
+        const bool m0 = active && keyl && q0 == kq, m1 = active && keyl && (q1 & ~IDX_OVF) == kq;
+        const bool ovf = active && sub == 1 && q1 != NAN64 && (q1 & IDX_OVF);
+        const uint64_t hmask = x.ballot(m0 || m1), omask = x.ballot(ovf);
+        const bool qhit = ((hmask >> (lane & ~3u)) & 0xF) != 0;
+        more = active && !qhit && ((omask >> ((lane & ~3u) + 1)) & 1);
+        if (m0 || m1) {
+            const uint64_t v = m0 ? v0 : v1;
+            const uint32_t row = code >> 8, pos = code & 0xFFu, val = (uint32_t)v;
+            const size_t at = (size_t)sm.stat[row][3] * a.nkp + pos;
+            a.hitaux[at] = (uint32_t)(v >> 32);
+            a.hitval[at] = val;
+            x.lds_add(&sm.stat[row][0], 1u);
+            x.lds_max(&sm.stat[row][1], val);
+            x.lds_min(&sm.stat[row][2], val);
+            x.lds_or(&sm.patched[row][pos >> 5], 1u << (pos & 31));
+        }
+        return x.ballot(more);
+    };
+    auto flush = [&]() {
+        x.sync();
+        constexpr int NB = 4;
+        for (uint32_t i0 = 0; i0 < qn; i0 += 16 * NB) {
+            uint32_t bq[NB], cd[NB];
+            uint64_t kq[NB], q0[NB], q1[NB];
+            bool actv[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const uint32_t ii = i0 + 16 * u + qd;
+                actv[u] = ii < qn;
+                const uint32_t ic = actv[u] ? ii : 0u;
+                kq[u] = sm.qkm[ic]; cd[u] = sm.qcode[ic];
+                bq[u] = actv[u] ? (uint32_t)hash_idx(kq[u], T.idx_shift) : 0u;
+                bucket_part(T.idx, bq[u], sub, &q0[u], &q1[u]);
+            }
+            uint64_t anymore = 0;
+            bool more[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                more[u] = false;
+                if (i0 + 16 * u < qn) anymore |= settle(actv[u], cd[u], kq[u], q0[u], q1[u], more[u]);
+            }
+            if (anymore) {  // (about one look-up in a thousand: the next bucket)
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    bool mo = more[u];
+                    uint32_t b = bq[u];
+                    while (x.ballot(mo)) {
+                        b = (b + 1) & (uint32_t)T.idx_mask;
+                        uint64_t n0 = 0, n1 = 0;
+                        if (mo) bucket_part(T.idx, b, sub, &n0, &n1);
+                        bool m2 = false;
+                        (void)settle(mo, cd[u], kq[u], n0, n1, m2);
+                        mo = m2;
+                    }
+                }
+            }
+        }
+        qn = 0;
+        x.sync();
+    };
+    // (the descriptor and the directory entry of the workgroup's next items are fetched an item ahead: three dependent round trips
+    // in front of every image otherwise)
+    uint4 d1 = desc(x.bid()), d2 = desc(x.bid() + S);
+    LocusDir ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
+    DBTK_STAMP_DECL
+    for (uint32_t item = x.bid(); item < nitems; item += S) {
+        DBTK_STAMP(42);  // headers of the item before
+        const uint4 d = d1;
+        const LocusDir ld = ld1;
+        const uint32_t locus = x.uni(d.x), lgnb = x.uni(ld.lgnb), trb = x.uni(ld.trbeg);
+        x.bsync();  // every wave is done with the image of the item before
+        {
+            const p2_v4u* src = reinterpret_cast<const p2_v4u*>(r.arena + 16ull * ld.off16 + LOC_HDR);
+            const uint32_t n16 = (ld.bytes - LOC_HDR) / 16;
+            p2_v4u t[IPT];
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                const uint32_t o = (uint32_t)x.tid() + (uint32_t)u * NW * 64;
+                t[u] = src[o < n16 ? o : 0u];
+            }
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                const uint32_t o = (uint32_t)x.tid() + (uint32_t)u * NW * 64;
+                if (o < n16) *reinterpret_cast<p2_v4u*>(&smb.img[o]) = t[u];
+            }
+        }
+        d1 = d2; d2 = desc(item + 2 * S);
+        ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
+        x.bsync();
+        uint32_t nrow = 0;  // rows of this wave in the item so far (uniform)
+        DBTK_STAMP(43);  // barriers, image into LDS, the next one's loads issued
+        while (cC.it == item) {
+            const uint32_t i = cC.i - a.t0;  // pair of the chunk: hit-buffer rows 2i, 2i + 1
+            const uint64_t o0 = o0C, o1 = o1C;
+            uint32_t len = (uint32_t)(o1 - o0);
+            if (len > lmax) { *a.errflag = DBTK_ERR_READ_TOO_LONG; len = lmax; }
+            const uint64_t a0 = o0 & ~3ull;
+            const uint32_t rsh = (uint32_t)(o0 - a0);
+            const uint32_t dw0 = rw0, dw1 = rw1;
+            {   // advance the pipeline
+                cC = cB; cB = cA; cA = next(cA);
+                const bool hasC = cC.it < nitems, hasB = cB.it < nitems;
+                o0C = hasC ? o0B : 0ull; o1C = hasC ? o1B : 0ull;
+                fetch_bytes(o0C, o1C);
+                fetch_offsets(hasB ? x.uni(pairA) : x.uni(pairA) * 0u);
+                pairA = surv_at(cA);
+            }
+            x.sync();  // the previous pair's LDS is dead
+            uint32_t bad = 0;
+            {
+                const uint32_t c0 = pack4_b2(dw0, &bad), c1 = pack4_b2(dw1, &bad);
+                reinterpret_cast<uint16_t*>(sm.pk[half])[hl ^ 1u] = (uint16_t)(((c0 >> 8) & 0xFF00u) | ((c1 >> 16) & 0xFFu));
+            }
+            const uint32_t nk = len >= k ? len - k + 1 : 0;
+            const bool clean = x.ballot(bad != 0 && 8 * hl < rsh + len) == 0;
+            const uint32_t row = nrow + half, hrow = 2 * i + half;
+            DBTK_STAMP(40);  // fetch pipeline, pack
+            uint64_t km[NPL];
+            bool pend[NPL];
+            uint32_t npend = 0, nres = 0;
+            if (clean) {
+                x.sync();
+                const uint64_t W = window_fw_clean(sm.pk[half], rsh + p0, 32);
+                const uint64_t RW = revcomp2(W, 32);
+                uint32_t bo[NPL];
+                uint4 tg[NPL];
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    const uint64_t fw = (W >> (2 * (32 - k - j))) & kmask, rc = (RW >> (2 * j)) & kmask;
+                    km[j] = fw < rc ? fw : rc;
+                    bo[j] = 8 * loc_bucket((uint32_t)km[j], (uint32_t)(km[j] >> 32), lgnb);
+                }
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) tg[j] = *reinterpret_cast<const uint4*>(bks + bo[j]);  // (the tags of the lane's positions: reads issued together)
+                // the slot whose tag matches (the last of them, should two match), then ITS pay word: one more 4-byte read instead of the
+                // bucket's four (registers)
+                uint32_t pay[NPL];
+                bool any[NPL];
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    const uint32_t lo = (uint32_t)km[j];
+                    uint32_t sl = 0;
+                    any[j] = false;
+                    if (tg[j].x == lo) { sl = 0; any[j] = true; }
+                    if (tg[j].y == lo) { sl = 1; any[j] = true; }
+                    if (tg[j].z == lo) { sl = 2; any[j] = true; }
+                    if (tg[j].w == lo) { sl = 3; any[j] = true; }
+                    pay[j] = bks[bo[j] + 4 + sl];
+                }
+                bool slow = false;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    const uint32_t extra = (uint32_t)(km[j] >> 32) >> lgnb, p = pay[j];
+                    const bool act = p0 + j < nk;
+                    const bool ok = any[j] && (p >> 24) == extra && (p & (LOC_FLANK | LOC_TR)) != (LOC_FLANK | LOC_TR);
+                    const bool again = act && !ok && any[j];  // a tag matched but not its entry (another slot of the bucket may): the plain search
+                    slow |= again;
+                    pay[j] = !act ? LOC_EMPTY : ok ? p : again ? LOC_EMPTY - 1 : LOC_MISS;
+                }
+                if (x.ballot(slow)) {  // (rare)
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j)
+                        if (pay[j] == LOC_EMPTY - 1) {
+                            const uint32_t lo = (uint32_t)km[j], extra = (uint32_t)(km[j] >> 32) >> lgnb;
+                            const uint32_t* bk = bks + bo[j];
+                            uint32_t p = LOC_MISS;
+                            for (int s2 = 0; s2 < 4; ++s2) {
+                                const uint32_t q = bk[4 + s2];
+                                if (bk[s2] == lo && (q >> 24) == extra && (q & (LOC_FLANK | LOC_TR)) != (LOC_FLANK | LOC_TR)) p = q;
+                            }
+                            pay[j] = p;
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    const bool act = p0 + j < nk;
+                    pend[j] = act && (pay[j] == LOC_MISS || (pay[j] & LOC_MULTI));
+                    npend += pend[j] ? 1u : 0u;
+                    const bool fnd = act && !pend[j];
+                    nres += fnd ? 1u : 0u;
+                    sm.res[half][p0 + j] = !fnd ? AUX_MISS : (pay[j] & LOC_FLANK) ? CLS_FLANK : trb + (pay[j] & LOC_SLOT);
+                }
+            } else {
+                // (rare) a non-ACGT byte somewhere in the pair: exact validity bits; a position with an invalid window is no k-mer,
+                // every other one is looked up in the index
+                uint32_t vb = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t sidx = 8 * hl + e, by = ((e < 4 ? dw0 : dw1) >> (8 * (e & 3))) & 0xFFu;
+                    const bool ok = sidx >= rsh && sidx < rsh + len && (by == 'A' || by == 'C' || by == 'G' || by == 'T');
+                    vb |= (ok ? 1u : 0u) << (7 - e);
+                }
+                reinterpret_cast<uint8_t*>(sm.vd[half])[hl ^ 1u] = (uint8_t)vb;
+                x.sync();
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    km[j] = p0 + j < nk ? window_kmer(sm.pk[half], sm.vd[half], rsh + p0 + j, k, nullptr, nullptr) : NAN64;
+                    pend[j] = km[j] != NAN64;
+                    npend += pend[j] ? 1u : 0u;
+                    sm.res[half][p0 + j] = AUX_MISS;
+                }
+            }
+            DBTK_STAMP(16);  // k-mers, image look-ups
+            {   // the row as the image answers it: its statistics, its aux words (16-byte stores)
+                const uint32_t nh = x.half_sum(nres);
+                if (hl == 0) {
+                    sm.stat[row][0] = nh; sm.stat[row][1] = nh ? locus << 1 : 0u; sm.stat[row][2] = nh ? locus << 1 : 0xFFFFFFFFu; sm.stat[row][3] = hrow;
+                    a.hitnk[hrow] = nk;
+                    a.hitoff[hrow] = o0;
+                }
+                if (hl < (uint32_t)NPL) sm.patched[row][hl] = 0u;
+                x.sync();
+                uint4* outa = reinterpret_cast<uint4*>(a.hitaux + (size_t)hrow * a.nkp);
+#pragma unroll
+                for (int c = 0; c < (32 * NPL + 127) / 128; ++c) {
+                    const uint32_t i4 = 32u * c + hl;
+                    if (4 * i4 < nk && i4 < 8u * NPL) outa[i4] = reinterpret_cast<const uint4*>(sm.res[half])[i4];
+                }
+            }
+            {   // the rest into the queue (a queue that cannot take them all is looked up first)
+                const uint32_t pex = x.wave_excl_scan(npend);
+                const uint32_t ptot = x.bcast(pex + npend, 63);
+                uint32_t done = 0;  // entries of this pair already queued (uniform)
+                while (done < ptot) {
+                    if (qn == (uint32_t)LOC_Q) flush();
+                    const uint32_t take = ptot - done < (uint32_t)LOC_Q - qn ? ptot - done : (uint32_t)LOC_Q - qn;
+                    uint32_t at = pex;
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j)
+                        if (pend[j]) {
+                            if (at >= done && at < done + take) {
+                                sm.qkm[qn + at - done] = km[j];
+                                sm.qcode[qn + at - done] = (row << 8) | (p0 + j);
+                            }
+                            ++at;
+                        }
+                    qn += take; done += take;
+                }
+            }
+            nrow += 2;
+            DBTK_STAMP(18);  // row statistics + stores, queue
+        }
+        // ---- the wave's rows of this item: what the index says about the queued k-mers, then the headers
+        if (qn) flush();
+        DBTK_STAMP(41);  // the queue against the index
+        x.sync();
+        bool genv = false;
+        uint32_t hrow = 0;
+        if ((uint32_t)lane < nrow) {
+            const uint32_t nh = sm.stat[lane][0], vmx = sm.stat[lane][1], vmn = sm.stat[lane][2];
+            hrow = sm.stat[lane][3];
+            const bool uniform = T.consistent && nh && vmx == vmn && !(vmx & 1u);
+            a.hithdr[hrow] = (uint64_t)(nh ? vmx : NOHIT) | ((uint64_t)nh << 32) | (uniform ? HDR_UNIFORM : 0ull);
+            genv = !uniform;
+        }
+        uint64_t gm = x.ballot(genv);
+        while (gm) {  // (rare) a read whose found k-mers do not share one index value: its value row
+            const uint32_t rr = (uint32_t)__builtin_ctzll(gm);
+            gm &= gm - 1;
+            const uint32_t hr = x.bcast(hrow, (int)rr), nk = a.hitnk[hr];
+            for (uint32_t pos = (uint32_t)lane; pos < ((nk + 3) & ~3u) && pos < 32u * NPL; pos += 64) {
+                const size_t at = (size_t)hr * a.nkp + pos;
+                if (!((sm.patched[rr][pos >> 5] >> (pos & 31)) & 1)) a.hitval[at] = a.hitaux[at] == AUX_MISS ? NOHIT : locus << 1;
+            }
+        }
+    }
+    DBTK_STAMP_FLUSH;
+}
+
+}  // namespace dbtk
+#endif

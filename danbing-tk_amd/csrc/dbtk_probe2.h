@@ -92,7 +92,8 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
     const uint32_t k = T.ksize, m = T.mz_m;  // k - m + 1 == WN (the launcher's condition)
     const uint32_t ns = *a.nsurv;
     const uint32_t tend = ns - a.t0 < a.tcap ? ns : a.t0 + a.tcap;
-    const uint32_t npr = ns > a.t0 ? tend - a.t0 : 0;  // pairs of this chunk of the list; pair i -> hit-buffer rows 2i, 2i + 1
+    const uint32_t npc = ns > a.t0 ? tend - a.t0 : 0;  // pairs of this chunk of the list; pair i -> hit-buffer rows 2i, 2i + 1
+    const uint32_t npr = a.sel ? *a.nsel : npc;         // ... of which this kernel takes all, or the ones listed in a.sel (dbtk_locus.h: the rest)
     // this wave's pairs: a contiguous range of the (locus-ordered) list
     const uint32_t per = (npr + x.nblocks() - 1) / x.nblocks();
     const uint64_t lo64 = (uint64_t)x.bid() * per;
@@ -105,11 +106,17 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
     // Three-deep fetch pipeline, all loads unconditional (clamped to something valid) so that they stay in flight:
     // while pair i is looked up, the bytes of pair i + 1 are on their way into registers, the offsets of pair i + 2
     // are being fetched, and the survivor entry of pair i + 3.
-    auto surv_of = [&](uint32_t i) { return a.surv[a.t0 + (i < hi ? i : 0u)]; };
+    // (place of the range's pair i in the chunk: i itself, or what the list says; its survivor entry is read an iteration after the
+    // place, so that neither load is waited for where it is issued)
+    auto place_of = [&](uint32_t i) -> uint32_t {
+        const uint32_t ic = i < hi ? i : (first < hi ? first : 0u);
+        return a.sel ? (npr ? a.sel[ic] : 0u) : ic;
+    };
     uint32_t rw0 = 0, rw1 = 0;  // pair i: dwords 2 hl and 2 hl + 1 of the mate, from its 4-byte-aligned start
     uint64_t o0C = 0, o1C = 0;  //         its offsets
     uint64_t o0B = 0, o1B = 0;  // pair i + 1: offsets (in flight)
     uint32_t pairA = 0;         // pair i + 2: survivor entry (in flight)
+    uint32_t plN = 0;           // pair i + 3: its place (in flight)
     auto fetch_bytes = [&](uint64_t o0, uint64_t o1) {
         uint32_t len = (uint32_t)(o1 - o0);
         if (len > lmax) len = lmax;
@@ -123,11 +130,12 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
         o0B = a.off[r]; o1B = a.off[r + 1];
     };
     if (first < hi) {
-        fetch_offsets(x.uni(surv_of(first)));
+        fetch_offsets(x.uni(a.surv[a.t0 + place_of(first)]));
         o0C = o0B; o1C = o1B;
         fetch_bytes(o0C, o1C);
-        if (first + 1 < hi) fetch_offsets(x.uni(surv_of(first + 1)));
-        pairA = surv_of(first + 2);
+        if (first + 1 < hi) fetch_offsets(x.uni(a.surv[a.t0 + place_of(first + 1)]));
+        pairA = a.surv[a.t0 + place_of(first + 2)];
+        plN = place_of(first + 3);
     }
     DBTK_STAMP_DECL
     for (uint32_t i = first; i < hi; ++i) {
@@ -138,12 +146,14 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
         const uint64_t a0 = o0 & ~3ull;
         const uint32_t rsh = (uint32_t)(o0 - a0);
         const uint32_t d0 = rw0, d1 = rw1;
+        const uint32_t place_v = place_of(i);  // (read again here, needed with the results: cheaper than a register through the pipeline)
         {   // advance the pipeline
             const bool hasB = i + 1 < hi, hasA = i + 2 < hi;
             o0C = hasB ? o0B : 0ull; o1C = hasB ? o1B : 0ull;
             fetch_bytes(o0C, o1C);
             fetch_offsets(hasA ? x.uni(pairA) : x.uni(pairA) * 0u);
-            pairA = surv_of(i + 3);
+            pairA = a.surv[a.t0 + plN];
+            plN = place_of(i + 4);
         }
         x.sync();  // the previous pair's LDS is dead
         uint32_t bad = 0;
@@ -344,7 +354,7 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
             }
             const uint32_t nh = x.half_sum(cnt), hmx = x.half_max(vmx), hmn = ~x.half_max(~vmn);
             const bool uniform = T.consistent && nh && hmx == hmn && !(hmx & 1u);
-            const uint32_t row = 2 * i + half;
+            const uint32_t row = 2 * x.uni(place_v) + half;
             if (hl == 0) {
                 a.hithdr[row] = (uint64_t)(nh ? hmx : NOHIT) | ((uint64_t)nh << 32) | (uniform ? HDR_UNIFORM : 0ull);
                 a.hitnk[row] = nk;

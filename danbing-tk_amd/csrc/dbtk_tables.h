@@ -104,6 +104,7 @@ constexpr uint64_t MZ_TURNED = 1ull << 63;
 constexpr uint64_t MZ_EMPTY = 0x3FFFFFFFFFFFFFFFull;  // poly-T at k = 31, never canonical (poly-A is): matches no k-mer, carries no flag
 
 struct DevTables;
+struct LocusDir;
 // ---- graph table (v1.3 threading): graphDB[locus] (GraphType = unordered_map<node, out-edge mask>,
 // src/aQueryFasta_thread.h:32, loader :550-575) and trKmers[locus] folded into ONE open-addressed table keyed by
 // (canonical k-mer, locus), so that a single probe answers everything the walk asks about a k-mer at a locus:
@@ -143,6 +144,7 @@ struct DevTables {
     const MzBucket* grmz; uint64_t grmz_mask;                 // its minimizer-grouped copy (dbtk_walkfast.h), nullptr: none
     const MzBucket* mz; uint64_t mz_mask; uint32_t mz_m;  // level 1 (mz_mask = buckets - 1 <= 2^28 - 1); nullptr: the probe kernel looks up the plain index
     const MzSlot* ovf; uint64_t ovf_mask;               // level 2 (ovf_mask = slots - 1 <= 2^32 - 1)
+    const LocusDir* ldir; const uint8_t* limg;          // per-locus images of the index (dbtk_locus.h), nullptr: none
 };
 
 DBTK_HD uint64_t hash_mix(uint64_t key) {

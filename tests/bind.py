@@ -499,6 +499,13 @@ class Emu(pkg._HostSide):
         self.L.emu_probe_stats(out.ctypes.data_as(u64p))
         return int(out[0]), int(out[1]), int(out[2])
 
+    def locus_stats(self):
+        """pairs the locus-resident probe body took in its small / large workgroups, pairs left to the lean body, since the last call"""
+        out = np.zeros(3, np.uint64)
+        self.L.emu_locus_stats.argtypes = [u64p]
+        self.L.emu_locus_stats(out.ctypes.data_as(u64p))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def aln_text(self, npairs):
         """as Context.aln_text: list of (pair, dst, text)"""
         self.L.emu_aln_text.restype = C.c_uint64

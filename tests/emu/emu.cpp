@@ -66,6 +66,7 @@ struct EmuX {
     uint32_t nblocks() const;
     int lane() const { return t & 63; }
     void sync() const;
+    void bsync() const;  // workgroup barrier (the waves of a block make different numbers of yields between two of them)
     uint64_t ballot(bool p) const;
     uint32_t wave_sum(uint32_t v) const;
     uint32_t wave_min(uint32_t v) const;
@@ -82,6 +83,7 @@ struct EmuX {
     void atomic_add(uint64_t* p, uint64_t v) const { *p += v; }
     uint32_t atomic_add(uint32_t* p, uint32_t v) const { uint32_t o = *p; *p += v; return o; }
     uint64_t atomic_cas(uint64_t* p, uint64_t e, uint64_t d) const { uint64_t o = *p; if (o == e) *p = d; return o; }
+    uint32_t atomic_cas32(uint32_t* p, uint32_t e, uint32_t d) const { uint32_t o = *p; if (o == e) *p = d; return o; }
     void atomic_max(uint64_t* p, uint64_t v) const { if (v > *p) *p = v; }
     void atomic_or(uint64_t* p, uint64_t v) const { *p |= v; }
     uint32_t atomic_or32(uint32_t* p, uint32_t v) const { uint32_t o = *p; *p |= v; return o; }
@@ -89,6 +91,8 @@ struct EmuX {
     uint32_t uni(uint32_t v) const { return v; }
     uint32_t lds_add(uint32_t* p, uint32_t v) const { uint32_t o = *p; *p += v; return o; }
     void lds_or(uint32_t* p, uint32_t v) const { *p |= v; }
+    void lds_max(uint32_t* p, uint32_t v) const { if (v > *p) *p = v; }
+    void lds_min(uint32_t* p, uint32_t v) const { if (v < *p) *p = v; }
     template <class T> T* smem() const;
 };
 
@@ -102,6 +106,8 @@ struct EmuBlock {
     std::vector<char> done;
     std::vector<uint64_t> scratch, vscratch;
     int cur = 0;
+    int bar_count = 0, ndone = 0;
+    uint64_t bar_gen = 0;
     std::function<void(EmuX&)> body;
 
     void yield() { emu_switch(&sp[cur], mainsp); }
@@ -115,6 +121,7 @@ void lane_entry() {
     EmuX x{b, t};
     b->body(x);
     b->done[t] = 1;
+    ++b->ndone;
     b->scratch[t] = 0;
     emu_switch(&b->sp[t], b->mainsp);  // never resumed
     __builtin_trap();
@@ -124,6 +131,12 @@ int EmuX::nthreads() const { return b->nt; }
 uint32_t EmuX::bid() const { return b->bid; }
 uint32_t EmuX::nblocks() const { return b->nblocks; }
 void EmuX::sync() const { b->yield(); }
+void EmuX::bsync() const {
+    const uint64_t gen = b->bar_gen;
+    if (++b->bar_count >= b->nt - b->ndone) { b->bar_count = 0; ++b->bar_gen; }
+    else while (b->bar_gen == gen) b->yield();
+    b->yield();
+}
 template <class T> T* EmuX::smem() const { return reinterpret_cast<T*>(b->smem.data()); }
 uint64_t EmuX::ballot(bool p) const {
     b->scratch[t] = p;
@@ -252,6 +265,7 @@ void run_grid(uint32_t nblocks, int nt, size_t smem_bytes, std::function<void(Em
     for (uint32_t bid = 0; bid < nblocks; ++bid) {
         b.bid = bid;
         b.smem.assign(smem_bytes / 8 + 2, 0xA5A5A5A5A5A5A5A5ull);  // LDS is NOT zeroed on the GPU either
+        b.bar_count = 0; b.ndone = 0;
         for (int t = 0; t < nt; ++t) {
             b.done[t] = 0;
             b.scratch[t] = 0;
@@ -288,6 +302,8 @@ struct EmuTables {
     std::vector<GrSlot> gr;
     std::vector<MzBucket> mz, grmz;
     std::vector<MzSlot> ovf;
+    std::vector<LocusDir> ldir;
+    std::vector<uint64_t> limg;  // (8-byte words: the images are read 16 bytes at a time)
     uint64_t stats[3] = {0, 0, 0};
     DevTables T;
 };
@@ -295,6 +311,7 @@ struct EmuTables {
 }  // namespace
 
 static uint64_t g_probe_runs[2] = {0, 0}, g_mz_turned = 0, g_walk_fast_runs = 0, g_walk_slow_pairs = 0;
+static uint64_t g_loc_pairs[3] = {0, 0, 0};  // pairs the locus-resident kernel took in its small / large workgroups, pairs left to the lean kernel
 extern "C" {
 
 void* emu_tables_create(const dbtk_rpgg_t* g) {
@@ -382,6 +399,31 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
         run_grid(3, 64, 0, [&](EmuX& x) { body_mz_insert(x, a); });
         T.mz = e->mz.data(); T.mz_mask = nb - 1; T.mz_m = a.m;
         T.ovf = e->ovf.data(); T.ovf_mask = ocap - 1;
+    }
+    // per-locus images of the index (dbtk_locus.h), as build_locus_images makes them on the device; every third locus goes without
+    // one here, so that every batch also exercises the hand-over to the global-table kernel
+    if (T.mz && T.consistent && nloci && loc_lg_min(g->ksize) <= LOC_LG_MAX && (!getenv("DBTK_LOCUS") || atoi(getenv("DBTK_LOCUS")))) {
+        std::vector<uint32_t> cnt(nloci, 0), bad(nloci, 0);
+        LocBuildArgs a;
+        memset(&a, 0, sizeof(a));
+        a.idx = e->idx.data(); a.nslots = icap; a.vv = e->vv.data(); a.trbeg = e->trbeg.data(); a.nloci = (uint32_t)nloci; a.ksize = g->ksize;
+        a.cnt = cnt.data(); a.bad = bad.data();
+        run_grid(3, 64, 0, [&](EmuX& x) { body_loc_count(x, a); });
+        e->ldir.assign(nloci, LocusDir{0, 0, 0, 0});
+        uint64_t at = 0;
+        for (uint64_t l = 0; l < nloci; ++l) {
+            const uint32_t lg = loc_lgnb_for(cnt[l], g->ksize);
+            e->ldir[l] = LocusDir{(uint32_t)(at / 16), 0u, lg, e->trbeg[l]};
+            if (!cnt[l] || lg > LOC_LG_MAX || l % 3 == 2) continue;
+            e->ldir[l].bytes = loc_image_bytes(lg);
+            at += e->ldir[l].bytes;
+        }
+        e->limg.assign(at / 8 + 2, 0);
+        a.dir = e->ldir.data(); a.arena = reinterpret_cast<uint8_t*>(e->limg.data());
+        run_grid(3, 64, 0, [&](EmuX& x) { body_loc_clear(x, a); });
+        run_grid(3, 64, 0, [&](EmuX& x) { body_loc_insert(x, a); });
+        for (uint64_t l = 0; l < nloci; ++l) if (bad[l]) e->ldir[l].bytes = 0;
+        T.ldir = e->ldir.data(); T.limg = reinterpret_cast<const uint8_t*>(e->limg.data());
     }
     if (!g->gr_cnt.empty()) {  // graph table: graph pass, then TR pass (as build_graph_table does on the device)
         const uint64_t ngr = g->gr_ks.size(), ntrf = g->tr_ks.size();
@@ -648,6 +690,7 @@ uint64_t emu_walk_results(dbtk_walk_res_t* res, uint32_t* tidx, uint64_t cap) {
 
 // which probe body the last calls of emu_align_ex dispatched: [0] general (body_probe), [1] lean (body_probe2); and the
 // keys level 1 of the last emu_tables_create turned away (= entries of its overflow table)
+void emu_locus_stats(uint64_t* out) { for (int i = 0; i < 3; ++i) { out[i] = g_loc_pairs[i]; g_loc_pairs[i] = 0; } }
 void emu_probe_stats(uint64_t* out) { out[0] = g_probe_runs[0]; out[1] = g_probe_runs[1]; out[2] = g_mz_turned; g_probe_runs[0] = g_probe_runs[1] = 0; }
 // pair-mode walks since the last call: runs of the lean first kernel, pairs it passed on to the second
 void emu_walk_stats(uint64_t* out) { out[0] = g_walk_fast_runs; out[1] = g_walk_slow_pairs; g_walk_fast_runs = g_walk_slow_pairs = 0; }
@@ -735,6 +778,35 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         const int npl = !a.T.mz || p->bubbles || (p->bait && qual) ? 0 : (maxlen <= 32 * 3 + a.T.mz_m - 1 ? 3 : maxlen <= 32 * 5 + a.T.mz_m - 1 ? 5 : 0);
         g_probe_runs[npl ? 1 : 0] += 1;
         const uint32_t grid_p2 = (grid_pair & 1) ? 8 : grid_pair + 2;  // (a multiple of 8: the lean body's per-XCD split of the list)
+        // the locus-resident kernel first, as launch_batch does (workgroups of 4 waves here; the small class takes the
+        // images of up to 512 buckets)
+        std::vector<uint4> items[2];
+        std::vector<uint32_t> rest(tcap + 64, 0);
+        uint32_t nit[3] = {0, 0, 0};
+        a.sel = nullptr; a.nsel = nullptr;
+        if (npl && a.T.ldir) {
+            constexpr int EMU_IMGB_S = LOC_HDR + (32 << 9), EMU_IMGB_L = LOC_HDR + (32 << LOC_LG_MAX);
+            const uint32_t item_cap = tcap / LOC_CH + (uint32_t)nloci + 2;
+            items[0].assign(item_cap, uint4{0, 0, 0, 0}); items[1].assign(item_cap, uint4{0, 0, 0, 0});
+            LocItemArgs ia;
+            memset(&ia, 0, sizeof(ia));
+            ia.hist = shist.data(); ia.nsurv = &small[0]; ia.flag = &small[1]; ia.dir = a.T.ldir; ia.nloci = (uint32_t)nloci; ia.t0 = t0; ia.tcap = tcap;
+            ia.cap_bytes[0] = EMU_IMGB_S; ia.cap_bytes[1] = EMU_IMGB_L;
+            ia.items[0] = items[0].data(); ia.items[1] = items[1].data(); ia.nitems = nit; ia.item_cap = item_cap; ia.rest = rest.data();
+            run_grid(2, 64, 0, [&](EmuX& x) { body_loc_items(x, ia); });
+            run_grid(2, 128, 0, [&](EmuX& x) { body_loc_rest(x, ia); });
+            LocRunArgs r0{a.T.ldir, a.T.limg, items[0].data(), &nit[0]}, r1{a.T.ldir, a.T.limg, items[1].data(), &nit[1]};
+            if (npl == 3) {
+                run_grid(3, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_S>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_S>(x, a, r0); });
+                run_grid(2, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_L>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_L>(x, a, r1); });
+            } else {
+                run_grid(3, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_S>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_S>(x, a, r0); });
+                run_grid(2, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_L>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_L>(x, a, r1); });
+            }
+            for (int c = 0; c < 2; ++c) for (uint32_t q = 0; q < nit[c]; ++q) g_loc_pairs[c] += items[c][q].z - items[c][q].y;
+            g_loc_pairs[2] += nit[2];
+            a.sel = rest.data(); a.nsel = &nit[2];
+        }
         if (npl == 3 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { body_probe2<3, 7>(x, a); });
         else if (npl == 3 && wn == 11) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { body_probe2<3, 11>(x, a); });
         else if (npl == 5 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<5>), [&](EmuX& x) { body_probe2<5, 7>(x, a); });

@@ -33,6 +33,7 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
     # the load-time check: index memberships == flank/TR sets  <=>  the class rides in the index slot
     assert E.consistent(T) == (0 if case == "inconsistent" else 1)
     E.probe_stats()
+    E.locus_stats()
     for i, kw in enumerate(c.param_sets):
         p = abi.default_params(ksize=c.k, trace=1, **kw)
         a = O.align(go, p, seq, off)
@@ -60,6 +61,13 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
     assert (lean > 0 and general == 0) if case in cases.LEAN_PROBE else (general > 0 and lean == 0), (general, lean)
     if case in ("shared", "spill"):
         assert turned > 0  # keys in the overflow table: level 2 of the lean body's look-ups is exercised
+    small, large, rest = E.locus_stats()
+    print(f"{case}: locus-resident body {small} + {large} pairs, lean body {rest}")
+    # (images are only built for an RPGG whose sets agree with its index; "spill" has too few survivors per locus for a list in locus order)
+    if case in cases.LEAN_PROBE and case not in ("inconsistent", "spill"):
+        assert small + large > 0 and rest > 0  # both the image path and the hand-over to the global tables ran
+    if case == "shared":
+        assert small > 0 and large > 0  # both classes of workgroup
     E.L.emu_tables_free(T)
     O.free(go)
     g.close()
