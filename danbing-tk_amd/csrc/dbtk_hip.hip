@@ -86,12 +86,14 @@ template <int NS, bool RECS> __global__ void __launch_bounds__(64, NS <= 3 ? 2 :
 
 // per-locus images of the index and the probe kernel that keeps one in LDS (dbtk_locus.h)
 __global__ void __launch_bounds__(256) k_loc_count(LocBuildArgs a) { DevX x{nullptr}; body_loc_count(x, a); }
-__global__ void __launch_bounds__(256) k_loc_clear(LocBuildArgs a) { DevX x{nullptr}; body_loc_clear(x, a); }
-__global__ void __launch_bounds__(256) k_loc_insert(LocBuildArgs a) { DevX x{nullptr}; body_loc_insert(x, a); }
+__global__ void __launch_bounds__(256) k_loc_scatter(LocBuildArgs a) { DevX x{nullptr}; body_loc_scatter(x, a); }
+__global__ void __launch_bounds__(64) k_loc_place(LocBuildArgs a) { DevX x{nullptr}; body_loc_place(x, a); }
 __global__ void __launch_bounds__(256) k_loc_items(LocItemArgs a) { DevX x{nullptr}; body_loc_items(x, a); }
 __global__ void __launch_bounds__(256) k_loc_rest(LocItemArgs a) { DevX x{nullptr}; body_loc_rest(x, a); }
-constexpr int LOC_IMGB_S = LOC_HDR + (32 << 10), LOC_IMGB_L = LOC_HDR + (32 << LOC_LG_MAX);  // largest image of the two workgroup classes
-constexpr int LOC_NW_S = 8, LOC_NW_L = 16;
+// three classes of workgroup by the size of the image (loc_image_bytes of 512, 1024, 2048 buckets): the smaller the image, the fewer
+// waves share it and the more workgroups a CU holds (4 x 4, 2 x 8, 1 x 16 waves)
+constexpr int LOC_IMGB_XS = LOC_HDR + (32 << 9) + (1 << 9), LOC_IMGB_S = LOC_HDR + (32 << 10) + (1 << 10), LOC_IMGB_L = LOC_HDR + (32 << LOC_LG_MAX) + (1 << LOC_LG_MAX);
+constexpr int LOC_NW_XS = 4, LOC_NW_S = 8, LOC_NW_L = 16;
 template <int NPL, int NW, int IMGB> __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_probe_locus(BatchArgs a, LocRunArgs r) {
     __shared__ LocSmemT<NPL, NW, IMGB> sm;
     DevX x{&sm};
@@ -228,8 +230,7 @@ struct dbtk_ctx {
     LocusDir* d_ldir = nullptr;   // per-locus images of the index (dbtk_locus.h): directory,
     uint8_t* d_limg = nullptr;    //   ... and the images
     uint64_t limg_bytes = 0, loc_nimg = 0, loc_left_out = 0;
-    int loc_blocks[4] = {0, 0, 0, 0};  // workgroups of k_probe_locus<3 | 5, small | large>
-    int loc_blocks_alt = 0;
+    int loc_blocks[6] = {0, 0, 0, 0, 0, 0};  // workgroups of k_probe_locus<3 | 5, class 0 | 1 | 2>
     uint32_t* d_vv = nullptr;
     uint8_t* d_qc = nullptr;
     uint16_t* d_perm = nullptr;
@@ -536,31 +537,52 @@ dbtk_status_t build_locus_images(dbtk_ctx* c) {
     HIPCHK(hipMemcpyAsync(cnt.data(), dcnt, nloci * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     std::vector<LocusDir> dir(nloci);
+    std::vector<uint64_t> ebeg(nloci + 1, 0);
     uint64_t at = 0, nimg = 0;
     for (uint64_t l = 0; l < nloci; ++l) {
         const uint32_t lg = loc_lgnb_for(cnt[l], g->ksize);
         dir[l] = LocusDir{(uint32_t)(at / 16), 0u, lg, (uint32_t)g->out_beg[l]};
-        if (!cnt[l] || lg > LOC_LG_MAX || at + loc_image_bytes(lg) > (16ull << 32)) continue;
+        ebeg[l + 1] = ebeg[l];
+        if (!cnt[l] || lg > LOC_LG_MAX || cnt[l] > 0xFFF0u || at + loc_image_bytes(lg) > (16ull << 32)) continue;
         dir[l].bytes = loc_image_bytes(lg);
         at += dir[l].bytes;
+        ebeg[l + 1] += cnt[l];
         ++nimg;
     }
     if (!nimg) { HIPCHK(hipFree(dcnt)); HIPCHK(hipFree(dbad)); return DBTK_OK; }
+    const uint64_t nent = ebeg[nloci];
+    const uint32_t gstride = 2 * (1u << LOC_LG_MAX) + 2;
+    uint64_t *debeg = nullptr, *dekey = nullptr, *dskey = nullptr, *dnleft = nullptr;
+    uint32_t *depay = nullptr, *dspay = nullptr;
+    uint16_t* dgscr = nullptr;
     HIPCHK(hipMalloc(&c->d_ldir, nloci * sizeof(LocusDir)));
     HIPCHK(hipMalloc(&c->d_limg, at + 16));
+    HIPCHK(hipMalloc(&debeg, (nloci + 1) * 8));
+    HIPCHK(hipMalloc(&dekey, (nent + 1) * 8)); HIPCHK(hipMalloc(&dskey, (nent + 1) * 8));
+    HIPCHK(hipMalloc(&depay, (nent + 1) * 4)); HIPCHK(hipMalloc(&dspay, (nent + 1) * 4));
+    HIPCHK(hipMalloc(&dgscr, nloci * (uint64_t)gstride * 2));
+    HIPCHK(hipMalloc(&dnleft, 8));
+    HIPCHK(hipMemsetAsync(dnleft, 0, 8, s));
+    HIPCHK(hipMemsetAsync(dcnt, 0, nloci * 4, s));  // (now the gather cursors)
     HIPCHK(hipMemcpyAsync(c->d_ldir, dir.data(), nloci * sizeof(LocusDir), hipMemcpyHostToDevice, s));
-    a.dir = c->d_ldir; a.arena = c->d_limg;
-    LAUNCH(k_loc_clear, dim3(4096), dim3(256), s, a);
-    LAUNCH(k_loc_insert, dim3(2048), dim3(256), s, a);
+    HIPCHK(hipMemcpyAsync(debeg, ebeg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
+    a.dir = c->d_ldir; a.arena = c->d_limg; a.ebeg = debeg; a.ecur = dcnt; a.ekey = dekey; a.epay = depay; a.skey = dskey; a.spay = dspay;
+    a.gscr = dgscr; a.gstride = gstride; a.nleft = dnleft;
+    LAUNCH(k_loc_scatter, dim3(2048), dim3(256), s, a);
+    LAUNCH(k_loc_place, dim3((uint32_t)((nloci + 63) / 64)), dim3(64), s, a);
+    uint64_t nleft = 0;
     HIPCHK(hipMemcpyAsync(bad.data(), dbad, nloci * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&nleft, dnleft, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     uint64_t nbad = 0;
     for (uint64_t l = 0; l < nloci; ++l) if (bad[l] && dir[l].bytes) { dir[l].bytes = 0; ++nbad; }
     if (nbad) HIPCHK(hipMemcpy(c->d_ldir, dir.data(), nloci * sizeof(LocusDir), hipMemcpyHostToDevice));
+    HIPCHK(hipFree(debeg)); HIPCHK(hipFree(dekey)); HIPCHK(hipFree(dskey)); HIPCHK(hipFree(depay)); HIPCHK(hipFree(dspay)); HIPCHK(hipFree(dgscr)); HIPCHK(hipFree(dnleft));
+    c->loc_left_out = nleft;
     HIPCHK(hipFree(dcnt)); HIPCHK(hipFree(dbad));
     c->limg_bytes = at; c->loc_nimg = nimg - nbad;
     c->T.ldir = c->d_ldir; c->T.limg = c->d_limg;
-    if (getenv("DBTK_VERBOSE")) fprintf(stderr, "locus images: %llu of %llu loci, %.1f MB\n", (unsigned long long)c->loc_nimg, (unsigned long long)nloci, at / 1e6);
+    if (getenv("DBTK_VERBOSE")) fprintf(stderr, "locus images: %llu of %llu loci, %.1f MB, %llu keys left out\n", (unsigned long long)c->loc_nimg, (unsigned long long)nloci, at / 1e6, (unsigned long long)c->loc_left_out);
     return DBTK_OK;
 }
 
@@ -733,7 +755,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     // pairs it leaves to the global-table kernel (dbtk_locus.h)
     const uint64_t surv_words = (3 * (npairs + 1) + nloci + 2 + SCAN_BLOCKS + 3) & ~3ull;
     const uint64_t item_cap = tcap / LOC_CH + nloci + 2;
-    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, surv_words + 2 * 4 * item_cap + tcap + 4);
+    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, surv_words + 3 * 4 * item_cap + tcap + 4);
     if (st) return st;
     if ((st = ensure(&c->d_hitoff, &c->hitoff_cap, tcap * 4))) return st;  // offsets, then headers
     if ((st = ensure(&c->d_hitva, &c->hitva_cap, tcap * 2 * nkp))) return st;
@@ -823,25 +845,25 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
                 memset(&ia, 0, sizeof(ia));
                 ia.hist = c->d_surv + 3 * (npairs + 1); ia.nsurv = c->d_small + 0; ia.flag = c->d_small + 6; ia.dir = a.T.ldir;
                 ia.nloci = (uint32_t)nloci; ia.t0 = a.t0; ia.tcap = (uint32_t)tcap;
-                static const bool no_large = [] { const char* e = getenv("DBTK_LOC_L"); return e && !atoi(e); }();  // diagnostic: small workgroups only
-                static const int nw_alt = [] { const char* e = getenv("DBTK_LOC_NW"); return e ? atoi(e) : 0; }();       // diagnostic: 4 waves per small workgroup
-                ia.cap_bytes[0] = LOC_IMGB_S; ia.cap_bytes[1] = no_large ? LOC_IMGB_S : LOC_IMGB_L;
-                ia.items[0] = reinterpret_cast<uint4*>(c->d_surv + surv_words); ia.items[1] = ia.items[0] + item_cap;
+                static const int loc_classes = [] { const char* e = getenv("DBTK_LOC_CLASSES"); return e ? atoi(e) : 7; }();  // diagnostic: bit c = class c in use
+                ia.cap_bytes[0] = (loc_classes & 1) ? LOC_IMGB_XS : 0; ia.cap_bytes[1] = (loc_classes & 2) ? LOC_IMGB_S : 0; ia.cap_bytes[2] = (loc_classes & 4) ? LOC_IMGB_L : 0;
+                for (int q = 0; q < 3; ++q) ia.items[q] = reinterpret_cast<uint4*>(c->d_surv + surv_words) + q * item_cap;
                 ia.nitems = c->d_small + 8; ia.item_cap = (uint32_t)item_cap;
-                ia.rest = c->d_surv + surv_words + 2 * 4 * item_cap;
-                HIPCHK(hipMemsetAsync(c->d_small + 8, 0, 3 * sizeof(uint32_t), s));
+                ia.rest = c->d_surv + surv_words + 3 * 4 * item_cap;
+                HIPCHK(hipMemsetAsync(c->d_small + 8, 0, 4 * sizeof(uint32_t), s));
                 LAUNCH(k_loc_items, dim3((uint32_t)((nloci + 255) / 256)), dim3(256), s, ia);
                 LAUNCH(k_loc_rest, dim3((uint32_t)std::min<uint64_t>((tcap + 255) / 256, (uint64_t)c->num_cu * 8)), dim3(256), s, ia);
-                LocRunArgs r0{a.T.ldir, a.T.limg, ia.items[0], c->d_small + 8}, r1{a.T.ldir, a.T.limg, ia.items[1], c->d_small + 9};
+                LocRunArgs r0{a.T.ldir, a.T.limg, ia.items[0], c->d_small + 8}, r1{a.T.ldir, a.T.limg, ia.items[1], c->d_small + 9}, r2{a.T.ldir, a.T.limg, ia.items[2], c->d_small + 10};
                 if (npl == 3) {
-                    LAUNCH((k_probe_locus<3, LOC_NW_S, LOC_IMGB_S>), dim3(c->loc_blocks[0]), dim3(LOC_NW_S * 64), s, a, r0);
-                    LAUNCH((k_probe_locus<3, LOC_NW_L, LOC_IMGB_L>), dim3(c->loc_blocks[1]), dim3(LOC_NW_L * 64), s, a, r1);
+                    LAUNCH((k_probe_locus<3, LOC_NW_XS, LOC_IMGB_XS>), dim3(c->loc_blocks[0]), dim3(LOC_NW_XS * 64), s, a, r0);
+                    LAUNCH((k_probe_locus<3, LOC_NW_S, LOC_IMGB_S>), dim3(c->loc_blocks[1]), dim3(LOC_NW_S * 64), s, a, r1);
+                    LAUNCH((k_probe_locus<3, LOC_NW_L, LOC_IMGB_L>), dim3(c->loc_blocks[2]), dim3(LOC_NW_L * 64), s, a, r2);
                 } else {
-                    if (nw_alt == 4) LAUNCH((k_probe_locus<5, 4, LOC_IMGB_S>), dim3(c->loc_blocks_alt), dim3(4 * 64), s, a, r0);
-                    else LAUNCH((k_probe_locus<5, LOC_NW_S, LOC_IMGB_S>), dim3(c->loc_blocks[2]), dim3(LOC_NW_S * 64), s, a, r0);
-                    LAUNCH((k_probe_locus<5, LOC_NW_L, LOC_IMGB_L>), dim3(c->loc_blocks[3]), dim3(LOC_NW_L * 64), s, a, r1);
+                    LAUNCH((k_probe_locus<5, LOC_NW_XS, LOC_IMGB_XS>), dim3(c->loc_blocks[3]), dim3(LOC_NW_XS * 64), s, a, r0);
+                    LAUNCH((k_probe_locus<5, LOC_NW_S, LOC_IMGB_S>), dim3(c->loc_blocks[4]), dim3(LOC_NW_S * 64), s, a, r1);
+                    LAUNCH((k_probe_locus<5, LOC_NW_L, LOC_IMGB_L>), dim3(c->loc_blocks[5]), dim3(LOC_NW_L * 64), s, a, r2);
                 }
-                a.sel = ia.rest; a.nsel = c->d_small + 10;
+                a.sel = ia.rest; a.nsel = c->d_small + 11;
             }
             // (a wave of the lean form works through one contiguous range of the list: as many waves as are resident at once)
             if (npl == 3 && wn == 7) LAUNCH((k_probe<3, 7>), dim3(c->num_cu * c->probe2_wpc[0]), dim3(64), s, a);
@@ -1003,19 +1025,16 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             }
             if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_probe<5, 7>: %d blocks per CU\n", c->probe2_wpc[2]);
             {   // the locus-resident kernel: as many workgroups as are resident (an item is short: the workgroups take them round robin)
-                const void* kl[4] = {(const void*)k_probe_locus<3, LOC_NW_S, LOC_IMGB_S>, (const void*)k_probe_locus<3, LOC_NW_L, LOC_IMGB_L>,
-                                     (const void*)k_probe_locus<5, LOC_NW_S, LOC_IMGB_S>, (const void*)k_probe_locus<5, LOC_NW_L, LOC_IMGB_L>};
-                for (int i = 0; i < 4; ++i) {
+                const void* kl[6] = {(const void*)k_probe_locus<3, LOC_NW_XS, LOC_IMGB_XS>, (const void*)k_probe_locus<3, LOC_NW_S, LOC_IMGB_S>, (const void*)k_probe_locus<3, LOC_NW_L, LOC_IMGB_L>,
+                                     (const void*)k_probe_locus<5, LOC_NW_XS, LOC_IMGB_XS>, (const void*)k_probe_locus<5, LOC_NW_S, LOC_IMGB_S>, (const void*)k_probe_locus<5, LOC_NW_L, LOC_IMGB_L>};
+                const int nwv[3] = {LOC_NW_XS, LOC_NW_S, LOC_NW_L};
+                for (int i = 0; i < 6; ++i) {
                     nb = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kl[i], ((i & 1) ? LOC_NW_L : LOC_NW_S) * 64, 0) != hipSuccess || nb <= 0) nb = 1;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kl[i], nwv[i % 3] * 64, 0) != hipSuccess || nb <= 0) nb = 1;
                     if (const char* ev = getenv("DBTK_LOC_BPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
                     c->loc_blocks[i] = c->num_cu * nb;
                     if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_probe_locus[%d]: %d workgroups per CU\n", i, nb);
                 }
-                nb = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_probe_locus<5, 4, LOC_IMGB_S>, 4 * 64, 0) != hipSuccess || nb <= 0) nb = 1;
-                if (const char* ev = getenv("DBTK_LOC_BPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
-                c->loc_blocks_alt = c->num_cu * nb;
             }
         }
         // resident waves of each resolve-kernel instance (one vote-spill scratch row per resident wave)

@@ -15,7 +15,7 @@
 // between loci (their index value is a `vv` list: marked in the image, fetched from the index).  The result per position is what
 // the global tables would have given, bit for bit: an image is a partition of the index, never a second opinion.
 //
-// The image (all words 32-bit; LOC_HDR bytes of header, then nb = 2^lgnb buckets of 32 bytes):
+// The image (LOC_HDR bytes of header, then nb = 2^lgnb buckets of 32 bytes, then nb displacement bytes):
 //   bucket  = tag[4], pay[4].  tag = low 32 bits of the canonical k-mer.  The bucket number is (hi ^ h(lo)) & (nb - 1) with hi the
 //             k-mer's bits from 32 up, so given the bucket and lo the low lgnb bits of hi are implied; the bits of hi above them
 //             (at most 8: 2k - 32 - lgnb <= 8 is the launcher's condition) sit in pay[31:24]: tag + bucket + those bits = the key.
@@ -23,11 +23,14 @@
 //             number `slot` (counter trbeg[l] + slot: IdxBucket::val's high word); LOC_MULTI: the key's index value is a vv list
 //             (or the RPGG's sets disagree about it): ask the index.  A free slot holds LOC_EMPTY (FLANK and TR both set, which
 //             no entry has).
-// A key whose bucket is full when it arrives is simply LEFT OUT of the image (buckets are at most half full: ~4 % of the keys): "not
-// in the image" never means "not in the index", the index answers for it like for any other k-mer the image does not hold.  So a
-// look-up is always exactly one bucket — every lane of a wave the same fixed work, no second probe that one lane in twenty would need
-// and every wave would therefore pay for.
-// Built on the GPU from the finished plain index (body_loc_count -> sizes on the host -> body_loc_clear -> body_loc_insert);
+// Hash and displace: a look-up must be exactly ONE bucket for every lane (a second probe that one lane in twenty needs is a second
+// probe every wave pays for), so no bucket may overflow — and at the loads that keep an image small (up to 0.8) a plain hash overflows
+// all the time.  The keys are therefore placed group by group: a key's GROUP is a second hash of its low word, every group has a
+// displacement byte, and the bucket of a key is (hi ^ h(lo)) + disp[group] (still a bijection between (bucket, low word) and the key).
+// The builder (one thread per locus, its keys sorted by group) gives the large groups their displacement first and tries 0 .. 255
+// until every key of the group finds a free slot.  A group for which none works is LEFT OUT of the image (never seen at these loads;
+// counted): "not in the image" never means "not in the index", the index answers for it like for any other k-mer the image does not hold.
+// Built on the GPU from the finished plain index (body_loc_count -> sizes on the host -> body_loc_scatter -> body_loc_place);
 // written to / read from the sidecar file PREF.dbtk.idx by the host (dbtk_hip.hip).
 #ifndef DBTK_LOCUS_H_
 #define DBTK_LOCUS_H_
@@ -48,14 +51,17 @@ struct LocusDir {
 };
 // smallest lgnb that leaves at most 8 bits of the key unaccounted for
 DBTK_HD uint32_t loc_lg_min(uint32_t k) { return 2 * k > 40 + LOC_LG_MIN ? 2 * k - 40 : LOC_LG_MIN; }
-// image of a locus with n keys: buckets at most half full
+// image of a locus with n keys: the smallest with a load of at most 0.8
 DBTK_HD uint32_t loc_lgnb_for(uint64_t nkeys, uint32_t k) {
     uint32_t lg = loc_lg_min(k);
-    while ((4ull << lg) < 2 * nkeys) ++lg;
+    while ((16ull << lg) < 5 * nkeys) ++lg;
     return lg;
 }
-DBTK_HD uint32_t loc_image_bytes(uint32_t lgnb) { return LOC_HDR + (32u << lgnb); }
-DBTK_HD uint32_t loc_bucket(uint32_t lo, uint32_t hi, uint32_t lgnb) { return (hi ^ ((lo * 0x9E3779B1u) >> 15)) & ((1u << lgnb) - 1); }
+DBTK_HD uint32_t loc_image_bytes(uint32_t lgnb) { return LOC_HDR + (32u << lgnb) + (1u << lgnb > 16u ? 1u << lgnb : 16u); }
+// bucket before the displacement: the low bits of hi, mixed with everything else of the key (its low word AND the bits of hi above the
+// bucket number, which the entry stores: k-mers that differ in their first bases only must not all want one bucket)
+DBTK_HD uint32_t loc_base(uint32_t lo, uint32_t hi, uint32_t lgnb) { return hi ^ (((lo ^ ((hi >> lgnb) * 0x85EBCA6Bu)) * 0x9E3779B1u) >> 15); }
+DBTK_HD uint32_t loc_group(uint32_t lo, uint32_t lgnb) { return ((lo ^ (lo >> 15)) * 0x85EBCA6Bu) >> (32 - lgnb); }  // as many groups as buckets
 
 // ------------------------------------------------------------------ build --
 struct LocBuildArgs {
@@ -67,7 +73,14 @@ struct LocBuildArgs {
     uint32_t* cnt;          // [nloci] pass 0: keys per locus
     const LocusDir* dir;    // later passes
     uint8_t* arena;
-    uint32_t* bad;          // [nloci] != 0: the image could not be built (a TR k-mer's number does not fit the slot field)
+    uint32_t* bad;          // [nloci] != 0: the image could not be built (a TR k-mer's number does not fit the slot field, ...)
+    const uint64_t* ebeg;   // [nloci + 1] first entry of each locus in the entry arrays
+    uint32_t* ecur;         // [nloci] entries gathered so far
+    uint64_t* ekey; uint32_t* epay;   // entries as gathered
+    uint64_t* skey; uint32_t* spay;   // ... and sorted by group
+    uint16_t* gscr;         // per locus gstride scratch words (2 * buckets + 2)
+    uint32_t gstride;
+    uint64_t* nleft;        // += keys left out of their image
 };
 // keys per locus
 template <class X>
@@ -82,33 +95,10 @@ DBTK_HD void body_loc_count(X& x, const LocBuildArgs& a) {
         } else if ((v >> 1) < a.nloci) x.atomic_add(&a.cnt[v >> 1], 1u);
     }
 }
-// every image empty: one block per locus at a time
+// the (key, pay) of every membership, gathered per locus: ent[ebeg[l] ..)
 template <class X>
-DBTK_HD void body_loc_clear(X& x, const LocBuildArgs& a) {
-    for (uint32_t l = x.bid(); l < a.nloci; l += x.nblocks()) {
-        const LocusDir d = a.dir[l];
-        if (!d.bytes) continue;
-        uint32_t* w = reinterpret_cast<uint32_t*>(a.arena + 16ull * d.off16);
-        const uint32_t nw = d.bytes / 4;
-        for (uint32_t i = (uint32_t)x.tid(); i < nw; i += (uint32_t)x.nthreads()) {
-            uint32_t v = 0;
-            if (i == 0) v = d.lgnb;
-            else if (i == 2) v = a.trbeg[l];
-            else if (i == 3) v = l;
-            else if (i >= LOC_HDR / 4 && ((i - LOC_HDR / 4) & 7) >= 4) v = LOC_EMPTY;
-            w[i] = v;
-        }
-    }
-}
-// one (key, locus) membership into the locus' image
-template <class X>
-DBTK_HD void loc_insert_one(X& x, const LocBuildArgs& a, uint64_t key, uint32_t l, uint32_t val, uint32_t aux) {
-    if (l >= a.nloci) return;
-    const LocusDir d = a.dir[l];
-    if (!d.bytes) return;
-    uint32_t* w = reinterpret_cast<uint32_t*>(a.arena + 16ull * d.off16);
-    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-    const uint32_t b = loc_bucket(lo, hi, d.lgnb), extra = hi >> d.lgnb;
+DBTK_HD void loc_scatter_one(X& x, const LocBuildArgs& a, uint64_t key, uint32_t l, uint32_t val, uint32_t aux) {
+    if (l >= a.nloci || !a.dir[l].bytes) return;
     uint32_t pay;
     if ((val & 1) || aux == CLS_NONE) pay = LOC_MULTI;
     else if (aux == CLS_FLANK) pay = LOC_FLANK;
@@ -117,15 +107,12 @@ DBTK_HD void loc_insert_one(X& x, const LocBuildArgs& a, uint64_t key, uint32_t 
         if (aux < a.trbeg[l] || slot > LOC_SLOT) { a.bad[l] = 1; return; }
         pay = LOC_TR | slot;
     }
-    if (extra > 0xFF) { a.bad[l] = 1; return; }
-    pay |= extra << 24;
-    uint32_t* bk = w + LOC_HDR / 4 + 8 * b;
-    for (int s = 0; s < 4; ++s)
-        if (x.atomic_cas32(&bk[4 + s], LOC_EMPTY, pay) == LOC_EMPTY) { bk[s] = lo; return; }
-    x.atomic_add(&w[1], 1u);  // the bucket is full: the key stays out of the image (the index answers for it)
+    const uint64_t at = a.ebeg[l] + x.atomic_add(&a.ecur[l], 1u);
+    if (at >= a.ebeg[l + 1]) { a.bad[l] = 1; return; }
+    a.ekey[at] = key; a.epay[at] = pay;
 }
 template <class X>
-DBTK_HD void body_loc_insert(X& x, const LocBuildArgs& a) {
+DBTK_HD void body_loc_scatter(X& x, const LocBuildArgs& a) {
     for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.nslots; i += (uint64_t)x.nblocks() * x.nthreads()) {
         uint64_t key = a.idx[i >> 2].key[i & 3];
         if (key == NAN64) continue;
@@ -134,8 +121,75 @@ DBTK_HD void body_loc_insert(X& x, const LocBuildArgs& a) {
         const uint32_t v = (uint32_t)va, aux = (uint32_t)(va >> 32);
         if (v & 1) {
             const uint32_t n = a.vv[v >> 1];
-            for (uint32_t j = 0; j < n; ++j) loc_insert_one(x, a, key, a.vv[(v >> 1) + 1 + j], v, aux);
-        } else loc_insert_one(x, a, key, v >> 1, v, aux);
+            for (uint32_t j = 0; j < n; ++j) loc_scatter_one(x, a, key, a.vv[(v >> 1) + 1 + j], v, aux);
+        } else loc_scatter_one(x, a, key, v >> 1, v, aux);
+    }
+}
+// One thread per locus: its keys sorted by group (a counting sort through the locus' scratch words), then group after group — the
+// groups of four and more keys first, then threes, twos, ones — the smallest displacement with which every key of the group finds a
+// free slot.
+template <class X>
+DBTK_HD void body_loc_place(X& x, const LocBuildArgs& a) {
+    for (uint32_t l = x.bid() * (uint32_t)x.nthreads() + (uint32_t)x.tid(); l < a.nloci; l += x.nblocks() * (uint32_t)x.nthreads()) {
+        const LocusDir d = a.dir[l];
+        if (!d.bytes) continue;
+        uint32_t* w = reinterpret_cast<uint32_t*>(a.arena + 16ull * d.off16);
+        const uint32_t nb = 1u << d.lgnb, mask = nb - 1;
+        uint32_t* bks = w + LOC_HDR / 4;
+        uint8_t* disp = reinterpret_cast<uint8_t*>(bks + 8 * nb);
+        w[0] = d.lgnb; w[1] = 0; w[2] = d.trbeg; w[3] = l;
+        for (uint32_t i = 0; i < 8 * nb; ++i) bks[i] = (i & 7) >= 4 ? LOC_EMPTY : 0u;
+        for (uint32_t i = 0; i < (nb > 16 ? nb : 16u); ++i) disp[i] = 0;
+        const uint64_t e0 = a.ebeg[l];
+        const uint32_t n = a.ecur[l] < (uint32_t)(a.ebeg[l + 1] - e0) ? a.ecur[l] : (uint32_t)(a.ebeg[l + 1] - e0);
+        uint16_t* gcnt = a.gscr + (size_t)l * a.gstride;   // keys per group, then (after the prefix sums) the groups' first places
+        uint16_t* gpos = gcnt + nb + 1;                    // next free place of each group during the scatter
+        if (n > 0xFFF0u) { a.bad[l] = 1; continue; }
+        for (uint32_t g = 0; g <= nb; ++g) gcnt[g] = 0;
+        for (uint32_t i = 0; i < n; ++i) ++gcnt[loc_group((uint32_t)a.ekey[e0 + i], d.lgnb)];
+        uint32_t run = 0;
+        for (uint32_t g = 0; g < nb; ++g) { const uint32_t c = gcnt[g]; gcnt[g] = (uint16_t)run; gpos[g] = (uint16_t)run; run += c; }
+        gcnt[nb] = (uint16_t)run;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t key = a.ekey[e0 + i];
+            const uint32_t at = gpos[loc_group((uint32_t)key, d.lgnb)]++;
+            a.skey[e0 + at] = key; a.spay[e0 + at] = a.epay[e0 + i];
+        }
+        uint32_t left = 0;
+        for (int cls = 4; cls >= 1; --cls)
+            for (uint32_t g = 0; g < nb; ++g) {
+                const uint32_t f = gcnt[g], sz = gcnt[g + 1] - f;
+                if (!sz || (cls == 4 ? sz < 4 : sz != (uint32_t)cls)) continue;
+                uint32_t dd = 0;
+                for (; dd < 256; ++dd) {  // every key of the group a free slot? (keys of the group that share a bucket need as many)
+                    bool ok = true;
+                    for (uint32_t t = 0; t < sz && ok; ++t) {
+                        const uint64_t key = a.skey[e0 + f + t];
+                        const uint32_t b = (loc_base((uint32_t)key, (uint32_t)(key >> 32), d.lgnb) + dd) & mask;
+                        uint32_t need = 1;
+                        for (uint32_t u = 0; u < t; ++u) {
+                            const uint64_t k2 = a.skey[e0 + f + u];
+                            if (((loc_base((uint32_t)k2, (uint32_t)(k2 >> 32), d.lgnb) + dd) & mask) == b) ++need;
+                        }
+                        uint32_t fr = 0;
+                        for (int s2 = 0; s2 < 4; ++s2) fr += bks[8 * b + 4 + s2] == LOC_EMPTY ? 1u : 0u;
+                        ok = fr >= need;
+                    }
+                    if (ok) break;
+                }
+                if (dd == 256) { left += sz; continue; }  // (the group stays out of the image: the index answers for its keys)
+                disp[g] = (uint8_t)dd;
+                for (uint32_t t = 0; t < sz; ++t) {
+                    const uint64_t key = a.skey[e0 + f + t];
+                    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+                    const uint32_t b = (loc_base(lo, hi, d.lgnb) + dd) & mask, extra = hi >> d.lgnb;
+                    if (extra > 0xFF) { a.bad[l] = 1; break; }
+                    for (int s2 = 0; s2 < 4; ++s2)
+                        if (bks[8 * b + 4 + s2] == LOC_EMPTY) { bks[8 * b + s2] = lo; bks[8 * b + 4 + s2] = a.spay[e0 + f + t] | (extra << 24); break; }
+                }
+            }
+        w[1] = left;
+        if (left) x.atomic_add(a.nleft, (uint64_t)left);
     }
 }
 
@@ -144,7 +198,8 @@ DBTK_HD void body_loc_insert(X& x, const LocBuildArgs& a) {
 // bucket.  (The kernel's unrolled fast path below does the same with its loads issued together.)
 DBTK_HD uint32_t loc_find(const uint32_t* img, uint64_t km) {
     const uint32_t lgnb = img[0], lo = (uint32_t)km, hi = (uint32_t)(km >> 32);
-    const uint32_t* bk = img + LOC_HDR / 4 + 8 * loc_bucket(lo, hi, lgnb);
+    const uint8_t* disp = reinterpret_cast<const uint8_t*>(img + LOC_HDR / 4 + (8u << lgnb));
+    const uint32_t* bk = img + LOC_HDR / 4 + 8 * ((loc_base(lo, hi, lgnb) + disp[loc_group(lo, lgnb)]) & ((1u << lgnb) - 1));
     const uint32_t extra = hi >> lgnb;
     for (int s = 0; s < 4; ++s) {
         const uint32_t p = bk[4 + s];
@@ -156,23 +211,23 @@ DBTK_HD uint32_t loc_find(const uint32_t* img, uint64_t km) {
 // ------------------------------------------------------------------ items --
 // After the survivor sort hist[l] is where the segment of key l ends in the sorted list (body_surv_scatter advanced every key's
 // first place past its last pair): the segment of l is [hist[l - 1], hist[l]).  One thread per key: the part of its segment inside
-// the chunk [t0, tend) of the list, cut into items of LOC_CH pairs, for the class of workgroup its image fits (0: small, 1: large).
+// the chunk [t0, tend) of the list, cut into items of LOC_CH pairs, for the class of workgroup its image fits (the smaller the image, the more workgroups a CU holds).
 struct LocItemArgs {
     const uint32_t* hist;     // [nloci + 1] segment ends (key nloci: no locus)
     const uint32_t* nsurv;
     const uint32_t* flag;     // the list is in locus order
     const LocusDir* dir;
     uint32_t nloci, t0, tcap;
-    uint32_t cap_bytes[2];    // largest image of each class
-    uint4* items[2];          // {locus, first, end, 0}
-    uint32_t* nitems;         // [2], then [2] = entries of `rest`
+    uint32_t cap_bytes[3];    // largest image of each class (0: the class is not in use)
+    uint4* items[3];          // {locus, first, end, 0}
+    uint32_t* nitems;         // [3], then [3] = entries of `rest`
     uint32_t item_cap;
     uint32_t* rest;           // chunk-relative indices of the pairs no item covers
 };
 DBTK_HD int loc_class(const LocItemArgs& a, uint32_t l) {
     if (l >= a.nloci) return -1;
     const uint32_t b = a.dir[l].bytes;
-    return !b ? -1 : b <= a.cap_bytes[0] ? 0 : b <= a.cap_bytes[1] ? 1 : -1;
+    return !b ? -1 : b <= a.cap_bytes[0] ? 0 : b <= a.cap_bytes[1] ? 1 : b <= a.cap_bytes[2] ? 2 : -1;
 }
 template <class X>
 DBTK_HD void body_loc_items(X& x, const LocItemArgs& a) {
@@ -217,7 +272,7 @@ DBTK_HD void body_loc_rest(X& x, const LocItemArgs& a) {
         const uint64_t m = x.ballot(mine);
         if (!m) continue;
         uint32_t base = 0;
-        if (x.lane() == 0) base = x.atomic_add(&a.nitems[2], (uint32_t)__builtin_popcountll(m));
+        if (x.lane() == 0) base = x.atomic_add(&a.nitems[3], (uint32_t)__builtin_popcountll(m));
         base = x.bcast(base, 0);
         if (mine) a.rest[base + (uint32_t)__builtin_popcountll(m & ((1ull << x.lane()) - 1))] = i;
     }
@@ -235,7 +290,7 @@ DBTK_HD void body_loc_rest(X& x, const LocItemArgs& a) {
 //   3  the per-read headers (found positions, the one index value or not); the rare read whose found k-mers do not all have one
 //      index value gets its value row (every position the image answered: 2 * locus; the patched ones already hold theirs).
 #ifndef DBTK_LOC_Q
-#define DBTK_LOC_Q 256
+#define DBTK_LOC_Q 128
 #endif
 constexpr int LOC_Q = DBTK_LOC_Q;              // queue entries per wave (the test emulator builds with a short queue: look-ups in the middle of a pair)
 constexpr int LOC_ROWS = 2 * (int)LOC_CH / 4;  // rows (mates) of one wave's pairs of an item, for workgroups of at least 4 waves
@@ -265,8 +320,7 @@ template <int NPL, int NW, int IMGB, class X>
 DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
     typedef LocSmemT<NPL, NW, IMGB> SM;
     static_assert(NW >= 4 && 2 * ((int)LOC_CH / NW) <= LOC_ROWS, "rows of a wave's pairs of one item");
-    static_assert((IMGB - (int)LOC_HDR) % (16 * NW * 64) == 0, "the largest image is a whole number of 16-byte loads per thread");
-    constexpr int IPT = (IMGB - (int)LOC_HDR) / (16 * NW * 64);  // 16-byte pieces of an image per thread
+    constexpr int IPT = ((IMGB - (int)LOC_HDR) / 16 + NW * 64 - 1) / (NW * 64);  // 16-byte pieces of an image per thread
     SM& smb = *x.template smem<SM>();
     const int lane = x.lane();
     const uint32_t wave = (uint32_t)x.tid() >> 6;
@@ -398,6 +452,7 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
         const uint4 d = d1;
         const LocusDir ld = ld1;
         const uint32_t locus = x.uni(d.x), lgnb = x.uni(ld.lgnb), trb = x.uni(ld.trbeg);
+        const uint8_t* dsp = reinterpret_cast<const uint8_t*>(bks + (8u << lgnb));
         x.bsync();  // every wave is done with the image of the item before
         {
             const p2_v4u* src = reinterpret_cast<const p2_v4u*>(r.arena + 16ull * ld.off16 + LOC_HDR);
@@ -458,8 +513,10 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                 for (int j = 0; j < NPL; ++j) {
                     const uint64_t fw = (W >> (2 * (32 - k - j))) & kmask, rc = (RW >> (2 * j)) & kmask;
                     km[j] = fw < rc ? fw : rc;
-                    bo[j] = 8 * loc_bucket((uint32_t)km[j], (uint32_t)(km[j] >> 32), lgnb);
+                    bo[j] = dsp[loc_group((uint32_t)km[j], lgnb)];  // (the groups' displacement bytes: reads issued together)
                 }
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) bo[j] = 8 * ((loc_base((uint32_t)km[j], (uint32_t)(km[j] >> 32), lgnb) + bo[j]) & ((1u << lgnb) - 1));
 #pragma unroll
                 for (int j = 0; j < NPL; ++j) tg[j] = *reinterpret_cast<const uint4*>(bks + bo[j]);  // (the tags of the lane's positions: reads issued together)
                 // the slot whose tag matches (the last of them, should two match), then ITS pay word: one more 4-byte read instead of the

@@ -500,11 +500,12 @@ class Emu(pkg._HostSide):
         return int(out[0]), int(out[1]), int(out[2])
 
     def locus_stats(self):
-        """pairs the locus-resident probe body took in its small / large workgroups, pairs left to the lean body, since the last call"""
-        out = np.zeros(3, np.uint64)
+        """(pairs the locus-resident probe body took in each of its three classes of workgroup, pairs left to the lean body) since
+        the last call; keys the last tables' images left out"""
+        out = np.zeros(5, np.uint64)
         self.L.emu_locus_stats.argtypes = [u64p]
         self.L.emu_locus_stats(out.ctypes.data_as(u64p))
-        return int(out[0]), int(out[1]), int(out[2])
+        return [int(out[0]), int(out[1]), int(out[2])], int(out[3]), int(out[4])
 
     def aln_text(self, npairs):
         """as Context.aln_text: list of (pair, dst, text)"""

@@ -311,7 +311,8 @@ struct EmuTables {
 }  // namespace
 
 static uint64_t g_probe_runs[2] = {0, 0}, g_mz_turned = 0, g_walk_fast_runs = 0, g_walk_slow_pairs = 0;
-static uint64_t g_loc_pairs[3] = {0, 0, 0};  // pairs the locus-resident kernel took in its small / large workgroups, pairs left to the lean kernel
+static uint64_t g_loc_left = 0;  // keys the last tables' images left out
+static uint64_t g_loc_pairs[4] = {0, 0, 0, 0};  // pairs the locus-resident kernel took in its three classes of workgroup, pairs left to the lean kernel
 extern "C" {
 
 void* emu_tables_create(const dbtk_rpgg_t* g) {
@@ -410,18 +411,30 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
         a.cnt = cnt.data(); a.bad = bad.data();
         run_grid(3, 64, 0, [&](EmuX& x) { body_loc_count(x, a); });
         e->ldir.assign(nloci, LocusDir{0, 0, 0, 0});
+        std::vector<uint64_t> ebeg(nloci + 1, 0);
         uint64_t at = 0;
         for (uint64_t l = 0; l < nloci; ++l) {
             const uint32_t lg = loc_lgnb_for(cnt[l], g->ksize);
             e->ldir[l] = LocusDir{(uint32_t)(at / 16), 0u, lg, e->trbeg[l]};
-            if (!cnt[l] || lg > LOC_LG_MAX || l % 3 == 2) continue;
+            ebeg[l + 1] = ebeg[l];
+            if (!cnt[l] || lg > LOC_LG_MAX || cnt[l] > 0xFFF0u || l % 3 == 2) continue;
             e->ldir[l].bytes = loc_image_bytes(lg);
             at += e->ldir[l].bytes;
+            ebeg[l + 1] += cnt[l];
         }
         e->limg.assign(at / 8 + 2, 0);
+        const uint64_t nent = ebeg[nloci];
+        const uint32_t gstride = 2 * (1u << LOC_LG_MAX) + 2;
+        std::vector<uint64_t> ekey(nent + 1), skey(nent + 1);
+        std::vector<uint32_t> epay(nent + 1), spay(nent + 1), ecur(nloci, 0);
+        std::vector<uint16_t> gscr(nloci * (size_t)gstride, 0);
+        uint64_t nleft = 0;
         a.dir = e->ldir.data(); a.arena = reinterpret_cast<uint8_t*>(e->limg.data());
-        run_grid(3, 64, 0, [&](EmuX& x) { body_loc_clear(x, a); });
-        run_grid(3, 64, 0, [&](EmuX& x) { body_loc_insert(x, a); });
+        a.ebeg = ebeg.data(); a.ecur = ecur.data(); a.ekey = ekey.data(); a.epay = epay.data(); a.skey = skey.data(); a.spay = spay.data();
+        a.gscr = gscr.data(); a.gstride = gstride; a.nleft = &nleft;
+        run_grid(3, 64, 0, [&](EmuX& x) { body_loc_scatter(x, a); });
+        run_grid(2, 64, 0, [&](EmuX& x) { body_loc_place(x, a); });
+        g_loc_left = nleft;
         for (uint64_t l = 0; l < nloci; ++l) if (bad[l]) e->ldir[l].bytes = 0;
         T.ldir = e->ldir.data(); T.limg = reinterpret_cast<const uint8_t*>(e->limg.data());
     }
@@ -690,7 +703,7 @@ uint64_t emu_walk_results(dbtk_walk_res_t* res, uint32_t* tidx, uint64_t cap) {
 
 // which probe body the last calls of emu_align_ex dispatched: [0] general (body_probe), [1] lean (body_probe2); and the
 // keys level 1 of the last emu_tables_create turned away (= entries of its overflow table)
-void emu_locus_stats(uint64_t* out) { for (int i = 0; i < 3; ++i) { out[i] = g_loc_pairs[i]; g_loc_pairs[i] = 0; } }
+void emu_locus_stats(uint64_t* out) { for (int i = 0; i < 4; ++i) { out[i] = g_loc_pairs[i]; g_loc_pairs[i] = 0; } out[4] = g_loc_left; }
 void emu_probe_stats(uint64_t* out) { out[0] = g_probe_runs[0]; out[1] = g_probe_runs[1]; out[2] = g_mz_turned; g_probe_runs[0] = g_probe_runs[1] = 0; }
 // pair-mode walks since the last call: runs of the lean first kernel, pairs it passed on to the second
 void emu_walk_stats(uint64_t* out) { out[0] = g_walk_fast_runs; out[1] = g_walk_slow_pairs; g_walk_fast_runs = g_walk_slow_pairs = 0; }
@@ -780,32 +793,36 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         const uint32_t grid_p2 = (grid_pair & 1) ? 8 : grid_pair + 2;  // (a multiple of 8: the lean body's per-XCD split of the list)
         // the locus-resident kernel first, as launch_batch does (workgroups of 4 waves here; the small class takes the
         // images of up to 512 buckets)
-        std::vector<uint4> items[2];
+        std::vector<uint4> items[3];
         std::vector<uint32_t> rest(tcap + 64, 0);
-        uint32_t nit[3] = {0, 0, 0};
+        uint32_t nit[4] = {0, 0, 0, 0};
         a.sel = nullptr; a.nsel = nullptr;
         if (npl && a.T.ldir) {
-            constexpr int EMU_IMGB_S = LOC_HDR + (32 << 9), EMU_IMGB_L = LOC_HDR + (32 << LOC_LG_MAX);
+            // (three classes of workgroup by image size as on the device: up to 512, 1024, 2048 buckets; 4 waves each here)
+            constexpr int EMU_IMGB_XS = LOC_HDR + (32 << 9) + (1 << 9), EMU_IMGB_S = LOC_HDR + (32 << 10) + (1 << 10), EMU_IMGB_L = LOC_HDR + (32 << LOC_LG_MAX) + (1 << LOC_LG_MAX);
             const uint32_t item_cap = tcap / LOC_CH + (uint32_t)nloci + 2;
-            items[0].assign(item_cap, uint4{0, 0, 0, 0}); items[1].assign(item_cap, uint4{0, 0, 0, 0});
+            for (int q = 0; q < 3; ++q) items[q].assign(item_cap, uint4{0, 0, 0, 0});
             LocItemArgs ia;
             memset(&ia, 0, sizeof(ia));
             ia.hist = shist.data(); ia.nsurv = &small[0]; ia.flag = &small[1]; ia.dir = a.T.ldir; ia.nloci = (uint32_t)nloci; ia.t0 = t0; ia.tcap = tcap;
-            ia.cap_bytes[0] = EMU_IMGB_S; ia.cap_bytes[1] = EMU_IMGB_L;
-            ia.items[0] = items[0].data(); ia.items[1] = items[1].data(); ia.nitems = nit; ia.item_cap = item_cap; ia.rest = rest.data();
+            ia.cap_bytes[0] = EMU_IMGB_XS; ia.cap_bytes[1] = EMU_IMGB_S; ia.cap_bytes[2] = EMU_IMGB_L;
+            for (int q = 0; q < 3; ++q) ia.items[q] = items[q].data();
+            ia.nitems = nit; ia.item_cap = item_cap; ia.rest = rest.data();
             run_grid(2, 64, 0, [&](EmuX& x) { body_loc_items(x, ia); });
             run_grid(2, 128, 0, [&](EmuX& x) { body_loc_rest(x, ia); });
-            LocRunArgs r0{a.T.ldir, a.T.limg, items[0].data(), &nit[0]}, r1{a.T.ldir, a.T.limg, items[1].data(), &nit[1]};
+            LocRunArgs r0{a.T.ldir, a.T.limg, items[0].data(), &nit[0]}, r1{a.T.ldir, a.T.limg, items[1].data(), &nit[1]}, r2{a.T.ldir, a.T.limg, items[2].data(), &nit[2]};
             if (npl == 3) {
-                run_grid(3, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_S>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_S>(x, a, r0); });
-                run_grid(2, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_L>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_L>(x, a, r1); });
+                run_grid(2, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_XS>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_XS>(x, a, r0); });
+                run_grid(3, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_S>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_S>(x, a, r1); });
+                run_grid(2, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_L>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_L>(x, a, r2); });
             } else {
-                run_grid(3, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_S>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_S>(x, a, r0); });
-                run_grid(2, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_L>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_L>(x, a, r1); });
+                run_grid(2, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_XS>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_XS>(x, a, r0); });
+                run_grid(3, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_S>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_S>(x, a, r1); });
+                run_grid(2, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_L>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_L>(x, a, r2); });
             }
-            for (int c = 0; c < 2; ++c) for (uint32_t q = 0; q < nit[c]; ++q) g_loc_pairs[c] += items[c][q].z - items[c][q].y;
-            g_loc_pairs[2] += nit[2];
-            a.sel = rest.data(); a.nsel = &nit[2];
+            for (int c = 0; c < 3; ++c) for (uint32_t q = 0; q < nit[c]; ++q) g_loc_pairs[c] += items[c][q].z - items[c][q].y;
+            g_loc_pairs[3] += nit[3];
+            a.sel = rest.data(); a.nsel = &nit[3];
         }
         if (npl == 3 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { body_probe2<3, 7>(x, a); });
         else if (npl == 3 && wn == 11) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { body_probe2<3, 11>(x, a); });
