@@ -75,6 +75,10 @@ class Rpgg:
         self._lib._chk(self._lib.L.dbtk_rpgg_output_order(self.h, _ptr(out, u64p)))
         return out
 
+    def set_index_cache(self, path, mode=1):
+        """The sidecar of the GPU-layout index images: 0 none, 1 load when present, 2 load or write (dbtk_rpgg_set_index_cache)."""
+        self._lib._chk(self._lib.L.dbtk_rpgg_set_index_cache(self.h, path.encode() if path else None, mode))
+
     def view(self):
         v = abi.RpggArrays()
         self._lib._chk(self._lib.L.dbtk_rpgg_view(self.h, C.byref(v)))
@@ -252,6 +256,13 @@ class Context:
         n = self._lib.L.dbtk_ctx_kernel_times(self.h, names, ms, cnt, 8)
         return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
 
+    def table_bytes(self):
+        """{table: HBM bytes} of the context's RPGG tables ("index_images:from_cache": 1 when the images came from the sidecar)."""
+        names = (C.c_char_p * 24)()
+        b = (C.c_uint64 * 24)()
+        n = self._lib.L.dbtk_ctx_table_bytes(self.h, names, b, 24)
+        return {names[i].decode(): int(b[i]) for i in range(n)}
+
     def timers_reset(self):
         self._lib.L.dbtk_ctx_timers_reset(self.h)
 
@@ -389,7 +400,7 @@ EXPORTS = [
     "dbtk_rpgg_load", "dbtk_rpgg_load_tr", "dbtk_rpgg_uid", "dbtk_rpgg_from_arrays", "dbtk_rpgg_free", "dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys",
     "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
-    "dbtk_allreduce", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_aln_text", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
+    "dbtk_allreduce", "dbtk_rpgg_set_index_cache", "dbtk_ctx_table_bytes", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_aln_text", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
     "dbtk_thread_batch", "dbtk_ctx_walk_results", "dbtk_ctx_aln_records", "dbtk_aln_format",
     "dbtk_ingest_create", "dbtk_ingest_free", "dbtk_ingest_chunk_buffer", "dbtk_ingest_block", "dbtk_ingest_submit", "dbtk_ingest_wait",
     "dbtk_ingest_align", "dbtk_ingest_spans", "dbtk_ingest_aln_lines",

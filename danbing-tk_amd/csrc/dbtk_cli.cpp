@@ -59,6 +59,7 @@ struct Opts {
     int simmode = 0, extractFastX = 0, verbosity = 0, ngpus = 1, gzLevel = 1, emitThreads = 0, ingestShards = 0, alnAligners = 0;
     bool correction = true;
     bool hostIngest = false; // --host-ingest: parse and pair on the host even where the device reader applies
+    bool writeIdxCache = false;  // --write-idx-cache: leave PREF.dbtk.idx (the GPU-layout index images) next to the RPGG for the next run
     bool parseOnly = false;  // --parse-only: run the ingest (reader, splitters, pairing) and report what it handed on; no GPU
     bool v13 = false;       // --v13-threading: -g/-gc/-gcc run the graph walk of the v1.3 contract instead of HEAD's dead path
     std::string alnGz;      // --aln-gz FILE: the -a / -ae records gzip-compressed into FILE (instead of plain on stdout)
@@ -333,6 +334,7 @@ int main(int argc, char* argv[]) {
         else if (a == "--v13-threading") o.v13 = true;
         else if (a == "--parse-only") o.parseOnly = true;
         else if (a == "--host-ingest") o.hostIngest = true;
+        else if (a == "--write-idx-cache") o.writeIdxCache = true;
         else if (a == "--aln-gz") o.alnGz = need(++argi);
         else if (a == "--emit-threads") o.emitThreads = atoi(need(++argi).c_str());
         else if (a == "--ingest-shards") o.ingestShards = atoi(need(++argi).c_str());
@@ -375,6 +377,11 @@ int main(int argc, char* argv[]) {
                        (o.extractFastX ? DBTK_LOAD_INDEX_ONLY : 0) | (walk ? DBTK_LOAD_GRAPH : 0), &rpgg))
         die_assert(dbtk_last_error());
     const uint64_t nloci = dbtk_rpgg_nloci(rpgg);
+    if (o.writeIdxCache) {  // (the file name follows dbtk_rpgg_load's: PREF[.name of the -t file].dbtk.idx)
+        std::string cp = o.trPrefix;
+        if (o.trim) { const size_t sl = o.trFname.find_last_of('/'); cp += "." + (sl == std::string::npos ? o.trFname : o.trFname.substr(sl + 1)); }
+        if (dbtk_rpgg_set_index_cache(rpgg, (cp + ".dbtk.idx").c_str(), 2)) die_assert(dbtk_last_error());
+    }
     fprintf(stderr, "total number of loci in %s: %llu\n", o.trFname.c_str(), (unsigned long long)nloci);
     fprintf(stderr, "deserialized graph/index and read tr.kmers in %ld sec.\n# unique kmers in kmerDBi: %llu\n", (long)(time(nullptr) - time1),
             (unsigned long long)dbtk_rpgg_nkeys(rpgg));
@@ -399,6 +406,19 @@ int main(int argc, char* argv[]) {
         for (int d = 0; d < o.ngpus; ++d)
             if (dbtk_ctx_create(rpgg, &P, d, &ctx[d])) die_assert(dbtk_last_error());
     fprintf(stderr, "load: RPGG files %.2f s, tables in HBM %.2f s\n", tl1 - tl0, wall() - tl1);
+    if (!o.parseOnly && ctx[0]) {  // what the RPGG occupies on a GPU, table by table
+        const char* nm[16]; uint64_t tb[16];
+        const int nt = dbtk_ctx_table_bytes(ctx[0], nm, tb, 16);
+        std::string line = "tables:";
+        char buf[96];
+        for (int i = 0; i < nt; ++i) {
+            if (!strcmp(nm[i], "index_images:from_cache")) { if (tb[i]) line += " (images from the sidecar)"; continue; }
+            if (!tb[i]) continue;
+            snprintf(buf, sizeof buf, " %s %.1f MB", nm[i], tb[i] / 1e6);
+            line += buf;
+        }
+        fprintf(stderr, "%s\n", line.c_str());
+    }
     // --parse-only: what the pairing stage handed to the aligner stage: pairs, bases, and an order-independent digest
     // of (title, seq1, seq2[, qual1, qual2]) per pair (FNV-1a per pair, summed), for the ingest tests (no GPU needed)
     std::atomic<uint64_t> po_pairs{0}, po_bases{0}, po_digest{0};

@@ -88,6 +88,7 @@ template <int NS, bool RECS> __global__ void __launch_bounds__(64, NS <= 3 ? 2 :
 __global__ void __launch_bounds__(256) k_loc_count(LocBuildArgs a) { DevX x{nullptr}; body_loc_count(x, a); }
 __global__ void __launch_bounds__(256) k_loc_scatter(LocBuildArgs a) { DevX x{nullptr}; body_loc_scatter(x, a); }
 __global__ void __launch_bounds__(64) k_loc_place(LocBuildArgs a) { DevX x{nullptr}; body_loc_place(x, a); }
+__global__ void __launch_bounds__(256) k_loc_verify(LocBuildArgs a) { DevX x{nullptr}; body_loc_verify(x, a); }
 __global__ void __launch_bounds__(256) k_loc_items(LocItemArgs a) { DevX x{nullptr}; body_loc_items(x, a); }
 __global__ void __launch_bounds__(256) k_loc_rest(LocItemArgs a) { DevX x{nullptr}; body_loc_rest(x, a); }
 // three classes of workgroup by the size of the image (loc_image_bytes of 512, 1024, 2048 buckets): the smaller the image, the fewer
@@ -206,6 +207,7 @@ struct TableShare {
     MzBucket* d_mz = nullptr; MzSlot* d_ovf = nullptr; GrSlot* d_gr = nullptr; MzBucket* d_grmz = nullptr; uint32_t* d_vv = nullptr; uint8_t* d_qc = nullptr; uint16_t* d_perm = nullptr;
     ClsSlot* d_tre = nullptr; ClsSlot* d_bait = nullptr;
     LocusDir* d_ldir = nullptr; uint8_t* d_limg = nullptr;
+    uint64_t bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // HBM bytes per table (dbtk_ctx_table_bytes)
     DevTables T;
     uint32_t consistent = 0;
 };
@@ -230,7 +232,10 @@ struct dbtk_ctx {
     LocusDir* d_ldir = nullptr;   // per-locus images of the index (dbtk_locus.h): directory,
     uint8_t* d_limg = nullptr;    //   ... and the images
     uint64_t limg_bytes = 0, loc_nimg = 0, loc_left_out = 0;
+    bool loc_from_cache = false;
+    uint64_t tb_idx = 0, tb_flt = 0, tb_cls = 0, tb_mz = 0, tb_ovf = 0, tb_gr = 0, tb_grmz = 0;  // bytes of the tables this context built
     int loc_blocks[6] = {0, 0, 0, 0, 0, 0};  // workgroups of k_probe_locus<3 | 5, class 0 | 1 | 2>
+    uint32_t* h_sortflag = nullptr;  // pinned: was the survivor list of the batch before in locus order? (a hint: see launch_batch)
     uint32_t* d_vv = nullptr;
     uint8_t* d_qc = nullptr;
     uint16_t* d_perm = nullptr;
@@ -345,6 +350,7 @@ void free_ctx(dbtk_ctx* c) {
                     c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_walk, c->d_trecs, c->d_loci, c->d_aln, c->d_txt, c->d_txtidx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->h_aln) (void)hipHostFree(c->h_aln);
+    if (c->h_sortflag) (void)hipHostFree(c->h_sortflag);
     std::vector<dbtk_ctx::Lane*> others{&c->alt};
     for (auto& l : c->parked) others.push_back(&l);
     for (dbtk_ctx::Lane* l : others) {
@@ -364,12 +370,14 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     hipStream_t s = c->stream;
     // ---- index
     const uint64_t nkeys = g->keys.size();
-    // slots = 4 per bucket; DBTK_IDX_SPARSITY (default 4) = minimum slots per key before rounding up to a power of two:
-    // at 4..8 slots per key a lookup leaves its home bucket about once in a thousand (HBM is plentiful: 16 B per slot)
-    uint64_t sparsity = 4;
+    // slots = 4 per bucket; DBTK_IDX_SPARSITY (default 2) = minimum slots per key before rounding up to a power of two:
+    // at 2..4 slots per key (8.6 GB at release scale; round 3 kept 4..8: 17 GB) one bucket in fifty is full, and the look-ups that
+    // then go on to the next one cost the probe kernels 2 % (tools/footprint_sweep.sh)
+    uint64_t sparsity = 2;
     if (const char* e = getenv("DBTK_IDX_SPARSITY")) { const long v = atol(e); if (v >= 2 && v <= 64) sparsity = (uint64_t)v; }
     const uint64_t icap = pow2_at_least(sparsity * nkeys + 8), nbkt = icap / 4;
     HIPCHK(hipMalloc(&c->d_idx, nbkt * sizeof(IdxBucket)));
+    c->tb_idx = nbkt * sizeof(IdxBucket);
     LAUNCH(k_fill_idx, dim3(2048), dim3(256), s, c->d_idx, icap);
     if (nkeys) {
         uint64_t* dk = nullptr; uint32_t* dv = nullptr;
@@ -385,6 +393,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
             if (bpk) {
                 c->flt_words = pow2_at_least((bpk * nkeys + 63) / 64);
                 HIPCHK(hipMalloc(&c->d_flt, c->flt_words * 8));
+                c->tb_flt = c->flt_words * 8;
                 HIPCHK(hipMemsetAsync(c->d_flt, 0, c->flt_words * 8, s));
                 FltBuildArgs fa{c->d_flt, log2u(c->flt_words), g->ksize, dk, nkeys};
                 LAUNCH(k_flt_insert, dim3(2048), dim3(256), s, fa);
@@ -400,8 +409,11 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     if (!g->vv.empty()) HIPCHK(hipMemcpyAsync(c->d_vv, g->vv.data(), g->vv.size() * 4, hipMemcpyHostToDevice, s));
     // ---- class table: TR pass first, then flank (flank overrides)
     const uint64_t ntrf = g->tr_ks.size(), nfl = g->fl_ks.size();
-    const uint64_t ccap = pow2_at_least(2 * (ntrf + nfl) + 2);
+    uint64_t cls_pct = 130;  // slots per entry, in percent, before rounding up to a power of two (DBTK_CLS_SPARSITY_PCT): only k-mers shared between loci are looked up here
+    if (const char* e = getenv("DBTK_CLS_SPARSITY_PCT")) { const long v = atol(e); if (v >= 110 && v <= 1600) cls_pct = (uint64_t)v; }
+    const uint64_t ccap = pow2_at_least((ntrf + nfl) * cls_pct / 100 + 2);
     HIPCHK(hipMalloc(&c->d_cls, ccap * sizeof(ClsSlot)));
+    c->tb_cls = ccap * sizeof(ClsSlot);
     HIPCHK(hipMemsetAsync(c->d_cls, 0xFF, ccap * sizeof(ClsSlot), s));
     uint64_t* dstats = nullptr;  // [0] index memberships, [1] of them missing from the class table, [2] class entries
     HIPCHK(hipMalloc(&dstats, 3 * 8));
@@ -484,11 +496,12 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         if (const char* e = getenv("DBTK_MZ")) on = atoi(e) != 0;
         const uint32_t m = mz_m_for_k(g->ksize);
         if (on && m && nkeys) {
-            uint64_t per = 6;  // buckets per 8 keys (17 GB at release scale): nine keys in ten then sit in their minimizer's bucket
+            uint64_t per = 3;  // buckets per 8 keys (8.6 GB at release scale; 6 made no measurable difference: the dense batches are the locus-resident kernel's now)
             if (const char* e = getenv("DBTK_MZ_SPARSITY")) { const long v = atol(e); if (v >= 1 && v <= 64) per = (uint64_t)v; }
             uint64_t nb = pow2_at_least(nkeys * per / 8 + 8);
             if (nb > (1ull << 28)) nb = 1ull << 28;  // the bucket number comes out of 28 bits of the minimizer's hash
             HIPCHK(hipMalloc(&c->d_mz, nb * sizeof(MzBucket)));
+            c->tb_mz = nb * sizeof(MzBucket);
             LAUNCH(k_mz_fill, dim3(2048), dim3(256), s, reinterpret_cast<uint64_t*>(c->d_mz), nb * 16, 1);
             uint64_t* dn = nullptr;
             HIPCHK(hipMalloc(&dn, 8));
@@ -499,9 +512,12 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
             HIPCHK(hipMemcpyAsync(&nturned, dn, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipFree(dn));
-            uint64_t ocap = pow2_at_least(16 * nturned + 8);  // level 2: those keys, at most a sixteenth full
+            uint64_t ovf_sp = 8;  // level 2: those keys, at most an eighth full (DBTK_OVF_SPARSITY; a sixteenth: twice the bytes for 1 % of the lean kernel's time)
+            if (const char* e = getenv("DBTK_OVF_SPARSITY")) { const long v = atol(e); if (v >= 2 && v <= 64) ovf_sp = (uint64_t)v; }
+            uint64_t ocap = pow2_at_least(ovf_sp * nturned + 8);
             if (ocap > (1ull << 32)) { set_error("overflow table of the probe kernel: more than 2^28 keys turned away by full buckets"); return DBTK_ERR_UNSUPPORTED; }
             HIPCHK(hipMalloc(&c->d_ovf, ocap * sizeof(MzSlot)));
+            c->tb_ovf = ocap * sizeof(MzSlot);
             LAUNCH(k_mz_fill, dim3(2048), dim3(256), s, reinterpret_cast<uint64_t*>(c->d_ovf), ocap * 2, 0);
             a.ovf = c->d_ovf; a.ovf_mask = (uint32_t)(ocap - 1); a.pass = 1;
             LAUNCH(k_mz_insert, dim3(2048), dim3(256), s, a);
@@ -515,6 +531,107 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     return build_locus_images(c);
 }
 
+// ---- the sidecar of the per-locus images (dbtk.h: dbtk_rpgg_set_index_cache): header, directory, arena — the bytes as they lie in HBM
+struct LocCacheHdr {
+    char magic[8];           // "DBTKIDX\1"
+    uint32_t version, ksize;
+    uint64_t nloci, nkeys, fingerprint, arena_bytes, nimg, left_out;
+    uint32_t lg_max, hdr_bytes;
+};
+constexpr uint32_t LOC_CACHE_VERSION = 2;  // (bumped with every change of the image layout or of its hashes)
+// what the images were built from: the handle's arrays, sampled (a different RPGG, another -t N order, a changed file: another value)
+static uint64_t rpgg_fingerprint(const dbtk_rpgg* g) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    auto mixin = [&](uint64_t v) { h = (h ^ v) * 0x100000001B3ull; h ^= h >> 29; };
+    mixin(g->ksize); mixin(g->nloci); mixin(g->keys.size()); mixin(g->vv.size()); mixin(g->tr_ks.size()); mixin(g->fl_ks.size());
+    auto sample = [&](const auto& v) { const size_t n = v.size(), st = n / 65536 + 1; for (size_t i = 0; i < n; i += st) mixin((uint64_t)v[i]); if (n) mixin((uint64_t)v[n - 1]); };
+    sample(g->keys); sample(g->vals); sample(g->vv); sample(g->tr_ks); sample(g->fl_ks); sample(g->out_slot); sample(g->out_beg); sample(g->tr_cnt); sample(g->fl_cnt);
+    return h;
+}
+// DBTK_OK: the images are in HBM, from the file; DBTK_ERR_FORMAT: no file, or not one of this RPGG / this layout / this build: the caller builds
+static dbtk_status_t load_locus_cache(dbtk_ctx* c, uint64_t fp) {
+    const dbtk_rpgg* g = c->g;
+    const uint64_t nloci = g->nloci;
+    FILE* f = fopen(g->idx_cache.c_str(), "rb");
+    if (!f) return DBTK_ERR_FORMAT;
+    struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{f};
+    LocCacheHdr h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "DBTKIDX\1", 8) != 0 || h.version != LOC_CACHE_VERSION || h.hdr_bytes != sizeof(h) ||
+        h.ksize != g->ksize || h.nloci != nloci || h.nkeys != g->keys.size() || h.fingerprint != fp || h.lg_max != LOC_LG_MAX ||
+        h.arena_bytes > (16ull << 32) || (h.arena_bytes & 15)) return DBTK_ERR_FORMAT;
+    std::vector<LocusDir> dir(nloci);
+    if (fread(dir.data(), sizeof(LocusDir), nloci, f) != nloci) return DBTK_ERR_FORMAT;
+    uint64_t nimg = 0;
+    for (uint64_t l = 0; l < nloci; ++l) {
+        const LocusDir& d = dir[l];
+        if (!d.bytes) continue;
+        if (d.lgnb < loc_lg_min(g->ksize) || d.lgnb > LOC_LG_MAX || d.bytes != loc_image_bytes(d.lgnb) || 16ull * d.off16 + d.bytes > h.arena_bytes ||
+            d.trbeg != (uint32_t)g->out_beg[l]) return DBTK_ERR_FORMAT;
+        ++nimg;
+    }
+    if (!nimg) return DBTK_ERR_FORMAT;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMalloc(&c->d_ldir, nloci * sizeof(LocusDir)));
+    HIPCHK(hipMalloc(&c->d_limg, h.arena_bytes + 16));
+    {   // the arena, through a pinned buffer, 64 MB at a time
+        const uint64_t CH = 64ull << 20;
+        uint8_t* pin = nullptr;
+        HIPCHK(hipHostMalloc((void**)&pin, CH, hipHostMallocDefault));
+        bool ok = true;
+        for (uint64_t at = 0; at < h.arena_bytes && ok; at += CH) {
+            const uint64_t n = std::min<uint64_t>(CH, h.arena_bytes - at);
+            ok = fread(pin, 1, n, f) == n && hipMemcpy(c->d_limg + at, pin, n, hipMemcpyHostToDevice) == hipSuccess;
+        }
+        (void)hipHostFree(pin);
+        if (!ok) { (void)hipFree(c->d_ldir); (void)hipFree(c->d_limg); c->d_ldir = nullptr; c->d_limg = nullptr; return DBTK_ERR_FORMAT; }
+    }
+    HIPCHK(hipMemcpyAsync(c->d_ldir, dir.data(), nloci * sizeof(LocusDir), hipMemcpyHostToDevice, s));
+    uint32_t* dbad = nullptr;
+    HIPCHK(hipMalloc(&dbad, nloci * 4));
+    HIPCHK(hipMemsetAsync(dbad, 0, nloci * 4, s));
+    LocBuildArgs a;
+    memset(&a, 0, sizeof(a));
+    a.trbeg = c->d_trbeg; a.nloci = (uint32_t)nloci; a.ksize = g->ksize; a.dir = c->d_ldir; a.arena = c->d_limg; a.bad = dbad;
+    LAUNCH(k_loc_verify, dim3(4096), dim3(256), s, a);
+    std::vector<uint32_t> bad(nloci);
+    HIPCHK(hipMemcpyAsync(bad.data(), dbad, nloci * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(dbad));
+    for (uint64_t l = 0; l < nloci; ++l)
+        if (bad[l]) {  // a damaged file: nothing of it is used
+            (void)hipFree(c->d_ldir); (void)hipFree(c->d_limg); c->d_ldir = nullptr; c->d_limg = nullptr;
+            return DBTK_ERR_FORMAT;
+        }
+    c->limg_bytes = h.arena_bytes; c->loc_nimg = nimg; c->loc_left_out = h.left_out; c->loc_from_cache = true;
+    c->T.ldir = c->d_ldir; c->T.limg = c->d_limg;
+    if (getenv("DBTK_VERBOSE")) fprintf(stderr, "locus images: %llu loci, %.1f MB, from %s\n", (unsigned long long)nimg, h.arena_bytes / 1e6, g->idx_cache.c_str());
+    return DBTK_OK;
+}
+// (best effort: a sidecar that cannot be written is not an error of the run)
+static void write_locus_cache(dbtk_ctx* c, uint64_t fp, const std::vector<LocusDir>& dir) {
+    const dbtk_rpgg* g = c->g;
+    const std::string tmp = g->idx_cache + ".tmp" + std::to_string((unsigned long long)g->uid);
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    LocCacheHdr h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "DBTKIDX\1", 8);
+    h.version = LOC_CACHE_VERSION; h.ksize = g->ksize; h.nloci = g->nloci; h.nkeys = g->keys.size(); h.fingerprint = fp;
+    h.arena_bytes = (c->limg_bytes + 15) & ~15ull; h.nimg = c->loc_nimg; h.left_out = c->loc_left_out; h.lg_max = LOC_LG_MAX; h.hdr_bytes = sizeof(h);
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(dir.data(), sizeof(LocusDir), dir.size(), f) == dir.size();
+    const uint64_t CH = 64ull << 20;
+    uint8_t* pin = nullptr;
+    if (ok && hipHostMalloc((void**)&pin, CH, hipHostMallocDefault) == hipSuccess) {
+        for (uint64_t at = 0; at < h.arena_bytes && ok; at += CH) {
+            const uint64_t n = std::min<uint64_t>(CH, h.arena_bytes - at);
+            ok = hipMemcpy(pin, c->d_limg + at, n, hipMemcpyDeviceToHost) == hipSuccess && fwrite(pin, 1, n, f) == n;
+        }
+        (void)hipHostFree(pin);
+    } else ok = false;
+    if (fclose(f) != 0) ok = false;
+    if (!ok || rename(tmp.c_str(), g->idx_cache.c_str()) != 0) remove(tmp.c_str());
+}
+
 // Per-locus images of the index (dbtk_locus.h), from the finished plain index: keys per locus -> image sizes (host) -> empty images
 // -> every (key, locus) membership into its locus' image.  DBTK_LOCUS=0: do without (the global tables answer every look-up).
 dbtk_status_t build_locus_images(dbtk_ctx* c) {
@@ -523,6 +640,11 @@ dbtk_status_t build_locus_images(dbtk_ctx* c) {
     const uint64_t nloci = g->nloci;
     if (const char* e = getenv("DBTK_LOCUS")) if (!atoi(e)) return DBTK_OK;
     if (!nloci || g->keys.empty() || loc_lg_min(g->ksize) > LOC_LG_MAX || !c->T.consistent) return DBTK_OK;
+    const uint64_t fp = rpgg_fingerprint(g);
+    if (g->idx_cache_mode >= 1 && !g->idx_cache.empty()) {
+        const dbtk_status_t lc = load_locus_cache(c, fp);
+        if (lc != DBTK_ERR_FORMAT) return lc;  // loaded (DBTK_OK), or a device error; DBTK_ERR_FORMAT: no usable file: build
+    }
     uint32_t *dcnt = nullptr, *dbad = nullptr;
     HIPCHK(hipMalloc(&dcnt, nloci * 4));
     HIPCHK(hipMalloc(&dbad, nloci * 4));
@@ -582,6 +704,7 @@ dbtk_status_t build_locus_images(dbtk_ctx* c) {
     HIPCHK(hipFree(dcnt)); HIPCHK(hipFree(dbad));
     c->limg_bytes = at; c->loc_nimg = nimg - nbad;
     c->T.ldir = c->d_ldir; c->T.limg = c->d_limg;
+    if (g->idx_cache_mode == 2 && !g->idx_cache.empty()) write_locus_cache(c, fp, dir);
     if (getenv("DBTK_VERBOSE")) fprintf(stderr, "locus images: %llu of %llu loci, %.1f MB, %llu keys left out\n", (unsigned long long)c->loc_nimg, (unsigned long long)nloci, at / 1e6, (unsigned long long)c->loc_left_out);
     return DBTK_OK;
 }
@@ -595,6 +718,7 @@ dbtk_status_t build_graph_table(dbtk_ctx* c) {
         if (g->out_beg[l + 1] - g->out_beg[l] >= (1ull << (32 - GR_SLOT_SHIFT))) { set_error("a locus has more than 2^21 TR k-mers: graph table slot field too small"); return DBTK_ERR_UNSUPPORTED; }
     const uint64_t cap = pow2_at_least(ngr + ngr / 2 + 2 * ntrf + 2);  // > the entries whatever the files hold; the two strands of a node share one, so the load is ~0.2-0.35
     HIPCHK(hipMalloc(&c->d_gr, cap * sizeof(GrSlot)));
+    c->tb_gr = cap * sizeof(GrSlot);
     HIPCHK(hipMemsetAsync(c->d_gr, 0xFF, cap * sizeof(GrSlot), s));
     std::vector<uint64_t> beg(nloci + 1, 0);
     uint64_t *dks = nullptr, *dbeg = nullptr, *dslot = nullptr, *dn = nullptr;
@@ -635,9 +759,12 @@ dbtk_status_t build_graph_table(dbtk_ctx* c) {
         if (const char* e = getenv("DBTK_MZ")) on = atoi(e) != 0;
         const uint32_t m = mz_m_for_k(g->ksize);
         if (on && m) {
-            uint64_t nb = pow2_at_least(nent * 6 / 8 + 8);  // 6 buckets per 8 entries, as the index's copy (17 GB at release scale)
+            uint64_t gper = 6;  // buckets per 8 entries, as the index's copy (DBTK_GRMZ_SPARSITY)
+            if (const char* e = getenv("DBTK_GRMZ_SPARSITY")) { const long v = atol(e); if (v >= 1 && v <= 64) gper = (uint64_t)v; }
+            uint64_t nb = pow2_at_least(nent * gper / 8 + 8);
             if (nb > (1ull << 28)) nb = 1ull << 28;
             HIPCHK(hipMalloc(&c->d_grmz, nb * sizeof(MzBucket)));
+            c->tb_grmz = nb * sizeof(MzBucket);
             LAUNCH(k_mz_fill, dim3(2048), dim3(256), s, reinterpret_cast<uint64_t*>(c->d_grmz), nb * 16, 1);
             GrMzBuildArgs ga{c->d_gr, cap, c->d_grmz, (uint32_t)(nb - 1), g->ksize, m};
             LAUNCH(k_grmz_insert, dim3(2048), dim3(256), s, ga);
@@ -827,6 +954,13 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         c->d_sorted = sa.sorted;
         a.surv = sa.sorted;
     }
+    // Was the list worth sorting?  Only a batch with several survivors per locus is put in locus order, and only then does the
+    // locus-resident probe kernel have anything to do; a WGS-like batch (one survivor per locus) would pay its six empty launches for
+    // nothing (40 us on a 1.2-ms step).  Which kind a batch is, is known on the device only — so the answer of the batch BEFORE comes
+    // back through a pinned word and decides whether this batch's launches include the locus path.  A hint, never a matter of
+    // results: the lean kernel looks up whatever the locus path does not take.
+    const bool locus_hint = !c->h_sortflag || *reinterpret_cast<volatile uint32_t*>(c->h_sortflag) != 0;
+    if (c->h_sortflag) HIPCHK(hipMemcpyAsync(c->h_sortflag, c->d_small + 6, 4, hipMemcpyDeviceToHost, s));
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         a.t0 = (uint32_t)(ch * tcap);
         if (tm) { if ((st = timed_slot(c, 1, &e))) return st; HIPCHK(hipEventRecord(c->timed[1].beg[e], s)); }
@@ -837,7 +971,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             const uint32_t wn = a.T.mz ? k - a.T.mz_m + 1 : 0;
             const int npl = !a.T.mz || a.edgebuf || a.qmaskbuf ? 0 : (max_read_len <= 32 * 3 + a.T.mz_m - 1 ? 3 : max_read_len <= 32 * 5 + a.T.mz_m - 1 ? 5 : 0);
             a.sel = nullptr; a.nsel = nullptr;
-            if (npl && a.T.ldir) {
+            if (npl && a.T.ldir && locus_hint) {
                 // The pairs of loci that have an image: the locus-resident kernel (dbtk_locus.h), image in LDS, one item = one locus'
                 // next LOC_CH pairs of the list; the lean kernel then takes what is left (loci without an image, pairs without a
                 // locus — and everything when the batch has too few survivors per locus for the list to be in locus order).
@@ -976,6 +1110,15 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
 
 extern "C" {
 
+int dbtk_ctx_table_bytes(dbtk_ctx_t* c, const char** names, uint64_t* bytes, int cap) {
+    if (!c || !names || !bytes || !c->share) return 0;
+    static const char* nm[12] = {"index", "presence_filter", "class_table", "index_by_minimizer", "index_overflow", "graph", "graph_by_minimizer",
+                                 "index_images", "index_images:from_cache", "vv+qc+perm+trbeg", "gates(tre,bait)", "total"};
+    int n = 0;
+    for (int i = 0; i < 12 && n < cap; ++i) { names[n] = nm[i]; bytes[n] = c->share->bytes[i]; ++n; }
+    return n;
+}
+
 static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_params_t* p, int device_id, dbtk_ctx_t** out) {
     if (!h || !p || !out) { set_error("null argument"); return DBTK_ERR_ARG; }
     *out = nullptr;
@@ -1088,6 +1231,13 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
                 t->d_idx = c->d_idx; t->d_flt = c->d_flt; t->flt_words = c->flt_words; t->d_trbeg = c->d_trbeg; t->d_cls = c->d_cls; t->d_mz = c->d_mz; t->d_ovf = c->d_ovf;
                 t->d_gr = c->d_gr; t->d_grmz = c->d_grmz; t->d_ldir = c->d_ldir; t->d_limg = c->d_limg; t->d_vv = c->d_vv; t->d_qc = c->d_qc; t->d_perm = c->d_perm; t->d_tre = c->d_tre; t->d_bait = c->d_bait;
                 t->T = c->T; t->consistent = c->consistent;
+                // HBM bytes per table: what this context built is added to what the share already holds
+                const uint64_t mine[9] = {c->tb_idx, c->tb_flt, c->tb_cls, c->tb_mz, c->tb_ovf, c->tb_gr, c->tb_grmz, c->limg_bytes, c->loc_from_cache ? 1u : 0u};
+                for (int i = 0; i < 9; ++i) if (mine[i]) t->bytes[i] = mine[i];
+                t->bytes[9] = (h->vv.size() + 1) * 4 + (h->qc.empty() ? 0 : h->nloci) + ((size_t)NHMAX * (NHMAX + 1) / 2 + 1) * 2 + (h->nloci + 1) * 4 + (c->d_ldir ? h->nloci * sizeof(LocusDir) : 0);
+                t->bytes[10] = (c->d_tre ? (c->T.tre_mask + 1) * sizeof(ClsSlot) : 0) + (c->d_bait ? (c->T.bait_mask + 1) * sizeof(ClsSlot) : 0);
+                t->bytes[11] = 0;
+                for (int i = 0; i < 11; ++i) if (i != 8) t->bytes[11] += t->bytes[i];
             };
             if (!sh) {
                 if ((st = build_tables(c))) break;
@@ -1131,6 +1281,10 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
         chk(hipMalloc(&c->d_ctr, (size_t)CTR_REP * CTR_STRIDE * 8), "hipMalloc counter replicas");
         if (!st) chk(hipMemsetAsync(c->d_ctr, 0, (size_t)CTR_REP * CTR_STRIDE * 8, c->stream), "memset");
         chk(hipMalloc(&c->d_small, 4 * SMALL_WORDS + 48 * 8), "hipMalloc small");
+        if (!getenv("DBTK_LOCUS_ALWAYS")) {  // (DBTK_LOCUS_ALWAYS=1: every batch launches the locus path: tests of small batches)
+            chk(hipHostMalloc((void**)&c->h_sortflag, 64, hipHostMallocDefault), "hipHostMalloc");
+            if (c->h_sortflag) *c->h_sortflag = 1u;
+        }
         if (!st) chk(hipMemsetAsync(c->d_small, 0, 4 * SMALL_WORDS + 48 * 8, c->stream), "memset");
         chk(hipMalloc(&c->d_vote, (size_t)c->vote_rows * (h->nloci + 1) * 8), "hipMalloc vote scratch");
         chk(hipMalloc(&c->d_epoch, (size_t)c->vote_rows * 16), "hipMalloc epoch");

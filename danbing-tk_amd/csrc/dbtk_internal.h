@@ -37,6 +37,9 @@ struct dbtk_rpgg {
     std::vector<uint64_t> out_slot;   // file index -> position in OUT.trkmc.ar
     std::vector<uint64_t> out_kmer;   // position -> k-mer
     std::vector<uint64_t> out_beg;    // nloci+1: first position of each locus
+    // sidecar of the GPU-layout per-locus index images (dbtk_locus.h; dbtk_rpgg_set_index_cache): its file and what to do with it
+    std::string idx_cache;
+    int idx_cache_mode = 0;           // 0: none; 1: load it when present and valid; 2: that, and write it after a build
 };
 
 namespace dbtk {

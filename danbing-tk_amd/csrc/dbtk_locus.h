@@ -193,6 +193,27 @@ DBTK_HD void body_loc_place(X& x, const LocBuildArgs& a) {
     }
 }
 
+// every entry of every image well-formed?  (an image read from the sidecar file: a TR k-mer's number indexes the counters)
+template <class X>
+DBTK_HD void body_loc_verify(X& x, const LocBuildArgs& a) {
+    for (uint32_t l = x.bid(); l < a.nloci; l += x.nblocks()) {
+        const LocusDir d = a.dir[l];
+        if (!d.bytes) continue;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(a.arena + 16ull * d.off16);
+        const uint32_t ntr = a.trbeg[l + 1] - a.trbeg[l];
+        bool bad = d.trbeg != a.trbeg[l] || w[0] != d.lgnb;
+        for (uint32_t i = (uint32_t)x.tid(); i < (8u << d.lgnb); i += (uint32_t)x.nthreads()) {
+            if ((i & 7) < 4) continue;
+            const uint32_t p = w[LOC_HDR / 4 + i];
+            if (p == LOC_EMPTY) continue;
+            const uint32_t cls = p & (LOC_MULTI | LOC_FLANK | LOC_TR);
+            if (cls != LOC_MULTI && cls != LOC_FLANK && cls != LOC_TR) bad = true;
+            if (cls == LOC_TR && (p & LOC_SLOT) >= ntr) bad = true;
+        }
+        if (bad) a.bad[l] = 1;
+    }
+}
+
 // ------------------------------------------------------------------ look-up --
 // pay of `km` in the image at `img` (LDS on the device), LOC_MISS when it is not there.  The plain form: every slot of the home
 // bucket.  (The kernel's unrolled fast path below does the same with its loads issued together.)

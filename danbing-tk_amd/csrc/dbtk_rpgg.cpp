@@ -481,6 +481,10 @@ size_t dbtk_aln_format(const void* rec, uint32_t cap, char* out, size_t out_cap)
 
 void dbtk_rpgg_free(dbtk_rpgg_t* h) { delete h; }
 uint64_t dbtk_rpgg_uid(const dbtk_rpgg_t* h) { return h ? h->uid : 0; }
+dbtk_status_t dbtk_rpgg_set_index_cache(dbtk_rpgg_t* h, const char* path, int mode) {
+    if (!h || mode < 0 || mode > 2 || (mode && (!path || !*path))) { dbtk::set_error("dbtk_rpgg_set_index_cache: handle, path, mode 0 .. 2"); return DBTK_ERR_ARG; }
+    return dbtk::guarded([&] { h->idx_cache = mode ? path : ""; h->idx_cache_mode = mode; return DBTK_OK; });
+}
 uint64_t dbtk_rpgg_nloci(const dbtk_rpgg_t* h) { return h ? h->nloci : 0; }
 uint64_t dbtk_rpgg_ntrkmers(const dbtk_rpgg_t* h) { return h ? h->out_kmer.size() : 0; }
 uint64_t dbtk_rpgg_nkeys(const dbtk_rpgg_t* h) { return h ? h->keys.size() : 0; }
@@ -628,13 +632,25 @@ static dbtk_status_t dbtk_write_outputs_impl(const dbtk_rpgg_t* h, const uint64_
 }
 
 // ---- the entry points above that parse files or allocate host memory, behind the exception barrier (dbtk_internal.h: guarded)
+// the sidecar of a handle loaded from files: PREF.dbtk.idx (PREF.<name of the TR file>.dbtk.idx for -t N: another output order, other images)
+static dbtk_status_t with_cache(dbtk_status_t st, const char* prefix, const char* tr_kmers_file, dbtk_rpgg_t** out) {
+    if (st || !out || !*out || !prefix) return st;
+    int mode = 1;
+    if (const char* e = getenv("DBTK_IDX_CACHE")) mode = atoi(e);
+    if (mode < 0 || mode > 2) mode = 1;
+    std::string path = std::string(prefix);
+    if (tr_kmers_file) { std::string t(tr_kmers_file); const size_t sl = t.find_last_of('/'); path += "." + (sl == std::string::npos ? t : t.substr(sl + 1)); }
+    (*out)->idx_cache = mode ? path + ".dbtk.idx" : "";
+    (*out)->idx_cache_mode = mode;
+    return st;
+}
 dbtk_status_t dbtk_rpgg_load(const char* prefix, uint32_t ksize, const char* qc_file, const char* bait_file,
                              uint32_t flags, dbtk_rpgg_t** out) {
-    return dbtk::guarded([&] { return dbtk_rpgg_load_impl(prefix, nullptr, ksize, qc_file, bait_file, flags, out); });
+    return dbtk::guarded([&] { return with_cache(dbtk_rpgg_load_impl(prefix, nullptr, ksize, qc_file, bait_file, flags, out), prefix, nullptr, out); });
 }
 dbtk_status_t dbtk_rpgg_load_tr(const char* prefix, const char* tr_kmers_file, uint32_t ksize, const char* qc_file, const char* bait_file,
                                 uint32_t flags, dbtk_rpgg_t** out) {
-    return dbtk::guarded([&] { return dbtk_rpgg_load_impl(prefix, tr_kmers_file, ksize, qc_file, bait_file, flags, out); });
+    return dbtk::guarded([&] { return with_cache(dbtk_rpgg_load_impl(prefix, tr_kmers_file, ksize, qc_file, bait_file, flags, out), prefix, tr_kmers_file, out); });
 }
 dbtk_status_t dbtk_rpgg_from_arrays(const dbtk_rpgg_arrays_t* a, dbtk_rpgg_t** out) {
     return dbtk::guarded([&] { return dbtk_rpgg_from_arrays_impl(a, out); });

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DBTK_ABI_VERSION 4u
+#define DBTK_ABI_VERSION 5u
 
 /* Reads longer than this are rejected (DBTK_ERR_READ_TOO_LONG).  The
  * reference's per-read k-mer multiplicity is a uint8_t pair (`PE_KMC`,
@@ -212,6 +212,13 @@ void          dbtk_rpgg_free(dbtk_rpgg_t* h);
  * shared by the contexts created from it; the id — not the handle's address, which the allocator hands out again — is the key,
  * so tables can never be taken for another RPGG's.  The handle must still outlive its contexts. */
 uint64_t      dbtk_rpgg_uid(const dbtk_rpgg_t* h);
+/* The sidecar of the GPU-layout index: the per-locus images of PREF.kmers.dbi the probe kernel keeps in LDS (what `ktools serialize`
+ * is to the reference's loaders, src/kmertools.cpp:221-345, one step further: the layout the GPU reads, built on the GPU in
+ * dbtk_ctx_create).  mode 0: no file; 1: load `path` when it is there and was built from this RPGG (a fingerprint of the
+ * handle's arrays and the layout version are checked, every image is verified on the device; anything else: built afresh);
+ * 2: the same, and (re)write the file after a build.  dbtk_rpgg_load sets path = PREF.dbtk.idx and the mode from
+ * DBTK_IDX_CACHE (default 1); a handle made from arrays has no file until this call names one. */
+dbtk_status_t dbtk_rpgg_set_index_cache(dbtk_rpgg_t* h, const char* path, int mode);
 uint64_t      dbtk_rpgg_nloci(const dbtk_rpgg_t* h);
 uint64_t      dbtk_rpgg_ntrkmers(const dbtk_rpgg_t* h);  /* == length of the counts vector */
 uint64_t      dbtk_rpgg_nkeys(const dbtk_rpgg_t* h);
@@ -383,6 +390,9 @@ dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n);
  * launches[i] launches of kernel names[i] (static strings).  Synchronises the
  * stream.  Returns how many kernels were filled (<= cap). */
 int  dbtk_ctx_kernel_times(dbtk_ctx_t* ctx, const char** names, double* total_ms, uint64_t* launches, int cap);
+/* HBM bytes of the context's RPGG tables (shared by the contexts of one handle on one device): names[i] (static strings) and
+ * bytes[i]; returns how many were filled (<= cap).  The entry "index_images:from_cache" is 1 when the images came from the sidecar. */
+int  dbtk_ctx_table_bytes(dbtk_ctx_t* ctx, const char** names, uint64_t* bytes, int cap);
 void dbtk_ctx_timers_reset(dbtk_ctx_t* ctx);
 void dbtk_ctx_timers_enable(dbtk_ctx_t* ctx, int on);  /* default 1: event records around every kernel of every batch (~30 us per batch);
                                                           * 0 = none; n > 1 = only around the kernels of every n-th batch (sampling) */

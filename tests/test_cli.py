@@ -102,6 +102,28 @@ def test_cli_reproduces_reference_binary(name, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_index_sidecar(tmp_path):
+    """--write-idx-cache leaves PREF.dbtk.idx next to the RPGG; the next run loads the GPU-layout index from it (the `tables:` line
+    says so) and prints the same bytes as the golden run — which never sees a sidecar, and writes none."""
+    name = GOLDEN_SETS[0]
+    d, cmds = golden_cmds(name)
+    w = str(tmp_path / "w")
+    os.makedirs(w)
+    for f in os.listdir(d):
+        shutil.copy(os.path.join(d, f), w)
+    line = next(l for l in cmds if " > " in l)
+    args, want = line.split(" > ")[0].split()[1:], open(os.path.join(d, line.split(" > ")[1]), "rb").read()
+    r0 = run(args, cwd=w)
+    assert r0.returncode == 0 and r0.stdout == want and not [f for f in os.listdir(w) if f.endswith(".dbtk.idx")]
+    r1 = run(args + ["--write-idx-cache"], cwd=w)
+    side = [f for f in os.listdir(w) if f.endswith(".dbtk.idx")]
+    assert r1.returncode == 0 and r1.stdout == want and len(side) == 1, r1.stderr.decode()[-1500:]
+    assert b"tables:" in r1.stderr and b"from the sidecar" not in r1.stderr
+    r2 = run(args, cwd=w)
+    assert r2.returncode == 0 and r2.stdout == want and b"images from the sidecar" in r2.stderr, r2.stderr.decode()[-1500:]
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(not synth.have_ref(), reason="oracle/_ref not built")
 def test_cli_vs_reference_binary_live(tmp_path):
     """A fresh mid-size case, reference binary and this CLI run side by side (FASTQ, mates not adjacent)."""

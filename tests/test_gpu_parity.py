@@ -82,6 +82,58 @@ def test_hip_matches_oracle(case, dbtk, oracle, tmp_path):
     g.close()
 
 
+def test_index_image_sidecar_round_trip(dbtk, oracle, tmp_path, monkeypatch):
+    """SURVEY 8 f2, second half: the GPU-layout index (the per-locus images the probe kernel keeps in LDS) written to
+    PREF.dbtk.idx and loaded from it: same results whether the images were built, loaded, or rebuilt because the file is
+    of another RPGG / damaged / of another layout version; the file is only written when asked for."""
+    monkeypatch.setenv("DBTK_LOCUS_ALWAYS", "1")
+    c = make_case("shared", str(tmp_path))
+    go = oracle.load(c.prefix, c.k, c.qc_file)
+    seq, off = c.reads.packed()
+    p = abi.default_params(ksize=c.k, trace=1, **c.param_sets[0])
+    o = oracle.align(go, p, seq, off)
+    side = c.prefix + ".dbtk.idx"
+
+    def run(mode=None, expect_cache=None):
+        g = dbtk.load(c.prefix, c.k, c.qc_file)
+        if mode is not None:
+            g.set_index_cache(side, mode)
+        ctx = dbtk.context(g, p)
+        tb = ctx.table_bytes()
+        assert tb["index_images"] > 0 and tb["total"] >= tb["index"] + tb["index_images"]
+        if expect_cache is not None:
+            assert tb["index_images:from_cache"] == expect_cache
+        recs, nrec = ctx.align(seq, off)
+        res = ctx.counts()
+        res["recs"] = recs
+        compare(o, res, g.output_order(), g.ntrkmers, c.reads.npairs)
+        ctx.close(); g.close()
+
+    run(expect_cache=0)                      # default mode 1: nothing to load, and nothing is written
+    assert not os.path.exists(side)
+    run(mode=2, expect_cache=0)              # built and written
+    assert os.path.getsize(side) > 1000
+    run(expect_cache=1)                      # the default now finds it
+    blob = bytearray(open(side, "rb").read())
+    blob[len(blob) // 2] ^= 0x20             # a flipped bit inside an image: the device-side check (or nothing at all: a tag) ...
+    open(side, "wb").write(bytes(blob))
+    run()                                    # ... either way the results stand
+    blob[40] ^= 0xFF                         # the fingerprint: not this RPGG's file
+    open(side, "wb").write(bytes(blob))
+    run(expect_cache=0)
+    open(side, "wb").write(bytes(blob[:100]))  # truncated
+    run(expect_cache=0)
+    run(mode=2, expect_cache=0)              # rewritten
+    run(expect_cache=1)
+    c2 = make_case("clean", str(tmp_path / "other"))   # another RPGG pointed at this file: rebuilt, not trusted
+    g2 = dbtk.load(c2.prefix, c2.k, c2.qc_file)
+    g2.set_index_cache(side, 1)
+    ctx2 = dbtk.context(g2, abi.default_params(ksize=c2.k))
+    assert ctx2.table_bytes()["index_images:from_cache"] == 0
+    ctx2.close(); g2.close()
+    oracle.free(go)
+
+
 @pytest.mark.skipif(not synth.have_ref(), reason="needs oracle/_ref (ktools serialize-bt builds the bait DB)")
 @pytest.mark.parametrize("fastq", [False, True])
 def test_bait_and_bubble_gates_match_oracle(dbtk, oracle, tmp_path, fastq):
