@@ -89,6 +89,8 @@ __global__ void __launch_bounds__(256) k_loc_count(LocBuildArgs a) { DevX x{null
 __global__ void __launch_bounds__(256) k_loc_scatter(LocBuildArgs a) { DevX x{nullptr}; body_loc_scatter(x, a); }
 __global__ void __launch_bounds__(64) k_loc_place(LocBuildArgs a) { DevX x{nullptr}; body_loc_place(x, a); }
 __global__ void __launch_bounds__(256) k_loc_verify(LocBuildArgs a) { DevX x{nullptr}; body_loc_verify(x, a); }
+__global__ void __launch_bounds__(256) k_gloc_count(LocBuildArgs a) { DevX x{nullptr}; body_gloc_count(x, a); }
+__global__ void __launch_bounds__(256) k_gloc_scatter(LocBuildArgs a) { DevX x{nullptr}; body_gloc_scatter(x, a); }
 __global__ void __launch_bounds__(256) k_loc_items(LocItemArgs a) { DevX x{nullptr}; body_loc_items(x, a); }
 __global__ void __launch_bounds__(256) k_loc_rest(LocItemArgs a) { DevX x{nullptr}; body_loc_rest(x, a); }
 // three classes of workgroup by the size of the image (loc_image_bytes of 512, 1024, 2048 buckets): the smaller the image, the fewer
@@ -144,6 +146,12 @@ template <int NPL, int WN> __global__ void __launch_bounds__(64) __attribute__((
     body_walk_fast<NPL, WN>(x, a);
 }
 __global__ void __launch_bounds__(256) k_grmz_insert(GrMzBuildArgs a) { DevX x{nullptr}; body_grmz_insert(x, a); }
+// ... and its form with the locus' graph image in LDS (dbtk_walkfast.h: body_walk_fast_locus; classes of workgroup as k_probe_locus)
+template <int NPL, int NW, int IMGB> __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_walk_fast_locus(WalkArgs a, LocRunArgs r) {
+    __shared__ WalkFastLocSmemT<NPL, NW, IMGB> sm;
+    DevX x{&sm};
+    body_walk_fast_locus<NPL, NW, IMGB>(x, a, r);
+}
 __global__ void __launch_bounds__(64, DBTK_WALK_WAVES) k_walk_pairs(WalkArgs a) {
     __shared__ __attribute__((aligned(16))) WalkSmem sm[2];  // one set of arrays per mate
     DevX x{sm};
@@ -206,8 +214,8 @@ struct TableShare {
     IdxBucket* d_idx = nullptr; uint64_t* d_flt = nullptr; uint64_t flt_words = 0; uint32_t* d_trbeg = nullptr; ClsSlot* d_cls = nullptr;
     MzBucket* d_mz = nullptr; MzSlot* d_ovf = nullptr; GrSlot* d_gr = nullptr; MzBucket* d_grmz = nullptr; uint32_t* d_vv = nullptr; uint8_t* d_qc = nullptr; uint16_t* d_perm = nullptr;
     ClsSlot* d_tre = nullptr; ClsSlot* d_bait = nullptr;
-    LocusDir* d_ldir = nullptr; uint8_t* d_limg = nullptr;
-    uint64_t bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // HBM bytes per table (dbtk_ctx_table_bytes)
+    LocusDir* d_ldir = nullptr; uint8_t* d_limg = nullptr; LocusDir* d_gldir = nullptr; uint8_t* d_glimg = nullptr;
+    uint64_t bytes[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // HBM bytes per table (dbtk_ctx_table_bytes)
     DevTables T;
     uint32_t consistent = 0;
 };
@@ -231,11 +239,15 @@ struct dbtk_ctx {
     MzBucket* d_grmz = nullptr;   //   ... and its minimizer-grouped copy (the lean walk kernel)
     LocusDir* d_ldir = nullptr;   // per-locus images of the index (dbtk_locus.h): directory,
     uint8_t* d_limg = nullptr;    //   ... and the images
+    LocusDir* d_gldir = nullptr;  // per-locus images of the graph table (walking contexts)
+    uint8_t* d_glimg = nullptr;
+    uint64_t glimg_bytes = 0;
+    int wfl_blocks[6] = {0, 0, 0, 0, 0, 0};  // workgroups of k_walk_fast_locus<3 | 5, class 0 | 1 | 2>
     uint64_t limg_bytes = 0, loc_nimg = 0, loc_left_out = 0;
     bool loc_from_cache = false;
     uint64_t tb_idx = 0, tb_flt = 0, tb_cls = 0, tb_mz = 0, tb_ovf = 0, tb_gr = 0, tb_grmz = 0;  // bytes of the tables this context built
     int loc_blocks[6] = {0, 0, 0, 0, 0, 0};  // workgroups of k_probe_locus<3 | 5, class 0 | 1 | 2>
-    uint32_t* h_sortflag = nullptr;  // pinned: was the survivor list of the batch before in locus order? (a hint: see launch_batch)
+    uint32_t* h_sortflag = nullptr;  // pinned: survivors [0] and sort flag [6] of the batch before (a hint: see launch_batch)
     uint32_t* d_vv = nullptr;
     uint8_t* d_qc = nullptr;
     uint16_t* d_perm = nullptr;
@@ -325,12 +337,12 @@ void release_share(dbtk_ctx* c) {
     std::lock_guard<std::mutex> l(g_share_m);
     TableShare* sh = c->share;
     if (!sh) {  // the context never got as far as sharing: the tables (if any) are its own
-        void* own[] = {c->d_flt, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_tre, c->d_bait, c->d_gr, c->d_grmz, c->d_mz, c->d_ovf, c->d_ldir, c->d_limg};
+        void* own[] = {c->d_flt, c->d_trbeg, c->d_idx, c->d_cls, c->d_vv, c->d_qc, c->d_perm, c->d_tre, c->d_bait, c->d_gr, c->d_grmz, c->d_mz, c->d_ovf, c->d_ldir, c->d_limg, c->d_gldir, c->d_glimg};
         for (void* p : own) if (p) (void)hipFree(p);
         return;
     }
     if (--sh->refs > 0) return;
-    void* ptrs[] = {sh->d_flt, sh->d_trbeg, sh->d_idx, sh->d_cls, sh->d_vv, sh->d_qc, sh->d_perm, sh->d_tre, sh->d_bait, sh->d_gr, sh->d_grmz, sh->d_mz, sh->d_ovf, sh->d_ldir, sh->d_limg};
+    void* ptrs[] = {sh->d_flt, sh->d_trbeg, sh->d_idx, sh->d_cls, sh->d_vv, sh->d_qc, sh->d_perm, sh->d_tre, sh->d_bait, sh->d_gr, sh->d_grmz, sh->d_mz, sh->d_ovf, sh->d_ldir, sh->d_limg, sh->d_gldir, sh->d_glimg};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     g_shares.erase(std::make_pair(c->g_uid, c->device));
     delete sh;
@@ -364,6 +376,7 @@ void free_ctx(dbtk_ctx* c) {
 }
 
 dbtk_status_t build_locus_images(dbtk_ctx* c);
+dbtk_status_t build_graph_images(dbtk_ctx* c);
 dbtk_status_t build_tables(dbtk_ctx* c) {
     const dbtk_rpgg* g = c->g;
     const uint64_t nloci = g->nloci;
@@ -538,7 +551,7 @@ struct LocCacheHdr {
     uint64_t nloci, nkeys, fingerprint, arena_bytes, nimg, left_out;
     uint32_t lg_max, hdr_bytes;
 };
-constexpr uint32_t LOC_CACHE_VERSION = 2;  // (bumped with every change of the image layout or of its hashes)
+constexpr uint32_t LOC_CACHE_VERSION = 3;  // (bumped with every change of the image layout or of its hashes)
 // what the images were built from: the handle's arrays, sampled (a different RPGG, another -t N order, a changed file: another value)
 static uint64_t rpgg_fingerprint(const dbtk_rpgg* g) {
     uint64_t h = 0xCBF29CE484222325ull;
@@ -709,6 +722,78 @@ dbtk_status_t build_locus_images(dbtk_ctx* c) {
     return DBTK_OK;
 }
 
+// The same images for the graph table (the lean walk kernel's; dbtk_locus.h: body_gloc_*), from the finished hashed table.  No sidecar.
+dbtk_status_t build_graph_images(dbtk_ctx* c) {
+    const dbtk_rpgg* g = c->g;
+    hipStream_t s = c->stream;
+    const uint64_t nloci = g->nloci;
+    if (const char* e = getenv("DBTK_LOCUS")) if (!atoi(e)) return DBTK_OK;
+    if (!nloci || !c->d_gr || loc_lg_min(g->ksize) > LOC_LG_MAX) return DBTK_OK;
+    uint32_t *dcnt = nullptr, *dbad = nullptr;
+    HIPCHK(hipMalloc(&dcnt, nloci * 4));
+    HIPCHK(hipMalloc(&dbad, nloci * 4));
+    HIPCHK(hipMemsetAsync(dcnt, 0, nloci * 4, s));
+    HIPCHK(hipMemsetAsync(dbad, 0, nloci * 4, s));
+    LocBuildArgs a;
+    memset(&a, 0, sizeof(a));
+    a.gr = c->d_gr; a.gr_nslots = c->T.gr_mask + 1; a.trbeg = c->d_trbeg; a.nloci = (uint32_t)nloci; a.ksize = g->ksize;
+    a.cnt = dcnt; a.bad = dbad;
+    LAUNCH(k_gloc_count, dim3(2048), dim3(256), s, a);
+    std::vector<uint32_t> cnt(nloci), bad(nloci);
+    HIPCHK(hipMemcpyAsync(cnt.data(), dcnt, nloci * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<LocusDir> dir(nloci);
+    std::vector<uint64_t> ebeg(nloci + 1, 0);
+    uint64_t at = 0, nimg = 0;
+    for (uint64_t l = 0; l < nloci; ++l) {
+        const uint32_t lg = loc_lgnb_for(cnt[l], g->ksize);
+        dir[l] = LocusDir{(uint32_t)(at / 16), 0u, lg, (uint32_t)g->out_beg[l]};
+        ebeg[l + 1] = ebeg[l];
+        if (!cnt[l] || lg > LOC_LG_MAX || cnt[l] > 0xFFF0u || at + loc_image_bytes(lg) > (16ull << 32) || g->out_beg[l + 1] - g->out_beg[l] >= GLOC_SLOT_MAX) continue;
+        dir[l].bytes = loc_image_bytes(lg);
+        at += dir[l].bytes;
+        ebeg[l + 1] += cnt[l];
+        ++nimg;
+    }
+    if (!nimg) { HIPCHK(hipFree(dcnt)); HIPCHK(hipFree(dbad)); return DBTK_OK; }
+    const uint64_t nent = ebeg[nloci];
+    const uint32_t gstride = 2 * (1u << LOC_LG_MAX) + 2;
+    uint64_t *debeg = nullptr, *dekey = nullptr, *dskey = nullptr, *dnleft = nullptr;
+    uint32_t *depay = nullptr, *dspay = nullptr;
+    uint16_t* dgscr = nullptr;
+    HIPCHK(hipMalloc(&c->d_gldir, nloci * sizeof(LocusDir)));
+    HIPCHK(hipMalloc(&c->d_glimg, at + 16));
+    HIPCHK(hipMalloc(&debeg, (nloci + 1) * 8));
+    HIPCHK(hipMalloc(&dekey, (nent + 1) * 8)); HIPCHK(hipMalloc(&dskey, (nent + 1) * 8));
+    HIPCHK(hipMalloc(&depay, (nent + 1) * 4)); HIPCHK(hipMalloc(&dspay, (nent + 1) * 4));
+    HIPCHK(hipMalloc(&dgscr, nloci * (uint64_t)gstride * 2));
+    HIPCHK(hipMalloc(&dnleft, 8));
+    HIPCHK(hipMemsetAsync(dnleft, 0, 8, s));
+    HIPCHK(hipMemsetAsync(dcnt, 0, nloci * 4, s));
+    HIPCHK(hipMemcpyAsync(c->d_gldir, dir.data(), nloci * sizeof(LocusDir), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(debeg, ebeg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
+    a.dir = c->d_gldir; a.arena = c->d_glimg; a.ebeg = debeg; a.ecur = dcnt; a.ekey = dekey; a.epay = depay; a.skey = dskey; a.spay = dspay;
+    a.gscr = dgscr; a.gstride = gstride; a.nleft = dnleft;
+    LAUNCH(k_gloc_scatter, dim3(2048), dim3(256), s, a);
+    LAUNCH(k_loc_place, dim3((uint32_t)((nloci + 63) / 64)), dim3(64), s, a);
+    uint64_t nleft = 0;
+    HIPCHK(hipMemcpyAsync(bad.data(), dbad, nloci * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&nleft, dnleft, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    uint64_t nbad = 0;
+    for (uint64_t l = 0; l < nloci; ++l) if ((bad[l] || false) && dir[l].bytes) { dir[l].bytes = 0; ++nbad; }
+    // (a group left out of a GRAPH image would read as "no node": unlike the index images there is no second look-up behind a miss, so
+    // such an image is not used at all)
+    if (nleft) { for (uint64_t l = 0; l < nloci; ++l) dir[l].bytes = 0; nbad = nimg; }
+    if (nbad) HIPCHK(hipMemcpy(c->d_gldir, dir.data(), nloci * sizeof(LocusDir), hipMemcpyHostToDevice));
+    HIPCHK(hipFree(debeg)); HIPCHK(hipFree(dekey)); HIPCHK(hipFree(dskey)); HIPCHK(hipFree(depay)); HIPCHK(hipFree(dspay)); HIPCHK(hipFree(dgscr)); HIPCHK(hipFree(dnleft));
+    HIPCHK(hipFree(dcnt)); HIPCHK(hipFree(dbad));
+    c->glimg_bytes = at;
+    c->T.gldir = c->d_gldir; c->T.glimg = c->d_glimg;
+    if (getenv("DBTK_VERBOSE")) fprintf(stderr, "graph images: %llu of %llu loci, %.1f MB\n", (unsigned long long)(nimg - nbad), (unsigned long long)nloci, at / 1e6);
+    return DBTK_OK;
+}
+
 // Graph table (dbtk_tables.h: GrSlot) from graphDB's flat arrays + the TR k-mers: graph pass, then TR pass.
 dbtk_status_t build_graph_table(dbtk_ctx* c) {
     const dbtk_rpgg* g = c->g;
@@ -772,7 +857,7 @@ dbtk_status_t build_graph_table(dbtk_ctx* c) {
             c->T.grmz = c->d_grmz; c->T.grmz_mask = nb - 1;
         }
     }
-    return DBTK_OK;
+    return build_graph_images(c);
 }
 
 // (key, locus) -> value table from per-locus arrays (tre edges: value unused; bait: min << 8 | max)
@@ -881,8 +966,8 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     // behind the survivor lists: the work items of the locus-resident probe kernel (two classes of workgroup) and the list of the
     // pairs it leaves to the global-table kernel (dbtk_locus.h)
     const uint64_t surv_words = (3 * (npairs + 1) + nloci + 2 + SCAN_BLOCKS + 3) & ~3ull;
-    const uint64_t item_cap = tcap / LOC_CH + nloci + 2;
-    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, surv_words + 3 * 4 * item_cap + tcap + 4);
+    const uint64_t item_cap = npairs / LOC_CH + nloci + 2;  // (of a chunk for the probe kernel, of the whole list for the walk's)
+    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, surv_words + 3 * 4 * item_cap + npairs + 4);
     if (st) return st;
     if ((st = ensure(&c->d_hitoff, &c->hitoff_cap, tcap * 4))) return st;  // offsets, then headers
     if ((st = ensure(&c->d_hitva, &c->hitva_cap, tcap * 2 * nkp))) return st;
@@ -954,13 +1039,17 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         c->d_sorted = sa.sorted;
         a.surv = sa.sorted;
     }
-    // Was the list worth sorting?  Only a batch with several survivors per locus is put in locus order, and only then does the
-    // locus-resident probe kernel have anything to do; a WGS-like batch (one survivor per locus) would pay its six empty launches for
-    // nothing (40 us on a 1.2-ms step).  Which kind a batch is, is known on the device only — so the answer of the batch BEFORE comes
-    // back through a pinned word and decides whether this batch's launches include the locus path.  A hint, never a matter of
-    // results: the lean kernel looks up whatever the locus path does not take.
-    const bool locus_hint = !c->h_sortflag || *reinterpret_cast<volatile uint32_t*>(c->h_sortflag) != 0;
-    if (c->h_sortflag) HIPCHK(hipMemcpyAsync(c->h_sortflag, c->d_small + 6, 4, hipMemcpyDeviceToHost, s));
+    // Does the locus-resident probe kernel have anything to do?  Only in a batch with many survivors per locus (list in locus order, loci
+    // with LOC_MIN_PAIRS pairs and more); a WGS-like batch (one survivor per locus) would pay its empty launches for nothing (40 us on a
+    // 1.2-ms step).  Which kind a batch is, is known on the device only — so the survivor count and the sort flag of the batch BEFORE
+    // come back through pinned words and decide for this one.  A hint, never a matter of results: the lean kernel looks up whatever
+    // the locus path does not take.
+    bool locus_hint = true;
+    if (c->h_sortflag) {
+        volatile uint32_t* hh = c->h_sortflag;
+        locus_hint = hh[6] != 0 && (uint64_t)hh[0] >= (uint64_t)LOC_MIN_PAIRS * nloci;
+        HIPCHK(hipMemcpyAsync(c->h_sortflag, c->d_small, 7 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         a.t0 = (uint32_t)(ch * tcap);
         if (tm) { if ((st = timed_slot(c, 1, &e))) return st; HIPCHK(hipEventRecord(c->timed[1].beg[e], s)); }
@@ -987,7 +1076,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
                 HIPCHK(hipMemsetAsync(c->d_small + 8, 0, 4 * sizeof(uint32_t), s));
                 LAUNCH(k_loc_items, dim3((uint32_t)((nloci + 255) / 256)), dim3(256), s, ia);
                 LAUNCH(k_loc_rest, dim3((uint32_t)std::min<uint64_t>((tcap + 255) / 256, (uint64_t)c->num_cu * 8)), dim3(256), s, ia);
-                LocRunArgs r0{a.T.ldir, a.T.limg, ia.items[0], c->d_small + 8}, r1{a.T.ldir, a.T.limg, ia.items[1], c->d_small + 9}, r2{a.T.ldir, a.T.limg, ia.items[2], c->d_small + 10};
+                LocRunArgs r0{a.T.ldir, a.T.limg, ia.items[0], c->d_small + 8, ia.rest, c->d_small + 11}, r1{a.T.ldir, a.T.limg, ia.items[1], c->d_small + 9, ia.rest, c->d_small + 11}, r2{a.T.ldir, a.T.limg, ia.items[2], c->d_small + 10, ia.rest, c->d_small + 11};
                 if (npl == 3) {
                     LAUNCH((k_probe_locus<3, LOC_NW_XS, LOC_IMGB_XS>), dim3(c->loc_blocks[0]), dim3(LOC_NW_XS * 64), s, a, r0);
                     LAUNCH((k_probe_locus<3, LOC_NW_S, LOC_IMGB_S>), dim3(c->loc_blocks[1]), dim3(LOC_NW_S * 64), s, a, r1);
@@ -1054,7 +1143,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         if (walk_txt) {  // text records: an arena sized for the worst case (two characters per entry, four strings), carved by the waves
             const uint32_t acap = std::min<uint32_t>(DBTK_THREAD_CAP, (max_read_len + max_read_len / 4 + 8 + 7) & ~7u);
             c->aln_cap = acap;
-            const uint64_t want = std::min<uint64_t>(npairs * (uint64_t)(8 + 8 * acap + 8) + (uint64_t)TXT_CHUNK * (c->walk_blocks + c->walkfast_blocks + 2), TXT_ARENA_MAX);
+            const uint64_t want = std::min<uint64_t>(npairs * (uint64_t)(8 + 8 * acap + 8) + (uint64_t)TXT_CHUNK * (c->walk_blocks + c->walkfast_blocks + 3 * 32 * c->num_cu + 2), TXT_ARENA_MAX);  // (a chunk per wave that writes: the walk kernels' waves, resident at most 32 per CU and kernel)
             if (want > c->txt_bytes) {
                 if (c->d_txt) HIPCHK(hipFree(c->d_txt));
                 c->d_txt = nullptr; c->txt_bytes = 0;
@@ -1093,6 +1182,32 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             HIPCHK(hipMemsetAsync(c->d_small + 5, 0, 4, s));
             // (four ranges per resident wave even out their different costs: 19.7 -> 18.7 ms per 4 M reads; not with text records, where
             // every block that writes takes a chunk of the arena)
+            if (w.T.gldir && locus_hint) {
+                // the pairs of loci with a graph image: the lean kernel's locus-resident form (dbtk_walkfast.h), over the whole list;
+                // the plain form then takes what is left
+                LocItemArgs ia;
+                memset(&ia, 0, sizeof(ia));
+                ia.hist = c->d_surv + 3 * (npairs + 1); ia.nsurv = c->d_small + 0; ia.flag = c->d_small + 6; ia.dir = w.T.gldir;
+                ia.nloci = (uint32_t)nloci; ia.t0 = 0; ia.tcap = (uint32_t)npairs;
+                ia.cap_bytes[0] = LOC_IMGB_XS; ia.cap_bytes[1] = LOC_IMGB_S; ia.cap_bytes[2] = LOC_IMGB_L;
+                for (int q = 0; q < 3; ++q) ia.items[q] = reinterpret_cast<uint4*>(c->d_surv + surv_words) + q * item_cap;
+                ia.nitems = c->d_small + 8; ia.item_cap = (uint32_t)item_cap;
+                ia.rest = c->d_surv + surv_words + 3 * 4 * item_cap;
+                HIPCHK(hipMemsetAsync(c->d_small + 8, 0, 4 * sizeof(uint32_t), s));
+                LAUNCH(k_loc_items, dim3((uint32_t)((nloci + 255) / 256)), dim3(256), s, ia);
+                LAUNCH(k_loc_rest, dim3((uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)c->num_cu * 8)), dim3(256), s, ia);
+                LocRunArgs r0{w.T.gldir, w.T.glimg, ia.items[0], c->d_small + 8, nullptr, nullptr}, r1{w.T.gldir, w.T.glimg, ia.items[1], c->d_small + 9, nullptr, nullptr}, r2{w.T.gldir, w.T.glimg, ia.items[2], c->d_small + 10, nullptr, nullptr};
+                if (wnpl == 3) {
+                    LAUNCH((k_walk_fast_locus<3, LOC_NW_XS, LOC_IMGB_XS>), dim3(c->wfl_blocks[0]), dim3(LOC_NW_XS * 64), s, w, r0);
+                    LAUNCH((k_walk_fast_locus<3, LOC_NW_S, LOC_IMGB_S>), dim3(c->wfl_blocks[1]), dim3(LOC_NW_S * 64), s, w, r1);
+                    LAUNCH((k_walk_fast_locus<3, LOC_NW_L, LOC_IMGB_L>), dim3(c->wfl_blocks[2]), dim3(LOC_NW_L * 64), s, w, r2);
+                } else {
+                    LAUNCH((k_walk_fast_locus<5, LOC_NW_XS, LOC_IMGB_XS>), dim3(c->wfl_blocks[3]), dim3(LOC_NW_XS * 64), s, w, r0);
+                    LAUNCH((k_walk_fast_locus<5, LOC_NW_S, LOC_IMGB_S>), dim3(c->wfl_blocks[4]), dim3(LOC_NW_S * 64), s, w, r1);
+                    LAUNCH((k_walk_fast_locus<5, LOC_NW_L, LOC_IMGB_L>), dim3(c->wfl_blocks[5]), dim3(LOC_NW_L * 64), s, w, r2);
+                }
+                w.sel = ia.rest; w.nsel = c->d_small + 11;
+            }
             const dim3 gf(walk_txt ? c->walkfast_blocks : 4 * c->walkfast_blocks);
             const bool w11 = w.T.grmz && k - mz_m_for_k(k) + 1 == 11;  // (windows of 7 m-mers for k = 19 .. 22, of 11 for k = 23 .. 26)
             if (wnpl == 3) { if (w11) LAUNCH((k_walk_fast<3, 11>), gf, dim3(64), s, w); else LAUNCH((k_walk_fast<3, 7>), gf, dim3(64), s, w); }
@@ -1112,10 +1227,10 @@ extern "C" {
 
 int dbtk_ctx_table_bytes(dbtk_ctx_t* c, const char** names, uint64_t* bytes, int cap) {
     if (!c || !names || !bytes || !c->share) return 0;
-    static const char* nm[12] = {"index", "presence_filter", "class_table", "index_by_minimizer", "index_overflow", "graph", "graph_by_minimizer",
-                                 "index_images", "index_images:from_cache", "vv+qc+perm+trbeg", "gates(tre,bait)", "total"};
+    static const char* nm[13] = {"index", "presence_filter", "class_table", "index_by_minimizer", "index_overflow", "graph", "graph_by_minimizer",
+                                 "index_images", "index_images:from_cache", "vv+qc+perm+trbeg", "gates(tre,bait)", "total", "graph_images"};
     int n = 0;
-    for (int i = 0; i < 12 && n < cap; ++i) { names[n] = nm[i]; bytes[n] = c->share->bytes[i]; ++n; }
+    for (int i = 0; i < 13 && n < cap; ++i) { names[n] = nm[i]; bytes[n] = c->share->bytes[i]; ++n; }
     return n;
 }
 
@@ -1217,6 +1332,16 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_walk_fast<5, 7>, 64, 0) != hipSuccess || nb <= 0) nb = 16;
             c->walkfast_blocks = c->num_cu * nb;
+            const void* kw[6] = {(const void*)k_walk_fast_locus<3, LOC_NW_XS, LOC_IMGB_XS>, (const void*)k_walk_fast_locus<3, LOC_NW_S, LOC_IMGB_S>, (const void*)k_walk_fast_locus<3, LOC_NW_L, LOC_IMGB_L>,
+                                 (const void*)k_walk_fast_locus<5, LOC_NW_XS, LOC_IMGB_XS>, (const void*)k_walk_fast_locus<5, LOC_NW_S, LOC_IMGB_S>, (const void*)k_walk_fast_locus<5, LOC_NW_L, LOC_IMGB_L>};
+            const int nwv[3] = {LOC_NW_XS, LOC_NW_S, LOC_NW_L};
+            for (int i = 0; i < 6; ++i) {
+                nb = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kw[i], nwv[i % 3] * 64, 0) != hipSuccess || nb <= 0) nb = 1;
+                if (const char* ev = getenv("DBTK_WFL_BPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
+                c->wfl_blocks[i] = c->num_cu * nb;
+                if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_walk_fast_locus[%d]: %d workgroups per CU\n", i, nb);
+            }
         }
         for (int i = 0; i < NKERN && !st; ++i)
             for (int j = 0; j < EVPOOL && !st; ++j)
@@ -1229,15 +1354,16 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             TableShare* sh = it != g_shares.end() ? it->second : nullptr;
             auto to_share = [&](TableShare* t) {
                 t->d_idx = c->d_idx; t->d_flt = c->d_flt; t->flt_words = c->flt_words; t->d_trbeg = c->d_trbeg; t->d_cls = c->d_cls; t->d_mz = c->d_mz; t->d_ovf = c->d_ovf;
-                t->d_gr = c->d_gr; t->d_grmz = c->d_grmz; t->d_ldir = c->d_ldir; t->d_limg = c->d_limg; t->d_vv = c->d_vv; t->d_qc = c->d_qc; t->d_perm = c->d_perm; t->d_tre = c->d_tre; t->d_bait = c->d_bait;
+                t->d_gr = c->d_gr; t->d_grmz = c->d_grmz; t->d_ldir = c->d_ldir; t->d_limg = c->d_limg; t->d_gldir = c->d_gldir; t->d_glimg = c->d_glimg; t->d_vv = c->d_vv; t->d_qc = c->d_qc; t->d_perm = c->d_perm; t->d_tre = c->d_tre; t->d_bait = c->d_bait;
                 t->T = c->T; t->consistent = c->consistent;
                 // HBM bytes per table: what this context built is added to what the share already holds
                 const uint64_t mine[9] = {c->tb_idx, c->tb_flt, c->tb_cls, c->tb_mz, c->tb_ovf, c->tb_gr, c->tb_grmz, c->limg_bytes, c->loc_from_cache ? 1u : 0u};
                 for (int i = 0; i < 9; ++i) if (mine[i]) t->bytes[i] = mine[i];
+                if (c->glimg_bytes) t->bytes[12] = c->glimg_bytes;
                 t->bytes[9] = (h->vv.size() + 1) * 4 + (h->qc.empty() ? 0 : h->nloci) + ((size_t)NHMAX * (NHMAX + 1) / 2 + 1) * 2 + (h->nloci + 1) * 4 + (c->d_ldir ? h->nloci * sizeof(LocusDir) : 0);
                 t->bytes[10] = (c->d_tre ? (c->T.tre_mask + 1) * sizeof(ClsSlot) : 0) + (c->d_bait ? (c->T.bait_mask + 1) * sizeof(ClsSlot) : 0);
                 t->bytes[11] = 0;
-                for (int i = 0; i < 11; ++i) if (i != 8) t->bytes[11] += t->bytes[i];
+                for (int i = 0; i < 13; ++i) if (i != 8 && i != 11) t->bytes[11] += t->bytes[i];
             };
             if (!sh) {
                 if ((st = build_tables(c))) break;
@@ -1246,7 +1372,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
                 g_shares[key] = sh;
             } else {
                 c->d_idx = sh->d_idx; c->d_flt = sh->d_flt; c->flt_words = sh->flt_words; c->d_trbeg = sh->d_trbeg; c->d_cls = sh->d_cls; c->d_mz = sh->d_mz; c->d_ovf = sh->d_ovf;
-                c->d_gr = sh->d_gr; c->d_grmz = sh->d_grmz; c->d_ldir = sh->d_ldir; c->d_limg = sh->d_limg; c->d_vv = sh->d_vv; c->d_qc = sh->d_qc; c->d_perm = sh->d_perm; c->d_tre = sh->d_tre; c->d_bait = sh->d_bait;
+                c->d_gr = sh->d_gr; c->d_grmz = sh->d_grmz; c->d_ldir = sh->d_ldir; c->d_limg = sh->d_limg; c->d_gldir = sh->d_gldir; c->d_glimg = sh->d_glimg; c->d_vv = sh->d_vv; c->d_qc = sh->d_qc; c->d_perm = sh->d_perm; c->d_tre = sh->d_tre; c->d_bait = sh->d_bait;
                 c->T = sh->T; c->consistent = sh->consistent;
             }
             c->share = sh;
@@ -1283,7 +1409,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
         chk(hipMalloc(&c->d_small, 4 * SMALL_WORDS + 48 * 8), "hipMalloc small");
         if (!getenv("DBTK_LOCUS_ALWAYS")) {  // (DBTK_LOCUS_ALWAYS=1: every batch launches the locus path: tests of small batches)
             chk(hipHostMalloc((void**)&c->h_sortflag, 64, hipHostMallocDefault), "hipHostMalloc");
-            if (c->h_sortflag) *c->h_sortflag = 1u;
+            if (c->h_sortflag) { c->h_sortflag[0] = 0xFFFFFFFFu; c->h_sortflag[6] = 1u; }
         }
         if (!st) chk(hipMemsetAsync(c->d_small, 0, 4 * SMALL_WORDS + 48 * 8, c->stream), "memset");
         chk(hipMalloc(&c->d_vote, (size_t)c->vote_rows * (h->nloci + 1) * 8), "hipMalloc vote scratch");

@@ -42,6 +42,7 @@ constexpr uint32_t LOC_EMPTY = 0xFFFFFFFEu;  // pay of a free slot (FLANK and TR
 constexpr uint32_t LOC_MISS = 0xFFFFFFFFu;   // look-up result: the k-mer is not in the image
 constexpr uint32_t LOC_HDR = 16;             // header bytes: lgnb, keys left out, trbeg[l], locus
 constexpr uint32_t LOC_CH = 64;              // pairs per item
+constexpr uint32_t LOC_MIN_PAIRS = 8;        // a locus with fewer pairs in the chunk is not worth fetching its image for (16 - 34 KB: the lines of a few pairs' global look-ups)
 constexpr uint32_t LOC_LG_MIN = 5, LOC_LG_MAX = 11;
 struct LocusDir {
     uint32_t off16;  // of the image in the arena, in units of 16 bytes
@@ -61,7 +62,9 @@ DBTK_HD uint32_t loc_image_bytes(uint32_t lgnb) { return LOC_HDR + (32u << lgnb)
 // bucket before the displacement: the low bits of hi, mixed with everything else of the key (its low word AND the bits of hi above the
 // bucket number, which the entry stores: k-mers that differ in their first bases only must not all want one bucket)
 DBTK_HD uint32_t loc_base(uint32_t lo, uint32_t hi, uint32_t lgnb) { return hi ^ (((lo ^ ((hi >> lgnb) * 0x85EBCA6Bu)) * 0x9E3779B1u) >> 15); }
-DBTK_HD uint32_t loc_group(uint32_t lo, uint32_t lgnb) { return ((lo ^ (lo >> 15)) * 0x85EBCA6Bu) >> (32 - lgnb); }  // as many groups as buckets
+// a key's group: as many groups as buckets; a function of the low word and of the bits of hi the entry stores (not of the bits the bucket
+// number implies): the k-mers of a tandem repeat that share their last 16 bases and differ in their first few must not all be one group
+DBTK_HD uint32_t loc_group(uint32_t lo, uint32_t hi, uint32_t lgnb) { const uint32_t v = lo ^ ((hi >> lgnb) * 0x9E3779B1u); return ((v ^ (v >> 15)) * 0x85EBCA6Bu) >> (32 - lgnb); }
 
 // ------------------------------------------------------------------ build --
 struct LocBuildArgs {
@@ -81,6 +84,8 @@ struct LocBuildArgs {
     uint16_t* gscr;         // per locus gstride scratch words (2 * buckets + 2)
     uint32_t gstride;
     uint64_t* nleft;        // += keys left out of their image
+    const GrSlot* gr;       // the graph images' source: the hashed graph table
+    uint64_t gr_nslots;
 };
 // keys per locus
 template <class X>
@@ -125,9 +130,36 @@ DBTK_HD void body_loc_scatter(X& x, const LocBuildArgs& a) {
         } else loc_scatter_one(x, a, key, v >> 1, v, aux);
     }
 }
+// ---- the same images for the GRAPH (the lean walk kernel, dbtk_walkfast.h): every (canonical k-mer, locus) entry of the hashed graph
+// table (dbtk_tables.h: GrSlot) in its locus' image, pay = extra << 24 | counter << 11 | the entry's 11 flag bits (out-edges and
+// "is a node" of both strands, "is a TR k-mer").  13 bits of counter: a locus with 8 191 TR k-mers or more has no graph image.
+constexpr uint32_t GLOC_SLOT_MAX = (1u << 13) - 1;
+template <class X>
+DBTK_HD void body_gloc_count(X& x, const LocBuildArgs& a) {
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.gr_nslots; i += (uint64_t)x.nblocks() * x.nthreads()) {
+        const GrSlot s = a.gr[i];
+        if (s.kmer == NAN64 || s.li == ~0ull) continue;
+        const uint32_t l = (uint32_t)(s.li >> 32);
+        if (l < a.nloci) x.atomic_add(&a.cnt[l], 1u);
+    }
+}
+template <class X>
+DBTK_HD void body_gloc_scatter(X& x, const LocBuildArgs& a) {
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < a.gr_nslots; i += (uint64_t)x.nblocks() * x.nthreads()) {
+        const GrSlot s = a.gr[i];
+        if (s.kmer == NAN64 || s.li == ~0ull) continue;
+        const uint32_t l = (uint32_t)(s.li >> 32), info = (uint32_t)s.li;
+        if (l >= a.nloci || !a.dir[l].bytes) continue;
+        const uint32_t slot = info >> GR_SLOT_SHIFT;
+        if (slot >= GLOC_SLOT_MAX) { a.bad[l] = 1; continue; }
+        const uint64_t at = a.ebeg[l] + x.atomic_add(&a.ecur[l], 1u);
+        if (at >= a.ebeg[l + 1]) { a.bad[l] = 1; continue; }
+        a.ekey[at] = s.kmer; a.epay[at] = (info & ((1u << GR_SLOT_SHIFT) - 1)) | (slot << GR_SLOT_SHIFT);
+    }
+}
+
 // One thread per locus: its keys sorted by group (a counting sort through the locus' scratch words), then group after group — the
-// groups of four and more keys first, then threes, twos, ones — the smallest displacement with which every key of the group finds a
-// free slot.
+// largest first — the smallest displacement with which every key of the group finds a free slot.
 template <class X>
 DBTK_HD void body_loc_place(X& x, const LocBuildArgs& a) {
     for (uint32_t l = x.bid() * (uint32_t)x.nthreads() + (uint32_t)x.tid(); l < a.nloci; l += x.nblocks() * (uint32_t)x.nthreads()) {
@@ -146,20 +178,21 @@ DBTK_HD void body_loc_place(X& x, const LocBuildArgs& a) {
         uint16_t* gpos = gcnt + nb + 1;                    // next free place of each group during the scatter
         if (n > 0xFFF0u) { a.bad[l] = 1; continue; }
         for (uint32_t g = 0; g <= nb; ++g) gcnt[g] = 0;
-        for (uint32_t i = 0; i < n; ++i) ++gcnt[loc_group((uint32_t)a.ekey[e0 + i], d.lgnb)];
+        for (uint32_t i = 0; i < n; ++i) ++gcnt[loc_group((uint32_t)a.ekey[e0 + i], (uint32_t)(a.ekey[e0 + i] >> 32), d.lgnb)];
         uint32_t run = 0;
         for (uint32_t g = 0; g < nb; ++g) { const uint32_t c = gcnt[g]; gcnt[g] = (uint16_t)run; gpos[g] = (uint16_t)run; run += c; }
         gcnt[nb] = (uint16_t)run;
         for (uint32_t i = 0; i < n; ++i) {
             const uint64_t key = a.ekey[e0 + i];
-            const uint32_t at = gpos[loc_group((uint32_t)key, d.lgnb)]++;
+            const uint32_t at = gpos[loc_group((uint32_t)key, (uint32_t)(key >> 32), d.lgnb)]++;
             a.skey[e0 + at] = key; a.spay[e0 + at] = a.epay[e0 + i];
         }
-        uint32_t left = 0;
-        for (int cls = 4; cls >= 1; --cls)
+        uint32_t left = 0, maxsz = 0;
+        for (uint32_t g = 0; g < nb; ++g) { const uint32_t sz = gcnt[g + 1] - gcnt[g]; maxsz = sz > maxsz ? sz : maxsz; }
+        for (uint32_t cls = maxsz; cls >= 1; --cls)  // the largest groups first, while the buckets are empty
             for (uint32_t g = 0; g < nb; ++g) {
                 const uint32_t f = gcnt[g], sz = gcnt[g + 1] - f;
-                if (!sz || (cls == 4 ? sz < 4 : sz != (uint32_t)cls)) continue;
+                if (sz != cls) continue;
                 uint32_t dd = 0;
                 for (; dd < 256; ++dd) {  // every key of the group a free slot? (keys of the group that share a bucket need as many)
                     bool ok = true;
@@ -177,7 +210,14 @@ DBTK_HD void body_loc_place(X& x, const LocBuildArgs& a) {
                     }
                     if (ok) break;
                 }
-                if (dd == 256) { left += sz; continue; }  // (the group stays out of the image: the index answers for its keys)
+                if (dd == 256) {
+#if defined(DBTK_LOC_DEBUG) && !defined(__HIPCC__)
+                    fprintf(stderr, "locus %u lgnb %u n %u: group %u size %u not placed:", l, d.lgnb, n, g, sz);
+                    for (uint32_t t = 0; t < sz && t < 12; ++t) fprintf(stderr, " %llx", (unsigned long long)a.skey[e0 + f + t]);
+                    fprintf(stderr, "\n");
+#endif
+                    left += sz; continue;  // (the group stays out of the image: the index answers for its keys)
+                }
                 disp[g] = (uint8_t)dd;
                 for (uint32_t t = 0; t < sz; ++t) {
                     const uint64_t key = a.skey[e0 + f + t];
@@ -220,7 +260,7 @@ DBTK_HD void body_loc_verify(X& x, const LocBuildArgs& a) {
 DBTK_HD uint32_t loc_find(const uint32_t* img, uint64_t km) {
     const uint32_t lgnb = img[0], lo = (uint32_t)km, hi = (uint32_t)(km >> 32);
     const uint8_t* disp = reinterpret_cast<const uint8_t*>(img + LOC_HDR / 4 + (8u << lgnb));
-    const uint32_t* bk = img + LOC_HDR / 4 + 8 * ((loc_base(lo, hi, lgnb) + disp[loc_group(lo, lgnb)]) & ((1u << lgnb) - 1));
+    const uint32_t* bk = img + LOC_HDR / 4 + 8 * ((loc_base(lo, hi, lgnb) + disp[loc_group(lo, hi, lgnb)]) & ((1u << lgnb) - 1));
     const uint32_t extra = hi >> lgnb;
     for (int s = 0; s < 4; ++s) {
         const uint32_t p = bk[4 + s];
@@ -261,7 +301,7 @@ DBTK_HD void body_loc_items(X& x, const LocItemArgs& a) {
         uint32_t lo = l ? a.hist[l - 1] : 0u, hi = a.hist[l];
         if (lo < a.t0) lo = a.t0;
         if (hi > tend) hi = tend;
-        if (lo >= hi) continue;
+        if (lo >= hi || hi - lo < LOC_MIN_PAIRS) continue;
         const uint32_t n = (hi - lo + LOC_CH - 1) / LOC_CH;
         const uint32_t base = x.atomic_add(&a.nitems[c], n);
         for (uint32_t j = 0; j < n && base + j < a.item_cap; ++j) {
@@ -289,6 +329,12 @@ DBTK_HD void body_loc_rest(X& x, const LocItemArgs& a) {
                 if (a.hist[mid] > t) hi = mid; else lo = mid + 1;
             }
             mine = loc_class(a, lo) < 0;
+            if (!mine) {  // (as body_loc_items decides: the segment's part inside the chunk)
+                uint32_t s0 = lo ? a.hist[lo - 1] : 0u, s1 = a.hist[lo];
+                if (s0 < a.t0) s0 = a.t0;
+                if (s1 > tend) s1 = tend;
+                mine = s1 - s0 < LOC_MIN_PAIRS;
+            }
         }
         const uint64_t m = x.ballot(mine);
         if (!m) continue;
@@ -335,7 +381,13 @@ struct LocRunArgs {
     const uint8_t* arena;
     const uint4* items;
     const uint32_t* nitems;
+    uint32_t* rest;       // the probe kernel only: the list of the pairs left to the global-table kernel, which this kernel appends to:
+    uint32_t* nrest;      //   a pair most of whose k-mers are NOT its locus' (below) is better off there
 };
+// A pair is handed back when more than this many of its positions miss the image: a read pair that merely touches the locus (a
+// stretch of genome that resembles it: it passed subfilter on one k-mer) would send nearly all its positions to the plain index one
+// by one, where the global-table kernel fetches a bucket per RUN of positions.  (A pair from the locus with an error or two: ~20-40.)
+constexpr uint32_t LOC_BAIL = 96;
 
 template <int NPL, int NW, int IMGB, class X>
 DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
@@ -534,7 +586,7 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                 for (int j = 0; j < NPL; ++j) {
                     const uint64_t fw = (W >> (2 * (32 - k - j))) & kmask, rc = (RW >> (2 * j)) & kmask;
                     km[j] = fw < rc ? fw : rc;
-                    bo[j] = dsp[loc_group((uint32_t)km[j], lgnb)];  // (the groups' displacement bytes: reads issued together)
+                    bo[j] = dsp[loc_group((uint32_t)km[j], (uint32_t)(km[j] >> 32), lgnb)];  // (the groups' displacement bytes: reads issued together)
                 }
 #pragma unroll
                 for (int j = 0; j < NPL; ++j) bo[j] = 8 * ((loc_base((uint32_t)km[j], (uint32_t)(km[j] >> 32), lgnb) + bo[j]) & ((1u << lgnb) - 1));
@@ -608,6 +660,13 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                     sm.res[half][p0 + j] = AUX_MISS;
                 }
             }
+            const uint32_t pex = x.wave_excl_scan(npend);
+            const uint32_t ptot = x.bcast(pex + npend, 63);
+            if (ptot > LOC_BAIL && r.rest) {  // (uniform) not this locus' pair after all: the global-table kernel's
+                if (lane == 0) r.rest[x.atomic_add(r.nrest, 1u)] = i;
+                DBTK_STAMP(16);
+                continue;
+            }
             DBTK_STAMP(16);  // k-mers, image look-ups
             {   // the row as the image answers it: its statistics, its aux words (16-byte stores)
                 const uint32_t nh = x.half_sum(nres);
@@ -626,8 +685,6 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                 }
             }
             {   // the rest into the queue (a queue that cannot take them all is looked up first)
-                const uint32_t pex = x.wave_excl_scan(npend);
-                const uint32_t ptot = x.bcast(pex + npend, 63);
                 uint32_t done = 0;  // entries of this pair already queued (uniform)
                 while (done < ptot) {
                     if (qn == (uint32_t)LOC_Q) flush();

@@ -145,6 +145,7 @@ struct DevTables {
     const MzBucket* mz; uint64_t mz_mask; uint32_t mz_m;  // level 1 (mz_mask = buckets - 1 <= 2^28 - 1); nullptr: the probe kernel looks up the plain index
     const MzSlot* ovf; uint64_t ovf_mask;               // level 2 (ovf_mask = slots - 1 <= 2^32 - 1)
     const LocusDir* ldir; const uint8_t* limg;          // per-locus images of the index (dbtk_locus.h), nullptr: none
+    const LocusDir* gldir; const uint8_t* glimg;        // ... and of the graph table (the lean walk kernel), nullptr: none
 };
 
 DBTK_HD uint64_t hash_mix(uint64_t key) {

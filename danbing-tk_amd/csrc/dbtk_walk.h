@@ -127,6 +127,10 @@ struct WalkArgs {
     // not decide.  body_walk_fast appends to it; body_walk_pairs takes its items from it (nullptr: every survivor).
     uint32_t* slow_list;
     uint32_t* nslow;
+    // body_walk_fast only: nullptr, or the places in the list of the pairs it is to take (the pairs of loci without a graph image:
+    // what body_walk_fast_locus leaves) and their number
+    const uint32_t* sel;
+    const uint32_t* nsel;
 };
 constexpr int8_t WALK_NOT_EVALUATED = -2;  // walk_ret of a mate whose walk nothing needed: its pair was kept by the other mate (dbtk.h)
 #ifdef DBTK_STAMPS

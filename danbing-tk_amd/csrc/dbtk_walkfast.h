@@ -57,6 +57,136 @@ struct __attribute__((aligned(16))) WalkFastSmemT {
     uint4 cache[P2_CACHE];    // {k-mer, info, locus} of single look-ups already made (info 0: no node): the wave works through the reads of a locus
     uint8_t tok[P2_CACHE];    // which lane writes an entry when several want to in one step
 };
+// The verdict on one pair from the graph nodes of its positions (gi[j]: info of the canonical k-mer at the pair's locus, 0: no node),
+// shared by the two forms of the lean kernel (nodes from the global tables / from the locus' image in LDS): the step test, the exact
+// counting of a kept pair, its text record, or the hand-over to the other kernel.
+struct WfState {
+    uint64_t c_feas = 0, c_inc = 0;
+    uint32_t nbuf = 0;
+    uint32_t txt_base = 0, txt_left = 0;  // text records (-a / -ae): arena bytes are taken TXT_CHUNK at a time, as in body_walk_pairs
+};
+template <int NPL, class X, class Flush>
+DBTK_HD void wf_decide(X& x, const WalkArgs& a, uint32_t i, uint32_t dst, uint32_t len, uint32_t nk, uint64_t badm, const uint64_t (&fw)[NPL],
+                       const uint64_t (&cn)[NPL], const uint32_t (&gi)[NPL], const bool (&act)[NPL], uint32_t* buf, WfState& S, Flush&& flush, bool texting,
+                       uint32_t* lcnt = nullptr, uint32_t lcap = 0) {
+    const int lane = x.lane();
+    const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5, p0 = hl * NPL;
+    const DevTables& T = a.T;
+    uint64_t& c_feas = S.c_feas; uint64_t& c_inc = S.c_inc;
+    uint32_t& nbuf = S.nbuf; uint32_t& txt_base = S.txt_base; uint32_t& txt_left = S.txt_left;
+    // oriented info of every position (as w_info), then the step test of walk_read: position p continues the walk iff the
+    // k-mer before it is a node with an out-edge labelled by p's last base (and is not p's k-mer itself: a homopolymer)
+    uint32_t go[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const bool isf = fw[j] == cn[j];
+        const uint32_t fa = gi[j] & 0x1Fu, fb = (gi[j] >> GR_OPP) & 0x1Fu;
+        go[j] = isf ? fa : fb;
+    }
+    uint32_t pg = x.shfl_up1(go[NPL - 1]);
+    uint32_t plo = x.shfl_up1((uint32_t)fw[NPL - 1]), phi = x.shfl_up1((uint32_t)(fw[NPL - 1] >> 32));
+    bool fail = false;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const uint64_t pv = ((uint64_t)phi << 32) | plo;
+        if (act[j]) {
+            if (p0 + j == 0) fail |= !(go[j] & GR_HAS);  // the anchor is the first k-mer
+            else fail |= !((pg & GR_HAS) && ((pg >> (uint32_t)(fw[j] & 3)) & 1) && fw[j] != pv);
+        }
+        pg = go[j]; plo = (uint32_t)fw[j]; phi = (uint32_t)(fw[j] >> 32);
+    }
+    const uint64_t failm = x.ballot(fail) | badm;
+    const uint64_t nkm = x.ballot(nk > 0);
+    const bool clean0 = (nkm & 1) && !(failm & 0xFFFFFFFFull), clean1 = ((nkm >> 32) & 1) && !(failm >> 32);
+    // (-a / -ae: the record holds both mates' alignments, so only a pair BOTH of whose mates thread cleanly is finished here — its
+    // strings are "len=" and the run lengths of the TR flags of its k-mers; any other pair goes on to the kernel that aligns)
+    if ((texting ? (clean0 && clean1) : (clean0 || clean1)) && !badm) {  // (uniform) the pair is kept: count the uncorrected k-mers of both mates (AQ.cpp:2189-2194)
+        // (a pair with a non-ACGT byte in either mate is passed on even when its other mate threads: the valid k-mers of the
+        // mate with the N count too, and which of its windows are valid is the other kernel's business)
+        c_feas += 2;
+        const uint32_t tb = T.trbeg[dst];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const bool hit = act[j] && (gi[j] & GR_TR);
+            // (the locus-resident form counts into the workgroup's LDS copy of the locus' counters, flushed once per item)
+            if (hit) { const uint32_t sl = gi[j] >> GR_SLOT_SHIFT; if (sl < lcap) x.lds_add(&lcnt[sl], 1u); else x.atomic_add(&a.counts[tb + sl], 1ull); }
+            c_inc += (uint64_t)__builtin_popcountll(x.ballot(hit));
+        }
+        if (lane == 0) {
+            a.walk_dst[i] = dst;
+            a.walk_ret[i] = (uint32_t)(uint8_t)(clean0 ? 1 : WALK_NOT_EVALUATED) | ((uint32_t)(uint8_t)(clean1 ? 1 : WALK_NOT_EVALUATED) << 8);
+        }
+        if (texting) {
+            // writeAnnot on cg.tr of a clean walk (one '=' / '.' per k-mer: is it a TR k-mer of the locus) = the run lengths of the
+            // flags; writeCigar on its cg.es (len matches) = "len=".  A run is printed by the lane of its last position: the flag of
+            // the position after it comes from the lane's own next position or, across lanes, from the ballot of first positions;
+            // where the run began is a max-scan over the positions where the flag changes (each mate's own scale, so that mate 1's
+            // scan never sees mate 0's).
+            bool f[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) f[j] = (gi[j] & GR_TR) != 0;
+            const uint64_t f0m = x.ballot(f[0]);
+            const bool fnext = lane < 63 && ((f0m >> (lane + 1)) & 1);  // (lane 31's successor is mate 1's first: never looked at, p0 + NPL - 1 >= nk - 1 there or inactive)
+            const uint32_t scale = half ? 4096u : 0u;
+            uint32_t chg = 0;  // (index + 1 on the mate's scale) of the last position of this lane that starts a run
+            bool fp = x.shfl_up1(f[NPL - 1] ? 1u : 0u) != 0;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                if (act[j] && (p0 + j == 0 || f[j] != fp)) chg = scale + p0 + j + 1;
+                fp = f[j];
+            }
+            const uint32_t inc = x.wave_scan_max(chg);
+            uint32_t before = x.shfl_up1(inc);  // the last run start in the lanes before this one
+            if (lane == 0 || before < scale + 1) before = scale + 1;  // (a mate's position 0 always starts a run; lane 32 must not see mate 0)
+            uint32_t rl[NPL], ol[NPL], tot = 0;
+            uint32_t st = before;
+            fp = x.shfl_up1(f[NPL - 1] ? 1u : 0u) != 0;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                if (act[j] && (p0 + j == 0 || f[j] != fp)) st = scale + p0 + j + 1;
+                fp = f[j];
+                const bool nx = j + 1 < NPL ? f[j + 1] : fnext;
+                const bool end = act[j] && (p0 + j + 1 == nk || nx != f[j]);
+                rl[j] = end ? (scale + p0 + j + 1) - st + 1 : 0u;
+                ol[j] = end ? (rl[j] >= 100 ? 3u : rl[j] >= 10 ? 2u : 1u) + 1u : 0u;
+                tot += ol[j];
+            }
+            const uint32_t ex = x.wave_excl_scan(tot), la = x.half_sum(tot);
+            const uint32_t la0 = x.bcast(la, 0), la1 = x.bcast(la, 32);
+            const uint32_t len0 = x.bcast(len, 0), len1 = x.bcast(len, 32);  // (each half holds its own mate's length)
+            const uint32_t lc0 = (len0 >= 100 ? 3u : len0 >= 10 ? 2u : 1u) + 1u, lc1 = (len1 >= 100 ? 3u : len1 >= 10 ? 2u : 1u) + 1u;
+            const uint32_t tlen = lc1 + 1 + la1 + 1 + lc0 + 1 + la0, need = (8 + tlen + 3) & ~3u;
+            if (need > txt_left) {
+                uint32_t b = 0;
+                if (lane == 0) b = txt_carve(x, a);
+                txt_base = x.bcast(b, 0);
+                txt_left = TXT_CHUNK;
+            }
+            if ((uint64_t)txt_base + need <= a.txt_cap) {
+                uint8_t* r = a.txt + txt_base;
+                if (lane == 0) {  // header, mate 1's CIGAR, the three tabs, mate 0's CIGAR
+                    reinterpret_cast<uint32_t*>(r)[0] = dst;
+                    reinterpret_cast<uint32_t*>(r)[1] = tlen;
+                    a.txt_idx[a.surv[i]] = txt_base;
+                    uint32_t q = w_fmt_int(r, 8, (int)len1);
+                    r[q] = '='; r[q + 1] = '\t';
+                    r[8 + lc1 + 1 + la1] = '\t';
+                    q = w_fmt_int(r, 8 + lc1 + 1 + la1 + 1, (int)len0);
+                    r[q] = '='; r[q + 1] = '\t';
+                }
+                uint32_t o = half ? 8 + lc1 + 1 + (ex - la0) : 8 + lc1 + 1 + la1 + 1 + lc0 + 1 + ex;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j)
+                    if (ol[j]) { const uint32_t q = w_fmt_int(r, o, (int)rl[j]); r[q] = f[j] ? '=' : '.'; o += ol[j]; }
+            } else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
+            txt_base += need; txt_left -= need;
+        }
+    } else {
+        if (lane == 0) buf[nbuf] = i;
+        if (++nbuf == (uint32_t)WF_BUF) flush();
+    }
+}
+
 // WN = k - m + 1 m-mers per window when the minimizer-grouped copy of the graph table exists (T.grmz), else unused
 template <int NPL, int WN, class X>
 DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
@@ -67,7 +197,7 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
     const DevTables& T = a.T;
     const uint32_t k = T.ksize;
     uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
-    const uint32_t nsurv = *a.nsurv;
+    const uint32_t nsurv = a.sel ? *a.nsel : *a.nsurv;  // pairs this kernel takes: the whole list, or the places a.sel names
     // a contiguous range of the (locus-ordered) survivor list per wave: the waves running side by side count into different loci
     const uint32_t per = (nsurv + x.nblocks() - 1) / x.nblocks();
     const uint64_t lo64 = (uint64_t)x.bid() * per;
@@ -76,24 +206,24 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint32_t p0 = hl * NPL;
     for (uint32_t e = (uint32_t)lane; e < (uint32_t)P2_CACHE; e += 64) sm.cache[e] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu};
-    uint64_t c_feas = 0, c_inc = 0;
-    uint32_t nbuf = 0;
-    uint32_t txt_base = 0, txt_left = 0;  // text records (-a / -ae): arena bytes are taken TXT_CHUNK at a time, as in body_walk_pairs
+    WfState S;
     const bool texting = a.txt && (a.P.aln & 3) != 0;
     auto flush = [&]() {
         x.sync();
         uint32_t base = 0;
-        if (lane == 0) base = x.atomic_add(a.nslow, nbuf);
+        if (lane == 0) base = x.atomic_add(a.nslow, S.nbuf);
         base = x.bcast(base, 0);
-        if ((uint32_t)lane < nbuf) a.slow_list[base + lane] = sm.buf[lane];
+        if ((uint32_t)lane < S.nbuf) a.slow_list[base + lane] = sm.buf[lane];
         x.sync();
-        nbuf = 0;
+        S.nbuf = 0;
     };
-    // three-deep fetch pipeline as in the probe kernel: bytes of pair i + 1, offsets of pair i + 2, (pair, locus) of pair i + 3
+    // three-deep fetch pipeline as in the probe kernel: bytes of pair i + 1, offsets of pair i + 2, (pair, locus) of pair i + 3; the
+    // place of pair i + 4 (i + 4 itself, or what a.sel says) is read an iteration before its list entries
     auto clampi = [&](uint32_t i) { return i < hi ? i : (first < hi ? first : 0u); };
+    auto place_of = [&](uint32_t i) -> uint32_t { const uint32_t ic = clampi(i); return a.sel ? (nsurv ? a.sel[ic] : 0u) : ic; };
     uint32_t rw0 = 0, rw1 = 0;
     uint64_t o0C = 0, o1C = 0, o0B = 0, o1B = 0;
-    uint32_t pairA = 0, dstA = NAN32, dstB = NAN32, dstC = NAN32;
+    uint32_t pairA = 0, dstA = NAN32, dstB = NAN32, dstC = NAN32, plN = 0;
     auto fetch_bytes = [&](uint64_t o0, uint64_t o1) {
         uint32_t len = (uint32_t)(o1 - o0);
         if (len > lmax) len = lmax;
@@ -107,14 +237,16 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
         o0B = a.off[r]; o1B = a.off[r + 1];
     };
     if (first < hi) {
-        fetch_offsets(x.uni(a.surv[first]));
-        dstC = a.walk_dst[first];
+        const uint32_t q0 = place_of(first), q1 = place_of(first + 1), q2 = place_of(first + 2);
+        fetch_offsets(x.uni(a.surv[q0]));
+        dstC = a.walk_dst[q0];
         o0C = o0B; o1C = o1B;
         fetch_bytes(o0C, o1C);
-        if (first + 1 < hi) { fetch_offsets(x.uni(a.surv[first + 1])); dstB = a.walk_dst[first + 1]; }
-        pairA = a.surv[clampi(first + 2)]; dstA = a.walk_dst[clampi(first + 2)];
+        if (first + 1 < hi) { fetch_offsets(x.uni(a.surv[q1])); dstB = a.walk_dst[q1]; }
+        pairA = a.surv[q2]; dstA = a.walk_dst[q2];
+        plN = place_of(first + 3);
     }
-    for (uint32_t i = first; i < hi; ++i) {
+    for (uint32_t ii = first; ii < hi; ++ii) {
         const uint64_t o0 = o0C, o1 = o1C;
         uint32_t len = (uint32_t)(o1 - o0);
         if (len > lmax) { if (a.errflag) *a.errflag = DBTK_ERR_READ_TOO_LONG; len = lmax; }
@@ -122,13 +254,15 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
         const uint32_t rsh = (uint32_t)(o0 - a0);
         const uint32_t d0 = rw0, d1 = rw1;
         const uint32_t dst = x.uni(dstC);
+        const uint32_t i = x.uni(place_of(ii));  // the pair's place in the list (read again here: cheaper than a register through the pipeline)
         {   // advance the pipeline
-            const bool hasB = i + 1 < hi, hasA = i + 2 < hi;
+            const bool hasB = ii + 1 < hi, hasA = ii + 2 < hi;
             o0C = hasB ? o0B : 0ull; o1C = hasB ? o1B : 0ull;
             fetch_bytes(o0C, o1C);
             dstC = dstB; dstB = dstA;
             fetch_offsets(hasA ? x.uni(pairA) : x.uni(pairA) * 0u);
-            pairA = a.surv[clampi(i + 3)]; dstA = a.walk_dst[clampi(i + 3)];
+            pairA = a.surv[plN]; dstA = a.walk_dst[plN];
+            plN = place_of(ii + 4);
         }
         if (dst == NAN32) continue;  // the pair never reached threading (uniform)
         x.sync();
@@ -181,8 +315,8 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
             q[j] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
         }
         if (badm) {  // (uniform) a pair with a non-ACGT byte is the other kernel's whatever its mates do
-            if (lane == 0) sm.buf[nbuf] = i;
-            if (++nbuf == (uint32_t)WF_BUF) flush();
+            if (lane == 0) sm.buf[S.nbuf] = i;
+            if (++S.nbuf == (uint32_t)WF_BUF) flush();
             continue;
         }
         if (T.grmz) {
@@ -283,121 +417,241 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
             for (int j = 0; j < NPL; ++j) open[j] = act[j];
             single();
         }
-        // oriented info of every position (as w_info), then the step test of walk_read: position p continues the walk iff the
-        // k-mer before it is a node with an out-edge labelled by p's last base (and is not p's k-mer itself: a homopolymer)
-        uint32_t go[NPL];
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const bool isf = fw[j] == cn[j];
-            const uint32_t fa = gi[j] & 0x1Fu, fb = (gi[j] >> GR_OPP) & 0x1Fu;
-            go[j] = isf ? fa : fb;
+        wf_decide<NPL>(x, a, i, dst, len, nk, badm, fw, cn, gi, act, sm.buf, S, flush, texting);
+    }
+    if (S.nbuf) flush();
+    if (lane == 0) {
+        if (S.c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], S.c_feas);
+        if (S.c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], S.c_inc);
+    }
+}
+
+// ---- the lean kernel with the locus' graph nodes resident in LDS (the probe kernel's remedy, dbtk_locus.h): a workgroup takes ITEMS
+// = (locus, up to LOC_CH consecutive pairs of its segment of the list), copies the locus' graph image into LDS and its waves get the
+// node of every position from there: one LDS bucket per position instead of a 128-byte line per run of positions plus the single
+// look-ups.  A pair whose destLocus is not the item's locus (the list is in the order of the pairs' first index hit, the vote may have
+// chosen another locus) goes to the other kernel like every pair this one cannot decide.
+template <int NPL, int NW>
+struct __attribute__((aligned(16))) WalkFastLocWaveSmemT {
+    uint32_t pk[2][20];
+    uint32_t buf[WF_BUF];
+};
+constexpr uint32_t WFL_CNT = 2048;  // counters of the item's locus kept in LDS (a locus with more TR k-mers counts the rest directly)
+template <int NPL, int NW, int IMGB>
+struct __attribute__((aligned(16))) WalkFastLocSmemT {
+    uint4 img[IMGB / 16];
+    uint32_t cnt[WFL_CNT];
+    WalkFastLocWaveSmemT<NPL, NW> w[NW];
+};
+template <int NPL, int NW, int IMGB, class X>
+DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) {
+    typedef WalkFastLocSmemT<NPL, NW, IMGB> SM;
+    constexpr int IPT = ((IMGB - (int)LOC_HDR) / 16 + NW * 64 - 1) / (NW * 64);
+    SM& smb = *x.template smem<SM>();
+    const int lane = x.lane();
+    const uint32_t wave = (uint32_t)x.tid() >> 6;
+    WalkFastLocWaveSmemT<NPL, NW>& sm = smb.w[wave];
+    const uint32_t* bks = reinterpret_cast<const uint32_t*>(smb.img);
+    const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5;
+    const DevTables& T = a.T;
+    const uint32_t k = T.ksize;
+    uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
+    const uint32_t nitems = *r.nitems;
+    const uint32_t lmax = 32u * NPL + k - 1;
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    const uint32_t p0 = hl * NPL;
+    const uint32_t S = x.nblocks();
+    WfState W;
+    const bool texting = a.txt && (a.P.aln & 3) != 0;
+    auto flush = [&]() {
+        x.sync();
+        uint32_t base = 0;
+        if (lane == 0) base = x.atomic_add(a.nslow, W.nbuf);
+        base = x.bcast(base, 0);
+        if ((uint32_t)lane < W.nbuf) a.slow_list[base + lane] = sm.buf[lane];
+        x.sync();
+        W.nbuf = 0;
+    };
+    // this wave's pairs, item after item (as body_probe_locus): the fetch pipeline runs along that sequence across items
+    struct Cur { uint32_t it; uint32_t i, end; };
+    auto desc = [&](uint32_t it) -> uint4 { return r.items[it < nitems ? it : 0u]; };
+    auto seek = [&](uint32_t it) -> Cur {
+        for (;;) {
+            if (it >= nitems) return Cur{it, 0u, 0u};
+            const uint4 d = desc(it);
+            if (d.y + wave < d.z) return Cur{it, d.y + wave, d.z};
+            it += S;
         }
-        uint32_t pg = x.shfl_up1(go[NPL - 1]);
-        uint32_t plo = x.shfl_up1((uint32_t)fw[NPL - 1]), phi = x.shfl_up1((uint32_t)(fw[NPL - 1] >> 32));
-        bool fail = false;
+    };
+    auto next = [&](const Cur& c) -> Cur {
+        if (c.it >= nitems) return c;
+        if (c.i + NW < c.end) return Cur{c.it, c.i + NW, c.end};
+        return seek(c.it + S);
+    };
+    uint32_t rw0 = 0, rw1 = 0;
+    uint64_t o0C = 0, o1C = 0, o0B = 0, o1B = 0;
+    uint32_t pairA = 0, dstA = NAN32, dstB = NAN32, dstC = NAN32;
+    auto fetch_bytes = [&](uint64_t o0, uint64_t o1) {
+        uint32_t len = (uint32_t)(o1 - o0);
+        if (len > lmax) len = lmax;
+        const uint64_t a0 = o0 & ~3ull;
+        const uint32_t nw = ((uint32_t)(o0 - a0) + len + 3) >> 2;
+        rw0 = *reinterpret_cast<const uint32_t*>(a.seq + (2 * hl < nw ? a0 + 8ull * hl : 0ull));
+        rw1 = *reinterpret_cast<const uint32_t*>(a.seq + (2 * hl + 1 < nw ? a0 + 8ull * hl + 4 : 0ull));
+    };
+    auto fetch_offsets = [&](uint32_t pair) {
+        const uint64_t rr = 2 * (uint64_t)pair + half;
+        o0B = a.off[rr]; o1B = a.off[rr + 1];
+    };
+    auto at_of = [&](const Cur& c) { return c.it < nitems ? c.i : 0u; };
+    Cur cC = seek(x.bid()), cB = next(cC), cA = next(cB);
+    if (cC.it < nitems) {
+        fetch_offsets(x.uni(a.surv[at_of(cC)]));
+        dstC = a.walk_dst[at_of(cC)];
+        o0C = o0B; o1C = o1B;
+        fetch_bytes(o0C, o1C);
+        if (cB.it < nitems) { fetch_offsets(x.uni(a.surv[at_of(cB)])); dstB = a.walk_dst[at_of(cB)]; }
+        pairA = a.surv[at_of(cA)]; dstA = a.walk_dst[at_of(cA)];
+    }
+    uint4 d1 = desc(x.bid()), d2 = desc(x.bid() + S);
+    LocusDir ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
+    for (uint32_t e = (uint32_t)x.tid(); e < WFL_CNT; e += (uint32_t)x.nthreads()) smb.cnt[e] = 0;
+    uint32_t trb_prev = 0;
+    // the item's counts: LDS -> the locus' counters (one add per counter the item's pairs touched, not one per k-mer of every pair)
+    auto flush_counts = [&]() {
+        for (uint32_t e = (uint32_t)x.tid(); e < WFL_CNT; e += (uint32_t)x.nthreads()) {
+            const uint32_t v = smb.cnt[e];
+            if (v) { x.atomic_add(&a.counts[trb_prev + e], (uint64_t)v); smb.cnt[e] = 0; }
+        }
+    };
+    for (uint32_t item = x.bid(); item < nitems; item += S) {
+        const uint4 d = d1;
+        const LocusDir ld = ld1;
+        const uint32_t locus = x.uni(d.x), lgnb = x.uni(ld.lgnb), trb = x.uni(ld.trbeg);
+        x.bsync();  // every wave is done with the image of the item before, and with its counts
+        flush_counts();
+        trb_prev = trb;
+        {
+            const p2_v4u* src = reinterpret_cast<const p2_v4u*>(r.arena + 16ull * ld.off16 + LOC_HDR);
+            const uint32_t n16 = (ld.bytes - LOC_HDR) / 16;
+            p2_v4u t[IPT];
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const uint64_t pv = ((uint64_t)phi << 32) | plo;
-            if (act[j]) {
-                if (p0 + j == 0) fail |= !(go[j] & GR_HAS);  // the anchor is the first k-mer
-                else fail |= !((pg & GR_HAS) && ((pg >> (uint32_t)(fw[j] & 3)) & 1) && fw[j] != pv);
+            for (int u = 0; u < IPT; ++u) {
+                const uint32_t o = (uint32_t)x.tid() + (uint32_t)u * NW * 64;
+                t[u] = src[o < n16 ? o : 0u];
             }
-            pg = go[j]; plo = (uint32_t)fw[j]; phi = (uint32_t)(fw[j] >> 32);
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                const uint32_t o = (uint32_t)x.tid() + (uint32_t)u * NW * 64;
+                if (o < n16) *reinterpret_cast<p2_v4u*>(&smb.img[o]) = t[u];
+            }
         }
-        const uint64_t failm = x.ballot(fail) | badm;
-        const uint64_t nkm = x.ballot(nk > 0);
-        const bool clean0 = (nkm & 1) && !(failm & 0xFFFFFFFFull), clean1 = ((nkm >> 32) & 1) && !(failm >> 32);
-        // (-a / -ae: the record holds both mates' alignments, so only a pair BOTH of whose mates thread cleanly is finished here — its
-        // strings are "len=" and the run lengths of the TR flags of its k-mers; any other pair goes on to the kernel that aligns)
-        if ((texting ? (clean0 && clean1) : (clean0 || clean1)) && !badm) {  // (uniform) the pair is kept: count the uncorrected k-mers of both mates (AQ.cpp:2189-2194)
-            // (a pair with a non-ACGT byte in either mate is passed on even when its other mate threads: the valid k-mers of the
-            // mate with the N count too, and which of its windows are valid is the other kernel's business)
-            c_feas += 2;
-            const uint32_t tb = T.trbeg[dst];
+        d1 = d2; d2 = desc(item + 2 * S);
+        ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
+        x.bsync();
+        const uint8_t* dsp = reinterpret_cast<const uint8_t*>(bks + (8u << lgnb));
+        while (cC.it == item) {
+            const uint32_t i = cC.i;  // place in the list
+            const uint64_t o0 = o0C, o1 = o1C;
+            uint32_t len = (uint32_t)(o1 - o0);
+            if (len > lmax) { if (a.errflag) *a.errflag = DBTK_ERR_READ_TOO_LONG; len = lmax; }
+            const uint64_t a0 = o0 & ~3ull;
+            const uint32_t rsh = (uint32_t)(o0 - a0);
+            const uint32_t dw0 = rw0, dw1 = rw1;
+            const uint32_t dst = x.uni(dstC);
+            {   // advance the pipeline
+                cC = cB; cB = cA; cA = next(cA);
+                const bool hasC = cC.it < nitems, hasB = cB.it < nitems;
+                o0C = hasC ? o0B : 0ull; o1C = hasC ? o1B : 0ull;
+                fetch_bytes(o0C, o1C);
+                dstC = dstB; dstB = dstA;
+                fetch_offsets(hasB ? x.uni(pairA) : x.uni(pairA) * 0u);
+                pairA = a.surv[at_of(cA)]; dstA = a.walk_dst[at_of(cA)];
+            }
+            if (dst == NAN32) continue;  // the pair never reached threading (uniform)
+            if (dst != locus) {          // (uniform, rare) voted to another locus than the list's order has it under: the other kernel's
+                if (lane == 0) sm.buf[W.nbuf] = i;
+                if (++W.nbuf == (uint32_t)WF_BUF) flush();
+                continue;
+            }
+            x.sync();
+            uint32_t bad = 0;
+            {
+                const uint32_t c0 = pack4_b2(dw0, &bad), c1 = pack4_b2(dw1, &bad);
+                reinterpret_cast<uint16_t*>(sm.pk[half])[hl ^ 1u] = (uint16_t)(((c0 >> 8) & 0xFF00u) | ((c1 >> 16) & 0xFFu));
+            }
+            const uint32_t nk = len >= k ? len - k + 1 : 0;
+            const uint64_t badm = x.ballot(bad != 0 && 8 * hl < rsh + len);
+            x.sync();
+            if (badm) {  // (uniform) a pair with a non-ACGT byte is the other kernel's whatever its mates do
+                if (lane == 0) sm.buf[W.nbuf] = i;
+                if (++W.nbuf == (uint32_t)WF_BUF) flush();
+                continue;
+            }
+            const uint64_t Wd = window_fw_clean(sm.pk[half], rsh + p0, 32);
+            const uint64_t RW = revcomp2(Wd, 32);
+            uint64_t fw[NPL], cn[NPL];
+            uint32_t gi[NPL], bo[NPL];
+            bool act[NPL];
+            uint4 tg[NPL];
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
-                const bool hit = act[j] && (gi[j] & GR_TR);
-                if (hit) x.atomic_add(&a.counts[tb + (gi[j] >> GR_SLOT_SHIFT)], 1ull);
-                c_inc += (uint64_t)__builtin_popcountll(x.ballot(hit));
+                fw[j] = (Wd >> (2 * (32 - k - j))) & kmask;
+                const uint64_t rc = (RW >> (2 * j)) & kmask;
+                cn[j] = fw[j] <= rc ? fw[j] : rc;
+                act[j] = p0 + j < nk;
+                bo[j] = dsp[loc_group((uint32_t)cn[j], (uint32_t)(cn[j] >> 32), lgnb)];
             }
-            if (lane == 0) {
-                a.walk_dst[i] = dst;
-                a.walk_ret[i] = (uint32_t)(uint8_t)(clean0 ? 1 : WALK_NOT_EVALUATED) | ((uint32_t)(uint8_t)(clean1 ? 1 : WALK_NOT_EVALUATED) << 8);
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) bo[j] = 8 * ((loc_base((uint32_t)cn[j], (uint32_t)(cn[j] >> 32), lgnb) + bo[j]) & ((1u << lgnb) - 1));
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) tg[j] = *reinterpret_cast<const uint4*>(bks + bo[j]);
+            bool any[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const uint32_t lo = (uint32_t)cn[j];
+                uint32_t sl = 0;
+                any[j] = false;
+                if (tg[j].x == lo) { sl = 0; any[j] = true; }
+                if (tg[j].y == lo) { sl = 1; any[j] = true; }
+                if (tg[j].z == lo) { sl = 2; any[j] = true; }
+                if (tg[j].w == lo) { sl = 3; any[j] = true; }
+                gi[j] = bks[bo[j] + 4 + sl];
             }
-            if (texting) {
-                // writeAnnot on cg.tr of a clean walk (one '=' / '.' per k-mer: is it a TR k-mer of the locus) = the run lengths of the
-                // flags; writeCigar on its cg.es (len matches) = "len=".  A run is printed by the lane of its last position: the flag of
-                // the position after it comes from the lane's own next position or, across lanes, from the ballot of first positions;
-                // where the run began is a max-scan over the positions where the flag changes (each mate's own scale, so that mate 1's
-                // scan never sees mate 0's).
-                bool f[NPL];
+            bool slow = false;
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) f[j] = (gi[j] & GR_TR) != 0;
-                const uint64_t f0m = x.ballot(f[0]);
-                const bool fnext = lane < 63 && ((f0m >> (lane + 1)) & 1);  // (lane 31's successor is mate 1's first: never looked at, p0 + NPL - 1 >= nk - 1 there or inactive)
-                const uint32_t scale = half ? 4096u : 0u;
-                uint32_t chg = 0;  // (index + 1 on the mate's scale) of the last position of this lane that starts a run
-                bool fp = x.shfl_up1(f[NPL - 1] ? 1u : 0u) != 0;
+            for (int j = 0; j < NPL; ++j) {
+                const uint32_t extra = (uint32_t)(cn[j] >> 32) >> lgnb, p = gi[j];
+                const bool ok = any[j] && (p >> 24) == extra && p != LOC_EMPTY;
+                slow |= act[j] && !ok && any[j];
+                gi[j] = !act[j] ? 0u : ok ? p : any[j] ? 0xFFFFFFFFu : 0u;
+            }
+            if (x.ballot(slow)) {  // (rare) a tag matched but not its entry: every slot of the bucket
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) {
-                    if (act[j] && (p0 + j == 0 || f[j] != fp)) chg = scale + p0 + j + 1;
-                    fp = f[j];
-                }
-                const uint32_t inc = x.wave_scan_max(chg);
-                uint32_t before = x.shfl_up1(inc);  // the last run start in the lanes before this one
-                if (lane == 0 || before < scale + 1) before = scale + 1;  // (a mate's position 0 always starts a run; lane 32 must not see mate 0)
-                uint32_t rl[NPL], ol[NPL], tot = 0;
-                uint32_t st = before;
-                fp = x.shfl_up1(f[NPL - 1] ? 1u : 0u) != 0;
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) {
-                    if (act[j] && (p0 + j == 0 || f[j] != fp)) st = scale + p0 + j + 1;
-                    fp = f[j];
-                    const bool nx = j + 1 < NPL ? f[j + 1] : fnext;
-                    const bool end = act[j] && (p0 + j + 1 == nk || nx != f[j]);
-                    rl[j] = end ? (scale + p0 + j + 1) - st + 1 : 0u;
-                    ol[j] = end ? (rl[j] >= 100 ? 3u : rl[j] >= 10 ? 2u : 1u) + 1u : 0u;
-                    tot += ol[j];
-                }
-                const uint32_t ex = x.wave_excl_scan(tot), la = x.half_sum(tot);
-                const uint32_t la0 = x.bcast(la, 0), la1 = x.bcast(la, 32);
-                const uint32_t len0 = x.bcast(len, 0), len1 = x.bcast(len, 32);  // (each half holds its own mate's length)
-                const uint32_t lc0 = (len0 >= 100 ? 3u : len0 >= 10 ? 2u : 1u) + 1u, lc1 = (len1 >= 100 ? 3u : len1 >= 10 ? 2u : 1u) + 1u;
-                const uint32_t tlen = lc1 + 1 + la1 + 1 + lc0 + 1 + la0, need = (8 + tlen + 3) & ~3u;
-                if (need > txt_left) {
-                    uint32_t b = 0;
-                    if (lane == 0) b = txt_carve(x, a);
-                    txt_base = x.bcast(b, 0);
-                    txt_left = TXT_CHUNK;
-                }
-                if ((uint64_t)txt_base + need <= a.txt_cap) {
-                    uint8_t* r = a.txt + txt_base;
-                    if (lane == 0) {  // header, mate 1's CIGAR, the three tabs, mate 0's CIGAR
-                        reinterpret_cast<uint32_t*>(r)[0] = dst;
-                        reinterpret_cast<uint32_t*>(r)[1] = tlen;
-                        a.txt_idx[a.surv[i]] = txt_base;
-                        uint32_t q = w_fmt_int(r, 8, (int)len1);
-                        r[q] = '='; r[q + 1] = '\t';
-                        r[8 + lc1 + 1 + la1] = '\t';
-                        q = w_fmt_int(r, 8 + lc1 + 1 + la1 + 1, (int)len0);
-                        r[q] = '='; r[q + 1] = '\t';
+                for (int j = 0; j < NPL; ++j)
+                    if (gi[j] == 0xFFFFFFFFu) {
+                        const uint32_t lo = (uint32_t)cn[j], extra = (uint32_t)(cn[j] >> 32) >> lgnb;
+                        const uint32_t* bk = bks + bo[j];
+                        uint32_t p = 0;
+                        for (int s2 = 0; s2 < 4; ++s2) {
+                            const uint32_t q = bk[4 + s2];
+                            if (bk[s2] == lo && (q >> 24) == extra && q != LOC_EMPTY) p = q;
+                        }
+                        gi[j] = p;
                     }
-                    uint32_t o = half ? 8 + lc1 + 1 + (ex - la0) : 8 + lc1 + 1 + la1 + 1 + lc0 + 1 + ex;
-#pragma unroll
-                    for (int j = 0; j < NPL; ++j)
-                        if (ol[j]) { const uint32_t q = w_fmt_int(r, o, (int)rl[j]); r[q] = f[j] ? '=' : '.'; o += ol[j]; }
-                } else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
-                txt_base += need; txt_left -= need;
             }
-        } else {
-            if (lane == 0) sm.buf[nbuf] = i;
-            if (++nbuf == (uint32_t)WF_BUF) flush();
+            // the image's pay word -> the graph table's info word: the flags as they are, the counter back at GR_SLOT_SHIFT (the extra tag bits dropped)
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) gi[j] &= 0x00FFFFFFu;
+            wf_decide<NPL>(x, a, i, dst, len, nk, badm, fw, cn, gi, act, sm.buf, W, flush, texting, smb.cnt, WFL_CNT);
         }
     }
-    if (nbuf) flush();
+    x.bsync();
+    flush_counts();
+    if (W.nbuf) flush();
     if (lane == 0) {
-        if (c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], c_feas);
-        if (c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], c_inc);
+        if (W.c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], W.c_feas);
+        if (W.c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], W.c_inc);
     }
 }
 

@@ -499,6 +499,13 @@ class Emu(pkg._HostSide):
         self.L.emu_probe_stats(out.ctypes.data_as(u64p))
         return int(out[0]), int(out[1]), int(out[2])
 
+    def walk_locus_stats(self):
+        """(pairs the lean walk body took in its locus-resident form, pairs left to its plain form) since the last call"""
+        out = np.zeros(2, np.uint64)
+        self.L.emu_walk_locus_stats.argtypes = [u64p]
+        self.L.emu_walk_locus_stats(out.ctypes.data_as(u64p))
+        return int(out[0]), int(out[1])
+
     def locus_stats(self):
         """(pairs the locus-resident probe body took in each of its three classes of workgroup, pairs left to the lean body) since
         the last call; keys the last tables' images left out"""

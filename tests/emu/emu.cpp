@@ -302,8 +302,8 @@ struct EmuTables {
     std::vector<GrSlot> gr;
     std::vector<MzBucket> mz, grmz;
     std::vector<MzSlot> ovf;
-    std::vector<LocusDir> ldir;
-    std::vector<uint64_t> limg;  // (8-byte words: the images are read 16 bytes at a time)
+    std::vector<LocusDir> ldir, gldir;
+    std::vector<uint64_t> limg, glimg;  // (8-byte words: the images are read 16 bytes at a time)
     uint64_t stats[3] = {0, 0, 0};
     DevTables T;
 };
@@ -311,6 +311,7 @@ struct EmuTables {
 }  // namespace
 
 static uint64_t g_probe_runs[2] = {0, 0}, g_mz_turned = 0, g_walk_fast_runs = 0, g_walk_slow_pairs = 0;
+static uint64_t g_wfl_pairs[2] = {0, 0};  // pairs the lean walk kernel took in its locus-resident form / left to its plain form
 static uint64_t g_loc_left = 0;  // keys the last tables' images left out
 static uint64_t g_loc_pairs[4] = {0, 0, 0, 0};  // pairs the locus-resident kernel took in its three classes of workgroup, pairs left to the lean kernel
 extern "C" {
@@ -460,6 +461,41 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
             GrMzBuildArgs ga{e->gr.data(), cap, e->grmz.data(), (uint32_t)(nb - 1), g->ksize, mz_m_for_k(g->ksize)};
             run_grid(3, 64, 0, [&](EmuX& x) { body_grmz_insert(x, ga); });
             T.grmz = e->grmz.data(); T.grmz_mask = nb - 1;
+        }
+        // the graph images (as build_graph_images on the device); every third locus without one here, as for the index images
+        if (T.grmz && loc_lg_min(g->ksize) <= LOC_LG_MAX && (!getenv("DBTK_LOCUS") || atoi(getenv("DBTK_LOCUS")))) {
+            std::vector<uint32_t> cnt(nloci, 0), bad(nloci, 0);
+            LocBuildArgs a;
+            memset(&a, 0, sizeof(a));
+            a.gr = e->gr.data(); a.gr_nslots = cap; a.trbeg = e->trbeg.data(); a.nloci = (uint32_t)nloci; a.ksize = g->ksize;
+            a.cnt = cnt.data(); a.bad = bad.data();
+            run_grid(3, 64, 0, [&](EmuX& x) { body_gloc_count(x, a); });
+            e->gldir.assign(nloci, LocusDir{0, 0, 0, 0});
+            std::vector<uint64_t> ebeg(nloci + 1, 0);
+            uint64_t at = 0;
+            for (uint64_t l = 0; l < nloci; ++l) {
+                const uint32_t lg = loc_lgnb_for(cnt[l], g->ksize);
+                e->gldir[l] = LocusDir{(uint32_t)(at / 16), 0u, lg, e->trbeg[l]};
+                ebeg[l + 1] = ebeg[l];
+                if (!cnt[l] || lg > LOC_LG_MAX || cnt[l] > 0xFFF0u || l % 3 == 1 || e->trbeg[l + 1] - e->trbeg[l] >= GLOC_SLOT_MAX) continue;
+                e->gldir[l].bytes = loc_image_bytes(lg);
+                at += e->gldir[l].bytes;
+                ebeg[l + 1] += cnt[l];
+            }
+            e->glimg.assign(at / 8 + 2, 0);
+            const uint64_t nent = ebeg[nloci];
+            const uint32_t gstride = 2 * (1u << LOC_LG_MAX) + 2;
+            std::vector<uint64_t> ekey(nent + 1), skey(nent + 1);
+            std::vector<uint32_t> epay(nent + 1), spay(nent + 1), ecur(nloci, 0);
+            std::vector<uint16_t> gscr(nloci * (size_t)gstride, 0);
+            uint64_t nleft = 0;
+            a.dir = e->gldir.data(); a.arena = reinterpret_cast<uint8_t*>(e->glimg.data());
+            a.ebeg = ebeg.data(); a.ecur = ecur.data(); a.ekey = ekey.data(); a.epay = epay.data(); a.skey = skey.data(); a.spay = spay.data();
+            a.gscr = gscr.data(); a.gstride = gstride; a.nleft = &nleft;
+            run_grid(3, 64, 0, [&](EmuX& x) { body_gloc_scatter(x, a); });
+            run_grid(2, 64, 0, [&](EmuX& x) { body_loc_place(x, a); });
+            for (uint64_t l = 0; l < nloci; ++l) if (bad[l] || nleft) e->gldir[l].bytes = 0;
+            T.gldir = e->gldir.data(); T.glimg = reinterpret_cast<const uint8_t*>(e->glimg.data());
         }
     }
     return e;
@@ -707,6 +743,7 @@ void emu_locus_stats(uint64_t* out) { for (int i = 0; i < 4; ++i) { out[i] = g_l
 void emu_probe_stats(uint64_t* out) { out[0] = g_probe_runs[0]; out[1] = g_probe_runs[1]; out[2] = g_mz_turned; g_probe_runs[0] = g_probe_runs[1] = 0; }
 // pair-mode walks since the last call: runs of the lean first kernel, pairs it passed on to the second
 void emu_walk_stats(uint64_t* out) { out[0] = g_walk_fast_runs; out[1] = g_walk_slow_pairs; g_walk_fast_runs = g_walk_slow_pairs = 0; }
+void emu_walk_locus_stats(uint64_t* out) { out[0] = g_wfl_pairs[0]; out[1] = g_wfl_pairs[1]; g_wfl_pairs[0] = g_wfl_pairs[1] = 0; }
 int emu_align(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, const uint8_t* seq, const uint64_t* off,
               uint64_t npairs, uint64_t* counts, uint64_t* kmc, uint32_t* nmapread, uint64_t* counters,
               dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec, uint32_t grid_k1, uint32_t grid_pair) {
@@ -810,7 +847,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
             ia.nitems = nit; ia.item_cap = item_cap; ia.rest = rest.data();
             run_grid(2, 64, 0, [&](EmuX& x) { body_loc_items(x, ia); });
             run_grid(2, 128, 0, [&](EmuX& x) { body_loc_rest(x, ia); });
-            LocRunArgs r0{a.T.ldir, a.T.limg, items[0].data(), &nit[0]}, r1{a.T.ldir, a.T.limg, items[1].data(), &nit[1]}, r2{a.T.ldir, a.T.limg, items[2].data(), &nit[2]};
+            LocRunArgs r0{a.T.ldir, a.T.limg, items[0].data(), &nit[0], rest.data(), &nit[3]}, r1{a.T.ldir, a.T.limg, items[1].data(), &nit[1], rest.data(), &nit[3]}, r2{a.T.ldir, a.T.limg, items[2].data(), &nit[2], rest.data(), &nit[3]};
             if (npl == 3) {
                 run_grid(2, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_XS>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_XS>(x, a, r0); });
                 run_grid(3, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_S>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_S>(x, a, r1); });
@@ -877,8 +914,37 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         uint32_t nslow = 0;
         const uint32_t kk = g->ksize;
         const int wnpl = (((p->aln & 3u) && !txtmode) || g_walk_trecs) ? 0 : walkfast_npl(maxlen, kk, w.T.grmz != nullptr);
+        std::vector<uint4> witems[3];
+        std::vector<uint32_t> wrest(npairs + 64, 0);
+        uint32_t wnit[4] = {0, 0, 0, 0};
         if (wnpl) {
             w.slow_list = slow.data(); w.nslow = &nslow;
+            if (w.T.gldir) {  // the locus-resident form first, as launch_batch does (4 waves per workgroup here)
+                constexpr int EMU_IMGB_XS = LOC_HDR + (32 << 9) + (1 << 9), EMU_IMGB_S = LOC_HDR + (32 << 10) + (1 << 10), EMU_IMGB_L = LOC_HDR + (32 << LOC_LG_MAX) + (1 << LOC_LG_MAX);
+                const uint32_t item_cap = (uint32_t)(npairs / LOC_CH + nloci + 2);
+                for (int q = 0; q < 3; ++q) witems[q].assign(item_cap, uint4{0, 0, 0, 0});
+                LocItemArgs ia;
+                memset(&ia, 0, sizeof(ia));
+                ia.hist = shist.data(); ia.nsurv = &small[0]; ia.flag = &small[1]; ia.dir = w.T.gldir; ia.nloci = (uint32_t)nloci; ia.t0 = 0; ia.tcap = (uint32_t)(npairs ? npairs : 1);
+                ia.cap_bytes[0] = EMU_IMGB_XS; ia.cap_bytes[1] = EMU_IMGB_S; ia.cap_bytes[2] = EMU_IMGB_L;
+                for (int q = 0; q < 3; ++q) ia.items[q] = witems[q].data();
+                ia.nitems = wnit; ia.item_cap = item_cap; ia.rest = wrest.data();
+                run_grid(2, 64, 0, [&](EmuX& x) { body_loc_items(x, ia); });
+                run_grid(2, 128, 0, [&](EmuX& x) { body_loc_rest(x, ia); });
+                LocRunArgs r0{w.T.gldir, w.T.glimg, witems[0].data(), &wnit[0], nullptr, nullptr}, r1{w.T.gldir, w.T.glimg, witems[1].data(), &wnit[1], nullptr, nullptr}, r2{w.T.gldir, w.T.glimg, witems[2].data(), &wnit[2], nullptr, nullptr};
+                if (wnpl == 3) {
+                    run_grid(2, 4 * 64, sizeof(WalkFastLocSmemT<3, 4, EMU_IMGB_XS>), [&](EmuX& x) { body_walk_fast_locus<3, 4, EMU_IMGB_XS>(x, w, r0); });
+                    run_grid(3, 4 * 64, sizeof(WalkFastLocSmemT<3, 4, EMU_IMGB_S>), [&](EmuX& x) { body_walk_fast_locus<3, 4, EMU_IMGB_S>(x, w, r1); });
+                    run_grid(2, 4 * 64, sizeof(WalkFastLocSmemT<3, 4, EMU_IMGB_L>), [&](EmuX& x) { body_walk_fast_locus<3, 4, EMU_IMGB_L>(x, w, r2); });
+                } else {
+                    run_grid(2, 4 * 64, sizeof(WalkFastLocSmemT<5, 4, EMU_IMGB_XS>), [&](EmuX& x) { body_walk_fast_locus<5, 4, EMU_IMGB_XS>(x, w, r0); });
+                    run_grid(3, 4 * 64, sizeof(WalkFastLocSmemT<5, 4, EMU_IMGB_S>), [&](EmuX& x) { body_walk_fast_locus<5, 4, EMU_IMGB_S>(x, w, r1); });
+                    run_grid(2, 4 * 64, sizeof(WalkFastLocSmemT<5, 4, EMU_IMGB_L>), [&](EmuX& x) { body_walk_fast_locus<5, 4, EMU_IMGB_L>(x, w, r2); });
+                }
+                for (int c = 0; c < 3; ++c) for (uint32_t q = 0; q < wnit[c]; ++q) g_wfl_pairs[0] += witems[c][q].z - witems[c][q].y;
+                g_wfl_pairs[1] += wnit[3];
+                w.sel = wrest.data(); w.nsel = &wnit[3];
+            }
             const bool w11 = w.T.grmz && kk - mz_m_for_k(kk) + 1 == 11;
             if (wnpl == 3) {
                 if (w11) run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<3>), [&](EmuX& x) { body_walk_fast<3, 11>(x, w); });

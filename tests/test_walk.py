@@ -429,7 +429,11 @@ def test_emulated_pair_mode_equals_oracle(tmp_path, k, seed):
         e = E.align(g, tb, p, seq, off)
         res, nres = E.walk_results(len(off))
         return dict(counts=e["counts"], counters=e["counters"], res=res, nres=nres, aln=E.aln_records(), order=order, txt=E.aln_text(len(off) // 2))
+    E.walk_locus_stats()
     check_pair_mode(run, O, oh, case, k, case.loci.nloci)
+    img, plain = E.walk_locus_stats()
+    print(f"k={k}: lean walk body: {img} pairs with the graph image in LDS, {plain} from the global tables")
+    assert (img > 0 and plain > 0) if k != 17 else img == 0  # (graph images exist where the minimizer-grouped tables do)
 
 
 # read lengths either side of what a half-wave of the lean walk kernel covers (walkfast_npl, dbtk_walkfast.h): with the minimizer-grouped
