@@ -622,11 +622,12 @@ int main(int argc, char* argv[]) {
     struct Left { std::string title, seq, qual; };
     int npipes = 1;  // ingest pipelines running side by side (set once the ranges are known)
     int nshards_now = 1;
+    FILE* handover_stream = nullptr;  // a pipe the device reader has read from: what it took but did not pair, then the rest of the pipe
     auto run_shard = [&](const int shard, const int gpu0, const int ngpu_here, const uint64_t lo, const uint64_t hi, std::vector<Left>& leftovers) {
     Reader in;
-    in.f = fopen(o.fastxFname.c_str(), "rb");
+    in.f = handover_stream ? handover_stream : fopen(o.fastxFname.c_str(), "rb");
     if (!in.f) die_assert("cannot open " + o.fastxFname);
-    if (lo && fseeko(in.f, (off_t)lo, SEEK_SET)) die_assert("cannot seek in " + o.fastxFname);
+    if (!handover_stream && lo && fseeko(in.f, (off_t)lo, SEEK_SET)) die_assert("cannot seek in " + o.fastxFname);
     uint64_t remaining = hi - lo;  // bytes of this range still to read
     uint64_t nReads = 0;
     double read_busy = 0, cut_busy = 0, pair_busy = 0, gpu_busy = 0, write_busy = 0;
@@ -1021,7 +1022,10 @@ int main(int argc, char* argv[]) {
     // block that is not a run of adjacent mates ends it: *resume = the input offset the host reader (run_shard: splitters +
     // park-by-title pairing) continues from — up to there every record was paired, so nothing is parked there, exactly as in
     // the reference's reader at that point.  Records (kam lines, -e) are written from the spans the device made, in file order.
-    auto run_device_ingest = [&](dbtk_ctx_t* cx, const uint64_t lo, const uint64_t hi, uint64_t* resume) {
+    // A pipe (`samtools fasta ... | danbing-tk ... -fa /dev/stdin`, the README's command line) is read the same way by ONE thread, chunk
+    // after chunk (a chunk is submitted once it is known whether another follows); when the host reader has to take over, the bytes
+    // already taken from the pipe but not paired go to *replay and the open descriptor to *pipe_fd: the host reader continues there.
+    auto run_device_ingest = [&](dbtk_ctx_t* cx, const uint64_t lo, const uint64_t hi, uint64_t* resume, const bool piped, std::string* replay, int* pipe_fd) {
         size_t CH = 32u << 20;
         if (const char* e = getenv("DBTK_INGEST_CHUNK")) { const long v = atol(e); if (v >= 4096) CH = (size_t)v; }  // (tests: many small blocks)
         const bool want_out = want_recs || emit_aln;  // records need titles and reads on the host: the slot's bytes stay until they are written
@@ -1036,13 +1040,64 @@ int main(int argc, char* argv[]) {
         double first_s = 0, wait_s = 0;
         const int fd = open(o.fastxFname.c_str(), O_RDONLY);
         if (fd < 0) die_assert("cannot open " + o.fastxFname);
-        const uint64_t total = hi - lo, nchunks = std::max<uint64_t>(1, (total + CH - 1) / CH);
+#ifdef F_SETPIPE_SZ
+        if (piped) (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);  // (a larger pipe buffer: fewer wake-ups of the producer; refused for a non-pipe, which is fine)
+#endif
+        const uint64_t total = piped ? 0 : hi - lo;
+        uint64_t nchunks = piped ? ~0ull : std::max<uint64_t>(1, (total + CH - 1) / CH);  // (a pipe: known once its end has been read)
         std::mutex m;
         std::condition_variable cv;
-        std::vector<char> filled(nchunks, 0);
+        std::vector<char> filled(piped ? 0 : nchunks, 0);
+        std::vector<uint64_t> chunk_n(piped ? 0 : nchunks, 0);  // bytes of each chunk
+        if (!piped) for (uint64_t j = 0; j < nchunks; ++j) chunk_n[j] = std::min<uint64_t>(CH, total - j * CH);
         uint64_t next_read = 0, nreleased = 0;
         bool stop = false;
         double rb = 0, gb = 0, wb = 0;
+        uint64_t pipe_cur = 0;  // (pipe) the chunk being read when the reader was told to stop
+        auto io_pipe = [&] {  // sequential: chunk j is handed on once chunk j + 1 has its first byte, or the pipe has ended
+            uint64_t j = 0;
+            bool have_byte = false;  // chunk j already holds bytes read as the look-ahead behind chunk j - 1
+            size_t got = 0;
+            for (;;) {
+                {
+                    std::unique_lock<std::mutex> l(m);
+                    cv.wait(l, [&] { return stop || j < nreleased + NS; });
+                    if (filled.size() <= j) { filled.resize(j + 1, 0); chunk_n.resize(j + 1, 0); }
+                    if (stop) { chunk_n[j] = got; pipe_cur = j; return; }
+                }
+                const double t0 = now();
+                char* dst = (char*)dbtk_ingest_chunk_buffer(ing, (uint32_t)(j % NS));
+                if (!have_byte) got = 0;
+                bool eof = false;
+                while (got < CH) {
+                    const ssize_t r = read(fd, dst + got, CH - got);
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r < 0) die_assert("read error on " + o.fastxFname);
+                    if (r == 0) { eof = true; break; }
+                    got += (size_t)r;
+                    if (have_byte || got == (size_t)r) {  // the first bytes of this chunk: the chunk before it is not the last one
+                        std::lock_guard<std::mutex> l(m);
+                        if (j > 0 && filled[j - 1] == 2) { filled[j - 1] = 1; cv.notify_all(); }
+                        have_byte = false;
+                    }
+                    { std::lock_guard<std::mutex> l(m); if (stop) { chunk_n[j] = got; pipe_cur = j; return; } }
+                }
+                {
+                    std::lock_guard<std::mutex> l(m);
+                    rb += now() - t0;
+                    chunk_n[j] = got;
+                    if (eof) {
+                        if (got == 0 && j > 0) { nchunks = j; if (filled[j - 1] == 2) filled[j - 1] = 1; }  // the chunk before was the last
+                        else { nchunks = j + 1; if (j > 0 && filled[j - 1] == 2) filled[j - 1] = 1; filled[j] = 1; }
+                        pipe_cur = j;
+                        cv.notify_all();
+                        return;
+                    }
+                    filled[j] = 2;  // full: whether it is the last one shows with the next read
+                }
+                ++j; got = 0; have_byte = false;
+            }
+        };
         auto io = [&] {
             for (;;) {
                 uint64_t j;
@@ -1071,9 +1126,10 @@ int main(int argc, char* argv[]) {
             }
         };
         std::vector<std::thread> ios;
-        int nio = (int)std::min<uint64_t>(nchunks, std::max(1u, std::min(8u, cpus / 2 / (unsigned)std::max(1, npipes))));  // (the pipelines share the host's threads)
-        if (const char* e = getenv("DBTK_INGEST_READERS")) { const int v = atoi(e); if (v > 0) nio = v; }
-        for (int i = 0; i < nio; ++i) ios.emplace_back(io);
+        int nio = piped ? 1 : (int)std::min<uint64_t>(nchunks, std::max(1u, std::min(8u, cpus / 2 / (unsigned)std::max(1, npipes))));  // (the pipelines share the host's threads)
+        if (const char* e = getenv("DBTK_INGEST_READERS")) { const int v = atoi(e); if (v > 0 && !piped) nio = v; }
+        if (piped) ios.emplace_back(io_pipe);
+        else for (int i = 0; i < nio; ++i) ios.emplace_back(io);
         auto release = [&] { { std::lock_guard<std::mutex> l(m); ++nreleased; } cv.notify_all(); };
         Chan<std::unique_ptr<Batch>> outq;
         outq.cap = NS;
@@ -1136,28 +1192,33 @@ int main(int argc, char* argv[]) {
             for (dbtk_ctx_t* wc : wctx) workers.emplace_back([&, wc] { Work w; while (wq.pop(w)) process(wc, w); });
         uint64_t jsub = 0, jaln = 0, nR = 0;
         *resume = hi;
+        bool handed = false;   // the host reader takes over
+        uint32_t hslot = 0;
         const bool sync = want_out || P.bubbles;  // (-bu replays every batch's novel edges on the host)
         while (jaln < nchunks) {
             for (;;) {  // submit what has been read, up to NS - 1 blocks ahead of the one about to be aligned — and never block i before block
                         // i + 1 - NS has been released: parsing block i puts its carried-over bytes in front of the NEXT slot's device block,
                         // which until then still holds the first record of the block that is being written from it
+                uint64_t nb = 0;
+                bool last_one = false;
                 {
                     std::unique_lock<std::mutex> l(m);
-                    auto can = [&] { return jsub < nchunks && jsub < jaln + NS && filled[jsub] != 0 && jsub + 1 < nreleased + NS; };
-                    if (jsub == jaln) cv.wait(l, can);
-                    else if (!can()) break;
+                    auto can = [&] { return jsub < nchunks && jsub < jaln + NS && jsub < filled.size() && filled[jsub] == 1 && jsub + 1 < nreleased + NS; };
+                    if (jsub == jaln) cv.wait(l, [&] { return can() || jaln >= nchunks; });
+                    if (!can()) break;
+                    nb = chunk_n[jsub]; last_one = jsub + 1 == nchunks;
                 }
-                const uint64_t nb = std::min<uint64_t>(CH, total - jsub * CH);
-                if (dbtk_ingest_submit(ing, (uint32_t)(jsub % NS), nb, jsub + 1 == nchunks)) die_assert(std::string("ingest: ") + dbtk_last_error());
+                if (dbtk_ingest_submit(ing, (uint32_t)(jsub % NS), nb, last_one)) die_assert(std::string("ingest: ") + dbtk_last_error());
                 ++jsub;
             }
+            if (jsub <= jaln) break;  // (a pipe that ended on a chunk boundary: nothing more was submitted)
             const double t0 = now();
             const uint32_t slot = (uint32_t)(jaln % NS);
             dbtk_ingest_info_t info;
             if (dbtk_ingest_wait(ing, slot, &info)) die_assert(std::string("ingest: ") + dbtk_last_error());
             wait_s += now() - t0;
             if (jaln == 0) first_s = now() - ts0;
-            if (info.flags & (DBTK_ING_DIRTY | DBTK_ING_LINES)) { *resume = lo + info.first_byte; std::lock_guard<std::mutex> l(gb_m); gb += now() - t0; break; }
+            if (info.flags & (DBTK_ING_DIRTY | DBTK_ING_LINES)) { *resume = lo + info.first_byte; handed = true; hslot = slot; std::lock_guard<std::mutex> l(gb_m); gb += now() - t0; break; }
             if (want_out) {
                 { std::lock_guard<std::mutex> l(gb_m); gb += now() - t0; }
                 const Work w{jaln, slot, info};
@@ -1169,7 +1230,7 @@ int main(int argc, char* argv[]) {
             }
             nR += 2 * (uint64_t)info.nkept;
             fprintf(stderr, "Buffered reading %llu\t%llu\t%d\n", 2 * (unsigned long long)info.nkept, (unsigned long long)nR, 0);
-            if (info.flags) { *resume = lo + info.cut_byte; break; }
+            if (info.flags) { *resume = lo + info.cut_byte; handed = true; hslot = slot; break; }
             ++jaln;
         }
         wq.close();
@@ -1177,12 +1238,24 @@ int main(int argc, char* argv[]) {
         { std::lock_guard<std::mutex> l(m); stop = true; }
         cv.notify_all();
         for (auto& t : ios) t.join();
+        if (piped && handed) {
+            // what was taken from the pipe from byte *resume on: the rest of the flagged block (its chunk, and in front of it the bytes
+            // carried over from the block before), then the chunks read behind it, in order; the pipe itself goes on from there
+            const uint64_t c0 = jaln * (uint64_t)CH;  // input offset of the flagged block's chunk (every chunk before it was full)
+            const char* cp = (const char*)dbtk_ingest_chunk_buffer(ing, hslot);
+            const uint64_t from = *resume - lo;
+            const int64_t rel = (int64_t)from - (int64_t)c0;  // (negative: inside the carried-over bytes in front of the chunk)
+            replay->assign(cp + rel, cp + (jaln < chunk_n.size() ? chunk_n[jaln] : 0));
+            for (uint64_t j = jaln + 1; j < chunk_n.size() && j <= pipe_cur; ++j)
+                if (chunk_n[j]) replay->append((const char*)dbtk_ingest_chunk_buffer(ing, (uint32_t)(j % NS)), chunk_n[j]);
+            *pipe_fd = fd;
+        } else if (piped && !handed) *resume = hi;
         outq.close();
         if (writer.joinable()) writer.join();
         const double tf0 = now();
         for (dbtk_ctx_t* wc : wctx) if (dbtk_ctx_synchronize(wc)) die_assert(dbtk_last_error());  // the kernels still in flight
         { std::lock_guard<std::mutex> lk(tot_m); spent_ingests.push_back(ing); }  // (its pinned and device buffers are freed at exit, not inside the batch loop)
-        close(fd);
+        if (!(piped && handed)) close(fd);
         fprintf(stderr, "device reader: %llu blocks of %zu MB on %d reader threads; setup %.3f s, first block parsed after %.3f s, waiting for parsed blocks %.3f s, drain %.3f s\n",
                 (unsigned long long)jaln, CH >> 20, nio, setup_s, first_s, wait_s, now() - tf0);
         std::lock_guard<std::mutex> lk(tot_m);
@@ -1279,17 +1352,33 @@ int main(int argc, char* argv[]) {
         const bool is_file = stat(o.fastxFname.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
         // (-a / -ae: the lines are assembled and gzip-compressed on the device too — a Huffman-only deflate, about zlib's level 1 in size; an
         // explicit --gz-level other than 1 keeps the host's zlib, and with it the host reader)
-        bool dev_ingest = !o.parseOnly && !o.hostIngest && !o.simmode && !P.trackbait && (!emit_aln || o.gzLevel == 1) && is_file;
+        bool dev_ingest = !o.parseOnly && !o.hostIngest && !o.simmode && !P.trackbait && (!emit_aln || o.gzLevel == 1) && (is_file || nshards == 1);
         if (const char* e = getenv("DBTK_DEVICE_INGEST")) if (atoi(e) == 0) dev_ingest = false;
         auto one = [&](int i) {
             uint64_t lo = nshards == 1 ? 0 : cuts[i];
             const uint64_t hi = nshards == 1 ? (is_file ? (uint64_t)sb.st_size : ~0ull) : cuts[i + 1];
             if (dev_ingest) {
                 uint64_t resume = lo;
-                run_device_ingest(ctx[i], lo, hi, &resume);
+                std::string replay;
+                int pfd = -1;
+                run_device_ingest(ctx[i], lo, hi, &resume, !is_file, &replay, &pfd);
                 if (resume >= hi) return;
                 fprintf(stderr, "device reader: input is not interleaved at byte %llu; the host reader takes over\n", (unsigned long long)resume);
                 lo = resume;
+                if (!is_file) {  // the pipe cannot be read again: a stream of what was taken but not paired, then the descriptor
+                    struct Cookie { std::string pre; size_t at; int fd; };
+                    Cookie* ck = new Cookie{std::move(replay), 0, pfd};
+                    cookie_io_functions_t fn;
+                    memset(&fn, 0, sizeof(fn));
+                    fn.read = [](void* c, char* buf, size_t n) -> ssize_t {
+                        Cookie* k = (Cookie*)c;
+                        if (k->at < k->pre.size()) { const size_t m2 = std::min(n, k->pre.size() - k->at); memcpy(buf, k->pre.data() + k->at, m2); k->at += m2; return (ssize_t)m2; }
+                        for (;;) { const ssize_t r = read(k->fd, buf, n); if (r < 0 && errno == EINTR) continue; return r; }
+                    };
+                    fn.close = [](void* c) -> int { Cookie* k = (Cookie*)c; close(k->fd); delete k; return 0; };
+                    handover_stream = fopencookie(ck, "rb", fn);
+                    if (!handover_stream) die_assert("fopencookie failed");
+                }
             }
             const auto r = nshards == 1 ? run_shard(0, 0, o.parseOnly ? o.ngpus : (int)ctx.size(), lo, ~0ull, lefts[0]) : run_shard(i, i, 1, lo, hi, lefts[i]);
             std::lock_guard<std::mutex> lk(tot_m);

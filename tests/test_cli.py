@@ -312,6 +312,59 @@ def test_cli_aln_gz_is_the_stdout_stream(tmp_path):
     assert open(os.path.join(w, "envsw.trkmc.ar"), "rb").read() == open(os.path.join(d, "refae.trkmc.ar"), "rb").read()
 
 
+@pytest.mark.gpu
+def test_cli_readme_pipe_takes_the_device_reader(tmp_path):
+    """/root/reference/README.md:38-39: `samtools fasta -n ... | danbing-tk -gc 85 3 -ae ... -fa /dev/stdin | gzip`.  Reads arriving
+    through a PIPE are parsed, paired, walked and formatted on the device like those of a file (stderr says so), stdout is the golden
+    -ae stream of g5, whatever the chunking; and a pipe whose records stop being interleaved halfway is handed over to the host reader
+    at exactly that byte (the bytes already taken from the pipe are replayed to it): same stdout and counts as from the file."""
+    d, _ = golden_cmds("g5_walk_k25")
+    w = str(tmp_path / "w")
+    shutil.copytree(d, w)
+    want = open(os.path.join(d, "refae.aln.txt"), "rb").read()
+    base = ["-gc", "85", "3", "-ae", "-ka", "-k", "25", "-cth", "45", "-fa", "/dev/stdin", "-qs", "pan", "-o"]
+    data = open(os.path.join(w, "reads.fa"), "rb").read()
+    for tag, chunk in (("p0", None), ("p1", "60000"), ("p2", "4096")):
+        env = dict(os.environ, DBTK_V13_THREADING="1")
+        if chunk:
+            env.update(DBTK_INGEST_CHUNK=chunk, DBTK_INGEST_SLOTS="3")
+        # (a real pipe: `cat` feeds it)
+        cat = subprocess.Popen(["cat", "reads.fa"], cwd=w, stdout=subprocess.PIPE)
+        r = subprocess.run([CLI] + base + [tag], cwd=w, stdin=cat.stdout, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        cat.wait()
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert r.stdout == want
+        assert open(os.path.join(w, tag + ".trkmc.ar"), "rb").read() == open(os.path.join(d, "refae.trkmc.ar"), "rb").read()
+        dev = [l for l in r.stderr.decode().splitlines() if l.startswith("device reader:")]
+        assert dev and "takes over" not in r.stderr.decode(), r.stderr.decode()[-1500:]
+    # a chunk boundary exactly at the end of the input (the look-ahead read finds the pipe closed), and an empty pipe
+    r = subprocess.run([CLI] + base + ["pe"], cwd=w, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, DBTK_V13_THREADING="1", DBTK_INGEST_CHUNK=str(len(data))))
+    assert r.returncode == 0 and r.stdout == want, r.stderr.decode()[-1500:]
+    r = subprocess.run([CLI] + base + ["pz"], cwd=w, input=b"", stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, DBTK_V13_THREADING="1"))
+    assert r.returncode == 0 and r.stdout == b"", r.stderr.decode()[-1500:]
+    # not interleaved from the middle on: records 2q, 2q + 1 of the second half swapped with their neighbours' so that mates are two apart
+    recs = [l for l in data.split(b">") if l]
+    half = (len(recs) // 4) * 2
+    tail = recs[half:]
+    mixed = recs[:half]
+    for q in range(0, len(tail) - 3, 4):
+        mixed += [tail[q], tail[q + 2], tail[q + 1], tail[q + 3]]
+    mixed += tail[len(tail) - len(tail) % 4:]
+    blob = b"".join(b">" + x for x in mixed)
+    open(os.path.join(w, "mixed.fa"), "wb").write(blob)
+    rf = subprocess.run([CLI] + base[:-5] + ["-fa", "mixed.fa", "-qs", "pan", "-o", "mf", "--host-ingest"], cwd=w, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                        env=dict(os.environ, DBTK_V13_THREADING="1"))
+    assert rf.returncode == 0, rf.stderr.decode()[-1500:]
+    for chunk in ("60000", "5000"):
+        rp = subprocess.run([CLI] + base + ["mp"], cwd=w, input=blob, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            env=dict(os.environ, DBTK_V13_THREADING="1", DBTK_INGEST_CHUNK=chunk, DBTK_INGEST_SLOTS="3"))
+        assert rp.returncode == 0, rp.stderr.decode()[-1500:]
+        assert b"the host reader takes over" in rp.stderr
+        assert sorted(rp.stdout.splitlines()) == sorted(rf.stdout.splitlines())
+        assert open(os.path.join(w, "mp.trkmc.ar"), "rb").read() == open(os.path.join(w, "mf.trkmc.ar"), "rb").read()
+
+
 # ---- the ingest (reader, splitters, pairing) on the CPU: `--parse-only` reports what the pairing stage handed on --------
 def _digest(reads, fastq):
     """pairs, bases and the order-independent digest dbtk_cli.cpp computes with --parse-only, from tests/refio.py's restatement
