@@ -219,6 +219,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # test-only (a one-GPU box): every rank on device 0, the reduce over gloo through host staging (RCCL refuses two ranks on one
+    # device) — the N > 1 code of this file (sharded read sets, barriers, MAX over ranks, the accumulators' all-reduce) then runs
+    # with two real ranks; no scaling number comes out of it
+    one_device = os.environ.get("DBTK_BENCH_ALL_ON_DEVICE0") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ranks_seen = 1
@@ -226,7 +232,10 @@ def main():
     # exercise exactly that code on a one-GPU box, under a launcher with DBTK_BENCH_FORCE_DIST=1 (a world of one)
     use_dist = world > 1 or (os.environ.get("DBTK_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         ranks_seen = dist.get_world_size()
 
     os.environ["DBTK_LANES"] = str(args.lanes)
@@ -302,7 +311,9 @@ def main():
             acc_inplace = acc_t.data_ptr() == acc_ptr
         except Exception:
             acc_inplace = False
-        if not acc_inplace:
+        if one_device:
+            acc_t, acc_inplace = torch.empty(acc_n, dtype=torch.int64), False  # (host staging for gloo)
+        elif not acc_inplace:
             acc_t = torch.empty(acc_n, dtype=torch.int64, device=dev)
 
     def barrier():
@@ -319,10 +330,10 @@ def main():
             return
         ctx.synchronize()
         if not acc_inplace:
-            assert hip.hipMemcpy(acc_t.data_ptr(), acc_ptr, acc_n * 8, 3) == 0
+            assert hip.hipMemcpy(acc_t.data_ptr(), acc_ptr, acc_n * 8, 4) == 0  # (hipMemcpyDefault: device or host staging)
         par.allreduce_accum(acc_t)  # RCCL sum; int64 adds wrap exactly like the reference's uint64 atomics
         if not acc_inplace:
-            assert hip.hipMemcpy(acc_ptr, acc_t.data_ptr(), acc_n * 8, 3) == 0
+            assert hip.hipMemcpy(acc_ptr, acc_t.data_ptr(), acc_n * 8, 4) == 0
 
     for _ in range(args.warmup):
         step()
@@ -347,9 +358,31 @@ def main():
     if world == 1:
         local_ctr = ctx.counters()
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_device else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    reduce_check = None
+    if use_dist and os.environ.get("DBTK_BENCH_REDUCE_CHECK") == "1":
+        # (tests) the reduced accumulators against the oracle on EVERY rank's reads: sum over ranks x steps
+        red = ctx.counts()
+        if rank == 0:
+            import bind
+            orc = bind.Oracle()
+            go = orc.from_arrays(arrs)
+            co = np.zeros(g.ntrkmers, np.uint64)
+            kmc = np.zeros(g.nloci, np.uint64); nmr = np.zeros(g.nloci, np.uint64); ctrs = None
+            for r_ in range(world):
+                s_, o_ = syn.reads(npairs, rlen=rlen, hit_frac=args.hit_frac, seed=1, first_pair=r_ * npairs, nthreads=nth)
+                oo = orc.align(go, params, s_, o_, trace=False)
+                np.add.at(co, g.output_order().astype(np.int64), oo["counts_file"])
+                kmc += oo["kmc"].astype(np.uint64); nmr += oo["nmapread"].astype(np.uint64)
+                ctrs = oo["counters"].astype(np.uint64) if ctrs is None else ctrs + oo["counters"].astype(np.uint64)
+            st = np.uint64(args.steps)
+            ok = bool((co * st == red["counts"]).all() and (kmc * st == red["kmc"]).all() and ((nmr * st).astype(np.uint32) == red["nmapread"]).all()
+                      and (ctrs * st == red["counters"]).all())
+            reduce_check = dict(ranks=world, steps=args.steps, pairs_per_rank=npairs, bit_exact=ok)
+            log(f"reduce check over {world} ranks x {args.steps} steps: {'bit-exact' if ok else 'MISMATCH'}")
+            orc.free(go)
     total_reads = 2 * npairs * args.steps * world
     value = total_reads / dt
     log(f"timed region: {args.steps} steps, {dt / args.steps * 1e3:.3f} ms/step, {value / 1e9:.2f} G reads/s on {world} GPU(s)")
@@ -678,7 +711,7 @@ def main():
                                    f"-k 21 -kf 4 1 -cth 45 -ka; RCCL all-reduce of counts at the end",
                        "lanes": args.lanes, "reads_per_gpu": args.reads, "read_len": rlen, "hit_frac": args.hit_frac, "k": 21, "cth": 45,
                        "kernel_source_hash": kernel_source_hash()},
-            "roofline": roof, "probe_roofline": probe_roof, "sustained": sustained, "mixes": mixes, "end_to_end": e2e, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roof, "probe_roofline": probe_roof, "reduce_check": reduce_check, "sustained": sustained, "mixes": mixes, "end_to_end": e2e, "cpu_baseline": cpu, "parity": parity,
             "two_lanes": two_lanes, "bench_wall_s": time.time() - t_start,
         }
         print(json.dumps(out), flush=True)

@@ -400,11 +400,16 @@ int main(int argc, char* argv[]) {
     P.bait = use_bait;
     P.bubbles = o.outputBubbles && !o.extractFastX && !o.threading;  // countNovelEdges only runs on the assignment path
     if (o.ngpus < 1) o.ngpus = 1;
+    // DBTK_DEVICE_MAP=a,b,...: logical GPU i runs on device map[i % n] (tests: `--gpus 2` on a one-GPU box, DBTK_DEVICE_MAP=0,0 — two
+    // contexts, two sharded readers, the cross-range pairing and the host merge all execute)
+    std::vector<int> devmap;
+    if (const char* e = getenv("DBTK_DEVICE_MAP")) { std::string v(e); size_t at = 0; while (at < v.size()) { devmap.push_back(atoi(v.c_str() + at)); at = v.find(',', at); if (at == std::string::npos) break; ++at; } }
+    auto dev_of = [&](int i) { return devmap.empty() ? i : devmap[(size_t)i % devmap.size()]; };
     std::vector<dbtk_ctx_t*> ctx(o.ngpus, nullptr);
     const double tl1 = wall();
     if (!o.parseOnly)
         for (int d = 0; d < o.ngpus; ++d)
-            if (dbtk_ctx_create(rpgg, &P, d, &ctx[d])) die_assert(dbtk_last_error());
+            if (dbtk_ctx_create(rpgg, &P, dev_of(d), &ctx[d])) die_assert(dbtk_last_error());
     fprintf(stderr, "load: RPGG files %.2f s, tables in HBM %.2f s\n", tl1 - tl0, wall() - tl1);
     if (!o.parseOnly && ctx[0]) {  // what the RPGG occupies on a GPU, table by table
         const char* nm[16]; uint64_t tb[16];
@@ -1333,7 +1338,7 @@ int main(int argc, char* argv[]) {
     if (!o.parseOnly)
         for (int i = (int)ctx.size(); i < nshards; ++i) {
             ctx.push_back(nullptr);
-            if (dbtk_ctx_create(rpgg, &P, i % o.ngpus, &ctx[i])) die_assert(dbtk_last_error());
+            if (dbtk_ctx_create(rpgg, &P, dev_of(i % o.ngpus), &ctx[i])) die_assert(dbtk_last_error());
         }
     // -a / -ae with one range: several aligner threads per GPU, each with a context of its own (they share the GPU's tables; their
     // accumulators are summed on the host at the end): while one fetches its batch's records and has them formatted and
@@ -1341,7 +1346,7 @@ int main(int argc, char* argv[]) {
     if (!o.parseOnly && emit_aln && nshards == 1)
         for (int i = (int)ctx.size(); i < aln_aligners * o.ngpus; ++i) {
             ctx.push_back(nullptr);
-            if (dbtk_ctx_create(rpgg, &P, i % o.ngpus, &ctx[i])) die_assert(dbtk_last_error());
+            if (dbtk_ctx_create(rpgg, &P, dev_of(i % o.ngpus), &ctx[i])) die_assert(dbtk_last_error());
         }
     std::vector<std::vector<Left>> lefts(nshards);
     {

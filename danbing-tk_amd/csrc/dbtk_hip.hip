@@ -42,6 +42,10 @@ __global__ void __launch_bounds__(256) k_idx_finalize(IdxBucket* b, uint64_t nsl
 __global__ void __launch_bounds__(256) k_cls_insert(ClsBuildArgs a) { DevX x{nullptr}; body_cls_insert(x, a); }
 __global__ void __launch_bounds__(256) k_idx_aux(IdxAuxArgs a) { DevX x{nullptr}; body_idx_aux(x, a); }
 
+// dst[i] += src[i] (dbtk_allreduce: contexts that share a device)
+__global__ void __launch_bounds__(256) k_accum_add(uint64_t* dst, const uint64_t* src, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
 // counters[c] += sum of its replicas; replicas back to zero
 __global__ void __launch_bounds__(64) k_fold_counters(uint64_t* counters, uint64_t* rep) {
     const uint32_t c = threadIdx.x;
@@ -1931,40 +1935,67 @@ dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n) {
     typedef int (*allReduce_t)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
     typedef int (*group_t)(void);
     typedef int (*commDestroy_t)(comm_t);
-    static void* lib = nullptr;
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) { set_error(std::string("cannot load librccl: ") + dlerror()); return DBTK_ERR_HIP; }
-    auto commInitAll = (commInitAll_t)dlsym(lib, "ncclCommInitAll");
-    auto allReduce = (allReduce_t)dlsym(lib, "ncclAllReduce");
-    auto groupStart = (group_t)dlsym(lib, "ncclGroupStart");
-    auto groupEnd = (group_t)dlsym(lib, "ncclGroupEnd");
-    auto commDestroy = (commDestroy_t)dlsym(lib, "ncclCommDestroy");
-    if (!commInitAll || !allReduce || !groupStart || !groupEnd || !commDestroy) { set_error("librccl lacks the expected symbols"); return DBTK_ERR_HIP; }
-    std::vector<comm_t> comms(n);
-    std::vector<int> devs(n);
     for (int i = 0; i < n; ++i) {
-        devs[i] = ctxs[i]->device;
         if (ctxs[i]->n_accum != ctxs[0]->n_accum) { set_error("contexts belong to different RPGGs"); return DBTK_ERR_ARG; }
         HIPCHK(hipSetDevice(ctxs[i]->device));
         HIPCHK(sync_all(ctxs[i]));
         const dbtk_status_t es = take_error_words(ctxs[i]);  // do not spread tainted accumulators over the other GPUs
         if (es) return es;
     }
-    if (commInitAll(comms.data(), n, devs.data()) != 0) { set_error("ncclCommInitAll failed"); return DBTK_ERR_HIP; }
-    const int ncclUint64 = 5, ncclSum = 0;
-    int rc = groupStart();
-    for (int i = 0; i < n && !rc; ++i) {
-        (void)hipSetDevice(ctxs[i]->device);
-        (void)sync_all(ctxs[i]);
-        rc = allReduce(ctxs[i]->d_accum, ctxs[i]->d_accum, ctxs[i]->n_accum, ncclUint64, ncclSum, comms[i], ctxs[i]->stream);
-    }
-    rc |= groupEnd();
+    // Contexts that share a device (several ingest pipelines per GPU; a one-GPU box standing in for several) are summed on that device
+    // first, into the first of them; RCCL then runs over one context per DISTINCT device (it refuses a device twice); at the end
+    // every context of a device gets its representative's sum.
+    std::vector<int> rep;  // index of the first context of each distinct device
+    std::vector<int> rep_of(n, 0);
     for (int i = 0; i < n; ++i) {
-        (void)hipSetDevice(ctxs[i]->device);
-        (void)hipStreamSynchronize(ctxs[i]->stream);
-        commDestroy(comms[i]);
+        int r = -1;
+        for (size_t q = 0; q < rep.size(); ++q) if (ctxs[rep[q]]->device == ctxs[i]->device) r = (int)q;
+        if (r < 0) { rep.push_back(i); r = (int)rep.size() - 1; }
+        rep_of[i] = rep[r];
     }
+    for (int i = 0; i < n; ++i)
+        if (rep_of[i] != i) {
+            dbtk_ctx* d = ctxs[rep_of[i]];
+            HIPCHK(hipSetDevice(d->device));
+            LAUNCH(k_accum_add, dim3(1024), dim3(256), d->stream, d->d_accum, ctxs[i]->d_accum, d->n_accum);
+            HIPCHK(hipStreamSynchronize(d->stream));
+        }
+    const int nd = (int)rep.size();
+    int rc = 0;
+    if (nd > 1) {
+        static void* lib = nullptr;
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { set_error(std::string("cannot load librccl: ") + dlerror()); return DBTK_ERR_HIP; }
+        auto commInitAll = (commInitAll_t)dlsym(lib, "ncclCommInitAll");
+        auto allReduce = (allReduce_t)dlsym(lib, "ncclAllReduce");
+        auto groupStart = (group_t)dlsym(lib, "ncclGroupStart");
+        auto groupEnd = (group_t)dlsym(lib, "ncclGroupEnd");
+        auto commDestroy = (commDestroy_t)dlsym(lib, "ncclCommDestroy");
+        if (!commInitAll || !allReduce || !groupStart || !groupEnd || !commDestroy) { set_error("librccl lacks the expected symbols"); return DBTK_ERR_HIP; }
+        std::vector<comm_t> comms(nd);
+        std::vector<int> devs(nd);
+        for (int q = 0; q < nd; ++q) devs[q] = ctxs[rep[q]]->device;
+        if (commInitAll(comms.data(), nd, devs.data()) != 0) { set_error("ncclCommInitAll failed"); return DBTK_ERR_HIP; }
+        const int ncclUint64 = 5, ncclSum = 0;
+        rc = groupStart();
+        for (int q = 0; q < nd && !rc; ++q) {
+            dbtk_ctx* c = ctxs[rep[q]];
+            (void)hipSetDevice(c->device);
+            rc = allReduce(c->d_accum, c->d_accum, c->n_accum, ncclUint64, ncclSum, comms[q], c->stream);
+        }
+        rc |= groupEnd();
+        for (int q = 0; q < nd; ++q) {
+            (void)hipSetDevice(ctxs[rep[q]]->device);
+            (void)hipStreamSynchronize(ctxs[rep[q]]->stream);
+            commDestroy(comms[q]);
+        }
+    }
+    for (int i = 0; i < n && !rc; ++i)
+        if (rep_of[i] != i) {
+            HIPCHK(hipSetDevice(ctxs[i]->device));
+            HIPCHK(hipMemcpy(ctxs[i]->d_accum, ctxs[rep_of[i]]->d_accum, ctxs[i]->n_accum * 8, hipMemcpyDeviceToDevice));
+        }
     if (rc) { set_error("ncclAllReduce failed"); return DBTK_ERR_HIP; }
     return DBTK_OK;
 }

@@ -102,6 +102,36 @@ def test_cli_reproduces_reference_binary(name, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_two_gpus_on_one_device(tmp_path):
+    """`--gpus 2` on a one-GPU box (DBTK_DEVICE_MAP=0,0): two contexts, the input cut into two ranges each with its own device
+    reader, the cross-range pairing of what the ranges leave over, the merge of the two contexts' accumulators on the host — the
+    output files are the single-GPU run's (= the reference binary's) byte for byte, stdout the same lines."""
+    name = GOLDEN_SETS[0]
+    d, cmds = golden_cmds(name)
+    w = str(tmp_path / "w")
+    os.makedirs(w)
+    for f in os.listdir(d):
+        shutil.copy(os.path.join(d, f), w)
+    ran = 0
+    for line in cmds:
+        parts = line.split(" > ")
+        args = parts[0].split()[1:]
+        tag = args[args.index("-o") + 1] if "-o" in args else None
+        if not tag or "-tb" in args:
+            continue
+        for extra_env in (dict(DBTK_SHARD_MIN="0"), dict(DBTK_SHARD_MIN="0", DBTK_INGEST_CHUNK="20000")):
+            r = run(args + ["--gpus", "2"], cwd=w, env=dict(os.environ, DBTK_DEVICE_MAP="0,0", **extra_env))
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            if len(parts) == 2:
+                assert sorted(r.stdout.splitlines()) == sorted(open(os.path.join(d, parts[1]), "rb").read().splitlines())
+            for f in sorted(os.listdir(d)):
+                if f.startswith(tag + ".") and f.endswith((".trkmc.ar", ".tr.summary.txt")):
+                    assert open(os.path.join(w, f), "rb").read() == open(os.path.join(d, f), "rb").read(), f
+        ran += 1
+    assert ran > 0
+
+
+@pytest.mark.gpu
 def test_cli_index_sidecar(tmp_path):
     """--write-idx-cache leaves PREF.dbtk.idx next to the RPGG; the next run loads the GPU-layout index from it (the `tables:` line
     says so) and prints the same bytes as the golden run — which never sees a sidecar, and writes none."""

@@ -538,6 +538,10 @@ def test_contexts_share_device_tables(dbtk, oracle, tmp_path):
     dbtk._chk(dbtk.L.dbtk_rpgg_from_arrays(C.byref(arrs), C.byref(h)))
     g = bind.pkg.Rpgg(dbtk, h)
     p = abi.default_params(ksize=21, cthreshold=45, okam=0)
+    seq, off = syn.reads(20000, hit_frac=0.5, seed=4)
+    c0 = dbtk.context(g, p)  # (once through everything first: what the HIP runtime allocates at a kernel's first launch — code objects,
+    c0.align(seq, off)       # scratch for the kernels that spill — is not the library's to give back, and must not count below)
+    c0.close()
     m0 = free_bytes()
     c1 = dbtk.context(g, p)
     m1 = free_bytes()
@@ -545,8 +549,7 @@ def test_contexts_share_device_tables(dbtk, oracle, tmp_path):
     c3 = dbtk.context(g, abi.default_params(ksize=21, cthreshold=30, okam=0))
     m3 = free_bytes()
     first, extra = m0 - m1, (m1 - m3) / 2
-    assert first > 500e6 and extra < 0.25 * first, (first, extra)   # tables ~1 GB here; a further context: accumulators + vote scratch
-    seq, off = syn.reads(20000, hit_frac=0.5, seed=4)
+    assert first > 250e6 and extra < 0.25 * first, (first, extra)   # tables ~0.5 GB here; a further context: accumulators + vote scratch
     go = oracle.from_arrays(arrs)
     o = oracle.align(go, p, seq, off, trace=False)
     c1.close()                                                        # the tables outlive their builder
@@ -610,6 +613,29 @@ def test_bench_collective_path_on_one_gpu():
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["parity"] and d["parity"]["bit_exact"] and d["parity"]["pairs"] >= 30000
     assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """The N > 1 code of bench.py with two REAL ranks on a one-GPU box (DBTK_BENCH_ALL_ON_DEVICE0=1: both ranks on device 0, gloo
+    with host staging in place of RCCL, which refuses two ranks on one device): each rank its own shard of the read set, barriers,
+    MAX over ranks, the all-reduce of the accumulators — and the reduced counts equal the oracle's over BOTH shards x steps."""
+    import json
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nloci", "2000", "--reads", "120000",
+           "--hit-frac", "0.5", "--mix-reads", "0", "--no-e2e", "--ref-reads", "0", "--cpu-seconds", "0"]
+    env = dict(os.environ, DBTK_BENCH_ALL_ON_DEVICE0="1", DBTK_BENCH_REDUCE_CHECK="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["reduce_check"] == dict(ranks=2, steps=2, pairs_per_rank=60000, bit_exact=True)
 
 
 def test_checked_launches_mode(tmp_path):
