@@ -42,7 +42,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_SOURCES = ("dbtk_kernels.h", "dbtk_probe2.h", "dbtk_walkfast.h", "dbtk_ingest.h", "dbtk_gz.h", "dbtk_walk.h", "dbtk_tables.h", "dbtk_sort.h", "dbtk_assign.h", "dbtk_devx.h", "dbtk_hip.hip")
+KERNEL_SOURCES = ("dbtk_kernels.h", "dbtk_probe2.h", "dbtk_locus.h", "dbtk_walkfast.h", "dbtk_ingest.h", "dbtk_gz.h", "dbtk_walk.h", "dbtk_tables.h", "dbtk_sort.h", "dbtk_assign.h", "dbtk_devx.h", "dbtk_hip.hip")
 
 
 def kernel_source_hash():
@@ -66,8 +66,10 @@ def parse_args(argv=None):
     ap.add_argument("--parity-pairs", type=int, default=100000, help="pairs whose oracle result is compared with the HIP path")
     ap.add_argument("--ref-reads", type=int, default=8_000_000, help="reads of the FASTA sample the reference binary is timed on (0 = skip the reference leg)")
     ap.add_argument("--ref-threads", type=int, nargs="*", default=None, help="-p values for the reference binary [1 8 <all host threads>]")
-    ap.add_argument("--mix-reads", type=int, default=4_000_000, help="reads per step of the extra mixes (all-hit, walk); 0 = skip them")
-    ap.add_argument("--mix-steps", type=int, default=10)
+    ap.add_argument("--mix-reads", type=int, default=10_000_000, help="reads per step of the extra mixes (all-hit, walk: config 2's batch size); 0 = skip them")
+    ap.add_argument("--mix-steps", type=int, default=5)
+    ap.add_argument("--only-mix", choices=("all_hit", "walk", "genome", "k25"), default=None,
+                    help="run this one of the extra mixes only (tools/profile_round.sh: one profiled command per mix)")
     ap.add_argument("--no-walk", action="store_true", help="skip the graph-walk mixes (threading = 2)")
     ap.add_argument("--k25-reads", type=int, default=10_000_000, help="reads per step of the k = 25 graph-walk mix (BASELINE config 4: pipeline/k25.json, -gc 85 3); 0 = skip it")
     ap.add_argument("--k25-parity-pairs", type=int, default=20000, help="pairs of the k = 25 mix whose oracle result (counts, counters, walk results) is compared")
@@ -163,13 +165,32 @@ def pmc_traffic(kernel, table, ctr_bases_per_launch):
     return k["FETCH_SIZE_KB"] * 1024.0 + add, f"profiles/{name} ({d.get('command', '')})", False
 
 
-def pmc_mix_traffic(kernel):
-    """HBM bytes of the largest launch of `kernel` in the all-hit mix, from the same summary (None if stale / absent)."""
-    d, _ = pmc_summary()
-    if d is None:
+# the kernels of a stage, by the names rocprofv3 reports: the probe stage is the locus-resident kernel's three classes of workgroup, the
+# lean kernel that takes the rest, and the two kernels that make the work lists; the walk is its lean kernel (both forms) and the
+# error-correcting one
+STAGE_KERNELS = {"k_probe": ("k_probe", "k_loc_items", "k_loc_rest"), "k_walk_pairs": ("k_walk_fast", "k_walk_pairs")}
+
+
+def pmc_mix(mix, stage):
+    """Per STEP of the mix `mix`, summed over the kernels of `stage`, from the committed summary (None if stale / absent): HBM bytes
+    fetched (FETCH_SIZE), L1 -> L2 read requests (TCP_TCC_READ_REQ), wave instructions, and the stage's duration by rocprofv3's own
+    kernel trace (to be read next to the HIP-event figure of this run)."""
+    d, name = pmc_summary()
+    m = d and d.get("mixes", {}).get(mix)
+    if not m or not m.get("steps"):
         return None
-    k = d.get("mix_all_hit", {}).get(kernel)
-    return k["FETCH_SIZE_KB"] * 1024.0 if k and "FETCH_SIZE_KB" in k else None
+    pre = STAGE_KERNELS.get(stage, (stage,))
+    ks = {k: v for k, v in m["kernels"].items() if k.startswith(pre)}
+    if not ks:
+        return None
+    st = float(m["steps"])
+    tot = lambda key: sum(v.get(key, 0.0) for v in ks.values())
+    out = dict(source=f"profiles/{name}", steps=m["steps"], kernels=sorted(ks),
+               traffic=tot("FETCH_SIZE_KB:sum") * 1024.0 / st if any("FETCH_SIZE_KB:sum" in v for v in ks.values()) else None,
+               l1_to_l2_read_requests=tot("TCP_TCC_READ_REQ_sum:sum") / st if any("TCP_TCC_READ_REQ_sum:sum" in v for v in ks.values()) else None,
+               insts_valu=tot("SQ_INSTS_VALU:sum") / st if any("SQ_INSTS_VALU:sum" in v for v in ks.values()) else None,
+               rocprof_ms=sum(v["calls"] * v["avg_ns"] for v in ks.values() if "avg_ns" in v) / st * 1e-6 if any("avg_ns" in v for v in ks.values()) else None)
+    return out
 
 
 def usable_cpus():
@@ -294,7 +315,8 @@ def main():
     g = pkg.Rpgg(dbtk, h)
     params = abi.default_params(ksize=21, n_filter=4, nm_filter=1, cthreshold=45, okam=0)
     ctx = dbtk.context(g, params, device=local_rank)
-    log(f"handle + HBM tables: {g.ntrkmers} TR k-mers, {time.time() - t0:.1f}s")
+    hbm_tables = ctx.table_bytes()
+    log(f"handle + HBM tables: {g.ntrkmers} TR k-mers, {time.time() - t0:.1f}s; {hbm_tables.get('total', 0) / 1e9:.1f} GB of tables")
     d_seq = torch.from_numpy(seq).to(dev)
     d_off = torch.from_numpy(off.view(np.int64)).to(dev)
     torch.cuda.synchronize()
@@ -421,6 +443,7 @@ def main():
     nhit = 0  # pairs of the all-hit FASTA the CLI walk legs read
     if solo and rank == 0:
         mixes = {}
+        only = args.only_mix
         if do_mixes:
             mp = args.mix_reads // 2
             # all-hit: every pair tiled from a locus (SURVEY 8d mix 1): the probe and resolve kernels carry the step
@@ -431,18 +454,20 @@ def main():
             d_ah = torch.from_numpy(ah_seq).to(dev)
             d_aho = torch.from_numpy(ah_off.view(np.int64)).to(dev)
             torch.cuda.synchronize()
-            ctx.timers_enable(1)
-            dta = time_steps(ctx, lambda: ctx.align_device(d_ah.data_ptr(), d_aho.data_ptr(), mp, rlen), args.mix_steps, 2)
-            ta = kernel_table(ctx.kernel_times(), algorithmic_bytes(abi, ctx.counters().astype(np.float64)), args.mix_steps, args.mix_steps)
-            doma = max((k for k in ta if ":" not in k), key=lambda k: ta[k]["avg_ms"] * ta[k]["launches"])
-            mixes["all_hit"] = dict(workload=f"{2 * mp} reads per step, 100 % of pairs from loci, -k 21 -kf 4 1 -cth 45 -ka",
-                                    value=2 * mp * args.mix_steps / dta, unit="reads/s", ms_per_step=dta / args.mix_steps * 1e3,
-                                    steps=args.mix_steps, roofline=dict(roofline_of(doma, ta), kernels=ta),
-                                    probe_roofline=dict(roofline_of("k_probe", ta), traffic=pmc_mix_traffic("k_probe"))
-                                    if "k_probe" in ta else None)
-            log(f"all-hit mix: {dta / args.mix_steps * 1e3:.3f} ms/step, {mixes['all_hit']['value'] / 1e9:.2f} G reads/s, dominant {doma} "
-                f"{ta[doma]['avg_ms']:.3f} ms = {ta[doma]['gbs']:.0f} GB/s algorithmic")
-            if do_walk:
+            if only in (None, "all_hit"):
+                ctx.timers_enable(1)
+                dta = time_steps(ctx, lambda: ctx.align_device(d_ah.data_ptr(), d_aho.data_ptr(), mp, rlen), args.mix_steps, 2)
+                ta = kernel_table(ctx.kernel_times(), algorithmic_bytes(abi, ctx.counters().astype(np.float64)), args.mix_steps, args.mix_steps)
+                doma = max((k for k in ta if ":" not in k), key=lambda k: ta[k]["avg_ms"] * ta[k]["launches"])
+                mixes["all_hit"] = dict(workload=f"{2 * mp} reads per step, 100 % of pairs from loci, -k 21 -kf 4 1 -cth 45 -ka",
+                                        value=2 * mp * args.mix_steps / dta, unit="reads/s", ms_per_step=dta / args.mix_steps * 1e3,
+                                        steps=args.mix_steps, roofline=dict(roofline_of(doma, ta), kernels=ta),
+                                        probe_roofline=dict(roofline_of("k_probe", ta), profiled=pmc_mix("all_hit", "k_probe"),
+                                                            traffic=(pmc_mix("all_hit", "k_probe") or {}).get("traffic"))
+                                        if "k_probe" in ta else None)
+                log(f"all-hit mix: {dta / args.mix_steps * 1e3:.3f} ms/step, {mixes['all_hit']['value'] / 1e9:.2f} G reads/s, dominant {doma} "
+                    f"{ta[doma]['avg_ms']:.3f} ms = {ta[doma]['gbs']:.0f} GB/s algorithmic")
+            if do_walk and only in (None, "walk"):
                 # config 4's path: every assigned pair walked through its locus' graph with error correction (-gc 85 3), exact counting
                 pw = abi.default_params(ksize=21, n_filter=4, nm_filter=1, cthreshold=45, okam=0, threading=abi.THREADING_V13, thread_cth=85,
                                         correction=1, maxncorrection=3)
@@ -459,39 +484,42 @@ def main():
                                             value=2 * mp * args.mix_steps / dtw, unit="reads/s", ms_per_step=dtw / args.mix_steps * 1e3,
                                             steps=args.mix_steps, reads_walked_per_step=cw[abi.C_THREADING] / args.mix_steps,
                                             reads_feasible_per_step=cw[abi.C_FEASIBLE] / args.mix_steps,
-                                            roofline=dict(roofline_of(domw, tw), kernels=tw))
+                                            roofline=dict(roofline_of(domw, tw), kernels=tw, profiled=pmc_mix("walk", "k_walk_pairs"),
+                                                          traffic=(pmc_mix("walk", "k_walk_pairs") or {}).get("traffic")))
                 log(f"walk mix: {dtw / args.mix_steps * 1e3:.3f} ms/step, {mixes['walk_gc85_3']['value'] / 1e6:.1f} M reads/s, dominant {domw} {tw[domw]['avg_ms']:.3f} ms")
                 ctxw.close()
             # genome-like background: WGS reads are not uniform random — repeat families shared with the flanks let far more pairs
             # through subfilter than the 2 % that come from a locus.  Here 15 % of the background pairs carry a 64-base stretch of
             # some locus (cut from an all-hit pair) over one of the sampled windows of each mate: they pass subfilter, reach the probe
             # kernel and die in kfilter.  Counts are not oracle-checked here (the parity run above uses the headline batch).
-            rng = np.random.default_rng(7)
-            gseq = seq[:2 * mp * rlen].copy()
-            pick = np.nonzero(rng.random(mp) < 0.15)[0]
-            src = rng.integers(0, mp, len(pick))
-            at = rng.choice(np.array([0, (rlen - 21 + 1) // 3, 2 * ((rlen - 21 + 1) // 3), rlen - 64]), len(pick))
-            at = np.minimum(at, rlen - 64)
-            at2 = np.minimum(rng.choice(np.array([0, (rlen - 21 + 1) // 3, 2 * ((rlen - 21 + 1) // 3), rlen - 64]), len(pick)), rlen - 64)
-            for q in range(64):  # (subfilter wants a hit in BOTH mates, AQ.cpp:172-188: a stretch in each)
-                gseq[2 * pick * rlen + at + q] = ah_seq[2 * src * rlen + 40 + q]
-                gseq[(2 * pick + 1) * rlen + at2 + q] = ah_seq[(2 * src + 1) * rlen + 40 + q]
-            d_g = torch.from_numpy(gseq).to(dev)
-            d_go = torch.from_numpy(ah_off.view(np.int64)).to(dev)
-            ctx.timers_enable(1)
-            dtg = time_steps(ctx, lambda: ctx.align_device(d_g.data_ptr(), d_go.data_ptr(), mp, rlen), args.mix_steps, 2)
-            cg = ctx.counters().astype(np.float64)
-            tg = kernel_table(ctx.kernel_times(), algorithmic_bytes(abi, cg), args.mix_steps, args.mix_steps)
-            domg = max((k for k in tg if ":" not in k), key=lambda k: tg[k]["avg_ms"] * tg[k]["launches"])
-            mixes["genome_like"] = dict(workload=f"{2 * mp} reads per step: the headline mix ({args.hit_frac:.0%} of pairs from loci) with 15 % of the background "
-                                                 f"pairs carrying, in each mate, a 64-base repeat shared with a locus over a sampled window, -k 21 -kf 4 1 -cth 45 -ka",
-                                        value=2 * mp * args.mix_steps / dtg, unit="reads/s", ms_per_step=dtg / args.mix_steps * 1e3, steps=args.mix_steps,
-                                        pairs_past_subfilter=cg[abi.C_SURVIVORS] / args.mix_steps / mp,
-                                        roofline=dict(roofline_of(domg, tg), kernels=tg))
-            log(f"genome-like mix: {dtg / args.mix_steps * 1e3:.3f} ms/step, {mixes['genome_like']['value'] / 1e9:.2f} G reads/s, "
-                f"{100 * mixes['genome_like']['pairs_past_subfilter']:.1f} % of pairs past subfilter, dominant {domg}")
-            del d_g, d_go, d_ah, d_aho
-            if do_walk and args.k25_reads > 0:
+            if only in (None, "genome"):
+                rng = np.random.default_rng(7)
+                gseq = seq[:2 * mp * rlen].copy()
+                pick = np.nonzero(rng.random(mp) < 0.15)[0]
+                src = rng.integers(0, mp, len(pick))
+                at = rng.choice(np.array([0, (rlen - 21 + 1) // 3, 2 * ((rlen - 21 + 1) // 3), rlen - 64]), len(pick))
+                at = np.minimum(at, rlen - 64)
+                at2 = np.minimum(rng.choice(np.array([0, (rlen - 21 + 1) // 3, 2 * ((rlen - 21 + 1) // 3), rlen - 64]), len(pick)), rlen - 64)
+                for q in range(64):  # (subfilter wants a hit in BOTH mates, AQ.cpp:172-188: a stretch in each)
+                    gseq[2 * pick * rlen + at + q] = ah_seq[2 * src * rlen + 40 + q]
+                    gseq[(2 * pick + 1) * rlen + at2 + q] = ah_seq[(2 * src + 1) * rlen + 40 + q]
+                d_g = torch.from_numpy(gseq).to(dev)
+                d_go = torch.from_numpy(ah_off.view(np.int64)).to(dev)
+                ctx.timers_enable(1)
+                dtg = time_steps(ctx, lambda: ctx.align_device(d_g.data_ptr(), d_go.data_ptr(), mp, rlen), args.mix_steps, 2)
+                cg = ctx.counters().astype(np.float64)
+                tg = kernel_table(ctx.kernel_times(), algorithmic_bytes(abi, cg), args.mix_steps, args.mix_steps)
+                domg = max((k for k in tg if ":" not in k), key=lambda k: tg[k]["avg_ms"] * tg[k]["launches"])
+                mixes["genome_like"] = dict(workload=f"{2 * mp} reads per step: the headline mix ({args.hit_frac:.0%} of pairs from loci) with 15 % of the background "
+                                                     f"pairs carrying, in each mate, a 64-base repeat shared with a locus over a sampled window, -k 21 -kf 4 1 -cth 45 -ka",
+                                            value=2 * mp * args.mix_steps / dtg, unit="reads/s", ms_per_step=dtg / args.mix_steps * 1e3, steps=args.mix_steps,
+                                            pairs_past_subfilter=cg[abi.C_SURVIVORS] / args.mix_steps / mp,
+                                            roofline=dict(roofline_of(domg, tg), kernels=tg))
+                log(f"genome-like mix: {dtg / args.mix_steps * 1e3:.3f} ms/step, {mixes['genome_like']['value'] / 1e9:.2f} G reads/s, "
+                    f"{100 * mixes['genome_like']['pairs_past_subfilter']:.1f} % of pairs past subfilter, dominant {domg}")
+                del d_g, d_go
+            del d_ah, d_aho
+            if do_walk and args.k25_reads > 0 and only in (None, "k25"):
                 # BASELINE config 4 as stated: k = 25 (pipeline/k25.json:5), -gc 85 3, every assigned pair walked, exact counting
                 t0 = time.time()
                 syn25 = pkg.Synth(nloci=args.nloci, k=25, flank=700, seed=20250808, nthreads=nth)
@@ -518,7 +546,8 @@ def main():
                                                          f"100 % of pairs from loci, --v13-threading -gc 85 3 -k 25 -kf 4 1 -cth 45 -ka",
                                                 value=2 * kp * args.mix_steps / dt25, unit="reads/s", ms_per_step=dt25 / args.mix_steps * 1e3, steps=args.mix_steps,
                                                 reads_walked_per_step=c25[abi.C_THREADING] / args.mix_steps, reads_feasible_per_step=c25[abi.C_FEASIBLE] / args.mix_steps,
-                                                roofline=dict(roofline_of(dom25, t25), kernels=t25), parity=None)
+                                                roofline=dict(roofline_of(dom25, t25), kernels=t25, profiled=pmc_mix("k25", "k_walk_pairs"),
+                                                              traffic=(pmc_mix("k25", "k_walk_pairs") or {}).get("traffic")), parity=None)
                 log(f"k = 25 walk mix: {dt25 / args.mix_steps * 1e3:.3f} ms/step, {mixes['walk_k25_gc85_3']['value'] / 1e6:.1f} M reads/s, dominant {dom25} {t25[dom25]['avg_ms']:.3f} ms")
                 del d_s25, d_o25
                 k25_check = None
@@ -711,7 +740,7 @@ def main():
                                    f"-k 21 -kf 4 1 -cth 45 -ka; RCCL all-reduce of counts at the end",
                        "lanes": args.lanes, "reads_per_gpu": args.reads, "read_len": rlen, "hit_frac": args.hit_frac, "k": 21, "cth": 45,
                        "kernel_source_hash": kernel_source_hash()},
-            "roofline": roof, "probe_roofline": probe_roof, "reduce_check": reduce_check, "sustained": sustained, "mixes": mixes, "end_to_end": e2e, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roof, "probe_roofline": probe_roof, "hbm_bytes_tables": hbm_tables, "reduce_check": reduce_check, "sustained": sustained, "mixes": mixes, "end_to_end": e2e, "cpu_baseline": cpu, "parity": parity,
             "two_lanes": two_lanes, "bench_wall_s": time.time() - t_start,
         }
         print(json.dumps(out), flush=True)

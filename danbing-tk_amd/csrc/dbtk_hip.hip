@@ -72,10 +72,10 @@ template <int NS> __global__ void __launch_bounds__(64) __attribute__((amdgpu_wa
 #ifndef DBTK_P2_WPE
 #define DBTK_P2_WPE 4  // waves per SIMD its registers are budgeted for (its LDS allows 16 waves per CU)
 #endif
-template <int NPL, int WN> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_P2_WPE, 8))) k_probe(BatchArgs a) {
+template <int NPL, int WN, bool SEL = false> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_P2_WPE, 8))) k_probe(BatchArgs a) {
     __shared__ Probe2SmemT<NPL> sm;
     DevX x{&sm};
-    body_probe2<NPL, WN>(x, a);
+    body_probe2<NPL, WN, SEL>(x, a);
 }
 template <int NS, bool RECS> __global__ void __launch_bounds__(64) k_pair_usual(BatchArgs a) {
     __shared__ UsualSmem sm;
@@ -1093,7 +1093,13 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
                 a.sel = ia.rest; a.nsel = c->d_small + 11;
             }
             // (a wave of the lean form works through one contiguous range of the list: as many waves as are resident at once)
-            if (npl == 3 && wn == 7) LAUNCH((k_probe<3, 7>), dim3(c->num_cu * c->probe2_wpc[0]), dim3(64), s, a);
+            if (a.sel) {  // (the form that takes its pairs from the list the locus path left)
+                if (npl == 3 && wn == 7) LAUNCH((k_probe<3, 7, true>), dim3(c->num_cu * c->probe2_wpc[0]), dim3(64), s, a);
+                else if (npl == 3 && wn == 11) LAUNCH((k_probe<3, 11, true>), dim3(c->num_cu * c->probe2_wpc[1]), dim3(64), s, a);
+                else if (npl == 5 && wn == 7) LAUNCH((k_probe<5, 7, true>), dim3(c->num_cu * c->probe2_wpc[2]), dim3(64), s, a);
+                else LAUNCH((k_probe<5, 11, true>), dim3(c->num_cu * c->probe2_wpc[3]), dim3(64), s, a);
+            }
+            else if (npl == 3 && wn == 7) LAUNCH((k_probe<3, 7>), dim3(c->num_cu * c->probe2_wpc[0]), dim3(64), s, a);
             else if (npl == 3 && wn == 11) LAUNCH((k_probe<3, 11>), dim3(c->num_cu * c->probe2_wpc[1]), dim3(64), s, a);
             else if (npl == 5 && wn == 7) LAUNCH((k_probe<5, 7>), dim3(c->num_cu * c->probe2_wpc[2]), dim3(64), s, a);
             else if (npl == 5 && wn == 11) LAUNCH((k_probe<5, 11>), dim3(c->num_cu * c->probe2_wpc[3]), dim3(64), s, a);

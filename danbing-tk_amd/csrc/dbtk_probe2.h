@@ -82,7 +82,9 @@ DBTK_HD void p2_fetch_runs(const uint32_t* rb, const MzBucket* mz, uint32_t nrun
     }
 }
 
-template <int NPL, int WN, class X>
+// SEL: the kernel takes the pairs a.sel lists (what the locus-resident kernel leaves) instead of the whole chunk — a compile-time
+// switch, so that the form without a list (every WGS-like batch) carries none of its registers or branches
+template <int NPL, int WN, bool SEL, class X>
 DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
     typedef Probe2SmemT<NPL> SM;
     SM& sm = *x.template smem<SM>();
@@ -93,7 +95,7 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
     const uint32_t ns = *a.nsurv;
     const uint32_t tend = ns - a.t0 < a.tcap ? ns : a.t0 + a.tcap;
     const uint32_t npc = ns > a.t0 ? tend - a.t0 : 0;  // pairs of this chunk of the list; pair i -> hit-buffer rows 2i, 2i + 1
-    const uint32_t npr = a.sel ? *a.nsel : npc;         // ... of which this kernel takes all, or the ones listed in a.sel (dbtk_locus.h: the rest)
+    const uint32_t npr = SEL ? *a.nsel : npc;         // ... of which this kernel takes all, or the ones listed in a.sel (dbtk_locus.h: the rest)
     // this wave's pairs: a contiguous range of the (locus-ordered) list
     const uint32_t per = (npr + x.nblocks() - 1) / x.nblocks();
     const uint64_t lo64 = (uint64_t)x.bid() * per;
@@ -110,7 +112,7 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
     // place, so that neither load is waited for where it is issued)
     auto place_of = [&](uint32_t i) -> uint32_t {
         const uint32_t ic = i < hi ? i : (first < hi ? first : 0u);
-        return a.sel ? (npr ? a.sel[ic] : 0u) : ic;
+        return SEL ? (npr ? a.sel[ic] : 0u) : ic;
     };
     uint32_t rw0 = 0, rw1 = 0;  // pair i: dwords 2 hl and 2 hl + 1 of the mate, from its 4-byte-aligned start
     uint64_t o0C = 0, o1C = 0;  //         its offsets

@@ -861,10 +861,10 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
             g_loc_pairs[3] += nit[3];
             a.sel = rest.data(); a.nsel = &nit[3];
         }
-        if (npl == 3 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { body_probe2<3, 7>(x, a); });
-        else if (npl == 3 && wn == 11) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { body_probe2<3, 11>(x, a); });
-        else if (npl == 5 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<5>), [&](EmuX& x) { body_probe2<5, 7>(x, a); });
-        else if (npl == 5 && wn == 11) run_grid(grid_p2, 64, sizeof(Probe2SmemT<5>), [&](EmuX& x) { body_probe2<5, 11>(x, a); });
+        if (npl == 3 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { if (a.sel) body_probe2<3, 7, true>(x, a); else body_probe2<3, 7, false>(x, a); });
+        else if (npl == 3 && wn == 11) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { if (a.sel) body_probe2<3, 11, true>(x, a); else body_probe2<3, 11, false>(x, a); });
+        else if (npl == 5 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<5>), [&](EmuX& x) { if (a.sel) body_probe2<5, 7, true>(x, a); else body_probe2<5, 7, false>(x, a); });
+        else if (npl == 5 && wn == 11) run_grid(grid_p2, 64, sizeof(Probe2SmemT<5>), [&](EmuX& x) { if (a.sel) body_probe2<5, 11, true>(x, a); else body_probe2<5, 11, false>(x, a); });
         switch (a.nkp / 64) {
             case 1: case 2:
                 if (!npl) run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<2>(x, a); });
