@@ -1324,6 +1324,10 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
             W_STAMP(3);  // look-ups resolved -> LDS
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
+                // The call site keeps a pair when EITHER mate is feasible and then counts the uncorrected k-mers of both (AQ.cpp:2082-2087,
+                // 2189-2194): once mate 0 has threaded, nothing but a record (thread records, -a / -ae) needs mate 1's walk — the most
+                // expensive thing this kernel does, and every pair on its list has two mates that did not thread cleanly.
+                if (m == 1 && ret[0] && !a.trecs && !arec && !a.txt) { ret[1] = WALK_NOT_EVALUATED; W_STAMP(5); continue; }
                 WalkState S;
                 if (a.P.diag & 1) { ret[m] = 1; S.flags = 0; S.nes = S.ntr = S.nkm = 0; S.ni = 0; S.ki = 0; S.nskip = S.ncorr = 0; }  // diagnostic: no walk
                 else ret[m] = walk_read(x, smm[m], a.T, a.P, dst, (int)len[m], S);

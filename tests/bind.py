@@ -374,9 +374,9 @@ class RefHarness:
 
 def walk_res_equal(mine, theirs, n, nloci, every_mate):
     """dbtk_ctx_walk_results against the oracle's: pair and destLocus always; the return codes exactly when every mate's
-    alignment was asked for (-a / -ae, trace) — otherwise a mate whose partner threads cleanly may be reported as
-    DBTK_WALK_NOT_EVALUATED (-2, dbtk.h): then its partner's code is 1 and the pair is kept.  Returns how many were skipped,
-    or -1 on a mismatch."""
+    alignment was asked for (-a / -ae, trace) — otherwise a mate whose partner threads (cleanly, or after error correction) may be
+    reported as DBTK_WALK_NOT_EVALUATED (-2, dbtk.h): then its partner's code is the oracle's, not 0, and the pair is kept.
+    Returns how many were skipped, or -1 on a mismatch."""
     if every_mate:
         return 0 if bytes(mine)[:8 * n] == bytes(theirs)[:8 * n] else -1
     skipped = 0
@@ -386,7 +386,7 @@ def walk_res_equal(mine, theirs, n, nloci, every_mate):
             return -1
         for m, t, other in ((a.ret1, b.ret1, a.ret2), (a.ret2, b.ret2, a.ret1)):
             if m == -2:
-                if other != 1 or b.dst == nloci:
+                if other in (0, -2) or b.dst == nloci:
                     return -1
                 skipped += 1
             elif m != t:

@@ -402,7 +402,7 @@ def check_pair_mode(run, O, oh, case, k, nloci, rlen=150, sets=((1, 0), (2, 1), 
         n = o["nres"]
         assert g["nres"] == n
         skipped = bind.walk_res_equal(g["res"], o["res"], n, nloci, every_mate=bool(aln))
-        assert skipped >= 0 and (aln or (skipped > 0) == lean)  # (without -a / -ae the lean first kernel decides most pairs)
+        assert skipped >= 0 and (aln or skipped > 0 or not lean)  # (without -a / -ae the lean first kernel decides most pairs; the other one stops at a pair's first threading mate)
         exp, _ = expected_aln(O, o, reads, aln, nloci)
         if aln:
             assert [(h.pair, h.dst, t) for h, t in g["aln"]] == exp

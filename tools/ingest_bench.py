@@ -49,6 +49,11 @@ def main():
         if a.chunk:
             env["DBTK_INGEST_CHUNK"] = a.chunk
         outs = {}
+        if os.environ.get("INGEST_BENCH_CAT"):  # how long the host takes to read the fresh file once, and again: is a first pass slow by itself?
+            for i in range(2):
+                t0 = time.time()
+                subprocess.run(["dd", "if=" + os.path.join(d, "reads.fa"), "of=/dev/null", "bs=32M"], stderr=subprocess.DEVNULL)
+                print(f"dd pass {i}: {time.time() - t0:.2f} s", flush=True)
         for rep in range(a.repeat):
             for tag, extra, ev in [("dev", [], {}), ("host", ["--host-ingest"], {})] + [("dev", [], dict(kv.split("=") for kv in v.split(","))) for v in a.variants]:
                 t0 = time.time()
