@@ -345,12 +345,6 @@ int main(int argc, char* argv[]) {
             abort();  // the reference does `throw;` with no active exception -> std::terminate
         }
     }
-    if (o.simmode && o.aln && (o.v13 || (getenv("DBTK_V13_THREADING") && atoi(getenv("DBTK_V13_THREADING"))))) {
-        // writeAlignments prints srcLocus and, in simulation mode, keeps -ae records of pairs threading removed (AQ.cpp:1744-1745,
-        // 2241-2247): not implemented — refuse rather than print '.' in the src column
-        fprintf(stderr, "-s with -a / -ae under --v13-threading is not supported (the src column and the simulation-mode -ae rule are not implemented)\n");
-        return 2;
-    }
     // DBTK_V13_THREADING=1 in the environment = --v13-threading: the README's command line for the v1.3 contract
     // (`danbing-tk -gc 85 3 -ae ...`, README.md:38-39) then runs unchanged
     if (const char* e = getenv("DBTK_V13_THREADING")) if (atoi(e) != 0) o.v13 = true;
@@ -395,7 +389,10 @@ int main(int argc, char* argv[]) {
     P.threading = walk ? DBTK_THREADING_V13 : (o.threading ? DBTK_THREADING_HEAD : 0);
     P.thread_cth = (uint32_t)o.thread_cth; P.maxncorrection = (uint32_t)o.maxncorrection;
     P.correction = o.correction;
-    P.aln = emit_aln ? ((o.aln_minimal ? 2u : 1u) | DBTK_ALN_TEXT) : 0;  // CIGAR / annotation strings are written by the GPU: a few tens of bytes per pair come back
+    // CIGAR / annotation strings are written by the GPU: a few tens of bytes per pair come back.  In simulation mode (-s) -ae keeps a
+    // walked pair when its source OR its destination is a locus (AQ.cpp:2241-2247): the device then makes a record for every walked
+    // pair (as for -a; dst = nloci where threading removed the pair) and the host applies that rule
+    P.aln = emit_aln ? (((o.aln_minimal && !o.simmode) ? 2u : 1u) | DBTK_ALN_TEXT) : 0;
     P.trackbait = (o.trackBait && use_bait) ? 1 : 0;  // -tb only does something inside the bait filter (AQ.cpp:2111-2119)
     P.bait = use_bait;
     P.bubbles = o.outputBubbles && !o.extractFastX && !o.threading;  // countNovelEdges only runs on the assignment path
@@ -506,7 +503,8 @@ int main(int argc, char* argv[]) {
                 const uint8_t* rec = b.aln.data() + b.aln_idx[p];
                 uint32_t dst, len;
                 memcpy(&dst, rec, 4); memcpy(&len, rec + 4, 4);
-                t += ".\t";  // srcLocus is -1 outside simulation mode
+                if (o.simmode) { t += std::to_string((unsigned long long)b.src[p]); t += '\t'; }  // sams[i].src (writeAlignments, AQ.cpp:1744-1745)
+                else t += ".\t";  // srcLocus is -1 outside simulation mode
                 t += std::to_string((int)dst); t += '\t';
                 const Batch::Span ti = b.title_s(p), s1 = b.seq_s(2 * p + 1), s0 = b.seq_s(2 * p);
                 t.append(ti.first, ti.second); t += '\t';
@@ -540,7 +538,15 @@ int main(int argc, char* argv[]) {
         b.aln_chunks.clear();
         b.aln_em.clear();
         const uint64_t npairs_b = b.nreads / 2;
-        for (uint64_t p = 0; p < npairs_b; ++p) if (b.aln_idx[p] != DBTK_NAN32) b.aln_em.push_back((uint32_t)p);
+        for (uint64_t p = 0; p < npairs_b; ++p)
+            if (b.aln_idx[p] != DBTK_NAN32) {
+                if (o.simmode && o.aln_minimal) {  // -s -ae: srcLocus != nloci or destLocus != nloci (AQ.cpp:2242)
+                    uint32_t dst;
+                    memcpy(&dst, b.aln.data() + b.aln_idx[p], 4);
+                    if (b.src[p] == nloci && dst == nloci) continue;
+                }
+                b.aln_em.push_back((uint32_t)p);
+            }
         const uint64_t n = b.naln = b.aln_em.size();
         if (!n) return;
         const uint64_t nch = (n + CH - 1) / CH;

@@ -42,7 +42,8 @@ constexpr uint32_t LOC_EMPTY = 0xFFFFFFFEu;  // pay of a free slot (FLANK and TR
 constexpr uint32_t LOC_MISS = 0xFFFFFFFFu;   // look-up result: the k-mer is not in the image
 constexpr uint32_t LOC_HDR = 16;             // header bytes: lgnb, keys left out, trbeg[l], locus
 constexpr uint32_t LOC_CH = 64;              // pairs per item
-constexpr uint32_t LOC_MIN_PAIRS = 8;        // a locus with fewer pairs in the chunk is not worth fetching its image for (16 - 34 KB: the lines of a few pairs' global look-ups)
+constexpr uint32_t LOC_MIN_PAIRS = 16;       // a locus with fewer pairs in the chunk is not worth fetching its image for (16 - 34 KB: the lines of a few pairs'
+                                             // global look-ups — and a locus with few pairs is more often one that reads merely resemble)
 constexpr uint32_t LOC_LG_MIN = 5, LOC_LG_MAX = 11;
 struct LocusDir {
     uint32_t off16;  // of the image in the arena, in units of 16 bytes
@@ -374,6 +375,7 @@ struct __attribute__((aligned(16))) LocWaveSmemT {
 template <int NPL, int NW, int IMGB>
 struct __attribute__((aligned(16))) LocSmemT {
     uint4 img[IMGB / 16];
+    uint32_t tally[4];  // of the item: pairs looked up so far, pairs of them handed back (LOC_BAIL)
     LocWaveSmemT<NPL> w[NW];
 };
 struct LocRunArgs {
@@ -544,6 +546,7 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
         }
         d1 = d2; d2 = desc(item + 2 * S);
         ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
+        if (x.tid() < 4) smb.tally[x.tid()] = 0;
         x.bsync();
         uint32_t nrow = 0;  // rows of this wave in the item so far (uniform)
         DBTK_STAMP(43);  // barriers, image into LDS, the next one's loads issued
@@ -564,6 +567,15 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                 pairA = surv_at(cA);
             }
             x.sync();  // the previous pair's LDS is dead
+            if (r.rest) {
+                // an item most of whose pairs so far were handed back is one of reads that merely resemble the locus: the rest of it goes
+                // the same way at once (which pairs that catches depends on the waves' timing; the results do not)
+                const uint32_t done = x.bcast(smb.tally[0], 0), gone = x.bcast(smb.tally[1], 0);  // (lane 0's reading: the other waves are adding)
+                if (done >= (uint32_t)NW && 4 * gone >= 3 * done) {
+                    if (lane == 0) r.rest[x.atomic_add(r.nrest, 1u)] = i;
+                    continue;
+                }
+            }
             uint32_t bad = 0;
             {
                 const uint32_t c0 = pack4_b2(dw0, &bad), c1 = pack4_b2(dw1, &bad);
@@ -662,6 +674,7 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
             }
             const uint32_t pex = x.wave_excl_scan(npend);
             const uint32_t ptot = x.bcast(pex + npend, 63);
+            if (lane == 0 && r.rest) { x.lds_add(&smb.tally[0], 1u); if (ptot > LOC_BAIL) x.lds_add(&smb.tally[1], 1u); }
             if (ptot > LOC_BAIL && r.rest) {  // (uniform) not this locus' pair after all: the global-table kernel's
                 if (lane == 0) r.rest[x.atomic_add(r.nrest, 1u)] = i;
                 DBTK_STAMP(16);

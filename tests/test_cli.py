@@ -395,6 +395,39 @@ def test_cli_readme_pipe_takes_the_device_reader(tmp_path):
         assert open(os.path.join(w, "mp.trkmc.ar"), "rb").read() == open(os.path.join(w, "mf.trkmc.ar"), "rb").read()
 
 
+@pytest.mark.gpu
+def test_cli_simulation_mode_alignments(tmp_path):
+    """-s 1 with -a / -ae under the v1.3 contract (writeAlignments prints sams[i].src, AQ.cpp:1744-1745; in simulation mode -ae keeps a
+    walked pair when its source OR its destination is a locus, AQ.cpp:2241-2247): the -a lines are the plain run's with the source
+    locus in the first column; the -ae lines are those of them whose source or destination is a locus."""
+    d, _ = golden_cmds("g5_walk_k25")
+    w = str(tmp_path / "w")
+    shutil.copytree(d, w)
+    nloci = sum(1 for l in open(os.path.join(w, "pan.tr.kmers")) if l.startswith(">"))
+    recs = [r for r in open(os.path.join(w, "reads.fa"), "rb").read().split(b">") if r]
+    out, srcs = [], {}
+    for i in range(0, len(recs) - 1, 2):  # titles >LOCUS.i (simmode 1, AQ.cpp:478-489); every fifth pair "not from a locus"
+        src = nloci if (i // 2) % 5 == 0 else (i // 2) % nloci
+        t = b"%d.p%d" % (src, i // 2)
+        srcs[">" + t.decode()] = src
+        for r in recs[i:i + 2]:
+            out.append(b">" + t + b"\n" + r.split(b"\n", 1)[1])
+    open(os.path.join(w, "sim.fa"), "wb").write(b"".join(out))
+    base = ["--v13-threading", "-gc", "85", "3", "-ka", "-k", "25", "-cth", "45", "-qs", "pan"]
+
+    def lines(extra, fa):
+        r = run(base + extra + ["-fa", fa], cwd=w)
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        return [l.split("\t") for l in r.stdout.decode().splitlines()]
+    plain = lines(["-a", "-o", "a0"], "sim.fa")
+    sim_a = lines(["-a", "-s", "1", "-o", "a1"], "sim.fa")
+    assert len(plain) == len(sim_a) > 100
+    assert [[str(srcs[l[2]])] + l[1:] for l in plain] == sim_a
+    sim_ae = lines(["-ae", "-s", "1", "-o", "a2"], "sim.fa")
+    assert sim_ae == [l for l in sim_a if int(l[0]) != nloci or int(l[1]) != nloci]
+    assert 0 < len(sim_ae) < len(sim_a) or all(int(l[1]) != nloci for l in sim_a)
+
+
 # ---- the ingest (reader, splitters, pairing) on the CPU: `--parse-only` reports what the pairing stage handed on --------
 def _digest(reads, fastq):
     """pairs, bases and the order-independent digest dbtk_cli.cpp computes with --parse-only, from tests/refio.py's restatement
