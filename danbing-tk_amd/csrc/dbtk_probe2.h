@@ -489,23 +489,17 @@ DBTK_HD void body_surv_key(X& x, const SurvSortArgs& a) {
         const uint32_t len = (uint32_t)(a.off[r + 1] - o0);
         uint32_t key = nloci;
         if (len >= k) {
-            // The key is the locus that at least TWO of the read's sampled k-mers name (one suffices when only one is sampled): a pair from
-            // the locus has all of them there but for sequencing errors; a pair that merely shares a stretch with the locus (it passed
-            // subfilter on one sampled k-mer) gets no key — it would only drag the locus' image into LDS to find nearly all its positions
-            // missing there (dbtk_locus.h), and lands in the segment the global-table kernel takes.
+            // The key is the locus of the first sampled k-mer that is in the index.  (Asking for two sampled k-mers to agree — to keep reads that
+            // merely share a stretch with a locus out of its segment — was measured and dropped: the second look-up costs the sort 0.25 ms per
+            // 10 M all-hit reads and 1.3 ms in the genome-like mix, and the locus kernel hands such pairs back by itself, dbtk_locus.h.)
             const uint32_t L = len - k + 1, S = NF > 1 ? L / (NF - 1) : 0;
-            uint32_t first = nloci, nsame = 0;
-            for (uint32_t sidx = 0; sidx < NF && nsame < 2; ++sidx) {
+            for (uint32_t sidx = 0; sidx < NF && key == nloci; ++sidx) {
                 const uint32_t pos = sidx != NF - 1 ? sidx * S : L - 1;
                 const uint64_t km = pos < L ? kmer_of_bytes(a.seq, o0 + pos, k) : NAN64;
                 if (km == NAN64) continue;
                 const uint32_t v = idx_lookup(a.T, km);
-                if (v == NOHIT) continue;
-                const uint32_t l = (v & 1u) ? a.T.vv[(v >> 1) + 1] : v >> 1;
-                if (first == nloci) { first = l; nsame = 1; }
-                else if (l == first) ++nsame;
+                if (v != NOHIT) key = (v & 1u) ? a.T.vv[(v >> 1) + 1] : v >> 1;
             }
-            if (nsame >= (NF > 1 ? 2u : 1u)) key = first;
         }
         if (key > nloci) key = nloci;
         a.key[t] = key;
