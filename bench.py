@@ -584,8 +584,9 @@ def main():
                 tcli = time.perf_counter() - t0
                 ing = [l for l in r.stderr.splitlines() if l.startswith("ingest:")]
                 e2e["cli"] = dict(wall_s=tcli, returncode=r.returncode, reads=2 * nref, batch_loop=ing[0] if ing else None,
+                                  load=" | ".join(l for l in r.stderr.splitlines() if l.startswith(("load:", "tables:", "total:"))) or None,
                                   note="this repo's danbing-tk on the reference leg's files: RPGG load + HBM tables + parse + pair + align + dump")
-                log(f"CLI end to end: {tcli:.1f}s wall; {ing[0] if ing else ''}")
+                log(f"CLI end to end: {tcli:.1f}s wall; {e2e['cli']['load']}; {ing[0] if ing else ''}")
                 # the batch loop on a file large enough for its steady state: the reader on the device (default for a regular file: the
                 # host only copies bytes, kernels find the records and pair the mates) and on the host (--host-ingest), same binary
                 need_bytes = args.ingest_reads * (rlen + 24)

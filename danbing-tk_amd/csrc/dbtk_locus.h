@@ -296,18 +296,32 @@ DBTK_HD void body_loc_items(X& x, const LocItemArgs& a) {
     if (!*a.flag) return;
     const uint32_t ns = *a.nsurv;
     const uint32_t tend = ns - a.t0 < a.tcap ? ns : a.t0 + a.tcap;
-    for (uint32_t l = x.bid() * (uint32_t)x.nthreads() + (uint32_t)x.tid(); l < a.nloci; l += x.nblocks() * (uint32_t)x.nthreads()) {
+    // (a wave reserves the places of its 64 keys' items with one atomic per class: 80 000 returning atomics on one counter took 0.6 ms)
+    const uint32_t lround = (a.nloci + 63) & ~63u;
+    for (uint32_t l = x.bid() * (uint32_t)x.nthreads() + (uint32_t)x.tid(); l < lround; l += x.nblocks() * (uint32_t)x.nthreads()) {
         const int c = loc_class(a, l);
-        if (c < 0) continue;
-        uint32_t lo = l ? a.hist[l - 1] : 0u, hi = a.hist[l];
-        if (lo < a.t0) lo = a.t0;
-        if (hi > tend) hi = tend;
-        if (lo >= hi || hi - lo < LOC_MIN_PAIRS) continue;
-        const uint32_t n = (hi - lo + LOC_CH - 1) / LOC_CH;
-        const uint32_t base = x.atomic_add(&a.nitems[c], n);
+        uint32_t lo = 0, hi = 0, n = 0;
+        if (c >= 0) {
+            lo = l ? a.hist[l - 1] : 0u; hi = a.hist[l];
+            if (lo < a.t0) lo = a.t0;
+            if (hi > tend) hi = tend;
+            if (lo < hi && hi - lo >= LOC_MIN_PAIRS) n = (hi - lo + LOC_CH - 1) / LOC_CH;
+        }
+        uint32_t base = 0;
+        for (int cc = 0; cc < 3; ++cc) {
+            const uint32_t mine = c == cc ? n : 0u;
+            const uint32_t ex = x.wave_excl_scan(mine);
+            const uint32_t tot = x.bcast(ex + mine, 63);
+            if (!tot) continue;  // (uniform)
+            uint32_t b = 0;
+            if (x.lane() == 0) b = x.atomic_add(&a.nitems[cc], tot);
+            b = x.bcast(b, 0);
+            if (c == cc) base = b + ex;
+        }
+        const uint32_t per = n ? (hi - lo + n - 1) / n : 0u;  // (items of equal size: 70 pairs are 35 + 35, not 64 + 6 — every item pays for the image)
         for (uint32_t j = 0; j < n && base + j < a.item_cap; ++j) {
-            const uint32_t f = lo + j * LOC_CH;
-            a.items[c][base + j] = uint4{l, f, f + LOC_CH < hi ? f + LOC_CH : hi, 0u};
+            const uint32_t f = lo + j * per;
+            a.items[c][base + j] = uint4{l, f, f + per < hi ? f + per : hi, 0u};
         }
     }
 }
