@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(256) k_loc_verify(LocBuildArgs a) { DevX x{nul
 __global__ void __launch_bounds__(256) k_gloc_count(LocBuildArgs a) { DevX x{nullptr}; body_gloc_count(x, a); }
 __global__ void __launch_bounds__(256) k_gloc_scatter(LocBuildArgs a) { DevX x{nullptr}; body_gloc_scatter(x, a); }
 __global__ void __launch_bounds__(256) k_loc_items(LocItemArgs a) { DevX x{nullptr}; body_loc_items(x, a); }
+__global__ void __launch_bounds__(1024) k_loc_split(LocSplitArgs a) { __shared__ LocSplitSmem sm; DevX x{&sm}; body_loc_split(x, a); }
 __global__ void __launch_bounds__(256) k_loc_rest(LocItemArgs a) { DevX x{nullptr}; body_loc_rest(x, a); }
 // three classes of workgroup by the size of the image (loc_image_bytes of 512, 1024, 2048 buckets): the smaller the image, the fewer
 // waves share it and the more workgroups a CU holds (4 x 4, 2 x 8, 1 x 16 waves)
@@ -971,7 +972,10 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     // pairs it leaves to the global-table kernel (dbtk_locus.h)
     const uint64_t surv_words = (3 * (npairs + 1) + nloci + 2 + SCAN_BLOCKS + 3) & ~3ull;
     const uint64_t item_cap = npairs / LOC_CH + nloci + 2;  // (of a chunk for the probe kernel, of the whole list for the walk's)
-    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, surv_words + 3 * 4 * item_cap + npairs + 4);
+    uint32_t split_blk = 0;  // most workgroups any locus-resident launch has: three lists of workgroup ranges behind the rest list
+    for (int q = 0; q < 6; ++q) split_blk = std::max(split_blk, (uint32_t)std::max(c->loc_blocks[q], c->wfl_blocks[q]));
+    const uint64_t split_at = surv_words + 3 * 4 * item_cap + npairs + 4;
+    dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, split_at + 3 * ((uint64_t)split_blk + 1));
     if (st) return st;
     if ((st = ensure(&c->d_hitoff, &c->hitoff_cap, tcap * 4))) return st;  // offsets, then headers
     if ((st = ensure(&c->d_hitva, &c->hitva_cap, tcap * 2 * nkp))) return st;
@@ -1080,7 +1084,17 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
                 HIPCHK(hipMemsetAsync(c->d_small + 8, 0, 4 * sizeof(uint32_t), s));
                 LAUNCH(k_loc_items, dim3((uint32_t)((nloci + 255) / 256)), dim3(256), s, ia);
                 LAUNCH(k_loc_rest, dim3((uint32_t)std::min<uint64_t>((tcap + 255) / 256, (uint64_t)c->num_cu * 8)), dim3(256), s, ia);
-                LocRunArgs r0{a.T.ldir, a.T.limg, ia.items[0], c->d_small + 8, ia.rest, c->d_small + 11}, r1{a.T.ldir, a.T.limg, ia.items[1], c->d_small + 9, ia.rest, c->d_small + 11}, r2{a.T.ldir, a.T.limg, ia.items[2], c->d_small + 10, ia.rest, c->d_small + 11};
+                LocSplitArgs sp;
+                memset(&sp, 0, sizeof(sp));
+                for (int q = 0; q < 3; ++q) {
+                    sp.items[q] = ia.items[q]; sp.starts[q] = c->d_surv + split_at + q * ((uint64_t)split_blk + 1);
+                    sp.nblk[q] = (uint32_t)c->loc_blocks[(npl == 3 ? 0 : 3) + q];
+                    sp.wfix[q] = 4u << q;  // (an image of the class costs about as much as that many pairs)
+                }
+                sp.nitems = c->d_small + 8; sp.item_cap = (uint32_t)item_cap;
+                LAUNCH(k_loc_split, dim3(3), dim3(1024), s, sp);
+                LocRunArgs r0{a.T.ldir, a.T.limg, ia.items[0], c->d_small + 8, ia.rest, c->d_small + 11, sp.starts[0]}, r1{a.T.ldir, a.T.limg, ia.items[1], c->d_small + 9, ia.rest, c->d_small + 11, sp.starts[1]},
+                    r2{a.T.ldir, a.T.limg, ia.items[2], c->d_small + 10, ia.rest, c->d_small + 11, sp.starts[2]};
                 if (npl == 3) {
                     LAUNCH((k_probe_locus<3, LOC_NW_XS, LOC_IMGB_XS>), dim3(c->loc_blocks[0]), dim3(LOC_NW_XS * 64), s, a, r0);
                     LAUNCH((k_probe_locus<3, LOC_NW_S, LOC_IMGB_S>), dim3(c->loc_blocks[1]), dim3(LOC_NW_S * 64), s, a, r1);
@@ -1153,7 +1167,9 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         if (walk_txt) {  // text records: an arena sized for the worst case (two characters per entry, four strings), carved by the waves
             const uint32_t acap = std::min<uint32_t>(DBTK_THREAD_CAP, (max_read_len + max_read_len / 4 + 8 + 7) & ~7u);
             c->aln_cap = acap;
-            const uint64_t want = std::min<uint64_t>(npairs * (uint64_t)(8 + 8 * acap + 8) + (uint64_t)TXT_CHUNK * (c->walk_blocks + c->walkfast_blocks + 3 * 32 * c->num_cu + 2), TXT_ARENA_MAX);  // (a chunk per wave that writes: the walk kernels' waves, resident at most 32 per CU and kernel)
+            uint64_t wfl_waves = 0;
+            for (int q = 0; q < 3; ++q) wfl_waves += (uint64_t)std::max(c->wfl_blocks[q], c->wfl_blocks[3 + q]) * (q == 0 ? LOC_NW_XS : q == 1 ? LOC_NW_S : LOC_NW_L);
+            const uint64_t want = std::min<uint64_t>(npairs * (uint64_t)(8 + 8 * acap + 8) + (uint64_t)TXT_CHUNK * (c->walk_blocks + c->walkfast_blocks + wfl_waves + 2), TXT_ARENA_MAX);  // (a chunk per wave that writes: every wave of the walk kernels' launches)
             if (want > c->txt_bytes) {
                 if (c->d_txt) HIPCHK(hipFree(c->d_txt));
                 c->d_txt = nullptr; c->txt_bytes = 0;
@@ -1206,7 +1222,17 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
                 HIPCHK(hipMemsetAsync(c->d_small + 8, 0, 4 * sizeof(uint32_t), s));
                 LAUNCH(k_loc_items, dim3((uint32_t)((nloci + 255) / 256)), dim3(256), s, ia);
                 LAUNCH(k_loc_rest, dim3((uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)c->num_cu * 8)), dim3(256), s, ia);
-                LocRunArgs r0{w.T.gldir, w.T.glimg, ia.items[0], c->d_small + 8, nullptr, nullptr}, r1{w.T.gldir, w.T.glimg, ia.items[1], c->d_small + 9, nullptr, nullptr}, r2{w.T.gldir, w.T.glimg, ia.items[2], c->d_small + 10, nullptr, nullptr};
+                LocSplitArgs sp;
+                memset(&sp, 0, sizeof(sp));
+                for (int q = 0; q < 3; ++q) {
+                    sp.items[q] = ia.items[q]; sp.starts[q] = c->d_surv + split_at + q * ((uint64_t)split_blk + 1);
+                    sp.nblk[q] = (uint32_t)c->wfl_blocks[(wnpl == 3 ? 0 : 3) + q];
+                    sp.wfix[q] = 4u << q;
+                }
+                sp.nitems = c->d_small + 8; sp.item_cap = (uint32_t)item_cap;
+                LAUNCH(k_loc_split, dim3(3), dim3(1024), s, sp);
+                LocRunArgs r0{w.T.gldir, w.T.glimg, ia.items[0], c->d_small + 8, nullptr, nullptr, sp.starts[0]}, r1{w.T.gldir, w.T.glimg, ia.items[1], c->d_small + 9, nullptr, nullptr, sp.starts[1]},
+                    r2{w.T.gldir, w.T.glimg, ia.items[2], c->d_small + 10, nullptr, nullptr, sp.starts[2]};
                 if (wnpl == 3) {
                     LAUNCH((k_walk_fast_locus<3, LOC_NW_XS, LOC_IMGB_XS>), dim3(c->wfl_blocks[0]), dim3(LOC_NW_XS * 64), s, w, r0);
                     LAUNCH((k_walk_fast_locus<3, LOC_NW_S, LOC_IMGB_S>), dim3(c->wfl_blocks[1]), dim3(LOC_NW_S * 64), s, w, r1);
@@ -1299,6 +1325,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
                 for (int i = 0; i < 6; ++i) {
                     nb = 0;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kl[i], nwv[i % 3] * 64, 0) != hipSuccess || nb <= 0) nb = 1;
+                    nb *= 2;  // (twice as many as are resident: each takes a contiguous, weight-balanced range of the items, k_loc_split, and the ones that start late even out what the weights do not see)
                     if (const char* ev = getenv("DBTK_LOC_BPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
                     c->loc_blocks[i] = c->num_cu * nb;
                     if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_probe_locus[%d]: %d workgroups per CU\n", i, nb);
@@ -1348,6 +1375,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             for (int i = 0; i < 6; ++i) {
                 nb = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kw[i], nwv[i % 3] * 64, 0) != hipSuccess || nb <= 0) nb = 1;
+                nb *= 2;  // (as for k_probe_locus: contiguous weight-balanced ranges, twice the resident workgroups)
                 if (const char* ev = getenv("DBTK_WFL_BPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
                 c->wfl_blocks[i] = c->num_cu * nb;
                 if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_walk_fast_locus[%d]: %d workgroups per CU\n", i, nb);

@@ -360,6 +360,70 @@ DBTK_HD void body_loc_rest(X& x, const LocItemArgs& a) {
     }
 }
 
+// ------------------------------------------------------------------ split --
+// Which items each workgroup of a class takes: a contiguous range of the class' item list, the ranges cut where the running sum of the
+// items' weights (pairs + a fixed part for the image) passes the multiples of total / workgroups.  (Item i, i + S, i + 2 S ... per
+// workgroup left the slowest of ~1000 workgroups 10-15 % behind the mean: 40-80 items of 16-64 pairs each do not average out.)
+// One workgroup per class; starts[c][j] .. starts[c][j + 1] are workgroup j's items.
+struct LocSplitArgs {
+    const uint4* items[3];
+    const uint32_t* nitems;  // [3]
+    uint32_t item_cap;
+    uint32_t nblk[3];        // workgroups of the class' launch (0: class not launched)
+    uint32_t wfix[3];        // an item's fixed cost, in pairs
+    uint32_t* starts[3];     // [nblk + 1]
+};
+struct LocSplitSmem { uint32_t wt[64]; };
+template <class X>
+DBTK_HD void body_loc_split(X& x, const LocSplitArgs& a) {
+    LocSplitSmem& sm = *x.template smem<LocSplitSmem>();
+    const uint32_t c = x.bid();
+    if (c >= 3 || !a.nblk[c]) return;
+    const uint32_t B = a.nblk[c], NT = (uint32_t)x.nthreads(), tid = (uint32_t)x.tid(), nwv = NT / 64, wave = tid >> 6;
+    const uint32_t n = a.nitems[c] < a.item_cap ? a.nitems[c] : a.item_cap;
+    const uint4* it = a.items[c];
+    uint32_t* st = a.starts[c];
+    const uint32_t lo = (uint32_t)((uint64_t)n * tid / NT), hi = (uint32_t)((uint64_t)n * (tid + 1) / NT);
+    // (eight items' loads in flight at a time: one dependent load after the other made this kernel 80 us)
+    auto weights8 = [&](uint32_t i0, uint32_t (&w)[8]) {
+        uint4 d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = it[i0 + u < hi ? i0 + u : lo];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = i0 + u < hi ? d[u].z - d[u].y + a.wfix[c] : 0u;
+    };
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i += 8) {
+        uint32_t w[8];
+        weights8(i, w);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += w[u];
+    }
+    const uint32_t ex = x.wave_excl_scan(sum);
+    if (x.lane() == 63) sm.wt[wave] = ex + sum;
+    x.bsync();
+    uint32_t base = 0, P = 0;
+    for (uint32_t w = 0; w < nwv; ++w) { const uint32_t v = sm.wt[w]; if (w < wave) base += v; P += v; }
+    if (!P) {  // no items: every workgroup's range is empty
+        for (uint32_t j = tid; j <= B; j += NT) st[j] = 0;
+        return;
+    }
+    if (tid == 0) st[0] = 0;
+    uint64_t e = (uint64_t)base + ex;  // weight before item i
+    uint64_t j = e * B / P + 1;        // the first cut point j * P / B behind e
+    for (uint32_t i = lo; i < hi; i += 8) {
+        uint32_t w[8];
+        weights8(i, w);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i + u >= hi) break;
+            e += w[u];
+            // the workgroups j whose cut point lies in (weight before the item, weight with it]: they start behind this item
+            for (; j <= B && j * P <= e * B; ++j) st[j] = i + u + 1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ the kernel --
 // A workgroup of NW waves per item.  Per item a wave owns the pairs q = wave, wave + NW, ... (at most LOC_CH / NW) and works in
 // three phases, so that the latency of what goes to the global index is paid once per item and not once per pair:
@@ -399,6 +463,7 @@ struct LocRunArgs {
     const uint32_t* nitems;
     uint32_t* rest;       // the probe kernel only: the list of the pairs left to the global-table kernel, which this kernel appends to:
     uint32_t* nrest;      //   a pair most of whose k-mers are NOT its locus' (below) is better off there
+    const uint32_t* starts;  // [workgroups + 1] the workgroups' ranges of the item list (body_loc_split)
 };
 // A pair is handed back when more than this many of its positions miss the image: a read pair that merely touches the locus (a
 // stretch of genome that resembles it: it passed subfilter on one k-mer) would send nearly all its positions to the plain index one
@@ -418,12 +483,12 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
     const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5;
     const DevTables& T = a.T;
     const uint32_t k = T.ksize;
-    const uint32_t nitems = *r.nitems;
+    const uint32_t ifirst = r.starts[x.bid()], nitems = r.starts[x.bid() + 1];  // this workgroup's items: [ifirst, nitems)
     const uint32_t lmax = 32u * NPL + k - 1;  // bases the lanes of a half cover (the launcher promised no read is longer)
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint32_t p0 = hl * NPL;
     const uint32_t sub = (uint32_t)lane & 3u, qd = (uint32_t)lane >> 2;
-    const uint32_t S = x.nblocks();
+    constexpr uint32_t S = 1;
     // This wave's pairs, item after item: pair q of an item is the wave's when q % NW == wave.  The fetch pipeline runs along that
     // sequence ACROSS items (while the workgroup waits for an image, the reads of its first pairs are already on their way).  All loads
     // unconditional, clamped to something valid, so that they stay in flight.
@@ -458,7 +523,7 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
         o0B = a.off[rr]; o1B = a.off[rr + 1];
     };
     auto surv_at = [&](const Cur& c) { return a.surv[c.it < nitems ? c.i : a.t0]; };
-    Cur cC = seek(x.bid()), cB = next(cC), cA = next(cB);  // pair being looked up; the one whose offsets / whose list entry are in flight
+    Cur cC = seek(ifirst), cB = next(cC), cA = next(cB);  // pair being looked up; the one whose offsets / whose list entry are in flight
     if (cC.it < nitems) {
         fetch_offsets(x.uni(surv_at(cC)));
         o0C = o0B; o1C = o1B;
@@ -533,10 +598,10 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
     };
     // (the descriptor and the directory entry of the workgroup's next items are fetched an item ahead: three dependent round trips
     // in front of every image otherwise)
-    uint4 d1 = desc(x.bid()), d2 = desc(x.bid() + S);
+    uint4 d1 = desc(ifirst), d2 = desc(ifirst + S);
     LocusDir ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
     DBTK_STAMP_DECL
-    for (uint32_t item = x.bid(); item < nitems; item += S) {
+    for (uint32_t item = ifirst; item < nitems; item += S) {
         DBTK_STAMP(42);  // headers of the item before
         const uint4 d = d1;
         const LocusDir ld = ld1;

@@ -456,11 +456,11 @@ DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) 
     const DevTables& T = a.T;
     const uint32_t k = T.ksize;
     uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
-    const uint32_t nitems = *r.nitems;
+    const uint32_t ifirst = r.starts[x.bid()], nitems = r.starts[x.bid() + 1];  // this workgroup's items: [ifirst, nitems) (body_loc_split)
     const uint32_t lmax = 32u * NPL + k - 1;
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint32_t p0 = hl * NPL;
-    const uint32_t S = x.nblocks();
+    constexpr uint32_t S = 1;
     WfState W;
     const bool texting = a.txt && (a.P.aln & 3) != 0;
     auto flush = [&]() {
@@ -504,7 +504,7 @@ DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) 
         o0B = a.off[rr]; o1B = a.off[rr + 1];
     };
     auto at_of = [&](const Cur& c) { return c.it < nitems ? c.i : 0u; };
-    Cur cC = seek(x.bid()), cB = next(cC), cA = next(cB);
+    Cur cC = seek(ifirst), cB = next(cC), cA = next(cB);
     if (cC.it < nitems) {
         fetch_offsets(x.uni(a.surv[at_of(cC)]));
         dstC = a.walk_dst[at_of(cC)];
@@ -513,7 +513,7 @@ DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) 
         if (cB.it < nitems) { fetch_offsets(x.uni(a.surv[at_of(cB)])); dstB = a.walk_dst[at_of(cB)]; }
         pairA = a.surv[at_of(cA)]; dstA = a.walk_dst[at_of(cA)];
     }
-    uint4 d1 = desc(x.bid()), d2 = desc(x.bid() + S);
+    uint4 d1 = desc(ifirst), d2 = desc(ifirst + S);
     LocusDir ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
     for (uint32_t e = (uint32_t)x.tid(); e < WFL_CNT; e += (uint32_t)x.nthreads()) smb.cnt[e] = 0;
     uint32_t trb_prev = 0;
@@ -524,7 +524,7 @@ DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) 
             if (v) { x.atomic_add(&a.counts[trb_prev + e], (uint64_t)v); smb.cnt[e] = 0; }
         }
     };
-    for (uint32_t item = x.bid(); item < nitems; item += S) {
+    for (uint32_t item = ifirst; item < nitems; item += S) {
         const uint4 d = d1;
         const LocusDir ld = ld1;
         const uint32_t locus = x.uni(d.x), lgnb = x.uni(ld.lgnb), trb = x.uni(ld.trbeg);

@@ -847,7 +847,20 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
             ia.nitems = nit; ia.item_cap = item_cap; ia.rest = rest.data();
             run_grid(2, 64, 0, [&](EmuX& x) { body_loc_items(x, ia); });
             run_grid(2, 128, 0, [&](EmuX& x) { body_loc_rest(x, ia); });
-            LocRunArgs r0{a.T.ldir, a.T.limg, items[0].data(), &nit[0], rest.data(), &nit[3]}, r1{a.T.ldir, a.T.limg, items[1].data(), &nit[1], rest.data(), &nit[3]}, r2{a.T.ldir, a.T.limg, items[2].data(), &nit[2], rest.data(), &nit[3]};
+            // the workgroups' ranges of the item lists (grids of 2, 3 and 2 workgroups below)
+            std::vector<uint32_t> starts[3];
+            LocSplitArgs sp;
+            memset(&sp, 0, sizeof(sp));
+            const uint32_t nblk_[3] = {2, 3, 2};
+            for (int q = 0; q < 3; ++q) { starts[q].assign(nblk_[q] + 1, 0xDEADBEEFu); sp.items[q] = items[q].data(); sp.starts[q] = starts[q].data(); sp.nblk[q] = nblk_[q]; sp.wfix[q] = 4u << q; }
+            sp.nitems = nit; sp.item_cap = item_cap;
+            run_grid(3, 256, sizeof(LocSplitSmem), [&](EmuX& x) { body_loc_split(x, sp); });
+            for (int q = 0; q < 3; ++q) {  // the ranges tile the list
+                if (starts[q][0] != 0 || starts[q][nblk_[q]] != std::min(nit[q], item_cap)) { fprintf(stderr, "emu: item ranges of class %d do not cover its list\n", q); abort(); }
+                for (uint32_t j = 0; j < nblk_[q]; ++j) if (starts[q][j] > starts[q][j + 1]) { fprintf(stderr, "emu: item ranges of class %d out of order\n", q); abort(); }
+            }
+            LocRunArgs r0{a.T.ldir, a.T.limg, items[0].data(), &nit[0], rest.data(), &nit[3], starts[0].data()}, r1{a.T.ldir, a.T.limg, items[1].data(), &nit[1], rest.data(), &nit[3], starts[1].data()},
+                r2{a.T.ldir, a.T.limg, items[2].data(), &nit[2], rest.data(), &nit[3], starts[2].data()};
             if (npl == 3) {
                 run_grid(2, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_XS>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_XS>(x, a, r0); });
                 run_grid(3, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_S>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_S>(x, a, r1); });
@@ -931,7 +944,17 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
                 ia.nitems = wnit; ia.item_cap = item_cap; ia.rest = wrest.data();
                 run_grid(2, 64, 0, [&](EmuX& x) { body_loc_items(x, ia); });
                 run_grid(2, 128, 0, [&](EmuX& x) { body_loc_rest(x, ia); });
-                LocRunArgs r0{w.T.gldir, w.T.glimg, witems[0].data(), &wnit[0], nullptr, nullptr}, r1{w.T.gldir, w.T.glimg, witems[1].data(), &wnit[1], nullptr, nullptr}, r2{w.T.gldir, w.T.glimg, witems[2].data(), &wnit[2], nullptr, nullptr};
+                std::vector<uint32_t> wstarts[3];
+                LocSplitArgs sp;
+                memset(&sp, 0, sizeof(sp));
+                const uint32_t nblk_[3] = {2, 3, 2};
+                for (int q = 0; q < 3; ++q) { wstarts[q].assign(nblk_[q] + 1, 0xDEADBEEFu); sp.items[q] = witems[q].data(); sp.starts[q] = wstarts[q].data(); sp.nblk[q] = nblk_[q]; sp.wfix[q] = 4u << q; }
+                sp.nitems = wnit; sp.item_cap = item_cap;
+                run_grid(3, 256, sizeof(LocSplitSmem), [&](EmuX& x) { body_loc_split(x, sp); });
+                for (int q = 0; q < 3; ++q)
+                    if (wstarts[q][0] != 0 || wstarts[q][nblk_[q]] != std::min(wnit[q], item_cap)) { fprintf(stderr, "emu: walk item ranges of class %d do not cover its list\n", q); abort(); }
+                LocRunArgs r0{w.T.gldir, w.T.glimg, witems[0].data(), &wnit[0], nullptr, nullptr, wstarts[0].data()}, r1{w.T.gldir, w.T.glimg, witems[1].data(), &wnit[1], nullptr, nullptr, wstarts[1].data()},
+                    r2{w.T.gldir, w.T.glimg, witems[2].data(), &wnit[2], nullptr, nullptr, wstarts[2].data()};
                 if (wnpl == 3) {
                     run_grid(2, 4 * 64, sizeof(WalkFastLocSmemT<3, 4, EMU_IMGB_XS>), [&](EmuX& x) { body_walk_fast_locus<3, 4, EMU_IMGB_XS>(x, w, r0); });
                     run_grid(3, 4 * 64, sizeof(WalkFastLocSmemT<3, 4, EMU_IMGB_S>), [&](EmuX& x) { body_walk_fast_locus<3, 4, EMU_IMGB_S>(x, w, r1); });

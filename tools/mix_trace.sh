@@ -12,7 +12,7 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 t0 = int(rows[0]["Start_Timestamp"])
 for r in rows:
     n = r["Kernel_Name"]
-    if any(t in n for t in ("k_probe", "k_loc_items", "k_loc_rest", "k_encode", "k_surv_key", "k_pair")):
+    if any(t in n for t in ("k_probe", "k_loc_", "k_encode", "k_surv_", "k_pair", "k_walk")):
         print(f"{(int(r['Start_Timestamp']) - t0) / 1e6:10.3f} ms  {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6:8.3f} ms  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>8s}  {n[:80]}")
 PY
 rm -rf gpurun_out/mixtrace

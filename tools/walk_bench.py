@@ -30,16 +30,21 @@ def main():
     d_seq = torch.from_numpy(seq).cuda()
     d_off = torch.from_numpy(off.view(np.int64)).cuda()
     torch.cuda.synchronize()
-    for corr, cth, name in ((1, 85, "-gc 85 3"), (0, 85, "-g 85 (no correction)"), (1, 130, "-gc 130 3 (every error ends the read early)")):
+    variants = ((1, 85, 0, "-gc 85 3"), (1, 85, 2 | abi.ALN_TEXT, "-gc 85 3 -ae (text records on the device)"), (0, 85, 0, "-g 85 (no correction)"),
+                (1, 130, 0, "-gc 130 3 (every error ends the read early)"))
+    for corr, cth, aln, name in variants[:int(os.environ.get('WALK_BENCH_VARIANTS', '4'))]:
         p = abi.default_params(ksize=21, cthreshold=45, okam=0, threading=2, thread_cth=cth, correction=corr, maxncorrection=3)
+        p.aln = aln
         p.diag = int(os.environ.get('DBTK_DIAG', '0'))
         ctx = lib.context(g, p)
+        # (text records only exist on the synchronous entry point: host buffers in, the kernels' own timers are what is read here)
+        step = (lambda: ctx.align(seq, off)) if aln else (lambda: ctx.align_device(d_seq.data_ptr(), d_off.data_ptr(), npairs, 150))
         for _ in range(2):
-            ctx.align_device(d_seq.data_ptr(), d_off.data_ptr(), npairs, 150)
+            step()
         ctx.synchronize()
         ctx.reset(); ctx.timers_reset()
         for _ in range(5):
-            ctx.align_device(d_seq.data_ptr(), d_off.data_ptr(), npairs, 150)
+            step()
         ctx.synchronize()
         kt = ctx.kernel_times()
         c = ctx.counters()
