@@ -168,7 +168,7 @@ def pmc_traffic(kernel, table, ctr_bases_per_launch):
 # the kernels of a stage, by the names rocprofv3 reports: the probe stage is the locus-resident kernel's three classes of workgroup, the
 # lean kernel that takes the rest, and the two kernels that make the work lists; the walk is its lean kernel (both forms) and the
 # error-correcting one
-STAGE_KERNELS = {"k_probe": ("k_probe", "k_loc_items", "k_loc_rest"), "k_walk_pairs": ("k_walk_fast", "k_walk_pairs")}
+STAGE_KERNELS = {"k_probe": ("k_probe", "k_loc_items", "k_loc_rest", "k_loc_split"), "k_walk_pairs": ("k_walk_fast", "k_walk_pairs")}
 
 
 def pmc_mix(mix, stage):
