@@ -983,8 +983,18 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     if ((st = ensure(&c->d_gen, &c->gen_cap, tcap))) return st;
     if ((st = ensure(&c->d_tickets, &c->tickets_cap, 2 * (nchunks + 1)))) return st;  // per chunk: a ticket counter and a passed-on counter
     const bool walking = c->P.threading == DBTK_THREADING_V13;
+    uint64_t slow_cap = 0, info_rows = 0;
     if (walking) {
-        if ((st = ensure(&c->d_walk, &c->walk_cap, 3 * npairs))) return st;  // destLocus | return codes | the fast kernel's leftovers
+        // destLocus | return codes | the fast kernel's passed-on list (its waves reserve WF_R places at a time) | the graph info of the
+        // passed-on pairs' positions (rows for an eighth of the pairs — with text records, where every pair with a dirty mate is passed
+        // on, for half of them; a pair beyond that is looked up again by the other kernel)
+        uint64_t wf_waves = 4ull * (uint64_t)c->walkfast_blocks;
+        for (int q = 0; q < 3; ++q) wf_waves += (uint64_t)std::max(c->wfl_blocks[q], c->wfl_blocks[3 + q]) * (q == 0 ? LOC_NW_XS : q == 1 ? LOC_NW_S : LOC_NW_L);
+        slow_cap = npairs + WF_R * wf_waves + 8;
+        info_rows = std::min<uint64_t>(slow_cap, std::max<uint64_t>(walk_txt ? npairs / 2 : npairs / 8, 4096));
+        static const bool no_info = getenv("DBTK_WALK_INFO") && atoi(getenv("DBTK_WALK_INFO")) == 0;  // diagnostic
+        if (no_info) info_rows = 0;
+        if ((st = ensure(&c->d_walk, &c->walk_cap, 2 * npairs + slow_cap + info_rows * 2 * 160))) return st;
         HIPCHK(hipMemsetAsync(c->d_walk, 0xFF, npairs * sizeof(uint32_t), s));  // NAN32: the pair does not reach threading
     }
     HIPCHK(hipMemsetAsync(c->d_small, 0, 3 * sizeof(uint32_t), s));  // nsurv, novf, nrec; the error word (3) stays until it has been reported
@@ -1205,6 +1215,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         if (tm) { if ((st = timed_slot(c, 4, &e))) return st; HIPCHK(hipEventRecord(c->timed[4].beg[e], s)); }
         if (wnpl) {
             w.slow_list = c->d_walk + 2 * npairs; w.nslow = c->d_small + 5;
+            if (info_rows) { w.slow_info = c->d_walk + 2 * npairs + slow_cap; w.info_cap = (uint32_t)std::min<uint64_t>(info_rows, 0x7FFFFFFFull); w.info_stride = 32u * (uint32_t)wnpl; }
             HIPCHK(hipMemsetAsync(c->d_small + 5, 0, 4, s));
             // (four ranges per resident wave even out their different costs: 19.7 -> 18.7 ms per 4 M reads; not with text records, where
             // every block that writes takes a chunk of the arena)

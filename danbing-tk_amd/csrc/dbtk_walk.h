@@ -125,13 +125,19 @@ struct WalkArgs {
     uint64_t* dbg;             // diagnostic build only (-DDBTK_STAMPS): per-phase cycle sums
     // pair mode in two kernels (body_walk_fast, then body_walk_pairs on what it passed on): survivors t the fast kernel could
     // not decide.  body_walk_fast appends to it; body_walk_pairs takes its items from it (nullptr: every survivor).
-    uint32_t* slow_list;
+    uint32_t* slow_list;       // entries: place in the list | WALK_HAS_INFO; WALK_NO_ENTRY: a reserved place nothing was put in
     uint32_t* nslow;
+    // what the fast kernel already knows about a pair it passes on: the graph table's info word of every position of both mates
+    // (row e of slow_info belongs to entry e of slow_list: [2][info_stride] words), so that body_walk_pairs need not look 260 k-mers up again
+    uint32_t* slow_info;       // nullptr: none
+    uint32_t info_cap;         // rows
+    uint32_t info_stride;      // words per mate (32 * NPL of the fast kernel that ran)
     // body_walk_fast only: nullptr, or the places in the list of the pairs it is to take (the pairs of loci without a graph image:
     // what body_walk_fast_locus leaves) and their number
     const uint32_t* sel;
     const uint32_t* nsel;
 };
+constexpr uint32_t WALK_HAS_INFO = 0x80000000u, WALK_NO_ENTRY = 0xFFFFFFFFu;
 constexpr int8_t WALK_NOT_EVALUATED = -2;  // walk_ret of a mate whose walk nothing needed: its pair was kept by the other mate (dbtk.h)
 #ifdef DBTK_STAMPS
 #define W_STAMP_DECL uint64_t wst[8] = {0}; uint64_t wlast = x.clock();
@@ -1011,6 +1017,47 @@ DBTK_HD void walk_probe_finish(X& x, WalkSmem& sm, const DevTables& T, uint32_t 
     }
     x.sync();
 }
+// The same two stages for a pair the fast kernel passed on WITH what it had looked up (WalkArgs::slow_info): the k-mers as
+// walk_probe_issue makes them and one coalesced row of info words instead of a graph-table probe sequence per position.
+struct WalkInfoRow { uint32_t v[W_R]; };
+template <class X>
+DBTK_HD void walk_info_issue(X& x, WalkSmem& sm, const DevTables& T, uint32_t len, const uint32_t* row, uint32_t stride, WalkInfoRow& R) {
+    const int lane = x.lane();
+    const uint32_t k = T.ksize;
+    const int nk = len >= k ? (int)(len - k + 1) : 0;
+#pragma unroll
+    for (int r = 0; r < W_R; ++r) {
+        const int i = 64 * r + lane;
+        if (i < nk) {
+            uint64_t fw = NAN64, f;
+            if (window_kmer(sm.pk, sm.vd, (uint32_t)i, k, &f, nullptr) != NAN64) fw = f;
+            sm.km[i] = fw;
+            sm.tr[i] = '*';
+        }
+        R.v[r] = row[(uint32_t)i < stride ? i : 0];
+    }
+}
+template <class X>
+DBTK_HD void walk_info_finish(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, uint32_t len, uint32_t stride, const WalkInfoRow& R, uint32_t* slot) {
+    const int lane = x.lane();
+    const uint32_t k = T.ksize;
+    const int nk = len >= k ? (int)(len - k + 1) : 0;
+#pragma unroll
+    for (int r = 0; r < W_R; ++r) {
+        const int i = 64 * r + lane;
+        uint32_t info = 0;
+        if (i < nk) {
+            const uint64_t fw = sm.km[i];
+            const bool has = fw != NAN64 && (uint32_t)i < stride;
+            if (has) info = R.v[r];
+            const bool isf = has && fw <= revcomp2(fw, k);  // the k-mer as read is its canonical form
+            const uint32_t a = info & 0x1Fu, b = (info >> GR_OPP) & 0x1Fu;
+            sm.gi[i] = (uint16_t)((isf ? (a | (b << GR_OPP)) : (b | (a << GR_OPP))) | (info & GR_TR));
+        }
+        if (slot) slot[i] = (info & GR_TR) ? T.trbeg[locus] + (info >> GR_SLOT_SHIFT) : NAN32;
+    }
+    x.sync();
+}
 // All stages for one read (function mode).  Returns the read's length (clamped to the arrays, flagged).
 template <class X>
 DBTK_HD int walk_load(X& x, WalkSmem& sm, const DevTables& T, const uint8_t* seq, uint64_t o0, uint64_t o1, uint32_t locus,
@@ -1258,13 +1305,17 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
     // -> their k-mers' graph look-ups.  What bounds this kernel is round trips per wave, so the chain is software-pipelined
     // over the wave's items (t, t + S, ...): while item i is walked, the bytes of item i + 1, the offsets of item i + 2 and
     // the (destLocus, pair) of item i + 3 are in flight; all of these loads are unconditional (clamped indices).
-    auto meta = [&](uint32_t i, uint32_t* dst, uint32_t* pair, uint32_t* tt) {
+    const uint32_t ncap = *a.nsurv;  // (an entry of the list is a place below this, or WALK_NO_ENTRY)
+    auto meta = [&](uint32_t i, uint32_t* dst, uint32_t* pair, uint32_t* tt, uint32_t* inf) {
         const uint32_t ic = i < nsurv ? i : 0u;
-        const uint32_t tc = a.slow_list ? a.slow_list[ic] : ic;  // (one more link of the chain in list mode: a dependent load)
+        const uint32_t e = a.slow_list ? a.slow_list[ic] : ic;  // (one more link of the chain in list mode: a dependent load)
+        const bool none = a.slow_list && e == WALK_NO_ENTRY;
+        const uint32_t tc0 = a.slow_list ? e & ~WALK_HAS_INFO : e, tc = !none && tc0 < ncap ? tc0 : 0u;
         const uint32_t d = a.walk_dst[tc];
         *pair = a.surv[tc];
-        *dst = i < nsurv ? d : NAN32;
+        *dst = i < nsurv && !none ? d : NAN32;
         *tt = tc;
+        *inf = a.slow_list && a.slow_info && !none && (e & WALK_HAS_INFO) && ic < a.info_cap ? ic : NAN32;
     };
     auto offs = [&](uint32_t pair, uint64_t o[3]) {
         o[0] = a.off[2 * (uint64_t)pair]; o[1] = a.off[2 * (uint64_t)pair + 1]; o[2] = a.off[2 * (uint64_t)pair + 2];
@@ -1276,11 +1327,11 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
     };
     auto uni64 = [&](uint64_t v) { return ((uint64_t)x.uni((uint32_t)(v >> 32)) << 32) | x.uni((uint32_t)v); };
     uint32_t tA = x.bid();
-    uint32_t dstA, pairA, dstB, pairB, dstC, pairC, dstD, pairD, ttA, ttB, ttC, ttD;
+    uint32_t dstA, pairA, dstB, pairB, dstC, pairC, dstD, pairD, ttA, ttB, ttC, ttD, infA, infB, infC, infD;
     uint64_t oA[3], oB[3], oC[3];
     uint32_t wA[2][2], wB[2][2];
-    meta(tA, &dstA, &pairA, &ttA); meta(tA + S_, &dstB, &pairB, &ttB); meta(tA + 2 * S_, &dstC, &pairC, &ttC);
-    dstA = x.uni(dstA); pairA = x.uni(pairA); dstB = x.uni(dstB); pairB = x.uni(pairB); ttA = x.uni(ttA); ttB = x.uni(ttB);
+    meta(tA, &dstA, &pairA, &ttA, &infA); meta(tA + S_, &dstB, &pairB, &ttB, &infB); meta(tA + 2 * S_, &dstC, &pairC, &ttC, &infC);
+    dstA = x.uni(dstA); pairA = x.uni(pairA); dstB = x.uni(dstB); pairB = x.uni(pairB); ttA = x.uni(ttA); ttB = x.uni(ttB); infA = x.uni(infA); infB = x.uni(infB);
     offs(pairA, oA); offs(pairB, oB);
     for (int q = 0; q < 3; ++q) { oA[q] = uni64(oA[q]); oB[q] = uni64(oB[q]); }
     raws(oA, wA);
@@ -1289,10 +1340,10 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
         W_STAMP(7);  // loop tail / pipeline rotation
         // the next items' loads, before anything of this item is waited for
         raws(oB, wB);
-        dstC = x.uni(dstC); pairC = x.uni(pairC); ttC = x.uni(ttC);
+        dstC = x.uni(dstC); pairC = x.uni(pairC); ttC = x.uni(ttC); infC = x.uni(infC);
         offs(pairC, oC);
-        meta(tA + 3 * S_, &dstD, &pairD, &ttD);
-        const uint32_t t = ttA, dst = dstA, pair = pairA;
+        meta(tA + 3 * S_, &dstD, &pairD, &ttD, &infD);
+        const uint32_t t = ttA, dst = dstA, pair = pairA, inf = infA;
         if (dst != NAN32) {
             int ret[2] = {0, 0};
             uint8_t* arec = nullptr;
@@ -1311,16 +1362,26 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
             len[0] = (uint32_t)(oA[1] - oA[0]); len[1] = (uint32_t)(oA[2] - oA[1]);
             for (int m = 0; m < 2; ++m) if (len[m] > (uint32_t)MAXL) { if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_READ_TOO_LONG; len[m] = MAXL; }
             // both mates: bytes -> LDS -> k-mers, and the graph look-ups of both in flight together
-            WalkProbe P0, P1;
             W_STAMP(0);  // prefetch issue + record slot
             walk_stage(x, smm[0], wA[0], oA[0], len[0]);
             walk_stage(x, smm[1], wA[1], oA[1], len[1]);
             W_STAMP(1);  // bytes (arrive) -> LDS, pack, cg.init
-            walk_probe_issue(x, smm[0], a.T, dst, len[0], P0, nullptr);
-            walk_probe_issue(x, smm[1], a.T, dst, len[1], P1, nullptr);
-            W_STAMP(2);  // k-mers + first-slot loads issued
-            walk_probe_finish(x, smm[0], a.T, dst, len[0], P0, smm[0].slot[0]);
-            walk_probe_finish(x, smm[1], a.T, dst, len[1], P1, smm[0].slot[1]);
+            if (inf != NAN32) {  // (uniform) the fast kernel looked every position up already: its row instead of the graph table
+                WalkInfoRow R0, R1;
+                const uint32_t* row = a.slow_info + (size_t)inf * 2 * a.info_stride;
+                walk_info_issue(x, smm[0], a.T, len[0], row, a.info_stride, R0);
+                walk_info_issue(x, smm[1], a.T, len[1], row + a.info_stride, a.info_stride, R1);
+                W_STAMP(2);
+                walk_info_finish(x, smm[0], a.T, dst, len[0], a.info_stride, R0, smm[0].slot[0]);
+                walk_info_finish(x, smm[1], a.T, dst, len[1], a.info_stride, R1, smm[0].slot[1]);
+            } else {
+                WalkProbe P0, P1;
+                walk_probe_issue(x, smm[0], a.T, dst, len[0], P0, nullptr);
+                walk_probe_issue(x, smm[1], a.T, dst, len[1], P1, nullptr);
+                W_STAMP(2);  // k-mers + first-slot loads issued
+                walk_probe_finish(x, smm[0], a.T, dst, len[0], P0, smm[0].slot[0]);
+                walk_probe_finish(x, smm[1], a.T, dst, len[1], P1, smm[0].slot[1]);
+            }
             W_STAMP(3);  // look-ups resolved -> LDS
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -1395,11 +1456,11 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
             W_STAMP(6);  // counting + results
         }
         // the pipeline moves on
-        dstA = dstB; pairA = pairB; ttA = ttB;
+        dstA = dstB; pairA = pairB; ttA = ttB; infA = infB;
         for (int q = 0; q < 3; ++q) { oA[q] = oB[q]; oB[q] = uni64(oC[q]); }
         for (int m = 0; m < 2; ++m) { wA[m][0] = wB[m][0]; wA[m][1] = wB[m][1]; }
-        dstB = dstC; pairB = pairC; ttB = ttC;
-        dstC = dstD; pairC = pairD; ttC = ttD;
+        dstB = dstC; pairB = pairC; ttB = ttC; infB = infC;
+        dstC = dstD; pairC = pairD; ttC = ttD; infC = infD;
     }
     if (a.aln && lane == 0)  // the slots of the last chunk that were not used
         for (; slot_used < ALN_CHUNK; ++slot_used) {

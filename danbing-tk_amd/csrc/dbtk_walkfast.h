@@ -36,7 +36,10 @@ DBTK_HD void body_grmz_insert(X& x, const GrMzBuildArgs& a) {
 // thread records are wanted — go to body_walk_pairs, the kernel that carries the error-correction machinery (and its 200+
 // registers); this one is the probe kernel's shape: one wave per pair, one mate per half-wave, NPL consecutive positions per
 // lane as shifts of one 32-base word, one 16-byte graph-table load per position, the feasibility of a mate one ballot.
-constexpr int WF_BUF = 64;
+#ifndef DBTK_WF_R
+#define DBTK_WF_R 2
+#endif
+constexpr uint32_t WF_R = DBTK_WF_R;  // places of the passed-on list a wave reserves at a time (what it does not use stays WALK_NO_ENTRY, an idle turn of the other kernel: 8 at a time cost that one 1 ms per 10 M reads, 1 at a time costs this one its atomics)
 // NPL of the lean kernel for a batch whose longest read has max_read_len bases (0: the kernel does not apply).  A half-wave's lanes hold the
 // k-mers of positions 0 .. 32 NPL - 1 — and, with the minimizer-grouped table, only the m-mers of those base positions: the window of the last
 // k-mer reaches m-mer len - m, so the bound is 32 NPL + m - 1 there (the probe kernel's), not 32 NPL + k - 1 (longer reads took the
@@ -51,7 +54,6 @@ DBTK_HD int walkfast_npl(uint32_t max_read_len, uint32_t k, bool grmz) {
 template <int NPL>
 struct __attribute__((aligned(16))) WalkFastSmemT {
     uint32_t pk[2][20];       // 2-bit stream of each mate from its 4-byte-aligned start
-    uint32_t buf[WF_BUF];     // passed-on survivors not yet appended to the list
     uint32_t rb[64 * NPL];    // bucket of every run of the pair (the minimizer-grouped copy of the graph table)
     uint4 stg[P2_RCH][P2_ROW];  // the buckets of a chunk of runs
     uint4 cache[P2_CACHE];    // {k-mer, info, locus} of single look-ups already made (info 0: no node): the wave works through the reads of a locus
@@ -62,18 +64,45 @@ struct __attribute__((aligned(16))) WalkFastSmemT {
 // counting of a kept pair, its text record, or the hand-over to the other kernel.
 struct WfState {
     uint64_t c_feas = 0, c_inc = 0;
-    uint32_t nbuf = 0;
+    uint32_t rbase = 0, rleft = 0;  // places of the passed-on list this wave has reserved and not used yet
     uint32_t txt_base = 0, txt_left = 0;  // text records (-a / -ae): arena bytes are taken TXT_CHUNK at a time, as in body_walk_pairs
 };
-template <int NPL, class X, class Flush>
+// A pair goes on to body_walk_pairs: its place in the list into the next reserved entry of the passed-on list — and, when the graph
+// info of all its positions is known (gi: this lane's NPL positions), that too: row e of slow_info for entry e, so that the other
+// kernel starts from what this one has looked up (260 graph-table probe sequences per pair otherwise, a quarter of its time).
+template <int NPL, class X>
+DBTK_HD void wf_hand_over(X& x, const WalkArgs& a, WfState& S, uint32_t i, const uint32_t* gi) {
+    const int lane = x.lane();
+    if (!S.rleft) {
+        uint32_t b = 0;
+        if (lane == 0) b = x.atomic_add(a.nslow, WF_R);
+        S.rbase = x.bcast(b, 0);
+        S.rleft = WF_R;
+    }
+    const uint32_t e = S.rbase + (WF_R - S.rleft);
+    --S.rleft;
+    const bool info = gi && a.slow_info && e < a.info_cap && a.info_stride == 32u * NPL;
+    if (lane == 0) a.slow_list[e] = i | (info ? WALK_HAS_INFO : 0u);
+    if (info) {
+        uint32_t* row = a.slow_info + ((size_t)e * 2 + ((uint32_t)lane >> 5)) * (32u * NPL) + ((uint32_t)lane & 31u) * NPL;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) row[j] = gi[j];
+    }
+}
+template <class X>
+DBTK_HD void wf_finish(X& x, const WalkArgs& a, WfState& S) {  // the reserved places nothing went into
+    if ((uint32_t)x.lane() < S.rleft) a.slow_list[S.rbase + (WF_R - S.rleft) + (uint32_t)x.lane()] = WALK_NO_ENTRY;
+    S.rleft = 0;
+}
+template <int NPL, class X>
 DBTK_HD void wf_decide(X& x, const WalkArgs& a, uint32_t i, uint32_t dst, uint32_t len, uint32_t nk, uint64_t badm, const uint64_t (&fw)[NPL],
-                       const uint64_t (&cn)[NPL], const uint32_t (&gi)[NPL], const bool (&act)[NPL], uint32_t* buf, WfState& S, Flush&& flush, bool texting,
+                       const uint64_t (&cn)[NPL], const uint32_t (&gi)[NPL], const bool (&act)[NPL], WfState& S, bool texting,
                        uint32_t* lcnt = nullptr, uint32_t lcap = 0) {
     const int lane = x.lane();
     const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5, p0 = hl * NPL;
     const DevTables& T = a.T;
     uint64_t& c_feas = S.c_feas; uint64_t& c_inc = S.c_inc;
-    uint32_t& nbuf = S.nbuf; uint32_t& txt_base = S.txt_base; uint32_t& txt_left = S.txt_left;
+    uint32_t& txt_base = S.txt_base; uint32_t& txt_left = S.txt_left;
     // oriented info of every position (as w_info), then the step test of walk_read: position p continues the walk iff the
     // k-mer before it is a node with an out-edge labelled by p's last base (and is not p's k-mer itself: a homopolymer)
     uint32_t go[NPL];
@@ -181,10 +210,7 @@ DBTK_HD void wf_decide(X& x, const WalkArgs& a, uint32_t i, uint32_t dst, uint32
             } else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
             txt_base += need; txt_left -= need;
         }
-    } else {
-        if (lane == 0) buf[nbuf] = i;
-        if (++nbuf == (uint32_t)WF_BUF) flush();
-    }
+    } else wf_hand_over<NPL>(x, a, S, i, badm ? nullptr : gi);
 }
 
 // WN = k - m + 1 m-mers per window when the minimizer-grouped copy of the graph table exists (T.grmz), else unused
@@ -208,15 +234,6 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
     for (uint32_t e = (uint32_t)lane; e < (uint32_t)P2_CACHE; e += 64) sm.cache[e] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu};
     WfState S;
     const bool texting = a.txt && (a.P.aln & 3) != 0;
-    auto flush = [&]() {
-        x.sync();
-        uint32_t base = 0;
-        if (lane == 0) base = x.atomic_add(a.nslow, S.nbuf);
-        base = x.bcast(base, 0);
-        if ((uint32_t)lane < S.nbuf) a.slow_list[base + lane] = sm.buf[lane];
-        x.sync();
-        S.nbuf = 0;
-    };
     // three-deep fetch pipeline as in the probe kernel: bytes of pair i + 1, offsets of pair i + 2, (pair, locus) of pair i + 3; the
     // place of pair i + 4 (i + 4 itself, or what a.sel says) is read an iteration before its list entries
     auto clampi = [&](uint32_t i) { return i < hi ? i : (first < hi ? first : 0u); };
@@ -315,8 +332,7 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
             q[j] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
         }
         if (badm) {  // (uniform) a pair with a non-ACGT byte is the other kernel's whatever its mates do
-            if (lane == 0) sm.buf[S.nbuf] = i;
-            if (++S.nbuf == (uint32_t)WF_BUF) flush();
+            wf_hand_over<NPL>(x, a, S, i, nullptr);
             continue;
         }
         if (T.grmz) {
@@ -417,9 +433,9 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
             for (int j = 0; j < NPL; ++j) open[j] = act[j];
             single();
         }
-        wf_decide<NPL>(x, a, i, dst, len, nk, badm, fw, cn, gi, act, sm.buf, S, flush, texting);
+        wf_decide<NPL>(x, a, i, dst, len, nk, badm, fw, cn, gi, act, S, texting);
     }
-    if (S.nbuf) flush();
+    wf_finish(x, a, S);
     if (lane == 0) {
         if (S.c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], S.c_feas);
         if (S.c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], S.c_inc);
@@ -434,7 +450,6 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
 template <int NPL, int NW>
 struct __attribute__((aligned(16))) WalkFastLocWaveSmemT {
     uint32_t pk[2][20];
-    uint32_t buf[WF_BUF];
 };
 constexpr uint32_t WFL_CNT = 2048;  // counters of the item's locus kept in LDS (a locus with more TR k-mers counts the rest directly)
 template <int NPL, int NW, int IMGB>
@@ -463,15 +478,6 @@ DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) 
     constexpr uint32_t S = 1;
     WfState W;
     const bool texting = a.txt && (a.P.aln & 3) != 0;
-    auto flush = [&]() {
-        x.sync();
-        uint32_t base = 0;
-        if (lane == 0) base = x.atomic_add(a.nslow, W.nbuf);
-        base = x.bcast(base, 0);
-        if ((uint32_t)lane < W.nbuf) a.slow_list[base + lane] = sm.buf[lane];
-        x.sync();
-        W.nbuf = 0;
-    };
     // this wave's pairs, item after item (as body_probe_locus): the fetch pipeline runs along that sequence across items
     struct Cur { uint32_t it; uint32_t i, end; };
     auto desc = [&](uint32_t it) -> uint4 { return r.items[it < nitems ? it : 0u]; };
@@ -570,8 +576,7 @@ DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) 
             }
             if (dst == NAN32) continue;  // the pair never reached threading (uniform)
             if (dst != locus) {          // (uniform, rare) voted to another locus than the list's order has it under: the other kernel's
-                if (lane == 0) sm.buf[W.nbuf] = i;
-                if (++W.nbuf == (uint32_t)WF_BUF) flush();
+                wf_hand_over<NPL>(x, a, W, i, nullptr);
                 continue;
             }
             x.sync();
@@ -584,8 +589,7 @@ DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) 
             const uint64_t badm = x.ballot(bad != 0 && 8 * hl < rsh + len);
             x.sync();
             if (badm) {  // (uniform) a pair with a non-ACGT byte is the other kernel's whatever its mates do
-                if (lane == 0) sm.buf[W.nbuf] = i;
-                if (++W.nbuf == (uint32_t)WF_BUF) flush();
+                wf_hand_over<NPL>(x, a, W, i, nullptr);
                 continue;
             }
             const uint64_t Wd = window_fw_clean(sm.pk[half], rsh + p0, 32);
@@ -643,12 +647,12 @@ DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) 
             // the image's pay word -> the graph table's info word: the flags as they are, the counter back at GR_SLOT_SHIFT (the extra tag bits dropped)
 #pragma unroll
             for (int j = 0; j < NPL; ++j) gi[j] &= 0x00FFFFFFu;
-            wf_decide<NPL>(x, a, i, dst, len, nk, badm, fw, cn, gi, act, sm.buf, W, flush, texting, smb.cnt, WFL_CNT);
+            wf_decide<NPL>(x, a, i, dst, len, nk, badm, fw, cn, gi, act, W, texting, smb.cnt, WFL_CNT);
         }
     }
     x.bsync();
     flush_counts();
-    if (W.nbuf) flush();
+    wf_finish(x, a, W);
     if (lane == 0) {
         if (W.c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], W.c_feas);
         if (W.c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], W.c_inc);

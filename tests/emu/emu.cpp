@@ -923,7 +923,12 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
             w.aln = alnraw.data(); w.aln_stride = g_aln_stride; w.aln_cap = g_aln_cap; w.aln_max = (uint32_t)amax; w.naln = &naln;
         }
         // the two-kernel form where nothing needs every mate's alignment, as launch_batch decides
-        std::vector<uint32_t> slow(npairs + 1, 0);
+        // (the passed-on list: the fast kernels' waves reserve WF_R places at a time; rows of graph info for HALF of its entries only,
+        // so that both of the other kernel's ways of getting a pair's graph nodes run in every test)
+        const size_t slow_cap = npairs + (size_t)WF_R * 64 * 16 + 8;
+        std::vector<uint32_t> slow(slow_cap, 0xABABABABu);
+        const size_t info_rows = std::min<size_t>(slow_cap, std::max<size_t>(npairs / 2, 4));
+        std::vector<uint32_t> slow_info(info_rows * 2 * 160, 0xCDCDCDCDu);
         uint32_t nslow = 0;
         const uint32_t kk = g->ksize;
         const int wnpl = (((p->aln & 3u) && !txtmode) || g_walk_trecs) ? 0 : walkfast_npl(maxlen, kk, w.T.grmz != nullptr);
@@ -932,6 +937,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         uint32_t wnit[4] = {0, 0, 0, 0};
         if (wnpl) {
             w.slow_list = slow.data(); w.nslow = &nslow;
+            w.slow_info = slow_info.data(); w.info_cap = (uint32_t)info_rows; w.info_stride = 32u * (uint32_t)wnpl;
             if (w.T.gldir) {  // the locus-resident form first, as launch_batch does (4 waves per workgroup here)
                 constexpr int EMU_IMGB_XS = LOC_HDR + (32 << 9) + (1 << 9), EMU_IMGB_S = LOC_HDR + (32 << 10) + (1 << 10), EMU_IMGB_L = LOC_HDR + (32 << LOC_LG_MAX) + (1 << LOC_LG_MAX);
                 const uint32_t item_cap = (uint32_t)(npairs / LOC_CH + nloci + 2);
@@ -976,7 +982,13 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
                 if (w11) run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<5>), [&](EmuX& x) { body_walk_fast<5, 11>(x, w); });
                 else run_grid(grid_pair + 1, 64, sizeof(WalkFastSmemT<5>), [&](EmuX& x) { body_walk_fast<5, 7>(x, w); });
             }
-            g_walk_fast_runs += 1; g_walk_slow_pairs += nslow;
+            if (nslow > slow_cap) { fprintf(stderr, "emu: the passed-on list outgrew its reservation bound\n"); abort(); }
+            uint32_t nreal = 0;
+            for (uint32_t q = 0; q < nslow; ++q) {
+                if (slow[q] == 0xABABABABu) { fprintf(stderr, "emu: a reserved place of the passed-on list was left unwritten\n"); abort(); }
+                nreal += slow[q] != WALK_NO_ENTRY;
+            }
+            g_walk_fast_runs += 1; g_walk_slow_pairs += nreal;
         }
         run_grid(grid_pair, 64, 2 * sizeof(WalkSmem), [&](EmuX& x) { body_walk_pairs(x, w); });
         if (txtmode) g_txt.resize(ntxt <= g_txt.size() ? ntxt : g_txt.size());

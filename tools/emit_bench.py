@@ -46,13 +46,14 @@ def main():
         if os.environ.get("EMIT_BENCH_ROCPROF"):
             pd = os.path.abspath(os.environ["EMIT_BENCH_ROCPROF"])
             os.makedirs(pd, exist_ok=True)
-            r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", pd, "--"] + base + ["-ae", "--aln-gz", "w_prof.aln.gz"],
+            prof_extra = [] if os.environ.get("EMIT_BENCH_ROCPROF_NOEMIT") else ["-ae", "--aln-gz", "w_prof.aln.gz"]
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", pd, "--"] + base + prof_extra,
                                cwd=d, capture_output=True, text=True, env=dict(os.environ, TMPDIR="/tmp"))
             print("rocprofv3 rc", r.returncode, [l for l in r.stderr.splitlines() if l.startswith("ingest:")])
             for root, _, files in os.walk(pd):
                 for f in files:
                     if f.endswith("kernel_stats.csv"):
-                        print("\n".join(l[:150] for l in open(os.path.join(root, f)).read().splitlines()[:22]))
+                        print("\n".join(l[:150] for l in open(os.path.join(root, f)).read().splitlines()[:int(os.environ.get('EMIT_BENCH_ROCPROF_LINES', '22'))]))
         for al, th in variants:
             run(["-ae", "--aln-gz", "w.aln.gz", "--host-ingest", "--aln-aligners", str(al), "--emit-threads", str(th)], f"-ae --aln-gz host A={al} T={th}")
         a, b = os.path.join(d, "w_dev.aln.gz"), os.path.join(d, "w.aln.gz")
