@@ -477,7 +477,8 @@ def main():
                                         correction=1, maxncorrection=3)
                 t0 = time.time()
                 ctxw = dbtk.context(g, pw, device=local_rank)
-                log(f"walk context (graph table in HBM): {time.time() - t0:.1f}s")
+                tbw = ctxw.table_bytes()
+                log(f"walk context (graph table in HBM): {time.time() - t0:.1f}s; tables of a walking context: {tbw.get('total', 0) / 1e9:.1f} GB")
                 ctxw.timers_enable(1)
                 dtw = time_steps(ctxw, lambda: ctxw.align_device(d_ah.data_ptr(), d_aho.data_ptr(), mp, rlen), args.mix_steps, 2)
                 cw = ctxw.counters().astype(np.float64)
@@ -487,7 +488,7 @@ def main():
                 mixes["walk_gc85_3"] = dict(workload=f"{2 * mp} reads per step, 100 % of pairs from loci, --v13-threading -gc 85 3 -k 21 -kf 4 1 -cth 45 -ka",
                                             value=2 * mp * args.mix_steps / dtw, unit="reads/s", ms_per_step=dtw / args.mix_steps * 1e3,
                                             steps=args.mix_steps, reads_walked_per_step=cw[abi.C_THREADING] / args.mix_steps,
-                                            reads_feasible_per_step=cw[abi.C_FEASIBLE] / args.mix_steps,
+                                            reads_feasible_per_step=cw[abi.C_FEASIBLE] / args.mix_steps, hbm_bytes_tables=tbw,
                                             roofline=dict(roofline_of(domw, tw), kernels=tw, profiled=pmc_mix("walk", "k_walk_pairs"),
                                                           traffic=(pmc_mix("walk", "k_walk_pairs") or {}).get("traffic")))
                 log(f"walk mix: {dtw / args.mix_steps * 1e3:.3f} ms/step, {mixes['walk_gc85_3']['value'] / 1e6:.1f} M reads/s, dominant {domw} {tw[domw]['avg_ms']:.3f} ms")

@@ -849,7 +849,7 @@ dbtk_status_t build_graph_table(dbtk_ctx* c) {
         if (const char* e = getenv("DBTK_MZ")) on = atoi(e) != 0;
         const uint32_t m = mz_m_for_k(g->ksize);
         if (on && m) {
-            uint64_t gper = 6;  // buckets per 8 entries, as the index's copy (DBTK_GRMZ_SPARSITY)
+            uint64_t gper = 3;  // buckets per 8 entries, as the index's copy (DBTK_GRMZ_SPARSITY; 6 was 17 GB at release scale for +0.6 % on the global lean walk kernel, which only takes what the locus-resident one leaves)
             if (const char* e = getenv("DBTK_GRMZ_SPARSITY")) { const long v = atol(e); if (v >= 1 && v <= 64) gper = (uint64_t)v; }
             uint64_t nb = pow2_at_least(nent * gper / 8 + 8);
             if (nb > (1ull << 28)) nb = 1ull << 28;
