@@ -992,8 +992,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         for (int q = 0; q < 3; ++q) wf_waves += (uint64_t)std::max(c->wfl_blocks[q], c->wfl_blocks[3 + q]) * (q == 0 ? LOC_NW_XS : q == 1 ? LOC_NW_S : LOC_NW_L);
         slow_cap = npairs + WF_R * wf_waves + 8;
         info_rows = std::min<uint64_t>(slow_cap, std::max<uint64_t>(walk_txt ? npairs / 2 : npairs / 8, 4096));
-        static const bool no_info = getenv("DBTK_WALK_INFO") && atoi(getenv("DBTK_WALK_INFO")) == 0;  // diagnostic
-        if (no_info) info_rows = 0;
+        if (const char* e = getenv("DBTK_WALK_INFO_ROWS")) info_rows = std::min<uint64_t>(slow_cap, (uint64_t)std::max<long>(atol(e), 0));  // diagnostic / tests: 0 = none, a few = both ways in one batch
         if ((st = ensure(&c->d_walk, &c->walk_cap, 2 * npairs + slow_cap + info_rows * 2 * 160))) return st;
         HIPCHK(hipMemsetAsync(c->d_walk, 0xFF, npairs * sizeof(uint32_t), s));  // NAN32: the pair does not reach threading
     }

@@ -514,6 +514,31 @@ def test_gpu_pair_mode_equals_oracle(tmp_path, k, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows", ["0", "5"])
+def test_gpu_pair_mode_with_few_graph_info_rows(tmp_path, monkeypatch, rows):
+    """The lean walk kernels hand the graph info of a passed-on pair's positions to the error-correction kernel as long as
+    there are rows for it (WalkArgs::slow_info); a pair beyond them is looked up again there.  With no rows, and with five (both
+    ways inside one batch), the results are the oracle's."""
+    monkeypatch.setenv("DBTK_WALK_INFO_ROWS", rows)
+    O = bind.Oracle()
+    D = bind.pkg.Dbtk()
+    case = WalkCase(str(tmp_path), f"gi{rows}", 21, 3)
+    oh = O.load(case.prefix, 21); O.load_graph(oh, case.prefix + ".graph.kmers")
+    g = D.load(case.prefix, 21, flags=abi.LOAD_GRAPH)
+    order = g.output_order()
+
+    def run(p, seq, off):
+        ctx = D.context(g, p, device=0)
+        ctx.align(seq, off)
+        r = ctx.counts()
+        res, _, nres = ctx.walk_results(len(off))
+        out = dict(counts=r["counts"], counters=r["counters"], res=res, nres=nres, aln=ctx.aln_records(), order=order, txt=ctx.aln_text(len(off) // 2))
+        ctx.close()
+        return out
+    check_pair_mode(run, O, oh, case, 21, case.loci.nloci)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k,rlen", [(21, r) for r in LIMIT_RLENS] + [(25, 110), (25, 113), (25, 175), (25, 184), (17, 112), (17, 176)])
 def test_gpu_pair_mode_at_the_lean_kernels_length_limits(tmp_path, k, rlen):
     O = bind.Oracle()
