@@ -95,7 +95,7 @@ def main():
     for lib, env in variants:
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--nloci", str(a.nloci), "--k", str(a.k), "--mix-reads", str(a.mix_reads),
                "--reads", str(a.reads), "--steps", str(a.steps), "--rounds", str(a.rounds), "--diag", str(a.diag)] + (["--lib", lib] if lib else [])
-        r = subprocess.run(cmd, env=dict(os.environ, DBTK_LANES=os.environ.get("DBTK_LANES", "1"), **env), capture_output=True, text=True)  # (one lane: a kernel's duration must not include its neighbour's)
+        r = subprocess.run(cmd, env={**os.environ, "DBTK_LANES": os.environ.get("DBTK_LANES", "1"), **env}, capture_output=True, text=True)  # (one lane: a kernel's duration must not include its neighbour's)
         line = [l for l in r.stdout.splitlines() if l.startswith("PROBE_BENCH ")]
         if not line:
             print(f"variant {lib} {env}: FAILED rc={r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-3000:]}", flush=True)
