@@ -263,6 +263,14 @@ class Context:
         n = self._lib.L.dbtk_ctx_table_bytes(self.h, names, b, 24)
         return {names[i].decode(): int(b[i]) for i in range(n)}
 
+    def path_stats(self):
+        """Which kernels took how many pairs since creation / reset (dbtk.h: DBTK_PS_*): a dict."""
+        v = (C.c_uint64 * 16)()
+        n = self._lib.L.dbtk_ctx_path_stats(self.h, v, 16)
+        v = [int(x) for x in v[:n]] + [0] * (16 - n)
+        return {"probe_items": v[0:3], "probe_pairs": v[3:6], "probe_rest": v[6], "walk_items": v[7:10], "walk_pairs": v[10:13],
+                "walk_rest": v[13], "fused_done": v[14], "fused_redone": v[15]}
+
     def timers_reset(self):
         self._lib.L.dbtk_ctx_timers_reset(self.h)
 
@@ -308,6 +316,10 @@ class Dbtk(_HostSide):
         L.dbtk_ctx_reset.argtypes = [C.c_void_p]
         L.dbtk_ctx_kernel_times.restype = C.c_int
         L.dbtk_ctx_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), u64p, C.c_int]
+        L.dbtk_ctx_path_stats.restype = C.c_int
+        L.dbtk_ctx_path_stats.argtypes = [C.c_void_p, u64p, C.c_int]
+        L.dbtk_ctx_table_bytes.restype = C.c_int
+        L.dbtk_ctx_table_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), u64p, C.c_int]
         L.dbtk_ctx_timers_reset.argtypes = [C.c_void_p]
         L.dbtk_ctx_timers_enable.argtypes = [C.c_void_p, C.c_int]
         L.dbtk_ctx_write_bubbles.restype = C.c_int
@@ -400,7 +412,7 @@ EXPORTS = [
     "dbtk_rpgg_load", "dbtk_rpgg_load_tr", "dbtk_rpgg_uid", "dbtk_rpgg_from_arrays", "dbtk_rpgg_free", "dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys",
     "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
-    "dbtk_allreduce", "dbtk_rpgg_set_index_cache", "dbtk_ctx_table_bytes", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_aln_text", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
+    "dbtk_allreduce", "dbtk_rpgg_set_index_cache", "dbtk_ctx_table_bytes", "dbtk_ctx_path_stats", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_aln_text", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
     "dbtk_thread_batch", "dbtk_ctx_walk_results", "dbtk_ctx_aln_records", "dbtk_aln_format",
     "dbtk_ingest_create", "dbtk_ingest_free", "dbtk_ingest_chunk_buffer", "dbtk_ingest_block", "dbtk_ingest_submit", "dbtk_ingest_wait",
     "dbtk_ingest_align", "dbtk_ingest_spans", "dbtk_ingest_aln_lines",
@@ -481,6 +493,7 @@ class Synth:
         L.dbtk_synth_nbases.restype = C.c_uint64
         L.dbtk_synth_nbases.argtypes = [C.c_void_p]
         L.dbtk_synth_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_uint64, u8p, C.c_uint32]
+        L.dbtk_synth_reads_loci.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_double, C.c_uint64, u8p, C.c_uint32]
         L.dbtk_synth_graph.argtypes = [C.c_void_p, C.c_uint32]
         L.dbtk_synth_write_files.restype = C.c_int
         L.dbtk_synth_write_files.argtypes = [C.c_void_p, C.c_char_p]
@@ -512,6 +525,15 @@ class Synth:
         if out is None:
             out = np.empty(npairs * 2 * rlen, np.uint8)
         self.L.dbtk_synth_reads(self.h, npairs, first_pair, rlen, float(hit_frac), seed, _ptr(out, u8p), nthreads)
+        off = np.arange(2 * npairs + 1, dtype=np.uint64) * np.uint64(rlen)
+        return out, off
+
+    def reads_loci(self, npairs, loci, rlen=150, odd_frac=0.1, seed=1, first_pair=0, nthreads=0):
+        """(seq bytes, offsets): pair p drawn from loci[p % len(loci)] — a DENSE slice (many pairs per locus: the regime of the
+        locus-resident kernels); odd_frac of the pairs chimeric (mate 2 from any locus) or foreign (both from any locus)."""
+        loci = np.ascontiguousarray(loci, np.uint32)
+        out = np.empty(npairs * 2 * rlen, np.uint8)
+        self.L.dbtk_synth_reads_loci(self.h, npairs, first_pair, rlen, _ptr(loci, C.POINTER(C.c_uint32)), len(loci), float(odd_frac), seed, _ptr(out, u8p), nthreads)
         off = np.arange(2 * npairs + 1, dtype=np.uint64) * np.uint64(rlen)
         return out, off
 

@@ -1055,11 +1055,11 @@ int main(int argc, char* argv[]) {
         if (piped) (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);  // (a larger pipe buffer: fewer wake-ups of the producer; refused for a non-pipe, which is fine)
 #endif
         const uint64_t total = piped ? 0 : hi - lo;
-        uint64_t nchunks = piped ? ~0ull : std::max<uint64_t>(1, (total + CH - 1) / CH);  // (a pipe: known once its end has been read)
+        std::atomic<uint64_t> nchunks{piped ? ~0ull : std::max<uint64_t>(1, (total + CH - 1) / CH)};  // (a pipe: known once its end has been read; the batch loop reads it without the lock)
         std::mutex m;
         std::condition_variable cv;
-        std::vector<char> filled(piped ? 0 : nchunks, 0);
-        std::vector<uint64_t> chunk_n(piped ? 0 : nchunks, 0);  // bytes of each chunk
+        std::vector<char> filled(piped ? 0 : nchunks.load(), 0);
+        std::vector<uint64_t> chunk_n(piped ? 0 : nchunks.load(), 0);  // bytes of each chunk
         if (!piped) for (uint64_t j = 0; j < nchunks; ++j) chunk_n[j] = std::min<uint64_t>(CH, total - j * CH);
         uint64_t next_read = 0, nreleased = 0;
         bool stop = false;
@@ -1067,7 +1067,6 @@ int main(int argc, char* argv[]) {
         uint64_t pipe_cur = 0;  // (pipe) the chunk being read when the reader was told to stop
         auto io_pipe = [&] {  // sequential: chunk j is handed on once chunk j + 1 has its first byte, or the pipe has ended
             uint64_t j = 0;
-            bool have_byte = false;  // chunk j already holds bytes read as the look-ahead behind chunk j - 1
             size_t got = 0;
             for (;;) {
                 {
@@ -1078,7 +1077,7 @@ int main(int argc, char* argv[]) {
                 }
                 const double t0 = now();
                 char* dst = (char*)dbtk_ingest_chunk_buffer(ing, (uint32_t)(j % NS));
-                if (!have_byte) got = 0;
+                got = 0;
                 bool eof = false;
                 while (got < CH) {
                     const ssize_t r = read(fd, dst + got, CH - got);
@@ -1086,10 +1085,9 @@ int main(int argc, char* argv[]) {
                     if (r < 0) die_assert("read error on " + o.fastxFname);
                     if (r == 0) { eof = true; break; }
                     got += (size_t)r;
-                    if (have_byte || got == (size_t)r) {  // the first bytes of this chunk: the chunk before it is not the last one
+                    if (got == (size_t)r) {  // the first bytes of this chunk: the chunk before it is not the last one
                         std::lock_guard<std::mutex> l(m);
                         if (j > 0 && filled[j - 1] == 2) { filled[j - 1] = 1; cv.notify_all(); }
-                        have_byte = false;
                     }
                     { std::lock_guard<std::mutex> l(m); if (stop) { chunk_n[j] = got; pipe_cur = j; return; } }
                 }
@@ -1106,7 +1104,7 @@ int main(int argc, char* argv[]) {
                     }
                     filled[j] = 2;  // full: whether it is the last one shows with the next read
                 }
-                ++j; got = 0; have_byte = false;
+                ++j; got = 0;
             }
         };
         auto io = [&] {
@@ -1137,7 +1135,7 @@ int main(int argc, char* argv[]) {
             }
         };
         std::vector<std::thread> ios;
-        int nio = piped ? 1 : (int)std::min<uint64_t>(nchunks, std::max(1u, std::min(8u, cpus / 2 / (unsigned)std::max(1, npipes))));  // (the pipelines share the host's threads)
+        int nio = piped ? 1 : (int)std::min<uint64_t>(nchunks.load(), std::max(1u, std::min(8u, cpus / 2 / (unsigned)std::max(1, npipes))));  // (the pipelines share the host's threads)
         if (const char* e = getenv("DBTK_INGEST_READERS")) { const int v = atoi(e); if (v > 0 && !piped) nio = v; }
         if (piped) ios.emplace_back(io_pipe);
         else for (int i = 0; i < nio; ++i) ios.emplace_back(io);
@@ -1229,6 +1227,13 @@ int main(int argc, char* argv[]) {
             if (dbtk_ingest_wait(ing, slot, &info)) die_assert(std::string("ingest: ") + dbtk_last_error());
             wait_s += now() - t0;
             if (jaln == 0) first_s = now() - ts0;
+            if (piped && info.flags) {
+                // the host reader takes over behind this block and replays what was taken from the pipe: the pipe's reader must stop BEFORE the
+                // block is released (by the writer, or below) — a released block lets it read chunk jaln + NS into this very slot, over the
+                // bytes the replay starts with
+                { std::lock_guard<std::mutex> l(m); stop = true; }
+                cv.notify_all();
+            }
             if (info.flags & (DBTK_ING_DIRTY | DBTK_ING_LINES)) { *resume = lo + info.first_byte; handed = true; hslot = slot; std::lock_guard<std::mutex> l(gb_m); gb += now() - t0; break; }
             if (want_out) {
                 { std::lock_guard<std::mutex> l(gb_m); gb += now() - t0; }

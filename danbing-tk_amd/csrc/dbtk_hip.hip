@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <deque>
@@ -16,6 +17,7 @@
 #include <atomic>
 #include <memory>
 #include <mutex>
+#include <random>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -93,6 +95,7 @@ __global__ void __launch_bounds__(256) k_loc_count(LocBuildArgs a) { DevX x{null
 __global__ void __launch_bounds__(256) k_loc_scatter(LocBuildArgs a) { DevX x{nullptr}; body_loc_scatter(x, a); }
 __global__ void __launch_bounds__(64) k_loc_place(LocBuildArgs a) { DevX x{nullptr}; body_loc_place(x, a); }
 __global__ void __launch_bounds__(256) k_loc_verify(LocBuildArgs a) { DevX x{nullptr}; body_loc_verify(x, a); }
+__global__ void __launch_bounds__(256) k_csum(const uint64_t* p, uint64_t n, uint64_t* out) { DevX x{nullptr}; body_csum(x, p, n, out); }
 __global__ void __launch_bounds__(256) k_gloc_count(LocBuildArgs a) { DevX x{nullptr}; body_gloc_count(x, a); }
 __global__ void __launch_bounds__(256) k_gloc_scatter(LocBuildArgs a) { DevX x{nullptr}; body_gloc_scatter(x, a); }
 __global__ void __launch_bounds__(256) k_loc_items(LocItemArgs a) { DevX x{nullptr}; body_loc_items(x, a); }
@@ -258,6 +261,7 @@ struct dbtk_ctx {
     uint16_t* d_perm = nullptr;
     uint64_t* d_accum = nullptr;  // counts | kmc | nmapread | counters
     uint64_t* d_ctr = nullptr;    // counter replicas (folded into d_accum's counters at the end of every batch)
+    uint64_t* d_pstats = nullptr; // path statistics (dbtk.h: dbtk_ctx_path_stats): which kernels took how many pairs; never part of the results
     uint64_t n_accum = 0, ntr = 0;
     uint32_t* d_small = nullptr;  // nsurv, novf, nrec, errflag
     uint32_t* d_surv = nullptr; uint64_t surv_cap = 0;  // the encode stage's survivor list | the list in locus order | keys | histogram
@@ -362,7 +366,7 @@ void free_ctx(dbtk_ctx* c) {
             if (c->timed[i].beg[j]) (void)hipEventDestroy(c->timed[i].beg[j]);
             if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
         }
-    void* ptrs[] = {c->d_ctr, c->d_accum, c->d_small, c->d_surv,
+    void* ptrs[] = {c->d_ctr, c->d_pstats, c->d_accum, c->d_small, c->d_surv,
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
                     c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_walk, c->d_trecs, c->d_loci, c->d_aln, c->d_txt, c->d_txtidx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -555,8 +559,9 @@ struct LocCacheHdr {
     uint32_t version, ksize;
     uint64_t nloci, nkeys, fingerprint, arena_bytes, nimg, left_out;
     uint32_t lg_max, hdr_bytes;
+    uint64_t checksum;       // of the directory and the arena (csum_term over their 8-byte words): a torn, mixed or bit-flipped file is not used
 };
-constexpr uint32_t LOC_CACHE_VERSION = 3;  // (bumped with every change of the image layout or of its hashes)
+constexpr uint32_t LOC_CACHE_VERSION = 4;  // (bumped with every change of the image layout or of its hashes)
 // what the images were built from: the handle's arrays, sampled (a different RPGG, another -t N order, a changed file: another value)
 static uint64_t rpgg_fingerprint(const dbtk_rpgg* g) {
     uint64_t h = 0xCBF29CE484222325ull;
@@ -565,6 +570,23 @@ static uint64_t rpgg_fingerprint(const dbtk_rpgg* g) {
     auto sample = [&](const auto& v) { const size_t n = v.size(), st = n / 65536 + 1; for (size_t i = 0; i < n; i += st) mixin((uint64_t)v[i]); if (n) mixin((uint64_t)v[n - 1]); };
     sample(g->keys); sample(g->vals); sample(g->vv); sample(g->tr_ks); sample(g->fl_ks); sample(g->out_slot); sample(g->out_beg); sample(g->tr_cnt); sample(g->fl_cnt);
     return h;
+}
+// checksum of the sidecar's payload: the directory (host) and the arena as it lies in HBM (device)
+static dbtk_status_t locus_cache_checksum(dbtk_ctx* c, const std::vector<LocusDir>& dir, const uint8_t* d_arena, uint64_t arena_bytes, uint64_t* out) {
+    static_assert(sizeof(LocusDir) == 16, "directory entries are two checksum words");
+    uint64_t hd = 0;
+    const uint64_t* dw = reinterpret_cast<const uint64_t*>(dir.data());
+    for (uint64_t i = 0; i < 2 * dir.size(); ++i) hd += csum_term(dw[i], i);
+    uint64_t* dsum = nullptr;
+    HIPCHK(hipMalloc(&dsum, 8));
+    HIPCHK(hipMemsetAsync(dsum, 0, 8, c->stream));
+    LAUNCH(k_csum, dim3(2048), dim3(256), c->stream, reinterpret_cast<const uint64_t*>(d_arena), arena_bytes / 8, dsum);
+    uint64_t ha = 0;
+    HIPCHK(hipMemcpyAsync(&ha, dsum, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(dsum));
+    *out = ha + hd * 0x9E3779B97F4A7C15ull + arena_bytes;
+    return DBTK_OK;
 }
 // DBTK_OK: the images are in HBM, from the file; DBTK_ERR_FORMAT: no file, or not one of this RPGG / this layout / this build: the caller builds
 static dbtk_status_t load_locus_cache(dbtk_ctx* c, uint64_t fp) {
@@ -603,23 +625,37 @@ static dbtk_status_t load_locus_cache(dbtk_ctx* c, uint64_t fp) {
         (void)hipHostFree(pin);
         if (!ok) { (void)hipFree(c->d_ldir); (void)hipFree(c->d_limg); c->d_ldir = nullptr; c->d_limg = nullptr; return DBTK_ERR_FORMAT; }
     }
+    auto drop = [&]() { (void)hipFree(c->d_ldir); (void)hipFree(c->d_limg); c->d_ldir = nullptr; c->d_limg = nullptr; return DBTK_ERR_FORMAT; };
+    {   // the bytes are the ones that were written (a torn write, two writers' blocks mixed, a flipped bit: not used)
+        uint64_t sum = 0;
+        const dbtk_status_t cs = locus_cache_checksum(c, dir, c->d_limg, h.arena_bytes, &sum);
+        if (cs) { (void)drop(); return cs; }
+        if (sum != h.checksum) return drop();
+    }
     HIPCHK(hipMemcpyAsync(c->d_ldir, dir.data(), nloci * sizeof(LocusDir), hipMemcpyHostToDevice, s));
-    uint32_t* dbad = nullptr;
+    // ... and they are THIS index's images: every entry looked up in the plain index just built from the RPGG, the entries of a locus
+    // counted against its keys in the index (a file of another RPGG of the same sizes, one rebuilt in place: not used)
+    uint32_t *dbad = nullptr, *dvcnt = nullptr, *dcnt = nullptr;
     HIPCHK(hipMalloc(&dbad, nloci * 4));
+    HIPCHK(hipMalloc(&dvcnt, nloci * 4));
+    HIPCHK(hipMalloc(&dcnt, nloci * 4));
     HIPCHK(hipMemsetAsync(dbad, 0, nloci * 4, s));
+    HIPCHK(hipMemsetAsync(dvcnt, 0, nloci * 4, s));
+    HIPCHK(hipMemsetAsync(dcnt, 0, nloci * 4, s));
     LocBuildArgs a;
     memset(&a, 0, sizeof(a));
-    a.trbeg = c->d_trbeg; a.nloci = (uint32_t)nloci; a.ksize = g->ksize; a.dir = c->d_ldir; a.arena = c->d_limg; a.bad = dbad;
+    a.idx = c->d_idx; a.nslots = (c->T.idx_mask + 1) * 4; a.idx_mask = c->T.idx_mask; a.idx_shift = c->T.idx_shift; a.vv = c->d_vv;
+    a.trbeg = c->d_trbeg; a.nloci = (uint32_t)nloci; a.ksize = g->ksize; a.dir = c->d_ldir; a.arena = c->d_limg; a.bad = dbad; a.vcnt = dvcnt; a.cnt = dcnt;
+    LAUNCH(k_loc_count, dim3(2048), dim3(256), s, a);
     LAUNCH(k_loc_verify, dim3(4096), dim3(256), s, a);
-    std::vector<uint32_t> bad(nloci);
+    std::vector<uint32_t> bad(nloci), vcnt(nloci), cnt(nloci);
     HIPCHK(hipMemcpyAsync(bad.data(), dbad, nloci * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(vcnt.data(), dvcnt, nloci * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(cnt.data(), dcnt, nloci * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipFree(dbad));
+    HIPCHK(hipFree(dbad)); HIPCHK(hipFree(dvcnt)); HIPCHK(hipFree(dcnt));
     for (uint64_t l = 0; l < nloci; ++l)
-        if (bad[l]) {  // a damaged file: nothing of it is used
-            (void)hipFree(c->d_ldir); (void)hipFree(c->d_limg); c->d_ldir = nullptr; c->d_limg = nullptr;
-            return DBTK_ERR_FORMAT;
-        }
+        if (bad[l] || (dir[l].bytes && vcnt[l] != cnt[l])) return drop();  // nothing of such a file is used
     c->limg_bytes = h.arena_bytes; c->loc_nimg = nimg; c->loc_left_out = h.left_out; c->loc_from_cache = true;
     c->T.ldir = c->d_ldir; c->T.limg = c->d_limg;
     if (getenv("DBTK_VERBOSE")) fprintf(stderr, "locus images: %llu loci, %.1f MB, from %s\n", (unsigned long long)nimg, h.arena_bytes / 1e6, g->idx_cache.c_str());
@@ -628,14 +664,18 @@ static dbtk_status_t load_locus_cache(dbtk_ctx* c, uint64_t fp) {
 // (best effort: a sidecar that cannot be written is not an error of the run)
 static void write_locus_cache(dbtk_ctx* c, uint64_t fp, const std::vector<LocusDir>& dir) {
     const dbtk_rpgg* g = c->g;
-    const std::string tmp = g->idx_cache + ".tmp" + std::to_string((unsigned long long)g->uid);
+    // (a name of its own per writer: two jobs on one RPGG prefix must not write into one file)
+    std::random_device rd;
+    const std::string tmp = g->idx_cache + ".tmp" + std::to_string((unsigned long long)getpid()) + "." + std::to_string((unsigned long long)g->uid) + "." + std::to_string((unsigned long long)rd());
+    uint64_t sum = 0;
+    if (locus_cache_checksum(c, dir, c->d_limg, (c->limg_bytes + 15) & ~15ull, &sum)) return;
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) return;
     LocCacheHdr h;
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, "DBTKIDX\1", 8);
     h.version = LOC_CACHE_VERSION; h.ksize = g->ksize; h.nloci = g->nloci; h.nkeys = g->keys.size(); h.fingerprint = fp;
-    h.arena_bytes = (c->limg_bytes + 15) & ~15ull; h.nimg = c->loc_nimg; h.left_out = c->loc_left_out; h.lg_max = LOC_LG_MAX; h.hdr_bytes = sizeof(h);
+    h.arena_bytes = (c->limg_bytes + 15) & ~15ull; h.nimg = c->loc_nimg; h.left_out = c->loc_left_out; h.lg_max = LOC_LG_MAX; h.hdr_bytes = sizeof(h); h.checksum = sum;
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(dir.data(), sizeof(LocusDir), dir.size(), f) == dir.size();
     const uint64_t CH = 64ull << 20;
     uint8_t* pin = nullptr;
@@ -646,6 +686,7 @@ static void write_locus_cache(dbtk_ctx* c, uint64_t fp, const std::vector<LocusD
         }
         (void)hipHostFree(pin);
     } else ok = false;
+    if (ok && (fflush(f) != 0 || fsync(fileno(f)) != 0)) ok = false;  // (on the disk before it takes the name)
     if (fclose(f) != 0) ok = false;
     if (!ok || rename(tmp.c_str(), g->idx_cache.c_str()) != 0) remove(tmp.c_str());
 }
@@ -1016,6 +1057,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     a.nmapread = a.kmc + c->g->nloci;
     a.counters = a.nmapread + c->g->nloci;
     a.ctr_rep = c->d_ctr;
+    a.pstats = c->d_pstats;
     a.recs = d_recs; a.rec_cap = rec_cap;
     a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch; a.vote_rows = (uint32_t)c->vote_rows;
     a.vote_busy = reinterpret_cast<uint64_t*>(c->d_epoch + ((c->vote_rows + 1) & ~1));  // (behind the epochs, 8-byte aligned)
@@ -1045,6 +1087,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         memset(&sa, 0, sizeof(sa));
         sa.T = c->T; sa.P = c->P; sa.seq = d_seq; sa.off = d_off; sa.surv = c->d_surv; sa.nsurv = c->d_small + 0;
         sa.sorted = c->d_surv + (npairs + 1); sa.key = sa.sorted + (npairs + 1); sa.hist = sa.key + (npairs + 1); sa.flag = c->d_small + 6;
+        sa.sort_min = c->h_sortflag ? SORT_MIN_PER_LOCUS : 0u;  // (no hint word = DBTK_LOCUS_ALWAYS: every batch sorted, every batch through the locus path)
         HIPCHK(hipMemsetAsync(sa.hist, 0, (nloci + 2) * sizeof(uint32_t), s));
         const uint32_t gs = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)c->num_cu * 8);
         if ((st = rec_beg(5))) return st;
@@ -1100,7 +1143,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
                     sp.nblk[q] = (uint32_t)c->loc_blocks[(npl == 3 ? 0 : 3) + q];
                     sp.wfix[q] = 4u << q;  // (an image of the class costs about as much as that many pairs)
                 }
-                sp.nitems = c->d_small + 8; sp.item_cap = (uint32_t)item_cap;
+                sp.nitems = c->d_small + 8; sp.item_cap = (uint32_t)item_cap; sp.stats = c->d_pstats;
                 LAUNCH(k_loc_split, dim3(3), dim3(1024), s, sp);
                 LocRunArgs r0{a.T.ldir, a.T.limg, ia.items[0], c->d_small + 8, ia.rest, c->d_small + 11, sp.starts[0]}, r1{a.T.ldir, a.T.limg, ia.items[1], c->d_small + 9, ia.rest, c->d_small + 11, sp.starts[1]},
                     r2{a.T.ldir, a.T.limg, ia.items[2], c->d_small + 10, ia.rest, c->d_small + 11, sp.starts[2]};
@@ -1168,7 +1211,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         w.T = c->T; w.P = c->P; w.P.aln &= 3u; w.seq = d_seq; w.off = d_off;
         w.surv = c->d_sorted; w.nsurv = c->d_small + 0;
         w.walk_dst = c->d_walk; w.walk_ret = c->d_walk + npairs;
-        w.counts = a.counts; w.counters = a.counters; w.ctr_rep = c->d_ctr;
+        w.counts = a.counts; w.counters = a.counters; w.ctr_rep = c->d_ctr; w.pstats = c->d_pstats;
         w.trecs = walk_trecs; w.errflag = c->d_small + 3;
 #ifdef DBTK_STAMPS
         w.dbg = reinterpret_cast<uint64_t*>(c->d_small + 32);
@@ -1239,7 +1282,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
                     sp.nblk[q] = (uint32_t)c->wfl_blocks[(wnpl == 3 ? 0 : 3) + q];
                     sp.wfix[q] = 4u << q;
                 }
-                sp.nitems = c->d_small + 8; sp.item_cap = (uint32_t)item_cap;
+                sp.nitems = c->d_small + 8; sp.item_cap = (uint32_t)item_cap; sp.stats = c->d_pstats + 7;
                 LAUNCH(k_loc_split, dim3(3), dim3(1024), s, sp);
                 LocRunArgs r0{w.T.gldir, w.T.glimg, ia.items[0], c->d_small + 8, nullptr, nullptr, sp.starts[0]}, r1{w.T.gldir, w.T.glimg, ia.items[1], c->d_small + 9, nullptr, nullptr, sp.starts[1]},
                     r2{w.T.gldir, w.T.glimg, ia.items[2], c->d_small + 10, nullptr, nullptr, sp.starts[2]};
@@ -1270,6 +1313,16 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
 }  // namespace
 
 extern "C" {
+
+int dbtk_ctx_path_stats(dbtk_ctx_t* c, uint64_t* out, int cap) {
+    if (!c || !out || cap <= 0) return 0;
+    if (hipSetDevice(c->device) != hipSuccess || sync_all(c) != hipSuccess) return 0;
+    uint64_t v[DBTK_PATH_STATS];
+    if (hipMemcpy(v, c->d_pstats, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    const int n = cap < (int)DBTK_PATH_STATS ? cap : (int)DBTK_PATH_STATS;
+    for (int i = 0; i < n; ++i) out[i] = v[i];
+    return n;
+}
 
 int dbtk_ctx_table_bytes(dbtk_ctx_t* c, const char** names, uint64_t* bytes, int cap) {
     if (!c || !names || !bytes || !c->share) return 0;
@@ -1454,6 +1507,8 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
         chk(hipMalloc(&c->d_accum, c->n_accum * 8), "hipMalloc accum");
         chk(hipMalloc(&c->d_ctr, (size_t)CTR_REP * CTR_STRIDE * 8), "hipMalloc counter replicas");
         if (!st) chk(hipMemsetAsync(c->d_ctr, 0, (size_t)CTR_REP * CTR_STRIDE * 8, c->stream), "memset");
+        chk(hipMalloc(&c->d_pstats, DBTK_PATH_STATS * 8), "hipMalloc path statistics");
+        if (!st) chk(hipMemsetAsync(c->d_pstats, 0, DBTK_PATH_STATS * 8, c->stream), "memset");
         chk(hipMalloc(&c->d_small, 4 * SMALL_WORDS + 48 * 8), "hipMalloc small");
         if (!getenv("DBTK_LOCUS_ALWAYS")) {  // (DBTK_LOCUS_ALWAYS=1: every batch launches the locus path: tests of small batches)
             chk(hipHostMalloc((void**)&c->h_sortflag, 64, hipHostMallocDefault), "hipHostMalloc");
@@ -1861,6 +1916,7 @@ dbtk_status_t dbtk_ctx_reset(dbtk_ctx_t* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(sync_all(c));
     HIPCHK(hipMemsetAsync(c->d_accum, 0, c->n_accum * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_pstats, 0, DBTK_PATH_STATS * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_small + 3, 0, 4, c->stream));  // a stale error word would be reported against the next run
     if (c->alt.d_small) HIPCHK(hipMemsetAsync(c->alt.d_small + 3, 0, 4, c->stream));
     for (auto& l : c->parked) if (l.d_small) HIPCHK(hipMemsetAsync(l.d_small + 3, 0, 4, c->stream));

@@ -210,6 +210,7 @@ struct BatchArgs {
                              // the walk kernel (dbtk_walk.h: body_walk_pairs) takes it from there
     const uint32_t* sel;     // the lean probe kernel only: nullptr, or the chunk-relative indices of the pairs it is to look up (the pairs the
     const uint32_t* nsel;    //   locus-resident kernel, dbtk_locus.h, does not take) and their number
+    uint64_t* pstats;        // nullptr, or the context's path statistics (dbtk.h: dbtk_ctx_path_stats)
     uint32_t vzero;          // always 0: `lane * vzero` makes an address look lane-dependent, so that a load whose value is only
                              // needed an iteration later is not turned into scalars (and waited for) right where it is issued
 };

@@ -87,6 +87,9 @@ struct LocBuildArgs {
     uint64_t* nleft;        // += keys left out of their image
     const GrSlot* gr;       // the graph images' source: the hashed graph table
     uint64_t gr_nslots;
+    uint64_t idx_mask;      // body_loc_verify: the plain index as a look-up table (buckets - 1, 64 - log2(buckets))
+    uint32_t idx_shift;
+    uint32_t* vcnt;         // [nloci] body_loc_verify: entries of the image that ARE the index's + the keys the image says it left out
 };
 // keys per locus
 template <class X>
@@ -234,7 +237,11 @@ DBTK_HD void body_loc_place(X& x, const LocBuildArgs& a) {
     }
 }
 
-// every entry of every image well-formed?  (an image read from the sidecar file: a TR k-mer's number indexes the counters)
+// An image read from the sidecar file, checked against the index it claims to be a partition of (structure alone lets a
+// stale or bit-flipped image send TR k-mers to the wrong counter): every entry's KEY is rebuilt from (bucket, tag, extra bits,
+// displacement) and looked up in the plain index as built from the RPGG; the entry must be what body_loc_scatter would have made of the
+// index's answer — the locus named by the value (or in its vv list), the same class, the same counter — and vcnt[l] = such entries + the
+// keys the image says it left out must equal the locus' key count (body_loc_count: the host compares), so nothing is missing either.
 template <class X>
 DBTK_HD void body_loc_verify(X& x, const LocBuildArgs& a) {
     for (uint32_t l = x.bid(); l < a.nloci; l += x.nblocks()) {
@@ -242,17 +249,56 @@ DBTK_HD void body_loc_verify(X& x, const LocBuildArgs& a) {
         if (!d.bytes) continue;
         const uint32_t* w = reinterpret_cast<const uint32_t*>(a.arena + 16ull * d.off16);
         const uint32_t ntr = a.trbeg[l + 1] - a.trbeg[l];
-        bool bad = d.trbeg != a.trbeg[l] || w[0] != d.lgnb;
-        for (uint32_t i = (uint32_t)x.tid(); i < (8u << d.lgnb); i += (uint32_t)x.nthreads()) {
-            if ((i & 7) < 4) continue;
-            const uint32_t p = w[LOC_HDR / 4 + i];
-            if (p == LOC_EMPTY) continue;
-            const uint32_t cls = p & (LOC_MULTI | LOC_FLANK | LOC_TR);
-            if (cls != LOC_MULTI && cls != LOC_FLANK && cls != LOC_TR) bad = true;
-            if (cls == LOC_TR && (p & LOC_SLOT) >= ntr) bad = true;
+        const uint32_t nb = 1u << d.lgnb, mask = nb - 1;
+        const uint8_t* disp = reinterpret_cast<const uint8_t*>(w + LOC_HDR / 4 + 8 * nb);
+        bool bad = d.trbeg != a.trbeg[l] || w[0] != d.lgnb || w[3] != l;
+        if (x.tid() == 0 && w[1]) x.atomic_add(&a.vcnt[l], w[1]);
+        const uint32_t nround = (4 * nb + (uint32_t)x.nthreads() - 1) / (uint32_t)x.nthreads() * (uint32_t)x.nthreads();
+        for (uint32_t i = (uint32_t)x.tid(); i < nround; i += (uint32_t)x.nthreads()) {
+            bool good = false;
+            if (i < 4 * nb) {
+                const uint32_t b = i >> 2, s2 = i & 3;
+                const uint32_t lo = w[LOC_HDR / 4 + 8 * b + s2], p = w[LOC_HDR / 4 + 8 * b + 4 + s2];
+                if (p != LOC_EMPTY) {
+                    const uint32_t cls = p & (LOC_MULTI | LOC_FLANK | LOC_TR), extra = p >> 24;
+                    const uint32_t hx = extra << d.lgnb;  // (the group and the hash see hi only through hi >> lgnb)
+                    // bucket = (loc_base(lo, hi) + disp) & mask and loc_base = hi ^ f(lo, hi >> lgnb): the low bits of hi follow
+                    const uint32_t hlow = (((b - disp[loc_group(lo, hx, d.lgnb)]) & mask) ^ loc_base(lo, hx, d.lgnb)) & mask;
+                    const uint64_t key = ((uint64_t)(hx | hlow) << 32) | lo;
+                    const uint64_t va = a.idx ? idx_lookup64_raw(a.idx, a.idx_mask, a.idx_shift, key) : (uint64_t)NOHIT;
+                    const uint32_t v = (uint32_t)va, aux = (uint32_t)(va >> 32);
+                    bool ok = v != NOHIT && (cls == LOC_MULTI || cls == LOC_FLANK || cls == LOC_TR);
+                    if (ok) {
+                        bool named = false;
+                        if (v & 1) { const uint32_t n = a.vv[v >> 1]; for (uint32_t j = 0; j < n; ++j) named |= a.vv[(v >> 1) + 1 + j] == l; }
+                        else named = (v >> 1) == l;
+                        uint32_t want;
+                        if ((v & 1) || aux == CLS_NONE) want = LOC_MULTI;
+                        else if (aux == CLS_FLANK) want = LOC_FLANK;
+                        else want = LOC_TR | ((aux - a.trbeg[l]) & LOC_SLOT);
+                        ok = named && (p & 0x00FFFFFFu) == want && (cls != LOC_TR || ((p & LOC_SLOT) < ntr && aux >= a.trbeg[l]));
+                    }
+                    good = ok;
+                    bad |= !ok;
+                }
+            }
+            const uint64_t m = x.ballot(good);
+            if (m && x.lane() == 0) x.atomic_add(&a.vcnt[l], (uint32_t)__builtin_popcountll(m));
         }
         if (bad) a.bad[l] = 1;
     }
+}
+// Order-independent 64-bit checksum of n 8-byte words (the sidecar's arena as it lies in HBM): sum of mixed (word, position) values.
+DBTK_HD uint64_t csum_term(uint64_t w, uint64_t i) {
+    uint64_t v = w ^ ((i + 1) * 0xD6E8FEB86659FD93ull);
+    v ^= v >> 32; v *= 0x9E3779B97F4A7C15ull; v ^= v >> 29;
+    return v;
+}
+template <class X>
+DBTK_HD void body_csum(X& x, const uint64_t* p, uint64_t n, uint64_t* out) {
+    uint64_t acc = 0;
+    for (uint64_t i = (uint64_t)x.bid() * x.nthreads() + x.tid(); i < n; i += (uint64_t)x.nblocks() * x.nthreads()) acc += csum_term(p[i], i);
+    if (acc) x.atomic_add(out, acc);
 }
 
 // ------------------------------------------------------------------ look-up --
@@ -372,6 +418,7 @@ struct LocSplitArgs {
     uint32_t nblk[3];        // workgroups of the class' launch (0: class not launched)
     uint32_t wfix[3];        // an item's fixed cost, in pairs
     uint32_t* starts[3];     // [nblk + 1]
+    uint64_t* stats;         // nullptr, or the context's path statistics (dbtk.h: dbtk_ctx_path_stats): [c] += items of class c, [3 + c] += their pairs
 };
 struct LocSplitSmem { uint32_t wt[64]; };
 template <class X>
@@ -404,6 +451,7 @@ DBTK_HD void body_loc_split(X& x, const LocSplitArgs& a) {
     x.bsync();
     uint32_t base = 0, P = 0;
     for (uint32_t w = 0; w < nwv; ++w) { const uint32_t v = sm.wt[w]; if (w < wave) base += v; P += v; }
+    if (a.stats && tid == 0 && n) { x.atomic_add(&a.stats[c], (uint64_t)n); x.atomic_add(&a.stats[3 + c], (uint64_t)P - (uint64_t)n * a.wfix[c]); }
     if (!P) {  // no items: every workgroup's range is empty
         for (uint32_t j = tid; j <= B; j += NT) st[j] = 0;
         return;

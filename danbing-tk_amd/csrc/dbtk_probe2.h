@@ -96,6 +96,7 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
     const uint32_t tend = ns - a.t0 < a.tcap ? ns : a.t0 + a.tcap;
     const uint32_t npc = ns > a.t0 ? tend - a.t0 : 0;  // pairs of this chunk of the list; pair i -> hit-buffer rows 2i, 2i + 1
     const uint32_t npr = SEL ? *a.nsel : npc;         // ... of which this kernel takes all, or the ones listed in a.sel (dbtk_locus.h: the rest)
+    if (SEL && a.pstats && x.bid() == 0 && lane == 0 && npr) x.atomic_add(&a.pstats[6], (uint64_t)npr);
     // this wave's pairs: a contiguous range of the (locus-ordered) list
     const uint32_t per = (npr + x.nblocks() - 1) / x.nblocks();
     const uint64_t lo64 = (uint64_t)x.bid() * per;
@@ -441,6 +442,8 @@ struct SurvSortArgs {
     uint32_t* sorted;        // [nsurv]: the list in key order
     uint32_t* flag;          // 1: sorted by key; 0: too few survivors for the order to matter (fewer than SORT_MIN_PER_LOCUS per locus:
                              // a WGS batch) — `sorted` is then a plain copy of the list and the key / histogram work is skipped
+    uint32_t sort_min;       // survivors per locus from which the list is sorted (SORT_MIN_PER_LOCUS; 0 under DBTK_LOCUS_ALWAYS: tests of a dense
+                             // slice — many pairs on few loci — of a large RPGG)
 };
 constexpr uint32_t SORT_MIN_PER_LOCUS = 4;
 // canonical k-mer of the k bytes at p; NAN64 if one of them is not A, C, G or T
@@ -479,7 +482,7 @@ DBTK_HD uint64_t kmer_of_bytes(const uint8_t* seq, uint64_t pos, uint32_t k) {
 template <class X>
 DBTK_HD void body_surv_key(X& x, const SurvSortArgs& a) {
     const uint32_t n = *a.nsurv, k = a.T.ksize, nloci = a.T.nloci;
-    const bool on = n >= SORT_MIN_PER_LOCUS * nloci;
+    const bool on = (uint64_t)n >= (uint64_t)a.sort_min * nloci;
     if (x.bid() == 0 && x.tid() == 0) *a.flag = on ? 1u : 0u;
     if (!on) return;
     const uint32_t NF = (a.P.n_filter && a.P.nm_filter) ? a.P.n_filter : 4u;  // subfilter's sampled positions (AQ.cpp:172-188); four without it

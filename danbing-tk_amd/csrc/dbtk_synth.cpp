@@ -481,4 +481,58 @@ void dbtk_synth_reads(void* h, uint64_t npairs, uint64_t first_pair, uint32_t rl
     });
 }
 
+// The same read model, but every pair is drawn from a locus of a given LIST (pair p from loci[(first_pair + p) % nsel], any of its
+// haplotypes): a dense slice — many pairs per locus, the regime of the locus-resident kernels (dbtk_locus.h) — on an RPGG of any size.
+// odd_frac of the pairs are not what the list says: half of them CHIMERIC (mate 1 from the listed locus, mate 2 from any locus of the
+// RPGG), half FOREIGN (both mates from any locus).
+void dbtk_synth_reads_loci(void* h, uint64_t npairs, uint64_t first_pair, uint32_t rlen, const uint32_t* loci, uint32_t nsel, double odd_frac,
+                           uint64_t seed, uint8_t* out, uint32_t nthreads) {
+    Synth* s = (Synth*)h;
+    const unsigned nth = nthreads ? nthreads : std::max(1u, std::thread::hardware_concurrency());
+    if (!nsel) return;
+    parallel_for(npairs, nth, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t p = b; p < e; ++p) {
+            Rng r(mix(seed ^ 0x5A5A5A5A5Aull, first_pair + p));
+            uint8_t* m1 = out + (2 * p) * (uint64_t)rlen;
+            uint8_t* m2 = m1 + rlen;
+            uint32_t l1 = loci[(first_pair + p) % nsel] % s->nloci, l2 = l1;
+            if (r.unit() < odd_frac) {
+                l2 = r.below(s->nloci);
+                if (r.below(2)) l1 = l2;  // foreign: both mates from the other locus; else chimeric
+            }
+            auto frag = [&](uint32_t l, const uint8_t*& hs, uint32_t& hl, uint32_t& fl, uint32_t& beg) {
+                const uint32_t h0 = s->locus_hap0[l], nh = s->locus_hap0[l + 1] - h0;
+                const uint32_t hi = h0 + r.below(nh ? nh : 1);
+                hs = s->seq.data() + s->hap_beg[hi];
+                hl = (uint32_t)(s->hap_beg[hi + 1] - s->hap_beg[hi]);
+                fl = 300 + r.below(201);
+                if (fl > hl) fl = hl;
+                if (fl < rlen) fl = rlen;
+                beg = r.below(hl - fl + 1);
+            };
+            const uint8_t *hs1, *hs2;
+            uint32_t hl1, fl1, beg1, hl2, fl2, beg2;
+            frag(l1, hs1, hl1, fl1, beg1);
+            if (l2 != l1) frag(l2, hs2, hl2, fl2, beg2); else { hs2 = hs1; hl2 = hl1; fl2 = fl1; beg2 = beg1; }
+            memcpy(m1, hs1 + beg1, rlen);
+            for (uint32_t i = 0; i < rlen; ++i) {
+                const uint8_t c = hs2[beg2 + fl2 - 1 - i];
+                m2[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+            }
+            const double sub = 0.001 + 0.004 * r.unit();
+            for (int m = 0; m < 2; ++m) {
+                uint8_t* x = m ? m2 : m1;
+                for (uint32_t i = 0; i < rlen; ++i)
+                    if (r.unit() < sub) x[i] = ACGT[r.below(4)];
+                if (r.unit() < 0.0001 * rlen) {
+                    const uint32_t at = 1 + r.below(rlen - 2);
+                    if (r.below(2)) { memmove(x + at + 1, x + at, rlen - at - 1); x[at] = ACGT[r.below(4)]; }
+                    else { memmove(x + at, x + at + 1, rlen - at - 1); x[rlen - 1] = ACGT[r.below(4)]; }
+                }
+            }
+            if (r.below(2)) for (uint32_t i = 0; i < rlen; ++i) std::swap(m1[i], m2[i]);
+        }
+    });
+}
+
 }  // extern "C"

@@ -194,17 +194,18 @@ DBTK_HD int bucket_find(const uint64_t k[4], uint64_t key) {
 }
 
 // kmerDBi.find(kmer): returns val | aux << 32, low word NOHIT on a miss.
-DBTK_HD uint64_t idx_lookup64(const DevTables& T, uint64_t key) {
-    uint64_t b = hash_idx(key, T.idx_shift);
+DBTK_HD uint64_t idx_lookup64_raw(const IdxBucket* idx, uint64_t idx_mask, uint32_t idx_shift, uint64_t key) {
+    uint64_t b = hash_idx(key, idx_shift);
     for (;;) {
         uint64_t k[4];
-        bucket_keys(&T.idx[b], k);
+        bucket_keys(&idx[b], k);
         const int r = bucket_find(k, key);
-        if (r < 4) return T.idx[b].val[r];
+        if (r < 4) return idx[b].val[r];
         if (r == BKT_MISS) return (uint64_t)NOHIT;
-        b = (b + 1) & T.idx_mask;
+        b = (b + 1) & idx_mask;
     }
 }
+DBTK_HD uint64_t idx_lookup64(const DevTables& T, uint64_t key) { return idx_lookup64_raw(T.idx, T.idx_mask, T.idx_shift, key); }
 DBTK_HD uint32_t idx_lookup(const DevTables& T, uint64_t key) { return (uint32_t)idx_lookup64(T, key); }
 // kmerDBi.count(kmer): the keys only
 DBTK_HD bool idx_contains(const DevTables& T, uint64_t key) {

@@ -136,6 +136,7 @@ struct WalkArgs {
     // what body_walk_fast_locus leaves) and their number
     const uint32_t* sel;
     const uint32_t* nsel;
+    uint64_t* pstats;          // nullptr, or the context's path statistics (dbtk.h: dbtk_ctx_path_stats)
 };
 constexpr uint32_t WALK_HAS_INFO = 0x80000000u, WALK_NO_ENTRY = 0xFFFFFFFFu;
 constexpr int8_t WALK_NOT_EVALUATED = -2;  // walk_ret of a mate whose walk nothing needed: its pair was kept by the other mate (dbtk.h)

@@ -224,6 +224,7 @@ DBTK_HD void body_walk_fast(X& x, const WalkArgs& a) {
     const uint32_t k = T.ksize;
     uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
     const uint32_t nsurv = a.sel ? *a.nsel : *a.nsurv;  // pairs this kernel takes: the whole list, or the places a.sel names
+    if (a.sel && a.pstats && x.bid() == 0 && lane == 0 && nsurv) x.atomic_add(&a.pstats[13], (uint64_t)nsurv);
     // a contiguous range of the (locus-ordered) survivor list per wave: the waves running side by side count into different loci
     const uint32_t per = (nsurv + x.nblocks() - 1) / x.nblocks();
     const uint64_t lo64 = (uint64_t)x.bid() * per;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DBTK_ABI_VERSION 5u
+#define DBTK_ABI_VERSION 6u
 
 /* Reads longer than this are rejected (DBTK_ERR_READ_TOO_LONG).  The
  * reference's per-read k-mer multiplicity is a uint8_t pair (`PE_KMC`,
@@ -393,6 +393,18 @@ int  dbtk_ctx_kernel_times(dbtk_ctx_t* ctx, const char** names, double* total_ms
 /* HBM bytes of the context's RPGG tables (shared by the contexts of one handle on one device): names[i] (static strings) and
  * bytes[i]; returns how many were filled (<= cap).  The entry "index_images:from_cache" is 1 when the images came from the sidecar. */
 int  dbtk_ctx_table_bytes(dbtk_ctx_t* ctx, const char** names, uint64_t* bytes, int cap);
+/* Which kernels took how many pairs since the context was created / reset (diagnostic; never part of the results — the hot loop of
+ * src/aQueryFasta_thread.cpp:2002-2249 has one path, this library several that must agree).  out[DBTK_PS_*]; returns words filled. */
+#define DBTK_PATH_STATS 16u
+#define DBTK_PS_PROBE_ITEMS   0u  /* [3] work items (locus, <= 64 pairs) of the locus-resident probe kernel, per class of image size */
+#define DBTK_PS_PROBE_PAIRS   3u  /* [3] pairs in those items */
+#define DBTK_PS_PROBE_REST    6u  /* pairs the lean probe kernel took from the list the locus path left (incl. pairs handed back) */
+#define DBTK_PS_WALK_ITEMS    7u  /* [3] the same for the locus-resident form of the lean walk kernel */
+#define DBTK_PS_WALK_PAIRS   10u  /* [3] */
+#define DBTK_PS_WALK_REST    13u  /* pairs its global-table form took */
+#define DBTK_PS_FUSED_DONE   14u  /* pairs the locus-resident probe kernel resolved itself (countHit shortcut + assignTRkmc + accumulate) */
+#define DBTK_PS_FUSED_REDONE 15u  /* ... of the pairs it had resolved ahead of the global look-ups, those it had to take back */
+int  dbtk_ctx_path_stats(dbtk_ctx_t* ctx, uint64_t* out, int cap);
 void dbtk_ctx_timers_reset(dbtk_ctx_t* ctx);
 void dbtk_ctx_timers_enable(dbtk_ctx_t* ctx, int on);  /* default 1: event records around every kernel of every batch (~30 us per batch);
                                                           * 0 = none; n > 1 = only around the kernels of every n-th batch (sampling) */

@@ -808,7 +808,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         SurvSortArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.T = e->T; sa.P = *p; sa.seq = a.seq; sa.off = off; sa.surv = surv.data(); sa.nsurv = &small[0];
-        sa.sorted = sorted.data(); sa.key = skey.data(); sa.hist = shist.data(); sa.flag = &small[1];
+        sa.sorted = sorted.data(); sa.key = skey.data(); sa.hist = shist.data(); sa.flag = &small[1]; sa.sort_min = SORT_MIN_PER_LOCUS;
         run_grid(3, 64, 0, [&](EmuX& x) { body_surv_key(x, sa); });
         run_grid(SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_surv_scan(x, sa, 0); });
         run_grid(SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_surv_scan(x, sa, 1); });

@@ -310,3 +310,31 @@ def test_synth_files_load_back(lib, tmp_path):
     assert np.array_equal(np.sort(arr(v.keys, v.nkeys, np.uint64)), np.sort(arr(a.keys, a.nkeys, np.uint64)))
     g.close()
     syn.close()
+
+
+def test_synth_dense_slice_reads_come_from_the_listed_loci(lib):
+    """dbtk_synth_reads_loci: pair p is drawn from loci[p % m] (the dense slices of the release-scale tests), deterministically; the
+    oracle assigns the clean pairs to exactly those loci."""
+    pkg = bind.pkg
+    syn = pkg.Synth(nloci=60, k=21, seed=9)
+    a = syn.arrays()
+    loci = np.array([7, 41, 3, 58], np.uint32)
+    seq, off = syn.reads_loci(400, loci, odd_frac=0.0, seed=3)
+    seq2, _ = syn.reads_loci(400, loci, odd_frac=0.0, seed=3)
+    assert (seq == seq2).all() and len(off) == 801
+    tail, _ = syn.reads_loci(100, loci, odd_frac=0.0, seed=3, first_pair=300)
+    assert (tail == seq[300 * 300:]).all()  # (a batch cut anywhere is the same stream)
+    O = bind.Oracle()
+    og = O.from_arrays(a)
+    p = pkg.abi.default_params(ksize=21, cthreshold=45, trace=1)
+    o = O.align(og, p, seq, off)
+    dst = np.array([o["recs"][i].dst0 for i in range(400)])  # (countHit's locus; dst is nloci again for a pair assignTRkmc rejects)
+    want = loci[np.arange(400) % 4]
+    hit = dst < 60
+    assert hit.sum() > 300 and (dst[hit] == want[hit]).all()
+    odd, _ = syn.reads_loci(400, loci, odd_frac=0.5, seed=3)
+    o2 = O.align(og, p, odd, off)
+    dst2 = np.array([o2["recs"][i].dst0 for i in range(400)])
+    assert ((dst2 < 60) & (dst2 != want)).sum() > 20  # foreign pairs land elsewhere
+    O.free(og)
+    syn.close()

@@ -393,6 +393,25 @@ def test_cli_readme_pipe_takes_the_device_reader(tmp_path):
         assert b"the host reader takes over" in rp.stderr
         assert sorted(rp.stdout.splitlines()) == sorted(rf.stdout.splitlines())
         assert open(os.path.join(w, "mp.trkmc.ar"), "rb").read() == open(os.path.join(w, "mf.trkmc.ar"), "rb").read()
+    # a pair whose TITLES are 1.1 MB in the middle of the input: what lies behind the last whole pair of a block outgrows the carry-over
+    # room (DBTK_ING_CARRY alone): that block is aligned and RELEASED before the host reader takes over behind it — and the pipe's reader
+    # must not refill its slot meanwhile (the replayed bytes start in that very buffer)
+    t = b"x" * 1_100_000
+    big = recs[:half] + [t + b"/1\n" + recs[half].split(b"\n", 1)[1], t + b"/2\n" + recs[half + 1].split(b"\n", 1)[1]] + recs[half + 2:]
+    blob = b"".join(b">" + x for x in big)
+    open(os.path.join(w, "big.fa"), "wb").write(blob)
+    rf = subprocess.run([CLI] + base[:-5] + ["-fa", "big.fa", "-qs", "pan", "-o", "bf", "--host-ingest"], cwd=w, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                        env=dict(os.environ, DBTK_V13_THREADING="1"))
+    assert rf.returncode == 0 and rf.stdout == want, rf.stderr.decode()[-1500:]
+    for slots in ("2", "3"):
+        cat = subprocess.Popen(["cat", "big.fa"], cwd=w, stdout=subprocess.PIPE)
+        rp = subprocess.run([CLI] + base + ["bp"], cwd=w, stdin=cat.stdout, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            env=dict(os.environ, DBTK_V13_THREADING="1", DBTK_INGEST_CHUNK="65536", DBTK_INGEST_SLOTS=slots))
+        cat.wait()
+        assert rp.returncode == 0, rp.stderr.decode()[-1500:]
+        assert b"the host reader takes over" in rp.stderr
+        assert sorted(rp.stdout.splitlines()) == sorted(rf.stdout.splitlines())
+        assert open(os.path.join(w, "bp.trkmc.ar"), "rb").read() == open(os.path.join(w, "bf.trkmc.ar"), "rb").read()
 
 
 @pytest.mark.gpu

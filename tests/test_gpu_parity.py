@@ -114,11 +114,51 @@ def test_index_image_sidecar_round_trip(dbtk, oracle, tmp_path, monkeypatch):
     run(mode=2, expect_cache=0)              # built and written
     assert os.path.getsize(side) > 1000
     run(expect_cache=1)                      # the default now finds it
-    blob = bytearray(open(side, "rb").read())
-    blob[len(blob) // 2] ^= 0x20             # a flipped bit inside an image: the device-side check (or nothing at all: a tag) ...
-    open(side, "wb").write(bytes(blob))
-    run()                                    # ... either way the results stand
-    blob[40] ^= 0xFF                         # the fingerprint: not this RPGG's file
+    good = open(side, "rb").read()
+    blob = bytearray(good)
+    for at in (len(blob) // 2, len(blob) - 9, 200):  # one flipped bit in an image (a tag, a pay word, a displacement byte), in the directory
+        blob[at] ^= 0x20
+        open(side, "wb").write(bytes(blob))
+        run(expect_cache=0)                  # the checksum does not match: rebuilt, never used
+        blob[at] ^= 0x20
+    # a file that is whole (its checksum holds) but is not THIS index's: the images of an RPGG whose TR k-mers have other counters.  The
+    # fingerprint is defeated on purpose (the one of this RPGG copied in); what refuses the file is the entry-by-entry look-up in the index.
+    import struct
+    hdr_fmt = "<8sIIQQQQQQIIQ"
+    hdr = list(struct.unpack_from(hdr_fmt, good, 0))
+    assert hdr[0] == b"DBTKIDX\x01" and hdr[10] == struct.calcsize(hdr_fmt)
+    body = bytearray(good[hdr[10]:])
+    nloci = hdr[3]
+    dirs = [struct.unpack_from("<IIII", body, 16 * l) for l in range(nloci)]  # {off16, bytes, lgnb, trbeg}
+    first = next(d for d in dirs if d[1])
+    arena0 = 16 * nloci + 16 * first[0]
+    # swap the pay words of two TR entries of the first image that differ (another counter for the same k-mer), keep the file's checksum right
+    lg = struct.unpack_from("<I", body, arena0)[0]
+    pays = [(b * 32 + 16 + 4 * s_, struct.unpack_from("<I", body, arena0 + 16 + b * 32 + 16 + 4 * s_)[0]) for b in range(1 << lg) for s_ in range(4)]
+    tr = [(o_, v) for o_, v in pays if v != 0xFFFFFFFE and (v >> 21) & 7 == 1]
+    (o1, v1), (o2, v2) = tr[0], next(t for t in tr[1:] if (t[1] & 0x1FFFFF) != (tr[0][1] & 0x1FFFFF))
+    struct.pack_into("<I", body, arena0 + 16 + o1, (v1 & ~0x1FFFFF) | (v2 & 0x1FFFFF))
+    struct.pack_into("<I", body, arena0 + 16 + o2, (v2 & ~0x1FFFFF) | (v1 & 0x1FFFFF))
+
+    def csum(words, base=0):
+        m = (1 << 64) - 1
+        tot = 0
+        for i, w in enumerate(words):
+            v = w ^ (((i + 1) * 0xD6E8FEB86659FD93) & m)
+            v ^= v >> 32; v = (v * 0x9E3779B97F4A7C15) & m; v ^= v >> 29
+            tot = (tot + v) & m
+        return tot
+    dirw = struct.unpack_from(f"<{2 * nloci}Q", body, 0)
+    arw = struct.unpack_from(f"<{hdr[6] // 8}Q", body, 16 * nloci)
+    hdr[11] = (csum(arw) + ((csum(dirw) * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)) + hdr[6]) & ((1 << 64) - 1)
+    forged = struct.pack(hdr_fmt, *hdr) + bytes(body)
+    assert struct.unpack_from(hdr_fmt, good, 0)[11] == (csum(struct.unpack_from(f"<{hdr[6] // 8}Q", good, hdr[10] + 16 * nloci)) + ((csum(dirw) * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)) + hdr[6]) & ((1 << 64) - 1)
+    open(side, "wb").write(forged)
+    run(expect_cache=0)                      # checksum fine, fingerprint fine, two counters swapped: refused by the look-up in the index
+    open(side, "wb").write(good)
+    run(expect_cache=1)
+    blob = bytearray(good)
+    blob[33] ^= 0xFF                         # the fingerprint: not this RPGG's file
     open(side, "wb").write(bytes(blob))
     run(expect_cache=0)
     open(side, "wb").write(bytes(blob[:100]))  # truncated
@@ -268,7 +308,104 @@ def test_device_entry_alternating_lanes(dbtk, oracle, tmp_path, lanes, monkeypat
     g.close()
 
 
-def test_release_scale_properties(dbtk, oracle):
+def locus_image_lg(arrs, k):
+    """lgnb of every locus' index image as dbtk_locus.h sizes it (loc_lgnb_for: the smallest table of 2^lg 4-slot buckets at a load of at
+    most 0.8 over the keys whose index value names the locus), from the flat arrays."""
+    nk, nloci = arrs.nkeys, arrs.nloci
+    vals = np.ctypeslib.as_array(arrs.vals, (nk,))
+    vv = np.ctypeslib.as_array(arrs.vv, (arrs.nvv,))
+    even = (vals & 1) == 0
+    cnt = np.bincount(vals[even] >> 1, minlength=nloci).astype(np.int64)
+    offs = (vals[~even] >> 1).astype(np.int64)
+    ns = vv[offs].astype(np.int64)
+    idx = np.repeat(offs + 1, ns) + (np.arange(int(ns.sum())) - np.repeat(np.cumsum(ns) - ns, ns))
+    cnt += np.bincount(vv[idx], minlength=nloci)[:nloci]
+    lgmin = max(5, 2 * k - 40)
+    lg = np.full(nloci, lgmin)
+    for l in range(lgmin, 16):
+        lg[(16 << l) < 5 * cnt] = l + 1
+    return lg, cnt
+
+
+def dense_slice_checks(monkeypatch, dbtk, oracle, syn, arrs, g, orc_g, k):
+    """the locus-resident kernels (dbtk_locus.h: k_probe_locus; dbtk_walkfast.h: k_walk_fast_locus) against the ORACLE on
+    the release-scale RPGG.  A uniform draw over 80 000 loci gives ~1 pair per locus and never reaches them; here ~1 400 loci of every
+    image class (every locus of the largest class) get 64 pairs each, 6 % of the pairs chimeric / foreign.  Device counters assert that
+    the locus path took >= 90 % of the pairs and every class; counts, kmc, nmapread, all counters, the trace records, the walk results and
+    the -ae text are the oracle's."""
+    lg, _ = locus_image_lg(arrs, k)
+    rng = np.random.default_rng(11 + k)
+    cls_of = lambda l: 0 if l <= 9 else 1 if l == 10 else 2 if l == 11 else -1
+    loci = []
+    for l in np.unique(lg):
+        if cls_of(int(l)) < 0:
+            continue
+        pool = np.flatnonzero(lg == l)
+        loci.append(pool if cls_of(int(l)) == 2 and len(pool) <= 400 else rng.choice(pool, min(len(pool), 650), replace=False))
+    loci = rng.permutation(np.concatenate(loci))
+    classes = sorted({cls_of(int(lg[l])) for l in loci})
+    assert len(loci) >= 600 and 2 in classes and 1 in classes and (k > 22 or 0 in classes), (len(loci), classes)
+    n = 64 * len(loci)
+    seq, off = syn.reads_loci(n, loci, odd_frac=0.06, seed=100 + k)
+    monkeypatch.setenv("DBTK_LOCUS_ALWAYS", "1")  # (read at context creation: every batch is sorted and offered to the locus path)
+    order, ntr = g.output_order(), g.ntrkmers
+    base = dict(ksize=k, n_filter=4, nm_filter=1, cthreshold=45, okam=0)
+    # 1. counting (the resolve kernels' regime), then with trace records (every pair through the general resolve kernel)
+    for trace in (0, 1):
+        p = abi.default_params(trace=trace, **base)
+        o = oracle.align(orc_g, p, seq, off, trace=bool(trace))
+        ctx = dbtk.context(g, p)
+        recs, nrec = ctx.align(seq, off)
+        res = ctx.counts()
+        res["recs"] = recs
+        compare(o, res, order, ntr, n, recs=bool(trace))
+        ps = ctx.path_stats()
+        surv = int(res["counters"][abi.C_SURVIVORS])
+        assert surv > 0.99 * n
+        assert surv - ps["probe_rest"] >= 0.9 * surv, (ps, surv)
+        for c in classes:
+            assert ps["probe_items"][c] > 0 and ps["probe_pairs"][c] >= 16 * ps["probe_items"][c], (c, ps)
+        ctx.close()
+    # 2. the graph walk (-gc 85 3): counts, counters, walk results; then -ae text on a part of the slice
+    pw = abi.default_params(threading=abi.THREADING_V13, thread_cth=85, correction=1, maxncorrection=3, **base)
+    ow = oracle.align_walk(orc_g, pw, seq, off, with_recs=False)
+    cw = dbtk.context(g, pw)
+    cw.align(seq, off)
+    r = cw.counts()
+    co = np.zeros(ntr, np.uint64)
+    np.add.at(co, order.astype(np.int64), ow["counts_file"])
+    assert (co == r["counts"]).all() and co.sum() > 0 and (ow["counters"] == r["counters"]).all(), (ow["counters"], r["counters"])
+    wres, _, nres = cw.walk_results(n)
+    assert nres == ow["nres"] and bind.walk_res_equal(wres, ow["res"], nres, g.nloci, every_mate=False) > 0
+    ps = cw.path_stats()
+    walked = sum(ps["walk_pairs"])
+    assert walked >= 0.85 * nres and all(ps["walk_items"][c] > 0 for c in classes), (ps, nres)
+    cw.close()
+    n2 = min(n, 12_000)
+    pa = abi.default_params(threading=abi.THREADING_V13, thread_cth=85, correction=1, maxncorrection=3, aln=2 | abi.ALN_TEXT, **base)
+    pa_o = abi.default_params(threading=abi.THREADING_V13, thread_cth=85, correction=1, maxncorrection=3, aln=2, **base)
+    s2, o2 = seq[:int(off[2 * n2])], off[:2 * n2 + 1]
+    oa = oracle.align_walk(orc_g, pa_o, s2, o2)
+    exp = []
+    for i in range(oa["nres"]):
+        w = oa["res"][i]
+        if w.dst == g.nloci:
+            continue
+        c1, a1 = oracle.cigar_annot(oa["trecs"][2 * i])
+        c2, a2 = oracle.cigar_annot(oa["trecs"][2 * i + 1])
+        exp.append((w.pair, w.dst, f"{c2}\t{a2}\t{c1}\t{a1}"))
+    ca = dbtk.context(g, pa)
+    ca.align(s2, o2)
+    assert ca.aln_text(n2) == exp and len(exp) > n2 // 2
+    ra = ca.counts()
+    co = np.zeros(ntr, np.uint64)
+    np.add.at(co, order.astype(np.int64), oa["counts_file"])
+    assert (co == ra["counts"]).all() and (oa["counters"] == ra["counters"]).all()
+    ca.close()
+    monkeypatch.delenv("DBTK_LOCUS_ALWAYS")
+
+
+def test_release_scale_properties(dbtk, oracle, monkeypatch):
     """BASELINE config 2 at its full size: the bench's release-scale synthetic RPGG (80 000 loci, 1.4e8 index keys) and
     10 M reads (2 % of the pairs from the loci).  Size-independent properties — additivity over batch splits, the
     counters' conservation laws, sum of counts == counted increments — plus the oracle itself on a 100 000-pair slice of
@@ -332,11 +469,12 @@ def test_release_scale_properties(dbtk, oracle):
     res, _, nres = cw.walk_results(n2)
     assert nres == ow["nres"] and bind.walk_res_equal(res, ow["res"], nres, g.nloci, every_mate=False) > 0
     cw.close()
+    dense_slice_checks(monkeypatch, dbtk, oracle, syn, arrs, g, orc_g, 21)
     oracle.free(orc_g)
     g.close()
 
 
-def test_release_scale_walk_k25(dbtk, oracle):
+def test_release_scale_walk_k25(dbtk, oracle, monkeypatch):
     """BASELINE config 4 as stated: a release-scale synthetic RPGG at k = 25 (pipeline/k25.json:5), all-hit reads through the graph
     walk with -gc 85 3: counts, all counters and the walk results of a 30 000-pair slice against the oracle; the whole 1 M-pair
     batch through size-independent properties (additivity over a split, counted increments == sum of counts)."""
@@ -376,6 +514,7 @@ def test_release_scale_walk_k25(dbtk, oracle):
     res, _, nres = whole.walk_results(n2)
     assert nres == ow["nres"] and bind.walk_res_equal(res, ow["res"], nres, g.nloci, every_mate=False) > 0
     whole.close()
+    dense_slice_checks(monkeypatch, dbtk, oracle, syn, arrs, g, orc_g, 25)
     oracle.free(orc_g)
     g.close()
 
