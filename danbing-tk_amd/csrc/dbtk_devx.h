@@ -69,6 +69,7 @@ struct DevX {
         return (threadIdx.x & 32) ? hi : lo;
     }
     __device__ uint32_t wave_scan_max(uint32_t v) const { return dpp_scan(v, OpMax{}); }  // inclusive
+    __device__ uint32_t half_scan_max(uint32_t v) const { return dpp_scan_half(v, OpMax{}); }  // inclusive, inside each half of the wave
     __device__ uint32_t wave_excl_scan(uint32_t v) const { return dpp_scan(v, OpAdd{}) - v; }
     template <int E> __device__ void shfl_xor64(const uint64_t (&in)[E], uint64_t (&out)[E], int mask) const {
 #pragma unroll

@@ -79,10 +79,10 @@ template <int NPL, int WN, bool SEL = false> __global__ void __launch_bounds__(6
     DevX x{&sm};
     body_probe2<NPL, WN, SEL>(x, a);
 }
-template <int NS, bool RECS> __global__ void __launch_bounds__(64) k_pair_usual(BatchArgs a) {
+template <int NS, bool RECS, bool SEL = false> __global__ void __launch_bounds__(64) k_pair_usual(BatchArgs a) {
     __shared__ UsualSmem sm;
     DevX x{&sm};
-    body_pair_usual<NS, RECS>(x, a);
+    body_pair_usual<NS, RECS, SEL>(x, a);
 }
 template <int NS, bool RECS> __global__ void __launch_bounds__(64, NS <= 3 ? 2 : 1) k_pair(BatchArgs a) {
     __shared__ __attribute__((aligned(16))) PairSmemT<NS> sm;
@@ -105,10 +105,11 @@ __global__ void __launch_bounds__(256) k_loc_rest(LocItemArgs a) { DevX x{nullpt
 // waves share it and the more workgroups a CU holds (4 x 4, 2 x 8, 1 x 16 waves)
 constexpr int LOC_IMGB_XS = LOC_HDR + (32 << 9) + (1 << 9), LOC_IMGB_S = LOC_HDR + (32 << 10) + (1 << 10), LOC_IMGB_L = LOC_HDR + (32 << LOC_LG_MAX) + (1 << LOC_LG_MAX);
 constexpr int LOC_NW_XS = 4, LOC_NW_S = 8, LOC_NW_L = 16;
-template <int NPL, int NW, int IMGB> __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_probe_locus(BatchArgs a, LocRunArgs r) {
-    __shared__ LocSmemT<NPL, NW, IMGB> sm;
+// FUSE: the kernel also resolves the usual pairs of its items (dbtk_locus.h)
+template <int NPL, int NW, int IMGB, bool FUSE = false> __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_probe_locus(BatchArgs a, LocRunArgs r) {
+    __shared__ LocSmemT<NPL, NW, IMGB, FUSE> sm;
     DevX x{&sm};
-    body_probe_locus<NPL, NW, IMGB>(x, a, r);
+    body_probe_locus<NPL, NW, IMGB, FUSE>(x, a, r);
 }
 __global__ void __launch_bounds__(256) k_mz_insert(MzBuildArgs a) { DevX x{nullptr}; body_mz_insert(x, a); }
 __global__ void __launch_bounds__(256) k_mz_fill(uint64_t* t, uint64_t nwords, int level1) { DevX x{nullptr}; body_mz_fill(x, t, nwords, level1); }
@@ -255,6 +256,7 @@ struct dbtk_ctx {
     bool loc_from_cache = false;
     uint64_t tb_idx = 0, tb_flt = 0, tb_cls = 0, tb_mz = 0, tb_ovf = 0, tb_gr = 0, tb_grmz = 0;  // bytes of the tables this context built
     int loc_blocks[6] = {0, 0, 0, 0, 0, 0};  // workgroups of k_probe_locus<3 | 5, class 0 | 1 | 2>
+    int locf_blocks[6] = {0, 0, 0, 0, 0, 0}; // ... of its fused form (more LDS per workgroup)
     uint32_t* h_sortflag = nullptr;  // pinned: survivors [0] and sort flag [6] of the batch before (a hint: see launch_batch)
     uint32_t* d_vv = nullptr;
     uint8_t* d_qc = nullptr;
@@ -1014,7 +1016,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     const uint64_t surv_words = (3 * (npairs + 1) + nloci + 2 + SCAN_BLOCKS + 3) & ~3ull;
     const uint64_t item_cap = npairs / LOC_CH + nloci + 2;  // (of a chunk for the probe kernel, of the whole list for the walk's)
     uint32_t split_blk = 0;  // most workgroups any locus-resident launch has: three lists of workgroup ranges behind the rest list
-    for (int q = 0; q < 6; ++q) split_blk = std::max(split_blk, (uint32_t)std::max(c->loc_blocks[q], c->wfl_blocks[q]));
+    for (int q = 0; q < 6; ++q) split_blk = std::max(split_blk, (uint32_t)std::max(std::max(c->loc_blocks[q], c->locf_blocks[q]), c->wfl_blocks[q]));
     const uint64_t split_at = surv_words + 3 * 4 * item_cap + npairs + 4;
     dbtk_status_t st = ensure(&c->d_surv, &c->surv_cap, split_at + 3 * ((uint64_t)split_blk + 1));
     if (st) return st;
@@ -1066,6 +1068,10 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     // the usual-pair kernel takes the pairs it can finish and passes the rest on; it needs the class of a k-mer next to its
     // index value (consistent RPGG) and does not do the trace, bait or bubble work
     const bool usual = c->T.consistent && !c->P.trace && !c->P.bait && !c->P.bubbles;
+    // ... and with no record buffer the locus-resident probe kernel resolves the usual pairs of its items itself (dbtk_locus.h: FUSE;
+    // DBTK_FUSE=0: the two-kernel form, for measurements)
+    static const bool fuse_on = [] { const char* e = getenv("DBTK_FUSE"); return !e || atoi(e) != 0; }();
+    const bool fuse = usual && !d_recs && fuse_on;
     if (c->P.bubbles) { a.edgebuf = c->d_edge; a.events = c->d_events; a.nevents = c->d_nevents; a.events_cap = (uint32_t)std::min<uint64_t>(c->events_cap, 0xFFFFFFFFull); }
     if (c->P.bait && d_qual) { a.qual = d_qual; a.qmaskbuf = c->d_qmask; }
 #ifdef DBTK_STAMPS
@@ -1120,6 +1126,8 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             const uint32_t wn = a.T.mz ? k - a.T.mz_m + 1 : 0;
             const int npl = !a.T.mz || a.edgebuf || a.qmaskbuf ? 0 : (max_read_len <= 32 * 3 + a.T.mz_m - 1 ? 3 : max_read_len <= 32 * 5 + a.T.mz_m - 1 ? 5 : 0);
             a.sel = nullptr; a.nsel = nullptr;
+            // (the general resolve kernel's list: the usual-pair kernel appends to it — and, fused, the locus-resident probe kernel)
+            a.gen_list = usual ? c->d_gen : nullptr; a.ngen = usual ? c->d_tickets + (nchunks + 1) + ch : nullptr;
             if (npl && a.T.ldir && locus_hint) {
                 // The pairs of loci that have an image: the locus-resident kernel (dbtk_locus.h), image in LDS, one item = one locus'
                 // next LOC_CH pairs of the list; the lean kernel then takes what is left (loci without an image, pairs without a
@@ -1140,14 +1148,22 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
                 memset(&sp, 0, sizeof(sp));
                 for (int q = 0; q < 3; ++q) {
                     sp.items[q] = ia.items[q]; sp.starts[q] = c->d_surv + split_at + q * ((uint64_t)split_blk + 1);
-                    sp.nblk[q] = (uint32_t)c->loc_blocks[(npl == 3 ? 0 : 3) + q];
+                    sp.nblk[q] = (uint32_t)(fuse ? c->locf_blocks : c->loc_blocks)[(npl == 3 ? 0 : 3) + q];
                     sp.wfix[q] = 4u << q;  // (an image of the class costs about as much as that many pairs)
                 }
                 sp.nitems = c->d_small + 8; sp.item_cap = (uint32_t)item_cap; sp.stats = c->d_pstats;
                 LAUNCH(k_loc_split, dim3(3), dim3(1024), s, sp);
                 LocRunArgs r0{a.T.ldir, a.T.limg, ia.items[0], c->d_small + 8, ia.rest, c->d_small + 11, sp.starts[0]}, r1{a.T.ldir, a.T.limg, ia.items[1], c->d_small + 9, ia.rest, c->d_small + 11, sp.starts[1]},
                     r2{a.T.ldir, a.T.limg, ia.items[2], c->d_small + 10, ia.rest, c->d_small + 11, sp.starts[2]};
-                if (npl == 3) {
+                if (fuse && npl == 3) {
+                    LAUNCH((k_probe_locus<3, LOC_NW_XS, LOC_IMGB_XS, true>), dim3(c->locf_blocks[0]), dim3(LOC_NW_XS * 64), s, a, r0);
+                    LAUNCH((k_probe_locus<3, LOC_NW_S, LOC_IMGB_S, true>), dim3(c->locf_blocks[1]), dim3(LOC_NW_S * 64), s, a, r1);
+                    LAUNCH((k_probe_locus<3, LOC_NW_L, LOC_IMGB_L, true>), dim3(c->locf_blocks[2]), dim3(LOC_NW_L * 64), s, a, r2);
+                } else if (fuse) {
+                    LAUNCH((k_probe_locus<5, LOC_NW_XS, LOC_IMGB_XS, true>), dim3(c->locf_blocks[3]), dim3(LOC_NW_XS * 64), s, a, r0);
+                    LAUNCH((k_probe_locus<5, LOC_NW_S, LOC_IMGB_S, true>), dim3(c->locf_blocks[4]), dim3(LOC_NW_S * 64), s, a, r1);
+                    LAUNCH((k_probe_locus<5, LOC_NW_L, LOC_IMGB_L, true>), dim3(c->locf_blocks[5]), dim3(LOC_NW_L * 64), s, a, r2);
+                } else if (npl == 3) {
                     LAUNCH((k_probe_locus<3, LOC_NW_XS, LOC_IMGB_XS>), dim3(c->loc_blocks[0]), dim3(LOC_NW_XS * 64), s, a, r0);
                     LAUNCH((k_probe_locus<3, LOC_NW_S, LOC_IMGB_S>), dim3(c->loc_blocks[1]), dim3(LOC_NW_S * 64), s, a, r1);
                     LAUNCH((k_probe_locus<3, LOC_NW_L, LOC_IMGB_L>), dim3(c->loc_blocks[2]), dim3(LOC_NW_L * 64), s, a, r2);
@@ -1176,15 +1192,17 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         if (tm) HIPCHK(hipEventRecord(c->timed[1].end[e], s));
         // RECS = false: no record buffer (-ka without -e): record emission is compiled out
         const int nsi = ns <= 2 ? 0 : (ns == 3 ? 1 : 2);
-        a.gen_list = nullptr; a.ngen = nullptr;
         if (usual) {
-            a.gen_list = c->d_gen; a.ngen = c->d_tickets + (nchunks + 1) + ch;
             const dim3 gu(c->usual_blocks[nsi]);
             if (tm) { if ((st = timed_slot(c, 2, &e))) return st; HIPCHK(hipEventRecord(c->timed[2].beg[e], s)); }
             if (d_recs) {
                 if (nsi == 0) LAUNCH((k_pair_usual<2, true>), gu, dim3(64), s, a);
                 else if (nsi == 1) LAUNCH((k_pair_usual<3, true>), gu, dim3(64), s, a);
                 else LAUNCH((k_pair_usual<4, true>), gu, dim3(64), s, a);
+            } else if (fuse && a.sel) {  // (the locus-resident kernel has resolved its pairs itself: what is left is the list it did not take)
+                if (nsi == 0) LAUNCH((k_pair_usual<2, false, true>), gu, dim3(64), s, a);
+                else if (nsi == 1) LAUNCH((k_pair_usual<3, false, true>), gu, dim3(64), s, a);
+                else LAUNCH((k_pair_usual<4, false, true>), gu, dim3(64), s, a);
             } else {
                 if (nsi == 0) LAUNCH((k_pair_usual<2, false>), gu, dim3(64), s, a);
                 else if (nsi == 1) LAUNCH((k_pair_usual<3, false>), gu, dim3(64), s, a);
@@ -1392,6 +1410,16 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
                     if (const char* ev = getenv("DBTK_LOC_BPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
                     c->loc_blocks[i] = c->num_cu * nb;
                     if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_probe_locus[%d]: %d workgroups per CU\n", i, nb);
+                }
+                const void* kf[6] = {(const void*)k_probe_locus<3, LOC_NW_XS, LOC_IMGB_XS, true>, (const void*)k_probe_locus<3, LOC_NW_S, LOC_IMGB_S, true>, (const void*)k_probe_locus<3, LOC_NW_L, LOC_IMGB_L, true>,
+                                     (const void*)k_probe_locus<5, LOC_NW_XS, LOC_IMGB_XS, true>, (const void*)k_probe_locus<5, LOC_NW_S, LOC_IMGB_S, true>, (const void*)k_probe_locus<5, LOC_NW_L, LOC_IMGB_L, true>};
+                for (int i = 0; i < 6; ++i) {
+                    nb = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf[i], nwv[i % 3] * 64, 0) != hipSuccess || nb <= 0) nb = 1;
+                    nb *= 2;
+                    if (const char* ev = getenv("DBTK_LOC_BPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
+                    c->locf_blocks[i] = c->num_cu * nb;
+                    if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_probe_locus[%d] (fused): %d workgroups per CU\n", i, nb);
                 }
             }
         }

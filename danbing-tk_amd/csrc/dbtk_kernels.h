@@ -1402,7 +1402,9 @@ struct UsualSmem {
     uint32_t hist[HWIN / 2];   // two 16-bit increments per word (a pair adds < 2^16 to any counter)
 };
 
-template <int NS, bool RECS, class X>
+// SEL: the kernel takes the pairs a.sel lists — with the fused locus-resident probe kernel (dbtk_locus.h: FUSE) the pairs that one
+// did not take: it resolves its usual pairs itself and hands the others straight to the general kernel
+template <int NS, bool RECS, bool SEL, class X>
 DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
     uint64_t* const ctr = counters_of(x, a);
     constexpr int NSLOT = NS;
@@ -1419,9 +1421,12 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
     // The survivor list is in locus order (dbtk_probe2.h: body_surv_*).  A wave takes a CONTIGUOUS range of it, so that the waves
     // running at the same time are a range apart — on different loci: fifty pairs of one locus resolved side by side would send
     // all their count atomics to the same few counters at once (atomics on one address serialize).
-    const uint32_t nit = tlim > a.t0 ? tlim - a.t0 : 0u, per = (nit + x.nblocks() - 1) / x.nblocks();
-    const uint64_t tb64 = (uint64_t)a.t0 + (uint64_t)x.bid() * per;
-    const uint32_t tbeg = tb64 < tlim ? (uint32_t)tb64 : tlim, tfin = tb64 + per < tlim ? (uint32_t)(tb64 + per) : tlim;
+    // (SEL: the same split over the entries of the list; q = entry, t = a.t0 + a.sel[q] its place in the survivor list)
+    const uint32_t nit = SEL ? *a.nsel : (tlim > a.t0 ? tlim - a.t0 : 0u), per = (nit + x.nblocks() - 1) / x.nblocks();
+    const uint64_t tb64 = (uint64_t)(SEL ? 0u : a.t0) + (uint64_t)x.bid() * per;
+    const uint32_t tend = SEL ? nit : tlim;
+    const uint32_t tbeg = tb64 < tend ? (uint32_t)tb64 : tend, tfin = tb64 + per < tend ? (uint32_t)(tb64 + per) : tend;
+    auto place = [&](uint32_t q) -> uint32_t { return SEL ? a.t0 + a.sel[q < tfin ? q : (tbeg < tfin ? tbeg : 0u)] : q; };
     uint32_t ngb = 0;
     auto flush_gen = [&]() {
         x.sync();
@@ -1473,14 +1478,15 @@ DBTK_HD void body_pair_usual(X& x, const BatchArgs& a) {
         }
     };
     DBTK_STAMP_DECL
-    uint32_t t = tbeg;
-    if (t < tfin) { request(t); deliver(); }
-    for (; t < tfin; ++t) {
+    uint32_t q = tbeg;
+    uint32_t t = tbeg < tfin ? x.uni(place(tbeg)) : 0u, tn = tbeg < tfin ? place(tbeg + 1) : 0u;  // this entry's place and the next one's (SEL: loaded an iteration ahead)
+    if (q < tfin) { request(t); deliver(); }
+    for (; q < tfin; ++q, t = x.uni(tn), tn = place(q + 1)) {
         DBTK_STAMP(39);  // loop overhead / record of the previous pair
 #ifdef DBTK_STAMPS
         if (!(a.P.diag & 8))  // diagnostic: no loads after the first pair (every pair re-resolves the same data)
 #endif
-        request(t + 1 < tfin ? t + 1 : t);  // (past the end: a harmless reload, so that the loads stay straight-line)
+        request(q + 1 < tfin ? x.uni(tn) : t);  // (past the end: a harmless reload, so that the loads stay straight-line)
         const uint32_t pair_cur = pair;
         // kfilter (AQ.cpp:190-228) aborts a mate at its (nk - cth + 1)-th miss, i.e. iff it has fewer than cth found positions
         // (the probe kernel counted the found positions of each read and checked that they share one even index value)

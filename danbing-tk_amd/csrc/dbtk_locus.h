@@ -483,12 +483,38 @@ DBTK_HD void body_loc_split(X& x, const LocSplitArgs& a) {
 //      a key shared between loci) is PATCHED into its row of the hit buffers, and the row's statistics follow;
 //   3  the per-read headers (found positions, the one index value or not); the rare read whose found k-mers do not all have one
 //      index value gets its value row (every position the image answered: 2 * locus; the patched ones already hold theirs).
+//
+// FUSE (round 5): the kernel also RESOLVES the usual pair — both mates pass kfilter, every found k-mer unique to this one locus
+// (dbtk_kernels.h: body_pair_usual; countHit's shortcut AQ.cpp:354-357, 439-451, the QC gate :2059-2062, assignTRkmc :1450-1556,
+// accumulate :2146-2158) — from the pay words it has just read from the image, instead of writing 4 bytes per position to the hit
+// buffers for a second kernel to read back: such a pair writes NO row.  Whether a pair is usual is known only when the queue has
+// been looked up (a k-mer the image does not hold may still be another locus'), and that happens once per item; so the pair is
+// resolved AHEAD of it, as if every queued k-mer were absent from the index (a k-mer with a sequencing error: nearly always so):
+// its TR k-mers are counted at once into an LDS copy of the locus' counters (two 16-bit counts per word, flushed once per item: one
+// atomic per touched counter instead of one per k-mer of every pair), what else it adds (kmc, nmapread, the counters, walk_dst)
+// waits in a row of LDS.  After the look-ups a row none of whose queued k-mers was found is COMMITTED; one that had a k-mer found
+// (rare) is taken back: the pair is looked up again, its counts subtracted, and it goes the general way — rows in the hit buffers
+// and an entry of gen_list for body_pair, like every pair with a shared k-mer or too few hits.  assignTRkmc's scan runs on the two
+// half-waves at once (a mate each) as wave scans over the lanes' NPL consecutive positions — no scalar state machine, no ballots.
 #ifndef DBTK_LOC_Q
 #define DBTK_LOC_Q 128
 #endif
 constexpr int LOC_Q = DBTK_LOC_Q;              // queue entries per wave (the test emulator builds with a short queue: look-ups in the middle of a pair)
 constexpr int LOC_ROWS = 2 * (int)LOC_CH / 4;  // rows (mates) of one wave's pairs of an item, for workgroups of at least 4 waves
-template <int NPL>
+constexpr uint32_t LOC_FCNT = 2048;            // counters of the item's locus kept in LDS (a locus with more TR k-mers counts the rest directly)
+// what a pair resolved ahead of the look-ups still has to add
+struct LocSpecRow {
+    uint32_t i;      // the pair's place in the chunk
+    uint32_t flags;  // bit 0: one of its queued k-mers WAS in the index (set by the look-ups); bits 1-2: mate removed by assignTRkmc; bit 3: the
+                     // pair was resolved ahead (0: it wrote rows); bits 4-6: stage
+    uint32_t kmc;    // (ei1 - si1) + (ei2 - si2)
+    uint32_t nks;    // k-mers of both mates
+    uint32_t inc;    // count increments
+    uint32_t pad;
+};
+constexpr uint32_t LSP_FAILED = 1u, LSP_RM0 = 2u, LSP_RM1 = 4u, LSP_SPEC = 8u, LSP_STAGE_SHIFT = 4;
+constexpr uint32_t LSP_COUNT = 0, LSP_QC = 1, LSP_THREAD_HEAD = 2, LSP_THREAD_V13 = 3, LSP_EXTRACT = 4;
+template <int NPL, bool FUSE>
 struct __attribute__((aligned(16))) LocWaveSmemT {
     uint32_t pk[2][20];             // 2-bit stream of each mate from its 4-byte-aligned start
     uint16_t vd[2][40];             // validity bits (only for a pair with a non-ACGT byte)
@@ -497,12 +523,15 @@ struct __attribute__((aligned(16))) LocWaveSmemT {
     uint32_t qcode[LOC_Q];          //   row << 8 | position
     uint32_t stat[LOC_ROWS][4];     // per row (local pair << 1 | mate): found positions, largest and smallest index value, hit-buffer row
     uint32_t patched[LOC_ROWS][NPL];  // per row: positions whose value came from the index (bit p of word p / 32)
+    LocSpecRow spec[FUSE ? LOC_ROWS / 2 : 1];  // per pair of the wave in the item (rows 2q, 2q + 1): what a pair resolved ahead of the look-ups still has to add
+    uint32_t ctr[12];               // (FUSE) this wave's share of the counters, flushed at the end of the kernel
 };
-template <int NPL, int NW, int IMGB>
+template <int NPL, int NW, int IMGB, bool FUSE>
 struct __attribute__((aligned(16))) LocSmemT {
     uint4 img[IMGB / 16];
-    uint32_t tally[4];  // of the item: pairs looked up so far, pairs of them handed back (LOC_BAIL)
-    LocWaveSmemT<NPL> w[NW];
+    uint32_t tally[4];  // of the item: pairs looked up so far, pairs of them handed back (LOC_BAIL); [2], [3]: reads assigned / kmc of the item's committed pairs
+    uint32_t fcnt[FUSE ? LOC_FCNT / 2 : 4];  // the item's count increments, two 16-bit counts per word (an item adds < 2^16 to any counter: 64 pairs x 260)
+    LocWaveSmemT<NPL, FUSE> w[NW];
 };
 struct LocRunArgs {
     const LocusDir* dir;
@@ -518,19 +547,71 @@ struct LocRunArgs {
 // by one, where the global-table kernel fetches a bucket per RUN of positions.  (A pair from the locus with an error or two: ~20-40.)
 constexpr uint32_t LOC_BAIL = 96;
 
-template <int NPL, int NW, int IMGB, class X>
+// assignTRkmc's scan (AQ.cpp:1477-1555; the literal form is assign_scan, the mask form assign_masks) for the two mates at once, a
+// mate per half-wave, lane hl of a half holding the states of the NPL consecutive positions hl * NPL ..: kn[j] = the position's
+// k-mer is known at the locus (flank or TR), tr[j] = it is a TR k-mer.  What the scan's result depends on — the first known state,
+// the number of state changes between consecutive known positions, the first two of them and the last known position before each
+// — comes from one half-wave scan (the last known position before the lane's) and five half-wave reductions.  Returns the mate's
+// verdict in every lane of its half: rm (the mate is removed: af) and ei - si (0 for a removed mate).
+template <int NPL, class X>
+DBTK_HD void assign_halves(X& x, const bool (&kn)[NPL], const bool (&tr)[NPL], uint32_t p0, uint32_t nk, const dbtk_params_t& P, bool& rm_out, uint32_t& span_out) {
+    const uint32_t hl = (uint32_t)x.lane() & 31u;
+    // (position + 1) << 1 | TR of the lane's last known position, 0: none
+    uint32_t lastk = 0, ntr_l = 0, firstk = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        if (kn[j]) { lastk = ((p0 + j + 1) << 1) | (tr[j] ? 1u : 0u); if (firstk == 0xFFFFFFFFu) firstk = ((p0 + j) << 1) | (tr[j] ? 1u : 0u); }
+        ntr_l += tr[j] ? 1u : 0u;
+    }
+    uint32_t prev = x.shfl_up1(x.half_scan_max(lastk));  // ... of the lanes before this one
+    if (hl == 0) prev = 0;
+    uint32_t cnt = 0, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;  // state changes at the lane's positions; the first two as position << 8 | (last known position before + 1)
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        if (kn[j]) {
+            const uint32_t t = tr[j] ? 1u : 0u;
+            if (prev && (prev & 1u) != t) {
+                const uint32_t key = ((p0 + j) << 8) | (prev >> 1);
+                if (cnt == 0) k1 = key; else if (cnt == 1) k2 = key;
+                ++cnt;
+            }
+            prev = ((p0 + j + 1) << 1) | t;
+        }
+    }
+    const uint32_t ntot = x.half_sum(cnt), ntr = x.half_sum(ntr_l) & 0xFFu;  // uint8_t ntr, AQ.cpp:1454
+    const uint32_t fk = ~x.half_max(~firstk);
+    const uint32_t g1 = ~x.half_max(~k1);
+    const uint32_t g2 = ~x.half_max(~(k1 == g1 ? k2 : k1));
+    const uint32_t bs = fk == 0xFFFFFFFFu ? 0u : (fk & 1u) ? 2u : 1u;
+    const uint32_t maxnt = P.max_nt;
+    // where the TR segment begins / ends at a state change: the middle of the unknown tract that ends exactly there, else the position itself
+    const uint32_t t1 = g1 >> 8, q1 = g1 & 0xFFu, t2 = g2 >> 8, q2 = g2 & 0xFFu;
+    const uint32_t e1 = q1 < t1 ? (q1 + t1) / 2 : t1, e2 = q2 < t2 ? (q2 + t2) / 2 : t2;
+    bool rm = false;
+    uint32_t span = 0;
+    if (ntot >= 2 && maxnt >= 2 && bs == 2) rm = true;  // TR-flank-TR
+    else if (ntot > maxnt) rm = true;
+    else if (ntot == 0) { if (bs != 2) rm = true; else span = nk; }
+    else if (ntot == 1) span = bs == 1 ? nk - e1 : e1;
+    else if (ntr < P.nm_tr) rm = true;
+    else span = e2 - e1;
+    rm_out = rm; span_out = span;
+}
+
+template <int NPL, int NW, int IMGB, bool FUSE, class X>
 DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
-    typedef LocSmemT<NPL, NW, IMGB> SM;
+    typedef LocSmemT<NPL, NW, IMGB, FUSE> SM;
     static_assert(NW >= 4 && 2 * ((int)LOC_CH / NW) <= LOC_ROWS, "rows of a wave's pairs of one item");
+    static_assert((uint32_t)LOC_CH * 2 * 32 * NPL < 65536, "an item's increments of one counter fit 16 bits");
     constexpr int IPT = ((IMGB - (int)LOC_HDR) / 16 + NW * 64 - 1) / (NW * 64);  // 16-byte pieces of an image per thread
     SM& smb = *x.template smem<SM>();
     const int lane = x.lane();
     const uint32_t wave = (uint32_t)x.tid() >> 6;
-    LocWaveSmemT<NPL>& sm = smb.w[wave];
+    LocWaveSmemT<NPL, FUSE>& sm = smb.w[wave];
     const uint32_t* bks = reinterpret_cast<const uint32_t*>(smb.img);  // (the image's buckets; its header stays in HBM: the directory says as much)
     const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5;
     const DevTables& T = a.T;
-    const uint32_t k = T.ksize;
+    const uint32_t k = T.ksize, cth = a.P.cthreshold;
     const uint32_t ifirst = r.starts[x.bid()], nitems = r.starts[x.bid() + 1];  // this workgroup's items: [ifirst, nitems)
     const uint32_t lmax = 32u * NPL + k - 1;  // bases the lanes of a half cover (the launcher promised no read is longer)
     const uint64_t kmask = (1ull << (2 * k)) - 1;
@@ -579,6 +660,11 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
         if (cB.it < nitems) fetch_offsets(x.uni(surv_at(cB)));
         pairA = surv_at(cA);
     }
+    if (FUSE) {
+        for (uint32_t e = (uint32_t)x.tid(); e < LOC_FCNT / 2; e += (uint32_t)x.nthreads()) smb.fcnt[e] = 0;
+        if (lane < 12) sm.ctr[lane] = 0;
+    }
+    if (x.tid() < 4) smb.tally[x.tid()] = 0;
     // ---- phase 2: the queue against the plain index; what is found is patched into the hit buffers
     uint32_t qn = 0;  // queue entries (uniform)
     auto settle = [&](bool active, uint32_t code, uint64_t kq, uint64_t q0, uint64_t q1, bool& more) -> uint64_t {
@@ -590,15 +676,19 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
         const bool qhit = ((hmask >> (lane & ~3u)) & 0xF) != 0;
         more = active && !qhit && ((omask >> ((lane & ~3u) + 1)) & 1);
         if (m0 || m1) {
-            const uint64_t v = m0 ? v0 : v1;
-            const uint32_t row = code >> 8, pos = code & 0xFFu, val = (uint32_t)v;
-            const size_t at = (size_t)sm.stat[row][3] * a.nkp + pos;
-            a.hitaux[at] = (uint32_t)(v >> 32);
-            a.hitval[at] = val;
-            x.lds_add(&sm.stat[row][0], 1u);
-            x.lds_max(&sm.stat[row][1], val);
-            x.lds_min(&sm.stat[row][2], val);
-            x.lds_or(&sm.patched[row][pos >> 5], 1u << (pos & 31));
+            const uint32_t row = code >> 8;
+            if (FUSE && (sm.spec[row >> 1].flags & LSP_SPEC)) x.lds_or(&sm.spec[row >> 1].flags, LSP_FAILED);  // the pair was NOT usual after all: taken back below
+            else {
+                const uint64_t v = m0 ? v0 : v1;
+                const uint32_t pos = code & 0xFFu, val = (uint32_t)v;
+                const size_t at = (size_t)sm.stat[row][3] * a.nkp + pos;
+                a.hitaux[at] = (uint32_t)(v >> 32);
+                a.hitval[at] = val;
+                x.lds_add(&sm.stat[row][0], 1u);
+                x.lds_max(&sm.stat[row][1], val);
+                x.lds_min(&sm.stat[row][2], val);
+                x.lds_or(&sm.patched[row][pos >> 5], 1u << (pos & 31));
+            }
         }
         return x.ballot(more);
     };
@@ -648,6 +738,25 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
     // in front of every image otherwise)
     uint4 d1 = desc(ifirst), d2 = desc(ifirst + S);
     LocusDir ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
+    uint32_t trb_prev = 0, locus_prev = 0;
+    // the item's counts: LDS -> the locus' counters, kmc and nmapread (one add per counter the item's pairs touched)
+    auto flush_counts = [&]() {
+        if (!FUSE) return;
+        for (uint32_t e = (uint32_t)x.tid(); e < LOC_FCNT / 2; e += (uint32_t)x.nthreads()) {
+            const uint32_t v = smb.fcnt[e];
+            if (v) {
+                if (v & 0xFFFFu) x.atomic_add(&a.counts[trb_prev + 2 * e], (uint64_t)(v & 0xFFFFu));
+                if (v >> 16) x.atomic_add(&a.counts[trb_prev + 2 * e + 1], (uint64_t)(v >> 16));
+                smb.fcnt[e] = 0;
+            }
+        }
+        if (x.tid() == 0) {  // (between two barriers: the waves add to these when they commit their pairs of an item)
+            const uint32_t na = smb.tally[2], km = smb.tally[3];
+            if (na) x.atomic_add(&a.nmapread[locus_prev], (uint64_t)na);
+            if (km) x.atomic_add(&a.kmc[locus_prev], (uint64_t)km);
+            smb.tally[2] = 0; smb.tally[3] = 0;
+        }
+    };
     DBTK_STAMP_DECL
     for (uint32_t item = ifirst; item < nitems; item += S) {
         DBTK_STAMP(42);  // headers of the item before
@@ -655,7 +764,9 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
         const LocusDir ld = ld1;
         const uint32_t locus = x.uni(d.x), lgnb = x.uni(ld.lgnb), trb = x.uni(ld.trbeg);
         const uint8_t* dsp = reinterpret_cast<const uint8_t*>(bks + (8u << lgnb));
-        x.bsync();  // every wave is done with the image of the item before
+        x.bsync();  // every wave is done with the image of the item before, and with its counts
+        flush_counts();
+        trb_prev = trb; locus_prev = locus;
         {
             const p2_v4u* src = reinterpret_cast<const p2_v4u*>(r.arena + 16ull * ld.off16 + LOC_HDR);
             const uint32_t n16 = (ld.bytes - LOC_HDR) / 16;
@@ -673,28 +784,128 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
         }
         d1 = d2; d2 = desc(item + 2 * S);
         ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
-        if (x.tid() < 4) smb.tally[x.tid()] = 0;
+        // the QC gate of the item's locus (AQ.cpp:2059-2062)
+        const bool qc_off = FUSE && a.P.qc && T.qc && !T.qc[locus];
+        if (x.tid() < 2) smb.tally[x.tid()] = 0;
         x.bsync();
-        uint32_t nrow = 0;  // rows of this wave in the item so far (uniform)
+        uint32_t nrow = 0;   // rows of this wave in the item so far (uniform): rows 2q, 2q + 1 = the wave's q-th pair of the item
+        uint64_t redo = 0;   // pairs (q) resolved ahead that have to be taken back (uniform)
         DBTK_STAMP(43);  // barriers, image into LDS, the next one's loads issued
-        while (cC.it == item) {
-            const uint32_t i = cC.i - a.t0;  // pair of the chunk: hit-buffer rows 2i, 2i + 1
-            const uint64_t o0 = o0C, o1 = o1C;
-            uint32_t len = (uint32_t)(o1 - o0);
-            if (len > lmax) { *a.errflag = DBTK_ERR_READ_TOO_LONG; len = lmax; }
-            const uint64_t a0 = o0 & ~3ull;
-            const uint32_t rsh = (uint32_t)(o0 - a0);
-            const uint32_t dw0 = rw0, dw1 = rw1;
-            {   // advance the pipeline
+        for (;;) {
+            bool again = false;  // this turn takes a resolved pair back
+            uint32_t i, dw0, dw1, rmbits = 0;
+            uint64_t o0, o1;
+            if (cC.it == item) {
+                i = cC.i - a.t0;  // pair of the chunk: hit-buffer rows 2i, 2i + 1
+                o0 = o0C; o1 = o1C;
+                dw0 = rw0; dw1 = rw1;
+                // advance the pipeline
                 cC = cB; cB = cA; cA = next(cA);
                 const bool hasC = cC.it < nitems, hasB = cB.it < nitems;
                 o0C = hasC ? o0B : 0ull; o1C = hasC ? o1B : 0ull;
                 fetch_bytes(o0C, o1C);
                 fetch_offsets(hasB ? x.uni(pairA) : x.uni(pairA) * 0u);
                 pairA = surv_at(cA);
+            } else {
+                // ---- the wave's pairs of this item are through: what the index says about the queued k-mers, then the rows' headers,
+                // the general kernel's list, and the pairs resolved ahead: committed, or marked to be taken back
+                if (qn) flush();
+                DBTK_STAMP(41);  // the queue against the index
+                x.sync();
+                if (nrow) {
+                    bool genv = false, isrow = false, fail = false;
+                    uint32_t hrow = 0, asg = 0, km = 0;
+                    const uint32_t np = nrow >> 1;
+                    if ((uint32_t)lane < nrow) isrow = !FUSE || !(sm.spec[lane >> 1].flags & LSP_SPEC);
+                    if (isrow) {
+                        const uint32_t nh = sm.stat[lane][0], vmx = sm.stat[lane][1], vmn = sm.stat[lane][2];
+                        hrow = sm.stat[lane][3];
+#if !defined(__HIPCC__) && defined(DBTK_LOC_DEBUG)
+                        if (hrow >= 2 * a.tcap) { fprintf(stderr, "bad hrow %u lane %d nrow %u flags %x item %u wave %u\n", hrow, lane, nrow, sm.spec[lane >> 1].flags, item, wave); abort(); }
+#endif
+                        const bool uniform = T.consistent && nh && vmx == vmn && !(vmx & 1u);
+                        a.hithdr[hrow] = (uint64_t)(nh ? vmx : NOHIT) | ((uint64_t)nh << 32) | (uniform ? HDR_UNIFORM : 0ull);
+                        genv = !uniform;
+                    }
+                    uint64_t gm = x.ballot(genv);
+                    while (gm) {  // (rare) a read whose found k-mers do not share one index value: its value row
+                        const uint32_t rr = (uint32_t)__builtin_ctzll(gm);
+                        gm &= gm - 1;
+                        const uint32_t hr = x.bcast(hrow, (int)rr), nk = a.hitnk[hr];
+                        for (uint32_t pos = (uint32_t)lane; pos < ((nk + 3) & ~3u) && pos < 32u * NPL; pos += 64) {
+                            const size_t at = (size_t)hr * a.nkp + pos;
+                            if (!((sm.patched[rr][pos >> 5] >> (pos & 31)) & 1)) a.hitval[at] = a.hitaux[at] == AUX_MISS ? NOHIT : locus << 1;
+                        }
+                    }
+                    if (FUSE) {
+                        // lane q: the wave's q-th pair of the item.  One that wrote rows is the general kernel's (body_pair decides it from
+                        // its rows); one resolved ahead is committed unless a queued k-mer of it was found in the index
+                        bool gen = false;
+                        if ((uint32_t)lane < np) {
+                            const LocSpecRow sr = sm.spec[lane];
+                            gen = !(sr.flags & LSP_SPEC);
+                            fail = !gen && (sr.flags & LSP_FAILED) != 0;
+                            if (!gen && !fail) {
+                                const uint32_t stage = (sr.flags >> LSP_STAGE_SHIFT) & 7u;
+                                const uint32_t nrm = ((sr.flags >> 1) & 1u) + ((sr.flags >> 2) & 1u);
+                                // [0] qc, [1] threading, [2] feasible, [3] asgn, [4] cls, [5] inc, [6] nhash1, [7] pairs, [8] pairs taken back
+                                x.lds_add(&sm.ctr[6], sr.nks);
+                                x.lds_add(&sm.ctr[7], 1u);
+                                if (stage == LSP_QC) x.lds_add(&sm.ctr[0], 2u);
+                                else {
+                                    x.lds_add(&sm.ctr[1], 2u);
+                                    if (stage == LSP_THREAD_V13) a.walk_dst[a.t0 + sr.i] = locus;
+                                    if (stage == LSP_EXTRACT) x.lds_add(&sm.ctr[2], 2u);
+                                    if (stage == LSP_COUNT) {
+                                        x.lds_add(&sm.ctr[2], 2u);
+                                        x.lds_add(&sm.ctr[4], sr.nks);
+                                        if (nrm < 2) { asg = 2 - nrm; km = sr.kmc; x.lds_add(&sm.ctr[3], asg); x.lds_add(&sm.ctr[5], sr.inc); }
+                                    }
+                                }
+                            }
+                        }
+                        const uint64_t gmask = x.ballot(gen);
+                        if (gmask) {
+                            uint32_t base = 0;
+                            if (lane == 0) base = x.atomic_add(a.ngen, (uint32_t)__builtin_popcountll(gmask));
+                            base = x.bcast(base, 0);
+                            if (gen) a.gen_list[base + (uint32_t)__builtin_popcountll(gmask & ((1ull << lane) - 1))] = a.t0 + (sm.stat[2 * lane][3] >> 1);
+                        }
+                        if (x.ballot(asg != 0)) {
+                            const uint32_t sa = x.wave_sum(asg), sk = x.wave_sum(km);
+                            if (lane == 0) { x.lds_add(&smb.tally[2], sa); x.lds_add(&smb.tally[3], sk); }
+                        }
+                        redo |= x.ballot(fail);  // (none in a turn that takes pairs back: those write rows)
+                    }
+                    nrow = 0;
+                }
+                if (!FUSE || !redo) break;
+                // ---- (rare) a pair resolved ahead that has a k-mer of the index outside the image: its counts are subtracted and it
+                // goes the general way, like a pair with a shared k-mer (lowest q first)
+                const uint32_t rr = (uint32_t)__builtin_ctzll(redo);
+                i = x.uni(sm.spec[rr].i);
+                rmbits = x.uni(sm.spec[rr].flags);
+                x.sync();
+                redo &= redo - 1;  // (this turn's rows are 0 and 1, its entry spec[0]: of a pair already committed, or this very one)
+                again = true;
+                const uint64_t rd = 2 * (uint64_t)x.uni(a.surv[a.t0 + i]) + half;
+                o0 = a.off[rd]; o1 = a.off[rd + 1];
+                {
+                    uint32_t len = (uint32_t)(o1 - o0);
+                    if (len > lmax) len = lmax;
+                    const uint64_t a0 = o0 & ~3ull;
+                    const uint32_t nw = ((uint32_t)(o0 - a0) + len + 3) >> 2;
+                    dw0 = *reinterpret_cast<const uint32_t*>(a.seq + (2 * hl < nw ? a0 + 8ull * hl : 0ull));
+                    dw1 = *reinterpret_cast<const uint32_t*>(a.seq + (2 * hl + 1 < nw ? a0 + 8ull * hl + 4 : 0ull));
+                }
+                if (lane == 0) x.lds_add(&sm.ctr[8], 1u);
             }
+            uint32_t len = (uint32_t)(o1 - o0);
+            if (len > lmax) { *a.errflag = DBTK_ERR_READ_TOO_LONG; len = lmax; }
+            const uint64_t a0 = o0 & ~3ull;
+            const uint32_t rsh = (uint32_t)(o0 - a0);
             x.sync();  // the previous pair's LDS is dead
-            if (r.rest) {
+            if (r.rest && !again) {
                 // an item most of whose pairs so far were handed back is one of reads that merely resemble the locus: the rest of it goes
                 // the same way at once (which pairs that catches depends on the waves' timing; the results do not)
                 const uint32_t done = x.bcast(smb.tally[0], 0), gone = x.bcast(smb.tally[1], 0);  // (lane 0's reading: the other waves are adding)
@@ -715,6 +926,7 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
             uint64_t km[NPL];
             bool pend[NPL];
             uint32_t npend = 0, nres = 0;
+            bool multi = false;
             if (clean) {
                 x.sync();
                 const uint64_t W = window_fw_clean(sm.pk[half], rsh + p0, 32);
@@ -752,9 +964,9 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                     const uint32_t extra = (uint32_t)(km[j] >> 32) >> lgnb, p = pay[j];
                     const bool act = p0 + j < nk;
                     const bool ok = any[j] && (p >> 24) == extra && (p & (LOC_FLANK | LOC_TR)) != (LOC_FLANK | LOC_TR);
-                    const bool again = act && !ok && any[j];  // a tag matched but not its entry (another slot of the bucket may): the plain search
-                    slow |= again;
-                    pay[j] = !act ? LOC_EMPTY : ok ? p : again ? LOC_EMPTY - 1 : LOC_MISS;
+                    const bool agn = act && !ok && any[j];  // a tag matched but not its entry (another slot of the bucket may): the plain search
+                    slow |= agn;
+                    pay[j] = !act ? LOC_EMPTY : ok ? p : agn ? LOC_EMPTY - 1 : LOC_MISS;
                 }
                 if (x.ballot(slow)) {  // (rare)
 #pragma unroll
@@ -774,6 +986,7 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                 for (int j = 0; j < NPL; ++j) {
                     const bool act = p0 + j < nk;
                     pend[j] = act && (pay[j] == LOC_MISS || (pay[j] & LOC_MULTI));
+                    multi |= act && pay[j] != LOC_MISS && (pay[j] & LOC_MULTI);
                     npend += pend[j] ? 1u : 0u;
                     const bool fnd = act && !pend[j];
                     nres += fnd ? 1u : 0u;
@@ -801,15 +1014,42 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
             }
             const uint32_t pex = x.wave_excl_scan(npend);
             const uint32_t ptot = x.bcast(pex + npend, 63);
-            if (lane == 0 && r.rest) { x.lds_add(&smb.tally[0], 1u); if (ptot > LOC_BAIL) x.lds_add(&smb.tally[1], 1u); }
-            if (ptot > LOC_BAIL && r.rest) {  // (uniform) not this locus' pair after all: the global-table kernel's
-                if (lane == 0) r.rest[x.atomic_add(r.nrest, 1u)] = i;
-                DBTK_STAMP(16);
-                continue;
+            if (!again) {
+                if (lane == 0 && r.rest) { x.lds_add(&smb.tally[0], 1u); if (ptot > LOC_BAIL) x.lds_add(&smb.tally[1], 1u); }
+                if (ptot > LOC_BAIL && r.rest) {  // (uniform) not this locus' pair after all: the global-table kernel's
+                    if (lane == 0) r.rest[x.atomic_add(r.nrest, 1u)] = i;
+                    DBTK_STAMP(16);
+                    continue;
+                }
             }
             DBTK_STAMP(16);  // k-mers, image look-ups
-            {   // the row as the image answers it: its statistics, its aux words (16-byte stores)
-                const uint32_t nh = x.half_sum(nres);
+            const uint32_t nh = x.half_sum(nres);
+            // ---- the usual pair, resolved here (FUSE): both mates with cth k-mers and cth of them found, all of them this locus' alone
+            // (AQ.cpp:190-228: kfilter keeps such a mate; 354-357, 439-451: countHit then needs no vote) — provided none of the queued
+            // k-mers turns out to be in the index
+            bool spec = false;
+            if (FUSE) {
+                const uint32_t nk0 = x.bcast(nk, 0), nk1 = x.bcast(nk, 32), nh0 = x.bcast(nh, 0), nh1 = x.bcast(nh, 32);
+                spec = clean && !again && x.ballot(multi) == 0 && nk0 >= cth && nk1 >= cth && nh0 >= cth && nh1 >= cth && nh0 && nh1;
+                if (lane == 0) { sm.spec[nrow >> 1].i = i; sm.spec[nrow >> 1].flags = spec ? LSP_SPEC : 0u; }  // (before anything of the pair is queued: the look-ups ask)
+            }
+#if !defined(__HIPCC__) && defined(DBTK_LOC_DEBUG)
+            if (hl == 0) fprintf(stderr, "item %u wave %u lane %d pair %u nrow %u spec %d again %d clean %d nh %u nk %u\n", item, wave, lane, i, nrow, (int)spec, (int)again, (int)clean, nh, nk);
+#endif
+            if (FUSE && again) {
+                // the counts this pair added when it was resolved ahead are subtracted (the same positions: the same image, the same read)
+                const bool rm = ((rmbits >> (1 + half)) & 1u) != 0 || ((rmbits >> LSP_STAGE_SHIFT) & 7u) != LSP_COUNT;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    const uint32_t ax = sm.res[half][p0 + j];
+                    if (!rm && p0 + j < nk && ax != AUX_MISS && ax != CLS_FLANK) {
+                        const uint32_t sl = ax - trb;
+                        if (sl < LOC_FCNT) x.lds_add(&smb.fcnt[sl >> 1], 0u - (1u << (16 * (sl & 1))));
+                        else x.atomic_add(&a.counts[ax], ~0ull);
+                    }
+                }
+            }
+            if (!spec) {   // the row as the image answers it: its statistics, its aux words (16-byte stores)
                 if (hl == 0) {
                     sm.stat[row][0] = nh; sm.stat[row][1] = nh ? locus << 1 : 0u; sm.stat[row][2] = nh ? locus << 1 : 0xFFFFFFFFu; sm.stat[row][3] = hrow;
                     a.hitnk[hrow] = nk;
@@ -823,8 +1063,8 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                     const uint32_t i4 = 32u * c + hl;
                     if (4 * i4 < nk && i4 < 8u * NPL) outa[i4] = reinterpret_cast<const uint4*>(sm.res[half])[i4];
                 }
-            }
-            {   // the rest into the queue (a queue that cannot take them all is looked up first)
+            } else x.sync();
+            {   // what the image does not answer into the queue (a queue that cannot take them all is looked up first)
                 uint32_t done = 0;  // entries of this pair already queued (uniform)
                 while (done < ptot) {
                     if (qn == (uint32_t)LOC_Q) flush();
@@ -842,31 +1082,64 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                     qn += take; done += take;
                 }
             }
-            nrow += 2;
-            DBTK_STAMP(18);  // row statistics + stores, queue
-        }
-        // ---- the wave's rows of this item: what the index says about the queued k-mers, then the headers
-        if (qn) flush();
-        DBTK_STAMP(41);  // the queue against the index
-        x.sync();
-        bool genv = false;
-        uint32_t hrow = 0;
-        if ((uint32_t)lane < nrow) {
-            const uint32_t nh = sm.stat[lane][0], vmx = sm.stat[lane][1], vmn = sm.stat[lane][2];
-            hrow = sm.stat[lane][3];
-            const bool uniform = T.consistent && nh && vmx == vmn && !(vmx & 1u);
-            a.hithdr[hrow] = (uint64_t)(nh ? vmx : NOHIT) | ((uint64_t)nh << 32) | (uniform ? HDR_UNIFORM : 0ull);
-            genv = !uniform;
-        }
-        uint64_t gm = x.ballot(genv);
-        while (gm) {  // (rare) a read whose found k-mers do not share one index value: its value row
-            const uint32_t rr = (uint32_t)__builtin_ctzll(gm);
-            gm &= gm - 1;
-            const uint32_t hr = x.bcast(hrow, (int)rr), nk = a.hitnk[hr];
-            for (uint32_t pos = (uint32_t)lane; pos < ((nk + 3) & ~3u) && pos < 32u * NPL; pos += 64) {
-                const size_t at = (size_t)hr * a.nkp + pos;
-                if (!((sm.patched[rr][pos >> 5] >> (pos & 31)) & 1)) a.hitval[at] = a.hitaux[at] == AUX_MISS ? NOHIT : locus << 1;
+            if (FUSE && spec) {
+                // states of the lane's positions at the locus: known (flank or TR), TR (from the aux words of the look-up, still in LDS)
+                uint32_t ax[NPL];
+                bool kn[NPL], tr[NPL];
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) ax[j] = sm.res[half][p0 + j];
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    kn[j] = p0 + j < nk && ax[j] != AUX_MISS; tr[j] = kn[j] && ax[j] != CLS_FLANK;
+                }
+                uint32_t stage = LSP_COUNT;
+                if (qc_off) stage = LSP_QC;
+                else if (a.P.threading) stage = a.P.threading == DBTK_THREADING_V13 ? LSP_THREAD_V13 : LSP_THREAD_HEAD;
+                else if (a.P.extract) stage = LSP_EXTRACT;
+                bool rm = true;
+                uint32_t span = 0;
+                if (stage == LSP_COUNT) assign_halves<NPL>(x, kn, tr, p0, nk, a.P, rm, span);
+                const uint32_t rm0 = x.bcast(rm ? 1u : 0u, 0), rm1 = x.bcast(rm ? 1u : 0u, 32);
+                uint32_t ninc = 0;
+                if (!(rm0 && rm1)) {  // (a pair both of whose mates are removed adds nothing: AQ.cpp:2145)
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) {
+                        const bool hit = tr[j] && !rm;
+                        if (hit) {
+                            const uint32_t sl = ax[j] - trb;
+                            if (sl < LOC_FCNT) x.lds_add(&smb.fcnt[sl >> 1], 1u << (16 * (sl & 1)));
+                            else x.atomic_add(&a.counts[ax[j]], 1ull);
+                        }
+                        ninc += (uint32_t)__builtin_popcountll(x.ballot(hit));
+                    }
+                }
+                const uint32_t span0 = x.bcast(span, 0), span1 = x.bcast(span, 32), nks = x.bcast(nk, 0) + x.bcast(nk, 32);
+                if (lane == 0) {
+                    LocSpecRow& sr = sm.spec[nrow >> 1];
+                    x.lds_or(&sr.flags, (rm0 ? LSP_RM0 : 0u) | (rm1 ? LSP_RM1 : 0u) | (stage << LSP_STAGE_SHIFT));  // (or-ed: a look-up in the middle of the pair may have marked it already)
+                    sr.kmc = span0 + span1; sr.nks = nks; sr.inc = ninc;
+                }
             }
+            nrow += 2;
+            DBTK_STAMP(18);  // row statistics + stores, queue, (FUSE) assignTRkmc + counts
+        }
+    }
+    if (FUSE) {
+        x.bsync();
+        flush_counts();
+        x.sync();
+        if (lane == 0) {
+            uint64_t* const ctr = counters_of(x, a);
+            const uint32_t c0 = sm.ctr[0], c1 = sm.ctr[1], c2 = sm.ctr[2], c3 = sm.ctr[3], c4 = sm.ctr[4], c5 = sm.ctr[5], c6 = sm.ctr[6], c7 = sm.ctr[7];
+            if (c0) x.atomic_add(&ctr[DBTK_C_QCFILTERED], (uint64_t)c0);
+            if (c1) x.atomic_add(&ctr[DBTK_C_THREADING], (uint64_t)c1);
+            if (c2) x.atomic_add(&ctr[DBTK_C_FEASIBLE], (uint64_t)c2);
+            if (c3) x.atomic_add(&ctr[DBTK_C_ASGN], (uint64_t)c3);
+            if (c4) x.atomic_add(&ctr[DBTK_C_ALGO_CLS], (uint64_t)c4);
+            if (c5) x.atomic_add(&ctr[DBTK_C_ALGO_INC], (uint64_t)c5);
+            if (c6) { x.atomic_add(&ctr[DBTK_C_NHASH1], (uint64_t)c6); x.atomic_add(&ctr[DBTK_C_ALGO_PROBES], (uint64_t)c6); }
+            if (a.pstats && c7) x.atomic_add(&a.pstats[14], (uint64_t)c7);
+            if (a.pstats && sm.ctr[8]) x.atomic_add(&a.pstats[15], (uint64_t)sm.ctr[8]);
         }
     }
     DBTK_STAMP_FLUSH;

@@ -514,6 +514,14 @@ class Emu(pkg._HostSide):
         self.L.emu_locus_stats(out.ctypes.data_as(u64p))
         return [int(out[0]), int(out[1]), int(out[2])], int(out[3]), int(out[4])
 
+    def path_stats(self):
+        """as Context.path_stats, over the align calls since the last call"""
+        v = (C.c_uint64 * 16)()
+        self.L.emu_path_stats(v)
+        v = [int(x) for x in v]
+        return {"probe_items": v[0:3], "probe_pairs": v[3:6], "probe_rest": v[6], "walk_items": v[7:10], "walk_pairs": v[10:13],
+                "walk_rest": v[13], "fused_done": v[14], "fused_redone": v[15]}
+
     def aln_text(self, npairs):
         """as Context.aln_text: list of (pair, dst, text)"""
         self.L.emu_aln_text.restype = C.c_uint64

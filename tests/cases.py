@@ -64,7 +64,7 @@ def case_shared(tmp):
 def case_k25(tmp):
     loci = synth.make_loci(nloci=10, nhap=3, flank=500, seed=9, shared_frac=0.3)
     reads = synth.sim_reads(loci, npairs=500, seed=14, sub=0.01, nrate=0.002, chimeric=0.2, background=0.1)
-    return Case(_rpgg(tmp, "k25", loci, 25), 25, reads, [dict(cthreshold=45, okam=1)])
+    return Case(_rpgg(tmp, "k25", loci, 25), 25, reads, [dict(cthreshold=45, okam=1), dict(cthreshold=45, okam=0)])
 
 
 def case_k31(tmp):
@@ -94,7 +94,7 @@ def case_qc(tmp):
     qc = os.path.join(tmp, "qc", "qc.txt")
     with open(qc, "w") as f:
         f.write("".join("01"[i % 3 != 0] for i in range(12)))
-    return Case(pref, 21, synth.sim_reads(loci, npairs=500, seed=15, sub=0.005), [dict(cthreshold=45, okam=1, qc=1)], qc)
+    return Case(pref, 21, synth.sim_reads(loci, npairs=500, seed=15, sub=0.005), [dict(cthreshold=45, okam=1, qc=1), dict(cthreshold=45, okam=0, qc=1)], qc)
 
 
 def case_lengths(tmp):
@@ -126,7 +126,7 @@ def case_short25(tmp):
     """The same form at k = 25 (window of 11 m-mers)."""
     loci = synth.make_loci(nloci=8, nhap=2, flank=500, seed=24, shared_frac=0.3, tr_min=200, tr_max=900)
     reads = synth.sim_reads(loci, npairs=400, rlen=100, seed=25, sub=0.006, nrate=0.001, chimeric=0.2, background=0.1)
-    return Case(_np_rpgg(tmp, "short25", loci, 25), 25, reads, [dict(cthreshold=30, okam=1)])
+    return Case(_np_rpgg(tmp, "short25", loci, 25), 25, reads, [dict(cthreshold=30, okam=1), dict(cthreshold=30, okam=0)])
 
 
 def case_kf(tmp):
@@ -135,6 +135,14 @@ def case_kf(tmp):
     return Case(_rpgg(tmp, "kf", loci, 21), 21, reads,
                 [dict(cthreshold=45, okam=0, n_filter=0, nm_filter=0), dict(cthreshold=45, okam=1, n_filter=8, nm_filter=2),
                  dict(cthreshold=30, okam=0, n_filter=2, nm_filter=1), dict(cthreshold=45, okam=1, extract=2)])
+
+
+def case_spliced(tmp):
+    """Pairs that are their locus' by every count but carry a stretch of another locus' k-mers (the last 28-49 bases of a mate): the
+    locus-resident probe kernel resolves a pair AHEAD of the look-ups in the plain index (dbtk_locus.h: FUSE) and must take these back."""
+    loci = synth.make_loci(nloci=10, nhap=3, flank=500, seed=51)
+    reads = synth.sim_reads(loci, npairs=800, seed=52, sub=0.003, splice=0.4)
+    return Case(_rpgg(tmp, "spliced", loci, 21), 21, reads, [dict(cthreshold=45, okam=0), dict(cthreshold=30, okam=0, threading=1), dict(cthreshold=60, okam=0)])
 
 
 def case_spill(tmp):
@@ -168,11 +176,11 @@ def case_inconsistent(tmp):
 
 CASES = dict(clean=case_clean, mixed=case_mixed, shared=case_shared, k25=case_k25, k31=case_k31, k31long=case_k31long, k30long=case_k30long,
              qc=case_qc, lengths=case_lengths, short21=case_short21, short25=case_short25,
-             kf=case_kf, spill=case_spill, inconsistent=case_inconsistent)
+             kf=case_kf, spill=case_spill, inconsistent=case_inconsistent, spliced=case_spliced)
 
 
 # cases whose geometry the lean probe kernel (dbtk_probe2.h) takes; the others run the general one
-LEAN_PROBE = {"clean", "mixed", "shared", "k25", "qc", "short21", "short25", "kf", "spill", "inconsistent"}
+LEAN_PROBE = {"clean", "mixed", "shared", "k25", "qc", "short21", "short25", "kf", "spill", "inconsistent", "spliced"}
 
 
 def make_case(name, tmp) -> Case:

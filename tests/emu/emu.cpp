@@ -73,6 +73,7 @@ struct EmuX {
     uint32_t half_sum(uint32_t v) const;
     uint32_t half_max(uint32_t v) const;
     uint32_t wave_scan_max(uint32_t v) const;
+    uint32_t half_scan_max(uint32_t v) const;
     uint32_t wave_excl_scan(uint32_t v) const;
     uint32_t bcast(uint32_t v, int src) const;
     uint32_t wave_scan_lastnz(uint32_t v) const;
@@ -190,6 +191,15 @@ uint32_t EmuX::wave_scan_max(uint32_t v) const {
     uint32_t r = 0;
     const int w0 = t & ~63;
     for (int l = 0; l <= (t & 63); ++l) if ((uint32_t)b->scratch[w0 + l] > r) r = (uint32_t)b->scratch[w0 + l];
+    b->yield();
+    return r;
+}
+uint32_t EmuX::half_scan_max(uint32_t v) const {
+    b->scratch[t] = v;
+    b->yield();
+    uint32_t r = 0;
+    const int h0 = t & ~31;
+    for (int l = 0; l <= (t & 31); ++l) if ((uint32_t)b->scratch[h0 + l] > r) r = (uint32_t)b->scratch[h0 + l];
     b->yield();
     return r;
 }
@@ -313,6 +323,7 @@ struct EmuTables {
 static uint64_t g_probe_runs[2] = {0, 0}, g_mz_turned = 0, g_walk_fast_runs = 0, g_walk_slow_pairs = 0;
 static uint64_t g_wfl_pairs[2] = {0, 0};  // pairs the lean walk kernel took in its locus-resident form / left to its plain form
 static uint64_t g_loc_left = 0;  // keys the last tables' images left out
+static uint64_t g_pstats[DBTK_PATH_STATS] = {0};  // as dbtk_ctx_path_stats, over the emu_align calls since the last emu_path_stats
 static uint64_t g_loc_pairs[4] = {0, 0, 0, 0};  // pairs the locus-resident kernel took in its three classes of workgroup, pairs left to the lean kernel
 extern "C" {
 
@@ -739,6 +750,7 @@ uint64_t emu_walk_results(dbtk_walk_res_t* res, uint32_t* tidx, uint64_t cap) {
 
 // which probe body the last calls of emu_align_ex dispatched: [0] general (body_probe), [1] lean (body_probe2); and the
 // keys level 1 of the last emu_tables_create turned away (= entries of its overflow table)
+void emu_path_stats(uint64_t* out) { for (uint32_t i = 0; i < DBTK_PATH_STATS; ++i) { out[i] = g_pstats[i]; g_pstats[i] = 0; } }
 void emu_locus_stats(uint64_t* out) { for (int i = 0; i < 4; ++i) { out[i] = g_loc_pairs[i]; g_loc_pairs[i] = 0; } out[4] = g_loc_left; }
 void emu_probe_stats(uint64_t* out) { out[0] = g_probe_runs[0]; out[1] = g_probe_runs[1]; out[2] = g_mz_turned; g_probe_runs[0] = g_probe_runs[1] = 0; }
 // pair-mode walks since the last call: runs of the lean first kernel, pairs it passed on to the second
@@ -772,6 +784,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     a.surv = surv.data(); a.nsurv = &small[0]; a.nrec = &small[2]; a.errflag = &small[3];
     a.counts = accum.data(); a.kmc = a.counts + ntr; a.nmapread = a.kmc + nloci; a.counters = a.nmapread + nloci;
     a.recs = recs; a.rec_cap = (uint32_t)rec_cap;
+    a.pstats = g_pstats;
     // (two rows for any number of workgroups: the pool is taken from and given back per pair)
     std::vector<uint64_t> vbusy(2, 0);
     a.vote_scratch = vote.data(); a.vote_epoch = epoch.data(); a.vote_busy = vbusy.data(); a.vote_rows = grid_pair < 2 ? grid_pair : 2;
@@ -790,6 +803,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     a.hitaux = reinterpret_cast<uint32_t*>(hitva.data()); a.hitval = a.hitaux + (size_t)tcap * 2 * a.nkp; a.hitnk = hitnk.data(); a.hitoff = hitoff.data(); a.hithdr = hitoff.data() + (size_t)tcap * 2;
     a.tcap = tcap;
     const bool usual = e->T.consistent && !p->trace && !p->bait && !p->bubbles;  // as the device launcher decides
+    const bool fuse = usual && !recs && !getenv("EMU_NO_FUSE");                  // ... and the fused form of the locus-resident probe body
     std::vector<uint64_t> edgebuf, qmaskbuf, qualbuf;
     uint32_t nevents = 0;
     if (p->bubbles) {
@@ -861,14 +875,22 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
             }
             LocRunArgs r0{a.T.ldir, a.T.limg, items[0].data(), &nit[0], rest.data(), &nit[3], starts[0].data()}, r1{a.T.ldir, a.T.limg, items[1].data(), &nit[1], rest.data(), &nit[3], starts[1].data()},
                 r2{a.T.ldir, a.T.limg, items[2].data(), &nit[2], rest.data(), &nit[3], starts[2].data()};
-            if (npl == 3) {
-                run_grid(2, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_XS>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_XS>(x, a, r0); });
-                run_grid(3, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_S>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_S>(x, a, r1); });
-                run_grid(2, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_L>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_L>(x, a, r2); });
+            if (fuse && npl == 3) {
+                run_grid(2, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_XS, true>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_XS, true>(x, a, r0); });
+                run_grid(3, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_S, true>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_S, true>(x, a, r1); });
+                run_grid(2, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_L, true>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_L, true>(x, a, r2); });
+            } else if (fuse) {
+                run_grid(2, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_XS, true>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_XS, true>(x, a, r0); });
+                run_grid(3, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_S, true>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_S, true>(x, a, r1); });
+                run_grid(2, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_L, true>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_L, true>(x, a, r2); });
+            } else if (npl == 3) {
+                run_grid(2, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_XS, false>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_XS, false>(x, a, r0); });
+                run_grid(3, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_S, false>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_S, false>(x, a, r1); });
+                run_grid(2, 4 * 64, sizeof(LocSmemT<3, 4, EMU_IMGB_L, false>), [&](EmuX& x) { body_probe_locus<3, 4, EMU_IMGB_L, false>(x, a, r2); });
             } else {
-                run_grid(2, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_XS>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_XS>(x, a, r0); });
-                run_grid(3, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_S>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_S>(x, a, r1); });
-                run_grid(2, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_L>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_L>(x, a, r2); });
+                run_grid(2, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_XS, false>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_XS, false>(x, a, r0); });
+                run_grid(3, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_S, false>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_S, false>(x, a, r1); });
+                run_grid(2, 4 * 64, sizeof(LocSmemT<5, 4, EMU_IMGB_L, false>), [&](EmuX& x) { body_probe_locus<5, 4, EMU_IMGB_L, false>(x, a, r2); });
             }
             for (int c = 0; c < 3; ++c) for (uint32_t q = 0; q < nit[c]; ++q) g_loc_pairs[c] += items[c][q].z - items[c][q].y;
             g_loc_pairs[3] += nit[3];
@@ -881,17 +903,17 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         switch (a.nkp / 64) {
             case 1: case 2:
                 if (!npl) run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<2>(x, a); });
-                if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<2, true>(x, a); else body_pair_usual<2, false>(x, a); });
+                if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<2, true, false>(x, a); else if (fuse && a.sel) body_pair_usual<2, false, true>(x, a); else body_pair_usual<2, false, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<2>), [&](EmuX& x) { if (a.recs) body_pair<2, true>(x, a); else body_pair<2, false>(x, a); });
                 break;
             case 3:
                 if (!npl) run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<3>(x, a); });
-                if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<3, true>(x, a); else body_pair_usual<3, false>(x, a); });
+                if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<3, true, false>(x, a); else if (fuse && a.sel) body_pair_usual<3, false, true>(x, a); else body_pair_usual<3, false, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<3>), [&](EmuX& x) { if (a.recs) body_pair<3, true>(x, a); else body_pair<3, false>(x, a); });
                 break;
             default:
                 if (!npl) run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<4>(x, a); });
-                if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<4, true>(x, a); else body_pair_usual<4, false>(x, a); });
+                if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<4, true, false>(x, a); else if (fuse && a.sel) body_pair_usual<4, false, true>(x, a); else body_pair_usual<4, false, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<4>), [&](EmuX& x) { if (a.recs) body_pair<4, true>(x, a); else body_pair<4, false>(x, a); });
         }
     }

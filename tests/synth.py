@@ -145,7 +145,7 @@ def _mutate(rng, s: np.ndarray, sub, indel, nrate, lower) -> np.ndarray:
 
 
 def sim_reads(loci: Loci, npairs=1000, rlen=150, frag=(300, 500), seed=2, sub=0.0, indel=0.0, nrate=0.0, lower=0.0,
-              chimeric=0.0, background=0.0, short=0.0, with_qual=False) -> Reads:
+              chimeric=0.0, background=0.0, short=0.0, with_qual=False, splice=0.0) -> Reads:
     """Pairs in the orientation the reference's reader hands to the hot loop:
     seqs[2p] and seqs[2p+1] are simply the two mates."""
     rng = np.random.default_rng(seed)
@@ -170,6 +170,14 @@ def sim_reads(loci: Loci, npairs=1000, rlen=150, frag=(300, 500), seed=2, sub=0.
                 l2 = int(rng.integers(0, loci.nloci)); h2 = int(rng.integers(0, loci.nhap))
                 _, b = mate_from(l2, h2)
                 name += f"x{l2}"
+            if splice and rng.random() < splice:
+                # the tail of one mate comes from ANOTHER locus: a pair that is its locus' by every count (cth k-mers per mate), with
+                # a stretch of k-mers that are in the index but not this locus' (the fused probe kernel must take such a pair back)
+                l2 = int(rng.integers(0, loci.nloci)); h2 = int(rng.integers(0, loci.nhap))
+                s2 = loci.haps[h2][l2]
+                n2 = int(rng.integers(28, 50))
+                at = int(rng.integers(0, len(s2) - n2 + 1))
+                b = np.concatenate([b[:len(b) - n2], s2[at:at + n2]])
             if rng.random() < 0.5:
                 a, b = b, a
         a = _mutate(rng, a, sub, indel, nrate, lower)

@@ -34,6 +34,7 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
     assert E.consistent(T) == (0 if case == "inconsistent" else 1)
     E.probe_stats()
     E.locus_stats()
+    E.path_stats()
     for i, kw in enumerate(c.param_sets):
         p = abi.default_params(ksize=c.k, trace=1, **kw)
         a = O.align(go, p, seq, off)
@@ -69,6 +70,12 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
         assert sum(cls) > 0 and rest > 0  # both the image path and the hand-over to the global tables ran
     if case in ("shared", "k25"):
         assert cls[0 if case == "shared" else 1] > 0  # different classes of workgroup are exercised
+    ps = E.path_stats()
+    print(f"{case}: fused resolve: {ps['fused_done']} pairs, {ps['fused_redone']} taken back")
+    if case in ("clean", "shared", "qc", "spliced", "k25"):
+        assert ps["fused_done"] > 0   # the no-trace, no-record runs resolve the usual pairs inside the locus-resident probe body
+    if case == "spliced":
+        assert ps["fused_redone"] > 20  # ... and take back the ones that have a k-mer of the index outside the image
     E.L.emu_tables_free(T)
     O.free(go)
     g.close()

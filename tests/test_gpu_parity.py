@@ -331,7 +331,7 @@ def dense_slice_checks(monkeypatch, dbtk, oracle, syn, arrs, g, orc_g, k):
     """the locus-resident kernels (dbtk_locus.h: k_probe_locus; dbtk_walkfast.h: k_walk_fast_locus) against the ORACLE on
     the release-scale RPGG.  A uniform draw over 80 000 loci gives ~1 pair per locus and never reaches them; here ~1 400 loci of every
     image class (every locus of the largest class) get 64 pairs each, 6 % of the pairs chimeric / foreign.  Device counters assert that
-    the locus path took >= 90 % of the pairs and every class; counts, kmc, nmapread, all counters, the trace records, the walk results and
+    the locus path took >= 90 % of the pairs (87 % at k = 25) and every class; counts, kmc, nmapread, all counters, the trace records, the walk results and
     the -ae text are the oracle's."""
     lg, _ = locus_image_lg(arrs, k)
     rng = np.random.default_rng(11 + k)
@@ -362,7 +362,9 @@ def dense_slice_checks(monkeypatch, dbtk, oracle, syn, arrs, g, orc_g, k):
         ps = ctx.path_stats()
         surv = int(res["counters"][abi.C_SURVIVORS])
         assert surv > 0.99 * n
-        assert surv - ps["probe_rest"] >= 0.9 * surv, (ps, surv)
+        # (6 % of the pairs are not their list locus'; a pair more than 96 of whose positions miss the image is handed to the lean kernel too:
+        # at k = 25 an error costs 25 positions — measured: 6.9 % of the pairs at k = 21, 10.1 % at k = 25)
+        assert surv - ps["probe_rest"] >= (0.9 if k < 23 else 0.87) * surv, (ps, surv)
         for c in classes:
             assert ps["probe_items"][c] > 0 and ps["probe_pairs"][c] >= 16 * ps["probe_items"][c], (c, ps)
         ctx.close()
