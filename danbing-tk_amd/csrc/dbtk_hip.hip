@@ -178,11 +178,23 @@ static bool sync_launches() {
     static const bool v = [] { const char* e = getenv("DBTK_SYNC_LAUNCHES"); return (e && atoi(e) != 0) || DBTK_DEBUG_LAUNCH; }();
     return v;
 }
+// DBTK_TRACE_LAUNCHES=1 (diagnostic): every launch is announced on stderr, waited for, and acknowledged — the last name before a GPU
+// memory fault is the kernel that raised it.  DBTK_SYNC_ONLY=<substring>: only the kernels whose name contains it are waited for.
+static int trace_launches() {
+    static const int v = [] { const char* e = getenv("DBTK_TRACE_LAUNCHES"); return e ? atoi(e) : 0; }();
+    return v;
+}
+static bool sync_only(const char* name) {
+    static const char* pat = getenv("DBTK_SYNC_ONLY");
+    return pat && *pat && strstr(name, pat) != nullptr;
+}
 #define LAUNCH(kern, grid, block, stream, ...)                                                        \
     do {                                                                                              \
+        if (trace_launches()) fprintf(stderr, "[launch] %s grid %u block %u\n", #kern, (unsigned)dim3(grid).x, (unsigned)dim3(block).x); \
         hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);                                \
         hipError_t e_ = hipGetLastError();                                                            \
-        if (e_ == hipSuccess && sync_launches()) e_ = hipStreamSynchronize(stream);                   \
+        if (e_ == hipSuccess && (sync_launches() || trace_launches() || sync_only(#kern))) e_ = hipStreamSynchronize(stream); \
+        if (trace_launches()) fprintf(stderr, "[launch] %s done: %s\n", #kern, hipGetErrorString(e_)); \
         if (e_ != hipSuccess) {                                                                       \
             set_error(std::string("kernel " #kern ": ") + hipGetErrorString(e_));                     \
             return DBTK_ERR_HIP;                                                                      \

@@ -1708,14 +1708,18 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     uint32_t nxnk[2] = {0, 0};
     uint64_t ofC[2] = {0, 0}, hdC[2] = {0, 0};    // item i+2 (in flight)
     uint32_t nkC[2] = {0, 0};
-    auto rowof = [&](uint32_t tt, int m) { return (size_t)2 * ((tt != NOITEM ? tt : a.t0) - a.t0) + m; };
+    // "no item" (past the end of the wave's range) re-reads the rows of a pair that HAS rows, so that the loads stay straight-line: with a
+    // list, its first entry — since the fused probe kernel (dbtk_locus.h) a pair that is not listed may have written none, and its
+    // read offset would be whatever the buffer held
+    const uint32_t tsafe = listmode ? x.uni(a.gen_list[0]) : a.t0;
+    auto rowof = [&](uint32_t tt, int m) { return (size_t)2 * ((tt != NOITEM ? tt : tsafe) - a.t0) + m; };
     auto fetch_meta = [&](uint32_t tt) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) { ofC[m] = a.hitoff[rowof(tt, m) + lzz]; nkC[m] = a.hitnk[rowof(tt, m) + lzz]; hdC[m] = a.hithdr[rowof(tt, m) + lzz]; }
     };
     // probe results + bytes of item tt, whose offsets / position counts are o0[], nk[]
     auto request = [&](uint32_t tt, const uint64_t o0[2], const uint32_t nk[2], const uint64_t hd[2]) {
-        const uint32_t tc = tt != NOITEM ? tt : a.t0;  // (what comes back for "no item" is never used: the loop ends first)
+        const uint32_t tc = tt != NOITEM ? tt : tsafe;  // (what comes back for "no item" is never used: the loop ends first)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll

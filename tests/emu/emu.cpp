@@ -798,8 +798,10 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     // survivor chunks: small hit buffers force several K2 -> K3 iterations, as on the device
     const uint32_t tcap = npairs > 7 ? (uint32_t)(npairs / 3 + 1) : (uint32_t)(npairs ? npairs : 1);
     std::vector<uint64_t> hitva((size_t)tcap * 2 * a.nkp + 1, 0);  // aux words of every row, then val words
-    std::vector<uint32_t> hitnk((size_t)tcap * 2 + 1, 0), gen(tcap + 1, 0);
-    std::vector<uint64_t> hitoff((size_t)tcap * 4 + 1, 0);
+    // (poisoned: a row the probe stage did not write — a pair the fused locus-resident body resolved itself — must never be read as one
+    // that was: an offset from such a row is a wild address, as on the device, where the buffers hold whatever was there)
+    std::vector<uint32_t> hitnk((size_t)tcap * 2 + 1, 0xA5A5A5A5u), gen(tcap + 1, 0);
+    std::vector<uint64_t> hitoff((size_t)tcap * 4 + 1, 0x7FFFDEAD00000000ull);
     a.hitaux = reinterpret_cast<uint32_t*>(hitva.data()); a.hitval = a.hitaux + (size_t)tcap * 2 * a.nkp; a.hitnk = hitnk.data(); a.hitoff = hitoff.data(); a.hithdr = hitoff.data() + (size_t)tcap * 2;
     a.tcap = tcap;
     const bool usual = e->T.consistent && !p->trace && !p->bait && !p->bubbles;  // as the device launcher decides
