@@ -108,6 +108,8 @@ def kernel_table(ktimes, alg, steps, timed_steps):
         u, g_ = kt.pop("k_pair_usual"), kt.get("k_pair", (0.0, 0))
         kt["k_pair"] = (u[0] + g_[0], max(u[1], g_[1]))
         kt["k_pair: usual-pair part"] = u
+    if "k_probe" in kt:
+        kt["k_probe: look-ups only"] = kt["k_probe"]  # (the same stage priced with its index look-ups alone: the round-4 figure's definition)
     out = {}
     for name, (ms, n) in kt.items():
         if not n:
@@ -120,12 +122,17 @@ def kernel_table(ktimes, alg, steps, timed_steps):
     return out
 
 
-def algorithmic_bytes(abi, ctr, walk_probes=0.0):
-    """B = 2L + 12 P + 4 V + 8 A + 16 I, split over the kernels that do the work."""
+def algorithmic_bytes(abi, ctr, walk_probes=0.0, ps=None):
+    """B = 2L + 12 P + 4 V + 8 A + 16 I, split over the kernels that do the work.  `ps` (dbtk_ctx_path_stats): the part
+    of A and I the fused locus-resident probe kernel did itself (it resolves the usual pairs of its items: dbtk_locus.h) is priced with
+    the probe stage, where its time is."""
+    fa = float(ps["fused_cls"]) if ps else 0.0
+    fi = float(ps["fused_inc"]) if ps else 0.0
     return {
         "k_encode_subfilter": ctr[abi.C_BASES] + 12.0 * (ctr[abi.C_ALGO_PROBES] - ctr[abi.C_NHASH1]),
-        "k_probe": 12.0 * ctr[abi.C_NHASH1],
-        "k_pair": 4.0 * ctr[abi.C_ALGO_VV] + 8.0 * ctr[abi.C_ALGO_CLS] + 16.0 * ctr[abi.C_ALGO_INC],
+        "k_probe": 12.0 * ctr[abi.C_NHASH1] + 8.0 * fa + 16.0 * fi,
+        "k_probe: look-ups only": 12.0 * ctr[abi.C_NHASH1],
+        "k_pair": 4.0 * ctr[abi.C_ALGO_VV] + 8.0 * (ctr[abi.C_ALGO_CLS] - fa) + 16.0 * (ctr[abi.C_ALGO_INC] - fi),
         # the walk: one graph look-up (8 B node + 1 B edge mask, the PREF.graph.umap entry) and one TR-set look-up (8 B) per
         # k-mer of both mates of every walked pair, + 16 B per count increment
         "k_walk_pairs": walk_probes * 17.0 + 16.0 * ctr[abi.C_ALGO_INC],
@@ -187,6 +194,8 @@ def pmc_mix(mix, stage):
     tot = lambda key: sum(v.get(key, 0.0) for v in ks.values())
     out = dict(source=f"profiles/{name}", steps=m["steps"], kernels=sorted(ks),
                traffic=tot("FETCH_SIZE_KB:sum") * 1024.0 / st if any("FETCH_SIZE_KB:sum" in v for v in ks.values()) else None,
+               write_traffic=tot("WRITE_SIZE_KB:sum") * 1024.0 / st if any("WRITE_SIZE_KB:sum" in v for v in ks.values()) else None,
+               insts_salu=tot("SQ_INSTS_SALU:sum") / st if any("SQ_INSTS_SALU:sum" in v for v in ks.values()) else None,
                l1_to_l2_read_requests=tot("TCP_TCC_READ_REQ_sum:sum") / st if any("TCP_TCC_READ_REQ_sum:sum" in v for v in ks.values()) else None,
                insts_valu=tot("SQ_INSTS_VALU:sum") / st if any("SQ_INSTS_VALU:sum" in v for v in ks.values()) else None,
                rocprof_ms=sum(v["calls"] * v["avg_ns"] for v in ks.values() if "avg_ns" in v) / st * 1e-6 if any("avg_ns" in v for v in ks.values()) else None)
@@ -214,6 +223,68 @@ def usable_cpus():
         except Exception:
             pass
     return n
+
+
+def dense_gpu_half(dbtk, mix, syn, arrs, g, params, k, per_lg=120, pairs_per_locus=64):
+    """A dense slice of the RPGG through the HIP path: `pairs_per_locus` pairs on each of up to per_lg loci of every image size (every
+    class of the locus-resident kernels), 6 % of them chimeric / foreign — in a context created under DBTK_LOCUS_ALWAYS=1, so that the
+    batch (tens of thousands of pairs on a release-scale RPGG) is sorted and offered to the locus path like a 10 M-read batch.
+    Returns what dense_oracle_half compares."""
+    import bind
+    pkg = bind.pkg
+    loci, classes = bind.dense_loci(arrs, k, per_lg=per_lg, seed=77 + k)
+    n = pairs_per_locus * len(loci)
+    seq, off = syn.reads_loci(n, loci, odd_frac=0.06, seed=300 + k)
+    old = os.environ.get("DBTK_LOCUS_ALWAYS")
+    os.environ["DBTK_LOCUS_ALWAYS"] = "1"
+    try:
+        ctx = dbtk.context(g, params, device=int(os.environ.get("LOCAL_RANK", "0")))
+    finally:
+        if old is None:
+            del os.environ["DBTK_LOCUS_ALWAYS"]
+        else:
+            os.environ["DBTK_LOCUS_ALWAYS"] = old
+    ctx.align(seq, off)
+    r = ctx.counts()
+    walking = params.threading == pkg.abi.THREADING_V13
+    res, nres = (None, 0)
+    if walking:
+        res, _, nres = ctx.walk_results(n)
+    ps = ctx.path_stats()
+    ctx.close()
+    return dict(mix=mix, k=k, params=params, seq=seq, off=off, n=n, counts=r, res=res, nres=nres, path=ps, classes=classes, nloci_slice=len(loci),
+                ntr=g.ntrkmers, order=g.output_order().astype(np.int64), nloci=g.nloci, walking=walking)
+
+
+def dense_oracle_half(orc, go, chk, log):
+    import bind
+    abi = bind.abi
+    t0 = time.time()
+    r = chk["counts"]
+    if chk["walking"]:
+        o = orc.align_walk(go, chk["params"], chk["seq"], chk["off"], with_recs=False)
+    else:
+        o = orc.align(go, chk["params"], chk["seq"], chk["off"], trace=False)
+    co = np.zeros(chk["ntr"], np.uint64)
+    np.add.at(co, chk["order"], o["counts_file"])
+    ok = bool((co == r["counts"]).all() and (o["counters"] == r["counters"]).all())
+    if chk["walking"]:
+        ok = ok and chk["nres"] == o["nres"] and bind.walk_res_equal(chk["res"], o["res"], chk["nres"], chk["nloci"], every_mate=False) >= 0
+    else:
+        ok = ok and bool((o["kmc"] == r["kmc"]).all() and (o["nmapread"] == r["nmapread"]).all())
+    ps = chk["path"]
+    surv = int(r["counters"][abi.C_SURVIVORS])
+    on_locus_path = (surv - ps["probe_rest"]) / max(surv, 1)
+    out = dict(pairs=chk["n"], loci=chk["nloci_slice"], image_classes=chk["classes"], bit_exact=ok, pairs_on_locus_path=on_locus_path,
+               probe_items=ps["probe_items"], fused_done=ps["fused_done"], fused_redone=ps["fused_redone"],
+               walk_items=ps["walk_items"] if chk["walking"] else None, walked=int(o["nres"]) if chk["walking"] else None,
+               note="dense slice (64 pairs per locus, 6 % chimeric / foreign) against oracle/: counts, kmc, nmapread, all counters"
+                    + (", walk results" if chk["walking"] else ""))
+    log(f"{chk['mix']}: dense-slice parity on {chk['n']} pairs over {chk['nloci_slice']} loci: {'bit-exact' if ok else 'MISMATCH'}; "
+        f"{100 * on_locus_path:.1f} % of the pairs on the locus path, {ps['fused_done']} resolved there ({time.time() - t0:.0f}s)")
+    if not ok:
+        raise SystemExit(f"GPU result of the {chk['mix']} dense slice differs from the oracle")
+    return out
 
 
 def time_steps(ctx, fn, steps, warmup):
@@ -379,8 +450,14 @@ def main():
     ktimes = ctx.kernel_times()      # HIP events recorded inside the timed region, read after it
     if world == 1:
         local_ctr = ctx.counters()
+    per_rank_ms = [dt / args.steps * 1e3]
     if use_dist:
+        # every rank's own time for the same K steps (barrier to barrier), so that a first multi-GPU run is diagnosable from its one
+        # line: `ms_per_step` is their maximum
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_device else dev)
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank_ms = [float(e.item()) / args.steps * 1e3 for e in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     reduce_check = None
@@ -440,6 +517,7 @@ def main():
 
     # ---- N = 1 extras: further read mixes, end to end, CPU baselines
     mixes, e2e, cpu, parity, k25_check = None, None, None, None, None
+    dense_checks = []  # per mix: the GPU half of its dense-slice parity check (the oracle half runs with the CPU legs)
     nhit = 0  # pairs of the all-hit FASTA the CLI walk legs read
     if solo and rank == 0:
         mixes = {}
@@ -460,12 +538,17 @@ def main():
                 ctxa = dbtk.context(g, params, device=local_rank)
                 ctxa.timers_enable(1)
                 dta = time_steps(ctxa, lambda: ctxa.align_device(d_ah.data_ptr(), d_aho.data_ptr(), mp, rlen), args.mix_steps, 2)
-                ta = kernel_table(ctxa.kernel_times(), algorithmic_bytes(abi, ctxa.counters().astype(np.float64)), args.mix_steps, args.mix_steps)
+                psa = ctxa.path_stats()
+                ta = kernel_table(ctxa.kernel_times(), algorithmic_bytes(abi, ctxa.counters().astype(np.float64), ps=psa), args.mix_steps, args.mix_steps)
+                if args.cpu_seconds > 0:
+                    dense_checks.append(dense_gpu_half(dbtk, "all_hit", syn, arrs, g, params, 21))
                 ctxa.close()
                 doma = max((k for k in ta if ":" not in k), key=lambda k: ta[k]["avg_ms"] * ta[k]["launches"])
                 mixes["all_hit"] = dict(workload=f"{2 * mp} reads per step, 100 % of pairs from loci, -k 21 -kf 4 1 -cth 45 -ka",
                                         value=2 * mp * args.mix_steps / dta, unit="reads/s", ms_per_step=dta / args.mix_steps * 1e3,
                                         steps=args.mix_steps, roofline=dict(roofline_of(doma, ta), kernels=ta),
+                                        path=dict(psa, note="pairs per step x steps + warm-up: which kernels took them (dbtk_ctx_path_stats); fused_done = pairs the "
+                                                            "locus-resident probe kernel resolved itself (no hit rows, no second kernel)"),
                                         probe_roofline=dict(roofline_of("k_probe", ta), profiled=pmc_mix("all_hit", "k_probe"),
                                                             traffic=(pmc_mix("all_hit", "k_probe") or {}).get("traffic"))
                                         if "k_probe" in ta else None)
@@ -492,6 +575,8 @@ def main():
                                             roofline=dict(roofline_of(domw, tw), kernels=tw, profiled=pmc_mix("walk", "k_walk_pairs"),
                                                           traffic=(pmc_mix("walk", "k_walk_pairs") or {}).get("traffic")))
                 log(f"walk mix: {dtw / args.mix_steps * 1e3:.3f} ms/step, {mixes['walk_gc85_3']['value'] / 1e6:.1f} M reads/s, dominant {domw} {tw[domw]['avg_ms']:.3f} ms")
+                if args.cpu_seconds > 0:
+                    dense_checks.append(dense_gpu_half(dbtk, "walk_gc85_3", syn, arrs, g, pw, 21))  # (before the walking context goes: they share the graph tables)
                 ctxw.close()
             # genome-like background: WGS reads are not uniform random — repeat families shared with the flanks let far more pairs
             # through subfilter than the 2 % that come from a locus.  Here 15 % of the background pairs carry a 64-base stretch of
@@ -559,15 +644,12 @@ def main():
                 if args.cpu_seconds > 0 and args.k25_parity_pairs > 0:
                     # the GPU half of the parity slice now, the oracle half with the CPU legs below: the k = 25 tables (80 GB with the walk's)
                     # do not stay in HBM while the command-line legs bring their own
-                    n25 = min(args.k25_parity_pairs, len(o25) // 2)
-                    ctx25.reset()
-                    ctx25.align(s25[:2 * n25 * rlen], o25[:2 * n25 + 1])
-                    r25 = ctx25.counts()
-                    res25, _, nres25 = ctx25.walk_results(n25)
-                    k25_check = (syn25, arrs25, p25, s25, o25, n25, r25, res25, nres25, g25.ntrkmers, g25.output_order().astype(np.int64), g25.nloci)
+                    k25_check = (syn25, arrs25, dense_gpu_half(dbtk, "walk_k25_gc85_3", syn25, arrs25, g25, p25, 25))
+                    ctx25.close()
                 else:
                     syn25.close()
-                ctx25.close(); g25.close()
+                    ctx25.close()
+                g25.close()
         if not args.no_e2e:
             # the same batch handed over as HOST buffers: validation + PCIe copies + kernels, one batch after the other
             e2e = {}
@@ -694,18 +776,17 @@ def main():
             port = dict(value=2 * done / t_cpu, unit="reads/s", cores=1, kind="port",
                         sample=f"first {2 * done} reads of the same read set and RPGG, oracle/dbtk_oracle.c on 1 host core, {t_cpu:.1f} s", checked=parity)
             log(f"oracle (port) on 1 core: {port['value']:.0f} reads/s")
+            # every mix against the oracle on a DENSE slice (64 pairs on each of a few hundred loci of every image class, 6 % of them
+            # chimeric / foreign): the regime in which the locus-resident kernels — the ones the mixes time — take the pairs
+            for chk in dense_checks:
+                mixes[chk["mix"]]["parity"] = dense_oracle_half(orc, go, chk, log)
             orc.free(go)
-            if k25_check:  # the k = 25 walk mix against the oracle on a slice: counts, counters, walk results
-                syn25, arrs25, p25, s25, o25, n25, r25, res25, nres25, ntr25, order25, nloci25 = k25_check
+            if k25_check:
+                syn25, arrs25, chk = k25_check
                 t0 = time.time()
                 go25 = orc.from_arrays(arrs25)
-                ow = orc.align_walk(go25, p25, s25[:2 * n25 * rlen], o25[:2 * n25 + 1], with_recs=False)
-                co = np.zeros(ntr25, np.uint64)
-                np.add.at(co, order25, ow["counts_file"])
-                ok = bool((co == r25["counts"]).all() and (ow["counters"] == r25["counters"]).all() and nres25 == ow["nres"]
-                          and bind.walk_res_equal(res25, ow["res"], nres25, nloci25, every_mate=False) >= 0)
-                mixes["walk_k25_gc85_3"]["parity"] = dict(pairs=n25, bit_exact=ok, walked=int(ow["nres"]))
-                log(f"k = 25 walk mix, parity on {n25} pairs ({ow['nres']} walked): {'bit-exact' if ok else 'MISMATCH'} ({time.time() - t0:.0f}s incl. oracle tables)")
+                mixes["walk_k25_gc85_3"]["parity"] = dense_oracle_half(orc, go25, chk, log)
+                log(f"(k = 25 oracle tables + slice: {time.time() - t0:.0f}s)")
                 orc.free(go25)
                 syn25.close()
         if do_ref:
@@ -738,7 +819,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "paired reads/sec aligned to RPGG (k=21)", "value": value, "unit": "reads/s", "n_gpus": world, "ranks_seen": ranks_seen,
+            "metric": "paired reads/sec aligned to RPGG (k=21)", "value": value, "unit": "reads/s", "n_gpus": world, "ranks_seen": ranks_seen, "per_rank_ms_per_step": per_rank_ms,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"release-scale synthetic RPGG ({args.nloci} loci, {arrs.nkeys} index keys, {g.ntrkmers} TR k-mers) "

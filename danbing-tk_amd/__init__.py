@@ -265,11 +265,11 @@ class Context:
 
     def path_stats(self):
         """Which kernels took how many pairs since creation / reset (dbtk.h: DBTK_PS_*): a dict."""
-        v = (C.c_uint64 * 16)()
-        n = self._lib.L.dbtk_ctx_path_stats(self.h, v, 16)
-        v = [int(x) for x in v[:n]] + [0] * (16 - n)
+        v = (C.c_uint64 * 20)()
+        n = self._lib.L.dbtk_ctx_path_stats(self.h, v, 20)
+        v = [int(x) for x in v[:n]] + [0] * (20 - n)
         return {"probe_items": v[0:3], "probe_pairs": v[3:6], "probe_rest": v[6], "walk_items": v[7:10], "walk_pairs": v[10:13],
-                "walk_rest": v[13], "fused_done": v[14], "fused_redone": v[15]}
+                "walk_rest": v[13], "fused_done": v[14], "fused_redone": v[15], "fused_cls": v[16], "fused_inc": v[17]}
 
     def timers_reset(self):
         self._lib.L.dbtk_ctx_timers_reset(self.h)
@@ -360,6 +360,7 @@ class Ingest:
         L.dbtk_ingest_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.IngestInfo)]
         L.dbtk_ingest_align.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(abi.PairRec), C.c_uint64, u64p]
         L.dbtk_ingest_spans.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.IngestSpan), C.c_uint64]
+        L.dbtk_ingest_align_merged.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_int]
         self.h = C.c_void_p()
         ctx._lib._chk(L.dbtk_ingest_create(ctx.h, int(bool(fastq)), int(min_read_size), self.chunk, self.nslots, int(bool(with_spans)), C.byref(self.h)))
 
@@ -383,6 +384,10 @@ class Ingest:
         nrec = C.c_uint64(0)
         self.ctx._lib._chk(self.L.dbtk_ingest_align(self.h, slot, ctx.h if ctx else None, int(sync), recs, info.nkept if want else 0, C.byref(nrec)))
         return recs, int(nrec.value)
+
+    def align_merged(self, slot, min_pairs, flush=False, ctx=None):
+        """dbtk_ingest_align_merged: the block appended to the context's merged batch (slot None: flush only)."""
+        self.ctx._lib._chk(self.L.dbtk_ingest_align_merged(self.h, 0xFFFFFFFF if slot is None else slot, ctx.h if ctx else None, int(min_pairs), int(flush)))
 
     def spans(self, slot, info):
         """[(title, read 2q, read 2q + 1, qual 2q, qual 2q + 1)] of the block's kept pairs, as bytes."""
@@ -415,7 +420,7 @@ EXPORTS = [
     "dbtk_allreduce", "dbtk_rpgg_set_index_cache", "dbtk_ctx_table_bytes", "dbtk_ctx_path_stats", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_aln_text", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
     "dbtk_thread_batch", "dbtk_ctx_walk_results", "dbtk_ctx_aln_records", "dbtk_aln_format",
     "dbtk_ingest_create", "dbtk_ingest_free", "dbtk_ingest_chunk_buffer", "dbtk_ingest_block", "dbtk_ingest_submit", "dbtk_ingest_wait",
-    "dbtk_ingest_align", "dbtk_ingest_spans", "dbtk_ingest_aln_lines",
+    "dbtk_ingest_align", "dbtk_ingest_align_merged", "dbtk_ingest_spans", "dbtk_ingest_aln_lines",
 ]
 
 # include/dbtk_pred.h (the danbing-tk-pred step)

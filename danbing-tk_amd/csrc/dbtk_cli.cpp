@@ -1204,6 +1204,9 @@ int main(int argc, char* argv[]) {
         bool handed = false;   // the host reader takes over
         uint32_t hslot = 0;
         const bool sync = want_out || P.bubbles;  // (-bu replays every batch's novel edges on the host)
+        const bool merged = !sync && !P.trace && !(P.bait && fq) && !getenv("DBTK_NO_MERGE");
+        uint64_t merge_pairs = std::max<uint64_t>(1ull << 20, 24 * nloci);  // (LOC_MIN_PAIRS = 16 pairs per locus and half as many again)
+        if (const char* e = getenv("DBTK_MERGE_PAIRS")) { const long long v = atoll(e); if (v > 0) merge_pairs = (uint64_t)v; }  // (tests: several merged batches)
         while (jaln < nchunks) {
             for (;;) {  // submit what has been read, up to NS - 1 blocks ahead of the one about to be aligned — and never block i before block
                         // i + 1 - NS has been released: parsing block i puts its carried-over bytes in front of the NEXT slot's device block,
@@ -1240,7 +1243,10 @@ int main(int argc, char* argv[]) {
                 const Work w{jaln, slot, info};
                 if (workers.empty()) process(cx, w); else wq.push(w);
             } else {
-                if (dbtk_ingest_align(ing, slot, nullptr, sync ? 1 : 0, nullptr, 0, nullptr)) die_assert(std::string("align: ") + dbtk_last_error());
+                // no records: the parsed blocks (~100 000 pairs each) are merged on the device into batches of merge_pairs pairs — the kernels
+                // that keep a locus' k-mers in LDS want many pairs per locus in a batch (how pairs are cut into batches changes no result)
+                if (merged ? dbtk_ingest_align_merged(ing, slot, nullptr, merge_pairs, 0) : dbtk_ingest_align(ing, slot, nullptr, sync ? 1 : 0, nullptr, 0, nullptr))
+                    die_assert(std::string("align: ") + dbtk_last_error());
                 { std::lock_guard<std::mutex> l(gb_m); gb += now() - t0; }
                 release();
             }
@@ -1251,6 +1257,11 @@ int main(int argc, char* argv[]) {
         }
         wq.close();
         for (auto& t : workers) t.join();
+        if (merged) {  // what is left of the merged batch
+            const double t0 = now();
+            if (dbtk_ingest_align_merged(ing, ~0u, nullptr, 0, 1)) die_assert(std::string("align: ") + dbtk_last_error());
+            std::lock_guard<std::mutex> l(gb_m); gb += now() - t0;
+        }
         { std::lock_guard<std::mutex> l(m); stop = true; }
         cv.notify_all();
         for (auto& t : ios) t.join();

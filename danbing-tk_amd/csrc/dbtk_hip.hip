@@ -95,6 +95,10 @@ __global__ void __launch_bounds__(256) k_loc_count(LocBuildArgs a) { DevX x{null
 __global__ void __launch_bounds__(256) k_loc_scatter(LocBuildArgs a) { DevX x{nullptr}; body_loc_scatter(x, a); }
 __global__ void __launch_bounds__(64) k_loc_place(LocBuildArgs a) { DevX x{nullptr}; body_loc_place(x, a); }
 __global__ void __launch_bounds__(256) k_loc_verify(LocBuildArgs a) { DevX x{nullptr}; body_loc_verify(x, a); }
+// offsets of a parsed block appended behind the merged batch's: dst[r] = src[r] + add, r = 0 .. n - 1
+__global__ void __launch_bounds__(256) k_off_rebase(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t add) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i] + add;
+}
 __global__ void __launch_bounds__(256) k_csum(const uint64_t* p, uint64_t n, uint64_t* out) { DevX x{nullptr}; body_csum(x, p, n, out); }
 __global__ void __launch_bounds__(256) k_gloc_count(LocBuildArgs a) { DevX x{nullptr}; body_gloc_count(x, a); }
 __global__ void __launch_bounds__(256) k_gloc_scatter(LocBuildArgs a) { DevX x{nullptr}; body_gloc_scatter(x, a); }
@@ -275,6 +279,9 @@ struct dbtk_ctx {
     uint16_t* d_perm = nullptr;
     uint64_t* d_accum = nullptr;  // counts | kmc | nmapread | counters
     uint64_t* d_ctr = nullptr;    // counter replicas (folded into d_accum's counters at the end of every batch)
+    uint8_t* m_flat = nullptr; uint64_t m_flat_cap = 0;   // the current lane's merged blocks (dbtk_ingest_align_merged; Lane::m_*)
+    uint64_t* m_off = nullptr; uint64_t m_off_cap = 0;
+    uint64_t m_bytes = 0, m_pairs = 0; uint32_t m_maxlen = 0;
     uint64_t* d_pstats = nullptr; // path statistics (dbtk.h: dbtk_ctx_path_stats): which kernels took how many pairs; never part of the results
     uint64_t n_accum = 0, ntr = 0;
     uint32_t* d_small = nullptr;  // nsurv, novf, nrec, errflag
@@ -339,6 +346,10 @@ struct dbtk_ctx {
         uint32_t* d_walk = nullptr; uint64_t walk_cap = 0;
         uint64_t* d_vote = nullptr;
         uint32_t* d_epoch = nullptr;
+        // blocks of the device reader merged into one batch (dbtk_ingest_align_merged): reads back to back, offsets
+        uint8_t* m_flat = nullptr; uint64_t m_flat_cap = 0;
+        uint64_t* m_off = nullptr; uint64_t m_off_cap = 0;
+        uint64_t m_bytes = 0, m_pairs = 0; uint32_t m_maxlen = 0;
     } alt;
     std::deque<Lane> parked;  // lanes beyond the second (DBTK_LANES > 2): switch_lane goes round all of them
     bool two_lanes = false;   // more than one lane
@@ -380,7 +391,7 @@ void free_ctx(dbtk_ctx* c) {
             if (c->timed[i].beg[j]) (void)hipEventDestroy(c->timed[i].beg[j]);
             if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
         }
-    void* ptrs[] = {c->d_ctr, c->d_pstats, c->d_accum, c->d_small, c->d_surv,
+    void* ptrs[] = {c->m_flat, c->m_off, c->d_ctr, c->d_pstats, c->d_accum, c->d_small, c->d_surv,
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
                     c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_walk, c->d_trecs, c->d_loci, c->d_aln, c->d_txt, c->d_txtidx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -389,7 +400,7 @@ void free_ctx(dbtk_ctx* c) {
     std::vector<dbtk_ctx::Lane*> others{&c->alt};
     for (auto& l : c->parked) others.push_back(&l);
     for (dbtk_ctx::Lane* l : others) {
-        void* aptrs[] = {l->d_small, l->d_surv, l->d_hitva, l->d_hitnk, l->d_hitoff, l->d_gen, l->d_tickets, l->d_vote, l->d_epoch, l->d_walk};
+        void* aptrs[] = {l->d_small, l->d_surv, l->d_hitva, l->d_hitnk, l->d_hitoff, l->d_gen, l->d_tickets, l->d_vote, l->d_epoch, l->d_walk, l->m_flat, l->m_off};
         for (void* p : aptrs) if (p) (void)hipFree(p);
         if (l != &c->alt && l->stream) (void)hipStreamDestroy(l->stream);
     }
@@ -979,6 +990,8 @@ void switch_lane(dbtk_ctx* c) {
     std::swap(c->d_tickets, c->alt.d_tickets); std::swap(c->tickets_cap, c->alt.tickets_cap);
     std::swap(c->d_walk, c->alt.d_walk); std::swap(c->walk_cap, c->alt.walk_cap);
     std::swap(c->d_vote, c->alt.d_vote); std::swap(c->d_epoch, c->alt.d_epoch);
+    std::swap(c->m_flat, c->alt.m_flat); std::swap(c->m_flat_cap, c->alt.m_flat_cap); std::swap(c->m_off, c->alt.m_off); std::swap(c->m_off_cap, c->alt.m_off_cap);
+    std::swap(c->m_bytes, c->alt.m_bytes); std::swap(c->m_pairs, c->alt.m_pairs); std::swap(c->m_maxlen, c->alt.m_maxlen);
     if (!c->parked.empty()) {  // round robin: the lane just left goes to the back of the queue, the longest-parked one is next
         c->parked.push_back(c->alt);
         c->alt = c->parked.front();
@@ -2371,6 +2384,67 @@ static dbtk_status_t dbtk_ingest_align_impl(dbtk_ingest_t* g, uint32_t slot, dbt
     return DBTK_OK;
 }
 
+// The parsed block of `slot` appended to the context's MERGED batch (device-to-device: the reads back to back behind the ones already
+// there, the offsets rebased), which is aligned once it holds min_pairs pairs — or now, with flush.  A 32-MB block is ~100 000 pairs;
+// the locus-resident kernels (dbtk_locus.h) want a batch with LOC_MIN_PAIRS pairs per locus: at release scale two million.  The
+// reference batches 300 000 reads per thread whatever the content (src/aQueryFasta_thread.cpp:1918-1976); pairs are independent and
+// every effect of one is an integer add, so how the pairs are cut into batches changes no result.  No records, no -b qualities,
+// no -bu (those go block by block through dbtk_ingest_align).  slot = ~0u: nothing to append (flush only).
+static dbtk_status_t dbtk_ingest_align_merged_impl(dbtk_ingest_t* g, uint32_t slot, dbtk_ctx_t* cx, uint64_t min_pairs, int flush) {
+    if (!g || (slot != ~0u && slot >= g->nslots)) { set_error("null argument"); return DBTK_ERR_ARG; }
+    dbtk_ctx* c = nullptr;
+    { const dbtk_status_t sc = ingest_ctx(g, cx, &c); if (sc) return sc; }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->P.bubbles || c->P.trace || (c->P.bait && g->with_qual)) { set_error("dbtk_ingest_align_merged: records, -bu and -b with qualities go block by block (dbtk_ingest_align)"); return DBTK_ERR_ARG; }
+    hipStream_t s = c->stream;
+    if (slot != ~0u) {
+        dbtk_ingest::Slot& S = g->slots[slot];
+        if (!S.waited) { set_error("dbtk_ingest_align_merged: wait for the block first"); return DBTK_ERR_ARG; }
+        const IngestHdr& h = S.hdr;
+        if (h.flags & (ING_F_DIRTY | ING_F_LINES_OVF)) { set_error("dbtk_ingest_align_merged: the block is not a run of adjacent mates; continue with a host reader at info.first_byte"); return DBTK_ERR_ARG; }
+        if (h.maxlen > DBTK_MAX_READ_LEN) {
+            set_error("read longer than DBTK_MAX_READ_LEN (256): the reference's PE_KMC is uint8_t, src/aQueryFasta_thread.cpp:42");
+            return DBTK_ERR_READ_TOO_LONG;
+        }
+        if (h.nkept) {
+            const uint64_t nb = h.flat_bytes, nr = 2ull * h.nkept;
+            // room: grown (copying what is there) when a block does not fit — the buffer ends up at min_pairs' worth plus a block
+            if (c->m_bytes + nb + 64 > c->m_flat_cap) {
+                const uint64_t want = std::max<uint64_t>((c->m_bytes + nb + 64) * 3 / 2, 64ull << 20);
+                uint8_t* nf = nullptr;
+                HIPCHK(hipMalloc(&nf, want));
+                if (c->m_bytes) HIPCHK(hipMemcpyAsync(nf, c->m_flat, c->m_bytes, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (c->m_flat) HIPCHK(hipFree(c->m_flat));
+                c->m_flat = nf; c->m_flat_cap = want;
+            }
+            if (2 * c->m_pairs + nr + 1 > c->m_off_cap) {
+                const uint64_t want = std::max<uint64_t>((2 * c->m_pairs + nr + 1) * 3 / 2, 1ull << 20);
+                uint64_t* no = nullptr;
+                HIPCHK(hipMalloc(&no, want * 8));
+                if (c->m_pairs) HIPCHK(hipMemcpyAsync(no, c->m_off, (2 * c->m_pairs + 1) * 8, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (c->m_off) HIPCHK(hipFree(c->m_off));
+                c->m_off = no; c->m_off_cap = want;
+            }
+            HIPCHK(hipMemcpyAsync(c->m_flat + c->m_bytes, S.d_flat, nb, hipMemcpyDeviceToDevice, s));
+            LAUNCH(k_off_rebase, dim3((uint32_t)std::min<uint64_t>((nr + 256) / 256, 1024)), dim3(256), s, c->m_off + 2 * c->m_pairs, S.d_off, nr + 1, c->m_bytes);
+            HIPCHK(hipEventRecord(S.aligned, s));  // (the slot's arrays are free again once they have been copied)
+            S.has_aligned = true;
+            c->m_bytes += nb; c->m_pairs += h.nkept;
+            c->m_maxlen = std::max<uint32_t>(c->m_maxlen, (uint32_t)h.maxlen);
+        }
+    }
+    if (c->m_pairs && (flush || c->m_pairs >= min_pairs)) {
+        const dbtk_status_t st = launch_batch(c, c->m_flat, c->m_off, ~0ull, c->m_pairs, c->m_maxlen, nullptr, 0, nullptr);
+        if (st) return st;
+        c->m_bytes = 0; c->m_pairs = 0; c->m_maxlen = 0;
+        // (the next blocks are merged into the OTHER lane's buffers, on its stream: this lane's kernels are reading these)
+        if (c->two_lanes) switch_lane(c);
+    }
+    return DBTK_OK;
+}
+
 static dbtk_status_t dbtk_ingest_spans_impl(dbtk_ingest_t* g, uint32_t slot, dbtk_ingest_span_t* spans, uint64_t cap) {
     if (!g || slot >= g->nslots || (!spans && cap)) { set_error("null argument"); return DBTK_ERR_ARG; }
     dbtk_ingest::Slot& S = g->slots[slot];
@@ -2529,6 +2603,9 @@ dbtk_status_t dbtk_ingest_wait(dbtk_ingest_t* g, uint32_t slot, dbtk_ingest_info
 }
 dbtk_status_t dbtk_ingest_align(dbtk_ingest_t* g, uint32_t slot, dbtk_ctx_t* cx, int sync, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec) {
     return dbtk::guarded([&] { return dbtk_ingest_align_impl(g, slot, cx, sync, recs, rec_cap, nrec); });
+}
+dbtk_status_t dbtk_ingest_align_merged(dbtk_ingest_t* g, uint32_t slot, dbtk_ctx_t* cx, uint64_t min_pairs, int flush) {
+    return dbtk::guarded([&] { return dbtk_ingest_align_merged_impl(g, slot, cx, min_pairs, flush); });
 }
 dbtk_status_t dbtk_ingest_spans(dbtk_ingest_t* g, uint32_t slot, dbtk_ingest_span_t* spans, uint64_t cap) {
     return dbtk::guarded([&] { return dbtk_ingest_spans_impl(g, slot, spans, cap); });

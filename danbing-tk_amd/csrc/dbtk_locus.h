@@ -926,6 +926,7 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
             uint64_t km[NPL];
             bool pend[NPL];
             uint32_t npend = 0, nres = 0;
+            uint32_t stbits = 0;  // (FUSE) bit j: the lane's j-th position is known at the locus (flank or TR), bit 8 + j: it is a TR k-mer
             bool multi = false;
             if (clean) {
                 x.sync();
@@ -991,6 +992,7 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                     const bool fnd = act && !pend[j];
                     nres += fnd ? 1u : 0u;
                     sm.res[half][p0 + j] = !fnd ? AUX_MISS : (pay[j] & LOC_FLANK) ? CLS_FLANK : trb + (pay[j] & LOC_SLOT);
+                    if (FUSE) stbits |= (fnd ? 1u : 0u) << j | (fnd && (pay[j] & LOC_TR) ? 1u : 0u) << (8 + j);
                 }
             } else {
                 // (rare) a non-ACGT byte somewhere in the pair: exact validity bits; a position with an invalid window is no k-mer,
@@ -1082,23 +1084,26 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                     qn += take; done += take;
                 }
             }
+            DBTK_STAMP(18);  // row statistics + stores, queue
             if (FUSE && spec) {
-                // states of the lane's positions at the locus: known (flank or TR), TR (from the aux words of the look-up, still in LDS)
-                uint32_t ax[NPL];
+                // states of the lane's positions at the locus: known (flank or TR), TR
                 bool kn[NPL], tr[NPL];
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) ax[j] = sm.res[half][p0 + j];
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) {
-                    kn[j] = p0 + j < nk && ax[j] != AUX_MISS; tr[j] = kn[j] && ax[j] != CLS_FLANK;
-                }
+                for (int j = 0; j < NPL; ++j) { kn[j] = (stbits >> j) & 1u; tr[j] = (stbits >> (8 + j)) & 1u; }
                 uint32_t stage = LSP_COUNT;
                 if (qc_off) stage = LSP_QC;
                 else if (a.P.threading) stage = a.P.threading == DBTK_THREADING_V13 ? LSP_THREAD_V13 : LSP_THREAD_HEAD;
                 else if (a.P.extract) stage = LSP_EXTRACT;
                 bool rm = true;
                 uint32_t span = 0;
-                if (stage == LSP_COUNT) assign_halves<NPL>(x, kn, tr, p0, nk, a.P, rm, span);
+                if (stage == LSP_COUNT) {
+                    // a mate without a TR k-mer is removed (no state change, first state flank: AQ.cpp:1531-1534), one all of whose known
+                    // k-mers are TR k-mers is the TR segment from end to end: only a mate with both needs the scan
+                    const uint64_t anytr = x.ballot((stbits >> 8) != 0), anyfl = x.ballot((stbits & 0xFFu & ~(stbits >> 8)) != 0);
+                    const bool t0 = (uint32_t)anytr != 0, t1 = (anytr >> 32) != 0, f0 = (uint32_t)anyfl != 0, f1 = (anyfl >> 32) != 0;
+                    if ((t0 && f0) || (t1 && f1)) assign_halves<NPL>(x, kn, tr, p0, nk, a.P, rm, span);
+                    else { const bool tm = half ? t1 : t0; rm = !tm; span = tm ? nk : 0u; }
+                }
                 const uint32_t rm0 = x.bcast(rm ? 1u : 0u, 0), rm1 = x.bcast(rm ? 1u : 0u, 32);
                 uint32_t ninc = 0;
                 if (!(rm0 && rm1)) {  // (a pair both of whose mates are removed adds nothing: AQ.cpp:2145)
@@ -1106,9 +1111,9 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                     for (int j = 0; j < NPL; ++j) {
                         const bool hit = tr[j] && !rm;
                         if (hit) {
-                            const uint32_t sl = ax[j] - trb;
+                            const uint32_t axj = sm.res[half][p0 + j], sl = axj - trb;  // (the aux words of the look-up are still in LDS)
                             if (sl < LOC_FCNT) x.lds_add(&smb.fcnt[sl >> 1], 1u << (16 * (sl & 1)));
-                            else x.atomic_add(&a.counts[ax[j]], 1ull);
+                            else x.atomic_add(&a.counts[axj], 1ull);
                         }
                         ninc += (uint32_t)__builtin_popcountll(x.ballot(hit));
                     }
@@ -1121,7 +1126,7 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                 }
             }
             nrow += 2;
-            DBTK_STAMP(18);  // row statistics + stores, queue, (FUSE) assignTRkmc + counts
+            DBTK_STAMP(1);  // (FUSE) assignTRkmc + counts
         }
     }
     if (FUSE) {
@@ -1140,6 +1145,8 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
             if (c6) { x.atomic_add(&ctr[DBTK_C_NHASH1], (uint64_t)c6); x.atomic_add(&ctr[DBTK_C_ALGO_PROBES], (uint64_t)c6); }
             if (a.pstats && c7) x.atomic_add(&a.pstats[14], (uint64_t)c7);
             if (a.pstats && sm.ctr[8]) x.atomic_add(&a.pstats[15], (uint64_t)sm.ctr[8]);
+            if (a.pstats && c4) x.atomic_add(&a.pstats[16], (uint64_t)c4);
+            if (a.pstats && c5) x.atomic_add(&a.pstats[17], (uint64_t)c5);
         }
     }
     DBTK_STAMP_FLUSH;

@@ -360,6 +360,13 @@ dbtk_status_t dbtk_ingest_wait(dbtk_ingest_t* ing, uint32_t slot, dbtk_ingest_in
 /* ctx: NULL = the ingest's own context; another context of the same RPGG on the same device lets several threads run the blocks of one
  * ingest through the hot path side by side (each thread its own context; sync = 1: its records, its text arena). */
 dbtk_status_t dbtk_ingest_align(dbtk_ingest_t* ing, uint32_t slot, dbtk_ctx_t* ctx, int sync, dbtk_pair_rec_t* recs, uint64_t rec_cap, uint64_t* nrec);
+/* The same without records, blocks MERGED into larger batches: the block of `slot` is appended (device to device) to the context's merged
+ * batch, which is aligned once it holds min_pairs pairs, or at once with flush != 0 (slot = ~0u: nothing to append, flush only — call it
+ * when the input has ended).  The reference cuts its input into batches of 300 000 reads per thread whatever they hold
+ * (src/aQueryFasta_thread.cpp:1918-1976); how the pairs are cut changes no result (every effect of a pair is an integer add), but the
+ * kernels that keep a locus' k-mers in LDS need batches with many pairs per locus.  Asynchronous like dbtk_ingest_align with sync = 0; the
+ * slot may be submitted again as soon as the call returns.  Not with trace, -bu, or -b on FASTQ (those need a block's own records). */
+dbtk_status_t dbtk_ingest_align_merged(dbtk_ingest_t* ing, uint32_t slot, dbtk_ctx_t* ctx, uint64_t min_pairs, int flush);
 dbtk_status_t dbtk_ingest_spans(dbtk_ingest_t* ing, uint32_t slot, dbtk_ingest_span_t* spans, uint64_t cap);
 /* -a / -ae with the device reader (params.aln | DBTK_ALN_TEXT): writeAlignments' lines (src/aQueryFasta_thread.cpp:1742-1759:
  * `. dst title seq2 seq1 cigar2 annot2 cigar1 annot1`) of the block aligned last with sync = 1, in pair order, assembled on the device
@@ -395,7 +402,7 @@ int  dbtk_ctx_kernel_times(dbtk_ctx_t* ctx, const char** names, double* total_ms
 int  dbtk_ctx_table_bytes(dbtk_ctx_t* ctx, const char** names, uint64_t* bytes, int cap);
 /* Which kernels took how many pairs since the context was created / reset (diagnostic; never part of the results — the hot loop of
  * src/aQueryFasta_thread.cpp:2002-2249 has one path, this library several that must agree).  out[DBTK_PS_*]; returns words filled. */
-#define DBTK_PATH_STATS 16u
+#define DBTK_PATH_STATS 20u
 #define DBTK_PS_PROBE_ITEMS   0u  /* [3] work items (locus, <= 64 pairs) of the locus-resident probe kernel, per class of image size */
 #define DBTK_PS_PROBE_PAIRS   3u  /* [3] pairs in those items */
 #define DBTK_PS_PROBE_REST    6u  /* pairs the lean probe kernel took from the list the locus path left (incl. pairs handed back) */
@@ -404,6 +411,8 @@ int  dbtk_ctx_table_bytes(dbtk_ctx_t* ctx, const char** names, uint64_t* bytes, 
 #define DBTK_PS_WALK_REST    13u  /* pairs its global-table form took */
 #define DBTK_PS_FUSED_DONE   14u  /* pairs the locus-resident probe kernel resolved itself (countHit shortcut + assignTRkmc + accumulate) */
 #define DBTK_PS_FUSED_REDONE 15u  /* ... of the pairs it had resolved ahead of the global look-ups, those it had to take back */
+#define DBTK_PS_FUSED_CLS    16u  /* of DBTK_C_ALGO_CLS / DBTK_C_ALGO_INC, the part that kernel did (its algorithmic bytes: 8 A + 16 I) */
+#define DBTK_PS_FUSED_INC    17u
 int  dbtk_ctx_path_stats(dbtk_ctx_t* ctx, uint64_t* out, int cap);
 void dbtk_ctx_timers_reset(dbtk_ctx_t* ctx);
 void dbtk_ctx_timers_enable(dbtk_ctx_t* ctx, int on);  /* default 1: event records around every kernel of every batch (~30 us per batch);

@@ -516,7 +516,7 @@ class Emu(pkg._HostSide):
 
     def path_stats(self):
         """as Context.path_stats, over the align calls since the last call"""
-        v = (C.c_uint64 * 16)()
+        v = (C.c_uint64 * 20)()
         self.L.emu_path_stats(v)
         v = [int(x) for x in v]
         return {"probe_items": v[0:3], "probe_pairs": v[3:6], "probe_rest": v[6], "walk_items": v[7:10], "walk_pairs": v[10:13],
@@ -634,3 +634,39 @@ class Emu(pkg._HostSide):
         if rc:
             raise RuntimeError(f"emu_align -> {rc}")
         return dict(counts=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs, nrec=int(nrec.value))
+
+
+def locus_image_lg(arrs, k):
+    """lgnb of every locus' index image as dbtk_locus.h sizes it (loc_lgnb_for: the smallest table of 2^lg 4-slot buckets at a load of at
+    most 0.8 over the keys whose index value names the locus), from the flat arrays; and the key counts."""
+    nk, nloci = arrs.nkeys, arrs.nloci
+    vals = np.ctypeslib.as_array(arrs.vals, (nk,))
+    vv = np.ctypeslib.as_array(arrs.vv, (arrs.nvv,))
+    even = (vals & 1) == 0
+    cnt = np.bincount(vals[even] >> 1, minlength=nloci).astype(np.int64)
+    offs = (vals[~even] >> 1).astype(np.int64)
+    ns = vv[offs].astype(np.int64)
+    idx = np.repeat(offs + 1, ns) + (np.arange(int(ns.sum())) - np.repeat(np.cumsum(ns) - ns, ns))
+    cnt += np.bincount(vv[idx], minlength=nloci)[:nloci]
+    lgmin = max(5, 2 * k - 40)
+    lg = np.full(nloci, lgmin)
+    for l in range(lgmin, 16):
+        lg[(16 << l) < 5 * cnt] = l + 1
+    return lg, cnt
+
+
+def dense_loci(arrs, k, per_lg=650, seed=1):
+    """Loci for a DENSE slice (Synth.reads_loci: many pairs per locus, the regime of the locus-resident kernels) covering every class of
+    image the kernels have (up to 512, 1024, 2048 buckets): up to per_lg loci of every image size, every locus of the largest class.
+    Returns (loci, classes present)."""
+    lg, _ = locus_image_lg(arrs, k)
+    rng = np.random.default_rng(seed)
+    cls_of = lambda l: 0 if l <= 9 else 1 if l == 10 else 2 if l == 11 else -1
+    loci = []
+    for l in np.unique(lg):
+        if cls_of(int(l)) < 0:
+            continue
+        pool = np.flatnonzero(lg == l)
+        loci.append(pool if cls_of(int(l)) == 2 and len(pool) <= 400 else rng.choice(pool, min(len(pool), per_lg), replace=False))
+    loci = rng.permutation(np.concatenate(loci))
+    return loci, sorted({cls_of(int(lg[l])) for l in loci})

@@ -308,24 +308,6 @@ def test_device_entry_alternating_lanes(dbtk, oracle, tmp_path, lanes, monkeypat
     g.close()
 
 
-def locus_image_lg(arrs, k):
-    """lgnb of every locus' index image as dbtk_locus.h sizes it (loc_lgnb_for: the smallest table of 2^lg 4-slot buckets at a load of at
-    most 0.8 over the keys whose index value names the locus), from the flat arrays."""
-    nk, nloci = arrs.nkeys, arrs.nloci
-    vals = np.ctypeslib.as_array(arrs.vals, (nk,))
-    vv = np.ctypeslib.as_array(arrs.vv, (arrs.nvv,))
-    even = (vals & 1) == 0
-    cnt = np.bincount(vals[even] >> 1, minlength=nloci).astype(np.int64)
-    offs = (vals[~even] >> 1).astype(np.int64)
-    ns = vv[offs].astype(np.int64)
-    idx = np.repeat(offs + 1, ns) + (np.arange(int(ns.sum())) - np.repeat(np.cumsum(ns) - ns, ns))
-    cnt += np.bincount(vv[idx], minlength=nloci)[:nloci]
-    lgmin = max(5, 2 * k - 40)
-    lg = np.full(nloci, lgmin)
-    for l in range(lgmin, 16):
-        lg[(16 << l) < 5 * cnt] = l + 1
-    return lg, cnt
-
 
 def dense_slice_checks(monkeypatch, dbtk, oracle, syn, arrs, g, orc_g, k):
     """the locus-resident kernels (dbtk_locus.h: k_probe_locus; dbtk_walkfast.h: k_walk_fast_locus) against the ORACLE on
@@ -333,17 +315,7 @@ def dense_slice_checks(monkeypatch, dbtk, oracle, syn, arrs, g, orc_g, k):
     image class (every locus of the largest class) get 64 pairs each, 6 % of the pairs chimeric / foreign.  Device counters assert that
     the locus path took >= 90 % of the pairs (87 % at k = 25) and every class; counts, kmc, nmapread, all counters, the trace records, the walk results and
     the -ae text are the oracle's."""
-    lg, _ = locus_image_lg(arrs, k)
-    rng = np.random.default_rng(11 + k)
-    cls_of = lambda l: 0 if l <= 9 else 1 if l == 10 else 2 if l == 11 else -1
-    loci = []
-    for l in np.unique(lg):
-        if cls_of(int(l)) < 0:
-            continue
-        pool = np.flatnonzero(lg == l)
-        loci.append(pool if cls_of(int(l)) == 2 and len(pool) <= 400 else rng.choice(pool, min(len(pool), 650), replace=False))
-    loci = rng.permutation(np.concatenate(loci))
-    classes = sorted({cls_of(int(lg[l])) for l in loci})
+    loci, classes = bind.dense_loci(arrs, k, per_lg=650, seed=11 + k)
     assert len(loci) >= 600 and 2 in classes and 1 in classes and (k > 22 or 0 in classes), (len(loci), classes)
     n = 64 * len(loci)
     seq, off = syn.reads_loci(n, loci, odd_frac=0.06, seed=100 + k)
@@ -776,6 +748,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"])  # (every rank's own time: a first multi-GPU run is diagnosable from the line)
     assert d["reduce_check"] == dict(ranks=2, steps=2, pairs_per_rank=60000, bit_exact=True)
 
 

@@ -5,6 +5,7 @@ arrives, which then is seqs[2p] and the parked one seqs[2p + 1]; pairs with a re
 CPU: the kernel bodies on the emulated lanes against a plain-Python restatement of that reader.  GPU: the library's
 dbtk_ingest_* against the host-buffer entry point on the same reads (tests/test_gpu_parity.py style), and the command line with
 and without the device reader (tests/test_cli.py)."""
+import os
 import random
 
 import pytest
@@ -269,6 +270,31 @@ def test_device_reader_asynchronous_blocks_and_flags(tmp_path):
     ctx.close()
     for k_ in ("counts", "kmc", "nmapread", "counters"):
         assert (want[k_] == got[k_]).all(), k_
+    # the same blocks MERGED into larger batches on the device (dbtk_ingest_align_merged): batches of >= 150 pairs cut wherever the blocks
+    # end, one batch for everything, and a walking context (v1.3 threading: the merged batch goes through the walk kernels)
+    for min_pairs, lanes in ((150, "2"), (10 ** 9, "1"), (1, "2")):
+        os.environ["DBTK_LANES"] = lanes
+        try:
+            ctx = dbtk.context(g, p)
+        finally:
+            del os.environ["DBTK_LANES"]
+        ing = bind.pkg.Ingest(ctx, False, 0, chunk, nslots=4, with_spans=False)
+        slots = []
+        for j in range(nblocks):
+            slots.append(ing.submit(data[j * chunk:(j + 1) * chunk], j == nblocks - 1))
+            if len(slots) == 3 or j == nblocks - 1:
+                for s in (slots if j == nblocks - 1 else slots[:1]):
+                    info = ing.wait(s)
+                    assert info.flags == 0
+                    ing.align_merged(s, min_pairs)
+                slots = [] if j == nblocks - 1 else slots[1:]
+        ing.align_merged(None, 0, flush=True)
+        ing.align_merged(None, 0, flush=True)  # (nothing left: a no-op)
+        got = ctx.counts()
+        ing.close()
+        ctx.close()
+        for k_ in ("counts", "kmc", "nmapread", "counters"):
+            assert (want[k_] == got[k_]).all(), (k_, min_pairs)
     # a singleton after 100 pairs
     recs = data.split(b">")[1:]
     cut = sum(len(r) + 1 for r in recs[:200])

@@ -21,7 +21,7 @@ done
 args=()
 for mix in all_hit walk k25; do
   i=0
-  for set in "${SETS[@]}"; do
+  for set in "${SETS[@]}" "WRITE_SIZE"; do  # (the probe stage's hit rows are WRITES: the fused kernel's whole point)
     i=$((i+1))
     rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcM_${mix}_${i}_$tag -- $MIX --only-mix $mix > /dev/null 2>&1
   done
