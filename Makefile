@@ -25,7 +25,7 @@ asan-build:
 # which ASan's stack-use-after-return bookkeeping cannot follow: that one check is off, everything else is on.
 asan: asan-build
 	LD_PRELOAD=$(LIBASAN) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \
-	DBTK_NO_REF=1 DBTK_ASAN=1 DBTK_ORACLE_LIB=$(CURDIR)/$(ASAN_DIR)/liboracle.so DBTK_EMU_LIB=$(CURDIR)/$(ASAN_DIR)/libdbtk_emu.so DBTK_CLI=$(CURDIR)/$(ASAN_DIR)/danbing-tk \
+	DBTK_NO_REF=1 DBTK_ASAN=1 DBTK_TIDY_EXIT=1 DBTK_ORACLE_LIB=$(CURDIR)/$(ASAN_DIR)/liboracle.so DBTK_EMU_LIB=$(CURDIR)/$(ASAN_DIR)/libdbtk_emu.so DBTK_CLI=$(CURDIR)/$(ASAN_DIR)/danbing-tk \
 	$(PY) -m pytest tests -x -q -m "not gpu" -k "not distributed" -p no:cacheprovider
 
 clean:

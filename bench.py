@@ -716,7 +716,9 @@ def main():
                     # on), on an all-hit read file so that every pair is walked and printed
                     legs = {}
                     base = [cli, "-k", "21", "-kf", "4", "1", "-cth", "45", "--v13-threading", "-gc", "85", "3", "-fa", "reads_hit.fa", "-qs", "pan", "-o", "cliw"]
-                    for name, extra in (("walk", []), ("walk_ae_gz", ["-ae", "--aln-gz", "cliw.aln.gz"]),
+                    # ("walk_again": a second pass over the same file — the first pass over a file another process has just written into
+                    # tmpfs is bound by the host's first touch of its pages)
+                    for name, extra in (("walk", []), ("walk_again", []), ("walk_ae_gz", ["-ae", "--aln-gz", "cliw.aln.gz"]),
                                         ("walk_ae_gz_host_zlib1", ["-ae", "--aln-gz", "cliwh.aln.gz", "--host-ingest"]),
                                         ("walk_ae_gz_level6", ["-ae", "--aln-gz", "cliw6.aln.gz", "--gz-level", "6"])):
                         t0 = time.perf_counter()

@@ -1547,9 +1547,16 @@ int main(int argc, char* argv[]) {
             }
         }
     }
-    for (auto g : spent_ingests) dbtk_ingest_free(g);
-    for (auto c : ctx) dbtk_ctx_free(c);
-    dbtk_rpgg_free(rpgg);
+    // Every output is written and closed.  Handing 28 - 47 GB of HBM tables, the pinned buffers and the 3 GB of the handle back piece by
+    // piece takes 0.2 - 0.3 s of a run whose batch loop takes as long: the process ends here and the driver reclaims them at once
+    // (DBTK_TIDY_EXIT=1: free everything first — leak checkers, make asan).
+    if (getenv("DBTK_TIDY_EXIT")) {
+        for (auto g : spent_ingests) dbtk_ingest_free(g);
+        for (auto c : ctx) dbtk_ctx_free(c);
+        dbtk_rpgg_free(rpgg);
+    }
     fprintf(stderr, "all done!\n");
+    fflush(stdout); fflush(stderr);
+    if (!getenv("DBTK_TIDY_EXIT")) _exit(0);
     return 0;
 }

@@ -1113,7 +1113,18 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     LAUNCH(k_encode_subfilter, dim3(g1), dim3(K1_NT), s, a);
     if ((st = rec_end(0))) return st;
     }
-    {   // the survivor list in locus order (dbtk_probe2.h: body_surv_*): what every later kernel indexes
+    // The survivor list in locus order (dbtk_probe2.h: body_surv_*): what every later kernel indexes.  A batch with few survivors per locus (a
+    // WGS batch) is not sorted — the four kernels then only find that out and copy the list — so when the batch BEFORE had fewer than half
+    // the survivors from which a list is sorted, they are not launched at all and the encode stage's own list is used (20 us of a 1.2-ms
+    // step).  A hint like the one below: the order of the list is never a matter of results.
+    bool sort_hint = true, locus_hint = true;
+    if (c->h_sortflag) {  // (both hints from ONE reading of the pinned words: the copy of the batch before may land at any time)
+        volatile uint32_t* hh = c->h_sortflag;
+        const uint32_t prev_surv = hh[0], prev_flag = hh[6];
+        sort_hint = prev_flag != 0 || 2 * (uint64_t)prev_surv >= (uint64_t)SORT_MIN_PER_LOCUS * nloci;
+        locus_hint = prev_flag != 0 && (uint64_t)prev_surv >= (uint64_t)LOC_MIN_PAIRS * nloci;
+    }
+    if (sort_hint) {
         SurvSortArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.T = c->T; sa.P = c->P; sa.seq = d_seq; sa.off = d_off; sa.surv = c->d_surv; sa.nsurv = c->d_small + 0;
@@ -1129,18 +1140,16 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         if ((st = rec_end(5))) return st;
         c->d_sorted = sa.sorted;
         a.surv = sa.sorted;
+    } else {
+        HIPCHK(hipMemsetAsync(c->d_small + 6, 0, sizeof(uint32_t), s));  // "not in locus order"
+        c->d_sorted = c->d_surv;
     }
     // Does the locus-resident probe kernel have anything to do?  Only in a batch with many survivors per locus (list in locus order, loci
     // with LOC_MIN_PAIRS pairs and more); a WGS-like batch (one survivor per locus) would pay its empty launches for nothing (40 us on a
     // 1.2-ms step).  Which kind a batch is, is known on the device only — so the survivor count and the sort flag of the batch BEFORE
     // come back through pinned words and decide for this one.  A hint, never a matter of results: the lean kernel looks up whatever
     // the locus path does not take.
-    bool locus_hint = true;
-    if (c->h_sortflag) {
-        volatile uint32_t* hh = c->h_sortflag;
-        locus_hint = hh[6] != 0 && (uint64_t)hh[0] >= (uint64_t)LOC_MIN_PAIRS * nloci;
-        HIPCHK(hipMemcpyAsync(c->h_sortflag, c->d_small, 7 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    }
+    if (c->h_sortflag) HIPCHK(hipMemcpyAsync(c->h_sortflag, c->d_small, 7 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         a.t0 = (uint32_t)(ch * tcap);
         if (tm) { if ((st = timed_slot(c, 1, &e))) return st; HIPCHK(hipEventRecord(c->timed[1].beg[e], s)); }

@@ -10,6 +10,7 @@
 #include <functional>
 #include <memory>
 #include <unordered_set>
+#include <chrono>
 #include <thread>
 #include <unordered_map>
 
@@ -41,7 +42,14 @@ dbtk_status_t read_kdb(const std::string& fn, uint64_t nloci, std::vector<uint64
     if (!f.f) { set_error("cannot open " + fn); return DBTK_ERR_IO; }
     uint64_t nl = 0, nk = 0;
     if (!f.read(&nl, 1)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
-    if (nl != nloci) { set_error(fn + ": locus count differs from tr.kmers"); return DBTK_ERR_FORMAT; }
+    if (nloci != ~0ull && nl != nloci) { set_error(fn + ": locus count differs from tr.kmers"); return DBTK_ERR_FORMAT; }
+    {   // (before anything is sized from the header: the file must hold what it announces)
+        const long at = ftell(f.f);
+        fseek(f.f, 0, SEEK_END);
+        const uint64_t fsz = (uint64_t)ftell(f.f);
+        fseek(f.f, at, SEEK_SET);
+        if (nl > fsz / 8) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+    }
     cnt.resize(nl);
     if (!f.read(cnt.data(), nl) || !f.read(&nk, 1)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
     uint64_t sum = 0;
@@ -55,6 +63,8 @@ dbtk_status_t read_kdb(const std::string& fn, uint64_t nloci, std::vector<uint64
 // PREF.tr.kmers: ">locus" lines and "KMER[\tVALUE]" lines; only the first field
 // is used (countLoci src/kmerIO.hpp:33-45, readKmersWithZeroCount
 // src/aQueryFasta_thread.h:469-480).
+// The text is cut at line ends into one piece per thread (484 MB of decimal k-mers at release scale: a second of one core); a piece's
+// k-mer lines before its first '>' line belong to the last locus of the piece before.
 dbtk_status_t read_tr_kmers(const std::string& fn, std::vector<uint64_t>& cnt, std::vector<uint64_t>& ks) {
     File f(fn, "rb");
     if (!f.f) { set_error("cannot open " + fn); return DBTK_ERR_IO; }
@@ -64,23 +74,59 @@ dbtk_status_t read_tr_kmers(const std::string& fn, std::vector<uint64_t>& cnt, s
     std::vector<char> buf((size_t)sz + 1);
     if (sz && fread(buf.data(), 1, (size_t)sz, f.f) != (size_t)sz) { set_error("short read on " + fn); return DBTK_ERR_IO; }
     buf[(size_t)sz] = '\n';
-    const char* p = buf.data();
-    const char* end = p + sz;
-    while (p < end) {
-        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p) + 1);
-        if (*p == '>') {
-            cnt.push_back(0);
-        } else if (nl > p) {
-            if (cnt.empty()) { set_error(fn + ": k-mer before the first '>' line"); return DBTK_ERR_FORMAT; }
-            uint64_t v = 0;
-            const char* q = p;
-            while (q < nl && (*q == ' ' || *q == '\t')) ++q;
-            if (q == nl || *q < '0' || *q > '9') { set_error(fn + ": not a k-mer line"); return DBTK_ERR_FORMAT; }
-            while (q < nl && *q >= '0' && *q <= '9') v = v * 10 + (uint64_t)(*q++ - '0');
-            ks.push_back(v);
-            cnt.back()++;
+    const char* const base = buf.data();
+    const char* const end = base + sz;
+    const unsigned nth = (size_t)sz < (8u << 20) ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<const char*> cut(nth + 1, end);
+    cut[0] = base;
+    for (unsigned t = 1; t < nth; ++t) {  // the first line start at or after the t-th share of the bytes
+        const char* p = base + (size_t)sz / nth * t;
+        if (p <= cut[t - 1]) { cut[t] = cut[t - 1]; continue; }
+        const char* nl = (const char*)memchr(p - 1, '\n', (size_t)(end - (p - 1)) + 1);
+        cut[t] = nl + 1 < end ? nl + 1 : end;
+    }
+    struct Piece { std::vector<uint64_t> cnt, ks; uint64_t head = 0; int err = 0; };  // head: k-mer lines before the piece's first '>' line
+    std::vector<Piece> pc(nth);
+    auto parse = [&](unsigned t) {
+        Piece& P = pc[t];
+        const char* p = cut[t];
+        const char* const pe = cut[t + 1];
+        bool seen = false;
+        while (p < pe) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p) + 1);
+            if (*p == '>') {
+                P.cnt.push_back(0);
+                seen = true;
+            } else if (nl > p) {
+                uint64_t v = 0;
+                const char* q = p;
+                while (q < nl && (*q == ' ' || *q == '\t')) ++q;
+                if (q == nl || *q < '0' || *q > '9') { P.err = 2; return; }
+                while (q < nl && *q >= '0' && *q <= '9') v = v * 10 + (uint64_t)(*q++ - '0');
+                P.ks.push_back(v);
+                if (seen) P.cnt.back()++; else P.head++;
+            }
+            p = nl + 1;
         }
-        p = nl + 1;
+    };
+    if (nth == 1) parse(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nth; ++t) th.emplace_back(parse, t);
+        for (auto& x : th) x.join();
+    }
+    size_t nl = 0, nk = 0;
+    for (auto& P : pc) { nl += P.cnt.size(); nk += P.ks.size(); }
+    cnt.reserve(cnt.size() + nl);
+    ks.reserve(ks.size() + nk);
+    for (auto& P : pc) {  // (in file order: the first error of the file is the one reported)
+        if (P.head) {
+            if (cnt.empty()) { set_error(fn + ": k-mer before the first '>' line"); return DBTK_ERR_FORMAT; }
+            cnt.back() += P.head;
+        }
+        if (P.err) { set_error(fn + ": not a k-mer line"); return DBTK_ERR_FORMAT; }
+        cnt.insert(cnt.end(), P.cnt.begin(), P.cnt.end());
+        ks.insert(ks.end(), P.ks.begin(), P.ks.end());
     }
     return DBTK_OK;
 }
@@ -163,16 +209,32 @@ namespace dbtk {
 // oracle here, instantiated the same way (identity hash, operator[] inserts).
 dbtk_status_t finish_rpgg(dbtk_rpgg* g) {
     const uint64_t nloci = g->nloci;
+    const auto tclk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tf0 = tclk();
     if (g->ksize < 2 || g->ksize > 31) { set_error("k must be in 2..31"); return DBTK_ERR_ARG; }
     if (g->tr_cnt.size() != nloci || g->fl_cnt.size() != nloci) { set_error("per-locus count arrays have the wrong length"); return DBTK_ERR_FORMAT; }
     if (nloci >= 0x7FFFFFFFull) { set_error("too many loci"); return DBTK_ERR_FORMAT; }
+    const unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     // every locus id reachable from the index must exist (the reference would index hits1[] out of bounds)
-    for (size_t i = 0; i < g->vals.size(); ++i) {
-        const uint32_t v = g->vals[i];
-        if (v & 1) {
-            const uint64_t o = v >> 1;
-            if (o >= g->vv.size() || o + 1 + g->vv[o] > g->vv.size()) { set_error("kmers.dbi: value points outside vv"); return DBTK_ERR_FORMAT; }
-        } else if ((v >> 1) >= nloci) { set_error("kmers.dbi: locus id out of range"); return DBTK_ERR_FORMAT; }
+    {
+        std::vector<int> bad(nth, 0);
+        std::vector<std::thread> tv;
+        const size_t nv = g->vals.size();
+        for (unsigned t = 0; t < nth; ++t)
+            tv.emplace_back([&, t]() {
+                for (size_t i = nv / nth * t, e = t + 1 == nth ? nv : nv / nth * (t + 1); i < e; ++i) {
+                    const uint32_t v = g->vals[i];
+                    if (v & 1) {
+                        const uint64_t o = v >> 1;
+                        if (o >= g->vv.size() || o + 1 + g->vv[o] > g->vv.size()) { bad[t] = 1; return; }
+                    } else if ((v >> 1) >= nloci) { bad[t] = 2; return; }
+                }
+            });
+        for (auto& x : tv) x.join();
+        for (int b : bad) {
+            if (b == 1) { set_error("kmers.dbi: value points outside vv"); return DBTK_ERR_FORMAT; }
+            if (b == 2) { set_error("kmers.dbi: locus id out of range"); return DBTK_ERR_FORMAT; }
+        }
     }
     for (size_t o = 0; o < g->vv.size();) {
         const uint64_t n = g->vv[o];
@@ -191,6 +253,7 @@ dbtk_status_t finish_rpgg(dbtk_rpgg* g) {
         for (uint64_t c : g->gr_cnt) s += c;
         if (g->gr_cnt.size() != nloci || s != g->gr_ks.size() || s != g->gr_ms.size()) { set_error("graph: per-locus counts do not add up"); return DBTK_ERR_FORMAT; }
     }
+    const double tf1 = tclk();
     std::vector<uint64_t> beg(nloci + 1, 0);
     for (uint64_t l = 0; l < nloci; ++l) beg[l + 1] = beg[l] + g->tr_cnt[l];
     const uint64_t ntr = beg[nloci];
@@ -199,7 +262,6 @@ dbtk_status_t finish_rpgg(dbtk_rpgg* g) {
     g->out_beg.assign(nloci + 1, 0);
     std::vector<uint64_t> uniq(nloci, 0);
     // pass 1 (parallel over loci): local order within each locus
-    const unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nth; ++t) {
         th.emplace_back([&, t]() {
@@ -222,14 +284,21 @@ dbtk_status_t finish_rpgg(dbtk_rpgg* g) {
         });
     }
     for (auto& x : th) x.join();
+    const double tf2 = tclk();
     for (uint64_t l = 0; l < nloci; ++l) g->out_beg[l + 1] = g->out_beg[l] + uniq[l];
     g->out_kmer.assign(g->out_beg[nloci], 0);
-    for (uint64_t l = 0; l < nloci; ++l)
-        for (uint64_t i = beg[l]; i < beg[l + 1]; ++i) {
-            g->out_slot[i] += g->out_beg[l];
-            g->out_kmer[g->out_slot[i]] = g->tr_ks[i];
-        }
+    th.clear();
+    for (unsigned t = 0; t < nth; ++t)  // (a locus' slots are its own range of out_kmer)
+        th.emplace_back([&, t]() {
+            for (uint64_t l = nloci / nth * t, e = t + 1 == nth ? nloci : nloci / nth * (t + 1); l < e; ++l)
+                for (uint64_t i = beg[l]; i < beg[l + 1]; ++i) {
+                    g->out_slot[i] += g->out_beg[l];
+                    g->out_kmer[g->out_slot[i]] = g->tr_ks[i];
+                }
+        });
+    for (auto& x : th) x.join();
     if (g->out_beg[nloci] >= 0xFFFFFFF0ull) { set_error("too many TR k-mers for 32-bit slots"); return DBTK_ERR_FORMAT; }
+    if (getenv("DBTK_VERBOSE")) fprintf(stderr, "rpgg finish: checks %.2f s, output order (unordered_map per locus, %u threads) %.2f s, slots %.2f s\n", tf1 - tf0, nth, tf2 - tf1, tclk() - tf2);
     return DBTK_OK;
 }
 
@@ -259,12 +328,30 @@ static dbtk_status_t dbtk_rpgg_load_impl(const char* prefix, const char* tr_kmer
     const bool side_kdb = !legacy && !(flags & DBTK_LOAD_INDEX_ONLY);
     std::thread side([&] {
         st_side = dbtk::guarded([&]() -> dbtk_status_t {  // (no exception may leave the thread: a damaged count field asks for terabytes)
-            dbtk_status_t s1 = read_tr_kmers(tr_kmers_file ? std::string(tr_kmers_file) : pref + ".tr.kmers", g->tr_cnt, g->tr_ks);
-            if (!s1 && side_kdb) {
+            // (PREF.fl.kdb — 0.9 GB at release scale — and PREF.tre.kdb come in on a thread of their own while the text of PREF.tr.kmers
+            // is parsed; their locus counts are checked against its once both are there)
+            dbtk_status_t s2 = DBTK_OK;
+            std::string err2;
+            std::thread kdb([&] {
+                if (!side_kdb) return;
+                s2 = dbtk::guarded([&]() -> dbtk_status_t {
+                    dbtk_status_t r = read_kdb(pref + ".fl.kdb", ~0ull, g->fl_cnt, g->fl_ks);
+                    if (!r) r = read_kdb(pref + ".tre.kdb", ~0ull, g->tre_cnt, g->tre_ks);
+                    return r;
+                });
+                if (s2) err2 = dbtk::g_err;
+            });
+            dbtk_status_t s1 = dbtk::guarded([&]() -> dbtk_status_t { return read_tr_kmers(tr_kmers_file ? std::string(tr_kmers_file) : pref + ".tr.kmers", g->tr_cnt, g->tr_ks); });
+            const std::string err1 = s1 ? dbtk::g_err : std::string();
+            kdb.join();
+            if (s1) { set_error(err1); return s1; }
+            if (s2) { set_error(err2); return s2; }
+            if (side_kdb) {
                 const uint64_t nl = g->tr_cnt.size();
-                if (!(s1 = read_kdb(pref + ".fl.kdb", nl, g->fl_cnt, g->fl_ks))) s1 = read_kdb(pref + ".tre.kdb", nl, g->tre_cnt, g->tre_ks);
+                if (g->fl_cnt.size() != nl) { set_error(pref + ".fl.kdb: locus count differs from tr.kmers"); return DBTK_ERR_FORMAT; }
+                if (g->tre_cnt.size() != nl) { set_error(pref + ".tre.kdb: locus count differs from tr.kmers"); return DBTK_ERR_FORMAT; }
             }
-            return s1;
+            return DBTK_OK;
         });
         if (st_side) err_side = dbtk::g_err;
     });
@@ -327,9 +414,13 @@ static dbtk_status_t dbtk_rpgg_load_impl(const char* prefix, const char* tr_kmer
     }
     return DBTK_OK;
     };
+    const auto tclk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tl0 = tclk();
     st = read_index();
+    const double tl1 = tclk();
     const std::string err_main = st ? dbtk::g_err : std::string();
     side.join();
+    const double tl2 = tclk();
     if (st_side) { set_error(err_side); return st_side; }  // (PREF.tr.kmers is what the reference opens first: its error comes first)
     if (st) { set_error(err_main); return st; }
     g->nloci = g->tr_cnt.size();
@@ -378,6 +469,7 @@ static dbtk_status_t dbtk_rpgg_load_impl(const char* prefix, const char* tr_kmer
         if (st) return st;
     }
     if ((st = dbtk::finish_rpgg(g.get()))) return st;
+    if (getenv("DBTK_VERBOSE")) fprintf(stderr, "rpgg load: index file %.2f s, + TR / flank / edge files (side thread) %.2f s, checks + output order %.2f s\n", tl1 - tl0, tl2 - tl1, tclk() - tl2);
     *out = g.release();
     return DBTK_OK;
 }
