@@ -1205,6 +1205,7 @@ int main(int argc, char* argv[]) {
         uint32_t hslot = 0;
         const bool sync = want_out || P.bubbles;  // (-bu replays every batch's novel edges on the host)
         const bool merged = !sync && !P.trace && !(P.bait && fq) && !getenv("DBTK_NO_MERGE");
+        double align_call_s = 0, align_call_max = 0, flush_s = 0;  // (time inside the align calls themselves: enqueueing, and whatever a batch has to allocate)
         uint64_t merge_pairs = std::max<uint64_t>(1ull << 20, 24 * nloci);  // (LOC_MIN_PAIRS = 16 pairs per locus and half as many again)
         if (const char* e = getenv("DBTK_MERGE_PAIRS")) { const long long v = atoll(e); if (v > 0) merge_pairs = (uint64_t)v; }  // (tests: several merged batches)
         while (jaln < nchunks) {
@@ -1245,8 +1246,10 @@ int main(int argc, char* argv[]) {
             } else {
                 // no records: the parsed blocks (~100 000 pairs each) are merged on the device into batches of merge_pairs pairs — the kernels
                 // that keep a locus' k-mers in LDS want many pairs per locus in a batch (how pairs are cut into batches changes no result)
+                const double ta0 = now();
                 if (merged ? dbtk_ingest_align_merged(ing, slot, nullptr, merge_pairs, 0) : dbtk_ingest_align(ing, slot, nullptr, sync ? 1 : 0, nullptr, 0, nullptr))
                     die_assert(std::string("align: ") + dbtk_last_error());
+                { const double dta = now() - ta0; align_call_s += dta; if (dta > align_call_max) align_call_max = dta; }
                 { std::lock_guard<std::mutex> l(gb_m); gb += now() - t0; }
                 release();
             }
@@ -1260,6 +1263,7 @@ int main(int argc, char* argv[]) {
         if (merged) {  // what is left of the merged batch
             const double t0 = now();
             if (dbtk_ingest_align_merged(ing, ~0u, nullptr, 0, 1)) die_assert(std::string("align: ") + dbtk_last_error());
+            flush_s = now() - t0;
             std::lock_guard<std::mutex> l(gb_m); gb += now() - t0;
         }
         { std::lock_guard<std::mutex> l(m); stop = true; }
@@ -1283,8 +1287,9 @@ int main(int argc, char* argv[]) {
         for (dbtk_ctx_t* wc : wctx) if (dbtk_ctx_synchronize(wc)) die_assert(dbtk_last_error());  // the kernels still in flight
         { std::lock_guard<std::mutex> lk(tot_m); spent_ingests.push_back(ing); }  // (its pinned and device buffers are freed at exit, not inside the batch loop)
         if (!(piped && handed)) close(fd);
-        fprintf(stderr, "device reader: %llu blocks of %zu MB on %d reader threads; setup %.3f s, first block parsed after %.3f s, waiting for parsed blocks %.3f s, drain %.3f s\n",
-                (unsigned long long)jaln, CH >> 20, nio, setup_s, first_s, wait_s, now() - tf0);
+        fprintf(stderr, "device reader: %llu blocks of %zu MB on %d reader threads; setup %.3f s, first block parsed after %.3f s, waiting for parsed blocks %.3f s, drain %.3f s; "
+                        "align calls %.3f s (longest %.3f s), last merged batch %.3f s%s\n",
+                (unsigned long long)jaln, CH >> 20, nio, setup_s, first_s, wait_s, now() - tf0, align_call_s, align_call_max, flush_s, merged ? "" : " (blocks one by one)");
         std::lock_guard<std::mutex> lk(tot_m);
         nReads += nR; read_busy += rb; gpu_busy += gb; write_busy += wb;
         dev_ingest_reads += nR;

@@ -15,6 +15,7 @@
 #include <deque>
 #include <map>
 #include <atomic>
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <random>
@@ -415,6 +416,11 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
     const dbtk_rpgg* g = c->g;
     const uint64_t nloci = g->nloci;
     hipStream_t s = c->stream;
+    // (DBTK_VERBOSE: where the start-up goes)
+    const bool verbose = getenv("DBTK_VERBOSE") != nullptr;
+    auto wallclk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tick_t = wallclk();
+    auto tick = [&](const char* what) { if (!verbose) return; (void)hipStreamSynchronize(s); const double n = wallclk(); fprintf(stderr, "tables: %s %.3f s\n", what, n - tick_t); tick_t = n; };
     // ---- index
     const uint64_t nkeys = g->keys.size();
     // slots = 4 per bucket; DBTK_IDX_SPARSITY (default 2) = minimum slots per key before rounding up to a power of two:
@@ -451,6 +457,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         HIPCHK(hipFree(dk));
         HIPCHK(hipFree(dv));
     }
+    tick("index + presence filter (H2D of keys and values, insert, finalize)");
     // ---- vv (never empty on the device: odd vals index it)
     HIPCHK(hipMalloc(&c->d_vv, (g->vv.size() + 1) * 4));
     if (!g->vv.empty()) HIPCHK(hipMemcpyAsync(c->d_vv, g->vv.data(), g->vv.size() * 4, hipMemcpyHostToDevice, s));
@@ -493,6 +500,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         HIPCHK(hipFree(dslot));
         HIPCHK(hipFree(dbeg));
     }
+    tick("class table (H2D of TR and flank k-mers, insert)");
     // ---- QC mask
     if (!g->qc.empty()) {
         HIPCHK(hipMalloc(&c->d_qc, nloci));
@@ -537,6 +545,7 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
         T.consistent = (st[1] == 0 && st[0] == st[2]) ? 1u : 0u;
         c->consistent = T.consistent;
     }
+    tick("permutation table, counters' first slots, index consistency + classes");
     {   // the probe kernel's minimizer-grouped copy of the index, for the values of k its lean form exists for
         // (DBTK_MZ=0: do without: the general probe kernel then looks every position up in the plain index)
         bool on = true;
@@ -575,7 +584,10 @@ dbtk_status_t build_tables(dbtk_ctx* c) {
             c->mz_turned = nturned;
         }
     }
-    return build_locus_images(c);
+    tick("index by minimizer + overflow table");
+    const dbtk_status_t li = build_locus_images(c);
+    tick("index images");
+    return li;
 }
 
 // ---- the sidecar of the per-locus images (dbtk.h: dbtk_rpgg_set_index_cache): header, directory, arena — the bytes as they lie in HBM
@@ -2419,7 +2431,10 @@ static dbtk_status_t dbtk_ingest_align_merged_impl(dbtk_ingest_t* g, uint32_t sl
             const uint64_t nb = h.flat_bytes, nr = 2ull * h.nkept;
             // room: grown (copying what is there) when a block does not fit — the buffer ends up at min_pairs' worth plus a block
             if (c->m_bytes + nb + 64 > c->m_flat_cap) {
-                const uint64_t want = std::max<uint64_t>((c->m_bytes + nb + 64) * 3 / 2, 64ull << 20);
+                // (the first time: room for a whole merged batch — min_pairs pairs of this block's longest read, and the block that takes it
+                // past that — so that a run does not grow its way there through a dozen allocations)
+                const uint64_t whole = c->m_flat_cap ? 0 : std::min<uint64_t>(min_pairs, 1ull << 22) * 2 * h.maxlen + nb + 64;
+                const uint64_t want = std::max<uint64_t>(std::max<uint64_t>((c->m_bytes + nb + 64) * 3 / 2, 64ull << 20), whole);
                 uint8_t* nf = nullptr;
                 HIPCHK(hipMalloc(&nf, want));
                 if (c->m_bytes) HIPCHK(hipMemcpyAsync(nf, c->m_flat, c->m_bytes, hipMemcpyDeviceToDevice, s));
@@ -2428,7 +2443,7 @@ static dbtk_status_t dbtk_ingest_align_merged_impl(dbtk_ingest_t* g, uint32_t sl
                 c->m_flat = nf; c->m_flat_cap = want;
             }
             if (2 * c->m_pairs + nr + 1 > c->m_off_cap) {
-                const uint64_t want = std::max<uint64_t>((2 * c->m_pairs + nr + 1) * 3 / 2, 1ull << 20);
+                const uint64_t want = std::max<uint64_t>(std::max<uint64_t>((2 * c->m_pairs + nr + 1) * 3 / 2, 1ull << 20), c->m_off_cap ? 0 : 2 * std::min<uint64_t>(min_pairs, 1ull << 22) + nr + 1);
                 uint64_t* no = nullptr;
                 HIPCHK(hipMalloc(&no, want * 8));
                 if (c->m_pairs) HIPCHK(hipMemcpyAsync(no, c->m_off, (2 * c->m_pairs + 1) * 8, hipMemcpyDeviceToDevice, s));

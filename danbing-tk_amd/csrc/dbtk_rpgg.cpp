@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <functional>
@@ -365,9 +366,34 @@ static dbtk_status_t dbtk_rpgg_load_impl(const char* prefix, const char* tr_kmer
         if (!f.f) { set_error("cannot open " + fn); return DBTK_ERR_IO; }
         uint64_t nk = 0, nvv = 0;
         if (!f.read(&nk, 1)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+        fseek(f.f, 0, SEEK_END);
+        const uint64_t fsz = (uint64_t)ftell(f.f);
+        if (nk > fsz / 12 || 8 + 12 * nk + 8 > fsz) { set_error("truncated " + fn); return DBTK_ERR_IO; }  // (before anything is sized from the header)
         g->keys.resize(nk);
         g->vals.resize(nk);
-        if (!f.read(g->keys.data(), nk) || !f.read(g->vals.data(), nk) || !f.read(&nvv, 1)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+        {   // 1.7 GB at release scale: the keys and the values come in as eight pieces side by side (one thread's fread: 0.45 s of the start-up)
+            const int fd = fileno(f.f);
+            const unsigned np = nk < (1u << 20) ? 1u : 8u;
+            std::vector<std::thread> rd;
+            std::vector<int> ok(2 * np, 1);
+            auto piece = [&](char* dst, uint64_t off, uint64_t n, int* good) {
+                while (n) {
+                    const ssize_t r = pread(fd, dst, (size_t)std::min<uint64_t>(n, 1ull << 30), (off_t)off);
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) { *good = 0; return; }
+                    dst += r; off += (uint64_t)r; n -= (uint64_t)r;
+                }
+            };
+            for (unsigned t = 0; t < np; ++t) {
+                const uint64_t a0 = nk / np * t, a1 = t + 1 == np ? nk : nk / np * (t + 1);
+                rd.emplace_back(piece, (char*)(g->keys.data() + a0), 8 + 8 * a0, 8 * (a1 - a0), &ok[2 * t]);
+                rd.emplace_back(piece, (char*)(g->vals.data() + a0), 8 + 8 * nk + 4 * a0, 4 * (a1 - a0), &ok[2 * t + 1]);
+            }
+            for (auto& x : rd) x.join();
+            for (int o : ok) if (!o) { set_error("truncated " + fn); return DBTK_ERR_IO; }
+        }
+        fseek(f.f, (long)(8 + 12 * nk), SEEK_SET);
+        if (!f.read(&nvv, 1) || nvv > fsz / 4) { set_error("truncated " + fn); return DBTK_ERR_IO; }
         g->vv.resize(nvv);
         if (!f.read(g->vv.data(), nvv)) { set_error("truncated " + fn); return DBTK_ERR_IO; }
     } else {

@@ -142,7 +142,7 @@ def case_spliced(tmp):
     locus-resident probe kernel resolves a pair AHEAD of the look-ups in the plain index (dbtk_locus.h: FUSE) and must take these back."""
     loci = synth.make_loci(nloci=10, nhap=3, flank=500, seed=51)
     reads = synth.sim_reads(loci, npairs=800, seed=52, sub=0.003, splice=0.4)
-    return Case(_rpgg(tmp, "spliced", loci, 21), 21, reads, [dict(cthreshold=45, okam=0), dict(cthreshold=30, okam=0, threading=1), dict(cthreshold=60, okam=0)])
+    return Case(_rpgg(tmp, "spliced", loci, 21), 21, reads, [dict(cthreshold=45, okam=0), dict(cthreshold=30, okam=0), dict(cthreshold=60, okam=0)])
 
 
 def case_spill(tmp):
