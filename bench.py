@@ -74,6 +74,7 @@ def parse_args(argv=None):
     ap.add_argument("--k25-reads", type=int, default=10_000_000, help="reads per step of the k = 25 graph-walk mix (BASELINE config 4: pipeline/k25.json, -gc 85 3); 0 = skip it")
     ap.add_argument("--k25-parity-pairs", type=int, default=20000, help="pairs of the k = 25 mix whose oracle result (counts, counters, walk results) is compared")
     ap.add_argument("--ingest-reads", type=int, default=64_000_000, help="reads of the FASTA the command line's batch loop is timed on (end_to_end.cli_ingest); 0 = skip")
+    ap.add_argument("--walk-long-reads", type=int, default=40_000_000, help="reads of the long all-hit FASTA the command line's walk is timed on with and without merged batches (end_to_end.cli_walk_emit.walk_long); 0 = skip")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="the timed step repeated for at least this long (`sustained`); 0 = skip")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (host buffers, CLI)")
     ap.add_argument("--lanes", type=int, default=1, choices=(1, 2, 3),
@@ -737,6 +738,42 @@ def main():
                                     "on the GPU (Huffman-only deflate, dbtk_gz.h); walk_ae_gz_host_zlib1 / _level6: zlib on the host's emit pool (level 1, "
                                     "level 6 = gzip's default), bound by deflate on a 16-CPU container.  With -ae every mate of every pair is aligned (the "
                                     "record holds both alignments); without it a pair is decided by its first cleanly threading mate")
+                    # a LONG all-hit input (4 x the read set above, > 2 GB: the command line then merges its parsed 32-MB blocks on the device
+                    # into batches of ~2 M pairs, which is what lets the locus-resident kernels take them: VERDICT r4 item 5) against the
+                    # same run with the blocks aligned one by one
+                    need = args.walk_long_reads * (rlen + 24)
+                    if args.walk_long_reads > 0 and shutil.disk_usage(ref_dir).free > 3 * need:
+                        longfa = os.path.join(ref_dir, "reads_hit_long.fa")
+                        with open(longfa, "wb") as out:
+                            part = 4_000_000
+                            for p0 in range(0, args.walk_long_reads // 2, part):
+                                n = min(part, args.walk_long_reads // 2 - p0)
+                                sq, _ = syn.reads(n, rlen=rlen, hit_frac=1.0, seed=2, first_pair=p0, nthreads=nth)
+                                syn.write_fasta(sq, n, os.path.join(ref_dir, "part.fa"), rlen=rlen, first_pair=p0)
+                                with open(os.path.join(ref_dir, "part.fa"), "rb") as f:
+                                    shutil.copyfileobj(f, out, 64 << 20)
+                                del sq
+                        os.unlink(os.path.join(ref_dir, "part.fa"))
+                        lbase = [a_ if a_ != "reads_hit.fa" else "reads_hit_long.fa" for a_ in base]
+                        long_legs = {}
+                        for name, env in (("merged", {}), ("blocks_one_by_one", {"DBTK_NO_MERGE": "1"}), ("merged_again", {})):
+                            r = subprocess.run(lbase[:-1] + ["cliwl_" + name], cwd=ref_dir, capture_output=True, text=True, env=dict(os.environ, **env))
+                            ing = [l for l in r.stderr.splitlines() if l.startswith("ingest:")]
+                            rate = float(ing[0].split("(")[1].split()[0]) * 1e6 if ing and r.returncode == 0 else None
+                            long_legs[name] = dict(returncode=r.returncode, value=rate, unit="reads/s", batch_loop=ing[0] if ing else None,
+                                                   detail=([l for l in r.stderr.splitlines() if l.startswith("device reader:")] or [None])[0])
+                        try:
+                            same = all(open(os.path.join(ref_dir, "cliwl_merged" + e), "rb").read() == open(os.path.join(ref_dir, "cliwl_blocks_one_by_one" + e), "rb").read()
+                                       for e in (".trkmc.ar", ".tr.summary.txt"))
+                        except OSError:
+                            same = False
+                        legs["walk_long"] = dict(long_legs, reads=args.walk_long_reads, same_outputs=same,
+                                                 note="--v13-threading -gc 85 3 (no -ae) on an all-hit FASTA of this many reads in /dev/shm: the batch loop with the "
+                                                      "parsed blocks merged on the device into ~2 M-pair batches (the default for inputs of 2 GB and more) and with every "
+                                                      "32-MB block its own batch")
+                        os.unlink(longfa)
+                        log(f"CLI walk on {args.walk_long_reads / 1e6:.0f} M all-hit reads: merged batches {(long_legs['merged']['value'] or 0) / 1e6:.0f} / "
+                            f"{(long_legs['merged_again']['value'] or 0) / 1e6:.0f} M reads/s, blocks one by one {(long_legs['blocks_one_by_one']['value'] or 0) / 1e6:.0f} M reads/s, same outputs: {same}")
                     e2e["cli_walk_emit"] = legs
                     log(f"CLI walk: {legs['walk']['wall_s']:.1f}s; with -ae --aln-gz: {legs['walk_ae_gz']['wall_s']:.1f}s "
                         f"({legs['aln_gz_bytes']} bytes of .aln.gz for {2 * nhit} reads)")

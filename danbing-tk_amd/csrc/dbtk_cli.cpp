@@ -428,7 +428,9 @@ int main(int argc, char* argv[]) {
     // ---- the batch loop (AQ.cpp:1869-2282) as three overlapped stages: parse + pair | align (one thread per GPU) | write
     const uint64_t readsPerBatch = (uint64_t)(300000 * o.readsPerBatchFactor);
     const uint64_t minReadSize = (uint16_t)o.Cthreshold + o.ksize - 1;
-    const bool want_recs = o.okam || o.extractFastX;
+    // (with -g / -gc no pair record is ever produced — at HEAD nothing happens behind the threading gate, AQ.cpp:2070-2090; under the v1.3
+    // contract the walk counts exactly and prints alignments, not kam lines — so no record buffer travels and the blocks take the record-free path)
+    const bool want_recs = !o.threading && (o.okam || o.extractFastX);
     const bool fq = o.isFastq;
     time1 = time(nullptr);
     fprintf(stderr, "threads created\n");
@@ -1204,7 +1206,10 @@ int main(int argc, char* argv[]) {
         bool handed = false;   // the host reader takes over
         uint32_t hslot = 0;
         const bool sync = want_out || P.bubbles;  // (-bu replays every batch's novel edges on the host)
-        const bool merged = !sync && !P.trace && !(P.bait && fq) && !getenv("DBTK_NO_MERGE");
+        // (merging pays when the input is long — a pipe, or a file of at least 2 GB: below that the loop is bound by reading the file, every
+        // block's kernels hide under the next block's bytes, and a merged batch's kernels would only start late.  DBTK_MERGE_PAIRS forces it.)
+        const bool long_input = piped || total >= (2ull << 30) || getenv("DBTK_MERGE_PAIRS");
+        const bool merged = !sync && !P.trace && !(P.bait && fq) && long_input && !getenv("DBTK_NO_MERGE");
         double align_call_s = 0, align_call_max = 0, flush_s = 0;  // (time inside the align calls themselves: enqueueing, and whatever a batch has to allocate)
         uint64_t merge_pairs = std::max<uint64_t>(1ull << 20, 24 * nloci);  // (LOC_MIN_PAIRS = 16 pairs per locus and half as many again)
         if (const char* e = getenv("DBTK_MERGE_PAIRS")) { const long long v = atoll(e); if (v > 0) merge_pairs = (uint64_t)v; }  // (tests: several merged batches)
