@@ -1519,6 +1519,13 @@ int main(int argc, char* argv[]) {
             for (int i = 0; i < DBTK_C_COUNT; ++i) counters[i] += r1[i];
         }
     }
+    {   // which kernels took the pairs (a diagnostic of this implementation, free-form like the rest of stderr)
+        uint64_t ps[DBTK_PATH_STATS] = {0}, one[DBTK_PATH_STATS];
+        for (int d = 0; d < nctx; ++d) { const int n = dbtk_ctx_path_stats(ctx[d], one, (int)DBTK_PATH_STATS); for (int i = 0; i < n; ++i) ps[i] += one[i]; }
+        fprintf(stderr, "kernel paths: locus-resident probe %llu pairs in %llu items (%llu resolved there, %llu taken back), lean probe %llu pairs; locus-resident walk %llu pairs in %llu items, global walk %llu pairs\n",
+                (unsigned long long)(ps[3] + ps[4] + ps[5]), (unsigned long long)(ps[0] + ps[1] + ps[2]), (unsigned long long)ps[14], (unsigned long long)ps[15], (unsigned long long)ps[6],
+                (unsigned long long)(ps[10] + ps[11] + ps[12]), (unsigned long long)(ps[7] + ps[8] + ps[9]), (unsigned long long)ps[13]);
+    }
     fprintf(stderr,
             "%llu reads processed in total.\n%llu reads removed by subsampled kmer-filter.\n%llu reads removed by kmer-filter.\n"
             "%llu reads removed by bait locus.\n%llu reads removed by qual filter.\n%llu reads removed during locus assignment.\n"

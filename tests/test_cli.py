@@ -336,11 +336,15 @@ def test_cli_aln_gz_is_the_stdout_stream(tmp_path):
         assert (on_device == len(want)) == (extra in ([], ["--emit-threads", "3", "--gz-level", "1"])), em
     # without records (the counting run of config 4) the command line MERGES its parsed blocks into larger batches on the device: whatever
     # the cut (every block its own batch, batches of >= 90 pairs, one batch, blocks aligned one by one as before), the counts are the golden ones
-    for tag, env in (("m1", dict(DBTK_MERGE_PAIRS="1")), ("m90", dict(DBTK_MERGE_PAIRS="90")), ("mall", {}), ("mno", dict(DBTK_NO_MERGE="1"))):
+    for tag, env in (("m1", dict(DBTK_MERGE_PAIRS="1")), ("m_all", dict(DBTK_MERGE_PAIRS="1000000")), ("mfile", {}), ("mno", dict(DBTK_NO_MERGE="1"))):
         r = subprocess.run([CLI, "--v13-threading", "-gc", "85", "3", "-ka", "-k", "25", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-o", tag], cwd=w,
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, DBTK_INGEST_CHUNK="20000", DBTK_INGEST_SLOTS="3", **env))
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, DBTK_INGEST_CHUNK="8000", DBTK_INGEST_SLOTS="3", **env))
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert open(os.path.join(w, tag + ".trkmc.ar"), "rb").read() == open(os.path.join(d, "refae.trkmc.ar"), "rb").read(), tag
+        paths = [l for l in r.stderr.decode().splitlines() if l.startswith("kernel paths:")][0].split()
+        on_locus_path = int(paths[4]) + int(paths[paths.index("walk") + 1])
+        # one merged batch (65 pairs per locus): enough for the kernels that keep a locus in LDS; the 8 000-byte blocks (6 pairs per locus) one by one: never
+        assert (on_locus_path > 0) == (tag == "m_all"), (tag, " ".join(paths))
     # the README's own command line for the v1.3 contract (README.md:38-39: no flag of ours), switched by the environment
     r = subprocess.run([CLI, "-gc", "85", "3", "-ae", "-ka", "-k", "25", "-cth", "45", "-fa", "reads.fa", "-qs", "pan", "-o", "envsw"], cwd=w,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, DBTK_V13_THREADING="1"))
