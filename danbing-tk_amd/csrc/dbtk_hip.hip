@@ -166,6 +166,14 @@ template <int NPL, int NW, int IMGB> __global__ void __launch_bounds__(NW * 64) 
     DevX x{&sm};
     body_walk_fast_locus<NPL, NW, IMGB>(x, a, r);
 }
+// the error-correcting walk for the pairs the lean kernel's locus-resident form could not decide: same items, the graph image in LDS again
+// (dbtk_walkfast.h: body_walk_pairs_locus); two waves per workgroup, each with its two WalkSmem
+constexpr int WPL_NW = 2;
+template <int IMGB> __global__ void __launch_bounds__(WPL_NW * 64) k_walk_pairs_locus(WalkArgs a, LocRunArgs r) {
+    __shared__ WalkPairsLocSmemT<WPL_NW, IMGB> sm;
+    DevX x{&sm};
+    body_walk_pairs_locus<WPL_NW, IMGB>(x, a, r);
+}
 __global__ void __launch_bounds__(64, DBTK_WALK_WAVES) k_walk_pairs(WalkArgs a) {
     __shared__ __attribute__((aligned(16))) WalkSmem sm[2];  // one set of arrays per mate
     DevX x{sm};
@@ -1075,6 +1083,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         if (const char* e = getenv("DBTK_WALK_INFO_ROWS")) info_rows = std::min<uint64_t>(slow_cap, (uint64_t)std::max<long>(atol(e), 0));  // diagnostic / tests: 0 = none, a few = both ways in one batch
         if ((st = ensure(&c->d_walk, &c->walk_cap, 2 * npairs + slow_cap + info_rows * 2 * 160))) return st;
         HIPCHK(hipMemsetAsync(c->d_walk, 0xFF, npairs * sizeof(uint32_t), s));  // NAN32: the pair does not reach threading
+        HIPCHK(hipMemsetAsync(c->d_walk + npairs, 0, npairs * sizeof(uint32_t), s));  // walk_ret: no pair is marked WALK_PENDING
     }
     HIPCHK(hipMemsetAsync(c->d_small, 0, 3 * sizeof(uint32_t), s));  // nsurv, novf, nrec; the error word (3) stays until it has been reported
     HIPCHK(hipMemsetAsync(c->d_tickets, 0, 2 * (nchunks + 1) * sizeof(uint32_t), s));
@@ -1350,6 +1359,11 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
                 LAUNCH(k_loc_split, dim3(3), dim3(1024), s, sp);
                 LocRunArgs r0{w.T.gldir, w.T.glimg, ia.items[0], c->d_small + 8, nullptr, nullptr, sp.starts[0]}, r1{w.T.gldir, w.T.glimg, ia.items[1], c->d_small + 9, nullptr, nullptr, sp.starts[1]},
                     r2{w.T.gldir, w.T.glimg, ia.items[2], c->d_small + 10, nullptr, nullptr, sp.starts[2]};
+                // (the pairs these cannot decide stay with their locus: marked in walk_ret, walked by k_walk_pairs_locus over the same items.
+                // DBTK_WALK_LOCUS_EC=0: they go on the list of the global-table kernel instead, as in round 4)
+                static const bool locus_ec = [] { const char* e = getenv("DBTK_WALK_LOCUS_EC"); return !e || atoi(e) != 0; }();
+                w.pend_locus = locus_ec ? 1u : 0u;
+                const int wq = wnpl == 3 ? 0 : 3;
                 if (wnpl == 3) {
                     LAUNCH((k_walk_fast_locus<3, LOC_NW_XS, LOC_IMGB_XS>), dim3(c->wfl_blocks[0]), dim3(LOC_NW_XS * 64), s, w, r0);
                     LAUNCH((k_walk_fast_locus<3, LOC_NW_S, LOC_IMGB_S>), dim3(c->wfl_blocks[1]), dim3(LOC_NW_S * 64), s, w, r1);
@@ -1359,6 +1373,12 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
                     LAUNCH((k_walk_fast_locus<5, LOC_NW_S, LOC_IMGB_S>), dim3(c->wfl_blocks[4]), dim3(LOC_NW_S * 64), s, w, r1);
                     LAUNCH((k_walk_fast_locus<5, LOC_NW_L, LOC_IMGB_L>), dim3(c->wfl_blocks[5]), dim3(LOC_NW_L * 64), s, w, r2);
                 }
+                if (locus_ec) {  // (the same grids: the workgroups' ranges of the item lists are the ones k_loc_split made for those launches)
+                    LAUNCH((k_walk_pairs_locus<LOC_IMGB_XS>), dim3(c->wfl_blocks[wq + 0]), dim3(WPL_NW * 64), s, w, r0);
+                    LAUNCH((k_walk_pairs_locus<LOC_IMGB_S>), dim3(c->wfl_blocks[wq + 1]), dim3(WPL_NW * 64), s, w, r1);
+                    LAUNCH((k_walk_pairs_locus<LOC_IMGB_L>), dim3(c->wfl_blocks[wq + 2]), dim3(WPL_NW * 64), s, w, r2);
+                }
+                w.pend_locus = 0;
                 w.sel = ia.rest; w.nsel = c->d_small + 11;
             }
             const dim3 gf(walk_txt ? c->walkfast_blocks : 4 * c->walkfast_blocks);

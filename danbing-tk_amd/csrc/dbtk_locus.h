@@ -60,12 +60,8 @@ DBTK_HD uint32_t loc_lgnb_for(uint64_t nkeys, uint32_t k) {
     return lg;
 }
 DBTK_HD uint32_t loc_image_bytes(uint32_t lgnb) { return LOC_HDR + (32u << lgnb) + (1u << lgnb > 16u ? 1u << lgnb : 16u); }
-// bucket before the displacement: the low bits of hi, mixed with everything else of the key (its low word AND the bits of hi above the
-// bucket number, which the entry stores: k-mers that differ in their first bases only must not all want one bucket)
-DBTK_HD uint32_t loc_base(uint32_t lo, uint32_t hi, uint32_t lgnb) { return hi ^ (((lo ^ ((hi >> lgnb) * 0x85EBCA6Bu)) * 0x9E3779B1u) >> 15); }
-// a key's group: as many groups as buckets; a function of the low word and of the bits of hi the entry stores (not of the bits the bucket
-// number implies): the k-mers of a tandem repeat that share their last 16 bases and differ in their first few must not all be one group
-DBTK_HD uint32_t loc_group(uint32_t lo, uint32_t hi, uint32_t lgnb) { const uint32_t v = lo ^ ((hi >> lgnb) * 0x9E3779B1u); return ((v ^ (v >> 15)) * 0x85EBCA6Bu) >> (32 - lgnb); }
+// (loc_base / loc_group — the image's bucket and group hashes — live in dbtk_tables.h: the graph look-up of the walk kernels uses them too)
+static_assert(LOC_EMPTY == GIMG_EMPTY, "one free-slot marker for both kinds of image");
 
 // ------------------------------------------------------------------ build --
 struct LocBuildArgs {

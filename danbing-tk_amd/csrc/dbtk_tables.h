@@ -146,7 +146,33 @@ struct DevTables {
     const MzSlot* ovf; uint64_t ovf_mask;               // level 2 (ovf_mask = slots - 1 <= 2^32 - 1)
     const LocusDir* ldir; const uint8_t* limg;          // per-locus images of the index (dbtk_locus.h), nullptr: none
     const LocusDir* gldir; const uint8_t* glimg;        // ... and of the graph table (the lean walk kernel), nullptr: none
+    // the graph image of ONE locus, resident in LDS (the buckets, behind the image's header): set by a kernel that works locus by locus
+    // (dbtk_walk.h: body_walk_pairs_locus) in its own copy of this struct; gr_lookup then answers from it.  nullptr: the global table
+    const uint32_t* gimg; uint32_t gimg_lgnb;
 };
+
+// ---- the per-locus images' hashes (dbtk_locus.h: an image is 2^lgnb buckets of 4 tags + 4 pay words, then a displacement byte per group)
+// bucket before the displacement: the low bits of hi, mixed with everything else of the key (its low word AND the bits of hi above the
+// bucket number, which the entry stores: k-mers that differ in their first bases only must not all want one bucket)
+DBTK_HD uint32_t loc_base(uint32_t lo, uint32_t hi, uint32_t lgnb) { return hi ^ (((lo ^ ((hi >> lgnb) * 0x85EBCA6Bu)) * 0x9E3779B1u) >> 15); }
+// a key's group: as many groups as buckets; a function of the low word and of the bits of hi the entry stores (not of the bits the bucket
+// number implies): the k-mers of a tandem repeat that share their last 16 bases and differ in their first few must not all be one group
+DBTK_HD uint32_t loc_group(uint32_t lo, uint32_t hi, uint32_t lgnb) { const uint32_t v = lo ^ ((hi >> lgnb) * 0x9E3779B1u); return ((v ^ (v >> 15)) * 0x85EBCA6Bu) >> (32 - lgnb); }
+constexpr uint32_t GIMG_EMPTY = 0xFFFFFFFEu;  // pay of a free slot
+// (canonical k-mer) -> info word of a GRAPH image (pay = extra << 24 | counter << 11 | the 11 flag bits); 0 when absent
+DBTK_HD uint32_t gimg_find(const uint32_t* bks, uint32_t lgnb, uint64_t canon) {
+    const uint32_t lo = (uint32_t)canon, hi = (uint32_t)(canon >> 32);
+    const uint8_t* disp = reinterpret_cast<const uint8_t*>(bks + (8u << lgnb));
+    const uint32_t* bk = bks + 8 * ((loc_base(lo, hi, lgnb) + disp[loc_group(lo, hi, lgnb)]) & ((1u << lgnb) - 1));
+    const uint32_t extra = hi >> lgnb;
+    uint32_t r = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t p = bk[4 + s];
+        if (bk[s] == lo && (p >> 24) == extra && p != GIMG_EMPTY) r = p & 0x00FFFFFFu;
+    }
+    return r;
+}
 
 DBTK_HD uint64_t hash_mix(uint64_t key) {
     key ^= key >> 29;
@@ -243,6 +269,7 @@ DBTK_HD uint32_t kl_lookup(const ClsSlot* tab, uint64_t mask, uint32_t shift, ui
 
 // (canonical k-mer, locus) -> info of the graph table; 0 when absent (a stored info is never 0)
 DBTK_HD uint32_t gr_lookup(const DevTables& T, uint64_t canon, uint32_t locus) {
+    if (T.gimg) return gimg_find(T.gimg, T.gimg_lgnb, canon);  // (the locus' own image, in LDS: the caller works on this locus only)
     uint64_t i = hash_cls(canon, locus, T.gr_shift);
     for (;;) {
         const GrSlot s = T.gr[i];

@@ -137,8 +137,10 @@ struct WalkArgs {
     const uint32_t* sel;
     const uint32_t* nsel;
     uint64_t* pstats;          // nullptr, or the context's path statistics (dbtk.h: dbtk_ctx_path_stats)
+    uint32_t pend_locus;       // the lean kernel's locus-resident form leaves the pairs it cannot decide to body_walk_pairs_locus (marked in walk_ret) instead of the list
 };
 constexpr uint32_t WALK_HAS_INFO = 0x80000000u, WALK_NO_ENTRY = 0xFFFFFFFFu;
+constexpr uint32_t WALK_PENDING = 0x80000000u;  // walk_ret of a pair the locus-resident lean kernel left to body_walk_pairs_locus (walk_ret is zeroed per batch)
 constexpr int8_t WALK_NOT_EVALUATED = -2;  // walk_ret of a mate whose walk nothing needed: its pair was kept by the other mate (dbtk.h)
 #ifdef DBTK_STAMPS
 #define W_STAMP_DECL uint64_t wst[8] = {0}; uint64_t wlast = x.clock();
@@ -987,7 +989,7 @@ DBTK_HD void walk_probe_issue(X& x, WalkSmem& sm, const DevTables& T, uint32_t l
             P.cn[r] = fw <= rc ? fw : rc;
             idx = hash_cls(P.cn[r], locus, T.gr_shift);
         }
-        P.first[r] = T.gr[idx];  // (a position without a k-mer reads slot 0 and ignores it)
+        if (!T.gimg) P.first[r] = T.gr[idx];  // (a position without a k-mer reads slot 0 and ignores it; with the locus' image in LDS: nothing to issue)
     }
 }
 template <class X>
@@ -999,7 +1001,8 @@ DBTK_HD void walk_probe_finish(X& x, WalkSmem& sm, const DevTables& T, uint32_t 
     for (int r = 0; r < W_R; ++r) {
         const int i = 64 * r + lane;
         uint32_t info = 0;
-        if (P.cn[r] != NAN64) {
+        if (P.cn[r] != NAN64 && T.gimg) info = gimg_find(T.gimg, T.gimg_lgnb, P.cn[r]);
+        else if (P.cn[r] != NAN64) {
             GrSlot sl = P.first[r];
             uint64_t j = hash_cls(P.cn[r], locus, T.gr_shift);
             for (;;) {
@@ -1288,6 +1291,136 @@ DBTK_HD_NOINLINE void walk_format_text(X& x, WalkSmem& sm, const WalkState& S, u
 // walked through graphDB[destLocus]; if either walk is feasible the pair is kept (nFeasibleReads += 2) and every
 // uncorrected k-mer of both mates that is a TR k-mer of the locus is counted ("exact" mode: the canonical multiset of
 // the reads' k-mers added to trKmers, i.e. one increment per position); else destLocus = nloci.
+// One pair of the pair-mode walk: both mates staged, their graph look-ups (or the fast kernel's row of them), isThreadFeasible x 2 with the
+// call site's short cut, records, exact counting, results.  Shared by body_walk_pairs (graph nodes from the global table, T = a.T) and
+// body_walk_pairs_locus (T = a copy of a.T that names the locus' graph image in LDS).
+struct WalkPairAcc {
+    uint64_t c_feas = 0, c_inc = 0;
+    uint32_t slot_base = 0, slot_used = ALN_CHUNK;  // alignment records: slots are taken ALN_CHUNK at a time (one atomic per chunk)
+    uint32_t txt_base = 0, txt_left = 0;             // text records: arena bytes are taken TXT_CHUNK at a time
+#ifdef DBTK_STAMPS
+    uint64_t wst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wlast = 0;
+#endif
+};
+template <class X>
+DBTK_HD void walk_pair(X& x, WalkSmem* smm, const WalkArgs& a, const DevTables& T, uint32_t t, uint32_t dst, uint32_t pair, uint32_t inf,
+                       const uint64_t (&oA)[3], const uint32_t (&wA)[2][2], WalkPairAcc& A) {
+    const int lane = x.lane();
+#ifdef DBTK_STAMPS
+    uint64_t (&wst)[8] = A.wst;
+    uint64_t& wlast = A.wlast;
+#endif
+        int ret[2] = {0, 0};
+        uint8_t* arec = nullptr;
+        if (a.aln) {
+            if (A.slot_used == ALN_CHUNK) {
+                uint32_t b = 0;
+                if (lane == 0) b = x.atomic_add(a.naln, ALN_CHUNK);
+                A.slot_base = x.bcast(b, 0);
+                A.slot_used = 0;
+            }
+            const uint32_t slot = A.slot_base + A.slot_used++;
+            if (slot < a.aln_max) arec = a.aln + (size_t)slot * a.aln_stride;
+            else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
+        }
+        uint32_t len[2];
+        len[0] = (uint32_t)(oA[1] - oA[0]); len[1] = (uint32_t)(oA[2] - oA[1]);
+        for (int m = 0; m < 2; ++m) if (len[m] > (uint32_t)MAXL) { if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_READ_TOO_LONG; len[m] = MAXL; }
+        // both mates: bytes -> LDS -> k-mers, and the graph look-ups of both in flight together
+        W_STAMP(0);  // prefetch issue + record slot
+        walk_stage(x, smm[0], wA[0], oA[0], len[0]);
+        walk_stage(x, smm[1], wA[1], oA[1], len[1]);
+        W_STAMP(1);  // bytes (arrive) -> LDS, pack, cg.init
+        if (inf != NAN32) {  // (uniform) the fast kernel looked every position up already: its row instead of the graph table
+            WalkInfoRow R0, R1;
+            const uint32_t* row = a.slow_info + (size_t)inf * 2 * a.info_stride;
+            walk_info_issue(x, smm[0], T, len[0], row, a.info_stride, R0);
+            walk_info_issue(x, smm[1], T, len[1], row + a.info_stride, a.info_stride, R1);
+            W_STAMP(2);
+            walk_info_finish(x, smm[0], T, dst, len[0], a.info_stride, R0, smm[0].slot[0]);
+            walk_info_finish(x, smm[1], T, dst, len[1], a.info_stride, R1, smm[0].slot[1]);
+        } else {
+            WalkProbe P0, P1;
+            walk_probe_issue(x, smm[0], T, dst, len[0], P0, nullptr);
+            walk_probe_issue(x, smm[1], T, dst, len[1], P1, nullptr);
+            W_STAMP(2);  // k-mers + first-slot loads issued
+            walk_probe_finish(x, smm[0], T, dst, len[0], P0, smm[0].slot[0]);
+            walk_probe_finish(x, smm[1], T, dst, len[1], P1, smm[0].slot[1]);
+        }
+        W_STAMP(3);  // look-ups resolved -> LDS
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            // The call site keeps a pair when EITHER mate is feasible and then counts the uncorrected k-mers of both (AQ.cpp:2082-2087,
+            // 2189-2194): once mate 0 has threaded, nothing but a record (thread records, -a / -ae) needs mate 1's walk — the most
+            // expensive thing this kernel does, and every pair on its list has two mates that did not thread cleanly.
+            if (m == 1 && ret[0] && !a.trecs && !arec && !a.txt) { ret[1] = WALK_NOT_EVALUATED; W_STAMP(5); continue; }
+            WalkState S;
+            if (a.P.diag & 1) { ret[m] = 1; S.flags = 0; S.nes = S.ntr = S.nkm = 0; S.ni = 0; S.ki = 0; S.nskip = S.ncorr = 0; }  // diagnostic: no walk
+            else ret[m] = walk_read(x, smm[m], T, a.P, dst, (int)len[m], S);
+            if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) { ret[m] = 0; if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_FORMAT; }
+            if (a.trecs) walk_store(x, smm[m], S, ret[m], &a.trecs[2 * (size_t)t + m]);
+            if (arec) walk_store_aln(x, smm[m], S, ret[m], arec, a.aln_cap, m);
+            if (a.txt) walk_format_text(x, smm[m], S, a.aln_cap);
+            W_STAMP(4 + m);  // the walk of mate m
+        }
+        const bool alned = ret[0] || ret[1];
+        if (arec && lane == 0) {  // -a: every walked pair; -ae: only the kept ones (AQ.cpp:2234)
+            dbtk_aln_hdr_t* h = reinterpret_cast<dbtk_aln_hdr_t*>(arec);
+            h->pair = (a.P.aln == 2 && !alned) ? NAN32 : pair;
+            h->dst = alned ? dst : T.nloci;
+            h->pad[0] = h->pad[1] = 0;
+        }
+        if (a.txt && (a.P.aln & 3) != 0 && ((a.P.aln & 3) == 1 || alned)) {  // -a: every walked pair; -ae: only the kept ones
+            // "cigar2 \t annot2 \t cigar1 \t annot1" (writeAlignments' order, AQ.cpp:1751-1757) behind an 8-byte header
+            const uint32_t lc1 = smm[0].txl[0], la1 = smm[0].txl[1], lc2 = smm[1].txl[0], la2 = smm[1].txl[1];
+            const uint32_t len = lc2 + 1 + la2 + 1 + lc1 + 1 + la1, need = (8 + len + 3) & ~3u;
+            if (need > A.txt_left) {  // (what is left of the old chunk stays unused)
+                uint32_t b = 0;
+                if (lane == 0) b = txt_carve(x, a);
+                A.txt_base = x.bcast(b, 0);
+                A.txt_left = TXT_CHUNK;
+            }
+            if ((uint64_t)A.txt_base + need <= a.txt_cap) {
+                uint8_t* r = a.txt + A.txt_base;
+                if (lane == 0) {
+                    reinterpret_cast<uint32_t*>(r)[0] = alned ? dst : T.nloci;
+                    reinterpret_cast<uint32_t*>(r)[1] = len;
+                    a.txt_idx[pair] = A.txt_base;
+                }
+                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                    uint8_t c;
+                    if (i < lc2) c = smm[1].txc[i];
+                    else if (i == lc2) c = '\t';
+                    else if (i < lc2 + 1 + la2) c = smm[1].txa[i - lc2 - 1];
+                    else if (i == lc2 + 1 + la2) c = '\t';
+                    else if (i < lc2 + la2 + 2 + lc1) c = smm[0].txc[i - lc2 - la2 - 2];
+                    else if (i == lc2 + la2 + 2 + lc1) c = '\t';
+                    else c = smm[0].txa[i - lc2 - la2 - lc1 - 3];
+                    r[8 + i] = c;
+                }
+            } else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
+            A.txt_base += need; A.txt_left -= need;
+        }
+        x.sync();
+        if (alned) {
+            A.c_feas += 2;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                for (int i = lane; i < NKMAX; i += 64) {
+                    const uint32_t s = smm[0].slot[m][i];
+                    const bool hit = s != NAN32;
+                    if (hit && !(a.P.diag & 2)) x.atomic_add(&a.counts[s], 1ull);  // (diagnostic 2: no count atomics)
+                    A.c_inc += (uint64_t)__builtin_popcountll(x.ballot(hit));
+                }
+        }
+        if (lane == 0) {
+            a.walk_dst[t] = alned ? dst : T.nloci;
+            a.walk_ret[t] = ((uint32_t)ret[0] & 0xFFu) | (((uint32_t)ret[1] & 0xFFu) << 8);
+        }
+        x.sync();
+        W_STAMP(6);  // counting + results
+}
+
 template <class X>
 DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
     WalkSmem* const smm = x.template smem<WalkSmem>();  // one set of arrays per mate
@@ -1299,9 +1432,7 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
     const uint32_t nsurv = a.slow_list ? *a.nslow : *a.nsurv;  // items: the fast kernel's leftovers, or every survivor
     if (nsurv == 0) return;  // (the clamped prefetches below read entry 0 of the survivor list)
     const uint32_t S_ = x.nblocks();
-    uint64_t c_feas = 0, c_inc = 0;
-    uint32_t slot_base = 0, slot_used = ALN_CHUNK;  // alignment records: slots are taken ALN_CHUNK at a time (one atomic per chunk)
-    uint32_t txt_base = 0, txt_left = 0;             // text records: arena bytes are taken TXT_CHUNK at a time
+    WalkPairAcc A;
     // A pair's data hangs on a chain of dependent loads: survivor -> (destLocus, pair index) -> the reads' offsets -> their bytes
     // -> their k-mers' graph look-ups.  What bounds this kernel is round trips per wave, so the chain is software-pipelined
     // over the wave's items (t, t + S, ...): while item i is walked, the bytes of item i + 1, the offsets of item i + 2 and
@@ -1336,7 +1467,11 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
     offs(pairA, oA); offs(pairB, oB);
     for (int q = 0; q < 3; ++q) { oA[q] = uni64(oA[q]); oB[q] = uni64(oB[q]); }
     raws(oA, wA);
-    W_STAMP_DECL
+#ifdef DBTK_STAMPS
+    uint64_t (&wst)[8] = A.wst;
+    uint64_t& wlast = A.wlast;
+    wlast = x.clock();
+#endif
     for (; tA < nsurv; tA += S_) {
         W_STAMP(7);  // loop tail / pipeline rotation
         // the next items' loads, before anything of this item is waited for
@@ -1345,117 +1480,7 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
         offs(pairC, oC);
         meta(tA + 3 * S_, &dstD, &pairD, &ttD, &infD);
         const uint32_t t = ttA, dst = dstA, pair = pairA, inf = infA;
-        if (dst != NAN32) {
-            int ret[2] = {0, 0};
-            uint8_t* arec = nullptr;
-            if (a.aln) {
-                if (slot_used == ALN_CHUNK) {
-                    uint32_t b = 0;
-                    if (lane == 0) b = x.atomic_add(a.naln, ALN_CHUNK);
-                    slot_base = x.bcast(b, 0);
-                    slot_used = 0;
-                }
-                const uint32_t slot = slot_base + slot_used++;
-                if (slot < a.aln_max) arec = a.aln + (size_t)slot * a.aln_stride;
-                else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
-            }
-            uint32_t len[2];
-            len[0] = (uint32_t)(oA[1] - oA[0]); len[1] = (uint32_t)(oA[2] - oA[1]);
-            for (int m = 0; m < 2; ++m) if (len[m] > (uint32_t)MAXL) { if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_READ_TOO_LONG; len[m] = MAXL; }
-            // both mates: bytes -> LDS -> k-mers, and the graph look-ups of both in flight together
-            W_STAMP(0);  // prefetch issue + record slot
-            walk_stage(x, smm[0], wA[0], oA[0], len[0]);
-            walk_stage(x, smm[1], wA[1], oA[1], len[1]);
-            W_STAMP(1);  // bytes (arrive) -> LDS, pack, cg.init
-            if (inf != NAN32) {  // (uniform) the fast kernel looked every position up already: its row instead of the graph table
-                WalkInfoRow R0, R1;
-                const uint32_t* row = a.slow_info + (size_t)inf * 2 * a.info_stride;
-                walk_info_issue(x, smm[0], a.T, len[0], row, a.info_stride, R0);
-                walk_info_issue(x, smm[1], a.T, len[1], row + a.info_stride, a.info_stride, R1);
-                W_STAMP(2);
-                walk_info_finish(x, smm[0], a.T, dst, len[0], a.info_stride, R0, smm[0].slot[0]);
-                walk_info_finish(x, smm[1], a.T, dst, len[1], a.info_stride, R1, smm[0].slot[1]);
-            } else {
-                WalkProbe P0, P1;
-                walk_probe_issue(x, smm[0], a.T, dst, len[0], P0, nullptr);
-                walk_probe_issue(x, smm[1], a.T, dst, len[1], P1, nullptr);
-                W_STAMP(2);  // k-mers + first-slot loads issued
-                walk_probe_finish(x, smm[0], a.T, dst, len[0], P0, smm[0].slot[0]);
-                walk_probe_finish(x, smm[1], a.T, dst, len[1], P1, smm[0].slot[1]);
-            }
-            W_STAMP(3);  // look-ups resolved -> LDS
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                // The call site keeps a pair when EITHER mate is feasible and then counts the uncorrected k-mers of both (AQ.cpp:2082-2087,
-                // 2189-2194): once mate 0 has threaded, nothing but a record (thread records, -a / -ae) needs mate 1's walk — the most
-                // expensive thing this kernel does, and every pair on its list has two mates that did not thread cleanly.
-                if (m == 1 && ret[0] && !a.trecs && !arec && !a.txt) { ret[1] = WALK_NOT_EVALUATED; W_STAMP(5); continue; }
-                WalkState S;
-                if (a.P.diag & 1) { ret[m] = 1; S.flags = 0; S.nes = S.ntr = S.nkm = 0; S.ni = 0; S.ki = 0; S.nskip = S.ncorr = 0; }  // diagnostic: no walk
-                else ret[m] = walk_read(x, smm[m], a.T, a.P, dst, (int)len[m], S);
-                if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) { ret[m] = 0; if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_FORMAT; }
-                if (a.trecs) walk_store(x, smm[m], S, ret[m], &a.trecs[2 * (size_t)t + m]);
-                if (arec) walk_store_aln(x, smm[m], S, ret[m], arec, a.aln_cap, m);
-                if (a.txt) walk_format_text(x, smm[m], S, a.aln_cap);
-                W_STAMP(4 + m);  // the walk of mate m
-            }
-            const bool alned = ret[0] || ret[1];
-            if (arec && lane == 0) {  // -a: every walked pair; -ae: only the kept ones (AQ.cpp:2234)
-                dbtk_aln_hdr_t* h = reinterpret_cast<dbtk_aln_hdr_t*>(arec);
-                h->pair = (a.P.aln == 2 && !alned) ? NAN32 : pair;
-                h->dst = alned ? dst : a.T.nloci;
-                h->pad[0] = h->pad[1] = 0;
-            }
-            if (a.txt && (a.P.aln & 3) != 0 && ((a.P.aln & 3) == 1 || alned)) {  // -a: every walked pair; -ae: only the kept ones
-                // "cigar2 \t annot2 \t cigar1 \t annot1" (writeAlignments' order, AQ.cpp:1751-1757) behind an 8-byte header
-                const uint32_t lc1 = smm[0].txl[0], la1 = smm[0].txl[1], lc2 = smm[1].txl[0], la2 = smm[1].txl[1];
-                const uint32_t len = lc2 + 1 + la2 + 1 + lc1 + 1 + la1, need = (8 + len + 3) & ~3u;
-                if (need > txt_left) {  // (what is left of the old chunk stays unused)
-                    uint32_t b = 0;
-                    if (lane == 0) b = txt_carve(x, a);
-                    txt_base = x.bcast(b, 0);
-                    txt_left = TXT_CHUNK;
-                }
-                if ((uint64_t)txt_base + need <= a.txt_cap) {
-                    uint8_t* r = a.txt + txt_base;
-                    if (lane == 0) {
-                        reinterpret_cast<uint32_t*>(r)[0] = alned ? dst : a.T.nloci;
-                        reinterpret_cast<uint32_t*>(r)[1] = len;
-                        a.txt_idx[pair] = txt_base;
-                    }
-                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                        uint8_t c;
-                        if (i < lc2) c = smm[1].txc[i];
-                        else if (i == lc2) c = '\t';
-                        else if (i < lc2 + 1 + la2) c = smm[1].txa[i - lc2 - 1];
-                        else if (i == lc2 + 1 + la2) c = '\t';
-                        else if (i < lc2 + la2 + 2 + lc1) c = smm[0].txc[i - lc2 - la2 - 2];
-                        else if (i == lc2 + la2 + 2 + lc1) c = '\t';
-                        else c = smm[0].txa[i - lc2 - la2 - lc1 - 3];
-                        r[8 + i] = c;
-                    }
-                } else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
-                txt_base += need; txt_left -= need;
-            }
-            x.sync();
-            if (alned) {
-                c_feas += 2;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    for (int i = lane; i < NKMAX; i += 64) {
-                        const uint32_t s = smm[0].slot[m][i];
-                        const bool hit = s != NAN32;
-                        if (hit && !(a.P.diag & 2)) x.atomic_add(&a.counts[s], 1ull);  // (diagnostic 2: no count atomics)
-                        c_inc += (uint64_t)__builtin_popcountll(x.ballot(hit));
-                    }
-            }
-            if (lane == 0) {
-                a.walk_dst[t] = alned ? dst : a.T.nloci;
-                a.walk_ret[t] = ((uint32_t)ret[0] & 0xFFu) | (((uint32_t)ret[1] & 0xFFu) << 8);
-            }
-            x.sync();
-            W_STAMP(6);  // counting + results
-        }
+        if (dst != NAN32) walk_pair(x, smm, a, a.T, t, dst, pair, inf, oA, wA, A);
         // the pipeline moves on
         dstA = dstB; pairA = pairB; ttA = ttB; infA = infB;
         for (int q = 0; q < 3; ++q) { oA[q] = oB[q]; oB[q] = uni64(oC[q]); }
@@ -1464,8 +1489,8 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
         dstC = dstD; pairC = pairD; ttC = ttD; infC = infD;
     }
     if (a.aln && lane == 0)  // the slots of the last chunk that were not used
-        for (; slot_used < ALN_CHUNK; ++slot_used) {
-            const uint32_t slot = slot_base + slot_used;
+        for (; A.slot_used < ALN_CHUNK; ++A.slot_used) {
+            const uint32_t slot = A.slot_base + A.slot_used;
             if (slot < a.aln_max) reinterpret_cast<dbtk_aln_hdr_t*>(a.aln + (size_t)slot * a.aln_stride)->pair = NAN32;
         }
     W_STAMP_FLUSH;
@@ -1473,8 +1498,8 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
     if (lane == 0 && a.dbg) for (int m_ = 0; m_ < 2; ++m_) for (int i_ = 0; i_ < 8; ++i_) if (smm[m_].dst_[i_]) x.atomic_add(&a.dbg[8 + i_], smm[m_].dst_[i_]);
 #endif
     if (lane == 0) {
-        if (c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], c_feas);
-        if (c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], c_inc);
+        if (A.c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], A.c_feas);
+        if (A.c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], A.c_inc);
     }
 }
 

@@ -210,6 +210,10 @@ DBTK_HD void wf_decide(X& x, const WalkArgs& a, uint32_t i, uint32_t dst, uint32
             } else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
             txt_base += need; txt_left -= need;
         }
+    } else if (lcnt && a.pend_locus) {
+        // the locus-resident form: the pair stays with its locus — body_walk_pairs_locus (dbtk_walkfast.h, below) walks it with the error
+        // correction's graph look-ups answered from the same image in LDS
+        if (lane == 0) a.walk_ret[i] = WALK_PENDING;
     } else wf_hand_over<NPL>(x, a, S, i, badm ? nullptr : gi);
 }
 
@@ -590,7 +594,8 @@ DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) 
             const uint64_t badm = x.ballot(bad != 0 && 8 * hl < rsh + len);
             x.sync();
             if (badm) {  // (uniform) a pair with a non-ACGT byte is the other kernel's whatever its mates do
-                wf_hand_over<NPL>(x, a, W, i, nullptr);
+                if (a.pend_locus) { if (lane == 0) a.walk_ret[i] = WALK_PENDING; }
+                else wf_hand_over<NPL>(x, a, W, i, nullptr);
                 continue;
             }
             const uint64_t Wd = window_fw_clean(sm.pk[half], rsh + p0, 32);
@@ -657,6 +662,131 @@ DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) 
     if (lane == 0) {
         if (W.c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], W.c_feas);
         if (W.c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], W.c_inc);
+    }
+}
+
+// ---- the error-correcting walk with the locus' graph nodes resident in LDS (round 5).  What body_walk_pairs costs is the chain of
+// dependent graph look-ups of a correction (walk_ec: the successor cube's two levels, the hypotheses' lock-step steps, the survivors'
+// extensions; then the rewritten window): eight round trips to the 8.6-GB table per correction, 45 000 cycles of a dirty mate's ~60 000
+// (tools/walk_bench.py with the stamps build).  The lean kernel's locus-resident form has the item's image in LDS already when it finds a
+// pair it cannot decide; this kernel goes over the SAME items, copies the image in again, and walks the pairs that kernel marked
+// (walk_ret == WALK_PENDING) with every look-up answered from LDS (DevTables::gimg: gr_lookup takes the image).  A workgroup of NW waves
+// per item, each wave with its two WalkSmem; a wave takes every NW-th marked pair of the item.
+template <int NW, int IMGB>
+struct __attribute__((aligned(16))) WalkPairsLocSmemT {
+    uint4 img[IMGB / 16];
+    WalkSmem w[NW][2];
+};
+template <int NW, int IMGB, class X>
+DBTK_HD void body_walk_pairs_locus(X& x, const WalkArgs& a, const LocRunArgs& r) {
+    typedef WalkPairsLocSmemT<NW, IMGB> SM;
+    constexpr int IPT = ((IMGB - (int)LOC_HDR) / 16 + NW * 64 - 1) / (NW * 64);
+    SM& smb = *x.template smem<SM>();
+    const int lane = x.lane();
+    const uint32_t wave = (uint32_t)x.tid() >> 6;
+    WalkSmem* const smm = smb.w[wave];
+#ifdef DBTK_STAMPS
+    if (lane == 0) for (int m_ = 0; m_ < 2; ++m_) for (int i_ = 0; i_ < 8; ++i_) smm[m_].dst_[i_] = 0;
+#endif
+    DevTables T = a.T;
+    T.gimg = reinterpret_cast<const uint32_t*>(smb.img);
+    uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
+    const uint32_t ifirst = r.starts[x.bid()], nitems = r.starts[x.bid() + 1];
+    auto desc = [&](uint32_t it) -> uint4 { return r.items[it < nitems ? it : 0u]; };
+    auto uni64 = [&](uint64_t v) { return ((uint64_t)x.uni((uint32_t)(v >> 32)) << 32) | x.uni((uint32_t)v); };
+    auto clampl = [&](uint64_t o0, uint64_t o1) { const uint64_t l = o1 - o0; return (uint32_t)(l > (uint64_t)MAXL ? (uint64_t)MAXL : l); };
+    WalkPairAcc A;
+    uint32_t nwalked = 0;
+#ifdef DBTK_STAMPS
+    A.wlast = x.clock();
+#endif
+    uint4 d1 = desc(ifirst), d2 = desc(ifirst + 1);
+    LocusDir ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
+    // (the marks of the next item's pairs are fetched an item ahead, like its descriptor: a wave that finds none of its own in an item
+    // goes straight to the barrier)
+    auto marks = [&](const uint4& d) -> uint32_t {
+        const uint32_t n = d.z - d.y;
+        return (uint32_t)lane < n ? a.walk_ret[d.y + (uint32_t)lane] : 0u;
+    };
+    uint32_t mk1 = ifirst < nitems ? marks(d1) : 0u;
+    for (uint32_t item = ifirst; item < nitems; ++item) {
+        const uint4 d = d1;
+        const LocusDir ld = ld1;
+        const uint32_t locus = x.uni(d.x);
+        const uint64_t pending = x.ballot(mk1 == WALK_PENDING);  // (the same in every wave of the workgroup)
+        d1 = d2; d2 = desc(item + 2);
+        ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
+        mk1 = item + 1 < nitems ? marks(d1) : 0u;
+        if (!pending) continue;  // (uniform over the workgroup: no barrier is skipped by some waves only)
+        x.bsync();  // every wave is done with the image of the item before
+        {
+            const p2_v4u* src = reinterpret_cast<const p2_v4u*>(r.arena + 16ull * ld.off16 + LOC_HDR);
+            const uint32_t n16 = (ld.bytes - LOC_HDR) / 16;
+            p2_v4u t[IPT];
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                const uint32_t o = (uint32_t)x.tid() + (uint32_t)u * NW * 64;
+                t[u] = src[o < n16 ? o : 0u];
+            }
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                const uint32_t o = (uint32_t)x.tid() + (uint32_t)u * NW * 64;
+                if (o < n16) *reinterpret_cast<p2_v4u*>(&smb.img[o]) = t[u];
+            }
+        }
+        T.gimg_lgnb = x.uni(ld.lgnb);
+        // this wave's pairs: every NW-th marked one.  Lane j holds the j-th of them: place, pair index, offsets (the two dependent loads
+        // of all of them in flight together)
+        uint32_t my_t = 0, my_pair = 0;
+        uint64_t my_o[3] = {0, 0, 0};
+        uint32_t nmine = 0;
+        {
+            uint64_t m = pending;
+            uint32_t rank = 0;
+            while (m) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                if (rank % NW == wave) { if ((uint32_t)lane == nmine) my_t = d.y + b; ++nmine; }
+                ++rank;
+            }
+        }
+        if ((uint32_t)lane < nmine) {
+            my_pair = a.surv[my_t];
+            my_o[0] = a.off[2 * (uint64_t)my_pair]; my_o[1] = a.off[2 * (uint64_t)my_pair + 1]; my_o[2] = a.off[2 * (uint64_t)my_pair + 2];
+        }
+        x.bsync();  // the image is in LDS
+        uint64_t oA[3] = {0, 0, 0}, oB[3];
+        uint32_t wA[2][2] = {{0, 0}, {0, 0}}, wB[2][2];
+        auto take = [&](uint32_t j, uint64_t (&o)[3], uint32_t (&w)[2][2]) {  // offsets and raw words of this wave's j-th pair (loads issued, not waited for)
+            for (int q = 0; q < 3; ++q) o[q] = ((uint64_t)x.bcast((uint32_t)(my_o[q] >> 32), (int)j) << 32) | x.bcast((uint32_t)my_o[q], (int)j);
+            walk_raw_words(a.seq, o[0], clampl(o[0], o[1]), lane, w[0]);
+            walk_raw_words(a.seq, o[1], clampl(o[1], o[2]), lane, w[1]);
+        };
+        if (nmine) take(0, oA, wA);
+        for (uint32_t j = 0; j < nmine; ++j) {
+            if (j + 1 < nmine) take(j + 1, oB, wB);
+            const uint32_t t = x.bcast(my_t, (int)j), pair = x.bcast(my_pair, (int)j);
+            walk_pair(x, smm, a, T, t, locus, pair, NAN32, oA, wA, A);
+            ++nwalked;
+            for (int q = 0; q < 3; ++q) oA[q] = oB[q];
+            for (int m = 0; m < 2; ++m) { wA[m][0] = wB[m][0]; wA[m][1] = wB[m][1]; }
+        }
+    }
+    if (a.aln && lane == 0)  // the slots of the last chunk that were not used
+        for (; A.slot_used < ALN_CHUNK; ++A.slot_used) {
+            const uint32_t slot = A.slot_base + A.slot_used;
+            if (slot < a.aln_max) reinterpret_cast<dbtk_aln_hdr_t*>(a.aln + (size_t)slot * a.aln_stride)->pair = NAN32;
+        }
+#ifdef DBTK_STAMPS
+    if (lane == 0 && a.dbg) {
+        for (int i_ = 0; i_ < 8; ++i_) if (A.wst[i_]) x.atomic_add(&a.dbg[i_], A.wst[i_]);
+        for (int m_ = 0; m_ < 2; ++m_) for (int i_ = 0; i_ < 8; ++i_) if (smm[m_].dst_[i_]) x.atomic_add(&a.dbg[8 + i_], smm[m_].dst_[i_]);
+    }
+#endif
+    if (lane == 0) {
+        if (A.c_feas) x.atomic_add(&ctr[DBTK_C_FEASIBLE], A.c_feas);
+        if (A.c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], A.c_inc);
+        if (a.pstats && nwalked) x.atomic_add(&a.pstats[18], (uint64_t)nwalked);
     }
 }
 

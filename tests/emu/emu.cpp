@@ -789,6 +789,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     std::vector<uint64_t> vbusy(2, 0);
     a.vote_scratch = vote.data(); a.vote_epoch = epoch.data(); a.vote_busy = vbusy.data(); a.vote_rows = grid_pair < 2 ? grid_pair : 2;
     std::vector<uint32_t> walk(2 * npairs + 2, NAN32);
+    std::fill(walk.begin() + npairs, walk.end(), 0u);  // (walk_ret is zeroed per batch: no pair is marked WALK_PENDING)
     a.walk_dst = walk.data();
     uint32_t maxlen = 1;
     for (uint64_t r = 0; r < 2 * npairs; ++r) maxlen = std::max<uint32_t>(maxlen, (uint32_t)(off[r + 1] - off[r]));
@@ -926,7 +927,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         w.surv = sorted.data(); w.nsurv = &small[0];
         w.walk_dst = walk.data(); w.walk_ret = walk.data() + npairs;
         w.counts = a.counts; w.counters = a.counters;
-        w.trecs = g_walk_trecs; w.errflag = &small[3];
+        w.trecs = g_walk_trecs; w.errflag = &small[3]; w.pstats = g_pstats;
         std::vector<uint8_t> alnraw;
         uint32_t naln = 0;
         g_aln.clear();
@@ -985,6 +986,8 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
                     if (wstarts[q][0] != 0 || wstarts[q][nblk_[q]] != std::min(wnit[q], item_cap)) { fprintf(stderr, "emu: walk item ranges of class %d do not cover its list\n", q); abort(); }
                 LocRunArgs r0{w.T.gldir, w.T.glimg, witems[0].data(), &wnit[0], nullptr, nullptr, wstarts[0].data()}, r1{w.T.gldir, w.T.glimg, witems[1].data(), &wnit[1], nullptr, nullptr, wstarts[1].data()},
                     r2{w.T.gldir, w.T.glimg, witems[2].data(), &wnit[2], nullptr, nullptr, wstarts[2].data()};
+                const bool pend_locus = !getenv("EMU_NO_LOCUS_EC");
+                w.pend_locus = pend_locus ? 1u : 0u;
                 if (wnpl == 3) {
                     run_grid(2, 4 * 64, sizeof(WalkFastLocSmemT<3, 4, EMU_IMGB_XS>), [&](EmuX& x) { body_walk_fast_locus<3, 4, EMU_IMGB_XS>(x, w, r0); });
                     run_grid(3, 4 * 64, sizeof(WalkFastLocSmemT<3, 4, EMU_IMGB_S>), [&](EmuX& x) { body_walk_fast_locus<3, 4, EMU_IMGB_S>(x, w, r1); });
@@ -994,6 +997,13 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
                     run_grid(3, 4 * 64, sizeof(WalkFastLocSmemT<5, 4, EMU_IMGB_S>), [&](EmuX& x) { body_walk_fast_locus<5, 4, EMU_IMGB_S>(x, w, r1); });
                     run_grid(2, 4 * 64, sizeof(WalkFastLocSmemT<5, 4, EMU_IMGB_L>), [&](EmuX& x) { body_walk_fast_locus<5, 4, EMU_IMGB_L>(x, w, r2); });
                 }
+                if (pend_locus) {  // the error-correcting walk over the same items, as launch_batch does (two waves per workgroup)
+                    run_grid(2, 2 * 64, sizeof(WalkPairsLocSmemT<2, EMU_IMGB_XS>), [&](EmuX& x) { body_walk_pairs_locus<2, EMU_IMGB_XS>(x, w, r0); });
+                    run_grid(3, 2 * 64, sizeof(WalkPairsLocSmemT<2, EMU_IMGB_S>), [&](EmuX& x) { body_walk_pairs_locus<2, EMU_IMGB_S>(x, w, r1); });
+                    run_grid(2, 2 * 64, sizeof(WalkPairsLocSmemT<2, EMU_IMGB_L>), [&](EmuX& x) { body_walk_pairs_locus<2, EMU_IMGB_L>(x, w, r2); });
+                    for (uint32_t t = 0; t < small[0]; ++t) if (walk[npairs + t] == WALK_PENDING) { fprintf(stderr, "emu: a pair left to body_walk_pairs_locus was not walked\n"); abort(); }
+                }
+                w.pend_locus = 0;
                 for (int c = 0; c < 3; ++c) for (uint32_t q = 0; q < wnit[c]; ++q) g_wfl_pairs[0] += witems[c][q].z - witems[c][q].y;
                 g_wfl_pairs[1] += wnit[3];
                 w.sel = wrest.data(); w.nsel = &wnit[3];

@@ -430,7 +430,11 @@ def test_emulated_pair_mode_equals_oracle(tmp_path, k, seed):
         res, nres = E.walk_results(len(off))
         return dict(counts=e["counts"], counters=e["counters"], res=res, nres=nres, aln=E.aln_records(), order=order, txt=E.aln_text(len(off) // 2))
     E.walk_locus_stats()
+    E.path_stats()
     check_pair_mode(run, O, oh, case, k, case.loci.nloci)
+    ec = E.path_stats()["walk_locus_ec"]
+    print(f"k={k}: error-correcting walk with the graph image in LDS: {ec} pairs")
+    assert (ec > 100) if k != 17 else ec == 0
     img, plain = E.walk_locus_stats()
     print(f"k={k}: lean walk body: {img} pairs with the graph image in LDS, {plain} from the global tables")
     assert (img > 0 and plain > 0) if k != 17 else img == 0  # (graph images exist where the minimizer-grouped tables do)
