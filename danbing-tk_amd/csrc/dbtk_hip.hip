@@ -1359,9 +1359,11 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
                 LAUNCH(k_loc_split, dim3(3), dim3(1024), s, sp);
                 LocRunArgs r0{w.T.gldir, w.T.glimg, ia.items[0], c->d_small + 8, nullptr, nullptr, sp.starts[0]}, r1{w.T.gldir, w.T.glimg, ia.items[1], c->d_small + 9, nullptr, nullptr, sp.starts[1]},
                     r2{w.T.gldir, w.T.glimg, ia.items[2], c->d_small + 10, nullptr, nullptr, sp.starts[2]};
-                // (the pairs these cannot decide stay with their locus: marked in walk_ret, walked by k_walk_pairs_locus over the same items.
-                // DBTK_WALK_LOCUS_EC=0: they go on the list of the global-table kernel instead, as in round 4)
-                static const bool locus_ec = [] { const char* e = getenv("DBTK_WALK_LOCUS_EC"); return !e || atoi(e) != 0; }();
+                // (DBTK_WALK_LOCUS_EC=1: the pairs these cannot decide stay with their locus — marked in walk_ret, walked by k_walk_pairs_locus
+                // over the same items with the error correction's graph look-ups answered from LDS.  Built and bit-exact in round 5, and
+                // MEASURED SLOWER than the global-table kernel (walk kernels 23.0 against 16.2 ms per 10 M reads: DESIGN 4.2) — the walk is not
+                // bound by its look-ups' round trips — so it is off unless asked for; the pairs go on the other kernel's list)
+                static const bool locus_ec = [] { const char* e = getenv("DBTK_WALK_LOCUS_EC"); return e && atoi(e) != 0; }();
                 w.pend_locus = locus_ec ? 1u : 0u;
                 const int wq = wnpl == 3 ? 0 : 3;
                 if (wnpl == 3) {

@@ -15,7 +15,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define DBTK_HD __host__ __device__ __forceinline__
+#ifdef DBTK_WALK_INLINE  /* diagnostic build: the walk's out-of-line routines inlined (tools/_variants) */
+#define DBTK_HD_NOINLINE __host__ __device__ __forceinline__
+#else
 #define DBTK_HD_NOINLINE __host__ __device__ __noinline__
+#endif
 #else
 #define DBTK_HD inline
 #define DBTK_HD_NOINLINE inline

@@ -675,6 +675,8 @@ DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) 
 template <int NW, int IMGB>
 struct __attribute__((aligned(16))) WalkPairsLocSmemT {
     uint4 img[IMGB / 16];
+    DevTables T;  // a.T with the image named in it: in LDS, because the walk's out-of-line routines take the tables by reference — a copy on the
+                  // stack would be scratch memory, a round trip to HBM for every field they read
     WalkSmem w[NW][2];
 };
 template <int NW, int IMGB, class X>
@@ -688,8 +690,9 @@ DBTK_HD void body_walk_pairs_locus(X& x, const WalkArgs& a, const LocRunArgs& r)
 #ifdef DBTK_STAMPS
     if (lane == 0) for (int m_ = 0; m_ < 2; ++m_) for (int i_ = 0; i_ < 8; ++i_) smm[m_].dst_[i_] = 0;
 #endif
-    DevTables T = a.T;
-    T.gimg = reinterpret_cast<const uint32_t*>(smb.img);
+    if (x.tid() == 0) { smb.T = a.T; smb.T.gimg = reinterpret_cast<const uint32_t*>(smb.img); smb.T.gimg_lgnb = 0; }
+    x.bsync();
+    const DevTables& T = smb.T;
     uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
     const uint32_t ifirst = r.starts[x.bid()], nitems = r.starts[x.bid() + 1];
     auto desc = [&](uint32_t it) -> uint4 { return r.items[it < nitems ? it : 0u]; };
@@ -701,7 +704,7 @@ DBTK_HD void body_walk_pairs_locus(X& x, const WalkArgs& a, const LocRunArgs& r)
     A.wlast = x.clock();
 #endif
     uint4 d1 = desc(ifirst), d2 = desc(ifirst + 1);
-    LocusDir ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
+    LocusDir ld1 = r.dir[x.uni(d1.x) < a.T.nloci ? x.uni(d1.x) : 0u];
     // (the marks of the next item's pairs are fetched an item ahead, like its descriptor: a wave that finds none of its own in an item
     // goes straight to the barrier)
     auto marks = [&](const uint4& d) -> uint32_t {
@@ -715,7 +718,7 @@ DBTK_HD void body_walk_pairs_locus(X& x, const WalkArgs& a, const LocRunArgs& r)
         const uint32_t locus = x.uni(d.x);
         const uint64_t pending = x.ballot(mk1 == WALK_PENDING);  // (the same in every wave of the workgroup)
         d1 = d2; d2 = desc(item + 2);
-        ld1 = r.dir[x.uni(d1.x) < T.nloci ? x.uni(d1.x) : 0u];
+        ld1 = r.dir[x.uni(d1.x) < a.T.nloci ? x.uni(d1.x) : 0u];
         mk1 = item + 1 < nitems ? marks(d1) : 0u;
         if (!pending) continue;  // (uniform over the workgroup: no barrier is skipped by some waves only)
         x.bsync();  // every wave is done with the image of the item before
@@ -734,7 +737,7 @@ DBTK_HD void body_walk_pairs_locus(X& x, const WalkArgs& a, const LocRunArgs& r)
                 if (o < n16) *reinterpret_cast<p2_v4u*>(&smb.img[o]) = t[u];
             }
         }
-        T.gimg_lgnb = x.uni(ld.lgnb);
+        if (x.tid() == 0) smb.T.gimg_lgnb = ld.lgnb;  // (between the item's two barriers)
         // this wave's pairs: every NW-th marked one.  Lane j holds the j-th of them: place, pair index, offsets (the two dependent loads
         // of all of them in flight together)
         uint32_t my_t = 0, my_pair = 0;

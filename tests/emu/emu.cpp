@@ -986,7 +986,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
                     if (wstarts[q][0] != 0 || wstarts[q][nblk_[q]] != std::min(wnit[q], item_cap)) { fprintf(stderr, "emu: walk item ranges of class %d do not cover its list\n", q); abort(); }
                 LocRunArgs r0{w.T.gldir, w.T.glimg, witems[0].data(), &wnit[0], nullptr, nullptr, wstarts[0].data()}, r1{w.T.gldir, w.T.glimg, witems[1].data(), &wnit[1], nullptr, nullptr, wstarts[1].data()},
                     r2{w.T.gldir, w.T.glimg, witems[2].data(), &wnit[2], nullptr, nullptr, wstarts[2].data()};
-                const bool pend_locus = !getenv("EMU_NO_LOCUS_EC");
+                const bool pend_locus = getenv("DBTK_WALK_LOCUS_EC") && atoi(getenv("DBTK_WALK_LOCUS_EC")) != 0;  // (as launch_batch: opt-in)
                 w.pend_locus = pend_locus ? 1u : 0u;
                 if (wnpl == 3) {
                     run_grid(2, 4 * 64, sizeof(WalkFastLocSmemT<3, 4, EMU_IMGB_XS>), [&](EmuX& x) { body_walk_fast_locus<3, 4, EMU_IMGB_XS>(x, w, r0); });
