@@ -606,7 +606,7 @@ struct LocCacheHdr {
     uint32_t lg_max, hdr_bytes;
     uint64_t checksum;       // of the directory and the arena (csum_term over their 8-byte words): a torn, mixed or bit-flipped file is not used
 };
-constexpr uint32_t LOC_CACHE_VERSION = 4;  // (bumped with every change of the image layout or of its hashes)
+constexpr uint32_t LOC_CACHE_VERSION = 5;  // (bumped with every change of the image layout or of its hashes)
 // what the images were built from: the handle's arrays, sampled (a different RPGG, another -t N order, a changed file: another value)
 static uint64_t rpgg_fingerprint(const dbtk_rpgg* g) {
     uint64_t h = 0xCBF29CE484222325ull;
@@ -690,6 +690,7 @@ static dbtk_status_t load_locus_cache(dbtk_ctx* c, uint64_t fp) {
     LocBuildArgs a;
     memset(&a, 0, sizeof(a));
     a.idx = c->d_idx; a.nslots = (c->T.idx_mask + 1) * 4; a.idx_mask = c->T.idx_mask; a.idx_shift = c->T.idx_shift; a.vv = c->d_vv;
+    a.cls = c->T.cls; a.cls_mask = c->T.cls_mask; a.cls_shift = c->T.cls_shift;
     a.trbeg = c->d_trbeg; a.nloci = (uint32_t)nloci; a.ksize = g->ksize; a.dir = c->d_ldir; a.arena = c->d_limg; a.bad = dbad; a.vcnt = dvcnt; a.cnt = dcnt;
     LAUNCH(k_loc_count, dim3(2048), dim3(256), s, a);
     LAUNCH(k_loc_verify, dim3(4096), dim3(256), s, a);
@@ -757,6 +758,7 @@ dbtk_status_t build_locus_images(dbtk_ctx* c) {
     LocBuildArgs a;
     memset(&a, 0, sizeof(a));
     a.idx = c->d_idx; a.nslots = (c->T.idx_mask + 1) * 4; a.vv = c->d_vv; a.trbeg = c->d_trbeg; a.nloci = (uint32_t)nloci; a.ksize = g->ksize;
+    a.cls = c->T.cls; a.cls_mask = c->T.cls_mask; a.cls_shift = c->T.cls_shift;
     a.cnt = dcnt; a.bad = dbad;
     LAUNCH(k_loc_count, dim3(2048), dim3(256), s, a);
     std::vector<uint32_t> cnt(nloci), bad(nloci);

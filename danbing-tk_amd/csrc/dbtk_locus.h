@@ -83,6 +83,9 @@ struct LocBuildArgs {
     uint64_t* nleft;        // += keys left out of their image
     const GrSlot* gr;       // the graph images' source: the hashed graph table
     uint64_t gr_nslots;
+    const ClsSlot* cls;     // the class table (flank / TR sets by (k-mer, locus)): the class AT THIS LOCUS of a key shared between loci
+    uint64_t cls_mask;      //   rides in its image entry next to LOC_MULTI (nullptr: such entries carry LOC_MULTI alone)
+    uint32_t cls_shift;
     uint64_t idx_mask;      // body_loc_verify: the plain index as a look-up table (buckets - 1, 64 - log2(buckets))
     uint32_t idx_shift;
     uint32_t* vcnt;         // [nloci] body_loc_verify: entries of the image that ARE the index's + the keys the image says it left out
@@ -101,11 +104,24 @@ DBTK_HD void body_loc_count(X& x, const LocBuildArgs& a) {
     }
 }
 // the (key, pay) of every membership, gathered per locus: ent[ebeg[l] ..)
+// pay of a key whose index value is a vv list (shared between loci), in the image of locus l of that list: LOC_MULTI, and — round 5 —
+// the key's class at l (flankDB[l] / trKmers[l]: what assignTRkmc asks, AQ.cpp:1466-1468) when the class table knows it: the fused probe
+// kernel then resolves a pair with such k-mers without the index (dbtk_locus.h: body_probe_locus)
+DBTK_HD uint32_t loc_multi_pay(const LocBuildArgs& a, uint64_t key, uint32_t l) {
+    if (!a.cls) return LOC_MULTI;
+    const uint32_t c = kl_lookup(a.cls, a.cls_mask, a.cls_shift, key, l);
+    if (c == CLS_NONE) return LOC_MULTI;
+    if (c == CLS_FLANK) return LOC_MULTI | LOC_FLANK;
+    const uint32_t slot = c - a.trbeg[l];
+    if (c < a.trbeg[l] || slot > LOC_SLOT) return LOC_MULTI;
+    return LOC_MULTI | LOC_TR | slot;
+}
 template <class X>
 DBTK_HD void loc_scatter_one(X& x, const LocBuildArgs& a, uint64_t key, uint32_t l, uint32_t val, uint32_t aux) {
     if (l >= a.nloci || !a.dir[l].bytes) return;
     uint32_t pay;
-    if ((val & 1) || aux == CLS_NONE) pay = LOC_MULTI;
+    if (val & 1) pay = loc_multi_pay(a, key, l);
+    else if (aux == CLS_NONE) pay = LOC_MULTI;
     else if (aux == CLS_FLANK) pay = LOC_FLANK;
     else {
         const uint32_t slot = aux - a.trbeg[l];
@@ -263,16 +279,17 @@ DBTK_HD void body_loc_verify(X& x, const LocBuildArgs& a) {
                     const uint64_t key = ((uint64_t)(hx | hlow) << 32) | lo;
                     const uint64_t va = a.idx ? idx_lookup64_raw(a.idx, a.idx_mask, a.idx_shift, key) : (uint64_t)NOHIT;
                     const uint32_t v = (uint32_t)va, aux = (uint32_t)(va >> 32);
-                    bool ok = v != NOHIT && (cls == LOC_MULTI || cls == LOC_FLANK || cls == LOC_TR);
+                    bool ok = v != NOHIT && (cls & (LOC_FLANK | LOC_TR)) != (LOC_FLANK | LOC_TR) && cls != 0;
                     if (ok) {
                         bool named = false;
                         if (v & 1) { const uint32_t n = a.vv[v >> 1]; for (uint32_t j = 0; j < n; ++j) named |= a.vv[(v >> 1) + 1 + j] == l; }
                         else named = (v >> 1) == l;
                         uint32_t want;
-                        if ((v & 1) || aux == CLS_NONE) want = LOC_MULTI;
+                        if (v & 1) want = loc_multi_pay(a, key, l);
+                        else if (aux == CLS_NONE) want = LOC_MULTI;
                         else if (aux == CLS_FLANK) want = LOC_FLANK;
                         else want = LOC_TR | ((aux - a.trbeg[l]) & LOC_SLOT);
-                        ok = named && (p & 0x00FFFFFFu) == want && (cls != LOC_TR || ((p & LOC_SLOT) < ntr && aux >= a.trbeg[l]));
+                        ok = named && (p & 0x00FFFFFFu) == want && (!(cls & LOC_TR) || ((p & LOC_SLOT) < ntr && ((v & 1) || aux >= a.trbeg[l])));
                     }
                     good = ok;
                     bad |= !ok;
@@ -506,7 +523,7 @@ struct LocSpecRow {
     uint32_t kmc;    // (ei1 - si1) + (ei2 - si2)
     uint32_t nks;    // k-mers of both mates
     uint32_t inc;    // count increments
-    uint32_t pad;
+    uint32_t pad;    // vv words of fillstats (pairs with k-mers shared between loci)
 };
 constexpr uint32_t LSP_FAILED = 1u, LSP_RM0 = 2u, LSP_RM1 = 4u, LSP_SPEC = 8u, LSP_STAGE_SHIFT = 4;
 constexpr uint32_t LSP_COUNT = 0, LSP_QC = 1, LSP_THREAD_HEAD = 2, LSP_THREAD_V13 = 3, LSP_EXTRACT = 4;
@@ -847,6 +864,7 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                                 // [0] qc, [1] threading, [2] feasible, [3] asgn, [4] cls, [5] inc, [6] nhash1, [7] pairs, [8] pairs taken back
                                 x.lds_add(&sm.ctr[6], sr.nks);
                                 x.lds_add(&sm.ctr[7], 1u);
+                                if (sr.pad) { x.lds_add(&sm.ctr[9], sr.pad); x.lds_add(&sm.ctr[10], 1u); }
                                 if (stage == LSP_QC) x.lds_add(&sm.ctr[0], 2u);
                                 else {
                                     x.lds_add(&sm.ctr[1], 2u);
@@ -922,7 +940,8 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
             uint64_t km[NPL];
             bool pend[NPL];
             uint32_t npend = 0, nres = 0;
-            uint32_t stbits = 0;  // (FUSE) bit j: the lane's j-th position is known at the locus (flank or TR), bit 8 + j: it is a TR k-mer
+            uint32_t stbits = 0;  // (FUSE) bit j: the lane's j-th position is known at the locus (flank or TR), bit 8 + j: it is a TR k-mer,
+                                  // bit 16 + j: its k-mer is SHARED between loci (known all the same: the image carries its class here)
             bool multi = false;
             if (clean) {
                 x.sync();
@@ -982,13 +1001,17 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
 #pragma unroll
                 for (int j = 0; j < NPL; ++j) {
                     const bool act = p0 + j < nk;
-                    pend[j] = act && (pay[j] == LOC_MISS || (pay[j] & LOC_MULTI));
-                    multi |= act && pay[j] != LOC_MISS && (pay[j] & LOC_MULTI);
+                    const bool inimg = act && pay[j] != LOC_MISS;
+                    const bool shared = inimg && (pay[j] & LOC_MULTI);                       // a key shared between loci: its index value is a vv list
+                    const bool classed = shared && (pay[j] & (LOC_FLANK | LOC_TR)) != 0;     // ... whose class at THIS locus the image carries
+                    pend[j] = act && (pay[j] == LOC_MISS || shared);
+                    multi |= shared && !(FUSE && classed);
                     npend += pend[j] ? 1u : 0u;
                     const bool fnd = act && !pend[j];
                     nres += fnd ? 1u : 0u;
-                    sm.res[half][p0 + j] = !fnd ? AUX_MISS : (pay[j] & LOC_FLANK) ? CLS_FLANK : trb + (pay[j] & LOC_SLOT);
-                    if (FUSE) stbits |= (fnd ? 1u : 0u) << j | (fnd && (pay[j] & LOC_TR) ? 1u : 0u) << (8 + j);
+                    const bool known = fnd || (FUSE && classed);  // the position's class at the locus is known from the image
+                    sm.res[half][p0 + j] = !known ? AUX_MISS : (pay[j] & LOC_FLANK) ? CLS_FLANK : trb + (pay[j] & LOC_SLOT);
+                    if (FUSE) stbits |= (known ? 1u : 0u) << j | (known && (pay[j] & LOC_TR) ? 1u : 0u) << (8 + j) | (classed ? 1u : 0u) << (16 + j);
                 }
             } else {
                 // (rare) a non-ACGT byte somewhere in the pair: exact validity bits; a position with an invalid window is no k-mer,
@@ -1026,11 +1049,58 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
             // (AQ.cpp:190-228: kfilter keeps such a mate; 354-357, 439-451: countHit then needs no vote) — provided none of the queued
             // k-mers turns out to be in the index
             bool spec = false;
+            uint32_t nshared = 0;  // (uniform) positions of the pair whose k-mer is shared between loci, when the pair is resolved here all the same
             if (FUSE) {
                 const uint32_t nk0 = x.bcast(nk, 0), nk1 = x.bcast(nk, 32), nh0 = x.bcast(nh, 0), nh1 = x.bcast(nh, 32);
                 spec = clean && !again && x.ballot(multi) == 0 && nk0 >= cth && nk1 >= cth && nh0 >= cth && nh1 >= cth && nh0 && nh1;
+                // A pair with k-mers SHARED between loci is still this locus' — whatever order fillstats' unstable sort leaves the k-mers
+                // in — when the k-mers unique to the locus alone decide: they sort first (one locus each: AQ.cpp:320-321), so the locus
+                // leads from the first k-mer on and every shared k-mer adds to it too (their lists hold it: that is why they are in its
+                // image); the early stop of find_matching_locus (AQ.cpp:383-419) falls inside that prefix when they outnumber the shared
+                // ones (top - second >= remain), and the second loop ends on them when each mate has cth of them — before any vv list
+                // is read.  countHit then accepts (both strands >= cth).  What the shared k-mers still cost the reference is one vv
+                // word each in fillstats (their distinct number: DBTK_C_ALGO_VV, below).
+                const uint64_t shm = x.ballot((stbits >> 16) != 0);
+                if (spec && shm) {
+                    const uint32_t ns = x.wave_sum((uint32_t)__builtin_popcount(stbits >> 16));
+                    if (nh0 + nh1 >= ns && ns <= (uint32_t)LOC_Q * 3 / 4) nshared = ns; else spec = false;  // (the cap: they are de-duplicated in the queue's array)
+                }
                 if (lane == 0) { sm.spec[nrow >> 1].i = i; sm.spec[nrow >> 1].flags = spec ? LSP_SPEC : 0u; }  // (before anything of the pair is queued: the look-ups ask)
             }
+            uint32_t pexq = pex, ptotq = ptot;  // places in the queue: without the shared k-mers when the pair is resolved here
+            uint32_t nvv = 0;                   // (uniform) vv words fillstats reads for the pair: one per DISTINCT shared k-mer (AQ.cpp:311-316)
+            if (FUSE && nshared) {
+                // distinct shared k-mers of the pair (the mates overlap, a repeat repeats): they are written behind the queue's entries
+                // (room: the queue is looked up first if need be) and every one is compared with the ones before it
+                if ((uint32_t)LOC_Q - qn < nshared) flush();
+                uint32_t mine = (uint32_t)__builtin_popcount(stbits >> 16);
+                const uint32_t at0 = x.wave_excl_scan(mine);
+                {
+                    uint32_t at = at0;
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) if ((stbits >> (16 + j)) & 1u) sm.qkm[qn + at++] = km[j];
+                }
+                x.sync();
+                uint32_t dupb = 0;
+                for (uint32_t e = 0; e + 1 < nshared; ++e) {  // (entry e against the lane's own later ones)
+                    const uint64_t ke = sm.qkm[qn + e];
+                    uint32_t at = at0;
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) if ((stbits >> (16 + j)) & 1u) { if (at > e && km[j] == ke) dupb |= 1u << j; ++at; }
+                }
+                nvv = nshared - x.wave_sum((uint32_t)__builtin_popcount(dupb));
+                x.sync();
+            }
+            if (FUSE && nshared) {
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) if ((stbits >> (16 + j)) & 1u) pend[j] = false;
+                uint32_t np2 = 0;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) np2 += pend[j] ? 1u : 0u;
+                pexq = x.wave_excl_scan(np2);
+                ptotq = x.bcast(pexq + np2, 63);
+            }
+
 #if !defined(__HIPCC__) && defined(DBTK_LOC_DEBUG)
             if (hl == 0) fprintf(stderr, "item %u wave %u lane %d pair %u nrow %u spec %d again %d clean %d nh %u nk %u\n", item, wave, lane, i, nrow, (int)spec, (int)again, (int)clean, nh, nk);
 #endif
@@ -1046,6 +1116,11 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                         else x.atomic_add(&a.counts[ax], ~0ull);
                     }
                 }
+            }
+            if (FUSE && !spec && (x.ballot((stbits >> 16) != 0))) {
+                // the pair goes the general way: a shared k-mer's class is then the index's business (its row gets what the look-up says)
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) if ((stbits >> (16 + j)) & 1u) sm.res[half][p0 + j] = AUX_MISS;
             }
             if (!spec) {   // the row as the image answers it: its statistics, its aux words (16-byte stores)
                 if (hl == 0) {
@@ -1064,10 +1139,10 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
             } else x.sync();
             {   // what the image does not answer into the queue (a queue that cannot take them all is looked up first)
                 uint32_t done = 0;  // entries of this pair already queued (uniform)
-                while (done < ptot) {
+                while (done < ptotq) {
                     if (qn == (uint32_t)LOC_Q) flush();
-                    const uint32_t take = ptot - done < (uint32_t)LOC_Q - qn ? ptot - done : (uint32_t)LOC_Q - qn;
-                    uint32_t at = pex;
+                    const uint32_t take = ptotq - done < (uint32_t)LOC_Q - qn ? ptotq - done : (uint32_t)LOC_Q - qn;
+                    uint32_t at = pexq;
 #pragma unroll
                     for (int j = 0; j < NPL; ++j)
                         if (pend[j]) {
@@ -1118,7 +1193,7 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
                 if (lane == 0) {
                     LocSpecRow& sr = sm.spec[nrow >> 1];
                     x.lds_or(&sr.flags, (rm0 ? LSP_RM0 : 0u) | (rm1 ? LSP_RM1 : 0u) | (stage << LSP_STAGE_SHIFT));  // (or-ed: a look-up in the middle of the pair may have marked it already)
-                    sr.kmc = span0 + span1; sr.nks = nks; sr.inc = ninc;
+                    sr.kmc = span0 + span1; sr.nks = nks; sr.inc = ninc; sr.pad = nvv;
                 }
             }
             nrow += 2;
@@ -1139,6 +1214,8 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
             if (c4) x.atomic_add(&ctr[DBTK_C_ALGO_CLS], (uint64_t)c4);
             if (c5) x.atomic_add(&ctr[DBTK_C_ALGO_INC], (uint64_t)c5);
             if (c6) { x.atomic_add(&ctr[DBTK_C_NHASH1], (uint64_t)c6); x.atomic_add(&ctr[DBTK_C_ALGO_PROBES], (uint64_t)c6); }
+            if (sm.ctr[9]) x.atomic_add(&ctr[DBTK_C_ALGO_VV], (uint64_t)sm.ctr[9]);
+            if (a.pstats && sm.ctr[10]) x.atomic_add(&a.pstats[19], (uint64_t)sm.ctr[10]);
             if (a.pstats && c7) x.atomic_add(&a.pstats[14], (uint64_t)c7);
             if (a.pstats && sm.ctr[8]) x.atomic_add(&a.pstats[15], (uint64_t)sm.ctr[8]);
             if (a.pstats && c4) x.atomic_add(&a.pstats[16], (uint64_t)c4);

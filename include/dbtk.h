@@ -413,6 +413,7 @@ int  dbtk_ctx_table_bytes(dbtk_ctx_t* ctx, const char** names, uint64_t* bytes, 
 #define DBTK_PS_FUSED_REDONE 15u  /* ... of the pairs it had resolved ahead of the global look-ups, those it had to take back */
 #define DBTK_PS_FUSED_CLS    16u  /* of DBTK_C_ALGO_CLS / DBTK_C_ALGO_INC, the part that kernel did (its algorithmic bytes: 8 A + 16 I) */
 #define DBTK_PS_FUSED_INC    17u
+#define DBTK_PS_FUSED_SHARED 19u /* ... of the pairs resolved there, those with k-mers shared between loci (decided by the k-mers unique to the locus) */
 #define DBTK_PS_WALK_LOCUS_EC 18u /* pairs the error-correcting walk took with the locus' graph image in LDS (k_walk_pairs_locus) */
 int  dbtk_ctx_path_stats(dbtk_ctx_t* ctx, uint64_t* out, int cap);
 void dbtk_ctx_timers_reset(dbtk_ctx_t* ctx);

@@ -420,6 +420,7 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
         LocBuildArgs a;
         memset(&a, 0, sizeof(a));
         a.idx = e->idx.data(); a.nslots = icap; a.vv = e->vv.data(); a.trbeg = e->trbeg.data(); a.nloci = (uint32_t)nloci; a.ksize = g->ksize;
+        a.cls = T.cls; a.cls_mask = T.cls_mask; a.cls_shift = T.cls_shift;
         a.cnt = cnt.data(); a.bad = bad.data();
         run_grid(3, 64, 0, [&](EmuX& x) { body_loc_count(x, a); });
         e->ldir.assign(nloci, LocusDir{0, 0, 0, 0});

@@ -92,7 +92,8 @@ def main():
         rlen = int(rng.choice([150, 150, 100, 250, 64] if not KSET else [150, 250, 200, 100]))
         reads = synth.sim_reads(loci, npairs=int(rng.integers(50, 900)), rlen=rlen, seed=seed + 7, sub=float(rng.choice([0.0, 0.005, 0.03])),
                                 indel=float(rng.choice([0.0, 0.002])), nrate=float(rng.choice([0.0, 0.003, 0.02])),
-                                chimeric=float(rng.choice([0.0, 0.3])), background=float(rng.choice([0.0, 0.3])), frag=(max(300, rlen), max(320, rlen) + 250))
+                                chimeric=float(rng.choice([0.0, 0.3])), background=float(rng.choice([0.0, 0.3])), frag=(max(300, rlen), max(320, rlen) + 250),
+                                splice=float(rng.choice([0.0, 0.0, 0.3])))  # (spliced pairs: the fused probe kernel resolves them ahead and must take them back)
         with tempfile.TemporaryDirectory() as d:
             pref = cases._np_rpgg(d, "f", loci, k)
             go, g = orc.load(pref, k, None), dbtk.load(pref, k, None)
@@ -104,8 +105,8 @@ def main():
             if rng.random() < 0.3:
                 kw.update(n_filter=int(rng.choice([2, 4, 8])), nm_filter=int(rng.choice([1, 2])))
             ok = True
-            for trace in (1, 0):
-                p = abi.default_params(ksize=k, trace=trace, **kw)
+            for trace, nokam in ((1, False), (0, False), (0, True)):  # (the last: no record buffer at all — the fused resolve of the locus-resident probe kernel)
+                p = abi.default_params(ksize=k, trace=trace, **(dict(kw, okam=0) if nokam else kw))
                 o = orc.align(go, p, seq, off, trace=bool(trace))
                 ctx = dbtk.context(g, p)
                 recs, nrec = ctx.align(seq, off)

@@ -71,7 +71,9 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
     if case in ("shared", "k25"):
         assert cls[0 if case == "shared" else 1] > 0  # different classes of workgroup are exercised
     ps = E.path_stats()
-    print(f"{case}: fused resolve: {ps['fused_done']} pairs, {ps['fused_redone']} taken back")
+    print(f"{case}: fused resolve: {ps['fused_done']} pairs ({ps['fused_shared']} with k-mers shared between loci), {ps['fused_redone']} taken back")
+    if case == "shared":
+        assert ps["fused_shared"] > 0  # pairs with shared k-mers decided by the k-mers unique to the locus: no sort, no vote
     if case in ("clean", "shared", "qc", "spliced", "k25"):
         assert ps["fused_done"] > 0   # the no-trace, no-record runs resolve the usual pairs inside the locus-resident probe body
     if case == "spliced":
