@@ -254,6 +254,7 @@ struct TableShare {
     uint32_t consistent = 0;
 };
 
+constexpr uint32_t TK_INLINE = 8;  // words in front of d_small (same allocation): the chunk counters of a batch of up to three chunks
 struct dbtk_ctx {
     TableShare* share = nullptr;
     const dbtk_rpgg* g = nullptr;
@@ -287,7 +288,8 @@ struct dbtk_ctx {
     uint8_t* d_qc = nullptr;
     uint16_t* d_perm = nullptr;
     uint64_t* d_accum = nullptr;  // counts | kmc | nmapread | counters
-    uint64_t* d_ctr = nullptr;    // counter replicas (folded into d_accum's counters at the end of every batch)
+    uint64_t* d_ctr = nullptr;    // counter replicas (folded into d_accum's counters before anything reads them: sync_all)
+    bool fold_pending = false;    // batches have been launched since the replicas were last folded
     uint8_t* m_flat = nullptr; uint64_t m_flat_cap = 0;   // the current lane's merged blocks (dbtk_ingest_align_merged; Lane::m_*)
     uint64_t* m_off = nullptr; uint64_t m_off_cap = 0;
     uint64_t m_bytes = 0, m_pairs = 0; uint32_t m_maxlen = 0;
@@ -400,7 +402,7 @@ void free_ctx(dbtk_ctx* c) {
             if (c->timed[i].beg[j]) (void)hipEventDestroy(c->timed[i].beg[j]);
             if (c->timed[i].end[j]) (void)hipEventDestroy(c->timed[i].end[j]);
         }
-    void* ptrs[] = {c->m_flat, c->m_off, c->d_ctr, c->d_pstats, c->d_accum, c->d_small, c->d_surv,
+    void* ptrs[] = {c->m_flat, c->m_off, c->d_ctr, c->d_pstats, c->d_accum, c->d_small ? c->d_small - TK_INLINE : nullptr, c->d_surv,
                     c->d_seq, c->d_off, c->d_recs, c->d_vote, c->d_epoch, c->d_hitva, c->d_hitnk, c->d_hitoff, c->d_gen, c->d_tickets,
                     c->d_qual, c->d_edge, c->d_qmask, c->d_events, c->d_nevents, c->d_walk, c->d_trecs, c->d_loci, c->d_aln, c->d_txt, c->d_txtidx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -409,7 +411,7 @@ void free_ctx(dbtk_ctx* c) {
     std::vector<dbtk_ctx::Lane*> others{&c->alt};
     for (auto& l : c->parked) others.push_back(&l);
     for (dbtk_ctx::Lane* l : others) {
-        void* aptrs[] = {l->d_small, l->d_surv, l->d_hitva, l->d_hitnk, l->d_hitoff, l->d_gen, l->d_tickets, l->d_vote, l->d_epoch, l->d_walk, l->m_flat, l->m_off};
+        void* aptrs[] = {l->d_small ? l->d_small - TK_INLINE : nullptr, l->d_surv, l->d_hitva, l->d_hitnk, l->d_hitoff, l->d_gen, l->d_tickets, l->d_vote, l->d_epoch, l->d_walk, l->m_flat, l->m_off};
         for (void* p : aptrs) if (p) (void)hipFree(p);
         if (l != &c->alt && l->stream) (void)hipStreamDestroy(l->stream);
     }
@@ -1020,10 +1022,19 @@ void switch_lane(dbtk_ctx* c) {
         c->parked.pop_front();
     }
 }
+// Every reader of the accumulators comes through here (counts, the all-reduce, reset, the caller of dbtk_ctx_accum_buffer after
+// dbtk_ctx_synchronize): the counter replicas are folded into the counters once, now, instead of at the end of every batch (a launch of
+// one wave + its gap: 14 us of a 1.2-ms step).
 hipError_t sync_all(dbtk_ctx* c) {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && c->alt.stream) e = hipStreamSynchronize(c->alt.stream);
     for (auto& l : c->parked) if (e == hipSuccess && l.stream) e = hipStreamSynchronize(l.stream);
+    if (e == hipSuccess && c->fold_pending && c->d_ctr && c->d_accum) {
+        hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, c->stream, c->d_accum + c->ntr + 2 * (uint64_t)c->g->nloci, c->d_ctr);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) c->fold_pending = false;
+    }
     return e;
 }
 dbtk_status_t timed_slot(dbtk_ctx* c, int k, int* slot) {
@@ -1071,7 +1082,11 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     if ((st = ensure(&c->d_hitva, &c->hitva_cap, tcap * 2 * nkp))) return st;
     if ((st = ensure(&c->d_hitnk, &c->hitnk_cap, tcap * 2))) return st;
     if ((st = ensure(&c->d_gen, &c->gen_cap, tcap))) return st;
-    if ((st = ensure(&c->d_tickets, &c->tickets_cap, 2 * (nchunks + 1)))) return st;  // per chunk: a ticket counter and a passed-on counter
+    // per chunk: a ticket counter and a passed-on counter — for up to three chunks in the TK_INLINE words in front of d_small, so that they
+    // and nsurv / novf / nrec are zeroed by ONE memset
+    const bool tk_inline = 2 * (nchunks + 1) <= TK_INLINE;
+    if (!tk_inline && (st = ensure(&c->d_tickets, &c->tickets_cap, 2 * (nchunks + 1)))) return st;
+    uint32_t* const tickets = tk_inline ? c->d_small - 2 * (nchunks + 1) : c->d_tickets;
     const bool walking = c->P.threading == DBTK_THREADING_V13;
     uint64_t slow_cap = 0, info_rows = 0;
     if (walking) {
@@ -1087,8 +1102,12 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         HIPCHK(hipMemsetAsync(c->d_walk, 0xFF, npairs * sizeof(uint32_t), s));  // NAN32: the pair does not reach threading
         HIPCHK(hipMemsetAsync(c->d_walk + npairs, 0, npairs * sizeof(uint32_t), s));  // walk_ret: no pair is marked WALK_PENDING
     }
-    HIPCHK(hipMemsetAsync(c->d_small, 0, 3 * sizeof(uint32_t), s));  // nsurv, novf, nrec; the error word (3) stays until it has been reported
-    HIPCHK(hipMemsetAsync(c->d_tickets, 0, 2 * (nchunks + 1) * sizeof(uint32_t), s));
+    // nsurv, novf, nrec; the error word (3) stays until it has been reported
+    if (tk_inline) HIPCHK(hipMemsetAsync(tickets, 0, (2 * (nchunks + 1) + 3) * sizeof(uint32_t), s));
+    else {
+        HIPCHK(hipMemsetAsync(c->d_small, 0, 3 * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(tickets, 0, 2 * (nchunks + 1) * sizeof(uint32_t), s));
+    }
     if (c->P.bubbles) {
         if ((st = ensure(&c->d_edge, &c->edge_cap, tcap * 2 * nkp))) return st;
         // every position of every kept mate could be novel; bounded so that the log stays < 6.4 GB
@@ -1108,6 +1127,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     a.counters = a.nmapread + c->g->nloci;
     a.ctr_rep = c->d_ctr;
     a.pstats = c->d_pstats;
+    a.sortflag = c->d_small + 6; a.hint_out = c->h_sortflag;
     a.recs = d_recs; a.rec_cap = rec_cap;
     a.vote_scratch = c->d_vote; a.vote_epoch = c->d_epoch; a.vote_rows = (uint32_t)c->vote_rows;
     a.vote_busy = reinterpret_cast<uint64_t*>(c->d_epoch + ((c->vote_rows + 1) & ~1));  // (behind the epochs, 8-byte aligned)
@@ -1163,16 +1183,13 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         if ((st = rec_end(5))) return st;
         c->d_sorted = sa.sorted;
         a.surv = sa.sorted;
-    } else {
-        HIPCHK(hipMemsetAsync(c->d_small + 6, 0, sizeof(uint32_t), s));  // "not in locus order"
-        c->d_sorted = c->d_surv;
-    }
+    } else c->d_sorted = c->d_surv;  // (the flag says "not in locus order": the encode stage cleared it)
     // Does the locus-resident probe kernel have anything to do?  Only in a batch with many survivors per locus (list in locus order, loci
     // with LOC_MIN_PAIRS pairs and more); a WGS-like batch (one survivor per locus) would pay its empty launches for nothing (40 us on a
     // 1.2-ms step).  Which kind a batch is, is known on the device only — so the survivor count and the sort flag of the batch BEFORE
     // come back through pinned words and decide for this one.  A hint, never a matter of results: the lean kernel looks up whatever
     // the locus path does not take.
-    if (c->h_sortflag) HIPCHK(hipMemcpyAsync(c->h_sortflag, c->d_small, 7 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    // (the words are written by the general resolve kernel, BatchArgs::hint_out: pinned memory is the device's to write)
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         a.t0 = (uint32_t)(ch * tcap);
         if (tm) { if ((st = timed_slot(c, 1, &e))) return st; HIPCHK(hipEventRecord(c->timed[1].beg[e], s)); }
@@ -1184,7 +1201,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             const int npl = !a.T.mz || a.edgebuf || a.qmaskbuf ? 0 : (max_read_len <= 32 * 3 + a.T.mz_m - 1 ? 3 : max_read_len <= 32 * 5 + a.T.mz_m - 1 ? 5 : 0);
             a.sel = nullptr; a.nsel = nullptr;
             // (the general resolve kernel's list: the usual-pair kernel appends to it — and, fused, the locus-resident probe kernel)
-            a.gen_list = usual ? c->d_gen : nullptr; a.ngen = usual ? c->d_tickets + (nchunks + 1) + ch : nullptr;
+            a.gen_list = usual ? c->d_gen : nullptr; a.ngen = usual ? tickets + (nchunks + 1) + ch : nullptr;
             if (npl && a.T.ldir && locus_hint) {
                 // The pairs of loci that have an image: the locus-resident kernel (dbtk_locus.h), image in LDS, one item = one locus'
                 // next LOC_CH pairs of the list; the lean kernel then takes what is left (loci without an image, pairs without a
@@ -1393,7 +1410,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         LAUNCH(k_walk_pairs, dim3(c->walk_blocks), dim3(64), s, w);
         if (tm) HIPCHK(hipEventRecord(c->timed[4].end[e], s));
     }
-    LAUNCH(k_fold_counters, dim3(1), dim3(64), s, a.counters, c->d_ctr);
+    c->fold_pending = true;  // (the counter replicas: folded by sync_all)
     HIPCHK(hipGetLastError());
     return DBTK_OK;
 }
@@ -1607,12 +1624,13 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
         if (!st) chk(hipMemsetAsync(c->d_ctr, 0, (size_t)CTR_REP * CTR_STRIDE * 8, c->stream), "memset");
         chk(hipMalloc(&c->d_pstats, DBTK_PATH_STATS * 8), "hipMalloc path statistics");
         if (!st) chk(hipMemsetAsync(c->d_pstats, 0, DBTK_PATH_STATS * 8, c->stream), "memset");
-        chk(hipMalloc(&c->d_small, 4 * SMALL_WORDS + 48 * 8), "hipMalloc small");
+        chk(hipMalloc(&c->d_small, 4 * (TK_INLINE + SMALL_WORDS) + 48 * 8), "hipMalloc small");
+        if (c->d_small) c->d_small += TK_INLINE;
         if (!getenv("DBTK_LOCUS_ALWAYS")) {  // (DBTK_LOCUS_ALWAYS=1: every batch launches the locus path: tests of small batches)
             chk(hipHostMalloc((void**)&c->h_sortflag, 64, hipHostMallocDefault), "hipHostMalloc");
             if (c->h_sortflag) { c->h_sortflag[0] = 0xFFFFFFFFu; c->h_sortflag[6] = 1u; }
         }
-        if (!st) chk(hipMemsetAsync(c->d_small, 0, 4 * SMALL_WORDS + 48 * 8, c->stream), "memset");
+        if (!st) chk(hipMemsetAsync(c->d_small - TK_INLINE, 0, 4 * (TK_INLINE + SMALL_WORDS) + 48 * 8, c->stream), "memset");
         chk(hipMalloc(&c->d_vote, (size_t)c->vote_rows * (h->nloci + 1) * 8), "hipMalloc vote scratch");
         chk(hipMalloc(&c->d_epoch, (size_t)c->vote_rows * 16), "hipMalloc epoch");
         if (st) break;
@@ -1632,12 +1650,13 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
         for (int li = 1; li < nlanes; ++li) {
             dbtk_ctx::Lane l;
             chk(hipStreamCreate(&l.stream), "hipStreamCreate");
-            chk(hipMalloc(&l.d_small, 4 * SMALL_WORDS + 48 * 8), "hipMalloc small");
+            chk(hipMalloc(&l.d_small, 4 * (TK_INLINE + SMALL_WORDS) + 48 * 8), "hipMalloc small");
+            if (l.d_small) l.d_small += TK_INLINE;
             chk(hipMalloc(&l.d_vote, (size_t)c->vote_rows * (h->nloci + 1) * 8), "hipMalloc vote scratch");
             chk(hipMalloc(&l.d_epoch, (size_t)c->vote_rows * 16), "hipMalloc epoch");
             if (li == 1) c->alt = l; else c->parked.push_back(l);
             if (st) break;
-            chk(hipMemsetAsync(l.d_small, 0, 4 * SMALL_WORDS + 48 * 8, c->stream), "memset");
+            chk(hipMemsetAsync(l.d_small - TK_INLINE, 0, 4 * (TK_INLINE + SMALL_WORDS) + 48 * 8, c->stream), "memset");
             chk(hipMemsetAsync(l.d_vote, 0, (size_t)c->vote_rows * (h->nloci + 1) * 8, c->stream), "memset");
             chk(hipMemsetAsync(l.d_epoch, 0, (size_t)c->vote_rows * 16, c->stream), "memset");
         }

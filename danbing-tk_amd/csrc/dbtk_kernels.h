@@ -211,6 +211,10 @@ struct BatchArgs {
     const uint32_t* sel;     // the lean probe kernel only: nullptr, or the chunk-relative indices of the pairs it is to look up (the pairs the
     const uint32_t* nsel;    //   locus-resident kernel, dbtk_locus.h, does not take) and their number
     uint64_t* pstats;        // nullptr, or the context's path statistics (dbtk.h: dbtk_ctx_path_stats)
+    uint32_t* sortflag;      // nullptr, or "the survivor list is in locus order" (dbtk_probe2.h: SurvSortArgs::flag): the encode stage clears it
+                             // (body_surv_key, when it runs, decides), so that a batch that is not sorted needs no memset between two kernels
+    uint32_t* hint_out;      // nullptr, or the host's pinned hint words (launch_batch: sort_hint, locus_hint): [0] survivors, [6] sort flag of this
+                             // batch, written by the general resolve kernel (a copy engine's round between two kernels cost 16 us of a 1.2-ms step)
     uint32_t vzero;          // always 0: `lane * vzero` makes an address look lane-dependent, so that a load whose value is only
                              // needed an iteration later is not turned into scalars (and waited for) right where it is issued
 };
@@ -337,7 +341,10 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     const uint32_t grp = lane >> 2, sub = lane & 3;  // pair of the tile this lane works for, sample phase
     uint32_t c_short = 0, c_sub = 0, c_nhash = 0, c_probe = 0, c_surv = 0;  // per-lane partial sums (a wave sees < 2^32 pairs)
     uint64_t c_bases = 0;
-    if (lane == 0 && x.bid() == 0) x.atomic_add(&ctr[DBTK_C_NREADS], 2 * a.npairs);  // nReads, AQ.cpp:1977
+    if (lane == 0 && x.bid() == 0) {
+        x.atomic_add(&ctr[DBTK_C_NREADS], 2 * a.npairs);  // nReads, AQ.cpp:1977
+        if (a.sortflag) *a.sortflag = 0u;
+    }
     const uint64_t ntiles = (a.npairs + K1_TP - 1) / K1_TP;
     const int lane_ = (int)lane; (void)lane_;
     // Bytes readable at a.seq.  The device entry point does not know the batch's length on the host (~0): the contract there is
@@ -1674,6 +1681,10 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     DBTK_STAMP_DECL
     const uint32_t nsurv = *a.nsurv;
     const uint32_t nslp = a.nkp >> 6;  // slots the hit buffers reserve per read
+    if (a.hint_out && x.bid() == 0 && lane == 0) {  // (a hint for the host's next launches: never a matter of results)
+        volatile uint32_t* h = a.hint_out;
+        h[0] = nsurv; h[6] = a.sortflag ? *a.sortflag : 0u;
+    }
 
     // Work items: every survivor of the chunk, or (after the usual-pair kernel) the ones it passed on.
     // Software pipeline, three deep, so that nothing is waited for in the iteration that requested it: the ticket of
