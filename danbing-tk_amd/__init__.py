@@ -265,11 +265,11 @@ class Context:
 
     def path_stats(self):
         """Which kernels took how many pairs since creation / reset (dbtk.h: DBTK_PS_*): a dict."""
-        v = (C.c_uint64 * 20)()
-        n = self._lib.L.dbtk_ctx_path_stats(self.h, v, 20)
-        v = [int(x) for x in v[:n]] + [0] * (20 - n)
+        v = (C.c_uint64 * 24)()
+        n = self._lib.L.dbtk_ctx_path_stats(self.h, v, 24)
+        v = [int(x) for x in v[:n]] + [0] * (24 - n)
         return {"probe_items": v[0:3], "probe_pairs": v[3:6], "probe_rest": v[6], "walk_items": v[7:10], "walk_pairs": v[10:13],
-                "walk_rest": v[13], "fused_done": v[14], "fused_redone": v[15], "fused_cls": v[16], "fused_inc": v[17], "walk_locus_ec": v[18], "fused_shared": v[19]}
+                "walk_rest": v[13], "fused_done": v[14], "fused_redone": v[15], "fused_cls": v[16], "fused_inc": v[17], "walk_locus_ec": v[18], "fused_shared": v[19], "lean_done": v[20]}
 
     def timers_reset(self):
         self._lib.L.dbtk_ctx_timers_reset(self.h)

@@ -50,9 +50,18 @@ __global__ void __launch_bounds__(256) k_accum_add(uint64_t* dst, const uint64_t
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
 // counters[c] += sum of its replicas; replicas back to zero
-__global__ void __launch_bounds__(64) k_fold_counters(uint64_t* counters, uint64_t* rep) {
+// (words DBTK_C_COUNT .. of a replica row: path statistics of the lean probe kernel, dbtk_probe2.h: P2_REP_*)
+__global__ void __launch_bounds__(64) k_fold_counters(uint64_t* counters, uint64_t* rep, uint64_t* pstats) {
     const uint32_t c = threadIdx.x;
-    if (c >= DBTK_C_COUNT) return;
+    static_assert(P2_REP_INC < CTR_STRIDE && P2_REP_DONE >= DBTK_C_COUNT, "spare words of a replica row");
+    if (c >= DBTK_C_COUNT) {
+        const uint32_t to = c == P2_REP_DONE ? 20u : c == P2_REP_CLS ? 16u : c == P2_REP_INC ? 17u : 0xFFFFFFFFu;
+        if (to == 0xFFFFFFFFu || !pstats) return;
+        uint64_t s = 0;
+        for (uint32_t r = 0; r < CTR_REP; ++r) s += atomicExch(reinterpret_cast<unsigned long long*>(&rep[(size_t)r * CTR_STRIDE + c]), 0ull);
+        pstats[to] += s;
+        return;
+    }
     uint64_t s = 0;
     for (uint32_t r = 0; r < CTR_REP; ++r) s += atomicExch(reinterpret_cast<unsigned long long*>(&rep[(size_t)r * CTR_STRIDE + c]), 0ull);
     if (s) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[c]), (unsigned long long)s);  // (the other lane may be folding too)
@@ -75,10 +84,10 @@ template <int NS> __global__ void __launch_bounds__(64) __attribute__((amdgpu_wa
 #ifndef DBTK_P2_WPE
 #define DBTK_P2_WPE 4  // waves per SIMD its registers are budgeted for (its LDS allows 16 waves per CU)
 #endif
-template <int NPL, int WN, bool SEL = false> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_P2_WPE, 8))) k_probe(BatchArgs a) {
+template <int NPL, int WN, bool SEL = false, bool FUSE = false> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBTK_P2_WPE, 8))) k_probe(BatchArgs a) {
     __shared__ Probe2SmemT<NPL> sm;
     DevX x{&sm};
-    body_probe2<NPL, WN, SEL>(x, a);
+    body_probe2<NPL, WN, SEL, FUSE>(x, a);
 }
 template <int NS, bool RECS, bool SEL = false> __global__ void __launch_bounds__(64) k_pair_usual(BatchArgs a) {
     __shared__ UsualSmem sm;
@@ -332,7 +341,7 @@ struct dbtk_ctx {
     std::vector<std::unordered_map<uint64_t, uint16_t>> baitDB_host;
     std::vector<dbtk_pair_rec_t> own_recs;  // record buffer when the caller passes none but -tb needs the bait-stage records
     uint64_t mz_turned = 0;       // keys in the overflow table
-    int k1_blocks = 0, probe_wpc = 32, probe2_wpc[4] = {8, 8, 8, 8};
+    int k1_blocks = 0, probe_wpc = 32, probe2_wpc[4] = {8, 8, 8, 8}, probe2f_wpc[4] = {8, 8, 8, 8};
     bool timers_on = true;
     uint32_t timers_every = 1;  // event records around the kernels of every n-th batch (8 records cost ~30 us per batch)
     uint64_t batch_no = 0;
@@ -1030,7 +1039,7 @@ hipError_t sync_all(dbtk_ctx* c) {
     if (e == hipSuccess && c->alt.stream) e = hipStreamSynchronize(c->alt.stream);
     for (auto& l : c->parked) if (e == hipSuccess && l.stream) e = hipStreamSynchronize(l.stream);
     if (e == hipSuccess && c->fold_pending && c->d_ctr && c->d_accum) {
-        hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, c->stream, c->d_accum + c->ntr + 2 * (uint64_t)c->g->nloci, c->d_ctr);
+        hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, c->stream, c->d_accum + c->ntr + 2 * (uint64_t)c->g->nloci, c->d_ctr, c->d_pstats);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e == hipSuccess) c->fold_pending = false;
@@ -1138,8 +1147,10 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     const bool usual = c->T.consistent && !c->P.trace && !c->P.bait && !c->P.bubbles;
     // ... and with no record buffer the locus-resident probe kernel resolves the usual pairs of its items itself (dbtk_locus.h: FUSE;
     // DBTK_FUSE=0: the two-kernel form, for measurements)
-    static const bool fuse_on = [] { const char* e = getenv("DBTK_FUSE"); return !e || atoi(e) != 0; }();
-    const bool fuse = usual && !d_recs && fuse_on;
+    // (DBTK_FUSE: bit 0 the locus-resident kernel's fusion, bit 1 the lean kernel's; default both)
+    static const int fuse_on = [] { const char* e = getenv("DBTK_FUSE"); return e ? atoi(e) : 3; }();
+    const bool fuse = usual && !d_recs && (fuse_on & 1);
+    const bool fuse_lean = usual && !d_recs && (fuse_on & 2);
     if (c->P.bubbles) { a.edgebuf = c->d_edge; a.events = c->d_events; a.nevents = c->d_nevents; a.events_cap = (uint32_t)std::min<uint64_t>(c->events_cap, 0xFFFFFFFFull); }
     if (c->P.bait && d_qual) { a.qual = d_qual; a.qmaskbuf = c->d_qmask; }
 #ifdef DBTK_STAMPS
@@ -1161,9 +1172,11 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     // the survivors from which a list is sorted, they are not launched at all and the encode stage's own list is used (20 us of a 1.2-ms
     // step).  A hint like the one below: the order of the list is never a matter of results.
     bool sort_hint = true, locus_hint = true;
+    uint32_t surv_hint = 0xFFFFFFFFu;  // pairs the lean probe kernel took in the batch before (no hint: "many")
     if (c->h_sortflag) {  // (both hints from ONE reading of the pinned words: the copy of the batch before may land at any time)
         volatile uint32_t* hh = c->h_sortflag;
         const uint32_t prev_surv = hh[0], prev_flag = hh[6];
+        surv_hint = hh[1];  // (pairs the lean probe kernel took)
         sort_hint = prev_flag != 0 || 2 * (uint64_t)prev_surv >= (uint64_t)SORT_MIN_PER_LOCUS * nloci;
         locus_hint = prev_flag != 0 && (uint64_t)prev_surv >= (uint64_t)LOC_MIN_PAIRS * nloci;
     }
@@ -1190,6 +1203,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     // come back through pinned words and decide for this one.  A hint, never a matter of results: the lean kernel looks up whatever
     // the locus path does not take.
     // (the words are written by the general resolve kernel, BatchArgs::hint_out: pinned memory is the device's to write)
+    bool lean_fused = false;
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         a.t0 = (uint32_t)(ch * tcap);
         if (tm) { if ((st = timed_slot(c, 1, &e))) return st; HIPCHK(hipEventRecord(c->timed[1].beg[e], s)); }
@@ -1198,7 +1212,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
             // lanes cover, none of the optional per-read extras (-bu edges, -b quality masks); otherwise the general form
             const dim3 gpr(c->num_cu * c->probe_wpc);
             const uint32_t wn = a.T.mz ? k - a.T.mz_m + 1 : 0;
-            const int npl = !a.T.mz || a.edgebuf || a.qmaskbuf ? 0 : (max_read_len <= 32 * 3 + a.T.mz_m - 1 ? 3 : max_read_len <= 32 * 5 + a.T.mz_m - 1 ? 5 : 0);
+            const int npl = !a.T.mz || a.edgebuf || a.qmaskbuf || (wn != 7 && wn != 11) ? 0 : (max_read_len <= 32 * 3 + a.T.mz_m - 1 ? 3 : max_read_len <= 32 * 5 + a.T.mz_m - 1 ? 5 : 0);
             a.sel = nullptr; a.nsel = nullptr;
             // (the general resolve kernel's list: the usual-pair kernel appends to it — and, fused, the locus-resident probe kernel)
             a.gen_list = usual ? c->d_gen : nullptr; a.ngen = usual ? tickets + (nchunks + 1) + ch : nullptr;
@@ -1249,16 +1263,31 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
                 a.sel = ia.rest; a.nsel = c->d_small + 11;
             }
             // (a wave of the lean form works through one contiguous range of the list: as many waves as are resident at once)
-            if (a.sel) {  // (the form that takes its pairs from the list the locus path left)
-                if (npl == 3 && wn == 7) LAUNCH((k_probe<3, 7, true>), dim3(c->num_cu * c->probe2_wpc[0]), dim3(64), s, a);
-                else if (npl == 3 && wn == 11) LAUNCH((k_probe<3, 11, true>), dim3(c->num_cu * c->probe2_wpc[1]), dim3(64), s, a);
-                else if (npl == 5 && wn == 7) LAUNCH((k_probe<5, 7, true>), dim3(c->num_cu * c->probe2_wpc[2]), dim3(64), s, a);
-                else LAUNCH((k_probe<5, 11, true>), dim3(c->num_cu * c->probe2_wpc[3]), dim3(64), s, a);
+            // four forms: with / without the list the locus path left (SEL), resolving the pairs its look-ups decide itself or not (FUSE)
+            lean_fused = fuse_lean && npl != 0 && (!a.sel || fuse);  // (pairs an UNFUSED locus-resident kernel took wait in their rows for the usual-pair kernel)
+            if (npl) {
+                const int vi = (npl == 3 ? 0 : 2) + (wn == 7 ? 0 : 1);
+                // blocks: eight rounds of the resident waves for a batch that leaves this kernel many pairs (see dbtk_ctx_create) — but a WGS-like
+                // batch has 100 000 survivors, three per block then, and what a block does once (its cache, its share of the counters, its entry in
+                // the general kernel's list) is then most of it (fused form, 10 M reads: 0.93 ms with 128 blocks per CU, 0.35 with 16).  So: whole
+                // rounds of the resident waves, ~32 pairs per block, by what the kernel took in the batch before (a hint, like the others: never
+                // a matter of results).
+                const int wpc_max = (lean_fused ? c->probe2f_wpc : c->probe2_wpc)[vi];
+                int wpc = wpc_max;
+                static const bool wpc_forced = getenv("DBTK_PROBE_WPC") != nullptr;
+                if (!wpc_forced) {
+                    const uint64_t resident = std::max<uint64_t>((uint64_t)wpc_max / 8, 1), per_round = resident * c->num_cu * 32;
+                    wpc = (int)(resident * std::min<uint64_t>(8, std::max<uint64_t>(1, ((uint64_t)surv_hint + per_round - 1) / per_round)));
+                }
+                const dim3 g2((uint32_t)c->num_cu * (uint32_t)wpc);
+#define DBTK_P2_LAUNCH(NPL_, WN_) \
+                do { if (a.sel && lean_fused) LAUNCH((k_probe<NPL_, WN_, true, true>), g2, dim3(64), s, a); \
+                     else if (a.sel) LAUNCH((k_probe<NPL_, WN_, true, false>), g2, dim3(64), s, a); \
+                     else if (lean_fused) LAUNCH((k_probe<NPL_, WN_, false, true>), g2, dim3(64), s, a); \
+                     else LAUNCH((k_probe<NPL_, WN_, false, false>), g2, dim3(64), s, a); } while (0)
+                if (vi == 0) DBTK_P2_LAUNCH(3, 7); else if (vi == 1) DBTK_P2_LAUNCH(3, 11); else if (vi == 2) DBTK_P2_LAUNCH(5, 7); else DBTK_P2_LAUNCH(5, 11);
+#undef DBTK_P2_LAUNCH
             }
-            else if (npl == 3 && wn == 7) LAUNCH((k_probe<3, 7>), dim3(c->num_cu * c->probe2_wpc[0]), dim3(64), s, a);
-            else if (npl == 3 && wn == 11) LAUNCH((k_probe<3, 11>), dim3(c->num_cu * c->probe2_wpc[1]), dim3(64), s, a);
-            else if (npl == 5 && wn == 7) LAUNCH((k_probe<5, 7>), dim3(c->num_cu * c->probe2_wpc[2]), dim3(64), s, a);
-            else if (npl == 5 && wn == 11) LAUNCH((k_probe<5, 11>), dim3(c->num_cu * c->probe2_wpc[3]), dim3(64), s, a);
             else if (ns <= 2) LAUNCH((k_probe_general<2>), gpr, dim3(64), s, a);
             else if (ns == 3) LAUNCH((k_probe_general<3>), gpr, dim3(64), s, a);
             else LAUNCH((k_probe_general<4>), gpr, dim3(64), s, a);
@@ -1266,7 +1295,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         if (tm) HIPCHK(hipEventRecord(c->timed[1].end[e], s));
         // RECS = false: no record buffer (-ka without -e): record emission is compiled out
         const int nsi = ns <= 2 ? 0 : (ns == 3 ? 1 : 2);
-        if (usual) {
+        if (usual && !lean_fused) {  // (the fused lean probe kernel has resolved what this kernel would, and filled the general kernel's list)
             const dim3 gu(c->usual_blocks[nsi]);
             if (tm) { if ((st = timed_slot(c, 2, &e))) return st; HIPCHK(hipEventRecord(c->timed[2].beg[e], s)); }
             if (d_recs) {
@@ -1485,6 +1514,14 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
                 if (const char* ev = getenv("DBTK_PROBE_WPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
                 c->probe2_wpc[i] = nb;
             }
+            const void* k2f[4] = {(const void*)k_probe<3, 7, false, true>, (const void*)k_probe<3, 11, false, true>, (const void*)k_probe<5, 7, false, true>, (const void*)k_probe<5, 11, false, true>};
+            for (int i = 0; i < 4; ++i) {  // (the fused forms: their own register count)
+                nb = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k2f[i], 64, 0) != hipSuccess || nb <= 0) nb = 8;
+                nb *= 8;
+                if (const char* ev = getenv("DBTK_PROBE_WPC")) { const int v = atoi(ev); if (v > 0) nb = v; }
+                c->probe2f_wpc[i] = nb;
+            }
             if (getenv("DBTK_VERBOSE")) fprintf(stderr, "k_probe<5, 7>: %d blocks per CU\n", c->probe2_wpc[2]);
             {   // the locus-resident kernel: as many workgroups as are resident (an item is short: the workgroups take them round robin)
                 const void* kl[6] = {(const void*)k_probe_locus<3, LOC_NW_XS, LOC_IMGB_XS>, (const void*)k_probe_locus<3, LOC_NW_S, LOC_IMGB_S>, (const void*)k_probe_locus<3, LOC_NW_L, LOC_IMGB_L>,
@@ -1628,7 +1665,7 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
         if (c->d_small) c->d_small += TK_INLINE;
         if (!getenv("DBTK_LOCUS_ALWAYS")) {  // (DBTK_LOCUS_ALWAYS=1: every batch launches the locus path: tests of small batches)
             chk(hipHostMalloc((void**)&c->h_sortflag, 64, hipHostMallocDefault), "hipHostMalloc");
-            if (c->h_sortflag) { c->h_sortflag[0] = 0xFFFFFFFFu; c->h_sortflag[6] = 1u; }
+            if (c->h_sortflag) { c->h_sortflag[0] = 0xFFFFFFFFu; c->h_sortflag[1] = 0xFFFFFFFFu; c->h_sortflag[6] = 1u; }
         }
         if (!st) chk(hipMemsetAsync(c->d_small - TK_INLINE, 0, 4 * (TK_INLINE + SMALL_WORDS) + 48 * 8, c->stream), "memset");
         chk(hipMalloc(&c->d_vote, (size_t)c->vote_rows * (h->nloci + 1) * 8), "hipMalloc vote scratch");

@@ -213,7 +213,7 @@ struct BatchArgs {
     uint64_t* pstats;        // nullptr, or the context's path statistics (dbtk.h: dbtk_ctx_path_stats)
     uint32_t* sortflag;      // nullptr, or "the survivor list is in locus order" (dbtk_probe2.h: SurvSortArgs::flag): the encode stage clears it
                              // (body_surv_key, when it runs, decides), so that a batch that is not sorted needs no memset between two kernels
-    uint32_t* hint_out;      // nullptr, or the host's pinned hint words (launch_batch: sort_hint, locus_hint): [0] survivors, [6] sort flag of this
+    uint32_t* hint_out;      // nullptr, or the host's pinned hint words (launch_batch: sort_hint, locus_hint): [0] survivors, [1] pairs the lean probe kernel took, [6] sort flag of this
                              // batch, written by the general resolve kernel (a copy engine's round between two kernels cost 16 us of a 1.2-ms step)
     uint32_t vzero;          // always 0: `lane * vzero` makes an address look lane-dependent, so that a load whose value is only
                              // needed an iteration later is not turned into scalars (and waited for) right where it is issued
@@ -1684,6 +1684,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     if (a.hint_out && x.bid() == 0 && lane == 0) {  // (a hint for the host's next launches: never a matter of results)
         volatile uint32_t* h = a.hint_out;
         h[0] = nsurv; h[6] = a.sortflag ? *a.sortflag : 0u;
+        h[1] = a.nsel ? *a.nsel : nsurv;  // pairs the lean probe kernel took
     }
 
     // Work items: every survivor of the chunk, or (after the usual-pair kernel) the ones it passed on.

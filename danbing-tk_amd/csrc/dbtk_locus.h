@@ -560,56 +560,7 @@ struct LocRunArgs {
 // by one, where the global-table kernel fetches a bucket per RUN of positions.  (A pair from the locus with an error or two: ~20-40.)
 constexpr uint32_t LOC_BAIL = 96;
 
-// assignTRkmc's scan (AQ.cpp:1477-1555; the literal form is assign_scan, the mask form assign_masks) for the two mates at once, a
-// mate per half-wave, lane hl of a half holding the states of the NPL consecutive positions hl * NPL ..: kn[j] = the position's
-// k-mer is known at the locus (flank or TR), tr[j] = it is a TR k-mer.  What the scan's result depends on — the first known state,
-// the number of state changes between consecutive known positions, the first two of them and the last known position before each
-// — comes from one half-wave scan (the last known position before the lane's) and five half-wave reductions.  Returns the mate's
-// verdict in every lane of its half: rm (the mate is removed: af) and ei - si (0 for a removed mate).
-template <int NPL, class X>
-DBTK_HD void assign_halves(X& x, const bool (&kn)[NPL], const bool (&tr)[NPL], uint32_t p0, uint32_t nk, const dbtk_params_t& P, bool& rm_out, uint32_t& span_out) {
-    const uint32_t hl = (uint32_t)x.lane() & 31u;
-    // (position + 1) << 1 | TR of the lane's last known position, 0: none
-    uint32_t lastk = 0, ntr_l = 0, firstk = 0xFFFFFFFFu;
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-        if (kn[j]) { lastk = ((p0 + j + 1) << 1) | (tr[j] ? 1u : 0u); if (firstk == 0xFFFFFFFFu) firstk = ((p0 + j) << 1) | (tr[j] ? 1u : 0u); }
-        ntr_l += tr[j] ? 1u : 0u;
-    }
-    uint32_t prev = x.shfl_up1(x.half_scan_max(lastk));  // ... of the lanes before this one
-    if (hl == 0) prev = 0;
-    uint32_t cnt = 0, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;  // state changes at the lane's positions; the first two as position << 8 | (last known position before + 1)
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-        if (kn[j]) {
-            const uint32_t t = tr[j] ? 1u : 0u;
-            if (prev && (prev & 1u) != t) {
-                const uint32_t key = ((p0 + j) << 8) | (prev >> 1);
-                if (cnt == 0) k1 = key; else if (cnt == 1) k2 = key;
-                ++cnt;
-            }
-            prev = ((p0 + j + 1) << 1) | t;
-        }
-    }
-    const uint32_t ntot = x.half_sum(cnt), ntr = x.half_sum(ntr_l) & 0xFFu;  // uint8_t ntr, AQ.cpp:1454
-    const uint32_t fk = ~x.half_max(~firstk);
-    const uint32_t g1 = ~x.half_max(~k1);
-    const uint32_t g2 = ~x.half_max(~(k1 == g1 ? k2 : k1));
-    const uint32_t bs = fk == 0xFFFFFFFFu ? 0u : (fk & 1u) ? 2u : 1u;
-    const uint32_t maxnt = P.max_nt;
-    // where the TR segment begins / ends at a state change: the middle of the unknown tract that ends exactly there, else the position itself
-    const uint32_t t1 = g1 >> 8, q1 = g1 & 0xFFu, t2 = g2 >> 8, q2 = g2 & 0xFFu;
-    const uint32_t e1 = q1 < t1 ? (q1 + t1) / 2 : t1, e2 = q2 < t2 ? (q2 + t2) / 2 : t2;
-    bool rm = false;
-    uint32_t span = 0;
-    if (ntot >= 2 && maxnt >= 2 && bs == 2) rm = true;  // TR-flank-TR
-    else if (ntot > maxnt) rm = true;
-    else if (ntot == 0) { if (bs != 2) rm = true; else span = nk; }
-    else if (ntot == 1) span = bs == 1 ? nk - e1 : e1;
-    else if (ntr < P.nm_tr) rm = true;
-    else span = e2 - e1;
-    rm_out = rm; span_out = span;
-}
+// (assign_halves — assignTRkmc for the two mates of a pair at once, a mate per half-wave — is in dbtk_assign.h)
 
 template <int NPL, int NW, int IMGB, bool FUSE, class X>
 DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {

@@ -30,6 +30,18 @@ namespace dbtk {
 constexpr int P2_RCH = DBTK_P2_RCH;  // runs (buckets) staged in LDS at a time (a pair of 150-bp reads has ~66: two chunks)
 constexpr int P2_ROW = 9;     // 16-byte granules per staged bucket: 8 + 1 of padding (rows on different LDS banks)
 constexpr int P2_CACHE = 128; // entries of the wave's cache of overflow look-ups
+// (FUSE) what the resolve part needs of the kernel's arguments, read from LDS where it is used: held in scalar registers across the
+// look-ups they cost the kernel its prefetched buckets (the register allocator spilt those: a spilled load is waited for where it is issued)
+struct P2FuseArgs {
+    uint64_t* counts; uint64_t* nmapread; uint64_t* kmc;
+    uint32_t* gen_list; uint32_t* ngen; uint32_t* walk_dst;
+    const uint8_t* qc;
+    uint64_t* pstats;
+    uint64_t* ctr;     // this block's row of the counter replicas (counters_of), or the counters themselves
+    uint32_t ctr_rep;  // ... which of the two: a row has CTR_STRIDE - DBTK_C_COUNT spare words, where the path statistics of this kernel go
+                       // (thousands of blocks adding to ONE word serialize: 18 ns each)
+    dbtk_params_t P;
+};
 template <int NPL>
 struct __attribute__((aligned(16))) Probe2SmemT {
     uint32_t pk[2][20];              // 2-bit stream of each mate from its 4-byte-aligned start: 16 words (+ slack)
@@ -41,7 +53,17 @@ struct __attribute__((aligned(16))) Probe2SmemT {
     };
     uint4 cache[P2_CACHE];           // {k-mer, val, aux} of overflow look-ups already made (val = NOHIT: not in the index)
     uint8_t tok[P2_CACHE];           // which lane writes an entry when several want to in one step
+    uint32_t gbuf[64];               // (FUSE) pairs for the general resolve kernel, not yet appended to its list
+    uint32_t fc[12];                 // (FUSE) this wave's sums for the counters (kept here, not in scalar registers: the kernel has none to spare)
+    P2FuseArgs fa;                   // (FUSE)
 };
+// (FUSE) the counters of the pair's locus that its TR k-mers fall on, staged in LDS where the buckets were (two 16-bit increments per
+// word), and flushed with lanes on consecutive counters: one memory-side read-modify-write per touched line instead of one per k-mer
+// (body_pair_usual has the measurements)
+constexpr uint32_t P2_HWIN = 2048;
+// spare words of a counter replica row (CTR_STRIDE = 32 words, DBTK_C_COUNT = 24 counters): the lean kernel's path statistics
+constexpr uint32_t P2_REP_DONE = 24, P2_REP_CLS = 25, P2_REP_INC = 26;
+static_assert(P2_HWIN / 2 * 4 <= sizeof(uint4) * P2_RCH * P2_ROW, "the counter window fits where the buckets were");
 
 // out[j] = min(f[j .. j + WN - 1]), j < NPL, sharing the part common to all windows (WN >= NPL)
 template <int NPL, int WN>
@@ -82,9 +104,133 @@ DBTK_HD void p2_fetch_runs(const uint32_t* rb, const MzBucket* mz, uint32_t nrun
     }
 }
 
+// (FUSE) the two ways the lean probe kernel finishes a pair itself, as functions of their own: inlined, their registers cost the look-ups
+// above them the prefetched buckets (see P2FuseArgs)
+template <int NPL> struct P2Rv { uint64_t v[NPL]; };  // look-up results of the lane's positions: val | aux << 32
+enum { P2C_QC, P2C_KF, P2C_THR, P2C_FEAS, P2C_ASGN, P2C_CLS, P2C_INC, P2C_NHASH1, P2C_DONE };  // sm.fc: a wave's share of a batch (< 2^32)
+// both mates cleared by kfilter: nothing is left to vote on (a background pair that got through subfilter on a shared repeat).  What kfilter
+// looked up before it gave up: the positions up to the (nk - cth + 1)-th miss; none for a mate with nk < cth (AQ.cpp:190-228).
+template <int NPL, class SM, class X>
+DBTK_HD_NOINLINE void p2_resolve_gone(X& x, SM& sm, P2Rv<NPL> rv, uint32_t nk) {
+    const int lane = x.lane();
+    const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5, p0 = hl * NPL, cth = sm.fa.P.cthreshold;
+    uint32_t mc = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) mc += (p0 + j < nk && (uint32_t)rv.v[j] == NOHIT) ? 1u : 0u;
+    uint32_t ex = x.wave_excl_scan(mc);
+    const uint32_t ex32 = x.bcast(ex, 32);
+    if (half) ex -= ex32;
+    uint32_t upto = 0;  // abort position + 1
+    if (nk >= cth) {
+        const uint32_t target = nk - cth + 1;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j)
+            if (p0 + j < nk && (uint32_t)rv.v[j] == NOHIT) { ++ex; if (ex == target) upto = p0 + j + 1; }
+    }
+    upto = x.half_max(upto);
+    const uint32_t looked = x.bcast(upto, 0) + x.bcast(upto, 32);
+    if (lane == 0) { sm.fc[P2C_NHASH1] += looked; sm.fc[P2C_KF] += 2; }
+}
+// the usual pair: both mates pass kfilter, every found k-mer unique to the locus v0 >> 1 — countHit needs no sort and no vote
+// (body_pair_usual has the argument); nks = k-mers of both mates, t = the pair's place in the survivor list
+template <int NPL, class SM, class X>
+DBTK_HD_NOINLINE void p2_resolve_usual(X& x, SM& sm, P2Rv<NPL> rv, uint32_t nk, uint32_t v0, uint32_t nks, uint32_t t) {
+    const int lane = x.lane();
+    const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5, p0 = hl * NPL;
+    const P2FuseArgs& fa = sm.fa;
+    auto tally = [&](int w, uint32_t v) { if (lane == 0) sm.fc[w] += v; };
+    tally(P2C_DONE, 1);
+    tally(P2C_NHASH1, nks);  // kfilter ran over both mates in full
+    const uint32_t dst = v0 >> 1;
+#if defined(DBTK_STAMPS) || defined(DBTK_LF_DIAG)
+    if (fa.P.diag & 64) return;  // diagnostic: verdict only
+#endif
+    if (fa.P.qc && fa.qc && !fa.qc[dst]) { tally(P2C_QC, 2); return; }  // AQ.cpp:2059-2062
+    if (fa.P.threading) {  // AQ.cpp:2070-2090; v1.3 (threading = 2): the walk kernels take the pair from here
+        tally(P2C_THR, 2);
+        if (fa.P.threading == DBTK_THREADING_V13 && lane == 0) fa.walk_dst[t] = dst;
+        return;
+    }
+    tally(P2C_THR, 2); tally(P2C_FEAS, 2);
+    if (fa.P.extract) return;  // AQ.cpp:2094-2099
+    tally(P2C_CLS, nks);
+    // assignTRkmc (AQ.cpp:2138-2144): the class of a found k-mer at the one locus rides with its index value
+    bool kn[NPL], tr[NPL];
+    uint32_t anyk = 0, anyt = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const uint32_t ax = (uint32_t)(rv.v[j] >> 32);
+        kn[j] = p0 + j < nk && (uint32_t)rv.v[j] != NOHIT && ax != CLS_NONE;
+        tr[j] = kn[j] && ax != CLS_FLANK;
+        anyk |= kn[j] && !tr[j] ? 1u : 0u; anyt |= tr[j] ? 1u : 0u;
+    }
+    // a mate without a TR k-mer is removed (no state change, first state flank: AQ.cpp:1531-1534), one all of whose known
+    // k-mers are TR k-mers is the TR segment from end to end: only a mate with both needs the scan
+    const uint64_t bt = x.ballot(anyt != 0), bf = x.ballot(anyk != 0);
+    const bool t0 = (uint32_t)bt != 0, t1 = (bt >> 32) != 0, f0 = (uint32_t)bf != 0, f1 = (bf >> 32) != 0;
+    bool rm = true;
+    uint32_t span = 0;
+    if ((t0 && f0) || (t1 && f1)) assign_halves<NPL>(x, kn, tr, p0, nk, fa.P, rm, span);
+    else { const bool tmate = half ? t1 : t0; rm = !tmate; span = tmate ? nk : 0u; }
+    const uint32_t rm0 = x.bcast(rm ? 1u : 0u, 0), rm1 = x.bcast(rm ? 1u : 0u, 32);
+    if (rm0 && rm1) return;
+    // accumulate (AQ.cpp:2145-2158)
+    tally(P2C_ASGN, 2 - rm0 - rm1);
+#if defined(DBTK_STAMPS) || defined(DBTK_LF_DIAG)
+    if (fa.P.diag & 128) return;  // diagnostic: no counting at all
+#endif
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const uint32_t ax = (uint32_t)(rv.v[j] >> 32);
+        if (tr[j] && !rm) { mn = ax < mn ? ax : mn; mx = ax > mx ? ax : mx; }
+    }
+    const uint32_t hmn2 = ~x.half_max(~mn), hmx2 = x.half_max(mx);
+    const uint32_t mnA = x.bcast(hmn2, 0), mnB = x.bcast(hmn2, 32), mxA = x.bcast(hmx2, 0), mxB = x.bcast(hmx2, 32);
+    const uint32_t base = mnA < mnB ? mnA : mnB, top = mxA > mxB ? mxA : mxB;
+    const uint32_t win = top >= base ? (top - base + 1 < P2_HWIN ? top - base + 1 : P2_HWIN) : 0u;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(sm.stg);
+    for (uint32_t w = (uint32_t)lane; w < (win + 1) / 2; w += 64) hist[w] = 0;
+    x.sync();
+    uint32_t ninc = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const bool hit = tr[j] && !rm;
+        if (hit) {
+            const uint32_t ax = (uint32_t)(rv.v[j] >> 32), o = ax - base;
+            if (o < win) x.lds_add(&hist[o >> 1], 1u << (16 * (o & 1)));
+            else x.atomic_add(&fa.counts[ax], 1ull);
+        }
+        ninc += (uint32_t)__builtin_popcountll(x.ballot(hit));
+    }
+    tally(P2C_INC, ninc);
+    x.sync();
+    const uint32_t span0 = x.bcast(span, 0), span1 = x.bcast(span, 32);
+#if defined(DBTK_STAMPS) || defined(DBTK_LF_DIAG)
+    if (!(fa.P.diag & 16))  // diagnostic: no per-locus atomics
+#endif
+    if (lane == 0) {
+        x.atomic_add(&fa.nmapread[dst], (uint64_t)(2 - rm0 - rm1));
+        x.atomic_add(&fa.kmc[dst], (uint64_t)span0 + span1);
+    }
+#if defined(DBTK_STAMPS) || defined(DBTK_LF_DIAG)
+    if (!(fa.P.diag & 4))  // diagnostic: no count atomics
+#endif
+    for (uint32_t i = (uint32_t)lane; i < win; i += 64) {
+        const uint32_t v = (hist[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+        if (v) x.atomic_add(&fa.counts[base + i], (uint64_t)v);
+    }
+}
+
+
 // SEL: the kernel takes the pairs a.sel lists (what the locus-resident kernel leaves) instead of the whole chunk — a compile-time
 // switch, so that the form without a list (every WGS-like batch) carries none of its registers or branches
-template <int NPL, int WN, bool SEL, class X>
+// FUSE: the kernel also RESOLVES the pairs whose look-ups decide them (what body_pair_usual, dbtk_kernels.h, does from the hit rows:
+// the usual pair — both mates pass kfilter, every found k-mer unique to one and the same locus — through QC gate, assignTRkmc
+// (assign_halves, dbtk_assign.h: the lanes hold the positions' states already) and the count increments; and the pair kfilter removes
+// altogether): such a pair writes no hit rows and no second kernel reads them.  Every other pair writes its rows as before and goes on
+// the general resolve kernel's list.  The launcher's conditions are body_pair_usual's: consistent RPGG, no records, no trace / -b / -bu.
+template <int NPL, int WN, bool SEL, bool FUSE, class X>
 DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
     typedef Probe2SmemT<NPL> SM;
     SM& sm = *x.template smem<SM>();
@@ -105,6 +251,25 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint32_t mmask = (uint32_t)((1ull << (2 * m)) - 1);
     const uint32_t p0 = hl * NPL;
+    // (FUSE) per-wave sums, flushed once at the end
+    if (FUSE && lane < 12) sm.fc[lane] = 0;
+    if (FUSE && lane == 0) {
+        sm.fa.counts = a.counts; sm.fa.nmapread = a.nmapread; sm.fa.kmc = a.kmc; sm.fa.gen_list = a.gen_list; sm.fa.ngen = a.ngen;
+        sm.fa.walk_dst = a.walk_dst; sm.fa.qc = a.T.qc; sm.fa.pstats = a.pstats; sm.fa.P = a.P;
+        sm.fa.ctr = counters_of(x, a); sm.fa.ctr_rep = a.ctr_rep ? 1u : 0u;
+    }
+    const P2FuseArgs& fa = sm.fa;
+    auto tally = [&](int w, uint32_t v) { if (lane == 0) sm.fc[w] += v; };
+    uint32_t ngb = 0;
+    auto flush_gen = [&]() {
+        x.sync();
+        uint32_t base = 0;
+        if (lane == 0) base = x.atomic_add(fa.ngen, ngb);
+        base = x.bcast(base, 0);
+        if ((uint32_t)lane < ngb) fa.gen_list[base + lane] = sm.gbuf[lane];
+        x.sync();
+        ngb = 0;
+    };
     for (uint32_t e = (uint32_t)lane; e < (uint32_t)P2_CACHE; e += 64) sm.cache[e] = uint4{0xFFFFFFFFu, 0x3FFFFFFFu, 0u, 0u};  // MZ_EMPTY
     // Three-deep fetch pipeline, all loads unconditional (clamped to something valid) so that they stay in flight:
     // while pair i is looked up, the bytes of pair i + 1 are on their way into registers, the offsets of pair i + 2
@@ -352,30 +517,89 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
                 cnt += fnd ? 1u : 0u;
                 vmx = fnd && v > vmx ? v : vmx;
                 vmn = fnd && v < vmn ? v : vmn;
-                sm.res[half][0][p0 + j] = fnd ? (uint32_t)(rv[j] >> 32) : AUX_MISS;
-                sm.res[half][1][p0 + j] = v;
+                if (!FUSE) {  // (FUSE: only once the pair is known to need its rows — the region may become the counter window)
+                    sm.res[half][0][p0 + j] = fnd ? (uint32_t)(rv[j] >> 32) : AUX_MISS;
+                    sm.res[half][1][p0 + j] = v;
+                }
             }
             const uint32_t nh = x.half_sum(cnt), hmx = x.half_max(vmx), hmn = ~x.half_max(~vmn);
             const bool uniform = T.consistent && nh && hmx == hmn && !(hmx & 1u);
-            const uint32_t row = 2 * x.uni(place_v) + half;
-            if (hl == 0) {
-                a.hithdr[row] = (uint64_t)(nh ? hmx : NOHIT) | ((uint64_t)nh << 32) | (uniform ? HDR_UNIFORM : 0ull);
-                a.hitnk[row] = nk;
-                a.hitoff[row] = o0;
-            }
-            x.sync();
-            uint4* outa = reinterpret_cast<uint4*>(a.hitaux + (size_t)row * a.nkp);
-            uint4* outv = reinterpret_cast<uint4*>(a.hitval + (size_t)row * a.nkp);
+            bool done = false;
+            if (FUSE) {
+                const uint32_t cth = fa.P.cthreshold;
+                P2Rv<NPL> rvs;
 #pragma unroll
-            for (int c = 0; c < (32 * NPL + 127) / 128; ++c) {
-                const uint32_t i4 = 32u * c + hl;
-                if (4 * i4 < nk && i4 < 8u * NPL) {
-                    outa[i4] = reinterpret_cast<const uint4*>(sm.res[half][0])[i4];
-                    if (!uniform) outv[i4] = reinterpret_cast<const uint4*>(sm.res[half][1])[i4];
+                for (int j = 0; j < NPL; ++j) rvs.v[j] = rv[j];
+                const uint32_t nk0 = x.bcast(nk, 0), nk1 = x.bcast(nk, 32), nh0 = x.bcast(nh, 0), nh1 = x.bcast(nh, 32);
+                const uint32_t v0 = x.bcast(hmx, 0), v1 = x.bcast(hmx, 32);
+                const bool u0 = x.bcast(uniform ? 1u : 0u, 0) != 0, u1 = x.bcast(uniform ? 1u : 0u, 32) != 0;
+                // kfilter (AQ.cpp:190-228) clears a mate with fewer than cth k-mers, or at its (nk - cth + 1)-th miss: iff it has fewer than cth found positions
+                const bool gone0 = nk0 < cth || nh0 < cth, gone1 = nk1 < cth || nh1 < cth;
+                if (gone0 && gone1) {
+                    p2_resolve_gone<NPL>(x, sm, rvs, nk);
+                    done = true;
+                } else if (!gone0 && !gone1 && nh0 && nh1 && u0 && u1 && v0 == v1) {
+                    p2_resolve_usual<NPL>(x, sm, rvs, nk, v0, nk0 + nk1, a.t0 + place_v);
+                    done = true;
+                } else {  // the general resolve kernel redoes this pair from its rows
+                    if (lane == 0) sm.gbuf[ngb] = a.t0 + place_v;
+                    if (++ngb == 64) flush_gen();
+                }
+            }
+            if (!done) {
+                if (FUSE) {
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) {
+                        const uint32_t v = p0 + j < nk ? (uint32_t)rv[j] : NOHIT;
+                        sm.res[half][0][p0 + j] = v != NOHIT ? (uint32_t)(rv[j] >> 32) : AUX_MISS;
+                        sm.res[half][1][p0 + j] = v;
+                    }
+                }
+                const uint32_t row = 2 * x.uni(place_v) + half;
+                if (hl == 0) {
+                    a.hithdr[row] = (uint64_t)(nh ? hmx : NOHIT) | ((uint64_t)nh << 32) | (uniform ? HDR_UNIFORM : 0ull);
+                    a.hitnk[row] = nk;
+                    a.hitoff[row] = o0;
+                }
+                x.sync();
+                uint4* outa = reinterpret_cast<uint4*>(a.hitaux + (size_t)row * a.nkp);
+                uint4* outv = reinterpret_cast<uint4*>(a.hitval + (size_t)row * a.nkp);
+#pragma unroll
+                for (int c = 0; c < (32 * NPL + 127) / 128; ++c) {
+                    const uint32_t i4 = 32u * c + hl;
+                    if (4 * i4 < nk && i4 < 8u * NPL) {
+                        outa[i4] = reinterpret_cast<const uint4*>(sm.res[half][0])[i4];
+                        if (!uniform) outv[i4] = reinterpret_cast<const uint4*>(sm.res[half][1])[i4];
+                    }
                 }
             }
         }
         DBTK_STAMP(42);  // results
+    }
+    if (FUSE) {
+        if (ngb) flush_gen();
+        x.sync();
+        if (lane == 0) {
+            uint64_t* const ctr = fa.ctr;
+            const uint32_t* f = sm.fc;
+            if (f[P2C_QC]) x.atomic_add(&ctr[DBTK_C_QCFILTERED], (uint64_t)f[P2C_QC]);
+            if (f[P2C_KF]) x.atomic_add(&ctr[DBTK_C_KMERFILTERED], (uint64_t)f[P2C_KF]);
+            if (f[P2C_THR]) x.atomic_add(&ctr[DBTK_C_THREADING], (uint64_t)f[P2C_THR]);
+            if (f[P2C_FEAS]) x.atomic_add(&ctr[DBTK_C_FEASIBLE], (uint64_t)f[P2C_FEAS]);
+            if (f[P2C_ASGN]) x.atomic_add(&ctr[DBTK_C_ASGN], (uint64_t)f[P2C_ASGN]);
+            if (f[P2C_CLS]) x.atomic_add(&ctr[DBTK_C_ALGO_CLS], (uint64_t)f[P2C_CLS]);
+            if (f[P2C_INC]) x.atomic_add(&ctr[DBTK_C_ALGO_INC], (uint64_t)f[P2C_INC]);
+            if (f[P2C_NHASH1]) { x.atomic_add(&ctr[DBTK_C_NHASH1], (uint64_t)f[P2C_NHASH1]); x.atomic_add(&ctr[DBTK_C_ALGO_PROBES], (uint64_t)f[P2C_NHASH1]); }
+            if (fa.ctr_rep) {  // (folded into the path statistics with the counters: k_fold_counters)
+                if (f[P2C_DONE]) x.atomic_add(&ctr[P2_REP_DONE], (uint64_t)f[P2C_DONE]);
+                if (f[P2C_CLS]) x.atomic_add(&ctr[P2_REP_CLS], (uint64_t)f[P2C_CLS]);
+                if (f[P2C_INC]) x.atomic_add(&ctr[P2_REP_INC], (uint64_t)f[P2C_INC]);
+            } else if (fa.pstats) {
+                if (f[P2C_DONE]) x.atomic_add(&fa.pstats[20], (uint64_t)f[P2C_DONE]);
+                if (f[P2C_CLS]) x.atomic_add(&fa.pstats[16], (uint64_t)f[P2C_CLS]);
+                if (f[P2C_INC]) x.atomic_add(&fa.pstats[17], (uint64_t)f[P2C_INC]);
+            }
+        }
     }
     DBTK_STAMP_FLUSH;
 }

@@ -402,7 +402,7 @@ int  dbtk_ctx_kernel_times(dbtk_ctx_t* ctx, const char** names, double* total_ms
 int  dbtk_ctx_table_bytes(dbtk_ctx_t* ctx, const char** names, uint64_t* bytes, int cap);
 /* Which kernels took how many pairs since the context was created / reset (diagnostic; never part of the results — the hot loop of
  * src/aQueryFasta_thread.cpp:2002-2249 has one path, this library several that must agree).  out[DBTK_PS_*]; returns words filled. */
-#define DBTK_PATH_STATS 20u
+#define DBTK_PATH_STATS 24u
 #define DBTK_PS_PROBE_ITEMS   0u  /* [3] work items (locus, <= 64 pairs) of the locus-resident probe kernel, per class of image size */
 #define DBTK_PS_PROBE_PAIRS   3u  /* [3] pairs in those items */
 #define DBTK_PS_PROBE_REST    6u  /* pairs the lean probe kernel took from the list the locus path left (incl. pairs handed back) */
@@ -414,6 +414,8 @@ int  dbtk_ctx_table_bytes(dbtk_ctx_t* ctx, const char** names, uint64_t* bytes, 
 #define DBTK_PS_FUSED_CLS    16u  /* of DBTK_C_ALGO_CLS / DBTK_C_ALGO_INC, the part that kernel did (its algorithmic bytes: 8 A + 16 I) */
 #define DBTK_PS_FUSED_INC    17u
 #define DBTK_PS_FUSED_SHARED 19u /* ... of the pairs resolved there, those with k-mers shared between loci (decided by the k-mers unique to the locus) */
+#define DBTK_PS_LEAN_DONE    20u /* pairs the LEAN probe kernel resolved itself (the usual pair, and the pair kfilter removes altogether are not counted
+                                  * here: only pairs resolved through assignTRkmc / QC / threading hand-over); its share of CLS / INC is in FUSED_CLS / _INC */
 #define DBTK_PS_WALK_LOCUS_EC 18u /* pairs the error-correcting walk took with the locus' graph image in LDS (k_walk_pairs_locus) */
 int  dbtk_ctx_path_stats(dbtk_ctx_t* ctx, uint64_t* out, int cap);
 void dbtk_ctx_timers_reset(dbtk_ctx_t* ctx);

@@ -516,11 +516,11 @@ class Emu(pkg._HostSide):
 
     def path_stats(self):
         """as Context.path_stats, over the align calls since the last call"""
-        v = (C.c_uint64 * 20)()
+        v = (C.c_uint64 * 24)()
         self.L.emu_path_stats(v)
         v = [int(x) for x in v]
         return {"probe_items": v[0:3], "probe_pairs": v[3:6], "probe_rest": v[6], "walk_items": v[7:10], "walk_pairs": v[10:13],
-                "walk_rest": v[13], "fused_done": v[14], "fused_redone": v[15], "walk_locus_ec": v[18], "fused_shared": v[19]}
+                "walk_rest": v[13], "fused_done": v[14], "fused_redone": v[15], "walk_locus_ec": v[18], "fused_shared": v[19], "lean_done": v[20]}
 
     def aln_text(self, npairs):
         """as Context.aln_text: list of (pair, dst, text)"""

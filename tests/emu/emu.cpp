@@ -807,7 +807,9 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     a.hitaux = reinterpret_cast<uint32_t*>(hitva.data()); a.hitval = a.hitaux + (size_t)tcap * 2 * a.nkp; a.hitnk = hitnk.data(); a.hitoff = hitoff.data(); a.hithdr = hitoff.data() + (size_t)tcap * 2;
     a.tcap = tcap;
     const bool usual = e->T.consistent && !p->trace && !p->bait && !p->bubbles;  // as the device launcher decides
-    const bool fuse = usual && !recs && !getenv("EMU_NO_FUSE");                  // ... and the fused form of the locus-resident probe body
+    const int fuse_bits = getenv("EMU_FUSE") ? atoi(getenv("EMU_FUSE")) : (getenv("EMU_NO_FUSE") ? 0 : 3);  // (as DBTK_FUSE: bit 0 locus-resident, bit 1 lean)
+    const bool fuse = usual && !recs && (fuse_bits & 1);                         // ... and the fused form of the locus-resident probe body
+    bool fuse_lean = usual && !recs && (fuse_bits & 2);                          // ... and of the lean one
     std::vector<uint64_t> edgebuf, qmaskbuf, qualbuf;
     uint32_t nevents = 0;
     if (p->bubbles) {
@@ -900,24 +902,25 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
             g_loc_pairs[3] += nit[3];
             a.sel = rest.data(); a.nsel = &nit[3];
         }
-        if (npl == 3 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { if (a.sel) body_probe2<3, 7, true>(x, a); else body_probe2<3, 7, false>(x, a); });
-        else if (npl == 3 && wn == 11) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { if (a.sel) body_probe2<3, 11, true>(x, a); else body_probe2<3, 11, false>(x, a); });
-        else if (npl == 5 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<5>), [&](EmuX& x) { if (a.sel) body_probe2<5, 7, true>(x, a); else body_probe2<5, 7, false>(x, a); });
-        else if (npl == 5 && wn == 11) run_grid(grid_p2, 64, sizeof(Probe2SmemT<5>), [&](EmuX& x) { if (a.sel) body_probe2<5, 11, true>(x, a); else body_probe2<5, 11, false>(x, a); });
+        if (a.sel && !fuse) fuse_lean = false;  // (pairs an unfused locus-resident body took wait in their rows for the usual-pair body)
+        if (npl == 3 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { if (a.sel && fuse_lean) body_probe2<3, 7, true, true>(x, a); else if (a.sel) body_probe2<3, 7, true, false>(x, a); else if (fuse_lean) body_probe2<3, 7, false, true>(x, a); else body_probe2<3, 7, false, false>(x, a); });
+        else if (npl == 3 && wn == 11) run_grid(grid_p2, 64, sizeof(Probe2SmemT<3>), [&](EmuX& x) { if (a.sel && fuse_lean) body_probe2<3, 11, true, true>(x, a); else if (a.sel) body_probe2<3, 11, true, false>(x, a); else if (fuse_lean) body_probe2<3, 11, false, true>(x, a); else body_probe2<3, 11, false, false>(x, a); });
+        else if (npl == 5 && wn == 7) run_grid(grid_p2, 64, sizeof(Probe2SmemT<5>), [&](EmuX& x) { if (a.sel && fuse_lean) body_probe2<5, 7, true, true>(x, a); else if (a.sel) body_probe2<5, 7, true, false>(x, a); else if (fuse_lean) body_probe2<5, 7, false, true>(x, a); else body_probe2<5, 7, false, false>(x, a); });
+        else if (npl == 5 && wn == 11) run_grid(grid_p2, 64, sizeof(Probe2SmemT<5>), [&](EmuX& x) { if (a.sel && fuse_lean) body_probe2<5, 11, true, true>(x, a); else if (a.sel) body_probe2<5, 11, true, false>(x, a); else if (fuse_lean) body_probe2<5, 11, false, true>(x, a); else body_probe2<5, 11, false, false>(x, a); });
         switch (a.nkp / 64) {
             case 1: case 2:
                 if (!npl) run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<2>(x, a); });
-                if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<2, true, false>(x, a); else if (fuse && a.sel) body_pair_usual<2, false, true>(x, a); else body_pair_usual<2, false, false>(x, a); });
+                if (usual && !(fuse_lean && npl)) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<2, true, false>(x, a); else if (fuse && a.sel) body_pair_usual<2, false, true>(x, a); else body_pair_usual<2, false, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<2>), [&](EmuX& x) { if (a.recs) body_pair<2, true>(x, a); else body_pair<2, false>(x, a); });
                 break;
             case 3:
                 if (!npl) run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<3>(x, a); });
-                if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<3, true, false>(x, a); else if (fuse && a.sel) body_pair_usual<3, false, true>(x, a); else body_pair_usual<3, false, false>(x, a); });
+                if (usual && !(fuse_lean && npl)) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<3, true, false>(x, a); else if (fuse && a.sel) body_pair_usual<3, false, true>(x, a); else body_pair_usual<3, false, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<3>), [&](EmuX& x) { if (a.recs) body_pair<3, true>(x, a); else body_pair<3, false>(x, a); });
                 break;
             default:
                 if (!npl) run_grid(grid_pair + 2, 64, sizeof(ProbeSmem), [&](EmuX& x) { body_probe<4>(x, a); });
-                if (usual) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<4, true, false>(x, a); else if (fuse && a.sel) body_pair_usual<4, false, true>(x, a); else body_pair_usual<4, false, false>(x, a); });
+                if (usual && !(fuse_lean && npl)) run_grid(grid_pair + 1, 64, sizeof(UsualSmem), [&](EmuX& x) { if (a.recs) body_pair_usual<4, true, false>(x, a); else if (fuse && a.sel) body_pair_usual<4, false, true>(x, a); else body_pair_usual<4, false, false>(x, a); });
                 run_grid(grid_pair, 64, sizeof(PairSmemT<4>), [&](EmuX& x) { if (a.recs) body_pair<4, true>(x, a); else body_pair<4, false>(x, a); });
         }
     }

@@ -2,6 +2,8 @@
 compiles for gfx950) run on the test-only SPMD emulator and compared with the
 oracle.  This is how the device logic is exercised where no GPU exists; the GPU
 suite (test_gpu_parity.py) repeats the same cases on hardware."""
+import os
+
 import numpy as np
 import pytest
 
@@ -52,12 +54,21 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
         # without trace the usual pair (one locus, >= cth hits per mate) skips the sort and the vote: same counts and totals
         p2 = abi.default_params(ksize=c.k, **kw)
         a2 = O.align(go, p2, seq, off, trace=False)
-        b2 = E.align(g, T, p2, seq, off, grid_k1=2, grid_pair=3)
         co2 = np.zeros(g.ntrkmers, np.uint64)
         np.add.at(co2, order, a2["counts_file"])
-        assert (co2 == b2["counts"]).all()
-        assert (a2["kmc"] == b2["kmc"]).all() and (a2["nmapread"] == b2["nmapread"]).all()
-        assert (a2["counters"] == b2["counters"]).all(), (a2["counters"], b2["counters"])
+        # (the probe bodies that resolve pairs themselves: both — the default —, the locus-resident one alone, the lean one alone, neither)
+        for fuse_bits in (None, "1", "2", "0"):
+            if fuse_bits is None:
+                os.environ.pop("EMU_FUSE", None)
+            else:
+                os.environ["EMU_FUSE"] = fuse_bits
+            try:
+                b2 = E.align(g, T, p2, seq, off, grid_k1=2, grid_pair=3)
+            finally:
+                os.environ.pop("EMU_FUSE", None)
+            assert (co2 == b2["counts"]).all(), fuse_bits
+            assert (a2["kmc"] == b2["kmc"]).all() and (a2["nmapread"] == b2["nmapread"]).all(), fuse_bits
+            assert (a2["counters"] == b2["counters"]).all(), (fuse_bits, a2["counters"], b2["counters"])
     general, lean, turned = E.probe_stats()  # the probe body the case is meant to exercise is the one that ran
     assert (lean > 0 and general == 0) if case in cases.LEAN_PROBE else (general > 0 and lean == 0), (general, lean)
     if case in ("shared", "spill"):
@@ -76,6 +87,7 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
         assert ps["fused_shared"] > 0  # pairs with shared k-mers decided by the k-mers unique to the locus: no sort, no vote
     if case in ("clean", "shared", "qc", "spliced", "k25"):
         assert ps["fused_done"] > 0   # the no-trace, no-record runs resolve the usual pairs inside the locus-resident probe body
+        assert ps["lean_done"] > 0    # ... and inside the lean one
     if case == "spliced":
         assert ps["fused_redone"] > 20  # ... and take back the ones that have a k-mer of the index outside the image
     E.L.emu_tables_free(T)

@@ -66,7 +66,7 @@ def child(a):
             lib.L.dbtk_debug_stamps(ctx.h, st.ctypes.data_as(abi.u64p))
             nrows = 2.0 * float(ctr[abi.C_SURVIVORS]) * (a.steps * a.rounds + 2) / a.steps  # (the stamps are not reset with the counters)
             # (lean kernel | locus-resident kernel: the two share the stamp words)
-            k2 = {43: "loop | barriers+image", 40: "fetch+pack(+windows+hashes)", 16: "minimizers | k-mers+image look-ups", 18: "level 1 | row stats+stores+queue", 41: "level 2 | queue against the index", 42: "results | item headers + commits", 1: "- | (fused) assignTRkmc + counts"}
+            k2 = {43: "loop | barriers+image", 40: "fetch+pack(+windows+hashes)", 16: "minimizers | k-mers+image look-ups", 18: "level 1 | row stats+stores+queue", 41: "level 2 | queue against the index", 42: "results | item headers + commits", 1: "- | (fused) assignTRkmc + counts", 44: "(fused) verdict + assignTRkmc | -", 45: "(fused) counter window + atomics issued | -"}
             res["stamps_cycles_per_read"] = {n: round(float(st[i]) / max(nrows, 1.0)) for i, n in k2.items()}
         out[name] = res
         del d_seq, d_off
