@@ -263,7 +263,9 @@ dbtk_status_t dbtk_thread_batch(dbtk_ctx_t* ctx, const uint8_t* seq_bytes, const
  * every result) needs params.trace or params.aln.  *n = number of results (DBTK_ERR_OVERFLOW if > cap). */
 /* ret1 / ret2 = isThreadFeasible's return codes (0 infeasible, 1 feasible, 2 feasible after correction), or
  * DBTK_WALK_NOT_EVALUATED: the pair was kept by its OTHER mate, which threads through the graph (as it stands, or after correction), and
- * nothing asked for this mate's alignment (no -a / -ae records, no params.trace) — the call site only ever uses `alned0 || alned1` (AQ.cpp:2082-2087). */
+ * nothing asked for this mate's alignment (no -a / -ae records, no params.trace) — the call site only ever uses `alned0 || alned1` (AQ.cpp:2082-2087).
+ * A mate that is not walked is not checked either: a condition only its walk would raise through the sticky error word (a walk longer than
+ * DBTK_THREAD_CAP entries) is not reported for it in this mode; with records or trace both mates are walked and checked. */
 #define DBTK_WALK_NOT_EVALUATED (-2)
 typedef struct dbtk_walk_res { uint32_t pair, dst; int8_t ret1, ret2; uint8_t pad[2]; } dbtk_walk_res_t;
 dbtk_status_t dbtk_ctx_walk_results(dbtk_ctx_t* ctx, dbtk_walk_res_t* res, dbtk_thread_rec_t* trecs, uint64_t cap, uint64_t* n);
