@@ -53,9 +53,9 @@ __global__ void __launch_bounds__(256) k_accum_add(uint64_t* dst, const uint64_t
 // (words DBTK_C_COUNT .. of a replica row: path statistics of the lean probe kernel, dbtk_probe2.h: P2_REP_*)
 __global__ void __launch_bounds__(64) k_fold_counters(uint64_t* counters, uint64_t* rep, uint64_t* pstats) {
     const uint32_t c = threadIdx.x;
-    static_assert(P2_REP_INC < CTR_STRIDE && P2_REP_DONE >= DBTK_C_COUNT, "spare words of a replica row");
+    static_assert(P2_REP_SHARED < CTR_STRIDE && P2_REP_DONE >= DBTK_C_COUNT, "spare words of a replica row");
     if (c >= DBTK_C_COUNT) {
-        const uint32_t to = c == P2_REP_DONE ? 20u : c == P2_REP_CLS ? 16u : c == P2_REP_INC ? 17u : 0xFFFFFFFFu;
+        const uint32_t to = c == P2_REP_DONE ? 20u : c == P2_REP_CLS ? 16u : c == P2_REP_INC ? 17u : c == P2_REP_SHARED ? 19u : 0xFFFFFFFFu;
         if (to == 0xFFFFFFFFu || !pstats) return;
         uint64_t s = 0;
         for (uint32_t r = 0; r < CTR_REP; ++r) s += atomicExch(reinterpret_cast<unsigned long long*>(&rep[(size_t)r * CTR_STRIDE + c]), 0ull);

@@ -36,6 +36,7 @@ struct P2FuseArgs {
     uint64_t* counts; uint64_t* nmapread; uint64_t* kmc;
     uint32_t* gen_list; uint32_t* ngen; uint32_t* walk_dst;
     const uint8_t* qc;
+    const ClsSlot* cls; uint64_t cls_mask; uint32_t cls_shift;  // the class table: (k-mer, locus) -> flank / counter (the shared-k-mer shortcut)
     uint64_t* pstats;
     uint64_t* ctr;     // this block's row of the counter replicas (counters_of), or the counters themselves
     uint32_t ctr_rep;  // ... which of the two: a row has CTR_STRIDE - DBTK_C_COUNT spare words, where the path statistics of this kernel go
@@ -62,7 +63,8 @@ struct __attribute__((aligned(16))) Probe2SmemT {
 // (body_pair_usual has the measurements)
 constexpr uint32_t P2_HWIN = 2048;
 // spare words of a counter replica row (CTR_STRIDE = 32 words, DBTK_C_COUNT = 24 counters): the lean kernel's path statistics
-constexpr uint32_t P2_REP_DONE = 24, P2_REP_CLS = 25, P2_REP_INC = 26;
+constexpr uint32_t P2_REP_DONE = 24, P2_REP_CLS = 25, P2_REP_INC = 26, P2_REP_SHARED = 27;
+constexpr uint32_t P2_SHARED_MAX = 96;  // shared positions of a pair the shortcut takes (as the locus-resident kernel's: dbtk_locus.h)
 static_assert(P2_HWIN / 2 * 4 <= sizeof(uint4) * P2_RCH * P2_ROW, "the counter window fits where the buckets were");
 
 // out[j] = min(f[j .. j + WN - 1]), j < NPL, sharing the part common to all windows (WN >= NPL)
@@ -107,7 +109,7 @@ DBTK_HD void p2_fetch_runs(const uint32_t* rb, const MzBucket* mz, uint32_t nrun
 // (FUSE) the two ways the lean probe kernel finishes a pair itself, as functions of their own: inlined, their registers cost the look-ups
 // above them the prefetched buckets (see P2FuseArgs)
 template <int NPL> struct P2Rv { uint64_t v[NPL]; };  // look-up results of the lane's positions: val | aux << 32
-enum { P2C_QC, P2C_KF, P2C_THR, P2C_FEAS, P2C_ASGN, P2C_CLS, P2C_INC, P2C_NHASH1, P2C_DONE };  // sm.fc: a wave's share of a batch (< 2^32)
+enum { P2C_QC, P2C_KF, P2C_THR, P2C_FEAS, P2C_ASGN, P2C_CLS, P2C_INC, P2C_NHASH1, P2C_DONE, P2C_VV, P2C_SHARED };  // sm.fc: a wave's share of a batch (< 2^32)
 // both mates cleared by kfilter: nothing is left to vote on (a background pair that got through subfilter on a shared repeat).  What kfilter
 // looked up before it gave up: the positions up to the (nk - cth + 1)-th miss; none for a mate with nk < cth (AQ.cpp:190-228).
 template <int NPL, class SM, class X>
@@ -223,6 +225,62 @@ DBTK_HD_NOINLINE void p2_resolve_usual(X& x, SM& sm, P2Rv<NPL> rv, uint32_t nk, 
 }
 
 
+// A pair with k-mers SHARED between loci is still locus L's — whatever order fillstats' unstable sort leaves the k-mers in — when the
+// k-mers unique to L alone decide (the argument is body_probe_locus', dbtk_locus.h: every found k-mer unique to L or shared with L in
+// its list, each mate cth unique ones, the unique ones at least as many as the shared ones): the caller has checked the counts, this
+// function asks the class table for every shared k-mer's class AT L (with a consistent RPGG "(k-mer, L) is in flankDB[L] / trKmers[L]"
+// is "L is in the k-mer's vv list") and, if all have one, resolves the pair as a usual pair of L with those classes.  What the shared
+// k-mers still cost the reference is one vv word each in fillstats (their DISTINCT number: DBTK_C_ALGO_VV, AQ.cpp:311-316).
+// The k-mers are re-made from the pair's 2-bit stream (sm.pk: every byte ACGT, the caller's condition); rsh = where the mate starts in it.
+template <int NPL, class SM, class X>
+DBTK_HD_NOINLINE bool p2_resolve_shared(X& x, SM& sm, P2Rv<NPL> rv, uint32_t nk, uint32_t rsh, uint32_t k, uint32_t L, uint32_t nshared, uint32_t nks, uint32_t t) {
+    const int lane = x.lane();
+    const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5, p0 = hl * NPL;
+    const P2FuseArgs& fa = sm.fa;
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    const uint64_t W = window_fw_clean(sm.pk[half], rsh + p0, 32), RW = revcomp2(W, 32);
+    uint64_t km[NPL];
+    bool sh[NPL], bad = false;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const uint64_t fw = (W >> (2 * (32 - k - j))) & kmask, rc = (RW >> (2 * j)) & kmask;
+        km[j] = fw < rc ? fw : rc;
+        sh[j] = p0 + j < nk && (uint32_t)rv.v[j] != NOHIT && ((uint32_t)rv.v[j] & 1u);
+        mine += sh[j] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        if (sh[j]) {
+            const uint32_t c = kl_lookup(fa.cls, fa.cls_mask, fa.cls_shift, km[j], L);
+            bad |= c == CLS_NONE;
+            rv.v[j] = (uint64_t)(2u * L) | ((uint64_t)c << 32);  // (from here on: a k-mer of L with that class)
+        }
+    }
+    if (x.ballot(bad)) return false;
+    // distinct shared k-mers of the pair (the mates overlap, a repeat repeats): every one against the ones before it
+    uint64_t* sk = reinterpret_cast<uint64_t*>(sm.stg);
+    const uint32_t at0 = x.wave_excl_scan(mine);
+    {
+        uint32_t at = at0;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) if (sh[j]) sk[at++] = km[j];
+    }
+    x.sync();
+    uint32_t dup = 0;
+    for (uint32_t e = 0; e + 1 < nshared; ++e) {
+        const uint64_t ke = sk[e];
+        uint32_t at = at0;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) if (sh[j]) { if (at > e && km[j] == ke) dup |= 1u << j; ++at; }
+    }
+    const uint32_t nvv = nshared - x.wave_sum((uint32_t)__builtin_popcount(dup));
+    x.sync();
+    if (lane == 0) { sm.fc[P2C_VV] += nvv; sm.fc[P2C_SHARED] += 1; }
+    p2_resolve_usual<NPL>(x, sm, rv, nk, 2u * L, nks, t);
+    return true;
+}
+
 // SEL: the kernel takes the pairs a.sel lists (what the locus-resident kernel leaves) instead of the whole chunk — a compile-time
 // switch, so that the form without a list (every WGS-like batch) carries none of its registers or branches
 // FUSE: the kernel also RESOLVES the pairs whose look-ups decide them (what body_pair_usual, dbtk_kernels.h, does from the hit rows:
@@ -257,6 +315,7 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
         sm.fa.counts = a.counts; sm.fa.nmapread = a.nmapread; sm.fa.kmc = a.kmc; sm.fa.gen_list = a.gen_list; sm.fa.ngen = a.ngen;
         sm.fa.walk_dst = a.walk_dst; sm.fa.qc = a.T.qc; sm.fa.pstats = a.pstats; sm.fa.P = a.P;
         sm.fa.ctr = counters_of(x, a); sm.fa.ctr_rep = a.ctr_rep ? 1u : 0u;
+        sm.fa.cls = a.T.cls; sm.fa.cls_mask = a.T.cls_mask; sm.fa.cls_shift = a.T.cls_shift;
     }
     const P2FuseArgs& fa = sm.fa;
     auto tally = [&](int w, uint32_t v) { if (lane == 0) sm.fc[w] += v; };
@@ -541,9 +600,28 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
                 } else if (!gone0 && !gone1 && nh0 && nh1 && u0 && u1 && v0 == v1) {
                     p2_resolve_usual<NPL>(x, sm, rvs, nk, v0, nk0 + nk1, a.t0 + place_v);
                     done = true;
-                } else {  // the general resolve kernel redoes this pair from its rows
-                    if (lane == 0) sm.gbuf[ngb] = a.t0 + place_v;
-                    if (++ngb == 64) flush_gen();
+                } else {
+                    if (clean && !gone0 && !gone1) {
+                        // k-mers shared between loci among the found ones: the pair may still be decided by the k-mers unique to one locus
+                        uint32_t cu = 0, cs = 0, umx = 0, umn = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int j = 0; j < NPL; ++j) {
+                            const uint32_t v = p0 + j < nk ? (uint32_t)rv[j] : NOHIT;
+                            const bool fnd = v != NOHIT, un = fnd && !(v & 1u);
+                            cu += un ? 1u : 0u; cs += fnd && !un ? 1u : 0u;
+                            umx = un && v > umx ? v : umx;
+                            umn = un && v < umn ? v : umn;
+                        }
+                        const uint32_t hu = x.half_sum(cu), hs = x.half_sum(cs), hux = x.half_max(umx), hun = ~x.half_max(~umn);
+                        const uint32_t u0n = x.bcast(hu, 0), u1n = x.bcast(hu, 32), ns = x.bcast(hs, 0) + x.bcast(hs, 32);
+                        const uint32_t x0 = x.bcast(hux, 0), x1 = x.bcast(hux, 32), n0 = x.bcast(hun, 0), n1 = x.bcast(hun, 32);
+                        if (T.consistent && ns && ns <= P2_SHARED_MAX && u0n >= cth && u1n >= cth && u0n + u1n >= ns && x0 == n0 && x1 == n1 && x0 == x1)
+                            done = p2_resolve_shared<NPL>(x, sm, rvs, nk, rsh, k, x0 >> 1, ns, nk0 + nk1, a.t0 + place_v);
+                    }
+                    if (!done) {  // the general resolve kernel redoes this pair from its rows
+                        if (lane == 0) sm.gbuf[ngb] = a.t0 + place_v;
+                        if (++ngb == 64) flush_gen();
+                    }
                 }
             }
             if (!done) {
@@ -590,14 +668,17 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
             if (f[P2C_CLS]) x.atomic_add(&ctr[DBTK_C_ALGO_CLS], (uint64_t)f[P2C_CLS]);
             if (f[P2C_INC]) x.atomic_add(&ctr[DBTK_C_ALGO_INC], (uint64_t)f[P2C_INC]);
             if (f[P2C_NHASH1]) { x.atomic_add(&ctr[DBTK_C_NHASH1], (uint64_t)f[P2C_NHASH1]); x.atomic_add(&ctr[DBTK_C_ALGO_PROBES], (uint64_t)f[P2C_NHASH1]); }
+            if (f[P2C_VV]) x.atomic_add(&ctr[DBTK_C_ALGO_VV], (uint64_t)f[P2C_VV]);
             if (fa.ctr_rep) {  // (folded into the path statistics with the counters: k_fold_counters)
                 if (f[P2C_DONE]) x.atomic_add(&ctr[P2_REP_DONE], (uint64_t)f[P2C_DONE]);
                 if (f[P2C_CLS]) x.atomic_add(&ctr[P2_REP_CLS], (uint64_t)f[P2C_CLS]);
                 if (f[P2C_INC]) x.atomic_add(&ctr[P2_REP_INC], (uint64_t)f[P2C_INC]);
+                if (f[P2C_SHARED]) x.atomic_add(&ctr[P2_REP_SHARED], (uint64_t)f[P2C_SHARED]);
             } else if (fa.pstats) {
                 if (f[P2C_DONE]) x.atomic_add(&fa.pstats[20], (uint64_t)f[P2C_DONE]);
                 if (f[P2C_CLS]) x.atomic_add(&fa.pstats[16], (uint64_t)f[P2C_CLS]);
                 if (f[P2C_INC]) x.atomic_add(&fa.pstats[17], (uint64_t)f[P2C_INC]);
+                if (f[P2C_SHARED]) x.atomic_add(&fa.pstats[19], (uint64_t)f[P2C_SHARED]);
             }
         }
     }

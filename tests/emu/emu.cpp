@@ -854,7 +854,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         std::vector<uint32_t> rest(tcap + 64, 0);
         uint32_t nit[4] = {0, 0, 0, 0};
         a.sel = nullptr; a.nsel = nullptr;
-        if (npl && a.T.ldir) {
+        if (npl && a.T.ldir && !getenv("EMU_NO_LOCUS")) {  // (EMU_NO_LOCUS: every pair through the lean body, as in a batch with few survivors per locus)
             // (three classes of workgroup by image size as on the device: up to 512, 1024, 2048 buckets; 4 waves each here)
             constexpr int EMU_IMGB_XS = LOC_HDR + (32 << 9) + (1 << 9), EMU_IMGB_S = LOC_HDR + (32 << 10) + (1 << 10), EMU_IMGB_L = LOC_HDR + (32 << LOC_LG_MAX) + (1 << LOC_LG_MAX);
             const uint32_t item_cap = tcap / LOC_CH + (uint32_t)nloci + 2;

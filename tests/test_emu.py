@@ -57,15 +57,20 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
         co2 = np.zeros(g.ntrkmers, np.uint64)
         np.add.at(co2, order, a2["counts_file"])
         # (the probe bodies that resolve pairs themselves: both — the default —, the locus-resident one alone, the lean one alone, neither)
-        for fuse_bits in (None, "1", "2", "0"):
-            if fuse_bits is None:
-                os.environ.pop("EMU_FUSE", None)
-            else:
+        # ("lean": no locus-resident body at all — a batch with few survivors per locus — so that the lean body sees every pair,
+        # those with k-mers shared between loci included)
+        for fuse_bits in (None, "1", "2", "0", "lean"):
+            os.environ.pop("EMU_FUSE", None)
+            os.environ.pop("EMU_NO_LOCUS", None)
+            if fuse_bits == "lean":
+                os.environ["EMU_NO_LOCUS"] = "1"
+            elif fuse_bits is not None:
                 os.environ["EMU_FUSE"] = fuse_bits
             try:
                 b2 = E.align(g, T, p2, seq, off, grid_k1=2, grid_pair=3)
             finally:
                 os.environ.pop("EMU_FUSE", None)
+                os.environ.pop("EMU_NO_LOCUS", None)
             assert (co2 == b2["counts"]).all(), fuse_bits
             assert (a2["kmc"] == b2["kmc"]).all() and (a2["nmapread"] == b2["nmapread"]).all(), fuse_bits
             assert (a2["counters"] == b2["counters"]).all(), (fuse_bits, a2["counters"], b2["counters"])
@@ -90,6 +95,19 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
         assert ps["lean_done"] > 0    # ... and inside the lean one
     if case == "spliced":
         assert ps["fused_redone"] > 20  # ... and take back the ones that have a k-mer of the index outside the image
+    if case in ("shared", "clean"):
+        # the lean body alone (no locus-resident body: a batch with few survivors per locus): it resolves its usual pairs itself, and in
+        # "shared" also pairs with k-mers shared between loci (the class of such a k-mer at the locus from the class table)
+        os.environ["EMU_NO_LOCUS"] = "1"
+        try:
+            E.align(g, T, abi.default_params(ksize=c.k, **{**c.param_sets[0], "okam": 0}), seq, off, grid_k1=2, grid_pair=3)
+        finally:
+            os.environ.pop("EMU_NO_LOCUS", None)
+        ps = E.path_stats()
+        print(f"{case}: lean body alone: {ps['lean_done']} pairs resolved, {ps['fused_shared']} with shared k-mers")
+        assert ps["lean_done"] > 0 and ps["fused_done"] == 0
+        if case == "shared":
+            assert ps["fused_shared"] > 0
     E.L.emu_tables_free(T)
     O.free(go)
     g.close()
