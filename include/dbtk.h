@@ -387,7 +387,9 @@ dbtk_status_t dbtk_ctx_counts(dbtk_ctx_t* ctx, uint64_t* counts, uint64_t* kmc,
 /* Device addresses + lengths of the same accumulators, for the one RCCL
  * all-reduce that replaces the reference's shared-memory atomics
  * (src/aQueryFasta_thread.cpp:2146-2158, 1887-1895) across GPUs.  All four live
- * in ONE contiguous uint64 buffer: *d_base, *n_u64 (nmapread widened to u64). */
+ * in ONE contiguous uint64 buffer: *d_base, *n_u64 (nmapread widened to u64).
+ * The buffer holds the results of every batch launched so far only after dbtk_ctx_synchronize (which also folds the kernels' private
+ * counter replicas into counters[]): a device-wide or stream synchronize of the caller's own is NOT enough. */
 dbtk_status_t dbtk_ctx_accum_buffer(dbtk_ctx_t* ctx, void** d_base, uint64_t* n_u64);
 dbtk_status_t dbtk_ctx_reset(dbtk_ctx_t* ctx);
 
