@@ -415,7 +415,7 @@ class Ingest:
 # every symbol include/dbtk.h declares (checked by the CPU test-suite)
 EXPORTS = [
     "dbtk_rpgg_load", "dbtk_rpgg_load_tr", "dbtk_rpgg_uid", "dbtk_rpgg_from_arrays", "dbtk_rpgg_free", "dbtk_rpgg_nloci", "dbtk_rpgg_ntrkmers", "dbtk_rpgg_nkeys",
-    "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
+    "dbtk_rpgg_view", "dbtk_rpgg_output_order", "dbtk_params_default", "dbtk_device_warmup", "dbtk_ctx_create", "dbtk_ctx_free", "dbtk_align_batch",
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
     "dbtk_allreduce", "dbtk_rpgg_set_index_cache", "dbtk_ctx_table_bytes", "dbtk_ctx_path_stats", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_aln_text", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
     "dbtk_thread_batch", "dbtk_ctx_walk_results", "dbtk_ctx_aln_records", "dbtk_aln_format",

@@ -34,6 +34,7 @@ struct dbtk_rpgg {
     std::vector<uint64_t> gr_cnt, gr_ks;    // PREF.graph.kmers / PREF.graph.umap (empty: no graph loaded)
     std::vector<uint8_t> gr_ms;
     // derived
+    bool order_done = false;          // out_slot / out_beg / out_kmer are made (finish_order: the loader runs it beside the index file's read)
     std::vector<uint64_t> out_slot;   // file index -> position in OUT.trkmc.ar
     std::vector<uint64_t> out_kmer;   // position -> k-mer
     std::vector<uint64_t> out_beg;    // nloci+1: first position of each locus

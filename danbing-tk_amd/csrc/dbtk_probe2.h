@@ -64,7 +64,10 @@ struct __attribute__((aligned(16))) Probe2SmemT {
 constexpr uint32_t P2_HWIN = 2048;
 // spare words of a counter replica row (CTR_STRIDE = 32 words, DBTK_C_COUNT = 24 counters): the lean kernel's path statistics
 constexpr uint32_t P2_REP_DONE = 24, P2_REP_CLS = 25, P2_REP_INC = 26, P2_REP_SHARED = 27;
-constexpr uint32_t P2_SHARED_MAX = 96;  // shared positions of a pair the shortcut takes (as the locus-resident kernel's: dbtk_locus.h)
+#ifndef DBTK_P2_SHARED_MAX
+#define DBTK_P2_SHARED_MAX 48  /* (16 / 32 / 48 / 96 measured: probe + resolve of a WGS-like step 0.477 / 0.473 / 0.455 / 0.469 ms; all-hit the same within 1 %) */
+#endif
+constexpr uint32_t P2_SHARED_MAX = DBTK_P2_SHARED_MAX;  // shared positions of a pair the shortcut takes: each costs a look-up in the class table
 static_assert(P2_HWIN / 2 * 4 <= sizeof(uint4) * P2_RCH * P2_ROW, "the counter window fits where the buckets were");
 
 // out[j] = min(f[j .. j + WN - 1]), j < NPL, sharing the part common to all windows (WN >= NPL)
@@ -318,7 +321,6 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
         sm.fa.cls = a.T.cls; sm.fa.cls_mask = a.T.cls_mask; sm.fa.cls_shift = a.T.cls_shift;
     }
     const P2FuseArgs& fa = sm.fa;
-    auto tally = [&](int w, uint32_t v) { if (lane == 0) sm.fc[w] += v; };
     uint32_t ngb = 0;
     auto flush_gen = [&]() {
         x.sync();

@@ -232,6 +232,9 @@ dbtk_status_t dbtk_rpgg_output_order(const dbtk_rpgg_t* h, uint64_t* out_slot);
 
 /* ---- context (one per GPU) ------------------------------------------------*/
 void          dbtk_params_default(dbtk_params_t* p);
+/* Optional: start the HIP runtime on `device_id` (its first call costs a few tenths of a second: library load, device context).  A caller
+ * that still has files to parse — dbtk_rpgg_load — may do this on a thread of its own meanwhile; dbtk_ctx_create does it otherwise. */
+dbtk_status_t dbtk_device_warmup(int device_id);
 dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int device_id,
                               dbtk_ctx_t** out);
 void          dbtk_ctx_free(dbtk_ctx_t* ctx);
