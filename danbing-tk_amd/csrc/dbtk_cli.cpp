@@ -265,6 +265,7 @@ void mate_fields(std::string& o, const dbtk_mate_rec_t& r) {
 
 int main(int argc, char* argv[]) {
     if (argc < 2) { usage(); return 0; }
+    double t_main; { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); t_main = t.tv_sec + 1e-9 * t.tv_nsec; }
     // big blocks come from the heap and stay there: batch buffers of tens of megabytes are grown and recycled all the time, and a
     // map / unmap per growth serialises every thread of the process on the kernel's memory-map lock
     mallopt(M_MMAP_THRESHOLD, 1 << 30);
@@ -441,6 +442,7 @@ int main(int argc, char* argv[]) {
     typedef std::unique_ptr<Batch> BatchP;
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
     const double loop_t0 = now();
+    const double t_loop = wall();
     // host threads worth starting: the hardware threads, capped by what the container may actually use (its CPU affinity and its
     // cgroup CPU quota: a 256-thread host with cpu.max = 16 cores runs 64 deflate threads four times slower each)
     auto usable_cpus = []() -> unsigned {
@@ -1507,6 +1509,7 @@ int main(int argc, char* argv[]) {
         return 0;
     }
     // ---- totals + dumps (AQ.cpp:2611-2656)
+    const double t_out = wall();
     const int nctx = (int)ctx.size();
     std::vector<uint64_t> counts(dbtk_rpgg_ntrkmers(rpgg)), kmc(nloci), counters(DBTK_C_COUNT);
     std::vector<uint32_t> nmapread(nloci);
@@ -1575,6 +1578,11 @@ int main(int argc, char* argv[]) {
         for (auto g : spent_ingests) dbtk_ingest_free(g);
         for (auto c : ctx) dbtk_ctx_free(c);
         dbtk_rpgg_free(rpgg);
+    }
+    if (getenv("DBTK_VERBOSE")) {  // where the process' wall time went (seconds since main(); the process itself started ~0.03 s earlier)
+        timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+        fprintf(stderr, "timeline: load from %.2f, tables from %.2f, batch loop from %.2f, counts + outputs from %.2f, done at %.2f\n", tl0 - t_main, tl1 - t_main,
+                t_loop - t_main, t_out - t_main, t.tv_sec + 1e-9 * t.tv_nsec - t_main);
     }
     fprintf(stderr, "all done!\n");
     fflush(stdout); fflush(stderr);

@@ -39,7 +39,7 @@ def main():
             t0 = time.perf_counter()
             r = subprocess.run([cli] + argv, cwd=d, capture_output=True, text=True, env=dict(os.environ, DBTK_VERBOSE="1", **env))
             w = time.perf_counter() - t0
-            keep = [l for l in r.stderr.splitlines() if l.startswith(("load:", "ingest:", "rpgg ", "device reader:", "total:", "tables: "))]
+            keep = [l for l in r.stderr.splitlines() if l.startswith(("load:", "ingest:", "rpgg ", "device reader:", "timeline:", "tables: "))]
             print(f"== {name}: rc {r.returncode}, {w:.2f} s wall")
             if name == "count again" and os.environ.get("CLI_E2E_ALL"):  # (every timing line the library and the command line print under DBTK_VERBOSE)
                 keep = r.stderr.splitlines()[:80]
