@@ -103,7 +103,13 @@ template <int NS, bool RECS> __global__ void __launch_bounds__(64, NS <= 3 ? 2 :
 // per-locus images of the index and the probe kernel that keeps one in LDS (dbtk_locus.h)
 __global__ void __launch_bounds__(256) k_loc_count(LocBuildArgs a) { DevX x{nullptr}; body_loc_count(x, a); }
 __global__ void __launch_bounds__(256) k_loc_scatter(LocBuildArgs a) { DevX x{nullptr}; body_loc_scatter(x, a); }
-__global__ void __launch_bounds__(64) k_loc_place(LocBuildArgs a) { DevX x{nullptr}; body_loc_place(x, a); }
+__global__ void __launch_bounds__(64) k_loc_place(LocBuildArgs a) { DevX x{nullptr}; body_loc_place(x, a); }  // (DBTK_LOC_PLACE_THREAD=1: the thread-per-locus form)
+template <int LGMAX, int LGLOW> __global__ void __launch_bounds__(64) k_loc_place_wave(LocBuildArgs a) {
+    __shared__ LocPlaceSmemT<LGMAX> sm;
+    DevX x{&sm};
+    body_loc_place_wave<LGMAX, LGLOW>(x, a);
+}
+
 __global__ void __launch_bounds__(256) k_loc_verify(LocBuildArgs a) { DevX x{nullptr}; body_loc_verify(x, a); }
 // offsets of a parsed block appended behind the merged batch's: dst[r] = src[r] + add, r = 0 .. n - 1
 __global__ void __launch_bounds__(256) k_off_rebase(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t add) {
@@ -750,6 +756,17 @@ static void write_locus_cache(dbtk_ctx* c, uint64_t fp, const std::vector<LocusD
 
 // Per-locus images of the index (dbtk_locus.h), from the finished plain index: keys per locus -> image sizes (host) -> empty images
 // -> every (key, locus) membership into its locus' image.  DBTK_LOCUS=0: do without (the global tables answer every look-up).
+// the images' placement: a wave per locus, three launches by image class (the LDS a block needs: 19 / 37 / 83 KB)
+static dbtk_status_t launch_loc_place(const LocBuildArgs& a, uint64_t nloci, hipStream_t s) {
+    static const bool per_thread = [] { const char* e = getenv("DBTK_LOC_PLACE_THREAD"); return e && atoi(e) != 0; }();
+    if (per_thread) { LAUNCH(k_loc_place, dim3((uint32_t)((nloci + 63) / 64)), dim3(64), s, a); return DBTK_OK; }
+    const dim3 g((uint32_t)std::min<uint64_t>(nloci, 8192));
+    LAUNCH((k_loc_place_wave<9, -1>), g, dim3(64), s, a);
+    LAUNCH((k_loc_place_wave<10, 9>), g, dim3(64), s, a);
+    LAUNCH((k_loc_place_wave<11, 10>), g, dim3(64), s, a);
+    return DBTK_OK;
+}
+
 dbtk_status_t build_locus_images(dbtk_ctx* c) {
     const dbtk_rpgg* g = c->g;
     hipStream_t s = c->stream;
@@ -761,6 +778,17 @@ dbtk_status_t build_locus_images(dbtk_ctx* c) {
         const dbtk_status_t lc = load_locus_cache(c, fp);
         if (lc != DBTK_ERR_FORMAT) return lc;  // loaded (DBTK_OK), or a device error; DBTK_ERR_FORMAT: no usable file: build
     }
+    static const bool verbose = getenv("DBTK_VERBOSE") != nullptr;
+    double tk0 = 0;
+    auto tk = [&](const char* what) {  // (DBTK_VERBOSE: where the build's time goes)
+        if (!verbose) return;
+        (void)hipStreamSynchronize(s);
+        timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+        const double now = t.tv_sec + 1e-9 * t.tv_nsec;
+        if (tk0 != 0) fprintf(stderr, "  images: %s %.3f s\n", what, now - tk0);
+        tk0 = now;
+    };
+    tk("");
     uint32_t *dcnt = nullptr, *dbad = nullptr;
     HIPCHK(hipMalloc(&dcnt, nloci * 4));
     HIPCHK(hipMalloc(&dbad, nloci * 4));
@@ -775,6 +803,7 @@ dbtk_status_t build_locus_images(dbtk_ctx* c) {
     std::vector<uint32_t> cnt(nloci), bad(nloci);
     HIPCHK(hipMemcpyAsync(cnt.data(), dcnt, nloci * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    tk("count");
     std::vector<LocusDir> dir(nloci);
     std::vector<uint64_t> ebeg(nloci + 1, 0);
     uint64_t at = 0, nimg = 0;
@@ -807,8 +836,11 @@ dbtk_status_t build_locus_images(dbtk_ctx* c) {
     HIPCHK(hipMemcpyAsync(debeg, ebeg.data(), (nloci + 1) * 8, hipMemcpyHostToDevice, s));
     a.dir = c->d_ldir; a.arena = c->d_limg; a.ebeg = debeg; a.ecur = dcnt; a.ekey = dekey; a.epay = depay; a.skey = dskey; a.spay = dspay;
     a.gscr = dgscr; a.gstride = gstride; a.nleft = dnleft;
+    tk("directory + allocations");
     LAUNCH(k_loc_scatter, dim3(2048), dim3(256), s, a);
-    LAUNCH(k_loc_place, dim3((uint32_t)((nloci + 63) / 64)), dim3(64), s, a);
+    tk("scatter");
+    { const dbtk_status_t stp = launch_loc_place(a, nloci, s); if (stp) return stp; }
+    tk("place");
     uint64_t nleft = 0;
     HIPCHK(hipMemcpyAsync(bad.data(), dbad, nloci * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&nleft, dnleft, 8, hipMemcpyDeviceToHost, s));
@@ -817,6 +849,7 @@ dbtk_status_t build_locus_images(dbtk_ctx* c) {
     for (uint64_t l = 0; l < nloci; ++l) if (bad[l] && dir[l].bytes) { dir[l].bytes = 0; ++nbad; }
     if (nbad) HIPCHK(hipMemcpy(c->d_ldir, dir.data(), nloci * sizeof(LocusDir), hipMemcpyHostToDevice));
     HIPCHK(hipFree(debeg)); HIPCHK(hipFree(dekey)); HIPCHK(hipFree(dskey)); HIPCHK(hipFree(depay)); HIPCHK(hipFree(dspay)); HIPCHK(hipFree(dgscr)); HIPCHK(hipFree(dnleft));
+    tk("read-back + frees");
     c->loc_left_out = nleft;
     HIPCHK(hipFree(dcnt)); HIPCHK(hipFree(dbad));
     c->limg_bytes = at; c->loc_nimg = nimg - nbad;
@@ -879,7 +912,7 @@ dbtk_status_t build_graph_images(dbtk_ctx* c) {
     a.dir = c->d_gldir; a.arena = c->d_glimg; a.ebeg = debeg; a.ecur = dcnt; a.ekey = dekey; a.epay = depay; a.skey = dskey; a.spay = dspay;
     a.gscr = dgscr; a.gstride = gstride; a.nleft = dnleft;
     LAUNCH(k_gloc_scatter, dim3(2048), dim3(256), s, a);
-    LAUNCH(k_loc_place, dim3((uint32_t)((nloci + 63) / 64)), dim3(64), s, a);
+    { const dbtk_status_t stp = launch_loc_place(a, nloci, s); if (stp) return stp; }
     uint64_t nleft = 0;
     HIPCHK(hipMemcpyAsync(bad.data(), dbad, nloci * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&nleft, dnleft, 8, hipMemcpyDeviceToHost, s));

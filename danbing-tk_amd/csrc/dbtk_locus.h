@@ -249,6 +249,132 @@ DBTK_HD void body_loc_place(X& x, const LocBuildArgs& a) {
     }
 }
 
+// The same placement by a WAVE per locus, the image being built in LDS and copied out once (round 5: one thread per locus took 0.19 s
+// of a 0.64-s table build at release scale — every word of the image and of the scratch arrays a memory round trip of its own).  What
+// differs from body_loc_place is the order of a group's keys — ascending by key instead of by where the gather left them, so that the
+// image is the same bit for bit from run to run whatever order the atomics of the passes before ran in — and with it at most which of a
+// bucket's four slots a key takes; the greedy order of the groups (largest first, then by number) and the rule for a group's displacement
+// (the smallest with which every key finds a free slot) are the same.  LGMAX: the launch takes the loci whose images have at most
+// 2^LGMAX buckets and more than 2^LGLOW (three launches by image class, like the kernels that use the images).
+template <int LGMAX>
+struct LocPlaceSmemT {
+    uint32_t bks[8u << LGMAX];     // the image's buckets as they will lie in the arena
+    uint32_t gcnt[(1u << LGMAX) + 1];  // keys per group, then the groups' first places
+    uint32_t gpos[1u << LGMAX];    // next free place of each group during the scatter
+    uint8_t disp[1u << LGMAX];
+    uint64_t gk[64];               // the keys of the group being placed
+    uint32_t gp[64];               // ... and their pay words
+};
+template <int LGMAX, int LGLOW, class X>
+DBTK_HD void body_loc_place_wave(X& x, const LocBuildArgs& a) {
+    typedef LocPlaceSmemT<LGMAX> SM;
+    SM& sm = *x.template smem<SM>();
+    const uint32_t lane = (uint32_t)x.lane();
+    for (uint32_t l = x.bid(); l < a.nloci; l += x.nblocks()) {
+        const LocusDir d = a.dir[l];
+        if (!d.bytes || d.lgnb > (uint32_t)LGMAX || (LGLOW >= 0 && d.lgnb <= (uint32_t)LGLOW)) continue;  // (uniform: one locus per wave)
+        uint32_t* w = reinterpret_cast<uint32_t*>(a.arena + 16ull * d.off16);
+        const uint32_t nb = 1u << d.lgnb, mask = nb - 1;
+        const uint64_t e0 = a.ebeg[l];
+        const uint32_t n = a.ecur[l] < (uint32_t)(a.ebeg[l + 1] - e0) ? a.ecur[l] : (uint32_t)(a.ebeg[l + 1] - e0);
+        if (n > 0xFFF0u) { if (lane == 0) a.bad[l] = 1; continue; }
+        x.sync();  // (the locus before is out of LDS)
+        for (uint32_t i = lane; i < 8 * nb; i += 64) sm.bks[i] = (i & 7) >= 4 ? LOC_EMPTY : 0u;
+        for (uint32_t i = lane; i < nb; i += 64) { sm.disp[i] = 0; sm.gcnt[i] = 0; }
+        if (lane == 0) sm.gcnt[nb] = 0;
+        x.sync();
+        // keys per group; the groups' first places (exclusive prefix sums, 64 groups at a time)
+        for (uint32_t i = lane; i < n; i += 64) { const uint64_t key = a.ekey[e0 + i]; x.lds_add(&sm.gcnt[loc_group((uint32_t)key, (uint32_t)(key >> 32), d.lgnb)], 1u); }
+        x.sync();
+        uint32_t run = 0, maxsz = 0;
+        for (uint32_t g0 = 0; g0 < nb; g0 += 64) {
+            const uint32_t c = g0 + lane < nb ? sm.gcnt[g0 + lane] : 0u;
+            const uint32_t ex = x.wave_excl_scan(c);
+            x.sync();
+            if (g0 + lane < nb) { sm.gcnt[g0 + lane] = run + ex; sm.gpos[g0 + lane] = run + ex; }
+            run += x.bcast(ex + c, 63);
+            maxsz = c > maxsz ? c : maxsz;
+        }
+        if (lane == 0) sm.gcnt[nb] = run;
+        maxsz = ~x.wave_min(~maxsz);
+        x.sync();
+        // the keys by group, in whatever order the lanes get there (skey / spay) ...
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint64_t key = a.ekey[e0 + i];
+            const uint32_t at = x.lds_add(&sm.gpos[loc_group((uint32_t)key, (uint32_t)(key >> 32), d.lgnb)], 1u);
+            a.skey[e0 + at] = key; a.spay[e0 + at] = a.epay[e0 + i];
+        }
+        x.sync();
+        // ... and within a group ascending by key (back into ekey / epay: the gathered order is not needed any more): a key's place is
+        // the number of smaller keys in its group (the keys of a locus are distinct)
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint64_t key = a.skey[e0 + i];
+            const uint32_t g = loc_group((uint32_t)key, (uint32_t)(key >> 32), d.lgnb), f = sm.gcnt[g], e = sm.gcnt[g + 1];
+            uint32_t rank = 0;
+            for (uint32_t j = f; j < e; ++j) rank += a.skey[e0 + j] < key ? 1u : 0u;
+            a.ekey[e0 + f + rank] = key; a.epay[e0 + f + rank] = a.spay[e0 + i];
+        }
+        x.sync();
+        uint32_t left = 0, bad = 0;
+        for (uint32_t cls = maxsz; cls >= 1; --cls)  // the largest groups first, while the buckets are empty
+            for (uint32_t g0 = 0; g0 < nb; g0 += 64) {
+                const uint32_t gl = g0 + lane;
+                uint64_t todo = x.ballot(gl < nb && sm.gcnt[gl < nb ? gl + 1 : 0] - sm.gcnt[gl < nb ? gl : 0] == cls);
+                while (todo) {
+                    const uint32_t g = g0 + (uint32_t)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const uint32_t f = sm.gcnt[g], sz = cls;
+                    if (sz > 64) { left += sz; continue; }  // (no group comes near that: the index answers for its keys)
+                    x.sync();
+                    if (lane < sz) { sm.gk[lane] = a.ekey[e0 + f + lane]; sm.gp[lane] = a.epay[e0 + f + lane]; }
+                    x.sync();
+                    uint32_t dd = 256;
+                    for (uint32_t d0 = 0; d0 < 256 && dd == 256; d0 += 64) {  // 64 displacements at a time: every key of the group a free slot?
+                        const uint32_t dt = d0 + lane;
+                        bool ok = true;
+                        for (uint32_t t = 0; t < sz && ok; ++t) {
+                            const uint64_t key = sm.gk[t];
+                            const uint32_t b = (loc_base((uint32_t)key, (uint32_t)(key >> 32), d.lgnb) + dt) & mask;
+                            uint32_t need = 1;
+                            for (uint32_t u = 0; u < t; ++u) {
+                                const uint64_t k2 = sm.gk[u];
+                                if (((loc_base((uint32_t)k2, (uint32_t)(k2 >> 32), d.lgnb) + dt) & mask) == b) ++need;
+                            }
+                            uint32_t fr = 0;
+                            for (int s2 = 0; s2 < 4; ++s2) fr += sm.bks[8 * b + 4 + s2] == LOC_EMPTY ? 1u : 0u;
+                            ok = fr >= need;
+                        }
+                        const uint64_t okm = x.ballot(ok);
+                        if (okm) dd = d0 + (uint32_t)__builtin_ctzll(okm);
+                    }
+                    if (dd == 256) { left += sz; continue; }  // (the group stays out of the image: the index answers for its keys)
+                    if (lane == 0) {
+                        sm.disp[g] = (uint8_t)dd;
+                        for (uint32_t t = 0; t < sz; ++t) {
+                            const uint64_t key = sm.gk[t];
+                            const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+                            const uint32_t b = (loc_base(lo, hi, d.lgnb) + dd) & mask, extra = hi >> d.lgnb;
+                            if (extra > 0xFF) { bad = 1; break; }
+                            for (int s2 = 0; s2 < 4; ++s2)
+                                if (sm.bks[8 * b + 4 + s2] == LOC_EMPTY) { sm.bks[8 * b + s2] = lo; sm.bks[8 * b + 4 + s2] = sm.gp[t] | (extra << 24); break; }
+                        }
+                    }
+                }
+            }
+        x.sync();
+        // the image, out of LDS: header, buckets (16-byte pieces), displacement bytes
+        uint32_t* bks = w + LOC_HDR / 4;
+        uint8_t* disp = reinterpret_cast<uint8_t*>(bks + 8 * nb);
+        if (lane == 0) {
+            w[0] = d.lgnb; w[1] = left; w[2] = d.trbeg; w[3] = l;
+            if (bad) a.bad[l] = 1;
+            if (left) x.atomic_add(a.nleft, (uint64_t)left);
+        }
+        for (uint32_t i = lane; i < 2 * nb; i += 64) reinterpret_cast<uint4*>(bks)[i] = reinterpret_cast<const uint4*>(sm.bks)[i];
+        for (uint32_t i = lane; i < (nb > 16 ? nb : 16u) / 4; i += 64) reinterpret_cast<uint32_t*>(disp)[i] = i < nb / 4 ? reinterpret_cast<const uint32_t*>(sm.disp)[i] : 0u;
+    }
+}
+
 // An image read from the sidecar file, checked against the index it claims to be a partition of (structure alone lets a
 // stale or bit-flipped image send TR k-mers to the wrong counter): every entry's KEY is rebuilt from (bucket, tag, extra bits,
 // displacement) and looked up in the plain index as built from the RPGG; the entry must be what body_loc_scatter would have made of the

@@ -446,7 +446,8 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
         a.ebeg = ebeg.data(); a.ecur = ecur.data(); a.ekey = ekey.data(); a.epay = epay.data(); a.skey = skey.data(); a.spay = spay.data();
         a.gscr = gscr.data(); a.gstride = gstride; a.nleft = &nleft;
         run_grid(3, 64, 0, [&](EmuX& x) { body_loc_scatter(x, a); });
-        run_grid(2, 64, 0, [&](EmuX& x) { body_loc_place(x, a); });
+        if (getenv("EMU_LOC_PLACE_THREAD")) run_grid(2, 64, 0, [&](EmuX& x) { body_loc_place(x, a); });  // (the thread-per-locus form)
+        else run_grid(3, 64, sizeof(LocPlaceSmemT<LOC_LG_MAX>), [&](EmuX& x) { body_loc_place_wave<LOC_LG_MAX, -1>(x, a); });
         g_loc_left = nleft;
         for (uint64_t l = 0; l < nloci; ++l) if (bad[l]) e->ldir[l].bytes = 0;
         T.ldir = e->ldir.data(); T.limg = reinterpret_cast<const uint8_t*>(e->limg.data());
@@ -505,7 +506,8 @@ void* emu_tables_create(const dbtk_rpgg_t* g) {
             a.ebeg = ebeg.data(); a.ecur = ecur.data(); a.ekey = ekey.data(); a.epay = epay.data(); a.skey = skey.data(); a.spay = spay.data();
             a.gscr = gscr.data(); a.gstride = gstride; a.nleft = &nleft;
             run_grid(3, 64, 0, [&](EmuX& x) { body_gloc_scatter(x, a); });
-            run_grid(2, 64, 0, [&](EmuX& x) { body_loc_place(x, a); });
+            if (getenv("EMU_LOC_PLACE_THREAD")) run_grid(2, 64, 0, [&](EmuX& x) { body_loc_place(x, a); });  // (the thread-per-locus form)
+        else run_grid(3, 64, sizeof(LocPlaceSmemT<LOC_LG_MAX>), [&](EmuX& x) { body_loc_place_wave<LOC_LG_MAX, -1>(x, a); });
             for (uint64_t l = 0; l < nloci; ++l) if (bad[l] || nleft) e->gldir[l].bytes = 0;
             T.gldir = e->gldir.data(); T.glimg = reinterpret_cast<const uint8_t*>(e->glimg.data());
         }
