@@ -124,20 +124,23 @@ def kernel_table(ktimes, alg, steps, timed_steps):
     return out
 
 
-def algorithmic_bytes(abi, ctr, walk_probes=0.0, ps=None):
+def algorithmic_bytes(abi, ctr, walk_probes=0.0, ps=None, walk=False):
     """B = 2L + 12 P + 4 V + 8 A + 16 I, split over the kernels that do the work.  `ps` (dbtk_ctx_path_stats): the part
     of A and I the fused locus-resident probe kernel did itself (it resolves the usual pairs of its items: dbtk_locus.h) is priced with
     the probe stage, where its time is."""
     fa = float(ps["fused_cls"]) if ps else 0.0
     fi = float(ps["fused_inc"]) if ps else 0.0
+    # v1.3 threading: k_pair hands a pair to the walk kernels BEFORE assignTRkmc / accumulate (dbtk_kernels.h, DBTK_STAGE_THREADING), and
+    # every count increment of the step is the walk kernels' (exact counting, AQ.cpp:2189-2194): 16 I is priced there, once
+    inc_pair = 0.0 if walk else ctr[abi.C_ALGO_INC] - fi
     return {
         "k_encode_subfilter": ctr[abi.C_BASES] + 12.0 * (ctr[abi.C_ALGO_PROBES] - ctr[abi.C_NHASH1]),
         "k_probe": 12.0 * ctr[abi.C_NHASH1] + 8.0 * fa + 16.0 * fi,
         "k_probe: look-ups only": 12.0 * ctr[abi.C_NHASH1],
-        "k_pair": 4.0 * ctr[abi.C_ALGO_VV] + 8.0 * (ctr[abi.C_ALGO_CLS] - fa) + 16.0 * (ctr[abi.C_ALGO_INC] - fi),
+        "k_pair": 4.0 * ctr[abi.C_ALGO_VV] + 8.0 * (ctr[abi.C_ALGO_CLS] - fa) + 16.0 * inc_pair,
         # the walk: one graph look-up (8 B node + 1 B edge mask, the PREF.graph.umap entry) and one TR-set look-up (8 B) per
         # k-mer of both mates of every walked pair, + 16 B per count increment
-        "k_walk_pairs": walk_probes * 17.0 + 16.0 * ctr[abi.C_ALGO_INC],
+        "k_walk_pairs": (walk_probes * 17.0 + 16.0 * ctr[abi.C_ALGO_INC]) if walk else 0.0,
     }
 
 
@@ -202,6 +205,138 @@ def pmc_mix(mix, stage):
                insts_valu=tot("SQ_INSTS_VALU:sum") / st if any("SQ_INSTS_VALU:sum" in v for v in ks.values()) else None,
                rocprof_ms=sum(v["calls"] * v["avg_ns"] for v in ks.values() if "avg_ns" in v) / st * 1e-6 if any("avg_ns" in v for v in ks.values()) else None)
     return out
+
+
+MAX_LINE = 6000  # the driver reads the last 8 001 characters of stdout: the one JSON line must fit with room
+
+
+def _r(v, sig=5):
+    """Floats to `sig` significant digits (the line is read by people and a parser, not used for arithmetic)."""
+    if isinstance(v, bool) or v is None:
+        return v
+    if isinstance(v, (float, np.floating)):
+        v = float(v)
+        return float(f"{v:.{sig}g}") if v == v and abs(v) != float("inf") else None
+    if isinstance(v, np.integer):
+        return int(v)
+    return v
+
+
+def _roof(r, formula=None):
+    if not r:
+        return None
+    o = {k: _r(r.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch", "avg_ms") if k in r}
+    if "traffic" in r:
+        o["traffic"] = _r(r.get("traffic"))
+    if r.get("traffic_source"):
+        o["traffic_source"] = str(r["traffic_source"]).split(" ")[0]
+    if "traffic_stale" in r:
+        o["traffic_stale"] = r["traffic_stale"]
+    if formula:
+        o["formula"] = formula
+    return o
+
+
+def compact_line(out):
+    """The ONE line the driver parses (< MAX_LINE characters).  Everything else — per-kernel tables of every mix, path statistics, the
+    command line's legs with their stderr lines, every reference run — goes to bench_detail.json."""
+    c = {k: _r(out[k]) for k in ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                  "vs_baseline", "dtype", "data")}
+    c["per_rank_ms_per_step"] = [_r(v, 6) for v in (out.get("per_rank_ms_per_step") or [])]
+    c["config"] = out["config"]
+    c["roofline"] = _roof(out.get("roofline"))
+    if out.get("probe_roofline"):
+        c["probe_roofline"] = _roof(out["probe_roofline"], "12*P of the k_probe launches of the timed steps / their HIP-event time (SURVEY 8d: look-ups only)")
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "usable_cpus", "kind", "host") if k in cb}
+        c["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:330]
+        if cb.get("runs"):
+            c["cpu_baseline"]["runs"] = [{"p": r["threads"], "reads_s": _r(r["value"], 4)} for r in cb["runs"]]
+        if cb.get("port"):
+            c["cpu_baseline"]["port_1core_reads_s"] = _r(cb["port"]["value"], 4)
+    else:
+        c["cpu_baseline"] = None
+    c["parity"] = out.get("parity")
+    if out.get("reduce_check") is not None:
+        c["reduce_check"] = out["reduce_check"]
+    if out.get("sustained"):
+        c["sustained_reads_s"] = _r(out["sustained"]["value"])
+    if out.get("two_lanes"):
+        c["two_lanes_reads_s"] = _r(out["two_lanes"]["value"])
+    if out.get("hbm_bytes_tables"):
+        c["hbm_bytes_tables_total"] = out["hbm_bytes_tables"].get("total")
+    mx = out.get("mixes") or {}
+    if mx:
+        cm = {}
+        for name, m in mx.items():
+            r = m.get("roofline") or {}
+            e = {"reads_s": _r(m.get("value")), "ms_per_step": _r(m.get("ms_per_step")), "dominant": r.get("kernel"), "dominant_ms": _r(r.get("avg_ms")),
+                 "frac": _r(r.get("frac"), 4)}
+            pr = m.get("probe_lookups_roofline")
+            if pr:
+                e["probe_stage_frac_lookups_only"] = _r(pr.get("frac"), 4)
+                e["probe_stage_ms"] = _r(pr.get("avg_ms"))
+            kp = (r.get("kernels") or {}).get("k_pair")
+            if kp:
+                e["k_pair_ms"] = _r(kp.get("avg_ms"))
+            if isinstance(m.get("parity"), dict):
+                e["parity_bit_exact"] = m["parity"].get("bit_exact")
+                e["parity_pairs"] = m["parity"].get("pairs")
+            cm[name] = e
+        c["mixes"] = cm
+    e2 = out.get("end_to_end") or {}
+    if e2:
+        ce = {}
+        hb = e2.get("host_buffers")
+        if hb:
+            ce["host_buffers_reads_s"] = _r(hb.get("value"))
+        ci = e2.get("cli_ingest") or {}
+        if ci:
+            ce["cli_reads"] = ci.get("reads")
+            ce["cli_first_pass_reads_s"] = _r((ci.get("device_reader") or {}).get("value"))
+            ce["cli_later_pass_reads_s"] = _r((ci.get("device_reader_again") or {}).get("value"))
+            ce["cli_same_outputs"] = ci.get("same_outputs")
+        cl = e2.get("cli") or {}
+        if cl:
+            ce["cli_8M_reads_wall_s"] = _r(cl.get("wall_s"), 4)
+            ce["cli_8M_reads_main_s"] = _r(cl.get("main_s"), 4)
+        cw = e2.get("cli_walk_emit") or {}
+        if cw:
+            rate = lambda leg: _r(_loop_rate((cw.get(leg) or {}).get("batch_loop")))
+            ce["cli_walk_reads_s"] = rate("walk")
+            ce["cli_walk_ae_gz_reads_s"] = rate("walk_ae_gz")
+            ce["aln_gz_bytes"] = cw.get("aln_gz_bytes")
+            ce["aln_gz_zlib1_bytes"] = cw.get("aln_gz_zlib1_bytes")
+            if cw.get("walk_k25"):
+                ce["cli_walk_k25_reads_s"] = rate("walk_k25")
+            wl = cw.get("walk_long") or {}
+            if wl:
+                ce["cli_walk_long_reads"] = wl.get("reads")
+                ce["cli_walk_long_first_pass_reads_s"] = _r((wl.get("merged") or {}).get("value"))
+                ce["cli_walk_long_later_pass_reads_s"] = _r((wl.get("merged_again") or {}).get("value"))
+        rl = out["config"].get("read_len", 150)
+        # a FASTA record of a 150-bp read with a short title is ~164 B; one GPU's PCIe 5.0 x16 link moves ~55 GB/s
+        ce["pcie_ceiling_reads_s"] = _r(55e9 / (rl + 14))
+        ce["note"] = ("`value` times reads already resident in HBM (contract); a FASTA feed over PCIe caps one GPU at pcie_ceiling_reads_s, "
+                      "and the drop-in command line reaches cli_first_pass / cli_later_pass (file in /dev/shm, batch loop only)")
+        c["end_to_end"] = ce
+    c["bench_wall_s"] = _r(out.get("bench_wall_s"), 4)
+    c["detail"] = "bench_detail.json"
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) >= MAX_LINE:  # never lose the contract's fields to a long note
+        for k in ("end_to_end", "mixes"):
+            if len(line) < MAX_LINE:
+                break
+            c.pop(k, None)
+            line = json.dumps(c, separators=(",", ":"))
+    return line
+
+
+def _loop_rate(batch_loop):
+    """reads/s of the command line's batch loop from its 'ingest: … (12.34 M reads/s)' line."""
+    m = re.search(r"\(([0-9.]+) M reads/s\)", batch_loop or "")
+    return float(m.group(1)) * 1e6 if m else None
 
 
 def usable_cpus():
@@ -491,12 +626,17 @@ def main():
     # ---- roofline (this rank): algorithmic bytes of SURVEY.md 8(d) per launch / HIP-event time
     ctr = local_ctr.astype(np.float64)
     timed_steps = (args.steps + args.timer_every - 1) // max(args.timer_every, 1) if args.timer_every > 1 else args.steps
-    table = kernel_table(ktimes, algorithmic_bytes(abi, ctr), args.steps, timed_steps)
+    ps0 = ctx.path_stats()  # (reset with the accumulators after the warm-up: the timed steps' pairs only)
+    table = kernel_table(ktimes, algorithmic_bytes(abi, ctr, ps=ps0), args.steps, timed_steps)
     dom = max((k for k in table if ":" not in k), key=lambda k: table[k]["avg_ms"] * table[k]["launches"])
     roof = roofline_of(dom, table)
     traffic, traffic_src, stale = pmc_traffic(dom, table, ctr[abi.C_BASES] / max(table[dom]["launches"], 1))
     roof.update(traffic=traffic, traffic_source=traffic_src, traffic_stale=stale, kernels=table)
-    probe_roof = roofline_of("k_probe", table) if "k_probe" in table else None
+    # the contract's probe figure: 12 B per index look-up of kfilter, nothing else, over the probe stage's time; the same stage
+    # priced with the classify / count work the fused kernel also does is roofline.kernels["k_probe"] in the detail file
+    probe_roof = roofline_of("k_probe: look-ups only", table) if "k_probe" in table else None
+    if probe_roof:
+        probe_roof["kernel"] = "k_probe"
 
     sustained = None
     if solo and args.sustain_seconds > 0:
@@ -551,6 +691,8 @@ def main():
                                         steps=args.mix_steps, roofline=dict(roofline_of(doma, ta), kernels=ta),
                                         path=dict(psa, note="pairs per step x steps + warm-up: which kernels took them (dbtk_ctx_path_stats); fused_done = pairs the "
                                                             "locus-resident probe kernel resolved itself (no hit rows, no second kernel)"),
+                                        probe_lookups_roofline=dict(roofline_of("k_probe: look-ups only", ta), kernel="k_probe",
+                                                                    formula="12 P / stage time (SURVEY 8d: the contract's probe figure)") if "k_probe" in ta else None,
                                         probe_roofline=dict(roofline_of("k_probe", ta), profiled=pmc_mix("all_hit", "k_probe"),
                                                             traffic=(pmc_mix("all_hit", "k_probe") or {}).get("traffic"))
                                         if "k_probe" in ta else None)
@@ -568,7 +710,7 @@ def main():
                 dtw = time_steps(ctxw, lambda: ctxw.align_device(d_ah.data_ptr(), d_aho.data_ptr(), mp, rlen), args.mix_steps, 2)
                 cw = ctxw.counters().astype(np.float64)
                 walked_kmers = cw[abi.C_THREADING] * (rlen - 21 + 1)  # k-mers of the reads that entered threading
-                tw = kernel_table(ctxw.kernel_times(), algorithmic_bytes(abi, cw, walked_kmers), args.mix_steps, args.mix_steps)
+                tw = kernel_table(ctxw.kernel_times(), algorithmic_bytes(abi, cw, walked_kmers, ps=ctxw.path_stats(), walk=True), args.mix_steps, args.mix_steps)
                 domw = max((k for k in tw if ":" not in k), key=lambda k: tw[k]["avg_ms"] * tw[k]["launches"])
                 mixes["walk_gc85_3"] = dict(workload=f"{2 * mp} reads per step, 100 % of pairs from loci, --v13-threading -gc 85 3 -k 21 -kf 4 1 -cth 45 -ka",
                                             value=2 * mp * args.mix_steps / dtw, unit="reads/s", ms_per_step=dtw / args.mix_steps * 1e3,
@@ -600,7 +742,7 @@ def main():
                 ctx.timers_enable(1)
                 dtg = time_steps(ctx, lambda: ctx.align_device(d_g.data_ptr(), d_go.data_ptr(), mp, rlen), args.mix_steps, 2)
                 cg = ctx.counters().astype(np.float64)
-                tg = kernel_table(ctx.kernel_times(), algorithmic_bytes(abi, cg), args.mix_steps, args.mix_steps)
+                tg = kernel_table(ctx.kernel_times(), algorithmic_bytes(abi, cg, ps=ctx.path_stats()), args.mix_steps, args.mix_steps)
                 domg = max((k for k in tg if ":" not in k), key=lambda k: tg[k]["avg_ms"] * tg[k]["launches"])
                 mixes["genome_like"] = dict(workload=f"{2 * mp} reads per step: the headline mix ({args.hit_frac:.0%} of pairs from loci) with 15 % of the background "
                                                      f"pairs carrying, in each mate, a 64-base repeat shared with a locus over a sampled window, -k 21 -kf 4 1 -cth 45 -ka",
@@ -632,7 +774,7 @@ def main():
                 ctx25.timers_enable(1)
                 dt25 = time_steps(ctx25, lambda: ctx25.align_device(d_s25.data_ptr(), d_o25.data_ptr(), kp, rlen), args.mix_steps, 2)
                 c25 = ctx25.counters().astype(np.float64)
-                t25 = kernel_table(ctx25.kernel_times(), algorithmic_bytes(abi, c25, c25[abi.C_THREADING] * (rlen - 25 + 1)), args.mix_steps, args.mix_steps)
+                t25 = kernel_table(ctx25.kernel_times(), algorithmic_bytes(abi, c25, c25[abi.C_THREADING] * (rlen - 25 + 1), ps=ctx25.path_stats(), walk=True), args.mix_steps, args.mix_steps)
                 dom25 = max((k for k in t25 if ":" not in k), key=lambda k: t25[k]["avg_ms"] * t25[k]["launches"])
                 mixes["walk_k25_gc85_3"] = dict(workload=f"synthetic release-scale RPGG at k = 25 ({args.nloci} loci, {arrs25.nkeys} index keys), {2 * kp} reads per step, "
                                                          f"100 % of pairs from loci, --v13-threading -gc 85 3 -k 25 -kf 4 1 -cth 45 -ka",
@@ -873,7 +1015,16 @@ def main():
             "roofline": roof, "probe_roofline": probe_roof, "hbm_bytes_tables": hbm_tables, "reduce_check": reduce_check, "sustained": sustained, "mixes": mixes, "end_to_end": e2e, "cpu_baseline": cpu, "parity": parity,
             "two_lanes": two_lanes, "bench_wall_s": time.time() - t_start,
         }
-        print(json.dumps(out), flush=True)
+        line = compact_line(out)
+        detail = os.environ.get("DBTK_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+        try:
+            with open(detail, "w") as fh:
+                json.dump(out, fh)
+            log(f"detail (mixes, per-kernel tables, end-to-end legs, reference runs): {detail}")
+        except OSError as e:
+            log(f"could not write {detail}: {e}")
+        assert len(line) < MAX_LINE, f"bench line is {len(line)} characters: the driver reads the last 8 000 of stdout"
+        print(line, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -6,6 +6,7 @@
 // device half of include/dbtk.h.  There is no host execution path: without a
 // HIP device dbtk_ctx_create fails with DBTK_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and enum values only: the library itself is dlopen()ed by dbtk_allreduce
 #include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
@@ -2217,11 +2218,15 @@ void dbtk_ctx_timers_reset(dbtk_ctx_t* c) {
 dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n) {
     if (!ctxs || n <= 0) { set_error("null argument"); return DBTK_ERR_ARG; }
     if (n == 1) return DBTK_OK;
-    typedef void* comm_t;
-    typedef int (*commInitAll_t)(comm_t*, int, const int*);
-    typedef int (*allReduce_t)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
-    typedef int (*group_t)(void);
-    typedef int (*commDestroy_t)(comm_t);
+    // RCCL is bound at run time (dlopen: a one-GPU caller needs no librccl), but its TYPES come from <rccl/rccl.h>: the function
+    // pointer types are decltype()s of the header's declarations and the enum values the header's own, so a changed signature or
+    // renumbered ncclDataType_t is a compile error here, not a silently wrong sum on the first 8-GPU run.
+    typedef ncclComm_t comm_t;
+    typedef decltype(&ncclCommInitAll) commInitAll_t;
+    typedef decltype(&ncclAllReduce) allReduce_t;
+    typedef decltype(&ncclGroupStart) group_t;
+    typedef decltype(&ncclCommDestroy) commDestroy_t;
+    static_assert(sizeof(uint64_t) == 8, "the accumulators are summed as ncclUint64");
     for (int i = 0; i < n; ++i) {
         if (ctxs[i]->n_accum != ctxs[0]->n_accum) { set_error("contexts belong to different RPGGs"); return DBTK_ERR_ARG; }
         HIPCHK(hipSetDevice(ctxs[i]->device));
@@ -2263,15 +2268,14 @@ dbtk_status_t dbtk_allreduce(dbtk_ctx_t** ctxs, int n) {
         std::vector<comm_t> comms(nd);
         std::vector<int> devs(nd);
         for (int q = 0; q < nd; ++q) devs[q] = ctxs[rep[q]]->device;
-        if (commInitAll(comms.data(), nd, devs.data()) != 0) { set_error("ncclCommInitAll failed"); return DBTK_ERR_HIP; }
-        const int ncclUint64 = 5, ncclSum = 0;
-        rc = groupStart();
+        if (commInitAll(comms.data(), nd, devs.data()) != ncclSuccess) { set_error("ncclCommInitAll failed"); return DBTK_ERR_HIP; }
+        rc = (int)groupStart();
         for (int q = 0; q < nd && !rc; ++q) {
             dbtk_ctx* c = ctxs[rep[q]];
             (void)hipSetDevice(c->device);
-            rc = allReduce(c->d_accum, c->d_accum, c->n_accum, ncclUint64, ncclSum, comms[q], c->stream);
+            rc = (int)allReduce(c->d_accum, c->d_accum, c->n_accum, ncclUint64, ncclSum, comms[q], c->stream);
         }
-        rc |= groupEnd();
+        rc |= (int)groupEnd();
         for (int q = 0; q < nd; ++q) {
             (void)hipSetDevice(ctxs[rep[q]]->device);
             (void)hipStreamSynchronize(ctxs[rep[q]]->stream);

@@ -725,11 +725,23 @@ def test_bench_collective_path_on_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
            str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--nloci", "3000", "--reads", "400000",
            "--mix-reads", "0", "--no-e2e", "--ref-reads", "0", "--cpu-seconds", "4", "--parity-pairs", "30000"]
-    env = dict(os.environ, DBTK_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="dbtk_bench_"), "detail.json")
+    env = dict(os.environ, DBTK_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), DBTK_BENCH_DETAIL=detail)
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert len(line) < 6000 and r.stdout.rstrip().endswith(line)  # the driver parses the LAST line out of an 8 000-character tail of stdout
     d = json.loads(line)
+    full = json.load(open(detail))  # per-kernel tables and everything else: the side file
+    assert full["roofline"]["kernels"] and full["value"] == pytest.approx(d["value"], rel=1e-3)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in d["cpu_baseline"], key
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["parity"] and d["parity"]["bit_exact"] and d["parity"]["pairs"] >= 30000
     assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
@@ -750,12 +762,13 @@ def test_bench_two_ranks_on_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
            str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nloci", "2000", "--reads", "120000",
            "--hit-frac", "0.5", "--mix-reads", "0", "--no-e2e", "--ref-reads", "0", "--cpu-seconds", "0"]
-    env = dict(os.environ, DBTK_BENCH_ALL_ON_DEVICE0="1", DBTK_BENCH_REDUCE_CHECK="1")
+    import tempfile
+    env = dict(os.environ, DBTK_BENCH_ALL_ON_DEVICE0="1", DBTK_BENCH_REDUCE_CHECK="1", DBTK_BENCH_DETAIL=os.path.join(tempfile.mkdtemp(prefix="dbtk_bench_"), "detail.json"))
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"])  # (every rank's own time: a first multi-GPU run is diagnosable from the line)
+    assert len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"], rel=1e-3)  # (every rank's own time: a first multi-GPU run is diagnosable from the line)
     assert d["reduce_check"] == dict(ranks=2, steps=2, pairs_per_rank=60000, bit_exact=True)
 
 

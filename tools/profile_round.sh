@@ -32,19 +32,24 @@ done
 python3 tools/pmc_json.py gpurun_out/${tag}_pmc.json "rocprofv3 --pmc <set> -- $HEAD  |  mixes: $MIX --only-mix <mix>" gpurun_out/pmcH?_$tag "${args[@]}" > /dev/null
 cp gpurun_out/${tag}_pmc.json profiles/${tag}_pmc.json
 STATS="python3 bench.py --cpu-seconds 0 --ref-reads 0 --mix-reads 0 --no-e2e --sustain-seconds 0 --no-extra-lanes"  # (one lane: a kernel's duration must not include its neighbour's)
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- $STATS > gpurun_out/${tag}_stats_bench.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- $STATS > gpurun_out/${tag}_stats_bench_line.json 2> /dev/null
 cp $(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats.csv
 rm -rf gpurun_out/prof_$tag gpurun_out/pmcH?_$tag gpurun_out/pmcM_*_$tag
 head -8 gpurun_out/${tag}_kernel_stats.csv; for mix in all_hit walk k25; do echo "== $mix"; grep -E "walk|probe|pair|encode" gpurun_out/${tag}_mix_${mix}_kernel_stats.csv | cut -d, -f1-4 | head -12; done
 fi
 [ "$what" = prof ] && exit 0
-python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.log
+# the ONE line the driver parses -> <tag>_bench_line.json; everything else (per-kernel tables, mixes, CLI legs) -> <tag>_bench.json
+DBTK_BENCH_DETAIL=gpurun_out/${tag}_bench.json python3 bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.log
 tail -14 gpurun_out/${tag}_bench.log
 python3 - <<PY
 import json
+line = open("gpurun_out/${tag}_bench_line.json").read().strip().splitlines()[-1]
+print("bench line:", len(line), "characters")
+c = json.loads(line)
+print({k: c[k] for k in ("value", "ms_per_step")}, c["roofline"], c.get("cpu_baseline", {}).get("value"))
 d = json.load(open("gpurun_out/${tag}_bench.json"))
-print({k: d[k] for k in ("value", "ms_per_step")}, d["roofline"]["traffic"], d["roofline"].get("traffic_stale"))
 for k, v in (d.get("mixes") or {}).items():
     if isinstance(v, dict) and "ms_per_step" in v:
-        print(k, round(v["ms_per_step"], 2), "ms/step", round(v["value"] / 1e6, 1), "M reads/s")
+        print(k, round(v["ms_per_step"], 2), "ms/step", round(v["value"] / 1e6, 1), "M reads/s", {n: round(x["avg_ms"], 2) for n, x in v["roofline"]["kernels"].items() if ":" not in n})
 PY
+echo "produced (copy these to profiles/, nothing else): gpurun_out/${tag}_pmc.json gpurun_out/${tag}_kernel_stats.csv gpurun_out/${tag}_mix_*_kernel_stats.csv gpurun_out/${tag}_bench.json gpurun_out/${tag}_bench_line.json gpurun_out/${tag}_bench.log"
