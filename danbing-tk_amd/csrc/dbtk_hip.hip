@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(64) k_gz_pack(GzArgs a) { DevX x{nullptr}; bod
 #define DBTK_WALK_WAVES 2  // waves per SIMD the pair kernel is compiled for (register budget 512 / this): 3, 4 and 5 measured no faster
 #endif
 __global__ void __launch_bounds__(64) k_walk_reads(WalkArgs a) {
-    __shared__ __attribute__((aligned(16))) WalkSmem sm;
+    __shared__ __attribute__((aligned(16))) WalkReadSmem sm;
     DevX x{&sm};
     body_walk_reads(x, a);
 }
@@ -191,8 +191,8 @@ template <int IMGB> __global__ void __launch_bounds__(WPL_NW * 64) k_walk_pairs_
     body_walk_pairs_locus<WPL_NW, IMGB>(x, a, r);
 }
 __global__ void __launch_bounds__(64, DBTK_WALK_WAVES) k_walk_pairs(WalkArgs a) {
-    __shared__ __attribute__((aligned(16))) WalkSmem sm[2];  // one set of arrays per mate
-    DevX x{sm};
+    __shared__ __attribute__((aligned(16))) WalkPairSmem sm;  // one set of arrays per mate + the tables / parameters
+    DevX x{&sm};
     body_walk_pairs(x, a);
 }
 

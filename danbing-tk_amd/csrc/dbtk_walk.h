@@ -179,6 +179,16 @@ DBTK_HD uint32_t txt_carve(X& x, const WalkArgs& a) {
     return x.atomic_add(a.ntxt, TXT_CHUNK);
 }
 
+struct WalkState {
+    int ki, ni, nkm, nes, ntr;
+    uint64_t nskip, ncorr;
+    uint32_t flags;
+};
+// What the walk's out-of-line routines share with their callers goes through LDS, never through the stack: a local whose address is
+// handed to a routine that is not inlined (a WalkState, an `int* out`, the kernel's argument struct behind `const DevTables&`) lives in
+// scratch memory — a store and a load through L2 / HBM per access, in exactly the phases of the walk that wait for memory anyway
+// (960 B of private segment per lane, 1.7 times as many write requests as read requests).
+enum { ST_NI, ST_NES, ST_WID, ST_SCORE, ST_FLAGS, ST_KI, ST_NM, ST_ND, ST_NINS, ST_N };
 struct WalkSmem {
     uint32_t raw[72];
     uint32_t pk[20];
@@ -194,8 +204,9 @@ struct WalkSmem {
     uint8_t scr[128];         // edit_kmers_backward: the read / graph bases of an edit tract
     uint8_t txc[WTXT], txa[WTXT];  // text form of the alignment: this mate's CIGAR and annotation
     uint32_t txl[2];               // their lengths
-    int32_t st[8];            // lane-0 regions hand their scalars back through here
+    int32_t st[ST_N + 1];     // the out-of-line routines' scalar results (ST_*), written by lane 0
     uint64_t st64[2];
+    WalkState ws;             // the walk's state across a call of an out-of-line routine (ws_put / ws_get)
 #ifdef DBTK_STAMPS
     uint64_t dst_[8], dlast;  // diagnostic: cycle sums of the slow walk's parts
 #endif
@@ -236,18 +247,32 @@ DBTK_HD void w_hyp(int id, int* type, uint32_t* nt0, uint32_t* nt1) {
     else *type = H_NONE;
 }
 
-struct WalkState {
-    int ki, ni, nkm, nes, ntr;
-    uint64_t nskip, ncorr;
-    uint32_t flags;
+// The tables and parameters as the out-of-line routines see them: a copy in LDS, one per workgroup (body_walk_*: made once at the start).
+struct WalkConst {
+    DevTables T;
+    dbtk_params_t P;
 };
+template <class X>
+DBTK_HD void ws_put(X& x, WalkSmem& sm, const WalkState& S) {
+    x.sync();
+    if (x.lane() == 0) sm.ws = S;
+    x.sync();
+}
+template <class X>
+DBTK_HD void ws_get(X& x, const WalkSmem& sm, WalkState& S) {
+    x.sync();
+    S.ki = (int)x.uni((uint32_t)sm.ws.ki); S.ni = (int)x.uni((uint32_t)sm.ws.ni); S.nkm = (int)x.uni((uint32_t)sm.ws.nkm);
+    S.nes = (int)x.uni((uint32_t)sm.ws.nes); S.ntr = (int)x.uni((uint32_t)sm.ws.ntr); S.flags = x.uni(sm.ws.flags);
+    const uint64_t a = sm.ws.nskip, b = sm.ws.ncorr;
+    S.nskip = ((uint64_t)x.uni((uint32_t)(a >> 32)) << 32) | x.uni((uint32_t)a);
+    S.ncorr = ((uint64_t)x.uni((uint32_t)(b >> 32)) << 32) | x.uni((uint32_t)b);
+}
 
 // errorCorrection_forward (AQ.cpp:898-1089) at index ki of the walk's k-mers, or — backward = true —
 // errorCorrection_backward (AQ.cpp:1091-1106): the same on the reverse-complemented prefix before the anchor ki1.
-// Returns skip; on success *wid = the winning hypothesis, *wscore its score.
+// Returns skip; on success sm.st[ST_WID] = the winning hypothesis, sm.st[ST_SCORE] its score; sm.st[ST_FLAGS] = DBTK_THREAD_F_* raised.
 template <class X>
-DBTK_HD_NOINLINE bool walk_ec(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, bool backward, int ki, int nkm, uint32_t mes,
-                     int* wid, uint32_t* wscore, uint32_t* flags) {
+DBTK_HD_NOINLINE bool walk_ec(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, bool backward, int ki, int nkm, uint32_t mes) {
     const int lane = x.lane();
     const uint32_t k = T.ksize;
     const uint64_t rmask = (1ull << 2 * (k - 1)) - 1;
@@ -263,7 +288,8 @@ DBTK_HD_NOINLINE bool walk_ec(X& x, WalkSmem& sm, const DevTables& T, uint32_t l
     // the node whose successors seed the hypotheses, and its out-edges
     const uint32_t gS = backward ? ((uint32_t)sm.gi[ki] >> GR_OPP) & 0x1Fu : (uint32_t)sm.gi[ki - 1] & 0x1Fu;
     const uint64_t S = backward ? revcomp2(sm.km[ki], k) : sm.km[ki - 1];
-    if (!(gS & GR_HAS)) { *flags |= DBTK_THREAD_F_MISSING_NODE; return true; }  // getOutNodes asserts
+    auto fail_missing = [&]() { x.sync(); if (lane == 0) { sm.st[ST_FLAGS] = (int32_t)DBTK_THREAD_F_MISSING_NODE; sm.st[ST_WID] = 0; sm.st[ST_SCORE] = 0; } x.sync(); return true; };
+    if (!(gS & GR_HAS)) return fail_missing();  // getOutNodes asserts
     const uint32_t mask0 = gS & 0xFu;
     // reachability: m1[nt0] = out-edges of successor nt0, m2[nt0][nt1] = out-edges of its successor nt1
     x.sync();
@@ -291,7 +317,7 @@ DBTK_HD_NOINLINE bool walk_ec(X& x, WalkSmem& sm, const DevTables& T, uint32_t l
         }
     }
     x.sync();
-    if (x.ballot(missing)) { *flags |= DBTK_THREAD_F_MISSING_NODE; return true; }
+    if (x.ballot(missing)) return fail_missing();
     uint32_t nts1 = 0, nts2 = 0, nn1[4];  // nn1[nt0] = get_nnts(nt0): nt1 with some nt2 behind it
     for (uint32_t a = 0; a < 4; ++a) {
         nts1 |= sm.cube[a];
@@ -397,8 +423,9 @@ DBTK_HD_NOINLINE bool walk_ec(X& x, WalkSmem& sm, const DevTables& T, uint32_t l
     const bool valid = type != H_NONE && cnt >= (twoed ? 2 * W_MSC : W_MSC) && (!twoed || mes > 1);
     const uint32_t key = valid ? (cnt << 8) | (255u - (uint32_t)lane) : 0u;
     const uint32_t best = ~x.wave_min(~key);
-    *wscore = best >> 8;
-    *wid = (int)(255u - (best & 255u));
+    x.sync();
+    if (lane == 0) { sm.st[ST_SCORE] = (int32_t)(best >> 8); sm.st[ST_WID] = (int32_t)(255u - (best & 255u)); sm.st[ST_FLAGS] = 0; }
+    x.sync();
     return best == 0;
 }
 
@@ -470,15 +497,18 @@ DBTK_HD bool walk_find_anchor(X& x, WalkSmem& sm, uint32_t k, WalkState& S) {
 
 // edit_kmers_forward, AQ.cpp:828-862
 template <class X>
-DBTK_HD_NOINLINE void walk_edit_forward(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, WalkState& S, int wid, uint32_t score) {
+DBTK_HD_NOINLINE void walk_edit_forward(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, int wid, uint32_t score) {
     const int lane = x.lane();
+    WalkState S;  // in: sm.ws; out: sm.ws
+    ws_get(x, sm, S);
     const uint32_t k = T.ksize;
     const uint64_t rmask = (1ull << 2 * (k - 1)) - 1;
     auto refresh = [&](int lo, int hi) { walk_refresh(x, sm, T, locus, S, lo, hi); };
     uint8_t et[2], eg[2];
     const int ne = w_edits(wid, et, eg);
     int nm = 0, nd = 0, nins = 0;
-    for (int e = 0; e < ne; ++e) { nm += et[e] == 'X'; nd += et[e] == 'D'; nins += et[e] == 'I'; }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) if (e < ne) { nm += et[e] == 'X'; nd += et[e] == 'D'; nins += et[e] == 'I'; }  // (fixed bounds: et / eg stay in registers)
     const int ki0 = S.ki, dt_km = nd - nins, dt_ki = nm + nd;
     const int n0 = S.nkm - ki0;
     // the bases to roll in after kmers[ki0 - 1]: the graph bases of the X / D edits, then the read's own bases from
@@ -487,7 +517,8 @@ DBTK_HD_NOINLINE void walk_edit_forward(X& x, WalkSmem& sm, const DevTables& T, 
     if (lane < 40) {
         uint8_t b = 4;
         int q = 0;
-        for (int e = 0; e < ne; ++e) if (et[e] != 'I') { if (lane == q) b = (uint8_t)w_code(eg[e]); ++q; }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) if (e < ne && et[e] != 'I') { if (lane == q) b = (uint8_t)w_code(eg[e]); ++q; }
         if (lane >= dt_ki) {
             const int o = nm + nins + (lane - dt_ki);  // old offset from ki0
             if (o < n0 && sm.km[ki0 + o] != NAN64) b = (uint8_t)(sm.km[ki0 + o] % 4);
@@ -533,28 +564,30 @@ DBTK_HD_NOINLINE void walk_edit_forward(X& x, WalkSmem& sm, const DevTables& T, 
     }
     x.sync();
     for (int i = lane; i < dt_ki + (int)score; i += 64) sm.tr[ki0 + i] = (sm.gi[ki0 + i] & GR_TR) ? '=' : '.';
-    if (lane < ne) { sm.es_t[S.ni + (int)k - 1 + lane] = et[lane]; sm.es_g[S.ni + (int)k - 1 + lane] = eg[lane]; }
+    if (lane < ne) { sm.es_t[S.ni + (int)k - 1 + lane] = lane == 0 ? et[0] : et[1]; sm.es_g[S.ni + (int)k - 1 + lane] = lane == 0 ? eg[0] : eg[1]; }
     for (int i = lane; i < (int)score; i += 64) sm.es_t[S.ni + ne + (int)k - 1 + i] = '=';
     x.sync();
     S.ni += ne + (int)score - 1;
     S.ki = ki + (int)score - 1;  // the last edited kmer
     S.ncorr += (uint64_t)ne;
+    ws_put(x, sm, S);
 }
 
-// edit_kmers_backward, AQ.cpp:649-825, for the anchor at *pki; txt's nm / nd / ni / score are handed back
+// edit_kmers_backward, AQ.cpp:649-825, for the anchor at ki; the state comes and goes in sm.ws; the anchor's new place and the edits'
+// nm / nd / ni are handed back in sm.st[ST_KI, ST_NM, ST_ND, ST_NINS]
 template <class X>
-DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, WalkState& S, int wid, uint32_t score, int* pki,
-                                         int* onm, int* ond, int* oni) {
+DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, int wid, uint32_t score, int ki) {
     const int lane = x.lane();
+    WalkState S;
+    ws_get(x, sm, S);
     const uint32_t k = T.ksize;
     auto refresh = [&](int lo, int hi) { walk_refresh(x, sm, T, locus, S, lo, hi); };
     uint8_t et[2], eg[2];
     const int ne = w_edits(wid, et, eg);
     int nm = 0, nd = 0, nins = 0;
-    for (int e = 0; e < ne; ++e) { nm += et[e] == 'X'; nd += et[e] == 'D'; nins += et[e] == 'I'; }
-    *onm = nm; *ond = nd; *oni = nins;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) if (e < ne) { nm += et[e] == 'X'; nd += et[e] == 'D'; nins += et[e] == 'I'; }  // (fixed bounds: et / eg stay in registers)
     const int dt_km = nd - nins;
-    int ki = *pki;
     S.ni += nd;
     if (dt_km > 0) {  // kmers.insert(begin + ki, 0) / cg.tr.insert(begin + ki, '*'), dt_km times
         w_shift(x, sm.km, ki, S.nkm, dt_km);
@@ -583,7 +616,8 @@ DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm, const DevTables& T,
     if (lane < 40) {
         uint8_t b = 0;
         int q = 0;
-        for (int e = 0; e < ne; ++e) if (et[e] != 'I') { if (lane == q) b = (uint8_t)(3 - w_code(eg[e])); ++q; }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) if (e < ne && et[e] != 'I') { if (lane == q) b = (uint8_t)(3 - w_code(eg[e])); ++q; }
         if (lane >= ncor && lane < ncor + next) b = (uint8_t)(sm.km[ki_ - 1 - (lane - ncor)] >> (2 * (k - 1)));
         sm.bases[lane] = b;
     }
@@ -624,14 +658,15 @@ DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm, const DevTables& T,
         for (int i = 0; i < nti_ + cni; ++i) if (sm.es_t[i] == 'I') ++cni;
         int nti = nti_ + cni - 1;  // cg.tr index -> cg.es index
         for (int i = 0; i < ne; ++i, --nti) {  // CIGAR of edits
-            if (et[i] == 'D') { ++nti; es_ins(nti); }
+            const uint8_t ti = i == 0 ? et[0] : et[1], gi_ = i == 0 ? eg[0] : eg[1];
+            if (ti == 'D') { ++nti; es_ins(nti); }
             if (sm.es_t[nti] == 'D') {
-                if (et[i] == 'I') { es_del(nti); --ni; }  // delete edit immediately
-                else sm.es_g[nti] = w_comp_char(eg[i]);
+                if (ti == 'I') { es_del(nti); --ni; }  // delete edit immediately
+                else sm.es_g[nti] = w_comp_char(gi_);
             } else {
                 while (sm.es_t[nti] == 'I') --nti;
-                sm.es_t[nti] = et[i];
-                sm.es_g[nti] = eg[i] ? w_comp_char(eg[i]) : (uint8_t)0;
+                sm.es_t[nti] = ti;
+                sm.es_g[nti] = gi_ ? w_comp_char(gi_) : (uint8_t)0;
             }
         }
         int e0 = nti + 1, e1 = e0;
@@ -665,7 +700,7 @@ DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm, const DevTables& T,
                 ncorr -= (uint64_t)(e1 - e0);
                 nskip -= (uint64_t)(e1 - e0);
             } else if (nets != nr) {  // D + I (same position) -> X: the tract shrinks
-                uint8_t rn[64], gn[64];
+                uint8_t* const rn = sm.scr; uint8_t* const gn = sm.scr + 64;  // (LDS: a private array indexed like this would be scratch memory)
                 for (int i = 0; i < nr && i < 64; ++i) { rn[i] = rnt(i); gn[i] = gnt(i); }
                 int dt_es = 0;
                 const int dt_es_ = nr - nets;
@@ -706,15 +741,21 @@ DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm, const DevTables& T,
     }
     x.sync();
     if (S.nes > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; S.nes = WCAP; }
-    *pki = ki;
+    if (lane == 0) { sm.st[ST_KI] = ki; sm.st[ST_NM] = nm; sm.st[ST_ND] = nd; sm.st[ST_NINS] = nins; }
+    ws_put(x, sm, S);
 }
 
-// isThreadFeasible in full (the read's arrays in sm, the state initialised): from its beginning (phase 0), or picking the main
-// loop up at S.ki (phase 1) where walk_read's inlined common path met its first event.  A separate function: the common path
-// (anchor at the first k-mer, runs of matches to the end) then stays small enough to live in registers — anything this
-// routine spills goes to scratch memory, behind the flood of graph look-ups the kernel keeps in flight.
+// isThreadFeasible in full (the read's arrays in sm, the state in sm.ws): from its beginning (phase 0), or picking the main loop up at
+// S.ki (phase 1) where walk_read's inlined common path met its first event.  Inlined since round 6: with the state, the tables and every
+// result of the routines below it passing through LDS, nothing of the walk is on the stack any more and the kernel has no private
+// segment at all (as a separate function it kept two callee-saved registers there: -DDBTK_WALK_SLOW_OUTLINE, tools/_variants).
+#ifdef DBTK_WALK_SLOW_OUTLINE
+#define DBTK_WALK_SLOW_FN DBTK_HD_NOINLINE
+#else
+#define DBTK_WALK_SLOW_FN DBTK_HD
+#endif
 template <class X>
-DBTK_HD_NOINLINE int walk_slow(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_t& P, uint32_t locus, int len, WalkState& S, int phase) {
+DBTK_WALK_SLOW_FN int walk_slow(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_t& P, uint32_t locus, int len, int phase) {
     const int lane = x.lane();
     const uint32_t k = T.ksize;
     const uint64_t rmask = (1ull << 2 * (k - 1)) - 1;
@@ -723,42 +764,45 @@ DBTK_HD_NOINLINE int walk_slow(X& x, WalkSmem& sm, const DevTables& T, const dbt
     const uint64_t nkmers = (uint64_t)(len - (int)k + 1);  // frozen (AQ.cpp:1126)
     const uint64_t maxnskip = nkmers >= P.thread_cth ? nkmers - P.thread_cth : 0;
 
-    // The walk's state lives in registers.  The rare, large pieces (error correction, the k-mer / CIGAR surgery) are separate
-    // functions so that the common path stays small; they get a COPY of the state: a reference would pin S in scratch memory
-    // and turn every `S.ki += run` of the common path into a load and a store.
+    // The walk's state lives in registers (in: sm.ws, out: sm.ws).  The rare, large pieces (error correction, the k-mer / CIGAR surgery) are
+    // separate functions so that the common path stays small; the state crosses those calls in sm.ws too (ws_put / ws_get): a reference to
+    // S would pin it in scratch memory and turn every `S.ki += run` of the common path into a load and a store.
+    WalkState S;
+    ws_get(x, sm, S);
     WS_BEGIN();
     auto find_anchor = [&]() { WS(5); const bool r_ = walk_find_anchor(x, sm, k, S); WS(4); return r_; };
-    auto edit_forward = [&](int wid, uint32_t score) { WS(5); WalkState t = S; walk_edit_forward(x, sm, T, locus, t, wid, score); S = t; WS(1); };
+    auto edit_forward = [&](int wid, uint32_t score) { WS(5); ws_put(x, sm, S); walk_edit_forward(x, sm, T, locus, wid, score); ws_get(x, sm, S); WS(1); };
     // (anchor = -1: the walk's own position S.ki, which the routine moves; else an earlier anchor, handed back)
-    auto edit_backward = [&](int wid, uint32_t score, int anchor, int* onm, int* ond, int* oni) -> int {
+    auto edit_backward = [&](int wid, uint32_t score, int anchor, int& onm, int& ond, int& oni) -> int {
         WS(5);
-        WalkState t = S;
-        int tki = anchor < 0 ? t.ki : anchor, a = 0, b = 0, c = 0;
-        walk_edit_backward(x, sm, T, locus, t, wid, score, &tki, &a, &b, &c);
-        S = t;
+        ws_put(x, sm, S);
+        walk_edit_backward(x, sm, T, locus, wid, score, anchor < 0 ? S.ki : anchor);
+        ws_get(x, sm, S);
+        const int tki = (int)x.uni((uint32_t)sm.st[ST_KI]);
+        onm = (int)x.uni((uint32_t)sm.st[ST_NM]); ond = (int)x.uni((uint32_t)sm.st[ST_ND]); oni = (int)x.uni((uint32_t)sm.st[ST_NINS]);
         WS(3);
         if (anchor < 0) S.ki = tki;
-        *onm = a; *ond = b; *oni = c;
         return tki;
     };
-    auto ec = [&](bool backward, int ki, uint32_t mes, int* wid, uint32_t* wscore) {
-        int w = 0; uint32_t sc = 0, fl = 0;
+    auto ec = [&](bool backward, int ki, uint32_t mes, int& wid, uint32_t& wscore) {
         WS(5);
-        const bool skip = walk_ec(x, sm, T, locus, backward, ki, S.nkm, mes, &w, &sc, &fl);
+        const bool skip = walk_ec(x, sm, T, locus, backward, ki, S.nkm, mes);
         WS(backward ? 2 : 0);
-        *wid = w; *wscore = sc; S.flags |= fl;
+        wid = (int)x.uni((uint32_t)sm.st[ST_WID]); wscore = x.uni((uint32_t)sm.st[ST_SCORE]); S.flags |= x.uni((uint32_t)sm.st[ST_FLAGS]);
         return skip;
     };
+    // every way out of the routine leaves the state in sm.ws
+#define W_RETURN(v) do { const int r__ = (v); ws_put(x, sm, S); return r__; } while (0)
 
-#define W_FAIL_CHECK() do { if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) return -1; } while (0)
+#define W_FAIL_CHECK() do { if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) W_RETURN(-1); } while (0)
     if (phase == 0) {
-    if (!find_anchor()) return 0;
+    if (!find_anchor()) W_RETURN(0);
     if (S.ki > 0 && correction && S.ncorr < maxc && (uint32_t)S.ki >= W_MSC + 1) {  // leading unaligned kmers: backward first
         const uint32_t mes = (uint32_t)S.ki >= 2 * W_MSC + 2 ? 2 : 1;
         int wid; uint32_t score;
-        const bool skip = ec(true, S.ki, mes, &wid, &score);
+        const bool skip = ec(true, S.ki, mes, wid, score);
         W_FAIL_CHECK();
-        if (!skip) { int a, b, c; (void)edit_backward(wid, score, -1, &a, &b, &c); W_FAIL_CHECK(); }
+        if (!skip) { int a, b, c; (void)edit_backward(wid, score, -1, a, b, c); W_FAIL_CHECK(); }
     }
     ++S.ki; ++S.ni;
     }
@@ -788,41 +832,41 @@ DBTK_HD_NOINLINE int walk_slow(X& x, WalkSmem& sm, const DevTables& T, const dbt
         if (kv == NAN64 || kv == pv) {  // "N" in read / homopolymer run
             if (lane == 0) { sm.tr[S.ki] = '*'; sm.es_t[S.ni + (int)k - 1] = '*'; }
             ++S.nskip;
-            if (S.nskip > maxnskip) return 0;
+            if (S.nskip > maxnskip) W_RETURN(0);
             ++S.ki; ++S.ni;
             continue;
         }
         if (pv == NAN64) {  // triggered after passing 'N'
             if (!find_anchor()) break;
-            if (S.nskip > maxnskip) return 0;
+            if (S.nskip > maxnskip) W_RETURN(0);
             ++S.ki; ++S.ni;
             continue;
         }
-        if (!(sm.gi[S.ki - 1] & GR_HAS)) { S.flags |= DBTK_THREAD_F_MISSING_NODE; return -1; }  // getOutNodes(node) asserts
+        if (!(sm.gi[S.ki - 1] & GR_HAS)) { S.flags |= DBTK_THREAD_F_MISSING_NODE; W_RETURN(-1); }  // getOutNodes(node) asserts
         // read kmer has no matching node in the graph, try error correction
         if ((uint64_t)S.ki + W_MSC >= nkmers) {  // not enough info
             S.nskip += nkmers - (uint64_t)S.ki;
-            return S.nskip <= maxnskip ? (S.ncorr ? 2 : 1) : 0;
+            W_RETURN(S.nskip <= maxnskip ? (S.ncorr ? 2 : 1) : 0);
         }
         if (correction && S.ncorr < maxc) {
             uint32_t mes = (uint32_t)(S.nkm - S.ki) >= 2 * W_MSC + 2 ? 2 : 1;
             int wid; uint32_t score;
-            bool skip = ec(false, S.ki, mes, &wid, &score);
+            bool skip = ec(false, S.ki, mes, wid, score);
             W_FAIL_CHECK();
             if (!skip) {  // passed forward correction
                 uint8_t et[2], eg[2];
                 S.nskip += (uint64_t)w_edits(wid, et, eg);
-                if (S.nskip > maxnskip) return 0;
+                if (S.nskip > maxnskip) W_RETURN(0);
                 edit_forward(wid, score);
                 W_FAIL_CHECK();
             } else {
                 if (!find_anchor()) break;
                 mes = 2;  // always have enough info to make 2 edits
-                skip = ec(true, S.ki, mes, &wid, &score);
+                skip = ec(true, S.ki, mes, wid, score);
                 W_FAIL_CHECK();
                 if (!skip) {  // passed reverse correction
                     int nm, nd, nins;
-                    (void)edit_backward(wid, score, -1, &nm, &nd, &nins);
+                    (void)edit_backward(wid, score, -1, nm, nd, nins);
                     W_FAIL_CHECK();
                     ++S.ncorr;
                     uint64_t ki64 = (uint64_t)S.ki;
@@ -835,11 +879,11 @@ DBTK_HD_NOINLINE int walk_slow(X& x, WalkSmem& sm, const DevTables& T, const dbt
                         ki1 = ki0 - (uint64_t)nm - (uint64_t)nd - sc;
                         mes = ki1 >= 2 * W_MSC + 2 ? 2 : 1;
                         if (ki1 < W_MSC + 1) break;
-                        if (!(sm.gi[ki1] & GR_HAS)) { S.flags |= DBTK_THREAD_F_MISSING_NODE; return -1; }  // assert(g.count(node_))
-                        skip = ec(true, (int)ki1, mes, &wid, &sc);
+                        if (!(sm.gi[ki1] & GR_HAS)) { S.flags |= DBTK_THREAD_F_MISSING_NODE; W_RETURN(-1); }  // assert(g.count(node_))
+                        skip = ec(true, (int)ki1, mes, wid, sc);
                         W_FAIL_CHECK();
                         if (!skip) {
-                            const int k1 = edit_backward(wid, sc, (int)ki1, &nm, &nd, &nins);
+                            const int k1 = edit_backward(wid, sc, (int)ki1, nm, nd, nins);
                             W_FAIL_CHECK();
                             ki1 = (uint64_t)k1;
                             S.ki += nd - nins;
@@ -853,22 +897,23 @@ DBTK_HD_NOINLINE int walk_slow(X& x, WalkSmem& sm, const DevTables& T, const dbt
                         x.sync();
                         S.nskip -= gap;
                     }
-                    if (S.nskip > maxnskip) return 0;
+                    if (S.nskip > maxnskip) W_RETURN(0);
                 }
                 if (skip) {  // either initial or iterative backward correction failed
                     if (!find_anchor()) break;
-                    if (S.nskip > maxnskip) return 0;
+                    if (S.nskip > maxnskip) W_RETURN(0);
                 }
             }
         } else {
             if (!find_anchor()) break;
-            if (S.nskip > maxnskip) return 0;
+            if (S.nskip > maxnskip) W_RETURN(0);
         }
         ++S.ki; ++S.ni;
     }
-#undef W_FAIL_CHECK
     WS(5);
-    return (S.nskip <= maxnskip && S.ncorr <= maxc) ? (S.ncorr ? 2 : 1) : 0;
+    W_RETURN((S.nskip <= maxnskip && S.ncorr <= maxc) ? (S.ncorr ? 2 : 1) : 0);
+#undef W_FAIL_CHECK
+#undef W_RETURN
 }
 
 // One read through isThreadFeasible.  The read's arrays must be in sm (walk_load).  Returns ret (wave-uniform).
@@ -907,9 +952,9 @@ DBTK_HD int walk_read(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_
         }
         if (S.ki >= S.nkm) { x.sync(); return 1; }  // nothing skipped, nothing corrected: feasible (AQ.cpp:1259)
     }
-    WalkState t = S;  // (a copy: S itself stays in registers)
-    const int ret = walk_slow(x, sm, T, P, locus, len, t, phase);
-    S = t;
+    ws_put(x, sm, S);  // (through LDS: S itself stays in registers on the common path, and nothing of it is ever on the stack)
+    const int ret = walk_slow(x, sm, T, P, locus, len, phase);
+    ws_get(x, sm, S);
     return ret;
 }
 
@@ -1079,8 +1124,10 @@ DBTK_HD int walk_load(X& x, WalkSmem& sm, const DevTables& T, const uint8_t* seq
 
 // What the walk left in LDS -> a thread record in HBM.
 template <class X>
-DBTK_HD_NOINLINE void walk_store(X& x, const WalkSmem& sm, const WalkState& S, int ret, dbtk_thread_rec_t* o) {
+DBTK_HD_NOINLINE void walk_store(X& x, const WalkSmem& sm, int ret, dbtk_thread_rec_t* o) {
     const int lane = x.lane();
+    WalkState S;  // (sm.ws: put there by the caller)
+    ws_get(x, sm, S);
     x.sync();
     if (lane == 0) {
         o->ret = ret; o->ni = S.ni; o->nkm = (uint32_t)S.nkm; o->nes = (uint32_t)S.nes; o->ntr = (uint32_t)S.ntr; o->flags = S.flags;
@@ -1097,8 +1144,10 @@ DBTK_HD_NOINLINE void walk_store(X& x, const WalkSmem& sm, const WalkState& S, i
 
 // What the walk left in LDS -> mate m's half of a compact alignment record.
 template <class X>
-DBTK_HD_NOINLINE void walk_store_aln(X& x, const WalkSmem& sm, const WalkState& S, int ret, uint8_t* rec, uint32_t cap, int m) {
+DBTK_HD_NOINLINE void walk_store_aln(X& x, const WalkSmem& sm, int ret, uint8_t* rec, uint32_t cap, int m) {
     const int lane = x.lane();
+    WalkState S;
+    ws_get(x, sm, S);
     dbtk_aln_hdr_t* h = reinterpret_cast<dbtk_aln_hdr_t*>(rec);
     uint8_t* es = rec + sizeof(dbtk_aln_hdr_t) + (size_t)(2 * m) * cap;
     uint8_t* tr = es + cap;
@@ -1114,25 +1163,43 @@ DBTK_HD_NOINLINE void walk_store_aln(X& x, const WalkSmem& sm, const WalkState& 
     x.sync();
 }
 
+// the LDS of a wave of body_walk_pairs: one set of arrays per mate + the tables / parameters
+struct WalkPairSmem {
+    WalkSmem w[2];
+    WalkConst c;
+};
+struct WalkReadSmem {  // ... of body_walk_reads
+    WalkSmem w;
+    WalkConst c;
+};
+template <class X>
+DBTK_HD void walk_const_init(X& x, WalkConst& c, const WalkArgs& a) {
+    if (x.lane() == 0) { c.T = a.T; c.P = a.P; }
+    x.sync();
+}
 // Function mode: read r against read_locus[r] (one wave per read, reads at a fixed stride).
 template <class X>
 DBTK_HD void body_walk_reads(X& x, const WalkArgs& a) {
-    WalkSmem& sm = *x.template smem<WalkSmem>();
+    WalkReadSmem& smb = *x.template smem<WalkReadSmem>();
+    WalkSmem& sm = smb.w;
+    walk_const_init(x, smb.c, a);
+    const DevTables& T_ = smb.c.T;
     const uint32_t k = a.T.ksize;
     for (uint32_t r = x.bid(); r < a.nreads; r += x.nblocks()) {
         const uint64_t o0 = a.off[r], o1 = a.off[r + 1];
         const uint32_t locus = a.read_locus[r];
         WalkState S;
         int ret = -1;
-        const int len = walk_load(x, sm, a.T, a.seq, o0, o1, locus, nullptr, a.noncak ? a.noncak + (size_t)r * MAXL : nullptr, a.errflag);
+        const int len = walk_load(x, sm, T_, a.seq, o0, o1, locus, nullptr, a.noncak ? a.noncak + (size_t)r * MAXL : nullptr, a.errflag);
         // the reference indexes kmers[0] of an empty vector when the read has no valid k-mer (the hot path never
         // hands such a read to the walk: both mates have one, AQ.cpp:2037)
         bool any = false;
         for (int i = x.lane(); i < len - (int)k + 1; i += 64) any |= sm.km[i] != NAN64;
-        if (len >= (int)k && locus < a.T.nloci && x.ballot(any)) ret = walk_read(x, sm, a.T, a.P, locus, len, S);
+        if (len >= (int)k && locus < a.T.nloci && x.ballot(any)) ret = walk_read(x, sm, T_, smb.c.P, locus, len, S);
         else { S.ki = 0; S.ni = 0; S.nkm = 0; S.nes = 0; S.ntr = 0; S.nskip = 0; S.ncorr = 0; S.flags = DBTK_THREAD_F_OVERFLOW; }
         if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) ret = -1;
-        walk_store(x, sm, S, ret, &a.trecs[r]);
+        ws_put(x, sm, S);
+        walk_store(x, sm, ret, &a.trecs[r]);
     }
 }
 
@@ -1278,7 +1345,9 @@ DBTK_HD uint32_t wave_fmt_annot(X& x, const uint8_t* tr, int sz, uint8_t* out) {
 }
 // this mate's two strings into its LDS text buffers
 template <class X>
-DBTK_HD_NOINLINE void walk_format_text(X& x, WalkSmem& sm, const WalkState& S, uint32_t cap) {
+DBTK_HD_NOINLINE void walk_format_text(X& x, WalkSmem& sm, uint32_t cap) {
+    WalkState S;
+    ws_get(x, sm, S);
     x.sync();
     const int nes = S.nes < (int)cap ? S.nes : (int)cap, ntr = S.ntr < (int)cap ? S.ntr : (int)cap;  // (as dbtk_aln_format clamps)
     const uint32_t lc = wave_fmt_cigar(x, sm.es_t, sm.es_g, nes, sm.txc);
@@ -1303,9 +1372,10 @@ struct WalkPairAcc {
 #endif
 };
 template <class X>
-DBTK_HD void walk_pair(X& x, WalkSmem* smm, const WalkArgs& a, const DevTables& T, uint32_t t, uint32_t dst, uint32_t pair, uint32_t inf,
+DBTK_HD void walk_pair(X& x, WalkSmem* smm, const WalkArgs& a, const WalkConst& C, uint32_t t, uint32_t dst, uint32_t pair, uint32_t inf,
                        const uint64_t (&oA)[3], const uint32_t (&wA)[2][2], WalkPairAcc& A) {
     const int lane = x.lane();
+    const DevTables& T = C.T;  // (the copy in LDS: the walk's out-of-line routines take the tables and the parameters by reference)
 #ifdef DBTK_STAMPS
     uint64_t (&wst)[8] = A.wst;
     uint64_t& wlast = A.wlast;
@@ -1356,11 +1426,12 @@ DBTK_HD void walk_pair(X& x, WalkSmem* smm, const WalkArgs& a, const DevTables& 
             if (m == 1 && ret[0] && !a.trecs && !arec && !a.txt) { ret[1] = WALK_NOT_EVALUATED; W_STAMP(5); continue; }
             WalkState S;
             if (a.P.diag & 1) { ret[m] = 1; S.flags = 0; S.nes = S.ntr = S.nkm = 0; S.ni = 0; S.ki = 0; S.nskip = S.ncorr = 0; }  // diagnostic: no walk
-            else ret[m] = walk_read(x, smm[m], T, a.P, dst, (int)len[m], S);
+            else ret[m] = walk_read(x, smm[m], T, C.P, dst, (int)len[m], S);
             if (S.flags & (DBTK_THREAD_F_MISSING_NODE | DBTK_THREAD_F_OVERFLOW)) { ret[m] = 0; if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_FORMAT; }
-            if (a.trecs) walk_store(x, smm[m], S, ret[m], &a.trecs[2 * (size_t)t + m]);
-            if (arec) walk_store_aln(x, smm[m], S, ret[m], arec, a.aln_cap, m);
-            if (a.txt) walk_format_text(x, smm[m], S, a.aln_cap);
+            if (a.trecs || arec || a.txt) ws_put(x, smm[m], S);  // (the record writers are out of line: the state goes to them through LDS)
+            if (a.trecs) walk_store(x, smm[m], ret[m], &a.trecs[2 * (size_t)t + m]);
+            if (arec) walk_store_aln(x, smm[m], ret[m], arec, a.aln_cap, m);
+            if (a.txt) walk_format_text(x, smm[m], a.aln_cap);
             W_STAMP(4 + m);  // the walk of mate m
         }
         const bool alned = ret[0] || ret[1];
@@ -1423,7 +1494,9 @@ DBTK_HD void walk_pair(X& x, WalkSmem* smm, const WalkArgs& a, const DevTables& 
 
 template <class X>
 DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
-    WalkSmem* const smm = x.template smem<WalkSmem>();  // one set of arrays per mate
+    WalkPairSmem& smb = *x.template smem<WalkPairSmem>();
+    WalkSmem* const smm = smb.w;  // one set of arrays per mate
+    walk_const_init(x, smb.c, a);
 #ifdef DBTK_STAMPS
     if (x.lane() == 0) for (int m_ = 0; m_ < 2; ++m_) for (int i_ = 0; i_ < 8; ++i_) smm[m_].dst_[i_] = 0;
 #endif
@@ -1480,7 +1553,7 @@ DBTK_HD void body_walk_pairs(X& x, const WalkArgs& a) {
         offs(pairC, oC);
         meta(tA + 3 * S_, &dstD, &pairD, &ttD, &infD);
         const uint32_t t = ttA, dst = dstA, pair = pairA, inf = infA;
-        if (dst != NAN32) walk_pair(x, smm, a, a.T, t, dst, pair, inf, oA, wA, A);
+        if (dst != NAN32) walk_pair(x, smm, a, smb.c, t, dst, pair, inf, oA, wA, A);
         // the pipeline moves on
         dstA = dstB; pairA = pairB; ttA = ttB; infA = infB;
         for (int q = 0; q < 3; ++q) { oA[q] = oB[q]; oB[q] = uni64(oC[q]); }

@@ -675,8 +675,8 @@ DBTK_HD void body_walk_fast_locus(X& x, const WalkArgs& a, const LocRunArgs& r) 
 template <int NW, int IMGB>
 struct __attribute__((aligned(16))) WalkPairsLocSmemT {
     uint4 img[IMGB / 16];
-    DevTables T;  // a.T with the image named in it: in LDS, because the walk's out-of-line routines take the tables by reference — a copy on the
-                  // stack would be scratch memory, a round trip to HBM for every field they read
+    WalkConst c;  // a.T with the image named in it (and a.P): in LDS, because the walk's out-of-line routines take the tables by reference — a
+                  // copy on the stack would be scratch memory, a round trip to HBM for every field they read
     WalkSmem w[NW][2];
 };
 template <int NW, int IMGB, class X>
@@ -690,9 +690,9 @@ DBTK_HD void body_walk_pairs_locus(X& x, const WalkArgs& a, const LocRunArgs& r)
 #ifdef DBTK_STAMPS
     if (lane == 0) for (int m_ = 0; m_ < 2; ++m_) for (int i_ = 0; i_ < 8; ++i_) smm[m_].dst_[i_] = 0;
 #endif
-    if (x.tid() == 0) { smb.T = a.T; smb.T.gimg = reinterpret_cast<const uint32_t*>(smb.img); smb.T.gimg_lgnb = 0; }
+    if (x.tid() == 0) { smb.c.T = a.T; smb.c.P = a.P; smb.c.T.gimg = reinterpret_cast<const uint32_t*>(smb.img); smb.c.T.gimg_lgnb = 0; }
     x.bsync();
-    const DevTables& T = smb.T;
+    const DevTables& T = smb.c.T;
     uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
     const uint32_t ifirst = r.starts[x.bid()], nitems = r.starts[x.bid() + 1];
     auto desc = [&](uint32_t it) -> uint4 { return r.items[it < nitems ? it : 0u]; };
@@ -737,7 +737,7 @@ DBTK_HD void body_walk_pairs_locus(X& x, const WalkArgs& a, const LocRunArgs& r)
                 if (o < n16) *reinterpret_cast<p2_v4u*>(&smb.img[o]) = t[u];
             }
         }
-        if (x.tid() == 0) smb.T.gimg_lgnb = ld.lgnb;  // (between the item's two barriers)
+        if (x.tid() == 0) smb.c.T.gimg_lgnb = ld.lgnb;  // (between the item's two barriers)
         // this wave's pairs: every NW-th marked one.  Lane j holds the j-th of them: place, pair index, offsets (the two dependent loads
         // of all of them in flight together)
         uint32_t my_t = 0, my_pair = 0;
@@ -769,7 +769,7 @@ DBTK_HD void body_walk_pairs_locus(X& x, const WalkArgs& a, const LocRunArgs& r)
         for (uint32_t j = 0; j < nmine; ++j) {
             if (j + 1 < nmine) take(j + 1, oB, wB);
             const uint32_t t = x.bcast(my_t, (int)j), pair = x.bcast(my_pair, (int)j);
-            walk_pair(x, smm, a, T, t, locus, pair, NAN32, oA, wA, A);
+            walk_pair(x, smm, a, smb.c, t, locus, pair, NAN32, oA, wA, A);
             ++nwalked;
             for (int q = 0; q < 3; ++q) oA[q] = oB[q];
             for (int m = 0; m < 2; ++m) { wA[m][0] = wB[m][0]; wA[m][1] = wB[m][1]; }

@@ -528,7 +528,7 @@ int emu_thread_batch(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p,
     memset(&w, 0, sizeof(w));
     w.T = e->T; w.P = *p; w.seq = (const uint8_t*)seqbuf.data(); w.off = off;
     w.read_locus = loci; w.nreads = (uint32_t)nreads; w.trecs = recs; w.errflag = &err;
-    run_grid(grid ? grid : 1, 64, sizeof(WalkSmem), [&](EmuX& x) { body_walk_reads(x, w); });
+    run_grid(grid ? grid : 1, 64, sizeof(WalkReadSmem), [&](EmuX& x) { body_walk_reads(x, w); });
     return (int)err;
 }
 void emu_tables_free(void* e) { delete (EmuTables*)e; }
@@ -1030,7 +1030,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
             }
             g_walk_fast_runs += 1; g_walk_slow_pairs += nreal;
         }
-        run_grid(grid_pair, 64, 2 * sizeof(WalkSmem), [&](EmuX& x) { body_walk_pairs(x, w); });
+        run_grid(grid_pair, 64, sizeof(WalkPairSmem), [&](EmuX& x) { body_walk_pairs(x, w); });
         if (txtmode) g_txt.resize(ntxt <= g_txt.size() ? ntxt : g_txt.size());
         if ((p->aln & 3u) && !txtmode) {  // as dbtk_ctx_aln_records: drop the invalid slots, pair order
             std::vector<std::pair<uint32_t, uint32_t>> order;
