@@ -133,11 +133,14 @@ def algorithmic_bytes(abi, ctr, walk_probes=0.0, ps=None, walk=False):
     # v1.3 threading: k_pair hands a pair to the walk kernels BEFORE assignTRkmc / accumulate (dbtk_kernels.h, DBTK_STAGE_THREADING), and
     # every count increment of the step is the walk kernels' (exact counting, AQ.cpp:2189-2194): 16 I is priced there, once
     inc_pair = 0.0 if walk else ctr[abi.C_ALGO_INC] - fi
+    # V: fillstats' vv words (DBTK_C_ALGO_VV) are the reference's on every path; the kernel that actually reads vv is k_pair — for the pairs it
+    # handles (path statistic pair_vv) plus the words of the votes it holds (vote_vv).  The fused probe kernels read none: unpriced.
+    v_pair = (float(ps.get("pair_vv", 0)) + float(ps.get("vote_vv", 0))) if ps else ctr[abi.C_ALGO_VV]
     return {
         "k_encode_subfilter": ctr[abi.C_BASES] + 12.0 * (ctr[abi.C_ALGO_PROBES] - ctr[abi.C_NHASH1]),
         "k_probe": 12.0 * ctr[abi.C_NHASH1] + 8.0 * fa + 16.0 * fi,
         "k_probe: look-ups only": 12.0 * ctr[abi.C_NHASH1],
-        "k_pair": 4.0 * ctr[abi.C_ALGO_VV] + 8.0 * (ctr[abi.C_ALGO_CLS] - fa) + 16.0 * inc_pair,
+        "k_pair": 4.0 * v_pair + 8.0 * (ctr[abi.C_ALGO_CLS] - fa) + 16.0 * inc_pair,
         # the walk: one graph look-up (8 B node + 1 B edge mask, the PREF.graph.umap entry) and one TR-set look-up (8 B) per
         # k-mer of both mates of every walked pair, + 16 B per count increment
         "k_walk_pairs": (walk_probes * 17.0 + 16.0 * ctr[abi.C_ALGO_INC]) if walk else 0.0,

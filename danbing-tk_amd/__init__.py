@@ -269,7 +269,7 @@ class Context:
         n = self._lib.L.dbtk_ctx_path_stats(self.h, v, 24)
         v = [int(x) for x in v[:n]] + [0] * (24 - n)
         return {"probe_items": v[0:3], "probe_pairs": v[3:6], "probe_rest": v[6], "walk_items": v[7:10], "walk_pairs": v[10:13],
-                "walk_rest": v[13], "fused_done": v[14], "fused_redone": v[15], "fused_cls": v[16], "fused_inc": v[17], "walk_locus_ec": v[18], "fused_shared": v[19], "lean_done": v[20]}
+                "walk_rest": v[13], "fused_done": v[14], "fused_redone": v[15], "fused_cls": v[16], "fused_inc": v[17], "walk_locus_ec": v[18], "fused_shared": v[19], "lean_done": v[20], "vote_vv": v[21], "pair_vv": v[22]}
 
     def timers_reset(self):
         self._lib.L.dbtk_ctx_timers_reset(self.h)

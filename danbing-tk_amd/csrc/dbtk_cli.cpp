@@ -364,7 +364,23 @@ int main(int argc, char* argv[]) {
     auto wall = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
     const double tl0 = wall();
     // (the HIP runtime's start — a few tenths of a second — beside the parsing of the RPGG files)
-    std::thread warm([&] { if (!o.parseOnly) { if (const char* e = getenv("DBTK_DEVICE_MAP")) (void)dbtk_device_warmup(atoi(e)); else (void)dbtk_device_warmup(0); } });
+    // (every device the run will use — logical GPU i on device map[i % n], the same rule as dev_of below — each warmed once; a failure is
+    // reported when the thread is joined, before the first context is created: ADVICE r5)
+    std::vector<int> warm_devs;
+    {
+        std::vector<int> wmap;
+        if (const char* e = getenv("DBTK_DEVICE_MAP")) { std::string v(e); size_t at = 0; while (at < v.size()) { wmap.push_back(atoi(v.c_str() + at)); at = v.find(',', at); if (at == std::string::npos) break; ++at; } }
+        for (int i = 0; i < (o.ngpus < 1 ? 1 : o.ngpus); ++i) {
+            const int d = wmap.empty() ? i : wmap[(size_t)i % wmap.size()];
+            if (std::find(warm_devs.begin(), warm_devs.end(), d) == warm_devs.end()) warm_devs.push_back(d);
+        }
+    }
+    std::string warm_err;
+    std::thread warm([&] {
+        if (o.parseOnly) return;
+        for (int d : warm_devs)
+            if (dbtk_device_warmup(d) != DBTK_OK && warm_err.empty()) warm_err = std::string("device ") + std::to_string(d) + ": " + dbtk_last_error();
+    });
     struct WarmJoin { std::thread& t; ~WarmJoin() { if (t.joinable()) t.join(); } } warm_join{warm};
     dbtk_rpgg_t* rpgg = nullptr;
     const bool use_bait = o.bait && !o.extractFastX && !o.threading;  // baitDB is only read and used on that path
@@ -408,6 +424,7 @@ int main(int argc, char* argv[]) {
     auto dev_of = [&](int i) { return devmap.empty() ? i : devmap[(size_t)i % devmap.size()]; };
     std::vector<dbtk_ctx_t*> ctx(o.ngpus, nullptr);
     if (warm.joinable()) warm.join();
+    if (!warm_err.empty()) die_assert("GPU warm-up failed: " + warm_err);
     const double tl1 = wall();
     if (!o.parseOnly)
         for (int d = 0; d < o.ngpus; ++d)
@@ -1573,8 +1590,11 @@ int main(int argc, char* argv[]) {
     }
     // Every output is written and closed.  Handing 28 - 47 GB of HBM tables, the pinned buffers and the 3 GB of the handle back piece by
     // piece takes 0.2 - 0.3 s of a run whose batch loop takes as long: the process ends here and the driver reclaims them at once
-    // (DBTK_TIDY_EXIT=1: free everything first — leak checkers, make asan).
-    if (getenv("DBTK_TIDY_EXIT")) {
+    // (DBTK_TIDY_EXIT=1: free everything first — leak checkers, make asan).  A process that runs under a tool which flushes its data in
+    // a library finalizer or an atexit handler (rocprofv3, gcov, anything preloaded) takes the tidy way by itself: _exit would skip those.
+    const bool tidy = getenv("DBTK_TIDY_EXIT") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("LD_PRELOAD") ||
+                      getenv("HSA_TOOLS_LIB") || getenv("GCOV_PREFIX");
+    if (tidy) {
         for (auto g : spent_ingests) dbtk_ingest_free(g);
         for (auto c : ctx) dbtk_ctx_free(c);
         dbtk_rpgg_free(rpgg);
@@ -1585,7 +1605,9 @@ int main(int argc, char* argv[]) {
                 t_loop - t_main, t_out - t_main, t.tv_sec + 1e-9 * t.tv_nsec - t_main);
     }
     fprintf(stderr, "all done!\n");
-    fflush(stdout); fflush(stderr);
-    if (!getenv("DBTK_TIDY_EXIT")) _exit(0);
+    const bool out_ok = fflush(stdout) == 0 && !ferror(stdout);  // (records go to stdout: a full disk or a closed pipe must not look like success)
+    fflush(stderr);
+    if (!out_ok) { fprintf(stderr, "danbing-tk: writing to stdout failed\n"); if (!tidy) _exit(1); return 1; }
+    if (!tidy) _exit(0);
     return 0;
 }

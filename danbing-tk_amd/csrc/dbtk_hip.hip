@@ -2108,6 +2108,11 @@ dbtk_status_t dbtk_ctx_reset(dbtk_ctx_t* c) {
     HIPCHK(hipMemsetAsync(c->d_small + 3, 0, 4, c->stream));  // a stale error word would be reported against the next run
     if (c->alt.d_small) HIPCHK(hipMemsetAsync(c->alt.d_small + 3, 0, 4, c->stream));
     for (auto& l : c->parked) if (l.d_small) HIPCHK(hipMemsetAsync(l.d_small + 3, 0, 4, c->stream));
+    // pairs appended by dbtk_ingest_align_merged and not yet aligned belong to the run that is being discarded: they must not be
+    // aligned into the fresh accumulators by the next append or flush
+    c->m_bytes = 0; c->m_pairs = 0; c->m_maxlen = 0;
+    c->alt.m_bytes = 0; c->alt.m_pairs = 0; c->alt.m_maxlen = 0;
+    for (auto& l : c->parked) { l.m_bytes = 0; l.m_pairs = 0; l.m_maxlen = 0; }
     HIPCHK(sync_all(c));
     return DBTK_OK;
 }
@@ -2546,27 +2551,37 @@ static dbtk_status_t dbtk_ingest_align_merged_impl(dbtk_ingest_t* g, uint32_t sl
         }
         if (h.nkept) {
             const uint64_t nb = h.flat_bytes, nr = 2ull * h.nkept;
-            // room: grown (copying what is there) when a block does not fit — the buffer ends up at min_pairs' worth plus a block
-            if (c->m_bytes + nb + 64 > c->m_flat_cap) {
-                // (the first time: room for a whole merged batch — min_pairs pairs of this block's longest read, and the block that takes it
-                // past that — so that a run does not grow its way there through a dozen allocations)
-                const uint64_t whole = c->m_flat_cap ? 0 : std::min<uint64_t>(min_pairs, 1ull << 22) * 2 * h.maxlen + nb + 64;
-                const uint64_t want = std::max<uint64_t>(std::max<uint64_t>((c->m_bytes + nb + 64) * 3 / 2, 64ull << 20), whole);
-                uint8_t* nf = nullptr;
-                HIPCHK(hipMalloc(&nf, want));
-                if (c->m_bytes) HIPCHK(hipMemcpyAsync(nf, c->m_flat, c->m_bytes, hipMemcpyDeviceToDevice, s));
-                HIPCHK(hipStreamSynchronize(s));
-                if (c->m_flat) HIPCHK(hipFree(c->m_flat));
-                c->m_flat = nf; c->m_flat_cap = want;
-            }
-            if (2 * c->m_pairs + nr + 1 > c->m_off_cap) {
-                const uint64_t want = std::max<uint64_t>(std::max<uint64_t>((2 * c->m_pairs + nr + 1) * 3 / 2, 1ull << 20), c->m_off_cap ? 0 : 2 * std::min<uint64_t>(min_pairs, 1ull << 22) + nr + 1);
-                uint64_t* no = nullptr;
-                HIPCHK(hipMalloc(&no, want * 8));
-                if (c->m_pairs) HIPCHK(hipMemcpyAsync(no, c->m_off, (2 * c->m_pairs + 1) * 8, hipMemcpyDeviceToDevice, s));
-                HIPCHK(hipStreamSynchronize(s));
-                if (c->m_off) HIPCHK(hipFree(c->m_off));
-                c->m_off = no; c->m_off_cap = want;
+            // room: sized ONCE, for a whole merged batch — min_pairs pairs of this block's longest read plus the block that takes it past
+            // that (min_pairs itself is bounded: 2^26 pairs, 20 GB of 150-bp reads) — and grown, copying what is there, only when
+            // later blocks hold longer reads.  An allocation that fails (beside 28 - 47 GB of tables) is not the end of the run: the
+            // pairs merged so far are aligned now, and the block starts a new batch in the room there is.
+            const uint64_t mp = std::min<uint64_t>(std::max<uint64_t>(min_pairs, 1), 1ull << 26);
+            if (c->m_bytes + nb + 64 > c->m_flat_cap || 2 * c->m_pairs + nr + 1 > c->m_off_cap) {
+                const uint64_t want_f = std::max<uint64_t>({(c->m_bytes + nb + 64) * 5 / 4, 64ull << 20, mp * 2 * h.maxlen + nb + 64});
+                const uint64_t want_o = std::max<uint64_t>({(2 * c->m_pairs + nr + 1) * 5 / 4, 1ull << 20, 2 * mp + nr + 1});
+                uint8_t* nf = nullptr; uint64_t* no = nullptr;
+                const bool grow_f = c->m_bytes + nb + 64 > c->m_flat_cap, grow_o = 2 * c->m_pairs + nr + 1 > c->m_off_cap;
+                bool ok = (!grow_f || hipMalloc(&nf, want_f) == hipSuccess) && (!grow_o || hipMalloc(&no, want_o * 8) == hipSuccess);
+                if (!ok) {
+                    (void)hipGetLastError();
+                    if (nf) (void)hipFree(nf);
+                    if (no) (void)hipFree(no);
+                    nf = nullptr; no = nullptr;
+                    if (c->m_pairs) {  // align what is there, wait for it, start over in the same buffers
+                        const dbtk_status_t st = launch_batch(c, c->m_flat, c->m_off, ~0ull, c->m_pairs, c->m_maxlen, nullptr, 0, nullptr);
+                        if (st) return st;
+                        HIPCHK(hipStreamSynchronize(s));
+                        c->m_bytes = 0; c->m_pairs = 0; c->m_maxlen = 0;
+                    }
+                    if (nb + 64 > c->m_flat_cap) { if (c->m_flat) HIPCHK(hipFree(c->m_flat)); c->m_flat = nullptr; c->m_flat_cap = 0; HIPCHK(hipMalloc(&nf, nb + 64)); c->m_flat = nf; c->m_flat_cap = nb + 64; }
+                    if (nr + 1 > c->m_off_cap) { if (c->m_off) HIPCHK(hipFree(c->m_off)); c->m_off = nullptr; c->m_off_cap = 0; HIPCHK(hipMalloc(&no, (nr + 1) * 8)); c->m_off = no; c->m_off_cap = nr + 1; }
+                } else {
+                    if (nf && c->m_bytes) HIPCHK(hipMemcpyAsync(nf, c->m_flat, c->m_bytes, hipMemcpyDeviceToDevice, s));
+                    if (no && c->m_pairs) HIPCHK(hipMemcpyAsync(no, c->m_off, (2 * c->m_pairs + 1) * 8, hipMemcpyDeviceToDevice, s));
+                    if ((nf && c->m_flat) || (no && c->m_off)) HIPCHK(hipStreamSynchronize(s));
+                    if (nf) { if (c->m_flat) HIPCHK(hipFree(c->m_flat)); c->m_flat = nf; c->m_flat_cap = want_f; }
+                    if (no) { if (c->m_off) HIPCHK(hipFree(c->m_off)); c->m_off = no; c->m_off_cap = want_o; }
+                }
             }
             HIPCHK(hipMemcpyAsync(c->m_flat + c->m_bytes, S.d_flat, nb, hipMemcpyDeviceToDevice, s));
             LAUNCH(k_off_rebase, dim3((uint32_t)std::min<uint64_t>((nr + 256) / 256, 1024)), dim3(256), s, c->m_off + 2 * c->m_pairs, S.d_off, nr + 1, c->m_bytes);

@@ -1678,6 +1678,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
     const bool okam = a.P.okam != 0;
     // per-block counters, flushed once at the end
     uint64_t c_kf = 0, c_hf = 0, c_qc = 0, c_thr = 0, c_feas = 0, c_asgn = 0, c_nhash1 = 0, c_vv = 0, c_cls = 0, c_inc = 0, c_bait = 0;
+    uint64_t c_vote = 0;  // vv words the vote read (a path statistic, DBTK_PS_VOTE_VV: which pairs are voted on at all depends on the path)
     DBTK_STAMP_DECL
     const uint32_t nsurv = *a.nsurv;
     const uint32_t nslp = a.nkp >> 6;  // slots the hit buffers reserve per read
@@ -2112,7 +2113,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 if (vote_parallel<NHMAX / 64, 2 * NHMAX>(x, sm.u.v.ord, sm.w.a.uval, sm.w.a.dd, sm.u.v.nml, sm.w.a.poff, sm.evd,
                                                         reinterpret_cast<uint32_t*>(&sm.u), reinterpret_cast<uint32_t*>(&sm.w), sm.evd, nu, cth,
                                                         ptop, pvvw)) {
-                    c_vv += pvvw;
+                    c_vote += pvvw;
                     dst0 = (uint32_t)ptop.idx;
                     nm1 = (int)ptop.fc; nm2 = (int)ptop.rc;
                 } else {  // events do not fit in LDS: the literal loop on one lane
@@ -2131,7 +2132,7 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                         Asgn top;
                         uint64_t nvvw = 0;
                         vote(T, sm.u.v.ord, sm.w.a.uval, sm.w.a.dd, (int)nu, cth, hmap, top, nvvw, sm.u.v.nml, sm.evd, sm.w.a.poff);
-                        c_vv += nvvw;
+                        c_vote += nvvw;
                         if (hmap.spilled) DBTK_COH_STORE(&a.vote_epoch[row], ep);
                         DBTK_COH_RELEASE();
                         DBTK_COH_STORE(&a.vote_busy[row], 0ull);
@@ -2344,6 +2345,8 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
         if (c_asgn) x.atomic_add(&ctr[DBTK_C_ASGN], c_asgn);
         if (c_bait) x.atomic_add(&ctr[DBTK_C_BAITFILTERED], c_bait);
         if (c_vv) x.atomic_add(&ctr[DBTK_C_ALGO_VV], c_vv);
+        if (c_vote && a.pstats) x.atomic_add(&a.pstats[DBTK_PS_VOTE_VV], c_vote);
+        if (c_vv && a.pstats) x.atomic_add(&a.pstats[DBTK_PS_PAIR_VV], c_vv);
         if (c_cls) x.atomic_add(&ctr[DBTK_C_ALGO_CLS], c_cls);
         if (c_inc) x.atomic_add(&ctr[DBTK_C_ALGO_INC], c_inc);
         if (c_nhash1) {

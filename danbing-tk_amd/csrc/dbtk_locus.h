@@ -1129,44 +1129,54 @@ DBTK_HD void body_probe_locus(X& x, const BatchArgs& a, const LocRunArgs& r) {
             uint32_t nshared = 0;  // (uniform) positions of the pair whose k-mer is shared between loci, when the pair is resolved here all the same
             if (FUSE) {
                 const uint32_t nk0 = x.bcast(nk, 0), nk1 = x.bcast(nk, 32), nh0 = x.bcast(nh, 0), nh1 = x.bcast(nh, 32);
-                spec = clean && !again && x.ballot(multi) == 0 && nk0 >= cth && nk1 >= cth && nh0 >= cth && nh1 >= cth && nh0 && nh1;
+                spec = clean && !again && x.ballot(multi) == 0 && nk0 >= cth && nk1 >= cth;
                 // A pair with k-mers SHARED between loci is still this locus' — whatever order fillstats' unstable sort leaves the k-mers
-                // in — when the k-mers unique to the locus alone decide: they sort first (one locus each: AQ.cpp:320-321), so the locus
-                // leads from the first k-mer on and every shared k-mer adds to it too (their lists hold it: that is why they are in its
-                // image); the early stop of find_matching_locus (AQ.cpp:383-419) falls inside that prefix when they outnumber the shared
-                // ones (top - second >= remain), and the second loop ends on them when each mate has cth of them — before any vv list
-                // is read.  countHit then accepts (both strands >= cth).  What the shared k-mers still cost the reference is one vv
-                // word each in fillstats (their distinct number: DBTK_C_ALGO_VV, below).
-                const uint64_t shm = x.ballot((stbits >> 16) != 0);
-                if (spec && shm) {
-                    const uint32_t ns = x.wave_sum((uint32_t)__builtin_popcount(stbits >> 16));
-                    if (nh0 + nh1 >= ns && ns <= (uint32_t)LOC_Q * 3 / 4) nshared = ns; else spec = false;  // (the cap: they are de-duplicated in the queue's array)
+                // in — when (i) every found k-mer names the locus (the unique ones by their value, the shared ones by being in its image:
+                // their vv lists hold it), (ii) at least one of them is unique to it and (iii) each mate has cth found positions, shared
+                // ones included.  std::sort orders by the number of loci (AQ.cpp:320-327: only the order among EQUAL keys is
+                // unspecified), so the k-mers unique to the locus come first: after the first of them the locus leads every other one
+                // by at least that k-mer's count, and every later k-mer adds to the locus what it adds to any other — inside a shared
+                // k-mer's list another locus may pass it for the moment (updatetop2, AQ.cpp:331-349), by the end of the list the locus
+                // is `top` again, and find_matching_locus only looks at `top` between k-mers (AQ.cpp:383).  Wherever its first loop
+                // breaks, the second (AQ.cpp:396-418) goes on adding the k-mers that hold top.idx — all of them — while a strand is
+                // below cth and the remaining counts could still lift it there: with D_m >= cth found positions in mate m, "fc < cth
+                // and cth - fc > remain" would mean D_1 - fc <= remain < cth - fc, i.e. D_1 < cth.  So it ends with fc >= cth and
+                // rc >= cth, and countHit accepts the locus (AQ.cpp:439-451).  The partial sums nm1 / nm2 do depend on the order: trace
+                // mode never comes here.  (Round 5 asked for cth UNIQUE positions per mate and no more shared than unique ones, at most
+                // 96: that left 1.3 % of an all-hit batch — pairs reaching into a flank shared with a neighbour — to body_pair's introsort.)
+                // What the shared k-mers still cost the reference is one vv word each in fillstats (their distinct number:
+                // DBTK_C_ALGO_VV, below).
+                const uint32_t sh = x.half_sum((uint32_t)__builtin_popcount(stbits >> 16));
+                const uint32_t s0 = x.bcast(sh, 0), s1 = x.bcast(sh, 32);
+                if (spec) {
+                    if (s0 + s1 == 0) spec = nh0 >= cth && nh1 >= cth && nh0 && nh1;
+                    else {
+                        spec = nh0 + s0 >= cth && nh1 + s1 >= cth && nh0 + nh1 >= 1;
+                        if (spec) nshared = s0 + s1;
+                    }
                 }
                 if (lane == 0) { sm.spec[nrow >> 1].i = i; sm.spec[nrow >> 1].flags = spec ? LSP_SPEC : 0u; }  // (before anything of the pair is queued: the look-ups ask)
             }
             uint32_t pexq = pex, ptotq = ptot;  // places in the queue: without the shared k-mers when the pair is resolved here
             uint32_t nvv = 0;                   // (uniform) vv words fillstats reads for the pair: one per DISTINCT shared k-mer (AQ.cpp:311-316)
             if (FUSE && nshared) {
-                // distinct shared k-mers of the pair (the mates overlap, a repeat repeats): they are written behind the queue's entries
-                // (room: the queue is looked up first if need be) and every one is compared with the ones before it
-                if ((uint32_t)LOC_Q - qn < nshared) flush();
-                uint32_t mine = (uint32_t)__builtin_popcount(stbits >> 16);
-                const uint32_t at0 = x.wave_excl_scan(mine);
-                {
-                    uint32_t at = at0;
-#pragma unroll
-                    for (int j = 0; j < NPL; ++j) if ((stbits >> (16 + j)) & 1u) sm.qkm[qn + at++] = km[j];
-                }
-                x.sync();
+                // distinct shared k-mers of the pair (the mates overlap, a repeat repeats): every one is handed round the wave from its
+                // lane's registers and compared with the ones after it — in the order (j, lane) — so that of equal ones all but the first
+                // are marked; no LDS, no cap on their number
                 uint32_t dupb = 0;
-                for (uint32_t e = 0; e + 1 < nshared; ++e) {  // (entry e against the lane's own later ones)
-                    const uint64_t ke = sm.qkm[qn + e];
-                    uint32_t at = at0;
 #pragma unroll
-                    for (int j = 0; j < NPL; ++j) if ((stbits >> (16 + j)) & 1u) { if (at > e && km[j] == ke) dupb |= 1u << j; ++at; }
+                for (int j = 0; j < NPL; ++j) {
+                    uint64_t mj = x.ballot(((stbits >> (16 + j)) & 1u) != 0);
+                    while (mj) {
+                        const int src = (int)__builtin_ctzll(mj);
+                        mj &= mj - 1;
+                        const uint64_t ke = ((uint64_t)x.bcast((uint32_t)(km[j] >> 32), src) << 32) | x.bcast((uint32_t)km[j], src);
+#pragma unroll
+                        for (int j2 = j; j2 < NPL; ++j2)
+                            if (((stbits >> (16 + j2)) & 1u) && km[j2] == ke && (j2 > j || lane > src)) dupb |= 1u << j2;
+                    }
                 }
                 nvv = nshared - x.wave_sum((uint32_t)__builtin_popcount(dupb));
-                x.sync();
             }
             if (FUSE && nshared) {
 #pragma unroll

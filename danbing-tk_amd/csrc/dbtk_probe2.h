@@ -65,7 +65,7 @@ constexpr uint32_t P2_HWIN = 2048;
 // spare words of a counter replica row (CTR_STRIDE = 32 words, DBTK_C_COUNT = 24 counters): the lean kernel's path statistics
 constexpr uint32_t P2_REP_DONE = 24, P2_REP_CLS = 25, P2_REP_INC = 26, P2_REP_SHARED = 27;
 #ifndef DBTK_P2_SHARED_MAX
-#define DBTK_P2_SHARED_MAX 48  /* (16 / 32 / 48 / 96 measured: probe + resolve of a WGS-like step 0.477 / 0.473 / 0.455 / 0.469 ms; all-hit the same within 1 %) */
+#define DBTK_P2_SHARED_MAX 320  /* no cap (round 5, when a pair over the cap cost body_pair a tenth of what it costs now: 16 / 32 / 48 / 96 measured 0.477 / 0.473 / 0.455 / 0.469 ms per WGS-like step) */
 #endif
 constexpr uint32_t P2_SHARED_MAX = DBTK_P2_SHARED_MAX;  // shared positions of a pair the shortcut takes: each costs a look-up in the class table
 static_assert(P2_HWIN / 2 * 4 <= sizeof(uint4) * P2_RCH * P2_ROW, "the counter window fits where the buckets were");
@@ -261,24 +261,22 @@ DBTK_HD_NOINLINE bool p2_resolve_shared(X& x, SM& sm, P2Rv<NPL> rv, uint32_t nk,
         }
     }
     if (x.ballot(bad)) return false;
-    // distinct shared k-mers of the pair (the mates overlap, a repeat repeats): every one against the ones before it
-    uint64_t* sk = reinterpret_cast<uint64_t*>(sm.stg);
-    const uint32_t at0 = x.wave_excl_scan(mine);
-    {
-        uint32_t at = at0;
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) if (sh[j]) sk[at++] = km[j];
-    }
-    x.sync();
+    // distinct shared k-mers of the pair (the mates overlap, a repeat repeats): every one is handed round the wave from its lane's
+    // registers and compared with the ones after it in the order (j, lane): of equal ones all but the first are marked
     uint32_t dup = 0;
-    for (uint32_t e = 0; e + 1 < nshared; ++e) {
-        const uint64_t ke = sk[e];
-        uint32_t at = at0;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) if (sh[j]) { if (at > e && km[j] == ke) dup |= 1u << j; ++at; }
+    for (int j = 0; j < NPL; ++j) {
+        uint64_t mj = x.ballot(sh[j]);
+        while (mj) {
+            const int src = (int)__builtin_ctzll(mj);
+            mj &= mj - 1;
+            const uint64_t ke = ((uint64_t)x.bcast((uint32_t)(km[j] >> 32), src) << 32) | x.bcast((uint32_t)km[j], src);
+#pragma unroll
+            for (int j2 = j; j2 < NPL; ++j2)
+                if (sh[j2] && km[j2] == ke && (j2 > j || lane > src)) dup |= 1u << j2;
+        }
     }
     const uint32_t nvv = nshared - x.wave_sum((uint32_t)__builtin_popcount(dup));
-    x.sync();
     if (lane == 0) { sm.fc[P2C_VV] += nvv; sm.fc[P2C_SHARED] += 1; }
     p2_resolve_usual<NPL>(x, sm, rv, nk, 2u * L, nks, t);
     return true;
@@ -617,8 +615,11 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
                         const uint32_t hu = x.half_sum(cu), hs = x.half_sum(cs), hux = x.half_max(umx), hun = ~x.half_max(~umn);
                         const uint32_t u0n = x.bcast(hu, 0), u1n = x.bcast(hu, 32), ns = x.bcast(hs, 0) + x.bcast(hs, 32);
                         const uint32_t x0 = x.bcast(hux, 0), x1 = x.bcast(hux, 32), n0 = x.bcast(hun, 0), n1 = x.bcast(hun, 32);
-                        if (T.consistent && ns && ns <= P2_SHARED_MAX && u0n >= cth && u1n >= cth && u0n + u1n >= ns && x0 == n0 && x1 == n1 && x0 == x1)
-                            done = p2_resolve_shared<NPL>(x, sm, rvs, nk, rsh, k, x0 >> 1, ns, nk0 + nk1, a.t0 + place_v);
+                        // (round 6: one k-mer unique to the locus is enough, and each mate needs cth FOUND positions — which "not gone" says —
+                        // not cth unique ones: body_probe_locus, dbtk_locus.h, has the argument)
+                        const uint32_t wx = x0 > x1 ? x0 : x1, wn = n0 < n1 ? n0 : n1;  // (a mate without a unique k-mer: 0 / ~0)
+                        if (T.consistent && ns && ns <= P2_SHARED_MAX && u0n + u1n >= 1 && wx == wn)
+                            done = p2_resolve_shared<NPL>(x, sm, rvs, nk, rsh, k, wx >> 1, ns, nk0 + nk1, a.t0 + place_v);
                     }
                     if (!done) {  // the general resolve kernel redoes this pair from its rows
                         if (lane == 0) sm.gbuf[ngb] = a.t0 + place_v;

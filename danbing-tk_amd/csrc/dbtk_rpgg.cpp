@@ -88,7 +88,7 @@ dbtk_status_t read_tr_kmers(const std::string& fn, std::vector<uint64_t>& cnt, s
     }
     struct Piece { std::vector<uint64_t> cnt, ks; uint64_t head = 0; int err = 0; };  // head: k-mer lines before the piece's first '>' line
     std::vector<Piece> pc(nth);
-    auto parse = [&](unsigned t) {
+    auto parse_piece = [&](unsigned t) {
         Piece& P = pc[t];
         const char* p = cut[t];
         const char* const pe = cut[t + 1];
@@ -110,6 +110,10 @@ dbtk_status_t read_tr_kmers(const std::string& fn, std::vector<uint64_t>& cnt, s
             p = nl + 1;
         }
     };
+    // (no exception may leave a thread: a bad_alloc from a piece's push_back becomes the piece's error — ADVICE r5)
+    auto parse = [&](unsigned t) {
+        try { parse_piece(t); } catch (const std::bad_alloc&) { pc[t].err = 3; } catch (...) { pc[t].err = 4; }
+    };
     if (nth == 1) parse(0);
     else {
         std::vector<std::thread> th;
@@ -121,10 +125,12 @@ dbtk_status_t read_tr_kmers(const std::string& fn, std::vector<uint64_t>& cnt, s
     cnt.reserve(cnt.size() + nl);
     ks.reserve(ks.size() + nk);
     for (auto& P : pc) {  // (in file order: the first error of the file is the one reported)
-        if (P.head) {
-            if (cnt.empty()) { set_error(fn + ": k-mer before the first '>' line"); return DBTK_ERR_FORMAT; }
-            cnt.back() += P.head;
-        }
+        if (P.err == 3) { set_error(fn + ": out of memory"); return DBTK_ERR_NOMEM; }
+        if (P.err == 4) { set_error(fn + ": internal error while parsing"); return DBTK_ERR_FORMAT; }
+        // a line before the file's first '>' is "a k-mer before the first '>' line" whether it parses as a k-mer or not (the message the
+        // one-threaded reader gave: a piece that stopped at a malformed line before any '>' counts it as head)
+        if ((P.head || (P.err && P.cnt.empty())) && cnt.empty()) { set_error(fn + ": k-mer before the first '>' line"); return DBTK_ERR_FORMAT; }
+        if (P.head) cnt.back() += P.head;
         if (P.err) { set_error(fn + ": not a k-mer line"); return DBTK_ERR_FORMAT; }
         cnt.insert(cnt.end(), P.cnt.begin(), P.cnt.end());
         ks.insert(ks.end(), P.ks.begin(), P.ks.end());

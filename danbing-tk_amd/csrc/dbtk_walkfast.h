@@ -692,7 +692,6 @@ DBTK_HD void body_walk_pairs_locus(X& x, const WalkArgs& a, const LocRunArgs& r)
 #endif
     if (x.tid() == 0) { smb.c.T = a.T; smb.c.P = a.P; smb.c.T.gimg = reinterpret_cast<const uint32_t*>(smb.img); smb.c.T.gimg_lgnb = 0; }
     x.bsync();
-    const DevTables& T = smb.c.T;
     uint64_t* const ctr = a.ctr_rep ? a.ctr_rep + (size_t)(x.bid() & (W_CTR_REP - 1)) * W_CTR_STRIDE : a.counters;
     const uint32_t ifirst = r.starts[x.bid()], nitems = r.starts[x.bid() + 1];
     auto desc = [&](uint32_t it) -> uint4 { return r.items[it < nitems ? it : 0u]; };

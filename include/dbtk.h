@@ -184,7 +184,9 @@ enum {
     DBTK_C_FEASIBLE, DBTK_C_ASGN, DBTK_C_NSHORT, DBTK_C_NHASH0, DBTK_C_NHASH1,
     /* algorithmic work of SURVEY.md 8(d): B = 2L + 12 P + 4 V + 8 A + 16 I per pair */
     DBTK_C_ALGO_PROBES,   /* P: index lookups the reference algorithm performs (subfilter + kfilter) */
-    DBTK_C_ALGO_VV,       /* V: uint32 words of vv read by fillstats / find_matching_locus */
+    DBTK_C_ALGO_VV,       /* V: uint32 words of vv read by fillstats (one per distinct k-mer whose index value is a list, AQ.cpp:311-316).  The
+                           * list words find_matching_locus goes on to read depend on the order std::sort leaves equal keys in, and a pair
+                           * whose outcome is proven without the vote reads none: they are the path statistic DBTK_PS_VOTE_VV, not a counter */
     DBTK_C_ALGO_CLS,      /* A: k-mers classified by assignTRkmc (one flank/TR lookup each) */
     DBTK_C_ALGO_INC,      /* I: TR k-mer count increments */
     DBTK_C_SURVIVORS,     /* pairs that passed subfilter (entered kfilter) */
@@ -423,6 +425,10 @@ int  dbtk_ctx_table_bytes(dbtk_ctx_t* ctx, const char** names, uint64_t* bytes, 
 #define DBTK_PS_FUSED_SHARED 19u /* ... of the pairs resolved there, those with k-mers shared between loci (decided by the k-mers unique to the locus) */
 #define DBTK_PS_LEAN_DONE    20u /* pairs the LEAN probe kernel resolved itself (the usual pair, and the pair kfilter removes altogether are not counted
                                   * here: only pairs resolved through assignTRkmc / QC / threading hand-over); its share of CLS / INC is in FUSED_CLS / _INC */
+#define DBTK_PS_VOTE_VV      21u /* vv words read by the votes that were held (find_matching_locus, AQ.cpp:364-422: body_pair's pairs only; <= what the
+                                  * reference reads for the same batch, which votes on every pair) */
+#define DBTK_PS_PAIR_VV      22u /* of DBTK_C_ALGO_VV (fillstats' words), the part of the pairs body_pair handled: the rest was accounted by the fused probe
+                                  * kernels, which read no vv word at all (bench.py prices each kernel with its own) */
 #define DBTK_PS_WALK_LOCUS_EC 18u /* pairs the error-correcting walk took with the locus' graph image in LDS (k_walk_pairs_locus) */
 int  dbtk_ctx_path_stats(dbtk_ctx_t* ctx, uint64_t* out, int cap);
 void dbtk_ctx_timers_reset(dbtk_ctx_t* ctx);

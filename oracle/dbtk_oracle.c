@@ -769,10 +769,18 @@ static inline void touch(hits_t* h, uint32_t locus) {
     }
 }
 
+/* vv words find_matching_locus read in every vote since the last orc_vote_vv_reset(): the reference votes on every pair, in the order
+ * std::sort left the k-mers in (AQ.cpp:364-422).  Kept beside the counters, not among them: the product proves most pairs' outcome without
+ * the vote and reads none of these words for them (include/dbtk.h: DBTK_PS_VOTE_VV is its own, smaller, figure).  Not thread-safe: the
+ * tests run one oracle call at a time. */
+static uint64_t orc_vote_vv_words = 0;
+uint64_t orc_vote_vv(void) { return orc_vote_vv_words; }
+void orc_vote_vv_reset(void) { orc_vote_vv_words = 0; }
+
 /* countHit, AQ.cpp:424-453 = fillstats (308-329) + find_matching_locus (364-422). */
 static uint64_t count_hit(const orc_rpgg_t* g, hit_t* its1, uint64_t n1, hit_t* its2, uint64_t n2, hits_t* H,
                           uint32_t cth, uint64_t* tri0, int* nm1, int* nm2, int* hf1, int* hf2, int* rm1, int* rm2,
-                          uint64_t* nvvw) {
+                          uint64_t* nvvw, uint64_t* nvote) {
     /* countDupRemove, AQ.cpp:257-296 */
     uint64_t n = n1 + n2;
     hit_o_t* all = (hit_o_t*)malloc((n + 1) * sizeof(hit_o_t));
@@ -821,7 +829,7 @@ static uint64_t count_hit(const orc_rpgg_t* g, hit_t* its1, uint64_t n1, hit_t* 
         uint32_t vi = su[i].val;
         if (vi % 2) {
             uint64_t j0 = (vi >> 1) + 1, j1 = j0 + g->vv[vi >> 1];
-            *nvvw += 1 + (j1 - j0);
+            *nvote += 1 + (j1 - j0);
             for (; j0 < j1; ++j0) {
                 uint32_t locus = g->vv[j0];
                 touch(H, locus);
@@ -844,9 +852,9 @@ static uint64_t count_hit(const orc_rpgg_t* g, hit_t* its1, uint64_t n1, hit_t* 
                 uint32_t vj = su[j].val;
                 if (vj % 2) {
                     uint64_t j0 = (vj >> 1) + 1, j1 = j0 + g->vv[vj >> 1];
-                    *nvvw += 1;
+                    *nvote += 1;
                     for (; j0 < j1; ++j0) {
-                        *nvvw += 1;
+                        *nvote += 1;
                         if (g->vv[j0] == top.idx) { top.fc += sdup[j].first; top.rc += sdup[j].second; break; }
                     }
                 } else if ((vj >> 1) == top.idx) {
@@ -1058,7 +1066,7 @@ int orc_align_walk(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* s
     uint64_t *caks1 = malloc(ML * 8), *caks2 = malloc(ML * 8), *caes1 = malloc(ML * 8), *caes2 = malloc(ML * 8);
     hit_t *its1 = malloc(ML * sizeof(hit_t)), *its2 = malloc(ML * sizeof(hit_t));
     uint64_t nShort = 0, nSub = 0, nKf = 0, nLocus = 0, nQC = 0, nThr = 0, nFeas = 0, nAsgn = 0, nhash0 = 0, nhash1 = 0, nprobe = 0;
-    uint64_t nvvw = 0, ncls = 0, ninc = 0, nsurv = 0, nbases = 0;
+    uint64_t nvvw = 0, nvote = 0, ncls = 0, ninc = 0, nsurv = 0, nbases = 0;
 
     for (uint64_t pi = 0; pi < npairs; ++pi) {
         const uint8_t* s1 = seq + off[2 * pi];     uint64_t l1 = off[2 * pi + 1] - off[2 * pi];
@@ -1093,7 +1101,7 @@ int orc_align_walk(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* s
             nKf += (uint64_t)(kf1 + kf2);
             if (rm1 && rm2) { stage = DBTK_STAGE_KFILTER; goto emit; }
             /* AQ.cpp:2056-2062 */
-            destLocus = count_hit(g, its1, n1, its2, n2, &H, p->cthreshold, &destLocus0, &nm1, &nm2, &hf1, &hf2, &rm1, &rm2, &nvvw);
+            destLocus = count_hit(g, its1, n1, its2, n2, &H, p->cthreshold, &destLocus0, &nm1, &nm2, &hf1, &hf2, &rm1, &rm2, &nvvw, &nvote);
             nLocus += (uint64_t)(hf1 + hf2);
             if (destLocus == nloci) { stage = DBTK_STAGE_LOCUS; goto emit; }
             if (p->qc && g->qc && !g->qc[destLocus]) { nQC += (uint64_t)(2 - rm1 - rm2); stage = DBTK_STAGE_QC; goto emit; }
@@ -1216,6 +1224,7 @@ int orc_align_walk(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* s
     C[DBTK_C_NHASH1] += nhash1;
     C[DBTK_C_ALGO_PROBES] += nprobe;
     C[DBTK_C_ALGO_VV] += nvvw;
+    orc_vote_vv_words += nvote;
     C[DBTK_C_ALGO_CLS] += ncls;
     C[DBTK_C_ALGO_INC] += ninc;
     C[DBTK_C_SURVIVORS] += nsurv;

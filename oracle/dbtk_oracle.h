@@ -37,6 +37,9 @@ const uint64_t* orc_rpgg_tr_ks(const orc_rpgg_t* g);
  * counts_fileorder[ntrkmers] is indexed like PREF.tr.kmers (file order), NOT
  * like OUT.trkmc.ar; all outputs ACCUMULATE.  recs: NULL, or npairs records
  * (one per pair, `trace` semantics of include/dbtk.h). */
+/* vv words read by the votes (find_matching_locus) of every orc_align* call since the last reset: see dbtk_oracle.c */
+uint64_t orc_vote_vv(void);
+void orc_vote_vv_reset(void);
 int orc_align(const orc_rpgg_t* g, const dbtk_params_t* p, const uint8_t* seq,
               const uint64_t* off, uint64_t npairs, uint64_t* counts_fileorder, uint64_t* kmc,
               uint32_t* nmapread, uint64_t* counters, dbtk_pair_rec_t* recs);

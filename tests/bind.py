@@ -63,6 +63,10 @@ class Oracle:
         L.orc_rpgg_nloci.argtypes = [C.c_void_p]
         L.orc_rpgg_ntrkmers.restype = C.c_uint64
         L.orc_rpgg_ntrkmers.argtypes = [C.c_void_p]
+        L.orc_vote_vv.restype = C.c_uint64
+        L.orc_vote_vv.argtypes = []
+        L.orc_vote_vv_reset.restype = None
+        L.orc_vote_vv_reset.argtypes = []
         L.orc_align.restype = C.c_int
         L.orc_align.argtypes = [C.c_void_p, C.POINTER(abi.Params), u8p, u64p, C.c_uint64, u64p, u64p, u32p, u64p,
                                 C.POINTER(abi.PairRec)]
@@ -145,11 +149,14 @@ class Oracle:
         seq = np.ascontiguousarray(seq, np.uint8)
         if seq.size == 0:
             seq = np.zeros(1, np.uint8)
+        self.L.orc_vote_vv_reset()
         rc = self.L.orc_align(h, C.byref(params), _p(seq, u8p), _p(off, u64p), npairs, _p(counts, u64p), _p(kmc, u64p),
                               _p(nmap, u32p), _p(ctr, u64p), recs)
         if rc:
             raise RuntimeError(f"orc_align -> {rc}")
-        return dict(counts_file=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs)
+        # vote_vv: the vv words the reference's votes read for this batch (it votes on every pair); the product's own figure, the path
+        # statistic "vote_vv", can only be smaller
+        return dict(counts_file=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs, vote_vv=int(self.L.orc_vote_vv()))
 
     def load_bait(self, h, bait_file):
         if self.L.orc_rpgg_load_bait(h, bait_file.encode()):
@@ -170,11 +177,13 @@ class Oracle:
         wo = WalkOut(res, trecs, npairs, 0)
         nev = C.c_uint64(0)
         seq = np.ascontiguousarray(seq, np.uint8)
+        self.L.orc_vote_vv_reset()
         rc = self.L.orc_align_walk(h, C.byref(params), _p(seq, u8p), _p(off, u64p), None, npairs, _p(counts, u64p), _p(kmc, u64p),
                                    _p(nmap, u32p), _p(ctr, u64p), recs, None, 0, C.byref(nev), C.byref(wo))
         if rc:
             raise RuntimeError(f"orc_align_walk -> {rc}")
-        return dict(counts_file=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs, res=res, trecs=trecs, nres=int(wo.n))
+        return dict(counts_file=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs, res=res, trecs=trecs, nres=int(wo.n),
+                    vote_vv=int(self.L.orc_vote_vv()))
 
     def qmask(self, qual: bytes, qth, k):
         m = np.zeros(max(len(qual), 1), np.uint8)
@@ -193,13 +202,14 @@ class Oracle:
         ev = (BubEvent * evcap)() if params.bubbles else None
         nev = C.c_uint64(0)
         seq = np.ascontiguousarray(seq, np.uint8)
+        self.L.orc_vote_vv_reset()
         rc = self.L.orc_align_ex(h, C.byref(params), _p(seq, u8p), _p(off, u64p), _p(qual, u8p), npairs, _p(counts, u64p),
                                  _p(kmc, u64p), _p(nmap, u32p), _p(ctr, u64p), recs, ev, evcap if ev else 0, C.byref(nev))
         if rc:
             raise RuntimeError(f"orc_align_ex -> {rc}")
         assert nev.value <= evcap
         return dict(counts_file=counts, kmc=kmc, nmapread=nmap, counters=ctr, recs=recs,
-                    events=events_array(ev, nev.value) if ev else None)
+                    events=events_array(ev, nev.value) if ev else None, vote_vv=int(self.L.orc_vote_vv()))
 
     def read2kmers_edges(self, read: bytes, k):
         n = max(len(read), 1)
@@ -520,7 +530,7 @@ class Emu(pkg._HostSide):
         self.L.emu_path_stats(v)
         v = [int(x) for x in v]
         return {"probe_items": v[0:3], "probe_pairs": v[3:6], "probe_rest": v[6], "walk_items": v[7:10], "walk_pairs": v[10:13],
-                "walk_rest": v[13], "fused_done": v[14], "fused_redone": v[15], "walk_locus_ec": v[18], "fused_shared": v[19], "lean_done": v[20]}
+                "walk_rest": v[13], "fused_done": v[14], "fused_redone": v[15], "walk_locus_ec": v[18], "fused_shared": v[19], "lean_done": v[20], "vote_vv": v[21]}
 
     def aln_text(self, npairs):
         """as Context.aln_text: list of (pair, dst, text)"""
