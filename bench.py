@@ -662,6 +662,7 @@ def main():
 
     # ---- N = 1 extras: further read mixes, end to end, CPU baselines
     mixes, e2e, cpu, parity, k25_check = None, None, None, None, None
+    k25_files = 0  # pairs of the k = 25 all-hit FASTA written for the command line's config-4 leg
     dense_checks = []  # per mix: the GPU half of its dense-slice parity check (the oracle half runs with the CPU legs)
     nhit = 0  # pairs of the all-hit FASTA the CLI walk legs read
     if solo and rank == 0:
@@ -786,6 +787,13 @@ def main():
                                                 roofline=dict(roofline_of(dom25, t25), kernels=t25, profiled=pmc_mix("k25", "k_walk_pairs"),
                                                               traffic=(pmc_mix("k25", "k_walk_pairs") or {}).get("traffic")), parity=None)
                 log(f"k = 25 walk mix: {dt25 / args.mix_steps * 1e3:.3f} ms/step, {mixes['walk_k25_gc85_3']['value'] / 1e6:.1f} M reads/s, dominant {dom25} {t25[dom25]['avg_ms']:.3f} ms")
+                if ref_dir and not args.no_e2e:
+                    # config 4 through the drop-in command line too: the k = 25 RPGG as the files the CLI loads, its reads as FASTA
+                    t0 = time.time()
+                    syn25.write_files(os.path.join(ref_dir, "pan25"))
+                    syn25.write_fasta(s25, kp, os.path.join(ref_dir, "reads_hit25.fa"), rlen=rlen)
+                    k25_files = kp
+                    log(f"k = 25 RPGG files + {2 * kp} reads as FASTA: {time.time() - t0:.1f}s")
                 del d_s25, d_o25
                 k25_check = None
                 if args.cpu_seconds > 0 and args.k25_parity_pairs > 0:
@@ -877,6 +885,19 @@ def main():
                         ing = [l for l in r.stderr.splitlines() if l.startswith("ingest:")]
                         em = [l for l in r.stderr.splitlines() if l.startswith("emit:")]
                         legs[name] = dict(wall_s=tw, returncode=r.returncode, batch_loop=ing[0] if ing else None, emit=em[0] if em else None)
+                    if k25_files and os.path.exists(os.path.join(ref_dir, "pan25.graph.umap")):
+                        # BASELINE config 4 through the command line: k = 25, -gc 85 3, every assigned pair walked
+                        b25 = [cli, "-k", "25", "-kf", "4", "1", "-cth", "45", "--v13-threading", "-gc", "85", "3", "-fa", "reads_hit25.fa", "-qs", "pan25", "-o", "cliw25"]
+                        for name in ("walk_k25", "walk_k25_again"):
+                            t0 = time.perf_counter()
+                            r = subprocess.run(b25, cwd=ref_dir, capture_output=True, text=True)
+                            tw = time.perf_counter() - t0
+                            ing = [l for l in r.stderr.splitlines() if l.startswith("ingest:")]
+                            legs[name] = dict(wall_s=tw, returncode=r.returncode, batch_loop=ing[0] if ing else None, reads=2 * k25_files,
+                                              load=([l for l in r.stderr.splitlines() if l.startswith("load:")] or [None])[0])
+                        log(f"CLI walk at k = 25 (config 4 through the command line): {legs['walk_k25']['batch_loop']}")
+                        for fn in ("reads_hit25.fa",):
+                            os.unlink(os.path.join(ref_dir, fn))
                     gz = os.path.join(ref_dir, "cliw.aln.gz")
                     legs["aln_gz_bytes"] = os.path.getsize(gz) if os.path.exists(gz) else None
                     legs["reads"] = 2 * nhit

@@ -1066,8 +1066,13 @@ int main(int argc, char* argv[]) {
         if (const char* e = getenv("DBTK_INGEST_CHUNK")) { const long v = atol(e); if (v >= 4096) CH = (size_t)v; }  // (tests: many small blocks)
         const bool want_out = want_recs || emit_aln;  // records need titles and reads on the host: the slot's bytes stay until they are written
                                                       // (-a / -ae lines are made on the device, from the spans)
-        uint32_t NS = 12;  // chunks on their way at once (being read, copied, parsed, or waiting for their records to be written): the readers
-                           // run this many chunks ahead of the oldest one not yet done with
+        // reader threads: pread is a memcpy out of the page cache into a pinned buffer — 1.3 to 4 GB/s per thread, against 30 GB/s and more
+        // that the GPU parses — so three quarters of the CPUs this process may use read (round 5: at most 8, which capped a first pass
+        // over a 10-GB file at 15 GB/s), never fewer than one nor more than 24
+        int nio_want = piped ? 1 : (int)std::max(1u, std::min(24u, cpus * 3 / 4 / (unsigned)std::max(1, npipes)));
+        if (const char* e = getenv("DBTK_INGEST_READERS")) { const int v = atoi(e); if (v > 0 && !piped) nio_want = v; }
+        uint32_t NS = (uint32_t)std::max(12, nio_want + 6);  // chunks on their way at once (being read, copied, parsed, or waiting for their records
+                                                             // to be written): the readers run this many chunks ahead of the oldest one not yet done with
         if (const char* e = getenv("DBTK_INGEST_SLOTS")) { const int v = atoi(e); if (v >= 2 && v <= 64) NS = (uint32_t)v; }
         dbtk_ingest_t* ing = nullptr;
         const double ts0 = now();
@@ -1160,8 +1165,7 @@ int main(int argc, char* argv[]) {
             }
         };
         std::vector<std::thread> ios;
-        int nio = piped ? 1 : (int)std::min<uint64_t>(nchunks.load(), std::max(1u, std::min(8u, cpus / 2 / (unsigned)std::max(1, npipes))));  // (the pipelines share the host's threads)
-        if (const char* e = getenv("DBTK_INGEST_READERS")) { const int v = atoi(e); if (v > 0 && !piped) nio = v; }
+        const int nio = piped ? 1 : (int)std::min<uint64_t>(nchunks.load(), (uint64_t)nio_want);  // (the pipelines share the host's threads)
         if (piped) ios.emplace_back(io_pipe);
         else for (int i = 0; i < nio; ++i) ios.emplace_back(io);
         auto release = [&] { { std::lock_guard<std::mutex> l(m); ++nreleased; } cv.notify_all(); };

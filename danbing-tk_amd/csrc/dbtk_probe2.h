@@ -116,7 +116,8 @@ enum { P2C_QC, P2C_KF, P2C_THR, P2C_FEAS, P2C_ASGN, P2C_CLS, P2C_INC, P2C_NHASH1
 // both mates cleared by kfilter: nothing is left to vote on (a background pair that got through subfilter on a shared repeat).  What kfilter
 // looked up before it gave up: the positions up to the (nk - cth + 1)-th miss; none for a mate with nk < cth (AQ.cpp:190-228).
 template <int NPL, class SM, class X>
-DBTK_HD_NOINLINE void p2_resolve_gone(X& x, SM& sm, P2Rv<NPL> rv, uint32_t nk) {
+DBTK_HD_NOINLINE void p2_resolve_gone(X& x, SM& sm_, P2Rv<NPL> rv, uint32_t nk) {
+    SM& sm = DBTK_LDS_REF(SM, sm_);  // (dbtk_tables.h: an out-of-line routine must be told that its reference is LDS)
     const int lane = x.lane();
     const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5, p0 = hl * NPL, cth = sm.fa.P.cthreshold;
     uint32_t mc = 0;
@@ -139,7 +140,8 @@ DBTK_HD_NOINLINE void p2_resolve_gone(X& x, SM& sm, P2Rv<NPL> rv, uint32_t nk) {
 // the usual pair: both mates pass kfilter, every found k-mer unique to the locus v0 >> 1 — countHit needs no sort and no vote
 // (body_pair_usual has the argument); nks = k-mers of both mates, t = the pair's place in the survivor list
 template <int NPL, class SM, class X>
-DBTK_HD_NOINLINE void p2_resolve_usual(X& x, SM& sm, P2Rv<NPL> rv, uint32_t nk, uint32_t v0, uint32_t nks, uint32_t t) {
+DBTK_HD_NOINLINE void p2_resolve_usual(X& x, SM& sm_, P2Rv<NPL> rv, uint32_t nk, uint32_t v0, uint32_t nks, uint32_t t) {
+    SM& sm = DBTK_LDS_REF(SM, sm_);
     const int lane = x.lane();
     const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5, p0 = hl * NPL;
     const P2FuseArgs& fa = sm.fa;
@@ -236,7 +238,8 @@ DBTK_HD_NOINLINE void p2_resolve_usual(X& x, SM& sm, P2Rv<NPL> rv, uint32_t nk, 
 // k-mers still cost the reference is one vv word each in fillstats (their DISTINCT number: DBTK_C_ALGO_VV, AQ.cpp:311-316).
 // The k-mers are re-made from the pair's 2-bit stream (sm.pk: every byte ACGT, the caller's condition); rsh = where the mate starts in it.
 template <int NPL, class SM, class X>
-DBTK_HD_NOINLINE bool p2_resolve_shared(X& x, SM& sm, P2Rv<NPL> rv, uint32_t nk, uint32_t rsh, uint32_t k, uint32_t L, uint32_t nshared, uint32_t nks, uint32_t t) {
+DBTK_HD_NOINLINE bool p2_resolve_shared(X& x, SM& sm_, P2Rv<NPL> rv, uint32_t nk, uint32_t rsh, uint32_t k, uint32_t L, uint32_t nshared, uint32_t nks, uint32_t t) {
+    SM& sm = DBTK_LDS_REF(SM, sm_);
     const int lane = x.lane();
     const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5, p0 = hl * NPL;
     const P2FuseArgs& fa = sm.fa;

@@ -271,12 +271,45 @@ DBTK_HD uint32_t kl_lookup(const ClsSlot* tab, uint64_t mask, uint32_t shift, ui
     }
 }
 
+// An object that is KNOWN to live in LDS, handed to a routine that is not inlined: the routine's parameter is a generic pointer, and when
+// several kernels call it with different LDS objects nothing tells the compiler otherwise — every access becomes a FLAT instruction
+// (slower than a ds_ one, and waited for with vmcnt(0) lgkmcnt(0) both).  Casting the reference to the LDS address space and back lets
+// the address-space inference of the routine's own body see it: ds_read / ds_write again.  (Host build, tests/emu: the reference itself.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DBTK_NO_LDS_REF)
+template <class TYPE> __device__ __forceinline__ TYPE& dbtk_lds_ref(TYPE& r) {
+    __builtin_assume(__builtin_amdgcn_is_shared((const void*)&r));
+    return r;
+}
+#define DBTK_LDS_REF(TYPE, ref) dbtk_lds_ref<TYPE>(ref)
+#else
+#define DBTK_LDS_REF(TYPE, ref) (ref)
+#endif
+
+// Loads through a pointer that is KNOWN to point into HBM although the compiler cannot see it (a DevTables copied into LDS hands its
+// pointers out as generic ones, and a generic load is a FLAT instruction: it counts on the LDS and the vector-memory counters both, may
+// return out of order with either kind, and so every wait for one is `s_waitcnt vmcnt(0) lgkmcnt(0)` — it drains whatever else is in
+// flight, the prefetched next items included).  With the address space stated they are plain global loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t dbtk_v4u_ __attribute__((vector_size(16)));
+DBTK_HD GrSlot gr_slot_load(const GrSlot* p) {
+    const dbtk_v4u_ v = *(const __attribute__((address_space(1))) dbtk_v4u_*)p;
+    GrSlot s;
+    s.kmer = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+    s.li = (uint64_t)v[2] | ((uint64_t)v[3] << 32);
+    return s;
+}
+DBTK_HD uint32_t hbm_load32(const uint32_t* p) { return *(const __attribute__((address_space(1))) uint32_t*)p; }
+#else
+DBTK_HD GrSlot gr_slot_load(const GrSlot* p) { return *p; }
+DBTK_HD uint32_t hbm_load32(const uint32_t* p) { return *p; }
+#endif
+
 // (canonical k-mer, locus) -> info of the graph table; 0 when absent (a stored info is never 0)
 DBTK_HD uint32_t gr_lookup(const DevTables& T, uint64_t canon, uint32_t locus) {
     if (T.gimg) return gimg_find(T.gimg, T.gimg_lgnb, canon);  // (the locus' own image, in LDS: the caller works on this locus only)
     uint64_t i = hash_cls(canon, locus, T.gr_shift);
     for (;;) {
-        const GrSlot s = T.gr[i];
+        const GrSlot s = gr_slot_load(&T.gr[i]);
         if (s.kmer == canon && (uint32_t)(s.li >> 32) == locus) return (uint32_t)s.li;
         if (s.kmer == NAN64) return 0;
         i = (i + 1) & T.gr_mask;

@@ -225,7 +225,7 @@ DBTK_HD uint32_t w_info(const DevTables& T, uint32_t locus, uint64_t fw, uint32_
     const uint64_t rc = revcomp2(fw, k);
     const bool isf = fw <= rc;
     const uint32_t info = gr_lookup(T, isf ? fw : rc, locus);
-    if (slot && (info & GR_TR)) *slot = T.trbeg[locus] + (info >> GR_SLOT_SHIFT);
+    if (slot && (info & GR_TR)) *slot = hbm_load32(&T.trbeg[locus]) + (info >> GR_SLOT_SHIFT);
     const uint32_t a = info & 0x1Fu, b = (info >> GR_OPP) & 0x1Fu;
     return (isf ? (a | (b << GR_OPP)) : (b | (a << GR_OPP))) | (info & GR_TR);
 }
@@ -272,7 +272,9 @@ DBTK_HD void ws_get(X& x, const WalkSmem& sm, WalkState& S) {
 // errorCorrection_backward (AQ.cpp:1091-1106): the same on the reverse-complemented prefix before the anchor ki1.
 // Returns skip; on success sm.st[ST_WID] = the winning hypothesis, sm.st[ST_SCORE] its score; sm.st[ST_FLAGS] = DBTK_THREAD_F_* raised.
 template <class X>
-DBTK_HD_NOINLINE bool walk_ec(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, bool backward, int ki, int nkm, uint32_t mes) {
+DBTK_HD_NOINLINE bool walk_ec(X& x, WalkSmem& sm_, const DevTables& T_, uint32_t locus, bool backward, int ki, int nkm, uint32_t mes) {
+    WalkSmem& sm = DBTK_LDS_REF(WalkSmem, sm_);
+    const DevTables& T = DBTK_LDS_REF(const DevTables, T_);
     const int lane = x.lane();
     const uint32_t k = T.ksize;
     const uint64_t rmask = (1ull << 2 * (k - 1)) - 1;
@@ -497,7 +499,9 @@ DBTK_HD bool walk_find_anchor(X& x, WalkSmem& sm, uint32_t k, WalkState& S) {
 
 // edit_kmers_forward, AQ.cpp:828-862
 template <class X>
-DBTK_HD_NOINLINE void walk_edit_forward(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, int wid, uint32_t score) {
+DBTK_HD_NOINLINE void walk_edit_forward(X& x, WalkSmem& sm_, const DevTables& T_, uint32_t locus, int wid, uint32_t score) {
+    WalkSmem& sm = DBTK_LDS_REF(WalkSmem, sm_);
+    const DevTables& T = DBTK_LDS_REF(const DevTables, T_);
     const int lane = x.lane();
     WalkState S;  // in: sm.ws; out: sm.ws
     ws_get(x, sm, S);
@@ -576,7 +580,9 @@ DBTK_HD_NOINLINE void walk_edit_forward(X& x, WalkSmem& sm, const DevTables& T, 
 // edit_kmers_backward, AQ.cpp:649-825, for the anchor at ki; the state comes and goes in sm.ws; the anchor's new place and the edits'
 // nm / nd / ni are handed back in sm.st[ST_KI, ST_NM, ST_ND, ST_NINS]
 template <class X>
-DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm, const DevTables& T, uint32_t locus, int wid, uint32_t score, int ki) {
+DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm_, const DevTables& T_, uint32_t locus, int wid, uint32_t score, int ki) {
+    WalkSmem& sm = DBTK_LDS_REF(WalkSmem, sm_);
+    const DevTables& T = DBTK_LDS_REF(const DevTables, T_);
     const int lane = x.lane();
     WalkState S;
     ws_get(x, sm, S);
@@ -755,7 +761,10 @@ DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm, const DevTables& T,
 #define DBTK_WALK_SLOW_FN DBTK_HD
 #endif
 template <class X>
-DBTK_WALK_SLOW_FN int walk_slow(X& x, WalkSmem& sm, const DevTables& T, const dbtk_params_t& P, uint32_t locus, int len, int phase) {
+DBTK_WALK_SLOW_FN int walk_slow(X& x, WalkSmem& sm_, const DevTables& T_, const dbtk_params_t& P_, uint32_t locus, int len, int phase) {
+    WalkSmem& sm = DBTK_LDS_REF(WalkSmem, sm_);
+    const DevTables& T = DBTK_LDS_REF(const DevTables, T_);
+    const dbtk_params_t& P = DBTK_LDS_REF(const dbtk_params_t, P_);
     const int lane = x.lane();
     const uint32_t k = T.ksize;
     const uint64_t rmask = (1ull << 2 * (k - 1)) - 1;
@@ -1034,7 +1043,7 @@ DBTK_HD void walk_probe_issue(X& x, WalkSmem& sm, const DevTables& T, uint32_t l
             P.cn[r] = fw <= rc ? fw : rc;
             idx = hash_cls(P.cn[r], locus, T.gr_shift);
         }
-        if (!T.gimg) P.first[r] = T.gr[idx];  // (a position without a k-mer reads slot 0 and ignores it; with the locus' image in LDS: nothing to issue)
+        if (!T.gimg) P.first[r] = gr_slot_load(&T.gr[idx]);  // (a position without a k-mer reads slot 0 and ignores it; with the locus' image in LDS: nothing to issue)
     }
 }
 template <class X>
@@ -1042,6 +1051,7 @@ DBTK_HD void walk_probe_finish(X& x, WalkSmem& sm, const DevTables& T, uint32_t 
     const int lane = x.lane();
     const uint32_t k = T.ksize;
     const int nk = len >= k ? (int)(len - k + 1) : 0;
+    const uint32_t trb = slot ? hbm_load32(&T.trbeg[locus]) : 0u;  // (once per read: inside the loop below it was a memory round trip per 64 positions)
 #pragma unroll
     for (int r = 0; r < W_R; ++r) {
         const int i = 64 * r + lane;
@@ -1054,7 +1064,7 @@ DBTK_HD void walk_probe_finish(X& x, WalkSmem& sm, const DevTables& T, uint32_t 
                 if (sl.kmer == P.cn[r] && (uint32_t)(sl.li >> 32) == locus) { info = (uint32_t)sl.li; break; }
                 if (sl.kmer == NAN64) break;
                 j = (j + 1) & T.gr_mask;
-                sl = T.gr[j];
+                sl = gr_slot_load(&T.gr[j]);
             }
         }
         if (i < nk) {
@@ -1062,7 +1072,7 @@ DBTK_HD void walk_probe_finish(X& x, WalkSmem& sm, const DevTables& T, uint32_t 
             const uint32_t a = info & 0x1Fu, b = (info >> GR_OPP) & 0x1Fu;
             sm.gi[i] = (uint16_t)((isf ? (a | (b << GR_OPP)) : (b | (a << GR_OPP))) | (info & GR_TR));
         }
-        if (slot) slot[i] = (info & GR_TR) ? T.trbeg[locus] + (info >> GR_SLOT_SHIFT) : NAN32;
+        if (slot) slot[i] = (info & GR_TR) ? trb + (info >> GR_SLOT_SHIFT) : NAN32;
     }
     x.sync();
 }
@@ -1091,6 +1101,7 @@ DBTK_HD void walk_info_finish(X& x, WalkSmem& sm, const DevTables& T, uint32_t l
     const int lane = x.lane();
     const uint32_t k = T.ksize;
     const int nk = len >= k ? (int)(len - k + 1) : 0;
+    const uint32_t trb = slot ? hbm_load32(&T.trbeg[locus]) : 0u;  // (once per read)
 #pragma unroll
     for (int r = 0; r < W_R; ++r) {
         const int i = 64 * r + lane;
@@ -1103,7 +1114,7 @@ DBTK_HD void walk_info_finish(X& x, WalkSmem& sm, const DevTables& T, uint32_t l
             const uint32_t a = info & 0x1Fu, b = (info >> GR_OPP) & 0x1Fu;
             sm.gi[i] = (uint16_t)((isf ? (a | (b << GR_OPP)) : (b | (a << GR_OPP))) | (info & GR_TR));
         }
-        if (slot) slot[i] = (info & GR_TR) ? T.trbeg[locus] + (info >> GR_SLOT_SHIFT) : NAN32;
+        if (slot) slot[i] = (info & GR_TR) ? trb + (info >> GR_SLOT_SHIFT) : NAN32;
     }
     x.sync();
 }
@@ -1124,7 +1135,8 @@ DBTK_HD int walk_load(X& x, WalkSmem& sm, const DevTables& T, const uint8_t* seq
 
 // What the walk left in LDS -> a thread record in HBM.
 template <class X>
-DBTK_HD_NOINLINE void walk_store(X& x, const WalkSmem& sm, int ret, dbtk_thread_rec_t* o) {
+DBTK_HD_NOINLINE void walk_store(X& x, const WalkSmem& sm_, int ret, dbtk_thread_rec_t* o) {
+    const WalkSmem& sm = DBTK_LDS_REF(const WalkSmem, sm_);
     const int lane = x.lane();
     WalkState S;  // (sm.ws: put there by the caller)
     ws_get(x, sm, S);
@@ -1144,7 +1156,8 @@ DBTK_HD_NOINLINE void walk_store(X& x, const WalkSmem& sm, int ret, dbtk_thread_
 
 // What the walk left in LDS -> mate m's half of a compact alignment record.
 template <class X>
-DBTK_HD_NOINLINE void walk_store_aln(X& x, const WalkSmem& sm, int ret, uint8_t* rec, uint32_t cap, int m) {
+DBTK_HD_NOINLINE void walk_store_aln(X& x, const WalkSmem& sm_, int ret, uint8_t* rec, uint32_t cap, int m) {
+    const WalkSmem& sm = DBTK_LDS_REF(const WalkSmem, sm_);
     const int lane = x.lane();
     WalkState S;
     ws_get(x, sm, S);
@@ -1345,7 +1358,8 @@ DBTK_HD uint32_t wave_fmt_annot(X& x, const uint8_t* tr, int sz, uint8_t* out) {
 }
 // this mate's two strings into its LDS text buffers
 template <class X>
-DBTK_HD_NOINLINE void walk_format_text(X& x, WalkSmem& sm, uint32_t cap) {
+DBTK_HD_NOINLINE void walk_format_text(X& x, WalkSmem& sm_, uint32_t cap) {
+    WalkSmem& sm = DBTK_LDS_REF(WalkSmem, sm_);
     WalkState S;
     ws_get(x, sm, S);
     x.sync();
