@@ -714,12 +714,13 @@ def main():
                 dtw = time_steps(ctxw, lambda: ctxw.align_device(d_ah.data_ptr(), d_aho.data_ptr(), mp, rlen), args.mix_steps, 2)
                 cw = ctxw.counters().astype(np.float64)
                 walked_kmers = cw[abi.C_THREADING] * (rlen - 21 + 1)  # k-mers of the reads that entered threading
-                tw = kernel_table(ctxw.kernel_times(), algorithmic_bytes(abi, cw, walked_kmers, ps=ctxw.path_stats(), walk=True), args.mix_steps, args.mix_steps)
+                psw = ctxw.path_stats()
+                tw = kernel_table(ctxw.kernel_times(), algorithmic_bytes(abi, cw, walked_kmers, ps=psw, walk=True), args.mix_steps, args.mix_steps)
                 domw = max((k for k in tw if ":" not in k), key=lambda k: tw[k]["avg_ms"] * tw[k]["launches"])
                 mixes["walk_gc85_3"] = dict(workload=f"{2 * mp} reads per step, 100 % of pairs from loci, --v13-threading -gc 85 3 -k 21 -kf 4 1 -cth 45 -ka",
                                             value=2 * mp * args.mix_steps / dtw, unit="reads/s", ms_per_step=dtw / args.mix_steps * 1e3,
                                             steps=args.mix_steps, reads_walked_per_step=cw[abi.C_THREADING] / args.mix_steps,
-                                            reads_feasible_per_step=cw[abi.C_FEASIBLE] / args.mix_steps, hbm_bytes_tables=tbw,
+                                            reads_feasible_per_step=cw[abi.C_FEASIBLE] / args.mix_steps, hbm_bytes_tables=tbw, path=psw,
                                             roofline=dict(roofline_of(domw, tw), kernels=tw, profiled=pmc_mix("walk", "k_walk_pairs"),
                                                           traffic=(pmc_mix("walk", "k_walk_pairs") or {}).get("traffic")))
                 log(f"walk mix: {dtw / args.mix_steps * 1e3:.3f} ms/step, {mixes['walk_gc85_3']['value'] / 1e6:.1f} M reads/s, dominant {domw} {tw[domw]['avg_ms']:.3f} ms")
@@ -778,12 +779,13 @@ def main():
                 ctx25.timers_enable(1)
                 dt25 = time_steps(ctx25, lambda: ctx25.align_device(d_s25.data_ptr(), d_o25.data_ptr(), kp, rlen), args.mix_steps, 2)
                 c25 = ctx25.counters().astype(np.float64)
-                t25 = kernel_table(ctx25.kernel_times(), algorithmic_bytes(abi, c25, c25[abi.C_THREADING] * (rlen - 25 + 1), ps=ctx25.path_stats(), walk=True), args.mix_steps, args.mix_steps)
+                ps25 = ctx25.path_stats()
+                t25 = kernel_table(ctx25.kernel_times(), algorithmic_bytes(abi, c25, c25[abi.C_THREADING] * (rlen - 25 + 1), ps=ps25, walk=True), args.mix_steps, args.mix_steps)
                 dom25 = max((k for k in t25 if ":" not in k), key=lambda k: t25[k]["avg_ms"] * t25[k]["launches"])
                 mixes["walk_k25_gc85_3"] = dict(workload=f"synthetic release-scale RPGG at k = 25 ({args.nloci} loci, {arrs25.nkeys} index keys), {2 * kp} reads per step, "
                                                          f"100 % of pairs from loci, --v13-threading -gc 85 3 -k 25 -kf 4 1 -cth 45 -ka",
                                                 value=2 * kp * args.mix_steps / dt25, unit="reads/s", ms_per_step=dt25 / args.mix_steps * 1e3, steps=args.mix_steps,
-                                                reads_walked_per_step=c25[abi.C_THREADING] / args.mix_steps, reads_feasible_per_step=c25[abi.C_FEASIBLE] / args.mix_steps,
+                                                reads_walked_per_step=c25[abi.C_THREADING] / args.mix_steps, reads_feasible_per_step=c25[abi.C_FEASIBLE] / args.mix_steps, path=ps25,
                                                 roofline=dict(roofline_of(dom25, t25), kernels=t25, profiled=pmc_mix("k25", "k_walk_pairs"),
                                                               traffic=(pmc_mix("k25", "k_walk_pairs") or {}).get("traffic")), parity=None)
                 log(f"k = 25 walk mix: {dt25 / args.mix_steps * 1e3:.3f} ms/step, {mixes['walk_k25_gc85_3']['value'] / 1e6:.1f} M reads/s, dominant {dom25} {t25[dom25]['avg_ms']:.3f} ms")

@@ -504,14 +504,30 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                         if ((a.T.flt[flt_word(fm, k, a.T.flt_logw)] & fb) != fb) km = NAN64;
                     }
                     const uint32_t hb = km != NAN64 ? (uint32_t)(hmix >> a.T.idx_shift) : 0u;
+                    // Which of the samples the filter let through are looked up in the table.  subfilter stops at its NM-th hit
+                    // (AQ.cpp:176-180), and everything after is never read from hm below: with NM == 1 — the default — only the FIRST
+                    // sample that may be in the index is looked up, and the next one only if that was one of the filter's false
+                    // positives.  A pair from a locus then costs one table line per mate instead of four (all-hit batches: the
+                    // encode kernel's table reads fall to a quarter); a background pair costs what it did (its samples end at the
+                    // filter), and one tile in twenty-five makes a second turn.
+                    const bool seq = NM == 1 && a.T.flt;  // (without the filter every sample "may be": all at once, as before)
+                    uint32_t mq = (uint32_t)(x.ballot(km != NAN64) >> (lane & ~3u)) & 0xFu;  // my pair's samples still to be looked up
+                    if (seq && hm[mate]) mq = 0;  // (NF > 4: a hit among the first four samples has ended the loop)
+                    uint32_t hits = 0;
+                    for (;;) {
+                    const uint32_t act = seq ? (mq & (0u - mq)) : mq;  // this turn's samples
+                    const uint64_t kmt = ((act >> sub) & 1u) ? km : NAN64;
                     // Two rounds; in round r the lane pairs {0,1} and {2,3} of the group look up samples 2r and 2r+1:
                     // each lane reads two of the bucket's four keys, so one load instruction fetches the keys of 32
                     // probes and a probe is ONE request to the memory system.
-                    uint32_t hits = 0;
+                    uint32_t hits_t = 0;
                     uint64_t kq[2], k0[2], k1[2];
                     uint32_t bq[2];
-                    kq[0] = quad_perm64<0, 0, 1, 1>(x, km); kq[1] = quad_perm64<2, 2, 3, 3>(x, km);
-                    bq[0] = x.template quad_perm<0, 0, 1, 1>(hb); bq[1] = x.template quad_perm<2, 2, 3, 3>(hb);
+                    kq[0] = quad_perm64<0, 0, 1, 1>(x, kmt); kq[1] = quad_perm64<2, 2, 3, 3>(x, kmt);
+                    {
+                        const uint32_t hbt = kmt != NAN64 ? hb : 0u;
+                        bq[0] = x.template quad_perm<0, 0, 1, 1>(hbt); bq[1] = x.template quad_perm<2, 2, 3, 3>(hbt);
+                    }
 #pragma unroll
                     for (int r = 0; r < 2; ++r)  // both rounds' loads in flight together: unconditional (bucket 0 for a lane without a probe)
                         bucket_part(a.T.idx, bq[r], sub & 1, &k0[r], &k1[r]);
@@ -535,7 +551,12 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                             }
                         }
                         const uint32_t g4 = (uint32_t)(hmask >> (lane & ~3u)) & 0xF;
-                        hits |= ((g4 & 3) ? 1u : 0u) << (2 * r) | ((g4 >> 2) ? 1u : 0u) << (2 * r + 1);
+                        hits_t |= ((g4 & 3) ? 1u : 0u) << (2 * r) | ((g4 >> 2) ? 1u : 0u) << (2 * r + 1);
+                    }
+                    hits |= hits_t;
+                    mq &= ~act;
+                    if (!seq || hits_t) mq = 0;  // all looked up / the first hit found: this pair is done
+                    if (x.ballot(mq != 0) == 0) break;  // (a false positive of the filter somewhere in the tile: its pair's next sample)
                     }
                     hm[mate] |= hits << s0;
                 }

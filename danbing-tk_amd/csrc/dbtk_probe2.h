@@ -65,7 +65,7 @@ constexpr uint32_t P2_HWIN = 2048;
 // spare words of a counter replica row (CTR_STRIDE = 32 words, DBTK_C_COUNT = 24 counters): the lean kernel's path statistics
 constexpr uint32_t P2_REP_DONE = 24, P2_REP_CLS = 25, P2_REP_INC = 26, P2_REP_SHARED = 27;
 #ifndef DBTK_P2_SHARED_MAX
-#define DBTK_P2_SHARED_MAX 320  /* no cap (round 5, when a pair over the cap cost body_pair a tenth of what it costs now: 16 / 32 / 48 / 96 measured 0.477 / 0.473 / 0.455 / 0.469 ms per WGS-like step) */
+#define DBTK_P2_SHARED_MAX 48  /* probe + resolve + body_pair of a WGS-like step: 16 / 32 / 48 / 96 measured 0.477 / 0.473 / 0.455 / 0.469 ms in round 5; round 6 (relaxed rule): 48: 0.459, no cap (320): 0.474 — a class-table look-up per shared position costs the lean kernel more than the pair costs body_pair */
 #endif
 constexpr uint32_t P2_SHARED_MAX = DBTK_P2_SHARED_MAX;  // shared positions of a pair the shortcut takes: each costs a look-up in the class table
 static_assert(P2_HWIN / 2 * 4 <= sizeof(uint4) * P2_RCH * P2_ROW, "the counter window fits where the buckets were");

@@ -198,12 +198,16 @@ struct WalkSmem {
                               // reverse complement; bit 10 its canonical form is a TR k-mer of the locus
     uint8_t tr[WCAP + 8];     // cg.tr
     uint8_t es_t[WCAP + 8], es_r[WCAP + 8], es_g[WCAP + 8];  // cg.es
-    uint32_t slot[2][NKMAX];  // per mate: counter of the UNcorrected k-mer at each position (NAN32: not a TR k-mer)
+    uint32_t slot[NKMAX];     // counter of the UNcorrected k-mer at each position of this mate (NAN32: not a TR k-mer)
     uint8_t bases[48];        // edit_kmers_*: bases to roll in / leading bases
     uint8_t cube[24];         // errorCorrection_forward: m1[4], m2[16]
     uint8_t scr[128];         // edit_kmers_backward: the read / graph bases of an edit tract
-    uint8_t txc[WTXT], txa[WTXT];  // text form of the alignment: this mate's CIGAR and annotation
-    uint32_t txl[2];               // their lengths
+    uint32_t txl[2];          // lengths of the text form of the alignment: this mate's CIGAR and annotation, which are written OVER km[]
+                              // (txc() / txa(): the walked k-mers are dead by then — walk_store, which wants them, runs first)
+    DBTK_HD uint8_t* txc() { return reinterpret_cast<uint8_t*>(km); }
+    DBTK_HD uint8_t* txa() { return reinterpret_cast<uint8_t*>(km) + WTXT; }
+    DBTK_HD const uint8_t* txc() const { return reinterpret_cast<const uint8_t*>(km); }
+    DBTK_HD const uint8_t* txa() const { return reinterpret_cast<const uint8_t*>(km) + WTXT; }
     int32_t st[ST_N + 1];     // the out-of-line routines' scalar results (ST_*), written by lane 0
     uint64_t st64[2];
     WalkState ws;             // the walk's state across a call of an out-of-line routine (ws_put / ws_get)
@@ -1364,8 +1368,9 @@ DBTK_HD_NOINLINE void walk_format_text(X& x, WalkSmem& sm_, uint32_t cap) {
     ws_get(x, sm, S);
     x.sync();
     const int nes = S.nes < (int)cap ? S.nes : (int)cap, ntr = S.ntr < (int)cap ? S.ntr : (int)cap;  // (as dbtk_aln_format clamps)
-    const uint32_t lc = wave_fmt_cigar(x, sm.es_t, sm.es_g, nes, sm.txc);
-    const uint32_t la = wave_fmt_annot(x, sm.tr, ntr, sm.txa);
+    static_assert(2 * WTXT <= (int)sizeof(sm.km), "the text buffers lie over the walked k-mers");
+    const uint32_t lc = wave_fmt_cigar(x, sm.es_t, sm.es_g, nes, sm.txc());
+    const uint32_t la = wave_fmt_annot(x, sm.tr, ntr, sm.txa());
     if (x.lane() == 0) { sm.txl[0] = lc; sm.txl[1] = la; }
     x.sync();
 }
@@ -1421,15 +1426,15 @@ DBTK_HD void walk_pair(X& x, WalkSmem* smm, const WalkArgs& a, const WalkConst& 
             walk_info_issue(x, smm[0], T, len[0], row, a.info_stride, R0);
             walk_info_issue(x, smm[1], T, len[1], row + a.info_stride, a.info_stride, R1);
             W_STAMP(2);
-            walk_info_finish(x, smm[0], T, dst, len[0], a.info_stride, R0, smm[0].slot[0]);
-            walk_info_finish(x, smm[1], T, dst, len[1], a.info_stride, R1, smm[0].slot[1]);
+            walk_info_finish(x, smm[0], T, dst, len[0], a.info_stride, R0, smm[0].slot);
+            walk_info_finish(x, smm[1], T, dst, len[1], a.info_stride, R1, smm[1].slot);
         } else {
             WalkProbe P0, P1;
             walk_probe_issue(x, smm[0], T, dst, len[0], P0, nullptr);
             walk_probe_issue(x, smm[1], T, dst, len[1], P1, nullptr);
             W_STAMP(2);  // k-mers + first-slot loads issued
-            walk_probe_finish(x, smm[0], T, dst, len[0], P0, smm[0].slot[0]);
-            walk_probe_finish(x, smm[1], T, dst, len[1], P1, smm[0].slot[1]);
+            walk_probe_finish(x, smm[0], T, dst, len[0], P0, smm[0].slot);
+            walk_probe_finish(x, smm[1], T, dst, len[1], P1, smm[1].slot);
         }
         W_STAMP(3);  // look-ups resolved -> LDS
 #pragma unroll
@@ -1474,13 +1479,13 @@ DBTK_HD void walk_pair(X& x, WalkSmem* smm, const WalkArgs& a, const WalkConst& 
                 }
                 for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
                     uint8_t c;
-                    if (i < lc2) c = smm[1].txc[i];
+                    if (i < lc2) c = smm[1].txc()[i];
                     else if (i == lc2) c = '\t';
-                    else if (i < lc2 + 1 + la2) c = smm[1].txa[i - lc2 - 1];
+                    else if (i < lc2 + 1 + la2) c = smm[1].txa()[i - lc2 - 1];
                     else if (i == lc2 + 1 + la2) c = '\t';
-                    else if (i < lc2 + la2 + 2 + lc1) c = smm[0].txc[i - lc2 - la2 - 2];
+                    else if (i < lc2 + la2 + 2 + lc1) c = smm[0].txc()[i - lc2 - la2 - 2];
                     else if (i == lc2 + la2 + 2 + lc1) c = '\t';
-                    else c = smm[0].txa[i - lc2 - la2 - lc1 - 3];
+                    else c = smm[0].txa()[i - lc2 - la2 - lc1 - 3];
                     r[8 + i] = c;
                 }
             } else if (lane == 0 && a.errflag) *a.errflag = DBTK_ERR_OVERFLOW;
@@ -1492,7 +1497,7 @@ DBTK_HD void walk_pair(X& x, WalkSmem* smm, const WalkArgs& a, const WalkConst& 
 #pragma unroll
             for (int m = 0; m < 2; ++m)
                 for (int i = lane; i < NKMAX; i += 64) {
-                    const uint32_t s = smm[0].slot[m][i];
+                    const uint32_t s = smm[m].slot[i];
                     const bool hit = s != NAN32;
                     if (hit && !(a.P.diag & 2)) x.atomic_add(&a.counts[s], 1ull);  // (diagnostic 2: no count atomics)
                     A.c_inc += (uint64_t)__builtin_popcountll(x.ballot(hit));

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DBTK_ABI_VERSION 6u
+#define DBTK_ABI_VERSION 7u  /* v7: DBTK_C_ALGO_VV = the vv words fillstats reads (the vote's words: DBTK_PS_VOTE_VV); DBTK_PS_PAIR_VV */
 
 /* Reads longer than this are rejected (DBTK_ERR_READ_TOO_LONG).  The
  * reference's per-read k-mer multiplicity is a uint8_t pair (`PE_KMC`,

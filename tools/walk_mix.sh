@@ -7,6 +7,6 @@ import sys, json
 d = json.load(open('gpurun_out/walk_mix_detail.json'))
 for k, v in d['mixes'].items():
     if isinstance(v, dict) and 'ms_per_step' in v:
-        print(k, round(v['ms_per_step'], 2), 'ms/step', round(v['value'] / 1e6, 1), 'M reads/s', {n: round(x['avg_ms'], 2) for n, x in v['roofline']['kernels'].items()}, v.get('parity'))
+        print(k, round(v['ms_per_step'], 2), 'ms/step', round(v['value'] / 1e6, 1), 'M reads/s', {n: round(x['avg_ms'], 2) for n, x in v['roofline']['kernels'].items() if ':' not in n}, {k_: v_ for k_, v_ in (v.get('path') or {}).items() if k_ in ('walk_items', 'walk_pairs', 'walk_rest', 'probe_rest', 'fused_done')})
 "
 tail -3 gpurun_out/walk_mix.err
