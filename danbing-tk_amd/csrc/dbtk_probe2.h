@@ -621,7 +621,10 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
                         // (round 6: one k-mer unique to the locus is enough, and each mate needs cth FOUND positions — which "not gone" says —
                         // not cth unique ones: body_probe_locus, dbtk_locus.h, has the argument)
                         const uint32_t wx = x0 > x1 ? x0 : x1, wn = n0 < n1 ? n0 : n1;  // (a mate without a unique k-mer: 0 / ~0)
-                        if (T.consistent && ns && ns <= P2_SHARED_MAX && u0n + u1n >= 1 && wx == wn)
+                        // (the cap on the shared positions — a class-table look-up each — only where body_pair is the cheaper place for the
+                        // pair: a WGS-like batch, !SEL.  The list the locus-resident kernel leaves, SEL, holds the pairs that reach a hundred
+                        // positions into a flank shared with a neighbour locus: 1.3 % of an all-hit batch, 2.2 ms of body_pair's introsort per step)
+                        if (T.consistent && ns && (SEL || ns <= P2_SHARED_MAX) && u0n + u1n >= 1 && wx == wn)
                             done = p2_resolve_shared<NPL>(x, sm, rvs, nk, rsh, k, wx >> 1, ns, nk0 + nk1, a.t0 + place_v);
                     }
                     if (!done) {  // the general resolve kernel redoes this pair from its rows
