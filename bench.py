@@ -903,6 +903,8 @@ def main():
                     gz = os.path.join(ref_dir, "cliw.aln.gz")
                     legs["aln_gz_bytes"] = os.path.getsize(gz) if os.path.exists(gz) else None
                     legs["reads"] = 2 * nhit
+                    gzh = os.path.join(ref_dir, "cliwh.aln.gz")
+                    legs["aln_gz_zlib1_bytes"] = os.path.getsize(gzh) if os.path.exists(gzh) else None
                     gz6 = os.path.join(ref_dir, "cliw6.aln.gz")
                     legs["aln_gz_level6_bytes"] = os.path.getsize(gz6) if os.path.exists(gz6) else None
                     legs["note"] = ("this repo's danbing-tk --v13-threading -gc 85 3 on an all-hit FASTA, without and with -ae --aln-gz: wall seconds "
