@@ -1114,9 +1114,7 @@ DBTK_HD void walk_info_finish(X& x, WalkSmem& sm, const DevTables& T, uint32_t l
             const uint64_t fw = sm.km[i];
             const bool has = fw != NAN64 && (uint32_t)i < stride;
             if (has) info = R.v[r];
-            const bool isf = has && fw <= revcomp2(fw, k);  // the k-mer as read is its canonical form
-            const uint32_t a = info & 0x1Fu, b = (info >> GR_OPP) & 0x1Fu;
-            sm.gi[i] = (uint16_t)((isf ? (a | (b << GR_OPP)) : (b | (a << GR_OPP))) | (info & GR_TR));
+            sm.gi[i] = (uint16_t)(info & 0x7FFu);  // (the row holds the info oriented as the read has the k-mer: wf_decide, dbtk_walkfast.h)
         }
         if (slot) slot[i] = (info & GR_TR) ? trb + (info >> GR_SLOT_SHIFT) : NAN32;
     }

@@ -214,7 +214,18 @@ DBTK_HD void wf_decide(X& x, const WalkArgs& a, uint32_t i, uint32_t dst, uint32
         // the locus-resident form: the pair stays with its locus — body_walk_pairs_locus (dbtk_walkfast.h, below) walks it with the error
         // correction's graph look-ups answered from the same image in LDS
         if (lane == 0) a.walk_ret[i] = WALK_PENDING;
-    } else wf_hand_over<NPL>(x, a, S, i, badm ? nullptr : gi);
+    } else {
+        // the row the error-correcting kernel gets: the info ORIENTED as the read has the k-mer (bits 0-9), so that it need not
+        // reverse-complement 260 k-mers again to find out (round 6: two revcomp2 per position were a twentieth of its instructions)
+        uint32_t og[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const bool isf = fw[j] == cn[j];
+            const uint32_t fa = gi[j] & 0x1Fu, fb = (gi[j] >> GR_OPP) & 0x1Fu;
+            og[j] = (isf ? (fa | (fb << GR_OPP)) : (fb | (fa << GR_OPP))) | (gi[j] & ~0x3FFu);
+        }
+        wf_hand_over<NPL>(x, a, S, i, badm ? nullptr : og);
+    }
 }
 
 // WN = k - m + 1 m-mers per window when the minimizer-grouped copy of the graph table exists (T.grmz), else unused
