@@ -2677,6 +2677,7 @@ static dbtk_status_t dbtk_ingest_aln_lines_impl(dbtk_ingest_t* g, uint32_t slot,
         GzArgs ga;
         memset(&ga, 0, sizeof(ga));
         ga.text = B.d_text; ga.total = B.d_totals; ga.out = B.d_gzout; ga.out_len = B.d_outlen; ga.crc_tab = g->d_crctab;
+        { static const bool lz = !(getenv("DBTK_GZ_LZ") && atoi(getenv("DBTK_GZ_LZ")) == 0); ga.lz = lz ? 1u : 0u; }
         ga.packed = B.d_packed; ga.packed_total = B.d_totals + 2;
         const uint32_t gm = (uint32_t)std::min<uint64_t>(nmem, (uint64_t)c->num_cu * 16);
         LAUNCH(k_gz_member, dim3(gm), dim3(64), s, ga);

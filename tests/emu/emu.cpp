@@ -1135,7 +1135,7 @@ int64_t emu_gz(const uint8_t* text, uint64_t n, uint8_t* packed, uint64_t packed
     gz_tables(tab.data());
     uint64_t total[2] = {n, 0}, ptotal = 0;
     std::vector<uint8_t> pk((size_t)(nmem + 1) * GZ_STRIDE);
-    GzArgs a{tx.data(), total, (uint8_t*)out.data(), out_len.data(), tab.data(), pk.data(), &ptotal};
+    GzArgs a{tx.data(), total, (uint8_t*)out.data(), out_len.data(), tab.data(), pk.data(), &ptotal, getenv("EMU_GZ_LZ") && atoi(getenv("EMU_GZ_LZ")) == 0 ? 0u : 1u};
     run_grid(grid ? grid : 2, 64, sizeof(GzSmem), [&](EmuX& x) { body_gz_member(x, a); });
     run_grid(ING_SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_gz_scan(x, a, 0); });
     run_grid(ING_SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_gz_scan(x, a, 1); });

@@ -131,8 +131,9 @@ def test_line_table_overflow_and_empty_input(emu):
 
 
 def test_emulated_gzip_members_gunzip_to_the_text(emu):
-    """dbtk_gz.h: the -a / -ae text as gzip members made by the kernel body (byte histogram, minimum-redundancy code lengths limited
-    to 15 bits, canonical codes, lanes writing at scanned bit offsets, CRC-32 combined from the lanes' spans): the system's zlib
+    """dbtk_gz.h: the -a / -ae text as gzip members made by the kernel body (LZ77 tokens per lane, literal / length and distance
+    histograms, minimum-redundancy code lengths limited to 15 bits, canonical codes, lanes writing at scanned bit offsets, CRC-32
+    combined from the lanes' spans): the system's zlib
     (which checks every member's CRC-32 and length) must return the text — alignment-like lines, all byte values, one symbol,
     incompressible bytes, a Fibonacci-skewed histogram (Huffman depths past 15), sizes around the member and span boundaries."""
     import gzip
@@ -157,7 +158,28 @@ def test_emulated_gzip_members_gunzip_to_the_text(emu):
         assert z.count(b"\x1f\x8b\x08") >= (len(t) + 65535) // 65536
     assert emu.gz(b"") == b""
     z = emu.gz(text[:200000])
-    assert len(z) < 1.1 * len(zlib.compress(text[:200000], 1))  # DNA-dominated text: a Huffman code alone is within 10 % of zlib's level 1
+    assert len(z) < 1.1 * len(zlib.compress(text[:200000], 1))  # DNA-dominated text with random titles: within 10 % of zlib's level 1
+    # Round 6 (LZ77 in the kernel body: per-lane greedy matches of >= 4 bytes at distances <= 16 KB): lines as a sequencer names them —
+    # titles that share a prefix with their neighbours', CIGARs and annotations mostly those of the line before — come out SMALLER than
+    # zlib's level 1 makes them (the DNA itself does not compress beyond its 2 bits per base either way)
+    def line2(i):
+        return (b".\t%d\tA00123:45:HXXX:1:1101:%d:%d\t" % (rng.randrange(80000), 1000 + i // 3, 5000 + rng.randrange(900)) +
+                bytes(rng.choice(ACGT) for _ in range(150)) + b"\t" + bytes(rng.choice(ACGT) for _ in range(150)) +
+                (b"\t150=\t130=\t150=\t130=\n" if rng.random() < 0.7 else b"\t70=XA79=\t50=21.59=\t150=\t130=\n"))
+    text2 = b"".join(line2(i) for i in range(600))
+    z2 = emu.gz(text2)
+    assert gzip.decompress(z2) == text2
+    assert len(z2) < len(zlib.compress(text2, 1)), (len(z2), len(zlib.compress(text2, 1)))
+    # (the switch DBTK_GZ_LZ=0 of the library: literals only — a valid, larger stream)
+    os.environ["EMU_GZ_LZ"] = "0"
+    try:
+        z0 = emu.gz(text2)
+    finally:
+        os.environ.pop("EMU_GZ_LZ", None)
+    assert gzip.decompress(z0) == text2 and len(z0) > len(z2)
+    # long matches, matches that end exactly at span / member boundaries, a repeat longer than the longest match (258)
+    for t in (b"ACGTTGCA" * 20000, (b"x" * 300 + b"\n") * 500, text2[:1024] * 70, bytes(rng.randrange(65, 69) for _ in range(1024)) * 65):
+        assert gzip.decompress(emu.gz(t, grid=2)) == t, len(t)
 
 
 # ---------------------------------------------------------------------------------------------------------------- GPU
