@@ -747,12 +747,14 @@ def main():
                 ctx.timers_enable(1)
                 dtg = time_steps(ctx, lambda: ctx.align_device(d_g.data_ptr(), d_go.data_ptr(), mp, rlen), args.mix_steps, 2)
                 cg = ctx.counters().astype(np.float64)
-                tg = kernel_table(ctx.kernel_times(), algorithmic_bytes(abi, cg, ps=ctx.path_stats()), args.mix_steps, args.mix_steps)
+                psg = ctx.path_stats()
+                tg = kernel_table(ctx.kernel_times(), algorithmic_bytes(abi, cg, ps=psg), args.mix_steps, args.mix_steps)
                 domg = max((k for k in tg if ":" not in k), key=lambda k: tg[k]["avg_ms"] * tg[k]["launches"])
                 mixes["genome_like"] = dict(workload=f"{2 * mp} reads per step: the headline mix ({args.hit_frac:.0%} of pairs from loci) with 15 % of the background "
                                                      f"pairs carrying, in each mate, a 64-base repeat shared with a locus over a sampled window, -k 21 -kf 4 1 -cth 45 -ka",
                                             value=2 * mp * args.mix_steps / dtg, unit="reads/s", ms_per_step=dtg / args.mix_steps * 1e3, steps=args.mix_steps,
-                                            pairs_past_subfilter=cg[abi.C_SURVIVORS] / args.mix_steps / mp,
+                                            pairs_past_subfilter=cg[abi.C_SURVIVORS] / args.mix_steps / mp, path=psg,
+                                            counters={n: int(cg[getattr(abi, "C_" + n)]) for n in ("SURVIVORS", "KMERFILTERED", "LOCUSFILTERED", "ASGN", "NHASH1")},
                                             roofline=dict(roofline_of(domg, tg), kernels=tg))
                 log(f"genome-like mix: {dtg / args.mix_steps * 1e3:.3f} ms/step, {mixes['genome_like']['value'] / 1e9:.2f} G reads/s, "
                     f"{100 * mixes['genome_like']['pairs_past_subfilter']:.1f} % of pairs past subfilter, dominant {domg}")

@@ -2708,7 +2708,7 @@ static dbtk_status_t dbtk_ingest_aln_lines_impl(dbtk_ingest_t* g, uint32_t slot,
 // ---- the entry points above that parse files or allocate host memory, behind the exception barrier (dbtk_internal.h: guarded)
 dbtk_status_t dbtk_device_warmup(int device_id) {
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device"); return DBTK_ERR_NO_DEVICE; }
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device: this library has no CPU execution path"); return DBTK_ERR_NO_DEVICE; }
     if (device_id < 0 || device_id >= n) { set_error("no such device"); return DBTK_ERR_ARG; }
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(hipFree(nullptr));  // (forces the device context)

@@ -317,6 +317,24 @@ def test_device_reader_asynchronous_blocks_and_flags(tmp_path):
         ctx.close()
         for k_ in ("counts", "kmc", "nmapread", "counters"):
             assert (want[k_] == got[k_]).all(), (k_, min_pairs)
+    # dbtk_ctx_reset discards pairs that were appended to the merged batch and not yet aligned: a flush after the reset finds
+    # nothing, and a fresh run on the same context gives the run's own counts
+    ctx = dbtk.context(g, p)
+    ing = bind.pkg.Ingest(ctx, False, 0, chunk, nslots=4, with_spans=False)
+    s0 = ing.submit(data[:chunk], nblocks == 1)
+    info = ing.wait(s0)
+    assert info.flags == 0 and info.nkept > 0
+    ing.align_merged(s0, 10 ** 9)  # appended, not aligned
+    ctx.reset()
+    ing.align_merged(None, 0, flush=True)
+    z = ctx.counts()
+    assert not z["counts"].any() and not z["kmc"].any() and not z["nmapread"].any() and not z["counters"].any()
+    ing.close()
+    ctx.align(seq, off)
+    got = ctx.counts()
+    ctx.close()
+    for k_ in ("counts", "kmc", "nmapread", "counters"):
+        assert (want[k_] == got[k_]).all(), (k_, "after reset")
     # a singleton after 100 pairs
     recs = data.split(b">")[1:]
     cut = sum(len(r) + 1 for r in recs[:200])
