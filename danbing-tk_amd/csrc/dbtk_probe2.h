@@ -112,14 +112,22 @@ DBTK_HD void p2_fetch_runs(const uint32_t* rb, const MzBucket* mz, uint32_t nrun
 // (FUSE) the two ways the lean probe kernel finishes a pair itself, as functions of their own: inlined, their registers cost the look-ups
 // above them the prefetched buckets (see P2FuseArgs)
 template <int NPL> struct P2Rv { uint64_t v[NPL]; };  // look-up results of the lane's positions: val | aux << 32
-enum { P2C_QC, P2C_KF, P2C_THR, P2C_FEAS, P2C_ASGN, P2C_CLS, P2C_INC, P2C_NHASH1, P2C_DONE, P2C_VV, P2C_SHARED };  // sm.fc: a wave's share of a batch (< 2^32)
-// both mates cleared by kfilter: nothing is left to vote on (a background pair that got through subfilter on a shared repeat).  What kfilter
-// looked up before it gave up: the positions up to the (nk - cth + 1)-th miss; none for a mate with nk < cth (AQ.cpp:190-228).
+enum { P2C_QC, P2C_KF, P2C_THR, P2C_FEAS, P2C_ASGN, P2C_CLS, P2C_INC, P2C_NHASH1, P2C_DONE, P2C_VV, P2C_SHARED, P2C_HF };  // sm.fc: a wave's share of a batch (< 2^32)
+// A mate kfilter clears takes its hit list with it (AQ.cpp:190-228).  gmask = which mates it clears (bit 0: mate 0, bit 1: mate 1).
+// Both: nothing is left to vote on (a background pair that got through subfilter on a shared repeat).  ONE (round 6): countHit runs on the
+// other mate's list alone, and cannot accept when that mate has fewer than 2 cth found positions — whatever the vote's order: the cleared
+// mate's strand of `top` stays 0, so test1 fails, and top.fc + top.rc is at most the kept mate's found positions, so test2 fails
+// (AQ.cpp:439-451) — the kept mate is "locus filtered" (hf), nothing else happens to the pair.  (A read that shares a 64-base stretch with
+// a locus and one more base by chance: 45 found positions of 130.  In a genome-like batch these pairs were 150 000 sorts and votes per step.)
+// What kfilter looked up before it gave up on a mate: the positions up to the (nk - cth + 1)-th miss; none for a mate with nk < cth; all of
+// a kept mate's.  What fillstats reads of vv for the kept mate: one word per DISTINCT found k-mer whose index value is a list.
+// The k-mers are re-made from the pair's 2-bit stream (sm.pk: every byte ACGT — the caller's condition when gmask != 3).
 template <int NPL, class SM, class X>
-DBTK_HD_NOINLINE void p2_resolve_gone(X& x, SM& sm_, P2Rv<NPL> rv, uint32_t nk) {
+DBTK_HD_NOINLINE void p2_resolve_gone(X& x, SM& sm_, P2Rv<NPL> rv, uint32_t nk, uint32_t gmask, uint32_t rsh, uint32_t k) {
     SM& sm = DBTK_LDS_REF(SM, sm_);  // (dbtk_tables.h: an out-of-line routine must be told that its reference is LDS)
     const int lane = x.lane();
     const uint32_t hl = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5, p0 = hl * NPL, cth = sm.fa.P.cthreshold;
+    const bool mygone = ((gmask >> half) & 1u) != 0;
     uint32_t mc = 0;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) mc += (p0 + j < nk && (uint32_t)rv.v[j] == NOHIT) ? 1u : 0u;
@@ -127,15 +135,55 @@ DBTK_HD_NOINLINE void p2_resolve_gone(X& x, SM& sm_, P2Rv<NPL> rv, uint32_t nk) 
     const uint32_t ex32 = x.bcast(ex, 32);
     if (half) ex -= ex32;
     uint32_t upto = 0;  // abort position + 1
-    if (nk >= cth) {
+    if (mygone && nk >= cth) {
         const uint32_t target = nk - cth + 1;
 #pragma unroll
         for (int j = 0; j < NPL; ++j)
             if (p0 + j < nk && (uint32_t)rv.v[j] == NOHIT) { ++ex; if (ex == target) upto = p0 + j + 1; }
     }
+    if (!mygone) upto = nk;  // (a kept mate: kfilter ran over all of it)
     upto = x.half_max(upto);
     const uint32_t looked = x.bcast(upto, 0) + x.bcast(upto, 32);
-    if (lane == 0) { sm.fc[P2C_NHASH1] += looked; sm.fc[P2C_KF] += 2; }
+    uint32_t nvv = 0;
+    if (gmask != 3u) {
+        bool sh[NPL];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            sh[j] = !mygone && p0 + j < nk && (uint32_t)rv.v[j] != NOHIT && ((uint32_t)rv.v[j] & 1u);
+            any |= sh[j];
+        }
+        if (x.ballot(any)) {  // (rare in such a pair) the distinct ones: handed round the wave, each compared with the ones after it
+            const uint64_t kmask = (1ull << (2 * k)) - 1;
+            const uint64_t W = window_fw_clean(sm.pk[half], rsh + p0, 32), RW = revcomp2(W, 32);
+            uint64_t km[NPL];
+            uint32_t mine = 0, dup = 0;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const uint64_t fw = (W >> (2 * (32 - k - j))) & kmask, rc = (RW >> (2 * j)) & kmask;
+                km[j] = fw < rc ? fw : rc;
+                mine += sh[j] ? 1u : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                uint64_t mj = x.ballot(sh[j]);
+                while (mj) {
+                    const int src = (int)__builtin_ctzll(mj);
+                    mj &= mj - 1;
+                    const uint64_t ke = ((uint64_t)x.bcast((uint32_t)(km[j] >> 32), src) << 32) | x.bcast((uint32_t)km[j], src);
+#pragma unroll
+                    for (int j2 = j; j2 < NPL; ++j2)
+                        if (sh[j2] && km[j2] == ke && (j2 > j || lane > src)) dup |= 1u << j2;
+                }
+            }
+            nvv = x.wave_sum(mine) - x.wave_sum((uint32_t)__builtin_popcount(dup));
+        }
+    }
+    if (lane == 0) {
+        sm.fc[P2C_NHASH1] += looked;
+        sm.fc[P2C_KF] += (gmask & 1u) + (gmask >> 1);
+        if (gmask != 3u) { sm.fc[P2C_HF] += 1; sm.fc[P2C_VV] += nvv; }
+    }
 }
 // the usual pair: both mates pass kfilter, every found k-mer unique to the locus v0 >> 1 — countHit needs no sort and no vote
 // (body_pair_usual has the argument); nks = k-mers of both mates, t = the pair's place in the survivor list
@@ -598,7 +646,10 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
                 // kfilter (AQ.cpp:190-228) clears a mate with fewer than cth k-mers, or at its (nk - cth + 1)-th miss: iff it has fewer than cth found positions
                 const bool gone0 = nk0 < cth || nh0 < cth, gone1 = nk1 < cth || nh1 < cth;
                 if (gone0 && gone1) {
-                    p2_resolve_gone<NPL>(x, sm, rvs, nk);
+                    p2_resolve_gone<NPL>(x, sm, rvs, nk, 3u, rsh, k);
+                    done = true;
+                } else if (clean && gone0 != gone1 && (gone0 ? nh1 : nh0) < 2 * cth) {
+                    p2_resolve_gone<NPL>(x, sm, rvs, nk, gone0 ? 1u : 2u, rsh, k);  // (one mate cleared, the other cannot carry the pair alone)
                     done = true;
                 } else if (!gone0 && !gone1 && nh0 && nh1 && u0 && u1 && v0 == v1) {
                     p2_resolve_usual<NPL>(x, sm, rvs, nk, v0, nk0 + nk1, a.t0 + place_v);
@@ -671,6 +722,7 @@ DBTK_HD void body_probe2(X& x, const BatchArgs& a) {
             const uint32_t* f = sm.fc;
             if (f[P2C_QC]) x.atomic_add(&ctr[DBTK_C_QCFILTERED], (uint64_t)f[P2C_QC]);
             if (f[P2C_KF]) x.atomic_add(&ctr[DBTK_C_KMERFILTERED], (uint64_t)f[P2C_KF]);
+            if (f[P2C_HF]) x.atomic_add(&ctr[DBTK_C_LOCUSFILTERED], (uint64_t)f[P2C_HF]);
             if (f[P2C_THR]) x.atomic_add(&ctr[DBTK_C_THREADING], (uint64_t)f[P2C_THR]);
             if (f[P2C_FEAS]) x.atomic_add(&ctr[DBTK_C_FEASIBLE], (uint64_t)f[P2C_FEAS]);
             if (f[P2C_ASGN]) x.atomic_add(&ctr[DBTK_C_ASGN], (uint64_t)f[P2C_ASGN]);

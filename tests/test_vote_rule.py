@@ -79,6 +79,31 @@ def test_order_cannot_matter_when_the_rule_holds():
     assert tried > 1000
 
 
+def test_one_kept_mate_below_two_cth_cannot_be_accepted():
+    """The other short cut of the lean probe kernel (dbtk_probe2.h: p2_resolve_gone with one mate cleared by kfilter): the vote runs on the
+    kept mate's list alone, so one strand of `top` stays 0 (test1 fails) and top.fc + top.rc is at most the kept mate's found positions
+    (test2 fails when they are fewer than 2 cth) — for ANY lists, any order."""
+    rng = np.random.default_rng(7)
+    for it in range(3000):
+        cth = int(rng.integers(1, 60))
+        strand = int(rng.integers(0, 2))
+        ent, D = [], 0
+        while True:
+            d = int(rng.integers(1, 4))
+            if D + d >= 2 * cth:
+                break
+            lst = [int(x) for x in rng.permutation(8)[:int(rng.integers(1, 6))]]
+            ent.append((lst, d if strand == 0 else 0, 0 if strand == 0 else d))
+            D += d
+            if rng.random() < 0.02:
+                break
+        if not ent:
+            continue
+        keys = np.array([len(e[0]) for e in ent], float) + rng.random(len(ent)) * 0.5
+        idx, fc, rc = vote([ent[i] for i in np.argsort(keys, kind="stable")], cth)
+        assert not ((fc >= cth and rc >= cth) or fc + rc >= 2 * cth), (it, cth, D, fc, rc)
+
+
 def test_the_rule_needs_its_premises():
     """Without a k-mer unique to L another locus of the lists may lead: the rule does not apply (the kernels send such a pair to the vote)."""
     ent = [([1, 0], 1, 1)] * 50  # every k-mer shared, locus 1 first in the lists
