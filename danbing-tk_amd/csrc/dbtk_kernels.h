@@ -2100,12 +2100,48 @@ DBTK_HD void body_pair(X& x, const BatchArgs& a) {
                 }
             }
             DBTK_STAMP(8);  // nml / single-locus test
+            // ---- (round 6) the pair whose vote cannot go any other way: the fused probe kernels' rule (dbtk_locus.h has the argument,
+            // tests/test_vote_rule.py checks it) for the pairs they do not take — more shared positions than the lean kernel looks classes
+            // up for, lists too long for a locus' image.  Every found k-mer names ONE locus L (the unique ones by their value, every
+            // multi-locus one by holding L in its list: the lists are in the LDS pool already), at least one is unique to L, both mates
+            // pass kfilter: L is `top` whatever order std::sort leaves equal keys in, and countHit accepts it.  No sort, no vote.
+            // (nm1 / nm2, the vote's partial sums, do depend on the order: trace mode votes.)
+            bool decided = false;
+            uint32_t Ldec = 0;
+            if (!single && !a.P.trace && !rm[0] && !rm[1] && nhit[0] >= cth && nhit[1] >= cth && nhit[0] && nhit[1]) {
+                uint32_t mx = 0, mn = 0xFFFFFFFFu;
+                for (uint32_t u = lane; u < nu; u += 64) {
+                    const uint32_t v = sm.w.a.uval[u];
+                    if (!(v & 1u)) { mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+                }
+                const uint32_t wmx = ~x.wave_min(~mx), wmn = x.wave_min(mn);
+                if (wmn != 0xFFFFFFFFu && wmx == wmn) {
+                    Ldec = wmx >> 1;
+                    const uint32_t* pool = sm.evd;
+                    const uint32_t b0 = EPL * (uint32_t)lane;
+                    bool bad = false;
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j) {
+                        const uint32_t u = b0 + j;
+                        if (u < nu && (sm.w.a.uval[u] & 1u)) {
+                            const uint32_t po = sm.w.a.poff[u], nn = sm.u.v.nml[u];
+                            bool has = false;
+                            if (po != 0xFFFFu) for (uint32_t q = 0; q < nn; ++q) has |= pool[po + q] == Ldec;
+                            bad |= !has;  // (a list that did not fit the pool: not decided here)
+                        }
+                    }
+                    decided = x.ballot(bad) == 0;
+                }
+            }
             // ---- P7 + P8: the permutation std::sort applies (AQ.cpp:320-327) and the vote
             const uint16_t* perm_row = T.permtab + (size_t)nu * (nu ? nu - 1 : 0) / 2;  // introsort of nu equal keys
             if (single) {
                 const uint32_t fr = vote_single_locus<EPL>(x, perm_row, sm.w.a.dd, nu, cth);
                 dst0 = x.uni(sm.w.a.uval[0]) >> 1;
                 nm1 = (int)(fr & 0xFFFF); nm2 = (int)(fr >> 16);
+            } else if (decided) {
+                dst0 = Ldec;
+                nm1 = (int)nhit[0]; nm2 = (int)nhit[1];  // (>= cth each: accepted below)
             } else {
                 if (alleq) { for (uint32_t i = lane; i < nu; i += 64) sm.u.v.ord[i] = perm_row[i]; }
                 else {

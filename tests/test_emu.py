@@ -109,21 +109,17 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
         if case == "shared":
             assert ps["fused_shared"] > 0
     if case == "shared":
-        # the vv words of the VOTE (find_matching_locus) are a path statistic, not a counter: the reference votes on every pair, the fused
-        # bodies prove most pairs' outcome without one.  With the fused resolve off the two figures are equal; with it on the device's is
-        # smaller — and the counter DBTK_C_ALGO_VV (fillstats' words) is the oracle's on every path (asserted above with the counters).
-        p3 = abi.default_params(ksize=c.k, **{**c.param_sets[0], "okam": 0})
-        a3 = O.align(go, p3, seq, off, trace=False)
-        for fuse_bits, same in (("0", True), (None, False)):
-            os.environ.pop("EMU_FUSE", None)
-            if fuse_bits is not None:
-                os.environ["EMU_FUSE"] = fuse_bits
-            try:
-                E.path_stats()
-                E.align(g, T, p3, seq, off, grid_k1=2, grid_pair=3)
-                ps = E.path_stats()
-            finally:
-                os.environ.pop("EMU_FUSE", None)
+        # the vv words of the VOTE (find_matching_locus) are a path statistic, not a counter: the reference votes on every pair, the kernels
+        # prove most pairs' outcome without one (the fused probe bodies, and — round 6 — body_pair itself).  In trace mode every vote is held
+        # (the records want its partial sums) and the two figures are equal; without, the device's is smaller — and the counter
+        # DBTK_C_ALGO_VV (fillstats' words) is the oracle's on every path (asserted above with the counters).
+        for tr, same in ((1, True), (0, False)):
+            p3 = abi.default_params(ksize=c.k, **{**c.param_sets[0], "okam": 0, "trace": tr})
+            a3 = O.align(go, p3, seq, off, trace=bool(tr))
+            E.path_stats()
+            E.align(g, T, p3, seq, off, grid_k1=2, grid_pair=3)
+            ps = E.path_stats()
+            fuse_bits = "trace" if tr else "no trace"
             assert a3["vote_vv"] > 0 and (ps["vote_vv"] == a3["vote_vv"] if same else ps["vote_vv"] < a3["vote_vv"]), (fuse_bits, ps["vote_vv"], a3["vote_vv"])
     E.L.emu_tables_free(T)
     O.free(go)
