@@ -35,6 +35,9 @@ def main():
             print(f"{tag:28s} rc={r.returncode} {ing[0] if ing else r.stderr[-400:]}", flush=True)
             if em:
                 print(f"{'':28s} {em[0]}", flush=True)
+        for al in [int(v) for v in os.environ.get("EMIT_BENCH_DEV_ALIGNERS", "").split(",") if v]:  # (the device path with other --aln-aligners)
+            run(["-ae", "--aln-gz", "w_dev.aln.gz", "--aln-aligners", str(al)], f"-ae --aln-gz (device) A={al}")
+            run(["-ae", "--aln-gz", "w_dev.aln.gz", "--aln-aligners", str(al)], f"-ae --aln-gz (device) A={al} again")
         run([], "no emit")
         run([], "no emit (again)")
         run(["--host-ingest"], "no emit, host reader")
