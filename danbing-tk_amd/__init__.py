@@ -419,7 +419,7 @@ EXPORTS = [
     "dbtk_align_batch_device", "dbtk_ctx_synchronize", "dbtk_ctx_counts", "dbtk_ctx_accum_buffer", "dbtk_ctx_reset",
     "dbtk_allreduce", "dbtk_rpgg_set_index_cache", "dbtk_ctx_table_bytes", "dbtk_ctx_path_stats", "dbtk_ctx_kernel_times", "dbtk_ctx_timers_reset", "dbtk_ctx_timers_enable", "dbtk_ctx_aln_text", "dbtk_ctx_write_bubbles", "dbtk_ctx_merge_bubbles", "dbtk_ctx_write_bait_hits", "dbtk_ctx_merge_bait_hits", "dbtk_write_outputs", "dbtk_rpgg_serialize", "dbtk_last_error", "dbtk_abi_version",
     "dbtk_thread_batch", "dbtk_ctx_walk_results", "dbtk_ctx_aln_records", "dbtk_aln_format",
-    "dbtk_ingest_create", "dbtk_ingest_free", "dbtk_ingest_chunk_buffer", "dbtk_ingest_block", "dbtk_ingest_submit", "dbtk_ingest_wait",
+    "dbtk_ingest_reserve_host", "dbtk_ingest_create", "dbtk_ingest_free", "dbtk_ingest_chunk_buffer", "dbtk_ingest_block", "dbtk_ingest_submit", "dbtk_ingest_wait",
     "dbtk_ingest_align", "dbtk_ingest_align_merged", "dbtk_ingest_spans", "dbtk_ingest_aln_lines",
 ]
 

@@ -4,7 +4,7 @@ import ctypes as C
 MAX_READ_LEN = 256
 NAN64 = 0xFFFFFFFFFFFFFFFF
 NAN32 = 0xFFFFFFFF
-ABI_VERSION = 7
+ABI_VERSION = 8
 ALN_TEXT = 4  # params.aln | ALN_TEXT: alignment records in text form (dbtk_ctx_aln_text)
 THREAD_CAP = 384
 ING_DIRTY, ING_LINES, ING_CARRY, ING_TAIL = 1, 2, 4, 8  # dbtk_ingest_info.flags

@@ -366,6 +366,42 @@ int main(int argc, char* argv[]) {
     // (the HIP runtime's start — a few tenths of a second — beside the parsing of the RPGG files)
     // (every device the run will use — logical GPU i on device map[i % n], the same rule as dev_of below — each warmed once; a failure is
     // reported when the thread is joined, before the first context is created: ADVICE r5)
+    // host threads worth starting: the hardware threads, capped by what the container may actually use (its CPU affinity and its
+    // cgroup CPU quota: a 256-thread host with cpu.max = 16 cores runs 64 deflate threads four times slower each)
+    auto usable_cpus = []() -> unsigned {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+            char q[64]; unsigned long long per = 0;
+            if (fscanf(f, "%63s %llu", q, &per) == 2 && per && strcmp(q, "max") != 0) n = std::min<unsigned>(n, (unsigned)std::max(1ull, (strtoull(q, nullptr, 10) + per - 1) / per));
+            fclose(f);
+        } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+            long long quota = -1, per = 100000;
+            if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+            fclose(f1);
+            if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 100000; fclose(f2); }
+            if (quota > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)((quota + per - 1) / per));
+        }
+        return n;
+    };
+    const unsigned cpus = usable_cpus();
+    // the shape of a device reader's ring (run_device_ingest below; also what the warm-up thread pins ahead of it)
+    auto ingest_chunk = [] { size_t CH = 32u << 20; if (const char* e = getenv("DBTK_INGEST_CHUNK")) { const long v = atol(e); if (v >= 4096) CH = (size_t)v; } return CH; };  // (tests: many small blocks)
+    auto ingest_readers = [&](bool piped, int npipes_) {
+        // reader threads: pread is a memcpy out of the page cache into a pinned buffer — 1.3 to 4 GB/s per thread, against 30 GB/s and more
+        // that the GPU parses — so three quarters of the CPUs this process may use read (round 5: at most 8, which capped a first pass
+        // over a 10-GB file at 15 GB/s), never fewer than one nor more than 24
+        int nio_want = piped ? 1 : (int)std::max(1u, std::min(24u, cpus * 3 / 4 / (unsigned)std::max(1, npipes_)));
+        if (const char* e = getenv("DBTK_INGEST_READERS")) { const int v = atoi(e); if (v > 0 && !piped) nio_want = v; }
+        return nio_want;
+    };
+    auto ingest_slots = [&](int nio_want) {
+        uint32_t NS = (uint32_t)std::max(12, nio_want + 6);  // chunks on their way at once (being read, copied, parsed, or waiting for their records
+                                                             // to be written): the readers run this many chunks ahead of the oldest one not yet done with
+        if (const char* e = getenv("DBTK_INGEST_SLOTS")) { const int v = atoi(e); if (v >= 2 && v <= 64) NS = (uint32_t)v; }
+        return NS;
+    };
     std::vector<int> warm_devs;
     {
         std::vector<int> wmap;
@@ -376,10 +412,34 @@ int main(int argc, char* argv[]) {
         }
     }
     std::string warm_err;
+    double pin_s = 0;
+    uint32_t pin_n = 0;
     std::thread warm([&] {
         if (o.parseOnly) return;
         for (int d : warm_devs)
             if (dbtk_device_warmup(d) != DBTK_OK && warm_err.empty()) warm_err = std::string("device ") + std::to_string(d) + ": " + dbtk_last_error();
+        if (!warm_err.empty()) return;
+        // the device reader's pinned buffers, beside the parsing of the RPGG files: pinned inside the batch loop (18 buffers of 33 MB, by a dozen
+        // reader threads at once) they took the loop's first 0.1 s, and every other allocation of those first blocks waited behind them.
+        // As many as the input has chunks, at most the ring (a pipe's length is not known: its one reader pins as it goes)
+        struct stat sb;
+        if (o.hostIngest || o.simmode || (o.trackBait && o.bait) || getenv("DBTK_NO_PIN_AHEAD") || stat(o.fastxFname.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return;
+        if (const char* e = getenv("DBTK_DEVICE_INGEST")) if (atoi(e) == 0) return;
+        const bool aln = o.v13 && o.threading && !o.extractFastX && o.aln;
+        if (aln && o.gzLevel != 1) return;
+        const size_t CH = ingest_chunk();
+        uint64_t min_size = 64u << 20;
+        if (const char* e = getenv("DBTK_SHARD_MIN")) min_size = strtoull(e, nullptr, 10);
+        const int want = std::max(o.ngpus < 1 ? 1 : o.ngpus, o.ingestShards);
+        const int np = (want > 1 && (uint64_t)sb.st_size > min_size) ? want : 1;
+        const uint32_t NS = ingest_slots(ingest_readers(false, np));
+        const uint64_t per = ((uint64_t)sb.st_size / (uint64_t)np + CH - 1) / CH + 1;
+        const uint32_t n = (uint32_t)std::min<uint64_t>(64, (uint64_t)np * std::min<uint64_t>(NS, per));
+        // (a block's lines: its bytes and a record per pair as text, a third of that as gzip members)
+        const uint64_t lines = !aln ? 0 : !o.alnGz.empty() ? CH / 2 : CH + CH / 4 + (1u << 20);
+        const double t0 = wall();
+        if (dbtk_ingest_reserve_host(warm_devs[0], CH, n, lines) != DBTK_OK) { fprintf(stderr, "pinning ahead failed (%s): the reader pins as it goes\n", dbtk_last_error()); return; }
+        pin_s = wall() - t0; pin_n = n;
     });
     struct WarmJoin { std::thread& t; ~WarmJoin() { if (t.joinable()) t.join(); } } warm_join{warm};
     dbtk_rpgg_t* rpgg = nullptr;
@@ -426,10 +486,29 @@ int main(int argc, char* argv[]) {
     if (warm.joinable()) warm.join();
     if (!warm_err.empty()) die_assert("GPU warm-up failed: " + warm_err);
     const double tl1 = wall();
+    // -a / -ae with one range: several aligner threads per GPU, each with a context of its own (they share the GPU's tables; their
+    // accumulators are summed on the host at the end): while one fetches its batch's records and has them formatted and
+    // deflated, the others keep the GPU busy — the emit then costs the batch loop next to nothing.  Created on a thread of their own
+    // beside the first context of their GPU: dbtk_ctx_create allocates what a context owns before it waits for the shared tables.
+    // (Whether the input is cut into ranges — in which case they are not used — is known later: then they are freed unused.)
+    const int aln_aligners = emit_aln ? (o.alnAligners > 0 ? o.alnAligners : 4) : 1;
+    std::vector<dbtk_ctx_t*> extra_ctx;
+    std::string extra_err;
+    std::thread extra;
+    if (!o.parseOnly && emit_aln && o.ngpus == 1 && o.ingestShards <= 1 && aln_aligners > 1)
+        extra = std::thread([&] {
+            for (int i = o.ngpus; i < aln_aligners * o.ngpus; ++i) {
+                dbtk_ctx_t* c = nullptr;
+                if (dbtk_ctx_create(rpgg, &P, dev_of(i % o.ngpus), &c)) { extra_err = dbtk_last_error(); return; }
+                extra_ctx.push_back(c);
+            }
+        });
+    struct ExtraJoin { std::thread& t; ~ExtraJoin() { if (t.joinable()) t.join(); } } extra_join{extra};
     if (!o.parseOnly)
         for (int d = 0; d < o.ngpus; ++d)
             if (dbtk_ctx_create(rpgg, &P, dev_of(d), &ctx[d])) die_assert(dbtk_last_error());
     fprintf(stderr, "load: RPGG files %.2f s, tables in HBM %.2f s\n", tl1 - tl0, wall() - tl1);
+    if (pin_n && getenv("DBTK_VERBOSE")) fprintf(stderr, "pinned ahead: %u chunk buffers in %.3f s (beside the RPGG files)\n", pin_n, pin_s);
     if (!o.parseOnly && ctx[0]) {  // what the RPGG occupies on a GPU, table by table
         const char* nm[16]; uint64_t tb[16];
         const int nt = dbtk_ctx_table_bytes(ctx[0], nm, tb, 16);
@@ -460,26 +539,6 @@ int main(int argc, char* argv[]) {
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
     const double loop_t0 = now();
     const double t_loop = wall();
-    // host threads worth starting: the hardware threads, capped by what the container may actually use (its CPU affinity and its
-    // cgroup CPU quota: a 256-thread host with cpu.max = 16 cores runs 64 deflate threads four times slower each)
-    auto usable_cpus = []() -> unsigned {
-        unsigned n = std::max(1u, std::thread::hardware_concurrency());
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
-        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
-            char q[64]; unsigned long long per = 0;
-            if (fscanf(f, "%63s %llu", q, &per) == 2 && per && strcmp(q, "max") != 0) n = std::min<unsigned>(n, (unsigned)std::max(1ull, (strtoull(q, nullptr, 10) + per - 1) / per));
-            fclose(f);
-        } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
-            long long quota = -1, per = 100000;
-            if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
-            fclose(f1);
-            if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 100000; fclose(f2); }
-            if (quota > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)((quota + per - 1) / per));
-        }
-        return n;
-    };
-    const unsigned cpus = usable_cpus();
     const unsigned hw = std::max(4u, std::min(std::thread::hardware_concurrency(), 8 * cpus));  // (what the thread counts below are derived from)
     FILE* gzout = nullptr;
     if (emit_aln && !o.alnGz.empty()) { gzout = fopen(o.alnGz.c_str(), "wb"); if (!gzout) die_assert("cannot create " + o.alnGz); }
@@ -556,7 +615,6 @@ int main(int argc, char* argv[]) {
     };
     std::vector<std::thread> emit_pool;
     if (emit_aln && !o.parseOnly) for (int i = 0; i < emit_threads; ++i) emit_pool.emplace_back(emit_worker);
-    const int aln_aligners = emit_aln ? (o.alnAligners > 0 ? o.alnAligners : 4) : 1;
     // Called by the batch's ALIGNER thread right after it has fetched the records (its sibling aligner threads keep the GPU busy
     // meanwhile: --aln-aligners contexts per GPU); the ordered writer then only writes the finished chunks.
     auto prepare_alignments = [&](Batch& b) {
@@ -1062,18 +1120,11 @@ int main(int argc, char* argv[]) {
     // after chunk (a chunk is submitted once it is known whether another follows); when the host reader has to take over, the bytes
     // already taken from the pipe but not paired go to *replay and the open descriptor to *pipe_fd: the host reader continues there.
     auto run_device_ingest = [&](dbtk_ctx_t* cx, const uint64_t lo, const uint64_t hi, uint64_t* resume, const bool piped, std::string* replay, int* pipe_fd) {
-        size_t CH = 32u << 20;
-        if (const char* e = getenv("DBTK_INGEST_CHUNK")) { const long v = atol(e); if (v >= 4096) CH = (size_t)v; }  // (tests: many small blocks)
+        const size_t CH = ingest_chunk();
         const bool want_out = want_recs || emit_aln;  // records need titles and reads on the host: the slot's bytes stay until they are written
                                                       // (-a / -ae lines are made on the device, from the spans)
-        // reader threads: pread is a memcpy out of the page cache into a pinned buffer — 1.3 to 4 GB/s per thread, against 30 GB/s and more
-        // that the GPU parses — so three quarters of the CPUs this process may use read (round 5: at most 8, which capped a first pass
-        // over a 10-GB file at 15 GB/s), never fewer than one nor more than 24
-        int nio_want = piped ? 1 : (int)std::max(1u, std::min(24u, cpus * 3 / 4 / (unsigned)std::max(1, npipes)));
-        if (const char* e = getenv("DBTK_INGEST_READERS")) { const int v = atoi(e); if (v > 0 && !piped) nio_want = v; }
-        uint32_t NS = (uint32_t)std::max(12, nio_want + 6);  // chunks on their way at once (being read, copied, parsed, or waiting for their records
-                                                             // to be written): the readers run this many chunks ahead of the oldest one not yet done with
-        if (const char* e = getenv("DBTK_INGEST_SLOTS")) { const int v = atoi(e); if (v >= 2 && v <= 64) NS = (uint32_t)v; }
+        const int nio_want = ingest_readers(piped, npipes);
+        const uint32_t NS = ingest_slots(nio_want);
         dbtk_ingest_t* ing = nullptr;
         const double ts0 = now();
         if (dbtk_ingest_create(cx, fq, (uint32_t)minReadSize, CH, NS, want_out, &ing)) die_assert(dbtk_last_error());
@@ -1193,6 +1244,7 @@ int main(int argc, char* argv[]) {
         // device), the spans of titles and reads.  With -a / -ae several worker threads do this side by side, each with a context of
         // its own (the contexts of a GPU share its tables): one's wait for its kernels and copies overlaps the others' kernels.
         struct Work { uint64_t index; uint32_t slot; dbtk_ingest_info_t info; };
+        const bool verbose_blocks = getenv("DBTK_VERBOSE") && atoi(getenv("DBTK_VERBOSE")) >= 2;
         std::mutex gb_m;
         auto process = [&](dbtk_ctx_t* wc, const Work& w) {
             const double t0 = now();
@@ -1202,6 +1254,7 @@ int main(int argc, char* argv[]) {
             const time_t t2 = time(nullptr);
             if (dbtk_ingest_align(ing, w.slot, wc, 1, want_recs ? b->recs.data() : nullptr, want_recs ? w.info.nkept : 0, &b->nrec)) die_assert(std::string("align: ") + dbtk_last_error());
             b->gpu_sec = (long)(time(nullptr) - t2);
+            const double t_al = now();
             if (emit_aln) {  // the block's lines, text or gzip members, straight from the device
                 const double tr0 = now();
                 uint64_t nb = 0, nl = 0, tb = 0;
@@ -1217,6 +1270,7 @@ int main(int argc, char* argv[]) {
                 if (dbtk_ingest_spans(ing, w.slot, b->spans.data(), w.info.nkept)) die_assert(std::string("ingest: ") + dbtk_last_error());
             }
             b->blk = (const char*)dbtk_ingest_block(ing, w.slot);
+            if (verbose_blocks) fprintf(stderr, "block %llu ctx %p: start %.4f align %.4f lines %.4f\n", (unsigned long long)w.index, (void*)wc, t0 - ts0, t_al - t0, now() - t_al);
             { std::lock_guard<std::mutex> l(gb_m); gb += now() - t0; }
             outq.push(std::move(b));
         };
@@ -1290,8 +1344,10 @@ int main(int argc, char* argv[]) {
             if (info.flags) { *resume = lo + info.cut_byte; handed = true; hslot = slot; break; }
             ++jaln;
         }
+        const double tl_loop = now() - ts0;
         wq.close();
         for (auto& t : workers) t.join();
+        const double tl_workers = now() - ts0;
         if (merged) {  // what is left of the merged batch
             const double t0 = now();
             if (dbtk_ingest_align_merged(ing, ~0u, nullptr, 0, 1)) die_assert(std::string("align: ") + dbtk_last_error());
@@ -1316,6 +1372,7 @@ int main(int argc, char* argv[]) {
         outq.close();
         if (writer.joinable()) writer.join();
         const double tf0 = now();
+        if (verbose_blocks) fprintf(stderr, "batch loop: submitted everything at %.4f, workers done at %.4f, writer done at %.4f\n", tl_loop, tl_workers, tf0 - ts0);
         for (dbtk_ctx_t* wc : wctx) if (dbtk_ctx_synchronize(wc)) die_assert(dbtk_last_error());  // the kernels still in flight
         { std::lock_guard<std::mutex> lk(tot_m); spent_ingests.push_back(ing); }  // (its pinned and device buffers are freed at exit, not inside the batch loop)
         if (!(piped && handed)) close(fd);
@@ -1399,11 +1456,13 @@ int main(int argc, char* argv[]) {
             ctx.push_back(nullptr);
             if (dbtk_ctx_create(rpgg, &P, dev_of(i % o.ngpus), &ctx[i])) die_assert(dbtk_last_error());
         }
-    // -a / -ae with one range: several aligner threads per GPU, each with a context of its own (they share the GPU's tables; their
-    // accumulators are summed on the host at the end): while one fetches its batch's records and has them formatted and
-    // deflated, the others keep the GPU busy — the emit then costs the batch loop next to nothing
+    // the further aligner contexts of -a / -ae (made beside the first one, above)
+    if (extra.joinable()) extra.join();
+    if (!extra_err.empty()) die_assert(extra_err);
+    if (nshards == 1) for (dbtk_ctx_t* c : extra_ctx) ctx.push_back(c);
+    else for (dbtk_ctx_t* c : extra_ctx) dbtk_ctx_free(c);
     if (!o.parseOnly && emit_aln && nshards == 1)
-        for (int i = (int)ctx.size(); i < aln_aligners * o.ngpus; ++i) {
+        for (int i = (int)ctx.size(); i < aln_aligners * o.ngpus; ++i) {  // (none were made ahead: several GPUs or --ingest-shards, and the input gave one range)
             ctx.push_back(nullptr);
             if (dbtk_ctx_create(rpgg, &P, dev_of(i % o.ngpus), &ctx[i])) die_assert(dbtk_last_error());
         }
@@ -1510,12 +1569,14 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, "cross-range pairing: %llu reads\n", (unsigned long long)nleft);
     }
     fflush(stdout);
+    const double t_tail0 = now();
     { std::lock_guard<std::mutex> l(ep_m); ep_stop = true; }
     ep_cv.notify_all();
     for (auto& t : emit_pool) t.join();
     if (fflush(stdout) != 0) die_assert("write to stdout failed");
     if (gzout && fclose(gzout) != 0) die_assert("closing the --aln-gz file failed");
     const int nsplit = nsplit_used;
+    if (getenv("DBTK_VERBOSE")) fprintf(stderr, "batch loop's tail (emit threads joined, outputs closed): %.3f s, from %.3f s\n", now() - t_tail0, t_tail0 - loop_t0);
     if (emit_aln) fprintf(stderr, "emit: record read-back %.2f s; formatting %.2f thread-s, deflate %.2f thread-s on %d emit threads (%u usable CPUs); %llu bytes out; "
                           "%llu bytes of text assembled%s on the device\n",
                           rec_us.load() / 1e6, fmt_us.load() / 1e6, gz_us.load() / 1e6, emit_threads, cpus, (unsigned long long)aln_bytes,

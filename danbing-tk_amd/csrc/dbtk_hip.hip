@@ -33,6 +33,22 @@
 
 using namespace dbtk;
 
+// DBTK_VERBOSE >= 2: every device / pinned allocation or release that takes longer than 0.2 ms says so (which line, how many bytes)
+static const bool g_alloc_trace = getenv("DBTK_VERBOSE") && atoi(getenv("DBTK_VERBOSE")) >= 2;
+template <class F>
+static inline hipError_t alloc_traced(const char* what, size_t bytes, int line, F f) {
+    if (!g_alloc_trace) return f();
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t r = f();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > 0.2) fprintf(stderr, "alloc: %s of %zu bytes at line %d: %.2f ms\n", what, bytes, line, ms);
+    return r;
+}
+#define hipMalloc(p, n) alloc_traced("hipMalloc", (size_t)(n), __LINE__, [&] { return (hipMalloc)((void**)(p), (size_t)(n)); })
+#define hipHostMalloc(p, n, f) alloc_traced("hipHostMalloc", (size_t)(n), __LINE__, [&] { return (hipHostMalloc)((void**)(p), (size_t)(n), (f)); })
+#define hipFree(p) alloc_traced("hipFree", 0, __LINE__, [&] { return (hipFree)((void*)(p)); })
+#define hipHostFree(p) alloc_traced("hipHostFree", 0, __LINE__, [&] { return (hipHostFree)((void*)(p)); })
+
 // --------------------------------------------------------------- kernels ---
 __global__ void __launch_bounds__(256) k_fill_idx(IdxBucket* b, uint64_t nslots) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1634,48 +1650,8 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             for (int j = 0; j < EVPOOL && !st; ++j)
                 if (hipEventCreate(&c->timed[i].beg[j]) != hipSuccess || hipEventCreate(&c->timed[i].end[j]) != hipSuccess) { set_error("hipEventCreate failed"); st = DBTK_ERR_HIP; }
         if (st) break;
-        {   // the tables: shared per (handle, device)
-            std::lock_guard<std::mutex> lk(g_share_m);
-            const auto key = std::make_pair(h->uid, device_id);
-            auto it = g_shares.find(key);
-            TableShare* sh = it != g_shares.end() ? it->second : nullptr;
-            auto to_share = [&](TableShare* t) {
-                t->d_idx = c->d_idx; t->d_flt = c->d_flt; t->flt_words = c->flt_words; t->d_trbeg = c->d_trbeg; t->d_cls = c->d_cls; t->d_mz = c->d_mz; t->d_ovf = c->d_ovf;
-                t->d_gr = c->d_gr; t->d_grmz = c->d_grmz; t->d_ldir = c->d_ldir; t->d_limg = c->d_limg; t->d_gldir = c->d_gldir; t->d_glimg = c->d_glimg; t->d_vv = c->d_vv; t->d_qc = c->d_qc; t->d_perm = c->d_perm; t->d_tre = c->d_tre; t->d_bait = c->d_bait;
-                t->T = c->T; t->consistent = c->consistent;
-                // HBM bytes per table: what this context built is added to what the share already holds
-                const uint64_t mine[9] = {c->tb_idx, c->tb_flt, c->tb_cls, c->tb_mz, c->tb_ovf, c->tb_gr, c->tb_grmz, c->limg_bytes, c->loc_from_cache ? 1u : 0u};
-                for (int i = 0; i < 9; ++i) if (mine[i]) t->bytes[i] = mine[i];
-                if (c->glimg_bytes) t->bytes[12] = c->glimg_bytes;
-                t->bytes[9] = (h->vv.size() + 1) * 4 + (h->qc.empty() ? 0 : h->nloci) + ((size_t)NHMAX * (NHMAX + 1) / 2 + 1) * 2 + (h->nloci + 1) * 4 + (c->d_ldir ? h->nloci * sizeof(LocusDir) : 0);
-                t->bytes[10] = (c->d_tre ? (c->T.tre_mask + 1) * sizeof(ClsSlot) : 0) + (c->d_bait ? (c->T.bait_mask + 1) * sizeof(ClsSlot) : 0);
-                t->bytes[11] = 0;
-                for (int i = 0; i < 13; ++i) if (i != 8 && i != 11) t->bytes[11] += t->bytes[i];
-            };
-            if (!sh) {
-                if ((st = build_tables(c))) break;
-                sh = new TableShare;
-                to_share(sh);
-                g_shares[key] = sh;
-            } else {
-                c->d_idx = sh->d_idx; c->d_flt = sh->d_flt; c->flt_words = sh->flt_words; c->d_trbeg = sh->d_trbeg; c->d_cls = sh->d_cls; c->d_mz = sh->d_mz; c->d_ovf = sh->d_ovf;
-                c->d_gr = sh->d_gr; c->d_grmz = sh->d_grmz; c->d_ldir = sh->d_ldir; c->d_limg = sh->d_limg; c->d_gldir = sh->d_gldir; c->d_glimg = sh->d_glimg; c->d_vv = sh->d_vv; c->d_qc = sh->d_qc; c->d_perm = sh->d_perm; c->d_tre = sh->d_tre; c->d_bait = sh->d_bait;
-                c->T = sh->T; c->consistent = sh->consistent;
-            }
-            c->share = sh;
-            ++sh->refs;
-            // optional tables, by the first context that needs them (only a walking context pays for the graph table)
-            if (p->threading == DBTK_THREADING_V13 && !c->d_gr) { if ((st = build_graph_table(c))) break; }
-            if (p->bubbles && !c->d_tre) {
-                if ((st = build_kl_table(c, h->tre_cnt, h->tre_ks, nullptr, &c->d_tre, &c->T.tre_mask, &c->T.tre_shift))) break;
-                c->T.tre = c->d_tre;
-            }
-            if (p->bait && !c->d_bait) {
-                if ((st = build_kl_table(c, h->bt_cnt, h->bt_ks, &h->bt_vs, &c->d_bait, &c->T.bait_mask, &c->T.bait_shift))) break;
-                c->T.bait = c->d_bait;
-            }
-            to_share(sh);
-        }
+        // what the context owns itself FIRST, the shared tables after it: a context created on a side thread while another one builds the
+        // tables (the command line's further aligner contexts for -a / -ae) has its buffers by the time the tables are there
         if (p->trackbait) {
             c->btTK.resize(h->nloci);
             c->baitDB_host.resize(h->nloci);
@@ -1730,6 +1706,49 @@ static dbtk_status_t dbtk_ctx_create_impl(const dbtk_rpgg_t* h, const dbtk_param
             chk(hipMemsetAsync(l.d_small - TK_INLINE, 0, 4 * (TK_INLINE + SMALL_WORDS) + 48 * 8, c->stream), "memset");
             chk(hipMemsetAsync(l.d_vote, 0, (size_t)c->vote_rows * (h->nloci + 1) * 8, c->stream), "memset");
             chk(hipMemsetAsync(l.d_epoch, 0, (size_t)c->vote_rows * 16, c->stream), "memset");
+        }
+        if (st) break;
+        {   // the tables: shared per (handle, device)
+            std::lock_guard<std::mutex> lk(g_share_m);
+            const auto key = std::make_pair(h->uid, device_id);
+            auto it = g_shares.find(key);
+            TableShare* sh = it != g_shares.end() ? it->second : nullptr;
+            auto to_share = [&](TableShare* t) {
+                t->d_idx = c->d_idx; t->d_flt = c->d_flt; t->flt_words = c->flt_words; t->d_trbeg = c->d_trbeg; t->d_cls = c->d_cls; t->d_mz = c->d_mz; t->d_ovf = c->d_ovf;
+                t->d_gr = c->d_gr; t->d_grmz = c->d_grmz; t->d_ldir = c->d_ldir; t->d_limg = c->d_limg; t->d_gldir = c->d_gldir; t->d_glimg = c->d_glimg; t->d_vv = c->d_vv; t->d_qc = c->d_qc; t->d_perm = c->d_perm; t->d_tre = c->d_tre; t->d_bait = c->d_bait;
+                t->T = c->T; t->consistent = c->consistent;
+                // HBM bytes per table: what this context built is added to what the share already holds
+                const uint64_t mine[9] = {c->tb_idx, c->tb_flt, c->tb_cls, c->tb_mz, c->tb_ovf, c->tb_gr, c->tb_grmz, c->limg_bytes, c->loc_from_cache ? 1u : 0u};
+                for (int i = 0; i < 9; ++i) if (mine[i]) t->bytes[i] = mine[i];
+                if (c->glimg_bytes) t->bytes[12] = c->glimg_bytes;
+                t->bytes[9] = (h->vv.size() + 1) * 4 + (h->qc.empty() ? 0 : h->nloci) + ((size_t)NHMAX * (NHMAX + 1) / 2 + 1) * 2 + (h->nloci + 1) * 4 + (c->d_ldir ? h->nloci * sizeof(LocusDir) : 0);
+                t->bytes[10] = (c->d_tre ? (c->T.tre_mask + 1) * sizeof(ClsSlot) : 0) + (c->d_bait ? (c->T.bait_mask + 1) * sizeof(ClsSlot) : 0);
+                t->bytes[11] = 0;
+                for (int i = 0; i < 13; ++i) if (i != 8 && i != 11) t->bytes[11] += t->bytes[i];
+            };
+            if (!sh) {
+                if ((st = build_tables(c))) break;
+                sh = new TableShare;
+                to_share(sh);
+                g_shares[key] = sh;
+            } else {
+                c->d_idx = sh->d_idx; c->d_flt = sh->d_flt; c->flt_words = sh->flt_words; c->d_trbeg = sh->d_trbeg; c->d_cls = sh->d_cls; c->d_mz = sh->d_mz; c->d_ovf = sh->d_ovf;
+                c->d_gr = sh->d_gr; c->d_grmz = sh->d_grmz; c->d_ldir = sh->d_ldir; c->d_limg = sh->d_limg; c->d_gldir = sh->d_gldir; c->d_glimg = sh->d_glimg; c->d_vv = sh->d_vv; c->d_qc = sh->d_qc; c->d_perm = sh->d_perm; c->d_tre = sh->d_tre; c->d_bait = sh->d_bait;
+                c->T = sh->T; c->consistent = sh->consistent;
+            }
+            c->share = sh;
+            ++sh->refs;
+            // optional tables, by the first context that needs them (only a walking context pays for the graph table)
+            if (p->threading == DBTK_THREADING_V13 && !c->d_gr) { if ((st = build_graph_table(c))) break; }
+            if (p->bubbles && !c->d_tre) {
+                if ((st = build_kl_table(c, h->tre_cnt, h->tre_ks, nullptr, &c->d_tre, &c->T.tre_mask, &c->T.tre_shift))) break;
+                c->T.tre = c->d_tre;
+            }
+            if (p->bait && !c->d_bait) {
+                if ((st = build_kl_table(c, h->bt_cnt, h->bt_ks, &h->bt_vs, &c->d_bait, &c->T.bait_mask, &c->T.bait_shift))) break;
+                c->T.bait = c->d_bait;
+            }
+            to_share(sh);
         }
         if (st) break;
         chk(hipStreamSynchronize(c->stream), "sync");
@@ -2344,6 +2363,35 @@ struct dbtk_ingest {
     std::unique_ptr<std::atomic<int>[]> lines_busy;
 };
 
+// Pinned host buffers made ahead of the ingest that uses them (dbtk_ingest_reserve_host): pinning runs at ~4 GB/s and holds a lock of the
+// runtime that every other allocation of the process waits for, so a caller with something else to do first (the command line: parsing the
+// RPGG files) pins beside that.  A buffer goes to the smallest pooled one that holds it; what the pool cannot serve is pinned on first use
+// as before; an ingest hands its buffers back when it is freed.
+namespace {
+struct PinnedPool {
+    std::mutex m;
+    std::vector<std::pair<uint8_t*, uint64_t>> free;
+} g_pinned;
+uint8_t* pinned_take(uint64_t need, uint64_t* cap) {
+    std::lock_guard<std::mutex> l(g_pinned.m);
+    size_t best = ~(size_t)0;
+    for (size_t i = 0; i < g_pinned.free.size(); ++i)
+        if (g_pinned.free[i].second >= need && (best == ~(size_t)0 || g_pinned.free[i].second < g_pinned.free[best].second)) best = i;
+    if (best == ~(size_t)0) return nullptr;
+    uint8_t* p = g_pinned.free[best].first;
+    *cap = g_pinned.free[best].second;
+    g_pinned.free.erase(g_pinned.free.begin() + (long)best);
+    return p;
+}
+void pinned_give(uint8_t* p, uint64_t cap) {
+    if (!p) return;
+    std::lock_guard<std::mutex> l(g_pinned.m);
+    g_pinned.free.emplace_back(p, cap);
+}
+inline uint32_t ingest_head_bytes(uint64_t chunk_bytes) { return (uint32_t)std::min<uint64_t>(1u << 20, (chunk_bytes + 15) & ~15ull); }
+inline uint64_t ingest_raw_bytes(uint64_t chunk_bytes) { return ((uint64_t)ingest_head_bytes(chunk_bytes) + chunk_bytes + 1 + 63) & ~63ull; }
+}  // namespace
+
 static void ingest_free_impl(dbtk_ingest* g) {
     if (!g) return;
     if (g->c) (void)hipSetDevice(g->c->device);
@@ -2351,8 +2399,8 @@ static void ingest_free_impl(dbtk_ingest* g) {
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->c) (void)sync_all(g->c);
     for (auto& S : g->slots) {
-        if (S.h_raw) (void)hipHostFree(S.h_raw);
-        if (S.h_lines) (void)hipHostFree(S.h_lines);
+        pinned_give(S.h_raw, g->raw_bytes);
+        pinned_give(S.h_lines, S.h_lines_cap);
         void* ptrs[] = {S.d_raw, S.d_tile, S.d_nlpos, S.d_pk, S.d_kept, S.d_off, S.d_flat, S.d_qual, S.d_spans};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (S.parsed) (void)hipEventDestroy(S.parsed);
@@ -2384,10 +2432,10 @@ static dbtk_status_t dbtk_ingest_create_impl(dbtk_ctx_t* c, uint32_t fastq, uint
     HIPCHK(hipSetDevice(c->device));
     dbtk_ingest* g = new dbtk_ingest;
     g->c = c; g->L = fastq ? 4 : 2; g->min_read = min_read_size; g->nslots = nslots; g->chunk = chunk_bytes;
-    g->head = (uint32_t)std::min<uint64_t>(1u << 20, (chunk_bytes + 15) & ~15ull);
+    g->head = ingest_head_bytes(chunk_bytes);
     g->with_spans = with_spans != 0;
     g->with_qual = fastq && c->P.bait;  // base qualities only matter to the bait filter
-    const uint64_t raw_bytes = ((uint64_t)g->head + chunk_bytes + 1 + 63) & ~63ull;
+    const uint64_t raw_bytes = ingest_raw_bytes(chunk_bytes);
     g->raw_bytes = raw_bytes;
     g->line_cap = (uint32_t)(raw_bytes / 8 + 64);
     g->pair_cap = g->line_cap / (2 * g->L) + 1;
@@ -2690,10 +2738,13 @@ static dbtk_status_t dbtk_ingest_aln_lines_impl(dbtk_ingest_t* g, uint32_t slot,
     if (B.h_totals[0] > tcap) { set_error("alignment lines overran their buffer"); return DBTK_ERR_OVERFLOW; }
     const uint64_t n = gz ? B.h_totals[2] : B.h_totals[0];
     if (n > S.h_lines_cap) {  // (pinned: the copy runs at the link's speed and the writer reads it where it lands)
-        if (S.h_lines) HIPCHK(hipHostFree(S.h_lines));
+        pinned_give(S.h_lines, S.h_lines_cap);
         S.h_lines = nullptr; S.h_lines_cap = 0;
-        HIPCHK(hipHostMalloc((void**)&S.h_lines, n + n / 4 + 4096, hipHostMallocDefault));
-        S.h_lines_cap = n + n / 4 + 4096;
+        uint64_t cap = 0;
+        uint8_t* pl = pinned_take(n, &cap);
+        if (pl && cap > 4 * n + (8u << 20)) { pinned_give(pl, cap); pl = nullptr; }  // (not a chunk buffer for a few lines)
+        if (!pl) { cap = n + n / 4 + 4096; HIPCHK(hipHostMalloc((void**)&pl, cap, hipHostMallocPortable)); }
+        S.h_lines = pl; S.h_lines_cap = cap;
     }
     if (n) {
         HIPCHK(hipMemcpyAsync(S.h_lines, gz ? B.d_packed : B.d_text, n, hipMemcpyDeviceToHost, s));
@@ -2713,6 +2764,22 @@ dbtk_status_t dbtk_device_warmup(int device_id) {
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(hipFree(nullptr));  // (forces the device context)
     return DBTK_OK;
+}
+
+dbtk_status_t dbtk_ingest_reserve_host(int device_id, uint64_t chunk_bytes, uint32_t nslots, uint64_t lines_bytes) {
+    return dbtk::guarded([&]() -> dbtk_status_t {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device: this library has no CPU execution path"); return DBTK_ERR_NO_DEVICE; }
+        if (device_id < 0 || device_id >= n) { set_error("no such device"); return DBTK_ERR_ARG; }
+        if (nslots > 64) { set_error("dbtk_ingest_reserve_host: at most 64 slots"); return DBTK_ERR_ARG; }
+        HIPCHK(hipSetDevice(device_id));
+        const uint64_t raw = chunk_bytes ? ingest_raw_bytes(chunk_bytes) : 0;
+        for (uint32_t i = 0; i < nslots; ++i) {  // (chunk and lines buffer of a slot together: the first blocks find both)
+            if (raw) { uint8_t* p = nullptr; HIPCHK(hipHostMalloc((void**)&p, raw, hipHostMallocPortable)); pinned_give(p, raw); }
+            if (lines_bytes) { uint8_t* p = nullptr; HIPCHK(hipHostMalloc((void**)&p, lines_bytes, hipHostMallocPortable)); pinned_give(p, lines_bytes); }
+        }
+        return DBTK_OK;
+    });
 }
 
 dbtk_status_t dbtk_ctx_create(const dbtk_rpgg_t* h, const dbtk_params_t* p, int device_id, dbtk_ctx_t** out) {
@@ -2753,8 +2820,10 @@ void* dbtk_ingest_chunk_buffer(dbtk_ingest_t* g, uint32_t slot) {
     if (!S.h_raw) {  // pinned on first use, by the caller's reader thread (several slots at once: the pinning of one overlaps the reading into another)
         std::lock_guard<std::mutex> l(g->slot_m[slot]);
         if (!S.h_raw) {
-            uint8_t* p = nullptr;
-            if (hipSetDevice(g->c->device) != hipSuccess || hipHostMalloc((void**)&p, g->raw_bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+            uint64_t cap = 0;
+            uint8_t* p = pinned_take(g->raw_bytes, &cap);
+            if (p && cap != g->raw_bytes) { pinned_give(p, cap); p = nullptr; }  // (a slot's buffer goes back to the pool as raw_bytes: exact fits only)
+            if (!p && (hipSetDevice(g->c->device) != hipSuccess || hipHostMalloc((void**)&p, g->raw_bytes, hipHostMallocPortable) != hipSuccess)) return nullptr;
             S.h_raw = p;
         }
     }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DBTK_ABI_VERSION 7u  /* v7: DBTK_C_ALGO_VV = the vv words fillstats reads (the vote's words: DBTK_PS_VOTE_VV); DBTK_PS_PAIR_VV */
+#define DBTK_ABI_VERSION 8u  /* v8: dbtk_ingest_reserve_host; v7: DBTK_C_ALGO_VV = the vv words fillstats reads (the vote's words: DBTK_PS_VOTE_VV); DBTK_PS_PAIR_VV */
 
 /* Reads longer than this are rejected (DBTK_ERR_READ_TOO_LONG).  The
  * reference's per-read k-mer multiplicity is a uint8_t pair (`PE_KMC`,
@@ -357,6 +357,13 @@ typedef struct dbtk_ingest_info {
  * (dbtk_ingest_block); index 0 = read 2q (the record that completed the pair), 1 = read 2q + 1 (the parked one). */
 typedef struct dbtk_ingest_span { uint32_t title, title_len, seq[2], seq_len[2], qual[2], qual_len[2]; } dbtk_ingest_span_t;
 /* with_spans: dbtk_ingest_spans will be called (the per-pair spans are then made with every block). */
+/* Optional (ABI v8): pin, ahead of dbtk_ingest_create and on any thread, the host buffers an ingest of this shape will use — `nslots`
+ * chunk buffers for `chunk_bytes` (0: none) and, if `lines_bytes` != 0, as many buffers of `lines_bytes` for the -a / -ae lines of a block
+ * (dbtk_ingest_aln_lines).  Pinning runs at a few GB/s and stalls every other allocation of the process meanwhile: a caller that still has
+ * files to parse (dbtk_rpgg_load) does it beside that; what is not there when an ingest asks is pinned on first use.  The buffers belong to
+ * the process: an ingest takes them, dbtk_ingest_free hands them back for the next one.  Replaces nothing in the reference (its reader
+ * std::getline()s into std::strings, src/aQueryFasta_thread.cpp:1918-1976). */
+dbtk_status_t dbtk_ingest_reserve_host(int device_id, uint64_t chunk_bytes, uint32_t nslots, uint64_t lines_bytes);
 dbtk_status_t dbtk_ingest_create(dbtk_ctx_t* ctx, uint32_t fastq, uint32_t min_read_size, uint64_t chunk_bytes, uint32_t nslots,
                                  uint32_t with_spans, dbtk_ingest_t** out);
 void          dbtk_ingest_free(dbtk_ingest_t* ing);
