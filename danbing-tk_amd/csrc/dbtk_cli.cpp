@@ -1129,6 +1129,7 @@ int main(int argc, char* argv[]) {
         const double ts0 = now();
         if (dbtk_ingest_create(cx, fq, (uint32_t)minReadSize, CH, NS, want_out, &ing)) die_assert(dbtk_last_error());
         const double setup_s = now() - ts0;
+        if (getenv("DBTK_VERBOSE")) fprintf(stderr, "device reader: created %.3f s into the batch loop's time\n", ts0 - loop_t0);
         double first_s = 0, wait_s = 0;
         const int fd = open(o.fastxFname.c_str(), O_RDONLY);
         if (fd < 0) die_assert("cannot open " + o.fastxFname);
