@@ -338,6 +338,11 @@ class Dbtk(_HostSide):
     def context(self, rpgg: Rpgg, params: abi.Params, device=0) -> Context:
         return Context(self, rpgg, params, device)
 
+    def reserve_host(self, device, chunk_bytes, nslots, lines_bytes=0):
+        """dbtk_ingest_reserve_host: pin an ingest's host buffers ahead of its creation (ABI v8)."""
+        self.L.dbtk_ingest_reserve_host.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64]
+        self._chk(self.L.dbtk_ingest_reserve_host(int(device), int(chunk_bytes), int(nslots), int(lines_bytes)))
+
     def allreduce(self, ctxs):
         arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
         self._chk(self.L.dbtk_allreduce(arr, len(ctxs)))

@@ -122,6 +122,16 @@ def test_no_cpu_fallback(lib):
     g.close()
 
 
+def test_reserve_host_needs_a_device(lib):
+    """dbtk_ingest_reserve_host (ABI v8) pins buffers for the device reader: without a HIP device it says so, like dbtk_ctx_create."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.DbtkError) as e:
+        lib.reserve_host(0, 1 << 20, 2)
+    assert e.value.status == abi.ERR_NO_DEVICE
+
+
 LEGACY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "legacy_v13")
 
 

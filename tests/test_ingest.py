@@ -225,6 +225,8 @@ def test_device_reader_feeds_the_hot_path_like_host_buffers(name, chunk, tmp_pat
     ctx.close()
     data = _fasta_of(c.reads, drop_newline=chunk == 20000)
     ctx = dbtk.context(g, p)
+    if chunk in (20000, 9000):  # the slots' pinned buffers made ahead (dbtk_ingest_reserve_host): two of the three, the third on first use
+        dbtk.reserve_host(0, chunk, 2)
     ing = bind.pkg.Ingest(ctx, False, minread, chunk, nslots=3)
     got_recs, titles, q0 = [], [], 0
     pos, pending = 0, []
