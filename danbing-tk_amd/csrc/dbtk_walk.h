@@ -517,7 +517,7 @@ DBTK_HD_NOINLINE void walk_edit_forward(X& x, WalkSmem& sm_, const DevTables& T_
     int nm = 0, nd = 0, nins = 0;
 #pragma unroll
     for (int e = 0; e < 2; ++e) if (e < ne) { nm += et[e] == 'X'; nd += et[e] == 'D'; nins += et[e] == 'I'; }  // (fixed bounds: et / eg stay in registers)
-    const int ki0 = S.ki, dt_km = nd - nins, dt_ki = nm + nd;
+    const int ki0 = S.ki, dlen = nd - nins, dpos = nm + nd;
     const int n0 = S.nkm - ki0;
     // the bases to roll in after kmers[ki0 - 1]: the graph bases of the X / D edits, then the read's own bases from
     // old position ki0 + nm + nins on, while they are good and the rewritten k-mer stays inside min(size, ki + k)
@@ -527,22 +527,22 @@ DBTK_HD_NOINLINE void walk_edit_forward(X& x, WalkSmem& sm_, const DevTables& T_
         int q = 0;
 #pragma unroll
         for (int e = 0; e < 2; ++e) if (e < ne && et[e] != 'I') { if (lane == q) b = (uint8_t)w_code(eg[e]); ++q; }
-        if (lane >= dt_ki) {
-            const int o = nm + nins + (lane - dt_ki);  // old offset from ki0
+        if (lane >= dpos) {
+            const int o = nm + nins + (lane - dpos);  // old offset from ki0
             if (o < n0 && sm.km[ki0 + o] != NAN64) b = (uint8_t)(sm.km[ki0 + o] % 4);
         }
         sm.bases[lane] = b;
     }
     x.sync();
-    if (dt_km) {
+    if (dlen) {
         const int from = ki0 + nm + nins;
-        w_shift(x, sm.km, from, S.nkm, dt_km);
-        w_shift(x, sm.gi, from, S.nkm, dt_km);
-        S.nkm += dt_km;
+        w_shift(x, sm.km, from, S.nkm, dlen);
+        w_shift(x, sm.gi, from, S.nkm, dlen);
+        S.nkm += dlen;
         if (S.nkm > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; S.nkm = WCAP; }
     }
-    const int ki = ki0 + dt_ki;
-    int nb = dt_ki;  // rewritten k-mers: the corrected ones, then the extended ones
+    const int ki = ki0 + dpos;
+    int nb = dpos;  // rewritten k-mers: the corrected ones, then the extended ones
     {
         const int lim = S.nkm < ki + (int)k ? S.nkm : ki + (int)k;
         for (int i = ki; i < lim; ++i) { if (sm.bases[nb] > 3) break; ++nb; }
@@ -556,8 +556,8 @@ DBTK_HD_NOINLINE void walk_edit_forward(X& x, WalkSmem& sm_, const DevTables& T_
         if (lane < nb) sm.km[ki0 + lane] = v;
     }
     refresh(ki0, ki0 + nb);
-    if (dt_km) {  // cg.tr.resize(size + dt_km, '*')
-        const int nn = S.ntr + dt_km;
+    if (dlen) {  // cg.tr.resize(size + dlen, '*')
+        const int nn = S.ntr + dlen;
         for (int i = S.ntr + lane; i < nn && i < WCAP; i += 64) sm.tr[i] = '*';
         S.ntr = nn > WCAP ? WCAP : nn;
     }
@@ -571,7 +571,7 @@ DBTK_HD_NOINLINE void walk_edit_forward(X& x, WalkSmem& sm_, const DevTables& T_
         if (S.nes > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; S.nes = WCAP; }
     }
     x.sync();
-    for (int i = lane; i < dt_ki + (int)score; i += 64) sm.tr[ki0 + i] = (sm.gi[ki0 + i] & GR_TR) ? '=' : '.';
+    for (int i = lane; i < dpos + (int)score; i += 64) sm.tr[ki0 + i] = (sm.gi[ki0 + i] & GR_TR) ? '=' : '.';
     if (lane < ne) { sm.es_t[S.ni + (int)k - 1 + lane] = lane == 0 ? et[0] : et[1]; sm.es_g[S.ni + (int)k - 1 + lane] = lane == 0 ? eg[0] : eg[1]; }
     for (int i = lane; i < (int)score; i += 64) sm.es_t[S.ni + ne + (int)k - 1 + i] = '=';
     x.sync();
@@ -597,21 +597,21 @@ DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm_, const DevTables& T
     int nm = 0, nd = 0, nins = 0;
 #pragma unroll
     for (int e = 0; e < 2; ++e) if (e < ne) { nm += et[e] == 'X'; nd += et[e] == 'D'; nins += et[e] == 'I'; }  // (fixed bounds: et / eg stay in registers)
-    const int dt_km = nd - nins;
+    const int dlen = nd - nins;
     S.ni += nd;
-    if (dt_km > 0) {  // kmers.insert(begin + ki, 0) / cg.tr.insert(begin + ki, '*'), dt_km times
-        w_shift(x, sm.km, ki, S.nkm, dt_km);
-        w_shift(x, sm.gi, ki, S.nkm, dt_km);
-        w_shift(x, sm.tr, ki, S.ntr, dt_km);
-        if (lane < dt_km) { sm.km[ki + lane] = 0; sm.gi[ki + lane] = 0; sm.tr[ki + lane] = '*'; }
-    } else if (dt_km < 0) {  // erase [ki + dt_km, ki)
-        w_shift(x, sm.km, ki, S.nkm, dt_km);
-        w_shift(x, sm.gi, ki, S.nkm, dt_km);
-        w_shift(x, sm.tr, ki, S.ntr, dt_km);
+    if (dlen > 0) {  // kmers.insert(begin + ki, 0) / cg.tr.insert(begin + ki, '*'), dlen times
+        w_shift(x, sm.km, ki, S.nkm, dlen);
+        w_shift(x, sm.gi, ki, S.nkm, dlen);
+        w_shift(x, sm.tr, ki, S.ntr, dlen);
+        if (lane < dlen) { sm.km[ki + lane] = 0; sm.gi[ki + lane] = 0; sm.tr[ki + lane] = '*'; }
+    } else if (dlen < 0) {  // erase [ki + dlen, ki)
+        w_shift(x, sm.km, ki, S.nkm, dlen);
+        w_shift(x, sm.gi, ki, S.nkm, dlen);
+        w_shift(x, sm.tr, ki, S.ntr, dlen);
     }
-    S.nkm += dt_km; S.ntr += dt_km;
+    S.nkm += dlen; S.ntr += dlen;
     if (S.nkm > WCAP || S.ntr > WCAP) { S.flags |= DBTK_THREAD_F_OVERFLOW; if (S.nkm > WCAP) S.nkm = WCAP; if (S.ntr > WCAP) S.ntr = WCAP; }
-    ki += dt_km;
+    ki += dlen;
     x.sync();
     // corrected kmers (X / D edits, walking down from the anchor), then extended ones while the old k-mers were good:
     // kmers[i - 1] = (kmers[i] >> 2) + leading base, the base being the complement of the edit's graph base or
@@ -643,14 +643,14 @@ DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm_, const DevTables& T
     refresh(ki - ncor - next, ki);
     // the rest is sequential byte work on a few entries: lane 0
     if (lane == 0) {
-        uint64_t nrk = 0;
+        uint64_t nstar = 0;
         const int lb = ki - nm - nd - (int)score;
         for (int i = ki - 1; i >= lb; --i) {
-            if (sm.tr[i] == '*') ++nrk;
+            if (sm.tr[i] == '*') ++nstar;
             sm.tr[i] = (sm.gi[i] & GR_TR) ? '=' : '.';
         }
-        nrk -= (uint64_t)(nm + nd);
-        uint64_t nskip = S.nskip - nrk, ncorr = S.ncorr + (uint64_t)ne;
+        nstar -= (uint64_t)(nm + nd);
+        uint64_t nskip = S.nskip - nstar, ncorr = S.ncorr + (uint64_t)ne;
         int ni = S.ni, nes = S.nes;
         auto es_ins = [&](int at) {
             if (nes >= WCAP) return;
@@ -663,36 +663,36 @@ DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm_, const DevTables& T
             --nes;
         };
         auto t_at = [&](int i) -> uint8_t { return (i < 0 || i >= nes) ? (uint8_t)0 : sm.es_t[i]; };
-        int cni = 0;  // cumulative # of ins
-        const int nti_ = ki - dt_km;
-        for (int i = 0; i < nti_ + cni; ++i) if (sm.es_t[i] == 'I') ++cni;
-        int nti = nti_ + cni - 1;  // cg.tr index -> cg.es index
-        for (int i = 0; i < ne; ++i, --nti) {  // CIGAR of edits
+        int ins_seen = 0;  // insertions already recorded in front of the entry: they hold a place in the edit string, none in the trace
+        const int tr_pos = ki - dlen;
+        for (int i = 0; i < tr_pos + ins_seen; ++i) if (sm.es_t[i] == 'I') ++ins_seen;
+        int es_pos = tr_pos + ins_seen - 1;  // the entry of the edit string that belongs to this place of the trace
+        for (int i = 0; i < ne; ++i, --es_pos) {  // the step's edits go into the edit string, newest first
             const uint8_t ti = i == 0 ? et[0] : et[1], gi_ = i == 0 ? eg[0] : eg[1];
-            if (ti == 'D') { ++nti; es_ins(nti); }
-            if (sm.es_t[nti] == 'D') {
-                if (ti == 'I') { es_del(nti); --ni; }  // delete edit immediately
-                else sm.es_g[nti] = w_comp_char(gi_);
+            if (ti == 'D') { ++es_pos; es_ins(es_pos); }
+            if (sm.es_t[es_pos] == 'D') {
+                if (ti == 'I') { es_del(es_pos); --ni; }  // an insertion meeting a pending deletion: the two annihilate
+                else sm.es_g[es_pos] = w_comp_char(gi_);
             } else {
-                while (sm.es_t[nti] == 'I') --nti;
-                sm.es_t[nti] = ti;
-                sm.es_g[nti] = gi_ ? w_comp_char(gi_) : (uint8_t)0;
+                while (sm.es_t[es_pos] == 'I') --es_pos;
+                sm.es_t[es_pos] = ti;
+                sm.es_g[es_pos] = gi_ ? w_comp_char(gi_) : (uint8_t)0;
             }
         }
-        int e0 = nti + 1, e1 = e0;
-        for (uint32_t i = 0; i < score; ++i, --nti) {  // CIGAR of extended alignment
-            const uint8_t c = sm.es_t[nti];
+        int e0 = es_pos + 1, e1 = e0;
+        for (uint32_t i = 0; i < score; ++i, --es_pos) {  // the positions the correction let the walk pass become matches
+            const uint8_t c = sm.es_t[es_pos];
             if (c == '=') { }
-            else if (c == '*') sm.es_t[nti] = '=';
+            else if (c == '*') sm.es_t[es_pos] = '=';
             else break;
         }
-        {   // find edit_tract
+        {   // widen [e0, e1) to the whole run of adjacent edits
             uint8_t c = t_at(e1);
             while (c == 'X' || c == 'D' || c == 'I') { ++e1; c = t_at(e1); }
             c = t_at(e0 - 1);
             while (c == 'X' || c == 'D' || c == 'I') { --e0; c = t_at(e0 - 1); }
         }
-        // merge edits if possible: rnts / gnts = the read / graph bases inside the tract
+        // adjacent edits are rewritten in their shortest form: compare the read's and the graph's bases over the run
         int nets = e1 - e0, nr = 0, ng = 0;
         for (int i = e0; i < e1; ++i) { nr += sm.es_r[i] != 0; ng += sm.es_g[i] != 0; }
         auto rnt = [&](int q) -> uint8_t { for (int i = e0; i < e1; ++i) if (sm.es_r[i] && q-- == 0) return sm.es_r[i]; return 0; };
@@ -700,32 +700,32 @@ DBTK_HD_NOINLINE void walk_edit_backward(X& x, WalkSmem& sm_, const DevTables& T
         if (nr == ng) {
             bool no_edit = true;
             for (int i = 0; i < nr; ++i) if (rnt(i) != gnt(i)) { no_edit = false; break; }
-            if (no_edit) {  // edits canceled out
-                int dt_es = 0;
+            if (no_edit) {  // same bases on both sides: the run was no edit at all
+                int slid = 0;
                 for (int i = e0; i < e1; ++i) {
-                    if (sm.es_t[i + dt_es] == 'D') { es_del(i + dt_es); --dt_es; }
-                    else { sm.es_t[i + dt_es] = '='; sm.es_g[i + dt_es] = 0; }
+                    if (sm.es_t[i + slid] == 'D') { es_del(i + slid); --slid; }
+                    else { sm.es_t[i + slid] = '='; sm.es_g[i + slid] = 0; }
                 }
-                ni += dt_es;
+                ni += slid;
                 ncorr -= (uint64_t)(e1 - e0);
                 nskip -= (uint64_t)(e1 - e0);
             } else if (nets != nr) {  // D + I (same position) -> X: the tract shrinks
                 uint8_t* const rn = sm.scr; uint8_t* const gn = sm.scr + 64;  // (LDS: a private array indexed like this would be scratch memory)
                 for (int i = 0; i < nr && i < 64; ++i) { rn[i] = rnt(i); gn[i] = gnt(i); }
-                int dt_es = 0;
-                const int dt_es_ = nr - nets;
+                int slid = 0;
+                const int shrink_by = nr - nets;
                 int j = 0, kk = 0;
                 for (int i = e0; i < e1; ++i) {
-                    if (sm.es_t[i + dt_es] == 'D' && dt_es != dt_es_) { es_del(i + dt_es); --dt_es; }
+                    if (sm.es_t[i + slid] == 'D' && slid != shrink_by) { es_del(i + slid); --slid; }
                     else {
-                        if (rn[kk & 63] == gn[kk & 63]) { sm.es_t[i + dt_es] = '='; sm.es_g[i + dt_es] = 0; }
-                        else { sm.es_t[i + dt_es] = 'X'; sm.es_g[i + dt_es] = gn[j & 63]; }
+                        if (rn[kk & 63] == gn[kk & 63]) { sm.es_t[i + slid] = '='; sm.es_g[i + slid] = 0; }
+                        else { sm.es_t[i + slid] = 'X'; sm.es_g[i + slid] = gn[j & 63]; }
                         ++j; ++kk;
                     }
                 }
-                ni += dt_es;
-                ncorr += (uint64_t)(int64_t)dt_es;
-                nskip += (uint64_t)(int64_t)dt_es;
+                ni += slid;
+                ncorr += (uint64_t)(int64_t)slid;
+                nskip += (uint64_t)(int64_t)slid;
             } else {  // match / mismatch only
                 for (int i = 0; i < nr; ++i) {
                     if (sm.es_r[e0 + i] && sm.es_r[e0 + i] == sm.es_g[e0 + i]) {  // (here every entry has both bases) edit reverted
