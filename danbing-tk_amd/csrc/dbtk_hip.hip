@@ -1177,6 +1177,7 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     if (c->P.bait && d_qual && (st = ensure(&c->d_qmask, &c->qmask_cap, tcap * 2 * 4))) return st;
     BatchArgs a;
     memset(&a, 0, sizeof(a));
+    { static const bool k1x = !(getenv("DBTK_K1_XCD") && atoi(getenv("DBTK_K1_XCD")) == 0); a.k1_xcd = k1x ? 1u : 0u; }
     a.T = c->T; a.P = c->P; a.P.aln &= 3u;
     a.seq = d_seq; a.off = d_off; a.seq_len = seq_len; a.npairs = npairs;
     a.surv = c->d_surv; a.nsurv = c->d_small + 0; a.nrec = c->d_small + 2; a.errflag = c->d_small + 3;

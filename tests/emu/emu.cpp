@@ -783,6 +783,7 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     BatchArgs a;
     memset(&a, 0, sizeof(a));
     a.T = e->T; a.P = *p;
+    a.k1_xcd = 1;  // (the encode stage's tiles in one contiguous range per XCD, as on the device: workgroup b stands for XCD b % 8)
     a.seq = (const uint8_t*)seqbuf.data(); a.off = off; a.seq_len = nbytes; a.npairs = npairs;
     a.surv = surv.data(); a.nsurv = &small[0]; a.nrec = &small[2]; a.errflag = &small[3];
     a.counts = accum.data(); a.kmc = a.counts + ntr; a.nmapread = a.kmc + nloci; a.counters = a.nmapread + nloci;

@@ -67,7 +67,7 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
             elif fuse_bits is not None:
                 os.environ["EMU_FUSE"] = fuse_bits
             try:
-                b2 = E.align(g, T, p2, seq, off, grid_k1=2, grid_pair=3)
+                b2 = E.align(g, T, p2, seq, off, grid_k1=11, grid_pair=3)
             finally:
                 os.environ.pop("EMU_FUSE", None)
                 os.environ.pop("EMU_NO_LOCUS", None)
@@ -100,7 +100,7 @@ def test_kernel_bodies_match_oracle(case, O, E, tmp_path):
         # "shared" also pairs with k-mers shared between loci (the class of such a k-mer at the locus from the class table)
         os.environ["EMU_NO_LOCUS"] = "1"
         try:
-            E.align(g, T, abi.default_params(ksize=c.k, **{**c.param_sets[0], "okam": 0}), seq, off, grid_k1=2, grid_pair=3)
+            E.align(g, T, abi.default_params(ksize=c.k, **{**c.param_sets[0], "okam": 0}), seq, off, grid_k1=9, grid_pair=3)
         finally:
             os.environ.pop("EMU_NO_LOCUS", None)
         ps = E.path_stats()
