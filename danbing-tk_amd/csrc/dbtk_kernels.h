@@ -362,8 +362,8 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     // wave-uniform base plus a 32-bit lane offset.  Chunks past the tile are simply read (they are the next tile's bytes;
     // the pack step never looks at them); a chunk that would cross the end of the batch reads the base instead and the
     // pack step replaces it.  Precondition (kept by the host side): 16 bytes are readable at a.seq.
-    auto fetch = [&](uint64_t p0, uint32_t np, uint64_t A0) {
-        const bool inb = A0 + 16 <= seq_len;
+    auto fetch = [&](uint64_t p0, uint32_t np, uint64_t A0, uint32_t nchf) {  // nchf: chunks of the tile (the lanes past them re-read its first chunk:
+        const bool inb = A0 + 16 <= seq_len;                                 // the fixed-size fetch asked for 2.4 lines of the NEXT tile per tile, round 6)
 #ifdef DBTK_STAMPS
         const uint8_t* base = a.seq + ((inb && !(a.P.diag & 2)) ? A0 : 0ull);  // (knob 2: no streaming traffic)
 #else
@@ -373,8 +373,8 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         const uint32_t rem = rem64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem64;  // bytes readable from base (saturated)
 #pragma unroll
         for (int j = 0; j < K1_PF; ++j) {
-            const uint32_t o = 16u * (lane + 64u * j);
-            const uint4 q = *reinterpret_cast<const uint4*>(base + (o + 16u <= rem ? o : 0u));
+            const uint32_t cj = lane + 64u * j, o = 16u * cj;
+            const uint4 q = *reinterpret_cast<const uint4*>(base + ((o + 16u <= rem && cj < nchf) ? o : 0u));
             w[j][0] = q.x; w[j][1] = q.y; w[j][2] = q.z; w[j][3] = q.w;
         }
         const uint32_t r = lane < 2 * np ? lane : 2 * np - 1;
@@ -407,7 +407,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     auto uni64 = [&](uint64_t v) { return ((uint64_t)x.uni((uint32_t)(v >> 32)) << 32) | x.uni((uint32_t)v); };
     if (tile < rhi) {
         cB0 = a.off[2 * tile_p0(tile)]; cB1 = a.off[2 * (tile_p0(tile) + tile_np(tile))];
-        fetch(tile_p0(tile), tile_np(tile), cB0 & ~15ull);
+        fetch(tile_p0(tile), tile_np(tile), cB0 & ~15ull, (uint32_t)((cB1 - (cB0 & ~15ull) + 15) >> 4));
     }
     if (tile + stride < rhi) { nB0 = a.off[2 * tile_p0(tile + stride) + lz]; nB1 = a.off[2 * (tile_p0(tile + stride) + tile_np(tile + stride)) + lz]; }
     for (; tile < rhi; tile += stride) {
@@ -468,7 +468,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         {   // unconditional (a dummy fetch of nothing past the last tile) so that the loads land straight in w/ro
             const bool h1 = t1 < rhi, h2 = t2 < rhi;
             const uint64_t A1 = cB0 & ~15ull;
-            fetch(h1 ? tile_p0(t1) : 0, h1 ? tile_np(t1) : 1u, h1 ? A1 : 0ull);
+            fetch(h1 ? tile_p0(t1) : 0, h1 ? tile_np(t1) : 1u, h1 ? A1 : 0ull, h1 ? (uint32_t)((cB1 - A1 + 15) >> 4) : 0u);
             nB0 = a.off[(h2 ? 2 * tile_p0(t2) : 0) + lz]; nB1 = a.off[(h2 ? 2 * (tile_p0(t2) + tile_np(t2)) : 0) + lz];
         }
         if (toolong) continue;
