@@ -290,7 +290,8 @@ DBTK_HD void bucket_part(const IdxBucket* idx, uint64_t b, uint32_t part, uint64
 constexpr int K1_NT = 64;
 constexpr int K1_TP = 16;                              // pairs per tile
 constexpr int K1_CH = K1_TP * 2 * MAXL / 16 + 4;       // 16-base chunks per tile (+ slack)
-constexpr int K1_SBF = 48;                             // survivors buffered per wave before one atomic appends them
+constexpr int K1_SBF = 240;                            // survivors buffered per wave before one atomic appends them (round 6: 48 -> 240: in a batch that hits,
+                                                       // 5 M survivors were 104 000 atomics on ONE word, 14 ns each = the kernel's 1.5 ms; 496: no further gain)
 constexpr int K1_PF = 5;                               // chunks per lane fetched ahead (320 chunks: a tile of 150 bp pairs has <= 301)
 struct K1Smem {
     uint32_t pk[K1_CH];
