@@ -1212,12 +1212,6 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     const bool tm = c->timers_on && (c->batch_no++ % c->timers_every) == 0;
     auto rec_beg = [&](int kslot) -> dbtk_status_t { if (!tm) return DBTK_OK; dbtk_status_t r = timed_slot(c, kslot, &e); if (r) return r; HIPCHK(hipEventRecord(c->timed[kslot].beg[e], s)); return DBTK_OK; };
     auto rec_end = [&](int kslot) -> dbtk_status_t { if (tm) HIPCHK(hipEventRecord(c->timed[kslot].end[e], s)); return DBTK_OK; };
-    {   // the encode stage
-    const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->k1_blocks ? ntiles : (uint64_t)c->k1_blocks);  // resident waves
-    if ((st = rec_beg(0))) return st;
-    LAUNCH(k_encode_subfilter, dim3(g1), dim3(K1_NT), s, a);
-    if ((st = rec_end(0))) return st;
-    }
     // The survivor list in locus order (dbtk_probe2.h: body_surv_*): what every later kernel indexes.  A batch with few survivors per locus (a
     // WGS batch) is not sorted — the four kernels then only find that out and copy the list — so when the batch BEFORE had fewer than half
     // the survivors from which a list is sorted, they are not launched at all and the encode stage's own list is used (20 us of a 1.2-ms
@@ -1231,12 +1225,24 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         sort_hint = prev_flag != 0 || 2 * (uint64_t)prev_surv >= (uint64_t)SORT_MIN_PER_LOCUS * nloci;
         locus_hint = prev_flag != 0 && (uint64_t)prev_surv >= (uint64_t)LOC_MIN_PAIRS * nloci;
     }
+    {   // the encode stage
+    const uint32_t g1 = (uint32_t)(ntiles < (uint64_t)c->k1_blocks ? ntiles : (uint64_t)c->k1_blocks);  // resident waves
+    // (the sort key of every survivor comes with it when the list is going to be sorted: the encode stage has the table line of the pair's
+    // first sampled k-mer in hand, body_surv_key would look it up again — 12 M requests per 10 M all-hit reads.  Its one-sample-per-turn
+    // form only: NM = 1 with the presence filter, the default.)
+    const bool k1_keys = sort_hint && c->P.n_filter && c->P.nm_filter == 1 && c->T.flt && !getenv("DBTK_NO_K1_KEYS");
+    a.skey = k1_keys ? c->d_surv + 2 * (npairs + 1) : nullptr;  // (= SurvSortArgs::key below)
+    if ((st = rec_beg(0))) return st;
+    LAUNCH(k_encode_subfilter, dim3(g1), dim3(K1_NT), s, a);
+    if ((st = rec_end(0))) return st;
+    }
     if (sort_hint) {
         SurvSortArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.T = c->T; sa.P = c->P; sa.seq = d_seq; sa.off = d_off; sa.surv = c->d_surv; sa.nsurv = c->d_small + 0;
         sa.sorted = c->d_surv + (npairs + 1); sa.key = sa.sorted + (npairs + 1); sa.hist = sa.key + (npairs + 1); sa.flag = c->d_small + 6;
         sa.sort_min = c->h_sortflag ? SORT_MIN_PER_LOCUS : 0u;  // (no hint word = DBTK_LOCUS_ALWAYS: every batch sorted, every batch through the locus path)
+        sa.have_keys = a.skey ? 1u : 0u;
         HIPCHK(hipMemsetAsync(sa.hist, 0, (nloci + 2) * sizeof(uint32_t), s));
         const uint32_t gs = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)c->num_cu * 8);
         if ((st = rec_beg(5))) return st;

@@ -215,6 +215,8 @@ struct BatchArgs {
                              // (body_surv_key, when it runs, decides), so that a batch that is not sorted needs no memset between two kernels
     uint32_t* hint_out;      // nullptr, or the host's pinned hint words (launch_batch: sort_hint, locus_hint): [0] survivors, [1] pairs the lean probe kernel took, [6] sort flag of this
                              // batch, written by the general resolve kernel (a copy engine's round between two kernels cost 16 us of a 1.2-ms step)
+    uint32_t* skey;          // nullptr, or [npairs]: the encode stage also writes, beside each survivor, the sort key body_surv_key would look up again — the
+                             // locus of the pair's first sampled k-mer of mate 1 that is in the index (it has just found it: the table line is in its L1)
     uint32_t k1_xcd;         // the encode stage cuts its tiles into one contiguous range per XCD (body_encode_subfilter); 0 = plain stride (DBTK_K1_XCD=0, the emulator)
     uint32_t vzero;          // always 0: `lane * vzero` makes an address look lane-dependent, so that a load whose value is only
                              // needed an iteration later is not turned into scalars (and waited for) right where it is issued
@@ -298,6 +300,8 @@ struct K1Smem {
     uint16_t vd[K1_CH];
     uint16_t rb[2 * K1_TP], rl[2 * K1_TP];  // per read of the tile: first base (relative to the tile's A0), length
     uint32_t sbuf[K1_SBF + K1_TP];          // survivors not yet appended to the global list
+    uint32_t kbuf[K1_SBF + K1_TP];          // ... and their sort keys (BatchArgs::skey)
+    uint32_t kgrp[K1_TP];                   // sort key of each pair of the tile in work
 };
 
 
@@ -388,6 +392,7 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         if (lane == 0) base = x.atomic_add(a.nsurv, nsb);
         base = x.bcast(base, 0);
         for (uint32_t i = lane; i < nsb; i += K1_NT) a.surv[base + i] = sm.sbuf[i];
+        if (a.skey) for (uint32_t i = lane; i < nsb; i += K1_NT) a.skey[base + i] = sm.kbuf[i];
         x.sync();
     };
     // Which tiles a wave takes.  Workgroup b runs on XCD b % 8 (round robin), and every XCD has an L2 of its own: with tile = b, b + nblocks, ...
@@ -564,6 +569,14 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                         }
                         const uint32_t g4 = (uint32_t)(hmask >> (lane & ~3u)) & 0xF;
                         hits_t |= ((g4 & 3) ? 1u : 0u) << (2 * r) | ((g4 >> 2) ? 1u : 0u) << (2 * r + 1);
+                        // (the sort key: mate 1's first sample found in the index — in this form one sample per pair is looked up per turn, in
+                        // sample order, so the lane that holds the matching key holds THE sample: its value is 32 bytes further in the line)
+                        if (a.skey && seq && mate == 0 && hitl) {
+                            const uint32_t slot = 2 * (sub & 1) + (k0[r] == kq[r] ? 0u : 1u);
+                            const uint32_t v = (uint32_t)a.T.idx[bq[r]].val[slot];
+                            uint32_t key = (v & 1u) ? a.T.vv[(v >> 1) + 1] : v >> 1;
+                            sm.kgrp[grp] = key > a.T.nloci ? a.T.nloci : key;
+                        }
                     }
                     hits |= hits_t;
                     mq &= ~act;
@@ -607,7 +620,9 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
         const uint64_t pm = x.ballot(pass);
         if (pm) {  // survivors go to the wave's LDS buffer (pair order inside the tile); one atomic per K1_SBF of them
             if (pass) {
-                sm.sbuf[nsb + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1))] = (uint32_t)(p0 + grp);
+                const uint32_t at = nsb + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1));
+                sm.sbuf[at] = (uint32_t)(p0 + grp);
+                if (a.skey) sm.kbuf[at] = sm.kgrp[grp];
                 ++c_surv;
             }
             nsb += (uint32_t)__builtin_popcountll(pm);

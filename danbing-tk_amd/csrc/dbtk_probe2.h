@@ -808,6 +808,7 @@ struct SurvSortArgs {
     uint32_t* sorted;        // [nsurv]: the list in key order
     uint32_t* flag;          // 1: sorted by key; 0: too few survivors for the order to matter (fewer than SORT_MIN_PER_LOCUS per locus:
                              // a WGS batch) — `sorted` is then a plain copy of the list and the key / histogram work is skipped
+    uint32_t have_keys;      // the encode stage has written key[] (BatchArgs::skey): body_surv_key only counts them
     uint32_t sort_min;       // survivors per locus from which the list is sorted (SORT_MIN_PER_LOCUS; 0 under DBTK_LOCUS_ALWAYS: tests of a dense
                              // slice — many pairs on few loci — of a large RPGG)
 };
@@ -853,6 +854,7 @@ DBTK_HD void body_surv_key(X& x, const SurvSortArgs& a) {
     if (!on) return;
     const uint32_t NF = (a.P.n_filter && a.P.nm_filter) ? a.P.n_filter : 4u;  // subfilter's sampled positions (AQ.cpp:172-188); four without it
     for (uint32_t t = x.bid() * (uint32_t)x.nthreads() + (uint32_t)x.tid(); t < n; t += x.nblocks() * (uint32_t)x.nthreads()) {
+        if (a.have_keys) { x.atomic_add(&a.hist[a.key[t]], 1u); continue; }
         const uint64_t r = 2 * (uint64_t)a.surv[t];
         const uint64_t o0 = a.off[r];
         const uint32_t len = (uint32_t)(a.off[r + 1] - o0);

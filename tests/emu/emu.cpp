@@ -825,13 +825,25 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         qmaskbuf.assign((size_t)tcap * 2 * 4 + 1, 0);
         a.qual = (const uint8_t*)qualbuf.data(); a.qmaskbuf = qmaskbuf.data();
     }
+    std::vector<uint32_t> sorted(npairs + 1), skey(npairs + 1, 0xDEADBEEFu), shist(nloci + 2 + SCAN_BLOCKS, 0);
+    // (the encode stage writes every survivor's sort key itself in its one-sample-per-turn form, as launch_batch has it do)
+    const bool k1_keys = p->n_filter && p->nm_filter == 1 && e->T.flt && !getenv("EMU_NO_K1_KEYS");
+    a.skey = k1_keys ? skey.data() : nullptr;
     run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter(x, a); });
-    std::vector<uint32_t> sorted(npairs + 1), skey(npairs + 1), shist(nloci + 2 + SCAN_BLOCKS, 0);
     {   // the survivor list in locus order, as launch_batch does
         SurvSortArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.T = e->T; sa.P = *p; sa.seq = a.seq; sa.off = off; sa.surv = surv.data(); sa.nsurv = &small[0];
         sa.sorted = sorted.data(); sa.key = skey.data(); sa.hist = shist.data(); sa.flag = &small[1]; sa.sort_min = SORT_MIN_PER_LOCUS;
+        if (k1_keys) {  // ... and they must be the keys body_surv_key looks up (sort_min 0: the keys of a small batch too)
+            std::vector<uint32_t> kref(npairs + 1), href(nloci + 2 + SCAN_BLOCKS, 0);
+            uint32_t fref = 0;
+            SurvSortArgs sr = sa;
+            sr.key = kref.data(); sr.hist = href.data(); sr.flag = &fref; sr.sort_min = 0; sr.have_keys = 0;
+            run_grid(3, 64, 0, [&](EmuX& x) { body_surv_key(x, sr); });
+            for (uint32_t t = 0; t < small[0]; ++t) if (kref[t] != skey[t]) return -78;
+            sa.have_keys = 1;
+        }
         run_grid(3, 64, 0, [&](EmuX& x) { body_surv_key(x, sa); });
         run_grid(SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_surv_scan(x, sa, 0); });
         run_grid(SCAN_BLOCKS, 64, 0, [&](EmuX& x) { body_surv_scan(x, sa, 1); });
