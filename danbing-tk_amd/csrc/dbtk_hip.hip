@@ -88,6 +88,12 @@ __global__ void __launch_bounds__(K1_NT, 4) k_encode_subfilter(BatchArgs a) {
     DevX x{&sm};
     body_encode_subfilter(x, a);
 }
+// (the form for a batch that hits: a mate's first sample alone before the other three, body_encode_subfilter<true>)
+__global__ void __launch_bounds__(K1_NT, 4) k_encode_subfilter_lazy(BatchArgs a) {
+    __shared__ __attribute__((aligned(16))) K1Smem sm;
+    DevX x{&sm};
+    body_encode_subfilter<true>(x, a);
+}
 // K2 / K3 are instantiated per NS = 64-position slots a read needs (2: <= 128 positions, 3: 150 bp reads, 4: up to 256 bp)
 #ifndef DBTK_K2_WPE
 #define DBTK_K2_WPE 4  // waves per SIMD the general probe kernel's registers are budgeted for
@@ -1232,8 +1238,16 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
     // form only: NM = 1 with the presence filter, the default.)
     const bool k1_keys = sort_hint && c->P.n_filter && c->P.nm_filter == 1 && c->T.flt && !getenv("DBTK_NO_K1_KEYS");
     a.skey = k1_keys ? c->d_surv + 2 * (npairs + 1) : nullptr;  // (= SurvSortArgs::key below)
+    bool k1_lazy = false;
+    {   // (lazy sampling when more than half of the batch before passed subfilter — a hint like the others; DBTK_K1_LAZY=0 / 1: never / always)
+        static const int lazy_env = getenv("DBTK_K1_LAZY") ? atoi(getenv("DBTK_K1_LAZY")) : -1;
+        bool lazy = lazy_env == 1;
+        if (lazy_env < 0 && c->h_sortflag) { const uint32_t prev_surv = ((volatile uint32_t*)c->h_sortflag)[0]; lazy = prev_surv != 0xFFFFFFFFu && 2 * (uint64_t)prev_surv >= npairs; }
+        k1_lazy = lazy;
+    }
     if ((st = rec_beg(0))) return st;
-    LAUNCH(k_encode_subfilter, dim3(g1), dim3(K1_NT), s, a);
+    if (k1_lazy) LAUNCH(k_encode_subfilter_lazy, dim3(g1), dim3(K1_NT), s, a);
+    else LAUNCH(k_encode_subfilter, dim3(g1), dim3(K1_NT), s, a);
     if ((st = rec_end(0))) return st;
     }
     if (sort_hint) {

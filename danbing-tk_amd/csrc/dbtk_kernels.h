@@ -336,7 +336,9 @@ DBTK_HD void load_tail_chunk(const uint8_t* seq, uint64_t seq_len, uint64_t g, u
     for (uint32_t b = 0; b < 16 && g + b < seq_len; ++b) w[b >> 2] |= (uint32_t)seq[g + b] << (8 * (b & 3));
 }
 
-template <class X>
+// LAZY: the form for a batch that hits (k_encode_subfilter_lazy; the launcher's hint: more than half of the batch before passed) — see "LAZY" below.
+// A template parameter, not an argument: the form every WGS-like batch runs must not carry the second pass' registers.
+template <bool LAZY = false, class X>
 DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
     uint64_t* const ctr = counters_of(x, a);
     using SM = K1Smem;
@@ -507,14 +509,24 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                 }
                 for (uint32_t s0 = 0; s0 < NF; s0 += 4) {
                     const uint32_t sidx = s0 + sub;
-                    uint64_t km = NAN64;
+                    uint64_t km_all = NAN64;
                     if (go && sidx < NF) {
                         const uint32_t pos = (sidx != NF - 1) ? sidx * S : L - 1;
-                        km = clean ? window_kmer_clean(sm.pk, bpos + pos, k) : window_kmer(sm.pk, sm.vd, bpos + pos, k, nullptr, nullptr);
+                        km_all = clean ? window_kmer_clean(sm.pk, bpos + pos, k) : window_kmer(sm.pk, sm.vd, bpos + pos, k, nullptr, nullptr);
                     }
 #ifdef DBTK_STAMPS
-                    if (a.P.diag & 1) km = NAN64;  // diagnostic: no probes
+                    if (a.P.diag & 1) km_all = NAN64;  // diagnostic: no probes
 #endif
+                    // LAZY: sample 0 alone first — filter word, table line —
+                    // and the other three only for a mate whose sample 0 is not in the index.  In a batch that hits, the first sample is
+                    // there nine times in ten and the other three filter words were requests for nothing (8 + 2 per pair, now 2 + 2: the
+                    // kernel runs at the chip's request ceiling).  A WGS-like batch would pay a second dependent round trip per tile: never lazy there.
+                    const bool lazy = LAZY && NM == 1 && a.T.flt && NF <= 4;
+                    uint32_t hits = 0;
+                    for (uint32_t ps = 0; ps < (lazy ? 2u : 1u); ++ps) {
+                    uint64_t km = km_all;
+                    if (lazy && ((ps == 0) != (sub == 0))) km = NAN64;  // (pass 0: sample 0; pass 1: the others ...
+                    if (lazy && hits) km = NAN64;                        //  ... of a mate still without a hit)
                     const uint64_t hmix = hash_mix(km);
                     if (a.T.flt && km != NAN64) {  // presence filter: "no" is final, and needs no HBM line
                         const uint64_t fm = kmix(km, k), fb = flt_bits(fm);
@@ -530,7 +542,6 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                     const bool seq = NM == 1 && a.T.flt;  // (without the filter every sample "may be": all at once, as before)
                     uint32_t mq = (uint32_t)(x.ballot(km != NAN64) >> (lane & ~3u)) & 0xFu;  // my pair's samples still to be looked up
                     if (seq && hm[mate]) mq = 0;  // (NF > 4: a hit among the first four samples has ended the loop)
-                    uint32_t hits = 0;
                     for (;;) {
                     const uint32_t act = seq ? (mq & (0u - mq)) : mq;  // this turn's samples
                     const uint64_t kmt = ((act >> sub) & 1u) ? km : NAN64;
@@ -582,6 +593,8 @@ DBTK_HD void body_encode_subfilter(X& x, const BatchArgs& a) {
                     mq &= ~act;
                     if (!seq || hits_t) mq = 0;  // all looked up / the first hit found: this pair is done
                     if (x.ballot(mq != 0) == 0) break;  // (a false positive of the filter somewhere in the tile: its pair's next sample)
+                    }
+                    if (!lazy || x.ballot(go && !hits) == 0) break;  // (lazy: a second pass only for a tile with a mate still undecided)
                     }
                     hm[mate] |= hits << s0;
                 }

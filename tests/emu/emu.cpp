@@ -829,7 +829,9 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
     // (the encode stage writes every survivor's sort key itself in its one-sample-per-turn form, as launch_batch has it do)
     const bool k1_keys = p->n_filter && p->nm_filter == 1 && e->T.flt && !getenv("EMU_NO_K1_KEYS");
     a.skey = k1_keys ? skey.data() : nullptr;
-    run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter(x, a); });
+    // (EMU_K1_LAZY=1: the encode stage's form for a batch that hits, body_encode_subfilter<true>)
+    if (getenv("EMU_K1_LAZY") && atoi(getenv("EMU_K1_LAZY"))) run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter<true>(x, a); });
+    else run_grid(grid_k1, K1_NT, sizeof(K1Smem), [&](EmuX& x) { body_encode_subfilter(x, a); });
     {   // the survivor list in locus order, as launch_batch does
         SurvSortArgs sa;
         memset(&sa, 0, sizeof(sa));

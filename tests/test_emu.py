@@ -193,6 +193,24 @@ def test_kernel_bodies_reproduce_reference_binary(name, E):
     g.close()
 
 
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_encode_stage_lazy_sampling(name, E, monkeypatch):
+    """body_encode_subfilter<true> (k_encode_subfilter_lazy, the form the launcher picks when most of the batch before passed subfilter: a
+    mate's first sample alone, the other three only if that one is not in the index) against the bytes the reference binary wrote; the
+    emulator also checks the sort keys it hands over against body_surv_key's."""
+    monkeypatch.setenv("EMU_K1_LAZY", "1")
+    d, p, reads, qc = golden_inputs(name)
+    g = E.load(os.path.join(d, "pan"), p.ksize, qc)
+    T = E.tables(g)
+    seq, off = reads.packed()
+    p.trace = 1
+    for grid in (3, 9):
+        b = E.align(g, T, p, seq, off, grid_k1=grid)
+        check_against_golden(d, b["counts"], b["kmc"], b["nmapread"], b["counters"], b["recs"], reads)
+    E.L.emu_tables_free(T)
+    g.close()
+
+
 def test_wave_formatters_are_writeCigar_and_writeAnnot(E):
     """The whole-wave CIGAR / annotation formatters of the -a / -ae walk (dbtk_walk.h: wave_fmt_*) vs the one-lane scans that restate
     writeCigar / writeAnnot (AQ.cpp:1683-1740; pinned to the reference's strings in tests/test_walk.py): runs across the 64-entry chunks,
