@@ -811,3 +811,16 @@ print("checked-launches ok")
     env = dict(os.environ, DBTK_SYNC_LAUNCHES="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "checked-launches ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"DBTK_K1_LAZY": "1"}, {"DBTK_K1_LAZY": "1", "DBTK_LOCUS_ALWAYS": "1"}, {"DBTK_K1_XCD": "0", "DBTK_NO_K1_KEYS": "1"}])
+def test_encode_kernel_forms_forced(env):
+    """The encode kernel's forms the launcher otherwise picks by a hint — k_encode_subfilter_lazy (a batch that hits), the sort keys handed over
+    or looked up again, the tiles per XCD or by plain stride — forced by their environment switches (read once per process: a child process),
+    each on a few random cases of tests/fuzz_parity.py against the oracle."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_parity.py"), "8", "424200"], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+    assert r.returncode == 0 and "8/8 seeds bit-exact" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -36,6 +36,10 @@ def main():
         noemit = [a for a in base if a not in ("-ae", "--aln-gz", "w.aln.gz")]
         r = subprocess.run(noemit, cwd=d, capture_output=True, text=True, env=dict(os.environ, DBTK_VERBOSE="1"))
         print("no emit:", "\n".join(l for l in r.stderr.splitlines() if l.startswith("ingest:") or l.startswith("device reader") or l.startswith("timeline")))
+        for ch in [x for x in os.environ.get("AE_CHUNKS", "").split(",") if x]:  # DBTK_INGEST_CHUNK sweep (MB), with and without -ae
+            for cmd, tag in ((base, "-ae"), (noemit, "no emit")):
+                r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, env=dict(os.environ, DBTK_INGEST_CHUNK=str(int(ch) << 20)))
+                print("chunk", ch, "MB", tag, [l for l in r.stderr.splitlines() if l.startswith("ingest:")][0][:62])
         for n in [x for x in os.environ.get("AE_SWEEP", "").split(",") if x]:
             for rep in range(2):
                 r = subprocess.run(base + ["--aln-aligners", n], cwd=d, capture_output=True, text=True)
