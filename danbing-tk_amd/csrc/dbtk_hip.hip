@@ -1257,6 +1257,8 @@ dbtk_status_t launch_batch(dbtk_ctx* c, const uint8_t* d_seq, const uint64_t* d_
         sa.sorted = c->d_surv + (npairs + 1); sa.key = sa.sorted + (npairs + 1); sa.hist = sa.key + (npairs + 1); sa.flag = c->d_small + 6;
         sa.sort_min = c->h_sortflag ? SORT_MIN_PER_LOCUS : 0u;  // (no hint word = DBTK_LOCUS_ALWAYS: every batch sorted, every batch through the locus path)
         sa.have_keys = a.skey ? 1u : 0u;
+        // (two arrays that live only between these kernels, in regions the locus lists take over afterwards: the items' and the rest list's)
+        sa.starts = c->d_surv + surv_words; sa.rank = c->d_surv + surv_words + 3 * 4 * item_cap;
         HIPCHK(hipMemsetAsync(sa.hist, 0, (nloci + 2) * sizeof(uint32_t), s));
         const uint32_t gs = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)c->num_cu * 8);
         if ((st = rec_beg(5))) return st;

@@ -808,6 +808,8 @@ struct SurvSortArgs {
     uint32_t* sorted;        // [nsurv]: the list in key order
     uint32_t* flag;          // 1: sorted by key; 0: too few survivors for the order to matter (fewer than SORT_MIN_PER_LOCUS per locus:
                              // a WGS batch) — `sorted` is then a plain copy of the list and the key / histogram work is skipped
+    uint32_t* rank;          // [nsurv]: a survivor's place among those of its key (what body_surv_key's counting atomic returned)
+    uint32_t* starts;        // [nloci + 1]: first place of each key (body_surv_scan); hist[] then holds each key's END, which is what the locus lists read
     uint32_t have_keys;      // the encode stage has written key[] (BatchArgs::skey): body_surv_key only counts them
     uint32_t sort_min;       // survivors per locus from which the list is sorted (SORT_MIN_PER_LOCUS; 0 under DBTK_LOCUS_ALWAYS: tests of a dense
                              // slice — many pairs on few loci — of a large RPGG)
@@ -854,7 +856,7 @@ DBTK_HD void body_surv_key(X& x, const SurvSortArgs& a) {
     if (!on) return;
     const uint32_t NF = (a.P.n_filter && a.P.nm_filter) ? a.P.n_filter : 4u;  // subfilter's sampled positions (AQ.cpp:172-188); four without it
     for (uint32_t t = x.bid() * (uint32_t)x.nthreads() + (uint32_t)x.tid(); t < n; t += x.nblocks() * (uint32_t)x.nthreads()) {
-        if (a.have_keys) { x.atomic_add(&a.hist[a.key[t]], 1u); continue; }
+        if (a.have_keys) { a.rank[t] = x.atomic_add(&a.hist[a.key[t]], 1u); continue; }
         const uint64_t r = 2 * (uint64_t)a.surv[t];
         const uint64_t o0 = a.off[r];
         const uint32_t len = (uint32_t)(a.off[r + 1] - o0);
@@ -874,10 +876,10 @@ DBTK_HD void body_surv_key(X& x, const SurvSortArgs& a) {
         }
         if (key > nloci) key = nloci;
         a.key[t] = key;
-        x.atomic_add(&a.hist[key], 1u);
+        a.rank[t] = x.atomic_add(&a.hist[key], 1u);
     }
 }
-// hist[] -> exclusive prefix sums (the first place of each key), in two steps of SCAN_BLOCKS one-wave blocks: the sum of every
+// hist[] (pairs per key) -> starts[] = exclusive prefix sums (the first place of each key) and hist[] = inclusive ones (its end), in two steps of SCAN_BLOCKS one-wave blocks: the sum of every
 // block's chunk, then each block scans its chunk from the sum of the chunks before it
 constexpr uint32_t SCAN_BLOCKS = 256;
 template <class X>
@@ -900,17 +902,17 @@ DBTK_HD void body_surv_scan(X& x, const SurvSortArgs& a, int step) {
     for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
         const uint32_t v = i0 + lane < hi ? a.hist[i0 + lane] : 0u;
         const uint32_t ex = x.wave_excl_scan(v);
-        if (i0 + lane < hi) a.hist[i0 + lane] = base + ex;
+        if (i0 + lane < hi) { a.starts[i0 + lane] = base + ex; a.hist[i0 + lane] = base + ex + v; }
         base += x.wave_sum(v);
     }
 }
-// one lane per survivor: into its key's next place
+// one lane per survivor: into its place — its key's first place + its rank among that key's survivors
 template <class X>
 DBTK_HD void body_surv_scatter(X& x, const SurvSortArgs& a) {
     const uint32_t n = *a.nsurv;
     const bool on = *a.flag != 0;
     for (uint32_t t = x.bid() * (uint32_t)x.nthreads() + (uint32_t)x.tid(); t < n; t += x.nblocks() * (uint32_t)x.nthreads())
-        a.sorted[on ? x.atomic_add(&a.hist[a.key[t]], 1u) : t] = a.surv[t];
+        a.sorted[on ? a.starts[a.key[t]] + a.rank[t] : t] = a.surv[t];  // (round 6: no second atomic per survivor — its rank came back from the first)
 }
 
 }  // namespace dbtk

@@ -837,11 +837,14 @@ int emu_align_ex(const dbtk_rpgg_t* g, void* tables, const dbtk_params_t* p, con
         memset(&sa, 0, sizeof(sa));
         sa.T = e->T; sa.P = *p; sa.seq = a.seq; sa.off = off; sa.surv = surv.data(); sa.nsurv = &small[0];
         sa.sorted = sorted.data(); sa.key = skey.data(); sa.hist = shist.data(); sa.flag = &small[1]; sa.sort_min = SORT_MIN_PER_LOCUS;
+        std::vector<uint32_t> srank(npairs + 1, 0), sstarts(nloci + 2, 0);
+        sa.rank = srank.data(); sa.starts = sstarts.data();
         if (k1_keys) {  // ... and they must be the keys body_surv_key looks up (sort_min 0: the keys of a small batch too)
             std::vector<uint32_t> kref(npairs + 1), href(nloci + 2 + SCAN_BLOCKS, 0);
             uint32_t fref = 0;
             SurvSortArgs sr = sa;
-            sr.key = kref.data(); sr.hist = href.data(); sr.flag = &fref; sr.sort_min = 0; sr.have_keys = 0;
+            std::vector<uint32_t> rref(npairs + 1, 0);
+            sr.key = kref.data(); sr.hist = href.data(); sr.rank = rref.data(); sr.flag = &fref; sr.sort_min = 0; sr.have_keys = 0;
             run_grid(3, 64, 0, [&](EmuX& x) { body_surv_key(x, sr); });
             for (uint32_t t = 0; t < small[0]; ++t) if (kref[t] != skey[t]) return -78;
             sa.have_keys = 1;
