@@ -2408,8 +2408,15 @@ uint8_t* pinned_take(uint64_t need, uint64_t* cap) {
 }
 void pinned_give(uint8_t* p, uint64_t cap) {
     if (!p) return;
-    std::lock_guard<std::mutex> l(g_pinned.m);
-    g_pinned.free.emplace_back(p, cap);
+    {
+        std::lock_guard<std::mutex> l(g_pinned.m);
+        uint64_t held = 0;
+        for (auto& b : g_pinned.free) held += b.second;
+        // (the pool is a hand-over between a reservation and an ingest, and between one ingest and the next: not a store without bounds —
+        // a process that makes ingests of many shapes gets its memory back beyond 128 buffers or 4 GB)
+        if (g_pinned.free.size() < 128 && held + cap <= (4ull << 30)) { g_pinned.free.emplace_back(p, cap); return; }
+    }
+    (void)(hipHostFree)(p);
 }
 inline uint32_t ingest_head_bytes(uint64_t chunk_bytes) { return (uint32_t)std::min<uint64_t>(1u << 20, (chunk_bytes + 15) & ~15ull); }
 inline uint64_t ingest_raw_bytes(uint64_t chunk_bytes) { return ((uint64_t)ingest_head_bytes(chunk_bytes) + chunk_bytes + 1 + 63) & ~63ull; }
